@@ -1,0 +1,158 @@
+/*
+ * tigar_hip.h -- C-ABI of libtigar_hip.so: the MI355X (gfx950) implementation of the
+ * tIGAr extraction hot path.  Loaded from Python with ctypes (tigar_amd/_lib.py).
+ *
+ * The reference has no C boundary on this path: its seams are Python method contracts
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference root).
+ *
+ * Conventions: every call returns 0 on success, non-zero on failure (message via
+ * tg_last_error()); device objects are opaque handles with explicit *_destroy; host
+ * arrays are plain pointers + sizes; row pointers / sizes are int64, column indices
+ * int32 (INDEX_TYPE='int32', tIGAr/common.py:43), values fp64.  Calls on one device are
+ * serialised on the library's stream; the library is not thread-safe.
+ */
+#ifndef TIGAR_HIP_H
+#define TIGAR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tg_csr_s *tg_csr_t;   /* device-resident CSR row block            */
+typedef struct tg_vec_s *tg_vec_t;   /* device-resident fp64 vector              */
+typedef struct tg_ptap_s *tg_ptap_t; /* symbolic plan of K = M^T A M             */
+typedef struct tg_comm_s *tg_comm_t; /* RCCL communicator + z-slab descriptor    */
+
+/* ---- runtime ------------------------------------------------------------------ */
+int tg_init(int device);                   /* binds the HIP device, creates the stream */
+int tg_shutdown(void);
+const char *tg_last_error(void);
+int tg_sync(void);                         /* hipStreamSynchronize on the library stream */
+int tg_device_info(char *name, int name_len, int *num_cu, int64_t *hbm_bytes);
+int tg_mem_info(int64_t *free_bytes, int64_t *total_bytes);
+/* HIP-event timers on the library's stream (bench.py roofline measurement). */
+int tg_timer_start(int slot);
+int tg_timer_stop(int slot, double *ms);   /* synchronises; elapsed ms since start(slot) */
+
+/* ---- vectors ------------------------------------------------------------------ */
+int tg_vec_create(int64_t n, tg_vec_t *out);               /* zero-initialised */
+int tg_vec_destroy(tg_vec_t v);
+int tg_vec_size(tg_vec_t v, int64_t *n);
+int tg_vec_upload(tg_vec_t v, const double *host, int64_t n);
+int tg_vec_download(tg_vec_t v, double *host, int64_t n);
+int tg_vec_fill(tg_vec_t v, double a);
+int tg_vec_copy(tg_vec_t dst, tg_vec_t src);
+int tg_vec_axpy(tg_vec_t y, double a, tg_vec_t x);          /* y += a x */
+int tg_vec_dot(tg_vec_t x, tg_vec_t y, double *out);        /* deterministic two-stage */
+/* as_backend_type(MTb).vec().setValues(zeroDofs, 0)  -- tIGAr/common.py:1154-1158 */
+int tg_vec_zero_entries(tg_vec_t y, const int32_t *dofs, int64_t n);
+/* separable load b[(a,b,c)] = scale * b0[a]*b1[b]*b2[c] (synthetic input) */
+int tg_vec_tensor3(tg_vec_t out, int d, const double *const *b1d, const int64_t *n,
+                   double scale, int64_t row0, int64_t row1);
+
+/* ---- CSR objects ---------------------------------------------------------------- */
+int tg_csr_from_host(int64_t nrows, int64_t ncols, const int64_t *rowptr,
+                     const int32_t *col, const double *val, tg_csr_t *out);
+int tg_csr_dims(tg_csr_t m, int64_t *nrows, int64_t *ncols, int64_t *nnz);
+int tg_csr_download(tg_csr_t m, int64_t *rowptr, int32_t *col, double *val);
+int tg_csr_destroy(tg_csr_t m);
+/* explicit M^T (the reference's FORM_MT switch, tIGAr/common.py:84,358-360);
+ * deterministic: rows of M^T sorted by FE row index. */
+int tg_csr_transpose(tg_csr_t m, tg_csr_t *out);
+/* fallback for arbitrary AbstractScalarBasis plug-ins (seam b-2, tIGAr/common.py:1683-1692):
+ * rows fed as (row, col, val) triplets from the host loop of generateM; applies the
+ * abs(v) > eps filter of tIGAr/common.py:1569, INSERT semantics (last wins), sorts columns. */
+int tg_csr_from_triplets(int64_t nrows, int64_t ncols, int64_t nt, const int64_t *rows,
+                         const int32_t *cols, const double *vals, double eps, tg_csr_t *out);
+
+/* ---- extraction-operator build (generateM) ------------------------------------- */
+/* One univariate B-spline direction of a tensor-product basis (BSpline1,
+ * tIGAr/BSplines.py:164-351) plus the FE node coordinates along that direction. */
+typedef struct {
+  int32_t p;              /* degree                                              */
+  int32_t nknots;         /* len(knots)                                          */
+  const double *ghost;    /* ghostKnots, length nknots + 2*(p+1)  (:204-212)     */
+  int32_t mult_first;     /* multiplicities[0]                                   */
+  int32_t mult_last;      /* multiplicities[-1]                                  */
+  int32_t ncp;            /* number of basis functions (:273-277)                */
+  int64_t nnodes;         /* FE nodes along this direction                       */
+  const double *nodes;    /* their parametric coordinates (host)                 */
+} tg_dir_t;
+
+/* Replaces AbstractCoordinateChartSpline.generateM / generateM_control
+ * (tIGAr/common.py:1460-1578) + BSpline.getNodesAndEvals (tIGAr/BSplines.py:450-503)
+ * + basisFuncsInner (tIGAr/BSplines.py:73-120) for BSpline bases on the implicit
+ * tensor FE node grid.  Rows = nodes in lexicographic order (direction 0 fastest),
+ * restricted to [row0,row1) (a z-slab); column = i + j*ncp0 + k*ncp0*ncp1 + col_offset;
+ * entries with fabs(v) > eps kept; columns sorted.  ncols = total columns of the block. */
+int tg_extract_csr_tensor(int d, const tg_dir_t *dirs, int32_t col_offset, int64_t ncols,
+                          double eps, int64_t row0, int64_t row1, tg_csr_t *out);
+/* Same with explicit node coordinates x[nrows*d] (dolfin-supplied / DG nodes). */
+int tg_extract_csr_points(int d, const tg_dir_t *dirs, int32_t col_offset, int64_t ncols,
+                          double eps, const double *x, int64_t nrows, tg_csr_t *out);
+/* vertical concatenation of row blocks (multi-field M: one block per field) */
+int tg_csr_vstack(int nblocks, const tg_csr_t *blocks, tg_csr_t *out);
+/* 1-D evaluation only (device twin of BSpline1.getKnotSpan/getNodes/basisFuncs):
+ * idx[n*(p+1)], val[n*(p+1)] in the reference's order (span-p .. span). */
+int tg_eval_basis_1d(const tg_dir_t *dir, const double *u, int64_t n, int32_t *span,
+                     int32_t *idx, double *val);
+
+/* ---- extraction application ------------------------------------------------------ */
+/* y = A x   (prolongation u = M*U, tIGAr/common.py:1259; K*p inside the Krylov solve).
+ * x must cover columns [col_base, col_base + size(x)). */
+int tg_spmv(tg_csr_t a, tg_vec_t x, tg_vec_t y);
+/* Y = A X for k <= 4 right-hand sides (cpFuncs = M_control * P, tIGAr/common.py:367-380);
+ * X, Y are column-major host arrays. */
+int tg_spmm_host(tg_csr_t a, const double *X, int k, double *Y);
+/* multTranspose / extractVector (tIGAr/common.py:97-109,1142-1160): y = M^T b using the
+ * explicit transpose mt (scatter-free, deterministic). */
+int tg_spmv_t(tg_csr_t mt, tg_vec_t b, tg_vec_t y);
+
+/* extractMatrix (tIGAr/common.py:1176-1204): K = M^T A M (PETSc MatPtAP [ext]).
+ * symbolic: pattern + plan; numeric: values (+ optional fused zeroRowsColumns).
+ * Row-block form: computes K rows [i0,i1) from mt rows [i0,i1) (local rows of `mt`
+ * start at global row mt_row0), A rows starting at a_row0, M rows starting at m_row0. */
+int tg_ptap_symbolic(tg_csr_t a, int64_t a_row0, tg_csr_t m, int64_t m_row0, tg_csr_t mt,
+                     int64_t mt_row0, tg_ptap_t *plan);
+int tg_ptap_numeric(tg_ptap_t plan, tg_csr_t a, tg_csr_t m, tg_csr_t mt,
+                    const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out);
+int tg_ptap_destroy(tg_ptap_t plan);
+/* MatZeroRowsColumns(K, zeroDofs, diag) [ext] as called at tIGAr/common.py:1200;
+ * K holds global rows [row0, row0+nrows). */
+int tg_zero_rows_cols(tg_csr_t k, int64_t row0, const int32_t *dofs, int64_t n, double diag);
+
+/* ---- Krylov solve (solveLinearSystem, tIGAr/common.py:1236-1263; seam b-4) -------- */
+enum { TG_KSP_CG = 0, TG_KSP_GMRES = 1 };
+enum { TG_PC_NONE = 0, TG_PC_JACOBI = 1 };
+/* status: 0 converged (rtol), 1 converged (atol), -1 max iterations, -2 breakdown/NaN */
+int tg_krylov_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, int pc, double rtol,
+                    double atol, int maxit, int restart, tg_comm_t comm, int *iters,
+                    double *resnorm, int *status);
+
+/* ---- synthetic FE-side input (NOT on the timed path) --------- */
+/* A = sum_t (x)_k F[t][k] with 1-D CSR factors sharing one pattern per direction
+ * (e.g. Q_p Laplace stiffness = K1xM1xM1 + M1xK1xM1 + M1xM1xK1); rows [row0,row1). */
+typedef struct {
+  int64_t n;               /* 1-D size                                   */
+  const int32_t *rowptr;   /* n+1                                        */
+  const int32_t *col;      /* shared pattern                             */
+  const double *val;       /* nterms * nnz1d values, term-major          */
+} tg_kron_dir_t;
+int tg_kron_sum_csr(int d, int nterms, const tg_kron_dir_t *dirs, int64_t row0,
+                    int64_t row1, tg_csr_t *out);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------- */
+int tg_comm_unique_id(char *id128);                          /* ncclGetUniqueId   */
+int tg_comm_create(const char *id128, int rank, int world, tg_comm_t *out);
+/* z-slab descriptor of the Krylov vectors: this rank owns global dofs [g0,g1); the SpMV
+ * needs halo_lo dofs below g0 (owned by rank-1) and halo_hi above g1 (rank+1). */
+int tg_comm_set_slab(tg_comm_t c, int64_t g0, int64_t g1, int64_t halo_lo, int64_t halo_hi,
+                     int64_t nglobal);
+int tg_comm_allreduce_sum(tg_comm_t c, double *host_inout, int n);
+int tg_comm_destroy(tg_comm_t c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

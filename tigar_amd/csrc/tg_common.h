@@ -1,0 +1,153 @@
+// Internal definitions shared by the HIP translation units of libtigar_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <vector>
+#include "../../include/tigar_hip.h"
+
+#define TG_MAX_DEGREE 8            // per-direction spline degree limit of the kernels
+#define TG_WAVE 64
+#define TG_CSR_PAD 8              // col/val allocations are padded: vector loads may over-read
+
+struct tg_ctx_t {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  int num_cu = 0;
+  bool ready = false;
+  hipEvent_t ev0[8], ev1[8];
+  // small persistent device scratch for reductions / scalars
+  double *scratch = nullptr;       // TG_SCRATCH_DOUBLES doubles
+  double *host_pinned = nullptr;   // 64 doubles, pinned
+};
+#define TG_SCRATCH_DOUBLES (1 << 16)
+extern tg_ctx_t g_tg;
+
+void tg_set_error(const char *fmt, ...);
+
+#define TG_CHECK_HIP(expr)                                                         \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      tg_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return 1;                                                                    \
+    }                                                                              \
+  } while (0)
+
+#define TG_REQUIRE(cond, ...)                                                      \
+  do {                                                                             \
+    if (!(cond)) {                                                                 \
+      tg_set_error(__VA_ARGS__);                                                   \
+      return 2;                                                                    \
+    }                                                                              \
+  } while (0)
+
+#define TG_REQUIRE_INIT() TG_REQUIRE(g_tg.ready, "tg_init() has not been called")
+
+#define TG_LAUNCH_CHECK() TG_CHECK_HIP(hipGetLastError())
+
+struct tg_vec_s {
+  int64_t n = 0;
+  double *d = nullptr;
+};
+
+struct tg_csr_s {
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  int64_t *rowptr = nullptr;   // device, nrows+1
+  int32_t *col = nullptr;      // device, nnz
+  double *val = nullptr;       // device, nnz
+  // SpMV plan (CSR-stream row blocks), built lazily
+  int32_t *rowblocks = nullptr;  // device, nblocks+1 row indices
+  int64_t nblocks = 0;
+  int32_t max_row_nnz = 0;
+  int spmv_mode = 0;             // 0 = not planned, 1 = stream (LDS), 2 = vector (wave/row)
+};
+
+template <typename T>
+static inline int tg_dmalloc(T **p, int64_t count) {
+  *p = nullptr;
+  if (count <= 0) count = 1;
+  TG_CHECK_HIP(hipMalloc((void **)p, (size_t)count * sizeof(T)));
+  return 0;
+}
+#define TG_TRY(expr)          \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc) return _rc;      \
+  } while (0)
+
+static inline int64_t tg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// device-wide in-place exclusive scan of int64 (n elements; out[n] gets the total if
+// total_slot != nullptr it is also copied to host) -- tg_core.hip
+int tg_exclusive_scan_i64(int64_t *d, int64_t n, int64_t *host_total);
+// deterministic reduction of `n` partial doubles (device) into out_dev[0..k) sums of k
+// interleaved streams -- tg_core.hip
+int tg_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, tg_csr_s **out);
+int tg_spmv_plan(tg_csr_s *a);
+int tg_spmv_raw(tg_csr_s *a, const double *x_shifted, double *y, double *dot_partial_with,
+                const double *dot_vec);
+
+int tg_csr_sort_rows(tg_csr_s *m);
+int tg_csr_transpose_block(tg_csr_s *m, int64_t row_base, int64_t out_ncols, tg_csr_s **out);
+int tg_build_dof_mask(const int32_t *dofs, int64_t n, int64_t ndofs_total, uint8_t **mask_out);
+int64_t tg_spmv_num_partials(tg_csr_s *a);
+
+// XCD-aware logical block id: hardware dispatches block b to XCD b % 8; give each XCD a
+// contiguous range of logical blocks so neighbouring rows share one L2.
+__device__ __forceinline__ int64_t tg_xcd_block(int64_t b, int64_t nb) {
+  const int64_t per = (nb + 7) >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+
+// ---- small host/device helpers shared by the translation units ----
+static inline int tg_grid_1d(int64_t n, int block) {
+  int64_t g = tg_cdiv(n, block);
+  int64_t cap = (int64_t)g_tg.num_cu * 8;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__device__ __forceinline__ double tg_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-wide sum for 256 threads; result valid in thread 0
+__device__ __forceinline__ double tg_block_sum256(double v, double *lds4) {
+  v = tg_wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) lds4[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) r = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ int64_t tg_wave_incl_scan_i64(int64_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int64_t t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// returns exclusive prefix of `v` over the 256-thread block and the block total
+__device__ __forceinline__ int64_t tg_block_excl_scan_i64(int64_t v, int64_t *lds5, int64_t *total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int64_t inc = tg_wave_incl_scan_i64(v);
+  if (lane == 63) lds5[w] = inc;
+  __syncthreads();
+  int64_t woff = 0;
+  for (int k = 0; k < w; k++) woff += lds5[k];
+  if (total) *total = lds5[0] + lds5[1] + lds5[2] + lds5[3];
+  __syncthreads();
+  return woff + inc - v;
+}

@@ -1,0 +1,421 @@
+// Runtime, vectors, CSR host<->device transfer, device-wide scan / reductions.
+#include "tg_common.h"
+#include <stdarg.h>
+
+tg_ctx_t g_tg;
+static char g_err[1024] = "";
+
+void tg_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *tg_last_error(void) { return g_err; }
+
+extern "C" int tg_init(int device) {
+  if (g_tg.ready && g_tg.device == device) return 0;
+  int count = 0;
+  TG_CHECK_HIP(hipGetDeviceCount(&count));
+  TG_REQUIRE(count > 0, "no HIP device visible");
+  TG_REQUIRE(device >= 0 && device < count, "device %d out of range (%d visible)", device, count);
+  TG_CHECK_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  TG_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  g_tg.device = device;
+  g_tg.num_cu = prop.multiProcessorCount;
+  TG_CHECK_HIP(hipStreamCreateWithFlags(&g_tg.stream, hipStreamNonBlocking));
+  for (int i = 0; i < 8; i++) {
+    TG_CHECK_HIP(hipEventCreate(&g_tg.ev0[i]));
+    TG_CHECK_HIP(hipEventCreate(&g_tg.ev1[i]));
+  }
+  TG_CHECK_HIP(hipMalloc((void **)&g_tg.scratch, TG_SCRATCH_DOUBLES * sizeof(double)));
+  TG_CHECK_HIP(hipHostMalloc((void **)&g_tg.host_pinned, 64 * sizeof(double), hipHostMallocDefault));
+  g_tg.ready = true;
+  return 0;
+}
+
+extern "C" int tg_shutdown(void) {
+  if (!g_tg.ready) return 0;
+  hipStreamSynchronize(g_tg.stream);
+  hipFree(g_tg.scratch);
+  hipHostFree(g_tg.host_pinned);
+  for (int i = 0; i < 8; i++) {
+    hipEventDestroy(g_tg.ev0[i]);
+    hipEventDestroy(g_tg.ev1[i]);
+  }
+  hipStreamDestroy(g_tg.stream);
+  g_tg = tg_ctx_t();
+  return 0;
+}
+
+extern "C" int tg_sync(void) {
+  TG_REQUIRE_INIT();
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  return 0;
+}
+
+extern "C" int tg_device_info(char *name, int name_len, int *num_cu, int64_t *hbm_bytes) {
+  TG_REQUIRE_INIT();
+  hipDeviceProp_t prop;
+  TG_CHECK_HIP(hipGetDeviceProperties(&prop, g_tg.device));
+  if (name && name_len > 0) {
+    snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (num_cu) *num_cu = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  return 0;
+}
+
+extern "C" int tg_mem_info(int64_t *free_bytes, int64_t *total_bytes) {
+  TG_REQUIRE_INIT();
+  size_t f = 0, t = 0;
+  TG_CHECK_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  return 0;
+}
+
+extern "C" int tg_timer_start(int slot) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(slot >= 0 && slot < 8, "timer slot out of range");
+  TG_CHECK_HIP(hipEventRecord(g_tg.ev0[slot], g_tg.stream));
+  return 0;
+}
+
+extern "C" int tg_timer_stop(int slot, double *ms) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(slot >= 0 && slot < 8, "timer slot out of range");
+  TG_CHECK_HIP(hipEventRecord(g_tg.ev1[slot], g_tg.stream));
+  TG_CHECK_HIP(hipEventSynchronize(g_tg.ev1[slot]));
+  float f = 0.f;
+  TG_CHECK_HIP(hipEventElapsedTime(&f, g_tg.ev0[slot], g_tg.ev1[slot]));
+  if (ms) *ms = (double)f;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ vectors
+extern "C" int tg_vec_create(int64_t n, tg_vec_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(n >= 0 && out, "bad arguments");
+  tg_vec_s *v = new tg_vec_s();
+  v->n = n;
+  if (tg_dmalloc(&v->d, n)) {
+    delete v;
+    return 1;
+  }
+  TG_CHECK_HIP(hipMemsetAsync(v->d, 0, (size_t)(n > 0 ? n : 1) * sizeof(double), g_tg.stream));
+  *out = v;
+  return 0;
+}
+
+extern "C" int tg_vec_destroy(tg_vec_t v) {
+  if (!v) return 0;
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  hipFree(v->d);
+  delete v;
+  return 0;
+}
+
+extern "C" int tg_vec_size(tg_vec_t v, int64_t *n) {
+  TG_REQUIRE(v && n, "bad arguments");
+  *n = v->n;
+  return 0;
+}
+
+extern "C" int tg_vec_upload(tg_vec_t v, const double *host, int64_t n) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(v && host && n == v->n, "size mismatch in tg_vec_upload (%lld vs %lld)", (long long)n,
+             (long long)(v ? v->n : -1));
+  TG_CHECK_HIP(hipMemcpyAsync(v->d, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  return 0;
+}
+
+extern "C" int tg_vec_download(tg_vec_t v, double *host, int64_t n) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(v && host && n == v->n, "size mismatch in tg_vec_download");
+  TG_CHECK_HIP(hipMemcpyAsync(host, v->d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  return 0;
+}
+
+__global__ void k_fill(double *x, int64_t n, double a) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) x[i] = a;
+}
+
+
+extern "C" int tg_vec_fill(tg_vec_t v, double a) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(v, "null vector");
+  hipLaunchKernelGGL(k_fill, dim3(tg_grid_1d(v->n, 256)), dim3(256), 0, g_tg.stream, v->d, v->n, a);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_vec_copy(tg_vec_t dst, tg_vec_t src) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(dst && src && dst->n == src->n, "size mismatch in tg_vec_copy");
+  TG_CHECK_HIP(hipMemcpyAsync(dst->d, src->d, (size_t)src->n * sizeof(double), hipMemcpyDeviceToDevice,
+                              g_tg.stream));
+  return 0;
+}
+
+__global__ void k_axpy(double *y, double a, const double *x, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] += a * x[i];
+}
+
+extern "C" int tg_vec_axpy(tg_vec_t y, double a, tg_vec_t x) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(x && y && x->n == y->n, "size mismatch in tg_vec_axpy");
+  hipLaunchKernelGGL(k_axpy, dim3(tg_grid_1d(y->n, 256)), dim3(256), 0, g_tg.stream, y->d, a, x->d, y->n);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- deterministic dot: fixed grid of partial sums, then one block folds them ---------
+
+
+#define TG_DOT_BLOCKS 1024
+__global__ void __launch_bounds__(256) k_dot_partial(const double *x, const double *y, int64_t n,
+                                                     double *partial) {
+  __shared__ double lds4[4];
+  double s = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) s += x[i] * y[i];
+  s = tg_block_sum256(s, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// folds `nstreams` interleaved partial streams: partial[b*nstreams + k]
+__global__ void __launch_bounds__(256) k_fold_partials(const double *partial, int nb, int nstreams,
+                                                       double *out) {
+  __shared__ double lds4[4];
+  for (int k = 0; k < nstreams; k++) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 256) s += partial[(int64_t)b * nstreams + k];
+    s = tg_block_sum256(s, lds4);
+    if (threadIdx.x == 0) out[k] = s;
+  }
+}
+
+extern "C" int tg_vec_dot(tg_vec_t x, tg_vec_t y, double *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(x && y && x->n == y->n && out, "size mismatch in tg_vec_dot");
+  double *partial = g_tg.scratch;
+  hipLaunchKernelGGL(k_dot_partial, dim3(TG_DOT_BLOCKS), dim3(256), 0, g_tg.stream, x->d, y->d, x->n, partial);
+  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(256), 0, g_tg.stream, partial, TG_DOT_BLOCKS, 1,
+                     partial + TG_DOT_BLOCKS);
+  TG_LAUNCH_CHECK();
+  TG_CHECK_HIP(hipMemcpyAsync(g_tg.host_pinned, partial + TG_DOT_BLOCKS, sizeof(double), hipMemcpyDeviceToHost,
+                              g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  *out = g_tg.host_pinned[0];
+  return 0;
+}
+
+__global__ void k_zero_entries(double *y, int64_t n, const int32_t *dofs, int64_t nd) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nd) {
+    int32_t d = dofs[i];
+    if (d >= 0 && d < n) y[d] = 0.0;
+  }
+}
+
+extern "C" int tg_vec_zero_entries(tg_vec_t y, const int32_t *dofs, int64_t n) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(y, "null vector");
+  if (n <= 0) return 0;
+  int32_t *d = nullptr;
+  TG_TRY(tg_dmalloc(&d, n));
+  TG_CHECK_HIP(hipMemcpyAsync(d, dofs, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream));
+  hipLaunchKernelGGL(k_zero_entries, dim3((unsigned)tg_cdiv(n, 256)), dim3(256), 0, g_tg.stream, y->d, y->n, d, n);
+  TG_LAUNCH_CHECK();
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  hipFree(d);
+  return 0;
+}
+
+__global__ void k_tensor3(double *out, int d, const double *b0, const double *b1, const double *b2, int64_t n0,
+                          int64_t n1, double scale, int64_t row0, int64_t nloc) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nloc; i += stride) {
+    int64_t r = row0 + i;
+    int64_t a = r % n0;
+    int64_t t = r / n0;
+    double v = b0[a];
+    if (d > 1) {
+      int64_t b = t % n1;
+      v *= b1[b];
+      if (d > 2) v *= b2[t / n1];
+    }
+    out[i] = scale * v;
+  }
+}
+
+extern "C" int tg_vec_tensor3(tg_vec_t out, int d, const double *const *b1d, const int64_t *n, double scale,
+                              int64_t row0, int64_t row1) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(out && d >= 1 && d <= 3 && row1 >= row0 && out->n == row1 - row0, "bad arguments to tg_vec_tensor3");
+  double *db[3] = {nullptr, nullptr, nullptr};
+  for (int k = 0; k < d; k++) {
+    TG_TRY(tg_dmalloc(&db[k], n[k]));
+    TG_CHECK_HIP(hipMemcpyAsync(db[k], b1d[k], (size_t)n[k] * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
+  }
+  hipLaunchKernelGGL(k_tensor3, dim3(tg_grid_1d(out->n, 256)), dim3(256), 0, g_tg.stream, out->d, d, db[0], db[1],
+                     db[2], n[0], d > 1 ? n[1] : 1, scale, row0, out->n);
+  TG_LAUNCH_CHECK();
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  for (int k = 0; k < d; k++) hipFree(db[k]);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ CSR objects
+int tg_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, tg_csr_s **out) {
+  tg_csr_s *m = new tg_csr_s();
+  m->nrows = nrows;
+  m->ncols = ncols;
+  m->nnz = nnz;
+  if (tg_dmalloc(&m->rowptr, nrows + 1) || tg_dmalloc(&m->col, nnz + TG_CSR_PAD) ||
+      tg_dmalloc(&m->val, nnz + TG_CSR_PAD)) {
+    hipFree(m->rowptr);
+    hipFree(m->col);
+    hipFree(m->val);
+    delete m;
+    return 1;
+  }
+  *out = m;
+  return 0;
+}
+
+extern "C" int tg_csr_from_host(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *col,
+                                const double *val, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(nrows >= 0 && ncols >= 0 && rowptr && out, "bad arguments to tg_csr_from_host");
+  int64_t nnz = rowptr[nrows] - rowptr[0];
+  TG_REQUIRE(rowptr[0] == 0, "rowptr[0] must be 0");
+  tg_csr_s *m = nullptr;
+  TG_TRY(tg_csr_alloc(nrows, ncols, nnz, &m));
+  TG_CHECK_HIP(hipMemcpyAsync(m->rowptr, rowptr, (size_t)(nrows + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
+                              g_tg.stream));
+  if (nnz > 0) {
+    TG_CHECK_HIP(hipMemcpyAsync(m->col, col, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream));
+    TG_CHECK_HIP(hipMemcpyAsync(m->val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
+  }
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  *out = m;
+  return 0;
+}
+
+extern "C" int tg_csr_dims(tg_csr_t m, int64_t *nrows, int64_t *ncols, int64_t *nnz) {
+  TG_REQUIRE(m, "null matrix");
+  if (nrows) *nrows = m->nrows;
+  if (ncols) *ncols = m->ncols;
+  if (nnz) *nnz = m->nnz;
+  return 0;
+}
+
+extern "C" int tg_csr_download(tg_csr_t m, int64_t *rowptr, int32_t *col, double *val) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(m, "null matrix");
+  if (rowptr)
+    TG_CHECK_HIP(hipMemcpyAsync(rowptr, m->rowptr, (size_t)(m->nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost,
+                                g_tg.stream));
+  if (col && m->nnz)
+    TG_CHECK_HIP(hipMemcpyAsync(col, m->col, (size_t)m->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, g_tg.stream));
+  if (val && m->nnz)
+    TG_CHECK_HIP(hipMemcpyAsync(val, m->val, (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  return 0;
+}
+
+extern "C" int tg_csr_destroy(tg_csr_t m) {
+  if (!m) return 0;
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  hipFree(m->rowptr);
+  hipFree(m->col);
+  hipFree(m->val);
+  hipFree(m->rowblocks);
+  delete m;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ scan
+// Exclusive scan of int64, tile = 256 threads x 8 items.
+#define TG_SCAN_ITEMS 8
+#define TG_SCAN_TILE (256 * TG_SCAN_ITEMS)
+
+
+
+__global__ void __launch_bounds__(256) k_scan_tile_sums(const int64_t *d, int64_t n, int64_t *sums) {
+  __shared__ int64_t lds5[4];
+  const int64_t base = (int64_t)blockIdx.x * TG_SCAN_TILE + (int64_t)threadIdx.x * TG_SCAN_ITEMS;
+  int64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < TG_SCAN_ITEMS; k++)
+    if (base + k < n) s += d[base + k];
+  int64_t total;
+  tg_block_excl_scan_i64(s, lds5, &total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) k_scan_tiles(int64_t *d, int64_t n, const int64_t *tile_offsets) {
+  __shared__ int64_t lds5[4];
+  const int64_t base = (int64_t)blockIdx.x * TG_SCAN_TILE + (int64_t)threadIdx.x * TG_SCAN_ITEMS;
+  int64_t v[TG_SCAN_ITEMS];
+  int64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < TG_SCAN_ITEMS; k++) {
+    v[k] = (base + k < n) ? d[base + k] : 0;
+    s += v[k];
+  }
+  int64_t ex = tg_block_excl_scan_i64(s, lds5, nullptr);
+  ex += tile_offsets ? tile_offsets[blockIdx.x] : 0;
+#pragma unroll
+  for (int k = 0; k < TG_SCAN_ITEMS; k++) {
+    if (base + k < n) d[base + k] = ex;
+    ex += v[k];
+  }
+}
+
+// in-place exclusive scan; recursion depth <= 3 for n up to 8.6e9
+static int tg_scan_rec(int64_t *d, int64_t n) {
+  if (n <= 0) return 0;
+  const int64_t ntiles = tg_cdiv(n, TG_SCAN_TILE);
+  if (ntiles == 1) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(256), 0, g_tg.stream, d, n, (const int64_t *)nullptr);
+    TG_LAUNCH_CHECK();
+    return 0;
+  }
+  int64_t *sums = nullptr;
+  TG_TRY(tg_dmalloc(&sums, ntiles));
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)ntiles), dim3(256), 0, g_tg.stream, d, n, sums);
+  TG_LAUNCH_CHECK();
+  int rc = tg_scan_rec(sums, ntiles);
+  if (!rc) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(256), 0, g_tg.stream, d, n, (const int64_t *)sums);
+    if (hipGetLastError() != hipSuccess) rc = 1;
+  }
+  hipStreamSynchronize(g_tg.stream);
+  hipFree(sums);
+  return rc;
+}
+
+// d has n+1 slots: d[0..n) hold counts, d[n] is ignored on input; on output d[i] =
+// exclusive prefix and d[n] = total.
+int tg_exclusive_scan_i64(int64_t *d, int64_t n, int64_t *host_total) {
+  TG_CHECK_HIP(hipMemsetAsync(d + n, 0, sizeof(int64_t), g_tg.stream));
+  TG_TRY(tg_scan_rec(d, n + 1));
+  if (host_total) {
+    TG_CHECK_HIP(hipMemcpyAsync(host_total, d + n, sizeof(int64_t), hipMemcpyDeviceToHost, g_tg.stream));
+    TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  }
+  return 0;
+}

@@ -1,0 +1,28 @@
+// RCCL communicator + z-slab descriptor (one process per GPU).
+#pragma once
+#include "tg_common.h"
+#include <rccl/rccl.h>
+
+struct tg_comm_s {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  // this rank owns global dofs [g0,g1); its SpMV needs halo_lo dofs below g0 and halo_hi
+  // above g1; send_lo / send_hi = what the neighbours need from this rank's ends
+  int64_t g0 = 0, g1 = 0, halo_lo = 0, halo_hi = 0, nglobal = 0;
+  int64_t send_lo = 0, send_hi = 0;
+  bool slab_set = false;
+};
+
+#define TG_CHECK_NCCL(expr)                                                           \
+  do {                                                                                \
+    ncclResult_t _r = (expr);                                                         \
+    if (_r != ncclSuccess) {                                                          \
+      tg_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); \
+      return 1;                                                                       \
+    }                                                                                 \
+  } while (0)
+
+// exchanges the halo of the extended vector xext = [halo_lo | owned | halo_hi] (device)
+int tg_comm_halo_exchange(tg_comm_s *c, double *xext);
+// in-place sum over ranks of n device doubles
+int tg_comm_allreduce_dev(tg_comm_s *c, double *dev, int n);

@@ -1,0 +1,117 @@
+// Multi-GPU plumbing: RCCL over xGMI.  The only data-path collectives of the hot path are
+// (1) the z-slab halo exchange of the Krylov direction vector before each SpMV (p planes,
+//     point-to-point with the two z-neighbours), and
+// (2) all-reduces of 1-31 doubles for dot products / norms.
+// Reference counterparts: PETSc VecScatter inside MatMult and MPI_Allreduce inside VecDot /
+// VecNorm of the KSP called at tIGAr/common.py:1255-1258 [ext].
+#include "tg_dist.h"
+
+extern "C" int tg_comm_unique_id(char *id128) {
+  TG_REQUIRE(id128, "null id buffer");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  ncclUniqueId id;
+  TG_CHECK_NCCL(ncclGetUniqueId(&id));
+  memcpy(id128, &id, 128);
+  return 0;
+}
+
+extern "C" int tg_comm_create(const char *id128, int rank, int world, tg_comm_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(id128 && out && world >= 1 && rank >= 0 && rank < world, "bad arguments to tg_comm_create");
+  tg_comm_s *c = new tg_comm_s();
+  c->rank = rank;
+  c->world = world;
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) {
+    tg_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r));
+    delete c;
+    return 1;
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int tg_comm_destroy(tg_comm_t c) {
+  if (!c) return 0;
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  delete c;
+  return 0;
+}
+
+int tg_comm_allreduce_dev(tg_comm_s *c, double *dev, int n) {
+  if (!c || c->world == 1) return 0;
+  TG_CHECK_NCCL(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, c->comm, g_tg.stream));
+  return 0;
+}
+
+extern "C" int tg_comm_allreduce_sum(tg_comm_t c, double *host_inout, int n) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(c && host_inout && n >= 1 && n <= 1024, "bad arguments to tg_comm_allreduce_sum");
+  double *d = g_tg.scratch + TG_SCRATCH_DOUBLES - 1024;
+  TG_CHECK_HIP(hipMemcpyAsync(d, host_inout, n * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
+  TG_TRY(tg_comm_allreduce_dev(c, d, n));
+  TG_CHECK_HIP(hipMemcpyAsync(host_inout, d, n * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  return 0;
+}
+
+extern "C" int tg_comm_set_slab(tg_comm_t c, int64_t g0, int64_t g1, int64_t halo_lo, int64_t halo_hi,
+                                int64_t nglobal) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(c && g0 >= 0 && g1 >= g0 && g1 <= nglobal && halo_lo >= 0 && halo_hi >= 0, "bad slab descriptor");
+  TG_REQUIRE(halo_lo <= g0 && g1 + halo_hi <= nglobal, "halo reaches outside the global range");
+  c->g0 = g0;
+  c->g1 = g1;
+  c->halo_lo = halo_lo;
+  c->halo_hi = halo_hi;
+  c->nglobal = nglobal;
+  // learn what the neighbours need from this rank: all-gather {g0,g1,halo_lo,halo_hi}
+  const int W = c->world;
+  std::vector<double> all((size_t)4 * W, 0.0);
+  all[4 * c->rank + 0] = (double)g0;
+  all[4 * c->rank + 1] = (double)g1;
+  all[4 * c->rank + 2] = (double)halo_lo;
+  all[4 * c->rank + 3] = (double)halo_hi;
+  if (W > 1) {
+    TG_REQUIRE(4 * W <= 1024, "world too large");
+    TG_TRY(tg_comm_allreduce_sum(c, all.data(), 4 * W));
+  }
+  c->send_lo = c->send_hi = 0;
+  if (c->rank > 0) {
+    TG_REQUIRE((int64_t)all[4 * (c->rank - 1) + 1] == g0, "slabs are not contiguous (rank %d)", c->rank);
+    c->send_lo = (int64_t)all[4 * (c->rank - 1) + 3];  // lower neighbour's halo_hi
+    TG_REQUIRE(halo_lo <= g0 - (int64_t)all[4 * (c->rank - 1) + 0], "halo_lo spans more than one neighbour slab");
+  } else
+    TG_REQUIRE(halo_lo == 0, "rank 0 cannot have a lower halo");
+  if (c->rank < W - 1) {
+    c->send_hi = (int64_t)all[4 * (c->rank + 1) + 2];  // upper neighbour's halo_lo
+    TG_REQUIRE(halo_hi <= (int64_t)all[4 * (c->rank + 1) + 1] - g1, "halo_hi spans more than one neighbour slab");
+  } else
+    TG_REQUIRE(halo_hi == 0, "last rank cannot have an upper halo");
+  TG_REQUIRE(c->send_lo <= g1 - g0 && c->send_hi <= g1 - g0, "neighbour halo larger than this slab");
+  c->slab_set = true;
+  return 0;
+}
+
+int tg_comm_halo_exchange(tg_comm_s *c, double *xext) {
+  if (!c || c->world == 1) return 0;
+  TG_REQUIRE(c->slab_set, "tg_comm_set_slab() has not been called");
+  double *own = xext + c->halo_lo;
+  const int64_t nloc = c->g1 - c->g0;
+  TG_CHECK_NCCL(ncclGroupStart());
+  if (c->rank > 0) {
+    if (c->send_lo > 0) TG_CHECK_NCCL(ncclSend(own, (size_t)c->send_lo, ncclDouble, c->rank - 1, c->comm, g_tg.stream));
+    if (c->halo_lo > 0) TG_CHECK_NCCL(ncclRecv(xext, (size_t)c->halo_lo, ncclDouble, c->rank - 1, c->comm, g_tg.stream));
+  }
+  if (c->rank < c->world - 1) {
+    if (c->send_hi > 0)
+      TG_CHECK_NCCL(ncclSend(own + nloc - c->send_hi, (size_t)c->send_hi, ncclDouble, c->rank + 1, c->comm, g_tg.stream));
+    if (c->halo_hi > 0)
+      TG_CHECK_NCCL(ncclRecv(own + nloc, (size_t)c->halo_hi, ncclDouble, c->rank + 1, c->comm, g_tg.stream));
+  }
+  TG_CHECK_NCCL(ncclGroupEnd());
+  return 0;
+}

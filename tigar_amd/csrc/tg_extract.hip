@@ -1,0 +1,553 @@
+// Extraction-operator build: M[row, col] = N_col(x_row), written directly as CSR.
+//
+// Device twin of the reference's only native routine, basisFuncsInner
+// (tIGAr/BSplines.py:73-120), of BSpline1.getKnotSpan/getNodes (:285-319),
+// BSpline.getNodesAndEvals (:450-503) and the row loop + eps filter of generateM
+// (tIGAr/common.py:1554-1571).
+//
+// Layout: wave-parallel.  One lane per candidate entry (i,j,k) of a row; a wave covers
+// floor(64 / C) rows at once (C = prod(p_k+1) candidates per row); survivors of the
+// |v| > eps filter are ranked with a ballot + popcount and stored straight to their CSR
+// slot, so every wave writes one contiguous segment of col[] / val[].  The kernel is
+// HBM-write-bound: 12 B per nnz + 8 B per row.
+#include "tg_common.h"
+#include <algorithm>
+
+// ----------------------------------------------------------------------------------------
+// 1-D evaluation.  All floating-point operations are the reference's, in the reference's
+// order, with contraction disabled (no FMA) so values are bit-identical to the CPU path.
+// ----------------------------------------------------------------------------------------
+struct tg_dir_dev {
+  int32_t p, nknots, mult_first, mult_last, ncp;
+  const double *ghost;  // device
+};
+
+__device__ __forceinline__ int tg_knot_span(const tg_dir_dev &D, double u) {
+  // numpy.searchsorted(knots, u) - 1 (side='left'), then the clamps of
+  // tIGAr/BSplines.py:302-307
+  const double *knots = D.ghost + (D.p + 1);
+  int lo = 0, hi = D.nknots;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (knots[mid] < u)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  int span = lo - 1;
+  const int nspans = D.nknots - 1;
+  const int cl = D.mult_first - 1;
+  const int ch = nspans - (D.mult_last - 1) - 1;
+  if (span < cl) span = cl;
+  if (span > ch) span = ch;
+  return span;
+}
+
+// N[0..p] = the p+1 non-zero basis functions at u in `span` (Cox-de Boor, A2.2 of
+// Piegl-Tiller exactly as coded at tIGAr/BSplines.py:102-119; only the last column of
+// the reference's ndu table is kept, the arithmetic is identical).
+__device__ __forceinline__ void tg_basis_funcs(const tg_dir_dev &D, int span, double u, double *N) {
+  const int p = D.p;
+  const int nG = p + 1;
+  const int i = span + 1;
+  const double *U = D.ghost;
+  double left[TG_MAX_DEGREE + 1], right[TG_MAX_DEGREE + 1];
+  N[0] = 1.0;
+  for (int j = 1; j <= p; j++) {
+    left[j] = __dsub_rn(u, U[i - j + nG]);
+    right[j] = __dsub_rn(U[i + j - 1 + nG], u);
+    double saved = 0.0;
+    for (int r = 0; r < j; r++) {
+      const double den = __dadd_rn(right[r + 1], left[j - r]);
+      const double temp = __ddiv_rn(N[r], den);
+      N[r] = __dadd_rn(saved, __dmul_rn(right[r + 1], temp));
+      saved = __dmul_rn(left[j - r], temp);
+    }
+    N[j] = saved;
+  }
+}
+
+__device__ __forceinline__ int tg_pymod(int v, int m) {
+  int r = v % m;
+  return r < 0 ? r + m : r;
+}
+
+// idx/val: [n x (p+1)].  sorted != 0: entries of a node sorted by basis index (needed so
+// that tensor candidates come out in CSR column order, also under periodic wrap).
+__global__ void k_eval_1d(tg_dir_dev D, const double *__restrict__ u, int64_t n, int32_t *__restrict__ span_out,
+                          int32_t *__restrict__ idx, double *__restrict__ val, int sorted) {
+  int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  const double x = u[a];
+  const int span = tg_knot_span(D, x);
+  double N[TG_MAX_DEGREE + 1];
+  int id[TG_MAX_DEGREE + 1];
+  tg_basis_funcs(D, span, x, N);
+  const int p = D.p;
+  for (int r = 0; r <= p; r++) id[r] = tg_pymod(span - p + r, D.ncp);
+  if (sorted) {
+    for (int r = 1; r <= p; r++) {  // insertion sort, p+1 <= 9
+      int ki = id[r];
+      double kv = N[r];
+      int q = r - 1;
+      while (q >= 0 && id[q] > ki) {
+        id[q + 1] = id[q];
+        N[q + 1] = N[q];
+        q--;
+      }
+      id[q + 1] = ki;
+      N[q + 1] = kv;
+    }
+  }
+  if (span_out) span_out[a] = span;
+  for (int r = 0; r <= p; r++) {
+    idx[a * (p + 1) + r] = id[r];
+    val[a * (p + 1) + r] = N[r];
+  }
+}
+
+struct tg_dir_tables {
+  double *ghost = nullptr, *nodes = nullptr, *val = nullptr;
+  int32_t *idx = nullptr;
+  void free_all() {
+    hipFree(ghost);
+    hipFree(nodes);
+    hipFree(val);
+    hipFree(idx);
+  }
+};
+
+static int tg_check_dir(const tg_dir_t &d) {
+  TG_REQUIRE(d.p >= 1 && d.p <= TG_MAX_DEGREE, "spline degree %d outside [1,%d]", d.p, TG_MAX_DEGREE);
+  TG_REQUIRE(d.nknots >= 2 && d.ghost && d.ncp >= 1, "bad knot data");
+  return 0;
+}
+
+// uploads one direction and evaluates its 1-D table for `n` coordinates (host pointer)
+static int tg_build_dir_table(const tg_dir_t &d, const double *coords, int64_t n, int64_t stride_elems,
+                              bool coords_on_device, tg_dir_tables *T, int32_t *span_dev, int sorted) {
+  TG_TRY(tg_check_dir(d));
+  const int64_t nghost = (int64_t)d.nknots + 2 * (d.p + 1);
+  TG_TRY(tg_dmalloc(&T->ghost, nghost));
+  TG_CHECK_HIP(hipMemcpyAsync(T->ghost, d.ghost, nghost * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
+  const double *dev_coords = coords;
+  if (!coords_on_device) {
+    TG_TRY(tg_dmalloc(&T->nodes, n));
+    TG_CHECK_HIP(hipMemcpyAsync(T->nodes, coords, n * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
+    dev_coords = T->nodes;
+  }
+  (void)stride_elems;
+  TG_TRY(tg_dmalloc(&T->idx, n * (d.p + 1)));
+  TG_TRY(tg_dmalloc(&T->val, n * (d.p + 1)));
+  tg_dir_dev D{d.p, d.nknots, d.mult_first, d.mult_last, d.ncp, T->ghost};
+  hipLaunchKernelGGL(k_eval_1d, dim3((unsigned)tg_cdiv(n, 256)), dim3(256), 0, g_tg.stream, D, dev_coords, n, span_dev,
+                     T->idx, T->val, sorted);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_eval_basis_1d(const tg_dir_t *dir, const double *u, int64_t n, int32_t *span, int32_t *idx,
+                                double *val) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(dir && u && n >= 0 && idx && val, "bad arguments to tg_eval_basis_1d");
+  if (n == 0) return 0;
+  tg_dir_tables T;
+  int32_t *span_dev = nullptr;
+  TG_TRY(tg_dmalloc(&span_dev, n));
+  int rc = tg_build_dir_table(*dir, u, n, 1, false, &T, span_dev, 0);
+  if (!rc) {
+    const int pp1 = dir->p + 1;
+    hipMemcpyAsync(idx, T.idx, n * pp1 * sizeof(int32_t), hipMemcpyDeviceToHost, g_tg.stream);
+    hipMemcpyAsync(val, T.val, n * pp1 * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream);
+    if (span) hipMemcpyAsync(span, span_dev, n * sizeof(int32_t), hipMemcpyDeviceToHost, g_tg.stream);
+    if (hipStreamSynchronize(g_tg.stream) != hipSuccess) {
+      tg_set_error("tg_eval_basis_1d: stream sync failed");
+      rc = 1;
+    }
+  }
+  T.free_all();
+  hipFree(span_dev);
+  return rc;
+}
+
+// ----------------------------------------------------------------------------------------
+// Tensor / point-cloud CSR build
+// ----------------------------------------------------------------------------------------
+struct tg_extract_params {
+  int d;
+  int pp1[3];            // p_k + 1
+  int C;                 // candidates per row = prod pp1
+  int rpw;               // rows per wave (C <= 64), else 1
+  int iters;             // row groups per wave
+  int64_t n[3];          // nodes per direction (tensor mode)
+  int64_t cstride[3];    // column strides 1, ncp0, ncp0*ncp1
+  const int32_t *idx[3];
+  const double *val[3];
+  int64_t col_offset;
+  double eps;
+  int64_t row0;          // first global row of the output block
+  int64_t nrows;         // rows in the output block
+  // tensor mode: pencils (fixed b,c) p0 .. p0+npencils, chunks of rows along direction 0
+  int64_t pencil0, npencils;
+  int32_t chunks_per_pencil;
+  int32_t rows_per_block;
+};
+
+// value of candidate (i,j,k): (Nu_i * Nv_j) * Nw_k, left to right (tIGAr/BSplines.py:473,500)
+template <int D>
+__device__ __forceinline__ double tg_cand_value(const tg_extract_params &P, const int64_t *t, int i, int j, int k) {
+  double v = P.val[0][t[0] * P.pp1[0] + i];
+  if (D > 1) v = v * P.val[1][t[1] * P.pp1[1] + j];
+  if (D > 2) v = v * P.val[2][t[2] * P.pp1[2] + k];
+  return v;
+}
+
+template <int D>
+__device__ __forceinline__ int64_t tg_cand_col(const tg_extract_params &P, const int64_t *t, int i, int j, int k) {
+  int64_t c = P.idx[0][t[0] * P.pp1[0] + i];
+  if (D > 1) c += P.cstride[1] * P.idx[1][t[1] * P.pp1[1] + j];
+  if (D > 2) c += P.cstride[2] * P.idx[2][t[2] * P.pp1[2] + k];
+  return c + P.col_offset;
+}
+
+// Per-block context: TENSOR: block = (pencil, chunk) -- one pencil = fixed (b,c), rows run
+// along direction 0; POINTS: rows are consecutive.  Computed once per block (two integer
+// divisions), so the per-lane row mapping below is add/compare only.
+struct tg_blk_ctx {
+  int64_t a0;      // first direction-0 index (TENSOR) / first row (POINTS) of the block
+  int64_t b, c;    // pencil coordinates
+  int64_t grow0;   // global row of a = 0 in this pencil
+};
+
+template <int D, bool POINTS>
+__device__ __forceinline__ tg_blk_ctx tg_block_ctx(const tg_extract_params &P, int64_t blk) {
+  tg_blk_ctx X;
+  if (POINTS) {
+    X.a0 = blk * P.rows_per_block;
+    X.b = X.c = 0;
+    X.grow0 = 0;
+  } else {
+    const int64_t pencil = P.pencil0 + blk / P.chunks_per_pencil;
+    const int chunk = (int)(blk % P.chunks_per_pencil);
+    X.a0 = (int64_t)chunk * P.rows_per_block;
+    X.b = (D == 2) ? pencil : ((D == 3) ? pencil % P.n[1] : 0);
+    X.c = (D == 3) ? pencil / P.n[1] : 0;
+    X.grow0 = P.n[0] * pencil;
+  }
+  return X;
+}
+
+// row_in_block -> local row + table indices; false if there is no such row
+template <int D, bool POINTS>
+__device__ __forceinline__ bool tg_lane_row(const tg_extract_params &P, const tg_blk_ctx &X, int row_in_block,
+                                            int64_t *lrow, int64_t *t) {
+  const int64_t a = X.a0 + row_in_block;
+  if (POINTS) {
+    if (a >= P.nrows) return false;
+    *lrow = a;
+    t[0] = t[1] = t[2] = a;
+    return true;
+  } else {
+    if (a >= P.n[0]) return false;
+    const int64_t lr = X.grow0 + a - P.row0;
+    if (lr < 0 || lr >= P.nrows) return false;
+    *lrow = lr;
+    t[0] = a;
+    t[1] = X.b;
+    t[2] = X.c;
+    return true;
+  }
+}
+
+// pass 1: per-row survivor counts -> rowptr[lrow] (scanned afterwards); thread per row
+template <int D, bool POINTS>
+__global__ void __launch_bounds__(256) k_extract_count(tg_extract_params P, int64_t *__restrict__ rowptr) {
+  const tg_blk_ctx X = tg_block_ctx<D, POINTS>(P, blockIdx.x);
+  for (int q = threadIdx.x; q < P.rows_per_block; q += 256) {
+    int64_t lrow, t[3];
+    if (!tg_lane_row<D, POINTS>(P, X, q, &lrow, t)) continue;
+    int cnt = 0;
+    const int nk = (D > 2) ? P.pp1[2] : 1, nj = (D > 1) ? P.pp1[1] : 1;
+    for (int k = 0; k < nk; k++)
+      for (int j = 0; j < nj; j++)
+        for (int i = 0; i < P.pp1[0]; i++) cnt += (fabs(tg_cand_value<D>(P, t, i, j, k)) > P.eps) ? 1 : 0;
+    rowptr[lrow] = cnt;
+  }
+}
+
+// pass 2: lane-per-candidate fill
+template <int D, bool POINTS>
+__global__ void __launch_bounds__(256)
+    k_extract_fill(tg_extract_params P, const int64_t *__restrict__ rowptr, int32_t *__restrict__ col,
+                   double *__restrict__ val) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const tg_blk_ctx X = tg_block_ctx<D, POINTS>(P, blockIdx.x);
+  if (P.C <= 64) {
+    const int rsub = lane / P.C;
+    const int c = lane - rsub * P.C;
+    const bool lane_used = rsub < P.rpw;
+    const int i = c % P.pp1[0];
+    const int jk = c / P.pp1[0];
+    const int j = (D > 1) ? jk % P.pp1[1] : 0;
+    const int k = (D > 2) ? jk / P.pp1[1] : 0;
+    const unsigned long long rowmask_base = (P.C == 64) ? ~0ull : ((1ull << P.C) - 1ull);
+    for (int it = 0; it < P.iters; it++) {
+      const int group = it * 4 + w;
+      int64_t lrow = 0, t[3] = {0, 0, 0};
+      const bool has = lane_used && tg_lane_row<D, POINTS>(P, X, group * P.rpw + rsub, &lrow, t);
+      double v = 0.0;
+      bool keep = false;
+      if (has) {
+        v = tg_cand_value<D>(P, t, i, j, k);
+        keep = fabs(v) > P.eps;
+      }
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const unsigned long long rowmask = rowmask_base << (rsub * P.C);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int rank = __popcll(m & rowmask & below);
+        const int64_t pos = rowptr[lrow] + rank;
+        col[pos] = (int32_t)tg_cand_col<D>(P, t, i, j, k);
+        val[pos] = v;
+      }
+    }
+  } else {
+    // C > 64: one row per wave, ceil(C/64) passes with a running offset
+    for (int it = 0; it < P.iters; it++) {
+      const int group = it * 4 + w;
+      int64_t lrow = 0, t[3] = {0, 0, 0};
+      const bool has = tg_lane_row<D, POINTS>(P, X, group, &lrow, t);  // wave-uniform
+      if (!has) continue;
+      int64_t base = rowptr[lrow];
+      for (int c0 = 0; c0 < P.C; c0 += 64) {
+        const int c = c0 + lane;
+        double v = 0.0;
+        bool keep = false;
+        int i = 0, j = 0, k = 0;
+        if (c < P.C) {
+          i = c % P.pp1[0];
+          const int jk = c / P.pp1[0];
+          j = (D > 1) ? jk % P.pp1[1] : 0;
+          k = (D > 2) ? jk / P.pp1[1] : 0;
+          v = tg_cand_value<D>(P, t, i, j, k);
+          keep = fabs(v) > P.eps;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+          const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+          const int64_t pos = base + __popcll(m & below);
+          col[pos] = (int32_t)tg_cand_col<D>(P, t, i, j, k);
+          val[pos] = v;
+        }
+        base += __popcll(m);
+      }
+    }
+  }
+}
+
+template <int D, bool POINTS>
+static int tg_run_extract(tg_extract_params &P, int64_t nblocks, int64_t ncols, tg_csr_t *out) {
+  int64_t *rowptr = nullptr;
+  TG_TRY(tg_dmalloc(&rowptr, P.nrows + 1));
+  hipMemsetAsync(rowptr, 0, (size_t)(P.nrows + 1) * sizeof(int64_t), g_tg.stream);
+  if (nblocks > 0) {
+    hipLaunchKernelGGL((k_extract_count<D, POINTS>), dim3((unsigned)nblocks), dim3(256), 0, g_tg.stream, P, rowptr);
+    TG_LAUNCH_CHECK();
+  }
+  int64_t nnz = 0;
+  if (tg_exclusive_scan_i64(rowptr, P.nrows, &nnz)) {
+    hipFree(rowptr);
+    return 1;
+  }
+  tg_csr_s *m = new tg_csr_s();
+  m->nrows = P.nrows;
+  m->ncols = ncols;
+  m->nnz = nnz;
+  m->rowptr = rowptr;
+  if (tg_dmalloc(&m->col, nnz + TG_CSR_PAD) || tg_dmalloc(&m->val, nnz + TG_CSR_PAD)) {
+    tg_csr_destroy(m);
+    return 1;
+  }
+  if (nblocks > 0 && nnz > 0) {
+    hipLaunchKernelGGL((k_extract_fill<D, POINTS>), dim3((unsigned)nblocks), dim3(256), 0, g_tg.stream, P, rowptr,
+                       m->col, m->val);
+    TG_LAUNCH_CHECK();
+  }
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  *out = m;
+  return 0;
+}
+
+static void tg_fill_common(tg_extract_params &P, int d, const tg_dir_t *dirs, int32_t col_offset, double eps) {
+  memset(&P, 0, sizeof(P));
+  P.d = d;
+  P.C = 1;
+  for (int k = 0; k < 3; k++) {
+    P.pp1[k] = (k < d) ? dirs[k].p + 1 : 1;
+    P.C *= P.pp1[k];
+  }
+  P.cstride[0] = 1;
+  P.cstride[1] = (d > 1) ? dirs[0].ncp : 0;
+  P.cstride[2] = (d > 2) ? (int64_t)dirs[0].ncp * dirs[1].ncp : 0;
+  P.col_offset = col_offset;
+  P.eps = eps;
+  P.rpw = (P.C <= 64) ? 64 / P.C : 1;
+  P.iters = 8;
+  P.rows_per_block = 4 * P.rpw * P.iters;
+}
+
+extern "C" int tg_extract_csr_tensor(int d, const tg_dir_t *dirs, int32_t col_offset, int64_t ncols, double eps,
+                                     int64_t row0, int64_t row1, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(d >= 1 && d <= 3 && dirs && out, "bad arguments to tg_extract_csr_tensor");
+  int64_t total = 1;
+  for (int k = 0; k < d; k++) {
+    TG_TRY(tg_check_dir(dirs[k]));
+    TG_REQUIRE(dirs[k].nnodes >= 1 && dirs[k].nodes, "direction %d has no nodes", k);
+    total *= dirs[k].nnodes;
+  }
+  TG_REQUIRE(row0 >= 0 && row1 >= row0 && row1 <= total, "row range [%lld,%lld) outside [0,%lld)", (long long)row0,
+             (long long)row1, (long long)total);
+  tg_extract_params P;
+  tg_fill_common(P, d, dirs, col_offset, eps);
+  tg_dir_tables T[3];
+  int rc = 0;
+  for (int k = 0; k < d && !rc; k++) {
+    rc = tg_build_dir_table(dirs[k], dirs[k].nodes, dirs[k].nnodes, 1, false, &T[k], nullptr, 1);
+    P.n[k] = dirs[k].nnodes;
+    P.idx[k] = T[k].idx;
+    P.val[k] = T[k].val;
+  }
+  for (int k = d; k < 3; k++) P.n[k] = 1;
+  if (!rc) {
+    P.row0 = row0;
+    P.nrows = row1 - row0;
+    const int64_t n0 = P.n[0];
+    P.pencil0 = row0 / n0;
+    const int64_t pencil1 = (row1 > row0) ? (row1 - 1) / n0 + 1 : P.pencil0;
+    P.npencils = pencil1 - P.pencil0;
+    P.chunks_per_pencil = (int32_t)tg_cdiv(n0, P.rows_per_block);
+    const int64_t nblocks = P.npencils * P.chunks_per_pencil;
+    if (nblocks >= (1ll << 31)) {
+      tg_set_error("tg_extract_csr_tensor: grid too large (%lld blocks)", (long long)nblocks);
+      rc = 2;
+    } else if (d == 1)
+      rc = tg_run_extract<1, false>(P, nblocks, ncols, out);
+    else if (d == 2)
+      rc = tg_run_extract<2, false>(P, nblocks, ncols, out);
+    else
+      rc = tg_run_extract<3, false>(P, nblocks, ncols, out);
+  }
+  hipStreamSynchronize(g_tg.stream);
+  for (int k = 0; k < d; k++) T[k].free_all();
+  return rc;
+}
+
+extern "C" int tg_extract_csr_points(int d, const tg_dir_t *dirs, int32_t col_offset, int64_t ncols, double eps,
+                                     const double *x, int64_t nrows, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(d >= 1 && d <= 3 && dirs && out && nrows >= 0 && (x || nrows == 0),
+             "bad arguments to tg_extract_csr_points");
+  tg_extract_params P;
+  tg_fill_common(P, d, dirs, col_offset, eps);
+  tg_dir_tables T[3];
+  int rc = 0;
+  // de-interleave coordinates on the host side of the ABI: x[row*d + k] -> per-direction arrays
+  std::vector<double> xk((size_t)(nrows > 0 ? nrows : 1));
+  for (int k = 0; k < d && !rc; k++) {
+    for (int64_t r = 0; r < nrows; r++) xk[r] = x[r * d + k];
+    rc = tg_build_dir_table(dirs[k], xk.data(), nrows, 1, false, &T[k], nullptr, 1);
+    if (!rc && hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;  // xk is reused
+    P.idx[k] = T[k].idx;
+    P.val[k] = T[k].val;
+    P.n[k] = nrows;
+  }
+  if (!rc) {
+    P.row0 = 0;
+    P.nrows = nrows;
+    const int64_t nblocks = tg_cdiv(nrows, P.rows_per_block);
+    if (d == 1)
+      rc = tg_run_extract<1, true>(P, nblocks, ncols, out);
+    else if (d == 2)
+      rc = tg_run_extract<2, true>(P, nblocks, ncols, out);
+    else
+      rc = tg_run_extract<3, true>(P, nblocks, ncols, out);
+  }
+  hipStreamSynchronize(g_tg.stream);
+  for (int k = 0; k < d; k++) T[k].free_all();
+  return rc;
+}
+
+// ----------------------------------------------------------------------------------------
+// vstack (multi-field M = one row block per field, tIGAr/common.py:1546-1573)
+// ----------------------------------------------------------------------------------------
+__global__ void k_copy_rowptr_shift(int64_t *dst, const int64_t *src, int64_t n, int64_t shift) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = src[i] + shift;
+}
+
+extern "C" int tg_csr_vstack(int nblocks, const tg_csr_t *blocks, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(nblocks >= 1 && blocks && out, "bad arguments to tg_csr_vstack");
+  int64_t nrows = 0, nnz = 0, ncols = blocks[0]->ncols;
+  for (int b = 0; b < nblocks; b++) {
+    TG_REQUIRE(blocks[b] && blocks[b]->ncols == ncols, "vstack: column count mismatch");
+    nrows += blocks[b]->nrows;
+    nnz += blocks[b]->nnz;
+  }
+  tg_csr_s *m = nullptr;
+  TG_TRY(tg_csr_alloc(nrows, ncols, nnz, &m));
+  int64_t r = 0, z = 0;
+  for (int b = 0; b < nblocks; b++) {
+    const tg_csr_s *s = blocks[b];
+    hipLaunchKernelGGL(k_copy_rowptr_shift, dim3(tg_grid_1d(s->nrows + 1, 256)), dim3(256), 0, g_tg.stream,
+                       m->rowptr + r, s->rowptr, s->nrows + 1, z);
+    if (s->nnz) {
+      hipMemcpyAsync(m->col + z, s->col, (size_t)s->nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, g_tg.stream);
+      hipMemcpyAsync(m->val + z, s->val, (size_t)s->nnz * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream);
+    }
+    r += s->nrows;
+    z += s->nnz;
+  }
+  TG_LAUNCH_CHECK();
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  *out = m;
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------
+// triplet fallback for arbitrary scalar-basis plug-ins (host sort; the Python loop that
+// feeds it dominates).  INSERT semantics: the last (row,col) write wins.
+// ----------------------------------------------------------------------------------------
+extern "C" int tg_csr_from_triplets(int64_t nrows, int64_t ncols, int64_t nt, const int64_t *rows,
+                                    const int32_t *cols, const double *vals, double eps, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(nrows >= 0 && ncols >= 0 && nt >= 0 && out, "bad arguments to tg_csr_from_triplets");
+  std::vector<int64_t> order;
+  order.reserve((size_t)nt);
+  for (int64_t t = 0; t < nt; t++) {
+    TG_REQUIRE(rows[t] >= 0 && rows[t] < nrows && cols[t] >= 0 && cols[t] < ncols, "triplet %lld out of range",
+               (long long)t);
+    if (fabs(vals[t]) > eps) order.push_back(t);
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+    if (rows[a] != rows[b]) return rows[a] < rows[b];
+    return cols[a] < cols[b];
+  });
+  std::vector<int64_t> rowptr((size_t)nrows + 1, 0);
+  std::vector<int32_t> c;
+  std::vector<double> v;
+  c.reserve(order.size());
+  v.reserve(order.size());
+  for (size_t q = 0; q < order.size(); q++) {
+    const int64_t t = order[q];
+    const bool dup = q + 1 < order.size() && rows[order[q + 1]] == rows[t] && cols[order[q + 1]] == cols[t];
+    if (dup) continue;  // a later INSERT overwrites this one
+    c.push_back(cols[t]);
+    v.push_back(vals[t]);
+    rowptr[(size_t)rows[t] + 1]++;
+  }
+  for (int64_t r = 0; r < nrows; r++) rowptr[(size_t)r + 1] += rowptr[(size_t)r];
+  return tg_csr_from_host(nrows, ncols, rowptr.data(), c.data(), v.data(), out);
+}

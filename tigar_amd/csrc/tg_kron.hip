@@ -1,0 +1,168 @@
+// Synthetic FE-side INPUT generator (not on the timed path):
+// A = sum_t (x)_k F[t][k], a Kronecker-sum of 1-D CSR factors on the tensor FE node grid,
+// e.g. the exact Q_p Laplace stiffness K1xM1xM1 + M1xK1xM1 + M1xM1xK1 that dolfin's
+// assemble() would hand to extractMatrix (tIGAr/common.py:1206-1220).  Rows are z-slab
+// ranges [row0,row1) in lexicographic node order (direction 0 fastest); columns global.
+#include "tg_common.h"
+#include <algorithm>
+
+#define TG_KRON_MAX_TERMS 4
+
+struct tg_kron_params {
+  int d, nterms;
+  int64_t n[3];
+  const int32_t *rowptr[3];
+  const int32_t *col[3];
+  const double *val[3];  // term-major: val[k][t*nnz1d[k] + q]
+  int64_t nnz1d[3];
+  int64_t row0, nrows;
+  int64_t pencil0, npencils;
+};
+
+__device__ __forceinline__ void tg_kron_pencil(const tg_kron_params &P, int64_t pencil, int64_t *b, int64_t *c) {
+  if (P.d == 1) {
+    *b = 0;
+    *c = 0;
+  } else if (P.d == 2) {
+    *b = pencil;
+    *c = 0;
+  } else {
+    *b = pencil % P.n[1];
+    *c = pencil / P.n[1];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_kron_count(tg_kron_params P, int64_t *__restrict__ rowptr) {
+  const int64_t pencil = P.pencil0 + blockIdx.x;
+  int64_t b, c;
+  tg_kron_pencil(P, pencil, &b, &c);
+  int64_t lyz = 1;
+  if (P.d > 1) lyz *= P.rowptr[1][b + 1] - P.rowptr[1][b];
+  if (P.d > 2) lyz *= P.rowptr[2][c + 1] - P.rowptr[2][c];
+  for (int64_t a = threadIdx.x; a < P.n[0]; a += 256) {
+    const int64_t lr = P.n[0] * pencil + a - P.row0;
+    if (lr < 0 || lr >= P.nrows) continue;
+    rowptr[lr] = (int64_t)(P.rowptr[0][a + 1] - P.rowptr[0][a]) * lyz;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_kron_fill(tg_kron_params P, const int64_t *__restrict__ rowptr, int32_t *__restrict__ col,
+                double *__restrict__ val) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t pencil = P.pencil0 + blockIdx.x;
+  int64_t b, c;
+  tg_kron_pencil(P, pencil, &b, &c);
+  const int y0 = (P.d > 1) ? P.rowptr[1][b] : 0;
+  const int ly = (P.d > 1) ? P.rowptr[1][b + 1] - y0 : 1;
+  const int z0 = (P.d > 2) ? P.rowptr[2][c] : 0;
+  const int lz = (P.d > 2) ? P.rowptr[2][c + 1] - z0 : 1;
+  for (int64_t a = w; a < P.n[0]; a += 4) {
+    const int64_t lr = P.n[0] * pencil + a - P.row0;
+    if (lr < 0 || lr >= P.nrows) continue;  // wave-uniform
+    const int x0 = P.rowptr[0][a];
+    const int lx = P.rowptr[0][a + 1] - x0;
+    const int L = lx * ly * lz;
+    const int64_t out0 = rowptr[lr];
+    for (int e = lane; e < L; e += 64) {
+      const int i = e % lx;
+      const int jk = e / lx;
+      const int j = jk % ly;
+      const int k = jk / ly;
+      int64_t cc = P.col[0][x0 + i];
+      if (P.d > 1) cc += P.n[0] * (int64_t)P.col[1][y0 + j];
+      if (P.d > 2) cc += P.n[0] * P.n[1] * (int64_t)P.col[2][z0 + k];
+      double s = 0.0;
+      for (int t = 0; t < P.nterms; t++) {
+        double v = P.val[0][t * P.nnz1d[0] + x0 + i];
+        if (P.d > 1) v *= P.val[1][t * P.nnz1d[1] + y0 + j];
+        if (P.d > 2) v *= P.val[2][t * P.nnz1d[2] + z0 + k];
+        s += v;
+      }
+      col[out0 + e] = (int32_t)cc;
+      val[out0 + e] = s;
+    }
+  }
+}
+
+extern "C" int tg_kron_sum_csr(int d, int nterms, const tg_kron_dir_t *dirs, int64_t row0, int64_t row1,
+                               tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(d >= 1 && d <= 3 && nterms >= 1 && nterms <= TG_KRON_MAX_TERMS && dirs && out,
+             "bad arguments to tg_kron_sum_csr");
+  tg_kron_params P;
+  memset(&P, 0, sizeof(P));
+  P.d = d;
+  P.nterms = nterms;
+  int64_t total = 1;
+  void *dev[9] = {nullptr};
+  int rc = 0;
+  for (int k = 0; k < 3; k++) P.n[k] = 1;
+  for (int k = 0; k < d && !rc; k++) {
+    const tg_kron_dir_t &D = dirs[k];
+    TG_REQUIRE(D.n >= 1 && D.rowptr && D.col && D.val, "bad 1-D factor %d", k);
+    const int64_t nnz1 = D.rowptr[D.n];
+    P.n[k] = D.n;
+    P.nnz1d[k] = nnz1;
+    total *= D.n;
+    int32_t *rp = nullptr, *cl = nullptr;
+    double *vl = nullptr;
+    rc = tg_dmalloc(&rp, D.n + 1) || tg_dmalloc(&cl, nnz1) || tg_dmalloc(&vl, nnz1 * nterms);
+    dev[3 * k] = rp;
+    dev[3 * k + 1] = cl;
+    dev[3 * k + 2] = vl;
+    if (rc) break;
+    hipMemcpyAsync(rp, D.rowptr, (D.n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+    hipMemcpyAsync(cl, D.col, nnz1 * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+    hipMemcpyAsync(vl, D.val, nnz1 * nterms * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
+    P.rowptr[k] = rp;
+    P.col[k] = cl;
+    P.val[k] = vl;
+  }
+  if (!rc && !(row0 >= 0 && row1 >= row0 && row1 <= total)) {
+    tg_set_error("tg_kron_sum_csr: row range outside [0,%lld)", (long long)total);
+    rc = 2;
+  }
+  tg_csr_s *m = nullptr;
+  if (!rc) {
+    P.row0 = row0;
+    P.nrows = row1 - row0;
+    P.pencil0 = row0 / P.n[0];
+    const int64_t pencil1 = (row1 > row0) ? (row1 - 1) / P.n[0] + 1 : P.pencil0;
+    P.npencils = pencil1 - P.pencil0;
+    int64_t *rowptr = nullptr;
+    rc = tg_dmalloc(&rowptr, P.nrows + 1);
+    if (!rc) {
+      hipMemsetAsync(rowptr, 0, (size_t)(P.nrows + 1) * sizeof(int64_t), g_tg.stream);
+      if (P.npencils > 0)
+        hipLaunchKernelGGL(k_kron_count, dim3((unsigned)P.npencils), dim3(256), 0, g_tg.stream, P, rowptr);
+      int64_t nnz = 0;
+      rc = tg_exclusive_scan_i64(rowptr, P.nrows, &nnz);
+      if (!rc) {
+        m = new tg_csr_s();
+        m->nrows = P.nrows;
+        m->ncols = total;
+        m->nnz = nnz;
+        m->rowptr = rowptr;
+        rc = tg_dmalloc(&m->col, nnz + TG_CSR_PAD) || tg_dmalloc(&m->val, nnz + TG_CSR_PAD);
+        if (!rc && P.npencils > 0 && nnz > 0) {
+          hipLaunchKernelGGL(k_kron_fill, dim3((unsigned)P.npencils), dim3(256), 0, g_tg.stream, P, rowptr, m->col,
+                             m->val);
+          if (hipGetLastError() != hipSuccess) {
+            tg_set_error("kron fill launch failed");
+            rc = 1;
+          }
+        }
+      } else
+        hipFree(rowptr);
+    }
+  }
+  hipStreamSynchronize(g_tg.stream);
+  for (int i = 0; i < 9; i++) hipFree(dev[i]);
+  if (rc) {
+    if (m) tg_csr_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return 0;
+}

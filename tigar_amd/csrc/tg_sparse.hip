@@ -1,0 +1,461 @@
+// CSR kernels on the application side of the extraction path:
+//   * explicit transpose M^T (reference FORM_MT option, tIGAr/common.py:84) -- deterministic
+//   * SpMV  y = A x      : K p in the Krylov solve, u = M U prolongation (common.py:1259),
+//                          M^T b through the explicit transpose (common.py:97-109)
+//   * MatZeroRowsColumns (common.py:1200)
+//
+// SpMV design (HBM-stream-bound, 12 B/nnz): "CSR-stream".  Rows are packed into row
+// blocks of at most TG_SPMV_CAP non-zeros; a workgroup streams its block's val[]/col[]
+// with 16-byte loads that ignore row boundaries (fully coalesced), multiplies by gathered
+// x (L2-resident), parks the products in LDS and then reduces row segments out of LDS.
+// No atomics: results are bit-reproducible.  Row blocks are laid out so that each XCD's
+// L2 sees one contiguous range of rows (x-gather locality).
+#include "tg_common.h"
+#include <algorithm>
+
+typedef double tg_d2 __attribute__((ext_vector_type(2)));
+typedef int tg_i4 __attribute__((ext_vector_type(4)));
+
+#define TG_SPMV_CAP 4096  // products (doubles) staged in LDS per workgroup
+
+// ----------------------------------------------------------------------------------------
+// plan
+// ----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_max_row_nnz(const int64_t *rowptr, int64_t nrows, int *out) {
+  __shared__ int lds[4];
+  int m = 0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nrows; i += stride) {
+    const int64_t l = rowptr[i + 1] - rowptr[i];
+    m = max(m, (int)min(l, (int64_t)0x7fffffff));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, max(max(lds[0], lds[1]), max(lds[2], lds[3])));
+}
+
+// rowblocks[b] = first row r with rowptr[r] >= b * quantum   (b = 0..nblocks), last = nrows
+__global__ void k_build_rowblocks(const int64_t *rowptr, int64_t nrows, int64_t quantum, int64_t nblocks,
+                                  int32_t *rowblocks) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nblocks) return;
+  if (b == nblocks) {
+    rowblocks[b] = (int32_t)nrows;
+    return;
+  }
+  const int64_t target = b * quantum;
+  int64_t lo = 0, hi = nrows;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid] < target)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  rowblocks[b] = (int32_t)lo;
+}
+
+int tg_spmv_plan(tg_csr_s *a) {
+  if (a->spmv_mode) return 0;
+  TG_REQUIRE(a->nrows < 0x7fffffffll, "too many rows for the SpMV plan");
+  int *dmax = (int *)g_tg.scratch;
+  TG_CHECK_HIP(hipMemsetAsync(dmax, 0, sizeof(int), g_tg.stream));
+  if (a->nrows > 0) {
+    hipLaunchKernelGGL(k_max_row_nnz, dim3(tg_grid_1d(a->nrows, 256)), dim3(256), 0, g_tg.stream, a->rowptr, a->nrows,
+                       dmax);
+    TG_LAUNCH_CHECK();
+  }
+  int hmax = 0;
+  TG_CHECK_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  a->max_row_nnz = hmax;
+  if (hmax <= TG_SPMV_CAP / 2) {
+    const int64_t quantum = TG_SPMV_CAP - hmax;
+    a->nblocks = a->nnz / quantum + 1;
+    TG_TRY(tg_dmalloc(&a->rowblocks, a->nblocks + 1));
+    hipLaunchKernelGGL(k_build_rowblocks, dim3((unsigned)tg_cdiv(a->nblocks + 1, 256)), dim3(256), 0, g_tg.stream,
+                       a->rowptr, a->nrows, quantum, a->nblocks, a->rowblocks);
+    TG_LAUNCH_CHECK();
+    a->spmv_mode = 1;
+  } else {
+    a->spmv_mode = 2;  // wave per row
+  }
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------
+// kernels
+// ----------------------------------------------------------------------------------------
+// DOT: additionally accumulates sum_r y[r] * dvec[r] into dot_partial[blockIdx.x]
+template <bool DOT>
+__global__ void __launch_bounds__(256)
+    k_spmv_stream(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+                  const double *__restrict__ x, double *__restrict__ y, const int32_t *__restrict__ rowblocks,
+                  int64_t nblocks, const double *__restrict__ dvec, double *__restrict__ dot_partial) {
+  __shared__ double prod[TG_SPMV_CAP];
+  __shared__ double red4[4];
+  const int tid = threadIdx.x;
+  const int64_t L = tg_xcd_block(blockIdx.x, nblocks);
+  double dsum = 0.0;
+  if (L < nblocks) {
+    const int64_t r0 = rowblocks[L], r1 = rowblocks[L + 1];
+    if (r1 > r0) {
+      const int64_t n0 = rowptr[r0], n1 = rowptr[r1];
+      const int64_t q0 = n0 & ~3ll;
+      for (int64_t t = q0 + 4 * tid; t < n1; t += 1024) {
+        // 16-byte streaming loads; allocations are padded so the tail over-read is legal
+        const tg_d2 v01 = __builtin_nontemporal_load(reinterpret_cast<const tg_d2 *>(val + t));
+        const tg_d2 v23 = __builtin_nontemporal_load(reinterpret_cast<const tg_d2 *>(val + t + 2));
+        const tg_i4 c = __builtin_nontemporal_load(reinterpret_cast<const tg_i4 *>(col + t));
+        const bool in0 = t >= n0, in1 = (t + 1 >= n0) && (t + 1 < n1), in2 = (t + 2 >= n0) && (t + 2 < n1),
+                   in3 = (t + 3 >= n0) && (t + 3 < n1);
+        const double x0 = in0 ? x[c.x] : 0.0;
+        const double x1 = in1 ? x[c.y] : 0.0;
+        const double x2 = in2 ? x[c.z] : 0.0;
+        const double x3 = in3 ? x[c.w] : 0.0;
+        const int64_t o = t - n0;
+        if (in0) prod[o] = v01.x * x0;
+        if (in1) prod[o + 1] = v01.y * x1;
+        if (in2) prod[o + 2] = v23.x * x2;
+        if (in3) prod[o + 3] = v23.y * x3;
+      }
+      __syncthreads();
+      const int nr = (int)(r1 - r0);
+      // lanes per row: largest power of two <= 256/nr, clipped to [1,64]
+      int G = 1;
+      while (G < 64 && G * 2 * nr <= 256) G <<= 1;
+      const int rows_per_pass = 256 / G;
+      const int sub = tid & (G - 1);
+      const int rgrp = tid / G;
+      for (int base = 0; base < nr; base += rows_per_pass) {
+        const int rr = base + rgrp;
+        double s = 0.0;
+        if (rr < nr) {
+          const int64_t a = rowptr[r0 + rr] - n0, b = rowptr[r0 + rr + 1] - n0;
+          for (int64_t q = a + sub; q < b; q += G) s += prod[q];
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (rr < nr && sub == 0) {
+          y[r0 + rr] = s;
+          if (DOT) dsum += s * dvec[r0 + rr];
+        }
+      }
+    }
+  }
+  if (DOT) {
+    dsum = tg_block_sum256(dsum, red4);
+    if (tid == 0) dot_partial[blockIdx.x] = dsum;
+  }
+}
+
+// generic fallback: one wave per row (rows longer than TG_SPMV_CAP/2)
+template <bool DOT>
+__global__ void __launch_bounds__(256)
+    k_spmv_vector(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+                  const double *__restrict__ x, double *__restrict__ y, int64_t nrows, const double *__restrict__ dvec,
+                  double *__restrict__ dot_partial) {
+  __shared__ double red4[4];
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  double dsum = 0.0;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    double s = 0.0;
+    for (int64_t q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) s += val[q] * x[col[q]];
+    s = tg_wave_sum(s);
+    if (lane == 0) {
+      y[r] = s;
+      if (DOT) dsum += s * dvec[r];
+    }
+  }
+  if (DOT) {
+    dsum = tg_block_sum256(dsum, red4);
+    if (threadIdx.x == 0) dot_partial[blockIdx.x] = dsum;
+  }
+}
+
+// y = A x with x addressed by the matrix's (global) column indices: x_shifted[col].
+// If dot_partial != nullptr also writes per-block partial sums of y . dvec (dvec indexed by
+// local row); the number of partials written is returned through the plan: nblocks (stream)
+// or the vector-mode grid size.  Returns the partial count via a->nblocks / grid.
+int tg_spmv_raw(tg_csr_s *a, const double *x_shifted, double *y, double *dot_partial, const double *dvec) {
+  TG_TRY(tg_spmv_plan(a));
+  if (a->nrows == 0) return 0;
+  if (a->spmv_mode == 1) {
+    const unsigned grid = (unsigned)(((a->nblocks + 7) / 8) * 8);  // tg_xcd_block needs a multiple of 8
+    if (dot_partial) {
+      TG_REQUIRE(grid <= TG_SCRATCH_DOUBLES / 2, "SpMV dot partials exceed scratch");
+      hipLaunchKernelGGL((k_spmv_stream<true>), dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val,
+                         x_shifted, y, a->rowblocks, a->nblocks, dvec, dot_partial);
+    } else
+      hipLaunchKernelGGL((k_spmv_stream<false>), dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val,
+                         x_shifted, y, a->rowblocks, a->nblocks, (const double *)nullptr, (double *)nullptr);
+  } else {
+    const unsigned grid = (unsigned)std::min<int64_t>(tg_cdiv(a->nrows, 4), (int64_t)g_tg.num_cu * 8);
+    if (dot_partial)
+      hipLaunchKernelGGL((k_spmv_vector<true>), dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val,
+                         x_shifted, y, a->nrows, dvec, dot_partial);
+    else
+      hipLaunchKernelGGL((k_spmv_vector<false>), dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val,
+                         x_shifted, y, a->nrows, (const double *)nullptr, (double *)nullptr);
+  }
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// number of dot partials tg_spmv_raw writes for this matrix
+int64_t tg_spmv_num_partials(tg_csr_s *a) {
+  if (a->spmv_mode == 1) return ((a->nblocks + 7) / 8) * 8;
+  return std::min<int64_t>(tg_cdiv(a->nrows, 4), (int64_t)g_tg.num_cu * 8);
+}
+
+extern "C" int tg_spmv(tg_csr_t a, tg_vec_t x, tg_vec_t y) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(a && x && y, "null argument to tg_spmv");
+  TG_REQUIRE(x->n == a->ncols, "tg_spmv: x has %lld entries, matrix has %lld columns", (long long)x->n,
+             (long long)a->ncols);
+  TG_REQUIRE(y->n == a->nrows, "tg_spmv: y has %lld entries, matrix has %lld rows", (long long)y->n,
+             (long long)a->nrows);
+  return tg_spmv_raw(a, x->d, y->d, nullptr, nullptr);
+}
+
+extern "C" int tg_spmv_t(tg_csr_t mt, tg_vec_t b, tg_vec_t y) { return tg_spmv(mt, b, y); }
+
+extern "C" int tg_spmm_host(tg_csr_t a, const double *X, int k, double *Y) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(a && X && Y && k >= 1, "bad arguments to tg_spmm_host");
+  tg_vec_t x = nullptr, y = nullptr;
+  TG_TRY(tg_vec_create(a->ncols, &x));
+  int rc = tg_vec_create(a->nrows, &y);
+  for (int j = 0; j < k && !rc; j++) {
+    rc = tg_vec_upload(x, X + (int64_t)j * a->ncols, a->ncols);
+    if (!rc) rc = tg_spmv(a, x, y);
+    if (!rc) rc = tg_vec_download(y, Y + (int64_t)j * a->nrows, a->nrows);
+  }
+  tg_vec_destroy(x);
+  tg_vec_destroy(y);
+  return rc;
+}
+
+// ----------------------------------------------------------------------------------------
+// transpose
+// ----------------------------------------------------------------------------------------
+__global__ void k_tr_count(const int32_t *__restrict__ col, int64_t nnz, unsigned long long *cnt) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) atomicAdd(&cnt[col[i]], 1ull);
+}
+
+// one wave per source row; lanes stride over its entries
+__global__ void __launch_bounds__(256)
+    k_tr_fill(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+              int64_t nrows, int64_t row_base, unsigned long long *cursor, int32_t *__restrict__ colT,
+              double *__restrict__ valT) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    for (int64_t q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) {
+      const unsigned long long pos = atomicAdd(&cursor[col[q]], 1ull);
+      colT[pos] = (int32_t)(r + row_base);
+      valT[pos] = val[q];
+    }
+  }
+}
+
+// sorts each row segment by column index: block per row, bitonic network in LDS
+template <int CAPACITY>
+__global__ void __launch_bounds__(256)
+    k_sort_rows(const int64_t *__restrict__ rowptr, int32_t *__restrict__ col, double *__restrict__ val,
+                int64_t nrows, int min_len, int max_len) {
+  __shared__ int32_t skey[CAPACITY];
+  __shared__ double sval[CAPACITY];
+  for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const int64_t a = rowptr[r];
+    const int len = (int)(rowptr[r + 1] - a);
+    if (len < min_len || len > max_len || len < 2) continue;  // uniform per block
+    int n2 = 1;
+    while (n2 < len) n2 <<= 1;
+    for (int i = threadIdx.x; i < n2; i += 256) {
+      skey[i] = (i < len) ? col[a + i] : 0x7fffffff;
+      sval[i] = (i < len) ? val[a + i] : 0.0;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = threadIdx.x; i < n2; i += 256) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const bool up = (i & k) == 0;
+            const int32_t ki = skey[i], kj = skey[ixj];
+            if ((ki > kj) == up) {
+              skey[i] = kj;
+              skey[ixj] = ki;
+              const double t = sval[i];
+              sval[i] = sval[ixj];
+              sval[ixj] = t;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = threadIdx.x; i < len; i += 256) {
+      col[a + i] = skey[i];
+      val[a + i] = sval[i];
+    }
+    __syncthreads();
+  }
+}
+
+// sorts the rows of `m` by column (values follow); used after atomically-ordered fills
+int tg_csr_sort_rows(tg_csr_s *m) {
+  if (m->nrows == 0 || m->nnz == 0) return 0;
+  int *dmax = (int *)g_tg.scratch;
+  TG_CHECK_HIP(hipMemsetAsync(dmax, 0, sizeof(int), g_tg.stream));
+  hipLaunchKernelGGL(k_max_row_nnz, dim3(tg_grid_1d(m->nrows, 256)), dim3(256), 0, g_tg.stream, m->rowptr, m->nrows,
+                     dmax);
+  int hmax = 0;
+  TG_CHECK_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  const unsigned grid = (unsigned)std::min<int64_t>(m->nrows, (int64_t)g_tg.num_cu * 64);
+  hipLaunchKernelGGL((k_sort_rows<512>), dim3(grid), dim3(256), 0, g_tg.stream, m->rowptr, m->col, m->val, m->nrows, 2,
+                     512);
+  if (hmax > 512)
+    hipLaunchKernelGGL((k_sort_rows<2048>), dim3(grid), dim3(256), 0, g_tg.stream, m->rowptr, m->col, m->val, m->nrows,
+                       513, 2048);
+  if (hmax > 2048)
+    hipLaunchKernelGGL((k_sort_rows<8192>), dim3(grid), dim3(256), 0, g_tg.stream, m->rowptr, m->col, m->val, m->nrows,
+                       2049, 8192);
+  TG_LAUNCH_CHECK();
+  if (hmax > 8192) {
+    // rare: very long rows -> host fallback
+    std::vector<int64_t> rp((size_t)m->nrows + 1);
+    std::vector<int32_t> c((size_t)m->nnz);
+    std::vector<double> v((size_t)m->nnz);
+    TG_TRY(tg_csr_download(m, rp.data(), c.data(), v.data()));
+    std::vector<std::pair<int32_t, double>> tmp;
+    for (int64_t r = 0; r < m->nrows; r++) {
+      const int64_t len = rp[r + 1] - rp[r];
+      if (len <= 8192) continue;
+      tmp.resize((size_t)len);
+      for (int64_t i = 0; i < len; i++) tmp[i] = {c[rp[r] + i], v[rp[r] + i]};
+      std::sort(tmp.begin(), tmp.end(), [](auto &x, auto &y) { return x.first < y.first; });
+      for (int64_t i = 0; i < len; i++) {
+        c[rp[r] + i] = tmp[i].first;
+        v[rp[r] + i] = tmp[i].second;
+      }
+    }
+    TG_CHECK_HIP(hipMemcpy(m->col, c.data(), (size_t)m->nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+    TG_CHECK_HIP(hipMemcpy(m->val, v.data(), (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+// transpose of a row block whose local rows start at global row `row_base`; the result has
+// m->ncols rows and its column indices are global row numbers of the source.
+int tg_csr_transpose_block(tg_csr_s *m, int64_t row_base, int64_t out_ncols, tg_csr_s **out) {
+  tg_csr_s *t = nullptr;
+  TG_TRY(tg_csr_alloc(m->ncols, out_ncols, m->nnz, &t));
+  TG_CHECK_HIP(hipMemsetAsync(t->rowptr, 0, (size_t)(m->ncols + 1) * sizeof(int64_t), g_tg.stream));
+  if (m->nnz > 0) {
+    hipLaunchKernelGGL(k_tr_count, dim3(tg_grid_1d(m->nnz, 256)), dim3(256), 0, g_tg.stream, m->col, m->nnz,
+                       (unsigned long long *)t->rowptr);
+    TG_LAUNCH_CHECK();
+  }
+  int64_t total = 0;
+  if (tg_exclusive_scan_i64(t->rowptr, m->ncols, &total) || total != m->nnz) {
+    if (total != m->nnz) tg_set_error("transpose: nnz mismatch after scan (%lld vs %lld)", (long long)total,
+                                      (long long)m->nnz);
+    tg_csr_destroy(t);
+    return 1;
+  }
+  if (m->nnz > 0) {
+    unsigned long long *cursor = nullptr;
+    TG_TRY(tg_dmalloc(&cursor, m->ncols + 1));
+    TG_CHECK_HIP(hipMemcpyAsync(cursor, t->rowptr, (size_t)(m->ncols + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice,
+                                g_tg.stream));
+    const unsigned grid = (unsigned)std::min<int64_t>(tg_cdiv(m->nrows, 4), (int64_t)g_tg.num_cu * 16);
+    hipLaunchKernelGGL(k_tr_fill, dim3(grid), dim3(256), 0, g_tg.stream, m->rowptr, m->col, m->val, m->nrows, row_base,
+                       cursor, t->col, t->val);
+    TG_LAUNCH_CHECK();
+    int rc = tg_csr_sort_rows(t);
+    hipStreamSynchronize(g_tg.stream);
+    hipFree(cursor);
+    if (rc) {
+      tg_csr_destroy(t);
+      return rc;
+    }
+  }
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  *out = t;
+  return 0;
+}
+
+extern "C" int tg_csr_transpose(tg_csr_t m, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(m && out, "null argument to tg_csr_transpose");
+  return tg_csr_transpose_block(m, 0, m->nrows, out);
+}
+
+// ----------------------------------------------------------------------------------------
+// MatZeroRowsColumns
+// ----------------------------------------------------------------------------------------
+__global__ void k_mark(uint8_t *mask, int64_t n, const int32_t *dofs, int64_t nd) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nd) {
+    const int32_t d = dofs[i];
+    if (d >= 0 && d < n) mask[d] = 1;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_zero_rows_cols(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, double *__restrict__ val,
+                     int64_t nrows, int64_t row0, const uint8_t *__restrict__ mask, double diag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    const int64_t g = r + row0;
+    const bool mr = mask[g] != 0;
+    for (int64_t q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) {
+      const int32_t c = col[q];
+      if (mr || mask[c]) val[q] = (mr && c == g) ? diag : 0.0;
+    }
+  }
+}
+
+// builds the byte mask over all `ncols` global dofs from a host index list (device pointer out)
+int tg_build_dof_mask(const int32_t *dofs, int64_t n, int64_t ndofs_total, uint8_t **mask_out) {
+  uint8_t *mask = nullptr;
+  TG_TRY(tg_dmalloc(&mask, ndofs_total));
+  TG_CHECK_HIP(hipMemsetAsync(mask, 0, (size_t)(ndofs_total > 0 ? ndofs_total : 1), g_tg.stream));
+  if (n > 0) {
+    int32_t *d = nullptr;
+    TG_TRY(tg_dmalloc(&d, n));
+    TG_CHECK_HIP(hipMemcpyAsync(d, dofs, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream));
+    hipLaunchKernelGGL(k_mark, dim3((unsigned)tg_cdiv(n, 256)), dim3(256), 0, g_tg.stream, mask, ndofs_total, d, n);
+    TG_LAUNCH_CHECK();
+    TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+    hipFree(d);
+  }
+  *mask_out = mask;
+  return 0;
+}
+
+extern "C" int tg_zero_rows_cols(tg_csr_t k, int64_t row0, const int32_t *dofs, int64_t n, double diag) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(k, "null matrix");
+  if (n <= 0 || k->nrows == 0) return 0;
+  uint8_t *mask = nullptr;
+  TG_TRY(tg_build_dof_mask(dofs, n, k->ncols, &mask));
+  const unsigned grid = (unsigned)std::min<int64_t>(tg_cdiv(k->nrows, 4), (int64_t)g_tg.num_cu * 16);
+  hipLaunchKernelGGL(k_zero_rows_cols, dim3(grid), dim3(256), 0, g_tg.stream, k->rowptr, k->col, k->val, k->nrows, row0,
+                     mask, diag);
+  TG_LAUNCH_CHECK();
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  hipFree(mask);
+  return 0;
+}

@@ -1,0 +1,423 @@
+"""
+Thin object layer over the C-ABI: device-resident vectors / CSR matrices and the kernels of
+the extraction path.  These are the objects the tIGAr-compatible API (``tigar_amd.common``)
+hands around in place of dolfin's PETScMatrix / PETScVector.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import check, handle, tg_dir_t, tg_kron_dir_t, c_f64p, c_i32p, c_i64p
+
+TG_KSP_CG, TG_KSP_GMRES = 0, 1
+TG_PC_NONE, TG_PC_JACOBI = 0, 1
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class DeviceVector(object):
+    """fp64 vector in HBM (stands in for dolfin PETScVector on this path)."""
+
+    def __init__(self, n=None, data=None, _handle=None):
+        L = _lib.lib()
+        self._h = handle()
+        if _handle is not None:
+            self._h = _handle
+            return
+        if data is not None:
+            data = _f64(data)
+            n = data.shape[0]
+        check(L.tg_vec_create(int(n), C.byref(self._h)), "tg_vec_create")
+        if data is not None:
+            check(L.tg_vec_upload(self._h, _p(data, c_f64p), n), "tg_vec_upload")
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().tg_vec_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def size(self):
+        n = C.c_int64()
+        check(_lib.lib().tg_vec_size(self._h, C.byref(n)))
+        return n.value
+
+    __len__ = size
+
+    # dolfin GenericVector-style accessors
+    def get_local(self):
+        out = np.empty(self.size(), dtype=np.float64)
+        check(_lib.lib().tg_vec_download(self._h, _p(out, c_f64p), out.shape[0]), "tg_vec_download")
+        return out
+
+    def set_local(self, values):
+        values = _f64(values)
+        check(_lib.lib().tg_vec_upload(self._h, _p(values, c_f64p), values.shape[0]), "tg_vec_upload")
+
+    to_numpy = get_local
+
+    def copy(self):
+        v = DeviceVector(self.size())
+        check(_lib.lib().tg_vec_copy(v._h, self._h))
+        return v
+
+    def zero(self):
+        check(_lib.lib().tg_vec_fill(self._h, 0.0))
+
+    def axpy(self, a, x):
+        check(_lib.lib().tg_vec_axpy(self._h, float(a), x._h))
+
+    def inner(self, other):
+        out = C.c_double()
+        check(_lib.lib().tg_vec_dot(self._h, other._h, C.byref(out)))
+        return out.value
+
+    def norm(self, kind="l2"):
+        return float(np.sqrt(self.inner(self)))
+
+    def zero_entries(self, dofs):
+        dofs = _i32(dofs)
+        if dofs.size:
+            check(_lib.lib().tg_vec_zero_entries(self._h, _p(dofs, c_i32p), dofs.size))
+
+
+class DeviceCSR(object):
+    """CSR row block in HBM: int64 rowptr, int32 (global) columns, fp64 values."""
+
+    def __init__(self, _handle):
+        self._h = _handle
+        self._T = None          # cached explicit transpose
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().tg_csr_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def from_scipy(A):
+        import scipy.sparse as sp
+        A = sp.csr_matrix(A)
+        A.sort_indices()
+        rowptr = _i64(A.indptr)
+        col = _i32(A.indices)
+        val = _f64(A.data)
+        h = handle()
+        check(_lib.lib().tg_csr_from_host(A.shape[0], A.shape[1], _p(rowptr, c_i64p), _p(col, c_i32p),
+                                          _p(val, c_f64p), C.byref(h)), "tg_csr_from_host")
+        return DeviceCSR(h)
+
+    @property
+    def shape(self):
+        r, c, z = C.c_int64(), C.c_int64(), C.c_int64()
+        check(_lib.lib().tg_csr_dims(self._h, C.byref(r), C.byref(c), C.byref(z)))
+        return (r.value, c.value)
+
+    @property
+    def nnz(self):
+        r, c, z = C.c_int64(), C.c_int64(), C.c_int64()
+        check(_lib.lib().tg_csr_dims(self._h, C.byref(r), C.byref(c), C.byref(z)))
+        return z.value
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        (nr, nc), nnz = self.shape, self.nnz
+        rowptr = np.empty(nr + 1, dtype=np.int64)
+        col = np.empty(nnz, dtype=np.int32)
+        val = np.empty(nnz, dtype=np.float64)
+        check(_lib.lib().tg_csr_download(self._h, _p(rowptr, c_i64p), _p(col, c_i32p), _p(val, c_f64p)),
+              "tg_csr_download")
+        return sp.csr_matrix((val, col, rowptr), shape=(nr, nc))
+
+    def transpose(self):
+        if self._T is None:
+            h = handle()
+            check(_lib.lib().tg_csr_transpose(self._h, C.byref(h)), "tg_csr_transpose")
+            self._T = DeviceCSR(h)
+        return self._T
+
+    def mult(self, x, y=None):
+        """y = A x"""
+        if y is None:
+            y = DeviceVector(self.shape[0])
+        check(_lib.lib().tg_spmv(self._h, x._h, y._h), "tg_spmv")
+        return y
+
+    def __mul__(self, x):
+        if isinstance(x, DeviceVector):
+            return self.mult(x)
+        return NotImplemented
+
+    def mult_transpose(self, b, y=None):
+        """y = A^T b through the explicit transpose (scatter-free)."""
+        T = self.transpose()
+        if y is None:
+            y = DeviceVector(T.shape[0])
+        check(_lib.lib().tg_spmv_t(T._h, b._h, y._h), "tg_spmv_t")
+        return y
+
+    def spmm_host(self, X):
+        X = np.asfortranarray(X, dtype=np.float64)
+        if X.ndim == 1:
+            X = X.reshape(-1, 1, order="F")
+        k = X.shape[1]
+        Y = np.empty((self.shape[0], k), dtype=np.float64, order="F")
+        check(_lib.lib().tg_spmm_host(self._h, _p(X, c_f64p), k, _p(Y, c_f64p)), "tg_spmm_host")
+        return Y
+
+    def zero_rows_cols(self, dofs, diag=1.0, row0=0):
+        dofs = _i32(dofs)
+        if dofs.size:
+            check(_lib.lib().tg_zero_rows_cols(self._h, int(row0), _p(dofs, c_i32p), dofs.size, float(diag)),
+                  "tg_zero_rows_cols")
+
+
+# ------------------------------------------------------------------------------- extraction
+class _DirPack(object):
+    """Keeps the numpy buffers of a tg_dir_t array alive."""
+
+    def __init__(self, splines1d, nodes1d):
+        self.keep = []
+        self.arr = (tg_dir_t * len(splines1d))()
+        for k, (s, x) in enumerate(zip(splines1d, nodes1d)):
+            ghost = _f64(s.ghostKnots)
+            x = _f64(x) if x is not None else np.zeros(0)
+            self.keep += [ghost, x]
+            d = self.arr[k]
+            d.p = int(s.p)
+            d.nknots = int(len(s.knots))
+            d.ghost = _p(ghost, c_f64p)
+            d.mult_first = int(s.multiplicities[0])
+            d.mult_last = int(s.multiplicities[-1])
+            d.ncp = int(s.ncp)
+            d.nnodes = int(x.shape[0])
+            d.nodes = _p(x, c_f64p)
+
+
+def extract_csr_tensor(splines1d, nodes1d, col_offset, ncols, eps, row0=None, row1=None):
+    """generateM for a BSpline on the implicit tensor node grid (kernel path)."""
+    pack = _DirPack(splines1d, nodes1d)
+    total = 1
+    for x in nodes1d:
+        total *= len(x)
+    row0 = 0 if row0 is None else int(row0)
+    row1 = total if row1 is None else int(row1)
+    h = handle()
+    check(_lib.lib().tg_extract_csr_tensor(len(splines1d), pack.arr, int(col_offset), int(ncols), float(eps),
+                                           row0, row1, C.byref(h)), "tg_extract_csr_tensor")
+    return DeviceCSR(h)
+
+
+def extract_csr_points(splines1d, x, col_offset, ncols, eps):
+    x = _f64(x)
+    if x.ndim == 1:
+        x = x.reshape(-1, 1)
+    pack = _DirPack(splines1d, [None] * len(splines1d))
+    h = handle()
+    check(_lib.lib().tg_extract_csr_points(len(splines1d), pack.arr, int(col_offset), int(ncols), float(eps),
+                                           _p(x, c_f64p), x.shape[0], C.byref(h)), "tg_extract_csr_points")
+    return DeviceCSR(h)
+
+
+def csr_vstack(blocks):
+    arr = (handle * len(blocks))(*[b._h for b in blocks])
+    h = handle()
+    check(_lib.lib().tg_csr_vstack(len(blocks), arr, C.byref(h)), "tg_csr_vstack")
+    return DeviceCSR(h)
+
+
+def csr_from_triplets(nrows, ncols, rows, cols, vals, eps):
+    rows, cols, vals = _i64(rows), _i32(cols), _f64(vals)
+    h = handle()
+    check(_lib.lib().tg_csr_from_triplets(int(nrows), int(ncols), rows.size, _p(rows, c_i64p), _p(cols, c_i32p),
+                                          _p(vals, c_f64p), float(eps), C.byref(h)), "tg_csr_from_triplets")
+    return DeviceCSR(h)
+
+
+def eval_basis_1d(spline1, u):
+    """Device twin of BSpline1.getKnotSpan / getNodes / basisFuncs for an array of u."""
+    u = _f64(u)
+    pack = _DirPack([spline1], [None])
+    n = u.shape[0]
+    span = np.empty(n, dtype=np.int32)
+    idx = np.empty((n, spline1.p + 1), dtype=np.int32)
+    val = np.empty((n, spline1.p + 1), dtype=np.float64)
+    check(_lib.lib().tg_eval_basis_1d(pack.arr, _p(u, c_f64p), n, _p(span, c_i32p), _p(idx, c_i32p),
+                                      _p(val, c_f64p)), "tg_eval_basis_1d")
+    return span, idx, val
+
+
+# ------------------------------------------------------------------------------- PtAP
+class PtAPPlan(object):
+    def __init__(self, h):
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().tg_ptap_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def ptap_symbolic(A, M, MT, a_row0=0, m_row0=0, mt_row0=0):
+    h = handle()
+    check(_lib.lib().tg_ptap_symbolic(A._h, int(a_row0), M._h, int(m_row0), MT._h, int(mt_row0), C.byref(h)),
+          "tg_ptap_symbolic")
+    return PtAPPlan(h)
+
+
+def ptap_numeric(plan, A, M, MT, zero_dofs=None, diag=1.0):
+    h = handle()
+    if zero_dofs is not None and len(zero_dofs):
+        zd = _i32(zero_dofs)
+        check(_lib.lib().tg_ptap_numeric(plan._h, A._h, M._h, MT._h, _p(zd, c_i32p), zd.size, float(diag),
+                                         C.byref(h)), "tg_ptap_numeric")
+    else:
+        check(_lib.lib().tg_ptap_numeric(plan._h, A._h, M._h, MT._h, None, 0, float(diag), C.byref(h)),
+              "tg_ptap_numeric")
+    return DeviceCSR(h)
+
+
+# ------------------------------------------------------------------------------- Krylov
+def krylov_solve(K, b, x, method="cg", pc="jacobi", rtol=1e-6, atol=1e-15, maxit=10000, restart=30, comm=None):
+    meth = {"cg": TG_KSP_CG, "gmres": TG_KSP_GMRES}[method]
+    pcc = {"none": TG_PC_NONE, "jacobi": TG_PC_JACOBI}[pc]
+    iters, status, res = C.c_int(), C.c_int(), C.c_double()
+    check(_lib.lib().tg_krylov_solve(K._h, b._h, x._h, meth, pcc, float(rtol), float(atol), int(maxit), int(restart),
+                                     comm._h if comm is not None else None, C.byref(iters), C.byref(res),
+                                     C.byref(status)), "tg_krylov_solve")
+    return iters.value, res.value, status.value
+
+
+# ------------------------------------------------------------------------------- synthetic inputs
+def kron_sum_csr(factors, row0=None, row1=None):
+    """A = sum_t kron(F[t][d-1], ..., F[t][0]) (direction 0 fastest).  ``factors[t][k]`` are
+    scipy CSR 1-D matrices; all terms must share one pattern per direction."""
+    import scipy.sparse as sp
+    nterms = len(factors)
+    d = len(factors[0])
+    arr = (tg_kron_dir_t * d)()
+    keep = []
+    total = 1
+    for k in range(d):
+        pat = sp.csr_matrix(factors[0][k])
+        pat.sort_indices()
+        n = pat.shape[0]
+        total *= n
+        vals = []
+        for t in range(nterms):
+            F = sp.csr_matrix(factors[t][k])
+            F.sort_indices()
+            if F.nnz != pat.nnz or not np.array_equal(F.indices, pat.indices) \
+                    or not np.array_equal(F.indptr, pat.indptr):
+                # bring onto the shared pattern (explicit zeros)
+                F = (F + pat * 0.0).tocsr()
+                F.sort_indices()
+                if not np.array_equal(F.indices, pat.indices):
+                    raise ValueError("1-D factors of direction %d do not share a pattern" % k)
+            vals.append(_f64(F.data))
+        rp, cl, vl = _i32(pat.indptr), _i32(pat.indices), _f64(np.concatenate(vals))
+        keep += [rp, cl, vl]
+        arr[k].n = n
+        arr[k].rowptr = _p(rp, c_i32p)
+        arr[k].col = _p(cl, c_i32p)
+        arr[k].val = _p(vl, c_f64p)
+    row0 = 0 if row0 is None else int(row0)
+    row1 = total if row1 is None else int(row1)
+    h = handle()
+    check(_lib.lib().tg_kron_sum_csr(d, nterms, arr, row0, row1, C.byref(h)), "tg_kron_sum_csr")
+    return DeviceCSR(h)
+
+
+def vec_tensor3(b1d, scale=1.0, row0=None, row1=None):
+    d = len(b1d)
+    bs = [_f64(b) for b in b1d]
+    n = _i64([b.shape[0] for b in bs])
+    total = int(np.prod(n))
+    row0 = 0 if row0 is None else int(row0)
+    row1 = total if row1 is None else int(row1)
+    out = DeviceVector(row1 - row0)
+    ptrs = (c_f64p * d)(*[_p(b, c_f64p) for b in bs])
+    check(_lib.lib().tg_vec_tensor3(out._h, d, ptrs, _p(n, c_i64p), float(scale), row0, row1), "tg_vec_tensor3")
+    return out
+
+
+# ------------------------------------------------------------------------------- timers / info
+def timer_start(slot=0):
+    check(_lib.lib().tg_timer_start(slot))
+
+
+def timer_stop(slot=0):
+    ms = C.c_double()
+    check(_lib.lib().tg_timer_stop(slot, C.byref(ms)))
+    return ms.value
+
+
+def sync():
+    check(_lib.lib().tg_sync())
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    ncu, hbm = C.c_int(), C.c_int64()
+    check(_lib.lib().tg_device_info(name, 256, C.byref(ncu), C.byref(hbm)))
+    return {"name": name.value.decode(), "num_cu": ncu.value, "hbm_bytes": hbm.value}
+
+
+def mem_info():
+    f, t = C.c_int64(), C.c_int64()
+    check(_lib.lib().tg_mem_info(C.byref(f), C.byref(t)))
+    return f.value, t.value
+
+
+# ------------------------------------------------------------------------------- multi-GPU
+class Comm(object):
+    """RCCL communicator (one process per GPU) + z-slab descriptor."""
+
+    def __init__(self, unique_id, rank, world):
+        self._h = handle()
+        self.rank, self.world = rank, world
+        check(_lib.lib().tg_comm_create(unique_id, rank, world, C.byref(self._h)), "tg_comm_create")
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(_lib.lib().tg_comm_unique_id(buf), "tg_comm_unique_id")
+        return buf.raw
+
+    def set_slab(self, g0, g1, halo_lo, halo_hi, nglobal):
+        check(_lib.lib().tg_comm_set_slab(self._h, int(g0), int(g1), int(halo_lo), int(halo_hi), int(nglobal)),
+              "tg_comm_set_slab")
+
+    def allreduce_sum(self, values):
+        v = _f64(np.atleast_1d(values)).copy()
+        check(_lib.lib().tg_comm_allreduce_sum(self._h, _p(v, c_f64p), v.size), "tg_comm_allreduce_sum")
+        return v
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().tg_comm_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
