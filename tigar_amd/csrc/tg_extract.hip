@@ -47,6 +47,7 @@ __device__ __forceinline__ int tg_knot_span(const tg_dir_dev &D, double u) {
 // Piegl-Tiller exactly as coded at tIGAr/BSplines.py:102-119; only the last column of
 // the reference's ndu table is kept, the arithmetic is identical).
 __device__ __forceinline__ void tg_basis_funcs(const tg_dir_dev &D, int span, double u, double *N) {
+#pragma clang fp contract(off)
   const int p = D.p;
   const int nG = p + 1;
   const int i = span + 1;
