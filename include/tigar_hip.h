@@ -35,6 +35,12 @@ int tg_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 int tg_timer_start(int slot);
 int tg_timer_stop(int slot, double *ms);   /* synchronises; elapsed ms since start(slot) */
 
+/* Per-kernel accounting filled by the library while it runs (HIP events on the library's
+ * stream, resolved at the next host sync).  slot 0: the SpMV inside tg_krylov_solve. */
+enum { TG_PROF_KSP_SPMV = 0, TG_PROF_NSLOTS = 4 };
+int tg_prof_reset(void);
+int tg_prof_get(int slot, double *total_ms, int64_t *count);
+
 /* ---- vectors ------------------------------------------------------------------ */
 int tg_vec_create(int64_t n, tg_vec_t *out);               /* zero-initialised */
 int tg_vec_destroy(tg_vec_t v);

@@ -1,0 +1,322 @@
+"""
+The ``BSplines`` module of tigar_amd -- same public surface as the reference's
+``tIGAr/BSplines.py`` (uniformKnots, BSpline1, BSpline, ExplicitBSplineControlMesh), with
+the FE mesh replaced by an implicit tensor-product Q_p node grid and every basis-function
+evaluation executed by the HIP kernels (device twin of ``basisFuncsInner``,
+tIGAr/BSplines.py:73-120).  Host code here is bookkeeping only (knot vectors, index maps).
+"""
+import numpy
+
+from .common import (AbstractScalarBasis, AbstractControlMesh, INDEX_TYPE,
+                     USE_RECT_ELEM_DEFAULT, worldcomm, DOLFIN_EPS, near, TensorNodeGrid)
+from . import device as _dev
+
+# custom eps for checking knots (tIGAr/BSplines.py:42)
+KNOT_NEAR_EPS = 10.0 * DOLFIN_EPS
+
+
+def uniformKnots(p, start, end, N, periodic=False, continuityDrop=0):
+    """
+    Uniform open (or periodic) knot vector of degree ``p`` with ``N`` elements; interior
+    knots have multiplicity ``continuityDrop+1``.  Same values as the reference
+    (tIGAr/BSplines.py:14-38): interior knots are ``start + float(i)*h``.
+    Raises ``ValueError`` where the reference prints an error and exits.
+    """
+    if continuityDrop >= p:
+        raise ValueError("Continuity drop too high for spline degree.")
+    retval = []
+    if not periodic:
+        retval += [start for _ in range(p - continuityDrop)]
+    h = (end - start) / float(N)
+    for i in range(0, N + 1):
+        retval += [start + float(i) * h for _ in range(continuityDrop + 1)]
+    if not periodic:
+        retval += [end for _ in range(p - continuityDrop)]
+    return retval
+
+
+class BSpline1(object):
+    """
+    Scalar univariate B-spline (knot bookkeeping of tIGAr/BSplines.py:164-351).
+    Evaluation methods run on the GPU.
+    """
+
+    def __init__(self, p, knots):
+        self.p = int(p)
+        self.knots = numpy.array(knots, dtype=numpy.float64)
+        self.computeNel()
+        # unique knots and multiplicities (needed for the FE node grid)
+        newKnot = numpy.ones(len(self.knots), dtype=bool)
+        for i in range(1, len(self.knots)):
+            newKnot[i] = not near(self.knots[i], self.knots[i - 1], eps=KNOT_NEAR_EPS)
+        # first knot of each run, exactly as the reference stores it
+        self.uniqueKnots = self.knots[newKnot].copy()
+        starts = numpy.flatnonzero(newKnot)
+        self.multiplicities = numpy.diff(numpy.append(starts, len(self.knots))).astype(INDEX_TYPE)
+        self.ncp = self.computeNcp()
+        self.nGhost = self.p + 1
+        self.ghostKnots = self.computeGhostKnots()
+
+    def computeNel(self):
+        """Number of non-degenerate knot spans (tIGAr/BSplines.py:236-244)."""
+        self.nel = 0
+        for i in range(1, len(self.knots)):
+            if not near(self.knots[i], self.knots[i - 1], eps=KNOT_NEAR_EPS):
+                self.nel += 1
+
+    def getKnot(self, i):
+        """Knot with a possibly out-of-range index: periodic ghost continuation
+        (tIGAr/BSplines.py:246-260)."""
+        n = len(self.knots)
+        if i < 0:
+            ii = n - int(self.multiplicities[-1]) + i
+            return self.knots[0] - (self.knots[-1] - self.knots[ii])
+        elif i >= n:
+            ii = i - n + int(self.multiplicities[0])
+            return self.knots[-1] + (self.knots[ii] - self.knots[0])
+        return self.knots[i]
+
+    def computeGhostKnots(self):
+        return numpy.array([self.getKnot(i) for i in
+                            range(-self.nGhost, len(self.knots) + self.nGhost)])
+
+    def normalizeKnotVector(self):
+        L = self.knots[-1] - self.knots[0]
+        self.knots = (self.knots - self.knots[0]) / L
+        self.uniqueKnots = (self.uniqueKnots - self.uniqueKnots[0]) / L
+        self.ghostKnots = self.computeGhostKnots()
+
+    def isDiscontinuous(self):
+        return bool(numpy.any(self.multiplicities[1:-1] > self.p))
+
+    def greville(self, i):
+        """Greville parameter of the i-th control point (tIGAr/BSplines.py:262-271)."""
+        retval = 0.0
+        for j in range(i, i + self.p):
+            retval += self.getKnot(j + 1)
+        retval /= float(self.p)
+        return retval
+
+    def computeNcp(self):
+        return len(self.knots) - int(self.multiplicities[0])
+
+    def getNcp(self):
+        return self.ncp
+
+    # ---- evaluation: device twin of getKnotSpan / getNodes / basisFuncs -------------
+    def evalBatch(self, us):
+        """(spans, nodes[n,p+1], values[n,p+1]) for an array of parameters."""
+        return _dev.eval_basis_1d(self, numpy.atleast_1d(numpy.asarray(us, dtype=numpy.float64)))
+
+    def getKnotSpan(self, u):
+        return int(self.evalBatch([u])[0][0])
+
+    def getNodes(self, u):
+        return [int(i) for i in self.evalBatch([u])[1][0]]
+
+    def basisFuncs(self, knotSpan, u):
+        # knotSpan is implied by u (the reference recomputes it the same way before calling)
+        return self.evalBatch([u])[2][0]
+
+    # ---- FE node grid along this direction ------------------------------------------
+    def feNodes(self, degree, dg=False):
+        """
+        Parametric coordinates of the Lagrange degree-``degree`` nodes on the knot mesh:
+        equispaced reference points mapped affinely, x = x0*(1-t) + x1*t with t = j/degree,
+        so vertex nodes lie exactly on the unique knots (the reference moves the dolfin
+        mesh vertices onto ``uniqueKnots``, tIGAr/BSplines.py:527-536).  CG: nel*degree+1
+        nodes; DG: nel*(degree+1).
+        """
+        uk = self.uniqueKnots
+        t = numpy.arange(degree + 1, dtype=numpy.float64) / float(degree)
+        x = uk[:-1, None] * (1.0 - t[None, :]) + uk[1:, None] * t[None, :]
+        x[:, 0] = uk[:-1]
+        x[:, -1] = uk[1:]
+        if dg:
+            return x.reshape(-1).copy()
+        return numpy.append(x[:, :-1].reshape(-1), uk[-1])
+
+
+def ij2dof(i, j, M):
+    return j * M + i
+
+
+def ijk2dof(i, j, k, M, N):
+    return k * (M * N) + j * M + i
+
+
+def dof2ij(dof, M):
+    return (dof % M, dof // M)
+
+
+def dof2ijk(dof, M, N):
+    ij = dof % (M * N)
+    return (ij % M, ij // M, dof // (M * N))
+
+
+class BSpline(AbstractScalarBasis):
+    """
+    ``AbstractScalarBasis`` for a uni-, bi- or tri-variate B-spline
+    (tIGAr/BSplines.py:374-649).
+    """
+
+    def __init__(self, degrees, kvecs, useRect=USE_RECT_ELEM_DEFAULT, overRefine=0):
+        self.nvar = len(degrees)
+        if self.nvar > 3 or self.nvar < 1:
+            raise ValueError("Unsupported parametric dimension.")
+        if not useRect:
+            raise NotImplementedError("simplicial extraction elements need FEniCS meshes; "
+                                      "tigar_amd extracts to tensor-product (quad/hex) elements")
+        if overRefine:
+            raise NotImplementedError("overRefine is only supported with simplicial elements "
+                                      "(tIGAr/BSplines.py:393)")
+        self.splines = [BSpline1(degrees[i], kvecs[i]) for i in range(self.nvar)]
+        self.useRect = useRect
+        self.overRefine = overRefine
+        self.ncp = self.computeNcp()
+        self.nel = self.computeNel()
+
+    def normalizeKnotVectors(self):
+        for s in self.splines:
+            s.normalizeKnotVector()
+
+    def needsDG(self):
+        return any(s.isDiscontinuous() for s in self.splines)
+
+    def useRectangularElements(self):
+        return self.useRect
+
+    def getPrealloc(self):
+        totalFuncs = 1
+        for spline in self.splines:
+            totalFuncs *= (spline.p + 1)
+        return totalFuncs
+
+    def getNodesAndEvalsBatch(self, X):
+        """Vectorised ``getNodesAndEvals``: X is [n, nvar]; returns (cols[n,C], vals[n,C]) in
+        the reference's entry order (i outer, then j, k innermost; value (Nu*Nv)*Nw)."""
+        X = numpy.asarray(X, dtype=numpy.float64).reshape(-1, self.nvar)
+        tabs = [self.splines[d].evalBatch(X[:, d]) for d in range(self.nvar)]
+        n = X.shape[0]
+        if self.nvar == 1:
+            return tabs[0][1].astype(numpy.int64), tabs[0][2]
+        M = self.splines[0].getNcp()
+        if self.nvar == 2:
+            cols = tabs[0][1][:, :, None].astype(numpy.int64) + M * tabs[1][1][:, None, :]
+            vals = tabs[0][2][:, :, None] * tabs[1][2][:, None, :]
+            return cols.reshape(n, -1), vals.reshape(n, -1)
+        N = self.splines[1].getNcp()
+        cols = (tabs[0][1][:, :, None, None].astype(numpy.int64) + M * tabs[1][1][:, None, :, None]
+                + M * N * tabs[2][1][:, None, None, :])
+        vals = (tabs[0][2][:, :, None, None] * tabs[1][2][:, None, :, None]) * tabs[2][2][:, None, None, :]
+        return cols.reshape(n, -1), vals.reshape(n, -1)
+
+    def getNodesAndEvals(self, xi):
+        cols, vals = self.getNodesAndEvalsBatch(numpy.asarray(xi, dtype=numpy.float64).reshape(1, -1))
+        return [[int(c), float(v)] for c, v in zip(cols[0], vals[0])]
+
+    def generateMesh(self, comm=worldcomm, degree=None, dg=False):
+        """The reference returns a dolfin mesh whose vertices are the unique knots
+        (tIGAr/BSplines.py:505-569); here the "mesh" is the implicit tensor node grid."""
+        deg = self.getDegree() if degree is None else degree
+        return TensorNodeGrid([s.feNodes(deg, dg) for s in self.splines],
+                              [s.uniqueKnots for s in self.splines], deg, dg)
+
+    def computeNcp(self):
+        prod = 1
+        for s in self.splines:
+            prod *= s.getNcp()
+        return prod
+
+    def getNcp(self):
+        return self.ncp
+
+    def getDegree(self):
+        deg = 0
+        for s in self.splines:
+            deg = max(deg, s.p) if self.useRect else deg + s.p
+        return deg
+
+    def computeNel(self):
+        nel = 1
+        for s in self.splines:
+            nel *= s.nel
+        return nel
+
+    def getSideDofs(self, direction, side, nLayers=1):
+        """DoFs on a ``side`` (0 or 1) perpendicular to ``direction``; ``nLayers`` layers of
+        control points.  Same ordering as tIGAr/BSplines.py:599-649 (corners repeat when
+        several sides are concatenated)."""
+        offsetSign = 1 - 2 * side
+        ncps = [s.getNcp() for s in self.splines]
+        retval = []
+        for absOffset in range(0, nLayers):
+            i = (0 if side == 0 else ncps[direction] - 1) + absOffset * offsetSign
+            if self.nvar == 1:
+                retval += [i]
+            elif self.nvar == 2:
+                M, N = ncps
+                if direction == 0:
+                    retval += [ij2dof(i, j, M) for j in range(N)]
+                elif direction == 1:
+                    retval += [ij2dof(j, i, M) for j in range(M)]
+            else:
+                M, N, O = ncps
+                if direction == 0:
+                    retval += (i + M * numpy.arange(N)[:, None] + M * N * numpy.arange(O)[None, :]) \
+                        .reshape(-1).tolist()
+                elif direction == 1:
+                    retval += (numpy.arange(M)[:, None] + M * i + M * N * numpy.arange(O)[None, :]) \
+                        .reshape(-1).tolist()
+                elif direction == 2:
+                    retval += (numpy.arange(M)[:, None] + M * numpy.arange(N)[None, :] + M * N * i) \
+                        .reshape(-1).tolist()
+        return retval
+
+
+class ExplicitBSplineControlMesh(AbstractControlMesh):
+    """
+    Control mesh of a B-spline with identical physical and parametric domains
+    (tIGAr/BSplines.py:910-963): Greville abscissae, unit weights.
+    """
+
+    def __init__(self, degrees, kvecs, extraDim=0, useRect=USE_RECT_ELEM_DEFAULT, overRefine=0):
+        self.scalarSpline = BSpline(degrees, kvecs, useRect=useRect, overRefine=overRefine)
+        self.nvar = len(degrees)
+        self.nsd = self.nvar + extraDim
+
+    def getScalarSpline(self):
+        return self.scalarSpline
+
+    def getHomogeneousCoordinate(self, node, direction):
+        if direction == self.nsd:
+            return 1.0
+        if direction < self.nvar:
+            if self.nvar == 1:
+                directionalIndex = node
+            elif self.nvar == 2:
+                directionalIndex = dof2ij(node, self.scalarSpline.splines[0].getNcp())[direction]
+            else:
+                M = self.scalarSpline.splines[0].getNcp()
+                N = self.scalarSpline.splines[1].getNcp()
+                directionalIndex = dof2ijk(node, M, N)[direction]
+            return self.scalarSpline.splines[direction].greville(directionalIndex)
+        return 0.0
+
+    def getHomogeneousCoordinates(self):
+        """All control points at once: array [ncp, nsd+1] (vectorised form of the per-node
+        loop at tIGAr/common.py:373-375)."""
+        sp_ = self.scalarSpline
+        ncps = [s.getNcp() for s in sp_.splines]
+        grev = [numpy.array([s.greville(i) for i in range(s.getNcp())]) for s in sp_.splines]
+        P = numpy.zeros((sp_.getNcp(), self.nsd + 1))
+        idx = numpy.arange(sp_.getNcp())
+        stride = 1
+        for d in range(self.nvar):
+            P[:, d] = grev[d][(idx // stride) % ncps[d]]
+            stride *= ncps[d]
+        P[:, self.nsd] = 1.0
+        return P
+
+    def getNsd(self):
+        return self.nsd

@@ -1,0 +1,654 @@
+"""
+The ``common`` module of tigar_amd: the reference's abstractions for generating extraction
+data and using it in analysis (tIGAr/common.py), re-implemented MI355X-first.
+
+What is kept: the ``AbstractExtractionGenerator`` / ``AbstractCoordinateChartSpline`` /
+``AbstractMultiFieldSpline`` / ``EqualOrderSpline`` / ``FieldListSpline`` class tree, the
+``AbstractScalarBasis`` / ``AbstractControlMesh`` plug-in interfaces, and
+``ExtractedSpline`` with ``extractVector`` / ``extractMatrix`` / ``solveLinearSystem`` /
+``setSolverOptions`` and the duck-typed ``linearSolver.solve(A, x, b)`` seam.
+
+What changes: FEniCS objects are replaced by device-resident ones (``DeviceCSR`` for
+``PETScMatrix``, ``DeviceVector`` for ``PETScVector``, ``TensorFunctionSpace`` for
+``FunctionSpace`` on the implicit Q_p node grid).  FE assembly of forms is FEniCS's job
+and is NOT part of this path; ``extractMatrix`` / ``extractVector`` accept any FE matrix /
+vector on ``V`` (scipy.sparse / numpy inputs are uploaded).  Errors raise exceptions
+instead of the reference's ``print("ERROR"); exit()``.
+"""
+import abc
+import os
+import numpy
+from numpy import array, zeros, arange
+
+from . import device as _dev
+from .device import DeviceCSR, DeviceVector
+
+# ---- module-level configuration, same names as tIGAr/common.py:35-84 ---------------------
+mpisize = int(os.environ.get("WORLD_SIZE", "1"))
+mpirank = int(os.environ.get("RANK", "0"))
+
+
+class _Comm(object):
+    """Stand-in for an MPI communicator handle (one process per GPU; RCCL underneath)."""
+
+    def __init__(self, size, rank):
+        self.size, self.rank = size, rank
+
+
+worldcomm = _Comm(mpisize, mpirank)
+selfcomm = _Comm(1, 0)
+
+INDEX_TYPE = 'int32'
+DEFAULT_PREALLOC = 500
+DEFAULT_DO_PERMUTATION = mpisize > 8
+DEFAULT_BASIS_FUNC_IGNORE_EPS = 1e-15
+EXTRACTION_DATA_FILE = "extraction-data.h5"
+EXTRACTION_INFO_FILE = "extraction-info.txt"
+EXTRACTION_H5_MESH_NAME = "/mesh"
+
+
+def EXTRACTION_H5_CONTROL_FUNC_NAME(dim):
+    return "/control" + str(dim)
+
+
+EXTRACTION_ZERO_DOFS_FILE = "zero-dofs.dat"
+EXTRACTION_MAT_FILE = "extraction-mat.dat"
+EXTRACTION_MAT_FILE_CTRL = "extraction-mat-ctrl.dat"
+USE_DG_DEFAULT = True
+USE_RECT_ELEM_DEFAULT = True
+# The reference's FORM_MT=False trades speed for memory; on the GPU the explicit transpose is
+# what makes M^T b and M^T A M scatter-free and deterministic, so it is always formed.
+FORM_MT = True
+
+DOLFIN_EPS = 3.0e-16
+
+
+def near(a, b, eps=DOLFIN_EPS):
+    """dolfin.near: |a-b| <= eps."""
+    return abs(a - b) <= eps
+
+
+# ---- FE-side stand-ins ------------------------------------------------------------------
+class TensorNodeGrid(object):
+    """The "mesh" of the extraction: a tensor-product grid of Lagrange nodes on the knot
+    mesh (replaces the dolfin mesh of tIGAr/BSplines.py:505-569)."""
+
+    def __init__(self, axes, vertices, degree, dg=False):
+        self.axes = [numpy.ascontiguousarray(a, dtype=numpy.float64) for a in axes]
+        self.vertices = vertices
+        self.degree = degree
+        self.dg = dg
+
+    def dim(self):
+        return len(self.axes)
+
+    def shape(self):
+        return [len(a) for a in self.axes]
+
+    def num_nodes(self):
+        n = 1
+        for a in self.axes:
+            n *= len(a)
+        return n
+
+    def coordinates(self):
+        """[num_nodes, dim] parametric node coordinates, direction 0 fastest."""
+        grids = numpy.meshgrid(*self.axes, indexing="ij")
+        return numpy.stack([g.ravel(order="F") for g in grids], axis=1)
+
+
+class TensorFunctionSpace(object):
+    """Stand-in for dolfin ``FunctionSpace``: ``nfields`` scalar Lagrange (or DG) fields
+    on node grids that share one knot mesh.  Dofs are field-major, nodes lexicographic
+    (dolfin's own numbering is unobservable downstream: K, M^T b and M U are invariant
+    under FE row permutations -- SURVEY.md section 7 hard part 3)."""
+
+    def __init__(self, grids, element):
+        self.grids = list(grids)
+        self.element = element
+
+    def num_sub_spaces(self):
+        return len(self.grids) if len(self.grids) > 1 else 0
+
+    def dim(self):
+        return sum(g.num_nodes() for g in self.grids)
+
+    def field_offset(self, field):
+        return sum(g.num_nodes() for g in self.grids[:field])
+
+    def tabulate_dof_coordinates(self):
+        return numpy.vstack([g.coordinates() for g in self.grids])
+
+
+class Function(object):
+    """Stand-in for dolfin ``Function``: FE coefficients in HBM."""
+
+    def __init__(self, V):
+        self.V = V
+        self._vec = DeviceVector(V.dim())
+
+    def vector(self):
+        return self._vec
+
+    def function_space(self):
+        return self.V
+
+
+def _as_device_vector(b):
+    if isinstance(b, DeviceVector):
+        return b
+    if hasattr(b, "vector") and callable(b.vector):
+        return b.vector()
+    return DeviceVector(data=numpy.asarray(b, dtype=numpy.float64))
+
+
+def _as_device_csr(A):
+    if isinstance(A, DeviceCSR):
+        return A
+    return DeviceCSR.from_scipy(A)
+
+
+def multTranspose(M, b):
+    """Returns ``M^T*b`` (tIGAr/common.py:97-109)."""
+    return M.mult_transpose(_as_device_vector(b))
+
+
+def generateIdentityPermutation(ownRange, comm=worldcomm):
+    """Index array of the ownership range (tIGAr/common.py:114-128)."""
+    return arange(ownRange[0], ownRange[1], dtype=INDEX_TYPE)
+
+
+# ---- extraction generators -----------------------------------------------------------------
+class AbstractExtractionGenerator(object):
+    """
+    Minimal set of functions needed to write extraction operators for a spline
+    (tIGAr/common.py:130-502).
+    """
+
+    __metaclass__ = abc.ABCMeta
+
+    def __init__(self, comm, *args):
+        if not isinstance(comm, _Comm):
+            args = (comm,) + args
+            self.comm = worldcomm
+        else:
+            self.comm = comm
+        self.customSetup(args)
+        self.genericSetup()
+
+    def getComm(self):
+        return self.comm
+
+    def useDG(self):
+        return USE_DG_DEFAULT
+
+    def extractionElement(self):
+        return "DG" if self.useDG() else "Lagrange"
+
+    @abc.abstractmethod
+    def customSetup(self, args):
+        return
+
+    @abc.abstractmethod
+    def getNFields(self):
+        return
+
+    @abc.abstractmethod
+    def getHomogeneousCoordinate(self, node, direction):
+        return
+
+    @abc.abstractmethod
+    def generateMesh(self):
+        return
+
+    @abc.abstractmethod
+    def getDegree(self, field):
+        return
+
+    @abc.abstractmethod
+    def getNcp(self, field):
+        return
+
+    @abc.abstractmethod
+    def getNsd(self):
+        return
+
+    def globalDof(self, field, localDof):
+        retval = localDof
+        for i in range(0, field):
+            retval += self.getNcp(i)
+        return retval
+
+    def generatePermutation(self):
+        total = sum(self.getNcp(i) for i in range(self.getNFields()))
+        return generateIdentityPermutation((0, total), self.comm)
+
+    def addZeroDofsGlobal(self, newDofs):
+        self.zeroDofs += list(newDofs)
+
+    def addZeroDofs(self, field, newDofs):
+        off = self.globalDof(field, 0)
+        self.addZeroDofsGlobal([int(d) + off for d in newDofs])
+
+    def getPrealloc(self, control):
+        return DEFAULT_PREALLOC
+
+    def getIgnoreEps(self):
+        return DEFAULT_BASIS_FUNC_IGNORE_EPS
+
+    @abc.abstractmethod
+    def generateM_control(self):
+        return
+
+    @abc.abstractmethod
+    def generateM(self):
+        return
+
+    def _homogeneousCoordinateArray(self):
+        """P[I, i] = getHomogeneousCoordinate(I, i) (loop of tIGAr/common.py:373-375),
+        vectorised when the control mesh offers it."""
+        cm = getattr(self, "getControlMesh", None)
+        if cm is not None and hasattr(self.getControlMesh(), "getHomogeneousCoordinates"):
+            return numpy.asarray(self.getControlMesh().getHomogeneousCoordinates(), dtype=numpy.float64)
+        ncp = self.getNcp(-1)
+        P = numpy.empty((ncp, self.nsd + 1))
+        for I in range(ncp):
+            for i in range(self.nsd + 1):
+                P[I, i] = self.getHomogeneousCoordinate(I, i)
+        return P
+
+    def genericSetup(self):
+        """Common setup (tIGAr/common.py:321-383): node grids in place of the FE mesh and
+        function spaces, M_control, M, and the FE-nodal control functions
+        cpFuncs[i] = M_control * P[:, i]."""
+        self.mesh = self.generateMesh()
+        self.nsd = self.getNsd()
+        elem = self.extractionElement()
+        dg = (elem == "DG")
+        self.V_control = TensorFunctionSpace([self._fieldGrid(-1, dg)], elem)
+        self.V = TensorFunctionSpace([self._fieldGrid(i, dg) for i in range(self.getNFields())], elem)
+        self.M_control = self.generateM_control()
+        self.M = self.generateM()
+        P = self._homogeneousCoordinateArray()
+        self.cpFuncs = []
+        for i in range(self.nsd + 1):
+            f = Function(self.V_control)
+            self.M_control.mult(DeviceVector(data=P[:, i]), f.vector())   # stays in HBM
+            self.cpFuncs += [f]
+        self.zeroDofs = []
+
+    def _fieldGrid(self, field, dg):
+        """Node grid of one scalar field (degree getDegree(field) on the shared knot mesh)."""
+        raise NotImplementedError
+
+    def applyPermutation(self):
+        """The reference permutes IGA dofs to follow dolfin's mesh partition
+        (tIGAr/common.py:407-433).  Here IGA dofs are partitioned in contiguous z-slabs,
+        which already align with the z-slab FE rows: identity permutation."""
+        self.permutation = self.generatePermutation()
+
+    def writeExtraction(self, dirname, doPermutation=DEFAULT_DO_PERMUTATION):
+        raise NotImplementedError("on-disk extraction format (HDF5 + PETSc binary, "
+                                  "tIGAr/common.py:435-502) is outside the GPU hot path (SURVEY f-2)")
+
+
+class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
+    """Spline with a single parametric coordinate chart (tIGAr/common.py:1435-1669)."""
+
+    @abc.abstractmethod
+    def getNodesAndEvals(self, x, field):
+        return
+
+    def _generate_block(self, field, col_offset, ncols, grid):
+        """Rows of the extraction matrix for one field: kernel path for tensor B-splines,
+        host-loop triplet fallback for arbitrary AbstractScalarBasis plug-ins (seam b-2)."""
+        basis = self.getScalarSpline(field) if hasattr(self, "getScalarSpline") else None
+        eps = self.getIgnoreEps()
+        from .BSplines import BSpline
+        if isinstance(basis, BSpline) and type(basis).getNodesAndEvals is BSpline.getNodesAndEvals:
+            return _dev.extract_csr_tensor(basis.splines, grid.axes, col_offset, ncols, eps)
+        # generic path: the reference's row loop (tIGAr/common.py:1554-1571)
+        X = grid.coordinates()
+        rows, cols, vals = [], [], []
+        for I in range(X.shape[0]):
+            for c, v in self.getNodesAndEvals(X[I], field):
+                rows.append(I)
+                cols.append(int(c) + col_offset)
+                vals.append(float(v))
+        return _dev.csr_from_triplets(X.shape[0], ncols, rows, cols, vals, eps)
+
+    def generateM_control(self):
+        """Extraction matrix of the scalar space of the control functions
+        (tIGAr/common.py:1460-1514)."""
+        return self._generate_block(-1, 0, self.getNcp(-1), self.V_control.grids[0])
+
+    def generateM(self):
+        """Extraction matrix of the mixed space of all unknown fields
+        (tIGAr/common.py:1516-1578): one row block per field, column offset = sum of the
+        previous fields' ncp."""
+        totalDofs = sum(self.getNcp(i) for i in range(self.getNFields()))
+        blocks = []
+        offset = 0
+        for field in range(self.getNFields()):
+            blocks.append(self._generate_block(field, offset, totalDofs, self.V.grids[field]))
+            offset += self.getNcp(field)
+        return blocks[0] if len(blocks) == 1 else _dev.csr_vstack(blocks)
+
+
+class AbstractScalarBasis(object):
+    """Scalar basis functions on a manifold with unique coordinates
+    (tIGAr/common.py:1673-1759)."""
+
+    __metaclass__ = abc.ABCMeta
+
+    @abc.abstractmethod
+    def getNodesAndEvals(self, xi):
+        return
+
+    @abc.abstractmethod
+    def getNcp(self):
+        return
+
+    @abc.abstractmethod
+    def generateMesh(self, comm=worldcomm):
+        return
+
+    @abc.abstractmethod
+    def getDegree(self):
+        return
+
+    def needsDG(self):
+        return True
+
+    @abc.abstractmethod
+    def useRectangularElements(self):
+        return
+
+    def getPrealloc(self):
+        return DEFAULT_PREALLOC
+
+
+class AbstractControlMesh(object):
+    """Mapping from parametric to physical space (tIGAr/common.py:1762-1791)."""
+
+    __metaclass__ = abc.ABCMeta
+
+    @abc.abstractmethod
+    def getHomogeneousCoordinate(self, node, direction):
+        return
+
+    @abc.abstractmethod
+    def getScalarSpline(self):
+        return
+
+    @abc.abstractmethod
+    def getNsd(self):
+        return
+
+
+class AbstractMultiFieldSpline(AbstractCoordinateChartSpline):
+    """General multi-field spline built from AbstractScalarBasis members
+    (tIGAr/common.py:1794-1885)."""
+
+    __metaclass__ = abc.ABCMeta
+
+    @abc.abstractmethod
+    def getControlMesh(self):
+        return
+
+    @abc.abstractmethod
+    def getFieldSpline(self, field):
+        return
+
+    def getPrealloc(self, control):
+        if control:
+            return self.getScalarSpline(-1).getPrealloc()
+        return max(self.getScalarSpline(i).getPrealloc() for i in range(self.getNFields()))
+
+    def getScalarSpline(self, field):
+        if field == -1:
+            return self.getControlMesh().getScalarSpline()
+        return self.getFieldSpline(field)
+
+    def getNsd(self):
+        return self.getControlMesh().getNsd()
+
+    def getHomogeneousCoordinate(self, node, direction):
+        return self.getControlMesh().getHomogeneousCoordinate(node, direction)
+
+    def getNodesAndEvals(self, x, field):
+        return self.getScalarSpline(field).getNodesAndEvals(x)
+
+    def generateMesh(self):
+        return self.getScalarSpline(-1).generateMesh(comm=self.comm)
+
+    def getDegree(self, field):
+        return self.getScalarSpline(field).getDegree()
+
+    def getNcp(self, field):
+        return self.getScalarSpline(field).getNcp()
+
+    def useDG(self):
+        for i in range(-1, self.getNFields()):
+            if self.getScalarSpline(i).needsDG():
+                return True
+        return False
+
+    def _fieldGrid(self, field, dg):
+        basis = self.getScalarSpline(field)
+        deg = self.getDegree(field)
+        try:
+            return basis.generateMesh(comm=self.comm, degree=deg, dg=dg)
+        except TypeError:
+            grid = basis.generateMesh(comm=self.comm)
+            if not isinstance(grid, TensorNodeGrid):
+                raise TypeError("scalar bases used with tigar_amd must return a TensorNodeGrid "
+                                "from generateMesh()")
+            return grid
+
+
+class EqualOrderSpline(AbstractMultiFieldSpline):
+    """All unknown fields discretised with the control mesh's scalar basis
+    (tIGAr/common.py:1891-1946).  ``EqualOrderSpline(numFields, controlMesh)``."""
+
+    def customSetup(self, args):
+        self.numFields = args[0]
+        self.controlMesh = args[1]
+
+    def getNFields(self):
+        return self.numFields
+
+    def getControlMesh(self):
+        return self.controlMesh
+
+    def getFieldSpline(self, field):
+        return self.getScalarSpline(-1)
+
+    def generateM(self):
+        # one unknown field on the control mesh's basis: M is M_control (same rows, same
+        # columns) -- share the device object instead of building it twice
+        if self.numFields == 1 and getattr(self, "M_control", None) is not None:
+            return self.M_control
+        return AbstractMultiFieldSpline.generateM(self)
+
+    def addZeroDofsByLocation(self, subdomain, field):
+        """Homogeneous Dirichlet BCs on the DoFs of ``field`` whose control points lie in
+        ``subdomain`` (object with ``inside(x, on_boundary)``); tIGAr/common.py:1915-1946."""
+        P = self._homogeneousCoordinateArray()
+        nsd = self.getNsd()
+        for I in range(P.shape[0]):
+            p = P[I, 0:nsd] / P[I, nsd]
+            if subdomain.inside(p, False) or subdomain.inside(p, True):
+                self.zeroDofs += [self.globalDof(field, I)]
+
+
+class FieldListSpline(AbstractMultiFieldSpline):
+    """Multi-field spline from a list of scalar bases (tIGAr/common.py:1949-1970).
+    ``FieldListSpline(controlMesh, fields)``."""
+
+    def customSetup(self, args):
+        self.controlMesh = args[0]
+        self.fields = args[1]
+
+    def getNFields(self):
+        return len(self.fields)
+
+    def getControlMesh(self):
+        return self.controlMesh
+
+    def getFieldSpline(self, field):
+        return self.fields[field]
+
+
+# ---- solver seam (b-4) ---------------------------------------------------------------------
+class PETScKrylovSolver(object):
+    """Look-alike of dolfin's ``PETScKrylovSolver(method, preconditioner)`` running on the
+    GPU; plugs into ``ExtractedSpline.linearSolver`` (tIGAr/common.py:1255-1258), as in
+    ``PETScKrylovSolver("gmres","jacobi")`` at demos/taylor-green/taylor-green-3d.py:89-90.
+    Defaults are dolfin's [ext]: rtol 1e-6, atol 1e-15, maxit 10000, error on
+    non-convergence."""
+
+    def __init__(self, method="cg", preconditioner="jacobi", comm=None):
+        if method == "default":
+            method = "gmres"
+        if preconditioner == "default":
+            preconditioner = "jacobi"
+        if method not in ("cg", "gmres"):
+            raise ValueError("unsupported Krylov method %r (cg, gmres)" % (method,))
+        if preconditioner not in ("none", "jacobi"):
+            raise ValueError("unsupported preconditioner %r (none, jacobi)" % (preconditioner,))
+        self.method, self.preconditioner = method, preconditioner
+        self.parameters = {"relative_tolerance": 1e-6, "absolute_tolerance": 1e-15,
+                           "maximum_iterations": 10000, "error_on_nonconvergence": True,
+                           "nonzero_initial_guess": False, "gmres_restart": 30,
+                           "report": False, "monitor_convergence": False}
+        self.comm = comm
+        self.last = None
+
+    def solve(self, A, x, b):
+        if self.parameters["nonzero_initial_guess"]:
+            raise NotImplementedError("nonzero_initial_guess")
+        A, x, b = _as_device_csr(A), _as_device_vector(x), _as_device_vector(b)
+        its, res, status = _dev.krylov_solve(
+            A, b, x, self.method, self.preconditioner, self.parameters["relative_tolerance"],
+            self.parameters["absolute_tolerance"], self.parameters["maximum_iterations"],
+            self.parameters["gmres_restart"], self.comm)
+        self.last = {"iterations": its, "residual_norm": res, "status": status}
+        if status < 0 and self.parameters["error_on_nonconvergence"]:
+            raise RuntimeError("Krylov solver (%s, %s) did not converge: status %d after %d iterations, "
+                               "preconditioned residual %.3e" % (self.method, self.preconditioner, status, its, res))
+        return its
+
+
+KrylovSolver = PETScKrylovSolver
+
+
+# ---- analysis side ---------------------------------------------------------------------------
+class ExtractedSpline(object):
+    """
+    An extracted spline (tIGAr/common.py:667-1433), restricted to the hot path: the
+    extraction operators, their application to FE matrices/vectors, and the linear solve.
+    UFL form construction (``grad``, ``dx``, ``rationalize`` ...) needs FEniCS and is not
+    provided here.
+    """
+
+    def __init__(self, sourceArg, quadDeg=None, mesh=None, doPermutation=DEFAULT_DO_PERMUTATION,
+                 comm=worldcomm):
+        if isinstance(sourceArg, AbstractExtractionGenerator):
+            self.initFromGenerator(sourceArg, quadDeg, doPermutation)
+        else:
+            raise NotImplementedError("reading extraction data from a directory "
+                                      "(tIGAr/common.py:748-894) is outside the GPU hot path (SURVEY f-2)")
+        self.genericSetup()
+
+    def initFromGenerator(self, generator, quadDeg, doPermutation=DEFAULT_DO_PERMUTATION):
+        """tIGAr/common.py:708-746 -- shares M, M_control, V, cpFuncs with the generator."""
+        if doPermutation:
+            generator.applyPermutation()
+        self.quadDeg = quadDeg
+        self.nsd = generator.getNsd()
+        self.elementType = generator.extractionElement()
+        self.nFields = generator.getNFields()
+        self.p_control = generator.getDegree(-1)
+        self.p = [generator.getDegree(i) for i in range(self.nFields)]
+        self.mesh = generator.mesh
+        self.cpFuncs = generator.cpFuncs
+        self.V = generator.V
+        self.V_control = generator.V_control
+        self.M = generator.M
+        self.M_control = generator.M_control
+        self.comm = generator.getComm()
+        self.zeroDofs = array(generator.zeroDofs, dtype=INDEX_TYPE)
+
+    def genericSetup(self):
+        self.setSolverOptions()
+        self.MT = self.M.transpose()          # explicit M^T, built once (FORM_MT)
+        self._ptap_plan = None
+        self._ptap_plan_key = None
+
+    # -- a-10
+    def extractVector(self, b, applyBCs=True):
+        """Apply extraction to an FE vector ``b``: ``M^T b``, zeroed at ``zeroDofs`` if
+        ``applyBCs`` (tIGAr/common.py:1142-1160)."""
+        MTb = self.M.mult_transpose(_as_device_vector(b))
+        if applyBCs:
+            MTb.zero_entries(self.zeroDofs)
+        return MTb
+
+    def assembleVector(self, form, applyBCs=True):
+        """``form``: anything with ``.assemble_vector(V)`` (see ``tigar_amd.forms``) or an
+        already assembled FE vector (tIGAr/common.py:1162-1173)."""
+        b = form.assemble_vector(self.V) if hasattr(form, "assemble_vector") else form
+        return self.extractVector(b, applyBCs=applyBCs)
+
+    # -- a-11
+    def extractMatrix(self, A, applyBCs=True, diag=1):
+        """Apply extraction to an FE matrix ``A``: ``M^T A M`` (PtAP), then rows and columns
+        of ``zeroDofs`` zeroed with ``diag`` on the diagonal (tIGAr/common.py:1176-1204).
+        The symbolic plan is cached and reused while A's pattern is unchanged."""
+        A = _as_device_csr(A)
+        key = (A.shape, A.nnz)
+        if self._ptap_plan is None or self._ptap_plan_key != key:
+            self._ptap_plan = _dev.ptap_symbolic(A, self.M, self.MT)
+            self._ptap_plan_key = key
+        zd = self.zeroDofs if applyBCs else None
+        return _dev.ptap_numeric(self._ptap_plan, A, self.M, self.MT, zd, float(diag))
+
+    def assembleMatrix(self, form, applyBCs=True, diag=1):
+        A = form.assemble_matrix(self.V) if hasattr(form, "assemble_matrix") else form
+        return self.extractMatrix(A, applyBCs=applyBCs, diag=diag)
+
+    def assembleLinearSystem(self, lhsForm, rhsForm, applyBCs=True):
+        return (self.assembleMatrix(lhsForm, applyBCs), self.assembleVector(rhsForm, applyBCs))
+
+    # -- a-12
+    def solveLinearSystem(self, MTAM, MTb, u):
+        """Solve ``MTAM*U = MTb`` and store ``M*U`` in the FE function ``u``; returns ``U``
+        (tIGAr/common.py:1236-1263).  With ``linearSolver == None`` the reference calls
+        dolfin's direct LU; there is no sparse direct solver on this path, so the default is
+        Jacobi-preconditioned GMRES at tight tolerance (1e-12) -- documented deviation."""
+        MTU = DeviceVector(self.M.shape[1])
+        if self.linearSolver is None:
+            solver = PETScKrylovSolver("gmres", "jacobi")
+            solver.parameters["relative_tolerance"] = 1e-12
+            solver.parameters["maximum_iterations"] = 100000
+            solver.solve(MTAM, MTU, MTb)
+        else:
+            self.linearSolver.solve(MTAM, MTU, MTb)
+        self.M.mult(MTU, _as_device_vector(u))
+        return MTU
+
+    def solveLinearVariationalProblem(self, residualForm, u, applyBCs=True):
+        """``residualForm`` must be an ``Equation``-like object with ``.lhs`` / ``.rhs``
+        forms (tIGAr/common.py:1266-1290)."""
+        MTAM, MTb = self.assembleLinearSystem(residualForm.lhs, residualForm.rhs, applyBCs)
+        return self.solveLinearSystem(MTAM, MTb, u)
+
+    def setSolverOptions(self, maxIters=20, relativeTolerance=1e-5, linearSolver=None):
+        """tIGAr/common.py:1292-1302."""
+        self.maxIters = maxIters
+        self.relativeTolerance = relativeTolerance
+        self.linearSolver = linearSolver
+
+    def FEtoIGA(self, u):
+        raise NotImplementedError("FEtoIGA (tIGAr/common.py:968-994) is outside the hot path")

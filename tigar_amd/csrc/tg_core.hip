@@ -30,6 +30,8 @@ extern "C" int tg_init(int device) {
     TG_CHECK_HIP(hipEventCreate(&g_tg.ev0[i]));
     TG_CHECK_HIP(hipEventCreate(&g_tg.ev1[i]));
   }
+  TG_CHECK_HIP(hipEventCreate(&g_tg.pev0));
+  TG_CHECK_HIP(hipEventCreate(&g_tg.pev1));
   TG_CHECK_HIP(hipMalloc((void **)&g_tg.scratch, TG_SCRATCH_DOUBLES * sizeof(double)));
   TG_CHECK_HIP(hipHostMalloc((void **)&g_tg.host_pinned, 64 * sizeof(double), hipHostMallocDefault));
   g_tg.ready = true;
@@ -74,6 +76,21 @@ extern "C" int tg_mem_info(int64_t *free_bytes, int64_t *total_bytes) {
   TG_CHECK_HIP(hipMemGetInfo(&f, &t));
   if (free_bytes) *free_bytes = (int64_t)f;
   if (total_bytes) *total_bytes = (int64_t)t;
+  return 0;
+}
+
+extern "C" int tg_prof_reset(void) {
+  for (int i = 0; i < TG_PROF_NSLOTS; i++) {
+    g_tg.prof_ms[i] = 0.0;
+    g_tg.prof_n[i] = 0;
+  }
+  return 0;
+}
+
+extern "C" int tg_prof_get(int slot, double *total_ms, int64_t *count) {
+  TG_REQUIRE(slot >= 0 && slot < TG_PROF_NSLOTS, "profile slot out of range");
+  if (total_ms) *total_ms = g_tg.prof_ms[slot];
+  if (count) *count = g_tg.prof_n[slot];
   return 0;
 }
 

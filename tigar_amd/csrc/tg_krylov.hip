@@ -196,7 +196,9 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
     TG_TRY(tg_comm_halo_exchange(comm, pext));
     // Kp = K p   (x addressed by global column index); then p . Kp on a fixed grid so the
     // reduction order (and the result) does not depend on the matrix size
+    hipEventRecord(g_tg.pev0, g_tg.stream);
     TG_TRY(tg_spmv_raw(k, pext - (row0 - hlo), kp, nullptr, nullptr));
+    hipEventRecord(g_tg.pev1, g_tg.stream);
     hipLaunchKernelGGL(k_dot2_partial, dim3(vg), dim3(256), 0, g_tg.stream, p, kp, n, partial);
     hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, g_tg.stream, partial, vg, 1, s_pkp);
     TG_TRY(tg_comm_allreduce_dev(comm, s_pkp, 1));
@@ -207,6 +209,13 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
     TG_TRY(tg_comm_allreduce_dev(comm, s_pair, 2));
     TG_CHECK_HIP(hipMemcpyAsync(rz_new, s_pair, sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream));
     TG_TRY(tg_read_scalars(s_pair, 2, h));
+    {
+      float ems = 0.f;  // the sync above also completed this iteration's SpMV event pair
+      if (hipEventElapsedTime(&ems, g_tg.pev0, g_tg.pev1) == hipSuccess) {
+        g_tg.prof_ms[TG_PROF_KSP_SPMV] += ems;
+        g_tg.prof_n[TG_PROF_KSP_SPMV] += 1;
+      }
+    }
     znorm = sqrt(h[1]);
     if (!(znorm == znorm)) {
       *status = -2;

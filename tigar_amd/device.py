@@ -373,6 +373,16 @@ def timer_stop(slot=0):
     return ms.value
 
 
+def prof_reset():
+    check(_lib.lib().tg_prof_reset())
+
+
+def prof_get(slot=0):
+    ms, n = C.c_double(), C.c_int64()
+    check(_lib.lib().tg_prof_get(slot, C.byref(ms), C.byref(n)))
+    return ms.value, n.value
+
+
 def sync():
     check(_lib.lib().tg_sync())
 
