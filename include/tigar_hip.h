@@ -31,6 +31,7 @@ const char *tg_last_error(void);
 int tg_sync(void);                         /* hipStreamSynchronize on the library stream */
 int tg_device_info(char *name, int name_len, int *num_cu, int64_t *hbm_bytes);
 int tg_mem_info(int64_t *free_bytes, int64_t *total_bytes);
+int tg_pool_trim(void);                    /* releases the caching allocator's free blocks */
 /* HIP-event timers on the library's stream (bench.py roofline measurement). */
 int tg_timer_start(int slot);
 int tg_timer_stop(int slot, double *ms);   /* synchronises; elapsed ms since start(slot) */
@@ -94,6 +95,12 @@ typedef struct {
  * entries with fabs(v) > eps kept; columns sorted.  ncols = total columns of the block. */
 int tg_extract_csr_tensor(int d, const tg_dir_t *dirs, int32_t col_offset, int64_t ncols,
                           double eps, int64_t row0, int64_t row1, tg_csr_t *out);
+/* The explicit transpose M^T of the same operator (the reference's FORM_MT object,
+ * tIGAr/common.py:84,358-360), written directly: rows = spline dofs [dof0,dof1) of this field,
+ * columns = fe_row_offset + lexicographic FE node index; bit-identical to transposing
+ * tg_extract_csr_tensor's result. */
+int tg_extract_csr_tensor_t(int d, const tg_dir_t *dirs, int64_t fe_row_offset, int64_t fe_rows_total,
+                            double eps, int64_t dof0, int64_t dof1, tg_csr_t *out);
 /* Same with explicit node coordinates x[nrows*d] (dolfin-supplied / DG nodes). */
 int tg_extract_csr_points(int d, const tg_dir_t *dirs, int32_t col_offset, int64_t ncols,
                           double eps, const double *x, int64_t nrows, tg_csr_t *out);

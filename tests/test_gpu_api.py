@@ -1,0 +1,169 @@
+"""GPU tests of the tIGAr-compatible API shell (tigar_amd.common / BSplines / forms) against the
+oracle: the demo flow of demos/poisson/poisson.py:44-122 without FEniCS."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import tigar_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import tigar_amd
+    from tigar_amd import BSplines, forms, device
+    device.device_info()
+    class NS: pass
+    ns = NS()
+    ns.t, ns.B, ns.F, ns.dev = tigar_amd, BSplines, forms, device
+    return ns
+
+
+def _demo(T, d, p, nel, solver):
+    B, t, F = T.B, T.t, T.F
+    kv = [B.uniformKnots(p, 0.0, 1.0, nel) for _ in range(d)]
+    splineMesh = B.ExplicitBSplineControlMesh([p] * d, kv)
+    gen = t.EqualOrderSpline(1, splineMesh)
+    scalarSpline = gen.getScalarSpline(0)
+    for direction in range(d):
+        for side in (0, 1):
+            gen.addZeroDofs(0, scalarSpline.getSideDofs(direction, side))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    spline.setSolverOptions(linearSolver=solver)
+    f = lambda x: np.sin(np.pi * x)
+    a = F.LaplaceForm()
+    L = F.SeparableLoadForm([f] * d, scale=d * np.pi ** 2)
+    u = t.Function(spline.V)
+    U = spline.solveLinearVariationalProblem(F.Equation(a, L), u)
+    return gen, spline, U, u
+
+
+@pytest.mark.parametrize("d,p,nel", [(2, 2, 16), (2, 3, 10), (3, 2, 6)])
+def test_poisson_demo_flow_matches_oracle(T, d, p, nel):
+    solver = T.t.PETScKrylovSolver("cg", "jacobi")
+    solver.parameters["relative_tolerance"] = 1e-11
+    gen, spline, U, u = _demo(T, d, p, nel, solver)
+    s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel)] * d)
+    f = lambda x: np.sin(np.pi * x)
+    A, b, _, _ = O.poisson_fe_system(s, f1d=[f] * d)
+    b = b * d * np.pi ** 2
+    zd = []
+    for direction in range(d):
+        for side in (0, 1):
+            zd += s.getSideDofs(direction, side)
+    assert list(spline.zeroDofs) == zd
+    Mo = O.generate_M_tensor(s)
+    M = gen.M.to_scipy()
+    assert np.array_equal(M.indptr, Mo.indptr) and np.array_equal(M.indices, Mo.indices)
+    assert np.array_equal(M.data, Mo.data)
+    MT = spline.MT.to_scipy()
+    assert abs(MT - Mo.T).max() == 0
+    Ko = O.extract_matrix(Mo, A, zd)
+    rhs = O.extract_vector(Mo, b, zd)
+    Uo, uo = O.solve_linear_system(Mo, Ko, rhs, "direct")
+    assert np.linalg.norm(U.get_local() - Uo) <= 1e-8 * np.linalg.norm(Uo)
+    assert np.linalg.norm(u.vector().get_local() - uo) <= 1e-8 * np.linalg.norm(uo)
+    # control functions (a-9): cpFuncs[i] = M_control * P[:, i]; Greville geometry => x_i itself
+    X, _ = O.fe_node_grid(s)
+    for i in range(d):
+        assert np.max(np.abs(gen.cpFuncs[i].vector().get_local() - X[:, i])) < 1e-14
+    assert np.max(np.abs(gen.cpFuncs[d].vector().get_local() - 1.0)) < 1e-14
+    # manufactured solution at the FE nodes
+    exact = np.prod(np.sin(np.pi * X), axis=1)
+    assert np.max(np.abs(u.vector().get_local() - exact)) < 0.05 * (8.0 / nel) ** (p + 1) + 1e-6
+
+
+def test_default_solver_and_external_matrix_inputs(T):
+    """extractMatrix / extractVector accept any FE matrix / vector on V (reef-knot style):
+    scipy and numpy inputs are uploaded; linearSolver=None falls back to tight GMRES."""
+    gen, spline, U, u = _demo(T, 2, 2, 8, None)
+    s = O.BSpline([2, 2], [O.uniform_knots(2, 0., 1., 8)] * 2)
+    A, b, _, _ = O.poisson_fe_system(s, f1d=[lambda x: np.sin(np.pi * x)] * 2)
+    rng = np.random.default_rng(0)
+    C = sp.random(A.shape[0], A.shape[0], density=0.002, random_state=rng, format="csr")
+    A2 = (A + C).tocsr()                       # "contact terms added by hand"
+    K = spline.extractMatrix(A2, applyBCs=True, diag=3.0).to_scipy()
+    Mo = O.generate_M_tensor(s)
+    Ko = O.extract_matrix(Mo, A2, list(spline.zeroDofs), diag=3.0)
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+    y = spline.extractVector(b, applyBCs=False).get_local()
+    assert np.max(np.abs(y - Mo.T @ b)) <= 1e-12 * np.max(np.abs(b))
+    y = T.t.multTranspose(spline.M, b).get_local()
+    assert np.max(np.abs(y - Mo.T @ b)) <= 1e-12 * np.max(np.abs(b))
+    # plan reuse (same pattern, new values) gives the same answer as a fresh plan
+    K2 = spline.extractMatrix(2.0 * A2, applyBCs=False).to_scipy()
+    assert abs(K2 - 2.0 * (Mo.T @ A2 @ Mo)).max() <= 1e-11 * abs(Ko).max()
+
+
+def test_multi_field_and_generic_basis_fallback(T):
+    B, t = T.B, T.t
+    p, nel = 2, 5
+    kv = [B.uniformKnots(p, 0., 1., nel)] * 2
+    cm = B.ExplicitBSplineControlMesh([p, p], kv)
+    gen3 = t.EqualOrderSpline(3, cm)                   # three unknown fields (shell-like)
+    s = O.BSpline([p, p], [O.uniform_knots(p, 0., 1., nel)] * 2)
+    Mo = O.generate_M_tensor(s, nfields=3)
+    M = gen3.M.to_scipy()
+    assert M.shape == Mo.shape and abs(M - Mo).max() == 0
+    assert abs(gen3.MT.to_scipy() - Mo.T).max() == 0
+    assert gen3.globalDof(2, 5) == 2 * s.getNcp() + 5
+    gen3.addZeroDofs(1, [0, 3])
+    assert gen3.zeroDofs == [s.getNcp(), s.getNcp() + 3]
+
+    # a user-defined AbstractScalarBasis goes through the host-loop / triplet fallback (seam b-2)
+    class MyBasis(t.AbstractScalarBasis):
+        def __init__(self, inner):
+            self.inner = inner
+        def getNodesAndEvals(self, xi):
+            return self.inner.getNodesAndEvals(xi)
+        def getNcp(self):
+            return self.inner.getNcp()
+        def generateMesh(self, comm=None, degree=None, dg=False):
+            return self.inner.generateMesh(degree=degree, dg=dg)
+        def getDegree(self):
+            return self.inner.getDegree()
+        def needsDG(self):
+            return False
+        def useRectangularElements(self):
+            return True
+        def getPrealloc(self):
+            return self.inner.getPrealloc()
+    genF = t.FieldListSpline(cm, [MyBasis(B.BSpline([p, p], kv))])
+    M1 = genF.M.to_scipy()
+    Mo1 = O.generate_M_tensor(s)
+    assert np.array_equal(M1.indptr, Mo1.indptr) and np.array_equal(M1.indices, Mo1.indices)
+    assert np.array_equal(M1.data, Mo1.data)
+
+
+def test_bspline_host_api_matches_golden(T):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_tensor.npz"))
+    B = T.B
+    for name in ("2d_p2_n4", "3d_p2_n2", "2d_p23_n3", "2d_periodic"):
+        pre = name + "/"
+        degs = [int(x) for x in g[pre + "degrees"]]
+        kvecs = [g[pre + "kvec%d" % k] for k in range(len(degs))]
+        s = B.BSpline(degs, kvecs)
+        cm = B.ExplicitBSplineControlMesh(degs, kvecs)
+        assert s.getNcp() == int(g[pre + "ncp"]) and s.getPrealloc() == int(g[pre + "prealloc"])
+        assert s.getDegree() == int(g[pre + "degree"]) and int(s.needsDG()) == int(g[pre + "needsDG"])
+        for direction in range(s.nvar):
+            for side in (0, 1):
+                for nl in (1, 2):
+                    assert s.getSideDofs(direction, side, nl) == list(g[pre + "side_%d_%d_%d" % (direction, side, nl)])
+        P = g[pre + "P"]
+        assert np.array_equal(cm.getHomogeneousCoordinates(), P)
+        assert cm.getHomogeneousCoordinate(3, 0) == P[3, 0]
+        for i in range(P.shape[1]):
+            assert np.array_equal(cm.homogeneousCoordinateDeviceVector(i).get_local(), P[:, i])
+        # single-point API (runs the device twin): reference's entry order and values
+        ne_cols, ne_vals = g[pre + "ne_cols"], g[pre + "ne_vals"]
+        grid = s.generateMesh()
+        X = grid.coordinates()
+        for r in (0, X.shape[0] // 2, X.shape[0] - 1):
+            ne = s.getNodesAndEvals(X[r])
+            assert [e[0] for e in ne] == list(ne_cols[r])
+            assert np.array_equal(np.array([e[1] for e in ne]), ne_vals[r])
+    with pytest.raises(ValueError):
+        B.uniformKnots(2, 0., 1., 4, False, 2)

@@ -310,3 +310,26 @@ def test_krylov_statuses(dev):
     assert its == 3 and status == -1                                          # max iterations
     with pytest.raises(Exception):
         dev.krylov_solve(K, dev.DeviceVector(n + 1), x, "cg")                 # size mismatch raises
+
+
+def test_transposed_extraction_equals_transpose(dev):
+    g = _golden()
+    for name in ("2d_p2_n4", "3d_p2_n2", "3d_p3_n2", "2d_nonuni", "2d_periodic", "1d_p4_n4", "2d_p23_n3"):
+        s, pre = _case(g, name)
+        axes = [O.fe_nodes_1d(sp1, s.getDegree()) for sp1 in s.splines]
+        n_fe = int(np.prod([len(a) for a in axes]))
+        MT = dev.extract_csr_tensor_t(s.splines, axes, 0, n_fe, 1e-15).to_scipy()
+        M = sp.csr_matrix((g[pre + "M_val"], g[pre + "M_col"], g[pre + "M_rowptr"]), shape=(n_fe, s.getNcp()))
+        R = M.T.tocsr()
+        R.sort_indices()
+        assert np.array_equal(MT.indptr, R.indptr), name
+        assert np.array_equal(MT.indices, R.indices), name
+        assert np.array_equal(MT.data, R.data), name            # bit-identical
+    # dof-range slabs and a column offset (multi-field layout)
+    s, pre = _case(g, "3d_p2_n4")
+    axes = [O.fe_nodes_1d(sp1, 2) for sp1 in s.splines]
+    n_fe = int(np.prod([len(a) for a in axes]))
+    full = dev.extract_csr_tensor_t(s.splines, axes, 7, n_fe + 20, 1e-15).to_scipy()
+    part = dev.extract_csr_tensor_t(s.splines, axes, 7, n_fe + 20, 1e-15, 50, 181).to_scipy()
+    assert abs(part - full[50:181]).max() == 0 and part.shape == (131, n_fe + 20)
+    assert full.indices.min() >= 7

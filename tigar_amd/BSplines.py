@@ -318,5 +318,20 @@ class ExplicitBSplineControlMesh(AbstractControlMesh):
         P[:, self.nsd] = 1.0
         return P
 
+    def homogeneousCoordinateDeviceVector(self, direction):
+        """Column ``direction`` of the control-point array as a device vector, expanded on the
+        GPU from its 1-D factors (Greville abscissae along ``direction``, ones elsewhere)."""
+        sp_ = self.scalarSpline
+        ncps = [s.getNcp() for s in sp_.splines]
+        if direction == self.nsd:
+            facs = [numpy.ones(n) for n in ncps]
+        elif direction < self.nvar:
+            facs = [numpy.ones(n) for n in ncps]
+            s = sp_.splines[direction]
+            facs[direction] = numpy.array([s.greville(i) for i in range(s.getNcp())])
+        else:
+            facs = [numpy.zeros(n) for n in ncps]
+        return _dev.vec_tensor3(facs)
+
     def getNsd(self):
         return self.nsd

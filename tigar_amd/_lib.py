@@ -40,6 +40,7 @@ PROTOTYPES = {
     "tg_sync": (C.c_int, []),
     "tg_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p]),
     "tg_mem_info": (C.c_int, [c_i64p, c_i64p]),
+    "tg_pool_trim": (C.c_int, []),
     "tg_timer_start": (C.c_int, [C.c_int]),
     "tg_timer_stop": (C.c_int, [C.c_int, c_f64p]),
     "tg_prof_reset": (C.c_int, []),
@@ -65,6 +66,8 @@ PROTOTYPES = {
                                        C.c_double, C.POINTER(handle)]),
     "tg_extract_csr_tensor": (C.c_int, [C.c_int, C.POINTER(tg_dir_t), C.c_int32, C.c_int64,
                                         C.c_double, C.c_int64, C.c_int64, C.POINTER(handle)]),
+    "tg_extract_csr_tensor_t": (C.c_int, [C.c_int, C.POINTER(tg_dir_t), C.c_int64, C.c_int64, C.c_double,
+                                          C.c_int64, C.c_int64, C.POINTER(handle)]),
     "tg_extract_csr_points": (C.c_int, [C.c_int, C.POINTER(tg_dir_t), C.c_int32, C.c_int64,
                                         C.c_double, c_f64p, C.c_int64, C.POINTER(handle)]),
     "tg_csr_vstack": (C.c_int, [C.c_int, C.POINTER(handle), C.POINTER(handle)]),

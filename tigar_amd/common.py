@@ -228,7 +228,7 @@ class AbstractExtractionGenerator(object):
 
     def addZeroDofs(self, field, newDofs):
         off = self.globalDof(field, 0)
-        self.addZeroDofsGlobal([int(d) + off for d in newDofs])
+        self.addZeroDofsGlobal((numpy.asarray(newDofs, dtype=numpy.int64) + off).tolist())
 
     def getPrealloc(self, control):
         return DEFAULT_PREALLOC
@@ -269,11 +269,20 @@ class AbstractExtractionGenerator(object):
         self.V = TensorFunctionSpace([self._fieldGrid(i, dg) for i in range(self.getNFields())], elem)
         self.M_control = self.generateM_control()
         self.M = self.generateM()
-        P = self._homogeneousCoordinateArray()
+        self.MT = self.generateMT()
+        self.M._T = self.MT           # M.mult_transpose() goes through the explicit transpose
         self.cpFuncs = []
+        cm = self.getControlMesh() if hasattr(self, "getControlMesh") else None
+        P = None
         for i in range(self.nsd + 1):
             f = Function(self.V_control)
-            self.M_control.mult(DeviceVector(data=P[:, i]), f.vector())   # stays in HBM
+            if cm is not None and hasattr(cm, "homogeneousCoordinateDeviceVector"):
+                Pi = cm.homogeneousCoordinateDeviceVector(i)      # built in HBM from 1-D factors
+            else:
+                if P is None:
+                    P = self._homogeneousCoordinateArray()
+                Pi = DeviceVector(data=P[:, i])
+            self.M_control.mult(Pi, f.vector())                   # stays in HBM
             self.cpFuncs += [f]
         self.zeroDofs = []
 
@@ -306,6 +315,7 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
         eps = self.getIgnoreEps()
         from .BSplines import BSpline
         if isinstance(basis, BSpline) and type(basis).getNodesAndEvals is BSpline.getNodesAndEvals:
+            self._fast_blocks[(field, col_offset)] = (basis, grid)
             return _dev.extract_csr_tensor(basis.splines, grid.axes, col_offset, ncols, eps)
         # generic path: the reference's row loop (tIGAr/common.py:1554-1571)
         X = grid.coordinates()
@@ -320,7 +330,29 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
     def generateM_control(self):
         """Extraction matrix of the scalar space of the control functions
         (tIGAr/common.py:1460-1514)."""
+        self._fast_blocks = {}
         return self._generate_block(-1, 0, self.getNcp(-1), self.V_control.grids[0])
+
+    def generateMT(self):
+        """Explicit transpose of ``M`` (the reference's optional ``MT``, FORM_MT at
+        tIGAr/common.py:84,358-360).  For tensor B-spline fields it is written directly by the
+        transposed extraction kernel; otherwise ``M`` is transposed on the device."""
+        nf = self.getNFields()
+        if self.M is self.M_control and (-1, 0) in self._fast_blocks:
+            basis, grid = self._fast_blocks[(-1, 0)]
+            return _dev.extract_csr_tensor_t(basis.splines, grid.axes, 0, grid.num_nodes(), self.getIgnoreEps())
+        blocks = []
+        offset = 0
+        fe_total = self.V.dim()
+        for field in range(nf):
+            key = (field, offset)
+            if key not in self._fast_blocks:
+                return self.M.transpose()
+            basis, grid = self._fast_blocks[key]
+            blocks.append(_dev.extract_csr_tensor_t(basis.splines, grid.axes, self.V.field_offset(field), fe_total,
+                                                    self.getIgnoreEps()))
+            offset += self.getNcp(field)
+        return blocks[0] if len(blocks) == 1 else _dev.csr_vstack(blocks)
 
     def generateM(self):
         """Extraction matrix of the mixed space of all unknown fields
@@ -578,11 +610,11 @@ class ExtractedSpline(object):
         self.M = generator.M
         self.M_control = generator.M_control
         self.comm = generator.getComm()
-        self.zeroDofs = array(generator.zeroDofs, dtype=INDEX_TYPE)
+        self.zeroDofs = numpy.asarray(generator.zeroDofs, dtype=INDEX_TYPE)
 
     def genericSetup(self):
         self.setSolverOptions()
-        self.MT = self.M.transpose()          # explicit M^T, built once (FORM_MT)
+        self.MT = self.M.transpose()          # explicit M^T (cached on M by the generator)
         self._ptap_plan = None
         self._ptap_plan_key = None
 

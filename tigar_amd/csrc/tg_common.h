@@ -68,12 +68,12 @@ struct tg_csr_s {
   int spmv_mode = 0;             // 0 = not planned, 1 = stream (LDS), 2 = vector (wave/row)
 };
 
+int tg_dmalloc_bytes(void **p, size_t bytes);   // caching allocator (tg_core.hip)
+void tg_dfree(void *p);
 template <typename T>
 static inline int tg_dmalloc(T **p, int64_t count) {
-  *p = nullptr;
   if (count <= 0) count = 1;
-  TG_CHECK_HIP(hipMalloc((void **)p, (size_t)count * sizeof(T)));
-  return 0;
+  return tg_dmalloc_bytes((void **)p, (size_t)count * sizeof(T));
 }
 #define TG_TRY(expr)          \
   do {                        \

@@ -41,6 +41,7 @@ extern "C" int tg_init(int device) {
 extern "C" int tg_shutdown(void) {
   if (!g_tg.ready) return 0;
   hipStreamSynchronize(g_tg.stream);
+  tg_pool_trim();
   hipFree(g_tg.scratch);
   hipHostFree(g_tg.host_pinned);
   for (int i = 0; i < 8; i++) {
@@ -112,6 +113,81 @@ extern "C" int tg_timer_stop(int slot, double *ms) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------ allocator
+// Caching device allocator.  hipMalloc / hipFree of multi-GB buffers cost up to ~0.1 ms per MB on
+// some hosts and hipFree synchronises the device; the hot path allocates its outputs (M, M^T,
+// K, temporaries) afresh on every call, so freed blocks are kept in a size-keyed pool and
+// handed out again.  All work runs on one stream, so reuse is stream-ordered and needs no sync.
+#include <map>
+#include <unordered_map>
+static std::multimap<size_t, void *> g_pool_free;
+static std::unordered_map<void *, size_t> g_pool_size;
+static size_t g_pool_bytes = 0;
+
+static size_t tg_pool_limit() {
+  static size_t lim = 0;
+  if (!lim) {
+    const char *s = getenv("TIGAR_POOL_GB");
+    lim = (size_t)(s ? atof(s) : 96.0) * (size_t)1 << 30;
+  }
+  return lim;
+}
+
+extern "C" int tg_pool_trim(void) {
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  for (auto &kv : g_pool_free) {
+    g_pool_size.erase(kv.second);
+    hipFree(kv.second);
+  }
+  g_pool_free.clear();
+  g_pool_bytes = 0;
+  return 0;
+}
+
+int tg_dmalloc_bytes(void **p, size_t bytes) {
+  *p = nullptr;
+  if (bytes == 0) bytes = 1;
+  bytes = (bytes + 255) & ~(size_t)255;
+  auto it = g_pool_free.lower_bound(bytes);
+  if (it != g_pool_free.end() && it->first <= bytes + bytes / 8 + 4096) {
+    *p = it->second;
+    g_pool_bytes -= it->first;
+    g_pool_free.erase(it);
+    return 0;
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    tg_pool_trim();
+    e = hipMalloc(p, bytes);
+  }
+  if (e != hipSuccess) {
+    *p = nullptr;
+    tg_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    return 1;
+  }
+  g_pool_size[*p] = bytes;
+  return 0;
+}
+
+void tg_dfree(void *p) {
+  if (!p) return;
+  auto it = g_pool_size.find(p);
+  if (it == g_pool_size.end()) {  // not ours (should not happen)
+    hipFree(p);
+    return;
+  }
+  const size_t bytes = it->second;
+  if (g_pool_bytes + bytes > tg_pool_limit()) {
+    if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+    g_pool_size.erase(it);
+    hipFree(p);
+    return;
+  }
+  g_pool_free.emplace(bytes, p);
+  g_pool_bytes += bytes;
+}
+
 // ------------------------------------------------------------------------------ vectors
 extern "C" int tg_vec_create(int64_t n, tg_vec_t *out) {
   TG_REQUIRE_INIT();
@@ -130,7 +206,7 @@ extern "C" int tg_vec_create(int64_t n, tg_vec_t *out) {
 extern "C" int tg_vec_destroy(tg_vec_t v) {
   if (!v) return 0;
   if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
-  hipFree(v->d);
+  tg_dfree(v->d);
   delete v;
   return 0;
 }
@@ -255,7 +331,7 @@ extern "C" int tg_vec_zero_entries(tg_vec_t y, const int32_t *dofs, int64_t n) {
   hipLaunchKernelGGL(k_zero_entries, dim3((unsigned)tg_cdiv(n, 256)), dim3(256), 0, g_tg.stream, y->d, y->n, d, n);
   TG_LAUNCH_CHECK();
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
-  hipFree(d);
+  tg_dfree(d);
   return 0;
 }
 
@@ -290,7 +366,7 @@ extern "C" int tg_vec_tensor3(tg_vec_t out, int d, const double *const *b1d, con
                      db[2], n[0], d > 1 ? n[1] : 1, scale, row0, out->n);
   TG_LAUNCH_CHECK();
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
-  for (int k = 0; k < d; k++) hipFree(db[k]);
+  for (int k = 0; k < d; k++) tg_dfree(db[k]);
   return 0;
 }
 
@@ -302,9 +378,9 @@ int tg_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, tg_csr_s **out) {
   m->nnz = nnz;
   if (tg_dmalloc(&m->rowptr, nrows + 1) || tg_dmalloc(&m->col, nnz + TG_CSR_PAD) ||
       tg_dmalloc(&m->val, nnz + TG_CSR_PAD)) {
-    hipFree(m->rowptr);
-    hipFree(m->col);
-    hipFree(m->val);
+    tg_dfree(m->rowptr);
+    tg_dfree(m->col);
+    tg_dfree(m->val);
     delete m;
     return 1;
   }
@@ -356,10 +432,10 @@ extern "C" int tg_csr_download(tg_csr_t m, int64_t *rowptr, int32_t *col, double
 extern "C" int tg_csr_destroy(tg_csr_t m) {
   if (!m) return 0;
   if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
-  hipFree(m->rowptr);
-  hipFree(m->col);
-  hipFree(m->val);
-  hipFree(m->rowblocks);
+  tg_dfree(m->rowptr);
+  tg_dfree(m->col);
+  tg_dfree(m->val);
+  tg_dfree(m->rowblocks);
   delete m;
   return 0;
 }
@@ -421,7 +497,7 @@ static int tg_scan_rec(int64_t *d, int64_t n) {
     if (hipGetLastError() != hipSuccess) rc = 1;
   }
   hipStreamSynchronize(g_tg.stream);
-  hipFree(sums);
+  tg_dfree(sums);
   return rc;
 }
 

@@ -111,10 +111,10 @@ struct tg_dir_tables {
   double *ghost = nullptr, *nodes = nullptr, *val = nullptr;
   int32_t *idx = nullptr;
   void free_all() {
-    hipFree(ghost);
-    hipFree(nodes);
-    hipFree(val);
-    hipFree(idx);
+    tg_dfree(ghost);
+    tg_dfree(nodes);
+    tg_dfree(val);
+    tg_dfree(idx);
   }
 };
 
@@ -167,7 +167,7 @@ extern "C" int tg_eval_basis_1d(const tg_dir_t *dir, const double *u, int64_t n,
     }
   }
   T.free_all();
-  hipFree(span_dev);
+  tg_dfree(span_dev);
   return rc;
 }
 
@@ -357,7 +357,7 @@ static int tg_run_extract(tg_extract_params &P, int64_t nblocks, int64_t ncols, 
   }
   int64_t nnz = 0;
   if (tg_exclusive_scan_i64(rowptr, P.nrows, &nnz)) {
-    hipFree(rowptr);
+    tg_dfree(rowptr);
     return 1;
   }
   tg_csr_s *m = new tg_csr_s();
@@ -477,6 +477,59 @@ extern "C" int tg_extract_csr_points(int d, const tg_dir_t *dirs, int32_t col_of
   hipStreamSynchronize(g_tg.stream);
   for (int k = 0; k < d; k++) T[k].free_all();
   return rc;
+}
+
+// ----------------------------------------------------------------------------------------
+// Transposed extraction: rows of M^T (one per spline basis function) written directly, as the
+// Kronecker product of the transposed 1-D evaluation tables with the same (Nu*Nv)*Nw
+// arithmetic and the same |v| > eps filter -- so M^T is bit-identical to transposing M, at
+// the cost of one more streaming write instead of a scatter + per-row sort.
+// ----------------------------------------------------------------------------------------
+int tg_kron_build_rect(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0, int64_t row1,
+                       int filter, double eps, int64_t col_offset, int64_t ncols_total, tg_csr_t *out);
+
+extern "C" int tg_extract_csr_tensor_t(int d, const tg_dir_t *dirs, int64_t fe_row_offset, int64_t fe_rows_total,
+                                       double eps, int64_t dof0, int64_t dof1, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(d >= 1 && d <= 3 && dirs && out, "bad arguments to tg_extract_csr_tensor_t");
+  std::vector<int32_t> rp[3], cl[3];
+  std::vector<double> vl[3];
+  tg_kron_dir_t kd[3];
+  int64_t cdim[3] = {1, 1, 1};
+  for (int k = 0; k < d; k++) {
+    TG_TRY(tg_check_dir(dirs[k]));
+    const int64_t n = dirs[k].nnodes;
+    const int pp1 = dirs[k].p + 1;
+    const int ncp = dirs[k].ncp;
+    TG_REQUIRE(n >= 1 && dirs[k].nodes, "direction %d has no nodes", k);
+    std::vector<int32_t> idx((size_t)n * pp1);
+    std::vector<double> val((size_t)n * pp1);
+    TG_TRY(tg_eval_basis_1d(&dirs[k], dirs[k].nodes, n, nullptr, idx.data(), val.data()));
+    // transpose the 1-D table on the host (a few thousand entries); exact zeros cannot
+    // survive the product filter and are dropped here
+    rp[k].assign((size_t)ncp + 1, 0);
+    for (int64_t a = 0; a < n; a++)
+      for (int r = 0; r < pp1; r++)
+        if (val[a * pp1 + r] != 0.0) rp[k][(size_t)idx[a * pp1 + r] + 1]++;
+    for (int i = 0; i < ncp; i++) rp[k][i + 1] += rp[k][i];
+    cl[k].resize((size_t)rp[k][ncp]);
+    vl[k].resize((size_t)rp[k][ncp]);
+    std::vector<int32_t> cur(rp[k].begin(), rp[k].end() - 1);
+    for (int64_t a = 0; a < n; a++)       // ascending node index => sorted columns
+      for (int r = 0; r < pp1; r++)
+        if (val[a * pp1 + r] != 0.0) {
+          const int i = idx[a * pp1 + r];
+          cl[k][cur[i]] = (int32_t)a;
+          vl[k][cur[i]] = val[a * pp1 + r];
+          cur[i]++;
+        }
+    kd[k].n = ncp;
+    kd[k].rowptr = rp[k].data();
+    kd[k].col = cl[k].data();
+    kd[k].val = vl[k].data();
+    cdim[k] = n;
+  }
+  return tg_kron_build_rect(d, 1, kd, cdim, dof0, dof1, 1, eps, fe_row_offset, fe_rows_total, out);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -5,6 +5,9 @@
 // ranges [row0,row1) in lexicographic node order (direction 0 fastest); columns global.
 #include "tg_common.h"
 #include <algorithm>
+#include <chrono>
+static double tg_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define TG_TRACE(msg) do { if (getenv("TIGAR_TRACE")) fprintf(stderr, "[trace] %s %.3f ms\n", msg, (tg_now() - _t0) * 1e3); } while (0)
 
 #define TG_KRON_MAX_TERMS 4
 
@@ -17,6 +20,10 @@ struct tg_kron_params {
   int64_t nnz1d[3];
   int64_t row0, nrows;
   int64_t pencil0, npencils;
+  int filter;          // 1: keep only |v| > eps (single term), as generateM does
+  double eps;
+  int64_t col_offset;
+  int64_t cstride[3];  // column strides of the product index
 };
 
 __device__ __forceinline__ void tg_kron_pencil(const tg_kron_params &P, int64_t pencil, int64_t *b, int64_t *c) {
@@ -42,7 +49,22 @@ __global__ void __launch_bounds__(256) k_kron_count(tg_kron_params P, int64_t *_
   for (int64_t a = threadIdx.x; a < P.n[0]; a += 256) {
     const int64_t lr = P.n[0] * pencil + a - P.row0;
     if (lr < 0 || lr >= P.nrows) continue;
-    rowptr[lr] = (int64_t)(P.rowptr[0][a + 1] - P.rowptr[0][a]) * lyz;
+    if (!P.filter) {
+      rowptr[lr] = (int64_t)(P.rowptr[0][a + 1] - P.rowptr[0][a]) * lyz;
+    } else {
+      const int y0 = (P.d > 1) ? P.rowptr[1][b] : 0, y1 = (P.d > 1) ? P.rowptr[1][b + 1] : 1;
+      const int z0 = (P.d > 2) ? P.rowptr[2][c] : 0, z1 = (P.d > 2) ? P.rowptr[2][c + 1] : 1;
+      int cnt = 0;
+      for (int k = z0; k < z1; k++)
+        for (int j = y0; j < y1; j++)
+          for (int i = P.rowptr[0][a]; i < P.rowptr[0][a + 1]; i++) {
+            double v = P.val[0][i];
+            if (P.d > 1) v *= P.val[1][j];
+            if (P.d > 2) v *= P.val[2][k];
+            cnt += (fabs(v) > P.eps) ? 1 : 0;
+          }
+      rowptr[lr] = cnt;
+    }
   }
 }
 
@@ -63,38 +85,78 @@ __global__ void __launch_bounds__(256)
     const int x0 = P.rowptr[0][a];
     const int lx = P.rowptr[0][a + 1] - x0;
     const int L = lx * ly * lz;
-    const int64_t out0 = rowptr[lr];
-    for (int e = lane; e < L; e += 64) {
-      const int i = e % lx;
-      const int jk = e / lx;
+    int64_t out0 = rowptr[lr];
+    for (int e0 = 0; e0 < L; e0 += 64) {
+      const int e = e0 + lane;
+      const bool in = e < L;
+      const int i = in ? e % lx : 0;
+      const int jk = in ? e / lx : 0;
       const int j = jk % ly;
       const int k = jk / ly;
       int64_t cc = P.col[0][x0 + i];
-      if (P.d > 1) cc += P.n[0] * (int64_t)P.col[1][y0 + j];
-      if (P.d > 2) cc += P.n[0] * P.n[1] * (int64_t)P.col[2][z0 + k];
+      if (P.d > 1) cc += P.cstride[1] * (int64_t)P.col[1][y0 + j];
+      if (P.d > 2) cc += P.cstride[2] * (int64_t)P.col[2][z0 + k];
       double s = 0.0;
       for (int t = 0; t < P.nterms; t++) {
-        double v = P.val[0][t * P.nnz1d[0] + x0 + i];
+        double v = P.val[0][t * P.nnz1d[0] + x0 + i];   // (x*y)*z, left to right
         if (P.d > 1) v *= P.val[1][t * P.nnz1d[1] + y0 + j];
         if (P.d > 2) v *= P.val[2][t * P.nnz1d[2] + z0 + k];
         s += v;
       }
-      col[out0 + e] = (int32_t)cc;
-      val[out0 + e] = s;
+      if (!P.filter) {
+        if (in) {
+          col[out0 + e] = (int32_t)(cc + P.col_offset);
+          val[out0 + e] = s;
+        }
+      } else {
+        const bool keep = in && fabs(s) > P.eps;
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+          const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+          const int64_t pos = out0 + __popcll(m & below);
+          col[pos] = (int32_t)(cc + P.col_offset);
+          val[pos] = s;
+        }
+        out0 += __popcll(m);
+      }
     }
   }
 }
 
+int tg_kron_build(int d, int nterms, const tg_kron_dir_t *dirs, int64_t row0, int64_t row1, int filter, double eps,
+                  int64_t col_offset, int64_t ncols_total, tg_csr_t *out);
+
 extern "C" int tg_kron_sum_csr(int d, int nterms, const tg_kron_dir_t *dirs, int64_t row0, int64_t row1,
                                tg_csr_t *out) {
+  return tg_kron_build(d, nterms, dirs, row0, row1, 0, 0.0, 0, -1, out);
+}
+
+// column index of the product = sum_k col_k * stride_k with strides 1, ncols_1d[0], ...; the 1-D
+// factors may be rectangular: ncols_1d is passed through tg_kron_dir_t.n of a SECOND array
+// when needed (here: stride_k = number of 1-D columns, given by `cdim`).
+int tg_kron_build_rect(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0, int64_t row1,
+                       int filter, double eps, int64_t col_offset, int64_t ncols_total, tg_csr_t *out);
+
+int tg_kron_build(int d, int nterms, const tg_kron_dir_t *dirs, int64_t row0, int64_t row1, int filter, double eps,
+                  int64_t col_offset, int64_t ncols_total, tg_csr_t *out) {
+  return tg_kron_build_rect(d, nterms, dirs, nullptr, row0, row1, filter, eps, col_offset, ncols_total, out);
+}
+
+int tg_kron_build_rect(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0, int64_t row1,
+                       int filter, double eps, int64_t col_offset, int64_t ncols_total, tg_csr_t *out) {
   TG_REQUIRE_INIT();
+  const double _t0 = tg_now();
   TG_REQUIRE(d >= 1 && d <= 3 && nterms >= 1 && nterms <= TG_KRON_MAX_TERMS && dirs && out,
              "bad arguments to tg_kron_sum_csr");
   tg_kron_params P;
   memset(&P, 0, sizeof(P));
   P.d = d;
   P.nterms = nterms;
-  int64_t total = 1;
+  P.filter = filter;
+  P.eps = eps;
+  P.col_offset = col_offset;
+  TG_REQUIRE(!filter || nterms == 1, "the eps filter applies to single-term products");
+  int64_t total = 1, ctotal = 1;
   void *dev[9] = {nullptr};
   int rc = 0;
   for (int k = 0; k < 3; k++) P.n[k] = 1;
@@ -105,6 +167,8 @@ extern "C" int tg_kron_sum_csr(int d, int nterms, const tg_kron_dir_t *dirs, int
     P.n[k] = D.n;
     P.nnz1d[k] = nnz1;
     total *= D.n;
+    P.cstride[k] = ctotal;
+    ctotal *= cdim ? cdim[k] : D.n;
     int32_t *rp = nullptr, *cl = nullptr;
     double *vl = nullptr;
     rc = tg_dmalloc(&rp, D.n + 1) || tg_dmalloc(&cl, nnz1) || tg_dmalloc(&vl, nnz1 * nterms);
@@ -137,14 +201,17 @@ extern "C" int tg_kron_sum_csr(int d, int nterms, const tg_kron_dir_t *dirs, int
       if (P.npencils > 0)
         hipLaunchKernelGGL(k_kron_count, dim3((unsigned)P.npencils), dim3(256), 0, g_tg.stream, P, rowptr);
       int64_t nnz = 0;
+      TG_TRACE("count launched");
       rc = tg_exclusive_scan_i64(rowptr, P.nrows, &nnz);
+      TG_TRACE("scan done");
       if (!rc) {
         m = new tg_csr_s();
         m->nrows = P.nrows;
-        m->ncols = total;
+        m->ncols = ncols_total >= 0 ? ncols_total : ctotal;
         m->nnz = nnz;
         m->rowptr = rowptr;
         rc = tg_dmalloc(&m->col, nnz + TG_CSR_PAD) || tg_dmalloc(&m->val, nnz + TG_CSR_PAD);
+        TG_TRACE("malloc done");
         if (!rc && P.npencils > 0 && nnz > 0) {
           hipLaunchKernelGGL(k_kron_fill, dim3((unsigned)P.npencils), dim3(256), 0, g_tg.stream, P, rowptr, m->col,
                              m->val);
@@ -154,11 +221,13 @@ extern "C" int tg_kron_sum_csr(int d, int nterms, const tg_kron_dir_t *dirs, int
           }
         }
       } else
-        hipFree(rowptr);
+        tg_dfree(rowptr);
     }
   }
   hipStreamSynchronize(g_tg.stream);
-  for (int i = 0; i < 9; i++) hipFree(dev[i]);
+  TG_TRACE("fill synced");
+  for (int i = 0; i < 9; i++) tg_dfree(dev[i]);
+  TG_TRACE("freed");
   if (rc) {
     if (m) tg_csr_destroy(m);
     return rc;

@@ -130,7 +130,7 @@ struct tg_krylov_ws {
   ~tg_krylov_ws() {
     if (buf) {
       hipStreamSynchronize(g_tg.stream);
-      hipFree(buf);
+      tg_dfree(buf);
     }
   }
 };

@@ -8,22 +8,30 @@
 //   finish :  rank-sort the <= (2p+1)^d entries of table 2 by column, apply the optional
 //             fused MatZeroRowsColumns, write the CSR row.
 //
-// symbolic pass = same traversal on indices only (row counts -> rowptr, table sizes).
+// The kernel is latency-sensitive (three dependent global loads per operand row), so the
+// row descriptors (start, length, scale) of a chunk of operand rows are first staged into LDS
+// by all threads at once, and groups of G lanes then walk the operand rows with U-way
+// unrolled 4+8-byte loads before touching the hash tables.
+//
+// One numeric pass, no separate symbolic pass: in BUMP mode every workgroup reserves its
+// row's space in a temporary array with one atomicAdd, row counts are scanned afterwards and
+// rows are copied into CSR order (costs 2x nnz(K) of traffic instead of a second traversal of
+// A and M).  Once a plan knows the row pointer (second call with the same pattern, e.g. a
+// Newton loop), rows are PLACED directly.
 // Inputs are row blocks (z-slabs) with GLOBAL column indices: local row = global - row0.
 #include "tg_common.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 
-int tg_build_dof_mask(const int32_t *dofs, int64_t n, int64_t ndofs_total, uint8_t **mask_out);
-
 struct tg_ptap_s {
   int64_t nrows = 0;        // K rows in this block
   int64_t ncols = 0;        // = M.ncols
-  int64_t nnz = 0;
-  int64_t *rowptr = nullptr;  // device, nrows+1
+  int64_t nnz = -1;         // known after the first numeric pass
+  int64_t *rowptr = nullptr;  // device, nrows+1 (valid when nnz >= 0)
   int64_t a_row0 = 0, m_row0 = 0, mt_row0 = 0;
   int ts1 = 0, ts2 = 0, g1 = 0, g2 = 0;
   int max_t = 0, max_k = 0;
+  double mean_k = 0.0;
 };
 
 struct tg_ptap_args {
@@ -38,143 +46,211 @@ struct tg_ptap_args {
   const double *m_val;
   int64_t a_row0, a_nrows, m_row0, m_nrows, mt_row0;
   int64_t nrows;       // K rows to compute
-  int64_t row_stride;  // symbolic sampling: row = idx * row_stride
+  int64_t row_stride;  // probing: row = idx * row_stride
   int ts1, ts2, lg1, lg2, g1, g2;
 };
 
-enum { TG_PTAP_OK = 0, TG_PTAP_OVF1 = 1, TG_PTAP_OVF2 = 2, TG_PTAP_RANGE = 3 };
+enum { TG_PTAP_OK = 0, TG_PTAP_OVF1 = 1, TG_PTAP_OVF2 = 2, TG_PTAP_RANGE = 3, TG_PTAP_CAP = 4 };
+enum { TG_MODE_PROBE = 0, TG_MODE_BUMP = 1, TG_MODE_PLACED = 2 };
+
+#define TG_PTAP_UNROLL 4
 
 __device__ __forceinline__ unsigned tg_hash(int32_t key, int lg) {
   return ((unsigned)key * 2654435761u) >> (32 - lg);
 }
 
-// returns false on table overflow
-template <bool NUMERIC>
-__device__ __forceinline__ bool tg_hash_insert(int32_t *keys, double *vals, int ts, int lg, int32_t key, double v) {
-  unsigned slot = tg_hash(key, lg);
-  for (int probe = 0; probe < ts; probe++) {
-    int32_t cur = keys[slot];
-    if (cur != key) {
-      if (cur != -1) {
-        slot = (slot + 1) & (ts - 1);
-        continue;
+// Bucketed hash tables: 4 keys per 16-byte bucket, one ds_read_b128 fetches a whole bucket.
+// With the load factor kept below ~0.4 a lookup of a key that is already present -- the
+// common case by a factor of 20-40 -- finishes in the first bucket: one LDS read, four
+// compares, one ds_add_f64.  Inserts CAS the first empty position of the bucket; a full
+// bucket without the key spills into the next bucket.  key < 0 = nothing to do.
+// Returns false on table overflow.
+typedef int tg_i4v __attribute__((ext_vector_type(4)));
+
+template <bool NUMERIC, int U>
+__device__ __forceinline__ bool tg_hash_insert_n(int32_t *keys, double *vals, int ts, int lg, const int32_t *key,
+                                                 const double *v) {
+  bool ok = true;
+  const int nb_mask = (ts >> 2) - 1;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int32_t k = key[u];
+    int b = (int)(tg_hash(k, lg) >> 2);
+    bool pending = k >= 0;
+    int rounds = 0;
+    while (__any(pending)) {
+      const tg_i4v kk = *reinterpret_cast<const tg_i4v *>(keys + 4 * b);
+      int pos = (kk.x == k) ? 0 : (kk.y == k) ? 1 : (kk.z == k) ? 2 : (kk.w == k) ? 3 : -1;
+      if (pending && pos < 0) {
+        const int e = (kk.x == -1) ? 0 : (kk.y == -1) ? 1 : (kk.z == -1) ? 2 : (kk.w == -1) ? 3 : -1;
+        if (e >= 0) {
+          const int32_t old = atomicCAS(&keys[4 * b + e], -1, k);
+          if (old == -1 || old == k) pos = e;   // else: somebody else took it, re-read this bucket
+        } else {
+          b = (b + 1) & nb_mask;               // bucket full of other keys
+        }
       }
-      cur = atomicCAS(&keys[slot], -1, key);
-      if (cur != -1 && cur != key) {
-        slot = (slot + 1) & (ts - 1);
-        continue;
+      const bool hit = pending && pos >= 0;
+      if (NUMERIC && hit) unsafeAtomicAdd(&vals[4 * b + pos], v[u]);
+      pending = pending && !hit;
+      if (++rounds > ts) {  // wave-uniform
+        ok = false;
+        break;
       }
     }
-    if (NUMERIC) unsafeAtomicAdd(&vals[slot], v);
-    return true;
   }
-  return false;
+  return ok;
 }
 
-// LDS carve (dynamic, 16-byte aligned offsets):
-//   keys1[ts1] int32 | list1[ts1] int32 | keys2[ts2] int32 | cnt[4] int32 | vals1[ts1] f64 | vals2[ts2] f64
+// walks operand rows [0,nch) described in LDS (start,len,scale) with groups of G lanes
 template <bool NUMERIC>
-__global__ void __launch_bounds__(256)
-    k_ptap(tg_ptap_args P, int64_t *__restrict__ k_rowptr_or_cnt, int32_t *__restrict__ k_col,
-           double *__restrict__ k_val, const uint8_t *__restrict__ mask, double diag, int *__restrict__ status,
-           int *__restrict__ maxima) {
+__device__ __forceinline__ bool tg_accumulate_rows(int nch, const int64_t *pre_start, const int *pre_len,
+                                                   const double *pre_w, const int32_t *__restrict__ col,
+                                                   const double *__restrict__ val, int G, int lg, int32_t *keys,
+                                                   double *vals, int ts, int lgts) {
+  const int tid = threadIdx.x;
+  const int sub = tid & (G - 1);
+  const int grp = tid >> lg;
+  const int ngrp = (int)blockDim.x >> lg;
+  bool ok = true;
+  for (int le = grp; le < nch; le += ngrp) {
+    const int64_t start = pre_start[le];
+    const int len = pre_len[le];
+    const double w = NUMERIC ? pre_w[le] : 0.0;
+    for (int o = sub; o < len; o += G * TG_PTAP_UNROLL) {
+      int32_t c[TG_PTAP_UNROLL];
+      double v[TG_PTAP_UNROLL];
+#pragma unroll
+      for (int u = 0; u < TG_PTAP_UNROLL; u++) {
+        // unconditional (clamped) loads: no branches in the load phase
+        const int oo = o + u * G;
+        const int oc = min(oo, len - 1);
+        const int32_t cc = col[start + oc];
+        c[u] = (oo < len) ? cc : -2;
+        v[u] = NUMERIC ? w * val[start + oc] : 0.0;
+      }
+      ok &= tg_hash_insert_n<NUMERIC, TG_PTAP_UNROLL>(keys, vals, ts, lgts, c, v);
+    }
+  }
+  return ok;
+}
+
+// LDS carve (dynamic, 16-byte aligned offsets), NT = threads per workgroup:
+//   keys1[ts1] | keys2[ts2] | cnt[4] | pre_len[NT]  (int32)
+//   pre_start[NT] (int64) | pre_w[NT] | vals1[ts1] | vals2[ts2]  (f64)
+template <int MODE, int NT>
+__global__ void __launch_bounds__(NT)
+    k_ptap(tg_ptap_args P, int64_t *__restrict__ row_cnt, int64_t *__restrict__ row_off, int32_t *__restrict__ k_col,
+           double *__restrict__ k_val, unsigned long long *__restrict__ cursor, int64_t capacity,
+           const uint8_t *__restrict__ mask, double diag, int *__restrict__ status, int *__restrict__ maxima) {
+  constexpr bool NUMERIC = MODE != TG_MODE_PROBE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int32_t *keys1 = reinterpret_cast<int32_t *>(smem);
-  int32_t *list1 = keys1 + P.ts1;
-  int32_t *keys2 = list1 + P.ts1;
+  int32_t *keys2 = keys1 + P.ts1;
   int32_t *cnt = keys2 + P.ts2;
-  double *vals1 = reinterpret_cast<double *>(cnt + 4);
+  int *pre_len = cnt + 4;
+  int64_t *pre_start = reinterpret_cast<int64_t *>(pre_len + NT);
+  double *pre_w = reinterpret_cast<double *>(pre_start + NT);
+  double *vals1 = pre_w + NT;
   double *vals2 = vals1 + (NUMERIC ? P.ts1 : 0);
 
   const int tid = threadIdx.x;
-  const int64_t nb = (int64_t)gridDim.x;
   const int64_t L = tg_xcd_block(blockIdx.x, P.nrows);
-  (void)nb;
   if (L >= P.nrows) return;
   const int64_t li = L * P.row_stride;  // local K / M^T row
+  const int lgts1 = 32 - __clz(P.ts1 - 1), lgts2 = 32 - __clz(P.ts2 - 1);
 
-  for (int s = tid; s < P.ts1; s += 256) {
+  for (int s = tid; s < P.ts1; s += NT) {
     keys1[s] = -1;
     if (NUMERIC) vals1[s] = 0.0;
   }
-  for (int s = tid; s < P.ts2; s += 256) {
+  for (int s = tid; s < P.ts2; s += NT) {
     keys2[s] = -1;
     if (NUMERIC) vals2[s] = 0.0;
   }
   if (tid < 4) cnt[tid] = 0;
   __syncthreads();
 
+  bool ovf1 = false, ovf2 = false, range = false;
   // ---- stage 1: T = (row i of M^T) * A
   {
     const int64_t e0 = P.mt_rowptr[li], e1 = P.mt_rowptr[li + 1];
-    const int sub = tid & (P.g1 - 1);
-    const int grp = tid >> P.lg1;
-    const int ngrp = 256 >> P.lg1;
-    bool ovf = false, range = false;
-    for (int64_t e = e0 + grp; e < e1; e += ngrp) {
-      const int64_t ra = (int64_t)P.mt_col[e] - P.a_row0;
-      if (ra < 0 || ra >= P.a_nrows) {
-        range = true;
-        continue;
+    for (int64_t c0 = e0; c0 < e1; c0 += NT) {
+      const int64_t e = c0 + tid;
+      if (e < e1) {
+        const int64_t ra = (int64_t)P.mt_col[e] - P.a_row0;
+        if (ra < 0 || ra >= P.a_nrows) {
+          range = true;
+          pre_len[tid] = 0;
+          pre_start[tid] = 0;
+        } else {
+          const int64_t s0 = P.a_rowptr[ra];
+          pre_start[tid] = s0;
+          pre_len[tid] = (int)(P.a_rowptr[ra + 1] - s0);
+        }
+        if (NUMERIC) pre_w[tid] = P.mt_val[e];
       }
-      const double w = NUMERIC ? P.mt_val[e] : 0.0;
-      const int64_t q1 = P.a_rowptr[ra + 1];
-      for (int64_t q = P.a_rowptr[ra] + sub; q < q1; q += P.g1) {
-        const double v = NUMERIC ? w * P.a_val[q] : 0.0;
-        if (!tg_hash_insert<NUMERIC>(keys1, vals1, P.ts1, 32 - __clz(P.ts1 - 1), P.a_col[q], v)) ovf = true;
-      }
+      __syncthreads();
+      const int nch = (int)min((int64_t)NT, e1 - c0);
+      if (!tg_accumulate_rows<NUMERIC>(nch, pre_start, pre_len, pre_w, P.a_col, P.a_val, P.g1, P.lg1, keys1, vals1,
+                                       P.ts1, lgts1))
+        ovf1 = true;
+      __syncthreads();
     }
-    if (ovf) atomicMax(status, TG_PTAP_OVF1);
-    if (range) atomicMax(status, TG_PTAP_RANGE);
   }
-  __syncthreads();
 
-  // ---- compact occupied slots of table 1
-  for (int s0 = 0; s0 < P.ts1; s0 += 256) {
-    const int s = s0 + tid;
-    const bool occ = (s < P.ts1) && keys1[s] != -1;
+  // ---- compact the occupied (key, value) pairs of table 1 to the front of its own storage
+  // (each chunk is read into registers before anything is written at or below it)
+  for (int c0 = 0; c0 < P.ts1; c0 += NT) {
+    const int slot = c0 + tid;
+    const int32_t key = (slot < P.ts1) ? keys1[slot] : -1;
+    const double tv = (NUMERIC && slot < P.ts1) ? vals1[slot] : 0.0;
+    __syncthreads();
+    const bool occ = key != -1;
     const unsigned long long m = __ballot(occ);
     int base = 0;
     if ((tid & 63) == 0 && m) base = atomicAdd(&cnt[0], __popcll(m));
     base = __shfl(base, 0, 64);
     if (occ) {
       const unsigned long long below = ((tid & 63) == 0) ? 0ull : (~0ull >> (64 - (tid & 63)));
-      list1[base + __popcll(m & below)] = s;
+      const int pos = base + __popcll(m & below);
+      keys1[pos] = key;
+      if (NUMERIC) vals1[pos] = tv;
     }
+    __syncthreads();
   }
-  __syncthreads();
   const int nT = cnt[0];
 
   // ---- stage 2: K row = T * M
-  {
-    const int sub = tid & (P.g2 - 1);
-    const int grp = tid >> P.lg2;
-    const int ngrp = 256 >> P.lg2;
-    bool ovf = false, range = false;
-    const int lgts2 = 32 - __clz(P.ts2 - 1);
-    for (int e = grp; e < nT; e += ngrp) {
-      const int slot = list1[e];
-      const int64_t sm = (int64_t)keys1[slot] - P.m_row0;
+  for (int c0 = 0; c0 < nT; c0 += NT) {
+    const int e = c0 + tid;
+    if (e < nT) {
+      const int64_t sm = (int64_t)keys1[e] - P.m_row0;
       if (sm < 0 || sm >= P.m_nrows) {
         range = true;
-        continue;
+        pre_len[tid] = 0;
+        pre_start[tid] = 0;
+      } else {
+        const int64_t s0 = P.m_rowptr[sm];
+        pre_start[tid] = s0;
+        pre_len[tid] = (int)(P.m_rowptr[sm + 1] - s0);
       }
-      const double w = NUMERIC ? vals1[slot] : 0.0;
-      const int64_t q1 = P.m_rowptr[sm + 1];
-      for (int64_t q = P.m_rowptr[sm] + sub; q < q1; q += P.g2) {
-        const double v = NUMERIC ? w * P.m_val[q] : 0.0;
-        if (!tg_hash_insert<NUMERIC>(keys2, vals2, P.ts2, lgts2, P.m_col[q], v)) ovf = true;
-      }
+      if (NUMERIC) pre_w[tid] = vals1[e];
     }
-    if (ovf) atomicMax(status, TG_PTAP_OVF2);
-    if (range) atomicMax(status, TG_PTAP_RANGE);
+    __syncthreads();
+    if (!tg_accumulate_rows<NUMERIC>(min(NT, nT - c0), pre_start, pre_len, pre_w, P.m_col, P.m_val, P.g2, P.lg2,
+                                     keys2, vals2, P.ts2, lgts2))
+      ovf2 = true;
+    __syncthreads();
   }
-  __syncthreads();
+  if (ovf1) atomicMax(status, TG_PTAP_OVF1);
+  if (ovf2) atomicMax(status, TG_PTAP_OVF2);
+  if (range) atomicMax(status, TG_PTAP_RANGE);
 
   // ---- compact table 2 into (ckey, cval) living in table-1 storage (no longer needed)
   int32_t *ckey = keys1;   // capacity ts1 >= ts2 (host guarantees)
   double *cval = vals1;
-  for (int s0 = 0; s0 < P.ts2; s0 += 256) {
+  for (int s0 = 0; s0 < P.ts2; s0 += NT) {
     const int s = s0 + tid;
     const bool occ = (s < P.ts2) && keys2[s] != -1;
     const unsigned long long m = __ballot(occ);
@@ -190,20 +266,42 @@ __global__ void __launch_bounds__(256)
   }
   __syncthreads();
   const int nK = cnt[1];
-  if (!NUMERIC) {
+  if (MODE == TG_MODE_PROBE) {
     if (tid == 0) {
-      k_rowptr_or_cnt[li] = nK;
+      row_cnt[li] = nK;
       atomicMax(&maxima[0], nT);
       atomicMax(&maxima[1], nK);
     }
     return;
   }
 
-  // ---- rank sort by column and write the CSR row (fused MatZeroRowsColumns)
-  const int64_t out0 = k_rowptr_or_cnt[li];
+  // ---- where does this row go?
+  int64_t out0;
+  if (MODE == TG_MODE_PLACED) {
+    out0 = row_off[li];
+    if (row_off[li + 1] - out0 != nK) {  // pattern changed since the plan was made
+      if (tid == 0) atomicMax(status, TG_PTAP_CAP);
+      return;
+    }
+  } else {
+    if (tid == 0) {
+      const unsigned long long o = atomicAdd(cursor, (unsigned long long)nK);
+      pre_start[0] = (int64_t)o;
+      row_cnt[li] = nK;
+      row_off[li] = (int64_t)o;
+    }
+    __syncthreads();
+    out0 = pre_start[0];
+    if (out0 + nK > capacity) {
+      if (tid == 0) atomicMax(status, TG_PTAP_CAP);
+      return;
+    }
+  }
+
+  // ---- rank sort by column and write the row (fused MatZeroRowsColumns)
   const int64_t gi = li + P.mt_row0;  // global K row
   const bool mrow = mask ? (mask[gi] != 0) : false;
-  for (int e = tid; e < nK; e += 256) {
+  for (int e = tid; e < nK; e += NT) {
     const int32_t key = ckey[e];
     int rank = 0;
     for (int f = 0; f < nK; f++) rank += (ckey[f] < key) ? 1 : 0;
@@ -211,6 +309,23 @@ __global__ void __launch_bounds__(256)
     if (mask && (mrow || mask[key])) v = (mrow && key == gi) ? diag : 0.0;
     k_col[out0 + rank] = key;
     k_val[out0 + rank] = v;
+  }
+}
+
+// copies bump-allocated rows into CSR order: wave per row
+__global__ void __launch_bounds__(256)
+    k_ptap_reorder(const int64_t *__restrict__ rowptr, const int64_t *__restrict__ tmp_off,
+                   const int32_t *__restrict__ tcol, const double *__restrict__ tval, int64_t nrows,
+                   int32_t *__restrict__ col, double *__restrict__ val) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    const int64_t dst = rowptr[r], n = rowptr[r + 1] - dst, src = tmp_off[r];
+    for (int64_t q = lane; q < n; q += 64) {
+      col[dst + q] = tcol[src + q];
+      val[dst + q] = tval[src + q];
+    }
   }
 }
 
@@ -224,17 +339,51 @@ static int tg_lg(int v) {
   while ((1 << l) < v) l++;
   return l;
 }
+static int tg_env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+// lanes per operand row: largest power of two <= 0.44 * mean row length, in [4,64]
 static int tg_group_for(double avg) {
-  if (avg >= 48) return 64;
-  if (avg >= 24) return 32;
-  if (avg >= 12) return 16;
-  return 8;
+  const double target = avg * 0.44;
+  int g = 4;
+  while (g < 64 && g * 2 <= target) g <<= 1;
+  return g;
 }
 
-static size_t tg_ptap_lds_bytes(int ts1, int ts2, bool numeric) {
-  size_t b = (size_t)ts1 * 4 * 2 + (size_t)ts2 * 4 + 16;
+static size_t tg_ptap_lds_bytes(int ts1, int ts2, bool numeric, int nt) {
+  size_t b = (size_t)ts1 * 4 + (size_t)ts2 * 4 + 16 + (size_t)nt * 4;  // int32 part
+  b += (size_t)nt * 8 * 2;                                             // pre_start, pre_w
   if (numeric) b += (size_t)ts1 * 8 + (size_t)ts2 * 8;
   return b;
+}
+
+// workgroup size: small tables -> many 256-thread groups per CU; big tables -> fewer, wider
+// groups so that a CU still holds >= 16 waves
+static int tg_ptap_threads(int ts1, int ts2, bool numeric) {
+  const int forced = tg_env_int("TIGAR_PTAP_NT", 0);
+  if (forced == 256 || forced == 512 || forced == 1024) return forced;
+  for (int nt = 256; nt <= 1024; nt *= 2) {
+    const size_t lds = tg_ptap_lds_bytes(ts1, ts2, numeric, nt);
+    const int blocks = (int)std::min<size_t>(8, (160 * 1024) / lds);
+    if (blocks * nt >= 1024 || nt == 1024) return nt;
+  }
+  return 1024;
+}
+
+template <int MODE>
+static void tg_ptap_launch(int nt, unsigned grid, size_t lds, const tg_ptap_args &P, int64_t *row_cnt,
+                           int64_t *row_off, int32_t *k_col, double *k_val, unsigned long long *cursor,
+                           int64_t capacity, const uint8_t *mask, double diag, int *status) {
+  if (nt == 256)
+    hipLaunchKernelGGL((k_ptap<MODE, 256>), dim3(grid), dim3(256), lds, g_tg.stream, P, row_cnt, row_off, k_col, k_val,
+                       cursor, capacity, mask, diag, status, status + 1);
+  else if (nt == 512)
+    hipLaunchKernelGGL((k_ptap<MODE, 512>), dim3(grid), dim3(512), lds, g_tg.stream, P, row_cnt, row_off, k_col, k_val,
+                       cursor, capacity, mask, diag, status, status + 1);
+  else
+    hipLaunchKernelGGL((k_ptap<MODE, 1024>), dim3(grid), dim3(1024), lds, g_tg.stream, P, row_cnt, row_off, k_col,
+                       k_val, cursor, capacity, mask, diag, status, status + 1);
 }
 
 static void tg_fill_args(tg_ptap_args &P, tg_csr_s *a, int64_t a_row0, tg_csr_s *m, int64_t m_row0, tg_csr_s *mt,
@@ -265,100 +414,87 @@ static int tg_status_error(int st) {
   return 0;
 }
 
+static void tg_ptap_set_lds_limits() {
+  static bool done = false;
+  if (done) return;
+#define TG_SETLIM(MODE, NT) \
+  hipFuncSetAttribute((const void *)k_ptap<MODE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+  TG_SETLIM(TG_MODE_PROBE, 256);
+  TG_SETLIM(TG_MODE_PROBE, 512);
+  TG_SETLIM(TG_MODE_PROBE, 1024);
+  TG_SETLIM(TG_MODE_BUMP, 256);
+  TG_SETLIM(TG_MODE_BUMP, 512);
+  TG_SETLIM(TG_MODE_BUMP, 1024);
+  TG_SETLIM(TG_MODE_PLACED, 256);
+  TG_SETLIM(TG_MODE_PLACED, 512);
+  TG_SETLIM(TG_MODE_PLACED, 1024);
+#undef TG_SETLIM
+  done = true;
+}
+
+// "symbolic" phase: probes a sample of rows to size the LDS hash tables and to estimate
+// nnz(K); the pattern itself is produced by the (single) numeric traversal.
 extern "C" int tg_ptap_symbolic(tg_csr_t a, int64_t a_row0, tg_csr_t m, int64_t m_row0, tg_csr_t mt,
                                 int64_t mt_row0, tg_ptap_t *plan_out) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(a && m && mt && plan_out, "null argument to tg_ptap_symbolic");
   TG_REQUIRE(mt->nrows <= m->ncols, "PtAP: M^T block has more rows than M has columns");
+  tg_ptap_set_lds_limits();
   tg_ptap_s *plan = new tg_ptap_s();
   plan->nrows = mt->nrows;
   plan->ncols = m->ncols;
   plan->a_row0 = a_row0;
   plan->m_row0 = m_row0;
   plan->mt_row0 = mt_row0;
-  plan->g1 = tg_group_for(a->nrows ? (double)a->nnz / (double)a->nrows : 1.0);
-  plan->g2 = tg_group_for(m->nrows ? (double)m->nnz / (double)m->nrows : 1.0);
-  if (tg_dmalloc(&plan->rowptr, plan->nrows + 1)) {
-    delete plan;
-    return 1;
-  }
-  hipMemsetAsync(plan->rowptr, 0, (size_t)(plan->nrows + 1) * sizeof(int64_t), g_tg.stream);
-  int *status = (int *)g_tg.scratch;  // [0] status, [1..2] maxima
+  plan->g1 = tg_env_int("TIGAR_PTAP_G1", tg_group_for(a->nrows ? (double)a->nnz / (double)a->nrows : 1.0));
+  plan->g2 = tg_env_int("TIGAR_PTAP_G2", tg_group_for(m->nrows ? (double)m->nnz / (double)m->nrows : 1.0));
   int rc = 0;
-  tg_ptap_args P;
-  tg_fill_args(P, a, a_row0, m, m_row0, mt, mt_row0);
-  P.g1 = plan->g1;
-  P.g2 = plan->g2;
-  P.lg1 = tg_lg(P.g1);
-  P.lg2 = tg_lg(P.g2);
   int h[3] = {0, 0, 0};
   if (plan->nrows > 0) {
-    // probe a sample of rows with large tables to size the real ones
-    int ts1 = 16384, ts2 = 4096;
-    const int64_t nsample = std::min<int64_t>(plan->nrows, 256);
-    int64_t *scratch_cnt = nullptr;
-    rc = tg_dmalloc(&scratch_cnt, plan->nrows + 1);
-    for (int attempt = 0; attempt < 2 && !rc; attempt++) {
+    int *status = (int *)g_tg.scratch;  // [0] status, [1..2] maxima
+    tg_ptap_args S;
+    tg_fill_args(S, a, a_row0, m, m_row0, mt, mt_row0);
+    S.g1 = plan->g1;
+    S.g2 = plan->g2;
+    S.lg1 = tg_lg(S.g1);
+    S.lg2 = tg_lg(S.g2);
+    const int64_t nsample = std::min<int64_t>(plan->nrows, 512);
+    S.nrows = nsample;
+    S.row_stride = std::max<int64_t>(1, plan->nrows / nsample);
+    S.ts1 = 16384;
+    S.ts2 = 4096;
+    int64_t *cnt = nullptr;
+    rc = tg_dmalloc(&cnt, plan->nrows + 1);
+    if (!rc) {
+      hipMemsetAsync(cnt, 0, (size_t)(plan->nrows + 1) * sizeof(int64_t), g_tg.stream);
       hipMemsetAsync(status, 0, 3 * sizeof(int), g_tg.stream);
-      tg_ptap_args S = P;
-      S.nrows = nsample;
-      S.row_stride = std::max<int64_t>(1, plan->nrows / nsample);
-      S.ts1 = ts1;
-      S.ts2 = ts2;
-      const size_t lds = tg_ptap_lds_bytes(ts1, ts2, false);
-      hipFuncSetAttribute((const void *)k_ptap<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL((k_ptap<false>), dim3((unsigned)(tg_cdiv(nsample, 8) * 8)), dim3(256), lds, g_tg.stream, S,
-                         scratch_cnt, (int32_t *)nullptr, (double *)nullptr, (const uint8_t *)nullptr, 0.0, status,
-                         status + 1);
+      const size_t lds = tg_ptap_lds_bytes(S.ts1, S.ts2, false, 1024);
+      tg_ptap_launch<TG_MODE_PROBE>(1024, (unsigned)(tg_cdiv(nsample, 8) * 8), lds, S, cnt, nullptr, nullptr, nullptr,
+                                    nullptr, 0, nullptr, 0.0, status);
       if (hipGetLastError() != hipSuccess) {
         tg_set_error("PtAP probe launch failed");
         rc = 1;
-        break;
+      } else {
+        hipMemcpyAsync(h, status, 3 * sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
+        // mean row length over the sample = sum(cnt)/nsample
+        int64_t total = 0;
+        rc = tg_exclusive_scan_i64(cnt, plan->nrows, &total);
+        hipStreamSynchronize(g_tg.stream);
+        if (!rc) rc = tg_status_error(h[0]);
+        if (!rc && h[0] != TG_PTAP_OK) {
+          tg_set_error("PtAP: a K row needs more than %d / %d LDS hash slots (intermediate / result)", S.ts1, S.ts2);
+          rc = 4;
+        }
+        plan->mean_k = (double)total / (double)nsample;
       }
-      hipMemcpyAsync(h, status, 3 * sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
-      hipStreamSynchronize(g_tg.stream);
-      if ((rc = tg_status_error(h[0]))) break;
-      if (h[0] == TG_PTAP_OK) break;
-      tg_set_error("PtAP: a K row needs more than %d / %d LDS hash slots (intermediate / result)", ts1, ts2);
-      rc = 4;
-    }
-    hipFree(scratch_cnt);
-    // full pass, growing the tables if a non-sampled row overflows
-    int cur1 = std::max(64, tg_pow2_ge((int64_t)h[1] * 3 / 2 + 8));
-    int cur2 = std::max(64, tg_pow2_ge((int64_t)h[2] * 3 / 2 + 8));
-    while (!rc) {
-      if (cur1 < cur2) cur1 = cur2;
-      hipMemsetAsync(status, 0, 3 * sizeof(int), g_tg.stream);
-      P.ts1 = cur1;
-      P.ts2 = cur2;
-      const size_t lds = tg_ptap_lds_bytes(cur1, cur2, false);
-      hipLaunchKernelGGL((k_ptap<false>), dim3((unsigned)(tg_cdiv(plan->nrows, 8) * 8)), dim3(256), lds, g_tg.stream, P,
-                         plan->rowptr, (int32_t *)nullptr, (double *)nullptr, (const uint8_t *)nullptr, 0.0, status,
-                         status + 1);
-      if (hipGetLastError() != hipSuccess) {
-        tg_set_error("PtAP symbolic launch failed (LDS %zu B)", lds);
-        rc = 1;
-        break;
-      }
-      hipMemcpyAsync(h, status, 3 * sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
-      hipStreamSynchronize(g_tg.stream);
-      if ((rc = tg_status_error(h[0]))) break;
-      if (h[0] == TG_PTAP_OK) break;
-      if (h[0] == TG_PTAP_OVF1) cur1 *= 2;
-      if (h[0] == TG_PTAP_OVF2) cur2 *= 2;
-      if (tg_ptap_lds_bytes(std::max(cur1, cur2), cur2, true) > 160 * 1024) {
-        tg_set_error("PtAP: K row too dense for the LDS tables (%d / %d slots)", cur1, cur2);
-        rc = 4;
-      }
+      tg_dfree(cnt);
     }
     plan->max_t = h[1];
     plan->max_k = h[2];
-    plan->ts1 = cur1;
-    plan->ts2 = cur2;
+    plan->ts2 = std::max(64, tg_pow2_ge((int64_t)h[2] * 5 / 2 + 8));
+    plan->ts1 = std::max(plan->ts2, std::max(64, tg_pow2_ge((int64_t)h[1] * 2 + 8)));
   }
-  if (!rc) rc = tg_exclusive_scan_i64(plan->rowptr, plan->nrows, &plan->nnz);
   if (rc) {
-    hipFree(plan->rowptr);
     delete plan;
     return rc;
   }
@@ -371,48 +507,131 @@ extern "C" int tg_ptap_numeric(tg_ptap_t plan, tg_csr_t a, tg_csr_t m, tg_csr_t 
   TG_REQUIRE_INIT();
   TG_REQUIRE(plan && a && m && mt && k_out, "null argument to tg_ptap_numeric");
   TG_REQUIRE(mt->nrows == plan->nrows && m->ncols == plan->ncols, "PtAP plan does not match the operands");
-  tg_csr_s *k = nullptr;
-  TG_TRY(tg_csr_alloc(plan->nrows, plan->ncols, plan->nnz, &k));
-  TG_CHECK_HIP(hipMemcpyAsync(k->rowptr, plan->rowptr, (size_t)(plan->nrows + 1) * sizeof(int64_t),
-                              hipMemcpyDeviceToDevice, g_tg.stream));
+  tg_ptap_set_lds_limits();
   int rc = 0;
   uint8_t *mask = nullptr;
-  if (nzero > 0) rc = tg_build_dof_mask(zero_dofs, nzero, plan->ncols, &mask);
-  if (!rc && plan->nrows > 0) {
-    tg_ptap_args P;
-    tg_fill_args(P, a, plan->a_row0, m, plan->m_row0, mt, plan->mt_row0);
-    P.g1 = plan->g1;
-    P.g2 = plan->g2;
-    P.lg1 = tg_lg(P.g1);
-    P.lg2 = tg_lg(P.g2);
-    P.ts1 = std::max(plan->ts1, plan->ts2);
-    P.ts2 = plan->ts2;
-    int *status = (int *)g_tg.scratch;
-    hipMemsetAsync(status, 0, 3 * sizeof(int), g_tg.stream);
-    const size_t lds = tg_ptap_lds_bytes(P.ts1, P.ts2, true);
-    hipFuncSetAttribute((const void *)k_ptap<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((k_ptap<true>), dim3((unsigned)(tg_cdiv(plan->nrows, 8) * 8)), dim3(256), lds, g_tg.stream, P,
-                       k->rowptr, k->col, k->val, (const uint8_t *)mask, diag, status, status + 1);
-    if (hipGetLastError() != hipSuccess) {
-      tg_set_error("PtAP numeric launch failed (LDS %zu B)", lds);
-      rc = 1;
-    } else {
+  if (nzero > 0) TG_TRY(tg_build_dof_mask(zero_dofs, nzero, plan->ncols, &mask));
+  tg_csr_s *k = nullptr;
+  int *status = (int *)g_tg.scratch;
+  tg_ptap_args P;
+  tg_fill_args(P, a, plan->a_row0, m, plan->m_row0, mt, plan->mt_row0);
+  P.g1 = plan->g1;
+  P.g2 = plan->g2;
+  P.lg1 = tg_lg(P.g1);
+  P.lg2 = tg_lg(P.g2);
+  const unsigned grid = (unsigned)(tg_cdiv(std::max<int64_t>(plan->nrows, 1), 8) * 8);
+
+  if (plan->nrows == 0) {
+    rc = tg_csr_alloc(0, plan->ncols, 0, &k);
+    if (!rc) hipMemsetAsync(k->rowptr, 0, sizeof(int64_t), g_tg.stream);
+  } else if (plan->nnz >= 0) {
+    // ---- pattern known: rows are placed directly
+    rc = tg_csr_alloc(plan->nrows, plan->ncols, plan->nnz, &k);
+    if (!rc) {
+      hipMemcpyAsync(k->rowptr, plan->rowptr, (size_t)(plan->nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice,
+                     g_tg.stream);
+      P.ts1 = plan->ts1;
+      P.ts2 = plan->ts2;
+      hipMemsetAsync(status, 0, 3 * sizeof(int), g_tg.stream);
+      const int nt = tg_ptap_threads(P.ts1, P.ts2, true);
+      const size_t lds = tg_ptap_lds_bytes(P.ts1, P.ts2, true, nt);
+      tg_ptap_launch<TG_MODE_PLACED>(nt, grid, lds, P, nullptr, k->rowptr, k->col, k->val, nullptr, 0, mask, diag,
+                                     status);
       int h = 0;
       hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
-      hipStreamSynchronize(g_tg.stream);
-      if (h != TG_PTAP_OK) {
+      if (hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        tg_set_error("PtAP numeric (placed) failed to run");
+        rc = 1;
+      } else if (h != TG_PTAP_OK) {
         rc = tg_status_error(h);
         if (!rc) {
-          tg_set_error("PtAP numeric: hash table overflow (%d); plan is stale for these operands", h);
+          tg_set_error("PtAP numeric: operands no longer match the plan's pattern (status %d)", h);
           rc = 4;
         }
       }
     }
+  } else {
+    // ---- first numeric pass: bump-allocate rows, scan counts, copy into CSR order
+    int64_t *cnt = nullptr, *off = nullptr;
+    unsigned long long *cursor = nullptr;
+    int32_t *tcol = nullptr;
+    double *tval = nullptr;
+    int ts1 = plan->ts1, ts2 = plan->ts2;
+    int64_t capacity = (int64_t)(plan->mean_k * 1.05 * (double)plan->nrows) + plan->max_k + 1024;
+    rc = tg_dmalloc(&cnt, plan->nrows + 1) || tg_dmalloc(&off, plan->nrows + 1) || tg_dmalloc(&cursor, 1);
+    for (int attempt = 0; attempt < 8 && !rc; attempt++) {
+      rc = tg_dmalloc(&tcol, capacity + TG_CSR_PAD) || tg_dmalloc(&tval, capacity + TG_CSR_PAD);
+      if (rc) break;
+      P.ts1 = std::max(ts1, ts2);
+      P.ts2 = ts2;
+      hipMemsetAsync(status, 0, 3 * sizeof(int), g_tg.stream);
+      hipMemsetAsync(cursor, 0, sizeof(unsigned long long), g_tg.stream);
+      hipMemsetAsync(cnt, 0, (size_t)(plan->nrows + 1) * sizeof(int64_t), g_tg.stream);
+      const int nt = tg_ptap_threads(P.ts1, P.ts2, true);
+      const size_t lds = tg_ptap_lds_bytes(P.ts1, P.ts2, true, nt);
+      if (lds > 160 * 1024) {
+        tg_set_error("PtAP: K row too dense for the LDS tables (%d / %d slots)", P.ts1, P.ts2);
+        rc = 4;
+        break;
+      }
+      tg_ptap_launch<TG_MODE_BUMP>(nt, grid, lds, P, cnt, off, tcol, tval, cursor, capacity, mask, diag, status);
+      int h = 0;
+      unsigned long long used = 0;
+      hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
+      hipMemcpyAsync(&used, cursor, sizeof(used), hipMemcpyDeviceToHost, g_tg.stream);
+      if (hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        tg_set_error("PtAP numeric failed to run (LDS %zu B)", lds);
+        rc = 1;
+        break;
+      }
+      if ((rc = tg_status_error(h))) break;
+      if (h == TG_PTAP_OK) break;
+      // grow whatever overflowed and retry
+      tg_dfree(tcol);
+      tg_dfree(tval);
+      tcol = nullptr;
+      tval = nullptr;
+      if (h == TG_PTAP_CAP) capacity = std::max<int64_t>((int64_t)used + 1024, capacity * 2);
+      if (h == TG_PTAP_OVF1) ts1 *= 2;
+      if (h == TG_PTAP_OVF2) ts2 *= 2;
+      if (attempt == 7) {
+        tg_set_error("PtAP numeric: could not size tables / output (status %d)", h);
+        rc = 4;
+      }
+    }
+    if (!rc) {
+      int64_t nnz = 0;
+      rc = tg_exclusive_scan_i64(cnt, plan->nrows, &nnz);
+      if (!rc) rc = tg_csr_alloc(plan->nrows, plan->ncols, nnz, &k);
+      if (!rc) {
+        hipMemcpyAsync(k->rowptr, cnt, (size_t)(plan->nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice,
+                       g_tg.stream);
+        const unsigned rg = (unsigned)std::min<int64_t>(tg_cdiv(plan->nrows, 4), (int64_t)g_tg.num_cu * 16);
+        hipLaunchKernelGGL(k_ptap_reorder, dim3(rg), dim3(256), 0, g_tg.stream, k->rowptr, off, tcol, tval,
+                           plan->nrows, k->col, k->val);
+        if (hipGetLastError() != hipSuccess) {
+          tg_set_error("PtAP reorder launch failed");
+          rc = 1;
+        }
+        // remember the pattern for later calls with the same operands' structure
+        plan->rowptr = cnt;
+        cnt = nullptr;
+        plan->nnz = nnz;
+        plan->ts1 = std::max(ts1, ts2);
+        plan->ts2 = ts2;
+      }
+    }
+    hipStreamSynchronize(g_tg.stream);
+    tg_dfree(cnt);
+    tg_dfree(off);
+    tg_dfree(cursor);
+    tg_dfree(tcol);
+    tg_dfree(tval);
   }
   hipStreamSynchronize(g_tg.stream);
-  hipFree(mask);
+  tg_dfree(mask);
   if (rc) {
-    tg_csr_destroy(k);
+    if (k) tg_csr_destroy(k);
     return rc;
   }
   *k_out = k;
@@ -422,7 +641,7 @@ extern "C" int tg_ptap_numeric(tg_ptap_t plan, tg_csr_t a, tg_csr_t m, tg_csr_t 
 extern "C" int tg_ptap_destroy(tg_ptap_t plan) {
   if (!plan) return 0;
   if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
-  hipFree(plan->rowptr);
+  tg_dfree(plan->rowptr);
   delete plan;
   return 0;
 }

@@ -383,7 +383,7 @@ int tg_csr_transpose_block(tg_csr_s *m, int64_t row_base, int64_t out_ncols, tg_
     TG_LAUNCH_CHECK();
     int rc = tg_csr_sort_rows(t);
     hipStreamSynchronize(g_tg.stream);
-    hipFree(cursor);
+    tg_dfree(cursor);
     if (rc) {
       tg_csr_destroy(t);
       return rc;
@@ -439,7 +439,7 @@ int tg_build_dof_mask(const int32_t *dofs, int64_t n, int64_t ndofs_total, uint8
     hipLaunchKernelGGL(k_mark, dim3((unsigned)tg_cdiv(n, 256)), dim3(256), 0, g_tg.stream, mask, ndofs_total, d, n);
     TG_LAUNCH_CHECK();
     TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
-    hipFree(d);
+    tg_dfree(d);
   }
   *mask_out = mask;
   return 0;
@@ -456,6 +456,6 @@ extern "C" int tg_zero_rows_cols(tg_csr_t k, int64_t row0, const int32_t *dofs, 
                      mask, diag);
   TG_LAUNCH_CHECK();
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
-  hipFree(mask);
+  tg_dfree(mask);
   return 0;
 }

@@ -226,6 +226,20 @@ def extract_csr_tensor(splines1d, nodes1d, col_offset, ncols, eps, row0=None, ro
     return DeviceCSR(h)
 
 
+def extract_csr_tensor_t(splines1d, nodes1d, fe_row_offset, fe_rows_total, eps, dof0=None, dof1=None):
+    """M^T of ``extract_csr_tensor`` written directly (rows = spline dofs [dof0,dof1))."""
+    pack = _DirPack(splines1d, nodes1d)
+    ncp = 1
+    for s in splines1d:
+        ncp *= int(s.ncp)
+    dof0 = 0 if dof0 is None else int(dof0)
+    dof1 = ncp if dof1 is None else int(dof1)
+    h = handle()
+    check(_lib.lib().tg_extract_csr_tensor_t(len(splines1d), pack.arr, int(fe_row_offset), int(fe_rows_total),
+                                             float(eps), dof0, dof1, C.byref(h)), "tg_extract_csr_tensor_t")
+    return DeviceCSR(h)
+
+
 def extract_csr_points(splines1d, x, col_offset, ncols, eps):
     x = _f64(x)
     if x.ndim == 1:
