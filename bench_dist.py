@@ -1,0 +1,145 @@
+"""
+z-slab driver of bench.py: one process per GPU (RCCL over xGMI for the Krylov halo exchange and
+the dot-product all-reduces), and -- also on a single GPU -- streaming of workloads whose M and
+A do not fit in HBM through the device in sub-slabs (only K stays resident).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def _bootstrap_comm(rank, world):
+    """RCCL unique id from rank 0 to everybody over torch.distributed/gloo (plumbing only)."""
+    from tigar_amd import device as dev
+    if world == 1:
+        return None, None
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo")
+    box = [dev.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return dev.Comm(box[0], rank, world), dist
+
+
+def pick_sub_planes(d, p, nel, planes_mine, free_bytes):
+    """dof planes per sub-slab so that one slab of A, M, M^T and the PtAP temporaries use at most
+    ~35% of the free HBM (K itself and its stacked copy need the rest)."""
+    nfe1 = nel * p + 1
+    plane_fe = nfe1 ** (d - 1)
+    nnzA_plane = plane_fe * ((2 * p + 1) ** d) * 0.55 * 12.0 * 1.0     # bytes per FE plane, generous
+    nnzM_plane = plane_fe * ((p + 1) ** d) * 12.0
+    per_dof_plane = p * (nnzA_plane + 2.2 * nnzM_plane) + (nel + p) ** (d - 1) * ((2 * p + 1) ** d) * 12.0 * 2
+    fixed = (2 * p * p + 2) * (nnzA_plane + 2.2 * nnzM_plane)
+    budget = 0.35 * free_bytes - fixed
+    n = int(max(1, min(planes_mine, budget // per_dof_plane)))
+    return n
+
+
+def run_distributed(args, d, p, nel, rank, world):
+    from tigar_amd import device as dev
+    from tigar_amd.common import TensorFunctionSpace
+    from tigar_amd.BSplines import ExplicitBSplineControlMesh, uniformKnots
+    from tigar_amd.forms import LaplaceForm, SeparableLoadForm
+    from tigar_amd.dist import SlabHotPath
+
+    comm, dist = _bootstrap_comm(rank, world)
+    if rank == 0:
+        log("[bench] device:", dev.device_info(), "world", world)
+    kvecs = [uniformKnots(p, 0.0, 1.0, nel) for _ in range(d)]
+    controlMesh = ExplicitBSplineControlMesh([p] * d, kvecs)
+    basis = controlMesh.getScalarSpline()
+    grid = basis.generateMesh(degree=p)
+    V = TensorFunctionSpace([grid], "Lagrange")
+    lap = LaplaceForm()
+    f1 = lambda x: np.sin(np.pi * x)
+    load = SeparableLoadForm([f1] * d, scale=d * np.pi ** 2)
+    zero_dofs = []
+    for direction in range(d):
+        for side in (0, 1):
+            zero_dofs += basis.getSideDofs(direction, side)
+    zero_dofs = np.asarray(zero_dofs, dtype=np.int32)
+
+    free_b, total_b = dev.mem_info()
+    probe = SlabHotPath(basis, grid, rank, world, None)
+    planes_mine = probe.k1 - probe.k0
+    sub = args.sub_planes or pick_sub_planes(d, p, nel, planes_mine, free_b)
+    del probe
+    path = SlabHotPath(basis, grid, rank, world, comm, sub_planes=sub)
+    if rank == 0:
+        log("[bench] z-slabs: %d dof planes on rank 0 in sub-slabs of %d; free HBM %.0f GB"
+            % (planes_mine, sub, free_b / 2 ** 30))
+
+    def barrier():
+        dev.sync()
+        if dist is not None:
+            dist.barrier()
+
+    stages = {}
+    state = {}
+
+    def step(record):
+        timers = {}
+        K, rhs = path.assemble(lambda r0, r1: lap.assemble_matrix(V, r0, r1),
+                               lambda r0, r1: load.assemble_vector(V, r0, r1), zero_dofs, 1.0, timers)
+        t0 = time.perf_counter()
+        U, its, res, status = path.solve(K, rhs, "cg", "jacobi", rtol=args.rtol)
+        u = path.prolong(U)
+        dev.sync()
+        timers["solve"] = time.perf_counter() - t0
+        if status < 0:
+            raise RuntimeError("CG did not converge: status %d after %d iterations" % (status, its))
+        if record:
+            for k, v in timers.items():
+                stages.setdefault(k, []).append(v)
+        state.update(K=K, U=U, u=u, its=its)
+
+    for _ in range(args.warmup):
+        step(False)
+    dev.prof_reset()
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        state.clear()
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    K = state["K"]
+    nnzK_local = K.nnz
+    ncp_local = K.shape[0]
+    nnzK = nnzK_local
+    if comm is not None:
+        nnzK = int(round(comm.allreduce_sum([float(nnzK_local)])[0]))
+    spmv_ms, spmv_n = dev.prof_get(0)
+
+    if args.check and rank == 0:
+        # manufactured solution at the FE nodes this rank owns
+        r0, r1 = path.mine["u_rows"]
+        n0 = grid.shape()
+        uh = state["u"].get_local()
+        if uh.size <= 40e6:
+            idx = np.arange(r0, r1)
+            exact = np.ones(idx.size)
+            stride = 1
+            for k in range(d):
+                exact *= np.sin(np.pi * grid.axes[k][(idx // stride) % n0[k]])
+                stride *= n0[k]
+            log("[bench] max nodal error vs manufactured solution (rank 0 rows): %.3e" % np.max(np.abs(uh - exact)))
+    mean_stages = {k: float(np.mean(v)) for k, v in stages.items()}
+    if rank == 0:
+        log("[bench] stages (mean s):", {k: round(v, 5) for k, v in mean_stages.items()}, "CG iterations:",
+            state["its"], "nnz(K) global:", nnzK)
+    t_input = mean_stages.pop("input", 0.0)
+    return {"ncp": basis.getNcp(), "nnzK": nnzK, "nnzK_local": nnzK_local, "ncp_local": ncp_local,
+            "elapsed": elapsed, "spmv_ms_total": spmv_ms, "spmv_count": spmv_n, "iterations": state["its"],
+            "stages": mean_stages, "t_input": t_input, "t_input_in_timed_region": True, "sub_planes": sub}

@@ -50,10 +50,13 @@ int tg_vec_upload(tg_vec_t v, const double *host, int64_t n);
 int tg_vec_download(tg_vec_t v, double *host, int64_t n);
 int tg_vec_fill(tg_vec_t v, double a);
 int tg_vec_copy(tg_vec_t dst, tg_vec_t src);
+int tg_vec_copy_range(tg_vec_t dst, int64_t dst_off, tg_vec_t src, int64_t src_off, int64_t n);
 int tg_vec_axpy(tg_vec_t y, double a, tg_vec_t x);          /* y += a x */
 int tg_vec_dot(tg_vec_t x, tg_vec_t y, double *out);        /* deterministic two-stage */
 /* as_backend_type(MTb).vec().setValues(zeroDofs, 0)  -- tIGAr/common.py:1154-1158 */
 int tg_vec_zero_entries(tg_vec_t y, const int32_t *dofs, int64_t n);
+/* same for a slab-local vector holding global entries [g0, g0 + size(y)) */
+int tg_vec_zero_entries_offset(tg_vec_t y, const int32_t *dofs, int64_t n, int64_t g0);
 /* separable load b[(a,b,c)] = scale * b0[a]*b1[b]*b2[c] (synthetic input) */
 int tg_vec_tensor3(tg_vec_t out, int d, const double *const *b1d, const int64_t *n,
                    double scale, int64_t row0, int64_t row1);
@@ -115,6 +118,9 @@ int tg_eval_basis_1d(const tg_dir_t *dir, const double *u, int64_t n, int32_t *s
 /* y = A x   (prolongation u = M*U, tIGAr/common.py:1259; K*p inside the Krylov solve).
  * x must cover columns [col_base, col_base + size(x)). */
 int tg_spmv(tg_csr_t a, tg_vec_t x, tg_vec_t y);
+/* same with x covering only the columns [x_col0, x_col0 + size(x)) of a row block whose
+ * entries all fall in that range (z-slab pieces of M, M^T, K) */
+int tg_spmv_offset(tg_csr_t a, tg_vec_t x, int64_t x_col0, tg_vec_t y);
 /* Y = A X for k <= 4 right-hand sides (cpFuncs = M_control * P, tIGAr/common.py:367-380);
  * X, Y are column-major host arrays. */
 int tg_spmm_host(tg_csr_t a, const double *X, int k, double *Y);
@@ -163,6 +169,8 @@ int tg_comm_create(const char *id128, int rank, int world, tg_comm_t *out);
 int tg_comm_set_slab(tg_comm_t c, int64_t g0, int64_t g1, int64_t halo_lo, int64_t halo_hi,
                      int64_t nglobal);
 int tg_comm_allreduce_sum(tg_comm_t c, double *host_inout, int n);
+/* xext = [halo_lo | x_local | halo_hi] with the halos fetched from the z-neighbours */
+int tg_comm_halo_extend(tg_comm_t c, tg_vec_t x_local, tg_vec_t xext);
 int tg_comm_destroy(tg_comm_t c);
 
 #ifdef __cplusplus

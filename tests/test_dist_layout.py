@@ -1,0 +1,96 @@
+"""CPU tests of the z-slab layout arithmetic (tigar_amd/dist.py) against the oracle's
+matrices, and a world_size-2 gloo run of the distributed Krylov pattern (halo exchange +
+scalar all-reduce) with the oracle standing in for the kernels."""
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+from oracle import tigar_oracle as O
+from tigar_amd.dist import ZSlabLayout, split_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup(d, p, nel, drop=0):
+    kv = O.uniform_knots(p, 0., 1., nel, False, drop)
+    s = O.BSpline([p] * d, [kv] * d)
+    Mo = O.generate_M_tensor(s)
+    A, b, _, _ = O.poisson_fe_system(s, f1d=[lambda x: np.sin(np.pi * x)] * d)
+    nodes = O.fe_nodes_1d(s.splines[-1], p)
+    ncps = [q.getNcp() for q in s.splines]
+    nfe = [len(O.fe_nodes_1d(q, p)) for q in s.splines]
+    lay = ZSlabLayout(s.splines[-1].knots, p, nodes, p, int(np.prod(ncps[:-1])), int(np.prod(nfe[:-1])))
+    return s, Mo, A, b, lay
+
+
+def test_split_range():
+    assert split_range(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert split_range(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+
+
+@pytest.mark.parametrize("d,p,nel,world,drop", [(2, 2, 9, 3, 0), (2, 3, 7, 2, 0), (3, 2, 5, 2, 0), (2, 4, 6, 4, 0),
+                                                 (1, 3, 12, 5, 0), (2, 3, 6, 3, 1)])
+def test_slab_extents_cover_and_are_tight(d, p, nel, world, drop):
+    s, Mo, A, b, lay = _setup(d, p, nel, drop)
+    K = (Mo.T @ A @ Mo).tocsr()
+    MT = Mo.T.tocsr()
+    A = A.tocsr()
+    owned = np.zeros(Mo.shape[0], dtype=int)
+    for (k0, k1) in split_range(lay.ncp, world):
+        if k1 == k0:
+            continue
+        S = lay.slab(k0, k1)
+        g0, g1 = S["dofs"]
+        cols = MT[g0:g1].indices
+        a0, a1 = S["a_rows"]
+        assert cols.min() >= a0 and cols.max() < a1               # rows of A needed by the slab
+        assert cols.min() < a0 + lay.plane_fe * lay.q + lay.plane_fe and cols.max() >= a1 - lay.plane_fe * (lay.q + 1)
+        ac = A[a0:a1].indices
+        m0, m1 = S["m_rows"]
+        assert ac.min() >= m0 and ac.max() < m1                   # rows of M needed
+        assert ac.min() < m0 + lay.plane_fe and ac.max() >= m1 - lay.plane_fe     # tight to a plane
+        kc = K[g0:g1].indices
+        hl, hh = S["halo"]
+        assert kc.min() >= g0 - hl and kc.max() < g1 + hh         # Krylov halo
+        assert kc.min() < g0 - hl + lay.plane_dofs and kc.max() >= g1 + hh - lay.plane_dofs
+        u0, u1 = S["u_rows"]
+        owned[u0:u1] += 1
+        if u1 > u0:
+            mc = Mo[u0:u1].indices
+            assert mc.min() >= g0 and mc.max() < g1 + hh          # prolongation needs only the upper halo
+    assert np.all(owned == 1)                                       # FE rows partitioned exactly
+
+
+def test_local_ptap_blocks_reproduce_global_K():
+    """K rows of a slab computed from the three local row blocks == rows of the global K."""
+    import scipy.sparse as sp
+    s, Mo, A, b, lay = _setup(3, 2, 4)
+    Kg = (Mo.T @ A @ Mo).tocsr()
+    for (k0, k1) in split_range(lay.ncp, 3):
+        S = lay.slab(k0, k1)
+        g0, g1 = S["dofs"]
+        a0, a1 = S["a_rows"]
+        m0, m1 = S["m_rows"]
+        MTl = Mo.T.tocsr()[g0:g1][:, a0:a1]
+        Al = A.tocsr()[a0:a1][:, m0:m1]
+        Ml = Mo[m0:m1]
+        Kl = (MTl @ Al @ Ml).tocsr()
+        assert abs(Kl - Kg[g0:g1]).max() < 1e-13 * abs(Kg).max()
+        yl = MTl @ b[a0:a1]
+        assert np.max(np.abs(yl - (Mo.T @ b)[g0:g1])) < 1e-13 * np.max(np.abs(b))
+
+
+def test_gloo_world2_distributed_cg_pattern():
+    """Two CPU processes (gloo): slab-local K rows, halo exchange of the direction vector with
+    the z-neighbour, all-reduced dot products -- the communication pattern of tg_krylov_solve --
+    must reproduce the serial solution."""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29631",
+           os.path.join(ROOT, "tests", "dist_cpu_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "DIST_OK" in out.stdout

@@ -167,3 +167,58 @@ def test_bspline_host_api_matches_golden(T):
             assert np.array_equal(np.array([e[1] for e in ne]), ne_vals[r])
     with pytest.raises(ValueError):
         B.uniformKnots(2, 0., 1., 4, False, 2)
+
+
+def test_slab_streaming_path_matches_resident_path(T):
+    """SlabHotPath (z-slab streaming, the single-GPU form of the multi-GPU pipeline) reproduces
+    the resident single-block path: K rows, M^T b, solution and prolongation."""
+    from tigar_amd.dist import SlabHotPath
+    from tigar_amd.common import TensorFunctionSpace
+    B, F, dev = T.B, T.F, T.dev
+    d, p, nel = 3, 2, 7
+    kv = [B.uniformKnots(p, 0., 1., nel)] * d
+    basis = B.ExplicitBSplineControlMesh([p] * d, kv).getScalarSpline()
+    grid = basis.generateMesh(degree=p)
+    V = TensorFunctionSpace([grid], "Lagrange")
+    lap = F.LaplaceForm()
+    load = F.SeparableLoadForm([lambda x: np.sin(np.pi * x)] * d, scale=2.0)
+    zd = []
+    for direction in range(d):
+        for side in (0, 1):
+            zd += basis.getSideDofs(direction, side)
+    ref = SlabHotPath(basis, grid)                                   # one slab = resident path
+    K0, r0 = ref.assemble(lambda a, b: lap.assemble_matrix(V, a, b), lambda a, b: load.assemble_vector(V, a, b), zd)
+    K0s = K0.to_scipy()
+    s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel)] * d)
+    Mo = O.generate_M_tensor(s)
+    Ao, bo, _, _ = O.poisson_fe_system(s, f1d=[lambda x: np.sin(np.pi * x)] * d)
+    Ko = O.extract_matrix(Mo, Ao, zd)
+    assert abs(K0s - Ko).max() <= 1e-12 * abs(Ko).max()
+    for sub in (1, 2, 4):
+        path = SlabHotPath(basis, grid, sub_planes=sub)
+        assert len(path.sub_slabs()) == -(-basis.splines[-1].getNcp() // sub)
+        timers = {}
+        K, r = path.assemble(lambda a, b: lap.assemble_matrix(V, a, b), lambda a, b: load.assemble_vector(V, a, b),
+                             zd, 1.0, timers)
+        Ks = K.to_scipy()
+        assert np.array_equal(Ks.indptr, K0s.indptr) and np.array_equal(Ks.indices, K0s.indices)
+        assert abs(Ks - K0s).max() <= 1e-13 * abs(K0s).max()
+        assert np.max(np.abs(r.get_local() - r0.get_local())) <= 1e-13 * np.max(np.abs(r0.get_local()))
+        U, its, res, status = path.solve(K, r, rtol=1e-10)
+        assert status == 0
+        u = path.prolong(U).get_local()
+        Uo, uo = O.solve_linear_system(Mo, Ko, O.extract_vector(Mo, 2.0 * bo, zd), "direct")
+        assert np.linalg.norm(U.get_local() - Uo) <= 1e-7 * np.linalg.norm(Uo)
+        assert np.linalg.norm(u - uo) <= 1e-7 * np.linalg.norm(uo)
+        assert set(timers) >= {"extract", "input", "ptap", "mtb", "stack"}
+
+
+def test_rccl_world1_comm_roundtrip(T):
+    """RCCL communicator with one rank: slab descriptor, halo extend and all-reduce are
+    identities; the distributed Krylov entry point runs through the comm branch."""
+    dev = T.dev
+    comm = dev.Comm(dev.Comm.unique_id(), 0, 1)
+    comm.set_slab(0, 10, 0, 0, 10)
+    assert comm.allreduce_sum([1.5, 2.5]).tolist() == [1.5, 2.5]
+    x = dev.DeviceVector(data=np.arange(10.0))
+    assert np.array_equal(comm.halo_extend(x).get_local(), np.arange(10.0))

@@ -52,9 +52,11 @@ PROTOTYPES = {
     "tg_vec_download": (C.c_int, [handle, c_f64p, C.c_int64]),
     "tg_vec_fill": (C.c_int, [handle, C.c_double]),
     "tg_vec_copy": (C.c_int, [handle, handle]),
+    "tg_vec_copy_range": (C.c_int, [handle, C.c_int64, handle, C.c_int64, C.c_int64]),
     "tg_vec_axpy": (C.c_int, [handle, C.c_double, handle]),
     "tg_vec_dot": (C.c_int, [handle, handle, c_f64p]),
     "tg_vec_zero_entries": (C.c_int, [handle, c_i32p, C.c_int64]),
+    "tg_vec_zero_entries_offset": (C.c_int, [handle, c_i32p, C.c_int64, C.c_int64]),
     "tg_vec_tensor3": (C.c_int, [handle, C.c_int, C.POINTER(c_f64p), c_i64p, C.c_double,
                                  C.c_int64, C.c_int64]),
     "tg_csr_from_host": (C.c_int, [C.c_int64, C.c_int64, c_i64p, c_i32p, c_f64p, C.POINTER(handle)]),
@@ -73,6 +75,7 @@ PROTOTYPES = {
     "tg_csr_vstack": (C.c_int, [C.c_int, C.POINTER(handle), C.POINTER(handle)]),
     "tg_eval_basis_1d": (C.c_int, [C.POINTER(tg_dir_t), c_f64p, C.c_int64, c_i32p, c_i32p, c_f64p]),
     "tg_spmv": (C.c_int, [handle, handle, handle]),
+    "tg_spmv_offset": (C.c_int, [handle, handle, C.c_int64, handle]),
     "tg_spmm_host": (C.c_int, [handle, c_f64p, C.c_int, c_f64p]),
     "tg_spmv_t": (C.c_int, [handle, handle, handle]),
     "tg_ptap_symbolic": (C.c_int, [handle, C.c_int64, handle, C.c_int64, handle, C.c_int64,
@@ -90,6 +93,7 @@ PROTOTYPES = {
     "tg_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(handle)]),
     "tg_comm_set_slab": (C.c_int, [handle, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "tg_comm_allreduce_sum": (C.c_int, [handle, c_f64p, C.c_int]),
+    "tg_comm_halo_extend": (C.c_int, [handle, handle, handle]),
     "tg_comm_destroy": (C.c_int, [handle]),
 }
 

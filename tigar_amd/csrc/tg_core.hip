@@ -257,6 +257,16 @@ extern "C" int tg_vec_copy(tg_vec_t dst, tg_vec_t src) {
   return 0;
 }
 
+extern "C" int tg_vec_copy_range(tg_vec_t dst, int64_t dst_off, tg_vec_t src, int64_t src_off, int64_t n) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(dst && src && n >= 0 && dst_off >= 0 && src_off >= 0 && dst_off + n <= dst->n && src_off + n <= src->n,
+             "range error in tg_vec_copy_range");
+  if (n)
+    TG_CHECK_HIP(hipMemcpyAsync(dst->d + dst_off, src->d + src_off, (size_t)n * sizeof(double),
+                                hipMemcpyDeviceToDevice, g_tg.stream));
+  return 0;
+}
+
 __global__ void k_axpy(double *y, double a, const double *x, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -313,22 +323,26 @@ extern "C" int tg_vec_dot(tg_vec_t x, tg_vec_t y, double *out) {
   return 0;
 }
 
-__global__ void k_zero_entries(double *y, int64_t n, const int32_t *dofs, int64_t nd) {
+__global__ void k_zero_entries(double *y, int64_t n, const int32_t *dofs, int64_t nd, int64_t g0) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nd) {
-    int32_t d = dofs[i];
+    const int64_t d = (int64_t)dofs[i] - g0;
     if (d >= 0 && d < n) y[d] = 0.0;
   }
 }
 
 extern "C" int tg_vec_zero_entries(tg_vec_t y, const int32_t *dofs, int64_t n) {
+  return tg_vec_zero_entries_offset(y, dofs, n, 0);
+}
+
+extern "C" int tg_vec_zero_entries_offset(tg_vec_t y, const int32_t *dofs, int64_t n, int64_t g0) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(y, "null vector");
   if (n <= 0) return 0;
   int32_t *d = nullptr;
   TG_TRY(tg_dmalloc(&d, n));
   TG_CHECK_HIP(hipMemcpyAsync(d, dofs, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream));
-  hipLaunchKernelGGL(k_zero_entries, dim3((unsigned)tg_cdiv(n, 256)), dim3(256), 0, g_tg.stream, y->d, y->n, d, n);
+  hipLaunchKernelGGL(k_zero_entries, dim3((unsigned)tg_cdiv(n, 256)), dim3(256), 0, g_tg.stream, y->d, y->n, d, n, g0);
   TG_LAUNCH_CHECK();
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
   tg_dfree(d);

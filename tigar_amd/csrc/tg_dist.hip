@@ -115,3 +115,13 @@ int tg_comm_halo_exchange(tg_comm_s *c, double *xext) {
   TG_CHECK_NCCL(ncclGroupEnd());
   return 0;
 }
+
+extern "C" int tg_comm_halo_extend(tg_comm_t c, tg_vec_t x_local, tg_vec_t xext) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(c && x_local && xext && c->slab_set, "bad arguments to tg_comm_halo_extend");
+  const int64_t nloc = c->g1 - c->g0;
+  TG_REQUIRE(x_local->n == nloc && xext->n == c->halo_lo + nloc + c->halo_hi, "tg_comm_halo_extend: size mismatch");
+  TG_CHECK_HIP(hipMemcpyAsync(xext->d + c->halo_lo, x_local->d, (size_t)nloc * sizeof(double), hipMemcpyDeviceToDevice,
+                              g_tg.stream));
+  return tg_comm_halo_exchange(c, xext->d);
+}

@@ -221,6 +221,15 @@ extern "C" int tg_spmv(tg_csr_t a, tg_vec_t x, tg_vec_t y) {
   return tg_spmv_raw(a, x->d, y->d, nullptr, nullptr);
 }
 
+extern "C" int tg_spmv_offset(tg_csr_t a, tg_vec_t x, int64_t x_col0, tg_vec_t y) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(a && x && y, "null argument to tg_spmv_offset");
+  TG_REQUIRE(x_col0 >= 0 && x_col0 + x->n <= a->ncols, "tg_spmv_offset: x range outside the matrix columns");
+  TG_REQUIRE(y->n == a->nrows, "tg_spmv_offset: y has %lld entries, matrix has %lld rows", (long long)y->n,
+             (long long)a->nrows);
+  return tg_spmv_raw(a, x->d - x_col0, y->d, nullptr, nullptr);
+}
+
 extern "C" int tg_spmv_t(tg_csr_t mt, tg_vec_t b, tg_vec_t y) { return tg_spmv(mt, b, y); }
 
 extern "C" int tg_spmm_host(tg_csr_t a, const double *X, int k, double *Y) {

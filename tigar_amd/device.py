@@ -91,10 +91,11 @@ class DeviceVector(object):
     def norm(self, kind="l2"):
         return float(np.sqrt(self.inner(self)))
 
-    def zero_entries(self, dofs):
+    def zero_entries(self, dofs, g0=0):
+        """y[d - g0] = 0 for the global dofs d that fall into this (slab-local) vector"""
         dofs = _i32(dofs)
         if dofs.size:
-            check(_lib.lib().tg_vec_zero_entries(self._h, _p(dofs, c_i32p), dofs.size))
+            check(_lib.lib().tg_vec_zero_entries_offset(self._h, _p(dofs, c_i32p), dofs.size, int(g0)))
 
 
 class DeviceCSR(object):
@@ -159,6 +160,13 @@ class DeviceCSR(object):
         if y is None:
             y = DeviceVector(self.shape[0])
         check(_lib.lib().tg_spmv(self._h, x._h, y._h), "tg_spmv")
+        return y
+
+    def mult_offset(self, x, x_col0, y=None):
+        """y = A x where x holds only the columns [x_col0, x_col0+len(x)) (slab pieces)"""
+        if y is None:
+            y = DeviceVector(self.shape[0])
+        check(_lib.lib().tg_spmv_offset(self._h, x._h, int(x_col0), y._h), "tg_spmv_offset")
         return y
 
     def __mul__(self, x):
@@ -376,6 +384,20 @@ def vec_tensor3(b1d, scale=1.0, row0=None, row1=None):
     return out
 
 
+def vec_copy_range(dst, dst_off, src, src_off, n):
+    check(_lib.lib().tg_vec_copy_range(dst._h, int(dst_off), src._h, int(src_off), int(n)), "tg_vec_copy_range")
+
+
+def vec_concat(parts):
+    out = DeviceVector(sum(p.size() for p in parts))
+    off = 0
+    for p in parts:
+        n = p.size()
+        check(_lib.lib().tg_vec_copy_range(out._h, off, p._h, 0, n), "tg_vec_copy_range")
+        off += n
+    return out
+
+
 # ------------------------------------------------------------------------------- timers / info
 def timer_start(slot=0):
     check(_lib.lib().tg_timer_start(slot))
@@ -430,8 +452,15 @@ class Comm(object):
         return buf.raw
 
     def set_slab(self, g0, g1, halo_lo, halo_hi, nglobal):
+        self.g0, self.g1, self.halo_lo, self.halo_hi, self.nglobal = g0, g1, halo_lo, halo_hi, nglobal
         check(_lib.lib().tg_comm_set_slab(self._h, int(g0), int(g1), int(halo_lo), int(halo_hi), int(nglobal)),
               "tg_comm_set_slab")
+
+    def halo_extend(self, x_local, xext=None):
+        if xext is None:
+            xext = DeviceVector(self.halo_lo + x_local.size() + self.halo_hi)
+        check(_lib.lib().tg_comm_halo_extend(self._h, x_local._h, xext._h), "tg_comm_halo_extend")
+        return xext
 
     def allreduce_sum(self, values):
         v = _f64(np.atleast_1d(values)).copy()

@@ -1,0 +1,222 @@
+"""
+z-slab decomposition of the extraction hot path -- used both for
+multi-GPU runs (one process per GPU, slabs distributed over ranks, RCCL halo exchange +
+scalar all-reduces in the Krylov solve) and for streaming a problem whose M and A do not fit
+in HBM through one GPU slab by slab (only K is kept resident).
+
+The reference gets its row-block distribution from dolfin's mesh partition and PETSc's
+parallel MatPtAP / VecScatter (tIGAr/common.py:1194-1195, 1255-1261 [ext]).  Here IGA dof
+index = i + j*ncp_x + k*ncp_x*ncp_y (tIGAr/BSplines.py:357-358), so contiguous dof ranges
+are slabs of "planes" along the last parametric direction; everything a slab of K rows needs
+(rows of M^T, rows of A, rows of M) is local in that direction, and its extent follows from
+the 1-D knot vector alone.  ``ZSlabLayout`` is pure host arithmetic (CPU-testable).
+"""
+import numpy as np
+
+
+def split_range(n, parts):
+    """Balanced contiguous split of range(n): list of (start, stop), len == parts."""
+    base, extra = divmod(n, parts)
+    out, s = [], 0
+    for r in range(parts):
+        e = s + base + (1 if r < extra else 0)
+        out.append((s, e))
+        s = e
+    return out
+
+
+class ZSlabLayout(object):
+    """Index arithmetic of slabs along the LAST parametric direction of a tensor B-spline.
+
+    knots / p: the open knot vector and degree of that direction; fe_nodes: its 1-D FE node
+    coordinates (CG Lagrange degree ``q`` on the unique-knot mesh, vertex nodes on knots);
+    plane_dofs / plane_fe: number of spline dofs / FE nodes per plane (product over the other
+    directions)."""
+
+    def __init__(self, knots, p, fe_nodes, q, plane_dofs, plane_fe):
+        self.knots = np.asarray(knots, dtype=np.float64)
+        self.p, self.q = int(p), int(q)
+        self.nodes = np.asarray(fe_nodes, dtype=np.float64)
+        self.ncp = len(self.knots) - (self.p + 1)
+        if not (np.all(self.knots[:p + 1] == self.knots[0]) and np.all(self.knots[-(p + 1):] == self.knots[-1])):
+            raise ValueError("z-slab decomposition needs an open knot vector in the slab direction")
+        self.nfe = len(self.nodes)
+        self.nel = (self.nfe - 1) // self.q
+        if self.nel * self.q + 1 != self.nfe:
+            raise ValueError("FE nodes are not a CG degree-%d grid" % self.q)
+        self.plane_dofs, self.plane_fe = int(plane_dofs), int(plane_fe)
+        # support of basis k = [knots[k], knots[k+p+1]]: FE planes whose node lies inside it
+        lo = np.searchsorted(self.nodes, self.knots[:self.ncp], side="left")
+        hi = np.searchsorted(self.nodes, self.knots[p + 1:p + 1 + self.ncp], side="right")
+        self.sup_lo, self.sup_hi = lo, hi          # FE planes [lo, hi) of every dof plane
+        # first basis function that is non-zero on FE plane a: left-biased span - p
+        span = np.searchsorted(self.knots, self.nodes, side="left") - 1
+        span = np.clip(span, p, len(self.knots) - p - 2)
+        self.first_basis = span - p
+
+    # ---- extents ------------------------------------------------------------------------
+    def fe_planes_of_dofs(self, k0, k1):
+        """FE planes [za, zb) holding the rows of M^T rows k0..k1 (the support of the slab)."""
+        return int(self.sup_lo[k0:k1].min()), int(self.sup_hi[k0:k1].max())
+
+    def fe_planes_coupled(self, za, zb):
+        """FE planes [ca, cb) that rows za..zb of an FE matrix on the CG grid couple to
+        (all nodes of every element touching the range)."""
+        q = self.q
+        e_lo = (za - 1) // q if (za > 0 and za % q == 0) else za // q
+        zl = zb - 1
+        e_hi = min(self.nel - 1, zl // q)
+        return int(max(0, q * e_lo)), int(min(self.nfe, q * (e_hi + 1) + 1))
+
+    def dof_halo(self, k0, k1):
+        """(halo_lo, halo_hi) in planes: dof planes outside [k0,k1) that rows of K couple to
+        (supports sharing an element with a support of the slab)."""
+        U, p = self.knots, self.p
+        lo_knot, hi_knot = U[k0], U[k1 - 1 + p + 1]
+        ks = np.arange(self.ncp)
+        overl = (U[ks] < hi_knot) & (U[ks + p + 1] > lo_knot)
+        idx = np.flatnonzero(overl)
+        return int(k0 - idx.min()), int(idx.max() + 1 - k1)
+
+    def owned_fe_planes(self, k0, k1):
+        """FE planes whose prolongation rows u = M U are computed by the owner of dof planes
+        [k0,k1): plane a belongs to the owner of the first basis function non-zero on it, so
+        its columns lie in [k0, k1 + p)."""
+        a = np.flatnonzero((self.first_basis >= k0) & (self.first_basis < k1))
+        if a.size == 0:
+            return 0, 0
+        return int(a.min()), int(a.max() + 1)
+
+    # ---- row ranges (global indices) of everything a slab of K rows needs ------------------
+    def slab(self, k0, k1):
+        za, zb = self.fe_planes_of_dofs(k0, k1)
+        ca, cb = self.fe_planes_coupled(za, zb)
+        hl, hh = self.dof_halo(k0, k1)
+        oa, ob = self.owned_fe_planes(k0, k1)
+        return {
+            "dofs": (k0 * self.plane_dofs, k1 * self.plane_dofs),           # rows of M^T / K
+            "a_rows": (za * self.plane_fe, zb * self.plane_fe),              # rows of A
+            "m_rows": (ca * self.plane_fe, cb * self.plane_fe),              # rows of M
+            "halo": (hl * self.plane_dofs, hh * self.plane_dofs),            # Krylov vector halo (dofs)
+            "u_rows": (oa * self.plane_fe, ob * self.plane_fe),              # prolongation rows
+        }
+
+
+def layout_for(bspline, grid):
+    """ZSlabLayout of a tigar_amd BSpline scalar basis on its TensorNodeGrid."""
+    s = bspline.splines[-1]
+    shape = grid.shape()
+    plane_fe = int(np.prod(shape[:-1])) if len(shape) > 1 else 1
+    ncps = [sp.getNcp() for sp in bspline.splines]
+    plane_dofs = int(np.prod(ncps[:-1])) if len(ncps) > 1 else 1
+    return ZSlabLayout(s.knots, s.p, grid.axes[-1], grid.degree, plane_dofs, plane_fe)
+
+
+class SlabHotPath(object):
+    """The hot path of one rank, streamed through HBM in sub-slabs of dof planes:
+
+        for every sub-slab:  M^T rows, M rows  <- extraction kernels (row ranges)
+                             A rows            <- ``a_rows(row0, row1)`` (FE-side input)
+                             K rows            <- PtAP on the three row blocks
+                             (M^T b) rows      <- slab SpMV
+        K_loc = vstack(K rows);  Krylov solve with halo exchange;  u_loc = M_own * U
+
+    With world == 1 and one sub-slab this is exactly the single-GPU path."""
+
+    def __init__(self, basis, grid, rank=0, world=1, comm=None, sub_planes=None, eps=1e-15):
+        from . import device as dev
+        self.dev = dev
+        self.basis, self.grid = basis, grid
+        self.rank, self.world, self.comm = rank, world, comm
+        self.eps = eps
+        self.layout = layout_for(basis, grid)
+        self.k0, self.k1 = split_range(self.layout.ncp, world)[rank]
+        self.sub_planes = sub_planes or (self.k1 - self.k0)
+        self.mine = self.layout.slab(self.k0, self.k1)
+        self.ncp = basis.getNcp()
+        self.n_fe = grid.num_nodes()
+        if comm is not None and world > 1:
+            g0, g1 = self.mine["dofs"]
+            comm.set_slab(g0, g1, self.mine["halo"][0], self.mine["halo"][1], self.ncp)
+
+    def sub_slabs(self):
+        out, k = [], self.k0
+        while k < self.k1:
+            e = min(self.k1, k + self.sub_planes)
+            out.append((k, e))
+            k = e
+        return out
+
+    def assemble(self, a_rows, b_rows, zero_dofs, diag=1.0, timers=None):
+        """K_loc (rows of this rank, global columns, BCs applied) and rhs_loc = (M^T b)_loc.
+        ``a_rows(r0, r1)`` / ``b_rows(r0, r1)`` return the FE matrix rows (DeviceCSR, global
+        columns) / FE vector entries (DeviceVector) of global FE rows [r0, r1)."""
+        import time
+        dev = self.dev
+        sp1, axes = self.basis.splines, self.grid.axes
+        zero_dofs = np.asarray(zero_dofs, dtype=np.int32)
+        k_blocks, rhs_parts = [], []
+        t = timers if timers is not None else {}
+
+        def tick(name, t0):
+            dev.sync()
+            t[name] = t.get(name, 0.0) + time.perf_counter() - t0
+
+        for (ka, kb) in self.sub_slabs():
+            S = self.layout.slab(ka, kb)
+            t0 = time.perf_counter()
+            MT = dev.extract_csr_tensor_t(sp1, axes, 0, self.n_fe, self.eps, S["dofs"][0], S["dofs"][1])
+            M = dev.extract_csr_tensor(sp1, axes, 0, self.ncp, self.eps, S["m_rows"][0], S["m_rows"][1])
+            tick("extract", t0)
+            t0 = time.perf_counter()
+            A = a_rows(S["a_rows"][0], S["a_rows"][1])
+            b = b_rows(S["a_rows"][0], S["a_rows"][1])
+            tick("input", t0)
+            t0 = time.perf_counter()
+            plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], S["m_rows"][0], S["dofs"][0])
+            k_blocks.append(dev.ptap_numeric(plan, A, M, MT, zero_dofs, diag))
+            tick("ptap", t0)
+            t0 = time.perf_counter()
+            y = MT.mult_offset(b, S["a_rows"][0])
+            y.zero_entries(zero_dofs, S["dofs"][0])
+            rhs_parts.append(y)
+            tick("mtb", t0)
+            del A, M, MT, b, plan
+        t0 = time.perf_counter()
+        K = k_blocks[0] if len(k_blocks) == 1 else dev.csr_vstack(k_blocks)
+        if len(rhs_parts) == 1:
+            rhs = rhs_parts[0]
+        else:
+            rhs = dev.vec_concat(rhs_parts)
+        tick("stack", t0)
+        return K, rhs
+
+    def solve(self, K, rhs, method="cg", pc="jacobi", rtol=1e-6, atol=1e-15, maxit=10000, restart=30):
+        dev = self.dev
+        U = dev.DeviceVector(K.shape[0])
+        its, res, status = dev.krylov_solve(K, rhs, U, method, pc, rtol, atol, maxit, restart,
+                                            self.comm if self.world > 1 else None)
+        return U, its, res, status
+
+    def prolong(self, U, chunk_bytes=8e9):
+        """u rows owned by this rank: u = M_own * U (tIGAr/common.py:1259), U with its halo.
+        M_own is regenerated in row chunks of ~chunk_bytes so that it never has to be resident."""
+        dev = self.dev
+        r0, r1 = self.mine["u_rows"]
+        if self.world > 1:
+            x = self.comm.halo_extend(U)
+            x_col0 = self.mine["dofs"][0] - self.mine["halo"][0]
+        else:
+            x, x_col0 = U, 0
+        u = dev.DeviceVector(r1 - r0)
+        per_row = 12.0 * float(np.prod([s1.p + 1 for s1 in self.basis.splines])) + 8.0
+        step = int(max(1, chunk_bytes // per_row))
+        for a in range(r0, r1, step):
+            b = min(r1, a + step)
+            M_own = dev.extract_csr_tensor(self.basis.splines, self.grid.axes, 0, self.ncp, self.eps, a, b)
+            if a == r0 and b == r1:
+                return M_own.mult_offset(x, x_col0, u)
+            y = M_own.mult_offset(x, x_col0)
+            dev.vec_copy_range(u, a - r0, y, 0, b - a)
+            del M_own, y
+        return u
