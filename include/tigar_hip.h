@@ -161,6 +161,15 @@ typedef struct {
 int tg_kron_sum_csr(int d, int nterms, const tg_kron_dir_t *dirs, int64_t row0,
                     int64_t row1, tg_csr_t *out);
 
+/* General Kronecker-product CSR builder on the device: out = sum_t (x)_k F[t][k] restricted to rows
+ * [row0,row1), with rectangular 1-D factors (cdim[k] = number of columns of direction k; NULL =
+ * square), optional |v| > eps filter (single term), a column offset and a total column count
+ * (-1 = prod cdim).  Used for the directional extraction operators I(x)I(x)M_x ... of the
+ * sum-factorised M^T A M and for their transposes. */
+int tg_kron_csr_rect(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0,
+                     int64_t row1, int filter, double eps, int64_t col_offset, int64_t ncols_total,
+                     tg_csr_t *out);
+
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------- */
 int tg_comm_unique_id(char *id128);                          /* ncclGetUniqueId   */
 int tg_comm_create(const char *id128, int rank, int world, tg_comm_t *out);

@@ -222,3 +222,45 @@ def test_rccl_world1_comm_roundtrip(T):
     assert comm.allreduce_sum([1.5, 2.5]).tolist() == [1.5, 2.5]
     x = dev.DeviceVector(data=np.arange(10.0))
     assert np.array_equal(comm.halo_extend(x).get_local(), np.arange(10.0))
+
+
+@pytest.mark.parametrize("d,p,nel", [(2, 2, 9), (2, 4, 5), (3, 2, 5), (3, 3, 4)])
+def test_sum_factorised_ptap_equals_direct(T, d, p, nel):
+    """K from the three directional PtAP stages == K from the one-shot PtAP == oracle, for an
+    arbitrary (non-symmetric, perturbed) FE matrix; also slab by slab."""
+    from tigar_amd.kronptap import KronExtraction, ptap_factored
+    from tigar_amd.dist import SlabHotPath
+    from tigar_amd.common import TensorFunctionSpace
+    B, F, dev = T.B, T.F, T.dev
+    kv = [B.uniformKnots(p, 0., 1., nel)] * d
+    basis = B.ExplicitBSplineControlMesh([p] * d, kv).getScalarSpline()
+    grid = basis.generateMesh(degree=p)
+    s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel)] * d)
+    Mo = O.generate_M_tensor(s)
+    Ao, bo, _, _ = O.poisson_fe_system(s, f1d=[lambda x: np.cos(x)] * d)
+    rng = np.random.default_rng(7)
+    Ao = Ao.tocsr().copy()
+    Ao.data = Ao.data * (1.0 + 0.3 * rng.standard_normal(Ao.nnz))        # destroys symmetry / tensor form
+    kx = KronExtraction(basis, grid)
+    assert kx.is_exact_for(Mo.nnz, 1e-15)
+    zd = basis.getSideDofs(0, 0) + basis.getSideDofs(d - 1, 1)
+    nz = grid.shape()[-1]
+    ncpz = basis.splines[-1].getNcp()
+    Ko = O.extract_matrix(Mo, Ao, zd, diag=2.0)
+    group_sets = [None] + ([[[0, 1], [2]], [[0], [1, 2]]] if d == 3 else [])
+    for groups in group_sets:
+        K = ptap_factored(kx, dev.DeviceCSR.from_scipy(Ao), (0, nz), (0, nz), (0, ncpz), zd, 2.0, groups).to_scipy()
+        assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices)
+        assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+    # slab-streamed, factored vs direct
+    V = TensorFunctionSpace([grid], "Lagrange")
+    Ad = dev.DeviceCSR.from_scipy(Ao)
+    def a_rows(r0, r1):
+        return dev.DeviceCSR.from_scipy(Ao[r0:r1])
+    def b_rows(r0, r1):
+        return dev.DeviceVector(data=bo[r0:r1])
+    for fac in (True, False):
+        path = SlabHotPath(basis, grid, sub_planes=2, factored=fac)
+        Ks, rs = path.assemble(a_rows, b_rows, zd, 2.0)
+        assert abs(Ks.to_scipy() - Ko).max() <= 1e-12 * abs(Ko).max()
+        assert np.max(np.abs(rs.get_local() - O.extract_vector(Mo, bo, zd))) <= 1e-12 * np.max(np.abs(bo))

@@ -89,6 +89,8 @@ PROTOTYPES = {
                                   C.POINTER(C.c_int)]),
     "tg_kron_sum_csr": (C.c_int, [C.c_int, C.c_int, C.POINTER(tg_kron_dir_t), C.c_int64, C.c_int64,
                                   C.POINTER(handle)]),
+    "tg_kron_csr_rect": (C.c_int, [C.c_int, C.c_int, C.POINTER(tg_kron_dir_t), c_i64p, C.c_int64, C.c_int64,
+                                   C.c_int, C.c_double, C.c_int64, C.c_int64, C.POINTER(handle)]),
     "tg_comm_unique_id": (C.c_int, [C.c_char_p]),
     "tg_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(handle)]),
     "tg_comm_set_slab": (C.c_int, [handle, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),

@@ -271,6 +271,16 @@ class AbstractExtractionGenerator(object):
         self.M = self.generateM()
         self.MT = self.generateMT()
         self.M._T = self.MT           # M.mult_transpose() goes through the explicit transpose
+        # Kronecker form of M (single tensor B-spline field, filter dropped only exact zeros):
+        # enables the sum-factorised M^T A M of tigar_amd/kronptap.py
+        self._kron = None
+        if self.getNFields() == 1 and (0, 0) in self._fast_blocks or (self.M is self.M_control
+                                                                        and (-1, 0) in self._fast_blocks):
+            from .kronptap import KronExtraction
+            basis, grid = self._fast_blocks.get((0, 0), self._fast_blocks.get((-1, 0)))
+            kx = KronExtraction(basis, grid)
+            if kx.is_exact_for(self.M.nnz, self.getIgnoreEps()):
+                self._kron = kx
         self.cpFuncs = []
         cm = self.getControlMesh() if hasattr(self, "getControlMesh") else None
         P = None
@@ -610,6 +620,7 @@ class ExtractedSpline(object):
         self.M = generator.M
         self.M_control = generator.M_control
         self.comm = generator.getComm()
+        self._kron = getattr(generator, "_kron", None)
         self.zeroDofs = numpy.asarray(generator.zeroDofs, dtype=INDEX_TYPE)
 
     def genericSetup(self):
@@ -639,6 +650,13 @@ class ExtractedSpline(object):
         of ``zeroDofs`` zeroed with ``diag`` on the diagonal (tIGAr/common.py:1176-1204).
         The symbolic plan is cached and reused while A's pattern is unchanged."""
         A = _as_device_csr(A)
+        zd = self.zeroDofs if applyBCs else None
+        if self._kron is not None:
+            from .kronptap import default_groups, ptap_factored
+            kx = self._kron
+            groups = default_groups(kx.d, max(s1.p for s1 in kx.basis.splines))
+            if len(groups) > 1:
+                return ptap_factored(kx, A, (0, kx.nfe[-1]), (0, kx.nfe[-1]), (0, kx.ncp[-1]), zd, float(diag), groups)
         key = (A.shape, A.nnz)
         if self._ptap_plan is None or self._ptap_plan_key != key:
             self._ptap_plan = _dev.ptap_symbolic(A, self.M, self.MT)

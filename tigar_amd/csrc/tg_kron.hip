@@ -137,6 +137,12 @@ extern "C" int tg_kron_sum_csr(int d, int nterms, const tg_kron_dir_t *dirs, int
 int tg_kron_build_rect(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0, int64_t row1,
                        int filter, double eps, int64_t col_offset, int64_t ncols_total, tg_csr_t *out);
 
+extern "C" int tg_kron_csr_rect(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0,
+                                int64_t row1, int filter, double eps, int64_t col_offset, int64_t ncols_total,
+                                tg_csr_t *out) {
+  return tg_kron_build_rect(d, nterms, dirs, cdim, row0, row1, filter, eps, col_offset, ncols_total, out);
+}
+
 int tg_kron_build(int d, int nterms, const tg_kron_dir_t *dirs, int64_t row0, int64_t row1, int filter, double eps,
                   int64_t col_offset, int64_t ncols_total, tg_csr_t *out) {
   return tg_kron_build_rect(d, nterms, dirs, nullptr, row0, row1, filter, eps, col_offset, ncols_total, out);

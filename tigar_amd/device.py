@@ -371,6 +371,34 @@ def kron_sum_csr(factors, row0=None, row1=None):
     return DeviceCSR(h)
 
 
+def kron_csr_rect(factors, row0=None, row1=None):
+    """kron(F[d-1], ..., F[0]) (direction 0 fastest) of rectangular scipy CSR 1-D factors, rows
+    [row0,row1); explicit zeros of the factors are kept."""
+    import scipy.sparse as sp
+    d = len(factors)
+    arr = (tg_kron_dir_t * d)()
+    keep = []
+    total = 1
+    cdim = np.empty(d, dtype=np.int64)
+    for k in range(d):
+        F = sp.csr_matrix(factors[k])
+        F.sort_indices()
+        rp, cl, vl = _i32(F.indptr), _i32(F.indices), _f64(F.data)
+        keep += [rp, cl, vl]
+        arr[k].n = F.shape[0]
+        arr[k].rowptr = _p(rp, c_i32p)
+        arr[k].col = _p(cl, c_i32p)
+        arr[k].val = _p(vl, c_f64p)
+        total *= F.shape[0]
+        cdim[k] = F.shape[1]
+    row0 = 0 if row0 is None else int(row0)
+    row1 = total if row1 is None else int(row1)
+    h = handle()
+    check(_lib.lib().tg_kron_csr_rect(d, 1, arr, _p(cdim, c_i64p), row0, row1, 0, 0.0, 0, -1, C.byref(h)),
+          "tg_kron_csr_rect")
+    return DeviceCSR(h)
+
+
 def vec_tensor3(b1d, scale=1.0, row0=None, row1=None):
     d = len(b1d)
     bs = [_f64(b) for b in b1d]

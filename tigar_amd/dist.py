@@ -123,9 +123,23 @@ class SlabHotPath(object):
 
     With world == 1 and one sub-slab this is exactly the single-GPU path."""
 
-    def __init__(self, basis, grid, rank=0, world=1, comm=None, sub_planes=None, eps=1e-15):
+    def __init__(self, basis, grid, rank=0, world=1, comm=None, sub_planes=None, eps=1e-15, factored=None):
         from . import device as dev
+        from .kronptap import KronExtraction
         self.dev = dev
+        self.kx = KronExtraction(basis, grid)
+        # sum-factorised PtAP when M is exactly a Kronecker product (checked against the
+        # closed-form nnz of M on the tensor grid); TIGAR_PTAP_FACTORED=0/1 overrides
+        import os
+        env = os.environ.get("TIGAR_PTAP_FACTORED")
+        from .kronptap import default_groups
+        self.groups = default_groups(basis.nvar, max(s1.p for s1 in basis.splines))
+        if env is not None and env not in ("0", "1"):           # e.g. TIGAR_PTAP_FACTORED=0,1;2 or 0;1;2
+            self.groups = [[int(c) for c in g.split(",")] for g in env.split(";")]
+        if factored is True and len(self.groups) == 1:
+            self.groups = [[k] for k in range(basis.nvar)]
+        self.factored = (factored if factored is not None else (env != "0" if env is not None else True)) \
+            and len(self.groups) > 1
         self.basis, self.grid = basis, grid
         self.rank, self.world, self.comm = rank, world, comm
         self.eps = eps
@@ -156,6 +170,7 @@ class SlabHotPath(object):
         sp1, axes = self.basis.splines, self.grid.axes
         zero_dofs = np.asarray(zero_dofs, dtype=np.int32)
         k_blocks, rhs_parts = [], []
+        ring = {"hi": 0, "pieces": []}      # plane-local stage results kept across sub-slabs
         t = timers if timers is not None else {}
 
         def tick(name, t0):
@@ -166,15 +181,36 @@ class SlabHotPath(object):
             S = self.layout.slab(ka, kb)
             t0 = time.perf_counter()
             MT = dev.extract_csr_tensor_t(sp1, axes, 0, self.n_fe, self.eps, S["dofs"][0], S["dofs"][1])
-            M = dev.extract_csr_tensor(sp1, axes, 0, self.ncp, self.eps, S["m_rows"][0], S["m_rows"][1])
+            use_factored = self.factored
+            if use_factored:
+                # exactness check of the Kronecker form on this slab: nnz(M^T rows) must equal the
+                # product of the 1-D counts restricted to the slab's dof planes
+                lz = self.kx.M1[-1].T.tocsr()
+                nz_last = int(lz.indptr[kb] - lz.indptr[ka])
+                expect = nz_last * int(np.prod([m.nnz for m in self.kx.M1[:-1]], dtype=np.float64))
+                use_factored = (MT.nnz == expect) and not any(np.any(np.abs(m.data) <= self.eps) for m in self.kx.M1)
+            M = None
+            if not use_factored:
+                M = dev.extract_csr_tensor(sp1, axes, 0, self.ncp, self.eps, S["m_rows"][0], S["m_rows"][1])
             tick("extract", t0)
             t0 = time.perf_counter()
-            A = a_rows(S["a_rows"][0], S["a_rows"][1])
+            pf = self.layout.plane_fe
+            if use_factored:
+                za, zb = S["a_rows"][0] // pf, S["a_rows"][1] // pf
+                new_lo = max(za, ring["hi"])               # FE planes not yet contracted
+                A = a_rows(new_lo * pf, zb * pf) if zb > new_lo else None
+                ring["new"] = (new_lo, zb)
+            else:
+                A = a_rows(S["a_rows"][0], S["a_rows"][1])
             b = b_rows(S["a_rows"][0], S["a_rows"][1])
             tick("input", t0)
             t0 = time.perf_counter()
-            plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], S["m_rows"][0], S["dofs"][0])
-            k_blocks.append(dev.ptap_numeric(plan, A, M, MT, zero_dofs, diag))
+            if use_factored:
+                k_blocks.append(self._factored_slab(A, S, ka, kb, zero_dofs, diag, ring))
+                plan = None
+            else:
+                plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], S["m_rows"][0], S["dofs"][0])
+                k_blocks.append(dev.ptap_numeric(plan, A, M, MT, zero_dofs, diag))
             tick("ptap", t0)
             t0 = time.perf_counter()
             y = MT.mult_offset(b, S["a_rows"][0])
@@ -190,6 +226,34 @@ class SlabHotPath(object):
             rhs = dev.vec_concat(rhs_parts)
         tick("stack", t0)
         return K, rhs
+
+    def _factored_slab(self, A_new, S, ka, kb, zero_dofs, diag, ring):
+        """Sum-factorised K rows of dof planes [ka,kb).  The plane-local stages (all direction
+        groups but the last) are applied once per FE plane: their results are kept in ``ring``
+        and shared by neighbouring sub-slabs (their supports overlap by ~p*p planes)."""
+        from .kronptap import contract
+        dev, kx, lay = self.dev, self.kx, self.layout
+        pf = lay.plane_fe
+        za, zb = S["a_rows"][0] // pf, S["a_rows"][1] // pf
+        new_lo, new_hi = ring["new"]
+        if A_new is not None:
+            cur, done = A_new, set()
+            ca, cb = lay.fe_planes_coupled(new_lo, new_hi)
+            for group in self.groups[:-1]:
+                after = done | set(group)
+                pl_out = kx.plane(after)
+                cur = contract(kx, cur, done, group, (new_lo, new_hi), (ca, cb), (new_lo * pl_out, new_hi * pl_out))
+                done = after
+            ring["pieces"].append((new_lo, new_hi, cur))
+            ring["hi"] = new_hi
+        ring["pieces"] = [pc for pc in ring["pieces"] if pc[1] > za]     # drop planes below the slab
+        lo = ring["pieces"][0][0]
+        blocks = [pc[2] for pc in ring["pieces"]]
+        cur = blocks[0] if len(blocks) == 1 else dev.csr_vstack(blocks)
+        done = set(sum(self.groups[:-1], []))
+        ca, cb = lay.fe_planes_coupled(lo, zb)
+        pl_out = kx.plane(done | set(self.groups[-1]))
+        return contract(kx, cur, done, self.groups[-1], (lo, zb), (ca, cb), (ka * pl_out, kb * pl_out), zero_dofs, diag)
 
     def solve(self, K, rhs, method="cg", pc="jacobi", rtol=1e-6, atol=1e-15, maxit=10000, restart=30):
         dev = self.dev

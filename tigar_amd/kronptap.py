@@ -1,0 +1,118 @@
+"""
+Sum-factorised M^T A M for extraction operators that are Kronecker products.
+
+For a tensor-product B-spline the extraction matrix produced by ``generateM`` is
+M = M_z (x) M_y (x) M_x (direction 0 fastest) whenever the ``abs(v) > eps`` filter of
+tIGAr/common.py:1569 removed nothing but exact zeros -- which is checked, not assumed.  Then
+
+    M = P_x P_y P_z,   P_x = I (x) I (x) M_x,  P_y = I (x) M_y (x) I,  P_z = M_z (x) I (x) I
+
+and K = M^T A M = P_z^T ( P_y^T ( P_x^T A P_x ) P_y ) P_z : three general PtAP calls (the same
+``k_ptap`` kernel, arbitrary FE matrix A) whose operators have <= p+1 entries per row instead
+of (p+1)^d.  Hash-accumulate work drops from sum_i |supp_i| * nnz(A_r) * ... to roughly
+(p+1) * nnz per stage -- 5.4x fewer LDS accumulations at 3-D p=3, 1.8x at p=2.  A is never assumed
+to have any structure.  Values agree with the one-shot product to rounding (entries of M are
+(Nu*Nv)*Nw either way); patterns are identical.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+from . import device as _dev
+
+
+class KronExtraction(object):
+    """1-D extraction matrices M_k (FE nodes x spline functions) of a tensor BSpline on its node
+    grid, taken from the device evaluation tables, plus the directional operators."""
+
+    def __init__(self, basis, grid):
+        self.basis, self.grid = basis, grid
+        self.d = basis.nvar
+        self.M1 = []
+        for k in range(self.d):
+            s = basis.splines[k]
+            _, idx, val = s.evalBatch(grid.axes[k])
+            n = len(grid.axes[k])
+            rows = np.repeat(np.arange(n), s.p + 1)
+            nz = val.ravel() != 0.0                      # exact zeros cannot pass the product filter
+            M1 = sp.coo_matrix((val.ravel()[nz], (rows[nz], idx.ravel()[nz])), shape=(n, s.getNcp())).tocsr()
+            M1.sort_indices()
+            self.M1.append(M1)
+        self.nfe = [m.shape[0] for m in self.M1]
+        self.ncp = [m.shape[1] for m in self.M1]
+        self.nnz_product = int(np.prod([m.nnz for m in self.M1], dtype=np.float64))
+
+    def is_exact_for(self, M_nnz, eps):
+        """True if generateM's filter dropped only exact zeros, i.e. M == kron(M_k) entrywise."""
+        small = any(np.any(np.abs(m.data) <= eps) for m in self.M1)
+        return (not small) and int(M_nnz) == self.nnz_product
+
+    # ---- index spaces: directions in `done` are spline-sized, the others FE-sized ---------------
+    def dims(self, done):
+        return [self.ncp[k] if k in done else self.nfe[k] for k in range(self.d)]
+
+    def plane(self, done):
+        """entries per plane of the last direction in the space where `done` is contracted"""
+        dm = self.dims(done)
+        return int(np.prod(dm[:-1])) if self.d > 1 else 1
+
+    def _factors(self, done, group, transpose):
+        """Operator contracting the directions in `group` (M_k there, identities elsewhere) acting
+        on the space where `done` is already contracted."""
+        dm = self.dims(done)
+        fac = []
+        for k in range(self.d):
+            if k in group:
+                fac.append(self.M1[k].T.tocsr() if transpose else self.M1[k])
+            else:
+                fac.append(sp.identity(dm[k], format="csr"))
+        return fac
+
+    def P(self, done, group, row0=None, row1=None):
+        return _dev.kron_csr_rect(self._factors(done, group, False), row0, row1)
+
+    def PT(self, done, group, row0=None, row1=None):
+        return _dev.kron_csr_rect(self._factors(done, group, True), row0, row1)
+
+
+def default_groups(d, p):
+    """Which directions to contract together.  One-shot ([[0..d-1]]) is the plain PtAP; splitting
+    cuts the hash-accumulate work but makes rows thinner (more per-row overhead), so it only pays
+    for 3-D, p >= 3: contract (x,y) together, then z."""
+    if d == 3 and p >= 3:
+        return [[0, 1], [2]]
+    return [list(range(d))]
+
+
+def contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs=None, diag=1.0):
+    """One contraction stage: rows ``out_rows`` (global row range in the space after the stage)
+    of  P^T cur P,  where ``cur`` holds the planes ``a_planes`` of the current space (global
+    columns within the planes ``c_planes``) and P contracts the directions in ``group``."""
+    pl_in = kx.plane(done)
+    MT = kx.PT(done, group, out_rows[0], out_rows[1])
+    Pm = kx.P(done, group, c_planes[0] * pl_in, c_planes[1] * pl_in)
+    plan = _dev.ptap_symbolic(cur, Pm, MT, a_planes[0] * pl_in, c_planes[0] * pl_in, out_rows[0])
+    return _dev.ptap_numeric(plan, cur, Pm, MT, zero_dofs, diag)
+
+
+def ptap_factored(kx, A, a_planes, c_planes, k_planes, zero_dofs=None, diag=1.0, groups=None):
+    """K rows of the dof planes ``k_planes`` from the FE rows ``A`` (DeviceCSR holding the FE
+    planes ``a_planes`` = [za,zb) of the last direction, global columns reaching the planes
+    ``c_planes`` = [ca,cb)), by contracting the direction groups one after the other.  Planes
+    refer to the LAST direction, which must be in the last group; for a resident single block pass
+    the full ranges."""
+    d = kx.d
+    if groups is None:
+        groups = [[k] for k in range(d)]
+    assert sorted(sum(groups, [])) == list(range(d)) and (d - 1) in groups[-1]
+    za, zb = a_planes
+    k0, k1 = k_planes
+    cur = A
+    done = set()
+    for gi, group in enumerate(groups):
+        last = (gi == len(groups) - 1)
+        after = done | set(group)
+        pl_out = kx.plane(after)
+        out_rows = (k0 * pl_out, k1 * pl_out) if last else (za * pl_out, zb * pl_out)
+        cur = contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs if last else None, diag)
+        done = after
+    return cur
