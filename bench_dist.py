@@ -89,9 +89,12 @@ def run_distributed(args, d, p, nel, rank, world):
                                lambda r0, r1: load.assemble_vector(V, r0, r1), zero_dofs, 1.0, timers)
         t0 = time.perf_counter()
         U, its, res, status = path.solve(K, rhs, "cg", "jacobi", rtol=args.rtol)
-        u = path.prolong(U)
         dev.sync()
         timers["solve"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        u = path.prolong(U)
+        dev.sync()
+        timers["prolong"] = time.perf_counter() - t0
         if status < 0:
             raise RuntimeError("CG did not converge: status %d after %d iterations" % (status, its))
         if record:

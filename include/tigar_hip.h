@@ -104,6 +104,10 @@ int tg_extract_csr_tensor(int d, const tg_dir_t *dirs, int32_t col_offset, int64
  * tg_extract_csr_tensor's result. */
 int tg_extract_csr_tensor_t(int d, const tg_dir_t *dirs, int64_t fe_row_offset, int64_t fe_rows_total,
                             double eps, int64_t dof0, int64_t dof1, tg_csr_t *out);
+/* Matrix-free y = M x for the same operator (rows [row0,row1), x holding the columns
+ * [x_col0, x_col0+size(x))): prolongation u = M*U (tIGAr/common.py:1259) without M in memory. */
+int tg_extract_apply_tensor(int d, const tg_dir_t *dirs, int32_t col_offset, double eps, int64_t row0,
+                            int64_t row1, tg_vec_t x, int64_t x_col0, tg_vec_t y);
 /* Same with explicit node coordinates x[nrows*d] (dolfin-supplied / DG nodes). */
 int tg_extract_csr_points(int d, const tg_dir_t *dirs, int32_t col_offset, int64_t ncols,
                           double eps, const double *x, int64_t nrows, tg_csr_t *out);

@@ -333,3 +333,23 @@ def test_transposed_extraction_equals_transpose(dev):
     part = dev.extract_csr_tensor_t(s.splines, axes, 7, n_fe + 20, 1e-15, 50, 181).to_scipy()
     assert abs(part - full[50:181]).max() == 0 and part.shape == (131, n_fe + 20)
     assert full.indices.min() >= 7
+
+
+def test_matrix_free_prolongation_equals_spmv(dev):
+    g = _golden()
+    rng = np.random.default_rng(11)
+    for name in ("2d_p2_n4", "3d_p2_n4", "3d_p3_n2", "2d_nonuni", "2d_periodic", "1d_p4_n4", "3d_p4_n2"):
+        s, pre = _case(g, name)
+        axes = [O.fe_nodes_1d(sp1, s.getDegree()) for sp1 in s.splines]
+        n_fe = int(np.prod([len(a) for a in axes]))
+        M = sp.csr_matrix((g[pre + "M_val"], g[pre + "M_col"], g[pre + "M_rowptr"]), shape=(n_fe, s.getNcp()))
+        x = rng.standard_normal(s.getNcp())
+        y = dev.extract_apply_tensor(s.splines, axes, 0, 1e-15, dev.DeviceVector(data=x)).get_local()
+        ref = M @ x
+        assert np.max(np.abs(y - ref)) <= 1e-14 * np.max(np.abs(M) @ np.abs(x))
+        # row range + shifted x window
+        r0, r1 = n_fe // 3, n_fe - 1
+        cols = M[r0:r1].indices
+        c0, c1 = cols.min(), cols.max() + 1
+        yp = dev.extract_apply_tensor(s.splines, axes, 0, 1e-15, dev.DeviceVector(data=x[c0:c1]), c0, r0, r1).get_local()
+        assert np.max(np.abs(yp - ref[r0:r1])) <= 1e-14 * np.max(np.abs(M) @ np.abs(x))

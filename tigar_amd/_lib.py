@@ -70,6 +70,8 @@ PROTOTYPES = {
                                         C.c_double, C.c_int64, C.c_int64, C.POINTER(handle)]),
     "tg_extract_csr_tensor_t": (C.c_int, [C.c_int, C.POINTER(tg_dir_t), C.c_int64, C.c_int64, C.c_double,
                                           C.c_int64, C.c_int64, C.POINTER(handle)]),
+    "tg_extract_apply_tensor": (C.c_int, [C.c_int, C.POINTER(tg_dir_t), C.c_int32, C.c_double, C.c_int64,
+                                          C.c_int64, handle, C.c_int64, handle]),
     "tg_extract_csr_points": (C.c_int, [C.c_int, C.POINTER(tg_dir_t), C.c_int32, C.c_int64,
                                         C.c_double, c_f64p, C.c_int64, C.POINTER(handle)]),
     "tg_csr_vstack": (C.c_int, [C.c_int, C.POINTER(handle), C.POINTER(handle)]),

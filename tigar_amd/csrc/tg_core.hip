@@ -119,6 +119,7 @@ extern "C" int tg_timer_stop(int slot, double *ms) {
 // K, temporaries) afresh on every call, so freed blocks are kept in a size-keyed pool and
 // handed out again.  All work runs on one stream, so reuse is stream-ordered and needs no sync.
 #include <map>
+#include <chrono>
 #include <unordered_map>
 static std::multimap<size_t, void *> g_pool_free;
 static std::unordered_map<void *, size_t> g_pool_size;
@@ -155,11 +156,19 @@ int tg_dmalloc_bytes(void **p, size_t bytes) {
     g_pool_free.erase(it);
     return 0;
   }
+  const bool trace = getenv("TIGAR_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) {
     (void)hipGetLastError();
+    if (trace) fprintf(stderr, "[trace] hipMalloc(%.1f MB) failed with %.1f GB pooled -> trim\n", bytes / 1048576.0,
+                       g_pool_bytes / 1073741824.0);
     tg_pool_trim();
     e = hipMalloc(p, bytes);
+  }
+  if (trace) {
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms > 20.0) fprintf(stderr, "[trace] slow hipMalloc(%.1f MB): %.1f ms\n", bytes / 1048576.0, ms);
   }
   if (e != hipSuccess) {
     *p = nullptr;
@@ -179,9 +188,14 @@ void tg_dfree(void *p) {
   }
   const size_t bytes = it->second;
   if (g_pool_bytes + bytes > tg_pool_limit()) {
+    const auto t0 = std::chrono::steady_clock::now();
     if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
     g_pool_size.erase(it);
     hipFree(p);
+    if (getenv("TIGAR_TRACE")) {
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (ms > 20.0) fprintf(stderr, "[trace] slow hipFree(%.1f MB) (pool full): %.1f ms\n", bytes / 1048576.0, ms);
+    }
     return;
   }
   g_pool_free.emplace(bytes, p);

@@ -346,6 +346,87 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+static void tg_fill_common(tg_extract_params &P, int d, const tg_dir_t *dirs, int32_t col_offset, double eps);
+
+// Matrix-free application y[row] = sum_c M[row, c] * x[c] of the same operator: the candidates of
+// a row are evaluated exactly as in k_extract_fill (same products, same filter) and contracted
+// with x on the fly, so M never has to exist in memory (prolongation u = M U of
+// tIGAr/common.py:1259 at sizes where M does not fit).  Lane per candidate, wave-level reduction.
+template <int D>
+__global__ void __launch_bounds__(256)
+    k_extract_apply(tg_extract_params P, const double *__restrict__ x, double *__restrict__ y) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const tg_blk_ctx X = tg_block_ctx<D, false>(P, blockIdx.x);
+  const int nwave_rows = P.rows_per_block / 4;      // rows handled by each wave of the block
+  for (int q = 0; q < nwave_rows; q++) {
+    int64_t lrow = 0, t[3] = {0, 0, 0};
+    const bool has = tg_lane_row<D, false>(P, X, w * nwave_rows + q, &lrow, t);   // wave-uniform
+    if (!has) continue;
+    double s = 0.0;
+    for (int c = lane; c < P.C; c += 64) {
+      const int i = c % P.pp1[0];
+      const int jk = c / P.pp1[0];
+      const int j = (D > 1) ? jk % P.pp1[1] : 0;
+      const int k = (D > 2) ? jk / P.pp1[1] : 0;
+      const double v = tg_cand_value<D>(P, t, i, j, k);
+      if (fabs(v) > P.eps) s += v * x[tg_cand_col<D>(P, t, i, j, k)];
+    }
+    s = tg_wave_sum(s);
+    if (lane == 0) y[lrow] = s;
+  }
+}
+
+extern "C" int tg_extract_apply_tensor(int d, const tg_dir_t *dirs, int32_t col_offset, double eps, int64_t row0,
+                                       int64_t row1, tg_vec_t x, int64_t x_col0, tg_vec_t y) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(d >= 1 && d <= 3 && dirs && x && y, "bad arguments to tg_extract_apply_tensor");
+  int64_t total = 1;
+  for (int k = 0; k < d; k++) {
+    TG_TRY(tg_check_dir(dirs[k]));
+    TG_REQUIRE(dirs[k].nnodes >= 1 && dirs[k].nodes, "direction %d has no nodes", k);
+    total *= dirs[k].nnodes;
+  }
+  TG_REQUIRE(row0 >= 0 && row1 >= row0 && row1 <= total && y->n == row1 - row0, "row range / y size mismatch");
+  tg_extract_params P;
+  tg_fill_common(P, d, dirs, col_offset, eps);
+  tg_dir_tables T[3];
+  int rc = 0;
+  for (int k = 0; k < d && !rc; k++) {
+    rc = tg_build_dir_table(dirs[k], dirs[k].nodes, dirs[k].nnodes, 1, false, &T[k], nullptr, 1);
+    P.n[k] = dirs[k].nnodes;
+    P.idx[k] = T[k].idx;
+    P.val[k] = T[k].val;
+  }
+  for (int k = d; k < 3; k++) P.n[k] = 1;
+  if (!rc && row1 > row0) {
+    P.row0 = row0;
+    P.nrows = row1 - row0;
+    P.rows_per_block = 32;
+    const int64_t n0 = P.n[0];
+    P.pencil0 = row0 / n0;
+    P.npencils = (row1 - 1) / n0 + 1 - P.pencil0;
+    P.chunks_per_pencil = (int32_t)tg_cdiv(n0, P.rows_per_block);
+    const int64_t nblocks = P.npencils * P.chunks_per_pencil;
+    const double *xs = x->d - x_col0;      // x holds the columns [x_col0, x_col0 + size(x))
+    if (nblocks >= (1ll << 31)) {
+      tg_set_error("tg_extract_apply_tensor: grid too large");
+      rc = 2;
+    } else if (d == 1)
+      hipLaunchKernelGGL((k_extract_apply<1>), dim3((unsigned)nblocks), dim3(256), 0, g_tg.stream, P, xs, y->d);
+    else if (d == 2)
+      hipLaunchKernelGGL((k_extract_apply<2>), dim3((unsigned)nblocks), dim3(256), 0, g_tg.stream, P, xs, y->d);
+    else
+      hipLaunchKernelGGL((k_extract_apply<3>), dim3((unsigned)nblocks), dim3(256), 0, g_tg.stream, P, xs, y->d);
+    if (!rc && hipGetLastError() != hipSuccess) {
+      tg_set_error("tg_extract_apply_tensor launch failed");
+      rc = 1;
+    }
+  }
+  hipStreamSynchronize(g_tg.stream);
+  for (int k = 0; k < d; k++) T[k].free_all();
+  return rc;
+}
+
 template <int D, bool POINTS>
 static int tg_run_extract(tg_extract_params &P, int64_t nblocks, int64_t ncols, tg_csr_t *out) {
   int64_t *rowptr = nullptr;

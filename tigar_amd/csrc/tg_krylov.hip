@@ -14,6 +14,8 @@
 #include "tg_dist.h"
 #include <math.h>
 #include <algorithm>
+#include <chrono>
+static double tk_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 #define TG_VEC_BLOCKS 1024
 
@@ -191,7 +193,9 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
   }
   int it = 0;
   *status = -1;
+  double t_launch = 0, t_sync = 0, t_all0 = tk_now();
   for (it = 1; it <= maxit; it++) {
+    const double _ta = tk_now();
     double *rz_old = s_rz + ((it - 1) & 1), *rz_new = s_rz + (it & 1);
     TG_TRY(tg_comm_halo_exchange(comm, pext));
     // Kp = K p   (x addressed by global column index); then p . Kp on a fixed grid so the
@@ -208,7 +212,10 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
     TG_LAUNCH_CHECK();
     TG_TRY(tg_comm_allreduce_dev(comm, s_pair, 2));
     TG_CHECK_HIP(hipMemcpyAsync(rz_new, s_pair, sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream));
+    const double _tb = tk_now();
     TG_TRY(tg_read_scalars(s_pair, 2, h));
+    t_launch += _tb - _ta;
+    t_sync += tk_now() - _tb;
     {
       float ems = 0.f;  // the sync above also completed this iteration's SpMV event pair
       if (hipEventElapsedTime(&ems, g_tg.pev0, g_tg.pev1) == hipSuccess) {
@@ -231,6 +238,9 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
   *iters = std::min(it, maxit);
   *resnorm = znorm;
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  if (getenv("TIGAR_TRACE"))
+    fprintf(stderr, "[trace] cg: %d its, loop %.3f s (launch %.3f s, sync wait %.3f s)\n", it, tk_now() - t_all0,
+            t_launch, t_sync);
   return 0;
 }
 

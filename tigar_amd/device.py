@@ -248,6 +248,21 @@ def extract_csr_tensor_t(splines1d, nodes1d, fe_row_offset, fe_rows_total, eps, 
     return DeviceCSR(h)
 
 
+def extract_apply_tensor(splines1d, nodes1d, col_offset, eps, x, x_col0=0, row0=None, row1=None, y=None):
+    """y = M x without forming M (same arithmetic as extract_csr_tensor followed by an SpMV)."""
+    pack = _DirPack(splines1d, nodes1d)
+    total = 1
+    for a in nodes1d:
+        total *= len(a)
+    row0 = 0 if row0 is None else int(row0)
+    row1 = total if row1 is None else int(row1)
+    if y is None:
+        y = DeviceVector(row1 - row0)
+    check(_lib.lib().tg_extract_apply_tensor(len(splines1d), pack.arr, int(col_offset), float(eps), row0, row1,
+                                             x._h, int(x_col0), y._h), "tg_extract_apply_tensor")
+    return y
+
+
 def extract_csr_points(splines1d, x, col_offset, ncols, eps):
     x = _f64(x)
     if x.ndim == 1:

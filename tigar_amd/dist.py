@@ -262,9 +262,9 @@ class SlabHotPath(object):
                                             self.comm if self.world > 1 else None)
         return U, its, res, status
 
-    def prolong(self, U, chunk_bytes=8e9):
+    def prolong(self, U):
         """u rows owned by this rank: u = M_own * U (tIGAr/common.py:1259), U with its halo.
-        M_own is regenerated in row chunks of ~chunk_bytes so that it never has to be resident."""
+        Matrix-free: the rows of M are evaluated and contracted with U on the fly."""
         dev = self.dev
         r0, r1 = self.mine["u_rows"]
         if self.world > 1:
@@ -272,15 +272,4 @@ class SlabHotPath(object):
             x_col0 = self.mine["dofs"][0] - self.mine["halo"][0]
         else:
             x, x_col0 = U, 0
-        u = dev.DeviceVector(r1 - r0)
-        per_row = 12.0 * float(np.prod([s1.p + 1 for s1 in self.basis.splines])) + 8.0
-        step = int(max(1, chunk_bytes // per_row))
-        for a in range(r0, r1, step):
-            b = min(r1, a + step)
-            M_own = dev.extract_csr_tensor(self.basis.splines, self.grid.axes, 0, self.ncp, self.eps, a, b)
-            if a == r0 and b == r1:
-                return M_own.mult_offset(x, x_col0, u)
-            y = M_own.mult_offset(x, x_col0)
-            dev.vec_copy_range(u, a - r0, y, 0, b - a)
-            del M_own, y
-        return u
+        return dev.extract_apply_tensor(self.basis.splines, self.grid.axes, 0, self.eps, x, x_col0, r0, r1)
