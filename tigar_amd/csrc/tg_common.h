@@ -65,6 +65,7 @@ struct tg_csr_s {
   int32_t *rowblocks = nullptr;  // device, nblocks+1 row indices
   int64_t nblocks = 0;
   int32_t max_row_nnz = 0;
+  int spmv_cap = 0;              // LDS products per workgroup of the stream plan
   int spmv_mode = 0;             // 0 = not planned, 1 = stream (LDS), 2 = vector (wave/row)
 };
 

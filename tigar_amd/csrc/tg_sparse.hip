@@ -6,7 +6,8 @@
 //
 // SpMV design (HBM-stream-bound, 12 B/nnz): "CSR-stream".  Rows are packed into row
 // blocks of at most TG_SPMV_CAP non-zeros; a workgroup streams its block's val[]/col[]
-// with 16-byte loads that ignore row boundaries (fully coalesced), multiplies by gathered
+// with 16-byte loads that ignore row boundaries (fully coalesced; every load of a block is issued
+// before its first dependent gather), multiplies by gathered
 // x (L2-resident), parks the products in LDS and then reduces row segments out of LDS.
 // No atomics: results are bit-reproducible.  Row blocks are laid out so that each XCD's
 // L2 sees one contiguous range of rows (x-gather locality).
@@ -71,8 +72,13 @@ int tg_spmv_plan(tg_csr_s *a) {
   TG_CHECK_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream));
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
   a->max_row_nnz = hmax;
-  if (hmax <= TG_SPMV_CAP / 2) {
-    const int64_t quantum = TG_SPMV_CAP - hmax;
+  const char *ecap = getenv("TIGAR_SPMV_CAP");
+  int cap = ecap ? atoi(ecap) : TG_SPMV_CAP;
+  if (cap != 1024 && cap != 2048 && cap != 4096 && cap != 8192) cap = TG_SPMV_CAP;
+  while (cap < 8192 && hmax > cap / 2) cap *= 2;
+  a->spmv_cap = cap;
+  if (hmax <= cap / 2) {
+    const int64_t quantum = cap - hmax;
     a->nblocks = a->nnz / quantum + 1;
     TG_TRY(tg_dmalloc(&a->rowblocks, a->nblocks + 1));
     hipLaunchKernelGGL(k_build_rowblocks, dim3((unsigned)tg_cdiv(a->nblocks + 1, 256)), dim3(256), 0, g_tg.stream,
@@ -89,12 +95,12 @@ int tg_spmv_plan(tg_csr_s *a) {
 // kernels
 // ----------------------------------------------------------------------------------------
 // DOT: additionally accumulates sum_r y[r] * dvec[r] into dot_partial[blockIdx.x]
-template <bool DOT>
+template <bool DOT, int CAP, bool NT>
 __global__ void __launch_bounds__(256)
     k_spmv_stream(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
                   const double *__restrict__ x, double *__restrict__ y, const int32_t *__restrict__ rowblocks,
                   int64_t nblocks, const double *__restrict__ dvec, double *__restrict__ dot_partial) {
-  __shared__ double prod[TG_SPMV_CAP];
+  __shared__ double prod[CAP];
   __shared__ double red4[4];
   const int tid = threadIdx.x;
   const int64_t L = tg_xcd_block(blockIdx.x, nblocks);
@@ -104,22 +110,47 @@ __global__ void __launch_bounds__(256)
     if (r1 > r0) {
       const int64_t n0 = rowptr[r0], n1 = rowptr[r1];
       const int64_t q0 = n0 & ~3ll;
-      for (int64_t t = q0 + 4 * tid; t < n1; t += 1024) {
-        // 16-byte streaming loads; allocations are padded so the tail over-read is legal
-        const tg_d2 v01 = __builtin_nontemporal_load(reinterpret_cast<const tg_d2 *>(val + t));
-        const tg_d2 v23 = __builtin_nontemporal_load(reinterpret_cast<const tg_d2 *>(val + t + 2));
-        const tg_i4 c = __builtin_nontemporal_load(reinterpret_cast<const tg_i4 *>(col + t));
-        const bool in0 = t >= n0, in1 = (t + 1 >= n0) && (t + 1 < n1), in2 = (t + 2 >= n0) && (t + 2 < n1),
-                   in3 = (t + 3 >= n0) && (t + 3 < n1);
-        const double x0 = in0 ? x[c.x] : 0.0;
-        const double x1 = in1 ? x[c.y] : 0.0;
-        const double x2 = in2 ? x[c.z] : 0.0;
-        const double x3 = in3 ? x[c.w] : 0.0;
-        const int64_t o = t - n0;
-        if (in0) prod[o] = v01.x * x0;
-        if (in1) prod[o + 1] = v01.y * x1;
-        if (in2) prod[o + 2] = v23.x * x2;
-        if (in3) prod[o + 3] = v23.y * x3;
+      // All streaming loads of the block are issued before the first dependent gather, and all
+      // gathers before the first LDS store: two memory latencies per block instead of two per
+      // 1024-entry slice.  (clamped addresses keep out-of-range slices legal and branch-free)
+      constexpr int SL = CAP / 1024;
+      tg_d2 v01[SL], v23[SL];
+      tg_i4 cc[SL];
+      const int64_t tlast = (n1 - 1) & ~3ll;
+#pragma unroll
+      for (int k = 0; k < SL; k++) {
+        int64_t t = q0 + 4 * tid + 1024 * k;
+        t = t > tlast ? tlast : t;
+        v01[k] = NT ? __builtin_nontemporal_load(reinterpret_cast<const tg_d2 *>(val + t))
+                    : *reinterpret_cast<const tg_d2 *>(val + t);
+        v23[k] = NT ? __builtin_nontemporal_load(reinterpret_cast<const tg_d2 *>(val + t + 2))
+                    : *reinterpret_cast<const tg_d2 *>(val + t + 2);
+        cc[k] = NT ? __builtin_nontemporal_load(reinterpret_cast<const tg_i4 *>(col + t))
+                   : *reinterpret_cast<const tg_i4 *>(col + t);
+      }
+      double xv[SL][4];
+#pragma unroll
+      for (int k = 0; k < SL; k++) {
+        int64_t t = q0 + 4 * tid + 1024 * k;
+        t = t > tlast ? tlast : t;
+        // entry t is always a real entry of the matrix; entries past n1 may lie in the padding
+        // of the arrays, so their (garbage) column is replaced before it is dereferenced
+        const int c0 = cc[k].x;
+        xv[k][0] = x[c0];
+        xv[k][1] = x[(t + 1 < n1) ? cc[k].y : c0];
+        xv[k][2] = x[(t + 2 < n1) ? cc[k].z : c0];
+        xv[k][3] = x[(t + 3 < n1) ? cc[k].w : c0];
+      }
+#pragma unroll
+      for (int k = 0; k < SL; k++) {
+        const int64_t t = q0 + 4 * tid + 1024 * k;
+        if (t <= tlast) {
+          const int64_t o = t - n0;
+          if (t >= n0) prod[o] = v01[k].x * xv[k][0];
+          if (t + 1 >= n0 && t + 1 < n1) prod[o + 1] = v01[k].y * xv[k][1];
+          if (t + 2 >= n0 && t + 2 < n1) prod[o + 2] = v23[k].x * xv[k][2];
+          if (t + 3 >= n0 && t + 3 < n1) prod[o + 3] = v23[k].y * xv[k][3];
+        }
       }
       __syncthreads();
       const int nr = (int)(r1 - r0);
@@ -185,13 +216,24 @@ int tg_spmv_raw(tg_csr_s *a, const double *x_shifted, double *y, double *dot_par
   if (a->nrows == 0) return 0;
   if (a->spmv_mode == 1) {
     const unsigned grid = (unsigned)(((a->nblocks + 7) / 8) * 8);  // tg_xcd_block needs a multiple of 8
-    if (dot_partial) {
-      TG_REQUIRE(grid <= TG_SCRATCH_DOUBLES / 2, "SpMV dot partials exceed scratch");
-      hipLaunchKernelGGL((k_spmv_stream<true>), dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val,
-                         x_shifted, y, a->rowblocks, a->nblocks, dvec, dot_partial);
-    } else
-      hipLaunchKernelGGL((k_spmv_stream<false>), dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val,
-                         x_shifted, y, a->rowblocks, a->nblocks, (const double *)nullptr, (double *)nullptr);
+    static int nt = -1;
+    if (nt < 0) nt = getenv("TIGAR_SPMV_NT") ? atoi(getenv("TIGAR_SPMV_NT")) : 0;
+    TG_REQUIRE(!dot_partial, "fused dot partials are not used any more");
+#define TG_SPMV_LAUNCH(CAP, NTF)                                                                                  \
+  hipLaunchKernelGGL((k_spmv_stream<false, CAP, NTF>), dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, \
+                     a->val, x_shifted, y, a->rowblocks, a->nblocks, (const double *)nullptr, (double *)nullptr)
+    if (nt) {
+      if (a->spmv_cap == 1024) TG_SPMV_LAUNCH(1024, true);
+      else if (a->spmv_cap == 2048) TG_SPMV_LAUNCH(2048, true);
+      else if (a->spmv_cap == 4096) TG_SPMV_LAUNCH(4096, true);
+      else TG_SPMV_LAUNCH(8192, true);
+    } else {
+      if (a->spmv_cap == 1024) TG_SPMV_LAUNCH(1024, false);
+      else if (a->spmv_cap == 2048) TG_SPMV_LAUNCH(2048, false);
+      else if (a->spmv_cap == 4096) TG_SPMV_LAUNCH(4096, false);
+      else TG_SPMV_LAUNCH(8192, false);
+    }
+#undef TG_SPMV_LAUNCH
   } else {
     const unsigned grid = (unsigned)std::min<int64_t>(tg_cdiv(a->nrows, 4), (int64_t)g_tg.num_cu * 8);
     if (dot_partial)
