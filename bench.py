@@ -223,6 +223,16 @@ def main():
     alg_bytes = spmv_bytes(res["nnzK_local"] if "nnzK_local" in res else res["nnzK"],
                            res["ncp_local"] if "ncp_local" in res else res["ncp"])
     achieved = alg_bytes / spmv_avg_s / 1e9 if spmv_avg_s > 0 else 0.0
+    # HBM traffic of the SpMV from the PMC passes (collected separately with rocprofv3 --pmc, as the
+    # microarchitecture guide prescribes; committed under profiles/): only quoted for the workload
+    # and GPU count it was measured on
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r1_spmv_pmc_summary.json")
+    if wl == "cfg3" and max(args.gpus, world) == 1 and not args.nel and os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file))["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
     out = {
         "metric": "DoF/s (extraction + M^T A M + M^T b + CG solve + prolongation)",
         "value": value, "unit": "DoF/s", "n_gpus": max(args.gpus, world), "steps": args.steps,
@@ -241,7 +251,9 @@ def main():
                    "parallelism": "z-slab x%d" % max(args.gpus, world)},
         "roofline": {"bound": "hbm", "kernel": "k_spmv_stream (K p in CG)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "launches": res["spmv_count"],
+                     "traffic": traffic, "traffic_source": "profiles/r1_spmv_pmc_summary.json (rocprofv3 --pmc "
+                     "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)" if traffic else None,
+                     "launches": res["spmv_count"],
                      "avg_launch_ms": spmv_avg_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
     }
     if not args.no_cpu_baseline:
