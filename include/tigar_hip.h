@@ -113,6 +113,14 @@ int tg_extract_csr_points(int d, const tg_dir_t *dirs, int32_t col_offset, int64
                           double eps, const double *x, int64_t nrows, tg_csr_t *out);
 /* vertical concatenation of row blocks (multi-field M: one block per field) */
 int tg_csr_vstack(int nblocks, const tg_csr_t *blocks, tg_csr_t *out);
+/* Incremental vstack: K is assembled slab by slab into ONE allocation (no second copy of a 70 GB
+ * matrix): create with an nnz capacity estimate, append row blocks in order (the block's arrays
+ * are copied device-to-device; the capacity grows geometrically if the estimate was short),
+ * finish to obtain the CSR object. */
+typedef struct tg_csr_builder_s *tg_csr_builder_t;
+int tg_csr_builder_create(int64_t nrows_total, int64_t ncols, int64_t nnz_capacity, tg_csr_builder_t *out);
+int tg_csr_builder_append(tg_csr_builder_t b, tg_csr_t block);
+int tg_csr_builder_finish(tg_csr_builder_t b, tg_csr_t *out);   /* destroys the builder */
 /* 1-D evaluation only (device twin of BSpline1.getKnotSpan/getNodes/basisFuncs):
  * idx[n*(p+1)], val[n*(p+1)] in the reference's order (span-p .. span). */
 int tg_eval_basis_1d(const tg_dir_t *dir, const double *u, int64_t n, int32_t *span,

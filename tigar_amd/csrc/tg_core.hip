@@ -118,6 +118,7 @@ extern "C" int tg_timer_stop(int slot, double *ms) {
 // some hosts and hipFree synchronises the device; the hot path allocates its outputs (M, M^T,
 // K, temporaries) afresh on every call, so freed blocks are kept in a size-keyed pool and
 // handed out again.  All work runs on one stream, so reuse is stream-ordered and needs no sync.
+#include <algorithm>
 #include <map>
 #include <chrono>
 #include <unordered_map>
@@ -129,7 +130,7 @@ static size_t tg_pool_limit() {
   static size_t lim = 0;
   if (!lim) {
     const char *s = getenv("TIGAR_POOL_GB");
-    lim = (size_t)(s ? atof(s) : 96.0) * (size_t)1 << 30;
+    lim = (size_t)((s ? atof(s) : 160.0) * (double)((size_t)1 << 30));
   }
   return lim;
 }
@@ -150,7 +151,8 @@ int tg_dmalloc_bytes(void **p, size_t bytes) {
   if (bytes == 0) bytes = 1;
   bytes = (bytes + 255) & ~(size_t)255;
   auto it = g_pool_free.lower_bound(bytes);
-  if (it != g_pool_free.end() && it->first <= bytes + bytes / 8 + 4096) {
+  // accept a cached block that is at most 12.5 % (or 32 MiB) larger than requested
+  if (it != g_pool_free.end() && it->first <= bytes + std::max<size_t>(bytes / 8, (size_t)32 << 20)) {
     *p = it->second;
     g_pool_bytes -= it->first;
     g_pool_free.erase(it);

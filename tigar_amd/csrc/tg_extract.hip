@@ -652,6 +652,85 @@ extern "C" int tg_csr_vstack(int nblocks, const tg_csr_t *blocks, tg_csr_t *out)
 }
 
 // ----------------------------------------------------------------------------------------
+// incremental vstack
+// ----------------------------------------------------------------------------------------
+struct tg_csr_builder_s {
+  tg_csr_s *m = nullptr;
+  int64_t rows_done = 0, nnz_done = 0, cap = 0;
+};
+
+extern "C" int tg_csr_builder_create(int64_t nrows_total, int64_t ncols, int64_t nnz_capacity,
+                                     tg_csr_builder_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(nrows_total >= 0 && ncols >= 0 && nnz_capacity >= 0 && out, "bad arguments to tg_csr_builder_create");
+  tg_csr_builder_s *b = new tg_csr_builder_s();
+  if (tg_csr_alloc(nrows_total, ncols, nnz_capacity, &b->m)) {
+    delete b;
+    return 1;
+  }
+  b->cap = nnz_capacity;
+  b->m->nnz = 0;
+  TG_CHECK_HIP(hipMemsetAsync(b->m->rowptr, 0, sizeof(int64_t), g_tg.stream));
+  *out = b;
+  return 0;
+}
+
+extern "C" int tg_csr_builder_append(tg_csr_builder_t b, tg_csr_t blk) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(b && b->m && blk, "null argument to tg_csr_builder_append");
+  TG_REQUIRE(blk->ncols == b->m->ncols, "builder: column count mismatch");
+  TG_REQUIRE(b->rows_done + blk->nrows <= b->m->nrows, "builder: more rows appended than announced");
+  if (b->nnz_done + blk->nnz > b->cap) {
+    // grow: new arrays, copy what is there
+    const int64_t ncap = std::max<int64_t>(b->nnz_done + blk->nnz, b->cap + b->cap / 4 + 1024);
+    int32_t *ncol = nullptr;
+    double *nval = nullptr;
+    TG_TRY(tg_dmalloc(&ncol, ncap + TG_CSR_PAD));
+    if (tg_dmalloc(&nval, ncap + TG_CSR_PAD)) {
+      tg_dfree(ncol);
+      return 1;
+    }
+    if (b->nnz_done) {
+      hipMemcpyAsync(ncol, b->m->col, (size_t)b->nnz_done * sizeof(int32_t), hipMemcpyDeviceToDevice, g_tg.stream);
+      hipMemcpyAsync(nval, b->m->val, (size_t)b->nnz_done * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream);
+    }
+    hipStreamSynchronize(g_tg.stream);
+    tg_dfree(b->m->col);
+    tg_dfree(b->m->val);
+    b->m->col = ncol;
+    b->m->val = nval;
+    b->cap = ncap;
+  }
+  if (blk->nrows) {
+    // rowptr entries 1..nrows of the block, shifted (entry 0 of the builder's range is already set)
+    hipLaunchKernelGGL(k_copy_rowptr_shift, dim3(tg_grid_1d(blk->nrows, 256)), dim3(256), 0, g_tg.stream,
+                       b->m->rowptr + b->rows_done + 1, blk->rowptr + 1, blk->nrows, b->nnz_done);
+  }
+  if (blk->nnz) {
+    hipMemcpyAsync(b->m->col + b->nnz_done, blk->col, (size_t)blk->nnz * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                   g_tg.stream);
+    hipMemcpyAsync(b->m->val + b->nnz_done, blk->val, (size_t)blk->nnz * sizeof(double), hipMemcpyDeviceToDevice,
+                   g_tg.stream);
+  }
+  TG_LAUNCH_CHECK();
+  b->rows_done += blk->nrows;
+  b->nnz_done += blk->nnz;
+  return 0;
+}
+
+extern "C" int tg_csr_builder_finish(tg_csr_builder_t b, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(b && b->m && out, "null argument to tg_csr_builder_finish");
+  TG_REQUIRE(b->rows_done == b->m->nrows, "builder: %lld of %lld rows appended", (long long)b->rows_done,
+             (long long)b->m->nrows);
+  b->m->nnz = b->nnz_done;
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  *out = b->m;
+  delete b;
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------
 // triplet fallback for arbitrary scalar-basis plug-ins (host sort; the Python loop that
 // feeds it dominates).  INSERT semantics: the last (row,col) write wins.
 // ----------------------------------------------------------------------------------------

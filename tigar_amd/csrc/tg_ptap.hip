@@ -70,29 +70,52 @@ typedef int tg_i4v __attribute__((ext_vector_type(4)));
 template <bool NUMERIC, int U>
 __device__ __forceinline__ bool tg_hash_insert_n(int32_t *keys, double *vals, int ts, int lg, const int32_t *key,
                                                  const double *v) {
-  bool ok = true;
   const int nb_mask = (ts >> 2) - 1;
+  // ---- fast round: the U home buckets are fetched back to back (independent LDS reads), then
+  // matched; a key that sits in its home bucket -- the overwhelmingly common case -- costs one
+  // read, four compares and one ds_add_f64 with a single exposed LDS latency for all U.
+  int b[U];
+  tg_i4v kk[U];
+  bool pending[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    b[u] = (int)(tg_hash(key[u], lg) >> 2);
+    kk[u] = *reinterpret_cast<const tg_i4v *>(keys + 4 * b[u]);
+  }
+  bool any_pending = false;
 #pragma unroll
   for (int u = 0; u < U; u++) {
     const int32_t k = key[u];
-    int b = (int)(tg_hash(k, lg) >> 2);
-    bool pending = k >= 0;
+    const int pos = (kk[u].x == k) ? 0 : (kk[u].y == k) ? 1 : (kk[u].z == k) ? 2 : (kk[u].w == k) ? 3 : -1;
+    const bool hit = (k >= 0) && (pos >= 0);
+    if (NUMERIC && hit) unsafeAtomicAdd(&vals[4 * b[u] + pos], v[u]);
+    pending[u] = (k >= 0) && !hit;
+    any_pending |= pending[u];
+  }
+  if (!__any(any_pending)) return true;
+  // ---- slow rounds: inserts and bucket spills
+  bool ok = true;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int32_t k = key[u];
+    int bb = b[u];
+    bool pend = pending[u];
     int rounds = 0;
-    while (__any(pending)) {
-      const tg_i4v kk = *reinterpret_cast<const tg_i4v *>(keys + 4 * b);
-      int pos = (kk.x == k) ? 0 : (kk.y == k) ? 1 : (kk.z == k) ? 2 : (kk.w == k) ? 3 : -1;
-      if (pending && pos < 0) {
-        const int e = (kk.x == -1) ? 0 : (kk.y == -1) ? 1 : (kk.z == -1) ? 2 : (kk.w == -1) ? 3 : -1;
+    while (__any(pend)) {
+      const tg_i4v q = *reinterpret_cast<const tg_i4v *>(keys + 4 * bb);
+      int pos = (q.x == k) ? 0 : (q.y == k) ? 1 : (q.z == k) ? 2 : (q.w == k) ? 3 : -1;
+      if (pend && pos < 0) {
+        const int e = (q.x == -1) ? 0 : (q.y == -1) ? 1 : (q.z == -1) ? 2 : (q.w == -1) ? 3 : -1;
         if (e >= 0) {
-          const int32_t old = atomicCAS(&keys[4 * b + e], -1, k);
+          const int32_t old = atomicCAS(&keys[4 * bb + e], -1, k);
           if (old == -1 || old == k) pos = e;   // else: somebody else took it, re-read this bucket
         } else {
-          b = (b + 1) & nb_mask;               // bucket full of other keys
+          bb = (bb + 1) & nb_mask;             // bucket full of other keys
         }
       }
-      const bool hit = pending && pos >= 0;
-      if (NUMERIC && hit) unsafeAtomicAdd(&vals[4 * b + pos], v[u]);
-      pending = pending && !hit;
+      const bool hit = pend && pos >= 0;
+      if (NUMERIC && hit) unsafeAtomicAdd(&vals[4 * bb + pos], v[u]);
+      pend = pend && !hit;
       if (++rounds > ts) {  // wave-uniform
         ok = false;
         break;
@@ -363,12 +386,23 @@ static size_t tg_ptap_lds_bytes(int ts1, int ts2, bool numeric, int nt) {
 static int tg_ptap_threads(int ts1, int ts2, bool numeric) {
   const int forced = tg_env_int("TIGAR_PTAP_NT", 0);
   if (forced == 256 || forced == 512 || forced == 1024) return forced;
+  // smallest workgroup that keeps >= 16 waves resident per CU (wider groups pay more per-row
+  // synchronisation; fewer waves expose LDS / memory latency)
   for (int nt = 256; nt <= 1024; nt *= 2) {
     const size_t lds = tg_ptap_lds_bytes(ts1, ts2, numeric, nt);
     const int blocks = (int)std::min<size_t>(8, (160 * 1024) / lds);
     if (blocks * nt >= 1024 || nt == 1024) return nt;
   }
   return 1024;
+}
+
+// resident waves per CU under that choice
+static int tg_ptap_waves(int ts1, int ts2) {
+  const int nt = tg_ptap_threads(ts1, ts2, true);
+  const size_t lds = tg_ptap_lds_bytes(ts1, ts2, true, nt);
+  if (lds > 160 * 1024) return 0;
+  const int blocks = (int)std::min<size_t>(2048 / nt, (160 * 1024) / lds);
+  return blocks * nt / 64;
 }
 
 template <int MODE>
@@ -491,8 +525,17 @@ extern "C" int tg_ptap_symbolic(tg_csr_t a, int64_t a_row0, tg_csr_t m, int64_t 
     }
     plan->max_t = h[1];
     plan->max_k = h[2];
-    plan->ts2 = std::max(64, tg_pow2_ge((int64_t)h[2] * 5 / 2 + 8));
-    plan->ts1 = std::max(plan->ts2, std::max(64, tg_pow2_ge((int64_t)h[1] * 2 + 8)));
+    // table sizes: power of two >= load_inv * entries (4-key buckets tolerate load factors ~0.6)
+    const double li1 = getenv("TIGAR_PTAP_LOADINV1") ? atof(getenv("TIGAR_PTAP_LOADINV1")) : 2.0;
+    const double li2 = getenv("TIGAR_PTAP_LOADINV2") ? atof(getenv("TIGAR_PTAP_LOADINV2")) : 2.5;
+    plan->ts2 = std::max(64, tg_pow2_ge((int64_t)(h[2] * li2) + 8));
+    plan->ts1 = std::max(plan->ts2, std::max(64, tg_pow2_ge((int64_t)(h[1] * li1) + 8)));
+    if (!getenv("TIGAR_PTAP_LOADINV1")) {
+      auto waves = [&](int t1) { return tg_ptap_waves(t1, plan->ts2); };
+      const int small = std::max(plan->ts2, std::max(64, tg_pow2_ge((int64_t)(h[1] * 1.3) + 8)));
+      // a denser table costs more probing: accept it only where occupancy is the problem
+      if (small < plan->ts1 && waves(plan->ts1) < 24 && waves(small) > waves(plan->ts1)) plan->ts1 = small;
+    }
   }
   if (rc) {
     delete plan;

@@ -281,6 +281,24 @@ def csr_vstack(blocks):
     return DeviceCSR(h)
 
 
+class CSRBuilder(object):
+    """Incremental vstack of row blocks into one allocation (K assembled slab by slab)."""
+
+    def __init__(self, nrows_total, ncols, nnz_capacity):
+        self._h = handle()
+        check(_lib.lib().tg_csr_builder_create(int(nrows_total), int(ncols), int(nnz_capacity), C.byref(self._h)),
+              "tg_csr_builder_create")
+
+    def append(self, block):
+        check(_lib.lib().tg_csr_builder_append(self._h, block._h), "tg_csr_builder_append")
+
+    def finish(self):
+        h = handle()
+        check(_lib.lib().tg_csr_builder_finish(self._h, C.byref(h)), "tg_csr_builder_finish")
+        self._h = None
+        return DeviceCSR(h)
+
+
 def csr_from_triplets(nrows, ncols, rows, cols, vals, eps):
     rows, cols, vals = _i64(rows), _i32(cols), _f64(vals)
     h = handle()

@@ -171,6 +171,8 @@ class SlabHotPath(object):
         zero_dofs = np.asarray(zero_dofs, dtype=np.int32)
         k_blocks, rhs_parts = [], []
         ring = {"hi": 0, "pieces": []}      # plane-local stage results kept across sub-slabs
+        builder = None
+        nslabs = len(self.sub_slabs())
         t = timers if timers is not None else {}
 
         def tick(name, t0):
@@ -206,12 +208,24 @@ class SlabHotPath(object):
             tick("input", t0)
             t0 = time.perf_counter()
             if use_factored:
-                k_blocks.append(self._factored_slab(A, S, ka, kb, zero_dofs, diag, ring))
+                kblk = self._factored_slab(A, S, ka, kb, zero_dofs, diag, ring)
                 plan = None
             else:
                 plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], S["m_rows"][0], S["dofs"][0])
-                k_blocks.append(dev.ptap_numeric(plan, A, M, MT, zero_dofs, diag))
+                kblk = dev.ptap_numeric(plan, A, M, MT, zero_dofs, diag)
             tick("ptap", t0)
+            t0 = time.perf_counter()
+            if nslabs == 1:
+                k_blocks.append(kblk)
+            else:
+                if builder is None:
+                    # capacity from the first slab's density (rows near the patch boundary are
+                    # sparser than interior ones, hence the margin); grows if short
+                    est = int(kblk.nnz / max(1, kb - ka) * (self.k1 - self.k0) * 1.08) + 1024
+                    builder = dev.CSRBuilder(self.mine["dofs"][1] - self.mine["dofs"][0], self.ncp, est)
+                builder.append(kblk)
+            del kblk
+            tick("stack", t0)
             t0 = time.perf_counter()
             y = MT.mult_offset(b, S["a_rows"][0])
             y.zero_entries(zero_dofs, S["dofs"][0])
@@ -219,7 +233,7 @@ class SlabHotPath(object):
             tick("mtb", t0)
             del A, M, MT, b, plan
         t0 = time.perf_counter()
-        K = k_blocks[0] if len(k_blocks) == 1 else dev.csr_vstack(k_blocks)
+        K = k_blocks[0] if builder is None else builder.finish()
         if len(rhs_parts) == 1:
             rhs = rhs_parts[0]
         else:
