@@ -149,6 +149,25 @@ int tg_ptap_symbolic(tg_csr_t a, int64_t a_row0, tg_csr_t m, int64_t m_row0, tg_
 int tg_ptap_numeric(tg_ptap_t plan, tg_csr_t a, tg_csr_t m, tg_csr_t mt,
                     const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out);
 int tg_ptap_destroy(tg_ptap_t plan);
+/* extractMatrix when the extraction operator is a Kronecker product (tensor B-splines): one
+ * contraction stage  out = P^T cur P  with P = (x)_k F_k, F_k = the 1-D matrix of direction k
+ * (n x m CSR + its transpose, host pointers) or the identity (rowptr == NULL).  `cur` is an
+ * arbitrary sparse row block on the tensor index space dims_in (rows starting at cur_row0,
+ * global columns); rows [out_row0,out_row1) of the result are produced.  Accumulates in a dense
+ * LDS box addressed directly (no hashing).  Returns 100 when the box would not fit in LDS --
+ * use tg_ptap_symbolic/numeric with explicit operators instead. */
+typedef struct {
+  int64_t n, m;                 /* F is n x m                                   */
+  const int32_t *rowptr;        /* n+1, NULL = identity (direction not contracted) */
+  const int32_t *col;
+  const double *val;
+  const int32_t *t_rowptr;      /* transpose, m+1                               */
+  const int32_t *t_col;
+  const double *t_val;
+} tg_kron1d_t;
+int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, const tg_kron1d_t *fac,
+                 int64_t out_row0, int64_t out_row1, const int32_t *zero_dofs, int64_t nzero, double diag,
+                 tg_csr_t *out);
 /* MatZeroRowsColumns(K, zeroDofs, diag) [ext] as called at tIGAr/common.py:1200;
  * K holds global rows [row0, row0+nrows). */
 int tg_zero_rows_cols(tg_csr_t k, int64_t row0, const int32_t *dofs, int64_t n, double diag);

@@ -224,8 +224,12 @@ def test_rccl_world1_comm_roundtrip(T):
     assert np.array_equal(comm.halo_extend(x).get_local(), np.arange(10.0))
 
 
+@pytest.mark.parametrize("box", ["1", "0"])
 @pytest.mark.parametrize("d,p,nel", [(2, 2, 9), (2, 4, 5), (3, 2, 5), (3, 3, 4)])
-def test_sum_factorised_ptap_equals_direct(T, d, p, nel):
+def test_sum_factorised_ptap_equals_direct(T, d, p, nel, box, monkeypatch):
+    # box=1: dense-LDS-box Kronecker kernel (tg_ptap_kron); box=0: the general hash kernel fed
+    # with explicit directional operators
+    monkeypatch.setenv("TIGAR_PTAP_BOX", box)
     """K from the three directional PtAP stages == K from the one-shot PtAP == oracle, for an
     arbitrary (non-symmetric, perturbed) FE matrix; also slab by slab."""
     from tigar_amd.kronptap import KronExtraction, ptap_factored

@@ -28,6 +28,11 @@ class tg_dir_t(C.Structure):
                 ("nnodes", C.c_int64), ("nodes", c_f64p)]
 
 
+class tg_kron1d_t(C.Structure):
+    _fields_ = [("n", C.c_int64), ("m", C.c_int64), ("rowptr", c_i32p), ("col", c_i32p), ("val", c_f64p),
+                ("t_rowptr", c_i32p), ("t_col", c_i32p), ("t_val", c_f64p)]
+
+
 class tg_kron_dir_t(C.Structure):
     _fields_ = [("n", C.c_int64), ("rowptr", c_i32p), ("col", c_i32p), ("val", c_f64p)]
 
@@ -88,6 +93,8 @@ PROTOTYPES = {
     "tg_ptap_numeric": (C.c_int, [handle, handle, handle, handle, c_i32p, C.c_int64, C.c_double,
                                   C.POINTER(handle)]),
     "tg_ptap_destroy": (C.c_int, [handle]),
+    "tg_ptap_kron": (C.c_int, [handle, C.c_int64, C.c_int, c_i64p, C.POINTER(tg_kron1d_t), C.c_int64, C.c_int64,
+                               c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
     "tg_zero_rows_cols": (C.c_int, [handle, C.c_int64, c_i32p, C.c_int64, C.c_double]),
     "tg_krylov_solve": (C.c_int, [handle, handle, handle, C.c_int, C.c_int, C.c_double, C.c_double,
                                   C.c_int, C.c_int, handle, C.POINTER(C.c_int), c_f64p,

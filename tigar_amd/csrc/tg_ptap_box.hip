@@ -1,0 +1,736 @@
+// extractMatrix for Kronecker-structured extraction operators:  K = P^T A P  with
+// P = (x)_k F_k, F_k = M_k (the 1-D extraction matrix) in the contracted directions and the
+// identity elsewhere.  A is an ARBITRARY sparse matrix on the tensor index space; only P's
+// structure is used: it fixes the factorisation (n0, n1, n2) of row/column indices.
+//
+// One workgroup per output row (I0,I1,I2):
+//   stage 1  T[s] = sum_r w_r A[r, s] over the tensor product of the 1-D supports of
+//            F_k^T rows I_k.  The columns s that can occur lie in a small box of the index
+//            space (support +- bandwidth of A per direction, the bandwidth is measured, not
+//            assumed), so T is a DENSE box in LDS addressed directly: one ds_add_f64 per
+//            product, no hashing, no probing.
+//   stage 2  the box is contracted with F_k direction by direction (sum factorisation): each
+//            output element is a short dot product read from LDS -- no atomics at all.
+//   finish   box entries that were structurally touched come out in lexicographic = column
+//            order: compaction by ballot/prefix, fused MatZeroRowsColumns, no sort.
+// "touched" flags are propagated through the contractions, so the pattern of the result is
+// the structural pattern of P^T A P exactly as the general hash kernel produces it.
+// If a box would not fit in LDS (or A couples outside the measured bandwidth, impossible by
+// construction) the host falls back to the general kernel (tg_ptap.hip).
+#include "tg_common.h"
+#include <algorithm>
+
+struct tg_box_args {
+  const int64_t *rowptr;
+  const int32_t *col;
+  const double *val;
+  int64_t row0, nrows;          // rows held by `cur` (global row index of local row 0)
+  int d;
+  int nin[3], nout[3];          // input / output index-space dimensions
+  int contracted[3];
+  const int32_t *mrp[3], *mcol[3];   // M_k (nin x nout) CSR, device
+  const double *mval[3];
+  const int32_t *trp[3], *tcol[3];   // M_k^T (nout x nin) CSR, device
+  const double *tval[3];
+  int W[3];                     // measured bandwidth of cur per direction
+  int64_t out_row0, out_nrows, row_stride;
+  double inv_n01, inv_n0;       // reciprocals for the index decomposition
+  int cap;                      // doubles per LDS buffer
+  int cap1;                     // doubles of the second (ping-pong) buffer
+  int ctab;                     // total entries of the contraction-table slices
+  int coff[3], cstr[3], loff[3]; // per direction: slice offset / entries per output row / list offset
+  int nlist;                    // total entries of the support lists
+  int g1, lg1;                  // lanes per input row in stage 1
+};
+
+// s = q*dsr + r for 0 <= s < 2^31 via an fp64 reciprocal (exact after one correction step)
+__device__ __forceinline__ void tg_divmod(unsigned s, unsigned dsr, double inv, unsigned *q, unsigned *r) {
+  unsigned qq = (unsigned)((double)s * inv);
+  int rr = (int)(s - qq * dsr);
+  if (rr < 0) {
+    qq--;
+    rr += (int)dsr;
+  } else if ((unsigned)rr >= dsr) {
+    qq++;
+    rr -= (int)dsr;
+  }
+  *q = qq;
+  *r = (unsigned)rr;
+}
+
+enum { TG_BOX_OK = 0, TG_BOX_TOOBIG = 1, TG_BOX_RANGE = 2, TG_BOX_CAP = 3, TG_BOX_OUTSIDE = 4 };
+enum { TG_BOXMODE_PROBE = 0, TG_BOXMODE_BUMP = 1 };
+
+// max |s_k - r_k| over all entries of cur, per direction
+__global__ void __launch_bounds__(256)
+    k_box_bandwidth(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nrows, int64_t row0,
+                    int n0, int n1, int *__restrict__ out3) {
+  __shared__ int red[3][4];
+  int w0 = 0, w1 = 0, w2 = 0;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t n01 = (int64_t)n0 * n1;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    const int64_t g = r + row0;
+    const int r2 = (int)(g / n01);
+    const int rem = (int)(g - (int64_t)r2 * n01);
+    const int r1 = rem / n0, r0 = rem - r1 * n0;
+    for (int64_t q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) {
+      const int64_t s = col[q];
+      const int s2 = (int)(s / n01);
+      const int sm = (int)(s - (int64_t)s2 * n01);
+      const int s1 = sm / n0, s0 = sm - s1 * n0;
+      w0 = max(w0, abs(s0 - r0));
+      w1 = max(w1, abs(s1 - r1));
+      w2 = max(w2, abs(s2 - r2));
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    w0 = max(w0, __shfl_down(w0, o, 64));
+    w1 = max(w1, __shfl_down(w1, o, 64));
+    w2 = max(w2, __shfl_down(w2, o, 64));
+  }
+  if (lane == 0) {
+    red[0][threadIdx.x >> 6] = w0;
+    red[1][threadIdx.x >> 6] = w1;
+    red[2][threadIdx.x >> 6] = w2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    atomicMax(&out3[k], max(max(red[k][0], red[k][1]), max(red[k][2], red[k][3])));
+  }
+}
+
+#define TG_BOX_NT 256
+#define TG_BOX_UNROLL 4
+#define TG_BOX_MAXLIST 96     // longest 1-D support list (entries of one row of F_k^T)
+#define TG_BOX_MAXD 48        // most output indices per direction reachable from one box
+
+// LDS carve (dynamic): buf0[cap] f64 | buf1[cap] f64 | pre_start[NT] i64 | pre_w[NT] f64 |
+//                      lw[3][MAXLIST] f64 | cw[3][ctab] f64 | pre_len[NT] i32 | misc[32] i32 |
+//                      la[3][MAXLIST] i32 | cptr[3][MAXD+1] i32 | ca[3][ctab] i32 | fl0[cap] u8 | fl1[cap] u8
+// The per-row critical path is a chain of dependent global loads, so everything the row needs
+// from the small 1-D tables is fetched in two cooperative rounds at the start (support lists,
+// then operand-row descriptors + the table slices of the contraction stage) and kept in LDS.
+template <int MODE>
+__global__ void __launch_bounds__(TG_BOX_NT)
+    k_ptap_box(tg_box_args P, int64_t *__restrict__ row_cnt, int64_t *__restrict__ row_off,
+               int32_t *__restrict__ k_col, double *__restrict__ k_val, unsigned long long *__restrict__ cursor,
+               int64_t capacity, const uint8_t *__restrict__ mask, double diag, int *__restrict__ status,
+               int *__restrict__ maxima) {
+  constexpr int NT = TG_BOX_NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *buf0 = reinterpret_cast<double *>(smem);
+  double *buf1 = buf0 + P.cap;
+  int64_t *pre_start = reinterpret_cast<int64_t *>(buf1 + P.cap1);
+  double *pre_w = reinterpret_cast<double *>(pre_start + NT);
+  double *lw = pre_w + NT;                       // support-list weights  [nlist]
+  double *cw = lw + P.nlist;                     // contraction-table values [ctab]
+  int *pre_len = reinterpret_cast<int *>(cw + P.ctab);
+  int *misc = pre_len + NT;
+  int *la = misc + 32;                           // support-list indices [nlist]
+  int *cptr = la + P.nlist;                      // entries per output row [3][MAXD]
+  int *ca = cptr + 3 * TG_BOX_MAXD;              // contraction-table input indices [ctab]
+  uint8_t *fl0 = reinterpret_cast<uint8_t *>(ca + P.ctab);
+  uint8_t *fl1 = fl0 + P.cap;
+
+  const int tid = threadIdx.x;
+  const int64_t L = tg_xcd_block(blockIdx.x, P.out_nrows);
+  if (L >= P.out_nrows) return;
+  const int64_t li = L * P.row_stride;
+  const int64_t R = P.out_row0 + li;            // global output row
+  int I[3];
+  {
+    const int64_t m01 = (int64_t)P.nout[0] * P.nout[1];
+    I[2] = (int)(R / m01);
+    const int rem = (int)(R - (int64_t)I[2] * m01);
+    I[1] = rem / P.nout[0];
+    I[0] = rem - I[1] * P.nout[0];
+  }
+  // ---- round 1: support lists of the contracted directions -> LDS
+  int e0[3], len[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (k < P.d && P.contracted[k]) {
+      e0[k] = P.trp[k][I[k]];
+      len[k] = min(P.trp[k][I[k] + 1] - e0[k], TG_BOX_MAXLIST);
+    } else {
+      e0[k] = 0;
+      len[k] = 1;
+    }
+  }
+  if (tid < 32) misc[tid] = (tid == 8 || tid == 10 || tid == 12) ? 0x7fffffff : ((tid == 9 || tid == 11 || tid == 13) ? -1 : 0);
+  {
+    const int k = tid >> 7 ? 2 : (tid >> 6 ? 1 : 0);      // waves 0,1 -> dirs 0,1 ; waves 2,3 -> dir 2
+    const int q = (k == 2) ? tid - 128 : (tid & 63);
+    if (k < P.d && P.contracted[k]) {
+      for (int e = q; e < len[k]; e += (k == 2 ? 128 : 64)) {
+        la[P.loff[k] + e] = P.tcol[k][e0[k] + e];
+        lw[P.loff[k] + e] = P.tval[k][e0[k] + e];
+      }
+    }
+  }
+  __syncthreads();
+  int lo[3], hi[3], bo[3], B[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (k < P.d && P.contracted[k]) {
+      lo[k] = len[k] > 0 ? la[P.loff[k]] : 0;
+      hi[k] = len[k] > 0 ? la[P.loff[k] + len[k] - 1] : 0;
+    } else
+      lo[k] = hi[k] = (k < P.d) ? I[k] : 0;
+    const int nk = (k < P.d) ? P.nin[k] : 1;
+    bo[k] = max(0, lo[k] - P.W[k]);
+    B[k] = min(nk - 1, hi[k] + P.W[k]) - bo[k] + 1;
+  }
+  int nbox = B[0] * B[1] * B[2];
+  if (nbox > P.cap) {  // uniform
+    if (tid == 0) atomicMax(status, TG_BOX_TOOBIG);
+    return;
+  }
+  // ---- round 2 (all issued together): output ranges of the contraction (first/last column of
+  // the rows [bo, bo+B) of M_k), descriptors of the first chunk of operand rows, box clearing
+  for (int k = 0; k < P.d; k++) {
+    if (!P.contracted[k]) continue;
+    for (int a = tid; a < B[k]; a += NT) {
+      const int p0 = P.mrp[k][bo[k] + a], p1 = P.mrp[k][bo[k] + a + 1];
+      if (p1 > p0) {
+        atomicMin(&misc[8 + 2 * k], P.mcol[k][p0]);
+        atomicMax(&misc[9 + 2 * k], P.mcol[k][p1 - 1]);
+      }
+    }
+  }
+  for (int s = tid; s < nbox; s += NT) {
+    buf0[s] = 0.0;
+    fl0[s] = 0;
+  }
+  const int ncombo = len[0] * len[1] * len[2];
+  const int64_t n01 = (int64_t)P.nin[0] * P.nin[1];
+  bool range = false, outside = false, toobig = false;
+  auto stage_rows = [&](int c0) {
+    const int c = c0 + tid;
+    if (c < ncombo) {
+      const int q0 = c % len[0];
+      const int q12 = c / len[0];
+      const int q1 = q12 % len[1];
+      const int q2 = q12 / len[1];
+      const int qq[3] = {q0, q1, q2};
+      int r[3];
+      double w = 1.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if (k < P.d && P.contracted[k]) {
+          r[k] = la[P.loff[k] + qq[k]];
+          w *= lw[P.loff[k] + qq[k]];
+        } else
+          r[k] = lo[k];
+      }
+      const int64_t lr = (int64_t)r[0] + (int64_t)P.nin[0] * r[1] + n01 * r[2] - P.row0;
+      if (lr < 0 || lr >= P.nrows) {
+        range = true;
+        pre_len[tid] = 0;
+        pre_start[tid] = 0;
+      } else {
+        const int64_t s0 = P.rowptr[lr];
+        pre_start[tid] = s0;
+        pre_len[tid] = (int)(P.rowptr[lr + 1] - s0);
+      }
+      pre_w[tid] = w;
+    }
+  };
+  stage_rows(0);
+  __syncthreads();
+  // table slices of the contraction stage: rows ilo..ihi of F_k^T, clipped to the box -> LDS
+  // (issued now, consumed after stage 1)
+  int ilo[3], D[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    ilo[k] = misc[8 + 2 * k];
+    const int ih = misc[9 + 2 * k];
+    D[k] = (k < P.d && P.contracted[k] && ih >= ilo[k]) ? ih - ilo[k] + 1 : 0;
+    if (D[k] > TG_BOX_MAXD) toobig = true;   // cannot happen: the host sized the tables from the same data
+  }
+  if (!toobig) {
+    const int k = tid >> 7 ? 2 : (tid >> 6 ? 1 : 0);
+    const int q = (k == 2) ? tid - 128 : (tid & 63);
+    if (k < P.d && P.contracted[k] && q < D[k]) {
+      // thread q copies the entries of row ilo+q that fall into the box; slot q*stride
+      const int iout = ilo[k] + q;
+      const int t0 = P.trp[k][iout], t1 = P.trp[k][iout + 1];
+      const int stride = P.cstr[k];
+      int n = 0;
+      for (int t = t0; t < t1 && n < stride; t++) {
+        const int a = P.tcol[k][t] - bo[k];
+        if ((unsigned)a < (unsigned)B[k]) {
+          ca[P.coff[k] + q * stride + n] = a;
+          cw[P.coff[k] + q * stride + n] = P.tval[k][t];
+          n++;
+        }
+      }
+      cptr[k * TG_BOX_MAXD + q] = n;
+    }
+  }
+
+  // ---- stage 1: scatter the weighted input rows into the dense box
+  for (int c0 = 0; c0 < ncombo; c0 += NT) {
+    if (c0 > 0) {
+      stage_rows(c0);
+      __syncthreads();
+    }
+    const int nch = min(NT, ncombo - c0);
+    const int sub = tid & (P.g1 - 1);
+    const int grp = tid >> P.lg1;
+    const int ngrp = NT >> P.lg1;
+    for (int le = grp; le < nch; le += ngrp) {
+      const int64_t start = pre_start[le];
+      const int ln = pre_len[le];
+      const double w = pre_w[le];
+      for (int o = sub; o < ln; o += P.g1 * TG_BOX_UNROLL) {
+        int32_t cc[TG_BOX_UNROLL];
+        double vv[TG_BOX_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TG_BOX_UNROLL; u++) {
+          const int oo = min(o + u * P.g1, ln - 1);
+          cc[u] = P.col[start + oo];
+          vv[u] = P.val[start + oo];
+        }
+#pragma unroll
+        for (int u = 0; u < TG_BOX_UNROLL; u++) {
+          if (o + u * P.g1 < ln) {
+            unsigned s2, sm, s1, s0;
+            tg_divmod((unsigned)cc[u], (unsigned)n01, P.inv_n01, &s2, &sm);
+            tg_divmod(sm, (unsigned)P.nin[0], P.inv_n0, &s1, &s0);
+            const int x0 = (int)s0 - bo[0], x1 = (int)s1 - bo[1], x2 = (int)s2 - bo[2];
+            if ((unsigned)x0 < (unsigned)B[0] && (unsigned)x1 < (unsigned)B[1] && (unsigned)x2 < (unsigned)B[2]) {
+              const int slot = x0 + B[0] * (x1 + B[1] * x2);
+              if (MODE != TG_BOXMODE_PROBE) unsafeAtomicAdd(&buf0[slot], w * vv[u]);
+              fl0[slot] = 1;
+            } else
+              outside = true;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (range) atomicMax(status, TG_BOX_RANGE);
+  if (outside) atomicMax(status, TG_BOX_OUTSIDE);
+  if (toobig) {
+    if (tid == 0) atomicMax(status, TG_BOX_TOOBIG);
+    return;
+  }
+
+  // ---- stage 2: contract the box with F_k, one direction after the other (LDS only, no atomics)
+  double *src = buf0, *dst = buf1;
+  uint8_t *fs = fl0, *fd = fl1;
+  int org[3] = {bo[0], bo[1], bo[2]};
+  for (int k = 0; k < P.d; k++) {
+    if (!P.contracted[k]) continue;      // uniform
+    int nB[3] = {B[0], B[1], B[2]};
+    nB[k] = D[k];
+    const int nnew = nB[0] * nB[1] * nB[2];
+    if (nnew > ((dst == buf0) ? P.cap : P.cap1)) {
+      if (tid == 0) atomicMax(status, TG_BOX_TOOBIG);
+      return;
+    }
+    for (int o = tid; o < nnew; o += NT) {
+      const int y0 = o % nB[0];
+      const int y12 = o / nB[0];
+      const int y1 = y12 % nB[1];
+      const int y2 = y12 / nB[1];
+      int y[3] = {y0, y1, y2};
+      const int q = y[k];
+      const int n = cptr[k * TG_BOX_MAXD + q];
+      const int sk = (k == 0) ? 1 : (k == 1 ? B[0] : B[0] * B[1]);   // stride of direction k in src
+      y[k] = 0;
+      const int base = y[0] + B[0] * (y[1] + B[1] * y[2]);
+      double acc = 0.0;
+      uint8_t tch = 0;
+      for (int t = 0; t < n; t++) {
+        const int si = base + sk * ca[P.coff[k] + q * P.cstr[k] + t];
+        acc += src[si] * cw[P.coff[k] + q * P.cstr[k] + t];
+        tch |= fs[si];
+      }
+      dst[o] = acc;
+      fd[o] = tch;
+    }
+    __syncthreads();
+    B[k] = D[k];
+    org[k] = ilo[k];
+    double *tp = src;
+    src = dst;
+    dst = tp;
+    uint8_t *tf = fs;
+    fs = fd;
+    fd = tf;
+  }
+  nbox = B[0] * B[1] * B[2];
+
+  // ---- count, place and write the touched entries in column order
+  int cnt_local = 0;
+  for (int s = tid; s < nbox; s += NT) cnt_local += fs[s] ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) cnt_local += __shfl_down(cnt_local, o, 64);
+  if ((tid & 63) == 0 && cnt_local) atomicAdd(&misc[0], cnt_local);
+  __syncthreads();
+  const int nK = misc[0];
+  if (MODE == TG_BOXMODE_PROBE) {
+    if (tid == 0) {
+      row_cnt[li] = nK;
+      atomicMax(&maxima[0], nbox);
+      atomicMax(&maxima[1], nK);
+    }
+    return;
+  }
+  if (tid == 0) {
+    const unsigned long long o = atomicAdd(cursor, (unsigned long long)nK);
+    pre_start[0] = (int64_t)o;
+    row_cnt[li] = nK;
+    row_off[li] = (int64_t)o;
+  }
+  __syncthreads();
+  const int64_t out0 = pre_start[0];
+  if (out0 + nK > capacity) {
+    if (tid == 0) atomicMax(status, TG_BOX_CAP);
+    return;
+  }
+  const bool mrow = mask ? (mask[R] != 0) : false;
+  const int64_t m0 = P.nout[0], m01 = (int64_t)P.nout[0] * P.nout[1];
+  int base = 0;
+  for (int s0 = 0; s0 < nbox; s0 += NT) {
+    const int s = s0 + tid;
+    const bool occ = (s < nbox) && fs[s];
+    const unsigned long long bm = __ballot(occ);
+    const int wv = tid >> 6, ln = tid & 63;
+    if (ln == 0) misc[16 + wv] = __popcll(bm);
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < wv; q++) woff += misc[16 + q];
+    const int chunk_total = misc[16] + misc[17] + misc[18] + misc[19];
+    if (occ) {
+      const unsigned long long below = (ln == 0) ? 0ull : (~0ull >> (64 - ln));
+      const int rank = base + woff + __popcll(bm & below);
+      const int x0 = s % B[0];
+      const int x12 = s / B[0];
+      const int x1 = x12 % B[1];
+      const int x2 = x12 / B[1];
+      const int64_t c = (int64_t)(org[0] + x0) + m0 * (org[1] + x1) + m01 * (org[2] + x2);
+      double v = src[s];
+      if (mask && (mrow || mask[c])) v = (mrow && c == R) ? diag : 0.0;
+      k_col[out0 + rank] = (int32_t)c;
+      k_val[out0 + rank] = v;
+    }
+    base += chunk_total;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_box_reorder(const int64_t *__restrict__ rowptr, const int64_t *__restrict__ tmp_off,
+                  const int32_t *__restrict__ tcol, const double *__restrict__ tval, int64_t nrows,
+                  int32_t *__restrict__ col, double *__restrict__ val) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    const int64_t dst = rowptr[r], n = rowptr[r + 1] - dst, src = tmp_off[r];
+    for (int64_t q = lane; q < n; q += 64) {
+      col[dst + q] = tcol[src + q];
+      val[dst + q] = tval[src + q];
+    }
+  }
+}
+
+static size_t tg_box_lds(int cap, int cap1, int ctab, int nlist) {
+  size_t b = ((size_t)cap + cap1) * 8 + TG_BOX_NT * 16 + (size_t)nlist * 8 + (size_t)ctab * 8;   // f64 / i64 part
+  b += TG_BOX_NT * 4 + 128 + (size_t)nlist * 4 + 3 * TG_BOX_MAXD * 4 + (size_t)ctab * 4;
+  b += (size_t)cap * 2 + 64;
+  return b;
+}
+
+// returns 0 ok, 100 = "use the general kernel" (box too large / not applicable), other = error
+extern "C" int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in,
+                            const tg_kron1d_t *fac, int64_t out_row0, int64_t out_row1, const int32_t *zero_dofs,
+                            int64_t nzero, double diag, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(cur && d >= 1 && d <= 3 && dims_in && fac && out && out_row1 >= out_row0, "bad arguments to tg_ptap_kron");
+  static bool lim = false;
+  if (!lim) {
+    hipFuncSetAttribute((const void *)k_ptap_box<TG_BOXMODE_PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    hipFuncSetAttribute((const void *)k_ptap_box<TG_BOXMODE_BUMP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    lim = true;
+  }
+  tg_box_args P;
+  memset(&P, 0, sizeof(P));
+  P.rowptr = cur->rowptr;
+  P.col = cur->col;
+  P.val = cur->val;
+  P.row0 = cur_row0;
+  P.nrows = cur->nrows;
+  P.d = d;
+  int64_t nin_total = 1, nout_total = 1;
+  std::vector<void *> dev;
+  int rc = 0;
+  int maxlen[3] = {1, 1, 1};
+  for (int k = 0; k < 3; k++) {
+    P.nin[k] = P.nout[k] = 1;
+    P.contracted[k] = 0;
+  }
+  for (int k = 0; k < d && !rc; k++) {
+    TG_REQUIRE(dims_in[k] >= 1 && dims_in[k] < (1ll << 31), "bad input dimension %d", k);
+    P.nin[k] = (int)dims_in[k];
+    P.nout[k] = P.nin[k];
+    if (fac[k].rowptr) {
+      const tg_kron1d_t &F = fac[k];
+      TG_REQUIRE(F.n == dims_in[k] && F.m >= 1 && F.col && F.val && F.t_rowptr && F.t_col && F.t_val,
+                 "bad 1-D factor %d", k);
+      P.contracted[k] = 1;
+      P.nout[k] = (int)F.m;
+      const int64_t nnz1 = F.rowptr[F.n];
+      int32_t *a = nullptr, *b = nullptr, *c = nullptr, *e = nullptr;
+      double *v = nullptr, *tv = nullptr;
+      rc = tg_dmalloc(&a, F.n + 1) || tg_dmalloc(&b, nnz1) || tg_dmalloc(&v, nnz1) || tg_dmalloc(&c, F.m + 1) ||
+           tg_dmalloc(&e, nnz1) || tg_dmalloc(&tv, nnz1);
+      dev.insert(dev.end(), {(void *)a, (void *)b, (void *)v, (void *)c, (void *)e, (void *)tv});
+      if (rc) break;
+      hipMemcpyAsync(a, F.rowptr, (F.n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+      hipMemcpyAsync(b, F.col, nnz1 * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+      hipMemcpyAsync(v, F.val, nnz1 * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
+      hipMemcpyAsync(c, F.t_rowptr, (F.m + 1) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+      hipMemcpyAsync(e, F.t_col, nnz1 * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+      hipMemcpyAsync(tv, F.t_val, nnz1 * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
+      P.mrp[k] = a;
+      P.mcol[k] = b;
+      P.mval[k] = v;
+      P.trp[k] = c;
+      P.tcol[k] = e;
+      P.tval[k] = tv;
+      for (int64_t i = 0; i < F.m; i++) {
+        const int p0 = F.t_rowptr[i], p1 = F.t_rowptr[i + 1];
+        if (p1 > p0) maxlen[k] = std::max(maxlen[k], F.t_col[p1 - 1] - F.t_col[p0] + 1);
+      }
+    }
+    nin_total *= P.nin[k];
+    nout_total *= P.nout[k];
+  }
+  auto cleanup = [&]() {
+    hipStreamSynchronize(g_tg.stream);
+    for (void *p : dev) tg_dfree(p);
+  };
+  if (rc) {
+    cleanup();
+    return rc;
+  }
+  if (!(out_row1 <= nout_total && cur->ncols == nin_total)) {
+    cleanup();
+    tg_set_error("tg_ptap_kron: index spaces do not match the operands (cols %lld vs %lld)", (long long)cur->ncols,
+                 (long long)nin_total);
+    return 2;
+  }
+  // measured bandwidth of cur per direction
+  int *status = (int *)g_tg.scratch;     // [0] status, [1..2] maxima, [4..6] bandwidth
+  hipMemsetAsync(status, 0, 8 * sizeof(int), g_tg.stream);
+  if (cur->nrows > 0)
+    hipLaunchKernelGGL(k_box_bandwidth, dim3((unsigned)std::min<int64_t>(tg_cdiv(cur->nrows, 4), (int64_t)g_tg.num_cu * 16)),
+                       dim3(256), 0, g_tg.stream, cur->rowptr, cur->col, cur->nrows, cur_row0, P.nin[0], P.nin[1],
+                       status + 4);
+  int hw[3] = {0, 0, 0};
+  hipMemcpyAsync(hw, status + 4, 3 * sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
+  hipStreamSynchronize(g_tg.stream);
+  int64_t boxmax = 1;
+  for (int k = 0; k < 3; k++) {
+    P.W[k] = hw[k];
+    const int nk = P.nin[k];
+    boxmax *= std::min<int64_t>(nk, (int64_t)maxlen[k] + 2 * hw[k]);
+  }
+  int cap = (int)std::min<int64_t>(boxmax, 1 << 20);
+  cap = (cap + 7) & ~7;
+  // per direction: largest box, most output indices reachable from a box, table/list layout
+  int maxB[3], Dmax[3] = {1, 1, 1};
+  int ctab = 0, nlist = 0, maxl = 1;
+  for (int k = 0; k < 3; k++) {
+    maxB[k] = (int)std::min<int64_t>(P.nin[k], (int64_t)maxlen[k] + 2 * hw[k]);
+    P.coff[k] = ctab;
+    P.cstr[k] = 0;
+    P.loff[k] = nlist;
+    if (k < d && P.contracted[k]) {
+      const tg_kron1d_t &F = fac[k];
+      Dmax[k] = 1;
+      for (int64_t a0 = 0; a0 + 1 <= F.n; a0++) {
+        const int64_t a1 = std::min<int64_t>(F.n, a0 + maxB[k]) - 1;
+        int c0 = 0x7fffffff, c1 = -1;
+        // first / last column over the rows of the window (rows are sorted; scan ends only)
+        for (int64_t a = a0; a <= a1; a++)
+          if (F.rowptr[a + 1] > F.rowptr[a]) {
+            c0 = std::min(c0, F.col[F.rowptr[a]]);
+            break;
+          }
+        for (int64_t a = a1; a >= a0; a--)
+          if (F.rowptr[a + 1] > F.rowptr[a]) {
+            c1 = std::max(c1, F.col[F.rowptr[a + 1] - 1]);
+            break;
+          }
+        if (c1 >= c0) Dmax[k] = std::max(Dmax[k], c1 - c0 + 1);
+      }
+      maxl = std::max(maxl, maxlen[k]);
+      int rowmax = 1;     // longest row of F^T (entries)
+      for (int64_t i = 0; i < F.m; i++) rowmax = std::max(rowmax, F.t_rowptr[i + 1] - F.t_rowptr[i]);
+      P.cstr[k] = rowmax;
+      ctab += Dmax[k] * rowmax;
+      nlist += rowmax;
+    }
+  }
+  ctab = (ctab + 7) & ~7;
+  nlist = (nlist + 7) & ~7;
+  // second buffer: sizes after the 1st and 3rd contraction
+  int64_t sz[4];
+  int nc = 0;
+  {
+    int64_t cur[3] = {maxB[0], maxB[1], maxB[2]};
+    for (int k = 0; k < d; k++)
+      if (P.contracted[k]) {
+        cur[k] = Dmax[k];
+        sz[nc++] = cur[0] * cur[1] * cur[2];
+      }
+  }
+  int64_t c1need = 8;
+  for (int q = 0; q < nc; q += 2) c1need = std::max(c1need, sz[q]);
+  for (int q = 1; q < nc; q += 2) cap = (int)std::max<int64_t>(cap, sz[q]);
+  const int cap1 = (int)((c1need + 7) & ~7);
+  P.ctab = ctab;
+  P.nlist = nlist;
+  P.cap1 = cap1;
+  bool too_many = false;
+  for (int k = 0; k < 3; k++) too_many |= Dmax[k] > TG_BOX_MAXD;
+  const size_t lds = tg_box_lds(cap, cap1, ctab, nlist);
+  if (boxmax > (1 << 20) || lds > 150 * 1024 || maxl > TG_BOX_MAXLIST || too_many) {
+    cleanup();
+    tg_set_error("tg_ptap_kron: accumulator box (%lld entries) does not fit in LDS", (long long)boxmax);
+    return 100;
+  }
+  P.cap = cap;
+  P.inv_n01 = 1.0 / ((double)P.nin[0] * (double)P.nin[1]);
+  P.inv_n0 = 1.0 / (double)P.nin[0];
+  if ((int64_t)P.nin[0] * P.nin[1] >= (1ll << 31) || nin_total >= (1ll << 31)) {
+    cleanup();
+    tg_set_error("tg_ptap_kron: index space too large for 32-bit decomposition");
+    return 100;
+  }
+  const double avg = cur->nrows ? (double)cur->nnz / (double)cur->nrows : 1.0;
+  {
+    const char *s = getenv("TIGAR_BOX_G1");
+    int g = s ? atoi(s) : 4;
+    if (!s) while (g < 64 && g * 2 <= avg * 0.44) g <<= 1;
+    P.g1 = g;
+    P.lg1 = 0;
+    while ((1 << P.lg1) < g) P.lg1++;
+  }
+  P.out_row0 = out_row0;
+  P.out_nrows = out_row1 - out_row0;
+  P.row_stride = 1;
+  const int64_t nrows = P.out_nrows;
+  tg_csr_s *k = nullptr;
+  uint8_t *mask = nullptr;
+  int64_t *cnt = nullptr, *off = nullptr;
+  unsigned long long *cursor = nullptr;
+  int32_t *tcol = nullptr;
+  double *tval = nullptr;
+  if (nrows == 0) {
+    rc = tg_csr_alloc(0, nout_total, 0, &k);
+    if (!rc) hipMemsetAsync(k->rowptr, 0, sizeof(int64_t), g_tg.stream);
+  } else {
+    if (nzero > 0) rc = tg_build_dof_mask(zero_dofs, nzero, nout_total, &mask);
+    if (!rc) rc = tg_dmalloc(&cnt, nrows + 1) || tg_dmalloc(&off, nrows + 1) || tg_dmalloc(&cursor, 1);
+    double mean_k = 0.0;
+    int hmax[3] = {0, 0, 0};
+    if (!rc) {
+      // probe a sample of rows: mean row length -> capacity of the temporary
+      tg_box_args S = P;
+      const int64_t nsample = std::min<int64_t>(nrows, 512);
+      S.out_nrows = nsample;
+      S.row_stride = std::max<int64_t>(1, nrows / nsample);
+      hipMemsetAsync(cnt, 0, (size_t)(nrows + 1) * sizeof(int64_t), g_tg.stream);
+      hipMemsetAsync(status, 0, 3 * sizeof(int), g_tg.stream);
+      hipLaunchKernelGGL((k_ptap_box<TG_BOXMODE_PROBE>), dim3((unsigned)(tg_cdiv(nsample, 8) * 8)), dim3(TG_BOX_NT), lds,
+                         g_tg.stream, S, cnt, (int64_t *)nullptr, (int32_t *)nullptr, (double *)nullptr,
+                         (unsigned long long *)nullptr, (int64_t)0, (const uint8_t *)nullptr, 0.0, status, status + 1);
+      hipMemcpyAsync(hmax, status, 3 * sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
+      int64_t total = 0;
+      rc = tg_exclusive_scan_i64(cnt, nrows, &total);
+      hipStreamSynchronize(g_tg.stream);
+      if (!rc && hmax[0] == TG_BOX_TOOBIG) rc = 100;
+      if (!rc && hmax[0] == TG_BOX_RANGE) {
+        tg_set_error("tg_ptap_kron: the row block does not cover the rows referenced (slab halo too small)");
+        rc = 3;
+      }
+      mean_k = (double)total / (double)nsample;
+    }
+    int64_t capacity = (int64_t)(mean_k * 1.05 * (double)nrows) + hmax[2] + 1024;
+    for (int attempt = 0; attempt < 6 && !rc; attempt++) {
+      rc = tg_dmalloc(&tcol, capacity + TG_CSR_PAD) || tg_dmalloc(&tval, capacity + TG_CSR_PAD);
+      if (rc) break;
+      hipMemsetAsync(status, 0, 3 * sizeof(int), g_tg.stream);
+      hipMemsetAsync(cursor, 0, sizeof(unsigned long long), g_tg.stream);
+      hipMemsetAsync(cnt, 0, (size_t)(nrows + 1) * sizeof(int64_t), g_tg.stream);
+      hipLaunchKernelGGL((k_ptap_box<TG_BOXMODE_BUMP>), dim3((unsigned)(tg_cdiv(nrows, 8) * 8)), dim3(TG_BOX_NT), lds,
+                         g_tg.stream, P, cnt, off, tcol, tval, cursor, capacity, (const uint8_t *)mask, diag, status,
+                         status + 1);
+      int h = 0;
+      unsigned long long used = 0;
+      hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
+      hipMemcpyAsync(&used, cursor, sizeof(used), hipMemcpyDeviceToHost, g_tg.stream);
+      if (hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        tg_set_error("tg_ptap_kron: kernel failed to run (LDS %zu B)", lds);
+        rc = 1;
+        break;
+      }
+      if (h == TG_BOX_OK) break;
+      tg_dfree(tcol);
+      tg_dfree(tval);
+      tcol = nullptr;
+      tval = nullptr;
+      if (h == TG_BOX_CAP) {
+        capacity = std::max<int64_t>((int64_t)used + 1024, capacity * 2);
+        continue;
+      }
+      if (h == TG_BOX_TOOBIG) {
+        rc = 100;
+        break;
+      }
+      tg_set_error("tg_ptap_kron: kernel status %d", h);
+      rc = h == TG_BOX_RANGE ? 3 : 4;
+    }
+    if (!rc) {
+      int64_t nnz = 0;
+      rc = tg_exclusive_scan_i64(cnt, nrows, &nnz);
+      if (!rc) rc = tg_csr_alloc(nrows, nout_total, nnz, &k);
+      if (!rc) {
+        hipMemcpyAsync(k->rowptr, cnt, (size_t)(nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream);
+        const unsigned rg = (unsigned)std::min<int64_t>(tg_cdiv(nrows, 4), (int64_t)g_tg.num_cu * 16);
+        hipLaunchKernelGGL(k_box_reorder, dim3(rg), dim3(256), 0, g_tg.stream, k->rowptr, off, tcol, tval, nrows, k->col,
+                           k->val);
+        if (hipGetLastError() != hipSuccess) {
+          tg_set_error("tg_ptap_kron: reorder launch failed");
+          rc = 1;
+        }
+      }
+    }
+  }
+  hipStreamSynchronize(g_tg.stream);
+  tg_dfree(cnt);
+  tg_dfree(off);
+  tg_dfree(cursor);
+  tg_dfree(tcol);
+  tg_dfree(tval);
+  tg_dfree(mask);
+  cleanup();
+  if (rc) {
+    if (k) tg_csr_destroy(k);
+    return rc;
+  }
+  *out = k;
+  return 0;
+}

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import check, handle, tg_dir_t, tg_kron_dir_t, c_f64p, c_i32p, c_i64p
+from ._lib import check, handle, tg_dir_t, tg_kron_dir_t, tg_kron1d_t, c_f64p, c_i32p, c_i64p
 
 TG_KSP_CG, TG_KSP_GMRES = 0, 1
 TG_PC_NONE, TG_PC_JACOBI = 0, 1
@@ -350,6 +350,42 @@ def ptap_numeric(plan, A, M, MT, zero_dofs=None, diag=1.0):
     else:
         check(_lib.lib().tg_ptap_numeric(plan._h, A._h, M._h, MT._h, None, 0, float(diag), C.byref(h)),
               "tg_ptap_numeric")
+    return DeviceCSR(h)
+
+
+def ptap_kron(cur, cur_row0, dims_in, factors, out_row0, out_row1, zero_dofs=None, diag=1.0):
+    """One Kronecker contraction stage out = P^T cur P (dense-box kernel).  ``factors[k]`` is a
+    scipy CSR 1-D matrix (n_k x m_k) or None for the identity.  Returns None when the kernel
+    declines (accumulator box too large for LDS) -- the caller then uses the general PtAP."""
+    import scipy.sparse as sp
+    d = len(dims_in)
+    arr = (tg_kron1d_t * d)()
+    keep = []
+    for k in range(d):
+        F = factors[k]
+        if F is None:
+            arr[k].n = int(dims_in[k])
+            arr[k].m = int(dims_in[k])
+            arr[k].rowptr = None
+            continue
+        F = sp.csr_matrix(F)
+        F.sort_indices()
+        FT = F.T.tocsr()
+        FT.sort_indices()
+        bufs = [_i32(F.indptr), _i32(F.indices), _f64(F.data), _i32(FT.indptr), _i32(FT.indices), _f64(FT.data)]
+        keep += bufs
+        arr[k].n, arr[k].m = F.shape
+        arr[k].rowptr, arr[k].col, arr[k].val = _p(bufs[0], c_i32p), _p(bufs[1], c_i32p), _p(bufs[2], c_f64p)
+        arr[k].t_rowptr, arr[k].t_col, arr[k].t_val = _p(bufs[3], c_i32p), _p(bufs[4], c_i32p), _p(bufs[5], c_f64p)
+    dims = _i64(dims_in)
+    h = handle()
+    zd = _i32(zero_dofs) if zero_dofs is not None and len(zero_dofs) else None
+    rc = _lib.lib().tg_ptap_kron(cur._h, int(cur_row0), d, _p(dims, c_i64p), arr, int(out_row0), int(out_row1),
+                                 _p(zd, c_i32p) if zd is not None else None, zd.size if zd is not None else 0,
+                                 float(diag), C.byref(h))
+    if rc == 100:
+        return None
+    check(rc, "tg_ptap_kron")
     return DeviceCSR(h)
 
 

@@ -88,6 +88,13 @@ def contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs=None,
     of  P^T cur P,  where ``cur`` holds the planes ``a_planes`` of the current space (global
     columns within the planes ``c_planes``) and P contracts the directions in ``group``."""
     pl_in = kx.plane(done)
+    import os
+    if os.environ.get("TIGAR_PTAP_BOX", "1") != "0":
+        dims_in = kx.dims(done)
+        factors = [kx.M1[k] if k in group else None for k in range(kx.d)]
+        out = _dev.ptap_kron(cur, a_planes[0] * pl_in, dims_in, factors, out_rows[0], out_rows[1], zero_dofs, diag)
+        if out is not None:
+            return out
     MT = kx.PT(done, group, out_rows[0], out_rows[1])
     Pm = kx.P(done, group, c_planes[0] * pl_in, c_planes[1] * pl_in)
     plan = _dev.ptap_symbolic(cur, Pm, MT, a_planes[0] * pl_in, c_planes[0] * pl_in, out_rows[0])
