@@ -34,7 +34,7 @@ struct tg_box_args {
   const double *tval[3];
   int W[3];                     // measured bandwidth of cur per direction
   int64_t out_row0, out_nrows, row_stride;
-  double inv_n01, inv_n0;       // reciprocals for the index decomposition
+  unsigned mg01, sh01, mg0, sh0; // magic numbers: s / (n0*n1) and s / n0 for 0 <= s < 2^31
   int cap;                      // doubles per LDS buffer
   int cap1;                     // doubles of the second (ping-pong) buffer
   int ctab;                     // total entries of the contraction-table slices
@@ -43,19 +43,29 @@ struct tg_box_args {
   int g1, lg1;                  // lanes per input row in stage 1
 };
 
-// s = q*dsr + r for 0 <= s < 2^31 via an fp64 reciprocal (exact after one correction step)
-__device__ __forceinline__ void tg_divmod(unsigned s, unsigned dsr, double inv, unsigned *q, unsigned *r) {
-  unsigned qq = (unsigned)((double)s * inv);
-  int rr = (int)(s - qq * dsr);
-  if (rr < 0) {
-    qq--;
-    rr += (int)dsr;
-  } else if ((unsigned)rr >= dsr) {
-    qq++;
-    rr -= (int)dsr;
-  }
+// s = q*dsr + r for 0 <= s < 2^31 by multiplication with a precomputed magic number:
+// q = umulhi(s, mg) >> sh  (exact: mg = ceil(2^(32+sh) / dsr), sh = ceil(log2 dsr) - 1 when dsr > 1)
+__device__ __forceinline__ void tg_divmod(unsigned s, unsigned dsr, unsigned mg, unsigned sh, unsigned *q,
+                                          unsigned *r) {
+  const unsigned qq = mg ? (__umulhi(s, mg) >> sh) : (s >> sh);   // mg == 0: dsr is a power of two
   *q = qq;
-  *r = (unsigned)rr;
+  *r = s - qq * dsr;
+}
+
+static void tg_magic(unsigned d, unsigned *mg, unsigned *sh) {
+  if ((d & (d - 1)) == 0) {   // power of two (incl. 1)
+    unsigned l = 0;
+    while ((1u << l) < d) l++;
+    *mg = 0;
+    *sh = l;
+    return;
+  }
+  unsigned l = 0;
+  while ((1ull << l) < d) l++;          // 2^(l-1) < d < 2^l
+  const unsigned s = l - 1;
+  const unsigned long long num = 1ull << (32 + s);
+  *mg = (unsigned)((num + d - 1) / d);  // < 2^32 because d > 2^(l-1)
+  *sh = s;
 }
 
 enum { TG_BOX_OK = 0, TG_BOX_TOOBIG = 1, TG_BOX_RANGE = 2, TG_BOX_CAP = 3, TG_BOX_OUTSIDE = 4 };
@@ -103,7 +113,6 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-#define TG_BOX_NT 256
 #define TG_BOX_UNROLL 4
 #define TG_BOX_MAXLIST 96     // longest 1-D support list (entries of one row of F_k^T)
 #define TG_BOX_MAXD 48        // most output indices per direction reachable from one box
@@ -114,13 +123,12 @@ __global__ void __launch_bounds__(256)
 // The per-row critical path is a chain of dependent global loads, so everything the row needs
 // from the small 1-D tables is fetched in two cooperative rounds at the start (support lists,
 // then operand-row descriptors + the table slices of the contraction stage) and kept in LDS.
-template <int MODE>
-__global__ void __launch_bounds__(TG_BOX_NT)
+template <int MODE, int NT>
+__global__ void __launch_bounds__(NT)
     k_ptap_box(tg_box_args P, int64_t *__restrict__ row_cnt, int64_t *__restrict__ row_off,
                int32_t *__restrict__ k_col, double *__restrict__ k_val, unsigned long long *__restrict__ cursor,
                int64_t capacity, const uint8_t *__restrict__ mask, double diag, int *__restrict__ status,
                int *__restrict__ maxima) {
-  constexpr int NT = TG_BOX_NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *buf0 = reinterpret_cast<double *>(smem);
   double *buf1 = buf0 + P.cap;
@@ -162,11 +170,10 @@ __global__ void __launch_bounds__(TG_BOX_NT)
     }
   }
   if (tid < 32) misc[tid] = (tid == 8 || tid == 10 || tid == 12) ? 0x7fffffff : ((tid == 9 || tid == 11 || tid == 13) ? -1 : 0);
-  {
-    const int k = tid >> 7 ? 2 : (tid >> 6 ? 1 : 0);      // waves 0,1 -> dirs 0,1 ; waves 2,3 -> dir 2
-    const int q = (k == 2) ? tid - 128 : (tid & 63);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
     if (k < P.d && P.contracted[k]) {
-      for (int e = q; e < len[k]; e += (k == 2 ? 128 : 64)) {
+      for (int e = tid; e < len[k]; e += NT) {
         la[P.loff[k] + e] = P.tcol[k][e0[k] + e];
         lw[P.loff[k] + e] = P.tval[k][e0[k] + e];
       }
@@ -253,9 +260,22 @@ __global__ void __launch_bounds__(TG_BOX_NT)
     if (D[k] > TG_BOX_MAXD) toobig = true;   // cannot happen: the host sized the tables from the same data
   }
   if (!toobig) {
-    const int k = tid >> 7 ? 2 : (tid >> 6 ? 1 : 0);
-    const int q = (k == 2) ? tid - 128 : (tid & 63);
-    if (k < P.d && P.contracted[k] && q < D[k]) {
+    // one (direction, output row) pair per thread, spread over the workgroup
+    int k = -1, q = 0;
+    {
+      int t = tid;
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) {
+        if (k < 0 && kk < P.d && P.contracted[kk]) {
+          if (t < D[kk]) {
+            k = kk;
+            q = t;
+          } else
+            t -= D[kk];
+        }
+      }
+    }
+    if (k >= 0) {
       // thread q copies the entries of row ilo+q that fall into the box; slot q*stride
       const int iout = ilo[k] + q;
       const int t0 = P.trp[k][iout], t1 = P.trp[k][iout + 1];
@@ -300,8 +320,8 @@ __global__ void __launch_bounds__(TG_BOX_NT)
         for (int u = 0; u < TG_BOX_UNROLL; u++) {
           if (o + u * P.g1 < ln) {
             unsigned s2, sm, s1, s0;
-            tg_divmod((unsigned)cc[u], (unsigned)n01, P.inv_n01, &s2, &sm);
-            tg_divmod(sm, (unsigned)P.nin[0], P.inv_n0, &s1, &s0);
+            tg_divmod((unsigned)cc[u], (unsigned)n01, P.mg01, P.sh01, &s2, &sm);
+            tg_divmod(sm, (unsigned)P.nin[0], P.mg0, P.sh0, &s1, &s0);
             const int x0 = (int)s0 - bo[0], x1 = (int)s1 - bo[1], x2 = (int)s2 - bo[2];
             if ((unsigned)x0 < (unsigned)B[0] && (unsigned)x1 < (unsigned)B[1] && (unsigned)x2 < (unsigned)B[2]) {
               const int slot = x0 + B[0] * (x1 + B[1] * x2);
@@ -405,9 +425,12 @@ __global__ void __launch_bounds__(TG_BOX_NT)
     const int wv = tid >> 6, ln = tid & 63;
     if (ln == 0) misc[16 + wv] = __popcll(bm);
     __syncthreads();
-    int woff = 0;
-    for (int q = 0; q < wv; q++) woff += misc[16 + q];
-    const int chunk_total = misc[16] + misc[17] + misc[18] + misc[19];
+    int woff = 0, chunk_total = 0;
+#pragma unroll
+    for (int q = 0; q < NT / 64; q++) {
+      if (q < wv) woff += misc[16 + q];
+      chunk_total += misc[16 + q];
+    }
     if (occ) {
       const unsigned long long below = (ln == 0) ? 0ull : (~0ull >> (64 - ln));
       const int rank = base + woff + __popcll(bm & below);
@@ -442,9 +465,9 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-static size_t tg_box_lds(int cap, int cap1, int ctab, int nlist) {
-  size_t b = ((size_t)cap + cap1) * 8 + TG_BOX_NT * 16 + (size_t)nlist * 8 + (size_t)ctab * 8;   // f64 / i64 part
-  b += TG_BOX_NT * 4 + 128 + (size_t)nlist * 4 + 3 * TG_BOX_MAXD * 4 + (size_t)ctab * 4;
+static size_t tg_box_lds(int cap, int cap1, int ctab, int nlist, int nt) {
+  size_t b = ((size_t)cap + cap1) * 8 + (size_t)nt * 16 + (size_t)nlist * 8 + (size_t)ctab * 8;   // f64 / i64 part
+  b += (size_t)nt * 4 + 128 + (size_t)nlist * 4 + 3 * TG_BOX_MAXD * 4 + (size_t)ctab * 4;
   b += (size_t)cap * 2 + 64;
   return b;
 }
@@ -457,9 +480,13 @@ extern "C" int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t
   TG_REQUIRE(cur && d >= 1 && d <= 3 && dims_in && fac && out && out_row1 >= out_row0, "bad arguments to tg_ptap_kron");
   static bool lim = false;
   if (!lim) {
-    hipFuncSetAttribute((const void *)k_ptap_box<TG_BOXMODE_PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipFuncSetAttribute((const void *)k_ptap_box<TG_BOXMODE_PROBE, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
                         160 * 1024);
-    hipFuncSetAttribute((const void *)k_ptap_box<TG_BOXMODE_BUMP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipFuncSetAttribute((const void *)k_ptap_box<TG_BOXMODE_BUMP, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    hipFuncSetAttribute((const void *)k_ptap_box<TG_BOXMODE_PROBE, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    hipFuncSetAttribute((const void *)k_ptap_box<TG_BOXMODE_BUMP, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                         160 * 1024);
     lim = true;
   }
@@ -605,15 +632,28 @@ extern "C" int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t
   P.cap1 = cap1;
   bool too_many = false;
   for (int k = 0; k < 3; k++) too_many |= Dmax[k] > TG_BOX_MAXD;
-  const size_t lds = tg_box_lds(cap, cap1, ctab, nlist);
+  // workgroup size: one wave per output row when a row has little work (few operand rows),
+  // a full 256-thread group otherwise
+  int64_t maxcombo = 1;
+  for (int k = 0; k < 3; k++) maxcombo *= (k < d && P.contracted[k]) ? std::max(1, P.cstr[k]) : 1;
+  int nt = 256;   // (a wave-per-row variant, nt = 64, measured slower: rows in flight are LDS-bound either way)
+  (void)maxcombo;
+  if (getenv("TIGAR_BOX_NT")) nt = atoi(getenv("TIGAR_BOX_NT")) == 64 ? 64 : 256;
+  // the table slices need one thread per (direction, output index)
+  {
+    int need = 0;
+    for (int k = 0; k < 3; k++) need += (k < d && P.contracted[k]) ? Dmax[k] : 0;
+    if (need > nt) nt = 256;
+  }
+  const size_t lds = tg_box_lds(cap, cap1, ctab, nlist, nt);
   if (boxmax > (1 << 20) || lds > 150 * 1024 || maxl > TG_BOX_MAXLIST || too_many) {
     cleanup();
     tg_set_error("tg_ptap_kron: accumulator box (%lld entries) does not fit in LDS", (long long)boxmax);
     return 100;
   }
   P.cap = cap;
-  P.inv_n01 = 1.0 / ((double)P.nin[0] * (double)P.nin[1]);
-  P.inv_n0 = 1.0 / (double)P.nin[0];
+  tg_magic((unsigned)((int64_t)P.nin[0] * P.nin[1]), &P.mg01, &P.sh01);
+  tg_magic((unsigned)P.nin[0], &P.mg0, &P.sh0);
   if ((int64_t)P.nin[0] * P.nin[1] >= (1ll << 31) || nin_total >= (1ll << 31)) {
     cleanup();
     tg_set_error("tg_ptap_kron: index space too large for 32-bit decomposition");
@@ -654,9 +694,16 @@ extern "C" int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t
       S.row_stride = std::max<int64_t>(1, nrows / nsample);
       hipMemsetAsync(cnt, 0, (size_t)(nrows + 1) * sizeof(int64_t), g_tg.stream);
       hipMemsetAsync(status, 0, 3 * sizeof(int), g_tg.stream);
-      hipLaunchKernelGGL((k_ptap_box<TG_BOXMODE_PROBE>), dim3((unsigned)(tg_cdiv(nsample, 8) * 8)), dim3(TG_BOX_NT), lds,
-                         g_tg.stream, S, cnt, (int64_t *)nullptr, (int32_t *)nullptr, (double *)nullptr,
-                         (unsigned long long *)nullptr, (int64_t)0, (const uint8_t *)nullptr, 0.0, status, status + 1);
+      if (nt == 64)
+        hipLaunchKernelGGL((k_ptap_box<TG_BOXMODE_PROBE, 64>), dim3((unsigned)(tg_cdiv(nsample, 8) * 8)), dim3(64), lds,
+                           g_tg.stream, S, cnt, (int64_t *)nullptr, (int32_t *)nullptr, (double *)nullptr,
+                           (unsigned long long *)nullptr, (int64_t)0, (const uint8_t *)nullptr, 0.0, status,
+                           status + 1);
+      else
+        hipLaunchKernelGGL((k_ptap_box<TG_BOXMODE_PROBE, 256>), dim3((unsigned)(tg_cdiv(nsample, 8) * 8)), dim3(256),
+                           lds, g_tg.stream, S, cnt, (int64_t *)nullptr, (int32_t *)nullptr, (double *)nullptr,
+                           (unsigned long long *)nullptr, (int64_t)0, (const uint8_t *)nullptr, 0.0, status,
+                           status + 1);
       hipMemcpyAsync(hmax, status, 3 * sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
       int64_t total = 0;
       rc = tg_exclusive_scan_i64(cnt, nrows, &total);
@@ -675,9 +722,14 @@ extern "C" int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t
       hipMemsetAsync(status, 0, 3 * sizeof(int), g_tg.stream);
       hipMemsetAsync(cursor, 0, sizeof(unsigned long long), g_tg.stream);
       hipMemsetAsync(cnt, 0, (size_t)(nrows + 1) * sizeof(int64_t), g_tg.stream);
-      hipLaunchKernelGGL((k_ptap_box<TG_BOXMODE_BUMP>), dim3((unsigned)(tg_cdiv(nrows, 8) * 8)), dim3(TG_BOX_NT), lds,
-                         g_tg.stream, P, cnt, off, tcol, tval, cursor, capacity, (const uint8_t *)mask, diag, status,
-                         status + 1);
+      if (nt == 64)
+        hipLaunchKernelGGL((k_ptap_box<TG_BOXMODE_BUMP, 64>), dim3((unsigned)(tg_cdiv(nrows, 8) * 8)), dim3(64), lds,
+                           g_tg.stream, P, cnt, off, tcol, tval, cursor, capacity, (const uint8_t *)mask, diag, status,
+                           status + 1);
+      else
+        hipLaunchKernelGGL((k_ptap_box<TG_BOXMODE_BUMP, 256>), dim3((unsigned)(tg_cdiv(nrows, 8) * 8)), dim3(256), lds,
+                           g_tg.stream, P, cnt, off, tcol, tval, cursor, capacity, (const uint8_t *)mask, diag, status,
+                           status + 1);
       int h = 0;
       unsigned long long used = 0;
       hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
