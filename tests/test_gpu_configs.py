@@ -1,0 +1,200 @@
+"""GPU parity tests for the remaining BASELINE configs at sizes the oracle finishes in seconds:
+cfg4 (2-D p=4 C^1 biharmonic, two clamped layers, demos/biharmonic/biharmonic.py) and cfg5
+(NURBS geometry through M_control*w, three unknown fields, GMRES), plus the DG node grid."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from oracle import tigar_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import tigar_amd
+    from tigar_amd import BSplines, forms, device, NURBS
+    device.device_info()
+
+    class NS:
+        pass
+    ns = NS()
+    ns.t, ns.B, ns.F, ns.dev, ns.N = tigar_amd, BSplines, forms, device, NURBS
+    return ns
+
+
+def _biharmonic(T, nel, p=4):
+    """demos/biharmonic/biharmonic.py:46-66,100-122: (-1,1)^2, u = v = 0 and du/dn = 0 through two
+    layers of zero dofs, manufactured solution (cos(pi x)+1)(cos(pi y)+1)."""
+    B, t, F = T.B, T.t, T.F
+    kv = [B.uniformKnots(p, -1.0, 1.0, nel) for _ in range(2)]
+    gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p, p], kv))
+    sp0 = gen.getScalarSpline(0)
+    for direction in (0, 1):
+        for side in (0, 1):
+            gen.addZeroDofs(0, sp0.getSideDofs(direction, side, nLayers=2))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    c = lambda x: np.cos(np.pi * x)
+    c1 = lambda x: np.cos(np.pi * x) + 1.0
+    pi4 = np.pi ** 4
+    # lap^2 u = pi^4 cos(pi x)(cos(pi y)+1) + 2 pi^4 cos(pi x)cos(pi y) + pi^4 (cos(pi x)+1)cos(pi y)
+    load = F.SumOfSeparableLoads([([c, c1], pi4), ([c, c], 2 * pi4), ([c1, c], pi4)])
+    solver = t.PETScKrylovSolver("cg", "jacobi")
+    solver.parameters["relative_tolerance"] = 1e-12
+    solver.parameters["maximum_iterations"] = 20000
+    spline.setSolverOptions(linearSolver=solver)
+    u = t.Function(spline.V)
+    U = spline.solveLinearVariationalProblem(F.Equation(F.BiharmonicForm(), load), u)
+    return gen, spline, U, u, solver
+
+
+def test_cfg4_biharmonic_matches_oracle_and_converges(T):
+    p = 4
+    errs = []
+    for nel in (4, 8):
+        gen, spline, U, u, solver = _biharmonic(T, nel, p)
+        s = O.BSpline([p, p], [O.uniform_knots(p, -1., 1., nel)] * 2)
+        Mo = O.generate_M_tensor(s)
+        M = gen.M.to_scipy()
+        assert np.array_equal(M.indptr, Mo.indptr) and np.array_equal(M.indices, Mo.indices)
+        assert np.array_equal(M.data, Mo.data)                      # p=4 extraction bit-exact
+        Ao = O.biharmonic_fe_system_2d(s)
+        A = T.F.BiharmonicForm().assemble_matrix(spline.V).to_scipy()
+        assert abs(A - Ao).max() <= 1e-11 * abs(Ao).max()
+        zd = list(spline.zeroDofs)
+        zo = []
+        for direction in (0, 1):
+            for side in (0, 1):
+                zo += s.getSideDofs(direction, side, 2)
+        assert zd == zo                                              # duplicates (corners) kept
+        K = spline.extractMatrix(A).to_scipy()
+        Ko = O.extract_matrix(Mo, Ao, zo)
+        assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices)
+        assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+        # solution vs direct solve of the oracle system with the same load
+        X, _ = O.fe_node_grid(s)
+        bo = None
+        uk = s.splines[0].uniqueKnots
+        c = lambda x: np.cos(np.pi * x)
+        c1 = lambda x: np.cos(np.pi * x) + 1.0
+        pi4 = np.pi ** 4
+        for (fx, fy, sc) in ((c, c1, pi4), (c, c, 2 * pi4), (c1, c, pi4)):
+            term = sc * np.kron(O.fe_1d_load(uk, p, fy), O.fe_1d_load(uk, p, fx))
+            bo = term if bo is None else bo + term
+        Uo, uo = O.solve_linear_system(Mo, Ko, O.extract_vector(Mo, bo, zo), "direct")
+        assert np.linalg.norm(U.get_local() - Uo) <= 1e-7 * np.linalg.norm(Uo)
+        exact = (np.cos(np.pi * X[:, 0]) + 1.0) * (np.cos(np.pi * X[:, 1]) + 1.0)
+        errs.append(np.max(np.abs(u.vector().get_local() - exact)))
+    assert errs[1] < errs[0] / 8.0            # high-order convergence under refinement
+    assert errs[1] < 1e-3
+
+
+def _refine_control_net(coarse_spline, fine_spline, Pw):
+    """Homogeneous control net of the same geometry on a refined knot vector: solve the
+    interpolation problem at the fine Greville points (exact, the spaces are nested)."""
+    nf = fine_spline.getNcp()
+    g = np.array([fine_spline.greville(i) for i in range(nf)])
+    Nf = np.zeros((nf, nf))
+    Nc = np.zeros((nf, coarse_spline.getNcp()))
+    for r, u in enumerate(g):
+        sf = fine_spline.getKnotSpan(u)
+        Nf[r, fine_spline.getNodes(u)] = fine_spline.basisFuncs(sf, u)
+        sc = coarse_spline.getKnotSpan(u)
+        Nc[r, coarse_spline.getNodes(u)] = coarse_spline.basisFuncs(sc, u)
+    return np.linalg.solve(Nf, Nc @ Pw)
+
+
+def test_cfg5_nurbs_geometry_three_fields_gmres(T):
+    """Quarter annulus (exact circular arcs need rational weights): the weights enter only
+    through cpFuncs = M_control * (homogeneous control net); three unknown fields; non-symmetric
+    diagonally dominant FE matrix on the 3-field pattern solved with Jacobi-GMRES."""
+    t, N, dev = T.t, T.N, T.dev
+    p, nel = 2, 6
+    # coarse exact geometry: radial (linear, degree-elevated to 2) x angular (quadratic arc)
+    w = 1.0 / np.sqrt(2.0)
+    arc = np.array([[1.0, 0.0, 1.0], [w, w, w], [0.0, 1.0, 1.0]])         # (w x, w y, w), radius 1
+    rad = np.array([1.0, 1.5, 2.0])                                         # radii 1..2, degree 2 (collinear)
+    coarse = [O.BSpline1(p, [0, 0, 0, 1, 1, 1]) for _ in range(2)]
+    fine_kv = O.uniform_knots(p, 0., 1., nel)
+    fine = [O.BSpline1(p, fine_kv) for _ in range(2)]
+    # control net [i (radial), j (angular), (wx, wy, w)]
+    Pw = np.zeros((3, 3, 3))
+    for i in range(3):
+        Pw[i, :, 0] = rad[i] * arc[:, 0]
+        Pw[i, :, 1] = rad[i] * arc[:, 1]
+        Pw[i, :, 2] = arc[:, 2]
+    # refine direction by direction
+    Pr = np.stack([_refine_control_net(coarse[0], fine[0], Pw[:, j, :]) for j in range(3)], axis=1)
+    Pf = np.stack([_refine_control_net(coarse[1], fine[1], Pr[i, :, :]) for i in range(Pr.shape[0])], axis=0)
+    cm = N.NURBSControlMesh([p, p], [fine_kv, fine_kv], Pf)
+    gen = t.EqualOrderSpline(3, cm)
+    nsd = gen.getNsd()
+    assert nsd == 2 and gen.getNFields() == 3
+    # geometry at the FE nodes: F = cpFuncs[i] / cpFuncs[nsd] lies on circles of radius 1 + xi
+    s = O.BSpline([p, p], [fine_kv, fine_kv])
+    X, _ = O.fe_node_grid(s)
+    cp = [f.vector().get_local() for f in gen.cpFuncs]
+    x, y, wt = cp[0] / cp[2], cp[1] / cp[2], cp[2]
+    assert np.max(np.abs(np.hypot(x, y) - (1.0 + X[:, 0]))) < 1e-13
+    assert wt.min() > 0.7 and wt.max() <= 1.0 + 1e-14
+    Mc = O.generate_M_tensor(s)
+    bnet = np.stack([Pf[..., c].ravel(order="F") for c in range(3)], axis=1)
+    for c in range(3):
+        assert np.max(np.abs(cp[c] - Mc @ bnet[:, c])) < 1e-13
+    # three-field extraction matrix = block diagonal of the scalar one
+    Mo = O.generate_M_tensor(s, nfields=3)
+    M = gen.M.to_scipy()
+    assert M.shape == Mo.shape and abs(M - Mo).max() == 0
+    # clamp two layers on one edge, all three fields (shell-like BC)
+    for field in range(3):
+        gen.addZeroDofs(field, gen.getScalarSpline(field).getSideDofs(0, 0, nLayers=2))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    # deterministic non-symmetric, diagonally dominant FE matrix coupling the three fields
+    A1, _, _, _ = O.poisson_fe_system(s)
+    n1 = A1.shape[0]
+    pat = (abs(A1) > 0).astype(np.float64).tocsr()
+    blocks = [[None] * 3 for _ in range(3)]
+    rng = np.random.default_rng(0)
+    for a in range(3):
+        for b in range(3):
+            Bk = pat.copy()
+            Bk.data = 0.05 * rng.standard_normal(Bk.nnz)
+            blocks[a][b] = Bk
+        blocks[a][a] = blocks[a][a] + sp.identity(n1) * 4.0
+    A = sp.bmat(blocks, format="csr")
+    bvec = rng.standard_normal(A.shape[0])
+    solver = t.PETScKrylovSolver("gmres", "jacobi")
+    solver.parameters["relative_tolerance"] = 1e-11
+    spline.setSolverOptions(linearSolver=solver)
+    K = spline.extractMatrix(A)
+    rhs = spline.extractVector(bvec)
+    u = t.Function(spline.V)
+    U = spline.solveLinearSystem(K, rhs, u)
+    zd = list(spline.zeroDofs)
+    Ko = O.extract_matrix(Mo, A, zd)
+    assert abs(K.to_scipy() - Ko).max() <= 1e-12 * abs(Ko).max()
+    Uo = spla.spsolve(Ko.tocsc(), O.extract_vector(Mo, bvec, zd))
+    assert np.linalg.norm(U.get_local() - Uo) <= 1e-8 * np.linalg.norm(Uo)
+    assert np.linalg.norm(u.vector().get_local() - Mo @ Uo) <= 1e-8 * np.linalg.norm(Mo @ Uo)
+    assert solver.last["status"] == 0 and solver.last["iterations"] > 1
+    # the oracle's GMRES restatement takes a comparable number of iterations
+    _, ito, _ = O.gmres_jacobi(Ko, O.extract_vector(Mo, bvec, zd), rtol=1e-11)
+    assert abs(solver.last["iterations"] - ito) <= max(3, ito // 5)
+
+
+def test_dg_node_grid_for_discontinuous_basis(T):
+    """A basis with an interior knot of multiplicity p+1 needs DG extraction
+    (tIGAr/BSplines.py:419-427, tIGAr/common.py:167-185): nel*(p+1) nodes per direction."""
+    B, t = T.B, T.t
+    p = 2
+    kv = [0, 0, 0, 0.5, 0.5, 0.5, 1, 1, 1]
+    cm = B.ExplicitBSplineControlMesh([p, p], [kv, kv])
+    gen = t.EqualOrderSpline(1, cm)
+    assert gen.useDG() and gen.extractionElement() == "DG"
+    s = O.BSpline([p, p], [kv, kv])
+    Mo = O.generate_M_tensor(s, dg=True)
+    M = gen.M.to_scipy()
+    assert M.shape == ((2 * 3) ** 2, s.getNcp())
+    assert np.array_equal(M.indptr, Mo.indptr) and np.array_equal(M.indices, Mo.indices)
+    assert np.array_equal(M.data, Mo.data)

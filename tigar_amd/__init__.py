@@ -13,3 +13,4 @@ from .common import (AbstractExtractionGenerator, AbstractCoordinateChartSpline,
                      AbstractControlMesh, AbstractMultiFieldSpline, EqualOrderSpline, FieldListSpline,
                      ExtractedSpline, PETScKrylovSolver, KrylovSolver, Function, TensorFunctionSpace,
                      TensorNodeGrid, multTranspose, generateIdentityPermutation)
+from .NURBS import NURBSControlMesh      # noqa: E402,F401

@@ -9,7 +9,7 @@
 static double tg_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define TG_TRACE(msg) do { if (getenv("TIGAR_TRACE")) fprintf(stderr, "[trace] %s %.3f ms\n", msg, (tg_now() - _t0) * 1e3); } while (0)
 
-#define TG_KRON_MAX_TERMS 4
+#define TG_KRON_MAX_TERMS 9
 
 struct tg_kron_params {
   int d, nterms;

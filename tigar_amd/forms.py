@@ -67,6 +67,41 @@ def fe_matrices_1d(vertices, p, nq=None):
     return Mm, Km
 
 
+def fe_matrices_1d_ext(vertices, p, nq=None):
+    """(mass, stiffness, S2[a,b] = int phi_a'' phi_b'', C[a,b] = int phi_a'' phi_b) element by
+    element (no inter-element terms, as dolfin assembles ``inner(lap(u),lap(v))*dx``), all on one
+    shared pattern."""
+    nq = p + 1 if nq is None else nq
+    t, w = _gauss01(nq)
+    phi, dphi = _lagrange01(p, t)
+    # second derivatives of the equispaced Lagrange basis by differentiating the interpolant
+    nodes = numpy.arange(p + 1) / float(p)
+    V = numpy.vander(nodes, p + 1, increasing=True)          # monomial coefficients of each basis fn
+    coef = numpy.linalg.solve(V, numpy.eye(p + 1))           # coef[:, a] = monomial coeffs of phi_a
+    d2 = numpy.zeros((p + 1, len(t)))
+    for a in range(p + 1):
+        for m in range(2, p + 1):
+            d2[a] += coef[m, a] * m * (m - 1) * t ** (m - 2)
+    me = (phi * w) @ phi.T
+    ke = (dphi * w) @ dphi.T
+    s2e = (d2 * w) @ d2.T
+    ce = (d2 * w) @ phi.T
+    v = numpy.asarray(vertices, dtype=numpy.float64)
+    h = numpy.diff(v)
+    nel = len(h)
+    n = nel * p + 1
+    loc = numpy.arange(p + 1)
+    rows = (numpy.arange(nel)[:, None, None] * p + loc[None, :, None]) + 0 * loc[None, None, :]
+    cols = (numpy.arange(nel)[:, None, None] * p + loc[None, None, :]) + 0 * loc[None, :, None]
+
+    def asm(e, scale):
+        A = sp.coo_matrix(((e[None, :, :] * scale[:, None, None]).ravel(), (rows.ravel(), cols.ravel())),
+                          shape=(n, n)).tocsr()
+        A.sort_indices()
+        return A
+    return asm(me, h), asm(ke, 1.0 / h), asm(s2e, 1.0 / h ** 3), asm(ce, 1.0 / h)
+
+
 def fe_load_1d(vertices, p, f, nq=None):
     nq = p + 1 if nq is None else nq
     t, w = _gauss01(nq)
@@ -125,6 +160,38 @@ class SeparableLoadForm(object):
 
     def assemble_vector(self, V, row0=None, row1=None):
         return _dev.vec_tensor3(self.vectors_1d(V), self.scale, row0, row1)
+
+
+class BiharmonicForm(object):
+    """a(u,v) = int (lap u)(lap v), element-wise (demos/biharmonic/biharmonic.py:100-103), 2-D:
+    S2xM + MxS2 + C^T x C + C x C^T with C[a,b] = int phi_a'' phi_b."""
+
+    def factors(self, V):
+        g = _single_grid(V)
+        if g.dim() != 2:
+            raise NotImplementedError("BiharmonicForm is provided for 2-D patches")
+        (Mx, _, S2x, Cx), (My, _, S2y, Cy) = [fe_matrices_1d_ext(g.vertices[k], g.degree) for k in range(2)]
+        return [[S2x, My], [Mx, S2y], [Cx.T.tocsr(), Cy], [Cx, Cy.T.tocsr()]]
+
+    def assemble_matrix(self, V, row0=None, row1=None):
+        return _dev.kron_sum_csr(self.factors(V), row0, row1)
+
+
+class SumOfSeparableLoads(object):
+    """L(v) = int f v with f = sum_t scale_t * prod_k f1d_t[k](x_k)."""
+
+    def __init__(self, terms):
+        self.terms = [SeparableLoadForm(f1d, scale) for f1d, scale in terms]
+
+    def assemble_vector(self, V, row0=None, row1=None):
+        out = None
+        for t in self.terms:
+            v = t.assemble_vector(V, row0, row1)
+            if out is None:
+                out = v
+            else:
+                out.axpy(1.0, v)
+        return out
 
 
 class Equation(object):
