@@ -14,17 +14,96 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+class HostRendezvous(object):
+    """Minimal TCP rendezvous between the ranks of one node (rank 0 listens on MASTER_ADDR at
+    MASTER_PORT + 17): hands out the RCCL unique id and provides the host-side barrier / max of the
+    bench contract.  Plain sockets: nothing but the Python standard library in the launcher path
+    (importing torch here would also pull a second RCCL / HIP runtime into the process)."""
+
+    def __init__(self, rank, world):
+        import socket
+        import struct
+        self.rank, self.world = rank, world
+        self.struct = struct
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("MASTER_PORT", "29500")) + 17
+        self.peers = []
+        if world == 1:
+            return
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            conns = {}
+            while len(conns) < world - 1:
+                c, _ = srv.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                r = struct.unpack("i", self._recv(c, 4))[0]
+                conns[r] = c
+            self.peers = [conns[r] for r in sorted(conns)]
+            srv.close()
+        else:
+            deadline = time.time() + 120.0
+            while True:
+                try:
+                    c = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.2)
+            c.settimeout(None)
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            c.sendall(struct.pack("i", rank))
+            self.peers = [c]
+
+    @staticmethod
+    def _recv(c, n):
+        buf = b""
+        while len(buf) < n:
+            part = c.recv(n - len(buf))
+            if not part:
+                raise ConnectionError("rendezvous peer closed the connection")
+            buf += part
+        return buf
+
+    def broadcast_bytes(self, data, n):
+        if self.world == 1:
+            return data
+        if self.rank == 0:
+            for c in self.peers:
+                c.sendall(data)
+            return data
+        return self._recv(self.peers[0], n)
+
+    def allreduce_max(self, value):
+        """max over ranks of a host double (also a barrier)"""
+        if self.world == 1:
+            return value
+        st = self.struct
+        if self.rank == 0:
+            vals = [value] + [st.unpack("d", self._recv(c, 8))[0] for c in self.peers]
+            m = max(vals)
+            for c in self.peers:
+                c.sendall(st.pack("d", m))
+            return m
+        self.peers[0].sendall(st.pack("d", value))
+        return st.unpack("d", self._recv(self.peers[0], 8))[0]
+
+    def barrier(self):
+        self.allreduce_max(0.0)
+
+
 def _bootstrap_comm(rank, world):
-    """RCCL unique id from rank 0 to everybody over torch.distributed/gloo (plumbing only)."""
+    """RCCL unique id from rank 0 to everybody (host-side plumbing only)."""
     from tigar_amd import device as dev
+    rdv = HostRendezvous(rank, world)
     if world == 1:
-        return None, None
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        dist.init_process_group("gloo")
-    box = [dev.Comm.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    return dev.Comm(box[0], rank, world), dist
+        return None, rdv
+    uid = dev.Comm.unique_id() if rank == 0 else None
+    uid = rdv.broadcast_bytes(uid, 128)
+    return dev.Comm(uid, rank, world), rdv
 
 
 def pick_sub_planes(d, p, nel, planes_mine, free_bytes):
@@ -48,7 +127,7 @@ def run_distributed(args, d, p, nel, rank, world):
     from tigar_amd.forms import LaplaceForm, SeparableLoadForm
     from tigar_amd.dist import SlabHotPath
 
-    comm, dist = _bootstrap_comm(rank, world)
+    comm, rdv = _bootstrap_comm(rank, world)
     if rank == 0:
         log("[bench] device:", dev.device_info(), "world", world)
     kvecs = [uniformKnots(p, 0.0, 1.0, nel) for _ in range(d)]
@@ -77,8 +156,7 @@ def run_distributed(args, d, p, nel, rank, world):
 
     def barrier():
         dev.sync()
-        if dist is not None:
-            dist.barrier()
+        rdv.barrier()
 
     stages = {}
     state = {}
@@ -112,11 +190,7 @@ def run_distributed(args, d, p, nel, rank, world):
         step(True)
     barrier()
     elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = rdv.allreduce_max(elapsed)
     K = state["K"]
     nnzK_local = K.nnz
     ncp_local = K.shape[0]

@@ -94,3 +94,33 @@ def test_gloo_world2_distributed_cg_pattern():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "DIST_OK" in out.stdout
+
+
+def _rdv_worker(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    from bench_dist import HostRendezvous
+    r = HostRendezvous(rank, world)
+    data = r.broadcast_bytes(bytes(range(128)) if rank == 0 else None, 128)
+    m = r.allreduce_max(float(rank) * 1.5)
+    r.barrier()
+    q.put((rank, data == bytes(range(128)), m))
+
+
+def test_host_rendezvous_three_ranks():
+    """The launcher-side TCP rendezvous of bench_dist.py (RCCL id broadcast, barrier, max)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, port = 3, 29741
+    procs = [ctx.Process(target=_rdv_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in reversed(procs):          # start rank 0 last: the others must retry connecting
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[0] for r in res] == [0, 1, 2]
+    assert all(r[1] for r in res)
+    assert all(r[2] == 3.0 for r in res)

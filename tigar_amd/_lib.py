@@ -132,7 +132,7 @@ def load(require_device=True, device=None):
         _lib = lib
     if require_device and not _device_ready:
         if device is None:
-            device = int(os.environ.get("LOCAL_RANK", os.environ.get("TIGAR_DEVICE", "0")))
+            device = int(os.environ.get("TIGAR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         rc = _lib.tg_init(int(device))
         if rc != 0:
             raise TigarHipError("tg_init(%d) failed: %s -- the extraction path needs an MI355X; "
