@@ -655,7 +655,9 @@ class ExtractedSpline(object):
             from .kronptap import default_groups, ptap_factored
             kx = self._kron
             groups = default_groups(kx.d, max(s1.p for s1 in kx.basis.splines))
-            if len(groups) > 1:
+            import os
+            if os.environ.get("TIGAR_PTAP_FACTORED", "1") != "0":
+                # Kronecker-structured M: dense-box kernel (one stage or sum-factorised stages)
                 return ptap_factored(kx, A, (0, kx.nfe[-1]), (0, kx.nfe[-1]), (0, kx.ncp[-1]), zd, float(diag), groups)
         key = (A.shape, A.nnz)
         if self._ptap_plan is None or self._ptap_plan_key != key:

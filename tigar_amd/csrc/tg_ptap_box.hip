@@ -32,7 +32,7 @@ struct tg_box_args {
   const double *mval[3];
   const int32_t *trp[3], *tcol[3];   // M_k^T (nout x nin) CSR, device
   const double *tval[3];
-  int W[3];                     // measured bandwidth of cur per direction
+  const int *blo[3], *bhi[3];   // box bounds (inclusive, input coordinates) per OUTPUT coordinate and direction
   int64_t out_row0, out_nrows, row_stride;
   unsigned mg01, sh01, mg0, sh0; // magic numbers: s / (n0*n1) and s / n0 for 0 <= s < 2^31
   int cap;                      // doubles per LDS buffer
@@ -71,12 +71,12 @@ static void tg_magic(unsigned d, unsigned *mg, unsigned *sh) {
 enum { TG_BOX_OK = 0, TG_BOX_TOOBIG = 1, TG_BOX_RANGE = 2, TG_BOX_CAP = 3, TG_BOX_OUTSIDE = 4 };
 enum { TG_BOXMODE_PROBE = 0, TG_BOXMODE_BUMP = 1 };
 
-// max |s_k - r_k| over all entries of cur, per direction
+// Reach of the rows of `cur` per direction and coordinate: for every row coordinate r_k,
+// lmax[k][r_k] = max (r_k - s_k), rmax[k][r_k] = max (s_k - r_k) over the row's columns s.
+// (arrays of size n0+n1+n2, zero-initialised; used to size the accumulator boxes tightly)
 __global__ void __launch_bounds__(256)
-    k_box_bandwidth(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nrows, int64_t row0,
-                    int n0, int n1, int *__restrict__ out3) {
-  __shared__ int red[3][4];
-  int w0 = 0, w1 = 0, w2 = 0;
+    k_box_reach(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nrows, int64_t row0,
+                int n0, int n1, int n2, int *__restrict__ lmax, int *__restrict__ rmax) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -86,30 +86,36 @@ __global__ void __launch_bounds__(256)
     const int r2 = (int)(g / n01);
     const int rem = (int)(g - (int64_t)r2 * n01);
     const int r1 = rem / n0, r0 = rem - r1 * n0;
+    int l0 = 0, l1 = 0, l2 = 0, h0 = 0, h1 = 0, h2 = 0;
     for (int64_t q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) {
       const int64_t s = col[q];
       const int s2 = (int)(s / n01);
       const int sm = (int)(s - (int64_t)s2 * n01);
       const int s1 = sm / n0, s0 = sm - s1 * n0;
-      w0 = max(w0, abs(s0 - r0));
-      w1 = max(w1, abs(s1 - r1));
-      w2 = max(w2, abs(s2 - r2));
+      l0 = max(l0, r0 - s0);
+      h0 = max(h0, s0 - r0);
+      l1 = max(l1, r1 - s1);
+      h1 = max(h1, s1 - r1);
+      l2 = max(l2, r2 - s2);
+      h2 = max(h2, s2 - r2);
     }
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    w0 = max(w0, __shfl_down(w0, o, 64));
-    w1 = max(w1, __shfl_down(w1, o, 64));
-    w2 = max(w2, __shfl_down(w2, o, 64));
-  }
-  if (lane == 0) {
-    red[0][threadIdx.x >> 6] = w0;
-    red[1][threadIdx.x >> 6] = w1;
-    red[2][threadIdx.x >> 6] = w2;
-  }
-  __syncthreads();
-  if (threadIdx.x < 3) {
-    const int k = threadIdx.x;
-    atomicMax(&out3[k], max(max(red[k][0], red[k][1]), max(red[k][2], red[k][3])));
+    for (int o = 32; o > 0; o >>= 1) {
+      l0 = max(l0, __shfl_down(l0, o, 64));
+      h0 = max(h0, __shfl_down(h0, o, 64));
+      l1 = max(l1, __shfl_down(l1, o, 64));
+      h1 = max(h1, __shfl_down(h1, o, 64));
+      l2 = max(l2, __shfl_down(l2, o, 64));
+      h2 = max(h2, __shfl_down(h2, o, 64));
+    }
+    if (lane == 0) {
+      // most rows do not raise the maxima: test before the atomic
+      if (lmax[r0] < l0) atomicMax(&lmax[r0], l0);
+      if (rmax[r0] < h0) atomicMax(&rmax[r0], h0);
+      if (lmax[n0 + r1] < l1) atomicMax(&lmax[n0 + r1], l1);
+      if (rmax[n0 + r1] < h1) atomicMax(&rmax[n0 + r1], h1);
+      if (lmax[n0 + n1 + r2] < l2) atomicMax(&lmax[n0 + n1 + r2], l2);
+      if (rmax[n0 + n1 + r2] < h2) atomicMax(&rmax[n0 + n1 + r2], h2);
+    }
   }
 }
 
@@ -188,9 +194,13 @@ __global__ void __launch_bounds__(NT)
       hi[k] = len[k] > 0 ? la[P.loff[k] + len[k] - 1] : 0;
     } else
       lo[k] = hi[k] = (k < P.d) ? I[k] : 0;
-    const int nk = (k < P.d) ? P.nin[k] : 1;
-    bo[k] = max(0, lo[k] - P.W[k]);
-    B[k] = min(nk - 1, hi[k] + P.W[k]) - bo[k] + 1;
+    if (k < P.d) {
+      bo[k] = P.blo[k][I[k]];
+      B[k] = P.bhi[k][I[k]] - bo[k] + 1;
+    } else {
+      bo[k] = 0;
+      B[k] = 1;
+    }
   }
   int nbox = B[0] * B[1] * B[2];
   if (nbox > P.cap) {  // uniform
@@ -557,21 +567,80 @@ extern "C" int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t
                  (long long)nin_total);
     return 2;
   }
-  // measured bandwidth of cur per direction
-  int *status = (int *)g_tg.scratch;     // [0] status, [1..2] maxima, [4..6] bandwidth
+  // measured reach of cur's rows per direction and coordinate -> tight accumulator boxes
+  int *status = (int *)g_tg.scratch;     // [0] status, [1..2] maxima
   hipMemsetAsync(status, 0, 8 * sizeof(int), g_tg.stream);
+  const int ntot = P.nin[0] + P.nin[1] + P.nin[2];
+  int *reach = nullptr;                  // lmax[ntot] | rmax[ntot]
+  rc = tg_dmalloc(&reach, 2 * (int64_t)ntot);
+  if (rc) {
+    cleanup();
+    return rc;
+  }
+  dev.push_back(reach);
+  hipMemsetAsync(reach, 0, 2 * (size_t)ntot * sizeof(int), g_tg.stream);
   if (cur->nrows > 0)
-    hipLaunchKernelGGL(k_box_bandwidth, dim3((unsigned)std::min<int64_t>(tg_cdiv(cur->nrows, 4), (int64_t)g_tg.num_cu * 16)),
+    hipLaunchKernelGGL(k_box_reach, dim3((unsigned)std::min<int64_t>(tg_cdiv(cur->nrows, 4), (int64_t)g_tg.num_cu * 16)),
                        dim3(256), 0, g_tg.stream, cur->rowptr, cur->col, cur->nrows, cur_row0, P.nin[0], P.nin[1],
-                       status + 4);
-  int hw[3] = {0, 0, 0};
-  hipMemcpyAsync(hw, status + 4, 3 * sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
+                       P.nin[2], reach, reach + ntot);
+  std::vector<int> hreach(2 * (size_t)ntot);
+  hipMemcpyAsync(hreach.data(), reach, 2 * (size_t)ntot * sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
   hipStreamSynchronize(g_tg.stream);
+  // box bounds per output coordinate: hull over the 1-D support of [a - lmax[a], a + rmax[a]]
+  int hw[3] = {0, 0, 0};                 // largest box extent beyond the support (only for reporting)
   int64_t boxmax = 1;
+  int maxBk[3] = {1, 1, 1};
+  std::vector<int> hb;                   // blo | bhi for the three directions, concatenated
+  size_t boff[3];
+  {
+    int coord0 = 0;
+    for (int k = 0; k < 3; k++) {
+      boff[k] = hb.size();
+      const int nk = P.nin[k];
+      const int mk = P.nout[k];
+      const int *L = hreach.data() + coord0, *Rr = hreach.data() + ntot + coord0;
+      std::vector<int> lo(mk), hi(mk);
+      for (int i = 0; i < mk; i++) {
+        int l = 0x7fffffff, h = -1;
+        if (k < d && P.contracted[k]) {
+          const tg_kron1d_t &F = fac[k];
+          for (int t = F.t_rowptr[i]; t < F.t_rowptr[i + 1]; t++) {
+            const int a = F.t_col[t];
+            l = std::min(l, a - L[a]);
+            h = std::max(h, a + Rr[a]);
+          }
+          if (h < l) {
+            l = 0;
+            h = 0;
+          }
+        } else {
+          l = i - L[i];
+          h = i + Rr[i];
+        }
+        l = std::max(l, 0);
+        h = std::min(h, nk - 1);
+        lo[i] = l;
+        hi[i] = h;
+        maxBk[k] = std::max(maxBk[k], h - l + 1);
+      }
+      hb.insert(hb.end(), lo.begin(), lo.end());
+      hb.insert(hb.end(), hi.begin(), hi.end());
+      coord0 += nk;
+      boxmax *= maxBk[k];
+      hw[k] = maxBk[k] - maxlen[k];
+    }
+  }
+  int *dbox = nullptr;
+  rc = tg_dmalloc(&dbox, (int64_t)hb.size());
+  if (rc) {
+    cleanup();
+    return rc;
+  }
+  dev.push_back(dbox);
+  hipMemcpyAsync(dbox, hb.data(), hb.size() * sizeof(int), hipMemcpyHostToDevice, g_tg.stream);
   for (int k = 0; k < 3; k++) {
-    P.W[k] = hw[k];
-    const int nk = P.nin[k];
-    boxmax *= std::min<int64_t>(nk, (int64_t)maxlen[k] + 2 * hw[k]);
+    P.blo[k] = dbox + boff[k];
+    P.bhi[k] = dbox + boff[k] + P.nout[k];
   }
   int cap = (int)std::min<int64_t>(boxmax, 1 << 20);
   cap = (cap + 7) & ~7;
@@ -579,7 +648,7 @@ extern "C" int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t
   int maxB[3], Dmax[3] = {1, 1, 1};
   int ctab = 0, nlist = 0, maxl = 1;
   for (int k = 0; k < 3; k++) {
-    maxB[k] = (int)std::min<int64_t>(P.nin[k], (int64_t)maxlen[k] + 2 * hw[k]);
+    maxB[k] = maxBk[k];
     P.coff[k] = ctab;
     P.cstr[k] = 0;
     P.loff[k] = nlist;

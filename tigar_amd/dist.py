@@ -139,8 +139,7 @@ class SlabHotPath(object):
         if factored is True and len(self.groups) == 1:
             self.groups = [[k] for k in range(basis.nvar)]
         explicit = env is not None and env not in ("0", "1")
-        self.factored = (factored if factored is not None else (env != "0" if env is not None else True)) \
-            and (len(self.groups) > 1 or explicit)
+        self.factored = (factored if factored is not None else (env != "0" if env is not None else True))
         self.basis, self.grid = basis, grid
         self.rank, self.world, self.comm = rank, world, comm
         self.eps = eps
