@@ -268,3 +268,30 @@ def test_sum_factorised_ptap_equals_direct(T, d, p, nel, box, monkeypatch):
         Ks, rs = path.assemble(a_rows, b_rows, zd, 2.0)
         assert abs(Ks.to_scipy() - Ko).max() <= 1e-12 * abs(Ko).max()
         assert np.max(np.abs(rs.get_local() - O.extract_vector(Mo, bo, zd))) <= 1e-12 * np.max(np.abs(bo))
+
+
+def test_box_kernel_sampled_reach_falls_back_to_exact(T, monkeypatch):
+    """The accumulator boxes are sized from a sampled scan of A's rows; an irregular A with a
+    long-range coupling in an unsampled row must be caught (entry outside its box) and redone with
+    the exact reach -- result still equals the oracle's M^T A M."""
+    from tigar_amd.kronptap import KronExtraction, ptap_factored
+    B, dev = T.B, T.dev
+    d, p, nel = 2, 2, 9
+    kv = [B.uniformKnots(p, 0., 1., nel)] * d
+    basis = B.ExplicitBSplineControlMesh([p] * d, kv).getScalarSpline()
+    grid = basis.generateMesh(degree=p)
+    s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel)] * d)
+    Mo = O.generate_M_tensor(s)
+    Ao, _, _, _ = O.poisson_fe_system(s)
+    Ao = Ao.tolil()
+    n = Ao.shape[0]
+    Ao[3, n - 5] = 0.37          # row 3 is not visited with stride 7; couples across the whole patch
+    Ao[n - 2, 11] = -0.21
+    Ao = Ao.tocsr()
+    monkeypatch.setenv("TIGAR_BOX_REACH_STRIDE", "7")
+    kx = KronExtraction(basis, grid)
+    nz = grid.shape()[-1]
+    K = ptap_factored(kx, dev.DeviceCSR.from_scipy(Ao), (0, nz), (0, nz), (0, basis.splines[-1].getNcp()),
+                      None, 1.0, [[0], [1]])
+    Ko = (Mo.T @ Ao @ Mo).tocsr()
+    assert abs(K.to_scipy() - Ko).max() <= 1e-12 * abs(Ko).max()

@@ -86,13 +86,16 @@ __global__ void __launch_bounds__(256)
     const int lx = P.rowptr[0][a + 1] - x0;
     const int L = lx * ly * lz;
     int64_t out0 = rowptr[lr];
+    // e -> (i, j, k): L < 2^20, so a float reciprocal with a +0.5 bias divides exactly
+    const float rlx = 1.0f / (float)lx, rly = 1.0f / (float)ly;
     for (int e0 = 0; e0 < L; e0 += 64) {
       const int e = e0 + lane;
       const bool in = e < L;
-      const int i = in ? e % lx : 0;
-      const int jk = in ? e / lx : 0;
-      const int j = jk % ly;
-      const int k = jk / ly;
+      const int ee = in ? e : 0;
+      const int jk = (int)(((float)ee + 0.5f) * rlx);
+      const int i = ee - jk * lx;
+      const int k = (int)(((float)jk + 0.5f) * rly);
+      const int j = jk - k * ly;
       int64_t cc = P.col[0][x0 + i];
       if (P.d > 1) cc += P.cstride[1] * (int64_t)P.col[1][y0 + j];
       if (P.d > 2) cc += P.cstride[2] * (int64_t)P.col[2][z0 + k];
