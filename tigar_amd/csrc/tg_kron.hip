@@ -126,6 +126,67 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Unfiltered fill, streaming form: the rows of one pencil (fixed b,c) are consecutive in the
+// output and their lengths are lx(a)*ly*lz, so the pencil's entries form ONE contiguous range.
+// The workgroup walks that range 256 entries at a time (fully coalesced 2-KB / 1-KB stores);
+// each thread finds its row by bisection over the row offsets kept in LDS.
+#define TG_KRON_MAXN0 4096
+__global__ void __launch_bounds__(256)
+    k_kron_fill_stream(tg_kron_params P, const int64_t *__restrict__ rowptr, int32_t *__restrict__ col,
+                       double *__restrict__ val) {
+  __shared__ int roff[TG_KRON_MAXN0 + 1];
+  const int tid = threadIdx.x;
+  const int64_t pencil = P.pencil0 + blockIdx.x;
+  int64_t b, c;
+  tg_kron_pencil(P, pencil, &b, &c);
+  const int y0 = (P.d > 1) ? P.rowptr[1][b] : 0;
+  const int ly = (P.d > 1) ? P.rowptr[1][b + 1] - y0 : 1;
+  const int z0 = (P.d > 2) ? P.rowptr[2][c] : 0;
+  const int lz = (P.d > 2) ? P.rowptr[2][c + 1] - z0 : 1;
+  const int lyz = ly * lz;
+  const int n0 = (int)P.n[0];
+  for (int a = tid; a <= n0; a += 256) roff[a] = P.rowptr[0][a] * lyz;
+  __syncthreads();
+  // rows of this pencil that belong to the output block
+  const int64_t g0 = P.n[0] * pencil;
+  const int a_lo = (int)max((int64_t)0, P.row0 - g0);
+  const int a_hi = (int)min((int64_t)n0, P.row0 + P.nrows - g0);
+  if (a_hi <= a_lo) return;
+  const int64_t base = rowptr[g0 + a_lo - P.row0] - roff[a_lo];   // output position of local offset 0
+  const float rly = 1.0f / (float)ly;
+  for (int t = roff[a_lo] + tid; t < roff[a_hi]; t += 256) {
+    // row a with roff[a] <= t < roff[a+1]
+    int lo = a_lo, hi = a_hi;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (roff[mid] <= t)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const int a = lo;
+    const int x0 = P.rowptr[0][a];
+    const int lx = P.rowptr[0][a + 1] - x0;
+    const int e = t - roff[a];
+    const int jk = (int)(((float)e + 0.5f) / (float)lx);
+    const int i = e - jk * lx;
+    const int k = (int)(((float)jk + 0.5f) * rly);
+    const int j = jk - k * ly;
+    int64_t cc = P.col[0][x0 + i];
+    if (P.d > 1) cc += P.cstride[1] * (int64_t)P.col[1][y0 + j];
+    if (P.d > 2) cc += P.cstride[2] * (int64_t)P.col[2][z0 + k];
+    double sum = 0.0;
+    for (int q = 0; q < P.nterms; q++) {
+      double v = P.val[0][q * P.nnz1d[0] + x0 + i];
+      if (P.d > 1) v *= P.val[1][q * P.nnz1d[1] + y0 + j];
+      if (P.d > 2) v *= P.val[2][q * P.nnz1d[2] + z0 + k];
+      sum += v;
+    }
+    col[base + t] = (int32_t)(cc + P.col_offset);
+    val[base + t] = sum;
+  }
+}
+
 int tg_kron_build(int d, int nterms, const tg_kron_dir_t *dirs, int64_t row0, int64_t row1, int filter, double eps,
                   int64_t col_offset, int64_t ncols_total, tg_csr_t *out);
 
@@ -222,8 +283,20 @@ int tg_kron_build_rect(int d, int nterms, const tg_kron_dir_t *dirs, const int64
         rc = tg_dmalloc(&m->col, nnz + TG_CSR_PAD) || tg_dmalloc(&m->val, nnz + TG_CSR_PAD);
         TG_TRACE("malloc done");
         if (!rc && P.npencils > 0 && nnz > 0) {
-          hipLaunchKernelGGL(k_kron_fill, dim3((unsigned)P.npencils), dim3(256), 0, g_tg.stream, P, rowptr, m->col,
-                             m->val);
+          int64_t lyzmax = 1;
+          for (int k = 1; k < d; k++) {
+            int mx = 1;
+            for (int64_t i = 0; i < dirs[k].n; i++) mx = std::max(mx, dirs[k].rowptr[i + 1] - dirs[k].rowptr[i]);
+            lyzmax *= mx;
+          }
+          const bool stream_ok = !filter && P.n[0] <= TG_KRON_MAXN0 && P.nnz1d[0] * lyzmax < (1ll << 30) &&
+                                 !getenv("TIGAR_KRON_ROWWISE");
+          if (stream_ok)
+            hipLaunchKernelGGL(k_kron_fill_stream, dim3((unsigned)P.npencils), dim3(256), 0, g_tg.stream, P, rowptr,
+                               m->col, m->val);
+          else
+            hipLaunchKernelGGL(k_kron_fill, dim3((unsigned)P.npencils), dim3(256), 0, g_tg.stream, P, rowptr, m->col,
+                               m->val);
           if (hipGetLastError() != hipSuccess) {
             tg_set_error("kron fill launch failed");
             rc = 1;

@@ -124,14 +124,25 @@ def _single_grid(V):
     return g
 
 
+def _memo(obj, V, build):
+    """1-D factors depend only on the space: build once per (form, V)"""
+    cache = obj.__dict__.setdefault("_cache", {})
+    key = id(V)
+    if key not in cache:
+        cache[key] = build()
+    return cache[key]
+
+
 class LaplaceForm(object):
     """a(u,v) = int grad u . grad v on the parametric box."""
 
     def factors(self, V):
-        g = _single_grid(V)
-        mk = [fe_matrices_1d(g.vertices[k], g.degree) for k in range(g.dim())]
-        d = g.dim()
-        return [[mk[k][1] if k == dd else mk[k][0] for k in range(d)] for dd in range(d)]
+        def build():
+            g = _single_grid(V)
+            mk = [fe_matrices_1d(g.vertices[k], g.degree) for k in range(g.dim())]
+            d = g.dim()
+            return [[mk[k][1] if k == dd else mk[k][0] for k in range(d)] for dd in range(d)]
+        return _memo(self, V, build)
 
     def assemble_matrix(self, V, row0=None, row1=None):
         return _dev.kron_sum_csr(self.factors(V), row0, row1)
@@ -155,8 +166,10 @@ class SeparableLoadForm(object):
         self.f1d, self.scale = list(f1d), float(scale)
 
     def vectors_1d(self, V):
-        g = _single_grid(V)
-        return [fe_load_1d(g.vertices[k], g.degree, self.f1d[k]) for k in range(g.dim())]
+        def build():
+            g = _single_grid(V)
+            return [fe_load_1d(g.vertices[k], g.degree, self.f1d[k]) for k in range(g.dim())]
+        return _memo(self, V, build)
 
     def assemble_vector(self, V, row0=None, row1=None):
         return _dev.vec_tensor3(self.vectors_1d(V), self.scale, row0, row1)
