@@ -117,6 +117,12 @@ def pick_sub_planes(d, p, nel, planes_mine, free_bytes):
     fixed = (2 * p * p + 2) * (nnzA_plane + 2.2 * nnzM_plane)
     budget = 0.35 * free_bytes - fixed
     n = int(max(1, min(planes_mine, budget // per_dof_plane)))
+    from tigar_amd.kronptap import default_groups
+    if len(default_groups(d, p)) == 3:
+        # direction-by-direction stages: the x-stage result (FE-sized in y and z) and its temporary
+        # are larger than the (x,y)-stage result the estimate above was made for (measured at
+        # 256^3 p=3: 5 planes best, 6 starts to thrash the allocator, 8 doubles the PtAP time)
+        n = max(1, min(n, (n * 5) // 8))
     return n
 
 

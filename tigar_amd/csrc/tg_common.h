@@ -10,7 +10,8 @@
 
 #define TG_MAX_DEGREE 8            // per-direction spline degree limit of the kernels
 #define TG_WAVE 64
-#define TG_CSR_PAD 8              // col/val allocations are padded: vector loads may over-read
+#define TG_CSR_PAD 264            // col/val allocations are padded: vector loads and the unrolled
+                                  // row loops of the box PtAP (64 lanes x 4) may over-read
 
 struct tg_ctx_t {
   int device = -1;

@@ -41,6 +41,21 @@ struct tg_box_args {
   int coff[3], cstr[3], loff[3]; // per direction: slice offset / entries per output row / list offset
   int nlist;                    // total entries of the support lists
   int g1, lg1;                  // lanes per input row in stage 1
+  // 24-bit column decoding relative to the box origin (all multiplies full rate): usable when
+  // n0*n1 < 2^23 and n0*n1*max(B2) <= 2^24; quotient = (hi ? mulhi24 : mul24)(e, m) >> sh
+  int fast24;
+  unsigned m24a, sh24a, hi24a;  // e / (n0*n1)  for 0 <= e < n0*n1*max(B2)
+  unsigned m24b, sh24b, hi24b;  // r / n0       for 0 <= r < n0*n1
+  unsigned long long *prof;     // optional per-phase cycle counters (TIGAR_BOX_PROF)
+};
+
+// "line" kernel (one contracted direction): a wave walks along direction u
+struct tg_line_args {
+  int a, u;                     // contracted direction, march direction (-1: none, single row per wave)
+  int mlen, ulo, uhi;           // rows per wave; range of I_u that intersects the requested rows
+  int64_t x0, nx, nchunk;       // cross-section indices [x0, x0+nx) x chunks of mlen along u
+  int capx, capy;               // doubles of the accumulator box / of the contracted box
+  int64_t grab;                 // output entries a wave reserves at a time
 };
 
 enum { TG_BOX_OK = 0, TG_BOX_TOOBIG = 1, TG_BOX_RANGE = 2, TG_BOX_CAP = 3, TG_BOX_OUTSIDE = 4 };
@@ -69,6 +84,73 @@ static void tg_magic(unsigned d, unsigned *mg, unsigned *sh) {
   const unsigned long long num = 1ull << (32 + s);
   *mg = (unsigned)((num + d - 1) / d);  // < 2^32 because d > 2^(l-1)
   *sh = s;
+}
+
+// ---- 24-bit arithmetic (v_mul_u32_u24 / v_mul_hi_u32_u24 / v_mad_i32_i24 issue at full rate on
+// CDNA; 32-bit integer multiplies at a quarter of it, and the decode of a column index needs six)
+__device__ __forceinline__ int tg_mad_i24(int a, int b, int c) {
+  int r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ unsigned tg_mulhi_u24(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned tg_mul_u24(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// variants taking the wave-uniform factor in a scalar register (no v_mov per use)
+__device__ __forceinline__ int tg_mad_i24s(int a, int sb, int c) {
+  int r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(sb), "v"(c));
+  return r;
+}
+__device__ __forceinline__ unsigned tg_mulhi_u24s(unsigned sa, unsigned b) {
+  unsigned r;
+  asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "s"(sa), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned tg_mul_u24s(unsigned sa, unsigned b) {
+  unsigned r;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(sa), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned tg_div24(unsigned e, unsigned m, unsigned sh, unsigned hi) {
+  return (hi ? tg_mulhi_u24(e, m) : tg_mul_u24(e, m)) >> sh;
+}
+
+// Magic number for floor(e / dsr), 0 <= e < bound <= 2^24, with 24-bit operands:
+// m = ceil(2^k / dsr) with 2^k >= bound*dsr is exact (classic round-up method); either the low
+// 32 bits of the 48-bit product suffice (k < 32, bound*m < 2^32) or k >= 32 and the high part is
+// used.  The result is verified at every multiple of dsr (both functions are monotone steps).
+static bool tg_magic24(unsigned dsr, uint64_t bound, unsigned *m, unsigned *sh, unsigned *hi) {
+  if (dsr == 0 || bound > (1ull << 24)) return false;
+  int k = 0;
+  while ((1ull << k) < bound * (uint64_t)dsr) k++;
+  for (int pass = 0; pass < 2; pass++) {
+    const int kk = pass == 0 ? k : std::max(k, 32);
+    if (kk > 47) return false;
+    const uint64_t mm = ((1ull << kk) + dsr - 1) / dsr;
+    if (mm >= (1ull << 24)) continue;
+    if (pass == 0 && (kk >= 32 || bound * mm >= (1ull << 32))) continue;
+    bool ok = true;
+    for (uint64_t j = 0; j * dsr < bound && ok; j++) {
+      const uint64_t e1 = j * dsr;                       // first value with quotient j
+      ok = ((e1 * mm) >> kk) == j;
+      if (j > 0) ok = ok && (((e1 - 1) * mm) >> kk) == j - 1;
+    }
+    if (ok && bound > 0) ok = (((bound - 1) * mm) >> kk) == (bound - 1) / dsr;
+    if (!ok) continue;
+    *m = (unsigned)mm;
+    *hi = kk >= 32 ? 1u : 0u;
+    *sh = (unsigned)(kk >= 32 ? kk - 32 : kk);
+    return true;
+  }
+  return false;
 }
 
 // Reach of the rows of `cur` per direction and coordinate: for every row coordinate r_k,
@@ -120,6 +202,7 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+#define TG_BOX_UNTOUCHED 0x8000000000000000ull   // bit pattern of -0.0 (line kernel: untouched slot)
 #define TG_BOX_UNROLL 4
 #define TG_BOX_MAXLIST 96     // longest 1-D support list (entries of one row of F_k^T)
 #define TG_BOX_MAXD 48        // most output indices per direction reachable from one box
@@ -476,6 +559,441 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// "Line" kernel: ONE contracted direction a, one WAVE per run of output rows.
+//
+// The workgroup-per-row kernel above is bound by latency, not by LDS atomics or bandwidth
+// (measured: dropping the atomics or half the operand rows changes nothing, the time is inversely
+// proportional to the resident workgroups; ~10 barriers and ~8 dependent global round trips per
+// row).  When only one direction is contracted a row has little work (|supp| operand rows), so the
+// fixed cost dominates.  Here a wave owns a run of consecutive output rows along an uncontracted
+// direction u: support list, contraction matrix and box extents of direction a are set up once per
+// run, there are no barriers at all, and per output row
+//   * the rowptr pairs of the operand rows were fetched during the previous row,
+//   * the entries of the operand rows are requested TG_LINE_NB wave-wide loads at a time before the
+//     first one is consumed (registers are the staging buffer),
+//   * columns are decoded with 24-bit multiplies relative to the box origin, one ds_add_f64 each,
+//   * the box is contracted out of registers against the dense (D x B_a) slice of F_a (LDS broadcast
+//     reads) and stored over the head of its own line (no second box), "touched" travels as a bit mask,
+//   * output space comes from a wave-private chunk of the temporary (one global atomic per
+//     TG grab, not per row); rows are put in final order by k_box_reorder as before.
+#define TG_LINE_NB 8
+
+__device__ __forceinline__ int64_t tg_readlane_i64(int64_t v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), l);
+  return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double tg_readlane_f64(double v, int l) {
+  return __longlong_as_double(tg_readlane_i64(__double_as_longlong(v), l));
+}
+
+// a wave-uniform pointer, forced into scalar registers (under register pressure the compiler keeps
+// uniform 64-bit values in VGPRs, which would turn every buffer load into a waterfall loop)
+__device__ __forceinline__ void *tg_uniform_ptr(const void *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (void *)(((unsigned long long)hi << 32) | lo);
+}
+
+template <int BAMAX, int DMAXT, int A, int U, bool HI>
+__global__ void __launch_bounds__(64)
+    k_ptap_line(tg_box_args P, tg_line_args Q, int64_t *__restrict__ row_cnt, int64_t *__restrict__ row_off,
+                int32_t *__restrict__ k_col, double *__restrict__ k_val, unsigned long long *__restrict__ cursor,
+                int64_t capacity, const uint8_t *__restrict__ mask, double diag, int *__restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *X = reinterpret_cast<double *>(smem);          // accumulator box [capx]
+  double *Fd = X + Q.capx;                               // dense slice of F_a^T: [DMAXT][BAMAX]
+  unsigned *fmask = reinterpret_cast<unsigned *>(Fd + DMAXT * BAMAX);   // [DMAXT] structural masks, bit (Ba-1-x)
+
+  const int lane = threadIdx.x;
+  constexpr int a = A, u = U;                     // contracted direction, direction of the run (-1: none)
+#ifdef TG_LINE_PROF
+  unsigned long long tstamp = 0;
+  if (P.prof) tstamp = __builtin_readcyclecounter();
+  auto lap = [&](int slot) {
+    if (P.prof) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      if (lane == 0) atomicAdd(&P.prof[slot], now - tstamp);
+      tstamp = now;
+    }
+  };
+#else
+  auto lap = [](int) {};
+#endif
+  const int64_t m01 = (int64_t)P.nout[0] * P.nout[1];
+  const int64_t n01 = (int64_t)P.nin[0] * P.nin[1];
+  // ---- the run of output rows of this wave
+  int I[3];
+  int Iu = 0, nsteps = 1;
+  int64_t Rfirst, rstep = 0;
+  if (u < 0) {
+    const int64_t L = tg_xcd_block(blockIdx.x, P.out_nrows);
+    if (L >= P.out_nrows) return;
+    Rfirst = P.out_row0 + L;
+    I[2] = (int)(Rfirst / m01);
+    const int rem = (int)(Rfirst - (int64_t)I[2] * m01);
+    I[1] = rem / P.nout[0];
+    I[0] = rem - I[1] * P.nout[0];
+  } else {
+    const int64_t nb = Q.nx * Q.nchunk;
+    const int64_t b = tg_xcd_block(blockIdx.x, nb);
+    if (b >= nb) return;
+    const int64_t c = b / Q.nx;
+    const int64_t x = Q.x0 + (b - c * Q.nx);
+    const int iu0 = Q.ulo + (int)c * Q.mlen;
+    int last = min(Q.mlen, Q.uhi + 1 - iu0);
+    I[0] = I[1] = I[2] = 0;
+    if (u == 0) {
+      I[1] = (int)(x % P.nout[1]);
+      I[2] = (int)(x / P.nout[1]);
+      I[0] = iu0;
+      rstep = 1;
+    } else if (u == 1) {
+      I[0] = (int)(x % P.nout[0]);
+      I[2] = (int)(x / P.nout[0]);
+      I[1] = iu0;
+      rstep = P.nout[0];
+    } else {
+      I[0] = (int)(x % P.nout[0]);
+      I[1] = (int)(x / P.nout[0]);
+      I[2] = iu0;
+      rstep = m01;
+    }
+    const int64_t R0 = (int64_t)I[0] + (int64_t)P.nout[0] * I[1] + m01 * I[2];
+    int first = 0;
+    if (R0 < P.out_row0) first = (int)((P.out_row0 - R0 + rstep - 1) / rstep);
+    const int64_t rend = P.out_row0 + P.out_nrows;
+    if (R0 + (int64_t)(last - 1) * rstep >= rend) last = (R0 < rend) ? (int)((rend - 1 - R0) / rstep) + 1 : 0;
+    if (first >= last) return;
+    Iu = iu0 + first;
+    Rfirst = R0 + (int64_t)first * rstep;
+    nsteps = last - first;
+  }
+  const int Ia = a == 0 ? I[0] : (a == 1 ? I[1] : I[2]);
+  const int32_t *trp = a == 0 ? P.trp[0] : (a == 1 ? P.trp[1] : P.trp[2]);
+  const int32_t *tcol = a == 0 ? P.tcol[0] : (a == 1 ? P.tcol[1] : P.tcol[2]);
+  const double *tval = a == 0 ? P.tval[0] : (a == 1 ? P.tval[1] : P.tval[2]);
+  const int32_t *mrp = a == 0 ? P.mrp[0] : (a == 1 ? P.mrp[1] : P.mrp[2]);
+  const int32_t *mcol = a == 0 ? P.mcol[0] : (a == 1 ? P.mcol[1] : P.mcol[2]);
+  const int *ublo = u == 0 ? P.blo[0] : (u == 1 ? P.blo[1] : P.blo[2]);
+  const int *ubhi = u == 0 ? P.bhi[0] : (u == 1 ? P.bhi[1] : P.bhi[2]);
+  // ---- support list of row Ia of F_a^T: lane j holds entry j
+  const int e0 = trp[Ia];
+  const int len = trp[Ia + 1] - e0;             // <= 64 (host)
+  int la = 0;
+  double lw = 0.0;
+  if (lane < len) {
+    la = tcol[e0 + lane];
+    lw = tval[e0 + lane];
+  }
+  int bo[3], B[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (k < P.d) {
+      bo[k] = P.blo[k][I[k]];
+      B[k] = P.bhi[k][I[k]] - bo[k] + 1;
+    } else {
+      bo[k] = 0;
+      B[k] = 1;
+    }
+  }
+  const int boa = a == 0 ? bo[0] : (a == 1 ? bo[1] : bo[2]);
+  const int Ba = a == 0 ? B[0] : (a == 1 ? B[1] : B[2]);
+  // ---- output indices reachable from the box along a: first/last column of rows [boa, boa+Ba) of M_a
+  int ilo = 0x7fffffff, ihi = -1;
+  for (int x = lane; x < Ba; x += 64) {
+    const int p0 = mrp[boa + x], p1 = mrp[boa + x + 1];
+    if (p1 > p0) {
+      ilo = min(ilo, mcol[p0]);
+      ihi = max(ihi, mcol[p1 - 1]);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    ilo = min(ilo, __shfl_xor(ilo, o, 64));
+    ihi = max(ihi, __shfl_xor(ihi, o, 64));
+  }
+  ilo = __builtin_amdgcn_readfirstlane(ilo);
+  ihi = __builtin_amdgcn_readfirstlane(ihi);
+  const int D = ihi >= ilo ? ihi - ilo + 1 : 0;
+  if (D > DMAXT || Ba > BAMAX) {
+    if (lane == 0) atomicMax(status, TG_BOX_TOOBIG);
+    return;
+  }
+  // ---- dense slice Fd[q][x] = F_a^T[ilo+q, boa+x], structural mask per q
+  for (int s = lane; s < DMAXT * BAMAX; s += 64) Fd[s] = 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  if (lane < D) {
+    unsigned bits = 0;
+    for (int t = trp[ilo + lane]; t < trp[ilo + lane + 1]; t++) {
+      const int x = tcol[t] - boa;
+      if ((unsigned)x < (unsigned)Ba) {
+        Fd[lane * BAMAX + x] = tval[t];
+        bits |= 1u << (Ba - 1 - x);
+      }
+    }
+    fmask[lane] = bits;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+  const int negn01 = -(int)n01, negn0 = -P.nin[0];
+  bool range = false, outside = false;
+  int64_t chunk_pos = 0, chunk_end = 0;         // wave-private piece of the temporary
+  // rowptr pair of operand row `lane` for the output row with coordinate iu along u
+  int64_t ns0 = 0, ns1 = 0;
+  auto fetch = [&](int iu) {
+    ns0 = ns1 = 0;
+    if (lane < len) {
+      const int r0 = a == 0 ? la : (u == 0 ? iu : I[0]);
+      const int r1 = a == 1 ? la : (u == 1 ? iu : I[1]);
+      const int r2 = a == 2 ? la : (u == 2 ? iu : I[2]);
+      const int64_t lr = (int64_t)r0 + (int64_t)P.nin[0] * r1 + n01 * r2 - P.row0;
+      if (lr < 0 || lr >= P.nrows)
+        range = true;
+      else {
+        ns0 = P.rowptr[lr];
+        ns1 = P.rowptr[lr + 1];
+      }
+    }
+  };
+  // box extent along u of step `lane` of the run (runs have at most 64 rows)
+  int ub0 = 0, ub1 = 0;
+  if (u >= 0 && lane < nsteps) {
+    ub0 = ublo[Iu + lane];
+    ub1 = ubhi[Iu + lane];
+  }
+  fetch(u >= 0 ? Iu : 0);
+  // ---- stream of (operand row, 64-entry pass) items, TG_LINE_NB at a time: all loads of a batch
+  // are issued (buffer loads, scalar base, no address VGPRs) before the first item is consumed.
+  // (Issuing batch i+1 before consuming batch i, and the next row's first batch before this row's
+  // contraction, was tried: the second register set costs half the resident waves and was 1.8x
+  // slower -- the kernel is bound by instruction issue once enough waves are resident.)
+  int64_t s0v = ns0;                              // operand rows of the output row being streamed
+  int lnv = (int)min((int64_t)0x7fffffff, ns1 - ns0);
+  int cj = 0, cp = 0;                             // uniform cursor of the loads: operand row, pass
+  int kj = 0, kp = 0;                             // the same walk, replayed when a batch is consumed
+  int lnk = lnv;                                  // row lengths of the output row being consumed
+  const int lastj = max(len, 1) - 1;
+  // (branch-free: items past the end of the row list reload the last row's first entries and are
+  // ignored by the consumer; one basic block per batch keeps the two register sets apart)
+  auto issue = [&](int32_t (&cc)[TG_LINE_NB], double (&vv)[TG_LINE_NB]) {
+#pragma unroll
+    for (int i = 0; i < TG_LINE_NB; i++) {
+      const bool act = cj < len;                  // uniform
+      const int jc = min(cj, lastj);
+      const int64_t s = tg_readlane_i64(s0v, jc);
+      const int l = __builtin_amdgcn_readlane(lnv, jc);
+      const int off = act ? cp * 64 : 0;
+      // entries past the end of the row are loaded (the arrays are padded) and masked.
+      // Buffer loads: the per-item base is a scalar resource, the only address VGPR is lane*4 / lane*8,
+      // so a batch needs no address registers and never waits on the other batch's destinations.
+      const __amdgpu_buffer_rsrc_t rc =
+          __builtin_amdgcn_make_buffer_rsrc(tg_uniform_ptr(P.col + (s + off)), 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rv =
+          __builtin_amdgcn_make_buffer_rsrc(tg_uniform_ptr(P.val + (s + off)), 0, 0x7fffffff, 0x00020000);
+      cc[i] = __builtin_amdgcn_raw_buffer_load_b32(rc, lane * 4, 0, 0);
+      vv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rv, lane * 8, 0, 0));
+      const bool endrow = (cp + 1) * 64 >= l;
+      cp = act ? (endrow ? 0 : cp + 1) : cp;
+      cj = (act && endrow) ? cj + 1 : cj;
+    }
+  };
+  lap(0);
+
+  for (int t = 0; t < nsteps; t++) {
+    const int64_t R = Rfirst + (int64_t)t * rstep;
+    const int64_t li = R - P.out_row0;
+    lnk = lnv;                                    // (lnv is replaced when the next row's loads start)
+    if (t + 1 < nsteps) fetch(Iu + t + 1);        // rowptr pairs of the next output row
+    const bool mrow = mask ? (mask[R] != 0) : false;
+    if (u >= 0) {
+      const int b0 = __builtin_amdgcn_readlane(ub0, t), b1 = __builtin_amdgcn_readlane(ub1, t);
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        if (k == u) {
+          bo[k] = b0;
+          B[k] = b1 - b0 + 1;
+        }
+    }
+    const int nbox = B[0] * B[1] * B[2];
+    if (nbox > Q.capx) {
+      if (lane == 0) atomicMax(status, TG_BOX_TOOBIG);
+      return;
+    }
+    {
+      unsigned long long *x64 = reinterpret_cast<unsigned long long *>(X);
+      for (int s = lane; s < nbox; s += 64) x64[s] = TG_BOX_UNTOUCHED;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+    // ---- scatter
+    {
+      const unsigned cref = (unsigned)((int64_t)bo[0] + (int64_t)P.nin[0] * bo[1] + n01 * bo[2]);
+      const unsigned emax = (unsigned)min((int64_t)0xffffffffll, n01 * B[2]);
+      const int B01 = B[0] * B[1];
+      const unsigned m24a = P.m24a, m24b = P.m24b;
+      // total shift of the 48-bit product (HI: the high word is shifted by the remainder)
+      const unsigned sh24a = HI ? P.sh24a : (P.hi24a ? P.sh24a + 32 : P.sh24a);
+      const unsigned sh24b = HI ? P.sh24b : (P.hi24b ? P.sh24b + 32 : P.sh24b);
+      // column -> box slot with 24-bit multiplies (the host only selects this kernel when they apply)
+      auto add = [&](int32_t c, double v, double w, bool live) {
+        const unsigned e = (unsigned)c - cref;
+        unsigned x2, x1;
+        if (HI) {
+          x2 = tg_mulhi_u24s(m24a, e) >> sh24a;
+        } else {
+          x2 = (unsigned)((((unsigned long long)tg_mulhi_u24s(m24a, e) << 32) | tg_mul_u24s(m24a, e)) >> sh24a);
+        }
+        const int rem = tg_mad_i24s((int)x2, negn01, (int)e);
+        if (HI) {
+          x1 = tg_mulhi_u24s(m24b, (unsigned)rem) >> sh24b;
+        } else {
+          x1 = (unsigned)((((unsigned long long)tg_mulhi_u24s(m24b, (unsigned)rem) << 32) | tg_mul_u24s(m24b, (unsigned)rem)) >> sh24b);
+        }
+        const int x0 = tg_mad_i24s((int)x1, negn0, rem);
+        const bool in = e < emax && (unsigned)x0 < (unsigned)B[0] && x1 < (unsigned)B[1];
+        const int slot = tg_mad_i24s((int)x2, B01, tg_mad_i24s((int)x1, B[0], x0));
+        if (live && in) unsafeAtomicAdd(&X[slot], fma(w, v, 0.0));
+        outside |= live && !in;
+      };
+      auto consume = [&](int32_t (&cc)[TG_LINE_NB], double (&vv)[TG_LINE_NB]) {
+#pragma unroll
+        for (int i = 0; i < TG_LINE_NB; i++) {
+          const bool act = kj < len;              // uniform
+          const int jc = min(kj, lastj);
+          const int l = __builtin_amdgcn_readlane(lnk, jc);
+          const int rem = act ? l - kp * 64 : 0;
+          if (rem > 0) add(cc[i], vv[i], tg_readlane_f64(lw, jc), lane < rem);
+          const bool endrow = (kp + 1) * 64 >= l;
+          kp = act ? (endrow ? 0 : kp + 1) : kp;
+          kj = (act && endrow) ? kj + 1 : kj;
+        }
+      };
+      kj = 0;
+      kp = 0;
+      cj = 0;
+      cp = 0;
+      while (cj < len) {
+        int32_t cc[TG_LINE_NB];
+        double vv[TG_LINE_NB];
+        issue(cc, vv);
+        consume(cc, vv);
+      }
+    }
+    if (t + 1 < nsteps) {
+      s0v = ns0;
+      lnv = (int)min((int64_t)0x7fffffff, ns1 - ns0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    lap(1);
+
+    // ---- contraction along a out of registers: lane <-> one line of the box along a
+    int Bc[3] = {B[0], B[1], B[2]};
+    int org[3] = {bo[0], bo[1], bo[2]};
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      if (k == a) {
+        Bc[k] = D;
+        org[k] = ilo;
+      }
+    const int nlines = nbox / Ba;               // product of the other two extents
+    const int nY = nlines * D;
+    const int sa = a == 0 ? 1 : (a == 1 ? B[0] : B[0] * B[1]);      // stride along a in X
+    // The contracted line overwrites the head of its own line of X (D <= Ba, host-checked): each lane
+    // has its whole line in registers before it stores, lines are disjoint, so no second box is needed.
+    int mycnt = 0;
+    const float invB0 = 1.0f / (float)B[0];
+    for (int o0 = 0; o0 < nlines; o0 += 64) {
+      const int o = o0 + lane;
+      const bool act = o < nlines;
+      int xb;                                     // offset of line o in X
+      if (a == 0)
+        xb = o * Ba;
+      else if (a == 1) {
+        const int x2 = (int)(((float)o + 0.5f) * invB0), x0 = o - x2 * B[0];
+        xb = x0 + B[0] * B[1] * x2;
+      } else
+        xb = o;
+      double xr[BAMAX];
+      unsigned tb = 0;                            // touched flags, bit (Ba-1-x) <-> x (shifted in)
+#pragma unroll
+      for (int x = 0; x < BAMAX; x++) {
+        xr[x] = -0.0;
+        if (x < Ba) {                             // uniform
+          if (act) xr[x] = X[xb + x * sa];
+          tb = tb + tb + (((unsigned long long)__double_as_longlong(xr[x]) != TG_BOX_UNTOUCHED) ? 1u : 0u);
+        }
+      }
+#pragma unroll 1
+      for (int q = 0; q < D; q++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int x = 0; x < BAMAX; x++)
+          if (x < Ba) acc = fma(xr[x], Fd[q * BAMAX + x], acc);   // untouched operands add +-0.0
+        const bool tch = (tb & fmask[q]) != 0;
+        if (act) {
+          X[xb + q * sa] = tch ? acc : -0.0;
+          mycnt += tch ? 1 : 0;
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) mycnt += __shfl_xor(mycnt, o, 64);
+    const int nK = __builtin_amdgcn_readfirstlane(mycnt);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    lap(2);
+
+    // ---- reserve, write: slots of the contracted box in lexicographic = column order
+    const unsigned long long *xbits = reinterpret_cast<const unsigned long long *>(X);
+    if (chunk_pos + nK > chunk_end) {             // uniform
+      unsigned long long o = 0;
+      // the rows of a run have similar lengths: reserve for what is left of the run, capped
+      const int64_t grab = max((int64_t)nK, min(Q.grab, (int64_t)nK * (nsteps - t) * 5 / 4 + 32));
+      if (lane == 0) o = atomicAdd(cursor, (unsigned long long)grab);
+      chunk_pos = tg_readlane_i64((int64_t)o, 0);
+      chunk_end = chunk_pos + grab;
+      if (chunk_end > capacity) {
+        if (lane == 0) atomicMax(status, TG_BOX_CAP);
+        return;
+      }
+    }
+    if (lane == 0) {
+      row_cnt[li] = nK;
+      row_off[li] = chunk_pos;
+    }
+    const int64_t m0 = P.nout[0];
+    const float inv0 = 1.0f / (float)Bc[0], inv1 = 1.0f / (float)Bc[1];
+    int64_t pos = chunk_pos;
+    for (int s0 = 0; s0 < nY; s0 += 64) {
+      const int s = s0 + lane;
+      // (exact: s < 2^16 and s * Bc < 2^21, far inside float precision at the half-integer offsets)
+      const int y12 = (int)(((float)s + 0.5f) * inv0);
+      const int y0 = s - y12 * Bc[0];
+      const int y2 = (int)(((float)y12 + 0.5f) * inv1);
+      const int y1 = y12 - y2 * Bc[1];
+      const int xi = y0 + B[0] * (y1 + B[1] * y2);
+      const bool occ = s < nY && xbits[xi] != TG_BOX_UNTOUCHED;
+      const unsigned long long bm = __ballot(occ);
+      if (occ) {
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int64_t dst = pos + __popcll(bm & below);
+        const int64_t c = (int64_t)(org[0] + y0) + m0 * (org[1] + y1) + m01 * (org[2] + y2);
+        double v = X[xi];
+        if (mask && (mrow || mask[c])) v = (mrow && c == R) ? diag : 0.0;
+        k_col[dst] = (int32_t)c;
+        k_val[dst] = v;
+      }
+      pos += __popcll(bm);
+    }
+    chunk_pos += nK;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    lap(3);
+  }
+  if (range) atomicMax(status, TG_BOX_RANGE);
+  if (outside) atomicMax(status, TG_BOX_OUTSIDE);
+}
+
 static size_t tg_box_lds(int cap, int cap1, int ctab, int nlist, int nt) {
   size_t b = ((size_t)cap + cap1) * 8 + (size_t)nt * 16 + (size_t)nlist * 8 + (size_t)ctab * 8;   // f64 / i64 part
   b += (size_t)nt * 4 + 128 + (size_t)nlist * 4 + 3 * TG_BOX_MAXD * 4 + (size_t)ctab * 4;
@@ -732,6 +1250,55 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
   P.cap = cap;
   tg_magic((unsigned)((int64_t)P.nin[0] * P.nin[1]), &P.mg01, &P.sh01);
   tg_magic((unsigned)P.nin[0], &P.mg0, &P.sh0);
+  {
+    const uint64_t n01u = (uint64_t)P.nin[0] * P.nin[1];
+    P.fast24 = 0;
+    if (!getenv("TIGAR_BOX_SLOWDECODE") && n01u < (1u << 23) && n01u * (uint64_t)maxBk[2] <= (1u << 24) &&
+        (int64_t)maxBk[0] * maxBk[1] < (1 << 23) &&
+        tg_magic24((unsigned)n01u, n01u * (uint64_t)maxBk[2], &P.m24a, &P.sh24a, &P.hi24a) &&
+        tg_magic24((unsigned)P.nin[0], n01u, &P.m24b, &P.sh24b, &P.hi24b))
+      P.fast24 = 1;
+  }
+  unsigned long long *prof = nullptr;
+  if (getenv("TIGAR_BOX_PROF") && !tg_dmalloc(&prof, 8)) {
+    dev.push_back(prof);
+    hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), g_tg.stream);
+    P.prof = prof;
+  }
+  // one contracted direction: wave-per-run "line" kernel
+  tg_line_args Q;
+  memset(&Q, 0, sizeof(Q));
+  int line_variant = 0;          // 0: no, 1: <20,10>, 2: <32,16>
+  size_t line_lds = 0;
+  {
+    int ncon = 0, a = -1;
+    for (int k = 0; k < d; k++)
+      if (P.contracted[k]) {
+        ncon++;
+        a = k;
+      }
+    const char *env = getenv("TIGAR_PTAP_LINE");
+    if (ncon == 1 && !(env && atoi(env) == 0) && P.cstr[a] <= 64 && boxmax <= (1 << 16) && P.fast24) {
+      if (maxBk[a] <= 20 && Dmax[a] <= 10)
+        line_variant = 1;
+      else if (maxBk[a] <= 32 && Dmax[a] <= 16)
+        line_variant = 2;
+      Q.a = a;
+      Q.capx = (int)((boxmax + 7) & ~7ll);
+      Q.capy = 0;                                  // (contracted in place)
+      if (Dmax[a] > maxBk[a]) line_variant = 0;
+      const int bam = line_variant == 1 ? 20 : 32, dmt = line_variant == 1 ? 10 : 16;
+      line_lds = ((size_t)Q.capx + (size_t)bam * dmt + dmt) * 8;
+      if (line_lds > 60 * 1024) line_variant = 0;
+      // direction of the runs: the first uncontracted one; instantiated (a, u) pairs only
+      int u = -1;
+      for (int k = 0; k < d && u < 0; k++)
+        if (!P.contracted[k] && P.nout[k] > 1) u = k;
+      if (!((a == 0 && u == 1) || (a >= 1 && u == 0))) u = -1;
+      if (u < 0 && a != 0) line_variant = 0;
+      Q.u = u;
+    }
+  }
   if ((int64_t)P.nin[0] * P.nin[1] >= (1ll << 31) || nin_total >= (1ll << 31)) {
     cleanup();
     tg_set_error("tg_ptap_kron: index space too large for 32-bit decomposition");
@@ -767,6 +1334,7 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
     if (!rc) {
       // probe a sample of rows: mean row length -> capacity of the temporary
       tg_box_args S = P;
+      S.prof = nullptr;
       const int64_t nsample = std::min<int64_t>(nrows, 512);
       S.out_nrows = nsample;
       S.row_stride = std::max<int64_t>(1, nrows / nsample);
@@ -795,13 +1363,72 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
       mean_k = (double)total / (double)nsample;
     }
     int64_t capacity = (int64_t)(mean_k * 1.05 * (double)nrows) + hmax[2] + 1024;
+    if (line_variant) capacity = (int64_t)(capacity * 1.3) + nrows / 8 * 64;   // slack of the wave-private chunks
     for (int attempt = 0; attempt < 6 && !rc; attempt++) {
       rc = tg_dmalloc(&tcol, capacity + TG_CSR_PAD) || tg_dmalloc(&tval, capacity + TG_CSR_PAD);
       if (rc) break;
       hipMemsetAsync(status, 0, 3 * sizeof(int), g_tg.stream);
       hipMemsetAsync(cursor, 0, sizeof(unsigned long long), g_tg.stream);
       hipMemsetAsync(cnt, 0, (size_t)(nrows + 1) * sizeof(int64_t), g_tg.stream);
-      if (nt == 64)
+      if (line_variant) {
+        // runs along the first uncontracted direction; output space in wave-private chunks
+        const int u = Q.u;
+        int64_t nwaves = nrows;
+        if (u >= 0) {
+          const int64_t m0 = P.nout[0], m1 = P.nout[1], m01 = m0 * m1;
+          const int64_t ra = out_row0, rb = out_row1 - 1;
+          int64_t ulo, uhi, x0, nx;
+          if (u == 2) {
+            ulo = ra / m01;
+            uhi = rb / m01;
+            x0 = 0;
+            nx = m01;
+          } else if (u == 1) {
+            ulo = 0;
+            uhi = m1 - 1;
+            x0 = m0 * (ra / m01);
+            nx = m0 * (rb / m01 - ra / m01 + 1);
+          } else {
+            ulo = 0;
+            uhi = m0 - 1;
+            x0 = ra / m0;
+            nx = rb / m0 - x0 + 1;
+          }
+          const int64_t span = uhi - ulo + 1;
+          int64_t T = std::min<int64_t>(getenv("TIGAR_LINE_RUN") ? std::max(1, atoi(getenv("TIGAR_LINE_RUN"))) : 32, span);
+          while (T > 1 && nx * tg_cdiv(span, T) < (int64_t)g_tg.num_cu * 64) T = (T + 1) / 2;
+          Q.mlen = (int)T;
+          Q.ulo = (int)ulo;
+          Q.uhi = (int)uhi;
+          Q.x0 = x0;
+          Q.nx = nx;
+          Q.nchunk = tg_cdiv(span, T);
+          nwaves = nx * Q.nchunk;
+        }
+        Q.grab = getenv("TIGAR_LINE_GRAB") ? atoll(getenv("TIGAR_LINE_GRAB")) : 8192;
+        const unsigned grid = (unsigned)(tg_cdiv(nwaves, 8) * 8);
+#define TG_LINE_LAUNCH(BA, DM, AA, UU)                                                                                 \
+  do {                                                                                                                  \
+    if (line_hi)                                                                                                        \
+      hipLaunchKernelGGL((k_ptap_line<BA, DM, AA, UU, true>), dim3(grid), dim3(64), line_lds, g_tg.stream, P, Q, cnt,  \
+                         off, tcol, tval, cursor, capacity, (const uint8_t *)mask, diag, status);                      \
+    else                                                                                                                \
+      hipLaunchKernelGGL((k_ptap_line<BA, DM, AA, UU, false>), dim3(grid), dim3(64), line_lds, g_tg.stream, P, Q, cnt, \
+                         off, tcol, tval, cursor, capacity, (const uint8_t *)mask, diag, status);                      \
+  } while (0)
+#define TG_LINE_DISPATCH(BA, DM)                                  \
+  do {                                                            \
+    if (Q.a == 0 && u == 1) TG_LINE_LAUNCH(BA, DM, 0, 1);         \
+    else if (Q.a == 1 && u == 0) TG_LINE_LAUNCH(BA, DM, 1, 0);    \
+    else if (Q.a == 2 && u == 0) TG_LINE_LAUNCH(BA, DM, 2, 0);    \
+    else TG_LINE_LAUNCH(BA, DM, 0, -1);                           \
+  } while (0)
+        const bool line_hi = P.hi24a && P.hi24b;
+        if (line_variant == 1)
+          TG_LINE_DISPATCH(20, 10);
+        else
+          TG_LINE_DISPATCH(32, 16);
+      } else if (nt == 64)
         hipLaunchKernelGGL((k_ptap_box<TG_BOXMODE_BUMP, 64>), dim3((unsigned)(tg_cdiv(nrows, 8) * 8)), dim3(64), lds,
                            g_tg.stream, P, cnt, off, tcol, tval, cursor, capacity, (const uint8_t *)mask, diag, status,
                            status + 1);
@@ -817,6 +1444,14 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
         tg_set_error("tg_ptap_kron: kernel failed to run (LDS %zu B)", lds);
         rc = 1;
         break;
+      }
+      if (prof) {
+        unsigned long long hp[8];
+        hipMemcpy(hp, prof, sizeof(hp), hipMemcpyDeviceToHost);
+        const double tot = (double)(hp[0] + hp[1] + hp[2] + hp[3]) + 1e-30;
+        fprintf(stderr, "[tigar] %s phases (%lld rows, fast24=%d): setup %.1f%%  scatter %.1f%%  contract %.1f%%  write %.1f%%\n",
+                line_variant ? "line" : "box", (long long)nrows, P.fast24, 100.0 * hp[0] / tot, 100.0 * hp[1] / tot,
+                100.0 * hp[2] / tot, 100.0 * hp[3] / tot);
       }
       if (h == TG_BOX_OK) break;
       tg_dfree(tcol);

@@ -135,7 +135,10 @@ class SlabHotPath(object):
         from .kronptap import default_groups
         self.groups = default_groups(basis.nvar, max(s1.p for s1 in basis.splines))
         if env is not None and env not in ("0", "1"):           # e.g. TIGAR_PTAP_FACTORED=0,1;2 or 0;1;2
-            self.groups = [[int(c) for c in g.split(",")] for g in env.split(";")]
+            g_env = [[int(c) for c in g.split(",") if int(c) < basis.nvar] for g in env.split(";")]
+            g_env = [g for g in g_env if g]
+            if sorted(sum(g_env, [])) == list(range(basis.nvar)):
+                self.groups = g_env
         if factored is True and len(self.groups) == 1:
             self.groups = [[k] for k in range(basis.nvar)]
         explicit = env is not None and env not in ("0", "1")
