@@ -201,6 +201,26 @@ int tg_kron_csr_rect(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t
                      int64_t row1, int filter, double eps, int64_t col_offset, int64_t ncols_total,
                      tg_csr_t *out);
 
+/* ---- FE-side operator assembly on mapped tensor-product patches ----
+ * Stands in for dolfin.assemble(form) (tIGAr/common.py:1206-1220) with the spline's measures:
+ * geometry F = cp[i]/cp[nsd] (tIGAr/common.py:917-921), metric g = DF^T DF, volume element
+ * sqrt(det g) (tIGAr/calculusUtils.py:66-70), Cartesian gradient through pinv(DF)
+ * (tIGAr/calculusUtils.py:56-64), Gauss-Legendre quadrature with nq points per direction
+ * (quadrature_degree 2p <-> nq = p+1).  Scalar Q_p Lagrange space on the tensor node grid with
+ * direction 0 fastest; nsd >= d (surfaces: Laplace-Beltrami). */
+typedef struct {
+  int d, p;                 /* parametric dimension, FE degree                        */
+  const double *verts[3];   /* element vertices per direction (host), nverts[k] each  */
+  int nverts[3];
+  int nsd;                  /* physical dimension, d <= nsd <= 3                      */
+  tg_vec_t cp[4];           /* nsd+1 homogeneous control functions on the FE nodes    */
+  int nq;                   /* Gauss points per direction                             */
+} tg_patch_t;
+/* form: 0 = (u,v), 1 = (grad u, grad v); result on the element-coupling pattern */
+int tg_assemble_mapped_matrix(const tg_patch_t *patch, int form, tg_csr_t *out);
+/* L(v) = (f_h, v) with f_h the nodal interpolant of fnodal */
+int tg_assemble_mapped_load(const tg_patch_t *patch, tg_vec_t fnodal, tg_vec_t out);
+
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------- */
 int tg_comm_unique_id(char *id128);                          /* ncclGetUniqueId   */
 int tg_comm_create(const char *id128, int rank, int world, tg_comm_t *out);

@@ -37,6 +37,11 @@ class tg_kron_dir_t(C.Structure):
     _fields_ = [("n", C.c_int64), ("rowptr", c_i32p), ("col", c_i32p), ("val", c_f64p)]
 
 
+class tg_patch_t(C.Structure):
+    _fields_ = [("d", C.c_int), ("p", C.c_int), ("verts", c_f64p * 3), ("nverts", C.c_int * 3),
+                ("nsd", C.c_int), ("cp", handle * 4), ("nq", C.c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/tigar_hip.h one to one
 PROTOTYPES = {
     "tg_init": (C.c_int, [C.c_int]),
@@ -103,6 +108,8 @@ PROTOTYPES = {
                                   C.POINTER(handle)]),
     "tg_kron_csr_rect": (C.c_int, [C.c_int, C.c_int, C.POINTER(tg_kron_dir_t), c_i64p, C.c_int64, C.c_int64,
                                    C.c_int, C.c_double, C.c_int64, C.c_int64, C.POINTER(handle)]),
+    "tg_assemble_mapped_matrix": (C.c_int, [C.POINTER(tg_patch_t), C.c_int, C.POINTER(handle)]),
+    "tg_assemble_mapped_load": (C.c_int, [C.POINTER(tg_patch_t), handle, handle]),
     "tg_comm_unique_id": (C.c_int, [C.c_char_p]),
     "tg_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(handle)]),
     "tg_comm_set_slab": (C.c_int, [handle, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import check, handle, tg_dir_t, tg_kron_dir_t, tg_kron1d_t, c_f64p, c_i32p, c_i64p
+from ._lib import check, handle, tg_dir_t, tg_kron_dir_t, tg_kron1d_t, tg_patch_t, c_f64p, c_i32p, c_i64p
 
 TG_KSP_CG, TG_KSP_GMRES = 0, 1
 TG_PC_NONE, TG_PC_JACOBI = 0, 1
@@ -466,6 +466,40 @@ def kron_csr_rect(factors, row0=None, row1=None):
     check(_lib.lib().tg_kron_csr_rect(d, 1, arr, _p(cdim, c_i64p), row0, row1, 0, 0.0, 0, -1, C.byref(h)),
           "tg_kron_csr_rect")
     return DeviceCSR(h)
+
+
+def _patch(vertices, p, cp, nq):
+    d = len(vertices)
+    pt = tg_patch_t()
+    keep = []
+    pt.d, pt.p, pt.nsd, pt.nq = d, int(p), len(cp) - 1, int(nq)
+    for k in range(d):
+        v = _f64(vertices[k])
+        keep.append(v)
+        pt.verts[k] = _p(v, c_f64p)
+        pt.nverts[k] = len(v)
+    for c, vec in enumerate(cp):
+        pt.cp[c] = vec._h
+    return pt, keep
+
+
+def assemble_mapped_matrix(vertices, p, cp, form, nq=None):
+    """FE mass (form 'mass') or stiffness ('laplace') matrix of the scalar Q_p space on the tensor
+    grid with element ``vertices`` per direction, geometry F = cp[i]/cp[nsd] given by DeviceVectors on
+    the FE nodes (dolfin.assemble stand-in, tIGAr/common.py:1206-1220, 917-945)."""
+    pt, keep = _patch(vertices, p, cp, p + 1 if nq is None else nq)
+    h = handle()
+    check(_lib.lib().tg_assemble_mapped_matrix(C.byref(pt), {"mass": 0, "laplace": 1}[form], C.byref(h)),
+          "tg_assemble_mapped_matrix")
+    return DeviceCSR(h)
+
+
+def assemble_mapped_load(vertices, p, cp, fnodal, nq=None):
+    """L(v) = int f_h v dx with f_h the nodal interpolant of the DeviceVector ``fnodal``."""
+    pt, keep = _patch(vertices, p, cp, p + 1 if nq is None else nq)
+    out = DeviceVector(n=fnodal.size())
+    check(_lib.lib().tg_assemble_mapped_load(C.byref(pt), fnodal._h, out._h), "tg_assemble_mapped_load")
+    return out
 
 
 def vec_tensor3(b1d, scale=1.0, row0=None, row1=None):

@@ -133,8 +133,25 @@ def _memo(obj, V, build):
     return cache[key]
 
 
+def _mapped(geometry, V, form):
+    """dolfin.assemble stand-in on a mapped patch: ``geometry`` is a generator / ExtractedSpline
+    whose ``cpFuncs`` (nsd+1 homogeneous control functions on the FE nodes of ``V_control``) define
+    F = cpFuncs[i]/cpFuncs[nsd] (tIGAr/common.py:917-921); metric-based measure and gradient."""
+    g = _single_grid(V)
+    gc = _single_grid(geometry.V_control)
+    if gc.shape() != g.shape():
+        raise ValueError("the geometry lives on a different node grid than the space")
+    cp = [f.vector() for f in geometry.cpFuncs]
+    return _dev.assemble_mapped_matrix([g.vertices[k] for k in range(g.dim())], g.degree, cp, form)
+
+
 class LaplaceForm(object):
-    """a(u,v) = int grad u . grad v on the parametric box."""
+    """a(u,v) = int grad u . grad v: on the parametric box (Kronecker sum of 1-D factors), or --
+    with ``geometry`` (a generator or ExtractedSpline) -- in physical space on the mapped patch,
+    grad and dx as ``spline.grad`` / ``spline.dx`` (tIGAr/common.py:917-945)."""
+
+    def __init__(self, geometry=None):
+        self.geometry = geometry
 
     def factors(self, V):
         def build():
@@ -145,18 +162,51 @@ class LaplaceForm(object):
         return _memo(self, V, build)
 
     def assemble_matrix(self, V, row0=None, row1=None):
+        if self.geometry is not None:
+            if row0 is not None or row1 is not None:
+                raise NotImplementedError("row blocks of mapped forms")
+            return _mapped(self.geometry, V, "laplace")
         return _dev.kron_sum_csr(self.factors(V), row0, row1)
 
 
 class MassForm(object):
-    """a(u,v) = int u v."""
+    """a(u,v) = int u v (``geometry``: see LaplaceForm)."""
+
+    def __init__(self, geometry=None):
+        self.geometry = geometry
 
     def factors(self, V):
         g = _single_grid(V)
         return [[fe_matrices_1d(g.vertices[k], g.degree)[0] for k in range(g.dim())]]
 
     def assemble_matrix(self, V, row0=None, row1=None):
+        if self.geometry is not None:
+            if row0 is not None or row1 is not None:
+                raise NotImplementedError("row blocks of mapped forms")
+            return _mapped(self.geometry, V, "mass")
         return _dev.kron_sum_csr(self.factors(V), row0, row1)
+
+
+class NodalLoadForm(object):
+    """L(v) = int f_h v dx on the mapped patch, f_h = nodal interpolant of ``f`` evaluated at the
+    physical node positions x = F(node) (array of shape [nnodes, nsd] -> values), or given node
+    values directly."""
+
+    def __init__(self, f, geometry):
+        self.f, self.geometry = f, geometry
+
+    def assemble_vector(self, V, row0=None, row1=None):
+        if row0 is not None or row1 is not None:
+            raise NotImplementedError("row blocks of mapped forms")
+        g = _single_grid(V)
+        cp = [fn.vector() for fn in self.geometry.cpFuncs]
+        if callable(self.f):
+            c = [v.get_local() for v in cp]
+            x = numpy.stack([c[i] / c[-1] for i in range(len(c) - 1)], axis=1)
+            fn = _dev.DeviceVector(data=numpy.asarray(self.f(x), dtype=numpy.float64))
+        else:
+            fn = self.f if isinstance(self.f, _dev.DeviceVector) else _dev.DeviceVector(data=self.f)
+        return _dev.assemble_mapped_load([g.vertices[k] for k in range(g.dim())], g.degree, cp, fn)
 
 
 class SeparableLoadForm(object):
