@@ -53,6 +53,7 @@ int tg_vec_copy(tg_vec_t dst, tg_vec_t src);
 int tg_vec_copy_range(tg_vec_t dst, int64_t dst_off, tg_vec_t src, int64_t src_off, int64_t n);
 int tg_vec_axpy(tg_vec_t y, double a, tg_vec_t x);          /* y += a x */
 int tg_vec_dot(tg_vec_t x, tg_vec_t y, double *out);        /* deterministic two-stage */
+int tg_vec_pointwise_mult(tg_vec_t w, tg_vec_t x, tg_vec_t y);   /* w = x .* y (VecPointwiseMult) */
 /* as_backend_type(MTb).vec().setValues(zeroDofs, 0)  -- tIGAr/common.py:1154-1158 */
 int tg_vec_zero_entries(tg_vec_t y, const int32_t *dofs, int64_t n);
 /* same for a slab-local vector holding global entries [g0, g0 + size(y)) */
@@ -171,6 +172,10 @@ int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, 
 /* MatZeroRowsColumns(K, zeroDofs, diag) [ext] as called at tIGAr/common.py:1200;
  * K holds global rows [row0, row0+nrows). */
 int tg_zero_rows_cols(tg_csr_t k, int64_t row0, const int32_t *dofs, int64_t n, double diag);
+/* out = a X + b Y diag(colscale) for X, Y on one sparsity pattern (checked); colscale may be NULL.
+ * Tangent matrices J(u) of Newton loops over the path (tIGAr/common.py:1304-1348), e.g.
+ * K + M diag(g'(u)): MatAXPY(SAME_NONZERO_PATTERN) + MatDiagonalScale [ext]. */
+int tg_csr_combine(double a, tg_csr_t X, double b, tg_csr_t Y, tg_vec_t colscale, tg_csr_t *out);
 
 /* ---- Krylov solve (solveLinearSystem, tIGAr/common.py:1236-1263; seam b-4) -------- */
 enum { TG_KSP_CG = 0, TG_KSP_GMRES = 1 };

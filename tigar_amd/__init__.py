@@ -12,5 +12,6 @@ from .common import *          # noqa: F401,F403
 from .common import (AbstractExtractionGenerator, AbstractCoordinateChartSpline, AbstractScalarBasis,
                      AbstractControlMesh, AbstractMultiFieldSpline, EqualOrderSpline, FieldListSpline,
                      ExtractedSpline, PETScKrylovSolver, KrylovSolver, Function, TensorFunctionSpace,
-                     TensorNodeGrid, multTranspose, generateIdentityPermutation)
+                     TensorNodeGrid, multTranspose, generateIdentityPermutation,
+                     ExtractedNonlinearProblem, ExtractedNonlinearSolver, NewtonSolver)
 from .NURBS import NURBSControlMesh      # noqa: E402,F401

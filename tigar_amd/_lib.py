@@ -108,6 +108,8 @@ PROTOTYPES = {
                                   C.POINTER(handle)]),
     "tg_kron_csr_rect": (C.c_int, [C.c_int, C.c_int, C.POINTER(tg_kron_dir_t), c_i64p, C.c_int64, C.c_int64,
                                    C.c_int, C.c_double, C.c_int64, C.c_int64, C.POINTER(handle)]),
+    "tg_vec_pointwise_mult": (C.c_int, [handle, handle, handle]),
+    "tg_csr_combine": (C.c_int, [C.c_double, handle, C.c_double, handle, handle, C.POINTER(handle)]),
     "tg_assemble_mapped_matrix": (C.c_int, [C.POINTER(tg_patch_t), C.c_int, C.POINTER(handle)]),
     "tg_assemble_mapped_load": (C.c_int, [C.POINTER(tg_patch_t), handle, handle]),
     "tg_comm_unique_id": (C.c_int, [C.c_char_p]),

@@ -17,6 +17,7 @@ instead of the reference's ``print("ERROR"); exit()``.
 """
 import abc
 import os
+import sys
 import numpy
 from numpy import array, zeros, arange
 
@@ -703,4 +704,133 @@ class ExtractedSpline(object):
         self.linearSolver = linearSolver
 
     def FEtoIGA(self, u):
-        raise NotImplementedError("FEtoIGA (tIGAr/common.py:968-994) is outside the hot path")
+        """IGA dofs from the FE coefficients of ``u`` by the pseudo-inverse problem
+        (M^T M) x = M^T u (tIGAr/common.py:968-994); uses ``self.linearSolver`` if set."""
+        uv = _as_device_vector(u)
+        MTtemp = self.extractVector(uv, applyBCs=False)
+        ident = DeviceCSR.from_scipy(_scipy_identity(self.M.shape[0]))
+        MTM = self.extractMatrix(ident, applyBCs=False)
+        x = DeviceVector(self.M.shape[1])
+        if self.linearSolver is None:
+            solver = PETScKrylovSolver("cg", "jacobi")
+            solver.parameters["relative_tolerance"] = 1e-12
+            solver.parameters["maximum_iterations"] = 100000
+            solver.solve(MTM, x, MTtemp)
+        else:
+            self.linearSolver.solve(MTM, x, MTtemp)
+        return x
+
+    def solveNonlinearVariationalProblem(self, residualForm, J, u, referenceError=None, igaDoFs=None):
+        """Newton iteration of tIGAr/common.py:1304-1348, same control flow: assemble
+        (M^T J M, M^T R) at the current ``u``, stop when ||M^T R|| / reference < relativeTolerance
+        (reference = first norm unless given), else solve for the increment and ``u <- u - du``
+        (``igaDoFs -= increment`` when IGA dofs are passed; they also seed ``u = M*igaDoFs``).
+        ``residualForm`` / ``J`` are form objects whose ``assemble_vector`` / ``assemble_matrix``
+        read the current state of ``u`` (as UFL forms reference their coefficient).  Prints the
+        reference's progress line; non-convergence raises instead of the reference's exit().
+        Returns the list of relative norms."""
+        returningDoFs = igaDoFs is not None
+        uv = _as_device_vector(u)
+        if returningDoFs:
+            self.M.mult(igaDoFs, uv)
+        history = []
+        converged = False
+        for i in range(0, self.maxIters):
+            MTAM, MTb = self.assembleLinearSystem(J, residualForm)
+            currentNorm = MTb.norm("l2")
+            if i == 0 and referenceError is None:
+                referenceError = currentNorm
+            relativeNorm = currentNorm / referenceError
+            history.append(relativeNorm)
+            if mpirank == 0:
+                print("Solver iteration: " + str(i) + " , Relative norm: " + str(relativeNorm))
+                sys.stdout.flush()
+            if relativeNorm < self.relativeTolerance:
+                converged = True
+                break
+            du = Function(self.V)
+            igaIncrement = self.solveLinearSystem(MTAM, MTb, du)
+            uv.axpy(-1.0, du.vector())
+            if returningDoFs:
+                igaDoFs.axpy(-1.0, igaIncrement)
+        if not converged:
+            raise RuntimeError("Nonlinear solver failed to converge.")
+        return history
+
+
+
+def _scipy_identity(n):
+    import scipy.sparse as _sp
+    return _sp.identity(n, format="csr")
+
+
+class NewtonSolver(object):
+    """Minimal stand-in for dolfin ``NewtonSolver`` [ext] driving an ``ExtractedNonlinearProblem``:
+    ``parameters`` relative_tolerance / absolute_tolerance / maximum_iterations /
+    relaxation_parameter; linear solves through ``linear_solver`` (``.solve(A,x,b)``) or the
+    spline's."""
+
+    def __init__(self, linear_solver=None):
+        self.linear_solver = linear_solver
+        self.parameters = {"relative_tolerance": 1e-9, "absolute_tolerance": 1e-10,
+                           "maximum_iterations": 50, "relaxation_parameter": 1.0,
+                           "error_on_nonconvergence": True}
+        self.last = {}
+
+    def solve(self, problem, x):
+        prm = self.parameters
+        r0 = None
+        for it in range(int(prm["maximum_iterations"]) + 1):
+            problem.form(None, None, None, x)
+            b = problem.F(None, x)
+            rn = b.norm("l2")
+            r0 = rn if r0 is None else r0
+            self.last = {"iterations": it, "residual": rn, "relative": rn / r0 if r0 > 0 else 0.0}
+            if rn < prm["absolute_tolerance"] or (r0 > 0 and rn / r0 < prm["relative_tolerance"]):
+                return it, True
+            if it == int(prm["maximum_iterations"]):
+                break
+            A = problem.J(None, x)
+            dx = DeviceVector(x.size())
+            ls = self.linear_solver or problem.spline.linearSolver
+            if ls is None:
+                ls = PETScKrylovSolver("gmres", "jacobi")
+                ls.parameters["relative_tolerance"] = 1e-12
+                ls.parameters["maximum_iterations"] = 100000
+            ls.solve(A, dx, b)
+            x.axpy(-float(prm["relaxation_parameter"]), dx)
+        if prm["error_on_nonconvergence"]:
+            raise RuntimeError("Newton solver did not converge")
+        return int(prm["maximum_iterations"]), False
+
+
+class ExtractedNonlinearProblem(object):
+    """Nonlinear problem posed on an extracted spline for external Newton/SNES-type solvers
+    (tIGAr/common.py:504-545): ``form`` pushes the IGA dofs into the FE solution (M*x), ``F`` / ``J``
+    return the extracted residual / tangent."""
+
+    def __init__(self, spline, residual, tangent, solution, **kwargs):
+        self.spline, self.residual, self.tangent, self.solution = spline, residual, tangent, solution
+
+    def form(self, A, P, B, x):
+        self.spline.M.mult(x, self.solution.vector())
+
+    def F(self, b, x):
+        return self.spline.assembleVector(self.residual)
+
+    def J(self, A, x):
+        return self.spline.assembleMatrix(self.tangent)
+
+
+class ExtractedNonlinearSolver(object):
+    """tIGAr/common.py:547-584: initial IGA dofs by ``FEtoIGA`` of the current solution, solve, then
+    the FE representation of the result is stored in ``problem.solution``."""
+
+    def __init__(self, problem, solver):
+        self.problem, self.solver = problem, solver
+
+    def solve(self):
+        tempVec = self.problem.spline.FEtoIGA(self.problem.solution)
+        self.solver.solve(self.problem, tempVec)
+        self.problem.spline.M.mult(tempVec, self.problem.solution.vector())
+        return tempVec

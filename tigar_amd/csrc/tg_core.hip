@@ -297,6 +297,21 @@ extern "C" int tg_vec_axpy(tg_vec_t y, double a, tg_vec_t x) {
   return 0;
 }
 
+__global__ void k_pointwise_mult(double *w, const double *x, const double *y, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) w[i] = x[i] * y[i];
+}
+
+// w = x .* y (PETSc VecPointwiseMult; w may alias x or y)
+extern "C" int tg_vec_pointwise_mult(tg_vec_t w, tg_vec_t x, tg_vec_t y) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(w && x && y && x->n == y->n && w->n == x->n, "size mismatch in tg_vec_pointwise_mult");
+  hipLaunchKernelGGL(k_pointwise_mult, dim3(tg_grid_1d(w->n, 256)), dim3(256), 0, g_tg.stream, w->d, x->d, y->d, w->n);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- deterministic dot: fixed grid of partial sums, then one block folds them ---------
 
 

@@ -510,3 +510,63 @@ extern "C" int tg_zero_rows_cols(tg_csr_t k, int64_t row0, const int32_t *dofs, 
   tg_dfree(mask);
   return 0;
 }
+
+// ---- out = a X + b Y diag(colscale) for two matrices on ONE pattern (tangent matrices of
+// semilinear problems: K + M diag(g'(u)); PETSc MatAXPY with SAME_NONZERO_PATTERN + MatDiagonalScale)
+__global__ void k_csr_combine(int64_t nnz, const int32_t *__restrict__ colx, const int32_t *__restrict__ coly,
+                              const double *__restrict__ vx, const double *__restrict__ vy, double a, double b,
+                              const double *__restrict__ cs, int32_t *__restrict__ colo, double *__restrict__ vo,
+                              int *__restrict__ mismatch) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; q < nnz; q += stride) {
+    const int32_t c = colx[q];
+    bad |= (c != coly[q]);
+    colo[q] = c;
+    vo[q] = a * vx[q] + b * vy[q] * (cs ? cs[c] : 1.0);
+  }
+  if (bad) atomicOr(mismatch, 1);
+}
+
+__global__ void k_rowptr_equal(int64_t n, const int64_t *__restrict__ a, const int64_t *__restrict__ b, int64_t *__restrict__ o,
+                               int *__restrict__ mismatch) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; q < n; q += stride) {
+    bad |= (a[q] != b[q]);
+    o[q] = a[q];
+  }
+  if (bad) atomicOr(mismatch, 1);
+}
+
+extern "C" int tg_csr_combine(double a, tg_csr_t X, double b, tg_csr_t Y, tg_vec_t colscale, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(X && Y && out, "bad arguments to tg_csr_combine");
+  TG_REQUIRE(X->nrows == Y->nrows && X->ncols == Y->ncols && X->nnz == Y->nnz, "tg_csr_combine: the operands differ in shape or nnz");
+  TG_REQUIRE(!colscale || colscale->n == X->ncols, "tg_csr_combine: column scaling has the wrong length");
+  tg_csr_s *m = nullptr;
+  TG_TRY(tg_csr_alloc(X->nrows, X->ncols, X->nnz, &m));
+  int *flag = (int *)g_tg.scratch;
+  hipMemsetAsync(flag, 0, sizeof(int), g_tg.stream);
+  hipLaunchKernelGGL(k_rowptr_equal, dim3(tg_grid_1d(X->nrows + 1, 256)), dim3(256), 0, g_tg.stream, X->nrows + 1, X->rowptr,
+                     Y->rowptr, m->rowptr, flag);
+  if (X->nnz > 0)
+    hipLaunchKernelGGL(k_csr_combine, dim3(tg_grid_1d(X->nnz, 256)), dim3(256), 0, g_tg.stream, X->nnz, X->col, Y->col, X->val,
+                       Y->val, a, b, colscale ? colscale->d : (const double *)nullptr, m->col, m->val, flag);
+  int h = 0;
+  hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
+  if (hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+    tg_csr_destroy(m);
+    tg_set_error("tg_csr_combine: kernel failed");
+    return 1;
+  }
+  if (h) {
+    tg_csr_destroy(m);
+    tg_set_error("tg_csr_combine: the operands do not share one sparsity pattern");
+    return 2;
+  }
+  *out = m;
+  return 0;
+}

@@ -83,6 +83,12 @@ class DeviceVector(object):
     def axpy(self, a, x):
         check(_lib.lib().tg_vec_axpy(self._h, float(a), x._h))
 
+    def pointwise_mult(self, other, out=None):
+        """out = self .* other (PETSc VecPointwiseMult)"""
+        out = DeviceVector(self.size()) if out is None else out
+        check(_lib.lib().tg_vec_pointwise_mult(out._h, self._h, other._h), "tg_vec_pointwise_mult")
+        return out
+
     def inner(self, other):
         out = C.c_double()
         check(_lib.lib().tg_vec_dot(self._h, other._h, C.byref(out)))
@@ -147,6 +153,13 @@ class DeviceCSR(object):
         check(_lib.lib().tg_csr_download(self._h, _p(rowptr, c_i64p), _p(col, c_i32p), _p(val, c_f64p)),
               "tg_csr_download")
         return sp.csr_matrix((val, col, rowptr), shape=(nr, nc))
+
+    def combine(self, a, other, b, colscale=None):
+        """a*self + b*other*diag(colscale) for two matrices on one pattern (checked on the device)"""
+        h = handle()
+        check(_lib.lib().tg_csr_combine(float(a), self._h, float(b), other._h,
+                                        colscale._h if colscale is not None else None, C.byref(h)), "tg_csr_combine")
+        return DeviceCSR(h)
 
     def transpose(self):
         if self._T is None:

@@ -262,3 +262,44 @@ class Equation(object):
 
     def __init__(self, lhs, rhs):
         self.lhs, self.rhs = lhs, rhs
+
+
+class SemilinearResidual(object):
+    """Residual of  -lap u + g(u) = f  in group-FE (product approximation) form on the scalar Q_p
+    space:  R_a = sum_b K_ab u_b + sum_b M_ab (g(u_b) - f_b), with K, M the stiffness and mass
+    matrices (identity geometry, or mapped with ``geometry``), ``u`` the current FE ``Function`` (read
+    at assembly time, as a UFL form reads its coefficient), ``g`` / ``dg`` callables mapping a
+    ``DeviceVector`` of nodal values to one (``lambda v: v.pointwise_mult(v).pointwise_mult(v)``).
+    ``tangent()`` gives the matching Jacobian form  J = K + M diag(g'(u)).  K and M are assembled
+    once and reused by every Newton step (fixed sparsity)."""
+
+    def __init__(self, u, f_nodal, g, dg, geometry=None):
+        self.u, self.g, self.dg, self.geometry = u, g, dg, geometry
+        self.f = f_nodal if isinstance(f_nodal, _dev.DeviceVector) else _dev.DeviceVector(data=f_nodal)
+        self._KM = None
+
+    def _matrices(self, V):
+        if self._KM is None:
+            self._KM = (LaplaceForm(self.geometry).assemble_matrix(V), MassForm(self.geometry).assemble_matrix(V))
+        return self._KM
+
+    def assemble_vector(self, V, row0=None, row1=None):
+        K, Mm = self._matrices(V)
+        uv = self.u.vector()
+        r = K.mult(uv)
+        t = self.g(uv)
+        t.axpy(-1.0, self.f)
+        r.axpy(1.0, Mm.mult(t))
+        return r
+
+    def tangent(self):
+        return _SemilinearTangent(self)
+
+
+class _SemilinearTangent(object):
+    def __init__(self, res):
+        self.res = res
+
+    def assemble_matrix(self, V, row0=None, row1=None):
+        K, Mm = self.res._matrices(V)
+        return K.combine(1.0, Mm, 1.0, self.res.dg(self.res.u.vector()))
