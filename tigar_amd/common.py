@@ -44,6 +44,7 @@ DEFAULT_PREALLOC = 500
 DEFAULT_DO_PERMUTATION = mpisize > 8
 DEFAULT_BASIS_FUNC_IGNORE_EPS = 1e-15
 EXTRACTION_DATA_FILE = "extraction-data.h5"
+EXTRACTION_DATA_NPZ = "extraction-data.npz"       # stand-in for the HDF5 file (no h5py/dolfin here)
 EXTRACTION_INFO_FILE = "extraction-info.txt"
 EXTRACTION_H5_MESH_NAME = "/mesh"
 
@@ -308,8 +309,39 @@ class AbstractExtractionGenerator(object):
         self.permutation = self.generatePermutation()
 
     def writeExtraction(self, dirname, doPermutation=DEFAULT_DO_PERMUTATION):
-        raise NotImplementedError("on-disk extraction format (HDF5 + PETSc binary, "
-                                  "tIGAr/common.py:435-502) is outside the GPU hot path (SURVEY f-2)")
+        """Writes the extraction data to ``dirname`` with the reference's file names and formats
+        (tIGAr/common.py:435-502): ``extraction-mat.dat`` / ``extraction-mat-ctrl.dat`` (PETSc binary
+        Mat of M / M_control), ``zero-dofs.dat`` (PETSc binary IS), ``extraction-info.txt`` (nsd,
+        element type, number of fields, then degree and ncp of the control field and of each field).
+        The reference's ``extraction-data.h5`` (dolfin mesh + control functions, HDF5) cannot be
+        produced without h5py/dolfin; the node grid and the control functions go to
+        ``extraction-data.npz`` instead, which only this package reads."""
+        from . import petscio
+        if doPermutation:
+            self.applyPermutation()
+        os.makedirs(dirname, exist_ok=True)
+        petscio.write_mat(os.path.join(dirname, EXTRACTION_MAT_FILE), self.M.to_scipy())
+        petscio.write_mat(os.path.join(dirname, EXTRACTION_MAT_FILE_CTRL), self.M_control.to_scipy())
+        petscio.write_is(os.path.join(dirname, EXTRACTION_ZERO_DOFS_FILE), numpy.asarray(self.zeroDofs, dtype=INDEX_TYPE))
+        fs = str(self.getNsd()) + "\n" + self.extractionElement() + "\n" + str(self.getNFields()) + "\n"
+        for i in range(-1, self.getNFields()):
+            fs += str(self.getDegree(i)) + "\n" + str(self.getNcp(i)) + "\n"
+        with open(os.path.join(dirname, EXTRACTION_INFO_FILE), "w") as f:
+            f.write(fs)
+        data = {"nfields": numpy.int64(self.getNFields())}
+        for name, V in (("control", self.V_control), ("fields", self.V)):
+            data[name + "_ngrids"] = numpy.int64(len(V.grids))
+            data[name + "_element"] = numpy.array(V.element)
+            for gi, g in enumerate(V.grids):
+                data["%s_%d_degree" % (name, gi)] = numpy.int64(g.degree)
+                data["%s_%d_dg" % (name, gi)] = numpy.int64(1 if g.dg else 0)
+                data["%s_%d_dim" % (name, gi)] = numpy.int64(g.dim())
+                for k in range(g.dim()):
+                    data["%s_%d_axis%d" % (name, gi, k)] = numpy.asarray(g.axes[k])
+                    data["%s_%d_vert%d" % (name, gi, k)] = numpy.asarray(g.vertices[k], dtype=numpy.float64)
+        for i, f in enumerate(self.cpFuncs):
+            data["control%d" % i] = f.vector().get_local()
+        numpy.savez(os.path.join(dirname, EXTRACTION_DATA_NPZ), **data)
 
 
 class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
@@ -600,9 +632,57 @@ class ExtractedSpline(object):
         if isinstance(sourceArg, AbstractExtractionGenerator):
             self.initFromGenerator(sourceArg, quadDeg, doPermutation)
         else:
-            raise NotImplementedError("reading extraction data from a directory "
-                                      "(tIGAr/common.py:748-894) is outside the GPU hot path (SURVEY f-2)")
+            self.initFromFilesystem(sourceArg, quadDeg, comm, mesh)
         self.genericSetup()
+
+    def initFromFilesystem(self, dirname, quadDeg, comm, mesh=None):
+        """Instance from the extraction data in directory ``dirname`` (tIGAr/common.py:748-894):
+        ``extraction-info.txt``, the PETSc binary matrices and index set, and this package's
+        ``extraction-data.npz`` in place of the HDF5 mesh/control-function file.  M is then an
+        arbitrary sparse matrix: extractMatrix uses the general PtAP kernel."""
+        from . import petscio
+        self.quadDeg = quadDeg
+        self.comm = comm
+        with open(os.path.join(dirname, EXTRACTION_INFO_FILE), "r") as f:
+            lines = f.read().split("\n")
+        self.nsd = int(lines[0])
+        self.elementType = lines[1]
+        self.nFields = int(lines[2])
+        self.p_control = int(lines[3])
+        ncp_control = int(lines[4])
+        self.p, ncp = [], []
+        for i in range(self.nFields):
+            self.p.append(int(lines[5 + 2 * i]))
+            ncp.append(int(lines[6 + 2 * i]))
+        npz_path = os.path.join(dirname, EXTRACTION_DATA_NPZ)
+        if not os.path.exists(npz_path):
+            raise IOError("%s not found: directories written by the reference carry the mesh and control "
+                          "functions in HDF5 (%s), which needs h5py/dolfin to read" % (npz_path, EXTRACTION_DATA_FILE))
+        data = numpy.load(npz_path)
+
+        def space(name):
+            grids = []
+            for gi in range(int(data[name + "_ngrids"])):
+                dim = int(data["%s_%d_dim" % (name, gi)])
+                axes = [data["%s_%d_axis%d" % (name, gi, k)] for k in range(dim)]
+                verts = [data["%s_%d_vert%d" % (name, gi, k)] for k in range(dim)]
+                grids.append(TensorNodeGrid(axes, verts, int(data["%s_%d_degree" % (name, gi)]),
+                                            bool(int(data["%s_%d_dg" % (name, gi)]))))
+            return TensorFunctionSpace(grids, str(data[name + "_element"]))
+        self.mesh = mesh
+        self.V_control = space("control")
+        self.V = space("fields")
+        self.cpFuncs = []
+        for i in range(self.nsd + 1):
+            f = Function(self.V_control)
+            f.vector().set_local(data["control%d" % i])
+            self.cpFuncs.append(f)
+        self.M_control = DeviceCSR.from_scipy(petscio.read_mat(os.path.join(dirname, EXTRACTION_MAT_FILE_CTRL)))
+        self.M = DeviceCSR.from_scipy(petscio.read_mat(os.path.join(dirname, EXTRACTION_MAT_FILE)))
+        if self.M_control.shape != (self.V_control.dim(), ncp_control) or self.M.shape != (self.V.dim(), sum(ncp)):
+            raise ValueError("extraction matrices in %s do not match extraction-info.txt" % dirname)
+        self.zeroDofs = numpy.asarray(petscio.read_is(os.path.join(dirname, EXTRACTION_ZERO_DOFS_FILE)), dtype=INDEX_TYPE)
+        self._kron = None
 
     def initFromGenerator(self, generator, quadDeg, doPermutation=DEFAULT_DO_PERMUTATION):
         """tIGAr/common.py:708-746 -- shares M, M_control, V, cpFuncs with the generator."""
