@@ -198,3 +198,95 @@ def test_dg_node_grid_for_discontinuous_basis(T):
     assert M.shape == ((2 * 3) ** 2, s.getNcp())
     assert np.array_equal(M.indptr, Mo.indptr) and np.array_equal(M.indices, Mo.indices)
     assert np.array_equal(M.data, Mo.data)
+
+
+def test_compatible_spline_fields_extract_like_oracle(T):
+    """RT-type compatible B-splines (tIGAr/compatibleSplines.py:21-101): fields of different
+    degrees per direction; M is the block-diagonal of the per-field extraction operators on each
+    field's own Q_(max degree) node grid, M_control that of the control mesh."""
+    from tigar_amd.compatibleSplines import BSplineCompat
+    import scipy.sparse as sp
+    B = T.B
+    kv = [B.uniformKnots(2, 0., 1., 4), B.uniformKnots(2, 0., 2., 3)]
+    cm = B.ExplicitBSplineControlMesh([2, 2], kv)
+    for kind, degs in (("RT", [1, 1]), ("N", [1, 2])):
+        gen = BSplineCompat(cm, kind, degs)
+        assert gen.getNFields() == 2
+        blocks = []
+        for i in range(2):
+            f = gen.getFieldSpline(i)
+            so = O.BSpline([s1.p for s1 in f.splines], [np.asarray(s1.knots) for s1 in f.splines])
+            blocks.append(O.generate_M_tensor(so))
+            assert gen.getDegree(i) == so.getDegree() and gen.getNcp(i) == so.getNcp()
+        Mo = sp.block_diag(blocks, format="csr")
+        M = gen.M.to_scipy()
+        assert M.shape == Mo.shape
+        assert np.array_equal(M.indptr, Mo.indptr) and np.array_equal(M.indices, Mo.indices)
+        assert np.array_equal(M.data, Mo.data)
+        Mc = gen.M_control.to_scipy()
+        Mco = O.generate_M_tensor(O.BSpline([2, 2], [O.uniform_knots(2, 0., 1., 4), O.uniform_knots(2, 0., 2., 3)]))
+        assert np.array_equal(Mc.data, Mco.data) and np.array_equal(Mc.indices, Mco.indices)
+        # the extraction path works on the mixed space: M^T A M of a block matrix, BCs on field 0
+        gen.addZeroDofs(0, gen.getFieldSpline(0).getSideDofs(0, 0))
+        spline = T.t.ExtractedSpline(gen, 4)
+        rng = np.random.default_rng(1)
+        A = sp.random(M.shape[0], M.shape[0], density=0.02, random_state=4, format="csr") + sp.identity(M.shape[0]) * 3.0
+        K = spline.extractMatrix(A.tocsr()).to_scipy()
+        Ko = O.extract_matrix(Mo, A.tocsr(), list(spline.zeroDofs))
+        assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+
+
+def test_multipatch_bspline_extraction_is_patchwise(T):
+    """MultiBSpline (tIGAr/BSplines.py:651-908): patches side by side (offset 2 in x), element-local
+    FE nodes, DoFs numbered patch after patch; the kernel path (patch-wise tensor extraction,
+    stacked) equals both the oracle's patch blocks and the generic getNodesAndEvals row loop."""
+    import scipy.sparse as sp
+    B, t = T.B, T.t
+    patches = [B.BSpline([2, 2], [B.uniformKnots(2, 0., 3., 3), B.uniformKnots(2, 0., 1., 2)]),
+               B.BSpline([2, 3], [B.uniformKnots(2, -1., 1., 2), B.uniformKnots(3, 0., 2., 3)])]
+    mb = B.MultiBSpline(patches)
+    assert mb.getNcp() == 5 * 4 + 4 * 6 and mb.doffsets == [0, 20] and mb.nel == 6 + 6
+    assert all(abs(s1.knots[0]) == 0.0 and s1.knots[-1] == 1.0 for pt in patches for s1 in pt.splines)
+    # point evaluation follows the reference's patch lookup and dof offsets
+    ne = mb.getNodesAndEvals(np.array([2.25, 0.5]))
+    loc = patches[1].getNodesAndEvals(np.array([0.25, 0.5]))
+    assert [c for c, _ in ne] == [c + 20 for c, _ in loc] and [v for _, v in ne] == [v for _, v in loc]
+
+    class CM(t.AbstractControlMesh):
+        def getScalarSpline(self):
+            return mb
+
+        def getNsd(self):
+            return 2
+
+        def getHomogeneousCoordinate(self, node, direction):
+            if direction == 2:
+                return 1.0
+            patch = 0 if node < 20 else 1
+            s = patches[patch]
+            local = node - mb.doffsets[patch]
+            M = s.splines[0].getNcp()
+            idx = (local % M, local // M)
+            return s.splines[direction].greville(idx[direction]) + (2.0 * patch if direction == 0 else 0.0)
+    gen = t.EqualOrderSpline(1, CM())
+    M = gen.M.to_scipy()
+    blocks = []
+    for pt in patches:
+        so = O.BSpline([s1.p for s1 in pt.splines], [np.asarray(s1.knots) for s1 in pt.splines])
+        blocks.append(O.generate_M_tensor(so, degree=3, dg=True))
+    Mo = sp.block_diag(blocks, format="csr")
+    assert M.shape == Mo.shape == (gen.V.dim(), 44)
+    assert np.array_equal(M.indptr, Mo.indptr) and np.array_equal(M.indices, Mo.indices) and np.array_equal(M.data, Mo.data)
+    # generic plug-in path (host row loop through getNodesAndEvals + tg_csr_from_triplets)
+    X = gen.V.grids[0].coordinates()
+    rows, cols, vals = [], [], []
+    for I in range(X.shape[0]):
+        for c, v in mb.getNodesAndEvals(X[I]):
+            rows.append(I), cols.append(c), vals.append(v)
+    Mg = T.dev.csr_from_triplets(X.shape[0], 44, rows, cols, vals, 1e-15).to_scipy()
+    # (x + 2*patch) - 2*patch is not x in floating point: the row loop sees coordinates that went
+    # through the patch shift, the kernel path evaluates at the patch-local nodes
+    assert abs(Mg - M).max() <= 4e-15 and Mg.nnz == M.nnz
+    # control functions reproduce the (shifted) identity map: partition of unity + Greville
+    cp = [f.vector().get_local() for f in gen.cpFuncs]
+    assert np.max(np.abs(cp[0] / cp[2] - X[:, 0])) < 1e-13 and np.max(np.abs(cp[1] / cp[2] - X[:, 1])) < 1e-13

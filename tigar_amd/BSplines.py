@@ -274,6 +274,76 @@ class BSpline(AbstractScalarBasis):
         return retval
 
 
+class MultiBSpline(AbstractScalarBasis):
+    """Several ``BSpline`` patches grouped into one scalar basis (tIGAr/BSplines.py:651-908): knot
+    vectors are normalised to (0,1), patch ``i`` occupies x in [2i, 2i+1] of the parametric domain,
+    DoFs of the patches are numbered one after the other.  (As in the reference there is no
+    merging of control points between patches yet: the extraction operator is block diagonal.)"""
+
+    def __init__(self, splines):
+        self.splines = splines
+        self.ncp = self.computeNcp()
+        for s in self.splines:
+            s.normalizeKnotVectors()
+        self.doffsets = []
+        ncp = 0
+        for s in self.splines:
+            self.doffsets += [ncp, ]
+            ncp += s.getNcp()
+        self.nvar = self.splines[0].nvar
+        self.useRect = self.splines[0].useRect
+        self.overRefine = self.splines[0].overRefine
+        self.nPatch = len(self.splines)
+        self.nel = self.computeNel()
+        if self.nvar == 1:
+            raise NotImplementedError("Univariate multipatch not yet supported.")   # (reference :745-747)
+
+    def computeNel(self):
+        return sum(s.nel for s in self.splines)
+
+    def computeNcp(self):
+        return sum(s.getNcp() for s in self.splines)
+
+    def getNcp(self):
+        return self.ncp
+
+    def needsDG(self):
+        return False
+
+    def useRectangularElements(self):
+        return self.useRect
+
+    def getPrealloc(self):
+        return self.splines[0].getPrealloc()
+
+    def getDegree(self):
+        return max(s.getDegree() for s in self.splines)
+
+    def patchFromCoordinates(self, xi):
+        return int(xi[0] + 0.5) // 2
+
+    def globalDofIndex(self, localDofIndex, patchIndex):
+        return self.doffsets[patchIndex] + localDofIndex
+
+    def localParametricCoordinates(self, xi, patchIndex):
+        retval = numpy.array(xi, dtype=numpy.float64)
+        retval[0] = xi[0] - 2.0 * float(patchIndex)
+        return retval
+
+    def getNodesAndEvals(self, xi):
+        patch = self.patchFromCoordinates(xi)
+        xi_local = self.localParametricCoordinates(xi, patch)
+        return [[self.globalDofIndex(pair[0], patch), pair[1]]
+                for pair in self.splines[patch].getNodesAndEvals(xi_local)]
+
+    def generateMesh(self, comm=worldcomm, degree=None, dg=False):
+        """The reference writes a mesh of disconnected cells, 4 (8) vertices per element
+        (tIGAr/BSplines.py:734-908); here: element-local node grids per patch."""
+        from .common import MultiPatchNodeGrid
+        deg = self.getDegree() if degree is None else degree
+        return MultiPatchNodeGrid([s.generateMesh(comm=comm, degree=deg, dg=True) for s in self.splines])
+
+
 class ExplicitBSplineControlMesh(AbstractControlMesh):
     """
     Control mesh of a B-spline with identical physical and parametric domains

@@ -99,6 +99,31 @@ class TensorNodeGrid(object):
         return numpy.stack([g.ravel(order="F") for g in grids], axis=1)
 
 
+class MultiPatchNodeGrid(object):
+    """Node set of a ``MultiBSpline``: the patches' node grids side by side, patch ``i`` shifted
+    by 2*i along direction 0 (the reference's multi-patch mesh of disconnected elements,
+    tIGAr/BSplines.py:734-860; each patch keeps element-local nodes)."""
+
+    def __init__(self, patches):
+        self.patches = list(patches)
+        self.degree = self.patches[0].degree
+        self.dg = True
+
+    def dim(self):
+        return self.patches[0].dim()
+
+    def num_nodes(self):
+        return sum(g.num_nodes() for g in self.patches)
+
+    def coordinates(self):
+        out = []
+        for i, g in enumerate(self.patches):
+            X = g.coordinates().copy()
+            X[:, 0] += 2.0 * float(i)
+            out.append(X)
+        return numpy.vstack(out)
+
+
 class TensorFunctionSpace(object):
     """Stand-in for dolfin ``FunctionSpace``: ``nfields`` scalar Lagrange (or DG) fields
     on node grids that share one knot mesh.  Dofs are field-major, nodes lexicographic
@@ -360,6 +385,12 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
         if isinstance(basis, BSpline) and type(basis).getNodesAndEvals is BSpline.getNodesAndEvals:
             self._fast_blocks[(field, col_offset)] = (basis, grid)
             return _dev.extract_csr_tensor(basis.splines, grid.axes, col_offset, ncols, eps)
+        from .BSplines import MultiBSpline
+        if isinstance(basis, MultiBSpline) and isinstance(grid, MultiPatchNodeGrid):
+            # patch by patch with the tensor kernel; rows stack, columns shift by the patch offsets
+            blocks = [_dev.extract_csr_tensor(sp.splines, g.axes, col_offset + basis.doffsets[i], ncols, eps)
+                      for i, (sp, g) in enumerate(zip(basis.splines, grid.patches))]
+            return blocks[0] if len(blocks) == 1 else _dev.csr_vstack(blocks)
         # generic path: the reference's row loop (tIGAr/common.py:1554-1571)
         X = grid.coordinates()
         rows, cols, vals = [], [], []
