@@ -210,8 +210,10 @@ def run_distributed(args, d, p, nel, rank, world):
         r0, r1 = path.mine["u_rows"]
         n0 = grid.shape()
         uh = state["u"].get_local()
-        if uh.size <= 40e6:
-            idx = np.arange(r0, r1)
+        if True:
+            # every node for small problems, every 97th for large ones (cfg3: 4.7 M of 455 M nodes)
+            idx = np.arange(r0, r1) if uh.size <= 40e6 else np.arange(r0, r1, 97)
+            uh = uh if uh.size <= 40e6 else uh[idx - r0]
             exact = np.ones(idx.size)
             stride = 1
             for k in range(d):

@@ -1,0 +1,83 @@
+"""BASELINE cfg2 at its FULL size (3-D, 128^3 elements, p=2: 17.0 M FE rows, 2.2 M DoFs) through
+size-independent properties -- no oracle can be run at this size in seconds:
+closed-form sizes, partition of unity, constants in the kernel of M^T A M,
+symmetry, MatZeroRowsColumns structure, linearity of extraction, and the manufactured solution."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg2_full_size_properties():
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, forms as F, device as dev
+    d, p, nel = 3, 2, 128
+    nnzM1 = 2 + (nel - 1) * p + nel * (p - 1) * (p + 1)
+    nnzA1 = (nel - 1) * (2 * p + 1) + 2 * (p + 1) + nel * (p - 1) * (p + 1)
+    nnzK1 = (nel + p) * (2 * p + 1) - p * (p + 1)
+    kv = [B.uniformKnots(p, 0., 1., nel)] * d
+    cm = B.ExplicitBSplineControlMesh([p] * d, kv)
+    gen = t.EqualOrderSpline(1, cm)
+    sp0 = gen.getScalarSpline(0)
+    nfe, ncp = (nel * p + 1) ** d, (nel + p) ** d
+    assert gen.M.shape == (nfe, ncp) and gen.M.nnz == nnzM1 ** d          # 262 144 000
+    A = F.LaplaceForm().assemble_matrix(gen.V)
+    assert A.nnz == nnzA1 ** d                                             # 1 076 890 625
+    ones_c = dev.DeviceVector(data=np.ones(ncp))
+    # partition of unity: M 1 = 1 at every FE node
+    m1 = gen.M.mult(ones_c).get_local()
+    assert np.max(np.abs(m1 - 1.0)) <= 4e-16 * (p + 1) ** d
+    # no BCs: constants are in the kernel of the stiffness matrix, before and after extraction
+    spline0 = t.ExtractedSpline(gen, 2 * p)
+    K0 = spline0.extractMatrix(A, applyBCs=False)
+    assert K0.shape == (ncp, ncp) and K0.nnz == nnzK1 ** d                 # 267 089 984
+    k1 = K0.mult(ones_c).get_local()
+    scale = float(np.max(np.abs(K0.mult(dev.DeviceVector(data=np.cos(np.arange(ncp) * 0.37))).get_local())))
+    assert np.max(np.abs(k1)) <= 1e-12 * scale
+    # symmetry and linearity on random vectors
+    rng = np.random.default_rng(5)
+    x, y = rng.standard_normal(ncp), rng.standard_normal(ncp)
+    dx, dy = dev.DeviceVector(data=x), dev.DeviceVector(data=y)
+    xKy, yKx = dx.inner(K0.mult(dy)), dy.inner(K0.mult(dx))
+    assert abs(xKy - yKx) <= 1e-11 * abs(xKy)
+    bfe = rng.standard_normal(nfe)
+    b1, b2 = dev.DeviceVector(data=bfe), dev.DeviceVector(data=2.5 * bfe)
+    e1 = spline0.extractVector(b1, applyBCs=False).get_local()
+    e2 = spline0.extractVector(b2, applyBCs=False).get_local()
+    assert np.max(np.abs(e2 - 2.5 * e1)) <= 1e-13 * np.max(np.abs(e2))
+    # <M^T b, x> = <b, M x>
+    lhs = float(e1 @ x)
+    rhs = dev.DeviceVector(data=bfe).inner(gen.M.mult(dx))
+    assert abs(lhs - rhs) <= 1e-11 * abs(lhs)
+    del K0
+    # with BCs: rows and columns of the boundary dofs are unit vectors, the rest of K is untouched
+    for direction in range(d):
+        for side in (0, 1):
+            gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    K = spline.extractMatrix(A, diag=3.0)
+    zd = np.unique(np.asarray(spline.zeroDofs))
+    assert zd.size == ncp - (nel + p - 2) ** d
+    ind = np.zeros(ncp)
+    ind[zd] = 1.0
+    kz = K.mult(dev.DeviceVector(data=ind)).get_local()
+    assert np.array_equal(kz, 3.0 * ind)                                  # diag on the BC rows, zero columns elsewhere
+    # manufactured solution of the Poisson problem (demos/poisson/poisson.py flow)
+    f1 = lambda s: np.sin(np.pi * s)
+    load = F.SeparableLoadForm([f1] * d, scale=d * np.pi ** 2)
+    solver = t.PETScKrylovSolver("cg", "jacobi")
+    solver.parameters["relative_tolerance"] = 1e-10
+    spline.setSolverOptions(linearSolver=solver)
+    u = t.Function(spline.V)
+    spline.solveLinearSystem(K, spline.assembleVector(load), u)
+    uh = u.vector().get_local()
+    g = spline.V.grids[0]
+    sample = np.arange(0, nfe, 97)
+    n0 = g.shape()
+    exact = np.ones(sample.size)
+    stride = 1
+    for k in range(d):
+        exact *= np.sin(np.pi * g.axes[k][(sample // stride) % n0[k]])
+        stride *= n0[k]
+    assert np.max(np.abs(uh[sample] - exact)) < 2e-6                       # O(h^3) at h = 1/128
+    assert solver.last["status"] == 0

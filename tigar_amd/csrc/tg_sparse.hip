@@ -78,7 +78,11 @@ int tg_spmv_plan(tg_csr_s *a) {
   while (cap < 8192 && hmax > cap / 2) cap *= 2;
   a->spmv_cap = cap;
   if (hmax <= cap / 2) {
-    const int64_t quantum = cap - hmax;
+    // a block holds fewer than quantum + hmax entries and the kernel starts at the entry index
+    // rounded DOWN to a multiple of 4 (aligned 16-byte loads): keep 3 entries of slack so that
+    // [n0 & ~3, n1) never exceeds the cap (without it a nearly full block dropped its last
+    // entries: 159 of 17 M rows of M wrong at 128^3 p=2, found by the full-size unity test)
+    const int64_t quantum = cap - hmax - 3;
     a->nblocks = a->nnz / quantum + 1;
     TG_TRY(tg_dmalloc(&a->rowblocks, a->nblocks + 1));
     hipLaunchKernelGGL(k_build_rowblocks, dim3((unsigned)tg_cdiv(a->nblocks + 1, 256)), dim3(256), 0, g_tg.stream,
