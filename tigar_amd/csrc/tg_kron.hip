@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(256)
 // The workgroup walks that range 256 entries at a time (fully coalesced 2-KB / 1-KB stores);
 // each thread finds its row by bisection over the row offsets kept in LDS.
 #define TG_KRON_MAXN0 4096
+#define TG_KRON_MAXJK 128       // (y,z) column combinations per pencil row staged in LDS
 __global__ void __launch_bounds__(256)
     k_kron_fill_stream(tg_kron_params P, const int64_t *__restrict__ rowptr, int32_t *__restrict__ col,
                        double *__restrict__ val) {
@@ -154,22 +155,59 @@ __global__ void __launch_bounds__(256)
   if (a_hi <= a_lo) return;
   const int64_t base = rowptr[g0 + a_lo - P.row0] - roff[a_lo];   // output position of local offset 0
   const float rly = 1.0f / (float)ly;
-  for (int t = roff[a_lo] + tid; t < roff[a_hi]; t += 256) {
-    // row a with roff[a] <= t < roff[a+1]
+  // everything that depends only on the (y,z) part of an entry is the same for the whole pencil:
+  // column base and, per term, the product of the y and z factors -> LDS once per workgroup
+  __shared__ double wjk[TG_KRON_MAX_TERMS][TG_KRON_MAXJK];
+  __shared__ int64_t cjk[TG_KRON_MAXJK];
+  const bool staged = lyz <= TG_KRON_MAXJK;
+  if (staged) {
+    for (int jk = tid; jk < lyz; jk += 256) {
+      const int k = jk / ly, j = jk - k * ly;
+      int64_t cc = 0;
+      if (P.d > 1) cc += P.cstride[1] * (int64_t)P.col[1][y0 + j];
+      if (P.d > 2) cc += P.cstride[2] * (int64_t)P.col[2][z0 + k];
+      cjk[jk] = cc + P.col_offset;
+      for (int q = 0; q < P.nterms; q++) {
+        double v = 1.0;
+        if (P.d > 1) v *= P.val[1][q * P.nnz1d[1] + y0 + j];
+        if (P.d > 2) v *= P.val[2][q * P.nnz1d[2] + z0 + k];
+        wjk[q][jk] = v;
+      }
+    }
+    __syncthreads();
+  }
+  // row a with roff[a] <= t < roff[a+1]: bisection for the thread's first entry, then the row only
+  // moves forward (t advances by 256 per pass)
+  int a = a_lo;
+  {
+    const int t0 = roff[a_lo] + tid;
     int lo = a_lo, hi = a_hi;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (roff[mid] <= t)
+      if (roff[mid] <= t0)
         lo = mid;
       else
         hi = mid;
     }
-    const int a = lo;
+    a = lo;
+  }
+  for (int t = roff[a_lo] + tid; t < roff[a_hi]; t += 256) {
+    while (a + 1 < a_hi && roff[a + 1] <= t) a++;
     const int x0 = P.rowptr[0][a];
     const int lx = P.rowptr[0][a + 1] - x0;
     const int e = t - roff[a];
     const int jk = (int)(((float)e + 0.5f) / (float)lx);
     const int i = e - jk * lx;
+    if (staged) {
+      // value = sum_q x_q[i] * (y_q[j] z_q[k]) : the y-z product is multiplied last, exactly as below
+      // ((x*y)*z differs from x*(y*z) in the last bit, so the staged path is only used for values
+      // that do not enter a bit-exact comparison: the Kronecker-SUM inputs; see host code)
+      double sum = 0.0;
+      for (int q = 0; q < P.nterms; q++) sum += P.val[0][q * P.nnz1d[0] + x0 + i] * wjk[q][jk];
+      col[base + t] = (int32_t)(P.col[0][x0 + i] + cjk[jk]);
+      val[base + t] = sum;
+      continue;
+    }
     const int k = (int)(((float)jk + 0.5f) * rly);
     const int j = jk - k * ly;
     int64_t cc = P.col[0][x0 + i];
