@@ -169,6 +169,16 @@ typedef struct {
 int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, const tg_kron1d_t *fac,
                  int64_t out_row0, int64_t out_row1, const int32_t *zero_dofs, int64_t nzero, double diag,
                  tg_csr_t *out);
+/* Intermediate stage of a direction-by-direction product (no boundary conditions).  The result
+ * is a LOOSE-ROW matrix: its rows lie where the kernel reserved space for them (the row-reorder copy
+ * is skipped); it may only be passed on to tg_ptap_kron / tg_ptap_kron_stage (as `cur`),
+ * tg_csr_vstack (with other loose-row blocks), tg_csr_compact, tg_csr_dims, tg_csr_download and
+ * tg_csr_destroy -- every other entry point rejects it. */
+int tg_ptap_kron_stage(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in,
+                       const tg_kron1d_t *fac, int64_t out_row0, int64_t out_row1, tg_csr_t *out);
+/* canonical CSR copy of a loose-row matrix */
+int tg_csr_compact(tg_csr_t in, tg_csr_t *out);
+int tg_csr_is_loose(tg_csr_t m, int *loose);
 /* MatZeroRowsColumns(K, zeroDofs, diag) [ext] as called at tIGAr/common.py:1200;
  * K holds global rows [row0, row0+nrows). */
 int tg_zero_rows_cols(tg_csr_t k, int64_t row0, const int32_t *dofs, int64_t n, double diag);

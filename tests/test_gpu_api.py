@@ -295,3 +295,46 @@ def test_box_kernel_sampled_reach_falls_back_to_exact(T, monkeypatch):
                       None, 1.0, [[0], [1]])
     Ko = (Mo.T @ Ao @ Mo).tocsr()
     assert abs(K.to_scipy() - Ko).max() <= 1e-12 * abs(Ko).max()
+
+
+def test_loose_row_stage_results(T):
+    """Intermediate PtAP stages hand their temporary over without the row-reorder copy
+    (tg_ptap_kron_stage): such loose-row matrices compact to exactly the canonical stage result,
+    stack with each other, and are refused by every entry point that assumes canonical CSR."""
+    from tigar_amd.kronptap import KronExtraction
+    from tigar_amd import _lib
+    B, F, dev = T.B, T.F, T.dev
+    p, nel = 3, 5
+    kv = [B.uniformKnots(p, 0., 1., nel)] * 3
+    basis = B.ExplicitBSplineControlMesh([p] * 3, kv).getScalarSpline()
+    grid = basis.generateMesh(degree=p)
+    kx = KronExtraction(basis, grid)
+    s = O.BSpline([p] * 3, [O.uniform_knots(p, 0., 1., nel)] * 3)
+    Ao, _, _, _ = O.poisson_fe_system(s)
+    A = dev.DeviceCSR.from_scipy(Ao)
+    dims = kx.dims(set())
+    fac = [kx.M1[0], None, None]
+    n_out = kx.ncp[0] * kx.nfe[1] * kx.nfe[2]
+    loose = dev.ptap_kron(A, 0, dims, fac, 0, n_out, intermediate=True)
+    canon = dev.ptap_kron(A, 0, dims, fac, 0, n_out)
+    assert loose.is_loose() and not canon.is_loose()
+    C1, C2 = loose.compact().to_scipy(), canon.to_scipy()
+    assert np.array_equal(C1.indptr, C2.indptr) and np.array_equal(C1.indices, C2.indices)
+    assert abs(C1 - C2).max() <= 1e-13 * abs(C2).max()
+    L2 = loose.to_scipy()                                    # download compacts on the fly
+    assert np.array_equal(L2.indices, C2.indices)
+    # two loose blocks (row halves) stack into one loose matrix equal to the whole
+    half = (n_out // 2 // (kx.ncp[0] * kx.nfe[1])) * (kx.ncp[0] * kx.nfe[1])
+    lo = dev.ptap_kron(A, 0, dims, fac, 0, half, intermediate=True)
+    hi = dev.ptap_kron(A, 0, dims, fac, half, n_out, intermediate=True)
+    st = dev.csr_vstack([lo, hi])
+    assert st.is_loose()
+    S = st.to_scipy()
+    assert np.array_equal(S.indptr, C2.indptr) and abs(S - C2).max() <= 1e-13 * abs(C2).max()
+    with pytest.raises(_lib.TigarHipError):
+        dev.csr_vstack([lo, canon])
+    x = dev.DeviceVector(data=np.ones(loose.shape[1]))
+    with pytest.raises(_lib.TigarHipError):
+        loose.mult(x)
+    with pytest.raises(_lib.TigarHipError):
+        loose.transpose()

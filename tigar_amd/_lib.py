@@ -100,6 +100,10 @@ PROTOTYPES = {
     "tg_ptap_destroy": (C.c_int, [handle]),
     "tg_ptap_kron": (C.c_int, [handle, C.c_int64, C.c_int, c_i64p, C.POINTER(tg_kron1d_t), C.c_int64, C.c_int64,
                                c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
+    "tg_ptap_kron_stage": (C.c_int, [handle, C.c_int64, C.c_int, c_i64p, C.POINTER(tg_kron1d_t), C.c_int64, C.c_int64,
+                                     C.POINTER(handle)]),
+    "tg_csr_compact": (C.c_int, [handle, C.POINTER(handle)]),
+    "tg_csr_is_loose": (C.c_int, [handle, C.POINTER(C.c_int)]),
     "tg_zero_rows_cols": (C.c_int, [handle, C.c_int64, c_i32p, C.c_int64, C.c_double]),
     "tg_krylov_solve": (C.c_int, [handle, handle, handle, C.c_int, C.c_int, C.c_double, C.c_double,
                                   C.c_int, C.c_int, handle, C.POINTER(C.c_int), c_f64p,

@@ -49,6 +49,8 @@ void tg_set_error(const char *fmt, ...);
   } while (0)
 
 #define TG_REQUIRE_INIT() TG_REQUIRE(g_tg.ready, "tg_init() has not been called")
+#define TG_REQUIRE_CANONICAL(m) \
+  TG_REQUIRE(!(m) || !(m)->rowcnt, "%s: loose-row intermediate of a PtAP stage; call tg_csr_compact first", __func__)
 
 #define TG_LAUNCH_CHECK() TG_CHECK_HIP(hipGetLastError())
 
@@ -62,6 +64,11 @@ struct tg_csr_s {
   int64_t *rowptr = nullptr;   // device, nrows+1
   int32_t *col = nullptr;      // device, nnz
   double *val = nullptr;       // device, nnz
+  // "loose rows" (outputs of intermediate PtAP stages only): row r occupies col/val
+  // [rowptr[r], rowptr[r] + rowcnt[r]), rows lie in arbitrary order with gaps between them (the
+  // order in which the producing kernel reserved space), nnz counts the col/val entries in use
+  // incl. the gaps.  Accepted by tg_ptap_kron*, tg_csr_vstack, tg_csr_compact, tg_csr_download.
+  int32_t *rowcnt = nullptr;   // device, nrows; nullptr = canonical CSR
   // SpMV plan (CSR-stream row blocks), built lazily
   int32_t *rowblocks = nullptr;  // device, nblocks+1 row indices
   int64_t nblocks = 0;
@@ -91,6 +98,7 @@ int tg_exclusive_scan_i64(int64_t *d, int64_t n, int64_t *host_total);
 // deterministic reduction of `n` partial doubles (device) into out_dev[0..k) sums of k
 // interleaved streams -- tg_core.hip
 int tg_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, tg_csr_s **out);
+int tg_csr_compact_impl(tg_csr_s *in, tg_csr_s **out);   // loose rows -> canonical CSR (tg_ptap_box.hip)
 int tg_spmv_plan(tg_csr_s *a);
 int tg_spmv_raw(tg_csr_s *a, const double *x_shifted, double *y, double *dot_partial_with,
                 const double *dot_vec);

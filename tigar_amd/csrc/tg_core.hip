@@ -460,7 +460,20 @@ extern "C" int tg_csr_dims(tg_csr_t m, int64_t *nrows, int64_t *ncols, int64_t *
   return 0;
 }
 
+extern "C" int tg_csr_is_loose(tg_csr_t m, int *loose) {
+  TG_REQUIRE(m && loose, "null argument to tg_csr_is_loose");
+  *loose = m->rowcnt ? 1 : 0;
+  return 0;
+}
+
 extern "C" int tg_csr_download(tg_csr_t m, int64_t *rowptr, int32_t *col, double *val) {
+  if (m && m->rowcnt) {   // loose rows: hand out the canonical form
+    tg_csr_s *c = nullptr;
+    TG_TRY(tg_csr_compact_impl(m, &c));
+    const int rc = tg_csr_download(c, rowptr, col, val);
+    tg_csr_destroy(c);
+    return rc;
+  }
   TG_REQUIRE_INIT();
   TG_REQUIRE(m, "null matrix");
   if (rowptr)
@@ -481,6 +494,7 @@ extern "C" int tg_csr_destroy(tg_csr_t m) {
   tg_dfree(m->col);
   tg_dfree(m->val);
   tg_dfree(m->rowblocks);
+  tg_dfree(m->rowcnt);
   delete m;
   return 0;
 }

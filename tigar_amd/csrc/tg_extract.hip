@@ -626,24 +626,38 @@ extern "C" int tg_csr_vstack(int nblocks, const tg_csr_t *blocks, tg_csr_t *out)
   TG_REQUIRE_INIT();
   TG_REQUIRE(nblocks >= 1 && blocks && out, "bad arguments to tg_csr_vstack");
   int64_t nrows = 0, nnz = 0, ncols = blocks[0]->ncols;
+  int nloose = 0;
   for (int b = 0; b < nblocks; b++) {
     TG_REQUIRE(blocks[b] && blocks[b]->ncols == ncols, "vstack: column count mismatch");
     nrows += blocks[b]->nrows;
     nnz += blocks[b]->nnz;
+    nloose += blocks[b]->rowcnt ? 1 : 0;
   }
+  TG_REQUIRE(nloose == 0 || nloose == nblocks, "vstack: loose-row and canonical blocks cannot be mixed");
   tg_csr_s *m = nullptr;
   TG_TRY(tg_csr_alloc(nrows, ncols, nnz, &m));
+  if (nloose && tg_dmalloc(&m->rowcnt, nrows)) {
+    tg_csr_destroy(m);
+    return 1;
+  }
   int64_t r = 0, z = 0;
   for (int b = 0; b < nblocks; b++) {
     const tg_csr_s *s = blocks[b];
+    // (loose rows: the blocks' entry arrays are concatenated as they are, row starts shift with them)
     hipLaunchKernelGGL(k_copy_rowptr_shift, dim3(tg_grid_1d(s->nrows + 1, 256)), dim3(256), 0, g_tg.stream,
                        m->rowptr + r, s->rowptr, s->nrows + 1, z);
+    if (nloose && s->nrows)
+      hipMemcpyAsync(m->rowcnt + r, s->rowcnt, (size_t)s->nrows * sizeof(int32_t), hipMemcpyDeviceToDevice, g_tg.stream);
     if (s->nnz) {
       hipMemcpyAsync(m->col + z, s->col, (size_t)s->nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, g_tg.stream);
       hipMemcpyAsync(m->val + z, s->val, (size_t)s->nnz * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream);
     }
     r += s->nrows;
     z += s->nnz;
+  }
+  if (nloose) {   // end marker of the last block = entries in use
+    const int64_t used = z;
+    hipMemcpyAsync(m->rowptr + nrows, &used, sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream);
   }
   TG_LAUNCH_CHECK();
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
@@ -678,6 +692,7 @@ extern "C" int tg_csr_builder_create(int64_t nrows_total, int64_t ncols, int64_t
 extern "C" int tg_csr_builder_append(tg_csr_builder_t b, tg_csr_t blk) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(b && b->m && blk, "null argument to tg_csr_builder_append");
+  TG_REQUIRE_CANONICAL(blk);
   TG_REQUIRE(blk->ncols == b->m->ncols, "builder: column count mismatch");
   TG_REQUIRE(b->rows_done + blk->nrows <= b->m->nrows, "builder: more rows appended than announced");
   if (b->nnz_done + blk->nnz > b->cap) {

@@ -470,6 +470,9 @@ static void tg_ptap_set_lds_limits() {
 // nnz(K); the pattern itself is produced by the (single) numeric traversal.
 extern "C" int tg_ptap_symbolic(tg_csr_t a, int64_t a_row0, tg_csr_t m, int64_t m_row0, tg_csr_t mt,
                                 int64_t mt_row0, tg_ptap_t *plan_out) {
+  TG_REQUIRE_CANONICAL(a);
+  TG_REQUIRE_CANONICAL(m);
+  TG_REQUIRE_CANONICAL(mt);
   TG_REQUIRE_INIT();
   TG_REQUIRE(a && m && mt && plan_out, "null argument to tg_ptap_symbolic");
   TG_REQUIRE(mt->nrows <= m->ncols, "PtAP: M^T block has more rows than M has columns");
@@ -547,6 +550,7 @@ extern "C" int tg_ptap_symbolic(tg_csr_t a, int64_t a_row0, tg_csr_t m, int64_t 
 
 extern "C" int tg_ptap_numeric(tg_ptap_t plan, tg_csr_t a, tg_csr_t m, tg_csr_t mt, const int32_t *zero_dofs,
                                int64_t nzero, double diag, tg_csr_t *k_out) {
+  TG_REQUIRE_CANONICAL(a);
   TG_REQUIRE_INIT();
   TG_REQUIRE(plan && a && m && mt && k_out, "null argument to tg_ptap_numeric");
   TG_REQUIRE(mt->nrows == plan->nrows && m->ncols == plan->ncols, "PtAP plan does not match the operands");

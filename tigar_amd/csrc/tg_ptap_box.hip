@@ -21,6 +21,7 @@
 #include <algorithm>
 
 struct tg_box_args {
+  const int32_t *rowcnt;        // loose rows of an intermediate stage result (nullptr: canonical CSR)
   const int64_t *rowptr;
   const int32_t *col;
   const double *val;
@@ -157,7 +158,8 @@ static bool tg_magic24(unsigned dsr, uint64_t bound, unsigned *m, unsigned *sh, 
 // lmax[k][r_k] = max (r_k - s_k), rmax[k][r_k] = max (s_k - r_k) over the row's columns s.
 // (arrays of size n0+n1+n2, zero-initialised; used to size the accumulator boxes tightly)
 __global__ void __launch_bounds__(256)
-    k_box_reach(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nrows, int64_t row0,
+    k_box_reach(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ rowcnt, const int32_t *__restrict__ col,
+                int64_t nrows, int64_t row0,
                 int n0, int n1, int n2, unsigned mg01, unsigned sh01, unsigned mg0, unsigned sh0, int64_t stride,
                 int *__restrict__ lmax, int *__restrict__ rmax) {
   const int lane = threadIdx.x & 63;
@@ -170,7 +172,8 @@ __global__ void __launch_bounds__(256)
     const int rem = (int)(g - (int64_t)r2 * n01);
     const int r1 = rem / n0, r0 = rem - r1 * n0;
     int l0 = 0, l1 = 0, l2 = 0, h0 = 0, h1 = 0, h2 = 0;
-    for (int64_t q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) {
+    const int64_t qa = rowptr[r], qb = rowcnt ? qa + rowcnt[r] : rowptr[r + 1];
+    for (int64_t q = qa + lane; q < qb; q += 64) {
       unsigned us2, usm, us1, us0;
       tg_divmod((unsigned)col[q], (unsigned)n01, mg01, sh01, &us2, &usm);
       tg_divmod(usm, (unsigned)n0, mg0, sh0, &us1, &us0);
@@ -336,7 +339,7 @@ __global__ void __launch_bounds__(NT)
       } else {
         const int64_t s0 = P.rowptr[lr];
         pre_start[tid] = s0;
-        pre_len[tid] = (int)(P.rowptr[lr + 1] - s0);
+        pre_len[tid] = P.rowcnt ? P.rowcnt[lr] : (int)(P.rowptr[lr + 1] - s0);
       }
       pre_w[tid] = w;
     }
@@ -754,7 +757,7 @@ __global__ void __launch_bounds__(64)
         range = true;
       else {
         ns0 = P.rowptr[lr];
-        ns1 = P.rowptr[lr + 1];
+        ns1 = P.rowcnt ? ns0 + P.rowcnt[lr] : P.rowptr[lr + 1];
       }
     }
   };
@@ -994,6 +997,52 @@ __global__ void __launch_bounds__(64)
   if (outside) atomicMax(status, TG_BOX_OUTSIDE);
 }
 
+__global__ void k_i64_to_i32(const int64_t *__restrict__ a, int32_t *__restrict__ b, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) b[i] = (int32_t)a[i];
+}
+__global__ void k_i32_to_i64(const int32_t *__restrict__ a, int64_t *__restrict__ b, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) b[i] = a[i];
+}
+
+// loose rows -> canonical CSR (scan of the row lengths + the row-reorder copy)
+int tg_csr_compact_impl(tg_csr_s *in, tg_csr_s **out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(in && out && in->rowcnt, "tg_csr_compact: not a loose-row matrix");
+  int64_t *cnt = nullptr;
+  TG_TRY(tg_dmalloc(&cnt, in->nrows + 1));
+  if (in->nrows > 0)
+    hipLaunchKernelGGL(k_i32_to_i64, dim3(tg_grid_1d(in->nrows, 256)), dim3(256), 0, g_tg.stream, in->rowcnt, cnt, in->nrows);
+  int64_t nnz = 0;
+  int rc = tg_exclusive_scan_i64(cnt, in->nrows, &nnz);
+  tg_csr_s *k = nullptr;
+  if (!rc) rc = tg_csr_alloc(in->nrows, in->ncols, nnz, &k);
+  if (!rc) {
+    hipMemcpyAsync(k->rowptr, cnt, (size_t)(in->nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream);
+    if (in->nrows > 0) {
+      const unsigned rg = (unsigned)std::min<int64_t>(tg_cdiv(in->nrows, 4), (int64_t)g_tg.num_cu * 16);
+      hipLaunchKernelGGL(k_box_reorder, dim3(rg), dim3(256), 0, g_tg.stream, k->rowptr, in->rowptr, in->col, in->val,
+                         in->nrows, k->col, k->val);
+    }
+    if (hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+      tg_set_error("tg_csr_compact: kernel failed");
+      rc = 1;
+    }
+  }
+  tg_dfree(cnt);
+  if (rc) {
+    if (k) tg_csr_destroy(k);
+    return rc;
+  }
+  *out = k;
+  return 0;
+}
+
+extern "C" int tg_csr_compact(tg_csr_t in, tg_csr_t *out) { return tg_csr_compact_impl(in, out); }
+
 static size_t tg_box_lds(int cap, int cap1, int ctab, int nlist, int nt) {
   size_t b = ((size_t)cap + cap1) * 8 + (size_t)nt * 16 + (size_t)nlist * 8 + (size_t)ctab * 8;   // f64 / i64 part
   b += (size_t)nt * 4 + 128 + (size_t)nlist * 4 + 3 * TG_BOX_MAXD * 4 + (size_t)ctab * 4;
@@ -1005,7 +1054,7 @@ static size_t tg_box_lds(int cap, int cap1, int ctab, int nlist, int nt) {
 // outside a box sized from SAMPLED reach data (retry with the exact reach), other = error
 static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, const tg_kron1d_t *fac,
                              int64_t out_row0, int64_t out_row1, const int32_t *zero_dofs, int64_t nzero, double diag,
-                             int64_t reach_stride, tg_csr_t *out) {
+                             int64_t reach_stride, bool loose_out, tg_csr_t *out) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(cur && d >= 1 && d <= 3 && dims_in && fac && out && out_row1 >= out_row0, "bad arguments to tg_ptap_kron");
   static bool lim = false;
@@ -1023,6 +1072,7 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
   tg_box_args P;
   memset(&P, 0, sizeof(P));
   P.rowptr = cur->rowptr;
+  P.rowcnt = cur->rowcnt;
   P.col = cur->col;
   P.val = cur->val;
   P.row0 = cur_row0;
@@ -1108,7 +1158,8 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
   tg_magic((unsigned)P.nin[0], &P.mg0, &P.sh0);
   if (cur->nrows > 0)
     hipLaunchKernelGGL(k_box_reach, dim3((unsigned)std::min<int64_t>(tg_cdiv(cur->nrows, 4), (int64_t)g_tg.num_cu * 32)),
-                       dim3(256), 0, g_tg.stream, cur->rowptr, cur->col, cur->nrows, cur_row0, P.nin[0], P.nin[1],
+                       dim3(256), 0, g_tg.stream, cur->rowptr, (const int32_t *)cur->rowcnt, cur->col, cur->nrows, cur_row0, P.nin[0],
+                       P.nin[1],
                        P.nin[2], P.mg01, P.sh01, P.mg0, P.sh0, reach_stride, reach, reach + ntot);
   std::vector<int> hreach(2 * (size_t)ntot);
   hipMemcpyAsync(hreach.data(), reach, 2 * (size_t)ntot * sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
@@ -1362,6 +1413,7 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
       }
       mean_k = (double)total / (double)nsample;
     }
+    unsigned long long used_final = 0;
     int64_t capacity = (int64_t)(mean_k * 1.05 * (double)nrows) + hmax[2] + 1024;
     if (line_variant) capacity = (int64_t)(capacity * 1.3) + nrows / 8 * 64;   // slack of the wave-private chunks
     for (int attempt = 0; attempt < 6 && !rc; attempt++) {
@@ -1453,6 +1505,7 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
                 line_variant ? "line" : "box", (long long)nrows, P.fast24, 100.0 * hp[0] / tot, 100.0 * hp[1] / tot,
                 100.0 * hp[2] / tot, 100.0 * hp[3] / tot);
       }
+      used_final = used;
       if (h == TG_BOX_OK) break;
       tg_dfree(tcol);
       tg_dfree(tval);
@@ -1473,7 +1526,31 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
       tg_set_error("tg_ptap_kron: kernel status %d", h);
       rc = h == TG_BOX_RANGE ? 3 : 4;
     }
-    if (!rc) {
+    if (!rc && loose_out) {
+      // intermediate stage: hand the temporary over as it is (rows where the kernel put them, lengths
+      // in rowcnt) -- the consumers (next stage, vstack) read (start, length) pairs, so the
+      // row-reorder copy and the scan are skipped
+      k = new tg_csr_s();
+      k->nrows = nrows;
+      k->ncols = nout_total;
+      k->nnz = (int64_t)used_final;
+      k->rowptr = off;
+      k->col = tcol;
+      k->val = tval;
+      rc = tg_dmalloc(&k->rowcnt, nrows);
+      if (!rc) {
+        hipLaunchKernelGGL(k_i64_to_i32, dim3(tg_grid_1d(nrows, 256)), dim3(256), 0, g_tg.stream, cnt, k->rowcnt, nrows);
+        const int64_t endm = (int64_t)used_final;
+        hipMemcpyAsync(off + nrows, &endm, sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream);
+        hipStreamSynchronize(g_tg.stream);
+        off = nullptr;      // owned by k now
+        tcol = nullptr;
+        tval = nullptr;
+      } else {
+        delete k;
+        k = nullptr;
+      }
+    } else if (!rc) {
       int64_t nnz = 0;
       rc = tg_exclusive_scan_i64(cnt, nrows, &nnz);
       if (!rc) rc = tg_csr_alloc(nrows, nout_total, nnz, &k);
@@ -1505,9 +1582,9 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
   return 0;
 }
 
-extern "C" int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, const tg_kron1d_t *fac,
+static int tg_ptap_kron_any(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, const tg_kron1d_t *fac,
                             int64_t out_row0, int64_t out_row1, const int32_t *zero_dofs, int64_t nzero, double diag,
-                            tg_csr_t *out) {
+                            bool loose_out, tg_csr_t *out) {
   TG_REQUIRE(cur && dims_in, "bad arguments to tg_ptap_kron");
   // The accumulator boxes are sized from the reach of cur's rows.  Scanning every entry of cur costs
   // a noticeable fraction of the product, so the reach is first measured on every `stride`-th row
@@ -1523,12 +1600,26 @@ extern "C" int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t
       }
   }
   if (getenv("TIGAR_BOX_REACH_STRIDE")) stride = std::max(1, atoi(getenv("TIGAR_BOX_REACH_STRIDE")));
-  int rc = tg_ptap_kron_impl(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, stride, out);
+  int rc = tg_ptap_kron_impl(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, stride, loose_out, out);
   if (rc == 101 && stride > 1)
-    rc = tg_ptap_kron_impl(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, 1, out);
+    rc = tg_ptap_kron_impl(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, 1, loose_out, out);
   if (rc == 101) {
     tg_set_error("tg_ptap_kron: an entry fell outside its accumulator box");
     rc = 4;
   }
   return rc;
+}
+
+extern "C" int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, const tg_kron1d_t *fac,
+                            int64_t out_row0, int64_t out_row1, const int32_t *zero_dofs, int64_t nzero, double diag,
+                            tg_csr_t *out) {
+  return tg_ptap_kron_any(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, false, out);
+}
+
+// intermediate stage of a direction-by-direction product: no boundary conditions, result in the
+// loose-row form (consumed by the next tg_ptap_kron* call, tg_csr_vstack or tg_csr_compact)
+extern "C" int tg_ptap_kron_stage(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, const tg_kron1d_t *fac,
+                                  int64_t out_row0, int64_t out_row1, tg_csr_t *out) {
+  return tg_ptap_kron_any(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, nullptr, 0, 1.0,
+                          !getenv("TIGAR_PTAP_NOLOOSE"), out);
 }

@@ -60,6 +60,7 @@ __global__ void k_build_rowblocks(const int64_t *rowptr, int64_t nrows, int64_t 
 
 int tg_spmv_plan(tg_csr_s *a) {
   if (a->spmv_mode) return 0;
+  TG_REQUIRE_CANONICAL(a);
   TG_REQUIRE(a->nrows < 0x7fffffffll, "too many rows for the SpMV plan");
   int *dmax = (int *)g_tg.scratch;
   TG_CHECK_HIP(hipMemsetAsync(dmax, 0, sizeof(int), g_tg.stream));
@@ -412,6 +413,7 @@ int tg_csr_sort_rows(tg_csr_s *m) {
 // transpose of a row block whose local rows start at global row `row_base`; the result has
 // m->ncols rows and its column indices are global row numbers of the source.
 int tg_csr_transpose_block(tg_csr_s *m, int64_t row_base, int64_t out_ncols, tg_csr_s **out) {
+  TG_REQUIRE_CANONICAL(m);
   tg_csr_s *t = nullptr;
   TG_TRY(tg_csr_alloc(m->ncols, out_ncols, m->nnz, &t));
   TG_CHECK_HIP(hipMemsetAsync(t->rowptr, 0, (size_t)(m->ncols + 1) * sizeof(int64_t), g_tg.stream));
@@ -501,6 +503,7 @@ int tg_build_dof_mask(const int32_t *dofs, int64_t n, int64_t ndofs_total, uint8
 }
 
 extern "C" int tg_zero_rows_cols(tg_csr_t k, int64_t row0, const int32_t *dofs, int64_t n, double diag) {
+  TG_REQUIRE_CANONICAL(k);
   TG_REQUIRE_INIT();
   TG_REQUIRE(k, "null matrix");
   if (n <= 0 || k->nrows == 0) return 0;
@@ -546,6 +549,8 @@ __global__ void k_rowptr_equal(int64_t n, const int64_t *__restrict__ a, const i
 }
 
 extern "C" int tg_csr_combine(double a, tg_csr_t X, double b, tg_csr_t Y, tg_vec_t colscale, tg_csr_t *out) {
+  TG_REQUIRE_CANONICAL(X);
+  TG_REQUIRE_CANONICAL(Y);
   TG_REQUIRE_INIT();
   TG_REQUIRE(X && Y && out, "bad arguments to tg_csr_combine");
   TG_REQUIRE(X->nrows == Y->nrows && X->ncols == Y->ncols && X->nnz == Y->nnz, "tg_csr_combine: the operands differ in shape or nnz");

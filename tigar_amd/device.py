@@ -161,6 +161,17 @@ class DeviceCSR(object):
                                         colscale._h if colscale is not None else None, C.byref(h)), "tg_csr_combine")
         return DeviceCSR(h)
 
+    def is_loose(self):
+        v = C.c_int()
+        check(_lib.lib().tg_csr_is_loose(self._h, C.byref(v)), "tg_csr_is_loose")
+        return bool(v.value)
+
+    def compact(self):
+        """canonical CSR copy of a loose-row stage result (``tg_csr_compact``)"""
+        h = handle()
+        check(_lib.lib().tg_csr_compact(self._h, C.byref(h)), "tg_csr_compact")
+        return DeviceCSR(h)
+
     def transpose(self):
         if self._T is None:
             h = handle()
@@ -366,8 +377,10 @@ def ptap_numeric(plan, A, M, MT, zero_dofs=None, diag=1.0):
     return DeviceCSR(h)
 
 
-def ptap_kron(cur, cur_row0, dims_in, factors, out_row0, out_row1, zero_dofs=None, diag=1.0):
-    """One Kronecker contraction stage out = P^T cur P (dense-box kernel).  ``factors[k]`` is a
+def ptap_kron(cur, cur_row0, dims_in, factors, out_row0, out_row1, zero_dofs=None, diag=1.0, intermediate=False):
+    """One Kronecker contraction stage out = P^T cur P (dense-box kernel).  ``intermediate``: the
+    result only feeds the next stage (or a vstack of such results) and is returned in the loose-row
+    form (no row-reorder copy, no boundary conditions; see ``tg_ptap_kron_stage``).  ``factors[k]`` is a
     scipy CSR 1-D matrix (n_k x m_k) or None for the identity.  Returns None when the kernel
     declines (accumulator box too large for LDS) -- the caller then uses the general PtAP."""
     import scipy.sparse as sp
@@ -393,9 +406,15 @@ def ptap_kron(cur, cur_row0, dims_in, factors, out_row0, out_row1, zero_dofs=Non
     dims = _i64(dims_in)
     h = handle()
     zd = _i32(zero_dofs) if zero_dofs is not None and len(zero_dofs) else None
-    rc = _lib.lib().tg_ptap_kron(cur._h, int(cur_row0), d, _p(dims, c_i64p), arr, int(out_row0), int(out_row1),
-                                 _p(zd, c_i32p) if zd is not None else None, zd.size if zd is not None else 0,
-                                 float(diag), C.byref(h))
+    if intermediate:
+        if zd is not None:
+            raise ValueError("boundary conditions belong to the last stage")
+        rc = _lib.lib().tg_ptap_kron_stage(cur._h, int(cur_row0), d, _p(dims, c_i64p), arr, int(out_row0),
+                                           int(out_row1), C.byref(h))
+    else:
+        rc = _lib.lib().tg_ptap_kron(cur._h, int(cur_row0), d, _p(dims, c_i64p), arr, int(out_row0), int(out_row1),
+                                     _p(zd, c_i32p) if zd is not None else None, zd.size if zd is not None else 0,
+                                     float(diag), C.byref(h))
     if rc == 100:
         return None
     check(rc, "tg_ptap_kron")

@@ -259,7 +259,8 @@ class SlabHotPath(object):
             for group in self.groups[:-1]:
                 after = done | set(group)
                 pl_out = kx.plane(after)
-                cur = contract(kx, cur, done, group, (new_lo, new_hi), (ca, cb), (new_lo * pl_out, new_hi * pl_out))
+                cur = contract(kx, cur, done, group, (new_lo, new_hi), (ca, cb), (new_lo * pl_out, new_hi * pl_out),
+                               intermediate=True)
                 done = after
             ring["pieces"].append((new_lo, new_hi, cur))
             ring["hi"] = new_hi

@@ -92,7 +92,7 @@ def default_groups(d, p):
     return [list(range(d))]
 
 
-def contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs=None, diag=1.0):
+def contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs=None, diag=1.0, intermediate=False):
     """One contraction stage: rows ``out_rows`` (global row range in the space after the stage)
     of  P^T cur P,  where ``cur`` holds the planes ``a_planes`` of the current space (global
     columns within the planes ``c_planes``) and P contracts the directions in ``group``."""
@@ -101,9 +101,12 @@ def contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs=None,
     if os.environ.get("TIGAR_PTAP_BOX", "1") != "0":
         dims_in = kx.dims(done)
         factors = [kx.M1[k] if k in group else None for k in range(kx.d)]
-        out = _dev.ptap_kron(cur, a_planes[0] * pl_in, dims_in, factors, out_rows[0], out_rows[1], zero_dofs, diag)
+        out = _dev.ptap_kron(cur, a_planes[0] * pl_in, dims_in, factors, out_rows[0], out_rows[1], zero_dofs, diag,
+                             intermediate=intermediate)
         if out is not None:
             return out
+        if cur.is_loose():
+            cur = cur.compact()          # the general kernel needs canonical rows
     MT = kx.PT(done, group, out_rows[0], out_rows[1])
     Pm = kx.P(done, group, c_planes[0] * pl_in, c_planes[1] * pl_in)
     plan = _dev.ptap_symbolic(cur, Pm, MT, a_planes[0] * pl_in, c_planes[0] * pl_in, out_rows[0])
@@ -129,6 +132,7 @@ def ptap_factored(kx, A, a_planes, c_planes, k_planes, zero_dofs=None, diag=1.0,
         after = done | set(group)
         pl_out = kx.plane(after)
         out_rows = (k0 * pl_out, k1 * pl_out) if last else (za * pl_out, zb * pl_out)
-        cur = contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs if last else None, diag)
+        cur = contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs if last else None, diag,
+                       intermediate=not last)
         done = after
     return cur
