@@ -216,6 +216,14 @@ int tg_kron_csr_rect(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t
                      int64_t row1, int filter, double eps, int64_t col_offset, int64_t ncols_total,
                      tg_csr_t *out);
 
+/* One 1-D sparse factor F (nout_k rows, CSR on the host, columns in [col_shift, col_shift+dims_in[k]))
+ * applied along direction k of a tensor-indexed vector (direction 0 fastest):
+ *     out[lo, I, hi] = sum_t F[I, c_t] in[lo, c_t - col_shift, hi].
+ * Three such passes give M^T b (multTranspose, tIGAr/common.py:97-109) and M U (:1259) of a
+ * Kronecker-structured extraction operator without forming M or M^T. */
+int tg_tensor_apply_1d(int d, const int64_t *dims_in, int k, int64_t nout_k, const int32_t *rowptr,
+                       const int32_t *col, const double *val, int64_t col_shift, tg_vec_t in, tg_vec_t out);
+
 /* ---- FE-side operator assembly on mapped tensor-product patches ----
  * Stands in for dolfin.assemble(form) (tIGAr/common.py:1206-1220) with the spline's measures:
  * geometry F = cp[i]/cp[nsd] (tIGAr/common.py:917-921), metric g = DF^T DF, volume element

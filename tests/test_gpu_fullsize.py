@@ -119,3 +119,8 @@ def test_slab_streamed_assembly_equals_resident_at_scale():
     y1, y2 = K_res.mult(x).get_local(), K_slab.mult(x).get_local()
     assert np.max(np.abs(y1 - y2)) <= 1e-12 * np.max(np.abs(y1))
     assert np.max(np.abs(rhs_res - rhs_slab.get_local())) <= 1e-13 * np.max(np.abs(rhs_res))
+    # sum-factorised prolongation (three 1-D passes) against the explicit M U
+    U = dev.DeviceVector(data=rng.standard_normal(K_res.shape[0]))
+    u_t = path.prolong(U).get_local()
+    u_e = gen.M.mult(U).get_local()
+    assert path.kron_exact and np.max(np.abs(u_t - u_e)) <= 1e-13 * np.max(np.abs(u_e))

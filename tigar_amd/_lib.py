@@ -114,6 +114,7 @@ PROTOTYPES = {
                                    C.c_int, C.c_double, C.c_int64, C.c_int64, C.POINTER(handle)]),
     "tg_vec_pointwise_mult": (C.c_int, [handle, handle, handle]),
     "tg_csr_combine": (C.c_int, [C.c_double, handle, C.c_double, handle, handle, C.POINTER(handle)]),
+    "tg_tensor_apply_1d": (C.c_int, [C.c_int, c_i64p, C.c_int, C.c_int64, c_i32p, c_i32p, c_f64p, C.c_int64, handle, handle]),
     "tg_assemble_mapped_matrix": (C.c_int, [C.POINTER(tg_patch_t), C.c_int, C.POINTER(handle)]),
     "tg_assemble_mapped_load": (C.c_int, [C.POINTER(tg_patch_t), handle, handle]),
     "tg_comm_unique_id": (C.c_int, [C.c_char_p]),

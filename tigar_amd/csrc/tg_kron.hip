@@ -355,3 +355,72 @@ int tg_kron_build_rect(int d, int nterms, const tg_kron_dir_t *dirs, const int64
   *out = m;
   return 0;
 }
+
+// ----------------------------------------------------------------------------------------
+// One 1-D sparse factor applied along one direction of a tensor-indexed vector:
+//   out[lo, I, hi] = sum_t F[I, c_t] * in[lo, c_t - col_shift, hi]
+// with lo running over the product of the dimensions below direction k (fastest) and hi over those
+// above.  M^T b and M U of a Kronecker-structured extraction operator are three such passes each
+// (sum factorisation: (p+1) or ~3p+1 terms per entry and direction instead of (p+1)^d / (3p+1)^d, and
+// neither M nor M^T is ever formed).
+__global__ void __launch_bounds__(256)
+    k_tensor_apply_1d(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci, const double *__restrict__ fv,
+                      int64_t n_lo, int64_t nin_k, int64_t nout_k, int64_t n_hi, int64_t col_shift,
+                      const double *__restrict__ in, double *__restrict__ out) {
+  const int64_t total = n_lo * nout_k * n_hi;
+  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; o < total; o += stride) {
+    const int64_t lo = o % n_lo;
+    const int64_t r = o / n_lo;
+    const int64_t I = r % nout_k, hi = r / nout_k;
+    const double *src = in + lo + n_lo * nin_k * hi;
+    double acc = 0.0;
+    for (int t = rp[I]; t < rp[I + 1]; t++) acc += fv[t] * src[n_lo * ((int64_t)ci[t] - col_shift)];
+    out[o] = acc;
+  }
+}
+
+extern "C" int tg_tensor_apply_1d(int d, const int64_t *dims_in, int k, int64_t nout_k, const int32_t *rowptr,
+                                  const int32_t *col, const double *val, int64_t col_shift, tg_vec_t in, tg_vec_t out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(d >= 1 && d <= 3 && dims_in && k >= 0 && k < d && nout_k >= 0 && rowptr && in && out,
+             "bad arguments to tg_tensor_apply_1d");
+  int64_t n_lo = 1, n_hi = 1, nin = 1;
+  for (int j = 0; j < d; j++) {
+    TG_REQUIRE(dims_in[j] >= 0, "negative dimension");
+    nin *= dims_in[j];
+    if (j < k) n_lo *= dims_in[j];
+    if (j > k) n_hi *= dims_in[j];
+  }
+  const int64_t nin_k = dims_in[k];
+  TG_REQUIRE(in->n == nin, "tg_tensor_apply_1d: input has %lld entries, dimensions give %lld", (long long)in->n, (long long)nin);
+  TG_REQUIRE(out->n == n_lo * nout_k * n_hi, "tg_tensor_apply_1d: output has %lld entries, expected %lld", (long long)out->n,
+             (long long)(n_lo * nout_k * n_hi));
+  const int64_t nnz1 = rowptr[nout_k];
+  for (int64_t t = 0; t < nnz1; t++)
+    TG_REQUIRE(col[t] - col_shift >= 0 && col[t] - col_shift < nin_k, "tg_tensor_apply_1d: factor column %d outside the input range", (int)col[t]);
+  if (out->n == 0) return 0;
+  int32_t *drp = nullptr, *dci = nullptr;
+  double *dfv = nullptr;
+  int rc = tg_dmalloc(&drp, nout_k + 1) || tg_dmalloc(&dci, nnz1) || tg_dmalloc(&dfv, nnz1);
+  if (!rc) {
+    hipMemcpyAsync(drp, rowptr, (size_t)(nout_k + 1) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+    if (nnz1) {
+      hipMemcpyAsync(dci, col, (size_t)nnz1 * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+      hipMemcpyAsync(dfv, val, (size_t)nnz1 * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
+    }
+    const int64_t blocks = std::min<int64_t>(tg_cdiv(out->n, 256), (int64_t)g_tg.num_cu * 32);
+    hipLaunchKernelGGL(k_tensor_apply_1d, dim3((unsigned)blocks), dim3(256), 0, g_tg.stream, drp, dci, dfv, n_lo, nin_k, nout_k,
+                       n_hi, col_shift, in->d, out->d);
+    if (hipGetLastError() != hipSuccess) {
+      tg_set_error("k_tensor_apply_1d failed to launch");
+      rc = 1;
+    }
+    hipStreamSynchronize(g_tg.stream);
+  }
+  tg_dfree(drp);
+  tg_dfree(dci);
+  tg_dfree(dfv);
+  return rc;
+}

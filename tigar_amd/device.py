@@ -534,6 +534,25 @@ def assemble_mapped_load(vertices, p, cp, fnodal, nq=None):
     return out
 
 
+def tensor_apply_1d(x, dims_in, k, F, col_shift=0):
+    """Apply the scipy CSR 1-D factor ``F`` (rows = output indices of direction k, columns = input
+    indices + col_shift) along direction ``k`` of the tensor-indexed DeviceVector ``x`` (direction 0
+    fastest); returns the new DeviceVector (``tg_tensor_apply_1d``)."""
+    import scipy.sparse as sp
+    F = sp.csr_matrix(F)
+    F.sort_indices()
+    dims = _i64(dims_in)
+    n_out = 1
+    for j, n in enumerate(dims_in):
+        n_out *= F.shape[0] if j == k else int(n)
+    out = DeviceVector(n=n_out)
+    rp, ci, fv = _i32(F.indptr), _i32(F.indices), _f64(F.data)
+    check(_lib.lib().tg_tensor_apply_1d(len(dims_in), _p(dims, c_i64p), int(k), int(F.shape[0]), _p(rp, c_i32p),
+                                        _p(ci, c_i32p), _p(fv, c_f64p), int(col_shift), x._h, out._h),
+          "tg_tensor_apply_1d")
+    return out
+
+
 def vec_tensor3(b1d, scale=1.0, row0=None, row1=None):
     d = len(b1d)
     bs = [_f64(b) for b in b1d]

@@ -11,6 +11,7 @@ are slabs of "planes" along the last parametric direction; everything a slab of 
 (rows of M^T, rows of A, rows of M) is local in that direction, and its extent follows from
 the 1-D knot vector alone.  ``ZSlabLayout`` is pure host arithmetic (CPU-testable).
 """
+import os
 import numpy as np
 
 
@@ -130,7 +131,6 @@ class SlabHotPath(object):
         self.kx = KronExtraction(basis, grid)
         # sum-factorised PtAP when M is exactly a Kronecker product (checked against the
         # closed-form nnz of M on the tensor grid); TIGAR_PTAP_FACTORED=0/1 overrides
-        import os
         env = os.environ.get("TIGAR_PTAP_FACTORED")
         from .kronptap import default_groups
         self.groups = default_groups(basis.nvar, max(s1.p for s1 in basis.splines))
@@ -144,6 +144,10 @@ class SlabHotPath(object):
         explicit = env is not None and env not in ("0", "1")
         self.factored = (factored if factored is not None else (env != "0" if env is not None else True))
         self.basis, self.grid = basis, grid
+        # sufficient condition for M == kron(M_k) entrywise without building anything: every product of
+        # 1-D entries stays above the filter threshold (generateM drops abs(v) <= eps)
+        mins = [float(np.min(np.abs(m.data))) if m.nnz else 0.0 for m in self.kx.M1]
+        self.kron_exact = bool(np.prod(mins) > eps) and os.environ.get("TIGAR_TENSOR_APPLY", "1") != "0"
         self.rank, self.world, self.comm = rank, world, comm
         self.eps = eps
         self.layout = layout_for(basis, grid)
@@ -185,9 +189,12 @@ class SlabHotPath(object):
         for (ka, kb) in self.sub_slabs():
             S = self.layout.slab(ka, kb)
             t0 = time.perf_counter()
-            MT = dev.extract_csr_tensor_t(sp1, axes, 0, self.n_fe, self.eps, S["dofs"][0], S["dofs"][1])
             use_factored = self.factored
-            if use_factored:
+            tensor_mtb = use_factored and self.kron_exact
+            MT = None
+            if not tensor_mtb:
+                MT = dev.extract_csr_tensor_t(sp1, axes, 0, self.n_fe, self.eps, S["dofs"][0], S["dofs"][1])
+            if use_factored and not tensor_mtb:
                 # exactness check of the Kronecker form on this slab: nnz(M^T rows) must equal the
                 # product of the 1-D counts restricted to the slab's dof planes
                 lz = self.kx.M1[-1].T.tocsr()
@@ -230,7 +237,10 @@ class SlabHotPath(object):
             del kblk
             tick("stack", t0)
             t0 = time.perf_counter()
-            y = MT.mult_offset(b, S["a_rows"][0])
+            if tensor_mtb:
+                y = self._mtb_tensor(b, S, ka, kb)
+            else:
+                y = MT.mult_offset(b, S["a_rows"][0])
             y.zero_entries(zero_dofs, S["dofs"][0])
             rhs_parts.append(y)
             tick("mtb", t0)
@@ -280,6 +290,36 @@ class SlabHotPath(object):
                                             self.comm if self.world > 1 else None)
         return U, its, res, status
 
+    def _mtb_tensor(self, b, S, ka, kb):
+        """(M^T b) of the dof planes [ka,kb) from the FE rows S["a_rows"] of b by sum factorisation:
+        M^T = M_z^T (x) M_y^T (x) M_x^T applied direction by direction (tIGAr/common.py:97-109 without
+        forming M^T; valid because M is exactly the Kronecker product, ``self.kron_exact``)."""
+        dev, kx, d = self.dev, self.kx, self.kx.d
+        pf = self.layout.plane_fe
+        za, zb = S["a_rows"][0] // pf, S["a_rows"][1] // pf
+        dims = list(kx.nfe[:-1]) + [zb - za]
+        t = b
+        for k in range(d - 1):
+            t = dev.tensor_apply_1d(t, dims, k, kx.M1[k].T.tocsr())
+            dims[k] = kx.ncp[k]
+        MzT = kx.M1[-1].T.tocsr()[ka:kb]
+        return dev.tensor_apply_1d(t, dims, d - 1, MzT, col_shift=za)
+
+    def _prolong_tensor(self, x, dof_plane0):
+        """u = M U on the FE planes this rank owns, U given on the dof planes starting at
+        ``dof_plane0`` (own planes + halo), direction by direction."""
+        dev, kx, d = self.dev, self.kx, self.kx.d
+        pf = self.layout.plane_fe
+        fa, fb = self.mine["u_rows"][0] // pf, self.mine["u_rows"][1] // pf
+        nk = x.size() // self.layout.plane_dofs
+        dims = list(kx.ncp[:-1]) + [nk]
+        t = x
+        for k in range(d - 1):
+            t = dev.tensor_apply_1d(t, dims, k, kx.M1[k])
+            dims[k] = kx.nfe[k]
+        Mz = kx.M1[-1][fa:fb]
+        return dev.tensor_apply_1d(t, dims, d - 1, Mz, col_shift=dof_plane0)
+
     def prolong(self, U):
         """u rows owned by this rank: u = M_own * U (tIGAr/common.py:1259), U with its halo.
         Matrix-free: the rows of M are evaluated and contracted with U on the fly."""
@@ -290,4 +330,6 @@ class SlabHotPath(object):
             x_col0 = self.mine["dofs"][0] - self.mine["halo"][0]
         else:
             x, x_col0 = U, 0
+        if self.kron_exact:
+            return self._prolong_tensor(x, x_col0 // self.layout.plane_dofs)
         return dev.extract_apply_tensor(self.basis.splines, self.grid.axes, 0, self.eps, x, x_col0, r0, r1)
