@@ -114,6 +114,10 @@ int tg_extract_csr_points(int d, const tg_dir_t *dirs, int32_t col_offset, int64
                           double eps, const double *x, int64_t nrows, tg_csr_t *out);
 /* vertical concatenation of row blocks (multi-field M: one block per field) */
 int tg_csr_vstack(int nblocks, const tg_csr_t *blocks, tg_csr_t *out);
+/* The same stacked matrix WITHOUT copying entries: a loose-row view whose rows point into the
+ * blocks' own col/val arrays (20 B per row are written instead of 12 B per entry).  The blocks
+ * (canonical or loose-row) must outlive the view; accepted where loose-row matrices are. */
+int tg_csr_vstack_view(int nblocks, const tg_csr_t *blocks, tg_csr_t *out);
 /* Incremental vstack: K is assembled slab by slab into ONE allocation (no second copy of a 70 GB
  * matrix): create with an nnz capacity estimate, append row blocks in order (the block's arrays
  * are copied device-to-device; the capacity grows geometrically if the estimate was short),

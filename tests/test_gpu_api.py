@@ -331,6 +331,23 @@ def test_loose_row_stage_results(T):
     assert st.is_loose()
     S = st.to_scipy()
     assert np.array_equal(S.indptr, C2.indptr) and abs(S - C2).max() <= 1e-13 * abs(C2).max()
+    # the stacked VIEW (row tables only, entries stay in the blocks) compacts to the same matrix and
+    # feeds the next stage like the copy does; also over canonical blocks
+    vw = dev.csr_vstack_view([lo, hi])
+    assert vw.is_loose()
+    V = vw.to_scipy()
+    assert np.array_equal(V.indptr, C2.indptr) and np.array_equal(V.indices, C2.indices) and abs(V - C2).max() <= 1e-13 * abs(C2).max()
+    c_lo = dev.ptap_kron(A, 0, dims, fac, 0, half)
+    c_hi = dev.ptap_kron(A, 0, dims, fac, half, n_out)
+    V2 = dev.csr_vstack_view([c_lo, c_hi]).to_scipy()
+    assert np.array_equal(V2.indices, C2.indices) and abs(V2 - C2).max() <= 1e-13 * abs(C2).max()
+    dims_y = kx.dims({0})
+    fac_y = [None, kx.M1[1], None]
+    n_y = kx.ncp[0] * kx.ncp[1] * kx.nfe[2]
+    y_from_view = dev.ptap_kron(vw, 0, dims_y, fac_y, 0, n_y).to_scipy()
+    y_from_copy = dev.ptap_kron(st, 0, dims_y, fac_y, 0, n_y).to_scipy()
+    assert np.array_equal(y_from_view.indices, y_from_copy.indices)
+    assert abs(y_from_view - y_from_copy).max() <= 1e-13 * abs(y_from_copy).max()
     with pytest.raises(_lib.TigarHipError):
         dev.csr_vstack([lo, canon])
     x = dev.DeviceVector(data=np.ones(loose.shape[1]))

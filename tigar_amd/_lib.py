@@ -86,6 +86,7 @@ PROTOTYPES = {
                                         C.c_double, c_f64p, C.c_int64, C.POINTER(handle)]),
     "tg_csr_vstack": (C.c_int, [C.c_int, C.POINTER(handle), C.POINTER(handle)]),
     "tg_csr_builder_create": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(handle)]),
+    "tg_csr_vstack_view": (C.c_int, [C.c_int, C.POINTER(handle), C.POINTER(handle)]),
     "tg_csr_builder_append": (C.c_int, [handle, handle]),
     "tg_csr_builder_finish": (C.c_int, [handle, C.POINTER(handle)]),
     "tg_eval_basis_1d": (C.c_int, [C.POINTER(tg_dir_t), c_f64p, C.c_int64, c_i32p, c_i32p, c_f64p]),

@@ -69,6 +69,11 @@ struct tg_csr_s {
   // order in which the producing kernel reserved space), nnz counts the col/val entries in use
   // incl. the gaps.  Accepted by tg_ptap_kron*, tg_csr_vstack, tg_csr_compact, tg_csr_download.
   int32_t *rowcnt = nullptr;   // device, nrows; nullptr = canonical CSR
+  // "view" over the entry arrays of several blocks (tg_csr_vstack_view): loose rows whose starts
+  // are element offsets relative to col / val of the FIRST block (they may point into the other
+  // blocks' allocations, hence separate offsets for val); col/val are borrowed, not owned
+  int64_t *rowptr_val = nullptr;   // device, nrows+1; nullptr = rowptr serves both arrays
+  bool view = false;
   // SpMV plan (CSR-stream row blocks), built lazily
   int32_t *rowblocks = nullptr;  // device, nblocks+1 row indices
   int64_t nblocks = 0;

@@ -491,8 +491,11 @@ extern "C" int tg_csr_destroy(tg_csr_t m) {
   if (!m) return 0;
   if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
   tg_dfree(m->rowptr);
-  tg_dfree(m->col);
-  tg_dfree(m->val);
+  tg_dfree(m->rowptr_val);
+  if (!m->view) {
+    tg_dfree(m->col);
+    tg_dfree(m->val);
+  }
   tg_dfree(m->rowblocks);
   tg_dfree(m->rowcnt);
   delete m;

@@ -634,6 +634,7 @@ extern "C" int tg_csr_vstack(int nblocks, const tg_csr_t *blocks, tg_csr_t *out)
     nloose += blocks[b]->rowcnt ? 1 : 0;
   }
   TG_REQUIRE(nloose == 0 || nloose == nblocks, "vstack: loose-row and canonical blocks cannot be mixed");
+  for (int b = 0; b < nblocks; b++) TG_REQUIRE(!blocks[b]->rowptr_val, "vstack: views cannot be stacked");
   tg_csr_s *m = nullptr;
   TG_TRY(tg_csr_alloc(nrows, ncols, nnz, &m));
   if (nloose && tg_dmalloc(&m->rowcnt, nrows)) {
@@ -658,6 +659,58 @@ extern "C" int tg_csr_vstack(int nblocks, const tg_csr_t *blocks, tg_csr_t *out)
   if (nloose) {   // end marker of the last block = entries in use
     const int64_t used = z;
     hipMemcpyAsync(m->rowptr + nrows, &used, sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream);
+  }
+  TG_LAUNCH_CHECK();
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  *out = m;
+  return 0;
+}
+
+// Row tables of a stacked matrix WITHOUT copying entries: row r of block b becomes the loose row
+// (first-block-relative offset of its entries in col / in val, length).  The intermediate stage
+// results of neighbouring sub-slabs are stacked like this for the last PtAP stage; only 20 B per row
+// are written instead of 12 B per entry.
+__global__ void k_view_rows(const int64_t *__restrict__ rp, const int32_t *__restrict__ rc, int64_t n, int64_t dcol,
+                            int64_t dval, int64_t *__restrict__ orp, int64_t *__restrict__ orv, int32_t *__restrict__ orc) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int64_t a = rp[i];
+    orp[i] = a + dcol;
+    orv[i] = a + dval;
+    orc[i] = rc ? rc[i] : (int32_t)(rp[i + 1] - a);
+  }
+}
+
+extern "C" int tg_csr_vstack_view(int nblocks, const tg_csr_t *blocks, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(nblocks >= 1 && blocks && out, "bad arguments to tg_csr_vstack_view");
+  int64_t nrows = 0, nnz = 0, ncols = blocks[0]->ncols;
+  for (int b = 0; b < nblocks; b++) {
+    TG_REQUIRE(blocks[b] && blocks[b]->ncols == ncols, "vstack view: column count mismatch");
+    TG_REQUIRE(!blocks[b]->rowptr_val, "vstack view: a view cannot be stacked again");
+    nrows += blocks[b]->nrows;
+    nnz += blocks[b]->nnz;
+  }
+  tg_csr_s *m = new tg_csr_s();
+  m->nrows = nrows;
+  m->ncols = ncols;
+  m->nnz = nnz;
+  m->view = true;
+  m->col = blocks[0]->col;
+  m->val = blocks[0]->val;
+  if (tg_dmalloc(&m->rowptr, nrows + 1) || tg_dmalloc(&m->rowptr_val, nrows + 1) || tg_dmalloc(&m->rowcnt, nrows)) {
+    tg_csr_destroy(m);
+    return 1;
+  }
+  int64_t r = 0;
+  for (int b = 0; b < nblocks; b++) {
+    const tg_csr_s *s = blocks[b];
+    const int64_t dcol = s->col - m->col, dval = s->val - m->val;     // element offsets (may be negative)
+    if (s->nrows)
+      hipLaunchKernelGGL(k_view_rows, dim3(tg_grid_1d(s->nrows, 256)), dim3(256), 0, g_tg.stream, s->rowptr,
+                         (const int32_t *)s->rowcnt, s->nrows, dcol, dval, m->rowptr + r, m->rowptr_val + r, m->rowcnt + r);
+    r += s->nrows;
   }
   TG_LAUNCH_CHECK();
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));

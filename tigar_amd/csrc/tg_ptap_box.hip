@@ -22,6 +22,7 @@
 
 struct tg_box_args {
   const int32_t *rowcnt;        // loose rows of an intermediate stage result (nullptr: canonical CSR)
+  const int64_t *rowptr_val;    // stacked view: separate row starts for the val array (nullptr: rowptr)
   const int64_t *rowptr;
   const int32_t *col;
   const double *val;
@@ -411,7 +412,7 @@ __global__ void __launch_bounds__(NT)
         for (int u = 0; u < TG_BOX_UNROLL; u++) {
           const int oo = min(o + u * P.g1, ln - 1);
           cc[u] = P.col[start + oo];
-          vv[u] = P.val[start + oo];
+          vv[u] = (MODE == TG_BOXMODE_PROBE) ? 0.0 : P.val[start + oo];   // (probe: pattern only; `start` may be a col-only offset)
         }
 #pragma unroll
         for (int u = 0; u < TG_BOX_UNROLL; u++) {
@@ -548,6 +549,7 @@ __global__ void __launch_bounds__(NT)
 
 __global__ void __launch_bounds__(256)
     k_box_reorder(const int64_t *__restrict__ rowptr, const int64_t *__restrict__ tmp_off,
+                  const int64_t *__restrict__ tmp_off_val,
                   const int32_t *__restrict__ tcol, const double *__restrict__ tval, int64_t nrows,
                   int32_t *__restrict__ col, double *__restrict__ val) {
   const int lane = threadIdx.x & 63;
@@ -555,9 +557,10 @@ __global__ void __launch_bounds__(256)
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t r = wave; r < nrows; r += nwaves) {
     const int64_t dst = rowptr[r], n = rowptr[r + 1] - dst, src = tmp_off[r];
+    const int64_t srcv = tmp_off_val ? tmp_off_val[r] : src;
     for (int64_t q = lane; q < n; q += 64) {
       col[dst + q] = tcol[src + q];
-      val[dst + q] = tval[src + q];
+      val[dst + q] = tval[srcv + q];
     }
   }
 }
@@ -745,9 +748,9 @@ __global__ void __launch_bounds__(64)
   bool range = false, outside = false;
   int64_t chunk_pos = 0, chunk_end = 0;         // wave-private piece of the temporary
   // rowptr pair of operand row `lane` for the output row with coordinate iu along u
-  int64_t ns0 = 0, ns1 = 0;
+  int64_t ns0 = 0, ns1 = 0, nsv = 0;
   auto fetch = [&](int iu) {
-    ns0 = ns1 = 0;
+    ns0 = ns1 = nsv = 0;
     if (lane < len) {
       const int r0 = a == 0 ? la : (u == 0 ? iu : I[0]);
       const int r1 = a == 1 ? la : (u == 1 ? iu : I[1]);
@@ -758,6 +761,7 @@ __global__ void __launch_bounds__(64)
       else {
         ns0 = P.rowptr[lr];
         ns1 = P.rowcnt ? ns0 + P.rowcnt[lr] : P.rowptr[lr + 1];
+        nsv = P.rowptr_val ? P.rowptr_val[lr] : ns0;
       }
     }
   };
@@ -774,6 +778,7 @@ __global__ void __launch_bounds__(64)
   // contraction, was tried: the second register set costs half the resident waves and was 1.8x
   // slower -- the kernel is bound by instruction issue once enough waves are resident.)
   int64_t s0v = ns0;                              // operand rows of the output row being streamed
+  int64_t s0val = nsv;                            // ... their starts in the val array (stacked views)
   int lnv = (int)min((int64_t)0x7fffffff, ns1 - ns0);
   int cj = 0, cp = 0;                             // uniform cursor of the loads: operand row, pass
   int kj = 0, kp = 0;                             // the same walk, replayed when a batch is consumed
@@ -787,6 +792,7 @@ __global__ void __launch_bounds__(64)
       const bool act = cj < len;                  // uniform
       const int jc = min(cj, lastj);
       const int64_t s = tg_readlane_i64(s0v, jc);
+      const int64_t sv = tg_readlane_i64(s0val, jc);
       const int l = __builtin_amdgcn_readlane(lnv, jc);
       const int off = act ? cp * 64 : 0;
       // entries past the end of the row are loaded (the arrays are padded) and masked.
@@ -795,7 +801,7 @@ __global__ void __launch_bounds__(64)
       const __amdgpu_buffer_rsrc_t rc =
           __builtin_amdgcn_make_buffer_rsrc(tg_uniform_ptr(P.col + (s + off)), 0, 0x7fffffff, 0x00020000);
       const __amdgpu_buffer_rsrc_t rv =
-          __builtin_amdgcn_make_buffer_rsrc(tg_uniform_ptr(P.val + (s + off)), 0, 0x7fffffff, 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc(tg_uniform_ptr(P.val + (sv + off)), 0, 0x7fffffff, 0x00020000);
       cc[i] = __builtin_amdgcn_raw_buffer_load_b32(rc, lane * 4, 0, 0);
       vv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rv, lane * 8, 0, 0));
       const bool endrow = (cp + 1) * 64 >= l;
@@ -887,6 +893,7 @@ __global__ void __launch_bounds__(64)
     }
     if (t + 1 < nsteps) {
       s0v = ns0;
+      s0val = nsv;
       lnv = (int)min((int64_t)0x7fffffff, ns1 - ns0);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1024,8 +1031,8 @@ int tg_csr_compact_impl(tg_csr_s *in, tg_csr_s **out) {
     hipMemcpyAsync(k->rowptr, cnt, (size_t)(in->nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream);
     if (in->nrows > 0) {
       const unsigned rg = (unsigned)std::min<int64_t>(tg_cdiv(in->nrows, 4), (int64_t)g_tg.num_cu * 16);
-      hipLaunchKernelGGL(k_box_reorder, dim3(rg), dim3(256), 0, g_tg.stream, k->rowptr, in->rowptr, in->col, in->val,
-                         in->nrows, k->col, k->val);
+      hipLaunchKernelGGL(k_box_reorder, dim3(rg), dim3(256), 0, g_tg.stream, k->rowptr, in->rowptr,
+                         (const int64_t *)in->rowptr_val, in->col, in->val, in->nrows, k->col, k->val);
     }
     if (hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
       tg_set_error("tg_csr_compact: kernel failed");
@@ -1073,6 +1080,7 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
   memset(&P, 0, sizeof(P));
   P.rowptr = cur->rowptr;
   P.rowcnt = cur->rowcnt;
+  P.rowptr_val = cur->rowptr_val;
   P.col = cur->col;
   P.val = cur->val;
   P.row0 = cur_row0;
@@ -1350,6 +1358,10 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
       Q.u = u;
     }
   }
+  if (cur->rowptr_val && !line_variant) {   // the box kernel reads col and val through one row start
+    cleanup();
+    return 102;
+  }
   if ((int64_t)P.nin[0] * P.nin[1] >= (1ll << 31) || nin_total >= (1ll << 31)) {
     cleanup();
     tg_set_error("tg_ptap_kron: index space too large for 32-bit decomposition");
@@ -1557,8 +1569,8 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
       if (!rc) {
         hipMemcpyAsync(k->rowptr, cnt, (size_t)(nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream);
         const unsigned rg = (unsigned)std::min<int64_t>(tg_cdiv(nrows, 4), (int64_t)g_tg.num_cu * 16);
-        hipLaunchKernelGGL(k_box_reorder, dim3(rg), dim3(256), 0, g_tg.stream, k->rowptr, off, tcol, tval, nrows, k->col,
-                           k->val);
+        hipLaunchKernelGGL(k_box_reorder, dim3(rg), dim3(256), 0, g_tg.stream, k->rowptr, off, (const int64_t *)nullptr,
+                           tcol, tval, nrows, k->col, k->val);
         if (hipGetLastError() != hipSuccess) {
           tg_set_error("tg_ptap_kron: reorder launch failed");
           rc = 1;
@@ -1601,6 +1613,13 @@ static int tg_ptap_kron_any(tg_csr_t cur, int64_t cur_row0, int d, const int64_t
   }
   if (getenv("TIGAR_BOX_REACH_STRIDE")) stride = std::max(1, atoi(getenv("TIGAR_BOX_REACH_STRIDE")));
   int rc = tg_ptap_kron_impl(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, stride, loose_out, out);
+  if (rc == 102) {   // stacked view into a kernel that cannot read it: compact once, then as usual
+    tg_csr_s *flat = nullptr;
+    TG_TRY(tg_csr_compact_impl(cur, &flat));
+    rc = tg_ptap_kron_any(flat, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, loose_out, out);
+    tg_csr_destroy(flat);
+    return rc;
+  }
   if (rc == 101 && stride > 1)
     rc = tg_ptap_kron_impl(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, 1, loose_out, out);
   if (rc == 101) {

@@ -305,6 +305,17 @@ def csr_vstack(blocks):
     return DeviceCSR(h)
 
 
+def csr_vstack_view(blocks):
+    """Stacked loose-row VIEW of the blocks (no entry copies, ``tg_csr_vstack_view``); the returned
+    object keeps the blocks alive."""
+    arr = (handle * len(blocks))(*[b._h for b in blocks])
+    h = handle()
+    check(_lib.lib().tg_csr_vstack_view(len(blocks), arr, C.byref(h)), "tg_csr_vstack_view")
+    out = DeviceCSR(h)
+    out._keep = list(blocks)
+    return out
+
+
 class CSRBuilder(object):
     """Incremental vstack of row blocks into one allocation (K assembled slab by slab)."""
 

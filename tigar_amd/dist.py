@@ -277,7 +277,13 @@ class SlabHotPath(object):
         ring["pieces"] = [pc for pc in ring["pieces"] if pc[1] > za]     # drop planes below the slab
         lo = ring["pieces"][0][0]
         blocks = [pc[2] for pc in ring["pieces"]]
-        cur = blocks[0] if len(blocks) == 1 else dev.csr_vstack(blocks)
+        # the last stage reads the pieces in place (row tables only; TIGAR_RING_COPY=1: stacked copy)
+        if len(blocks) == 1:
+            cur = blocks[0]
+        elif os.environ.get("TIGAR_RING_COPY") == "1":
+            cur = dev.csr_vstack(blocks)
+        else:
+            cur = dev.csr_vstack_view(blocks)
         done = set(sum(self.groups[:-1], []))
         ca, cb = lay.fe_planes_coupled(lo, zb)
         pl_out = kx.plane(done | set(self.groups[-1]))

@@ -105,8 +105,8 @@ def contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs=None,
                              intermediate=intermediate)
         if out is not None:
             return out
-        if cur.is_loose():
-            cur = cur.compact()          # the general kernel needs canonical rows
+    if cur.is_loose():
+        cur = cur.compact()              # the general kernel needs canonical rows
     MT = kx.PT(done, group, out_rows[0], out_rows[1])
     Pm = kx.P(done, group, c_planes[0] * pl_in, c_planes[1] * pl_in)
     plan = _dev.ptap_symbolic(cur, Pm, MT, a_planes[0] * pl_in, c_planes[0] * pl_in, out_rows[0])
