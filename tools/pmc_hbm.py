@@ -1,0 +1,41 @@
+"""HBM traffic per kernel from two separate rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE), as the
+MI355X guide prescribes (no trace domains besides --kernel-trace; gfx950: FETCH_SIZE x2 for wide
+coalesced streams).  usage: python tools/pmc_hbm.py out.json -- <command ...>"""
+import csv, glob, json, os, shutil, subprocess, sys, tempfile, collections
+
+
+def one_pass(counter, cmd):
+    out = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    subprocess.call(["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", out, "-o", "p", "--output-format", "csv", "--"] + cmd,
+                    cwd="/tmp", env=env, stdout=open(os.path.join(out, "log"), "w"), stderr=subprocess.STDOUT)
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                a = acc[r["Kernel_Name"]]
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+    shutil.rmtree(out, ignore_errors=True)
+    return acc
+
+
+def main():
+    cut = sys.argv.index("--")
+    dst, cmd = sys.argv[1], sys.argv[cut + 1:]
+    cmd = [os.path.abspath(c) if c.endswith(".py") and os.path.exists(c) else c for c in cmd]
+    fetch, write = one_pass("FETCH_SIZE", cmd), one_pass("WRITE_SIZE", cmd)
+    rows = []
+    for k in sorted(fetch, key=lambda k: -fetch[k][1]):
+        n, f = fetch[k]
+        w = write.get(k, [0, 0.0])[1]
+        rows.append({"kernel": k[:90], "launches": n, "hbm_read_GB_total_corrected": 2.0 * f * 1024 / 1e9,
+                     "hbm_write_GB_total": w * 1024 / 1e9})
+    json.dump({"command": " ".join(cmd), "note": "FETCH_SIZE/WRITE_SIZE in KB, separate passes; reads x2 (gfx950 correction), "
+               "writes as counted", "kernels": rows[:14]}, open(dst, "w"), indent=1)
+    for r in rows[:10]:
+        print("%-70s %5d  read %9.2f GB  write %9.2f GB" % (r["kernel"][:70], r["launches"], r["hbm_read_GB_total_corrected"], r["hbm_write_GB_total"]))
+
+
+if __name__ == "__main__":
+    main()
