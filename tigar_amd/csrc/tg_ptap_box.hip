@@ -1604,7 +1604,7 @@ static int tg_ptap_kron_any(tg_csr_t cur, int64_t cur_row0, int d, const int64_t
   // the kernel flags any entry that falls outside a box, in which case the exact reach is used.
   int64_t stride = 1;
   if (cur->nrows > (1 << 20) && !getenv("TIGAR_BOX_EXACT_REACH")) {
-    const int64_t cand[5] = {7, 11, 13, 17, 19};
+    const int64_t cand[5] = {29, 31, 37, 41, 43};
     for (int c = 0; c < 5; c++)
       if (dims_in[0] % cand[c] != 0) {
         stride = cand[c];
