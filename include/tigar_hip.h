@@ -180,6 +180,12 @@ int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, 
  * tg_csr_destroy -- every other entry point rejects it. */
 int tg_ptap_kron_stage(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in,
                        const tg_kron1d_t *fac, int64_t out_row0, int64_t out_row1, tg_csr_t *out);
+/* Last stage with the result appended to a slab-wise builder of K (tg_csr_builder_*): the rows
+ * [out_row0,out_row1) must be the next rows the builder expects; saves the block allocation and the
+ * copy of tg_csr_builder_append.  Returns 100 like tg_ptap_kron when the kernel declines. */
+int tg_ptap_kron_append(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in,
+                        const tg_kron1d_t *fac, int64_t out_row0, int64_t out_row1,
+                        const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_builder_t dest);
 /* canonical CSR copy of a loose-row matrix */
 int tg_csr_compact(tg_csr_t in, tg_csr_t *out);
 int tg_csr_is_loose(tg_csr_t m, int *loose);

@@ -103,6 +103,8 @@ PROTOTYPES = {
                                c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
     "tg_ptap_kron_stage": (C.c_int, [handle, C.c_int64, C.c_int, c_i64p, C.POINTER(tg_kron1d_t), C.c_int64, C.c_int64,
                                      C.POINTER(handle)]),
+    "tg_ptap_kron_append": (C.c_int, [handle, C.c_int64, C.c_int, c_i64p, C.POINTER(tg_kron1d_t), C.c_int64, C.c_int64,
+                                      c_i32p, C.c_int64, C.c_double, handle]),
     "tg_csr_compact": (C.c_int, [handle, C.POINTER(handle)]),
     "tg_csr_is_loose": (C.c_int, [handle, C.POINTER(C.c_int)]),
     "tg_zero_rows_cols": (C.c_int, [handle, C.c_int64, c_i32p, C.c_int64, C.c_double]),

@@ -103,6 +103,11 @@ int tg_exclusive_scan_i64(int64_t *d, int64_t n, int64_t *host_total);
 // deterministic reduction of `n` partial doubles (device) into out_dev[0..k) sums of k
 // interleaved streams -- tg_core.hip
 int tg_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, tg_csr_s **out);
+struct tg_csr_builder_s {      // incremental vstack into one allocation (tg_extract.hip)
+  tg_csr_s *m = nullptr;
+  int64_t rows_done = 0, nnz_done = 0, cap = 0;
+};
+int tg_csr_builder_reserve(tg_csr_builder_s *b, int64_t nrows, int64_t nnz);   // room for one more block (may grow)
 int tg_csr_compact_impl(tg_csr_s *in, tg_csr_s **out);   // loose rows -> canonical CSR (tg_ptap_box.hip)
 int tg_spmv_plan(tg_csr_s *a);
 int tg_spmv_raw(tg_csr_s *a, const double *x_shifted, double *y, double *dot_partial_with,

@@ -721,11 +721,6 @@ extern "C" int tg_csr_vstack_view(int nblocks, const tg_csr_t *blocks, tg_csr_t 
 // ----------------------------------------------------------------------------------------
 // incremental vstack
 // ----------------------------------------------------------------------------------------
-struct tg_csr_builder_s {
-  tg_csr_s *m = nullptr;
-  int64_t rows_done = 0, nnz_done = 0, cap = 0;
-};
-
 extern "C" int tg_csr_builder_create(int64_t nrows_total, int64_t ncols, int64_t nnz_capacity,
                                      tg_csr_builder_t *out) {
   TG_REQUIRE_INIT();
@@ -742,15 +737,12 @@ extern "C" int tg_csr_builder_create(int64_t nrows_total, int64_t ncols, int64_t
   return 0;
 }
 
-extern "C" int tg_csr_builder_append(tg_csr_builder_t b, tg_csr_t blk) {
-  TG_REQUIRE_INIT();
-  TG_REQUIRE(b && b->m && blk, "null argument to tg_csr_builder_append");
-  TG_REQUIRE_CANONICAL(blk);
-  TG_REQUIRE(blk->ncols == b->m->ncols, "builder: column count mismatch");
-  TG_REQUIRE(b->rows_done + blk->nrows <= b->m->nrows, "builder: more rows appended than announced");
-  if (b->nnz_done + blk->nnz > b->cap) {
+int tg_csr_builder_reserve(tg_csr_builder_s *b, int64_t nrows, int64_t nnz) {
+  TG_REQUIRE(b && b->m, "null builder");
+  TG_REQUIRE(b->rows_done + nrows <= b->m->nrows, "builder: more rows appended than announced");
+  if (b->nnz_done + nnz > b->cap) {
     // grow: new arrays, copy what is there
-    const int64_t ncap = std::max<int64_t>(b->nnz_done + blk->nnz, b->cap + b->cap / 4 + 1024);
+    const int64_t ncap = std::max<int64_t>(b->nnz_done + nnz, b->cap + b->cap / 4 + 1024);
     int32_t *ncol = nullptr;
     double *nval = nullptr;
     TG_TRY(tg_dmalloc(&ncol, ncap + TG_CSR_PAD));
@@ -769,6 +761,15 @@ extern "C" int tg_csr_builder_append(tg_csr_builder_t b, tg_csr_t blk) {
     b->m->val = nval;
     b->cap = ncap;
   }
+  return 0;
+}
+
+extern "C" int tg_csr_builder_append(tg_csr_builder_t b, tg_csr_t blk) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(b && b->m && blk, "null argument to tg_csr_builder_append");
+  TG_REQUIRE_CANONICAL(blk);
+  TG_REQUIRE(blk->ncols == b->m->ncols, "builder: column count mismatch");
+  TG_TRY(tg_csr_builder_reserve(b, blk->nrows, blk->nnz));
   if (blk->nrows) {
     // rowptr entries 1..nrows of the block, shifted (entry 0 of the builder's range is already set)
     hipLaunchKernelGGL(k_copy_rowptr_shift, dim3(tg_grid_1d(blk->nrows, 256)), dim3(256), 0, g_tg.stream,

@@ -1009,6 +1009,11 @@ __global__ void k_i64_to_i32(const int64_t *__restrict__ a, int32_t *__restrict_
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) b[i] = (int32_t)a[i];
 }
+__global__ void k_shift_i64(int64_t *__restrict__ dst, const int64_t *__restrict__ src, int64_t n, int64_t shift) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = src[i] + shift;
+}
 __global__ void k_i32_to_i64(const int32_t *__restrict__ a, int64_t *__restrict__ b, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1061,9 +1066,9 @@ static size_t tg_box_lds(int cap, int cap1, int ctab, int nlist, int nt) {
 // outside a box sized from SAMPLED reach data (retry with the exact reach), other = error
 static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, const tg_kron1d_t *fac,
                              int64_t out_row0, int64_t out_row1, const int32_t *zero_dofs, int64_t nzero, double diag,
-                             int64_t reach_stride, bool loose_out, tg_csr_t *out) {
+                             int64_t reach_stride, bool loose_out, tg_csr_builder_s *dest, tg_csr_t *out) {
   TG_REQUIRE_INIT();
-  TG_REQUIRE(cur && d >= 1 && d <= 3 && dims_in && fac && out && out_row1 >= out_row0, "bad arguments to tg_ptap_kron");
+  TG_REQUIRE(cur && d >= 1 && d <= 3 && dims_in && fac && (out || dest) && out_row1 >= out_row0, "bad arguments to tg_ptap_kron");
   static bool lim = false;
   if (!lim) {
     hipFuncSetAttribute((const void *)k_ptap_box<TG_BOXMODE_PROBE, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1562,6 +1567,32 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
         delete k;
         k = nullptr;
       }
+    } else if (!rc && dest) {
+      // last stage of a slab: rows go straight into the slab-wise builder of K (no block of its own,
+      // no second copy by tg_csr_builder_append)
+      int64_t nnz = 0;
+      rc = tg_exclusive_scan_i64(cnt, nrows, &nnz);
+      if (!rc && dest->m->ncols != nout_total) {
+        tg_set_error("tg_ptap_kron_append: the builder has %lld columns, the product %lld", (long long)dest->m->ncols,
+                     (long long)nout_total);
+        rc = 2;
+      }
+      if (!rc) rc = tg_csr_builder_reserve(dest, nrows, nnz);
+      if (!rc) {
+        int64_t *rp = dest->m->rowptr + dest->rows_done;       // rp[0] == nnz_done already
+        hipLaunchKernelGGL(k_shift_i64, dim3(tg_grid_1d(nrows, 256)), dim3(256), 0, g_tg.stream, rp + 1, cnt + 1, nrows,
+                           dest->nnz_done);
+        const unsigned rg = (unsigned)std::min<int64_t>(tg_cdiv(nrows, 4), (int64_t)g_tg.num_cu * 16);
+        hipLaunchKernelGGL(k_box_reorder, dim3(rg), dim3(256), 0, g_tg.stream, rp, off, (const int64_t *)nullptr, tcol, tval,
+                           nrows, dest->m->col, dest->m->val);
+        if (hipGetLastError() != hipSuccess) {
+          tg_set_error("tg_ptap_kron_append: reorder launch failed");
+          rc = 1;
+        } else {
+          dest->rows_done += nrows;
+          dest->nnz_done += nnz;
+        }
+      }
     } else if (!rc) {
       int64_t nnz = 0;
       rc = tg_exclusive_scan_i64(cnt, nrows, &nnz);
@@ -1590,13 +1621,16 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
     if (k) tg_csr_destroy(k);
     return rc;
   }
-  *out = k;
+  if (out)
+    *out = k;
+  else if (k)
+    tg_csr_destroy(k);
   return 0;
 }
 
 static int tg_ptap_kron_any(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, const tg_kron1d_t *fac,
                             int64_t out_row0, int64_t out_row1, const int32_t *zero_dofs, int64_t nzero, double diag,
-                            bool loose_out, tg_csr_t *out) {
+                            bool loose_out, tg_csr_builder_s *dest, tg_csr_t *out) {
   TG_REQUIRE(cur && dims_in, "bad arguments to tg_ptap_kron");
   // The accumulator boxes are sized from the reach of cur's rows.  Scanning every entry of cur costs
   // a noticeable fraction of the product, so the reach is first measured on every `stride`-th row
@@ -1612,16 +1646,16 @@ static int tg_ptap_kron_any(tg_csr_t cur, int64_t cur_row0, int d, const int64_t
       }
   }
   if (getenv("TIGAR_BOX_REACH_STRIDE")) stride = std::max(1, atoi(getenv("TIGAR_BOX_REACH_STRIDE")));
-  int rc = tg_ptap_kron_impl(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, stride, loose_out, out);
+  int rc = tg_ptap_kron_impl(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, stride, loose_out, dest, out);
   if (rc == 102) {   // stacked view into a kernel that cannot read it: compact once, then as usual
     tg_csr_s *flat = nullptr;
     TG_TRY(tg_csr_compact_impl(cur, &flat));
-    rc = tg_ptap_kron_any(flat, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, loose_out, out);
+    rc = tg_ptap_kron_any(flat, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, loose_out, dest, out);
     tg_csr_destroy(flat);
     return rc;
   }
   if (rc == 101 && stride > 1)
-    rc = tg_ptap_kron_impl(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, 1, loose_out, out);
+    rc = tg_ptap_kron_impl(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, 1, loose_out, dest, out);
   if (rc == 101) {
     tg_set_error("tg_ptap_kron: an entry fell outside its accumulator box");
     rc = 4;
@@ -1632,7 +1666,7 @@ static int tg_ptap_kron_any(tg_csr_t cur, int64_t cur_row0, int d, const int64_t
 extern "C" int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, const tg_kron1d_t *fac,
                             int64_t out_row0, int64_t out_row1, const int32_t *zero_dofs, int64_t nzero, double diag,
                             tg_csr_t *out) {
-  return tg_ptap_kron_any(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, false, out);
+  return tg_ptap_kron_any(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, false, nullptr, out);
 }
 
 // intermediate stage of a direction-by-direction product: no boundary conditions, result in the
@@ -1640,5 +1674,14 @@ extern "C" int tg_ptap_kron(tg_csr_t cur, int64_t cur_row0, int d, const int64_t
 extern "C" int tg_ptap_kron_stage(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, const tg_kron1d_t *fac,
                                   int64_t out_row0, int64_t out_row1, tg_csr_t *out) {
   return tg_ptap_kron_any(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, nullptr, 0, 1.0,
-                          !getenv("TIGAR_PTAP_NOLOOSE"), out);
+                          !getenv("TIGAR_PTAP_NOLOOSE"), nullptr, out);
+}
+
+// last stage of a slab with the result appended to a slab-wise builder of K (the rows must be the next
+// rows the builder expects); returns 100 like tg_ptap_kron when the kernel declines (nothing appended)
+extern "C" int tg_ptap_kron_append(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in, const tg_kron1d_t *fac,
+                                   int64_t out_row0, int64_t out_row1, const int32_t *zero_dofs, int64_t nzero, double diag,
+                                   tg_csr_builder_t dest) {
+  TG_REQUIRE(dest && dest->m, "null builder");
+  return tg_ptap_kron_any(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, false, dest, nullptr);
 }

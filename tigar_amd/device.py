@@ -388,10 +388,12 @@ def ptap_numeric(plan, A, M, MT, zero_dofs=None, diag=1.0):
     return DeviceCSR(h)
 
 
-def ptap_kron(cur, cur_row0, dims_in, factors, out_row0, out_row1, zero_dofs=None, diag=1.0, intermediate=False):
+def ptap_kron(cur, cur_row0, dims_in, factors, out_row0, out_row1, zero_dofs=None, diag=1.0, intermediate=False,
+              append_to=None):
     """One Kronecker contraction stage out = P^T cur P (dense-box kernel).  ``intermediate``: the
     result only feeds the next stage (or a vstack of such results) and is returned in the loose-row
-    form (no row-reorder copy, no boundary conditions; see ``tg_ptap_kron_stage``).  ``factors[k]`` is a
+    form (no row-reorder copy, no boundary conditions; see ``tg_ptap_kron_stage``).  ``append_to``: a
+    ``CSRBuilder`` that receives the rows directly (``tg_ptap_kron_append``); returns True then.  ``factors[k]`` is a
     scipy CSR 1-D matrix (n_k x m_k) or None for the identity.  Returns None when the kernel
     declines (accumulator box too large for LDS) -- the caller then uses the general PtAP."""
     import scipy.sparse as sp
@@ -417,6 +419,14 @@ def ptap_kron(cur, cur_row0, dims_in, factors, out_row0, out_row1, zero_dofs=Non
     dims = _i64(dims_in)
     h = handle()
     zd = _i32(zero_dofs) if zero_dofs is not None and len(zero_dofs) else None
+    if append_to is not None:
+        rc = _lib.lib().tg_ptap_kron_append(cur._h, int(cur_row0), d, _p(dims, c_i64p), arr, int(out_row0), int(out_row1),
+                                            _p(zd, c_i32p) if zd is not None else None, zd.size if zd is not None else 0,
+                                            float(diag), append_to._h)
+        if rc == 100:
+            return None
+        check(rc, "tg_ptap_kron_append")
+        return True
     if intermediate:
         if zd is not None:
             raise ValueError("boundary conditions belong to the last stage")

@@ -218,14 +218,17 @@ class SlabHotPath(object):
             tick("input", t0)
             t0 = time.perf_counter()
             if use_factored:
-                kblk = self._factored_slab(A, S, ka, kb, zero_dofs, diag, ring)
+                kblk = self._factored_slab(A, S, ka, kb, zero_dofs, diag, ring,
+                                           builder if os.environ.get("TIGAR_SLAB_APPEND", "1") != "0" else None)
                 plan = None
             else:
                 plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], S["m_rows"][0], S["dofs"][0])
                 kblk = dev.ptap_numeric(plan, A, M, MT, zero_dofs, diag)
             tick("ptap", t0)
             t0 = time.perf_counter()
-            if nslabs == 1:
+            if kblk is True:
+                pass                 # the last stage appended its rows to the builder itself
+            elif nslabs == 1:
                 k_blocks.append(kblk)
             else:
                 if builder is None:
@@ -254,7 +257,7 @@ class SlabHotPath(object):
         tick("stack", t0)
         return K, rhs
 
-    def _factored_slab(self, A_new, S, ka, kb, zero_dofs, diag, ring):
+    def _factored_slab(self, A_new, S, ka, kb, zero_dofs, diag, ring, builder=None):
         """Sum-factorised K rows of dof planes [ka,kb).  The plane-local stages (all direction
         groups but the last) are applied once per FE plane: their results are kept in ``ring``
         and shared by neighbouring sub-slabs (their supports overlap by ~p*p planes)."""
@@ -287,7 +290,8 @@ class SlabHotPath(object):
         done = set(sum(self.groups[:-1], []))
         ca, cb = lay.fe_planes_coupled(lo, zb)
         pl_out = kx.plane(done | set(self.groups[-1]))
-        return contract(kx, cur, done, self.groups[-1], (lo, zb), (ca, cb), (ka * pl_out, kb * pl_out), zero_dofs, diag)
+        return contract(kx, cur, done, self.groups[-1], (lo, zb), (ca, cb), (ka * pl_out, kb * pl_out), zero_dofs, diag,
+                        append_to=builder)
 
     def solve(self, K, rhs, method="cg", pc="jacobi", rtol=1e-6, atol=1e-15, maxit=10000, restart=30):
         dev = self.dev

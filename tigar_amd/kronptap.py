@@ -92,7 +92,8 @@ def default_groups(d, p):
     return [list(range(d))]
 
 
-def contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs=None, diag=1.0, intermediate=False):
+def contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs=None, diag=1.0, intermediate=False,
+             append_to=None):
     """One contraction stage: rows ``out_rows`` (global row range in the space after the stage)
     of  P^T cur P,  where ``cur`` holds the planes ``a_planes`` of the current space (global
     columns within the planes ``c_planes``) and P contracts the directions in ``group``."""
@@ -102,9 +103,9 @@ def contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs=None,
         dims_in = kx.dims(done)
         factors = [kx.M1[k] if k in group else None for k in range(kx.d)]
         out = _dev.ptap_kron(cur, a_planes[0] * pl_in, dims_in, factors, out_rows[0], out_rows[1], zero_dofs, diag,
-                             intermediate=intermediate)
+                             intermediate=intermediate, append_to=append_to)
         if out is not None:
-            return out
+            return out               # (True: the rows went straight into the builder)
     if cur.is_loose():
         cur = cur.compact()              # the general kernel needs canonical rows
     MT = kx.PT(done, group, out_rows[0], out_rows[1])
