@@ -185,6 +185,10 @@ def run_distributed(args, d, p, nel, rank, world):
             for k, v in timers.items():
                 stages.setdefault(k, []).append(v)
         state.update(K=K, U=U, u=u, its=its)
+        if os.environ.get("TIGAR_TRACE"):
+            pb, nb, nl = dev.pool_stats()
+            fr, tot = dev.mem_info()
+            log("[bench] pool: %.1f GB free in %d blocks, %d blocks live; device free %.1f GB" % (pb / 2 ** 30, nb, nl, fr / 2 ** 30))
 
     for _ in range(args.warmup):
         step(False)

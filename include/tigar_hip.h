@@ -31,7 +31,9 @@ const char *tg_last_error(void);
 int tg_sync(void);                         /* hipStreamSynchronize on the library stream */
 int tg_device_info(char *name, int name_len, int *num_cu, int64_t *hbm_bytes);
 int tg_mem_info(int64_t *free_bytes, int64_t *total_bytes);
-int tg_pool_trim(void);                    /* releases the caching allocator's free blocks */
+int tg_pool_trim(void);
+/* caching allocator statistics: bytes / blocks held free in the pool, blocks handed out */
+int tg_pool_stats(int64_t *pooled_bytes, int64_t *pooled_blocks, int64_t *live_blocks);                    /* releases the caching allocator's free blocks */
 /* HIP-event timers on the library's stream (bench.py roofline measurement). */
 int tg_timer_start(int slot);
 int tg_timer_stop(int slot, double *ms);   /* synchronises; elapsed ms since start(slot) */

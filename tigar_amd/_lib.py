@@ -51,6 +51,7 @@ PROTOTYPES = {
     "tg_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p]),
     "tg_mem_info": (C.c_int, [c_i64p, c_i64p]),
     "tg_pool_trim": (C.c_int, []),
+    "tg_pool_stats": (C.c_int, [c_i64p, c_i64p, c_i64p]),
     "tg_timer_start": (C.c_int, [C.c_int]),
     "tg_timer_stop": (C.c_int, [C.c_int, c_f64p]),
     "tg_prof_reset": (C.c_int, []),

@@ -129,10 +129,26 @@ static size_t g_pool_bytes = 0;
 static size_t tg_pool_limit() {
   static size_t lim = 0;
   if (!lim) {
+    // default: three quarters of the device memory.  hipMalloc costs 30 ms/GB and up on this stack, so
+    // every block that is needed again next step should stay cached: at cfg3 the blocks cached at the
+    // end of a step (111 GB) plus K (75 GB, freed when the next step starts) need 186 GB -- with the
+    // former 160 GB limit K's arrays or ~25 GB of smaller blocks were given back and re-allocated
+    // EVERY step (0.7-2 s).  A failing hipMalloc trims the pool and retries, so the limit is not a
+    // safety margin.
     const char *s = getenv("TIGAR_POOL_GB");
-    lim = (size_t)((s ? atof(s) : 160.0) * (double)((size_t)1 << 30));
+    double gb = 160.0;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) gb = 0.75 * (double)tot / (double)((size_t)1 << 30);
+    lim = (size_t)((s ? atof(s) : gb) * (double)((size_t)1 << 30));
   }
   return lim;
+}
+
+extern "C" int tg_pool_stats(int64_t *pooled_bytes, int64_t *pooled_blocks, int64_t *live_blocks) {
+  if (pooled_bytes) *pooled_bytes = (int64_t)g_pool_bytes;
+  if (pooled_blocks) *pooled_blocks = (int64_t)g_pool_free.size();
+  if (live_blocks) *live_blocks = (int64_t)g_pool_size.size() - (int64_t)g_pool_free.size();
+  return 0;
 }
 
 extern "C" int tg_pool_trim(void) {
@@ -190,15 +206,32 @@ void tg_dfree(void *p) {
   }
   const size_t bytes = it->second;
   if (g_pool_bytes + bytes > tg_pool_limit()) {
+    // pool full: hipMalloc costs ~30 ms/GB on this stack (1.5 s for the 50 GB value array of K), so
+    // the LARGE blocks are the ones worth keeping -- evict cached blocks smaller than the incoming one,
+    // smallest first, before giving the incoming block back to the driver
     const auto t0 = std::chrono::steady_clock::now();
-    if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
-    g_pool_size.erase(it);
-    hipFree(p);
-    if (getenv("TIGAR_TRACE")) {
-      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      if (ms > 20.0) fprintf(stderr, "[trace] slow hipFree(%.1f MB) (pool full): %.1f ms\n", bytes / 1048576.0, ms);
+    bool synced = false;
+    while (g_pool_bytes + bytes > tg_pool_limit() && !g_pool_free.empty() && g_pool_free.begin()->first < bytes) {
+      auto sm = g_pool_free.begin();
+      if (!synced && g_tg.ready) {
+        hipStreamSynchronize(g_tg.stream);
+        synced = true;
+      }
+      g_pool_bytes -= sm->first;
+      g_pool_size.erase(sm->second);
+      hipFree(sm->second);
+      g_pool_free.erase(sm);
     }
-    return;
+    if (g_pool_bytes + bytes > tg_pool_limit()) {
+      if (!synced && g_tg.ready) hipStreamSynchronize(g_tg.stream);
+      g_pool_size.erase(it);
+      hipFree(p);
+      if (getenv("TIGAR_TRACE")) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > 20.0) fprintf(stderr, "[trace] slow hipFree(%.1f MB) (pool full): %.1f ms\n", bytes / 1048576.0, ms);
+      }
+      return;
+    }
   }
   g_pool_free.emplace(bytes, p);
   g_pool_bytes += bytes;

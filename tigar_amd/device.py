@@ -633,6 +633,13 @@ def device_info():
     return {"name": name.value.decode(), "num_cu": ncu.value, "hbm_bytes": hbm.value}
 
 
+def pool_stats():
+    """(bytes held free by the caching allocator, free blocks, blocks in use)"""
+    a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+    check(_lib.lib().tg_pool_stats(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
 def mem_info():
     f, t = C.c_int64(), C.c_int64()
     check(_lib.lib().tg_mem_info(C.byref(f), C.byref(t)))
