@@ -107,22 +107,19 @@ def _bootstrap_comm(rank, world):
 
 
 def pick_sub_planes(d, p, nel, planes_mine, free_bytes):
-    """dof planes per sub-slab so that one slab of A, M, M^T and the PtAP temporaries use at most
-    ~35% of the free HBM (K itself and its stacked copy need the rest)."""
+    """dof planes per sub-slab so that one slab of A and the PtAP temporaries use at most about half
+    of the free HBM (K needs the rest)."""
     nfe1 = nel * p + 1
     plane_fe = nfe1 ** (d - 1)
     nnzA_plane = plane_fe * ((2 * p + 1) ** d) * 0.55 * 12.0 * 1.0     # bytes per FE plane, generous
     nnzM_plane = plane_fe * ((p + 1) ** d) * 12.0
     per_dof_plane = p * (nnzA_plane + 2.2 * nnzM_plane) + (nel + p) ** (d - 1) * ((2 * p + 1) ** d) * 12.0 * 2
     fixed = (2 * p * p + 2) * (nnzA_plane + 2.2 * nnzM_plane)
-    budget = 0.35 * free_bytes - fixed
+    # (half of the free HBM: measured at 256^3 p=3 with the 3/4-of-HBM allocator pool, per step:
+    # 5 planes 1.59 s of input+PtAP, 8: 1.53 s, 12: 1.44 s, 16: 1.41 s with 75 GB still free at the end
+    # of a step, 20: allocation failures and pool trimming start, 24: 5.6 s)
+    budget = 0.5 * free_bytes - fixed
     n = int(max(1, min(planes_mine, budget // per_dof_plane)))
-    from tigar_amd.kronptap import default_groups
-    if len(default_groups(d, p)) == 3:
-        # direction-by-direction stages: the x-stage result (FE-sized in y and z) and its temporary
-        # are larger than the (x,y)-stage result the estimate above was made for (measured at
-        # 256^3 p=3: 5 planes best, 6 starts to thrash the allocator, 8 doubles the PtAP time)
-        n = max(1, min(n, (n * 5) // 8))
     return n
 
 

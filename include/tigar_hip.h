@@ -191,6 +191,7 @@ int tg_ptap_kron_append(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *di
 /* canonical CSR copy of a loose-row matrix */
 int tg_csr_compact(tg_csr_t in, tg_csr_t *out);
 int tg_csr_is_loose(tg_csr_t m, int *loose);
+int tg_csr_rowptr_at(tg_csr_t m, int64_t r, int64_t *out);   /* rowptr[r], 0 <= r <= nrows */
 /* MatZeroRowsColumns(K, zeroDofs, diag) [ext] as called at tIGAr/common.py:1200;
  * K holds global rows [row0, row0+nrows). */
 int tg_zero_rows_cols(tg_csr_t k, int64_t row0, const int32_t *dofs, int64_t n, double diag);

@@ -108,6 +108,7 @@ PROTOTYPES = {
                                       c_i32p, C.c_int64, C.c_double, handle]),
     "tg_csr_compact": (C.c_int, [handle, C.POINTER(handle)]),
     "tg_csr_is_loose": (C.c_int, [handle, C.POINTER(C.c_int)]),
+    "tg_csr_rowptr_at": (C.c_int, [handle, C.c_int64, c_i64p]),
     "tg_zero_rows_cols": (C.c_int, [handle, C.c_int64, c_i32p, C.c_int64, C.c_double]),
     "tg_krylov_solve": (C.c_int, [handle, handle, handle, C.c_int, C.c_int, C.c_double, C.c_double,
                                   C.c_int, C.c_int, handle, C.POINTER(C.c_int), c_f64p,

@@ -161,6 +161,11 @@ class DeviceCSR(object):
                                         colscale._h if colscale is not None else None, C.byref(h)), "tg_csr_combine")
         return DeviceCSR(h)
 
+    def rowptr_at(self, r):
+        v = C.c_int64()
+        check(_lib.lib().tg_csr_rowptr_at(self._h, int(r), C.byref(v)), "tg_csr_rowptr_at")
+        return v.value
+
     def is_loose(self):
         v = C.c_int()
         check(_lib.lib().tg_csr_is_loose(self._h, C.byref(v)), "tg_csr_is_loose")

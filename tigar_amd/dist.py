@@ -234,7 +234,13 @@ class SlabHotPath(object):
                 if builder is None:
                     # capacity from the first slab's density (rows near the patch boundary are
                     # sparser than interior ones, hence the margin); grows if short
-                    est = int(kblk.nnz / max(1, kb - ka) * (self.k1 - self.k0) * 1.08) + 1024
+                    # from the densest (last = most interior) dof plane of the first slab: rows near
+                    # the patch boundary are sparser, so the slab average underestimates and the
+                    # builder would have to grow (a second 75 GB allocation and copy at cfg3)
+                    pd = self.layout.plane_dofs
+                    nr = kblk.shape[0]
+                    last = kblk.nnz - kblk.rowptr_at(nr - pd) if nr >= pd else kblk.nnz
+                    est = int(max(kblk.nnz / max(1, kb - ka), last) * (self.k1 - self.k0) * 1.01) + 1024
                     builder = dev.CSRBuilder(self.mine["dofs"][1] - self.mine["dofs"][0], self.ncp, est)
                 builder.append(kblk)
             del kblk
