@@ -249,7 +249,7 @@ def main():
                                                                 - (res["t_input"] if res.get("t_input_in_timed_region") else 0.0)),
                    "sub_planes": res.get("sub_planes"),
                    "parallelism": "z-slab x%d" % max(args.gpus, world)},
-        "roofline": {"bound": "hbm", "kernel": "k_spmv_stream (K p in CG)", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "k_spmv_lane (K p in CG)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": "profiles/r1_spmv_pmc_summary.json (rocprofv3 --pmc "
                      "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)" if traffic else None,
