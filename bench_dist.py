@@ -16,7 +16,7 @@ def log(*a):
 
 class HostRendezvous(object):
     """Minimal TCP rendezvous between the ranks of one node (rank 0 listens on MASTER_ADDR at
-    MASTER_PORT + 17): hands out the RCCL unique id and provides the host-side barrier / max of the
+    MASTER_PORT + 17, or the next free candidate): hands out the RCCL unique id and provides the host-side barrier / max of the
     bench contract.  Plain sockets: nothing but the Python standard library in the launcher path
     (importing torch here would also pull a second RCCL / HIP runtime into the process)."""
 
@@ -26,36 +26,66 @@ class HostRendezvous(object):
         self.rank, self.world = rank, world
         self.struct = struct
         addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-        port = int(os.environ.get("MASTER_PORT", "29500")) + 17
+        base = int(os.environ.get("MASTER_PORT", "29500"))
+        # candidate ports (the first free one is used; a port taken by something else is skipped: both
+        # sides check a magic word that is derived from MASTER_PORT)
+        ports = [base + 17 + 101 * k for k in range(8)]
+        magic = struct.pack("q", 0x7469676172000000 ^ base)
         self.peers = []
         if world == 1:
             return
         if rank == 0:
-            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, port))
-            srv.listen(world)
+            srv = None
+            for port in ports:
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind((addr, port))
+                    srv.listen(world)
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise OSError("no free rendezvous port among %s" % ports)
             conns = {}
             while len(conns) < world - 1:
                 c, _ = srv.accept()
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                r = struct.unpack("i", self._recv(c, 4))[0]
-                conns[r] = c
+                try:
+                    c.settimeout(10.0)
+                    hello = self._recv(c, 12)
+                    c.settimeout(None)
+                except (OSError, ConnectionError):
+                    c.close()
+                    continue
+                if hello[:8] != magic:
+                    c.close()
+                    continue
+                c.sendall(magic)
+                conns[struct.unpack("i", hello[8:])[0]] = c
             self.peers = [conns[r] for r in sorted(conns)]
             srv.close()
         else:
-            deadline = time.time() + 120.0
-            while True:
-                try:
-                    c = socket.create_connection((addr, port), timeout=5.0)
-                    break
-                except OSError:
+            deadline = time.time() + 180.0
+            c = None
+            while c is None:
+                for port in ports:
+                    try:
+                        cand = socket.create_connection((addr, port), timeout=5.0)
+                        cand.sendall(magic + struct.pack("i", rank))
+                        if self._recv(cand, 8) == magic:
+                            c = cand
+                            break
+                        cand.close()
+                    except (OSError, ConnectionError):
+                        pass
+                if c is None:
                     if time.time() > deadline:
-                        raise
+                        raise OSError("rendezvous with rank 0 failed on ports %s" % ports)
                     time.sleep(0.2)
             c.settimeout(None)
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            c.sendall(struct.pack("i", rank))
             self.peers = [c]
 
     @staticmethod

@@ -124,3 +124,27 @@ def test_host_rendezvous_three_ranks():
     assert [r[0] for r in res] == [0, 1, 2]
     assert all(r[1] for r in res)
     assert all(r[2] == 3.0 for r in res)
+
+
+def test_host_rendezvous_skips_a_busy_port():
+    """MASTER_PORT + 17 already taken by an unrelated listener (which answers nothing): rank 0 binds
+    the next candidate, the other rank finds it through the magic-word handshake."""
+    import multiprocessing as mp
+    import socket
+    world, port = 2, 29963
+    blocker = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    blocker.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    blocker.bind(("127.0.0.1", port + 17))
+    blocker.listen(4)
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_rdv_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=180) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        blocker.close()
+    assert [r[0] for r in res] == [0, 1] and all(r[1] for r in res)
