@@ -225,7 +225,7 @@ def test_rccl_world1_comm_roundtrip(T):
 
 
 @pytest.mark.parametrize("box", ["1", "0"])
-@pytest.mark.parametrize("d,p,nel", [(2, 2, 9), (2, 4, 5), (3, 2, 5), (3, 3, 4)])
+@pytest.mark.parametrize("d,p,nel", [(2, 2, 9), (2, 4, 5), (3, 2, 5), (3, 3, 4), (3, 4, 3), (1, 3, 7)])
 def test_sum_factorised_ptap_equals_direct(T, d, p, nel, box, monkeypatch):
     # box=1: dense-LDS-box Kronecker kernel (tg_ptap_kron); box=0: the general hash kernel fed
     # with explicit directional operators
