@@ -143,35 +143,50 @@ def run_single(args, d, p, nel):
 
 # ------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(d, p, budget_nel):
-    """Oracle (CPU restatement, scipy/numpy = the same CSR algorithms PETSc AIJ uses: row-wise
-    insertion, Gustavson PtAP, CSR SpMV, Jacobi-CG) on a bounded sample of the same workload
-    (same d, p; fewer elements), one core."""
+    """The oracle's C + OpenMP restatement (oracle/tigar_oracle_c.c: the CSR algorithms PETSc AIJ runs on
+    the CPU -- row-wise generateM, Gustavson PtAP + MatZeroRowsColumns, scatter-add M^T b, Jacobi-CG with
+    PETSc's convergence test) on all host cores, on a bounded sample of the same workload (same d, p;
+    fewer elements).  FE inputs A, b are generated beforehand (untimed, as on the GPU side)."""
     from oracle import tigar_oracle as O
+    from oracle import tigar_oracle_c as OC
     nel = budget_nel
+    # one thread per usable core, at most 32 (the sample is small; more threads only add barrier cost)
+    OC.set_threads(min(32, OC.usable_cores()))
     t0 = time.perf_counter()
     s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel)] * d)
     f = lambda x: np.sin(np.pi * x)
-    A, b, _, _ = O.poisson_fe_system(s, f1d=[f] * d)
+    # FE inputs from the device generator (identical matrices, seconds instead of half a minute of
+    # scipy.kron); they are inputs of the baseline, not part of what is timed
+    from tigar_amd.BSplines import ExplicitBSplineControlMesh, uniformKnots
+    from tigar_amd.common import TensorFunctionSpace
+    from tigar_amd.forms import LaplaceForm, SeparableLoadForm
+    basis = ExplicitBSplineControlMesh([p] * d, [uniformKnots(p, 0.0, 1.0, nel) for _ in range(d)]).getScalarSpline()
+    V_in = TensorFunctionSpace([basis.generateMesh(degree=p)], "Lagrange")
+    A = LaplaceForm().assemble_matrix(V_in).to_scipy()
+    b = SeparableLoadForm([f] * d, scale=d * np.pi ** 2).assemble_vector(V_in).get_local()
     t_in = time.perf_counter() - t0
     t0 = time.perf_counter()
-    M = O.generate_M_tensor(s)
+    M = OC.generate_M_tensor(s)
     zd = []
     for direction in range(d):
         for side in (0, 1):
             zd += s.getSideDofs(direction, side)
     t1 = time.perf_counter()
-    K = O.extract_matrix(M, A, zd)
-    rhs = O.extract_vector(M, b, zd)
+    K = OC.extract_matrix(M, A, zd)
+    rhs = OC.extract_vector(M, b, zd)
     t2 = time.perf_counter()
-    U, its, _ = O.cg_jacobi(K, rhs, rtol=1e-6)
-    u = M @ U
+    U, its, _ = OC.cg_jacobi(K, rhs, rtol=1e-6)
+    u = OC.spmv(M, U)
     t3 = time.perf_counter()
     total = t3 - t0
     ncp = s.getNcp()
-    return {"value": ncp / total, "unit": "DoF/s", "cores": 1, "kind": "port",
+    X, _ = O.fe_node_grid(s)
+    err = float(np.max(np.abs(u - np.prod(np.sin(np.pi * X), axis=1))))
+    return {"value": ncp / total, "unit": "DoF/s", "cores": OC.num_threads(), "kind": "port",
             "sample": "%dD p=%d %d^%d elements (%d DoFs): extract %.2fs, M^T A M + M^T b %.2fs, "
-                      "CG(%d its)+prolongation %.2fs; scipy/numpy oracle, 1 core; inputs %.2fs untimed"
-                      % (d, p, nel, d, ncp, t1 - t0, t2 - t1, its, t3 - t2, t_in)}
+                      "CG(%d its)+prolongation %.2fs; C+OpenMP oracle on %d threads; max nodal error %.1e; "
+                      "inputs %.2fs untimed"
+                      % (d, p, nel, d, ncp, t1 - t0, t2 - t1, its, t3 - t2, OC.num_threads(), err, t_in)}
 
 
 def main():
@@ -257,7 +272,9 @@ def main():
                      "avg_launch_ms": spmv_avg_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
     }
     if not args.no_cpu_baseline:
-        cpu_nel = args.cpu_nel or ({2: 40, 3: 20, 4: 12}.get(p, 16) if d == 3 else min(nel, 128))
+        # a bounded sample: seconds of work on the 16 cores the GPU box grants (the A*M intermediate of
+        # the Gustavson PtAP needs ~7 GB of host memory at p=3, 40^3 elements)
+        cpu_nel = args.cpu_nel or ({2: 80, 3: 40, 4: 16}.get(p, 16) if d == 3 else min(nel, 256))
         out["cpu_baseline"] = cpu_baseline(d, p, cpu_nel)
     print(json.dumps(out), flush=True)
 
