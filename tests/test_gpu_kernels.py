@@ -353,3 +353,29 @@ def test_matrix_free_prolongation_equals_spmv(dev):
         c0, c1 = cols.min(), cols.max() + 1
         yp = dev.extract_apply_tensor(s.splines, axes, 0, 1e-15, dev.DeviceVector(data=x[c0:c1]), c0, r0, r1).get_local()
         assert np.max(np.abs(yp - ref[r0:r1])) <= 1e-14 * np.max(np.abs(M) @ np.abs(x))
+
+
+def test_spmv_row_block_packing_stress(dev):
+    """Row blocks of the stream SpMV are packed up to the LDS capacity: random matrices whose row
+    lengths make blocks land exactly at, just below and above the cap (incl. empty rows, rows longer
+    than cap/2 -> wave-per-row mode), against scipy.  (A nearly full block once dropped its last
+    entries: the aligned start of the 16-byte loads was not budgeted.)"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(42)
+    for trial, (nrows, ncols, lens) in enumerate([
+            (3000, 5000, lambda n: rng.integers(20, 35, n)),                 # M-like rows, blocks ~ full
+            (2000, 4000, lambda n: np.full(n, 27)),                          # constant 27: 151 rows = 4077
+            (1500, 3000, lambda n: rng.choice([0, 1, 63, 64, 65, 343], n)),  # mixed, empty rows
+            (600, 6000, lambda n: rng.integers(1300, 1400, n)),              # M^T-like rows (~1331)
+            (300, 9000, lambda n: rng.integers(2040, 2056, n)),              # around cap/2
+            (64, 20000, lambda n: rng.integers(3000, 9000, n))]):            # longer than any block
+        L = np.minimum(lens(nrows), ncols).astype(np.int64)
+        indptr = np.concatenate([[0], np.cumsum(L)])
+        indices = np.concatenate([np.sort(rng.choice(ncols, int(l), replace=False)) for l in L]) if L.sum() else np.zeros(0, int)
+        data = rng.standard_normal(int(L.sum()))
+        A = sp.csr_matrix((data, indices.astype(np.int32), indptr), shape=(nrows, ncols))
+        dA = dev.DeviceCSR.from_scipy(A)
+        x = rng.standard_normal(ncols)
+        y = dA.mult(dev.DeviceVector(data=x)).get_local()
+        ref = A @ x
+        assert np.max(np.abs(y - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))), trial
