@@ -124,3 +124,41 @@ def test_slab_streamed_assembly_equals_resident_at_scale():
     u_t = path.prolong(U).get_local()
     u_e = gen.M.mult(U).get_local()
     assert path.kron_exact and np.max(np.abs(u_t - u_e)) <= 1e-13 * np.max(np.abs(u_e))
+
+
+def test_gmres_on_nonsymmetric_system_at_scale():
+    """Jacobi-GMRES(30) (the solver of the 3-D demos, demos/taylor-green/taylor-green-3d.py:89-90) on a
+    non-symmetric K = M^T A M + BCs with 0.5 M unknowns: true residual after convergence."""
+    import scipy.sparse as sp
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, forms as F, device as dev
+    d, p, nel = 3, 2, 78
+    kv = [B.uniformKnots(p, 0., 1., nel)] * d
+    gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p] * d, kv))
+    sp0 = gen.getScalarSpline(0)
+    for direction in range(d):
+        gen.addZeroDofs(0, sp0.getSideDofs(direction, 0))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    Alap = F.LaplaceForm().assemble_matrix(gen.V)
+    Amass = F.MassForm().assemble_matrix(gen.V)
+    n = Alap.shape[0]
+    rng = np.random.default_rng(9)
+    w = dev.DeviceVector(data=1.0 + 0.5 * rng.random(n))
+    A = Alap.combine(1.0, Amass, 40.0, w)                 # K_fe + 40 M_fe diag(w): not symmetric
+    K = spline.extractMatrix(A)
+    ncp = K.shape[0]
+    assert ncp == (nel + p) ** d
+    xs = rng.standard_normal(ncp)
+    xs[np.unique(np.asarray(spline.zeroDofs))] = 0.0
+    b = K.mult(dev.DeviceVector(data=xs))
+    x = dev.DeviceVector(ncp)
+    its, res, status = dev.krylov_solve(K, b, x, "gmres", "jacobi", rtol=1e-10, maxit=5000, restart=30)
+    assert status == 0 and its > 5
+    r = K.mult(x)
+    r.axpy(-1.0, b)
+    assert r.norm() <= 1e-7 * b.norm()
+    assert np.max(np.abs(x.get_local() - xs)) <= 1e-6 * np.max(np.abs(xs))
+    # the transposed system differs: K really is non-symmetric
+    y1 = dev.DeviceVector(data=rng.standard_normal(ncp))
+    y2 = dev.DeviceVector(data=rng.standard_normal(ncp))
+    assert abs(y1.inner(K.mult(y2)) - y2.inner(K.mult(y1))) > 1e-10 * abs(y1.inner(K.mult(y2)))
