@@ -584,7 +584,7 @@ __global__ void __launch_bounds__(256)
 //     reads) and stored over the head of its own line (no second box), "touched" travels as a bit mask,
 //   * output space comes from a wave-private chunk of the temporary (one global atomic per
 //     TG grab, not per row); rows are put in final order by k_box_reorder as before.
-#define TG_LINE_NB 8
+#define TG_LINE_NB 4
 
 __device__ __forceinline__ int64_t tg_readlane_i64(int64_t v, int l) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, l);
@@ -773,7 +773,11 @@ __global__ void __launch_bounds__(64)
   }
   fetch(u >= 0 ? Iu : 0);
   // ---- stream of (operand row, 64-entry pass) items, TG_LINE_NB at a time: all loads of a batch
-  // are issued (buffer loads, scalar base, no address VGPRs) before the first item is consumed.
+  // are issued (buffer loads, scalar base, no address VGPRs) before the first item is consumed, and
+  // the uniform per-item state the consumer needs (entry count, weight of the operand row) is read
+  // out of the lanes at issue time, so the consumer does not walk the row list a second time
+  // (that replay cost ~10 % of the kernel; batches of 2/3/4/6/8: 35.5/34.5/33.3/33.3/33.0 ms on the
+  // x stage of 96^3 p=3).
   // (Issuing batch i+1 before consuming batch i, and the next row's first batch before this row's
   // contraction, was tried: the second register set costs half the resident waves and was 1.8x
   // slower -- the kernel is bound by instruction issue once enough waves are resident.)
@@ -781,12 +785,10 @@ __global__ void __launch_bounds__(64)
   int64_t s0val = nsv;                            // ... their starts in the val array (stacked views)
   int lnv = (int)min((int64_t)0x7fffffff, ns1 - ns0);
   int cj = 0, cp = 0;                             // uniform cursor of the loads: operand row, pass
-  int kj = 0, kp = 0;                             // the same walk, replayed when a batch is consumed
-  int lnk = lnv;                                  // row lengths of the output row being consumed
   const int lastj = max(len, 1) - 1;
-  // (branch-free: items past the end of the row list reload the last row's first entries and are
-  // ignored by the consumer; one basic block per batch keeps the two register sets apart)
-  auto issue = [&](int32_t (&cc)[TG_LINE_NB], double (&vv)[TG_LINE_NB]) {
+  // (branch-free: items past the end of the row list reload the last row's first entries and carry
+  // an entry count of 0)
+  auto issue = [&](int32_t (&cc)[TG_LINE_NB], double (&vv)[TG_LINE_NB], int (&rem)[TG_LINE_NB], double (&ww)[TG_LINE_NB]) {
 #pragma unroll
     for (int i = 0; i < TG_LINE_NB; i++) {
       const bool act = cj < len;                  // uniform
@@ -795,6 +797,8 @@ __global__ void __launch_bounds__(64)
       const int64_t sv = tg_readlane_i64(s0val, jc);
       const int l = __builtin_amdgcn_readlane(lnv, jc);
       const int off = act ? cp * 64 : 0;
+      rem[i] = act ? l - off : 0;                  // entries of this item (uniform)
+      ww[i] = tg_readlane_f64(lw, jc);             // weight of its operand row (uniform)
       // entries past the end of the row are loaded (the arrays are padded) and masked.
       // Buffer loads: the per-item base is a scalar resource, the only address VGPR is lane*4 / lane*8,
       // so a batch needs no address registers and never waits on the other batch's destinations.
@@ -814,7 +818,6 @@ __global__ void __launch_bounds__(64)
   for (int t = 0; t < nsteps; t++) {
     const int64_t R = Rfirst + (int64_t)t * rstep;
     const int64_t li = R - P.out_row0;
-    lnk = lnv;                                    // (lnv is replaced when the next row's loads start)
     if (t + 1 < nsteps) fetch(Iu + t + 1);        // rowptr pairs of the next output row
     const bool mrow = mask ? (mask[R] != 0) : false;
     if (u >= 0) {
@@ -867,28 +870,16 @@ __global__ void __launch_bounds__(64)
         if (live && in) unsafeAtomicAdd(&X[slot], fma(w, v, 0.0));
         outside |= live && !in;
       };
-      auto consume = [&](int32_t (&cc)[TG_LINE_NB], double (&vv)[TG_LINE_NB]) {
-#pragma unroll
-        for (int i = 0; i < TG_LINE_NB; i++) {
-          const bool act = kj < len;              // uniform
-          const int jc = min(kj, lastj);
-          const int l = __builtin_amdgcn_readlane(lnk, jc);
-          const int rem = act ? l - kp * 64 : 0;
-          if (rem > 0) add(cc[i], vv[i], tg_readlane_f64(lw, jc), lane < rem);
-          const bool endrow = (kp + 1) * 64 >= l;
-          kp = act ? (endrow ? 0 : kp + 1) : kp;
-          kj = (act && endrow) ? kj + 1 : kj;
-        }
-      };
-      kj = 0;
-      kp = 0;
       cj = 0;
       cp = 0;
       while (cj < len) {
         int32_t cc[TG_LINE_NB];
-        double vv[TG_LINE_NB];
-        issue(cc, vv);
-        consume(cc, vv);
+        double vv[TG_LINE_NB], ww[TG_LINE_NB];
+        int rem[TG_LINE_NB];
+        issue(cc, vv, rem, ww);
+#pragma unroll
+        for (int i = 0; i < TG_LINE_NB; i++)
+          if (rem[i] > 0) add(cc[i], vv[i], ww[i], lane < rem[i]);
       }
     }
     if (t + 1 < nsteps) {
