@@ -605,7 +605,7 @@ __device__ __forceinline__ void *tg_uniform_ptr(const void *p) {
 }
 
 template <int BAMAX, int DMAXT, int A, int U, bool HI>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAMAX <= 20 ? 5 : 4)))
     k_ptap_line(tg_box_args P, tg_line_args Q, int64_t *__restrict__ row_cnt, int64_t *__restrict__ row_off,
                 int32_t *__restrict__ k_col, double *__restrict__ k_val, unsigned long long *__restrict__ cursor,
                 int64_t capacity, const uint8_t *__restrict__ mask, double diag, int *__restrict__ status) {
@@ -781,10 +781,13 @@ __global__ void __launch_bounds__(64)
   // (Issuing batch i+1 before consuming batch i, and the next row's first batch before this row's
   // contraction, was tried: the second register set costs half the resident waves and was 1.8x
   // slower -- the kernel is bound by instruction issue once enough waves are resident.)
-  int64_t s0v = ns0;                              // operand rows of the output row being streamed
-  int64_t s0val = nsv;                            // ... their starts in the val array (stacked views)
+  // operand rows of the output row being streamed: byte addresses of their first col / val entries
+  // (computed per lane once per output row; the stream below only reads them out of the lanes, so an
+  // item costs no scalar address arithmetic -- the scalar unit is the busiest one in this kernel)
+  int64_t s0v = (int64_t)(uintptr_t)(P.col + ns0);
+  int64_t s0val = (int64_t)(uintptr_t)(P.val + nsv);
   int lnv = (int)min((int64_t)0x7fffffff, ns1 - ns0);
-  int cj = 0, cp = 0;                             // uniform cursor of the loads: operand row, pass
+  int cj = 0, cp = 0;                             // uniform cursor of the loads: operand row, entry offset of the pass
   const int lastj = max(len, 1) - 1;
   // (branch-free: items past the end of the row list reload the last row's first entries and carry
   // an entry count of 0)
@@ -796,20 +799,21 @@ __global__ void __launch_bounds__(64)
       const int64_t s = tg_readlane_i64(s0v, jc);
       const int64_t sv = tg_readlane_i64(s0val, jc);
       const int l = __builtin_amdgcn_readlane(lnv, jc);
-      const int off = act ? cp * 64 : 0;
+      const int off = act ? cp : 0;
       rem[i] = act ? l - off : 0;                  // entries of this item (uniform)
       ww[i] = tg_readlane_f64(lw, jc);             // weight of its operand row (uniform)
       // entries past the end of the row are loaded (the arrays are padded) and masked.
       // Buffer loads: the per-item base is a scalar resource, the only address VGPR is lane*4 / lane*8,
       // so a batch needs no address registers and never waits on the other batch's destinations.
       const __amdgpu_buffer_rsrc_t rc =
-          __builtin_amdgcn_make_buffer_rsrc(tg_uniform_ptr(P.col + (s + off)), 0, 0x7fffffff, 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)s, 0, 0x7fffffff, 0x00020000);
       const __amdgpu_buffer_rsrc_t rv =
-          __builtin_amdgcn_make_buffer_rsrc(tg_uniform_ptr(P.val + (sv + off)), 0, 0x7fffffff, 0x00020000);
-      cc[i] = __builtin_amdgcn_raw_buffer_load_b32(rc, lane * 4, 0, 0);
-      vv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rv, lane * 8, 0, 0));
-      const bool endrow = (cp + 1) * 64 >= l;
-      cp = act ? (endrow ? 0 : cp + 1) : cp;
+          __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)sv, 0, 0x7fffffff, 0x00020000);
+      // (the pass offset goes into the scalar offset field of the load)
+      cc[i] = __builtin_amdgcn_raw_buffer_load_b32(rc, lane * 4, off << 2, 0);
+      vv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rv, lane * 8, off << 3, 0));
+      const bool endrow = cp + 64 >= l;
+      cp = act ? (endrow ? 0 : cp + 64) : cp;
       cj = (act && endrow) ? cj + 1 : cj;
     }
   };
@@ -883,8 +887,8 @@ __global__ void __launch_bounds__(64)
       }
     }
     if (t + 1 < nsteps) {
-      s0v = ns0;
-      s0val = nsv;
+      s0v = (int64_t)(uintptr_t)(P.col + ns0);
+      s0val = (int64_t)(uintptr_t)(P.val + nsv);
       lnv = (int)min((int64_t)0x7fffffff, ns1 - ns0);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
