@@ -148,7 +148,11 @@ def pick_sub_planes(d, p, nel, planes_mine, free_bytes):
     # (half of the free HBM: measured at 256^3 p=3 with the 3/4-of-HBM allocator pool, per step:
     # 5 planes 1.59 s of input+PtAP, 8: 1.53 s, 12: 1.44 s, 16: 1.41 s with 75 GB still free at the end
     # of a step, 20: allocation failures and pool trimming start, 24: 5.6 s)
-    budget = 0.5 * free_bytes - fixed
+    # ... less the sliced copy of K's values that lives during the Krylov solve (tg_sell.hip: 8 B per
+    # entry + ~2 % padding; measured at 256^3 p=3 with the copy: 14 planes 3.5 s per step (allocator
+    # thrashing), 11: 2.13 s, 9: 2.12 s, 7: 2.13 s)
+    sell_bytes = 8.4 * planes_mine * (nel + p) ** (d - 1) * ((2 * p + 1) ** d)
+    budget = 0.5 * free_bytes - fixed - sell_bytes
     n = int(max(1, min(planes_mine, budget // per_dof_plane)))
     return n
 
@@ -235,6 +239,9 @@ def run_distributed(args, d, p, nel, rank, world):
     if comm is not None:
         nnzK = int(round(comm.allreduce_sum([float(nnzK_local)])[0]))
     spmv_ms, spmv_n = dev.prof_get(0)
+    # which product kernel the solver used: the sliced copy (tg_sell.hip) if K has the structure
+    sell_classes, sell_padded = K.spmv_sell(True)
+    K.spmv_sell(False)
 
     if args.check and rank == 0:
         # manufactured solution at the FE nodes this rank owns
@@ -258,4 +265,5 @@ def run_distributed(args, d, p, nel, rank, world):
     t_input = mean_stages.pop("input", 0.0)
     return {"ncp": basis.getNcp(), "nnzK": nnzK, "nnzK_local": nnzK_local, "ncp_local": ncp_local,
             "elapsed": elapsed, "spmv_ms_total": spmv_ms, "spmv_count": spmv_n, "iterations": state["its"],
-            "stages": mean_stages, "t_input": t_input, "t_input_in_timed_region": True, "sub_planes": sub}
+            "stages": mean_stages, "t_input": t_input, "t_input_in_timed_region": True, "sub_planes": sub,
+            "sell_classes": sell_classes, "sell_padded": sell_padded}

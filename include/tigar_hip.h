@@ -140,6 +140,16 @@ int tg_spmv(tg_csr_t a, tg_vec_t x, tg_vec_t y);
 /* same with x covering only the columns [x_col0, x_col0 + size(x)) of a row block whose
  * entries all fall in that range (z-slab pieces of M, M^T, K) */
 int tg_spmv_offset(tg_csr_t a, tg_vec_t x, int64_t x_col0, tg_vec_t y);
+/* Sliced, pattern-compressed copy of the VALUES of `a` for repeated products (tg_sell.hip).  The
+ * Krylov solvers build and drop it themselves for every solve (the K p of KSP on PETSc AIJ,
+ * tIGAr/common.py:1255-1258); this entry point keeps one on the matrix so that tg_spmv / tg_spmv_offset
+ * use it as well.  It is a snapshot: request it again after changing values.  Stencil-like matrices
+ * (K = M^T A M of tensor-product patches) are accepted -- rows in slices of 64, one sorted union of
+ * column offsets col - row per slice, values as dense [offsets][64] blocks, 8 B instead of 12 B per
+ * entry and no gather -- others are declined and keep the CSR kernel (nclasses = 0).  Rows are summed
+ * sequentially in ascending column order (PETSc's order); padded positions add +0.0.
+ * enable = 0 drops the copy.  nclasses / padded (may be NULL): dictionary size, doubles stored. */
+int tg_spmv_sell(tg_csr_t a, int enable, int *nclasses, int64_t *padded);
 /* Y = A X for k <= 4 right-hand sides (cpFuncs = M_control * P, tIGAr/common.py:367-380);
  * X, Y are column-major host arrays. */
 int tg_spmm_host(tg_csr_t a, const double *X, int k, double *Y);

@@ -379,3 +379,107 @@ def test_spmv_row_block_packing_stress(dev):
         y = dA.mult(dev.DeviceVector(data=x)).get_local()
         ref = A @ x
         assert np.max(np.abs(y - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))), trial
+
+
+def _stencil_matrix(rng, shape, reach, drop_rows=()):
+    """Stencil matrix on a tensor grid stored as general CSR (what K = M^T A M looks like): row i couples to
+    the grid points within `reach` in every direction, truncated at the boundary; random values."""
+    import itertools
+    n = int(np.prod(shape))
+    idx = np.arange(n).reshape(shape[::-1])          # x fastest
+    rows, cols = [], []
+    for off in itertools.product(*[range(-reach, reach + 1)] * len(shape)):
+        src = [slice(max(0, -o), s - max(0, o)) for o, s in zip(off[::-1], shape[::-1])]
+        dst = [slice(max(0, o), s - max(0, -o)) for o, s in zip(off[::-1], shape[::-1])]
+        rows.append(idx[tuple(src)].ravel())
+        cols.append(idx[tuple(dst)].ravel())
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    keep = ~np.isin(rows, np.asarray(drop_rows, dtype=np.int64))
+    rows, cols = rows[keep], cols[keep]
+    A = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(n, n))
+    A.sort_indices()
+    return A
+
+
+def test_spmv_sliced_copy_matches_csr(dev):
+    """tg_spmv_sell: products through the sliced, pattern-compressed copy agree with the CSR kernel to
+    rounding (sequential row sums instead of the tree of the CSR kernel); stencil matrices are accepted,
+    unstructured ones declined; empty rows, a ragged last slice, slices that straddle grid lines and
+    an x that covers only part of the columns (mult_offset) are covered."""
+    if os.environ.get("TIGAR_SPMV_SELL") == "0":
+        pytest.skip("sliced copy disabled by TIGAR_SPMV_SELL=0")
+    rng = np.random.default_rng(11)
+    cases = [
+        ("3d reach 3", _stencil_matrix(rng, (20, 18, 16), 3), True),
+        ("3d reach 2, 9 rows per line (slices span 7 lines)", _stencil_matrix(rng, (9, 30, 12), 2), True),
+        ("2d reach 2", _stencil_matrix(rng, (40, 37), 2), True),
+        ("1d reach 1", _stencil_matrix(rng, (5000,), 1), True),
+        ("2d with empty rows", _stencil_matrix(rng, (30, 30), 3, drop_rows=[0, 5, 6, 7, 450, 899]), True),
+        ("random", _rand_csr(rng, 3000, 3000, 0.01), False),
+    ]
+    for name, A, accepted in cases:
+        x = rng.standard_normal(A.shape[1])
+        dx = dev.DeviceVector(data=x)
+        dA = dev.DeviceCSR.from_scipy(A)
+        y0 = dA.mult(dx).get_local()
+        ncls, padded = dA.spmv_sell(True)
+        assert (ncls > 0) == accepted, (name, ncls)
+        if accepted:
+            assert A.nnz <= padded <= 1.5 * A.nnz + 4096, (name, padded, A.nnz)
+        y1 = dA.mult(dx).get_local()
+        scale = np.abs(A) @ np.abs(x) + 1e-300
+        assert np.max(np.abs(y1 - y0) / scale) < 4e-16 * max(1, A.getnnz(axis=1).max()) ** 0.5, name
+        ref = A @ x
+        assert np.max(np.abs(y1 - ref) / scale) < 1e-14, name
+        assert dA.spmv_sell(False) == (0, 0)
+        assert np.array_equal(dA.mult(dx).get_local(), y0), name
+    # a row block whose x holds only the columns it needs (z-slab pieces): clamping of padded positions
+    A = _stencil_matrix(rng, (12, 11, 10), 2)
+    n01 = 12 * 11
+    r0, r1 = 3 * n01, 6 * n01
+    c0, c1 = 1 * n01, 8 * n01
+    B = A[r0:r1].tocsr()
+    x = rng.standard_normal(A.shape[1])
+    dB = dev.DeviceCSR.from_scipy(B)
+    dxs = dev.DeviceVector(data=x[c0:c1])
+    y0 = dB.mult_offset(dxs, c0).get_local()
+    assert dB.spmv_sell(True)[0] > 0      # local row i <-> column offsets shifted by r0: still a stencil
+    y1 = dB.mult_offset(dxs, c0).get_local()
+    ref = B @ x
+    scale = np.abs(B) @ np.abs(x)
+    assert np.max(np.abs(y1 - ref) / scale) < 1e-14 and np.max(np.abs(y1 - y0) / scale) < 1e-14
+
+
+def test_krylov_uses_sliced_copy_and_drops_it(dev):
+    """K = M^T A M of a 3-D p=3 patch after MatZeroRowsColumns: the solvers take the products through the
+    sliced copy (built per solve, gone afterwards); solution and iteration count agree with the solve on
+    the CSR kernel (TIGAR_SPMV_SELL=0 semantics via an explicit decline) to solver tolerance."""
+    if os.environ.get("TIGAR_SPMV_SELL") == "0":
+        pytest.skip("sliced copy disabled by TIGAR_SPMV_SELL=0")
+    s, A, b, M1, K1, zd = _poisson_setup(3, 3, 14)
+    M = _extract(dev, s)
+    MT = M.transpose()
+    Ad = dev.DeviceCSR.from_scipy(A)
+    K = dev.ptap_numeric(dev.ptap_symbolic(Ad, M, MT), Ad, M, MT, zd, 1.0)
+    y = M.mult_transpose(dev.DeviceVector(data=b))
+    y.zero_entries(zd)
+    ncls, padded = K.spmv_sell(True)
+    assert ncls > 0 and K.nnz <= padded <= 1.5 * K.nnz + 4096
+    U1 = dev.DeviceVector(s.getNcp())
+    its1, res1, st1 = dev.krylov_solve(K, y, U1, method="cg", pc="jacobi", rtol=1e-10, atol=1e-30)
+    K.spmv_sell(False)                    # declined from now on: CSR kernel
+    U0 = dev.DeviceVector(s.getNcp())
+    its0, res0, st0 = dev.krylov_solve(K, y, U0, method="cg", pc="jacobi", rtol=1e-10, atol=1e-30)
+    assert st0 == 0 and st1 == 0 and abs(its0 - its1) <= 1
+    u0, u1 = U0.get_local(), U1.get_local()
+    assert np.linalg.norm(u0 - u1) <= 1e-8 * np.linalg.norm(u0)
+    for method in ("cg", "gmres"):
+        Kf = dev.ptap_numeric(dev.ptap_symbolic(Ad, M, MT), Ad, M, MT, zd, 1.0)   # fresh: the solver builds the copy itself
+        U2 = dev.DeviceVector(s.getNcp())
+        its2, res2, st2 = dev.krylov_solve(Kf, y, U2, method=method, pc="jacobi", rtol=1e-10, atol=1e-30)
+        assert st2 == 0 and np.linalg.norm(U2.get_local() - u0) <= 1e-7 * np.linalg.norm(u0)
+        # changing values after a solve is safe: nothing stale is kept
+        Kf.zero_rows_cols(np.arange(0, s.getNcp(), 7, dtype=np.int32), 1.0)
+        xx = dev.DeviceVector(data=np.ones(s.getNcp()))
+        ref = Kf.to_scipy() @ np.ones(s.getNcp())
+        assert np.max(np.abs(Kf.mult(xx).get_local() - ref)) <= 1e-12 * np.max(np.abs(ref))

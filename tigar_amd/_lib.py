@@ -93,6 +93,7 @@ PROTOTYPES = {
     "tg_eval_basis_1d": (C.c_int, [C.POINTER(tg_dir_t), c_f64p, C.c_int64, c_i32p, c_i32p, c_f64p]),
     "tg_spmv": (C.c_int, [handle, handle, handle]),
     "tg_spmv_offset": (C.c_int, [handle, handle, C.c_int64, handle]),
+    "tg_spmv_sell": (C.c_int, [handle, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "tg_spmm_host": (C.c_int, [handle, c_f64p, C.c_int, c_f64p]),
     "tg_spmv_t": (C.c_int, [handle, handle, handle]),
     "tg_ptap_symbolic": (C.c_int, [handle, C.c_int64, handle, C.c_int64, handle, C.c_int64,

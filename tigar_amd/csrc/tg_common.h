@@ -59,6 +59,8 @@ struct tg_vec_s {
   double *d = nullptr;
 };
 
+struct tg_sell_s;   // sliced, pattern-compressed copy for repeated products (tg_sell.hip)
+
 struct tg_csr_s {
   int64_t nrows = 0, ncols = 0, nnz = 0;
   int64_t *rowptr = nullptr;   // device, nrows+1
@@ -80,6 +82,11 @@ struct tg_csr_s {
   int32_t max_row_nnz = 0;
   int spmv_cap = 0;              // LDS products per workgroup of the stream plan
   int spmv_mode = 0;             // 0 = not planned, 1 = stream (LDS), 2 = vector (wave/row)
+  // snapshot of the VALUES in the sliced layout of tg_sell.hip: built by the Krylov solvers for the
+  // duration of a solve, or on request (tg_spmv_sell) -- then the caller re-requests it after
+  // changing values
+  tg_sell_s *sell = nullptr;
+  int sell_state = 0;            // 0 = not tried, 1 = in use, -1 = declined
 };
 
 int tg_dmalloc_bytes(void **p, size_t bytes);   // caching allocator (tg_core.hip)
@@ -110,8 +117,11 @@ struct tg_csr_builder_s {      // incremental vstack into one allocation (tg_ext
 int tg_csr_builder_reserve(tg_csr_builder_s *b, int64_t nrows, int64_t nnz);   // room for one more block (may grow)
 int tg_csr_compact_impl(tg_csr_s *in, tg_csr_s **out);   // loose rows -> canonical CSR (tg_ptap_box.hip)
 int tg_spmv_plan(tg_csr_s *a);
-int tg_spmv_raw(tg_csr_s *a, const double *x_shifted, double *y, double *dot_partial_with,
-                const double *dot_vec);
+// y = A x with x addressed by column index: x_shifted[col]; [cmin, cmax] = columns x_shifted may be read at
+int tg_spmv_raw(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y);
+int tg_sell_plan(tg_csr_s *a);          // tg_sell.hip
+void tg_sell_drop(tg_csr_s *a);
+int tg_sell_spmv(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y);
 
 int tg_csr_sort_rows(tg_csr_s *m);
 int tg_csr_transpose_block(tg_csr_s *m, int64_t row_base, int64_t out_ncols, tg_csr_s **out);

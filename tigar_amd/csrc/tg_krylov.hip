@@ -15,6 +15,28 @@
 #include <math.h>
 #include <algorithm>
 #include <chrono>
+
+// The products of one solve go through the sliced, pattern-compressed copy of tg_sell.hip when the
+// matrix has the structure (built here, dropped when the solve returns: the copy is a snapshot of
+// the values).  A copy requested by the caller (tg_spmv_sell) is used and left alone.
+struct tg_sell_guard {
+  tg_csr_s *k;
+  bool temp = false;
+  int rc = 0;
+  explicit tg_sell_guard(tg_csr_s *m) : k(m) {
+    if (k->sell_state == 0) {
+      rc = tg_sell_plan(k);
+      temp = true;
+    }
+  }
+  ~tg_sell_guard() {
+    if (temp) {
+      tg_sell_drop(k);
+      k->sell_state = 0;
+    }
+  }
+};
+
 static double tk_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 #define TG_VEC_BLOCKS 1024
@@ -162,6 +184,8 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
   double *s_pair = scal + 4;  // (rz_new, zz) written together
   const int vg = tg_vec_grid(n);
   TG_TRY(tg_spmv_plan(k));
+  tg_sell_guard sell_guard(k);   // sliced copy of the values for the products of this solve
+  TG_TRY(sell_guard.rc);
 
   if (n > 0) {
     const unsigned jg = (unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16);
@@ -201,7 +225,7 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
     // Kp = K p   (x addressed by global column index); then p . Kp on a fixed grid so the
     // reduction order (and the result) does not depend on the matrix size
     hipEventRecord(g_tg.pev0, g_tg.stream);
-    TG_TRY(tg_spmv_raw(k, pext - (row0 - hlo), kp, nullptr, nullptr));
+    TG_TRY(tg_spmv_raw(k, pext - (row0 - hlo), row0 - hlo, row0 - hlo + next - 1, kp));
     hipEventRecord(g_tg.pev1, g_tg.stream);
     hipLaunchKernelGGL(k_dot2_partial, dim3(vg), dim3(256), 0, g_tg.stream, p, kp, n, partial);
     hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, g_tg.stream, partial, vg, 1, s_pkp);
@@ -337,6 +361,8 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
   double *scal = g_tg.scratch + TG_SCRATCH_DOUBLES - 2048;
   const int vg = std::min(tg_vec_grid(n), 256);
   TG_TRY(tg_spmv_plan(k));
+  tg_sell_guard sell_guard(k);   // sliced copy of the values for the products of this solve
+  TG_TRY(sell_guard.rc);
   if (n > 0) {
     const unsigned jg = (unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16);
     hipLaunchKernelGGL(k_jacobi_setup, dim3(jg), dim3(256), 0, g_tg.stream, k->rowptr, k->col, k->val, n, row0,
@@ -357,7 +383,7 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
     } else {
       TG_CHECK_HIP(hipMemcpyAsync(xin, x->d, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream));
       TG_TRY(tg_comm_halo_exchange(comm, ext));
-      TG_TRY(tg_spmv_raw(k, ext - (row0 - hlo), w, nullptr, nullptr));
+      TG_TRY(tg_spmv_raw(k, ext - (row0 - hlo), row0 - hlo, row0 - hlo + next - 1, w));
       hipLaunchKernelGGL(k_prec_residual, dim3(vg), dim3(256), 0, g_tg.stream, b->d, (const double *)w, dinv, V, n,
                          partial);
     }
@@ -395,7 +421,7 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
       TG_CHECK_HIP(hipMemcpyAsync(xin, V + (int64_t)j * n, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice,
                                   g_tg.stream));
       TG_TRY(tg_comm_halo_exchange(comm, ext));
-      TG_TRY(tg_spmv_raw(k, ext - (row0 - hlo), w, nullptr, nullptr));
+      TG_TRY(tg_spmv_raw(k, ext - (row0 - hlo), row0 - hlo, row0 - hlo + next - 1, w));
       hipLaunchKernelGGL(k_mul_inplace, dim3(vg), dim3(256), 0, g_tg.stream, w, dinv, n);
       // classical Gram-Schmidt (PETSc default, no refinement [ext])
       hipLaunchKernelGGL(k_multi_dot, dim3(vg), dim3(256), 0, g_tg.stream, V, n, j + 1, w, n, partial);

@@ -1,0 +1,485 @@
+// Sliced, pattern-compressed copy of a CSR matrix for repeated products (the K p of the Krylov
+// solve, tIGAr/common.py:1255-1258; PETSc KSP on an AIJ matrix in the reference).
+//
+// K = M^T A M of a tensor-product patch is a stencil matrix stored as general CSR.  The plain CSR
+// product (tg_sparse.hip) sits on the practical HBM ceiling of the box at 12 B per entry, and the
+// gather x[col] is its second limit, so the only way to a faster product is fewer bytes
+// AND a cheaper gather at once.  This plan provides both, from the CSR arrays alone (nothing about
+// the origin of the matrix is assumed, matrices without the structure are declined):
+//
+//   * rows are cut into slices of 64 consecutive rows = one wave, lane i owns row 64 s + i;
+//   * the column OFFSETS col - row that occur in a slice are collected into one sorted union pattern
+//     U_s; slices with the same set of row patterns share one dictionary entry (a 3-D p=3 patch with
+//     17 M rows has a few hundred of them, a few hundred KB in total);
+//   * the values are stored slice by slice as a dense [|U_s|][64] block (zero where a row has no entry
+//     at that offset: 2 % padding at 256^3 p=3);
+//   * the product is  y[r] = sum_k V_s[k][lane] * x[r + U_s[k]]:  the value load is one coalesced
+//     512-byte line per k, the x load is 64 CONSECUTIVE doubles (r + const), U_s[k] comes through the
+//     scalar unit, there are no column indices, no row pointers, no LDS and no reduction across lanes.
+//     Each row is summed sequentially in ascending column order -- the order of PETSc's AIJ MatMult.
+//
+// Exactness: every entry of the matrix is located in its slice's union by binary search during the
+// conversion; an entry that is not found (a hash collision when grouping rows / slices) makes the
+// plan fail and the matrix keeps the CSR kernel.  A padded position multiplies a stored 0.0 with a
+// (clamped, valid) x: it adds +0.0 to the row sum.
+#include "tg_common.h"
+#include <algorithm>
+#include <vector>
+
+#define TG_SELL_C 64           // rows per slice
+#define TG_SELL_TABLE 16384    // hash slots for slice classes
+#define TG_SELL_MAXCLASS 4096  // distinct slice classes accepted
+#define TG_SELL_WMAX 2048      // widest union pattern accepted
+#define TG_SELL_CAT 8192       // offsets of the distinct rows of a slice that are merged in LDS (power of two)
+
+struct tg_sell_s {
+  int64_t nslices = 0;
+  int64_t padded = 0;            // doubles in val
+  double *val = nullptr;         // [slice][k][lane]
+  int64_t *slice_ptr = nullptr;  // nslices + 1 offsets into val
+  int32_t *slice_cls = nullptr;  // class id per slice
+  int32_t *cls_w = nullptr;      // width per class
+  int32_t *cls_off = nullptr;    // [class][TG_SELL_WMAX] sorted offsets
+  int nclasses = 0;
+};
+
+void tg_sell_free(tg_sell_s *s) {
+  if (!s) return;
+  tg_dfree(s->val);
+  tg_dfree(s->slice_ptr);
+  tg_dfree(s->slice_cls);
+  tg_dfree(s->cls_w);
+  tg_dfree(s->cls_off);
+  delete s;
+}
+
+__device__ __forceinline__ unsigned long long tg_sell_mix(unsigned long long z) {
+  z *= 0x9E3779B97F4A7C15ull;
+  z ^= z >> 32;
+  z *= 0xD6E8FEB86659FD93ull;
+  z ^= z >> 32;
+  return z;
+}
+
+// ---- 1. one wave per row: hash of (length, offsets in order)
+__global__ void __launch_bounds__(256)
+    k_sell_rowhash(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nrows,
+                   unsigned long long *__restrict__ rowhash) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    const int64_t a = rowptr[r], b = rowptr[r + 1];
+    unsigned long long h = 0;
+    for (int64_t q = a + lane; q < b; q += 64)
+      h += tg_sell_mix(((unsigned long long)(q - a) << 32) | (unsigned)(col[q] - (int32_t)r));
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+    h = tg_sell_mix(h + (unsigned long long)(b - a)) | 1ull;
+    if (lane == 0) rowhash[r] = h;
+  }
+}
+
+// ---- 2. one wave per slice: class key = hash of the SET of row hashes of the slice
+// ctl[0] = number of classes, ctl[1] = overflow
+__global__ void __launch_bounds__(256)
+    k_sell_slice_class(const unsigned long long *__restrict__ rowhash, int64_t nrows, int64_t nslices,
+                       unsigned long long *__restrict__ keys, int *__restrict__ rep, int32_t *__restrict__ slot_of_slice,
+                       int *__restrict__ ctl) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t s = wave; s < nslices; s += nwaves) {
+    const int64_t r = s * TG_SELL_C + lane;
+    const unsigned long long h = r < nrows ? rowhash[r] : 0ull;
+    // set semantics: a hash counts once (lane is the first one holding it)
+    bool first = h != 0ull;
+    for (int j = 1; j < 64; j++) {
+      const unsigned long long o = __shfl(h, (lane + 64 - j) & 63, 64);
+      if (lane >= j && o == h) first = false;
+    }
+    unsigned long long k = first ? tg_sell_mix(h) : 0ull;   // commutative combination of the set
+    for (int o = 32; o > 0; o >>= 1) k += __shfl_xor(k, o, 64);
+    k = tg_sell_mix(k) | 1ull;
+    if (lane == 0) {
+      unsigned slot = (unsigned)(k >> 17) & (TG_SELL_TABLE - 1);
+      int probes = 0;
+      for (;;) {
+        unsigned long long cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0ull) {
+          cur = atomicCAS(&keys[slot], 0ull, k);
+          if (cur == 0ull) {
+            if (atomicAdd(&ctl[0], 1) >= TG_SELL_MAXCLASS) atomicExch(&ctl[1], 1);
+            cur = k;
+          }
+        }
+        if (cur == k) break;
+        slot = (slot + 1) & (TG_SELL_TABLE - 1);
+        if (++probes >= TG_SELL_TABLE) {
+          atomicExch(&ctl[1], 1);
+          break;
+        }
+      }
+      if ((int)s < __hip_atomic_load(&rep[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&rep[slot], (int)s);
+      slot_of_slice[s] = (int32_t)slot;
+    }
+  }
+}
+
+// ---- 3. dense class ids
+__global__ void k_sell_class_ids(const unsigned long long *__restrict__ keys, const int *__restrict__ rep,
+                                 int *__restrict__ id_of_slot, int *__restrict__ rep_of_id, int *__restrict__ counter) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= TG_SELL_TABLE) return;
+  if (keys[s] == 0ull) {
+    id_of_slot[s] = -1;
+    return;
+  }
+  const int id = atomicAdd(counter, 1);
+  id_of_slot[s] = id;
+  rep_of_id[id] = rep[s];
+}
+
+// ---- 4. one workgroup per class: union of the offsets of the representative slice's distinct rows
+// (concatenate in LDS, bitonic sort, unique) -> cls_off[id][0..w), cls_w[id];  ctl[1] on overflow
+__global__ void __launch_bounds__(256)
+    k_sell_class_union(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nrows,
+                       const unsigned long long *__restrict__ rowhash, const int *__restrict__ rep_of_id,
+                       int32_t *__restrict__ cls_off, int32_t *__restrict__ cls_w, int *__restrict__ ctl) {
+  __shared__ int buf[TG_SELL_CAT];
+  __shared__ unsigned long long hs[64];
+  __shared__ int start[65];
+  __shared__ int cnt[257];
+  const int tid = threadIdx.x;
+  const int id = blockIdx.x;
+  const int64_t r0 = (int64_t)rep_of_id[id] * TG_SELL_C;
+  if (tid < 64) hs[tid] = (r0 + tid < nrows) ? rowhash[r0 + tid] : 0ull;
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+    for (int i = 0; i < 64; i++) {
+      bool first = hs[i] != 0ull;
+      for (int j = 0; j < i && first; j++) first = hs[j] != hs[i];
+      start[i] = tot;
+      if (first) tot += (int)min((int64_t)TG_SELL_CAT + 1, rowptr[r0 + i + 1] - rowptr[r0 + i]);
+      else start[i] = -1 - tot;   // negative: not copied
+      if (tot > TG_SELL_CAT) tot = TG_SELL_CAT + 1;
+    }
+    start[64] = tot;
+  }
+  __syncthreads();
+  const int tot = start[64];
+  if (tot > TG_SELL_CAT) {
+    if (tid == 0) {
+      atomicExch(&ctl[1], 1);
+      cls_w[id] = 0;
+    }
+    return;
+  }
+  int n2 = 1;
+  while (n2 < tot) n2 <<= 1;
+  for (int i = tid; i < n2; i += 256) buf[i] = 0x7fffffff;
+  __syncthreads();
+  for (int i = 0; i < 64; i++) {
+    const int st = start[i];
+    if (st < 0) continue;
+    const int64_t a = rowptr[r0 + i], b = rowptr[r0 + i + 1];
+    for (int64_t q = a + tid; q < b; q += 256) buf[st + (int)(q - a)] = col[q] - (int32_t)(r0 + i);
+  }
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n2; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const int x = buf[i], y = buf[l];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) {
+            buf[i] = y;
+            buf[l] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  // unique: thread t owns [t*chunk, (t+1)*chunk)
+  const int chunk = (n2 + 255) / 256;
+  const int lo = tid * chunk, hi = min(n2, lo + chunk);
+  int c = 0;
+  for (int i = lo; i < hi; i++)
+    if (i < tot && (i == 0 || buf[i] != buf[i - 1])) c++;
+  cnt[tid + 1] = c;
+  if (tid == 0) cnt[0] = 0;
+  __syncthreads();
+  if (tid == 0)
+    for (int i = 1; i <= 256; i++) cnt[i] += cnt[i - 1];
+  __syncthreads();
+  const int w = cnt[256];
+  if (w > TG_SELL_WMAX) {
+    if (tid == 0) {
+      atomicExch(&ctl[1], 1);
+      cls_w[id] = 0;
+    }
+    return;
+  }
+  int o = cnt[tid];
+  for (int i = lo; i < hi; i++)
+    if (i < tot && (i == 0 || buf[i] != buf[i - 1])) cls_off[(int64_t)id * TG_SELL_WMAX + o++] = buf[i];
+  if (tid == 0) cls_w[id] = w;
+}
+
+// ---- 5. class id and padded size of every slice
+__global__ void k_sell_slice_sizes(const int32_t *__restrict__ slot_of_slice, const int *__restrict__ id_of_slot,
+                                   const int32_t *__restrict__ cls_w, int64_t nslices, int32_t *__restrict__ slice_cls,
+                                   int64_t *__restrict__ slice_ptr) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslices) return;
+  const int id = id_of_slot[slot_of_slice[s]];
+  slice_cls[s] = id;
+  slice_ptr[s] = (int64_t)cls_w[id] * TG_SELL_C;
+}
+
+// ---- 6. conversion: one workgroup per slice.  The slice's entries are contiguous in the CSR arrays
+// (coalesced reads); every entry is located in the slice's union -- position k of its row if the row
+// has the full union (the common case), else by bisection of U[k..w) -- and parked in an LDS tile
+// [w][R rows]; the tile then goes out as runs of R consecutive doubles (R = 8 for w = 343: 64-byte
+// runs instead of scattered 8-byte writes), zeros included, so the output needs no memset.
+#define TG_SELL_TILE 3072   // doubles (24 KB)
+__global__ void __launch_bounds__(256)
+    k_sell_convert(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+                   int64_t nrows, int64_t nslices, const int64_t *__restrict__ slice_ptr,
+                   const int32_t *__restrict__ slice_cls, const int32_t *__restrict__ cls_w,
+                   const int32_t *__restrict__ cls_off, double *__restrict__ out, int *__restrict__ fail) {
+  __shared__ double tile[TG_SELL_TILE];
+  __shared__ int U[TG_SELL_WMAX];
+  __shared__ int rs[TG_SELL_C + 1];
+  const int tid = threadIdx.x;
+  const int64_t s = blockIdx.x;
+  const int id = slice_cls[s];
+  const int w = cls_w[id];
+  if (w == 0) return;
+  for (int k = tid; k < w; k += 256) U[k] = cls_off[(int64_t)id * TG_SELL_WMAX + k];
+  const int64_t r0 = s * TG_SELL_C;
+  const int nr = (int)min((int64_t)TG_SELL_C, nrows - r0);
+  const int64_t e0 = rowptr[r0];
+  if (tid <= TG_SELL_C) rs[tid] = (int)(rowptr[r0 + min(tid, nr)] - e0);
+  int R = TG_SELL_C;                      // rows per tile: power of two, w * R <= TG_SELL_TILE
+  while (R > 1 && w * R > TG_SELL_TILE) R >>= 1;
+  const int lR = 31 - __builtin_clz(R);
+  double *o = out + slice_ptr[s];
+  bool bad = false;
+  for (int g0 = 0; g0 < TG_SELL_C; g0 += R) {
+    __syncthreads();                      // (U, rs staged; previous tile written out)
+    for (int i = tid; i < w * R; i += 256) tile[i] = 0.0;
+    __syncthreads();
+    const int t0 = rs[min(g0, nr)], t1 = rs[min(g0 + R, nr)];
+    int row = g0;
+    // (4 entries per thread and pass: all loads of a pass are issued before the first look-up)
+    for (int tb = t0 + tid; tb < t1; tb += 1024) {
+      int cc[4];
+      double vv[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int t = min(tb + 256 * j, t1 - 1);
+        cc[j] = col[e0 + t];
+        vv[j] = val[e0 + t];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int t = tb + 256 * j;
+        if (t >= t1) break;
+        while (t >= rs[row + 1]) row++;
+        const int k = t - rs[row];
+        const int off = cc[j] - (int32_t)(r0 + row);
+        int p = k;
+        if (!(p < w && U[p] == off)) {
+          int lo = k, hi = w;   // first position with U >= off (the k-th offset of a row is at position >= k)
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (U[mid] < off) lo = mid + 1;
+            else hi = mid;
+          }
+          p = lo;
+          if (!(p < w && U[p] == off)) {
+            bad = true;
+            continue;
+          }
+        }
+        tile[(p << lR) + (row - g0)] = vv[j];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < w * R; i += 256) o[(int64_t)(i >> lR) * TG_SELL_C + g0 + (i & (R - 1))] = tile[i];
+  }
+  if (bad) atomicExch(fail, 1);
+}
+
+// ---- the product
+// One wave per slice.  U_s[k] is wave-uniform (read through the scalar unit), the x load of a wave is
+// 64 consecutive doubles, clamped into the valid column range [cmin, cmax] of x (only padded
+// positions -- stored 0.0 -- can fall outside).
+#define TG_SELL_UNROLL 8
+__global__ void __launch_bounds__(256)
+    k_spmv_sell(const double *__restrict__ V, const int64_t *__restrict__ slice_ptr, const int32_t *__restrict__ slice_cls,
+                const int32_t *__restrict__ cls_w, const int32_t *__restrict__ cls_off, const double *__restrict__ x,
+                double *__restrict__ y, int64_t nrows, int64_t nslices, int cmin, int cmax) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwb = (nslices + 3) >> 2;                      // workgroups of 4 slices
+  const int64_t Lb = tg_xcd_block(blockIdx.x, nwb);
+  const int64_t s = __builtin_amdgcn_readfirstlane((int)(Lb * 4 + (threadIdx.x >> 6)));
+  if (Lb >= nwb || s >= nslices) return;
+  const int id = slice_cls[s];
+  const int w = cls_w[id];
+  const int32_t *__restrict__ U = cls_off + (int64_t)id * TG_SELL_WMAX;
+  const double *__restrict__ v = V + slice_ptr[s] + lane;
+  const int r = (int)(s * TG_SELL_C) + lane;
+  double sum = 0.0;
+  int k = 0;
+  for (; k + TG_SELL_UNROLL <= w; k += TG_SELL_UNROLL) {
+    double vv[TG_SELL_UNROLL], xx[TG_SELL_UNROLL];
+#pragma unroll
+    for (int j = 0; j < TG_SELL_UNROLL; j++) {
+      vv[j] = __builtin_nontemporal_load(v + (int64_t)(k + j) * TG_SELL_C);
+      xx[j] = x[min(max(r + U[k + j], cmin), cmax)];
+    }
+#pragma unroll
+    for (int j = 0; j < TG_SELL_UNROLL; j++) sum += vv[j] * xx[j];
+  }
+  for (; k < w; k++) sum += v[(int64_t)k * TG_SELL_C] * x[min(max(r + U[k], cmin), cmax)];
+  if (r < nrows) y[r] = sum;
+}
+
+int tg_sell_spmv(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y) {
+  tg_sell_s *S = a->sell;
+  const int64_t nwb = (S->nslices + 3) / 4;
+  const unsigned grid = (unsigned)(((nwb + 7) / 8) * 8);
+  hipLaunchKernelGGL(k_spmv_sell, dim3(grid), dim3(256), 0, g_tg.stream, S->val, S->slice_ptr, S->slice_cls, S->cls_w,
+                     S->cls_off, x_shifted, y, a->nrows, S->nslices, (int)cmin, (int)cmax);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// Builds the plan if the matrix has the structure; a->sell_state: 1 = in use, -1 = declined.
+int tg_sell_plan(tg_csr_s *a) {
+  if (a->sell_state) return 0;
+  TG_REQUIRE_CANONICAL(a);
+  a->sell_state = -1;
+  static int enabled = getenv("TIGAR_SPMV_SELL") ? atoi(getenv("TIGAR_SPMV_SELL")) : 1;
+  if (!enabled || a->nrows < 1 || a->nnz < 1 || a->nrows >= 0x7fffffffll - 64 || a->ncols >= 0x7fffffffll) return 0;
+  const int64_t nrows = a->nrows, nslices = tg_cdiv(nrows, TG_SELL_C);
+  int *ctl = (int *)g_tg.scratch;   // [0] classes, [1] overflow, [2] conversion failure, [3] id counter
+  unsigned long long *rowhash = nullptr, *keys = nullptr;
+  int *rep = nullptr, *ids = nullptr;   // id_of_slot[TABLE] | rep_of_id[MAXCLASS]
+  int32_t *slot_of_slice = nullptr;
+  tg_sell_s *S = new tg_sell_s;
+  int rc = 0;
+  bool declined = false;
+  auto step = [&](int r) {
+    if (!rc && r) rc = r;
+    return rc == 0;
+  };
+  auto hip_ok = [&](hipError_t e) {
+    if (!rc && e != hipSuccess) {
+      tg_set_error("tg_sell_plan: %s", hipGetErrorString(e));
+      rc = 1;
+    }
+    return rc == 0;
+  };
+  do {
+    const int ctl0[4] = {0, 0, 0, 0};
+    if (!hip_ok(hipMemcpyAsync(ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice, g_tg.stream))) break;
+    if (!step(tg_dmalloc(&rowhash, nrows)) || !step(tg_dmalloc(&keys, TG_SELL_TABLE)) ||
+        !step(tg_dmalloc(&rep, TG_SELL_TABLE)) || !step(tg_dmalloc(&ids, TG_SELL_TABLE + TG_SELL_MAXCLASS + 1)) ||
+        !step(tg_dmalloc(&slot_of_slice, nslices)))
+      break;
+    hipMemsetAsync(keys, 0, sizeof(unsigned long long) * TG_SELL_TABLE, g_tg.stream);
+    hipMemsetAsync(rep, 0x7f, sizeof(int) * TG_SELL_TABLE, g_tg.stream);
+    const unsigned wg = (unsigned)std::min<int64_t>(tg_cdiv(nrows, 4), (int64_t)g_tg.num_cu * 16);
+    hipLaunchKernelGGL(k_sell_rowhash, dim3(wg), dim3(256), 0, g_tg.stream, a->rowptr, a->col, nrows, rowhash);
+    const unsigned sg = (unsigned)std::min<int64_t>(tg_cdiv(nslices, 4), (int64_t)g_tg.num_cu * 16);
+    hipLaunchKernelGGL(k_sell_slice_class, dim3(sg), dim3(256), 0, g_tg.stream, rowhash, nrows, nslices, keys, rep,
+                       slot_of_slice, ctl);
+    int h[4];
+    if (!hip_ok(hipMemcpyAsync(h, ctl, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream)) ||
+        !hip_ok(hipStreamSynchronize(g_tg.stream)))
+      break;
+    const int ncls = h[0];
+    if (h[1] || ncls < 1 || ncls > TG_SELL_MAXCLASS) {
+      declined = true;
+      break;
+    }
+    int *id_of_slot = ids, *rep_of_id = ids + TG_SELL_TABLE;
+    if (!step(tg_dmalloc(&S->cls_w, ncls)) || !step(tg_dmalloc(&S->cls_off, (int64_t)ncls * TG_SELL_WMAX)) ||
+        !step(tg_dmalloc(&S->slice_cls, nslices)) || !step(tg_dmalloc(&S->slice_ptr, nslices + 1)))
+      break;
+    hipLaunchKernelGGL(k_sell_class_ids, dim3(TG_SELL_TABLE / 256), dim3(256), 0, g_tg.stream, keys, rep, id_of_slot,
+                       rep_of_id, ctl + 3);
+    hipLaunchKernelGGL(k_sell_class_union, dim3(ncls), dim3(256), 0, g_tg.stream, a->rowptr, a->col, nrows, rowhash,
+                       rep_of_id, S->cls_off, S->cls_w, ctl);
+    hipLaunchKernelGGL(k_sell_slice_sizes, dim3((unsigned)tg_cdiv(nslices, 256)), dim3(256), 0, g_tg.stream,
+                       slot_of_slice, id_of_slot, S->cls_w, nslices, S->slice_cls, S->slice_ptr);
+    if (!hip_ok(hipGetLastError())) break;
+    int64_t padded = 0;
+    if (!step(tg_exclusive_scan_i64(S->slice_ptr, nslices, &padded))) break;
+    if (!hip_ok(hipMemcpyAsync(h, ctl, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream)) ||
+        !hip_ok(hipStreamSynchronize(g_tg.stream)))
+      break;
+    // worth it only with moderate padding (8 B per stored position against 12 B per entry + gather)
+    if (h[1] || padded > a->nnz + a->nnz / 2 + 4096) {
+      declined = true;
+      break;
+    }
+    if (!step(tg_dmalloc(&S->val, padded))) {
+      // no room for the copy: not an error, the CSR kernel stays
+      rc = 0;
+      declined = true;
+      break;
+    }
+    hipLaunchKernelGGL(k_sell_convert, dim3((unsigned)nslices), dim3(256), 0, g_tg.stream, a->rowptr, a->col,
+                       a->val, nrows, nslices, S->slice_ptr, S->slice_cls, S->cls_w, S->cls_off, S->val, ctl + 2);
+    if (!hip_ok(hipGetLastError())) break;
+    if (!hip_ok(hipMemcpyAsync(h, ctl, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream)) ||
+        !hip_ok(hipStreamSynchronize(g_tg.stream)))
+      break;
+    if (h[2]) {
+      declined = true;   // an entry was not found in its slice's union: hash collision
+      break;
+    }
+    S->nslices = nslices;
+    S->padded = padded;
+    S->nclasses = ncls;
+  } while (0);
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  tg_dfree(rowhash);
+  tg_dfree(keys);
+  tg_dfree(rep);
+  tg_dfree(ids);
+  tg_dfree(slot_of_slice);
+  if (rc || declined) {
+    tg_sell_free(S);
+    return rc;
+  }
+  a->sell = S;
+  a->sell_state = 1;
+  return 0;
+}
+
+void tg_sell_drop(tg_csr_s *a) {
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  tg_sell_free(a->sell);
+  a->sell = nullptr;
+}
+
+extern "C" int tg_spmv_sell(tg_csr_t a, int enable, int *nclasses, int64_t *padded) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(a, "null argument to tg_spmv_sell");
+  if (enable) {
+    if (a->sell_state < 0) a->sell_state = 0;   // explicit request: try (again)
+    TG_TRY(tg_sell_plan(a));
+  } else {
+    tg_sell_drop(a);
+    a->sell_state = -1;
+  }
+  if (nclasses) *nclasses = a->sell_state == 1 ? a->sell->nclasses : 0;
+  if (padded) *padded = a->sell_state == 1 ? a->sell->padded : 0;
+  return 0;
+}

@@ -268,11 +268,12 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// y = A x with x addressed by the matrix's (global) column indices: x_shifted[col].
-// If dot_partial != nullptr also writes per-block partial sums of y . dvec (dvec indexed by
-// local row); the number of partials written is returned through the plan: nblocks (stream)
-// or the vector-mode grid size.  Returns the partial count via a->nblocks / grid.
-int tg_spmv_raw(tg_csr_s *a, const double *x_shifted, double *y, double *dot_partial, const double *dvec) {
+// y = A x with x addressed by the matrix's (global) column indices: x_shifted[col], valid for
+// cmin <= col <= cmax.
+int tg_spmv_raw(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y) {
+  double *dot_partial = nullptr;
+  const double *dvec = nullptr;
+  if (a->sell_state == 1 && a->sell) return a->nrows ? tg_sell_spmv(a, x_shifted, cmin, cmax, y) : 0;
   TG_TRY(tg_spmv_plan(a));
   if (a->nrows == 0) return 0;
   if (a->spmv_mode == 1) {
@@ -334,7 +335,7 @@ extern "C" int tg_spmv(tg_csr_t a, tg_vec_t x, tg_vec_t y) {
              (long long)a->ncols);
   TG_REQUIRE(y->n == a->nrows, "tg_spmv: y has %lld entries, matrix has %lld rows", (long long)y->n,
              (long long)a->nrows);
-  return tg_spmv_raw(a, x->d, y->d, nullptr, nullptr);
+  return tg_spmv_raw(a, x->d, 0, a->ncols - 1, y->d);
 }
 
 extern "C" int tg_spmv_offset(tg_csr_t a, tg_vec_t x, int64_t x_col0, tg_vec_t y) {
@@ -343,7 +344,7 @@ extern "C" int tg_spmv_offset(tg_csr_t a, tg_vec_t x, int64_t x_col0, tg_vec_t y
   TG_REQUIRE(x_col0 >= 0 && x_col0 + x->n <= a->ncols, "tg_spmv_offset: x range outside the matrix columns");
   TG_REQUIRE(y->n == a->nrows, "tg_spmv_offset: y has %lld entries, matrix has %lld rows", (long long)y->n,
              (long long)a->nrows);
-  return tg_spmv_raw(a, x->d - x_col0, y->d, nullptr, nullptr);
+  return tg_spmv_raw(a, x->d - x_col0, x_col0, x_col0 + x->n - 1, y->d);
 }
 
 extern "C" int tg_spmv_t(tg_csr_t mt, tg_vec_t b, tg_vec_t y) { return tg_spmv(mt, b, y); }

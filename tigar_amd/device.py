@@ -191,6 +191,14 @@ class DeviceCSR(object):
         check(_lib.lib().tg_spmv(self._h, x._h, y._h), "tg_spmv")
         return y
 
+    def spmv_sell(self, enable=True):
+        """Keep (or drop) the sliced, pattern-compressed copy of the values for repeated products
+        (tg_spmv_sell; a snapshot -- request it again after changing values).  Returns (number of slice
+        classes, doubles stored); (0, 0) if the matrix has no such structure or enable is False."""
+        n, padded = C.c_int(0), C.c_int64(0)
+        check(_lib.lib().tg_spmv_sell(self._h, 1 if enable else 0, C.byref(n), C.byref(padded)), "tg_spmv_sell")
+        return n.value, padded.value
+
     def mult_offset(self, x, x_col0, y=None):
         """y = A x where x holds only the columns [x_col0, x_col0+len(x)) (slab pieces)"""
         if y is None:
