@@ -17,6 +17,8 @@ path = SlabHotPath(basis, grid, sub_planes=int(sys.argv[3]) if len(sys.argv) > 3
 K, rhs = path.assemble(lambda a, b: lap.assemble_matrix(V, a, b), lambda a, b: dev.DeviceVector(b - a), [])
 n = K.shape[0]
 x = dev.DeviceVector(data=np.random.default_rng(0).standard_normal(n)); y = dev.DeviceVector(n)
+if os.environ.get('SELL', '1') != '0':
+    print('sliced copy:', K.spmv_sell(True))
 K.mult(x, y); dev.sync()
 reps = 20
 dev.timer_start(0)
