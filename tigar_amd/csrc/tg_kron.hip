@@ -191,6 +191,50 @@ __global__ void __launch_bounds__(256)
     }
     a = lo;
   }
+  if (staged && P.nterms <= 4) {
+    // four entries per thread and pass: the look-ups of an entry (row offsets, 1-D tables: L1/LDS
+    // latencies in series) are independent of the other three, so they overlap
+    const int tend = roff[a_hi];
+    const int nt = P.nterms;
+    for (int tb = roff[a_lo] + tid; tb < tend; tb += 1024) {
+      int aa[4], x0v[4], iv[4], jkv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int t = min(tb + 256 * u, tend - 1);
+        while (a + 1 < a_hi && roff[a + 1] <= t) a++;
+        aa[u] = a;
+        x0v[u] = P.rowptr[0][a];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int t = min(tb + 256 * u, tend - 1);
+        const int lx = P.rowptr[0][aa[u] + 1] - x0v[u];
+        const int e = t - roff[aa[u]];
+        jkv[u] = (int)(((float)e + 0.5f) / (float)lx);
+        iv[u] = e - jkv[u] * lx;
+      }
+      double xv[4][4];
+      int32_t cx[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        cx[u] = P.col[0][x0v[u] + iv[u]];
+#pragma unroll
+        for (int q = 0; q < 4; q++) xv[u][q] = q < nt ? P.val[0][q * P.nnz1d[0] + x0v[u] + iv[u]] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int t = tb + 256 * u;
+        if (t >= tend) break;
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (q < nt) sum += xv[u][q] * wjk[q][jkv[u]];
+        col[base + t] = (int32_t)(cx[u] + cjk[jkv[u]]);
+        val[base + t] = sum;
+      }
+    }
+    return;
+  }
   for (int t = roff[a_lo] + tid; t < roff[a_hi]; t += 256) {
     while (a + 1 < a_hi && roff[a + 1] <= t) a++;
     const int x0 = P.rowptr[0][a];
