@@ -953,8 +953,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAMAX <
     const unsigned long long *xbits = reinterpret_cast<const unsigned long long *>(X);
     if (chunk_pos + nK > chunk_end) {             // uniform
       unsigned long long o = 0;
-      // the rows of a run have similar lengths: reserve for what is left of the run, capped
-      const int64_t grab = max((int64_t)nK, min(Q.grab, (int64_t)nK * (nsteps - t) * 5 / 4 + 32));
+      // the rows of a run have similar lengths: reserve for the next few rows of the run (what is
+      // left of a chunk at the end of the run is lost, so the look-ahead is short: reserving for the
+      // whole run from its first row wasted 70 % of the temporary when the run length was a multiple
+      // of the period of the row lengths and every run started on a long row)
+      const int64_t grab = max((int64_t)nK, min(Q.grab, (int64_t)nK * min(nsteps - t, 8) * 9 / 8 + 32));
       if (lane == 0) o = atomicAdd(cursor, (unsigned long long)grab);
       chunk_pos = tg_readlane_i64((int64_t)o, 0);
       chunk_end = chunk_pos + grab;
@@ -1459,7 +1462,9 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
             nx = rb / m0 - x0 + 1;
           }
           const int64_t span = uhi - ulo + 1;
-          int64_t T = std::min<int64_t>(getenv("TIGAR_LINE_RUN") ? std::max(1, atoi(getenv("TIGAR_LINE_RUN"))) : 32, span);
+          // rows per wave: 20 measured best at 96^3 and 256^3 p=3 (x/y/z stage at 96^3: 32 rows 30.9 / 15.8 / 8.5 ms,
+          // 24: 30.2 / 15.1 / 8.1, 20: 29.0 / 13.2 / 7.3, 16: 29.6 / 14.2 / 7.3, 12: 29.4 / 13.7 / 7.0)
+          int64_t T = std::min<int64_t>(getenv("TIGAR_LINE_RUN") ? std::max(1, atoi(getenv("TIGAR_LINE_RUN"))) : 20, span);
           while (T > 1 && nx * tg_cdiv(span, T) < (int64_t)g_tg.num_cu * 64) T = (T + 1) / 2;
           Q.mlen = (int)T;
           Q.ulo = (int)ulo;
@@ -1524,6 +1529,9 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
       tcol = nullptr;
       tval = nullptr;
       if (h == TG_BOX_CAP) {
+        if (getenv("TIGAR_TRACE"))
+          fprintf(stderr, "[tigar] ptap temporary too small: capacity %lld, used %llu, rows %lld, mean row %.1f, run %d -> retry\n",
+                  (long long)capacity, used, (long long)nrows, mean_k, Q.mlen);
         capacity = std::max<int64_t>((int64_t)used + 1024, capacity * 2);
         continue;
       }
