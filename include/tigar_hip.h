@@ -29,6 +29,15 @@ int tg_init(int device);                   /* binds the HIP device, creates the 
 int tg_shutdown(void);
 const char *tg_last_error(void);
 int tg_sync(void);                         /* hipStreamSynchronize on the library stream */
+/* Second stream.  Every call of the library works on the CURRENT stream (0 after tg_init).
+ * tg_stream_set(1) makes a second stream current: what a caller enqueues there (e.g. the FE input of the
+ * next sub-slab -- in the reference the FE assembly is dolfin's job, tIGAr/common.py:1206-1220) runs
+ * beside the work on stream 0.  tg_stream_wait(a, b): stream a waits for everything enqueued so far on
+ * stream b (device side, no host synchronisation); the caller orders the hand-over of objects
+ * between the streams with it.  Freed device blocks are re-used across the streams safely (events).
+ * tg_sync synchronises the current stream only. */
+int tg_stream_set(int stream);
+int tg_stream_wait(int waiter, int waited);
 int tg_device_info(char *name, int name_len, int *num_cu, int64_t *hbm_bytes);
 int tg_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 int tg_pool_trim(void);

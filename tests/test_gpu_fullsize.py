@@ -134,6 +134,46 @@ def test_slab_streamed_assembly_equals_resident_at_scale():
     u_t = path.prolong(U).get_local()
     u_e = gen.M.mult(U).get_local()
     assert path.kron_exact and np.max(np.abs(u_t - u_e)) <= 1e-13 * np.max(np.abs(u_e))
+    # the same assembly with the FE inputs of the next sub-slab produced on the second stream
+    # (tg_stream_set / tg_stream_wait; blocks re-used across the streams are ordered by events)
+    import os
+    os.environ["TIGAR_OVERLAP"] = "1"
+    try:
+        for rep in range(3):
+            K_ov, rhs_ov = path.assemble(lambda a, b: lap.assemble_matrix(gen.V, a, b),
+                                         lambda a, b: load.assemble_vector(gen.V, a, b), zd, 1.0)
+            assert K_ov.nnz == K_res.nnz
+            y3 = K_ov.mult(x).get_local()
+            assert np.max(np.abs(y1 - y3)) <= 1e-12 * np.max(np.abs(y1))
+            assert np.max(np.abs(rhs_res - rhs_ov.get_local())) <= 1e-13 * np.max(np.abs(rhs_res))
+            del K_ov, rhs_ov
+    finally:
+        os.environ.pop("TIGAR_OVERLAP", None)
+        dev.stream_set(0)
+
+
+def test_second_stream_hand_over():
+    """tg_stream_set / tg_stream_wait: objects produced on stream 1 and consumed (and released) on stream 0,
+    many times over so that freed blocks travel between the streams through the pool."""
+    from tigar_amd import device as dev
+    rng = np.random.default_rng(3)
+    n = 1 << 20
+    try:
+        for rep in range(20):
+            a = rng.standard_normal(n)
+            dev.stream_set(1)
+            v1 = dev.DeviceVector(data=a)          # upload + kernels on stream 1
+            v2 = dev.DeviceVector(data=2.0 * a)
+            v1.axpy(3.0, v2)                       # v1 = a + 6 a
+            dev.stream_set(0)
+            dev.stream_wait(0, 1)
+            w = dev.DeviceVector(data=np.ones(n))
+            w.axpy(0.5, v1)                        # consumed on stream 0
+            del v1, v2                             # released on the consuming stream
+            assert np.max(np.abs(w.get_local() - (1.0 + 3.5 * a))) <= 4e-15 * (1.0 + 3.5 * np.max(np.abs(a)))   # (fma rounding)
+            del w
+    finally:
+        dev.stream_set(0)
 
 
 def test_gmres_on_nonsymmetric_system_at_scale():

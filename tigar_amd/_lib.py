@@ -48,6 +48,8 @@ PROTOTYPES = {
     "tg_shutdown": (C.c_int, []),
     "tg_last_error": (C.c_char_p, []),
     "tg_sync": (C.c_int, []),
+    "tg_stream_set": (C.c_int, [C.c_int]),
+    "tg_stream_wait": (C.c_int, [C.c_int, C.c_int]),
     "tg_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p]),
     "tg_mem_info": (C.c_int, [c_i64p, c_i64p]),
     "tg_pool_trim": (C.c_int, []),

@@ -15,7 +15,16 @@
 
 struct tg_ctx_t {
   int device = -1;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;    // the CURRENT stream: every launch / copy of the library goes here
+  // Optional second stream (tg_stream_set): lets a producer of inputs (the FE input generator of the
+  // next sub-slab: a pure HBM write stream) run beside the issue-bound PtAP kernels of the current
+  // one.  `stream` and `scratch` alias the pair selected last; the allocator orders the reuse of
+  // freed blocks across the two streams with events once the second stream has been used.
+  hipStream_t streams[2] = {nullptr, nullptr};
+  double *scratches[2] = {nullptr, nullptr};
+  hipEvent_t xev = nullptr;
+  int cur_stream = 0;
+  bool multi = false;
   int num_cu = 0;
   bool ready = false;
   hipEvent_t ev0[8], ev1[8];

@@ -34,15 +34,59 @@ extern "C" int tg_init(int device) {
   TG_CHECK_HIP(hipEventCreate(&g_tg.pev1));
   TG_CHECK_HIP(hipMalloc((void **)&g_tg.scratch, TG_SCRATCH_DOUBLES * sizeof(double)));
   TG_CHECK_HIP(hipHostMalloc((void **)&g_tg.host_pinned, 64 * sizeof(double), hipHostMallocDefault));
+  TG_CHECK_HIP(hipEventCreateWithFlags(&g_tg.xev, hipEventDisableTiming));
+  g_tg.streams[0] = g_tg.stream;
+  g_tg.scratches[0] = g_tg.scratch;
+  g_tg.cur_stream = 0;
+  g_tg.multi = false;
   g_tg.ready = true;
+  return 0;
+}
+
+// ---- second stream
+extern "C" int tg_stream_set(int i) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(i == 0 || i == 1, "tg_stream_set: stream %d (0 or 1)", i);
+  if (i == 1 && !g_tg.streams[1]) {
+    // lowest priority: what runs here is meant to fill the gaps the work on stream 0 leaves (with equal
+    // priorities the producer's big grid starves the many small, latency-bound kernels of a PtAP stage:
+    // k_box_reach 0.34 -> 2.2 ms, no net gain)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    TG_CHECK_HIP(hipStreamCreateWithPriority(&g_tg.streams[1], hipStreamNonBlocking, prio_lo));
+    TG_CHECK_HIP(hipMalloc((void **)&g_tg.scratches[1], TG_SCRATCH_DOUBLES * sizeof(double)));
+  }
+  if (i == 1 && !g_tg.multi) {
+    // blocks freed so far carry no events: make them safe for both streams once
+    TG_CHECK_HIP(hipStreamSynchronize(g_tg.streams[0]));
+    g_tg.multi = true;
+  }
+  g_tg.cur_stream = i;
+  g_tg.stream = g_tg.streams[i];
+  g_tg.scratch = g_tg.scratches[i];
+  return 0;
+}
+
+// stream `waiter` waits for everything enqueued so far on stream `waited` (no host synchronisation)
+extern "C" int tg_stream_wait(int waiter, int waited) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE((waiter == 0 || waiter == 1) && (waited == 0 || waited == 1), "tg_stream_wait: streams are 0 and 1");
+  if (waiter == waited || !g_tg.streams[waiter] || !g_tg.streams[waited]) return 0;
+  TG_CHECK_HIP(hipEventRecord(g_tg.xev, g_tg.streams[waited]));
+  TG_CHECK_HIP(hipStreamWaitEvent(g_tg.streams[waiter], g_tg.xev, 0));
   return 0;
 }
 
 extern "C" int tg_shutdown(void) {
   if (!g_tg.ready) return 0;
-  hipStreamSynchronize(g_tg.stream);
+  for (int i = 0; i < 2; i++)
+    if (g_tg.streams[i]) hipStreamSynchronize(g_tg.streams[i]);
   tg_pool_trim();
-  hipFree(g_tg.scratch);
+  hipFree(g_tg.scratches[0]);
+  if (g_tg.scratches[1]) hipFree(g_tg.scratches[1]);
+  if (g_tg.streams[1]) hipStreamDestroy(g_tg.streams[1]);
+  if (g_tg.xev) hipEventDestroy(g_tg.xev);
+  g_tg.stream = g_tg.streams[0];
   hipHostFree(g_tg.host_pinned);
   for (int i = 0; i < 8; i++) {
     hipEventDestroy(g_tg.ev0[i]);
@@ -125,6 +169,33 @@ extern "C" int tg_timer_stop(int slot, double *ms) {
 static std::multimap<size_t, void *> g_pool_free;
 static std::unordered_map<void *, size_t> g_pool_size;
 static size_t g_pool_bytes = 0;
+// Two-stream mode.  A block belongs to the stream that was current when it was allocated; objects
+// cross streams only by the caller's hand-over (tg_stream_wait, then use AND release on the consuming
+// stream).  A freed block records an event on the stream it is freed on and, if that is not the stream
+// it was allocated on, on that one as well; whoever takes it out of the pool on stream c waits for the
+// recorded event of the other stream (its own stream is ordered anyway) -- and prefers blocks that need
+// no such wait, so that the temporaries of one stream do not tie it to the kernels of the other.
+struct tg_block_events {
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  bool rec[2] = {false, false};
+};
+static std::unordered_map<void *, tg_block_events> g_pool_ev;
+static std::unordered_map<void *, int> g_live_sid;     // stream of allocation (two-stream mode only)
+
+static void tg_pool_sync_all() {
+  if (!g_tg.ready) return;
+  for (int i = 0; i < 2; i++)
+    if (g_tg.streams[i]) hipStreamSynchronize(g_tg.streams[i]);
+}
+
+static void tg_pool_drop_events(void *p) {
+  g_live_sid.erase(p);
+  auto it = g_pool_ev.find(p);
+  if (it == g_pool_ev.end()) return;
+  for (int i = 0; i < 2; i++)
+    if (it->second.ev[i]) hipEventDestroy(it->second.ev[i]);
+  g_pool_ev.erase(it);
+}
 
 static size_t tg_pool_limit() {
   static size_t lim = 0;
@@ -152,9 +223,10 @@ extern "C" int tg_pool_stats(int64_t *pooled_bytes, int64_t *pooled_blocks, int6
 }
 
 extern "C" int tg_pool_trim(void) {
-  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  tg_pool_sync_all();
   for (auto &kv : g_pool_free) {
     g_pool_size.erase(kv.second);
+    tg_pool_drop_events(kv.second);
     hipFree(kv.second);
   }
   g_pool_free.clear();
@@ -178,11 +250,38 @@ int tg_dmalloc_bytes(void **p, size_t bytes) {
   }
   auto it = g_pool_free.lower_bound(bytes);
   // accept a cached block that is at most 12.5 % (or 32 MiB) larger than requested
-  if (it != g_pool_free.end() && it->first <= bytes + std::max<size_t>(bytes / 8, (size_t)32 << 20)) {
-    *p = it->second;
-    g_pool_bytes -= it->first;
-    g_pool_free.erase(it);
-    return 0;
+  const size_t fit = bytes + std::max<size_t>(bytes / 8, (size_t)32 << 20);
+  if (it != g_pool_free.end() && it->first <= fit) {
+    if (g_tg.multi) {
+      // prefer a block that carries no event of the other stream
+      const int other = 1 - g_tg.cur_stream;
+      auto pick = it;
+      int scanned = 0;
+      for (auto c = it; c != g_pool_free.end() && c->first <= fit && scanned < 32; ++c, ++scanned) {
+        auto ev = g_pool_ev.find(c->second);
+        if (ev == g_pool_ev.end() || !ev->second.rec[other]) {
+          pick = c;
+          break;
+        }
+      }
+      it = pick;
+      auto ev = g_pool_ev.find(it->second);
+      const bool tied = ev != g_pool_ev.end() && ev->second.rec[other] && ev->second.ev[other];
+      if (tied && it->first < ((size_t)256 << 20)) {
+        // a small block that would tie this stream to the kernels in flight on the other one (the
+        // producer releases its tables right after launching its fill kernel): a fresh block is cheaper
+        it = g_pool_free.end();
+      } else {
+        if (tied) TG_CHECK_HIP(hipStreamWaitEvent(g_tg.stream, ev->second.ev[other], 0));
+        g_live_sid[it->second] = g_tg.cur_stream;
+      }
+    }
+    if (it != g_pool_free.end()) {
+      *p = it->second;
+      g_pool_bytes -= it->first;
+      g_pool_free.erase(it);
+      return 0;
+    }
   }
   const bool trace = getenv("TIGAR_TRACE") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
@@ -207,6 +306,7 @@ int tg_dmalloc_bytes(void **p, size_t bytes) {
     return 1;
   }
   g_pool_size[*p] = bytes;
+  if (g_tg.multi) g_live_sid[*p] = g_tg.cur_stream;
   return 0;
 }
 
@@ -227,23 +327,47 @@ void tg_dfree(void *p) {
     while (g_pool_bytes + bytes > tg_pool_limit() && !g_pool_free.empty() && g_pool_free.begin()->first < bytes) {
       auto sm = g_pool_free.begin();
       if (!synced && g_tg.ready) {
-        hipStreamSynchronize(g_tg.stream);
+        tg_pool_sync_all();
         synced = true;
       }
       g_pool_bytes -= sm->first;
       g_pool_size.erase(sm->second);
+      tg_pool_drop_events(sm->second);
       hipFree(sm->second);
       g_pool_free.erase(sm);
     }
     if (g_pool_bytes + bytes > tg_pool_limit()) {
-      if (!synced && g_tg.ready) hipStreamSynchronize(g_tg.stream);
+      if (!synced && g_tg.ready) tg_pool_sync_all();
       g_pool_size.erase(it);
+      tg_pool_drop_events(p);
       hipFree(p);
       if (getenv("TIGAR_TRACE")) {
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (ms > 20.0) fprintf(stderr, "[trace] slow hipFree(%.1f MB) (pool full): %.1f ms\n", bytes / 1048576.0, ms);
       }
       return;
+    }
+  }
+  if (g_tg.multi && g_tg.ready) {
+    tg_block_events &be = g_pool_ev[p];
+    int asid = g_tg.cur_stream;
+    auto ls = g_live_sid.find(p);
+    if (ls != g_live_sid.end()) {
+      asid = ls->second;
+      g_live_sid.erase(ls);
+    } else {
+      asid = -1;   // allocated before the second stream existed: stream 0, already synchronised
+    }
+    for (int i = 0; i < 2; i++) {
+      be.rec[i] = false;
+      if (!g_tg.streams[i] || (i != g_tg.cur_stream && i != asid)) continue;
+      if (!be.ev[i] && hipEventCreateWithFlags(&be.ev[i], hipEventDisableTiming) != hipSuccess) be.ev[i] = nullptr;
+      if (be.ev[i] && hipEventRecord(be.ev[i], g_tg.streams[i]) == hipSuccess) {
+        be.rec[i] = true;
+      } else {
+        // cannot order the reuse with an event: a host synchronisation of that stream does it
+        hipStreamSynchronize(g_tg.streams[i]);
+      }
     }
   }
   g_pool_free.emplace(bytes, p);
@@ -267,7 +391,10 @@ extern "C" int tg_vec_create(int64_t n, tg_vec_t *out) {
 
 extern "C" int tg_vec_destroy(tg_vec_t v) {
   if (!v) return 0;
-  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  // (the block goes back to the pool and its re-use is ordered behind the work in flight; with two
+  // streams a host synchronisation here would serialise them -- a temporary released on the producer
+  // stream would wait for the producer's own kernel)
+  if (g_tg.ready && !g_tg.multi) hipStreamSynchronize(g_tg.stream);
   tg_dfree(v->d);
   delete v;
   return 0;
@@ -545,7 +672,7 @@ extern "C" int tg_csr_download(tg_csr_t m, int64_t *rowptr, int32_t *col, double
 
 extern "C" int tg_csr_destroy(tg_csr_t m) {
   if (!m) return 0;
-  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  if (g_tg.ready && !g_tg.multi) hipStreamSynchronize(g_tg.stream);
   tg_dfree(m->rowptr);
   tg_dfree(m->rowptr_val);
   if (!m->view) {

@@ -388,8 +388,9 @@ int tg_kron_build_rect(int d, int nterms, const tg_kron_dir_t *dirs, const int64
         tg_dfree(rowptr);
     }
   }
-  hipStreamSynchronize(g_tg.stream);
-  TG_TRACE("fill synced");
+  // (no synchronisation: the host tables were consumed before the scan returned its total, and the
+  // device copies go back to the pool, whose re-use is ordered behind the fill kernel -- the caller may
+  // overlap the fill with work on the other stream)
   for (int i = 0; i < 9; i++) tg_dfree(dev[i]);
   TG_TRACE("freed");
   if (rc) {

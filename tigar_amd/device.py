@@ -639,6 +639,16 @@ def sync():
     check(_lib.lib().tg_sync())
 
 
+def stream_set(i):
+    """Make stream ``i`` (0 or 1) the current stream of the library (tg_stream_set)."""
+    check(_lib.lib().tg_stream_set(int(i)), "tg_stream_set")
+
+
+def stream_wait(waiter, waited):
+    """Stream ``waiter`` waits (on the device) for everything enqueued so far on stream ``waited``."""
+    check(_lib.lib().tg_stream_wait(int(waiter), int(waited)), "tg_stream_wait")
+
+
 def device_info():
     name = C.create_string_buffer(256)
     ncu, hbm = C.c_int(), C.c_int64()

@@ -186,7 +186,41 @@ class SlabHotPath(object):
             dev.sync()
             t[name] = t.get(name, 0.0) + time.perf_counter() - t0
 
-        for (ka, kb) in self.sub_slabs():
+        # Optional (TIGAR_OVERLAP=1): the FE inputs of sub-slab i+1 are requested on the library's second
+        # stream before the contraction of sub-slab i is enqueued on the first (only on the fully
+        # factorised path, where the rows each sub-slab needs are known up front).  Measured at
+        # 256^3 p=3: the kernels do run side by side (rocprof: the 6 ms fill stretches over the whole
+        # 28 ms of a sub-slab's PtAP), but both are bound by instruction issue on the same CUs -- the
+        # input time disappears from the host's view (0.20 -> 0.03 s) and the PtAP grows by the same
+        # amount (1.03 -> 1.18 s), with or without a low-priority producer stream.  Off by default.
+        subs = self.sub_slabs()
+        overlap = (self.factored and self.kron_exact and len(subs) > 1
+                   and os.environ.get("TIGAR_OVERLAP", "0") == "1")
+        sched = []
+        if overlap:
+            pf0, hi = self.layout.plane_fe, 0
+            for (ka, kb) in subs:
+                S0 = self.layout.slab(ka, kb)
+                za, zb = S0["a_rows"][0] // pf0, S0["a_rows"][1] // pf0
+                lo = max(za, hi)
+                sched.append((lo, zb, S0["a_rows"]))
+                if zb > lo:
+                    hi = zb
+
+        def produce(i):
+            lo, zb, arows = sched[i]
+            dev.stream_set(1)
+            try:
+                # the vector first: producers of small objects tend to end with a host synchronisation
+                # (uploads from host arrays), which must not sit behind the long fill kernel of the matrix
+                b_i = b_rows(arows[0], arows[1])
+                A_i = a_rows(lo * self.layout.plane_fe, zb * self.layout.plane_fe) if zb > lo else None
+            finally:
+                dev.stream_set(0)
+            return A_i, b_i
+
+        nxt = produce(0) if overlap else None
+        for islab, (ka, kb) in enumerate(subs):
             S = self.layout.slab(ka, kb)
             t0 = time.perf_counter()
             use_factored = self.factored
@@ -207,14 +241,20 @@ class SlabHotPath(object):
             tick("extract", t0)
             t0 = time.perf_counter()
             pf = self.layout.plane_fe
-            if use_factored:
+            if overlap:
+                dev.stream_wait(0, 1)                      # the inputs of this sub-slab are complete
+                A, b = nxt
+                ring["new"] = (sched[islab][0], sched[islab][1])
+                nxt = produce(islab + 1) if islab + 1 < len(subs) else None
+            elif use_factored:
                 za, zb = S["a_rows"][0] // pf, S["a_rows"][1] // pf
                 new_lo = max(za, ring["hi"])               # FE planes not yet contracted
                 A = a_rows(new_lo * pf, zb * pf) if zb > new_lo else None
                 ring["new"] = (new_lo, zb)
+                b = b_rows(S["a_rows"][0], S["a_rows"][1])
             else:
                 A = a_rows(S["a_rows"][0], S["a_rows"][1])
-            b = b_rows(S["a_rows"][0], S["a_rows"][1])
+                b = b_rows(S["a_rows"][0], S["a_rows"][1])
             tick("input", t0)
             t0 = time.perf_counter()
             if use_factored:

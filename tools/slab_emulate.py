@@ -28,7 +28,7 @@ probe = SlabHotPath(basis, grid, rank, world, None)
 planes = probe.k1 - probe.k0
 sub = int(sys.argv[5]) if len(sys.argv) > 5 else pick_sub_planes(d, p, nel, planes, free_b)
 path = SlabHotPath(basis, grid, rank, world, None, sub_planes=sub)
-for it in range(2):
+for it in range(int(os.environ.get("PASSES", "2"))):
     timers = {}
     t0 = time.perf_counter()
     K, rhs = path.assemble(lambda r0, r1: lap.assemble_matrix(V, r0, r1), lambda r0, r1: load.assemble_vector(V, r0, r1),
