@@ -18,6 +18,8 @@
 // If a box would not fit in LDS (or A couples outside the measured bandwidth, impossible by
 // construction) the host falls back to the general kernel (tg_ptap.hip).
 #include "tg_common.h"
+#include <array>
+#include <map>
 #include <algorithm>
 
 struct tg_box_args {
@@ -1397,7 +1399,23 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
     if (!rc) rc = tg_dmalloc(&cnt, nrows + 1) || tg_dmalloc(&off, nrows + 1) || tg_dmalloc(&cursor, 1);
     double mean_k = 0.0;
     int hmax[3] = {0, 0, 0};
-    if (!rc) {
+    // Capacity of the temporary: from the last product with the same signature (stage, index spaces in
+    // the first two directions, kernel variant) if there was one -- entries actually used per row, chunk
+    // slack included, largest value seen -- else from a probe of 512 sample rows.  A stage of a
+    // streamed assembly is called once per sub-slab with the same signature; probe + scan + host round
+    // trip cost ~0.8 ms of the ~9 ms a stage takes at 256^3 p=3.  An estimate that turns out too small
+    // is caught by the kernel (TG_BOX_CAP) and retried with a larger temporary as before.
+    const std::array<int, 8> cap_key = {d, P.contracted[0] | (P.contracted[1] << 1) | (P.contracted[2] << 2), P.nin[0],
+                                        P.nin[1], P.nout[0], P.nout[1], line_variant, loose_out ? 1 : (dest ? 2 : 0)};
+    static std::map<std::array<int, 8>, std::pair<double, int>> cap_cache;
+    static const bool force_probe = getenv("TIGAR_PTAP_PROBE") && atoi(getenv("TIGAR_PTAP_PROBE")) == 1;
+    const auto cached = cap_cache.find(cap_key);
+    const bool have_cached = !force_probe && cached != cap_cache.end();
+    if (!rc && have_cached) {
+      mean_k = cached->second.first;
+      hmax[2] = cached->second.second;
+    }
+    if (!rc && !have_cached) {
       // probe a sample of rows: mean row length -> capacity of the temporary
       tg_box_args S = P;
       S.prof = nullptr;
@@ -1430,7 +1448,8 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
     }
     unsigned long long used_final = 0;
     int64_t capacity = (int64_t)(mean_k * 1.05 * (double)nrows) + hmax[2] + 1024;
-    if (line_variant) capacity = (int64_t)(capacity * 1.3) + nrows / 8 * 64;   // slack of the wave-private chunks
+    if (line_variant && !have_cached) capacity = (int64_t)(capacity * 1.3) + nrows / 8 * 64;   // slack of the wave-private chunks
+    if (have_cached) capacity = (int64_t)(mean_k * 1.10 * (double)nrows) + hmax[2] + 65536;      // (measured use incl. slack)
     for (int attempt = 0; attempt < 6 && !rc; attempt++) {
       rc = tg_dmalloc(&tcol, capacity + TG_CSR_PAD) || tg_dmalloc(&tval, capacity + TG_CSR_PAD);
       if (rc) break;
@@ -1523,7 +1542,14 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
                 100.0 * hp[2] / tot, 100.0 * hp[3] / tot);
       }
       used_final = used;
-      if (h == TG_BOX_OK) break;
+      if (h == TG_BOX_OK) {
+        if (nrows > 0) {
+          std::pair<double, int> &c = cap_cache[cap_key];
+          c.first = std::max(c.first, (double)used / (double)nrows);
+          c.second = std::max(c.second, hmax[2]);
+        }
+        break;
+      }
       tg_dfree(tcol);
       tg_dfree(tval);
       tcol = nullptr;
