@@ -66,14 +66,16 @@ def test_full_size_properties(d, p, nel, tol):
     assert np.array_equal(kz, 3.0 * ind)                                  # diag on the BC rows, zero columns elsewhere
     # the sliced, pattern-compressed copy the Krylov solvers multiply with (tg_spmv_sell) reproduces the
     # CSR product at full size, incl. the exact unit rows / zero columns of the boundary dofs
-    yc = K.mult(dx).get_local()
-    ncls, padded = K.spmv_sell(True)
-    assert ncls > 0 and K.nnz <= padded <= 1.2 * K.nnz
-    ys = K.mult(dx).get_local()
-    kzs = K.mult(dev.DeviceVector(data=ind)).get_local()
-    K.spmv_sell(False)
-    assert np.max(np.abs(ys - yc)) <= 1e-13 * np.max(np.abs(yc))
-    assert np.array_equal(kzs, 3.0 * ind)
+    import os
+    if os.environ.get("TIGAR_SPMV_SELL") != "0":
+        yc = K.mult(dx).get_local()
+        ncls, padded = K.spmv_sell(True)
+        assert ncls > 0 and K.nnz <= padded <= 1.2 * K.nnz
+        ys = K.mult(dx).get_local()
+        kzs = K.mult(dev.DeviceVector(data=ind)).get_local()
+        K.spmv_sell(False)
+        assert np.max(np.abs(ys - yc)) <= 1e-13 * np.max(np.abs(yc))
+        assert np.array_equal(kzs, 3.0 * ind)
     # manufactured solution of the Poisson problem (demos/poisson/poisson.py flow)
     f1 = lambda s: np.sin(np.pi * s)
     load = F.SeparableLoadForm([f1] * d, scale=d * np.pi ** 2)
