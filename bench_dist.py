@@ -148,11 +148,11 @@ def pick_sub_planes(d, p, nel, planes_mine, free_bytes):
     # (half of the free HBM: measured at 256^3 p=3 with the 3/4-of-HBM allocator pool, per step:
     # 5 planes 1.59 s of input+PtAP, 8: 1.53 s, 12: 1.44 s, 16: 1.41 s with 75 GB still free at the end
     # of a step, 20: allocation failures and pool trimming start, 24: 5.6 s)
-    # ... less the sliced copy of K's values that lives during the Krylov solve (tg_sell.hip: 8 B per
-    # entry + ~2 % padding; measured at 256^3 p=3 with the copy: 14 planes 3.5 s per step (allocator
-    # thrashing), 11: 2.13 s, 9: 2.12 s, 7: 2.13 s)
-    sell_bytes = 8.4 * planes_mine * (nel + p) ** (d - 1) * ((2 * p + 1) ** d)
-    budget = 0.5 * free_bytes - fixed - sell_bytes
+    # (the sliced copy of K's values that lives during the Krylov solve, 47 GB at 256^3 p=3, is stored in
+    # idle blocks of the allocator's pool -- the PtAP temporaries sized here -- so it needs no budget of
+    # its own; when it still asked the driver for one block, 14 planes thrashed the allocator (3.5 s per
+    # step) and 7 were the safe choice)
+    budget = 0.5 * free_bytes - fixed
     n = int(max(1, min(planes_mine, budget // per_dof_plane)))
     return n
 

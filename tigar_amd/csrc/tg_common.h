@@ -100,6 +100,7 @@ struct tg_csr_s {
 
 int tg_dmalloc_bytes(void **p, size_t bytes);   // caching allocator (tg_core.hip)
 void tg_dfree(void *p);
+int tg_pool_take_largest(size_t min_bytes, void **p, size_t *bytes);   // 1 = none; nothing is allocated
 template <typename T>
 static inline int tg_dmalloc(T **p, int64_t count) {
   if (count <= 0) count = 1;

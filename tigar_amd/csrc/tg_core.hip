@@ -310,6 +310,29 @@ int tg_dmalloc_bytes(void **p, size_t bytes) {
   return 0;
 }
 
+// Takes the LARGEST cached block of at least min_bytes out of the pool (nothing is allocated): for
+// consumers that can live in several pieces of any size (the sliced copy of tg_sell.hip) and would
+// otherwise ask the driver for tens of GB while as much sits idle in the pool.  Returns 1 if there is none.
+int tg_pool_take_largest(size_t min_bytes, void **p, size_t *bytes) {
+  *p = nullptr;
+  *bytes = 0;
+  if (g_pool_free.empty()) return 1;
+  auto it = std::prev(g_pool_free.end());
+  if (it->first < min_bytes) return 1;
+  if (g_tg.multi) {
+    auto ev = g_pool_ev.find(it->second);
+    const int other = 1 - g_tg.cur_stream;
+    if (ev != g_pool_ev.end() && ev->second.rec[other] && ev->second.ev[other])
+      TG_CHECK_HIP(hipStreamWaitEvent(g_tg.stream, ev->second.ev[other], 0));
+    g_live_sid[it->second] = g_tg.cur_stream;
+  }
+  *p = it->second;
+  *bytes = it->first;
+  g_pool_bytes -= it->first;
+  g_pool_free.erase(it);
+  return 0;
+}
+
 void tg_dfree(void *p) {
   if (!p) return;
   auto it = g_pool_size.find(p);

@@ -35,8 +35,12 @@
 struct tg_sell_s {
   int64_t nslices = 0;
   int64_t padded = 0;            // doubles in val
-  double *val = nullptr;         // [slice][k][lane]
-  int64_t *slice_ptr = nullptr;  // nslices + 1 offsets into val
+  // values: [slice][k][lane] blocks, stored in a few pieces -- idle blocks of the caching allocator's
+  // pool first (tens of GB of PtAP temporaries sit there while the solve runs), one fresh allocation
+  // for what is left -- so slices are addressed by pointer
+  std::vector<void *> pieces;
+  int64_t *slice_ptr = nullptr;  // nslices + 1 prefix of the block sizes (doubles)
+  int64_t *slice_addr = nullptr; // nslices device addresses of the blocks
   int32_t *slice_cls = nullptr;  // class id per slice
   int32_t *cls_w = nullptr;      // width per class
   int32_t *cls_off = nullptr;    // [class][TG_SELL_WMAX] sorted offsets
@@ -45,8 +49,9 @@ struct tg_sell_s {
 
 void tg_sell_free(tg_sell_s *s) {
   if (!s) return;
-  tg_dfree(s->val);
+  for (void *q : s->pieces) tg_dfree(q);
   tg_dfree(s->slice_ptr);
+  tg_dfree(s->slice_addr);
   tg_dfree(s->slice_cls);
   tg_dfree(s->cls_w);
   tg_dfree(s->cls_off);
@@ -246,9 +251,9 @@ __global__ void k_sell_slice_sizes(const int32_t *__restrict__ slot_of_slice, co
 #define TG_SELL_TILE 3072   // doubles (24 KB)
 __global__ void __launch_bounds__(256)
     k_sell_convert(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
-                   int64_t nrows, int64_t nslices, const int64_t *__restrict__ slice_ptr,
+                   int64_t nrows, int64_t nslices, const int64_t *__restrict__ slice_addr,
                    const int32_t *__restrict__ slice_cls, const int32_t *__restrict__ cls_w,
-                   const int32_t *__restrict__ cls_off, double *__restrict__ out, int *__restrict__ fail) {
+                   const int32_t *__restrict__ cls_off, int *__restrict__ fail) {
   __shared__ double tile[TG_SELL_TILE];
   __shared__ int U[TG_SELL_WMAX];
   __shared__ int rs[TG_SELL_C + 1];
@@ -265,7 +270,7 @@ __global__ void __launch_bounds__(256)
   int R = TG_SELL_C;                      // rows per tile: power of two, w * R <= TG_SELL_TILE
   while (R > 1 && w * R > TG_SELL_TILE) R >>= 1;
   const int lR = 31 - __builtin_clz(R);
-  double *o = out + slice_ptr[s];
+  double *o = reinterpret_cast<double *>(slice_addr[s]);
   bool bad = false;
   for (int g0 = 0; g0 < TG_SELL_C; g0 += R) {
     __syncthreads();                      // (U, rs staged; previous tile written out)
@@ -319,7 +324,7 @@ __global__ void __launch_bounds__(256)
 // positions -- stored 0.0 -- can fall outside).
 #define TG_SELL_UNROLL 8
 __global__ void __launch_bounds__(256)
-    k_spmv_sell(const double *__restrict__ V, const int64_t *__restrict__ slice_ptr, const int32_t *__restrict__ slice_cls,
+    k_spmv_sell(const int64_t *__restrict__ slice_addr, const int32_t *__restrict__ slice_cls,
                 const int32_t *__restrict__ cls_w, const int32_t *__restrict__ cls_off, const double *__restrict__ x,
                 double *__restrict__ y, int64_t nrows, int64_t nslices, int cmin, int cmax) {
   const int lane = threadIdx.x & 63;
@@ -330,7 +335,7 @@ __global__ void __launch_bounds__(256)
   const int id = slice_cls[s];
   const int w = cls_w[id];
   const int32_t *__restrict__ U = cls_off + (int64_t)id * TG_SELL_WMAX;
-  const double *__restrict__ v = V + slice_ptr[s] + lane;
+  const double *__restrict__ v = reinterpret_cast<const double *>(slice_addr[s]) + lane;
   const int r = (int)(s * TG_SELL_C) + lane;
   double sum = 0.0;
   int k = 0;
@@ -352,7 +357,7 @@ int tg_sell_spmv(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cma
   tg_sell_s *S = a->sell;
   const int64_t nwb = (S->nslices + 3) / 4;
   const unsigned grid = (unsigned)(((nwb + 7) / 8) * 8);
-  hipLaunchKernelGGL(k_spmv_sell, dim3(grid), dim3(256), 0, g_tg.stream, S->val, S->slice_ptr, S->slice_cls, S->cls_w,
+  hipLaunchKernelGGL(k_spmv_sell, dim3(grid), dim3(256), 0, g_tg.stream, S->slice_addr, S->slice_cls, S->cls_w,
                      S->cls_off, x_shifted, y, a->nrows, S->nslices, (int)cmin, (int)cmax);
   TG_LAUNCH_CHECK();
   return 0;
@@ -428,14 +433,72 @@ int tg_sell_plan(tg_csr_s *a) {
       declined = true;
       break;
     }
-    if (!step(tg_dmalloc(&S->val, padded))) {
-      // no room for the copy: not an error, the CSR kernel stays
-      rc = 0;
-      declined = true;
+    // ---- storage: pieces at slice granularity.  The prefix of the block sizes comes to the host (8 B
+    // per slice), pieces are cut where a block from the pool ends
+    std::vector<int64_t> hptr((size_t)nslices + 1);
+    if (!hip_ok(hipMemcpyAsync(hptr.data(), S->slice_ptr, sizeof(int64_t) * (size_t)(nslices + 1), hipMemcpyDeviceToHost,
+                               g_tg.stream)) ||
+        !hip_ok(hipStreamSynchronize(g_tg.stream)))
       break;
+    std::vector<int64_t> first, base;      // first slice and device address of every piece
+    {
+      static const bool use_pool = !(getenv("TIGAR_SELL_POOL") && atoi(getenv("TIGAR_SELL_POOL")) == 0);
+      int64_t s0 = 0;
+      bool failed = false;
+      while (s0 < nslices && !failed) {
+        const int64_t left = (hptr[(size_t)nslices] - hptr[(size_t)s0]) * 8;
+        void *blk = nullptr;
+        size_t got = 0;
+        // pool blocks of at least 1 GiB (or everything that is left); else one fresh allocation
+        if (!use_pool || tg_pool_take_largest((size_t)std::min<int64_t>(left, (int64_t)1 << 30), &blk, &got)) {
+          if (tg_dmalloc_bytes(&blk, (size_t)std::max<int64_t>(left, 8))) {
+            failed = true;
+            break;
+          }
+          got = (size_t)std::max<int64_t>(left, 8);
+        }
+        S->pieces.push_back(blk);
+        // slices [s0, s1) fit into this block
+        const int64_t cap = hptr[(size_t)s0] + (int64_t)(got / 8);
+        int64_t s1 = (int64_t)(std::upper_bound(hptr.begin() + s0, hptr.end(), cap) - hptr.begin()) - 1;
+        if (s1 <= s0) {
+          // the block does not even hold one slice: give it back and allocate the rest freshly
+          S->pieces.pop_back();
+          tg_dfree(blk);
+          if (tg_dmalloc_bytes(&blk, (size_t)left)) {
+            failed = true;
+            break;
+          }
+          S->pieces.push_back(blk);
+          s1 = nslices;
+        }
+        first.push_back(s0);
+        base.push_back((int64_t)(uintptr_t)blk - hptr[(size_t)s0] * 8);   // address of "offset 0" for this piece
+        s0 = s1;
+      }
+      if (failed) {
+        // no room for the copy: not an error, the CSR kernel stays
+        rc = 0;
+        declined = true;
+        break;
+      }
+    }
+    if (!step(tg_dmalloc(&S->slice_addr, nslices))) break;
+    {
+      // slice_addr[s] = base[piece(s)] + 8 * slice_ptr[s]
+      std::vector<int64_t> haddr((size_t)nslices);
+      size_t pc = 0;
+      for (int64_t sl = 0; sl < nslices; sl++) {
+        while (pc + 1 < first.size() && first[pc + 1] <= sl) pc++;
+        haddr[(size_t)sl] = base[pc] + hptr[(size_t)sl] * 8;
+      }
+      if (!hip_ok(hipMemcpyAsync(S->slice_addr, haddr.data(), sizeof(int64_t) * (size_t)nslices, hipMemcpyHostToDevice,
+                                 g_tg.stream)) ||
+          !hip_ok(hipStreamSynchronize(g_tg.stream)))
+        break;
     }
     hipLaunchKernelGGL(k_sell_convert, dim3((unsigned)nslices), dim3(256), 0, g_tg.stream, a->rowptr, a->col,
-                       a->val, nrows, nslices, S->slice_ptr, S->slice_cls, S->cls_w, S->cls_off, S->val, ctl + 2);
+                       a->val, nrows, nslices, S->slice_addr, S->slice_cls, S->cls_w, S->cls_off, ctl + 2);
     if (!hip_ok(hipGetLastError())) break;
     if (!hip_ok(hipMemcpyAsync(h, ctl, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream)) ||
         !hip_ok(hipStreamSynchronize(g_tg.stream)))
