@@ -1449,7 +1449,10 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
     unsigned long long used_final = 0;
     int64_t capacity = (int64_t)(mean_k * 1.05 * (double)nrows) + hmax[2] + 1024;
     if (line_variant && !have_cached) capacity = (int64_t)(capacity * 1.3) + nrows / 8 * 64;   // slack of the wave-private chunks
-    if (have_cached) capacity = (int64_t)(mean_k * 1.10 * (double)nrows) + hmax[2] + 65536;      // (measured use incl. slack)
+    // (measured use incl. the slack of the wave-private chunks, which varies with the order in which the
+    // waves reserve: +20 %.  With +10 % a stage of 128^3 p=2 overflowed now and then, and a retry means
+    // a new size class from hipMalloc: 0.19 instead of 0.035 s)
+    if (have_cached) capacity = (int64_t)(mean_k * 1.20 * (double)nrows) + hmax[2] + 65536;
     for (int attempt = 0; attempt < 6 && !rc; attempt++) {
       rc = tg_dmalloc(&tcol, capacity + TG_CSR_PAD) || tg_dmalloc(&tval, capacity + TG_CSR_PAD);
       if (rc) break;
@@ -1558,6 +1561,11 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
         if (getenv("TIGAR_TRACE"))
           fprintf(stderr, "[tigar] ptap temporary too small: capacity %lld, used %llu, rows %lld, mean row %.1f, run %d -> retry\n",
                   (long long)capacity, used, (long long)nrows, mean_k, Q.mlen);
+        if (nrows > 0) {
+          std::pair<double, int> &c = cap_cache[cap_key];      // what was reserved before the kernel gave up is a lower bound
+          c.first = std::max(c.first, (double)used / (double)nrows);
+          c.second = std::max(c.second, hmax[2]);
+        }
         capacity = std::max<int64_t>((int64_t)used + 1024, capacity * 2);
         continue;
       }

@@ -78,8 +78,9 @@ def default_groups(d, p):
     """Which directions to contract together.  One-shot ([[0..d-1]]) is the plain PtAP with the
     workgroup-per-row box kernel; one direction at a time runs the wave-per-run line kernel
     (k_ptap_line) three times with 2.5x fewer products at 3-D p=3.  Measured on MI355X: the one-shot
-    product wins for p = 2 and in 2-D (51.6 vs 57.6 ms at 128^3 p=2), x|y|z wins for 3-D p >= 3
-    (ptap 1.60 s vs 2.06 s per step at 256^3 p=3)."""
+    product wins in 2-D (3.1 vs 3.2 ms at 256^2 p=4), x|y|z wins in 3-D (ptap 1.60 s vs 2.06 s per step
+    at 256^3 p=3 when the line kernel was new; at 128^3 p=2 the one-shot product won then, 51.6 vs 57.6 ms,
+    and loses now: 51.5 vs 35.0 ms)."""
     import os
     env = os.environ.get("TIGAR_PTAP_GROUPS")            # e.g. "0;1;2" or "0,1;2" (experiments)
     if env:
@@ -87,7 +88,7 @@ def default_groups(d, p):
         groups = [g for g in groups if g]
         if sorted(sum(groups, [])) == list(range(d)) and (d - 1) in groups[-1]:
             return groups
-    if d == 3 and p >= 3:
+    if d == 3 and p >= 2:
         return [[0], [1], [2]]
     return [list(range(d))]
 
