@@ -222,6 +222,7 @@ def run_distributed(args, d, p, nel, rank, world):
             log("[bench] pool: %.1f GB free in %d blocks, %d blocks live; device free %.1f GB" % (pb / 2 ** 30, nb, nl, fr / 2 ** 30))
 
     for _ in range(args.warmup):
+        state.clear()        # (the previous step's K must not stay alive beside the one being assembled)
         step(False)
     dev.prof_reset()
     barrier()

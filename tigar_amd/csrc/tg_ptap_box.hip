@@ -1407,13 +1407,21 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
     // is caught by the kernel (TG_BOX_CAP) and retried with a larger temporary as before.
     const std::array<int, 8> cap_key = {d, P.contracted[0] | (P.contracted[1] << 1) | (P.contracted[2] << 2), P.nin[0],
                                         P.nin[1], P.nout[0], P.nout[1], line_variant, loose_out ? 1 : (dest ? 2 : 0)};
-    static std::map<std::array<int, 8>, std::pair<double, int>> cap_cache;
+    // (first: largest use per row seen, second: capacity per row of the last allocation that was large
+    // enough -- re-used as it is, so that the same sub-slab asks for the same block in every step: a
+    // capacity recomputed from the use would land in another size class than the probe-sized
+    // allocation of the first step and cost a round of hipMalloc in the second)
+    struct tg_cap_entry {
+      double used_pr = 0.0, cap_pr = 0.0;
+      int hmax2 = 0;
+    };
+    static std::map<std::array<int, 8>, tg_cap_entry> cap_cache;
     static const bool force_probe = getenv("TIGAR_PTAP_PROBE") && atoi(getenv("TIGAR_PTAP_PROBE")) == 1;
     const auto cached = cap_cache.find(cap_key);
     const bool have_cached = !force_probe && cached != cap_cache.end();
     if (!rc && have_cached) {
-      mean_k = cached->second.first;
-      hmax[2] = cached->second.second;
+      mean_k = cached->second.used_pr;
+      hmax[2] = cached->second.hmax2;
     }
     if (!rc && !have_cached) {
       // probe a sample of rows: mean row length -> capacity of the temporary
@@ -1452,7 +1460,7 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
     // (measured use incl. the slack of the wave-private chunks, which varies with the order in which the
     // waves reserve: +20 %.  With +10 % a stage of 128^3 p=2 overflowed now and then, and a retry means
     // a new size class from hipMalloc: 0.19 instead of 0.035 s)
-    if (have_cached) capacity = (int64_t)(mean_k * 1.20 * (double)nrows) + hmax[2] + 65536;
+    if (have_cached) capacity = (int64_t)(cached->second.cap_pr * (double)nrows) + 65536;
     for (int attempt = 0; attempt < 6 && !rc; attempt++) {
       rc = tg_dmalloc(&tcol, capacity + TG_CSR_PAD) || tg_dmalloc(&tval, capacity + TG_CSR_PAD);
       if (rc) break;
@@ -1547,9 +1555,13 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
       used_final = used;
       if (h == TG_BOX_OK) {
         if (nrows > 0) {
-          std::pair<double, int> &c = cap_cache[cap_key];
-          c.first = std::max(c.first, (double)used / (double)nrows);
-          c.second = std::max(c.second, hmax[2]);
+          tg_cap_entry &c = cap_cache[cap_key];
+          c.used_pr = std::max(c.used_pr, (double)used / (double)nrows);
+          c.hmax2 = std::max(c.hmax2, hmax[2]);
+          const double cp = (double)std::max<int64_t>(capacity - 65536, 0) / (double)nrows;
+          // fixed once it has worked (a capacity that follows the largest use seen creeps upwards over
+          // the first steps and every change is a round of hipMalloc); only an overflow moves it
+          if (c.cap_pr == 0.0 || attempt > 0) c.cap_pr = cp;
         }
         break;
       }
@@ -1562,9 +1574,9 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
           fprintf(stderr, "[tigar] ptap temporary too small: capacity %lld, used %llu, rows %lld, mean row %.1f, run %d -> retry\n",
                   (long long)capacity, used, (long long)nrows, mean_k, Q.mlen);
         if (nrows > 0) {
-          std::pair<double, int> &c = cap_cache[cap_key];      // what was reserved before the kernel gave up is a lower bound
-          c.first = std::max(c.first, (double)used / (double)nrows);
-          c.second = std::max(c.second, hmax[2]);
+          tg_cap_entry &c = cap_cache[cap_key];      // what was reserved before the kernel gave up is a lower bound
+          c.used_pr = std::max(c.used_pr, (double)used / (double)nrows);
+          c.hmax2 = std::max(c.hmax2, hmax[2]);
         }
         capacity = std::max<int64_t>((int64_t)used + 1024, capacity * 2);
         continue;

@@ -36,4 +36,17 @@ for it in range(int(os.environ.get("PASSES", "2"))):
     dev.sync()
     print("rank %d/%d: %d planes in sub-slabs of %d, pass %d: %.3f s" % (rank, world, planes, sub, it, time.perf_counter() - t0),
           {k: round(v, 4) for k, v in timers.items()}, "nnz(K_loc) =", K.nnz, flush=True)
+    if it == int(os.environ.get("PASSES", "2")) - 1:
+        # the product of the Krylov solve on this rank's row block (x addressed by global column)
+        x = dev.DeviceVector(data=np.random.default_rng(0).standard_normal(K.shape[1]))
+        y = dev.DeviceVector(K.shape[0])
+        for label, en in (("CSR", False), ("sliced copy", True)):
+            info = K.spmv_sell(en)
+            K.mult(x, y); dev.sync()
+            dev.timer_start(0)
+            for _ in range(20):
+                K.mult(x, y)
+            ms = dev.timer_stop(0) / 20
+            print("  K_loc x on %s %s: %.3f ms" % (label, info, ms), flush=True)
+        K.spmv_sell(False)
     del K, rhs
