@@ -292,7 +292,7 @@ def main():
                               "= moved_GBps, moved_frac_of_peak of the 8 TB/s peak, and frac can exceed that")
                      if sell else None},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and max(args.gpus, world) == 1:      # (rank 0 at N=1 only: the other ranks would wait for it)
         # a bounded sample: seconds of work on the 16 cores the GPU box grants (the A*M intermediate of
         # the Gustavson PtAP needs ~7 GB of host memory at p=3, 40^3 elements)
         cpu_nel = args.cpu_nel or ({2: 80, 3: 40, 4: 16}.get(p, 16) if d == 3 else min(nel, 256))
