@@ -2,16 +2,23 @@
 """
 bench.py -- tIGAr extraction hot path on MI355X: extraction-operator build (generateM) ->
 M^T A M + M^T b (extractMatrix / extractVector) -> Krylov solve (solveLinearSystem), on a
-synthetic tensor-product B-spline Poisson patch.
+synthetic tensor-product B-spline Poisson patch, driven through the
+reference's own API surface (EqualOrderSpline -> ExtractedSpline -> assembleMatrix / assembleVector
+-> solveLinearSystem) for every workload and rank count.
 
     python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg3|auto]
 
-One "step" = one full pass of the hot path over the patch.  FE-side inputs (A, b: FEniCS's
-job in the reference) are generated on the device BEFORE the timed region and are resident in
-HBM when it starts whenever they fit (cfg2); for cfg3 (A = 684 GB) they are regenerated per
-z-sub-slab inside the timed region and their time is reported separately.  Default workload:
-cfg3 = 3D 256^3 p=3 (the configuration BASELINE.json's metric is quoted on), streamed through
-one GPU in z-slabs or sharded over N GPUs.  Rank 0 prints ONE JSON line.
+One "step" = one full pass of the hot path over the patch: generator construction (1-D tables, M or
+its implicit form, control functions), explicit/implicit M^T, M^T A M with boundary conditions, M^T b,
+Jacobi-CG, prolongation u = M U.  FE-side inputs (A, b: FEniCS's job in the reference) are resident in
+HBM when the timed region starts whenever they fit (cfg2: A 13 GB; b always); cfg3's A (684 GB) is
+produced per z-sub-slab inside the timed region and its time is reported separately.  Default
+workload: cfg3 = 3D 256^3 p=3 (the configuration BASELINE.json's metric is quoted on).
+
+N > 1: one process per GPU.  Launched by `python -m torch.distributed.run` (RANK / WORLD_SIZE /
+LOCAL_RANK / MASTER_* in the environment) the script is one rank; launched plainly with --gpus N it
+spawns the N ranks itself.  The patch is split into z-slabs of dof planes; `n_gpus` and
+`parallelism` are what the communicator reports, not what argv asked for.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -52,98 +59,142 @@ def spmv_bytes(nnzK, ncp):
     return 12 * nnzK + 4 * (ncp + 1) + 16 * ncp
 
 
-# ------------------------------------------------------------------------------------ 1 GPU
-def run_single(args, d, p, nel):
+# ------------------------------------------------------------------------------------ the path
+def run(args, d, p, nel):
     from tigar_amd import device as dev
-    from tigar_amd.common import (EqualOrderSpline, ExtractedSpline, PETScKrylovSolver, Function,
-                                  TensorFunctionSpace)
+    from tigar_amd import common as tc
+    from tigar_amd.common import EqualOrderSpline, ExtractedSpline, PETScKrylovSolver, Function, TensorFunctionSpace
     from tigar_amd.BSplines import ExplicitBSplineControlMesh, uniformKnots
     from tigar_amd.forms import LaplaceForm, SeparableLoadForm
 
-    info = dev.device_info()
-    log("[bench] device:", info)
+    comm = tc.worldcomm                       # size / rank from the launcher's environment
+    rank, world = comm.rank, comm.size
+    transport = comm.transport()
+    dcomm = comm.device()                     # RCCL (or host-staged) communicator, None on one rank
+    if rank == 0:
+        log("[bench] device:", dev.device_info(), "ranks", world,
+            "communicator", dcomm.info() if dcomm is not None else None)
     kvecs = [uniformKnots(p, 0.0, 1.0, nel) for _ in range(d)]
     controlMesh = ExplicitBSplineControlMesh([p] * d, kvecs)
     basis = controlMesh.getScalarSpline()
+    lap = LaplaceForm()
+    f1 = lambda x: np.sin(np.pi * x)
+    load = SeparableLoadForm([f1] * d, scale=d * np.pi ** 2)
 
-    # ---- FE-side inputs, resident in HBM before the timed region (not part of the path)
+    # ---- FE-side inputs resident in HBM before the timed region, when they fit (not part of the path)
+    cnt = counts(d, p, nel)
     t0 = time.perf_counter()
     V_in = TensorFunctionSpace([basis.generateMesh(degree=p)], "Lagrange")
-    A = LaplaceForm().assemble_matrix(V_in)
-    f1 = lambda x: np.sin(np.pi * x)
-    b = SeparableLoadForm([f1] * d, scale=d * np.pi ** 2).assemble_vector(V_in)
+    free_b, _ = dev.mem_info()
+    a_resident = world == 1 and args.slab != 1 and \
+        12.0 * (2 * cnt["nnzM"] + cnt["nnzA"] + 2 * cnt["nnzK"]) <= 0.6 * free_b
+    A_in = lap.assemble_matrix(V_in) if a_resident else None
+    b_in = load.assemble_vector(V_in) if world == 1 else None
     dev.sync()
-    t_input = time.perf_counter() - t0
-    log("[bench] inputs: A %s nnz %d, b %d  (%.3f s, untimed)" % (A.shape, A.nnz, b.size(), t_input))
+    t_input_pre = time.perf_counter() - t0
+    if not a_resident:
+        os.environ["TIGAR_IMPLICIT_M"] = "1"        # A arrives in row blocks: M stays implicit, K is built slab by slab
+    if rank == 0:
+        log("[bench] inputs resident before the timed region: A %s, b %s (%.3f s, untimed)"
+            % ("yes" if a_resident else "no (row blocks produced inside the step)",
+               "yes" if b_in is not None else "no (rank-local rows produced inside the step)", t_input_pre))
 
     stages = {}
+    state = {}
 
     def step(record):
         ts = [time.perf_counter()]
+        rec = {}
 
         def mark(name):
             dev.sync()
             ts.append(time.perf_counter())
-            if record:
-                stages.setdefault(name, []).append(ts[-1] - ts[-2])
+            rec[name] = ts[-1] - ts[-2]
 
-        gen = EqualOrderSpline(1, controlMesh)             # generateM_control / generateM / cpFuncs
+        gen = EqualOrderSpline(comm, 1, controlMesh)       # generateM_control / generateM (or implicit) / cpFuncs
         sp_ = gen.getScalarSpline(0)
         for direction in range(d):
             for side in (0, 1):
                 gen.addZeroDofs(0, sp_.getSideDofs(direction, side))
         mark("extract")
-        spline = ExtractedSpline(gen, 2 * p)               # explicit M^T
+        spline = ExtractedSpline(gen, 2 * p)               # M^T
         mark("transpose")
-        K = spline.extractMatrix(A)                        # M^T A M + zeroRowsColumns
+        spline.stage_timers = {}
+        K = spline.extractMatrix(A_in) if a_resident else spline.assembleMatrix(lap)   # M^T A M + zeroRowsColumns
         mark("ptap")
-        rhs = spline.extractVector(b)                      # M^T b + BCs
+        rhs = spline.extractVector(b_in) if b_in is not None else spline.assembleVector(load)   # M^T b + BCs
         mark("mtb")
         solver = PETScKrylovSolver("cg", "jacobi")
         solver.parameters["relative_tolerance"] = args.rtol
         spline.setSolverOptions(linearSolver=solver)
-        u = Function(spline.V)
+        u = Function(spline.V, spline.localFERange() if world > 1 else None)
         U = spline.solveLinearSystem(K, rhs, u)            # CG + prolongation u = M U
         mark("solve")
-        return gen, spline, K, U, u, solver
+        t_in = spline.stage_timers.get("input", 0.0)
+        rec["fe_input"] = t_in
+        rec["ptap"] -= t_in
+        if record:
+            for k, v in rec.items():
+                stages.setdefault(k, []).append(v)
+        state.update(gen=gen, spline=spline, K=K, U=U, u=u, solver=solver)
+        if os.environ.get("TIGAR_TRACE"):
+            pb, nb, nl = dev.pool_stats()
+            fr, tot = dev.mem_info()
+            log("[bench] pool: %.1f GB free in %d blocks, %d blocks live; device free %.1f GB; sub-slab timers %s"
+                % (pb / 2 ** 30, nb, nl, fr / 2 ** 30, {k: round(v, 4) for k, v in spline.stage_timers.items()}))
+
+    def barrier():
+        dev.sync()
+        transport.barrier()
 
     for _ in range(args.warmup):
-        out = step(False)
-        del out
+        state.clear()        # (the previous step's K must not stay alive beside the one being assembled)
+        step(False)
     dev.prof_reset()
-    dev.sync()
+    barrier()
     t_start = time.perf_counter()
-    last = None
     for _ in range(args.steps):
-        last = None
-        last = step(True)
-    dev.sync()
-    elapsed = time.perf_counter() - t_start
-    gen, spline, K, U, u, solver = last
-    ncp = K.shape[0]
-    nnzK = K.nnz
+        state.clear()
+        step(True)
+    barrier()
+    elapsed = transport.allreduce_max(time.perf_counter() - t_start)
+
+    gen, spline, K, u, solver = state["gen"], state["spline"], state["K"], state["u"], state["solver"]
+    ncp = gen.getNcp(0)
+    nnzK_local, ncp_local = K.nnz, K.shape[0]
+    nnzK = nnzK_local if dcomm is None else int(round(dcomm.allreduce_sum([float(nnzK_local)])[0]))
     spmv_ms, spmv_n = dev.prof_get(0)
-    Kd = K if hasattr(K, "spmv_sell") else None
-    sell_classes, sell_padded = (0, 0)
-    if Kd is not None:
-        sell_classes, sell_padded = Kd.spmv_sell(True)
-        Kd.spmv_sell(False)
+    sell_classes, sell_padded = K.spmv_sell(True)         # which product kernel the solver used
+    K.spmv_sell(False)
     its = solver.last["iterations"]
-    log("[bench] stages (mean s):", {k: round(float(np.mean(v)), 5) for k, v in stages.items()},
-        "CG iterations:", its, "nnz(K):", nnzK, "nnz(M):", gen.M.nnz)
+    mean_stages = {k: float(np.mean(v)) for k, v in stages.items()}
 
-    # sanity: manufactured solution u = prod sin(pi x_k) at the FE nodes
-    if args.check:
-        X = spline.V.grids[0].coordinates() if ncp < 3e6 else None
-        if X is not None:
-            uh = u.vector().get_local()
-            exact = np.prod(np.sin(np.pi * X), axis=1)
-            log("[bench] max nodal error vs manufactured solution: %.3e" % np.max(np.abs(uh - exact)))
-
-    result = {"ncp": ncp, "nnzK": nnzK, "elapsed": elapsed, "spmv_ms_total": spmv_ms, "spmv_count": spmv_n,
-              "iterations": its, "stages": {k: float(np.mean(v)) for k, v in stages.items()},
-              "t_input": t_input, "sell_padded": sell_padded, "sell_classes": sell_classes}
-    return result
+    if args.check and rank == 0:
+        # manufactured solution u = prod sin(pi x_k) at the FE nodes this rank owns
+        grid = spline.V.grids[0]
+        r0, r1 = spline.localFERange()
+        n0 = grid.shape()
+        uh = u.vector().get_local()
+        # every node for small problems, every 97th for large ones (cfg3: 4.7 M of 455 M nodes)
+        idx = np.arange(r0, r1) if uh.size <= 40e6 else np.arange(r0, r1, 97)
+        uh = uh if uh.size <= 40e6 else uh[idx - r0]
+        exact = np.ones(idx.size)
+        stride = 1
+        for k in range(d):
+            exact *= np.sin(np.pi * grid.axes[k][(idx // stride) % n0[k]])
+            stride *= n0[k]
+        log("[bench] max nodal error vs manufactured solution (rank 0 rows): %.3e" % np.max(np.abs(uh - exact)))
+    if rank == 0:
+        log("[bench] stages (mean s):", {k: round(v, 5) for k, v in mean_stages.items()}, "CG iterations:", its,
+            "nnz(K) global:", nnzK, "M implicit:", bool(getattr(gen.M, "is_implicit", False)))
+    info = dcomm.info() if dcomm is not None else (0, 1, "none")
+    ndev = dev.device_count()
+    return {"ncp": ncp, "nnzK": nnzK, "nnzK_local": nnzK_local, "ncp_local": ncp_local, "elapsed": elapsed,
+            "spmv_ms_total": spmv_ms, "spmv_count": spmv_n, "iterations": its, "stages": mean_stages,
+            "t_input": mean_stages.get("fe_input", 0.0), "t_input_in_timed_region": not a_resident,
+            "t_input_pre": t_input_pre, "sub_planes": spline._slab.sub_planes if spline._slab is not None else None,
+            "sell_classes": sell_classes, "sell_padded": sell_padded, "implicit_M": bool(getattr(gen.M, "is_implicit", False)),
+            "comm_world": info[1], "comm_kind": info[2], "n_devices_used": min(info[1], ndev) if info[1] > 1 else 1}
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
@@ -207,12 +258,19 @@ def main():
     ap.add_argument("--check", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nel", type=int, default=0)
-    ap.add_argument("--sub-planes", type=int, default=0, help="dof planes per streamed sub-slab (0 = auto)")
-    ap.add_argument("--slab", type=int, default=-1, help="1: force the z-slab streaming path on one GPU")
+    ap.add_argument("--slab", type=int, default=-1, help="1: force the implicit-M / z-slab streaming path on one GPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched plainly: become the launcher of N ranks (one per GPU), like torch.distributed.run would
+        from tigar_amd.launch import spawn_local
+        sys.exit(spawn_local(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        log("[bench] note: --gpus %d but the launcher started %d ranks; reporting what the communicator spans"
+            % (args.gpus, world))
     wl = args.workload
     if wl == "auto":
         wl = "cfg3"        # the configuration BASELINE.json's metric is quoted on (256^3, p=3)
@@ -225,74 +283,73 @@ def main():
         d = args.d
     cnt = counts(d, p, nel)
 
-    # M + M^T + A + K resident at once needs ~ (2*nnzM + nnzA + 2*nnzK) * 12 B: stream in z-slabs
-    # when that does not fit in ~60% of HBM (cfg3), or when asked to
-    resident_bytes = 12.0 * (2 * cnt["nnzM"] + cnt["nnzA"] + 2 * cnt["nnzK"])
-    use_slab = (args.gpus > 1 or world > 1 or args.slab == 1 or (args.slab != 0 and resident_bytes > 0.6 * 288e9))
-    if use_slab:
-        from bench_dist import run_distributed       # z-slab pipeline (+ RCCL when world > 1)
-        res = run_distributed(args, d, p, nel, rank, world)
-    else:
-        res = run_single(args, d, p, nel)
+    res = run(args, d, p, nel)
     if rank != 0:
         return
 
+    n_gpus = res["n_devices_used"]
     ms_per_step = 1e3 * res["elapsed"] / args.steps
     value = res["ncp"] / (res["elapsed"] / args.steps)
     spmv_avg_s = (res["spmv_ms_total"] / max(res["spmv_count"], 1)) * 1e-3
-    alg_bytes = spmv_bytes(res["nnzK_local"] if "nnzK_local" in res else res["nnzK"],
-                           res["ncp_local"] if "ncp_local" in res else res["ncp"])
-    achieved = alg_bytes / spmv_avg_s / 1e9 if spmv_avg_s > 0 else 0.0
-    # HBM traffic of the SpMV from the PMC passes (collected separately with rocprofv3 --pmc, as the
-    # microarchitecture guide prescribes; committed under profiles/): only quoted for the workload
-    # and GPU count it was measured on
-    traffic = None
+    ncp_l, nnzK_l = res["ncp_local"], res["nnzK_local"]
+    csr_bytes = spmv_bytes(nnzK_l, ncp_l)
     sell = res.get("sell_padded", 0) > 0 and os.environ.get("TIGAR_SPMV_SELL", "1") != "0"
     kernel = "k_spmv_sell" if sell else "k_spmv_lane"
+    # bytes the product kernel has to move in ITS format: the sliced copy streams 8 B per stored position
+    # (values only; the offset dictionary is cache resident), class id + address per slice, x once and y once;
+    # the general CSR kernel moves SURVEY.md section 8(d)'s CSR bytes
+    fmt_bytes = (8.0 * res["sell_padded"] + 12.0 * ((ncp_l + 63) // 64) + 16.0 * ncp_l) if sell else float(csr_bytes)
+    achieved = fmt_bytes / spmv_avg_s / 1e9 if spmv_avg_s > 0 else 0.0
+    # HBM traffic of this kernel from the PMC passes (rocprofv3 --pmc in separate runs, as the microarchitecture
+    # guide prescribes; committed under profiles/): an OFFLINE measurement, quoted only for the workload and
+    # rank count it was taken on
+    traffic, traffic_src = None, None
     pmc_file = os.path.join(ROOT, "profiles", "r1_spmv_pmc_summary.json")
-    if wl == "cfg3" and max(args.gpus, world) == 1 and not args.nel and os.path.exists(pmc_file):
+    if wl == "cfg3" and res["comm_world"] == 1 and not args.nel and not args.p and os.path.exists(pmc_file):
         try:
             pmc = json.load(open(pmc_file))
-            traffic = pmc["hbm_bytes_per_launch"] if kernel in pmc["kernel"] else None
+            if kernel in pmc["kernel"]:
+                traffic = pmc["hbm_bytes_per_launch"]
+                traffic_src = ("offline: profiles/r1_spmv_pmc_summary.json (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 "
+                               "correction + WRITE_SIZE, separate passes; not measured in this run)")
         except Exception:
             traffic = None
-    # bytes the product kernel has to move in ITS format: the sliced copy streams 8 B per stored
-    # position (values only; the offset dictionary is cache resident), class id + offset per slice,
-    # x once and y once -- against SURVEY.md section 8(d)'s CSR figure (12 B per entry) in `achieved`
-    ncp_l = res["ncp_local"] if "ncp_local" in res else res["ncp"]
-    fmt_bytes = (8.0 * res["sell_padded"] + 12.0 * ((ncp_l + 63) // 64) + 16.0 * ncp_l) if sell else alg_bytes
+    par = "z-slab x%d ranks on %d GPU%s (%s)" % (res["comm_world"], n_gpus, "s" if n_gpus > 1 else "", res["comm_kind"]) \
+        if res["comm_world"] > 1 else "1 GPU"
     out = {
         "metric": "DoF/s (extraction + M^T A M + M^T b + CG solve + prolongation)",
-        "value": value, "unit": "DoF/s", "n_gpus": max(args.gpus, world), "steps": args.steps,
+        "value": value, "unit": "DoF/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %dD %d^%d elements p=%d B-spline Poisson, Q_p extraction, "
                                "Jacobi-CG rtol %.0e" % (wl, d, nel, d, p, args.rtol),
+                   "api": "EqualOrderSpline -> ExtractedSpline.assembleMatrix/extractMatrix, assembleVector/"
+                          "extractVector, solveLinearSystem(PETScKrylovSolver('cg','jacobi'))",
                    "dofs": res["ncp"], "fe_rows": cnt["rows_fe"], "nnz_M": cnt["nnzM"], "nnz_A": cnt["nnzA"],
                    "nnz_K": res["nnzK"], "cg_iterations": res["iterations"],
+                   "M_implicit": res["implicit_M"],
                    "stages_s": {k: round(v, 6) for k, v in res["stages"].items()},
                    "fe_input_generation_s": round(res["t_input"], 6),
-                   "fe_input_inside_timed_region": bool(res.get("t_input_in_timed_region", False)),
+                   "fe_input_inside_timed_region": bool(res["t_input_in_timed_region"]),
                    "value_excluding_fe_input": res["ncp"] / max(1e-12, res["elapsed"] / args.steps
-                                                                - (res["t_input"] if res.get("t_input_in_timed_region") else 0.0)),
+                                                                - (res["t_input"] if res["t_input_in_timed_region"] else 0.0)),
                    "sub_planes": res.get("sub_planes"),
-                   "parallelism": "z-slab x%d" % max(args.gpus, world)},
-        "roofline": {"bound": "hbm", "kernel": "%s (K p in CG)" % kernel, "achieved": achieved,
+                   "ranks": res["comm_world"], "communicator": res["comm_kind"],
+                   "parallelism": par},
+        "roofline": {"bound": "hbm", "kernel": "%s (K u in CG)" % kernel, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": "profiles/r1_spmv_pmc_summary.json (rocprofv3 --pmc "
-                     "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)" if traffic else None,
-                     "launches": res["spmv_count"],
-                     "avg_launch_ms": spmv_avg_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
-                     "format_bytes_per_launch": fmt_bytes,
-                     "moved_GBps": fmt_bytes / spmv_avg_s / 1e9 if spmv_avg_s > 0 else 0.0,
-                     "moved_frac_of_peak": fmt_bytes / spmv_avg_s / 1e9 / HBM_PEAK_GBS if spmv_avg_s > 0 else 0.0,
-                     "note": ("achieved/frac are quoted on the CSR bytes of SURVEY.md 8(d) (12 B per entry) as the "
-                              "contract asks; the kernel streams a sliced, pattern-compressed copy of the values "
-                              "(8 B per stored position, no column indices), so it moves format_bytes_per_launch "
-                              "= moved_GBps, moved_frac_of_peak of the 8 TB/s peak, and frac can exceed that")
-                     if sell else None},
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "launches": res["spmv_count"], "avg_launch_ms": spmv_avg_s * 1e3,
+                     "bytes_per_launch": fmt_bytes,
+                     "bytes_definition": ("sliced, pattern-compressed copy of K's values: 8 B per stored position + "
+                                          "12 B per 64-row slice + x read once + y written once (what this kernel "
+                                          "must move; no column indices are streamed)") if sell else
+                                         "CSR: 12 B per entry + row pointers + x + y (SURVEY.md 8d)",
+                     "csr_bytes_per_launch": csr_bytes,
+                     "effective_csr_GBps": csr_bytes / spmv_avg_s / 1e9 if spmv_avg_s > 0 else 0.0,
+                     "effective_csr_frac_of_peak": csr_bytes / spmv_avg_s / 1e9 / HBM_PEAK_GBS if spmv_avg_s > 0 else 0.0},
     }
-    if not args.no_cpu_baseline and max(args.gpus, world) == 1:      # (rank 0 at N=1 only: the other ranks would wait for it)
+    if not args.no_cpu_baseline and res["comm_world"] == 1:      # (rank 0 at N=1 only: the other ranks would wait for it)
         # a bounded sample: seconds of work on the 16 cores the GPU box grants (the A*M intermediate of
         # the Gustavson PtAP needs ~7 GB of host memory at p=3, 40^3 elements)
         cpu_nel = args.cpu_nel or ({2: 80, 3: 40, 4: 16}.get(p, 16) if d == 3 else min(nel, 256))

@@ -65,6 +65,8 @@ int tg_vec_copy_range(tg_vec_t dst, int64_t dst_off, tg_vec_t src, int64_t src_o
 int tg_vec_axpy(tg_vec_t y, double a, tg_vec_t x);          /* y += a x */
 int tg_vec_dot(tg_vec_t x, tg_vec_t y, double *out);        /* deterministic two-stage */
 int tg_vec_pointwise_mult(tg_vec_t w, tg_vec_t x, tg_vec_t y);   /* w = x .* y (VecPointwiseMult) */
+/* GenericVector::norm: kind 0 = "l1", 1 = "l2", 2 = "linf" (tIGAr/common.py:1330 norm(MTb)) */
+int tg_vec_norm(tg_vec_t x, int kind, double *out);
 /* as_backend_type(MTb).vec().setValues(zeroDofs, 0)  -- tIGAr/common.py:1154-1158 */
 int tg_vec_zero_entries(tg_vec_t y, const int32_t *dofs, int64_t n);
 /* same for a slab-local vector holding global entries [g0, g0 + size(y)) */
@@ -78,6 +80,10 @@ int tg_csr_from_host(int64_t nrows, int64_t ncols, const int64_t *rowptr,
                      const int32_t *col, const double *val, tg_csr_t *out);
 int tg_csr_dims(tg_csr_t m, int64_t *nrows, int64_t *ncols, int64_t *nnz);
 int tg_csr_download(tg_csr_t m, int64_t *rowptr, int32_t *col, double *val);
+/* rows [r0,r1) only: rowptr_out[r1-r0+1] relative to the first entry; col/val NULL = sizes only (two-call
+ * protocol).  PETSc counterpart: MatGetRow on a row sample of MTAM (tIGAr/common.py:1194-1204) [ext]. */
+int tg_csr_download_rows(tg_csr_t m, int64_t r0, int64_t r1, int64_t *rowptr_out, int32_t *col, double *val,
+                         int64_t cap);
 int tg_csr_destroy(tg_csr_t m);
 /* explicit M^T (the reference's FORM_MT switch, tIGAr/common.py:84,358-360);
  * deterministic: rows of M^T sorted by FE row index. */
@@ -222,10 +228,17 @@ int tg_csr_combine(double a, tg_csr_t X, double b, tg_csr_t Y, tg_vec_t colscale
 /* ---- Krylov solve (solveLinearSystem, tIGAr/common.py:1236-1263; seam b-4) -------- */
 enum { TG_KSP_CG = 0, TG_KSP_GMRES = 1 };
 enum { TG_PC_NONE = 0, TG_PC_JACOBI = 1 };
-/* status: 0 converged (rtol), 1 converged (atol), -1 max iterations, -2 breakdown/NaN */
+/* status: 0 converged (rtol), 1 converged (atol), -1 max iterations, -2 breakdown/NaN,
+ * -3 stagnation (GMRES: 25 restart cycles in a row without progress) */
 int tg_krylov_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, int pc, double rtol,
                     double atol, int maxit, int restart, tg_comm_t comm, int *iters,
                     double *resnorm, int *status);
+/* same with flags: TG_KSP_NONZERO_GUESS = x holds the initial guess (dolfin's solver parameter
+ * "nonzero_initial_guess" [ext]; the convergence test stays relative to ||B b||, PETSc's default) */
+enum { TG_KSP_NONZERO_GUESS = 1 };
+int tg_krylov_solve_flags(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, int pc, double rtol,
+                          double atol, int maxit, int restart, int flags, tg_comm_t comm, int *iters,
+                          double *resnorm, int *status);
 
 /* ---- synthetic FE-side input (NOT on the timed path) --------- */
 /* A = sum_t (x)_k F[t][k] with 1-D CSR factors sharing one pattern per direction
@@ -279,6 +292,18 @@ int tg_assemble_mapped_load(const tg_patch_t *patch, tg_vec_t fnodal, tg_vec_t o
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------- */
 int tg_comm_unique_id(char *id128);                          /* ncclGetUniqueId   */
 int tg_comm_create(const char *id128, int rank, int world, tg_comm_t *out);
+/* Host-staged communicator: the same solver code, its two exchanges (halo pieces with the z-neighbours,
+ * sums of a few doubles over all ranks) staged through pinned host memory and carried by the caller's
+ * transport (MPI-style callbacks; 0 = ok).  For process groups RCCL cannot form (ranks sharing a GPU).
+ * PETSc counterparts: VecScatter in MatMult, MPI_Allreduce in VecDot/VecNorm (tIGAr/common.py:1255-1258). */
+typedef int (*tg_host_allreduce_fn)(void *ctx, double *inout, int n);
+typedef int (*tg_host_sendrecv_fn)(void *ctx, int peer, const double *send, int64_t nsend, double *recv,
+                                   int64_t nrecv);
+int tg_comm_create_host(int rank, int world, tg_host_allreduce_fn allreduce, tg_host_sendrecv_fn sendrecv,
+                        void *ctx, tg_comm_t *out);
+/* ranks the communicator really spans (RCCL: ncclCommCount) and its kind (0 = RCCL, 1 = host-staged) */
+int tg_comm_info(tg_comm_t c, int *rank, int *world, int *kind);
+int tg_device_count(int *n);                                 /* visible GPUs      */
 /* z-slab descriptor of the Krylov vectors: this rank owns global dofs [g0,g1); the SpMV
  * needs halo_lo dofs below g0 (owned by rank-1) and halo_hi above g1 (rank+1). */
 int tg_comm_set_slab(tg_comm_t c, int64_t g0, int64_t g1, int64_t halo_lo, int64_t halo_hi,

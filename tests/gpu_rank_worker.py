@@ -1,0 +1,53 @@
+"""One rank of the multi-rank -m gpu tests (launched by tigar_amd.launch.spawn_local from
+tests/test_gpu_multirank.py): the hot path through the public API on a patch split into z-slabs,
+rank-local results written to ``outdir/rank<r>.npz`` for comparison with the single-rank run."""
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    outdir, d, p, nel, method = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    import tigar_amd as t
+    from tigar_amd import common as tc, BSplines as B, forms as F
+    comm = tc.worldcomm
+    dcomm = comm.device()
+    rank_r, world_r, kind = dcomm.info()
+    kv = [B.uniformKnots(p, 0., 1., nel) for _ in range(d)]
+    gen = t.EqualOrderSpline(comm, 1, B.ExplicitBSplineControlMesh([p] * d, kv))
+    assert getattr(gen.M, "is_implicit", False)          # several ranks: no rank holds all rows of M
+    sp0 = gen.getScalarSpline(0)
+    for direction in range(d):
+        for side in (0, 1):
+            gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    K = spline.assembleMatrix(F.LaplaceForm(), diag=1.5)
+    f1 = lambda x: np.sin(np.pi * x)
+    rhs = spline.assembleVector(F.SeparableLoadForm([f1] * d, scale=d * np.pi ** 2))
+    solver = t.PETScKrylovSolver(method, "jacobi")
+    solver.parameters["relative_tolerance"] = 1e-10
+    spline.setSolverOptions(linearSolver=solver)
+    u = t.Function(spline.V, spline.localFERange())
+    U = spline.solveLinearSystem(K, rhs, u)
+    # second solve from the converged state: must stop at once (non-zero initial guess path with halo)
+    solver.parameters["nonzero_initial_guess"] = True
+    from tigar_amd.device import DeviceVector
+    U2 = DeviceVector(data=U.get_local())
+    its2 = solver.solve(K, U2, rhs)
+    Ks = K.to_scipy()
+    g0, g1 = spline.localDofRange()
+    r0, r1 = spline.localFERange()
+    cp0 = gen.cpFuncs[0].vector().get_local()
+    np.savez(os.path.join(outdir, "rank%d.npz" % comm.rank), g=np.array([g0, g1, r0, r1]),
+             K_indptr=Ks.indptr, K_indices=Ks.indices, K_data=Ks.data, rhs=rhs.get_local(), U=U.get_local(),
+             u=u.vector().get_local(), its=np.array([solver.last["iterations"], its2]),
+             comm=np.array([rank_r, world_r, 0 if kind == "rccl" else 1]), cp0=cp0,
+             U2=U2.get_local())
+    comm.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,12 +96,23 @@ def test_gloo_world2_distributed_cg_pattern():
     assert "DIST_OK" in out.stdout
 
 
+def test_socket_transport_world2_distributed_cg_pattern():
+    """The same pattern carried by the product's own launcher and TCP transport
+    (tigar_amd.launch.spawn_local + SocketTransport: what bench.py --gpus N and the host-staged device
+    communicator use)."""
+    sys.path.insert(0, ROOT)
+    from tigar_amd.launch import spawn_local
+    env = {"PYTHONPATH": ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")}
+    rc = spawn_local(2, [os.path.join(ROOT, "tests", "dist_cpu_worker.py"), "socket"], env_extra=env, port=29877)
+    assert rc == 0
+
+
 def _rdv_worker(rank, world, port, q):
     import os
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
-    from bench_dist import HostRendezvous
+    from tigar_amd.launch import HostRendezvous
     r = HostRendezvous(rank, world)
     data = r.broadcast_bytes(bytes(range(128)) if rank == 0 else None, 128)
     m = r.allreduce_max(float(rank) * 1.5)
@@ -110,7 +121,7 @@ def _rdv_worker(rank, world, port, q):
 
 
 def test_host_rendezvous_three_ranks():
-    """The launcher-side TCP rendezvous of bench_dist.py (RCCL id broadcast, barrier, max)."""
+    """The launcher-side TCP transport of tigar_amd/launch.py (RCCL id broadcast, barrier, max)."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -105,27 +105,45 @@ def _refine_control_net(coarse_spline, fine_spline, Pw):
     return np.linalg.solve(Nf, Nc @ Pw)
 
 
-def test_cfg5_nurbs_geometry_three_fields_gmres(T):
+def _elevate(Pw):
+    """degree elevation by one of a Bezier curve given by homogeneous control points [n+1, c]"""
+    n = Pw.shape[0] - 1
+    out = np.zeros((n + 2, Pw.shape[1]))
+    out[0], out[-1] = Pw[0], Pw[-1]
+    for i in range(1, n + 1):
+        a = i / float(n + 1)
+        out[i] = a * Pw[i - 1] + (1.0 - a) * Pw[i]
+    return out
+
+
+@pytest.mark.parametrize("p,nel", [(2, 6), (3, 128)])
+def test_cfg5_nurbs_geometry_three_fields_gmres(T, p, nel):
     """Quarter annulus (exact circular arcs need rational weights): the weights enter only
     through cpFuncs = M_control * (homogeneous control net); three unknown fields; non-symmetric
-    diagonally dominant FE matrix on the 3-field pattern solved with Jacobi-GMRES."""
+    diagonally dominant FE matrix on the 3-field pattern solved with Jacobi-GMRES.
+    (3, 128) is BASELINE cfg5 at its full size: 128 x 128 elements, p=3, 3 fields, 444 675 FE rows,
+    51 483 DoFs, nnz(A) = 33 212 169 over the 9 field blocks."""
     t, N, dev = T.t, T.N, T.dev
-    p, nel = 2, 6
-    # coarse exact geometry: radial (linear, degree-elevated to 2) x angular (quadratic arc)
+    # coarse exact geometry: radial (linear) x angular (quadratic rational arc), degree-elevated to p
     w = 1.0 / np.sqrt(2.0)
     arc = np.array([[1.0, 0.0, 1.0], [w, w, w], [0.0, 1.0, 1.0]])         # (w x, w y, w), radius 1
-    rad = np.array([1.0, 1.5, 2.0])                                         # radii 1..2, degree 2 (collinear)
-    coarse = [O.BSpline1(p, [0, 0, 0, 1, 1, 1]) for _ in range(2)]
+    rad = np.array([[1.0], [2.0]])                                          # radii 1..2, linear
+    while arc.shape[0] < p + 1:
+        arc = _elevate(arc)
+    while rad.shape[0] < p + 1:
+        rad = _elevate(rad)
+    rad = rad[:, 0]
+    coarse = [O.BSpline1(p, [0] * (p + 1) + [1] * (p + 1)) for _ in range(2)]
     fine_kv = O.uniform_knots(p, 0., 1., nel)
     fine = [O.BSpline1(p, fine_kv) for _ in range(2)]
     # control net [i (radial), j (angular), (wx, wy, w)]
-    Pw = np.zeros((3, 3, 3))
-    for i in range(3):
+    Pw = np.zeros((p + 1, p + 1, 3))
+    for i in range(p + 1):
         Pw[i, :, 0] = rad[i] * arc[:, 0]
         Pw[i, :, 1] = rad[i] * arc[:, 1]
         Pw[i, :, 2] = arc[:, 2]
     # refine direction by direction
-    Pr = np.stack([_refine_control_net(coarse[0], fine[0], Pw[:, j, :]) for j in range(3)], axis=1)
+    Pr = np.stack([_refine_control_net(coarse[0], fine[0], Pw[:, j, :]) for j in range(p + 1)], axis=1)
     Pf = np.stack([_refine_control_net(coarse[1], fine[1], Pr[i, :, :]) for i in range(Pr.shape[0])], axis=0)
     cm = N.NURBSControlMesh([p, p], [fine_kv, fine_kv], Pf)
     gen = t.EqualOrderSpline(3, cm)
@@ -136,12 +154,14 @@ def test_cfg5_nurbs_geometry_three_fields_gmres(T):
     X, _ = O.fe_node_grid(s)
     cp = [f.vector().get_local() for f in gen.cpFuncs]
     x, y, wt = cp[0] / cp[2], cp[1] / cp[2], cp[2]
-    assert np.max(np.abs(np.hypot(x, y) - (1.0 + X[:, 0]))) < 1e-13
+    assert np.max(np.abs(np.hypot(x, y) - (1.0 + X[:, 0]))) < 1e-12
     assert wt.min() > 0.7 and wt.max() <= 1.0 + 1e-14
+    if nel == 128:
+        assert gen.M.shape == (444675, 51483) and gen.M.nnz == 5938947
     Mc = O.generate_M_tensor(s)
     bnet = np.stack([Pf[..., c].ravel(order="F") for c in range(3)], axis=1)
     for c in range(3):
-        assert np.max(np.abs(cp[c] - Mc @ bnet[:, c])) < 1e-13
+        assert np.max(np.abs(cp[c] - Mc @ bnet[:, c])) < 1e-13 * max(1.0, np.max(np.abs(bnet[:, c])))
     # three-field extraction matrix = block diagonal of the scalar one
     Mo = O.generate_M_tensor(s, nfields=3)
     M = gen.M.to_scipy()
@@ -163,6 +183,8 @@ def test_cfg5_nurbs_geometry_three_fields_gmres(T):
             blocks[a][b] = Bk
         blocks[a][a] = blocks[a][a] + sp.identity(n1) * 4.0
     A = sp.bmat(blocks, format="csr")
+    if nel == 128:
+        assert A.nnz == 33212169
     bvec = rng.standard_normal(A.shape[0])
     solver = t.PETScKrylovSolver("gmres", "jacobi")
     solver.parameters["relative_tolerance"] = 1e-11
@@ -173,7 +195,11 @@ def test_cfg5_nurbs_geometry_three_fields_gmres(T):
     U = spline.solveLinearSystem(K, rhs, u)
     zd = list(spline.zeroDofs)
     Ko = O.extract_matrix(Mo, A, zd)
-    assert abs(K.to_scipy() - Ko).max() <= 1e-12 * abs(Ko).max()
+    Ks = K.to_scipy()
+    assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
+    if nel == 128:
+        assert Ks.nnz == 7371225
+    assert abs(Ks - Ko).max() <= 1e-12 * abs(Ko).max()
     Uo = spla.spsolve(Ko.tocsc(), O.extract_vector(Mo, bvec, zd))
     assert np.linalg.norm(U.get_local() - Uo) <= 1e-8 * np.linalg.norm(Uo)
     assert np.linalg.norm(u.vector().get_local() - Mo @ Uo) <= 1e-8 * np.linalg.norm(Mo @ Uo)

@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import scipy.sparse as sp
+import scipy.sparse.linalg as spla
 
 from oracle import tigar_oracle as O
 
@@ -483,3 +484,85 @@ def test_krylov_uses_sliced_copy_and_drops_it(dev):
         xx = dev.DeviceVector(data=np.ones(s.getNcp()))
         ref = Kf.to_scipy() @ np.ones(s.getNcp())
         assert np.max(np.abs(Kf.mult(xx).get_local() - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("d,p,nel,rtol", [(3, 2, 16, 1e-6), (3, 3, 10, 1e-6), (3, 3, 10, 1e-10), (2, 4, 24, 1e-8)])
+def test_single_reduction_cg_tracks_textbook_cg(dev, d, p, nel, rtol):
+    """The device CG is the single-reduction (Chronopoulos-Gear) recurrence with the norm history read two
+    iterations late; it must stop at the same iteration (+-1) as the textbook recurrence the oracle restates from
+    PETSc's KSPCG, with the same solution, and must not run past convergence (frozen updates)."""
+    s, A, b, M1, K1, zd = _poisson_setup(d, p, nel)
+    Mo = O.generate_M_tensor(s)
+    Ko = O.extract_matrix(Mo, A, zd)
+    rhs = O.extract_vector(Mo, b, zd)
+    Uo, ito, reso = O.cg_jacobi(Ko, rhs, rtol=rtol, atol=1e-30)
+    K = dev.DeviceCSR.from_scipy(Ko)
+    y = dev.DeviceVector(data=rhs)
+    U = dev.DeviceVector(s.getNcp())
+    its, res, status = dev.krylov_solve(K, y, U, method="cg", pc="jacobi", rtol=rtol, atol=1e-30, maxit=5000)
+    assert status == 0 and abs(its - ito) <= 1
+    Uh = U.get_local()
+    assert np.linalg.norm(Uh - Uo) <= 20 * rtol * np.linalg.norm(Uo)
+    # the reported norm is the preconditioned residual norm of the returned iterate (nothing ran past it)
+    dinv = 1.0 / Ko.diagonal()
+    true = np.linalg.norm(dinv * (rhs - Ko @ Uh))
+    assert abs(true - res) <= 1e-6 * max(res, true) + 1e-3 * rtol * np.linalg.norm(dinv * rhs)
+    # bit-reproducible from run to run (fixed reduction grids, frozen tail)
+    U2 = dev.DeviceVector(s.getNcp())
+    its2, res2, _ = dev.krylov_solve(K, y, U2, method="cg", pc="jacobi", rtol=rtol, atol=1e-30, maxit=5000)
+    assert its2 == its and res2 == res and np.array_equal(U2.get_local(), Uh)
+    # iteration limit inside the look-ahead window
+    for cap in (1, 2, 3):
+        Uc = dev.DeviceVector(s.getNcp())
+        itc, _, stc = dev.krylov_solve(K, y, Uc, method="cg", pc="jacobi", rtol=1e-30, atol=1e-300, maxit=cap)
+        assert itc == cap and stc == -1
+
+
+@pytest.mark.parametrize("method", ["cg", "gmres"])
+def test_krylov_nonzero_initial_guess(dev, method):
+    """dolfin's "nonzero_initial_guess" [ext]: x holds the start vector; the tolerance stays relative to ||B b||."""
+    s, A, b, M1, K1, zd = _poisson_setup(3, 2, 8)
+    Mo = O.generate_M_tensor(s)
+    Ko = O.extract_matrix(Mo, A, zd)
+    rhs = O.extract_vector(Mo, b, zd)
+    Uo = spla.spsolve(Ko.tocsc(), rhs)
+    K = dev.DeviceCSR.from_scipy(Ko)
+    y = dev.DeviceVector(data=rhs)
+    n = s.getNcp()
+    x0 = dev.DeviceVector(n)
+    it0, _, st0 = dev.krylov_solve(K, y, x0, method, "jacobi", rtol=1e-10, atol=1e-30)
+    rng = np.random.default_rng(2)
+    # from a random start: same solution
+    x1 = dev.DeviceVector(data=rng.standard_normal(n))
+    it1, _, st1 = dev.krylov_solve(K, y, x1, method, "jacobi", rtol=1e-10, atol=1e-30, nonzero_initial_guess=True)
+    assert st0 == 0 and st1 == 0 and it1 > 0
+    assert np.linalg.norm(x1.get_local() - Uo) <= 1e-7 * np.linalg.norm(Uo)
+    # from a good start: far fewer iterations than from zero
+    x2 = dev.DeviceVector(data=Uo * (1.0 + 1e-6))
+    it2, _, st2 = dev.krylov_solve(K, y, x2, method, "jacobi", rtol=1e-10, atol=1e-30, nonzero_initial_guess=True)
+    assert st2 == 0 and it2 < it0 // 2
+    assert np.linalg.norm(x2.get_local() - Uo) <= 1e-7 * np.linalg.norm(Uo)
+    # from the exact solution: no iteration at all, x untouched
+    x3 = dev.DeviceVector(data=Uo)
+    it3, _, st3 = dev.krylov_solve(K, y, x3, method, "jacobi", rtol=1e-8, atol=1e-30, nonzero_initial_guess=True)
+    assert it3 == 0 and st3 == 0 and np.array_equal(x3.get_local(), Uo)
+    # through the dolfin-style solver object
+    import tigar_amd as t
+    sol = t.PETScKrylovSolver(method, "jacobi")
+    sol.parameters["nonzero_initial_guess"] = True
+    sol.parameters["relative_tolerance"] = 1e-10
+    x4 = dev.DeviceVector(data=Uo * (1.0 + 1e-6))
+    sol.solve(K, x4, y)
+    assert sol.last["iterations"] == it2
+
+
+def test_vector_norm_kinds(dev):
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal(100003)
+    a[77] = -9.5
+    v = dev.DeviceVector(data=a)
+    assert abs(v.norm("l2") - np.linalg.norm(a)) <= 1e-13 * np.linalg.norm(a)
+    assert abs(v.norm("l1") - np.sum(np.abs(a))) <= 1e-12 * np.sum(np.abs(a))
+    assert v.norm("linf") == 9.5
+    with pytest.raises(ValueError):
+        v.norm("frobenius")

@@ -1,0 +1,94 @@
+"""The multi-rank hot path on real hardware: z-slab row blocks of K per rank, halo exchange + fused 3-scalar
+all-reduce per CG iteration (tg_cg / tg_gmres with a communicator), rank-local prolongation -- against the
+single-rank run through the same public API.
+
+Two communicators over the same solver code:
+* host-staged (tg_comm_create_host + the TCP transport of tigar_amd/launch.py): two ranks SHARING one GPU, so it
+  runs on the 1-GPU test box;
+* RCCL (ncclSend/ncclRecv/ncclAllReduce over xGMI): needs >= 2 visible GPUs, skipped otherwise.
+The reference's counterpart is PETSc's row-block MatPtAP / KSP with VecScatter ghost updates
+(tIGAr/common.py:1194-1195, 1255-1261)."""
+import os
+import sys
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _single(d, p, nel, method):
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, forms as F, common as tc
+    kv = [B.uniformKnots(p, 0., 1., nel) for _ in range(d)]
+    gen = t.EqualOrderSpline(tc.selfcomm, 1, B.ExplicitBSplineControlMesh([p] * d, kv))
+    sp0 = gen.getScalarSpline(0)
+    for direction in range(d):
+        for side in (0, 1):
+            gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
+    spline = t.ExtractedSpline(gen, 2 * p, comm=tc.selfcomm)
+    K = spline.assembleMatrix(F.LaplaceForm(), diag=1.5)
+    f1 = lambda x: np.sin(np.pi * x)
+    rhs = spline.assembleVector(F.SeparableLoadForm([f1] * d, scale=d * np.pi ** 2))
+    solver = t.PETScKrylovSolver(method, "jacobi")
+    solver.parameters["relative_tolerance"] = 1e-10
+    spline.setSolverOptions(linearSolver=solver)
+    u = t.Function(spline.V)
+    U = spline.solveLinearSystem(K, rhs, u)
+    return (K.to_scipy(), rhs.get_local(), U.get_local(), u.vector().get_local(), solver.last["iterations"],
+            gen.cpFuncs[0].vector().get_local())
+
+
+def _run_ranks(tmp_path, world, kind, d, p, nel, method, port):
+    from tigar_amd.launch import spawn_local
+    env = {"PYTHONPATH": ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), "TIGAR_COMM": kind}
+    if kind == "host":
+        env["TIGAR_DEVICE"] = "0"                       # every rank on the one GPU
+    rc = spawn_local(world, [os.path.join(ROOT, "tests", "gpu_rank_worker.py"), str(tmp_path), str(d), str(p),
+                             str(nel), method], env_extra=env, port=port)
+    assert rc == 0, "a rank failed"
+    return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+
+
+def _compare(parts, ref, world, kind):
+    Ks, rhs, U, u, its, cp0 = ref
+    Ks = Ks.tocsr()
+    dof_cover = np.zeros(Ks.shape[0], dtype=int)
+    fe_cover = np.zeros(u.shape[0], dtype=int)
+    for r, z in enumerate(parts):
+        g0, g1, r0, r1 = [int(v) for v in z["g"]]
+        assert list(z["comm"]) == [r, world, 0 if kind == "rccl" else 1]     # what the communicator itself reports
+        Kl = sp.csr_matrix((z["K_data"], z["K_indices"], z["K_indptr"]), shape=(g1 - g0, Ks.shape[1]))
+        Kr = Ks[g0:g1]
+        assert np.array_equal(Kl.indptr, Kr.indptr) and np.array_equal(Kl.indices, Kr.indices)   # pattern identical
+        assert abs(Kl - Kr).max() <= 1e-12 * abs(Ks).max()
+        assert np.max(np.abs(z["rhs"] - rhs[g0:g1])) <= 1e-13 * np.max(np.abs(rhs))
+        assert np.max(np.abs(z["U"] - U[g0:g1])) <= 1e-8 * np.max(np.abs(U))
+        assert np.max(np.abs(z["u"] - u[r0:r1])) <= 1e-8 * np.max(np.abs(u))
+        assert np.max(np.abs(z["cp0"] - cp0[r0:r1])) <= 1e-14
+        assert abs(int(z["its"][0]) - its) <= 1          # same Krylov iteration count as the single-rank solve
+        assert int(z["its"][1]) <= 2                     # restart from the solution: (almost) converged at once
+        assert np.max(np.abs(z["U2"] - z["U"])) <= 1e-8 * np.max(np.abs(U))
+        dof_cover[g0:g1] += 1
+        fe_cover[r0:r1] += 1
+    assert np.all(dof_cover == 1) and np.all(fe_cover == 1)       # rows partitioned exactly
+
+
+@pytest.mark.parametrize("d,p,nel,method,world", [(3, 2, 20, "cg", 2), (3, 3, 14, "cg", 3), (3, 2, 12, "gmres", 2)])
+def test_host_staged_ranks_sharing_one_gpu(tmp_path, d, p, nel, method, world):
+    ref = _single(d, p, nel, method)
+    parts = _run_ranks(tmp_path, world, "host", d, p, nel, method, 29500 + 37 * (d * 100 + p * 10 + world))
+    _compare(parts, ref, world, "host")
+
+
+@pytest.mark.parametrize("d,p,nel,method", [(3, 3, 24, "cg"), (3, 2, 16, "gmres")])
+def test_rccl_ranks_one_gpu_each(tmp_path, d, p, nel, method):
+    from tigar_amd import device as dev
+    ndev = dev.device_count()
+    if ndev < 2:
+        pytest.skip("RCCL needs one GPU per rank; %d visible" % ndev)
+    world = min(ndev, 4)
+    ref = _single(d, p, nel, method)
+    parts = _run_ranks(tmp_path, world, "rccl", d, p, nel, method, 29900 + world)
+    _compare(parts, ref, world, "rccl")

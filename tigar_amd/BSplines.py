@@ -115,8 +115,13 @@ class BSpline1(object):
         return [int(i) for i in self.evalBatch([u])[1][0]]
 
     def basisFuncs(self, knotSpan, u):
-        # knotSpan is implied by u (the reference recomputes it the same way before calling)
-        return self.evalBatch([u])[2][0]
+        """The p+1 basis values at ``u`` (tIGAr/BSplines.py:321-351).  The device twin derives the span
+        from ``u`` exactly as ``getKnotSpan`` does (the reference's callers pass that value); any other
+        span is refused instead of being silently ignored."""
+        span, _, val = self.evalBatch([u])
+        if knotSpan is not None and int(knotSpan) != int(span[0]):
+            raise ValueError("basisFuncs: knotSpan %d is not getKnotSpan(u) = %d" % (int(knotSpan), int(span[0])))
+        return val[0]
 
     # ---- FE node grid along this direction ------------------------------------------
     def feNodes(self, degree, dg=False):
@@ -280,29 +285,31 @@ class MultiBSpline(AbstractScalarBasis):
     DoFs of the patches are numbered one after the other.  (As in the reference there is no
     merging of control points between patches yet: the extraction operator is block diagonal.)"""
 
+    PATCH_PITCH = 2.0           # parametric distance between the origins of neighbouring patches
+
     def __init__(self, splines):
         self.splines = splines
-        self.ncp = self.computeNcp()
-        for s in self.splines:
-            s.normalizeKnotVectors()
-        self.doffsets = []
-        ncp = 0
-        for s in self.splines:
-            self.doffsets += [ncp, ]
-            ncp += s.getNcp()
-        self.nvar = self.splines[0].nvar
-        self.useRect = self.splines[0].useRect
-        self.overRefine = self.splines[0].overRefine
-        self.nPatch = len(self.splines)
-        self.nel = self.computeNel()
+        if not len(splines):
+            raise ValueError("MultiBSpline needs at least one patch")
+        lead = splines[0]
+        self.nvar, self.useRect, self.overRefine = lead.nvar, lead.useRect, lead.overRefine
         if self.nvar == 1:
             raise NotImplementedError("Univariate multipatch not yet supported.")   # (reference :745-747)
+        self.nPatch = len(splines)
+        for patch in splines:
+            patch.normalizeKnotVectors()       # every patch on (0,1): patch index follows from x alone
+        # DoFs of the patches are numbered one after the other: exclusive prefix sums of the patch sizes
+        sizes = numpy.array([patch.getNcp() for patch in splines], dtype=numpy.int64)
+        ends = numpy.cumsum(sizes)
+        self.doffsets = [int(v) for v in (ends - sizes)]
+        self.ncp = int(ends[-1])
+        self.nel = self.computeNel()
 
     def computeNel(self):
-        return sum(s.nel for s in self.splines)
+        return int(sum(patch.nel for patch in self.splines))
 
     def computeNcp(self):
-        return sum(s.getNcp() for s in self.splines)
+        return int(sum(patch.getNcp() for patch in self.splines))
 
     def getNcp(self):
         return self.ncp
@@ -317,24 +324,25 @@ class MultiBSpline(AbstractScalarBasis):
         return self.splines[0].getPrealloc()
 
     def getDegree(self):
-        return max(s.getDegree() for s in self.splines)
+        return max(patch.getDegree() for patch in self.splines)
 
     def patchFromCoordinates(self, xi):
-        return int(xi[0] + 0.5) // 2
+        # patch i covers x in [2i, 2i+1]: round to the nearest integer, two units per patch
+        return int(xi[0] + 0.5) // int(self.PATCH_PITCH)
 
     def globalDofIndex(self, localDofIndex, patchIndex):
-        return self.doffsets[patchIndex] + localDofIndex
+        return localDofIndex + self.doffsets[patchIndex]
 
     def localParametricCoordinates(self, xi, patchIndex):
-        retval = numpy.array(xi, dtype=numpy.float64)
-        retval[0] = xi[0] - 2.0 * float(patchIndex)
-        return retval
+        shift = numpy.zeros(len(xi))
+        shift[0] = self.PATCH_PITCH * float(patchIndex)
+        return numpy.asarray(xi, dtype=numpy.float64) - shift
 
     def getNodesAndEvals(self, xi):
-        patch = self.patchFromCoordinates(xi)
-        xi_local = self.localParametricCoordinates(xi, patch)
-        return [[self.globalDofIndex(pair[0], patch), pair[1]]
-                for pair in self.splines[patch].getNodesAndEvals(xi_local)]
+        ip = self.patchFromCoordinates(xi)
+        off = self.doffsets[ip]
+        local = self.splines[ip].getNodesAndEvals(self.localParametricCoordinates(xi, ip))
+        return [[node + off, value] for node, value in local]
 
     def generateMesh(self, comm=worldcomm, degree=None, dg=False):
         """The reference writes a mesh of disconnected cells, 4 (8) vertices per element

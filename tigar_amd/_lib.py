@@ -42,6 +42,9 @@ class tg_patch_t(C.Structure):
                 ("nsd", C.c_int), ("cp", handle * 4), ("nq", C.c_int)]
 
 
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_f64p, C.c_int)
+HOST_SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, c_f64p, C.c_int64, c_f64p, C.c_int64)
+
 # name -> (restype, argtypes); mirrors include/tigar_hip.h one to one
 PROTOTYPES = {
     "tg_init": (C.c_int, [C.c_int]),
@@ -68,6 +71,7 @@ PROTOTYPES = {
     "tg_vec_copy_range": (C.c_int, [handle, C.c_int64, handle, C.c_int64, C.c_int64]),
     "tg_vec_axpy": (C.c_int, [handle, C.c_double, handle]),
     "tg_vec_dot": (C.c_int, [handle, handle, c_f64p]),
+    "tg_vec_norm": (C.c_int, [handle, C.c_int, c_f64p]),
     "tg_vec_zero_entries": (C.c_int, [handle, c_i32p, C.c_int64]),
     "tg_vec_zero_entries_offset": (C.c_int, [handle, c_i32p, C.c_int64, C.c_int64]),
     "tg_vec_tensor3": (C.c_int, [handle, C.c_int, C.POINTER(c_f64p), c_i64p, C.c_double,
@@ -75,6 +79,7 @@ PROTOTYPES = {
     "tg_csr_from_host": (C.c_int, [C.c_int64, C.c_int64, c_i64p, c_i32p, c_f64p, C.POINTER(handle)]),
     "tg_csr_dims": (C.c_int, [handle, c_i64p, c_i64p, c_i64p]),
     "tg_csr_download": (C.c_int, [handle, c_i64p, c_i32p, c_f64p]),
+    "tg_csr_download_rows": (C.c_int, [handle, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f64p, C.c_int64]),
     "tg_csr_destroy": (C.c_int, [handle]),
     "tg_csr_transpose": (C.c_int, [handle, C.POINTER(handle)]),
     "tg_csr_from_triplets": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f64p,
@@ -116,6 +121,9 @@ PROTOTYPES = {
     "tg_krylov_solve": (C.c_int, [handle, handle, handle, C.c_int, C.c_int, C.c_double, C.c_double,
                                   C.c_int, C.c_int, handle, C.POINTER(C.c_int), c_f64p,
                                   C.POINTER(C.c_int)]),
+    "tg_krylov_solve_flags": (C.c_int, [handle, handle, handle, C.c_int, C.c_int, C.c_double, C.c_double,
+                                        C.c_int, C.c_int, C.c_int, handle, C.POINTER(C.c_int), c_f64p,
+                                        C.POINTER(C.c_int)]),
     "tg_kron_sum_csr": (C.c_int, [C.c_int, C.c_int, C.POINTER(tg_kron_dir_t), C.c_int64, C.c_int64,
                                   C.POINTER(handle)]),
     "tg_kron_csr_rect": (C.c_int, [C.c_int, C.c_int, C.POINTER(tg_kron_dir_t), c_i64p, C.c_int64, C.c_int64,
@@ -127,6 +135,10 @@ PROTOTYPES = {
     "tg_assemble_mapped_load": (C.c_int, [C.POINTER(tg_patch_t), handle, handle]),
     "tg_comm_unique_id": (C.c_int, [C.c_char_p]),
     "tg_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(handle)]),
+    "tg_comm_create_host": (C.c_int, [C.c_int, C.c_int, HOST_ALLREDUCE_FN, HOST_SENDRECV_FN, C.c_void_p,
+                                      C.POINTER(handle)]),
+    "tg_comm_info": (C.c_int, [handle, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "tg_comm_set_slab": (C.c_int, [handle, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "tg_comm_allreduce_sum": (C.c_int, [handle, c_f64p, C.c_int]),
     "tg_comm_halo_extend": (C.c_int, [handle, handle, handle]),

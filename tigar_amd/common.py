@@ -30,10 +30,29 @@ mpirank = int(os.environ.get("RANK", "0"))
 
 
 class _Comm(object):
-    """Stand-in for an MPI communicator handle (one process per GPU; RCCL underneath)."""
+    """Stand-in for an MPI communicator handle: one process per GPU.  ``transport`` is the host-side message
+    layer (``tigar_amd.launch.Transport``), ``device()`` the device communicator of the Krylov solve (RCCL over
+    xGMI, or host-staged where ranks share a GPU); both are created on first use from the launcher's
+    environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
 
-    def __init__(self, size, rank):
+    def __init__(self, size, rank, transport=None, device_comm=None):
         self.size, self.rank = size, rank
+        self._transport, self._device = transport, device_comm
+
+    def transport(self):
+        if self._transport is None:
+            from .launch import SocketTransport, Transport
+            self._transport = SocketTransport(self.rank, self.size) if self.size > 1 else Transport()
+        return self._transport
+
+    def device(self):
+        if self.size > 1 and self._device is None:
+            from .launch import device_comm
+            self._device = device_comm(self.transport())
+        return self._device
+
+    def barrier(self):
+        self.transport().barrier()
 
 
 worldcomm = _Comm(mpisize, mpirank)
@@ -150,9 +169,11 @@ class TensorFunctionSpace(object):
 class Function(object):
     """Stand-in for dolfin ``Function``: FE coefficients in HBM."""
 
-    def __init__(self, V):
+    def __init__(self, V, local_range=None):
         self.V = V
-        self._vec = DeviceVector(V.dim())
+        # with several ranks a function holds the FE rows [r0, r1) its rank owns (set by the solve)
+        self.local_range = local_range
+        self._vec = DeviceVector(V.dim() if local_range is None else local_range[1] - local_range[0])
 
     def vector(self):
         return self._vec
@@ -301,8 +322,10 @@ class AbstractExtractionGenerator(object):
         # Kronecker form of M (single tensor B-spline field, filter dropped only exact zeros):
         # enables the sum-factorised M^T A M of tigar_amd/kronptap.py
         self._kron = None
-        if self.getNFields() == 1 and (0, 0) in self._fast_blocks or (self.M is self.M_control
-                                                                        and (-1, 0) in self._fast_blocks):
+        if getattr(self.M, "is_implicit", False):
+            self._kron = self.M.kx
+        elif self.getNFields() == 1 and (0, 0) in self._fast_blocks or (self.M is self.M_control
+                                                                          and (-1, 0) in self._fast_blocks):
             from .kronptap import KronExtraction
             basis, grid = self._fast_blocks.get((0, 0), self._fast_blocks.get((-1, 0)))
             kx = KronExtraction(basis, grid)
@@ -311,15 +334,27 @@ class AbstractExtractionGenerator(object):
         self.cpFuncs = []
         cm = self.getControlMesh() if hasattr(self, "getControlMesh") else None
         P = None
+        self._slab_engine = None
+        if self.comm.size > 1 and getattr(self.M_control, "is_implicit", False):
+            # several ranks: every rank evaluates the control functions on the FE rows it owns only
+            # (the reference's cpFuncs are distributed dolfin Functions, tIGAr/common.py:367-380)
+            from .dist import SlabHotPath
+            kx = self.M_control.kx
+            self._slab_engine = SlabHotPath(kx.basis, kx.grid, self.comm.rank, self.comm.size, self.comm.device(),
+                                            sub_planes="auto", eps=self.M_control.eps, kx=kx)
         for i in range(self.nsd + 1):
-            f = Function(self.V_control)
             if cm is not None and hasattr(cm, "homogeneousCoordinateDeviceVector"):
                 Pi = cm.homogeneousCoordinateDeviceVector(i)      # built in HBM from 1-D factors
             else:
                 if P is None:
                     P = self._homogeneousCoordinateArray()
                 Pi = DeviceVector(data=P[:, i])
-            self.M_control.mult(Pi, f.vector())                   # stays in HBM
+            if self._slab_engine is not None:
+                f = Function(self.V_control, self._slab_engine.mine["u_rows"])
+                f._vec = self._slab_engine._prolong_tensor(Pi, 0)
+            else:
+                f = Function(self.V_control)
+                self.M_control.mult(Pi, f.vector())               # stays in HBM
             self.cpFuncs += [f]
         self.zeroDofs = []
 
@@ -384,6 +419,10 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
         from .BSplines import BSpline
         if isinstance(basis, BSpline) and type(basis).getNodesAndEvals is BSpline.getNodesAndEvals:
             self._fast_blocks[(field, col_offset)] = (basis, grid)
+            if field == -1 and self._single_shared_field():
+                lazy = self._implicit_block(basis, grid, eps)
+                if lazy is not None:
+                    return lazy
             return _dev.extract_csr_tensor(basis.splines, grid.axes, col_offset, ncols, eps)
         from .BSplines import MultiBSpline
         if isinstance(basis, MultiBSpline) and isinstance(grid, MultiPatchNodeGrid):
@@ -401,6 +440,30 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
                 vals.append(float(v))
         return _dev.csr_from_triplets(X.shape[0], ncols, rows, cols, vals, eps)
 
+    def _single_shared_field(self):
+        """one unknown field on the control mesh's own basis: M is M_control"""
+        return False
+
+    def _implicit_block(self, basis, grid, eps):
+        """``ImplicitExtraction`` in place of the CSR block when M (and M^T) would not fit beside the rest of
+        the path -- 24 B per entry against a third of the free HBM -- or when the patch is spread over several
+        ranks (no rank ever holds all rows); TIGAR_IMPLICIT_M=1/0 forces / forbids it.  Only offered when M
+        is exactly the Kronecker product of its 1-D factors (the filter of tIGAr/common.py:1569 dropped
+        nothing but exact zeros)."""
+        from .kronptap import KronExtraction
+        from .implicit import ImplicitExtraction
+        env = os.environ.get("TIGAR_IMPLICIT_M")
+        if env == "0":
+            return None
+        kx = KronExtraction(basis, grid)
+        if not kx.products_stay_above(eps):
+            return None
+        if env != "1" and self.comm.size == 1:
+            free_b, _ = _dev.mem_info()
+            if 24.0 * kx.nnz_product + 16.0 * grid.num_nodes() <= free_b / 3.0:
+                return None
+        return ImplicitExtraction(kx, eps)
+
     def generateM_control(self):
         """Extraction matrix of the scalar space of the control functions
         (tIGAr/common.py:1460-1514)."""
@@ -412,6 +475,8 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
         tIGAr/common.py:84,358-360).  For tensor B-spline fields it is written directly by the
         transposed extraction kernel; otherwise ``M`` is transposed on the device."""
         nf = self.getNFields()
+        if getattr(self.M, "is_implicit", False):
+            return self.M.transpose()
         if self.M is self.M_control and (-1, 0) in self._fast_blocks:
             basis, grid = self._fast_blocks[(-1, 0)]
             return _dev.extract_csr_tensor_t(basis.splines, grid.axes, 0, grid.num_nodes(), self.getIgnoreEps())
@@ -570,6 +635,9 @@ class EqualOrderSpline(AbstractMultiFieldSpline):
     def getFieldSpline(self, field):
         return self.getScalarSpline(-1)
 
+    def _single_shared_field(self):
+        return self.numFields == 1
+
     def generateM(self):
         # one unknown field on the control mesh's basis: M is M_control (same rows, same
         # columns) -- share the device object instead of building it twice
@@ -630,23 +698,45 @@ class PETScKrylovSolver(object):
                            "report": False, "monitor_convergence": False}
         self.comm = comm
         self.last = None
+        self.note = None       # appended to the non-convergence message (who chose this solver)
+
+    REASONS = {-1: "iteration limit reached", -2: "breakdown (NaN / zero pivot in the recurrence)",
+               -3: "stagnation (25 GMRES restart cycles without progress)"}
 
     def solve(self, A, x, b):
-        if self.parameters["nonzero_initial_guess"]:
-            raise NotImplementedError("nonzero_initial_guess")
+        """``x`` is the output; with ``parameters["nonzero_initial_guess"]`` it also holds the start vector
+        (the convergence test stays relative to ||B b||, PETSc's default [ext])."""
         A, x, b = _as_device_csr(A), _as_device_vector(x), _as_device_vector(b)
         its, res, status = _dev.krylov_solve(
             A, b, x, self.method, self.preconditioner, self.parameters["relative_tolerance"],
             self.parameters["absolute_tolerance"], self.parameters["maximum_iterations"],
-            self.parameters["gmres_restart"], self.comm)
+            self.parameters["gmres_restart"], self.comm,
+            nonzero_initial_guess=bool(self.parameters["nonzero_initial_guess"]))
         self.last = {"iterations": its, "residual_norm": res, "status": status}
         if status < 0 and self.parameters["error_on_nonconvergence"]:
-            raise RuntimeError("Krylov solver (%s, %s) did not converge: status %d after %d iterations, "
-                               "preconditioned residual %.3e" % (self.method, self.preconditioner, status, its, res))
+            raise RuntimeError("Krylov solver (%s, %s) did not converge: %s after %d iterations, preconditioned "
+                               "residual %.3e.%s" % (self.method, self.preconditioner,
+                                                     self.REASONS.get(status, "status %d" % status), its, res,
+                                                     self.note or ""))
         return its
 
 
 KrylovSolver = PETScKrylovSolver
+
+
+def _default_linear_solver(method="gmres"):
+    """What runs when ``linearSolver`` is None.  The reference calls dolfin's ``solve`` there, i.e. a sparse
+    direct LU (tIGAr/common.py:1255-1256 [ext]); this path has no sparse direct factorisation, so the default
+    is Jacobi-preconditioned GMRES(30) (CG for the normal equations of ``FEtoIGA``) to a relative residual of
+    1e-12, bounded by PETSc's default 10 000 iterations and by the solver's stagnation guard -- on systems where
+    that is not enough (strongly indefinite, zero diagonal blocks) it stops early with an error that says so
+    instead of iterating on; pass a ``linearSolver`` (any object with ``solve(A, x, b)``) in that case."""
+    solver = PETScKrylovSolver(method, "jacobi")
+    solver.parameters["relative_tolerance"] = 1e-12
+    solver.parameters["maximum_iterations"] = 10000
+    solver.note = ("  (linearSolver=None: the reference would have run dolfin's direct LU here; tigar_amd's default "
+                   "is this Krylov solver -- set ExtractedSpline.linearSolver for ill-conditioned systems)")
+    return solver
 
 
 # ---- analysis side ---------------------------------------------------------------------------
@@ -732,6 +822,7 @@ class ExtractedSpline(object):
         self.M = generator.M
         self.M_control = generator.M_control
         self.comm = generator.getComm()
+        self._generator_engine = getattr(generator, "_slab_engine", None)
         self._kron = getattr(generator, "_kron", None)
         self.zeroDofs = numpy.asarray(generator.zeroDofs, dtype=INDEX_TYPE)
 
@@ -740,11 +831,61 @@ class ExtractedSpline(object):
         self.MT = self.M.transpose()          # explicit M^T (cached on M by the generator)
         self._ptap_plan = None
         self._ptap_plan_key = None
+        self._slab = None
+
+    # -- streamed / distributed engine -------------------------------------------------------------
+    def _implicit(self):
+        return bool(getattr(self.M, "is_implicit", False))
+
+    def _distributed(self):
+        return self.comm is not None and getattr(self.comm, "size", 1) > 1
+
+    def _slab_path(self):
+        """The z-slab engine (``tigar_amd.dist.SlabHotPath``) behind extractMatrix / extractVector /
+        solveLinearSystem when M is implicit or the patch is spread over several ranks: rows of K in
+        sub-slabs of dof planes, only K resident (PETSc's row-block MatPtAP, tIGAr/common.py:1194-1195)."""
+        if self._slab is None and getattr(self, "_generator_engine", None) is not None:
+            self._slab = self._generator_engine
+        if self._slab is None:
+            if self._kron is None:
+                raise NotImplementedError("the streamed / multi-GPU path needs a single tensor-product B-spline field")
+            from .dist import SlabHotPath
+            kx = self._kron
+            dc = self.comm.device() if self._distributed() else None
+            self._slab = SlabHotPath(kx.basis, kx.grid, self.comm.rank if dc is not None else 0,
+                                     self.comm.size if dc is not None else 1, dc, sub_planes="auto",
+                                     eps=getattr(self.M, "eps", DEFAULT_BASIS_FUNC_IGNORE_EPS), kx=kx)
+        return self._slab
+
+    def localDofRange(self):
+        """IGA dofs [g0, g1) owned by this rank (PETSc getOwnershipRange of MTAM's rows)."""
+        if self._distributed():
+            return self._slab_path().mine["dofs"]
+        return (0, self.M.shape[1])
+
+    def localFERange(self):
+        """FE rows whose prolongation u = M U this rank computes."""
+        if self._distributed():
+            return self._slab_path().mine["u_rows"]
+        return (0, self.M.shape[0])
 
     # -- a-10
     def extractVector(self, b, applyBCs=True):
         """Apply extraction to an FE vector ``b``: ``M^T b``, zeroed at ``zeroDofs`` if
         ``applyBCs`` (tIGAr/common.py:1142-1160)."""
+        from .implicit import LazyFEVector
+        if isinstance(b, LazyFEVector) or self._distributed():
+            if isinstance(b, LazyFEVector):
+                rows = b.rows
+            else:
+                full = _as_device_vector(b)       # replicated FE vector: every rank takes its rows
+
+                def rows(r0, r1):
+                    piece = DeviceVector(r1 - r0)
+                    _dev.vec_copy_range(piece, 0, full, r0, r1 - r0)
+                    return piece
+            return self._slab_path().assemble_vector(rows, self.zeroDofs if applyBCs else None,
+                                                     getattr(self, "stage_timers", None))
         MTb = self.M.mult_transpose(_as_device_vector(b))
         if applyBCs:
             MTb.zero_entries(self.zeroDofs)
@@ -752,8 +893,16 @@ class ExtractedSpline(object):
 
     def assembleVector(self, form, applyBCs=True):
         """``form``: anything with ``.assemble_vector(V)`` (see ``tigar_amd.forms``) or an
-        already assembled FE vector (tIGAr/common.py:1162-1173)."""
-        b = form.assemble_vector(self.V) if hasattr(form, "assemble_vector") else form
+        already assembled FE vector (tIGAr/common.py:1162-1173).  With several ranks the form is
+        asked for the FE rows each rank needs (``assemble_vector(V, row0, row1)``)."""
+        if hasattr(form, "assemble_vector"):
+            if self._distributed():
+                from .implicit import LazyFEVector
+                b = LazyFEVector(lambda r0, r1: form.assemble_vector(self.V, r0, r1), self.V.dim())
+            else:
+                b = form.assemble_vector(self.V)
+        else:
+            b = form
         return self.extractVector(b, applyBCs=applyBCs)
 
     # -- a-11
@@ -761,8 +910,15 @@ class ExtractedSpline(object):
         """Apply extraction to an FE matrix ``A``: ``M^T A M`` (PtAP), then rows and columns
         of ``zeroDofs`` zeroed with ``diag`` on the diagonal (tIGAr/common.py:1176-1204).
         The symbolic plan is cached and reused while A's pattern is unchanged."""
-        A = _as_device_csr(A)
+        from .implicit import LazyFEMatrix
         zd = self.zeroDofs if applyBCs else None
+        if isinstance(A, LazyFEMatrix) or self._distributed():
+            if isinstance(A, LazyFEMatrix):
+                a_rows = A.rows
+            else:
+                raise NotImplementedError("with several ranks pass the FE matrix as a LazyFEMatrix (row blocks)")
+            return self._slab_path().assemble_matrix(a_rows, zd, float(diag), getattr(self, "stage_timers", None))
+        A = _as_device_csr(A)
         if self._kron is not None:
             from .kronptap import default_groups, ptap_factored
             kx = self._kron
@@ -771,15 +927,37 @@ class ExtractedSpline(object):
             if os.environ.get("TIGAR_PTAP_FACTORED", "1") != "0":
                 # Kronecker-structured M: dense-box kernel (one stage or sum-factorised stages)
                 return ptap_factored(kx, A, (0, kx.nfe[-1]), (0, kx.nfe[-1]), (0, kx.ncp[-1]), zd, float(diag), groups)
+        if self._implicit():
+            raise NotImplementedError("general PtAP with an implicit extraction operator: materialise M "
+                                      "(TIGAR_IMPLICIT_M=0) or pass a tensor-product FE matrix")
         key = (A.shape, A.nnz)
-        if self._ptap_plan is None or self._ptap_plan_key != key:
+        fresh = self._ptap_plan is None or self._ptap_plan_key != key
+        if fresh:
             self._ptap_plan = _dev.ptap_symbolic(A, self.M, self.MT)
             self._ptap_plan_key = key
-        zd = self.zeroDofs if applyBCs else None
-        return _dev.ptap_numeric(self._ptap_plan, A, self.M, self.MT, zd, float(diag))
+        try:
+            return _dev.ptap_numeric(self._ptap_plan, A, self.M, self.MT, zd, float(diag))
+        except _dev.TigarHipError:
+            if fresh:
+                raise
+            # same shape and nnz but another sparsity pattern than the cached plan's: the reference
+            # recomputes the symbolic product on every call (tIGAr/common.py:1194-1195) -- plan again
+            self._ptap_plan = _dev.ptap_symbolic(A, self.M, self.MT)
+            return _dev.ptap_numeric(self._ptap_plan, A, self.M, self.MT, zd, float(diag))
 
     def assembleMatrix(self, form, applyBCs=True, diag=1):
-        A = form.assemble_matrix(self.V) if hasattr(form, "assemble_matrix") else form
+        """tIGAr/common.py:1206-1220.  When the assembled FE matrix cannot be resident next to K (implicit
+        M: cfg3's A is 684 GB) or the patch is spread over several ranks, the form is asked for row blocks
+        (``assemble_matrix(V, row0, row1)``) as the z-slab pipeline consumes them."""
+        if hasattr(form, "assemble_matrix"):
+            if self._implicit() or self._distributed():
+                from .implicit import LazyFEMatrix
+                n = self.V.dim()
+                A = LazyFEMatrix(lambda r0, r1: form.assemble_matrix(self.V, r0, r1), (n, n))
+            else:
+                A = form.assemble_matrix(self.V)
+        else:
+            A = form
         return self.extractMatrix(A, applyBCs=applyBCs, diag=diag)
 
     def assembleLinearSystem(self, lhsForm, rhsForm, applyBCs=True):
@@ -791,15 +969,18 @@ class ExtractedSpline(object):
         (tIGAr/common.py:1236-1263).  With ``linearSolver == None`` the reference calls
         dolfin's direct LU; there is no sparse direct solver on this path, so the default is
         Jacobi-preconditioned GMRES at tight tolerance (1e-12) -- documented deviation."""
-        MTU = DeviceVector(self.M.shape[1])
-        if self.linearSolver is None:
-            solver = PETScKrylovSolver("gmres", "jacobi")
-            solver.parameters["relative_tolerance"] = 1e-12
-            solver.parameters["maximum_iterations"] = 100000
-            solver.solve(MTAM, MTU, MTb)
+        MTU = DeviceVector(MTAM.shape[0])          # (local rows of MTAM: all of them on one rank)
+        solver = self.linearSolver if self.linearSolver is not None else _default_linear_solver()
+        if self._distributed() and getattr(solver, "comm", False) is None:
+            solver.comm = self.comm.device()
+        solver.solve(MTAM, MTU, MTb)
+        if self._distributed():
+            # u = M U on the FE rows this rank owns, U with its halo (tIGAr/common.py:1259-1261:
+            # M*MTU followed by the ghost update)
+            u_loc = self._slab_path().prolong(MTU)
+            u._vec, u.local_range = u_loc, self._slab_path().mine["u_rows"]
         else:
-            self.linearSolver.solve(MTAM, MTU, MTb)
-        self.M.mult(MTU, _as_device_vector(u))
+            self.M.mult(MTU, _as_device_vector(u))
         return MTU
 
     def solveLinearVariationalProblem(self, residualForm, u, applyBCs=True):
@@ -822,13 +1003,8 @@ class ExtractedSpline(object):
         ident = DeviceCSR.from_scipy(_scipy_identity(self.M.shape[0]))
         MTM = self.extractMatrix(ident, applyBCs=False)
         x = DeviceVector(self.M.shape[1])
-        if self.linearSolver is None:
-            solver = PETScKrylovSolver("cg", "jacobi")
-            solver.parameters["relative_tolerance"] = 1e-12
-            solver.parameters["maximum_iterations"] = 100000
-            solver.solve(MTM, x, MTtemp)
-        else:
-            self.linearSolver.solve(MTM, x, MTtemp)
+        solver = self.linearSolver if self.linearSolver is not None else _default_linear_solver("cg")
+        solver.solve(MTM, x, MTtemp)
         return x
 
     def solveNonlinearVariationalProblem(self, residualForm, J, u, referenceError=None, igaDoFs=None):
@@ -903,11 +1079,7 @@ class NewtonSolver(object):
                 break
             A = problem.J(None, x)
             dx = DeviceVector(x.size())
-            ls = self.linear_solver or problem.spline.linearSolver
-            if ls is None:
-                ls = PETScKrylovSolver("gmres", "jacobi")
-                ls.parameters["relative_tolerance"] = 1e-12
-                ls.parameters["maximum_iterations"] = 100000
+            ls = self.linear_solver or problem.spline.linearSolver or _default_linear_solver()
             ls.solve(A, dx, b)
             x.axpy(-float(prm["relaxation_parameter"]), dx)
         if prm["error_on_nonconvergence"]:

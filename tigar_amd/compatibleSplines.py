@@ -1,63 +1,67 @@
 """
-Div- and curl-conforming (RT / N type) B-spline fields, mirroring the construction part of
-``tIGAr/compatibleSplines.py`` (Buffa et al., https://epubs.siam.org/doi/10.1137/100786708):
-``generateFieldsCompat`` (:21-66) and ``BSplineCompat`` (:69-101).  Extraction of the resulting
-multi-field spline (different degrees per field and direction) runs through the same HIP kernels as
-every other ``AbstractMultiFieldSpline``.  The UFL-level helpers of the reference module
-(``iteratedDivFreeSolve``, ``ExtractedBSplineRT/N`` with ``pushforward*``, ``div``, ``curl``) need FEniCS
-and are not part of this package.
+Div- and curl-conforming (RT / N type) B-spline fields: the construction half of
+``tIGAr/compatibleSplines.py`` (Buffa et al., https://epubs.siam.org/doi/10.1137/100786708) --
+``generateFieldsCompat`` (:21-66) and ``BSplineCompat`` (:69-101).  The resulting multi-field spline
+(per-field, per-direction degrees) is extracted by the same HIP kernels as every other
+``AbstractMultiFieldSpline``.  The UFL-level half of the reference module (``iteratedDivFreeSolve``,
+``ExtractedBSplineRT/N``, ``pushforward*``, ``div``, ``curl``) needs FEniCS and is not provided.
 """
-import copy
-
-from numpy import array, concatenate
+import numpy
 
 from .common import AbstractMultiFieldSpline
 from .BSplines import BSpline
 
 
+def _raised_directions(RTorN, nvar, field):
+    """Mask over the parametric directions: True where component ``field`` is one degree higher.
+    RT: along its own direction; N: in every other direction."""
+    own = numpy.arange(nvar) == field
+    if RTorN == "RT":
+        return own
+    if RTorN == "N":
+        return ~own
+    return numpy.zeros(nvar, dtype=bool)          # (the reference raises nothing for other tags)
+
+
+def _knot_vector(breakpoints, degree, periodic):
+    """Breakpoints with the end knots repeated to multiplicity degree+1 (open vector); periodic
+    directions keep the bare breakpoints (tIGAr/compatibleSplines.py:54-61)."""
+    u = numpy.asarray(breakpoints, dtype=numpy.float64)
+    if periodic:
+        return u.copy()
+    return numpy.r_[numpy.full(degree, u[0]), u, numpy.full(degree, u[-1])]
+
+
 def generateFieldsCompat(controlMesh, RTorN, degrees, periodicities=None):
-    """List of ``BSpline`` scalar bases for the components of an RT- or N-type compatible spline
-    discretisation: field i is k-refined along (RT) or perpendicular to (N) direction i, re-using
-    the unique knots of the control mesh's scalar ``BSpline``; open knot vectors unless periodic
-    (tIGAr/compatibleSplines.py:21-66)."""
+    """Scalar ``BSpline`` bases of the components of an RT- or N-type compatible discretisation on
+    the breakpoints of the control mesh's scalar spline (tIGAr/compatibleSplines.py:21-66).
+    ``degrees`` are the base degrees per direction, ``periodicities`` an optional list of flags."""
+    base = controlMesh.getScalarSpline()
     nvar = len(degrees)
-    useRect = controlMesh.getScalarSpline().useRectangularElements()
-    fields = []
-    for i in range(0, nvar):
-        knotVectors = []
-        scalarDegrees = []
-        for j in range(0, nvar):
-            degree = degrees[j]
-            if ((RTorN == "RT") and (j == i)) or ((RTorN == "N") and (not j == i)):
-                degree += 1
-            knots = copy.copy(controlMesh.getScalarSpline().splines[j].uniqueKnots)
-            if periodicities is None or (not periodicities[j]):
-                for k in range(0, degree):
-                    knots = concatenate((array([knots[0], ]), knots, array([knots[-1], ])))
-            knotVectors += [knots, ]
-            scalarDegrees += [degree, ]
-        fields += [BSpline(scalarDegrees, knotVectors, useRect), ]
-    return fields
+    periodic = [bool(periodicities[k]) if periodicities is not None else False for k in range(nvar)]
+    out = []
+    for field in range(nvar):
+        q = numpy.asarray(degrees, dtype=int) + _raised_directions(RTorN, nvar, field)
+        kvecs = [_knot_vector(base.splines[k].uniqueKnots, int(q[k]), periodic[k]) for k in range(nvar)]
+        out.append(BSpline([int(v) for v in q], kvecs, base.useRectangularElements()))
+    return out
 
 
 class BSplineCompat(AbstractMultiFieldSpline):
-    """Extraction generator for a compatible spline of type RT or N with no other fields
+    """Extraction generator of a compatible spline of type RT or N with no further fields
     (tIGAr/compatibleSplines.py:69-101): ``BSplineCompat(controlMesh, "RT"|"N", degrees[,
     periodicities])``."""
 
     def customSetup(self, args):
-        self.controlMesh = args[0]
-        self.RTorN = args[1]
-        self.degrees = args[2]
+        self.controlMesh, self.RTorN, self.degrees = args[0], args[1], args[2]
         self.periodicities = args[3] if len(args) > 3 else None
-        self.fields = generateFieldsCompat(self.controlMesh, self.RTorN, self.degrees,
-                                           periodicities=self.periodicities)
+        self.fields = generateFieldsCompat(self.controlMesh, self.RTorN, self.degrees, self.periodicities)
 
     def getControlMesh(self):
         return self.controlMesh
 
-    def getFieldSpline(self, field):
-        return self.fields[field]
-
     def getNFields(self):
         return len(self.fields)
+
+    def getFieldSpline(self, field):
+        return self.fields[field]

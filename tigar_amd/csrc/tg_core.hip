@@ -550,6 +550,49 @@ extern "C" int tg_vec_dot(tg_vec_t x, tg_vec_t y, double *out) {
   return 0;
 }
 
+// l1 / linf norms (dolfin GenericVector::norm("l1"|"linf") [ext]): fixed grid of partials, one folding block
+__global__ void __launch_bounds__(256) k_absnorm_partial(const double *x, int64_t n, int use_max, double *partial) {
+  __shared__ double lds[256];
+  double s = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double a = fabs(x[i]);
+    s = use_max ? ((a > s || a != a) ? a : s) : s + a;   // NaN propagates in both norms
+  }
+  lds[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const double b = lds[threadIdx.x + o], a = lds[threadIdx.x];
+      lds[threadIdx.x] = use_max ? ((b > a || b != b) ? b : a) : a + b;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = lds[0];
+}
+
+extern "C" int tg_vec_norm(tg_vec_t x, int kind, double *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(x && out && kind >= 0 && kind <= 2, "bad arguments to tg_vec_norm (kind 0 = l1, 1 = l2, 2 = linf)");
+  if (kind == 1) {
+    TG_TRY(tg_vec_dot(x, x, out));
+    *out = sqrt(*out);
+    return 0;
+  }
+  double *partial = g_tg.scratch;
+  hipLaunchKernelGGL(k_absnorm_partial, dim3(TG_DOT_BLOCKS), dim3(256), 0, g_tg.stream, x->d, x->n, kind == 2 ? 1 : 0,
+                     partial);
+  hipLaunchKernelGGL(k_absnorm_partial, dim3(1), dim3(256), 0, g_tg.stream, partial, (int64_t)TG_DOT_BLOCKS,
+                     kind == 2 ? 1 : 0, partial + TG_DOT_BLOCKS);
+  TG_LAUNCH_CHECK();
+  TG_CHECK_HIP(hipMemcpyAsync(g_tg.host_pinned, partial + TG_DOT_BLOCKS, sizeof(double), hipMemcpyDeviceToHost,
+                              g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  *out = g_tg.host_pinned[0];
+  return 0;
+}
+
 __global__ void k_zero_entries(double *y, int64_t n, const int32_t *dofs, int64_t nd, int64_t g0) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nd) {
@@ -663,6 +706,31 @@ extern "C" int tg_csr_rowptr_at(tg_csr_t m, int64_t r, int64_t *out) {
   TG_REQUIRE_CANONICAL(m);
   TG_CHECK_HIP(hipMemcpyAsync(out, m->rowptr + r, sizeof(int64_t), hipMemcpyDeviceToHost, g_tg.stream));
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  return 0;
+}
+
+// rows [r0, r1) of a device matrix to the host: rowptr_out[r1-r0+1] (relative to the first entry handed out),
+// then at most `cap` entries.  Two-call protocol: with col/val == nullptr only the row pointers are filled, so
+// the caller can size its buffers.  Parity tests sample rows of matrices that are too large to download whole.
+extern "C" int tg_csr_download_rows(tg_csr_t m, int64_t r0, int64_t r1, int64_t *rowptr_out, int32_t *col, double *val,
+                                    int64_t cap) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(m && rowptr_out && r0 >= 0 && r1 >= r0 && r1 <= m->nrows, "tg_csr_download_rows: bad row range");
+  TG_REQUIRE_CANONICAL(m);
+  const int64_t n = r1 - r0;
+  TG_CHECK_HIP(hipMemcpyAsync(rowptr_out, m->rowptr + r0, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost,
+                              g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  const int64_t e0 = rowptr_out[0], cnt = rowptr_out[n] - e0;
+  for (int64_t i = 0; i <= n; i++) rowptr_out[i] -= e0;
+  if (!col && !val) return 0;
+  TG_REQUIRE(col && val && cnt <= cap, "tg_csr_download_rows: %lld entries do not fit the buffers (%lld)",
+             (long long)cnt, (long long)cap);
+  if (cnt > 0) {
+    TG_CHECK_HIP(hipMemcpyAsync(col, m->col + e0, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, g_tg.stream));
+    TG_CHECK_HIP(hipMemcpyAsync(val, m->val + e0, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
+    TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  }
   return 0;
 }
 

@@ -6,6 +6,13 @@
 struct tg_comm_s {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
+  // host-staged variant (tg_comm_create_host): exchanges go through pinned host memory and the caller's transport
+  int kind = 0;                       // 0 = RCCL, 1 = host-staged
+  tg_host_allreduce_fn h_allreduce = nullptr;
+  tg_host_sendrecv_fn h_sendrecv = nullptr;
+  void *h_ctx = nullptr;
+  double *stage = nullptr;            // pinned
+  int64_t stage_cap = 0;
   // this rank owns global dofs [g0,g1); its SpMV needs halo_lo dofs below g0 and halo_hi
   // above g1; send_lo / send_hi = what the neighbours need from this rank's ends
   int64_t g0 = 0, g1 = 0, halo_lo = 0, halo_hi = 0, nglobal = 0;

@@ -5,6 +5,7 @@
 // Reference counterparts: PETSc VecScatter inside MatMult and MPI_Allreduce inside VecDot /
 // VecNorm of the KSP called at tIGAr/common.py:1255-1258 [ext].
 #include "tg_dist.h"
+#include <algorithm>
 
 extern "C" int tg_comm_unique_id(char *id128) {
   TG_REQUIRE(id128, "null id buffer");
@@ -33,16 +34,73 @@ extern "C" int tg_comm_create(const char *id128, int rank, int world, tg_comm_t 
   return 0;
 }
 
+extern "C" int tg_comm_create_host(int rank, int world, tg_host_allreduce_fn allreduce, tg_host_sendrecv_fn sendrecv,
+                                   void *ctx, tg_comm_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(out && world >= 1 && rank >= 0 && rank < world && allreduce && sendrecv, "bad arguments to tg_comm_create_host");
+  tg_comm_s *c = new tg_comm_s();
+  c->rank = rank;
+  c->world = world;
+  c->kind = 1;
+  c->h_allreduce = allreduce;
+  c->h_sendrecv = sendrecv;
+  c->h_ctx = ctx;
+  *out = c;
+  return 0;
+}
+
+extern "C" int tg_comm_info(tg_comm_t c, int *rank, int *world, int *kind) {
+  TG_REQUIRE(c && rank && world && kind, "null argument to tg_comm_info");
+  *rank = c->rank;
+  *world = c->world;
+  *kind = c->kind;
+  if (c->kind == 0 && c->comm) {   // what RCCL itself reports, not what the caller claimed
+    int n = 0, r = -1;
+    TG_CHECK_NCCL(ncclCommCount(c->comm, &n));
+    TG_CHECK_NCCL(ncclCommUserRank(c->comm, &r));
+    *world = n;
+    *rank = r;
+  }
+  return 0;
+}
+
+extern "C" int tg_device_count(int *n) {
+  TG_REQUIRE(n, "null argument to tg_device_count");
+  TG_CHECK_HIP(hipGetDeviceCount(n));
+  return 0;
+}
+
 extern "C" int tg_comm_destroy(tg_comm_t c) {
   if (!c) return 0;
   if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
   if (c->comm) ncclCommDestroy(c->comm);
+  if (c->stage) hipHostFree(c->stage);
   delete c;
+  return 0;
+}
+
+static int tg_comm_stage_reserve(tg_comm_s *c, int64_t doubles) {
+  if (doubles <= c->stage_cap) return 0;
+  if (c->stage) hipHostFree(c->stage);
+  c->stage = nullptr;
+  c->stage_cap = 0;
+  TG_CHECK_HIP(hipHostMalloc((void **)&c->stage, (size_t)doubles * sizeof(double), hipHostMallocDefault));
+  c->stage_cap = doubles;
   return 0;
 }
 
 int tg_comm_allreduce_dev(tg_comm_s *c, double *dev, int n) {
   if (!c || c->world == 1) return 0;
+  if (c->kind == 1) {
+    TG_TRY(tg_comm_stage_reserve(c, std::max<int64_t>(n, 64)));
+    TG_CHECK_HIP(hipMemcpyAsync(c->stage, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
+    TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+    TG_REQUIRE(c->h_allreduce(c->h_ctx, c->stage, n) == 0, "host transport: allreduce failed (rank %d)", c->rank);
+    TG_CHECK_HIP(hipMemcpyAsync(dev, c->stage, (size_t)n * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
+    // the staging buffer is reused by the next exchange: the copy must have left it
+    TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+    return 0;
+  }
   TG_CHECK_NCCL(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, c->comm, g_tg.stream));
   return 0;
 }
@@ -101,18 +159,53 @@ int tg_comm_halo_exchange(tg_comm_s *c, double *xext) {
   TG_REQUIRE(c->slab_set, "tg_comm_set_slab() has not been called");
   double *own = xext + c->halo_lo;
   const int64_t nloc = c->g1 - c->g0;
+  if (c->kind == 1) {
+    // staging layout: [send_lo | send_hi | recv_lo (halo_lo) | recv_hi (halo_hi)]
+    const int64_t total = c->send_lo + c->send_hi + c->halo_lo + c->halo_hi;
+    TG_TRY(tg_comm_stage_reserve(c, std::max<int64_t>(total, 64)));
+    double *s_lo = c->stage, *s_hi = s_lo + c->send_lo, *r_lo = s_hi + c->send_hi, *r_hi = r_lo + c->halo_lo;
+    if (c->send_lo > 0)
+      TG_CHECK_HIP(hipMemcpyAsync(s_lo, own, (size_t)c->send_lo * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
+    if (c->send_hi > 0)
+      TG_CHECK_HIP(hipMemcpyAsync(s_hi, own + nloc - c->send_hi, (size_t)c->send_hi * sizeof(double),
+                                  hipMemcpyDeviceToHost, g_tg.stream));
+    TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+    // lower neighbour first, then the upper one: the chain rank 0 <-> 1, 1 <-> 2, ... cannot dead-lock
+    // because every exchange sends and receives at once
+    if (c->rank > 0 && (c->send_lo > 0 || c->halo_lo > 0))
+      TG_REQUIRE(c->h_sendrecv(c->h_ctx, c->rank - 1, s_lo, c->send_lo, r_lo, c->halo_lo) == 0,
+                 "host transport: exchange with rank %d failed", c->rank - 1);
+    if (c->rank < c->world - 1 && (c->send_hi > 0 || c->halo_hi > 0))
+      TG_REQUIRE(c->h_sendrecv(c->h_ctx, c->rank + 1, s_hi, c->send_hi, r_hi, c->halo_hi) == 0,
+                 "host transport: exchange with rank %d failed", c->rank + 1);
+    if (c->halo_lo > 0)
+      TG_CHECK_HIP(hipMemcpyAsync(xext, r_lo, (size_t)c->halo_lo * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
+    if (c->halo_hi > 0)
+      TG_CHECK_HIP(hipMemcpyAsync(own + nloc, r_hi, (size_t)c->halo_hi * sizeof(double), hipMemcpyHostToDevice,
+                                  g_tg.stream));
+    TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+    return 0;
+  }
   TG_CHECK_NCCL(ncclGroupStart());
+  // between GroupStart and GroupEnd the first error is remembered and the group is still closed
+  ncclResult_t first = ncclSuccess;
+  auto note = [&](ncclResult_t r) {
+    if (r != ncclSuccess && first == ncclSuccess) first = r;
+  };
   if (c->rank > 0) {
-    if (c->send_lo > 0) TG_CHECK_NCCL(ncclSend(own, (size_t)c->send_lo, ncclDouble, c->rank - 1, c->comm, g_tg.stream));
-    if (c->halo_lo > 0) TG_CHECK_NCCL(ncclRecv(xext, (size_t)c->halo_lo, ncclDouble, c->rank - 1, c->comm, g_tg.stream));
+    if (c->send_lo > 0) note(ncclSend(own, (size_t)c->send_lo, ncclDouble, c->rank - 1, c->comm, g_tg.stream));
+    if (c->halo_lo > 0) note(ncclRecv(xext, (size_t)c->halo_lo, ncclDouble, c->rank - 1, c->comm, g_tg.stream));
   }
   if (c->rank < c->world - 1) {
     if (c->send_hi > 0)
-      TG_CHECK_NCCL(ncclSend(own + nloc - c->send_hi, (size_t)c->send_hi, ncclDouble, c->rank + 1, c->comm, g_tg.stream));
-    if (c->halo_hi > 0)
-      TG_CHECK_NCCL(ncclRecv(own + nloc, (size_t)c->halo_hi, ncclDouble, c->rank + 1, c->comm, g_tg.stream));
+      note(ncclSend(own + nloc - c->send_hi, (size_t)c->send_hi, ncclDouble, c->rank + 1, c->comm, g_tg.stream));
+    if (c->halo_hi > 0) note(ncclRecv(own + nloc, (size_t)c->halo_hi, ncclDouble, c->rank + 1, c->comm, g_tg.stream));
   }
-  TG_CHECK_NCCL(ncclGroupEnd());
+  note(ncclGroupEnd());
+  if (first != ncclSuccess) {
+    tg_set_error("halo exchange (rank %d): %s", c->rank, ncclGetErrorString(first));
+    return 1;
+  }
   return 0;
 }
 

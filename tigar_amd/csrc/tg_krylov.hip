@@ -70,76 +70,134 @@ __global__ void __launch_bounds__(256) k_jacobi_setup(const int64_t *__restrict_
   }
 }
 
-// r = b ; z = dinv*r ; p = z ; partial sums of r.z and z.z
-__global__ void __launch_bounds__(256) k_cg_init(const double *__restrict__ b, const double *__restrict__ dinv,
-                                                 double *__restrict__ r, double *__restrict__ p, double *__restrict__ x,
-                                                 int64_t n, double *__restrict__ partial) {
+// ---------------------------------------------------------------------------------------- CG
+// Single-reduction CG (Chronopoulos & Gear 1989; PETSc: KSPCG with -ksp_cg_single_reduction [ext]): the
+// same iterates as the textbook recurrence in exact arithmetic, but the three inner products of an
+// iteration -- gamma = (r,u), delta = (K u, u), nu = (u,u), u = B r -- are available at one point, so a
+// multi-GPU iteration costs ONE all-reduce of three doubles (24 B) instead of two, and nothing in the loop
+// needs the host: step lengths are computed on the device from the reduced scalars by every workgroup of
+// the update kernel, which also freezes the state once nu <= tol^2.  The host enqueues iterations ahead of
+// the device and reads the norm history two iterations late (pinned ring + events); after convergence the
+// at most two extra iterations in flight are no-ops, so x is the iterate of the converged iteration.
+//
+//   u = B r, w = K u                                  (r = b - K x0)
+//   p = u + beta p ; s = w + beta s                   (s = K p)
+//   x += alpha p ; r -= alpha s ; u = B r ; w = K u
+//   beta' = gamma'/gamma ; alpha' = gamma' / (delta' - beta' gamma' / alpha)
+struct tg_cg_scal {     // device-resident scalars of one parity
+  double gamma, delta, nu;       // reduced over blocks (and ranks) for the CURRENT u
+  double gamma_prev, alpha_prev; // state of the recurrence
+};
+
+// r = b - kx0 (kx0 may be null) ; u = dinv r ; p = s = 0 ; partials of (r,u), (u,u)
+__global__ void __launch_bounds__(256) k_cg1_init(const double *__restrict__ b, const double *__restrict__ kx0,
+                                                  const double *__restrict__ dinv, double *__restrict__ r,
+                                                  double *__restrict__ u, double *__restrict__ p,
+                                                  double *__restrict__ s, int64_t n, double *__restrict__ partial) {
   __shared__ double lds4[4];
-  double rz = 0.0, zz = 0.0;
+  double g = 0.0, nu = 0.0;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    const double ri = b[i];
-    const double zi = dinv[i] * ri;
+    const double ri = kx0 ? b[i] - kx0[i] : b[i];
+    const double ui = dinv[i] * ri;
     r[i] = ri;
-    p[i] = zi;
-    x[i] = 0.0;
-    rz += ri * zi;
-    zz += zi * zi;
+    u[i] = ui;
+    p[i] = 0.0;
+    s[i] = 0.0;
+    g += ri * ui;
+    nu += ui * ui;
   }
-  rz = tg_block_sum256(rz, lds4);
-  zz = tg_block_sum256(zz, lds4);
+  g = tg_block_sum256(g, lds4);
+  nu = tg_block_sum256(nu, lds4);
   if (threadIdx.x == 0) {
-    partial[2 * blockIdx.x] = rz;
-    partial[2 * blockIdx.x + 1] = zz;
+    partial[2 * blockIdx.x] = g;
+    partial[2 * blockIdx.x + 1] = nu;
   }
 }
 
-// alpha = rz_old / pKp ; x += alpha p ; r -= alpha Kp ; z = dinv r ; partials of r.z, z.z
-__global__ void __launch_bounds__(256)
-    k_cg_update(const double *__restrict__ scal_rz_old, const double *__restrict__ scal_pkp,
-                const double *__restrict__ p, const double *__restrict__ kp, const double *__restrict__ dinv,
-                double *__restrict__ x, double *__restrict__ r, int64_t n, double *__restrict__ partial) {
+// partial of (w, u)
+__global__ void __launch_bounds__(256) k_cg1_dot(const double *__restrict__ w, const double *__restrict__ u, int64_t n,
+                                                 double *__restrict__ partial) {
   __shared__ double lds4[4];
-  const double alpha = scal_rz_old[0] / scal_pkp[0];
-  double rz = 0.0, zz = 0.0;
+  double d = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) d += w[i] * u[i];
+  d = tg_block_sum256(d, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = d;
+}
+
+// folds the (gamma, nu) partials of the update kernel and the delta partials of the dot kernel into cur->{gamma,delta,nu}
+__global__ void __launch_bounds__(256) k_cg1_fold(const double *__restrict__ part_gn, const double *__restrict__ part_d,
+                                                  int nb, tg_cg_scal *cur) {
+  __shared__ double lds4[4];
+  double g = 0.0, nu = 0.0, d = 0.0;
+  for (int b = threadIdx.x; b < nb; b += 256) {
+    g += part_gn[2 * b];
+    nu += part_gn[2 * b + 1];
+    d += part_d[b];
+  }
+  g = tg_block_sum256(g, lds4);
+  d = tg_block_sum256(d, lds4);
+  nu = tg_block_sum256(nu, lds4);
+  if (threadIdx.x == 0) {
+    cur->gamma = g;
+    cur->delta = d;
+    cur->nu = nu;
+  }
+}
+
+// one CG step from the scalars of `cur`; writes the recurrence state of the next parity into `nxt`
+__global__ void __launch_bounds__(256)
+    k_cg1_update(const tg_cg_scal *__restrict__ cur, tg_cg_scal *__restrict__ nxt, double tol2, int first,
+                 const double *__restrict__ w, const double *__restrict__ dinv, double *__restrict__ u,
+                 double *__restrict__ p, double *__restrict__ s, double *__restrict__ x, double *__restrict__ r,
+                 int64_t n, double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  const double gamma = cur->gamma, delta = cur->delta, nu = cur->nu;
+  // converged (or broken down: NaN) before this step: keep everything as it is
+  const bool frozen = !(nu > tol2);
+  double beta = 0.0, alpha;
+  if (first)
+    alpha = gamma / delta;
+  else {
+    beta = gamma / cur->gamma_prev;
+    alpha = gamma / (delta - beta * gamma / cur->alpha_prev);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    nxt->gamma_prev = frozen ? cur->gamma_prev : gamma;
+    nxt->alpha_prev = frozen ? cur->alpha_prev : alpha;
+  }
+  if (frozen) {
+    if (threadIdx.x == 0) {   // the fold of the next parity must reproduce the same gamma, nu
+      partial[2 * blockIdx.x] = blockIdx.x == 0 ? gamma : 0.0;
+      partial[2 * blockIdx.x + 1] = blockIdx.x == 0 ? nu : 0.0;
+    }
+    return;
+  }
+  double g = 0.0, nn = 0.0;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    x[i] += alpha * p[i];
-    const double ri = r[i] - alpha * kp[i];
+    const double pi = u[i] + beta * p[i];
+    const double si = w[i] + beta * s[i];
+    p[i] = pi;
+    s[i] = si;
+    x[i] += alpha * pi;
+    const double ri = r[i] - alpha * si;
     r[i] = ri;
-    const double zi = dinv[i] * ri;
-    rz += ri * zi;
-    zz += zi * zi;
+    const double ui = dinv[i] * ri;
+    u[i] = ui;
+    g += ri * ui;
+    nn += ui * ui;
   }
-  rz = tg_block_sum256(rz, lds4);
-  zz = tg_block_sum256(zz, lds4);
+  g = tg_block_sum256(g, lds4);
+  nn = tg_block_sum256(nn, lds4);
   if (threadIdx.x == 0) {
-    partial[2 * blockIdx.x] = rz;
-    partial[2 * blockIdx.x + 1] = zz;
+    partial[2 * blockIdx.x] = g;
+    partial[2 * blockIdx.x + 1] = nn;
   }
-}
-
-// beta = rz_new / rz_old ; p = dinv r + beta p
-__global__ void __launch_bounds__(256)
-    k_cg_direction(const double *__restrict__ scal_rz_new, const double *__restrict__ scal_rz_old,
-                   const double *__restrict__ r, const double *__restrict__ dinv, double *__restrict__ p, int64_t n) {
-  const double beta = scal_rz_new[0] / scal_rz_old[0];
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) p[i] = dinv[i] * r[i] + beta * p[i];
-}
-
-__global__ void __launch_bounds__(256) k_dot2_partial(const double *__restrict__ a, const double *__restrict__ b,
-                                                      int64_t n, double *__restrict__ partial) {
-  __shared__ double lds4[4];
-  double s = 0.0;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) s += a[i] * b[i];
-  s = tg_block_sum256(s, lds4);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
 static inline int tg_vec_grid(int64_t n) {
@@ -166,105 +224,165 @@ static int tg_read_scalars(const double *dev, int n, double *host) {
   return 0;
 }
 
-static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, tg_comm_s *comm,
-                 int *iters, double *resnorm, int *status) {
+#define TG_CG_RING 8
+struct tg_cg_ring {     // per-iteration events: norm history copies and SpMV timing
+  hipEvent_t done[TG_CG_RING], t0[TG_CG_RING], t1[TG_CG_RING];
+  bool ok = false;
+  int init() {
+    for (int i = 0; i < TG_CG_RING; i++) {
+      TG_CHECK_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+      TG_CHECK_HIP(hipEventCreate(&t0[i]));
+      TG_CHECK_HIP(hipEventCreate(&t1[i]));
+    }
+    ok = true;
+    return 0;
+  }
+  ~tg_cg_ring() {
+    if (!ok) return;
+    for (int i = 0; i < TG_CG_RING; i++) {
+      hipEventDestroy(done[i]);
+      hipEventDestroy(t0[i]);
+      hipEventDestroy(t1[i]);
+    }
+  }
+};
+
+static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, int nonzero_guess,
+                 tg_comm_s *comm, int *iters, double *resnorm, int *status) {
   const int64_t n = k->nrows;
   const int64_t hlo = comm ? comm->halo_lo : 0, hhi = comm ? comm->halo_hi : 0;
   const int64_t row0 = comm ? comm->g0 : 0;
   const int64_t next = hlo + n + hhi;
   tg_krylov_ws ws;
-  // layout: pext[next] | r[n] | kp[n] | dinv[n]
-  TG_TRY(tg_dmalloc(&ws.buf, next + 3 * n));
-  double *pext = ws.buf, *p = pext + hlo, *r = pext + next, *kp = r + n, *dinv = kp + n;
-  TG_CHECK_HIP(hipMemsetAsync(pext, 0, (size_t)next * sizeof(double), g_tg.stream));
-  double *partial = g_tg.scratch;                       // up to 32768 partial doubles
-  double *scal = g_tg.scratch + TG_SCRATCH_DOUBLES - 2048;  // rz[2], pkp, rz/zz pair
-  double *s_rz = scal;        // [0],[1] alternate old/new
-  double *s_pkp = scal + 2;
-  double *s_pair = scal + 4;  // (rz_new, zz) written together
+  // layout: uext[next] | r[n] | w[n] | p[n] | s[n] | dinv[n]
+  TG_TRY(tg_dmalloc(&ws.buf, next + 5 * n));
+  double *uext = ws.buf, *u = uext + hlo, *r = uext + next, *w = r + n, *p = w + n, *s = p + n, *dinv = s + n;
+  TG_CHECK_HIP(hipMemsetAsync(uext, 0, (size_t)next * sizeof(double), g_tg.stream));
+  double *part_gn = g_tg.scratch;                          // 2 * TG_VEC_BLOCKS
+  double *part_d = g_tg.scratch + 2 * TG_VEC_BLOCKS;       // TG_VEC_BLOCKS
+  tg_cg_scal *sc = (tg_cg_scal *)(g_tg.scratch + TG_SCRATCH_DOUBLES - 2048);   // two parities
   const int vg = tg_vec_grid(n);
   TG_TRY(tg_spmv_plan(k));
   tg_sell_guard sell_guard(k);   // sliced copy of the values for the products of this solve
   TG_TRY(sell_guard.rc);
+  tg_cg_ring ring;
+  TG_TRY(ring.init());
+  double *hist = g_tg.host_pinned + 8;                     // TG_CG_RING x 3 doubles (pinned)
+  const double *ushift = uext - (row0 - hlo);              // u addressed by global column index
+  const int64_t cmin = row0 - hlo, cmax = row0 - hlo + next - 1;
 
   if (n > 0) {
     const unsigned jg = (unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16);
     hipLaunchKernelGGL(k_jacobi_setup, dim3(jg), dim3(256), 0, g_tg.stream, k->rowptr, k->col, k->val, n, row0,
                        pc == TG_PC_JACOBI ? 1 : 0, dinv);
   }
-  hipLaunchKernelGGL(k_cg_init, dim3(vg), dim3(256), 0, g_tg.stream, b->d, dinv, r, p, x->d, n, partial);
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, g_tg.stream, partial, vg, 2, s_pair);
+  // reference norm: ||B b|| -- also with a non-zero initial guess (KSPConvergedDefault without
+  // -ksp_converged_use_initial_residual_norm [ext])
+  double bnorm2 = 0.0;
+  if (nonzero_guess) {
+    hipLaunchKernelGGL(k_cg1_init, dim3(vg), dim3(256), 0, g_tg.stream, b->d, (const double *)nullptr, dinv, r, u, p, s,
+                       n, part_gn);
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, g_tg.stream, part_gn, vg, 2, (double *)&sc[0]);
+    TG_LAUNCH_CHECK();
+    TG_TRY(tg_comm_allreduce_dev(comm, (double *)&sc[0], 2));
+    double h2[2];
+    TG_TRY(tg_read_scalars((double *)&sc[0], 2, h2));
+    bnorm2 = h2[1];
+    // r = b - K x0: x0 with its halo goes through uext, the product lands in w
+    TG_CHECK_HIP(hipMemcpyAsync(u, x->d, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream));
+    TG_TRY(tg_comm_halo_exchange(comm, uext));
+    TG_TRY(tg_spmv_raw(k, ushift, cmin, cmax, w));
+    hipLaunchKernelGGL(k_cg1_init, dim3(vg), dim3(256), 0, g_tg.stream, b->d, (const double *)w, dinv, r, u, p, s, n,
+                       part_gn);
+  } else {
+    TG_CHECK_HIP(hipMemsetAsync(x->d, 0, (size_t)std::max<int64_t>(n, 1) * sizeof(double), g_tg.stream));
+    hipLaunchKernelGGL(k_cg1_init, dim3(vg), dim3(256), 0, g_tg.stream, b->d, (const double *)nullptr, dinv, r, u, p, s,
+                       n, part_gn);
+  }
   TG_LAUNCH_CHECK();
-  TG_TRY(tg_comm_allreduce_dev(comm, s_pair, 2));
-  double h[2];
-  TG_TRY(tg_read_scalars(s_pair, 2, h));
-  // rz_old <- rz
-  TG_CHECK_HIP(hipMemcpyAsync(s_rz, s_pair, sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream));
-  const double znorm0 = sqrt(h[1]);
+  // w = K u, delta; scalars of parity 0
+  auto product_and_reduce = [&](tg_cg_scal *cur, int slot) -> int {
+    TG_TRY(tg_comm_halo_exchange(comm, uext));
+    hipEventRecord(ring.t0[slot], g_tg.stream);
+    TG_TRY(tg_spmv_raw(k, ushift, cmin, cmax, w));
+    hipEventRecord(ring.t1[slot], g_tg.stream);
+    hipLaunchKernelGGL(k_cg1_dot, dim3(vg), dim3(256), 0, g_tg.stream, w, u, n, part_d);
+    hipLaunchKernelGGL(k_cg1_fold, dim3(1), dim3(256), 0, g_tg.stream, part_gn, part_d, vg, cur);
+    TG_LAUNCH_CHECK();
+    TG_TRY(tg_comm_allreduce_dev(comm, (double *)cur, 3));
+    TG_CHECK_HIP(hipMemcpyAsync(hist + 3 * slot, cur, 3 * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
+    TG_CHECK_HIP(hipEventRecord(ring.done[slot], g_tg.stream));
+    return 0;
+  };
+  auto account = [&](int slot) {
+    float ems = 0.f;
+    if (hipEventElapsedTime(&ems, ring.t0[slot], ring.t1[slot]) == hipSuccess) {
+      g_tg.prof_ms[TG_PROF_KSP_SPMV] += ems;
+      g_tg.prof_n[TG_PROF_KSP_SPMV] += 1;
+    }
+  };
+  TG_TRY(product_and_reduce(&sc[0], 0));
+  TG_CHECK_HIP(hipEventSynchronize(ring.done[0]));
+  account(0);
+  const double nu0 = hist[2];
+  const double znorm_init = sqrt(nu0);
+  const double znorm0 = nonzero_guess ? sqrt(bnorm2) : znorm_init;
   const double tol = std::max(rtol * znorm0, atol);
-  double znorm = znorm0;
+  // host and device take the SAME decision: both compare nu = ||B r||^2 with this tol2
+  const double tol2 = tol * tol;
   *iters = 0;
   *status = 0;
-  if (!(znorm0 == znorm0)) {
+  *resnorm = znorm_init;
+  if (!(znorm_init == znorm_init) || !(znorm0 == znorm0)) {
     *status = -2;
-    *resnorm = znorm0;
     return 0;
   }
-  if (znorm0 <= atol) {
-    *status = 1;
-    *resnorm = znorm0;
+  if (!(nu0 > tol2)) {
+    *status = (znorm_init <= atol && !(znorm_init <= rtol * znorm0)) ? 1 : 0;
     return 0;
   }
-  int it = 0;
+  // iterations are enqueued `look` ahead of the one whose norm the host has seen
+  const int look = 2;
   *status = -1;
-  double t_launch = 0, t_sync = 0, t_all0 = tk_now();
-  for (it = 1; it <= maxit; it++) {
-    const double _ta = tk_now();
-    double *rz_old = s_rz + ((it - 1) & 1), *rz_new = s_rz + (it & 1);
-    TG_TRY(tg_comm_halo_exchange(comm, pext));
-    // Kp = K p   (x addressed by global column index); then p . Kp on a fixed grid so the
-    // reduction order (and the result) does not depend on the matrix size
-    hipEventRecord(g_tg.pev0, g_tg.stream);
-    TG_TRY(tg_spmv_raw(k, pext - (row0 - hlo), row0 - hlo, row0 - hlo + next - 1, kp));
-    hipEventRecord(g_tg.pev1, g_tg.stream);
-    hipLaunchKernelGGL(k_dot2_partial, dim3(vg), dim3(256), 0, g_tg.stream, p, kp, n, partial);
-    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, g_tg.stream, partial, vg, 1, s_pkp);
-    TG_TRY(tg_comm_allreduce_dev(comm, s_pkp, 1));
-    hipLaunchKernelGGL(k_cg_update, dim3(vg), dim3(256), 0, g_tg.stream, rz_old, s_pkp, p, kp, dinv, x->d, r, n,
-                       partial);
-    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, g_tg.stream, partial, vg, 2, s_pair);
-    TG_LAUNCH_CHECK();
-    TG_TRY(tg_comm_allreduce_dev(comm, s_pair, 2));
-    TG_CHECK_HIP(hipMemcpyAsync(rz_new, s_pair, sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream));
-    const double _tb = tk_now();
-    TG_TRY(tg_read_scalars(s_pair, 2, h));
-    t_launch += _tb - _ta;
-    t_sync += tk_now() - _tb;
-    {
-      float ems = 0.f;  // the sync above also completed this iteration's SpMV event pair
-      if (hipEventElapsedTime(&ems, g_tg.pev0, g_tg.pev1) == hipSuccess) {
-        g_tg.prof_ms[TG_PROF_KSP_SPMV] += ems;
-        g_tg.prof_n[TG_PROF_KSP_SPMV] += 1;
-      }
-    }
-    znorm = sqrt(h[1]);
-    if (!(znorm == znorm)) {
+  int seen = 0;           // iterations whose norm the host has read
+  int it_conv = -1;
+  double znorm = znorm_init;
+  const double t_all0 = tk_now();
+  auto observe = [&](int it) -> bool {   // reads iteration `it`; true when the loop has to stop
+    const int slot = it % TG_CG_RING;
+    if (hipEventSynchronize(ring.done[slot]) != hipSuccess) return true;
+    account(slot);
+    const double nu = hist[3 * slot + 2];
+    znorm = sqrt(nu);
+    seen = it;
+    if (!(nu == nu)) {
       *status = -2;
-      break;
+      it_conv = it;
+      return true;
     }
-    if (znorm <= tol) {
+    if (!(nu > tol2)) {
       *status = (znorm <= atol && !(znorm <= rtol * znorm0)) ? 1 : 0;
-      break;
+      it_conv = it;
+      return true;
     }
-    hipLaunchKernelGGL(k_cg_direction, dim3(vg), dim3(256), 0, g_tg.stream, rz_new, rz_old, r, dinv, p, n);
-    TG_LAUNCH_CHECK();
+    return false;
+  };
+  int it = 0;
+  bool stop = false;
+  for (it = 1; it <= maxit && !stop; it++) {
+    tg_cg_scal *cur = &sc[(it - 1) & 1], *nxt = &sc[it & 1];
+    hipLaunchKernelGGL(k_cg1_update, dim3(vg), dim3(256), 0, g_tg.stream, cur, nxt, tol2, it == 1 ? 1 : 0, w, dinv, u, p,
+                       s, x->d, r, n, part_gn);
+    TG_TRY(product_and_reduce(nxt, it % TG_CG_RING));
+    if (it - look >= 1) stop = observe(it - look);
   }
-  *iters = std::min(it, maxit);
+  const int enq = it - 1;                       // iterations enqueued
+  for (int j = seen + 1; j <= enq && it_conv < 0; j++) observe(j);
+  *iters = it_conv >= 0 ? it_conv : std::min(enq, maxit);
   *resnorm = znorm;
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
   if (getenv("TIGAR_TRACE"))
-    fprintf(stderr, "[trace] cg: %d its, loop %.3f s (launch %.3f s, sync wait %.3f s)\n", it, tk_now() - t_all0,
-            t_launch, t_sync);
+    fprintf(stderr, "[trace] cg: %d its (%d enqueued), loop %.3f s\n", *iters, enq, tk_now() - t_all0);
   return 0;
 }
 
@@ -345,7 +463,7 @@ __global__ void k_lincomb_add(double *__restrict__ x, const double *__restrict__
 }
 
 static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, int restart,
-                    tg_comm_s *comm, int *iters, double *resnorm, int *status) {
+                    int nonzero_guess, tg_comm_s *comm, int *iters, double *resnorm, int *status) {
   const int64_t n = k->nrows;
   const int64_t hlo = comm ? comm->halo_lo : 0, hhi = comm ? comm->halo_hi : 0;
   const int64_t row0 = comm ? comm->g0 : 0;
@@ -368,16 +486,32 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
     hipLaunchKernelGGL(k_jacobi_setup, dim3(jg), dim3(256), 0, g_tg.stream, k->rowptr, k->col, k->val, n, row0,
                        pc == TG_PC_JACOBI ? 1 : 0, dinv);
   }
-  TG_CHECK_HIP(hipMemsetAsync(x->d, 0, (size_t)std::max<int64_t>(n, 1) * sizeof(double), g_tg.stream));
+  double bnorm = -1.0;   // ||B b||: the reference norm when the initial guess is not zero [ext]
+  if (nonzero_guess) {
+    hipLaunchKernelGGL(k_prec_residual, dim3(vg), dim3(256), 0, g_tg.stream, b->d, (const double *)nullptr, dinv, V, n,
+                       partial);
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, g_tg.stream, partial, vg, 1, scal);
+    TG_LAUNCH_CHECK();
+    TG_TRY(tg_comm_allreduce_dev(comm, scal, 1));
+    double hb;
+    TG_TRY(tg_read_scalars(scal, 1, &hb));
+    bnorm = sqrt(hb);
+  } else
+    TG_CHECK_HIP(hipMemsetAsync(x->d, 0, (size_t)std::max<int64_t>(n, 1) * sizeof(double), g_tg.stream));
   std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2);
   auto Hat = [&](int i, int j) -> double & { return H[(size_t)i * m + j]; };
   double beta0 = -1.0, tol = 0.0, res = 0.0;
   int its = 0;
   *status = -1;
   bool first = true;
+  // stagnation guard: restarted GMRES can stall for good on indefinite / badly scaled systems (where the
+  // reference's default direct solver simply solves); 25 restart cycles in a row that each reduce the
+  // residual by less than 0.1 % end the solve with status -3 instead of running to the iteration limit
+  double cycle_res = -1.0;
+  int stagnant = 0;
   while (its < maxit) {
     // r = B (b - K x)
-    if (first) {
+    if (first && !nonzero_guess) {
       hipLaunchKernelGGL(k_prec_residual, dim3(vg), dim3(256), 0, g_tg.stream, b->d, (const double *)nullptr, dinv, V,
                          n, partial);
     } else {
@@ -395,7 +529,7 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
     const double beta = sqrt(hh);
     res = beta;
     if (first) {
-      beta0 = beta;
+      beta0 = nonzero_guess ? bnorm : beta;
       tol = std::max(rtol * beta0, atol);
       first = false;
       if (!(beta == beta)) {
@@ -411,6 +545,14 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
       *status = 0;
       break;
     }
+    if (cycle_res >= 0.0) {
+      stagnant = (beta > 0.999 * cycle_res) ? stagnant + 1 : 0;
+      if (stagnant >= 25) {
+        *status = -3;
+        break;
+      }
+    }
+    cycle_res = beta;
     hipLaunchKernelGGL(k_scale_to, dim3(vg), dim3(256), 0, g_tg.stream, V, V, 1.0 / beta, n);
     std::fill(g.begin(), g.end(), 0.0);
     g[0] = beta;
@@ -490,6 +632,13 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
 
 extern "C" int tg_krylov_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, int pc, double rtol, double atol,
                                int maxit, int restart, tg_comm_t comm, int *iters, double *resnorm, int *status) {
+  return tg_krylov_solve_flags(k, b, x, method, pc, rtol, atol, maxit, restart, 0, comm, iters, resnorm, status);
+}
+
+extern "C" int tg_krylov_solve_flags(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, int pc, double rtol, double atol,
+                                     int maxit, int restart, int flags, tg_comm_t comm, int *iters, double *resnorm,
+                                     int *status) {
+  const int g_krylov_nonzero_guess = (flags & TG_KSP_NONZERO_GUESS) ? 1 : 0;
   TG_REQUIRE_INIT();
   TG_REQUIRE(k && b && x && iters && resnorm && status, "null argument to tg_krylov_solve");
   TG_REQUIRE(b->n == k->nrows && x->n == k->nrows, "tg_krylov_solve: vector length != local rows");
@@ -500,10 +649,10 @@ extern "C" int tg_krylov_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, i
     TG_REQUIRE(k->nrows == k->ncols, "tg_krylov_solve: matrix must be square");
     comm = nullptr;
   }
-  if (method == TG_KSP_CG) return tg_cg(k, b, x, pc, rtol, atol, maxit, comm, iters, resnorm, status);
+  if (method == TG_KSP_CG) return tg_cg(k, b, x, pc, rtol, atol, maxit, g_krylov_nonzero_guess, comm, iters, resnorm, status);
   if (method == TG_KSP_GMRES) {
     TG_REQUIRE(restart >= 1 && restart <= 200, "GMRES restart out of range");
-    return tg_gmres(k, b, x, pc, rtol, atol, maxit, restart, comm, iters, resnorm, status);
+    return tg_gmres(k, b, x, pc, rtol, atol, maxit, restart, g_krylov_nonzero_guess, comm, iters, resnorm, status);
   }
   tg_set_error("unknown Krylov method %d", method);
   return 2;

@@ -7,10 +7,11 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import check, handle, tg_dir_t, tg_kron_dir_t, tg_kron1d_t, tg_patch_t, c_f64p, c_i32p, c_i64p
+from ._lib import TigarHipError, check, handle, tg_dir_t, tg_kron_dir_t, tg_kron1d_t, tg_patch_t, c_f64p, c_i32p, c_i64p
 
 TG_KSP_CG, TG_KSP_GMRES = 0, 1
 TG_PC_NONE, TG_PC_JACOBI = 0, 1
+TG_KSP_NONZERO_GUESS = 1
 
 
 def _f64(a):
@@ -95,7 +96,13 @@ class DeviceVector(object):
         return out.value
 
     def norm(self, kind="l2"):
-        return float(np.sqrt(self.inner(self)))
+        """dolfin GenericVector.norm: "l1", "l2" or "linf"."""
+        kinds = {"l1": 0, "l2": 1, "linf": 2}
+        if kind not in kinds:
+            raise ValueError("unsupported norm type %r (l1, l2, linf)" % (kind,))
+        out = C.c_double()
+        check(_lib.lib().tg_vec_norm(self._h, kinds[kind], C.byref(out)), "tg_vec_norm")
+        return out.value
 
     def zero_entries(self, dofs, g0=0):
         """y[d - g0] = 0 for the global dofs d that fall into this (slab-local) vector"""
@@ -153,6 +160,20 @@ class DeviceCSR(object):
         check(_lib.lib().tg_csr_download(self._h, _p(rowptr, c_i64p), _p(col, c_i32p), _p(val, c_f64p)),
               "tg_csr_download")
         return sp.csr_matrix((val, col, rowptr), shape=(nr, nc))
+
+    def rows_to_scipy(self, r0, r1):
+        """Rows [r0, r1) as a scipy CSR block (r1-r0 x ncols) -- for matrices too large to download whole."""
+        import scipy.sparse as sp
+        n = int(r1) - int(r0)
+        rowptr = np.empty(n + 1, dtype=np.int64)
+        check(_lib.lib().tg_csr_download_rows(self._h, int(r0), int(r1), _p(rowptr, c_i64p), None, None, 0),
+              "tg_csr_download_rows")
+        cnt = int(rowptr[-1])
+        col = np.empty(max(cnt, 1), dtype=np.int32)
+        val = np.empty(max(cnt, 1), dtype=np.float64)
+        check(_lib.lib().tg_csr_download_rows(self._h, int(r0), int(r1), _p(rowptr, c_i64p), _p(col, c_i32p),
+                                              _p(val, c_f64p), col.shape[0]), "tg_csr_download_rows")
+        return sp.csr_matrix((val[:cnt], col[:cnt], rowptr), shape=(n, self.shape[1]))
 
     def combine(self, a, other, b, colscale=None):
         """a*self + b*other*diag(colscale) for two matrices on one pattern (checked on the device)"""
@@ -456,13 +477,15 @@ def ptap_kron(cur, cur_row0, dims_in, factors, out_row0, out_row1, zero_dofs=Non
 
 
 # ------------------------------------------------------------------------------- Krylov
-def krylov_solve(K, b, x, method="cg", pc="jacobi", rtol=1e-6, atol=1e-15, maxit=10000, restart=30, comm=None):
+def krylov_solve(K, b, x, method="cg", pc="jacobi", rtol=1e-6, atol=1e-15, maxit=10000, restart=30, comm=None,
+                 nonzero_initial_guess=False):
     meth = {"cg": TG_KSP_CG, "gmres": TG_KSP_GMRES}[method]
     pcc = {"none": TG_PC_NONE, "jacobi": TG_PC_JACOBI}[pc]
     iters, status, res = C.c_int(), C.c_int(), C.c_double()
-    check(_lib.lib().tg_krylov_solve(K._h, b._h, x._h, meth, pcc, float(rtol), float(atol), int(maxit), int(restart),
-                                     comm._h if comm is not None else None, C.byref(iters), C.byref(res),
-                                     C.byref(status)), "tg_krylov_solve")
+    flags = TG_KSP_NONZERO_GUESS if nonzero_initial_guess else 0
+    check(_lib.lib().tg_krylov_solve_flags(K._h, b._h, x._h, meth, pcc, float(rtol), float(atol), int(maxit),
+                                           int(restart), flags, comm._h if comm is not None else None,
+                                           C.byref(iters), C.byref(res), C.byref(status)), "tg_krylov_solve")
     return iters.value, res.value, status.value
 
 
@@ -568,7 +591,7 @@ def assemble_mapped_load(vertices, p, cp, fnodal, nq=None):
     return out
 
 
-def tensor_apply_1d(x, dims_in, k, F, col_shift=0):
+def tensor_apply_1d(x, dims_in, k, F, col_shift=0, out=None):
     """Apply the scipy CSR 1-D factor ``F`` (rows = output indices of direction k, columns = input
     indices + col_shift) along direction ``k`` of the tensor-indexed DeviceVector ``x`` (direction 0
     fastest); returns the new DeviceVector (``tg_tensor_apply_1d``)."""
@@ -579,7 +602,10 @@ def tensor_apply_1d(x, dims_in, k, F, col_shift=0):
     n_out = 1
     for j, n in enumerate(dims_in):
         n_out *= F.shape[0] if j == k else int(n)
-    out = DeviceVector(n=n_out)
+    if out is None:
+        out = DeviceVector(n=n_out)
+    elif out.size() != n_out:
+        raise ValueError("tensor_apply_1d: output vector has %d entries, expected %d" % (out.size(), n_out))
     rp, ci, fv = _i32(F.indptr), _i32(F.indices), _f64(F.data)
     check(_lib.lib().tg_tensor_apply_1d(len(dims_in), _p(dims, c_i64p), int(k), int(F.shape[0]), _p(rp, c_i32p),
                                         _p(ci, c_i32p), _p(fv, c_f64p), int(col_shift), x._h, out._h),
@@ -649,6 +675,13 @@ def stream_wait(waiter, waited):
     check(_lib.lib().tg_stream_wait(int(waiter), int(waited)), "tg_stream_wait")
 
 
+def device_count():
+    """visible GPUs (no device is bound by this call)"""
+    n = C.c_int()
+    check(_lib.load(require_device=False).tg_device_count(C.byref(n)), "tg_device_count")
+    return n.value
+
+
 def device_info():
     name = C.create_string_buffer(256)
     ncu, hbm = C.c_int(), C.c_int64()
@@ -700,6 +733,12 @@ class Comm(object):
         check(_lib.lib().tg_comm_allreduce_sum(self._h, _p(v, c_f64p), v.size), "tg_comm_allreduce_sum")
         return v
 
+    def info(self):
+        """(rank, world, kind) as the communicator itself reports them (RCCL: ncclCommUserRank / ncclCommCount)"""
+        r, w, k = C.c_int(), C.c_int(), C.c_int()
+        check(_lib.lib().tg_comm_info(self._h, C.byref(r), C.byref(w), C.byref(k)), "tg_comm_info")
+        return r.value, w.value, ("rccl", "host")[k.value]
+
     def __del__(self):
         try:
             if self._h:
@@ -707,3 +746,36 @@ class Comm(object):
                 self._h = None
         except Exception:
             pass
+
+
+class HostComm(Comm):
+    """Host-staged communicator (``tg_comm_create_host``): the solver's halo exchange and scalar reductions
+    are staged through pinned host memory and carried by ``transport`` (``tigar_amd.launch.Transport``)."""
+
+    def __init__(self, transport):
+        self._h = handle()
+        self.transport = transport
+        self.rank, self.world = transport.rank, transport.world
+
+        def allreduce(ctx, ptr, n):
+            try:
+                a = np.ctypeslib.as_array(ptr, shape=(int(n),))
+                transport.allreduce_sum(a)
+                return 0
+            except Exception as e:           # an exception must not unwind through the C frames
+                self._err = e
+                return 1
+
+        def sendrecv(ctx, peer, sptr, ns, rptr, nr):
+            try:
+                send = np.ctypeslib.as_array(sptr, shape=(int(ns),)) if ns > 0 else np.zeros(0)
+                recv = np.ctypeslib.as_array(rptr, shape=(int(nr),)) if nr > 0 else np.zeros(0)
+                transport.sendrecv(int(peer), send, recv)
+                return 0
+            except Exception as e:
+                self._err = e
+                return 1
+        self._err = None
+        self._cb = (_lib.HOST_ALLREDUCE_FN(allreduce), _lib.HOST_SENDRECV_FN(sendrecv))   # keep the thunks alive
+        check(_lib.lib().tg_comm_create_host(self.rank, self.world, self._cb[0], self._cb[1], None, C.byref(self._h)),
+              "tg_comm_create_host")

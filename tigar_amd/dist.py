@@ -113,6 +113,23 @@ def layout_for(bspline, grid):
     return ZSlabLayout(s.knots, s.p, grid.axes[-1], grid.degree, plane_dofs, plane_fe)
 
 
+def pick_sub_planes(d, p, nel, planes_mine, free_bytes):
+    """dof planes per sub-slab so that one slab of A and the PtAP temporaries use at most about half
+    of the free HBM (K needs the rest).  Measured at 256^3 p=3 with the 3/4-of-HBM allocator pool, per step:
+    5 planes 1.59 s of input+PtAP, 8: 1.53 s, 12: 1.44 s, 16: 1.41 s with 75 GB still free at the end of a
+    step, 20: allocation failures and pool trimming start, 24: 5.6 s.  (The sliced copy of K's values that
+    lives during the Krylov solve, 47 GB at 256^3 p=3, is stored in idle blocks of the allocator's pool --
+    the PtAP temporaries sized here -- so it needs no budget of its own.)"""
+    nfe1 = nel * p + 1
+    plane_fe = nfe1 ** (d - 1)
+    nnzA_plane = plane_fe * ((2 * p + 1) ** d) * 0.55 * 12.0        # bytes per FE plane, generous
+    nnzM_plane = plane_fe * ((p + 1) ** d) * 12.0
+    per_dof_plane = p * (nnzA_plane + 2.2 * nnzM_plane) + (nel + p) ** (d - 1) * ((2 * p + 1) ** d) * 12.0 * 2
+    fixed = (2 * p * p + 2) * (nnzA_plane + 2.2 * nnzM_plane)
+    budget = 0.5 * free_bytes - fixed
+    return int(max(1, min(planes_mine, budget // per_dof_plane)))
+
+
 class SlabHotPath(object):
     """The hot path of one rank, streamed through HBM in sub-slabs of dof planes:
 
@@ -124,11 +141,11 @@ class SlabHotPath(object):
 
     With world == 1 and one sub-slab this is exactly the single-GPU path."""
 
-    def __init__(self, basis, grid, rank=0, world=1, comm=None, sub_planes=None, eps=1e-15, factored=None):
+    def __init__(self, basis, grid, rank=0, world=1, comm=None, sub_planes=None, eps=1e-15, factored=None, kx=None):
         from . import device as dev
         from .kronptap import KronExtraction
         self.dev = dev
-        self.kx = KronExtraction(basis, grid)
+        self.kx = kx if kx is not None else KronExtraction(basis, grid)
         # sum-factorised PtAP when M is exactly a Kronecker product (checked against the
         # closed-form nnz of M on the tensor grid); TIGAR_PTAP_FACTORED=0/1 overrides
         env = os.environ.get("TIGAR_PTAP_FACTORED")
@@ -152,6 +169,11 @@ class SlabHotPath(object):
         self.eps = eps
         self.layout = layout_for(basis, grid)
         self.k0, self.k1 = split_range(self.layout.ncp, world)[rank]
+        if sub_planes == "auto":
+            free_b, _ = dev.mem_info()
+            pmax = max(s1.p for s1 in basis.splines)
+            nelmax = max(s1.nel for s1 in basis.splines)
+            sub_planes = pick_sub_planes(basis.nvar, pmax, nelmax, self.k1 - self.k0, free_b)
         self.sub_planes = sub_planes or (self.k1 - self.k0)
         self.mine = self.layout.slab(self.k0, self.k1)
         self.ncp = basis.getNcp()
@@ -175,7 +197,8 @@ class SlabHotPath(object):
         import time
         dev = self.dev
         sp1, axes = self.basis.splines, self.grid.axes
-        zero_dofs = np.asarray(zero_dofs, dtype=np.int32)
+        zero_dofs = np.asarray(zero_dofs if zero_dofs is not None else [], dtype=np.int32)
+        with_rhs = b_rows is not None
         k_blocks, rhs_parts = [], []
         ring = {"hi": 0, "pieces": []}      # plane-local stage results kept across sub-slabs
         builder = None
@@ -213,7 +236,7 @@ class SlabHotPath(object):
             try:
                 # the vector first: producers of small objects tend to end with a host synchronisation
                 # (uploads from host arrays), which must not sit behind the long fill kernel of the matrix
-                b_i = b_rows(arows[0], arows[1])
+                b_i = b_rows(arows[0], arows[1]) if with_rhs else None
                 A_i = a_rows(lo * self.layout.plane_fe, zb * self.layout.plane_fe) if zb > lo else None
             finally:
                 dev.stream_set(0)
@@ -226,7 +249,7 @@ class SlabHotPath(object):
             use_factored = self.factored
             tensor_mtb = use_factored and self.kron_exact
             MT = None
-            if not tensor_mtb:
+            if not tensor_mtb and (with_rhs or not use_factored):
                 MT = dev.extract_csr_tensor_t(sp1, axes, 0, self.n_fe, self.eps, S["dofs"][0], S["dofs"][1])
             if use_factored and not tensor_mtb:
                 # exactness check of the Kronecker form on this slab: nnz(M^T rows) must equal the
@@ -251,10 +274,10 @@ class SlabHotPath(object):
                 new_lo = max(za, ring["hi"])               # FE planes not yet contracted
                 A = a_rows(new_lo * pf, zb * pf) if zb > new_lo else None
                 ring["new"] = (new_lo, zb)
-                b = b_rows(S["a_rows"][0], S["a_rows"][1])
+                b = b_rows(S["a_rows"][0], S["a_rows"][1]) if with_rhs else None
             else:
                 A = a_rows(S["a_rows"][0], S["a_rows"][1])
-                b = b_rows(S["a_rows"][0], S["a_rows"][1])
+                b = b_rows(S["a_rows"][0], S["a_rows"][1]) if with_rhs else None
             tick("input", t0)
             t0 = time.perf_counter()
             if use_factored:
@@ -286,22 +309,53 @@ class SlabHotPath(object):
             del kblk
             tick("stack", t0)
             t0 = time.perf_counter()
-            if tensor_mtb:
-                y = self._mtb_tensor(b, S, ka, kb)
-            else:
-                y = MT.mult_offset(b, S["a_rows"][0])
-            y.zero_entries(zero_dofs, S["dofs"][0])
-            rhs_parts.append(y)
-            tick("mtb", t0)
+            if with_rhs:
+                if tensor_mtb:
+                    y = self._mtb_tensor(b, S, ka, kb)
+                else:
+                    y = MT.mult_offset(b, S["a_rows"][0])
+                y.zero_entries(zero_dofs, S["dofs"][0])
+                rhs_parts.append(y)
+                tick("mtb", t0)
             del A, M, MT, b, plan
         t0 = time.perf_counter()
         K = k_blocks[0] if builder is None else builder.finish()
-        if len(rhs_parts) == 1:
-            rhs = rhs_parts[0]
-        else:
-            rhs = dev.vec_concat(rhs_parts)
+        rhs = None
+        if with_rhs:
+            rhs = rhs_parts[0] if len(rhs_parts) == 1 else dev.vec_concat(rhs_parts)
         tick("stack", t0)
         return K, rhs
+
+    def assemble_matrix(self, a_rows, zero_dofs, diag=1.0, timers=None):
+        """K_loc = rows of M^T A M owned by this rank (extractMatrix, tIGAr/common.py:1176-1204)."""
+        return self.assemble(a_rows, None, zero_dofs, diag, timers)[0]
+
+    def assemble_vector(self, b_rows, zero_dofs=None, timers=None):
+        """(M^T b)_loc with the boundary entries zeroed (extractVector, tIGAr/common.py:1142-1160): one
+        sum-factorised pass over the FE rows in the support of this rank's dofs when M is exactly the
+        Kronecker product, explicit M^T rows sub-slab by sub-slab otherwise.  ``b_rows(r0, r1)`` returns
+        the FE entries [r0, r1) as a DeviceVector."""
+        import time
+        dev = self.dev
+        t0 = time.perf_counter()
+        zero_dofs = np.asarray(zero_dofs if zero_dofs is not None else [], dtype=np.int32)
+        if self.kron_exact:
+            S = self.mine
+            y = self._mtb_tensor(b_rows(S["a_rows"][0], S["a_rows"][1]), S, self.k0, self.k1)
+        else:
+            parts = []
+            for (ka, kb) in self.sub_slabs():
+                S = self.layout.slab(ka, kb)
+                MT = dev.extract_csr_tensor_t(self.basis.splines, self.grid.axes, 0, self.n_fe, self.eps,
+                                              S["dofs"][0], S["dofs"][1])
+                parts.append(MT.mult_offset(b_rows(S["a_rows"][0], S["a_rows"][1]), S["a_rows"][0]))
+                del MT
+            y = parts[0] if len(parts) == 1 else dev.vec_concat(parts)
+        y.zero_entries(zero_dofs, self.mine["dofs"][0])
+        if timers is not None:
+            dev.sync()
+            timers["mtb"] = timers.get("mtb", 0.0) + time.perf_counter() - t0
+        return y
 
     def _factored_slab(self, A_new, S, ka, kb, zero_dofs, diag, ring, builder=None):
         """Sum-factorised K rows of dof planes [ka,kb).  The plane-local stages (all direction
@@ -339,11 +393,12 @@ class SlabHotPath(object):
         return contract(kx, cur, done, self.groups[-1], (lo, zb), (ca, cb), (ka * pl_out, kb * pl_out), zero_dofs, diag,
                         append_to=builder)
 
-    def solve(self, K, rhs, method="cg", pc="jacobi", rtol=1e-6, atol=1e-15, maxit=10000, restart=30):
+    def solve(self, K, rhs, method="cg", pc="jacobi", rtol=1e-6, atol=1e-15, maxit=10000, restart=30, x0=None):
         dev = self.dev
-        U = dev.DeviceVector(K.shape[0])
+        U = dev.DeviceVector(K.shape[0]) if x0 is None else x0
         its, res, status = dev.krylov_solve(K, rhs, U, method, pc, rtol, atol, maxit, restart,
-                                            self.comm if self.world > 1 else None)
+                                            self.comm if self.world > 1 else None,
+                                            nonzero_initial_guess=x0 is not None)
         return U, its, res, status
 
     def _mtb_tensor(self, b, S, ka, kb):
@@ -356,9 +411,9 @@ class SlabHotPath(object):
         dims = list(kx.nfe[:-1]) + [zb - za]
         t = b
         for k in range(d - 1):
-            t = dev.tensor_apply_1d(t, dims, k, kx.M1[k].T.tocsr())
+            t = dev.tensor_apply_1d(t, dims, k, kx.M1T[k])
             dims[k] = kx.ncp[k]
-        MzT = kx.M1[-1].T.tocsr()[ka:kb]
+        MzT = kx.M1T[-1][ka:kb]
         return dev.tensor_apply_1d(t, dims, d - 1, MzT, col_shift=za)
 
     def _prolong_tensor(self, x, dof_plane0):

@@ -127,7 +127,9 @@ def _single_grid(V):
 def _memo(obj, V, build):
     """1-D factors depend only on the space: build once per (form, V)"""
     cache = obj.__dict__.setdefault("_cache", {})
-    key = id(V)
+    # keyed on what the factors are computed from (id(V) can be recycled after garbage collection)
+    key = tuple((g.degree, bool(g.dg), tuple(numpy.asarray(v, dtype=numpy.float64).tobytes() for v in g.vertices))
+                if hasattr(g, "vertices") else id(g) for g in V.grids)
     if key not in cache:
         cache[key] = build()
     return cache[key]

@@ -1,0 +1,115 @@
+"""
+Extraction operators that are never materialised.
+
+``generateM`` (tIGAr/common.py:1516-1578) stores M as a PETSc AIJ matrix.  For a tensor-product
+B-spline on its Q_p node grid M is the Kronecker product of the 1-D extraction matrices whenever the
+``abs(v) > eps`` filter (tIGAr/common.py:1569) dropped nothing but exact zeros -- checked, not assumed --
+and at BASELINE cfg3 (256^3, p=3) its CSR form would need 271 GB (M) + 271 GB (M^T).  ``ImplicitExtraction``
+stands in for the matrix object behind the unchanged generator / ``ExtractedSpline`` API: it knows its
+shape and nnz, applies M and M^T by three 1-D passes (``tg_tensor_apply_1d``), materialises row ranges on
+request (``rows``; the same ``k_extract_fill`` kernel as the resident path, so the entries are the
+reference's bit for bit) and hands ``extractMatrix`` the 1-D factors for the sum-factorised PtAP.
+"""
+import numpy as np
+
+from . import device as _dev
+
+
+class LazyFEMatrix(object):
+    """FE matrix given by a producer of row blocks instead of a resident CSR matrix: ``rows(r0, r1)``
+    returns the global FE rows [r0, r1) as a ``DeviceCSR`` with global column indices.  What
+    ``dolfin.assemble`` hands to ``extractMatrix`` in the reference (tIGAr/common.py:1206-1220) when the
+    assembled matrix does not fit in HBM at once (cfg3: 684 GB)."""
+
+    def __init__(self, producer, shape):
+        self._producer = producer
+        self.shape = (int(shape[0]), int(shape[1]))
+
+    def rows(self, r0, r1):
+        return self._producer(int(r0), int(r1))
+
+
+class LazyFEVector(object):
+    """FE vector given by a producer of entry ranges: ``rows(r0, r1)`` -> ``DeviceVector``."""
+
+    def __init__(self, producer, n):
+        self._producer = producer
+        self.n = int(n)
+
+    def size(self):
+        return self.n
+
+    def rows(self, r0, r1):
+        return self._producer(int(r0), int(r1))
+
+
+class ImplicitExtraction(object):
+    """M = M_(d-1) (x) ... (x) M_0 of a tensor ``BSpline`` on its node grid, not stored.
+
+    ``kx``: the ``KronExtraction`` (1-D factors); ``transposed``: this object stands for M^T."""
+
+    is_implicit = True
+
+    def __init__(self, kx, eps, transposed=False, _pair=None):
+        self.kx, self.eps, self.transposed = kx, float(eps), bool(transposed)
+        self._T = _pair
+        nfe, ncp = int(np.prod(kx.nfe, dtype=np.int64)), int(np.prod(kx.ncp, dtype=np.int64))
+        self._shape = (ncp, nfe) if transposed else (nfe, ncp)
+
+    # ---- what the API reads from a matrix object ------------------------------------------------
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def nnz(self):
+        return self.kx.nnz_product
+
+    def transpose(self):
+        if self._T is None:
+            self._T = ImplicitExtraction(self.kx, self.eps, not self.transposed, _pair=self)
+        return self._T
+
+    def _apply(self, x, transposed, y=None):
+        kx, d = self.kx, self.kx.d
+        dims = list(kx.ncp if not transposed else kx.nfe)
+        t = x
+        for k in range(d):
+            F = kx.M1T[k] if transposed else kx.M1[k]
+            t = _dev.tensor_apply_1d(t, dims, k, F, out=y if k == d - 1 else None)
+            dims[k] = F.shape[0]
+        return t
+
+    def mult(self, x, y=None):
+        """y = M x (or M^T x for the transposed object): one 1-D pass per direction."""
+        return self._apply(x, self.transposed, y)
+
+    def mult_transpose(self, b, y=None):
+        return self._apply(b, not self.transposed, y)
+
+    def __mul__(self, x):
+        if isinstance(x, _dev.DeviceVector):
+            return self.mult(x)
+        return NotImplemented
+
+    # ---- materialisation ---------------------------------------------------------------------------
+    def rows(self, r0, r1):
+        """Rows [r0, r1) as a ``DeviceCSR`` (global columns): the extraction kernels on a row range."""
+        sp1, axes = self.kx.basis.splines, self.kx.grid.axes
+        if self.transposed:
+            return _dev.extract_csr_tensor_t(sp1, axes, 0, self._shape[1], self.eps, r0, r1)
+        return _dev.extract_csr_tensor(sp1, axes, 0, self._shape[1], self.eps, r0, r1)
+
+    def materialise(self):
+        need = 12.0 * self.nnz + 8.0 * self._shape[0]
+        free_b, _ = _dev.mem_info()
+        if need > 0.8 * free_b:
+            raise MemoryError("the extraction operator needs %.0f GB as a CSR matrix (%.0f GB of HBM free); "
+                              "use rows(r0, r1) for row ranges" % (need / 1e9, free_b / 1e9))
+        return self.rows(0, self._shape[0])
+
+    def to_scipy(self):
+        return self.materialise().to_scipy()
+
+    def rows_to_scipy(self, r0, r1):
+        return self.rows(r0, r1).to_scipy()

@@ -37,9 +37,18 @@ class KronExtraction(object):
             M1 = sp.coo_matrix((val.ravel()[nz], (rows[nz], idx.ravel()[nz])), shape=(n, s.getNcp())).tocsr()
             M1.sort_indices()
             self.M1.append(M1)
+        self.M1T = [m.T.tocsr() for m in self.M1]
+        for m in self.M1T:
+            m.sort_indices()
         self.nfe = [m.shape[0] for m in self.M1]
         self.ncp = [m.shape[1] for m in self.M1]
         self.nnz_product = int(np.prod([m.nnz for m in self.M1], dtype=np.float64))
+
+    def products_stay_above(self, eps):
+        """Sufficient condition for M == kron(M_k) entrywise WITHOUT building M: every product of stored 1-D
+        entries stays above the filter threshold of generateM (abs(v) > eps, tIGAr/common.py:1569)."""
+        mins = [float(np.min(np.abs(m.data))) if m.nnz else 0.0 for m in self.M1]
+        return bool(np.prod(mins) > eps)
 
     def is_exact_for(self, M_nnz, eps):
         """True if generateM's filter dropped only exact zeros, i.e. M == kron(M_k) entrywise."""

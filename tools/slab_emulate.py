@@ -9,7 +9,7 @@ from tigar_amd.common import TensorFunctionSpace
 from tigar_amd.BSplines import ExplicitBSplineControlMesh, uniformKnots
 from tigar_amd.forms import LaplaceForm, SeparableLoadForm
 from tigar_amd.dist import SlabHotPath
-from bench_dist import pick_sub_planes
+from tigar_amd.dist import pick_sub_planes
 
 p, nel, rank, world = (int(a) for a in sys.argv[1:5])
 d = 3
