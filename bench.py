@@ -85,7 +85,7 @@ def run(args, d, p, nel):
     cnt = counts(d, p, nel)
     t0 = time.perf_counter()
     V_in = TensorFunctionSpace([basis.generateMesh(degree=p)], "Lagrange")
-    free_b, _ = dev.mem_info()
+    free_b = dev.mem_info()[0] + dev.pool_stats()[0]
     a_resident = world == 1 and args.slab != 1 and \
         12.0 * (2 * cnt["nnzM"] + cnt["nnzA"] + 2 * cnt["nnzK"]) <= 0.6 * free_b
     A_in = lap.assemble_matrix(V_in) if a_resident else None

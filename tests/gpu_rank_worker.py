@@ -32,6 +32,7 @@ def main():
     spline.setSolverOptions(linearSolver=solver)
     u = t.Function(spline.V, spline.localFERange())
     U = spline.solveLinearSystem(K, rhs, u)
+    its1 = solver.last["iterations"]
     # second solve from the converged state: must stop at once (non-zero initial guess path with halo)
     solver.parameters["nonzero_initial_guess"] = True
     from tigar_amd.device import DeviceVector
@@ -43,7 +44,7 @@ def main():
     cp0 = gen.cpFuncs[0].vector().get_local()
     np.savez(os.path.join(outdir, "rank%d.npz" % comm.rank), g=np.array([g0, g1, r0, r1]),
              K_indptr=Ks.indptr, K_indices=Ks.indices, K_data=Ks.data, rhs=rhs.get_local(), U=U.get_local(),
-             u=u.vector().get_local(), its=np.array([solver.last["iterations"], its2]),
+             u=u.vector().get_local(), its=np.array([its1, its2]),
              comm=np.array([rank_r, world_r, 0 if kind == "rccl" else 1]), cp0=cp0,
              U2=U2.get_local())
     comm.barrier()

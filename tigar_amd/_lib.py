@@ -166,7 +166,15 @@ def load(require_device=True, device=None):
         _lib = lib
     if require_device and not _device_ready:
         if device is None:
-            device = int(os.environ.get("TIGAR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            if "TIGAR_DEVICE" in os.environ:
+                device = int(os.environ["TIGAR_DEVICE"])
+            else:
+                # one process per GPU; more local ranks than GPUs share devices round-robin (the communicator
+                # is then host-staged, tigar_amd/launch.py)
+                ndev = C.c_int(0)
+                if _lib.tg_device_count(C.byref(ndev)) != 0 or ndev.value < 1:
+                    raise TigarHipError("no MI355X visible: %s -- there is no CPU fallback" % _lib.tg_last_error().decode())
+                device = int(os.environ.get("LOCAL_RANK", "0")) % ndev.value
         rc = _lib.tg_init(int(device))
         if rc != 0:
             raise TigarHipError("tg_init(%d) failed: %s -- the extraction path needs an MI355X; "

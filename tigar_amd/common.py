@@ -459,7 +459,7 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
         if not kx.products_stay_above(eps):
             return None
         if env != "1" and self.comm.size == 1:
-            free_b, _ = _dev.mem_info()
+            free_b = _dev.mem_info()[0] + _dev.pool_stats()[0]      # idle blocks of the caching allocator count as free
             if 24.0 * kx.nnz_product + 16.0 * grid.num_nodes() <= free_b / 3.0:
                 return None
         return ImplicitExtraction(kx, eps)

@@ -338,7 +338,7 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
     return 0;
   }
   if (!(nu0 > tol2)) {
-    *status = (znorm_init <= atol && !(znorm_init <= rtol * znorm0)) ? 1 : 0;
+    *status = (znorm_init <= atol) ? 1 : 0;     // (b = 0: the absolute tolerance is what was met)
     return 0;
   }
   // iterations are enqueued `look` ahead of the one whose norm the host has seen

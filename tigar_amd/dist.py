@@ -170,7 +170,8 @@ class SlabHotPath(object):
         self.layout = layout_for(basis, grid)
         self.k0, self.k1 = split_range(self.layout.ncp, world)[rank]
         if sub_planes == "auto":
-            free_b, _ = dev.mem_info()
+            # what the path can use: free device memory plus what the library's caching allocator holds idle
+            free_b = dev.mem_info()[0] + dev.pool_stats()[0]
             pmax = max(s1.p for s1 in basis.splines)
             nelmax = max(s1.nel for s1 in basis.splines)
             sub_planes = pick_sub_planes(basis.nvar, pmax, nelmax, self.k1 - self.k0, free_b)

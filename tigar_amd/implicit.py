@@ -102,7 +102,7 @@ class ImplicitExtraction(object):
 
     def materialise(self):
         need = 12.0 * self.nnz + 8.0 * self._shape[0]
-        free_b, _ = _dev.mem_info()
+        free_b = _dev.mem_info()[0] + _dev.pool_stats()[0]
         if need > 0.8 * free_b:
             raise MemoryError("the extraction operator needs %.0f GB as a CSR matrix (%.0f GB of HBM free); "
                               "use rows(r0, r1) for row ranges" % (need / 1e9, free_b / 1e9))

@@ -26,14 +26,14 @@ def main():
     cmd = [os.path.abspath(c) if c.endswith(".py") and os.path.exists(c) else c for c in cmd]
     fetch, write = one_pass("FETCH_SIZE", cmd), one_pass("WRITE_SIZE", cmd)
     rows = []
-    for k in sorted(fetch, key=lambda k: -fetch[k][1]):
-        n, f = fetch[k]
+    for k in sorted(set(fetch) | set(write), key=lambda k: -(2.0 * fetch.get(k, [0, 0.0])[1] + write.get(k, [0, 0.0])[1])):
+        n, f = fetch.get(k, [write.get(k, [0, 0.0])[0], 0.0])
         w = write.get(k, [0, 0.0])[1]
         rows.append({"kernel": k[:90], "launches": n, "hbm_read_GB_total_corrected": 2.0 * f * 1024 / 1e9,
                      "hbm_write_GB_total": w * 1024 / 1e9})
     json.dump({"command": " ".join(cmd), "note": "FETCH_SIZE/WRITE_SIZE in KB, separate passes; reads x2 (gfx950 correction), "
-               "writes as counted", "kernels": rows[:14]}, open(dst, "w"), indent=1)
-    for r in rows[:10]:
+               "writes as counted", "kernels": rows[:30]}, open(dst, "w"), indent=1)
+    for r in rows[:30]:
         print("%-70s %5d  read %9.2f GB  write %9.2f GB" % (r["kernel"][:70], r["launches"], r["hbm_read_GB_total_corrected"], r["hbm_write_GB_total"]))
 
 
