@@ -143,6 +143,7 @@ typedef struct tg_csr_builder_s *tg_csr_builder_t;
 int tg_csr_builder_create(int64_t nrows_total, int64_t ncols, int64_t nnz_capacity, tg_csr_builder_t *out);
 int tg_csr_builder_append(tg_csr_builder_t b, tg_csr_t block);
 int tg_csr_builder_finish(tg_csr_builder_t b, tg_csr_t *out);   /* destroys the builder */
+int tg_csr_builder_destroy(tg_csr_builder_t b);                 /* abandons an unfinished builder */
 /* 1-D evaluation only (device twin of BSpline1.getKnotSpan/getNodes/basisFuncs):
  * idx[n*(p+1)], val[n*(p+1)] in the reference's order (span-p .. span). */
 int tg_eval_basis_1d(const tg_dir_t *dir, const double *u, int64_t n, int32_t *span,
@@ -213,6 +214,30 @@ int tg_ptap_kron_stage(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dim
 int tg_ptap_kron_append(tg_csr_t cur, int64_t cur_row0, int d, const int64_t *dims_in,
                         const tg_kron1d_t *fac, int64_t out_row0, int64_t out_row1,
                         const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_builder_t dest);
+/* ---- tensor-pattern extractMatrix (tIGAr/common.py:1176-1204 for tensor-product patches) ----
+ * K = M^T A M in three "line walk" passes when A carries the element-coupling pattern of the Q_p node
+ * grid (what dolfin assembles for any form on V); the pattern is verified entry by entry while A is read
+ * and status 100 means "another pattern: use tg_ptap_kron* / tg_ptap_*".  No column decode, no LDS, no
+ * atomics: results are bit-reproducible.  See csrc/tg_tensor_body.h. */
+typedef struct {
+  int p;                   /* spline degree = degree of the CG Lagrange grid, 1..3                    */
+  int nel;                 /* elements; nfe = p*nel+1 FE nodes, ncp = nel+p spline functions           */
+  const double *wl;        /* host [nel][p+1][p+1]: value at node p*e+j of spline function e+q         */
+} tg_tensor_dir_t;
+typedef struct tg_tensor_plan_s *tg_tensor_plan_t;
+typedef struct tg_tensor_planes_s *tg_tensor_planes_t;
+int tg_tensor_plan_create(int d, const tg_tensor_dir_t *dirs, tg_tensor_plan_t *out);
+int tg_tensor_plan_destroy(tg_tensor_plan_t plan);
+/* x and y passes over the FE planes [z0,z1) of the last direction; `a` holds FE rows from a_row0 on (whole
+ * planes, global columns).  The result (dense blocks, no indices) feeds tg_tensor_zstage and can be kept
+ * across sub-slabs. */
+int tg_tensor_planes(tg_tensor_plan_t plan, tg_csr_t a, int64_t a_row0, int z0, int z1, tg_tensor_planes_t *out);
+int tg_tensor_planes_destroy(tg_tensor_planes_t p);
+/* z pass: rows of K for the dof planes [ka,kb) from pieces that together hold the FE planes in their support;
+ * MatZeroRowsColumns(zero_dofs, diag) fused; appended to `dest` (next rows of a slab-wise builder) or, with
+ * dest == NULL, returned as a new matrix in *out. */
+int tg_tensor_zstage(tg_tensor_plan_t plan, int npieces, const tg_tensor_planes_t *pieces, int ka, int kb,
+                     const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_builder_t dest, tg_csr_t *out);
 /* canonical CSR copy of a loose-row matrix */
 int tg_csr_compact(tg_csr_t in, tg_csr_t *out);
 int tg_csr_is_loose(tg_csr_t m, int *loose);

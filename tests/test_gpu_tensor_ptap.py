@@ -1,0 +1,132 @@
+"""-m gpu: the tensor-pattern extractMatrix path (csrc/tg_tensor_body.h: line walks without column decode, LDS or
+atomics) on the device, against the oracle's M^T A M + MatZeroRowsColumns, against the general kernels, and for
+run-to-run bit-reproducibility of K (SURVEY.md section 7 hard part 4)."""
+import os
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import tigar_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _patch(p, nels, knots=None):
+    import tigar_amd as t
+    from tigar_amd import BSplines as B
+    kvs = knots if knots is not None else [B.uniformKnots(p, 0., 1., n) for n in nels]
+    gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p] * 3, kvs))
+    sp0 = gen.getScalarSpline(0)
+    for direction in range(3):
+        for side in (0, 1):
+            gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
+    return gen, t.ExtractedSpline(gen, 2 * p)
+
+
+def _random_fe_matrix(p, nels, seed=0):
+    pats = []
+    for k in range(3):
+        nfe = p * nels[k] + 1
+        P1 = sp.lil_matrix((nfe, nfe))
+        for e in range(nels[k]):
+            P1[p * e:p * e + p + 1, p * e:p * e + p + 1] = 1.0
+        pats.append(P1.tocsr())
+    A = O.kron_dir0_fastest(pats).tocsr()
+    A.sort_indices()
+    A.data = np.random.default_rng(seed).standard_normal(A.nnz)
+    return A
+
+
+@pytest.mark.parametrize("p,nels", [(2, (3, 4, 2)), (3, (2, 3, 4)), (1, (3, 2, 4)), (2, (1, 1, 1)), (3, (5, 4, 6)), (2, (9, 7, 8))])
+def test_device_walks_vs_oracle(p, nels):
+    from tigar_amd.tensorptap import TensorPtAP
+    from tigar_amd import device as dev
+    gen, spline = _patch(p, nels)
+    plan = TensorPtAP.for_extraction(spline._kron)
+    assert plan is not None                                   # the patch qualifies
+    A = _random_fe_matrix(p, nels, seed=p)
+    s = O.BSpline([p] * 3, [O.uniform_knots(p, 0., 1., n) for n in nels])
+    Mo = O.generate_M_tensor(s)
+    zd = list(spline.zeroDofs)
+    Ko = O.extract_matrix(Mo, A, zd, diag=2.5)
+    Ad = dev.DeviceCSR.from_scipy(A)
+    nfe2, ncp2 = p * nels[2] + 1, nels[2] + p
+    piece = plan.planes(Ad, 0, 0, nfe2)
+    assert piece is not None
+    K = plan.zstage([piece], 0, ncp2, zd, 2.5).to_scipy()
+    assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices)
+    assert np.max(np.abs(K.data - Ko.data)) <= 1e-13 * np.max(np.abs(Ko.data))
+    # through the public API (extractMatrix picks the same path), three times: bit-identical
+    K1 = spline.extractMatrix(A, diag=2.5).to_scipy()
+    assert np.array_equal(K1.data, K.data) and np.array_equal(K1.indices, K.indices)
+    for _ in range(2):
+        assert np.array_equal(spline.extractMatrix(A, diag=2.5).to_scipy().data, K.data)
+    # sub-slabs of dof planes reading planes from two pieces: bit-identical to the single pass
+    if nfe2 >= 3 and ncp2 >= 2:
+        cut, pcut = ncp2 // 2, nfe2 // 2
+        pa, pb = plan.planes(Ad, 0, 0, pcut), plan.planes(Ad, 0, pcut, nfe2)
+        Ka = plan.zstage([pa, pb], 0, cut, zd, 2.5).to_scipy()
+        Kb = plan.zstage([pa, pb], cut, ncp2, zd, 2.5).to_scipy()
+        assert np.array_equal(sp.vstack([Ka, Kb]).tocsr().data, K.data)
+    # the general kernels agree to rounding
+    os.environ["TIGAR_PTAP_TENSOR"] = "0"
+    try:
+        gen2, spline2 = _patch(p, nels)
+        Kg = spline2.extractMatrix(A, diag=2.5).to_scipy()
+    finally:
+        os.environ.pop("TIGAR_PTAP_TENSOR", None)
+    assert np.array_equal(Kg.indices, K.indices)
+    assert np.max(np.abs(Kg.data - K.data)) <= 1e-12 * np.max(np.abs(K.data))
+
+
+def test_other_patterns_fall_back_to_the_general_kernels():
+    """an FE matrix with an extra coupling (contact term, demos/kl-shell-svk/reef-knot.py:460-467) or a missing
+    entry is not taken by the fast path; extractMatrix still returns M^T A M"""
+    p, nels = 2, (3, 3, 3)
+    gen, spline = _patch(p, nels)
+    A = _random_fe_matrix(p, nels, seed=11).tolil()
+    A[5, A.shape[0] - 3] = 0.75                                  # couples two far-apart nodes
+    A = A.tocsr()
+    s = O.BSpline([p] * 3, [O.uniform_knots(p, 0., 1., n) for n in nels])
+    Mo = O.generate_M_tensor(s)
+    zd = list(spline.zeroDofs)
+    Ko = O.extract_matrix(Mo, A, zd)
+    K = spline.extractMatrix(A).to_scipy()
+    assert np.array_equal(K.indices, Ko.indices)
+    assert np.max(np.abs(K.data - Ko.data)) <= 1e-12 * np.max(np.abs(Ko.data))
+    from tigar_amd.tensorptap import TensorPtAP
+    from tigar_amd import device as dev
+    plan = TensorPtAP.for_extraction(spline._kron)
+    assert plan.planes(dev.DeviceCSR.from_scipy(A), 0, 0, p * nels[2] + 1) is None
+
+
+def test_streamed_sub_slabs_with_tensor_ring_match_resident():
+    """SlabHotPath with the tensor ring (B2 planes kept across sub-slabs, rows of K written straight into the
+    builder at closed-form positions) against the resident product, and a declined pattern in the streamed path"""
+    from tigar_amd import forms as F, device as dev
+    from tigar_amd.dist import SlabHotPath
+    p, nels = 3, (6, 5, 9)
+    gen, spline = _patch(p, nels)
+    lap = F.LaplaceForm()
+    A = lap.assemble_matrix(gen.V)
+    K_res = spline.extractMatrix(A).to_scipy()
+    zd = list(spline.zeroDofs)
+    basis = gen.getScalarSpline(0)
+    for sub in (1, 2, 5):
+        path = SlabHotPath(basis, gen.V.grids[0], sub_planes=sub)
+        K = path.assemble_matrix(lambda a, b: lap.assemble_matrix(gen.V, a, b), zd, 1.0).to_scipy()
+        assert np.array_equal(K.indptr, K_res.indptr) and np.array_equal(K.indices, K_res.indices)
+        assert np.array_equal(K.data, K_res.data)                   # same walks, same order: bit-identical
+    # a producer whose rows are not on the pattern: the streamed assembly restarts on the general stages
+    As = A.to_scipy().tolil()
+    As[7, As.shape[0] - 5] = 0.5
+    As = As.tocsr()
+
+    def rows(a, b):
+        return dev.DeviceCSR.from_scipy(As[a:b])
+    path = SlabHotPath(basis, gen.V.grids[0], sub_planes=3)
+    K = path.assemble_matrix(rows, zd, 1.0).to_scipy()
+    s = O.BSpline([p] * 3, [O.uniform_knots(p, 0., 1., n) for n in nels])
+    Ko = O.extract_matrix(O.generate_M_tensor(s), As, zd)
+    assert np.array_equal(K.indices, Ko.indices)
+    assert np.max(np.abs(K.data - Ko.data)) <= 1e-12 * np.max(np.abs(Ko.data))

@@ -33,6 +33,10 @@ class tg_kron1d_t(C.Structure):
                 ("t_rowptr", c_i32p), ("t_col", c_i32p), ("t_val", c_f64p)]
 
 
+class tg_tensor_dir_t(C.Structure):
+    _fields_ = [("p", C.c_int), ("nel", C.c_int), ("wl", c_f64p)]
+
+
 class tg_kron_dir_t(C.Structure):
     _fields_ = [("n", C.c_int64), ("rowptr", c_i32p), ("col", c_i32p), ("val", c_f64p)]
 
@@ -97,6 +101,7 @@ PROTOTYPES = {
     "tg_csr_vstack_view": (C.c_int, [C.c_int, C.POINTER(handle), C.POINTER(handle)]),
     "tg_csr_builder_append": (C.c_int, [handle, handle]),
     "tg_csr_builder_finish": (C.c_int, [handle, C.POINTER(handle)]),
+    "tg_csr_builder_destroy": (C.c_int, [handle]),
     "tg_eval_basis_1d": (C.c_int, [C.POINTER(tg_dir_t), c_f64p, C.c_int64, c_i32p, c_i32p, c_f64p]),
     "tg_spmv": (C.c_int, [handle, handle, handle]),
     "tg_spmv_offset": (C.c_int, [handle, handle, C.c_int64, handle]),
@@ -114,6 +119,12 @@ PROTOTYPES = {
                                      C.POINTER(handle)]),
     "tg_ptap_kron_append": (C.c_int, [handle, C.c_int64, C.c_int, c_i64p, C.POINTER(tg_kron1d_t), C.c_int64, C.c_int64,
                                       c_i32p, C.c_int64, C.c_double, handle]),
+    "tg_tensor_plan_create": (C.c_int, [C.c_int, C.POINTER(tg_tensor_dir_t), C.POINTER(handle)]),
+    "tg_tensor_plan_destroy": (C.c_int, [handle]),
+    "tg_tensor_planes": (C.c_int, [handle, handle, C.c_int64, C.c_int, C.c_int, C.POINTER(handle)]),
+    "tg_tensor_planes_destroy": (C.c_int, [handle]),
+    "tg_tensor_zstage": (C.c_int, [handle, C.c_int, C.POINTER(handle), C.c_int, C.c_int, c_i32p, C.c_int64,
+                                   C.c_double, handle, C.POINTER(handle)]),
     "tg_csr_compact": (C.c_int, [handle, C.POINTER(handle)]),
     "tg_csr_is_loose": (C.c_int, [handle, C.POINTER(C.c_int)]),
     "tg_csr_rowptr_at": (C.c_int, [handle, C.c_int64, c_i64p]),

@@ -787,6 +787,14 @@ extern "C" int tg_csr_builder_append(tg_csr_builder_t b, tg_csr_t blk) {
   return 0;
 }
 
+// abandons a builder that was not finished (its matrix is released)
+extern "C" int tg_csr_builder_destroy(tg_csr_builder_t b) {
+  if (!b) return 0;
+  if (b->m) tg_csr_destroy(b->m);
+  delete b;
+  return 0;
+}
+
 extern "C" int tg_csr_builder_finish(tg_csr_builder_t b, tg_csr_t *out) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(b && b->m && out, "null argument to tg_csr_builder_finish");

@@ -1,0 +1,358 @@
+// Host side and kernel wrappers of the tensor-pattern extractMatrix path (see tg_tensor_body.h for the
+// algorithm).  K = M^T A M for a tensor-product B-spline patch in three line-walk passes:
+//
+//   tg_tensor_planes   FE planes [z0,z1) of A (any CSR matrix; its pattern is VERIFIED against the closed form
+//                      while it is read -- status 100 = "not this pattern, use the general kernels")
+//                      -> x pass -> y pass -> dense B2 planes (plane-local, cached by the caller across sub-slabs)
+//   tg_tensor_zstage   B2 planes of one or several pieces -> rows of K for dof planes [ka,kb), written in CSR
+//                      order at closed-form positions into a new matrix or straight into the slab-wise builder,
+//                      MatZeroRowsColumns(zeroDofs, diag) fused (tIGAr/common.py:1199-1200).
+#include "tg_common.h"
+#include "tg_tensor_body.h"
+#include <algorithm>
+#include <vector>
+
+struct tg_tensor_plan_s {
+  int P = 0;
+  tt_dir_t dir[3];
+  // device tables (owned)
+  double *wl[3] = {nullptr, nullptr, nullptr};
+  int32_t *rps[3] = {nullptr, nullptr, nullptr}, *kps[3] = {nullptr, nullptr, nullptr};
+  // lines of direction 1 by block extent: short (P+1) and vertex (2P+1)
+  int32_t *lines1[2] = {nullptr, nullptr};
+  int nlines1[2] = {0, 0};
+  std::vector<int32_t> h_rps[3], h_kps[3];
+  int *status = nullptr;   // device flag
+};
+
+struct tg_tensor_planes_s {
+  int z0 = 0, z1 = 0;
+  double *buf = nullptr;            // B2 planes
+  std::vector<int64_t> pb;          // offset of plane r2 in buf, indexed r2 - z0
+};
+
+template <int P>
+__global__ void __launch_bounds__(64) k_tt_x(tt_x_args A) {
+  const int bad = tt_x_lane<P>(A, blockIdx.x, blockIdx.y, threadIdx.x);
+  if (bad) atomicOr(A.status, 1);
+}
+template <int P>
+__global__ void __launch_bounds__(64) k_tt_y(tt_y_args A) {
+  tt_y_lane<P>(A, blockIdx.x, blockIdx.y, threadIdx.x);
+}
+template <int P>
+__global__ void __launch_bounds__(64) k_tt_z(tt_z_args A) {
+  tt_z_lane<P>(A, blockIdx.x, threadIdx.x);
+}
+__global__ void __launch_bounds__(256) k_tt_rowptr(tt_rowptr_args A, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tt_rowptr_one(A, i);
+}
+
+template <typename T>
+static int tt_upload(T **dst, const std::vector<T> &h) {
+  TG_TRY(tg_dmalloc(dst, (int64_t)std::max<size_t>(h.size(), 1)));
+  if (!h.empty())
+    TG_CHECK_HIP(hipMemcpyAsync(*dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));   // (h may be a temporary)
+  return 0;
+}
+
+static int tt_rn_host(int P, int a, int nfe) { return (a % P == 0 && a > 0 && a < nfe - 1) ? 2 * P + 1 : P + 1; }
+
+extern "C" int tg_tensor_plan_destroy(tg_tensor_plan_t p) {
+  if (!p) return 0;
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  for (int k = 0; k < 3; k++) {
+    tg_dfree(p->wl[k]);
+    tg_dfree(p->rps[k]);
+    tg_dfree(p->kps[k]);
+  }
+  tg_dfree(p->lines1[0]);
+  tg_dfree(p->lines1[1]);
+  tg_dfree(p->status);
+  delete p;
+  return 0;
+}
+
+extern "C" int tg_tensor_plan_create(int d, const tg_tensor_dir_t *dirs, tg_tensor_plan_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(d == 3 && dirs && out, "tg_tensor_plan_create: three parametric directions expected");
+  const int P = dirs[0].p;
+  TG_REQUIRE(P >= 1 && P <= 3 && dirs[1].p == P && dirs[2].p == P,
+             "tg_tensor_plan_create: equal degrees 1..3 in all directions ((2p+1)^2 lanes must fit a wave)");
+  tg_tensor_plan_s *pl = new tg_tensor_plan_s();
+  pl->P = P;
+  int rc = 0;
+  for (int k = 0; k < 3 && !rc; k++) {
+    const int nel = dirs[k].nel, nfe = P * nel + 1, ncp = nel + P;
+    if (nel < 1 || !dirs[k].wl) {
+      tg_set_error("tg_tensor_plan_create: bad direction %d", k);
+      rc = 2;
+      break;
+    }
+    std::vector<double> w(dirs[k].wl, dirs[k].wl + (size_t)nel * (P + 1) * (P + 1));
+    pl->h_rps[k].assign(nfe + 1, 0);
+    for (int a = 0; a < nfe; a++) pl->h_rps[k][a + 1] = pl->h_rps[k][a] + tt_rn_host(P, a, nfe);
+    pl->h_kps[k].assign(ncp + 1, 0);
+    for (int i = 0; i < ncp; i++)
+      pl->h_kps[k][i + 1] = pl->h_kps[k][i] + (std::min(ncp - 1, i + P) - std::max(0, i - P) + 1);
+    rc = tt_upload(&pl->wl[k], w);
+    if (!rc) rc = tt_upload(&pl->rps[k], pl->h_rps[k]);
+    if (!rc) rc = tt_upload(&pl->kps[k], pl->h_kps[k]);
+    pl->dir[k].nel = nel;
+    pl->dir[k].nfe = nfe;
+    pl->dir[k].ncp = ncp;
+    pl->dir[k].wl = pl->wl[k];
+    pl->dir[k].rps = pl->rps[k];
+    pl->dir[k].kps = pl->kps[k];
+  }
+  if (!rc) {
+    std::vector<int32_t> ls, lv;
+    const int nfe1 = pl->dir[1].nfe;
+    for (int a = 0; a < nfe1; a++) (tt_rn_host(P, a, nfe1) == P + 1 ? ls : lv).push_back(a);
+    pl->nlines1[0] = (int)ls.size();
+    pl->nlines1[1] = (int)lv.size();
+    rc = tt_upload(&pl->lines1[0], ls);
+    if (!rc) rc = tt_upload(&pl->lines1[1], lv);
+    if (!rc) rc = tg_dmalloc(&pl->status, 4);
+  }
+  if (rc) {
+    tg_tensor_plan_destroy(pl);
+    return rc;
+  }
+  *out = pl;
+  return 0;
+}
+
+extern "C" int tg_tensor_planes_destroy(tg_tensor_planes_t p) {
+  if (!p) return 0;
+  if (g_tg.ready && !g_tg.multi) hipStreamSynchronize(g_tg.stream);
+  tg_dfree(p->buf);
+  delete p;
+  return 0;
+}
+
+#define TT_DISPATCH_P(P, CALL) \
+  do {                         \
+    if ((P) == 1) {            \
+      CALL(1);                 \
+    } else if ((P) == 2) {     \
+      CALL(2);                 \
+    } else {                   \
+      CALL(3);                 \
+    }                          \
+  } while (0)
+
+extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0, int z0, int z1,
+                                tg_tensor_planes_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(pl && a && out, "null argument to tg_tensor_planes");
+  TG_REQUIRE_CANONICAL(a);
+  const int P = pl->P, W = 2 * P + 1;
+  const tt_dir_t &D0 = pl->dir[0], &D1 = pl->dir[1], &D2 = pl->dir[2];
+  const int64_t plane_fe = (int64_t)D0.nfe * D1.nfe;
+  TG_REQUIRE(z0 >= 0 && z1 > z0 && z1 <= D2.nfe, "tg_tensor_planes: plane range out of bounds");
+  TG_REQUIRE(a_row0 % plane_fe == 0 && a_row0 <= z0 * plane_fe && a_row0 + a->nrows >= z1 * plane_fe,
+             "tg_tensor_planes: the FE rows given do not cover whole planes [%d,%d)", z0, z1);
+  if (a->ncols != plane_fe * D2.nfe) return 100;     // not a matrix on this node grid
+  const int aplane0 = (int)(a_row0 / plane_fe);
+  const int np = z1 - z0;
+  // plane bases of the two intermediates (B1: [c2][m0][c1] blocks, B2: [m1][m0][c2] blocks)
+  std::vector<int64_t> pb1(np + 1, 0), pb2(np + 1, 0);
+  std::vector<int32_t> pls[2];
+  for (int q = 0; q < np; q++) {
+    const int n2 = tt_rn_host(P, z0 + q, D2.nfe);
+    pb1[q + 1] = pb1[q] + (int64_t)W * n2 * D0.ncp * pl->h_rps[1][D1.nfe];
+    pb2[q + 1] = pb2[q] + (int64_t)W * W * n2 * D0.ncp * D1.ncp;
+    pls[n2 == P + 1 ? 0 : 1].push_back(z0 + q);
+  }
+  double *b1 = nullptr;
+  int64_t *d_pb1 = nullptr, *d_pb2 = nullptr;
+  int32_t *d_pl[2] = {nullptr, nullptr};
+  tg_tensor_planes_s *res = new tg_tensor_planes_s();
+  res->z0 = z0;
+  res->z1 = z1;
+  res->pb = pb2;
+  int rc = tg_dmalloc(&b1, pb1[np]);
+  if (!rc) rc = tg_dmalloc(&res->buf, pb2[np]);
+  if (!rc) rc = tt_upload(&d_pb1, pb1);
+  if (!rc) rc = tt_upload(&d_pb2, pb2);
+  if (!rc) rc = tt_upload(&d_pl[0], pls[0]);
+  if (!rc) rc = tt_upload(&d_pl[1], pls[1]);
+  if (!rc && hipMemsetAsync(pl->status, 0, sizeof(int), g_tg.stream) != hipSuccess) rc = 1;
+  int bad = 0;
+  if (!rc) {
+    // x pass: one launch per (plane class, line class)
+    for (int pc = 0; pc < 2; pc++) {
+      if (pls[pc].empty()) continue;
+      const int n2 = pc == 0 ? P + 1 : W;
+      for (int lc = 0; lc < 2; lc++) {
+        if (!pl->nlines1[lc]) continue;
+        const int n1 = lc == 0 ? P + 1 : W;
+        tt_x_args X;
+        X.rowptr = a->rowptr;
+        X.col = a->col;
+        X.val = a->val;
+        X.aplane0 = aplane0;
+        X.d0 = D0;
+        X.nfe1 = D1.nfe;
+        X.nfe2 = D2.nfe;
+        X.rps1 = D1.rps;
+        X.lines = pl->lines1[lc];
+        X.nlines = pl->nlines1[lc];
+        X.n1 = n1;
+        X.L = std::max(1, 64 / (n1 * n2));
+        X.planes = d_pl[pc];
+        X.n2 = n2;
+        X.b1 = b1;
+        X.pb1 = d_pb1;
+        X.z0 = z0;
+        X.status = pl->status;
+        const dim3 grid((unsigned)tg_cdiv(X.nlines, X.L), (unsigned)pls[pc].size());
+#define TT_X(PP) hipLaunchKernelGGL((k_tt_x<PP>), grid, dim3(64), 0, g_tg.stream, X)
+        TT_DISPATCH_P(P, TT_X);
+#undef TT_X
+      }
+    }
+    // y pass: one launch per plane class
+    for (int pc = 0; pc < 2; pc++) {
+      if (pls[pc].empty()) continue;
+      const int n2 = pc == 0 ? P + 1 : W;
+      tt_y_args Y;
+      Y.b1 = b1;
+      Y.pb1 = d_pb1;
+      Y.b2 = res->buf;
+      Y.pb2 = d_pb2;
+      Y.z0 = z0;
+      Y.d1 = D1;
+      Y.ncp0 = D0.ncp;
+      Y.planes = d_pl[pc];
+      Y.n2 = n2;
+      Y.L = std::max(1, 64 / (W * n2));
+      const dim3 grid((unsigned)tg_cdiv(D0.ncp, Y.L), (unsigned)pls[pc].size());
+#define TT_Y(PP) hipLaunchKernelGGL((k_tt_y<PP>), grid, dim3(64), 0, g_tg.stream, Y)
+      TT_DISPATCH_P(P, TT_Y);
+#undef TT_Y
+    }
+    if (hipGetLastError() != hipSuccess) {
+      tg_set_error("tg_tensor_planes: kernel launch failed");
+      rc = 1;
+    }
+    if (!rc && hipMemcpyAsync(&bad, pl->status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
+    if (!rc && hipStreamSynchronize(g_tg.stream) != hipSuccess) {
+      tg_set_error("tg_tensor_planes: %s", hipGetErrorString(hipGetLastError()));
+      rc = 1;
+    }
+  }
+  tg_dfree(b1);
+  tg_dfree(d_pb1);
+  tg_dfree(d_pb2);
+  tg_dfree(d_pl[0]);
+  tg_dfree(d_pl[1]);
+  if (rc || bad) {
+    tg_tensor_planes_destroy(res);
+    return rc ? rc : 100;          // 100: A does not have the element-coupling pattern -> general path
+  }
+  *out = res;
+  return 0;
+}
+
+extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tensor_planes_t *pieces, int ka, int kb,
+                                const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_builder_t dest,
+                                tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(pl && pieces && npieces >= 1 && (dest || out), "null argument to tg_tensor_zstage");
+  const int P = pl->P, W = 2 * P + 1;
+  const tt_dir_t &D0 = pl->dir[0], &D1 = pl->dir[1], &D2 = pl->dir[2];
+  TG_REQUIRE(ka >= 0 && kb > ka && kb <= D2.ncp, "tg_tensor_zstage: dof planes out of range");
+  const int e_begin = std::max(0, ka - P), e_end = std::min(D2.nel, kb);
+  const int plo = e_begin == 0 ? 0 : P * e_begin + 1, phi = P * e_end;      // FE planes read: [plo, phi]
+  std::vector<const double *> ptr(phi - plo + 1, nullptr);
+  for (int q = 0; q < npieces; q++) {
+    const tg_tensor_planes_s *pc = pieces[q];
+    TG_REQUIRE(pc, "tg_tensor_zstage: null piece");
+    for (int r = std::max(plo, pc->z0); r <= std::min(phi, pc->z1 - 1); r++) ptr[r - plo] = pc->buf + pc->pb[r - pc->z0];
+  }
+  for (size_t i = 0; i < ptr.size(); i++)
+    TG_REQUIRE(ptr[i], "tg_tensor_zstage: FE plane %d is in none of the pieces", plo + (int)i);
+  const int64_t pd = (int64_t)D0.ncp * D1.ncp;
+  const int64_t nrows = (int64_t)(kb - ka) * pd;
+  const int64_t w01 = (int64_t)pl->h_kps[0][D0.ncp] * pl->h_kps[1][D1.ncp];
+  const int64_t nnz = w01 * (pl->h_kps[2][kb] - pl->h_kps[2][ka]);
+  const int64_t ncols = pd * D2.ncp;
+  // destination
+  tg_csr_s *m = nullptr;
+  int64_t row_at = 0, nnz_at = 0;
+  if (dest) {
+    TG_REQUIRE(dest->m && dest->m->ncols == ncols, "tg_tensor_zstage: builder has other dimensions");
+    TG_TRY(tg_csr_builder_reserve(dest, nrows, nnz));
+    m = dest->m;
+    row_at = dest->rows_done;
+    nnz_at = dest->nnz_done;
+  } else {
+    TG_TRY(tg_csr_alloc(nrows, ncols, nnz, &m));
+  }
+  uint8_t *mask = nullptr;
+  const double **d_ptr = nullptr;
+  int rc = 0;
+  if (zero_dofs && nzero > 0) rc = tg_build_dof_mask(zero_dofs, nzero, ncols, &mask);
+  if (!rc) rc = tt_upload(&d_ptr, ptr);
+  if (!rc) {
+    tt_rowptr_args R;
+    R.kps0 = D0.kps;
+    R.kps1 = D1.kps;
+    R.kps2 = D2.kps;
+    R.ncp0 = D0.ncp;
+    R.ncp1 = D1.ncp;
+    R.ka = ka;
+    R.kb = kb;
+    R.base = nnz_at;
+    R.rowptr_out = m->rowptr + row_at;
+    hipLaunchKernelGGL(k_tt_rowptr, dim3((unsigned)tg_cdiv(nrows, 256)), dim3(256), 0, g_tg.stream, R, nrows);
+    const int64_t end = nnz_at + nnz;
+    if (hipMemcpyAsync(m->rowptr + row_at + nrows, &end, sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess)
+      rc = 1;
+    tt_z_args Z;
+    Z.planes = d_ptr;
+    Z.plane_lo = plo;
+    Z.d2 = D2;
+    Z.ncp0 = D0.ncp;
+    Z.ncp1 = D1.ncp;
+    Z.kps0 = D0.kps;
+    Z.kps1 = D1.kps;
+    Z.ka = ka;
+    Z.kb = kb;
+    Z.L = std::max(1, 64 / (W * W));
+    Z.kcol = m->col + nnz_at;
+    Z.kval = m->val + nnz_at;
+    Z.mask = mask;
+    Z.diag = diag;
+    const unsigned grid = (unsigned)tg_cdiv(pd, Z.L);
+#define TT_Z(PP) hipLaunchKernelGGL((k_tt_z<PP>), dim3(grid), dim3(64), 0, g_tg.stream, Z)
+    TT_DISPATCH_P(P, TT_Z);
+#undef TT_Z
+    if (hipGetLastError() != hipSuccess) {
+      tg_set_error("tg_tensor_zstage: kernel launch failed");
+      rc = 1;
+    }
+    if (!rc && hipStreamSynchronize(g_tg.stream) != hipSuccess) {   // (`end`, the mask and the pointer table are released below)
+      tg_set_error("tg_tensor_zstage: %s", hipGetErrorString(hipGetLastError()));
+      rc = 1;
+    }
+  }
+  tg_dfree(mask);
+  tg_dfree(d_ptr);
+  if (rc) {
+    if (!dest) tg_csr_destroy(m);
+    return rc;
+  }
+  if (dest) {
+    dest->rows_done += nrows;
+    dest->nnz_done += nnz;
+  } else {
+    m->nnz = nnz;
+    *out = m;
+  }
+  return 0;
+}

@@ -1,0 +1,446 @@
+// extractMatrix for tensor-product patches whose FE matrix carries the element-coupling pattern of the Q_p
+// node grid ("tensor-pattern" fast path of tIGAr/common.py:1176-1204, K = M^T A M with M = M_z (x) M_y (x) M_x).
+//
+// The general kernels (tg_ptap.hip, tg_ptap_box.hip) decode every column index of A and scatter into LDS
+// boxes; each entry of A passes through that instruction stream p+1 times.  When A's pattern is the
+// Kronecker product of the 1-D element-coupling patterns -- what dolfin assembles for ANY form on the Q_p
+// space; verified here entry by entry, never assumed -- row (a, r1, r2) of A is a dense little tensor
+// [c2][c1][c0] in CSR order, the position of every entry is known in closed form, and
+//
+//     K = P_z^T ( P_y^T ( P_x^T A P_x ) P_y ) P_z
+//
+// becomes three passes of one "line walk" with NO column decode, NO LDS, NO atomics and NO cross-lane
+// traffic: a lane owns one pair of passive column coordinates, walks the contracted direction row by row,
+// reads its n_t consecutive values of the row block (the lanes of a line cover the block contiguously),
+// applies the column-side contraction with the element's (p+1)x(p+1) local extraction weights (wave-uniform
+// scalars) and adds the result to a ring of p+1 live output rows held in registers; an output row is stored
+// when the walk leaves its support.  Every entry of A is loaded once; intermediates are dense blocks without
+// column indices; K leaves the last pass directly in CSR order at closed-form positions, with
+// MatZeroRowsColumns fused.  Accumulation order is fixed, so K is bit-reproducible (SURVEY.md section 7,
+// hard part 4).
+//
+// Everything in this header is plain C++ over (block, lane) indices: the HIP kernels in tg_ptap_tensor.hip
+// call it with blockIdx / threadIdx, and tests/emu/tensor_emu.cpp runs the very same code lane by lane on the
+// host to pin the index arithmetic in the CPU suite (test infrastructure; the product
+// library contains only the device build).
+//
+// Structure assumed of direction t (checked on the host before this path is taken): CG Lagrange degree P on
+// nel elements (nfe = P*nel+1 nodes, vertex nodes shared), open knot vector with simple interior knots, so
+// that every node of element e (j = 0..P, node P*e+j) has its non-zero spline functions among dofs e..e+P
+// ("local weights" wl[e][j][q], q = dof - e), the vertex nodes additionally none at dof e (j = 0, e > 0).
+#pragma once
+#include <stdint.h>
+
+#include <math.h>
+
+#ifdef __HIPCC__
+#define TT_DEV __device__ __forceinline__
+#define TT_MEM __device__ __forceinline__
+#else
+#define TT_DEV static inline
+#define TT_MEM inline
+#endif
+
+struct tt_dir_t {
+  int nel, nfe, ncp;
+  const double *wl;      // [nel][P+1][P+1] local extraction weights (see above)
+  const int32_t *rps;    // [nfe+1] exclusive prefix sums of the 1-D row lengths of the FE pattern
+  const int32_t *kps;    // [ncp+1] exclusive prefix sums of the widths of K's 1-D rows (clipped band)
+};
+
+// 1-D element-coupling pattern of the CG degree-P grid: row a couples to columns [lo, lo+n)
+template <int P>
+TT_DEV int tt_rn(int a, int nfe) {
+  return (a % P == 0 && a > 0 && a < nfe - 1) ? 2 * P + 1 : P + 1;
+}
+template <int P>
+TT_DEV int tt_rlo(int a, int nfe) {
+  if (a % P == 0 && a > 0) return a - P;          // vertex between two elements, or the last node
+  return (a / P) * P;                             // interior node of element a/P, or node 0
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The walk along the contracted direction.  IO supplies
+//   template <int N> void load(int a, int clo, double *v)   the lane's N values of row a (columns clo..clo+N-1)
+//   void emit(int i, const double *row)                     the finished output row i: row[m] <-> column dof i-P+m
+// Elements e_begin..e_end-1 are walked; an output row i is emitted after element min(i, nel-1), i.e. complete
+// rows are those with all of their elements [i-P, i] inside the walked range (the caller filters).
+template <int P, class IO>
+TT_DEV void tt_walk(const tt_dir_t &D, int e_begin, int e_end, IO &io) {
+  constexpr int W = 2 * P + 1, Q = P + 1, NW = Q * Q;
+  double acc[Q][W];
+#pragma unroll
+  for (int r = 0; r < Q; r++)
+#pragma unroll
+    for (int m = 0; m < W; m++) acc[r][m] = 0.0;
+
+  if (e_begin == 0) {   // opening vertex: node 0 = node j = 0 of element 0
+    const double *we = D.wl;
+    double v[Q], C[Q];
+    io.template load<Q>(0, 0, v);
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < Q; j++) s = fma(v[j], we[j * Q + q], s);
+      C[q] = s;
+    }
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+      const double wr = we[r];                    // node j = 0, dof 0 + r
+#pragma unroll
+      for (int q = 0; q < Q; q++) acc[r][q - r + P] = fma(wr, C[q], acc[r][q - r + P]);
+    }
+  }
+  for (int e = e_begin; e < e_end; e++) {
+    const double *we = D.wl + (int64_t)e * NW;
+    const int a0 = P * e;
+    // interior nodes of element e: columns = the element's P+1 nodes
+#pragma unroll
+    for (int j = 1; j < P; j++) {
+      double v[Q], C[Q];
+      io.template load<Q>(a0 + j, a0, v);
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+        double s = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < Q; jj++) s = fma(v[jj], we[jj * Q + q], s);
+        C[q] = s;
+      }
+#pragma unroll
+      for (int r = 0; r < Q; r++) {
+        const double wr = we[j * Q + r];
+#pragma unroll
+        for (int q = 0; q < Q; q++) acc[r][q - r + P] = fma(wr, C[q], acc[r][q - r + P]);
+      }
+    }
+    // closing vertex P*(e+1): node j = P of element e; its columns also cover element e+1 unless it is the last node
+    if (e + 1 < D.nel) {
+      const double *wn = we + NW;
+      double v[W], C[Q + 1];
+      io.template load<W>(a0 + P, a0, v);
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+        double s = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < Q; jj++) s = fma(v[jj], we[jj * Q + q], s);
+        C[q] = s;
+      }
+      C[Q] = 0.0;
+#pragma unroll
+      for (int q = 1; q <= Q; q++) {              // dofs e+q from the nodes j' = 1..P of element e+1 (dof (e+1)+(q-1))
+        double s = C[q];
+#pragma unroll
+        for (int jj = 1; jj < Q; jj++) s = fma(v[P + jj], wn[jj * Q + (q - 1)], s);
+        C[q] = s;
+      }
+#pragma unroll
+      for (int r = 0; r < Q; r++) {
+        const double wr = we[P * Q + r];
+#pragma unroll
+        for (int q = 0; q <= Q; q++) {
+          // column dof e+q against output dof e+r; q - r + P == 2P+1 only for (q, r) = (P+1, 0), whose row weight
+          // (the closing vertex at dof e) is structurally absent (host-checked)
+          if (q - r + P < W) acc[r][q - r + P] = fma(wr, C[q], acc[r][q - r + P]);
+        }
+      }
+    } else {
+      double v[Q], C[Q];
+      io.template load<Q>(a0 + P, a0, v);
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+        double s = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < Q; jj++) s = fma(v[jj], we[jj * Q + q], s);
+        C[q] = s;
+      }
+#pragma unroll
+      for (int r = 0; r < Q; r++) {
+        const double wr = we[P * Q + r];
+#pragma unroll
+        for (int q = 0; q < Q; q++) acc[r][q - r + P] = fma(wr, C[q], acc[r][q - r + P]);
+      }
+    }
+    io.emit(e, acc[0]);                           // no later element touches dof e
+#pragma unroll
+    for (int r = 0; r < P; r++)
+#pragma unroll
+      for (int m = 0; m < W; m++) acc[r][m] = acc[r + 1][m];
+#pragma unroll
+    for (int m = 0; m < W; m++) acc[P][m] = 0.0;
+  }
+  if (e_end == D.nel) {
+#pragma unroll
+    for (int r = 0; r < P; r++) io.emit(D.nel + r, acc[r]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// stage X: A (CSR, verified) -> B1.   Rows of B1: (i0, r1, r2), block [c2][m0][c1] (c1 fastest).
+struct tt_x_args {
+  const int64_t *rowptr;
+  const int32_t *col;
+  const double *val;
+  int aplane0;           // FE plane (direction 2) of A's first row
+  tt_dir_t d0;
+  int nfe1, nfe2;
+  const int32_t *rps1;   // direction 1 prefix sums (addresses in B1)
+  const int32_t *lines;  // the lines r1 of this class
+  int nlines, L, n1;     // lines per wave, block extent in direction 1 of these lines
+  const int32_t *planes; // FE planes r2 of this class (global)
+  int n2;                // their block extent in direction 2
+  double *b1;
+  const int64_t *pb1;    // offset of plane r2 in b1, indexed r2 - z0
+  int z0;
+  int *status;           // bit 0: pattern mismatch
+};
+
+template <int P>
+struct tt_io_x {
+  const int64_t *rowptr;
+  const int32_t *col;
+  const double *val;
+  int64_t rowbase, off_s, off_v;
+  int32_t colbase;
+  int64_t len_s, len_v;
+  bool valid;
+  int bad;
+  double *out;
+  int64_t ostride_i, ostride_m;
+  template <int N>
+  TT_MEM void load(int a, int clo, double *v) {
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = 0.0;
+    if (!valid) return;
+    const int64_t s = rowptr[rowbase + a], e = rowptr[rowbase + a + 1];
+    if (e - s != (N == P + 1 ? len_s : len_v)) {
+      bad = 1;
+      return;
+    }
+    const int64_t o = s + (N == P + 1 ? off_s : off_v);
+    const int32_t c0 = colbase + clo;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      v[j] = val[o + j];
+      if (col[o + j] != c0 + j) bad = 1;
+    }
+  }
+  TT_MEM void emit(int i, const double *row) {
+    if (!valid) return;
+    double *d = out + ostride_i * i;
+#pragma unroll
+    for (int m = 0; m < 2 * P + 1; m++) d[m * ostride_m] = row[m];
+  }
+};
+
+template <int P>
+TT_DEV int tt_x_lane(const tt_x_args &A, int bx, int by, int lane) {
+  constexpr int W = 2 * P + 1;
+  const int plane = A.planes[by];
+  const int lpl = A.n1 * A.n2;
+  const int sub = lane / lpl, l = lane - sub * lpl;
+  const int li = bx * A.L + sub;
+  tt_io_x<P> io;
+  io.valid = sub < A.L && li < A.nlines;
+  const int r1 = io.valid ? A.lines[li] : 0;
+  const int c1 = l % A.n1, c2 = l / A.n1;
+  io.rowptr = A.rowptr;
+  io.col = A.col;
+  io.val = A.val;
+  io.rowbase = (int64_t)A.d0.nfe * (r1 + (int64_t)A.nfe1 * (plane - A.aplane0));
+  io.off_s = (int64_t)l * (P + 1);
+  io.off_v = (int64_t)l * W;
+  io.len_s = (int64_t)(P + 1) * lpl;
+  io.len_v = (int64_t)W * lpl;
+  io.colbase = (int32_t)((int64_t)A.d0.nfe * ((tt_rlo<P>(r1, A.nfe1) + c1) + (int64_t)A.nfe1 * (tt_rlo<P>(plane, A.nfe2) + c2)));
+  io.bad = 0;
+  // consistency of the class tables with the grid (cheap, uniform)
+  if (io.valid && (tt_rn<P>(r1, A.nfe1) != A.n1 || tt_rn<P>(plane, A.nfe2) != A.n2)) io.bad = 1;
+  const int64_t wn2 = (int64_t)W * A.n2;
+  io.out = A.b1 + A.pb1[plane - A.z0] + wn2 * A.d0.ncp * A.rps1[r1] + (int64_t)c2 * W * A.n1 + c1;
+  io.ostride_i = wn2 * A.n1;
+  io.ostride_m = A.n1;
+  tt_walk<P>(A.d0, 0, A.d0.nel, io);
+  return io.bad;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// stage Y: B1 -> B2.   Rows of B2: (i0, i1, r2), block [m1][m0][c2] (c2 fastest).
+struct tt_y_args {
+  const double *b1;
+  const int64_t *pb1;
+  double *b2;
+  const int64_t *pb2;
+  int z0;
+  tt_dir_t d1;
+  int ncp0;
+  const int32_t *planes;
+  int n2, L;
+};
+
+template <int P>
+struct tt_io_y {
+  const double *in;
+  const int32_t *rps;
+  int64_t ustride, clane;
+  bool valid;
+  double *out;
+  int64_t ostride_i, ostride_m;
+  template <int N>
+  TT_MEM void load(int a, int clo, double *v) {
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = 0.0;
+    if (!valid) return;
+    const int64_t o = ustride * rps[a] + clane * N;
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = in[o + j];
+  }
+  TT_MEM void emit(int i, const double *row) {
+    if (!valid) return;
+    double *d = out + ostride_i * i;
+#pragma unroll
+    for (int m = 0; m < 2 * P + 1; m++) d[m * ostride_m] = row[m];
+  }
+};
+
+template <int P>
+TT_DEV void tt_y_lane(const tt_y_args &A, int bx, int by, int lane) {
+  constexpr int W = 2 * P + 1;
+  const int plane = A.planes[by];
+  const int lpl = W * A.n2;
+  const int sub = lane / lpl, l = lane - sub * lpl;
+  const int i0 = bx * A.L + sub;
+  tt_io_y<P> io;
+  io.valid = sub < A.L && i0 < A.ncp0;
+  const int m0 = l % W, c2 = l / W;
+  const int64_t wn2 = (int64_t)W * A.n2;
+  io.in = A.b1 + A.pb1[plane - A.z0];
+  io.rps = A.d1.rps;
+  io.ustride = wn2 * A.ncp0;
+  io.clane = wn2 * i0 + l;
+  io.out = A.b2 + A.pb2[plane - A.z0] + (int64_t)W * wn2 * i0 + (int64_t)m0 * A.n2 + c2;
+  io.ostride_i = (int64_t)W * wn2 * A.ncp0;
+  io.ostride_m = wn2;
+  tt_walk<P>(A.d1, 0, A.d1.nel, io);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// stage Z: B2 planes -> rows of K (CSR order, closed-form positions, MatZeroRowsColumns fused).
+struct tt_z_args {
+  const double *const *planes;   // pointer to the B2 block of FE plane r2, indexed r2 - plane_lo
+  int plane_lo;
+  tt_dir_t d2;
+  int ncp0, ncp1;
+  const int32_t *kps0, *kps1;
+  int ka, kb;                    // dof planes whose rows are written
+  int L;
+  int32_t *kcol;                 // destination arrays, already offset to the first entry of dof plane ka
+  double *kval;
+  const uint8_t *mask;           // zeroDofs as a byte mask over all dofs, or null
+  double diag;
+};
+
+template <int P>
+struct tt_io_z {
+  const double *const *planes;
+  int plane_lo;
+  int64_t clane;
+  bool valid, inwin;
+  // K addressing
+  const int32_t *kps2;
+  int ka, kb, i0, i1, m0, m1, ncp0, ncp1, w0n, w1n, w0lo, w1lo;
+  int64_t w01tot, rowoff01;
+  int32_t *kcol;
+  double *kval;
+  const uint8_t *mask;
+  double diag;
+  template <int N>
+  TT_MEM void load(int a, int clo, double *v) {
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = 0.0;
+    if (!valid) return;
+    const double *pl = planes[a - plane_lo];
+    const int64_t o = clane * N;
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = pl[o + j];
+  }
+  TT_MEM void emit(int i2, const double *row) {
+    if (!valid || !inwin || i2 < ka || i2 >= kb) return;
+    const int w2n = kps2[i2 + 1] - kps2[i2];
+    const int w2lo = i2 < P ? P - i2 : 0;
+    const int64_t rowstart = w01tot * (kps2[i2] - kps2[ka]) + (int64_t)w2n * rowoff01;
+    const int64_t R = i0 + (int64_t)ncp0 * (i1 + (int64_t)ncp1 * i2);
+    const bool mrow = mask && mask[R];
+    const int64_t within = (int64_t)(m1 - w1lo) * w0n + (m0 - w0lo);
+    const int64_t c01 = (i0 - P + m0) + (int64_t)ncp0 * (i1 - P + m1);
+#pragma unroll
+    for (int m2 = 0; m2 < 2 * P + 1; m2++) {
+      if (m2 >= w2lo && m2 < w2lo + w2n) {
+        const int64_t pos = rowstart + (int64_t)(m2 - w2lo) * w1n * w0n + within;
+        const int64_t c = c01 + (int64_t)ncp0 * ncp1 * (i2 - P + m2);
+        double v = row[m2];
+        if (mask && (mrow || mask[c])) v = (mrow && c == R) ? diag : 0.0;
+        kcol[pos] = (int32_t)c;
+        kval[pos] = v;
+      }
+    }
+  }
+};
+
+template <int P>
+TT_DEV void tt_z_lane(const tt_z_args &A, int bx, int lane) {
+  constexpr int W = 2 * P + 1;
+  const int lpl = W * W;
+  const int sub = lane / lpl, l = lane - sub * lpl;
+  const int64_t line = (int64_t)bx * A.L + sub;
+  tt_io_z<P> io;
+  io.valid = sub < A.L && line < (int64_t)A.ncp0 * A.ncp1;
+  const int i0 = io.valid ? (int)(line % A.ncp0) : 0, i1 = io.valid ? (int)(line / A.ncp0) : 0;
+  const int m0 = l % W, m1 = l / W;
+  io.planes = A.planes;
+  io.plane_lo = A.plane_lo;
+  io.clane = (int64_t)lpl * (i0 + (int64_t)A.ncp0 * i1) + l;
+  io.kps2 = A.d2.kps;
+  io.ka = A.ka;
+  io.kb = A.kb;
+  io.i0 = i0;
+  io.i1 = i1;
+  io.m0 = m0;
+  io.m1 = m1;
+  io.ncp0 = A.ncp0;
+  io.ncp1 = A.ncp1;
+  io.w0n = A.kps0[i0 + 1] - A.kps0[i0];
+  io.w1n = A.kps1[i1 + 1] - A.kps1[i1];
+  io.w0lo = i0 < P ? P - i0 : 0;
+  io.w1lo = i1 < P ? P - i1 : 0;
+  io.inwin = m0 >= io.w0lo && m0 < io.w0lo + io.w0n && m1 >= io.w1lo && m1 < io.w1lo + io.w1n;
+  const int64_t w0tot = A.kps0[A.ncp0], w1tot = A.kps1[A.ncp1];
+  io.w01tot = w0tot * w1tot;
+  io.rowoff01 = w0tot * A.kps1[i1] + (int64_t)io.w1n * A.kps0[i0];
+  io.kcol = A.kcol;
+  io.kval = A.kval;
+  io.mask = A.mask;
+  io.diag = A.diag;
+  const int nel = A.d2.nel;
+  const int e_begin = A.ka - P > 0 ? A.ka - P : 0;
+  const int e_end = A.kb < nel ? A.kb : nel;
+  tt_walk<P>(A.d2, e_begin, e_end, io);
+}
+
+// row pointer of K for the rows of dof planes [ka, kb): rowptr_out[R - ka*ncp0*ncp1] = base + closed form
+struct tt_rowptr_args {
+  const int32_t *kps0, *kps1, *kps2;
+  int ncp0, ncp1, ka, kb;
+  int64_t base;
+  int64_t *rowptr_out;
+};
+TT_DEV void tt_rowptr_one(const tt_rowptr_args &A, int64_t idx) {
+  const int64_t pd = (int64_t)A.ncp0 * A.ncp1;
+  const int i2 = A.ka + (int)(idx / pd);
+  const int64_t rem = idx % pd;
+  const int i1 = (int)(rem / A.ncp0), i0 = (int)(rem % A.ncp0);
+  const int64_t w0tot = A.kps0[A.ncp0], w1tot = A.kps1[A.ncp1];
+  const int w2n = A.kps2[i2 + 1] - A.kps2[i2], w1n = A.kps1[i1 + 1] - A.kps1[i1];
+  A.rowptr_out[idx] = A.base + w0tot * w1tot * (A.kps2[i2] - A.kps2[A.ka]) +
+                      (int64_t)w2n * (w0tot * A.kps1[i1] + (int64_t)w1n * A.kps0[i0]);
+}

@@ -367,6 +367,14 @@ class CSRBuilder(object):
         self._h = None
         return DeviceCSR(h)
 
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().tg_csr_builder_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
 
 def csr_from_triplets(nrows, ncols, rows, cols, vals, eps):
     rows, cols, vals = _i64(rows), _i32(cols), _f64(vals)

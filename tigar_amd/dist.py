@@ -130,6 +130,10 @@ def pick_sub_planes(d, p, nel, planes_mine, free_bytes):
     return int(max(1, min(planes_mine, budget // per_dof_plane)))
 
 
+class _TensorDeclined(Exception):
+    """the FE matrix does not have the element-coupling pattern the tensor-pattern PtAP needs"""
+
+
 class SlabHotPath(object):
     """The hot path of one rank, streamed through HBM in sub-slabs of dof planes:
 
@@ -218,6 +222,14 @@ class SlabHotPath(object):
         # input time disappears from the host's view (0.20 -> 0.03 s) and the PtAP grows by the same
         # amount (1.03 -> 1.18 s), with or without a low-priority producer stream.  Off by default.
         subs = self.sub_slabs()
+        # tensor-pattern fast path (csrc/tg_tensor_body.h): the plane-local passes give dense B2 planes that are
+        # kept in the ring, the z pass writes the rows of K at closed-form positions (exact capacity known)
+        from .tensorptap import TensorPtAP
+        tplan = TensorPtAP.for_extraction(self.kx) if (self.factored and self.kron_exact and not getattr(
+            self, "_tensor_declined", False)) else None
+        ring["tensor"] = tplan
+        if tplan is not None and nslabs > 1:
+            builder = dev.CSRBuilder(self.mine["dofs"][1] - self.mine["dofs"][0], self.ncp, tplan.k_nnz(self.k0, self.k1))
         overlap = (self.factored and self.kron_exact and len(subs) > 1
                    and os.environ.get("TIGAR_OVERLAP", "0") == "1")
         sched = []
@@ -282,8 +294,15 @@ class SlabHotPath(object):
             tick("input", t0)
             t0 = time.perf_counter()
             if use_factored:
-                kblk = self._factored_slab(A, S, ka, kb, zero_dofs, diag, ring,
-                                           builder if os.environ.get("TIGAR_SLAB_APPEND", "1") != "0" else None)
+                try:
+                    kblk = self._factored_slab(A, S, ka, kb, zero_dofs, diag, ring,
+                                               builder if os.environ.get("TIGAR_SLAB_APPEND", "1") != "0" else None)
+                except _TensorDeclined:
+                    # A does not carry the element-coupling pattern (found while it was read): start over with
+                    # the general stages (nothing of this call is kept)
+                    self._tensor_declined = True
+                    del A, b, builder, ring
+                    return self.assemble(a_rows, b_rows, zero_dofs, diag, timers)
                 plan = None
             else:
                 plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], S["m_rows"][0], S["dofs"][0])
@@ -367,6 +386,16 @@ class SlabHotPath(object):
         pf = lay.plane_fe
         za, zb = S["a_rows"][0] // pf, S["a_rows"][1] // pf
         new_lo, new_hi = ring["new"]
+        tplan = ring.get("tensor")
+        if tplan is not None:
+            if A_new is not None:
+                piece = tplan.planes(A_new, new_lo * pf, new_lo, new_hi)
+                if piece is None:
+                    raise _TensorDeclined()
+                ring["pieces"].append((new_lo, new_hi, piece))
+                ring["hi"] = new_hi
+            ring["pieces"] = [pc for pc in ring["pieces"] if pc[1] > za]
+            return tplan.zstage([pc[2] for pc in ring["pieces"]], ka, kb, zero_dofs, diag, append_to=builder)
         if A_new is not None:
             cur, done = A_new, set()
             ca, cb = lay.fe_planes_coupled(new_lo, new_hi)

@@ -131,11 +131,19 @@ def ptap_factored(kx, A, a_planes, c_planes, k_planes, zero_dofs=None, diag=1.0,
     refer to the LAST direction, which must be in the last group; for a resident single block pass
     the full ranges."""
     d = kx.d
+    za, zb = a_planes
+    k0, k1 = k_planes
+    # tensor-pattern fast path (csrc/tg_tensor_body.h): line walks without column decode; declines (None)
+    # when the patch or A's pattern does not qualify, and the general stages below take over
+    from .tensorptap import TensorPtAP
+    plan = TensorPtAP.for_extraction(kx)
+    if plan is not None and not A.is_loose():
+        piece = plan.planes(A, za * kx.plane(set()), za, zb)
+        if piece is not None:
+            return plan.zstage([piece], k0, k1, zero_dofs, diag)
     if groups is None:
         groups = [[k] for k in range(d)]
     assert sorted(sum(groups, [])) == list(range(d)) and (d - 1) in groups[-1]
-    za, zb = a_planes
-    k0, k1 = k_planes
     cur = A
     done = set()
     for gi, group in enumerate(groups):

@@ -1,0 +1,171 @@
+"""
+Host side of the tensor-pattern extractMatrix path (csrc/tg_tensor_body.h, csrc/tg_ptap_tensor.hip):
+K = M^T A M (tIGAr/common.py:1176-1204) for a tensor-product B-spline patch whose FE matrix carries the
+element-coupling pattern of the Q_p node grid, in three line-walk passes without column decode, LDS or atomics.
+
+This module decides -- from the 1-D extraction matrices alone -- whether a patch has the structure the walk
+relies on, and builds the per-element local weight tables.  The FE matrix itself is checked on the device,
+entry by entry, while it is read (``planes`` returns None when it has another pattern and the caller falls
+back to the general kernels).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from . import device as _dev
+from ._lib import check, handle, c_f64p, c_i32p, tg_tensor_dir_t
+
+
+def local_weights(M1, p, nel):
+    """wl[e, j, q] = M1[p*e + j, e + q] (value at node j of element e of spline function e+q), or None when a
+    stored entry of M1 lies outside that window, i.e. the direction does not have the structure of an open
+    knot vector with simple interior knots on the CG degree-p grid."""
+    M1 = M1.tocsr()
+    nfe, ncp = M1.shape
+    if nfe != p * nel + 1 or ncp != nel + p:
+        return None
+    wl = np.zeros((nel, p + 1, p + 1))
+    rows = np.repeat(np.arange(nfe), np.diff(M1.indptr))
+    cols, vals = M1.indices, M1.data
+    for (a, c, v) in zip(rows, cols, vals):
+        if v == 0.0:
+            continue
+        homes = []                         # (element, local node) pairs this node belongs to
+        if a % p == 0:
+            if a > 0:
+                homes.append((a // p - 1, p))
+            if a < nfe - 1:
+                homes.append((a // p, 0))
+        else:
+            homes.append((a // p, a % p))
+        for (e, j) in homes:
+            q = c - e
+            if q < 0 or q > p:
+                return None
+            wl[e, j, q] = v
+    return wl
+
+
+def band_pattern_ok(M1, p, nel):
+    """structural pattern of the 1-D K (= M1^T pattern(A1) M1 as PETSc's symbolic product sees it) is the
+    full band |i - i'| <= p clipped to the matrix"""
+    import scipy.sparse as sp
+    nfe, ncp = M1.shape
+    rows, cols = [], []
+    for e in range(nel):
+        idx = np.arange(p * e, p * e + p + 1)
+        rows.append(np.repeat(idx, p + 1))
+        cols.append(np.tile(idx, p + 1))
+    A1 = sp.csr_matrix((np.ones(sum(len(r) for r in rows)), (np.concatenate(rows), np.concatenate(cols))),
+                       shape=(nfe, nfe))
+    Mp = (abs(M1) > 0).astype(np.float64)
+    K1 = (Mp.T @ A1 @ Mp).tocsr()
+    K1.sort_indices()
+    K1.eliminate_zeros()
+    for i in range(ncp):
+        lo, hi = max(0, i - p), min(ncp - 1, i + p)
+        c = K1.indices[K1.indptr[i]:K1.indptr[i + 1]]
+        if len(c) != hi - lo + 1 or c[0] != lo or c[-1] != hi:
+            return False
+    return True
+
+
+class TensorPlanes(object):
+    """B2 planes of FE planes [z0, z1) (device, dense blocks); input of the z pass"""
+
+    def __init__(self, h, z0, z1):
+        self._h, self.z0, self.z1 = h, z0, z1
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().tg_tensor_planes_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class TensorPtAP(object):
+    """Plan of the tensor-pattern PtAP for one patch (1-D tables in HBM)."""
+
+    def __init__(self, p, nels, wls):
+        self.p, self.nels = int(p), [int(n) for n in nels]
+        self._keep = [np.ascontiguousarray(w, dtype=np.float64) for w in wls]
+        arr = (tg_tensor_dir_t * 3)()
+        for k in range(3):
+            arr[k].p = self.p
+            arr[k].nel = self.nels[k]
+            arr[k].wl = self._keep[k].ctypes.data_as(c_f64p)
+        self._h = handle()
+        check(_lib.lib().tg_tensor_plan_create(3, arr, C.byref(self._h)), "tg_tensor_plan_create")
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().tg_tensor_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def structure(kx):
+        """(p, nels, wls) if the patch of the ``KronExtraction`` has the structure of the fast path, else None"""
+        if kx.d != 3:
+            return None
+        grid = kx.grid
+        ps = [s.p for s in kx.basis.splines]
+        p = ps[0]
+        if any(q != p for q in ps) or p < 1 or p > 3 or getattr(grid, "dg", False) or grid.degree != p:
+            return None
+        nels, wls = [], []
+        for k in range(3):
+            nel = len(grid.vertices[k]) - 1
+            wl = local_weights(kx.M1[k], p, nel)
+            if wl is None or not band_pattern_ok(kx.M1[k], p, nel):
+                return None
+            nels.append(nel)
+            wls.append(wl)
+        return p, nels, wls
+
+    @staticmethod
+    def for_extraction(kx):
+        """plan cached on the ``KronExtraction`` (None if the patch does not qualify or TIGAR_PTAP_TENSOR=0)"""
+        if os.environ.get("TIGAR_PTAP_TENSOR", "1") == "0":
+            return None
+        if not hasattr(kx, "_tensor_plan"):
+            st = TensorPtAP.structure(kx)
+            kx._tensor_plan = TensorPtAP(*st) if st is not None else None
+        return kx._tensor_plan
+
+    def k_nnz(self, ka, kb):
+        """entries of the rows of K of the dof planes [ka, kb) (clipped band, Kronecker product)"""
+        def widths(nel):
+            n = nel + self.p
+            i = np.arange(n)
+            return np.minimum(n - 1, i + self.p) - np.maximum(0, i - self.p) + 1
+        w0, w1, w2 = [widths(n) for n in self.nels]
+        return int(w0.sum()) * int(w1.sum()) * int(w2[ka:kb].sum())
+
+    def planes(self, A, a_row0, z0, z1):
+        """x and y passes over the FE planes [z0, z1) of A (DeviceCSR holding whole planes from FE row a_row0
+        on, global columns).  None: A does not have the element-coupling pattern (verified on the device)."""
+        h = handle()
+        rc = _lib.lib().tg_tensor_planes(self._h, A._h, int(a_row0), int(z0), int(z1), C.byref(h))
+        if rc == 100:
+            return None
+        check(rc, "tg_tensor_planes")
+        return TensorPlanes(h, int(z0), int(z1))
+
+    def zstage(self, pieces, ka, kb, zero_dofs=None, diag=1.0, append_to=None):
+        """rows of K for the dof planes [ka, kb): a new DeviceCSR, or True when appended to the builder"""
+        arr = (handle * len(pieces))(*[pc._h for pc in pieces])
+        zd = np.ascontiguousarray(zero_dofs, dtype=np.int32) if zero_dofs is not None and len(zero_dofs) else None
+        out = handle()
+        check(_lib.lib().tg_tensor_zstage(self._h, len(pieces), arr, int(ka), int(kb),
+                                          zd.ctypes.data_as(c_i32p) if zd is not None else None,
+                                          zd.size if zd is not None else 0, float(diag),
+                                          append_to._h if append_to is not None else None, C.byref(out)),
+              "tg_tensor_zstage")
+        return True if append_to is not None else _dev.DeviceCSR(out)
