@@ -27,8 +27,8 @@ static void run_z(const tt_z_args &A, int gx) {
 extern "C" {
 // one launch of the x pass for one (plane class, line class); returns the mismatch flag
 int emu_x(int P, const int64_t *rowptr, const int32_t *col, const double *val, int aplane0, int nel0, int nfe1, int nfe2,
-          const double *wl0, const int32_t *rps1, const int32_t *lines, int nlines, int L, int n1, const int32_t *planes,
-          int nplanes, int n2, double *b1, const int64_t *pb1, int z0) {
+          const double *wl0, const int32_t *rps0, const int32_t *rps1, const int32_t *rps2, const int32_t *lines, int nlines, int L, int n1, const int32_t *planes,
+          int nplanes, int n2, double *b1, const int64_t *pb1, int z0, int64_t nrows_slab) {
   tt_x_args A;
   A.rowptr = rowptr;
   A.col = col;
@@ -38,8 +38,23 @@ int emu_x(int P, const int64_t *rowptr, const int32_t *col, const double *val, i
   A.d0.nfe = P * nel0 + 1;
   A.d0.ncp = nel0 + P;
   A.d0.wl = wl0;
-  A.d0.rps = nullptr;
+  A.d0.rps = rps0;
   A.d0.kps = nullptr;
+  A.rps2 = rps2;
+  {   // what k_tt_check_rows does before the x pass
+    tt_check_args Cq;
+    Cq.rowptr = rowptr;
+    Cq.nfe0 = A.d0.nfe;
+    Cq.nfe1 = nfe1;
+    Cq.nfe2 = nfe2;
+    Cq.aplane0 = aplane0;
+    Cq.z0 = z0;
+    const int64_t nr = (int64_t)nrows_slab;
+    for (int64_t i = 0; i < nr; i++) {
+      const int bad = P == 1 ? tt_check_row<1>(Cq, i) : (P == 2 ? tt_check_row<2>(Cq, i) : tt_check_row<3>(Cq, i));
+      if (bad) return 1;
+    }
+  }
   A.nfe1 = nfe1;
   A.nfe2 = nfe2;
   A.rps1 = rps1;

@@ -87,8 +87,10 @@ def _emulated_ptap(emu, p, nels, wls, A, plane_splits, dof_splits, zero_dofs, di
                 n1 = p + 1 if lc == 0 else W
                 L = max(1, 64 // (n1 * n2))
                 bad = emu.emu_x(p, _p(rp, c_i64p), _p(cs, c_i32p), _p(vs, c_f64p), z0, nels[0], nfe[1], nfe[2],
-                                _p(wls[0], c_f64p), _p(tabs[1][0], c_i32p), _p(lines[lc], c_i32p), len(lines[lc]), L, n1,
-                                _p(planes, c_i32p), len(planes), n2, _p(b1, c_f64p), _p(pb1, c_i64p), z0)
+                                _p(wls[0], c_f64p), _p(tabs[0][0], c_i32p), _p(tabs[1][0], c_i32p), _p(tabs[2][0], c_i32p),
+                                _p(lines[lc], c_i32p), len(lines[lc]), L, n1,
+                                _p(planes, c_i32p), len(planes), n2, _p(b1, c_f64p), _p(pb1, c_i64p), z0,
+                                C.c_int64(r1 - r0))
                 if bad:
                     return None
             L = max(1, 64 // (W * n2))

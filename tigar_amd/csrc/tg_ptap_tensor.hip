@@ -32,7 +32,13 @@ struct tg_tensor_planes_s {
 };
 
 template <int P>
+__global__ void __launch_bounds__(256) k_tt_check_rows(tt_check_args A, int64_t n, int *status) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && tt_check_row<P>(A, i)) atomicOr(status, 1);
+}
+template <int P>
 __global__ void __launch_bounds__(64) k_tt_x(tt_x_args A) {
+  if (*(volatile int *)A.status) return;     // row lengths differ from the pattern: the closed-form addresses do not apply
   const int bad = tt_x_lane<P>(A, blockIdx.x, blockIdx.y, threadIdx.x);
   if (bad) atomicOr(A.status, 1);
 }
@@ -183,6 +189,20 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
   if (!rc && hipMemsetAsync(pl->status, 0, sizeof(int), g_tg.stream) != hipSuccess) rc = 1;
   int bad = 0;
   if (!rc) {
+    // row lengths of the planes against the pattern (8 B per row; the x pass then needs no row pointers)
+    {
+      tt_check_args Cq;
+      Cq.rowptr = a->rowptr;
+      Cq.nfe0 = D0.nfe;
+      Cq.nfe1 = D1.nfe;
+      Cq.nfe2 = D2.nfe;
+      Cq.aplane0 = aplane0;
+      Cq.z0 = z0;
+      const int64_t nr = (int64_t)np * plane_fe;
+#define TT_C(PP) hipLaunchKernelGGL((k_tt_check_rows<PP>), dim3((unsigned)tg_cdiv(nr, 256)), dim3(256), 0, g_tg.stream, Cq, nr, pl->status)
+      TT_DISPATCH_P(P, TT_C);
+#undef TT_C
+    }
     // x pass: one launch per (plane class, line class)
     for (int pc = 0; pc < 2; pc++) {
       if (pls[pc].empty()) continue;
@@ -194,6 +214,7 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
         X.rowptr = a->rowptr;
         X.col = a->col;
         X.val = a->val;
+        X.rps2 = D2.rps;
         X.aplane0 = aplane0;
         X.d0 = D0;
         X.nfe1 = D1.nfe;

@@ -41,6 +41,21 @@
 #define TT_MEM inline
 #endif
 
+// Small read-only tables (local weights, prefix sums) are read through the constant address space: with a
+// wave-uniform index the loads go through the scalar unit (s_load) and the values live in SGPRs -- as plain global
+// loads the compiler keeps a copy per lane (they could alias the stores of the kernel)
+#ifdef __HIPCC__
+typedef const double __attribute__((address_space(4))) *tt_cdp;
+typedef const int32_t __attribute__((address_space(4))) *tt_cip;
+#define TT_CD(p) ((tt_cdp)(p))
+#define TT_CI(p) ((tt_cip)(p))
+#else
+typedef const double *tt_cdp;
+typedef const int32_t *tt_cip;
+#define TT_CD(p) (p)
+#define TT_CI(p) (p)
+#endif
+
 struct tt_dir_t {
   int nel, nfe, ncp;
   const double *wl;      // [nel][P+1][P+1] local extraction weights (see above)
@@ -75,7 +90,7 @@ TT_DEV void tt_walk(const tt_dir_t &D, int e_begin, int e_end, IO &io) {
     for (int m = 0; m < W; m++) acc[r][m] = 0.0;
 
   if (e_begin == 0) {   // opening vertex: node 0 = node j = 0 of element 0
-    const double *we = D.wl;
+    tt_cdp we = TT_CD(D.wl);
     double v[Q], C[Q];
     io.template load<Q>(0, 0, v);
 #pragma unroll
@@ -93,7 +108,7 @@ TT_DEV void tt_walk(const tt_dir_t &D, int e_begin, int e_end, IO &io) {
     }
   }
   for (int e = e_begin; e < e_end; e++) {
-    const double *we = D.wl + (int64_t)e * NW;
+    tt_cdp we = TT_CD(D.wl) + (int64_t)e * NW;
     const int a0 = P * e;
     // interior nodes of element e: columns = the element's P+1 nodes
 #pragma unroll
@@ -116,7 +131,7 @@ TT_DEV void tt_walk(const tt_dir_t &D, int e_begin, int e_end, IO &io) {
     }
     // closing vertex P*(e+1): node j = P of element e; its columns also cover element e+1 unless it is the last node
     if (e + 1 < D.nel) {
-      const double *wn = we + NW;
+      tt_cdp wn = we + NW;
       double v[W], C[Q + 1];
       io.template load<W>(a0 + P, a0, v);
 #pragma unroll
@@ -181,6 +196,7 @@ struct tt_x_args {
   const int64_t *rowptr;
   const int32_t *col;
   const double *val;
+  const int32_t *rps2;   // direction 2 prefix sums
   int aplane0;           // FE plane (direction 2) of A's first row
   tt_dir_t d0;
   int nfe1, nfe2;
@@ -197,33 +213,33 @@ struct tt_x_args {
 
 template <int P>
 struct tt_io_x {
-  const int64_t *rowptr;
   const int32_t *col;
   const double *val;
-  int64_t rowbase, off_s, off_v;
+  tt_cip ps0;                 // prefix sums of the 1-D row lengths of direction 0
+  int64_t linebase;           // entry index of the line's first row block (+ the lane's offset is added per row)
+  int64_t lpl;                // entries of one row block per 1-D entry: n1*n2
+  int64_t off_s, off_v;       // lane offset inside a short / vertex row block
   int32_t colbase;
-  int64_t len_s, len_v;
   bool valid;
   int bad;
   double *out;
   int64_t ostride_i, ostride_m;
+  // Row starts follow in closed form from the row LENGTHS (checked for every row by k_tt_check_rows before this
+  // kernel runs; a mismatch stops the pass), so no row pointer is read here and nothing depends on a previous load.
   template <int N>
   TT_MEM void load(int a, int clo, double *v) {
 #pragma unroll
     for (int j = 0; j < N; j++) v[j] = 0.0;
     if (!valid) return;
-    const int64_t s = rowptr[rowbase + a], e = rowptr[rowbase + a + 1];
-    if (e - s != (N == P + 1 ? len_s : len_v)) {
-      bad = 1;
-      return;
-    }
-    const int64_t o = s + (N == P + 1 ? off_s : off_v);
+    const int64_t o = linebase + lpl * ps0[a] + (N == P + 1 ? off_s : off_v);
     const int32_t c0 = colbase + clo;
+    int32_t diff = 0;
 #pragma unroll
     for (int j = 0; j < N; j++) {
       v[j] = val[o + j];
-      if (col[o + j] != c0 + j) bad = 1;
+      diff |= col[o + j] ^ (c0 + j);
     }
+    bad |= diff;
   }
   TT_MEM void emit(int i, const double *row) {
     if (!valid) return;
@@ -244,14 +260,17 @@ TT_DEV int tt_x_lane(const tt_x_args &A, int bx, int by, int lane) {
   io.valid = sub < A.L && li < A.nlines;
   const int r1 = io.valid ? A.lines[li] : 0;
   const int c1 = l % A.n1, c2 = l / A.n1;
-  io.rowptr = A.rowptr;
   io.col = A.col;
   io.val = A.val;
-  io.rowbase = (int64_t)A.d0.nfe * (r1 + (int64_t)A.nfe1 * (plane - A.aplane0));
+  io.ps0 = TT_CI(A.d0.rps);
+  {
+    // entry index of row block (a = 0, r1, plane): separable prefix sums of the block sizes n0*n1*n2
+    const int64_t t0 = A.d0.rps[A.d0.nfe], t1 = A.rps1[A.nfe1];
+    io.linebase = A.rowptr[0] + t0 * t1 * (A.rps2[plane] - A.rps2[A.aplane0]) + (int64_t)A.n2 * t0 * A.rps1[r1];
+  }
+  io.lpl = lpl;
   io.off_s = (int64_t)l * (P + 1);
   io.off_v = (int64_t)l * W;
-  io.len_s = (int64_t)(P + 1) * lpl;
-  io.len_v = (int64_t)W * lpl;
   io.colbase = (int32_t)((int64_t)A.d0.nfe * ((tt_rlo<P>(r1, A.nfe1) + c1) + (int64_t)A.nfe1 * (tt_rlo<P>(plane, A.nfe2) + c2)));
   io.bad = 0;
   // consistency of the class tables with the grid (cheap, uniform)
@@ -262,6 +281,23 @@ TT_DEV int tt_x_lane(const tt_x_args &A, int bx, int by, int lane) {
   io.ostride_m = A.n1;
   tt_walk<P>(A.d0, 0, A.d0.nel, io);
   return io.bad;
+}
+
+// Row lengths of A against the element-coupling pattern: row (a, r1, r2) must hold n0(a)*n1(r1)*n2(r2) entries.
+// idx runs over the rows of the planes [z0, z1); returns 1 on a mismatch.
+struct tt_check_args {
+  const int64_t *rowptr;
+  int nfe0, nfe1, nfe2, aplane0, z0;
+};
+template <int P>
+TT_DEV int tt_check_row(const tt_check_args &A, int64_t idx) {
+  const int64_t pf = (int64_t)A.nfe0 * A.nfe1;
+  const int r2 = A.z0 + (int)(idx / pf);
+  const int64_t rem = idx % pf;
+  const int r1 = (int)(rem / A.nfe0), a = (int)(rem % A.nfe0);
+  const int64_t r = idx + (int64_t)(A.z0 - A.aplane0) * pf;
+  const int64_t want = (int64_t)tt_rn<P>(a, A.nfe0) * tt_rn<P>(r1, A.nfe1) * tt_rn<P>(r2, A.nfe2);
+  return (A.rowptr[r + 1] - A.rowptr[r]) != want;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -281,7 +317,7 @@ struct tt_y_args {
 template <int P>
 struct tt_io_y {
   const double *in;
-  const int32_t *rps;
+  tt_cip rps;
   int64_t ustride, clane;
   bool valid;
   double *out;
@@ -315,7 +351,7 @@ TT_DEV void tt_y_lane(const tt_y_args &A, int bx, int by, int lane) {
   const int m0 = l % W, c2 = l / W;
   const int64_t wn2 = (int64_t)W * A.n2;
   io.in = A.b1 + A.pb1[plane - A.z0];
-  io.rps = A.d1.rps;
+  io.rps = TT_CI(A.d1.rps);
   io.ustride = wn2 * A.ncp0;
   io.clane = wn2 * i0 + l;
   io.out = A.b2 + A.pb2[plane - A.z0] + (int64_t)W * wn2 * i0 + (int64_t)m0 * A.n2 + c2;
