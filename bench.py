@@ -198,21 +198,21 @@ def run(args, d, p, nel):
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(d, p, budget_nel):
-    """The oracle's C + OpenMP restatement (oracle/tigar_oracle_c.c: the CSR algorithms PETSc AIJ runs on
-    the CPU -- row-wise generateM, Gustavson PtAP + MatZeroRowsColumns, scatter-add M^T b, Jacobi-CG with
-    PETSc's convergence test) on all host cores, on a bounded sample of the same workload (same d, p;
-    fewer elements).  FE inputs A, b are generated beforehand (untimed, as on the GPU side)."""
+def _cpu_sample(d, p, nel, threads, factored=False):
+    """One pass of the path on the host for a d-D degree-p patch with nel^d elements: the oracle's C + OpenMP
+    restatement (oracle/tigar_oracle_c.c: the CSR algorithms PETSc AIJ runs on the CPU -- row-wise generateM,
+    Gustavson PtAP + MatZeroRowsColumns, scatter-add M^T b, Jacobi-CG with PETSc's convergence test) on `threads`
+    threads.  ``factored``: M^T A M as the direction-by-direction product P_z^T(P_y^T(P_x^T A P_x)P_y)P_z with scipy's
+    (single-threaded) sparse products -- the algorithm the GPU path uses, on the CPU.  FE inputs A, b are generated
+    beforehand (untimed, as on the GPU side)."""
+    import scipy.sparse as sp
     from oracle import tigar_oracle as O
     from oracle import tigar_oracle_c as OC
-    nel = budget_nel
-    # one thread per usable core, at most 32 (the sample is small; more threads only add barrier cost)
-    OC.set_threads(min(32, OC.usable_cores()))
+    OC.set_threads(threads)
     t0 = time.perf_counter()
     s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel)] * d)
     f = lambda x: np.sin(np.pi * x)
-    # FE inputs from the device generator (identical matrices, seconds instead of half a minute of
-    # scipy.kron); they are inputs of the baseline, not part of what is timed
+    # FE inputs from the device generator (identical matrices, seconds instead of half a minute of scipy.kron)
     from tigar_amd.BSplines import ExplicitBSplineControlMesh, uniformKnots
     from tigar_amd.common import TensorFunctionSpace
     from tigar_amd.forms import LaplaceForm, SeparableLoadForm
@@ -228,21 +228,64 @@ def cpu_baseline(d, p, budget_nel):
         for side in (0, 1):
             zd += s.getSideDofs(direction, side)
     t1 = time.perf_counter()
-    K = OC.extract_matrix(M, A, zd)
-    rhs = OC.extract_vector(M, b, zd)
+    if factored:
+        M1 = [O.generate_M_tensor(O.BSpline([p], [O.uniform_knots(p, 0., 1., nel)])).tocsr() for _ in range(d)]
+        cur = A.tocsr()
+        for k in range(d):
+            dims = [M1[j].shape[1] if j < k else M1[j].shape[0] for j in range(d)]
+            facs = [M1[j] if j == k else sp.identity(dims[j], format="csr") for j in range(d)]
+            Pk = O.kron_dir0_fastest(facs).tocsr()
+            cur = (Pk.T @ (cur @ Pk)).tocsr()
+        K = O.zero_rows_columns(cur, zd, 1.0)
+    else:
+        K = OC.extract_matrix(M, A, zd)
     t2 = time.perf_counter()
+    rhs = OC.extract_vector(M, b, zd)
+    t3 = time.perf_counter()
     U, its, _ = OC.cg_jacobi(K, rhs, rtol=1e-6)
     u = OC.spmv(M, U)
-    t3 = time.perf_counter()
-    total = t3 - t0
+    t4 = time.perf_counter()
     ncp = s.getNcp()
     X, _ = O.fe_node_grid(s)
     err = float(np.max(np.abs(u - np.prod(np.sin(np.pi * X), axis=1))))
-    return {"value": ncp / total, "unit": "DoF/s", "cores": OC.num_threads(), "kind": "port",
-            "sample": "%dD p=%d %d^%d elements (%d DoFs): extract %.2fs, M^T A M + M^T b %.2fs, "
-                      "CG(%d its)+prolongation %.2fs; C+OpenMP oracle on %d threads; max nodal error %.1e; "
-                      "inputs %.2fs untimed"
-                      % (d, p, nel, d, ncp, t1 - t0, t2 - t1, its, t3 - t2, OC.num_threads(), err, t_in)}
+    return {"nel": nel, "ncp": ncp, "threads": OC.num_threads(), "extract_s": t1 - t0, "ptap_s": t2 - t1, "mtb_s": t3 - t2,
+            "solve_s": t4 - t3, "its": its, "total_s": t4 - t0, "err": err, "inputs_s": t_in, "nnzK": int(K.nnz)}
+
+
+def cpu_baseline(d, p, nel_all, nel_one, nel_target, its_target):
+    """the CPU restatement on ONE thread and on all cores the box grants, on bounded samples of
+    the same workload (same d, p; fewer elements), plus the stated extrapolation to the benchmark size (set-up linear
+    in the DoFs, solve = iterations x per-iteration time) and the sum-factorised product on one thread, so that the
+    algorithmic gain is visible apart from the hardware gain.  A reported baseline, not a target."""
+    from oracle import tigar_oracle_c as OC
+    cores = min(32, OC.usable_cores())       # (the samples are small; more threads only add barrier cost)
+    allc = _cpu_sample(d, p, nel_all, cores)
+    one = _cpu_sample(d, p, nel_one, 1)
+    fac = _cpu_sample(d, p, nel_one, 1, factored=True)
+
+    def extrapolate(smp):
+        ncp_t = (nel_target + p) ** d
+        setup = (smp["extract_s"] + smp["ptap_s"] + smp["mtb_s"]) * ncp_t / smp["ncp"]
+        solve = smp["solve_s"] / max(smp["its"], 1) * its_target * ncp_t / smp["ncp"]
+        return {"seconds": setup + solve, "DoF_per_s": ncp_t / (setup + solve)}
+    fmt = lambda q: ("%dD p=%d %d^%d elements (%d DoFs) on %d thread%s: extract %.2fs, M^T A M %.2fs, M^T b %.2fs, "
+                     "CG(%d its)+prolongation %.2fs; max nodal error %.1e"
+                     % (d, p, q["nel"], d, q["ncp"], q["threads"], "s" if q["threads"] > 1 else "", q["extract_s"], q["ptap_s"],
+                        q["mtb_s"], q["its"], q["solve_s"], q["err"]))
+    return {"value": allc["ncp"] / allc["total_s"], "unit": "DoF/s", "cores": allc["threads"], "kind": "port",
+            "sample": fmt(allc) + "; C+OpenMP restatement of the PETSc AIJ algorithms (oracle/tigar_oracle_c.c); inputs "
+                      "%.2fs untimed" % allc["inputs_s"],
+            "one_thread": {"value": one["ncp"] / one["total_s"], "unit": "DoF/s", "sample": fmt(one)},
+            "one_thread_sum_factorised_ptap": {"ptap_s": fac["ptap_s"], "gustavson_ptap_s": one["ptap_s"],
+                                               "value": fac["ncp"] / fac["total_s"], "unit": "DoF/s",
+                                               "note": "M^T A M as P_z^T(P_y^T(P_x^T A P_x)P_y)P_z with scipy sparse products "
+                                                       "(the GPU path's algorithm on one CPU thread), same sample"},
+            "extrapolated_to_benchmark_size": {
+                "nel": nel_target, "cg_iterations": its_target,
+                "all_cores": extrapolate(allc), "one_thread": extrapolate(one),
+                "method": "set-up (extract + M^T A M + M^T b) linear in the DoFs; solve = per-iteration time of the sample "
+                          "x DoF ratio x the iteration count measured on the GPU at the benchmark size; the benchmark size "
+                          "itself cannot be held on the host (M 271 GB, A 684 GB)"}}
 
 
 def main():
@@ -353,7 +396,8 @@ def main():
         # a bounded sample: seconds of work on the 16 cores the GPU box grants (the A*M intermediate of
         # the Gustavson PtAP needs ~7 GB of host memory at p=3, 40^3 elements)
         cpu_nel = args.cpu_nel or ({2: 80, 3: 40, 4: 16}.get(p, 16) if d == 3 else min(nel, 256))
-        out["cpu_baseline"] = cpu_baseline(d, p, cpu_nel)
+        one_nel = max(4, int(round(cpu_nel * 0.6))) if d == 3 else max(4, cpu_nel // 2)
+        out["cpu_baseline"] = cpu_baseline(d, p, cpu_nel, one_nel, nel, res["iterations"])
     print(json.dumps(out), flush=True)
 
 

@@ -119,6 +119,7 @@ void emu_z(int P, const double *const *planes, int plane_lo, int nel2, const dou
   A.L = L;
   A.kcol = kcol;
   A.kval = kval;
+  A.kdiag = nullptr;
   A.mask = mask;
   A.diag = diag;
   const int64_t pd = (int64_t)ncp0 * ncp1;

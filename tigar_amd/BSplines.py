@@ -396,20 +396,24 @@ class ExplicitBSplineControlMesh(AbstractControlMesh):
         P[:, self.nsd] = 1.0
         return P
 
-    def homogeneousCoordinateDeviceVector(self, direction):
-        """Column ``direction`` of the control-point array as a device vector, expanded on the
-        GPU from its 1-D factors (Greville abscissae along ``direction``, ones elsewhere)."""
+    def homogeneousCoordinateFactors(self, direction):
+        """1-D factors of column ``direction`` of the control-point array: it is the tensor product of
+        Greville abscissae along ``direction`` and ones elsewhere (weights: all ones; extra dimensions: zero)."""
         sp_ = self.scalarSpline
         ncps = [s.getNcp() for s in sp_.splines]
         if direction == self.nsd:
-            facs = [numpy.ones(n) for n in ncps]
-        elif direction < self.nvar:
+            return [numpy.ones(n) for n in ncps]
+        if direction < self.nvar:
             facs = [numpy.ones(n) for n in ncps]
             s = sp_.splines[direction]
             facs[direction] = numpy.array([s.greville(i) for i in range(s.getNcp())])
-        else:
-            facs = [numpy.zeros(n) for n in ncps]
-        return _dev.vec_tensor3(facs)
+            return facs
+        return [numpy.zeros(n) for n in ncps]
+
+    def homogeneousCoordinateDeviceVector(self, direction):
+        """Column ``direction`` of the control-point array as a device vector, expanded on the
+        GPU from its 1-D factors."""
+        return _dev.vec_tensor3(self.homogeneousCoordinateFactors(direction))
 
     def getNsd(self):
         return self.nsd

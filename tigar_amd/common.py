@@ -342,7 +342,20 @@ class AbstractExtractionGenerator(object):
             kx = self.M_control.kx
             self._slab_engine = SlabHotPath(kx.basis, kx.grid, self.comm.rank, self.comm.size, self.comm.device(),
                                             sub_planes="auto", eps=self.M_control.eps, kx=kx)
+        separable = (getattr(self.M_control, "is_implicit", False) and cm is not None
+                     and hasattr(cm, "homogeneousCoordinateFactors"))
         for i in range(self.nsd + 1):
+            if separable:
+                # M_control and the control net are both tensor products: so is the control function,
+                # (M_z g_z) (x) (M_y g_y) (x) (M_x g_x) -- one write pass over the FE rows this rank owns
+                kx = self.M_control.kx
+                facs = cm.homogeneousCoordinateFactors(i)
+                fe1d = [kx.M1[k] @ numpy.asarray(facs[k], dtype=numpy.float64) for k in range(kx.d)]
+                rng = self._slab_engine.mine["u_rows"] if self._slab_engine is not None else None
+                f = Function(self.V_control, rng)
+                f._vec = _dev.vec_tensor3(fe1d, 1.0, rng[0] if rng else None, rng[1] if rng else None)
+                self.cpFuncs += [f]
+                continue
             if cm is not None and hasattr(cm, "homogeneousCoordinateDeviceVector"):
                 Pi = cm.homogeneousCoordinateDeviceVector(i)      # built in HBM from 1-D factors
             else:

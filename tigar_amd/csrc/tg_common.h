@@ -96,6 +96,11 @@ struct tg_csr_s {
   // changing values
   tg_sell_s *sell = nullptr;
   int sell_state = 0;            // 0 = not tried, 1 = in use, -1 = declined
+  // diagonal of a square row block (entry (r, row0 + r)) recorded by the kernel that wrote the values (the z pass of
+  // the tensor-pattern PtAP): the Jacobi set-up of the Krylov solvers then needs no pass over the matrix.  Dropped
+  // by every function that changes values afterwards.
+  double *diag_cache = nullptr;
+  int64_t diag_rows = 0;         // rows of diag_cache that are valid (from row 0)
 };
 
 int tg_dmalloc_bytes(void **p, size_t bytes);   // caching allocator (tg_core.hip)

@@ -772,6 +772,7 @@ extern "C" int tg_csr_destroy(tg_csr_t m) {
   }
   tg_dfree(m->rowblocks);
   tg_dfree(m->rowcnt);
+  tg_dfree(m->diag_cache);
   tg_sell_drop(m);
   delete m;
   return 0;

@@ -52,6 +52,17 @@ __global__ void __launch_bounds__(256) k_fold(const double *partial, int nb, int
   }
 }
 
+// dinv from a recorded diagonal (tg_csr_s::diag_cache)
+__global__ void __launch_bounds__(256) k_jacobi_from_diag(const double *__restrict__ diag, int64_t n, int use_jacobi,
+                                                         double *__restrict__ dinv) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double d = diag[i];
+    dinv[i] = (use_jacobi && d != 0.0) ? 1.0 / d : 1.0;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_jacobi_setup(const int64_t *__restrict__ rowptr,
                                                       const int32_t *__restrict__ col,
                                                       const double *__restrict__ val, int64_t nrows, int64_t row0,
@@ -271,7 +282,10 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
   const double *ushift = uext - (row0 - hlo);              // u addressed by global column index
   const int64_t cmin = row0 - hlo, cmax = row0 - hlo + next - 1;
 
-  if (n > 0) {
+  if (n > 0 && k->diag_cache && k->diag_rows == n) {
+    hipLaunchKernelGGL(k_jacobi_from_diag, dim3(tg_vec_grid(n)), dim3(256), 0, g_tg.stream, k->diag_cache, n,
+                       pc == TG_PC_JACOBI ? 1 : 0, dinv);
+  } else if (n > 0) {
     const unsigned jg = (unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16);
     hipLaunchKernelGGL(k_jacobi_setup, dim3(jg), dim3(256), 0, g_tg.stream, k->rowptr, k->col, k->val, n, row0,
                        pc == TG_PC_JACOBI ? 1 : 0, dinv);
@@ -481,7 +495,10 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
   TG_TRY(tg_spmv_plan(k));
   tg_sell_guard sell_guard(k);   // sliced copy of the values for the products of this solve
   TG_TRY(sell_guard.rc);
-  if (n > 0) {
+  if (n > 0 && k->diag_cache && k->diag_rows == n) {
+    hipLaunchKernelGGL(k_jacobi_from_diag, dim3(tg_vec_grid(n)), dim3(256), 0, g_tg.stream, k->diag_cache, n,
+                       pc == TG_PC_JACOBI ? 1 : 0, dinv);
+  } else if (n > 0) {
     const unsigned jg = (unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16);
     hipLaunchKernelGGL(k_jacobi_setup, dim3(jg), dim3(256), 0, g_tg.stream, k->rowptr, k->col, k->val, n, row0,
                        pc == TG_PC_JACOBI ? 1 : 0, dinv);

@@ -345,6 +345,13 @@ extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tenso
     Z.ka = ka;
     Z.kb = kb;
     Z.L = std::max(1, 64 / (W * W));
+    // the diagonal is recorded while the rows are written (only while every row so far came from here)
+    if (row_at == 0 && !m->diag_cache) {
+      if (tg_dmalloc(&m->diag_cache, m->nrows)) m->diag_cache = nullptr;
+      m->diag_rows = 0;
+    }
+    const bool keep_diag = m->diag_cache && m->diag_rows == row_at;
+    Z.kdiag = keep_diag ? m->diag_cache + row_at : nullptr;
     Z.kcol = m->col + nnz_at;
     Z.kval = m->val + nnz_at;
     Z.mask = mask;
@@ -368,6 +375,7 @@ extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tenso
     if (!dest) tg_csr_destroy(m);
     return rc;
   }
+  if (m->diag_cache && m->diag_rows == row_at) m->diag_rows = row_at + nrows;
   if (dest) {
     dest->rows_done += nrows;
     dest->nnz_done += nnz;

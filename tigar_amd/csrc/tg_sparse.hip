@@ -577,6 +577,9 @@ extern "C" int tg_zero_rows_cols(tg_csr_t k, int64_t row0, const int32_t *dofs, 
   TG_REQUIRE_INIT();
   TG_REQUIRE(k, "null matrix");
   if (n <= 0 || k->nrows == 0) return 0;
+  tg_dfree(k->diag_cache);      // values change: a recorded diagonal is stale
+  k->diag_cache = nullptr;
+  k->diag_rows = 0;
   uint8_t *mask = nullptr;
   TG_TRY(tg_build_dof_mask(dofs, n, k->ncols, &mask));
   const unsigned grid = (unsigned)std::min<int64_t>(tg_cdiv(k->nrows, 4), (int64_t)g_tg.num_cu * 16);

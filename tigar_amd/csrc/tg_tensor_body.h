@@ -372,6 +372,7 @@ struct tt_z_args {
   int L;
   int32_t *kcol;                 // destination arrays, already offset to the first entry of dof plane ka
   double *kval;
+  double *kdiag;                 // diagonal of the rows written (index: row - first row of dof plane ka), or null
   const uint8_t *mask;           // zeroDofs as a byte mask over all dofs, or null
   double diag;
 };
@@ -388,6 +389,7 @@ struct tt_io_z {
   int64_t w01tot, rowoff01;
   int32_t *kcol;
   double *kval;
+  double *kdiag;
   const uint8_t *mask;
   double diag;
   template <int N>
@@ -418,6 +420,7 @@ struct tt_io_z {
         if (mask && (mrow || mask[c])) v = (mrow && c == R) ? diag : 0.0;
         kcol[pos] = (int32_t)c;
         kval[pos] = v;
+        if (m2 == P && kdiag && m0 == P && m1 == P) kdiag[R - (int64_t)ka * ncp0 * ncp1] = v;   // c == R
       }
     }
   }
@@ -455,6 +458,7 @@ TT_DEV void tt_z_lane(const tt_z_args &A, int bx, int lane) {
   io.rowoff01 = w0tot * A.kps1[i1] + (int64_t)io.w1n * A.kps0[i0];
   io.kcol = A.kcol;
   io.kval = A.kval;
+  io.kdiag = A.kdiag;
   io.mask = A.mask;
   io.diag = A.diag;
   const int nel = A.d2.nel;
