@@ -265,6 +265,13 @@ int tg_krylov_solve_flags(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, int pc
                           double atol, int maxit, int restart, int flags, tg_comm_t comm, int *iters,
                           double *resnorm, int *status);
 
+/* ---- direct solve: what solveLinearSystem runs when linearSolver is None (dolfin solve() = sparse LU [ext],
+ * tIGAr/common.py:1255-1256).  Banded LU with partial pivoting in LAPACK's dgbtrf storage / pivoting scheme. */
+/* half-bandwidths of a square matrix and the bytes its band storage (2*kl+ku+1 rows) would take */
+int tg_lu_band_info(tg_csr_t k, int *kl, int *ku, int64_t *bytes);
+/* x = K^-1 b (x may be b); info > 0: U(info-1,info-1) == 0 exactly, nothing was solved */
+int tg_lu_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *info);
+
 /* ---- synthetic FE-side input (NOT on the timed path) --------- */
 /* A = sum_t (x)_k F[t][k] with 1-D CSR factors sharing one pattern per direction
  * (e.g. Q_p Laplace stiffness = K1xM1xM1 + M1xK1xM1 + M1xM1xK1); rows [row0,row1). */

@@ -1,0 +1,165 @@
+"""-m gpu: the direct solver behind ``linearSolver=None`` (dolfin's solve() = sparse LU in the reference,
+tIGAr/common.py:1255-1256): banded LU with partial pivoting (csrc/tg_lu.hip) against scipy's SuperLU on systems
+where Jacobi-Krylov methods fail, on the biharmonic demo flow, and the hand-over to GMRES for large systems."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from oracle import tigar_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_banded_lu_with_pivoting_vs_superlu():
+    from tigar_amd import device as dev
+    rng = np.random.default_rng(1)
+    for (n, kl, ku) in [(1, 0, 0), (7, 2, 1), (200, 5, 9), (1500, 40, 17), (3000, 130, 130)]:
+        diags = {}
+        for o in range(-kl, ku + 1):
+            diags[o] = rng.standard_normal(n - abs(o))
+        A = sp.diags(list(diags.values()), list(diags.keys()), shape=(n, n), format="csr")
+        A = A.tolil()
+        for i in range(0, n if n > 1 else 0, 3):   # tiny / zero diagonal entries: no solve without row interchanges
+            A[i, i] = 0.0 if i % 2 == 0 else 1e-14
+        A = A.tocsr()
+        xs = rng.standard_normal(n)
+        b = A @ xs
+        K = dev.DeviceCSR.from_scipy(A)
+        bl, bu, nb = dev.lu_band_info(K)
+        assert bl <= kl and bu <= ku and nb == (2 * bl + bu + 1) * n * 8
+        x = dev.DeviceVector(n)
+        info = dev.lu_solve(K, dev.DeviceVector(data=b), x)
+        assert info == 0
+        ref = spla.spsolve(A.tocsc(), b)
+        err = np.linalg.norm(x.get_local() - ref) / np.linalg.norm(ref)
+        res = np.linalg.norm(A @ x.get_local() - b) / np.linalg.norm(b)
+        # random band matrices are badly conditioned: backward error is the criterion (as small as SuperLU's),
+        # the forward error only where the condition number allows
+        res_ref = np.linalg.norm(A @ ref - b) / np.linalg.norm(b)
+        assert res < 1e-10 and res <= 100 * max(res_ref, 1e-16), (n, kl, ku, res, res_ref, err)
+        if n <= 200:
+            assert err < 1e-6 * max(1.0, np.linalg.cond(A.toarray()) * 1e-10), (n, err)
+
+
+def test_saddle_point_system_where_jacobi_krylov_stalls():
+    """[[A, B], [B^T, 0]]: zero diagonal block (PCJACOBI substitutes 1), indefinite -- the kind of system the
+    reference's default LU handles and a Jacobi-Krylov default does not"""
+    import tigar_amd as t
+    from tigar_amd import device as dev
+    rng = np.random.default_rng(2)
+    n1, n2 = 300, 120
+    A = sp.diags([rng.random(n1) + 2.0, -np.ones(n1 - 1), -np.ones(n1 - 1)], [0, 1, -1], format="csr")
+    B = sp.random(n1, n2, density=0.05, random_state=3, format="csr") + sp.eye(n1, n2, format="csr")
+    K = sp.bmat([[A, B], [B.T, None]], format="csr")
+    xs = rng.standard_normal(n1 + n2)
+    b = K @ xs
+    lu = t.PETScLUSolver()
+    x = dev.DeviceVector(n1 + n2)
+    lu.solve(K, x, b)
+    assert np.linalg.norm(x.get_local() - xs) <= 1e-8 * np.linalg.norm(xs)
+    assert lu.last["info"] == 0
+    # singular system: explicit error, no garbage
+    S = K.tolil()
+    S[5, :] = 0.0
+    with pytest.raises(RuntimeError):
+        lu.solve(S.tocsr(), dev.DeviceVector(n1 + n2), b)
+
+
+def test_default_solver_is_direct_on_the_biharmonic_demo_flow():
+    """demos/biharmonic/biharmonic.py with the reference's default (direct) solve: p = 4, clamped, 64 x 64 elements
+    (4624 DoFs), and BASELINE cfg4's size 256 x 256 (67600 DoFs, half-bandwidth 1044) against the manufactured
+    solution"""
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, forms as F
+    p = 4
+    errs = {}
+    for nel in (16, 64, 256):
+        kv = [B.uniformKnots(p, -1.0, 1.0, nel) for _ in range(2)]
+        gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p, p], kv))
+        sp0 = gen.getScalarSpline(0)
+        for direction in (0, 1):
+            for side in (0, 1):
+                gen.addZeroDofs(0, sp0.getSideDofs(direction, side, nLayers=2))
+        spline = t.ExtractedSpline(gen, 2 * p)
+        assert spline.linearSolver is None
+        c = lambda x: np.cos(np.pi * x)
+        c1 = lambda x: np.cos(np.pi * x) + 1.0
+        pi4 = np.pi ** 4
+        load = F.SumOfSeparableLoads([([c, c1], pi4), ([c, c], 2 * pi4), ([c1, c], pi4)])
+        u = t.Function(spline.V)
+        U = spline.solveLinearVariationalProblem(F.Equation(F.BiharmonicForm(), load), u)
+        X = spline.V.grids[0].coordinates()
+        exact = (np.cos(np.pi * X[:, 0]) + 1.0) * (np.cos(np.pi * X[:, 1]) + 1.0)
+        errs[nel] = np.max(np.abs(u.vector().get_local() - exact))
+        if nel == 16:
+            s = O.BSpline([p, p], [O.uniform_knots(p, -1., 1., nel)] * 2)
+            Mo = O.generate_M_tensor(s)
+            Ao = O.biharmonic_fe_system_2d(s)
+            zo = list(spline.zeroDofs)
+            Ko = O.extract_matrix(Mo, Ao, zo)
+            bo = spline.assembleVector(load).get_local()
+            Uo = spla.spsolve(Ko.tocsc(), bo)
+            assert np.linalg.norm(U.get_local() - Uo) <= 1e-9 * np.linalg.norm(Uo)     # direct vs direct
+        if nel == 256:
+            # cond(K) ~ h^-4: the forward error of ANY direct solve is round-off dominated here (~cond * eps); the
+            # backward error is what the factorisation controls
+            K = spline.assembleMatrix(F.BiharmonicForm())
+            rhs = spline.assembleVector(load)
+            r = K.mult(U)
+            r.axpy(-1.0, rhs)
+            Kn = float(np.sqrt((K.to_scipy().data ** 2).sum()))
+            assert r.norm() <= 1e-12 * Kn * U.norm()           # normwise backward error
+            assert K.shape[0] == 67600
+    assert errs[64] < errs[16] / 50.0 and errs[256] < 1e-3
+
+
+def test_default_solver_reorders_field_major_systems_and_hands_large_ones_to_gmres():
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, forms as F, common as tc, device as dev
+    # three fields numbered field after field: bandwidth ~ 2 n/3 as numbered, small after reverse Cuthill-McKee
+    p, nel = 2, 24
+    kv = [B.uniformKnots(p, 0., 1., nel)] * 2
+    gen = t.EqualOrderSpline(3, B.ExplicitBSplineControlMesh([p, p], kv))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    s = O.BSpline([p, p], [O.uniform_knots(p, 0., 1., nel)] * 2)
+    A1, _, _, _ = O.poisson_fe_system(s)
+    n1 = A1.shape[0]
+    rng = np.random.default_rng(0)
+    pat = (abs(A1) > 0).astype(np.float64).tocsr()
+    blocks = [[None] * 3 for _ in range(3)]
+    for a in range(3):
+        for b_ in range(3):
+            Bk = pat.copy()
+            Bk.data = 0.05 * rng.standard_normal(Bk.nnz)
+            blocks[a][b_] = Bk
+        blocks[a][a] = blocks[a][a] + sp.identity(n1) * 4.0
+    A = sp.bmat(blocks, format="csr")
+    K = spline.extractMatrix(A)
+    bvec = rng.standard_normal(A.shape[0])
+    rhs = spline.extractVector(bvec)
+    lu = t.PETScLUSolver()
+    lu.parameters["reorder"] = True
+    x = dev.DeviceVector(K.shape[0])
+    lu.solve(K, x, rhs)
+    assert lu.last["reordered"] and lu.last["kl"] < K.shape[0] // 6
+    ref = spla.spsolve(K.to_scipy().tocsc(), rhs.get_local())
+    assert np.linalg.norm(x.get_local() - ref) <= 1e-10 * np.linalg.norm(ref)
+    # a 3-D system beyond the direct solver's budget goes to Jacobi-GMRES (and says so in `last`)
+    p, nel = 2, 48
+    kv = [B.uniformKnots(p, 0., 1., nel)] * 3
+    gen3 = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p] * 3, kv))
+    sp0 = gen3.getScalarSpline(0)
+    for direction in range(3):
+        for side in (0, 1):
+            gen3.addZeroDofs(0, sp0.getSideDofs(direction, side))
+    spl3 = t.ExtractedSpline(gen3, 2 * p)
+    f1 = lambda x_: np.sin(np.pi * x_)
+    K3, b3 = spl3.assembleLinearSystem(F.LaplaceForm(), F.SeparableLoadForm([f1] * 3, scale=3 * np.pi ** 2))
+    d = tc._default_linear_solver()
+    x3 = dev.DeviceVector(K3.shape[0])
+    d.solve(K3, x3, b3)
+    assert d.last["solver"] == "gmres" and d.last["status"] == 0
+    r = K3.mult(x3)
+    r.axpy(-1.0, b3)
+    assert r.norm() <= 1e-9 * b3.norm()

@@ -737,19 +737,101 @@ class PETScKrylovSolver(object):
 KrylovSolver = PETScKrylovSolver
 
 
+class PETScLUSolver(object):
+    """Look-alike of dolfin's ``PETScLUSolver`` / ``LUSolver``: direct solve on the GPU by banded LU with partial
+    pivoting (``tg_lu_solve``, LAPACK dgbtrf's storage and pivoting).  Plugs into ``ExtractedSpline.linearSolver``.
+    IGA matrices of tensor-product patches are banded in the patch numbering; for other orderings (several fields
+    numbered field after field) ``parameters["reorder"]`` (default "auto") applies a reverse Cuthill-McKee
+    permutation of the pattern first.  Refuses systems whose band storage exceeds ``max_band_bytes``."""
+
+    def __init__(self, method="default", comm=None):
+        self.parameters = {"reorder": "auto", "max_band_bytes": 16 * 2 ** 30, "report": False,
+                           "symmetric": False, "reuse_factorization": False}
+        self.last = None
+
+    def band_cost(self, A):
+        """(bytes of band storage, multiply-adds) of factorising ``A`` as it is numbered"""
+        kl, ku, nb = _dev.lu_band_info(A)
+        return nb, 2.0 * A.shape[0] * kl * (kl + ku)
+
+    def solve(self, A, x, b):
+        A, x, b = _as_device_csr(A), _as_device_vector(x), _as_device_vector(b)
+        n = A.shape[0]
+        kl, ku, nb = _dev.lu_band_info(A)
+        perm = None
+        mode = self.parameters["reorder"]
+        if mode is True or (mode == "auto" and nb > 2 ** 28 and (kl + ku) > n // 8):
+            # bandwidth-reducing ordering of the PATTERN on the host (symbolic step; values stay on the device
+            # except for this one re-upload of the permuted matrix)
+            import scipy.sparse as _sp
+            from scipy.sparse.csgraph import reverse_cuthill_mckee
+            S = A.to_scipy()
+            pat = (abs(S) + abs(S.T)).tocsr()
+            prm = numpy.asarray(reverse_cuthill_mckee(pat, symmetric_mode=True), dtype=numpy.int64)
+            Sp = S[prm][:, prm].tocsr()
+            Ap = DeviceCSR.from_scipy(Sp)
+            kl2, ku2, nb2 = _dev.lu_band_info(Ap)
+            if nb2 < nb:
+                A, perm, kl, ku, nb = Ap, prm, kl2, ku2, nb2
+        if nb > self.parameters["max_band_bytes"]:
+            raise MemoryError("direct solve: the band storage of this %d x %d system (half-bandwidths %d / %d) needs %.1f GB; "
+                              "use a Krylov solver (PETScKrylovSolver) for systems of this size" % (n, n, kl, ku, nb / 2 ** 30))
+        if perm is not None:
+            bp = DeviceVector(data=b.get_local()[perm])
+            xp = DeviceVector(n)
+            info = _dev.lu_solve(A, bp, xp)
+            if info == 0:
+                out = numpy.empty(n)
+                out[perm] = xp.get_local()
+                x.set_local(out)
+        else:
+            info = _dev.lu_solve(A, b, x)
+        self.last = {"info": info, "kl": kl, "ku": ku, "band_bytes": nb, "reordered": perm is not None}
+        if info != 0:
+            raise RuntimeError("direct solve: the matrix is singular (exact zero pivot in column %d)" % (info - 1))
+        return 1
+
+
+LUSolver = PETScLUSolver
+
+
+class _DefaultSolver(object):
+    """What runs when ``linearSolver`` is None.  The reference calls dolfin's ``solve`` there, i.e. a sparse direct LU
+    (tIGAr/common.py:1255-1256 [ext]) -- every demo relies on it.  Here: the banded direct solver above whenever its
+    cost is moderate (band storage <= 8 GB and <= 4e12 multiply-adds: all 2-D patches of the demos, small 3-D ones),
+    otherwise Jacobi-preconditioned GMRES(30) (CG for the normal equations of ``FEtoIGA``) to a relative residual of
+    1e-12, bounded by PETSc's default 10 000 iterations and by the solver's stagnation guard, with an error message
+    that names the deviation when it gives up."""
+
+    def __init__(self, method="gmres"):
+        self.method = method
+        self.comm = None
+        self.last = None
+
+    def solve(self, A, x, b):
+        A = _as_device_csr(A)
+        if self.comm is None and os.environ.get("TIGAR_DEFAULT_SOLVER", "auto") != "krylov":
+            lu = PETScLUSolver()
+            kl, ku, nb = _dev.lu_band_info(A)
+            flops = 2.0 * A.shape[0] * kl * (kl + ku)
+            if (nb <= 8 * 2 ** 30 and flops <= 4e12 and A.shape[0] <= 400000) or \
+                    os.environ.get("TIGAR_DEFAULT_SOLVER") == "lu":
+                lu.solve(A, x, b)
+                self.last = dict(lu.last, solver="lu")
+                return 1
+        ks = PETScKrylovSolver(self.method, "jacobi", comm=self.comm)
+        ks.parameters["relative_tolerance"] = 1e-12
+        ks.parameters["maximum_iterations"] = 10000
+        ks.note = ("  (linearSolver=None: the reference would have run dolfin's direct LU here; this system is too large for "
+                   "tigar_amd's banded direct solver, so Jacobi-%s was used -- set ExtractedSpline.linearSolver for "
+                   "ill-conditioned systems)" % self.method.upper())
+        ks.solve(A, x, b)
+        self.last = dict(ks.last, solver=self.method)
+        return ks.last["iterations"]
+
+
 def _default_linear_solver(method="gmres"):
-    """What runs when ``linearSolver`` is None.  The reference calls dolfin's ``solve`` there, i.e. a sparse
-    direct LU (tIGAr/common.py:1255-1256 [ext]); this path has no sparse direct factorisation, so the default
-    is Jacobi-preconditioned GMRES(30) (CG for the normal equations of ``FEtoIGA``) to a relative residual of
-    1e-12, bounded by PETSc's default 10 000 iterations and by the solver's stagnation guard -- on systems where
-    that is not enough (strongly indefinite, zero diagonal blocks) it stops early with an error that says so
-    instead of iterating on; pass a ``linearSolver`` (any object with ``solve(A, x, b)``) in that case."""
-    solver = PETScKrylovSolver(method, "jacobi")
-    solver.parameters["relative_tolerance"] = 1e-12
-    solver.parameters["maximum_iterations"] = 10000
-    solver.note = ("  (linearSolver=None: the reference would have run dolfin's direct LU here; tigar_amd's default "
-                   "is this Krylov solver -- set ExtractedSpline.linearSolver for ill-conditioned systems)")
-    return solver
+    return _DefaultSolver(method)
 
 
 # ---- analysis side ---------------------------------------------------------------------------

@@ -1,0 +1,246 @@
+// Direct solve of K U = M^T b: banded LU with partial pivoting.
+//
+// With `linearSolver == None` the reference's solveLinearSystem calls dolfin's `solve(A, x, b)`, i.e. a sparse
+// direct LU (tIGAr/common.py:1255-1256 [ext]); every demo of the reference relies on it (biharmonic, shells,
+// penalty and saddle-point systems on which Jacobi-Krylov methods stall).  IGA matrices of a tensor-product
+// patch are banded in the patch numbering (half-bandwidth ~ p * ncp_x in 2-D), so the direct solver here is a
+// dense-band factorisation in LAPACK's dgbtrf storage and pivoting scheme (unblocked dgbtf2: row interchanges
+// within the band, U's bandwidth grows to kl+ku), one column at a time:
+//   k_lu_pivot   one workgroup: pivot search in column j, row interchange, multipliers
+//   k_lu_update  rank-1 update of the trailing (km x (ju-j)) window, many workgroups
+// followed by forward / backward substitution in one persistent workgroup each.  Launch-bound (2 launches per
+// column), meant for the moderate sizes where the reference uses LU; large 3-D systems belong to the Krylov solvers.
+#include "tg_common.h"
+#include <algorithm>
+
+struct tg_lu_state {     // device-resident control block
+  int ju;                // last column touched by the row interchanges so far (LAPACK's JU), 0-based
+  int info;              // 0, or 1 + index of the first exactly-zero pivot
+  int km, jp;            // of the current column
+  double pivinv;
+};
+
+// AB(i, j) of the LAPACK band layout: element (row r, col c) at ab[(kv + r - c) + ldab * c]
+__global__ void __launch_bounds__(256) k_lu_scatter(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                    const double *__restrict__ val, int64_t n, int kv, int64_t ldab,
+                                                    double *__restrict__ ab) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n; r += nwaves)
+    for (int64_t q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) {
+      const int64_t c = col[q];
+      ab[(kv + r - c) + ldab * c] += val[q];       // (+=: duplicate entries of a row add up, as in MatSetValues ADD)
+    }
+}
+
+__global__ void __launch_bounds__(256) k_lu_bandwidth(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                      int64_t n, int *__restrict__ kl, int *__restrict__ ku) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t a = rowptr[r], b = rowptr[r + 1];
+  if (b <= a) return;
+  // (columns are sorted within a row)
+  const int64_t lo = r - col[a], hi = col[b - 1] - r;
+  if (lo > 0) atomicMax(kl, (int)lo);
+  if (hi > 0) atomicMax(ku, (int)hi);
+}
+
+__global__ void __launch_bounds__(256)
+    k_lu_pivot(double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, int64_t j, int32_t *__restrict__ ipiv,
+               tg_lu_state *st) {
+  __shared__ double sval[256];
+  __shared__ int sidx[256];
+  const int tid = threadIdx.x;
+  const int km = (int)min((int64_t)kl, n - 1 - j);
+  double *cj = ab + kv + ldab * j;                 // cj[i] = A(j+i, j)
+  double best = -1.0;
+  int bi = 0;
+  for (int i = tid; i <= km; i += 256) {
+    const double a = fabs(cj[i]);
+    if (a > best || (a != a && best == best)) {   // first maximum; NaN wins so that it surfaces
+      best = a;
+      bi = i;
+    }
+  }
+  sval[tid] = best;
+  sidx[tid] = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      const double b2 = sval[tid + o];
+      const int i2 = sidx[tid + o];
+      if (b2 > sval[tid] || (b2 == sval[tid] && i2 < sidx[tid])) {
+        sval[tid] = b2;
+        sidx[tid] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  const int jp = sidx[0];
+  const double piv = cj[jp];
+  int ju = st->ju;
+  __syncthreads();
+  if (tid == 0) {
+    ipiv[j] = (int32_t)(j + jp);
+    ju = max(ju, (int)min(j + (int64_t)(kv - kl) + jp, n - 1));     // ku = kv - kl
+    st->ju = ju;
+    st->km = km;
+    st->jp = jp;
+    if (piv == 0.0 && st->info == 0) st->info = (int)(j + 1);
+    st->pivinv = piv != 0.0 ? 1.0 / piv : 0.0;
+    sidx[1] = ju;
+  }
+  __syncthreads();
+  ju = sidx[1];
+  if (piv == 0.0) return;
+  // interchange rows j and j+jp over the columns j..ju (stride ldab-1 walks along a row of the band)
+  if (jp != 0) {
+    const int64_t len = ju - j + 1;
+    for (int64_t t = tid; t < len; t += 256) {
+      double *p = cj + t * (ldab - 1);
+      const double a = p[jp], b = p[0];
+      p[jp] = b;
+      p[0] = a;
+    }
+  }
+  __syncthreads();
+  const double pinv = 1.0 / piv;
+  for (int i = 1 + tid; i <= km; i += 256) cj[i] *= pinv;
+}
+
+__global__ void __launch_bounds__(256)
+    k_lu_update(double *__restrict__ ab, int64_t ldab, int kv, int64_t j, const tg_lu_state *__restrict__ st) {
+  const int km = st->km;
+  const int64_t nc = st->ju - j;                   // trailing columns j+1..ju
+  if (km <= 0 || nc <= 0 || st->pivinv == 0.0) return;
+  const double *l = ab + kv + ldab * j;            // l[i], i = 1..km: multipliers
+  // 2-D tiling: x over rows (contiguous in memory), y over columns
+  for (int64_t c = blockIdx.y; c < nc; c += gridDim.y) {
+    double *cc = ab + kv + ldab * (j + 1 + c) - (1 + c);     // cc[i] = A(j+i, j+1+c)
+    const double u = cc[0];
+    if (u == 0.0) continue;
+    for (int i = 1 + blockIdx.x * 256 + threadIdx.x; i <= km; i += gridDim.x * 256) cc[i] -= l[i] * u;
+  }
+}
+
+// forward substitution with the row interchanges, then backward substitution; one workgroup
+__global__ void __launch_bounds__(1024)
+    k_lu_solve(const double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, const int32_t *__restrict__ ipiv,
+               double *__restrict__ x) {
+  const int tid = threadIdx.x;
+  for (int64_t j = 0; j < n; j++) {
+    const int km = (int)min((int64_t)kl, n - 1 - j);
+    const int64_t jp = ipiv[j];
+    __syncthreads();
+    if (tid == 0 && jp != j) {
+      const double t = x[jp];
+      x[jp] = x[j];
+      x[j] = t;
+    }
+    __syncthreads();
+    const double xj = x[j];
+    const double *l = ab + kv + ldab * j;
+    for (int i = 1 + tid; i <= km; i += 1024) x[j + i] -= l[i] * xj;
+  }
+  for (int64_t j = n - 1; j >= 0; j--) {
+    __syncthreads();
+    const double *cj = ab + kv + ldab * j;         // cj[-i] = U(j-i, j)
+    if (tid == 0) x[j] = x[j] / cj[0];
+    __syncthreads();
+    const double xj = x[j];
+    const int kk = (int)min((int64_t)kv, j);
+    for (int i = 1 + tid; i <= kk; i += 1024) x[j - i] -= cj[-i] * xj;
+  }
+}
+
+extern "C" int tg_lu_band_info(tg_csr_t k, int *kl_out, int *ku_out, int64_t *bytes_out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(k && kl_out && ku_out && bytes_out, "null argument to tg_lu_band_info");
+  TG_REQUIRE_CANONICAL(k);
+  TG_REQUIRE(k->nrows == k->ncols, "tg_lu_band_info: square matrix expected");
+  int *d = (int *)(g_tg.scratch);
+  TG_CHECK_HIP(hipMemsetAsync(d, 0, 2 * sizeof(int), g_tg.stream));
+  if (k->nrows > 0)
+    hipLaunchKernelGGL(k_lu_bandwidth, dim3((unsigned)tg_cdiv(k->nrows, 256)), dim3(256), 0, g_tg.stream, k->rowptr, k->col,
+                       k->nrows, d, d + 1);
+  TG_LAUNCH_CHECK();
+  int h[2];
+  TG_CHECK_HIP(hipMemcpyAsync(h, d, 2 * sizeof(int), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  *kl_out = h[0];
+  *ku_out = h[1];
+  *bytes_out = (int64_t)(2 * (int64_t)h[0] + h[1] + 1) * k->nrows * (int64_t)sizeof(double);
+  return 0;
+}
+
+// status 0 = solved; info > 0: U(info-1, info-1) is exactly zero (the matrix is singular to working precision)
+extern "C" int tg_lu_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *info) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(k && b && x && info, "null argument to tg_lu_solve");
+  TG_REQUIRE_CANONICAL(k);
+  const int64_t n = k->nrows;
+  TG_REQUIRE(k->ncols == n && b->n == n && x->n == n, "tg_lu_solve: square system with matching vectors expected");
+  *info = 0;
+  if (n == 0) return 0;
+  int kl = 0, ku = 0;
+  int64_t bytes = 0;
+  TG_TRY(tg_lu_band_info(k, &kl, &ku, &bytes));
+  const int kv = kl + ku;
+  const int64_t ldab = 2 * (int64_t)kl + ku + 1;
+  double *ab = nullptr;
+  int32_t *ipiv = nullptr;
+  tg_lu_state *st = nullptr;
+  int rc = tg_dmalloc(&ab, ldab * n);
+  if (!rc) rc = tg_dmalloc(&ipiv, n);
+  if (!rc) rc = tg_dmalloc_bytes((void **)&st, sizeof(tg_lu_state));
+  if (!rc && hipMemsetAsync(ab, 0, (size_t)(ldab * n) * sizeof(double), g_tg.stream) != hipSuccess) rc = 1;
+  if (!rc) {
+    tg_lu_state h0;
+    h0.ju = 0;
+    h0.info = 0;
+    h0.km = 0;
+    h0.jp = 0;
+    h0.pivinv = 0.0;
+    if (hipMemcpyAsync(st, &h0, sizeof(h0), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess) rc = 1;
+    hipStreamSynchronize(g_tg.stream);
+  }
+  if (!rc) {
+    hipLaunchKernelGGL(k_lu_scatter, dim3((unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16)), dim3(256), 0,
+                       g_tg.stream, k->rowptr, k->col, k->val, n, kv, ldab, ab);
+    // trailing window of a column: at most kl rows x kv columns
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(kl, 256), 64));
+    const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)kv, (int64_t)g_tg.num_cu * 8 / gx));
+    for (int64_t j = 0; j < n; j++) {
+      hipLaunchKernelGGL(k_lu_pivot, dim3(1), dim3(256), 0, g_tg.stream, ab, ldab, n, kl, kv, j, ipiv, st);
+      if (kl > 0 && j + 1 < n)
+        hipLaunchKernelGGL(k_lu_update, dim3(gx, gy), dim3(256), 0, g_tg.stream, ab, ldab, kv, j, st);
+    }
+    if (hipGetLastError() != hipSuccess) {
+      tg_set_error("tg_lu_solve: kernel launch failed");
+      rc = 1;
+    }
+  }
+  if (!rc) {
+    tg_lu_state h1;
+    if (hipMemcpyAsync(&h1, st, sizeof(h1), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
+    if (!rc && hipStreamSynchronize(g_tg.stream) != hipSuccess) {
+      tg_set_error("tg_lu_solve: %s", hipGetErrorString(hipGetLastError()));
+      rc = 1;
+    }
+    if (!rc) *info = h1.info;
+  }
+  if (!rc && *info == 0) {
+    if (x->d != b->d &&
+        hipMemcpyAsync(x->d, b->d, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess)
+      rc = 1;
+    hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), 0, g_tg.stream, ab, ldab, n, kl, kv, ipiv, x->d);
+    if (hipGetLastError() != hipSuccess) rc = 1;
+    if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
+    if (rc) tg_set_error("tg_lu_solve: substitution failed");
+  }
+  tg_dfree(ab);
+  tg_dfree(ipiv);
+  tg_dfree(st);
+  return rc;
+}

@@ -497,6 +497,20 @@ def krylov_solve(K, b, x, method="cg", pc="jacobi", rtol=1e-6, atol=1e-15, maxit
     return iters.value, res.value, status.value
 
 
+def lu_band_info(K):
+    """(kl, ku, bytes of the band storage) of a square DeviceCSR"""
+    kl, ku, nb = C.c_int(), C.c_int(), C.c_int64()
+    check(_lib.lib().tg_lu_band_info(K._h, C.byref(kl), C.byref(ku), C.byref(nb)), "tg_lu_band_info")
+    return kl.value, ku.value, nb.value
+
+
+def lu_solve(K, b, x):
+    """x = K^-1 b by banded LU with partial pivoting; returns LAPACK's info (0 = ok, j+1 = exact zero pivot at j)"""
+    info = C.c_int()
+    check(_lib.lib().tg_lu_solve(K._h, b._h, x._h, C.byref(info)), "tg_lu_solve")
+    return info.value
+
+
 # ------------------------------------------------------------------------------- synthetic inputs
 def kron_sum_csr(factors, row0=None, row1=None):
     """A = sum_t kron(F[t][d-1], ..., F[t][0]) (direction 0 fastest).  ``factors[t][k]`` are
