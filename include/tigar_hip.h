@@ -265,6 +265,14 @@ int tg_krylov_solve_flags(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, int pc
                           double atol, int maxit, int restart, int flags, tg_comm_t comm, int *iters,
                           double *resnorm, int *status);
 
+/* generateM for a spline given by element-wise Bezier extraction operators (Rhino T-splines,
+ * tIGAr/RhinoTSplines.py:37-137 + the row loop of tIGAr/common.py:1554-1571): FE row (e, n) holds
+ * N_a = sum_b coef[a][b] * bern[e][n][b] for the functions a of element e (eoff[e] <= a < eoff[e+1], global index
+ * nodes[a] + col_offset, ascending per element), entries with abs(v) <= eps dropped. */
+int tg_extract_csr_bezier(int64_t nel, int nloc, int nbern, const double *bern, const int64_t *eoff,
+                          const int32_t *nodes, const double *coef, int32_t col_offset, int64_t ncols, double eps,
+                          tg_csr_t *out);
+
 /* ---- direct solve: what solveLinearSystem runs when linearSolver is None (dolfin solve() = sparse LU [ext],
  * tIGAr/common.py:1255-1256).  Banded LU with partial pivoting in LAPACK's dgbtrf storage / pivoting scheme. */
 /* half-bandwidths of a square matrix and the bytes its band storage (2*kl+ku+1 rows) would take */

@@ -96,6 +96,8 @@ PROTOTYPES = {
                                           C.c_int64, handle, C.c_int64, handle]),
     "tg_extract_csr_points": (C.c_int, [C.c_int, C.POINTER(tg_dir_t), C.c_int32, C.c_int64,
                                         C.c_double, c_f64p, C.c_int64, C.POINTER(handle)]),
+    "tg_extract_csr_bezier": (C.c_int, [C.c_int64, C.c_int, C.c_int, c_f64p, c_i64p, c_i32p, c_f64p, C.c_int32, C.c_int64,
+                                        C.c_double, C.POINTER(handle)]),
     "tg_csr_vstack": (C.c_int, [C.c_int, C.POINTER(handle), C.POINTER(handle)]),
     "tg_csr_builder_create": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(handle)]),
     "tg_csr_vstack_view": (C.c_int, [C.c_int, C.POINTER(handle), C.POINTER(handle)]),

@@ -437,6 +437,9 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
                 if lazy is not None:
                     return lazy
             return _dev.extract_csr_tensor(basis.splines, grid.axes, col_offset, ncols, eps)
+        if hasattr(basis, "extractBlockOnDevice") and type(self).getNodesAndEvals is AbstractMultiFieldSpline.getNodesAndEvals:
+            # bases that bring their own batched device evaluation (Rhino T-splines: csrc/tg_bezier.hip)
+            return basis.extractBlockOnDevice(grid, col_offset, ncols, eps)
         from .BSplines import MultiBSpline
         if isinstance(basis, MultiBSpline) and isinstance(grid, MultiPatchNodeGrid):
             # patch by patch with the tensor kernel; rows stack, columns shift by the patch offsets

@@ -332,6 +332,20 @@ def extract_csr_points(splines1d, x, col_offset, ncols, eps):
     return DeviceCSR(h)
 
 
+def extract_csr_bezier(bern, eoff, nodes, coef, col_offset, ncols, eps):
+    """Extraction rows of a spline given by element-wise Bezier extraction operators (``tg_extract_csr_bezier``):
+    ``bern[e, n, b]`` Bernstein values at FE node n of element e, ``eoff`` offsets of the elements in ``nodes`` (global
+    function indices, ascending per element) and ``coef`` (their extraction rows)."""
+    bern, coef = _f64(bern), _f64(coef)
+    nel, nloc, nbern = bern.shape
+    eoff, nodes = _i64(eoff), _i32(nodes)
+    h = handle()
+    check(_lib.lib().tg_extract_csr_bezier(int(nel), int(nloc), int(nbern), _p(bern, c_f64p), _p(eoff, c_i64p),
+                                           _p(nodes, c_i32p), _p(coef, c_f64p), int(col_offset), int(ncols), float(eps),
+                                           C.byref(h)), "tg_extract_csr_bezier")
+    return DeviceCSR(h)
+
+
 def csr_vstack(blocks):
     arr = (handle * len(blocks))(*[b._h for b in blocks])
     h = handle()

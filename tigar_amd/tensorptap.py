@@ -26,50 +26,37 @@ def local_weights(M1, p, nel):
     nfe, ncp = M1.shape
     if nfe != p * nel + 1 or ncp != nel + p:
         return None
+    a = np.repeat(np.arange(nfe), np.diff(M1.indptr))
+    c, v = M1.indices.astype(np.int64), M1.data
+    keep = v != 0.0
+    a, c, v = a[keep], c[keep], v[keep]
     wl = np.zeros((nel, p + 1, p + 1))
-    rows = np.repeat(np.arange(nfe), np.diff(M1.indptr))
-    cols, vals = M1.indices, M1.data
-    for (a, c, v) in zip(rows, cols, vals):
-        if v == 0.0:
-            continue
-        homes = []                         # (element, local node) pairs this node belongs to
-        if a % p == 0:
-            if a > 0:
-                homes.append((a // p - 1, p))
-            if a < nfe - 1:
-                homes.append((a // p, 0))
-        else:
-            homes.append((a // p, a % p))
-        for (e, j) in homes:
-            q = c - e
-            if q < 0 or q > p:
-                return None
-            wl[e, j, q] = v
+    vertex = (a % p) == 0
+    # every node belongs to element a // p as local node a % p (not the last node) ...
+    m1 = a < nfe - 1
+    e1, j1 = a[m1] // p, a[m1] % p
+    q1 = c[m1] - e1
+    # ... and a vertex node (but the first) also to the element before it, as its local node p
+    m2 = vertex & (a > 0)
+    e2 = a[m2] // p - 1
+    q2 = c[m2] - e2
+    if np.any(q1 < 0) or np.any(q1 > p) or np.any(q2 < 0) or np.any(q2 > p):
+        return None
+    wl[e1, j1, q1] = v[m1]
+    wl[e2, p, q2] = v[m2]
     return wl
 
 
 def band_pattern_ok(M1, p, nel):
     """structural pattern of the 1-D K (= M1^T pattern(A1) M1 as PETSc's symbolic product sees it) is the
-    full band |i - i'| <= p clipped to the matrix"""
-    import scipy.sparse as sp
-    nfe, ncp = M1.shape
-    rows, cols = [], []
-    for e in range(nel):
-        idx = np.arange(p * e, p * e + p + 1)
-        rows.append(np.repeat(idx, p + 1))
-        cols.append(np.tile(idx, p + 1))
-    A1 = sp.csr_matrix((np.ones(sum(len(r) for r in rows)), (np.concatenate(rows), np.concatenate(cols))),
-                       shape=(nfe, nfe))
-    Mp = (abs(M1) > 0).astype(np.float64)
-    K1 = (Mp.T @ A1 @ Mp).tocsr()
-    K1.sort_indices()
-    K1.eliminate_zeros()
-    for i in range(ncp):
-        lo, hi = max(0, i - p), min(ncp - 1, i + p)
-        c = K1.indices[K1.indptr[i]:K1.indptr[i + 1]]
-        if len(c) != hi - lo + 1 or c[0] != lo or c[-1] != hi:
-            return False
-    return True
+    full band |i - i'| <= p clipped to the matrix: with every stored column of element e's nodes inside
+    [e, e+p] (``local_weights``) the band cannot be exceeded, and it is full iff every pair of functions
+    (e+q, e+q') is stored at some node of element e, for every e."""
+    wl = local_weights(M1, p, nel)
+    if wl is None:
+        return False
+    present = (wl != 0.0).any(axis=1)                 # [nel, p+1]: function e+q is stored at some node of element e
+    return bool(present.all())
 
 
 class TensorPlanes(object):
