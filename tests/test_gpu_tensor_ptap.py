@@ -130,3 +130,20 @@ def test_streamed_sub_slabs_with_tensor_ring_match_resident():
     Ko = O.extract_matrix(O.generate_M_tensor(s), As, zd)
     assert np.array_equal(K.indices, Ko.indices)
     assert np.max(np.abs(K.data - Ko.data)) <= 1e-12 * np.max(np.abs(Ko.data))
+
+
+def test_general_kernels_run_to_run_spread_is_bounded(monkeypatch):
+    """The general PtAP kernels (other patterns, p = 4, 2-D) accumulate K with LDS floating-point atomics, so their
+    last bits may differ from run to run; the spread stays within a few ulp * sqrt(terms) of the row scale.  (The
+    tensor-pattern path is bit-reproducible, see above; TIGAR_PTAP_TENSOR=0 selects the general kernels.)"""
+    monkeypatch.setenv("TIGAR_PTAP_TENSOR", "0")
+    p, nels = 3, (6, 5, 7)
+    gen, spline = _patch(p, nels)
+    A = _random_fe_matrix(p, nels, seed=21)
+    runs = [spline.extractMatrix(A).to_scipy() for _ in range(4)]
+    ref = runs[0]
+    terms = (3 * p + 1) ** 3 * (p + 1) ** 3            # products that can meet in one entry of K
+    scale = np.max(np.abs(ref.data))
+    for K in runs[1:]:
+        assert np.array_equal(K.indices, ref.indices)
+        assert np.max(np.abs(K.data - ref.data)) <= 4 * 2.3e-16 * np.sqrt(terms) * scale

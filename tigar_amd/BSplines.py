@@ -142,6 +142,12 @@ class BSpline1(object):
         return numpy.append(x[:, :-1].reshape(-1), uk[-1])
 
 
+class _IndexList(list):
+    """a list of dof indices that keeps the numpy array it came from (``.array``); any mutation through the list
+    interface is not tracked, so consumers compare lengths before trusting the array"""
+    array = None
+
+
 def ij2dof(i, j, M):
     return j * M + i
 
@@ -248,35 +254,39 @@ class BSpline(AbstractScalarBasis):
             nel *= s.nel
         return nel
 
-    def getSideDofs(self, direction, side, nLayers=1):
-        """DoFs on a ``side`` (0 or 1) perpendicular to ``direction``; ``nLayers`` layers of
-        control points.  Same ordering as tIGAr/BSplines.py:599-649 (corners repeat when
-        several sides are concatenated)."""
+    def getSideDofsArray(self, direction, side, nLayers=1):
+        """``getSideDofs`` as one int64 array (same order)."""
         offsetSign = 1 - 2 * side
         ncps = [s.getNcp() for s in self.splines]
-        retval = []
+        ar = numpy.arange
+        parts = []
         for absOffset in range(0, nLayers):
             i = (0 if side == 0 else ncps[direction] - 1) + absOffset * offsetSign
             if self.nvar == 1:
-                retval += [i]
+                parts.append(numpy.array([i], dtype=numpy.int64))
             elif self.nvar == 2:
                 M, N = ncps
-                if direction == 0:
-                    retval += [ij2dof(i, j, M) for j in range(N)]
-                elif direction == 1:
-                    retval += [ij2dof(j, i, M) for j in range(M)]
+                parts.append(i + M * ar(N, dtype=numpy.int64) if direction == 0 else ar(M, dtype=numpy.int64) + M * i)
             else:
                 M, N, O = ncps
-                if direction == 0:
-                    retval += (i + M * numpy.arange(N)[:, None] + M * N * numpy.arange(O)[None, :]) \
-                        .reshape(-1).tolist()
+                if direction == 0:          # (j outer, k inner: tIGAr/BSplines.py:627-630)
+                    blk = i + M * ar(N, dtype=numpy.int64)[:, None] + M * N * ar(O, dtype=numpy.int64)[None, :]
                 elif direction == 1:
-                    retval += (numpy.arange(M)[:, None] + M * i + M * N * numpy.arange(O)[None, :]) \
-                        .reshape(-1).tolist()
-                elif direction == 2:
-                    retval += (numpy.arange(M)[:, None] + M * numpy.arange(N)[None, :] + M * N * i) \
-                        .reshape(-1).tolist()
-        return retval
+                    blk = ar(M, dtype=numpy.int64)[:, None] + M * i + M * N * ar(O, dtype=numpy.int64)[None, :]
+                else:
+                    blk = ar(M, dtype=numpy.int64)[:, None] + M * ar(N, dtype=numpy.int64)[None, :] + M * N * i
+                parts.append(blk.reshape(-1))
+        return numpy.concatenate(parts) if parts else numpy.zeros(0, dtype=numpy.int64)
+
+    def getSideDofs(self, direction, side, nLayers=1):
+        """DoFs on a ``side`` (0 or 1) perpendicular to ``direction``; ``nLayers`` layers of
+        control points.  Same ordering as tIGAr/BSplines.py:599-649 (corners repeat when
+        several sides are concatenated).  A plain list, as in the reference; it remembers the array it
+        was made from so that ``addZeroDofs`` need not convert 10^5 Python ints back."""
+        arr = self.getSideDofsArray(direction, side, nLayers)
+        out = _IndexList(arr.tolist())
+        out.array = arr
+        return out
 
 
 class MultiBSpline(AbstractScalarBasis):

@@ -271,12 +271,41 @@ class AbstractExtractionGenerator(object):
         total = sum(self.getNcp(i) for i in range(self.getNFields()))
         return generateIdentityPermutation((0, total), self.comm)
 
+    # ``zeroDofs`` is a plain Python list in the reference (tIGAr/common.py:254-282; user code appends to it).  Large
+    # index sets (6 faces x 259^2 at cfg3) are kept as numpy chunks behind it: the list is only materialised when
+    # somebody reads the attribute, the path itself takes ``zeroDofsArray()``.
+    @property
+    def zeroDofs(self):
+        chunks = self.__dict__.get("_zero_chunks", [])
+        if chunks:
+            self.__dict__["_zero_list"] = self.__dict__.get("_zero_list", []) + numpy.concatenate(chunks).tolist()
+            self.__dict__["_zero_chunks"] = []
+        return self.__dict__.setdefault("_zero_list", [])
+
+    @zeroDofs.setter
+    def zeroDofs(self, value):
+        self.__dict__["_zero_list"] = list(value)
+        self.__dict__["_zero_chunks"] = []
+
+    def zeroDofsArray(self):
+        """all zero dofs so far, in insertion order (duplicates kept), as one int64 array"""
+        parts = [numpy.asarray(self.__dict__.get("_zero_list", []), dtype=numpy.int64)] + \
+            self.__dict__.get("_zero_chunks", [])
+        return numpy.concatenate(parts) if len(parts) > 1 else parts[0]
+
+    @staticmethod
+    def _index_array(dofs):
+        src = getattr(dofs, "array", None)
+        if src is not None and len(src) == len(dofs):       # a list made by getSideDofs, untouched since
+            return src
+        return numpy.asarray(dofs, dtype=numpy.int64).reshape(-1)
+
     def addZeroDofsGlobal(self, newDofs):
-        self.zeroDofs += list(newDofs)
+        self.__dict__.setdefault("_zero_chunks", []).append(numpy.array(self._index_array(newDofs), dtype=numpy.int64))
 
     def addZeroDofs(self, field, newDofs):
         off = self.globalDof(field, 0)
-        self.addZeroDofsGlobal((numpy.asarray(newDofs, dtype=numpy.int64) + off).tolist())
+        self.__dict__.setdefault("_zero_chunks", []).append(self._index_array(newDofs) + off)
 
     def getPrealloc(self, control):
         return DEFAULT_PREALLOC
@@ -922,7 +951,7 @@ class ExtractedSpline(object):
         self.comm = generator.getComm()
         self._generator_engine = getattr(generator, "_slab_engine", None)
         self._kron = getattr(generator, "_kron", None)
-        self.zeroDofs = numpy.asarray(generator.zeroDofs, dtype=INDEX_TYPE)
+        self.zeroDofs = generator.zeroDofsArray().astype(INDEX_TYPE)
 
     def genericSetup(self):
         self.setSolverOptions()
