@@ -300,6 +300,12 @@ int tg_kron_sum_csr(int d, int nterms, const tg_kron_dir_t *dirs, int64_t row0,
 int tg_kron_csr_rect(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0,
                      int64_t row1, int filter, double eps, int64_t col_offset, int64_t ncols_total,
                      tg_csr_t *out);
+/* generateM / its transpose for a tensor-product B-spline whose abs(v) > eps filter drops nothing but exact zeros
+ * (the caller checks that on the 1-D tables): out = F[2] (x) F[1] (x) F[0] restricted to rows [row0,row1), values
+ * (v0*v1)*v2 in the reference's order (tIGAr/BSplines.py:450-503), written by a pencil walk with closed-form row
+ * starts (no count pass, no scan); cdim[k] = columns of direction k; columns shifted by col_offset. */
+int tg_kron3_csr(int d, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0, int64_t row1,
+                 int64_t col_offset, int64_t ncols_total, tg_csr_t *out);
 
 /* One 1-D sparse factor F (nout_k rows, CSR on the host, columns in [col_shift, col_shift+dims_in[k]))
  * applied along direction k of a tensor-indexed vector (direction 0 fastest):

@@ -143,6 +143,8 @@ PROTOTYPES = {
                                   C.POINTER(handle)]),
     "tg_kron_csr_rect": (C.c_int, [C.c_int, C.c_int, C.POINTER(tg_kron_dir_t), c_i64p, C.c_int64, C.c_int64,
                                    C.c_int, C.c_double, C.c_int64, C.c_int64, C.POINTER(handle)]),
+    "tg_kron3_csr": (C.c_int, [C.c_int, C.POINTER(tg_kron_dir_t), c_i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                               C.POINTER(handle)]),
     "tg_vec_pointwise_mult": (C.c_int, [handle, handle, handle]),
     "tg_csr_combine": (C.c_int, [C.c_double, handle, C.c_double, handle, handle, C.POINTER(handle)]),
     "tg_tensor_apply_1d": (C.c_int, [C.c_int, c_i64p, C.c_int, C.c_int64, c_i32p, c_i32p, c_f64p, C.c_int64, handle, handle]),

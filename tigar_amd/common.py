@@ -355,10 +355,9 @@ class AbstractExtractionGenerator(object):
             self._kron = self.M.kx
         elif self.getNFields() == 1 and (0, 0) in self._fast_blocks or (self.M is self.M_control
                                                                           and (-1, 0) in self._fast_blocks):
-            from .kronptap import KronExtraction
             basis, grid = self._fast_blocks.get((0, 0), self._fast_blocks.get((-1, 0)))
-            kx = KronExtraction(basis, grid)
-            if kx.is_exact_for(self.M.nnz, self.getIgnoreEps()):
+            kx = self._kron_tables(basis, grid)
+            if kx is not None and kx.is_exact_for(self.M.nnz, self.getIgnoreEps()):
                 self._kron = kx
         self.cpFuncs = []
         cm = self.getControlMesh() if hasattr(self, "getControlMesh") else None
@@ -371,13 +370,19 @@ class AbstractExtractionGenerator(object):
             kx = self.M_control.kx
             self._slab_engine = SlabHotPath(kx.basis, kx.grid, self.comm.rank, self.comm.size, self.comm.device(),
                                             sub_planes="auto", eps=self.M_control.eps, kx=kx)
-        separable = (getattr(self.M_control, "is_implicit", False) and cm is not None
-                     and hasattr(cm, "homogeneousCoordinateFactors"))
+        # M_control a Kronecker product (implicit, or stored and checked entry count against the product of the
+        # 1-D counts) and the control net a tensor product of 1-D factors: so is every control function
+        kx_c = None
+        if cm is not None and hasattr(cm, "homogeneousCoordinateFactors"):
+            if getattr(self.M_control, "is_implicit", False):
+                kx_c = self.M_control.kx
+            elif self._kron is not None and self.M is self.M_control:
+                kx_c = self._kron
+        separable = kx_c is not None
         for i in range(self.nsd + 1):
             if separable:
-                # M_control and the control net are both tensor products: so is the control function,
                 # (M_z g_z) (x) (M_y g_y) (x) (M_x g_x) -- one write pass over the FE rows this rank owns
-                kx = self.M_control.kx
+                kx = kx_c
                 facs = cm.homogeneousCoordinateFactors(i)
                 fe1d = [kx.M1[k] @ numpy.asarray(facs[k], dtype=numpy.float64) for k in range(kx.d)]
                 rng = self._slab_engine.mine["u_rows"] if self._slab_engine is not None else None
@@ -465,6 +470,12 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
                 lazy = self._implicit_block(basis, grid, eps)
                 if lazy is not None:
                     return lazy
+            # exact Kronecker form (every product of stored 1-D entries passes the filter, checked on the 1-D
+            # tables; no periodic wrap): pencil walk with closed-form row starts, same entries bit for bit
+            kx = self._kron_tables(basis, grid)
+            if kx is not None and kx.products_stay_above(eps) and kx.columns_ascending() \
+                    and os.environ.get("TIGAR_EXTRACT_KRON", "1") != "0":
+                return _dev.kron3_csr(kx.M1, None, None, col_offset, ncols)
             return _dev.extract_csr_tensor(basis.splines, grid.axes, col_offset, ncols, eps)
         if hasattr(basis, "extractBlockOnDevice") and type(self).getNodesAndEvals is AbstractMultiFieldSpline.getNodesAndEvals:
             # bases that bring their own batched device evaluation (Rhino T-splines: csrc/tg_bezier.hip)
@@ -489,6 +500,18 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
         """one unknown field on the control mesh's own basis: M is M_control"""
         return False
 
+    def _kron_tables(self, basis, grid):
+        """1-D extraction tables of a tensor basis on its grid (``KronExtraction``), built once per (basis, grid)"""
+        cache = self.__dict__.setdefault("_kx_cache", {})
+        key = (id(basis), id(grid))
+        if key not in cache:
+            from .kronptap import KronExtraction
+            try:
+                cache[key] = (KronExtraction(basis, grid), basis, grid)     # (the objects are kept alive with the key)
+            except Exception:
+                cache[key] = (None, basis, grid)
+        return cache[key][0]
+
     def _implicit_block(self, basis, grid, eps):
         """``ImplicitExtraction`` in place of the CSR block when M (and M^T) would not fit beside the rest of
         the path -- 24 B per entry against a third of the free HBM -- or when the patch is spread over several
@@ -500,8 +523,8 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
         env = os.environ.get("TIGAR_IMPLICIT_M")
         if env == "0":
             return None
-        kx = KronExtraction(basis, grid)
-        if not kx.products_stay_above(eps):
+        kx = self._kron_tables(basis, grid)
+        if kx is None or not kx.products_stay_above(eps):
             return None
         if env != "1" and self.comm.size == 1:
             free_b = _dev.mem_info()[0] + _dev.pool_stats()[0]      # idle blocks of the caching allocator count as free
@@ -522,9 +545,15 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
         nf = self.getNFields()
         if getattr(self.M, "is_implicit", False):
             return self.M.transpose()
+        def transposed_block(basis, grid, fe_offset, fe_total):
+            kx = self._kron_tables(basis, grid)
+            if kx is not None and kx.products_stay_above(self.getIgnoreEps()) and kx.columns_ascending() \
+                    and os.environ.get("TIGAR_EXTRACT_KRON", "1") != "0":
+                return _dev.kron3_csr(kx.M1T, None, None, fe_offset, fe_total)
+            return _dev.extract_csr_tensor_t(basis.splines, grid.axes, fe_offset, fe_total, self.getIgnoreEps())
         if self.M is self.M_control and (-1, 0) in self._fast_blocks:
             basis, grid = self._fast_blocks[(-1, 0)]
-            return _dev.extract_csr_tensor_t(basis.splines, grid.axes, 0, grid.num_nodes(), self.getIgnoreEps())
+            return transposed_block(basis, grid, 0, grid.num_nodes())
         blocks = []
         offset = 0
         fe_total = self.V.dim()
@@ -533,8 +562,7 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
             if key not in self._fast_blocks:
                 return self.M.transpose()
             basis, grid = self._fast_blocks[key]
-            blocks.append(_dev.extract_csr_tensor_t(basis.splines, grid.axes, self.V.field_offset(field), fe_total,
-                                                    self.getIgnoreEps()))
+            blocks.append(transposed_block(basis, grid, self.V.field_offset(field), fe_total))
             offset += self.getNcp(field)
         return blocks[0] if len(blocks) == 1 else _dev.csr_vstack(blocks)
 

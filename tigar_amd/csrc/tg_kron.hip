@@ -469,3 +469,194 @@ extern "C" int tg_tensor_apply_1d(int d, const int64_t *dims_in, int k, int64_t 
   tg_dfree(dfv);
   return rc;
 }
+
+// ----------------------------------------------------------------------------------------
+// generateM for a tensor-product B-spline whose filter drops nothing but exact zeros (checked by the caller on the
+// 1-D tables): M = M_2 (x) M_1 (x) M_0 entry by entry, values (v0*v1)*v2 in the reference's order
+// (tIGAr/BSplines.py:450-503), and equally M^T from the transposed 1-D factors.  "Pencil walk": the rows of a pencil
+// (fixed (b, c), a running) are consecutive in the output and their entries contiguous, row a holding n0(a) * n12
+// entries in (k, j, i) order.  A lane owns one (j, k) combination of one pencil -- its value v1*v2-free prefix (the
+// reference multiplies left to right, so v1 and v2 are applied per entry), its column offset and its rank among the
+// pencil's combinations -- walks a, and writes the n0(a) consecutive (col, val) pairs of its combination; the lanes
+// of a pencil cover a row contiguously and consecutive rows follow each other: pure streaming stores.  Row starts
+// follow in closed form from three 1-D prefix sums: no count pass, no scan.
+struct tg_kron3_args {
+  int d;
+  int64_t n[3];                  // rows per direction
+  const int32_t *rp[3];          // 1-D CSR row pointers (device)
+  const int32_t *ci[3];
+  const double *cv[3];
+  const int64_t *ps[3];          // exclusive prefix sums of the 1-D row lengths (n[k] + 1 entries)
+  int64_t cstride[3];
+  int64_t col_offset;
+  int64_t row0, nrows;           // output rows [row0, row0 + nrows)
+  int64_t out0;                  // entry index of row row0 in the closed form (subtracted)
+  int slot;                      // lanes reserved per pencil: max n1 * max n2
+  int L;                         // pencils per wave
+  int64_t npencils;
+};
+
+__device__ __forceinline__ int64_t tg_kron3_rowstart(const tg_kron3_args &A, int64_t a, int64_t b, int64_t c) {
+  // entries before row (a, b, c): separable prefix sums of n0 * n1 * n2
+  const int64_t t0 = A.ps[0][A.n[0]];
+  if (A.d == 1) return A.ps[0][a];
+  const int64_t n1 = A.ps[1][b + 1] - A.ps[1][b];
+  if (A.d == 2) return t0 * A.ps[1][b] + n1 * A.ps[0][a];
+  const int64_t t1 = A.ps[1][A.n[1]];
+  const int64_t n2 = A.ps[2][c + 1] - A.ps[2][c];
+  return t0 * t1 * A.ps[2][c] + n2 * (t0 * A.ps[1][b] + n1 * A.ps[0][a]);
+}
+
+__global__ void __launch_bounds__(64) k_kron3_rowptr(tg_kron3_args A, int64_t *__restrict__ rowptr) {
+  const int64_t lr = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (lr > A.nrows) return;
+  const int64_t r = A.row0 + lr;
+  const int64_t total = A.n[0] * A.n[1] * A.n[2];
+  if (r >= total) {            // (only lr == nrows at the very end of the matrix)
+    rowptr[lr] = A.ps[0][A.n[0]] * (A.d > 1 ? A.ps[1][A.n[1]] : 1) * (A.d > 2 ? A.ps[2][A.n[2]] : 1) - A.out0;
+    return;
+  }
+  const int64_t a = r % A.n[0], bc = r / A.n[0];
+  const int64_t b = A.d > 1 ? bc % A.n[1] : 0, c = A.d > 2 ? bc / A.n[1] : 0;
+  rowptr[lr] = tg_kron3_rowstart(A, a, b, c) - A.out0;
+}
+
+__global__ void __launch_bounds__(64)
+    k_kron3_fill(tg_kron3_args A, int32_t *__restrict__ col, double *__restrict__ val) {
+  const int lane = threadIdx.x;
+  const int sub = lane / A.slot, l = lane - sub * A.slot;
+  // pencils intersecting the row range: first pencil = row0 / n0
+  const int64_t pencil = A.row0 / A.n[0] + (int64_t)blockIdx.x * A.L + sub;
+  if (sub >= A.L || pencil >= A.npencils) return;
+  const int64_t b = A.d > 1 ? pencil % A.n[1] : 0, c = A.d > 2 ? pencil / A.n[1] : 0;
+  const int y0 = A.d > 1 ? A.rp[1][b] : 0, n1 = A.d > 1 ? A.rp[1][b + 1] - y0 : 1;
+  const int z0 = A.d > 2 ? A.rp[2][c] : 0, n2 = A.d > 2 ? A.rp[2][c + 1] - z0 : 1;
+  const int64_t n12 = (int64_t)n1 * n2;
+  const int64_t g0 = A.n[0] * pencil;              // global row of a = 0
+  const int64_t a_lo = max((int64_t)0, A.row0 - g0), a_hi = min(A.n[0], A.row0 + A.nrows - g0);
+  if (a_hi <= a_lo) return;
+  const int64_t base = tg_kron3_rowstart(A, 0, b, c) - A.out0;   // entry index of row (0, b, c)
+  // (rows with more than 64 combinations -- transposed factors at p = 3 -- take several passes of the lanes)
+  for (int lc = l; lc < n12; lc += A.slot) {
+    const int k = lc / n1, j = lc - k * n1;        // rank lc = k * n1 + j: (k, j) order = column order
+    const double v1 = A.d > 1 ? A.cv[1][y0 + j] : 1.0, v2 = A.d > 2 ? A.cv[2][z0 + k] : 1.0;
+    int64_t cjk = A.col_offset;
+    if (A.d > 1) cjk += A.cstride[1] * (int64_t)A.ci[1][y0 + j];
+    if (A.d > 2) cjk += A.cstride[2] * (int64_t)A.ci[2][z0 + k];
+    for (int64_t a = a_lo; a < a_hi; a++) {
+      const int x0 = A.rp[0][a], n0 = A.rp[0][a + 1] - x0;
+      const int64_t pos = base + n12 * A.ps[0][a] + (int64_t)lc * n0;
+      for (int i = 0; i < n0; i++) {
+        double v = A.cv[0][x0 + i];                // (v0 * v1) * v2, left to right as the reference multiplies
+        if (A.d > 1) v = v * v1;
+        if (A.d > 2) v = v * v2;
+        col[pos + i] = (int32_t)(A.ci[0][x0 + i] + cjk);
+        val[pos + i] = v;
+      }
+    }
+  }
+}
+
+extern "C" int tg_kron3_csr(int d, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0, int64_t row1,
+                            int64_t col_offset, int64_t ncols_total, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(d >= 1 && d <= 3 && dirs && cdim && out, "bad arguments to tg_kron3_csr");
+  tg_kron3_args A;
+  memset(&A, 0, sizeof(A));
+  A.d = d;
+  A.col_offset = col_offset;
+  int64_t total = 1, ctotal = 1;
+  std::vector<std::vector<int64_t>> hps(3);
+  int maxn[3] = {1, 1, 1};
+  void *dev[12] = {nullptr};
+  int rc = 0;
+  for (int k = 0; k < 3; k++) A.n[k] = 1;
+  for (int k = 0; k < d && !rc; k++) {
+    const tg_kron_dir_t &D = dirs[k];
+    TG_REQUIRE(D.n >= 1 && D.rowptr && D.col && D.val, "bad 1-D factor %d", k);
+    const int64_t nnz1 = D.rowptr[D.n];
+    A.n[k] = D.n;
+    total *= D.n;
+    A.cstride[k] = ctotal;
+    ctotal *= cdim[k];
+    hps[k].assign((size_t)D.n + 1, 0);
+    for (int64_t r = 0; r < D.n; r++) {
+      const int len = D.rowptr[r + 1] - D.rowptr[r];
+      hps[k][(size_t)r + 1] = hps[k][(size_t)r] + len;
+      maxn[k] = std::max(maxn[k], len);
+      for (int q = D.rowptr[r] + 1; q < D.rowptr[r + 1]; q++)
+        TG_REQUIRE(D.col[q] > D.col[q - 1], "tg_kron3_csr: 1-D factor %d row %lld is not in ascending column order", k,
+                   (long long)r);
+    }
+    int32_t *rp = nullptr, *cl = nullptr;
+    double *vl = nullptr;
+    int64_t *ps = nullptr;
+    rc = tg_dmalloc(&rp, D.n + 1) || tg_dmalloc(&cl, nnz1) || tg_dmalloc(&vl, nnz1) || tg_dmalloc(&ps, D.n + 1);
+    dev[4 * k] = rp;
+    dev[4 * k + 1] = cl;
+    dev[4 * k + 2] = vl;
+    dev[4 * k + 3] = ps;
+    if (rc) break;
+    hipMemcpyAsync(rp, D.rowptr, (size_t)(D.n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+    if (nnz1) {
+      hipMemcpyAsync(cl, D.col, (size_t)nnz1 * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+      hipMemcpyAsync(vl, D.val, (size_t)nnz1 * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
+    }
+    hipMemcpyAsync(ps, hps[k].data(), (size_t)(D.n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream);
+    A.rp[k] = rp;
+    A.ci[k] = cl;
+    A.cv[k] = vl;
+    A.ps[k] = ps;
+  }
+  tg_csr_s *m = nullptr;
+  if (!rc) {
+    if (ctotal > ncols_total - col_offset || row0 < 0 || row1 < row0 || row1 > total) {
+      tg_set_error("tg_kron3_csr: bad row range / column space");
+      rc = 2;
+    }
+  }
+  if (!rc) {
+    auto rowstart = [&](int64_t r) -> int64_t {
+      if (r >= total) return hps[0][(size_t)A.n[0]] * (d > 1 ? hps[1][(size_t)A.n[1]] : 1) * (d > 2 ? hps[2][(size_t)A.n[2]] : 1);
+      const int64_t a = r % A.n[0], bc = r / A.n[0];
+      const int64_t b = d > 1 ? bc % A.n[1] : 0, c = d > 2 ? bc / A.n[1] : 0;
+      const int64_t t0 = hps[0][(size_t)A.n[0]];
+      if (d == 1) return hps[0][(size_t)a];
+      const int64_t n1 = hps[1][(size_t)b + 1] - hps[1][(size_t)b];
+      if (d == 2) return t0 * hps[1][(size_t)b] + n1 * hps[0][(size_t)a];
+      const int64_t t1 = hps[1][(size_t)A.n[1]], n2 = hps[2][(size_t)c + 1] - hps[2][(size_t)c];
+      return t0 * t1 * hps[2][(size_t)c] + n2 * (t0 * hps[1][(size_t)b] + n1 * hps[0][(size_t)a]);
+    };
+    A.row0 = row0;
+    A.nrows = row1 - row0;
+    A.out0 = rowstart(row0);
+    const int64_t nnz = rowstart(row1) - A.out0;
+    A.slot = std::min(64, maxn[1] * maxn[2]);
+    A.L = std::max(1, 64 / A.slot);
+    A.npencils = total / A.n[0];
+    rc = tg_csr_alloc(A.nrows, ncols_total, nnz, &m);
+    if (!rc && A.nrows > 0) {
+      hipLaunchKernelGGL(k_kron3_rowptr, dim3((unsigned)tg_cdiv(A.nrows + 1, 64)), dim3(64), 0, g_tg.stream, A, m->rowptr);
+      const int64_t p_first = row0 / A.n[0], p_last = (row1 - 1) / A.n[0];
+      hipLaunchKernelGGL(k_kron3_fill, dim3((unsigned)tg_cdiv(p_last - p_first + 1, A.L)), dim3(64), 0, g_tg.stream, A,
+                         m->col, m->val);
+      if (hipGetLastError() != hipSuccess) {
+        tg_set_error("tg_kron3_csr: kernel launch failed");
+        rc = 1;
+      }
+    } else if (!rc) {
+      const int64_t zero = 0;
+      hipMemcpyAsync(m->rowptr, &zero, sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream);
+    }
+    // (the host tables above are read by the copies: wait before they go out of scope)
+    hipStreamSynchronize(g_tg.stream);
+  } else
+    hipStreamSynchronize(g_tg.stream);
+  for (int i = 0; i < 12; i++) tg_dfree(dev[i]);
+  if (rc) {
+    if (m) tg_csr_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return 0;
+}

@@ -593,6 +593,37 @@ def kron_csr_rect(factors, row0=None, row1=None):
     return DeviceCSR(h)
 
 
+def kron3_csr(factors, row0=None, row1=None, col_offset=0, ncols_total=None):
+    """kron(F[d-1], ..., F[0]) (direction 0 fastest) of rectangular scipy CSR 1-D factors WITHOUT explicit zeros, rows
+    [row0,row1), values (v0*v1)*v2: the extraction matrix of a tensor B-spline (or its transpose, from the transposed
+    factors) when the filter of generateM drops only exact zeros (``tg_kron3_csr``, pencil walk)."""
+    import scipy.sparse as sp
+    d = len(factors)
+    arr = (tg_kron_dir_t * d)()
+    keep = []
+    total, ctotal = 1, 1
+    cdim = np.empty(d, dtype=np.int64)
+    for k in range(d):
+        F = sp.csr_matrix(factors[k])
+        F.sort_indices()
+        rp, cl, vl = _i32(F.indptr), _i32(F.indices), _f64(F.data)
+        keep += [rp, cl, vl]
+        arr[k].n = F.shape[0]
+        arr[k].rowptr = _p(rp, c_i32p)
+        arr[k].col = _p(cl, c_i32p)
+        arr[k].val = _p(vl, c_f64p)
+        total *= F.shape[0]
+        ctotal *= F.shape[1]
+        cdim[k] = F.shape[1]
+    row0 = 0 if row0 is None else int(row0)
+    row1 = total if row1 is None else int(row1)
+    h = handle()
+    check(_lib.lib().tg_kron3_csr(d, arr, _p(cdim, c_i64p), row0, row1, int(col_offset),
+                                  int(ncols_total if ncols_total is not None else ctotal + col_offset), C.byref(h)),
+          "tg_kron3_csr")
+    return DeviceCSR(h)
+
+
 def _patch(vertices, p, cp, nq):
     d = len(vertices)
     pt = tg_patch_t()

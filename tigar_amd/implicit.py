@@ -95,6 +95,9 @@ class ImplicitExtraction(object):
     # ---- materialisation ---------------------------------------------------------------------------
     def rows(self, r0, r1):
         """Rows [r0, r1) as a ``DeviceCSR`` (global columns): the extraction kernels on a row range."""
+        if self.kx.columns_ascending():
+            # (an implicit operator is an exact Kronecker product by construction: pencil walk, closed-form row starts)
+            return _dev.kron3_csr(self.kx.M1T if self.transposed else self.kx.M1, r0, r1, 0, self._shape[1])
         sp1, axes = self.kx.basis.splines, self.kx.grid.axes
         if self.transposed:
             return _dev.extract_csr_tensor_t(sp1, axes, 0, self._shape[1], self.eps, r0, r1)

@@ -31,6 +31,7 @@ class KronExtraction(object):
         for k in range(self.d):
             s = basis.splines[k]
             _, idx, val = s.evalBatch(grid.axes[k])
+            self.__dict__.setdefault("_tables", []).append((None, idx, val))
             n = len(grid.axes[k])
             rows = np.repeat(np.arange(n), s.p + 1)
             nz = val.ravel() != 0.0                      # exact zeros cannot pass the product filter
@@ -49,6 +50,16 @@ class KronExtraction(object):
         entries stays above the filter threshold of generateM (abs(v) > eps, tIGAr/common.py:1569)."""
         mins = [float(np.min(np.abs(m.data))) if m.nnz else 0.0 for m in self.M1]
         return bool(np.prod(mins) > eps)
+
+    def columns_ascending(self):
+        """no periodic wrap: the functions of every 1-D node appear in ascending index order (then candidate order
+        = column order and the Kronecker rows come out sorted)"""
+        for k in range(self.d):
+            s = self.basis.splines[k]
+            _, idx, _ = self._tables[k]
+            if np.any(np.diff(idx, axis=1) <= 0):
+                return False
+        return True
 
     def is_exact_for(self, M_nnz, eps):
         """True if generateM's filter dropped only exact zeros, i.e. M == kron(M_k) entrywise."""
