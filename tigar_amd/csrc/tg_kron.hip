@@ -521,39 +521,49 @@ __global__ void __launch_bounds__(64) k_kron3_rowptr(tg_kron3_args A, int64_t *_
   rowptr[lr] = tg_kron3_rowstart(A, a, b, c) - A.out0;
 }
 
-__global__ void __launch_bounds__(64)
-    k_kron3_fill(tg_kron3_args A, int32_t *__restrict__ col, double *__restrict__ val) {
-  const int lane = threadIdx.x;
-  const int sub = lane / A.slot, l = lane - sub * A.slot;
-  // pencils intersecting the row range: first pencil = row0 / n0
-  const int64_t pencil = A.row0 / A.n[0] + (int64_t)blockIdx.x * A.L + sub;
-  if (sub >= A.L || pencil >= A.npencils) return;
+// One workgroup per pencil: the pencil's entries form one contiguous range of n12 * nnz0 entries (rows a = 0..n0-1
+// follow each other, row a holding n0(a) * n12 entries in (k, j, i) order).  Thread t of a pass owns entry t of that
+// range -- fully coalesced 2-KB / 1-KB stores; its row is rowof[t / n12] (a look-up in the 1-D entry -> row table),
+// its (k, j) combination and i follow by two small divisions; the (j, k) parts (v1, v2, column offset) sit in LDS.
+#define TG_KRON3_MAXJK 256
+__global__ void __launch_bounds__(256)
+    k_kron3_fill(tg_kron3_args A, const int32_t *__restrict__ rowof, int32_t *__restrict__ col, double *__restrict__ val) {
+  __shared__ double s_v1[TG_KRON3_MAXJK], s_v2[TG_KRON3_MAXJK];
+  __shared__ int64_t s_c[TG_KRON3_MAXJK];
+  const int tid = threadIdx.x;
+  const int64_t pencil = A.row0 / A.n[0] + blockIdx.x;
+  if (pencil >= A.npencils) return;
   const int64_t b = A.d > 1 ? pencil % A.n[1] : 0, c = A.d > 2 ? pencil / A.n[1] : 0;
   const int y0 = A.d > 1 ? A.rp[1][b] : 0, n1 = A.d > 1 ? A.rp[1][b + 1] - y0 : 1;
   const int z0 = A.d > 2 ? A.rp[2][c] : 0, n2 = A.d > 2 ? A.rp[2][c + 1] - z0 : 1;
-  const int64_t n12 = (int64_t)n1 * n2;
-  const int64_t g0 = A.n[0] * pencil;              // global row of a = 0
-  const int64_t a_lo = max((int64_t)0, A.row0 - g0), a_hi = min(A.n[0], A.row0 + A.nrows - g0);
-  if (a_hi <= a_lo) return;
-  const int64_t base = tg_kron3_rowstart(A, 0, b, c) - A.out0;   // entry index of row (0, b, c)
-  // (rows with more than 64 combinations -- transposed factors at p = 3 -- take several passes of the lanes)
-  for (int lc = l; lc < n12; lc += A.slot) {
+  const int n12 = n1 * n2;
+  for (int lc = tid; lc < n12; lc += 256) {
     const int k = lc / n1, j = lc - k * n1;        // rank lc = k * n1 + j: (k, j) order = column order
-    const double v1 = A.d > 1 ? A.cv[1][y0 + j] : 1.0, v2 = A.d > 2 ? A.cv[2][z0 + k] : 1.0;
+    s_v1[lc] = A.d > 1 ? A.cv[1][y0 + j] : 1.0;
+    s_v2[lc] = A.d > 2 ? A.cv[2][z0 + k] : 1.0;
     int64_t cjk = A.col_offset;
     if (A.d > 1) cjk += A.cstride[1] * (int64_t)A.ci[1][y0 + j];
     if (A.d > 2) cjk += A.cstride[2] * (int64_t)A.ci[2][z0 + k];
-    for (int64_t a = a_lo; a < a_hi; a++) {
-      const int x0 = A.rp[0][a], n0 = A.rp[0][a + 1] - x0;
-      const int64_t pos = base + n12 * A.ps[0][a] + (int64_t)lc * n0;
-      for (int i = 0; i < n0; i++) {
-        double v = A.cv[0][x0 + i];                // (v0 * v1) * v2, left to right as the reference multiplies
-        if (A.d > 1) v = v * v1;
-        if (A.d > 2) v = v * v2;
-        col[pos + i] = (int32_t)(A.ci[0][x0 + i] + cjk);
-        val[pos + i] = v;
-      }
-    }
+    s_c[lc] = cjk;
+  }
+  __syncthreads();
+  const int64_t g0 = A.n[0] * pencil;              // global row of a = 0
+  const int64_t a_lo = max((int64_t)0, A.row0 - g0), a_hi = min(A.n[0], A.row0 + A.nrows - g0);
+  if (a_hi <= a_lo || n12 == 0) return;
+  const int64_t base = tg_kron3_rowstart(A, 0, b, c) - A.out0;   // entry index of row (0, b, c)
+  const int64_t t_lo = (int64_t)n12 * A.ps[0][a_lo], t_hi = (int64_t)n12 * A.ps[0][a_hi];
+  for (int64_t t = t_lo + tid; t < t_hi; t += 256) {
+    // q = t / n12: the 1-D entry of direction 0 this output entry descends from (32-bit division where it suffices)
+    const int64_t q = t < 0x7fffffffll ? (int64_t)((uint32_t)t / (uint32_t)n12) : t / n12;
+    const int a = rowof[q];
+    const int x0 = A.rp[0][a], n0 = A.rp[0][a + 1] - x0;
+    const int e = (int)(t - (int64_t)n12 * x0);    // position inside row a (x0 == ps0[a])
+    const int jk = e / n0, i = e - jk * n0;
+    double v = A.cv[0][x0 + i];                    // (v0 * v1) * v2, left to right as the reference multiplies
+    if (A.d > 1) v = v * s_v1[jk];
+    if (A.d > 2) v = v * s_v2[jk];
+    col[base + t] = (int32_t)(A.ci[0][x0 + i] + s_c[jk]);
+    val[base + t] = v;
   }
 }
 
@@ -631,15 +641,31 @@ extern "C" int tg_kron3_csr(int d, const tg_kron_dir_t *dirs, const int64_t *cdi
     A.nrows = row1 - row0;
     A.out0 = rowstart(row0);
     const int64_t nnz = rowstart(row1) - A.out0;
-    A.slot = std::min(64, maxn[1] * maxn[2]);
-    A.L = std::max(1, 64 / A.slot);
+    A.slot = maxn[1] * maxn[2];
+    A.L = 1;
     A.npencils = total / A.n[0];
-    rc = tg_csr_alloc(A.nrows, ncols_total, nnz, &m);
+    if (A.slot > TG_KRON3_MAXJK) {
+      tg_set_error("tg_kron3_csr: more than %d (j,k) combinations per row", TG_KRON3_MAXJK);
+      rc = 2;
+    }
+    int32_t *d_rowof = nullptr;
+    if (!rc) {
+      const tg_kron_dir_t &D0 = dirs[0];
+      std::vector<int32_t> rowof((size_t)std::max<int64_t>(D0.rowptr[D0.n], 1), 0);
+      for (int64_t r = 0; r < D0.n; r++)
+        for (int q = D0.rowptr[r]; q < D0.rowptr[r + 1]; q++) rowof[(size_t)q] = (int32_t)r;
+      rc = tg_dmalloc(&d_rowof, (int64_t)rowof.size());
+      if (!rc) {
+        hipMemcpyAsync(d_rowof, rowof.data(), rowof.size() * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+        hipStreamSynchronize(g_tg.stream);
+      }
+    }
+    if (!rc) rc = tg_csr_alloc(A.nrows, ncols_total, nnz, &m);
     if (!rc && A.nrows > 0) {
       hipLaunchKernelGGL(k_kron3_rowptr, dim3((unsigned)tg_cdiv(A.nrows + 1, 64)), dim3(64), 0, g_tg.stream, A, m->rowptr);
       const int64_t p_first = row0 / A.n[0], p_last = (row1 - 1) / A.n[0];
-      hipLaunchKernelGGL(k_kron3_fill, dim3((unsigned)tg_cdiv(p_last - p_first + 1, A.L)), dim3(64), 0, g_tg.stream, A,
-                         m->col, m->val);
+      hipLaunchKernelGGL(k_kron3_fill, dim3((unsigned)(p_last - p_first + 1)), dim3(256), 0, g_tg.stream, A, d_rowof, m->col,
+                         m->val);
       if (hipGetLastError() != hipSuccess) {
         tg_set_error("tg_kron3_csr: kernel launch failed");
         rc = 1;
@@ -650,6 +676,7 @@ extern "C" int tg_kron3_csr(int d, const tg_kron_dir_t *dirs, const int64_t *cdi
     }
     // (the host tables above are read by the copies: wait before they go out of scope)
     hipStreamSynchronize(g_tg.stream);
+    tg_dfree(d_rowof);
   } else
     hipStreamSynchronize(g_tg.stream);
   for (int i = 0; i < 12; i++) tg_dfree(dev[i]);
