@@ -347,13 +347,13 @@ def main():
     # guide prescribes; committed under profiles/): an OFFLINE measurement, quoted only for the workload and
     # rank count it was taken on
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r1_spmv_pmc_summary.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r2_spmv_pmc_summary.json")
     if wl == "cfg3" and res["comm_world"] == 1 and not args.nel and not args.p and os.path.exists(pmc_file):
         try:
             pmc = json.load(open(pmc_file))
             if kernel in pmc["kernel"]:
                 traffic = pmc["hbm_bytes_per_launch"]
-                traffic_src = ("offline: profiles/r1_spmv_pmc_summary.json (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 "
+                traffic_src = ("offline: profiles/r2_spmv_pmc_summary.json (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 "
                                "correction + WRITE_SIZE, separate passes; not measured in this run)")
         except Exception:
             traffic = None
@@ -392,6 +392,20 @@ def main():
                      "effective_csr_GBps": csr_bytes / spmv_avg_s / 1e9 if spmv_avg_s > 0 else 0.0,
                      "effective_csr_frac_of_peak": csr_bytes / spmv_avg_s / 1e9 / HBM_PEAK_GBS if spmv_avg_s > 0 else 0.0},
     }
+    if wl == "cfg3" and res["comm_world"] == 1 and not args.nel and not args.p:
+        # the general-CSR contract keeps a tracked number: the same step with the fast path switched off (offline runs,
+        # committed under profiles/; A arbitrary sparse in both, M Kronecker in the first, nothing assumed in the second)
+        ref = {}
+        for key, fn in (("arbitrary_A_kronecker_M_line_kernels", "r2_bench_cfg3_general_line.json"),
+                        ("fully_general_hash_ptap_M_slabs_materialised", "r2_bench_cfg3_general_hash.json")):
+            try:
+                g = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                ref[key] = {"value": g["value"], "ms_per_step": g["ms_per_step"], "ptap_s": g["config"]["stages_s"]["ptap"],
+                            "source": "offline: profiles/" + fn}
+            except Exception:
+                pass
+        if ref:
+            out["config"]["general_path_reference"] = ref
     if not args.no_cpu_baseline and res["comm_world"] == 1:      # (rank 0 at N=1 only: the other ranks would wait for it)
         # a bounded sample: seconds of work on the 16 cores the GPU box grants (the A*M intermediate of
         # the Gustavson PtAP needs ~7 GB of host memory at p=3, 40^3 elements)

@@ -272,8 +272,25 @@ __global__ void __launch_bounds__(256)
 int tg_kron_build(int d, int nterms, const tg_kron_dir_t *dirs, int64_t row0, int64_t row1, int filter, double eps,
                   int64_t col_offset, int64_t ncols_total, tg_csr_t *out);
 
+static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0, int64_t row1,
+                          int64_t col_offset, int64_t ncols_total, tg_csr_t *out);
+
 extern "C" int tg_kron_sum_csr(int d, int nterms, const tg_kron_dir_t *dirs, int64_t row0, int64_t row1,
                                tg_csr_t *out) {
+  // streamed fill with closed-form row starts (k_kron3_fill_sum) whenever the rows are short enough for its LDS tables
+  if (d >= 1 && d <= 3 && dirs && nterms >= 1 && nterms <= 9 && !getenv("TIGAR_KRON_LEGACY")) {
+    int64_t cdim[3] = {1, 1, 1}, total = 1;
+    int mx[3] = {1, 1, 1};
+    bool ok = true;
+    for (int k = 0; k < d && ok; k++) {
+      ok = dirs[k].n >= 1 && dirs[k].rowptr && dirs[k].col && dirs[k].val;
+      if (!ok) break;
+      cdim[k] = dirs[k].n;
+      total *= dirs[k].n;
+      for (int64_t r = 0; r < dirs[k].n; r++) mx[k] = std::max(mx[k], dirs[k].rowptr[r + 1] - dirs[k].rowptr[r]);
+    }
+    if (ok && mx[1] * mx[2] <= 256) return tg_kron3_build(d, nterms, dirs, cdim, row0, row1, 0, total, out);
+  }
   return tg_kron_build(d, nterms, dirs, row0, row1, 0, 0.0, 0, -1, out);
 }
 
@@ -491,9 +508,11 @@ struct tg_kron3_args {
   int64_t col_offset;
   int64_t row0, nrows;           // output rows [row0, row0 + nrows)
   int64_t out0;                  // entry index of row row0 in the closed form (subtracted)
-  int slot;                      // lanes reserved per pencil: max n1 * max n2
-  int L;                         // pencils per wave
+  int slot;                      // max n1 * max n2
+  int L;
   int64_t npencils;
+  int nterms;                    // Kronecker SUM: values are term-major, cv[k][t * nnz1d[k] + q]
+  int64_t nnz1d[3];
 };
 
 __device__ __forceinline__ int64_t tg_kron3_rowstart(const tg_kron3_args &A, int64_t a, int64_t b, int64_t c) {
@@ -567,14 +586,73 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// the same stream for a Kronecker SUM of terms on one pattern (synthetic FE input: Laplace = K1xM1xM1 + ...):
+// value = sum_t x_t[i] * (y_t[j] z_t[k])
+#define TG_KRON3_MAXT 9
+__global__ void __launch_bounds__(256)
+    k_kron3_fill_sum(tg_kron3_args A, const int32_t *__restrict__ rowof, int32_t *__restrict__ col,
+                     double *__restrict__ val) {
+  extern __shared__ double s_dyn[];                // w[nterms][slot] then column offsets (int64) [slot]
+  double *s_w = s_dyn;
+  int64_t *s_c = reinterpret_cast<int64_t *>(s_dyn + (size_t)A.nterms * A.slot);
+  const int tid = threadIdx.x;
+  const int64_t pencil = A.row0 / A.n[0] + blockIdx.x;
+  if (pencil >= A.npencils) return;
+  const int64_t b = A.d > 1 ? pencil % A.n[1] : 0, c = A.d > 2 ? pencil / A.n[1] : 0;
+  const int y0 = A.d > 1 ? A.rp[1][b] : 0, n1 = A.d > 1 ? A.rp[1][b + 1] - y0 : 1;
+  const int z0 = A.d > 2 ? A.rp[2][c] : 0, n2 = A.d > 2 ? A.rp[2][c + 1] - z0 : 1;
+  const int n12 = n1 * n2;
+  for (int lc = tid; lc < n12; lc += 256) {
+    const int k = lc / n1, j = lc - k * n1;
+    for (int t = 0; t < A.nterms; t++) {
+      double w = 1.0;
+      if (A.d > 1) w *= A.cv[1][t * A.nnz1d[1] + y0 + j];
+      if (A.d > 2) w *= A.cv[2][t * A.nnz1d[2] + z0 + k];
+      s_w[t * A.slot + lc] = w;
+    }
+    int64_t cjk = A.col_offset;
+    if (A.d > 1) cjk += A.cstride[1] * (int64_t)A.ci[1][y0 + j];
+    if (A.d > 2) cjk += A.cstride[2] * (int64_t)A.ci[2][z0 + k];
+    s_c[lc] = cjk;
+  }
+  __syncthreads();
+  const int64_t g0 = A.n[0] * pencil;
+  const int64_t a_lo = max((int64_t)0, A.row0 - g0), a_hi = min(A.n[0], A.row0 + A.nrows - g0);
+  if (a_hi <= a_lo || n12 == 0) return;
+  const int64_t base = tg_kron3_rowstart(A, 0, b, c) - A.out0;
+  const int64_t t_lo = (int64_t)n12 * A.ps[0][a_lo], t_hi = (int64_t)n12 * A.ps[0][a_hi];
+  for (int64_t t = t_lo + tid; t < t_hi; t += 256) {
+    const int64_t q = t < 0x7fffffffll ? (int64_t)((uint32_t)t / (uint32_t)n12) : t / n12;
+    const int a = rowof[q];
+    const int x0 = A.rp[0][a], n0 = A.rp[0][a + 1] - x0;
+    const int e = (int)(t - (int64_t)n12 * x0);
+    const int jk = e / n0, i = e - jk * n0;
+    double sum = 0.0;
+    for (int u = 0; u < A.nterms; u++) sum += A.cv[0][u * A.nnz1d[0] + x0 + i] * s_w[u * A.slot + jk];
+    col[base + t] = (int32_t)(A.ci[0][x0 + i] + s_c[jk]);
+    val[base + t] = sum;
+  }
+}
+
+static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0, int64_t row1,
+                          int64_t col_offset, int64_t ncols_total, tg_csr_t *out);
+
 extern "C" int tg_kron3_csr(int d, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0, int64_t row1,
                             int64_t col_offset, int64_t ncols_total, tg_csr_t *out) {
+  return tg_kron3_build(d, 0, dirs, cdim, row0, row1, col_offset, ncols_total, out);
+}
+
+// nterms == 0: single product with the reference's value order (extraction operators); nterms >= 1: Kronecker sum
+static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0, int64_t row1,
+                          int64_t col_offset, int64_t ncols_total, tg_csr_t *out) {
   TG_REQUIRE_INIT();
-  TG_REQUIRE(d >= 1 && d <= 3 && dirs && cdim && out, "bad arguments to tg_kron3_csr");
+  TG_REQUIRE(d >= 1 && d <= 3 && dirs && cdim && out && nterms >= 0 && nterms <= TG_KRON3_MAXT, "bad arguments to tg_kron3_csr");
+  const int nval = nterms > 0 ? nterms : 1;
   tg_kron3_args A;
   memset(&A, 0, sizeof(A));
   A.d = d;
   A.col_offset = col_offset;
+  A.nterms = nterms;
   int64_t total = 1, ctotal = 1;
   std::vector<std::vector<int64_t>> hps(3);
   int maxn[3] = {1, 1, 1};
@@ -586,6 +664,7 @@ extern "C" int tg_kron3_csr(int d, const tg_kron_dir_t *dirs, const int64_t *cdi
     TG_REQUIRE(D.n >= 1 && D.rowptr && D.col && D.val, "bad 1-D factor %d", k);
     const int64_t nnz1 = D.rowptr[D.n];
     A.n[k] = D.n;
+    A.nnz1d[k] = nnz1;
     total *= D.n;
     A.cstride[k] = ctotal;
     ctotal *= cdim[k];
@@ -601,7 +680,7 @@ extern "C" int tg_kron3_csr(int d, const tg_kron_dir_t *dirs, const int64_t *cdi
     int32_t *rp = nullptr, *cl = nullptr;
     double *vl = nullptr;
     int64_t *ps = nullptr;
-    rc = tg_dmalloc(&rp, D.n + 1) || tg_dmalloc(&cl, nnz1) || tg_dmalloc(&vl, nnz1) || tg_dmalloc(&ps, D.n + 1);
+    rc = tg_dmalloc(&rp, D.n + 1) || tg_dmalloc(&cl, nnz1) || tg_dmalloc(&vl, nnz1 * nval) || tg_dmalloc(&ps, D.n + 1);
     dev[4 * k] = rp;
     dev[4 * k + 1] = cl;
     dev[4 * k + 2] = vl;
@@ -610,7 +689,7 @@ extern "C" int tg_kron3_csr(int d, const tg_kron_dir_t *dirs, const int64_t *cdi
     hipMemcpyAsync(rp, D.rowptr, (size_t)(D.n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
     if (nnz1) {
       hipMemcpyAsync(cl, D.col, (size_t)nnz1 * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
-      hipMemcpyAsync(vl, D.val, (size_t)nnz1 * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
+      hipMemcpyAsync(vl, D.val, (size_t)(nnz1 * nval) * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
     }
     hipMemcpyAsync(ps, hps[k].data(), (size_t)(D.n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream);
     A.rp[k] = rp;
@@ -664,8 +743,12 @@ extern "C" int tg_kron3_csr(int d, const tg_kron_dir_t *dirs, const int64_t *cdi
     if (!rc && A.nrows > 0) {
       hipLaunchKernelGGL(k_kron3_rowptr, dim3((unsigned)tg_cdiv(A.nrows + 1, 64)), dim3(64), 0, g_tg.stream, A, m->rowptr);
       const int64_t p_first = row0 / A.n[0], p_last = (row1 - 1) / A.n[0];
-      hipLaunchKernelGGL(k_kron3_fill, dim3((unsigned)(p_last - p_first + 1)), dim3(256), 0, g_tg.stream, A, d_rowof, m->col,
-                         m->val);
+      if (nterms == 0)
+        hipLaunchKernelGGL(k_kron3_fill, dim3((unsigned)(p_last - p_first + 1)), dim3(256), 0, g_tg.stream, A, d_rowof,
+                           m->col, m->val);
+      else
+        hipLaunchKernelGGL(k_kron3_fill_sum, dim3((unsigned)(p_last - p_first + 1)), dim3(256),
+                           (size_t)(nterms + 1) * A.slot * sizeof(double), g_tg.stream, A, d_rowof, m->col, m->val);
       if (hipGetLastError() != hipSuccess) {
         tg_set_error("tg_kron3_csr: kernel launch failed");
         rc = 1;
