@@ -173,6 +173,8 @@ class SlabHotPath(object):
         self.eps = eps
         self.layout = layout_for(basis, grid)
         self.k0, self.k1 = split_range(self.layout.ncp, world)[rank]
+        if sub_planes == "auto" and os.environ.get("TIGAR_SUB_PLANES"):
+            sub_planes = int(os.environ["TIGAR_SUB_PLANES"])          # (experiments)
         if sub_planes == "auto":
             # what the path can use: free device memory plus what the library's caching allocator holds idle
             free_b = dev.mem_info()[0] + dev.pool_stats()[0]
