@@ -261,9 +261,30 @@ def device_comm(transport, kind=None):
         kind = "rccl" if ndev >= local else "host"
     if kind == "host":
         return dev.HostComm(transport)
-    uid = dev.Comm.unique_id() if transport.rank == 0 else None
-    uid = transport.broadcast_bytes(uid, 128)
-    return dev.Comm(uid, transport.rank, transport.world)
+    # RCCL; if the group cannot be formed on some rank (all ranks learn it through the transport) every rank falls
+    # back to the host-staged communicator instead of failing the run
+    comm, err = None, None
+    try:
+        uid = dev.Comm.unique_id() if transport.rank == 0 else None
+    except Exception as e:                      # (rank 0 only)
+        uid, err = None, e
+    flag = np.array([1.0 if (transport.rank == 0 and uid is None) else 0.0])
+    transport.allreduce_sum(flag)
+    if flag[0] == 0.0:
+        uid = transport.broadcast_bytes(uid, 128)
+        try:
+            comm = dev.Comm(uid, transport.rank, transport.world)
+        except Exception as e:
+            err = e
+    bad = np.array([0.0 if comm is not None else 1.0])
+    transport.allreduce_sum(bad)
+    if bad[0] > 0.0:
+        if transport.rank == 0:
+            print("[tigar_amd] RCCL communicator could not be created on %d rank(s) (%s); using the host-staged "
+                  "communicator" % (int(bad[0]), err), file=sys.stderr, flush=True)
+        comm = None
+        return dev.HostComm(transport)
+    return comm
 
 
 def spawn_local(nproc, argv, env_extra=None, port=None):
