@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtigar_hip.so")
+LIB_PATH = os.environ.get("TIGAR_LIB_PATH", os.path.join(_HERE, "libtigar_hip.so"))   # (override: A/B of two builds)
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)

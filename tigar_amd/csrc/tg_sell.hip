@@ -26,6 +26,13 @@
 #include <algorithm>
 #include <vector>
 
+#ifndef TG_SELL_UNROLL
+#define TG_SELL_UNROLL 8
+#endif
+#ifndef TG_SELL_G
+#define TG_SELL_G 2            // positions per group: 2 or 4 (16 or 32 contiguous bytes per lane)
+#endif
+
 #define TG_SELL_C 64           // rows per slice
 #define TG_SELL_TABLE 16384    // hash slots for slice classes
 #define TG_SELL_MAXCLASS 4096  // distinct slice classes accepted
@@ -240,7 +247,8 @@ __global__ void k_sell_slice_sizes(const int32_t *__restrict__ slot_of_slice, co
   if (s >= nslices) return;
   const int id = id_of_slot[slot_of_slice[s]];
   slice_cls[s] = id;
-  slice_ptr[s] = (int64_t)cls_w[id] * TG_SELL_C;
+  // positions come in groups of TG_SELL_G (16-byte loads per lane), the last group padded with zeros
+  slice_ptr[s] = (int64_t)((cls_w[id] + TG_SELL_G - 1) / TG_SELL_G) * TG_SELL_G * TG_SELL_C;
 }
 
 // ---- 6. conversion: one workgroup per slice.  The slice's entries are contiguous in the CSR arrays
@@ -313,7 +321,18 @@ __global__ void __launch_bounds__(256)
       }
     }
     __syncthreads();
-    for (int i = tid; i < w * R; i += 256) o[(int64_t)(i >> lR) * TG_SELL_C + g0 + (i & (R - 1))] = tile[i];
+    // layout of a slice: [group of TG_SELL_G positions][lane][TG_SELL_G] -- the product kernel loads 16 bytes per
+    // lane and instruction; written here as 16-byte pieces (two positions of one lane)
+    const int wg = (w + TG_SELL_G - 1) / TG_SELL_G;
+    for (int i = tid; i < wg * (TG_SELL_G / 2) * R; i += 256) {
+      const int rr = i & (R - 1), q = i >> lR;            // q = group * (G/2) + half
+      const int grp = q / (TG_SELL_G / 2), half = q - grp * (TG_SELL_G / 2);
+      const int k = grp * TG_SELL_G + 2 * half;
+      double2 v2;
+      v2.x = (k < w) ? tile[(k << lR) + rr] : 0.0;
+      v2.y = (k + 1 < w) ? tile[((k + 1) << lR) + rr] : 0.0;
+      reinterpret_cast<double2 *>(o)[((int64_t)grp * TG_SELL_C + g0 + rr) * (TG_SELL_G / 2) + half] = v2;
+    }
   }
   if (bad) atomicExch(fail, 1);
 }
@@ -322,7 +341,6 @@ __global__ void __launch_bounds__(256)
 // One wave per slice.  U_s[k] is wave-uniform (read through the scalar unit), the x load of a wave is
 // 64 consecutive doubles, clamped into the valid column range [cmin, cmax] of x (only padded
 // positions -- stored 0.0 -- can fall outside).
-#define TG_SELL_UNROLL 8
 __global__ void __launch_bounds__(256)
     k_spmv_sell(const int64_t *__restrict__ slice_addr, const int32_t *__restrict__ slice_cls,
                 const int32_t *__restrict__ cls_w, const int32_t *__restrict__ cls_off, const double *__restrict__ x,
@@ -335,21 +353,44 @@ __global__ void __launch_bounds__(256)
   const int id = slice_cls[s];
   const int w = cls_w[id];
   const int32_t *__restrict__ U = cls_off + (int64_t)id * TG_SELL_WMAX;
-  const double *__restrict__ v = reinterpret_cast<const double *>(slice_addr[s]) + lane;
+  typedef double tg_d2 __attribute__((ext_vector_type(2)));
+  constexpr int H = TG_SELL_G / 2;                          // 16-byte pieces per group and lane
+  const tg_d2 *__restrict__ v = reinterpret_cast<const tg_d2 *>(slice_addr[s]) + (int64_t)lane * H;
   const int r = (int)(s * TG_SELL_C) + lane;
   double sum = 0.0;
-  int k = 0;
-  for (; k + TG_SELL_UNROLL <= w; k += TG_SELL_UNROLL) {
-    double vv[TG_SELL_UNROLL], xx[TG_SELL_UNROLL];
+  const int wg = (w + TG_SELL_G - 1) / TG_SELL_G;          // groups (the last one zero-padded)
+  // the TG_SELL_G positions of a group are adjacent in memory per lane: 16-byte loads; rows still add up in ascending
+  // column order (a padded position multiplies a stored 0.0 with a clamped x)
+  constexpr int GU = TG_SELL_UNROLL / TG_SELL_G;            // groups per batch of loads
+  int g = 0;
+  for (; g + GU <= wg; g += GU) {
+    tg_d2 vv[GU * H];
+    double xx[GU * TG_SELL_G];
 #pragma unroll
-    for (int j = 0; j < TG_SELL_UNROLL; j++) {
-      vv[j] = __builtin_nontemporal_load(v + (int64_t)(k + j) * TG_SELL_C);
-      xx[j] = x[min(max(r + U[k + j], cmin), cmax)];
+    for (int j = 0; j < GU; j++) {
+#pragma unroll
+      for (int h = 0; h < H; h++) vv[j * H + h] = __builtin_nontemporal_load(v + ((int64_t)(g + j) * TG_SELL_C) * H + h);
+#pragma unroll
+      for (int q = 0; q < TG_SELL_G; q++) {
+        const int k = min((g + j) * TG_SELL_G + q, w - 1);
+        xx[j * TG_SELL_G + q] = x[min(max(r + U[k], cmin), cmax)];
+      }
     }
 #pragma unroll
-    for (int j = 0; j < TG_SELL_UNROLL; j++) sum += vv[j] * xx[j];
+    for (int j = 0; j < GU * H; j++) {
+      sum += vv[j].x * xx[2 * j];
+      sum += vv[j].y * xx[2 * j + 1];
+    }
   }
-  for (; k < w; k++) sum += v[(int64_t)k * TG_SELL_C] * x[min(max(r + U[k], cmin), cmax)];
+  for (; g < wg; g++) {
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      const tg_d2 t = v[((int64_t)g * TG_SELL_C) * H + h];
+      const int k0 = min(g * TG_SELL_G + 2 * h, w - 1), k1 = min(g * TG_SELL_G + 2 * h + 1, w - 1);
+      sum += t.x * x[min(max(r + U[k0], cmin), cmax)];
+      sum += t.y * x[min(max(r + U[k1], cmin), cmax)];
+    }
+  }
   if (r < nrows) y[r] = sum;
 }
 
