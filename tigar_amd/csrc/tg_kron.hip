@@ -589,6 +589,9 @@ __global__ void __launch_bounds__(256)
 // the same stream for a Kronecker SUM of terms on one pattern (synthetic FE input: Laplace = K1xM1xM1 + ...):
 // value = sum_t x_t[i] * (y_t[j] z_t[k])
 #define TG_KRON3_MAXT 9
+#ifndef TG_KRON3_Z
+#define TG_KRON3_Z 4
+#endif
 __global__ void __launch_bounds__(256)
     k_kron3_fill_sum(tg_kron3_args A, const int32_t *__restrict__ rowof, int32_t *__restrict__ col,
                      double *__restrict__ val) {
@@ -621,16 +624,55 @@ __global__ void __launch_bounds__(256)
   if (a_hi <= a_lo || n12 == 0) return;
   const int64_t base = tg_kron3_rowstart(A, 0, b, c) - A.out0;
   const int64_t t_lo = (int64_t)n12 * A.ps[0][a_lo], t_hi = (int64_t)n12 * A.ps[0][a_hi];
-  for (int64_t t = t_lo + tid; t < t_hi; t += 256) {
-    const int64_t q = t < 0x7fffffffll ? (int64_t)((uint32_t)t / (uint32_t)n12) : t / n12;
-    const int a = rowof[q];
-    const int x0 = A.rp[0][a], n0 = A.rp[0][a + 1] - x0;
-    const int e = (int)(t - (int64_t)n12 * x0);
-    const int jk = e / n0, i = e - jk * n0;
-    double sum = 0.0;
-    for (int u = 0; u < A.nterms; u++) sum += A.cv[0][u * A.nnz1d[0] + x0 + i] * s_w[u * A.slot + jk];
-    col[base + t] = (int32_t)(A.ci[0][x0 + i] + s_c[jk]);
-    val[base + t] = sum;
+  // TG_KRON3_Z consecutive entries per thread: (row, (j,k) combination, i) of the first by division, of the others by
+  // stepping (i, then jk, then row) -- the kernel is bound by this integer arithmetic, not by the stores (9.6 ms per
+  // 31 GB launch with two divisions per entry, 7.9 ms with four entries per division; one work item per (row, jk) with
+  // its n0 entries written by one thread: 24 ms, the stores of a wave are then 8-byte pieces n0*8 bytes apart) -- and
+  // 16-byte stores: one per four columns, one per two values
+  typedef int tg_i4 __attribute__((ext_vector_type(4)));
+  typedef double tg_d2 __attribute__((ext_vector_type(2)));
+  for (int64_t t4 = t_lo + TG_KRON3_Z * (int64_t)tid; t4 < t_hi; t4 += 256 * TG_KRON3_Z) {
+    int cc[TG_KRON3_Z];
+    double vv[TG_KRON3_Z];
+    const int64_t q = t4 < 0x7fffffffll ? (int64_t)((uint32_t)t4 / (uint32_t)n12) : t4 / n12;
+    int a = rowof[q];
+    int x0 = A.rp[0][a], n0 = A.rp[0][a + 1] - x0;
+    const int e = (int)(t4 - (int64_t)n12 * x0);
+    int jk = e / n0, i = e - jk * n0;
+#pragma unroll
+    for (int z = 0; z < TG_KRON3_Z; z++) {
+      double sum = 0.0;
+      for (int u = 0; u < A.nterms; u++) sum += A.cv[0][u * A.nnz1d[0] + x0 + i] * s_w[u * A.slot + jk];
+      cc[z] = (int32_t)(A.ci[0][x0 + i] + s_c[jk]);
+      vv[z] = sum;
+      if (++i == n0) {
+        i = 0;
+        if (++jk == n12) {
+          jk = 0;
+          do {                                   // next non-empty row (an empty 1-D row holds no entries)
+            a++;
+          } while (a + 1 < (int)A.n[0] && A.rp[0][a + 1] == A.rp[0][a]);
+          if (a >= (int)A.n[0]) a = (int)A.n[0] - 1;   // (past the pencil: the value is not stored)
+          x0 = A.rp[0][a];
+          n0 = max(A.rp[0][a + 1] - x0, 1);
+        }
+      }
+    }
+    if (t4 + TG_KRON3_Z - 1 < t_hi) {
+#pragma unroll
+      for (int z = 0; z < TG_KRON3_Z; z += 4) {
+        tg_i4 c4 = {cc[z], cc[z + 1], cc[z + 2], cc[z + 3]};
+        tg_d2 v01 = {vv[z], vv[z + 1]}, v23 = {vv[z + 2], vv[z + 3]};
+        __builtin_memcpy(col + base + t4 + z, &c4, 16);
+        __builtin_memcpy(val + base + t4 + z, &v01, 16);
+        __builtin_memcpy(val + base + t4 + z + 2, &v23, 16);
+      }
+    } else {
+      for (int z = 0; z < TG_KRON3_Z && t4 + z < t_hi; z++) {
+        col[base + t4 + z] = cc[z];
+        val[base + t4 + z] = vv[z];
+      }
+    }
   }
 }
 
