@@ -169,11 +169,12 @@ class TensorFunctionSpace(object):
 class Function(object):
     """Stand-in for dolfin ``Function``: FE coefficients in HBM."""
 
-    def __init__(self, V, local_range=None):
+    def __init__(self, V, local_range=None, vector=None):
         self.V = V
         # with several ranks a function holds the FE rows [r0, r1) its rank owns (set by the solve)
         self.local_range = local_range
-        self._vec = DeviceVector(V.dim() if local_range is None else local_range[1] - local_range[0])
+        self._vec = vector if vector is not None else \
+            DeviceVector(V.dim() if local_range is None else local_range[1] - local_range[0])
 
     def vector(self):
         return self._vec
@@ -386,9 +387,8 @@ class AbstractExtractionGenerator(object):
                 facs = cm.homogeneousCoordinateFactors(i)
                 fe1d = [kx.M1[k] @ numpy.asarray(facs[k], dtype=numpy.float64) for k in range(kx.d)]
                 rng = self._slab_engine.mine["u_rows"] if self._slab_engine is not None else None
-                f = Function(self.V_control, rng)
-                f._vec = _dev.vec_tensor3(fe1d, 1.0, rng[0] if rng else None, rng[1] if rng else None)
-                self.cpFuncs += [f]
+                self.cpFuncs += [Function(self.V_control, rng,
+                                          vector=_dev.vec_tensor3(fe1d, 1.0, rng[0] if rng else None, rng[1] if rng else None))]
                 continue
             if cm is not None and hasattr(cm, "homogeneousCoordinateDeviceVector"):
                 Pi = cm.homogeneousCoordinateDeviceVector(i)      # built in HBM from 1-D factors

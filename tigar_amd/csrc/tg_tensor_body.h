@@ -49,11 +49,15 @@ typedef const double __attribute__((address_space(4))) *tt_cdp;
 typedef const int32_t __attribute__((address_space(4))) *tt_cip;
 #define TT_CD(p) ((tt_cdp)(p))
 #define TT_CI(p) ((tt_cip)(p))
+typedef const double __attribute__((address_space(1))) *tt_gdp;   // pointer known to point to global memory
+#define TT_GD(p) ((tt_gdp)(p))
 #else
 typedef const double *tt_cdp;
 typedef const int32_t *tt_cip;
+typedef const double *tt_gdp;
 #define TT_CD(p) (p)
 #define TT_CI(p) (p)
+#define TT_GD(p) (p)
 #endif
 
 struct tt_dir_t {
@@ -397,7 +401,7 @@ struct tt_io_z {
 #pragma unroll
     for (int j = 0; j < N; j++) v[j] = 0.0;
     if (!valid) return;
-    const double *pl = planes[a - plane_lo];
+    tt_gdp pl = TT_GD(planes[a - plane_lo]);      // (a pointer read from a table: say that it is global, not flat)
     const int64_t o = clane * N;
 #pragma unroll
     for (int j = 0; j < N; j++) v[j] = pl[o + j];
