@@ -48,8 +48,9 @@ int tg_timer_start(int slot);
 int tg_timer_stop(int slot, double *ms);   /* synchronises; elapsed ms since start(slot) */
 
 /* Per-kernel accounting filled by the library while it runs (HIP events on the library's
- * stream, resolved at the next host sync).  slot 0: the SpMV inside tg_krylov_solve. */
-enum { TG_PROF_KSP_SPMV = 0, TG_PROF_NSLOTS = 4 };
+ * stream, resolved at the next host sync).  slot 0: the SpMV inside tg_krylov_solve; slot 1 (count only): those of
+ * them whose halo-free rows were computed while the halo exchange with the neighbour ranks was under way. */
+enum { TG_PROF_KSP_SPMV = 0, TG_PROF_KSP_OVERLAPPED = 1, TG_PROF_NSLOTS = 4 };
 int tg_prof_reset(void);
 int tg_prof_get(int slot, double *total_ms, int64_t *count);
 
@@ -88,6 +89,14 @@ int tg_csr_destroy(tg_csr_t m);
 /* explicit M^T (the reference's FORM_MT switch, tIGAr/common.py:84,358-360);
  * deterministic: rows of M^T sorted by FE row index. */
 int tg_csr_transpose(tg_csr_t m, tg_csr_t *out);
+/* IGA dof permutation (tIGAr/common.py:407-433 applyPermutation, 1583-1665 generatePermutation).
+ * tg_partition_mode: mt = transposed extraction pattern (rows = IGA dofs, columns = FE rows); fe_owner[j] (host, one
+ * entry per FE row, 0 <= owner < world) = the rank owning FE row j; owner_out[i] (host) = the rank owning the most FE
+ * rows of dof i's support, the lowest such rank on a tie (scipy.stats.mode), 0 for an empty row.
+ * tg_csr_permute_columns: copy of m with column c renamed new_of_old[c] (host, ncols entries, a permutation), rows
+ * re-sorted: MatPermute with identity rows. */
+int tg_partition_mode(tg_csr_t mt, const int32_t *fe_owner, int world, int32_t *owner_out);
+int tg_csr_permute_columns(tg_csr_t m, const int32_t *new_of_old, tg_csr_t *out);
 /* fallback for arbitrary AbstractScalarBasis plug-ins (seam b-2, tIGAr/common.py:1683-1692):
  * rows fed as (row, col, val) triplets from the host loop of generateM; applies the
  * abs(v) > eps filter of tIGAr/common.py:1569, INSERT semantics (last wins), sorts columns. */

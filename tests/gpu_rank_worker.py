@@ -31,8 +31,11 @@ def main():
     solver.parameters["relative_tolerance"] = 1e-10
     spline.setSolverOptions(linearSolver=solver)
     u = t.Function(spline.V, spline.localFERange())
+    from tigar_amd import device as dev
+    dev.prof_reset()
     U = spline.solveLinearSystem(K, rhs, u)
     its1 = solver.last["iterations"]
+    overlapped = dev.prof_get(1)[1]                      # products that ran beside their halo exchange
     # second solve from the converged state: must stop at once (non-zero initial guess path with halo)
     solver.parameters["nonzero_initial_guess"] = True
     from tigar_amd.device import DeviceVector
@@ -46,7 +49,7 @@ def main():
              K_indptr=Ks.indptr, K_indices=Ks.indices, K_data=Ks.data, rhs=rhs.get_local(), U=U.get_local(),
              u=u.vector().get_local(), its=np.array([its1, its2]),
              comm=np.array([rank_r, world_r, 0 if kind == "rccl" else 1]), cp0=cp0,
-             U2=U2.get_local())
+             U2=U2.get_local(), overlapped=np.array([overlapped]))
     comm.barrier()
 
 

@@ -40,9 +40,10 @@ def _single(d, p, nel, method):
             gen.cpFuncs[0].vector().get_local())
 
 
-def _run_ranks(tmp_path, world, kind, d, p, nel, method, port):
+def _run_ranks(tmp_path, world, kind, d, p, nel, method, port, env_more=None):
     from tigar_amd.launch import spawn_local
     env = {"PYTHONPATH": ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), "TIGAR_COMM": kind}
+    env.update(env_more or {})
     if kind == "host":
         env["TIGAR_DEVICE"] = "0"                       # every rank on the one GPU
     rc = spawn_local(world, [os.path.join(ROOT, "tests", "gpu_rank_worker.py"), str(tmp_path), str(d), str(p),
@@ -80,6 +81,23 @@ def test_host_staged_ranks_sharing_one_gpu(tmp_path, d, p, nel, method, world):
     ref = _single(d, p, nel, method)
     parts = _run_ranks(tmp_path, world, "host", d, p, nel, method, 29500 + 37 * (d * 100 + p * 10 + world))
     _compare(parts, ref, world, "host")
+
+
+def test_products_beside_the_halo_exchange_change_nothing(tmp_path):
+    """CG computes the rows without halo columns while the halo of the direction vector travels (tg_comm_halo_begin /
+    _end on the communicator's stream); every row is summed by the same kernel in the same order either way, so the
+    iterates are bit-identical to those with the exchange in front of the product (TIGAR_CG_OVERLAP=0)."""
+    d, p, nel, world = 3, 2, 24, 3
+    a, b = tmp_path / "on", tmp_path / "off"
+    a.mkdir(), b.mkdir()
+    on = _run_ranks(a, world, "host", d, p, nel, "cg", 31337)
+    off = _run_ranks(b, world, "host", d, p, nel, "cg", 31737, {"TIGAR_CG_OVERLAP": "0"})
+    for r in range(world):
+        # every product of the solve (the host runs up to two iterations ahead of the one it has seen converge)
+        assert int(on[r]["its"][0]) + 1 <= int(on[r]["overlapped"][0]) <= int(on[r]["its"][0]) + 3
+        assert int(off[r]["overlapped"][0]) == 0
+        assert int(on[r]["its"][0]) == int(off[r]["its"][0])
+        assert np.array_equal(on[r]["U"], off[r]["U"])
 
 
 @pytest.mark.parametrize("d,p,nel,method", [(3, 3, 24, "cg"), (3, 2, 16, "gmres")])

@@ -409,13 +409,26 @@ class AbstractExtractionGenerator(object):
         """Node grid of one scalar field (degree getDegree(field) on the shared knot mesh)."""
         raise NotImplementedError
 
-    def applyPermutation(self):
-        """The reference permutes IGA dofs to follow dolfin's mesh partition
-        (tIGAr/common.py:407-433).  Here IGA dofs are partitioned in contiguous z-slabs,
-        which already align with the z-slab FE rows: identity permutation."""
-        self.permutation = self.generatePermutation()
+    def applyPermutation(self, nparts=None, fe_owner=None):
+        """Renumbers the IGA dofs with ``generatePermutation`` (tIGAr/common.py:407-433): the columns of M move
+        (MatPermute with the identity on the rows: new column j = old column perm[j]) and the zero dofs are renamed
+        (the AO of :425-433: old dof a becomes the j with perm[j] = a).  With one part -- and for tensor patches in
+        z-slabs, whose dof slabs already follow the FE slabs -- the permutation is the identity and nothing moves."""
+        kw = {}
+        if nparts is not None or fe_owner is not None:
+            kw = {"nparts": nparts, "fe_owner": fe_owner}
+        self.permutation = perm = numpy.asarray(self.generatePermutation(**kw), dtype=numpy.int64)
+        if perm.size == 0 or numpy.array_equal(perm, numpy.arange(perm.size)):
+            return
+        new_of_old = numpy.empty(perm.size, dtype=numpy.int64)
+        new_of_old[perm] = numpy.arange(perm.size)
+        self.M = self.M.permute_columns(new_of_old)
+        self.MT = self.M.transpose()
+        self._kron = None                      # (M is no Kronecker product in the new numbering)
+        self._fast_blocks = {}
+        self.zeroDofs = new_of_old[self.zeroDofsArray()].tolist()
 
-    def writeExtraction(self, dirname, doPermutation=DEFAULT_DO_PERMUTATION):
+    def writeExtraction(self, dirname, doPermutation=DEFAULT_DO_PERMUTATION, nparts=None):
         """Writes the extraction data to ``dirname`` with the reference's file names and formats
         (tIGAr/common.py:435-502): ``extraction-mat.dat`` / ``extraction-mat-ctrl.dat`` (PETSc binary
         Mat of M / M_control), ``zero-dofs.dat`` (PETSc binary IS), ``extraction-info.txt`` (nsd,
@@ -425,7 +438,7 @@ class AbstractExtractionGenerator(object):
         ``extraction-data.npz`` instead, which only this package reads."""
         from . import petscio
         if doPermutation:
-            self.applyPermutation()
+            self.applyPermutation(nparts=nparts)      # (nparts: the number of ranks that will read the directory)
         os.makedirs(dirname, exist_ok=True)
         petscio.write_mat(os.path.join(dirname, EXTRACTION_MAT_FILE), self.M.to_scipy())
         petscio.write_mat(os.path.join(dirname, EXTRACTION_MAT_FILE_CTRL), self.M_control.to_scipy())
@@ -458,13 +471,17 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
     def getNodesAndEvals(self, x, field):
         return
 
-    def _generate_block(self, field, col_offset, ncols, grid):
+    def _generate_block(self, field, col_offset, ncols, grid, support_only=False):
         """Rows of the extraction matrix for one field: kernel path for tensor B-splines,
-        host-loop triplet fallback for arbitrary AbstractScalarBasis plug-ins (seam b-2)."""
+        host-loop triplet fallback for arbitrary AbstractScalarBasis plug-ins (seam b-2).
+        ``support_only``: every function ``getNodesAndEvals`` returns is kept whatever its value (the pattern
+        ``generatePermutation`` works on, tIGAr/common.py:1621-1629), always as a stored matrix."""
         basis = self.getScalarSpline(field) if hasattr(self, "getScalarSpline") else None
-        eps = self.getIgnoreEps()
+        eps = -1.0 if support_only else self.getIgnoreEps()
         from .BSplines import BSpline
         if isinstance(basis, BSpline) and type(basis).getNodesAndEvals is BSpline.getNodesAndEvals:
+            if support_only:
+                return _dev.extract_csr_tensor(basis.splines, grid.axes, col_offset, ncols, eps)
             self._fast_blocks[(field, col_offset)] = (basis, grid)
             if field == -1 and self._single_shared_field():
                 lazy = self._implicit_block(basis, grid, eps)
@@ -566,7 +583,7 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
             offset += self.getNcp(field)
         return blocks[0] if len(blocks) == 1 else _dev.csr_vstack(blocks)
 
-    def generateM(self):
+    def generateM(self, support_only=False):
         """Extraction matrix of the mixed space of all unknown fields
         (tIGAr/common.py:1516-1578): one row block per field, column offset = sum of the
         previous fields' ncp."""
@@ -574,9 +591,42 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
         blocks = []
         offset = 0
         for field in range(self.getNFields()):
-            blocks.append(self._generate_block(field, offset, totalDofs, self.V.grids[field]))
+            blocks.append(self._generate_block(field, offset, totalDofs, self.V.grids[field], support_only))
             offset += self.getNcp(field)
         return blocks[0] if len(blocks) == 1 else _dev.csr_vstack(blocks)
+
+    def feRowOwners(self, nparts):
+        """Rank of every FE row when the FE side is cut into ``nparts`` pieces the way this package cuts it: every
+        field's nodes in ``nparts`` contiguous runs of (nearly) equal length -- whole node planes first for a
+        tensor grid -- and piece r of every field on rank r.  (The reference takes the ownership from dolfin's mesh
+        partition, tIGAr/common.py:1598-1600, 1612-1618.)"""
+        owners = []
+        for field in range(self.getNFields()):
+            n = self.V.grids[field].num_nodes()
+            owners.append((numpy.arange(n, dtype=numpy.int64) * int(nparts)) // max(n, 1))
+        return numpy.concatenate(owners).astype(numpy.int32)
+
+    def generatePermutation(self, nparts=None, fe_owner=None):
+        """Order of the IGA dofs that follows the partition of the FE rows (tIGAr/common.py:1583-1665): every dof
+        goes to the rank that owns most of the FE nodes of its support (``scipy.stats.mode`` there: the lowest
+        rank on a tie; the support is everything ``getNodesAndEvals`` returns, zeros included), and the dofs are
+        sorted by that rank.  Returns ``perm`` with new dof j = old dof perm[j] (the argsort the reference hands to
+        MatPermute); the sort is stable, so within a rank the dofs keep their order.
+
+        ``nparts``: number of ranks the extraction is prepared for (default: the size of the communicator);
+        ``fe_owner``: owner of every FE row when it is not ``feRowOwners(nparts)``.  One part, or an operator that
+        is never stored (tensor patch in z-slabs: the slabs of dofs already follow the slabs of FE rows): identity."""
+        total = sum(self.getNcp(i) for i in range(self.getNFields()))
+        nparts = int(self.comm.size if nparts is None else nparts)
+        if fe_owner is not None:
+            fe_owner = numpy.asarray(fe_owner, dtype=numpy.int32)
+            nparts = max(nparts, int(fe_owner.max()) + 1 if fe_owner.size else 1)
+        if nparts <= 1 or getattr(self.M, "is_implicit", False):
+            return generateIdentityPermutation((0, total), self.comm)
+        if fe_owner is None:
+            fe_owner = self.feRowOwners(nparts)
+        owner = self.generateM(support_only=True).transpose().majority_owner(fe_owner, nparts)
+        return numpy.argsort(owner, kind="stable").astype(INDEX_TYPE)
 
 
 class AbstractScalarBasis(object):
@@ -711,12 +761,12 @@ class EqualOrderSpline(AbstractMultiFieldSpline):
     def _single_shared_field(self):
         return self.numFields == 1
 
-    def generateM(self):
+    def generateM(self, support_only=False):
         # one unknown field on the control mesh's basis: M is M_control (same rows, same
         # columns) -- share the device object instead of building it twice
-        if self.numFields == 1 and getattr(self, "M_control", None) is not None:
+        if self.numFields == 1 and getattr(self, "M_control", None) is not None and not support_only:
             return self.M_control
-        return AbstractMultiFieldSpline.generateM(self)
+        return AbstractMultiFieldSpline.generateM(self, support_only)
 
     def addZeroDofsByLocation(self, subdomain, field):
         """Homogeneous Dirichlet BCs on the DoFs of ``field`` whose control points lie in

@@ -137,6 +137,9 @@ int tg_spmv_raw(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax
 int tg_sell_plan(tg_csr_s *a);          // tg_sell.hip
 void tg_sell_drop(tg_csr_s *a);
 int tg_sell_spmv(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y);
+int64_t tg_sell_slice_rows(void);
+int tg_sell_spmv_rows(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y, int64_t r0,
+                      int64_t r1);
 
 int tg_csr_sort_rows(tg_csr_s *m);
 int tg_csr_transpose_block(tg_csr_s *m, int64_t row_base, int64_t out_ncols, tg_csr_s **out);

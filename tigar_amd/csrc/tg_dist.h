@@ -18,6 +18,11 @@ struct tg_comm_s {
   int64_t g0 = 0, g1 = 0, halo_lo = 0, halo_hi = 0, nglobal = 0;
   int64_t send_lo = 0, send_hi = 0;
   bool slab_set = false;
+  // the halo exchange runs on a stream of its own so that the rows of a product that need no halo can be
+  // computed meanwhile (tg_comm_halo_begin / tg_comm_halo_end); created on first use
+  hipStream_t xstream = nullptr;
+  hipEvent_t x_ready = nullptr, x_done = nullptr;
+  bool x_open = false;
 };
 
 #define TG_CHECK_NCCL(expr)                                                           \
@@ -31,5 +36,10 @@ struct tg_comm_s {
 
 // exchanges the halo of the extended vector xext = [halo_lo | owned | halo_hi] (device)
 int tg_comm_halo_exchange(tg_comm_s *c, double *xext);
+// the same in two halves: `begin` starts the exchange of the owned ends as they are on the current stream at
+// this point; work enqueued on the current stream between the two calls must not read the halo entries; after
+// `end` the current stream sees the received halo
+int tg_comm_halo_begin(tg_comm_s *c, double *xext);
+int tg_comm_halo_end(tg_comm_s *c, double *xext);
 // in-place sum over ranks of n device doubles
 int tg_comm_allreduce_dev(tg_comm_s *c, double *dev, int n);

@@ -73,6 +73,12 @@ extern "C" int tg_device_count(int *n) {
 extern "C" int tg_comm_destroy(tg_comm_t c) {
   if (!c) return 0;
   if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  if (c->xstream) {
+    hipStreamSynchronize(c->xstream);
+    hipEventDestroy(c->x_ready);
+    hipEventDestroy(c->x_done);
+    hipStreamDestroy(c->xstream);
+  }
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->stage) hipHostFree(c->stage);
   delete c;
@@ -91,6 +97,7 @@ static int tg_comm_stage_reserve(tg_comm_s *c, int64_t doubles) {
 
 int tg_comm_allreduce_dev(tg_comm_s *c, double *dev, int n) {
   if (!c || c->world == 1) return 0;
+  TG_REQUIRE(!c->x_open, "all-reduce between tg_comm_halo_begin and tg_comm_halo_end");
   if (c->kind == 1) {
     TG_TRY(tg_comm_stage_reserve(c, std::max<int64_t>(n, 64)));
     TG_CHECK_HIP(hipMemcpyAsync(c->stage, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
@@ -154,36 +161,37 @@ extern "C" int tg_comm_set_slab(tg_comm_t c, int64_t g0, int64_t g1, int64_t hal
   return 0;
 }
 
-int tg_comm_halo_exchange(tg_comm_s *c, double *xext) {
+static int tg_comm_xstream(tg_comm_s *c) {
+  if (c->xstream) return 0;
+  int prio_lo = 0, prio_hi = 0;
+  TG_CHECK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  TG_CHECK_HIP(hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, prio_hi));
+  TG_CHECK_HIP(hipEventCreateWithFlags(&c->x_ready, hipEventDisableTiming));
+  TG_CHECK_HIP(hipEventCreateWithFlags(&c->x_done, hipEventDisableTiming));
+  return 0;
+}
+
+// staging layout of the host variant: [send_lo | send_hi | recv_lo (halo_lo) | recv_hi (halo_hi)]
+int tg_comm_halo_begin(tg_comm_s *c, double *xext) {
   if (!c || c->world == 1) return 0;
   TG_REQUIRE(c->slab_set, "tg_comm_set_slab() has not been called");
+  TG_REQUIRE(!c->x_open, "tg_comm_halo_begin: the previous exchange has not been ended");
+  TG_TRY(tg_comm_xstream(c));
   double *own = xext + c->halo_lo;
   const int64_t nloc = c->g1 - c->g0;
+  // the exchange stream starts from the state of the current stream
+  TG_CHECK_HIP(hipEventRecord(c->x_ready, g_tg.stream));
+  TG_CHECK_HIP(hipStreamWaitEvent(c->xstream, c->x_ready, 0));
   if (c->kind == 1) {
-    // staging layout: [send_lo | send_hi | recv_lo (halo_lo) | recv_hi (halo_hi)]
     const int64_t total = c->send_lo + c->send_hi + c->halo_lo + c->halo_hi;
     TG_TRY(tg_comm_stage_reserve(c, std::max<int64_t>(total, 64)));
-    double *s_lo = c->stage, *s_hi = s_lo + c->send_lo, *r_lo = s_hi + c->send_hi, *r_hi = r_lo + c->halo_lo;
+    double *s_lo = c->stage, *s_hi = s_lo + c->send_lo;
     if (c->send_lo > 0)
-      TG_CHECK_HIP(hipMemcpyAsync(s_lo, own, (size_t)c->send_lo * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
+      TG_CHECK_HIP(hipMemcpyAsync(s_lo, own, (size_t)c->send_lo * sizeof(double), hipMemcpyDeviceToHost, c->xstream));
     if (c->send_hi > 0)
       TG_CHECK_HIP(hipMemcpyAsync(s_hi, own + nloc - c->send_hi, (size_t)c->send_hi * sizeof(double),
-                                  hipMemcpyDeviceToHost, g_tg.stream));
-    TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
-    // lower neighbour first, then the upper one: the chain rank 0 <-> 1, 1 <-> 2, ... cannot dead-lock
-    // because every exchange sends and receives at once
-    if (c->rank > 0 && (c->send_lo > 0 || c->halo_lo > 0))
-      TG_REQUIRE(c->h_sendrecv(c->h_ctx, c->rank - 1, s_lo, c->send_lo, r_lo, c->halo_lo) == 0,
-                 "host transport: exchange with rank %d failed", c->rank - 1);
-    if (c->rank < c->world - 1 && (c->send_hi > 0 || c->halo_hi > 0))
-      TG_REQUIRE(c->h_sendrecv(c->h_ctx, c->rank + 1, s_hi, c->send_hi, r_hi, c->halo_hi) == 0,
-                 "host transport: exchange with rank %d failed", c->rank + 1);
-    if (c->halo_lo > 0)
-      TG_CHECK_HIP(hipMemcpyAsync(xext, r_lo, (size_t)c->halo_lo * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
-    if (c->halo_hi > 0)
-      TG_CHECK_HIP(hipMemcpyAsync(own + nloc, r_hi, (size_t)c->halo_hi * sizeof(double), hipMemcpyHostToDevice,
-                                  g_tg.stream));
-    TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+                                  hipMemcpyDeviceToHost, c->xstream));
+    c->x_open = true;
     return 0;
   }
   TG_CHECK_NCCL(ncclGroupStart());
@@ -193,20 +201,54 @@ int tg_comm_halo_exchange(tg_comm_s *c, double *xext) {
     if (r != ncclSuccess && first == ncclSuccess) first = r;
   };
   if (c->rank > 0) {
-    if (c->send_lo > 0) note(ncclSend(own, (size_t)c->send_lo, ncclDouble, c->rank - 1, c->comm, g_tg.stream));
-    if (c->halo_lo > 0) note(ncclRecv(xext, (size_t)c->halo_lo, ncclDouble, c->rank - 1, c->comm, g_tg.stream));
+    if (c->send_lo > 0) note(ncclSend(own, (size_t)c->send_lo, ncclDouble, c->rank - 1, c->comm, c->xstream));
+    if (c->halo_lo > 0) note(ncclRecv(xext, (size_t)c->halo_lo, ncclDouble, c->rank - 1, c->comm, c->xstream));
   }
   if (c->rank < c->world - 1) {
     if (c->send_hi > 0)
-      note(ncclSend(own + nloc - c->send_hi, (size_t)c->send_hi, ncclDouble, c->rank + 1, c->comm, g_tg.stream));
-    if (c->halo_hi > 0) note(ncclRecv(own + nloc, (size_t)c->halo_hi, ncclDouble, c->rank + 1, c->comm, g_tg.stream));
+      note(ncclSend(own + nloc - c->send_hi, (size_t)c->send_hi, ncclDouble, c->rank + 1, c->comm, c->xstream));
+    if (c->halo_hi > 0) note(ncclRecv(own + nloc, (size_t)c->halo_hi, ncclDouble, c->rank + 1, c->comm, c->xstream));
   }
   note(ncclGroupEnd());
   if (first != ncclSuccess) {
     tg_set_error("halo exchange (rank %d): %s", c->rank, ncclGetErrorString(first));
     return 1;
   }
+  c->x_open = true;
   return 0;
+}
+
+int tg_comm_halo_end(tg_comm_s *c, double *xext) {
+  if (!c || c->world == 1) return 0;
+  TG_REQUIRE(c->x_open, "tg_comm_halo_end without tg_comm_halo_begin");
+  c->x_open = false;
+  if (c->kind == 1) {
+    double *own = xext + c->halo_lo;
+    const int64_t nloc = c->g1 - c->g0;
+    double *s_lo = c->stage, *s_hi = s_lo + c->send_lo, *r_lo = s_hi + c->send_hi, *r_hi = r_lo + c->halo_lo;
+    TG_CHECK_HIP(hipStreamSynchronize(c->xstream));
+    // lower neighbour first, then the upper one: the chain rank 0 <-> 1, 1 <-> 2, ... cannot dead-lock
+    // because every exchange sends and receives at once
+    if (c->rank > 0 && (c->send_lo > 0 || c->halo_lo > 0))
+      TG_REQUIRE(c->h_sendrecv(c->h_ctx, c->rank - 1, s_lo, c->send_lo, r_lo, c->halo_lo) == 0,
+                 "host transport: exchange with rank %d failed", c->rank - 1);
+    if (c->rank < c->world - 1 && (c->send_hi > 0 || c->halo_hi > 0))
+      TG_REQUIRE(c->h_sendrecv(c->h_ctx, c->rank + 1, s_hi, c->send_hi, r_hi, c->halo_hi) == 0,
+                 "host transport: exchange with rank %d failed", c->rank + 1);
+    if (c->halo_lo > 0)
+      TG_CHECK_HIP(hipMemcpyAsync(xext, r_lo, (size_t)c->halo_lo * sizeof(double), hipMemcpyHostToDevice, c->xstream));
+    if (c->halo_hi > 0)
+      TG_CHECK_HIP(hipMemcpyAsync(own + nloc, r_hi, (size_t)c->halo_hi * sizeof(double), hipMemcpyHostToDevice,
+                                  c->xstream));
+  }
+  TG_CHECK_HIP(hipEventRecord(c->x_done, c->xstream));
+  TG_CHECK_HIP(hipStreamWaitEvent(g_tg.stream, c->x_done, 0));
+  return 0;
+}
+
+int tg_comm_halo_exchange(tg_comm_s *c, double *xext) {
+  TG_TRY(tg_comm_halo_begin(c, xext));
+  return tg_comm_halo_end(c, xext);
 }
 
 extern "C" int tg_comm_halo_extend(tg_comm_t c, tg_vec_t x_local, tg_vec_t xext) {

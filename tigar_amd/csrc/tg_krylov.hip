@@ -258,6 +258,24 @@ struct tg_cg_ring {     // per-iteration events: norm history copies and SpMV ti
   }
 };
 
+// out[0] = 1 + the last row with an entry left of column c_lo, out[1] = the first row with an entry at or right of
+// column c_hi (rows in canonical form: ascending columns); out preset to {0, n}
+__global__ void __launch_bounds__(256)
+    k_halo_rows(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t n, int64_t c_lo,
+                int64_t c_hi, int *out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int lo = 0, hi = 0x7fffffff;
+  for (; i < n; i += stride) {
+    const int64_t a = rowptr[i], e = rowptr[i + 1];
+    if (e <= a) continue;
+    if ((int64_t)col[a] < c_lo) lo = max(lo, (int)i + 1);
+    if ((int64_t)col[e - 1] >= c_hi) hi = min(hi, (int)i);
+  }
+  if (lo > 0) atomicMax(&out[0], lo);
+  if (hi != 0x7fffffff) atomicMin(&out[1], hi);
+}
+
 static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, int nonzero_guess,
                  tg_comm_s *comm, int *iters, double *resnorm, int *status) {
   const int64_t n = k->nrows;
@@ -314,11 +332,46 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
                        n, part_gn);
   }
   TG_LAUNCH_CHECK();
+  // Rows [in0, in1) of this block have no entry in a halo column: their part of the product runs while the halo of u
+  // is exchanged on the communicator's stream; the rows at the two ends follow when it has arrived.  (Needs the
+  // sliced copy, whose launches can be restricted to row ranges; TIGAR_CG_OVERLAP=0 keeps the exchange in front.)
+  int64_t in0 = 0, in1 = 0;
+  static int overlap_on = getenv("TIGAR_CG_OVERLAP") ? atoi(getenv("TIGAR_CG_OVERLAP")) : 1;
+  if (comm && comm->world > 1 && overlap_on && k->sell_state == 1 && k->sell && n > 0 && n < 0x7fffffffll) {
+    int *d_ends = (int *)(g_tg.scratch + TG_SCRATCH_DOUBLES - 2048 + 64);
+    const int ends0[2] = {0, (int)n};
+    int ends[2];
+    TG_CHECK_HIP(hipMemcpyAsync(d_ends, ends0, sizeof(ends0), hipMemcpyHostToDevice, g_tg.stream));
+    hipLaunchKernelGGL(k_halo_rows, dim3(vg), dim3(256), 0, g_tg.stream, k->rowptr, k->col, n, row0, row0 + n, d_ends);
+    TG_LAUNCH_CHECK();
+    TG_CHECK_HIP(hipMemcpyAsync(ends, d_ends, sizeof(ends), hipMemcpyDeviceToHost, g_tg.stream));
+    TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+    const int64_t C = tg_sell_slice_rows();
+    in0 = tg_cdiv((int64_t)ends[0], C) * C;
+    in1 = ((int64_t)ends[1] / C) * C;
+    if (in1 <= in0) in0 = in1 = 0;
+    if (getenv("TIGAR_TRACE"))
+      fprintf(stderr, "[trace] cg rank %d: rows without halo columns [%lld, %lld) of %lld\n", comm->rank, (long long)in0,
+              (long long)in1, (long long)n);
+  }
+  auto product = [&]() -> int {
+    if (in1 > in0) {
+      TG_TRY(tg_comm_halo_begin(comm, uext));
+      int rc = tg_sell_spmv_rows(k, ushift, cmin, cmax, w, in0, in1);
+      TG_TRY(tg_comm_halo_end(comm, uext));      // (also after a failed launch: the exchange is collective)
+      TG_TRY(rc);
+      TG_TRY(tg_sell_spmv_rows(k, ushift, cmin, cmax, w, 0, in0));
+      TG_TRY(tg_sell_spmv_rows(k, ushift, cmin, cmax, w, in1, n));
+      g_tg.prof_n[TG_PROF_KSP_OVERLAPPED] += 1;
+      return 0;
+    }
+    TG_TRY(tg_comm_halo_exchange(comm, uext));
+    return tg_spmv_raw(k, ushift, cmin, cmax, w);
+  };
   // w = K u, delta; scalars of parity 0
   auto product_and_reduce = [&](tg_cg_scal *cur, int slot) -> int {
-    TG_TRY(tg_comm_halo_exchange(comm, uext));
     hipEventRecord(ring.t0[slot], g_tg.stream);
-    TG_TRY(tg_spmv_raw(k, ushift, cmin, cmax, w));
+    TG_TRY(product());
     hipEventRecord(ring.t1[slot], g_tg.stream);
     hipLaunchKernelGGL(k_cg1_dot, dim3(vg), dim3(256), 0, g_tg.stream, w, u, n, part_d);
     hipLaunchKernelGGL(k_cg1_fold, dim3(1), dim3(256), 0, g_tg.stream, part_gn, part_d, vg, cur);

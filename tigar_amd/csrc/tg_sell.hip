@@ -344,12 +344,12 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     k_spmv_sell(const int64_t *__restrict__ slice_addr, const int32_t *__restrict__ slice_cls,
                 const int32_t *__restrict__ cls_w, const int32_t *__restrict__ cls_off, const double *__restrict__ x,
-                double *__restrict__ y, int64_t nrows, int64_t nslices, int cmin, int cmax) {
+                double *__restrict__ y, int64_t nrows, int64_t s_begin, int64_t s_end, int cmin, int cmax) {
   const int lane = threadIdx.x & 63;
-  const int64_t nwb = (nslices + 3) >> 2;                      // workgroups of 4 slices
+  const int64_t nwb = (s_end - s_begin + 3) >> 2;              // workgroups of 4 slices (of the range [s_begin, s_end))
   const int64_t Lb = tg_xcd_block(blockIdx.x, nwb);
-  const int64_t s = __builtin_amdgcn_readfirstlane((int)(Lb * 4 + (threadIdx.x >> 6)));
-  if (Lb >= nwb || s >= nslices) return;
+  const int64_t s = __builtin_amdgcn_readfirstlane((int)(s_begin + Lb * 4 + (threadIdx.x >> 6)));
+  if (Lb >= nwb || s >= s_end) return;
   const int id = slice_cls[s];
   const int w = cls_w[id];
   const int32_t *__restrict__ U = cls_off + (int64_t)id * TG_SELL_WMAX;
@@ -394,12 +394,23 @@ __global__ void __launch_bounds__(256)
   if (r < nrows) y[r] = sum;
 }
 
+int64_t tg_sell_slice_rows(void) { return TG_SELL_C; }
+
 int tg_sell_spmv(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y) {
+  return tg_sell_spmv_rows(a, x_shifted, cmin, cmax, y, 0, a->nrows);
+}
+
+// rows [r0, r1) only; r0 a multiple of the slice height (the callers split at slice boundaries)
+int tg_sell_spmv_rows(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y, int64_t r0,
+                      int64_t r1) {
   tg_sell_s *S = a->sell;
-  const int64_t nwb = (S->nslices + 3) / 4;
+  TG_REQUIRE(r0 >= 0 && r1 <= a->nrows && r0 % TG_SELL_C == 0, "tg_sell_spmv_rows: bad row range");
+  if (r1 <= r0) return 0;
+  const int64_t s0 = r0 / TG_SELL_C, s1 = std::min<int64_t>(tg_cdiv(r1, TG_SELL_C), S->nslices);
+  const int64_t nwb = (s1 - s0 + 3) / 4;
   const unsigned grid = (unsigned)(((nwb + 7) / 8) * 8);
   hipLaunchKernelGGL(k_spmv_sell, dim3(grid), dim3(256), 0, g_tg.stream, S->slice_addr, S->slice_cls, S->cls_w,
-                     S->cls_off, x_shifted, y, a->nrows, S->nslices, (int)cmin, (int)cmax);
+                     S->cls_off, x_shifted, y, std::min<int64_t>(r1, a->nrows), s0, s1, (int)cmin, (int)cmax);
   TG_LAUNCH_CHECK();
   return 0;
 }

@@ -521,6 +521,110 @@ int tg_csr_transpose_block(tg_csr_s *m, int64_t row_base, int64_t out_ncols, tg_
   return 0;
 }
 
+// ----------------------------------------------------------------------------------------
+// IGA dof permutation (tIGAr/common.py:407-433, 1583-1665)
+// ----------------------------------------------------------------------------------------
+__global__ void k_relabel_cols(const int32_t *__restrict__ col, const int32_t *__restrict__ new_of_old, int64_t nnz,
+                               int32_t *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) out[i] = new_of_old[col[i]];
+}
+
+// Copy of m with column c renamed new_of_old[c] (a permutation of 0..ncols-1, host array) and the rows put back
+// into ascending column order: MatPermute with the identity on the rows, as applyPermutation uses it.
+extern "C" int tg_csr_permute_columns(tg_csr_t m, const int32_t *new_of_old, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(m && new_of_old && out, "null argument to tg_csr_permute_columns");
+  TG_REQUIRE_CANONICAL(m);
+  {
+    std::vector<char> seen((size_t)m->ncols, 0);
+    for (int64_t c = 0; c < m->ncols; c++) {
+      const int64_t t = new_of_old[c];
+      TG_REQUIRE(t >= 0 && t < m->ncols && !seen[(size_t)t], "tg_csr_permute_columns: not a permutation (entry %lld)",
+                 (long long)c);
+      seen[(size_t)t] = 1;
+    }
+  }
+  tg_csr_s *t = nullptr;
+  TG_TRY(tg_csr_alloc(m->nrows, m->ncols, m->nnz, &t));
+  int32_t *map = nullptr;
+  int rc = tg_dmalloc(&map, std::max<int64_t>(m->ncols, 1));
+  if (!rc && m->ncols > 0 &&
+      hipMemcpyAsync(map, new_of_old, (size_t)m->ncols * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess)
+    rc = 1;
+  if (!rc && hipMemcpyAsync(t->rowptr, m->rowptr, (size_t)(m->nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice,
+                            g_tg.stream) != hipSuccess)
+    rc = 1;
+  if (!rc && m->nnz > 0) {
+    if (hipMemcpyAsync(t->val, m->val, (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess)
+      rc = 1;
+    hipLaunchKernelGGL(k_relabel_cols, dim3(tg_grid_1d(m->nnz, 256)), dim3(256), 0, g_tg.stream, m->col, map, m->nnz,
+                       t->col);
+    if (!rc && hipGetLastError() != hipSuccess) rc = 1;
+    if (!rc) rc = tg_csr_sort_rows(t);
+  }
+  hipStreamSynchronize(g_tg.stream);
+  tg_dfree(map);
+  if (rc) {
+    tg_set_error("tg_csr_permute_columns failed");
+    tg_csr_destroy(t);
+    return 1;
+  }
+  *out = t;
+  return 0;
+}
+
+// One thread per row of mt (= an IGA dof; its columns are the FE rows of its support): counts of the owners of those
+// FE rows in the thread's own line of `cnt`, then the most frequent owner, the lowest rank on a tie like
+// scipy.stats.mode in the reference.  Serial per row, no atomics.
+__global__ void k_partition_mode(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nrows,
+                                 const int32_t *__restrict__ fe_owner, int world, int32_t *__restrict__ cnt,
+                                 int32_t *__restrict__ owner) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nrows; i += stride) {
+    int32_t *c = cnt + i * world;
+    for (int r = 0; r < world; r++) c[r] = 0;
+    for (int64_t q = rowptr[i]; q < rowptr[i + 1]; q++) c[fe_owner[col[q]]]++;
+    int best = 0;
+    for (int r = 1; r < world; r++)
+      if (c[r] > c[best]) best = r;
+    owner[i] = best;
+  }
+}
+
+extern "C" int tg_partition_mode(tg_csr_t mt, const int32_t *fe_owner, int world, int32_t *owner_out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(mt && fe_owner && owner_out && world >= 1, "bad arguments to tg_partition_mode");
+  for (int64_t j = 0; j < mt->ncols; j++)
+    TG_REQUIRE(fe_owner[j] >= 0 && fe_owner[j] < world, "tg_partition_mode: FE row %lld has owner %d of %d ranks",
+               (long long)j, (int)fe_owner[j], world);
+  if (mt->nrows == 0) return 0;
+  TG_REQUIRE(mt->nrows * (int64_t)world < (1ll << 32), "tg_partition_mode: %lld dofs x %d ranks is beyond the count table",
+             (long long)mt->nrows, world);
+  int32_t *own_fe = nullptr, *cnt = nullptr, *own = nullptr;
+  int rc = tg_dmalloc(&own_fe, std::max<int64_t>(mt->ncols, 1));
+  if (!rc) rc = tg_dmalloc(&cnt, mt->nrows * (int64_t)world);
+  if (!rc) rc = tg_dmalloc(&own, mt->nrows);
+  if (!rc && mt->ncols > 0 &&
+      hipMemcpyAsync(own_fe, fe_owner, (size_t)mt->ncols * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess)
+    rc = 1;
+  if (!rc) {
+    hipLaunchKernelGGL(k_partition_mode, dim3(tg_grid_1d(mt->nrows, 256)), dim3(256), 0, g_tg.stream, mt->rowptr, mt->col,
+                       mt->nrows, own_fe, world, cnt, own);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(owner_out, own, (size_t)mt->nrows * sizeof(int32_t), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess)
+      rc = 1;
+  }
+  if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
+  if (own_fe) tg_dfree(own_fe);
+  if (cnt) tg_dfree(cnt);
+  if (own) tg_dfree(own);
+  if (rc) tg_set_error("tg_partition_mode failed");
+  return rc;
+}
+
 extern "C" int tg_csr_transpose(tg_csr_t m, tg_csr_t *out) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(m && out, "null argument to tg_csr_transpose");

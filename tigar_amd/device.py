@@ -205,6 +205,26 @@ class DeviceCSR(object):
             self._T = DeviceCSR(h)
         return self._T
 
+    def permute_columns(self, new_of_old):
+        """copy with column c renamed ``new_of_old[c]`` and rows re-sorted (MatPermute with identity rows)"""
+        m = np.ascontiguousarray(new_of_old, dtype=np.int32)
+        if m.size != self.shape[1]:
+            raise ValueError("permute_columns: %d entries for %d columns" % (m.size, self.shape[1]))
+        h = handle()
+        check(_lib.lib().tg_csr_permute_columns(self._h, m.ctypes.data_as(c_i32p), C.byref(h)), "tg_csr_permute_columns")
+        return DeviceCSR(h)
+
+    def majority_owner(self, fe_owner, world):
+        """for every row (an IGA dof of a transposed extraction pattern) the rank owning most of its columns
+        (FE rows, owner given per column); lowest rank on ties (tg_partition_mode)"""
+        own = np.ascontiguousarray(fe_owner, dtype=np.int32)
+        if own.size != self.shape[1]:
+            raise ValueError("majority_owner: %d owners for %d columns" % (own.size, self.shape[1]))
+        out = np.zeros(self.shape[0], dtype=np.int32)
+        check(_lib.lib().tg_partition_mode(self._h, own.ctypes.data_as(c_i32p), int(world), out.ctypes.data_as(c_i32p)),
+              "tg_partition_mode")
+        return out
+
     def mult(self, x, y=None):
         """y = A x"""
         if y is None:
