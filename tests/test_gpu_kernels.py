@@ -451,6 +451,62 @@ def test_spmv_sliced_copy_matches_csr(dev):
     assert np.max(np.abs(y1 - ref) / scale) < 1e-14 and np.max(np.abs(y1 - y0) / scale) < 1e-14
 
 
+def test_sliced_copy_reuses_the_classes_of_an_equal_pattern(dev):
+    """Matrices that differ in their values only (a Newton loop, tIGAr/common.py:1304-1348) reuse the slice classes of
+    the first one (TG_PROF_SELL_SHAPE_REUSED counts it); a matrix of the same size with another pattern is found out
+    while its entries are placed -- its product is right and the stale classes are forgotten."""
+    if os.environ.get("TIGAR_SPMV_SELL") == "0" or os.environ.get("TIGAR_SELL_CACHE") == "0":
+        pytest.skip("sliced copy or its cache disabled")
+    rng = np.random.default_rng(23)
+    A = _stencil_matrix(rng, (17, 15, 13), 2)
+    x = rng.standard_normal(A.shape[1])
+    dx = dev.DeviceVector(data=x)
+    reused = lambda: dev.prof_get(2)[1]
+    dA = dev.DeviceCSR.from_scipy(A)
+    assert dA.spmv_sell(True)[0] > 0
+    y_first = dA.mult(dx).get_local()
+    n0 = reused()
+    B = A.copy()
+    B.data = rng.standard_normal(B.nnz)                       # same pattern, other values, another object
+    dB = dev.DeviceCSR.from_scipy(B)
+    shape_b = dB.spmv_sell(True)
+    assert shape_b == dA.spmv_sell(True) or shape_b[0] > 0
+    assert reused() >= n0 + 1
+    scale = np.abs(B) @ np.abs(x)
+    assert np.max(np.abs(dB.mult(dx).get_local() - B @ x) / scale) < 1e-14
+    # the copy built on reused classes is the copy a fresh classification gives: bit-identical products
+    dB2 = dev.DeviceCSR.from_scipy(B)
+    os.environ["TIGAR_SELL_CACHE"] = "0"                      # (read at every plan)
+    try:
+        n2 = reused()
+        dB2.spmv_sell(True)
+        assert reused() == n2
+    finally:
+        del os.environ["TIGAR_SELL_CACHE"]
+    assert np.array_equal(dB2.mult(dx).get_local(), dB.mult(dx).get_local())
+    # same nrows / ncols / nnz, one entry moved far away: not the same pattern
+    Cm = A.tolil()
+    r = A.shape[0] // 2
+    cols_r = A.indices[A.indptr[r]:A.indptr[r + 1]]
+    far = (cols_r[-1] + 1500) % A.shape[1]
+    assert far not in cols_r
+    Cm[r, cols_r[0]] = 0.0
+    Cm = Cm.tocsr()
+    Cm.eliminate_zeros()
+    Cm = Cm.tolil()
+    Cm[r, far] = 3.25
+    Cm = Cm.tocsr()
+    Cm.sort_indices()
+    assert Cm.nnz == A.nnz and Cm.shape == A.shape
+    dC = dev.DeviceCSR.from_scipy(Cm)
+    n1 = reused()
+    dC.spmv_sell(True)                                        # accepted with classes of its own, or declined
+    assert reused() == n1
+    scale = np.abs(Cm) @ np.abs(x)
+    assert np.max(np.abs(dC.mult(dx).get_local() - Cm @ x) / scale) < 1e-14
+    assert np.max(np.abs(dA.mult(dx).get_local() - y_first)) == 0
+
+
 def test_krylov_uses_sliced_copy_and_drops_it(dev):
     """K = M^T A M of a 3-D p=3 patch after MatZeroRowsColumns: the solvers take the products through the
     sliced copy (built per solve, gone afterwards); solution and iteration count agree with the solve on

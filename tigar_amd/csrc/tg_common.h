@@ -136,6 +136,7 @@ int tg_spmv_plan(tg_csr_s *a);
 int tg_spmv_raw(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y);
 int tg_sell_plan(tg_csr_s *a);          // tg_sell.hip
 void tg_sell_drop(tg_csr_s *a);
+void tg_sell_cache_clear(void);
 int tg_sell_spmv(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y);
 int64_t tg_sell_slice_rows(void);
 int tg_sell_spmv_rows(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y, int64_t r0,

@@ -81,6 +81,7 @@ extern "C" int tg_shutdown(void) {
   if (!g_tg.ready) return 0;
   for (int i = 0; i < 2; i++)
     if (g_tg.streams[i]) hipStreamSynchronize(g_tg.streams[i]);
+  tg_sell_cache_clear();
   tg_pool_trim();
   hipFree(g_tg.scratches[0]);
   if (g_tg.scratches[1]) hipFree(g_tg.scratches[1]);

@@ -24,6 +24,7 @@
 // (clamped, valid) x: it adds +0.0 to the row sum.
 #include "tg_common.h"
 #include <algorithm>
+#include <memory>
 #include <vector>
 
 #ifndef TG_SELL_UNROLL
@@ -39,31 +40,54 @@
 #define TG_SELL_WMAX 2048      // widest union pattern accepted
 #define TG_SELL_CAT 8192       // offsets of the distinct rows of a slice that are merged in LDS (power of two)
 
-struct tg_sell_s {
+// What depends on the PATTERN of the matrix only: the slice classes and the sizes of the value blocks.  Shared
+// between the copies of matrices with the same pattern and kept in a small cache (below), so that a Newton loop or a
+// sequence of solves whose matrices differ in their values only pays for the classification once.
+struct tg_sell_shape {
+  int64_t nrows = 0, ncols = 0, nnz = 0;   // of the matrix it was built from (the cache key)
   int64_t nslices = 0;
   int64_t padded = 0;            // doubles in val
+  int64_t *slice_ptr = nullptr;  // nslices + 1 prefix of the block sizes (doubles)
+  int32_t *slice_cls = nullptr;  // class id per slice
+  int32_t *cls_w = nullptr;      // width per class
+  int32_t *cls_off = nullptr;    // [class][TG_SELL_WMAX] sorted offsets
+  int nclasses = 0;
+  std::vector<int64_t> hptr;     // slice_ptr on the host
+  ~tg_sell_shape() {
+    if (!g_tg.ready) return;
+    tg_dfree(slice_ptr);
+    tg_dfree(slice_cls);
+    tg_dfree(cls_w);
+    tg_dfree(cls_off);
+  }
+};
+
+struct tg_sell_s {
+  std::shared_ptr<tg_sell_shape> shape;
+  int64_t nslices = 0;
+  int64_t padded = 0;
   // values: [slice][k][lane] blocks, stored in a few pieces -- idle blocks of the caching allocator's
   // pool first (tens of GB of PtAP temporaries sit there while the solve runs), one fresh allocation
   // for what is left -- so slices are addressed by pointer
   std::vector<void *> pieces;
-  int64_t *slice_ptr = nullptr;  // nslices + 1 prefix of the block sizes (doubles)
   int64_t *slice_addr = nullptr; // nslices device addresses of the blocks
-  int32_t *slice_cls = nullptr;  // class id per slice
-  int32_t *cls_w = nullptr;      // width per class
-  int32_t *cls_off = nullptr;    // [class][TG_SELL_WMAX] sorted offsets
+  // (of the shape)
+  int32_t *slice_cls = nullptr, *cls_w = nullptr, *cls_off = nullptr;
   int nclasses = 0;
 };
 
 void tg_sell_free(tg_sell_s *s) {
   if (!s) return;
   for (void *q : s->pieces) tg_dfree(q);
-  tg_dfree(s->slice_ptr);
   tg_dfree(s->slice_addr);
-  tg_dfree(s->slice_cls);
-  tg_dfree(s->cls_w);
-  tg_dfree(s->cls_off);
   delete s;
 }
+
+// the shapes used last (most recent first)
+static std::vector<std::shared_ptr<tg_sell_shape>> g_sell_shapes;
+#define TG_SELL_SHAPES 3
+
+void tg_sell_cache_clear(void) { g_sell_shapes.clear(); }
 
 __device__ __forceinline__ unsigned long long tg_sell_mix(unsigned long long z) {
   z *= 0x9E3779B97F4A7C15ull;
@@ -269,9 +293,12 @@ __global__ void __launch_bounds__(256)
   const int64_t s = blockIdx.x;
   const int id = slice_cls[s];
   const int w = cls_w[id];
-  if (w == 0) return;
-  for (int k = tid; k < w; k += 256) U[k] = cls_off[(int64_t)id * TG_SELL_WMAX + k];
   const int64_t r0 = s * TG_SELL_C;
+  if (w == 0) {     // a class without entries; a slice that has some does not belong to it (shape of another matrix)
+    if (tid == 0 && rowptr[min(r0 + (int64_t)TG_SELL_C, nrows)] > rowptr[r0]) atomicExch(fail, 1);
+    return;
+  }
+  for (int k = tid; k < w; k += 256) U[k] = cls_off[(int64_t)id * TG_SELL_WMAX + k];
   const int nr = (int)min((int64_t)TG_SELL_C, nrows - r0);
   const int64_t e0 = rowptr[r0];
   if (tid <= TG_SELL_C) rs[tid] = (int)(rowptr[r0 + min(tid, nr)] - e0);
@@ -415,19 +442,14 @@ int tg_sell_spmv_rows(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_
   return 0;
 }
 
-// Builds the plan if the matrix has the structure; a->sell_state: 1 = in use, -1 = declined.
-int tg_sell_plan(tg_csr_s *a) {
-  if (a->sell_state) return 0;
-  TG_REQUIRE_CANONICAL(a);
-  a->sell_state = -1;
-  static int enabled = getenv("TIGAR_SPMV_SELL") ? atoi(getenv("TIGAR_SPMV_SELL")) : 1;
-  if (!enabled || a->nrows < 1 || a->nnz < 1 || a->nrows >= 0x7fffffffll - 64 || a->ncols >= 0x7fffffffll) return 0;
+// ---- classification: the shape of the matrix' pattern, or declined
+static int tg_sell_classify(tg_csr_s *a, std::shared_ptr<tg_sell_shape> *out, bool *declined_out) {
   const int64_t nrows = a->nrows, nslices = tg_cdiv(nrows, TG_SELL_C);
   int *ctl = (int *)g_tg.scratch;   // [0] classes, [1] overflow, [2] conversion failure, [3] id counter
   unsigned long long *rowhash = nullptr, *keys = nullptr;
   int *rep = nullptr, *ids = nullptr;   // id_of_slot[TABLE] | rep_of_id[MAXCLASS]
   int32_t *slot_of_slice = nullptr;
-  tg_sell_s *S = new tg_sell_s;
+  std::shared_ptr<tg_sell_shape> S = std::make_shared<tg_sell_shape>();
   int rc = 0;
   bool declined = false;
   auto step = [&](int r) {
@@ -485,13 +507,61 @@ int tg_sell_plan(tg_csr_s *a) {
       declined = true;
       break;
     }
-    // ---- storage: pieces at slice granularity.  The prefix of the block sizes comes to the host (8 B
-    // per slice), pieces are cut where a block from the pool ends
-    std::vector<int64_t> hptr((size_t)nslices + 1);
-    if (!hip_ok(hipMemcpyAsync(hptr.data(), S->slice_ptr, sizeof(int64_t) * (size_t)(nslices + 1), hipMemcpyDeviceToHost,
-                               g_tg.stream)) ||
+    // the prefix of the block sizes comes to the host (8 B per slice): the storage is cut into pieces with it
+    S->hptr.resize((size_t)nslices + 1);
+    if (!hip_ok(hipMemcpyAsync(S->hptr.data(), S->slice_ptr, sizeof(int64_t) * (size_t)(nslices + 1),
+                               hipMemcpyDeviceToHost, g_tg.stream)) ||
         !hip_ok(hipStreamSynchronize(g_tg.stream)))
       break;
+    S->nrows = nrows;
+    S->ncols = a->ncols;
+    S->nnz = a->nnz;
+    S->nslices = nslices;
+    S->padded = padded;
+    S->nclasses = ncls;
+  } while (0);
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  tg_dfree(rowhash);
+  tg_dfree(keys);
+  tg_dfree(rep);
+  tg_dfree(ids);
+  tg_dfree(slot_of_slice);
+  *declined_out = declined;
+  if (!rc && !declined) *out = S;
+  return rc;
+}
+
+// ---- storage and conversion of the values for a given shape.  *mismatch: an entry of the matrix has no place in the
+// shape (a shape taken from the cache that belongs to another pattern, or a hash collision of the classification)
+static int tg_sell_store(tg_csr_s *a, const std::shared_ptr<tg_sell_shape> &shape, tg_sell_s **out, bool *declined_out,
+                         bool *mismatch) {
+  const int64_t nrows = a->nrows, nslices = shape->nslices;
+  int *ctl = (int *)g_tg.scratch;
+  tg_sell_s *S = new tg_sell_s;
+  S->shape = shape;
+  S->slice_cls = shape->slice_cls;
+  S->cls_w = shape->cls_w;
+  S->cls_off = shape->cls_off;
+  S->nslices = nslices;
+  S->padded = shape->padded;
+  S->nclasses = shape->nclasses;
+  const std::vector<int64_t> &hptr = shape->hptr;
+  int rc = 0;
+  bool declined = false;
+  *mismatch = false;
+  auto step = [&](int r) {
+    if (!rc && r) rc = r;
+    return rc == 0;
+  };
+  auto hip_ok = [&](hipError_t e) {
+    if (!rc && e != hipSuccess) {
+      tg_set_error("tg_sell_plan: %s", hipGetErrorString(e));
+      rc = 1;
+    }
+    return rc == 0;
+  };
+  do {
+    // ---- storage: pieces at slice granularity, cut where a block from the pool ends
     std::vector<int64_t> first, base;      // first slice and device address of every piece
     {
       static const bool use_pool = !(getenv("TIGAR_SELL_POOL") && atoi(getenv("TIGAR_SELL_POOL")) == 0);
@@ -549,6 +619,8 @@ int tg_sell_plan(tg_csr_s *a) {
           !hip_ok(hipStreamSynchronize(g_tg.stream)))
         break;
     }
+    int h[4] = {0, 0, 0, 0};
+    if (!hip_ok(hipMemcpyAsync(ctl, h, sizeof(h), hipMemcpyHostToDevice, g_tg.stream))) break;
     hipLaunchKernelGGL(k_sell_convert, dim3((unsigned)nslices), dim3(256), 0, g_tg.stream, a->rowptr, a->col,
                        a->val, nrows, nslices, S->slice_addr, S->slice_cls, S->cls_w, S->cls_off, ctl + 2);
     if (!hip_ok(hipGetLastError())) break;
@@ -556,22 +628,59 @@ int tg_sell_plan(tg_csr_s *a) {
         !hip_ok(hipStreamSynchronize(g_tg.stream)))
       break;
     if (h[2]) {
-      declined = true;   // an entry was not found in its slice's union: hash collision
+      *mismatch = true;   // an entry was not found in its slice's union
+      declined = true;
       break;
     }
-    S->nslices = nslices;
-    S->padded = padded;
-    S->nclasses = ncls;
   } while (0);
   if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
-  tg_dfree(rowhash);
-  tg_dfree(keys);
-  tg_dfree(rep);
-  tg_dfree(ids);
-  tg_dfree(slot_of_slice);
+  *declined_out = declined;
   if (rc || declined) {
     tg_sell_free(S);
     return rc;
+  }
+  *out = S;
+  return 0;
+}
+
+// Builds the plan if the matrix has the structure; a->sell_state: 1 = in use, -1 = declined.
+int tg_sell_plan(tg_csr_s *a) {
+  if (a->sell_state) return 0;
+  TG_REQUIRE_CANONICAL(a);
+  a->sell_state = -1;
+  static int enabled = getenv("TIGAR_SPMV_SELL") ? atoi(getenv("TIGAR_SPMV_SELL")) : 1;
+  const int cache_on = getenv("TIGAR_SELL_CACHE") ? atoi(getenv("TIGAR_SELL_CACHE")) : 1;
+  if (!enabled || a->nrows < 1 || a->nnz < 1 || a->nrows >= 0x7fffffffll - 64 || a->ncols >= 0x7fffffffll) return 0;
+  tg_sell_s *S = nullptr;
+  bool declined = false, mismatch = false;
+  // a shape of the same size from an earlier matrix: every entry is located in it during the conversion, so a shape
+  // that belongs to another pattern is found out there (and forgotten), never used
+  if (cache_on) {
+    for (size_t i = 0; i < g_sell_shapes.size() && !S; i++) {
+      std::shared_ptr<tg_sell_shape> sh = g_sell_shapes[i];
+      if (sh->nrows != a->nrows || sh->ncols != a->ncols || sh->nnz != a->nnz) continue;
+      TG_TRY(tg_sell_store(a, sh, &S, &declined, &mismatch));
+      if (mismatch) {
+        g_sell_shapes.erase(g_sell_shapes.begin() + (long)i);
+        i--;
+        continue;
+      }
+      if (declined) return 0;        // (no room for the values)
+      g_sell_shapes.erase(g_sell_shapes.begin() + (long)i);
+      g_sell_shapes.insert(g_sell_shapes.begin(), sh);
+      g_tg.prof_n[TG_PROF_SELL_SHAPE_REUSED] += 1;
+    }
+  }
+  if (!S) {
+    std::shared_ptr<tg_sell_shape> sh;
+    TG_TRY(tg_sell_classify(a, &sh, &declined));
+    if (declined) return 0;
+    TG_TRY(tg_sell_store(a, sh, &S, &declined, &mismatch));
+    if (declined) return 0;
+    if (cache_on) {
+      g_sell_shapes.insert(g_sell_shapes.begin(), sh);
+      if (g_sell_shapes.size() > TG_SELL_SHAPES) g_sell_shapes.pop_back();
+    }
   }
   a->sell = S;
   a->sell_state = 1;
