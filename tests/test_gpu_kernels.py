@@ -261,6 +261,16 @@ def test_kron_generator_matches_oracle_input(dev):
         n = A.shape[0]
         part = dev.kron_sum_csr(factors, n // 3, n - 2).to_scipy()
         assert abs(part - A[n // 3:n - 2]).max() <= 1e-13 * np.max(np.abs(A.data))
+        # the wave-per-row stream (default) and the thread-per-entry-group stream write the same matrix bit for bit
+        os.environ["TIGAR_KRON3_THREADS"] = "1"
+        try:
+            At = dev.kron_sum_csr(factors).to_scipy()
+            pt = dev.kron_sum_csr(factors, n // 3, n - 2).to_scipy()
+        finally:
+            del os.environ["TIGAR_KRON3_THREADS"]
+        for X, Y in ((Ad, At), (part, pt)):
+            assert np.array_equal(X.indptr, Y.indptr) and np.array_equal(X.indices, Y.indices)
+            assert np.array_equal(X.data, Y.data)
 
 
 @pytest.mark.parametrize("d,p,nel,method", [(2, 2, 16, "cg"), (2, 3, 12, "cg"), (3, 2, 8, "cg"),

@@ -177,6 +177,9 @@ def load(require_device=True, device=None):
                 "libtigar_hip.so not found at %s -- build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)"
                 % LIB_PATH)
+        # the host driver of the target boxes shares device memory between processes through dmabuf only; RCCL's
+        # intra-node transport needs this set before the HIP runtime starts (kept if the caller chose a value)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)      # AttributeError if a declared symbol is missing

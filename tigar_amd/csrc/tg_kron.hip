@@ -676,6 +676,134 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The same sum with one WAVE per row of the pencil: lanes <-> consecutive entries t = jk * n0 + i of the row, so a store
+// instruction of a wave is one contiguous 512-byte (values) / 256-byte (columns) run.
+//   * tables: one LDS line of NT+1 doubles per (j,k) combination of the pencil {w_0..w_NT-1, column offset} and one per
+//     1-D entry i of the wave's current row {x_0..x_NT-1, column}: two 16-byte LDS reads each at NT = 3, immediate offsets;
+//   * everything that is the same for the lanes of a wave (row, its length, its output address, the reciprocal) is forced
+//     into scalar registers (readfirstlane): the stores take a scalar base and a 32-bit lane offset;
+//   * jk = t / n0 is a multiply-shift (t < 2^12: exact with the 20-bit reciprocal);
+//   * the 1-D data of the wave's NEXT row are fetched while the current one is streamed.
+// History (31 GB launch, cfg3): thread per group of four entries with stepping decode 7.7 ms; this structure with 60 vector
+// instructions per entry (64-bit per-lane addresses, run-time table strides) 7.7 ms -- both bound by the vector ALU, not by
+// the stores (SQ_INSTS_VALU x 4 cycles = 78 % of the SIMD cycles of the launch); as written here (29 per entry) 6.2 ms
+// where the thread kernel takes 7.7 in the same process, 7.3 in a process whose buffers landed on slower memory (the
+// rate of a pure write stream is a property of the buffer: 5.6-6.7 TB/s, tools/mb/write_bw.hip); stores alone 5.5 ms.  Sums run over the terms in ascending order from
+// 0.0 like k_kron3_fill_sum: identical values.
+#define TG_KRON3_N0 16
+template <int NT, int TG_K3_Z>      // terms of the sum; entries per lane and pass
+__global__ void __launch_bounds__(256)
+    k_kron3_fill_sum_rows(tg_kron3_args A, int32_t *__restrict__ col, double *__restrict__ val) {
+  constexpr int S = NT + 1;                        // doubles per table line
+  extern __shared__ double s_jk[];                 // [slot][S]
+  __shared__ double s_xl[4][TG_KRON3_N0][S];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t pencil = A.row0 / A.n[0] + blockIdx.x;
+  if (pencil >= A.npencils) return;
+  const int64_t b = A.d > 1 ? pencil % A.n[1] : 0, c = A.d > 2 ? pencil / A.n[1] : 0;
+  const int y0 = A.d > 1 ? A.rp[1][b] : 0, n1 = A.d > 1 ? A.rp[1][b + 1] - y0 : 1;
+  const int z0 = A.d > 2 ? A.rp[2][c] : 0, n2 = A.d > 2 ? A.rp[2][c + 1] - z0 : 1;
+  const int n12 = n1 * n2;
+  for (int lc = tid; lc < n12; lc += 256) {
+    const int k = lc / n1, j = lc - k * n1;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      double w = 1.0;
+      if (A.d > 1) w *= A.cv[1][t * A.nnz1d[1] + y0 + j];
+      if (A.d > 2) w *= A.cv[2][t * A.nnz1d[2] + z0 + k];
+      s_jk[lc * S + t] = w;
+    }
+    int64_t cjk = A.col_offset;
+    if (A.d > 1) cjk += A.cstride[1] * (int64_t)A.ci[1][y0 + j];
+    if (A.d > 2) cjk += A.cstride[2] * (int64_t)A.ci[2][z0 + k];
+    s_jk[lc * S + NT] = __longlong_as_double(cjk);
+  }
+  __syncthreads();
+  const int64_t g0 = A.n[0] * pencil;
+  const int64_t a_lo = max((int64_t)0, A.row0 - g0), a_hi = min(A.n[0], A.row0 + A.nrows - g0);
+  if (a_hi <= a_lo || n12 == 0) return;
+  const int64_t base = tg_kron3_rowstart(A, 0, b, c) - A.out0;
+  int px0 = 0, pn0 = 0, pci = 0;
+  int64_t pps = 0;
+  double pcv[NT];
+  auto fetch = [&](int64_t a) {
+    px0 = A.rp[0][a];
+    pn0 = A.rp[0][a + 1] - px0;
+    pps = A.ps[0][a];
+    if (lane < pn0) {
+#pragma unroll
+      for (int u = 0; u < NT; u++) pcv[u] = A.cv[0][u * A.nnz1d[0] + px0 + lane];
+      pci = A.ci[0][px0 + lane];
+    }
+  };
+  if (a_lo + wave < a_hi) fetch(a_lo + wave);
+  for (int64_t a = a_lo + wave; a < a_hi; a += 4) {
+    const int n0 = __builtin_amdgcn_readfirstlane(pn0);
+    const int64_t ps_a = ((int64_t)__builtin_amdgcn_readfirstlane((int)(pps >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)pps);
+    // (the reads of the previous row are done before these writes: LDS operations of a wave execute in order)
+    if (lane < n0) {
+#pragma unroll
+      for (int u = 0; u < NT; u++) s_xl[wave][lane][u] = pcv[u];
+      s_xl[wave][lane][NT] = __longlong_as_double((int64_t)pci);
+    }
+    if (a + 4 < a_hi) fetch(a + 4);
+    if (n0 == 0) continue;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int tot = n0 * n12;
+    const unsigned magic = ((1u << 20) + (unsigned)n0 - 1u) / (unsigned)n0;
+    const int64_t rowbase = base + (int64_t)n12 * ps_a;
+    double *__restrict__ vrow = val + rowbase;
+    int32_t *__restrict__ crow = col + rowbase;
+    const double *xl = &s_xl[wave][0][0];
+    // TG_K3_Z entries per lane and pass: all LDS reads of a pass are issued before the first multiply waits.  Full
+    // passes run without bounds checks, the last partial one with them.
+    auto entry = [&](unsigned t, double &v_out, int32_t &c_out) {
+      const unsigned jk = __umul24(t, magic) >> 20, i = t - __umul24(jk, (unsigned)n0);
+      const double *pj = s_jk + jk * S, *pi = xl + i * S;
+      double xs[NT], ws[NT];
+#pragma unroll
+      for (int u = 0; u < NT; u++) {
+        xs[u] = pi[u];
+        ws[u] = pj[u];
+      }
+      c_out = (int32_t)__double_as_longlong(pi[NT]) + (int32_t)__double_as_longlong(pj[NT]);
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < NT; u++) acc += xs[u] * ws[u];
+      v_out = acc;
+    };
+    const int full = tot / (64 * TG_K3_Z);           // (scalar)
+    int t0 = lane;
+    for (int q = 0; q < full; q++, t0 += 64 * TG_K3_Z) {
+      double sum[TG_K3_Z];
+      int32_t cc[TG_K3_Z];
+#pragma unroll
+      for (int z = 0; z < TG_K3_Z; z++) entry((unsigned)(t0 + 64 * z), sum[z], cc[z]);
+#pragma unroll
+      for (int z = 0; z < TG_K3_Z; z++) {
+        crow[t0 + 64 * z] = cc[z];
+        vrow[t0 + 64 * z] = sum[z];
+      }
+    }
+#pragma unroll
+    for (int z = 0; z < TG_K3_Z; z++) {
+      const int t = t0 + 64 * z;
+      if (t < tot) {
+        double v;
+        int32_t cidx;
+        entry((unsigned)t, v, cidx);
+        crow[t] = cidx;
+        vrow[t] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0, int64_t row1,
                           int64_t col_offset, int64_t ncols_total, tg_csr_t *out);
 
@@ -788,6 +916,16 @@ static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const in
       if (nterms == 0)
         hipLaunchKernelGGL(k_kron3_fill, dim3((unsigned)(p_last - p_first + 1)), dim3(256), 0, g_tg.stream, A, d_rowof,
                            m->col, m->val);
+      else if (nterms <= 3 && maxn[0] <= TG_KRON3_N0 && (int64_t)maxn[0] * A.slot < (1 << 12) &&
+               !getenv("TIGAR_KRON3_THREADS")) {
+        const dim3 grid((unsigned)(p_last - p_first + 1));
+        const size_t lds = (size_t)(nterms + 1) * A.slot * sizeof(double);
+#define TG_K3_LAUNCH(NT, Z) hipLaunchKernelGGL((k_kron3_fill_sum_rows<NT, Z>), grid, dim3(256), lds, g_tg.stream, A, m->col, m->val)
+        if (nterms == 1) TG_K3_LAUNCH(1, 2);
+        else if (nterms == 2) TG_K3_LAUNCH(2, 2);
+        else TG_K3_LAUNCH(3, 2);      // (1, 2 or 4 entries per pass: equal within the spread, A/B inside one process)
+#undef TG_K3_LAUNCH
+      }
       else
         hipLaunchKernelGGL(k_kron3_fill_sum, dim3((unsigned)(p_last - p_first + 1)), dim3(256),
                            (size_t)(nterms + 1) * A.slot * sizeof(double), g_tg.stream, A, d_rowof, m->col, m->val);
