@@ -59,6 +59,22 @@ __global__ void __launch_bounds__(256) k_write_csr_rows(double *__restrict__ v, 
   }
 }
 
+// mixed streams: R reads of 16 B per lane for every write of 16 B (R = 0: pure write handled above; W = 0: pure read)
+template <int R, int W>
+__global__ void __launch_bounds__(256) k_mix(const d2 *__restrict__ in, d2 *__restrict__ out, int64_t n_vec, double *sink) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  d2 acc = {0.0, 0.0};
+  for (; i < n_vec; i += stride) {
+    d2 t = {1.0, 2.0};
+#pragma unroll
+    for (int r = 0; r < R; r++) t += in[i + (int64_t)r * n_vec];
+    if (W) out[i] = t;
+    else acc += t;
+  }
+  if (!W && acc.x == 12345.678) *sink = acc.y;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 int main(int argc, char **argv) {
@@ -148,6 +164,28 @@ int main(int argc, char **argv) {
       timeit(nm, [&] { hipLaunchKernelGGL(k_write_csr_rows, dim3((unsigned)(ne / chunk)), dim3(256), 0, st, v, c, chunk, rowlen, 1.0); });
     }
     launch_scale = 1.0;
+  }
+  {
+    // mixed traffic on the same buffer: the first R quarters are read, the last quarter written
+    const int64_t nq = n / 2 / 4;          // 16-byte vectors per quarter
+    d2 *in = (d2 *)o, *out = (d2 *)o + 3 * nq;
+    double *sink = o;
+    const int g = 256 * 64;
+    auto run = [&](const char *nm, double bytes, auto launch) {
+      launch();
+      hipStreamSynchronize(st);
+      hipEventRecord(e0, st);
+      for (int r = 0; r < 5; r++) launch();
+      hipEventRecord(e1, st);
+      hipEventSynchronize(e1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, e0, e1);
+      printf("%-52s %8.3f ms  %6.2f TB/s\n", nm, ms / 5, bytes / (ms / 5) / 1e9);
+    };
+    run("pure read (3 streams)", 3.0 * nq * 16, [&] { hipLaunchKernelGGL((k_mix<3, 0>), dim3(g), dim3(256), 0, st, in, out, nq, sink); });
+    run("copy (1 read : 1 write)", 2.0 * nq * 16, [&] { hipLaunchKernelGGL((k_mix<1, 1>), dim3(g), dim3(256), 0, st, in, out, nq, sink); });
+    run("2 reads : 1 write", 3.0 * nq * 16, [&] { hipLaunchKernelGGL((k_mix<2, 1>), dim3(g), dim3(256), 0, st, in, out, nq, sink); });
+    run("3 reads : 1 write", 4.0 * nq * 16, [&] { hipLaunchKernelGGL((k_mix<3, 1>), dim3(g), dim3(256), 0, st, in, out, nq, sink); });
   }
   hipFree(o);
   return 0;

@@ -1,0 +1,57 @@
+"""profiles/r2_roofline_table.md from the committed per-kernel durations (tools/kernel_trace.py --sum) and PMC byte counts
+(tools/pmc_hbm.py) of each workload.  usage: python tools/roofline_table.py > profiles/r2_roofline_table.md"""
+import json, os, re
+
+HERE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+WORK = [("cfg3 (256^3 p=3)", "r2_cfg3_kernel_stats.txt", "r2_cfg3_pmc_hbm.json"),
+        ("cfg2 (128^3 p=2)", "r2_cfg2_kernel_stats.txt", "r2_cfg2_pmc_hbm.json")]
+
+
+def short(name):
+    return re.sub(r"\s+", " ", name.strip())[:52]
+
+
+def main():
+    print("# Achieved HBM rates per kernel, round 2 (one MI355X)\n")
+    print("Per launch: average duration from `rocprofv3 --kernel-trace` (`r2_cfg*_kernel_stats.txt`, summarised from the trace\n"
+          "database by `tools/kernel_trace.py --sum`), HBM bytes from the PMC passes (`r2_cfg*_pmc_hbm.json`: FETCH_SIZE and\n"
+          "WRITE_SIZE in separate runs, reads x2 = the gfx950 correction of the guide, calibrated for 8 B/lane streams by\n"
+          "`k_cg1_dot` / `k_cg1_update`, DESIGN.md section 5).  Rate = (read + written) / duration, as a fraction of the 8 TB/s\n"
+          "HBM3E peak and of the ceiling a plain streaming kernel of the same read:write mix reaches on these boxes\n"
+          "(`r2_hbm_ceilings.txt`, `tools/mb/write_bw.hip`: pure read 6.2-6.4, pure write 5.9-6.6, mixed 5.1-5.3 TB/s; the\n"
+          "rate of a buffer depends on where it was placed, 5.6-6.7 for pure writes).  Durations and counters come from\n"
+          "different runs of the same command, so rows of kernels whose launches vary in size (sub-slabs) are averages.\n")
+    print("| workload | kernel | avg ms | read GB | written GB | TB/s | of 8 TB/s | of the streaming ceiling |")
+    print("|---|---|---|---|---|---|---|---|")
+    for label, fstats, fpmc in WORK:
+        dur = {}
+        for line in open(os.path.join(HERE, fstats)):
+            m = re.match(r"\s*(\S+)\s+(\d+) x\s+([\d.]+) ms total\s+([\d.]+) ms avg", line)
+            if m:
+                dur[m.group(1).replace(".kd", "")] = (int(m.group(2)), float(m.group(4)))
+        pmc = json.load(open(os.path.join(HERE, fpmc)))["kernels"]
+        for k in pmc:
+            name = k["kernel"]
+            key = None
+            for d in dur:
+                # mangled name in the stats file, demangled in the counter file: match on the bare function name
+                bare = re.match(r"(?:void )?([A-Za-z_0-9]+)", name).group(1)
+                if bare in d:
+                    key = d
+                    break
+            if key is None or k["launches"] == 0:
+                continue
+            n, ms = dur[key]
+            r, w = k["hbm_read_GB_total_corrected"] / k["launches"], k["hbm_write_GB_total"] / k["launches"]
+            if r + w < 0.05 or ms < 0.03:
+                continue
+            rate = (r + w) / ms
+            frac_w = w / (r + w)
+            ceiling = 6.3 if frac_w < 0.05 else (6.2 if frac_w > 0.95 else 5.2)
+            print("| %s | `%s` | %.3f | %.3f | %.3f | %.2f | %.0f %% | %.0f %% |" % (label, short(name), ms, r, w, rate, 100 * rate / 8.0,
+                                                                                  100 * rate / ceiling))
+        print("")
+
+
+if __name__ == "__main__":
+    main()
