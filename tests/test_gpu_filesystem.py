@@ -53,3 +53,50 @@ def test_extraction_directory_round_trip(tmp_path):
     os.remove(os.path.join(d, "extraction-data.npz"))
     with pytest.raises(IOError):
         t.ExtractedSpline(d, 4)
+
+
+def test_round_trip_of_generators_on_other_node_sets(tmp_path):
+    """writeExtraction / ExtractedSpline(dirname) for the node sets that are not one tensor grid: the Bezier-element
+    mesh of a Rhino T-spline and the multi-patch mesh of a MultiBSpline (the reference writes both through the same
+    generic code, tIGAr/common.py:435-502)."""
+    import tigar_amd as t
+    from tigar_amd import BSplines as B
+    from tigar_amd.RhinoTSplines import RhinoTSplineControlMesh
+    fname = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tspline_bicubic_patch.iga")
+    gens = [t.EqualOrderSpline(1, RhinoTSplineControlMesh(fname))]
+
+    patches = [B.BSpline([2, 2], [B.uniformKnots(2, 0., 3., 3), B.uniformKnots(2, 0., 1., 2)]),
+               B.BSpline([2, 2], [B.uniformKnots(2, -1., 1., 2), B.uniformKnots(2, 0., 2., 3)])]
+    mb = B.MultiBSpline(patches)
+
+    class CM(t.AbstractControlMesh):
+        def getScalarSpline(self):
+            return mb
+
+        def getNsd(self):
+            return 2
+
+        def getHomogeneousCoordinate(self, node, direction):
+            if direction == 2:
+                return 1.0
+            patch = 0 if node < mb.doffsets[1] else 1
+            s = patches[patch]
+            local = node - mb.doffsets[patch]
+            m0 = s.splines[0].getNcp()
+            idx = (local % m0, local // m0)
+            return s.splines[direction].greville(idx[direction]) + (2.0 * patch if direction == 0 else 0.0)
+    gens.append(t.EqualOrderSpline(1, CM()))
+
+    for k, gen in enumerate(gens):
+        gen.addZeroDofs(0, [0, 3])
+        d = str(tmp_path / ("extraction%d" % k))
+        gen.writeExtraction(d)
+        s_dir = t.ExtractedSpline(d, 4)
+        s_gen = t.ExtractedSpline(gen, 4)
+        assert type(s_dir.V.grids[0]) is type(s_gen.V.grids[0]) and s_dir.V.dim() == s_gen.V.dim()
+        assert np.array_equal(s_dir.V.grids[0].coordinates(), s_gen.V.grids[0].coordinates())
+        Ma, Mb = s_gen.M.to_scipy(), s_dir.M.to_scipy()
+        assert np.array_equal(Ma.indptr, Mb.indptr) and np.array_equal(Ma.indices, Mb.indices) and np.array_equal(Ma.data, Mb.data)
+        for a, b in zip(s_gen.cpFuncs, s_dir.cpFuncs):
+            assert np.array_equal(a.vector().get_local(), b.vector().get_local())
+        assert list(s_dir.zeroDofs) == [0, 3]

@@ -143,6 +143,46 @@ class MultiPatchNodeGrid(object):
         return numpy.vstack(out)
 
 
+def _grid_to_arrays(g, key, data):
+    """node grid -> entries of the ``extraction-data.npz`` archive under the prefix ``key`` (written by
+    ``writeExtraction``, read back by ``_grid_from_arrays``)"""
+    if isinstance(g, TensorNodeGrid):
+        data[key + "_kind"] = numpy.array("tensor")
+        data[key + "_degree"] = numpy.int64(g.degree)
+        data[key + "_dg"] = numpy.int64(1 if g.dg else 0)
+        data[key + "_dim"] = numpy.int64(g.dim())
+        for k in range(g.dim()):
+            data["%s_axis%d" % (key, k)] = numpy.asarray(g.axes[k])
+            data["%s_vert%d" % (key, k)] = numpy.asarray(g.vertices[k], dtype=numpy.float64)
+    elif isinstance(g, MultiPatchNodeGrid):
+        data[key + "_kind"] = numpy.array("multipatch")
+        data[key + "_npatches"] = numpy.int64(len(g.patches))
+        for i, gp in enumerate(g.patches):
+            _grid_to_arrays(gp, "%s_patch%d" % (key, i), data)
+    elif type(g).__name__ == "BezierElementNodeGrid":
+        data[key + "_kind"] = numpy.array("bezier")
+        data[key + "_nel"] = numpy.int64(g.nel)
+        data[key + "_degree"] = numpy.int64(g.degree)
+    else:
+        raise NotImplementedError("writeExtraction: node grid of type %s has no archive form" % type(g).__name__)
+
+
+def _grid_from_arrays(data, key):
+    kind = str(data[key + "_kind"]) if key + "_kind" in data else "tensor"       # (archives of round 1: tensor grids only)
+    if kind == "tensor":
+        dim = int(data[key + "_dim"])
+        return TensorNodeGrid([data["%s_axis%d" % (key, k)] for k in range(dim)],
+                              [data["%s_vert%d" % (key, k)] for k in range(dim)],
+                              int(data[key + "_degree"]), bool(int(data[key + "_dg"])))
+    if kind == "multipatch":
+        return MultiPatchNodeGrid([_grid_from_arrays(data, "%s_patch%d" % (key, i))
+                                   for i in range(int(data[key + "_npatches"]))])
+    if kind == "bezier":
+        from .RhinoTSplines import BezierElementNodeGrid
+        return BezierElementNodeGrid(int(data[key + "_nel"]), int(data[key + "_degree"]))
+    raise ValueError("extraction-data.npz: unknown node grid kind %r" % kind)
+
+
 class TensorFunctionSpace(object):
     """Stand-in for dolfin ``FunctionSpace``: ``nfields`` scalar Lagrange (or DG) fields
     on node grids that share one knot mesh.  Dofs are field-major, nodes lexicographic
@@ -453,12 +493,7 @@ class AbstractExtractionGenerator(object):
             data[name + "_ngrids"] = numpy.int64(len(V.grids))
             data[name + "_element"] = numpy.array(V.element)
             for gi, g in enumerate(V.grids):
-                data["%s_%d_degree" % (name, gi)] = numpy.int64(g.degree)
-                data["%s_%d_dg" % (name, gi)] = numpy.int64(1 if g.dg else 0)
-                data["%s_%d_dim" % (name, gi)] = numpy.int64(g.dim())
-                for k in range(g.dim()):
-                    data["%s_%d_axis%d" % (name, gi, k)] = numpy.asarray(g.axes[k])
-                    data["%s_%d_vert%d" % (name, gi, k)] = numpy.asarray(g.vertices[k], dtype=numpy.float64)
+                _grid_to_arrays(g, "%s_%d" % (name, gi), data)
         for i, f in enumerate(self.cpFuncs):
             data["control%d" % i] = f.vector().get_local()
         numpy.savez(os.path.join(dirname, EXTRACTION_DATA_NPZ), **data)
@@ -989,11 +1024,7 @@ class ExtractedSpline(object):
         def space(name):
             grids = []
             for gi in range(int(data[name + "_ngrids"])):
-                dim = int(data["%s_%d_dim" % (name, gi)])
-                axes = [data["%s_%d_axis%d" % (name, gi, k)] for k in range(dim)]
-                verts = [data["%s_%d_vert%d" % (name, gi, k)] for k in range(dim)]
-                grids.append(TensorNodeGrid(axes, verts, int(data["%s_%d_degree" % (name, gi)]),
-                                            bool(int(data["%s_%d_dg" % (name, gi)]))))
+                grids.append(_grid_from_arrays(data, "%s_%d" % (name, gi)))
             return TensorFunctionSpace(grids, str(data[name + "_element"]))
         self.mesh = mesh
         self.V_control = space("control")
