@@ -140,7 +140,7 @@ void tg_sell_cache_clear(void);
 int tg_sell_spmv(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y);
 int64_t tg_sell_slice_rows(void);
 int tg_sell_spmv_rows(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y, int64_t r0,
-                      int64_t r1);
+                      int64_t r1, const double *gate, double gate_tol);
 
 int tg_csr_sort_rows(tg_csr_s *m);
 int tg_csr_transpose_block(tg_csr_s *m, int64_t row_base, int64_t out_ncols, tg_csr_s **out);

@@ -332,6 +332,7 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
                        n, part_gn);
   }
   TG_LAUNCH_CHECK();
+  double tol2_dev = 0.0;        // the tolerance the gated products compare with (set once the reference norm is known)
   // Rows [in0, in1) of this block have no entry in a halo column: their part of the product runs while the halo of u
   // is exchanged on the communicator's stream; the rows at the two ends follow when it has arrived.  (Needs the
   // sliced copy, whose launches can be restricted to row ranges; TIGAR_CG_OVERLAP=0 keeps the exchange in front.)
@@ -354,24 +355,28 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
       fprintf(stderr, "[trace] cg rank %d: rows without halo columns [%lld, %lld) of %lld\n", comm->rank, (long long)in0,
               (long long)in1, (long long)n);
   }
-  auto product = [&]() -> int {
+  // `gate`: the norm (device) the update in front of this product tested; with that update frozen (converged while the
+  // host was still enqueueing) u is unchanged and so is w = K u: the launch returns at once
+  const bool sliced = k->sell_state == 1 && k->sell && n > 0;
+  auto product = [&](const double *gate) -> int {
     if (in1 > in0) {
       TG_TRY(tg_comm_halo_begin(comm, uext));
-      int rc = tg_sell_spmv_rows(k, ushift, cmin, cmax, w, in0, in1);
+      int rc = tg_sell_spmv_rows(k, ushift, cmin, cmax, w, in0, in1, gate, tol2_dev);
       TG_TRY(tg_comm_halo_end(comm, uext));      // (also after a failed launch: the exchange is collective)
       TG_TRY(rc);
-      TG_TRY(tg_sell_spmv_rows(k, ushift, cmin, cmax, w, 0, in0));
-      TG_TRY(tg_sell_spmv_rows(k, ushift, cmin, cmax, w, in1, n));
+      TG_TRY(tg_sell_spmv_rows(k, ushift, cmin, cmax, w, 0, in0, gate, tol2_dev));
+      TG_TRY(tg_sell_spmv_rows(k, ushift, cmin, cmax, w, in1, n, gate, tol2_dev));
       g_tg.prof_n[TG_PROF_KSP_OVERLAPPED] += 1;
       return 0;
     }
     TG_TRY(tg_comm_halo_exchange(comm, uext));
+    if (sliced && gate) return tg_sell_spmv_rows(k, ushift, cmin, cmax, w, 0, n, gate, tol2_dev);
     return tg_spmv_raw(k, ushift, cmin, cmax, w);
   };
   // w = K u, delta; scalars of parity 0
-  auto product_and_reduce = [&](tg_cg_scal *cur, int slot) -> int {
+  auto product_and_reduce = [&](tg_cg_scal *cur, int slot, const double *gate) -> int {
     hipEventRecord(ring.t0[slot], g_tg.stream);
-    TG_TRY(product());
+    TG_TRY(product(gate));
     hipEventRecord(ring.t1[slot], g_tg.stream);
     hipLaunchKernelGGL(k_cg1_dot, dim3(vg), dim3(256), 0, g_tg.stream, w, u, n, part_d);
     hipLaunchKernelGGL(k_cg1_fold, dim3(1), dim3(256), 0, g_tg.stream, part_gn, part_d, vg, cur);
@@ -388,7 +393,7 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
       g_tg.prof_n[TG_PROF_KSP_SPMV] += 1;
     }
   };
-  TG_TRY(product_and_reduce(&sc[0], 0));
+  TG_TRY(product_and_reduce(&sc[0], 0, nullptr));
   TG_CHECK_HIP(hipEventSynchronize(ring.done[0]));
   account(0);
   const double nu0 = hist[2];
@@ -397,6 +402,7 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
   const double tol = std::max(rtol * znorm0, atol);
   // host and device take the SAME decision: both compare nu = ||B r||^2 with this tol2
   const double tol2 = tol * tol;
+  tol2_dev = tol2;
   *iters = 0;
   *status = 0;
   *resnorm = znorm_init;
@@ -440,7 +446,7 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
     tg_cg_scal *cur = &sc[(it - 1) & 1], *nxt = &sc[it & 1];
     hipLaunchKernelGGL(k_cg1_update, dim3(vg), dim3(256), 0, g_tg.stream, cur, nxt, tol2, it == 1 ? 1 : 0, w, dinv, u, p,
                        s, x->d, r, n, part_gn);
-    TG_TRY(product_and_reduce(nxt, it % TG_CG_RING));
+    TG_TRY(product_and_reduce(nxt, it % TG_CG_RING, &cur->nu));
     if (it - look >= 1) stop = observe(it - look);
   }
   const int enq = it - 1;                       // iterations enqueued

@@ -371,7 +371,11 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     k_spmv_sell(const int64_t *__restrict__ slice_addr, const int32_t *__restrict__ slice_cls,
                 const int32_t *__restrict__ cls_w, const int32_t *__restrict__ cls_off, const double *__restrict__ x,
-                double *__restrict__ y, int64_t nrows, int64_t s_begin, int64_t s_end, int cmin, int cmax) {
+                double *__restrict__ y, int64_t nrows, int64_t s_begin, int64_t s_end, int cmin, int cmax,
+                const double *__restrict__ gate, double gate_tol) {
+  // (a solver that runs ahead of its convergence test gates the products it enqueues on the norm the device has by
+  // then: with the iteration frozen, x and therefore y = K x are what they were)
+  if (gate && !(*gate > gate_tol)) return;
   const int lane = threadIdx.x & 63;
   const int64_t nwb = (s_end - s_begin + 3) >> 2;              // workgroups of 4 slices (of the range [s_begin, s_end))
   const int64_t Lb = tg_xcd_block(blockIdx.x, nwb);
@@ -424,12 +428,13 @@ __global__ void __launch_bounds__(256)
 int64_t tg_sell_slice_rows(void) { return TG_SELL_C; }
 
 int tg_sell_spmv(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y) {
-  return tg_sell_spmv_rows(a, x_shifted, cmin, cmax, y, 0, a->nrows);
+  return tg_sell_spmv_rows(a, x_shifted, cmin, cmax, y, 0, a->nrows, nullptr, 0.0);
 }
 
-// rows [r0, r1) only; r0 a multiple of the slice height (the callers split at slice boundaries)
+// rows [r0, r1) only; r0 a multiple of the slice height (the callers split at slice boundaries).  With `gate` (device
+// pointer) the launch leaves y alone unless *gate > gate_tol.
 int tg_sell_spmv_rows(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y, int64_t r0,
-                      int64_t r1) {
+                      int64_t r1, const double *gate, double gate_tol) {
   tg_sell_s *S = a->sell;
   TG_REQUIRE(r0 >= 0 && r1 <= a->nrows && r0 % TG_SELL_C == 0, "tg_sell_spmv_rows: bad row range");
   if (r1 <= r0) return 0;
@@ -437,7 +442,7 @@ int tg_sell_spmv_rows(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_
   const int64_t nwb = (s1 - s0 + 3) / 4;
   const unsigned grid = (unsigned)(((nwb + 7) / 8) * 8);
   hipLaunchKernelGGL(k_spmv_sell, dim3(grid), dim3(256), 0, g_tg.stream, S->slice_addr, S->slice_cls, S->cls_w,
-                     S->cls_off, x_shifted, y, std::min<int64_t>(r1, a->nrows), s0, s1, (int)cmin, (int)cmax);
+                     S->cls_off, x_shifted, y, std::min<int64_t>(r1, a->nrows), s0, s1, (int)cmin, (int)cmax, gate, gate_tol);
   TG_LAUNCH_CHECK();
   return 0;
 }
