@@ -36,15 +36,36 @@ __global__ void __launch_bounds__(256) k_tt_check_rows(tt_check_args A, int64_t 
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && tt_check_row<P>(A, i)) atomicOr(status, 1);
 }
+// All (plane class, line class) combinations of a pass in ONE launch: every wave walks a whole line, so a launch ends with
+// a partly filled last round of waves (26.9 k waves on 4096 slots: 6.6 rounds); four launches pay that four times
+// (x+y over 36 planes at cfg3, both variants alternating inside one process: 12.36 vs 12.49 ms).
+// Workgroups [first[c], first[c+1]) belong to class c, x fastest; the classes with the widest windows come first.
+struct tt_x_multi {
+  tt_x_args c[4];
+  unsigned first[5], gx[4];
+  int n;
+};
+struct tt_y_multi {
+  tt_y_args c[2];
+  unsigned first[3], gx[2];
+  int n;
+};
 template <int P>
-__global__ void __launch_bounds__(64) k_tt_x(tt_x_args A) {
+__global__ void __launch_bounds__(64) k_tt_x_multi(tt_x_multi M) {
+  int c = 0;
+  while (c + 1 < M.n && blockIdx.x >= M.first[c + 1]) c++;
+  const tt_x_args &A = M.c[c];
   if (*(volatile int *)A.status) return;     // row lengths differ from the pattern: the closed-form addresses do not apply
-  const int bad = tt_x_lane<P>(A, blockIdx.x, blockIdx.y, threadIdx.x);
+  const unsigned local = blockIdx.x - M.first[c];
+  const int bad = tt_x_lane<P>(A, (int)(local % M.gx[c]), (int)(local / M.gx[c]), threadIdx.x);
   if (bad) atomicOr(A.status, 1);
 }
 template <int P>
-__global__ void __launch_bounds__(64) k_tt_y(tt_y_args A) {
-  tt_y_lane<P>(A, blockIdx.x, blockIdx.y, threadIdx.x);
+__global__ void __launch_bounds__(64) k_tt_y_multi(tt_y_multi M) {
+  int c = 0;
+  while (c + 1 < M.n && blockIdx.x >= M.first[c + 1]) c++;
+  const unsigned local = blockIdx.x - M.first[c];
+  tt_y_lane<P>(M.c[c], (int)(local % M.gx[c]), (int)(local / M.gx[c]), threadIdx.x);
 }
 template <int P>
 __global__ void __launch_bounds__(64) k_tt_z(tt_z_args A) {
@@ -203,58 +224,74 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
       TT_DISPATCH_P(P, TT_C);
 #undef TT_C
     }
-    // x pass: one launch per (plane class, line class)
-    for (int pc = 0; pc < 2; pc++) {
-      if (pls[pc].empty()) continue;
-      const int n2 = pc == 0 ? P + 1 : W;
-      for (int lc = 0; lc < 2; lc++) {
-        if (!pl->nlines1[lc]) continue;
-        const int n1 = lc == 0 ? P + 1 : W;
-        tt_x_args X;
-        X.rowptr = a->rowptr;
-        X.col = a->col;
-        X.val = a->val;
-        X.rps2 = D2.rps;
-        X.aplane0 = aplane0;
-        X.d0 = D0;
-        X.nfe1 = D1.nfe;
-        X.nfe2 = D2.nfe;
-        X.rps1 = D1.rps;
-        X.lines = pl->lines1[lc];
-        X.nlines = pl->nlines1[lc];
-        X.n1 = n1;
-        X.L = std::max(1, 64 / (n1 * n2));
-        X.planes = d_pl[pc];
-        X.n2 = n2;
-        X.b1 = b1;
-        X.pb1 = d_pb1;
-        X.z0 = z0;
-        X.status = pl->status;
-        const dim3 grid((unsigned)tg_cdiv(X.nlines, X.L), (unsigned)pls[pc].size());
-#define TT_X(PP) hipLaunchKernelGGL((k_tt_x<PP>), grid, dim3(64), 0, g_tg.stream, X)
+    // x pass: the (plane class, line class) combinations in one launch, widest windows first
+    {
+      tt_x_multi XM;
+      memset(&XM, 0, sizeof(XM));
+      for (int pc = 1; pc >= 0; pc--) {
+        if (pls[pc].empty()) continue;
+        const int n2 = pc == 0 ? P + 1 : W;
+        for (int lc = 1; lc >= 0; lc--) {
+          if (!pl->nlines1[lc]) continue;
+          const int n1 = lc == 0 ? P + 1 : W;
+          tt_x_args &X = XM.c[XM.n];
+          X.rowptr = a->rowptr;
+          X.col = a->col;
+          X.val = a->val;
+          X.rps2 = D2.rps;
+          X.aplane0 = aplane0;
+          X.d0 = D0;
+          X.nfe1 = D1.nfe;
+          X.nfe2 = D2.nfe;
+          X.rps1 = D1.rps;
+          X.lines = pl->lines1[lc];
+          X.nlines = pl->nlines1[lc];
+          X.n1 = n1;
+          X.L = std::max(1, 64 / (n1 * n2));
+          X.planes = d_pl[pc];
+          X.n2 = n2;
+          X.b1 = b1;
+          X.pb1 = d_pb1;
+          X.z0 = z0;
+          X.status = pl->status;
+          XM.gx[XM.n] = (unsigned)tg_cdiv(X.nlines, X.L);
+          XM.first[XM.n + 1] = XM.first[XM.n] + XM.gx[XM.n] * (unsigned)pls[pc].size();
+          XM.n++;
+        }
+      }
+      if (XM.n > 0 && XM.first[XM.n] > 0) {
+#define TT_X(PP) hipLaunchKernelGGL((k_tt_x_multi<PP>), dim3(XM.first[XM.n]), dim3(64), 0, g_tg.stream, XM)
         TT_DISPATCH_P(P, TT_X);
 #undef TT_X
       }
     }
-    // y pass: one launch per plane class
-    for (int pc = 0; pc < 2; pc++) {
-      if (pls[pc].empty()) continue;
-      const int n2 = pc == 0 ? P + 1 : W;
-      tt_y_args Y;
-      Y.b1 = b1;
-      Y.pb1 = d_pb1;
-      Y.b2 = res->buf;
-      Y.pb2 = d_pb2;
-      Y.z0 = z0;
-      Y.d1 = D1;
-      Y.ncp0 = D0.ncp;
-      Y.planes = d_pl[pc];
-      Y.n2 = n2;
-      Y.L = std::max(1, 64 / (W * n2));
-      const dim3 grid((unsigned)tg_cdiv(D0.ncp, Y.L), (unsigned)pls[pc].size());
-#define TT_Y(PP) hipLaunchKernelGGL((k_tt_y<PP>), grid, dim3(64), 0, g_tg.stream, Y)
-      TT_DISPATCH_P(P, TT_Y);
+    // y pass: both plane classes in one launch
+    {
+      tt_y_multi YM;
+      memset(&YM, 0, sizeof(YM));
+      for (int pc = 1; pc >= 0; pc--) {
+        if (pls[pc].empty()) continue;
+        const int n2 = pc == 0 ? P + 1 : W;
+        tt_y_args &Y = YM.c[YM.n];
+        Y.b1 = b1;
+        Y.pb1 = d_pb1;
+        Y.b2 = res->buf;
+        Y.pb2 = d_pb2;
+        Y.z0 = z0;
+        Y.d1 = D1;
+        Y.ncp0 = D0.ncp;
+        Y.planes = d_pl[pc];
+        Y.n2 = n2;
+        Y.L = std::max(1, 64 / (W * n2));
+        YM.gx[YM.n] = (unsigned)tg_cdiv(D0.ncp, Y.L);
+        YM.first[YM.n + 1] = YM.first[YM.n] + YM.gx[YM.n] * (unsigned)pls[pc].size();
+        YM.n++;
+      }
+      if (YM.n > 0 && YM.first[YM.n] > 0) {
+#define TT_Y(PP) hipLaunchKernelGGL((k_tt_y_multi<PP>), dim3(YM.first[YM.n]), dim3(64), 0, g_tg.stream, YM)
+        TT_DISPATCH_P(P, TT_Y);
 #undef TT_Y
+      }
     }
     if (hipGetLastError() != hipSuccess) {
       tg_set_error("tg_tensor_planes: kernel launch failed");
