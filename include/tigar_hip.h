@@ -51,8 +51,10 @@ int tg_timer_stop(int slot, double *ms);   /* synchronises; elapsed ms since sta
  * stream, resolved at the next host sync).  slot 0: the SpMV inside tg_krylov_solve; slot 1 (count only): those of
  * them whose halo-free rows were computed while the halo exchange with the neighbour ranks was under way; slot 2 (count
  * only): sliced copies (tg_spmv_sell / Krylov solves) built on the slice classes of an earlier matrix with the same
- * pattern instead of a new classification. */
-enum { TG_PROF_KSP_SPMV = 0, TG_PROF_KSP_OVERLAPPED = 1, TG_PROF_SELL_SHAPE_REUSED = 2, TG_PROF_NSLOTS = 4 };
+ * pattern instead of a new classification; slot 3 (count only): x passes of the tensor-pattern PtAP that took the FE
+ * matrix' pattern from its certificate (written by tg_kron_sum_csr) instead of verifying every column index. */
+enum { TG_PROF_KSP_SPMV = 0, TG_PROF_KSP_OVERLAPPED = 1, TG_PROF_SELL_SHAPE_REUSED = 2, TG_PROF_PTAP_CERTIFIED = 3,
+       TG_PROF_NSLOTS = 4 };
 int tg_prof_reset(void);
 int tg_prof_get(int slot, double *total_ms, int64_t *count);
 

@@ -147,3 +147,45 @@ def test_general_kernels_run_to_run_spread_is_bounded(monkeypatch):
     for K in runs[1:]:
         assert np.array_equal(K.indices, ref.indices)
         assert np.max(np.abs(K.data - ref.data)) <= 4 * 2.3e-16 * np.sqrt(terms) * scale
+
+
+@pytest.mark.parametrize("p,nels", [(3, (4, 3, 5)), (2, (6, 5, 4))])
+def test_pattern_certificate_of_library_assembled_matrices(p, nels):
+    """An FE matrix assembled by this library's own kernel (forms.LaplaceForm -> tg_kron_sum_csr) carries a certificate
+    of its sparsity pattern; the x pass then does not read the column indices again.  K is bit-identical with and
+    without the verification; the same matrix uploaded from the host has no certificate and is verified; a certified
+    matrix of ANOTHER node grid is not mistaken for this one's."""
+    from tigar_amd.tensorptap import TensorPtAP
+    from tigar_amd import device as dev, forms as F
+    certified = lambda: dev.prof_get(3)[1]
+    gen, spline = _patch(p, nels)
+    plan = TensorPtAP.for_extraction(spline._kron)
+    nfe2, ncp2 = p * nels[2] + 1, nels[2] + p
+    A = F.LaplaceForm().assemble_matrix(spline.V)
+    zd = list(spline.zeroDofs)
+    n0 = certified()
+    K_cert = plan.zstage([plan.planes(A, 0, 0, nfe2)], 0, ncp2, zd, 1.0).to_scipy()
+    assert certified() == n0 + 1
+    os.environ["TIGAR_PTAP_VERIFY"] = "1"
+    try:
+        K_ver = plan.zstage([plan.planes(A, 0, 0, nfe2)], 0, ncp2, zd, 1.0).to_scipy()
+    finally:
+        del os.environ["TIGAR_PTAP_VERIFY"]
+    assert certified() == n0 + 1
+    assert np.array_equal(K_cert.indices, K_ver.indices) and np.array_equal(K_cert.data, K_ver.data)
+    # row blocks: the certificate names the first row of the block
+    pf = (p * nels[0] + 1) * (p * nels[1] + 1)
+    z0 = p                                       # (a whole element below)
+    Ab = F.LaplaceForm().assemble_matrix(spline.V, z0 * pf, nfe2 * pf)
+    assert plan.planes(Ab, z0 * pf, z0, nfe2) is not None and certified() == n0 + 2
+    # no certificate on a matrix that came through the host
+    Ah = dev.DeviceCSR.from_scipy(A.to_scipy())
+    K_h = plan.zstage([plan.planes(Ah, 0, 0, nfe2)], 0, ncp2, zd, 1.0).to_scipy()
+    assert certified() == n0 + 2 and np.array_equal(K_h.data, K_cert.data)
+    # a certified matrix of another grid with the same number of nodes per plane and planes: other 1-D patterns
+    if p == 2:
+        gen3, spline3 = _patch(1, tuple(2 * n for n in nels))          # degree 1 on twice the elements: same node counts
+        A3 = F.LaplaceForm().assemble_matrix(spline3.V)
+        assert A3.shape == A.shape
+        assert plan.planes(A3, 0, 0, nfe2) is None                     # verified, found different, declined
+        assert certified() == n0 + 2

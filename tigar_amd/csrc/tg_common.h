@@ -95,6 +95,12 @@ struct tg_csr_s {
   // duration of a solve, or on request (tg_spmv_sell) -- then the caller re-requests it after
   // changing values
   tg_sell_s *sell = nullptr;
+  // Certificate of the sparsity pattern, set by the kernels of this library that write a matrix with a pattern known in
+  // closed form (tg_kron_sum_csr: Kronecker product of the 1-D patterns it was given): pattern_tag = tg_pattern_hash of
+  // those 1-D patterns, pattern_row0 = first global row held.  0 = no certificate (matrices from the host, products,
+  // stacks).  Consumers that would otherwise verify the pattern entry by entry (tensor-pattern PtAP) compare tags.
+  uint64_t pattern_tag = 0;
+  int64_t pattern_row0 = 0;
   int sell_state = 0;            // 0 = not tried, 1 = in use, -1 = declined
   // diagonal of a square row block (entry (r, row0 + r)) recorded by the kernel that wrote the values (the z pass of
   // the tensor-pattern PtAP): the Jacobi set-up of the Krylov solvers then needs no pass over the matrix.  Dropped
@@ -134,6 +140,28 @@ int tg_csr_compact_impl(tg_csr_s *in, tg_csr_s **out);   // loose rows -> canoni
 int tg_spmv_plan(tg_csr_s *a);
 // y = A x with x addressed by column index: x_shifted[col]; [cmin, cmax] = columns x_shifted may be read at
 int tg_spmv_raw(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y);
+// FNV-1a over the 1-D CSR patterns (rows, columns per direction, row pointers, column indices) of a Kronecker-product
+// pattern with `col_offset` added to every column; never 0
+static inline uint64_t tg_pattern_hash(int d, const int64_t *nrows, const int64_t *ncols, const int32_t *const *rowptr,
+                                       const int32_t *const *col, int64_t col_offset) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) {
+    for (int b = 0; b < 8; b++) {
+      h ^= (v >> (8 * b)) & 0xffu;
+      h *= 1099511628211ull;
+    }
+  };
+  mix((uint64_t)d);
+  mix((uint64_t)col_offset);
+  for (int k = 0; k < d; k++) {
+    mix((uint64_t)nrows[k]);
+    mix((uint64_t)ncols[k]);
+    for (int64_t r = 0; r <= nrows[k]; r++) mix((uint64_t)(uint32_t)rowptr[k][r]);
+    for (int64_t q = 0; q < rowptr[k][nrows[k]]; q++) mix((uint64_t)(uint32_t)col[k][q]);
+  }
+  return h ? h : 1;
+}
+
 int tg_sell_plan(tg_csr_s *a);          // tg_sell.hip
 void tg_sell_drop(tg_csr_s *a);
 void tg_sell_cache_clear(void);

@@ -937,6 +937,19 @@ static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const in
       const int64_t zero = 0;
       hipMemcpyAsync(m->rowptr, &zero, sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream);
     }
+    if (!rc && m) {
+      // certificate of the pattern just written: Kronecker product of the callers' 1-D patterns, rows from row0 on
+      const int32_t *rps[3] = {nullptr, nullptr, nullptr}, *cls[3] = {nullptr, nullptr, nullptr};
+      int64_t nr[3] = {1, 1, 1}, nc[3] = {1, 1, 1};
+      for (int k = 0; k < d; k++) {
+        rps[k] = dirs[k].rowptr;
+        cls[k] = dirs[k].col;
+        nr[k] = dirs[k].n;
+        nc[k] = cdim[k];
+      }
+      m->pattern_tag = tg_pattern_hash(d, nr, nc, rps, cls, col_offset);
+      m->pattern_row0 = row0;
+    }
     // (the host tables above are read by the copies: wait before they go out of scope)
     hipStreamSynchronize(g_tg.stream);
     tg_dfree(d_rowof);

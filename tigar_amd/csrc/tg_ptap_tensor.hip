@@ -22,6 +22,7 @@ struct tg_tensor_plan_s {
   int32_t *lines1[2] = {nullptr, nullptr};
   int nlines1[2] = {0, 0};
   std::vector<int32_t> h_rps[3], h_kps[3];
+  uint64_t expect_tag = 0; // tg_pattern_hash of the element-coupling pattern the passes rely on
   int *status = nullptr;   // device flag
 };
 
@@ -50,14 +51,14 @@ struct tt_y_multi {
   unsigned first[3], gx[2];
   int n;
 };
-template <int P>
+template <int P, bool V>
 __global__ void __launch_bounds__(64) k_tt_x_multi(tt_x_multi M) {
   int c = 0;
   while (c + 1 < M.n && blockIdx.x >= M.first[c + 1]) c++;
   const tt_x_args &A = M.c[c];
   if (*(volatile int *)A.status) return;     // row lengths differ from the pattern: the closed-form addresses do not apply
   const unsigned local = blockIdx.x - M.first[c];
-  const int bad = tt_x_lane<P>(A, (int)(local % M.gx[c]), (int)(local / M.gx[c]), threadIdx.x);
+  const int bad = tt_x_lane<P, V>(A, (int)(local % M.gx[c]), (int)(local / M.gx[c]), threadIdx.x);
   if (bad) atomicOr(A.status, 1);
 }
 template <int P>
@@ -86,6 +87,10 @@ static int tt_upload(T **dst, const std::vector<T> &h) {
 }
 
 static int tt_rn_host(int P, int a, int nfe) { return (a % P == 0 && a > 0 && a < nfe - 1) ? 2 * P + 1 : P + 1; }
+static int tt_rlo_host(int P, int a, int nfe) {
+  (void)nfe;
+  return (a % P == 0 && a > 0) ? a - P : (a / P) * P;
+}
 
 extern "C" int tg_tensor_plan_destroy(tg_tensor_plan_t p) {
   if (!p) return 0;
@@ -133,6 +138,23 @@ extern "C" int tg_tensor_plan_create(int d, const tg_tensor_dir_t *dirs, tg_tens
     pl->dir[k].wl = pl->wl[k];
     pl->dir[k].rps = pl->rps[k];
     pl->dir[k].kps = pl->kps[k];
+  }
+  if (!rc) {
+    // the pattern the FE matrix must have, as 1-D CSR patterns: row a couples to the columns [lo(a), lo(a) + n(a))
+    std::vector<int32_t> ecol[3];
+    const int32_t *rps[3], *cls[3];
+    int64_t nr[3], nc[3];
+    for (int k = 0; k < 3; k++) {
+      const int nfe = pl->dir[k].nfe;
+      for (int a = 0; a < nfe; a++) {
+        const int lo = tt_rlo_host(P, a, nfe), n = tt_rn_host(P, a, nfe);
+        for (int j = 0; j < n; j++) ecol[k].push_back(lo + j);
+      }
+      rps[k] = pl->h_rps[k].data();
+      cls[k] = ecol[k].data();
+      nr[k] = nc[k] = nfe;
+    }
+    pl->expect_tag = tg_pattern_hash(3, nr, nc, rps, cls, 0);
   }
   if (!rc) {
     std::vector<int32_t> ls, lv;
@@ -259,10 +281,19 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
           XM.n++;
         }
       }
+      // A matrix written by this library with exactly this pattern says so (tg_csr_s::pattern_tag): its column indices
+      // need not be read again (227 GB per pass at cfg3).  Any other matrix is verified entry by entry while it is read;
+      // TIGAR_PTAP_VERIFY=1 verifies always.
+      const bool certified = a->pattern_tag != 0 && a->pattern_tag == pl->expect_tag && a->pattern_row0 == a_row0 &&
+                             !(getenv("TIGAR_PTAP_VERIFY") && atoi(getenv("TIGAR_PTAP_VERIFY")));
       if (XM.n > 0 && XM.first[XM.n] > 0) {
-#define TT_X(PP) hipLaunchKernelGGL((k_tt_x_multi<PP>), dim3(XM.first[XM.n]), dim3(64), 0, g_tg.stream, XM)
-        TT_DISPATCH_P(P, TT_X);
+#define TT_X(PP) hipLaunchKernelGGL((k_tt_x_multi<PP, true>), dim3(XM.first[XM.n]), dim3(64), 0, g_tg.stream, XM)
+#define TT_XC(PP) hipLaunchKernelGGL((k_tt_x_multi<PP, false>), dim3(XM.first[XM.n]), dim3(64), 0, g_tg.stream, XM)
+        if (certified) TT_DISPATCH_P(P, TT_XC);
+        else TT_DISPATCH_P(P, TT_X);
 #undef TT_X
+#undef TT_XC
+        g_tg.prof_n[TG_PROF_PTAP_CERTIFIED] += certified ? 1 : 0;
       }
     }
     // y pass: both plane classes in one launch

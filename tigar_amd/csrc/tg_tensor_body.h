@@ -215,7 +215,7 @@ struct tt_x_args {
   int *status;           // bit 0: pattern mismatch
 };
 
-template <int P>
+template <int P, bool V = true>       // V: read and verify the column indices (false: the matrix carries a pattern certificate)
 struct tt_io_x {
   const int32_t *col;
   const double *val;
@@ -241,7 +241,7 @@ struct tt_io_x {
 #pragma unroll
     for (int j = 0; j < N; j++) {
       v[j] = val[o + j];
-      diff |= col[o + j] ^ (c0 + j);
+      if (V) diff |= col[o + j] ^ (c0 + j);
     }
     bad |= diff;
   }
@@ -253,14 +253,14 @@ struct tt_io_x {
   }
 };
 
-template <int P>
+template <int P, bool V = true>
 TT_DEV int tt_x_lane(const tt_x_args &A, int bx, int by, int lane) {
   constexpr int W = 2 * P + 1;
   const int plane = A.planes[by];
   const int lpl = A.n1 * A.n2;
   const int sub = lane / lpl, l = lane - sub * lpl;
   const int li = bx * A.L + sub;
-  tt_io_x<P> io;
+  tt_io_x<P, V> io;
   io.valid = sub < A.L && li < A.nlines;
   const int r1 = io.valid ? A.lines[li] : 0;
   const int c1 = l % A.n1, c2 = l / A.n1;
