@@ -164,6 +164,7 @@ def run(args, d, p, nel):
     nnzK_local, ncp_local = K.nnz, K.shape[0]
     nnzK = nnzK_local if dcomm is None else int(round(dcomm.allreduce_sum([float(nnzK_local)])[0]))
     spmv_ms, spmv_n = dev.prof_get(0)
+    ptap_certified = dev.prof_get(3)[1]                   # x passes that took A's pattern from its certificate
     sell_classes, sell_padded = K.spmv_sell(True)         # which product kernel the solver used
     K.spmv_sell(False)
     its = solver.last["iterations"]
@@ -194,6 +195,7 @@ def run(args, d, p, nel):
             "t_input": mean_stages.get("fe_input", 0.0), "t_input_in_timed_region": not a_resident,
             "t_input_pre": t_input_pre, "sub_planes": spline._slab.sub_planes if spline._slab is not None else None,
             "sell_classes": sell_classes, "sell_padded": sell_padded, "implicit_M": bool(getattr(gen.M, "is_implicit", False)),
+            "ptap_certified": int(ptap_certified),
             "comm_world": info[1], "comm_kind": info[2], "n_devices_used": min(info[1], ndev) if info[1] > 1 else 1}
 
 
@@ -371,6 +373,10 @@ def main():
                    "dofs": res["ncp"], "fe_rows": cnt["rows_fe"], "nnz_M": cnt["nnzM"], "nnz_A": cnt["nnzA"],
                    "nnz_K": res["nnzK"], "cg_iterations": res["iterations"],
                    "M_implicit": res["implicit_M"],
+                   "fe_matrix_pattern": ("certified by the assembly kernel that wrote it (tg_kron_sum_csr): the PtAP does not "
+                                         "re-read the column indices; TIGAR_PTAP_VERIFY=1 verifies them entry by entry, "
+                                         "+0.05 s per step at cfg3" if res.get("ptap_certified", 0) > 0
+                                         else "verified entry by entry while the PtAP reads it"),
                    "stages_s": {k: round(v, 6) for k, v in res["stages"].items()},
                    "fe_input_generation_s": round(res["t_input"], 6),
                    "fe_input_inside_timed_region": bool(res["t_input_in_timed_region"]),
