@@ -140,16 +140,14 @@ int tg_csr_compact_impl(tg_csr_s *in, tg_csr_s **out);   // loose rows -> canoni
 int tg_spmv_plan(tg_csr_s *a);
 // y = A x with x addressed by column index: x_shifted[col]; [cmin, cmax] = columns x_shifted may be read at
 int tg_spmv_raw(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y);
-// FNV-1a over the 1-D CSR patterns (rows, columns per direction, row pointers, column indices) of a Kronecker-product
+// multiplicative hash (FNV prime, word-wise) over the 1-D CSR patterns (rows, columns per direction, row pointers, column indices) of a Kronecker-product
 // pattern with `col_offset` added to every column; never 0
 static inline uint64_t tg_pattern_hash(int d, const int64_t *nrows, const int64_t *ncols, const int32_t *const *rowptr,
                                        const int32_t *const *col, int64_t col_offset) {
   uint64_t h = 1469598103934665603ull;
-  auto mix = [&](uint64_t v) {
-    for (int b = 0; b < 8; b++) {
-      h ^= (v >> (8 * b)) & 0xffu;
-      h *= 1099511628211ull;
-    }
+  auto mix = [&](uint64_t v) {       // (one multiply per word: this runs on tables of ~10^4 entries at every assembly call)
+    h = (h ^ v) * 1099511628211ull;
+    h ^= h >> 29;
   };
   mix((uint64_t)d);
   mix((uint64_t)col_offset);
@@ -165,6 +163,8 @@ static inline uint64_t tg_pattern_hash(int d, const int64_t *nrows, const int64_
 int tg_sell_plan(tg_csr_s *a);          // tg_sell.hip
 void tg_sell_drop(tg_csr_s *a);
 void tg_sell_cache_clear(void);
+void tg_kron_cache_clear(void);
+int tg_h2d_staged(void *dst, const void *src, size_t bytes);   // stream-ordered upload of a small host table, no wait
 int tg_sell_spmv(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y);
 int64_t tg_sell_slice_rows(void);
 int tg_sell_spmv_rows(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y, int64_t r0,

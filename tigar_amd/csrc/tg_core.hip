@@ -77,11 +77,56 @@ extern "C" int tg_stream_wait(int waiter, int waited) {
   return 0;
 }
 
+// ---- small host tables to the device in stream order, without waiting: the bytes are parked in a ring of pinned slots,
+// so the caller's array may go out of scope at once and the copy runs when the stream gets there.  A slot is reused only
+// after the copy that read it has completed (its event).  Larger tables take the waiting path.
+#define TG_STAGE_SLOTS 64
+#define TG_STAGE_BYTES (64 * 1024)
+static char *g_stage_buf = nullptr;
+static hipEvent_t g_stage_ev[TG_STAGE_SLOTS];
+static bool g_stage_used[TG_STAGE_SLOTS];
+static int g_stage_next = 0;
+
+int tg_h2d_staged(void *dst, const void *src, size_t bytes) {
+  if (bytes == 0) return 0;
+  if (bytes > TG_STAGE_BYTES) {
+    TG_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_tg.stream));
+    TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+    return 0;
+  }
+  if (!g_stage_buf) {
+    TG_CHECK_HIP(hipHostMalloc((void **)&g_stage_buf, (size_t)TG_STAGE_SLOTS * TG_STAGE_BYTES, hipHostMallocDefault));
+    for (int i = 0; i < TG_STAGE_SLOTS; i++) {
+      TG_CHECK_HIP(hipEventCreateWithFlags(&g_stage_ev[i], hipEventDisableTiming));
+      g_stage_used[i] = false;
+    }
+  }
+  const int slot = g_stage_next;
+  g_stage_next = (g_stage_next + 1) % TG_STAGE_SLOTS;
+  if (g_stage_used[slot]) TG_CHECK_HIP(hipEventSynchronize(g_stage_ev[slot]));
+  char *stage = g_stage_buf + (size_t)slot * TG_STAGE_BYTES;
+  memcpy(stage, src, bytes);
+  TG_CHECK_HIP(hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, g_tg.stream));
+  TG_CHECK_HIP(hipEventRecord(g_stage_ev[slot], g_tg.stream));
+  g_stage_used[slot] = true;
+  return 0;
+}
+
+static void tg_stage_release(void) {
+  if (!g_stage_buf) return;
+  for (int i = 0; i < TG_STAGE_SLOTS; i++) hipEventDestroy(g_stage_ev[i]);
+  hipHostFree(g_stage_buf);
+  g_stage_buf = nullptr;
+  g_stage_next = 0;
+}
+
 extern "C" int tg_shutdown(void) {
   if (!g_tg.ready) return 0;
   for (int i = 0; i < 2; i++)
     if (g_tg.streams[i]) hipStreamSynchronize(g_tg.streams[i]);
   tg_sell_cache_clear();
+  tg_kron_cache_clear();
+  tg_stage_release();
   tg_pool_trim();
   hipFree(g_tg.scratches[0]);
   if (g_tg.scratches[1]) hipFree(g_tg.scratches[1]);

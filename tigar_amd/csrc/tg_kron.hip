@@ -812,6 +812,54 @@ extern "C" int tg_kron3_csr(int d, const tg_kron_dir_t *dirs, const int64_t *cdi
   return tg_kron3_build(d, 0, dirs, cdim, row0, row1, col_offset, ncols_total, out);
 }
 
+// Device copies of the 1-D tables of the last few factor sets: a row-block producer calls tg_kron_sum_csr once per
+// sub-slab with the same factors, and the uploads (with the wait that keeps the host arrays alive) stood between the
+// kernels of consecutive sub-slabs.
+struct tg_kron3_tables {
+  uint64_t key = 0;
+  int d = 0, nval = 0;
+  int64_t n[3] = {0, 0, 0}, nnz1d[3] = {0, 0, 0};
+  void *dev[12] = {nullptr};
+  int32_t *rowof = nullptr;
+};
+static std::vector<tg_kron3_tables> g_k3_tables;
+#define TG_KRON3_TABLES 4
+
+static void tg_kron3_tables_free(tg_kron3_tables &t) {
+  if (!g_tg.ready) return;
+  for (int i = 0; i < 12; i++) tg_dfree(t.dev[i]);
+  tg_dfree(t.rowof);
+}
+
+void tg_kron_cache_clear(void) {
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  for (auto &t : g_k3_tables) tg_kron3_tables_free(t);
+  g_k3_tables.clear();
+}
+
+static uint64_t tg_kron3_key(int d, int nval, const tg_kron_dir_t *dirs) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) {
+    h = (h ^ v) * 1099511628211ull;
+    h ^= h >> 29;
+  };
+  mix((uint64_t)d);
+  mix((uint64_t)nval);
+  for (int k = 0; k < d; k++) {
+    const tg_kron_dir_t &D = dirs[k];
+    const int64_t nnz1 = D.rowptr[D.n];
+    mix((uint64_t)D.n);
+    for (int64_t r = 0; r <= D.n; r++) mix((uint64_t)(uint32_t)D.rowptr[r]);
+    for (int64_t q = 0; q < nnz1; q++) mix((uint64_t)(uint32_t)D.col[q]);
+    for (int64_t q = 0; q < nnz1 * nval; q++) {
+      uint64_t bits;
+      memcpy(&bits, &D.val[q], 8);
+      mix(bits);
+    }
+  }
+  return h ? h : 1;
+}
+
 // nterms == 0: single product with the reference's value order (extraction operators); nterms >= 1: Kronecker sum
 static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0, int64_t row1,
                           int64_t col_offset, int64_t ncols_total, tg_csr_t *out) {
@@ -829,9 +877,19 @@ static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const in
   void *dev[12] = {nullptr};
   int rc = 0;
   for (int k = 0; k < 3; k++) A.n[k] = 1;
+  for (int k = 0; k < d; k++)
+    TG_REQUIRE(dirs[k].n >= 1 && dirs[k].rowptr && dirs[k].col && dirs[k].val, "bad 1-D factor %d", k);
+  // tables of these factors already on the device?
+  const uint64_t key = tg_kron3_key(d, nval, dirs);
+  int hit = -1;
+  for (size_t i = 0; i < g_k3_tables.size() && hit < 0; i++) {
+    const tg_kron3_tables &t = g_k3_tables[i];
+    bool same = t.key == key && t.d == d && t.nval == nval;
+    for (int k = 0; k < d && same; k++) same = t.n[k] == dirs[k].n && t.nnz1d[k] == dirs[k].rowptr[dirs[k].n];
+    if (same) hit = (int)i;
+  }
   for (int k = 0; k < d && !rc; k++) {
     const tg_kron_dir_t &D = dirs[k];
-    TG_REQUIRE(D.n >= 1 && D.rowptr && D.col && D.val, "bad 1-D factor %d", k);
     const int64_t nnz1 = D.rowptr[D.n];
     A.n[k] = D.n;
     A.nnz1d[k] = nnz1;
@@ -850,18 +908,25 @@ static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const in
     int32_t *rp = nullptr, *cl = nullptr;
     double *vl = nullptr;
     int64_t *ps = nullptr;
-    rc = tg_dmalloc(&rp, D.n + 1) || tg_dmalloc(&cl, nnz1) || tg_dmalloc(&vl, nnz1 * nval) || tg_dmalloc(&ps, D.n + 1);
-    dev[4 * k] = rp;
-    dev[4 * k + 1] = cl;
-    dev[4 * k + 2] = vl;
-    dev[4 * k + 3] = ps;
-    if (rc) break;
-    hipMemcpyAsync(rp, D.rowptr, (size_t)(D.n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
-    if (nnz1) {
-      hipMemcpyAsync(cl, D.col, (size_t)nnz1 * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
-      hipMemcpyAsync(vl, D.val, (size_t)(nnz1 * nval) * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
+    if (hit >= 0) {
+      rp = (int32_t *)g_k3_tables[(size_t)hit].dev[4 * k];
+      cl = (int32_t *)g_k3_tables[(size_t)hit].dev[4 * k + 1];
+      vl = (double *)g_k3_tables[(size_t)hit].dev[4 * k + 2];
+      ps = (int64_t *)g_k3_tables[(size_t)hit].dev[4 * k + 3];
+    } else {
+      rc = tg_dmalloc(&rp, D.n + 1) || tg_dmalloc(&cl, nnz1) || tg_dmalloc(&vl, nnz1 * nval) || tg_dmalloc(&ps, D.n + 1);
+      dev[4 * k] = rp;
+      dev[4 * k + 1] = cl;
+      dev[4 * k + 2] = vl;
+      dev[4 * k + 3] = ps;
+      if (rc) break;
+      hipMemcpyAsync(rp, D.rowptr, (size_t)(D.n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+      if (nnz1) {
+        hipMemcpyAsync(cl, D.col, (size_t)nnz1 * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+        hipMemcpyAsync(vl, D.val, (size_t)(nnz1 * nval) * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
+      }
+      hipMemcpyAsync(ps, hps[k].data(), (size_t)(D.n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream);
     }
-    hipMemcpyAsync(ps, hps[k].data(), (size_t)(D.n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream);
     A.rp[k] = rp;
     A.ci[k] = cl;
     A.cv[k] = vl;
@@ -897,8 +962,8 @@ static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const in
       tg_set_error("tg_kron3_csr: more than %d (j,k) combinations per row", TG_KRON3_MAXJK);
       rc = 2;
     }
-    int32_t *d_rowof = nullptr;
-    if (!rc) {
+    int32_t *d_rowof = hit >= 0 ? g_k3_tables[(size_t)hit].rowof : nullptr;
+    if (!rc && hit < 0) {
       const tg_kron_dir_t &D0 = dirs[0];
       std::vector<int32_t> rowof((size_t)std::max<int64_t>(D0.rowptr[D0.n], 1), 0);
       for (int64_t r = 0; r < D0.n; r++)
@@ -950,9 +1015,33 @@ static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const in
       m->pattern_tag = tg_pattern_hash(d, nr, nc, rps, cls, col_offset);
       m->pattern_row0 = row0;
     }
-    // (the host tables above are read by the copies: wait before they go out of scope)
-    hipStreamSynchronize(g_tg.stream);
-    tg_dfree(d_rowof);
+    if (hit < 0) {
+      // (the host tables above are read by the copies: wait before they go out of scope)
+      hipStreamSynchronize(g_tg.stream);
+      if (!rc) {
+        // keep the device tables for the next call with these factors
+        tg_kron3_tables t;
+        t.key = key;
+        t.d = d;
+        t.nval = nval;
+        for (int k = 0; k < d; k++) {
+          t.n[k] = dirs[k].n;
+          t.nnz1d[k] = dirs[k].rowptr[dirs[k].n];
+        }
+        for (int i = 0; i < 12; i++) t.dev[i] = dev[i];
+        t.rowof = d_rowof;
+        if (g_k3_tables.size() >= TG_KRON3_TABLES) {
+          tg_kron3_tables_free(g_k3_tables.back());
+          g_k3_tables.pop_back();
+        }
+        g_k3_tables.insert(g_k3_tables.begin(), t);
+        for (int i = 0; i < 12; i++) dev[i] = nullptr;
+        d_rowof = nullptr;
+      }
+      tg_dfree(d_rowof);
+    } else if (hit > 0) {
+      std::swap(g_k3_tables[0], g_k3_tables[(size_t)hit]);     // most recent first
+    }
   } else
     hipStreamSynchronize(g_tg.stream);
   for (int i = 0; i < 12; i++) tg_dfree(dev[i]);

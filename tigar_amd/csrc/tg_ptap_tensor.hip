@@ -80,9 +80,7 @@ __global__ void __launch_bounds__(256) k_tt_rowptr(tt_rowptr_args A, int64_t n) 
 template <typename T>
 static int tt_upload(T **dst, const std::vector<T> &h) {
   TG_TRY(tg_dmalloc(dst, (int64_t)std::max<size_t>(h.size(), 1)));
-  if (!h.empty())
-    TG_CHECK_HIP(hipMemcpyAsync(*dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, g_tg.stream));
-  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));   // (h may be a temporary)
+  if (!h.empty()) TG_TRY(tg_h2d_staged(*dst, h.data(), h.size() * sizeof(T)));   // (h may be a temporary)
   return 0;
 }
 
@@ -231,6 +229,7 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
   if (!rc) rc = tt_upload(&d_pl[1], pls[1]);
   if (!rc && hipMemsetAsync(pl->status, 0, sizeof(int), g_tg.stream) != hipSuccess) rc = 1;
   int bad = 0;
+  bool certified_pass = false;
   if (!rc) {
     // row lengths of the planes against the pattern (8 B per row; the x pass then needs no row pointers)
     {
@@ -284,7 +283,7 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
       // A matrix written by this library with exactly this pattern says so (tg_csr_s::pattern_tag): its column indices
       // need not be read again (227 GB per pass at cfg3).  Any other matrix is verified entry by entry while it is read;
       // TIGAR_PTAP_VERIFY=1 verifies always.
-      const bool certified = a->pattern_tag != 0 && a->pattern_tag == pl->expect_tag && a->pattern_row0 == a_row0 &&
+      const bool certified = certified_pass = a->pattern_tag != 0 && a->pattern_tag == pl->expect_tag && a->pattern_row0 == a_row0 &&
                              !(getenv("TIGAR_PTAP_VERIFY") && atoi(getenv("TIGAR_PTAP_VERIFY")));
       if (XM.n > 0 && XM.first[XM.n] > 0) {
 #define TT_X(PP) hipLaunchKernelGGL((k_tt_x_multi<PP, true>), dim3(XM.first[XM.n]), dim3(64), 0, g_tg.stream, XM)
@@ -328,10 +327,14 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
       tg_set_error("tg_tensor_planes: kernel launch failed");
       rc = 1;
     }
-    if (!rc && hipMemcpyAsync(&bad, pl->status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
-    if (!rc && hipStreamSynchronize(g_tg.stream) != hipSuccess) {
-      tg_set_error("tg_tensor_planes: %s", hipGetErrorString(hipGetLastError()));
-      rc = 1;
+    // a matrix whose pattern was verified entry by entry may have failed: the caller is told now (status 100).  A
+    // certified matrix cannot, and the host goes on enqueueing (the z stage reads the flag when it waits anyway).
+    if (!certified_pass) {
+      if (!rc && hipMemcpyAsync(&bad, pl->status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
+      if (!rc && hipStreamSynchronize(g_tg.stream) != hipSuccess) {
+        tg_set_error("tg_tensor_planes: %s", hipGetErrorString(hipGetLastError()));
+        rc = 1;
+      }
     }
   }
   tg_dfree(b1);
@@ -432,8 +435,16 @@ extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tenso
       tg_set_error("tg_tensor_zstage: kernel launch failed");
       rc = 1;
     }
+    // the flag of the x / y passes that fed this stage (read here when they ran on a certified matrix without waiting)
+    int passes_bad = 0;
+    if (!rc && hipMemcpyAsync(&passes_bad, pl->status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
     if (!rc && hipStreamSynchronize(g_tg.stream) != hipSuccess) {   // (`end`, the mask and the pointer table are released below)
       tg_set_error("tg_tensor_zstage: %s", hipGetErrorString(hipGetLastError()));
+      rc = 1;
+    }
+    if (!rc && passes_bad) {
+      tg_set_error("tg_tensor_zstage: the planes of this stage come from a matrix whose rows do not have the lengths of "
+                   "the pattern it was certified for");
       rc = 1;
     }
   }
