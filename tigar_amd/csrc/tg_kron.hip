@@ -467,11 +467,11 @@ extern "C" int tg_tensor_apply_1d(int d, const int64_t *dims_in, int k, int64_t 
   double *dfv = nullptr;
   int rc = tg_dmalloc(&drp, nout_k + 1) || tg_dmalloc(&dci, nnz1) || tg_dmalloc(&dfv, nnz1);
   if (!rc) {
-    hipMemcpyAsync(drp, rowptr, (size_t)(nout_k + 1) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
-    if (nnz1) {
-      hipMemcpyAsync(dci, col, (size_t)nnz1 * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
-      hipMemcpyAsync(dfv, val, (size_t)nnz1 * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
-    }
+    // (stream-ordered uploads through the pinned ring: no wait, the tables are released to the pool in stream order)
+    rc = tg_h2d_staged(drp, rowptr, (size_t)(nout_k + 1) * sizeof(int32_t));
+    if (!rc && nnz1) rc = tg_h2d_staged(dci, col, (size_t)nnz1 * sizeof(int32_t)) || tg_h2d_staged(dfv, val, (size_t)nnz1 * sizeof(double));
+  }
+  if (!rc) {
     const int64_t blocks = std::min<int64_t>(tg_cdiv(out->n, 256), (int64_t)g_tg.num_cu * 32);
     hipLaunchKernelGGL(k_tensor_apply_1d, dim3((unsigned)blocks), dim3(256), 0, g_tg.stream, drp, dci, dfv, n_lo, nin_k, nout_k,
                        n_hi, col_shift, in->d, out->d);
@@ -479,7 +479,6 @@ extern "C" int tg_tensor_apply_1d(int d, const int64_t *dims_in, int k, int64_t 
       tg_set_error("k_tensor_apply_1d failed to launch");
       rc = 1;
     }
-    hipStreamSynchronize(g_tg.stream);
   }
   tg_dfree(drp);
   tg_dfree(dci);
