@@ -632,3 +632,37 @@ def test_vector_norm_kinds(dev):
     assert v.norm("linf") == 9.5
     with pytest.raises(ValueError):
         v.norm("frobenius")
+
+
+def test_factor_table_cache_and_staged_uploads(dev):
+    """tg_kron_sum_csr keeps the device copies of the last four factor sets; small host tables travel through a ring of
+    pinned 64 KB slots without a wait, larger ones take the waiting path.  Six factor sets in rotation (evictions and
+    hits), many more uploads than the ring has slots, and a 1-D factor beyond the slot size: same results as scipy."""
+    rng = np.random.default_rng(3)
+
+    def factor(n, width):
+        rows = np.repeat(np.arange(n), width)
+        cols = (rows + np.tile(np.arange(width), n)) % n
+        A = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(n, n))
+        A.sort_indices()
+        return A
+    sets = []
+    for k in range(6):
+        fx, fy = factor(7 + k, 2), factor(5 + (k % 3), 3)
+        sets.append(([[fx, fy]], sp.kron(fy, fx).tocsr()))
+    for rep in range(3):
+        for fac, ref in sets:
+            got = dev.kron_sum_csr(fac).to_scipy()
+            assert abs(got - ref).max() <= 1e-15 * abs(ref).max()
+    # many small uploads in a row (more than the ring holds) and one table larger than a slot
+    x = rng.standard_normal(40)
+    dx = dev.DeviceVector(data=x)
+    F = factor(40, 3)
+    for _ in range(200):
+        y = dev.tensor_apply_1d(dx, [40], 0, F)
+    assert np.max(np.abs(y.get_local() - F @ x)) < 1e-13
+    n = 9000                                                  # 27000 entries: 216 KB of values, 108 KB of columns
+    Fb = factor(n, 3)
+    xb = rng.standard_normal(n)
+    yb = dev.tensor_apply_1d(dev.DeviceVector(data=xb), [n], 0, Fb)
+    assert np.max(np.abs(yb.get_local() - Fb @ xb)) < 1e-12

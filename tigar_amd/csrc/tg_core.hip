@@ -669,15 +669,30 @@ __global__ void k_tensor3(double *out, int d, const double *b0, const double *b1
                           int64_t n1, double scale, int64_t row0, int64_t nloc) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // (64-bit divisions cost ~100 instructions each and made this store stream ALU-bound: 32-bit ones where the index allows)
+  const bool small = row0 + nloc < 0xffffffffll;
   for (; i < nloc; i += stride) {
     int64_t r = row0 + i;
-    int64_t a = r % n0;
-    int64_t t = r / n0;
+    int64_t a, b = 0, c = 0;
+    if (small) {
+      const uint32_t r32 = (uint32_t)r, t32 = r32 / (uint32_t)n0;
+      a = r32 - t32 * (uint32_t)n0;
+      if (d > 1) {
+        c = t32 / (uint32_t)n1;
+        b = t32 - (uint32_t)c * (uint32_t)n1;
+      }
+    } else {
+      a = r % n0;
+      const int64_t t = r / n0;
+      if (d > 1) {
+        b = t % n1;
+        c = t / n1;
+      }
+    }
     double v = b0[a];
     if (d > 1) {
-      int64_t b = t % n1;
       v *= b1[b];
-      if (d > 2) v *= b2[t / n1];
+      if (d > 2) v *= b2[c];
     }
     out[i] = scale * v;
   }
@@ -690,13 +705,12 @@ extern "C" int tg_vec_tensor3(tg_vec_t out, int d, const double *const *b1d, con
   double *db[3] = {nullptr, nullptr, nullptr};
   for (int k = 0; k < d; k++) {
     TG_TRY(tg_dmalloc(&db[k], n[k]));
-    TG_CHECK_HIP(hipMemcpyAsync(db[k], b1d[k], (size_t)n[k] * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
+    TG_TRY(tg_h2d_staged(db[k], b1d[k], (size_t)n[k] * sizeof(double)));
   }
   hipLaunchKernelGGL(k_tensor3, dim3(tg_grid_1d(out->n, 256)), dim3(256), 0, g_tg.stream, out->d, d, db[0], db[1],
                      db[2], n[0], d > 1 ? n[1] : 1, scale, row0, out->n);
   TG_LAUNCH_CHECK();
-  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
-  for (int k = 0; k < d; k++) tg_dfree(db[k]);
+  for (int k = 0; k < d; k++) tg_dfree(db[k]);      // (stream order: the pool hands them out to later work only)
   return 0;
 }
 

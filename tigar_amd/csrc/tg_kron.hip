@@ -432,10 +432,21 @@ __global__ void __launch_bounds__(256)
   const int64_t total = n_lo * nout_k * n_hi;
   int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool small = total < 0xffffffffll;       // (32-bit divisions where the index allows: the 64-bit ones dominate otherwise)
   for (; o < total; o += stride) {
-    const int64_t lo = o % n_lo;
-    const int64_t r = o / n_lo;
-    const int64_t I = r % nout_k, hi = r / nout_k;
+    int64_t lo, I, hi;
+    if (small) {
+      const uint32_t o32 = (uint32_t)o, r32 = o32 / (uint32_t)n_lo;
+      lo = o32 - r32 * (uint32_t)n_lo;
+      const uint32_t h32 = r32 / (uint32_t)nout_k;
+      I = r32 - h32 * (uint32_t)nout_k;
+      hi = h32;
+    } else {
+      lo = o % n_lo;
+      const int64_t r = o / n_lo;
+      I = r % nout_k;
+      hi = r / nout_k;
+    }
     const double *src = in + lo + n_lo * nin_k * hi;
     double acc = 0.0;
     for (int t = rp[I]; t < rp[I + 1]; t++) acc += fv[t] * src[n_lo * ((int64_t)ci[t] - col_shift)];
