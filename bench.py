@@ -402,7 +402,8 @@ def main():
         # the general-CSR contract keeps a tracked number: the same step with the fast path switched off (offline runs,
         # committed under profiles/; A arbitrary sparse in both, M Kronecker in the first, nothing assumed in the second)
         ref = {}
-        for key, fn in (("arbitrary_A_kronecker_M_line_kernels", "r2_bench_cfg3_general_line.json"),
+        for key, fn in (("fe_matrix_pattern_verified_entry_by_entry", "r2_bench_cfg3_pattern_verified.json"),
+                        ("arbitrary_A_kronecker_M_line_kernels", "r2_bench_cfg3_general_line.json"),
                         ("fully_general_hash_ptap_M_slabs_materialised", "r2_bench_cfg3_general_hash.json")):
             try:
                 g = json.load(open(os.path.join(ROOT, "profiles", fn)))
