@@ -83,8 +83,9 @@ void tg_sell_free(tg_sell_s *s) {
   delete s;
 }
 
-// the shapes used last (most recent first)
-static std::vector<std::shared_ptr<tg_sell_shape>> g_sell_shapes;
+// the shapes used last (most recent first).  Allocated once and never destroyed: a destructor running at process exit
+// would call into the allocator (and HIP) after their own static state may be gone; tg_shutdown empties it explicitly.
+static std::vector<std::shared_ptr<tg_sell_shape>> &g_sell_shapes = *new std::vector<std::shared_ptr<tg_sell_shape>>();
 #define TG_SELL_SHAPES 3
 
 void tg_sell_cache_clear(void) { g_sell_shapes.clear(); }
