@@ -26,8 +26,7 @@ __global__ void __launch_bounds__(256)
     k_bezier_rows(tg_bez_args A, int64_t *__restrict__ rowptr, int32_t *__restrict__ col, double *__restrict__ val) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= A.nrows) return;
-  const int64_t e = r / A.nloc;
-  const int n = (int)(r - e * A.nloc);
+  const int64_t e = r / A.nloc;                 // element of this FE row (rows are element-major)
   const double *B = A.bern + r * A.nbern;
   const int64_t a0 = A.eoff[e], a1 = A.eoff[e + 1];
   int64_t pos = FILL ? rowptr[r] : 0;
