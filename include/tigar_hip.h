@@ -99,6 +99,12 @@ int tg_csr_transpose(tg_csr_t m, tg_csr_t *out);
  * rows of dof i's support, the lowest such rank on a tie (scipy.stats.mode), 0 for an empty row.
  * tg_csr_permute_columns: copy of m with column c renamed new_of_old[c] (host, ncols entries, a permutation), rows
  * re-sorted: MatPermute with identity rows. */
+/* Field blocks of a matrix on a mixed space whose dofs are numbered field after field (the FE matrices of
+ * EqualOrderSpline(nFields > 1), tIGAr/common.py:1891-1914): tg_csr_block cuts out rows [r0, r1) x columns [c0, c1)
+ * (columns renumbered from 0); tg_csr_from_blocks puts nf x nf blocks of one shape together, blocks[i * nf + j] at block
+ * row i, block column j.  Used to run the scalar tensor-pattern PtAP block by block. */
+int tg_csr_block(tg_csr_t a, int64_t r0, int64_t r1, int64_t c0, int64_t c1, tg_csr_t *out);
+int tg_csr_from_blocks(int nf, const tg_csr_t *blocks, tg_csr_t *out);
 int tg_partition_mode(tg_csr_t mt, const int32_t *fe_owner, int world, int32_t *owner_out);
 int tg_csr_permute_columns(tg_csr_t m, const int32_t *new_of_old, tg_csr_t *out);
 /* fallback for arbitrary AbstractScalarBasis plug-ins (seam b-2, tIGAr/common.py:1683-1692):

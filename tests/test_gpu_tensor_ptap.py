@@ -189,3 +189,66 @@ def test_pattern_certificate_of_library_assembled_matrices(p, nels):
         assert A3.shape == A.shape
         assert plan.planes(A3, 0, 0, nfe2) is None                     # verified, found different, declined
         assert certified() == n0 + 2
+
+
+@pytest.mark.parametrize("p,nels,nF", [(2, (3, 4, 2), 3), (3, (3, 2, 3), 2), (1, (4, 3, 5), 3)])
+def test_several_fields_on_one_basis_go_block_by_block(p, nels, nF):
+    """EqualOrderSpline(nFields > 1) in 3-D (elasticity-like): M = diag(M_s, ..., M_s) with dofs numbered field after
+    field, so block (i, j) of M^T A M is M_s^T A_ij M_s -- the scalar tensor-pattern passes on the blocks cut out of A
+    (tg_csr_block), put together (tg_csr_from_blocks), MatZeroRowsColumns on the whole.  Against the oracle's product
+    with the block-diagonal M (pattern and values), with a pair of uncoupled fields (an empty block), a non-symmetric A,
+    and against the general kernels."""
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, device as dev
+    kvs = [B.uniformKnots(p, 0., 1., n) for n in nels]
+    gen = t.EqualOrderSpline(nF, B.ExplicitBSplineControlMesh([p] * 3, kvs))
+    sp0 = gen.getScalarSpline(0)
+    for f in range(nF):
+        gen.addZeroDofs(f, sp0.getSideDofs(f % 3, 0))
+        gen.addZeroDofs(f, sp0.getSideDofs((f + 1) % 3, 1, nLayers=2))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    assert spline._kron is None and spline._kron_scalar is not None
+    rng = np.random.default_rng(7 * p + nF)
+    rows = []
+    for i in range(nF):
+        row = []
+        for j in range(nF):
+            blk = _random_fe_matrix(p, nels, seed=100 * i + j)
+            if nF == 3 and (i, j) in ((0, 2), (2, 0)):
+                blk = sp.csr_matrix(blk.shape)                        # fields 0 and 2 not coupled
+            row.append(blk)
+        rows.append(row)
+    A = sp.bmat(rows, format="csr")
+    A.sort_indices()
+    s = O.BSpline([p] * 3, [O.uniform_knots(p, 0., 1., n) for n in nels])
+    Mo = O.generate_M_tensor(s, nfields=nF)
+    zd = list(spline.zeroDofs)
+    Ko = O.extract_matrix(Mo, A, zd, diag=3.0)
+    calls = []
+    orig = spline._extract_matrix_by_field_blocks
+    spline._extract_matrix_by_field_blocks = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    K = spline.extractMatrix(A, diag=3.0).to_scipy()
+    assert calls == [1]
+    assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices)
+    assert np.max(np.abs(K.data - Ko.data)) <= 1e-13 * np.max(np.abs(Ko.data))
+    assert np.array_equal(spline.extractMatrix(A, diag=3.0).to_scipy().data, K.data)      # bit-reproducible
+    os.environ["TIGAR_PTAP_FACTORED"] = "0"
+    try:
+        Kg = spline.extractMatrix(A, diag=3.0).to_scipy()
+    finally:
+        del os.environ["TIGAR_PTAP_FACTORED"]
+    assert np.array_equal(Kg.indptr, K.indptr) and np.array_equal(Kg.indices, K.indices)
+    assert np.max(np.abs(Kg.data - K.data)) <= 1e-12 * np.max(np.abs(K.data))
+    # a block without the element-coupling pattern is multiplied by the general kernels -- that block alone, on the
+    # scalar operands; also with the tensor passes switched off altogether
+    Ar = A.tolil()
+    Ar[1, A.shape[1] - 2] = 0.5
+    Ar = Ar.tocsr()
+    Ar.sort_indices()
+    Kro = O.extract_matrix(Mo, Ar, zd, diag=3.0)
+    Kr = spline.extractMatrix(Ar, diag=3.0).to_scipy()
+    assert calls == [1, 1, 1]
+    assert np.array_equal(Kr.indptr, Kro.indptr) and np.array_equal(Kr.indices, Kro.indices)
+    assert np.max(np.abs(Kr.data - Kro.data)) <= 1e-12 * np.max(np.abs(Kro.data))
+    Kb = orig(dev.DeviceCSR.from_scipy(A), np.asarray(zd), 3.0, False).to_scipy()
+    assert np.array_equal(Kb.indices, K.indices) and np.max(np.abs(Kb.data - K.data)) <= 1e-12 * np.max(np.abs(K.data))

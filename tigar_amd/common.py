@@ -392,6 +392,7 @@ class AbstractExtractionGenerator(object):
         # Kronecker form of M (single tensor B-spline field, filter dropped only exact zeros):
         # enables the sum-factorised M^T A M of tigar_amd/kronptap.py
         self._kron = None
+        self._kron_scalar = None           # several fields on ONE tensor basis (EqualOrderSpline(nFields > 1)): its tables
         if getattr(self.M, "is_implicit", False):
             self._kron = self.M.kx
         elif self.getNFields() == 1 and (0, 0) in self._fast_blocks or (self.M is self.M_control
@@ -400,6 +401,23 @@ class AbstractExtractionGenerator(object):
             kx = self._kron_tables(basis, grid)
             if kx is not None and kx.is_exact_for(self.M.nnz, self.getIgnoreEps()):
                 self._kron = kx
+        elif self.getNFields() > 1 and not getattr(self.M, "is_implicit", False):
+            # every field block built by the tensor kernels from the same basis on the same node grid, and each block
+            # exactly the Kronecker product of its 1-D factors (entry count checked): M = diag(M_s, ..., M_s)
+            keys = []
+            offset = 0
+            for f in range(self.getNFields()):
+                keys.append((f, offset))
+                offset += self.getNcp(f)
+            if all(k in self._fast_blocks for k in keys):
+                b0, g0 = self._fast_blocks[keys[0]]
+                same = all(self._fast_blocks[k][0] is b0 and self._fast_blocks[k][1].axes is not None and
+                           all(numpy.array_equal(a, b) for a, b in zip(self._fast_blocks[k][1].axes, g0.axes))
+                           for k in keys)
+                kx = self._kron_tables(b0, g0) if same else None
+                if kx is not None and self.M.nnz == self.getNFields() * kx.nnz_product and \
+                        kx.products_stay_above(self.getIgnoreEps()):
+                    self._kron_scalar = kx
         self.cpFuncs = []
         cm = self.getControlMesh() if hasattr(self, "getControlMesh") else None
         P = None
@@ -465,6 +483,7 @@ class AbstractExtractionGenerator(object):
         self.M = self.M.permute_columns(new_of_old)
         self.MT = self.M.transpose()
         self._kron = None                      # (M is no Kronecker product in the new numbering)
+        self._kron_scalar = None
         self._fast_blocks = {}
         self.zeroDofs = new_of_old[self.zeroDofsArray()].tolist()
 
@@ -1060,6 +1079,7 @@ class ExtractedSpline(object):
         self.comm = generator.getComm()
         self._generator_engine = getattr(generator, "_slab_engine", None)
         self._kron = getattr(generator, "_kron", None)
+        self._kron_scalar = getattr(generator, "_kron_scalar", None)
         self.zeroDofs = generator.zeroDofsArray().astype(INDEX_TYPE)
 
     def genericSetup(self):
@@ -1155,11 +1175,15 @@ class ExtractedSpline(object):
                 raise NotImplementedError("with several ranks pass the FE matrix as a LazyFEMatrix (row blocks)")
             return self._slab_path().assemble_matrix(a_rows, zd, float(diag), getattr(self, "stage_timers", None))
         A = _as_device_csr(A)
+        by_blocks = self._kron is None and getattr(self, "_kron_scalar", None) is not None
+        if by_blocks and os.environ.get("TIGAR_PTAP_FACTORED", "1") != "0":
+            K = self._extract_matrix_by_field_blocks(A, zd, float(diag))
+            if K is not None:
+                return K
         if self._kron is not None:
             from .kronptap import default_groups, ptap_factored
             kx = self._kron
             groups = default_groups(kx.d, max(s1.p for s1 in kx.basis.splines))
-            import os
             if os.environ.get("TIGAR_PTAP_FACTORED", "1") != "0":
                 # Kronecker-structured M: dense-box kernel (one stage or sum-factorised stages)
                 return ptap_factored(kx, A, (0, kx.nfe[-1]), (0, kx.nfe[-1]), (0, kx.ncp[-1]), zd, float(diag), groups)
@@ -1174,12 +1198,77 @@ class ExtractedSpline(object):
         try:
             return _dev.ptap_numeric(self._ptap_plan, A, self.M, self.MT, zd, float(diag))
         except _dev.TigarHipError:
+            if fresh and by_blocks:
+                # rows of the whole product beyond the general kernels' per-row tables (three fields at p = 3 in 3-D):
+                # the same kernels block by block, on the scalar operands
+                self._ptap_plan = self._ptap_plan_key = None
+                K = self._extract_matrix_by_field_blocks(A, zd, float(diag), tensor=False)
+                if K is not None:
+                    return K
             if fresh:
                 raise
             # same shape and nnz but another sparsity pattern than the cached plan's: the reference
             # recomputes the symbolic product on every call (tIGAr/common.py:1194-1195) -- plan again
             self._ptap_plan = _dev.ptap_symbolic(A, self.M, self.MT)
             return _dev.ptap_numeric(self._ptap_plan, A, self.M, self.MT, zd, float(diag))
+
+    def _extract_matrix_by_field_blocks(self, A, zd, diag, tensor=True):
+        """M^T A M for several fields on one tensor basis (M = diag(M_s, ..., M_s), dofs field after field): block
+        (i, j) of the result is M_s^T A_ij M_s, computed on the block cut out of A -- by the scalar tensor-pattern
+        passes (csrc/tg_tensor_body.h) where the patch and the block qualify, by the general kernels on the scalar
+        operands otherwise (whose per-row tables hold a scalar row's intermediate, not that of nFields of them).  The
+        blocks are put together and MatZeroRowsColumns is applied to the whole (tIGAr/common.py:1194-1200).  None
+        when A is not a matrix on this mixed space."""
+        from .tensorptap import TensorPtAP
+        kx = self._kron_scalar
+        plan = TensorPtAP.for_extraction(kx) if tensor else None
+        nF = self.nFields
+        nfe = int(numpy.prod(kx.nfe, dtype=numpy.int64))
+        ncp = int(numpy.prod(kx.ncp, dtype=numpy.int64))
+        if A.shape != (nF * nfe, nF * nfe):
+            return None
+        nz, kz = int(kx.nfe[-1]), int(kx.ncp[-1])
+        # FE planes per call of the x / y passes: their first intermediate is about 2.5 x the block's own bytes
+        step = max(kx.basis.splines[-1].p, min(nz, int(2.0e10 // max(1.0, 12.0 * 2.5 * (A.nnz / float(nF * nF)) / nz))))
+        scalar = {}
+
+        def general(Aij):
+            if not scalar:
+                scalar["M"] = self.M.block(0, nfe, 0, ncp)
+                scalar["MT"] = scalar["M"].transpose()
+            return _dev.ptap_numeric(_dev.ptap_symbolic(Aij, scalar["M"], scalar["MT"]), Aij, scalar["M"], scalar["MT"])
+
+        blocks = []
+        for i in range(nF):
+            row = []
+            for j in range(nF):
+                Aij = A.block(i * nfe, (i + 1) * nfe, j * nfe, (j + 1) * nfe)
+                Kij = None
+                if Aij.nnz == 0:
+                    # fields i and j are not coupled by this form: no entries in this block of the product either
+                    import scipy.sparse as _sp
+                    Kij = DeviceCSR.from_scipy(_sp.csr_matrix((ncp, ncp)))
+                elif plan is not None:
+                    pieces = []
+                    for z0 in range(0, nz, step):
+                        pc = plan.planes(Aij, 0, z0, min(nz, z0 + step))
+                        if pc is None:
+                            pieces = None
+                            break
+                        pieces.append(pc)
+                    if pieces is not None:
+                        Kij = plan.zstage(pieces, 0, kz)
+                    del pieces
+                if Kij is None:
+                    Kij = general(Aij)
+                row.append(Kij)
+                del Aij
+            blocks.append(row)
+        K = _dev.csr_from_blocks(blocks)
+        del blocks
+        if zd is not None and len(zd):
+            K.zero_rows_cols(numpy.asarray(zd, dtype=numpy.int32), diag)
+        return K
 
     def assembleMatrix(self, form, applyBCs=True, diag=1):
         """tIGAr/common.py:1206-1220.  When the assembled FE matrix cannot be resident next to K (implicit

@@ -522,6 +522,198 @@ int tg_csr_transpose_block(tg_csr_s *m, int64_t row_base, int64_t out_ncols, tg_
 }
 
 // ----------------------------------------------------------------------------------------
+// field blocks of a mixed-space matrix (rows and columns field-major): cut one out, put nF x nF of them together
+// ----------------------------------------------------------------------------------------
+__global__ void k_add_i64(int64_t *__restrict__ p, int64_t n, int64_t add) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] += add;
+}
+
+// first position q in [a, e) with col[q] >= c (columns ascending)
+__device__ __forceinline__ int64_t tg_lower_bound_col(const int32_t *__restrict__ col, int64_t a, int64_t e, int64_t c) {
+  while (a < e) {
+    const int64_t m = (a + e) >> 1;
+    if ((int64_t)col[m] < c) a = m + 1;
+    else e = m;
+  }
+  return a;
+}
+
+__global__ void k_block_count(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t r0, int64_t n,
+                              int64_t c0, int64_t c1, int64_t *__restrict__ out_len, int64_t *__restrict__ first) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int64_t a = rowptr[r0 + i], e = rowptr[r0 + i + 1];
+    const int64_t lo = tg_lower_bound_col(col, a, e, c0), hi = tg_lower_bound_col(col, lo, e, c1);
+    out_len[i] = hi - lo;
+    first[i] = lo;
+  }
+}
+
+// one wave per row: copies the row's segment, columns shifted
+__global__ void __launch_bounds__(256)
+    k_block_fill(const int32_t *__restrict__ col, const double *__restrict__ val, const int64_t *__restrict__ first,
+                 const int64_t *__restrict__ orowptr, int64_t n, int32_t cshift, int32_t *__restrict__ ocol,
+                 double *__restrict__ oval) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n; r += nwaves) {
+    const int64_t o = orowptr[r], len = orowptr[r + 1] - o, src = first[r];
+    for (int64_t q = lane; q < len; q += 64) {
+      ocol[o + q] = col[src + q] + cshift;
+      oval[o + q] = val[src + q];
+    }
+  }
+}
+
+// rows [r0, r1) of a, entries with c0 <= column < c1, columns renumbered from 0: the (i, j) field block of a matrix
+// on a mixed space whose dofs are numbered field after field
+extern "C" int tg_csr_block(tg_csr_t a, int64_t r0, int64_t r1, int64_t c0, int64_t c1, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(a && out && r0 >= 0 && r1 >= r0 && r1 <= a->nrows && c0 >= 0 && c1 >= c0 && c1 <= a->ncols,
+             "bad arguments to tg_csr_block");
+  TG_REQUIRE_CANONICAL(a);
+  const int64_t n = r1 - r0;
+  int64_t *len = nullptr, *first = nullptr;
+  int rc = tg_dmalloc(&len, n + 1) || tg_dmalloc(&first, std::max<int64_t>(n, 1));
+  tg_csr_s *m = nullptr;
+  int64_t total = 0;
+  if (!rc && n > 0) {
+    hipLaunchKernelGGL(k_block_count, dim3(tg_grid_1d(n, 256)), dim3(256), 0, g_tg.stream, a->rowptr, a->col, r0, n, c0, c1,
+                       len, first);
+    if (hipGetLastError() != hipSuccess) rc = 1;
+  }
+  if (!rc) rc = tg_exclusive_scan_i64(len, n, &total);
+  if (!rc) rc = tg_csr_alloc(n, c1 - c0, total, &m);
+  if (!rc) {
+    if (hipMemcpyAsync(m->rowptr, len, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess)
+      rc = 1;
+    if (!rc && total > 0) {
+      const unsigned grid = (unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16);
+      hipLaunchKernelGGL(k_block_fill, dim3(grid), dim3(256), 0, g_tg.stream, a->col, a->val, first, m->rowptr, n,
+                         (int32_t)(-c0), m->col, m->val);
+      if (hipGetLastError() != hipSuccess) rc = 1;
+    }
+  }
+  if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
+  tg_dfree(len);
+  tg_dfree(first);
+  if (rc) {
+    if (m) tg_csr_destroy(m);
+    tg_set_error("tg_csr_block failed");
+    return 1;
+  }
+  *out = m;
+  return 0;
+}
+
+struct tg_merge_args {
+  const int64_t *rowptr[16];     // [i * nf + j] (one block row at a time: nf entries used)
+  const int32_t *col[16];
+  const double *val[16];
+  int nf;
+  int64_t n, m;                  // rows and columns of one block
+};
+
+__global__ void k_merge_count(tg_merge_args A, int64_t *__restrict__ out_len) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; r < A.n; r += stride) {
+    int64_t s = 0;
+    for (int j = 0; j < A.nf; j++) s += A.rowptr[j][r + 1] - A.rowptr[j][r];
+    out_len[r] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_merge_fill(tg_merge_args A, const int64_t *__restrict__ orowptr, int32_t *__restrict__ ocol,
+                 double *__restrict__ oval) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < A.n; r += nwaves) {
+    int64_t o = orowptr[r];
+    for (int j = 0; j < A.nf; j++) {
+      const int64_t a = A.rowptr[j][r], len = A.rowptr[j][r + 1] - a;
+      const int32_t shift = (int32_t)(j * A.m);
+      for (int64_t q = lane; q < len; q += 64) {
+        ocol[o + q] = A.col[j][a + q] + shift;
+        oval[o + q] = A.val[j][a + q];
+      }
+      o += len;
+    }
+  }
+}
+
+// blocks[i * nf + j] (all n x m): the matrix with field-major rows and columns whose (i, j) block is blocks[i*nf+j]
+extern "C" int tg_csr_from_blocks(int nf, const tg_csr_t *blocks, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(nf >= 1 && nf <= 16 && blocks && out, "bad arguments to tg_csr_from_blocks");
+  const int64_t n = blocks[0] ? blocks[0]->nrows : 0, mcols = blocks[0] ? blocks[0]->ncols : 0;
+  int64_t nnz = 0;
+  for (int q = 0; q < nf * nf; q++) {
+    TG_REQUIRE(blocks[q] && blocks[q]->nrows == n && blocks[q]->ncols == mcols, "tg_csr_from_blocks: block %d has another shape", q);
+    TG_REQUIRE_CANONICAL(blocks[q]);
+    nnz += blocks[q]->nnz;
+  }
+  TG_REQUIRE((int64_t)nf * mcols < 0x7fffffffll, "tg_csr_from_blocks: more than 2^31 columns");
+  tg_csr_s *m = nullptr;
+  TG_TRY(tg_csr_alloc((int64_t)nf * n, (int64_t)nf * mcols, nnz, &m));
+  int rc = 0;
+  int64_t at = 0;
+  for (int i = 0; i < nf && !rc; i++) {
+    tg_merge_args A;
+    memset(&A, 0, sizeof(A));
+    A.nf = nf;
+    A.n = n;
+    A.m = mcols;
+    int64_t block_row_nnz = 0;
+    for (int j = 0; j < nf; j++) {
+      A.rowptr[j] = blocks[i * nf + j]->rowptr;
+      A.col[j] = blocks[i * nf + j]->col;
+      A.val[j] = blocks[i * nf + j]->val;
+      block_row_nnz += blocks[i * nf + j]->nnz;
+    }
+    int64_t *orp = m->rowptr + (int64_t)i * n;
+    if (n > 0) {
+      hipLaunchKernelGGL(k_merge_count, dim3(tg_grid_1d(n, 256)), dim3(256), 0, g_tg.stream, A, orp);
+      if (hipGetLastError() != hipSuccess) rc = 1;
+    }
+    int64_t total = 0;
+    // (the scan writes n + 1 entries: the last one is the first of the next block row, rewritten there)
+    if (!rc) rc = tg_exclusive_scan_i64(orp, n, &total);
+    if (!rc && total != block_row_nnz) {
+      tg_set_error("tg_csr_from_blocks: block row %d holds %lld entries, its blocks %lld", i, (long long)total,
+                   (long long)block_row_nnz);
+      rc = 1;
+    }
+    if (!rc && n > 0 && total > 0) {
+      // row starts of this block row are relative to its first entry: the fill adds `at` through the base pointers
+      const unsigned grid = (unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16);
+      hipLaunchKernelGGL(k_merge_fill, dim3(grid), dim3(256), 0, g_tg.stream, A, orp, m->col + at, m->val + at);
+      if (hipGetLastError() != hipSuccess) rc = 1;
+    }
+    if (!rc && n > 0 && at > 0) {
+      // make the row pointers of this block row global
+      hipLaunchKernelGGL(k_add_i64, dim3(tg_grid_1d(n + 1, 256)), dim3(256), 0, g_tg.stream, orp, n + 1, at);
+      if (hipGetLastError() != hipSuccess) rc = 1;
+    }
+    at += total;
+  }
+  if (!rc && n == 0) hipMemsetAsync(m->rowptr, 0, sizeof(int64_t), g_tg.stream);
+  if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
+  if (rc) {
+    tg_csr_destroy(m);
+    return 1;
+  }
+  *out = m;
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------
 // IGA dof permutation (tIGAr/common.py:407-433, 1583-1665)
 // ----------------------------------------------------------------------------------------
 __global__ void k_relabel_cols(const int32_t *__restrict__ col, const int32_t *__restrict__ new_of_old, int64_t nnz,

@@ -205,6 +205,12 @@ class DeviceCSR(object):
             self._T = DeviceCSR(h)
         return self._T
 
+    def block(self, r0, r1, c0, c1):
+        """rows [r0, r1) x columns [c0, c1) as a matrix of its own, columns renumbered from 0 (tg_csr_block)"""
+        h = handle()
+        check(_lib.lib().tg_csr_block(self._h, int(r0), int(r1), int(c0), int(c1), C.byref(h)), "tg_csr_block")
+        return DeviceCSR(h)
+
     def permute_columns(self, new_of_old):
         """copy with column c renamed ``new_of_old[c]`` and rows re-sorted (MatPermute with identity rows)"""
         m = np.ascontiguousarray(new_of_old, dtype=np.int32)
@@ -363,6 +369,18 @@ def extract_csr_bezier(bern, eoff, nodes, coef, col_offset, ncols, eps):
     check(_lib.lib().tg_extract_csr_bezier(int(nel), int(nloc), int(nbern), _p(bern, c_f64p), _p(eoff, c_i64p),
                                            _p(nodes, c_i32p), _p(coef, c_f64p), int(col_offset), int(ncols), float(eps),
                                            C.byref(h)), "tg_extract_csr_bezier")
+    return DeviceCSR(h)
+
+
+def csr_from_blocks(blocks):
+    """nf x nf blocks of one shape (list of rows of DeviceCSR) -> the matrix with field-major rows and columns"""
+    nf = len(blocks)
+    flat = [b for row in blocks for b in row]
+    if any(len(row) != nf for row in blocks):
+        raise ValueError("csr_from_blocks: a square arrangement of blocks is expected")
+    arr = (handle * len(flat))(*[b._h for b in flat])
+    h = handle()
+    check(_lib.lib().tg_csr_from_blocks(nf, arr, C.byref(h)), "tg_csr_from_blocks")
     return DeviceCSR(h)
 
 
