@@ -1291,9 +1291,9 @@ class ExtractedSpline(object):
     # -- a-12
     def solveLinearSystem(self, MTAM, MTb, u):
         """Solve ``MTAM*U = MTb`` and store ``M*U`` in the FE function ``u``; returns ``U``
-        (tIGAr/common.py:1236-1263).  With ``linearSolver == None`` the reference calls
-        dolfin's direct LU; there is no sparse direct solver on this path, so the default is
-        Jacobi-preconditioned GMRES at tight tolerance (1e-12) -- documented deviation."""
+        (tIGAr/common.py:1236-1263).  With ``linearSolver == None`` the reference calls dolfin's direct LU;
+        here: the banded LU of csrc/tg_lu.hip while its band storage fits (``_DefaultSolver``), Jacobi-GMRES at
+        tight tolerance beyond, with a message that says so."""
         MTU = DeviceVector(MTAM.shape[0])          # (local rows of MTAM: all of them on one rank)
         solver = self.linearSolver if self.linearSolver is not None else _default_linear_solver()
         if self._distributed() and getattr(solver, "comm", False) is None:
