@@ -98,7 +98,17 @@ int main(int argc, char **argv) {
         hipEventSynchronize(e1);
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
-        printf("buffer %d at %p: %.2f TB/s\n", b, (void *)buf[b], 5 * n * 8.0 / ms / 1e9);
+        printf("buffer %d at %p: write %.2f TB/s", b, (void *)buf[b], 5 * n * 8.0 / ms / 1e9);
+        // the same buffer as a read stream
+        hipLaunchKernelGGL((k_mix<1, 0>), dim3(8192), dim3(256), 0, 0, (const d2 *)buf[b], (d2 *)nullptr, n / 2, buf[b]);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, 0);
+        for (int r = 0; r < 5; r++)
+          hipLaunchKernelGGL((k_mix<1, 0>), dim3(8192), dim3(256), 0, 0, (const d2 *)buf[b], (d2 *)nullptr, n / 2, buf[b]);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("   read %.2f TB/s\n", 5 * n * 8.0 / ms / 1e9);
       }
     return 0;
   }
