@@ -67,6 +67,23 @@ def fe_matrices_1d(vertices, p, nq=None):
     return Mm, Km
 
 
+def fe_gradient_1d(vertices, p, nq=None):
+    """G[a,b] = int phi_a' phi_b of the 1-D CG Lagrange degree-p basis (scipy CSR on the element-coupling pattern of
+    ``fe_matrices_1d``, explicit zeros kept): the mixed first-derivative factor of vector-valued forms."""
+    nq = p + 1 if nq is None else nq
+    t, w = _gauss01(nq)
+    phi, dphi = _lagrange01(p, t)
+    ge = (dphi * w) @ phi.T                          # (the 1/h of the derivative and the h of dx cancel)
+    nel = len(vertices) - 1
+    n = nel * p + 1
+    loc = numpy.arange(p + 1)
+    rows = (numpy.arange(nel)[:, None, None] * p + loc[None, :, None]) + 0 * loc[None, None, :]
+    cols = (numpy.arange(nel)[:, None, None] * p + loc[None, None, :]) + 0 * loc[None, :, None]
+    G = sp.coo_matrix((numpy.tile(ge, (nel, 1, 1)).ravel(), (rows.ravel(), cols.ravel())), shape=(n, n)).tocsr()
+    G.sort_indices()
+    return G
+
+
 def fe_matrices_1d_ext(vertices, p, nq=None):
     """(mass, stiffness, S2[a,b] = int phi_a'' phi_b'', C[a,b] = int phi_a'' phi_b) element by
     element (no inter-element terms, as dolfin assembles ``inner(lap(u),lap(v))*dx``), all on one
@@ -169,6 +186,57 @@ class LaplaceForm(object):
                 raise NotImplementedError("row blocks of mapped forms")
             return _mapped(self.geometry, V, "laplace")
         return _dev.kron_sum_csr(self.factors(V), row0, row1)
+
+
+class ElasticityForm(object):
+    """a(u,v) = int lambda div u div v + 2 mu eps(u):eps(v) on the parametric box of a d-field space (all fields on one
+    CG node grid, dofs field after field -- the space of ``EqualOrderSpline(d, ...)``):
+    block (i, j) = lambda int d_i phi_a d_j phi_b + mu int d_j phi_a d_i phi_b + delta_ij mu int grad phi_a . grad phi_b,
+    each a Kronecker sum of 1-D factors (mass M, stiffness K, G[a,b] = int phi_a' phi_b) on the element-coupling pattern,
+    written block by block by the Kronecker-sum kernel and put together on the device.  What a dolfin user writes as
+    ``inner(sigma(u), eps(v))*dx`` for ``demos``-style linear elasticity on an identity-geometry patch."""
+
+    def __init__(self, lmbda=1.0, mu=1.0):
+        self.lmbda, self.mu = float(lmbda), float(mu)
+
+    def _grid(self, V):
+        g = V.grids[0]
+        if g.dg or len(V.grids) != g.dim() or any(
+                gi.degree != g.degree or any(not numpy.array_equal(a, b) for a, b in zip(gi.axes, g.axes)) for gi in V.grids):
+            raise NotImplementedError("ElasticityForm: as many fields as parametric directions, all on one CG node grid")
+        return g
+
+    def block_factors(self, V):
+        """factors[i][j] = list of terms, each a list of d 1-D matrices (direction 0 first)"""
+        def build():
+            g = self._grid(V)
+            d = g.dim()
+            one = [fe_matrices_1d(g.vertices[k], g.degree) + (fe_gradient_1d(g.vertices[k], g.degree),) for k in range(d)]
+            Mk, Kk, Gk = [o[0] for o in one], [o[1] for o in one], [o[2] for o in one]
+            lam, mu = self.lmbda, self.mu
+            out = [[None] * d for _ in range(d)]
+            for i in range(d):
+                for j in range(d):
+                    if i == j:
+                        terms = []
+                        for k in range(d):
+                            c = (lam + 2.0 * mu) if k == i else mu
+                            terms.append([(c * Kk[q]) if q == k else Mk[q] for q in range(d)])
+                    else:
+                        # int d_i phi_a d_j phi_b: G in direction i, G^T in direction j; and the transposed pairing
+                        t1 = [(lam * Gk[q]) if q == i else (Gk[q].T.tocsr() if q == j else Mk[q]) for q in range(d)]
+                        t2 = [(mu * Gk[q].T.tocsr()) if q == i else (Gk[q] if q == j else Mk[q]) for q in range(d)]
+                        terms = [t1, t2]
+                    out[i][j] = terms
+            return out
+        return _memo(self, V, build)
+
+    def assemble_matrix(self, V, row0=None, row1=None):
+        if row0 is not None or row1 is not None:
+            raise NotImplementedError("row blocks of the elasticity form")
+        fac = self.block_factors(V)
+        d = len(fac)
+        return _dev.csr_from_blocks([[_dev.kron_sum_csr(fac[i][j]) for j in range(d)] for i in range(d)])
 
 
 class MassForm(object):
