@@ -103,6 +103,8 @@ int tg_csr_transpose(tg_csr_t m, tg_csr_t *out);
  * EqualOrderSpline(nFields > 1), tIGAr/common.py:1891-1914): tg_csr_block cuts out rows [r0, r1) x columns [c0, c1)
  * (columns renumbered from 0); tg_csr_from_blocks puts nf x nf blocks of one shape together, blocks[i * nf + j] at block
  * row i, block column j.  Used to run the scalar tensor-pattern PtAP block by block. */
+/* C = A + B on the union of the two patterns (MatAXPY, DIFFERENT_NONZERO_PATTERN [ext]); ascending columns. */
+int tg_csr_add(tg_csr_t a, tg_csr_t b, tg_csr_t *out);
 int tg_csr_block(tg_csr_t a, int64_t r0, int64_t r1, int64_t c0, int64_t c1, tg_csr_t *out);
 int tg_csr_from_blocks(int nf, const tg_csr_t *blocks, tg_csr_t *out);
 int tg_partition_mode(tg_csr_t mt, const int32_t *fe_owner, int world, int32_t *owner_out);
@@ -252,6 +254,12 @@ int tg_tensor_plan_destroy(tg_tensor_plan_t plan);
  * across sub-slabs. */
 int tg_tensor_planes(tg_tensor_plan_t plan, tg_csr_t a, int64_t a_row0, int z0, int z1, tg_tensor_planes_t *out);
 int tg_tensor_planes_destroy(tg_tensor_planes_t p);
+/* An FE matrix on the plan's node grid with ANOTHER pattern than the element-coupling one (entries added by hand, or
+ * missing): on_pattern = the matrix with exactly that pattern holding A's entries that lie on it (zeros elsewhere; it
+ * carries the pattern certificate), remainder = the other entries as a CSR matrix of A's shape.
+ * M^T A M = M^T on_pattern M (tg_tensor_planes / tg_tensor_zstage) + M^T remainder M (tg_ptap_*), tg_csr_add.
+ * Returns 100 when A is not a square matrix on the whole node grid. */
+int tg_tensor_split(tg_tensor_plan_t plan, tg_csr_t a, tg_csr_t *on_pattern, tg_csr_t *remainder);
 /* z pass: rows of K for the dof planes [ka,kb) from pieces that together hold the FE planes in their support;
  * MatZeroRowsColumns(zero_dofs, diag) fused; appended to `dest` (next rows of a slab-wise builder) or, with
  * dest == NULL, returned as a new matrix in *out. */

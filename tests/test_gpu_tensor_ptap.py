@@ -252,3 +252,74 @@ def test_several_fields_on_one_basis_go_block_by_block(p, nels, nF):
     assert np.max(np.abs(Kr.data - Kro.data)) <= 1e-12 * np.max(np.abs(Kro.data))
     Kb = orig(dev.DeviceCSR.from_scipy(A), np.asarray(zd), 3.0, False).to_scipy()
     assert np.array_equal(Kb.indices, K.indices) and np.max(np.abs(Kb.data - K.data)) <= 1e-12 * np.max(np.abs(K.data))
+
+
+@pytest.mark.parametrize("p,nels", [(2, (4, 3, 5)), (3, (3, 3, 2)), (1, (5, 4, 3))])
+def test_matrix_with_entries_outside_the_pattern_is_split(p, nels):
+    """An FE matrix with couplings added by hand (demos/kl-shell-svk/reef-knot.py:466 adds contact terms) and with some
+    entries of the element-coupling pattern missing: the part on the pattern goes through the line walks, the rest
+    through the general kernels, the products are added on the union of their patterns and the boundary conditions
+    applied to the sum.  Against the oracle's M^T A M (values; pattern = structural pattern of the product), and the
+    pieces themselves against A.  Entries of the pattern that A does not store count as stored zeros on this path: the
+    product's pattern is that of the full band plus the remainder's -- a superset of what PETSc's symbolic product
+    would allocate for such an A (and the diagonal of a constrained row always exists for MatZeroRowsColumns)."""
+    from tigar_amd.tensorptap import TensorPtAP
+    from tigar_amd import device as dev
+    gen, spline = _patch(p, nels)
+    plan = TensorPtAP.for_extraction(spline._kron)
+    A0 = _random_fe_matrix(p, nels, seed=11)
+    n = A0.shape[0]
+    rng = np.random.default_rng(4)
+    # drop a few entries of the pattern, add far couplings (some rows get many), keep it non-symmetric
+    A = A0.tolil()
+    for r in rng.choice(n, size=12, replace=False):
+        cols = A0.indices[A0.indptr[r]:A0.indptr[r + 1]]
+        cols = cols[cols != r]                      # (a missing DIAGONAL entry is another matter: see the docstring)
+        A[r, cols[rng.integers(0, cols.size)]] = 0.0
+    extra_rows = rng.choice(n, size=15, replace=False)
+    for r in extra_rows:
+        for c in rng.choice(n, size=int(rng.integers(1, 40)), replace=False):
+            A[r, c] = rng.standard_normal()
+    A = A.tocsr()
+    A.eliminate_zeros()
+    A.sort_indices()
+    Ad = dev.DeviceCSR.from_scipy(A)
+    assert plan.planes(Ad, 0, 0, p * nels[2] + 1) is None                    # not the pattern
+    on, off = plan.split(Ad)
+    on_s, off_s = on.to_scipy(), off.to_scipy()
+    assert on_s.nnz == A0.nnz and np.array_equal(on_s.indices, A0.indices)    # exactly the pattern, zeros where A has none
+    assert abs(on_s + off_s - A).max() == 0.0 and off_s.nnz > 0
+    assert off_s.multiply(abs(A0) > 0).nnz == 0                               # nothing of the remainder lies on the pattern
+    s = O.BSpline([p] * 3, [O.uniform_knots(p, 0., 1., m) for m in nels])
+    Mo = O.generate_M_tensor(s)
+    zd = list(spline.zeroDofs)
+    Ko = O.extract_matrix(Mo, A, zd, diag=2.0)
+    K = spline.extractMatrix(A, diag=2.0).to_scipy()
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+    # pattern: union of the band (structural product of the pattern part) and the product of the remainder
+    band = O.extract_matrix(Mo, sp.csr_matrix((np.ones(A0.nnz), A0.indices, A0.indptr), shape=A0.shape), [], 1.0)
+    rest = O.extract_matrix(Mo, sp.csr_matrix((np.ones(off_s.nnz), off_s.indices, off_s.indptr), shape=A0.shape), [], 1.0)
+    union = ((abs(band) + abs(rest)) > 0).tocsr()
+    union.sort_indices()
+    assert np.array_equal(K.indptr, union.indptr) and np.array_equal(K.indices, union.indices)
+    # the same result with the split switched off (general line kernels on the whole matrix)
+    os.environ["TIGAR_PTAP_SPLIT"] = "0"
+    try:
+        Kg = spline.extractMatrix(A, diag=2.0).to_scipy()
+    finally:
+        del os.environ["TIGAR_PTAP_SPLIT"]
+    assert abs(Kg - K).max() <= 1e-12 * abs(K).max()
+    # A + B on the union pattern (tg_csr_add) on its own
+    B1, B2 = _rand_pair(rng, 300, 200)
+    S = dev.DeviceCSR.from_scipy(B1).add(dev.DeviceCSR.from_scipy(B2)).to_scipy()
+    R = (B1 + B2).tocsr()
+    assert abs(S - R).max() < 1e-15 and S.has_sorted_indices
+    U = ((abs(B1) > 0).astype(int) + (abs(B2) > 0).astype(int)).tocsr()
+    assert S.nnz == U.nnz
+
+
+def _rand_pair(rng, n, m):
+    a = sp.random(n, m, density=0.05, random_state=np.random.RandomState(1), format="csr")
+    b = sp.random(n, m, density=0.01, random_state=np.random.RandomState(2), format="csr")
+    a.sort_indices(), b.sort_indices()
+    return a, b

@@ -86,6 +86,8 @@ PROTOTYPES = {
     "tg_csr_download_rows": (C.c_int, [handle, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f64p, C.c_int64]),
     "tg_csr_destroy": (C.c_int, [handle]),
     "tg_csr_transpose": (C.c_int, [handle, C.POINTER(handle)]),
+    "tg_csr_add": (C.c_int, [handle, handle, C.POINTER(handle)]),
+    "tg_tensor_split": (C.c_int, [handle, handle, C.POINTER(handle), C.POINTER(handle)]),
     "tg_csr_block": (C.c_int, [handle, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(handle)]),
     "tg_csr_from_blocks": (C.c_int, [C.c_int, C.POINTER(handle), C.POINTER(handle)]),
     "tg_partition_mode": (C.c_int, [handle, c_i32p, C.c_int, c_i32p]),

@@ -1186,7 +1186,9 @@ class ExtractedSpline(object):
             groups = default_groups(kx.d, max(s1.p for s1 in kx.basis.splines))
             if os.environ.get("TIGAR_PTAP_FACTORED", "1") != "0":
                 # Kronecker-structured M: dense-box kernel (one stage or sum-factorised stages)
-                return ptap_factored(kx, A, (0, kx.nfe[-1]), (0, kx.nfe[-1]), (0, kx.ncp[-1]), zd, float(diag), groups)
+                stored = None if self._implicit() else (self.M, self.MT)
+                return ptap_factored(kx, A, (0, kx.nfe[-1]), (0, kx.nfe[-1]), (0, kx.ncp[-1]), zd, float(diag), groups,
+                                     stored=stored)
         if self._implicit():
             raise NotImplementedError("general PtAP with an implicit extraction operator: materialise M "
                                       "(TIGAR_IMPLICIT_M=0) or pass a tensor-product FE matrix")
@@ -1233,6 +1235,12 @@ class ExtractedSpline(object):
         scalar = {}
 
         def general(Aij):
+            if tensor:
+                # the scalar machinery for a Kronecker M: pattern split (entries outside the element-coupling pattern
+                # apart), else the general line kernels
+                from .kronptap import default_groups, ptap_factored
+                groups = default_groups(kx.d, max(s1.p for s1 in kx.basis.splines))
+                return ptap_factored(kx, Aij, (0, nz), (0, nz), (0, kz), None, 1.0, groups)
             if not scalar:
                 scalar["M"] = self.M.block(0, nfe, 0, ncp)
                 scalar["MT"] = scalar["M"].transpose()

@@ -23,6 +23,7 @@ struct tg_tensor_plan_s {
   int nlines1[2] = {0, 0};
   std::vector<int32_t> h_rps[3], h_kps[3];
   uint64_t expect_tag = 0; // tg_pattern_hash of the element-coupling pattern the passes rely on
+  std::vector<int32_t> h_ecol[3];   // that pattern's 1-D column indices (rows as in h_rps)
   int *status = nullptr;   // device flag
 };
 
@@ -153,6 +154,7 @@ extern "C" int tg_tensor_plan_create(int d, const tg_tensor_dir_t *dirs, tg_tens
       nr[k] = nc[k] = nfe;
     }
     pl->expect_tag = tg_pattern_hash(3, nr, nc, rps, cls, 0);
+    for (int k = 0; k < 3; k++) pl->h_ecol[k] = ecol[k];
   }
   if (!rc) {
     std::vector<int32_t> ls, lv;
@@ -347,6 +349,152 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
     return rc ? rc : 100;          // 100: A does not have the element-coupling pattern -> general path
   }
   *out = res;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// An FE matrix on the node grid whose pattern is NOT the element-coupling pattern (couplings added by hand: contact
+// terms, constraints; or entries missing): split into the part that lies on the pattern -- copied to the closed-form
+// positions of a matrix that has exactly the pattern (zeros where A has no entry) -- and the remainder, a CSR matrix of
+// the entries outside.  M^T A M = M^T A_on M (the line-walk passes) + M^T A_off M (general kernels, few entries).
+struct tt_split_args {
+  const int64_t *rowptr;     // A
+  const int32_t *col;
+  const double *val;
+  int nfe0, nfe1, nfe2;
+  const int64_t *crowptr;    // the conforming matrix (rows in closed form)
+  double *cval;
+  int64_t nrows;
+};
+
+template <int P>
+__device__ __forceinline__ bool tt_split_slot(const tt_split_args &A, int a0, int a1, int a2, int32_t c, int &slot) {
+  const uint32_t cu = (uint32_t)c, t = cu / (uint32_t)A.nfe0;
+  const int b0 = (int)(cu - t * (uint32_t)A.nfe0);
+  const int b2 = (int)(t / (uint32_t)A.nfe1), b1 = (int)(t - (uint32_t)b2 * (uint32_t)A.nfe1);
+  const int l0 = tt_rlo<P>(a0, A.nfe0), n0 = tt_rn<P>(a0, A.nfe0);
+  const int l1 = tt_rlo<P>(a1, A.nfe1), n1 = tt_rn<P>(a1, A.nfe1);
+  const int l2 = tt_rlo<P>(a2, A.nfe2), n2 = tt_rn<P>(a2, A.nfe2);
+  const int d0 = b0 - l0, d1 = b1 - l1, d2 = b2 - l2;
+  const bool in = d0 >= 0 && d0 < n0 && d1 >= 0 && d1 < n1 && d2 >= 0 && d2 < n2;
+  slot = (d2 * n1 + d1) * n0 + d0;
+  return in;
+}
+
+// one wave per row.  FILL = false: entries on the pattern go to their slots, the others are counted (rem_len);
+// FILL = true: the others are copied in order to the remainder (rem_rowptr scanned in between)
+template <int P, bool FILL>
+__global__ void __launch_bounds__(256)
+    k_tt_split(tt_split_args A, int64_t *__restrict__ rem_rowptr, int32_t *__restrict__ rem_col,
+               double *__restrict__ rem_val) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < A.nrows; r += nwaves) {
+    const uint32_t ru = (uint32_t)r, t = ru / (uint32_t)A.nfe0;
+    const int a0 = (int)(ru - t * (uint32_t)A.nfe0);
+    const int a2 = (int)(t / (uint32_t)A.nfe1), a1 = (int)(t - (uint32_t)a2 * (uint32_t)A.nfe1);
+    const int64_t b = A.rowptr[r], e = A.rowptr[r + 1], cb = A.crowptr[r];
+    int64_t out = FILL ? rem_rowptr[r] : 0;
+    int cnt = 0;
+    for (int64_t q0 = b; q0 < e; q0 += 64) {
+      const int64_t q = q0 + lane;
+      bool off = false;
+      int32_t c = 0;
+      double v = 0.0;
+      if (q < e) {
+        c = A.col[q];
+        v = A.val[q];
+        int slot;
+        const bool in = tt_split_slot<P>(A, a0, a1, a2, c, slot);
+        if (in) {
+          if (!FILL) A.cval[cb + slot] = v;
+        } else
+          off = true;
+      }
+      const unsigned long long m = __ballot(off);
+      if (FILL) {
+        if (off) {
+          const int64_t pos = out + __popcll(m & ((1ull << lane) - 1ull));
+          rem_col[pos] = c;
+          rem_val[pos] = v;
+        }
+        out += __popcll(m);
+      } else
+        cnt += __popcll(m);
+    }
+    if (!FILL && lane == 0) rem_rowptr[r] = cnt;
+  }
+}
+
+extern "C" int tg_tensor_split(tg_tensor_plan_t pl, tg_csr_t a, tg_csr_t *on_pattern, tg_csr_t *remainder) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(pl && a && on_pattern && remainder, "null argument to tg_tensor_split");
+  TG_REQUIRE_CANONICAL(a);
+  const int P = pl->P;
+  const tt_dir_t &D0 = pl->dir[0], &D1 = pl->dir[1], &D2 = pl->dir[2];
+  const int64_t n = (int64_t)D0.nfe * D1.nfe * D2.nfe;
+  if (a->nrows != n || a->ncols != n || n >= 0xffffffffll) return 100;     // not a (whole) matrix on this node grid
+  // the matrix with exactly the pattern, values zero: the Kronecker product of the 1-D patterns (carries the certificate)
+  std::vector<double> zeros[3];
+  tg_kron_dir_t dirs[3];
+  for (int k = 0; k < 3; k++) {
+    zeros[k].assign(pl->h_ecol[k].size(), 0.0);
+    dirs[k].n = pl->dir[k].nfe;
+    dirs[k].rowptr = pl->h_rps[k].data();
+    dirs[k].col = pl->h_ecol[k].data();
+    dirs[k].val = zeros[k].data();
+  }
+  tg_csr_s *conf = nullptr, *rem = nullptr;
+  TG_TRY(tg_kron_sum_csr(3, 1, dirs, 0, n, &conf));
+  int rc = 0;
+  if (conf->pattern_tag != pl->expect_tag) {
+    tg_set_error("tg_tensor_split: the pattern matrix does not carry the plan's certificate");
+    rc = 1;
+  }
+  int64_t *rlen = nullptr;
+  if (!rc) rc = tg_dmalloc(&rlen, n + 1);
+  tt_split_args S;
+  S.rowptr = a->rowptr;
+  S.col = a->col;
+  S.val = a->val;
+  S.nfe0 = D0.nfe;
+  S.nfe1 = D1.nfe;
+  S.nfe2 = D2.nfe;
+  S.crowptr = conf->rowptr;
+  S.cval = conf->val;
+  S.nrows = n;
+  const unsigned grid = (unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 32);
+  if (!rc) {
+    // (the values written by the Kronecker kernel are 0.0 * ... = 0.0: every slot A does not fill stays zero)
+#define TT_S0(PP) hipLaunchKernelGGL((k_tt_split<PP, false>), dim3(grid), dim3(256), 0, g_tg.stream, S, rlen, (int32_t *)nullptr, (double *)nullptr)
+    TT_DISPATCH_P(P, TT_S0);
+#undef TT_S0
+    if (hipGetLastError() != hipSuccess) rc = 1;
+  }
+  int64_t total = 0;
+  if (!rc) rc = tg_exclusive_scan_i64(rlen, n, &total);
+  if (!rc) rc = tg_csr_alloc(n, n, total, &rem);
+  if (!rc) {
+    if (hipMemcpyAsync(rem->rowptr, rlen, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess)
+      rc = 1;
+    if (!rc && total > 0) {
+#define TT_S1(PP) hipLaunchKernelGGL((k_tt_split<PP, true>), dim3(grid), dim3(256), 0, g_tg.stream, S, rem->rowptr, rem->col, rem->val)
+      TT_DISPATCH_P(P, TT_S1);
+#undef TT_S1
+      if (hipGetLastError() != hipSuccess) rc = 1;
+    }
+  }
+  if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
+  tg_dfree(rlen);
+  if (rc) {
+    tg_csr_destroy(conf);
+    if (rem) tg_csr_destroy(rem);
+    tg_set_error("tg_tensor_split failed");
+    return 1;
+  }
+  *on_pattern = conf;
+  *remainder = rem;
   return 0;
 }
 

@@ -714,6 +714,136 @@ extern "C" int tg_csr_from_blocks(int nf, const tg_csr_t *blocks, tg_csr_t *out)
 }
 
 // ----------------------------------------------------------------------------------------
+// C = A + B on the union of the two patterns (MatAXPY with DIFFERENT_NONZERO_PATTERN [ext]); rows in ascending column
+// order.  One thread per row walks both rows (B is the small operand where this is used: the product of the entries of
+// an FE matrix that lie outside the element-coupling pattern).
+template <bool FILL>
+__global__ void k_csr_add(const int64_t *__restrict__ arp, const int32_t *__restrict__ ac, const double *__restrict__ av,
+                          const int64_t *__restrict__ brp, const int32_t *__restrict__ bc, const double *__restrict__ bv,
+                          int64_t n, int64_t *__restrict__ crp, int32_t *__restrict__ cc, double *__restrict__ cv) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; r < n; r += stride) {
+    int64_t i = arp[r], j = brp[r];
+    const int64_t ie = arp[r + 1], je = brp[r + 1];
+    int64_t o = FILL ? crp[r] : 0;
+    if (!FILL && j == je) {                       // (the common case: nothing to add in this row)
+      crp[r] = ie - i;
+      continue;
+    }
+    while (i < ie || j < je) {
+      const int32_t ca = i < ie ? ac[i] : 0x7fffffff, cb = j < je ? bc[j] : 0x7fffffff;
+      if (FILL) {
+        if (ca == cb) {
+          cc[o] = ca;
+          cv[o] = av[i] + bv[j];
+        } else if (ca < cb) {
+          cc[o] = ca;
+          cv[o] = av[i];
+        } else {
+          cc[o] = cb;
+          cv[o] = bv[j];
+        }
+      }
+      o++;
+      if (ca <= cb) i++;
+      if (cb <= ca) j++;
+    }
+    if (!FILL) crp[r] = o;
+  }
+}
+
+// rows without an entry of B: copied by a wave (coalesced) instead of the thread walk
+__global__ void __launch_bounds__(256)
+    k_csr_add_copy(const int64_t *__restrict__ arp, const int32_t *__restrict__ ac, const double *__restrict__ av,
+                   const int64_t *__restrict__ brp, int64_t n, const int64_t *__restrict__ crp, int32_t *__restrict__ cc,
+                   double *__restrict__ cv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n; r += nwaves) {
+    if (brp[r + 1] != brp[r]) continue;
+    const int64_t a = arp[r], len = arp[r + 1] - a, o = crp[r];
+    for (int64_t q = lane; q < len; q += 64) {
+      cc[o + q] = ac[a + q];
+      cv[o + q] = av[a + q];
+    }
+  }
+}
+
+__global__ void k_csr_add_mixed(const int64_t *__restrict__ arp, const int32_t *__restrict__ ac,
+                                const double *__restrict__ av, const int64_t *__restrict__ brp,
+                                const int32_t *__restrict__ bc, const double *__restrict__ bv, int64_t n,
+                                const int64_t *__restrict__ crp, int32_t *__restrict__ cc, double *__restrict__ cv) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; r < n; r += stride) {
+    int64_t i = arp[r], j = brp[r];
+    const int64_t ie = arp[r + 1], je = brp[r + 1];
+    if (j == je) continue;                        // (copied by k_csr_add_copy)
+    int64_t o = crp[r];
+    while (i < ie || j < je) {
+      const int32_t ca = i < ie ? ac[i] : 0x7fffffff, cb = j < je ? bc[j] : 0x7fffffff;
+      if (ca == cb) {
+        cc[o] = ca;
+        cv[o] = av[i] + bv[j];
+      } else if (ca < cb) {
+        cc[o] = ca;
+        cv[o] = av[i];
+      } else {
+        cc[o] = cb;
+        cv[o] = bv[j];
+      }
+      o++;
+      if (ca <= cb) i++;
+      if (cb <= ca) j++;
+    }
+  }
+}
+
+extern "C" int tg_csr_add(tg_csr_t a, tg_csr_t b, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(a && b && out, "null argument to tg_csr_add");
+  TG_REQUIRE(a->nrows == b->nrows && a->ncols == b->ncols, "tg_csr_add: shapes differ");
+  TG_REQUIRE_CANONICAL(a);
+  TG_REQUIRE_CANONICAL(b);
+  const int64_t n = a->nrows;
+  int64_t *len = nullptr;
+  TG_TRY(tg_dmalloc(&len, n + 1));
+  int rc = 0;
+  tg_csr_s *m = nullptr;
+  if (n > 0) {
+    hipLaunchKernelGGL((k_csr_add<false>), dim3(tg_grid_1d(n, 256)), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val,
+                       b->rowptr, b->col, b->val, n, len, (int32_t *)nullptr, (double *)nullptr);
+    if (hipGetLastError() != hipSuccess) rc = 1;
+  }
+  int64_t total = 0;
+  if (!rc) rc = tg_exclusive_scan_i64(len, n, &total);
+  if (!rc) rc = tg_csr_alloc(n, a->ncols, total, &m);
+  if (!rc) {
+    if (hipMemcpyAsync(m->rowptr, len, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess)
+      rc = 1;
+    if (!rc && n > 0 && total > 0) {
+      const unsigned wg = (unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16);
+      hipLaunchKernelGGL(k_csr_add_copy, dim3(wg), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val, b->rowptr, n,
+                         m->rowptr, m->col, m->val);
+      hipLaunchKernelGGL(k_csr_add_mixed, dim3(tg_grid_1d(n, 256)), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val,
+                         b->rowptr, b->col, b->val, n, m->rowptr, m->col, m->val);
+      if (hipGetLastError() != hipSuccess) rc = 1;
+    }
+  }
+  if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
+  tg_dfree(len);
+  if (rc) {
+    if (m) tg_csr_destroy(m);
+    tg_set_error("tg_csr_add failed");
+    return 1;
+  }
+  *out = m;
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------
 // IGA dof permutation (tIGAr/common.py:407-433, 1583-1665)
 // ----------------------------------------------------------------------------------------
 __global__ void k_relabel_cols(const int32_t *__restrict__ col, const int32_t *__restrict__ new_of_old, int64_t nnz,

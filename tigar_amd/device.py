@@ -205,6 +205,12 @@ class DeviceCSR(object):
             self._T = DeviceCSR(h)
         return self._T
 
+    def add(self, other):
+        """self + other on the union of the two patterns (tg_csr_add)"""
+        h = handle()
+        check(_lib.lib().tg_csr_add(self._h, other._h, C.byref(h)), "tg_csr_add")
+        return DeviceCSR(h)
+
     def block(self, r0, r1, c0, c1):
         """rows [r0, r1) x columns [c0, c1) as a matrix of its own, columns renumbered from 0 (tg_csr_block)"""
         h = handle()

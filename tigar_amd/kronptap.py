@@ -14,6 +14,8 @@ of (p+1)^d.  Hash-accumulate work drops from sum_i |supp_i| * nnz(A_r) * ... to 
 to have any structure.  Values agree with the one-shot product to rounding (entries of M are
 (Nu*Nv)*Nw either way); patterns are identical.
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -135,7 +137,7 @@ def contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs=None,
     return _dev.ptap_numeric(plan, cur, Pm, MT, zero_dofs, diag)
 
 
-def ptap_factored(kx, A, a_planes, c_planes, k_planes, zero_dofs=None, diag=1.0, groups=None):
+def ptap_factored(kx, A, a_planes, c_planes, k_planes, zero_dofs=None, diag=1.0, groups=None, _split=True, stored=None):
     """K rows of the dof planes ``k_planes`` from the FE rows ``A`` (DeviceCSR holding the FE
     planes ``a_planes`` = [za,zb) of the last direction, global columns reaching the planes
     ``c_planes`` = [ca,cb)), by contracting the direction groups one after the other.  Planes
@@ -152,6 +154,27 @@ def ptap_factored(kx, A, a_planes, c_planes, k_planes, zero_dofs=None, diag=1.0,
         piece = plan.planes(A, za * kx.plane(set()), za, zb)
         if piece is not None:
             return plan.zstage([piece], k0, k1, zero_dofs, diag)
+        # Another pattern (couplings added by hand -- contact, constraints -- or entries missing).  A whole resident
+        # matrix is split: what lies on the pattern goes through the line walks, the few entries outside through the
+        # general stages below, and the two products are added on the union of their patterns (the structural pattern
+        # of the whole product); the boundary conditions follow on the sum.  Worth it while the remainder is small.
+        whole = (za, zb) == (0, kx.nfe[-1]) and (k0, k1) == (0, kx.ncp[-1]) and A.shape[0] == A.shape[1]
+        if _split and whole and os.environ.get("TIGAR_PTAP_SPLIT", "1") != "0":
+            parts = plan.split(A)
+            if parts is not None and parts[1].nnz <= 0.25 * A.nnz:
+                on, off = parts
+                K = plan.zstage([plan.planes(on, 0, za, zb)], k0, k1)
+                if off.nnz:
+                    if stored is not None:
+                        # few entries anywhere in the matrix: the hash kernels (any sparsity) with the stored M, M^T
+                        M, MT = stored
+                        Kr = _dev.ptap_numeric(_dev.ptap_symbolic(off, M, MT), off, M, MT)
+                    else:
+                        Kr = ptap_factored(kx, off, a_planes, c_planes, k_planes, None, diag, groups, _split=False)
+                    K = K.add(Kr)
+                if zero_dofs is not None and len(zero_dofs):
+                    K.zero_rows_cols(np.asarray(zero_dofs, dtype=np.int32), diag)
+                return K
     if groups is None:
         groups = [[k] for k in range(d)]
     assert sorted(sum(groups, [])) == list(range(d)) and (d - 1) in groups[-1]

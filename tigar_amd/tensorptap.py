@@ -145,6 +145,17 @@ class TensorPtAP(object):
         check(rc, "tg_tensor_planes")
         return TensorPlanes(h, int(z0), int(z1))
 
+    def split(self, A):
+        """(on_pattern, remainder) of a whole FE matrix on this node grid (tg_tensor_split): the entries of A that lie on
+        the element-coupling pattern at their places in a matrix that has exactly that pattern, and the others as a CSR
+        matrix.  None when A is not a square matrix on the grid."""
+        on, off = handle(), handle()
+        rc = _lib.lib().tg_tensor_split(self._h, A._h, C.byref(on), C.byref(off))
+        if rc == 100:
+            return None
+        check(rc, "tg_tensor_split")
+        return _dev.DeviceCSR(on), _dev.DeviceCSR(off)
+
     def zstage(self, pieces, ka, kb, zero_dofs=None, diag=1.0, append_to=None):
         """rows of K for the dof planes [ka, kb): a new DeviceCSR, or True when appended to the builder"""
         arr = (handle * len(pieces))(*[pc._h for pc in pieces])
