@@ -717,39 +717,22 @@ extern "C" int tg_csr_from_blocks(int nf, const tg_csr_t *blocks, tg_csr_t *out)
 // C = A + B on the union of the two patterns (MatAXPY with DIFFERENT_NONZERO_PATTERN [ext]); rows in ascending column
 // order.  One thread per row walks both rows (B is the small operand where this is used: the product of the entries of
 // an FE matrix that lie outside the element-coupling pattern).
-template <bool FILL>
-__global__ void k_csr_add(const int64_t *__restrict__ arp, const int32_t *__restrict__ ac, const double *__restrict__ av,
-                          const int64_t *__restrict__ brp, const int32_t *__restrict__ bc, const double *__restrict__ bv,
-                          int64_t n, int64_t *__restrict__ crp, int32_t *__restrict__ cc, double *__restrict__ cv) {
+__global__ void k_csr_add_count(const int64_t *__restrict__ arp, const int32_t *__restrict__ ac,
+                                const int64_t *__restrict__ brp, const int32_t *__restrict__ bc, int64_t n,
+                                int64_t *__restrict__ crp) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; r < n; r += stride) {
     int64_t i = arp[r], j = brp[r];
     const int64_t ie = arp[r + 1], je = brp[r + 1];
-    int64_t o = FILL ? crp[r] : 0;
-    if (!FILL && j == je) {                       // (the common case: nothing to add in this row)
-      crp[r] = ie - i;
-      continue;
+    int64_t o = ie - i;                           // (the common case: nothing to add in this row)
+    while (j < je) {                              // columns of B that A does not have
+      const int32_t cb = bc[j];
+      while (i < ie && ac[i] < cb) i++;
+      if (!(i < ie && ac[i] == cb)) o++;
+      j++;
     }
-    while (i < ie || j < je) {
-      const int32_t ca = i < ie ? ac[i] : 0x7fffffff, cb = j < je ? bc[j] : 0x7fffffff;
-      if (FILL) {
-        if (ca == cb) {
-          cc[o] = ca;
-          cv[o] = av[i] + bv[j];
-        } else if (ca < cb) {
-          cc[o] = ca;
-          cv[o] = av[i];
-        } else {
-          cc[o] = cb;
-          cv[o] = bv[j];
-        }
-      }
-      o++;
-      if (ca <= cb) i++;
-      if (cb <= ca) j++;
-    }
-    if (!FILL) crp[r] = o;
+    crp[r] = o;
   }
 }
 
@@ -813,8 +796,8 @@ extern "C" int tg_csr_add(tg_csr_t a, tg_csr_t b, tg_csr_t *out) {
   int rc = 0;
   tg_csr_s *m = nullptr;
   if (n > 0) {
-    hipLaunchKernelGGL((k_csr_add<false>), dim3(tg_grid_1d(n, 256)), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val,
-                       b->rowptr, b->col, b->val, n, len, (int32_t *)nullptr, (double *)nullptr);
+    hipLaunchKernelGGL(k_csr_add_count, dim3(tg_grid_1d(n, 256)), dim3(256), 0, g_tg.stream, a->rowptr, a->col, b->rowptr,
+                       b->col, n, len);
     if (hipGetLastError() != hipSuccess) rc = 1;
   }
   int64_t total = 0;
