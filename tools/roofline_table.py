@@ -14,7 +14,8 @@ def short(name):
 def main():
     print("# Achieved HBM rates per kernel, round 2 (one MI355X)\n")
     print("Per launch: average duration from `rocprofv3 --kernel-trace` (`r2_cfg*_kernel_stats.txt`, summarised from the trace\n"
-          "database by `tools/kernel_trace.py --sum`), HBM bytes from the PMC passes (`r2_cfg*_pmc_hbm.json`: FETCH_SIZE and\n"
+          "database by `tools/kernel_trace.py --sum`; `r2_cfg*_rocprofv3_kernel_stats.csv` is rocprofv3's own `--stats` output of\n"
+          "the same command, `--output-format csv`), HBM bytes from the PMC passes (`r2_cfg*_pmc_hbm.json`: FETCH_SIZE and\n"
           "WRITE_SIZE in separate runs, reads x2 = the gfx950 correction of the guide, calibrated for 8 B/lane streams by\n"
           "`k_cg1_dot` / `k_cg1_update`, DESIGN.md section 5).  Rate = (read + written) / duration, as a fraction of the 8 TB/s\n"
           "HBM3E peak and of the ceiling a plain streaming kernel of the same read:write mix reaches on these boxes\n"
