@@ -119,7 +119,9 @@ def pick_sub_planes(d, p, nel, planes_mine, free_bytes):
     5 planes 1.59 s of input+PtAP, 8: 1.53 s, 12: 1.44 s, 16: 1.41 s with 75 GB still free at the end of a
     step, 20: allocation failures and pool trimming start, 24: 5.6 s.  (The sliced copy of K's values that
     lives during the Krylov solve, 47 GB at 256^3 p=3, is stored in idle blocks of the allocator's pool --
-    the PtAP temporaries sized here -- so it needs no budget of its own.)"""
+    the PtAP temporaries sized here -- so it needs no budget of its own.)  The tensor-pattern passes of round 2 need
+    less per plane (A rows + two dense intermediates, 1.6 GB per FE plane at 256^3 p=3) and are insensitive to the
+    choice: 12 planes (what this returns there) 1.145 s per step, 16: 1.148 s, 20: the allocator starts trimming."""
     nfe1 = nel * p + 1
     plane_fe = nfe1 ** (d - 1)
     nnzA_plane = plane_fe * ((2 * p + 1) ** d) * 0.55 * 12.0        # bytes per FE plane, generous
