@@ -170,6 +170,7 @@ def run(args, d, p, nel):
     its = solver.last["iterations"]
     mean_stages = {k: float(np.mean(v)) for k, v in stages.items()}
 
+    nodal_error = None
     if args.check and rank == 0:
         # manufactured solution u = prod sin(pi x_k) at the FE nodes this rank owns
         grid = spline.V.grids[0]
@@ -184,7 +185,8 @@ def run(args, d, p, nel):
         for k in range(d):
             exact *= np.sin(np.pi * grid.axes[k][(idx // stride) % n0[k]])
             stride *= n0[k]
-        log("[bench] max nodal error vs manufactured solution (rank 0 rows): %.3e" % np.max(np.abs(uh - exact)))
+        nodal_error = float(np.max(np.abs(uh - exact)))
+        log("[bench] max nodal error vs manufactured solution (rank 0 rows): %.3e" % nodal_error)
     if rank == 0:
         log("[bench] stages (mean s):", {k: round(v, 5) for k, v in mean_stages.items()}, "CG iterations:", its,
             "nnz(K) global:", nnzK, "M implicit:", bool(getattr(gen.M, "is_implicit", False)))
@@ -195,7 +197,7 @@ def run(args, d, p, nel):
             "t_input": mean_stages.get("fe_input", 0.0), "t_input_in_timed_region": not a_resident,
             "t_input_pre": t_input_pre, "sub_planes": spline._slab.sub_planes if spline._slab is not None else None,
             "sell_classes": sell_classes, "sell_padded": sell_padded, "implicit_M": bool(getattr(gen.M, "is_implicit", False)),
-            "ptap_certified": int(ptap_certified),
+            "ptap_certified": int(ptap_certified), "nodal_error": nodal_error,
             "comm_world": info[1], "comm_kind": info[2], "n_devices_used": min(info[1], ndev) if info[1] > 1 else 1}
 
 
@@ -373,6 +375,7 @@ def main():
                    "dofs": res["ncp"], "fe_rows": cnt["rows_fe"], "nnz_M": cnt["nnzM"], "nnz_A": cnt["nnzA"],
                    "nnz_K": res["nnzK"], "cg_iterations": res["iterations"],
                    "M_implicit": res["implicit_M"],
+                   "max_nodal_error_vs_manufactured_solution": res.get("nodal_error"),
                    "fe_matrix_pattern": ("certified by the assembly kernel that wrote it (tg_kron_sum_csr): the PtAP does not "
                                          "re-read the column indices; TIGAR_PTAP_VERIFY=1 verifies them entry by entry, "
                                          "+0.05 s per step at cfg3" if res.get("ptap_certified", 0) > 0
