@@ -52,9 +52,11 @@ int tg_timer_stop(int slot, double *ms);   /* synchronises; elapsed ms since sta
  * them whose halo-free rows were computed while the halo exchange with the neighbour ranks was under way; slot 2 (count
  * only): sliced copies (tg_spmv_sell / Krylov solves) built on the slice classes of an earlier matrix with the same
  * pattern instead of a new classification; slot 3 (count only): x passes of the tensor-pattern PtAP that took the FE
- * matrix' pattern from its certificate (written by tg_kron_sum_csr) instead of verifying every column index. */
+ * matrix' pattern from its certificate (written by tg_kron_sum_csr) instead of verifying every column index; slot 4 (count only): host waits
+ * (hipStreamSynchronize / transport calls) the device communicator needed inside halo exchanges and all-reduces -- 0 for
+ * RCCL and for the IPC communicator, whose exchanges are enqueued only. */
 enum { TG_PROF_KSP_SPMV = 0, TG_PROF_KSP_OVERLAPPED = 1, TG_PROF_SELL_SHAPE_REUSED = 2, TG_PROF_PTAP_CERTIFIED = 3,
-       TG_PROF_NSLOTS = 4 };
+       TG_PROF_COMM_HOST_WAITS = 4, TG_PROF_NSLOTS = 8 };
 int tg_prof_reset(void);
 int tg_prof_get(int slot, double *total_ms, int64_t *count);
 
@@ -365,6 +367,10 @@ int tg_assemble_mapped_load(const tg_patch_t *patch, tg_vec_t fnodal, tg_vec_t o
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------- */
 int tg_comm_unique_id(char *id128);                          /* ncclGetUniqueId   */
 int tg_comm_create(const char *id128, int rank, int world, tg_comm_t *out);
+/* the same with a second RCCL communicator for the halo send/recv pairs (exchange stream), so that they and the
+ * all-reduces (solver stream) never share one; id_halo may be NULL.  ncclCommInitRank is given TIGAR_RCCL_TIMEOUT_S
+ * seconds (default 180) and reported as failed afterwards instead of blocking for ever. */
+int tg_comm_create2(const char *id_reduce128, const char *id_halo128, int rank, int world, tg_comm_t *out);
 /* Host-staged communicator: the same solver code, its two exchanges (halo pieces with the z-neighbours,
  * sums of a few doubles over all ranks) staged through pinned host memory and carried by the caller's
  * transport (MPI-style callbacks; 0 = ok).  For process groups RCCL cannot form (ranks sharing a GPU).
@@ -374,7 +380,16 @@ typedef int (*tg_host_sendrecv_fn)(void *ctx, int peer, const double *send, int6
                                    int64_t nrecv);
 int tg_comm_create_host(int rank, int world, tg_host_allreduce_fn allreduce, tg_host_sendrecv_fn sendrecv,
                         void *ctx, tg_comm_t *out);
-/* ranks the communicator really spans (RCCL: ncclCommCount) and its kind (0 = RCCL, 1 = host-staged) */
+/* IPC communicator: no host in the loop and no RCCL -- halo planes are pushed by a kernel into the neighbour's device
+ * mailbox (hipIpcOpenMemHandle: the same GPU when ranks share one, an xGMI peer otherwise), flags and the slots of
+ * the small all-reduce live in the shared file `shm_path` (created and sized to tg_comm_ipc_shm_bytes() zero bytes by
+ * the launcher before any rank calls this; at most 16 ranks of one node), waits happen inside the kernels with a
+ * wall-clock limit (TIGAR_IPC_TIMEOUT_S, default 60): an exchange is enqueue-only, a dead peer surfaces as an error
+ * at the next host wait instead of hanging the GPU.  SURVEY 8(e): "direct xGMI peer copies". */
+int tg_comm_ipc_shm_bytes(int64_t *bytes);
+int tg_comm_create_ipc(const char *shm_path, int rank, int world, tg_comm_t *out);
+int tg_comm_rank_device(tg_comm_t c, int rank, int *device);
+/* ranks the communicator really spans (RCCL: ncclCommCount) and its kind (0 = RCCL, 1 = host-staged, 2 = IPC) */
 int tg_comm_info(tg_comm_t c, int *rank, int *world, int *kind);
 int tg_device_count(int *n);                                 /* visible GPUs      */
 /* z-slab descriptor of the Krylov vectors: this rank owns global dofs [g0,g1); the SpMV

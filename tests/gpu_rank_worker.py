@@ -36,6 +36,8 @@ def main():
     U = spline.solveLinearSystem(K, rhs, u)
     its1 = solver.last["iterations"]
     overlapped = dev.prof_get(1)[1]                      # products that ran beside their halo exchange
+    host_waits = dev.prof_get(4)[1]                      # host waits of the communicator inside the exchanges of the solve
+    resnorm = solver.last.get("residual_norm", np.nan)
     # second solve from the converged state: must stop at once (non-zero initial guess path with halo)
     solver.parameters["nonzero_initial_guess"] = True
     from tigar_amd.device import DeviceVector
@@ -48,8 +50,9 @@ def main():
     np.savez(os.path.join(outdir, "rank%d.npz" % comm.rank), g=np.array([g0, g1, r0, r1]),
              K_indptr=Ks.indptr, K_indices=Ks.indices, K_data=Ks.data, rhs=rhs.get_local(), U=U.get_local(),
              u=u.vector().get_local(), its=np.array([its1, its2]),
-             comm=np.array([rank_r, world_r, 0 if kind == "rccl" else 1]), cp0=cp0,
-             U2=U2.get_local(), overlapped=np.array([overlapped]))
+             comm=np.array([rank_r, world_r, dev.Comm.KINDS.index(kind)]), cp0=cp0,
+             U2=U2.get_local(), overlapped=np.array([overlapped]), host_waits=np.array([host_waits]),
+             resnorm=np.array([resnorm]))
     comm.barrier()
 
 

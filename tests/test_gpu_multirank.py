@@ -44,7 +44,7 @@ def _run_ranks(tmp_path, world, kind, d, p, nel, method, port, env_more=None):
     from tigar_amd.launch import spawn_local
     env = {"PYTHONPATH": ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), "TIGAR_COMM": kind}
     env.update(env_more or {})
-    if kind == "host":
+    if kind in ("host", "ipc"):
         env["TIGAR_DEVICE"] = "0"                       # every rank on the one GPU
     rc = spawn_local(world, [os.path.join(ROOT, "tests", "gpu_rank_worker.py"), str(tmp_path), str(d), str(p),
                              str(nel), method], env_extra=env, port=port)
@@ -59,7 +59,7 @@ def _compare(parts, ref, world, kind):
     fe_cover = np.zeros(u.shape[0], dtype=int)
     for r, z in enumerate(parts):
         g0, g1, r0, r1 = [int(v) for v in z["g"]]
-        assert list(z["comm"]) == [r, world, 0 if kind == "rccl" else 1]     # what the communicator itself reports
+        assert list(z["comm"]) == [r, world, ("rccl", "host", "ipc").index(kind)]   # what the communicator itself reports
         Kl = sp.csr_matrix((z["K_data"], z["K_indices"], z["K_indptr"]), shape=(g1 - g0, Ks.shape[1]))
         Kr = Ks[g0:g1]
         assert np.array_equal(Kl.indptr, Kr.indptr) and np.array_equal(Kl.indices, Kr.indices)   # pattern identical
@@ -98,6 +98,53 @@ def test_products_beside_the_halo_exchange_change_nothing(tmp_path):
         assert int(off[r]["overlapped"][0]) == 0
         assert int(on[r]["its"][0]) == int(off[r]["its"][0])
         assert np.array_equal(on[r]["U"], off[r]["U"])
+
+
+@pytest.mark.parametrize("d,p,nel,method,world", [(3, 2, 20, "cg", 2), (3, 3, 14, "cg", 3), (3, 2, 12, "gmres", 2)])
+def test_ipc_ranks_sharing_one_gpu(tmp_path, d, p, nel, method, world):
+    """The IPC communicator (device mailboxes through hipIpcOpenMemHandle + flags in shared memory, waits inside the
+    kernels): the same checks as the host-staged one, and no host wait inside any exchange of the CG solve."""
+    ref = _single(d, p, nel, method)
+    parts = _run_ranks(tmp_path, world, "ipc", d, p, nel, method, 30100 + 37 * (d * 100 + p * 10 + world))
+    _compare(parts, ref, world, "ipc")
+    for z in parts:
+        assert int(z["host_waits"][0]) == 0
+
+
+def test_ipc_iterates_are_those_of_the_host_staged_run(tmp_path):
+    """The enqueue-only CG (iterations enqueued two ahead of the norm the host has seen, products past convergence
+    gated on the device, halo beside the interior rows) over the IPC communicator gives bit for bit the iterate of the
+    host-staged run, whose every exchange waits for the host: both reductions add the ranks' contributions in rank
+    order, the halo carries the same doubles, and the two iterations enqueued past convergence change nothing
+    (they used to: the frozen update handed the already reduced scalars to the next all-reduce on EVERY rank)."""
+    d, p, nel, world = 3, 2, 24, 3
+    a, b = tmp_path / "ipc", tmp_path / "host"
+    a.mkdir(), b.mkdir()
+    ipc = _run_ranks(a, world, "ipc", d, p, nel, "cg", 32137)
+    host = _run_ranks(b, world, "host", d, p, nel, "cg", 32537)
+    for r in range(world):
+        assert int(ipc[r]["its"][0]) == int(host[r]["its"][0])
+        assert np.array_equal(ipc[r]["U"], host[r]["U"])
+        assert np.array_equal(ipc[r]["u"], host[r]["u"])
+        assert ipc[r]["resnorm"][0] == host[r]["resnorm"][0]
+        assert int(ipc[r]["host_waits"][0]) == 0 and int(host[r]["host_waits"][0]) > 0
+        assert int(ipc[r]["overlapped"][0]) >= int(ipc[r]["its"][0]) + 1      # products beside the exchange
+
+
+@pytest.mark.parametrize("kind,world", [("host", 3), ("ipc", 2), ("ipc", 3)])
+def test_iterations_enqueued_past_convergence_change_nothing(tmp_path, kind, world):
+    """The host enqueues CG iterations two ahead of the norm it has read; the ones past convergence must leave x, the
+    reported norm and the iteration count exactly as a run that reads every norm first (TIGAR_CG_LOOK=0).  With several
+    ranks the frozen update has to hand gamma / nu to the next all-reduce ONCE, not once per rank."""
+    d, p, nel = 3, 2, 18
+    a, b = tmp_path / "ahead", tmp_path / "lockstep"
+    a.mkdir(), b.mkdir()
+    ahead = _run_ranks(a, world, kind, d, p, nel, "cg", 33137 + world)
+    lock = _run_ranks(b, world, kind, d, p, nel, "cg", 33537 + world, {"TIGAR_CG_LOOK": "0"})
+    for r in range(world):
+        assert int(ahead[r]["its"][0]) == int(lock[r]["its"][0])
+        assert np.array_equal(ahead[r]["U"], lock[r]["U"])
+        assert ahead[r]["resnorm"][0] == lock[r]["resnorm"][0]
 
 
 @pytest.mark.parametrize("d,p,nel,method", [(3, 3, 24, "cg"), (3, 2, 16, "gmres")])

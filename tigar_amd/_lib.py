@@ -158,6 +158,10 @@ PROTOTYPES = {
     "tg_assemble_mapped_load": (C.c_int, [C.POINTER(tg_patch_t), handle, handle]),
     "tg_comm_unique_id": (C.c_int, [C.c_char_p]),
     "tg_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(handle)]),
+    "tg_comm_create2": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(handle)]),
+    "tg_comm_ipc_shm_bytes": (C.c_int, [C.POINTER(C.c_int64)]),
+    "tg_comm_create_ipc": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(handle)]),
+    "tg_comm_rank_device": (C.c_int, [handle, C.c_int, C.POINTER(C.c_int)]),
     "tg_comm_create_host": (C.c_int, [C.c_int, C.c_int, HOST_ALLREDUCE_FN, HOST_SENDRECV_FN, C.c_void_p,
                                       C.POINTER(handle)]),
     "tg_comm_info": (C.c_int, [handle, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

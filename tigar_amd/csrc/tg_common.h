@@ -29,8 +29,8 @@ struct tg_ctx_t {
   bool ready = false;
   hipEvent_t ev0[8], ev1[8];
   hipEvent_t pev0 = nullptr, pev1 = nullptr;   // per-kernel accounting
-  double prof_ms[4] = {0, 0, 0, 0};
-  int64_t prof_n[4] = {0, 0, 0, 0};
+  double prof_ms[TG_PROF_NSLOTS] = {0};
+  int64_t prof_n[TG_PROF_NSLOTS] = {0};
   // small persistent device scratch for reductions / scalars
   double *scratch = nullptr;       // TG_SCRATCH_DOUBLES doubles
   double *host_pinned = nullptr;   // 64 doubles, pinned

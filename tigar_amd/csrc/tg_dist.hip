@@ -4,8 +4,126 @@
 // (2) all-reduces of 1-31 doubles for dot products / norms.
 // Reference counterparts: PETSc VecScatter inside MatMult and MPI_Allreduce inside VecDot /
 // VecNorm of the KSP called at tIGAr/common.py:1255-1258 [ext].
+//
+// Three communicators carry the same solver code:
+//   kind 0  RCCL: ncclSend/ncclRecv for the halo (own communicator, exchange stream), ncclAllReduce (second
+//           communicator, solver stream);
+//   kind 1  host-staged: pinned staging + the caller's transport (a host wait per exchange);
+//   kind 2  IPC: device mailboxes opened through HIP IPC + flags in shared host memory, waits inside the kernels
+//           -- enqueue-only like RCCL, and it also works for ranks that SHARE a GPU (SURVEY 8e's "direct xGMI
+//           peer copies").
 #include "tg_dist.h"
 #include <algorithm>
+#include <chrono>
+#include <future>
+#include <thread>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+// ------------------------------------------------------------------------------------------ IPC kernels
+__device__ __forceinline__ unsigned long long tg_ld_sys(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void tg_st_sys(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// spins until *p >= v; false after `tmo` wall-clock ticks or when another rank has given up
+__device__ __forceinline__ bool tg_spin_ge(const unsigned long long *p, unsigned long long v, tg_ipc_shm *s,
+                                           long long tmo) {
+  if (tg_ld_sys(p) >= v) return true;
+  const long long t0 = wall_clock64();
+  unsigned n = 0;
+  while (tg_ld_sys(p) < v) {
+    __builtin_amdgcn_s_sleep(4);
+    if ((++n & 31u) == 0) {
+      if (tg_ld_sys(&s->abort_word) != 0ull) return false;
+      if (wall_clock64() - t0 > tmo) return false;
+    }
+  }
+  return true;
+}
+__device__ __forceinline__ void tg_ipc_give_up(tg_ipc_shm *s, int rank, unsigned long long what) {
+  tg_st_sys(&s->status[rank], what);
+  tg_st_sys(&s->abort_word, 1ull + (unsigned long long)rank);
+}
+
+// in-place sum over ranks of n <= TG_IPC_AR_MAX doubles: every rank publishes its contribution in its slot of the
+// shared table, waits for the others' and adds the slots up in rank order -- every rank gets the same bits, the bits
+// of the host-staged reduction (which also adds in rank order)
+__global__ void __launch_bounds__(256) k_ipc_allreduce(tg_ipc_shm *s, int rank, int world, double *dev, int n,
+                                                       unsigned long long seq, long long tmo) {
+  __shared__ int ok_lds;
+  const int par = (int)(seq & 1ull), tid = threadIdx.x;
+  if (tid == 0) ok_lds = 1;
+  for (int t = tid; t < n; t += 256)
+    __hip_atomic_store(&s->ar_slot[par][rank][t], dev[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __atomic_thread_fence(__ATOMIC_RELEASE);   // (system scope)
+  __syncthreads();
+  if (tid == 0) tg_st_sys(&s->ar_flag[par][rank], seq);
+  if (tid < world && tid != rank)
+    if (!tg_spin_ge(&s->ar_flag[par][tid], seq, s, tmo)) ok_lds = 0;
+  __syncthreads();
+  if (!ok_lds) {
+    if (tid == 0) tg_ipc_give_up(s, rank, 1ull);
+    return;
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  for (int t = tid; t < n; t += 256) {
+    double acc = 0.0;
+    for (int r = 0; r < world; r++)
+      acc += __hip_atomic_load(&s->ar_slot[par][r][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    dev[t] = acc;
+  }
+}
+
+struct tg_ipc_leg {          // one direction of a halo exchange
+  double *dst;
+  const double *src;
+  long long n;               // doubles; 0 = this leg does not exist
+  unsigned long long *wait;  // flag to wait for before copying (ack of the receiver / arrival flag)
+  unsigned long long wait_val;
+  unsigned long long *post;  // flag to set when every block has copied
+  unsigned long long post_val;
+};
+struct tg_ipc_legs {
+  tg_ipc_leg leg[2];
+};
+
+// copies both legs; a block waits for a leg's condition itself (its acquire makes the data visible to ITS cache
+// hierarchy), the last block to finish posts the flags
+__global__ void __launch_bounds__(256) k_ipc_move(tg_ipc_legs L, tg_ipc_shm *s, int rank, unsigned *done, long long tmo,
+                                                  unsigned long long what) {
+  __shared__ int ok_lds;
+  const int tid = threadIdx.x;
+  if (tid == 0) ok_lds = 1;
+  __syncthreads();
+  for (int k = 0; k < 2; k++) {
+    const tg_ipc_leg &g = L.leg[k];
+    if (g.n <= 0) continue;
+    if (tid == 0 && g.wait)
+      if (!tg_spin_ge(g.wait, g.wait_val, s, tmo)) ok_lds = 0;
+    __syncthreads();
+    if (!ok_lds) break;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < g.n; i += stride) g.dst[i] = g.src[i];
+  }
+  __atomic_thread_fence(__ATOMIC_RELEASE);   // (system scope: the copied data before the flags)
+  __syncthreads();
+  if (tid == 0) {
+    if (!ok_lds) tg_ipc_give_up(s, rank, what);
+    const unsigned prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ok_lds)
+        for (int k = 0; k < 2; k++)
+          if (L.leg[k].n > 0 && L.leg[k].post) tg_st_sys(L.leg[k].post, L.leg[k].post_val);
+    }
+  }
+}
+
+static inline void tg_comm_host_wait() { g_tg.prof_n[TG_PROF_COMM_HOST_WAITS] += 1; }
 
 extern "C" int tg_comm_unique_id(char *id128) {
   TG_REQUIRE(id128, "null id buffer");
@@ -16,22 +134,199 @@ extern "C" int tg_comm_unique_id(char *id128) {
   return 0;
 }
 
+// ncclCommInitRank blocks for ever when a rank never arrives: run it on a helper thread and give up after
+// TIGAR_RCCL_TIMEOUT_S seconds (default 180; the thread is abandoned then -- the caller falls back to another
+// communicator or fails the run)
+static int tg_nccl_init_with_timeout(ncclComm_t *comm, int world, const ncclUniqueId &id, int rank, const char *what) {
+  const char *e = getenv("TIGAR_RCCL_TIMEOUT_S");
+  const double limit = e ? atof(e) : 180.0;
+  struct shared_t {
+    std::promise<ncclResult_t> done;
+    ncclComm_t comm = nullptr;
+  };
+  auto sh = std::make_shared<shared_t>();
+  std::future<ncclResult_t> fut = sh->done.get_future();
+  const int device = g_tg.device;
+  std::thread th([sh, world, id, rank, device]() {
+    ncclResult_t r = ncclSystemError;
+    if (hipSetDevice(device) == hipSuccess) r = ncclCommInitRank(&sh->comm, world, id, rank);
+    sh->done.set_value(r);
+  });
+  if (fut.wait_for(std::chrono::duration<double>(limit)) != std::future_status::ready) {
+    th.detach();
+    tg_set_error("ncclCommInitRank (%s, rank %d of %d) did not return within %.0f s", what, rank, world, limit);
+    return 1;
+  }
+  th.join();
+  const ncclResult_t r = fut.get();
+  if (r != ncclSuccess) {
+    tg_set_error("ncclCommInitRank (%s) failed: %s", what, ncclGetErrorString(r));
+    return 1;
+  }
+  *comm = sh->comm;
+  return 0;
+}
+
 extern "C" int tg_comm_create(const char *id128, int rank, int world, tg_comm_t *out) {
+  return tg_comm_create2(id128, nullptr, rank, world, out);
+}
+
+// two RCCL communicators over the same ranks: `id_reduce` carries the all-reduces on the solver's stream, `id_halo`
+// (may be null: one communicator for both) the send/recv pairs on the exchange stream -- RCCL orders the operations of
+// ONE communicator across streams with extra event dependencies, two communicators keep the streams independent
+extern "C" int tg_comm_create2(const char *id_reduce, const char *id_halo, int rank, int world, tg_comm_t *out) {
   TG_REQUIRE_INIT();
-  TG_REQUIRE(id128 && out && world >= 1 && rank >= 0 && rank < world, "bad arguments to tg_comm_create");
+  TG_REQUIRE(id_reduce && out && world >= 1 && rank >= 0 && rank < world, "bad arguments to tg_comm_create");
   tg_comm_s *c = new tg_comm_s();
   c->rank = rank;
   c->world = world;
   ncclUniqueId id;
-  memcpy(&id, id128, 128);
-  ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
-  if (r != ncclSuccess) {
-    tg_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r));
+  memcpy(&id, id_reduce, 128);
+  if (tg_nccl_init_with_timeout(&c->comm, world, id, rank, "all-reduce") != 0) {
     delete c;
     return 1;
   }
+  c->comm_x = c->comm;
+  if (id_halo && world > 1) {
+    memcpy(&id, id_halo, 128);
+    if (tg_nccl_init_with_timeout(&c->comm_x, world, id, rank, "halo") != 0) {
+      ncclCommDestroy(c->comm);
+      delete c;
+      return 1;
+    }
+  }
   *out = c;
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------ IPC communicator
+extern "C" int tg_comm_ipc_shm_bytes(int64_t *bytes) {
+  TG_REQUIRE(bytes, "null argument");
+  *bytes = (int64_t)((sizeof(tg_ipc_shm) + 4095) / 4096 * 4096);
+  return 0;
+}
+
+static int tg_ipc_allreduce_host(tg_comm_s *c, double *host_inout, int n);
+
+static int tg_ipc_close_peers(tg_comm_s *c) {
+  for (int k = 0; k < 2; k++)
+    if (c->peer_mail[k]) {
+      TG_CHECK_HIP(hipIpcCloseMemHandle(c->peer_mail[k]));
+      c->peer_mail[k] = nullptr;
+    }
+  return 0;
+}
+
+// (re)allocates the own mailbox with room for `cap` doubles, publishes its handle and opens the neighbours'.
+// Collective: every rank calls it at the same point.
+static int tg_ipc_mailboxes(tg_comm_s *c, int64_t cap, bool first) {
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  if (c->xstream) TG_CHECK_HIP(hipStreamSynchronize(c->xstream));
+  TG_TRY(tg_ipc_close_peers(c));
+  if (!first) {   // nobody may still map the block that is about to be freed
+    double one = 1.0;
+    TG_TRY(tg_ipc_allreduce_host(c, &one, 1));
+  }
+  if (cap > c->mail_cap || !c->mail) {
+    if (c->mail) TG_CHECK_HIP(hipFree(c->mail));
+    c->mail = nullptr;
+    cap = std::max<int64_t>(cap, 8192);
+    TG_CHECK_HIP(hipMalloc((void **)&c->mail, (size_t)cap * sizeof(double)));
+    TG_CHECK_HIP(hipMemset(c->mail, 0, (size_t)cap * sizeof(double)));
+    c->mail_cap = cap;
+  }
+  tg_ipc_shm *s = c->shm;
+  TG_CHECK_HIP(hipIpcGetMemHandle(&s->mail_h[c->rank], c->mail));
+  s->mail_cap[c->rank] = c->mail_cap;
+  s->device_of[c->rank] = g_tg.device;
+  c->mail_generation += 1;
+  __atomic_store_n(&s->mail_gen[c->rank], c->mail_generation, __ATOMIC_RELEASE);
+  const char *e = getenv("TIGAR_IPC_TIMEOUT_S");
+  const double limit = e ? atof(e) : 60.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < 2; k++) {
+    const int nb = k == 0 ? c->rank - 1 : c->rank + 1;
+    if (nb < 0 || nb >= c->world) continue;
+    while (__atomic_load_n(&s->mail_gen[nb], __ATOMIC_ACQUIRE) < c->mail_generation) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+        tg_set_error("IPC communicator: rank %d did not publish its mailbox within %.0f s", nb, limit);
+        return 1;
+      }
+      usleep(100);
+    }
+    hipIpcMemHandle_t h = s->mail_h[nb];
+    TG_CHECK_HIP(hipIpcOpenMemHandle((void **)&c->peer_mail[k], h, hipIpcMemLazyEnablePeerAccess));
+  }
+  return 0;
+}
+
+extern "C" int tg_comm_create_ipc(const char *shm_path, int rank, int world, tg_comm_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(shm_path && out && world >= 1 && world <= TG_IPC_MAXW && rank >= 0 && rank < world,
+             "bad arguments to tg_comm_create_ipc (at most %d ranks)", TG_IPC_MAXW);
+  int64_t bytes = 0;
+  tg_comm_ipc_shm_bytes(&bytes);
+  const int fd = open(shm_path, O_RDWR);
+  TG_REQUIRE(fd >= 0, "IPC communicator: cannot open %s", shm_path);
+  struct stat st;
+  if (fstat(fd, &st) != 0 || st.st_size < bytes) {
+    close(fd);
+    tg_set_error("IPC communicator: %s is smaller than %lld bytes", shm_path, (long long)bytes);
+    return 2;
+  }
+  void *m = mmap(nullptr, (size_t)bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  TG_REQUIRE(m != MAP_FAILED, "IPC communicator: mmap of %s failed", shm_path);
+  tg_comm_s *c = new tg_comm_s();
+  c->rank = rank;
+  c->world = world;
+  c->kind = 2;
+  c->shm = (tg_ipc_shm *)m;
+  auto fail = [&](int rc) {
+    tg_comm_destroy(c);
+    return rc;
+  };
+  if (hipHostRegister(m, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
+    tg_set_error("IPC communicator: hipHostRegister of the shared flags failed");
+    return fail(1);
+  }
+  c->shm_registered = true;
+  if (hipHostGetDevicePointer((void **)&c->shm_dev, m, 0) != hipSuccess) {
+    tg_set_error("IPC communicator: no device pointer for the shared flags");
+    return fail(1);
+  }
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, g_tg.device) != hipSuccess || khz <= 0) khz = 100000;
+  const char *e = getenv("TIGAR_IPC_TIMEOUT_S");
+  c->tmo_ticks = (long long)((e ? atof(e) : 60.0) * 1000.0 * khz);
+  if (hipMalloc((void **)&c->done_ctr, 4 * sizeof(unsigned)) != hipSuccess ||
+      hipMemset(c->done_ctr, 0, 4 * sizeof(unsigned)) != hipSuccess) {
+    tg_set_error("IPC communicator: allocation failed");
+    return fail(1);
+  }
+  const char *mb = getenv("TIGAR_IPC_MAILBOX_MB");
+  const int64_t cap = (int64_t)((mb ? atof(mb) : 8.0) * 1048576.0 / 8.0);
+  if (world > 1) {
+    int rc = tg_ipc_mailboxes(c, cap, true);
+    if (rc) return fail(rc);
+  }
+  *out = c;
+  return 0;
+}
+
+// status of the exchanges enqueued so far (call after a host wait): 0 = fine
+int tg_comm_check(tg_comm_s *c) {
+  if (!c || c->kind != 2 || !c->shm) return 0;
+  const unsigned long long ab = __atomic_load_n(&c->shm->abort_word, __ATOMIC_ACQUIRE);
+  if (ab == 0ull) return 0;
+  const unsigned long long mine = __atomic_load_n(&c->shm->status[c->rank], __ATOMIC_ACQUIRE);
+  static const char *what[] = {"", "an all-reduce", "the receiver's acknowledgement of a halo push", "the arrival of a halo"};
+  if (mine)
+    tg_set_error("IPC communicator (rank %d): gave up waiting for %s (a peer rank is gone or stuck)", c->rank,
+                 what[mine < 4 ? mine : 0]);
+  else
+    tg_set_error("IPC communicator (rank %d): rank %llu gave up waiting; the exchange is void", c->rank, ab - 1ull);
+  return 3;
 }
 
 extern "C" int tg_comm_create_host(int rank, int world, tg_host_allreduce_fn allreduce, tg_host_sendrecv_fn sendrecv,
@@ -64,6 +359,13 @@ extern "C" int tg_comm_info(tg_comm_t c, int *rank, int *world, int *kind) {
   return 0;
 }
 
+// devices the ranks of an IPC communicator sit on (as each rank published it); other kinds: -1
+extern "C" int tg_comm_rank_device(tg_comm_t c, int rank, int *device) {
+  TG_REQUIRE(c && device && rank >= 0 && rank < c->world, "bad arguments to tg_comm_rank_device");
+  *device = (c->kind == 2 && c->shm && c->world > 1) ? c->shm->device_of[rank] : (rank == c->rank ? g_tg.device : -1);
+  return 0;
+}
+
 extern "C" int tg_device_count(int *n) {
   TG_REQUIRE(n, "null argument to tg_device_count");
   TG_CHECK_HIP(hipGetDeviceCount(n));
@@ -79,8 +381,21 @@ extern "C" int tg_comm_destroy(tg_comm_t c) {
     hipEventDestroy(c->x_done);
     hipStreamDestroy(c->xstream);
   }
+  if (c->comm_x && c->comm_x != c->comm) ncclCommDestroy(c->comm_x);
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->stage) hipHostFree(c->stage);
+  if (c->kind == 2) {
+    for (int k = 0; k < 2; k++)
+      if (c->peer_mail[k]) hipIpcCloseMemHandle(c->peer_mail[k]);
+    if (c->mail) hipFree(c->mail);
+    if (c->done_ctr) hipFree(c->done_ctr);
+    if (c->shm) {
+      int64_t bytes = 0;
+      tg_comm_ipc_shm_bytes(&bytes);
+      if (c->shm_registered) hipHostUnregister(c->shm);
+      munmap(c->shm, (size_t)bytes);
+    }
+  }
   delete c;
   return 0;
 }
@@ -106,6 +421,14 @@ int tg_comm_allreduce_dev(tg_comm_s *c, double *dev, int n) {
     TG_CHECK_HIP(hipMemcpyAsync(dev, c->stage, (size_t)n * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
     // the staging buffer is reused by the next exchange: the copy must have left it
     TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+    tg_comm_host_wait();
+    return 0;
+  }
+  if (c->kind == 2) {
+    TG_REQUIRE(n >= 1 && n <= TG_IPC_AR_MAX, "IPC all-reduce of %d doubles (at most %d)", n, TG_IPC_AR_MAX);
+    hipLaunchKernelGGL(k_ipc_allreduce, dim3(1), dim3(256), 0, g_tg.stream, c->shm_dev, c->rank, c->world, dev, n,
+                       ++c->ar_seq, c->tmo_ticks);
+    TG_LAUNCH_CHECK();
     return 0;
   }
   TG_CHECK_NCCL(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, c->comm, g_tg.stream));
@@ -120,8 +443,10 @@ extern "C" int tg_comm_allreduce_sum(tg_comm_t c, double *host_inout, int n) {
   TG_TRY(tg_comm_allreduce_dev(c, d, n));
   TG_CHECK_HIP(hipMemcpyAsync(host_inout, d, n * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
-  return 0;
+  return tg_comm_check(c);
 }
+
+static int tg_ipc_allreduce_host(tg_comm_s *c, double *host_inout, int n) { return tg_comm_allreduce_sum(c, host_inout, n); }
 
 extern "C" int tg_comm_set_slab(tg_comm_t c, int64_t g0, int64_t g1, int64_t halo_lo, int64_t halo_hi,
                                 int64_t nglobal) {
@@ -157,6 +482,19 @@ extern "C" int tg_comm_set_slab(tg_comm_t c, int64_t g0, int64_t g1, int64_t hal
   } else
     TG_REQUIRE(halo_hi == 0, "last rank cannot have an upper halo");
   TG_REQUIRE(c->send_lo <= g1 - g0 && c->send_hi <= g1 - g0, "neighbour halo larger than this slab");
+  if (c->kind == 2 && W > 1) {
+    // layout of the neighbours' mailboxes (2 slots of [from below: their halo_lo | from above: their halo_hi]) and
+    // room in the own one; the mailboxes grow together when any rank needs more
+    for (int k = 0; k < 2; k++) {
+      const int nb = k == 0 ? c->rank - 1 : c->rank + 1;
+      const bool there = nb >= 0 && nb < W;
+      c->peer_halo[k][0] = there ? (int64_t)all[4 * nb + 2] : 0;
+      c->peer_halo[k][1] = there ? (int64_t)all[4 * nb + 3] : 0;
+    }
+    double grow = 2 * (halo_lo + halo_hi) > c->mail_cap ? 1.0 : 0.0;
+    TG_TRY(tg_comm_allreduce_sum(c, &grow, 1));
+    if (grow > 0.0) TG_TRY(tg_ipc_mailboxes(c, 2 * (halo_lo + halo_hi), false));
+  }
   c->slab_set = true;
   return 0;
 }
@@ -194,6 +532,34 @@ int tg_comm_halo_begin(tg_comm_s *c, double *xext) {
     c->x_open = true;
     return 0;
   }
+  if (c->kind == 2) {
+    // push the own ends into the neighbours' mailboxes (slot = message number & 1) once they have consumed the
+    // message that used the slot before; the last block posts the arrival flags
+    tg_ipc_legs L;
+    memset(&L, 0, sizeof(L));
+    tg_ipc_shm *sd = c->shm_dev;
+    if (c->rank > 0 && c->send_lo > 0) {          // to the lower neighbour's "from above" area
+      const unsigned long long t = ++c->tx[0];
+      const int64_t slot = (c->peer_halo[0][0] + c->peer_halo[0][1]) * (int64_t)(t & 1ull);
+      L.leg[0] = {c->peer_mail[0] + slot + c->peer_halo[0][0], own, (long long)c->send_lo,
+                  &sd->halo_ack[c->rank - 1][1], t >= 2 ? t - 2 : 0ull, &sd->halo_flag[c->rank - 1][1], t};
+    }
+    if (c->rank < c->world - 1 && c->send_hi > 0) {   // to the upper neighbour's "from below" area
+      const unsigned long long t = ++c->tx[1];
+      const int64_t slot = (c->peer_halo[1][0] + c->peer_halo[1][1]) * (int64_t)(t & 1ull);
+      L.leg[1] = {c->peer_mail[1] + slot, own + nloc - c->send_hi, (long long)c->send_hi,
+                  &sd->halo_ack[c->rank + 1][0], t >= 2 ? t - 2 : 0ull, &sd->halo_flag[c->rank + 1][0], t};
+    }
+    const int64_t total = c->send_lo + c->send_hi;
+    if (total > 0) {
+      const unsigned grid = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, tg_cdiv(total, 4096)));
+      hipLaunchKernelGGL(k_ipc_move, dim3(grid), dim3(256), 0, c->xstream, L, sd, c->rank, c->done_ctr, c->tmo_ticks,
+                         2ull);
+      TG_LAUNCH_CHECK();
+    }
+    c->x_open = true;
+    return 0;
+  }
   TG_CHECK_NCCL(ncclGroupStart());
   // between GroupStart and GroupEnd the first error is remembered and the group is still closed
   ncclResult_t first = ncclSuccess;
@@ -201,13 +567,13 @@ int tg_comm_halo_begin(tg_comm_s *c, double *xext) {
     if (r != ncclSuccess && first == ncclSuccess) first = r;
   };
   if (c->rank > 0) {
-    if (c->send_lo > 0) note(ncclSend(own, (size_t)c->send_lo, ncclDouble, c->rank - 1, c->comm, c->xstream));
-    if (c->halo_lo > 0) note(ncclRecv(xext, (size_t)c->halo_lo, ncclDouble, c->rank - 1, c->comm, c->xstream));
+    if (c->send_lo > 0) note(ncclSend(own, (size_t)c->send_lo, ncclDouble, c->rank - 1, c->comm_x, c->xstream));
+    if (c->halo_lo > 0) note(ncclRecv(xext, (size_t)c->halo_lo, ncclDouble, c->rank - 1, c->comm_x, c->xstream));
   }
   if (c->rank < c->world - 1) {
     if (c->send_hi > 0)
-      note(ncclSend(own + nloc - c->send_hi, (size_t)c->send_hi, ncclDouble, c->rank + 1, c->comm, c->xstream));
-    if (c->halo_hi > 0) note(ncclRecv(own + nloc, (size_t)c->halo_hi, ncclDouble, c->rank + 1, c->comm, c->xstream));
+      note(ncclSend(own + nloc - c->send_hi, (size_t)c->send_hi, ncclDouble, c->rank + 1, c->comm_x, c->xstream));
+    if (c->halo_hi > 0) note(ncclRecv(own + nloc, (size_t)c->halo_hi, ncclDouble, c->rank + 1, c->comm_x, c->xstream));
   }
   note(ncclGroupEnd());
   if (first != ncclSuccess) {
@@ -227,6 +593,7 @@ int tg_comm_halo_end(tg_comm_s *c, double *xext) {
     const int64_t nloc = c->g1 - c->g0;
     double *s_lo = c->stage, *s_hi = s_lo + c->send_lo, *r_lo = s_hi + c->send_hi, *r_hi = r_lo + c->halo_lo;
     TG_CHECK_HIP(hipStreamSynchronize(c->xstream));
+    tg_comm_host_wait();
     // lower neighbour first, then the upper one: the chain rank 0 <-> 1, 1 <-> 2, ... cannot dead-lock
     // because every exchange sends and receives at once
     if (c->rank > 0 && (c->send_lo > 0 || c->halo_lo > 0))
@@ -240,6 +607,32 @@ int tg_comm_halo_end(tg_comm_s *c, double *xext) {
     if (c->halo_hi > 0)
       TG_CHECK_HIP(hipMemcpyAsync(own + nloc, r_hi, (size_t)c->halo_hi * sizeof(double), hipMemcpyHostToDevice,
                                   c->xstream));
+  }
+  if (c->kind == 2) {
+    // pull the arrived planes out of the own mailbox into the halo of xext, acknowledge
+    double *own = xext + c->halo_lo;
+    const int64_t nloc = c->g1 - c->g0;
+    tg_ipc_legs L;
+    memset(&L, 0, sizeof(L));
+    tg_ipc_shm *sd = c->shm_dev;
+    if (c->rank > 0 && c->halo_lo > 0) {
+      const unsigned long long t = ++c->rx[0];
+      const int64_t slot = (c->halo_lo + c->halo_hi) * (int64_t)(t & 1ull);
+      L.leg[0] = {xext, c->mail + slot, (long long)c->halo_lo, &sd->halo_flag[c->rank][0], t, &sd->halo_ack[c->rank][0], t};
+    }
+    if (c->rank < c->world - 1 && c->halo_hi > 0) {
+      const unsigned long long t = ++c->rx[1];
+      const int64_t slot = (c->halo_lo + c->halo_hi) * (int64_t)(t & 1ull);
+      L.leg[1] = {own + nloc, c->mail + slot + c->halo_lo, (long long)c->halo_hi, &sd->halo_flag[c->rank][1], t,
+                  &sd->halo_ack[c->rank][1], t};
+    }
+    const int64_t total = c->halo_lo + c->halo_hi;
+    if (total > 0) {
+      const unsigned grid = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, tg_cdiv(total, 4096)));
+      hipLaunchKernelGGL(k_ipc_move, dim3(grid), dim3(256), 0, c->xstream, L, sd, c->rank, c->done_ctr + 1,
+                         c->tmo_ticks, 3ull);
+      TG_LAUNCH_CHECK();
+    }
   }
   TG_CHECK_HIP(hipEventRecord(c->x_done, c->xstream));
   TG_CHECK_HIP(hipStreamWaitEvent(g_tg.stream, c->x_done, 0));

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) k_cg1_fold(const double *__restrict__ par
 
 // one CG step from the scalars of `cur`; writes the recurrence state of the next parity into `nxt`
 __global__ void __launch_bounds__(256)
-    k_cg1_update(const tg_cg_scal *__restrict__ cur, tg_cg_scal *__restrict__ nxt, double tol2, int first,
+    k_cg1_update(const tg_cg_scal *__restrict__ cur, tg_cg_scal *__restrict__ nxt, double tol2, int first, int lead,
                  const double *__restrict__ w, const double *__restrict__ dinv, double *__restrict__ u,
                  double *__restrict__ p, double *__restrict__ s, double *__restrict__ x, double *__restrict__ r,
                  int64_t n, double *__restrict__ partial) {
@@ -181,9 +181,13 @@ __global__ void __launch_bounds__(256)
     nxt->alpha_prev = frozen ? cur->alpha_prev : alpha;
   }
   if (frozen) {
-    if (threadIdx.x == 0) {   // the fold of the next parity must reproduce the same gamma, nu
-      partial[2 * blockIdx.x] = blockIdx.x == 0 ? gamma : 0.0;
-      partial[2 * blockIdx.x + 1] = blockIdx.x == 0 ? nu : 0.0;
+    // the fold AND the all-reduce of the next parity must reproduce the same gamma, nu: they are already summed over
+    // the ranks, so only the leading rank hands them on (every other rank contributes zeros; all ranks take the same
+    // branch because they compare the same reduced nu)
+    if (threadIdx.x == 0) {
+      const bool carrier = lead && blockIdx.x == 0;
+      partial[2 * blockIdx.x] = carrier ? gamma : 0.0;
+      partial[2 * blockIdx.x + 1] = carrier ? nu : 0.0;
     }
     return;
   }
@@ -415,7 +419,10 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
     return 0;
   }
   // iterations are enqueued `look` ahead of the one whose norm the host has seen
-  const int look = 2;
+  // (TIGAR_CG_LOOK=0 makes the host read every norm before it enqueues the next iteration: nothing runs past convergence;
+  //  the tests compare the two modes bit for bit)
+  static const int look_env = getenv("TIGAR_CG_LOOK") ? std::max(0, std::min(TG_CG_RING - 2, atoi(getenv("TIGAR_CG_LOOK")))) : 2;
+  const int look = look_env;
   *status = -1;
   int seen = 0;           // iterations whose norm the host has read
   int it_conv = -1;
@@ -442,10 +449,11 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
   };
   int it = 0;
   bool stop = false;
+  const int lead = (!comm || comm->rank == 0) ? 1 : 0;
   for (it = 1; it <= maxit && !stop; it++) {
     tg_cg_scal *cur = &sc[(it - 1) & 1], *nxt = &sc[it & 1];
-    hipLaunchKernelGGL(k_cg1_update, dim3(vg), dim3(256), 0, g_tg.stream, cur, nxt, tol2, it == 1 ? 1 : 0, w, dinv, u, p,
-                       s, x->d, r, n, part_gn);
+    hipLaunchKernelGGL(k_cg1_update, dim3(vg), dim3(256), 0, g_tg.stream, cur, nxt, tol2, it == 1 ? 1 : 0, lead, w, dinv,
+                       u, p, s, x->d, r, n, part_gn);
     TG_TRY(product_and_reduce(nxt, it % TG_CG_RING, &cur->nu));
     if (it - look >= 1) stop = observe(it - look);
   }
@@ -454,6 +462,7 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
   *iters = it_conv >= 0 ? it_conv : std::min(enq, maxit);
   *resnorm = znorm;
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  TG_TRY(tg_comm_check(comm));
   if (getenv("TIGAR_TRACE"))
     fprintf(stderr, "[trace] cg: %d its (%d enqueued), loop %.3f s\n", *iters, enq, tk_now() - t_all0);
   return 0;
@@ -703,6 +712,7 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
   *iters = its;
   *resnorm = res;
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  TG_TRY(tg_comm_check(comm));
   return 0;
 }
 

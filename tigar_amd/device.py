@@ -817,10 +817,12 @@ def mem_info():
 class Comm(object):
     """RCCL communicator (one process per GPU) + z-slab descriptor."""
 
-    def __init__(self, unique_id, rank, world):
+    KINDS = ("rccl", "host", "ipc")
+
+    def __init__(self, unique_id, rank, world, unique_id_halo=None):
         self._h = handle()
         self.rank, self.world = rank, world
-        check(_lib.lib().tg_comm_create(unique_id, rank, world, C.byref(self._h)), "tg_comm_create")
+        check(_lib.lib().tg_comm_create2(unique_id, unique_id_halo, rank, world, C.byref(self._h)), "tg_comm_create")
 
     @staticmethod
     def unique_id():
@@ -848,7 +850,16 @@ class Comm(object):
         """(rank, world, kind) as the communicator itself reports them (RCCL: ncclCommUserRank / ncclCommCount)"""
         r, w, k = C.c_int(), C.c_int(), C.c_int()
         check(_lib.lib().tg_comm_info(self._h, C.byref(r), C.byref(w), C.byref(k)), "tg_comm_info")
-        return r.value, w.value, ("rccl", "host")[k.value]
+        return r.value, w.value, self.KINDS[k.value]
+
+    def rank_devices(self):
+        """device index of every rank as the ranks published them (IPC communicator; None entries otherwise)"""
+        out = []
+        for r in range(self.world):
+            d = C.c_int(-1)
+            check(_lib.lib().tg_comm_rank_device(self._h, r, C.byref(d)), "tg_comm_rank_device")
+            out.append(d.value if d.value >= 0 else None)
+        return out
 
     def __del__(self):
         try:
@@ -890,3 +901,44 @@ class HostComm(Comm):
         self._cb = (_lib.HOST_ALLREDUCE_FN(allreduce), _lib.HOST_SENDRECV_FN(sendrecv))   # keep the thunks alive
         check(_lib.lib().tg_comm_create_host(self.rank, self.world, self._cb[0], self._cb[1], None, C.byref(self._h)),
               "tg_comm_create_host")
+
+
+class IpcComm(Comm):
+    """IPC communicator (``tg_comm_create_ipc``): halo planes pushed into the neighbour's device mailbox through HIP
+    IPC, flags and all-reduce slots in a shared-memory file, all waits inside kernels -- enqueue-only like RCCL, but
+    it also serves ranks that share a GPU.  ``transport`` only carries the name of the shared file and two barriers."""
+
+    def __init__(self, transport):
+        import os
+        import tempfile
+        self._h = handle()
+        self.transport = transport
+        self.rank, self.world = transport.rank, transport.world
+        nbytes = C.c_int64(0)
+        check(_lib.lib().tg_comm_ipc_shm_bytes(C.byref(nbytes)), "tg_comm_ipc_shm_bytes")
+        path = None
+        if self.rank == 0:
+            base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+            fd, path = tempfile.mkstemp(prefix="tigar_ipc_", dir=base)
+            os.ftruncate(fd, nbytes.value)          # zero-filled
+            os.close(fd)
+        raw = (path or "").encode().ljust(512, b"\0")
+        raw = transport.broadcast_bytes(raw, 512)
+        path = raw.rstrip(b"\0").decode()
+        err = None
+        try:
+            check(_lib.lib().tg_comm_create_ipc(path.encode(), self.rank, self.world, C.byref(self._h)),
+                  "tg_comm_create_ipc")
+        except Exception as e:                      # every rank has to reach the barrier
+            err = e
+        bad = np.array([0.0 if err is None else 1.0])
+        transport.allreduce_sum(bad)
+        if self.rank == 0:
+            try:
+                os.unlink(path)                     # the mappings keep the memory alive
+            except OSError:
+                pass
+        if err is not None:
+            raise err
+        if bad[0] > 0.0:
+            raise _lib.TigarHipError("IPC communicator: %d rank(s) could not set it up" % int(bad[0]))

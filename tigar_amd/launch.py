@@ -9,9 +9,13 @@ barrier, small host reductions) plus, on top of it, a device communicator of lib
 
 * RCCL (``device.Comm``: ncclSend/Recv halo exchange + ncclAllReduce over xGMI) -- the product path on a
   multi-GPU node; the transport only carries the 128-byte RCCL id to the ranks;
+* IPC (``device.IpcComm``): halo planes pushed by a kernel into the neighbour's device mailbox (HIP IPC), flags
+  and the slots of the small all-reduce in a shared-memory file, waits inside the kernels -- enqueue-only like
+  RCCL; used where RCCL cannot form a group (several ranks sharing one GPU, e.g. on a 1-GPU box) and as the
+  fallback when RCCL fails to initialise;
 * host-staged (``device.HostComm``): the same solver code with its exchanges staged through pinned host
-  memory and carried by the transport.  Used where RCCL cannot form a group (several ranks sharing one GPU,
-  e.g. the 2-process tests on a 1-GPU box) -- it moves the same bytes between the same ranks.
+  memory and carried by the transport (one host wait per exchange) -- the last resort, and the reference the
+  other two are compared with bit for bit.
 
 Only the Python standard library is needed here (no torch import in the launch path: importing it would
 pull a second HIP / RCCL runtime into the process).  ``tests/`` adapt ``torch.distributed`` (gloo) to the
@@ -248,9 +252,11 @@ HostRendezvous = SocketTransport          # (name used by round-1 callers)
 
 
 def device_comm(transport, kind=None):
-    """Device communicator over ``transport``: RCCL when every rank has its own GPU, host-staged when ranks
-    share devices (``TIGAR_COMM=host`` forces the latter; ``TIGAR_COMM=rccl`` the former).  Returns None
-    for a single rank."""
+    """Device communicator over ``transport``: RCCL when every rank has its own GPU, the IPC communicator when ranks
+    share devices (``TIGAR_COMM=rccl|ipc|host`` forces one; ``host`` = staged through pinned memory and the transport,
+    a host wait per exchange).  A communicator that cannot be formed on some rank -- all ranks learn it through the
+    transport -- falls back in the order rccl -> ipc -> host instead of failing the run.  Returns None for a single
+    rank."""
     from . import device as dev
     if transport.world == 1:
         return None
@@ -258,33 +264,46 @@ def device_comm(transport, kind=None):
     if kind is None:
         ndev = dev.device_count()
         local = int(os.environ.get("LOCAL_WORLD_SIZE", transport.world))
-        kind = "rccl" if ndev >= local else "host"
+        kind = "rccl" if ndev >= local else "ipc"
     if kind == "host":
         return dev.HostComm(transport)
-    # RCCL; if the group cannot be formed on some rank (all ranks learn it through the transport) every rank falls
-    # back to the host-staged communicator instead of failing the run
+
+    def agreed(comm, err, what, fallback):
+        bad = np.array([0.0 if comm is not None else 1.0])
+        transport.allreduce_sum(bad)
+        if bad[0] > 0.0:
+            if transport.rank == 0:
+                print("[tigar_amd] %s communicator could not be created on %d rank(s) (%s); using the %s communicator"
+                      % (what, int(bad[0]), err, fallback), file=sys.stderr, flush=True)
+            return None
+        return comm
+
+    if kind == "rccl":
+        comm, err = None, None
+        try:
+            uid = (dev.Comm.unique_id() + dev.Comm.unique_id()) if transport.rank == 0 else None
+        except Exception as e:                      # (rank 0 only)
+            uid, err = None, e
+        flag = np.array([1.0 if (transport.rank == 0 and uid is None) else 0.0])
+        transport.allreduce_sum(flag)
+        if flag[0] == 0.0:
+            uid = transport.broadcast_bytes(uid, 256)
+            try:
+                comm = dev.Comm(uid[:128], transport.rank, transport.world, unique_id_halo=uid[128:])
+            except Exception as e:
+                err = e
+        comm = agreed(comm, err, "RCCL", "IPC")
+        if comm is not None:
+            return comm
     comm, err = None, None
     try:
-        uid = dev.Comm.unique_id() if transport.rank == 0 else None
-    except Exception as e:                      # (rank 0 only)
-        uid, err = None, e
-    flag = np.array([1.0 if (transport.rank == 0 and uid is None) else 0.0])
-    transport.allreduce_sum(flag)
-    if flag[0] == 0.0:
-        uid = transport.broadcast_bytes(uid, 128)
-        try:
-            comm = dev.Comm(uid, transport.rank, transport.world)
-        except Exception as e:
-            err = e
-    bad = np.array([0.0 if comm is not None else 1.0])
-    transport.allreduce_sum(bad)
-    if bad[0] > 0.0:
-        if transport.rank == 0:
-            print("[tigar_amd] RCCL communicator could not be created on %d rank(s) (%s); using the host-staged "
-                  "communicator" % (int(bad[0]), err), file=sys.stderr, flush=True)
-        comm = None
-        return dev.HostComm(transport)
-    return comm
+        comm = dev.IpcComm(transport)
+    except Exception as e:
+        err = e
+    comm = agreed(comm, err, "IPC", "host-staged")
+    if comm is not None:
+        return comm
+    return dev.HostComm(transport)
 
 
 def spawn_local(nproc, argv, env_extra=None, port=None):
