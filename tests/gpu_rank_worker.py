@@ -43,6 +43,17 @@ def main():
     from tigar_amd.device import DeviceVector
     U2 = DeviceVector(data=U.get_local())
     its2 = solver.solve(K, U2, rhs)
+    # optional: the same system at a ladder of tolerances (so that some solve ends with its norm just below the
+    # tolerance, the case in which an iteration enqueued past convergence could come back to life)
+    ladder_U, ladder_res, ladder_its = [], [], []
+    if method == "cg" and os.environ.get("TIGAR_TEST_RTOLS"):
+        solver.parameters["nonzero_initial_guess"] = False
+        for rt in [float(v) for v in os.environ["TIGAR_TEST_RTOLS"].split(",")]:
+            solver.parameters["relative_tolerance"] = rt
+            Ux = DeviceVector(U.size())
+            ladder_its.append(solver.solve(K, Ux, rhs))
+            ladder_U.append(Ux.get_local())
+            ladder_res.append(solver.last["residual_norm"])
     Ks = K.to_scipy()
     g0, g1 = spline.localDofRange()
     r0, r1 = spline.localFERange()
@@ -52,7 +63,8 @@ def main():
              u=u.vector().get_local(), its=np.array([its1, its2]),
              comm=np.array([rank_r, world_r, dev.Comm.KINDS.index(kind)]), cp0=cp0,
              U2=U2.get_local(), overlapped=np.array([overlapped]), host_waits=np.array([host_waits]),
-             resnorm=np.array([resnorm]))
+             resnorm=np.array([resnorm]), ladder_U=np.array(ladder_U), ladder_res=np.array(ladder_res),
+             ladder_its=np.array(ladder_its))
     comm.barrier()
 
 

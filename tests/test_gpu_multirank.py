@@ -139,12 +139,18 @@ def test_iterations_enqueued_past_convergence_change_nothing(tmp_path, kind, wor
     d, p, nel = 3, 2, 18
     a, b = tmp_path / "ahead", tmp_path / "lockstep"
     a.mkdir(), b.mkdir()
-    ahead = _run_ranks(a, world, kind, d, p, nel, "cg", 33137 + world)
-    lock = _run_ranks(b, world, kind, d, p, nel, "cg", 33537 + world, {"TIGAR_CG_LOOK": "0"})
+    ladder = {"TIGAR_TEST_RTOLS": ",".join("%g" % (10.0 ** (-0.5 * k)) for k in range(4, 24))}
+    ahead = _run_ranks(a, world, kind, d, p, nel, "cg", 33137 + world, ladder)
+    lock = _run_ranks(b, world, kind, d, p, nel, "cg", 33537 + world, dict(ladder, TIGAR_CG_LOOK="0"))
     for r in range(world):
         assert int(ahead[r]["its"][0]) == int(lock[r]["its"][0])
         assert np.array_equal(ahead[r]["U"], lock[r]["U"])
         assert ahead[r]["resnorm"][0] == lock[r]["resnorm"][0]
+        # twenty tolerances: some solves end with world * ||B r||^2 above tol^2 although ||B r||^2 itself is below
+        assert len(ahead[r]["ladder_its"]) == 20
+        assert np.array_equal(ahead[r]["ladder_its"], lock[r]["ladder_its"])
+        assert np.array_equal(ahead[r]["ladder_res"], lock[r]["ladder_res"])
+        assert np.array_equal(ahead[r]["ladder_U"], lock[r]["ladder_U"])
 
 
 @pytest.mark.parametrize("d,p,nel,method", [(3, 3, 24, "cg"), (3, 2, 16, "gmres")])
