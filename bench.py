@@ -34,24 +34,86 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 
 WORKLOADS = {
-    # name: (dim, degree, elements per direction)  -- BASELINE.json configs[1], configs[2]
+    # name: (dim, degree, elements per direction)  -- BASELINE.json configs[1..4]
     "cfg2": (3, 2, 128),
     "cfg3": (3, 3, 256),
     "cfg1": (2, 2, 32),
-    "cfg4": (2, 4, 256),
+    "cfg4": (2, 4, 256),      # demos/biharmonic: (-1,1)^2, two clamped layers, default solver = direct LU
+    "cfg5": (2, 3, 128),      # NURBS quarter annulus, 3 fields, non-symmetric A on the 3-field pattern, GMRES
 }
+DEFAULT_SOLVER = {"cfg4": "lu", "cfg5": "gmres"}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def counts(d, p, nel):
+def counts(d, p, nel, nf=1):
     nnzM1 = 2 + (nel - 1) * p + nel * (p - 1) * (p + 1)
     nnzA1 = (nel - 1) * (2 * p + 1) + 2 * (p + 1) + nel * (p - 1) * (p + 1)
     nnzK1 = (nel + p) * (2 * p + 1) - p * (p + 1)
-    return {"rows_fe": (nel * p + 1) ** d, "ncp": (nel + p) ** d, "nnzM": nnzM1 ** d, "nnzA": nnzA1 ** d,
-            "nnzK": nnzK1 ** d}
+    return {"rows_fe": nf * (nel * p + 1) ** d, "ncp": nf * (nel + p) ** d, "nnzM": nf * nnzM1 ** d,
+            "nnzA": nf * nf * nnzA1 ** d, "nnzK": nf * nf * nnzK1 ** d}
+
+
+def ptap_bytes(cnt):
+    # 12 nnz(A) + 2 * 12 nnz(M) + 12 nnz(K) (+ row pointers)
+    return 12.0 * cnt["nnzA"] + 24.0 * cnt["nnzM"] + 12.0 * cnt["nnzK"] + 8.0 * (2 * cnt["rows_fe"] + cnt["ncp"])
+
+
+def _elevate(Pw):
+    """degree elevation by one of a Bezier curve given by homogeneous control points [n+1, c]"""
+    n = Pw.shape[0] - 1
+    out = np.zeros((n + 2, Pw.shape[1]))
+    out[0], out[-1] = Pw[0], Pw[-1]
+    for i in range(1, n + 1):
+        a = i / float(n + 1)
+        out[i] = a * Pw[i - 1] + (1.0 - a) * Pw[i]
+    return out
+
+
+def _refined_net(coarse, fine, Pw):
+    """control net of the same curve on a refined knot vector: interpolation at the fine Greville points"""
+    nf = fine.getNcp()
+    Nf, Nc = np.zeros((nf, nf)), np.zeros((nf, coarse.getNcp()))
+    for r in range(nf):
+        u = fine.greville(r)
+        Nf[r, fine.getNodes(u)] = fine.basisFuncs(fine.getKnotSpan(u), u)
+        Nc[r, coarse.getNodes(u)] = coarse.basisFuncs(coarse.getKnotSpan(u), u)
+    return np.linalg.solve(Nf, Nc @ Pw)
+
+
+def quarter_annulus_mesh(p, nel):
+    """cfg5's geometry: exact quarter annulus, radii 1..2, rational arc knot-refined to nel x nel
+    elements of degree p -- deterministic, no RNG."""
+    from tigar_amd.BSplines import BSpline1, uniformKnots
+    from tigar_amd.NURBS import NURBSControlMesh
+    w = 1.0 / np.sqrt(2.0)
+    arc = np.array([[1.0, 0.0, 1.0], [w, w, w], [0.0, 1.0, 1.0]])
+    rad = np.array([[1.0], [2.0]])
+    while arc.shape[0] < p + 1:
+        arc = _elevate(arc)
+    while rad.shape[0] < p + 1:
+        rad = _elevate(rad)
+    rad = rad[:, 0]
+    kv = uniformKnots(p, 0.0, 1.0, nel)
+    coarse = BSpline1(p, [0.0] * (p + 1) + [1.0] * (p + 1))
+    fine = BSpline1(p, kv)
+    Pw = np.zeros((p + 1, p + 1, 3))
+    for i in range(p + 1):
+        Pw[i, :, 0], Pw[i, :, 1], Pw[i, :, 2] = rad[i] * arc[:, 0], rad[i] * arc[:, 1], arc[:, 2]
+    Pr = np.stack([_refined_net(coarse, fine, Pw[:, j, :]) for j in range(p + 1)], axis=1)
+    Pf = np.stack([_refined_net(coarse, fine, Pr[i, :, :]) for i in range(Pr.shape[0])], axis=0)
+    return NURBSControlMesh([p, p], [kv, kv], Pf)
+
+
+def hashed_values(n, seed):
+    """counter-based hash -> doubles in (-1, 1): value k depends on (seed, k) only (splitmix64)"""
+    z = (np.arange(n, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)) + np.uint64(0x9E3779B97F4A7C15)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (2.0 / 9007199254740992.0) - 1.0
 
 
 def spmv_bytes(nnzK, ncp):
@@ -60,36 +122,71 @@ def spmv_bytes(nnzK, ncp):
 
 
 # ------------------------------------------------------------------------------------ the path
-def run(args, d, p, nel):
+def run(args, wl, d, p, nel):
     from tigar_amd import device as dev
     from tigar_amd import common as tc
-    from tigar_amd.common import EqualOrderSpline, ExtractedSpline, PETScKrylovSolver, Function, TensorFunctionSpace
+    from tigar_amd.common import (EqualOrderSpline, ExtractedSpline, PETScKrylovSolver, PETScLUSolver, Function,
+                                  TensorFunctionSpace)
     from tigar_amd.BSplines import ExplicitBSplineControlMesh, uniformKnots
-    from tigar_amd.forms import LaplaceForm, SeparableLoadForm
+    from tigar_amd.forms import LaplaceForm, SeparableLoadForm, BiharmonicForm, SumOfSeparableLoads
 
     comm = tc.worldcomm                       # size / rank from the launcher's environment
     rank, world = comm.rank, comm.size
     transport = comm.transport()
-    dcomm = comm.device()                     # RCCL (or host-staged) communicator, None on one rank
+    dcomm = comm.device()                     # RCCL / IPC / host-staged communicator, None on one rank
     if rank == 0:
         log("[bench] device:", dev.device_info(), "ranks", world,
             "communicator", dcomm.info() if dcomm is not None else None)
-    kvecs = [uniformKnots(p, 0.0, 1.0, nel) for _ in range(d)]
-    controlMesh = ExplicitBSplineControlMesh([p] * d, kvecs)
+    nf, nlayers, lo = 1, 1, 0.0
+    method = args.solver if args.solver != "auto" else DEFAULT_SOLVER.get(wl, "cg")
+    if wl == "cfg5":
+        controlMesh, nf, nlayers = quarter_annulus_mesh(p, nel), 3, 2
+    else:
+        if wl == "cfg4":
+            lo, nlayers = -1.0, 2
+        controlMesh = ExplicitBSplineControlMesh([p] * d, [uniformKnots(p, lo, 1.0, nel) for _ in range(d)])
     basis = controlMesh.getScalarSpline()
-    lap = LaplaceForm()
     f1 = lambda x: np.sin(np.pi * x)
-    load = SeparableLoadForm([f1] * d, scale=d * np.pi ** 2)
+    if wl == "cfg4":
+        # demos/biharmonic/biharmonic.py:100-122: u = (cos(pi x)+1)(cos(pi y)+1)
+        c, c1, pi4 = (lambda x: np.cos(np.pi * x)), (lambda x: np.cos(np.pi * x) + 1.0), np.pi ** 4
+        lap = BiharmonicForm()
+        load = SumOfSeparableLoads([([c, c1], pi4), ([c, c], 2 * pi4), ([c1, c], pi4)])
+        exact1 = [c1, c1]
+    else:
+        lap = LaplaceForm()
+        load = SeparableLoadForm([f1] * d, scale=d * np.pi ** 2)
+        exact1 = [f1] * d
 
     # ---- FE-side inputs resident in HBM before the timed region, when they fit (not part of the path)
-    cnt = counts(d, p, nel)
+    cnt = counts(d, p, nel, nf)
     t0 = time.perf_counter()
     V_in = TensorFunctionSpace([basis.generateMesh(degree=p)], "Lagrange")
     free_b = dev.mem_info()[0] + dev.pool_stats()[0]
     a_resident = world == 1 and args.slab != 1 and \
         12.0 * (2 * cnt["nnzM"] + cnt["nnzA"] + 2 * cnt["nnzK"]) <= 0.6 * free_b
-    A_in = lap.assemble_matrix(V_in) if a_resident else None
-    b_in = load.assemble_vector(V_in) if world == 1 else None
+    if wl == "cfg5":
+        # a deterministic non-symmetric, diagonally dominant matrix on the 3-field Q_p pattern, values
+        # from a counter-based hash (seed 0); uploaded from the host like a matrix dolfin assembled (no certificate)
+        import scipy.sparse as sp
+        assert world == 1, "cfg5 is a replicas-only configuration (SURVEY.md 8e)"
+        pat = lap.assemble_matrix(V_in).to_scipy().tocsr()
+        pat.sort_indices()
+        blocks = [[None] * nf for _ in range(nf)]
+        for a in range(nf):
+            for b in range(nf):
+                Bk = pat.copy()
+                Bk.data = 0.05 * hashed_values(Bk.nnz, 3 * a + b)
+                blocks[a][b] = Bk if a != b else (Bk + 4.0 * sp.identity(pat.shape[0], format="csr")).tocsr()
+        A_host = sp.bmat(blocks, format="csr")
+        assert A_host.nnz == cnt["nnzA"], (A_host.nnz, cnt["nnzA"])
+        A_in = dev.DeviceCSR.from_scipy(A_host)
+        b_in = dev.DeviceVector(data=hashed_values(A_host.shape[0], 1000))
+        del A_host, blocks, pat
+        a_resident = True
+    else:
+        A_in = lap.assemble_matrix(V_in) if a_resident else None
+        b_in = load.assemble_vector(V_in) if world == 1 else None
     dev.sync()
     t_input_pre = time.perf_counter() - t0
     if not a_resident:
@@ -102,6 +199,14 @@ def run(args, d, p, nel):
     stages = {}
     state = {}
 
+    def make_solver():
+        if method == "lu":
+            return PETScLUSolver()
+        solver = PETScKrylovSolver(method, "jacobi")
+        solver.parameters["relative_tolerance"] = args.rtol
+        solver.parameters["maximum_iterations"] = 100000
+        return solver
+
     def step(record):
         ts = [time.perf_counter()]
         rec = {}
@@ -111,11 +216,15 @@ def run(args, d, p, nel):
             ts.append(time.perf_counter())
             rec[name] = ts[-1] - ts[-2]
 
-        gen = EqualOrderSpline(comm, 1, controlMesh)       # generateM_control / generateM (or implicit) / cpFuncs
-        sp_ = gen.getScalarSpline(0)
-        for direction in range(d):
-            for side in (0, 1):
-                gen.addZeroDofs(0, sp_.getSideDofs(direction, side))
+        gen = EqualOrderSpline(comm, nf, controlMesh)      # generateM_control / generateM (or implicit) / cpFuncs
+        for field in range(nf):
+            sp_ = gen.getScalarSpline(field)
+            if wl == "cfg5":                               # shell-like clamp: two layers on one edge, every field
+                gen.addZeroDofs(field, sp_.getSideDofs(0, 0, nLayers=nlayers))
+                continue
+            for direction in range(d):
+                for side in (0, 1):
+                    gen.addZeroDofs(field, sp_.getSideDofs(direction, side, nLayers=nlayers))
         mark("extract")
         spline = ExtractedSpline(gen, 2 * p)               # M^T
         mark("transpose")
@@ -124,11 +233,10 @@ def run(args, d, p, nel):
         mark("ptap")
         rhs = spline.extractVector(b_in) if b_in is not None else spline.assembleVector(load)   # M^T b + BCs
         mark("mtb")
-        solver = PETScKrylovSolver("cg", "jacobi")
-        solver.parameters["relative_tolerance"] = args.rtol
+        solver = make_solver()
         spline.setSolverOptions(linearSolver=solver)
         u = Function(spline.V, spline.localFERange() if world > 1 else None)
-        U = spline.solveLinearSystem(K, rhs, u)            # CG + prolongation u = M U
+        U = spline.solveLinearSystem(K, rhs, u)            # Krylov / LU + prolongation u = M U
         mark("solve")
         t_in = spline.stage_timers.get("input", 0.0)
         rec["fe_input"] = t_in
@@ -136,7 +244,7 @@ def run(args, d, p, nel):
         if record:
             for k, v in rec.items():
                 stages.setdefault(k, []).append(v)
-        state.update(gen=gen, spline=spline, K=K, U=U, u=u, solver=solver)
+        state.update(gen=gen, spline=spline, K=K, U=U, u=u, solver=solver, rhs=rhs)
         if os.environ.get("TIGAR_TRACE"):
             pb, nb, nl = dev.pool_stats()
             fr, tot = dev.mem_info()
@@ -160,19 +268,58 @@ def run(args, d, p, nel):
     elapsed = transport.allreduce_max(time.perf_counter() - t_start)
 
     gen, spline, K, u, solver = state["gen"], state["spline"], state["K"], state["u"], state["solver"]
-    ncp = gen.getNcp(0)
+    ncp = sum(gen.getNcp(f) for f in range(nf))
     nnzK_local, ncp_local = K.nnz, K.shape[0]
     nnzK = nnzK_local if dcomm is None else int(round(dcomm.allreduce_sum([float(nnzK_local)])[0]))
     spmv_ms, spmv_n = dev.prof_get(0)
     ptap_certified = dev.prof_get(3)[1]                   # x passes that took A's pattern from its certificate
+    comm_host_waits = dev.prof_get(4)[1]
     sell_classes, sell_padded = K.spmv_sell(True)         # which product kernel the solver used
     K.spmv_sell(False)
-    its = solver.last["iterations"]
+    its = solver.last.get("iterations", 0) if solver.last else 0
     mean_stages = {k: float(np.mean(v)) for k, v in stages.items()}
 
+    # ---- per-rank self-check of the solve that was timed: || rhs - K U || over the rank's rows (halo through the
+    # communicator), relative to || rhs ||; a communicator that lost or reordered an exchange shows up here
+    self_check = None
+    try:
+        U_loc, rhs_loc = state["U"], state["rhs"]
+        if dcomm is not None:
+            xext = dcomm.halo_extend(U_loc)
+            g0 = dcomm.g0 - dcomm.halo_lo
+            KU = K.mult_offset(xext, g0)
+        else:
+            KU = K.mult(U_loc)
+        if KU is not None:
+            rr = rhs_loc.get_local() - KU.get_local()
+            num, den = float(rr @ rr), float(rhs_loc.get_local() @ rhs_loc.get_local())
+            if dcomm is not None:
+                num, den = [float(v) for v in dcomm.allreduce_sum([num, den])]
+            self_check = float(np.sqrt(num / den)) if den > 0 else 0.0
+            if rank == 0:
+                log("[bench] self-check ||rhs - K U|| / ||rhs|| over all ranks: %.3e" % self_check)
+    except Exception as e:                                # (diagnostic only)
+        log("[bench] self-check skipped:", repr(e))
+
+    # ---- companion figure: the same step with A's pattern verified entry by entry (what a matrix handed over by
+    # dolfin pays), measured live after the timed loop
+    verified = None
+    if ptap_certified > 0 and args.companion:
+        os.environ["TIGAR_PTAP_VERIFY"] = "1"
+        try:
+            state.clear()
+            barrier()
+            t1 = time.perf_counter()
+            step(False)
+            barrier()
+            verified = transport.allreduce_max(time.perf_counter() - t1)
+        finally:
+            del os.environ["TIGAR_PTAP_VERIFY"]
+        gen, spline, K, u, solver = state["gen"], state["spline"], state["K"], state["u"], state["solver"]
+
     nodal_error = None
-    if args.check and rank == 0:
-        # manufactured solution u = prod sin(pi x_k) at the FE nodes this rank owns
+    if args.check and rank == 0 and wl != "cfg5":
+        # manufactured solution at the FE nodes this rank owns
         grid = spline.V.grids[0]
         r0, r1 = spline.localFERange()
         n0 = grid.shape()
@@ -183,22 +330,28 @@ def run(args, d, p, nel):
         exact = np.ones(idx.size)
         stride = 1
         for k in range(d):
-            exact *= np.sin(np.pi * grid.axes[k][(idx // stride) % n0[k]])
+            exact *= exact1[k](grid.axes[k][(idx // stride) % n0[k]])
             stride *= n0[k]
         nodal_error = float(np.max(np.abs(uh - exact)))
         log("[bench] max nodal error vs manufactured solution (rank 0 rows): %.3e" % nodal_error)
     if rank == 0:
-        log("[bench] stages (mean s):", {k: round(v, 5) for k, v in mean_stages.items()}, "CG iterations:", its,
+        log("[bench] stages (mean s):", {k: round(v, 5) for k, v in mean_stages.items()}, "iterations:", its,
             "nnz(K) global:", nnzK, "M implicit:", bool(getattr(gen.M, "is_implicit", False)))
     info = dcomm.info() if dcomm is not None else (0, 1, "none")
     ndev = dev.device_count()
+    n_used = 1
+    if info[1] > 1:
+        devs = dcomm.rank_devices() if info[2] == "ipc" else None
+        n_used = len(set(devs)) if devs and all(v is not None for v in devs) else min(info[1], ndev)
     return {"ncp": ncp, "nnzK": nnzK, "nnzK_local": nnzK_local, "ncp_local": ncp_local, "elapsed": elapsed,
             "spmv_ms_total": spmv_ms, "spmv_count": spmv_n, "iterations": its, "stages": mean_stages,
             "t_input": mean_stages.get("fe_input", 0.0), "t_input_in_timed_region": not a_resident,
             "t_input_pre": t_input_pre, "sub_planes": spline._slab.sub_planes if spline._slab is not None else None,
             "sell_classes": sell_classes, "sell_padded": sell_padded, "implicit_M": bool(getattr(gen.M, "is_implicit", False)),
-            "ptap_certified": int(ptap_certified), "nodal_error": nodal_error,
-            "comm_world": info[1], "comm_kind": info[2], "n_devices_used": min(info[1], ndev) if info[1] > 1 else 1}
+            "ptap_certified": int(ptap_certified), "nodal_error": nodal_error, "method": method, "nf": nf,
+            "solver_last": {k: v for k, v in (solver.last or {}).items() if isinstance(v, (int, float, str, bool))},
+            "self_check": self_check, "verified_step_s": verified, "comm_host_waits": int(comm_host_waits),
+            "comm_world": info[1], "comm_kind": info[2], "n_devices_used": n_used}
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
@@ -306,6 +459,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nel", type=int, default=0)
     ap.add_argument("--slab", type=int, default=-1, help="1: force the implicit-M / z-slab streaming path on one GPU")
+    ap.add_argument("--solver", default="auto", help="cg | gmres | lu (auto: cg; cfg4 lu as demos/biharmonic; cfg5 gmres)")
+    ap.add_argument("--companion", type=int, default=1,
+                    help="1: after the timed loop run one more step with the FE matrix' pattern verified entry by entry")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -328,11 +484,10 @@ def main():
         p = args.p
     if args.d:
         d = args.d
-    cnt = counts(d, p, nel)
-
-    res = run(args, d, p, nel)
+    res = run(args, wl, d, p, nel)
     if rank != 0:
         return
+    cnt = counts(d, p, nel, res["nf"])
 
     n_gpus = res["n_devices_used"]
     ms_per_step = 1e3 * res["elapsed"] / args.steps
@@ -363,17 +518,24 @@ def main():
             traffic = None
     par = "z-slab x%d ranks on %d GPU%s (%s)" % (res["comm_world"], n_gpus, "s" if n_gpus > 1 else "", res["comm_kind"]) \
         if res["comm_world"] > 1 else "1 GPU"
+    step_s = res["elapsed"] / args.steps
+    t_in_timed = res["t_input"] if res["t_input_in_timed_region"] else 0.0
+    desc = {"cfg4": "B-spline biharmonic on (-1,1)^2, two clamped layers (demos/biharmonic)",
+            "cfg5": "NURBS quarter annulus, 3 fields, hashed non-symmetric A on the 3-field pattern"}.get(wl, "B-spline Poisson")
+    solver_desc = {"cg": "Jacobi-CG rtol %.0e" % args.rtol, "gmres": "Jacobi-GMRES(30) rtol %.0e" % args.rtol,
+                   "lu": "direct banded LU (the reference's default solver)"}[res["method"]]
+    solver_api = {"cg": "PETScKrylovSolver('cg','jacobi')", "gmres": "PETScKrylovSolver('gmres','jacobi')",
+                  "lu": "PETScLUSolver()"}[res["method"]]
     out = {
         "metric": "DoF/s (extraction + M^T A M + M^T b + CG solve + prolongation)",
         "value": value, "unit": "DoF/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s: %dD %d^%d elements p=%d B-spline Poisson, Q_p extraction, "
-                               "Jacobi-CG rtol %.0e" % (wl, d, nel, d, p, args.rtol),
+        "config": {"workload": "%s: %dD %d^%d elements p=%d %s, Q_p extraction, %s" % (wl, d, nel, d, p, desc, solver_desc),
                    "api": "EqualOrderSpline -> ExtractedSpline.assembleMatrix/extractMatrix, assembleVector/"
-                          "extractVector, solveLinearSystem(PETScKrylovSolver('cg','jacobi'))",
+                          "extractVector, solveLinearSystem(%s)" % solver_api,
                    "dofs": res["ncp"], "fe_rows": cnt["rows_fe"], "nnz_M": cnt["nnzM"], "nnz_A": cnt["nnzA"],
-                   "nnz_K": res["nnzK"], "cg_iterations": res["iterations"],
+                   "nnz_K": res["nnzK"], "cg_iterations": res["iterations"], "solver": res["solver_last"],
                    "M_implicit": res["implicit_M"],
                    "max_nodal_error_vs_manufactured_solution": res.get("nodal_error"),
                    "fe_matrix_pattern": ("certified by the assembly kernel that wrote it (tg_kron_sum_csr): the PtAP does not "
@@ -383,12 +545,23 @@ def main():
                    "stages_s": {k: round(v, 6) for k, v in res["stages"].items()},
                    "fe_input_generation_s": round(res["t_input"], 6),
                    "fe_input_inside_timed_region": bool(res["t_input_in_timed_region"]),
-                   "value_excluding_fe_input": res["ncp"] / max(1e-12, res["elapsed"] / args.steps
-                                                                - (res["t_input"] if res["t_input_in_timed_region"] else 0.0)),
+                   # SURVEY.md 8(d) excludes the FE assembly of A, b from the metric; `value` keeps it when it has to
+                   # happen inside the step (conservative), this is the figure by the survey's definition
+                   "value_excluding_fe_input": res["ncp"] / max(1e-12, step_s - t_in_timed),
+                   # the same step with A's pattern verified entry by entry (a matrix handed over without certificate,
+                   # e.g. uploaded from dolfin): one extra step measured live after the timed loop
+                   "value_pattern_verified": (res["ncp"] / res["verified_step_s"]) if res.get("verified_step_s") else None,
+                   "ms_per_step_pattern_verified": 1e3 * res["verified_step_s"] if res.get("verified_step_s") else None,
+                   "self_check_rel_residual_all_ranks": res.get("self_check"),
+                   "communicator_host_waits_in_timed_steps": res.get("comm_host_waits"),
+                   "ptap": {"stage_s": res["stages"].get("ptap"), "algorithmic_bytes": ptap_bytes(cnt),
+                            "achieved_GBps": ptap_bytes(cnt) / max(1e-12, res["stages"].get("ptap", 0.0)) / 1e9,
+                            "frac_of_hbm_peak": ptap_bytes(cnt) / max(1e-12, res["stages"].get("ptap", 0.0)) / 1e9 / HBM_PEAK_GBS,
+                            "bytes_definition": "SURVEY.md 8d: 12 nnz(A) + 24 nnz(M) + 12 nnz(K) + row pointers, stage wall time"},
                    "sub_planes": res.get("sub_planes"),
                    "ranks": res["comm_world"], "communicator": res["comm_kind"],
                    "parallelism": par},
-        "roofline": {"bound": "hbm", "kernel": "%s (K u in CG)" % kernel, "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "%s (K u in %s)" % (kernel, res["method"].upper()), "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "launches": res["spmv_count"], "avg_launch_ms": spmv_avg_s * 1e3,
@@ -401,6 +574,13 @@ def main():
                      "effective_csr_GBps": csr_bytes / spmv_avg_s / 1e9 if spmv_avg_s > 0 else 0.0,
                      "effective_csr_frac_of_peak": csr_bytes / spmv_avg_s / 1e9 / HBM_PEAK_GBS if spmv_avg_s > 0 else 0.0},
     }
+    if res["spmv_count"] == 0:
+        # no Krylov product was timed (direct solve): the dominant kernel of the path is the triple product
+        pt = out["config"]["ptap"]
+        out["roofline"] = {"bound": "hbm", "kernel": "M^T A M stage (all its kernels; wall time of the stage)",
+                           "achieved": pt["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": pt["frac_of_hbm_peak"], "traffic": None,
+                           "bytes_per_launch": pt["algorithmic_bytes"], "bytes_definition": pt["bytes_definition"]}
     if wl == "cfg3" and res["comm_world"] == 1 and not args.nel and not args.p:
         # the general-CSR contract keeps a tracked number: the same step with the fast path switched off (offline runs,
         # committed under profiles/; A arbitrary sparse in both, M Kronecker in the first, nothing assumed in the second)
@@ -416,7 +596,7 @@ def main():
                 pass
         if ref:
             out["config"]["general_path_reference"] = ref
-    if not args.no_cpu_baseline and res["comm_world"] == 1:      # (rank 0 at N=1 only: the other ranks would wait for it)
+    if not args.no_cpu_baseline and res["comm_world"] == 1 and wl in ("cfg1", "cfg2", "cfg3"):   # (rank 0 at N=1 only)
         # a bounded sample: seconds of work on the 16 cores the GPU box grants (the A*M intermediate of
         # the Gustavson PtAP needs ~7 GB of host memory at p=3, 40^3 elements)
         cpu_nel = args.cpu_nel or ({2: 80, 3: 40, 4: 16}.get(p, 16) if d == 3 else min(nel, 256))

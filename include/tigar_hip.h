@@ -400,6 +400,10 @@ int tg_comm_allreduce_sum(tg_comm_t c, double *host_inout, int n);
 /* xext = [halo_lo | x_local | halo_hi] with the halos fetched from the z-neighbours */
 int tg_comm_halo_extend(tg_comm_t c, tg_vec_t x_local, tg_vec_t xext);
 int tg_comm_destroy(tg_comm_t c);
+/* one small all-reduce and three halo exchanges with known values on a stream of their own, every host wait bounded by
+ * timeout_s: 0 = works; 4 = an exchange did not complete (drop the communicator WITHOUT destroying it); else wrong
+ * values / errors.  Collective; the launcher falls back to the next kind of communicator on failure. */
+int tg_comm_selftest(tg_comm_t c, double timeout_s);
 
 #ifdef __cplusplus
 }

@@ -131,6 +131,19 @@ def test_ipc_iterates_are_those_of_the_host_staged_run(tmp_path):
         assert int(ipc[r]["overlapped"][0]) >= int(ipc[r]["its"][0]) + 1      # products beside the exchange
 
 
+def test_ipc_dead_peer_is_an_error_not_a_hang(tmp_path):
+    """A rank that is gone must not leave its peers spinning on the GPU: the waits inside the IPC kernels give up
+    after TIGAR_IPC_TIMEOUT_S seconds of wall clock and the next host wait reports it."""
+    from tigar_amd.launch import spawn_local
+    env = {"PYTHONPATH": ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), "TIGAR_COMM": "ipc", "TIGAR_DEVICE": "0",
+           "TIGAR_IPC_TIMEOUT_S": "3"}
+    rc = spawn_local(2, [os.path.join(ROOT, "tests", "ipc_dead_peer_worker.py"), str(tmp_path)], env_extra=env, port=34211)
+    assert rc == 0
+    secs, msg = open(os.path.join(str(tmp_path), "rank0.txt")).read().split("\n")[:2]
+    assert "gave up waiting for an all-reduce" in msg
+    assert 2.0 <= float(secs) <= 20.0
+
+
 @pytest.mark.parametrize("kind,world", [("host", 3), ("ipc", 2), ("ipc", 3)])
 def test_iterations_enqueued_past_convergence_change_nothing(tmp_path, kind, world):
     """The host enqueues CG iterations two ahead of the norm it has read; the ones past convergence must leave x, the

@@ -170,6 +170,7 @@ PROTOTYPES = {
     "tg_comm_allreduce_sum": (C.c_int, [handle, c_f64p, C.c_int]),
     "tg_comm_halo_extend": (C.c_int, [handle, handle, handle]),
     "tg_comm_destroy": (C.c_int, [handle]),
+    "tg_comm_selftest": (C.c_int, [handle, C.c_double]),
 }
 
 _lib = None

@@ -58,6 +58,8 @@ struct tg_comm_s {
   hipStream_t xstream = nullptr;
   hipEvent_t x_ready = nullptr, x_done = nullptr;
   bool x_open = false;
+  // > 0: host waits of tg_comm_allreduce_sum give up after this many seconds (tg_comm_selftest)
+  double host_wait_limit = 0.0;
 };
 
 #define TG_CHECK_NCCL(expr)                                                           \

@@ -23,11 +23,27 @@
 #include <unistd.h>
 
 // ------------------------------------------------------------------------------------------ IPC kernels
+// Everything another process reads or writes goes through SYSTEM-scope relaxed atomics (sc0 sc1 on gfx950: stores
+// write through to memory, loads miss every non-coherent cache level), so no exchange needs a cache-wide
+// write-back or invalidate -- a release / acquire FENCE at system scope costs ~0.1 ms while the products of two
+// ranks stream through the L2s (measured) -- and the order "payload, then flag" is kept by waiting for the stores
+// of the workgroup to be acknowledged (workgroup-scope release fence = s_waitcnt vmcnt(0)) before the flag goes out.
 __device__ __forceinline__ unsigned long long tg_ld_sys(const unsigned long long *p) {
-  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ void tg_st_sys(unsigned long long *p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double tg_ld_sys(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void tg_st_sys(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// all stores this workgroup has issued are acknowledged by memory when every thread has passed this point
+__device__ __forceinline__ void tg_stores_done_block() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
 }
 // spins until *p >= v; false after `tmo` wall-clock ticks or when another rank has given up
 __device__ __forceinline__ bool tg_spin_ge(const unsigned long long *p, unsigned long long v, tg_ipc_shm *s,
@@ -36,8 +52,8 @@ __device__ __forceinline__ bool tg_spin_ge(const unsigned long long *p, unsigned
   const long long t0 = wall_clock64();
   unsigned n = 0;
   while (tg_ld_sys(p) < v) {
-    __builtin_amdgcn_s_sleep(4);
-    if ((++n & 31u) == 0) {
+    __builtin_amdgcn_s_sleep(2);
+    if ((++n & 63u) == 0) {
       if (tg_ld_sys(&s->abort_word) != 0ull) return false;
       if (wall_clock64() - t0 > tmo) return false;
     }
@@ -57,10 +73,8 @@ __global__ void __launch_bounds__(256) k_ipc_allreduce(tg_ipc_shm *s, int rank, 
   __shared__ int ok_lds;
   const int par = (int)(seq & 1ull), tid = threadIdx.x;
   if (tid == 0) ok_lds = 1;
-  for (int t = tid; t < n; t += 256)
-    __hip_atomic_store(&s->ar_slot[par][rank][t], dev[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __atomic_thread_fence(__ATOMIC_RELEASE);   // (system scope)
-  __syncthreads();
+  for (int t = tid; t < n; t += 256) tg_st_sys(&s->ar_slot[par][rank][t], dev[t]);
+  tg_stores_done_block();
   if (tid == 0) tg_st_sys(&s->ar_flag[par][rank], seq);
   if (tid < world && tid != rank)
     if (!tg_spin_ge(&s->ar_flag[par][tid], seq, s, tmo)) ok_lds = 0;
@@ -69,11 +83,9 @@ __global__ void __launch_bounds__(256) k_ipc_allreduce(tg_ipc_shm *s, int rank, 
     if (tid == 0) tg_ipc_give_up(s, rank, 1ull);
     return;
   }
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   for (int t = tid; t < n; t += 256) {
     double acc = 0.0;
-    for (int r = 0; r < world; r++)
-      acc += __hip_atomic_load(&s->ar_slot[par][r][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int r = 0; r < world; r++) acc += tg_ld_sys(&s->ar_slot[par][r][t]);
     dev[t] = acc;
   }
 }
@@ -91,8 +103,10 @@ struct tg_ipc_legs {
   tg_ipc_leg leg[2];
 };
 
-// copies both legs; a block waits for a leg's condition itself (its acquire makes the data visible to ITS cache
-// hierarchy), the last block to finish posts the flags
+// copies both legs; REMOTE = 1: the destination is another rank's mailbox (system-scope stores), REMOTE = 0: the
+// source is the own mailbox another rank filled (system-scope loads).  Every block waits for a leg's condition
+// itself; the last block to finish posts the flags.
+template <int REMOTE>
 __global__ void __launch_bounds__(256) k_ipc_move(tg_ipc_legs L, tg_ipc_shm *s, int rank, unsigned *done, long long tmo,
                                                   unsigned long long what) {
   __shared__ int ok_lds;
@@ -107,13 +121,17 @@ __global__ void __launch_bounds__(256) k_ipc_move(tg_ipc_legs L, tg_ipc_shm *s, 
     __syncthreads();
     if (!ok_lds) break;
     const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + tid; i < g.n; i += stride) g.dst[i] = g.src[i];
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < g.n; i += stride) {
+      if (REMOTE)
+        tg_st_sys(g.dst + i, g.src[i]);
+      else
+        g.dst[i] = tg_ld_sys(g.src + i);
+    }
   }
-  __atomic_thread_fence(__ATOMIC_RELEASE);   // (system scope: the copied data before the flags)
-  __syncthreads();
+  tg_stores_done_block();
   if (tid == 0) {
     if (!ok_lds) tg_ipc_give_up(s, rank, what);
-    const unsigned prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == gridDim.x - 1) {
       __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (ok_lds)
@@ -435,6 +453,28 @@ int tg_comm_allreduce_dev(tg_comm_s *c, double *dev, int n) {
   return 0;
 }
 
+// hipStreamSynchronize, or -- with a limit -- polling so that a collective whose peer never arrives comes back
+static int tg_comm_wait_stream(tg_comm_s *c, hipStream_t st) {
+  if (!c || c->host_wait_limit <= 0.0) {
+    TG_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) {
+      tg_set_error("communicator: stream failed while waiting: %s", hipGetErrorString(q));
+      return 1;
+    }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->host_wait_limit) {
+      tg_set_error("communicator (rank %d): an exchange did not complete within %.0f s", c->rank, c->host_wait_limit);
+      return 4;
+    }
+    usleep(200);
+  }
+}
+
 extern "C" int tg_comm_allreduce_sum(tg_comm_t c, double *host_inout, int n) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(c && host_inout && n >= 1 && n <= 1024, "bad arguments to tg_comm_allreduce_sum");
@@ -442,7 +482,7 @@ extern "C" int tg_comm_allreduce_sum(tg_comm_t c, double *host_inout, int n) {
   TG_CHECK_HIP(hipMemcpyAsync(d, host_inout, n * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
   TG_TRY(tg_comm_allreduce_dev(c, d, n));
   TG_CHECK_HIP(hipMemcpyAsync(host_inout, d, n * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
-  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  TG_TRY(tg_comm_wait_stream(c, g_tg.stream));
   return tg_comm_check(c);
 }
 
@@ -503,6 +543,7 @@ static int tg_comm_xstream(tg_comm_s *c) {
   if (c->xstream) return 0;
   int prio_lo = 0, prio_hi = 0;
   TG_CHECK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  if (getenv("TIGAR_XSTREAM_PRIO") && atoi(getenv("TIGAR_XSTREAM_PRIO")) == 0) prio_hi = prio_lo;   // (experiments)
   TG_CHECK_HIP(hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, prio_hi));
   TG_CHECK_HIP(hipEventCreateWithFlags(&c->x_ready, hipEventDisableTiming));
   TG_CHECK_HIP(hipEventCreateWithFlags(&c->x_done, hipEventDisableTiming));
@@ -553,8 +594,8 @@ int tg_comm_halo_begin(tg_comm_s *c, double *xext) {
     const int64_t total = c->send_lo + c->send_hi;
     if (total > 0) {
       const unsigned grid = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, tg_cdiv(total, 4096)));
-      hipLaunchKernelGGL(k_ipc_move, dim3(grid), dim3(256), 0, c->xstream, L, sd, c->rank, c->done_ctr, c->tmo_ticks,
-                         2ull);
+      hipLaunchKernelGGL(k_ipc_move<1>, dim3(grid), dim3(256), 0, c->xstream, L, sd, c->rank, c->done_ctr,
+                         c->tmo_ticks, 2ull);
       TG_LAUNCH_CHECK();
     }
     c->x_open = true;
@@ -629,7 +670,7 @@ int tg_comm_halo_end(tg_comm_s *c, double *xext) {
     const int64_t total = c->halo_lo + c->halo_hi;
     if (total > 0) {
       const unsigned grid = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, tg_cdiv(total, 4096)));
-      hipLaunchKernelGGL(k_ipc_move, dim3(grid), dim3(256), 0, c->xstream, L, sd, c->rank, c->done_ctr + 1,
+      hipLaunchKernelGGL(k_ipc_move<0>, dim3(grid), dim3(256), 0, c->xstream, L, sd, c->rank, c->done_ctr + 1,
                          c->tmo_ticks, 3ull);
       TG_LAUNCH_CHECK();
     }
@@ -652,4 +693,54 @@ extern "C" int tg_comm_halo_extend(tg_comm_t c, tg_vec_t x_local, tg_vec_t xext)
   TG_CHECK_HIP(hipMemcpyAsync(xext->d + c->halo_lo, x_local->d, (size_t)nloc * sizeof(double), hipMemcpyDeviceToDevice,
                               g_tg.stream));
   return tg_comm_halo_exchange(c, xext->d);
+}
+
+// One small all-reduce and one halo exchange with known values on a stream of their own, every host wait bounded by
+// `timeout_s`: 0 = the communicator works on every rank's side of it; 4 = an exchange did not complete (the stream is
+// abandoned: the caller should drop the communicator WITHOUT destroying it and fall back to another kind); other
+// codes = wrong values / errors.  Collective.  Leaves no slab set.
+extern "C" int tg_comm_selftest(tg_comm_t c, double timeout_s) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(c, "null communicator");
+  if (c->world == 1) return 0;
+  hipStream_t saved = g_tg.stream, tmp = nullptr;
+  TG_CHECK_HIP(hipStreamCreateWithFlags(&tmp, hipStreamNonBlocking));
+  g_tg.stream = tmp;
+  c->host_wait_limit = timeout_s > 0.0 ? timeout_s : 60.0;
+  const int W = c->world, R = c->rank;
+  const int64_t nloc = 4096, h = 512;
+  double *xext = nullptr;
+  int rc = 0;
+  auto body = [&]() -> int {
+    double v[2] = {(double)(R + 1), 1.0};
+    TG_TRY(tg_comm_allreduce_sum(c, v, 2));
+    TG_REQUIRE(v[0] == 0.5 * W * (W + 1) && v[1] == (double)W, "self-test: all-reduce returned %g, %g on rank %d", v[0], v[1], R);
+    const int64_t hlo = R > 0 ? h : 0, hhi = R < W - 1 ? h : 0;
+    TG_TRY(tg_comm_set_slab(c, R * nloc, (R + 1) * nloc, hlo, hhi, (int64_t)W * nloc));
+    const int64_t next = hlo + nloc + hhi;
+    TG_CHECK_HIP(hipMalloc((void **)&xext, (size_t)next * sizeof(double)));
+    std::vector<double> host((size_t)next, -1.0);
+    for (int64_t i = 0; i < nloc; i++) host[(size_t)(hlo + i)] = (double)(R * nloc + i) + 0.25;
+    TG_CHECK_HIP(hipMemcpyAsync(xext, host.data(), (size_t)next * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
+    for (int rep = 0; rep < 3; rep++) TG_TRY(tg_comm_halo_exchange(c, xext));   // (three: both mailbox slots and a reuse)
+    TG_TRY(tg_comm_wait_stream(c, g_tg.stream));
+    TG_TRY(tg_comm_check(c));
+    TG_CHECK_HIP(hipMemcpy(host.data(), xext, (size_t)next * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < next; i++)
+      TG_REQUIRE(host[(size_t)i] == (double)(R * nloc - hlo + i) + 0.25, "self-test: halo entry %lld of rank %d is %g",
+                 (long long)i, R, host[(size_t)i]);
+    double ok = 1.0;
+    TG_TRY(tg_comm_allreduce_sum(c, &ok, 1));
+    TG_REQUIRE(ok == (double)W, "self-test: closing all-reduce returned %g", ok);
+    return 0;
+  };
+  rc = body();
+  g_tg.stream = saved;
+  c->host_wait_limit = 0.0;
+  c->slab_set = false;
+  if (rc != 4) {   // (a stream with an exchange stuck on it cannot be waited for)
+    if (xext) hipFree(xext);
+    hipStreamDestroy(tmp);
+  }
+  return rc;
 }

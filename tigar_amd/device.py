@@ -852,6 +852,18 @@ class Comm(object):
         check(_lib.lib().tg_comm_info(self._h, C.byref(r), C.byref(w), C.byref(k)), "tg_comm_info")
         return r.value, w.value, self.KINDS[k.value]
 
+    def selftest(self, timeout_s=60.0):
+        """small all-reduce + halo exchanges with known values, host waits bounded; raises on failure.  After a
+        time-out the communicator must be abandoned, not destroyed (``abandon()``)."""
+        rc = _lib.lib().tg_comm_selftest(self._h, float(timeout_s))
+        if rc == 4:
+            self.abandon()
+        check(rc, "tg_comm_selftest")
+
+    def abandon(self):
+        """forget the handle without tearing the communicator down (its exchanges are stuck on the device)"""
+        self._h = None
+
     def rank_devices(self):
         """device index of every rank as the ranks published them (IPC communicator; None entries otherwise)"""
         out = []

@@ -267,6 +267,7 @@ def device_comm(transport, kind=None):
         kind = "rccl" if ndev >= local else "ipc"
     if kind == "host":
         return dev.HostComm(transport)
+    selftest_s = float(os.environ.get("TIGAR_COMM_SELFTEST_S", "60"))
 
     def agreed(comm, err, what, fallback):
         bad = np.array([0.0 if comm is not None else 1.0])
@@ -290,16 +291,18 @@ def device_comm(transport, kind=None):
             uid = transport.broadcast_bytes(uid, 256)
             try:
                 comm = dev.Comm(uid[:128], transport.rank, transport.world, unique_id_halo=uid[128:])
+                comm.selftest(selftest_s)
             except Exception as e:
-                err = e
+                comm, err = None, e
         comm = agreed(comm, err, "RCCL", "IPC")
         if comm is not None:
             return comm
     comm, err = None, None
     try:
         comm = dev.IpcComm(transport)
+        comm.selftest(selftest_s)
     except Exception as e:
-        err = e
+        comm, err = None, e
     comm = agreed(comm, err, "IPC", "host-staged")
     if comm is not None:
         return comm
