@@ -150,6 +150,41 @@ def test_cfg3_full_size_through_the_api_against_kronecker_oracle():
         bound = 4e-16 * np.sqrt(len(cols)) * float(np.abs(vals) @ np.abs(x[cols])) + 1e-300
         assert abs(y_csr[r] - yr) <= 50 * bound and abs(y_sell[r] - yr) <= 50 * bound
 
+    # ---- whole-matrix checks (every one of the 5.8e9 entries takes part):
+    # (a) K x for a separable x = xz (x) xy (x) xx that vanishes on the boundary: zeroRowsColumns(K0) x = P (K0 x), and
+    #     K0 x = sum_d (x)_k [k1 or m1] x_k needs only 1-D products -- compared in all 17.4 M entries
+    x1 = [rng.standard_normal(n) for _ in range(D)]
+    for v in x1:
+        v[0] = v[-1] = 0.0
+    kx = [k1 @ v for v in x1]
+    mx = [m1 @ v for v in x1]
+
+    def kron3(az, ay, ax):
+        return (az[:, None, None] * ay[None, :, None] * ax[None, None, :]).reshape(-1)
+    ref = kron3(mx[2], mx[1], kx[0]) + kron3(mx[2], kx[1], mx[0]) + kron3(kx[2], mx[1], mx[0])
+    ref[zmask] = 0.0
+    xs = kron3(x1[2], x1[1], x1[0])
+    got = K.mult(dev.DeviceVector(data=xs)).get_local()
+    assert np.max(np.abs(got - ref)) <= 2e-12 * np.max(np.abs(ref))
+    assert np.all(got[zmask] == 0.0)
+    # (b) x supported on the boundary dofs only: every entry of a zeroed row or column must be exactly zero and the
+    #     diagonal exactly `diag`:  K x == diag x, bit for bit
+    xb = np.where(zmask, rng.standard_normal(ncp), 0.0)
+    got = K.mult(dev.DeviceVector(data=xb)).get_local()
+    assert np.array_equal(got, diag * xb)
+    # (c) symmetry of the assembled operator: x^T K y == y^T K x for random (non-separable) x, y
+    yv = rng.standard_normal(ncp)
+    Kx, Ky = y_csr, K.mult(dev.DeviceVector(data=yv)).get_local()
+    a, b = float(yv @ Kx), float(x @ Ky)
+    assert abs(a - b) <= 1e-11 * (np.abs(yv) @ np.abs(Kx))
+    # (d) without boundary conditions the Laplace operator annihilates constants (partition of unity): K0 1 = 0
+    K0 = spline.assembleMatrix(F.LaplaceForm(), applyBCs=False)
+    assert K0.nnz == K.nnz
+    one = K0.mult(dev.DeviceVector(data=np.ones(ncp))).get_local()
+    rowsum_abs = float(np.max(np.abs(k1).sum(axis=1))) * float(np.max(np.abs(m1).sum(axis=1))) ** 2 * 3.0
+    assert np.max(np.abs(one)) <= 1e-12 * rowsum_abs
+    del K0
+
     # ---- Jacobi-CG on the full system + matrix-free prolongation: manufactured solution
     load3 = F.SeparableLoadForm([f1] * D, scale=D * np.pi ** 2)
     rhs3 = spline.assembleVector(load3)
