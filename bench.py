@@ -75,11 +75,13 @@ def _elevate(Pw):
 def _refined_net(coarse, fine, Pw):
     """control net of the same curve on a refined knot vector: interpolation at the fine Greville points"""
     nf = fine.getNcp()
+    us = np.array([fine.greville(r) for r in range(nf)])
     Nf, Nc = np.zeros((nf, nf)), np.zeros((nf, coarse.getNcp()))
-    for r in range(nf):
-        u = fine.greville(r)
-        Nf[r, fine.getNodes(u)] = fine.basisFuncs(fine.getKnotSpan(u), u)
-        Nc[r, coarse.getNodes(u)] = coarse.basisFuncs(coarse.getKnotSpan(u), u)
+    rows = np.arange(nf)[:, None]
+    _, idx, val = fine.evalBatch(us)                     # (one device call per spline instead of one per point)
+    Nf[rows, idx] = val
+    _, idx, val = coarse.evalBatch(us)
+    Nc[rows, idx] = val
     return np.linalg.solve(Nf, Nc @ Pw)
 
 

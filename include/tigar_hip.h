@@ -251,6 +251,11 @@ typedef struct tg_tensor_plan_s *tg_tensor_plan_t;
 typedef struct tg_tensor_planes_s *tg_tensor_planes_t;
 int tg_tensor_plan_create(int d, const tg_tensor_dir_t *dirs, tg_tensor_plan_t *out);
 int tg_tensor_plan_destroy(tg_tensor_plan_t plan);
+/* The same for a patch with TWO parametric directions and nfields fields on one scalar basis (M = I (x) M_y (x) M_x,
+ * dofs field after field; degrees 1..4): K = M^T A M of the whole matrix in two passes, MatZeroRowsColumns fused.
+ * A must hold nfields^2 blocks that all carry the element-coupling pattern (verified; 100 = another pattern). */
+int tg_tensor2_plan_create(int nfields, const tg_tensor_dir_t *dirs, tg_tensor_plan_t *out);
+int tg_tensor2_ptap(tg_tensor_plan_t plan, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *out);
 /* x and y passes over the FE planes [z0,z1) of the last direction; `a` holds FE rows from a_row0 on (whole
  * planes, global columns).  The result (dense blocks, no indices) feeds tg_tensor_zstage and can be kept
  * across sub-slabs. */
@@ -289,7 +294,7 @@ int tg_krylov_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, int pc, doub
                     double *resnorm, int *status);
 /* same with flags: TG_KSP_NONZERO_GUESS = x holds the initial guess (dolfin's solver parameter
  * "nonzero_initial_guess" [ext]; the convergence test stays relative to ||B b||, PETSc's default) */
-enum { TG_KSP_NONZERO_GUESS = 1 };
+enum { TG_KSP_NONZERO_GUESS = 1, TG_KSP_STAGNATION_GUARD = 2 };
 int tg_krylov_solve_flags(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, int pc, double rtol,
                           double atol, int maxit, int restart, int flags, tg_comm_t comm, int *iters,
                           double *resnorm, int *status);

@@ -46,7 +46,7 @@ def main():
     # optional: the same system at a ladder of tolerances (so that some solve ends with its norm just below the
     # tolerance, the case in which an iteration enqueued past convergence could come back to life)
     ladder_U, ladder_res, ladder_its = [], [], []
-    if method == "cg" and os.environ.get("TIGAR_TEST_RTOLS"):
+    if os.environ.get("TIGAR_TEST_RTOLS"):
         solver.parameters["nonzero_initial_guess"] = False
         for rt in [float(v) for v in os.environ["TIGAR_TEST_RTOLS"].split(",")]:
             solver.parameters["relative_tolerance"] = rt

@@ -306,6 +306,59 @@ def test_krylov_solution_vs_direct(dev, d, p, nel, method):
     assert np.max(np.abs(u - exact)) < 5e-3 * np.max(np.abs(exact)) * (16.0 / nel) ** 2 * 4
 
 
+@pytest.mark.parametrize("restart", [30, 7])
+def test_gmres_host_free_matches_the_oracle_recurrence(dev, restart):
+    """GMRES(m) with the Hessenberg column, the Givens recurrence and the convergence decision on the device (the host
+    only enqueues and reads the residual history two iterations late): iteration count within +-1 of the oracle's
+    restatement of KSPGMRES (also across restarts), the reported norm is the recurrence's estimate of the iterate
+    returned, b = 0 and the iteration limit are reported as PETSc does, and the solve is bit-reproducible."""
+    s, A, b, M1, K1, zd = _poisson_setup(2, 3, 10)
+    Mo = O.generate_M_tensor(s)
+    Ko = O.extract_matrix(Mo, A, zd).tocsr()
+    rng = np.random.default_rng(3)
+    # non-symmetric and well enough conditioned for GMRES(7) to converge in a few dozen iterations: the off-diagonal
+    # part damped, an upper side band added
+    D = sp.diags(Ko.diagonal())
+    Ko = (D + 0.35 * (Ko - D) + sp.diags(0.3 * rng.standard_normal(Ko.shape[0] - 1), 1)).tocsr()
+    rhs = O.extract_vector(Mo, b, zd)
+    K = dev.DeviceCSR.from_scipy(Ko)
+    n = Ko.shape[0]
+    y = dev.DeviceVector(data=rhs)
+    runs = []
+    for rep in range(3):
+        U = dev.DeviceVector(n)
+        its, res, status = dev.krylov_solve(K, y, U, method="gmres", pc="jacobi", rtol=1e-9, atol=1e-30, maxit=5000,
+                                            restart=restart)
+        runs.append((its, res, status, U.get_local()))
+    its, res, status, Uh = runs[0]
+    assert status == 0
+    for r in runs[1:]:
+        assert r[0] == its and r[1] == res and np.array_equal(r[3], Uh)            # deterministic
+    xo, ito, reso = O.gmres_jacobi(Ko, rhs, rtol=1e-9, atol=1e-30, restart=restart)
+    assert abs(its - ito) <= 1
+    assert np.linalg.norm(Uh - xo) <= 1e-6 * np.linalg.norm(xo)
+    # the reported estimate against the true preconditioned residual of the returned iterate
+    dinv = 1.0 / Ko.diagonal()
+    true = np.linalg.norm(dinv * (rhs - Ko @ Uh))
+    assert abs(true - res) <= 1e-3 * np.linalg.norm(dinv * rhs) * 1e-9 + 0.05 * res
+    # iteration limit inside and at the end of a cycle: x is the iterate of the last iteration done
+    for lim in (3, restart, restart + 2):
+        U = dev.DeviceVector(n)
+        it2, res2, st2 = dev.krylov_solve(K, y, U, method="gmres", pc="jacobi", rtol=1e-14, atol=1e-30, maxit=lim,
+                                          restart=restart)
+        assert it2 == lim and st2 == -1
+        xo2, _, reso2 = O.gmres_jacobi(Ko, rhs, rtol=1e-14, atol=1e-30, maxit=lim, restart=restart)
+        assert np.linalg.norm(U.get_local() - xo2) <= 1e-7 * np.linalg.norm(xo2)
+    # b = 0
+    z, x0 = dev.DeviceVector(n), dev.DeviceVector(n)
+    it3, res3, st3 = dev.krylov_solve(K, z, x0, "gmres")
+    assert it3 == 0 and st3 == 1 and np.all(x0.get_local() == 0)
+    # restart from the solution: converged before the first iteration
+    U2 = dev.DeviceVector(data=Uh)
+    it4, res4, st4 = dev.krylov_solve(K, y, U2, "gmres", rtol=1e-8, atol=1e-30, nonzero_initial_guess=True)
+    assert it4 == 0 and st4 == 0 and np.array_equal(U2.get_local(), Uh)
+
+
 def test_krylov_statuses(dev):
     s, A, b, M1, K1, zd = _poisson_setup(2, 2, 8)
     Mo = O.generate_M_tensor(s)

@@ -144,8 +144,9 @@ def test_ipc_dead_peer_is_an_error_not_a_hang(tmp_path):
     assert 2.0 <= float(secs) <= 20.0
 
 
-@pytest.mark.parametrize("kind,world", [("host", 3), ("ipc", 2), ("ipc", 3)])
-def test_iterations_enqueued_past_convergence_change_nothing(tmp_path, kind, world):
+@pytest.mark.parametrize("kind,world,method", [("host", 3, "cg"), ("ipc", 2, "cg"), ("ipc", 3, "cg"), ("ipc", 2, "gmres"),
+                                               ("host", 3, "gmres")])
+def test_iterations_enqueued_past_convergence_change_nothing(tmp_path, kind, world, method):
     """The host enqueues CG iterations two ahead of the norm it has read; the ones past convergence must leave x, the
     reported norm and the iteration count exactly as a run that reads every norm first (TIGAR_CG_LOOK=0).  With several
     ranks the frozen update has to hand gamma / nu to the next all-reduce ONCE, not once per rank."""
@@ -153,8 +154,8 @@ def test_iterations_enqueued_past_convergence_change_nothing(tmp_path, kind, wor
     a, b = tmp_path / "ahead", tmp_path / "lockstep"
     a.mkdir(), b.mkdir()
     ladder = {"TIGAR_TEST_RTOLS": ",".join("%g" % (10.0 ** (-0.5 * k)) for k in range(4, 24))}
-    ahead = _run_ranks(a, world, kind, d, p, nel, "cg", 33137 + world, ladder)
-    lock = _run_ranks(b, world, kind, d, p, nel, "cg", 33537 + world, dict(ladder, TIGAR_CG_LOOK="0"))
+    ahead = _run_ranks(a, world, kind, d, p, nel, method, 33137 + world, ladder)
+    lock = _run_ranks(b, world, kind, d, p, nel, method, 33537 + world, dict(ladder, TIGAR_CG_LOOK="0"))
     for r in range(world):
         assert int(ahead[r]["its"][0]) == int(lock[r]["its"][0])
         assert np.array_equal(ahead[r]["U"], lock[r]["U"])

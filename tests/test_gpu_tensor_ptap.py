@@ -323,3 +323,105 @@ def _rand_pair(rng, n, m):
     b = sp.random(n, m, density=0.01, random_state=np.random.RandomState(2), format="csr")
     a.sort_indices(), b.sort_indices()
     return a, b
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 2-D patches (one or several fields on one basis; degrees up to 4): tg_tensor2_ptap
+def _patch2(p, nels, nF, lo=-1.0):
+    import tigar_amd as t
+    from tigar_amd import BSplines as B
+    kvs = [B.uniformKnots(p, lo, 1., n) for n in nels]
+    gen = t.EqualOrderSpline(nF, B.ExplicitBSplineControlMesh([p] * 2, kvs))
+    for f in range(nF):
+        sp0 = gen.getScalarSpline(f)
+        for direction in range(2):
+            for side in (0, 1):
+                gen.addZeroDofs(f, sp0.getSideDofs(direction, side, nLayers=2 if p > 2 else 1))
+    return gen, t.ExtractedSpline(gen, 2 * p)
+
+
+def _random_fe_matrix2(p, nels, nF, seed=0):
+    pats = []
+    for k in range(2):
+        nfe = p * nels[k] + 1
+        P1 = sp.lil_matrix((nfe, nfe))
+        for e in range(nels[k]):
+            P1[p * e:p * e + p + 1, p * e:p * e + p + 1] = 1.0
+        pats.append(P1.tocsr())
+    pat = O.kron_dir0_fastest(pats).tocsr()
+    A = sp.bmat([[pat] * nF for _ in range(nF)], format="csr")
+    A.sort_indices()
+    A.data = np.random.default_rng(seed).standard_normal(A.nnz)
+    return A
+
+
+@pytest.mark.parametrize("p,nels,nF", [(4, (3, 2), 1), (4, (40, 37), 1), (3, (4, 3), 3), (3, (33, 21), 3), (2, (5, 4), 2),
+                                        (1, (3, 3), 1), (4, (1, 1), 1), (2, (70, 3), 4)])
+def test_2d_device_walks_vs_oracle(p, nels, nF):
+    from tigar_amd.tensorptap import TensorPtAP2D
+    from tigar_amd import device as dev
+    gen, spline = _patch2(p, nels, nF)
+    kx = spline._kron if nF == 1 else spline._kron_scalar
+    plan = TensorPtAP2D.for_extraction(kx, nF)
+    assert plan is not None                                   # the patch qualifies
+    A = _random_fe_matrix2(p, nels, nF, seed=p)
+    s = O.BSpline([p] * 2, [O.uniform_knots(p, -1., 1., n) for n in nels])
+    Mo = O.generate_M_tensor(s, nfields=nF)
+    zd = list(spline.zeroDofs)
+    Ko = O.extract_matrix(Mo, A, zd, diag=2.5)
+    Ad = dev.DeviceCSR.from_scipy(A)
+    Kd = plan.ptap(Ad, zd, 2.5)
+    assert Kd is not None
+    K = Kd.to_scipy()
+    assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices)
+    assert np.max(np.abs(K.data - Ko.data)) <= 1e-13 * np.max(np.abs(Ko.data))
+    # through the public API (extractMatrix picks the same path), three times: bit-identical
+    dev.prof_reset()
+    for _ in range(3):
+        K1 = spline.extractMatrix(A, diag=2.5).to_scipy()
+        assert np.array_equal(K1.data, K.data) and np.array_equal(K1.indices, K.indices)
+    # no boundary conditions
+    K0 = spline.extractMatrix(A, applyBCs=False).to_scipy()
+    Ko0 = O.extract_matrix(Mo, A, None)
+    assert np.array_equal(K0.indices, Ko0.indices) and np.max(np.abs(K0.data - Ko0.data)) <= 1e-13 * np.max(np.abs(Ko0.data))
+    # the general kernels agree to rounding; the Jacobi solve uses the diagonal recorded by the final pass
+    os.environ["TIGAR_PTAP_TENSOR"] = "0"
+    try:
+        gen2, spline2 = _patch2(p, nels, nF)
+        Kg = spline2.extractMatrix(A, diag=2.5).to_scipy()
+    finally:
+        os.environ.pop("TIGAR_PTAP_TENSOR", None)
+    assert np.array_equal(Kg.indices, K.indices)
+    assert np.max(np.abs(Kg.data - K.data)) <= 1e-12 * np.max(np.abs(K.data))
+
+
+def test_2d_other_patterns_fall_back_to_the_general_kernels():
+    """a block with an entry outside the element-coupling pattern (or a missing one): the fast path declines on the
+    device, extractMatrix still returns the oracle's product through the general kernels"""
+    p, nels, nF = 3, (6, 5), 2
+    gen, spline = _patch2(p, nels, nF)
+    A = _random_fe_matrix2(p, nels, nF, seed=2).tolil()
+    A[3, A.shape[1] - 2] = 0.7                                 # a coupling added by hand
+    A = A.tocsr()
+    s = O.BSpline([p] * 2, [O.uniform_knots(p, -1., 1., n) for n in nels])
+    Mo = O.generate_M_tensor(s, nfields=nF)
+    zd = list(spline.zeroDofs)
+    Ko = O.extract_matrix(Mo, A, zd)
+    K = spline.extractMatrix(A).to_scipy()
+    K.sort_indices()
+    D = (K - Ko).tocsr()
+    assert abs(D).max() <= 1e-12 * abs(Ko).max()
+    # certified scalar matrix (assembled by the library on this grid): K equal with and without verification
+    from tigar_amd import forms as F, device as dev
+    gen1, spline1 = _patch2(4, (12, 9), 1)
+    A1 = F.BiharmonicForm().assemble_matrix(spline1.V)
+    dev.prof_reset()
+    Ka = spline1.extractMatrix(A1).to_scipy()
+    assert dev.prof_get(3)[1] == 1                              # pattern taken from the certificate
+    os.environ["TIGAR_PTAP_VERIFY"] = "1"
+    try:
+        Kb = spline1.extractMatrix(A1).to_scipy()
+    finally:
+        os.environ.pop("TIGAR_PTAP_VERIFY", None)
+    assert dev.prof_get(3)[1] == 1
+    assert np.array_equal(Ka.data, Kb.data) and np.array_equal(Ka.indices, Kb.indices)

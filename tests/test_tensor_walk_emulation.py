@@ -246,3 +246,126 @@ def test_structure_checks_reject_other_knot_vectors():
     # the plain open vector passes
     M1o = O.generate_M_tensor(O.BSpline([p], [O.uniform_knots(p, 0., 1., nel)])).tocsr()
     assert TP.local_weights(M1o, p, nel) is not None and TP.band_pattern_ok(M1o, p, nel)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 2-D patches with nF fields on one basis (cfg4: biharmonic p = 4; cfg5: three fields): x pass with the field index
+# as a dense third direction, then the final pass along direction 1 that writes K in CSR order
+def _emulated_ptap_2d(emu, p, nels, nF, wls, A, zero_dofs, diag, ech=(0, 0)):
+    """mirror of tg_tensor2_ptap (csrc/tg_ptap_tensor.hip) on host arrays"""
+    W = 2 * p + 1
+    nfe = [p * n + 1 for n in nels]
+    ncp = [n + p for n in nels]
+    tabs = [_tables(p, n) for n in nels]
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    rowptr, col, val = A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.float64)
+    t1 = int(tabs[1][0][nfe[1]])
+    plane_b1 = W * nF * ncp[0] * t1
+    b1 = np.full(plane_b1 * nF, np.nan)
+    pb1 = (np.arange(nF + 1) * plane_b1).astype(np.int64)
+    planes = np.arange(nF, dtype=np.int32)
+    rps2 = (np.arange(nF + 1) * nF).astype(np.int32)
+    first = True
+    for n1 in (W, p + 1):
+        lines = np.array([a for a in range(nfe[1]) if _rn(p, a, nfe[1]) == n1], dtype=np.int32)
+        if not len(lines):
+            continue
+        L = max(1, 64 // (n1 * nF))
+        bad = emu.emu_x2(p, _p(rowptr, c_i64p), _p(col, c_i32p), _p(val, c_f64p), nels[0], nfe[1], nF, _p(wls[0], c_f64p),
+                         _p(tabs[0][0], c_i32p), _p(tabs[1][0], c_i32p), _p(rps2, c_i32p), _p(lines, c_i32p), len(lines), L,
+                         n1, _p(planes, c_i32p), _p(b1, c_f64p), _p(pb1, c_i64p), ech[0], 1 if first else 0)
+        first = False
+        if bad:
+            return None
+    assert not np.any(np.isnan(b1))                                        # every block entry written (once per piece)
+    ntot = nF * ncp[0] * ncp[1]
+    nnz = nF * nF * int(tabs[0][1][ncp[0]]) * int(tabs[1][1][ncp[1]])
+    mask = None
+    if zero_dofs is not None and len(zero_dofs):
+        mask = np.zeros(ntot, dtype=np.uint8)
+        mask[np.asarray(zero_dofs)] = 1
+    kcol = np.full(nnz, -1, dtype=np.int32)
+    kval = np.full(nnz, np.nan)
+    kdiag = np.full(ntot, np.nan)
+    krow = np.zeros(ntot + 1, dtype=np.int64)
+    emu.emu_y2(p, _p(b1, c_f64p), C.c_int64(plane_b1), nels[1], _p(wls[1], c_f64p), _p(tabs[1][0], c_i32p),
+               _p(tabs[1][1], c_i32p), ncp[0], nF, _p(tabs[0][1], c_i32p), max(1, 64 // (W * nF)), ech[1],
+               _p(kcol, c_i32p), _p(kval, c_f64p), _p(kdiag, c_f64p),
+               _p(mask, C.POINTER(C.c_uint8)) if mask is not None else None, C.c_double(diag), _p(krow, c_i64p))
+    krow[ntot] = nnz
+    assert np.all(kcol >= 0) and not np.any(np.isnan(kval))
+    K = sp.csr_matrix((kval, kcol, krow), shape=(ntot, ntot))
+    assert np.array_equal(kdiag, K.diagonal())                             # the diagonal recorded on the way
+    return K
+
+
+def _setup_2d(p, nels, nF, seed=0):
+    from tigar_amd import tensorptap as TP
+    kvs = [O.uniform_knots(p, -1., 1., n) for n in nels]
+    s = O.BSpline([p] * 2, kvs)
+    Mo = O.generate_M_tensor(s, nfields=nF)
+    wls = []
+    for k in range(2):
+        M1 = O.generate_M_tensor(O.BSpline([p], [kvs[k]])).tocsr()
+        wl = TP.local_weights(M1, p, nels[k])
+        assert wl is not None and TP.band_pattern_ok(M1, p, nels[k])
+        wls.append(np.ascontiguousarray(wl))
+    pats = []
+    for k in range(2):
+        nfe = p * nels[k] + 1
+        P1 = sp.lil_matrix((nfe, nfe))
+        for e in range(nels[k]):
+            P1[p * e:p * e + p + 1, p * e:p * e + p + 1] = 1.0
+        pats.append(P1.tocsr())
+    pat = O.kron_dir0_fastest(pats).tocsr()
+    A = sp.bmat([[pat] * nF for _ in range(nF)], format="csr")
+    A.sort_indices()
+    rng = np.random.default_rng(seed)
+    A.data = rng.standard_normal(A.nnz)
+    ncp = s.getNcp()
+    zd = []
+    for f in range(nF):
+        for direction in range(2):
+            for side in (0, 1):
+                zd += [f * ncp + v for v in s.getSideDofs(direction, side, 2 if p > 2 else 1)]
+    return s, Mo, wls, A, zd
+
+
+@pytest.mark.parametrize("p,nels,nF", [(4, (3, 2), 1), (3, (4, 3), 3), (2, (5, 4), 2), (1, (3, 3), 1), (4, (1, 1), 1),
+                                        (3, (2, 5), 1)])
+def test_2d_walks_reproduce_oracle_ptap(emu, p, nels, nF):
+    s, Mo, wls, A, zd = _setup_2d(p, nels, nF)
+    Ko = O.extract_matrix(Mo, A, zd, diag=2.5)
+    K = _emulated_ptap_2d(emu, p, nels, nF, wls, A, zd, 2.5)
+    _check(K, Ko)
+    _check(_emulated_ptap_2d(emu, p, nels, nF, wls, A, None, 1.0), O.extract_matrix(Mo, A, None))
+
+
+@pytest.mark.parametrize("p,nF", [(4, 1), (3, 2), (2, 1)])
+def test_2d_walks_in_pieces_are_bit_identical(emu, p, nF):
+    """the walks cut into pieces of a few elements (each piece re-reads p elements to warm its ring up): same K bit for
+    bit, every entry of B1 and K written exactly once"""
+    nels = (9, 7)
+    s, Mo, wls, A, zd = _setup_2d(p, nels, nF, seed=4)
+    K_ref = _emulated_ptap_2d(emu, p, nels, nF, wls, A, zd, 1.0)
+    _check(K_ref, O.extract_matrix(Mo, A, zd))
+    for ech in ((1, 1), (2, 3), (4, 2), (8, 6), (5, 0), (0, 4)):
+        K = _emulated_ptap_2d(emu, p, nels, nF, wls, A, zd, 1.0, ech=ech)
+        assert np.array_equal(K.indices, K_ref.indices) and np.array_equal(K.data, K_ref.data)
+
+
+def test_2d_other_patterns_are_declined(emu):
+    p, nels, nF = 3, (2, 2), 2
+    s, Mo, wls, A, zd = _setup_2d(p, nels, nF)
+    A1 = A.copy().tolil()
+    A1[20, A1.rows[20][2]] = 0.0
+    A1 = A1.tocsr()
+    A1.eliminate_zeros()
+    assert _emulated_ptap_2d(emu, p, nels, nF, wls, A1, zd, 1.0) is None
+    A2 = A.copy()
+    A2.indices = A2.indices.copy()
+    q = A2.indptr[31]                                                          # first entry of row 31
+    assert A2.indices[q] >= 1
+    A2.indices[q] -= 1                                                         # same row length, one column moved
+    assert _emulated_ptap_2d(emu, p, nels, nF, wls, A2, zd, 1.0) is None

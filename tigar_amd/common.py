@@ -872,7 +872,11 @@ class PETScKrylovSolver(object):
         self.parameters = {"relative_tolerance": 1e-6, "absolute_tolerance": 1e-15,
                            "maximum_iterations": 10000, "error_on_nonconvergence": True,
                            "nonzero_initial_guess": False, "gmres_restart": 30,
-                           "report": False, "monitor_convergence": False}
+                           "report": False, "monitor_convergence": False,
+                           # (not a dolfin parameter) give up with status -3 after 25 GMRES restart cycles without
+                           # progress instead of running to the iteration limit as PETSc does; set by the default
+                           # solver that stands in for the reference's direct LU on large systems
+                           "stagnation_guard": False}
         self.comm = comm
         self.last = None
         self.note = None       # appended to the non-convergence message (who chose this solver)
@@ -888,7 +892,8 @@ class PETScKrylovSolver(object):
             A, b, x, self.method, self.preconditioner, self.parameters["relative_tolerance"],
             self.parameters["absolute_tolerance"], self.parameters["maximum_iterations"],
             self.parameters["gmres_restart"], self.comm,
-            nonzero_initial_guess=bool(self.parameters["nonzero_initial_guess"]))
+            nonzero_initial_guess=bool(self.parameters["nonzero_initial_guess"]),
+            stagnation_guard=bool(self.parameters.get("stagnation_guard", False)))
         self.last = {"iterations": its, "residual_norm": res, "status": status}
         if status < 0 and self.parameters["error_on_nonconvergence"]:
             raise RuntimeError("Krylov solver (%s, %s) did not converge: %s after %d iterations, preconditioned "
@@ -986,6 +991,7 @@ class _DefaultSolver(object):
         ks = PETScKrylovSolver(self.method, "jacobi", comm=self.comm)
         ks.parameters["relative_tolerance"] = 1e-12
         ks.parameters["maximum_iterations"] = 10000
+        ks.parameters["stagnation_guard"] = True
         ks.note = ("  (linearSolver=None: the reference would have run dolfin's direct LU here; this system is too large for "
                    "tigar_amd's banded direct solver, so Jacobi-%s was used -- set ExtractedSpline.linearSolver for "
                    "ill-conditioned systems)" % self.method.upper())
@@ -1176,6 +1182,16 @@ class ExtractedSpline(object):
             return self._slab_path().assemble_matrix(a_rows, zd, float(diag), getattr(self, "stage_timers", None))
         A = _as_device_csr(A)
         by_blocks = self._kron is None and getattr(self, "_kron_scalar", None) is not None
+        # 2-D tensor patches (one or several fields on one basis): the whole product in two line-walk passes when A
+        # carries the element-coupling pattern (verified on the device; csrc/tg_tensor_body.h)
+        kx2 = self._kron if self._kron is not None else getattr(self, "_kron_scalar", None)
+        if kx2 is not None and kx2.d == 2 and not A.is_loose() and os.environ.get("TIGAR_PTAP_FACTORED", "1") != "0":
+            from .tensorptap import TensorPtAP2D
+            plan2 = TensorPtAP2D.for_extraction(kx2, self.nFields if by_blocks else 1)
+            if plan2 is not None:
+                K = plan2.ptap(A, zd, float(diag))
+                if K is not None:
+                    return K
         if by_blocks and os.environ.get("TIGAR_PTAP_FACTORED", "1") != "0":
             K = self._extract_matrix_by_field_blocks(A, zd, float(diag))
             if K is not None:

@@ -544,25 +544,236 @@ __global__ void k_lincomb_add(double *__restrict__ x, const double *__restrict__
   }
 }
 
+// ---- host-free GMRES(m): the Hessenberg column, the Givens recurrence, the residual estimate and the
+// convergence decision live on the device (one single-thread kernel per inner iteration); the host enqueues
+// iterations ahead of the one whose residual it has read (pinned ring, two iterations late, as in tg_cg) and
+// everything enqueued past convergence is gated on the device flag `live`.  Two reductions per inner iteration
+// (classical Gram-Schmidt coefficients, then the norm of the orthogonalised vector -- PETSc's default
+// KSPGMRESClassicalGramSchmidtOrthogonalization without refinement [ext]), each one all-reduce with several ranks.
+struct tg_gm_state {
+  double live;        // 1.0 while iterating; 0.0 once converged / broken down / out of iterations (gate of the products)
+  double res;         // current estimate of the preconditioned residual norm
+  double tol;
+  double beta0;       // reference norm
+  int its, status, kused, cycle;
+};
+
+// cycle start from the reduced ||r||^2 in scal[0]; `first`: also fixes the tolerance (bnorm2 >= 0: reference norm^2)
+__global__ void k_gm_start(tg_gm_state *st, const double *scal, int first, double rtol, double atol, double bnorm2,
+                           double *g, int m) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (!first && st->live == 0.0) return;
+  const double beta = sqrt(scal[0]);
+  st->res = beta;
+  if (first) {
+    const double beta0 = bnorm2 >= 0.0 ? sqrt(bnorm2) : beta;
+    st->beta0 = beta0;
+    st->tol = fmax(rtol * beta0, atol);
+    st->its = 0;
+    st->kused = 0;
+    st->cycle = 0;
+    st->status = -1;
+    st->live = 1.0;
+    if (!(beta == beta) || !(beta0 == beta0)) {
+      st->status = -2;
+      st->live = 0.0;
+      return;
+    }
+    if (beta0 <= atol) {
+      st->status = 1;
+      st->live = 0.0;
+      return;
+    }
+  }
+  if (beta <= st->tol) {
+    st->status = 0;
+    st->live = 0.0;
+    return;
+  }
+  st->cycle += 1;
+  g[0] = beta;
+  for (int i = 1; i <= m; i++) g[i] = 0.0;
+}
+
+// dst = src / norm   (norm = st->res when `norm2` is null, else sqrt(*norm2)); nothing when the solve is over
+__global__ void __launch_bounds__(256) k_gm_scale(const tg_gm_state *st, double *__restrict__ dst,
+                                                  const double *__restrict__ src, const double *norm2, int64_t n) {
+  if (st->live == 0.0) return;
+  const double nrm = norm2 ? sqrt(*norm2) : st->res;
+  const double a = nrm > 0.0 ? 1.0 / nrm : 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = a * src[i];
+}
+
+// w <- dinv * w (preconditioning fused) and partial[b*(k+1)+j] = sum_i V_j[i] * w[i],  j = 0..k
+__global__ void __launch_bounds__(256) k_gm_dots(const tg_gm_state *st, const double *__restrict__ V, int64_t ld, int kp1,
+                                                 double *__restrict__ w, const double *__restrict__ dinv, int64_t n,
+                                                 double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  if (st->live == 0.0) return;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int j = 0; j < kp1; j++) {
+    const double *vj = V + (int64_t)j * ld;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+      double wi = w[i];
+      if (j == 0) {               // (a thread always revisits its own entries: the scaled value is what it reads back)
+        wi *= dinv[i];
+        w[i] = wi;
+      }
+      s += vj[i] * wi;
+    }
+    s = tg_block_sum256(s, lds4);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * kp1 + j] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_gm_fold(const tg_gm_state *st, const double *partial, int nb, int nstreams,
+                                                 double *out) {
+  __shared__ double lds4[4];
+  if (st && st->live == 0.0) return;
+  for (int k = 0; k < nstreams; k++) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 256) s += partial[(int64_t)b * nstreams + k];
+    s = tg_block_sum256(s, lds4);
+    if (threadIdx.x == 0) out[k] = s;
+  }
+}
+
+// w -= sum_j h[j] V_j ; partial of w.w
+__global__ void __launch_bounds__(256) k_gm_orth(const tg_gm_state *st, const double *__restrict__ V, int64_t ld, int kp1,
+                                                 const double *__restrict__ h, double *__restrict__ w, int64_t n,
+                                                 double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  if (st->live == 0.0) return;
+  double ss = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    double wi = w[i];
+    for (int j = 0; j < kp1; j++) wi -= h[j] * V[(int64_t)j * ld + i];
+    w[i] = wi;
+    ss += wi * wi;
+  }
+  ss = tg_block_sum256(ss, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = ss;
+}
+
+// column j of the Hessenberg matrix: rotations of the earlier columns, the new rotation, the residual estimate, the
+// decision (hcol[0..j] = Gram-Schmidt coefficients, hcol[j+1] = ||w||^2)
+__global__ void k_gm_givens(tg_gm_state *st, int j, int m, const double *hcol, double *H, double *cs, double *sn,
+                            double *g, int maxit, double *hist) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (st->live != 0.0) {
+    double *Hj = H + (int64_t)j * (m + 1);
+    for (int i = 0; i <= j; i++) Hj[i] = hcol[i];
+    Hj[j + 1] = sqrt(hcol[j + 1]);
+    for (int i = 0; i < j; i++) {
+      const double t = cs[i] * Hj[i] + sn[i] * Hj[i + 1];
+      Hj[i + 1] = -sn[i] * Hj[i] + cs[i] * Hj[i + 1];
+      Hj[i] = t;
+    }
+    const double den = hypot(Hj[j], Hj[j + 1]);
+    if (den == 0.0 || !(den == den)) {
+      st->status = -2;
+      st->live = 0.0;
+    } else {
+      cs[j] = Hj[j] / den;
+      sn[j] = Hj[j + 1] / den;
+      Hj[j] = den;
+      Hj[j + 1] = 0.0;
+      g[j + 1] = -sn[j] * g[j];
+      g[j] = cs[j] * g[j];
+      st->its += 1;
+      st->kused = j + 1;
+      st->res = fabs(g[j + 1]);
+      if (st->res <= st->tol) {
+        st->status = 0;
+        st->live = 0.0;
+      } else if (st->its >= maxit)
+        st->live = 0.0;        // (status stays -1: iteration limit)
+    }
+  }
+  hist[0] = st->res;
+  hist[1] = st->live;
+  hist[2] = (double)st->its;
+  hist[3] = (double)st->cycle;
+}
+
+// end of a cycle: y from the triangular system of the columns used, x += V y, the cycle is closed (kused = 0)
+__global__ void k_gm_solve_y(const tg_gm_state *st, int m, const double *H, const double *g, double *y) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int ku = st->kused;
+  for (int i = ku - 1; i >= 0; i--) {
+    double s = g[i];
+    for (int c = i + 1; c < ku; c++) s -= H[(int64_t)c * (m + 1) + i] * y[c];
+    y[i] = s / H[(int64_t)i * (m + 1) + i];
+  }
+}
+__global__ void __launch_bounds__(256) k_gm_update_x(const tg_gm_state *st, double *__restrict__ x,
+                                                     const double *__restrict__ V, int64_t ld, const double *__restrict__ y,
+                                                     int64_t n) {
+  const int ku = st->kused;
+  if (ku <= 0) return;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    double s = x[i];
+    for (int j = 0; j < ku; j++) s += y[j] * V[(int64_t)j * ld + i];
+    x[i] = s;
+  }
+}
+__global__ void k_gm_close(tg_gm_state *st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) st->kused = 0;
+}
+// dst = dinv * (b - kx) (kx may be null); partial of dst.dst; nothing once the solve is over (st may be null)
+__global__ void __launch_bounds__(256) k_gm_residual(const tg_gm_state *st, const double *__restrict__ b,
+                                                     const double *__restrict__ kx, const double *__restrict__ dinv,
+                                                     double *__restrict__ dst, int64_t n, double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  if (st && st->live == 0.0) return;
+  double ss = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double v = dinv[i] * (kx ? b[i] - kx[i] : b[i]);
+    dst[i] = v;
+    ss += v * v;
+  }
+  ss = tg_block_sum256(ss, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = ss;
+}
+
 static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, int restart,
-                    int nonzero_guess, tg_comm_s *comm, int *iters, double *resnorm, int *status) {
+                    int nonzero_guess, int stagnation_guard, tg_comm_s *comm, int *iters, double *resnorm, int *status) {
   const int64_t n = k->nrows;
   const int64_t hlo = comm ? comm->halo_lo : 0, hhi = comm ? comm->halo_hi : 0;
   const int64_t row0 = comm ? comm->g0 : 0;
   const int64_t next = hlo + n + hhi;
   const int m = restart;
   tg_krylov_ws ws;
-  // layout: ext[next] (SpMV input with halo) | w[n] | dinv[n] | V[(m+1) n] | hdev[m+2]
-  TG_TRY(tg_dmalloc(&ws.buf, next + 2 * n + (int64_t)(m + 1) * n + (m + 2)));
-  double *ext = ws.buf, *xin = ext + hlo, *w = ext + next, *dinv = w + n, *V = dinv + n,
-         *hdev = V + (int64_t)(m + 1) * n;
+  // layout: ext[next] (SpMV input with halo) | w[n] | dinv[n] | V[(m+1) n] | small: H[(m+1) m] cs[m] sn[m] g[m+1] y[m]
+  //         hcol[m+2] scal[4] state
+  const int64_t nsmall = (int64_t)(m + 1) * m + 3 * (int64_t)m + (m + 1) + (m + 2) + 4 + 16;
+  TG_TRY(tg_dmalloc(&ws.buf, next + 2 * n + (int64_t)(m + 1) * n + nsmall));
+  double *ext = ws.buf, *xin = ext + hlo, *w = ext + next, *dinv = w + n, *V = dinv + n;
+  double *H = V + (int64_t)(m + 1) * n, *cs = H + (int64_t)(m + 1) * m, *sn = cs + m, *g = sn + m, *y = g + (m + 1),
+         *hdev = y + m, *scal = hdev + (m + 2);
+  tg_gm_state *st = (tg_gm_state *)(scal + 4);
   TG_CHECK_HIP(hipMemsetAsync(ext, 0, (size_t)next * sizeof(double), g_tg.stream));
+  TG_CHECK_HIP(hipMemsetAsync(H, 0, (size_t)nsmall * sizeof(double), g_tg.stream));
   double *partial = g_tg.scratch;
-  double *scal = g_tg.scratch + TG_SCRATCH_DOUBLES - 2048;
   const int vg = std::min(tg_vec_grid(n), 256);
   TG_TRY(tg_spmv_plan(k));
   tg_sell_guard sell_guard(k);   // sliced copy of the values for the products of this solve
   TG_TRY(sell_guard.rc);
+  const bool sliced = k->sell_state == 1 && k->sell && n > 0;
+  tg_cg_ring ring;
+  TG_TRY(ring.init());
+  double *hist = g_tg.host_pinned + 8;                     // TG_CG_RING x 4 doubles (pinned)
+  const double *xshift = ext - (row0 - hlo);
+  const int64_t cmin = row0 - hlo, cmax = row0 - hlo + next - 1;
   if (n > 0 && k->diag_cache && k->diag_rows == n) {
     hipLaunchKernelGGL(k_jacobi_from_diag, dim3(tg_vec_grid(n)), dim3(256), 0, g_tg.stream, k->diag_cache, n,
                        pc == TG_PC_JACOBI ? 1 : 0, dinv);
@@ -571,147 +782,140 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
     hipLaunchKernelGGL(k_jacobi_setup, dim3(jg), dim3(256), 0, g_tg.stream, k->rowptr, k->col, k->val, n, row0,
                        pc == TG_PC_JACOBI ? 1 : 0, dinv);
   }
-  double bnorm = -1.0;   // ||B b||: the reference norm when the initial guess is not zero [ext]
+  // w = K * (the vector in xin, halo exchanged); products past the end of the solve return at once (sliced copy)
+  // (slot >= 0: timed with the event pair of that ring slot -- the product of an inner iteration, accounted when the
+  //  host reads that iteration's history entry)
+  auto product = [&](bool gated, int slot) -> int {
+    if (slot >= 0) hipEventRecord(ring.t0[slot], g_tg.stream);
+    TG_TRY(tg_comm_halo_exchange(comm, ext));
+    if (sliced && gated)
+      TG_TRY(tg_sell_spmv_rows(k, xshift, cmin, cmax, w, 0, n, &st->live, 0.5));
+    else
+      TG_TRY(tg_spmv_raw(k, xshift, cmin, cmax, w));
+    if (slot >= 0) hipEventRecord(ring.t1[slot], g_tg.stream);
+    return 0;
+  };
+  // reference norm ||B b|| when the initial guess is not zero [ext]
+  double bnorm2 = -1.0;
   if (nonzero_guess) {
-    hipLaunchKernelGGL(k_prec_residual, dim3(vg), dim3(256), 0, g_tg.stream, b->d, (const double *)nullptr, dinv, V, n,
-                       partial);
-    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, g_tg.stream, partial, vg, 1, scal);
+    hipLaunchKernelGGL(k_gm_residual, dim3(vg), dim3(256), 0, g_tg.stream, (const tg_gm_state *)nullptr, b->d,
+                       (const double *)nullptr, dinv, V, n, partial);
+    hipLaunchKernelGGL(k_gm_fold, dim3(1), dim3(256), 0, g_tg.stream, (const tg_gm_state *)nullptr, partial, vg, 1, scal);
     TG_LAUNCH_CHECK();
     TG_TRY(tg_comm_allreduce_dev(comm, scal, 1));
-    double hb;
-    TG_TRY(tg_read_scalars(scal, 1, &hb));
-    bnorm = sqrt(hb);
+    TG_TRY(tg_read_scalars(scal, 1, &bnorm2));
   } else
     TG_CHECK_HIP(hipMemsetAsync(x->d, 0, (size_t)std::max<int64_t>(n, 1) * sizeof(double), g_tg.stream));
-  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2);
-  auto Hat = [&](int i, int j) -> double & { return H[(size_t)i * m + j]; };
-  double beta0 = -1.0, tol = 0.0, res = 0.0;
-  int its = 0;
-  *status = -1;
-  bool first = true;
-  // stagnation guard: restarted GMRES can stall for good on indefinite / badly scaled systems (where the
-  // reference's default direct solver simply solves); 25 restart cycles in a row that each reduce the
-  // residual by less than 0.1 % end the solve with status -3 instead of running to the iteration limit
+
+  static const int look_env = getenv("TIGAR_CG_LOOK") ? std::max(0, std::min(TG_CG_RING - 2, atoi(getenv("TIGAR_CG_LOOK")))) : 2;
+  const int look = look_env;
+  int enq = 0, seen = 0;          // inner iterations enqueued / read back
+  bool stop = false;
+  double h_res = 0.0, h_live = 1.0;
+  int h_its = 0;
+  // stagnation guard (opt-in): 25 restart cycles in a row that each reduce the residual by less than 0.1 %
   double cycle_res = -1.0;
-  int stagnant = 0;
-  while (its < maxit) {
-    // r = B (b - K x)
+  int stagnant = 0, last_cycle_seen = 0;
+  bool stagnated = false;
+  auto observe = [&](int it) -> bool {
+    const int slot = it % TG_CG_RING;
+    if (hipEventSynchronize(ring.done[slot]) != hipSuccess) return true;
+    if (h_live != 0.0) {          // (products enqueued past the end return at once: not counted)
+      float ems = 0.f;
+      if (hipEventElapsedTime(&ems, ring.t0[slot], ring.t1[slot]) == hipSuccess) {
+        g_tg.prof_ms[TG_PROF_KSP_SPMV] += ems;
+        g_tg.prof_n[TG_PROF_KSP_SPMV] += 1;
+      }
+    }
+    h_res = hist[4 * slot];
+    h_live = hist[4 * slot + 1];
+    h_its = (int)hist[4 * slot + 2];
+    const int cyc = (int)hist[4 * slot + 3];
+    seen = it;
+    if (stagnation_guard && cyc != last_cycle_seen) {     // first iteration of a new cycle: compare the cycles' ends
+      if (cycle_res >= 0.0) {
+        stagnant = (h_res > 0.999 * cycle_res) ? stagnant + 1 : 0;
+        if (stagnant >= 25) stagnated = true;
+      }
+      cycle_res = h_res;
+      last_cycle_seen = cyc;
+    }
+    return h_live == 0.0 || stagnated;
+  };
+  bool first = true;
+  while (!stop) {
+    // r = B (b - K x), beta = ||r||, v_0 = r / beta
     if (first && !nonzero_guess) {
-      hipLaunchKernelGGL(k_prec_residual, dim3(vg), dim3(256), 0, g_tg.stream, b->d, (const double *)nullptr, dinv, V,
-                         n, partial);
+      hipLaunchKernelGGL(k_gm_residual, dim3(vg), dim3(256), 0, g_tg.stream, (const tg_gm_state *)nullptr, b->d,
+                         (const double *)nullptr, dinv, V, n, partial);
     } else {
       TG_CHECK_HIP(hipMemcpyAsync(xin, x->d, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream));
-      TG_TRY(tg_comm_halo_exchange(comm, ext));
-      TG_TRY(tg_spmv_raw(k, ext - (row0 - hlo), row0 - hlo, row0 - hlo + next - 1, w));
-      hipLaunchKernelGGL(k_prec_residual, dim3(vg), dim3(256), 0, g_tg.stream, b->d, (const double *)w, dinv, V, n,
-                         partial);
+      TG_TRY(product(!first, -1));
+      hipLaunchKernelGGL(k_gm_residual, dim3(vg), dim3(256), 0, g_tg.stream, first ? (const tg_gm_state *)nullptr : st, b->d,
+                         (const double *)w, dinv, V, n, partial);
     }
-    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, g_tg.stream, partial, vg, 1, scal);
+    hipLaunchKernelGGL(k_gm_fold, dim3(1), dim3(256), 0, g_tg.stream, first ? (const tg_gm_state *)nullptr : st, partial, vg,
+                       1, scal);
     TG_LAUNCH_CHECK();
     TG_TRY(tg_comm_allreduce_dev(comm, scal, 1));
-    double hh;
-    TG_TRY(tg_read_scalars(scal, 1, &hh));
-    const double beta = sqrt(hh);
-    res = beta;
+    hipLaunchKernelGGL(k_gm_start, dim3(1), dim3(1), 0, g_tg.stream, st, scal, first ? 1 : 0, rtol, atol, bnorm2, g, m);
+    hipLaunchKernelGGL(k_gm_scale, dim3(vg), dim3(256), 0, g_tg.stream, st, V, V, (const double *)nullptr, n);
+    TG_LAUNCH_CHECK();
     if (first) {
-      beta0 = nonzero_guess ? bnorm : beta;
-      tol = std::max(rtol * beta0, atol);
+      // the tolerance is fixed now; an immediate end (b = 0, converged start) is read before anything is enqueued
+      tg_gm_state h0;
+      TG_CHECK_HIP(hipMemcpyAsync(g_tg.host_pinned + 40, st, sizeof(tg_gm_state), hipMemcpyDeviceToHost, g_tg.stream));
+      TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+      memcpy(&h0, g_tg.host_pinned + 40, sizeof(h0));
+      h_res = h0.res;
+      if (h0.live == 0.0) {
+        *iters = 0;
+        *resnorm = h0.res;
+        *status = h0.status;
+        return tg_comm_check(comm);
+      }
       first = false;
-      if (!(beta == beta)) {
-        *status = -2;
-        break;
-      }
-      if (beta0 <= atol) {
-        *status = 1;
-        break;
-      }
     }
-    if (beta <= tol) {
-      *status = 0;
-      break;
-    }
-    if (cycle_res >= 0.0) {
-      stagnant = (beta > 0.999 * cycle_res) ? stagnant + 1 : 0;
-      if (stagnant >= 25) {
-        *status = -3;
-        break;
-      }
-    }
-    cycle_res = beta;
-    hipLaunchKernelGGL(k_scale_to, dim3(vg), dim3(256), 0, g_tg.stream, V, V, 1.0 / beta, n);
-    std::fill(g.begin(), g.end(), 0.0);
-    g[0] = beta;
-    int kused = 0;
-    bool done = false;
-    for (int j = 0; j < m; j++) {
-      // w = B K v_j
+    for (int j = 0; j < m && !stop; j++) {
+      // w = B K v_j ; Gram-Schmidt against v_0..v_j ; v_{j+1} ; column j of H
       TG_CHECK_HIP(hipMemcpyAsync(xin, V + (int64_t)j * n, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice,
                                   g_tg.stream));
-      TG_TRY(tg_comm_halo_exchange(comm, ext));
-      TG_TRY(tg_spmv_raw(k, ext - (row0 - hlo), row0 - hlo, row0 - hlo + next - 1, w));
-      hipLaunchKernelGGL(k_mul_inplace, dim3(vg), dim3(256), 0, g_tg.stream, w, dinv, n);
-      // classical Gram-Schmidt (PETSc default, no refinement [ext])
-      hipLaunchKernelGGL(k_multi_dot, dim3(vg), dim3(256), 0, g_tg.stream, V, n, j + 1, w, n, partial);
-      hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, g_tg.stream, partial, vg, j + 1, hdev);
+      TG_TRY(product(true, (enq + 1) % TG_CG_RING));
+      hipLaunchKernelGGL(k_gm_dots, dim3(vg), dim3(256), 0, g_tg.stream, st, V, n, j + 1, w, dinv, n, partial);
+      hipLaunchKernelGGL(k_gm_fold, dim3(1), dim3(256), 0, g_tg.stream, st, partial, vg, j + 1, hdev);
+      TG_LAUNCH_CHECK();
       TG_TRY(tg_comm_allreduce_dev(comm, hdev, j + 1));
-      hipLaunchKernelGGL(k_gs_update, dim3(vg), dim3(256), 0, g_tg.stream, V, n, j + 1, hdev, w, n, partial);
-      hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, g_tg.stream, partial, vg, 1, hdev + j + 1);
+      hipLaunchKernelGGL(k_gm_orth, dim3(vg), dim3(256), 0, g_tg.stream, st, V, n, j + 1, hdev, w, n, partial);
+      hipLaunchKernelGGL(k_gm_fold, dim3(1), dim3(256), 0, g_tg.stream, st, partial, vg, 1, hdev + j + 1);
       TG_LAUNCH_CHECK();
       TG_TRY(tg_comm_allreduce_dev(comm, hdev + j + 1, 1));
-      TG_TRY(tg_read_scalars(hdev, j + 2, hcol.data()));
-      for (int i = 0; i <= j; i++) Hat(i, j) = hcol[i];
-      const double hn = sqrt(hcol[j + 1]);
-      Hat(j + 1, j) = hn;
-      if (hn != 0.0)
-        hipLaunchKernelGGL(k_scale_to, dim3(vg), dim3(256), 0, g_tg.stream, V + (int64_t)(j + 1) * n, w, 1.0 / hn, n);
-      for (int i = 0; i < j; i++) {
-        const double t = cs[i] * Hat(i, j) + sn[i] * Hat(i + 1, j);
-        Hat(i + 1, j) = -sn[i] * Hat(i, j) + cs[i] * Hat(i + 1, j);
-        Hat(i, j) = t;
-      }
-      const double den = hypot(Hat(j, j), Hat(j + 1, j));
-      if (den == 0.0 || !(den == den)) {
-        *status = -2;
-        done = true;
-        kused = j;
-        break;
-      }
-      cs[j] = Hat(j, j) / den;
-      sn[j] = Hat(j + 1, j) / den;
-      Hat(j, j) = den;
-      Hat(j + 1, j) = 0.0;
-      g[j + 1] = -sn[j] * g[j];
-      g[j] = cs[j] * g[j];
-      its++;
-      kused = j + 1;
-      res = fabs(g[j + 1]);
-      if (res <= tol) {
-        *status = 0;
-        done = true;
-        break;
-      }
-      if (its >= maxit) {
-        done = true;
-        break;
-      }
-    }
-    // back substitution, x += V y
-    for (int i = kused - 1; i >= 0; i--) {
-      double s = g[i];
-      for (int c = i + 1; c < kused; c++) s -= Hat(i, c) * y[c];
-      y[i] = s / Hat(i, i);
-    }
-    if (kused > 0) {
-      TG_CHECK_HIP(hipMemcpyAsync(hdev, y.data(), kused * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
-      hipLaunchKernelGGL(k_lincomb_add, dim3(vg), dim3(256), 0, g_tg.stream, x->d, V, n, kused, hdev, n);
+      hipLaunchKernelGGL(k_gm_scale, dim3(vg), dim3(256), 0, g_tg.stream, st, V + (int64_t)(j + 1) * n, w,
+                         (const double *)(hdev + j + 1), n);
+      enq++;
+      const int slot = enq % TG_CG_RING;
+      // (the pinned slot is written by the kernel's successor copy: device history entry first)
+      hipLaunchKernelGGL(k_gm_givens, dim3(1), dim3(1), 0, g_tg.stream, st, j, m, hdev, H, cs, sn, g, maxit, scal);
       TG_LAUNCH_CHECK();
-      TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+      TG_CHECK_HIP(hipMemcpyAsync(hist + 4 * slot, scal, 4 * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
+      TG_CHECK_HIP(hipEventRecord(ring.done[slot], g_tg.stream));
+      if (enq - look >= 1) stop = observe(enq - look);
     }
-    if (done) break;
+    // close the cycle: x += V y for the columns used (also after convergence inside the cycle)
+    hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(1), 0, g_tg.stream, (const tg_gm_state *)st, m, H, g, y);
+    hipLaunchKernelGGL(k_gm_update_x, dim3(vg), dim3(256), 0, g_tg.stream, (const tg_gm_state *)st, x->d, V, n, y, n);
+    hipLaunchKernelGGL(k_gm_close, dim3(1), dim3(1), 0, g_tg.stream, st);
+    TG_LAUNCH_CHECK();
+    if (!stop && enq >= maxit + look) stop = true;   // (the device stops counting at maxit; do not enqueue for ever)
   }
-  *iters = its;
-  *resnorm = res;
+  for (int j = seen + 1; j <= enq; j++)
+    if (observe(j) && h_live == 0.0) break;
+  TG_CHECK_HIP(hipMemcpyAsync(g_tg.host_pinned + 40, st, sizeof(tg_gm_state), hipMemcpyDeviceToHost, g_tg.stream));
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  tg_gm_state hf;
+  memcpy(&hf, g_tg.host_pinned + 40, sizeof(hf));
+  *iters = hf.its;
+  *resnorm = hf.res;
+  *status = (stagnated && hf.live != 0.0) ? -3 : hf.status;
   TG_TRY(tg_comm_check(comm));
   return 0;
 }
@@ -738,7 +942,8 @@ extern "C" int tg_krylov_solve_flags(tg_csr_t k, tg_vec_t b, tg_vec_t x, int met
   if (method == TG_KSP_CG) return tg_cg(k, b, x, pc, rtol, atol, maxit, g_krylov_nonzero_guess, comm, iters, resnorm, status);
   if (method == TG_KSP_GMRES) {
     TG_REQUIRE(restart >= 1 && restart <= 200, "GMRES restart out of range");
-    return tg_gmres(k, b, x, pc, rtol, atol, maxit, restart, g_krylov_nonzero_guess, comm, iters, resnorm, status);
+    return tg_gmres(k, b, x, pc, rtol, atol, maxit, restart, g_krylov_nonzero_guess, (flags & TG_KSP_STAGNATION_GUARD) ? 1 : 0,
+                    comm, iters, resnorm, status);
   }
   tg_set_error("unknown Krylov method %d", method);
   return 2;

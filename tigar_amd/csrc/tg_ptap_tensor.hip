@@ -14,6 +14,8 @@
 
 struct tg_tensor_plan_s {
   int P = 0;
+  int d = 3;               // 2: patch with two parametric directions and nF fields (tg_tensor2_ptap)
+  int nF = 1;
   tt_dir_t dir[3];
   // device tables (owned)
   double *wl[3] = {nullptr, nullptr, nullptr};
@@ -29,6 +31,7 @@ struct tg_tensor_plan_s {
 
 struct tg_tensor_planes_s {
   int z0 = 0, z1 = 0;
+  int *status = nullptr;            // device flag of the passes that produced these planes (read by the z stage)
   double *buf = nullptr;            // B2 planes
   std::vector<int64_t> pb;          // offset of plane r2 in buf, indexed r2 - z0
 };
@@ -178,6 +181,7 @@ extern "C" int tg_tensor_planes_destroy(tg_tensor_planes_t p) {
   if (!p) return 0;
   if (g_tg.ready && !g_tg.multi) hipStreamSynchronize(g_tg.stream);
   tg_dfree(p->buf);
+  tg_dfree(p->status);
   delete p;
   return 0;
 }
@@ -197,6 +201,7 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
                                 tg_tensor_planes_t *out) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(pl && a && out, "null argument to tg_tensor_planes");
+  TG_REQUIRE(pl->d == 3, "tg_tensor_planes: the plan belongs to a 2-D patch (tg_tensor2_ptap)");
   TG_REQUIRE_CANONICAL(a);
   const int P = pl->P, W = 2 * P + 1;
   const tt_dir_t &D0 = pl->dir[0], &D1 = pl->dir[1], &D2 = pl->dir[2];
@@ -225,11 +230,14 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
   res->pb = pb2;
   int rc = tg_dmalloc(&b1, pb1[np]);
   if (!rc) rc = tg_dmalloc(&res->buf, pb2[np]);
+  if (!rc) rc = tg_dmalloc(&res->status, 4);
   if (!rc) rc = tt_upload(&d_pb1, pb1);
   if (!rc) rc = tt_upload(&d_pb2, pb2);
   if (!rc) rc = tt_upload(&d_pl[0], pls[0]);
   if (!rc) rc = tt_upload(&d_pl[1], pls[1]);
-  if (!rc && hipMemsetAsync(pl->status, 0, sizeof(int), g_tg.stream) != hipSuccess) rc = 1;
+  // (one flag per set of planes, not per plan: with a certified matrix nobody waits here, and the flag of an earlier
+  //  piece of the ring must still be there when the z stage reads it)
+  if (!rc && hipMemsetAsync(res->status, 0, sizeof(int), g_tg.stream) != hipSuccess) rc = 1;
   int bad = 0;
   bool certified_pass = false;
   if (!rc) {
@@ -242,8 +250,9 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
       Cq.nfe2 = D2.nfe;
       Cq.aplane0 = aplane0;
       Cq.z0 = z0;
+      Cq.dense2 = 0;
       const int64_t nr = (int64_t)np * plane_fe;
-#define TT_C(PP) hipLaunchKernelGGL((k_tt_check_rows<PP>), dim3((unsigned)tg_cdiv(nr, 256)), dim3(256), 0, g_tg.stream, Cq, nr, pl->status)
+#define TT_C(PP) hipLaunchKernelGGL((k_tt_check_rows<PP>), dim3((unsigned)tg_cdiv(nr, 256)), dim3(256), 0, g_tg.stream, Cq, nr, res->status)
       TT_DISPATCH_P(P, TT_C);
 #undef TT_C
     }
@@ -276,7 +285,7 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
           X.b1 = b1;
           X.pb1 = d_pb1;
           X.z0 = z0;
-          X.status = pl->status;
+          X.status = res->status;
           XM.gx[XM.n] = (unsigned)tg_cdiv(X.nlines, X.L);
           XM.first[XM.n + 1] = XM.first[XM.n] + XM.gx[XM.n] * (unsigned)pls[pc].size();
           XM.n++;
@@ -332,7 +341,7 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
     // a matrix whose pattern was verified entry by entry may have failed: the caller is told now (status 100).  A
     // certified matrix cannot, and the host goes on enqueueing (the z stage reads the flag when it waits anyway).
     if (!certified_pass) {
-      if (!rc && hipMemcpyAsync(&bad, pl->status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
+      if (!rc && hipMemcpyAsync(&bad, res->status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
       if (!rc && hipStreamSynchronize(g_tg.stream) != hipSuccess) {
         tg_set_error("tg_tensor_planes: %s", hipGetErrorString(hipGetLastError()));
         rc = 1;
@@ -430,6 +439,7 @@ __global__ void __launch_bounds__(256)
 extern "C" int tg_tensor_split(tg_tensor_plan_t pl, tg_csr_t a, tg_csr_t *on_pattern, tg_csr_t *remainder) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(pl && a && on_pattern && remainder, "null argument to tg_tensor_split");
+  TG_REQUIRE(pl->d == 3, "tg_tensor_split: 3-D plans only");
   TG_REQUIRE_CANONICAL(a);
   const int P = pl->P;
   const tt_dir_t &D0 = pl->dir[0], &D1 = pl->dir[1], &D2 = pl->dir[2];
@@ -503,6 +513,7 @@ extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tenso
                                 tg_csr_t *out) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(pl && pieces && npieces >= 1 && (dest || out), "null argument to tg_tensor_zstage");
+  TG_REQUIRE(pl->d == 3, "tg_tensor_zstage: 3-D plans only");
   const int P = pl->P, W = 2 * P + 1;
   const tt_dir_t &D0 = pl->dir[0], &D1 = pl->dir[1], &D2 = pl->dir[2];
   TG_REQUIRE(ka >= 0 && kb > ka && kb <= D2.ncp, "tg_tensor_zstage: dof planes out of range");
@@ -584,12 +595,17 @@ extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tenso
       rc = 1;
     }
     // the flag of the x / y passes that fed this stage (read here when they ran on a certified matrix without waiting)
-    int passes_bad = 0;
-    if (!rc && hipMemcpyAsync(&passes_bad, pl->status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
+    std::vector<int> piece_bad((size_t)npieces, 0);
+    for (int q = 0; q < npieces && !rc; q++)
+      if (pieces[q]->status &&
+          hipMemcpyAsync(&piece_bad[(size_t)q], pieces[q]->status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess)
+        rc = 1;
     if (!rc && hipStreamSynchronize(g_tg.stream) != hipSuccess) {   // (`end`, the mask and the pointer table are released below)
       tg_set_error("tg_tensor_zstage: %s", hipGetErrorString(hipGetLastError()));
       rc = 1;
     }
+    int passes_bad = 0;
+    for (int q = 0; q < npieces; q++) passes_bad |= piece_bad[(size_t)q];
     if (!rc && passes_bad) {
       tg_set_error("tg_tensor_zstage: the planes of this stage come from a matrix whose rows do not have the lengths of "
                    "the pattern it was certified for");
@@ -610,5 +626,286 @@ extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tenso
     m->nnz = nnz;
     *out = m;
   }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 2-D patches, nF fields on one scalar basis (cfg4: biharmonic p = 4; cfg5: three fields p = 3):
+// K = P_y^T (P_x^T A P_x) P_y with M = I_nF (x) M_y (x) M_x.  A = [A_fg] must hold nF x nF blocks that ALL carry the
+// element-coupling pattern of the Q_p grid (row (a, r1, f): nF * n1 * n0 entries [g][c1][c0]); verified on the device
+// like the 3-D path (status 100 = another pattern: general kernels).  Two passes, both cut into pieces of `ech`
+// elements along the walked direction -- a 2-D patch has only ~nfe lines, far too few waves otherwise.
+#define TT_DISPATCH_P4(P, CALL) \
+  do {                          \
+    if ((P) == 4) {             \
+      CALL(4);                  \
+    } else                      \
+      TT_DISPATCH_P(P, CALL);   \
+  } while (0)
+
+struct tt_x2_multi {
+  tt_x_args c[2];
+  unsigned first[3], gx[2];
+  int n, nF;
+};
+template <int P, bool V>
+__global__ void __launch_bounds__(64) k_tt_x2(tt_x2_multi M) {
+  int c = 0;
+  while (c + 1 < M.n && blockIdx.x >= M.first[c + 1]) c++;
+  const tt_x_args &A = M.c[c];
+  if (*(volatile int *)A.status) return;
+  const unsigned local = blockIdx.x - M.first[c];
+  const unsigned bx = local % M.gx[c], rest = local / M.gx[c];
+  const int bad = tt_x_lane<P, V>(A, (int)bx, (int)(rest % (unsigned)M.nF), threadIdx.x, (int)(rest / (unsigned)M.nF));
+  if (bad) atomicOr(A.status, 1);
+}
+template <int P>
+__global__ void __launch_bounds__(64) k_tt_y2(tt_y2_args A, unsigned gx) {
+  const unsigned bx = blockIdx.x % gx, rest = blockIdx.x / gx;
+  tt_y2_lane<P>(A, (int)bx, (int)(rest % (unsigned)A.nF), (int)(rest / (unsigned)A.nF), threadIdx.x);
+}
+__global__ void __launch_bounds__(256) k_tt_rowptr2(tt_rowptr2_args A, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tt_rowptr2_one(A, i);
+}
+
+extern "C" int tg_tensor2_plan_create(int nfields, const tg_tensor_dir_t *dirs, tg_tensor_plan_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(dirs && out && nfields >= 1, "bad arguments to tg_tensor2_plan_create");
+  const int P = dirs[0].p;
+  TG_REQUIRE(P >= 1 && P <= 4 && dirs[1].p == P, "tg_tensor2_plan_create: equal degrees 1..4 in both directions");
+  TG_REQUIRE((2 * P + 1) * nfields <= 64, "tg_tensor2_plan_create: (2p+1) * nfields lanes must fit a wave");
+  tg_tensor_plan_s *pl = new tg_tensor_plan_s();
+  pl->P = P;
+  pl->d = 2;
+  pl->nF = nfields;
+  int rc = 0;
+  for (int k = 0; k < 2 && !rc; k++) {
+    const int nel = dirs[k].nel, nfe = P * nel + 1, ncp = nel + P;
+    if (nel < 1 || !dirs[k].wl) {
+      tg_set_error("tg_tensor2_plan_create: bad direction %d", k);
+      rc = 2;
+      break;
+    }
+    std::vector<double> w(dirs[k].wl, dirs[k].wl + (size_t)nel * (P + 1) * (P + 1));
+    pl->h_rps[k].assign(nfe + 1, 0);
+    for (int a = 0; a < nfe; a++) pl->h_rps[k][a + 1] = pl->h_rps[k][a] + tt_rn_host(P, a, nfe);
+    pl->h_kps[k].assign(ncp + 1, 0);
+    for (int i = 0; i < ncp; i++)
+      pl->h_kps[k][i + 1] = pl->h_kps[k][i] + (std::min(ncp - 1, i + P) - std::max(0, i - P) + 1);
+    rc = tt_upload(&pl->wl[k], w);
+    if (!rc) rc = tt_upload(&pl->rps[k], pl->h_rps[k]);
+    if (!rc) rc = tt_upload(&pl->kps[k], pl->h_kps[k]);
+    pl->dir[k].nel = nel;
+    pl->dir[k].nfe = nfe;
+    pl->dir[k].ncp = ncp;
+    pl->dir[k].wl = pl->wl[k];
+    pl->dir[k].rps = pl->rps[k];
+    pl->dir[k].kps = pl->kps[k];
+  }
+  if (!rc) {
+    // direction 2 = the field index: row f couples to all nF fields
+    pl->h_rps[2].assign(nfields + 1, 0);
+    for (int f = 0; f <= nfields; f++) pl->h_rps[2][f] = f * nfields;
+    rc = tt_upload(&pl->rps[2], pl->h_rps[2]);
+    pl->dir[2].nel = 0;
+    pl->dir[2].nfe = pl->dir[2].ncp = nfields;
+    pl->dir[2].rps = pl->rps[2];
+  }
+  if (!rc && nfields == 1) {
+    // certificate of a scalar matrix written by tg_kron_sum_csr on this grid (two directions)
+    std::vector<int32_t> ecol[2];
+    const int32_t *rps[2], *cls[2];
+    int64_t nr[2], nc[2];
+    for (int k = 0; k < 2; k++) {
+      const int nfe = pl->dir[k].nfe;
+      for (int a = 0; a < nfe; a++) {
+        const int lo = tt_rlo_host(P, a, nfe), n = tt_rn_host(P, a, nfe);
+        for (int j = 0; j < n; j++) ecol[k].push_back(lo + j);
+      }
+      rps[k] = pl->h_rps[k].data();
+      cls[k] = ecol[k].data();
+      nr[k] = nc[k] = nfe;
+    }
+    pl->expect_tag = tg_pattern_hash(2, nr, nc, rps, cls, 0);
+  }
+  if (!rc) {
+    std::vector<int32_t> ls, lv;
+    const int nfe1 = pl->dir[1].nfe;
+    for (int a = 0; a < nfe1; a++) (tt_rn_host(P, a, nfe1) == P + 1 ? ls : lv).push_back(a);
+    pl->nlines1[0] = (int)ls.size();
+    pl->nlines1[1] = (int)lv.size();
+    rc = tt_upload(&pl->lines1[0], ls);
+    if (!rc) rc = tt_upload(&pl->lines1[1], lv);
+    if (!rc) rc = tg_dmalloc(&pl->status, 4);
+  }
+  if (rc) {
+    tg_tensor_plan_destroy(pl);
+    return rc;
+  }
+  *out = pl;
+  return 0;
+}
+
+extern "C" int tg_tensor2_ptap(tg_tensor_plan_t pl, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag,
+                               tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(pl && a && out, "null argument to tg_tensor2_ptap");
+  TG_REQUIRE(pl->d == 2, "tg_tensor2_ptap: the plan belongs to a 3-D patch");
+  TG_REQUIRE_CANONICAL(a);
+  const int P = pl->P, W = 2 * P + 1, nF = pl->nF;
+  const tt_dir_t &D0 = pl->dir[0], &D1 = pl->dir[1];
+  const int64_t nfe = (int64_t)D0.nfe * D1.nfe, ncp = (int64_t)D0.ncp * D1.ncp;
+  if (a->nrows != nF * nfe || a->ncols != nF * nfe) return 100;        // not a matrix on this mixed space
+  const int64_t t0 = pl->h_rps[0][D0.nfe], t1 = pl->h_rps[1][D1.nfe];
+  if (a->nnz != (int64_t)nF * nF * t0 * t1) return 100;                 // (cheap: the pattern has exactly this many entries)
+  const int64_t w0tot = pl->h_kps[0][D0.ncp], w1tot = pl->h_kps[1][D1.ncp];
+  const int64_t knnz = (int64_t)nF * nF * w0tot * w1tot, krows = nF * ncp;
+  TG_REQUIRE(nF * nfe < 0x7fffffffll && krows < 0x7fffffffll, "tg_tensor2_ptap: index range");
+  // elements per piece of the walks: enough pieces to give the chip a few thousand waves, not so short that the P
+  // re-read elements of a piece dominate
+  auto pick_ech = [&](int nel, int64_t waves_per_piece, const char *env, int floor_ech) {
+    if (getenv(env)) {                       // (experiments)
+      const int e = atoi(getenv(env));
+      return e >= nel ? 0 : std::max(1, e);
+    }
+    int ech = nel;
+    while (ech > floor_ech && (int64_t)tg_cdiv(nel, ech) * waves_per_piece < 2048) ech = (ech + 1) / 2;
+    return ech >= nel ? 0 : ech;
+  };
+  const int64_t plane_b1 = (int64_t)W * nF * D0.ncp * t1;
+  double *b1 = nullptr;
+  tg_csr_s *m = nullptr;
+  uint8_t *mask = nullptr;
+  int64_t *d_pb1 = nullptr;
+  int32_t *d_planes = nullptr;
+  int rc = tg_dmalloc(&b1, plane_b1 * nF);
+  if (!rc) rc = tg_csr_alloc(krows, krows, knnz, &m);
+  if (!rc && zero_dofs && nzero > 0) rc = tg_build_dof_mask(zero_dofs, nzero, krows, &mask);
+  {
+    std::vector<int64_t> pb1(nF + 1, 0);
+    std::vector<int32_t> planes(nF, 0);
+    for (int f = 0; f < nF; f++) {
+      pb1[f + 1] = pb1[f] + plane_b1;
+      planes[f] = f;
+    }
+    if (!rc) rc = tt_upload(&d_pb1, pb1);
+    if (!rc) rc = tt_upload(&d_planes, planes);
+  }
+  if (!rc && hipMemsetAsync(pl->status, 0, sizeof(int), g_tg.stream) != hipSuccess) rc = 1;
+  int bad = 0;
+  if (!rc) {
+    tt_check_args Cq;
+    Cq.rowptr = a->rowptr;
+    Cq.nfe0 = D0.nfe;
+    Cq.nfe1 = D1.nfe;
+    Cq.nfe2 = nF;
+    Cq.aplane0 = 0;
+    Cq.z0 = 0;
+    Cq.dense2 = 1;
+    const int64_t nr = nF * nfe;
+#define TT_C(PP) hipLaunchKernelGGL((k_tt_check_rows<PP>), dim3((unsigned)tg_cdiv(nr, 256)), dim3(256), 0, g_tg.stream, Cq, nr, pl->status)
+    TT_DISPATCH_P4(P, TT_C);
+#undef TT_C
+    // x pass: both line classes in one launch
+    tt_x2_multi XM;
+    memset(&XM, 0, sizeof(XM));
+    XM.nF = nF;
+    int64_t waves = 0;
+    for (int lc = 1; lc >= 0; lc--)
+      if (pl->nlines1[lc]) waves += tg_cdiv(pl->nlines1[lc], std::max(1, 64 / ((lc == 0 ? P + 1 : W) * nF))) * nF;
+    const int ech0 = pick_ech(D0.nel, waves, "TIGAR_TT2_ECH_X", 4 * P);
+    const unsigned np0 = ech0 ? (unsigned)tg_cdiv(D0.nel, ech0) : 1u;
+    for (int lc = 1; lc >= 0; lc--) {
+      if (!pl->nlines1[lc]) continue;
+      const int n1 = lc == 0 ? P + 1 : W;
+      tt_x_args &X = XM.c[XM.n];
+      X.rowptr = a->rowptr;
+      X.col = a->col;
+      X.val = a->val;
+      X.rps2 = pl->rps[2];
+      X.aplane0 = 0;
+      X.d0 = D0;
+      X.nfe1 = D1.nfe;
+      X.nfe2 = nF;
+      X.rps1 = D1.rps;
+      X.lines = pl->lines1[lc];
+      X.nlines = pl->nlines1[lc];
+      X.n1 = n1;
+      X.n2 = nF;
+      X.L = std::max(1, 64 / (n1 * nF));
+      X.planes = d_planes;
+      X.b1 = b1;
+      X.pb1 = d_pb1;
+      X.z0 = 0;
+      X.status = pl->status;
+      X.dense2 = 1;
+      X.ech = ech0;
+      XM.gx[XM.n] = (unsigned)tg_cdiv(X.nlines, X.L);
+      XM.first[XM.n + 1] = XM.first[XM.n] + XM.gx[XM.n] * (unsigned)nF * np0;
+      XM.n++;
+    }
+    const bool certified = a->pattern_tag != 0 && a->pattern_tag == pl->expect_tag && a->pattern_row0 == 0 &&
+                           !(getenv("TIGAR_PTAP_VERIFY") && atoi(getenv("TIGAR_PTAP_VERIFY")));
+    if (XM.n > 0 && XM.first[XM.n] > 0) {
+#define TT_X(PP) hipLaunchKernelGGL((k_tt_x2<PP, true>), dim3(XM.first[XM.n]), dim3(64), 0, g_tg.stream, XM)
+#define TT_XC(PP) hipLaunchKernelGGL((k_tt_x2<PP, false>), dim3(XM.first[XM.n]), dim3(64), 0, g_tg.stream, XM)
+      if (certified) TT_DISPATCH_P4(P, TT_XC);
+      else TT_DISPATCH_P4(P, TT_X);
+#undef TT_X
+#undef TT_XC
+      g_tg.prof_n[TG_PROF_PTAP_CERTIFIED] += certified ? 1 : 0;
+    }
+    // final pass along direction 1: rows of K
+    tt_rowptr2_args R;
+    R.kps0 = D0.kps;
+    R.kps1 = D1.kps;
+    R.ncp0 = D0.ncp;
+    R.ncp1 = D1.ncp;
+    R.nF = nF;
+    R.rowptr_out = m->rowptr;
+    hipLaunchKernelGGL(k_tt_rowptr2, dim3((unsigned)tg_cdiv(krows, 256)), dim3(256), 0, g_tg.stream, R, krows);
+    if (hipMemcpyAsync(m->rowptr + krows, &knnz, sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess) rc = 1;
+    tt_y2_args Y;
+    Y.b1 = b1;
+    Y.plane_b1 = plane_b1;
+    Y.d1 = D1;
+    Y.ncp0 = D0.ncp;
+    Y.nF = nF;
+    Y.kps0 = D0.kps;
+    Y.L = std::max(1, 64 / (W * nF));
+    const unsigned gx = (unsigned)tg_cdiv(D0.ncp, Y.L);
+    Y.ech = pick_ech(D1.nel, (int64_t)gx * nF, "TIGAR_TT2_ECH_Y", 2 * P);
+    const unsigned np1 = Y.ech ? (unsigned)tg_cdiv(D1.nel, Y.ech) : 1u;
+    if (!m->diag_cache && tg_dmalloc(&m->diag_cache, krows)) m->diag_cache = nullptr;
+    Y.kdiag = m->diag_cache;
+    Y.kcol = m->col;
+    Y.kval = m->val;
+    Y.mask = mask;
+    Y.diag = diag;
+#define TT_Y2(PP) hipLaunchKernelGGL((k_tt_y2<PP>), dim3(gx * (unsigned)nF * np1), dim3(64), 0, g_tg.stream, Y, gx)
+    TT_DISPATCH_P4(P, TT_Y2);
+#undef TT_Y2
+    if (hipGetLastError() != hipSuccess) {
+      tg_set_error("tg_tensor2_ptap: kernel launch failed");
+      rc = 1;
+    }
+    if (!rc && hipMemcpyAsync(&bad, pl->status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
+    if (!rc && hipStreamSynchronize(g_tg.stream) != hipSuccess) {
+      tg_set_error("tg_tensor2_ptap: %s", hipGetErrorString(hipGetLastError()));
+      rc = 1;
+    }
+  }
+  tg_dfree(b1);
+  tg_dfree(mask);
+  tg_dfree(d_pb1);
+  tg_dfree(d_planes);
+  if (rc || bad) {
+    if (m) tg_csr_destroy(m);
+    return rc ? rc : 100;
+  }
+  m->nnz = knnz;
+  m->diag_rows = m->diag_cache ? krows : 0;
+  *out = m;
   return 0;
 }

@@ -213,6 +213,12 @@ struct tt_x_args {
   const int64_t *pb1;    // offset of plane r2 in b1, indexed r2 - z0
   int z0;
   int *status;           // bit 0: pattern mismatch
+  // 2-D patches with nF fields (tt_y2_*): direction 2 is the FIELD index -- "dense": every row couples to all nfe2 = nF
+  // of them (row block [g][c1][c0]) and nothing is contracted there
+  int dense2;
+  // the walk in pieces of `ech` elements (0: the whole direction at once), piece index = third argument of tt_x_lane:
+  // short directions (2-D patches) have too few lines to fill the chip otherwise; a piece re-reads P elements
+  int ech;
 };
 
 template <int P, bool V = true>       // V: read and verify the column indices (false: the matrix carries a pattern certificate)
@@ -226,6 +232,7 @@ struct tt_io_x {
   int32_t colbase;
   bool valid;
   int bad;
+  int elo, ehi;               // output rows emitted by this piece of the walk
   double *out;
   int64_t ostride_i, ostride_m;
   // Row starts follow in closed form from the row LENGTHS (checked for every row by k_tt_check_rows before this
@@ -246,15 +253,26 @@ struct tt_io_x {
     bad |= diff;
   }
   TT_MEM void emit(int i, const double *row) {
-    if (!valid) return;
+    if (!valid || i < elo || i >= ehi) return;
     double *d = out + ostride_i * i;
 #pragma unroll
     for (int m = 0; m < 2 * P + 1; m++) d[m * ostride_m] = row[m];
   }
 };
 
+// the elements a piece of a chunked walk visits and the rows it emits (ech = 0: everything)
+TT_DEV void tt_piece(int ech, int piece, int P, int nel, int &e0, int &e1, int &lo, int &hi) {
+  e0 = 0, e1 = nel, lo = 0, hi = 0x7fffffff;
+  if (ech > 0) {
+    lo = piece * ech;
+    e0 = lo - P > 0 ? lo - P : 0;
+    e1 = lo + ech < nel ? lo + ech : nel;
+    if (e1 < nel) hi = lo + ech;
+  }
+}
+
 template <int P, bool V = true>
-TT_DEV int tt_x_lane(const tt_x_args &A, int bx, int by, int lane) {
+TT_DEV int tt_x_lane(const tt_x_args &A, int bx, int by, int lane, int piece = 0) {
   constexpr int W = 2 * P + 1;
   const int plane = A.planes[by];
   const int lpl = A.n1 * A.n2;
@@ -275,15 +293,18 @@ TT_DEV int tt_x_lane(const tt_x_args &A, int bx, int by, int lane) {
   io.lpl = lpl;
   io.off_s = (int64_t)l * (P + 1);
   io.off_v = (int64_t)l * W;
-  io.colbase = (int32_t)((int64_t)A.d0.nfe * ((tt_rlo<P>(r1, A.nfe1) + c1) + (int64_t)A.nfe1 * (tt_rlo<P>(plane, A.nfe2) + c2)));
+  const int rlo2 = A.dense2 ? 0 : tt_rlo<P>(plane, A.nfe2), rn2 = A.dense2 ? A.nfe2 : tt_rn<P>(plane, A.nfe2);
+  io.colbase = (int32_t)((int64_t)A.d0.nfe * ((tt_rlo<P>(r1, A.nfe1) + c1) + (int64_t)A.nfe1 * (rlo2 + c2)));
   io.bad = 0;
   // consistency of the class tables with the grid (cheap, uniform)
-  if (io.valid && (tt_rn<P>(r1, A.nfe1) != A.n1 || tt_rn<P>(plane, A.nfe2) != A.n2)) io.bad = 1;
+  if (io.valid && (tt_rn<P>(r1, A.nfe1) != A.n1 || rn2 != A.n2)) io.bad = 1;
   const int64_t wn2 = (int64_t)W * A.n2;
   io.out = A.b1 + A.pb1[plane - A.z0] + wn2 * A.d0.ncp * A.rps1[r1] + (int64_t)c2 * W * A.n1 + c1;
   io.ostride_i = wn2 * A.n1;
   io.ostride_m = A.n1;
-  tt_walk<P>(A.d0, 0, A.d0.nel, io);
+  int e0, e1;
+  tt_piece(A.ech, piece, P, A.d0.nel, e0, e1, io.elo, io.ehi);
+  tt_walk<P>(A.d0, e0, e1, io);
   return io.bad;
 }
 
@@ -292,6 +313,7 @@ TT_DEV int tt_x_lane(const tt_x_args &A, int bx, int by, int lane) {
 struct tt_check_args {
   const int64_t *rowptr;
   int nfe0, nfe1, nfe2, aplane0, z0;
+  int dense2;                // direction 2 = fields (see tt_x_args)
 };
 template <int P>
 TT_DEV int tt_check_row(const tt_check_args &A, int64_t idx) {
@@ -300,7 +322,7 @@ TT_DEV int tt_check_row(const tt_check_args &A, int64_t idx) {
   const int64_t rem = idx % pf;
   const int r1 = (int)(rem / A.nfe0), a = (int)(rem % A.nfe0);
   const int64_t r = idx + (int64_t)(A.z0 - A.aplane0) * pf;
-  const int64_t want = (int64_t)tt_rn<P>(a, A.nfe0) * tt_rn<P>(r1, A.nfe1) * tt_rn<P>(r2, A.nfe2);
+  const int64_t want = (int64_t)tt_rn<P>(a, A.nfe0) * tt_rn<P>(r1, A.nfe1) * (A.dense2 ? A.nfe2 : tt_rn<P>(r2, A.nfe2));
   return (A.rowptr[r + 1] - A.rowptr[r]) != want;
 }
 
@@ -469,6 +491,128 @@ TT_DEV void tt_z_lane(const tt_z_args &A, int bx, int lane) {
   const int e_begin = A.ka - P > 0 ? A.ka - P : 0;
   const int e_end = A.kb < nel ? A.kb : nel;
   tt_walk<P>(A.d2, e_begin, e_end, io);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 2-D patches (nF fields on one basis): K = P_y^T (P_x^T A P_x) P_y, the x pass above (direction 2 = field index,
+// dense) followed by this FINAL pass along direction 1: B1 rows (i0, r1, f) with block [g][m0][c1] -> rows of K in CSR
+// order.  Row (i0, i1, f) of K holds nF * w1n(i1) * w0n(i0) entries [g][m1][m0] (columns ascending).
+struct tt_y2_args {
+  const double *b1;
+  int64_t plane_b1;              // doubles of B1 per field f
+  tt_dir_t d1;
+  int ncp0, nF;
+  const int32_t *kps0;
+  int L, ech;
+  int32_t *kcol;
+  double *kval;
+  double *kdiag;                 // diagonal of K (index: row), or null
+  const uint8_t *mask;           // zeroDofs as a byte mask over all dofs, or null
+  double diag;
+};
+
+template <int P>
+struct tt_io_y2 {
+  const double *in;
+  tt_cip rps;
+  int64_t ustride, clane;
+  bool valid, inwin;
+  int elo, ehi;
+  tt_cip kps1;
+  int f, g, i0, m0, ncp0, ncp1, nF, w0n, w0lo;
+  int64_t w0tot, w1tot, kp0;     // kp0 = kps0[i0]
+  int32_t *kcol;
+  double *kval;
+  double *kdiag;
+  const uint8_t *mask;
+  double diag;
+  template <int N>
+  TT_MEM void load(int a, int clo, double *v) {
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = 0.0;
+    if (!valid) return;
+    const int64_t o = ustride * rps[a] + clane * N;
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = in[o + j];
+  }
+  TT_MEM void emit(int i1, const double *row) {
+    if (!valid || !inwin || i1 < elo || i1 >= ehi) return;
+    const int w1n = kps1[i1 + 1] - kps1[i1];
+    const int w1lo = i1 < P ? P - i1 : 0;
+    const int64_t pd = (int64_t)ncp0 * ncp1;
+    const int64_t R = i0 + (int64_t)ncp0 * i1 + pd * f;
+    const int64_t rowstart = (int64_t)nF * ((int64_t)f * w0tot * w1tot + w0tot * kps1[i1] + (int64_t)w1n * kp0);
+    const int64_t base = rowstart + (int64_t)g * w1n * w0n + (m0 - w0lo);
+    const int64_t c0g = (i0 - P + m0) + pd * g;
+    const bool mrow = mask && mask[R];
+#pragma unroll
+    for (int m1 = 0; m1 < 2 * P + 1; m1++) {
+      if (m1 >= w1lo && m1 < w1lo + w1n) {
+        const int64_t pos = base + (int64_t)(m1 - w1lo) * w0n;
+        const int64_t c = c0g + (int64_t)ncp0 * (i1 - P + m1);
+        double v = row[m1];
+        if (mask && (mrow || mask[c])) v = (mrow && c == R) ? diag : 0.0;
+        kcol[pos] = (int32_t)c;
+        kval[pos] = v;
+        if (kdiag && c == R) kdiag[R] = v;
+      }
+    }
+  }
+};
+
+// grid: bx = group of lines (i0) x by = field f x piece of the walk
+template <int P>
+TT_DEV void tt_y2_lane(const tt_y2_args &A, int bx, int by, int piece, int lane) {
+  constexpr int W = 2 * P + 1;
+  const int lpl = W * A.nF;
+  const int sub = lane / lpl, l = lane - sub * lpl;
+  const int i0 = bx * A.L + sub;
+  tt_io_y2<P> io;
+  io.valid = sub < A.L && i0 < A.ncp0;
+  const int m0 = l % W, g = l / W;
+  const int64_t wn2 = (int64_t)W * A.nF;
+  io.in = A.b1 + A.plane_b1 * by;
+  io.rps = TT_CI(A.d1.rps);
+  io.ustride = wn2 * A.ncp0;
+  io.clane = wn2 * (io.valid ? i0 : 0) + l;
+  io.kps1 = TT_CI(A.d1.kps);
+  io.f = by;
+  io.g = g;
+  io.i0 = io.valid ? i0 : 0;
+  io.m0 = m0;
+  io.ncp0 = A.ncp0;
+  io.ncp1 = A.d1.ncp;
+  io.nF = A.nF;
+  io.kp0 = A.kps0[io.i0];
+  io.w0n = A.kps0[io.i0 + 1] - A.kps0[io.i0];
+  io.w0lo = io.i0 < P ? P - io.i0 : 0;
+  io.inwin = m0 >= io.w0lo && m0 < io.w0lo + io.w0n;
+  io.w0tot = A.kps0[A.ncp0];
+  io.w1tot = A.d1.kps[A.d1.ncp];
+  io.kcol = A.kcol;
+  io.kval = A.kval;
+  io.kdiag = A.kdiag;
+  io.mask = A.mask;
+  io.diag = A.diag;
+  int e0, e1;
+  tt_piece(A.ech, piece, P, A.d1.nel, e0, e1, io.elo, io.ehi);
+  tt_walk<P>(A.d1, e0, e1, io);
+}
+
+// row pointer of K of a 2-D patch with nF fields: row R = i0 + ncp0*(i1 + ncp1*f)
+struct tt_rowptr2_args {
+  const int32_t *kps0, *kps1;
+  int ncp0, ncp1, nF;
+  int64_t *rowptr_out;
+};
+TT_DEV void tt_rowptr2_one(const tt_rowptr2_args &A, int64_t idx) {
+  const int64_t pd = (int64_t)A.ncp0 * A.ncp1;
+  const int f = (int)(idx / pd);
+  const int64_t rem = idx % pd;
+  const int i1 = (int)(rem / A.ncp0), i0 = (int)(rem % A.ncp0);
+  const int64_t w0tot = A.kps0[A.ncp0], w1tot = A.kps1[A.ncp1];
+  const int w1n = A.kps1[i1 + 1] - A.kps1[i1];
+  A.rowptr_out[idx] = (int64_t)A.nF * ((int64_t)f * w0tot * w1tot + w0tot * A.kps1[i1] + (int64_t)w1n * A.kps0[i0]);
 }
 
 // row pointer of K for the rows of dof planes [ka, kb): rowptr_out[R - ka*ncp0*ncp1] = base + closed form

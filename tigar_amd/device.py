@@ -12,6 +12,7 @@ from ._lib import TigarHipError, check, handle, tg_dir_t, tg_kron_dir_t, tg_kron
 TG_KSP_CG, TG_KSP_GMRES = 0, 1
 TG_PC_NONE, TG_PC_JACOBI = 0, 1
 TG_KSP_NONZERO_GUESS = 1
+TG_KSP_STAGNATION_GUARD = 2
 
 
 def _f64(a):
@@ -544,11 +545,11 @@ def ptap_kron(cur, cur_row0, dims_in, factors, out_row0, out_row1, zero_dofs=Non
 
 # ------------------------------------------------------------------------------- Krylov
 def krylov_solve(K, b, x, method="cg", pc="jacobi", rtol=1e-6, atol=1e-15, maxit=10000, restart=30, comm=None,
-                 nonzero_initial_guess=False):
+                 nonzero_initial_guess=False, stagnation_guard=False):
     meth = {"cg": TG_KSP_CG, "gmres": TG_KSP_GMRES}[method]
     pcc = {"none": TG_PC_NONE, "jacobi": TG_PC_JACOBI}[pc]
     iters, status, res = C.c_int(), C.c_int(), C.c_double()
-    flags = TG_KSP_NONZERO_GUESS if nonzero_initial_guess else 0
+    flags = (TG_KSP_NONZERO_GUESS if nonzero_initial_guess else 0) | (TG_KSP_STAGNATION_GUARD if stagnation_guard else 0)
     check(_lib.lib().tg_krylov_solve_flags(K._h, b._h, x._h, meth, pcc, float(rtol), float(atol), int(maxit),
                                            int(restart), flags, comm._h if comm is not None else None,
                                            C.byref(iters), C.byref(res), C.byref(status)), "tg_krylov_solve")

@@ -18,6 +18,46 @@ from . import device as _dev
 from ._lib import check, handle, c_f64p, c_i32p, tg_tensor_dir_t
 
 
+# Structure checks and plans are functions of the 1-D extraction matrices alone; generators are rebuilt often (every
+# pass of a Newton loop or a benchmark step builds a new one on the same knot vectors), so both are kept keyed on the
+# CONTENT of those matrices (digest of values and indices) -- never on object identity.
+_WL_CACHE = {}
+_PLAN_CACHE = {}
+_CACHE_MAX = 16
+
+
+def _digest(M1):
+    import hashlib
+    M1 = M1.tocsr()
+    h = hashlib.blake2b(digest_size=16)
+    h.update(np.ascontiguousarray(M1.indptr).tobytes())
+    h.update(np.ascontiguousarray(M1.indices).tobytes())
+    h.update(np.ascontiguousarray(M1.data).tobytes())
+    return h.digest()
+
+
+def checked_weights(M1, p, nel):
+    """``local_weights`` when the direction also passes ``band_pattern_ok``, else None; cached on the content of M1"""
+    key = (int(p), int(nel), M1.shape, _digest(M1))
+    if key not in _WL_CACHE:
+        if len(_WL_CACHE) >= 4 * _CACHE_MAX:
+            _WL_CACHE.clear()
+        wl = local_weights(M1, p, nel)
+        _WL_CACHE[key] = wl if wl is not None and band_pattern_ok(M1, p, nel) else None
+    return _WL_CACHE[key], key
+
+
+def _cached_plan(kind, p, nels, nfields, keys, build):
+    key = (kind, int(p), tuple(int(n) for n in nels), int(nfields), tuple(keys))
+    plan = _PLAN_CACHE.pop(key, None)
+    if plan is None:
+        plan = build()
+        while len(_PLAN_CACHE) >= _CACHE_MAX:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+    _PLAN_CACHE[key] = plan                     # (most recently used last)
+    return plan
+
+
 def local_weights(M1, p, nel):
     """wl[e, j, q] = M1[p*e + j, e + q] (value at node j of element e of spline function e+q), or None when a
     stored entry of M1 lies outside that window, i.e. the direction does not have the structure of an open
@@ -106,24 +146,28 @@ class TensorPtAP(object):
         p = ps[0]
         if any(q != p for q in ps) or p < 1 or p > 3 or getattr(grid, "dg", False) or grid.degree != p:
             return None
-        nels, wls = [], []
+        nels, wls, keys = [], [], []
         for k in range(3):
             nel = len(grid.vertices[k]) - 1
-            wl = local_weights(kx.M1[k], p, nel)
-            if wl is None or not band_pattern_ok(kx.M1[k], p, nel):
+            wl, key = checked_weights(kx.M1[k], p, nel)
+            if wl is None:
                 return None
             nels.append(nel)
             wls.append(wl)
+            keys.append(key)
+        kx._tensor_keys = keys
         return p, nels, wls
 
     @staticmethod
     def for_extraction(kx):
-        """plan cached on the ``KronExtraction`` (None if the patch does not qualify or TIGAR_PTAP_TENSOR=0)"""
+        """plan cached on the ``KronExtraction`` (None if the patch does not qualify or TIGAR_PTAP_TENSOR=0); patches
+        with the same 1-D extraction matrices share one plan"""
         if os.environ.get("TIGAR_PTAP_TENSOR", "1") == "0":
             return None
         if not hasattr(kx, "_tensor_plan"):
             st = TensorPtAP.structure(kx)
-            kx._tensor_plan = TensorPtAP(*st) if st is not None else None
+            kx._tensor_plan = _cached_plan("3d", st[0], st[1], 1, kx._tensor_keys, lambda: TensorPtAP(*st)) \
+                if st is not None else None
         return kx._tensor_plan
 
     def k_nnz(self, ka, kb):
@@ -167,3 +211,75 @@ class TensorPtAP(object):
                                           append_to._h if append_to is not None else None, C.byref(out)),
               "tg_tensor_zstage")
         return True if append_to is not None else _dev.DeviceCSR(out)
+
+
+class TensorPtAP2D(object):
+    """Plan of the tensor-pattern PtAP for a patch with TWO parametric directions and ``nfields`` fields on one scalar
+    basis (csrc/tg_ptap_tensor.hip: tg_tensor2_*): the whole product in two line-walk passes, degrees 1..4."""
+
+    def __init__(self, p, nels, wls, nfields=1):
+        self.p, self.nels, self.nfields = int(p), [int(n) for n in nels], int(nfields)
+        self._keep = [np.ascontiguousarray(w, dtype=np.float64) for w in wls]
+        arr = (tg_tensor_dir_t * 2)()
+        for k in range(2):
+            arr[k].p = self.p
+            arr[k].nel = self.nels[k]
+            arr[k].wl = self._keep[k].ctypes.data_as(c_f64p)
+        self._h = handle()
+        check(_lib.lib().tg_tensor2_plan_create(self.nfields, arr, C.byref(self._h)), "tg_tensor2_plan_create")
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().tg_tensor_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def structure(kx):
+        """(p, nels, wls) if the 2-D patch of the ``KronExtraction`` has the structure of the fast path, else None"""
+        if kx.d != 2:
+            return None
+        grid = kx.grid
+        ps = [s.p for s in kx.basis.splines]
+        p = ps[0]
+        if any(q != p for q in ps) or p < 1 or p > 4 or getattr(grid, "dg", False) or grid.degree != p:
+            return None
+        nels, wls, keys = [], [], []
+        for k in range(2):
+            nel = len(grid.vertices[k]) - 1
+            wl, key = checked_weights(kx.M1[k], p, nel)
+            if wl is None:
+                return None
+            nels.append(nel)
+            wls.append(wl)
+            keys.append(key)
+        kx._tensor_keys = keys
+        return p, nels, wls
+
+    @staticmethod
+    def for_extraction(kx, nfields=1):
+        """plan cached on the ``KronExtraction`` per number of fields (None if the patch does not qualify or
+        TIGAR_PTAP_TENSOR=0)"""
+        if os.environ.get("TIGAR_PTAP_TENSOR", "1") == "0":
+            return None
+        cache = kx.__dict__.setdefault("_tensor2_plans", {})
+        if nfields not in cache:
+            st = TensorPtAP2D.structure(kx)
+            ok = st is not None and (2 * st[0] + 1) * nfields <= 64
+            cache[nfields] = _cached_plan("2d", st[0], st[1], nfields, kx._tensor_keys,
+                                          lambda: TensorPtAP2D(*st, nfields=nfields)) if ok else None
+        return cache[nfields]
+
+    def ptap(self, A, zero_dofs=None, diag=1.0):
+        """K = M^T A M with MatZeroRowsColumns fused, or None when A does not carry the element-coupling pattern in all
+        of its nfields^2 blocks (verified on the device)."""
+        zd = np.ascontiguousarray(zero_dofs, dtype=np.int32) if zero_dofs is not None and len(zero_dofs) else None
+        out = handle()
+        rc = _lib.lib().tg_tensor2_ptap(self._h, A._h, zd.ctypes.data_as(c_i32p) if zd is not None else None,
+                                        zd.size if zd is not None else 0, float(diag), C.byref(out))
+        if rc == 100:
+            return None
+        check(rc, "tg_tensor2_ptap")
+        return _dev.DeviceCSR(out)
