@@ -662,9 +662,20 @@ __global__ void __launch_bounds__(256) k_gm_orth(const tg_gm_state *st, const do
 
 // column j of the Hessenberg matrix: rotations of the earlier columns, the new rotation, the residual estimate, the
 // decision (hcol[0..j] = Gram-Schmidt coefficients, hcol[j+1] = ||w||^2)
-__global__ void k_gm_givens(tg_gm_state *st, int j, int m, const double *hcol, double *H, double *cs, double *sn,
-                            double *g, int maxit, double *hist) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One workgroup: folds the partials of ||w||^2 first (hcol[j+1]; `reduced`: several ranks -- fold and all-reduce were
+// done in front), then thread 0 runs the recurrence; the history entry goes straight to pinned host memory.
+__global__ void __launch_bounds__(256)
+    k_gm_givens(tg_gm_state *st, int j, int m, double *hcol, const double *partial, int nb, int reduced, double *H,
+                double *cs, double *sn, double *g, int maxit, double *hist) {
+  __shared__ double lds4[4];
+  if (!reduced && st->live != 0.0) {
+    double ssum = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 256) ssum += partial[b];
+    ssum = tg_block_sum256(ssum, lds4);
+    if (threadIdx.x == 0) hcol[j + 1] = ssum;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   if (st->live != 0.0) {
     double *Hj = H + (int64_t)j * (m + 1);
     for (int i = 0; i <= j; i++) Hj[i] = hcol[i];
@@ -772,6 +783,8 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
   tg_cg_ring ring;
   TG_TRY(ring.init());
   double *hist = g_tg.host_pinned + 8;                     // TG_CG_RING x 4 doubles (pinned)
+  double *hist_dev = nullptr;                              // the same ring as the kernels address it
+  TG_CHECK_HIP(hipHostGetDevicePointer((void **)&hist_dev, hist, 0));
   const double *xshift = ext - (row0 - hlo);
   const int64_t cmin = row0 - hlo, cmax = row0 - hlo + next - 1;
   if (n > 0 && k->diag_cache && k->diag_rows == n) {
@@ -785,13 +798,20 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
   // w = K * (the vector in xin, halo exchanged); products past the end of the solve return at once (sliced copy)
   // (slot >= 0: timed with the event pair of that ring slot -- the product of an inner iteration, accounted when the
   //  host reads that iteration's history entry)
-  auto product = [&](bool gated, int slot) -> int {
+  // w = K src.  One rank: the product reads src where it lies; several: src goes into the extended vector first and
+  // its halo is exchanged.
+  auto product = [&](const double *src, bool gated, int slot) -> int {
+    const double *xs = src;
+    if (comm) {
+      TG_CHECK_HIP(hipMemcpyAsync(xin, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream));
+      xs = xshift;
+    }
     if (slot >= 0) hipEventRecord(ring.t0[slot], g_tg.stream);
     TG_TRY(tg_comm_halo_exchange(comm, ext));
     if (sliced && gated)
-      TG_TRY(tg_sell_spmv_rows(k, xshift, cmin, cmax, w, 0, n, &st->live, 0.5));
+      TG_TRY(tg_sell_spmv_rows(k, xs, cmin, cmax, w, 0, n, &st->live, 0.5));
     else
-      TG_TRY(tg_spmv_raw(k, xshift, cmin, cmax, w));
+      TG_TRY(tg_spmv_raw(k, xs, cmin, cmax, w));
     if (slot >= 0) hipEventRecord(ring.t1[slot], g_tg.stream);
     return 0;
   };
@@ -849,8 +869,7 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
       hipLaunchKernelGGL(k_gm_residual, dim3(vg), dim3(256), 0, g_tg.stream, (const tg_gm_state *)nullptr, b->d,
                          (const double *)nullptr, dinv, V, n, partial);
     } else {
-      TG_CHECK_HIP(hipMemcpyAsync(xin, x->d, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream));
-      TG_TRY(product(!first, -1));
+      TG_TRY(product(x->d, !first, -1));
       hipLaunchKernelGGL(k_gm_residual, dim3(vg), dim3(256), 0, g_tg.stream, first ? (const tg_gm_state *)nullptr : st, b->d,
                          (const double *)w, dinv, V, n, partial);
     }
@@ -878,25 +897,26 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
     }
     for (int j = 0; j < m && !stop; j++) {
       // w = B K v_j ; Gram-Schmidt against v_0..v_j ; v_{j+1} ; column j of H
-      TG_CHECK_HIP(hipMemcpyAsync(xin, V + (int64_t)j * n, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice,
-                                  g_tg.stream));
-      TG_TRY(product(true, (enq + 1) % TG_CG_RING));
+      TG_TRY(product(V + (int64_t)j * n, true, (enq + 1) % TG_CG_RING));
       hipLaunchKernelGGL(k_gm_dots, dim3(vg), dim3(256), 0, g_tg.stream, st, V, n, j + 1, w, dinv, n, partial);
       hipLaunchKernelGGL(k_gm_fold, dim3(1), dim3(256), 0, g_tg.stream, st, partial, vg, j + 1, hdev);
       TG_LAUNCH_CHECK();
       TG_TRY(tg_comm_allreduce_dev(comm, hdev, j + 1));
       hipLaunchKernelGGL(k_gm_orth, dim3(vg), dim3(256), 0, g_tg.stream, st, V, n, j + 1, hdev, w, n, partial);
-      hipLaunchKernelGGL(k_gm_fold, dim3(1), dim3(256), 0, g_tg.stream, st, partial, vg, 1, hdev + j + 1);
-      TG_LAUNCH_CHECK();
-      TG_TRY(tg_comm_allreduce_dev(comm, hdev + j + 1, 1));
-      hipLaunchKernelGGL(k_gm_scale, dim3(vg), dim3(256), 0, g_tg.stream, st, V + (int64_t)(j + 1) * n, w,
-                         (const double *)(hdev + j + 1), n);
+      if (comm) {
+        hipLaunchKernelGGL(k_gm_fold, dim3(1), dim3(256), 0, g_tg.stream, st, partial, vg, 1, hdev + j + 1);
+        TG_LAUNCH_CHECK();
+        TG_TRY(tg_comm_allreduce_dev(comm, hdev + j + 1, 1));
+      }
       enq++;
       const int slot = enq % TG_CG_RING;
-      // (the pinned slot is written by the kernel's successor copy: device history entry first)
-      hipLaunchKernelGGL(k_gm_givens, dim3(1), dim3(1), 0, g_tg.stream, st, j, m, hdev, H, cs, sn, g, maxit, scal);
+      // the recurrence BEFORE v_{j+1} is scaled: both read ||w||^2 from hcol[j+1], and the scaling is skipped once the
+      // recurrence has ended the solve (the basis vector is not needed then)
+      hipLaunchKernelGGL(k_gm_givens, dim3(1), dim3(256), 0, g_tg.stream, st, j, m, hdev, partial, vg, comm ? 1 : 0, H, cs,
+                         sn, g, maxit, hist_dev + 4 * slot);
+      hipLaunchKernelGGL(k_gm_scale, dim3(vg), dim3(256), 0, g_tg.stream, st, V + (int64_t)(j + 1) * n, w,
+                         (const double *)(hdev + j + 1), n);
       TG_LAUNCH_CHECK();
-      TG_CHECK_HIP(hipMemcpyAsync(hist + 4 * slot, scal, 4 * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
       TG_CHECK_HIP(hipEventRecord(ring.done[slot], g_tg.stream));
       if (enq - look >= 1) stop = observe(enq - look);
     }
