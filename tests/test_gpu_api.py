@@ -169,6 +169,49 @@ def test_bspline_host_api_matches_golden(T):
         B.uniformKnots(2, 0., 1., 4, False, 2)
 
 
+def test_periodic_patch_through_the_generator_takes_the_pencil_walk(T):
+    """generateM of a periodic patch through the public API: the Kronecker pencil walk (closed-form row starts, no count
+    pass) now also serves periodic directions -- rows are Kronecker products of the 1-D rows sorted by function index --
+    and gives the reference's matrix bit for bit, as the general count / scan / fill kernels do (TIGAR_EXTRACT_KRON=0);
+    M^T b and the transposed matrix likewise."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_tensor.npz"))
+    B, t = T.B, T.t
+    pre = "2d_periodic/"
+    degs = [int(x) for x in g[pre + "degrees"]]
+    kvecs = [g[pre + "kvec%d" % k] for k in range(len(degs))]
+    rp = g[pre + "M_rowptr"]
+    Mg = sp.csr_matrix((g[pre + "M_val"], g[pre + "M_col"], rp), shape=(len(rp) - 1, int(g[pre + "ncp"])))
+    mats = []
+    for env in (None, "0"):
+        if env is not None:
+            os.environ["TIGAR_EXTRACT_KRON"] = env
+        try:
+            gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh(degs, kvecs))
+        finally:
+            os.environ.pop("TIGAR_EXTRACT_KRON", None)
+        if env is None:
+            assert gen._kron is not None and gen._kron.columns_distinct() and not gen._kron.columns_ascending()
+        M = gen.M.to_scipy()
+        assert np.array_equal(M.indptr, Mg.indptr) and np.array_equal(M.indices, Mg.indices)
+        assert np.array_equal(M.data, Mg.data)
+        MT = gen.MT.to_scipy()
+        MgT = Mg.T.tocsr()
+        MgT.sort_indices()
+        assert np.array_equal(MT.indices, MgT.indices) and np.array_equal(MT.data, MgT.data)
+        mats.append(M)
+    # a 3-D patch periodic in one direction, against the oracle
+    p, nel = 2, 5
+    kv3 = [B.uniformKnots(p, 0., 1., nel), B.uniformKnots(p, 0., 1., nel, True), B.uniformKnots(p, 0., 1., 4)]
+    gen3 = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p] * 3, kv3))
+    s3 = O.BSpline([p] * 3, [O.uniform_knots(p, 0., 1., nel), O.uniform_knots(p, 0., 1., nel, periodic=True),
+                             O.uniform_knots(p, 0., 1., 4)])
+    Mo3 = O.generate_M_tensor(s3)
+    M3 = gen3.M.to_scipy()
+    assert np.array_equal(M3.indptr, Mo3.indptr) and np.array_equal(M3.indices, Mo3.indices)
+    assert np.array_equal(M3.data, Mo3.data)
+
+
 def test_slab_streaming_path_matches_resident_path(T):
     """SlabHotPath (z-slab streaming, the single-GPU form of the multi-GPU pipeline) reproduces
     the resident single-block path: K rows, M^T b, solution and prolongation."""

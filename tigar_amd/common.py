@@ -542,9 +542,10 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
                 if lazy is not None:
                     return lazy
             # exact Kronecker form (every product of stored 1-D entries passes the filter, checked on the 1-D
-            # tables; no periodic wrap): pencil walk with closed-form row starts, same entries bit for bit
+            # tables; periodic directions included as long as a node names no function twice): pencil walk with
+            # closed-form row starts, same entries bit for bit
             kx = self._kron_tables(basis, grid)
-            if kx is not None and kx.products_stay_above(eps) and kx.columns_ascending() \
+            if kx is not None and kx.products_stay_above(eps) and kx.columns_distinct() \
                     and os.environ.get("TIGAR_EXTRACT_KRON", "1") != "0":
                 return _dev.kron3_csr(kx.M1, None, None, col_offset, ncols)
             return _dev.extract_csr_tensor(basis.splines, grid.axes, col_offset, ncols, eps)
@@ -618,7 +619,7 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
             return self.M.transpose()
         def transposed_block(basis, grid, fe_offset, fe_total):
             kx = self._kron_tables(basis, grid)
-            if kx is not None and kx.products_stay_above(self.getIgnoreEps()) and kx.columns_ascending() \
+            if kx is not None and kx.products_stay_above(self.getIgnoreEps()) and kx.columns_distinct() \
                     and os.environ.get("TIGAR_EXTRACT_KRON", "1") != "0":
                 return _dev.kron3_csr(kx.M1T, None, None, fe_offset, fe_total)
             return _dev.extract_csr_tensor_t(basis.splines, grid.axes, fe_offset, fe_total, self.getIgnoreEps())

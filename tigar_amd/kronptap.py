@@ -63,6 +63,17 @@ class KronExtraction(object):
                 return False
         return True
 
+    def columns_distinct(self):
+        """the functions of every 1-D node are pairwise different (a periodic direction with fewer functions than p+1
+        would name one twice: PETSc's INSERT keeps the last value there, a Kronecker factor cannot).  With distinct
+        functions the 1-D rows -- stored sorted by function index -- reproduce the reference's rows also under
+        periodic wrap: the filtered, column-sorted tensor row IS the Kronecker product of the sorted 1-D rows."""
+        for k in range(self.d):
+            _, idx, _ = self._tables[k]
+            if np.any(np.diff(np.sort(idx, axis=1), axis=1) == 0):
+                return False
+        return True
+
     def is_exact_for(self, M_nnz, eps):
         """True if generateM's filter dropped only exact zeros, i.e. M == kron(M_k) entrywise."""
         small = any(np.any(np.abs(m.data) <= eps) for m in self.M1)
