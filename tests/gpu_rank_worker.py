@@ -9,6 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def dev_csr(A):
+    from tigar_amd.device import DeviceCSR
+    return DeviceCSR.from_scipy(A)
+
+
 def main():
     outdir, d, p, nel, method = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     import tigar_amd as t
@@ -16,15 +21,24 @@ def main():
     comm = tc.worldcomm
     dcomm = comm.device()
     rank_r, world_r, kind = dcomm.info()
-    kv = [B.uniformKnots(p, 0., 1., nel) for _ in range(d)]
+    periodic0 = os.environ.get("TIGAR_TEST_PERIODIC0") == "1"      # direction 0 periodic (the slab direction stays open)
+    explicit = os.environ.get("TIGAR_TEST_EXPLICIT_A")             # "device" / "scipy": an assembled A instead of a form
+    kv = [B.uniformKnots(p, 0., 1., nel, periodic0 and k == 0) for k in range(d)]
     gen = t.EqualOrderSpline(comm, 1, B.ExplicitBSplineControlMesh([p] * d, kv))
     assert getattr(gen.M, "is_implicit", False)          # several ranks: no rank holds all rows of M
     sp0 = gen.getScalarSpline(0)
-    for direction in range(d):
+    for direction in range(1 if periodic0 else 0, d):
         for side in (0, 1):
             gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
     spline = t.ExtractedSpline(gen, 2 * p)
-    K = spline.assembleMatrix(F.LaplaceForm(), diag=1.5)
+    if explicit:
+        # every rank holds the whole assembled matrix (with a coupling added by hand, as reef-knot.py:460-467 does)
+        A = F.LaplaceForm().assemble_matrix(spline.V).to_scipy().tolil()
+        A[5, A.shape[1] - 7] = 0.25
+        A = A.tocsr()
+        K = spline.extractMatrix(A if explicit == "scipy" else dev_csr(A), diag=1.5)
+    else:
+        K = spline.assembleMatrix(F.LaplaceForm(), diag=1.5)
     f1 = lambda x: np.sin(np.pi * x)
     rhs = spline.assembleVector(F.SeparableLoadForm([f1] * d, scale=d * np.pi ** 2))
     solver = t.PETScKrylovSolver(method, "jacobi")

@@ -212,6 +212,26 @@ def test_periodic_patch_through_the_generator_takes_the_pencil_walk(T):
     assert np.array_equal(M3.data, Mo3.data)
 
 
+@pytest.mark.parametrize("nel", [6, 9])
+def test_extract_matrix_on_a_periodic_patch(T, nel):
+    """M^T A M on a patch that is periodic in x: supports wrap around, so the box / line kernels (one interval of
+    operands per direction) are not taken; the general stages give the oracle's product (pattern and values)."""
+    t, B, F = T.t, T.B, T.F
+    d, p = 3, 2
+    kv = [B.uniformKnots(p, 0., 1., nel, k == 0) for k in range(d)]
+    gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p] * d, kv))
+    sp0 = gen.getScalarSpline(0)
+    for direction in (1, 2):
+        for side in (0, 1):
+            gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    A = F.LaplaceForm().assemble_matrix(spline.V)
+    K = spline.extractMatrix(A, diag=1.5).to_scipy()
+    Ko = O.extract_matrix(gen.M.to_scipy(), A.to_scipy(), list(spline.zeroDofs), diag=1.5)
+    assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices)
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+
+
 def test_slab_streaming_path_matches_resident_path(T):
     """SlabHotPath (z-slab streaming, the single-GPU form of the multi-GPU pipeline) reproduces
     the resident single-block path: K rows, M^T b, solution and prolongation."""

@@ -18,17 +18,22 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _single(d, p, nel, method):
+def _single(d, p, nel, method, periodic0=False, explicit=False):
     import tigar_amd as t
     from tigar_amd import BSplines as B, forms as F, common as tc
-    kv = [B.uniformKnots(p, 0., 1., nel) for _ in range(d)]
+    kv = [B.uniformKnots(p, 0., 1., nel, periodic0 and k == 0) for k in range(d)]
     gen = t.EqualOrderSpline(tc.selfcomm, 1, B.ExplicitBSplineControlMesh([p] * d, kv))
     sp0 = gen.getScalarSpline(0)
-    for direction in range(d):
+    for direction in range(1 if periodic0 else 0, d):
         for side in (0, 1):
             gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
     spline = t.ExtractedSpline(gen, 2 * p, comm=tc.selfcomm)
-    K = spline.assembleMatrix(F.LaplaceForm(), diag=1.5)
+    if explicit:
+        A = F.LaplaceForm().assemble_matrix(spline.V).to_scipy().tolil()
+        A[5, A.shape[1] - 7] = 0.25
+        K = spline.extractMatrix(A.tocsr(), diag=1.5)
+    else:
+        K = spline.assembleMatrix(F.LaplaceForm(), diag=1.5)
     f1 = lambda x: np.sin(np.pi * x)
     rhs = spline.assembleVector(F.SeparableLoadForm([f1] * d, scale=d * np.pi ** 2))
     solver = t.PETScKrylovSolver(method, "jacobi")
@@ -129,6 +134,25 @@ def test_ipc_iterates_are_those_of_the_host_staged_run(tmp_path):
         assert ipc[r]["resnorm"][0] == host[r]["resnorm"][0]
         assert int(ipc[r]["host_waits"][0]) == 0 and int(host[r]["host_waits"][0]) > 0
         assert int(ipc[r]["overlapped"][0]) >= int(ipc[r]["its"][0]) + 1      # products beside the exchange
+
+
+@pytest.mark.parametrize("how", ["device", "scipy"])
+def test_explicit_fe_matrix_with_several_ranks(tmp_path, how):
+    """extractMatrix(A) with an ASSEMBLED matrix (here with a coupling added by hand, outside the element-coupling
+    pattern) on several ranks: every rank cuts the row blocks of its slab out of its copy; K rows and the solution equal
+    the single-rank product (tIGAr/common.py:1194-1195 applies MatPtAP to whatever distributed A it is given)."""
+    d, p, nel, world = 3, 2, 10, 2
+    ref = _single(d, p, nel, "gmres", explicit=True)
+    parts = _run_ranks(tmp_path, world, "ipc", d, p, nel, "gmres", 34411 + len(how), {"TIGAR_TEST_EXPLICIT_A": how})
+    _compare(parts, ref, world, "ipc")
+
+
+def test_patch_periodic_across_the_slabs_with_several_ranks(tmp_path):
+    """a patch that is periodic in x: only the slab direction (the last one) needs an open knot vector"""
+    d, p, nel, world = 3, 2, 9, 3
+    ref = _single(d, p, nel, "cg", periodic0=True)
+    parts = _run_ranks(tmp_path, world, "ipc", d, p, nel, "cg", 34611, {"TIGAR_TEST_PERIODIC0": "1"})
+    _compare(parts, ref, world, "ipc")
 
 
 def test_ipc_dead_peer_is_an_error_not_a_hang(tmp_path):

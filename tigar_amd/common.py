@@ -1179,7 +1179,10 @@ class ExtractedSpline(object):
             if isinstance(A, LazyFEMatrix):
                 a_rows = A.rows
             else:
-                raise NotImplementedError("with several ranks pass the FE matrix as a LazyFEMatrix (row blocks)")
+                # an assembled FE matrix handed to every rank (the reference's A is a distributed PETSc matrix whose
+                # rows MatPtAP redistributes, tIGAr/common.py:1194-1195): every rank cuts the row blocks of its slab out
+                # of its copy -- on the device when it is a DeviceCSR, on the host (then uploaded) when it is scipy
+                a_rows = self._row_blocks_of(A)
             return self._slab_path().assemble_matrix(a_rows, zd, float(diag), getattr(self, "stage_timers", None))
         A = _as_device_csr(A)
         by_blocks = self._kron is None and getattr(self, "_kron_scalar", None) is not None
@@ -1230,6 +1233,18 @@ class ExtractedSpline(object):
             # recomputes the symbolic product on every call (tIGAr/common.py:1194-1195) -- plan again
             self._ptap_plan = _dev.ptap_symbolic(A, self.M, self.MT)
             return _dev.ptap_numeric(self._ptap_plan, A, self.M, self.MT, zd, float(diag))
+
+    @staticmethod
+    def _row_blocks_of(A):
+        """``rows(r0, r1)`` of an explicit FE matrix: DeviceCSR row blocks with global columns"""
+        if isinstance(A, DeviceCSR):
+            ncols = A.shape[1]
+            return lambda r0, r1: A.block(int(r0), int(r1), 0, ncols)
+        import scipy.sparse as _sp
+        if not _sp.issparse(A):
+            raise TypeError("extractMatrix: a DeviceCSR, a scipy sparse matrix or a LazyFEMatrix is expected")
+        Ah = _sp.csr_matrix(A)
+        return lambda r0, r1: DeviceCSR.from_scipy(Ah[int(r0):int(r1)])
 
     def _extract_matrix_by_field_blocks(self, A, zd, diag, tensor=True):
         """M^T A M for several fields on one tensor basis (M = diag(M_s, ..., M_s), dofs field after field): block

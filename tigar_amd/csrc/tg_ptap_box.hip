@@ -1706,8 +1706,10 @@ static int tg_ptap_kron_any(tg_csr_t cur, int64_t cur_row0, int d, const int64_t
   if (rc == 101 && stride > 1)
     rc = tg_ptap_kron_impl(cur, cur_row0, d, dims_in, fac, out_row0, out_row1, zero_dofs, nzero, diag, 1, loose_out, dest, out);
   if (rc == 101) {
+    // also with the exact reach: the support of an output row is not one interval per direction (periodic wrap) --
+    // not a product for the box kernels; the caller takes the general ones (100 = declined, nothing was written)
     tg_set_error("tg_ptap_kron: an entry fell outside its accumulator box");
-    rc = 4;
+    rc = 100;
   }
   return rc;
 }

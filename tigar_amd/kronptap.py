@@ -133,7 +133,11 @@ def contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs=None,
     columns within the planes ``c_planes``) and P contracts the directions in ``group``."""
     pl_in = kx.plane(done)
     import os
-    if os.environ.get("TIGAR_PTAP_BOX", "1") != "0":
+    # the box / line kernels address an output row's operands as ONE interval per direction: a patch with a periodic
+    # direction (supports that wrap around) takes the general kernels in every stage
+    if "_wraps" not in kx.__dict__:
+        kx._wraps = not kx.columns_ascending()
+    if os.environ.get("TIGAR_PTAP_BOX", "1") != "0" and not kx._wraps:
         dims_in = kx.dims(done)
         factors = [kx.M1[k] if k in group else None for k in range(kx.d)]
         out = _dev.ptap_kron(cur, a_planes[0] * pl_in, dims_in, factors, out_rows[0], out_rows[1], zero_dofs, diag,
