@@ -303,21 +303,38 @@ def run(args, wl, d, p, nel):
     except Exception as e:                                # (diagnostic only)
         log("[bench] self-check skipped:", repr(e))
 
-    # ---- companion figure: the same step with A's pattern verified entry by entry (what a matrix handed over by
-    # dolfin pays), measured live after the timed loop
-    verified = None
-    if ptap_certified > 0 and args.companion:
-        os.environ["TIGAR_PTAP_VERIFY"] = "1"
+    # ---- companion figures, measured live after the timed loop (one extra step each):
+    #  * "materialised": the FE matrix written in row blocks inside the step and read back by the PtAP (what the step
+    #    costs when the form is not a Kronecker sum the PtAP can fuse -- TIGAR_PTAP_FUSED=0);
+    #  * "pattern_verified": additionally with A's pattern verified entry by entry (a matrix handed over without the
+    #    library's certificate, e.g. uploaded from dolfin -- TIGAR_PTAP_VERIFY=1)
+    companions = {}
+    fused = (not a_resident) and mean_stages.get("fe_input", 1.0) < 1e-3 and ptap_certified == 0 and wl in ("cfg1", "cfg2", "cfg3")
+
+    def extra_step(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
         try:
             state.clear()
             barrier()
             t1 = time.perf_counter()
             step(False)
             barrier()
-            verified = transport.allreduce_max(time.perf_counter() - t1)
+            return transport.allreduce_max(time.perf_counter() - t1)
         finally:
-            del os.environ["TIGAR_PTAP_VERIFY"]
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    if args.companion and fused:
+        companions["materialised"] = extra_step({"TIGAR_PTAP_FUSED": "0"})
+        companions["pattern_verified"] = extra_step({"TIGAR_PTAP_FUSED": "0", "TIGAR_PTAP_VERIFY": "1"})
+    elif args.companion and ptap_certified > 0:
+        companions["pattern_verified"] = extra_step({"TIGAR_PTAP_VERIFY": "1"})
+    if companions:
         gen, spline, K, u, solver = state["gen"], state["spline"], state["K"], state["u"], state["solver"]
+    verified = companions.get("pattern_verified")
 
     nodal_error = None
     if args.check and rank == 0 and wl != "cfg5":
@@ -352,7 +369,8 @@ def run(args, wl, d, p, nel):
             "sell_classes": sell_classes, "sell_padded": sell_padded, "implicit_M": bool(getattr(gen.M, "is_implicit", False)),
             "ptap_certified": int(ptap_certified), "nodal_error": nodal_error, "method": method, "nf": nf,
             "solver_last": {k: v for k, v in (solver.last or {}).items() if isinstance(v, (int, float, str, bool))},
-            "self_check": self_check, "verified_step_s": verified, "comm_host_waits": int(comm_host_waits),
+            "self_check": self_check, "verified_step_s": verified, "materialised_step_s": companions.get("materialised"),
+            "fused": bool(fused), "comm_host_waits": int(comm_host_waits),
             "comm_world": info[1], "comm_kind": info[2], "n_devices_used": n_used}
 
 
@@ -540,9 +558,13 @@ def main():
                    "nnz_K": res["nnzK"], "cg_iterations": res["iterations"], "solver": res["solver_last"],
                    "M_implicit": res["implicit_M"],
                    "max_nodal_error_vs_manufactured_solution": res.get("nodal_error"),
-                   "fe_matrix_pattern": ("certified by the assembly kernel that wrote it (tg_kron_sum_csr): the PtAP does not "
-                                         "re-read the column indices; TIGAR_PTAP_VERIFY=1 verifies them entry by entry, "
-                                         "+0.05 s per step at cfg3" if res.get("ptap_certified", 0) > 0
+                   "fe_matrix_pattern": ("never materialised: the form is a Kronecker sum of 1-D matrices and the first PtAP pass "
+                                         "forms the entries itself, bit for bit as tg_kron_sum_csr would have written them "
+                                         "(SURVEY 8d: fused A-generation; the PtAP roofline below is quoted on the "
+                                         "MATERIALISED byte count)" if res.get("fused") else
+                                         "certified by the assembly kernel that wrote it (tg_kron_sum_csr): the PtAP does not "
+                                         "re-read the column indices; TIGAR_PTAP_VERIFY=1 verifies them entry by entry"
+                                         if res.get("ptap_certified", 0) > 0
                                          else "verified entry by entry while the PtAP reads it"),
                    "stages_s": {k: round(v, 6) for k, v in res["stages"].items()},
                    "fe_input_generation_s": round(res["t_input"], 6),
@@ -554,6 +576,11 @@ def main():
                    # e.g. uploaded from dolfin): one extra step measured live after the timed loop
                    "value_pattern_verified": (res["ncp"] / res["verified_step_s"]) if res.get("verified_step_s") else None,
                    "ms_per_step_pattern_verified": 1e3 * res["verified_step_s"] if res.get("verified_step_s") else None,
+                   # the step with the FE matrix written in row blocks and read back (no fusion of a Kronecker-sum form
+                   # into the first PtAP pass): what `value` was before round 3
+                   "value_fe_matrix_materialised": (res["ncp"] / res["materialised_step_s"]) if res.get("materialised_step_s") else None,
+                   "ms_per_step_fe_matrix_materialised": 1e3 * res["materialised_step_s"] if res.get("materialised_step_s") else None,
+                   "fe_matrix_fused_into_ptap": res.get("fused"),
                    "self_check_rel_residual_all_ranks": res.get("self_check"),
                    "communicator_host_waits_in_timed_steps": res.get("comm_host_waits"),
                    "ptap": {"stage_s": res["stages"].get("ptap"), "algorithmic_bytes": ptap_bytes(cnt),

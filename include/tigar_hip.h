@@ -325,6 +325,14 @@ typedef struct {
 } tg_kron_dir_t;
 int tg_kron_sum_csr(int d, int nterms, const tg_kron_dir_t *dirs, int64_t row0,
                     int64_t row1, tg_csr_t *out);
+/* The same planes for an FE matrix GIVEN AS A KRONECKER SUM of 1-D matrices (dirs[k]: the 1-D pattern of direction k
+ * and nterms value sets, term-major -- the arguments of tg_kron_sum_csr): the matrix is never written, its entries are
+ * formed inside the x pass exactly as tg_kron_sum_csr forms them, so the planes are bit for bit those of
+ * tg_tensor_planes on the materialised matrix.  100: the 1-D patterns are not the element-coupling patterns of the
+ * plan, or more than three terms (materialise and call tg_tensor_planes).  SURVEY 8(d): "If the build fuses A-generation
+ * into PtAP (never materialising A) ...". */
+int tg_tensor_planes_kron(tg_tensor_plan_t plan, int nterms, const tg_kron_dir_t *dirs, int z0, int z1,
+                          tg_tensor_planes_t *out);
 
 /* General Kronecker-product CSR builder on the device: out = sum_t (x)_k F[t][k] restricted to rows
  * [row0,row1), with rectangular 1-D factors (cdim[k] = number of columns of direction k; NULL =

@@ -425,3 +425,44 @@ def test_2d_other_patterns_fall_back_to_the_general_kernels():
         os.environ.pop("TIGAR_PTAP_VERIFY", None)
     assert dev.prof_get(3)[1] == 1
     assert np.array_equal(Ka.data, Kb.data) and np.array_equal(Ka.indices, Kb.indices)
+
+
+def test_kronecker_sum_forms_are_fused_into_the_x_pass_bit_for_bit():
+    """assembleMatrix(form) with a form that is a Kronecker sum of 1-D matrices (LaplaceForm, MassForm on the identity
+    geometry) on a streamed / implicit patch: the FE matrix is never written -- the x pass forms its entries exactly as
+    tg_kron_sum_csr would have -- and K equals, bit for bit, the K of the unfused path (TIGAR_PTAP_FUSED=0: row blocks
+    materialised, then read), over several sub-slabs, with boundary conditions, for one- and three-term forms."""
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, forms as F
+    for p, nels, form in ((3, (6, 5, 9), F.LaplaceForm()), (2, (7, 8, 10), F.MassForm()), (1, (4, 4, 6), F.LaplaceForm())):
+        Ks = []
+        for fused in ("1", "0"):
+            os.environ["TIGAR_PTAP_FUSED"] = fused
+            os.environ["TIGAR_IMPLICIT_M"] = "1"
+            os.environ["TIGAR_SUB_PLANES"] = "4"
+            try:
+                kvs = [B.uniformKnots(p, 0., 1., n) for n in nels]
+                gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p] * 3, kvs))
+                sp0 = gen.getScalarSpline(0)
+                for direction in range(3):
+                    for side in (0, 1):
+                        gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
+                spline = t.ExtractedSpline(gen, 2 * p)
+                spline.stage_timers = {}
+                K = spline.assembleMatrix(form, diag=2.0)
+                assert getattr(gen.M, "is_implicit", False)
+                # the fused path produces no FE input at all
+                assert (spline.stage_timers.get("input", 0.0) < 1e-3) == (fused == "1") or fused == "0"
+                Ks.append(K.to_scipy())
+            finally:
+                for k in ("TIGAR_PTAP_FUSED", "TIGAR_IMPLICIT_M", "TIGAR_SUB_PLANES"):
+                    os.environ.pop(k, None)
+        assert np.array_equal(Ks[0].indptr, Ks[1].indptr) and np.array_equal(Ks[0].indices, Ks[1].indices)
+        assert np.array_equal(Ks[0].data, Ks[1].data)
+        # and both are the oracle's product
+        s = O.BSpline([p] * 3, [O.uniform_knots(p, 0., 1., n) for n in nels])
+        Mo = O.generate_M_tensor(s)
+        Ao = form.assemble_matrix(spline.V).to_scipy()
+        Ko = O.extract_matrix(Mo, Ao, list(spline.zeroDofs), diag=2.0)
+        assert np.array_equal(Ks[0].indices, Ko.indices)
+        assert np.max(np.abs(Ks[0].data - Ko.data)) <= 1e-12 * np.max(np.abs(Ko.data))

@@ -133,6 +133,7 @@ PROTOTYPES = {
     "tg_tensor2_ptap": (C.c_int, [handle, handle, c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
     "tg_tensor_planes": (C.c_int, [handle, handle, C.c_int64, C.c_int, C.c_int, C.POINTER(handle)]),
     "tg_tensor_planes_destroy": (C.c_int, [handle]),
+    "tg_tensor_planes_kron": (C.c_int, [handle, C.c_int, C.POINTER(tg_kron_dir_t), C.c_int, C.c_int, C.POINTER(handle)]),
     "tg_tensor_zstage": (C.c_int, [handle, C.c_int, C.POINTER(handle), C.c_int, C.c_int, c_i32p, C.c_int64,
                                    C.c_double, handle, C.POINTER(handle)]),
     "tg_csr_compact": (C.c_int, [handle, C.POINTER(handle)]),

@@ -1176,14 +1176,17 @@ class ExtractedSpline(object):
         from .implicit import LazyFEMatrix
         zd = self.zeroDofs if applyBCs else None
         if isinstance(A, LazyFEMatrix) or self._distributed():
+            a_fac = None
             if isinstance(A, LazyFEMatrix):
                 a_rows = A.rows
+                a_fac = A.kron_factors
             else:
                 # an assembled FE matrix handed to every rank (the reference's A is a distributed PETSc matrix whose
                 # rows MatPtAP redistributes, tIGAr/common.py:1194-1195): every rank cuts the row blocks of its slab out
                 # of its copy -- on the device when it is a DeviceCSR, on the host (then uploaded) when it is scipy
                 a_rows = self._row_blocks_of(A)
-            return self._slab_path().assemble_matrix(a_rows, zd, float(diag), getattr(self, "stage_timers", None))
+            return self._slab_path().assemble_matrix(a_rows, zd, float(diag), getattr(self, "stage_timers", None),
+                                                     a_factors=a_fac)
         A = _as_device_csr(A)
         by_blocks = self._kron is None and getattr(self, "_kron_scalar", None) is not None
         # 2-D tensor patches (one or several fields on one basis): the whole product in two line-walk passes when A
@@ -1318,7 +1321,10 @@ class ExtractedSpline(object):
             if self._implicit() or self._distributed():
                 from .implicit import LazyFEMatrix
                 n = self.V.dim()
-                A = LazyFEMatrix(lambda r0, r1: form.assemble_matrix(self.V, r0, r1), (n, n))
+                fac = None
+                if hasattr(form, "factors") and getattr(form, "geometry", None) is None and self.nFields == 1:
+                    fac = form.factors(self.V)          # Kronecker sum of 1-D matrices: may be fused into the PtAP
+                A = LazyFEMatrix(lambda r0, r1: form.assemble_matrix(self.V, r0, r1), (n, n), kron_factors=fac)
             else:
                 A = form.assemble_matrix(self.V)
         else:

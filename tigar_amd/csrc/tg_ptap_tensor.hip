@@ -24,6 +24,10 @@ struct tg_tensor_plan_s {
   int32_t *lines1[2] = {nullptr, nullptr};
   int nlines1[2] = {0, 0};
   std::vector<int32_t> h_rps[3], h_kps[3];
+  // 1-D value tables of the Kronecker-sum form used last by tg_tensor_planes_kron (device, term-major), and their key
+  double *kcv[3] = {nullptr, nullptr, nullptr};
+  uint64_t kcv_key = 0;
+  int kcv_terms = 0;
   uint64_t expect_tag = 0; // tg_pattern_hash of the element-coupling pattern the passes rely on
   std::vector<int32_t> h_ecol[3];   // that pattern's 1-D column indices (rows as in h_rps)
   int *status = nullptr;   // device flag
@@ -105,6 +109,7 @@ extern "C" int tg_tensor_plan_destroy(tg_tensor_plan_t p) {
   tg_dfree(p->lines1[0]);
   tg_dfree(p->lines1[1]);
   tg_dfree(p->status);
+  for (int k = 0; k < 3; k++) tg_dfree(p->kcv[k]);
   delete p;
   return 0;
 }
@@ -356,6 +361,173 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
   if (rc || bad) {
     tg_tensor_planes_destroy(res);
     return rc ? rc : 100;          // 100: A does not have the element-coupling pattern -> general path
+  }
+  *out = res;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// x and y passes for an FE matrix given as a Kronecker sum of 1-D matrices on the element-coupling pattern: the matrix
+// is never materialised (tt_xg_lane); everything downstream (y pass, z stage) is unchanged and the planes returned are
+// bit for bit those tg_tensor_planes computes from the matrix tg_kron_sum_csr would have written.
+template <int NT>
+struct tt_xg_multi {
+  tt_xg_args<NT> c[4];
+  unsigned first[5], gx[4];
+  int n;
+};
+template <int P, int NT>
+__global__ void __launch_bounds__(64) k_tt_xg_multi(tt_xg_multi<NT> M) {
+  int c = 0;
+  while (c + 1 < M.n && blockIdx.x >= M.first[c + 1]) c++;
+  const unsigned local = blockIdx.x - M.first[c];
+  tt_xg_lane<P, NT>(M.c[c], (int)(local % M.gx[c]), (int)(local / M.gx[c]), threadIdx.x);
+}
+
+template <int NT>
+static int tt_launch_xg(tg_tensor_plan_s *pl, int z0, const std::vector<int32_t> *pls, int32_t *const *d_pl, double *b1,
+                        const int64_t *d_pb1, const int *nnz1d) {
+  const int P = pl->P, W = 2 * P + 1;
+  const tt_dir_t &D0 = pl->dir[0], &D1 = pl->dir[1], &D2 = pl->dir[2];
+  tt_xg_multi<NT> XM;
+  memset(&XM, 0, sizeof(XM));
+  for (int pc = 1; pc >= 0; pc--) {
+    if (pls[pc].empty()) continue;
+    const int n2 = pc == 0 ? P + 1 : W;
+    for (int lc = 1; lc >= 0; lc--) {
+      if (!pl->nlines1[lc]) continue;
+      const int n1 = lc == 0 ? P + 1 : W;
+      tt_xg_args<NT> &X = XM.c[XM.n];
+      X.d0 = D0;
+      X.cv0 = pl->kcv[0];
+      X.cv1 = pl->kcv[1];
+      X.cv2 = pl->kcv[2];
+      X.nnz0 = nnz1d[0];
+      X.nnz1 = nnz1d[1];
+      X.nnz2 = nnz1d[2];
+      X.rps1 = D1.rps;
+      X.rps2 = D2.rps;
+      X.nfe1 = D1.nfe;
+      X.nfe2 = D2.nfe;
+      X.lines = pl->lines1[lc];
+      X.nlines = pl->nlines1[lc];
+      X.n1 = n1;
+      X.L = std::max(1, 64 / (n1 * n2));
+      X.planes = d_pl[pc];
+      X.n2 = n2;
+      X.b1 = b1;
+      X.pb1 = d_pb1;
+      X.z0 = z0;
+      XM.gx[XM.n] = (unsigned)tg_cdiv(X.nlines, X.L);
+      XM.first[XM.n + 1] = XM.first[XM.n] + XM.gx[XM.n] * (unsigned)pls[pc].size();
+      XM.n++;
+    }
+  }
+  if (XM.n == 0 || XM.first[XM.n] == 0) return 0;
+#define TT_XG(PP) hipLaunchKernelGGL((k_tt_xg_multi<PP, NT>), dim3(XM.first[XM.n]), dim3(64), 0, g_tg.stream, XM)
+  TT_DISPATCH_P(P, TT_XG);
+#undef TT_XG
+  return 0;
+}
+
+extern "C" int tg_tensor_planes_kron(tg_tensor_plan_t pl, int nterms, const tg_kron_dir_t *dirs, int z0, int z1,
+                                     tg_tensor_planes_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(pl && dirs && out, "null argument to tg_tensor_planes_kron");
+  TG_REQUIRE(pl->d == 3, "tg_tensor_planes_kron: 3-D plans only");
+  if (nterms < 1 || nterms > 3) return 100;
+  const int P = pl->P, W = 2 * P + 1;
+  const tt_dir_t &D0 = pl->dir[0], &D1 = pl->dir[1], &D2 = pl->dir[2];
+  TG_REQUIRE(z0 >= 0 && z1 > z0 && z1 <= D2.nfe, "tg_tensor_planes_kron: plane range out of bounds");
+  // the 1-D factors must sit on exactly the 1-D element-coupling patterns of the plan
+  int nnz1d[3];
+  uint64_t key = 1469598103934665603ull ^ (uint64_t)nterms;
+  for (int k = 0; k < 3; k++) {
+    const int nfe = pl->dir[k].nfe;
+    if (dirs[k].n != nfe || !dirs[k].rowptr || !dirs[k].col || !dirs[k].val) return 100;
+    if (memcmp(dirs[k].rowptr, pl->h_rps[k].data(), (size_t)(nfe + 1) * sizeof(int32_t)) != 0) return 100;
+    nnz1d[k] = pl->h_rps[k][nfe];
+    if (memcmp(dirs[k].col, pl->h_ecol[k].data(), (size_t)nnz1d[k] * sizeof(int32_t)) != 0) return 100;
+    const uint64_t *w = (const uint64_t *)dirs[k].val;
+    for (int64_t i = 0; i < (int64_t)nterms * nnz1d[k]; i++) key = (key ^ w[i]) * 1099511628211ull + (uint64_t)k;
+  }
+  if (key != pl->kcv_key || nterms != pl->kcv_terms || !pl->kcv[0]) {
+    // (the previous tables may still be read by kernels in flight: released to the pool in stream order)
+    for (int k = 0; k < 3; k++) {
+      tg_dfree(pl->kcv[k]);
+      pl->kcv[k] = nullptr;
+      TG_TRY(tg_dmalloc(&pl->kcv[k], (int64_t)nterms * nnz1d[k]));
+      TG_TRY(tg_h2d_staged(pl->kcv[k], dirs[k].val, (size_t)nterms * nnz1d[k] * sizeof(double)));
+    }
+    pl->kcv_key = key;
+    pl->kcv_terms = nterms;
+  }
+  const int np = z1 - z0;
+  std::vector<int64_t> pb1(np + 1, 0), pb2(np + 1, 0);
+  std::vector<int32_t> pls[2];
+  for (int q = 0; q < np; q++) {
+    const int n2 = tt_rn_host(P, z0 + q, D2.nfe);
+    pb1[q + 1] = pb1[q] + (int64_t)W * n2 * D0.ncp * pl->h_rps[1][D1.nfe];
+    pb2[q + 1] = pb2[q] + (int64_t)W * W * n2 * D0.ncp * D1.ncp;
+    pls[n2 == P + 1 ? 0 : 1].push_back(z0 + q);
+  }
+  double *b1 = nullptr;
+  int64_t *d_pb1 = nullptr, *d_pb2 = nullptr;
+  int32_t *d_pl[2] = {nullptr, nullptr};
+  tg_tensor_planes_s *res = new tg_tensor_planes_s();
+  res->z0 = z0;
+  res->z1 = z1;
+  res->pb = pb2;
+  int rc = tg_dmalloc(&b1, pb1[np]);
+  if (!rc) rc = tg_dmalloc(&res->buf, pb2[np]);
+  if (!rc) rc = tg_dmalloc(&res->status, 4);
+  if (!rc) rc = tt_upload(&d_pb1, pb1);
+  if (!rc) rc = tt_upload(&d_pb2, pb2);
+  if (!rc) rc = tt_upload(&d_pl[0], pls[0]);
+  if (!rc) rc = tt_upload(&d_pl[1], pls[1]);
+  if (!rc && hipMemsetAsync(res->status, 0, sizeof(int), g_tg.stream) != hipSuccess) rc = 1;
+  if (!rc) {
+    if (nterms == 1) rc = tt_launch_xg<1>(pl, z0, pls, d_pl, b1, d_pb1, nnz1d);
+    else if (nterms == 2) rc = tt_launch_xg<2>(pl, z0, pls, d_pl, b1, d_pb1, nnz1d);
+    else rc = tt_launch_xg<3>(pl, z0, pls, d_pl, b1, d_pb1, nnz1d);
+    tt_y_multi YM;
+    memset(&YM, 0, sizeof(YM));
+    for (int pc = 1; pc >= 0; pc--) {
+      if (pls[pc].empty()) continue;
+      const int n2 = pc == 0 ? P + 1 : W;
+      tt_y_args &Y = YM.c[YM.n];
+      Y.b1 = b1;
+      Y.pb1 = d_pb1;
+      Y.b2 = res->buf;
+      Y.pb2 = d_pb2;
+      Y.z0 = z0;
+      Y.d1 = D1;
+      Y.ncp0 = D0.ncp;
+      Y.planes = d_pl[pc];
+      Y.n2 = n2;
+      Y.L = std::max(1, 64 / (W * n2));
+      YM.gx[YM.n] = (unsigned)tg_cdiv(D0.ncp, Y.L);
+      YM.first[YM.n + 1] = YM.first[YM.n] + YM.gx[YM.n] * (unsigned)pls[pc].size();
+      YM.n++;
+    }
+    if (!rc && YM.n > 0 && YM.first[YM.n] > 0) {
+#define TT_Y(PP) hipLaunchKernelGGL((k_tt_y_multi<PP>), dim3(YM.first[YM.n]), dim3(64), 0, g_tg.stream, YM)
+      TT_DISPATCH_P(P, TT_Y);
+#undef TT_Y
+    }
+    if (hipGetLastError() != hipSuccess) {
+      tg_set_error("tg_tensor_planes_kron: kernel launch failed");
+      rc = 1;
+    }
+  }
+  tg_dfree(b1);
+  tg_dfree(d_pb1);
+  tg_dfree(d_pb2);
+  tg_dfree(d_pl[0]);
+  tg_dfree(d_pl[1]);
+  if (rc) {
+    tg_tensor_planes_destroy(res);
+    return rc;
   }
   *out = res;
   return 0;

@@ -308,6 +308,85 @@ TT_DEV int tt_x_lane(const tt_x_args &A, int bx, int by, int lane, int piece = 0
   return io.bad;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// stage X for an FE matrix GIVEN AS A KRONECKER SUM  A = sum_u F2u (x) F1u (x) F0u  of 1-D matrices on the
+// element-coupling pattern (what the forms of tigar_amd.forms assemble on an identity-geometry patch): the matrix is
+// never written -- the lane forms its entries while it walks,
+//     A[(a, r1, r2), (c0, c1, c2)] = sum_u F0u[a][c0] * (F1u[r1][c1] * F2u[r2][c2]),
+// the bracket being constant along the walk (one scalar per term in the lane) and F0u[a][.] wave-uniform (scalar
+// loads).  The sum is formed exactly as tg_kron_sum_csr forms it (terms in order, fused multiply-adds), so the
+// result is bit for bit what the x pass computes from the materialised matrix.
+template <int NT>
+struct tt_xg_args {
+  tt_dir_t d0;
+  const double *cv0, *cv1, *cv2;   // 1-D values, term-major: cv[u * nnz + q]
+  int nnz0, nnz1, nnz2;
+  const int32_t *rps1, *rps2;      // prefix sums of the 1-D row lengths (= positions of the 1-D rows)
+  int nfe1, nfe2;
+  const int32_t *lines;
+  int nlines, L, n1;
+  const int32_t *planes;
+  int n2;
+  double *b1;
+  const int64_t *pb1;
+  int z0;
+};
+
+template <int P, int NT>
+struct tt_io_xg {
+  tt_cdp f0;
+  tt_cip ps0;
+  int nnz0;
+  double g[NT];
+  bool valid;
+  double *out;
+  int64_t ostride_i, ostride_m;
+  template <int N>
+  TT_MEM void load(int a, int clo, double *v) {
+    (void)clo;
+    tt_cdp f = f0 + ps0[a];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      double acc = fma(f[j], g[0], 0.0);
+#pragma unroll
+      for (int u = 1; u < NT; u++) acc = fma(f[(int64_t)u * nnz0 + j], g[u], acc);
+      v[j] = valid ? acc : 0.0;
+    }
+  }
+  TT_MEM void emit(int i, const double *row) {
+    if (!valid) return;
+    double *d = out + ostride_i * i;
+#pragma unroll
+    for (int m = 0; m < 2 * P + 1; m++) d[m * ostride_m] = row[m];
+  }
+};
+
+template <int P, int NT>
+TT_DEV void tt_xg_lane(const tt_xg_args<NT> &A, int bx, int by, int lane) {
+  constexpr int W = 2 * P + 1;
+  const int plane = A.planes[by];
+  const int lpl = A.n1 * A.n2;
+  const int sub = lane / lpl, l = lane - sub * lpl;
+  const int li = bx * A.L + sub;
+  tt_io_xg<P, NT> io;
+  io.valid = sub < A.L && li < A.nlines;
+  const int r1 = io.valid ? A.lines[li] : 0;
+  const int c1 = l % A.n1, c2 = l / A.n1;
+  io.f0 = TT_CD(A.cv0);
+  io.ps0 = TT_CI(A.d0.rps);
+  io.nnz0 = A.nnz0;
+  {
+    const int q1 = A.rps1[r1] + (io.valid ? c1 : 0), q2 = A.rps2[plane] + (io.valid ? c2 : 0);
+#pragma unroll
+    for (int u = 0; u < NT; u++) io.g[u] = A.cv1[(int64_t)u * A.nnz1 + q1] * A.cv2[(int64_t)u * A.nnz2 + q2];
+  }
+  const int64_t wn2 = (int64_t)W * A.n2;
+  io.out = A.b1 + A.pb1[plane - A.z0] + wn2 * A.d0.ncp * A.rps1[r1] + (int64_t)c2 * W * A.n1 + c1;
+  io.ostride_i = wn2 * A.n1;
+  io.ostride_m = A.n1;
+  tt_walk<P>(A.d0, 0, A.d0.nel, io);
+}
+
 // Row lengths of A against the element-coupling pattern: row (a, r1, r2) must hold n0(a)*n1(r1)*n2(r2) entries.
 // idx runs over the rows of the planes [z0, z1); returns 1 on a mismatch.
 struct tt_check_args {

@@ -200,7 +200,7 @@ class SlabHotPath(object):
         parts = -(-n // max(1, self.sub_planes))
         return [(self.k0 + (n * q) // parts, self.k0 + (n * (q + 1)) // parts) for q in range(parts)]
 
-    def assemble(self, a_rows, b_rows, zero_dofs, diag=1.0, timers=None):
+    def assemble(self, a_rows, b_rows, zero_dofs, diag=1.0, timers=None, a_factors=None):
         """K_loc (rows of this rank, global columns, BCs applied) and rhs_loc = (M^T b)_loc.
         ``a_rows(r0, r1)`` / ``b_rows(r0, r1)`` return the FE matrix rows (DeviceCSR, global
         columns) / FE vector entries (DeviceVector) of global FE rows [r0, r1)."""
@@ -233,6 +233,11 @@ class SlabHotPath(object):
         tplan = TensorPtAP.for_extraction(self.kx) if (self.factored and self.kron_exact and not getattr(
             self, "_tensor_declined", False)) else None
         ring["tensor"] = tplan
+        # an FE matrix that is a Kronecker sum of 1-D matrices on the element-coupling pattern is never written: the x
+        # pass forms its entries (tg_tensor_planes_kron; TIGAR_PTAP_FUSED=0 materialises the row blocks as before)
+        ring["kron"] = None
+        if tplan is not None and a_factors is not None and os.environ.get("TIGAR_PTAP_FUSED", "1") != "0":
+            ring["kron"] = tplan.pack_kron_factors(a_factors)
         if tplan is not None and nslabs > 1:
             builder = dev.CSRBuilder(self.mine["dofs"][1] - self.mine["dofs"][0], self.ncp, tplan.k_nnz(self.k0, self.k1))
         overlap = (self.factored and self.kron_exact and len(subs) > 1
@@ -290,7 +295,10 @@ class SlabHotPath(object):
             elif use_factored:
                 za, zb = S["a_rows"][0] // pf, S["a_rows"][1] // pf
                 new_lo = max(za, ring["hi"])               # FE planes not yet contracted
-                A = a_rows(new_lo * pf, zb * pf) if zb > new_lo else None
+                if ring.get("kron") is not None:
+                    A = "kron" if zb > new_lo else None    # (nothing to produce: the PtAP forms the entries itself)
+                else:
+                    A = a_rows(new_lo * pf, zb * pf) if zb > new_lo else None
                 ring["new"] = (new_lo, zb)
                 b = b_rows(S["a_rows"][0], S["a_rows"][1]) if with_rhs else None
             else:
@@ -307,7 +315,7 @@ class SlabHotPath(object):
                     # the general stages (nothing of this call is kept)
                     self._tensor_declined = True
                     del A, b, builder, ring
-                    return self.assemble(a_rows, b_rows, zero_dofs, diag, timers)
+                    return self.assemble(a_rows, b_rows, zero_dofs, diag, timers, a_factors)
                 plan = None
             else:
                 plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], S["m_rows"][0], S["dofs"][0])
@@ -351,9 +359,9 @@ class SlabHotPath(object):
         tick("stack", t0)
         return K, rhs
 
-    def assemble_matrix(self, a_rows, zero_dofs, diag=1.0, timers=None):
+    def assemble_matrix(self, a_rows, zero_dofs, diag=1.0, timers=None, a_factors=None):
         """K_loc = rows of M^T A M owned by this rank (extractMatrix, tIGAr/common.py:1176-1204)."""
-        return self.assemble(a_rows, None, zero_dofs, diag, timers)[0]
+        return self.assemble(a_rows, None, zero_dofs, diag, timers, a_factors)[0]
 
     def assemble_vector(self, b_rows, zero_dofs=None, timers=None):
         """(M^T b)_loc with the boundary entries zeroed (extractVector, tIGAr/common.py:1142-1160): one
@@ -394,7 +402,12 @@ class SlabHotPath(object):
         tplan = ring.get("tensor")
         if tplan is not None:
             if A_new is not None:
-                piece = tplan.planes(A_new, new_lo * pf, new_lo, new_hi)
+                if isinstance(A_new, str):                 # "kron": the matrix is a Kronecker sum, formed inside the x pass
+                    piece = tplan.planes_kron(ring["kron"], new_lo, new_hi)
+                    if piece is None:
+                        ring["kron"] = None
+                else:
+                    piece = tplan.planes(A_new, new_lo * pf, new_lo, new_hi)
                 if piece is None:
                     raise _TensorDeclined()
                 ring["pieces"].append((new_lo, new_hi, piece))

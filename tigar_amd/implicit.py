@@ -21,9 +21,12 @@ class LazyFEMatrix(object):
     ``dolfin.assemble`` hands to ``extractMatrix`` in the reference (tIGAr/common.py:1206-1220) when the
     assembled matrix does not fit in HBM at once (cfg3: 684 GB)."""
 
-    def __init__(self, producer, shape):
+    def __init__(self, producer, shape, kron_factors=None):
         self._producer = producer
         self.shape = (int(shape[0]), int(shape[1]))
+        # the matrix as a Kronecker sum of 1-D matrices (factors[t][k], scipy CSR) when its producer is one -- the PtAP
+        # can then form the entries inside its first pass instead of reading row blocks (never materialised)
+        self.kron_factors = kron_factors
 
     def rows(self, r0, r1):
         return self._producer(int(r0), int(r1))

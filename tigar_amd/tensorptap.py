@@ -189,6 +189,62 @@ class TensorPtAP(object):
         check(rc, "tg_tensor_planes")
         return TensorPlanes(h, int(z0), int(z1))
 
+    def pack_kron_factors(self, factors):
+        """ctypes arguments of ``tg_tensor_planes_kron`` for a Kronecker-sum form (``factors[t][k]``: scipy CSR 1-D
+        matrices, all terms on one pattern per direction), or None when the form has more than three terms / terms on
+        different patterns"""
+        import scipy.sparse as sp
+        from ._lib import tg_kron_dir_t
+        nterms = len(factors)
+        if nterms < 1 or nterms > 3 or any(len(f) != 3 for f in factors):
+            return None
+        arr = (tg_kron_dir_t * 3)()
+        keep = []
+        for k in range(3):
+            pat = sp.csr_matrix(factors[0][k])
+            pat.sort_indices()
+            vals = []
+            for t in range(nterms):
+                F = sp.csr_matrix(factors[t][k])
+                F.sort_indices()
+                if F.shape != pat.shape or F.nnz != pat.nnz or not np.array_equal(F.indptr, pat.indptr) \
+                        or not np.array_equal(F.indices, pat.indices):
+                    return None
+                vals.append(np.ascontiguousarray(F.data, dtype=np.float64))
+            # the 1-D element-coupling pattern of the CG degree-p grid: row a couples to [lo(a), lo(a) + n(a))
+            p, nfe = self.p, self.p * self.nels[k] + 1
+            if pat.shape != (nfe, nfe):
+                return None
+            a = np.arange(nfe)
+            vertex = (a % p == 0) & (a > 0)
+            n = np.where(vertex & (a < nfe - 1), 2 * p + 1, p + 1)
+            lo = np.where(vertex, a - p, (a // p) * p)
+            want_ptr = np.concatenate([[0], np.cumsum(n)])
+            if not np.array_equal(pat.indptr, want_ptr) or \
+                    not np.array_equal(pat.indices, np.repeat(lo, n) + (np.arange(want_ptr[-1]) - np.repeat(want_ptr[:-1], n))):
+                return None
+            rp = np.ascontiguousarray(pat.indptr, dtype=np.int32)
+            cl = np.ascontiguousarray(pat.indices, dtype=np.int32)
+            vl = np.ascontiguousarray(np.concatenate(vals), dtype=np.float64)
+            keep += [rp, cl, vl]
+            arr[k].n = pat.shape[0]
+            arr[k].rowptr = rp.ctypes.data_as(c_i32p)
+            arr[k].col = cl.ctypes.data_as(c_i32p)
+            arr[k].val = vl.ctypes.data_as(c_f64p)
+        return nterms, arr, keep
+
+    def planes_kron(self, packed, z0, z1):
+        """x and y passes over the FE planes [z0, z1) of the matrix sum_t kron(F[t][2], F[t][1], F[t][0]) WITHOUT writing
+        it (``packed`` from ``pack_kron_factors``): bit for bit the planes ``planes`` computes from the materialised
+        matrix.  None: the 1-D patterns are not the element-coupling patterns of this patch."""
+        nterms, arr, _keep = packed
+        h = handle()
+        rc = _lib.lib().tg_tensor_planes_kron(self._h, int(nterms), arr, int(z0), int(z1), C.byref(h))
+        if rc == 100:
+            return None
+        check(rc, "tg_tensor_planes_kron")
+        return TensorPlanes(h, int(z0), int(z1))
+
     def split(self, A):
         """(on_pattern, remainder) of a whole FE matrix on this node grid (tg_tensor_split): the entries of A that lie on
         the element-coupling pattern at their places in a matrix that has exactly that pattern, and the others as a CSR
