@@ -379,9 +379,9 @@ def _cpu_sample(d, p, nel, threads, factored=False):
     """One pass of the path on the host for a d-D degree-p patch with nel^d elements: the oracle's C + OpenMP
     restatement (oracle/tigar_oracle_c.c: the CSR algorithms PETSc AIJ runs on the CPU -- row-wise generateM,
     Gustavson PtAP + MatZeroRowsColumns, scatter-add M^T b, Jacobi-CG with PETSc's convergence test) on `threads`
-    threads.  ``factored``: M^T A M as the direction-by-direction product P_z^T(P_y^T(P_x^T A P_x)P_y)P_z with scipy's
-    (single-threaded) sparse products -- the algorithm the GPU path uses, on the CPU.  FE inputs A, b are generated
-    beforehand (untimed, as on the GPU side)."""
+    threads.  ``factored``: M^T A M as the direction-by-direction product P_z^T(P_y^T(P_x^T A P_x)P_y)P_z built from the
+    same C Gustavson kernel -- the algorithm the GPU path uses, on the CPU, so that the algorithmic and the hardware gain
+    separate.  FE inputs A, b are generated beforehand (untimed, as on the GPU side)."""
     import scipy.sparse as sp
     from oracle import tigar_oracle as O
     from oracle import tigar_oracle_c as OC
@@ -405,17 +405,12 @@ def _cpu_sample(d, p, nel, threads, factored=False):
         for side in (0, 1):
             zd += s.getSideDofs(direction, side)
     t1 = time.perf_counter()
+    # (the intermediate A*M is held in blocks of at most 3e8 entries = 3.6 GB: tgo_ptap_blocked)
     if factored:
         M1 = [O.generate_M_tensor(O.BSpline([p], [O.uniform_knots(p, 0., 1., nel)])).tocsr() for _ in range(d)]
-        cur = A.tocsr()
-        for k in range(d):
-            dims = [M1[j].shape[1] if j < k else M1[j].shape[0] for j in range(d)]
-            facs = [M1[j] if j == k else sp.identity(dims[j], format="csr") for j in range(d)]
-            Pk = O.kron_dir0_fastest(facs).tocsr()
-            cur = (Pk.T @ (cur @ Pk)).tocsr()
-        K = O.zero_rows_columns(cur, zd, 1.0)
+        K = OC.ptap_sum_factorised(M1, A, zd, 1.0, max_am_entries=int(3e8))
     else:
-        K = OC.extract_matrix(M, A, zd)
+        K = OC.extract_matrix(M, A, zd, max_am_entries=int(3e8))
     t2 = time.perf_counter()
     rhs = OC.extract_vector(M, b, zd)
     t3 = time.perf_counter()
@@ -436,9 +431,13 @@ def cpu_baseline(d, p, nel_all, nel_one, nel_target, its_target):
     algorithmic gain is visible apart from the hardware gain.  A reported baseline, not a target."""
     from oracle import tigar_oracle_c as OC
     cores = min(32, OC.usable_cores())       # (the samples are small; more threads only add barrier cost)
+    t0 = time.perf_counter()
     allc = _cpu_sample(d, p, nel_all, cores)
+    if time.perf_counter() - t0 > 60.0 and d == 3:
+        nel_one = max(4, min(nel_one, 16))       # (a slow host: keep the whole baseline within a few minutes)
     one = _cpu_sample(d, p, nel_one, 1)
     fac = _cpu_sample(d, p, nel_one, 1, factored=True)
+    log("[bench] cpu baseline: %.1f s in all" % (time.perf_counter() - t0))
 
     def extrapolate(smp):
         ncp_t = (nel_target + p) ** d
@@ -455,8 +454,9 @@ def cpu_baseline(d, p, nel_all, nel_one, nel_target, its_target):
             "one_thread": {"value": one["ncp"] / one["total_s"], "unit": "DoF/s", "sample": fmt(one)},
             "one_thread_sum_factorised_ptap": {"ptap_s": fac["ptap_s"], "gustavson_ptap_s": one["ptap_s"],
                                                "value": fac["ncp"] / fac["total_s"], "unit": "DoF/s",
-                                               "note": "M^T A M as P_z^T(P_y^T(P_x^T A P_x)P_y)P_z with scipy sparse products "
-                                                       "(the GPU path's algorithm on one CPU thread), same sample"},
+                                               "note": "M^T A M as P_z^T(P_y^T(P_x^T A P_x)P_y)P_z, every stage by the same C "
+                                                       "Gustavson kernel (the GPU path's algorithm on one CPU thread), same sample"},
+
             "extrapolated_to_benchmark_size": {
                 "nel": nel_target, "cg_iterations": its_target,
                 "all_cores": extrapolate(allc), "one_thread": extrapolate(one),
@@ -626,10 +626,27 @@ def main():
         if ref:
             out["config"]["general_path_reference"] = ref
     if not args.no_cpu_baseline and res["comm_world"] == 1 and wl in ("cfg1", "cfg2", "cfg3"):   # (rank 0 at N=1 only)
-        # a bounded sample: seconds of work on the 16 cores the GPU box grants (the A*M intermediate of
-        # the Gustavson PtAP needs ~7 GB of host memory at p=3, 40^3 elements)
-        cpu_nel = args.cpu_nel or ({2: 80, 3: 40, 4: 16}.get(p, 16) if d == 3 else min(nel, 256))
-        one_nel = max(4, int(round(cpu_nel * 0.6))) if d == 3 else max(4, cpu_nel // 2)
+        # bounded samples (SURVEY 8d / BASELINE.md section 4 plan 64^3 at p=3): all cores at 64^3 elements when the host has
+        # the memory for it (A 10.7 GB + M, M^T 8.4 GB + blocks of A*M of 3.6 GB; checked against MemAvailable -- a
+        # box must not be driven out of memory), else 48^3 / 40^3; one thread at half that edge (a one-thread 64^3
+        # Gustavson product alone would take over a minute)
+        avail = 0.0
+        try:
+            for line in open("/proc/meminfo"):
+                if line.startswith("MemAvailable:"):
+                    avail = float(line.split()[1]) * 1024.0
+        except OSError:
+            pass
+        if d == 3:
+            def need(n):      # bytes: A, M, M^T, scipy copies and the bounded intermediate, generously
+                c = counts(d, p, n)
+                return 2.2 * 12.0 * c["nnzA"] + 3.0 * 12.0 * c["nnzM"] + 8e9
+            ladder = {2: (128, 96, 80), 3: (64, 48, 40), 4: (32, 24, 16)}.get(p, (16,))
+            cpu_nel = args.cpu_nel or next((n for n in ladder if need(n) <= 0.6 * avail), ladder[-1])
+            one_nel = max(4, int(round(cpu_nel * 0.375)))       # (64 -> 24: a one-thread Gustavson product of a few seconds)
+        else:
+            cpu_nel = args.cpu_nel or min(nel, 256)
+            one_nel = max(4, cpu_nel // 2)
         out["cpu_baseline"] = cpu_baseline(d, p, cpu_nel, one_nel, nel, res["iterations"])
     print(json.dumps(out), flush=True)
 

@@ -139,8 +139,18 @@ static int cmp_i32(const void *a, const void *b) {
 
 /* ---- C = X * Y (Gustavson, row-wise, dense accumulator + marker per thread), columns sorted.
  * Two passes; returns nnz(C).  crp must hold nrx+1 entries. */
+static int64_t spgemm_off(int64_t nrx, int64_t ncy, const int64_t *xrp, const int32_t *xci, const double *xcv,
+                          const int64_t *yrp, const int32_t *yci, const double *ycv, int64_t yoff, int64_t *crp,
+                          int32_t **cci_out, double **ccv_out);
 static int64_t spgemm(int64_t nrx, int64_t ncy, const int64_t *xrp, const int32_t *xci, const double *xcv, const int64_t *yrp,
                       const int32_t *yci, const double *ycv, int64_t *crp, int32_t **cci_out, double **ccv_out) {
+  return spgemm_off(nrx, ncy, xrp, xci, xcv, yrp, yci, ycv, 0, crp, cci_out, ccv_out);
+}
+/* rows of X index the rows of Y shifted by yoff (Y holds the rows yoff, yoff+1, ... of a larger matrix); the row
+ * pointer of X may be a slice of a larger one (entries are addressed by xrp[r] .. xrp[r+1] as they stand) */
+static int64_t spgemm_off(int64_t nrx, int64_t ncy, const int64_t *xrp, const int32_t *xci, const double *xcv,
+                          const int64_t *yrp, const int32_t *yci, const double *ycv, int64_t yoff, int64_t *crp,
+                          int32_t **cci_out, double **ccv_out) {
 #pragma omp parallel
   {
     int64_t *mark = (int64_t *)malloc(sizeof(int64_t) * (size_t)ncy);
@@ -149,7 +159,7 @@ static int64_t spgemm(int64_t nrx, int64_t ncy, const int64_t *xrp, const int32_
     for (int64_t r = 0; r < nrx; r++) {
       int64_t cnt = 0;
       for (int64_t q = xrp[r]; q < xrp[r + 1]; q++) {
-        int32_t k = xci[q];
+        int64_t k = (int64_t)xci[q] - yoff;
         for (int64_t t = yrp[k]; t < yrp[k + 1]; t++)
           if (mark[yci[t]] != r) {
             mark[yci[t]] = r;
@@ -174,7 +184,7 @@ static int64_t spgemm(int64_t nrx, int64_t ncy, const int64_t *xrp, const int32_
     for (int64_t r = 0; r < nrx; r++) {
       int64_t o = crp[r], cnt = 0;
       for (int64_t q = xrp[r]; q < xrp[r + 1]; q++) {
-        int32_t k = xci[q];
+        int64_t k = (int64_t)xci[q] - yoff;
         double xv = xcv[q];
         for (int64_t t = yrp[k]; t < yrp[k + 1]; t++) {
           int32_t c = yci[t];
@@ -258,6 +268,128 @@ int64_t tgo_ptap(int64_t nfe, int64_t ncp, const int64_t *mrp, const int32_t *mc
   g_kci = NULL;
   g_kcv = NULL;
   return 0;
+}
+
+/* ---- the same product with the intermediate A*M bounded: rows of K in blocks; for a block the FE rows its M^T rows
+ * reference form a range [f0, f1) (contiguous z-slabs on a tensor patch), (A M) is computed for that range only, then
+ * M^T[block] * (A M)[f0:f1].  Blocks are cut so that an upper bound of the entries of (A M)[f0:f1] stays below
+ * max_am_entries.  Same two-call protocol and result as tgo_ptap (rows recomputed in overlapping ranges cost time, not
+ * accuracy: every row of K is produced once, in one block). */
+int64_t tgo_ptap_blocked(int64_t nfe, int64_t ncp, const int64_t *mrp, const int32_t *mci, const double *mcv,
+                         const int64_t *arp, const int32_t *aci, const double *acv, const int32_t *zero_dofs, int64_t nzero,
+                         double diag, int64_t max_am_entries, int64_t *krp, int32_t *kcol, double *kval) {
+  if (kcol && kval) {
+    if (!g_krp || g_knr != ncp) return -1;
+    memcpy(krp, g_krp, sizeof(int64_t) * (size_t)(ncp + 1));
+    memcpy(kcol, g_kci, sizeof(int32_t) * (size_t)g_krp[ncp]);
+    memcpy(kval, g_kcv, sizeof(double) * (size_t)g_krp[ncp]);
+    free(g_krp);
+    free(g_kci);
+    free(g_kcv);
+    g_krp = NULL;
+    g_kci = NULL;
+    g_kcv = NULL;
+    return 0;
+  }
+  free(g_krp);
+  free(g_kci);
+  free(g_kcv);
+  int64_t mnnz = mrp[nfe];
+  int64_t *trp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ncp + 1));
+  int32_t *tci = (int32_t *)malloc(sizeof(int32_t) * (size_t)(mnnz > 0 ? mnnz : 1));
+  double *tcv = (double *)malloc(sizeof(double) * (size_t)(mnnz > 0 ? mnnz : 1));
+  csr_transpose(nfe, ncp, mrp, mci, mcv, trp, tci, tcv);
+  /* entries per row of A*M, estimated from the exact count of a sample of rows (a bound from the row lengths alone
+   * overestimates a tensor patch by (p+1)^d: the supports of neighbouring nodes coincide) */
+  double avg_am = 1.0;
+  {
+    const int64_t nsamp = nfe < 2000 ? nfe : 2000;
+    int64_t *mark = (int64_t *)malloc(sizeof(int64_t) * (size_t)ncp);
+    for (int64_t c = 0; c < ncp; c++) mark[c] = -1;
+    int64_t total = 0;
+    for (int64_t sidx = 0; sidx < nsamp; sidx++) {
+      const int64_t f = (nfe * sidx) / nsamp;
+      for (int64_t q = arp[f]; q < arp[f + 1]; q++) {
+        const int32_t k = aci[q];
+        for (int64_t t = mrp[k]; t < mrp[k + 1]; t++)
+          if (mark[mci[t]] != f) {
+            mark[mci[t]] = f;
+            total++;
+          }
+      }
+    }
+    free(mark);
+    avg_am = nsamp > 0 ? 1.15 * (double)total / (double)nsamp + 1.0 : 1.0;
+  }
+  int64_t *ub = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nfe + 1));
+  for (int64_t f = 0; f <= nfe; f++) ub[f] = (int64_t)(avg_am * (double)f);
+  /* FE range referenced by every row of M^T (columns are sorted) */
+  g_krp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ncp + 1));
+  g_krp[0] = 0;
+  int64_t cap = 1 << 20, used = 0;
+  g_kci = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+  g_kcv = (double *)malloc(sizeof(double) * (size_t)cap);
+  int64_t r0 = 0;
+  while (r0 < ncp) {
+    int64_t f0 = nfe, f1 = 0, r1 = r0;
+    while (r1 < ncp) {
+      int64_t lo = f0, hi = f1;
+      if (trp[r1 + 1] > trp[r1]) {
+        if (tci[trp[r1]] < lo) lo = tci[trp[r1]];
+        if ((int64_t)tci[trp[r1 + 1] - 1] + 1 > hi) hi = (int64_t)tci[trp[r1 + 1] - 1] + 1;
+      }
+      if (r1 > r0 && hi > lo && ub[hi] - ub[lo] > max_am_entries) break;
+      f0 = lo;
+      f1 = hi;
+      r1++;
+    }
+    if (f1 > f0) {
+      int64_t nb = f1 - f0;
+      int64_t *amrp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nb + 1));
+      int32_t *amci;
+      double *amcv;
+      spgemm(nb, ncp, arp + f0, aci, acv, mrp, mci, mcv, amrp, &amci, &amcv);
+      int64_t *brp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(r1 - r0 + 1));
+      int32_t *bci;
+      double *bcv;
+      int64_t bnnz = spgemm_off(r1 - r0, ncp, trp + r0, tci, tcv, amrp, amci, amcv, f0, brp, &bci, &bcv);
+      if (used + bnnz > cap) {
+        while (used + bnnz > cap) cap *= 2;
+        g_kci = (int32_t *)realloc(g_kci, sizeof(int32_t) * (size_t)cap);
+        g_kcv = (double *)realloc(g_kcv, sizeof(double) * (size_t)cap);
+      }
+      memcpy(g_kci + used, bci, sizeof(int32_t) * (size_t)bnnz);
+      memcpy(g_kcv + used, bcv, sizeof(double) * (size_t)bnnz);
+      for (int64_t r = r0; r < r1; r++) g_krp[r + 1] = used + brp[r - r0 + 1];
+      used += bnnz;
+      free(amrp);
+      free(amci);
+      free(amcv);
+      free(brp);
+      free(bci);
+      free(bcv);
+    } else
+      for (int64_t r = r0; r < r1; r++) g_krp[r + 1] = used;
+    r0 = r1;
+  }
+  g_knr = ncp;
+  free(trp);
+  free(tci);
+  free(tcv);
+  free(ub);
+  if (nzero > 0) {
+    unsigned char *mask = (unsigned char *)calloc((size_t)ncp, 1);
+    for (int64_t z = 0; z < nzero; z++) mask[zero_dofs[z]] = 1;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < ncp; r++)
+      for (int64_t q = g_krp[r]; q < g_krp[r + 1]; q++) {
+        int32_t c = g_kci[q];
+        if (mask[r] || mask[c]) g_kcv[q] = (mask[r] && c == r) ? diag : 0.0;
+      }
+    free(mask);
+  }
+  if (krp) memcpy(krp, g_krp, sizeof(int64_t) * (size_t)(ncp + 1));
+  return g_krp[ncp];
 }
 
 void tgo_spmv(int64_t nr, const int64_t *rp, const int32_t *ci, const double *cv, const double *x, double *y) {

@@ -36,6 +36,7 @@ def lib():
         L.tgo_num_threads.restype = C.c_int
         L.tgo_generate_M.restype = C.c_int64
         L.tgo_ptap.restype = C.c_int64
+        L.tgo_ptap_blocked.restype = C.c_int64
         L.tgo_cg_jacobi.restype = C.c_int
         _LIB = L
     return _LIB
@@ -108,9 +109,12 @@ def _csr(A):
             np.ascontiguousarray(A.data, dtype=np.float64))
 
 
-def extract_matrix(M, A, zero_dofs, diag=1.0):
-    """M^T A M + MatZeroRowsColumns(zero_dofs, diag) (scipy CSR)."""
+def extract_matrix(M, A, zero_dofs, diag=1.0, max_am_entries=None):
+    """M^T A M + MatZeroRowsColumns(zero_dofs, diag) (scipy CSR).  ``max_am_entries``: bound on the entries of the
+    intermediate A*M held at a time (rows of K in blocks, ``tgo_ptap_blocked``); None: one block."""
     L = lib()
+    if max_am_entries is not None:
+        return _extract_matrix_blocked(M, A, zero_dofs, diag, int(max_am_entries))
     mrp, mci, mcv = _csr(M)
     arp, aci, acv = _csr(A)
     nfe, ncp = M.shape
@@ -124,6 +128,38 @@ def extract_matrix(M, A, zero_dofs, diag=1.0):
     rc = L.tgo_ptap(*args, _p(krp, _i64p), _p(kc, _i32p), _p(kv, _f64p))
     assert rc == 0
     return sp.csr_matrix((kv[:nnz], kc[:nnz], krp), shape=(ncp, ncp))
+
+
+def _extract_matrix_blocked(M, A, zero_dofs, diag, max_am_entries):
+    L = lib()
+    mrp, mci, mcv = _csr(M)
+    arp, aci, acv = _csr(A)
+    nfe, ncp = M.shape
+    zd = np.ascontiguousarray(zero_dofs if zero_dofs is not None else [], dtype=np.int32)
+    krp = np.zeros(ncp + 1, dtype=np.int64)
+    args = (C.c_int64(nfe), C.c_int64(ncp), _p(mrp, _i64p), _p(mci, _i32p), _p(mcv, _f64p), _p(arp, _i64p), _p(aci, _i32p),
+            _p(acv, _f64p), _p(zd, _i32p), C.c_int64(zd.size), C.c_double(diag), C.c_int64(max_am_entries))
+    nnz = L.tgo_ptap_blocked(*args, _p(krp, _i64p), None, None)
+    kc = np.empty(max(nnz, 1), dtype=np.int32)
+    kv = np.empty(max(nnz, 1), dtype=np.float64)
+    rc = L.tgo_ptap_blocked(*args, _p(krp, _i64p), _p(kc, _i32p), _p(kv, _f64p))
+    assert rc == 0
+    return sp.csr_matrix((kv[:nnz], kc[:nnz], krp), shape=(ncp, ncp))
+
+
+def ptap_sum_factorised(M1, A, zero_dofs, diag=1.0, max_am_entries=None):
+    """K = P_z^T (P_y^T (P_x^T A P_x) P_y) P_z with P_k = I (x) M_k (x) I, every stage by the same C Gustavson products
+    as ``extract_matrix`` (the GPU path's algorithm restated on the CPU; M1: the 1-D extraction matrices, direction 0
+    first).  The boundary conditions go with the last stage."""
+    d = len(M1)
+    cur = sp.csr_matrix(A)
+    for k in range(d):
+        dims = [M1[j].shape[1] if j < k else M1[j].shape[0] for j in range(d)]
+        facs = [sp.csr_matrix(M1[j]) if j == k else sp.identity(dims[j], format="csr") for j in range(d)]
+        Pk = O.kron_dir0_fastest(facs).tocsr()
+        last = k == d - 1
+        cur = extract_matrix(Pk, cur, zero_dofs if last else [], diag, max_am_entries)
+    return cur
 
 
 def extract_vector(M, b, zero_dofs):

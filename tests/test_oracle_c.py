@@ -44,3 +44,26 @@ def test_c_twin_periodic_and_nonuniform_rows():
     Mo, Mc = O.generate_M_tensor(s), OC.generate_M_tensor(s)
     assert np.array_equal(Mc.indptr, Mo.indptr) and np.array_equal(Mc.indices, Mo.indices) and np.array_equal(Mc.data, Mo.data)
     assert OC.num_threads() >= 1
+
+
+@pytest.mark.parametrize("d,p,nel", [(2, 3, 6), (3, 2, 5), (3, 3, 3)])
+def test_blocked_and_sum_factorised_products_equal_the_one_block_product(d, p, nel):
+    """tgo_ptap_blocked (rows of K in blocks so that the intermediate A*M stays bounded -- what lets the CPU baseline run at
+    64^3 elements) and the direction-by-direction product built from the same C Gustavson kernel give the K of the plain
+    two-product PtAP: pattern identical, values to rounding; also with blocks of a single row of K."""
+    s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel)] * d)
+    Mo = O.generate_M_tensor(s)
+    Ao, _, _, _ = O.poisson_fe_system(s)
+    rng = np.random.default_rng(5)
+    Ap = Ao.tocsr().copy()
+    Ap.data = Ap.data * (1.0 + 0.3 * rng.standard_normal(Ap.nnz))
+    zd = s.getSideDofs(0, 0) + s.getSideDofs(d - 1, 1)
+    Kref = OC.extract_matrix(Mo, Ap, zd, diag=1.5)
+    for cap in (1, 5000, 10 ** 9):
+        Kb = OC.extract_matrix(Mo, Ap, zd, diag=1.5, max_am_entries=cap)
+        assert np.array_equal(Kb.indptr, Kref.indptr) and np.array_equal(Kb.indices, Kref.indices)
+        assert np.array_equal(Kb.data, Kref.data)                       # the same products in the same order, row by row
+    M1 = [O.generate_M_tensor(O.BSpline([p], [O.uniform_knots(p, 0., 1., nel)])).tocsr() for _ in range(d)]
+    Kf = OC.ptap_sum_factorised(M1, Ap, zd, diag=1.5, max_am_entries=20000)
+    assert np.array_equal(Kf.indptr, Kref.indptr) and np.array_equal(Kf.indices, Kref.indices)
+    assert abs(Kf - Kref).max() <= 1e-13 * abs(Kref).max()
