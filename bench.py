@@ -328,6 +328,7 @@ def run(args, wl, d, p, nel):
                 else:
                     os.environ[k] = v
     if args.companion and fused:
+        extra_step({"TIGAR_PTAP_FUSED": "0"})       # (untimed: the allocator's pool has no blocks of the row-block sizes yet)
         companions["materialised"] = extra_step({"TIGAR_PTAP_FUSED": "0"})
         companions["pattern_verified"] = extra_step({"TIGAR_PTAP_FUSED": "0", "TIGAR_PTAP_VERIFY": "1"})
     elif args.companion and ptap_certified > 0:
