@@ -527,13 +527,13 @@ def main():
     # guide prescribes; committed under profiles/): an OFFLINE measurement, quoted only for the workload and
     # rank count it was taken on
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r2_spmv_pmc_summary.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r3_spmv_pmc_summary.json")
     if wl == "cfg3" and res["comm_world"] == 1 and not args.nel and not args.p and os.path.exists(pmc_file):
         try:
             pmc = json.load(open(pmc_file))
             if kernel in pmc["kernel"]:
                 traffic = pmc["hbm_bytes_per_launch"]
-                traffic_src = ("offline: profiles/r2_spmv_pmc_summary.json (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 "
+                traffic_src = ("offline: profiles/r3_spmv_pmc_summary.json (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 "
                                "correction + WRITE_SIZE, separate passes; not measured in this run)")
         except Exception:
             traffic = None
@@ -615,9 +615,10 @@ def main():
         # the general-CSR contract keeps a tracked number: the same step with the fast path switched off (offline runs,
         # committed under profiles/; A arbitrary sparse in both, M Kronecker in the first, nothing assumed in the second)
         ref = {}
-        for key, fn in (("fe_matrix_pattern_verified_entry_by_entry", "r2_bench_cfg3_pattern_verified.json"),
-                        ("arbitrary_A_kronecker_M_line_kernels", "r2_bench_cfg3_general_line.json"),
-                        ("fully_general_hash_ptap_M_slabs_materialised", "r2_bench_cfg3_general_hash.json")):
+        for key, fn in (("fe_matrix_materialised_in_row_blocks", "r3_bench_cfg3_fe_matrix_materialised.json"),
+                        ("fe_matrix_pattern_verified_entry_by_entry", "r3_bench_cfg3_pattern_verified.json"),
+                        ("arbitrary_A_kronecker_M_line_kernels", "r3_bench_cfg3_general_line.json"),
+                        ("fully_general_hash_ptap_M_slabs_materialised", "r3_bench_cfg3_general_hash.json")):
             try:
                 g = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 ref[key] = {"value": g["value"], "ms_per_step": g["ms_per_step"], "ptap_s": g["config"]["stages_s"]["ptap"],

@@ -163,3 +163,58 @@ def test_default_solver_reorders_field_major_systems_and_hands_large_ones_to_gmr
     r = K3.mult(x3)
     r.axpy(-1.0, b3)
     assert r.norm() <= 1e-9 * b3.norm()
+
+
+def test_default_solver_tries_the_rcm_band_before_giving_lu_up():
+    """linearSolver=None on a field-major three-field system whose band as numbered (~2n/3) is far beyond the direct
+    solver's budget: the reverse Cuthill-McKee band is evaluated before falling back to Jacobi-GMRES, and the system is
+    solved directly like the reference's default LU would; also: a non-zero initial guess set in u reaches the
+    Krylov solver through solveLinearSystem (tIGAr/common.py:1250-1254), and a side-dof list edited in place is honoured."""
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, common as tc, device as dev
+    p, nel, nF = 2, 120, 3
+    kv = [B.uniformKnots(p, 0., 1., nel)] * 2
+    gen = t.EqualOrderSpline(nF, B.ExplicitBSplineControlMesh([p, p], kv))
+    sp0 = gen.getScalarSpline(0)
+    dofs = sp0.getSideDofs(0, 0)
+    ref_sorted = sorted(dofs, reverse=True)
+    dofs.sort(reverse=True)                                  # edited in place, same length: the list must win
+    gen.addZeroDofs(0, dofs)
+    assert gen.zeroDofsArray().tolist() == ref_sorted
+    for f in (1, 2):
+        gen.addZeroDofs(f, gen.getScalarSpline(f).getSideDofs(0, 0))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    pat = __import__("tigar_amd.forms", fromlist=["x"]).LaplaceForm().assemble_matrix(
+        t.TensorFunctionSpace([sp0.generateMesh(degree=p)], "Lagrange")).to_scipy().tocsr()
+    rng = np.random.default_rng(1)
+    blocks = [[None] * nF for _ in range(nF)]
+    for a in range(nF):
+        for b_ in range(nF):
+            Bk = pat.copy()
+            Bk.data = 0.05 * rng.standard_normal(Bk.nnz)
+            blocks[a][b_] = Bk if a != b_ else (Bk + 4.0 * sp.identity(pat.shape[0], format="csr")).tocsr()
+    A = sp.bmat(blocks, format="csr")
+    K = spline.extractMatrix(A)
+    rhs = spline.extractVector(rng.standard_normal(A.shape[0]))
+    kl, ku, nb = dev.lu_band_info(K)
+    assert nb > 8 * 2 ** 30                                   # as numbered: beyond the budget
+    d = tc._default_linear_solver()
+    x = dev.DeviceVector(K.shape[0])
+    d.solve(K, x, rhs)
+    assert d.last["solver"] == "lu" and d.last["reordered"] and d.last["band_bytes"] < 4 * 2 ** 30
+    r = K.mult(x)
+    r.axpy(-1.0, rhs)
+    assert r.norm() <= 1e-10 * rhs.norm()
+    # non-zero initial guess through the public solve path: the solver must start from M^T u as the reference does
+    solver = t.PETScKrylovSolver("gmres", "jacobi")
+    solver.parameters.update({"relative_tolerance": 1e-12, "maximum_iterations": 2, "error_on_nonconvergence": False,
+                              "nonzero_initial_guess": True})
+    spline.setSolverOptions(linearSolver=solver)
+    u = t.Function(spline.V)
+    u.vector().set_local(rng.standard_normal(spline.V.dim()))
+    x0 = spline.M.mult_transpose(u.vector())
+    want = dev.DeviceVector(data=x0.get_local())
+    dev.krylov_solve(K, rhs, want, "gmres", "jacobi", rtol=1e-12, maxit=2, nonzero_initial_guess=True)
+    U = spline.solveLinearSystem(K, rhs, u)
+    assert solver.last["iterations"] == 2
+    assert np.array_equal(U.get_local(), want.get_local())

@@ -325,7 +325,9 @@ class AbstractExtractionGenerator(object):
 
     @zeroDofs.setter
     def zeroDofs(self, value):
-        self.__dict__["_zero_list"] = list(value)
+        # (``self.zeroDofs += [dof]`` hands back the very list the getter returned: keep it, do not copy it per append)
+        if value is not self.__dict__.get("_zero_list"):
+            self.__dict__["_zero_list"] = list(value)
         self.__dict__["_zero_chunks"] = []
 
     def zeroDofsArray(self):
@@ -337,9 +339,12 @@ class AbstractExtractionGenerator(object):
     @staticmethod
     def _index_array(dofs):
         src = getattr(dofs, "array", None)
-        if src is not None and len(src) == len(dofs):       # a list made by getSideDofs, untouched since
+        arr = numpy.asarray(dofs, dtype=numpy.int64).reshape(-1)
+        # a list made by getSideDofs carries its numpy twin; it is trusted only while the list still says the same
+        # (a list edited in place with its length kept -- dofs[i] = ..., sort(), reverse() -- must win)
+        if src is not None and len(src) == arr.size and numpy.array_equal(src, arr):
             return src
-        return numpy.asarray(dofs, dtype=numpy.int64).reshape(-1)
+        return arr
 
     def addZeroDofsGlobal(self, newDofs):
         self.__dict__.setdefault("_zero_chunks", []).append(numpy.array(self._index_array(newDofs), dtype=numpy.int64))
@@ -984,8 +989,26 @@ class _DefaultSolver(object):
             lu = PETScLUSolver()
             kl, ku, nb = _dev.lu_band_info(A)
             flops = 2.0 * A.shape[0] * kl * (kl + ku)
-            if (nb <= 8 * 2 ** 30 and flops <= 4e12 and A.shape[0] <= 400000) or \
-                    os.environ.get("TIGAR_DEFAULT_SOLVER") == "lu":
+            fits = nb <= 8 * 2 ** 30 and flops <= 4e12 and A.shape[0] <= 400000
+            if not fits and A.shape[0] <= 400000 and A.nnz <= 2e8:
+                # as numbered the band is too wide -- field-major systems of several fields (kl ~ n (nF-1)/nF): the saddle
+                # point and elasticity cases where the reference's direct solver matters.  Evaluate the band of the
+                # reverse Cuthill-McKee ordering of the pattern before giving LU up.
+                import scipy.sparse as _sp
+                from scipy.sparse.csgraph import reverse_cuthill_mckee
+                S = A.to_scipy()
+                pat = _sp.csr_matrix((numpy.ones(S.nnz, dtype=numpy.int8), S.indices, S.indptr), shape=S.shape)
+                prm = numpy.asarray(reverse_cuthill_mckee((pat + pat.T).tocsr(), symmetric_mode=True), dtype=numpy.int64)
+                inv = numpy.empty_like(prm)
+                inv[prm] = numpy.arange(prm.size)
+                coo = S.tocoo()
+                dist = inv[coo.row] - inv[coo.col]
+                kl2, ku2 = int(max(0, dist.max())), int(max(0, -dist.min()))
+                nb2 = 8.0 * A.shape[0] * (2 * kl2 + ku2 + 1)
+                if nb2 <= 8 * 2 ** 30 and 2.0 * A.shape[0] * kl2 * (kl2 + ku2) <= 4e12:
+                    fits = True
+                    lu.parameters["reorder"] = True
+            if fits or os.environ.get("TIGAR_DEFAULT_SOLVER") == "lu":
                 lu.solve(A, x, b)
                 self.last = dict(lu.last, solver="lu")
                 return 1
@@ -1342,6 +1365,9 @@ class ExtractedSpline(object):
         tight tolerance beyond, with a message that says so."""
         MTU = DeviceVector(MTAM.shape[0])          # (local rows of MTAM: all of them on one rank)
         solver = self.linearSolver if self.linearSolver is not None else _default_linear_solver()
+        if getattr(solver, "parameters", {}).get("nonzero_initial_guess", False) and not self._distributed():
+            # the reference sizes AND seeds MTU = M^T u.vector() (tIGAr/common.py:1250-1254): a guess set in u is used
+            self.M.mult_transpose(_as_device_vector(u), MTU)
         if self._distributed() and getattr(solver, "comm", False) is None:
             solver.comm = self.comm.device()
         solver.solve(MTAM, MTU, MTb)

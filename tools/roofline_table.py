@@ -1,10 +1,14 @@
-"""profiles/r2_roofline_table.md from the committed per-kernel durations (tools/kernel_trace.py --sum) and PMC byte counts
-(tools/pmc_hbm.py) of each workload.  usage: python tools/roofline_table.py > profiles/r2_roofline_table.md"""
-import json, os, re
+"""profiles/r<N>_roofline_table.md from the committed per-kernel durations (tools/kernel_trace.py --sum) and PMC byte
+counts (tools/pmc_hbm.py) of each workload.  usage: python tools/roofline_table.py [round] > profiles/r3_roofline_table.md"""
+import json, os, re, sys
 
 HERE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-WORK = [("cfg3 (256^3 p=3)", "r2_cfg3_kernel_stats.txt", "r2_cfg3_pmc_hbm.json"),
-        ("cfg2 (128^3 p=2)", "r2_cfg2_kernel_stats.txt", "r2_cfg2_pmc_hbm.json")]
+RND = sys.argv[1] if len(sys.argv) > 1 else "3"
+WORK = [("cfg3 (256^3 p=3)", "r%s_cfg3_kernel_stats.txt" % RND, "r%s_cfg3_pmc_hbm.json" % RND),
+        ("cfg2 (128^3 p=2)", "r%s_cfg2_kernel_stats.txt" % RND, "r%s_cfg2_pmc_hbm.json" % RND),
+        ("cfg4 (256^2 p=4, CG)", "r%s_cfg4_kernel_stats.txt" % RND, "r%s_cfg4_pmc_hbm.json" % RND),
+        ("cfg5 (128^2 p=3, 3 fields)", "r%s_cfg5_kernel_stats.txt" % RND, "r%s_cfg5_pmc_hbm.json" % RND)]
+WORK = [w for w in WORK if os.path.exists(os.path.join(HERE, w[1])) and os.path.exists(os.path.join(HERE, w[2]))]
 
 
 def short(name):
@@ -12,16 +16,17 @@ def short(name):
 
 
 def main():
-    print("# Achieved HBM rates per kernel, round 2 (one MI355X)\n")
-    print("Per launch: average duration from `rocprofv3 --kernel-trace` (`r2_cfg*_kernel_stats.txt`, summarised from the trace\n"
-          "database by `tools/kernel_trace.py --sum`; `r2_cfg*_rocprofv3_kernel_stats.csv` is rocprofv3's own `--stats` output of\n"
-          "the same command, `--output-format csv`), HBM bytes from the PMC passes (`r2_cfg*_pmc_hbm.json`: FETCH_SIZE and\n"
+    print("# Achieved HBM rates per kernel, round %s (one MI355X)\n" % RND)
+    print("Per launch: average duration from `rocprofv3 --kernel-trace` (`rN_cfg*_kernel_stats.txt`, summarised from the trace\n"
+          "database by `tools/kernel_trace.py --sum`; `rN_cfg*_rocprofv3_kernel_stats.csv` is rocprofv3's own `--stats` output of\n"
+          "the same command, `--output-format csv`), HBM bytes from the PMC passes (`rN_cfg*_pmc_hbm.json`: FETCH_SIZE and\n"
           "WRITE_SIZE in separate runs, reads x2 = the gfx950 correction of the guide, calibrated for 8 B/lane streams by\n"
           "`k_cg1_dot` / `k_cg1_update`, DESIGN.md section 5).  Rate = (read + written) / duration, as a fraction of the 8 TB/s\n"
           "HBM3E peak and of the ceiling a plain streaming kernel of the same read:write mix reaches on these boxes\n"
           "(`r2_hbm_ceilings.txt`, `tools/mb/write_bw.hip`: pure read 6.2-6.4, pure write 5.9-6.6, mixed 5.1-5.3 TB/s; the\n"
           "rate of a buffer depends on where it was placed, 5.6-6.7 for pure writes).  Durations and counters come from\n"
-          "different runs of the same command, so rows of kernels whose launches vary in size (sub-slabs) are averages.\n")
+          "different runs of the same command, so rows of kernels whose launches vary in size (sub-slabs) are averages.\n"
+          "(rN = r%s in the file names.)\n" % RND)
     print("| workload | kernel | avg ms | read GB | written GB | TB/s | of 8 TB/s | of the streaming ceiling |")
     print("|---|---|---|---|---|---|---|---|")
     for label, fstats, fpmc in WORK:
