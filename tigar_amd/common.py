@@ -941,7 +941,10 @@ class PETScLUSolver(object):
             import scipy.sparse as _sp
             from scipy.sparse.csgraph import reverse_cuthill_mckee
             S = A.to_scipy()
-            pat = (abs(S) + abs(S.T)).tocsr()
+            # (the STORED pattern: entries zeroed by MatZeroRowsColumns stay in the band storage, so they must stay in
+            #  the graph -- scipy's sum of abs(S) would drop them and leave the boundary dofs isolated)
+            ones = _sp.csr_matrix((numpy.ones(S.nnz, dtype=numpy.int8), S.indices, S.indptr), shape=S.shape)
+            pat = (ones + ones.T).tocsr()
             prm = numpy.asarray(reverse_cuthill_mckee(pat, symmetric_mode=True), dtype=numpy.int64)
             Sp = S[prm][:, prm].tocsr()
             Ap = DeviceCSR.from_scipy(Sp)
