@@ -109,6 +109,8 @@ int tg_csr_transpose(tg_csr_t m, tg_csr_t *out);
 int tg_csr_add(tg_csr_t a, tg_csr_t b, tg_csr_t *out);
 int tg_csr_block(tg_csr_t a, int64_t r0, int64_t r1, int64_t c0, int64_t c1, tg_csr_t *out);
 int tg_csr_from_blocks(int nf, const tg_csr_t *blocks, tg_csr_t *out);
+/* out row r = row rows[r] of a (host index array; any selection or order, repetitions allowed), columns untouched */
+int tg_csr_gather_rows(tg_csr_t a, const int64_t *rows, int64_t n, tg_csr_t *out);
 int tg_partition_mode(tg_csr_t mt, const int32_t *fe_owner, int world, int32_t *owner_out);
 int tg_csr_permute_columns(tg_csr_t m, const int32_t *new_of_old, tg_csr_t *out);
 /* fallback for arbitrary AbstractScalarBasis plug-ins (seam b-2, tIGAr/common.py:1683-1692):

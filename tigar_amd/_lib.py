@@ -90,6 +90,7 @@ PROTOTYPES = {
     "tg_tensor_split": (C.c_int, [handle, handle, C.POINTER(handle), C.POINTER(handle)]),
     "tg_csr_block": (C.c_int, [handle, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(handle)]),
     "tg_csr_from_blocks": (C.c_int, [C.c_int, C.POINTER(handle), C.POINTER(handle)]),
+    "tg_csr_gather_rows": (C.c_int, [handle, c_i64p, C.c_int64, C.POINTER(handle)]),
     "tg_partition_mode": (C.c_int, [handle, c_i32p, C.c_int, c_i32p]),
     "tg_csr_permute_columns": (C.c_int, [handle, c_i32p, C.POINTER(handle)]),
     "tg_csr_from_triplets": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f64p,

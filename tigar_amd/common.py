@@ -213,8 +213,12 @@ class Function(object):
         self.V = V
         # with several ranks a function holds the FE rows [r0, r1) its rank owns (set by the solve)
         self.local_range = local_range
-        self._vec = vector if vector is not None else \
-            DeviceVector(V.dim() if local_range is None else local_range[1] - local_range[0])
+        # (several fields with several ranks: one range per field, a list of (r0, r1))
+        if local_range is not None and len(local_range) and isinstance(local_range[0], (tuple, list)):
+            nloc = sum(int(b) - int(a) for a, b in local_range)
+        else:
+            nloc = V.dim() if local_range is None else local_range[1] - local_range[0]
+        self._vec = vector if vector is not None else DeviceVector(nloc)
 
     def vector(self):
         return self._vec
@@ -398,7 +402,9 @@ class AbstractExtractionGenerator(object):
         # enables the sum-factorised M^T A M of tigar_amd/kronptap.py
         self._kron = None
         self._kron_scalar = None           # several fields on ONE tensor basis (EqualOrderSpline(nFields > 1)): its tables
-        if getattr(self.M, "is_implicit", False):
+        if getattr(self.M, "is_implicit", False) and getattr(self.M, "nfields", 1) > 1:
+            self._kron_scalar = self.M.kx        # diag(M_s, ..., M_s), never stored
+        elif getattr(self.M, "is_implicit", False):
             self._kron = self.M.kx
         elif self.getNFields() == 1 and (0, 0) in self._fast_blocks or (self.M is self.M_control
                                                                           and (-1, 0) in self._fast_blocks):
@@ -542,8 +548,8 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
             if support_only:
                 return _dev.extract_csr_tensor(basis.splines, grid.axes, col_offset, ncols, eps)
             self._fast_blocks[(field, col_offset)] = (basis, grid)
-            if field == -1 and self._single_shared_field():
-                lazy = self._implicit_block(basis, grid, eps)
+            if field == -1 and (self._single_shared_field() or self._fields_on_control_basis()):
+                lazy = self._implicit_block(basis, grid, eps, several_fields=not self._single_shared_field())
                 if lazy is not None:
                     return lazy
             # exact Kronecker form (every product of stored 1-D entries passes the filter, checked on the 1-D
@@ -577,6 +583,11 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
         """one unknown field on the control mesh's own basis: M is M_control"""
         return False
 
+    def _fields_on_control_basis(self):
+        """every unknown field is discretised with the control mesh's scalar basis (EqualOrderSpline): M is the block
+        diagonal of M_control"""
+        return False
+
     def _kron_tables(self, basis, grid):
         """1-D extraction tables of a tensor basis on its grid (``KronExtraction``), built once per (basis, grid)"""
         cache = self.__dict__.setdefault("_kx_cache", {})
@@ -589,7 +600,7 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
                 cache[key] = (None, basis, grid)
         return cache[key][0]
 
-    def _implicit_block(self, basis, grid, eps):
+    def _implicit_block(self, basis, grid, eps, several_fields=False):
         """``ImplicitExtraction`` in place of the CSR block when M (and M^T) would not fit beside the rest of
         the path -- 24 B per entry against a third of the free HBM -- or when the patch is spread over several
         ranks (no rank ever holds all rows); TIGAR_IMPLICIT_M=1/0 forces / forbids it.  Only offered when M
@@ -605,8 +616,9 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
             return None
         if env != "1" and self.comm.size == 1:
             free_b = _dev.mem_info()[0] + _dev.pool_stats()[0]      # idle blocks of the caching allocator count as free
-            if 24.0 * kx.nnz_product + 16.0 * grid.num_nodes() <= free_b / 3.0:
-                return None
+            nf = self.getNFields() if several_fields else 1
+            if several_fields or 24.0 * nf * kx.nnz_product + 16.0 * nf * grid.num_nodes() <= free_b / 3.0:
+                return None                     # (several fields on one rank: stored, block by block as before)
         return ImplicitExtraction(kx, eps)
 
     def generateM_control(self):
@@ -648,6 +660,12 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
         (tIGAr/common.py:1516-1578): one row block per field, column offset = sum of the
         previous fields' ncp."""
         totalDofs = sum(self.getNcp(i) for i in range(self.getNFields()))
+        if self.getNFields() > 1 and not support_only and self._fields_on_control_basis() and \
+                getattr(getattr(self, "M_control", None), "is_implicit", False):
+            # several ranks (or TIGAR_IMPLICIT_M=1): no rank holds all rows -- the block diagonal of the implicit
+            # scalar operator stands in for the matrix
+            from .implicit import BlockImplicitExtraction
+            return BlockImplicitExtraction(self.M_control.kx, self.getNFields(), self.M_control.eps)
         blocks = []
         offset = 0
         for field in range(self.getNFields()):
@@ -820,6 +838,9 @@ class EqualOrderSpline(AbstractMultiFieldSpline):
 
     def _single_shared_field(self):
         return self.numFields == 1
+
+    def _fields_on_control_basis(self):
+        return True
 
     def generateM(self, support_only=False):
         # one unknown field on the control mesh's basis: M is M_control (same rows, same
@@ -1133,11 +1154,19 @@ class ExtractedSpline(object):
         """The z-slab engine (``tigar_amd.dist.SlabHotPath``) behind extractMatrix / extractVector /
         solveLinearSystem when M is implicit or the patch is spread over several ranks: rows of K in
         sub-slabs of dof planes, only K resident (PETSc's row-block MatPtAP, tIGAr/common.py:1194-1195)."""
-        if self._slab is None and getattr(self, "_generator_engine", None) is not None:
+        if self._slab is None and getattr(self, "_generator_engine", None) is not None and self.nFields == 1:
             self._slab = self._generator_engine
+        if self._slab is None and self._kron is None and getattr(self, "_kron_scalar", None) is not None:
+            # several fields on one tensor basis: the scalar engine per block, fields interleaved plane by plane
+            from .dist import FieldSlabPath
+            kx = self._kron_scalar
+            dc = self.comm.device() if self._distributed() else None
+            self._slab = FieldSlabPath(kx.basis, kx.grid, self.nFields, self.comm.rank if dc is not None else 0,
+                                       self.comm.size if dc is not None else 1, dc, sub_planes="auto",
+                                       eps=getattr(self.M, "eps", DEFAULT_BASIS_FUNC_IGNORE_EPS), kx=kx)
         if self._slab is None:
             if self._kron is None:
-                raise NotImplementedError("the streamed / multi-GPU path needs a single tensor-product B-spline field")
+                raise NotImplementedError("the streamed / multi-GPU path needs tensor-product B-spline fields on one basis")
             from .dist import SlabHotPath
             kx = self._kron
             dc = self.comm.device() if self._distributed() else None
@@ -1148,13 +1177,24 @@ class ExtractedSpline(object):
 
     def localDofRange(self):
         """IGA dofs [g0, g1) owned by this rank (PETSc getOwnershipRange of MTAM's rows)."""
-        if self._distributed():
+        if self._distributed() or (self._implicit() and self.nFields > 1):
             return self._slab_path().mine["dofs"]
         return (0, self.M.shape[1])
 
+    def localDofIndices(self):
+        """Reference (field-after-field) index of every entry of this rank's IGA vectors and rows of MTAM, in local order.
+        One field: the contiguous range ``localDofRange()``.  Several fields on several ranks: the dofs are renumbered
+        plane by plane across the fields so that a rank's block stays contiguous (``tigar_amd.dist.FieldSlabPath``) -- as
+        the reference renumbers the IGA dofs for parallel runs (generatePermutation, tIGAr/common.py:1583-1665)."""
+        sp_ = self._slab_path() if (self._distributed() or self._implicit()) else None
+        if sp_ is not None and hasattr(sp_, "local_dof_indices"):
+            return sp_.local_dof_indices()
+        g0, g1 = self.localDofRange()
+        return numpy.arange(g0, g1, dtype=numpy.int64)
+
     def localFERange(self):
-        """FE rows whose prolongation u = M U this rank computes."""
-        if self._distributed():
+        """FE rows whose prolongation u = M U this rank computes (several fields: one range per field)."""
+        if self._distributed() or (self._implicit() and self.nFields > 1):
             return self._slab_path().mine["u_rows"]
         return (0, self.M.shape[0])
 
@@ -1163,7 +1203,9 @@ class ExtractedSpline(object):
         """Apply extraction to an FE vector ``b``: ``M^T b``, zeroed at ``zeroDofs`` if
         ``applyBCs`` (tIGAr/common.py:1142-1160)."""
         from .implicit import LazyFEVector
-        if isinstance(b, LazyFEVector) or self._distributed():
+        if isinstance(b, LazyFEVector) or self._distributed() or (self._implicit() and self.nFields > 1):
+            # (several fields with an implicit operator: the field-block engine and its plane-wise numbering, also on
+            #  one rank -- K, M^T b and U must share it)
             if isinstance(b, LazyFEVector):
                 rows = b.rows
             else:
@@ -1203,6 +1245,10 @@ class ExtractedSpline(object):
         zd = self.zeroDofs if applyBCs else None
         if isinstance(A, LazyFEMatrix) or self._distributed():
             a_fac = None
+            if self.nFields > 1 and self._kron is None and getattr(self, "_kron_scalar", None) is not None:
+                return self._slab_path().assemble_matrix(self._block_producer(A), zd, float(diag),
+                                                         getattr(self, "stage_timers", None),
+                                                         block_factors=getattr(A, "block_factors", None))
             if isinstance(A, LazyFEMatrix):
                 a_rows = A.rows
                 a_fac = A.kron_factors
@@ -1262,6 +1308,20 @@ class ExtractedSpline(object):
             # recomputes the symbolic product on every call (tIGAr/common.py:1194-1195) -- plan again
             self._ptap_plan = _dev.ptap_symbolic(A, self.M, self.MT)
             return _dev.ptap_numeric(self._ptap_plan, A, self.M, self.MT, zd, float(diag))
+
+    def _block_producer(self, A):
+        """``a_block(f, g, r0, r1)`` for the field-block engine: rows [r0, r1) of block (f, g) of an FE matrix on the mixed
+        space, columns of one field; None where the producer says the fields are not coupled"""
+        from .implicit import LazyFEMatrix
+        nfe = self.V.dim() // self.nFields
+        if isinstance(A, LazyFEMatrix) and getattr(A, "block_rows", None) is not None:
+            return A.block_rows
+        rows = A.rows if isinstance(A, LazyFEMatrix) else self._row_blocks_of(A)
+
+        def a_block(f, g, r0, r1):
+            blk = rows(f * nfe + int(r0), f * nfe + int(r1))
+            return blk.block(0, int(r1) - int(r0), g * nfe, (g + 1) * nfe)
+        return a_block
 
     @staticmethod
     def _row_blocks_of(A):
@@ -1351,6 +1411,10 @@ class ExtractedSpline(object):
                 if hasattr(form, "factors") and getattr(form, "geometry", None) is None and self.nFields == 1:
                     fac = form.factors(self.V)          # Kronecker sum of 1-D matrices: may be fused into the PtAP
                 A = LazyFEMatrix(lambda r0, r1: form.assemble_matrix(self.V, r0, r1), (n, n), kron_factors=fac)
+                if self.nFields > 1 and hasattr(form, "assemble_block"):
+                    # forms on a mixed space hand out their field blocks (rows of one block, columns of one field)
+                    A.block_rows = lambda f, g, r0, r1: form.assemble_block(self.V, f, g, r0, r1)
+                    A.block_factors = form.block_factors(self.V) if hasattr(form, "block_factors") else None
             else:
                 A = form.assemble_matrix(self.V)
         else:
@@ -1374,7 +1438,7 @@ class ExtractedSpline(object):
         if self._distributed() and getattr(solver, "comm", False) is None:
             solver.comm = self.comm.device()
         solver.solve(MTAM, MTU, MTb)
-        if self._distributed():
+        if self._distributed() or (self._implicit() and self.nFields > 1):
             # u = M U on the FE rows this rank owns, U with its halo (tIGAr/common.py:1259-1261:
             # M*MTU followed by the ghost update)
             u_loc = self._slab_path().prolong(MTU)

@@ -1061,3 +1061,71 @@ extern "C" int tg_csr_combine(double a, tg_csr_t X, double b, tg_csr_t Y, tg_vec
   *out = m;
   return 0;
 }
+
+// ----------------------------------------------------------------------------------------
+// out row r = a row rows[r]: any selection / reordering of rows (with repetitions), columns untouched.  Used to bring
+// the row blocks of a multi-field product from field-major order into the plane-interleaved order of the
+// distributed numbering (tigar_amd/dist.py: FieldSlabPath).
+__global__ void k_gather_len(const int64_t *__restrict__ arp, const int64_t *__restrict__ rows, int64_t n,
+                             int64_t *__restrict__ len) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) len[r] = arp[rows[r] + 1] - arp[rows[r]];
+}
+__global__ void __launch_bounds__(256)
+    k_gather_copy(const int64_t *__restrict__ arp, const int32_t *__restrict__ ac, const double *__restrict__ av,
+                  const int64_t *__restrict__ rows, int64_t n, const int64_t *__restrict__ orp, int32_t *__restrict__ oc,
+                  double *__restrict__ ov) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n; r += nwaves) {
+    const int64_t a = arp[rows[r]], len = arp[rows[r] + 1] - a, o = orp[r];
+    for (int64_t q = lane; q < len; q += 64) {
+      oc[o + q] = ac[a + q];
+      ov[o + q] = av[a + q];
+    }
+  }
+}
+
+extern "C" int tg_csr_gather_rows(tg_csr_t a, const int64_t *rows, int64_t n, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(a && out && n >= 0 && (rows || n == 0), "bad arguments to tg_csr_gather_rows");
+  TG_REQUIRE_CANONICAL(a);
+  for (int64_t r = 0; r < n; r++)
+    TG_REQUIRE(rows[r] >= 0 && rows[r] < a->nrows, "tg_csr_gather_rows: row %lld out of range", (long long)rows[r]);
+  int64_t *d_rows = nullptr, *len = nullptr;
+  tg_csr_s *m = nullptr;
+  int rc = tg_dmalloc(&d_rows, std::max<int64_t>(n, 1));
+  if (!rc) rc = tg_dmalloc(&len, n + 1);
+  if (!rc && n > 0 &&
+      hipMemcpyAsync(d_rows, rows, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess)
+    rc = 1;
+  int64_t total = 0;
+  if (!rc && n > 0) {
+    hipLaunchKernelGGL(k_gather_len, dim3(tg_grid_1d(n, 256)), dim3(256), 0, g_tg.stream, a->rowptr, d_rows, n, len);
+    if (hipGetLastError() != hipSuccess) rc = 1;
+  }
+  if (!rc) rc = tg_exclusive_scan_i64(len, n, &total);
+  if (!rc) rc = tg_csr_alloc(n, a->ncols, total, &m);
+  if (!rc) {
+    if (hipMemcpyAsync(m->rowptr, len, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess)
+      rc = 1;
+    if (!rc && n > 0 && total > 0) {
+      const unsigned grid = (unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 32);
+      hipLaunchKernelGGL(k_gather_copy, dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val, d_rows, n,
+                         m->rowptr, m->col, m->val);
+      if (hipGetLastError() != hipSuccess) rc = 1;
+    }
+  }
+  if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;     // (`rows` is the caller's host array)
+  tg_dfree(d_rows);
+  tg_dfree(len);
+  if (rc) {
+    if (m) tg_csr_destroy(m);
+    tg_set_error("tg_csr_gather_rows failed");
+    return 1;
+  }
+  m->nnz = total;
+  *out = m;
+  return 0;
+}

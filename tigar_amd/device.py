@@ -218,6 +218,13 @@ class DeviceCSR(object):
         check(_lib.lib().tg_csr_block(self._h, int(r0), int(r1), int(c0), int(c1), C.byref(h)), "tg_csr_block")
         return DeviceCSR(h)
 
+    def gather_rows(self, rows):
+        """new matrix whose row r is row ``rows[r]`` of this one (tg_csr_gather_rows)"""
+        m = np.ascontiguousarray(rows, dtype=np.int64)
+        h = handle()
+        check(_lib.lib().tg_csr_gather_rows(self._h, m.ctypes.data_as(c_i64p), m.size, C.byref(h)), "tg_csr_gather_rows")
+        return DeviceCSR(h)
+
     def permute_columns(self, new_of_old):
         """copy with column c renamed ``new_of_old[c]`` and rows re-sorted (MatPermute with identity rows)"""
         m = np.ascontiguousarray(new_of_old, dtype=np.int32)

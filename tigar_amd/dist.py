@@ -492,3 +492,132 @@ class SlabHotPath(object):
         if self.kron_exact:
             return self._prolong_tensor(x, x_col0 // self.layout.plane_dofs)
         return dev.extract_apply_tensor(self.basis.splines, self.grid.axes, 0, self.eps, x, x_col0, r0, r1)
+
+
+class FieldSlabPath(object):
+    """The z-slab path for ``nfields`` fields on ONE tensor basis (M = diag(M_s, ..., M_s); the reference numbers such dofs
+    field after field, tIGAr/common.py:242-252).  A rank owns the dof planes [k0, k1) of EVERY field, so that its rows of
+    K form one contiguous block and the Krylov halo is p planes on either side, the distributed numbering interleaves
+    the fields plane by plane:
+
+        new index of (field f, plane k, in-plane index ij)  =  k * nF * pd  +  f * pd  +  ij      (pd = dofs per plane)
+
+    -- a renumbering of the IGA dofs for parallel runs as the reference's ``generatePermutation`` is one
+    (``local_dof_indices()`` gives the reference index of every local entry).  Block (f, g) of the product is M_s^T A_fg M_s:
+    the scalar ``SlabHotPath`` computes its rows for the rank's planes (tensor-pattern passes, fused Kronecker forms,
+    general stages -- whatever the block qualifies for), the blocks are put together, rows and columns brought into the
+    interleaved order, and MatZeroRowsColumns is applied to the whole (tIGAr/common.py:1194-1200)."""
+
+    def __init__(self, basis, grid, nfields, rank=0, world=1, comm=None, sub_planes="auto", eps=1e-15, kx=None):
+        from . import device as dev
+        self.dev = dev
+        self.nF = int(nfields)
+        # the scalar engine never talks to the communicator: the slab of the Krylov vectors is set here, for all fields
+        self.scalar = SlabHotPath(basis, grid, rank, world, None, sub_planes, eps, kx=kx)
+        self.rank, self.world, self.comm = rank, world, comm
+        S = self.scalar
+        self.layout = S.layout
+        self.pd = S.layout.plane_dofs
+        self.k0, self.k1 = S.k0, S.k1
+        self.ncp1 = S.ncp                       # dofs of one field
+        self.nfe1 = S.n_fe
+        self.ncp = self.nF * self.ncp1
+        self.sub_planes = S.sub_planes
+        nF, pd = self.nF, self.pd
+        hl, hh = S.mine["halo"][0] // pd, S.mine["halo"][1] // pd
+        self.halo_planes = (hl, hh)
+        ur = S.mine["u_rows"]
+        self.mine = {"dofs": (self.k0 * nF * pd, self.k1 * nF * pd),
+                     "halo": (hl * nF * pd, hh * nF * pd),
+                     "u_rows": [(f * self.nfe1 + ur[0], f * self.nfe1 + ur[1]) for f in range(nF)]}
+        if comm is not None and world > 1:
+            comm.set_slab(self.mine["dofs"][0], self.mine["dofs"][1], self.mine["halo"][0], self.mine["halo"][1], self.ncp)
+
+    # ---- numbering ------------------------------------------------------------------------------------------
+    def new_of_old(self):
+        """distributed index of every reference (field-major) dof"""
+        nF, pd, n1 = self.nF, self.pd, self.ncp1
+        old = np.arange(self.ncp, dtype=np.int64)
+        f, s = old // n1, old % n1
+        return (s // pd) * (nF * pd) + f * pd + (s % pd)
+
+    def local_dof_indices(self):
+        """reference (field-major) index of every entry of this rank's vectors / rows of K, in local order"""
+        nF, pd, n1 = self.nF, self.pd, self.ncp1
+        loc = np.arange(self.mine["dofs"][0], self.mine["dofs"][1], dtype=np.int64)
+        k, r = loc // (nF * pd), loc % (nF * pd)
+        return (r // pd) * n1 + k * pd + (r % pd)
+
+    def _interleave_vec(self, parts):
+        """[field][plane-major local] -> local vector in the interleaved order"""
+        dev, nF, pd = self.dev, self.nF, self.pd
+        nk = self.k1 - self.k0
+        out = dev.DeviceVector(nk * nF * pd)
+        for k in range(nk):
+            for f in range(nF):
+                dev.vec_copy_range(out, (k * nF + f) * pd, parts[f], k * pd, pd)
+        return out
+
+    # ---- the path ---------------------------------------------------------------------------------------------
+    def assemble_matrix(self, a_block, zero_dofs, diag=1.0, timers=None, block_factors=None):
+        """``a_block(f, g, r0, r1)``: rows [r0, r1) of block (f, g) of the FE matrix as a DeviceCSR with the columns of
+        ONE field (0 .. nfe-1), or None when the fields are not coupled; ``block_factors[f][g]``: the block as a
+        Kronecker sum of 1-D matrices (fused into the first pass where the patch qualifies)."""
+        dev, S, nF, pd = self.dev, self.scalar, self.nF, self.pd
+        nloc1 = (self.k1 - self.k0) * pd
+        import scipy.sparse as sp
+        blocks = []
+        for f in range(nF):
+            row = []
+            for g in range(nF):
+                fac = block_factors[f][g] if block_factors is not None else None
+                ar = S.mine["a_rows"]
+                probe = a_block(f, g, ar[0], min(ar[0] + 1, ar[1])) if fac is not None else a_block(f, g, ar[0], ar[1])
+                if probe is None or (fac is None and probe.nnz == 0):
+                    # fields f and g are not coupled (on this rank's rows): no entries in this block of the product
+                    row.append(dev.DeviceCSR.from_scipy(sp.csr_matrix((nloc1, self.ncp1))))
+                    continue
+                del probe
+                S._tensor_declined = False          # (every block is judged on its own pattern)
+                Kfg = S.assemble(lambda r0, r1, f=f, g=g: a_block(f, g, r0, r1), None, None, 1.0, timers, fac)[0]
+                row.append(Kfg)
+            blocks.append(row)
+        K = dev.csr_from_blocks(blocks)            # rows (f, k - k0, ij) local, columns (g, k', ij') field-major
+        del blocks
+        nk = self.k1 - self.k0
+        # rows into (k, f, ij) order
+        l = np.arange(nk * nF * pd, dtype=np.int64)
+        k, r = l // (nF * pd), l % (nF * pd)
+        K = K.gather_rows((r // pd) * (nk * pd) + k * pd + (r % pd))
+        n2o = self.new_of_old()
+        K = K.permute_columns(n2o)
+        if zero_dofs is not None and len(zero_dofs):
+            K.zero_rows_cols(n2o[np.asarray(zero_dofs, dtype=np.int64)].astype(np.int32), diag, self.mine["dofs"][0])
+        return K
+
+    def assemble_vector(self, b_rows, zero_dofs=None, timers=None):
+        dev, S, nF = self.dev, self.scalar, self.nF
+        parts = [S.assemble_vector(lambda r0, r1, f=f: b_rows(f * self.nfe1 + r0, f * self.nfe1 + r1), None, timers)
+                 for f in range(nF)]
+        y = self._interleave_vec(parts)
+        if zero_dofs is not None and len(zero_dofs):
+            y.zero_entries(self.new_of_old()[np.asarray(zero_dofs, dtype=np.int64)].astype(np.int32), self.mine["dofs"][0])
+        return y
+
+    def prolong(self, U):
+        """FE rows of u = M U this rank owns, field after field (``mine["u_rows"]``), from the local U (interleaved)"""
+        dev, S, nF, pd = self.dev, self.scalar, self.nF, self.pd
+        hl, hh = self.halo_planes
+        if self.world > 1:
+            x = self.comm.halo_extend(U)
+            plane0 = self.k0 - hl
+        else:
+            x, plane0 = U, self.k0
+        nplanes = x.size() // (nF * pd)
+        out = []
+        for f in range(nF):
+            xf = dev.DeviceVector(nplanes * pd)
+            for k in range(nplanes):
+                dev.vec_copy_range(xf, k * pd, x, (k * nF + f) * pd, pd)
+            out.append(S._prolong_tensor(xf, plane0))
+        return dev.vec_concat(out)

@@ -231,9 +231,13 @@ class ElasticityForm(object):
             return out
         return _memo(self, V, build)
 
+    def assemble_block(self, V, i, j, row0=None, row1=None):
+        """rows [row0, row1) of block (i, j) (fields i, j; columns of one field)"""
+        return _dev.kron_sum_csr(self.block_factors(V)[i][j], row0, row1)
+
     def assemble_matrix(self, V, row0=None, row1=None):
         if row0 is not None or row1 is not None:
-            raise NotImplementedError("row blocks of the elasticity form")
+            raise NotImplementedError("row blocks of the elasticity form: use assemble_block")
         fac = self.block_factors(V)
         d = len(fac)
         return _dev.csr_from_blocks([[_dev.kron_sum_csr(fac[i][j]) for j in range(d)] for i in range(d)])

@@ -27,6 +27,10 @@ class LazyFEMatrix(object):
         # the matrix as a Kronecker sum of 1-D matrices (factors[t][k], scipy CSR) when its producer is one -- the PtAP
         # can then form the entries inside its first pass instead of reading row blocks (never materialised)
         self.kron_factors = kron_factors
+        # several fields: block_rows(f, g, r0, r1) -> rows of ONE field block with the columns of one field (or None when
+        # the fields are not coupled), block_factors[f][g] -> that block as a Kronecker sum
+        self.block_rows = None
+        self.block_factors = None
 
     def rows(self, r0, r1):
         return self._producer(int(r0), int(r1))
@@ -119,3 +123,62 @@ class ImplicitExtraction(object):
 
     def rows_to_scipy(self, r0, r1):
         return self.rows(r0, r1).to_scipy()
+
+
+class BlockImplicitExtraction(object):
+    """M = diag(M_s, ..., M_s) of ``nfields`` fields on ONE tensor basis (``EqualOrderSpline(nFields > 1)``), dofs and FE
+    rows field after field, M_s = the implicit scalar operator -- not stored.  Stands in for the matrix object when the
+    patch is spread over several ranks (no rank holds all rows) or M would not fit."""
+
+    is_implicit = True
+
+    def __init__(self, kx, nfields, eps, transposed=False, _pair=None):
+        self.kx, self.nfields, self.eps, self.transposed = kx, int(nfields), float(eps), bool(transposed)
+        self.scalar = ImplicitExtraction(kx, eps, transposed)
+        self._T = _pair
+        r, c = self.scalar.shape
+        self._shape = (self.nfields * r, self.nfields * c)
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def nnz(self):
+        return self.nfields * self.kx.nnz_product
+
+    def transpose(self):
+        if self._T is None:
+            self._T = BlockImplicitExtraction(self.kx, self.nfields, self.eps, not self.transposed, _pair=self)
+        return self._T
+
+    def _apply(self, x, op, y=None):
+        r, c = op.shape
+        out = y if y is not None else _dev.DeviceVector(self.nfields * r)
+        for f in range(self.nfields):
+            xf = _dev.DeviceVector(c)
+            _dev.vec_copy_range(xf, 0, x, f * c, c)
+            yf = op.mult(xf)
+            _dev.vec_copy_range(out, f * r, yf, 0, r)
+        return out
+
+    def mult(self, x, y=None):
+        return self._apply(x, self.scalar, y)
+
+    def mult_transpose(self, b, y=None):
+        return self._apply(b, self.scalar.transpose(), y)
+
+    def __mul__(self, x):
+        if isinstance(x, _dev.DeviceVector):
+            return self.mult(x)
+        return NotImplemented
+
+    def materialise(self):
+        """the block-diagonal matrix as a DeviceCSR (tests, small patches)"""
+        import scipy.sparse as sp
+        blk = self.scalar.to_scipy()
+        return _dev.DeviceCSR.from_scipy(sp.block_diag([blk] * self.nfields, format="csr"))
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.block_diag([self.scalar.to_scipy()] * self.nfields, format="csr")
