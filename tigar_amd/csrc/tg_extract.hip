@@ -264,11 +264,35 @@ __device__ __forceinline__ bool tg_lane_row(const tg_extract_params &P, const tg
 template <int D, bool POINTS>
 __global__ void __launch_bounds__(256) k_extract_count(tg_extract_params P, int64_t *__restrict__ rowptr) {
   const tg_blk_ctx X = tg_block_ctx<D, POINTS>(P, blockIdx.x);
+  const int nk = (D > 2) ? P.pp1[2] : 1, nj = (D > 1) ? P.pp1[1] : 1;
+  // TENSOR mode: the factors of the directions 1 and 2 belong to the pencil, not to the row
+  __shared__ double v1r[TG_MAX_DEGREE + 1], v2r[TG_MAX_DEGREE + 1];
+  if (!POINTS) {
+    if (threadIdx.x <= TG_MAX_DEGREE) {
+      const int q = threadIdx.x;
+      v1r[q] = (D > 1 && q < nj) ? P.val[1][X.b * P.pp1[1] + q] : 1.0;
+      v2r[q] = (D > 2 && q < nk) ? P.val[2][X.c * P.pp1[2] + q] : 1.0;
+    }
+    __syncthreads();
+  }
   for (int q = threadIdx.x; q < P.rows_per_block; q += 256) {
     int64_t lrow, t[3];
     if (!tg_lane_row<D, POINTS>(P, X, q, &lrow, t)) continue;
     int cnt = 0;
-    const int nk = (D > 2) ? P.pp1[2] : 1, nj = (D > 1) ? P.pp1[1] : 1;
+    if (!POINTS) {
+      for (int i = 0; i < P.pp1[0]; i++) {
+        const double v0 = P.val[0][t[0] * P.pp1[0] + i];
+        for (int k = 0; k < nk; k++)
+          for (int j = 0; j < nj; j++) {
+            double v = v0;
+            if (D > 1) v = v * v1r[j];
+            if (D > 2) v = v * v2r[k];
+            cnt += (fabs(v) > P.eps) ? 1 : 0;
+          }
+      }
+      rowptr[lrow] = cnt;
+      continue;
+    }
     for (int k = 0; k < nk; k++)
       for (int j = 0; j < nj; j++)
         for (int i = 0; i < P.pp1[0]; i++) cnt += (fabs(tg_cand_value<D>(P, t, i, j, k)) > P.eps) ? 1 : 0;
@@ -292,24 +316,66 @@ __global__ void __launch_bounds__(256)
     const int j = (D > 1) ? jk % P.pp1[1] : 0;
     const int k = (D > 2) ? jk / P.pp1[1] : 0;
     const unsigned long long rowmask_base = (P.C == 64) ? ~0ull : ((1ull << P.C) - 1ull);
-    for (int it = 0; it < P.iters; it++) {
-      const int group = it * 4 + w;
-      int64_t lrow = 0, t[3] = {0, 0, 0};
-      const bool has = lane_used && tg_lane_row<D, POINTS>(P, X, group * P.rpw + rsub, &lrow, t);
-      double v = 0.0;
-      bool keep = false;
-      if (has) {
-        v = tg_cand_value<D>(P, t, i, j, k);
-        keep = fabs(v) > P.eps;
+    // TENSOR mode: a block walks ONE pencil (b, c fixed), so the lane's factors of the directions 1 and 2 and its column
+    // part are the same for every row: loaded once (the product order (v0 * v1) * v2 of the reference is kept)
+    double v1 = 1.0, v2 = 1.0;
+    int64_t cjk = P.col_offset;
+    if (!POINTS && lane_used) {
+      if (D > 1) {
+        v1 = P.val[1][X.b * P.pp1[1] + j];
+        cjk += P.cstride[1] * P.idx[1][X.b * P.pp1[1] + j];
       }
-      const unsigned long long m = __ballot(keep);
-      if (keep) {
-        const unsigned long long rowmask = rowmask_base << (rsub * P.C);
-        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const int rank = __popcll(m & rowmask & below);
-        const int64_t pos = rowptr[lrow] + rank;
-        col[pos] = (int32_t)tg_cand_col<D>(P, t, i, j, k);
-        val[pos] = v;
+      if (D > 2) {
+        v2 = P.val[2][X.c * P.pp1[2] + k];
+        cjk += P.cstride[2] * P.idx[2][X.c * P.pp1[2] + k];
+      }
+    }
+    // four row groups at a time: their table values, row starts and 1-D column parts are requested before the first
+    // ballot (the loads of a group are independent of the other groups'; one at a time the kernel waits for each)
+    constexpr int U = 4;
+    for (int it0 = 0; it0 < P.iters; it0 += U) {
+      int64_t lrow[U], t0[U], rs[U];
+      double v[U];
+      int32_t c0[U];
+      bool has[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int group = (it0 + u) * 4 + w;
+        int64_t t[3] = {0, 0, 0};
+        lrow[u] = 0;
+        has[u] = (it0 + u < P.iters) && lane_used && tg_lane_row<D, POINTS>(P, X, group * P.rpw + rsub, &lrow[u], t);
+        t0[u] = t[0];
+        v[u] = 0.0;
+        c0[u] = 0;
+        rs[u] = 0;
+        if (has[u]) {
+          if (POINTS) {
+            v[u] = tg_cand_value<D>(P, t, i, j, k);
+            c0[u] = (int32_t)tg_cand_col<D>(P, t, i, j, k);
+          } else {
+            v[u] = P.val[0][t[0] * P.pp1[0] + i];
+            c0[u] = P.idx[0][t[0] * P.pp1[0] + i];
+          }
+          rs[u] = rowptr[lrow[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        double vv = v[u];
+        if (!POINTS) {
+          if (D > 1) vv = vv * v1;
+          if (D > 2) vv = vv * v2;
+        }
+        const bool keep = has[u] && fabs(vv) > P.eps;
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+          const unsigned long long rowmask = rowmask_base << (rsub * P.C);
+          const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+          const int rank = __popcll(m & rowmask & below);
+          const int64_t pos = rs[u] + rank;
+          col[pos] = POINTS ? c0[u] : (int32_t)(cjk + c0[u]);
+          val[pos] = vv;
+        }
       }
     }
   } else {
@@ -474,7 +540,14 @@ static void tg_fill_common(tg_extract_params &P, int d, const tg_dir_t *dirs, in
   P.col_offset = col_offset;
   P.eps = eps;
   P.rpw = (P.C <= 64) ? 64 / P.C : 1;
-  P.iters = 8;
+  // rows per block: the per-block set-up (pencil coordinates, the lane's factors of the directions 1 and 2) is paid once
+  // per block and the count pass works a thread per row, so more rows per block help -- up to 16 row groups per wave
+  // (cfg2, TIGAR_EXTRACT_KRON=0: fill 1.34 / 1.25 / 1.93 ms and count 0.28 / 0.23 / 0.25 ms for 8 / 16 / 32 groups: with
+  // 32 a pencil of 257 rows is two blocks of 256 + 1 rows); not more than a short first direction has
+  const int64_t n0 = dirs[0].nnodes > 0 ? dirs[0].nnodes : 256;
+  int iters = (int)tg_cdiv(tg_cdiv(n0, 4 * P.rpw), 4) * 4;           // multiples of the unroll of the fill kernel
+  if (getenv("TIGAR_EXTRACT_ITERS")) iters = std::max(4, atoi(getenv("TIGAR_EXTRACT_ITERS")) / 4 * 4);   // (experiments)
+  P.iters = std::max(4, std::min(iters, 16));
   P.rows_per_block = 4 * P.rpw * P.iters;
 }
 
