@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_lu_bandwidth(const int64_t *__restrict_
 
 __global__ void __launch_bounds__(256)
     k_lu_pivot(double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, int64_t j, int32_t *__restrict__ ipiv,
-               tg_lu_state *st) {
+               tg_lu_state *st, int swap_trailing) {
   __shared__ double sval[256];
   __shared__ int sidx[256];
   const int tid = threadIdx.x;
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256)
   if (piv == 0.0) return;
   // interchange rows j and j+jp over the columns j..ju (stride ldab-1 walks along a row of the band)
   if (jp != 0) {
-    const int64_t len = ju - j + 1;
+    const int64_t len = swap_trailing ? ju - j + 1 : 1;      // (fused path: the other columns are interchanged by k_lu_step)
     for (int64_t t = tid; t < len; t += 256) {
       double *p = cj + t * (ldab - 1);
       const double a = p[jp], b = p[0];
@@ -122,6 +122,109 @@ __global__ void __launch_bounds__(256)
     if (u == 0.0) continue;
     for (int i = 1 + blockIdx.x * 256 + threadIdx.x; i <= km; i += gridDim.x * 256) cc[i] -= l[i] * u;
   }
+}
+
+// One launch per column (round 3; the two launches per column were the cost: 67 600 columns x 2 x 8 us at cfg4).
+// State of column j (found by the launch before): pivot row jp, km, 1/pivot, ju; column j itself is final (swapped,
+// multipliers scaled).  Launch j: every workgroup first applies the row interchange of column j to its trailing
+// columns, then the rank-1 update -- exactly the operations of k_lu_pivot + k_lu_update in the same order, so the
+// factors are bit for bit the same.  Workgroup (0, 0) owns column j+1: it brings it up to date FIRST, then searches its
+// pivot, interchanges inside that column, scales the multipliers and writes the state of column j+1 (the interchange
+// of the other columns is left to launch j+1).
+__global__ void __launch_bounds__(256)
+    k_lu_step(double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, int64_t j, int32_t *__restrict__ ipiv,
+              tg_lu_state *st2) {
+  __shared__ double sval[256];
+  __shared__ int sidx[256];
+  const tg_lu_state *st = st2 + (j & 1);
+  tg_lu_state *nx = st2 + ((j + 1) & 1);
+  const int tid = threadIdx.x;
+  const int km = st->km, jp = st->jp, ju = st->ju;
+  const bool live = st->pivinv != 0.0;             // (a zero pivot: LAPACK goes on without eliminating)
+  const double *l = ab + kv + ldab * j;            // l[i], i = 1..km: multipliers of column j
+  const int64_t nc = ju - j;                       // trailing columns j+1..ju
+  const bool lead = blockIdx.x == 0 && blockIdx.y == 0;
+  // the leader's column j+1 (c = 0) first, alone; the others (and the leader afterwards) share the columns c >= 1
+  if (lead && nc >= 1) {
+    double *cc = ab + kv + ldab * (j + 1) - 1;     // cc[i] = A(j+i, j+1)
+    if (live && jp != 0 && tid == 0) {
+      const double a = cc[jp], b = cc[0];
+      cc[jp] = b;
+      cc[0] = a;
+    }
+    __syncthreads();
+    const double u = cc[0];
+    if (live && u != 0.0)
+      for (int i = 1 + tid; i <= km; i += 256) cc[i] -= l[i] * u;
+    __syncthreads();
+  }
+  if (live)
+    for (int64_t c = 1 + blockIdx.y; c < nc; c += gridDim.y) {   // (one workgroup per column: uniform trip count)
+      double *cc = ab + kv + ldab * (j + 1 + c) - (1 + c);     // cc[i] = A(j+i, j+1+c)
+      double u = cc[0];
+      if (jp != 0) {
+        const double ajp = cc[jp];
+        __syncthreads();                             // everybody has read the two entries
+        if (tid == 0) {
+          cc[0] = ajp;
+          cc[jp] = u;
+        }
+        u = ajp;
+        __syncthreads();
+      }
+      if (u != 0.0)
+        for (int i = 1 + tid; i <= km; i += 256) cc[i] -= l[i] * u;
+    }
+  if (!lead) return;
+  // ---- column j+1: pivot search, interchange inside the column, multipliers, state
+  const int64_t j1 = j + 1;
+  if (j1 >= n) return;
+  __syncthreads();
+  const int km1 = (int)min((int64_t)kl, n - 1 - j1);
+  double *cj = ab + kv + ldab * j1;                // cj[i] = A(j1+i, j1)
+  double best = -1.0;
+  int bi = 0;
+  for (int i = tid; i <= km1; i += 256) {
+    const double a = fabs(cj[i]);
+    if (a > best || (a != a && best == best)) {
+      best = a;
+      bi = i;
+    }
+  }
+  sval[tid] = best;
+  sidx[tid] = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      const double b2 = sval[tid + o];
+      const int i2 = sidx[tid + o];
+      if (b2 > sval[tid] || (b2 == sval[tid] && i2 < sidx[tid])) {
+        sval[tid] = b2;
+        sidx[tid] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  const int jp1 = sidx[0];
+  const double piv = cj[jp1];
+  __syncthreads();
+  if (tid == 0) {
+    ipiv[j1] = (int32_t)(j1 + jp1);
+    nx->ju = max(ju, (int)min(j1 + (int64_t)(kv - kl) + jp1, n - 1));
+    nx->km = km1;
+    nx->jp = jp1;
+    nx->info = (piv == 0.0 && st->info == 0) ? (int)(j1 + 1) : st->info;
+    nx->pivinv = piv != 0.0 ? 1.0 / piv : 0.0;
+    if (piv != 0.0 && jp1 != 0) {
+      const double a = cj[jp1], b = cj[0];
+      cj[jp1] = b;
+      cj[0] = a;
+    }
+  }
+  __syncthreads();
+  if (piv == 0.0) return;
+  const double pinv = 1.0 / piv;
+  for (int i = 1 + tid; i <= km1; i += 256) cj[i] *= pinv;
 }
 
 // forward substitution with the row interchanges, then backward substitution; one workgroup
@@ -193,7 +296,7 @@ extern "C" int tg_lu_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *info) {
   tg_lu_state *st = nullptr;
   int rc = tg_dmalloc(&ab, ldab * n);
   if (!rc) rc = tg_dmalloc(&ipiv, n);
-  if (!rc) rc = tg_dmalloc_bytes((void **)&st, sizeof(tg_lu_state));
+  if (!rc) rc = tg_dmalloc_bytes((void **)&st, 2 * sizeof(tg_lu_state));
   if (!rc && hipMemsetAsync(ab, 0, (size_t)(ldab * n) * sizeof(double), g_tg.stream) != hipSuccess) rc = 1;
   if (!rc) {
     tg_lu_state h0;
@@ -203,18 +306,29 @@ extern "C" int tg_lu_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *info) {
     h0.jp = 0;
     h0.pivinv = 0.0;
     if (hipMemcpyAsync(st, &h0, sizeof(h0), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess) rc = 1;
+    if (!rc && hipMemcpyAsync(st + 1, &h0, sizeof(h0), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess) rc = 1;
     hipStreamSynchronize(g_tg.stream);
   }
   if (!rc) {
     hipLaunchKernelGGL(k_lu_scatter, dim3((unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16)), dim3(256), 0,
                        g_tg.stream, k->rowptr, k->col, k->val, n, kv, ldab, ab);
-    // trailing window of a column: at most kl rows x kv columns
-    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(kl, 256), 64));
-    const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)kv, (int64_t)g_tg.num_cu * 8 / gx));
-    for (int64_t j = 0; j < n; j++) {
-      hipLaunchKernelGGL(k_lu_pivot, dim3(1), dim3(256), 0, g_tg.stream, ab, ldab, n, kl, kv, j, ipiv, st);
-      if (kl > 0 && j + 1 < n)
-        hipLaunchKernelGGL(k_lu_update, dim3(gx, gy), dim3(256), 0, g_tg.stream, ab, ldab, kv, j, st);
+    // column 0: pivot search alone (its state lands in slot 0); then ONE launch per column: launch j interchanges and
+    // eliminates with column j and prepares column j+1 (TIGAR_LU_FUSED=0: the two launches per column of round 2)
+    static const int fused = getenv("TIGAR_LU_FUSED") ? atoi(getenv("TIGAR_LU_FUSED")) : 1;
+    if (fused) {
+      hipLaunchKernelGGL(k_lu_pivot, dim3(1), dim3(256), 0, g_tg.stream, ab, ldab, n, kl, kv, (int64_t)0, ipiv, st, 0);
+      const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)kv, (int64_t)g_tg.num_cu * 8));
+      for (int64_t j = 0; j + 1 < n; j++)
+        hipLaunchKernelGGL(k_lu_step, dim3(1, gy), dim3(256), 0, g_tg.stream, ab, ldab, n, kl, kv, j, ipiv, st);
+    } else {
+      // trailing window of a column: at most kl rows x kv columns
+      const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(kl, 256), 64));
+      const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)kv, (int64_t)g_tg.num_cu * 8 / gx));
+      for (int64_t j = 0; j < n; j++) {
+        hipLaunchKernelGGL(k_lu_pivot, dim3(1), dim3(256), 0, g_tg.stream, ab, ldab, n, kl, kv, j, ipiv, st, 1);
+        if (kl > 0 && j + 1 < n)
+          hipLaunchKernelGGL(k_lu_update, dim3(gx, gy), dim3(256), 0, g_tg.stream, ab, ldab, kv, j, st);
+      }
     }
     if (hipGetLastError() != hipSuccess) {
       tg_set_error("tg_lu_solve: kernel launch failed");
@@ -223,7 +337,9 @@ extern "C" int tg_lu_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *info) {
   }
   if (!rc) {
     tg_lu_state h1;
-    if (hipMemcpyAsync(&h1, st, sizeof(h1), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
+    // (fused: the state of the last column is in slot (n-1) & 1; `info` is carried from slot to slot)
+    static const int fused1 = getenv("TIGAR_LU_FUSED") ? atoi(getenv("TIGAR_LU_FUSED")) : 1;
+    if (hipMemcpyAsync(&h1, st + (fused1 ? ((n - 1) & 1) : 0), sizeof(h1), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
     if (!rc && hipStreamSynchronize(g_tg.stream) != hipSuccess) {
       tg_set_error("tg_lu_solve: %s", hipGetErrorString(hipGetLastError()));
       rc = 1;
