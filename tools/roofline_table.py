@@ -7,7 +7,10 @@ RND = sys.argv[1] if len(sys.argv) > 1 else "3"
 WORK = [("cfg3 (256^3 p=3)", "r%s_cfg3_kernel_stats.txt" % RND, "r%s_cfg3_pmc_hbm.json" % RND),
         ("cfg2 (128^3 p=2)", "r%s_cfg2_kernel_stats.txt" % RND, "r%s_cfg2_pmc_hbm.json" % RND),
         ("cfg4 (256^2 p=4, CG)", "r%s_cfg4_kernel_stats.txt" % RND, "r%s_cfg4_pmc_hbm.json" % RND),
-        ("cfg5 (128^2 p=3, 3 fields)", "r%s_cfg5_kernel_stats.txt" % RND, "r%s_cfg5_pmc_hbm.json" % RND)]
+        ("cfg5 (128^2 p=3, 3 fields)", "r%s_cfg5_kernel_stats.txt" % RND, "r%s_cfg5_pmc_hbm.json" % RND),
+        # the general extraction kernels (count / scan / fill: active filter, explicit points), forced with TIGAR_EXTRACT_KRON=0
+        ("cfg2, general M build", "r%s_cfg2_general_extraction_kernel_stats.txt" % RND,
+         "r%s_cfg2_general_extraction_pmc_hbm.json" % RND)]
 WORK = [w for w in WORK if os.path.exists(os.path.join(HERE, w[1])) and os.path.exists(os.path.join(HERE, w[2]))]
 
 
@@ -50,6 +53,8 @@ def main():
             n, ms = dur[key]
             r, w = k["hbm_read_GB_total_corrected"] / k["launches"], k["hbm_write_GB_total"] / k["launches"]
             if r + w < 0.05 or ms < 0.03:
+                continue
+            if label.endswith("general M build") and "k_extract" not in name:
                 continue
             rate = (r + w) / ms
             frac_w = w / (r + w)
