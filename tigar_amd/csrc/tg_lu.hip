@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256)
 
 // forward substitution with the row interchanges, then backward substitution; one workgroup
 __global__ void __launch_bounds__(1024)
-    k_lu_solve(const double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, const int32_t *__restrict__ ipiv,
+    k_lu_solve_global(const double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, const int32_t *__restrict__ ipiv,
                double *__restrict__ x) {
   const int tid = threadIdx.x;
   for (int64_t j = 0; j < n; j++) {
@@ -255,6 +255,140 @@ __global__ void __launch_bounds__(1024)
     const int kk = (int)min((int64_t)kv, j);
     for (int i = 1 + tid; i <= kk; i += 1024) x[j - i] -= cj[-i] * xj;
   }
+}
+
+// forward substitution with the row interchanges, then backward substitution; one workgroup.  The entries of x a step
+// touches form a window of kl+1 (forward) / kv+1 (backward) consecutive entries that slides by one per step: the window
+// lives in LDS as a ring (entry x[q] at q mod W), so a step costs one barrier and no global round trip -- the multipliers
+// of the step after next are requested before the barrier (201 -> ~60 ms at cfg4: 67 600 steps each way).
+// barrier that orders the LDS traffic of the workgroup only: __syncthreads() also waits for every outstanding GLOBAL
+// load, i.e. for the multipliers of the next step that are requested on purpose before they are needed
+#define TG_LDS_BARRIER()                                            \
+  do {                                                              \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
+    __builtin_amdgcn_s_barrier();                                   \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
+  } while (0)
+#define TG_LU_R 6            // entries of a step per thread held in registers: windows of up to 6 * 1024 entries
+#define TG_LU_CH 1024        // entries of x that enter the window at a time
+// ring slot of entry (base entry at slot b) + off, 0 <= off < W   (32-bit: a 64-bit modulo per access costs more than the step)
+__device__ __forceinline__ int tg_slot(int b, int off, int W) {
+  const int q = b + off;
+  return q >= W ? q - W : q;
+}
+__device__ __forceinline__ void tg_lu_load_col(const double *__restrict__ col, int sign, int cnt, int tid, double *v) {
+#pragma unroll
+  for (int q = 0; q < TG_LU_R; q++) {
+    const int i = 1 + tid + 1024 * q;
+    v[q] = i <= cnt ? col[sign * i] : 0.0;
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+    k_lu_solve(const double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, const int32_t *__restrict__ ipiv,
+               double *__restrict__ x) {
+  extern __shared__ double ring[];                 // W doubles; entry x[q] lives at slot q mod W
+  const int tid = threadIdx.x;
+  const int W = kv + 2 + TG_LU_CH;
+  double va[TG_LU_R], vb[TG_LU_R];
+  // ---- forward: the window [j, j + kl] lies inside the loaded range [j, top); `top` grows by TG_LU_CH entries at a time
+  // (all threads load, one wait per TG_LU_CH steps).  The multipliers and the pivot row of step j+1 are requested during
+  // step j into the OTHER register set (two steps per trip of the loop: no copies, so nothing waits for them early).
+  int64_t top = min(n, (int64_t)kl + 1 + TG_LU_CH);
+  for (int64_t q = tid; q < top; q += 1024) ring[(int)(q % W)] = x[q];
+  int b = 0;                                       // slot of entry j
+  int tb = (int)(top % W);                         // slot of entry top
+  int jpa = n > 0 ? (int)(ipiv[0] - 0) : 0, jpb = 0;   // pivot offsets jp - j
+  tg_lu_load_col(ab + kv, 1, (int)min((int64_t)kl, n - 1), tid, va);
+  __syncthreads();
+#define TG_FWD_STEP(J, CUR, NXT, JPC, JPN)                                                      \
+  {                                                                                             \
+    const int64_t j_ = (J);                                                                     \
+    const int km = (int)min((int64_t)kl, n - 1 - j_);                                           \
+    if (j_ + 1 < n) {                                                                           \
+      JPN = (int)(ipiv[j_ + 1] - (j_ + 1));                                                     \
+      tg_lu_load_col(ab + kv + ldab * (j_ + 1), 1, (int)min((int64_t)kl, n - 2 - j_), tid, NXT); \
+    }                                                                                           \
+    if (tid == 0 && JPC != 0) {                                                                 \
+      const int sp = tg_slot(b, JPC, W);                                                        \
+      const double t = ring[sp];                                                                \
+      ring[sp] = ring[b];                                                                       \
+      ring[b] = t;                                                                              \
+    }                                                                                           \
+    TG_LDS_BARRIER();                                                                           \
+    const double xj = ring[b];                                                                  \
+    _Pragma("unroll") for (int q = 0; q < TG_LU_R; q++) {                                       \
+      const int i = 1 + tid + 1024 * q;                                                         \
+      if (i <= km) ring[tg_slot(b, i, W)] -= CUR[q] * xj;                                       \
+    }                                                                                           \
+    if (tid == 0) x[j_] = xj;                                                                   \
+    if (top < n && j_ + 1 + kl + 1 > top) {                                                     \
+      const int64_t e1 = min(n, top + TG_LU_CH);                                                \
+      for (int64_t e = top + tid; e < e1; e += 1024) ring[tg_slot(tb, (int)(e - top), W)] = x[e]; \
+      tb = tg_slot(tb, (int)(e1 - top), W);                                                     \
+      top = e1;                                                                                 \
+    }                                                                                           \
+    TG_LDS_BARRIER();                                                                           \
+    b = tg_slot(b, 1, W);                                                                       \
+  }
+  {
+    int64_t j = 0;
+    for (; j + 1 < n; j += 2) {
+      TG_FWD_STEP(j, va, vb, jpa, jpb)
+      TG_FWD_STEP(j + 1, vb, va, jpb, jpa)
+    }
+    if (j < n) TG_FWD_STEP(j, va, vb, jpa, jpb)
+  }
+#undef TG_FWD_STEP
+  __syncthreads();                                 // (the forward values written to x are visible to the whole workgroup)
+  // ---- backward: the window [j - kv, j] lies inside the loaded range [lo, j]
+  int64_t lo = max((int64_t)0, n - 1 - kv - TG_LU_CH);
+  for (int64_t q = lo + tid; q <= n - 1; q += 1024) ring[(int)(q % W)] = x[q];
+  b = n > 0 ? (int)((n - 1) % W) : 0;              // slot of entry j
+  int lb = (int)(lo % W);                          // slot of entry lo
+  double da = 1.0, db = 1.0;
+  if (n > 0) {
+    const double *cj = ab + kv + ldab * (n - 1);
+    tg_lu_load_col(cj, -1, (int)min((int64_t)kv, n - 1), tid, va);
+    da = cj[0];
+  }
+  __syncthreads();
+#define TG_BWD_STEP(J, CUR, NXT, DC, DN)                                                        \
+  {                                                                                             \
+    const int64_t j_ = (J);                                                                     \
+    const int kk = (int)min((int64_t)kv, j_);                                                   \
+    if (j_ >= 1) {                                                                              \
+      const double *c1 = ab + kv + ldab * (j_ - 1);                                             \
+      tg_lu_load_col(c1, -1, (int)min((int64_t)kv, j_ - 1), tid, NXT);                          \
+      DN = c1[0];                                                                               \
+    }                                                                                           \
+    const double xj = ring[b] / DC;                                                             \
+    TG_LDS_BARRIER();                                                                           \
+    _Pragma("unroll") for (int q = 0; q < TG_LU_R; q++) {                                       \
+      const int i = 1 + tid + 1024 * q;                                                         \
+      if (i <= kk) ring[tg_slot(b, W - i, W)] -= CUR[q] * xj;                                   \
+    }                                                                                           \
+    if (tid == 0) x[j_] = xj;                                                                   \
+    if (lo > 0 && lo > j_ - 1 - kv) {                                                           \
+      const int64_t e0 = max((int64_t)0, lo - TG_LU_CH);                                        \
+      const int cnt = (int)(lo - e0);                                                           \
+      const int nb_ = tg_slot(lb, W - cnt, W);                                                  \
+      for (int e = tid; e < cnt; e += 1024) ring[tg_slot(nb_, e, W)] = x[e0 + e];               \
+      lb = nb_;                                                                                 \
+      lo = e0;                                                                                  \
+    }                                                                                           \
+    TG_LDS_BARRIER();                                                                           \
+    b = tg_slot(b, W - 1, W);                                                                   \
+  }
+  {
+    int64_t j = n - 1;
+    for (; j >= 1; j -= 2) {
+      TG_BWD_STEP(j, va, vb, da, db)
+      TG_BWD_STEP(j - 1, vb, va, db, da)
+    }
+    if (j == 0) TG_BWD_STEP(0, va, vb, da, db)
+  }
+#undef TG_BWD_STEP
 }
 
 extern "C" int tg_lu_band_info(tg_csr_t k, int *kl_out, int *ku_out, int64_t *bytes_out) {
@@ -350,7 +484,11 @@ extern "C" int tg_lu_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *info) {
     if (x->d != b->d &&
         hipMemcpyAsync(x->d, b->d, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess)
       rc = 1;
-    hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), 0, g_tg.stream, ab, ldab, n, kl, kv, ipiv, x->d);
+    if (kv + 1 <= TG_LU_R * 1024 && !getenv("TIGAR_LU_SOLVE_GLOBAL"))
+      hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), (size_t)(kv + 2 + TG_LU_CH) * sizeof(double), g_tg.stream, ab, ldab, n, kl, kv,
+                         ipiv, x->d);
+    else
+      hipLaunchKernelGGL(k_lu_solve_global, dim3(1), dim3(1024), 0, g_tg.stream, ab, ldab, n, kl, kv, ipiv, x->d);
     if (hipGetLastError() != hipSuccess) rc = 1;
     if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
     if (rc) tg_set_error("tg_lu_solve: substitution failed");
