@@ -42,6 +42,46 @@ def test_banded_lu_with_pivoting_vs_superlu():
             assert err < 1e-6 * max(1.0, np.linalg.cond(A.toarray()) * 1e-10), (n, err)
 
 
+def test_blocked_factorisation_gives_the_factors_of_the_column_by_column_one(monkeypatch):
+    """Panel + trailing-column kernels (NB columns per pair of launches) apply the same operations to every entry in
+    the same order as one launch per column: the solutions agree bit for bit, at every panel width, with zero and
+    tiny pivots (row interchanges across panel borders) and with a singular matrix (same `info`)."""
+    from tigar_amd import device as dev
+    rng = np.random.default_rng(7)
+    for (n, kl, ku) in [(7, 2, 1), (97, 5, 9), (700, 40, 17), (1500, 130, 130), (64, 63, 63)]:
+        diags = {o: rng.standard_normal(n - abs(o)) for o in range(-kl, ku + 1)}
+        A = sp.diags(list(diags.values()), list(diags.keys()), shape=(n, n), format="csr").tolil()
+        for i in range(0, n, 3):
+            A[i, i] = 0.0 if i % 2 == 0 else 1e-14
+        A = A.tocsr()
+        b = dev.DeviceVector(data=A @ rng.standard_normal(n))
+        K = dev.DeviceCSR.from_scipy(A)
+        monkeypatch.setenv("TIGAR_LU_BLOCKED", "0")
+        x0 = dev.DeviceVector(n)
+        assert dev.lu_solve(K, b, x0) == 0
+        for nb in ("", "2", "4", "5", "32"):
+            monkeypatch.setenv("TIGAR_LU_BLOCKED", "1")
+            if nb:
+                monkeypatch.setenv("TIGAR_LU_NB", nb)
+            else:
+                monkeypatch.delenv("TIGAR_LU_NB", raising=False)
+            x1 = dev.DeviceVector(n)
+            assert dev.lu_solve(K, b, x1) == 0
+            assert np.array_equal(x0.get_local().view(np.int64), x1.get_local().view(np.int64)), (n, kl, ku, nb)
+        monkeypatch.delenv("TIGAR_LU_NB", raising=False)
+    # singular: a zero column inside the band -> the same first zero pivot reported
+    n = 50
+    A = sp.diags([np.ones(n - 1), 2 * np.ones(n), np.ones(n - 1)], [-1, 0, 1], format="lil")
+    A[:, 20] = 0.0
+    A[20, :] = 0.0
+    K = dev.DeviceCSR.from_scipy(sp.csr_matrix(A))
+    infos = []
+    for blocked in ("0", "1"):
+        monkeypatch.setenv("TIGAR_LU_BLOCKED", blocked)
+        infos.append(dev.lu_solve(K, dev.DeviceVector(data=np.ones(n)), dev.DeviceVector(n)))
+    assert infos[0] == infos[1] == 21, infos
+
+
 def test_saddle_point_system_where_jacobi_krylov_stalls():
     """[[A, B], [B^T, 0]]: zero diagonal block (PCJACOBI substitutes 1), indefinite -- the kind of system the
     reference's default LU handles and a Jacobi-Krylov default does not"""

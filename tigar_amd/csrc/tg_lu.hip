@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256)
     double *cc = ab + kv + ldab * (j + 1 + c) - (1 + c);     // cc[i] = A(j+i, j+1+c)
     const double u = cc[0];
     if (u == 0.0) continue;
-    for (int i = 1 + blockIdx.x * 256 + threadIdx.x; i <= km; i += gridDim.x * 256) cc[i] -= l[i] * u;
+    for (int i = 1 + blockIdx.x * 256 + threadIdx.x; i <= km; i += gridDim.x * 256) cc[i] = fma(-l[i], u, cc[i]);
   }
 }
 
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     const double u = cc[0];
     if (live && u != 0.0)
-      for (int i = 1 + tid; i <= km; i += 256) cc[i] -= l[i] * u;
+      for (int i = 1 + tid; i <= km; i += 256) cc[i] = fma(-l[i], u, cc[i]);
     __syncthreads();
   }
   if (live)
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256)
         __syncthreads();
       }
       if (u != 0.0)
-        for (int i = 1 + tid; i <= km; i += 256) cc[i] -= l[i] * u;
+        for (int i = 1 + tid; i <= km; i += 256) cc[i] = fma(-l[i], u, cc[i]);
     }
   if (!lead) return;
   // ---- column j+1: pivot search, interchange inside the column, multipliers, state
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(1024)
     __syncthreads();
     const double xj = x[j];
     const double *l = ab + kv + ldab * j;
-    for (int i = 1 + tid; i <= km; i += 1024) x[j + i] -= l[i] * xj;
+    for (int i = 1 + tid; i <= km; i += 1024) x[j + i] = fma(-l[i], xj, x[j + i]);
   }
   for (int64_t j = n - 1; j >= 0; j--) {
     __syncthreads();
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(1024)
     __syncthreads();
     const double xj = x[j];
     const int kk = (int)min((int64_t)kv, j);
-    for (int i = 1 + tid; i <= kk; i += 1024) x[j - i] -= cj[-i] * xj;
+    for (int i = 1 + tid; i <= kk; i += 1024) x[j - i] = fma(-cj[-i], xj, x[j - i]);
   }
 }
 
@@ -261,6 +261,267 @@ __global__ void __launch_bounds__(1024)
 // touches form a window of kl+1 (forward) / kv+1 (backward) consecutive entries that slides by one per step: the window
 // lives in LDS as a ring (entry x[q] at q mod W), so a step costs one barrier and no global round trip -- the multipliers
 // of the step after next are requested before the barrier (201 -> ~60 ms at cfg4: 67 600 steps each way).
+// ------------------------------------------------------------------------------------------------------
+// Blocked factorisation (round 3): NB columns per pair of launches instead of one launch per column.
+//   k_lu_panel   ONE workgroup factorises the panel (rows j0 .. j0+NB-1+kl of the columns j0 .. j0+NB-1) in LDS: pivot
+//                search, interchange, multipliers and the rank-1 updates INSIDE the panel, column by column;
+//   k_lu_trail   one workgroup per trailing column (j0+NB .. ju): the panel's interchanges, then the NB eliminations, in
+//                the panel's order, on the column held in LDS.
+// Every entry receives the same operations in the same order as in the column-by-column algorithm (interchange and
+// elimination of step jj, then of step jj+1, ...), so the factors are bit
+// for bit the same.  Positions outside the band are never touched: a multiplier of column jj exists for the rows
+// jj+1 .. jj+kl only, a trailing column holds the rows >= c - kv only -- no work arrays as in dgbtrf, the loops are
+// bounded instead.
+// copy of the panel between the band storage and LDS: four columns at a time (four independent loads in flight)
+template <bool LOAD>
+__device__ __forceinline__ void tg_lu_panel_copy(double *__restrict__ ab, double *P, int64_t ldab, int64_t n, int kl, int kv,
+                                                 int64_t j0, int nbc, int H, int tid) {
+  const int rmax = (int)min((int64_t)H - 1, n - 1 - j0);
+  for (int lc0 = 0; lc0 < nbc; lc0 += 4)
+    for (int lr = tid; lr <= rmax; lr += 1024) {
+      double v[4];
+      bool ok[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int lc = lc0 + q;
+        ok[q] = lc < nbc && lr >= lc - kv && lr <= lc + kl;            // (rows above the band are not stored)
+        double *g = ab + kv + lr - lc + ldab * (j0 + lc);              // A(j0 + lr, j0 + lc)
+        if (LOAD) v[q] = ok[q] ? *g : 0.0;
+        else if (ok[q]) *g = P[lc * H + lr];
+      }
+      if (LOAD) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (ok[q]) P[(lc0 + q) * H + lr] = v[q];
+      }
+    }
+}
+
+// wave-wide maximum of a 64-bit key / minimum of a 32-bit value through DPP (row shifts, then the row broadcasts of
+// GFX9); every lane receives the result
+__device__ __forceinline__ unsigned long long tg_wave_max_u64(unsigned long long v) {
+#define TG_DPP_STEP(ctrl, rmask)                                                                      \
+  {                                                                                                   \
+    const int lo = __builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xF, false);              \
+    const int hi = __builtin_amdgcn_update_dpp((int)(v >> 32), (int)(v >> 32), ctrl, rmask, 0xF, false); \
+    const unsigned long long o = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;             \
+    v = o > v ? o : v;                                                                                \
+  }
+  TG_DPP_STEP(0x111, 0xF)   // row_shr:1
+  TG_DPP_STEP(0x112, 0xF)   // row_shr:2
+  TG_DPP_STEP(0x114, 0xF)   // row_shr:4
+  TG_DPP_STEP(0x118, 0xF)   // row_shr:8
+  TG_DPP_STEP(0x142, 0xA)   // row_bcast:15 into rows 1, 3
+  TG_DPP_STEP(0x143, 0xC)   // row_bcast:31 into rows 2, 3
+#undef TG_DPP_STEP
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ int tg_wave_min_i32(int v) {
+#define TG_DPP_STEP(ctrl, rmask)                                                   \
+  {                                                                                \
+    const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xF, false);      \
+    v = o < v ? o : v;                                                             \
+  }
+  TG_DPP_STEP(0x111, 0xF)
+  TG_DPP_STEP(0x112, 0xF)
+  TG_DPP_STEP(0x114, 0xF)
+  TG_DPP_STEP(0x118, 0xF)
+  TG_DPP_STEP(0x142, 0xA)
+  TG_DPP_STEP(0x143, 0xC)
+#undef TG_DPP_STEP
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// One workgroup on one CU: four waves per SIMD share its issue slots, so the kernel is bound by its instruction
+// count -- the search reduces through DPP (no LDS tree), the update walks the columns with the multiplier in a
+// register (no index arithmetic per entry).
+__global__ void __launch_bounds__(1024)
+    k_lu_panel(double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, int64_t j0, int nb,
+               int32_t *__restrict__ ipiv, tg_lu_state *st) {
+  extern __shared__ double P[];                    // [nb][H], H = kl + nb: P[lc * H + lr] = A(j0 + lr, j0 + lc)
+  __shared__ unsigned long long wkey[16];
+  __shared__ int widx[16];
+  const int tid = threadIdx.x, wv = tid >> 6;
+  const int H = kl + nb;
+  const int nbc = (int)min((int64_t)nb, n - j0);
+  const int ku = kv - kl;
+  int ju = st->ju, info = st->info;                // (every thread carries the same copy)
+  tg_lu_panel_copy<true>(ab, P, ldab, n, kl, kv, j0, nbc, H, tid);
+  __syncthreads();
+  for (int jj = 0; jj < nbc; jj++) {
+    const int64_t j = j0 + jj;
+    const int km = (int)min((int64_t)kl, n - 1 - j);
+    double *cj = P + jj * H + jj;                  // cj[i] = A(j + i, j)
+    // first maximum of |cj[0..km]|: the bit pattern of |a| orders like |a| (and a NaN above everything, so that it
+    // surfaces); ties go to the smallest index
+    unsigned long long key = 0;
+    int bi = 0x7fffffff;
+    for (int i = tid; i <= km; i += 1024) {
+      const unsigned long long k2 = (unsigned long long)__double_as_longlong(fabs(cj[i]));
+      if (k2 > key || bi == 0x7fffffff) {
+        key = k2;
+        bi = i;
+      }
+    }
+    const unsigned long long wmax = tg_wave_max_u64(key);
+    const int wi = tg_wave_min_i32(key == wmax ? bi : 0x7fffffff);
+    if ((tid & 63) == 0) {
+      wkey[wv] = wmax;
+      widx[wv] = wi;
+    }
+    __syncthreads();
+    unsigned long long bk = wkey[0];
+    int jp = widx[0];
+#pragma unroll
+    for (int w = 1; w < 16; w++) {
+      const unsigned long long k2 = wkey[w];
+      const int i2 = widx[w];
+      if (k2 > bk || (k2 == bk && i2 < jp)) {
+        bk = k2;
+        jp = i2;
+      }
+    }
+    const double piv = cj[jp], a0 = cj[0];
+    ju = max(ju, (int)min(j + (int64_t)ku + jp, n - 1));
+    if (tid == 0) ipiv[j] = (int32_t)(j + jp);
+    if (piv == 0.0 && info == 0) info = (int)(j + 1);
+    __syncthreads();                               // every thread has read the partial maxima, cj[0] and cj[jp]
+    if (piv == 0.0) continue;                      // (uniform) LAPACK goes on without eliminating
+    const int lcl = (int)min((int64_t)(nbc - 1), (int64_t)ju - j0);     // last panel column the step touches
+    const int ncol = lcl - jj;
+    // interchange (the other panel columns: one thread each; column jj itself through a0 / piv) and multipliers
+    if (jp != 0) {
+      if (tid < ncol) {
+        double *q = P + (jj + 1 + tid) * H + jj;
+        const double a = q[jp], b = q[0];
+        q[jp] = b;
+        q[0] = a;
+      }
+      if (tid == 0) cj[0] = piv;
+    }
+    const double pinv = 1.0 / piv;
+    for (int i = 1 + tid; i <= km; i += 1024) cj[i] = (i == jp ? a0 : cj[i]) * pinv;
+    __syncthreads();
+    // rank-1 update of the panel columns jj+1 .. lcl: a thread keeps its multiplier and walks the columns
+    for (int i = 1 + tid; i <= km; i += 1024) {
+      const double l = cj[i];
+      double *cc = P + (jj + 1) * H + jj;          // cc[i] = A(j + i, j + 1 + c)
+      for (int c = 0; c < ncol; c++, cc += H) {
+        const double u = cc[0];
+        if (u != 0.0) cc[i] = fma(-l, u, cc[i]);
+      }
+    }
+    __syncthreads();
+  }
+  tg_lu_panel_copy<false>(ab, P, ldab, n, kl, kv, j0, nbc, H, tid);
+  if (tid == 0) {
+    st->ju = ju;
+    st->info = info;
+  }
+}
+
+// trailing columns, one workgroup each (all of them resident at once: the kernel is bound by its instruction count).
+// NP > 0: a thread owns NP pairs of adjacent rows; the multipliers of a step, its pivot and its interchange are
+// fetched one step ahead, so that a step costs LDS work only.  NP = 0: any kl.
+template <int NP>
+__global__ void __launch_bounds__(256)
+    k_lu_trail(double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, int64_t j0, int nb,
+               const int32_t *__restrict__ ipiv, const tg_lu_state *__restrict__ st) {
+  extern __shared__ double col[];                  // col[r - j0], rows j0 .. j0 + nb - 1 + kl
+  const int tid = threadIdx.x;
+  const int nbc = (int)min((int64_t)nb, n - j0);
+  const int64_t ju = st->ju;
+  constexpr int NR = NP > 0 ? NP : 1;
+  for (int64_t c = j0 + nbc + blockIdx.x; c <= ju; c += gridDim.x) {   // (uniform per workgroup)
+    const int64_t rlo = max(j0, c - kv), rhi = min(n - 1, j0 + nbc - 1 + (int64_t)kl);
+    double *cc = ab + kv - c + ldab * c;           // cc[r] = A(r, c)
+    __syncthreads();
+    for (int64_t r = rlo + tid; r <= rhi; r += 256) col[r - j0] = cc[r];
+    const int jj0 = (int)(rlo - j0);               // steps before: their row is above this column's band (zero)
+    double la[NR], lb[NR], d0n = 0.0;
+    int64_t r2n = 0;
+    if (NP > 0 && jj0 < nbc) {
+      const int64_t j = j0 + jj0;
+      const double *lj = ab + kv + ldab * j;
+      const int km = (int)min((int64_t)kl, n - 1 - j);
+      d0n = lj[0];
+      r2n = ipiv[j];
+#pragma unroll
+      for (int q = 0; q < NR; q++) {
+        const int i = 1 + 2 * tid + 512 * q;
+        la[q] = i <= km ? lj[i] : 0.0;
+        lb[q] = i + 1 <= km ? lj[i + 1] : 0.0;
+      }
+    }
+    __syncthreads();
+    for (int jj = jj0; jj < nbc; jj++) {
+      const int64_t j = j0 + jj;
+      const double *lj = ab + kv + ldab * j;       // lj[i] = L(j + i, j); lj[0] = U(j, j)
+      const int km = (int)min((int64_t)kl, n - 1 - j);
+      double ca[NR], cb[NR], d0;
+      int64_t r2;
+      if (NP > 0) {
+        d0 = d0n;
+        r2 = r2n;
+#pragma unroll
+        for (int q = 0; q < NR; q++) {
+          ca[q] = la[q];
+          cb[q] = lb[q];
+        }
+        if (jj + 1 < nbc) {
+          const double *l1 = lj + ldab;
+          const int km1 = (int)min((int64_t)kl, n - 2 - j);
+          d0n = l1[0];
+          r2n = ipiv[j + 1];
+#pragma unroll
+          for (int q = 0; q < NR; q++) {
+            const int i = 1 + 2 * tid + 512 * q;
+            la[q] = i <= km1 ? l1[i] : 0.0;
+            lb[q] = i + 1 <= km1 ? l1[i + 1] : 0.0;
+          }
+        }
+      } else {
+        d0 = lj[0];
+        r2 = ipiv[j];
+      }
+      if (d0 == 0.0) continue;                     // zero pivot: the column was neither interchanged nor eliminated
+      // the interchange of step jj comes AFTER the eliminations of the steps before it (the multipliers of the columns
+      // to the left are stored un-interchanged, as dgbtf2 leaves them), so the two cannot be separated
+      double u = col[jj];
+      if (r2 != j) {
+        const double a = col[r2 - j0];
+        __syncthreads();                           // every thread has read both
+        if (tid == 0) {
+          col[r2 - j0] = u;
+          col[jj] = a;
+        }
+        u = a;
+        __syncthreads();
+      }
+      if (u != 0.0) {
+        if (NP > 0) {
+#pragma unroll
+          for (int q = 0; q < NR; q++) {
+            const int i = 1 + 2 * tid + 512 * q;
+            if (i + 1 <= km) {
+              col[jj + i] = fma(-ca[q], u, col[jj + i]);
+              col[jj + i + 1] = fma(-cb[q], u, col[jj + i + 1]);
+            } else if (i <= km) {
+              col[jj + i] = fma(-ca[q], u, col[jj + i]);
+            }
+          }
+        } else {
+          for (int i = 1 + tid; i <= km; i += 256) col[jj + i] = fma(-lj[i], u, col[jj + i]);
+        }
+      }
+      __syncthreads();
+    }
+    for (int64_t r = rlo + tid; r <= rhi; r += 256) cc[r] = col[r - j0];
+  }
+}
+
 // barrier that orders the LDS traffic of the workgroup only: __syncthreads() also waits for every outstanding GLOBAL
 // load, i.e. for the multipliers of the next step that are requested on purpose before they are needed
 #define TG_LDS_BARRIER()                                            \
@@ -319,7 +580,7 @@ __global__ void __launch_bounds__(1024)
     const double xj = ring[b];                                                                  \
     _Pragma("unroll") for (int q = 0; q < TG_LU_R; q++) {                                       \
       const int i = 1 + tid + 1024 * q;                                                         \
-      if (i <= km) ring[tg_slot(b, i, W)] -= CUR[q] * xj;                                       \
+      if (i <= km) ring[tg_slot(b, i, W)] = fma(-CUR[q], xj, ring[tg_slot(b, i, W)]);                                       \
     }                                                                                           \
     if (tid == 0) x[j_] = xj;                                                                   \
     if (top < n && j_ + 1 + kl + 1 > top) {                                                     \
@@ -366,7 +627,7 @@ __global__ void __launch_bounds__(1024)
     TG_LDS_BARRIER();                                                                           \
     _Pragma("unroll") for (int q = 0; q < TG_LU_R; q++) {                                       \
       const int i = 1 + tid + 1024 * q;                                                         \
-      if (i <= kk) ring[tg_slot(b, W - i, W)] -= CUR[q] * xj;                                   \
+      if (i <= kk) ring[tg_slot(b, W - i, W)] = fma(-CUR[q], xj, ring[tg_slot(b, W - i, W)]);                                   \
     }                                                                                           \
     if (tid == 0) x[j_] = xj;                                                                   \
     if (lo > 0 && lo > j_ - 1 - kv) {                                                           \
@@ -428,6 +689,7 @@ extern "C" int tg_lu_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *info) {
   double *ab = nullptr;
   int32_t *ipiv = nullptr;
   tg_lu_state *st = nullptr;
+  bool blocked_used = false;
   int rc = tg_dmalloc(&ab, ldab * n);
   if (!rc) rc = tg_dmalloc(&ipiv, n);
   if (!rc) rc = tg_dmalloc_bytes((void **)&st, 2 * sizeof(tg_lu_state));
@@ -448,8 +710,40 @@ extern "C" int tg_lu_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *info) {
                        g_tg.stream, k->rowptr, k->col, k->val, n, kv, ldab, ab);
     // column 0: pivot search alone (its state lands in slot 0); then ONE launch per column: launch j interchanges and
     // eliminates with column j and prepares column j+1 (TIGAR_LU_FUSED=0: the two launches per column of round 2)
-    static const int fused = getenv("TIGAR_LU_FUSED") ? atoi(getenv("TIGAR_LU_FUSED")) : 1;
-    if (fused) {
+    const int fused = getenv("TIGAR_LU_FUSED") ? atoi(getenv("TIGAR_LU_FUSED")) : 1;
+    const int blocked = getenv("TIGAR_LU_BLOCKED") ? atoi(getenv("TIGAR_LU_BLOCKED")) : 1;
+    // panel width: the widest of 32 / 16 / 8 / 4 columns whose panel ((kl + nb) x nb doubles) fits in LDS
+    int nb = 0;
+    for (int cand = 32; cand >= 4 && !nb; cand >>= 1)
+      if ((size_t)(kl + cand) * cand * sizeof(double) <= 140 * 1024) nb = cand;
+    if (getenv("TIGAR_LU_NB")) nb = atoi(getenv("TIGAR_LU_NB"));
+    bool use_blocked = blocked && nb >= 2 && kl > 0;
+    if (use_blocked) {
+      const size_t lds = (size_t)(kl + nb) * nb * sizeof(double);
+      if (hipFuncSetAttribute((const void *)k_lu_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        use_blocked = false;
+      }
+    }
+    blocked_used = use_blocked;
+    if (use_blocked) {
+      const size_t lds = (size_t)(kl + nb) * nb * sizeof(double);
+      const unsigned gt = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)kv + nb, (int64_t)g_tg.num_cu * 8));
+      for (int64_t j0 = 0; j0 < n; j0 += nb) {
+        hipLaunchKernelGGL(k_lu_panel, dim3(1), dim3(1024), lds, g_tg.stream, ab, ldab, n, kl, kv, j0, nb, ipiv, st);
+        if (j0 + nb < n) {
+          const size_t ldt = (size_t)(kl + nb) * sizeof(double);
+#define TG_LU_TRAIL(NI) hipLaunchKernelGGL(k_lu_trail<NI>, dim3(gt), dim3(256), ldt, g_tg.stream, ab, ldab, n, kl, kv, j0, nb, \
+                                           (const int32_t *)ipiv, (const tg_lu_state *)st)
+          if (kl <= 512) TG_LU_TRAIL(1);
+          else if (kl <= 1024) TG_LU_TRAIL(2);
+          else if (kl <= 1536) TG_LU_TRAIL(3);
+          else if (kl <= 2048) TG_LU_TRAIL(4);
+          else TG_LU_TRAIL(0);
+#undef TG_LU_TRAIL
+        }
+      }
+    } else if (fused) {
       hipLaunchKernelGGL(k_lu_pivot, dim3(1), dim3(256), 0, g_tg.stream, ab, ldab, n, kl, kv, (int64_t)0, ipiv, st, 0);
       const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)kv, (int64_t)g_tg.num_cu * 8));
       for (int64_t j = 0; j + 1 < n; j++)
@@ -472,8 +766,8 @@ extern "C" int tg_lu_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *info) {
   if (!rc) {
     tg_lu_state h1;
     // (fused: the state of the last column is in slot (n-1) & 1; `info` is carried from slot to slot)
-    static const int fused1 = getenv("TIGAR_LU_FUSED") ? atoi(getenv("TIGAR_LU_FUSED")) : 1;
-    if (hipMemcpyAsync(&h1, st + (fused1 ? ((n - 1) & 1) : 0), sizeof(h1), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
+    const int fused1 = getenv("TIGAR_LU_FUSED") ? atoi(getenv("TIGAR_LU_FUSED")) : 1;
+    if (hipMemcpyAsync(&h1, st + ((fused1 && !blocked_used) ? ((n - 1) & 1) : 0), sizeof(h1), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
     if (!rc && hipStreamSynchronize(g_tg.stream) != hipSuccess) {
       tg_set_error("tg_lu_solve: %s", hipGetErrorString(hipGetLastError()));
       rc = 1;
