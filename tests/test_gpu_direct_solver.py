@@ -48,7 +48,10 @@ def test_blocked_factorisation_gives_the_factors_of_the_column_by_column_one(mon
     tiny pivots (row interchanges across panel borders) and with a singular matrix (same `info`)."""
     from tigar_amd import device as dev
     rng = np.random.default_rng(7)
-    for (n, kl, ku) in [(7, 2, 1), (97, 5, 9), (700, 40, 17), (1500, 130, 130), (64, 63, 63)]:
+    # (the band widths walk through the instantiations of the register panel: 1, 2, 3 rows per thread with 256 threads,
+    # 3 with 384, then the 8-column panels; other panel widths and TIGAR_LU_PANEL_REG=0 run the panel in LDS)
+    for (n, kl, ku) in [(7, 2, 1), (97, 5, 9), (700, 40, 17), (1500, 130, 130), (64, 63, 63), (900, 300, 20),
+                        (1400, 600, 600), (1500, 1000, 30), (1800, 1300, 10), (2300, 2000, 50)]:
         diags = {o: rng.standard_normal(n - abs(o)) for o in range(-kl, ku + 1)}
         A = sp.diags(list(diags.values()), list(diags.keys()), shape=(n, n), format="csr").tolil()
         for i in range(0, n, 3):
@@ -59,8 +62,10 @@ def test_blocked_factorisation_gives_the_factors_of_the_column_by_column_one(mon
         monkeypatch.setenv("TIGAR_LU_BLOCKED", "0")
         x0 = dev.DeviceVector(n)
         assert dev.lu_solve(K, b, x0) == 0
-        for nb in ("", "2", "4", "5", "32"):
+        for nb in ("", "lds", "2", "4", "5", "8"):
             monkeypatch.setenv("TIGAR_LU_BLOCKED", "1")
+            monkeypatch.setenv("TIGAR_LU_PANEL_REG", "0" if nb == "lds" else "1")
+            nb = "" if nb == "lds" else nb
             if nb:
                 monkeypatch.setenv("TIGAR_LU_NB", nb)
             else:
@@ -69,6 +74,7 @@ def test_blocked_factorisation_gives_the_factors_of_the_column_by_column_one(mon
             assert dev.lu_solve(K, b, x1) == 0
             assert np.array_equal(x0.get_local().view(np.int64), x1.get_local().view(np.int64)), (n, kl, ku, nb)
         monkeypatch.delenv("TIGAR_LU_NB", raising=False)
+        monkeypatch.delenv("TIGAR_LU_PANEL_REG", raising=False)
     # singular: a zero column inside the band -> the same first zero pivot reported
     n = 50
     A = sp.diags([np.ones(n - 1), 2 * np.ones(n), np.ones(n - 1)], [-1, 0, 1], format="lil")

@@ -272,6 +272,14 @@ __global__ void __launch_bounds__(1024)
 // for bit the same.  Positions outside the band are never touched: a multiplier of column jj exists for the rows
 // jj+1 .. jj+kl only, a trailing column holds the rows >= c - kv only -- no work arrays as in dgbtrf, the loops are
 // bounded instead.
+// barrier that orders the LDS traffic of the workgroup only: __syncthreads() also waits for every outstanding GLOBAL
+// load, i.e. for the multipliers of the next step that are requested on purpose before they are needed
+#define TG_LDS_BARRIER()                                            \
+  do {                                                              \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
+    __builtin_amdgcn_s_barrier();                                   \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
+  } while (0)
 // copy of the panel between the band storage and LDS: four columns at a time (four independent loads in flight)
 template <bool LOAD>
 __device__ __forceinline__ void tg_lu_panel_copy(double *__restrict__ ab, double *P, int64_t ldab, int64_t n, int kl, int kv,
@@ -334,16 +342,22 @@ __device__ __forceinline__ int tg_wave_min_i32(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-// One workgroup on one CU: four waves per SIMD share its issue slots, so the kernel is bound by its instruction
-// count -- the search reduces through DPP (no LDS tree), the update walks the columns with the multiplier in a
-// register (no index arithmetic per entry).
+// One workgroup on one CU: its four waves per SIMD share the issue slots, so an instruction that all sixteen waves
+// execute costs sixteen cycles -- the kernel is bound by the instructions of a step, not by LDS or arithmetic.  Hence:
+//   search    ONE wave scans the column (a contiguous chunk per lane, so that the first lane holding the maximum holds its
+//             first occurrence), reduces through DPP and publishes pivot row, pivot, A(j, j) and the reciprocal;
+//   interchange + multipliers   one thread per column to the right / per pair of rows;
+//   rank-1 update               a thread keeps its two multipliers and walks the columns.
+// Three barriers per step, all of them waiting for LDS only (__syncthreads() would wait for global stores as well);
+// the pivot indices go to global memory at the end.
 __global__ void __launch_bounds__(1024)
     k_lu_panel(double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, int64_t j0, int nb,
                int32_t *__restrict__ ipiv, tg_lu_state *st) {
   extern __shared__ double P[];                    // [nb][H], H = kl + nb: P[lc * H + lr] = A(j0 + lr, j0 + lc)
-  __shared__ unsigned long long wkey[16];
-  __shared__ int widx[16];
-  const int tid = threadIdx.x, wv = tid >> 6;
+  __shared__ double sh_piv[3];                     // pivot, A(j, j) before the interchange, 1 / pivot
+  __shared__ int sh_jp;
+  __shared__ int spiv[32];
+  const int tid = threadIdx.x;
   const int H = kl + nb;
   const int nbc = (int)min((int64_t)nb, n - j0);
   const int ku = kv - kl;
@@ -354,92 +368,319 @@ __global__ void __launch_bounds__(1024)
     const int64_t j = j0 + jj;
     const int km = (int)min((int64_t)kl, n - 1 - j);
     double *cj = P + jj * H + jj;                  // cj[i] = A(j + i, j)
-    // first maximum of |cj[0..km]|: the bit pattern of |a| orders like |a| (and a NaN above everything, so that it
-    // surfaces); ties go to the smallest index
-    unsigned long long key = 0;
-    int bi = 0x7fffffff;
-    for (int i = tid; i <= km; i += 1024) {
-      const unsigned long long k2 = (unsigned long long)__double_as_longlong(fabs(cj[i]));
-      if (k2 > key || bi == 0x7fffffff) {
-        key = k2;
-        bi = i;
-      }
-    }
-    const unsigned long long wmax = tg_wave_max_u64(key);
-    const int wi = tg_wave_min_i32(key == wmax ? bi : 0x7fffffff);
-    if ((tid & 63) == 0) {
-      wkey[wv] = wmax;
-      widx[wv] = wi;
-    }
-    __syncthreads();
-    unsigned long long bk = wkey[0];
-    int jp = widx[0];
+    if (tid < 64) {
+      // first maximum of |cj[0..km]|: the bit pattern of |a| orders like |a| (and a NaN above everything, so that it
+      // surfaces); ties go to the smallest index
+      const int chunk = (km + 64) >> 6;
+      const int lo = tid * chunk, hi = min(lo + chunk - 1, km);
+      unsigned long long key = 0;
+      int bi = -1;
+      for (int i8 = lo; i8 <= hi; i8 += 8) {        // eight independent LDS reads in flight
+        double v[8];
 #pragma unroll
-    for (int w = 1; w < 16; w++) {
-      const unsigned long long k2 = wkey[w];
-      const int i2 = widx[w];
-      if (k2 > bk || (k2 == bk && i2 < jp)) {
-        bk = k2;
-        jp = i2;
+        for (int q = 0; q < 8; q++) v[q] = i8 + q <= hi ? cj[i8 + q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const unsigned long long k2 = (unsigned long long)__double_as_longlong(fabs(v[q]));
+          if (i8 + q <= hi && (k2 > key || bi < 0)) {
+            key = k2;
+            bi = i8 + q;
+          }
+        }
+      }
+      const unsigned long long wmax = tg_wave_max_u64(key);
+      const unsigned long long holders = __ballot(bi >= 0 && key == wmax);
+      const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)holders) - 1);
+      const int jp = __shfl(bi, first);
+      if (tid == 0) {
+        const double piv = cj[jp];
+        sh_jp = jp;
+        sh_piv[0] = piv;
+        sh_piv[1] = cj[0];
+        sh_piv[2] = piv != 0.0 ? 1.0 / piv : 0.0;
+        spiv[jj] = (int)(j + jp);
       }
     }
-    const double piv = cj[jp], a0 = cj[0];
+    TG_LDS_BARRIER();
+    const int jp = sh_jp;
+    const double piv = sh_piv[0];
     ju = max(ju, (int)min(j + (int64_t)ku + jp, n - 1));
-    if (tid == 0) ipiv[j] = (int32_t)(j + jp);
     if (piv == 0.0 && info == 0) info = (int)(j + 1);
-    __syncthreads();                               // every thread has read the partial maxima, cj[0] and cj[jp]
-    if (piv == 0.0) continue;                      // (uniform) LAPACK goes on without eliminating
     const int lcl = (int)min((int64_t)(nbc - 1), (int64_t)ju - j0);     // last panel column the step touches
-    const int ncol = lcl - jj;
-    // interchange (the other panel columns: one thread each; column jj itself through a0 / piv) and multipliers
-    if (jp != 0) {
-      if (tid < ncol) {
-        double *q = P + (jj + 1 + tid) * H + jj;
-        const double a = q[jp], b = q[0];
-        q[jp] = b;
-        q[0] = a;
+    const int ncol = piv != 0.0 ? lcl - jj : 0;    // (a zero pivot: LAPACK goes on without eliminating)
+    if (piv != 0.0) {                              // (uniform)
+      const double a0 = sh_piv[1], pinv = sh_piv[2];
+      if (jp != 0) {
+        if (tid < ncol) {                          // interchange in the columns to the right
+          double *q = P + (jj + 1 + tid) * H + jj;
+          const double a = q[jp], b = q[0];
+          q[jp] = b;
+          q[0] = a;
+        }
+        if (tid == 0) cj[0] = piv;                 // ... and in column jj (row jp: below, through a0)
       }
-      if (tid == 0) cj[0] = piv;
-    }
-    const double pinv = 1.0 / piv;
-    for (int i = 1 + tid; i <= km; i += 1024) cj[i] = (i == jp ? a0 : cj[i]) * pinv;
-    __syncthreads();
-    // rank-1 update of the panel columns jj+1 .. lcl: a thread keeps its multiplier and walks the columns
-    for (int i = 1 + tid; i <= km; i += 1024) {
-      const double l = cj[i];
-      double *cc = P + (jj + 1) * H + jj;          // cc[i] = A(j + i, j + 1 + c)
-      for (int c = 0; c < ncol; c++, cc += H) {
-        const double u = cc[0];
-        if (u != 0.0) cc[i] = fma(-l, u, cc[i]);
+      for (int i0 = 1 + 2 * tid; i0 <= km; i0 += 2048) {               // multipliers: a pair of rows per thread
+        const int i1 = i0 + 1;
+        cj[i0] = (i0 == jp ? a0 : cj[i0]) * pinv;
+        if (i1 <= km) cj[i1] = (i1 == jp ? a0 : cj[i1]) * pinv;
       }
     }
-    __syncthreads();
+    TG_LDS_BARRIER();
+    if (ncol > 0)
+      for (int i0 = 1 + 2 * tid; i0 <= km; i0 += 2048) {               // rank-1 update of the columns jj+1 .. lcl
+        const bool h1 = i0 + 1 <= km;
+        const double l0 = cj[i0], l1 = h1 ? cj[i0 + 1] : 0.0;
+        double *cc = P + (jj + 1) * H + jj;        // cc[i] = A(j + i, j + 1 + c)
+        int c = 0;
+        for (; c + 4 <= ncol; c += 4, cc += 4 * H) {
+          double u[4], x0[4], x1[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            u[q] = cc[q * H];
+            x0[q] = cc[q * H + i0];
+            x1[q] = h1 ? cc[q * H + i0 + 1] : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (u[q] != 0.0) {
+              cc[q * H + i0] = fma(-l0, u[q], x0[q]);
+              if (h1) cc[q * H + i0 + 1] = fma(-l1, u[q], x1[q]);
+            }
+        }
+        for (; c < ncol; c++, cc += H) {
+          const double u = cc[0];
+          if (u != 0.0) {
+            cc[i0] = fma(-l0, u, cc[i0]);
+            if (h1) cc[i0 + 1] = fma(-l1, u, cc[i0 + 1]);
+          }
+        }
+      }
+    TG_LDS_BARRIER();
   }
   tg_lu_panel_copy<false>(ab, P, ldab, n, kl, kv, j0, nbc, H, tid);
+  if (tid < nbc) ipiv[j0 + tid] = spiv[tid];
   if (tid == 0) {
     st->ju = ju;
     st->info = info;
   }
 }
 
-// trailing columns, one workgroup each (all of them resident at once: the kernel is bound by its instruction count).
-// NP > 0: a thread owns NP pairs of adjacent rows; the multipliers of a step, its pivot and its interchange are
-// fetched one step ahead, so that a step costs LDS work only.  NP = 0: any kl.
+// The panel in REGISTERS (round 3, after the LDS panel above proved bound by LDS bandwidth and by the issue slots that
+// sixteen waves share; cfg4: 54 us per 16 columns in LDS, 39 us here): NT threads, thread t owns the panel rows t, t + NT,
+// ... (RS of them) of all NB columns.  A step:
+// every thread proposes the largest of its own candidates, the waves reduce through DPP, four partial results meet in
+// LDS | the owner of the pivot row and the owner of row j publish their rows (columns j .. ) | everyone reads them,
+// takes part in the interchange if it owns one of the two rows, scales its multipliers and updates its own entries.
+// Two barriers per step, LDS traffic of a few hundred bytes, the update is plain FMAs on registers.  All loops are
+// unrolled (the register file is indexed statically).
+// a value that is the same in every lane, moved to scalar registers
+__device__ __forceinline__ double tg_uniform_f64(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+struct tg_lu_panel_ctx {
+  unsigned long long *wkey;
+  int *widx;
+  double *urow, *r0row;
+  int *spiv;
+  int64_t n, j0;
+  int kl, ku, nbc, tid, ju, info;
+};
+// step JJ of the register panel (a template recursion: the register file is indexed statically)
+template <int NB, int RS, int NT, int JJ>
+__device__ __forceinline__ void tg_lu_panel_step(double (&a)[RS][NB], tg_lu_panel_ctx &X) {
+  if constexpr (JJ < NB) {
+    if (JJ >= X.nbc) return;                       // (uniform)
+    const int tid = X.tid;
+    const int64_t j = X.j0 + JJ;
+    const int km = (int)min((int64_t)X.kl, X.n - 1 - j);
+    // first maximum of |A(j .. j + km, j)|: the bit pattern of |a| orders like |a| (and a NaN above everything, so that it
+    // surfaces); ties go to the smallest row
+    unsigned long long key = 0;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int s = 0; s < RS; s++) {
+      const int lr = tid + NT * s;
+      const unsigned long long k2 = (unsigned long long)__double_as_longlong(fabs(a[s][JJ]));
+      if (lr >= JJ && lr <= JJ + km && (k2 > key || bi == 0x7fffffff)) {
+        key = k2;
+        bi = lr - JJ;
+      }
+    }
+    const unsigned long long wmax = tg_wave_max_u64(key);
+    const int wi = tg_wave_min_i32(key == wmax ? bi : 0x7fffffff);
+    if ((tid & 63) == 0) {
+      X.wkey[tid >> 6] = wmax;
+      X.widx[tid >> 6] = wi;
+    }
+    TG_LDS_BARRIER();
+    unsigned long long bk = X.wkey[0];
+    int jp = X.widx[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; w++) {
+      const unsigned long long k2 = X.wkey[w];
+      const int i2 = X.widx[w];
+      if (k2 > bk || (k2 == bk && i2 < jp)) {
+        bk = k2;
+        jp = i2;
+      }
+    }
+    // everything below that is the same in every lane is moved to scalar registers, so that the branches on it are
+    // scalar branches and only the code of the slot that owns a row is executed (the kernel is bound by its instruction
+    // count: straight-line code, executed once)
+    jp = __builtin_amdgcn_readfirstlane(jp);
+    const int lrp = JJ + jp;                       // the pivot row (relative to j0)
+    const int sp = lrp / NT, tp = lrp - sp * NT;
+#pragma unroll
+    for (int s = 0; s < RS; s++)
+      if (sp == s) {                               // (scalar branch: the asm keeps it from becoming selects)
+        asm volatile("" ::: "memory");
+        if (tid == tp) {
+#pragma unroll
+          for (int c = JJ; c < NB; c++) X.urow[c] = a[s][c];
+        }
+      }
+    if (tid == JJ) {
+#pragma unroll
+      for (int c = JJ; c < NB; c++) X.r0row[c] = a[0][c];
+      X.spiv[JJ] = (int)(j + jp);
+    }
+    TG_LDS_BARRIER();
+    const double piv = tg_uniform_f64(X.urow[JJ]);
+    X.ju = max(X.ju, (int)min(j + (int64_t)X.ku + jp, X.n - 1));
+    if (piv == 0.0) {                              // (uniform) LAPACK goes on without eliminating
+      if (X.info == 0) X.info = (int)(j + 1);
+    } else {
+      const int lcl = __builtin_amdgcn_readfirstlane((int)min((int64_t)(X.nbc - 1), (int64_t)X.ju - X.j0));    // last panel column the step touches
+      const double pinv = 1.0 / piv;
+      double uc[NB];
+#pragma unroll
+      for (int c = JJ + 1; c < NB; c++) uc[c] = tg_uniform_f64(X.urow[c]);
+      if (jp != 0) {                               // interchange of the rows JJ and lrp, columns JJ .. (past lcl: zeros)
+        asm volatile("" ::: "memory");
+        if (tid == JJ) {
+          a[0][JJ] = piv;
+#pragma unroll
+          for (int c = JJ + 1; c < NB; c++) a[0][c] = uc[c];
+        }
+#pragma unroll
+        for (int s = 0; s < RS; s++)
+          if (sp == s) {
+            asm volatile("" ::: "memory");
+            if (tid == tp) {
+#pragma unroll
+              for (int c = JJ; c < NB; c++) a[s][c] = X.r0row[c];
+            }
+          }
+      }
+      // multipliers; a row outside JJ+1 .. JJ+km gets the multiplier 0: for the rows past the band (nothing stored, zeros
+      // that are never written back) the update below is then an exact no-op, the rows <= JJ (slot 0 only) are protected
+      double l[RS];
+#pragma unroll
+      for (int s = 0; s < RS; s++) {
+        const int lr = tid + NT * s;
+        const bool inr = lr > JJ && lr <= JJ + km;
+        l[s] = inr ? a[s][JJ] * pinv : 0.0;
+        a[s][JJ] = inr ? l[s] : a[s][JJ];
+      }
+#pragma unroll
+      for (int c = JJ + 1; c < NB; c++)
+        if (c <= lcl && uc[c] != 0.0) {            // (uniform: a scalar branch around RS FMAs)
+          asm volatile("" ::: "memory");
+          a[0][c] = tid > JJ ? fma(-l[0], uc[c], a[0][c]) : a[0][c];
+#pragma unroll
+          for (int s = 1; s < RS; s++) a[s][c] = fma(-l[s], uc[c], a[s][c]);
+        }
+    }
+    tg_lu_panel_step<NB, RS, NT, JJ + 1>(a, X);
+  }
+}
+
+template <int NB, int RS, int NT>
+__global__ void __launch_bounds__(NT)
+    k_lu_panel_reg(double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, int64_t j0, int32_t *__restrict__ ipiv,
+                   tg_lu_state *st) {
+  __shared__ unsigned long long wkey[NT / 64];
+  __shared__ int widx[NT / 64];
+  __shared__ double urow[NB], r0row[NB];           // the pivot row / row j, columns j .. , before the interchange
+  __shared__ int spiv[NB];
+  const int tid = threadIdx.x;
+  const int nbc = (int)min((int64_t)NB, n - j0);
+  const int rmax = (int)min((int64_t)kl + NB - 1, n - 1 - j0);         // last row of the panel (relative to j0)
+  double a[RS][NB];                                // a[s][c] = A(j0 + tid + NT s, j0 + c); 0 where nothing is stored
+#pragma unroll
+  for (int s = 0; s < RS; s++) {
+    const int lr = tid + NT * s;
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      const bool ok = c < nbc && lr <= rmax && lr >= c - kv && lr <= c + kl;
+      a[s][c] = ok ? ab[kv + lr - c + ldab * (j0 + c)] : 0.0;
+    }
+  }
+  tg_lu_panel_ctx X;
+  X.wkey = wkey;
+  X.widx = widx;
+  X.urow = urow;
+  X.r0row = r0row;
+  X.spiv = spiv;
+  X.n = n;
+  X.j0 = j0;
+  X.kl = kl;
+  X.ku = kv - kl;
+  X.nbc = nbc;
+  X.tid = tid;
+  X.ju = st->ju;                                   // (every thread carries the same copy)
+  X.info = st->info;
+  tg_lu_panel_step<NB, RS, NT, 0>(a, X);
+#pragma unroll
+  for (int s = 0; s < RS; s++) {
+    const int lr = tid + NT * s;
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      const bool ok = c < nbc && lr <= rmax && lr >= c - kv && lr <= c + kl;
+      if (ok) ab[kv + lr - c + ldab * (j0 + c)] = a[s][c];
+    }
+  }
+  __syncthreads();
+  if (tid < nbc) ipiv[j0 + tid] = spiv[tid];
+  if (tid == 0) {
+    st->ju = X.ju;
+    st->info = X.info;
+  }
+}
+
+// Trailing columns: a workgroup takes TG_LU_TC adjacent columns (in LDS) through the nb steps of the panel; the
+// multipliers of a step are fetched a step ahead, with the pivot and the interchange of the step.  Measured at cfg4
+// (kl = 1044, nb = 16): 22 us with one column per workgroup, 24 / 32 us with two / four (the columns in LDS make the
+// steps LDS-bandwidth bound, 16 B per FMA, whatever the grouping; holding the multipliers of all steps in registers
+// halved the occupancy and was slower still).  NP > 0: a thread owns NP pairs of adjacent rows (kl <= 512 NP); NP = 0:
+// any kl, multipliers read where they are used.
+#define TG_LU_TC 1
 template <int NP>
 __global__ void __launch_bounds__(256)
     k_lu_trail(double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, int64_t j0, int nb,
                const int32_t *__restrict__ ipiv, const tg_lu_state *__restrict__ st) {
-  extern __shared__ double col[];                  // col[r - j0], rows j0 .. j0 + nb - 1 + kl
+  extern __shared__ double col[];                  // [TG_LU_TC][W]: col[t * W + r - j0], rows j0 .. j0 + nb - 1 + kl
   const int tid = threadIdx.x;
+  const int W = kl + nb;
   const int nbc = (int)min((int64_t)nb, n - j0);
   const int64_t ju = st->ju;
   constexpr int NR = NP > 0 ? NP : 1;
-  for (int64_t c = j0 + nbc + blockIdx.x; c <= ju; c += gridDim.x) {   // (uniform per workgroup)
-    const int64_t rlo = max(j0, c - kv), rhi = min(n - 1, j0 + nbc - 1 + (int64_t)kl);
-    double *cc = ab + kv - c + ldab * c;           // cc[r] = A(r, c)
+  const int64_t rhi = min(n - 1, j0 + nbc - 1 + (int64_t)kl);
+  for (int64_t c0 = j0 + nbc + (int64_t)TG_LU_TC * blockIdx.x; c0 <= ju; c0 += (int64_t)TG_LU_TC * gridDim.x) {
     __syncthreads();
-    for (int64_t r = rlo + tid; r <= rhi; r += 256) col[r - j0] = cc[r];
-    const int jj0 = (int)(rlo - j0);               // steps before: their row is above this column's band (zero)
+    // rows above a column's band (r < c - kv) and columns past ju enter as zeros and are never written back
+    for (int64_t r = j0 + tid; r <= rhi; r += 256) {
+      double v[TG_LU_TC];
+#pragma unroll
+      for (int t = 0; t < TG_LU_TC; t++) {
+        const int64_t c = c0 + t;
+        v[t] = (c <= ju && r >= c - kv) ? ab[kv + r - c + ldab * c] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < TG_LU_TC; t++) col[t * W + (r - j0)] = v[t];
+    }
+    const int jj0 = (int)max((int64_t)0, c0 - kv - j0);                // steps before: row j is above every band of the group
     double la[NR], lb[NR], d0n = 0.0;
     int64_t r2n = 0;
     if (NP > 0 && jj0 < nbc) {
@@ -489,47 +730,63 @@ __global__ void __launch_bounds__(256)
       if (d0 == 0.0) continue;                     // zero pivot: the column was neither interchanged nor eliminated
       // the interchange of step jj comes AFTER the eliminations of the steps before it (the multipliers of the columns
       // to the left are stored un-interchanged, as dgbtf2 leaves them), so the two cannot be separated
-      double u = col[jj];
       if (r2 != j) {
-        const double a = col[r2 - j0];
-        __syncthreads();                           // every thread has read both
-        if (tid == 0) {
-          col[r2 - j0] = u;
-          col[jj] = a;
+        if (tid < TG_LU_TC) {
+          double *q = col + tid * W;
+          const double a = q[r2 - j0], b = q[jj];
+          q[r2 - j0] = b;
+          q[jj] = a;
         }
-        u = a;
-        __syncthreads();
+        TG_LDS_BARRIER();
       }
-      if (u != 0.0) {
+      double u[TG_LU_TC];
+      bool any = false;
+#pragma unroll
+      for (int t = 0; t < TG_LU_TC; t++) {
+        u[t] = col[t * W + jj];
+        any = any || u[t] != 0.0;
+      }
+      if (any) {                                   // (uniform)
         if (NP > 0) {
 #pragma unroll
           for (int q = 0; q < NR; q++) {
             const int i = 1 + 2 * tid + 512 * q;
             if (i + 1 <= km) {
-              col[jj + i] = fma(-ca[q], u, col[jj + i]);
-              col[jj + i + 1] = fma(-cb[q], u, col[jj + i + 1]);
+#pragma unroll
+              for (int t = 0; t < TG_LU_TC; t++)
+                if (u[t] != 0.0) {
+                  double *x = col + t * W + jj + i;
+                  const double x0 = x[0], x1 = x[1];
+                  x[0] = fma(-ca[q], u[t], x0);
+                  x[1] = fma(-cb[q], u[t], x1);
+                }
             } else if (i <= km) {
-              col[jj + i] = fma(-ca[q], u, col[jj + i]);
+#pragma unroll
+              for (int t = 0; t < TG_LU_TC; t++)
+                if (u[t] != 0.0) col[t * W + jj + i] = fma(-ca[q], u[t], col[t * W + jj + i]);
             }
           }
         } else {
-          for (int i = 1 + tid; i <= km; i += 256) col[jj + i] = fma(-lj[i], u, col[jj + i]);
+          for (int i = 1 + tid; i <= km; i += 256) {
+            const double l = lj[i];
+#pragma unroll
+            for (int t = 0; t < TG_LU_TC; t++)
+              if (u[t] != 0.0) col[t * W + jj + i] = fma(-l, u[t], col[t * W + jj + i]);
+          }
         }
       }
-      __syncthreads();
+      TG_LDS_BARRIER();                            // (LDS only: the multipliers of the next step stay in flight)
     }
-    for (int64_t r = rlo + tid; r <= rhi; r += 256) cc[r] = col[r - j0];
+    for (int64_t r = j0 + tid; r <= rhi; r += 256) {
+#pragma unroll
+      for (int t = 0; t < TG_LU_TC; t++) {
+        const int64_t c = c0 + t;
+        if (c <= ju && r >= c - kv) ab[kv + r - c + ldab * c] = col[t * W + (r - j0)];
+      }
+    }
   }
 }
 
-// barrier that orders the LDS traffic of the workgroup only: __syncthreads() also waits for every outstanding GLOBAL
-// load, i.e. for the multipliers of the next step that are requested on purpose before they are needed
-#define TG_LDS_BARRIER()                                            \
-  do {                                                              \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
-    __builtin_amdgcn_s_barrier();                                   \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
-  } while (0)
 #define TG_LU_R 6            // entries of a step per thread held in registers: windows of up to 6 * 1024 entries
 #define TG_LU_CH 1024        // entries of x that enter the window at a time
 // ring slot of entry (base entry at slot b) + off, 0 <= off < W   (32-bit: a 64-bit modulo per access costs more than the step)
@@ -712,36 +969,47 @@ extern "C" int tg_lu_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *info) {
     // eliminates with column j and prepares column j+1 (TIGAR_LU_FUSED=0: the two launches per column of round 2)
     const int fused = getenv("TIGAR_LU_FUSED") ? atoi(getenv("TIGAR_LU_FUSED")) : 1;
     const int blocked = getenv("TIGAR_LU_BLOCKED") ? atoi(getenv("TIGAR_LU_BLOCKED")) : 1;
-    // panel width: the widest of 32 / 16 / 8 / 4 columns whose panel ((kl + nb) x nb doubles) fits in LDS
+    // panel width: the widest of 16 / 8 / 4 columns whose panel ((kl + nb) x nb doubles) fits in LDS
     int nb = 0;
-    for (int cand = 32; cand >= 4 && !nb; cand >>= 1)
+    for (int cand = 16; cand >= 4 && !nb; cand >>= 1)
       if ((size_t)(kl + cand) * cand * sizeof(double) <= 140 * 1024) nb = cand;
-    if (getenv("TIGAR_LU_NB")) nb = atoi(getenv("TIGAR_LU_NB"));
+    if (getenv("TIGAR_LU_NB")) nb = std::min(32, atoi(getenv("TIGAR_LU_NB")));
     bool use_blocked = blocked && nb >= 2 && kl > 0;
-    if (use_blocked) {
-      const size_t lds = (size_t)(kl + nb) * nb * sizeof(double);
-      if (hipFuncSetAttribute((const void *)k_lu_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        (void)hipGetLastError();
-        use_blocked = false;
+    typedef void (*trail_fn)(double *, int64_t, int64_t, int, int, int64_t, int, const int32_t *, const tg_lu_state *);
+    const trail_fn trail = kl <= 512 ? k_lu_trail<1> : kl <= 1024 ? k_lu_trail<2> : kl <= 1536 ? k_lu_trail<3>
+                           : kl <= 2048 ? k_lu_trail<4> : k_lu_trail<0>;
+    typedef void (*panel_reg_fn)(double *, int64_t, int64_t, int, int, int64_t, int32_t *, tg_lu_state *);
+    panel_reg_fn panel_reg = nullptr;              // (TIGAR_LU_PANEL_REG=0: the panel in LDS)
+    int panel_nt = 0;
+    if (!(getenv("TIGAR_LU_PANEL_REG") && atoi(getenv("TIGAR_LU_PANEL_REG")) == 0)) {
+      const int rows = kl + nb;                    // rows of the panel: NT threads x RS rows each
+      if (nb == 16) {
+        if (rows <= 256) panel_reg = k_lu_panel_reg<16, 1, 256>, panel_nt = 256;
+        else if (rows <= 512) panel_reg = k_lu_panel_reg<16, 2, 256>, panel_nt = 256;
+        else if (rows <= 768) panel_reg = k_lu_panel_reg<16, 3, 256>, panel_nt = 256;
+        else if (rows <= 1152) panel_reg = k_lu_panel_reg<16, 3, 384>, panel_nt = 384;
+      } else if (nb == 8) {
+        if (rows <= 1536) panel_reg = k_lu_panel_reg<8, 4, 384>, panel_nt = 384;
+        else if (rows <= 2304) panel_reg = k_lu_panel_reg<8, 6, 384>, panel_nt = 384;
       }
+    }
+    const size_t lds = (size_t)(kl + nb) * nb * sizeof(double);        // the panel
+    const size_t ldt = (size_t)TG_LU_TC * (kl + nb) * sizeof(double);  // TG_LU_TC trailing columns
+    if (use_blocked &&
+        (hipFuncSetAttribute((const void *)k_lu_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+         hipFuncSetAttribute((const void *)trail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldt) != hipSuccess)) {
+      (void)hipGetLastError();
+      use_blocked = false;
     }
     blocked_used = use_blocked;
     if (use_blocked) {
-      const size_t lds = (size_t)(kl + nb) * nb * sizeof(double);
-      const unsigned gt = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)kv + nb, (int64_t)g_tg.num_cu * 8));
+      const unsigned gt = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv((int64_t)kv + nb, TG_LU_TC), (int64_t)g_tg.num_cu * 8));
       for (int64_t j0 = 0; j0 < n; j0 += nb) {
-        hipLaunchKernelGGL(k_lu_panel, dim3(1), dim3(1024), lds, g_tg.stream, ab, ldab, n, kl, kv, j0, nb, ipiv, st);
-        if (j0 + nb < n) {
-          const size_t ldt = (size_t)(kl + nb) * sizeof(double);
-#define TG_LU_TRAIL(NI) hipLaunchKernelGGL(k_lu_trail<NI>, dim3(gt), dim3(256), ldt, g_tg.stream, ab, ldab, n, kl, kv, j0, nb, \
-                                           (const int32_t *)ipiv, (const tg_lu_state *)st)
-          if (kl <= 512) TG_LU_TRAIL(1);
-          else if (kl <= 1024) TG_LU_TRAIL(2);
-          else if (kl <= 1536) TG_LU_TRAIL(3);
-          else if (kl <= 2048) TG_LU_TRAIL(4);
-          else TG_LU_TRAIL(0);
-#undef TG_LU_TRAIL
-        }
+        if (panel_reg) hipLaunchKernelGGL(panel_reg, dim3(1), dim3(panel_nt), 0, g_tg.stream, ab, ldab, n, kl, kv, j0, ipiv, st);
+        else hipLaunchKernelGGL(k_lu_panel, dim3(1), dim3(1024), lds, g_tg.stream, ab, ldab, n, kl, kv, j0, nb, ipiv, st);
+        if (j0 + nb >= n) break;
+        hipLaunchKernelGGL(trail, dim3(gt), dim3(256), ldt, g_tg.stream, ab, ldab, n, kl, kv, j0, nb, (const int32_t *)ipiv,
+                             (const tg_lu_state *)st);
       }
     } else if (fused) {
       hipLaunchKernelGGL(k_lu_pivot, dim3(1), dim3(256), 0, g_tg.stream, ab, ldab, n, kl, kv, (int64_t)0, ipiv, st, 0);
