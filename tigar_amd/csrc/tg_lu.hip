@@ -787,126 +787,144 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-#define TG_LU_R 6            // entries of a step per thread held in registers: windows of up to 6 * 1024 entries
 #define TG_LU_CH 1024        // entries of x that enter the window at a time
 // ring slot of entry (base entry at slot b) + off, 0 <= off < W   (32-bit: a 64-bit modulo per access costs more than the step)
 __device__ __forceinline__ int tg_slot(int b, int off, int W) {
   const int q = b + off;
   return q >= W ? q - W : q;
 }
-__device__ __forceinline__ void tg_lu_load_col(const double *__restrict__ col, int sign, int cnt, int tid, double *v) {
+template <int R, int NT>
+__device__ __forceinline__ void tg_lu_load_col(const double *__restrict__ col, int sign, int cnt, int tid, double (&v)[R]) {
 #pragma unroll
-  for (int q = 0; q < TG_LU_R; q++) {
-    const int i = 1 + tid + 1024 * q;
-    v[q] = i <= cnt ? col[sign * i] : 0.0;
+  for (int q = 0; q < R; q++) {
+    const int i = 1 + tid + NT * q;
+    v[q] = col[sign * (i <= cnt ? i : 0)];         // (unconditional: a branch around a load makes the compiler wait for
+  }                                                //  ALL outstanding loads at the next use; entries past cnt are not used)
+}
+
+// Substitution with the window of x that a step touches in an LDS ring (one workgroup of NT threads; entries enter
+// TG_LU_CH at a time).  A step is one LDS-only barrier (two for a forward step with an interchange) and R guarded FMAs per thread:
+// the interchange of a forward step is not carried out first -- every thread reads x[j + jp] as the value of the step,
+// and the owner of entry j + jp continues from the old x[j].  The entries of a column (and its pivot) are requested D steps before their use, into the register
+// slot the step D before has just emptied.  R = entries of a column per thread (windows of up to R * NT entries).
+template <int R, int D, int NT>
+__global__ void __launch_bounds__(NT)
+    k_lu_fwd(const double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, const int32_t *__restrict__ ipiv,
+             double *__restrict__ x) {
+  extern __shared__ double ring[];                 // W doubles; entry x[q] lives at slot q mod W
+  const int tid = threadIdx.x;
+  const int W = kl + 2 + TG_LU_CH;
+  // the window [j, j + kl] lies inside the loaded range [j, top); `top` grows by TG_LU_CH entries at a time
+  int64_t top = min(n, (int64_t)kl + 1 + TG_LU_CH);
+  for (int64_t q = tid; q < top; q += NT) ring[(int)(q % W)] = x[q];
+  int b = 0;                                       // slot of entry j
+  int tb = (int)(top % W);                         // slot of entry top
+  double L[D][R];
+  int JP[D];                                       // pivot offsets jp - j
+#pragma unroll
+  for (int k = 0; k < D; k++) {
+    JP[k] = 0;
+    if (k < n) {
+      JP[k] = (int)(ipiv[k] - k);
+      tg_lu_load_col<R, NT>(ab + kv + ldab * k, 1, (int)min((int64_t)kl, n - 1 - k), tid, L[k]);
+    }
+  }
+  __syncthreads();
+  for (int64_t j0 = 0; j0 < n; j0 += D) {
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      const int64_t j = j0 + k;
+      if (j < n) {                                 // (uniform)
+        const int km = (int)min((int64_t)kl, n - 1 - j);
+        const int jp = JP[k];
+        const double xj = ring[tg_slot(b, jp, W)], r0 = ring[b];
+        if (jp != 0) TG_LDS_BARRIER();             // (uniform) every thread has x[j + jp] before its owner overwrites it
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+          const int i = 1 + tid + NT * q;
+          if (i <= km) {
+            const int sl = tg_slot(b, i, W);
+            const double v = ring[sl];
+            ring[sl] = fma(-L[k][q], xj, i == jp ? r0 : v);
+          }
+        }
+        if (tid == 0) x[j] = xj;
+        {                                          // the slot is free: column j + D (past the end: the last column again)
+          const int64_t j2 = min(j + D, n - 1);
+          JP[k] = (int)(ipiv[j2] - j2);
+          tg_lu_load_col<R, NT>(ab + kv + ldab * j2, 1, (int)min((int64_t)kl, n - 1 - j2), tid, L[k]);
+        }
+        if (top < n && j + 1 + kl + 1 > top) {
+          const int64_t e1 = min(n, top + TG_LU_CH);
+          for (int64_t e = top + tid; e < e1; e += NT) ring[tg_slot(tb, (int)(e - top), W)] = x[e];
+          tb = tg_slot(tb, (int)(e1 - top), W);
+          top = e1;
+        }
+        TG_LDS_BARRIER();
+        b = tg_slot(b, 1, W);
+      }
+    }
   }
 }
 
-__global__ void __launch_bounds__(1024)
-    k_lu_solve(const double *__restrict__ ab, int64_t ldab, int64_t n, int kl, int kv, const int32_t *__restrict__ ipiv,
-               double *__restrict__ x) {
-  extern __shared__ double ring[];                 // W doubles; entry x[q] lives at slot q mod W
+template <int R, int D, int NT>
+__global__ void __launch_bounds__(NT)
+    k_lu_bwd(const double *__restrict__ ab, int64_t ldab, int64_t n, int kv, double *__restrict__ x) {
+  extern __shared__ double ring[];
   const int tid = threadIdx.x;
   const int W = kv + 2 + TG_LU_CH;
-  double va[TG_LU_R], vb[TG_LU_R];
-  // ---- forward: the window [j, j + kl] lies inside the loaded range [j, top); `top` grows by TG_LU_CH entries at a time
-  // (all threads load, one wait per TG_LU_CH steps).  The multipliers and the pivot row of step j+1 are requested during
-  // step j into the OTHER register set (two steps per trip of the loop: no copies, so nothing waits for them early).
-  int64_t top = min(n, (int64_t)kl + 1 + TG_LU_CH);
-  for (int64_t q = tid; q < top; q += 1024) ring[(int)(q % W)] = x[q];
-  int b = 0;                                       // slot of entry j
-  int tb = (int)(top % W);                         // slot of entry top
-  int jpa = n > 0 ? (int)(ipiv[0] - 0) : 0, jpb = 0;   // pivot offsets jp - j
-  tg_lu_load_col(ab + kv, 1, (int)min((int64_t)kl, n - 1), tid, va);
-  __syncthreads();
-#define TG_FWD_STEP(J, CUR, NXT, JPC, JPN)                                                      \
-  {                                                                                             \
-    const int64_t j_ = (J);                                                                     \
-    const int km = (int)min((int64_t)kl, n - 1 - j_);                                           \
-    if (j_ + 1 < n) {                                                                           \
-      JPN = (int)(ipiv[j_ + 1] - (j_ + 1));                                                     \
-      tg_lu_load_col(ab + kv + ldab * (j_ + 1), 1, (int)min((int64_t)kl, n - 2 - j_), tid, NXT); \
-    }                                                                                           \
-    if (tid == 0 && JPC != 0) {                                                                 \
-      const int sp = tg_slot(b, JPC, W);                                                        \
-      const double t = ring[sp];                                                                \
-      ring[sp] = ring[b];                                                                       \
-      ring[b] = t;                                                                              \
-    }                                                                                           \
-    TG_LDS_BARRIER();                                                                           \
-    const double xj = ring[b];                                                                  \
-    _Pragma("unroll") for (int q = 0; q < TG_LU_R; q++) {                                       \
-      const int i = 1 + tid + 1024 * q;                                                         \
-      if (i <= km) ring[tg_slot(b, i, W)] = fma(-CUR[q], xj, ring[tg_slot(b, i, W)]);                                       \
-    }                                                                                           \
-    if (tid == 0) x[j_] = xj;                                                                   \
-    if (top < n && j_ + 1 + kl + 1 > top) {                                                     \
-      const int64_t e1 = min(n, top + TG_LU_CH);                                                \
-      for (int64_t e = top + tid; e < e1; e += 1024) ring[tg_slot(tb, (int)(e - top), W)] = x[e]; \
-      tb = tg_slot(tb, (int)(e1 - top), W);                                                     \
-      top = e1;                                                                                 \
-    }                                                                                           \
-    TG_LDS_BARRIER();                                                                           \
-    b = tg_slot(b, 1, W);                                                                       \
-  }
-  {
-    int64_t j = 0;
-    for (; j + 1 < n; j += 2) {
-      TG_FWD_STEP(j, va, vb, jpa, jpb)
-      TG_FWD_STEP(j + 1, vb, va, jpb, jpa)
-    }
-    if (j < n) TG_FWD_STEP(j, va, vb, jpa, jpb)
-  }
-#undef TG_FWD_STEP
-  __syncthreads();                                 // (the forward values written to x are visible to the whole workgroup)
-  // ---- backward: the window [j - kv, j] lies inside the loaded range [lo, j]
+  // the window [j - kv, j] lies inside the loaded range [lo, j]
   int64_t lo = max((int64_t)0, n - 1 - kv - TG_LU_CH);
-  for (int64_t q = lo + tid; q <= n - 1; q += 1024) ring[(int)(q % W)] = x[q];
-  b = n > 0 ? (int)((n - 1) % W) : 0;              // slot of entry j
+  for (int64_t q = lo + tid; q <= n - 1; q += NT) ring[(int)(q % W)] = x[q];
+  int b = (int)((n - 1) % W);                      // slot of entry j
   int lb = (int)(lo % W);                          // slot of entry lo
-  double da = 1.0, db = 1.0;
-  if (n > 0) {
-    const double *cj = ab + kv + ldab * (n - 1);
-    tg_lu_load_col(cj, -1, (int)min((int64_t)kv, n - 1), tid, va);
-    da = cj[0];
+  double U[D][R], DG[D];
+#pragma unroll
+  for (int k = 0; k < D; k++) {
+    DG[k] = 1.0;
+    const int64_t j = n - 1 - k;
+    if (j >= 0) {
+      const double *cj = ab + kv + ldab * j;
+      tg_lu_load_col<R, NT>(cj, -1, (int)min((int64_t)kv, j), tid, U[k]);
+      DG[k] = cj[0];
+    }
   }
   __syncthreads();
-#define TG_BWD_STEP(J, CUR, NXT, DC, DN)                                                        \
-  {                                                                                             \
-    const int64_t j_ = (J);                                                                     \
-    const int kk = (int)min((int64_t)kv, j_);                                                   \
-    if (j_ >= 1) {                                                                              \
-      const double *c1 = ab + kv + ldab * (j_ - 1);                                             \
-      tg_lu_load_col(c1, -1, (int)min((int64_t)kv, j_ - 1), tid, NXT);                          \
-      DN = c1[0];                                                                               \
-    }                                                                                           \
-    const double xj = ring[b] / DC;                                                             \
-    TG_LDS_BARRIER();                                                                           \
-    _Pragma("unroll") for (int q = 0; q < TG_LU_R; q++) {                                       \
-      const int i = 1 + tid + 1024 * q;                                                         \
-      if (i <= kk) ring[tg_slot(b, W - i, W)] = fma(-CUR[q], xj, ring[tg_slot(b, W - i, W)]);                                   \
-    }                                                                                           \
-    if (tid == 0) x[j_] = xj;                                                                   \
-    if (lo > 0 && lo > j_ - 1 - kv) {                                                           \
-      const int64_t e0 = max((int64_t)0, lo - TG_LU_CH);                                        \
-      const int cnt = (int)(lo - e0);                                                           \
-      const int nb_ = tg_slot(lb, W - cnt, W);                                                  \
-      for (int e = tid; e < cnt; e += 1024) ring[tg_slot(nb_, e, W)] = x[e0 + e];               \
-      lb = nb_;                                                                                 \
-      lo = e0;                                                                                  \
-    }                                                                                           \
-    TG_LDS_BARRIER();                                                                           \
-    b = tg_slot(b, W - 1, W);                                                                   \
-  }
-  {
-    int64_t j = n - 1;
-    for (; j >= 1; j -= 2) {
-      TG_BWD_STEP(j, va, vb, da, db)
-      TG_BWD_STEP(j - 1, vb, va, db, da)
+  for (int64_t j0 = n - 1; j0 >= 0; j0 -= D) {
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      const int64_t j = j0 - k;
+      if (j >= 0) {                                // (uniform)
+        const int kk = (int)min((int64_t)kv, j);
+        const double xj = ring[b] / DG[k];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+          const int i = 1 + tid + NT * q;
+          if (i <= kk) {
+            const int sl = tg_slot(b, W - i, W);
+            ring[sl] = fma(-U[k][q], xj, ring[sl]);
+          }
+        }
+        if (tid == 0) x[j] = xj;
+        {
+          const int64_t j2 = max(j - D, (int64_t)0);
+          const double *c2 = ab + kv + ldab * j2;
+          tg_lu_load_col<R, NT>(c2, -1, (int)min((int64_t)kv, j2), tid, U[k]);
+          DG[k] = c2[0];
+        }
+        if (lo > 0 && lo > j - 1 - kv) {
+          const int64_t e0 = max((int64_t)0, lo - TG_LU_CH);
+          const int cnt = (int)(lo - e0);
+          const int nb_ = tg_slot(lb, W - cnt, W);
+          for (int e = tid; e < cnt; e += NT) ring[tg_slot(nb_, e, W)] = x[e0 + e];
+          lb = nb_;
+          lo = e0;
+        }
+        TG_LDS_BARRIER();
+        b = tg_slot(b, W - 1, W);
+      }
     }
-    if (j == 0) TG_BWD_STEP(0, va, vb, da, db)
   }
-#undef TG_BWD_STEP
 }
 
 extern "C" int tg_lu_band_info(tg_csr_t k, int *kl_out, int *ku_out, int64_t *bytes_out) {
@@ -1046,10 +1064,22 @@ extern "C" int tg_lu_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *info) {
     if (x->d != b->d &&
         hipMemcpyAsync(x->d, b->d, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess)
       rc = 1;
-    if (kv + 1 <= TG_LU_R * 1024 && !getenv("TIGAR_LU_SOLVE_GLOBAL"))
-      hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), (size_t)(kv + 2 + TG_LU_CH) * sizeof(double), g_tg.stream, ab, ldab, n, kl, kv,
-                         ipiv, x->d);
-    else
+    // 1024 threads x R entries each (measured at cfg4: 256 / 512 threads with more entries each are slower, 148 / 103 ms
+    // against 89 ms)
+    const int nt = 1024;
+    const int rf = (int)tg_cdiv(std::max(kl, 1), nt), rb = (int)tg_cdiv(std::max(kv, 1), nt);
+    if (rb <= 6 && !getenv("TIGAR_LU_SOLVE_GLOBAL")) {
+      typedef void (*fwd_fn)(const double *, int64_t, int64_t, int, int, const int32_t *, double *);
+      typedef void (*bwd_fn)(const double *, int64_t, int64_t, int, double *);
+      const fwd_fn fwd = rf <= 1 ? k_lu_fwd<1, 16, 1024> : rf == 2 ? k_lu_fwd<2, 16, 1024> : rf == 3 ? k_lu_fwd<3, 8, 1024>
+                         : rf == 4 ? k_lu_fwd<4, 8, 1024> : k_lu_fwd<6, 4, 1024>;
+      const bwd_fn bwd = rb <= 1 ? k_lu_bwd<1, 16, 1024> : rb == 2 ? k_lu_bwd<2, 16, 1024> : rb == 3 ? k_lu_bwd<3, 8, 1024>
+                         : rb == 4 ? k_lu_bwd<4, 8, 1024> : k_lu_bwd<6, 4, 1024>;
+      hipLaunchKernelGGL(fwd, dim3(1), dim3(nt), (size_t)(kl + 2 + TG_LU_CH) * sizeof(double), g_tg.stream, (const double *)ab,
+                         ldab, n, kl, kv, (const int32_t *)ipiv, x->d);
+      hipLaunchKernelGGL(bwd, dim3(1), dim3(nt), (size_t)(kv + 2 + TG_LU_CH) * sizeof(double), g_tg.stream, (const double *)ab,
+                         ldab, n, kv, x->d);
+    } else
       hipLaunchKernelGGL(k_lu_solve_global, dim3(1), dim3(1024), 0, g_tg.stream, ab, ldab, n, kl, kv, ipiv, x->d);
     if (hipGetLastError() != hipSuccess) rc = 1;
     if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
