@@ -40,6 +40,7 @@ stats)
   stats cfg3 --steps 5 --warmup 1 $W
   stats cfg2 --workload cfg2 --steps 5 --warmup 1 $W
   stats cfg4 --workload cfg4 --solver cg --rtol 1e-10 --steps 3 --warmup 1 $W
+  stats cfg4_lu --workload cfg4 --solver lu --steps 2 --warmup 1 $W
   stats cfg5 --workload cfg5 --rtol 1e-10 --steps 3 --warmup 1 $W
   ;;
 pmc)
