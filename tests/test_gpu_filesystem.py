@@ -21,8 +21,26 @@ def test_extraction_directory_round_trip(tmp_path):
             gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
     d = str(tmp_path / "extraction")
     gen.writeExtraction(d)
-    assert sorted(os.listdir(d)) == ["extraction-data.npz", "extraction-info.txt", "extraction-mat-ctrl.dat",
+    assert sorted(os.listdir(d)) == ["extraction-data.h5", "extraction-info.txt", "extraction-mat-ctrl.dat",
                                      "extraction-mat.dat", "zero-dofs.dat"]
+    # the HDF5 file: the groups dolfin's HDF5File writes (tIGAr/common.py:460-467), in this package's node numbering
+    from tigar_amd import h5io
+    with h5io.H5File(os.path.join(d, "extraction-data.h5"), "r") as h5:
+        X, topo = h5.read_dataset("/mesh/coordinates"), h5.read_dataset("/mesh/topology")
+        nel = 6
+        assert X.shape == ((nel + 1) ** 2, 2) and topo.shape == (nel ** 2, 4)
+        assert h5.read_attr("/mesh/topology", "celltype") == "quadrilateral"
+        assert np.array_equal(h5.read_dataset("/mesh/cell_indices"), np.arange(nel ** 2))
+        nodes = gen.V_control.grids[0].coordinates()
+        for i in range(3):                                  # x, y and the weight of the NURBS geometry
+            name = "/control%d" % i
+            assert np.array_equal(h5.read_dataset(name + "/vector_0"), gen.cpFuncs[i].vector().get_local())
+            assert h5.read_attr(name, "signature") == "FiniteElement('Q', quadrilateral, 2)"
+            cd = h5.read_dataset(name + "/cell_dofs").reshape(nel ** 2, 9)
+            assert np.array_equal(h5.read_dataset(name + "/x_cell_dofs"), 9 * np.arange(nel ** 2 + 1))
+            for c in (0, 7, nel ** 2 - 1):                  # the nodes of a cell lie inside the cell
+                lo, hi = X[topo[c]].min(0), X[topo[c]].max(0)
+                assert (nodes[cd[c]] >= lo - 1e-14).all() and (nodes[cd[c]] <= hi + 1e-14).all()
     info = open(os.path.join(d, "extraction-info.txt")).read().split("\n")
     assert info[:7] == ["2", "Lagrange", "1", "2", str(gen.getNcp(-1)), "2", str(gen.getNcp(0))]
     M = gen.M.to_scipy()
@@ -49,8 +67,13 @@ def test_extraction_directory_round_trip(tmp_path):
     u1 = solve(s_gen, gen)
     u2 = solve(s_dir, s_dir)          # geometry from the files; M through the general hash PtAP
     assert np.max(np.abs(u1 - u2)) <= 1e-10 * np.max(np.abs(u1))
-    # a directory without the data file (as written by the reference: HDF5) is reported, not guessed
-    os.remove(os.path.join(d, "extraction-data.npz"))
+    # a data file without this package's group (as the reference writes it: M in dolfin's dof numbering) is reported,
+    # not guessed; so is a directory without the file
+    with h5io.H5File(os.path.join(d, "extraction-data.h5"), "w") as h5:
+        h5.write_dataset("/mesh/coordinates", X)
+    with pytest.raises(IOError, match="not written by this package"):
+        t.ExtractedSpline(d, 4)
+    os.remove(os.path.join(d, "extraction-data.h5"))
     with pytest.raises(IOError):
         t.ExtractedSpline(d, 4)
 

@@ -63,7 +63,8 @@ DEFAULT_PREALLOC = 500
 DEFAULT_DO_PERMUTATION = mpisize > 8
 DEFAULT_BASIS_FUNC_IGNORE_EPS = 1e-15
 EXTRACTION_DATA_FILE = "extraction-data.h5"
-EXTRACTION_DATA_NPZ = "extraction-data.npz"       # stand-in for the HDF5 file (no h5py/dolfin here)
+EXTRACTION_DATA_NPZ = "extraction-data.npz"       # what rounds 1-2 wrote in place of the HDF5 file (still read)
+EXTRACTION_H5_PRIVATE = "/tigar_amd"               # group of extraction-data.h5 with this package's node-set description
 EXTRACTION_INFO_FILE = "extraction-info.txt"
 EXTRACTION_H5_MESH_NAME = "/mesh"
 
@@ -181,6 +182,61 @@ def _grid_from_arrays(data, key):
         from .RhinoTSplines import BezierElementNodeGrid
         return BezierElementNodeGrid(int(data[key + "_nel"]), int(data[key + "_degree"]))
     raise ValueError("extraction-data.npz: unknown node grid kind %r" % kind)
+
+
+_CELL_NAMES = {1: "interval", 2: "quadrilateral", 3: "hexahedron"}
+
+
+def _knot_mesh_arrays(g):
+    """(coordinates [nv, d], topology [ncells, 2^d]) of the knot mesh under a tensor node grid, laid out as dolfin's
+    tensor-product meshes are (vertices and cells with direction 0 fastest, the vertices of a cell in lexicographic
+    order): the content of ``/mesh`` in extraction-data.h5 (tIGAr/common.py:463)."""
+    d = g.dim()
+    verts = [numpy.asarray(v, dtype=numpy.float64) for v in g.vertices]
+    nv = [len(v) for v in verts]
+    grids = numpy.meshgrid(*verts, indexing="ij")
+    X = numpy.stack([q.ravel(order="F") for q in grids], axis=1)
+    stride = numpy.cumprod([1] + nv[:-1])
+    cells = numpy.meshgrid(*[numpy.arange(n - 1, dtype=numpy.int64) for n in nv], indexing="ij")
+    base = sum(c.ravel(order="F") * int(stride[k]) for k, c in enumerate(cells))
+    corners = numpy.zeros(1, dtype=numpy.int64)
+    for k in range(d):                                 # lexicographic corners, direction 0 fastest
+        corners = numpy.concatenate([corners, corners + int(stride[k])])
+    return X, base[:, None] + corners[None, :]
+
+
+def _cell_dofs_arrays(g):
+    """[ncells, (p+1)^d] node numbers of every knot-mesh cell, in this package's numbering (direction 0 fastest; a dolfin
+    ``FunctionSpace`` on the same mesh numbers them its own way, which cannot be reproduced without dolfin)."""
+    d, p = g.dim(), int(g.degree)
+    nn = g.shape()
+    step = p + 1 if g.dg else p
+    nel = [(n // (p + 1)) if g.dg else ((n - 1) // max(p, 1)) for n in nn] if p > 0 else [n for n in nn]
+    stride = numpy.cumprod([1] + nn[:-1])
+    cells = numpy.meshgrid(*[numpy.arange(n, dtype=numpy.int64) for n in nel], indexing="ij")
+    base = sum(c.ravel(order="F") * int(step * stride[k]) for k, c in enumerate(cells))
+    loc = numpy.zeros(1, dtype=numpy.int64)
+    for k in range(d):                                 # local nodes, direction 0 fastest
+        loc = (loc[None, :] + (numpy.arange(p + 1, dtype=numpy.int64) * int(stride[k]))[:, None]).ravel()
+    return base[:, None] + loc[None, :]
+
+
+class _H5Archive(object):
+    """the private group of extraction-data.h5 read like the npz archive of rounds 1-2 (arrays: datasets; strings and
+    scalars: attributes of the group)"""
+
+    def __init__(self, f):
+        self.f = f
+
+    def __contains__(self, key):
+        return self.f.exists(EXTRACTION_H5_PRIVATE + "/" + key) or self.f.has_attr(EXTRACTION_H5_PRIVATE, key)
+
+    def __getitem__(self, key):
+        if self.f.exists(EXTRACTION_H5_PRIVATE + "/" + key):
+            return self.f.read_dataset(EXTRACTION_H5_PRIVATE + "/" + key)
+        if self.f.has_attr(EXTRACTION_H5_PRIVATE, key):
+            return self.f.read_attr(EXTRACTION_H5_PRIVATE, key)
+        raise KeyError(key)
 
 
 class TensorFunctionSpace(object):
@@ -503,9 +559,12 @@ class AbstractExtractionGenerator(object):
         (tIGAr/common.py:435-502): ``extraction-mat.dat`` / ``extraction-mat-ctrl.dat`` (PETSc binary
         Mat of M / M_control), ``zero-dofs.dat`` (PETSc binary IS), ``extraction-info.txt`` (nsd,
         element type, number of fields, then degree and ncp of the control field and of each field).
-        The reference's ``extraction-data.h5`` (dolfin mesh + control functions, HDF5) cannot be
-        produced without h5py/dolfin; the node grid and the control functions go to
-        ``extraction-data.npz`` instead, which only this package reads."""
+        ``extraction-data.h5`` is written through libhdf5 (``tigar_amd/h5io.py``) with the groups dolfin's ``HDF5File``
+        writes (tIGAr/common.py:460-467): ``/mesh`` (``coordinates``, ``topology`` with its ``celltype``, ``cell_indices``;
+        tensor node sets) and ``/control<i>`` (``vector_0``, ``cell_dofs``, ``x_cell_dofs``, ``cells``, the element's
+        ``signature``) -- in THIS package's node numbering (dolfin's own cannot be reproduced without dolfin; the layout
+        follows dolfin 2019's HDF5File and is not pinned against a dolfin-written file) -- plus the group ``/tigar_amd``
+        with the node-set description ``initFromFilesystem`` rebuilds the function spaces from."""
         from . import petscio
         if doPermutation:
             self.applyPermutation(nparts=nparts)      # (nparts: the number of ranks that will read the directory)
@@ -524,9 +583,38 @@ class AbstractExtractionGenerator(object):
             data[name + "_element"] = numpy.array(V.element)
             for gi, g in enumerate(V.grids):
                 _grid_to_arrays(g, "%s_%d" % (name, gi), data)
-        for i, f in enumerate(self.cpFuncs):
-            data["control%d" % i] = f.vector().get_local()
-        numpy.savez(os.path.join(dirname, EXTRACTION_DATA_NPZ), **data)
+        from . import h5io
+        with h5io.H5File(os.path.join(dirname, EXTRACTION_DATA_FILE), "w") as f:
+            g0 = self.V_control.grids[0]
+            cell_dofs = None
+            if isinstance(g0, TensorNodeGrid):
+                X, topo = _knot_mesh_arrays(g0)
+                f.create_group(EXTRACTION_H5_MESH_NAME)
+                f.write_dataset(EXTRACTION_H5_MESH_NAME + "/coordinates", X)
+                f.write_dataset(EXTRACTION_H5_MESH_NAME + "/topology", topo,
+                                attrs={"celltype": _CELL_NAMES[g0.dim()], "partition": numpy.zeros(1, dtype=numpy.uint64)})
+                f.write_dataset(EXTRACTION_H5_MESH_NAME + "/cell_indices", numpy.arange(topo.shape[0], dtype=numpy.int64))
+                cell_dofs = _cell_dofs_arrays(g0)
+                family = {1: ("Lagrange", "Discontinuous Lagrange"), 2: ("Q", "DQ"), 3: ("Q", "DQ")}[g0.dim()][1 if g0.dg else 0]
+                signature = "FiniteElement('%s', %s, %d)" % (family, _CELL_NAMES[g0.dim()], int(g0.degree))
+            for i, fn in enumerate(self.cpFuncs):
+                name = EXTRACTION_H5_CONTROL_FUNC_NAME(i)
+                f.create_group(name)
+                f.write_dataset(name + "/vector_0", fn.vector().get_local(), attrs={"partition": numpy.zeros(1, dtype=numpy.uint64)})
+                if cell_dofs is not None:
+                    f.write_dataset(name + "/cell_dofs", cell_dofs.ravel())
+                    f.write_dataset(name + "/x_cell_dofs", numpy.arange(cell_dofs.shape[0] + 1, dtype=numpy.int64) * cell_dofs.shape[1])
+                    f.write_dataset(name + "/cells", numpy.arange(cell_dofs.shape[0], dtype=numpy.int64))
+                    f.write_attr(name, "signature", signature)
+            f.create_group(EXTRACTION_H5_PRIVATE)
+            for k, v in data.items():
+                v = numpy.asarray(v)
+                if v.dtype.kind in "US":
+                    f.write_attr(EXTRACTION_H5_PRIVATE, k, str(v))
+                elif v.ndim == 0:
+                    f.write_attr(EXTRACTION_H5_PRIVATE, k, v.astype(numpy.int64 if v.dtype.kind in "iub" else numpy.float64))
+                else:
+                    f.write_dataset(EXTRACTION_H5_PRIVATE + "/" + k, v.astype(numpy.int64 if v.dtype.kind in "iub" else numpy.float64))
 
 
 class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
@@ -1071,8 +1159,8 @@ class ExtractedSpline(object):
 
     def initFromFilesystem(self, dirname, quadDeg, comm, mesh=None):
         """Instance from the extraction data in directory ``dirname`` (tIGAr/common.py:748-894):
-        ``extraction-info.txt``, the PETSc binary matrices and index set, and this package's
-        ``extraction-data.npz`` in place of the HDF5 mesh/control-function file.  M is then an
+        ``extraction-info.txt``, the PETSc binary matrices and index set, and ``extraction-data.h5`` (control functions
+        from ``/control<i>/vector_0``, node sets from the group ``/tigar_amd``; see ``writeExtraction``).  M is then an
         arbitrary sparse matrix: extractMatrix uses the general PtAP kernel."""
         from . import petscio
         self.quadDeg = quadDeg
@@ -1088,11 +1176,23 @@ class ExtractedSpline(object):
         for i in range(self.nFields):
             self.p.append(int(lines[5 + 2 * i]))
             ncp.append(int(lines[6 + 2 * i]))
-        npz_path = os.path.join(dirname, EXTRACTION_DATA_NPZ)
-        if not os.path.exists(npz_path):
-            raise IOError("%s not found: directories written by the reference carry the mesh and control "
-                          "functions in HDF5 (%s), which needs h5py/dolfin to read" % (npz_path, EXTRACTION_DATA_FILE))
-        data = numpy.load(npz_path)
+        h5_path, npz_path = os.path.join(dirname, EXTRACTION_DATA_FILE), os.path.join(dirname, EXTRACTION_DATA_NPZ)
+        h5 = None
+        if os.path.exists(h5_path):
+            from . import h5io
+            h5 = h5io.H5File(h5_path, "r")
+            if not h5.exists(EXTRACTION_H5_PRIVATE):
+                h5.close()
+                raise IOError("%s carries no group %s: it was not written by this package.  Directories written by the "
+                              "reference hold M in dolfin's own dof numbering, which cannot be matched to node positions "
+                              "without dolfin" % (h5_path, EXTRACTION_H5_PRIVATE))
+            data = _H5Archive(h5)
+            control = [h5.read_dataset(EXTRACTION_H5_CONTROL_FUNC_NAME(i) + "/vector_0") for i in range(self.nsd + 1)]
+        elif os.path.exists(npz_path):                     # directories written by rounds 1-2 of this package
+            data = numpy.load(npz_path)
+            control = [data["control%d" % i] for i in range(self.nsd + 1)]
+        else:
+            raise IOError("neither %s nor %s found" % (h5_path, npz_path))
 
         def space(name):
             grids = []
@@ -1105,8 +1205,10 @@ class ExtractedSpline(object):
         self.cpFuncs = []
         for i in range(self.nsd + 1):
             f = Function(self.V_control)
-            f.vector().set_local(data["control%d" % i])
+            f.vector().set_local(control[i])
             self.cpFuncs.append(f)
+        if h5 is not None:
+            h5.close()
         self.M_control = DeviceCSR.from_scipy(petscio.read_mat(os.path.join(dirname, EXTRACTION_MAT_FILE_CTRL)))
         self.M = DeviceCSR.from_scipy(petscio.read_mat(os.path.join(dirname, EXTRACTION_MAT_FILE)))
         if self.M_control.shape != (self.V_control.dim(), ncp_control) or self.M.shape != (self.V.dim(), sum(ncp)):
