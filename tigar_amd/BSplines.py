@@ -124,15 +124,27 @@ class BSpline1(object):
         return val[0]
 
     # ---- FE node grid along this direction ------------------------------------------
-    def feNodes(self, degree, dg=False):
+    def feVertices(self, refine=0):
+        """vertices of the extraction mesh in this direction: the unique knots, every span halved ``refine`` times
+        (``refine(mesh)`` of tIGAr/BSplines.py:566-568 bisects every edge: midpoints exactly (a + b) / 2)"""
+        uk = numpy.asarray(self.uniqueKnots, dtype=numpy.float64)
+        for _ in range(int(refine)):
+            mid = 0.5 * (uk[:-1] + uk[1:])
+            out = numpy.empty(2 * len(uk) - 1)
+            out[0::2] = uk
+            out[1::2] = mid
+            uk = out
+        return uk
+
+    def feNodes(self, degree, dg=False, refine=0):
         """
         Parametric coordinates of the Lagrange degree-``degree`` nodes on the knot mesh:
         equispaced reference points mapped affinely, x = x0*(1-t) + x1*t with t = j/degree,
         so vertex nodes lie exactly on the unique knots (the reference moves the dolfin
         mesh vertices onto ``uniqueKnots``, tIGAr/BSplines.py:527-536).  CG: nel*degree+1
-        nodes; DG: nel*(degree+1).
+        nodes; DG: nel*(degree+1).  ``refine``: on the mesh refined that many times.
         """
-        uk = self.uniqueKnots
+        uk = self.feVertices(refine)
         t = numpy.arange(degree + 1, dtype=numpy.float64) / float(degree)
         x = uk[:-1, None] * (1.0 - t[None, :]) + uk[1:, None] * t[None, :]
         x[:, 0] = uk[:-1]
@@ -175,13 +187,13 @@ class BSpline(AbstractScalarBasis):
         self.nvar = len(degrees)
         if self.nvar > 3 or self.nvar < 1:
             raise ValueError("Unsupported parametric dimension.")
-        if not useRect:
-            raise NotImplementedError("simplicial extraction elements need FEniCS meshes; "
-                                      "tigar_amd extracts to tensor-product (quad/hex) elements")
-        if overRefine:
+        if overRefine and useRect:
             raise NotImplementedError("overRefine is only supported with simplicial elements "
                                       "(tIGAr/BSplines.py:393)")
         self.splines = [BSpline1(degrees[i], kvecs[i]) for i in range(self.nvar)]
+        if not useRect and any(s.isDiscontinuous() for s in self.splines):
+            raise NotImplementedError("simplicial extraction elements of a discontinuous spline space: the nodes of DG "
+                                      "simplices are per triangle / tetrahedron, not a tensor lattice")
         self.useRect = useRect
         self.overRefine = overRefine
         self.ncp = self.computeNcp()
@@ -230,8 +242,16 @@ class BSpline(AbstractScalarBasis):
         """The reference returns a dolfin mesh whose vertices are the unique knots
         (tIGAr/BSplines.py:505-569); here the "mesh" is the implicit tensor node grid."""
         deg = self.getDegree() if degree is None else degree
-        return TensorNodeGrid([s.feNodes(deg, dg) for s in self.splines],
-                              [s.uniqueKnots for s in self.splines], deg, dg)
+        # Simplicial elements (useRect=False, tIGAr/BSplines.py:520-523,543-549): dolfin's UnitSquareMesh / UnitCubeMesh
+        # split every knot-span cell into 2 triangles / 6 tetrahedra, the extraction space is P_q on them with q = the
+        # SUM of the degrees (getDegree), and ``overRefine`` bisects the edges that many times.  The P_q nodes of those
+        # simplices are the points of the degree-q lattice of the (refined) cell, all of them: the node SET is the tensor
+        # lattice below and M -- the basis evaluated at the nodes -- is the reference's up to dolfin's row numbering.
+        # (FE objects assembled by ``forms`` use the Q_q cells of the same lattice: Q_q contains P_q, the spline space
+        # lies in both, so M^T A M is the same Galerkin matrix of the spline space.)
+        r = 0 if self.useRect else self.overRefine
+        return TensorNodeGrid([s.feNodes(deg, dg, r) for s in self.splines],
+                              [s.feVertices(r) for s in self.splines], deg, dg)
 
     def computeNcp(self):
         prod = 1
