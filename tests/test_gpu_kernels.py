@@ -247,6 +247,78 @@ def test_ptap_general_unstructured_operands(dev):
         assert abs(K - Ko).max() <= 1e-12 * max(abs(Ko).max(), 1e-300)
 
 
+def test_extraction_operators_of_a_3d_quartic_patch(dev):
+    """3-D p = 4 with more than p + 1 elements per direction: a row of M^T meets (p (p + 1) + 1)^2 = 441 (j, k)
+    combinations of FE nodes -- more than the 256 the closed-form kernel used to hold in LDS (it refused such patches)."""
+    p, nel = 4, 6
+    s = O.BSpline([p] * 3, [O.uniform_knots(p, 0., 1., nel)] * 3)
+    Mo = O.generate_M_tensor(s)
+    M = _extract(dev, s)
+    Ms = M.to_scipy()
+    assert np.array_equal(Ms.indptr, Mo.indptr) and np.array_equal(Ms.indices, Mo.indices) and np.array_equal(Ms.data, Mo.data)
+    MTo = Mo.T.tocsr()
+    MTo.sort_indices()
+    for MT in (M.transpose().to_scipy(),
+               dev.extract_csr_tensor_t(s.splines, [O.fe_nodes_1d(sp1, p) for sp1 in s.splines], 0, Mo.shape[0], 1e-15)
+               .to_scipy()):
+        assert np.array_equal(MT.indptr, MTo.indptr) and np.array_equal(MT.indices, MTo.indices)
+        assert np.array_equal(MT.data, MTo.data)
+
+
+def test_general_hash_ptap_is_bit_reproducible_and_scale_aware(dev):
+    """The hash kernel (nothing assumed about M) adds into its LDS tables with atomics, i.e. in an order that differs from
+    run to run; the terms are added as integers on a grid derived from a bound of the row's accumulators (tg_fix,
+    csrc/tg_common.h), so K is the same to the last bit in every run.  The grid follows the ROW: rows of A scaled by 1e+-12
+    (penalty terms, badly scaled units) keep their relative accuracy; Inf / NaN operands surface as NaN in their rows."""
+    rng = np.random.default_rng(11)
+    nfe, ncp = 1500, 300
+    A = _rand_csr(rng, nfe, nfe, 0.02)
+    M = _rand_csr(rng, nfe, ncp, 0.04)
+    Md, Ad = dev.DeviceCSR.from_scipy(M), dev.DeviceCSR.from_scipy(A)
+    MT = Md.transpose()
+    plan = dev.ptap_symbolic(Ad, Md, MT)
+    runs = [dev.ptap_numeric(plan, Ad, Md, MT).to_scipy() for _ in range(5)]
+    fresh = dev.ptap_numeric(dev.ptap_symbolic(Ad, Md, MT), Ad, Md, MT).to_scipy()      # bump-allocated first pass
+    for K in runs[1:] + [fresh]:
+        assert np.array_equal(K.indptr, runs[0].indptr) and np.array_equal(K.indices, runs[0].indices)
+        assert np.array_equal(K.data.view(np.int64), runs[0].data.view(np.int64))
+    Ko = (M.T @ A @ M).tocsr()
+    assert abs(runs[0] - Ko).max() <= 1e-13 * abs(Ko).max()
+    # rows of A of very different scale (penalty terms, units): the grid follows the row of K -- every entry is within
+    # a few 1e-16 (the comparison product's own rounding) of the largest sum of |terms| of ITS row (a floating-point sum is relative to each entry's own terms; entries
+    # more than ~1e6 below their row's largest therefore carry fewer than 16 digits here)
+    scale = 10.0 ** rng.integers(-12, 13, size=nfe)
+    As = (sp.diags(scale) @ A).tocsr()
+    Ks = dev.ptap_numeric(plan, dev.DeviceCSR.from_scipy(As), Md, MT).to_scipy()
+    Kso = (M.T @ As @ M).tocsr()
+    mag = (abs(M).T @ abs(As) @ abs(M)).tocsr()           # sum of the |terms| of every entry
+    err = abs(Ks - Kso).tocsr()
+    row_err = np.asarray(err.max(axis=1).todense()).ravel()
+    row_mag = np.asarray(mag.max(axis=1).todense()).ravel()
+    assert (row_err <= 2e-15 * row_mag).all(), np.max(row_err / np.maximum(row_mag, 1e-300))
+    # scaling of K's own rows and columns (M^T D A D M with D on the dof side is what a change of units does): each row
+    # keeps full relative accuracy
+    dscale = 10.0 ** rng.integers(-9, 10, size=ncp)
+    Msc = (M @ sp.diags(dscale)).tocsr()
+    Mscd = dev.DeviceCSR.from_scipy(Msc)
+    Kd = dev.ptap_numeric(dev.ptap_symbolic(Ad, Mscd, Mscd.transpose()), Ad, Mscd, Mscd.transpose()).to_scipy()
+    Kdo = (Msc.T @ A @ Msc).tocsr()
+    magd = (abs(Msc).T @ abs(A) @ abs(Msc)).tocsr()
+    row_err = np.asarray(abs(Kd - Kdo).max(axis=1).todense()).ravel()
+    row_mag = np.asarray(magd.max(axis=1).todense()).ravel()
+    assert (row_err <= 2e-15 * row_mag).all()
+    # non-finite operands
+    Ab = A.copy()
+    Ab.data[7] = np.inf
+    Kb = dev.ptap_numeric(plan, dev.DeviceCSR.from_scipy(Ab), Md, MT).to_scipy()
+    bad_rows = np.unique(M[Ab.tocoo().row[7]].indices)
+    assert np.isnan(Kb.data[Kb.indptr[bad_rows[0]]:Kb.indptr[bad_rows[0] + 1]]).all()
+    good = np.setdiff1d(np.arange(ncp), bad_rows)
+    if good.size:
+        g = good[0]
+        assert np.array_equal(Kb.data[Kb.indptr[g]:Kb.indptr[g + 1]], runs[0].data[runs[0].indptr[g]:runs[0].indptr[g + 1]])
+
+
 def test_kron_generator_matches_oracle_input(dev):
     for d, p, nel in ((2, 2, 6), (3, 2, 4), (3, 3, 3), (1, 4, 5)):
         s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel)] * d)

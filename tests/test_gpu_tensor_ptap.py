@@ -132,21 +132,35 @@ def test_streamed_sub_slabs_with_tensor_ring_match_resident():
     assert np.max(np.abs(K.data - Ko.data)) <= 1e-12 * np.max(np.abs(Ko.data))
 
 
-def test_general_kernels_run_to_run_spread_is_bounded(monkeypatch):
-    """The general PtAP kernels (other patterns, p = 4, 2-D) accumulate K with LDS floating-point atomics, so their
-    last bits may differ from run to run; the spread stays within a few ulp * sqrt(terms) of the row scale.  (The
-    tensor-pattern path is bit-reproducible, see above; TIGAR_PTAP_TENSOR=0 selects the general kernels.)"""
+@pytest.mark.parametrize("d,p,nel,factored", [(3, 3, 12, "1"), (2, 5, 40, "1"), (2, 3, 120, "1"), (3, 2, 10, "0")])
+def test_general_kernels_are_bit_reproducible(monkeypatch, d, p, nel, factored):
+    """The general PtAP kernels (other patterns, p > 4, arbitrary M; TIGAR_PTAP_TENSOR=0 selects them) give the same K to
+    the last bit in every run.  The line kernels (3-D, one direction at a time) own their accumulators wave by wave; the
+    box kernel (2-D: several waves scatter into one LDS box; up to round 2 two thirds of the entries of these 2-D cases
+    changed their last bits from run to run) and the hash kernel (TIGAR_PTAP_FACTORED=0: nothing assumed about M) add
+    integers on a grid derived from a bound of the row's accumulators (tg_fix, csrc/tg_common.h).  K stays within
+    rounding of the tensor-pattern path where that applies."""
+    import scipy.sparse as sp
+    import tigar_amd as t
+    from tigar_amd import BSplines as B
     monkeypatch.setenv("TIGAR_PTAP_TENSOR", "0")
-    p, nels = 3, (6, 5, 7)
-    gen, spline = _patch(p, nels)
-    A = _random_fe_matrix(p, nels, seed=21)
+    monkeypatch.setenv("TIGAR_PTAP_FACTORED", factored)
+    gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p] * d, [B.uniformKnots(p, 0., 1., nel)] * d))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    i = np.arange(p * nel + 1)
+    C1 = sp.csr_matrix(np.abs(i[:, None] - i[None, :]) <= p)           # a band that contains the element coupling
+    P = C1
+    for _ in range(d - 1):
+        P = sp.kron(C1, P, format="csr")
+    A = P.astype(np.float64).tocsr()
+    A.data = np.random.default_rng(3).standard_normal(A.nnz)
     runs = [spline.extractMatrix(A).to_scipy() for _ in range(4)]
-    ref = runs[0]
-    terms = (3 * p + 1) ** 3 * (p + 1) ** 3            # products that can meet in one entry of K
-    scale = np.max(np.abs(ref.data))
     for K in runs[1:]:
-        assert np.array_equal(K.indices, ref.indices)
-        assert np.max(np.abs(K.data - ref.data)) <= 4 * 2.3e-16 * np.sqrt(terms) * scale
+        assert np.array_equal(K.indptr, runs[0].indptr) and np.array_equal(K.indices, runs[0].indices)
+        assert np.array_equal(K.data.view(np.int64), runs[0].data.view(np.int64))
+    M = gen.M.to_scipy()
+    Ko = (M.T @ A @ M).tocsr()
+    assert abs(runs[0] - Ko).max() <= 1e-13 * abs(Ko).max()
 
 
 @pytest.mark.parametrize("p,nels", [(3, (4, 3, 5)), (2, (6, 5, 4))])

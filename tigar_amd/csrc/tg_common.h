@@ -209,6 +209,44 @@ __device__ __forceinline__ double tg_block_sum256(double v, double *lds4) {
   return r;
 }
 
+// ---- order-independent accumulation (the general PtAP kernels): a sum whose terms arrive in an order that differs from
+// run to run (LDS atomics) is made bit-reproducible by adding INTEGERS.  With B >= the sum of the |terms| of any
+// accumulator of the row, every term is rounded to the grid 2^e, e = exponent(B) - 61, and the 62-bit integers are added
+// with 64-bit integer atomics: exact, hence independent of the order.  The grid lies 8 bits below the last bit of a
+// term as large as B / 2, so terms within 2^-9 of the bound are not rounded at all and the rounding of the smaller ones
+// (B 2^-62 each) stays below what a floating-point sum of the same terms may lose when its partial sums come near B.
+struct tg_fix_t {
+  double inv;     // 2^-e
+  double scale;   // 2^e
+};
+__device__ __forceinline__ tg_fix_t tg_fix_make(double bound) {
+  tg_fix_t f;
+  int e = ((bound > 0.0 && bound <= 1.7e308) ? ilogb(bound) : 0) - 61;
+  e = max(e, -1000);                               // (2^-e must be a finite double)
+  f.inv = ldexp(1.0, -e);
+  f.scale = ldexp(1.0, e);
+  return f;
+}
+__device__ __forceinline__ unsigned long long tg_fix(double v, const tg_fix_t &f) {
+  return (unsigned long long)__double2ll_rn(v * f.inv);
+}
+__device__ __forceinline__ double tg_unfix(unsigned long long n, const tg_fix_t &f) {
+  return __ll2double_rn((long long)n) * f.scale;
+}
+// sum over the workgroup in a fixed order (tree in LDS; `scratch`: blockDim.x doubles, free before and after)
+__device__ __forceinline__ double tg_block_sum_ordered(double x, double *scratch) {
+  const int tid = threadIdx.x;
+  scratch[tid] = x;
+  __syncthreads();
+  for (int o = (int)blockDim.x >> 1; o > 0; o >>= 1) {
+    if (tid < o) scratch[tid] += scratch[tid + o];
+    __syncthreads();
+  }
+  const double r = scratch[0];
+  __syncthreads();
+  return r;
+}
+
 __device__ __forceinline__ int64_t tg_wave_incl_scan_i64(int64_t v) {
   const int lane = threadIdx.x & 63;
 #pragma unroll

@@ -554,11 +554,12 @@ __global__ void __launch_bounds__(64) k_kron3_rowptr(tg_kron3_args A, int64_t *_
 // follow each other, row a holding n0(a) * n12 entries in (k, j, i) order).  Thread t of a pass owns entry t of that
 // range -- fully coalesced 2-KB / 1-KB stores; its row is rowof[t / n12] (a look-up in the 1-D entry -> row table),
 // its (k, j) combination and i follow by two small divisions; the (j, k) parts (v1, v2, column offset) sit in LDS.
-#define TG_KRON3_MAXJK 256
+#define TG_KRON3_MAXJK 2048     // (j, k) combinations of a row: 24 bytes of LDS each, sized per launch
 __global__ void __launch_bounds__(256)
     k_kron3_fill(tg_kron3_args A, const int32_t *__restrict__ rowof, int32_t *__restrict__ col, double *__restrict__ val) {
-  __shared__ double s_v1[TG_KRON3_MAXJK], s_v2[TG_KRON3_MAXJK];
-  __shared__ int64_t s_c[TG_KRON3_MAXJK];
+  extern __shared__ double s_k3[];                 // [3][A.slot]: v1, v2, column offset of every (j, k) combination
+  double *s_v1 = s_k3, *s_v2 = s_k3 + A.slot;
+  int64_t *s_c = reinterpret_cast<int64_t *>(s_k3 + 2 * A.slot);
   const int tid = threadIdx.x;
   const int64_t pencil = A.row0 / A.n[0] + blockIdx.x;
   if (pencil >= A.npencils) return;
@@ -989,7 +990,7 @@ static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const in
       hipLaunchKernelGGL(k_kron3_rowptr, dim3((unsigned)tg_cdiv(A.nrows + 1, 64)), dim3(64), 0, g_tg.stream, A, m->rowptr);
       const int64_t p_first = row0 / A.n[0], p_last = (row1 - 1) / A.n[0];
       if (nterms == 0)
-        hipLaunchKernelGGL(k_kron3_fill, dim3((unsigned)(p_last - p_first + 1)), dim3(256), 0, g_tg.stream, A, d_rowof,
+        hipLaunchKernelGGL(k_kron3_fill, dim3((unsigned)(p_last - p_first + 1)), dim3(256), (size_t)A.slot * 24, g_tg.stream, A, d_rowof,
                            m->col, m->val);
       else if (nterms <= 3 && maxn[0] <= TG_KRON3_N0 && (int64_t)maxn[0] * A.slot < (1 << 12) &&
                !getenv("TIGAR_KRON3_THREADS")) {

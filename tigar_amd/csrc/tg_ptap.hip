@@ -48,6 +48,7 @@ struct tg_ptap_args {
   int64_t nrows;       // K rows to compute
   int64_t row_stride;  // probing: row = idx * row_stride
   int ts1, ts2, lg1, lg2, g1, g2;
+  const double *a_rowmax, *m_rowmax;   // largest |entry| of every row of A / M (numeric modes: bounds of the accumulators)
 };
 
 enum { TG_PTAP_OK = 0, TG_PTAP_OVF1 = 1, TG_PTAP_OVF2 = 2, TG_PTAP_RANGE = 3, TG_PTAP_CAP = 4 };
@@ -67,9 +68,10 @@ __device__ __forceinline__ unsigned tg_hash(int32_t key, int lg) {
 // Returns false on table overflow.
 typedef int tg_i4v __attribute__((ext_vector_type(4)));
 
+// The values are accumulated as integers (tg_fix, tg_common.h): `vals` holds 64-bit integers until the table is compacted.
 template <bool NUMERIC, int U>
-__device__ __forceinline__ bool tg_hash_insert_n(int32_t *keys, double *vals, int ts, int lg, const int32_t *key,
-                                                 const double *v) {
+__device__ __forceinline__ bool tg_hash_insert_n(int32_t *keys, unsigned long long *vals, int ts, int lg, const int32_t *key,
+                                                 const unsigned long long *v) {
   const int nb_mask = (ts >> 2) - 1;
   // ---- fast round: the U home buckets are fetched back to back (independent LDS reads), then
   // matched; a key that sits in its home bucket -- the overwhelmingly common case -- costs one
@@ -88,7 +90,7 @@ __device__ __forceinline__ bool tg_hash_insert_n(int32_t *keys, double *vals, in
     const int32_t k = key[u];
     const int pos = (kk[u].x == k) ? 0 : (kk[u].y == k) ? 1 : (kk[u].z == k) ? 2 : (kk[u].w == k) ? 3 : -1;
     const bool hit = (k >= 0) && (pos >= 0);
-    if (NUMERIC && hit) unsafeAtomicAdd(&vals[4 * b[u] + pos], v[u]);
+    if (NUMERIC && hit) atomicAdd(&vals[4 * b[u] + pos], v[u]);
     pending[u] = (k >= 0) && !hit;
     any_pending |= pending[u];
   }
@@ -114,7 +116,7 @@ __device__ __forceinline__ bool tg_hash_insert_n(int32_t *keys, double *vals, in
         }
       }
       const bool hit = pend && pos >= 0;
-      if (NUMERIC && hit) unsafeAtomicAdd(&vals[4 * bb + pos], v[u]);
+      if (NUMERIC && hit) atomicAdd(&vals[4 * bb + pos], v[u]);
       pend = pend && !hit;
       if (++rounds > ts) {  // wave-uniform
         ok = false;
@@ -130,7 +132,7 @@ template <bool NUMERIC>
 __device__ __forceinline__ bool tg_accumulate_rows(int nch, const int64_t *pre_start, const int *pre_len,
                                                    const double *pre_w, const int32_t *__restrict__ col,
                                                    const double *__restrict__ val, int G, int lg, int32_t *keys,
-                                                   double *vals, int ts, int lgts) {
+                                                   unsigned long long *vals, int ts, int lgts, const tg_fix_t &fx) {
   const int tid = threadIdx.x;
   const int sub = tid & (G - 1);
   const int grp = tid >> lg;
@@ -142,7 +144,7 @@ __device__ __forceinline__ bool tg_accumulate_rows(int nch, const int64_t *pre_s
     const double w = NUMERIC ? pre_w[le] : 0.0;
     for (int o = sub; o < len; o += G * TG_PTAP_UNROLL) {
       int32_t c[TG_PTAP_UNROLL];
-      double v[TG_PTAP_UNROLL];
+      unsigned long long v[TG_PTAP_UNROLL];
 #pragma unroll
       for (int u = 0; u < TG_PTAP_UNROLL; u++) {
         // unconditional (clamped) loads: no branches in the load phase
@@ -150,7 +152,7 @@ __device__ __forceinline__ bool tg_accumulate_rows(int nch, const int64_t *pre_s
         const int oc = min(oo, len - 1);
         const int32_t cc = col[start + oc];
         c[u] = (oo < len) ? cc : -2;
-        v[u] = NUMERIC ? w * val[start + oc] : 0.0;
+        v[u] = NUMERIC ? tg_fix(w * val[start + oc], fx) : 0ull;
       }
       ok &= tg_hash_insert_n<NUMERIC, TG_PTAP_UNROLL>(keys, vals, ts, lgts, c, v);
     }
@@ -174,8 +176,8 @@ __global__ void __launch_bounds__(NT)
   int *pre_len = cnt + 4;
   int64_t *pre_start = reinterpret_cast<int64_t *>(pre_len + NT);
   double *pre_w = reinterpret_cast<double *>(pre_start + NT);
-  double *vals1 = pre_w + NT;
-  double *vals2 = vals1 + (NUMERIC ? P.ts1 : 0);
+  unsigned long long *vals1 = reinterpret_cast<unsigned long long *>(pre_w + NT);
+  unsigned long long *vals2 = vals1 + (NUMERIC ? P.ts1 : 0);
 
   const int tid = threadIdx.x;
   const int64_t L = tg_xcd_block(blockIdx.x, P.nrows);
@@ -185,19 +187,32 @@ __global__ void __launch_bounds__(NT)
 
   for (int s = tid; s < P.ts1; s += NT) {
     keys1[s] = -1;
-    if (NUMERIC) vals1[s] = 0.0;
+    if (NUMERIC) vals1[s] = 0ull;
   }
   for (int s = tid; s < P.ts2; s += NT) {
     keys2[s] = -1;
-    if (NUMERIC) vals2[s] = 0.0;
+    if (NUMERIC) vals2[s] = 0ull;
   }
   if (tid < 4) cnt[tid] = 0;
   __syncthreads();
 
   bool ovf1 = false, ovf2 = false, range = false;
   // ---- stage 1: T = (row i of M^T) * A
+  bool nonfinite = false;
   {
     const int64_t e0 = P.mt_rowptr[li], e1 = P.mt_rowptr[li + 1];
+    // bound of every entry of T: sum over the operand rows of |weight| * (largest |entry| of the row)
+    tg_fix_t fx = tg_fix_make(1.0);
+    if (NUMERIC) {
+      double bsum = 0.0;
+      for (int64_t e = e0 + tid; e < e1; e += NT) {
+        const int64_t ra = (int64_t)P.mt_col[e] - P.a_row0;
+        if (ra >= 0 && ra < P.a_nrows) bsum += fabs(P.mt_val[e]) * P.a_rowmax[ra];
+      }
+      const double b1 = tg_block_sum_ordered(bsum, pre_w);
+      nonfinite = !(b1 <= 1.7e308);
+      fx = tg_fix_make(b1);
+    }
     for (int64_t c0 = e0; c0 < e1; c0 += NT) {
       const int64_t e = c0 + tid;
       if (e < e1) {
@@ -216,10 +231,14 @@ __global__ void __launch_bounds__(NT)
       __syncthreads();
       const int nch = (int)min((int64_t)NT, e1 - c0);
       if (!tg_accumulate_rows<NUMERIC>(nch, pre_start, pre_len, pre_w, P.a_col, P.a_val, P.g1, P.lg1, keys1, vals1,
-                                       P.ts1, lgts1))
+                                       P.ts1, lgts1, fx))
         ovf1 = true;
       __syncthreads();
     }
+    // the integers of table 1 back to floating point (in place; a slot is read and written by one thread)
+    if (NUMERIC)
+      for (int s = tid; s < P.ts1; s += NT) vals1[s] = (unsigned long long)__double_as_longlong(tg_unfix(vals1[s], fx));
+    __syncthreads();
   }
 
   // ---- compact the occupied (key, value) pairs of table 1 to the front of its own storage
@@ -227,7 +246,7 @@ __global__ void __launch_bounds__(NT)
   for (int c0 = 0; c0 < P.ts1; c0 += NT) {
     const int slot = c0 + tid;
     const int32_t key = (slot < P.ts1) ? keys1[slot] : -1;
-    const double tv = (NUMERIC && slot < P.ts1) ? vals1[slot] : 0.0;
+    const double tv = (NUMERIC && slot < P.ts1) ? __longlong_as_double((long long)vals1[slot]) : 0.0;
     __syncthreads();
     const bool occ = key != -1;
     const unsigned long long m = __ballot(occ);
@@ -238,13 +257,24 @@ __global__ void __launch_bounds__(NT)
       const unsigned long long below = ((tid & 63) == 0) ? 0ull : (~0ull >> (64 - (tid & 63)));
       const int pos = base + __popcll(m & below);
       keys1[pos] = key;
-      if (NUMERIC) vals1[pos] = tv;
+      if (NUMERIC) vals1[pos] = (unsigned long long)__double_as_longlong(tv);
     }
     __syncthreads();
   }
   const int nT = cnt[0];
 
-  // ---- stage 2: K row = T * M
+  // ---- stage 2: K row = T * M; bound of its entries: sum over T of |T_c| * (largest |entry| of row c of M)
+  tg_fix_t fx2 = tg_fix_make(1.0);
+  if (NUMERIC) {
+    double bsum = 0.0;
+    for (int e = tid; e < nT; e += NT) {
+      const int64_t sm = (int64_t)keys1[e] - P.m_row0;
+      if (sm >= 0 && sm < P.m_nrows) bsum += fabs(__longlong_as_double((long long)vals1[e])) * P.m_rowmax[sm];
+    }
+    const double b2 = tg_block_sum_ordered(bsum, pre_w);
+    nonfinite = nonfinite || !(b2 <= 1.7e308);
+    fx2 = tg_fix_make(b2);
+  }
   for (int c0 = 0; c0 < nT; c0 += NT) {
     const int e = c0 + tid;
     if (e < nT) {
@@ -258,11 +288,11 @@ __global__ void __launch_bounds__(NT)
         pre_start[tid] = s0;
         pre_len[tid] = (int)(P.m_rowptr[sm + 1] - s0);
       }
-      if (NUMERIC) pre_w[tid] = vals1[e];
+      if (NUMERIC) pre_w[tid] = __longlong_as_double((long long)vals1[e]);
     }
     __syncthreads();
     if (!tg_accumulate_rows<NUMERIC>(min(NT, nT - c0), pre_start, pre_len, pre_w, P.m_col, P.m_val, P.g2, P.lg2,
-                                     keys2, vals2, P.ts2, lgts2))
+                                     keys2, vals2, P.ts2, lgts2, fx2))
       ovf2 = true;
     __syncthreads();
   }
@@ -272,7 +302,7 @@ __global__ void __launch_bounds__(NT)
 
   // ---- compact table 2 into (ckey, cval) living in table-1 storage (no longer needed)
   int32_t *ckey = keys1;   // capacity ts1 >= ts2 (host guarantees)
-  double *cval = vals1;
+  double *cval = reinterpret_cast<double *>(vals1);
   for (int s0 = 0; s0 < P.ts2; s0 += NT) {
     const int s = s0 + tid;
     const bool occ = (s < P.ts2) && keys2[s] != -1;
@@ -284,7 +314,7 @@ __global__ void __launch_bounds__(NT)
       const unsigned long long below = ((tid & 63) == 0) ? 0ull : (~0ull >> (64 - (tid & 63)));
       const int pos = base + __popcll(m & below);
       ckey[pos] = keys2[s];
-      cval[pos] = vals2[s];
+      cval[pos] = nonfinite ? __longlong_as_double(0x7ff8000000000000ll) : tg_unfix(vals2[s], fx2);   // (Inf / NaN operands: NaN)
     }
   }
   __syncthreads();
@@ -332,6 +362,26 @@ __global__ void __launch_bounds__(NT)
     if (mask && (mrow || mask[key])) v = (mrow && key == gi) ? diag : 0.0;
     k_col[out0 + rank] = key;
     k_val[out0 + rank] = v;
+  }
+}
+
+// largest |entry| of every row (wave per row): the bounds of the integer accumulation
+__global__ void __launch_bounds__(256)
+    k_row_absmax(const int64_t *__restrict__ rowptr, const double *__restrict__ val, int64_t nrows, double *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    double m = 0.0;
+    for (int64_t q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) {
+      const double a = fabs(val[q]);
+      m = (a > m || a != a) ? a : m;              // (a NaN surfaces)
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double b = __shfl_xor(m, o);
+      m = (b > m || b != b) ? b : m;
+    }
+    if (lane == 0) out[r] = m;
   }
 }
 
@@ -438,6 +488,8 @@ static void tg_fill_args(tg_ptap_args &P, tg_csr_s *a, int64_t a_row0, tg_csr_s 
   P.mt_row0 = mt_row0;
   P.nrows = mt->nrows;
   P.row_stride = 1;
+  P.a_rowmax = nullptr;
+  P.m_rowmax = nullptr;
 }
 
 static int tg_status_error(int st) {
@@ -567,6 +619,23 @@ extern "C" int tg_ptap_numeric(tg_ptap_t plan, tg_csr_t a, tg_csr_t m, tg_csr_t 
   P.lg1 = tg_lg(P.g1);
   P.lg2 = tg_lg(P.g2);
   const unsigned grid = (unsigned)(tg_cdiv(std::max<int64_t>(plan->nrows, 1), 8) * 8);
+  double *a_rowmax = nullptr, *m_rowmax = nullptr;
+  if (plan->nrows > 0) {
+    rc = tg_dmalloc(&a_rowmax, std::max<int64_t>(a->nrows, 1)) || tg_dmalloc(&m_rowmax, std::max<int64_t>(m->nrows, 1));
+    if (rc) {
+      tg_dfree(a_rowmax);
+      tg_dfree(mask);
+      return rc;
+    }
+    if (a->nrows > 0)
+      hipLaunchKernelGGL(k_row_absmax, dim3((unsigned)std::min<int64_t>(tg_cdiv(a->nrows, 4), (int64_t)g_tg.num_cu * 16)), dim3(256),
+                         0, g_tg.stream, a->rowptr, a->val, a->nrows, a_rowmax);
+    if (m->nrows > 0)
+      hipLaunchKernelGGL(k_row_absmax, dim3((unsigned)std::min<int64_t>(tg_cdiv(m->nrows, 4), (int64_t)g_tg.num_cu * 16)), dim3(256),
+                         0, g_tg.stream, m->rowptr, m->val, m->nrows, m_rowmax);
+  }
+  P.a_rowmax = a_rowmax;
+  P.m_rowmax = m_rowmax;
 
   if (plan->nrows == 0) {
     rc = tg_csr_alloc(0, plan->ncols, 0, &k);
@@ -677,6 +746,8 @@ extern "C" int tg_ptap_numeric(tg_ptap_t plan, tg_csr_t a, tg_csr_t m, tg_csr_t 
   }
   hipStreamSynchronize(g_tg.stream);
   tg_dfree(mask);
+  tg_dfree(a_rowmax);
+  tg_dfree(m_rowmax);
   if (rc) {
     if (k) tg_csr_destroy(k);
     return rc;

@@ -51,6 +51,7 @@ struct tg_box_args {
   unsigned m24a, sh24a, hi24a;  // e / (n0*n1)  for 0 <= e < n0*n1*max(B2)
   unsigned m24b, sh24b, hi24b;  // r / n0       for 0 <= r < n0*n1
   unsigned long long *prof;     // optional per-phase cycle counters (TIGAR_BOX_PROF)
+  const double *rowmax;         // largest |entry| of every row of `cur` (box kernel, numeric mode: bound of the accumulators)
 };
 
 // "line" kernel (one contracted direction): a wave walks along direction u
@@ -347,6 +348,35 @@ __global__ void __launch_bounds__(NT)
       pre_w[tid] = w;
     }
   };
+  // bound of every accumulator of the box: sum over the operand rows of |weight| * (largest |entry| of the row); the
+  // scatter adds integers on the grid derived from it (tg_fix, tg_common.h: bit-reproducible whatever the order)
+  tg_fix_t fx = tg_fix_make(1.0);
+  bool nonfinite = false;
+  if (MODE != TG_BOXMODE_PROBE) {
+    double bsum = 0.0;
+    for (int c = tid; c < ncombo; c += NT) {
+      const int q0 = c % len[0];
+      const int q12 = c / len[0];
+      const int q1 = q12 % len[1];
+      const int q2 = q12 / len[1];
+      const int qq[3] = {q0, q1, q2};
+      int r[3];
+      double w = 1.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if (k < P.d && P.contracted[k]) {
+          r[k] = la[P.loff[k] + qq[k]];
+          w *= lw[P.loff[k] + qq[k]];
+        } else
+          r[k] = lo[k];
+      }
+      const int64_t lr = (int64_t)r[0] + (int64_t)P.nin[0] * r[1] + n01 * r[2] - P.row0;
+      if (lr >= 0 && lr < P.nrows) bsum += fabs(w) * P.rowmax[lr];
+    }
+    const double b1 = tg_block_sum_ordered(bsum, pre_w);
+    nonfinite = !(b1 <= 1.7e308);
+    fx = tg_fix_make(b1);
+  }
   stage_rows(0);
   __syncthreads();
   // table slices of the contraction stage: rows ilo..ihi of F_k^T, clipped to the box -> LDS
@@ -425,7 +455,7 @@ __global__ void __launch_bounds__(NT)
             const int x0 = (int)s0 - bo[0], x1 = (int)s1 - bo[1], x2 = (int)s2 - bo[2];
             if ((unsigned)x0 < (unsigned)B[0] && (unsigned)x1 < (unsigned)B[1] && (unsigned)x2 < (unsigned)B[2]) {
               const int slot = x0 + B[0] * (x1 + B[1] * x2);
-              if (MODE != TG_BOXMODE_PROBE) unsafeAtomicAdd(&buf0[slot], w * vv[u]);
+              if (MODE != TG_BOXMODE_PROBE) atomicAdd(reinterpret_cast<unsigned long long *>(buf0) + slot, tg_fix(w * vv[u], fx));
               fl0[slot] = 1;
             } else
               outside = true;
@@ -440,6 +470,12 @@ __global__ void __launch_bounds__(NT)
   if (toobig) {
     if (tid == 0) atomicMax(status, TG_BOX_TOOBIG);
     return;
+  }
+  if (MODE != TG_BOXMODE_PROBE) {   // the integers of the box back to floating point (Inf / NaN operands: NaN)
+    for (int s2 = tid; s2 < nbox; s2 += NT)
+      buf0[s2] = nonfinite ? __longlong_as_double(0x7ff8000000000000ll)
+                           : tg_unfix(reinterpret_cast<const unsigned long long *>(buf0)[s2], fx);
+    __syncthreads();
   }
 
   // ---- stage 2: contract the box with F_k, one direction after the other (LDS only, no atomics)
@@ -1055,6 +1091,29 @@ int tg_csr_compact_impl(tg_csr_s *in, tg_csr_s **out) {
 
 extern "C" int tg_csr_compact(tg_csr_t in, tg_csr_t *out) { return tg_csr_compact_impl(in, out); }
 
+// largest |entry| of every row of the operand of a stage (canonical CSR, loose rows, or a stacked view): wave per row
+__global__ void __launch_bounds__(256)
+    k_box_row_absmax(const int64_t *__restrict__ rowptr, const int64_t *__restrict__ rowptr_val, const int32_t *__restrict__ rowcnt,
+                     const double *__restrict__ val, int64_t nrows, double *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    const int64_t len = rowcnt ? (int64_t)rowcnt[r] : rowptr[r + 1] - rowptr[r];
+    const int64_t s0 = rowptr_val ? rowptr_val[r] : rowptr[r];
+    double m = 0.0;
+    for (int64_t q = lane; q < len; q += 64) {
+      const double a = fabs(val[s0 + q]);
+      m = (a > m || a != a) ? a : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double b = __shfl_xor(m, o);
+      m = (b > m || b != b) ? b : m;
+    }
+    if (lane == 0) out[r] = m;
+  }
+}
+
 static size_t tg_box_lds(int cap, int cap1, int ctab, int nlist, int nt) {
   size_t b = ((size_t)cap + cap1) * 8 + (size_t)nt * 16 + (size_t)nlist * 8 + (size_t)ctab * 8;   // f64 / i64 part
   b += (size_t)nt * 4 + 128 + (size_t)nlist * 4 + 3 * TG_BOX_MAXD * 4 + (size_t)ctab * 4;
@@ -1461,6 +1520,18 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
     // waves reserve: +20 %.  With +10 % a stage of 128^3 p=2 overflowed now and then, and a retry means
     // a new size class from hipMalloc: 0.19 instead of 0.035 s)
     if (have_cached) capacity = (int64_t)(cached->second.cap_pr * (double)nrows) + 65536;
+    if (!rc && !line_variant) {        // row maxima of the operand: bounds of the box kernel's integer accumulation
+      double *rowmax = nullptr;
+      rc = tg_dmalloc(&rowmax, std::max<int64_t>(cur->nrows, 1));
+      if (!rc) {
+        dev.push_back(rowmax);
+        if (cur->nrows > 0)
+          hipLaunchKernelGGL(k_box_row_absmax, dim3((unsigned)std::min<int64_t>(tg_cdiv(cur->nrows, 4), (int64_t)g_tg.num_cu * 16)),
+                             dim3(256), 0, g_tg.stream, cur->rowptr, (const int64_t *)cur->rowptr_val, (const int32_t *)cur->rowcnt,
+                             cur->val, cur->nrows, rowmax);
+        P.rowmax = rowmax;
+      }
+    }
     for (int attempt = 0; attempt < 6 && !rc; attempt++) {
       rc = tg_dmalloc(&tcol, capacity + TG_CSR_PAD) || tg_dmalloc(&tval, capacity + TG_CSR_PAD);
       if (rc) break;
@@ -1527,6 +1598,10 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
           TG_LINE_DISPATCH(20, 10);
         else
           TG_LINE_DISPATCH(32, 16);
+      } else if (!P.rowmax) {
+        tg_set_error("tg_ptap_kron: internal error (no row maxima for the box kernel)");
+        rc = 1;
+        break;
       } else if (nt == 64)
         hipLaunchKernelGGL((k_ptap_box<TG_BOXMODE_BUMP, 64>), dim3((unsigned)(tg_cdiv(nrows, 8) * 8)), dim3(64), lds,
                            g_tg.stream, P, cnt, off, tcol, tval, cursor, capacity, (const uint8_t *)mask, diag, status,
