@@ -133,3 +133,28 @@ def test_poisson_on_nurbs_annulus_converges(T):
         errs.append(np.max(np.abs(u.vector().get_local() - exact(X))))
     assert errs[1] < errs[0] / 5.0 and errs[2] < errs[1] / 5.0      # p = 2: rate ~3
     assert errs[2] < 2e-4
+
+
+def test_mapped_assembly_is_bit_reproducible(T):
+    """Elements are assembled colour by colour (parity of the element index per direction: elements of one colour share
+    no node), without atomics: the same bits in every run, also with many elements around every node (odd element
+    counts: the last colour is smaller)."""
+    t, B, dev = T.t, T.B, T.dev
+    for d, p, nel in ((2, 3, (37, 24)), (3, 2, (9, 7, 8))):
+        gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p] * d, [B.uniformKnots(p, 0., 1., n) for n in nel]))
+        g = gen.V.grids[0]
+        X = [gen.cpFuncs[i].vector().get_local() for i in range(d)]
+        wgt = 1.0 + 0.2 * X[0] * X[1]
+        cp = [(X[i] + 0.1 * X[(i + 1) % d] ** 2) * wgt for i in range(d)] + [wgt]
+        uks = [np.asarray(g.vertices[k]) for k in range(d)]
+        dcp = [dev.DeviceVector(data=c) for c in cp]
+        f = dev.DeviceVector(data=np.sin(3 * X[0]) + X[1])
+        Mo, Ko, bo = O.mapped_fe_system(uks, p, cp, fnodal=f.get_local()) if np.prod(nel) < 600 else (None, None, None)
+        runs = [(dev.assemble_mapped_matrix(uks, p, dcp, "laplace").to_scipy(), dev.assemble_mapped_load(uks, p, dcp, f).get_local())
+                for _ in range(3)]
+        for K, b in runs[1:]:
+            assert np.array_equal(K.data.view(np.int64), runs[0][0].data.view(np.int64))
+            assert np.array_equal(b.view(np.int64), runs[0][1].view(np.int64))
+        if Ko is not None:
+            assert abs(runs[0][0] - Ko).max() <= 1e-12 * abs(Ko).max()
+            assert np.max(np.abs(runs[0][1] - bo)) <= 1e-13 * np.max(np.abs(bo))

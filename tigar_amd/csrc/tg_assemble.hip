@@ -35,6 +35,8 @@ struct tg_asm_args {
   double *val;
   const double *fnod;          // load: nodal values
   double *bout;
+  int colour[3];               // this launch: the elements with el[k] = colour[k] (mod 2) -- they share no node
+  int ncol[3];                 // ... of which there are ncol[k] per direction
 };
 
 __device__ __forceinline__ void tg_sym_inverse(int d, const double *g, double *gi, double *det) {
@@ -89,16 +91,18 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
   double *S = G + (size_t)nqt * 9;                 // [nqt]     w sqrt(det g)   (load: times f_h)
   double *fl = S + nqt;                            // [nloc]    load: nodal values
   const int tid = threadIdx.x, nt = blockDim.x;
-  // element
+  // element: the blockIdx-th of this launch's colour.  Elements of one colour share no node, so they add into the output
+  // without atomics; the 2^d colours follow each other in a fixed order: the assembled values are bit-reproducible
+  // (global floating-point atomics added the contributions of the elements around a node in arrival order)
   int64_t e = blockIdx.x;
   int el[3] = {0, 0, 0};
-  el[0] = (int)(e % P.nel[0]);
-  e /= P.nel[0];
+  el[0] = 2 * (int)(e % P.ncol[0]) + P.colour[0];
+  e /= P.ncol[0];
   if (d > 1) {
-    el[1] = (int)(e % P.nel[1]);
-    e /= P.nel[1];
+    el[1] = 2 * (int)(e % P.ncol[1]) + P.colour[1];
+    e /= P.ncol[1];
   }
-  if (d > 2) el[2] = (int)e;
+  if (d > 2) el[2] = 2 * (int)e + P.colour[2];
   double h[3] = {1.0, 1.0, 1.0};
   for (int k = 0; k < d; k++) h[k] = P.verts[k][el[k] + 1] - P.verts[k][el[k]];
   for (int s = tid; s < 2 * p1 * nq1 + nq1; s += nt) tl[s] = P.tab[s];
@@ -162,7 +166,7 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
       }
       const int64_t node = (int64_t)(el[0] * P.p + ak[0]) +
                            (int64_t)P.n[0] * ((d > 1 ? el[1] * P.p + ak[1] : 0) + (int64_t)P.n[1] * (d > 2 ? el[2] * P.p + ak[2] : 0));
-      unsafeAtomicAdd(&P.bout[node], acc);
+      P.bout[node] += acc;
     }
     return;
   }
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
       pos += pstride * (c - lo);
       pstride *= width;
     }
-    unsafeAtomicAdd(&P.val[P.rowptr[row] + pos], acc);
+    P.val[P.rowptr[row] + pos] += acc;
   }
 }
 
@@ -374,8 +378,18 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, tg_csr_t *mout, tg
     return 2;
   }
   const int nt = (form == 2) ? 128 : 256;
-  hipLaunchKernelGGL(k_assemble_mapped, dim3((unsigned)nelem), dim3(nt), lds, g_tg.stream, A);
-  const bool bad = hipGetLastError() != hipSuccess;
+  bool bad = false;
+  for (int c = 0; c < (1 << d) && !bad; c++) {       // one launch per colour (parity of the element index per direction)
+    int64_t nblk = 1;
+    for (int k = 0; k < 3; k++) {
+      A.colour[k] = k < d ? (c >> k) & 1 : 0;
+      A.ncol[k] = k < d ? (A.nel[k] - A.colour[k] + 1) / 2 : 1;
+      nblk *= A.ncol[k];
+    }
+    if (nblk == 0) continue;
+    hipLaunchKernelGGL(k_assemble_mapped, dim3((unsigned)nblk), dim3(nt), lds, g_tg.stream, A);
+    bad = hipGetLastError() != hipSuccess;
+  }
   cleanup();
   if (bad) {
     if (m) tg_csr_destroy(m);
