@@ -265,6 +265,28 @@ def test_extraction_operators_of_a_3d_quartic_patch(dev):
         assert np.array_equal(MT.data, MTo.data)
 
 
+def test_tensor_apply_along_the_fastest_direction_line_kernel(dev, monkeypatch):
+    """M^T b and M U apply the 1-D factors direction by direction; along the fastest direction whole lines go through LDS
+    (k_tensor_apply_lines).  Same terms in the same order as the gather kernel: bitwise equal results, for factors with
+    rows of different lengths, empty rows and shifted columns."""
+    rng = np.random.default_rng(4)
+    for nin, nout, nhi, T, shift in ((769, 259, 5000, 10, 0), (259, 769, 4500, 4, 0), (40, 17, 6000, 7, 3), (832, 30, 4200, 3, 0)):
+        F = sp.random(nout, nin, density=min(1.0, T / nin), random_state=7, format="lil")
+        F[1, :] = 0.0                                        # an empty row
+        F[0, : min(nin, 2 * T)] = 1.5                        # a long one
+        F = sp.csr_matrix(F)
+        F.data = rng.standard_normal(F.nnz)
+        x = rng.standard_normal(nin * nhi)
+        ref = (F @ x.reshape(nhi, nin).T).T.ravel()
+        Fs = sp.csr_matrix((F.data, F.indices + shift, F.indptr), shape=(nout, nin + shift))
+        outs = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("TIGAR_APPLY_LINES", flag)
+            outs[flag] = dev.tensor_apply_1d(dev.DeviceVector(data=x), [nin, nhi], 0, Fs, col_shift=shift).get_local()
+        assert np.array_equal(outs["0"].view(np.int64), outs["1"].view(np.int64))
+        assert np.max(np.abs(outs["1"] - ref)) <= 1e-13 * np.max(np.abs(ref))
+
+
 def test_general_hash_ptap_is_bit_reproducible_and_scale_aware(dev):
     """The hash kernel (nothing assumed about M) adds into its LDS tables with atomics, i.e. in an order that differs from
     run to run; the terms are added as integers on a grid derived from a bound of the row's accumulators (tg_fix,

@@ -454,6 +454,82 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The same along the FASTEST direction (n_lo = 1): there the entries an output needs are neighbours in memory and the
+// factor rows of neighbouring outputs differ, so the kernel above spends its time on per-lane table and gather loads
+// (2.1 ms for the 452 M -> 153 M pass of M^T b at cfg3, 34 % of the HBM peak).  Here a WAVE takes a whole line: the line
+// goes to LDS with coalesced loads, the factor sits in LDS in padded column-major form (term j of output I at [j][I]: the
+// lanes of a wave read consecutive words), and an output is T LDS reads and T FMAs in the factor's own term order.
+#define TG_APPLY_LINES_NT 1024       // sixteen waves share one copy of the factor
+#define TG_APPLY_LINES_NL 13         // entries of a line per lane: lines of up to 64 * 13 = 832 entries
+__global__ void __launch_bounds__(TG_APPLY_LINES_NT)
+    k_tensor_apply_lines(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci, const double *__restrict__ fv,
+                         int nin_k, int nout_k, int64_t n_hi, int64_t col_shift, int maxt, const double *__restrict__ in,
+                         double *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_al[];
+  double *ell_v = reinterpret_cast<double *>(smem_al);                       // [maxt][nout_k]
+  double *buf = ell_v + (size_t)maxt * nout_k;                               // [waves][nin_k]
+  int32_t *ell_c = reinterpret_cast<int32_t *>(buf + (size_t)(TG_APPLY_LINES_NT / 64) * nin_k);   // [maxt][nout_k]; -1: no term
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int I = tid; I < nout_k; I += TG_APPLY_LINES_NT) {
+    const int t0 = rp[I], n = rp[I + 1] - t0;
+    for (int j = 0; j < maxt; j++) {
+      ell_c[j * nout_k + I] = j < n ? (int32_t)(ci[t0 + j] - col_shift) : -1;
+      ell_v[j * nout_k + I] = j < n ? fv[t0 + j] : 0.0;
+    }
+  }
+  __syncthreads();
+  double *line = buf + (size_t)w * nin_k;
+  const int64_t nw = (int64_t)gridDim.x * (TG_APPLY_LINES_NT / 64);
+  int64_t hi = (int64_t)blockIdx.x * (TG_APPLY_LINES_NT / 64) + w;
+  // the next line travels in registers while the current one is worked on (unconditional loads, index clamped: a
+  // branch around a load would make the compiler wait for all loads at the next use)
+  double nx[TG_APPLY_LINES_NL];
+  {
+    const double *src = in + (int64_t)nin_k * min(hi, n_hi - 1);
+#pragma unroll
+    for (int q = 0; q < TG_APPLY_LINES_NL; q++) nx[q] = src[min(lane + 64 * q, nin_k - 1)];
+  }
+  for (; hi < n_hi; hi += nw) {
+#pragma unroll
+    for (int q = 0; q < TG_APPLY_LINES_NL; q++)
+      if (lane + 64 * q < nin_k) line[lane + 64 * q] = nx[q];
+    // (the line is private to the wave, whose LDS operations execute in order: a compiler fence is all it takes)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      const double *src = in + (int64_t)nin_k * min(hi + nw, n_hi - 1);
+#pragma unroll
+      for (int q = 0; q < TG_APPLY_LINES_NL; q++) nx[q] = src[min(lane + 64 * q, nin_k - 1)];
+    }
+    double *dst = out + (int64_t)nout_k * hi;
+    for (int I0 = lane; I0 < nout_k; I0 += 256) {                            // four outputs per lane at a time
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int j = 0; j < maxt; j++) {
+        int c[4];
+        double v[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int I = min(I0 + 64 * u, nout_k - 1);
+          c[u] = ell_c[j * nout_k + I];
+          v[u] = ell_v[j * nout_k + I];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = line[max(c[u], 0)];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (c[u] >= 0) acc[u] += v[u] * x[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (I0 + 64 * u < nout_k) dst[I0 + 64 * u] = acc[u];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 extern "C" int tg_tensor_apply_1d(int d, const int64_t *dims_in, int k, int64_t nout_k, const int32_t *rowptr,
                                   const int32_t *col, const double *val, int64_t col_shift, tg_vec_t in, tg_vec_t out) {
   TG_REQUIRE_INIT();
@@ -482,7 +558,26 @@ extern "C" int tg_tensor_apply_1d(int d, const int64_t *dims_in, int k, int64_t 
     rc = tg_h2d_staged(drp, rowptr, (size_t)(nout_k + 1) * sizeof(int32_t));
     if (!rc && nnz1) rc = tg_h2d_staged(dci, col, (size_t)nnz1 * sizeof(int32_t)) || tg_h2d_staged(dfv, val, (size_t)nnz1 * sizeof(double));
   }
-  if (!rc) {
+  int maxt = 0;
+  for (int64_t i = 0; i < nout_k; i++) maxt = std::max(maxt, rowptr[i + 1] - rowptr[i]);
+  // the line kernel: fastest direction, lines and table fit in LDS, enough lines to fill the chip (TIGAR_APPLY_LINES=0: off)
+  const size_t lines_lds = (size_t)maxt * nout_k * 12 + (size_t)(TG_APPLY_LINES_NT / 64) * nin_k * 8 + 16;
+  const bool lines_on = !(getenv("TIGAR_APPLY_LINES") && atoi(getenv("TIGAR_APPLY_LINES")) == 0);
+  bool use_lines = lines_on && n_lo == 1 && maxt >= 1 && lines_lds <= 150 * 1024 && n_hi >= 16 * (int64_t)g_tg.num_cu &&
+                   nin_k <= 64 * TG_APPLY_LINES_NL && nout_k < (1 << 24);
+  if (use_lines && hipFuncSetAttribute((const void *)k_tensor_apply_lines, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lines_lds) != hipSuccess) {
+    (void)hipGetLastError();
+    use_lines = false;
+  }
+  if (!rc && use_lines) {
+    const int64_t blocks = std::min<int64_t>(tg_cdiv(n_hi, TG_APPLY_LINES_NT / 64), (int64_t)g_tg.num_cu);
+    hipLaunchKernelGGL(k_tensor_apply_lines, dim3((unsigned)blocks), dim3(TG_APPLY_LINES_NT), lines_lds, g_tg.stream, drp, dci, dfv,
+                       (int)nin_k, (int)nout_k, n_hi, col_shift, maxt, in->d, out->d);
+    if (hipGetLastError() != hipSuccess) {
+      tg_set_error("k_tensor_apply_lines failed to launch");
+      rc = 1;
+    }
+  } else if (!rc) {
     const int64_t blocks = std::min<int64_t>(tg_cdiv(out->n, 256), (int64_t)g_tg.num_cu * 32);
     hipLaunchKernelGGL(k_tensor_apply_1d, dim3((unsigned)blocks), dim3(256), 0, g_tg.stream, drp, dci, dfv, n_lo, nin_k, nout_k,
                        n_hi, col_shift, in->d, out->d);
