@@ -140,8 +140,10 @@ __global__ void __launch_bounds__(256) k_cg1_dot(const double *__restrict__ w, c
 }
 
 // folds the (gamma, nu) partials of the update kernel and the delta partials of the dot kernel into cur->{gamma,delta,nu}
+// (`hist`: the history entry of the iteration in pinned host memory, written here when one rank runs alone -- a
+// device-to-host copy of 24 bytes is a blit kernel of its own, 4 us per iteration)
 __global__ void __launch_bounds__(256) k_cg1_fold(const double *__restrict__ part_gn, const double *__restrict__ part_d,
-                                                  int nb, tg_cg_scal *cur) {
+                                                  int nb, tg_cg_scal *cur, double *hist) {
   __shared__ double lds4[4];
   double g = 0.0, nu = 0.0, d = 0.0;
   for (int b = threadIdx.x; b < nb; b += 256) {
@@ -156,6 +158,11 @@ __global__ void __launch_bounds__(256) k_cg1_fold(const double *__restrict__ par
     cur->gamma = g;
     cur->delta = d;
     cur->nu = nu;
+    if (hist) {
+      hist[0] = g;
+      hist[1] = d;
+      hist[2] = nu;
+    }
   }
 }
 
@@ -301,6 +308,9 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
   tg_cg_ring ring;
   TG_TRY(ring.init());
   double *hist = g_tg.host_pinned + 8;                     // TG_CG_RING x 3 doubles (pinned)
+  double *hist_dev = nullptr;                              // the same ring as a kernel addresses it (one rank only)
+  if (!(comm && comm->world > 1) && !getenv("TIGAR_CG_HIST_COPY"))
+    TG_CHECK_HIP(hipHostGetDevicePointer((void **)&hist_dev, hist, 0));
   const double *ushift = uext - (row0 - hlo);              // u addressed by global column index
   const int64_t cmin = row0 - hlo, cmax = row0 - hlo + next - 1;
 
@@ -383,10 +393,13 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
     TG_TRY(product(gate));
     hipEventRecord(ring.t1[slot], g_tg.stream);
     hipLaunchKernelGGL(k_cg1_dot, dim3(vg), dim3(256), 0, g_tg.stream, w, u, n, part_d);
-    hipLaunchKernelGGL(k_cg1_fold, dim3(1), dim3(256), 0, g_tg.stream, part_gn, part_d, vg, cur);
+    hipLaunchKernelGGL(k_cg1_fold, dim3(1), dim3(256), 0, g_tg.stream, part_gn, part_d, vg, cur,
+                       hist_dev ? hist_dev + 3 * slot : (double *)nullptr);
     TG_LAUNCH_CHECK();
-    TG_TRY(tg_comm_allreduce_dev(comm, (double *)cur, 3));
-    TG_CHECK_HIP(hipMemcpyAsync(hist + 3 * slot, cur, 3 * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
+    if (!hist_dev) {                             // several ranks: the entry is what the all-reduce leaves
+      TG_TRY(tg_comm_allreduce_dev(comm, (double *)cur, 3));
+      TG_CHECK_HIP(hipMemcpyAsync(hist + 3 * slot, cur, 3 * sizeof(double), hipMemcpyDeviceToHost, g_tg.stream));
+    }
     TG_CHECK_HIP(hipEventRecord(ring.done[slot], g_tg.stream));
     return 0;
   };
