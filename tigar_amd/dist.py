@@ -180,6 +180,14 @@ class SlabHotPath(object):
         if sub_planes == "auto":
             # what the path can use: free device memory plus what the library's caching allocator holds idle
             free_b = dev.mem_info()[0] + dev.pool_stats()[0]
+            if world > 1:
+                # ranks that share a GPU (fewer devices than local ranks) all see the same free memory: each takes its share
+                # (eight ranks of cfg3 on one GPU ran out of memory when every one of them sized its sub-slabs for all of it)
+                try:
+                    local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+                    free_b //= max(1, -(-local // max(1, dev.device_count())))
+                except Exception:
+                    pass
             pmax = max(s1.p for s1 in basis.splines)
             nelmax = max(s1.nel for s1 in basis.splines)
             sub_planes = pick_sub_planes(basis.nvar, pmax, nelmax, self.k1 - self.k0, free_b)

@@ -34,8 +34,7 @@ bench)
   TIGAR_PTAP_TENSOR=0 bench cfg3_general_line --steps 3 --warmup 1 $W
   TIGAR_PTAP_TENSOR=0 TIGAR_PTAP_FACTORED=0 TIGAR_IMPLICIT_M=1 bench cfg3_general_hash --steps 2 --warmup 1 $W
   TIGAR_COMM=ipc TIGAR_DEVICE=0 bench cfg2_2ranks_ipc_one_gpu --workload cfg2 --gpus 2 --steps 5 --warmup 2 $W
-  # (8 ranks of cfg3 on ONE GPU need all of its memory and ran out of it next to the other lines: not part of the set)
-  # TIGAR_COMM=ipc TIGAR_DEVICE=0 bench cfg3_8ranks_ipc_one_gpu --gpus 8 --steps 2 --warmup 1 $W
+  TIGAR_COMM=ipc TIGAR_DEVICE=0 bench cfg3_8ranks_ipc_one_gpu --gpus 8 --steps 2 --warmup 1 $W
   ;;
 stats)
   stats cfg3 --steps 5 --warmup 1 $W
