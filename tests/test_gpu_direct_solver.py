@@ -49,9 +49,10 @@ def test_blocked_factorisation_gives_the_factors_of_the_column_by_column_one(mon
     from tigar_amd import device as dev
     rng = np.random.default_rng(7)
     # (the band widths walk through the instantiations of the register panel: 1, 2, 3 rows per thread with 256 threads,
-    # 3 with 384, then the 8-column panels; other panel widths and TIGAR_LU_PANEL_REG=0 run the panel in LDS)
+    # 3 with 384, then the 8-column panels; other panel widths and TIGAR_LU_PANEL_REG=0 run the panel in LDS; the widest
+    # band takes 4-column panels in LDS and the trailing kernel that reads its multipliers in place)
     for (n, kl, ku) in [(7, 2, 1), (97, 5, 9), (700, 40, 17), (1500, 130, 130), (64, 63, 63), (900, 300, 20),
-                        (1400, 600, 600), (1500, 1000, 30), (1800, 1300, 10), (2300, 2000, 50)]:
+                        (1400, 600, 600), (1500, 1000, 30), (1800, 1300, 10), (2300, 2000, 50), (2900, 2500, 20)]:
         diags = {o: rng.standard_normal(n - abs(o)) for o in range(-kl, ku + 1)}
         A = sp.diags(list(diags.values()), list(diags.keys()), shape=(n, n), format="csr").tolil()
         for i in range(0, n, 3):
