@@ -287,11 +287,12 @@ def test_tensor_apply_along_the_fastest_direction_line_kernel(dev, monkeypatch):
         assert np.max(np.abs(outs["1"] - ref)) <= 1e-13 * np.max(np.abs(ref))
 
 
-def test_general_hash_ptap_is_bit_reproducible_and_scale_aware(dev):
+def test_general_hash_ptap_is_bit_reproducible_and_scale_aware(dev, monkeypatch):
     """The hash kernel (nothing assumed about M) adds into its LDS tables with atomics, i.e. in an order that differs from
-    run to run; the terms are added as integers on a grid derived from a bound of the row's accumulators (tg_fix,
-    csrc/tg_common.h), so K is the same to the last bit in every run.  The grid follows the ROW: rows of A scaled by 1e+-12
-    (penalty terms, badly scaled units) keep their relative accuracy; Inf / NaN operands surface as NaN in their rows."""
+    run to run.  Rows of K whose operand rows are of one scale add INTEGERS on a grid derived from a bound of the row's
+    accumulators (tg_fix, csrc/tg_common.h): the same bits in every run, every entry within 2^-62 of its row's largest sum
+    of magnitudes.  Rows that mix scales (a penalty of 1e12 in one FE row) would lose digits on such a grid and accumulate
+    in floating point instead: accurate per entry.  TIGAR_PTAP_ACCUM=int|float forces either."""
     rng = np.random.default_rng(11)
     nfe, ncp = 1500, 300
     A = _rand_csr(rng, nfe, nfe, 0.02)
@@ -306,35 +307,48 @@ def test_general_hash_ptap_is_bit_reproducible_and_scale_aware(dev):
         assert np.array_equal(K.data.view(np.int64), runs[0].data.view(np.int64))
     Ko = (M.T @ A @ M).tocsr()
     assert abs(runs[0] - Ko).max() <= 1e-13 * abs(Ko).max()
-    # rows of A of very different scale (penalty terms, units): the grid follows the row of K -- every entry is within
-    # a few 1e-16 (the comparison product's own rounding) of the largest sum of |terms| of ITS row (a floating-point sum is relative to each entry's own terms; entries
-    # more than ~1e6 below their row's largest therefore carry fewer than 16 digits here)
+
+    def entry_and_row_errors(K, Mx, Ax):
+        Kx = (Mx.T @ Ax @ Mx).tocsr()
+        mag = (abs(Mx).T @ abs(Ax) @ abs(Mx)).tocsr()       # sum of the |terms| of every entry
+        err = abs(K - Kx).tocsr()
+        mag.sort_indices()
+        inv = mag.copy()
+        inv.data = 1.0 / inv.data
+        per_entry = err.multiply(inv).max() if err.nnz else 0.0
+        per_row = np.max(np.asarray(err.max(axis=1).todense()).ravel() /
+                         np.maximum(np.asarray(mag.max(axis=1).todense()).ravel(), 1e-300))
+        return per_entry, per_row
+
+    # rows of A of very different scale (penalty terms, units): such rows of K accumulate in floating point, every entry
+    # is accurate relative to ITS OWN terms; forced onto the integer grid the error is relative to the row's largest
     scale = 10.0 ** rng.integers(-12, 13, size=nfe)
     As = (sp.diags(scale) @ A).tocsr()
-    Ks = dev.ptap_numeric(plan, dev.DeviceCSR.from_scipy(As), Md, MT).to_scipy()
-    Kso = (M.T @ As @ M).tocsr()
-    mag = (abs(M).T @ abs(As) @ abs(M)).tocsr()           # sum of the |terms| of every entry
-    err = abs(Ks - Kso).tocsr()
-    row_err = np.asarray(err.max(axis=1).todense()).ravel()
-    row_mag = np.asarray(mag.max(axis=1).todense()).ravel()
-    assert (row_err <= 2e-15 * row_mag).all(), np.max(row_err / np.maximum(row_mag, 1e-300))
-    # scaling of K's own rows and columns (M^T D A D M with D on the dof side is what a change of units does): each row
-    # keeps full relative accuracy
+    Asd = dev.DeviceCSR.from_scipy(As)
+    per_entry, per_row = entry_and_row_errors(dev.ptap_numeric(plan, Asd, Md, MT).to_scipy(), M, As)
+    assert per_entry <= 4e-15, per_entry
+    monkeypatch.setenv("TIGAR_PTAP_ACCUM", "int")
+    per_entry_int, per_row_int = entry_and_row_errors(dev.ptap_numeric(plan, Asd, Md, MT).to_scipy(), M, As)
+    assert per_row_int <= 4e-15 and per_entry_int > 1e-12, (per_entry_int, per_row_int)
+    monkeypatch.setenv("TIGAR_PTAP_ACCUM", "float")
+    per_entry, _ = entry_and_row_errors(dev.ptap_numeric(plan, Ad, Md, MT).to_scipy(), M, A)
+    assert per_entry <= 4e-15
+    monkeypatch.delenv("TIGAR_PTAP_ACCUM")
+    # scaling of the dofs (a change of units of the unknowns: M D): every row of K is of one scale in its operands
+    # (the rows of A are untouched), integers, and each row keeps full accuracy relative to its own largest entry
     dscale = 10.0 ** rng.integers(-9, 10, size=ncp)
     Msc = (M @ sp.diags(dscale)).tocsr()
     Mscd = dev.DeviceCSR.from_scipy(Msc)
-    Kd = dev.ptap_numeric(dev.ptap_symbolic(Ad, Mscd, Mscd.transpose()), Ad, Mscd, Mscd.transpose()).to_scipy()
-    Kdo = (Msc.T @ A @ Msc).tocsr()
-    magd = (abs(Msc).T @ abs(A) @ abs(Msc)).tocsr()
-    row_err = np.asarray(abs(Kd - Kdo).max(axis=1).todense()).ravel()
-    row_mag = np.asarray(magd.max(axis=1).todense()).ravel()
-    assert (row_err <= 2e-15 * row_mag).all()
-    # non-finite operands
+    Kd = [dev.ptap_numeric(dev.ptap_symbolic(Ad, Mscd, Mscd.transpose()), Ad, Mscd, Mscd.transpose()).to_scipy() for _ in range(2)]
+    assert np.array_equal(Kd[0].data.view(np.int64), Kd[1].data.view(np.int64))
+    _, per_row = entry_and_row_errors(Kd[0], Msc, A)
+    assert per_row <= 4e-15
+    # non-finite operands surface as NaN in the rows they reach, the other rows are untouched
     Ab = A.copy()
     Ab.data[7] = np.inf
     Kb = dev.ptap_numeric(plan, dev.DeviceCSR.from_scipy(Ab), Md, MT).to_scipy()
     bad_rows = np.unique(M[Ab.tocoo().row[7]].indices)
-    assert np.isnan(Kb.data[Kb.indptr[bad_rows[0]]:Kb.indptr[bad_rows[0] + 1]]).all()
+    assert not np.isfinite(Kb.data[Kb.indptr[bad_rows[0]]:Kb.indptr[bad_rows[0] + 1]]).all()
     good = np.setdiff1d(np.arange(ncp), bad_rows)
     if good.size:
         g = good[0]

@@ -218,6 +218,7 @@ __device__ __forceinline__ double tg_block_sum256(double v, double *lds4) {
 struct tg_fix_t {
   double inv;     // 2^-e
   double scale;   // 2^e
+  int fp;         // 1: this row accumulates floating-point numbers instead (see tg_fix_choose)
 };
 __device__ __forceinline__ tg_fix_t tg_fix_make(double bound) {
   tg_fix_t f;
@@ -225,13 +226,54 @@ __device__ __forceinline__ tg_fix_t tg_fix_make(double bound) {
   e = max(e, -1000);                               // (2^-e must be a finite double)
   f.inv = ldexp(1.0, -e);
   f.scale = ldexp(1.0, e);
+  f.fp = 0;
   return f;
 }
+// The grid belongs to the ROW of K: an entry keeps 62 bits relative to the largest sum of magnitudes of its row.  That is
+// as good as floating point when the operand rows of the row are of one scale, and not when they are not -- a penalty or
+// contact term of 1e12 in one FE row would leave the ordinary entries of the K rows it touches with seven digits.  So a
+// row whose operand rows differ by more than 2^16 in their largest entries (or hold Inf / NaN) accumulates in floating
+// point as before round 3 (accurate per entry, last bits dependent on the order); `mode`: 0 this rule, 1 always
+// integers, 2 always floating point (TIGAR_PTAP_ACCUM=auto|int|float).
+__device__ __forceinline__ tg_fix_t tg_fix_choose(double bound, double rowmax_lo, double rowmax_hi, int mode) {
+  tg_fix_t f = tg_fix_make(bound);
+  const bool finite = bound <= 1.7e308;            // (false for NaN as well)
+  const bool one_scale = !(rowmax_hi > 65536.0 * rowmax_lo);
+  f.fp = mode == 2 || !finite || (mode == 0 && !one_scale);
+  return f;
+}
+// what is added to the accumulator (integer or the bits of the floating-point term), the addition itself, and the way back
 __device__ __forceinline__ unsigned long long tg_fix(double v, const tg_fix_t &f) {
-  return (unsigned long long)__double2ll_rn(v * f.inv);
+  return f.fp ? (unsigned long long)__double_as_longlong(v) : (unsigned long long)__double2ll_rn(v * f.inv);
+}
+__device__ __forceinline__ void tg_fix_add(unsigned long long *slot, unsigned long long t, const tg_fix_t &f) {
+  if (f.fp)
+    unsafeAtomicAdd(reinterpret_cast<double *>(slot), __longlong_as_double((long long)t));
+  else
+    atomicAdd(slot, t);
 }
 __device__ __forceinline__ double tg_unfix(unsigned long long n, const tg_fix_t &f) {
-  return __ll2double_rn((long long)n) * f.scale;
+  return f.fp ? __longlong_as_double((long long)n) : __ll2double_rn((long long)n) * f.scale;
+}
+// smallest / largest of a non-negative quantity over the workgroup (entries < 0 are ignored; `scratch`: blockDim.x doubles)
+__device__ __forceinline__ void tg_block_minmax(double lo, double hi, double *scratch, double *out_lo, double *out_hi) {
+  const int tid = threadIdx.x;
+  scratch[tid] = hi;
+  __syncthreads();
+  for (int o = (int)blockDim.x >> 1; o > 0; o >>= 1) {
+    if (tid < o) scratch[tid] = fmax(scratch[tid], scratch[tid + o]);
+    __syncthreads();
+  }
+  *out_hi = scratch[0];
+  __syncthreads();
+  scratch[tid] = lo;
+  __syncthreads();
+  for (int o = (int)blockDim.x >> 1; o > 0; o >>= 1) {
+    if (tid < o) scratch[tid] = fmin(scratch[tid], scratch[tid + o]);
+    __syncthreads();
+  }
+  *out_lo = scratch[0];
+  __syncthreads();
 }
 // sum over the workgroup in a fixed order (tree in LDS; `scratch`: blockDim.x doubles, free before and after)
 __device__ __forceinline__ double tg_block_sum_ordered(double x, double *scratch) {

@@ -22,6 +22,7 @@
 #include "tg_common.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstring>
 
 struct tg_ptap_s {
   int64_t nrows = 0;        // K rows in this block
@@ -49,6 +50,7 @@ struct tg_ptap_args {
   int64_t row_stride;  // probing: row = idx * row_stride
   int ts1, ts2, lg1, lg2, g1, g2;
   const double *a_rowmax, *m_rowmax;   // largest |entry| of every row of A / M (numeric modes: bounds of the accumulators)
+  int accum_mode;                      // 0: integers unless the operand rows differ too much in scale, 1: integers, 2: floating point
 };
 
 enum { TG_PTAP_OK = 0, TG_PTAP_OVF1 = 1, TG_PTAP_OVF2 = 2, TG_PTAP_RANGE = 3, TG_PTAP_CAP = 4 };
@@ -71,7 +73,7 @@ typedef int tg_i4v __attribute__((ext_vector_type(4)));
 // The values are accumulated as integers (tg_fix, tg_common.h): `vals` holds 64-bit integers until the table is compacted.
 template <bool NUMERIC, int U>
 __device__ __forceinline__ bool tg_hash_insert_n(int32_t *keys, unsigned long long *vals, int ts, int lg, const int32_t *key,
-                                                 const unsigned long long *v) {
+                                                 const unsigned long long *v, const tg_fix_t &fx) {
   const int nb_mask = (ts >> 2) - 1;
   // ---- fast round: the U home buckets are fetched back to back (independent LDS reads), then
   // matched; a key that sits in its home bucket -- the overwhelmingly common case -- costs one
@@ -90,7 +92,7 @@ __device__ __forceinline__ bool tg_hash_insert_n(int32_t *keys, unsigned long lo
     const int32_t k = key[u];
     const int pos = (kk[u].x == k) ? 0 : (kk[u].y == k) ? 1 : (kk[u].z == k) ? 2 : (kk[u].w == k) ? 3 : -1;
     const bool hit = (k >= 0) && (pos >= 0);
-    if (NUMERIC && hit) atomicAdd(&vals[4 * b[u] + pos], v[u]);
+    if (NUMERIC && hit) tg_fix_add(&vals[4 * b[u] + pos], v[u], fx);
     pending[u] = (k >= 0) && !hit;
     any_pending |= pending[u];
   }
@@ -116,7 +118,7 @@ __device__ __forceinline__ bool tg_hash_insert_n(int32_t *keys, unsigned long lo
         }
       }
       const bool hit = pend && pos >= 0;
-      if (NUMERIC && hit) atomicAdd(&vals[4 * bb + pos], v[u]);
+      if (NUMERIC && hit) tg_fix_add(&vals[4 * bb + pos], v[u], fx);
       pend = pend && !hit;
       if (++rounds > ts) {  // wave-uniform
         ok = false;
@@ -154,7 +156,7 @@ __device__ __forceinline__ bool tg_accumulate_rows(int nch, const int64_t *pre_s
         c[u] = (oo < len) ? cc : -2;
         v[u] = NUMERIC ? tg_fix(w * val[start + oc], fx) : 0ull;
       }
-      ok &= tg_hash_insert_n<NUMERIC, TG_PTAP_UNROLL>(keys, vals, ts, lgts, c, v);
+      ok &= tg_hash_insert_n<NUMERIC, TG_PTAP_UNROLL>(keys, vals, ts, lgts, c, v, fx);
     }
   }
   return ok;
@@ -198,20 +200,27 @@ __global__ void __launch_bounds__(NT)
 
   bool ovf1 = false, ovf2 = false, range = false;
   // ---- stage 1: T = (row i of M^T) * A
-  bool nonfinite = false;
+  int row_fp = 0;                      // this row accumulates in floating point (both stages)
   {
     const int64_t e0 = P.mt_rowptr[li], e1 = P.mt_rowptr[li + 1];
     // bound of every entry of T: sum over the operand rows of |weight| * (largest |entry| of the row)
     tg_fix_t fx = tg_fix_make(1.0);
     if (NUMERIC) {
-      double bsum = 0.0;
+      double bsum = 0.0, rlo = 1.7e308, rhi = 0.0;
       for (int64_t e = e0 + tid; e < e1; e += NT) {
         const int64_t ra = (int64_t)P.mt_col[e] - P.a_row0;
-        if (ra >= 0 && ra < P.a_nrows) bsum += fabs(P.mt_val[e]) * P.a_rowmax[ra];
+        if (ra >= 0 && ra < P.a_nrows) {
+          const double rm = P.a_rowmax[ra];
+          bsum += fabs(P.mt_val[e]) * rm;
+          if (P.mt_val[e] != 0.0 && rm != 0.0) {   // (a NaN fails both comparisons below and reaches the sum)
+            rlo = fmin(rlo, rm);
+            rhi = fmax(rhi, rm);
+          }
+        }
       }
       const double b1 = tg_block_sum_ordered(bsum, pre_w);
-      nonfinite = !(b1 <= 1.7e308);
-      fx = tg_fix_make(b1);
+      tg_block_minmax(rlo, rhi, pre_w, &rlo, &rhi);
+      fx = tg_fix_choose(b1, rlo, rhi, P.accum_mode);
     }
     for (int64_t c0 = e0; c0 < e1; c0 += NT) {
       const int64_t e = c0 + tid;
@@ -239,6 +248,7 @@ __global__ void __launch_bounds__(NT)
     if (NUMERIC)
       for (int s = tid; s < P.ts1; s += NT) vals1[s] = (unsigned long long)__double_as_longlong(tg_unfix(vals1[s], fx));
     __syncthreads();
+    row_fp = fx.fp;
   }
 
   // ---- compact the occupied (key, value) pairs of table 1 to the front of its own storage
@@ -272,8 +282,7 @@ __global__ void __launch_bounds__(NT)
       if (sm >= 0 && sm < P.m_nrows) bsum += fabs(__longlong_as_double((long long)vals1[e])) * P.m_rowmax[sm];
     }
     const double b2 = tg_block_sum_ordered(bsum, pre_w);
-    nonfinite = nonfinite || !(b2 <= 1.7e308);
-    fx2 = tg_fix_make(b2);
+    fx2 = tg_fix_choose(b2, 1.0, 1.0, row_fp ? 2 : 1);
   }
   for (int c0 = 0; c0 < nT; c0 += NT) {
     const int e = c0 + tid;
@@ -314,7 +323,7 @@ __global__ void __launch_bounds__(NT)
       const unsigned long long below = ((tid & 63) == 0) ? 0ull : (~0ull >> (64 - (tid & 63)));
       const int pos = base + __popcll(m & below);
       ckey[pos] = keys2[s];
-      cval[pos] = nonfinite ? __longlong_as_double(0x7ff8000000000000ll) : tg_unfix(vals2[s], fx2);   // (Inf / NaN operands: NaN)
+      cval[pos] = tg_unfix(vals2[s], fx2);
     }
   }
   __syncthreads();
@@ -490,6 +499,8 @@ static void tg_fill_args(tg_ptap_args &P, tg_csr_s *a, int64_t a_row0, tg_csr_s 
   P.row_stride = 1;
   P.a_rowmax = nullptr;
   P.m_rowmax = nullptr;
+  const char *am = getenv("TIGAR_PTAP_ACCUM");
+  P.accum_mode = am && !strcmp(am, "int") ? 1 : am && !strcmp(am, "float") ? 2 : 0;
 }
 
 static int tg_status_error(int st) {

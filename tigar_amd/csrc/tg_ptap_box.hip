@@ -21,6 +21,7 @@
 #include <array>
 #include <map>
 #include <algorithm>
+#include <cstring>
 
 struct tg_box_args {
   const int32_t *rowcnt;        // loose rows of an intermediate stage result (nullptr: canonical CSR)
@@ -52,6 +53,7 @@ struct tg_box_args {
   unsigned m24b, sh24b, hi24b;  // r / n0       for 0 <= r < n0*n1
   unsigned long long *prof;     // optional per-phase cycle counters (TIGAR_BOX_PROF)
   const double *rowmax;         // largest |entry| of every row of `cur` (box kernel, numeric mode: bound of the accumulators)
+  int accum_mode;               // 0: integers unless the operand rows differ too much in scale, 1: integers, 2: floating point
 };
 
 // "line" kernel (one contracted direction): a wave walks along direction u
@@ -351,9 +353,8 @@ __global__ void __launch_bounds__(NT)
   // bound of every accumulator of the box: sum over the operand rows of |weight| * (largest |entry| of the row); the
   // scatter adds integers on the grid derived from it (tg_fix, tg_common.h: bit-reproducible whatever the order)
   tg_fix_t fx = tg_fix_make(1.0);
-  bool nonfinite = false;
   if (MODE != TG_BOXMODE_PROBE) {
-    double bsum = 0.0;
+    double bsum = 0.0, rlo = 1.7e308, rhi = 0.0;
     for (int c = tid; c < ncombo; c += NT) {
       const int q0 = c % len[0];
       const int q12 = c / len[0];
@@ -371,11 +372,18 @@ __global__ void __launch_bounds__(NT)
           r[k] = lo[k];
       }
       const int64_t lr = (int64_t)r[0] + (int64_t)P.nin[0] * r[1] + n01 * r[2] - P.row0;
-      if (lr >= 0 && lr < P.nrows) bsum += fabs(w) * P.rowmax[lr];
+      if (lr >= 0 && lr < P.nrows) {
+        const double rm = P.rowmax[lr];
+        bsum += fabs(w) * rm;
+        if (w != 0.0 && rm != 0.0) {
+          rlo = fmin(rlo, rm);
+          rhi = fmax(rhi, rm);
+        }
+      }
     }
     const double b1 = tg_block_sum_ordered(bsum, pre_w);
-    nonfinite = !(b1 <= 1.7e308);
-    fx = tg_fix_make(b1);
+    tg_block_minmax(rlo, rhi, pre_w, &rlo, &rhi);
+    fx = tg_fix_choose(b1, rlo, rhi, P.accum_mode);
   }
   stage_rows(0);
   __syncthreads();
@@ -455,7 +463,7 @@ __global__ void __launch_bounds__(NT)
             const int x0 = (int)s0 - bo[0], x1 = (int)s1 - bo[1], x2 = (int)s2 - bo[2];
             if ((unsigned)x0 < (unsigned)B[0] && (unsigned)x1 < (unsigned)B[1] && (unsigned)x2 < (unsigned)B[2]) {
               const int slot = x0 + B[0] * (x1 + B[1] * x2);
-              if (MODE != TG_BOXMODE_PROBE) atomicAdd(reinterpret_cast<unsigned long long *>(buf0) + slot, tg_fix(w * vv[u], fx));
+              if (MODE != TG_BOXMODE_PROBE) tg_fix_add(reinterpret_cast<unsigned long long *>(buf0) + slot, tg_fix(w * vv[u], fx), fx);
               fl0[slot] = 1;
             } else
               outside = true;
@@ -471,10 +479,8 @@ __global__ void __launch_bounds__(NT)
     if (tid == 0) atomicMax(status, TG_BOX_TOOBIG);
     return;
   }
-  if (MODE != TG_BOXMODE_PROBE) {   // the integers of the box back to floating point (Inf / NaN operands: NaN)
-    for (int s2 = tid; s2 < nbox; s2 += NT)
-      buf0[s2] = nonfinite ? __longlong_as_double(0x7ff8000000000000ll)
-                           : tg_unfix(reinterpret_cast<const unsigned long long *>(buf0)[s2], fx);
+  if (MODE != TG_BOXMODE_PROBE && !fx.fp) {   // the integers of the box back to floating point
+    for (int s2 = tid; s2 < nbox; s2 += NT) buf0[s2] = tg_unfix(reinterpret_cast<const unsigned long long *>(buf0)[s2], fx);
     __syncthreads();
   }
 
@@ -1142,6 +1148,10 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
   }
   tg_box_args P;
   memset(&P, 0, sizeof(P));
+  {
+    const char *am = getenv("TIGAR_PTAP_ACCUM");
+    P.accum_mode = am && !strcmp(am, "int") ? 1 : am && !strcmp(am, "float") ? 2 : 0;
+  }
   P.rowptr = cur->rowptr;
   P.rowcnt = cur->rowcnt;
   P.rowptr_val = cur->rowptr_val;
