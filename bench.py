@@ -482,6 +482,9 @@ def main():
     ap.add_argument("--cpu-nel", type=int, default=0)
     ap.add_argument("--slab", type=int, default=-1, help="1: force the implicit-M / z-slab streaming path on one GPU")
     ap.add_argument("--solver", default="auto", help="cg | gmres | lu (auto: cg; cfg4 lu as demos/biharmonic; cfg5 gmres)")
+    ap.add_argument("--live-traffic", type=int, default=-1,
+                    help="1 / 0: measure the HBM traffic of the product kernel with rocprofv3 --pmc in a child run of this "
+                         "command (default: when N = 1, the headline workload, rocprofv3 present and no profiler around this run)")
     ap.add_argument("--companion", type=int, default=1,
                     help="1: after the timed loop run one more step with the FE matrix' pattern verified entry by entry")
     args = ap.parse_args()
@@ -506,6 +509,29 @@ def main():
         p = args.p
     if args.d:
         d = args.d
+    # HBM traffic of the product kernel, LIVE: two child runs of this very command (one step after one warm-up) under
+    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no trace domains besides --kernel-trace, reads x2
+    # on gfx950: tools/pmc_hbm.py) BEFORE this process touches the GPU (afterwards its own 150 GB leave a child no room).
+    # Bounded (300 s), optional, never allowed to break the line; evaluated after the timed run.
+    pmc_rows = None
+    live = args.live_traffic
+    if live < 0:
+        import shutil
+        profiled = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        live = int(wl == "cfg3" and world == 1 and args.gpus == 1 and not args.nel and not args.p and not args.d and
+                   shutil.which("rocprofv3") is not None and not profiled)
+    if live and world == 1 and args.gpus == 1:
+        import subprocess, tempfile
+        dst = os.path.join(tempfile.mkdtemp(prefix="tigar_pmc_", dir="/tmp"), "pmc.json")
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "pmc_hbm.py"), dst, "--", sys.executable, os.path.abspath(__file__),
+               "--workload", wl, "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--companion", "0", "--live-traffic", "0",
+               "--rtol", repr(args.rtol), "--solver", args.solver, "--check", "0"]
+        try:
+            env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCPROF", "ROCP_"))}
+            subprocess.run(cmd, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, check=False)
+            pmc_rows = json.load(open(dst))["kernels"]
+        except Exception as e:                          # noqa: BLE001
+            log("[bench] live PMC pass skipped: %s" % (e,))
     res = run(args, wl, d, p, nel)
     if rank != 0:
         return
@@ -538,6 +564,17 @@ def main():
                                "correction + WRITE_SIZE, separate passes; not measured in this run)")
         except Exception:
             traffic = None
+    if pmc_rows:                                     # the live passes taken before the run (see above)
+        rows = [r for r in pmc_rows if r["kernel"].startswith(kernel)]
+        solves = 2                                      # (the child: one warm-up + one step)
+        gated = 2 * solves if res["method"] == "cg" else 0     # products enqueued past convergence return at once
+        if rows and rows[0]["launches"] > gated:
+            n_real = rows[0]["launches"] - gated
+            live_traffic = (rows[0]["hbm_read_GB_total_corrected"] + rows[0]["hbm_write_GB_total"]) * 1e9 / n_real
+            if 0.5 * fmt_bytes < live_traffic < 4.0 * fmt_bytes:      # (a sane count: else the offline figure stays)
+                traffic = live_traffic
+                traffic_src = ("live: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE in two child runs of this command "
+                               "before the timed run (tools/pmc_hbm.py), %d launches that moved data" % n_real)
     par = "z-slab x%d ranks on %d GPU%s (%s)" % (res["comm_world"], n_gpus, "s" if n_gpus > 1 else "", res["comm_kind"]) \
         if res["comm_world"] > 1 else "1 GPU"
     step_s = res["elapsed"] / args.steps
