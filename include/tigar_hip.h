@@ -62,6 +62,8 @@ int tg_prof_get(int slot, double *total_ms, int64_t *count);
 
 /* ---- vectors ------------------------------------------------------------------ */
 int tg_vec_create(int64_t n, tg_vec_t *out);               /* zero-initialised */
+int tg_vec_create_uninit(int64_t n, tg_vec_t *out);        /* contents undefined: for outputs a kernel overwrites entirely
+                                                              (PETSc's VecDuplicate leaves the values unset as well) */
 int tg_vec_destroy(tg_vec_t v);
 int tg_vec_size(tg_vec_t v, int64_t *n);
 int tg_vec_upload(tg_vec_t v, const double *host, int64_t n);

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "tg_prof_reset": (C.c_int, []),
     "tg_prof_get": (C.c_int, [C.c_int, c_f64p, c_i64p]),
     "tg_vec_create": (C.c_int, [C.c_int64, C.POINTER(handle)]),
+    "tg_vec_create_uninit": (C.c_int, [C.c_int64, C.POINTER(handle)]),
     "tg_vec_destroy": (C.c_int, [handle]),
     "tg_vec_size": (C.c_int, [handle, c_i64p]),
     "tg_vec_upload": (C.c_int, [handle, c_f64p, C.c_int64]),

@@ -458,6 +458,19 @@ extern "C" int tg_vec_create(int64_t n, tg_vec_t *out) {
   return 0;
 }
 
+extern "C" int tg_vec_create_uninit(int64_t n, tg_vec_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(n >= 0 && out, "bad arguments");
+  tg_vec_s *v = new tg_vec_s();
+  v->n = n;
+  if (tg_dmalloc(&v->d, n)) {
+    delete v;
+    return 1;
+  }
+  *out = v;
+  return 0;
+}
+
 extern "C" int tg_vec_destroy(tg_vec_t v) {
   if (!v) return 0;
   // (the block goes back to the pool and its re-use is ordered behind the work in flight; with two

@@ -34,7 +34,8 @@ def _p(a, t):
 class DeviceVector(object):
     """fp64 vector in HBM (stands in for dolfin PETScVector on this path)."""
 
-    def __init__(self, n=None, data=None, _handle=None):
+    def __init__(self, n=None, data=None, _handle=None, zero=True):
+        """``zero=False``: contents undefined (an output some kernel overwrites entirely; no fill pass)"""
         L = _lib.lib()
         self._h = handle()
         if _handle is not None:
@@ -43,7 +44,10 @@ class DeviceVector(object):
         if data is not None:
             data = _f64(data)
             n = data.shape[0]
-        check(L.tg_vec_create(int(n), C.byref(self._h)), "tg_vec_create")
+        if zero and data is None:
+            check(L.tg_vec_create(int(n), C.byref(self._h)), "tg_vec_create")
+        else:
+            check(L.tg_vec_create_uninit(int(n), C.byref(self._h)), "tg_vec_create_uninit")
         if data is not None:
             check(L.tg_vec_upload(self._h, _p(data, c_f64p), n), "tg_vec_upload")
 
@@ -722,7 +726,7 @@ def tensor_apply_1d(x, dims_in, k, F, col_shift=0, out=None):
     for j, n in enumerate(dims_in):
         n_out *= F.shape[0] if j == k else int(n)
     if out is None:
-        out = DeviceVector(n=n_out)
+        out = DeviceVector(n=n_out, zero=False)          # (every entry is written by the pass)
     elif out.size() != n_out:
         raise ValueError("tensor_apply_1d: output vector has %d entries, expected %d" % (out.size(), n_out))
     rp, ci, fv = _i32(F.indptr), _i32(F.indices), _f64(F.data)
@@ -739,7 +743,7 @@ def vec_tensor3(b1d, scale=1.0, row0=None, row1=None):
     total = int(np.prod(n))
     row0 = 0 if row0 is None else int(row0)
     row1 = total if row1 is None else int(row1)
-    out = DeviceVector(row1 - row0)
+    out = DeviceVector(row1 - row0, zero=False)          # (every entry is written)
     ptrs = (c_f64p * d)(*[_p(b, c_f64p) for b in bs])
     check(_lib.lib().tg_vec_tensor3(out._h, d, ptrs, _p(n, c_i64p), float(scale), row0, row1), "tg_vec_tensor3")
     return out
