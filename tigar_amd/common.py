@@ -682,8 +682,16 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
         key = (id(basis), id(grid))
         if key not in cache:
             from .kronptap import KronExtraction
+            # the fields of an equal-order spline (and its control field) sit on node grids of equal content: one set of
+            # 1-D tables serves them all (each KronExtraction evaluates the basis at every node of every direction)
+            twin = None
+            for (kx2, b2, g2) in cache.values():
+                if kx2 is not None and b2 is basis and g2.degree == grid.degree and bool(g2.dg) == bool(grid.dg) and \
+                        len(g2.axes) == len(grid.axes) and all(numpy.array_equal(a, b) for a, b in zip(g2.axes, grid.axes)):
+                    twin = kx2
+                    break
             try:
-                cache[key] = (KronExtraction(basis, grid), basis, grid)     # (the objects are kept alive with the key)
+                cache[key] = (twin if twin is not None else KronExtraction(basis, grid), basis, grid)   # (objects kept alive with the key)
             except Exception:
                 cache[key] = (None, basis, grid)
         return cache[key][0]
