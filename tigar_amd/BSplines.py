@@ -155,9 +155,20 @@ class BSpline1(object):
 
 
 class _IndexList(list):
-    """a list of dof indices that keeps the numpy array it came from (``.array``); any mutation through the list
-    interface is not tracked, so consumers compare lengths before trusting the array"""
+    """a list of dof indices that keeps the numpy array it came from (``.array``); every mutation through the list
+    interface drops the array, so a consumer may trust ``.array`` while it is there (no pass over the entries)"""
     array = None
+
+    def _dropped(name):                                    # noqa: N805
+        def method(self, *a, **k):
+            self.array = None
+            return getattr(list, name)(self, *a, **k)
+        method.__name__ = name
+        return method
+    for _n in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "extend", "insert", "pop", "remove",
+               "reverse", "sort", "clear"):
+        locals()[_n] = _dropped(_n)
+    del _n, _dropped
 
 
 def ij2dof(i, j, M):

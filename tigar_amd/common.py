@@ -398,13 +398,12 @@ class AbstractExtractionGenerator(object):
 
     @staticmethod
     def _index_array(dofs):
+        # a list made by getSideDofs carries its numpy twin until the list is edited (every mutating method of the list
+        # drops it): no pass over 67 000 Python integers per face at 256^3
         src = getattr(dofs, "array", None)
-        arr = numpy.asarray(dofs, dtype=numpy.int64).reshape(-1)
-        # a list made by getSideDofs carries its numpy twin; it is trusted only while the list still says the same
-        # (a list edited in place with its length kept -- dofs[i] = ..., sort(), reverse() -- must win)
-        if src is not None and len(src) == arr.size and numpy.array_equal(src, arr):
+        if src is not None and type(dofs).__name__ == "_IndexList" and len(src) == len(dofs):
             return src
-        return arr
+        return numpy.asarray(dofs, dtype=numpy.int64).reshape(-1)
 
     def addZeroDofsGlobal(self, newDofs):
         self.__dict__.setdefault("_zero_chunks", []).append(numpy.array(self._index_array(newDofs), dtype=numpy.int64))
