@@ -47,3 +47,23 @@ def test_product_bspline1_bookkeeping_bit_exact():
         assert np.array_equal(s.ghostKnots, g[pre + "ghostKnots"])
         assert int(s.isDiscontinuous()) == int(g[pre + "disc"])
         assert np.array_equal(np.array([s.greville(i) for i in range(s.ncp)]), g[pre + "greville"])
+
+
+def test_multi_patch_side_dofs_and_mesh_file_name():
+    """``MultiBSpline.getPatchSideDofs`` (tIGAr/BSplines.py:898-908): the side dofs of one patch in the global numbering,
+    in the order of ``BSpline.getSideDofs``; ``generateMeshXMLFileName`` (tIGAr/common.py:88-93): the md5 name the
+    reference derives from the communicator and the rank."""
+    import hashlib
+    from tigar_amd import BSplines as B, common as tc
+    patches = [B.BSpline([2, 2], [B.uniformKnots(2, 0., 3., 3), B.uniformKnots(2, 0., 1., 2)]),
+               B.BSpline([2, 3], [B.uniformKnots(2, -1., 1., 2), B.uniformKnots(3, 0., 2., 3)])]
+    mb = B.MultiBSpline(patches)
+    for patch in (0, 1):
+        for direction in (0, 1):
+            for side in (0, 1):
+                for layers in (1, 2):
+                    want = [mb.globalDofIndex(d, patch) for d in mb.splines[patch].getSideDofs(direction, side, layers)]
+                    assert mb.getPatchSideDofs(patch, direction, side, layers) == want
+    assert mb.getPatchSideDofs(1, 0, 0)[0] == patches[0].getNcp()          # patch 1 starts after patch 0's functions
+    name = tc.generateMeshXMLFileName(tc.worldcomm)
+    assert name == "mesh-" + hashlib.md5((repr(tc.worldcomm) + repr(tc.worldcomm.rank)).encode("utf-8")).hexdigest() + ".xml"

@@ -374,6 +374,11 @@ class MultiBSpline(AbstractScalarBasis):
     def globalDofIndex(self, localDofIndex, patchIndex):
         return localDofIndex + self.doffsets[patchIndex]
 
+    def getPatchSideDofs(self, patch, direction, side, nLayers=1):
+        """``BSpline.getSideDofs`` of patch ``patch``, in the global numbering (tIGAr/BSplines.py:898-908)."""
+        local = self.splines[patch].getSideDofsArray(direction, side, nLayers)
+        return (local + int(self.doffsets[patch])).tolist()
+
     def localParametricCoordinates(self, xi, patchIndex):
         shift = numpy.zeros(len(xi))
         shift[0] = self.PATCH_PITCH * float(patchIndex)

@@ -85,6 +85,14 @@ FORM_MT = True
 DOLFIN_EPS = 3.0e-16
 
 
+def generateMeshXMLFileName(comm):
+    """name of the scratch mesh file of a communicator / rank pair (tIGAr/common.py:88-93; the product writes no such
+    file -- the node grids are never serialised as XML -- but scripts that clean up after the reference call this)"""
+    import hashlib
+    s = repr(comm) + repr(getattr(comm, "rank", 0))
+    return "mesh-" + str(hashlib.md5(s.encode("utf-8")).hexdigest()) + ".xml"
+
+
 def near(a, b, eps=DOLFIN_EPS):
     """dolfin.near: |a-b| <= eps."""
     return abs(a - b) <= eps
