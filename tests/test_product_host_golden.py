@@ -67,3 +67,24 @@ def test_multi_patch_side_dofs_and_mesh_file_name():
     assert mb.getPatchSideDofs(1, 0, 0)[0] == patches[0].getNcp()          # patch 1 starts after patch 0's functions
     name = tc.generateMeshXMLFileName(tc.worldcomm)
     assert name == "mesh-" + hashlib.md5((repr(tc.worldcomm) + repr(tc.worldcomm.rank)).encode("utf-8")).hexdigest() + ".xml"
+
+
+def test_side_dof_lists_drop_their_array_when_edited():
+    """``getSideDofs`` returns a list (the reference's type) that carries the numpy array it came from, so that
+    ``addZeroDofs`` needs no pass over 67 000 Python integers per face; any edit through the list interface drops the
+    array and the list's own content is what counts."""
+    from tigar_amd import BSplines as B
+    from tigar_amd.common import AbstractExtractionGenerator as G
+    s = B.BSpline([2, 2], [B.uniformKnots(2, 0., 1., 4)] * 2)
+    dofs = s.getSideDofs(0, 0)
+    assert isinstance(dofs, list) and dofs.array is not None and G._index_array(dofs) is dofs.array
+    edits = [lambda d: d.sort(reverse=True), lambda d: d.reverse(), lambda d: d.__setitem__(0, 99), lambda d: d.append(7),
+             lambda d: d.extend([1, 2]), lambda d: d.pop(), lambda d: d.remove(d[1]), lambda d: d.insert(0, 5),
+             lambda d: d.__delitem__(0), lambda d: d.clear(), lambda d: d.__iadd__([3])]
+    for edit in edits:
+        d = s.getSideDofs(1, 1)
+        edit(d)
+        assert d.array is None
+        assert np.array_equal(G._index_array(d), np.asarray(list(d), dtype=np.int64))
+    d = s.getSideDofs(1, 0)
+    assert type(d + [1]) is list and type(d[1:3]) is list and d.array is not None      # copies are plain lists
