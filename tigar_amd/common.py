@@ -1360,7 +1360,10 @@ class ExtractedSpline(object):
         The symbolic plan is cached and reused while A's pattern is unchanged."""
         from .implicit import LazyFEMatrix
         zd = self.zeroDofs if applyBCs else None
-        if isinstance(A, LazyFEMatrix) or self._distributed():
+        if isinstance(A, LazyFEMatrix) or self._distributed() or (self._implicit() and self.nFields > 1):
+            # (several fields with an implicit operator, also on one rank: the field-block engine and its plane-wise
+            #  numbering -- the same guard as extractVector / solveLinearSystem, so that K, M^T b and U share it;
+            #  an explicit A -- FEtoIGA's identity, an uploaded matrix -- is cut into the blocks the engine asks for)
             a_fac = None
             if self.nFields > 1 and self._kron is None and getattr(self, "_kron_scalar", None) is not None:
                 return self._slab_path().assemble_matrix(self._block_producer(A), zd, float(diag),
@@ -1549,9 +1552,14 @@ class ExtractedSpline(object):
         tight tolerance beyond, with a message that says so."""
         MTU = DeviceVector(MTAM.shape[0])          # (local rows of MTAM: all of them on one rank)
         solver = self.linearSolver if self.linearSolver is not None else _default_linear_solver()
-        if getattr(solver, "parameters", {}).get("nonzero_initial_guess", False) and not self._distributed():
-            # the reference sizes AND seeds MTU = M^T u.vector() (tIGAr/common.py:1250-1254): a guess set in u is used
-            self.M.mult_transpose(_as_device_vector(u), MTU)
+        if getattr(solver, "parameters", {}).get("nonzero_initial_guess", False):
+            # the reference sizes AND seeds MTU = M^T u.vector() (tIGAr/common.py:1250-1254): a guess set in u is used.
+            # Distributed or several implicit fields: through the slab engine, which gives the rank's rows of M^T u in
+            # the numbering K and M^T b carry
+            if self._distributed() or (self._implicit() and self.nFields > 1):
+                MTU = self._initial_guess_through_slabs(u)
+            else:
+                self.M.mult_transpose(_as_device_vector(u), MTU)
         if self._distributed() and getattr(solver, "comm", False) is None:
             solver.comm = self.comm.device()
         solver.solve(MTAM, MTU, MTb)
@@ -1563,6 +1571,29 @@ class ExtractedSpline(object):
         else:
             self.M.mult(MTU, _as_device_vector(u))
         return MTU
+
+    def _initial_guess_through_slabs(self, u):
+        """The rank's rows of M^T u for a guess set in ``u`` (a replicated FE vector, or a Function that holds the rank's
+        own FE rows ``u.local_range`` as solveLinearSystem leaves it: rows outside count as zero)"""
+        vec = _as_device_vector(u)
+        rng = getattr(u, "local_range", None)
+        n = self.V.dim()
+        if rng is None or vec.size() == n:
+            full = vec
+        else:
+            full = DeviceVector(n)
+            full.fill(0.0)
+            ranges = [rng] if numpy.isscalar(rng[0]) else list(rng)
+            off = 0
+            for (a, b) in ranges:
+                _dev.vec_copy_range(full, int(a), vec, off, int(b) - int(a))
+                off += int(b) - int(a)
+
+        def rows(r0, r1):
+            piece = DeviceVector(r1 - r0)
+            _dev.vec_copy_range(piece, 0, full, r0, r1 - r0)
+            return piece
+        return self._slab_path().assemble_vector(rows, None)
 
     def solveLinearVariationalProblem(self, residualForm, u, applyBCs=True):
         """``residualForm`` must be an ``Equation``-like object with ``.lhs`` / ``.rhs``

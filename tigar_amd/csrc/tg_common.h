@@ -160,6 +160,22 @@ static inline uint64_t tg_pattern_hash(int d, const int64_t *nrows, const int64_
   return h ? h : 1;
 }
 
+// wave-per-row Gustavson PtAP (tg_ptap_wave.hip): table sizes / lane groups of the two stages and, after the first numeric
+// pass, the row pointer of K
+struct tg_gw_plan {
+  bool usable = false;
+  int ts_am = 0, ts_k = 0;        // slots of a wave's table: rows of A M / rows of K
+  int lg_m = 6, lg_am = 6;        // log2 of the lanes that walk one operand row: rows of M / rows of A M
+  int max_am = 0, max_k = 0;
+  double mean_am = 0.0, mean_k = 0.0;
+  int64_t *k_rowptr = nullptr;    // device, nrows + 1 (valid when k_nnz >= 0)
+  int64_t k_nnz = -1;
+};
+int tg_ptap_wave_plan(tg_csr_s *a, tg_csr_s *m, int64_t m_row0, tg_csr_s *mt, int max_k, double mean_k, tg_gw_plan *plan);
+void tg_ptap_wave_plan_free(tg_gw_plan *plan);
+int tg_ptap_wave_numeric(tg_gw_plan *plan, tg_csr_s *a, int64_t a_row0, tg_csr_s *m, int64_t m_row0, tg_csr_s *mt,
+                         int64_t mt_row0, const uint8_t *mask, double diag, tg_csr_s **k_out);
+
 int tg_sell_plan(tg_csr_s *a);          // tg_sell.hip
 void tg_sell_drop(tg_csr_s *a);
 void tg_sell_cache_clear(void);

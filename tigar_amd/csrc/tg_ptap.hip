@@ -33,6 +33,7 @@ struct tg_ptap_s {
   int ts1 = 0, ts2 = 0, g1 = 0, g2 = 0;
   int max_t = 0, max_k = 0;
   double mean_k = 0.0;
+  tg_gw_plan wave;          // the wave-per-row kernels (tg_ptap_wave.hip) take the product when their tables fit
 };
 
 struct tg_ptap_args {
@@ -503,6 +504,11 @@ static void tg_fill_args(tg_ptap_args &P, tg_csr_s *a, int64_t a_row0, tg_csr_s 
   P.accum_mode = am && !strcmp(am, "int") ? 1 : am && !strcmp(am, "float") ? 2 : 0;
 }
 
+static int P_accum_mode_env() {
+  const char *am = getenv("TIGAR_PTAP_ACCUM");
+  return am && !strcmp(am, "int") ? 1 : am && !strcmp(am, "float") ? 2 : 0;
+}
+
 static int tg_status_error(int st) {
   if (st == TG_PTAP_RANGE) {
     tg_set_error("PtAP: a row block does not cover the rows referenced (slab halo too small)");
@@ -603,6 +609,7 @@ extern "C" int tg_ptap_symbolic(tg_csr_t a, int64_t a_row0, tg_csr_t m, int64_t 
       if (small < plan->ts1 && waves(plan->ts1) < 24 && waves(small) > waves(plan->ts1)) plan->ts1 = small;
     }
   }
+  if (!rc && plan->nrows > 0) rc = tg_ptap_wave_plan(a, m, m_row0, mt, plan->max_k, plan->mean_k, &plan->wave);
   if (rc) {
     delete plan;
     return rc;
@@ -622,6 +629,19 @@ extern "C" int tg_ptap_numeric(tg_ptap_t plan, tg_csr_t a, tg_csr_t m, tg_csr_t 
   uint8_t *mask = nullptr;
   if (nzero > 0) TG_TRY(tg_build_dof_mask(zero_dofs, nzero, plan->ncols, &mask));
   tg_csr_s *k = nullptr;
+  // (TIGAR_PTAP_ACCUM=int asks for the integer grid of the workgroup kernel: the wave kernels add floating-point numbers)
+  if (plan->wave.usable && plan->nrows > 0 && P_accum_mode_env() != 1) {
+    // two Gustavson products, one wave per row (tg_ptap_wave.hip); 100 = declined, the workgroup kernel below takes over
+    rc = tg_ptap_wave_numeric(&plan->wave, a, plan->a_row0, m, plan->m_row0, mt, plan->mt_row0, mask, diag, &k);
+    if (rc != 100) {
+      tg_dfree(mask);
+      if (!rc) *k_out = k;
+      return rc;
+    }
+    plan->wave.usable = false;
+    rc = 0;
+    k = nullptr;
+  }
   int *status = (int *)g_tg.scratch;
   tg_ptap_args P;
   tg_fill_args(P, a, plan->a_row0, m, plan->m_row0, mt, plan->mt_row0);
@@ -771,6 +791,7 @@ extern "C" int tg_ptap_destroy(tg_ptap_t plan) {
   if (!plan) return 0;
   if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
   tg_dfree(plan->rowptr);
+  tg_ptap_wave_plan_free(&plan->wave);
   delete plan;
   return 0;
 }

@@ -1,0 +1,849 @@
+// extractMatrix for arbitrary sparse operands, second generation (round 4): K = M^T (A M) as TWO row-wise Gustavson
+// products (PETSc's MatPtAP does the same two-step product [ext]; tIGAr/common.py:1194-1195), one WAVE per output row.
+//
+//   stage 1:  (A M)_r = sum_s  A[r,s]    * M[s,:]        r = FE rows of the block        (intermediate, in HBM)
+//   stage 2:  K_i     = sum_r  M^T[i,r]  * (A M)[r,:]    i = dofs of the block
+//
+// Why not the fused workgroup-per-row kernel of tg_ptap.hip (round 1-3): its first table holds a row of M^T A -- (3p+1)^d
+// keys, 50-100 KB of LDS -- so a CU holds one workgroup, the barriers between the staging and the hashing phases and the
+// dependent chain global load -> hash -> LDS read -> LDS atomic are exposed (SQ counters at 48^3 p=3: 70 % of the wave
+// cycles waiting, vector ALU 23 % busy, 66 vector instructions per 64 accumulations), and since the waves of a workgroup add
+// into one table in an order that differs from run to run it needs integer accumulation to be reproducible.  Here a row
+// of either product is small (<= a few hundred keys): the table is PRIVATE to a wave (3-12 KB), a CU holds 13-32 waves
+// that never synchronise, the LDS operations of one wave execute in program order and the lanes of one instruction carry
+// distinct keys, so plain floating-point ds_add_f64 gives the same bits on every run -- no integer grid, no scale rule.
+// One templated row routine serves both stages (outer row -> operand rows -> hash accumulate).
+//
+// Lanes: groups of G = 2^LG lanes walk one operand row (G chosen from the mean operand row length), U operand rows are
+// in flight per group before the table is touched.  The intermediate is written in the loose-row form (space reserved with
+// one atomic per row, (start, count) per row); K's rows are rank-sorted, MatZeroRowsColumns applied on the way, and go to
+// their CSR place directly when the plan knows the row pointer (second call with the same pattern) or through a
+// reserve-scan-reorder pass otherwise.
+#include "tg_common.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+
+enum { GW_COUNT = 0, GW_BUMP = 1, GW_PLACED = 2 };
+enum { GW_OK = 0, GW_OVF = 1, GW_RANGE = 3, GW_CAP = 4 };
+
+struct gw_args {
+  // outer matrix X (canonical CSR block): row x gives (operand row index, weight) pairs
+  const int64_t *x_rowptr;
+  const int32_t *x_col;
+  const double *x_val;
+  int64_t x_nrows;
+  int64_t row_stride;   // probing: row = index * row_stride
+  // operand matrix Y: row (x_col - y_row0) occupies y_col / y_val [y_start[r], y_start[r] + len), len = y_cnt[r] (loose
+  // rows) or y_start[r+1] - y_start[r] (canonical CSR, y_cnt == nullptr)
+  // The columns of Y come MIXED (gw_mix: a bijection of the 32-bit column index whose bit fields are the two slots of the
+  // cuckoo tables): every entry of an operand matrix is looked up ~100 times, its hash is computed once (k_gw_mix for M,
+  // the first stage writes the intermediate's columns mixed); only the rows of K turn them back (gw_unmix).
+  const int64_t *y_start;
+  const int32_t *y_cnt;
+  const uint32_t *y_mix;
+  const double *y_val;
+  int64_t y_row0, y_nrows;
+  int ts, lgts;         // slots of a wave's table (power of two)
+  int rows_per_wave;
+  // order in which the rows are handed to the waves (scheduling only, the result does not depend on it): n0 > 0 = the rows
+  // are the points of an n0 x n1 x (x_nrows / n0 n1) lattice, direction 0 fastest, and are visited tile by tile
+  // (t0 x t1 x t2 points) so that the rows in flight on an XCD share their operand rows through its L2
+  int64_t n0, n1;
+  int t0, t1, t2;
+  int debug;
+  // where a row of the temporary goes (BUMP): out_stride > 0 = row li at li * out_stride (its length must not exceed the
+  // stride), 0 = space reserved with an atomic on one counter.  One atomic per row on ONE address is a serial resource
+  // of its own: 12 ns each -- 87 ms for the 7.2 M rows of A M at 64^3 elements, as long as the whole product took.
+  int64_t out_stride;
+};
+
+// index in tile-major order -> lattice point -> row (tiles clipped at the lattice's far faces)
+__device__ __forceinline__ int64_t gw_tile_row(const gw_args &P, int64_t idx) {
+  const int64_t n0 = P.n0, n1 = P.n1, n2 = P.x_nrows / (n0 * n1);
+  const int64_t slab = (int64_t)P.t2 * n0 * n1;
+  const int64_t tz = idx / slab;
+  int64_t rem = idx - tz * slab;
+  const int64_t h = min((int64_t)P.t2, n2 - tz * P.t2);
+  const int64_t strip = (int64_t)P.t1 * n0 * h;
+  const int64_t ty = rem / strip;
+  rem -= ty * strip;
+  const int64_t w1 = min((int64_t)P.t1, n1 - ty * P.t1);
+  const int64_t blk = (int64_t)P.t0 * w1 * h;
+  const int64_t tx = rem / blk;
+  rem -= tx * blk;
+  const int64_t w0 = min((int64_t)P.t0, n0 - tx * P.t0);
+  const int64_t lz = rem / (w0 * w1);
+  rem -= lz * w0 * w1;
+  const int64_t ly = rem / w0, lx = rem - ly * w0;
+  return (tx * P.t0 + lx) + n0 * ((ty * P.t1 + ly) + n1 * (tz * P.t2 + lz));
+}
+
+// LDS of one wave: ts slots of 8 bytes, ts / 2 accumulators of 8 bytes, ts / 2 keys of 4 bytes
+__host__ __device__ static inline size_t gw_wave_bytes(int ts) { return (size_t)ts * 8 + (size_t)(ts >> 1) * 12; }
+
+__device__ __forceinline__ int64_t gw_readlane_i64(int64_t v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), l);
+  return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double gw_readlane_f64(double v, int l) {
+  return __longlong_as_double(gw_readlane_i64(__double_as_longlong(v), l));
+}
+
+// ---- a wave's accumulator table.  Cuckoo hashing with two slots per key: a key lives at T[h1(key)] or T[half + h2(key)],
+// nowhere else, so a lookup is two LDS reads and two compares -- no probe loop, whatever the load.  (Linear probing was
+// measured first: at any load factor a group of 4 x 64 keys holds a displaced one, every group took the probe loop, and a
+// batch cost 330 cycles per SIMD instead of the ~90 its instructions need.)  A slot holds (key, id) as one 64-bit word,
+// id = position of the key's accumulator in the dense arrays vals[] / kid[]: evictions move the pair with one ds_wrxchg_rtn_b64
+// and the values never move; the finished row is kid[0..n) / vals[0..n) without a scan of the table.
+struct gw_tab {
+  unsigned long long *T;   // ts slots: [0, half) first choice, [half, ts) second choice; all ones = empty
+  double *vals;            // cap accumulators
+  uint32_t *kid;           // cap keys (mixed, before any re-seeding), in order of first touch
+  int half, lgh, cap;
+  unsigned seed;
+};
+#define GW_EMPTY 0xFFFFFFFFFFFFFFFFull
+// operand rows in flight per lane group before the table is touched.  The waves are bound by the latency of their operand
+// loads (2 us per group under load), and the tables limit the waves per SIMD (5 with the tables of A M, 2-3 with those of
+// K at p = 3): the loads in flight have to come from the depth of a wave's own queue.
+#ifndef GW_U1
+#define GW_U1 4
+#endif
+#ifndef GW_U2
+#define GW_U2 8
+#endif
+#define GW_U(FINAL) ((FINAL) ? GW_U2 : GW_U1)
+#define GW_MAXIT 48
+
+// Both slots of a key come out of ONE mixed word (two 32-bit multiplies with an xor-shift in between, murmur's finaliser).
+// A multiplicative hash alone will not do: the columns of a row are lattice points c0 + dx + n0 dy + n0 n1 dz, a linear hash
+// collides as a function of the DIFFERENCE of two keys, so a difference that collides in both tables puts whole chains of
+// keys onto the same two slots -- in every row of the matrix alike (measured: 512 slots fail for the 125 columns of a row of
+// A M at p = 3, 1024 do not).  The mix is a bijection (odd multipliers, xor-shifts): the tables store and compare the mixed
+// word itself, gw_unmix gives the column back.
+__host__ __device__ __forceinline__ unsigned gw_mix(unsigned key) {
+  unsigned m = key * 0x9E3779B1u;
+  m ^= m >> 15;
+  m *= 0x85EBCA77u;
+  m ^= m >> 13;
+  return m;
+}
+__host__ __device__ __forceinline__ unsigned gw_unmix(unsigned m) {
+  m ^= m >> 13;
+  m ^= m >> 26;
+  m *= 0xB6C92F47u;        // inverse of 0x85EBCA77 mod 2^32
+  m ^= m >> 15;
+  m ^= m >> 30;
+  return m * 0x0E8B2F51u;  // inverse of 0x9E3779B1
+}
+// a row that does not settle with the plain mix is started over with the keys permuted once more (rare: uniform branch)
+template <bool SEEDED>
+__device__ __forceinline__ unsigned gw_reseed(unsigned m, unsigned seed) {
+  if (!SEEDED) return m;
+  m = (m ^ seed) * 0xC2B2AE35u;
+  return m ^ (m >> 16);
+}
+__device__ __forceinline__ unsigned gw_s1(unsigned m, int lgh) { return m >> (32 - lgh); }
+__device__ __forceinline__ unsigned gw_s2(unsigned m, int lgh, int half) { return (unsigned)half + ((m >> (32 - 2 * lgh)) & (unsigned)(half - 1)); }
+// (an empty slot is all ones: if it matches a key that happens to be 0xFFFFFFFF the id comes out negative = not found)
+__device__ __forceinline__ int gw_find(unsigned long long e1, unsigned long long e2, unsigned key) {
+  return ((unsigned)e1 == key) ? (int)(e1 >> 32) : ((unsigned)e2 == key) ? (int)(e2 >> 32) : -1;
+}
+
+// the lanes with `pend` carry keys that the group's fast round did not find: look again (an earlier batch of the group
+// may have brought the key in), insert what is still missing, add.  Lanes of one lane group carry distinct keys; with
+// several groups per instruction (LG < 6) the groups take turns.  Returns false when the table is full / a chain does
+// not end (the host retries with a larger table).
+template <int LG, bool SEEDED>
+__device__ __forceinline__ bool gw_insert_new(const gw_tab &t, int &n, unsigned m0, double v, bool pend) {
+  constexpr int NG = 64 >> LG;
+  const int lane = threadIdx.x & 63, grp = lane >> LG;
+  const unsigned key = gw_reseed<SEEDED>(m0, t.seed);
+  const unsigned s1 = gw_s1(key, t.lgh), s2 = gw_s2(key, t.lgh, t.half);
+  for (int g = 0; g < NG; g++) {
+    const bool mine = pend && (NG == 1 || grp == g);
+    if (!__any(mine)) continue;
+    int id = -1;
+    if (mine) id = gw_find(t.T[s1], t.T[s2], key);
+    const bool need = mine && id < 0;
+    const unsigned long long m = __ballot(need);
+    if (need) id = n + __popcll(m & ((1ull << lane) - 1ull));
+    n += __popcll(m);
+    if (n > t.cap) return false;                     // wave-uniform
+    bool active = need;
+    unsigned long long cur = ((unsigned long long)(unsigned)id << 32) | key;
+    unsigned slot = s1;
+    if (need) t.kid[id] = m0;                         // (vals[id] is zero since the row was started)
+    for (int it = 0; it < GW_MAXIT && __any(active); it++) {
+      if (active) {
+        const unsigned long long old = atomicExch(&t.T[slot], cur);
+        if (old == GW_EMPTY) {
+          active = false;
+        } else {                                      // evicted pair: on to its other slot
+          const unsigned a = gw_s1((unsigned)old, t.lgh);
+          slot = (slot == a) ? gw_s2((unsigned)old, t.lgh, t.half) : a;
+          cur = old;
+        }
+      }
+    }
+    if (__any(active)) return false;
+    if (mine) unsafeAtomicAdd(&t.vals[id], v);
+  }
+  return true;
+}
+
+// U keys per lane: the 2 U slots are read back to back, then matched; a key that is present -- the common case by a factor
+// of 50-300 -- costs two LDS reads, two compares and one ds_add_f64.
+template <int U, int LG, bool SEEDED>
+__device__ __forceinline__ bool gw_accum(const gw_tab &t, int &n, const unsigned *m0, const bool *valid, const double *v) {
+  unsigned long long e1[U], e2[U];
+  unsigned key[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    key[u] = gw_reseed<SEEDED>(m0[u], t.seed);
+    e1[u] = t.T[gw_s1(key[u], t.lgh)];
+    e2[u] = t.T[gw_s2(key[u], t.lgh, t.half)];
+  }
+  bool pending[U];
+  bool any_pending = false;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int id = gw_find(e1[u], e2[u], key[u]);
+    const bool hit = valid[u] && id >= 0;
+    if (hit) unsafeAtomicAdd(&t.vals[id], v[u]);
+    pending[u] = valid[u] && id < 0;
+    any_pending |= pending[u];
+  }
+  if (!__any(any_pending)) return true;
+  bool ok = true;
+#pragma unroll
+  for (int u = 0; u < U; u++)
+    if (__any(pending[u])) ok = ok && gw_insert_new<LG, SEEDED>(t, n, m0[u], v[u], pending[u]);
+  return ok;
+}
+
+// accumulates output row `xr` into the wave's table
+template <int LG, int U, bool SEEDED>
+__device__ __forceinline__ void gw_row(const gw_args &P, int64_t xr, const gw_tab &t, int &n, bool &ovf, bool &range) {
+  constexpr int G = 1 << LG, NG = 64 >> LG;
+  const int lane = threadIdx.x & 63, sub = lane & (G - 1), grp = lane >> LG;
+  // (the row is the wave's: bounds and counts are told to the compiler as scalars)
+  const int64_t e0 = gw_readlane_i64(P.x_rowptr[xr], 0), e1 = gw_readlane_i64(P.x_rowptr[xr + 1], 0);
+  for (int64_t c0 = e0; c0 < e1; c0 += 64) {
+    const int nb = __builtin_amdgcn_readfirstlane((int)min((int64_t)64, e1 - c0));
+    int64_t st = 0;
+    int ln = 0;
+    double w = 0.0;
+    if (lane < nb) {
+      const int64_t yr = (int64_t)P.x_col[c0 + lane] - P.y_row0;
+      w = P.x_val[c0 + lane];
+      if (yr < 0 || yr >= P.y_nrows) {
+        range = true;
+      } else {
+        st = P.y_start[yr];
+        ln = P.y_cnt ? P.y_cnt[yr] : (int)(P.y_start[yr + 1] - st);
+      }
+    }
+    for (int j = 0; j < nb; j += U * NG) {
+      unsigned m0[U];
+      bool valid[U];
+      double v[U];
+      int lnu[U];
+      int64_t stu[U];
+      double wu[U];
+      int longest = 0;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        // (every lane takes part in the cross-lane reads; what a lane beyond the chunk fetched is dropped afterwards)
+        int jj, lraw;
+        if (LG == 6) {
+          jj = j + u;                                   // wave-uniform: the row's start travels in scalar registers
+          const int src = min(jj, 63);
+          stu[u] = gw_readlane_i64(st, src);
+          lraw = __builtin_amdgcn_readlane(ln, src);
+          wu[u] = gw_readlane_f64(w, src);
+        } else {
+          jj = j + u * NG + grp;
+          const int src = min(jj, 63);
+          stu[u] = __shfl(st, src, 64);
+          lraw = __shfl(ln, src, 64);
+          wu[u] = __shfl(w, src, 64);
+        }
+        lnu[u] = jj < nb ? lraw : 0;
+        longest = max(longest, lnu[u]);
+        // unconditional loads, no clamp: a lane beyond the end of its row reads the entries that follow (the arrays are
+        // padded by TG_CSR_PAD) and is dropped by `valid`
+        const uint32_t *pm = P.y_mix + stu[u];
+        const double *pv = P.y_val + stu[u];
+        m0[u] = pm[sub];
+        v[u] = wu[u] * pv[sub];
+        valid[u] = sub < lnu[u];
+      }
+      if (!gw_accum<U, LG, SEEDED>(t, n, m0, valid, v)) ovf = true;
+      if (__any(longest > G)) {                         // operand rows longer than a lane group: the rest, one chunk at a time
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          for (int o = G + sub; __any(o - sub < lnu[u]); o += G) {
+            unsigned m1[1];
+            bool valid1[1];
+            double v1[1];
+            const int oc = min(o, max(lnu[u] - 1, 0));
+            m1[0] = P.y_mix[stu[u] + oc];
+            v1[0] = wu[u] * P.y_val[stu[u] + oc];
+            valid1[0] = o < lnu[u];
+            if (!gw_accum<1, LG, SEEDED>(t, n, m1, valid1, v1)) ovf = true;
+          }
+        }
+      }
+      if (ovf) return;                                  // (wave-uniform: the flags come out of ballots)
+    }
+  }
+}
+
+// mixed column indices of an operand matrix (one pass: 4 bytes read, 4 written per entry)
+__global__ void __launch_bounds__(256) k_gw_mix(const int32_t *__restrict__ col, int64_t n, uint32_t *__restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) out[q] = gw_mix((unsigned)col[q]);
+}
+
+// FINAL = false: rows of the intermediate in the loose-row form (out_off / out_cnt per row, entries in table order).
+// FINAL = true : rows of K, rank-sorted by column, MatZeroRowsColumns fused; BUMP reserves space in the temporary and records
+//                (row_cnt, row_off) for the scan + reorder pass, PLACED writes at row_off[li] and checks the length.
+// COUNT: nothing is written; maxima[0] = longest row, sum[0] += lengths (row sample of the plan).
+template <int MODE, bool FINAL, int LG>
+__global__ void __launch_bounds__(256)
+    k_gw(gw_args P, int64_t *__restrict__ out_off, int32_t *__restrict__ out_cnt, int64_t *__restrict__ row_cnt,
+         uint32_t *__restrict__ ocol, double *__restrict__ oval, unsigned long long *__restrict__ cursor, int64_t capacity,
+         const uint8_t *__restrict__ mask, double diag, int64_t out_row0, int *__restrict__ status,
+         int *__restrict__ maxima, unsigned long long *__restrict__ sum) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  gw_tab t;
+  t.half = P.ts >> 1;
+  t.lgh = P.lgts - 1;
+  t.cap = P.ts >> 1;
+  t.seed = 0u;
+  char *mine = smem + (size_t)wave * gw_wave_bytes(P.ts);
+  t.T = reinterpret_cast<unsigned long long *>(mine);
+  t.vals = reinterpret_cast<double *>(t.T + P.ts);
+  t.kid = reinterpret_cast<uint32_t *>(t.vals + t.cap);
+  const int64_t rpb = 4 * (int64_t)P.rows_per_wave;
+  const int64_t nblk = (P.x_nrows + rpb - 1) / rpb;
+  const int64_t L = tg_xcd_block(blockIdx.x, nblk);
+  if (L >= nblk) return;
+  bool ovf = false, range = false, cap = false;
+  for (int jr = 0; jr < P.rows_per_wave; jr++) {
+    const int64_t idx = L * rpb + 4 * (int64_t)jr + wave;     // the four waves of a workgroup work on neighbouring rows
+    if (idx >= P.x_nrows) break;
+    const int64_t li = P.n0 > 0 ? gw_tile_row(P, idx) : idx * P.row_stride;
+    // a row whose keys do not settle in the table (a cuckoo chain that does not end: ~1e-4 of the rows at a third of the
+    // slots in use) is started over with the keys permuted once more (every row begins with the plain mix)
+    int n = 0;
+    bool row_ovf = true;
+    for (int attempt = 0; attempt < 4 && row_ovf; attempt++) {
+      if (attempt) t.seed = t.seed * 0x2545F491u + 0x9E3779B9u;
+      for (int s = lane; s < P.ts; s += 64) t.T[s] = GW_EMPTY;
+      for (int s = lane; s < t.cap; s += 64) t.vals[s] = 0.0;
+      n = 0;
+      row_ovf = false;
+      if (attempt == 0)
+        gw_row<LG, GW_U(FINAL), false>(P, li, t, n, row_ovf, range);
+      else
+        gw_row<LG, GW_U(FINAL), true>(P, li, t, n, row_ovf, range);
+      if (n > t.cap) break;                    // more keys than accumulators: another seed does not help
+    }
+    if (row_ovf) {
+      ovf = true;
+      continue;
+    }
+    if (MODE == GW_COUNT) {
+      if (lane == 0) {
+        atomicMax(&maxima[0], n);
+        atomicAdd(sum, (unsigned long long)n);
+      }
+      continue;
+    }
+    // ---- where does the row go?
+    int64_t o0;
+    if (MODE == GW_PLACED) {
+      o0 = out_off[li];
+      if (out_off[li + 1] - o0 != n) {       // pattern changed since the plan was made
+        cap = true;
+        continue;
+      }
+    } else {
+      if (P.out_stride > 0) {
+        o0 = li * P.out_stride;
+        if (n > P.out_stride) {              // (the host doubles the stride)
+          cap = true;
+          if (lane == 0) atomicMax(&maxima[0], n);
+          continue;
+        }
+      } else {
+        unsigned long long o = 0;
+        if (lane == 0) o = atomicAdd(cursor, (unsigned long long)n);
+        o0 = gw_readlane_i64((int64_t)o, 0);
+      }
+      if (FINAL) {
+        if (lane == 0) {
+          row_cnt[li] = n;
+          out_off[li] = o0;
+        }
+      } else if (lane == 0) {
+        out_off[li] = o0;
+        out_cnt[li] = n;
+      }
+      if (o0 + n > capacity) {
+        cap = true;
+        continue;
+      }
+    }
+    if (!FINAL) {
+      for (int e = lane; e < n; e += 64) {            // (columns stay mixed: the second stage looks them up as they are)
+        ocol[o0 + e] = t.kid[e];
+        oval[o0 + e] = t.vals[e];
+      }
+    } else {
+      const int64_t gi = li + out_row0;       // global K row
+      const bool mrow = mask ? (mask[gi] != 0) : false;
+      for (int e = lane; e < n; e += 64) t.kid[e] = gw_unmix(t.kid[e]);      // back to column indices
+      for (int e = lane; e < n; e += 64) {
+        const int32_t key = (int32_t)t.kid[e];
+        int rank = 0;
+        for (int f = 0; f < n; f++) rank += ((int32_t)t.kid[f] < key) ? 1 : 0;
+        double x = t.vals[e];
+        if (mask && (mrow || mask[key])) x = (mrow && key == gi) ? diag : 0.0;
+        ocol[o0 + rank] = (uint32_t)key;
+        oval[o0 + rank] = x;
+      }
+    }
+  }
+  if (lane == 0) {
+    if (ovf) atomicMax(status, GW_OVF);
+    if (range) atomicMax(status, GW_RANGE);
+    if (cap) atomicMax(status, GW_CAP);
+  }
+}
+
+// copies reserved rows into CSR order: wave per row
+__global__ void __launch_bounds__(256)
+    k_gw_reorder(const int64_t *__restrict__ rowptr, const int64_t *__restrict__ tmp_off, const int32_t *__restrict__ tcol,
+                 const double *__restrict__ tval, int64_t nrows, int32_t *__restrict__ col, double *__restrict__ val) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    const int64_t dst = rowptr[r], n = rowptr[r + 1] - dst, src = tmp_off[r];
+    for (int64_t q = lane; q < n; q += 64) {
+      col[dst + q] = tcol[src + q];
+      val[dst + q] = tval[src + q];
+    }
+  }
+}
+
+static int gw_lg(int v) {
+  int l = 0;
+  while ((1 << l) < v) l++;
+  return l;
+}
+static int gw_pow2_ge(int64_t v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+// lanes per operand row from its mean length: the smallest power of two >= 0.75 * mean, in [8, 64]
+static int gw_lg_group(double mean) {
+  int g = 8;
+  while (g < 64 && g < 0.75 * mean) g <<= 1;
+  return gw_lg(g);
+}
+static int gw_env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+template <int MODE, bool FINAL>
+static void gw_launch(int lg, unsigned grid, size_t lds, const gw_args &P, int64_t *out_off, int32_t *out_cnt,
+                      int64_t *row_cnt, uint32_t *ocol, double *oval, unsigned long long *cursor, int64_t capacity,
+                      const uint8_t *mask, double diag, int64_t out_row0, int *status, unsigned long long *sum) {
+#define GW_GO(LGV)                                                                                                    \
+  hipLaunchKernelGGL((k_gw<MODE, FINAL, LGV>), dim3(grid), dim3(256), lds, g_tg.stream, P, out_off, out_cnt, row_cnt, \
+                     ocol, oval, cursor, capacity, mask, diag, out_row0, status, status + 1, sum)
+  switch (lg) {
+    case 3: GW_GO(3); break;
+    case 4: GW_GO(4); break;
+    case 5: GW_GO(5); break;
+    default: GW_GO(6); break;
+  }
+#undef GW_GO
+}
+
+static void gw_set_lds_limits() {
+  static bool done = false;
+  if (done) return;
+#define GW_LIM(MODE, FINAL, LGV) \
+  hipFuncSetAttribute((const void *)k_gw<MODE, FINAL, LGV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define GW_LIM4(MODE, FINAL) \
+  GW_LIM(MODE, FINAL, 3);    \
+  GW_LIM(MODE, FINAL, 4);    \
+  GW_LIM(MODE, FINAL, 5);    \
+  GW_LIM(MODE, FINAL, 6)
+  GW_LIM4(GW_COUNT, false);
+  GW_LIM4(GW_BUMP, false);
+  GW_LIM4(GW_BUMP, true);
+  GW_LIM4(GW_PLACED, true);
+#undef GW_LIM4
+#undef GW_LIM
+  done = true;
+}
+
+// lattice hint "n0,n1,t0,t1,t2" (experiments: TIGAR_PTAP_WAVE_TILE1 / _TILE2); ignored unless the rows are whole planes
+static void gw_tile_hint(gw_args &P, const char *env) {
+  P.n0 = P.n1 = 0;
+  P.t0 = P.t1 = P.t2 = 1;
+  const char *s = getenv(env);
+  long long n0 = 0, n1 = 0;
+  int t0 = 8, t1 = 8, t2 = 8;
+  if (!s || sscanf(s, "%lld,%lld,%d,%d,%d", &n0, &n1, &t0, &t1, &t2) < 2) return;
+  if (n0 <= 0 || n1 <= 0 || t0 <= 0 || t1 <= 0 || t2 <= 0 || P.x_nrows % (n0 * n1) != 0) return;
+  P.n0 = n0;
+  P.n1 = n1;
+  P.t0 = t0;
+  P.t1 = t1;
+  P.t2 = t2;
+}
+
+// mixed copy of a matrix' column indices (padded like the column array itself)
+static int gw_mix_columns(tg_csr_s *m, uint32_t **out) {
+  TG_TRY(tg_dmalloc(out, m->nnz + TG_CSR_PAD));
+  if (m->nnz > 0)
+    hipLaunchKernelGGL(k_gw_mix, dim3((unsigned)std::min<int64_t>(tg_cdiv(m->nnz, 256), (int64_t)g_tg.num_cu * 32)), dim3(256), 0,
+                       g_tg.stream, m->col, m->nnz, *out);
+  hipMemsetAsync(*out + m->nnz, 0, TG_CSR_PAD * sizeof(uint32_t), g_tg.stream);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+static void gw_fill_stage1(gw_args &P, tg_csr_s *a, tg_csr_s *m, const uint32_t *m_mix, int64_t m_row0) {
+  P.n0 = P.n1 = 0;
+  P.t0 = P.t1 = P.t2 = 1;
+  P.debug = getenv("TIGAR_PTAP_WAVE_DEBUG") ? atoi(getenv("TIGAR_PTAP_WAVE_DEBUG")) : 0;
+  P.out_stride = 0;
+  P.x_rowptr = a->rowptr;
+  P.x_col = a->col;
+  P.x_val = a->val;
+  P.x_nrows = a->nrows;
+  P.row_stride = 1;
+  P.y_start = m->rowptr;
+  P.y_cnt = nullptr;
+  P.y_mix = m_mix;
+  P.y_val = m->val;
+  P.y_row0 = m_row0;
+  P.y_nrows = m->nrows;
+}
+
+static unsigned gw_grid(int64_t nrows, int rows_per_wave) {
+  const int64_t nblk = tg_cdiv(std::max<int64_t>(nrows, 1), 4 * (int64_t)rows_per_wave);
+  return (unsigned)(tg_cdiv(nblk, 8) * 8);
+}
+
+// sizes the tables of stage 1 from a sample of A's rows; the tables of stage 2 come from the caller's probe of K's rows
+int tg_ptap_wave_plan(tg_csr_s *a, tg_csr_s *m, int64_t m_row0, tg_csr_s *mt, int max_k, double mean_k, tg_gw_plan *plan) {
+  plan->usable = false;
+  if (gw_env_int("TIGAR_PTAP_WAVE", 1) == 0) return 0;
+  if (a->nrows <= 0 || mt->nrows <= 0 || a->nnz <= 0 || m->nnz <= 0) return 0;
+  gw_set_lds_limits();
+  int *status = (int *)g_tg.scratch;           // [0] status, [1] maximum, [2..3] sum
+  unsigned long long *sum = (unsigned long long *)(status + 2);
+  uint32_t *m_mix = nullptr;
+  TG_TRY(gw_mix_columns(m, &m_mix));
+  gw_args S;
+  gw_fill_stage1(S, a, m, m_mix, m_row0);
+  const int64_t nsample = std::min<int64_t>(a->nrows, 4096);
+  S.x_nrows = nsample;
+  S.row_stride = std::max<int64_t>(1, a->nrows / nsample);
+  S.ts = 2048;                                 // 4 waves x 2048 x 14 B = 112 KB
+  S.lgts = 11;
+  S.rows_per_wave = 4;
+  plan->lg_m = gw_env_int("TIGAR_PTAP_WAVE_LG1", gw_lg_group((double)m->nnz / (double)std::max<int64_t>(m->nrows, 1)));
+  TG_CHECK_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int), g_tg.stream));
+  gw_launch<GW_COUNT, false>(plan->lg_m, gw_grid(nsample, S.rows_per_wave), 4 * gw_wave_bytes(S.ts), S, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, 0, nullptr, 0.0, 0, status, sum);
+  int h[4] = {0, 0, 0, 0};
+  const hipError_t e1 = hipGetLastError();
+  const hipError_t e2 = hipMemcpyAsync(h, status, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream);
+  const hipError_t e3 = hipStreamSynchronize(g_tg.stream);
+  tg_dfree(m_mix);
+  TG_CHECK_HIP(e1);
+  TG_CHECK_HIP(e2);
+  TG_CHECK_HIP(e3);
+  if (h[0] == GW_RANGE) {
+    tg_set_error("PtAP: a row block does not cover the rows referenced (slab halo too small)");
+    return 3;
+  }
+  if (getenv("TIGAR_PTAP_WAVE_DEBUG")) fprintf(stderr, "[gw] probe status %d max %d sum %d lg_m %d\n", h[0], h[1], h[2], plan->lg_m);
+  if (h[0] != GW_OK) return 0;                 // a row of A M fills the probe's table: the workgroup kernel's business
+  unsigned long long total;
+  memcpy(&total, &h[2], sizeof(total));
+  plan->max_am = h[1];
+  plan->mean_am = (double)total / (double)nsample;
+  plan->max_k = max_k;
+  plan->mean_k = mean_k;
+  const double load_inv = getenv("TIGAR_PTAP_WAVE_LOADINV") ? atof(getenv("TIGAR_PTAP_WAVE_LOADINV")) : 2.5;
+  plan->ts_am = std::max(64, gw_pow2_ge((int64_t)(plan->max_am * load_inv) + 4));
+  plan->ts_k = std::max(64, gw_pow2_ge((int64_t)(max_k * load_inv) + 4));
+  plan->lg_am = gw_env_int("TIGAR_PTAP_WAVE_LG2", gw_lg_group(plan->mean_am));
+  if (getenv("TIGAR_PTAP_WAVE_DEBUG"))
+    fprintf(stderr, "[gw] max_am %d mean_am %.1f max_k %d mean_k %.1f ts %d / %d lg %d / %d\n", plan->max_am, plan->mean_am, max_k,
+            mean_k, plan->ts_am, plan->ts_k, plan->lg_m, plan->lg_am);
+  // (the four tables of a workgroup have to fit the 160 KB of a CU: 2048 slots each)
+  plan->usable = 4 * gw_wave_bytes(plan->ts_am) <= 160 * 1024 && 4 * gw_wave_bytes(plan->ts_k) <= 160 * 1024;
+  return 0;
+}
+
+void tg_ptap_wave_plan_free(tg_gw_plan *plan) {
+  tg_dfree(plan->k_rowptr);
+  plan->k_rowptr = nullptr;
+  plan->k_nnz = -1;
+}
+
+// Returns 0 with *k_out set, 100 when the kernels decline (tables beyond their limits after the retries: the caller falls
+// back to the workgroup kernel), another value on error.
+int tg_ptap_wave_numeric(tg_gw_plan *plan, tg_csr_s *a, int64_t a_row0, tg_csr_s *m, int64_t m_row0, tg_csr_s *mt,
+                         int64_t mt_row0, const uint8_t *mask, double diag, tg_csr_s **k_out) {
+  gw_set_lds_limits();
+  int *status = (int *)g_tg.scratch;
+  unsigned long long *sum = (unsigned long long *)(status + 2);
+  int rc = 0;
+  int64_t *am_off = nullptr;
+  int32_t *am_cnt = nullptr;
+  uint32_t *am_col = nullptr, *m_mix = nullptr;     // (am_col: the intermediate's columns, mixed)
+  double *am_val = nullptr;
+  unsigned long long *cursor = nullptr;
+  int64_t *cnt = nullptr, *off = nullptr;
+  int32_t *tcol = nullptr;
+  double *tval = nullptr;
+  tg_csr_s *k = nullptr;
+  auto cleanup = [&]() {
+    tg_dfree(am_off);
+    tg_dfree(am_cnt);
+    tg_dfree(am_col);
+    tg_dfree(m_mix);
+    tg_dfree(am_val);
+    tg_dfree(cursor);
+    tg_dfree(cnt);
+    tg_dfree(off);
+    tg_dfree(tcol);
+    tg_dfree(tval);
+  };
+  rc = tg_dmalloc(&am_off, a->nrows + 1) || tg_dmalloc(&am_cnt, a->nrows + 1) || tg_dmalloc(&cursor, 2);
+  if (rc) {
+    cleanup();
+    return rc;
+  }
+  // ---- stage 1: the intermediate A M in loose rows
+  rc = gw_mix_columns(m, &m_mix);
+  if (rc) {
+    cleanup();
+    return rc;
+  }
+  gw_args P1;
+  gw_fill_stage1(P1, a, m, m_mix, m_row0);
+  P1.rows_per_wave = gw_env_int("TIGAR_PTAP_WAVE_RPW1", 8);
+  gw_tile_hint(P1, "TIGAR_PTAP_WAVE_TILE1");
+  // rows of the temporary at a fixed stride (no atomics) unless the longest row is far above the mean
+  int64_t stride1 = (plan->max_am <= 2.0 * plan->mean_am + 32.0 && gw_env_int("TIGAR_PTAP_WAVE_STRIDED", 1)) ? ((plan->max_am + 7) & ~7) : 0;
+  int64_t cap1 = stride1 ? stride1 * a->nrows : (int64_t)(plan->mean_am * 1.08 * (double)a->nrows) + plan->max_am + 4096;
+  bool done = false;
+  for (int attempt = 0; attempt < 6 && !done; attempt++) {
+    rc = tg_dmalloc(&am_col, cap1 + TG_CSR_PAD) || tg_dmalloc(&am_val, cap1 + TG_CSR_PAD);
+    if (rc) break;
+    P1.ts = plan->ts_am;
+    P1.lgts = gw_lg(plan->ts_am);
+    P1.out_stride = stride1;
+    const size_t lds = 4 * gw_wave_bytes(P1.ts);
+    if (lds > 160 * 1024) {
+      rc = 100;
+      break;
+    }
+    hipMemsetAsync(status, 0, 4 * sizeof(int), g_tg.stream);
+    hipMemsetAsync(cursor, 0, 2 * sizeof(unsigned long long), g_tg.stream);
+    gw_launch<GW_BUMP, false>(plan->lg_m, gw_grid(a->nrows, P1.rows_per_wave), lds, P1, am_off, am_cnt, nullptr, am_col, am_val,
+                              cursor, cap1, nullptr, 0.0, 0, status, sum);
+    int h = 0;
+    unsigned long long used = 0;
+    hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
+    hipMemcpyAsync(&used, cursor, sizeof(used), hipMemcpyDeviceToHost, g_tg.stream);
+    if (hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+      tg_set_error("PtAP (wave kernels): stage A M failed to run (LDS %zu B)", lds);
+      rc = 1;
+      break;
+    }
+    if (h == GW_RANGE) {
+      tg_set_error("PtAP: a row block does not cover the rows referenced (slab halo too small)");
+      rc = 3;
+      break;
+    }
+    if (getenv("TIGAR_PTAP_WAVE_DEBUG"))
+      fprintf(stderr, "[gw] stage 1 attempt %d: status %d used %llu cap %lld ts %d\n", attempt, h, used, (long long)cap1, plan->ts_am);
+    if (h == GW_OK) {
+      done = true;
+      plan->mean_am = std::max(plan->mean_am, (double)used / (double)a->nrows);
+      break;
+    }
+    tg_dfree(am_col);
+    tg_dfree(am_val);
+    am_col = nullptr;
+    am_val = nullptr;
+    if (h == GW_OVF) {
+      plan->ts_am *= 2;
+      if (!stride1) cap1 = std::max<int64_t>(cap1, (int64_t)used + 4096);
+    } else if (stride1) {
+      int hm = 0;
+      hipMemcpy(&hm, status + 1, sizeof(int), hipMemcpyDeviceToHost);
+      plan->max_am = std::max(plan->max_am, hm);
+      stride1 = (std::max<int64_t>(hm, stride1 + stride1 / 4) + 7) & ~(int64_t)7;
+      cap1 = stride1 * a->nrows;
+    } else {
+      cap1 = std::max<int64_t>((int64_t)used + 4096, cap1 + cap1 / 2);
+    }
+  }
+  if (!rc && !done) rc = 100;
+  if (rc) {
+    cleanup();
+    return rc;
+  }
+  tg_dfree(m_mix);
+  m_mix = nullptr;
+  // ---- stage 2: K = M^T (A M), operand rows = the loose rows of the intermediate (FE row r -> r - a_row0)
+  gw_args P2;
+  P2.x_rowptr = mt->rowptr;
+  P2.x_col = mt->col;
+  P2.x_val = mt->val;
+  P2.x_nrows = mt->nrows;
+  P2.row_stride = 1;
+  P2.y_start = am_off;
+  P2.y_cnt = am_cnt;
+  P2.y_mix = am_col;
+  P2.y_val = am_val;
+  P2.y_row0 = a_row0;
+  P2.y_nrows = a->nrows;
+  P2.debug = P1.debug & ~1;
+  P2.out_stride = 0;
+  P2.rows_per_wave = gw_env_int("TIGAR_PTAP_WAVE_RPW2", 2);
+  gw_tile_hint(P2, "TIGAR_PTAP_WAVE_TILE2");
+  const int64_t nrows = mt->nrows;
+  if (plan->k_nnz >= 0) {
+    // ---- pattern known: rows are placed directly
+    rc = tg_csr_alloc(nrows, m->ncols, plan->k_nnz, &k);
+    if (!rc) {
+      hipMemcpyAsync(k->rowptr, plan->k_rowptr, (size_t)(nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream);
+      P2.ts = plan->ts_k;
+      P2.lgts = gw_lg(plan->ts_k);
+      hipMemsetAsync(status, 0, 4 * sizeof(int), g_tg.stream);
+      gw_launch<GW_PLACED, true>(plan->lg_am, gw_grid(nrows, P2.rows_per_wave), 4 * gw_wave_bytes(P2.ts), P2, k->rowptr, nullptr,
+                                 nullptr, (uint32_t *)k->col, k->val, nullptr, 0, mask, diag, mt_row0, status, sum);
+      int h = 0;
+      hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
+      if (hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        tg_set_error("PtAP (wave kernels): numeric pass (placed) failed to run");
+        rc = 1;
+      } else if (h == GW_RANGE) {
+        tg_set_error("PtAP: a row block does not cover the rows referenced (slab halo too small)");
+        rc = 3;
+      } else if (h != GW_OK) {
+        tg_set_error("PtAP numeric: operands no longer match the plan's pattern (status %d)", h);
+        rc = 4;
+      }
+    }
+  } else {
+    int64_t stride2 = (plan->max_k <= 2.0 * plan->mean_k + 32.0 && gw_env_int("TIGAR_PTAP_WAVE_STRIDED", 1)) ? ((plan->max_k + 7) & ~7) : 0;
+    int64_t cap2 = stride2 ? stride2 * nrows : (int64_t)(plan->mean_k * 1.05 * (double)nrows) + plan->max_k + 1024;
+    rc = tg_dmalloc(&cnt, nrows + 1) || tg_dmalloc(&off, nrows + 1);
+    done = false;
+    for (int attempt = 0; attempt < 6 && !rc && !done; attempt++) {
+      rc = tg_dmalloc(&tcol, cap2 + TG_CSR_PAD) || tg_dmalloc(&tval, cap2 + TG_CSR_PAD);
+      if (rc) break;
+      P2.ts = plan->ts_k;
+      P2.lgts = gw_lg(plan->ts_k);
+      P2.out_stride = stride2;
+      const size_t lds = 4 * gw_wave_bytes(P2.ts);
+      if (lds > 160 * 1024) {
+        rc = 100;
+        break;
+      }
+      hipMemsetAsync(status, 0, 4 * sizeof(int), g_tg.stream);
+      hipMemsetAsync(cursor, 0, 2 * sizeof(unsigned long long), g_tg.stream);
+      hipMemsetAsync(cnt, 0, (size_t)(nrows + 1) * sizeof(int64_t), g_tg.stream);
+      gw_launch<GW_BUMP, true>(plan->lg_am, gw_grid(nrows, P2.rows_per_wave), lds, P2, off, nullptr, cnt, (uint32_t *)tcol, tval, cursor, cap2,
+                               mask, diag, mt_row0, status, sum);
+      int h = 0;
+      unsigned long long used = 0;
+      hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
+      hipMemcpyAsync(&used, cursor, sizeof(used), hipMemcpyDeviceToHost, g_tg.stream);
+      if (hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        tg_set_error("PtAP (wave kernels): stage M^T (A M) failed to run (LDS %zu B)", lds);
+        rc = 1;
+        break;
+      }
+      if (h == GW_RANGE) {
+        tg_set_error("PtAP: a row block does not cover the rows referenced (slab halo too small)");
+        rc = 3;
+        break;
+      }
+      if (getenv("TIGAR_PTAP_WAVE_DEBUG"))
+        fprintf(stderr, "[gw] stage 2 attempt %d: status %d used %llu cap %lld ts %d\n", attempt, h, used, (long long)cap2, plan->ts_k);
+      if (h == GW_OK) {
+        done = true;
+        break;
+      }
+      tg_dfree(tcol);
+      tg_dfree(tval);
+      tcol = nullptr;
+      tval = nullptr;
+      if (h == GW_OVF) {
+        plan->ts_k *= 2;
+        if (!stride2) cap2 = std::max<int64_t>(cap2, (int64_t)used + 1024);
+      } else if (stride2) {
+        int hm = 0;
+        hipMemcpy(&hm, status + 1, sizeof(int), hipMemcpyDeviceToHost);
+        plan->max_k = std::max(plan->max_k, hm);
+        stride2 = (std::max<int64_t>(hm, stride2 + stride2 / 4) + 7) & ~(int64_t)7;
+        cap2 = stride2 * nrows;
+      } else {
+        cap2 = std::max<int64_t>((int64_t)used + 1024, cap2 + cap2 / 2);
+      }
+    }
+    if (!rc && !done) rc = 100;
+    if (!rc) {
+      int64_t nnz = 0;
+      rc = tg_exclusive_scan_i64(cnt, nrows, &nnz);
+      if (!rc) rc = tg_csr_alloc(nrows, m->ncols, nnz, &k);
+      if (!rc) {
+        hipMemcpyAsync(k->rowptr, cnt, (size_t)(nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream);
+        const unsigned rg = (unsigned)std::min<int64_t>(tg_cdiv(nrows, 4), (int64_t)g_tg.num_cu * 16);
+        hipLaunchKernelGGL(k_gw_reorder, dim3(std::max(1u, rg)), dim3(256), 0, g_tg.stream, k->rowptr, off, tcol, tval, nrows,
+                           k->col, k->val);
+        if (hipGetLastError() != hipSuccess) {
+          tg_set_error("PtAP reorder launch failed");
+          rc = 1;
+        }
+        // remember the pattern for later calls with the same operands' structure
+        tg_dfree(plan->k_rowptr);
+        plan->k_rowptr = cnt;
+        cnt = nullptr;
+        plan->k_nnz = nnz;
+      }
+    }
+  }
+  hipStreamSynchronize(g_tg.stream);
+  cleanup();
+  if (rc) {
+    if (k) tg_csr_destroy(k);
+    return rc;
+  }
+  *k_out = k;
+  return 0;
+}
