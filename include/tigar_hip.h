@@ -209,6 +209,12 @@ int tg_ptap_symbolic(tg_csr_t a, int64_t a_row0, tg_csr_t m, int64_t m_row0, tg_
 int tg_ptap_numeric(tg_ptap_t plan, tg_csr_t a, tg_csr_t m, tg_csr_t mt,
                     const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out);
 int tg_ptap_destroy(tg_ptap_t plan);
+/* Which kernels tg_ptap_symbolic plans for: 0 = chosen from the operands (default), 1 = two row-wise Gustavson products
+ * with one wave per row (csrc/tg_ptap_wave.hip: faster for long operand rows, 3-D p >= 3), 2 = the fused
+ * workgroup-per-row kernel (csrc/tg_ptap.hip).  The result is the same matrix either way (MatPtAP, tIGAr/common.py:1194-1195);
+ * a caller that streams the product in row blocks with overlapping operands states its preference here.  Returns the
+ * previous setting. */
+int tg_ptap_prefer(int kernels);
 /* extractMatrix when the extraction operator is a Kronecker product (tensor B-splines): one
  * contraction stage  out = P^T cur P  with P = (x)_k F_k, F_k = the 1-D matrix of direction k
  * (n x m CSR + its transpose, host pointers) or the identity (rowptr == NULL).  `cur` is an

@@ -123,6 +123,7 @@ PROTOTYPES = {
     "tg_ptap_numeric": (C.c_int, [handle, handle, handle, handle, c_i32p, C.c_int64, C.c_double,
                                   C.POINTER(handle)]),
     "tg_ptap_destroy": (C.c_int, [handle]),
+    "tg_ptap_prefer": (C.c_int, [C.c_int]),
     "tg_ptap_kron": (C.c_int, [handle, C.c_int64, C.c_int, c_i64p, C.POINTER(tg_kron1d_t), C.c_int64, C.c_int64,
                                c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
     "tg_ptap_kron_stage": (C.c_int, [handle, C.c_int64, C.c_int, c_i64p, C.POINTER(tg_kron1d_t), C.c_int64, C.c_int64,

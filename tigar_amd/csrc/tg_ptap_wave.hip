@@ -550,9 +550,25 @@ static unsigned gw_grid(int64_t nrows, int rows_per_wave) {
 }
 
 // sizes the tables of stage 1 from a sample of A's rows; the tables of stage 2 come from the caller's probe of K's rows
+static int g_gw_prefer = 0;
+extern "C" int tg_ptap_prefer(int kernels) {
+  const int old = g_gw_prefer;
+  if (kernels >= 0 && kernels <= 2) g_gw_prefer = kernels;
+  return old;
+}
+
 int tg_ptap_wave_plan(tg_csr_s *a, tg_csr_s *m, int64_t m_row0, tg_csr_s *mt, int max_k, double mean_k, tg_gw_plan *plan) {
   plan->usable = false;
-  if (gw_env_int("TIGAR_PTAP_WAVE", 1) == 0) return 0;
+  // Where the wave kernels win (MI355X, profiles/r4_general_ptap.md): operand rows that fill a wave -- 3-D patches of
+  // degree >= 3 held resident (48^3 ... 96^3 elements: 1.5-1.8 x).  Short rows (2-D, p = 2, T-spline cells: 12-27 entries)
+  // leave most lanes of a row-per-wave walk idle and the fused kernel is up to 2 x faster there; so is it when the product
+  // is streamed in row blocks whose operand rows overlap (every block recomputes the rows of A M in its halo).
+  // TIGAR_PTAP_WAVE=1/0 and tg_ptap_prefer() override the rule.
+  const int forced = gw_env_int("TIGAR_PTAP_WAVE", -1);
+  const int pref = forced == 1 ? 1 : forced == 0 ? 2 : g_gw_prefer;
+  if (pref == 2) return 0;
+  const double mean_m = (double)m->nnz / (double)std::max<int64_t>(m->nrows, 1);
+  if (pref == 0 && mean_m < 40.0) return 0;
   if (a->nrows <= 0 || mt->nrows <= 0 || a->nnz <= 0 || m->nnz <= 0) return 0;
   gw_set_lds_limits();
   int *status = (int *)g_tg.scratch;           // [0] status, [1] maximum, [2..3] sum

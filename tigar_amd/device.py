@@ -488,6 +488,12 @@ def ptap_symbolic(A, M, MT, a_row0=0, m_row0=0, mt_row0=0):
     return PtAPPlan(h)
 
 
+def ptap_prefer(kernels):
+    """0: kernels of the general PtAP chosen from the operands, 1: wave-per-row Gustavson products, 2: fused
+    workgroup-per-row kernel; returns the previous setting (``tg_ptap_prefer``)"""
+    return int(_lib.lib().tg_ptap_prefer(int(kernels)))
+
+
 def ptap_numeric(plan, A, M, MT, zero_dofs=None, diag=1.0):
     h = handle()
     if zero_dofs is not None and len(zero_dofs):

@@ -326,7 +326,14 @@ class SlabHotPath(object):
                     return self.assemble(a_rows, b_rows, zero_dofs, diag, timers, a_factors)
                 plan = None
             else:
-                plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], S["m_rows"][0], S["dofs"][0])
+                # (streamed in sub-slabs the operand rows of neighbouring blocks overlap: the fused kernel, which forms only
+                #  what a row of K needs, is the faster one there -- 10.7 against 15.0 s at cfg3; one block: the library's rule)
+                old_pref = dev.ptap_prefer(2) if nslabs > 1 else None
+                try:
+                    plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], S["m_rows"][0], S["dofs"][0])
+                finally:
+                    if old_pref is not None:
+                        dev.ptap_prefer(old_pref)
                 kblk = dev.ptap_numeric(plan, A, M, MT, zero_dofs, diag)
             tick("ptap", t0)
             t0 = time.perf_counter()
