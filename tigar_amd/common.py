@@ -196,9 +196,11 @@ _CELL_NAMES = {1: "interval", 2: "quadrilateral", 3: "hexahedron"}
 
 
 def _knot_mesh_arrays(g):
-    """(coordinates [nv, d], topology [ncells, 2^d]) of the knot mesh under a tensor node grid, laid out as dolfin's
-    tensor-product meshes are (vertices and cells with direction 0 fastest, the vertices of a cell in lexicographic
-    order): the content of ``/mesh`` in extraction-data.h5 (tIGAr/common.py:463)."""
+    """(coordinates [nv, d], topology [ncells, 2^d]) of the knot mesh under a tensor node grid: vertices and cells with
+    direction 0 fastest, the vertices of a cell in lexicographic order -- the content of ``/mesh`` in extraction-data.h5
+    (tIGAr/common.py:463).  The GROUP layout is dolfin's; whether dolfin's own quadrilateral / hexahedral meshes order
+    the vertices of a cell this way has not been checked against dolfin (absent here), and nothing in this package
+    depends on it: the node sets are rebuilt from the group ``/tigar_amd``."""
     d = g.dim()
     verts = [numpy.asarray(v, dtype=numpy.float64) for v in g.vertices]
     nv = [len(v) for v in verts]
@@ -591,6 +593,14 @@ class AbstractExtractionGenerator(object):
             for gi, g in enumerate(V.grids):
                 _grid_to_arrays(g, "%s_%d" % (name, gi), data)
         from . import h5io
+        if not h5io.available():
+            # no libhdf5 on this machine: the archive rounds 1-2 wrote (still read by ExtractedSpline(dirname))
+            import warnings
+            warnings.warn("libhdf5 not found (TIGAR_HDF5_LIB): writing %s instead of %s" % (EXTRACTION_DATA_NPZ, EXTRACTION_DATA_FILE))
+            for i, fn in enumerate(self.cpFuncs):
+                data["control%d" % i] = fn.vector().get_local()
+            numpy.savez(os.path.join(dirname, EXTRACTION_DATA_NPZ), **data)
+            return
         with h5io.H5File(os.path.join(dirname, EXTRACTION_DATA_FILE), "w") as f:
             g0 = self.V_control.grids[0]
             cell_dofs = None

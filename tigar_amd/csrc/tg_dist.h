@@ -42,6 +42,7 @@ struct tg_comm_s {
   unsigned long long ar_seq = 0, tx[2] = {0, 0}, rx[2] = {0, 0};
   unsigned *done_ctr = nullptr;       // device: block counters of the push / pull kernels
   long long tmo_ticks = 0;
+  int khz = 0;                       // wall-clock rate of the device (ticks per millisecond)
   int mail_generation = 0;
   tg_host_allreduce_fn h_allreduce = nullptr;
   tg_host_sendrecv_fn h_sendrecv = nullptr;

@@ -27,7 +27,11 @@
 // write through to memory, loads miss every non-coherent cache level), so no exchange needs a cache-wide
 // write-back or invalidate -- a release / acquire FENCE at system scope costs ~0.1 ms while the products of two
 // ranks stream through the L2s (measured) -- and the order "payload, then flag" is kept by waiting for the stores
-// of the workgroup to be acknowledged (workgroup-scope release fence = s_waitcnt vmcnt(0)) before the flag goes out.
+// of the workgroup to be ACKNOWLEDGED before the flag goes out: an explicit `s_waitcnt vmcnt(0)` (gfx9 family: vmcnt
+// counts stores as well; a system-scope store is acknowledged once it is visible at system scope), then the barrier.
+// The workgroup-scope release fence that stood here alone in round 3 happens to lower to the same wait with this
+// toolchain, but LLVM's memory model for gfx90a+ allows it to omit the wait outside tgsplit mode: the order
+// must not depend on that.  gfx950 only (gfx10+ counts stores on vscnt).
 __device__ __forceinline__ unsigned long long tg_ld_sys(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -42,7 +46,8 @@ __device__ __forceinline__ void tg_st_sys(double *p, double v) {
 }
 // all stores this workgroup has issued are acknowledged by memory when every thread has passed this point
 __device__ __forceinline__ void tg_stores_done_block() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // compiler: nothing moves below
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // hardware: every store of this wave acknowledged
   __syncthreads();
 }
 // spins until *p >= v; false after `tmo` wall-clock ticks or when another rank has given up
@@ -51,9 +56,14 @@ __device__ __forceinline__ bool tg_spin_ge(const unsigned long long *p, unsigned
   if (tg_ld_sys(p) >= v) return true;
   const long long t0 = wall_clock64();
   unsigned n = 0;
+  // exponential back-off: the first polls come 128 cycles apart (a peer on its own GPU answers within microseconds), the
+  // interval doubles every 64 polls up to ~8 k cycles -- ranks that SHARE a GPU (verification runs: eight ranks of cfg2
+  // spent 1.16 s per solve spinning at the short interval, their polls and the peers' kernels on the same CUs) leave the
+  // issue slots and the memory pipeline to whoever they are waiting for
   while (tg_ld_sys(p) < v) {
-    __builtin_amdgcn_s_sleep(2);
-    if ((++n & 63u) == 0) {
+    const unsigned lvl = min(n >> 6, 6u);
+    for (unsigned k = 0; k < (1u << lvl); k++) __builtin_amdgcn_s_sleep(2);
+    if ((++n & 15u) == 0 || lvl >= 4u) {
       if (tg_ld_sys(&s->abort_word) != 0ull) return false;
       if (wall_clock64() - t0 > tmo) return false;
     }
@@ -260,7 +270,7 @@ static int tg_ipc_mailboxes(tg_comm_s *c, int64_t cap, bool first) {
   c->mail_generation += 1;
   __atomic_store_n(&s->mail_gen[c->rank], c->mail_generation, __ATOMIC_RELEASE);
   const char *e = getenv("TIGAR_IPC_TIMEOUT_S");
-  const double limit = e ? atof(e) : 60.0;
+  const double limit = e ? atof(e) : 1800.0;
   const auto t0 = std::chrono::steady_clock::now();
   for (int k = 0; k < 2; k++) {
     const int nb = k == 0 ? c->rank - 1 : c->rank + 1;
@@ -315,8 +325,12 @@ extern "C" int tg_comm_create_ipc(const char *shm_path, int rank, int world, tg_
   }
   int khz = 0;
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, g_tg.device) != hipSuccess || khz <= 0) khz = 100000;
+  // Ranks reach a matching exchange far apart in ordinary runs (rank-0-only I/O, uneven assembly, ranks sharing a GPU):
+  // the device-side waits give up after 30 minutes unless TIGAR_IPC_TIMEOUT_S says otherwise; the self-test, whose
+  // exchanges are back to back on every rank, runs with its own short limit (tg_comm_selftest).
   const char *e = getenv("TIGAR_IPC_TIMEOUT_S");
-  c->tmo_ticks = (long long)((e ? atof(e) : 60.0) * 1000.0 * khz);
+  c->khz = khz;
+  c->tmo_ticks = (long long)((e ? atof(e) : 1800.0) * 1000.0 * khz);
   if (hipMalloc((void **)&c->done_ctr, 4 * sizeof(unsigned)) != hipSuccess ||
       hipMemset(c->done_ctr, 0, 4 * sizeof(unsigned)) != hipSuccess) {
     tg_set_error("IPC communicator: allocation failed");
@@ -707,6 +721,8 @@ extern "C" int tg_comm_selftest(tg_comm_t c, double timeout_s) {
   TG_CHECK_HIP(hipStreamCreateWithFlags(&tmp, hipStreamNonBlocking));
   g_tg.stream = tmp;
   c->host_wait_limit = timeout_s > 0.0 ? timeout_s : 60.0;
+  const long long saved_tmo = c->tmo_ticks;
+  if (c->kind == 2 && c->khz > 0) c->tmo_ticks = std::min(saved_tmo, (long long)(c->host_wait_limit * 1000.0 * c->khz));
   const int W = c->world, R = c->rank;
   const int64_t nloc = 4096, h = 512;
   double *xext = nullptr;
@@ -737,6 +753,7 @@ extern "C" int tg_comm_selftest(tg_comm_t c, double timeout_s) {
   rc = body();
   g_tg.stream = saved;
   c->host_wait_limit = 0.0;
+  c->tmo_ticks = saved_tmo;
   c->slab_set = false;
   if (rc != 4) {   // (a stream with an exchange stuck on it cannot be waited for)
     if (xext) hipFree(xext);
