@@ -57,6 +57,9 @@ def main():
     from tigar_amd.device import DeviceVector
     U2 = DeviceVector(data=U.get_local())
     its2 = solver.solve(K, U2, rhs)
+    # the guess solveLinearSystem reads from u when the solver asks for one (the reference seeds MTU = M^T u.vector(),
+    # tIGAr/common.py:1250-1254): rank-local FE rows + ghost rows of the neighbours, through the slab engine
+    guess = spline._initial_guess_through_slabs(u).get_local()
     # optional: the same system at a ladder of tolerances (so that some solve ends with its norm just below the
     # tolerance, the case in which an iteration enqueued past convergence could come back to life)
     ladder_U, ladder_res, ladder_its = [], [], []
@@ -74,7 +77,7 @@ def main():
     cp0 = gen.cpFuncs[0].vector().get_local()
     np.savez(os.path.join(outdir, "rank%d.npz" % comm.rank), g=np.array([g0, g1, r0, r1]),
              K_indptr=Ks.indptr, K_indices=Ks.indices, K_data=Ks.data, rhs=rhs.get_local(), U=U.get_local(),
-             u=u.vector().get_local(), its=np.array([its1, its2]),
+             u=u.vector().get_local(), its=np.array([its1, its2]), guess=guess,
              comm=np.array([rank_r, world_r, dev.Comm.KINDS.index(kind)]), cp0=cp0,
              U2=U2.get_local(), overlapped=np.array([overlapped]), host_waits=np.array([host_waits]),
              resnorm=np.array([resnorm]), ladder_U=np.array(ladder_U), ladder_res=np.array(ladder_res),

@@ -285,9 +285,21 @@ class Function(object):
         else:
             nloc = V.dim() if local_range is None else local_range[1] - local_range[0]
         self._vec = vector if vector is not None else DeviceVector(nloc)
+        self._ghoster = None          # set by the spline that drives a distributed solve (ExtractedSpline.ghostedVector)
 
     def vector(self):
         return self._vec
+
+    def ghosted(self):
+        """FE coefficients as a vector of the full length of V, valid on every row the forms of THIS rank read: its own
+        rows plus the ghost rows held by the z-neighbours (dolfin's ghost update of a distributed Function [ext]; the
+        reference's forms read the ghosted vector after ``u.assign``, tIGAr/common.py:1343).  One rank: the vector itself."""
+        if self.local_range is None:
+            return self._vec
+        if self._ghoster is None:
+            raise RuntimeError("a rank-local Function can only be read by forms after the spline that owns it has been "
+                               "asked for a ghost update (ExtractedSpline.ghostedVector / solveNonlinearVariationalProblem)")
+        return self._ghoster(self)
 
     def function_space(self):
         return self.V
@@ -1582,20 +1594,90 @@ class ExtractedSpline(object):
             self.M.mult(MTU, _as_device_vector(u))
         return MTU
 
-    def _initial_guess_through_slabs(self, u):
-        """The rank's rows of M^T u for a guess set in ``u`` (a replicated FE vector, or a Function that holds the rank's
-        own FE rows ``u.local_range`` as solveLinearSystem leaves it: rows outside count as zero)"""
+    # -- rank-local FE functions (tIGAr/common.py:1304-1348 runs on distributed PETSc vectors with ghost updates)
+    def localFunction(self, u=None):
+        """A Function that holds the FE rows this rank owns (``localFERange()``): a fresh one, or the rows of ``u`` cut out
+        of a replicated full-length Function / vector.  The form objects read it through ``Function.ghosted()``."""
+        rng = self.localFERange()
+        f = Function(self.V, rng if self._distributed() else None)
+        f._ghoster = self.ghostedVector
+        if u is not None:
+            src = _as_device_vector(u)
+            if src.size() == f.vector().size():
+                _dev.vec_copy_range(f.vector(), 0, src, 0, src.size())
+            else:
+                _dev.vec_copy_range(f.vector(), 0, src, int(rng[0]), int(rng[1]) - int(rng[0]))
+        return f
+
+    def ghostedVector(self, u):
+        """Full-length vector with the rank-local FE function ``u`` in place and the ghost rows the rank's forms read --
+        the FE rows its rows of A couple to beyond its own, ``m_rows`` of its slab -- fetched from the z-neighbours
+        (host-staged through the transport: one exchange per assembly, as dolfin's ghost update after ``u.assign``).
+        Rows outside the window are zero."""
         vec = _as_device_vector(u)
-        rng = getattr(u, "local_range", None)
         n = self.V.dim()
-        if rng is None or vec.size() == n:
+        if not self._distributed() or vec.size() == n:
+            return vec
+        if self.nFields != 1:
+            raise NotImplementedError("ghost update of rank-local FE functions: one field")
+        slab = self._slab_path()
+        lay, world, rank = slab.layout, slab.world, slab.rank
+        from .dist import split_range
+        ranges = split_range(lay.ncp, world)
+        own = [lay.slab(a, b)["u_rows"] for (a, b) in ranges]
+        need = [lay.slab(a, b)["m_rows"] for (a, b) in ranges]
+        ua, ub = own[rank]
+        if vec.size() != ub - ua:
+            raise ValueError("ghostedVector: the function does not hold this rank's FE rows")
+        host = vec.get_local()
+        full = numpy.zeros(n)
+        full[ua:ub] = host
+        tr = self.comm.transport()
+        for nb in (rank - 1, rank + 1):
+            if nb < 0 or nb >= world:
+                continue
+            # what the neighbour needs of my rows, what I need of its rows (both follow from the layout alone)
+            if nb < rank:
+                s0, s1 = ua, min(ub, need[nb][1])            # my lowest rows, up to the end of its window
+                r0, r1 = max(need[rank][0], own[nb][0]), ua
+                if need[rank][0] < own[nb][0]:
+                    raise NotImplementedError("ghost rows reach beyond the neighbouring rank (slabs thinner than the coupling)")
+            else:
+                s0, s1 = max(ua, need[nb][0]), ub
+                r0, r1 = ub, min(need[rank][1], own[nb][1])
+                if need[rank][1] > own[nb][1]:
+                    raise NotImplementedError("ghost rows reach beyond the neighbouring rank (slabs thinner than the coupling)")
+            send = numpy.ascontiguousarray(full[s0:s1]) if s1 > s0 else numpy.zeros(0)
+            recv = numpy.zeros(max(0, r1 - r0))
+            tr.sendrecv(nb, send, recv)
+            if r1 > r0:
+                full[r0:r1] = recv
+        return DeviceVector(data=full)
+
+    def globalNorm(self, v, kind="l2"):
+        """Norm of an IGA vector over all ranks (PETSc VecNorm on the distributed M^T b, tIGAr/common.py:1330): the local
+        sums go through the device communicator's all-reduce -- every rank gets the same bits."""
+        if not self._distributed():
+            return v.norm(kind)
+        if kind != "l2":
+            raise ValueError("globalNorm: l2")
+        return float(numpy.sqrt(self.comm.device().allreduce_sum(numpy.array([v.inner(v)]))[0]))
+
+    def _initial_guess_through_slabs(self, u):
+        """The rank's rows of M^T u for a guess set in ``u``: a replicated full-length FE vector, or a Function that holds
+        the rank's own FE rows as solveLinearSystem leaves it -- then with the ghost rows of the z-neighbours, so that the
+        dofs next to a slab boundary get every contribution (the reference's MatMultTranspose on distributed vectors)"""
+        vec = _as_device_vector(u)
+        n = self.V.dim()
+        if vec.size() == n:
             full = vec
+        elif self.nFields == 1:
+            full = self.ghostedVector(u)
         else:
+            # several fields: the rank's own rows of every field in place (ghost rows count as zero: a guess, not a result)
             full = DeviceVector(n)
-            full.fill(0.0)
-            ranges = [rng] if numpy.isscalar(rng[0]) else list(rng)
             off = 0
-            for (a, b) in ranges:
+            for (a, b) in list(getattr(u, "local_range", None) or []):
                 _dev.vec_copy_range(full, int(a), vec, off, int(b) - int(a))
                 off += int(b) - int(a)
 
@@ -1639,14 +1721,24 @@ class ExtractedSpline(object):
         reference's progress line; non-convergence raises instead of the reference's exit().
         Returns the list of relative norms."""
         returningDoFs = igaDoFs is not None
+        dist = self._distributed()
+        if dist:
+            # several ranks: u, du and igaDoFs are rank-local (FE rows localFERange(), dofs localDofRange()), the norm is
+            # global, the forms read u through Function.ghosted() -- the reference's loop on distributed PETSc vectors
+            if u.local_range is None:
+                loc = self.localFunction(u)          # a replicated Function: every rank keeps its rows
+                u._vec, u.local_range = loc.vector(), loc.local_range
+            u._ghoster = self.ghostedVector
+            if returningDoFs:
+                u._vec = self._slab_path().prolong(igaDoFs)
         uv = _as_device_vector(u)
-        if returningDoFs:
+        if returningDoFs and not dist:
             self.M.mult(igaDoFs, uv)
         history = []
         converged = False
         for i in range(0, self.maxIters):
             MTAM, MTb = self.assembleLinearSystem(J, residualForm)
-            currentNorm = MTb.norm("l2")
+            currentNorm = self.globalNorm(MTb, "l2")
             if i == 0 and referenceError is None:
                 referenceError = currentNorm
             relativeNorm = currentNorm / referenceError
@@ -1657,7 +1749,7 @@ class ExtractedSpline(object):
             if relativeNorm < self.relativeTolerance:
                 converged = True
                 break
-            du = Function(self.V)
+            du = Function(self.V, self.localFERange() if dist else None)
             igaIncrement = self.solveLinearSystem(MTAM, MTb, du)
             uv.axpy(-1.0, du.vector())
             if returningDoFs:

@@ -357,9 +357,21 @@ class SemilinearResidual(object):
             self._KM = (LaplaceForm(self.geometry).assemble_matrix(V), MassForm(self.geometry).assemble_matrix(V))
         return self._KM
 
+    def _row_blocks(self, V, row0, row1):
+        """rows [row0, row1) of K and M (cut once per row range: a Newton loop asks for the same blocks every step)"""
+        key = (int(row0), int(row1))
+        if getattr(self, "_blocks", None) is None or self._blocks[0] != key:
+            K, Mm = self._matrices(V)
+            n = K.shape[1]
+            self._blocks = (key, K.block(key[0], key[1], 0, n), Mm.block(key[0], key[1], 0, n))
+        return self._blocks[1], self._blocks[2]
+
     def assemble_vector(self, V, row0=None, row1=None):
         K, Mm = self._matrices(V)
-        uv = self.u.vector()
+        # (a rank-local u: its ghosted form -- own rows + the rows of the z-neighbours this rank's rows couple to)
+        uv = self.u.ghosted() if hasattr(self.u, "ghosted") else self.u.vector()
+        if row0 is not None and (row0, row1) != (0, K.shape[0]):
+            K, Mm = self._row_blocks(V, row0, row1)
         r = K.mult(uv)
         t = self.g(uv)
         t.axpy(-1.0, self.f)
@@ -376,4 +388,7 @@ class _SemilinearTangent(object):
 
     def assemble_matrix(self, V, row0=None, row1=None):
         K, Mm = self.res._matrices(V)
-        return K.combine(1.0, Mm, 1.0, self.res.dg(self.res.u.vector()))
+        uv = self.res.u.ghosted() if hasattr(self.res.u, "ghosted") else self.res.u.vector()
+        if row0 is not None and (row0, row1) != (0, K.shape[0]):
+            K, Mm = self.res._row_blocks(V, row0, row1)
+        return K.combine(1.0, Mm, 1.0, self.res.dg(uv))
