@@ -39,7 +39,7 @@ def _demo(T, d, p, nel, solver):
     return gen, spline, U, u
 
 
-@pytest.mark.parametrize("d,p,nel", [(2, 2, 16), (2, 3, 10), (3, 2, 6)])
+@pytest.mark.parametrize("d,p,nel", [(2, 2, 16), (2, 2, 32), (2, 3, 10), (3, 2, 6)])      # (2, 2, 32) = BASELINE cfg1 exactly
 def test_poisson_demo_flow_matches_oracle(T, d, p, nel):
     solver = T.t.PETScKrylovSolver("cg", "jacobi")
     solver.parameters["relative_tolerance"] = 1e-11

@@ -123,3 +123,63 @@ def test_round_trip_of_generators_on_other_node_sets(tmp_path):
         for a, b in zip(s_gen.cpFuncs, s_dir.cpFuncs):
             assert np.array_equal(a.vector().get_local(), b.vector().get_local())
         assert list(s_dir.zeroDofs) == [0, 3]
+
+
+def _petsc_mat_bytes(A):
+    """PETSc's MatLoad layout (big-endian: classid 1211216, rows, cols, nnz | row lengths | column indices | values),
+    encoded HERE with struct.pack -- independently of tigar_amd.petscio, as tests/test_petscio.py restates it"""
+    import struct
+    import scipy.sparse as sp
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    lens = np.diff(A.indptr)
+    return (struct.pack(">4i", 1211216, A.shape[0], A.shape[1], A.nnz) + struct.pack(">%di" % A.shape[0], *lens)
+            + struct.pack(">%di" % A.nnz, *A.indices) + struct.pack(">%dd" % A.nnz, *A.data))
+
+
+def test_directory_with_independently_encoded_petsc_files_against_the_oracle(tmp_path):
+    """Known answer instead of a round trip: the PETSc binary files of the directory are byte strings
+    produced by this test's own struct.pack encoder from the ORACLE's extraction matrices and zero dofs (the product
+    wrote only the node-set description); ExtractedSpline(dirname) reads them and M^T A M, M^T b and the solution are
+    compared with the oracle's (tIGAr/common.py:748-894 -> 1176-1204)."""
+    import struct
+    import tigar_amd as t
+    from tigar_amd import BSplines as B
+    from oracle import tigar_oracle as O
+    d, p, nel = 2, 2, 8
+    kv = [B.uniformKnots(p, 0., 1., nel)] * d
+    gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p] * d, kv))
+    dirname = str(tmp_path / "extraction")
+    gen.writeExtraction(dirname)                      # (node sets, control functions, info file)
+    s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel)] * d)
+    Mo = O.generate_M_tensor(s)
+    zd = []
+    for direction in range(d):
+        for side in (0, 1):
+            zd += s.getSideDofs(direction, side)
+    with open(os.path.join(dirname, "extraction-mat.dat"), "wb") as f:
+        f.write(_petsc_mat_bytes(Mo))
+    with open(os.path.join(dirname, "extraction-mat-ctrl.dat"), "wb") as f:
+        f.write(_petsc_mat_bytes(Mo))
+    with open(os.path.join(dirname, "zero-dofs.dat"), "wb") as f:
+        f.write(struct.pack(">%di" % (2 + len(zd)), 1211218, len(zd), *zd))
+    spline = t.ExtractedSpline(dirname, 2 * p)
+    assert spline.zeroDofs.tolist() == zd                       # duplicates (corners) kept as written
+    fn = lambda x: np.sin(np.pi * x)
+    A, b, _, _ = O.poisson_fe_system(s, f1d=[fn] * d)
+    K = spline.extractMatrix(A).to_scipy().tocsr()
+    K.sort_indices()
+    Ko = O.extract_matrix(Mo, A, zd).tocsr()
+    Ko.sort_indices()
+    assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices)
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+    rhs = spline.extractVector(b)
+    assert np.max(np.abs(rhs.get_local() - O.extract_vector(Mo, b, zd))) <= 1e-13 * np.max(np.abs(b))
+    solver = t.PETScKrylovSolver("cg", "jacobi")
+    solver.parameters["relative_tolerance"] = 1e-12
+    spline.setSolverOptions(linearSolver=solver)
+    u = t.Function(spline.V)
+    U = spline.solveLinearSystem(spline.extractMatrix(A), rhs, u)
+    Uo, uo = O.solve_linear_system(Mo, Ko, O.extract_vector(Mo, b, zd), "direct")
+    assert np.max(np.abs(U.get_local() - Uo)) <= 1e-9 * np.max(np.abs(Uo))
+    assert np.max(np.abs(u.vector().get_local() - uo)) <= 1e-9 * np.max(np.abs(uo))
