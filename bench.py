@@ -358,6 +358,16 @@ def run(args, wl, d, p, nel):
     if rank == 0:
         log("[bench] stages (mean s):", {k: round(v, 5) for k, v in mean_stages.items()}, "iterations:", its,
             "nnz(K) global:", nnzK, "M implicit:", bool(getattr(gen.M, "is_implicit", False)))
+    # per-rank stage times (a first multi-GPU run has to be diagnosable from its one line: which rank, which stage)
+    stage_names = sorted(mean_stages)
+    per_rank = None
+    if world > 1:
+        tab = np.zeros((world, len(stage_names) + 2))
+        tab[rank, :len(stage_names)] = [mean_stages[k] for k in stage_names]
+        tab[rank, -2], tab[rank, -1] = float(K.shape[0]), float(K.nnz)
+        transport.allreduce_sum(tab)
+        per_rank = [dict({k: round(float(tab[r, i]), 6) for i, k in enumerate(stage_names)}, rank=r, dof_rows=int(tab[r, -2]),
+                         nnz_K=int(tab[r, -1])) for r in range(world)]
     info = dcomm.info() if dcomm is not None else (0, 1, "none")
     ndev = dev.device_count()
     n_used = 1
@@ -373,7 +383,11 @@ def run(args, wl, d, p, nel):
             "solver_last": {k: v for k, v in (solver.last or {}).items() if isinstance(v, (int, float, str, bool))},
             "self_check": self_check, "verified_step_s": verified, "materialised_step_s": companions.get("materialised"),
             "fused": bool(fused), "comm_host_waits": int(comm_host_waits),
-            "comm_world": info[1], "comm_kind": info[2], "n_devices_used": n_used}
+            "comm_world": info[1], "comm_kind": info[2], "n_devices_used": n_used, "per_rank_stages": per_rank,
+            "comm_requested": getattr(dcomm, "requested_kind", None) if dcomm is not None else None,
+            "comm_fallback": getattr(dcomm, "fallback_notes", None) if dcomm is not None else None,
+            "comm_devices": (dcomm.rank_devices() if (dcomm is not None and info[2] == "ipc") else None),
+            "devices_visible": ndev}
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
@@ -426,7 +440,18 @@ def _cpu_sample(d, p, nel, threads, factored=False):
             "solve_s": t4 - t3, "its": its, "total_s": t4 - t0, "err": err, "inputs_s": t_in, "nnzK": int(K.nnz)}
 
 
-def cpu_baseline(d, p, nel_all, nel_one, nel_target, its_target):
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(d, p, nel_all, nel_one, nel_target, its_target, gpu_general=None):
     """the CPU restatement on ONE thread and on all cores the box grants, on bounded samples of
     the same workload (same d, p; fewer elements), plus the stated extrapolation to the benchmark size (set-up linear
     in the DoFs, solve = iterations x per-iteration time) and the sum-factorised product on one thread, so that the
@@ -436,7 +461,7 @@ def cpu_baseline(d, p, nel_all, nel_one, nel_target, its_target):
     t0 = time.perf_counter()
     allc = _cpu_sample(d, p, nel_all, cores)
     if time.perf_counter() - t0 > 60.0 and d == 3:
-        nel_one = max(4, min(nel_one, 16))       # (a slow host: keep the whole baseline within a few minutes)
+        nel_one = max(4, min(nel_one, 24))       # (a slow host: keep the whole baseline within a few minutes)
     one = _cpu_sample(d, p, nel_one, 1)
     fac = _cpu_sample(d, p, nel_one, 1, factored=True)
     log("[bench] cpu baseline: %.1f s in all" % (time.perf_counter() - t0))
@@ -450,7 +475,14 @@ def cpu_baseline(d, p, nel_all, nel_one, nel_target, its_target):
                      "CG(%d its)+prolongation %.2fs; max nodal error %.1e"
                      % (d, p, q["nel"], d, q["ncp"], q["threads"], "s" if q["threads"] > 1 else "", q["extract_s"], q["ptap_s"],
                         q["mtb_s"], q["its"], q["solve_s"], q["err"]))
+    like = None
+    if gpu_general:
+        # like against like: both sides Gustavson-class products of arbitrary sparse operands (nothing assumed about A
+        # or M) -- not the fused tensor-pattern path against Gustavson
+        cpu_ext = extrapolate(allc)["DoF_per_s"]
+        like = dict(gpu_general, cpu_all_cores_extrapolated_DoF_per_s=cpu_ext, ratio=gpu_general["value"] / cpu_ext)
     return {"value": allc["ncp"] / allc["total_s"], "unit": "DoF/s", "cores": allc["threads"], "kind": "port",
+            "cpu_model": _cpu_model(), "nproc": os.cpu_count(), "gpu_general_path_over_cpu_gustavson": like,
             "sample": fmt(allc) + "; C+OpenMP restatement of the PETSc AIJ algorithms (oracle/tigar_oracle_c.c); inputs "
                       "%.2fs untimed" % allc["inputs_s"],
             "one_thread": {"value": one["ncp"] / one["total_s"], "unit": "DoF/s", "sample": fmt(one)},
@@ -628,6 +660,10 @@ def main():
                             "bytes_definition": "SURVEY.md 8d: 12 nnz(A) + 24 nnz(M) + 12 nnz(K) + row pointers, stage wall time"},
                    "sub_planes": res.get("sub_planes"),
                    "ranks": res["comm_world"], "communicator": res["comm_kind"],
+                   "communicator_requested": res.get("comm_requested"),
+                   "communicator_fallback": res.get("comm_fallback") or None,
+                   "devices_visible": res.get("devices_visible"), "device_of_rank": res.get("comm_devices"),
+                   "per_rank_stages_s": res.get("per_rank_stages"),
                    "parallelism": par},
         "roofline": {"bound": "hbm", "kernel": "%s (K u in %s)" % (kernel, res["method"].upper()), "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -683,11 +719,18 @@ def main():
                 return 2.2 * 12.0 * c["nnzA"] + 3.0 * 12.0 * c["nnzM"] + 8e9
             ladder = {2: (128, 96, 80), 3: (64, 48, 40), 4: (32, 24, 16)}.get(p, (16,))
             cpu_nel = args.cpu_nel or next((n for n in ladder if need(n) <= 0.6 * avail), ladder[-1])
-            one_nel = max(4, int(round(cpu_nel * 0.375)))       # (64 -> 24: a one-thread Gustavson product of a few seconds)
+            # one thread at three quarters of that edge (64 -> 48: BASELINE.md section 4's plan; the Gustavson intermediate
+            # is held in blocks there as well; ~35 s)
+            one_nel = max(4, int(round(cpu_nel * 0.75)))
         else:
             cpu_nel = args.cpu_nel or min(nel, 256)
             one_nel = max(4, cpu_nel // 2)
-        out["cpu_baseline"] = cpu_baseline(d, p, cpu_nel, one_nel, nel, res["iterations"])
+        gpu_general = None
+        gref = out["config"].get("general_path_reference", {})
+        for key in ("fully_general_hash_ptap_M_slabs_materialised",):
+            if key in gref:
+                gpu_general = {"value": gref[key]["value"], "unit": "DoF/s", "what": key, "source": gref[key]["source"]}
+        out["cpu_baseline"] = cpu_baseline(d, p, cpu_nel, one_nel, nel, res["iterations"], gpu_general)
     print(json.dumps(out), flush=True)
 
 

@@ -265,14 +265,22 @@ def device_comm(transport, kind=None):
         ndev = dev.device_count()
         local = int(os.environ.get("LOCAL_WORLD_SIZE", transport.world))
         kind = "rccl" if ndev >= local else "ipc"
+    requested = kind
+    notes = []               # why a communicator other than the requested one serves (kept on the object: bench lines quote it)
+
+    def done(comm):
+        comm.requested_kind, comm.fallback_notes = requested, list(notes)
+        return comm
     if kind == "host":
-        return dev.HostComm(transport)
+        return done(dev.HostComm(transport))
     selftest_s = float(os.environ.get("TIGAR_COMM_SELFTEST_S", "60"))
 
     def agreed(comm, err, what, fallback):
         bad = np.array([0.0 if comm is not None else 1.0])
         transport.allreduce_sum(bad)
         if bad[0] > 0.0:
+            notes.append("%s failed on %d rank(s)%s -> %s" % (what, int(bad[0]), (" (rank %d: %s)" % (transport.rank, err)) if err
+                                                             is not None else "", fallback))
             if transport.rank == 0:
                 print("[tigar_amd] %s communicator could not be created on %d rank(s) (%s); using the %s communicator"
                       % (what, int(bad[0]), err, fallback), file=sys.stderr, flush=True)
@@ -296,7 +304,7 @@ def device_comm(transport, kind=None):
                 comm, err = None, e
         comm = agreed(comm, err, "RCCL", "IPC")
         if comm is not None:
-            return comm
+            return done(comm)
     comm, err = None, None
     try:
         comm = dev.IpcComm(transport)
@@ -305,8 +313,8 @@ def device_comm(transport, kind=None):
         comm, err = None, e
     comm = agreed(comm, err, "IPC", "host-staged")
     if comm is not None:
-        return comm
-    return dev.HostComm(transport)
+        return done(comm)
+    return done(dev.HostComm(transport))
 
 
 def spawn_local(nproc, argv, env_extra=None, port=None):
