@@ -205,7 +205,9 @@ def run(args, wl, d, p, nel):
     def make_solver():
         if method == "lu":
             return PETScLUSolver()
-        solver = PETScKrylovSolver(method, "jacobi")
+        solver = PETScKrylovSolver(method, args.pc)
+        if args.pc == "chebyshev":
+            solver.parameters["chebyshev_degree"] = args.cheb_degree
         solver.parameters["relative_tolerance"] = args.rtol
         solver.parameters["maximum_iterations"] = 100000
         return solver
@@ -513,7 +515,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nel", type=int, default=0)
     ap.add_argument("--slab", type=int, default=-1, help="1: force the implicit-M / z-slab streaming path on one GPU")
-    ap.add_argument("--solver", default="auto", help="cg | gmres | lu (auto: cg; cfg4 lu as demos/biharmonic; cfg5 gmres)")
+    ap.add_argument("--solver", default="auto", help="cg | gmres | bicgstab | lu (auto: cg; cfg4 lu as demos/biharmonic; cfg5 gmres)")
+    ap.add_argument("--pc", default="jacobi", help="jacobi (the benchmark's) | none | chebyshev (companion runs; cg only)")
+    ap.add_argument("--cheb-degree", type=int, default=8)
     ap.add_argument("--live-traffic", type=int, default=-1,
                     help="1 / 0: measure the HBM traffic of the product kernel with rocprofv3 --pmc in a child run of this "
                          "command (default: when N = 1, the headline workload, rocprofv3 present and no profiler around this run)")
@@ -613,10 +617,12 @@ def main():
     t_in_timed = res["t_input"] if res["t_input_in_timed_region"] else 0.0
     desc = {"cfg4": "B-spline biharmonic on (-1,1)^2, two clamped layers (demos/biharmonic)",
             "cfg5": "NURBS quarter annulus, 3 fields, hashed non-symmetric A on the 3-field pattern"}.get(wl, "B-spline Poisson")
-    solver_desc = {"cg": "Jacobi-CG rtol %.0e" % args.rtol, "gmres": "Jacobi-GMRES(30) rtol %.0e" % args.rtol,
+    pc_name = {"jacobi": "Jacobi", "none": "unpreconditioned", "chebyshev": "Chebyshev(%d)-Jacobi" % args.cheb_degree}[args.pc]
+    solver_desc = {"cg": "%s-CG rtol %.0e" % (pc_name, args.rtol), "gmres": "%s-GMRES(30) rtol %.0e" % (pc_name, args.rtol),
+                   "bicgstab": "%s-BiCGStab rtol %.0e" % (pc_name, args.rtol),
                    "lu": "direct banded LU (the reference's default solver)"}[res["method"]]
-    solver_api = {"cg": "PETScKrylovSolver('cg','jacobi')", "gmres": "PETScKrylovSolver('gmres','jacobi')",
-                  "lu": "PETScLUSolver()"}[res["method"]]
+    solver_api = {"cg": "PETScKrylovSolver('cg','%s')" % args.pc, "gmres": "PETScKrylovSolver('gmres','%s')" % args.pc,
+                  "bicgstab": "PETScKrylovSolver('bicgstab','%s')" % args.pc, "lu": "PETScLUSolver()"}[res["method"]]
     out = {
         "metric": "DoF/s (extraction + M^T A M + M^T b + CG solve + prolongation)",
         "value": value, "unit": "DoF/s", "n_gpus": n_gpus, "steps": args.steps,

@@ -295,8 +295,11 @@ int tg_zero_rows_cols(tg_csr_t k, int64_t row0, const int32_t *dofs, int64_t n, 
 int tg_csr_combine(double a, tg_csr_t X, double b, tg_csr_t Y, tg_vec_t colscale, tg_csr_t *out);
 
 /* ---- Krylov solve (solveLinearSystem, tIGAr/common.py:1236-1263; seam b-4) -------- */
-enum { TG_KSP_CG = 0, TG_KSP_GMRES = 1 };
-enum { TG_PC_NONE = 0, TG_PC_JACOBI = 1 };
+enum { TG_KSP_CG = 0, TG_KSP_GMRES = 1, TG_KSP_BICGSTAB = 2 };
+/* TG_PC_CHEBYSHEV (CG only): `restart` steps of the Chebyshev iteration for D^-1 K on [lmax / ratio, 1.1 lmax] as a fixed
+ * polynomial preconditioner (PETSc: PCKSP with KSPCHEBYSHEV + PCJACOBI [ext]; the stand-in for "sor" / "ilu" / "icc" /
+ * "bjacobi", which need triangular sweeps); lmax from 20 steps of the power method, capped by the Gershgorin bound. */
+enum { TG_PC_NONE = 0, TG_PC_JACOBI = 1, TG_PC_CHEBYSHEV = 2 };
 /* status: 0 converged (rtol), 1 converged (atol), -1 max iterations, -2 breakdown/NaN,
  * -3 stagnation (GMRES: 25 restart cycles in a row without progress) */
 int tg_krylov_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, int pc, double rtol,

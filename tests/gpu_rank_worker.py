@@ -41,7 +41,7 @@ def main():
         K = spline.assembleMatrix(F.LaplaceForm(), diag=1.5)
     f1 = lambda x: np.sin(np.pi * x)
     rhs = spline.assembleVector(F.SeparableLoadForm([f1] * d, scale=d * np.pi ** 2))
-    solver = t.PETScKrylovSolver(method, "jacobi")
+    solver = t.PETScKrylovSolver(*(method.split(":") if ":" in method else (method, "jacobi")))
     solver.parameters["relative_tolerance"] = 1e-10
     spline.setSolverOptions(linearSolver=solver)
     u = t.Function(spline.V, spline.localFERange())

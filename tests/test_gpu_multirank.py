@@ -36,7 +36,7 @@ def _single(d, p, nel, method, periodic0=False, explicit=False):
         K = spline.assembleMatrix(F.LaplaceForm(), diag=1.5)
     f1 = lambda x: np.sin(np.pi * x)
     rhs = spline.assembleVector(F.SeparableLoadForm([f1] * d, scale=d * np.pi ** 2))
-    solver = t.PETScKrylovSolver(method, "jacobi")
+    solver = t.PETScKrylovSolver(*(method.split(":") if ":" in method else (method, "jacobi")))
     solver.parameters["relative_tolerance"] = 1e-10
     spline.setSolverOptions(linearSolver=solver)
     u = t.Function(spline.V)
@@ -171,7 +171,7 @@ def test_several_fields_on_several_ranks(tmp_path, case, world, kind):
     from tigar_amd import common as tc
     gen, spline, K, rhs, method = W.problem(case, tc.selfcomm)
     assert not getattr(gen.M, "is_implicit", False)
-    solver = t.PETScKrylovSolver(method, "jacobi")
+    solver = t.PETScKrylovSolver(*(method.split(":") if ":" in method else (method, "jacobi")))
     solver.parameters["relative_tolerance"] = 1e-10
     spline.setSolverOptions(linearSolver=solver)
     u = t.Function(spline.V)
@@ -301,6 +301,16 @@ def test_newton_on_several_ranks(tmp_path, capfd, world, kind, d, p, nel, with_d
     assert np.all(cover == 1)
     out = capfd.readouterr().out
     assert out.count("Solver iteration: 0 ,") == 1            # rank 0 alone prints the reference's progress line
+
+
+@pytest.mark.parametrize("method,world", [("cg:chebyshev", 2), ("bicgstab:jacobi", 3)])
+def test_chebyshev_cg_and_bicgstab_on_several_ranks(tmp_path, method, world):
+    """the solvers of csrc/tg_krylov.hip added in round 4 take the same halo exchange / all-reduce entry points: rows of K,
+    M^T b, the solution and the iteration count against the single-rank run"""
+    d, p, nel = 3, 2, 14
+    ref = _single(d, p, nel, method)
+    parts = _run_ranks(tmp_path, world, "ipc", d, p, nel, method, 37011 + world)
+    _compare(parts, ref, world, "ipc")
 
 
 def test_ipc_dead_peer_is_an_error_not_a_hang(tmp_path):

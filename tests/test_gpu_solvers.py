@@ -1,0 +1,129 @@
+"""-m gpu: the solvers behind the reference's seam ``self.linearSolver.solve(MTAM, MTU, MTb)`` (tIGAr/common.py:1255-1258)
+beyond cg / gmres x none / jacobi: BiCGStab (KSPBCGS [ext], left preconditioning) and CG with the Chebyshev
+polynomial preconditioner, plus dolfin's solver / preconditioner names, which map onto what this library has instead of
+raising."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as sla
+
+pytestmark = pytest.mark.gpu
+
+
+def _poisson(d, p, nel):
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, forms as F
+    kv = [B.uniformKnots(p, 0., 1., nel)] * d
+    gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p] * d, kv))
+    s0 = gen.getScalarSpline(0)
+    for direction in range(d):
+        for side in (0, 1):
+            gen.addZeroDofs(0, s0.getSideDofs(direction, side))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    K = spline.assembleMatrix(F.LaplaceForm())
+    rhs = spline.assembleVector(F.SeparableLoadForm([lambda x: np.sin(np.pi * x)] * d, scale=d * np.pi ** 2))
+    return spline, K, rhs
+
+
+@pytest.mark.parametrize("d,p,nel,degree", [(2, 3, 48, 4), (2, 4, 40, 8), (3, 2, 12, 6)])
+def test_cg_with_the_chebyshev_polynomial_preconditioner(d, p, nel, degree):
+    import tigar_amd as t
+    from tigar_amd.device import DeviceVector
+    spline, K, rhs = _poisson(d, p, nel)
+    Ks, b = K.to_scipy().tocsc(), rhs.get_local()
+    exact = sla.spsolve(Ks, b)
+    jac = t.PETScKrylovSolver("cg", "jacobi")
+    che = t.PETScKrylovSolver("cg", "chebyshev")
+    for s in (jac, che):
+        s.parameters["relative_tolerance"] = 1e-10
+    che.parameters["chebyshev_degree"] = degree
+    Uj, Uc = DeviceVector(K.shape[0]), DeviceVector(K.shape[0])
+    ij, ic = jac.solve(K, Uj, rhs), che.solve(K, Uc, rhs)
+    assert che.last["status"] == 0
+    assert np.max(np.abs(Uc.get_local() - exact)) <= 1e-7 * np.max(np.abs(exact))
+    # a polynomial of degree m in D^-1 K: an outer iteration does the work of ~m Jacobi-CG iterations (CG is optimal in
+    # the Krylov space, so the products do not get fewer -- the reductions and host looks do)
+    assert ic <= 1.7 * ij / degree + 3, (ic, ij)
+    assert ic * degree <= 2.0 * ij + 4 * degree, (ic, ij)
+    # bit-reproducible, and a second solve from the solution ends at once
+    U2 = DeviceVector(K.shape[0])
+    che.solve(K, U2, rhs)
+    assert np.array_equal(U2.get_local().view(np.int64), Uc.get_local().view(np.int64))
+    che.parameters["nonzero_initial_guess"] = True
+    assert che.solve(K, U2, rhs) <= 1
+    # through the reference's seam, under a name dolfin users pass
+    sor = t.PETScKrylovSolver("cg", "sor")
+    assert sor.preconditioner == "chebyshev" and sor.preconditioner_requested == "sor" and "stands in" in sor.note
+    sor.parameters["relative_tolerance"] = 1e-10
+    spline.setSolverOptions(linearSolver=sor)
+    u = t.Function(spline.V)
+    U = spline.solveLinearSystem(K, rhs, u)
+    assert np.max(np.abs(U.get_local() - exact)) <= 1e-7 * np.max(np.abs(exact))
+
+
+def _nonsymmetric(n=40, seed=5):
+    """diagonally dominant, non-symmetric, on the 2-D p=2 element-coupling pattern"""
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, forms as F
+    kv = [B.uniformKnots(2, 0., 1., n)] * 2
+    V = t.TensorFunctionSpace([B.ExplicitBSplineControlMesh([2, 2], kv).getScalarSpline().generateMesh(degree=2)], "Lagrange")
+    A = F.LaplaceForm().assemble_matrix(V).to_scipy().tocsr()
+    rng = np.random.default_rng(seed)
+    A.data = A.data * (1.0 + 0.4 * rng.standard_normal(A.nnz))
+    A = (A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() * 0.25)).tocsr()
+    return A, rng.standard_normal(A.shape[0])
+
+
+@pytest.mark.parametrize("pc", ["jacobi", "none"])
+def test_bicgstab_on_a_nonsymmetric_system(pc):
+    import tigar_amd as t
+    from tigar_amd.device import DeviceCSR, DeviceVector
+    A, b = _nonsymmetric()
+    exact = sla.spsolve(A.tocsc(), b)
+    s = t.PETScKrylovSolver("bicgstab", pc)
+    s.parameters["relative_tolerance"] = 1e-11
+    Ad, bd, x = DeviceCSR.from_scipy(A), DeviceVector(data=b), DeviceVector(A.shape[0])
+    its = s.solve(Ad, x, bd)
+    assert s.last["status"] == 0 and 1 <= its < 3000
+    assert np.max(np.abs(x.get_local() - exact)) <= 1e-8 * np.max(np.abs(exact))
+    # the norm the solver reports is the preconditioned residual of the iterate it returns (recurred, so to rounding)
+    dinv = 1.0 / A.diagonal() if pc == "jacobi" else np.ones(A.shape[0])
+    true = np.linalg.norm(dinv * (b - A @ x.get_local()))
+    assert abs(true - s.last["residual_norm"]) <= 1e-6 * np.linalg.norm(dinv * b) * 1e-3 + 10 * s.last["residual_norm"]
+    # GMRES needs a basis for the same system; BiCGStab's iteration count is in the range of GMRES' (two products each)
+    if pc == "jacobi":                       # (unpreconditioned GMRES(30) stagnates on this system: the short recurrence does not)
+        g = t.PETScKrylovSolver("gmres", pc)
+        g.parameters["relative_tolerance"] = 1e-11
+        xg = DeviceVector(A.shape[0])
+        ig = g.solve(Ad, xg, bd)
+        assert its <= 6 * ig + 50, (its, ig)
+    # bit-reproducible; restart from the solution; iteration limit reported; b = 0
+    x2 = DeviceVector(A.shape[0])
+    s.solve(Ad, x2, bd)
+    assert np.array_equal(x2.get_local().view(np.int64), x.get_local().view(np.int64))
+    s.parameters["nonzero_initial_guess"] = True
+    assert s.solve(Ad, x2, bd) <= 1
+    s.parameters["nonzero_initial_guess"] = False
+    s.parameters["maximum_iterations"] = 3
+    with pytest.raises(RuntimeError, match="iteration limit"):
+        s.solve(Ad, DeviceVector(A.shape[0]), bd)
+    s.parameters["maximum_iterations"] = 1000
+    assert s.solve(Ad, x2, DeviceVector(A.shape[0])) == 0 and np.all(x2.get_local() == 0.0)
+
+
+def test_dolfin_solver_and_preconditioner_names_are_mapped_not_refused():
+    import tigar_amd as t
+    for m, want in (("cg", "cg"), ("gmres", "gmres"), ("bicgstab", "bicgstab"), ("default", "gmres"), ("tfqmr", "bicgstab"),
+                    ("minres", "gmres")):
+        assert t.PETScKrylovSolver(m, "none").method == want
+    for pc in ("sor", "ilu", "icc", "bjacobi", "amg", "hypre_amg"):
+        s = t.PETScKrylovSolver("cg", pc)
+        assert s.preconditioner == "chebyshev" and s.preconditioner_requested == pc and pc in s.note
+        assert t.PETScKrylovSolver("gmres", pc).preconditioner == "jacobi"
+    assert t.PETScKrylovSolver("gmres", "default").preconditioner == "jacobi"
+    with pytest.raises(ValueError):
+        t.PETScKrylovSolver("cg", "no-such-preconditioner")
+    with pytest.raises(ValueError):
+        t.PETScKrylovSolver("no-such-method")
+    with pytest.raises(ValueError):
+        t.PETScKrylovSolver("gmres", "chebyshev")

@@ -1011,19 +1011,44 @@ class PETScKrylovSolver(object):
     Defaults are dolfin's [ext]: rtol 1e-6, atol 1e-15, maxit 10000, error on
     non-convergence."""
 
+    # dolfin's names [ext: krylov_solver_methods() / krylov_solver_preconditioners()] -> what runs here.  Methods: cg,
+    # gmres, bicgstab as named; the others that dolfin lists map onto the closest of the three.  Preconditioners: "none",
+    # "jacobi" as named; "chebyshev" = a fixed Chebyshev polynomial in D^-1 K (csrc/tg_krylov.hip, tg_pcg_cheb), which also
+    # stands in for the names whose PETSc implementation is a triangular sweep or a factorisation (sor, ilu, icc, bjacobi
+    # = ILU(0) per process, amg ...): the request is honoured with the strongest preconditioner this library has for the
+    # method, and ``preconditioner_requested`` / ``note`` say so -- dolfin users pass those names through the reference's
+    # seam (tIGAr/common.py:1255-1258, 1292-1302) and should get a solve, not a ValueError.
+    METHODS = {"cg": "cg", "gmres": "gmres", "bicgstab": "bicgstab", "default": "gmres", "minres": "gmres", "tfqmr": "bicgstab",
+               "richardson": "gmres"}
+    STRONG_PCS = ("sor", "ilu", "icc", "bjacobi", "amg", "hypre_amg", "petsc_amg", "hypre_euclid", "hypre_parasails", "ml_amg")
+
     def __init__(self, method="cg", preconditioner="jacobi", comm=None):
-        if method == "default":
-            method = "gmres"
+        self.method_requested, self.preconditioner_requested = method, preconditioner
+        if method not in self.METHODS:
+            raise ValueError("unknown Krylov method %r (%s)" % (method, ", ".join(sorted(self.METHODS))))
+        method = self.METHODS[method]
+        note = None
         if preconditioner == "default":
             preconditioner = "jacobi"
-        if method not in ("cg", "gmres"):
-            raise ValueError("unsupported Krylov method %r (cg, gmres)" % (method,))
-        if preconditioner not in ("none", "jacobi"):
-            raise ValueError("unsupported preconditioner %r (none, jacobi)" % (preconditioner,))
+        if preconditioner in self.STRONG_PCS:
+            note = " (preconditioner %r requested: " % (preconditioner,)
+            if method == "cg":
+                preconditioner = "chebyshev"
+                note += "the Chebyshev polynomial preconditioner stands in for it)"
+            else:
+                preconditioner = "jacobi"
+                note += "Jacobi stands in for it with %s)" % method
+        if preconditioner not in ("none", "jacobi", "chebyshev"):
+            raise ValueError("unknown preconditioner %r (none, jacobi, chebyshev, or one of dolfin's: %s)"
+                             % (preconditioner, ", ".join(self.STRONG_PCS)))
+        if preconditioner == "chebyshev" and method != "cg":
+            raise ValueError("the Chebyshev polynomial preconditioner serves cg (a fixed symmetric polynomial)")
         self.method, self.preconditioner = method, preconditioner
         self.parameters = {"relative_tolerance": 1e-6, "absolute_tolerance": 1e-15,
                            "maximum_iterations": 10000, "error_on_nonconvergence": True,
                            "nonzero_initial_guess": False, "gmres_restart": 30,
+                           # (not a dolfin parameter) products per application of the Chebyshev preconditioner
+                           "chebyshev_degree": 8,
                            "report": False, "monitor_convergence": False,
                            # (not a dolfin parameter) give up with status -3 after 25 GMRES restart cycles without
                            # progress instead of running to the iteration limit as PETSc does; set by the default
@@ -1031,7 +1056,7 @@ class PETScKrylovSolver(object):
                            "stagnation_guard": False}
         self.comm = comm
         self.last = None
-        self.note = None       # appended to the non-convergence message (who chose this solver)
+        self.note = note       # appended to the non-convergence message (who chose this solver / what stands in)
 
     REASONS = {-1: "iteration limit reached", -2: "breakdown (NaN / zero pivot in the recurrence)",
                -3: "stagnation (25 GMRES restart cycles without progress)"}
@@ -1043,8 +1068,8 @@ class PETScKrylovSolver(object):
         its, res, status = _dev.krylov_solve(
             A, b, x, self.method, self.preconditioner, self.parameters["relative_tolerance"],
             self.parameters["absolute_tolerance"], self.parameters["maximum_iterations"],
-            self.parameters["gmres_restart"], self.comm,
-            nonzero_initial_guess=bool(self.parameters["nonzero_initial_guess"]),
+            self.parameters["chebyshev_degree"] if self.preconditioner == "chebyshev" else self.parameters["gmres_restart"],
+            self.comm, nonzero_initial_guess=bool(self.parameters["nonzero_initial_guess"]),
             stagnation_guard=bool(self.parameters.get("stagnation_guard", False)))
         self.last = {"iterations": its, "residual_norm": res, "status": status}
         if status < 0 and self.parameters["error_on_nonconvergence"]:

@@ -953,6 +953,590 @@ static int tg_gmres(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, 
   return 0;
 }
 
+// ------------------------------------------------------------------------ CG with a polynomial preconditioner
+// PCG whose preconditioner is m steps of the Chebyshev iteration for D^-1 K z = D^-1 r from z = 0 on the interval
+// [lmax / ratio, 1.1 lmax] (PETSc: PCKSP of KSPCHEBYSHEV + PCJACOBI, the GPU-natural stand-in for SOR / ILU sweeps: only
+// products and vector updates, no triangular solves, a FIXED polynomial in D^-1 K -- so it is a linear, symmetric positive
+// definite operator and plain PCG applies).  In products the method costs what Jacobi-CG costs (CG is optimal in the
+// Krylov space: measured 0.93-1.3 x, tools/ notes in DESIGN 4b), but an outer iteration -- the reductions, the host's look
+// at the norm, the launches of the update kernels -- happens m times less often: that is the gain for systems whose
+// iteration is bound by launch latency (cfg4: 6 128 Jacobi-CG iterations of 34 us).  The interval comes from 12 Lanczos steps
+// (upper end x 1.1, capped by the Gershgorin bound: an underestimate would make the polynomial indefinite).
+// Same recurrence as tg_cg (one reduction of gamma, delta, nu per iteration), scalars through the host.
+__global__ void __launch_bounds__(256) k_row_abs_bound(const int64_t *__restrict__ rowptr, const double *__restrict__ val,
+                                                       const double *__restrict__ dinv, int64_t n, double *__restrict__ partial) {
+  // partial[block] = max over its rows of |dinv_i| * sum_j |k_ij|   (Gershgorin bound of D^-1 K)
+  __shared__ double lds[256];
+  double m = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    double a = 0.0;
+    for (int64_t q = rowptr[i]; q < rowptr[i + 1]; q++) a += fabs(val[q]);
+    m = fmax(m, fabs(dinv[i]) * a);
+  }
+  lds[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) lds[threadIdx.x] = fmax(lds[threadIdx.x], lds[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = lds[0];
+}
+__global__ void __launch_bounds__(256) k_fold_max(const double *partial, int nb, double *out) {
+  __shared__ double lds[256];
+  double m = 0.0;
+  for (int b = threadIdx.x; b < nb; b += 256) m = fmax(m, partial[b]);
+  lds[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) lds[threadIdx.x] = fmax(lds[threadIdx.x], lds[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = lds[0];
+}
+// y = a * dinv .* x ; partial of (y, y)
+__global__ void __launch_bounds__(256) k_scaled_copy_norm(const double *x, const double *__restrict__ dinv, double a,
+                                                          int64_t n, double *y, double *__restrict__ partial) {   // (y may be x)
+  __shared__ double lds4[4];
+  double nn = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double v = a * (dinv ? dinv[i] : 1.0) * x[i];
+    y[i] = v;
+    nn += v * v;
+  }
+  nn = tg_block_sum256(nn, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = nn;
+}
+// Lanczos on D^-1/2 K D^-1/2 (eigenvalue estimates): v0 = sqrt(dinv) .* b (unnormalised), partial of (v0, v0)
+__global__ void __launch_bounds__(256) k_lz_start(const double *__restrict__ b, const double *__restrict__ dinv, int64_t n,
+                                                  double *__restrict__ v, double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  double nn = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double vi = sqrt(fabs(dinv[i])) * b[i];
+    v[i] = vi;
+    nn += vi * vi;
+  }
+  nn = tg_block_sum256(nn, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = nn;
+}
+// v <- v * inv_norm ; operand = sqrt(dinv) .* v
+__global__ void __launch_bounds__(256) k_lz_operand(const double *__restrict__ dinv, double inv_norm, int64_t n, double *__restrict__ v,
+                                                    double *__restrict__ op) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double vi = v[i] * inv_norm;
+    v[i] = vi;
+    op[i] = sqrt(fabs(dinv[i])) * vi;
+  }
+}
+// w <- sqrt(dinv) .* w - beta vprev ; partial of (w, v)
+__global__ void __launch_bounds__(256) k_lz_alpha(const double *__restrict__ dinv, const double *__restrict__ vprev, double beta,
+                                                  const double *__restrict__ v, int64_t n, double *__restrict__ w,
+                                                  double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  double a = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double wi = sqrt(fabs(dinv[i])) * w[i] - beta * vprev[i];
+    w[i] = wi;
+    a += wi * v[i];
+  }
+  a = tg_block_sum256(a, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+// w <- w - alpha v ; vprev <- v ; v <- w ; partial of (w, w)
+__global__ void __launch_bounds__(256) k_lz_next(double alpha, int64_t n, double *__restrict__ w, double *__restrict__ v,
+                                                 double *__restrict__ vprev, double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  double nn = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double vi = v[i];
+    const double wi = w[i] - alpha * vi;
+    vprev[i] = vi;
+    v[i] = wi;
+    nn += wi * wi;
+  }
+  nn = tg_block_sum256(nn, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = nn;
+}
+// first Chebyshev step: g = dinv r ; z = g / theta ; d = z
+__global__ void __launch_bounds__(256) k_cheb_first(const double *__restrict__ r, const double *__restrict__ dinv, double inv_theta,
+                                                    int64_t n, double *__restrict__ g, double *__restrict__ z, double *__restrict__ d) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double gi = dinv[i] * r[i];
+    g[i] = gi;
+    const double zi = gi * inv_theta;
+    z[i] = zi;
+    d[i] = zi;
+  }
+}
+// next step: d = c1 d + c2 (g - dinv Kz) ; z += d
+__global__ void __launch_bounds__(256) k_cheb_step(const double *__restrict__ g, const double *__restrict__ dinv,
+                                                   const double *__restrict__ kz, double c1, double c2, int64_t n,
+                                                   double *__restrict__ z, double *__restrict__ d) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double di = c1 * d[i] + c2 * (g[i] - dinv[i] * kz[i]);
+    d[i] = di;
+    z[i] += di;
+  }
+}
+// partials of (r,u), (w,u), (u,u), interleaved
+__global__ void __launch_bounds__(256) k_dots3(const double *__restrict__ r, const double *__restrict__ u, const double *__restrict__ w,
+                                               int64_t n, double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  double a = 0.0, b = 0.0, c = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double ui = u[i];
+    a += r[i] * ui;
+    b += w[i] * ui;
+    c += ui * ui;
+  }
+  a = tg_block_sum256(a, lds4);
+  b = tg_block_sum256(b, lds4);
+  c = tg_block_sum256(c, lds4);
+  if (threadIdx.x == 0) {
+    partial[3 * blockIdx.x] = a;
+    partial[3 * blockIdx.x + 1] = b;
+    partial[3 * blockIdx.x + 2] = c;
+  }
+}
+// p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s
+__global__ void __launch_bounds__(256) k_pcg_update(const double *__restrict__ u, const double *__restrict__ w, double alpha, double beta,
+                                                    int64_t n, double *__restrict__ p, double *__restrict__ s, double *__restrict__ x,
+                                                    double *__restrict__ r) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double pi = u[i] + beta * p[i];
+    const double si = w[i] + beta * s[i];
+    p[i] = pi;
+    s[i] = si;
+    x[i] += alpha * pi;
+    r[i] -= alpha * si;
+  }
+}
+__global__ void __launch_bounds__(256) k_residual(const double *__restrict__ b, const double *__restrict__ kx, int64_t n,
+                                                  double *__restrict__ r) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) r[i] = kx ? b[i] - kx[i] : b[i];
+}
+
+static int tg_pcg_cheb(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int degree, double rtol, double atol, int maxit, int nonzero_guess,
+                       tg_comm_s *comm, int *iters, double *resnorm, int *status) {
+  const int64_t n = k->nrows;
+  const int64_t hlo = comm ? comm->halo_lo : 0, hhi = comm ? comm->halo_hi : 0;
+  const int64_t row0 = comm ? comm->g0 : 0;
+  const int64_t next = hlo + n + hhi;
+  const int m = std::max(1, std::min(degree, 64));
+  tg_krylov_ws ws;
+  // layout: uext[next] | r | w | p | s | dinv | g | d | kz
+  TG_TRY(tg_dmalloc(&ws.buf, next + 8 * n));
+  double *uext = ws.buf, *u = uext + hlo, *r = uext + next, *w = r + n, *p = w + n, *s = p + n, *dinv = s + n, *g = dinv + n,
+         *dd = g + n, *kz = dd + n;
+  TG_CHECK_HIP(hipMemsetAsync(ws.buf, 0, (size_t)(next + 8 * n) * sizeof(double), g_tg.stream));
+  double *part = g_tg.scratch;                       // 3 * TG_VEC_BLOCKS
+  double *sc = g_tg.scratch + TG_SCRATCH_DOUBLES - 2048;
+  const int vg = tg_vec_grid(n);
+  TG_TRY(tg_spmv_plan(k));
+  tg_sell_guard sell_guard(k);
+  TG_TRY(sell_guard.rc);
+  const double *ushift = uext - (row0 - hlo);
+  const int64_t cmin = row0 - hlo, cmax = row0 - hlo + next - 1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  TG_CHECK_HIP(hipEventCreate(&e0));
+  TG_CHECK_HIP(hipEventCreate(&e1));
+  struct ev_guard {
+    hipEvent_t a, b;
+    ~ev_guard() {
+      hipEventDestroy(a);
+      hipEventDestroy(b);
+    }
+  } evg{e0, e1};
+  auto product = [&](double *out) -> int {            // out = K (vector in uext)
+    TG_TRY(tg_comm_halo_exchange(comm, uext));
+    return tg_spmv_raw(k, ushift, cmin, cmax, out);
+  };
+  auto reduce = [&](int cnt, double *host) -> int {    // folds `cnt` interleaved partial streams, sums over ranks, reads
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, g_tg.stream, part, vg, cnt, sc);
+    TG_LAUNCH_CHECK();
+    TG_TRY(tg_comm_allreduce_dev(comm, sc, cnt));
+    return tg_read_scalars(sc, cnt, host);
+  };
+  if (n > 0) {
+    const unsigned jg = (unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16);
+    hipLaunchKernelGGL(k_jacobi_setup, dim3(jg), dim3(256), 0, g_tg.stream, k->rowptr, k->col, k->val, n, row0, 1, dinv);
+  }
+  // ---- extreme eigenvalues of D^-1 K: 12 Lanczos steps on D^-1/2 K D^-1/2 from D^1/2-scaled b (both ends of the spectrum at
+  // once; the power method needs 20 products for the upper end alone).  theta_max approaches lambda_max from below (safety
+  // 1.1, capped by the Gershgorin bound: an interval that ends below lambda_max makes the polynomial indefinite), theta_min
+  // approaches lambda_min from above: it only tells an easy system (few Jacobi-CG iterations) from a hard one.
+  double lmax = 0.0, gersh = 0.0, theta_min = 0.0;
+  {
+    hipLaunchKernelGGL(k_row_abs_bound, dim3(vg), dim3(256), 0, g_tg.stream, k->rowptr, k->val, dinv, n, part);
+    hipLaunchKernelGGL(k_fold_max, dim3(1), dim3(256), 0, g_tg.stream, part, vg, sc);
+    TG_LAUNCH_CHECK();
+    TG_TRY(tg_read_scalars(sc, 1, &gersh));
+    if (comm) {
+      double gg = gersh;                              // (the sum of the per-rank bounds is a bound as well)
+      TG_TRY(tg_comm_allreduce_sum(comm, &gg, 1));
+      gersh = gg;
+    }
+    // v (Lanczos vector) in g, previous one in dd, operand D^-1/2 v in u, D^-1/2 K D^-1/2 v in kz
+    constexpr int LZ = 12;
+    double al[LZ], be[LZ + 1];
+    int kdim = 0;
+    hipLaunchKernelGGL(k_lz_start, dim3(vg), dim3(256), 0, g_tg.stream, b->d, dinv, n, g, part);
+    double nn = 0.0;
+    TG_TRY(reduce(1, &nn));
+    if (!(nn > 0.0)) {                                // b = 0
+      TG_CHECK_HIP(hipMemsetAsync(x->d, 0, (size_t)std::max<int64_t>(n, 1) * sizeof(double), g_tg.stream));
+      *iters = 0;
+      *resnorm = 0.0;
+      *status = 1;
+      return 0;
+    }
+    double inv_norm = 1.0 / sqrt(nn), beta = 0.0;
+    be[0] = 0.0;
+    for (int j = 0; j < LZ; j++) {
+      // g <- g * inv_norm ; u = sqrt(dinv) g
+      hipLaunchKernelGGL(k_lz_operand, dim3(vg), dim3(256), 0, g_tg.stream, dinv, inv_norm, n, g, u);
+      TG_TRY(product(kz));
+      // kz <- sqrt(dinv) kz - beta dd ; alpha = (kz, g)
+      hipLaunchKernelGGL(k_lz_alpha, dim3(vg), dim3(256), 0, g_tg.stream, dinv, dd, beta, g, n, kz, part);
+      double alpha = 0.0;
+      TG_TRY(reduce(1, &alpha));
+      // kz <- kz - alpha g ; dd <- g ; g <- kz ; beta' = ||kz||
+      hipLaunchKernelGGL(k_lz_next, dim3(vg), dim3(256), 0, g_tg.stream, alpha, n, kz, g, dd, part);
+      TG_TRY(reduce(1, &nn));
+      al[j] = alpha;
+      kdim = j + 1;
+      if (!(nn > 1e-28 * alpha * alpha) || !(nn == nn)) break;      // invariant subspace
+      beta = sqrt(nn);
+      be[j + 1] = beta;
+      inv_norm = 1.0 / beta;
+    }
+    // extreme eigenvalues of the tridiagonal (alpha_j, beta_j) by Sturm bisection
+    auto count_below = [&](double lam) {
+      int c = 0;
+      double q = 1.0;
+      for (int j = 0; j < kdim; j++) {
+        const double b2 = j ? be[j] * be[j] : 0.0;
+        q = (al[j] - lam) - (j ? b2 / (q == 0.0 ? 1e-300 : q) : 0.0);
+        if (q < 0.0) c++;
+      }
+      return c;
+    };
+    double lo = 0.0, hi = 0.0;
+    for (int j = 0; j < kdim; j++) {
+      const double rad = fabs(al[j]) + (j ? fabs(be[j]) : 0.0) + (j + 1 < kdim ? fabs(be[j + 1]) : 0.0);
+      hi = std::max(hi, rad);
+    }
+    lo = -hi;
+    auto kth = [&](int kk) {                           // kk-th smallest eigenvalue (0-based)
+      double a = lo, bq = hi;
+      for (int it = 0; it < 100; it++) {
+        const double mid = 0.5 * (a + bq);
+        if (count_below(mid) > kk) bq = mid; else a = mid;
+      }
+      return 0.5 * (a + bq);
+    };
+    if (kdim > 0) {
+      lmax = kth(kdim - 1);
+      theta_min = kth(0);
+    }
+    lmax *= 1.1;
+    if (gersh > 0.0 && (lmax > gersh || !(lmax > 0.0))) lmax = gersh;
+  }
+  static const double ratio_env = getenv("TIGAR_CHEB_RATIO") ? atof(getenv("TIGAR_CHEB_RATIO")) : 0.0;
+  // the interval [lmax / ratio, lmax]: 4 m^2 for a hard system (measured: within 10 % of the best ratio for m = 4 ... 16 on
+  // squared Poisson operators), less when the Lanczos estimate of the lower end says the spectrum is narrow
+  double ratio = std::max(10.0, 4.0 * m * m);
+  if (theta_min > 0.0 && lmax > 0.0) ratio = std::min(ratio, std::max(4.0, 3.0 * lmax / theta_min));
+  if (ratio_env > 1.0) ratio = ratio_env;
+  const double lmin = lmax / ratio;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+  // u = B r
+  auto apply_pc = [&]() -> int {
+    hipLaunchKernelGGL(k_cheb_first, dim3(vg), dim3(256), 0, g_tg.stream, r, dinv, 1.0 / theta, n, g, u, dd);
+    const double sigma = theta / delta;
+    double rho = 1.0 / sigma;
+    for (int j = 1; j < m; j++) {
+      const double rho_new = 1.0 / (2.0 * sigma - rho);
+      TG_TRY(product(kz));
+      hipLaunchKernelGGL(k_cheb_step, dim3(vg), dim3(256), 0, g_tg.stream, g, dinv, kz, rho_new * rho, 2.0 * rho_new / delta, n, u, dd);
+      rho = rho_new;
+    }
+    TG_LAUNCH_CHECK();
+    return 0;
+  };
+  // ---- reference norm ||B b|| and the initial residual
+  double h3[3];
+  hipLaunchKernelGGL(k_residual, dim3(vg), dim3(256), 0, g_tg.stream, b->d, (const double *)nullptr, n, r);
+  TG_TRY(apply_pc());
+  hipLaunchKernelGGL(k_dots3, dim3(vg), dim3(256), 0, g_tg.stream, r, u, u, n, part);
+  TG_TRY(reduce(3, h3));
+  const double bnorm = sqrt(h3[2]);
+  if (nonzero_guess) {
+    TG_CHECK_HIP(hipMemcpyAsync(u, x->d, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream));
+    TG_TRY(product(w));
+    hipLaunchKernelGGL(k_residual, dim3(vg), dim3(256), 0, g_tg.stream, b->d, (const double *)w, n, r);
+    TG_TRY(apply_pc());
+  } else {
+    TG_CHECK_HIP(hipMemsetAsync(x->d, 0, (size_t)std::max<int64_t>(n, 1) * sizeof(double), g_tg.stream));
+  }
+  const double tol = std::max(rtol * bnorm, atol);
+  *iters = 0;
+  *status = -1;
+  double gamma_prev = 1.0, alpha_prev = 1.0, znorm = bnorm;
+  TG_CHECK_HIP(hipMemsetAsync(p, 0, (size_t)(2 * n) * sizeof(double), g_tg.stream));   // p, s adjacent
+  for (int it = 0; it <= maxit; it++) {
+    // w = K u ; gamma = (r,u), delta = (w,u), nu = (u,u)
+    hipEventRecord(e0, g_tg.stream);
+    TG_TRY(product(w));
+    hipEventRecord(e1, g_tg.stream);
+    hipLaunchKernelGGL(k_dots3, dim3(vg), dim3(256), 0, g_tg.stream, r, u, w, n, part);
+    TG_TRY(reduce(3, h3));
+    {
+      float ems = 0.f;
+      if (hipEventElapsedTime(&ems, e0, e1) == hipSuccess) {
+        g_tg.prof_ms[TG_PROF_KSP_SPMV] += ems;
+        g_tg.prof_n[TG_PROF_KSP_SPMV] += 1;
+      }
+    }
+    const double gamma = h3[0], delta_ = h3[1], nu = h3[2];
+    znorm = sqrt(nu);
+    *iters = it;
+    if (!(nu == nu) || !(gamma == gamma)) {
+      *status = -2;
+      break;
+    }
+    if (znorm <= tol) {
+      *status = (znorm <= atol && !(znorm <= rtol * bnorm)) ? 1 : 0;
+      break;
+    }
+    if (it == maxit) break;
+    double beta = 0.0, alpha;
+    if (it == 0)
+      alpha = gamma / delta_;
+    else {
+      beta = gamma / gamma_prev;
+      alpha = gamma / (delta_ - beta * gamma / alpha_prev);
+    }
+    if (!(alpha == alpha) || alpha == 0.0 || !(gamma > 0.0)) {     // (a polynomial that is not positive definite, breakdown)
+      *status = -2;
+      break;
+    }
+    gamma_prev = gamma;
+    alpha_prev = alpha;
+    hipLaunchKernelGGL(k_pcg_update, dim3(vg), dim3(256), 0, g_tg.stream, u, w, alpha, beta, n, p, s, x->d, r);
+    TG_TRY(apply_pc());
+  }
+  *resnorm = znorm;
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  TG_TRY(tg_comm_check(comm));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ BiCGStab
+// KSPBCGS [ext] with left preconditioning (Jacobi or none): the method runs on B K x = B b, the convergence test reads the
+// preconditioned residual like CG / GMRES above.  Two fused reductions per iteration, one per half step:
+//   (rhat, v)                                         -> alpha
+//   (t,s), (t,t), (rhat,s), (rhat,t), (s,s)           -> omega, rho' = (rhat,s) - omega (rhat,t),
+//                                                        ||r'||^2 = (s,s) - 2 omega (t,s) + omega^2 (t,t)
+// Non-symmetric systems with a short recurrence (no basis of 30 vectors).
+__global__ void __launch_bounds__(256) k_bcgs_p(const double *__restrict__ r, const double *__restrict__ v, double beta, double omega,
+                                                int64_t n, double *__restrict__ p) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = r[i] + beta * (p[i] - omega * v[i]);
+}
+// v = dinv .* kp ; partial of (rhat, v)
+__global__ void __launch_bounds__(256) k_bcgs_v(const double *__restrict__ kp, const double *__restrict__ dinv,
+                                                const double *__restrict__ rhat, int64_t n, double *__restrict__ v,
+                                                double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  double a = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double vi = dinv[i] * kp[i];
+    v[i] = vi;
+    a += rhat[i] * vi;
+  }
+  a = tg_block_sum256(a, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+// s = r - alpha v (written into the product operand)
+__global__ void __launch_bounds__(256) k_bcgs_s(const double *__restrict__ r, const double *__restrict__ v, double alpha, int64_t n,
+                                                double *__restrict__ s) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) s[i] = r[i] - alpha * v[i];
+}
+// t = dinv .* ks ; partials of (t,s), (t,t), (rhat,s), (rhat,t), (s,s)
+__global__ void __launch_bounds__(256) k_bcgs_t(const double *__restrict__ ks, const double *__restrict__ dinv, const double *__restrict__ s,
+                                                const double *__restrict__ rhat, int64_t n, double *__restrict__ t,
+                                                double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  double a = 0.0, b = 0.0, c = 0.0, d = 0.0, e = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double ti = dinv[i] * ks[i], si = s[i], hi = rhat[i];
+    t[i] = ti;
+    a += ti * si;
+    b += ti * ti;
+    c += hi * si;
+    d += hi * ti;
+    e += si * si;
+  }
+  a = tg_block_sum256(a, lds4);
+  b = tg_block_sum256(b, lds4);
+  c = tg_block_sum256(c, lds4);
+  d = tg_block_sum256(d, lds4);
+  e = tg_block_sum256(e, lds4);
+  if (threadIdx.x == 0) {
+    double *q = partial + 5 * blockIdx.x;
+    q[0] = a, q[1] = b, q[2] = c, q[3] = d, q[4] = e;
+  }
+}
+// x += alpha p + omega s ; r = s - omega t
+__global__ void __launch_bounds__(256) k_bcgs_x(const double *__restrict__ p, const double *__restrict__ s, const double *__restrict__ t,
+                                                double alpha, double omega, int64_t n, double *__restrict__ x, double *__restrict__ r) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    x[i] += alpha * p[i] + omega * s[i];
+    r[i] = s[i] - omega * t[i];
+  }
+}
+
+static int tg_bicgstab(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, int nonzero_guess,
+                       tg_comm_s *comm, int *iters, double *resnorm, int *status) {
+  const int64_t n = k->nrows;
+  const int64_t hlo = comm ? comm->halo_lo : 0, hhi = comm ? comm->halo_hi : 0;
+  const int64_t row0 = comm ? comm->g0 : 0;
+  const int64_t next = hlo + n + hhi;
+  tg_krylov_ws ws;
+  // layout: opext[next] (operand of the products: p, then s) | r | rhat | v | t | kp | dinv | pvec
+  TG_TRY(tg_dmalloc(&ws.buf, next + 7 * n));
+  double *opext = ws.buf, *op = opext + hlo, *r = opext + next, *rhat = r + n, *v = rhat + n, *t = v + n, *kp = t + n,
+         *dinv = kp + n, *pv = dinv + n;
+  TG_CHECK_HIP(hipMemsetAsync(ws.buf, 0, (size_t)(next + 7 * n) * sizeof(double), g_tg.stream));
+  double *part = g_tg.scratch;                       // 5 * TG_VEC_BLOCKS
+  double *sc = g_tg.scratch + TG_SCRATCH_DOUBLES - 2048;
+  const int vg = tg_vec_grid(n);
+  TG_TRY(tg_spmv_plan(k));
+  tg_sell_guard sell_guard(k);
+  TG_TRY(sell_guard.rc);
+  const double *opshift = opext - (row0 - hlo);
+  const int64_t cmin = row0 - hlo, cmax = row0 - hlo + next - 1;
+  auto product = [&](double *out) -> int {
+    TG_TRY(tg_comm_halo_exchange(comm, opext));
+    return tg_spmv_raw(k, opshift, cmin, cmax, out);
+  };
+  auto reduce = [&](int cnt, double *host) -> int {
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, g_tg.stream, part, vg, cnt, sc);
+    TG_LAUNCH_CHECK();
+    TG_TRY(tg_comm_allreduce_dev(comm, sc, cnt));
+    return tg_read_scalars(sc, cnt, host);
+  };
+  if (n > 0) {
+    const unsigned jg = (unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16);
+    hipLaunchKernelGGL(k_jacobi_setup, dim3(jg), dim3(256), 0, g_tg.stream, k->rowptr, k->col, k->val, n, row0,
+                       pc == TG_PC_JACOBI ? 1 : 0, dinv);
+  }
+  // reference norm ||B b||; r = B (b - K x0)
+  double h5[5];
+  hipLaunchKernelGGL(k_scaled_copy_norm, dim3(vg), dim3(256), 0, g_tg.stream, b->d, (const double *)dinv, 1.0, n, r, part);
+  TG_TRY(reduce(1, h5));
+  const double bnorm = sqrt(h5[0]);
+  double rnorm2 = h5[0];
+  if (nonzero_guess) {
+    TG_CHECK_HIP(hipMemcpyAsync(op, x->d, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream));
+    TG_TRY(product(kp));
+    hipLaunchKernelGGL(k_residual, dim3(vg), dim3(256), 0, g_tg.stream, b->d, (const double *)kp, n, t);
+    hipLaunchKernelGGL(k_scaled_copy_norm, dim3(vg), dim3(256), 0, g_tg.stream, t, (const double *)dinv, 1.0, n, r, part);
+    TG_TRY(reduce(1, h5));
+    rnorm2 = h5[0];
+  } else {
+    TG_CHECK_HIP(hipMemsetAsync(x->d, 0, (size_t)std::max<int64_t>(n, 1) * sizeof(double), g_tg.stream));
+  }
+  TG_CHECK_HIP(hipMemcpyAsync(rhat, r, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream));
+  const double tol = std::max(rtol * bnorm, atol);
+  double rho = rnorm2, alpha = 1.0, omega = 1.0, beta = 0.0, znorm = sqrt(rnorm2);
+  *iters = 0;
+  *status = -1;
+  if (!(znorm == znorm)) {
+    *status = -2;
+  } else if (znorm <= tol) {
+    *status = (znorm <= atol && !(znorm <= rtol * bnorm)) ? 1 : 0;
+  } else {
+    for (int it = 1; it <= maxit; it++) {
+      // p = r + beta (p - omega v)   (first step: p = r since p = v = 0, beta = 0)
+      hipLaunchKernelGGL(k_bcgs_p, dim3(vg), dim3(256), 0, g_tg.stream, r, v, beta, omega, n, pv);
+      TG_CHECK_HIP(hipMemcpyAsync(op, pv, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream));
+      TG_TRY(product(kp));
+      hipLaunchKernelGGL(k_bcgs_v, dim3(vg), dim3(256), 0, g_tg.stream, kp, dinv, rhat, n, v, part);
+      TG_TRY(reduce(1, h5));
+      const double rv = h5[0];
+      if (!(rv == rv) || rv == 0.0) {
+        *status = -2;
+        *iters = it;
+        break;
+      }
+      alpha = rho / rv;
+      hipLaunchKernelGGL(k_bcgs_s, dim3(vg), dim3(256), 0, g_tg.stream, r, v, alpha, n, op);
+      TG_TRY(product(kp));
+      hipLaunchKernelGGL(k_bcgs_t, dim3(vg), dim3(256), 0, g_tg.stream, kp, dinv, op, rhat, n, t, part);
+      TG_TRY(reduce(5, h5));
+      const double ts = h5[0], tt = h5[1], hs = h5[2], ht = h5[3], ss = h5[4];
+      omega = tt > 0.0 ? ts / tt : 0.0;
+      hipLaunchKernelGGL(k_bcgs_x, dim3(vg), dim3(256), 0, g_tg.stream, pv, op, t, alpha, omega, n, x->d, r);
+      TG_LAUNCH_CHECK();
+      const double rho_new = hs - omega * ht;
+      const double rn2 = std::max(0.0, ss - 2.0 * omega * ts + omega * omega * tt);
+      znorm = sqrt(rn2);
+      *iters = it;
+      if (!(znorm == znorm)) {
+        *status = -2;
+        break;
+      }
+      if (znorm <= tol) {
+        *status = (znorm <= atol && !(znorm <= rtol * bnorm)) ? 1 : 0;
+        break;
+      }
+      if (omega == 0.0 || rho == 0.0 || !(rho_new == rho_new)) {
+        *status = -2;
+        break;
+      }
+      beta = (rho_new / rho) * (alpha / omega);
+      rho = rho_new;
+    }
+  }
+  *resnorm = znorm;
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  TG_TRY(tg_comm_check(comm));
+  return 0;
+}
+
 extern "C" int tg_krylov_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, int pc, double rtol, double atol,
                                int maxit, int restart, tg_comm_t comm, int *iters, double *resnorm, int *status) {
   return tg_krylov_solve_flags(k, b, x, method, pc, rtol, atol, maxit, restart, 0, comm, iters, resnorm, status);
@@ -972,7 +1556,13 @@ extern "C" int tg_krylov_solve_flags(tg_csr_t k, tg_vec_t b, tg_vec_t x, int met
     TG_REQUIRE(k->nrows == k->ncols, "tg_krylov_solve: matrix must be square");
     comm = nullptr;
   }
+  if (method == TG_KSP_CG && pc == TG_PC_CHEBYSHEV)
+    // (`restart` carries the degree of the polynomial: the number of products per application + 1)
+    return tg_pcg_cheb(k, b, x, restart, rtol, atol, maxit, g_krylov_nonzero_guess, comm, iters, resnorm, status);
+  TG_REQUIRE(pc == TG_PC_NONE || pc == TG_PC_JACOBI, "the Chebyshev polynomial preconditioner serves CG only");
   if (method == TG_KSP_CG) return tg_cg(k, b, x, pc, rtol, atol, maxit, g_krylov_nonzero_guess, comm, iters, resnorm, status);
+  if (method == TG_KSP_BICGSTAB)
+    return tg_bicgstab(k, b, x, pc, rtol, atol, maxit, g_krylov_nonzero_guess, comm, iters, resnorm, status);
   if (method == TG_KSP_GMRES) {
     TG_REQUIRE(restart >= 1 && restart <= 200, "GMRES restart out of range");
     return tg_gmres(k, b, x, pc, rtol, atol, maxit, restart, g_krylov_nonzero_guess, (flags & TG_KSP_STAGNATION_GUARD) ? 1 : 0,
