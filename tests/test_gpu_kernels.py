@@ -50,7 +50,16 @@ def test_basis_1d_device_twin_bit_exact(dev):
         assert np.array_equal(val, g[pre + "ders"]), "case %d: values differ" % ci   # bit-exact
 
 
-def test_extraction_matches_reference_golden_bit_exact(dev):
+@pytest.fixture(params=["closed-form", "count-fill"])
+def extraction_path(request, monkeypatch):
+    """tg_extract_csr_tensor takes the closed-form pencil walk when the 1-D tables prove that the filter acts factor by
+    factor, the count / scan / fill kernels otherwise; TIGAR_EXTRACT_SEPARABLE=0 forces the latter: both are pinned"""
+    if request.param == "count-fill":
+        monkeypatch.setenv("TIGAR_EXTRACT_SEPARABLE", "0")
+    return request.param
+
+
+def test_extraction_matches_reference_golden_bit_exact(dev, extraction_path):
     g = _golden()
     for name in g["names"]:
         name = str(name)
@@ -61,7 +70,7 @@ def test_extraction_matches_reference_golden_bit_exact(dev):
         assert np.array_equal(M.data, g[pre + "M_val"]), name        # values bit-exact
 
 
-def test_extraction_row_range_slabs(dev):
+def test_extraction_row_range_slabs(dev, extraction_path):
     s = O.BSpline([2, 2, 2], [O.uniform_knots(2, 0., 1., 5), O.uniform_knots(2, 0., 1., 4),
                               O.uniform_knots(2, 0., 1., 6)])
     Mfull = O.generate_M_tensor(s)
@@ -77,7 +86,7 @@ def test_extraction_row_range_slabs(dev):
 
 
 @pytest.mark.parametrize("d,p,nel", [(2, 2, 32), (2, 4, 16), (3, 2, 12), (3, 3, 8), (2, 3, 40), (3, 4, 3)])
-def test_extraction_vs_oracle_medium(dev, d, p, nel):
+def test_extraction_vs_oracle_medium(dev, d, p, nel, extraction_path):
     s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel)] * d)
     Mo = O.generate_M_tensor(s)
     M = _extract(dev, s).to_scipy()
@@ -99,7 +108,7 @@ def test_extraction_points_mode_matches_tensor(dev):
         assert np.array_equal(M.data, g[pre + "M_val"]), name
 
 
-def test_eps_filter_is_strict_and_on_the_product(dev):
+def test_eps_filter_is_strict_and_on_the_product(dev, extraction_path):
     s = O.BSpline([2, 2], [O.uniform_knots(2, 0., 1., 4)] * 2)
     for eps in (1e-15, 1e-3, 0.05, 0.2):
         Mo = O.generate_M_tensor(s, ignore_eps=eps)
