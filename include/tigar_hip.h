@@ -22,6 +22,7 @@ extern "C" {
 typedef struct tg_csr_s *tg_csr_t;   /* device-resident CSR row block            */
 typedef struct tg_vec_s *tg_vec_t;   /* device-resident fp64 vector              */
 typedef struct tg_ptap_s *tg_ptap_t; /* symbolic plan of K = M^T A M             */
+typedef struct tg_cellplan_s *tg_cellplan_t; /* K = M^T A M on a cell-local FE space: dense blocks per cell */
 typedef struct tg_comm_s *tg_comm_t; /* RCCL communicator + z-slab descriptor    */
 
 /* ---- runtime ------------------------------------------------------------------ */
@@ -215,6 +216,17 @@ int tg_ptap_destroy(tg_ptap_t plan);
  * a caller that streams the product in row blocks with overlapping operands states its preference here.  Returns the
  * previous setting. */
 int tg_ptap_prefer(int kernels);
+/* extractMatrix on a CELL-LOCAL FE space (the meshes of disconnected cells of tIGAr/RhinoTSplines.py:195-240 and
+ * tIGAr/BSplines.py:800-860: b nodes per cell, numbered cell after cell), where an assembled A is block diagonal with one
+ * dense b x b block per cell: K = sum_c S_c^T (M_c^T A_c M_c) S_c -- dense element matrices out of LDS, merged into K by
+ * the look-up stage of the wave kernels.  The plan depends on M only (host-built: md [ncell][b][nfmax] dense rows of M per
+ * cell over the cell's function list fl [ncell][nfmax] (nf[c] of them used), incidence: row i -> rows c * nfmax + q of
+ * the element matrices holding function i, borrowed for the plan's lifetime; max_k / mean_k: row lengths of K).
+ * tg_cellplan_ptap returns 100 when `a` is not such a block-diagonal matrix (use tg_ptap_*). */
+int tg_cellplan_create(int64_t ncell, int b, int nfmax, int64_t ncols, const double *md_host, const int32_t *fl_host,
+                       const int32_t *nf_host, tg_csr_t incidence, int max_k, double mean_k, tg_cellplan_t *out);
+int tg_cellplan_ptap(tg_cellplan_t plan, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out);
+int tg_cellplan_destroy(tg_cellplan_t plan);
 /* extractMatrix when the extraction operator is a Kronecker product (tensor B-splines): one
  * contraction stage  out = P^T cur P  with P = (x)_k F_k, F_k = the 1-D matrix of direction k
  * (n x m CSR + its transpose, host pointers) or the identity (rowptr == NULL).  `cur` is an

@@ -124,6 +124,10 @@ PROTOTYPES = {
                                   C.POINTER(handle)]),
     "tg_ptap_destroy": (C.c_int, [handle]),
     "tg_ptap_prefer": (C.c_int, [C.c_int]),
+    "tg_cellplan_create": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int64, c_f64p, c_i32p, c_i32p, handle, C.c_int, C.c_double,
+                                     C.POINTER(handle)]),
+    "tg_cellplan_ptap": (C.c_int, [handle, handle, c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
+    "tg_cellplan_destroy": (C.c_int, [handle]),
     "tg_ptap_kron": (C.c_int, [handle, C.c_int64, C.c_int, c_i64p, C.POINTER(tg_kron1d_t), C.c_int64, C.c_int64,
                                c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
     "tg_ptap_kron_stage": (C.c_int, [handle, C.c_int64, C.c_int, c_i64p, C.POINTER(tg_kron1d_t), C.c_int64, C.c_int64,

@@ -43,6 +43,8 @@ struct gw_args {
   const int32_t *y_cnt;
   const uint32_t *y_mix;
   const double *y_val;
+  const int64_t *y_start_mix;   // where the row's columns start in y_mix when that differs from y_start (rows that share
+                                // one column list: the element matrices of the cell-block product); nullptr = y_start
   int64_t y_row0, y_nrows;
   int ts, lgts;         // slots of a wave's table (power of two)
   int rows_per_wave;
@@ -225,7 +227,7 @@ __device__ __forceinline__ bool gw_accum(const gw_tab &t, int &n, const unsigned
 }
 
 // accumulates output row `xr` into the wave's table
-template <int LG, int U, bool SEEDED>
+template <int LG, int U, bool SEEDED, bool SHARED>
 __device__ __forceinline__ void gw_row(const gw_args &P, int64_t xr, const gw_tab &t, int &n, bool &ovf, bool &range) {
   constexpr int G = 1 << LG, NG = 64 >> LG;
   const int lane = threadIdx.x & 63, sub = lane & (G - 1), grp = lane >> LG;
@@ -233,7 +235,7 @@ __device__ __forceinline__ void gw_row(const gw_args &P, int64_t xr, const gw_ta
   const int64_t e0 = gw_readlane_i64(P.x_rowptr[xr], 0), e1 = gw_readlane_i64(P.x_rowptr[xr + 1], 0);
   for (int64_t c0 = e0; c0 < e1; c0 += 64) {
     const int nb = __builtin_amdgcn_readfirstlane((int)min((int64_t)64, e1 - c0));
-    int64_t st = 0;
+    int64_t st = 0, stm = 0;
     int ln = 0;
     double w = 0.0;
     if (lane < nb) {
@@ -243,6 +245,7 @@ __device__ __forceinline__ void gw_row(const gw_args &P, int64_t xr, const gw_ta
         range = true;
       } else {
         st = P.y_start[yr];
+        stm = SHARED ? P.y_start_mix[yr] : st;
         ln = P.y_cnt ? P.y_cnt[yr] : (int)(P.y_start[yr + 1] - st);
       }
     }
@@ -251,7 +254,7 @@ __device__ __forceinline__ void gw_row(const gw_args &P, int64_t xr, const gw_ta
       bool valid[U];
       double v[U];
       int lnu[U];
-      int64_t stu[U];
+      int64_t stu[U], smu[U];
       double wu[U];
       int longest = 0;
 #pragma unroll
@@ -262,12 +265,14 @@ __device__ __forceinline__ void gw_row(const gw_args &P, int64_t xr, const gw_ta
           jj = j + u;                                   // wave-uniform: the row's start travels in scalar registers
           const int src = min(jj, 63);
           stu[u] = gw_readlane_i64(st, src);
+          smu[u] = SHARED ? gw_readlane_i64(stm, src) : stu[u];
           lraw = __builtin_amdgcn_readlane(ln, src);
           wu[u] = gw_readlane_f64(w, src);
         } else {
           jj = j + u * NG + grp;
           const int src = min(jj, 63);
           stu[u] = __shfl(st, src, 64);
+          smu[u] = SHARED ? __shfl(stm, src, 64) : stu[u];
           lraw = __shfl(ln, src, 64);
           wu[u] = __shfl(w, src, 64);
         }
@@ -275,7 +280,7 @@ __device__ __forceinline__ void gw_row(const gw_args &P, int64_t xr, const gw_ta
         longest = max(longest, lnu[u]);
         // unconditional loads, no clamp: a lane beyond the end of its row reads the entries that follow (the arrays are
         // padded by TG_CSR_PAD) and is dropped by `valid`
-        const uint32_t *pm = P.y_mix + stu[u];
+        const uint32_t *pm = P.y_mix + smu[u];
         const double *pv = P.y_val + stu[u];
         m0[u] = pm[sub];
         v[u] = wu[u] * pv[sub];
@@ -290,7 +295,7 @@ __device__ __forceinline__ void gw_row(const gw_args &P, int64_t xr, const gw_ta
             bool valid1[1];
             double v1[1];
             const int oc = min(o, max(lnu[u] - 1, 0));
-            m1[0] = P.y_mix[stu[u] + oc];
+            m1[0] = P.y_mix[smu[u] + oc];
             v1[0] = wu[u] * P.y_val[stu[u] + oc];
             valid1[0] = o < lnu[u];
             if (!gw_accum<1, LG, SEEDED>(t, n, m1, valid1, v1)) ovf = true;
@@ -312,7 +317,7 @@ __global__ void __launch_bounds__(256) k_gw_mix(const int32_t *__restrict__ col,
 // FINAL = true : rows of K, rank-sorted by column, MatZeroRowsColumns fused; BUMP reserves space in the temporary and records
 //                (row_cnt, row_off) for the scan + reorder pass, PLACED writes at row_off[li] and checks the length.
 // COUNT: nothing is written; maxima[0] = longest row, sum[0] += lengths (row sample of the plan).
-template <int MODE, bool FINAL, int LG>
+template <int MODE, bool FINAL, int LG, bool SHARED = false>
 __global__ void __launch_bounds__(256)
     k_gw(gw_args P, int64_t *__restrict__ out_off, int32_t *__restrict__ out_cnt, int64_t *__restrict__ row_cnt,
          uint32_t *__restrict__ ocol, double *__restrict__ oval, unsigned long long *__restrict__ cursor, int64_t capacity,
@@ -349,9 +354,9 @@ __global__ void __launch_bounds__(256)
       n = 0;
       row_ovf = false;
       if (attempt == 0)
-        gw_row<LG, GW_U(FINAL), false>(P, li, t, n, row_ovf, range);
+        gw_row<LG, GW_U(FINAL), false, SHARED>(P, li, t, n, row_ovf, range);
       else
-        gw_row<LG, GW_U(FINAL), true>(P, li, t, n, row_ovf, range);
+        gw_row<LG, GW_U(FINAL), true, SHARED>(P, li, t, n, row_ovf, range);
       if (n > t.cap) break;                    // more keys than accumulators: another seed does not help
     }
     if (row_ovf) {
@@ -531,6 +536,7 @@ static void gw_fill_stage1(gw_args &P, tg_csr_s *a, tg_csr_s *m, const uint32_t 
   P.t0 = P.t1 = P.t2 = 1;
   P.debug = getenv("TIGAR_PTAP_WAVE_DEBUG") ? atoi(getenv("TIGAR_PTAP_WAVE_DEBUG")) : 0;
   P.out_stride = 0;
+  P.y_start_mix = nullptr;
   P.x_rowptr = a->rowptr;
   P.x_col = a->col;
   P.x_val = a->val;
@@ -740,6 +746,7 @@ int tg_ptap_wave_numeric(tg_gw_plan *plan, tg_csr_s *a, int64_t a_row0, tg_csr_s
   P2.x_val = mt->val;
   P2.x_nrows = mt->nrows;
   P2.row_stride = 1;
+  P2.y_start_mix = nullptr;
   P2.y_start = am_off;
   P2.y_cnt = am_cnt;
   P2.y_mix = am_col;
@@ -847,6 +854,354 @@ int tg_ptap_wave_numeric(tg_gw_plan *plan, tg_csr_s *a, int64_t a_row0, tg_csr_s
           rc = 1;
         }
         // remember the pattern for later calls with the same operands' structure
+        tg_dfree(plan->k_rowptr);
+        plan->k_rowptr = cnt;
+        cnt = nullptr;
+        plan->k_nnz = nnz;
+      }
+    }
+  }
+  hipStreamSynchronize(g_tg.stream);
+  cleanup();
+  if (rc) {
+    if (k) tg_csr_destroy(k);
+    return rc;
+  }
+  *k_out = k;
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Cell-block product (round 4): K = M^T A M when the FE space is CELL-LOCAL -- every cell carries its own b nodes, numbered
+// cell after cell, as the meshes of disconnected cells the reference builds for Rhino T-splines and multi-patch B-splines
+// (tIGAr/RhinoTSplines.py:195-240, tIGAr/BSplines.py:800-860), so that a matrix assembled on it is block diagonal with one
+// dense b x b block per cell.  Then
+//
+//     K = sum_c  S_c^T ( M_c^T A_c M_c ) S_c ,      M_c = the rows of M of cell c as a dense b x nf_c block over the
+//                                                   cell's own list of functions, S_c = that list as a selection
+//
+// -- the "supernodal" form of the product: the multiply-adds run on dense little blocks without any look-up
+// (k_cell_element: one wave per cell, E_c = M_c^T (A_c M_c) out of LDS), and only the nf_c^2 entries of an element
+// matrix are merged into K by look-up: the second Gustavson stage of the wave kernels above with the rows of the element
+// matrices as operand rows (weight 1), each row of K gathering the rows (c, q) of the cells that contain its function.
+// 12 x fewer accumulations by look-up than the row-wise product on the T-spline benchmark.
+// The plan (cell function lists, dense M_c, incidence) depends on M only: built once per extraction operator on the host
+// (tigar_amd/cellptap.py), kept here on the device.  A is verified to be block diagonal with dense blocks (row lengths
+// and first / last column of every row: rows are sorted) -- status 100 otherwise, the caller takes the general kernels.
+struct tg_cellplan_s {
+  int64_t ncell = 0, ncols = 0;
+  int b = 0, nfmax = 0;
+  double *md = nullptr;          // [ncell][b][nfmax] dense rows of M per cell (zero where a node has no entry)
+  uint32_t *flmix = nullptr;     // [ncell][nfmax] the cell's functions, mixed (gw_mix), padded
+  int32_t *nf = nullptr;         // [ncell]
+  int64_t *e_start = nullptr, *e_start_mix = nullptr;   // per row (c, q) of the element matrices: where its values / columns start
+  int32_t *e_cnt = nullptr;
+  tg_csr_s *inc = nullptr;       // incidence: row i -> rows (c, q) of the element matrices with function i (borrowed)
+  int max_k = 0;
+  double mean_k = 0.0;
+  tg_gw_plan gw;
+};
+
+// one wave per cell: E_c = M_c^T (A_c M_c).  Lanes: groups of G = 2^LGF lanes <-> the function index f, 64 / G rows at once.
+template <int LGF>
+__global__ void __launch_bounds__(256)
+    k_cell_element(const double *__restrict__ aval, const double *__restrict__ md, const int32_t *__restrict__ nfc, int64_t ncell,
+                   int b, int nfmax, double *__restrict__ eval) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int G = 1 << LGF, NG = 64 >> LGF;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & (G - 1), grp = lane >> LGF;
+  const size_t per_wave = (size_t)b * b + 2 * (size_t)b * nfmax;
+  double *As = reinterpret_cast<double *>(smem) + wave * per_wave;
+  double *Ms = As + (size_t)b * b, *Ts = Ms + (size_t)b * nfmax;
+  const int64_t c = (int64_t)blockIdx.x * 4 + wave;
+  if (c >= ncell) return;
+  const int nf = nfc[c];
+  const double *ac = aval + c * (int64_t)b * b, *mc = md + c * (int64_t)b * nfmax;
+  for (int s = lane; s < b * b; s += 64) As[s] = ac[s];
+  for (int s = lane; s < b * nfmax; s += 64) Ms[s] = mc[s];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  // T = A_c M_c : [b][nf]
+  for (int r0 = 0; r0 < b; r0 += NG) {
+    const int r = r0 + grp;
+    double acc = 0.0;
+    if (r < b && sub < nf)
+      for (int q = 0; q < b; q++) acc = fma(As[r * b + q], Ms[q * nfmax + sub], acc);
+    if (r < b && sub < nfmax) Ts[r * nfmax + sub] = acc;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // E = M_c^T T : [nf][nf], row (c, q) at (c * nfmax + q) * nfmax
+  double *ec = eval + c * (int64_t)nfmax * nfmax;
+  for (int q0 = 0; q0 < nf; q0 += NG) {
+    const int q = q0 + grp;
+    double acc = 0.0;
+    if (q < nf && sub < nf) {
+      for (int r = 0; r < b; r++) acc = fma(Ms[r * nfmax + q], Ts[r * nfmax + sub], acc);
+      ec[(int64_t)q * nfmax + sub] = acc;
+    }
+  }
+}
+
+// every row of A: b entries, the first at column (row / b) * b, the last at + b - 1 (rows are sorted: the block, dense)
+__global__ void __launch_bounds__(256) k_cell_check(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nrows,
+                                                  int b, int *__restrict__ bad) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool wrong = false;
+  for (; r < nrows; r += stride) {
+    const int64_t a = rowptr[r], e = rowptr[r + 1];
+    const int64_t c0 = (r / b) * b;
+    if (a != r * b || e - a != b || col[a] != c0 || col[e - 1] != c0 + b - 1) wrong = true;
+  }
+  if (wrong) atomicMax(bad, 1);
+}
+
+extern "C" int tg_cellplan_create(int64_t ncell, int b, int nfmax, int64_t ncols, const double *md_host, const int32_t *fl_host,
+                                  const int32_t *nf_host, tg_csr_t incidence, int max_k, double mean_k, tg_cellplan_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(ncell > 0 && b >= 1 && b <= 64 && nfmax >= 1 && nfmax <= 64 && md_host && fl_host && nf_host && incidence && out,
+             "bad arguments to tg_cellplan_create");
+  TG_REQUIRE(incidence->nrows == ncols && incidence->ncols == ncell * nfmax, "tg_cellplan_create: incidence of the wrong shape");
+  tg_cellplan_s *pl = new tg_cellplan_s();
+  pl->ncell = ncell;
+  pl->ncols = ncols;
+  pl->b = b;
+  pl->nfmax = nfmax;
+  pl->inc = incidence;
+  pl->max_k = max_k;
+  pl->mean_k = mean_k;
+  const int64_t nrowsE = ncell * nfmax;
+  std::vector<uint32_t> mix((size_t)nrowsE);
+  std::vector<int64_t> st((size_t)nrowsE), stm((size_t)nrowsE);
+  std::vector<int32_t> cnt((size_t)nrowsE);
+  for (int64_t c = 0; c < ncell; c++)
+    for (int q = 0; q < nfmax; q++) {
+      const int64_t k = c * nfmax + q;
+      mix[(size_t)k] = gw_mix((unsigned)(q < nf_host[c] ? fl_host[k] : 0));
+      st[(size_t)k] = k * nfmax;
+      stm[(size_t)k] = c * nfmax;
+      cnt[(size_t)k] = q < nf_host[c] ? nf_host[c] : 0;
+    }
+  int rc = tg_dmalloc(&pl->md, ncell * (int64_t)b * nfmax) || tg_dmalloc(&pl->flmix, nrowsE + TG_CSR_PAD) || tg_dmalloc(&pl->nf, ncell) ||
+           tg_dmalloc(&pl->e_start, nrowsE) || tg_dmalloc(&pl->e_start_mix, nrowsE) || tg_dmalloc(&pl->e_cnt, nrowsE);
+  if (!rc) {
+    hipMemcpyAsync(pl->md, md_host, (size_t)(ncell * (int64_t)b * nfmax) * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
+    hipMemsetAsync(pl->flmix, 0, (size_t)(nrowsE + TG_CSR_PAD) * sizeof(uint32_t), g_tg.stream);
+    hipMemcpyAsync(pl->flmix, mix.data(), mix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, g_tg.stream);
+    hipMemcpyAsync(pl->nf, nf_host, (size_t)ncell * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+    hipMemcpyAsync(pl->e_start, st.data(), st.size() * sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream);
+    hipMemcpyAsync(pl->e_start_mix, stm.data(), stm.size() * sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream);
+    hipMemcpyAsync(pl->e_cnt, cnt.data(), cnt.size() * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+    if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
+  }
+  if (rc) {
+    tg_cellplan_destroy(pl);
+    return rc;
+  }
+  const double load_inv = 2.5;
+  pl->gw.ts_k = std::max(64, gw_pow2_ge((int64_t)(max_k * load_inv) + 4));
+  pl->gw.lg_am = gw_lg_group((double)nfmax);
+  pl->gw.max_k = max_k;
+  pl->gw.mean_k = mean_k;
+  *out = pl;
+  return 0;
+}
+
+extern "C" int tg_cellplan_destroy(tg_cellplan_t pl) {
+  if (!pl) return 0;
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  tg_dfree(pl->md);
+  tg_dfree(pl->flmix);
+  tg_dfree(pl->nf);
+  tg_dfree(pl->e_start);
+  tg_dfree(pl->e_start_mix);
+  tg_dfree(pl->e_cnt);
+  tg_ptap_wave_plan_free(&pl->gw);
+  delete pl;
+  return 0;
+}
+
+template <int MODE>
+static void gw_launch_shared(int lg, unsigned grid, size_t lds, const gw_args &P, int64_t *out_off, int64_t *row_cnt, uint32_t *ocol,
+                             double *oval, unsigned long long *cursor, int64_t capacity, const uint8_t *mask, double diag, int *status,
+                             unsigned long long *sum) {
+#define GW_GOS(LGV)                                                                                                                  \
+  do {                                                                                                                               \
+    hipFuncSetAttribute((const void *)k_gw<MODE, true, LGV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);          \
+    hipLaunchKernelGGL((k_gw<MODE, true, LGV, true>), dim3(grid), dim3(256), lds, g_tg.stream, P, out_off, (int32_t *)nullptr, row_cnt, \
+                       ocol, oval, cursor, capacity, mask, diag, (int64_t)0, status, status + 1, sum);                               \
+  } while (0)
+  switch (lg) {
+    case 3: GW_GOS(3); break;
+    case 4: GW_GOS(4); break;
+    case 5: GW_GOS(5); break;
+    default: GW_GOS(6); break;
+  }
+#undef GW_GOS
+}
+
+extern "C" int tg_cellplan_ptap(tg_cellplan_t pl, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(pl && a && k_out, "null argument to tg_cellplan_ptap");
+  TG_REQUIRE_CANONICAL(a);
+  const int64_t nfe = pl->ncell * pl->b;
+  if (a->nrows != nfe || a->ncols != nfe || a->nnz != nfe * pl->b) return 100;
+  int *status = (int *)g_tg.scratch;
+  unsigned long long *sum = (unsigned long long *)(status + 2);
+  int hbad = 0;
+  hipMemsetAsync(status, 0, 4 * sizeof(int), g_tg.stream);
+  hipLaunchKernelGGL(k_cell_check, dim3((unsigned)std::min<int64_t>(tg_cdiv(nfe, 256), (int64_t)g_tg.num_cu * 16)), dim3(256), 0,
+                     g_tg.stream, a->rowptr, a->col, nfe, pl->b, status);
+  TG_LAUNCH_CHECK();
+  TG_CHECK_HIP(hipMemcpyAsync(&hbad, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  if (hbad) return 100;                     // not block diagonal with dense b x b blocks: the general kernels
+  uint8_t *mask = nullptr;
+  if (nzero > 0) TG_TRY(tg_build_dof_mask(zero_dofs, nzero, pl->ncols, &mask));
+  double *eval = nullptr;
+  int64_t *cnt = nullptr, *off = nullptr;
+  int32_t *tcol = nullptr;
+  double *tval = nullptr;
+  unsigned long long *cursor = nullptr;
+  tg_csr_s *k = nullptr;
+  auto cleanup = [&]() {
+    tg_dfree(eval);
+    tg_dfree(cnt);
+    tg_dfree(off);
+    tg_dfree(tcol);
+    tg_dfree(tval);
+    tg_dfree(cursor);
+    tg_dfree(mask);
+  };
+  const int64_t nrowsE = pl->ncell * pl->nfmax;
+  int rc = tg_dmalloc(&eval, nrowsE * pl->nfmax + TG_CSR_PAD) || tg_dmalloc(&cursor, 2);
+  if (rc) {
+    cleanup();
+    return rc;
+  }
+  // ---- element matrices
+  {
+    const size_t lds = 4 * ((size_t)pl->b * pl->b + 2 * (size_t)pl->b * pl->nfmax) * sizeof(double);
+    const unsigned grid = (unsigned)tg_cdiv(pl->ncell, 4);
+    const int lgf = gw_lg(pl->nfmax <= 8 ? 8 : pl->nfmax <= 16 ? 16 : pl->nfmax <= 32 ? 32 : 64);
+#define CELL_GO(LGV)                                                                                                    \
+  do {                                                                                                                  \
+    hipFuncSetAttribute((const void *)k_cell_element<LGV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
+    hipLaunchKernelGGL((k_cell_element<LGV>), dim3(grid), dim3(256), lds, g_tg.stream, a->val, pl->md, pl->nf, pl->ncell, \
+                       pl->b, pl->nfmax, eval);                                                                         \
+  } while (0)
+    if (lds > 160 * 1024) {
+      cleanup();
+      return 100;
+    }
+    switch (lgf) {
+      case 3: CELL_GO(3); break;
+      case 4: CELL_GO(4); break;
+      case 5: CELL_GO(5); break;
+      default: CELL_GO(6); break;
+    }
+#undef CELL_GO
+    if (hipGetLastError() != hipSuccess) {
+      tg_set_error("cell-block PtAP: the element kernel failed to launch");
+      cleanup();
+      return 1;
+    }
+  }
+  // ---- K rows: the second Gustavson stage over the rows of the element matrices
+  gw_set_lds_limits();
+  gw_args P2;
+  memset(&P2, 0, sizeof(P2));
+  P2.x_rowptr = pl->inc->rowptr;
+  P2.x_col = pl->inc->col;
+  P2.x_val = pl->inc->val;
+  P2.x_nrows = pl->inc->nrows;
+  P2.row_stride = 1;
+  P2.y_start = pl->e_start;
+  P2.y_start_mix = pl->e_start_mix;
+  P2.y_cnt = pl->e_cnt;
+  P2.y_mix = pl->flmix;
+  P2.y_val = eval;
+  P2.y_row0 = 0;
+  P2.y_nrows = nrowsE;
+  P2.rows_per_wave = 2;
+  P2.t0 = P2.t1 = P2.t2 = 1;
+  const int64_t nrows = pl->ncols;
+  tg_gw_plan *plan = &pl->gw;
+  if (plan->k_nnz >= 0) {
+    rc = tg_csr_alloc(nrows, pl->ncols, plan->k_nnz, &k);
+    if (!rc) {
+      hipMemcpyAsync(k->rowptr, plan->k_rowptr, (size_t)(nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream);
+      P2.ts = plan->ts_k;
+      P2.lgts = gw_lg(plan->ts_k);
+      hipMemsetAsync(status, 0, 4 * sizeof(int), g_tg.stream);
+      gw_launch_shared<GW_PLACED>(plan->lg_am, gw_grid(nrows, P2.rows_per_wave), 4 * gw_wave_bytes(P2.ts), P2, k->rowptr, nullptr,
+                                  (uint32_t *)k->col, k->val, nullptr, 0, mask, diag, status, sum);
+      int h = 0;
+      hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
+      if (hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        tg_set_error("cell-block PtAP: numeric pass (placed) failed to run");
+        rc = 1;
+      } else if (h != GW_OK) {
+        tg_set_error("cell-block PtAP: the operands no longer match the plan's pattern (status %d)", h);
+        rc = 4;
+      }
+    }
+  } else {
+    int64_t stride2 = (plan->max_k + 7) & ~7;
+    int64_t cap2 = stride2 * nrows;
+    rc = tg_dmalloc(&cnt, nrows + 1) || tg_dmalloc(&off, nrows + 1);
+    bool done = false;
+    for (int attempt = 0; attempt < 6 && !rc && !done; attempt++) {
+      rc = tg_dmalloc(&tcol, cap2 + TG_CSR_PAD) || tg_dmalloc(&tval, cap2 + TG_CSR_PAD);
+      if (rc) break;
+      P2.ts = plan->ts_k;
+      P2.lgts = gw_lg(plan->ts_k);
+      P2.out_stride = stride2;
+      const size_t lds = 4 * gw_wave_bytes(P2.ts);
+      if (lds > 160 * 1024) {
+        rc = 100;
+        break;
+      }
+      hipMemsetAsync(status, 0, 4 * sizeof(int), g_tg.stream);
+      hipMemsetAsync(cnt, 0, (size_t)(nrows + 1) * sizeof(int64_t), g_tg.stream);
+      gw_launch_shared<GW_BUMP>(plan->lg_am, gw_grid(nrows, P2.rows_per_wave), lds, P2, off, cnt, (uint32_t *)tcol, tval, cursor, cap2,
+                                mask, diag, status, sum);
+      int h[2] = {0, 0};
+      hipMemcpyAsync(h, status, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream);
+      if (hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        tg_set_error("cell-block PtAP: the gather stage failed to run (LDS %zu B)", lds);
+        rc = 1;
+        break;
+      }
+      if (h[0] == GW_OK) {
+        done = true;
+        break;
+      }
+      tg_dfree(tcol);
+      tg_dfree(tval);
+      tcol = nullptr;
+      tval = nullptr;
+      if (h[0] == GW_OVF)
+        plan->ts_k *= 2;
+      else if (h[0] == GW_CAP) {
+        plan->max_k = std::max(plan->max_k, h[1]);
+        stride2 = (std::max<int64_t>(h[1], stride2 + stride2 / 4) + 7) & ~(int64_t)7;
+        cap2 = stride2 * nrows;
+      } else {
+        tg_set_error("cell-block PtAP: kernel status %d", h[0]);
+        rc = 4;
+      }
+    }
+    if (!rc && !done) rc = 100;
+    if (!rc) {
+      int64_t nnz = 0;
+      rc = tg_exclusive_scan_i64(cnt, nrows, &nnz);
+      if (!rc) rc = tg_csr_alloc(nrows, pl->ncols, nnz, &k);
+      if (!rc) {
+        hipMemcpyAsync(k->rowptr, cnt, (size_t)(nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream);
+        const unsigned rg = (unsigned)std::min<int64_t>(tg_cdiv(nrows, 4), (int64_t)g_tg.num_cu * 16);
+        hipLaunchKernelGGL(k_gw_reorder, dim3(std::max(1u, rg)), dim3(256), 0, g_tg.stream, k->rowptr, off, tcol, tval, nrows, k->col,
+                           k->val);
         tg_dfree(plan->k_rowptr);
         plan->k_rowptr = cnt;
         cnt = nullptr;
