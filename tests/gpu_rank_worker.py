@@ -31,6 +31,8 @@ def main():
         for side in (0, 1):
             gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
     spline = t.ExtractedSpline(gen, 2 * p)
+    from tigar_amd import device as dev
+    dev.prof_reset()
     if explicit:
         # every rank holds the whole assembled matrix (with a coupling added by hand, as reef-knot.py:460-467 does)
         A = F.LaplaceForm().assemble_matrix(spline.V).to_scipy().tolil()
@@ -39,13 +41,13 @@ def main():
         K = spline.extractMatrix(A if explicit == "scipy" else dev_csr(A), diag=1.5)
     else:
         K = spline.assembleMatrix(F.LaplaceForm(), diag=1.5)
+    tensor_walks = dev.prof_get(5)[1]                    # final stages of the tensor-pattern PtAP that delivered rows of K
     f1 = lambda x: np.sin(np.pi * x)
     rhs = spline.assembleVector(F.SeparableLoadForm([f1] * d, scale=d * np.pi ** 2))
     solver = t.PETScKrylovSolver(*(method.split(":") if ":" in method else (method, "jacobi")))
     solver.parameters["relative_tolerance"] = 1e-10
     spline.setSolverOptions(linearSolver=solver)
     u = t.Function(spline.V, spline.localFERange())
-    from tigar_amd import device as dev
     dev.prof_reset()
     U = spline.solveLinearSystem(K, rhs, u)
     its1 = solver.last["iterations"]
@@ -81,7 +83,7 @@ def main():
              comm=np.array([rank_r, world_r, dev.Comm.KINDS.index(kind)]), cp0=cp0,
              U2=U2.get_local(), overlapped=np.array([overlapped]), host_waits=np.array([host_waits]),
              resnorm=np.array([resnorm]), ladder_U=np.array(ladder_U), ladder_res=np.array(ladder_res),
-             ladder_its=np.array(ladder_its))
+             ladder_its=np.array(ladder_its), tensor_walks=np.array([tensor_walks]))
     comm.barrier()
 
 

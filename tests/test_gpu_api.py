@@ -212,22 +212,75 @@ def test_periodic_patch_through_the_generator_takes_the_pencil_walk(T):
     assert np.array_equal(M3.data, Mo3.data)
 
 
-@pytest.mark.parametrize("nel", [6, 9])
-def test_extract_matrix_on_a_periodic_patch(T, nel):
-    """M^T A M on a patch that is periodic in x: supports wrap around, so the box / line kernels (one interval of
-    operands per direction) are not taken; the general stages give the oracle's product (pattern and values)."""
-    t, B, F = T.t, T.B, T.F
+@pytest.mark.parametrize("nel,periodic", [(6, (0,)), (9, (0,)), (7, (2,)), (8, (0, 1, 2)), (5, (1, 2))])
+def test_extract_matrix_on_a_periodic_patch(T, nel, periodic):
+    """M^T A M on a patch with periodic directions (tIGAr/BSplines.py:204-212, 246-260): supports wrap around, which the
+    line walks (one interval of operands per direction) cannot address -- they run on the space BEFORE the wrapped
+    functions are identified (nel + p functions per periodic direction, the structure of an open knot vector) and the
+    identification K = R^T K_u R follows as one pass of the general kernels (kronptap.KronExtraction.unwrapped / fold).
+    Pattern and values against the oracle's product with the reference's M; the walks did run (counter)."""
+    import os
+    t, B, F, dev = T.t, T.B, T.F, T.dev
     d, p = 3, 2
-    kv = [B.uniformKnots(p, 0., 1., nel, k == 0) for k in range(d)]
+    kv = [B.uniformKnots(p, 0., 1., nel, k in periodic) for k in range(d)]
     gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p] * d, kv))
     sp0 = gen.getScalarSpline(0)
-    for direction in (1, 2):
-        for side in (0, 1):
-            gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
+    for direction in range(d):
+        if direction not in periodic:
+            for side in (0, 1):
+                gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
+    if len(periodic) == d:
+        gen.addZeroDofs(0, [0, 11])                       # (all-periodic Laplacian: pin something)
     spline = t.ExtractedSpline(gen, 2 * p)
     A = F.LaplaceForm().assemble_matrix(spline.V)
+    dev.prof_reset()
     K = spline.extractMatrix(A, diag=1.5).to_scipy()
+    assert dev.prof_get(5)[1] > 0
     Ko = O.extract_matrix(gen.M.to_scipy(), A.to_scipy(), list(spline.zeroDofs), diag=1.5)
+    assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices)
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+    # an FE matrix with a coupling outside the element pattern (added by hand): split / general stages under the fold
+    A2 = A.to_scipy().tolil()
+    A2[3, A2.shape[1] - 5] = 0.25
+    A2 = A2.tocsr()
+    K2 = spline.extractMatrix(A2, diag=1.5).to_scipy()
+    Ko2 = O.extract_matrix(gen.M.to_scipy(), A2, list(spline.zeroDofs), diag=1.5)
+    assert abs(K2 - Ko2).max() <= 1e-12 * abs(Ko2).max()
+    # the general stages alone (TIGAR_PTAP_UNWRAP=0) give the same matrix
+    os.environ["TIGAR_PTAP_UNWRAP"] = "0"
+    try:
+        spline_g = t.ExtractedSpline(gen, 2 * p)
+        dev.prof_reset()
+        Kg = spline_g.extractMatrix(A, diag=1.5).to_scipy()
+        assert dev.prof_get(5)[1] == 0
+    finally:
+        del os.environ["TIGAR_PTAP_UNWRAP"]
+    assert np.array_equal(Kg.indices, K.indices) and abs(Kg - K).max() <= 1e-12 * abs(Ko).max()
+
+
+@pytest.mark.parametrize("p,nel,nfields", [(2, 8, 1), (3, 9, 1), (4, 11, 1), (2, 7, 3)])
+def test_extract_matrix_on_a_doubly_periodic_2d_patch(T, p, nel, nfields):
+    """the 2-D line walks under periodic directions (demos/taylor-green-2d.py builds its velocity and pressure spaces
+    on periodic uniform knots): one and several fields on one basis, against the oracle's product"""
+    t, B, F, dev = T.t, T.B, T.F, T.dev
+    kv = [B.uniformKnots(p, 0., 1., nel, True), B.uniformKnots(p, 0., 1., nel + 1, True)]
+    gen = t.EqualOrderSpline(nfields, B.ExplicitBSplineControlMesh([p, p], kv))
+    gen.addZeroDofs(0, [0, 5])
+    spline = t.ExtractedSpline(gen, 2 * p)
+    pats = []
+    for n in (nel, nel + 1):                                                   # element-coupling pattern of the Q_p grid
+        P1 = sp.lil_matrix((p * n + 1, p * n + 1))
+        for e in range(n):
+            P1[p * e:p * e + p + 1, p * e:p * e + p + 1] = 1.0
+        pats.append(P1.tocsr())
+    pat = O.kron_dir0_fastest(pats).tocsr()
+    A = sp.bmat([[pat] * nfields for _ in range(nfields)], format="csr")
+    A.sort_indices()
+    A.data = np.random.default_rng(p + nel).standard_normal(A.nnz)             # values arbitrary, non-symmetric
+    dev.prof_reset()
+    K = spline.extractMatrix(A, diag=2.0).to_scipy()
+    assert dev.prof_get(5)[1] > 0
+    Ko = O.extract_matrix(gen.M.to_scipy(), A, list(spline.zeroDofs), diag=2.0)
     assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices)
     assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
 

@@ -156,6 +156,8 @@ def test_patch_periodic_across_the_slabs_with_several_ranks(tmp_path):
     ref = _single(d, p, nel, "cg", periodic0=True)
     parts = _run_ranks(tmp_path, world, "ipc", d, p, nel, "cg", 34611, {"TIGAR_TEST_PERIODIC0": "1"})
     _compare(parts, ref, world, "ipc")
+    # every rank's rows of K came out of the tensor line walks (on the unwrapped space, then folded: kronptap.unwrapped)
+    assert all(int(q["tensor_walks"][0]) > 0 for q in parts)
 
 
 @pytest.mark.parametrize("case,world,kind", [("shell2d", 2, "ipc"), ("elasticity3d", 3, "ipc"), ("shell2d", 3, "host")])

@@ -1433,11 +1433,20 @@ class ExtractedSpline(object):
         kx2 = self._kron if self._kron is not None else getattr(self, "_kron_scalar", None)
         if kx2 is not None and kx2.d == 2 and not A.is_loose() and os.environ.get("TIGAR_PTAP_FACTORED", "1") != "0":
             from .tensorptap import TensorPtAP2D
-            plan2 = TensorPtAP2D.for_extraction(kx2, self.nFields if by_blocks else 1)
+            nF2 = self.nFields if by_blocks else 1
+            plan2 = TensorPtAP2D.for_extraction(kx2, nF2)
             if plan2 is not None:
                 K = plan2.ptap(A, zd, float(diag))
                 if K is not None:
                     return K
+            elif os.environ.get("TIGAR_PTAP_UNWRAP", "1") != "0":
+                # periodic directions (tIGAr/BSplines.py:204-212): the walks on the space before the wrapped functions
+                # are identified, then K = R^T K_u R (kronptap.KronExtraction.unwrapped / fold)
+                ku2 = kx2.unwrapped()
+                plan2 = TensorPtAP2D.for_extraction(ku2, nF2) if ku2 is not None else None
+                K_u = plan2.ptap(A, None, 1.0) if plan2 is not None else None
+                if K_u is not None:
+                    return ku2.fold(K_u, zd, float(diag), nfields=nF2)
         if by_blocks and os.environ.get("TIGAR_PTAP_FACTORED", "1") != "0":
             K = self._extract_matrix_by_field_blocks(A, zd, float(diag))
             if K is not None:

@@ -791,6 +791,7 @@ extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tenso
     return rc;
   }
   if (m->diag_cache && m->diag_rows == row_at) m->diag_rows = row_at + nrows;
+  g_tg.prof_n[TG_PROF_PTAP_TENSOR_WALKS] += 1;
   if (dest) {
     dest->rows_done += nrows;
     dest->nnz_done += nnz;
@@ -1078,6 +1079,7 @@ extern "C" int tg_tensor2_ptap(tg_tensor_plan_t pl, tg_csr_t a, const int32_t *z
   }
   m->nnz = knnz;
   m->diag_rows = m->diag_cache ? krows : 0;
+  g_tg.prof_n[TG_PROF_PTAP_TENSOR_WALKS] += 1;
   *out = m;
   return 0;
 }

@@ -240,6 +240,15 @@ class SlabHotPath(object):
         from .tensorptap import TensorPtAP
         tplan = TensorPtAP.for_extraction(self.kx) if (self.factored and self.kron_exact and not getattr(
             self, "_tensor_declined", False)) else None
+        # directions other than the slab direction that wrap (periodic, tIGAr/BSplines.py:204-212): the walks on the
+        # unwrapped space, this rank's rows of K_u folded at the end (kronptap.KronExtraction.unwrapped / fold)
+        fold = None
+        if tplan is None and self.factored and self.kron_exact and not getattr(self, "_tensor_declined", False) \
+                and os.environ.get("TIGAR_PTAP_UNWRAP", "1") != "0":
+            ku = self.kx.unwrapped()
+            if ku is not None and np.array_equal(ku.fold_maps[-1], np.arange(ku.ncp[-1])):
+                tplan = TensorPtAP.for_extraction(ku)
+                fold = ku if tplan is not None else None
         ring["tensor"] = tplan
         # an FE matrix that is a Kronecker sum of 1-D matrices on the element-coupling pattern is never written: the x
         # pass forms its entries (tg_tensor_planes_kron; TIGAR_PTAP_FUSED=0 materialises the row blocks as before)
@@ -247,7 +256,11 @@ class SlabHotPath(object):
         if tplan is not None and a_factors is not None and os.environ.get("TIGAR_PTAP_FUSED", "1") != "0":
             ring["kron"] = tplan.pack_kron_factors(a_factors)
         if tplan is not None and nslabs > 1:
-            builder = dev.CSRBuilder(self.mine["dofs"][1] - self.mine["dofs"][0], self.ncp, tplan.k_nnz(self.k0, self.k1))
+            if fold is None:
+                builder = dev.CSRBuilder(self.mine["dofs"][1] - self.mine["dofs"][0], self.ncp, tplan.k_nnz(self.k0, self.k1))
+            else:
+                pl_u = int(np.prod(fold.ncp[:-1]))
+                builder = dev.CSRBuilder((self.k1 - self.k0) * pl_u, pl_u * fold.ncp[-1], tplan.k_nnz(self.k0, self.k1))
         overlap = (self.factored and self.kron_exact and len(subs) > 1
                    and os.environ.get("TIGAR_OVERLAP", "0") == "1")
         sched = []
@@ -316,7 +329,7 @@ class SlabHotPath(object):
             t0 = time.perf_counter()
             if use_factored:
                 try:
-                    kblk = self._factored_slab(A, S, ka, kb, zero_dofs, diag, ring,
+                    kblk = self._factored_slab(A, S, ka, kb, zero_dofs if fold is None else None, diag, ring,
                                                builder if os.environ.get("TIGAR_SLAB_APPEND", "1") != "0" else None)
                 except _TensorDeclined:
                     # A does not carry the element-coupling pattern (found while it was read): start over with
@@ -348,11 +361,11 @@ class SlabHotPath(object):
                     # from the densest (last = most interior) dof plane of the first slab: rows near
                     # the patch boundary are sparser, so the slab average underestimates and the
                     # builder would have to grow (a second 75 GB allocation and copy at cfg3)
-                    pd = self.layout.plane_dofs
+                    pd = self.layout.plane_dofs if fold is None else int(np.prod(fold.ncp[:-1]))
                     nr = kblk.shape[0]
                     last = kblk.nnz - kblk.rowptr_at(nr - pd) if nr >= pd else kblk.nnz
                     est = int(max(kblk.nnz / max(1, kb - ka), last) * (self.k1 - self.k0) * 1.01) + 1024
-                    builder = dev.CSRBuilder(self.mine["dofs"][1] - self.mine["dofs"][0], self.ncp, est)
+                    builder = dev.CSRBuilder((self.k1 - self.k0) * pd, self.ncp if fold is None else pd * fold.ncp[-1], est)
                 builder.append(kblk)
             del kblk
             tick("stack", t0)
@@ -368,6 +381,8 @@ class SlabHotPath(object):
             del A, M, MT, b, plan
         t0 = time.perf_counter()
         K = k_blocks[0] if builder is None else builder.finish()
+        if fold is not None:
+            K = fold.fold(K, zero_dofs, diag, planes=(self.k0, self.k1))
         rhs = None
         if with_rhs:
             rhs = rhs_parts[0] if len(rhs_parts) == 1 else dev.vec_concat(rhs_parts)

@@ -74,6 +74,110 @@ class KronExtraction(object):
                 return False
         return True
 
+    # ---- periodic directions: the space before the identification of the wrapped functions --------------------
+    def unwrapped(self):
+        """The extraction onto the UNWRAPPED space of a patch with periodic directions, or None when no direction wraps
+        (or one cannot be unwrapped).
+
+        A periodic B-spline direction (tIGAr/BSplines.py:204-212, 246-260: ghost knots continue the knot vector, ncp =
+        len(knots) - multiplicity of the first) numbers the p+1 functions of a span ``(i - p + q) mod ncp``.  Before the
+        ``mod`` the functions of consecutive spans form the same chain e, e+1, ... as on an open knot vector with simple
+        interior knots: nel + p functions, the last p of which are the first p again.  So M = M_u R with M_u the
+        extraction onto that chain -- which has exactly the structure of the tensor line walks (``tensorptap.py``) -- and
+        R the 0/1 identification matrix, one entry per row:  K = M^T A M = R^T (M_u^T A M_u) R.  ``fold`` applies R.
+
+        The unwrapped function index of every node is found from the node tables alone (monotone continuation of the
+        first function along the nodes), not from a convention about where the numbering starts."""
+        if "_unwrapped" in self.__dict__:
+            return self._unwrapped
+        self._unwrapped = None
+        if self.columns_ascending() or not self.columns_distinct():
+            return None
+        ku = KronExtraction.__new__(KronExtraction)
+        ku.basis, ku.grid, ku.d = self.basis, self.grid, self.d
+        ku.M1, ku._tables, maps = [], [], []
+        for k in range(self.d):
+            _, idx, val = self._tables[k]
+            idx = np.asarray(idx, dtype=np.int64)
+            val = np.asarray(val, dtype=np.float64)
+            ncp, p = self.ncp[k], idx.shape[1] - 1
+            if np.all(np.diff(idx, axis=1) > 0):
+                ku.M1.append(self.M1[k])
+                ku._tables.append(self._tables[k])
+                maps.append(np.arange(ncp, dtype=np.int64))
+                continue
+            if np.any((idx[:, 1:] - idx[:, :-1]) % ncp != 1):
+                return None                               # not a chain of consecutive functions
+            step = np.concatenate([[0], (idx[1:, 0] - idx[:-1, 0]) % ncp])
+            if np.any(step > p + 1):
+                return None
+            g = np.cumsum(step)[:, None] + np.arange(p + 1, dtype=np.int64)[None, :]
+            n, n_u = idx.shape[0], int(g.max()) + 1
+            rows = np.repeat(np.arange(n), p + 1)
+            nz = val.ravel() != 0.0
+            M1u = sp.coo_matrix((val.ravel()[nz], (rows[nz], g.ravel()[nz])), shape=(n, n_u)).tocsr()
+            M1u.sort_indices()
+            fold = (np.arange(n_u, dtype=np.int64) + int(idx[0, 0])) % ncp
+            R1 = sp.csr_matrix((np.ones(n_u), fold, np.arange(n_u + 1)), shape=(n_u, ncp))
+            if abs(M1u @ R1 - self.M1[k]).max() != 0.0:
+                return None
+            ku.M1.append(M1u)
+            ku._tables.append((None, g, val))
+            maps.append(fold)
+        ku.M1T = [m.T.tocsr() for m in ku.M1]
+        for m in ku.M1T:
+            m.sort_indices()
+        ku.nfe = [m.shape[0] for m in ku.M1]
+        ku.ncp = [m.shape[1] for m in ku.M1]
+        ku.nnz_product = int(np.prod([m.nnz for m in ku.M1], dtype=np.float64))
+        ku.fold_maps, ku.wrapped_ncp = maps, list(self.ncp)
+        ku._unwrapped = None
+        self._unwrapped = ku
+        return ku
+
+    def fold_operators(self, nfields=1):
+        """(R, R^T) on the device for an UNWRAPPED extraction (``unwrapped``): R[g, fold(g)] = 1, unwrapped dofs x dofs,
+        direction 0 fastest, ``nfields`` fields numbered field after field; kept on the object"""
+        cache = self.__dict__.setdefault("_fold_ops", {})
+        if nfields not in cache:
+            m = self.fold_maps[0]
+            stride = self.wrapped_ncp[0]
+            for k in range(1, self.d):
+                m = (m[None, :] + stride * self.fold_maps[k][:, None]).ravel()
+                stride *= self.wrapped_ncp[k]
+            n_u, n = m.size, stride
+            if nfields > 1:
+                m = (m[None, :] + n * np.arange(nfields, dtype=np.int64)[:, None]).ravel()
+            R = sp.csr_matrix((np.ones(m.size), m, np.arange(m.size + 1)), shape=(n_u * nfields, n * nfields))
+            RT = R.T.tocsr()
+            RT.sort_indices()
+            cache[nfields] = (_dev.DeviceCSR.from_scipy(R), RT, {})
+        return cache[nfields]
+
+    def fold(self, K_u, zero_dofs=None, diag=1.0, planes=None, nfields=1):
+        """K = R^T K_u R with MatZeroRowsColumns applied (tIGAr/common.py:1196-1204): the rows of the wrapped functions
+        are added to the rows they are identified with, the columns renamed -- one pass of the general PtAP kernels
+        over K_u (its cost: one accumulation per entry).  ``planes`` = (k0, k1): K_u holds the rows of the dof planes
+        [k0, k1) of the last direction only (global unwrapped columns), and so does the result (a direction that wraps
+        cannot be the slab direction)."""
+        R, RT_host, rt_cache = self.fold_operators(nfields)
+        if planes is None:
+            a_row0 = mt_row0 = 0
+            key = None
+        else:
+            assert nfields == 1 and np.array_equal(self.fold_maps[-1], np.arange(self.ncp[-1]))
+            pl_u = int(np.prod(self.ncp[:-1])) if self.d > 1 else 1
+            pl = int(np.prod(self.wrapped_ncp[:-1])) if self.d > 1 else 1
+            a_row0, mt_row0 = planes[0] * pl_u, planes[0] * pl
+            key = (int(planes[0]), int(planes[1]))
+        if key not in rt_cache:
+            if len(rt_cache) > 4:
+                rt_cache.clear()
+            rt_cache[key] = _dev.DeviceCSR.from_scipy(RT_host if key is None else RT_host[key[0] * pl:key[1] * pl])
+        RT = rt_cache[key]
+        plan = _dev.ptap_symbolic(K_u, R, RT, a_row0, 0, mt_row0)
+        return _dev.ptap_numeric(plan, K_u, R, RT, zero_dofs, diag)
+
     def is_exact_for(self, M_nnz, eps):
         """True if generateM's filter dropped only exact zeros, i.e. M == kron(M_k) entrywise."""
         small = any(np.any(np.abs(m.data) <= eps) for m in self.M1)
@@ -165,6 +269,13 @@ def ptap_factored(kx, A, a_planes, c_planes, k_planes, zero_dofs=None, diag=1.0,
     # when the patch or A's pattern does not qualify, and the general stages below take over
     from .tensorptap import TensorPtAP
     plan = TensorPtAP.for_extraction(kx)
+    if plan is None and not A.is_loose() and (za, zb) == (0, kx.nfe[-1]) and (k0, k1) == (0, kx.ncp[-1]) \
+            and os.environ.get("TIGAR_PTAP_UNWRAP", "1") != "0":
+        # periodic directions: the line walks on the unwrapped space, then the identification of the wrapped functions
+        ku = kx.unwrapped()
+        if ku is not None and TensorPtAP.for_extraction(ku) is not None:
+            K_u = ptap_factored(ku, A, a_planes, c_planes, (0, ku.ncp[-1]), None, 1.0, None, _split)
+            return ku.fold(K_u, zero_dofs, diag)
     if plan is not None and not A.is_loose():
         piece = plan.planes(A, za * kx.plane(set()), za, zb)
         if piece is not None:
