@@ -331,6 +331,42 @@ def test_slab_streaming_path_matches_resident_path(T):
         assert set(timers) >= {"extract", "input", "ptap", "mtb", "stack"}
 
 
+@pytest.mark.parametrize("p,nel,fused", [(2, 12, True), (3, 10, False)])
+def test_periodic_patch_streamed_in_sub_slabs(T, p, nel, fused):
+    """a patch periodic in x and y streamed through the slab engine (the slab direction z stays open): the tensor line walks
+    run on the unwrapped space sub-slab by sub-slab, the rank's rows of K_u are folded at the end (kronptap.unwrapped /
+    fold); K rows, M^T b against the one-slab path and the oracle -- FE matrix as Kronecker-sum factors fused into the
+    first pass and as materialised row blocks"""
+    from tigar_amd.dist import SlabHotPath
+    from tigar_amd.common import TensorFunctionSpace
+    B, F, dev = T.B, T.F, T.dev
+    d = 3
+    kv = [B.uniformKnots(p, 0., 1., nel, True), B.uniformKnots(p, 0., 1., nel + 1, True), B.uniformKnots(p, 0., 1., nel - 1)]
+    basis = B.ExplicitBSplineControlMesh([p] * d, kv).getScalarSpline()
+    grid = basis.generateMesh(degree=p)
+    V = TensorFunctionSpace([grid], "Lagrange")
+    lap = F.LaplaceForm()
+    load = F.SeparableLoadForm([lambda x: np.sin(2 * np.pi * x)] * 2 + [lambda x: np.sin(np.pi * x)], scale=2.0)
+    zd = basis.getSideDofs(2, 0) + basis.getSideDofs(2, 1)
+    a_fac = lap.factors(V) if fused else None
+    a_rows, b_rows = (lambda a, b: lap.assemble_matrix(V, a, b)), (lambda a, b: load.assemble_vector(V, a, b))
+    s = O.BSpline([p] * d, [O.uniform_knots(p, 0., 1., nel, True), O.uniform_knots(p, 0., 1., nel + 1, True),
+                            O.uniform_knots(p, 0., 1., nel - 1)])
+    Mo = O.generate_M_tensor(s)
+    Ao = lap.assemble_matrix(V).to_scipy()
+    Ko = O.extract_matrix(Mo, Ao, zd, diag=1.25)
+    ro = O.extract_vector(Mo, load.assemble_vector(V).get_local(), zd)
+    for sub in (None, 3, 5):
+        path = SlabHotPath(basis, grid, sub_planes=sub)
+        dev.prof_reset()
+        K, r = path.assemble(a_rows, b_rows, zd, 1.25, None, a_fac)
+        assert dev.prof_get(5)[1] >= len(path.sub_slabs())                   # every sub-slab through the walks
+        Ks = K.to_scipy()
+        assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
+        assert abs(Ks - Ko).max() <= 1e-12 * abs(Ko).max()
+        assert np.max(np.abs(r.get_local() - ro)) <= 1e-12 * np.max(np.abs(ro))
+
+
 def test_rccl_world1_comm_roundtrip(T):
     """RCCL communicator with one rank: slab descriptor, halo extend and all-reduce are
     identities; the distributed Krylov entry point runs through the comm branch."""

@@ -10,7 +10,10 @@ WORK = [("cfg3 (256^3 p=3)", "r%s_cfg3_kernel_stats.txt" % RND, "r%s_cfg3_pmc_hb
         ("cfg5 (128^2 p=3, 3 fields)", "r%s_cfg5_kernel_stats.txt" % RND, "r%s_cfg5_pmc_hbm.json" % RND),
         # the general extraction kernels (count / scan / fill: active filter, explicit points), forced with TIGAR_EXTRACT_KRON=0
         ("cfg2, general M build", "r%s_cfg2_general_extraction_kernel_stats.txt" % RND,
-         "r%s_cfg2_general_extraction_pmc_hbm.json" % RND)]
+         "r%s_cfg2_general_extraction_pmc_hbm.json" % RND),
+        # the same with the separable-filter shortcut off too (TIGAR_EXTRACT_SEPARABLE=0): the count / scan / fill kernels
+        ("cfg2, general M build, count / fill kernels", "r%s_cfg2_general_extraction_count_fill_kernel_stats.txt" % RND,
+         "r%s_cfg2_general_extraction_count_fill_pmc_hbm.json" % RND)]
 WORK = [w for w in WORK if os.path.exists(os.path.join(HERE, w[1])) and os.path.exists(os.path.join(HERE, w[2]))]
 
 
@@ -45,7 +48,7 @@ def main():
             for d in dur:
                 # mangled name in the stats file, demangled in the counter file: match on the bare function name
                 bare = re.match(r"(?:void )?([A-Za-z_0-9]+)", name).group(1)
-                if bare in d:
+                if "%d%s" % (len(bare), bare) in d or bare == d:       # (_Z<len><name>...: exact function name)
                     key = d
                     break
             if key is None or k["launches"] == 0:
@@ -54,8 +57,8 @@ def main():
             r, w = k["hbm_read_GB_total_corrected"] / k["launches"], k["hbm_write_GB_total"] / k["launches"]
             if r + w < 0.05 or ms < 0.03:
                 continue
-            if label.endswith("general M build") and "k_extract" not in name:
-                continue
+            if "general M build" in label and "k_extract" not in name and not re.match(r"k_kron3_(fill|rowptr)\(", name):
+                continue                                   # (k_kron3_fill_sum_rows is the FE matrix of the bench, not M)
             rate = (r + w) / ms
             frac_w = w / (r + w)
             ceiling = 6.3 if frac_w < 0.05 else (6.2 if frac_w > 0.95 else 5.2)
