@@ -277,6 +277,7 @@ def run(args, wl, d, p, nel):
     nnzK_local, ncp_local = K.nnz, K.shape[0]
     nnzK = nnzK_local if dcomm is None else int(round(dcomm.allreduce_sum([float(nnzK_local)])[0]))
     spmv_ms, spmv_n = dev.prof_get(0)
+    ksp_persistent = dev.prof_get(6)[1]
     ptap_certified = dev.prof_get(3)[1]                   # x passes that took A's pattern from its certificate
     comm_host_waits = dev.prof_get(4)[1]
     sell_classes, sell_padded = K.spmv_sell(True)         # which product kernel the solver used
@@ -377,7 +378,7 @@ def run(args, wl, d, p, nel):
         devs = dcomm.rank_devices() if info[2] == "ipc" else None
         n_used = len(set(devs)) if devs and all(v is not None for v in devs) else min(info[1], ndev)
     return {"ncp": ncp, "nnzK": nnzK, "nnzK_local": nnzK_local, "ncp_local": ncp_local, "elapsed": elapsed,
-            "spmv_ms_total": spmv_ms, "spmv_count": spmv_n, "iterations": its, "stages": mean_stages,
+            "spmv_ms_total": spmv_ms, "spmv_count": spmv_n, "ksp_persistent": ksp_persistent, "iterations": its, "stages": mean_stages,
             "t_input": mean_stages.get("fe_input", 0.0), "t_input_in_timed_region": not a_resident,
             "t_input_pre": t_input_pre, "sub_planes": spline._slab.sub_planes if spline._slab is not None else None,
             "sell_classes": sell_classes, "sell_padded": sell_padded, "implicit_M": bool(getattr(gen.M, "is_implicit", False)),
@@ -581,6 +582,11 @@ def main():
     csr_bytes = spmv_bytes(nnzK_l, ncp_l)
     sell = res.get("sell_padded", 0) > 0 and os.environ.get("TIGAR_SPMV_SELL", "1") != "0"
     kernel = "k_spmv_sell" if sell else "k_spmv_lane"
+    persistent = res.get("ksp_persistent", 0) > 0
+    if persistent:
+        # small systems: the whole CG loop is one kernel with K in registers (csrc/tg_krylov_small.hip); the "launch" below
+        # is one ITERATION of it (product, inner products, two device-wide barriers, updates), not a product kernel
+        kernel = "k_cg_persistent (per iteration; K register-resident)"
     # bytes the product kernel has to move in ITS format: the sliced copy streams 8 B per stored position
     # (values only; the offset dictionary is cache resident), class id + address per slice, x once and y once;
     # the general CSR kernel moves SURVEY.md section 8(d)'s CSR bytes
@@ -684,6 +690,13 @@ def main():
                      "effective_csr_GBps": csr_bytes / spmv_avg_s / 1e9 if spmv_avg_s > 0 else 0.0,
                      "effective_csr_frac_of_peak": csr_bytes / spmv_avg_s / 1e9 / HBM_PEAK_GBS if spmv_avg_s > 0 else 0.0},
     }
+    if persistent:
+        out["roofline"]["bytes_definition"] = ("SURVEY.md 8d's CSR bytes of one product K u, for reference only: the kernel holds K in "
+                                               "registers and reads it ONCE per solve; per iteration it moves the vector u and the "
+                                               "partial sums -- the iteration is bound by two device-wide barriers, not by HBM")
+        out["roofline"]["bytes_per_launch"] = float(csr_bytes)
+        out["roofline"]["achieved"] = csr_bytes / spmv_avg_s / 1e9 if spmv_avg_s > 0 else 0.0
+        out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
     if res["spmv_count"] == 0:
         # no Krylov product was timed (direct solve): the dominant kernel of the path is the triple product
         pt = out["config"]["ptap"]
@@ -697,8 +710,8 @@ def main():
         ref = {}
         for key, fn in (("fe_matrix_materialised_in_row_blocks", "r3_bench_cfg3_fe_matrix_materialised.json"),
                         ("fe_matrix_pattern_verified_entry_by_entry", "r3_bench_cfg3_pattern_verified.json"),
-                        ("arbitrary_A_kronecker_M_line_kernels", "r3_bench_cfg3_general_line.json"),
-                        ("fully_general_hash_ptap_M_slabs_materialised", "r3_bench_cfg3_general_hash.json")):
+                        ("arbitrary_A_kronecker_M_line_kernels", "r4_bench_cfg3_general_line.json"),
+                        ("fully_general_hash_ptap_M_slabs_materialised", "r4_bench_cfg3_general_hash.json")):
             try:
                 g = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 ref[key] = {"value": g["value"], "ms_per_step": g["ms_per_step"], "ptap_s": g["config"]["stages_s"]["ptap"],

@@ -127,3 +127,56 @@ def test_dolfin_solver_and_preconditioner_names_are_mapped_not_refused():
         t.PETScKrylovSolver("no-such-method")
     with pytest.raises(ValueError):
         t.PETScKrylovSolver("gmres", "chebyshev")
+
+
+@pytest.mark.parametrize("d,p,nel,pc", [(2, 3, 48, "jacobi"), (2, 4, 40, "none"), (3, 2, 12, "jacobi"), (2, 2, 9, "jacobi")])
+def test_persistent_cg_for_small_systems(d, p, nel, pc, monkeypatch):
+    """the whole CG loop in one cooperative kernel with two device-wide barriers per iteration (csrc/tg_krylov_small.hip;
+    taken by itself for systems that fit the Infinity Cache): the recurrence of the multi-kernel loop, so the same
+    iteration count (sums are formed in another order: +-1), the same solution; initial guess, maxit, b = 0,
+    bit-reproducibility"""
+    import tigar_amd as t
+    from tigar_amd.device import DeviceVector
+    spline, K, rhs = _poisson(d, p, nel)
+    Ks, b = K.to_scipy().tocsc(), rhs.get_local()
+    exact = sla.spsolve(Ks, b)
+
+    def run(mode, guess=None, rtol=1e-10, maxit=None, vec=rhs):
+        monkeypatch.setenv("TIGAR_KSP_PERSISTENT", mode)
+        s = t.PETScKrylovSolver("cg", pc)
+        s.parameters["relative_tolerance"] = rtol
+        if maxit is not None:
+            s.parameters["maximum_iterations"] = maxit
+            s.parameters["error_on_nonconvergence"] = False
+        U = DeviceVector(K.shape[0]) if guess is None else DeviceVector(data=guess)
+        if guess is not None:
+            s.parameters["nonzero_initial_guess"] = True
+        its = s.solve(K, U, vec)
+        return its, U.get_local(), dict(s.last)
+
+    i1, U1, l1 = run("1")
+    i0, U0, l0 = run("0")
+    assert l1["status"] == 0 and abs(i1 - i0) <= 1, (i1, i0)
+    assert np.max(np.abs(U1 - exact)) <= 1e-7 * np.max(np.abs(exact))
+    assert np.max(np.abs(U1 - U0)) <= 1e-8 * np.max(np.abs(exact))
+    assert abs(l1["residual_norm"] - l0["residual_norm"]) <= 0.5 * l0["residual_norm"] + 1e-300
+    i1b, U1b, _ = run("1")
+    assert i1b == i1 and np.array_equal(U1b.view(np.int64), U1.view(np.int64))          # bit-reproducible
+    # a guess: from the solution at once; from a perturbed solution in fewer iterations, to the same answer
+    ig, Ug, lg = run("1", guess=U1)
+    assert ig <= 1
+    pert = U1 * (1.0 + 1e-3 * np.cos(np.arange(U1.size)))
+    ig1, Ug1, _ = run("1", guess=pert)
+    ig0, Ug0, _ = run("0", guess=pert)
+    assert abs(ig1 - ig0) <= 1
+    assert np.max(np.abs(Ug1 - exact)) <= 1e-7 * np.max(np.abs(exact))
+    # the iteration limit
+    im, Um, lm = run("1", maxit=5)
+    im0, Um0, lm0 = run("0", maxit=5)
+    assert im == 5 == im0 and lm["status"] == lm0["status"] != 0
+    assert np.max(np.abs(Um - Um0)) <= 1e-10 * np.max(np.abs(Um0))
+    # b = 0
+    zero = DeviceVector(K.shape[0])
+    iz, Uz, lz = run("1", vec=zero)
+    iz0, _, lz0 = run("0", vec=zero)
+    assert iz == 0 == iz0 and not Uz.any() and lz["status"] == lz0["status"]

@@ -188,6 +188,10 @@ int tg_sell_spmv_rows(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_
 
 int tg_csr_sort_rows(tg_csr_s *m);
 int tg_csr_transpose_block(tg_csr_s *m, int64_t row_base, int64_t out_ncols, tg_csr_s **out);
+// persistent single-kernel Krylov loop for small systems (tg_krylov_small.hip)
+bool tg_cg_persistent_applies(const tg_csr_s *k);
+int tg_cg_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, int nonzero_guess,
+                     int *iters, double *resnorm, int *status);
 int tg_build_dof_mask(const int32_t *dofs, int64_t n, int64_t ndofs_total, uint8_t **mask_out);
 int64_t tg_spmv_num_partials(tg_csr_s *a);
 

@@ -1560,6 +1560,11 @@ extern "C" int tg_krylov_solve_flags(tg_csr_t k, tg_vec_t b, tg_vec_t x, int met
     // (`restart` carries the degree of the polynomial: the number of products per application + 1)
     return tg_pcg_cheb(k, b, x, restart, rtol, atol, maxit, g_krylov_nonzero_guess, comm, iters, resnorm, status);
   TG_REQUIRE(pc == TG_PC_NONE || pc == TG_PC_JACOBI, "the Chebyshev polynomial preconditioner serves CG only");
+  if (method == TG_KSP_CG && !comm && tg_cg_persistent_applies(k)) {
+    // small systems (K in the Infinity Cache): the whole loop in one persistent kernel; 100 = could not run, the loop below does
+    const int rcp = tg_cg_persistent(k, b, x, pc, rtol, atol, maxit, g_krylov_nonzero_guess, iters, resnorm, status);
+    if (rcp != 100) return rcp;
+  }
   if (method == TG_KSP_CG) return tg_cg(k, b, x, pc, rtol, atol, maxit, g_krylov_nonzero_guess, comm, iters, resnorm, status);
   if (method == TG_KSP_BICGSTAB)
     return tg_bicgstab(k, b, x, pc, rtol, atol, maxit, g_krylov_nonzero_guess, comm, iters, resnorm, status);

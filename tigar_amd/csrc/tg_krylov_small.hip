@@ -1,0 +1,449 @@
+// Krylov solves of SMALL systems in ONE persistent kernel (round 4).
+//
+// solveLinearSystem (tIGAr/common.py:1236-1263) on the 2-D configurations -- cfg4: 67 600 unknowns, 65 MB of K; cfg5:
+// 51 483 unknowns, 89 MB -- is bound by launches, not by bytes: an iteration of the single-reduction CG of tg_krylov.hip is
+// four dependent launches (product, inner product, fold, update: 33 us) around 10 us of memory traffic, and K sits in the
+// 256 MB Infinity Cache the whole time.  Here the whole loop is one kernel: one workgroup per CU owns a contiguous block of
+// rows -- its part of every vector, its rows of K --, the iteration is
+//
+//     w = K u (own rows)            partial (r,u), (w,u), (u,u) of the own rows  ->  HBM slot of the workgroup
+//     -- grid barrier --
+//     every workgroup sums ALL partials in the same fixed order (identical scalars everywhere, no broadcast),
+//     decides convergence, forms alpha / beta, updates p, s, x, r, u = B r on its rows
+//     -- grid barrier --            (u complete before the next product)
+//
+// i.e. the recurrence of tg_cg (Chronopoulos & Gear; KSPCG -ksp_cg_single_reduction [ext]) with two device-wide barriers per
+// iteration instead of four kernel boundaries.  The barrier is a counter + generation word in HBM (agent-scope atomics,
+// release before / acquire after: gfx950 has one L2 per XCD, the fences write back and invalidate what the other XCDs must
+// see), waited for with s_sleep and a wall-clock limit -- a barrier that cannot complete (a workgroup not resident) ends the
+// kernel with an error instead of hanging the GPU; the launch is cooperative, so residency of all workgroups is checked by
+// the runtime.  Sums are formed in a fixed order: the iterates are bit-reproducible run to run (they differ from tg_cg's in
+// the last bits: other partial sums).
+#include "tg_common.h"
+#include <algorithm>
+
+#define PS_NT 512                // threads per workgroup: 2 waves per SIMD, 256 registers per lane -- a CU's share of K fits
+#define PS_GROUPS (PS_NT / 32)   // groups of 32 lanes, one row each at a time
+#define PS_MAXG 512              // workgroups at most (partials are folded by one pass of a workgroup)
+
+#define PS_FAN 16                // workgroups per first-level counter of the barrier
+struct tg_ps_ctrl {
+  unsigned gen;
+  int abort_flag;
+  unsigned pad0[30];
+  unsigned top;                  // second level: groups that are complete
+  unsigned pad1[31];
+  unsigned grp[(PS_MAXG / PS_FAN) * 32];   // first level, one 128-byte line per group of PS_FAN workgroups
+  double out[8];                 // [0] iterations, [1] nu at the end, [2] nu0 (reference), [3] status, [4..7] phase ticks
+};
+
+struct tg_ps_args {
+  const int64_t *rowptr;
+  const int32_t *col;
+  const double *val;
+  int64_t n;
+  const double *b;
+  double *x;
+  double *u;                     // u = B r, all rows (the other workgroups gather it)
+  double *partial;               // [G][4]
+  tg_ps_ctrl *ctrl;
+  double rtol, atol;
+  int maxit, jacobi, nonzero_guess, pad;
+  long long budget_ticks;        // wall_clock64 ticks the kernel may wait at one barrier
+};
+
+__device__ __forceinline__ bool ps_barrier(tg_ps_ctrl *c, unsigned G, unsigned &gen, long long budget) {
+  // The stores of the workgroup are ordered before thread 0's release by the workgroup barrier (cumulativity), the loads after
+  // its acquire likewise: ONE write-back and ONE invalidate per workgroup and barrier -- with a fence in every wave, or an
+  // acquire load in the spin loop, every poll invalidated the L2 (measured: 90 us per barrier instead of 3).
+  __syncthreads();
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    const unsigned target = gen + 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // two levels (atomics on ONE address are served one after the other, ~12 ns each: 256 of them are 3 us)
+    const unsigned grp = blockIdx.x / PS_FAN, ngrp = (G + PS_FAN - 1) / PS_FAN;
+    const unsigned gsz = grp + 1 < ngrp ? PS_FAN : G - grp * PS_FAN;
+    bool last = false;
+    if (__hip_atomic_fetch_add(&c->grp[32 * grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsz - 1) {
+      __hip_atomic_store(&c->grp[32 * grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+      if (__hip_atomic_fetch_add(&c->top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1) last = true;
+    }
+    if (last) {
+      __hip_atomic_store(&c->top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+      __hip_atomic_store(&c->gen, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const long long t0 = wall_clock64();
+      unsigned spins = 0;
+      while (__hip_atomic_load(&c->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0u) {
+          if (__hip_atomic_load(&c->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            ok = 0;
+            break;
+          }
+          if (wall_clock64() - t0 > budget) {
+            __hip_atomic_store(&c->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = 0;
+            break;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_ok = ok;
+  }
+  gen++;
+  __syncthreads();
+  return s_ok != 0;
+}
+
+// three sums over the workgroup at once, fixed order (wave shuffles, then the wave sums by threads 0..2); valid in every thread
+__device__ __forceinline__ void ps_block_sum3(double &a, double &b, double &c, double *lds /* [3 * 17] */) {
+  a = tg_wave_sum(a);
+  b = tg_wave_sum(b);
+  c = tg_wave_sum(c);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    lds[w] = a;
+    lds[17 + w] = b;
+    lds[34 + w] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = 0.0;
+    for (int q = 0; q < PS_NT / 64; q++) t += lds[17 * threadIdx.x + q];
+    lds[17 * threadIdx.x + 16] = t;
+  }
+  __syncthreads();
+  a = lds[16];
+  b = lds[33];
+  c = lds[50];
+  __syncthreads();                       // (the slots are written again by the next call)
+}
+
+// The rows of the workgroup live in REGISTERS: 32 lanes per row, EPR entries of the row per lane, RI rows per group of lanes
+// (local row = group + 32 * ri), padded with (value 0, own column) -- 32 slots of (8 B value, 4 B column) per thread, a
+// whole CU holds 384 KB of K.  The workgroup's part of every vector lives in LDS; only u = B r goes to HBM (the other
+// workgroups gather it), x at the end.
+#define PS_ROWS_MAX 1024           // local rows at most (vectors in LDS)
+struct ps_lds {
+  double x[PS_ROWS_MAX], r[PS_ROWS_MAX], p[PS_ROWS_MAX], s[PS_ROWS_MAX], u[PS_ROWS_MAX], w[PS_ROWS_MAX], dinv[PS_ROWS_MAX];
+  double red[3 * 17];
+};
+
+template <int EPR, int RI>
+__device__ __forceinline__ void ps_product(const double (&v)[RI][EPR], const unsigned (&c)[RI][EPR], const double *__restrict__ xg,
+                                           double *__restrict__ w_lds, int nloc) {
+  // c: BYTE offsets into xg (uniform base + 32-bit lane offset: no 64-bit address per entry).  The gathers are issued in
+  // batches of PS_BATCH rows -- all of them at once (what the scheduler does when left alone) needs two registers per entry
+  // for the values in flight on top of the three that hold the entry, and the kernel spills.
+  constexpr int PS_BATCH = EPR >= 3 ? 6 : EPR == 2 ? 9 : 18;
+  const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
+  // (raw buffer loads: the descriptor in scalar registers, ONE 32-bit register per entry for the offset -- as pointers the
+  //  compiler kept a 64-bit offset per entry: 4 registers per entry instead of 3)
+  const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc((void *)xg, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+  for (int r0 = 0; r0 < RI; r0 += PS_BATCH) {
+    double xs[PS_BATCH][EPR];
+#pragma unroll
+    for (int ri = r0; ri < r0 + PS_BATCH && ri < RI; ri++)
+#pragma unroll
+      for (int k = 0; k < EPR; k++)
+        xs[ri - r0][k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xb, (int)c[ri][k], 0, 0));
+#pragma unroll
+    for (int ri = r0; ri < r0 + PS_BATCH && ri < RI; ri++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < EPR; k++) acc = fma(v[ri][k], xs[ri - r0][k], acc);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      const int lrow = g + PS_GROUPS * ri;
+      if (l == 0 && lrow < nloc) w_lds[lrow] = acc;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int EPR, int RI>
+__global__ void __launch_bounds__(PS_NT) k_cg_persistent(tg_ps_args A) {
+  extern __shared__ double ps_dyn[];
+  ps_lds &L = *(ps_lds *)ps_dyn;
+  const unsigned G = gridDim.x;
+  unsigned gen = 0;
+  const int64_t per = (A.n + G - 1) / G;
+  const int64_t c0r = (int64_t)blockIdx.x * per, c0 = c0r < A.n ? c0r : A.n, c1 = c0 + per < A.n ? c0 + per : A.n;
+  const int nloc = (int)(c1 - c0);
+  const int tid = threadIdx.x, g = tid >> 5, l = tid & 31;
+  // ---- the rows of K into registers; the Jacobi diagonal (PCJACOBI [ext]: 1 where the diagonal is zero / absent)
+  double v[RI][EPR];
+  unsigned c[RI][EPR];           // byte offsets of the columns
+#pragma unroll
+  for (int ri = 0; ri < RI; ri++) {
+    const int lrow = g + PS_GROUPS * ri;
+    const int64_t row = c0 + lrow;
+    const bool live = lrow < nloc;
+    const int64_t a = live ? A.rowptr[row] : 0, e = live ? A.rowptr[row + 1] : 0;
+    double dd = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPR; k++) {
+      const int64_t q = a + l + 32 * k;
+      const bool in = q < e;
+      v[ri][k] = in ? A.val[q] : 0.0;
+      const int cq = in ? A.col[q] : (int)(live ? row : 0);
+      c[ri][k] = 8u * (unsigned)cq;
+      if (in && cq == row) dd = v[ri][k];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) dd += __shfl_xor(dd, o, 64);
+    if (l == 0 && live) L.dinv[lrow] = (A.jacobi && dd != 0.0) ? 1.0 / dd : 1.0;
+  }
+  __syncthreads();
+  double bn = 0.0;                         // ||B b||^2 of the own rows (reference norm when a guess is given)
+  if (A.nonzero_guess) {
+    ps_product<EPR, RI>(v, c, A.x, L.w, nloc);      // r = b - K x0: all of x0 was written before the launch
+    __syncthreads();
+  }
+  double gp = 0.0, np = 0.0, dp = 0.0;     // this thread's terms of (r,u), (u,u), (w,u)
+  for (int i = tid; i < nloc; i += PS_NT) {
+    const double bi = A.b[c0 + i];
+    const double ri = A.nonzero_guess ? bi - L.w[i] : bi;
+    const double ui = L.dinv[i] * ri;
+    const double ub = L.dinv[i] * bi;
+    bn += ub * ub;
+    L.x[i] = A.nonzero_guess ? A.x[c0 + i] : 0.0;
+    L.r[i] = ri;
+    L.u[i] = ui;
+    L.p[i] = 0.0;
+    L.s[i] = 0.0;
+    A.u[c0 + i] = ui;
+    gp += ri * ui;
+    np += ui * ui;
+  }
+  {
+    double z0 = 0.0, z1 = 0.0;
+    ps_block_sum3(bn, z0, z1, L.red);
+    if (tid == 0) A.partial[4 * blockIdx.x + 3] = bn;
+  }
+  if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;          // u complete
+  double gamma_prev = 0.0, alpha_prev = 0.0, tol2 = 0.0, nu0 = 0.0, nu = 0.0;
+  int it = 0, status = -1;
+  long long t_spmv = 0, t_bar1 = 0, t_upd = 0, t_bar2 = 0;
+#ifdef PS_TIMING
+  long long t_mark = wall_clock64();
+#endif
+#ifdef PS_TIMING
+#define PS_MARK(acc)                       \
+  do {                                     \
+    const long long now_ = wall_clock64(); \
+    acc += now_ - t_mark;                  \
+    t_mark = now_;                         \
+  } while (0)
+#else
+#define PS_MARK(acc) (void)acc
+#endif
+  for (;;) {
+    // ---- w = K u on the own rows, the three inner products of the own rows
+    ps_product<EPR, RI>(v, c, A.u, L.w, nloc);
+    __syncthreads();
+    dp = 0.0;
+    for (int i = tid; i < nloc; i += PS_NT) dp += L.w[i] * L.u[i];
+    {
+      double a = gp, b = dp, cc = np;
+      ps_block_sum3(a, b, cc, L.red);
+      if (tid == 0) {
+        A.partial[4 * blockIdx.x] = a;
+        A.partial[4 * blockIdx.x + 1] = b;
+        A.partial[4 * blockIdx.x + 2] = cc;
+      }
+    }
+    PS_MARK(t_spmv);
+    if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
+    PS_MARK(t_bar1);
+    double gamma = 0.0, delta = 0.0;
+    nu = 0.0;
+    if (tid < (int)G) {
+      gamma = A.partial[4 * tid];
+      delta = A.partial[4 * tid + 1];
+      nu = A.partial[4 * tid + 2];
+    }
+    ps_block_sum3(gamma, delta, nu, L.red);
+    if (it == 0) {
+      // reference norm: ||B r0||, or ||B b|| with a guess (KSPConvergedDefault [ext]); as tg_cg
+      double ref = nu;
+      if (A.nonzero_guess) {
+        double t = tid < (int)G ? A.partial[4 * tid + 3] : 0.0, z0 = 0.0, z1 = 0.0;
+        ps_block_sum3(t, z0, z1, L.red);
+        ref = t;
+      }
+      nu0 = ref;
+      const double tol = fmax(A.rtol * sqrt(ref), A.atol);
+      tol2 = tol * tol;
+    }
+    if (!(nu == nu)) {
+      status = -2;
+      break;
+    }
+    if (!(nu > tol2)) {
+      const double zn = sqrt(nu);
+      status = it == 0 ? (zn <= A.atol ? 1 : 0) : ((zn <= A.atol && !(zn <= A.rtol * sqrt(nu0))) ? 1 : 0);
+      break;
+    }
+    if (it >= A.maxit) break;
+    double beta = 0.0, alpha;
+    if (it == 0)
+      alpha = gamma / delta;
+    else {
+      beta = gamma / gamma_prev;
+      alpha = gamma / (delta - beta * gamma / alpha_prev);
+    }
+    gamma_prev = gamma;
+    alpha_prev = alpha;
+    gp = 0.0;
+    np = 0.0;
+    for (int i = tid; i < nloc; i += PS_NT) {
+      const double pi = L.u[i] + beta * L.p[i];
+      const double si = L.w[i] + beta * L.s[i];
+      L.p[i] = pi;
+      L.s[i] = si;
+      L.x[i] += alpha * pi;
+      const double ri = L.r[i] - alpha * si;
+      L.r[i] = ri;
+      const double ui = L.dinv[i] * ri;
+      L.u[i] = ui;
+      A.u[c0 + i] = ui;
+      gp += ri * ui;
+      np += ui * ui;
+    }
+    it++;
+    PS_MARK(t_upd);
+    if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;        // u complete before the next product
+    PS_MARK(t_bar2);
+  }
+  for (int i = tid; i < nloc; i += PS_NT) A.x[c0 + i] = L.x[i];
+  if (blockIdx.x == 0 && tid == 0) {
+    A.ctrl->out[0] = (double)it;
+    A.ctrl->out[1] = nu;
+    A.ctrl->out[2] = nu0;
+    A.ctrl->out[3] = (double)status;
+    A.ctrl->out[4] = (double)t_spmv;
+    A.ctrl->out[5] = (double)t_bar1;
+    A.ctrl->out[6] = (double)t_upd;
+    A.ctrl->out[7] = (double)t_bar2;
+  }
+}
+
+// Whether a system is taken by the persistent loop: one rank, at least a few thousand rows (below, the launches are not what
+// the solve costs), rows of at most 128 entries, and all of K in the registers of one workgroup per CU
+// (TIGAR_KSP_PERSISTENT=0 turns it off, =1 lifts the lower limit).
+static const int PS_RI[4][4] = {{16, 32, 48, 56}, {8, 16, 24, 28}, {6, 12, 17, 18}, {4, 8, 12, 14}};   // rows per group of lanes, by EPR
+static bool ps_shape(const tg_csr_s *k, int *epr_out, int *ri_out, int *g_out) {
+  const int64_t n = k->nrows;
+  const int maxlen = k->max_row_nnz;
+  if (maxlen < 1 || maxlen > 128) return false;
+  const int epr = (maxlen + 31) / 32;
+  int G = std::min<int>(g_tg.num_cu, PS_MAXG);
+  G = (int)std::min<int64_t>(G, std::max<int64_t>(1, tg_cdiv(n, PS_GROUPS)));
+  const int64_t per = tg_cdiv(n, G);
+  if (per > PS_ROWS_MAX) return false;
+  for (int q = 0; q < 4; q++)
+    if (per <= (int64_t)PS_RI[epr - 1][q] * PS_GROUPS) {
+      *epr_out = epr;
+      *ri_out = PS_RI[epr - 1][q];
+      *g_out = G;
+      return true;
+    }
+  return false;
+}
+
+bool tg_cg_persistent_applies(const tg_csr_s *k) {
+  const int mode = getenv("TIGAR_KSP_PERSISTENT") ? atoi(getenv("TIGAR_KSP_PERSISTENT")) : -1;
+  if (mode == 0 || k->nrows < 1 || k->nrows != k->ncols || k->nnz < 1) return false;
+  return mode == 1 || k->nrows >= 4096;
+}
+
+// Returns 0 with the results set, 100 when the kernel could not be used (K beyond the registers, workgroups not resident,
+// barrier time-out): the caller runs the multi-kernel loop instead.
+int tg_cg_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, int nonzero_guess,
+                     int *iters, double *resnorm, int *status) {
+  const int64_t n = k->nrows;
+  TG_TRY(tg_spmv_plan(k));                   // (longest row)
+  int epr = 0, ri = 0, G = 0;
+  if (!ps_shape(k, &epr, &ri, &G)) return 100;
+  double *buf = nullptr;
+  const int64_t ctrl_doubles = (int64_t)(sizeof(tg_ps_ctrl) + 7) / 8 + 16;
+  TG_TRY(tg_dmalloc(&buf, n + 4 * (int64_t)G + 16 + ctrl_doubles));
+  tg_ps_args A;
+  memset(&A, 0, sizeof(A));
+  A.rowptr = k->rowptr;
+  A.col = k->col;
+  A.val = k->val;
+  A.n = n;
+  A.b = b->d;
+  A.x = x->d;
+  A.u = buf;
+  A.partial = buf + n;
+  A.ctrl = (tg_ps_ctrl *)(((uintptr_t)(buf + n + 4 * (int64_t)G) + 127) & ~(uintptr_t)127);
+  A.rtol = rtol;
+  A.atol = atol;
+  A.maxit = maxit;
+  A.jacobi = pc == TG_PC_JACOBI ? 1 : 0;
+  A.nonzero_guess = nonzero_guess;
+  A.budget_ticks = 100000000ll * 5;          // wall_clock64 runs at 100 MHz: 5 s at one barrier
+  hipMemsetAsync(A.ctrl, 0, sizeof(tg_ps_ctrl), g_tg.stream);
+  void *params[] = {&A};
+  const void *fn = nullptr;
+#define PS_PICK(E, R) \
+  if (epr == E && ri == R) fn = (const void *)k_cg_persistent<E, R>
+  PS_PICK(1, 16); PS_PICK(1, 32); PS_PICK(1, 48); PS_PICK(1, 56);
+  PS_PICK(2, 8); PS_PICK(2, 16); PS_PICK(2, 24); PS_PICK(2, 28);
+  PS_PICK(3, 6); PS_PICK(3, 12); PS_PICK(3, 17); PS_PICK(3, 18);
+  PS_PICK(4, 4); PS_PICK(4, 8); PS_PICK(4, 12); PS_PICK(4, 14);
+#undef PS_PICK
+  if (!fn) {
+    tg_dfree(buf);
+    return 100;
+  }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEventCreate(&ev0);
+  hipEventCreate(&ev1);
+  hipEventRecord(ev0, g_tg.stream);
+  hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)G), dim3(PS_NT), params, sizeof(ps_lds), g_tg.stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    hipEventDestroy(ev0);
+    hipEventDestroy(ev1);
+    tg_dfree(buf);
+    return 100;
+  }
+  hipEventRecord(ev1, g_tg.stream);
+  tg_ps_ctrl h;
+  e = hipMemcpyAsync(&h, A.ctrl, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream);
+  const hipError_t e2 = hipStreamSynchronize(g_tg.stream);
+  float ems = 0.f;
+  if (e2 == hipSuccess && hipEventElapsedTime(&ems, ev0, ev1) != hipSuccess) ems = 0.f;
+  hipEventDestroy(ev0);
+  hipEventDestroy(ev1);
+  tg_dfree(buf);
+  if (e != hipSuccess || e2 != hipSuccess) {
+    tg_set_error("persistent CG: %s", hipGetErrorString(e2 != hipSuccess ? e2 : e));
+    return 1;
+  }
+  if (h.abort_flag) return 100;
+  if (getenv("TIGAR_TRACE"))
+    fprintf(stderr, "[trace] persistent cg: %d its, workgroup 0 per iteration: product+dots %.2f us, barrier %.2f us, fold+update %.2f us, "
+            "barrier %.2f us (%d workgroups, %d entries per lane and row, %d rows per group of lanes)\n", (int)h.out[0], h.out[4] / 100.0 / std::max(1.0, h.out[0]),
+            h.out[5] / 100.0 / std::max(1.0, h.out[0]), h.out[6] / 100.0 / std::max(1.0, h.out[0]),
+            h.out[7] / 100.0 / std::max(1.0, h.out[0]), G, epr, ri);
+  g_tg.prof_n[TG_PROF_KSP_PERSISTENT] += 1;
+  g_tg.prof_ms[TG_PROF_KSP_PERSISTENT] += ems;
+  g_tg.prof_n[TG_PROF_KSP_SPMV] += (int64_t)h.out[0] + 1 + (nonzero_guess ? 1 : 0);
+  g_tg.prof_ms[TG_PROF_KSP_SPMV] += ems;
+  *iters = (int)h.out[0];
+  *resnorm = sqrt(h.out[1]);
+  *status = (int)h.out[3];
+  return 0;
+}
