@@ -586,7 +586,7 @@ def main():
     if persistent:
         # small systems: the whole CG loop is one kernel with K in registers (csrc/tg_krylov_small.hip); the "launch" below
         # is one ITERATION of it (product, inner products, two device-wide barriers, updates), not a product kernel
-        kernel = "k_cg_persistent (per iteration; K register-resident)"
+        kernel = "%s (per iteration; K register-resident)" % ("k_gmres_persistent" if res["method"] == "gmres" else "k_cg_persistent")
     # bytes the product kernel has to move in ITS format: the sliced copy streams 8 B per stored position
     # (values only; the offset dictionary is cache resident), class id + address per slice, x once and y once;
     # the general CSR kernel moves SURVEY.md section 8(d)'s CSR bytes

@@ -56,8 +56,8 @@ int tg_timer_stop(int slot, double *ms);   /* synchronises; elapsed ms since sta
  * matrix' pattern from its certificate (written by tg_kron_sum_csr) instead of verifying every column index; slot 4 (count only): host waits
  * (hipStreamSynchronize / transport calls) the device communicator needed inside halo exchanges and all-reduces -- 0 for
  * RCCL and for the IPC communicator, whose exchanges are enqueued only; slot 5 (count only): final stages of the
- * tensor-pattern PtAP (tg_tensor_zstage, tg_tensor2_ptap) that delivered rows of K -- "the line walks ran"; slot 6: CG
- * solves that ran as ONE persistent kernel (small systems, csrc/tg_krylov_small.hip): count, and the time of those kernels
+ * tensor-pattern PtAP (tg_tensor_zstage, tg_tensor2_ptap) that delivered rows of K -- "the line walks ran"; slot 6: CG /
+ * GMRES solves that ran as ONE persistent kernel (small systems, csrc/tg_krylov_small.hip): count, and the time of those kernels
  * (their products are also counted in slot 0, with the kernel time spread over them -- an iteration, not a product). */
 enum { TG_PROF_KSP_SPMV = 0, TG_PROF_KSP_OVERLAPPED = 1, TG_PROF_SELL_SHAPE_REUSED = 2, TG_PROF_PTAP_CERTIFIED = 3,
        TG_PROF_COMM_HOST_WAITS = 4, TG_PROF_PTAP_TENSOR_WALKS = 5, TG_PROF_KSP_PERSISTENT = 6, TG_PROF_NSLOTS = 8 };

@@ -180,3 +180,55 @@ def test_persistent_cg_for_small_systems(d, p, nel, pc, monkeypatch):
     iz, Uz, lz = run("1", vec=zero)
     iz0, _, lz0 = run("0", vec=zero)
     assert iz == 0 == iz0 and not Uz.any() and lz["status"] == lz0["status"]
+
+
+@pytest.mark.parametrize("pc,restart", [("jacobi", 30), ("jacobi", 5), ("none", 12)])
+def test_persistent_gmres_for_small_systems(pc, restart, monkeypatch):
+    """GMRES(m) in one cooperative kernel (csrc/tg_krylov_small.hip: rows of K in registers, the workgroup's rows of the
+    basis in LDS, three device-wide barriers per inner iteration) against the multi-kernel loop on a non-symmetric system:
+    iteration count (restart cycles included), solution, reported norm, guess, iteration limit, b = 0, bit-reproducibility"""
+    import tigar_amd as t
+    from tigar_amd.device import DeviceCSR, DeviceVector
+    A, b = _nonsymmetric(n=36, seed=9)
+    # (more weight on the diagonal: the short restarts must converge, not stagnate)
+    A = (A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() * 0.5)).tocsr()
+    exact = sla.spsolve(A.tocsc(), b)
+    Ad = DeviceCSR.from_scipy(A)
+
+    def run(mode, guess=None, rtol=1e-10, maxit=None, vec=b):
+        monkeypatch.setenv("TIGAR_KSP_PERSISTENT", mode)
+        s = t.PETScKrylovSolver("gmres", pc)
+        s.parameters["relative_tolerance"] = rtol
+        s.parameters["gmres_restart"] = restart
+        if maxit is not None:
+            s.parameters["maximum_iterations"] = maxit
+            s.parameters["error_on_nonconvergence"] = False
+        x = DeviceVector(A.shape[0]) if guess is None else DeviceVector(data=guess)
+        if guess is not None:
+            s.parameters["nonzero_initial_guess"] = True
+        its = s.solve(Ad, x, DeviceVector(data=vec))
+        return its, x.get_local(), dict(s.last)
+
+    i1, x1, l1 = run("1")
+    i0, x0, l0 = run("0")
+    assert l1["status"] == 0 == l0["status"] and abs(i1 - i0) <= 1, (i1, i0)
+    assert i1 > restart or restart == 30                                       # (the short restarts do cycle)
+    assert np.max(np.abs(x1 - exact)) <= 1e-7 * np.max(np.abs(exact))
+    assert np.max(np.abs(x1 - x0)) <= 1e-8 * np.max(np.abs(exact))
+    assert abs(l1["residual_norm"] - l0["residual_norm"]) <= 0.5 * l0["residual_norm"] + 1e-300
+    i1b, x1b, _ = run("1")
+    assert i1b == i1 and np.array_equal(x1b.view(np.int64), x1.view(np.int64))  # bit-reproducible
+    ig, xg, lg = run("1", guess=x1)
+    assert ig <= 1 and lg["status"] == 0
+    pert = x1 * (1.0 + 1e-3 * np.cos(np.arange(x1.size)))
+    ig1, xg1, _ = run("1", guess=pert)
+    ig0, xg0, _ = run("0", guess=pert)
+    assert abs(ig1 - ig0) <= 1
+    assert np.max(np.abs(xg1 - exact)) <= 1e-7 * np.max(np.abs(exact))
+    im, xm, lm = run("1", maxit=7)
+    im0, xm0, lm0 = run("0", maxit=7)
+    assert im == 7 == im0 and lm["status"] == lm0["status"] != 0
+    assert np.max(np.abs(xm - xm0)) <= 1e-9 * np.max(np.abs(xm0))
+    iz, xz, lz = run("1", vec=np.zeros(A.shape[0]))
+    iz0, _, lz0 = run("0", vec=np.zeros(A.shape[0]))
+    assert iz == 0 == iz0 and not xz.any() and lz["status"] == lz0["status"]

@@ -1570,6 +1570,10 @@ extern "C" int tg_krylov_solve_flags(tg_csr_t k, tg_vec_t b, tg_vec_t x, int met
     return tg_bicgstab(k, b, x, pc, rtol, atol, maxit, g_krylov_nonzero_guess, comm, iters, resnorm, status);
   if (method == TG_KSP_GMRES) {
     TG_REQUIRE(restart >= 1 && restart <= 200, "GMRES restart out of range");
+    if (!comm && !(flags & TG_KSP_STAGNATION_GUARD) && tg_cg_persistent_applies(k)) {
+      const int rcp = tg_gmres_persistent(k, b, x, pc, rtol, atol, maxit, restart, g_krylov_nonzero_guess, iters, resnorm, status);
+      if (rcp != 100) return rcp;
+    }
     return tg_gmres(k, b, x, pc, rtol, atol, maxit, restart, g_krylov_nonzero_guess, (flags & TG_KSP_STAGNATION_GUARD) ? 1 : 0,
                     comm, iters, resnorm, status);
   }

@@ -141,7 +141,7 @@ __device__ __forceinline__ void ps_product(const double (&v)[RI][EPR], const uns
   // c: BYTE offsets into xg (uniform base + 32-bit lane offset: no 64-bit address per entry).  The gathers are issued in
   // batches of PS_BATCH rows -- all of them at once (what the scheduler does when left alone) needs two registers per entry
   // for the values in flight on top of the three that hold the entry, and the kernel spills.
-  constexpr int PS_BATCH = EPR >= 3 ? 6 : EPR == 2 ? 9 : 18;
+  constexpr int PS_BATCH = EPR >= 5 ? 2 : EPR == 4 ? 3 : EPR == 3 ? 4 : EPR == 2 ? 6 : 12;
   const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
   // (raw buffer loads: the descriptor in scalar registers, ONE 32-bit register per entry for the offset -- as pointers the
   //  compiler kept a 64-bit offset per entry: 4 registers per entry instead of 3)
@@ -336,19 +336,281 @@ __global__ void __launch_bounds__(PS_NT) k_cg_persistent(tg_ps_args A) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// GMRES(m) the same way (tg_gmres of tg_krylov.hip: left Jacobi preconditioning, classical Gram-Schmidt without refinement,
+// Givens recurrence for the residual estimate, restart from the true residual -- KSPGMRES defaults [ext]; same counting of
+// iterations, same status codes).  On top of the rows of K in registers a workgroup keeps ITS ROWS OF THE WHOLE BASIS
+// v_0..v_m in LDS (31 x 256 rows x 8 B = 62 KB); every workgroup folds the partial Gram-Schmidt sums itself, in the same
+// order, and runs the Givens recurrence redundantly -- identical H, identical decisions, no broadcast.  Three device-wide
+// barriers per inner iteration (v_j complete | coefficients | norm) where the multi-kernel loop has seven launches.
+#define PG_M 30                   // restart length at most
+#define PG_ROWS 256               // local rows at most (the basis of the workgroup in LDS)
+struct pg_lds {
+  double V[(PG_M + 1) * PG_ROWS];
+  double x[PG_ROWS], w[PG_ROWS], dinv[PG_ROWS], b[PG_ROWS];
+  double H[(PG_M + 1) * PG_M], cs[PG_M], sn[PG_M], g[PG_M + 1], y[PG_M], h[PG_M + 2];
+  double red[3 * 17];
+  double st[8];                   // [0] live, [1] res, [2] tol, [3] beta0, [4] its, [5] status, [6] kused
+};
+
+struct tg_pg_args {
+  tg_ps_args P;
+  int m;
+  double *pdots;                  // [G][PG_M + 1] partial Gram-Schmidt sums
+  double *pnorm;                  // [G][2]        partial norms
+};
+
+// sums of nstreams columns of partial[G][ld] into out[0..nstreams): wave w takes the streams w, w + 8, ...; fixed order
+__device__ __forceinline__ void pg_fold(const double *__restrict__ partial, int ld, unsigned G, int nstreams, double *out) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int s = w; s < nstreams; s += PS_NT / 64) {
+    double t = 0.0;
+    for (unsigned b = lane; b < G; b += 64) t += partial[(int64_t)b * ld + s];
+    t = tg_wave_sum(t);
+    if (lane == 0) out[s] = t;
+  }
+  __syncthreads();
+}
+
+template <int EPR, int RI>
+__global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
+  extern __shared__ double ps_dyn[];
+  pg_lds &L = *(pg_lds *)ps_dyn;
+  const tg_ps_args &A = Q.P;
+  const int m = Q.m;
+  const unsigned G = gridDim.x;
+  unsigned gen = 0;
+  const int64_t per = (A.n + G - 1) / G;
+  const int64_t c0r = (int64_t)blockIdx.x * per, c0 = c0r < A.n ? c0r : A.n, c1 = c0 + per < A.n ? c0 + per : A.n;
+  const int nloc = (int)(c1 - c0);
+  const int tid = threadIdx.x, g = tid >> 5, l = tid & 31, lane = tid & 63, wv = tid >> 6;
+  double v[RI][EPR];
+  unsigned c[RI][EPR];
+#pragma unroll
+  for (int ri = 0; ri < RI; ri++) {
+    const int lrow = g + PS_GROUPS * ri;
+    const int64_t row = c0 + lrow;
+    const bool live = lrow < nloc;
+    const int64_t a = live ? A.rowptr[row] : 0, e = live ? A.rowptr[row + 1] : 0;
+    double dd = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPR; k++) {
+      const int64_t q = a + l + 32 * k;
+      const bool in = q < e;
+      v[ri][k] = in ? A.val[q] : 0.0;
+      const int cq = in ? A.col[q] : (int)(live ? row : 0);
+      c[ri][k] = 8u * (unsigned)cq;
+      if (in && cq == row) dd = v[ri][k];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) dd += __shfl_xor(dd, o, 64);
+    if (l == 0 && live) L.dinv[lrow] = (A.jacobi && dd != 0.0) ? 1.0 / dd : 1.0;
+  }
+  __syncthreads();
+  const bool mine = tid < nloc;            // one row per thread (nloc <= PG_ROWS <= PS_NT)
+  double bn = 0.0;
+  if (mine) {
+    L.b[tid] = A.b[c0 + tid];
+    L.x[tid] = A.nonzero_guess ? A.x[c0 + tid] : 0.0;
+    const double ub = L.dinv[tid] * L.b[tid];
+    bn = ub * ub;
+  }
+  double bnorm2 = -1.0;
+  if (A.nonzero_guess) {
+    // reference norm ||B b|| [ext], and x0 where the other workgroups gather it
+    double z0 = 0.0, z1 = 0.0;
+    ps_block_sum3(bn, z0, z1, L.red);
+    if (tid == 0) Q.pnorm[2 * blockIdx.x + 1] = bn;
+    if (mine) A.u[c0 + tid] = L.x[tid];
+    if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
+    pg_fold(Q.pnorm + 1, 2, G, 1, L.h);
+    bnorm2 = L.h[0];
+    __syncthreads();
+  }
+  bool first = true;
+  int its = 0, status = -1, kused = 0;
+  double res = 0.0, tol = 0.0;
+  bool alive = true;
+  while (alive) {
+    // ---- r = B (b - K x), beta = ||r||, v_0 = r / beta
+    if (!(first && !A.nonzero_guess)) {
+      if (!first) {
+        if (mine) A.u[c0 + tid] = L.x[tid];
+        if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
+      }
+      ps_product<EPR, RI>(v, c, A.u, L.w, nloc);
+      __syncthreads();
+    }
+    double rr = 0.0;
+    if (mine) {
+      const double ri = L.dinv[tid] * ((first && !A.nonzero_guess) ? L.b[tid] : L.b[tid] - L.w[tid]);
+      L.V[tid] = ri;
+      rr = ri * ri;
+    }
+    {
+      double z0 = 0.0, z1 = 0.0;
+      ps_block_sum3(rr, z0, z1, L.red);
+      if (tid == 0) Q.pnorm[2 * blockIdx.x] = rr;
+    }
+    if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
+    pg_fold(Q.pnorm, 2, G, 1, L.h);
+    const double beta = sqrt(L.h[0]);
+    __syncthreads();
+    res = beta;
+    if (first) {
+      const double beta0 = bnorm2 >= 0.0 ? sqrt(bnorm2) : beta;
+      tol = fmax(A.rtol * beta0, A.atol);
+      if (!(beta == beta) || !(beta0 == beta0)) {
+        status = -2;
+        break;
+      }
+      if (beta0 <= A.atol) {
+        status = 1;
+        break;
+      }
+      first = false;
+    }
+    if (beta <= tol) {
+      status = 0;
+      break;
+    }
+    if (tid == 0) {
+      L.g[0] = beta;
+      for (int i = 1; i <= m; i++) L.g[i] = 0.0;
+    }
+    if (mine) {
+      const double v0 = L.V[tid] / beta;
+      L.V[tid] = v0;
+      A.u[c0 + tid] = v0;
+    }
+    if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;          // v_0 complete
+    kused = 0;
+    for (int j = 0; j < m && alive; j++) {
+      // ---- w = B K v_j
+      ps_product<EPR, RI>(v, c, A.u, L.w, nloc);
+      __syncthreads();
+      if (mine) L.w[tid] *= L.dinv[tid];
+      __syncthreads();
+      // ---- Gram-Schmidt coefficients h_i = (v_i, w), i = 0..j: wave wv takes i = wv, wv + 8, ...
+      for (int i = wv; i <= j; i += PS_NT / 64) {
+        double t = 0.0;
+        for (int r = lane; r < nloc; r += 64) t += L.V[i * PG_ROWS + r] * L.w[r];
+        t = tg_wave_sum(t);
+        if (lane == 0) Q.pdots[(int64_t)blockIdx.x * (PG_M + 1) + i] = t;
+      }
+      if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
+      pg_fold(Q.pdots, PG_M + 1, G, j + 1, L.h);
+      // ---- w -= sum h_i v_i, ||w||^2
+      double ss = 0.0;
+      if (mine) {
+        double wi = L.w[tid];
+        for (int i = 0; i <= j; i++) wi -= L.h[i] * L.V[i * PG_ROWS + tid];
+        L.w[tid] = wi;
+        ss = wi * wi;
+      }
+      {
+        double z0 = 0.0, z1 = 0.0;
+        ps_block_sum3(ss, z0, z1, L.red);
+        if (tid == 0) Q.pnorm[2 * blockIdx.x] = ss;
+      }
+      if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
+      pg_fold(Q.pnorm, 2, G, 1, L.h + j + 1);
+      // ---- column j of H: earlier rotations, the new one, the residual estimate, the decision (thread 0; k_gm_givens)
+      if (tid == 0) {
+        double *Hj = L.H + j * (PG_M + 1);
+        for (int i = 0; i <= j; i++) Hj[i] = L.h[i];
+        Hj[j + 1] = sqrt(L.h[j + 1]);
+        for (int i = 0; i < j; i++) {
+          const double t = L.cs[i] * Hj[i] + L.sn[i] * Hj[i + 1];
+          Hj[i + 1] = -L.sn[i] * Hj[i] + L.cs[i] * Hj[i + 1];
+          Hj[i] = t;
+        }
+        const double den = hypot(Hj[j], Hj[j + 1]);
+        double live = 1.0, st_status = -1.0;
+        if (den == 0.0 || !(den == den)) {
+          st_status = -2.0;
+          live = 0.0;
+        } else {
+          L.cs[j] = Hj[j] / den;
+          L.sn[j] = Hj[j + 1] / den;
+          Hj[j] = den;
+          Hj[j + 1] = 0.0;
+          L.g[j + 1] = -L.sn[j] * L.g[j];
+          L.g[j] = L.cs[j] * L.g[j];
+          L.st[4] = (double)(its + 1);
+          L.st[6] = (double)(j + 1);
+          L.st[1] = fabs(L.g[j + 1]);
+          if (L.st[1] <= tol) {
+            st_status = 0.0;
+            live = 0.0;
+          } else if (its + 1 >= A.maxit)
+            live = 0.0;
+        }
+        if (st_status == -2.0) {               // breakdown: the iteration does not count
+          L.st[4] = (double)its;
+          L.st[6] = (double)kused;
+          L.st[1] = res;
+        }
+        L.st[0] = live;
+        L.st[5] = st_status;
+      }
+      __syncthreads();
+      its = (int)L.st[4];
+      kused = (int)L.st[6];
+      res = L.st[1];
+      if (L.st[0] == 0.0) {
+        alive = false;
+        status = (int)L.st[5];
+      }
+      __syncthreads();
+      if (alive && j + 1 < m) {
+        // (the last vector of a cycle is never multiplied: the cycle closes below)
+        if (mine) {
+          const double nrm = sqrt(L.h[j + 1]);
+          const double vn = (nrm > 0.0 ? 1.0 / nrm : 0.0) * L.w[tid];
+          L.V[(j + 1) * PG_ROWS + tid] = vn;
+          A.u[c0 + tid] = vn;
+        }
+        if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;        // v_{j+1} complete
+      }
+    }
+    // ---- close the cycle: y from the triangular system of the columns used, x += V y
+    if (tid == 0) {
+      for (int i = kused - 1; i >= 0; i--) {
+        double t = L.g[i];
+        for (int cc = i + 1; cc < kused; cc++) t -= L.H[cc * (PG_M + 1) + i] * L.y[cc];
+        L.y[i] = t / L.H[i * (PG_M + 1) + i];
+      }
+    }
+    __syncthreads();
+    if (mine) {
+      double t = L.x[tid];
+      for (int i = 0; i < kused; i++) t += L.y[i] * L.V[i * PG_ROWS + tid];
+      L.x[tid] = t;
+    }
+    __syncthreads();
+  }
+  if (mine) A.x[c0 + tid] = L.x[tid];
+  if (blockIdx.x == 0 && tid == 0) {
+    A.ctrl->out[0] = (double)its;
+    A.ctrl->out[1] = res;
+    A.ctrl->out[3] = (double)status;
+  }
+}
+
 // Whether a system is taken by the persistent loop: one rank, at least a few thousand rows (below, the launches are not what
 // the solve costs), rows of at most 128 entries, and all of K in the registers of one workgroup per CU
 // (TIGAR_KSP_PERSISTENT=0 turns it off, =1 lifts the lower limit).
-static const int PS_RI[4][4] = {{16, 32, 48, 56}, {8, 16, 24, 28}, {6, 12, 17, 18}, {4, 8, 12, 14}};   // rows per group of lanes, by EPR
-static bool ps_shape(const tg_csr_s *k, int *epr_out, int *ri_out, int *g_out) {
+static const int PS_RI[5][4] = {{16, 32, 48, 56}, {8, 16, 24, 28}, {6, 12, 17, 18}, {4, 8, 12, 14}, {4, 8, 11, 13}};   // rows per group of lanes, by EPR
+static bool ps_shape(const tg_csr_s *k, int64_t rows_max, int *epr_out, int *ri_out, int *g_out) {
   const int64_t n = k->nrows;
   const int maxlen = k->max_row_nnz;
-  if (maxlen < 1 || maxlen > 128) return false;
+  if (maxlen < 1 || maxlen > 160) return false;
   const int epr = (maxlen + 31) / 32;
   int G = std::min<int>(g_tg.num_cu, PS_MAXG);
   G = (int)std::min<int64_t>(G, std::max<int64_t>(1, tg_cdiv(n, PS_GROUPS)));
   const int64_t per = tg_cdiv(n, G);
-  if (per > PS_ROWS_MAX) return false;
+  if (per > rows_max) return false;
   for (int q = 0; q < 4; q++)
     if (per <= (int64_t)PS_RI[epr - 1][q] * PS_GROUPS) {
       *epr_out = epr;
@@ -372,7 +634,7 @@ int tg_cg_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol,
   const int64_t n = k->nrows;
   TG_TRY(tg_spmv_plan(k));                   // (longest row)
   int epr = 0, ri = 0, G = 0;
-  if (!ps_shape(k, &epr, &ri, &G)) return 100;
+  if (!ps_shape(k, PS_ROWS_MAX, &epr, &ri, &G)) return 100;
   double *buf = nullptr;
   const int64_t ctrl_doubles = (int64_t)(sizeof(tg_ps_ctrl) + 7) / 8 + 16;
   TG_TRY(tg_dmalloc(&buf, n + 4 * (int64_t)G + 16 + ctrl_doubles));
@@ -402,6 +664,7 @@ int tg_cg_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol,
   PS_PICK(2, 8); PS_PICK(2, 16); PS_PICK(2, 24); PS_PICK(2, 28);
   PS_PICK(3, 6); PS_PICK(3, 12); PS_PICK(3, 17); PS_PICK(3, 18);
   PS_PICK(4, 4); PS_PICK(4, 8); PS_PICK(4, 12); PS_PICK(4, 14);
+  PS_PICK(5, 4); PS_PICK(5, 8); PS_PICK(5, 11); PS_PICK(5, 13);
 #undef PS_PICK
   if (!fn) {
     tg_dfree(buf);
@@ -444,6 +707,93 @@ int tg_cg_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol,
   g_tg.prof_ms[TG_PROF_KSP_SPMV] += ems;
   *iters = (int)h.out[0];
   *resnorm = sqrt(h.out[1]);
+  *status = (int)h.out[3];
+  return 0;
+}
+
+// GMRES(m), m <= 30, one rank, no stagnation guard: as tg_cg_persistent (100 = not taken, the caller runs tg_gmres)
+int tg_gmres_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, int restart,
+                        int nonzero_guess, int *iters, double *resnorm, int *status) {
+  const int64_t n = k->nrows;
+  if (restart < 1 || restart > PG_M) return 100;
+  TG_TRY(tg_spmv_plan(k));
+  int epr = 0, ri = 0, G = 0;
+  if (!ps_shape(k, PG_ROWS, &epr, &ri, &G)) return 100;
+  double *buf = nullptr;
+  const int64_t ctrl_doubles = (int64_t)(sizeof(tg_ps_ctrl) + 7) / 8 + 16;
+  const int64_t npart = (int64_t)G * (PG_M + 1) + 2 * (int64_t)G;
+  TG_TRY(tg_dmalloc(&buf, n + npart + 16 + ctrl_doubles));
+  tg_pg_args Q;
+  memset(&Q, 0, sizeof(Q));
+  tg_ps_args &A = Q.P;
+  A.rowptr = k->rowptr;
+  A.col = k->col;
+  A.val = k->val;
+  A.n = n;
+  A.b = b->d;
+  A.x = x->d;
+  A.u = buf;
+  Q.pdots = buf + n;
+  Q.pnorm = Q.pdots + (int64_t)G * (PG_M + 1);
+  A.ctrl = (tg_ps_ctrl *)(((uintptr_t)(buf + n + npart) + 127) & ~(uintptr_t)127);
+  A.rtol = rtol;
+  A.atol = atol;
+  A.maxit = maxit;
+  A.jacobi = pc == TG_PC_JACOBI ? 1 : 0;
+  A.nonzero_guess = nonzero_guess;
+  A.budget_ticks = 100000000ll * 5;
+  Q.m = restart;
+  hipMemsetAsync(A.ctrl, 0, sizeof(tg_ps_ctrl), g_tg.stream);
+  void *params[] = {&Q};
+  const void *fn = nullptr;
+#define PS_PICK(E, R) \
+  if (epr == E && ri == R) fn = (const void *)k_gmres_persistent<E, R>
+  PS_PICK(1, 16); PS_PICK(1, 32); PS_PICK(1, 48); PS_PICK(1, 56);
+  PS_PICK(2, 8); PS_PICK(2, 16); PS_PICK(2, 24); PS_PICK(2, 28);
+  PS_PICK(3, 6); PS_PICK(3, 12); PS_PICK(3, 17); PS_PICK(3, 18);
+  PS_PICK(4, 4); PS_PICK(4, 8); PS_PICK(4, 12); PS_PICK(4, 14);
+  PS_PICK(5, 4); PS_PICK(5, 8); PS_PICK(5, 11); PS_PICK(5, 13);
+#undef PS_PICK
+  if (!fn || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pg_lds)) != hipSuccess) {
+    (void)hipGetLastError();
+    tg_dfree(buf);
+    return 100;
+  }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEventCreate(&ev0);
+  hipEventCreate(&ev1);
+  hipEventRecord(ev0, g_tg.stream);
+  hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)G), dim3(PS_NT), params, sizeof(pg_lds), g_tg.stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    hipEventDestroy(ev0);
+    hipEventDestroy(ev1);
+    tg_dfree(buf);
+    return 100;
+  }
+  hipEventRecord(ev1, g_tg.stream);
+  tg_ps_ctrl h;
+  e = hipMemcpyAsync(&h, A.ctrl, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream);
+  const hipError_t e2 = hipStreamSynchronize(g_tg.stream);
+  float ems = 0.f;
+  if (e2 == hipSuccess && hipEventElapsedTime(&ems, ev0, ev1) != hipSuccess) ems = 0.f;
+  hipEventDestroy(ev0);
+  hipEventDestroy(ev1);
+  tg_dfree(buf);
+  if (e != hipSuccess || e2 != hipSuccess) {
+    tg_set_error("persistent GMRES: %s", hipGetErrorString(e2 != hipSuccess ? e2 : e));
+    return 1;
+  }
+  if (h.abort_flag) return 100;
+  if (getenv("TIGAR_TRACE"))
+    fprintf(stderr, "[trace] persistent gmres(%d): %d its in %.3f ms (%d workgroups, %d entries per lane and row, %d rows per group)\n",
+            restart, (int)h.out[0], ems, G, epr, ri);
+  g_tg.prof_n[TG_PROF_KSP_PERSISTENT] += 1;
+  g_tg.prof_ms[TG_PROF_KSP_PERSISTENT] += ems;
+  g_tg.prof_n[TG_PROF_KSP_SPMV] += (int64_t)h.out[0] + 1;
+  g_tg.prof_ms[TG_PROF_KSP_SPMV] += ems;
+  *iters = (int)h.out[0];
+  *resnorm = h.out[1];
   *status = (int)h.out[3];
   return 0;
 }
