@@ -363,8 +363,10 @@ struct tg_pg_args {
 // sums of nstreams columns of partial[G][ld] into out[0..nstreams): wave w takes the streams w, w + 8, ...; fixed order
 __device__ __forceinline__ void pg_fold(const double *__restrict__ partial, int ld, unsigned G, int nstreams, double *out) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll 1
   for (int s = w; s < nstreams; s += PS_NT / 64) {
     double t = 0.0;
+#pragma unroll 1
     for (unsigned b = lane; b < G; b += 64) t += partial[(int64_t)b * ld + s];
     t = tg_wave_sum(t);
     if (lane == 0) out[s] = t;
@@ -476,6 +478,7 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
     }
     if (tid == 0) {
       L.g[0] = beta;
+      #pragma unroll 1
       for (int i = 1; i <= m; i++) L.g[i] = 0.0;
     }
     if (mine) {
@@ -485,6 +488,7 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
     }
     if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;          // v_0 complete
     kused = 0;
+    #pragma unroll 1
     for (int j = 0; j < m && alive; j++) {
       // ---- w = B K v_j
       ps_product<EPR, RI>(v, c, A.u, L.w, nloc);
@@ -492,8 +496,10 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
       if (mine) L.w[tid] *= L.dinv[tid];
       __syncthreads();
       // ---- Gram-Schmidt coefficients h_i = (v_i, w), i = 0..j: wave wv takes i = wv, wv + 8, ...
+      #pragma unroll 1
       for (int i = wv; i <= j; i += PS_NT / 64) {
         double t = 0.0;
+        #pragma unroll 1
         for (int r = lane; r < nloc; r += 64) t += L.V[i * PG_ROWS + r] * L.w[r];
         t = tg_wave_sum(t);
         if (lane == 0) Q.pdots[(int64_t)blockIdx.x * (PG_M + 1) + i] = t;
@@ -504,6 +510,7 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
       double ss = 0.0;
       if (mine) {
         double wi = L.w[tid];
+        #pragma unroll 1
         for (int i = 0; i <= j; i++) wi -= L.h[i] * L.V[i * PG_ROWS + tid];
         L.w[tid] = wi;
         ss = wi * wi;
@@ -518,8 +525,10 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
       // ---- column j of H: earlier rotations, the new one, the residual estimate, the decision (thread 0; k_gm_givens)
       if (tid == 0) {
         double *Hj = L.H + j * (PG_M + 1);
+        #pragma unroll 1
         for (int i = 0; i <= j; i++) Hj[i] = L.h[i];
         Hj[j + 1] = sqrt(L.h[j + 1]);
+        #pragma unroll 1
         for (int i = 0; i < j; i++) {
           const double t = L.cs[i] * Hj[i] + L.sn[i] * Hj[i + 1];
           Hj[i + 1] = -L.sn[i] * Hj[i] + L.cs[i] * Hj[i + 1];
@@ -576,8 +585,10 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
     }
     // ---- close the cycle: y from the triangular system of the columns used, x += V y
     if (tid == 0) {
+      #pragma unroll 1
       for (int i = kused - 1; i >= 0; i--) {
         double t = L.g[i];
+        #pragma unroll 1
         for (int cc = i + 1; cc < kused; cc++) t -= L.H[cc * (PG_M + 1) + i] * L.y[cc];
         L.y[i] = t / L.H[i * (PG_M + 1) + i];
       }
@@ -585,6 +596,7 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
     __syncthreads();
     if (mine) {
       double t = L.x[tid];
+      #pragma unroll 1
       for (int i = 0; i < kused; i++) t += L.y[i] * L.V[i * PG_ROWS + tid];
       L.x[tid] = t;
     }
