@@ -1566,6 +1566,10 @@ extern "C" int tg_krylov_solve_flags(tg_csr_t k, tg_vec_t b, tg_vec_t x, int met
     if (rcp != 100) return rcp;
   }
   if (method == TG_KSP_CG) return tg_cg(k, b, x, pc, rtol, atol, maxit, g_krylov_nonzero_guess, comm, iters, resnorm, status);
+  if (method == TG_KSP_BICGSTAB && !comm && tg_cg_persistent_applies(k)) {
+    const int rcp = tg_bicgstab_persistent(k, b, x, pc, rtol, atol, maxit, g_krylov_nonzero_guess, iters, resnorm, status);
+    if (rcp != 100) return rcp;
+  }
   if (method == TG_KSP_BICGSTAB)
     return tg_bicgstab(k, b, x, pc, rtol, atol, maxit, g_krylov_nonzero_guess, comm, iters, resnorm, status);
   if (method == TG_KSP_GMRES) {

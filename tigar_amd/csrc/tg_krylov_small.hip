@@ -610,6 +610,208 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// BiCGStab the same way (tg_bicgstab of tg_krylov.hip: KSPBCGS [ext] with left Jacobi preconditioning, the two fused
+// reductions per iteration -- (rhat,v), then (t,s), (t,t), (rhat,s), (rhat,t), (s,s) --, the same breakdown and convergence
+// rules and status codes).  The multi-kernel loop reads both reductions back on the HOST (two round trips per iteration,
+// 90 us); here every workgroup folds them itself: four device-wide barriers per iteration (p complete | (rhat,v) | s
+// complete | the five sums), the workgroup's rows of r, rhat, p, v, s, t, x in LDS.
+struct pb_lds {
+  double x[PS_ROWS_MAX], r[PS_ROWS_MAX], rhat[PS_ROWS_MAX], p[PS_ROWS_MAX], v[PS_ROWS_MAX], s[PS_ROWS_MAX], t[PS_ROWS_MAX],
+      w[PS_ROWS_MAX], dinv[PS_ROWS_MAX];
+  double red[3 * 17];
+  double f[8];
+};
+
+template <int EPR, int RI>
+__global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
+  extern __shared__ double ps_dyn[];
+  pb_lds &L = *(pb_lds *)ps_dyn;
+  const tg_ps_args &A = Q.P;
+  const unsigned G = gridDim.x;
+  unsigned gen = 0;
+  const int64_t per = (A.n + G - 1) / G;
+  const int64_t c0r = (int64_t)blockIdx.x * per, c0 = c0r < A.n ? c0r : A.n, c1 = c0 + per < A.n ? c0 + per : A.n;
+  const int nloc = (int)(c1 - c0);
+  const int tid = threadIdx.x, g = tid >> 5, l = tid & 31;
+  double v[RI][EPR];
+  unsigned c[RI][EPR];
+#pragma unroll
+  for (int ri = 0; ri < RI; ri++) {
+    const int lrow = g + PS_GROUPS * ri;
+    const int64_t row = c0 + lrow;
+    const bool live = lrow < nloc;
+    const int64_t a = live ? A.rowptr[row] : 0, e = live ? A.rowptr[row + 1] : 0;
+    double dd = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPR; k++) {
+      const int64_t q = a + l + 32 * k;
+      const bool in = q < e;
+      v[ri][k] = in ? A.val[q] : 0.0;
+      const int cq = in ? A.col[q] : (int)(live ? row : 0);
+      c[ri][k] = 8u * (unsigned)cq;
+      if (in && cq == row) dd = v[ri][k];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) dd += __shfl_xor(dd, o, 64);
+    if (l == 0 && live) L.dinv[lrow] = (A.jacobi && dd != 0.0) ? 1.0 / dd : 1.0;
+  }
+  __syncthreads();
+  // ---- reference norm ||B b||, r = B (b - K x0), rhat = r
+  double bn = 0.0;
+#pragma unroll 1
+  for (int i = tid; i < nloc; i += PS_NT) {
+    const double ub = L.dinv[i] * A.b[c0 + i];
+    bn += ub * ub;
+    L.x[i] = A.nonzero_guess ? A.x[c0 + i] : 0.0;
+  }
+  if (A.nonzero_guess) {
+    ps_product<EPR, RI>(v, c, A.x, L.w, nloc);
+    __syncthreads();
+  }
+  double rn = 0.0;
+#pragma unroll 1
+  for (int i = tid; i < nloc; i += PS_NT) {
+    const double ri = L.dinv[i] * (A.nonzero_guess ? A.b[c0 + i] - L.w[i] : A.b[c0 + i]);
+    L.r[i] = ri;
+    L.rhat[i] = ri;
+    L.p[i] = 0.0;
+    L.v[i] = 0.0;
+    rn += ri * ri;
+  }
+  {
+    double z = 0.0;
+    ps_block_sum3(bn, rn, z, L.red);
+    if (tid == 0) {
+      Q.pnorm[2 * blockIdx.x] = bn;
+      Q.pnorm[2 * blockIdx.x + 1] = rn;
+    }
+  }
+  if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
+  pg_fold(Q.pnorm, 2, G, 2, L.f);
+  const double bnorm = sqrt(L.f[0]);
+  double rho = L.f[1], alpha = 1.0, omega = 1.0, beta = 0.0, znorm = sqrt(L.f[1]);
+  __syncthreads();
+  const double tol = fmax(A.rtol * bnorm, A.atol);
+  int its = 0, status = -1;
+  if (!(znorm == znorm))
+    status = -2;
+  else if (znorm <= tol)
+    status = (znorm <= A.atol && !(znorm <= A.rtol * bnorm)) ? 1 : 0;
+  else {
+#pragma unroll 1
+    for (int it = 1; it <= A.maxit; it++) {
+      // p = r + beta (p - omega v); into the gather buffer
+#pragma unroll 1
+      for (int i = tid; i < nloc; i += PS_NT) {
+        const double pi = L.r[i] + beta * (L.p[i] - omega * L.v[i]);
+        L.p[i] = pi;
+        A.u[c0 + i] = pi;
+      }
+      if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
+      ps_product<EPR, RI>(v, c, A.u, L.w, nloc);
+      __syncthreads();
+      double hv = 0.0;
+#pragma unroll 1
+      for (int i = tid; i < nloc; i += PS_NT) {
+        const double vi = L.dinv[i] * L.w[i];
+        L.v[i] = vi;
+        hv += L.rhat[i] * vi;
+      }
+      {
+        double z0 = 0.0, z1 = 0.0;
+        ps_block_sum3(hv, z0, z1, L.red);
+        if (tid == 0) Q.pnorm[2 * blockIdx.x] = hv;
+      }
+      if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
+      pg_fold(Q.pnorm, 2, G, 1, L.f);
+      const double rv = L.f[0];
+      __syncthreads();
+      if (!(rv == rv) || rv == 0.0) {
+        status = -2;
+        its = it;
+        break;
+      }
+      alpha = rho / rv;
+      // s = r - alpha v; into the gather buffer
+#pragma unroll 1
+      for (int i = tid; i < nloc; i += PS_NT) {
+        const double si = L.r[i] - alpha * L.v[i];
+        L.s[i] = si;
+        A.u[c0 + i] = si;
+      }
+      if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
+      ps_product<EPR, RI>(v, c, A.u, L.w, nloc);
+      __syncthreads();
+      double ts = 0.0, tt = 0.0, hs = 0.0, ht = 0.0, ss = 0.0;
+#pragma unroll 1
+      for (int i = tid; i < nloc; i += PS_NT) {
+        const double ti = L.dinv[i] * L.w[i], si = L.s[i], hi = L.rhat[i];
+        L.t[i] = ti;
+        ts += ti * si;
+        tt += ti * ti;
+        hs += hi * si;
+        ht += hi * ti;
+        ss += si * si;
+      }
+      {
+        ps_block_sum3(ts, tt, hs, L.red);
+        double z = 0.0;
+        ps_block_sum3(ht, ss, z, L.red);
+        if (tid == 0) {
+          double *o = Q.pdots + (int64_t)blockIdx.x * (PG_M + 1);
+          o[0] = ts;
+          o[1] = tt;
+          o[2] = hs;
+          o[3] = ht;
+          o[4] = ss;
+        }
+      }
+      if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
+      pg_fold(Q.pdots, PG_M + 1, G, 5, L.f);
+      ts = L.f[0];
+      tt = L.f[1];
+      hs = L.f[2];
+      ht = L.f[3];
+      ss = L.f[4];
+      __syncthreads();
+      omega = tt > 0.0 ? ts / tt : 0.0;
+      // x += alpha p + omega s ; r = s - omega t
+#pragma unroll 1
+      for (int i = tid; i < nloc; i += PS_NT) {
+        L.x[i] += alpha * L.p[i] + omega * L.s[i];
+        L.r[i] = L.s[i] - omega * L.t[i];
+      }
+      const double rho_new = hs - omega * ht;
+      const double rn2 = fmax(0.0, ss - 2.0 * omega * ts + omega * omega * tt);
+      znorm = sqrt(rn2);
+      its = it;
+      if (!(znorm == znorm)) {
+        status = -2;
+        break;
+      }
+      if (znorm <= tol) {
+        status = (znorm <= A.atol && !(znorm <= A.rtol * bnorm)) ? 1 : 0;
+        break;
+      }
+      if (omega == 0.0 || rho == 0.0 || !(rho_new == rho_new)) {
+        status = -2;
+        break;
+      }
+      beta = (rho_new / rho) * (alpha / omega);
+      rho = rho_new;
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int i = tid; i < nloc; i += PS_NT) A.x[c0 + i] = L.x[i];
+  if (blockIdx.x == 0 && tid == 0) {
+    A.ctrl->out[0] = (double)its;
+    A.ctrl->out[1] = znorm;
+    A.ctrl->out[3] = (double)status;
+  }
+}
+
 // Whether a system is taken by the persistent loop: one rank, at least a few thousand rows (below, the launches are not what
 // the solve costs), rows of at most 128 entries, and all of K in the registers of one workgroup per CU
 // (TIGAR_KSP_PERSISTENT=0 turns it off, =1 lifts the lower limit).
@@ -723,14 +925,16 @@ int tg_cg_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol,
   return 0;
 }
 
-// GMRES(m), m <= 30, one rank, no stagnation guard: as tg_cg_persistent (100 = not taken, the caller runs tg_gmres)
-int tg_gmres_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, int restart,
-                        int nonzero_guess, int *iters, double *resnorm, int *status) {
+// GMRES(m), m <= 30, one rank, no stagnation guard (restart >= 1), or BiCGStab (restart = 0): as tg_cg_persistent
+// (100 = not taken, the caller runs tg_gmres / tg_bicgstab)
+static int ps_run_pg(bool bicgstab, tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, int restart,
+                     int nonzero_guess, int *iters, double *resnorm, int *status) {
   const int64_t n = k->nrows;
-  if (restart < 1 || restart > PG_M) return 100;
+  if (!bicgstab && (restart < 1 || restart > PG_M)) return 100;
   TG_TRY(tg_spmv_plan(k));
   int epr = 0, ri = 0, G = 0;
-  if (!ps_shape(k, PG_ROWS, &epr, &ri, &G)) return 100;
+  if (!ps_shape(k, bicgstab ? PS_ROWS_MAX : PG_ROWS, &epr, &ri, &G)) return 100;
+  const size_t lds_bytes = bicgstab ? sizeof(pb_lds) : sizeof(pg_lds);
   double *buf = nullptr;
   const int64_t ctrl_doubles = (int64_t)(sizeof(tg_ps_ctrl) + 7) / 8 + 16;
   const int64_t npart = (int64_t)G * (PG_M + 1) + 2 * (int64_t)G;
@@ -759,14 +963,14 @@ int tg_gmres_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rt
   void *params[] = {&Q};
   const void *fn = nullptr;
 #define PS_PICK(E, R) \
-  if (epr == E && ri == R) fn = (const void *)k_gmres_persistent<E, R>
+  if (epr == E && ri == R) fn = bicgstab ? (const void *)k_bicgstab_persistent<E, R> : (const void *)k_gmres_persistent<E, R>
   PS_PICK(1, 16); PS_PICK(1, 32); PS_PICK(1, 48); PS_PICK(1, 56);
   PS_PICK(2, 8); PS_PICK(2, 16); PS_PICK(2, 24); PS_PICK(2, 28);
   PS_PICK(3, 6); PS_PICK(3, 12); PS_PICK(3, 17); PS_PICK(3, 18);
   PS_PICK(4, 4); PS_PICK(4, 8); PS_PICK(4, 12); PS_PICK(4, 14);
   PS_PICK(5, 4); PS_PICK(5, 8); PS_PICK(5, 11); PS_PICK(5, 13);
 #undef PS_PICK
-  if (!fn || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pg_lds)) != hipSuccess) {
+  if (!fn || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
     (void)hipGetLastError();
     tg_dfree(buf);
     return 100;
@@ -775,7 +979,7 @@ int tg_gmres_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rt
   hipEventCreate(&ev0);
   hipEventCreate(&ev1);
   hipEventRecord(ev0, g_tg.stream);
-  hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)G), dim3(PS_NT), params, sizeof(pg_lds), g_tg.stream);
+  hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)G), dim3(PS_NT), params, lds_bytes, g_tg.stream);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     hipEventDestroy(ev0);
@@ -793,19 +997,28 @@ int tg_gmres_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rt
   hipEventDestroy(ev1);
   tg_dfree(buf);
   if (e != hipSuccess || e2 != hipSuccess) {
-    tg_set_error("persistent GMRES: %s", hipGetErrorString(e2 != hipSuccess ? e2 : e));
+    tg_set_error("persistent %s: %s", bicgstab ? "BiCGStab" : "GMRES", hipGetErrorString(e2 != hipSuccess ? e2 : e));
     return 1;
   }
   if (h.abort_flag) return 100;
   if (getenv("TIGAR_TRACE"))
-    fprintf(stderr, "[trace] persistent gmres(%d): %d its in %.3f ms (%d workgroups, %d entries per lane and row, %d rows per group)\n",
-            restart, (int)h.out[0], ems, G, epr, ri);
+    fprintf(stderr, "[trace] persistent %s(%d): %d its in %.3f ms (%d workgroups, %d entries per lane and row, %d rows per group)\n",
+            bicgstab ? "bicgstab" : "gmres", restart, (int)h.out[0], ems, G, epr, ri);
   g_tg.prof_n[TG_PROF_KSP_PERSISTENT] += 1;
   g_tg.prof_ms[TG_PROF_KSP_PERSISTENT] += ems;
-  g_tg.prof_n[TG_PROF_KSP_SPMV] += (int64_t)h.out[0] + 1;
+  g_tg.prof_n[TG_PROF_KSP_SPMV] += (bicgstab ? 2 : 1) * (int64_t)h.out[0] + 1;
   g_tg.prof_ms[TG_PROF_KSP_SPMV] += ems;
   *iters = (int)h.out[0];
   *resnorm = h.out[1];
   *status = (int)h.out[3];
   return 0;
+}
+
+int tg_gmres_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, int restart,
+                        int nonzero_guess, int *iters, double *resnorm, int *status) {
+  return ps_run_pg(false, k, b, x, pc, rtol, atol, maxit, restart, nonzero_guess, iters, resnorm, status);
+}
+int tg_bicgstab_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, int nonzero_guess,
+                           int *iters, double *resnorm, int *status) {
+  return ps_run_pg(true, k, b, x, pc, rtol, atol, maxit, 0, nonzero_guess, iters, resnorm, status);
 }
