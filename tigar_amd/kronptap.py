@@ -57,7 +57,6 @@ class KronExtraction(object):
         """no periodic wrap: the functions of every 1-D node appear in ascending index order (then candidate order
         = column order and the Kronecker rows come out sorted)"""
         for k in range(self.d):
-            s = self.basis.splines[k]
             _, idx, _ = self._tables[k]
             if np.any(np.diff(idx, axis=1) <= 0):
                 return False
