@@ -154,8 +154,12 @@ def test_persistent_cg_for_small_systems(d, p, nel, pc, monkeypatch):
         its = s.solve(K, U, vec)
         return its, U.get_local(), dict(s.last)
 
+    from tigar_amd import device as _dev
+    _dev.prof_reset()
     i1, U1, l1 = run("1")
+    assert _dev.prof_get(6)[1] == 1                      # the persistent kernel did run
     i0, U0, l0 = run("0")
+    assert _dev.prof_get(6)[1] == 1
     assert l1["status"] == 0 and abs(i1 - i0) <= 1, (i1, i0)
     assert np.max(np.abs(U1 - exact)) <= 1e-7 * np.max(np.abs(exact))
     assert np.max(np.abs(U1 - U0)) <= 1e-8 * np.max(np.abs(exact))
@@ -209,8 +213,12 @@ def test_persistent_gmres_for_small_systems(pc, restart, monkeypatch):
         its = s.solve(Ad, x, DeviceVector(data=vec))
         return its, x.get_local(), dict(s.last)
 
+    from tigar_amd import device as _dev
+    _dev.prof_reset()
     i1, x1, l1 = run("1")
+    assert _dev.prof_get(6)[1] == 1                      # the persistent kernel did run
     i0, x0, l0 = run("0")
+    assert _dev.prof_get(6)[1] == 1
     assert l1["status"] == 0 == l0["status"] and abs(i1 - i0) <= 1, (i1, i0)
     assert i1 > restart or restart == 30                                       # (the short restarts do cycle)
     assert np.max(np.abs(x1 - exact)) <= 1e-7 * np.max(np.abs(exact))
@@ -257,8 +265,12 @@ def test_persistent_bicgstab_for_small_systems(pc, monkeypatch):
         its = s.solve(Ad, x, DeviceVector(data=vec))
         return its, x.get_local(), dict(s.last)
 
+    from tigar_amd import device as _dev
+    _dev.prof_reset()
     i1, x1, l1 = run("1")
+    assert _dev.prof_get(6)[1] == 1                      # the persistent kernel did run
     i0, x0, l0 = run("0")
+    assert _dev.prof_get(6)[1] == 1
     # (BiCGStab converges erratically on this system and amplifies the last bits of the sums: 274 against 233 iterations)
     assert l1["status"] == 0 == l0["status"] and abs(i1 - i0) <= 0.35 * i0 + 10, (i1, i0)
     assert np.max(np.abs(x1 - exact)) <= 1e-8 * np.max(np.abs(exact))

@@ -1022,3 +1022,4 @@ int tg_bicgstab_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double
                            int *iters, double *resnorm, int *status) {
   return ps_run_pg(true, k, b, x, pc, rtol, atol, maxit, 0, nonzero_guess, iters, resnorm, status);
 }
+
