@@ -26,6 +26,7 @@
 #define PS_GROUPS (PS_NT / 32)   // groups of 32 lanes, one row each at a time
 #define PS_MAXG 512              // workgroups at most (partials are folded by one pass of a workgroup)
 
+#define PS_AUX_SC1 16            // cache-policy bit of the buffer loads: sc1 (agent scope) on gfx940+
 #define PS_FAN 16                // workgroups per first-level counter of the barrier
 struct tg_ps_ctrl {
   unsigned gen;
@@ -52,28 +53,35 @@ struct tg_ps_args {
   long long budget_ticks;        // wall_clock64 ticks the kernel may wait at one barrier
 };
 
+// What the workgroups exchange -- the gathered vector, the partial sums, the barrier words -- goes through AGENT-SCOPE relaxed
+// atomic stores and loads (sc1 on gfx950: written through to / read from the level that is coherent across the XCDs), so the
+// barrier needs NO cache maintenance: every wave waits for its own stores (s_waitcnt vmcnt(0)), the workgroup meets, thread 0
+// arrives.  Measured (tools/mb/grid_barrier.hip, 256 workgroups, 2 KB exchanged per workgroup): 2.5 us per barrier; with a
+// release fence before and an acquire fence after (buffer_wbl2 / buffer_inv of a whole L2) 8.5 us; with the fences in every
+// wave 31 us; plain stores and loads without fences read stale data -- each XCD has its own L2 --, also in memory
+// allocated fine-grained.
+__device__ __forceinline__ void ps_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ps_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ bool ps_barrier(tg_ps_ctrl *c, unsigned G, unsigned &gen, long long budget) {
-  // The stores of the workgroup are ordered before thread 0's release by the workgroup barrier (cumulativity), the loads after
-  // its acquire likewise: ONE write-back and ONE invalidate per workgroup and barrier -- with a fence in every wave, or an
-  // acquire load in the spin loop, every poll invalidated the L2 (measured: 90 us per barrier instead of 3).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   __shared__ int s_ok;
   if (threadIdx.x == 0) {
     int ok = 1;
     const unsigned target = gen + 1;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    // two levels (atomics on ONE address are served one after the other, ~12 ns each: 256 of them are 3 us)
+    // two levels (atomics on ONE address are served one after the other: 256 of them are 3.7 us, 16 + 16 are 1.7)
     const unsigned grp = blockIdx.x / PS_FAN, ngrp = (G + PS_FAN - 1) / PS_FAN;
     const unsigned gsz = grp + 1 < ngrp ? PS_FAN : G - grp * PS_FAN;
     bool last = false;
     if (__hip_atomic_fetch_add(&c->grp[32 * grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsz - 1) {
       __hip_atomic_store(&c->grp[32 * grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (__hip_atomic_fetch_add(&c->top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1) last = true;
     }
     if (last) {
       __hip_atomic_store(&c->top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(&c->gen, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       const long long t0 = wall_clock64();
@@ -93,7 +101,6 @@ __device__ __forceinline__ bool ps_barrier(tg_ps_ctrl *c, unsigned G, unsigned &
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     s_ok = ok;
   }
   gen++;
@@ -153,7 +160,7 @@ __device__ __forceinline__ void ps_product(const double (&v)[RI][EPR], const uns
     for (int ri = r0; ri < r0 + PS_BATCH && ri < RI; ri++)
 #pragma unroll
       for (int k = 0; k < EPR; k++)
-        xs[ri - r0][k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xb, (int)c[ri][k], 0, 0));
+        xs[ri - r0][k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xb, (int)c[ri][k], 0, PS_AUX_SC1));
 #pragma unroll
     for (int ri = r0; ri < r0 + PS_BATCH && ri < RI; ri++) {
       double acc = 0.0;
@@ -219,14 +226,14 @@ __global__ void __launch_bounds__(PS_NT) k_cg_persistent(tg_ps_args A) {
     L.u[i] = ui;
     L.p[i] = 0.0;
     L.s[i] = 0.0;
-    A.u[c0 + i] = ui;
+    ps_store(&A.u[c0 + i], ui);
     gp += ri * ui;
     np += ui * ui;
   }
   {
     double z0 = 0.0, z1 = 0.0;
     ps_block_sum3(bn, z0, z1, L.red);
-    if (tid == 0) A.partial[4 * blockIdx.x + 3] = bn;
+    if (tid == 0) ps_store(&A.partial[4 * blockIdx.x + 3], bn);
   }
   if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;          // u complete
   double gamma_prev = 0.0, alpha_prev = 0.0, tol2 = 0.0, nu0 = 0.0, nu = 0.0;
@@ -255,9 +262,9 @@ __global__ void __launch_bounds__(PS_NT) k_cg_persistent(tg_ps_args A) {
       double a = gp, b = dp, cc = np;
       ps_block_sum3(a, b, cc, L.red);
       if (tid == 0) {
-        A.partial[4 * blockIdx.x] = a;
-        A.partial[4 * blockIdx.x + 1] = b;
-        A.partial[4 * blockIdx.x + 2] = cc;
+        ps_store(&A.partial[4 * blockIdx.x], a);
+        ps_store(&A.partial[4 * blockIdx.x + 1], b);
+        ps_store(&A.partial[4 * blockIdx.x + 2], cc);
       }
     }
     PS_MARK(t_spmv);
@@ -266,16 +273,16 @@ __global__ void __launch_bounds__(PS_NT) k_cg_persistent(tg_ps_args A) {
     double gamma = 0.0, delta = 0.0;
     nu = 0.0;
     if (tid < (int)G) {
-      gamma = A.partial[4 * tid];
-      delta = A.partial[4 * tid + 1];
-      nu = A.partial[4 * tid + 2];
+      gamma = ps_load(&A.partial[4 * tid]);
+      delta = ps_load(&A.partial[4 * tid + 1]);
+      nu = ps_load(&A.partial[4 * tid + 2]);
     }
     ps_block_sum3(gamma, delta, nu, L.red);
     if (it == 0) {
       // reference norm: ||B r0||, or ||B b|| with a guess (KSPConvergedDefault [ext]); as tg_cg
       double ref = nu;
       if (A.nonzero_guess) {
-        double t = tid < (int)G ? A.partial[4 * tid + 3] : 0.0, z0 = 0.0, z1 = 0.0;
+        double t = tid < (int)G ? ps_load(&A.partial[4 * tid + 3]) : 0.0, z0 = 0.0, z1 = 0.0;
         ps_block_sum3(t, z0, z1, L.red);
         ref = t;
       }
@@ -314,7 +321,7 @@ __global__ void __launch_bounds__(PS_NT) k_cg_persistent(tg_ps_args A) {
       L.r[i] = ri;
       const double ui = L.dinv[i] * ri;
       L.u[i] = ui;
-      A.u[c0 + i] = ui;
+      ps_store(&A.u[c0 + i], ui);
       gp += ri * ui;
       np += ui * ui;
     }
@@ -367,7 +374,7 @@ __device__ __forceinline__ void pg_fold(const double *__restrict__ partial, int 
   for (int s = w; s < nstreams; s += PS_NT / 64) {
     double t = 0.0;
 #pragma unroll 1
-    for (unsigned b = lane; b < G; b += 64) t += partial[(int64_t)b * ld + s];
+    for (unsigned b = lane; b < G; b += 64) t += ps_load(&partial[(int64_t)b * ld + s]);
     t = tg_wave_sum(t);
     if (lane == 0) out[s] = t;
   }
@@ -422,8 +429,8 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
     // reference norm ||B b|| [ext], and x0 where the other workgroups gather it
     double z0 = 0.0, z1 = 0.0;
     ps_block_sum3(bn, z0, z1, L.red);
-    if (tid == 0) Q.pnorm[2 * blockIdx.x + 1] = bn;
-    if (mine) A.u[c0 + tid] = L.x[tid];
+    if (tid == 0) ps_store(&Q.pnorm[2 * blockIdx.x + 1], bn);
+    if (mine) ps_store(&A.u[c0 + tid], L.x[tid]);
     if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
     pg_fold(Q.pnorm + 1, 2, G, 1, L.h);
     bnorm2 = L.h[0];
@@ -437,7 +444,7 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
     // ---- r = B (b - K x), beta = ||r||, v_0 = r / beta
     if (!(first && !A.nonzero_guess)) {
       if (!first) {
-        if (mine) A.u[c0 + tid] = L.x[tid];
+        if (mine) ps_store(&A.u[c0 + tid], L.x[tid]);
         if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
       }
       ps_product<EPR, RI>(v, c, A.u, L.w, nloc);
@@ -452,7 +459,7 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
     {
       double z0 = 0.0, z1 = 0.0;
       ps_block_sum3(rr, z0, z1, L.red);
-      if (tid == 0) Q.pnorm[2 * blockIdx.x] = rr;
+      if (tid == 0) ps_store(&Q.pnorm[2 * blockIdx.x], rr);
     }
     if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
     pg_fold(Q.pnorm, 2, G, 1, L.h);
@@ -484,7 +491,7 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
     if (mine) {
       const double v0 = L.V[tid] / beta;
       L.V[tid] = v0;
-      A.u[c0 + tid] = v0;
+      ps_store(&A.u[c0 + tid], v0);
     }
     if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;          // v_0 complete
     kused = 0;
@@ -502,7 +509,7 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
         #pragma unroll 1
         for (int r = lane; r < nloc; r += 64) t += L.V[i * PG_ROWS + r] * L.w[r];
         t = tg_wave_sum(t);
-        if (lane == 0) Q.pdots[(int64_t)blockIdx.x * (PG_M + 1) + i] = t;
+        if (lane == 0) ps_store(&Q.pdots[(int64_t)blockIdx.x * (PG_M + 1) + i], t);
       }
       if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
       pg_fold(Q.pdots, PG_M + 1, G, j + 1, L.h);
@@ -518,7 +525,7 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
       {
         double z0 = 0.0, z1 = 0.0;
         ps_block_sum3(ss, z0, z1, L.red);
-        if (tid == 0) Q.pnorm[2 * blockIdx.x] = ss;
+        if (tid == 0) ps_store(&Q.pnorm[2 * blockIdx.x], ss);
       }
       if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
       pg_fold(Q.pnorm, 2, G, 1, L.h + j + 1);
@@ -578,7 +585,7 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
           const double nrm = sqrt(L.h[j + 1]);
           const double vn = (nrm > 0.0 ? 1.0 / nrm : 0.0) * L.w[tid];
           L.V[(j + 1) * PG_ROWS + tid] = vn;
-          A.u[c0 + tid] = vn;
+          ps_store(&A.u[c0 + tid], vn);
         }
         if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;        // v_{j+1} complete
       }
@@ -683,8 +690,8 @@ __global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
     double z = 0.0;
     ps_block_sum3(bn, rn, z, L.red);
     if (tid == 0) {
-      Q.pnorm[2 * blockIdx.x] = bn;
-      Q.pnorm[2 * blockIdx.x + 1] = rn;
+      ps_store(&Q.pnorm[2 * blockIdx.x], bn);
+      ps_store(&Q.pnorm[2 * blockIdx.x + 1], rn);
     }
   }
   if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
@@ -706,7 +713,7 @@ __global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
       for (int i = tid; i < nloc; i += PS_NT) {
         const double pi = L.r[i] + beta * (L.p[i] - omega * L.v[i]);
         L.p[i] = pi;
-        A.u[c0 + i] = pi;
+        ps_store(&A.u[c0 + i], pi);
       }
       if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
       ps_product<EPR, RI>(v, c, A.u, L.w, nloc);
@@ -721,7 +728,7 @@ __global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
       {
         double z0 = 0.0, z1 = 0.0;
         ps_block_sum3(hv, z0, z1, L.red);
-        if (tid == 0) Q.pnorm[2 * blockIdx.x] = hv;
+        if (tid == 0) ps_store(&Q.pnorm[2 * blockIdx.x], hv);
       }
       if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
       pg_fold(Q.pnorm, 2, G, 1, L.f);
@@ -738,7 +745,7 @@ __global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
       for (int i = tid; i < nloc; i += PS_NT) {
         const double si = L.r[i] - alpha * L.v[i];
         L.s[i] = si;
-        A.u[c0 + i] = si;
+        ps_store(&A.u[c0 + i], si);
       }
       if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
       ps_product<EPR, RI>(v, c, A.u, L.w, nloc);
@@ -760,11 +767,11 @@ __global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
         ps_block_sum3(ht, ss, z, L.red);
         if (tid == 0) {
           double *o = Q.pdots + (int64_t)blockIdx.x * (PG_M + 1);
-          o[0] = ts;
-          o[1] = tt;
-          o[2] = hs;
-          o[3] = ht;
-          o[4] = ss;
+          ps_store(o + 0, ts);
+          ps_store(o + 1, tt);
+          ps_store(o + 2, hs);
+          ps_store(o + 3, ht);
+          ps_store(o + 4, ss);
         }
       }
       if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
