@@ -292,3 +292,46 @@ def test_persistent_bicgstab_for_small_systems(pc, monkeypatch):
     iz, xz, lz = run("1", vec=np.zeros(A.shape[0]))
     iz0, _, lz0 = run("0", vec=np.zeros(A.shape[0]))
     assert iz == 0 == iz0 and not xz.any() and lz["status"] == lz0["status"]
+
+
+@pytest.mark.parametrize("d,p,nel,degree", [(2, 3, 48, 4), (2, 4, 40, 8), (3, 2, 12, 6), (2, 2, 30, 1)])
+def test_persistent_chebyshev_cg_for_small_systems(d, p, nel, degree, monkeypatch):
+    """CG with the Chebyshev polynomial preconditioner in one cooperative kernel (one device-wide barrier per inner product,
+    two gather buffers used alternately) against the multi-kernel loop: the interval comes from the same Lanczos steps, so
+    the iteration counts agree (+-1) and the solutions to the tolerance"""
+    import tigar_amd as t
+    from tigar_amd import device as _dev
+    from tigar_amd.device import DeviceVector
+    spline, K, rhs = _poisson(d, p, nel)
+    exact = sla.spsolve(K.to_scipy().tocsc(), rhs.get_local())
+
+    def run(mode, guess=None, maxit=None, vec=rhs):
+        monkeypatch.setenv("TIGAR_KSP_PERSISTENT", mode)
+        s = t.PETScKrylovSolver("cg", "chebyshev")
+        s.parameters["relative_tolerance"] = 1e-10
+        s.parameters["chebyshev_degree"] = degree
+        if maxit is not None:
+            s.parameters["maximum_iterations"] = maxit
+            s.parameters["error_on_nonconvergence"] = False
+        U = DeviceVector(K.shape[0]) if guess is None else DeviceVector(data=guess)
+        if guess is not None:
+            s.parameters["nonzero_initial_guess"] = True
+        its = s.solve(K, U, vec)
+        return its, U.get_local(), dict(s.last)
+
+    _dev.prof_reset()
+    i1, U1, l1 = run("1")
+    assert _dev.prof_get(6)[1] == 1                      # the persistent kernel did run
+    i0, U0, l0 = run("0")
+    assert _dev.prof_get(6)[1] == 1
+    assert l1["status"] == 0 == l0["status"] and abs(i1 - i0) <= 1, (i1, i0)
+    assert np.max(np.abs(U1 - exact)) <= 1e-7 * np.max(np.abs(exact))
+    assert np.max(np.abs(U1 - U0)) <= 1e-8 * np.max(np.abs(exact))
+    i1b, U1b, _ = run("1")
+    assert i1b == i1 and np.array_equal(U1b.view(np.int64), U1.view(np.int64))
+    ig, _, lg = run("1", guess=U1)
+    assert ig <= 1 and lg["status"] == 0
+    im, Um, lm = run("1", maxit=3)
+    im0, Um0, lm0 = run("0", maxit=3)
+    assert im == 3 == im0 and lm["status"] == lm0["status"] != 0
+    assert np.max(np.abs(Um - Um0)) <= 1e-10 * np.max(np.abs(Um0))

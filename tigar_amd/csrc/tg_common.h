@@ -196,6 +196,8 @@ int tg_gmres_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rt
                         int nonzero_guess, int *iters, double *resnorm, int *status);
 int tg_bicgstab_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, double atol, int maxit, int nonzero_guess,
                            int *iters, double *resnorm, int *status);
+int tg_pcg_cheb_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int m, double theta, double delta, double rtol, double atol,
+                           int maxit, int nonzero_guess, int *iters, double *resnorm, int *status);
 int tg_build_dof_mask(const int32_t *dofs, int64_t n, int64_t ndofs_total, uint8_t **mask_out);
 int64_t tg_spmv_num_partials(tg_csr_s *a);
 

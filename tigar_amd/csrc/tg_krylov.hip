@@ -1272,6 +1272,11 @@ static int tg_pcg_cheb(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int degree, double
   if (ratio_env > 1.0) ratio = ratio_env;
   const double lmin = lmax / ratio;
   const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+  if (!comm && tg_cg_persistent_applies(k)) {
+    // small systems: the loop below as one persistent kernel (tg_krylov_small.hip); 100 = not taken
+    const int rcp = tg_pcg_cheb_persistent(k, b, x, m, theta, delta, rtol, atol, maxit, nonzero_guess, iters, resnorm, status);
+    if (rcp != 100) return rcp;
+  }
   // u = B r
   auto apply_pc = [&]() -> int {
     hipLaunchKernelGGL(k_cheb_first, dim3(vg), dim3(256), 0, g_tg.stream, r, dinv, 1.0 / theta, n, g, u, dd);

@@ -819,6 +819,214 @@ __global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// CG with the Chebyshev polynomial preconditioner the same way (tg_pcg_cheb of tg_krylov.hip: u = p_m(D^-1 K) D^-1 r by m - 1
+// steps of the Chebyshev iteration on [theta - delta, theta + delta] -- the interval comes from the caller's Lanczos steps --,
+// then the single-reduction CG recurrence).  The inner steps need no inner product: ONE device-wide barrier per product (the
+// iterate complete), the gather vector in two buffers used alternately so that nobody overwrites what a slower workgroup
+// still reads; the outer step adds the barrier of the three sums.
+struct pc_lds {
+  double x[PS_ROWS_MAX], r[PS_ROWS_MAX], p[PS_ROWS_MAX], s[PS_ROWS_MAX], u[PS_ROWS_MAX], w[PS_ROWS_MAX], dinv[PS_ROWS_MAX],
+      g[PS_ROWS_MAX], d[PS_ROWS_MAX];
+  double red[3 * 17];
+  double f[8];
+};
+struct tg_pc_args {
+  tg_ps_args P;
+  int m;
+  double theta, delta;
+  double *u2;                     // the second gather buffer
+  double *psum;                   // [G][4] partial sums
+};
+
+template <int EPR, int RI>
+__global__ void __launch_bounds__(PS_NT) k_pcg_cheb_persistent(tg_pc_args Q) {
+  extern __shared__ double ps_dyn[];
+  pc_lds &L = *(pc_lds *)ps_dyn;
+  const tg_ps_args &A = Q.P;
+  const unsigned G = gridDim.x;
+  unsigned gen = 0;
+  const int64_t per = (A.n + G - 1) / G;
+  const int64_t c0r = (int64_t)blockIdx.x * per, c0 = c0r < A.n ? c0r : A.n, c1 = c0 + per < A.n ? c0 + per : A.n;
+  const int nloc = (int)(c1 - c0);
+  const int tid = threadIdx.x, g = tid >> 5, l = tid & 31;
+  double v[RI][EPR];
+  unsigned c[RI][EPR];
+#pragma unroll
+  for (int ri = 0; ri < RI; ri++) {
+    const int lrow = g + PS_GROUPS * ri;
+    const int64_t row = c0 + lrow;
+    const bool live = lrow < nloc;
+    const int64_t a = live ? A.rowptr[row] : 0, e = live ? A.rowptr[row + 1] : 0;
+    double dd = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPR; k++) {
+      const int64_t q = a + l + 32 * k;
+      const bool in = q < e;
+      v[ri][k] = in ? A.val[q] : 0.0;
+      const int cq = in ? A.col[q] : (int)(live ? row : 0);
+      c[ri][k] = 8u * (unsigned)cq;
+      if (in && cq == row) dd = v[ri][k];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) dd += __shfl_xor(dd, o, 64);
+    if (l == 0 && live) L.dinv[lrow] = dd != 0.0 ? 1.0 / dd : 1.0;       // (the polynomial is in D^-1 K: always Jacobi)
+  }
+  __syncthreads();
+  int flip = 0;                                    // which gather buffer the next write goes to
+  double *const gb[2] = {A.u, Q.u2};
+  const double inv_theta = 1.0 / Q.theta, sigma = Q.theta / Q.delta;
+  bool ok = true;
+  // u = B r on the own rows (L.u); every product reads the iterate of ALL rows from a gather buffer
+  auto apply_pc = [&]() {
+#pragma unroll 1
+    for (int i = tid; i < nloc; i += PS_NT) {
+      const double gi = L.dinv[i] * L.r[i];
+      L.g[i] = gi;
+      const double zi = gi * inv_theta;
+      L.u[i] = zi;
+      L.d[i] = zi;
+    }
+    double rho = 1.0 / sigma;
+#pragma unroll 1
+    for (int j = 1; j < Q.m && ok; j++) {
+      const double rho_new = 1.0 / (2.0 * sigma - rho);
+      const double cc1 = rho_new * rho, cc2 = 2.0 * rho_new / Q.delta;
+      double *buf = gb[flip];
+      flip ^= 1;
+#pragma unroll 1
+      for (int i = tid; i < nloc; i += PS_NT) ps_store(&buf[c0 + i], L.u[i]);
+      if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) {
+        ok = false;
+        break;
+      }
+      ps_product<EPR, RI>(v, c, buf, L.w, nloc);
+      __syncthreads();
+#pragma unroll 1
+      for (int i = tid; i < nloc; i += PS_NT) {
+        const double di = cc1 * L.d[i] + cc2 * (L.g[i] - L.dinv[i] * L.w[i]);
+        L.d[i] = di;
+        L.u[i] += di;
+      }
+      rho = rho_new;
+    }
+    __syncthreads();
+  };
+  // w = K y on the own rows (y of all rows through a gather buffer)
+  auto product_of = [&](const double *own) {
+    double *buf = gb[flip];
+    flip ^= 1;
+#pragma unroll 1
+    for (int i = tid; i < nloc; i += PS_NT) ps_store(&buf[c0 + i], own[i]);
+    if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) {
+      ok = false;
+      return;
+    }
+    ps_product<EPR, RI>(v, c, buf, L.w, nloc);
+    __syncthreads();
+  };
+  // ---- reference norm ||B b||: u = B b
+#pragma unroll 1
+  for (int i = tid; i < nloc; i += PS_NT) {
+    L.r[i] = A.b[c0 + i];
+    L.x[i] = A.nonzero_guess ? A.x[c0 + i] : 0.0;
+    L.p[i] = 0.0;
+    L.s[i] = 0.0;
+  }
+  __syncthreads();
+  apply_pc();
+  if (!ok) return;
+  double bn = 0.0;
+#pragma unroll 1
+  for (int i = tid; i < nloc; i += PS_NT) bn += L.u[i] * L.u[i];
+  {
+    double z0 = 0.0, z1 = 0.0;
+    ps_block_sum3(bn, z0, z1, L.red);
+    if (tid == 0) ps_store(&Q.psum[4 * blockIdx.x + 3], bn);
+  }
+  if (A.nonzero_guess) {
+    product_of(L.x);
+    if (!ok) return;
+#pragma unroll 1
+    for (int i = tid; i < nloc; i += PS_NT) L.r[i] = A.b[c0 + i] - L.w[i];
+    __syncthreads();
+    apply_pc();
+    if (!ok) return;
+  }
+  double gamma_prev = 1.0, alpha_prev = 1.0, znorm = 0.0, tol = 0.0, bnorm = 0.0;
+  int its = 0, status = -1;
+#pragma unroll 1
+  for (int it = 0; it <= A.maxit; it++) {
+    product_of(L.u);
+    if (!ok) return;
+    double a = 0.0, b = 0.0, cc = 0.0;
+#pragma unroll 1
+    for (int i = tid; i < nloc; i += PS_NT) {
+      const double ui = L.u[i];
+      a += L.r[i] * ui;
+      b += L.w[i] * ui;
+      cc += ui * ui;
+    }
+    ps_block_sum3(a, b, cc, L.red);
+    if (tid == 0) {
+      ps_store(&Q.psum[4 * blockIdx.x], a);
+      ps_store(&Q.psum[4 * blockIdx.x + 1], b);
+      ps_store(&Q.psum[4 * blockIdx.x + 2], cc);
+    }
+    if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
+    pg_fold(Q.psum, 4, G, 4, L.f);
+    const double gamma = L.f[0], delta_ = L.f[1], nu = L.f[2];
+    if (it == 0) {
+      bnorm = sqrt(L.f[3]);
+      tol = fmax(A.rtol * bnorm, A.atol);
+    }
+    __syncthreads();
+    znorm = sqrt(nu);
+    its = it;
+    if (!(nu == nu) || !(gamma == gamma)) {
+      status = -2;
+      break;
+    }
+    if (znorm <= tol) {
+      status = (znorm <= A.atol && !(znorm <= A.rtol * bnorm)) ? 1 : 0;
+      break;
+    }
+    if (it == A.maxit) break;
+    double beta = 0.0, alpha;
+    if (it == 0)
+      alpha = gamma / delta_;
+    else {
+      beta = gamma / gamma_prev;
+      alpha = gamma / (delta_ - beta * gamma / alpha_prev);
+    }
+    if (!(alpha == alpha) || alpha == 0.0 || !(gamma > 0.0)) {
+      status = -2;
+      break;
+    }
+    gamma_prev = gamma;
+    alpha_prev = alpha;
+#pragma unroll 1
+    for (int i = tid; i < nloc; i += PS_NT) {
+      const double pi = L.u[i] + beta * L.p[i];
+      const double si = L.w[i] + beta * L.s[i];
+      L.p[i] = pi;
+      L.s[i] = si;
+      L.x[i] += alpha * pi;
+      L.r[i] -= alpha * si;
+    }
+    __syncthreads();
+    apply_pc();
+    if (!ok) return;
+  }
+#pragma unroll 1
+  for (int i = tid; i < nloc; i += PS_NT) A.x[c0 + i] = L.x[i];
+  if (blockIdx.x == 0 && tid == 0) {
+    A.ctrl->out[0] = (double)its;
+    A.ctrl->out[1] = znorm;
+    A.ctrl->out[3] = (double)status;
+  }
+}
+
 // Whether a system is taken by the persistent loop: one rank, at least a few thousand rows (below, the launches are not what
 // the solve costs), rows of at most 128 entries, and all of K in the registers of one workgroup per CU
 // (TIGAR_KSP_PERSISTENT=0 turns it off, =1 lifts the lower limit).
@@ -1030,3 +1238,90 @@ int tg_bicgstab_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double
   return ps_run_pg(true, k, b, x, pc, rtol, atol, maxit, 0, nonzero_guess, iters, resnorm, status);
 }
 
+
+// CG with the Chebyshev polynomial preconditioner of degree m on [theta - delta, theta + delta] (from tg_pcg_cheb's Lanczos
+// steps); 100 = not taken
+int tg_pcg_cheb_persistent(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int m, double theta, double delta, double rtol, double atol,
+                           int maxit, int nonzero_guess, int *iters, double *resnorm, int *status) {
+  const int64_t n = k->nrows;
+  TG_TRY(tg_spmv_plan(k));
+  int epr = 0, ri = 0, G = 0;
+  if (!ps_shape(k, PS_ROWS_MAX, &epr, &ri, &G) || !(delta > 0.0) || !(theta > delta)) return 100;
+  double *buf = nullptr;
+  const int64_t ctrl_doubles = (int64_t)(sizeof(tg_ps_ctrl) + 7) / 8 + 16;
+  TG_TRY(tg_dmalloc(&buf, 2 * n + 4 * (int64_t)G + 16 + ctrl_doubles));
+  tg_pc_args Q;
+  memset(&Q, 0, sizeof(Q));
+  tg_ps_args &A = Q.P;
+  A.rowptr = k->rowptr;
+  A.col = k->col;
+  A.val = k->val;
+  A.n = n;
+  A.b = b->d;
+  A.x = x->d;
+  A.u = buf;
+  Q.u2 = buf + n;
+  Q.psum = buf + 2 * n;
+  A.ctrl = (tg_ps_ctrl *)(((uintptr_t)(buf + 2 * n + 4 * (int64_t)G) + 127) & ~(uintptr_t)127);
+  A.rtol = rtol;
+  A.atol = atol;
+  A.maxit = maxit;
+  A.jacobi = 1;
+  A.nonzero_guess = nonzero_guess;
+  A.budget_ticks = 100000000ll * 5;
+  Q.m = m;
+  Q.theta = theta;
+  Q.delta = delta;
+  hipMemsetAsync(A.ctrl, 0, sizeof(tg_ps_ctrl), g_tg.stream);
+  void *params[] = {&Q};
+  const void *fn = nullptr;
+#define PS_PICK(E, R) \
+  if (epr == E && ri == R) fn = (const void *)k_pcg_cheb_persistent<E, R>
+  PS_PICK(1, 16); PS_PICK(1, 32); PS_PICK(1, 48); PS_PICK(1, 56);
+  PS_PICK(2, 8); PS_PICK(2, 16); PS_PICK(2, 24); PS_PICK(2, 28);
+  PS_PICK(3, 6); PS_PICK(3, 12); PS_PICK(3, 17); PS_PICK(3, 18);
+  PS_PICK(4, 4); PS_PICK(4, 8); PS_PICK(4, 12); PS_PICK(4, 14);
+  PS_PICK(5, 4); PS_PICK(5, 8); PS_PICK(5, 11); PS_PICK(5, 13);
+#undef PS_PICK
+  if (!fn || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pc_lds)) != hipSuccess) {
+    (void)hipGetLastError();
+    tg_dfree(buf);
+    return 100;
+  }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEventCreate(&ev0);
+  hipEventCreate(&ev1);
+  hipEventRecord(ev0, g_tg.stream);
+  hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)G), dim3(PS_NT), params, sizeof(pc_lds), g_tg.stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    hipEventDestroy(ev0);
+    hipEventDestroy(ev1);
+    tg_dfree(buf);
+    return 100;
+  }
+  hipEventRecord(ev1, g_tg.stream);
+  tg_ps_ctrl h;
+  e = hipMemcpyAsync(&h, A.ctrl, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream);
+  const hipError_t e2 = hipStreamSynchronize(g_tg.stream);
+  float ems = 0.f;
+  if (e2 == hipSuccess && hipEventElapsedTime(&ems, ev0, ev1) != hipSuccess) ems = 0.f;
+  hipEventDestroy(ev0);
+  hipEventDestroy(ev1);
+  tg_dfree(buf);
+  if (e != hipSuccess || e2 != hipSuccess) {
+    tg_set_error("persistent Chebyshev-CG: %s", hipGetErrorString(e2 != hipSuccess ? e2 : e));
+    return 1;
+  }
+  if (h.abort_flag) return 100;
+  if (getenv("TIGAR_TRACE"))
+    fprintf(stderr, "[trace] persistent chebyshev(%d)-cg: %d its in %.3f ms (%d workgroups)\n", m, (int)h.out[0], ems, G);
+  g_tg.prof_n[TG_PROF_KSP_PERSISTENT] += 1;
+  g_tg.prof_ms[TG_PROF_KSP_PERSISTENT] += ems;
+  g_tg.prof_n[TG_PROF_KSP_SPMV] += ((int64_t)h.out[0] + 2) * m;
+  g_tg.prof_ms[TG_PROF_KSP_SPMV] += ems;
+  *iters = (int)h.out[0];
+  *resnorm = h.out[1];
+  *status = (int)h.out[3];
+  return 0;
+}
