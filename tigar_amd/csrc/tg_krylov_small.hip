@@ -1027,7 +1027,7 @@ __global__ void __launch_bounds__(PS_NT) k_pcg_cheb_persistent(tg_pc_args Q) {
   }
 }
 
-// Whether a system is taken by the persistent loop: one rank, at least a few thousand rows (below, the launches are not what
+// Whether a system is taken by the persistent loop: one rank, at least a thousand rows (below, the launches are not what
 // the solve costs), rows of at most 128 entries, and all of K in the registers of one workgroup per CU
 // (TIGAR_KSP_PERSISTENT=0 turns it off, =1 lifts the lower limit).
 static const int PS_RI[5][4] = {{16, 32, 48, 56}, {8, 16, 24, 28}, {6, 12, 17, 18}, {4, 8, 12, 14}, {4, 8, 11, 13}};   // rows per group of lanes, by EPR
@@ -1053,7 +1053,7 @@ static bool ps_shape(const tg_csr_s *k, int64_t rows_max, int *epr_out, int *ri_
 bool tg_cg_persistent_applies(const tg_csr_s *k) {
   const int mode = getenv("TIGAR_KSP_PERSISTENT") ? atoi(getenv("TIGAR_KSP_PERSISTENT")) : -1;
   if (mode == 0 || k->nrows < 1 || k->nrows != k->ncols || k->nnz < 1) return false;
-  return mode == 1 || k->nrows >= 4096;
+  return mode == 1 || k->nrows >= 1024;
 }
 
 // Returns 0 with the results set, 100 when the kernel could not be used (K beyond the registers, workgroups not resident,
