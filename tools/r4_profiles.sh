@@ -68,5 +68,13 @@ pmc)
   TIGAR_EXTRACT_KRON=0 pmc cfg2_general_extraction --workload cfg2 --steps 3 --warmup 1 $W
   TIGAR_EXTRACT_KRON=0 TIGAR_EXTRACT_SEPARABLE=0 pmc cfg2_general_extraction_count_fill --workload cfg2 --steps 3 --warmup 1 $W
   ;;
+small)
+  # the 2-D configurations again after the persistent Krylov kernels (tg_krylov_small.hip) went in
+  stats cfg4 --workload cfg4 --solver cg --rtol 1e-10 --steps 3 --warmup 1 $W
+  stats cfg4_cheb --workload cfg4 --solver cg --pc chebyshev --rtol 1e-10 --steps 3 --warmup 1 $W
+  stats cfg5 --workload cfg5 --rtol 1e-10 --steps 3 --warmup 1 $W
+  pmc cfg4 --workload cfg4 --solver cg --rtol 1e-6 --steps 3 --warmup 1 $W
+  pmc cfg5 --workload cfg5 --rtol 1e-10 --steps 3 --warmup 1 $W
+  ;;
 esac
 ls $O | head -80

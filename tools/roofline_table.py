@@ -32,7 +32,10 @@ def main():
           "(`r2_hbm_ceilings.txt`, `tools/mb/write_bw.hip`: pure read 6.2-6.4, pure write 5.9-6.6, mixed 5.1-5.3 TB/s; the\n"
           "rate of a buffer depends on where it was placed, 5.6-6.7 for pure writes).  Durations and counters come from\n"
           "different runs of the same command, so rows of kernels whose launches vary in size (sub-slabs) are averages.\n"
-          "(rN = r%s in the file names.)\n" % RND)
+          "(rN = r%s in the file names.)  `k_cg_persistent` / `k_gmres_persistent` / `k_bicgstab_persistent` / `k_pcg_cheb_persistent`\n"
+          "(round 4) are WHOLE Krylov solves in one kernel each: K sits in registers, what they read from HBM is the vector the\n"
+          "workgroups exchange (agent-scope loads, once per product) -- they are bound by their device-wide barriers, not by HBM,\n"
+          "and their rows are here for the byte counts only.\n" % RND)
     print("| workload | kernel | avg ms | read GB | written GB | TB/s | of 8 TB/s | of the streaming ceiling |")
     print("|---|---|---|---|---|---|---|---|")
     for label, fstats, fpmc in WORK:
