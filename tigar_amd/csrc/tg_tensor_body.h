@@ -344,7 +344,11 @@ struct tt_io_xg {
   template <int N>
   TT_MEM void load(int a, int clo, double *v) {
     (void)clo;
-    tt_cdp f = f0 + ps0[a];
+    // position of row a in the 1-D factor: its pattern is the element-coupling pattern (checked on the host,
+    // tensorptap.pack_kron_factors), so the prefix sum of the row lengths is closed form -- (P+1) a + P * (interior vertices
+    // before a) -- and the address of the row does not wait for a scalar load of ps0[a] (two dependent scalar-memory
+    // latencies per node were what the walk waited for most: 36 % VALU busy at 3.3 waves per SIMD)
+    tt_cdp f = f0 + ((P + 1) * a + P * ((a - 1) / P));
 #pragma unroll
     for (int j = 0; j < N; j++) {
       double acc = fma(f[j], g[0], 0.0);
