@@ -378,10 +378,12 @@ struct tt_xg_multi {
 };
 template <int P, int NT>
 __global__ void __launch_bounds__(64) k_tt_xg_multi(tt_xg_multi<NT> M) {
+  // (the piece of the walk is the slowest-varying index: see tt_xg_args::ech)
+  const unsigned piece = blockIdx.x / M.first[M.n], b = blockIdx.x - piece * M.first[M.n];
   int c = 0;
-  while (c + 1 < M.n && blockIdx.x >= M.first[c + 1]) c++;
-  const unsigned local = blockIdx.x - M.first[c];
-  tt_xg_lane<P, NT>(M.c[c], (int)(local % M.gx[c]), (int)(local / M.gx[c]), threadIdx.x);
+  while (c + 1 < M.n && b >= M.first[c + 1]) c++;
+  const unsigned local = b - M.first[c];
+  tt_xg_lane<P, NT>(M.c[c], (int)(local % M.gx[c]), (int)(local / M.gx[c]), threadIdx.x, (int)piece);
 }
 
 template <int NT>
@@ -391,6 +393,18 @@ static int tt_launch_xg(tg_tensor_plan_s *pl, int z0, const std::vector<int32_t>
   const tt_dir_t &D0 = pl->dir[0], &D1 = pl->dir[1], &D2 = pl->dir[2];
   tt_xg_multi<NT> XM;
   memset(&XM, 0, sizeof(XM));
+  // The walk in pieces, the piece as the slowest-varying block index: what a wave reads through the scalar unit per element --
+  // the rows of the x factor of every term (P nodes x NT terms x ~1.5 (P + 1) doubles) and the local weights ((P + 1)^2
+  // doubles) -- is 0.56 KB at P = 3 with three terms, 140 KB for the whole direction at cfg3: the waves of a CU, spread over
+  // the direction, kept missing the 16 KB scalar cache (six batches of scalar loads per element, each waited for: 36 % of the
+  // vector cycles busy).  With all resident workgroups inside one window of ~12 KB the loads hit: 3.41 -> 2.34 ms per
+  // sub-slab at cfg3 (pieces of 8 / 12 / 16 / 20 / 24 / 32 / 40 / 48 / 64 elements: 2.60 / 2.46 / 2.38 / 2.34 / 2.35 / 2.38 /
+  // 2.63 / 2.97 / 3.34 ms; a piece re-walks P elements, its rows are bit for bit those of the whole walk).
+  // TIGAR_TT_XG_ECH=n sets the piece length, 0 walks the direction at once.
+  static const int ech_env = getenv("TIGAR_TT_XG_ECH") ? atoi(getenv("TIGAR_TT_XG_ECH")) : -1;
+  const double per_element = 8.0 * (P * NT * 1.5 * (P + 1) + (P + 1) * (P + 1));
+  int ech = ech_env >= 0 ? ech_env : (int)(12288.0 / per_element);
+  ech = ech > 0 && ech < D0.nel ? std::max(ech, 2 * P) : 0;
   for (int pc = 1; pc >= 0; pc--) {
     if (pls[pc].empty()) continue;
     const int n2 = pc == 0 ? P + 1 : W;
@@ -418,13 +432,15 @@ static int tt_launch_xg(tg_tensor_plan_s *pl, int z0, const std::vector<int32_t>
       X.b1 = b1;
       X.pb1 = d_pb1;
       X.z0 = z0;
+      X.ech = ech;
       XM.gx[XM.n] = (unsigned)tg_cdiv(X.nlines, X.L);
       XM.first[XM.n + 1] = XM.first[XM.n] + XM.gx[XM.n] * (unsigned)pls[pc].size();
       XM.n++;
     }
   }
   if (XM.n == 0 || XM.first[XM.n] == 0) return 0;
-#define TT_XG(PP) hipLaunchKernelGGL((k_tt_xg_multi<PP, NT>), dim3(XM.first[XM.n]), dim3(64), 0, g_tg.stream, XM)
+  const unsigned npieces = ech > 0 ? (unsigned)tg_cdiv(D0.nel, ech) : 1u;
+#define TT_XG(PP) hipLaunchKernelGGL((k_tt_xg_multi<PP, NT>), dim3(XM.first[XM.n] * npieces), dim3(64), 0, g_tg.stream, XM)
   TT_DISPATCH_P(P, TT_XG);
 #undef TT_XG
   return 0;

@@ -330,6 +330,10 @@ struct tt_xg_args {
   double *b1;
   const int64_t *pb1;
   int z0;
+  // the walk in pieces of `ech` elements (0: the whole direction at once), as tt_x_args::ech: with the piece as the
+  // slowest-varying block index the workgroups resident at one time read the SAME few KB of the Kronecker-factor rows and
+  // local weights, which then stay in the scalar cache
+  int ech;
 };
 
 template <int P, int NT>
@@ -341,6 +345,7 @@ struct tt_io_xg {
   bool valid;
   double *out;
   int64_t ostride_i, ostride_m;
+  int elo, ehi;                    // rows emitted by this piece of the walk
   template <int N>
   TT_MEM void load(int a, int clo, double *v) {
     (void)clo;
@@ -358,7 +363,7 @@ struct tt_io_xg {
     }
   }
   TT_MEM void emit(int i, const double *row) {
-    if (!valid) return;
+    if (!valid || i < elo || i >= ehi) return;
     double *d = out + ostride_i * i;
 #pragma unroll
     for (int m = 0; m < 2 * P + 1; m++) d[m * ostride_m] = row[m];
@@ -366,7 +371,7 @@ struct tt_io_xg {
 };
 
 template <int P, int NT>
-TT_DEV void tt_xg_lane(const tt_xg_args<NT> &A, int bx, int by, int lane) {
+TT_DEV void tt_xg_lane(const tt_xg_args<NT> &A, int bx, int by, int lane, int piece = 0) {
   constexpr int W = 2 * P + 1;
   const int plane = A.planes[by];
   const int lpl = A.n1 * A.n2;
@@ -388,7 +393,9 @@ TT_DEV void tt_xg_lane(const tt_xg_args<NT> &A, int bx, int by, int lane) {
   io.out = A.b1 + A.pb1[plane - A.z0] + wn2 * A.d0.ncp * A.rps1[r1] + (int64_t)c2 * W * A.n1 + c1;
   io.ostride_i = wn2 * A.n1;
   io.ostride_m = A.n1;
-  tt_walk<P>(A.d0, 0, A.d0.nel, io);
+  int e0, e1;
+  tt_piece(A.ech, piece, P, A.d0.nel, e0, e1, io.elo, io.ehi);
+  tt_walk<P>(A.d0, e0, e1, io);
 }
 
 // Row lengths of A against the element-coupling pattern: row (a, r1, r2) must hold n0(a)*n1(r1)*n2(r2) entries.
