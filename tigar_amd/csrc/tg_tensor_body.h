@@ -72,6 +72,12 @@ template <int P>
 TT_DEV int tt_rn(int a, int nfe) {
   return (a % P == 0 && a > 0 && a < nfe - 1) ? 2 * P + 1 : P + 1;
 }
+// position of row a in that pattern = the prefix sum of the row lengths, in closed form: (P+1) a + P * (interior vertices
+// before a).  The walks use it instead of loading rps[a]: the addresses of a row's entries then do not depend on a scalar load.
+template <int P>
+TT_DEV int tt_rps(int a) {
+  return (P + 1) * a + (a > 0 ? P * ((a - 1) / P) : 0);
+}
 template <int P>
 TT_DEV int tt_rlo(int a, int nfe) {
   if (a % P == 0 && a > 0) return a - P;          // vertex between two elements, or the last node
@@ -242,7 +248,9 @@ struct tt_io_x {
 #pragma unroll
     for (int j = 0; j < N; j++) v[j] = 0.0;
     if (!valid) return;
-    const int64_t o = linebase + lpl * ps0[a] + (N == P + 1 ? off_s : off_v);
+    // (ps0[a] in closed form -- the row lengths are those of the element-coupling pattern, verified by k_tt_check_rows --:
+    //  the addresses of the row's values do not wait for a scalar load)
+    const int64_t o = linebase + lpl * tt_rps<P>(a) + (N == P + 1 ? off_s : off_v);
     const int32_t c0 = colbase + clo;
     int32_t diff = 0;
 #pragma unroll
@@ -353,7 +361,7 @@ struct tt_io_xg {
     // tensorptap.pack_kron_factors), so the prefix sum of the row lengths is closed form -- (P+1) a + P * (interior vertices
     // before a) -- and the address of the row does not wait for a scalar load of ps0[a] (two dependent scalar-memory
     // latencies per node were what the walk waited for most: 36 % VALU busy at 3.3 waves per SIMD)
-    tt_cdp f = f0 + ((P + 1) * a + P * ((a - 1) / P));
+    tt_cdp f = f0 + tt_rps<P>(a);
 #pragma unroll
     for (int j = 0; j < N; j++) {
       double acc = fma(f[j], g[0], 0.0);
