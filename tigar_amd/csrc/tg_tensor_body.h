@@ -451,7 +451,7 @@ struct tt_io_y {
 #pragma unroll
     for (int j = 0; j < N; j++) v[j] = 0.0;
     if (!valid) return;
-    const int64_t o = ustride * rps[a] + clane * N;
+    const int64_t o = ustride * tt_rps<P>(a) + clane * N;      // (closed form: see tt_rps)
 #pragma unroll
     for (int j = 0; j < N; j++) v[j] = in[o + j];
   }
@@ -629,7 +629,7 @@ struct tt_io_y2 {
 #pragma unroll
     for (int j = 0; j < N; j++) v[j] = 0.0;
     if (!valid) return;
-    const int64_t o = ustride * rps[a] + clane * N;
+    const int64_t o = ustride * tt_rps<P>(a) + clane * N;      // (closed form: see tt_rps)
 #pragma unroll
     for (int j = 0; j < N; j++) v[j] = in[o + j];
   }
