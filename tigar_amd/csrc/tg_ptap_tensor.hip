@@ -61,12 +61,14 @@ struct tt_y_multi {
 };
 template <int P, bool V>
 __global__ void __launch_bounds__(64) k_tt_x_multi(tt_x_multi M) {
+  // (the piece of the walk, if it is cut into pieces, is the slowest-varying index: tt_xg_args::ech)
+  const unsigned piece = blockIdx.x / M.first[M.n], b = blockIdx.x - piece * M.first[M.n];
   int c = 0;
-  while (c + 1 < M.n && blockIdx.x >= M.first[c + 1]) c++;
+  while (c + 1 < M.n && b >= M.first[c + 1]) c++;
   const tt_x_args &A = M.c[c];
   if (*(volatile int *)A.status) return;     // row lengths differ from the pattern: the closed-form addresses do not apply
-  const unsigned local = blockIdx.x - M.first[c];
-  const int bad = tt_x_lane<P, V>(A, (int)(local % M.gx[c]), (int)(local / M.gx[c]), threadIdx.x);
+  const unsigned local = b - M.first[c];
+  const int bad = tt_x_lane<P, V>(A, (int)(local % M.gx[c]), (int)(local / M.gx[c]), threadIdx.x, (int)piece);
   if (bad) atomicOr(A.status, 1);
 }
 template <int P>
@@ -262,6 +264,14 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
 #undef TT_C
     }
     // x pass: the (plane class, line class) combinations in one launch, widest windows first
+    // The walk in TWO pieces (each lane walks half of the direction; the second piece re-reads the rows of A of p elements:
+    // +1-2 % of A): 6.71 -> 6.27 ms per sub-slab at cfg3 with the FE matrix materialised, 3.76 -> 3.50 ms at cfg2; three and
+    // more pieces (96, 64, 48 elements at cfg3) gave nothing (6.76-6.86 ms) -- unlike the pass that forms A's entries itself
+    // this one is not waiting for its scalar tables.  TIGAR_TT_X_ECH=n: pieces of n elements, 0: one walk.
+    static const int x_ech_env = getenv("TIGAR_TT_X_ECH") ? atoi(getenv("TIGAR_TT_X_ECH")) : -1;
+    const int x_ech_pick = x_ech_env >= 0 ? x_ech_env : (D0.nel >= 64 ? (D0.nel + 1) / 2 : 0);
+    const int x_ech = x_ech_pick > 0 && x_ech_pick < D0.nel ? std::max(x_ech_pick, 2 * P) : 0;
+    const unsigned x_pieces = x_ech > 0 ? (unsigned)tg_cdiv(D0.nel, x_ech) : 1u;
     {
       tt_x_multi XM;
       memset(&XM, 0, sizeof(XM));
@@ -291,6 +301,7 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
           X.pb1 = d_pb1;
           X.z0 = z0;
           X.status = res->status;
+          X.ech = x_ech;
           XM.gx[XM.n] = (unsigned)tg_cdiv(X.nlines, X.L);
           XM.first[XM.n + 1] = XM.first[XM.n] + XM.gx[XM.n] * (unsigned)pls[pc].size();
           XM.n++;
@@ -302,8 +313,8 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
       const bool certified = certified_pass = a->pattern_tag != 0 && a->pattern_tag == pl->expect_tag && a->pattern_row0 == a_row0 &&
                              !(getenv("TIGAR_PTAP_VERIFY") && atoi(getenv("TIGAR_PTAP_VERIFY")));
       if (XM.n > 0 && XM.first[XM.n] > 0) {
-#define TT_X(PP) hipLaunchKernelGGL((k_tt_x_multi<PP, true>), dim3(XM.first[XM.n]), dim3(64), 0, g_tg.stream, XM)
-#define TT_XC(PP) hipLaunchKernelGGL((k_tt_x_multi<PP, false>), dim3(XM.first[XM.n]), dim3(64), 0, g_tg.stream, XM)
+#define TT_X(PP) hipLaunchKernelGGL((k_tt_x_multi<PP, true>), dim3(XM.first[XM.n] * x_pieces), dim3(64), 0, g_tg.stream, XM)
+#define TT_XC(PP) hipLaunchKernelGGL((k_tt_x_multi<PP, false>), dim3(XM.first[XM.n] * x_pieces), dim3(64), 0, g_tg.stream, XM)
         if (certified) TT_DISPATCH_P(P, TT_XC);
         else TT_DISPATCH_P(P, TT_X);
 #undef TT_X
