@@ -59,6 +59,14 @@ struct tt_y_multi {
   unsigned first[3], gx[2];
   int n;
 };
+// piece length of the y walk (TIGAR_TT_Y_ECH=n for experiments; default 0 = one walk: the pass is HBM-bound, two / three /
+// four pieces at cfg3 gave 3.07 / 3.12 / 3.05 ms against 3.07)
+static int tt_y_ech(int nel, int P) {
+  static const int env = getenv("TIGAR_TT_Y_ECH") ? atoi(getenv("TIGAR_TT_Y_ECH")) : 0;
+  const int pick = env;
+  return pick > 0 && pick < nel ? std::max(pick, 2 * P) : 0;
+}
+static unsigned tt_pieces(int nel, int ech) { return ech > 0 ? (unsigned)tg_cdiv(nel, ech) : 1u; }
 template <int P, bool V>
 __global__ void __launch_bounds__(64) k_tt_x_multi(tt_x_multi M) {
   // (the piece of the walk, if it is cut into pieces, is the slowest-varying index: tt_xg_args::ech)
@@ -73,10 +81,11 @@ __global__ void __launch_bounds__(64) k_tt_x_multi(tt_x_multi M) {
 }
 template <int P>
 __global__ void __launch_bounds__(64) k_tt_y_multi(tt_y_multi M) {
+  const unsigned piece = blockIdx.x / M.first[M.n], b = blockIdx.x - piece * M.first[M.n];
   int c = 0;
-  while (c + 1 < M.n && blockIdx.x >= M.first[c + 1]) c++;
-  const unsigned local = blockIdx.x - M.first[c];
-  tt_y_lane<P>(M.c[c], (int)(local % M.gx[c]), (int)(local / M.gx[c]), threadIdx.x);
+  while (c + 1 < M.n && b >= M.first[c + 1]) c++;
+  const unsigned local = b - M.first[c];
+  tt_y_lane<P>(M.c[c], (int)(local % M.gx[c]), (int)(local / M.gx[c]), threadIdx.x, (int)piece);
 }
 template <int P>
 __global__ void __launch_bounds__(64) k_tt_z(tt_z_args A) {
@@ -340,12 +349,14 @@ extern "C" int tg_tensor_planes(tg_tensor_plan_t pl, tg_csr_t a, int64_t a_row0,
         Y.planes = d_pl[pc];
         Y.n2 = n2;
         Y.L = std::max(1, 64 / (W * n2));
+        Y.ech = tt_y_ech(D1.nel, P);
         YM.gx[YM.n] = (unsigned)tg_cdiv(D0.ncp, Y.L);
         YM.first[YM.n + 1] = YM.first[YM.n] + YM.gx[YM.n] * (unsigned)pls[pc].size();
         YM.n++;
       }
       if (YM.n > 0 && YM.first[YM.n] > 0) {
-#define TT_Y(PP) hipLaunchKernelGGL((k_tt_y_multi<PP>), dim3(YM.first[YM.n]), dim3(64), 0, g_tg.stream, YM)
+#define TT_Y(PP) \
+  hipLaunchKernelGGL((k_tt_y_multi<PP>), dim3(YM.first[YM.n] * tt_pieces(D1.nel, tt_y_ech(D1.nel, P))), dim3(64), 0, g_tg.stream, YM)
         TT_DISPATCH_P(P, TT_Y);
 #undef TT_Y
       }
@@ -533,12 +544,14 @@ extern "C" int tg_tensor_planes_kron(tg_tensor_plan_t pl, int nterms, const tg_k
       Y.planes = d_pl[pc];
       Y.n2 = n2;
       Y.L = std::max(1, 64 / (W * n2));
+      Y.ech = tt_y_ech(D1.nel, P);
       YM.gx[YM.n] = (unsigned)tg_cdiv(D0.ncp, Y.L);
       YM.first[YM.n + 1] = YM.first[YM.n] + YM.gx[YM.n] * (unsigned)pls[pc].size();
       YM.n++;
     }
     if (!rc && YM.n > 0 && YM.first[YM.n] > 0) {
-#define TT_Y(PP) hipLaunchKernelGGL((k_tt_y_multi<PP>), dim3(YM.first[YM.n]), dim3(64), 0, g_tg.stream, YM)
+#define TT_Y(PP) \
+  hipLaunchKernelGGL((k_tt_y_multi<PP>), dim3(YM.first[YM.n] * tt_pieces(D1.nel, tt_y_ech(D1.nel, P))), dim3(64), 0, g_tg.stream, YM)
       TT_DISPATCH_P(P, TT_Y);
 #undef TT_Y
     }

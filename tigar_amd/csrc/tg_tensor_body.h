@@ -436,6 +436,7 @@ struct tt_y_args {
   int ncp0;
   const int32_t *planes;
   int n2, L;
+  int ech;                       // the walk in pieces of `ech` elements (0: the whole direction), as tt_x_args::ech
 };
 
 template <int P>
@@ -444,6 +445,7 @@ struct tt_io_y {
   tt_cip rps;
   int64_t ustride, clane;
   bool valid;
+  int elo, ehi;                  // rows emitted by this piece of the walk
   double *out;
   int64_t ostride_i, ostride_m;
   template <int N>
@@ -456,7 +458,7 @@ struct tt_io_y {
     for (int j = 0; j < N; j++) v[j] = in[o + j];
   }
   TT_MEM void emit(int i, const double *row) {
-    if (!valid) return;
+    if (!valid || i < elo || i >= ehi) return;
     double *d = out + ostride_i * i;
 #pragma unroll
     for (int m = 0; m < 2 * P + 1; m++) d[m * ostride_m] = row[m];
@@ -464,7 +466,7 @@ struct tt_io_y {
 };
 
 template <int P>
-TT_DEV void tt_y_lane(const tt_y_args &A, int bx, int by, int lane) {
+TT_DEV void tt_y_lane(const tt_y_args &A, int bx, int by, int lane, int piece = 0) {
   constexpr int W = 2 * P + 1;
   const int plane = A.planes[by];
   const int lpl = W * A.n2;
@@ -481,7 +483,9 @@ TT_DEV void tt_y_lane(const tt_y_args &A, int bx, int by, int lane) {
   io.out = A.b2 + A.pb2[plane - A.z0] + (int64_t)W * wn2 * i0 + (int64_t)m0 * A.n2 + c2;
   io.ostride_i = (int64_t)W * wn2 * A.ncp0;
   io.ostride_m = wn2;
-  tt_walk<P>(A.d1, 0, A.d1.nel, io);
+  int e0, e1;
+  tt_piece(A.ech, piece, P, A.d1.nel, e0, e1, io.elo, io.ehi);
+  tt_walk<P>(A.d1, e0, e1, io);
 }
 
 // ------------------------------------------------------------------------------------------------------
