@@ -448,7 +448,12 @@ def test_kronecker_sum_forms_are_fused_into_the_x_pass_bit_for_bit():
     materialised, then read), over several sub-slabs, with boundary conditions, for one- and three-term forms."""
     import tigar_amd as t
     from tigar_amd import BSplines as B, forms as F
-    for p, nels, form in ((3, (6, 5, 9), F.LaplaceForm()), (2, (7, 8, 10), F.MassForm()), (1, (4, 4, 6), F.LaplaceForm())):
+    # (the long x directions make both x passes walk in PIECES -- the fused one in pieces of ~12 KB of scalar tables: 21
+    #  elements at p = 3 with three terms, 85 at p = 2 with one, 118 at p = 1; the other in two halves from 64 elements on --
+    #  with a last piece shorter than the others)
+    for p, nels, form in ((3, (6, 5, 9), F.LaplaceForm()), (2, (7, 8, 10), F.MassForm()), (1, (4, 4, 6), F.LaplaceForm()),
+                          (3, (50, 3, 5), F.LaplaceForm()), (2, (95, 3, 4), F.MassForm()), (1, (130, 3, 4), F.LaplaceForm()),
+                          (3, (70, 2, 4), F.MassForm())):
         Ks = []
         for fused in ("1", "0"):
             os.environ["TIGAR_PTAP_FUSED"] = fused
