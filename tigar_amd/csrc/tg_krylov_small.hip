@@ -175,6 +175,49 @@ __device__ __forceinline__ void ps_product(const double (&v)[RI][EPR], const uns
   }
 }
 
+// The same with the last EL of the EPR entries per lane and row held in LDS (lv / lc: [RI][EL][PS_NT]) instead of registers:
+// for rows of 129-160 entries (cfg5: 147) the 65 slots of a lane do not fit the register file next to the GMRES body -- the
+// kernel spilled ~100 registers per lane to scratch, re-read in every product.
+template <int EPR, int RI, int EL>
+__device__ __forceinline__ void ps_product_l(const double (&v)[RI][EPR - EL], const unsigned (&c)[RI][EPR - EL],
+                                             const double *__restrict__ lv, const unsigned *__restrict__ lc,
+                                             const double *__restrict__ xg, double *__restrict__ w_lds, int nloc) {
+  constexpr int ER = EPR - EL;
+  constexpr int PS_BATCH = EPR >= 5 ? 2 : EPR == 4 ? 3 : EPR == 3 ? 4 : EPR == 2 ? 6 : 12;
+  const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
+  const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc((void *)xg, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+  for (int r0 = 0; r0 < RI; r0 += PS_BATCH) {
+    double xs[PS_BATCH][EPR];
+    double lvv[PS_BATCH][EL > 0 ? EL : 1];
+#pragma unroll
+    for (int ri = r0; ri < r0 + PS_BATCH && ri < RI; ri++) {
+#pragma unroll
+      for (int k = 0; k < ER; k++)
+        xs[ri - r0][k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xb, (int)c[ri][k], 0, PS_AUX_SC1));
+#pragma unroll
+      for (int k = 0; k < EL; k++) {
+        const int at = (ri * EL + k) * PS_NT + threadIdx.x;
+        lvv[ri - r0][k] = lv[at];
+        xs[ri - r0][ER + k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xb, (int)lc[at], 0, PS_AUX_SC1));
+      }
+    }
+#pragma unroll
+    for (int ri = r0; ri < r0 + PS_BATCH && ri < RI; ri++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < ER; k++) acc = fma(v[ri][k], xs[ri - r0][k], acc);
+#pragma unroll
+      for (int k = 0; k < EL; k++) acc = fma(lvv[ri - r0][k], xs[ri - r0][ER + k], acc);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      const int lrow = g + PS_GROUPS * ri;
+      if (l == 0 && lrow < nloc) w_lds[lrow] = acc;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <int EPR, int RI>
 __global__ void __launch_bounds__(PS_NT) k_cg_persistent(tg_ps_args A) {
   extern __shared__ double ps_dyn[];
@@ -351,7 +394,7 @@ __global__ void __launch_bounds__(PS_NT) k_cg_persistent(tg_ps_args A) {
 // order, and runs the Givens recurrence redundantly -- identical H, identical decisions, no broadcast.  Three device-wide
 // barriers per inner iteration (v_j complete | coefficients | norm) where the multi-kernel loop has seven launches.
 #define PG_M 30                   // restart length at most
-#define PG_ROWS 256               // local rows at most (the basis of the workgroup in LDS)
+#define PG_ROWS 224               // local rows at most (the basis of the workgroup in LDS; 224: room for one layer of K)
 struct pg_lds {
   double V[(PG_M + 1) * PG_ROWS];
   double x[PG_ROWS], w[PG_ROWS], dinv[PG_ROWS], b[PG_ROWS];
@@ -381,10 +424,13 @@ __device__ __forceinline__ void pg_fold(const double *__restrict__ partial, int 
   __syncthreads();
 }
 
-template <int EPR, int RI>
+template <int EPR, int RI, int EL>
 __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
   extern __shared__ double ps_dyn[];
   pg_lds &L = *(pg_lds *)ps_dyn;
+  constexpr int ER = EPR - EL;
+  double *const lv = ps_dyn + (sizeof(pg_lds) + 7) / 8;           // [RI][EL][PS_NT] values, then the byte offsets
+  unsigned *const lc = (unsigned *)(lv + (size_t)RI * (EL > 0 ? EL : 0) * PS_NT);
   const tg_ps_args &A = Q.P;
   const int m = Q.m;
   const unsigned G = gridDim.x;
@@ -393,8 +439,8 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
   const int64_t c0r = (int64_t)blockIdx.x * per, c0 = c0r < A.n ? c0r : A.n, c1 = c0 + per < A.n ? c0 + per : A.n;
   const int nloc = (int)(c1 - c0);
   const int tid = threadIdx.x, g = tid >> 5, l = tid & 31, lane = tid & 63, wv = tid >> 6;
-  double v[RI][EPR];
-  unsigned c[RI][EPR];
+  double v[RI][ER];
+  unsigned c[RI][ER];
 #pragma unroll
   for (int ri = 0; ri < RI; ri++) {
     const int lrow = g + PS_GROUPS * ri;
@@ -406,10 +452,16 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
     for (int k = 0; k < EPR; k++) {
       const int64_t q = a + l + 32 * k;
       const bool in = q < e;
-      v[ri][k] = in ? A.val[q] : 0.0;
+      const double vq = in ? A.val[q] : 0.0;
       const int cq = in ? A.col[q] : (int)(live ? row : 0);
-      c[ri][k] = 8u * (unsigned)cq;
-      if (in && cq == row) dd = v[ri][k];
+      if (k < ER) {
+        v[ri][k < ER ? k : 0] = vq;
+        c[ri][k < ER ? k : 0] = 8u * (unsigned)cq;
+      } else {
+        lv[(ri * EL + (k - ER)) * PS_NT + tid] = vq;
+        lc[(ri * EL + (k - ER)) * PS_NT + tid] = 8u * (unsigned)cq;
+      }
+      if (in && cq == row) dd = vq;
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) dd += __shfl_xor(dd, o, 64);
@@ -447,7 +499,7 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
         if (mine) ps_store(&A.u[c0 + tid], L.x[tid]);
         if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
       }
-      ps_product<EPR, RI>(v, c, A.u, L.w, nloc);
+      ps_product_l<EPR, RI, EL>(v, c, lv, lc, A.u, L.w, nloc);
       __syncthreads();
     }
     double rr = 0.0;
@@ -498,7 +550,7 @@ __global__ void __launch_bounds__(PS_NT) k_gmres_persistent(tg_pg_args Q) {
     #pragma unroll 1
     for (int j = 0; j < m && alive; j++) {
       // ---- w = B K v_j
-      ps_product<EPR, RI>(v, c, A.u, L.w, nloc);
+      ps_product_l<EPR, RI, EL>(v, c, lv, lc, A.u, L.w, nloc);
       __syncthreads();
       if (mine) L.w[tid] *= L.dinv[tid];
       __syncthreads();
@@ -630,10 +682,13 @@ struct pb_lds {
   double f[8];
 };
 
-template <int EPR, int RI>
+template <int EPR, int RI, int EL>
 __global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
   extern __shared__ double ps_dyn[];
   pb_lds &L = *(pb_lds *)ps_dyn;
+  constexpr int ER = EPR - EL;
+  double *const lv = ps_dyn + (sizeof(pb_lds) + 7) / 8;           // [RI][EL][PS_NT] values of K held in LDS, then the offsets
+  unsigned *const lc = (unsigned *)(lv + (size_t)RI * (EL > 0 ? EL : 0) * PS_NT);
   const tg_ps_args &A = Q.P;
   const unsigned G = gridDim.x;
   unsigned gen = 0;
@@ -641,8 +696,8 @@ __global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
   const int64_t c0r = (int64_t)blockIdx.x * per, c0 = c0r < A.n ? c0r : A.n, c1 = c0 + per < A.n ? c0 + per : A.n;
   const int nloc = (int)(c1 - c0);
   const int tid = threadIdx.x, g = tid >> 5, l = tid & 31;
-  double v[RI][EPR];
-  unsigned c[RI][EPR];
+  double v[RI][ER];
+  unsigned c[RI][ER];
 #pragma unroll
   for (int ri = 0; ri < RI; ri++) {
     const int lrow = g + PS_GROUPS * ri;
@@ -654,10 +709,16 @@ __global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
     for (int k = 0; k < EPR; k++) {
       const int64_t q = a + l + 32 * k;
       const bool in = q < e;
-      v[ri][k] = in ? A.val[q] : 0.0;
+      const double vq = in ? A.val[q] : 0.0;
       const int cq = in ? A.col[q] : (int)(live ? row : 0);
-      c[ri][k] = 8u * (unsigned)cq;
-      if (in && cq == row) dd = v[ri][k];
+      if (k < ER) {
+        v[ri][k < ER ? k : 0] = vq;
+        c[ri][k < ER ? k : 0] = 8u * (unsigned)cq;
+      } else {
+        lv[(ri * EL + (k - ER)) * PS_NT + tid] = vq;
+        lc[(ri * EL + (k - ER)) * PS_NT + tid] = 8u * (unsigned)cq;
+      }
+      if (in && cq == row) dd = vq;
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) dd += __shfl_xor(dd, o, 64);
@@ -673,7 +734,7 @@ __global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
     L.x[i] = A.nonzero_guess ? A.x[c0 + i] : 0.0;
   }
   if (A.nonzero_guess) {
-    ps_product<EPR, RI>(v, c, A.x, L.w, nloc);
+    ps_product_l<EPR, RI, EL>(v, c, lv, lc, A.x, L.w, nloc);
     __syncthreads();
   }
   double rn = 0.0;
@@ -716,7 +777,7 @@ __global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
         ps_store(&A.u[c0 + i], pi);
       }
       if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
-      ps_product<EPR, RI>(v, c, A.u, L.w, nloc);
+      ps_product_l<EPR, RI, EL>(v, c, lv, lc, A.u, L.w, nloc);
       __syncthreads();
       double hv = 0.0;
 #pragma unroll 1
@@ -748,7 +809,7 @@ __global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
         ps_store(&A.u[c0 + i], si);
       }
       if (!ps_barrier(A.ctrl, G, gen, A.budget_ticks)) return;
-      ps_product<EPR, RI>(v, c, A.u, L.w, nloc);
+      ps_product_l<EPR, RI, EL>(v, c, lv, lc, A.u, L.w, nloc);
       __syncthreads();
       double ts = 0.0, tt = 0.0, hs = 0.0, ht = 0.0, ss = 0.0;
 #pragma unroll 1
@@ -1149,7 +1210,7 @@ static int ps_run_pg(bool bicgstab, tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int p
   TG_TRY(tg_spmv_plan(k));
   int epr = 0, ri = 0, G = 0;
   if (!ps_shape(k, bicgstab ? PS_ROWS_MAX : PG_ROWS, &epr, &ri, &G)) return 100;
-  const size_t lds_bytes = bicgstab ? sizeof(pb_lds) : sizeof(pg_lds);
+  size_t lds_bytes = bicgstab ? sizeof(pb_lds) : sizeof(pg_lds);
   double *buf = nullptr;
   const int64_t ctrl_doubles = (int64_t)(sizeof(tg_ps_ctrl) + 7) / 8 + 16;
   const int64_t npart = (int64_t)G * (PG_M + 1) + 2 * (int64_t)G;
@@ -1177,15 +1238,28 @@ static int ps_run_pg(bool bicgstab, tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int p
   hipMemsetAsync(A.ctrl, 0, sizeof(tg_ps_ctrl), g_tg.stream);
   void *params[] = {&Q};
   const void *fn = nullptr;
-#define PS_PICK(E, R) \
-  if (epr == E && ri == R) fn = bicgstab ? (const void *)k_bicgstab_persistent<E, R> : (const void *)k_gmres_persistent<E, R>
+  int el = 0;                                // layers of K in LDS (GMRES with rows of 129-160 entries)
+#define PS_PICK(E, R)                                                                                  \
+  if (epr == E && ri == R) {                                                                           \
+    if (bicgstab && E == 5 && R >= 11) {                                                               \
+      fn = (const void *)k_bicgstab_persistent<E, R, (E == 5 && R >= 11) ? 1 : 0>;                     \
+      el = 1;                                                                                          \
+    } else if (bicgstab)                                                                               \
+      fn = (const void *)k_bicgstab_persistent<E, R, 0>;                                               \
+    else if (E == 5 && R >= 11) {                                                                      \
+      fn = (const void *)k_gmres_persistent<E, R, (E == 5 && R >= 11) ? 1 : 0>;                        \
+      el = 1;                                                                                          \
+    } else                                                                                             \
+      fn = (const void *)k_gmres_persistent<E, R, 0>;                                                  \
+  }
   PS_PICK(1, 16); PS_PICK(1, 32); PS_PICK(1, 48); PS_PICK(1, 56);
   PS_PICK(2, 8); PS_PICK(2, 16); PS_PICK(2, 24); PS_PICK(2, 28);
   PS_PICK(3, 6); PS_PICK(3, 12); PS_PICK(3, 17); PS_PICK(3, 18);
   PS_PICK(4, 4); PS_PICK(4, 8); PS_PICK(4, 12); PS_PICK(4, 14);
   PS_PICK(5, 4); PS_PICK(5, 8); PS_PICK(5, 11); PS_PICK(5, 13);
 #undef PS_PICK
-  if (!fn || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+  if (el) lds_bytes = (((bicgstab ? sizeof(pb_lds) : sizeof(pg_lds)) + 7) / 8) * 8 + (size_t)ri * el * PS_NT * 12;
+  if (!fn || lds_bytes > 160 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
     (void)hipGetLastError();
     tg_dfree(buf);
     return 100;
