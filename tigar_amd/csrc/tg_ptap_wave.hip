@@ -901,7 +901,77 @@ struct tg_cellplan_s {
   int max_k = 0;
   double mean_k = 0.0;
   tg_gw_plan gw;
+  // known after the first product: the columns of K and, for every entry (c, q, r) of the element matrices, its PLACE in its
+  // row of K (the slot of column fl[c][r] in row fl[c][q]; rows of at most 255 entries) -- the merge then needs no look-up
+  int32_t *k_col = nullptr;
+  uint8_t *slot = nullptr;       // [ncell * nfmax][nfmax]
 };
+
+// slot[(c, q)][r] = position of column fl[c][r] in row fl[c][q] of K (binary search in the sorted row), 255 = not an entry
+__global__ void __launch_bounds__(256) k_cell_slots(const uint32_t *__restrict__ flmix, const int32_t *__restrict__ nfc, int64_t ncell,
+                                                    int nfmax, const int64_t *__restrict__ krowptr, const int32_t *__restrict__ kcol,
+                                                    uint8_t *__restrict__ slot, int *__restrict__ bad) {
+  const int64_t total = ncell * (int64_t)nfmax * nfmax, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int r = (int)(t % nfmax);
+    const int64_t cq = t / nfmax, c = cq / nfmax;
+    const int q = (int)(cq - c * nfmax), nf = nfc[c];
+    uint8_t sl = 255;
+    if (q < nf && r < nf) {
+      const int64_t i = gw_unmix(flmix[c * nfmax + q]);
+      const int32_t j = (int32_t)gw_unmix(flmix[c * nfmax + r]);
+      int64_t lo = krowptr[i], hi = krowptr[i + 1];
+      const int64_t a = lo;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (kcol[mid] < j) lo = mid + 1; else hi = mid;
+      }
+      if (lo < krowptr[i + 1] && kcol[lo] == j && lo - a < 255) sl = (uint8_t)(lo - a);
+      else atomicOr(bad, 1);
+    }
+    slot[t] = sl;
+  }
+}
+
+// K rows from the element matrices by PLACES: one wave per row of K; the 64 / LPR groups of lanes take the incident rows
+// (c, q) in turn and add their nf values into the group's own accumulators (places within one row are distinct: plain
+// read-modify-write), the groups' accumulators are added in a fixed order; MatZeroRowsColumns on the way out.
+template <int LGR>
+__global__ void __launch_bounds__(256)
+    k_cell_merge(const int64_t *__restrict__ irowptr, const int32_t *__restrict__ icol, const double *__restrict__ eval,
+                 const uint8_t *__restrict__ slot, const int32_t *__restrict__ nfc, int nfmax, int64_t nrows,
+                 const int64_t *__restrict__ krowptr, const int32_t *__restrict__ kcol, const uint8_t *__restrict__ mask, double diag,
+                 double *__restrict__ kval) {
+  constexpr int LPR = 1 << LGR, NG = 64 >> LGR;
+  __shared__ double acc_all[4][NG][256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> LGR, sub = lane & (LPR - 1);
+  double(*acc)[256] = acc_all[wave];
+  const int64_t wstride = (int64_t)gridDim.x * 4;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < nrows; i += wstride) {
+    const int64_t k0 = krowptr[i];
+    const int n = (int)(krowptr[i + 1] - k0);
+    for (int e = lane; e < NG * 256; e += 64) acc[0][e] = 0.0;       // (rows of one wave: no barrier needed, LDS ops are in order)
+    for (int64_t x = irowptr[i] + grp; x < irowptr[i + 1]; x += NG) {
+      const int64_t cq = icol[x];
+      const int nf = nfc[cq / nfmax];
+      for (int r = sub; r < nf; r += LPR) {
+        const uint8_t sl = slot[cq * nfmax + r];
+        if (sl != 255) acc[grp][sl] += eval[cq * nfmax + r];
+      }
+    }
+    const bool mrow = mask && mask[i];
+    for (int e = lane; e < n; e += 64) {
+      double v = acc[0][e];
+#pragma unroll
+      for (int g = 1; g < NG; g++) v += acc[g][e];
+      if (mask) {
+        const int32_t c = kcol[k0 + e];
+        if (mrow || mask[c]) v = (mrow && c == i) ? diag : 0.0;
+      }
+      kval[k0 + e] = v;
+    }
+  }
+}
 
 // one wave per cell: E_c = M_c^T (A_c M_c).  Lanes: groups of G = 2^LGF lanes <-> the function index f, 64 / G rows at once.
 template <int LGF>
@@ -1016,6 +1086,8 @@ extern "C" int tg_cellplan_destroy(tg_cellplan_t pl) {
   tg_dfree(pl->e_start);
   tg_dfree(pl->e_start_mix);
   tg_dfree(pl->e_cnt);
+  tg_dfree(pl->k_col);
+  tg_dfree(pl->slot);
   tg_ptap_wave_plan_free(&pl->gw);
   delete pl;
   return 0;
@@ -1127,7 +1199,35 @@ extern "C" int tg_cellplan_ptap(tg_cellplan_t pl, tg_csr_t a, const int32_t *zer
   P2.t0 = P2.t1 = P2.t2 = 1;
   const int64_t nrows = pl->ncols;
   tg_gw_plan *plan = &pl->gw;
-  if (plan->k_nnz >= 0) {
+  // values of K by places (k_cell_merge) into an allocated k with its row pointer and columns set
+  auto merge_by_places = [&](tg_csr_s *kk) -> int {
+    const unsigned grid = (unsigned)std::min<int64_t>(tg_cdiv(nrows, 4), (int64_t)g_tg.num_cu * 32);
+#define CELL_MERGE(LGV)                                                                                                         \
+  hipLaunchKernelGGL((k_cell_merge<LGV>), dim3(std::max(1u, grid)), dim3(256), 0, g_tg.stream, pl->inc->rowptr, pl->inc->col, eval, \
+                     pl->slot, pl->nf, pl->nfmax, nrows, kk->rowptr, kk->col, mask, diag, kk->val)
+    if (pl->nfmax <= 16) CELL_MERGE(4);
+    else if (pl->nfmax <= 32) CELL_MERGE(5);
+    else CELL_MERGE(6);
+#undef CELL_MERGE
+    if (hipGetLastError() != hipSuccess) {
+      tg_set_error("cell-block PtAP: the merge kernel failed to launch");
+      return 1;
+    }
+    return 0;
+  };
+  if (plan->k_nnz >= 0 && pl->slot && pl->k_col && !getenv("TIGAR_CELL_MERGE_HASH")) {
+    // ---- pattern and places known: no look-up at all
+    rc = tg_csr_alloc(nrows, pl->ncols, plan->k_nnz, &k);
+    if (!rc) {
+      hipMemcpyAsync(k->rowptr, plan->k_rowptr, (size_t)(nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream);
+      hipMemcpyAsync(k->col, pl->k_col, (size_t)plan->k_nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, g_tg.stream);
+      rc = merge_by_places(k);
+      if (!rc && hipStreamSynchronize(g_tg.stream) != hipSuccess) {
+        tg_set_error("cell-block PtAP: merge by places failed to run");
+        rc = 1;
+      }
+    }
+  } else if (plan->k_nnz >= 0) {
     rc = tg_csr_alloc(nrows, pl->ncols, plan->k_nnz, &k);
     if (!rc) {
       hipMemcpyAsync(k->rowptr, plan->k_rowptr, (size_t)(nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream);
@@ -1206,6 +1306,32 @@ extern "C" int tg_cellplan_ptap(tg_cellplan_t pl, tg_csr_t a, const int32_t *zer
         plan->k_rowptr = cnt;
         cnt = nullptr;
         plan->k_nnz = nnz;
+        // the places of the element entries in their rows of K, for all later products -- and for THIS one: its values
+        // are formed again by places, so that every product on the plan adds in the same order (bit for bit the same K)
+        if (plan->max_k <= 255 && nnz < 0x7fffffffll * 4 && !getenv("TIGAR_CELL_MERGE_HASH")) {
+          tg_dfree(pl->k_col);
+          tg_dfree(pl->slot);
+          pl->k_col = nullptr;
+          pl->slot = nullptr;
+          int *bad = status + 3;
+          int hbad2 = 0;
+          if (!tg_dmalloc(&pl->k_col, nnz + TG_CSR_PAD) && !tg_dmalloc(&pl->slot, nrowsE * pl->nfmax + 16)) {
+            hipMemcpyAsync(pl->k_col, k->col, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, g_tg.stream);
+            hipMemsetAsync(bad, 0, sizeof(int), g_tg.stream);
+            hipLaunchKernelGGL(k_cell_slots, dim3((unsigned)std::min<int64_t>(tg_cdiv(nrowsE * pl->nfmax, 256), (int64_t)g_tg.num_cu * 32)),
+                               dim3(256), 0, g_tg.stream, pl->flmix, pl->nf, pl->ncell, pl->nfmax, k->rowptr, k->col, pl->slot, bad);
+            hipMemcpyAsync(&hbad2, bad, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
+            if (hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) hbad2 = 1;
+          } else
+            hbad2 = 1;
+          if (hbad2) {                       // (a row of more than 255 entries, or no memory: the look-up merge stays)
+            tg_dfree(pl->k_col);
+            tg_dfree(pl->slot);
+            pl->k_col = nullptr;
+            pl->slot = nullptr;
+          } else
+            rc = merge_by_places(k);
+        }
       }
     }
   }
