@@ -230,6 +230,20 @@ int tg_cellplan_create(int64_t ncell, int b, int nfmax, int64_t ncols, const dou
                        const int32_t *nf_host, tg_csr_t incidence, int max_k, double mean_k, tg_cellplan_t *out);
 int tg_cellplan_ptap(tg_cellplan_t plan, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out);
 int tg_cellplan_destroy(tg_cellplan_t plan);
+
+/* K = R^T K_u R for a 0/1 matrix R with ONE entry per row, MatZeroRowsColumns (tIGAr/common.py:1196-1204) fused, on a PLAN:
+ * after the tensor line walks ran on the unwrapped space of a patch with periodic directions (tIGAr/BSplines.py:204-212,
+ * 310-319: `% ncp` in getNodes; R = which unwrapped function is which spline function) the rows of K_u that R identifies are
+ * added and the columns renamed.  tg_foldplan_create takes the pattern of K from a first product made with the general
+ * kernels (tg_ptap_numeric(K_u, R, R^T)) and stores the place of every entry of K_u in its row of K; tg_foldplan_apply then
+ * is one pass over K_u without any look-up (status 100: K_u has another pattern than the plan's -- checksum of its row
+ * pointer and columns -- or a row of K too long for the 16-bit places: use the general kernels).  ku: rows ku_row0 ... of
+ * K_u with global (unwrapped) columns; r: all rows of R; rt: the rows rt_row0 ... of R^T = the rows of K (borrowed by the
+ * plan: it must outlive it). */
+typedef struct tg_foldplan_s *tg_foldplan_t;
+int tg_foldplan_create(tg_csr_t ku, int64_t ku_row0, tg_csr_t r, tg_csr_t rt, int64_t rt_row0, tg_csr_t k, tg_foldplan_t *out);
+int tg_foldplan_apply(tg_foldplan_t plan, tg_csr_t ku, const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out);
+int tg_foldplan_destroy(tg_foldplan_t plan);
 /* extractMatrix when the extraction operator is a Kronecker product (tensor B-splines): one
  * contraction stage  out = P^T cur P  with P = (x)_k F_k, F_k = the 1-D matrix of direction k
  * (n x m CSR + its transpose, host pointers) or the identity (rowptr == NULL).  `cur` is an

@@ -128,6 +128,9 @@ PROTOTYPES = {
                                      C.POINTER(handle)]),
     "tg_cellplan_ptap": (C.c_int, [handle, handle, c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
     "tg_cellplan_destroy": (C.c_int, [handle]),
+    "tg_foldplan_create": (C.c_int, [handle, C.c_int64, handle, handle, C.c_int64, handle, C.POINTER(handle)]),
+    "tg_foldplan_apply": (C.c_int, [handle, handle, c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
+    "tg_foldplan_destroy": (C.c_int, [handle]),
     "tg_ptap_kron": (C.c_int, [handle, C.c_int64, C.c_int, c_i64p, C.POINTER(tg_kron1d_t), C.c_int64, C.c_int64,
                                c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
     "tg_ptap_kron_stage": (C.c_int, [handle, C.c_int64, C.c_int, c_i64p, C.POINTER(tg_kron1d_t), C.c_int64, C.c_int64,

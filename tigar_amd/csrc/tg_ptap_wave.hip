@@ -1344,3 +1344,206 @@ extern "C" int tg_cellplan_ptap(tg_cellplan_t pl, tg_csr_t a, const int32_t *zer
   *k_out = k;
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fold by places (round 4): K = R^T K_u R for a 0/1 matrix R with ONE entry per row -- the identification of the wrapped
+// functions of a periodic patch after the tensor line walks ran on the unwrapped space (tigar_amd/kronptap.py:
+// KronExtraction.unwrapped / fold; tIGAr/BSplines.py:204-212, 310-319: `% ncp` in getNodes).  The first product on a pattern
+// goes through the general kernels (R as the extraction operator) and gives the pattern of K; the plan then stores for every
+// entry of K_u its PLACE in the row of K it is added to (16 bits), and every later product -- the pattern of K_u is the
+// closed-form tensor pattern, the same at every call -- is one wave per row of K adding its source rows into LDS accumulators
+// at the stored places (distinct within a source row: plain read-modify-write; the source rows one after the other): no
+// look-up, one pass over K_u, a fixed order of additions.
+struct tg_foldplan_s {
+  int64_t u_nrows = 0, u_ncols = 0, u_nnz = 0, u_row0 = 0;
+  unsigned long long u_sum = 0;        // checksum of K_u's pattern
+  int64_t nrows = 0, ncols = 0, nnz = 0, rt_row0 = 0;
+  int max_k = 0;
+  int64_t *k_rowptr = nullptr;
+  int32_t *k_col = nullptr;
+  uint16_t *place = nullptr;           // [u_nnz]
+  tg_csr_s *rt = nullptr;              // (borrowed) rows of R^T = rows of K: the K_u rows that are added
+};
+
+__global__ void __launch_bounds__(256) k_fold_checksum(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nrows,
+                                                       int64_t nnz, unsigned long long *__restrict__ out) {
+  unsigned long long s = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride)
+    s += (unsigned long long)(unsigned)col[e] * (unsigned long long)(2 * e + 1);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nrows; i += stride)
+    s += (unsigned long long)rowptr[i] * 0x9E3779B97F4A7C15ull + (unsigned long long)i;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+// place of every entry of the K_u rows named by R^T: one wave per row of K, its source rows in turn
+__global__ void __launch_bounds__(256)
+    k_fold_places(const int64_t *__restrict__ trowptr, const int32_t *__restrict__ tcol, int64_t nrows, int64_t u_row0,
+                  const int64_t *__restrict__ urowptr, const int32_t *__restrict__ ucol, const int32_t *__restrict__ map,
+                  const int64_t *__restrict__ krowptr, const int32_t *__restrict__ kcol, uint16_t *__restrict__ place, int *__restrict__ bad) {
+  // (two entries of ONE source row with the same place -- columns g and g + n of an unwrapped row that are both stored, which
+  //  the tensor pattern of a patch with at least 2p+1 elements per periodic direction never has -- would make the plain
+  //  read-modify-write of k_fold_apply lose an addend: found here with a bitmap of the row of K, no plan then)
+  __shared__ unsigned seen_all[4][2048];
+  const int lane = threadIdx.x & 63;
+  unsigned *seen = seen_all[threadIdx.x >> 6];
+  const int64_t wstride = (int64_t)gridDim.x * 4;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < nrows; i += wstride) {
+    const int64_t k0 = krowptr[i], k1 = krowptr[i + 1];
+    const int words = (int)((k1 - k0 + 31) >> 5);
+    for (int64_t x = trowptr[i]; x < trowptr[i + 1]; x++) {
+      const int64_t g = (int64_t)tcol[x] - u_row0;
+      for (int w = lane; w < words; w += 64) seen[w] = 0u;
+      for (int64_t e = urowptr[g] + lane; e < urowptr[g + 1]; e += 64) {
+        const int32_t j = map[ucol[e]];
+        int64_t lo = k0, hi = k1;
+        while (lo < hi) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (kcol[mid] < j) lo = mid + 1; else hi = mid;
+        }
+        if (lo < k1 && kcol[lo] == j && lo - k0 < 65535) {
+          const unsigned pos = (unsigned)(lo - k0);
+          place[e] = (uint16_t)pos;
+          if (atomicOr(&seen[pos >> 5], 1u << (pos & 31)) & (1u << (pos & 31))) atomicOr(bad, 1);
+        } else {
+          place[e] = 0xffff;
+          atomicOr(bad, 1);
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_fold_apply(const int64_t *__restrict__ trowptr, const int32_t *__restrict__ tcol, int64_t nrows, int64_t u_row0, int64_t row0,
+                 const int64_t *__restrict__ urowptr, const double *__restrict__ uval, const uint16_t *__restrict__ place,
+                 const int64_t *__restrict__ krowptr, const int32_t *__restrict__ kcol, int max_k, const uint8_t *__restrict__ mask,
+                 double diag, double *__restrict__ kval) {
+  extern __shared__ double fold_acc[];
+  const int lane = threadIdx.x & 63;
+  double *acc = fold_acc + (size_t)(threadIdx.x >> 6) * max_k;
+  const int64_t wstride = (int64_t)gridDim.x * 4;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < nrows; i += wstride) {
+    const int64_t k0 = krowptr[i];
+    const int n = (int)(krowptr[i + 1] - k0);
+    for (int e = lane; e < n; e += 64) acc[e] = 0.0;
+    for (int64_t x = trowptr[i]; x < trowptr[i + 1]; x++) {
+      const int64_t g = (int64_t)tcol[x] - u_row0;
+      for (int64_t e = urowptr[g] + lane; e < urowptr[g + 1]; e += 64) acc[place[e]] += uval[e];
+    }
+    const int64_t R = row0 + i;
+    const bool mrow = mask && mask[R];
+    for (int e = lane; e < n; e += 64) {
+      double v = acc[e];
+      if (mask) {
+        const int32_t c = kcol[k0 + e];
+        if (mrow || mask[c]) v = (mrow && c == R) ? diag : 0.0;
+      }
+      kval[k0 + e] = v;
+    }
+  }
+}
+
+static int fold_checksum(tg_csr_s *ku, unsigned long long *out) {
+  unsigned long long *d = (unsigned long long *)(g_tg.scratch + 64);
+  TG_CHECK_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), g_tg.stream));
+  hipLaunchKernelGGL(k_fold_checksum, dim3((unsigned)std::min<int64_t>(tg_cdiv(std::max<int64_t>(ku->nnz, 1), 256), (int64_t)g_tg.num_cu * 32)),
+                     dim3(256), 0, g_tg.stream, ku->rowptr, ku->col, ku->nrows, ku->nnz, d);
+  TG_LAUNCH_CHECK();
+  TG_CHECK_HIP(hipMemcpyAsync(out, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  return 0;
+}
+
+extern "C" int tg_foldplan_destroy(tg_foldplan_t pl) {
+  if (!pl) return 0;
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  tg_dfree(pl->k_rowptr);
+  tg_dfree(pl->k_col);
+  tg_dfree(pl->place);
+  delete pl;
+  return 0;
+}
+
+// k: the product R^T K_u R as the general kernels gave it (its PATTERN is taken); returns 100 when a row of K holds 65 535
+// entries or more (no plan: keep using the general kernels)
+extern "C" int tg_foldplan_create(tg_csr_t ku, int64_t ku_row0, tg_csr_t r, tg_csr_t rt, int64_t rt_row0, tg_csr_t k, tg_foldplan_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(ku && r && rt && k && out, "null argument to tg_foldplan_create");
+  TG_REQUIRE(r->nnz == r->nrows && r->nrows == ku->ncols && rt->ncols == r->nrows && k->nrows == rt->nrows && k->ncols == r->ncols,
+             "tg_foldplan_create: operands do not fit");
+  TG_REQUIRE_CANONICAL(ku);
+  TG_REQUIRE_CANONICAL(k);
+  tg_foldplan_s *pl = new tg_foldplan_s();
+  pl->u_nrows = ku->nrows;
+  pl->u_ncols = ku->ncols;
+  pl->u_nnz = ku->nnz;
+  pl->u_row0 = ku_row0;
+  pl->nrows = k->nrows;
+  pl->ncols = k->ncols;
+  pl->nnz = k->nnz;
+  pl->rt_row0 = rt_row0;
+  pl->rt = rt;
+  int rc = tg_spmv_plan(k);
+  pl->max_k = std::max(1, k->max_row_nnz);
+  if (!rc && (pl->max_k >= 65535 || 4 * (size_t)pl->max_k * sizeof(double) > 160 * 1024)) rc = 100;
+  if (!rc) rc = tg_dmalloc(&pl->k_rowptr, k->nrows + 1) || tg_dmalloc(&pl->k_col, k->nnz + TG_CSR_PAD) || tg_dmalloc(&pl->place, ku->nnz + 8);
+  if (!rc) rc = fold_checksum(ku, &pl->u_sum);
+  if (!rc) {
+    hipMemcpyAsync(pl->k_rowptr, k->rowptr, (size_t)(k->nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream);
+    hipMemcpyAsync(pl->k_col, k->col, (size_t)k->nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, g_tg.stream);
+    int *bad = (int *)g_tg.scratch;
+    hipMemsetAsync(bad, 0, sizeof(int), g_tg.stream);
+    hipLaunchKernelGGL(k_fold_places, dim3((unsigned)std::min<int64_t>(tg_cdiv(std::max<int64_t>(k->nrows, 1), 4), (int64_t)g_tg.num_cu * 32)),
+                       dim3(256), 0, g_tg.stream, rt->rowptr, rt->col, k->nrows, ku_row0, ku->rowptr, ku->col, r->col, pl->k_rowptr, pl->k_col,
+                       pl->place, bad);
+    int hbad = 0;
+    hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream);
+    if (hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+      tg_set_error("tg_foldplan_create: kernels failed");
+      rc = 1;
+    } else if (hbad)
+      rc = 100;                              // an entry of K_u without a place in K: not the product's pattern
+  }
+  if (rc) {
+    tg_foldplan_destroy(pl);
+    return rc;
+  }
+  *out = pl;
+  return 0;
+}
+
+// K = R^T K_u R on the plan's patterns, MatZeroRowsColumns fused; 100 = K_u has another pattern than the plan's
+extern "C" int tg_foldplan_apply(tg_foldplan_t pl, tg_csr_t ku, const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(pl && ku && k_out, "null argument to tg_foldplan_apply");
+  if (ku->nrows != pl->u_nrows || ku->ncols != pl->u_ncols || ku->nnz != pl->u_nnz || ku->rowcnt) return 100;
+  unsigned long long sum = 0;
+  TG_TRY(fold_checksum(ku, &sum));
+  if (sum != pl->u_sum) return 100;
+  uint8_t *mask = nullptr;
+  if (nzero > 0) TG_TRY(tg_build_dof_mask(zero_dofs, nzero, pl->ncols, &mask));
+  tg_csr_s *k = nullptr;
+  int rc = tg_csr_alloc(pl->nrows, pl->ncols, pl->nnz, &k);
+  if (!rc) {
+    hipMemcpyAsync(k->rowptr, pl->k_rowptr, (size_t)(pl->nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream);
+    hipMemcpyAsync(k->col, pl->k_col, (size_t)pl->nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, g_tg.stream);
+    const size_t lds = 4 * (size_t)pl->max_k * sizeof(double);
+    hipFuncSetAttribute((const void *)k_fold_apply, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(k_fold_apply, dim3((unsigned)std::min<int64_t>(tg_cdiv(std::max<int64_t>(pl->nrows, 1), 4), (int64_t)g_tg.num_cu * 64)),
+                       dim3(256), lds, g_tg.stream, pl->rt->rowptr, pl->rt->col, pl->nrows, pl->u_row0, pl->rt_row0, ku->rowptr, ku->val,
+                       pl->place, k->rowptr, k->col, pl->max_k, mask, diag, k->val);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(g_tg.stream) != hipSuccess) {
+      tg_set_error("tg_foldplan_apply: the kernel failed");
+      rc = 1;
+    }
+  }
+  tg_dfree(mask);
+  if (rc) {
+    if (k) tg_csr_destroy(k);
+    return rc;
+  }
+  *k_out = k;
+  return 0;
+}

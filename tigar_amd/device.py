@@ -506,6 +506,41 @@ def ptap_numeric(plan, A, M, MT, zero_dofs=None, diag=1.0):
     return DeviceCSR(h)
 
 
+class FoldPlan(object):
+    """K = R^T K_u R on stored places (``tg_foldplan_*``): ``create`` from a first product made with the general kernels,
+    ``apply`` for every later K_u with the same pattern (None: another pattern -- use the general kernels)"""
+
+    def __init__(self, h, keep):
+        self._h, self._keep = h, keep
+
+    @staticmethod
+    def create(K_u, R, RT, ku_row0, rt_row0, K):
+        h = handle()
+        rc = _lib.lib().tg_foldplan_create(K_u._h, int(ku_row0), R._h, RT._h, int(rt_row0), K._h, C.byref(h))
+        if rc == 100:
+            return None
+        check(rc, "tg_foldplan_create")
+        return FoldPlan(h, (R, RT))
+
+    def apply(self, K_u, zero_dofs=None, diag=1.0):
+        zd = _i32(zero_dofs) if zero_dofs is not None and len(zero_dofs) else None
+        out = handle()
+        rc = _lib.lib().tg_foldplan_apply(self._h, K_u._h, _p(zd, c_i32p) if zd is not None else None,
+                                          zd.size if zd is not None else 0, float(diag), C.byref(out))
+        if rc == 100:
+            return None
+        check(rc, "tg_foldplan_apply")
+        return DeviceCSR(out)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().tg_foldplan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 def ptap_kron(cur, cur_row0, dims_in, factors, out_row0, out_row1, zero_dofs=None, diag=1.0, intermediate=False,
               append_to=None):
     """One Kronecker contraction stage out = P^T cur P (dense-box kernel).  ``intermediate``: the

@@ -176,10 +176,30 @@ class KronExtraction(object):
         RT = rt_cache[key]
         if K_u.is_loose():
             K_u = K_u.compact()
-        # (measured, 96^3 p=3 periodic in all directions: 36 ms of the 45 ms product -- a row of K gathers ONE row of K_u almost
-        #  everywhere, so every key is new to the row's table; the same stage on the wave kernels' cuckoo tables took as long)
+        # The first product on a pattern goes through the general kernels with R as the operator (96^3 p=3 periodic in all
+        # directions: 36 ms of a 45 ms product -- a row of K gathers ONE row of K_u almost everywhere, so every key is new to
+        # the row's table); it gives the pattern of K, and a plan then keeps the PLACE of every entry of K_u in its row of K:
+        # all later products (K_u of the tensor walks has the same closed-form pattern every time) are one pass over K_u
+        # without look-up (tg_foldplan_*).  The values of the first product come from the plan as well: same order of additions.
+        plans = self.__dict__.setdefault("_fold_plans", {})
+        pkey = (key, nfields, K_u.shape, K_u.nnz)
+        fp = plans.get(pkey)
+        if fp is not None:
+            K = fp.apply(K_u, zero_dofs, diag)
+            if K is not None:
+                return K
         plan = _dev.ptap_symbolic(K_u, R, RT, a_row0, 0, mt_row0)
-        return _dev.ptap_numeric(plan, K_u, R, RT, zero_dofs, diag)
+        K = _dev.ptap_numeric(plan, K_u, R, RT, zero_dofs, diag)
+        if os.environ.get("TIGAR_FOLD_PLAN", "1") != "0" and K_u.nnz <= 1.5e9:
+            if len(plans) > 4:
+                plans.clear()
+            fp = _dev.FoldPlan.create(K_u, R, RT, a_row0, mt_row0, K)
+            plans[pkey] = fp
+            if fp is not None:
+                K2 = fp.apply(K_u, zero_dofs, diag)
+                if K2 is not None:
+                    return K2
+        return K
 
     def is_exact_for(self, M_nnz, eps):
         """True if generateM's filter dropped only exact zeros, i.e. M == kron(M_k) entrywise."""
