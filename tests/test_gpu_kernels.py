@@ -169,6 +169,31 @@ def test_spmv_stream_and_vector_modes(dev):
     assert np.all(y == 0)
 
 
+def test_spmv_of_empty_rows_does_not_read_recycled_memory(dev):
+    """a block of empty rows has no entry to clamp the streaming loads to: the kernels used to read entry n1 - 1 < n0 and to
+    gather x at the column found there -- harmless in fresh memory (zeros), a memory fault when the allocator recycled a
+    block full of other numbers (found when a full test run died in front of an empty matrix).  Here: the pool is dirtied
+    with blocks of the sizes the arrays of an empty matrix take, then empty matrices and matrices with long runs of empty
+    rows are multiplied."""
+    rng = np.random.default_rng(11)
+    junk = np.frombuffer(rng.integers(2 ** 30, 2 ** 31 - 1, size=2 * 4096, dtype=np.int32).tobytes(), dtype=np.float64)
+    for n in (20, 300, 5000):
+        for size in (132, 264, 265, 528, n + 1):
+            v = [dev.DeviceVector(data=junk[:size].copy()) for _ in range(6)]
+            del v
+        A = sp.csr_matrix((n, n))
+        y = dev.DeviceCSR.from_scipy(A).mult(dev.DeviceVector(data=np.ones(n))).get_local()
+        assert y.shape == (n,) and not y.any()
+        # empty rows in front of, between and behind stored ones
+        B = sp.lil_matrix((n, n))
+        B[n // 2, 3] = 2.0
+        B[n - 1, n - 1] = -1.5
+        B = B.tocsr()
+        x = rng.standard_normal(n)
+        yb = dev.DeviceCSR.from_scipy(B).mult(dev.DeviceVector(data=x)).get_local()
+        assert np.array_equal(yb, B @ x)
+
+
 def test_spmv_bit_reproducible(dev):
     s = O.BSpline([2] * 3, [O.uniform_knots(2, 0., 1., 10)] * 3)
     M = _extract(dev, s)

@@ -112,8 +112,12 @@ __global__ void __launch_bounds__(256)
   double dsum = 0.0;
   if (L < nblocks) {
     const int64_t r0 = rowblocks[L], r1 = rowblocks[L + 1];
-    if (r1 > r0) {
-      const int64_t n0 = rowptr[r0], n1 = rowptr[r1];
+    const int64_t n0 = r1 > r0 ? rowptr[r0] : 0, n1 = r1 > r0 ? rowptr[r1] : 0;
+    if (r1 > r0 && n1 <= n0) {
+      // a block of EMPTY rows (an empty matrix: one block): nothing to stream -- the clamped loads below would read entry
+      // n1 - 1 < n0, which for n0 = 0 lies in front of the arrays, and gather x at whatever column they find there
+      for (int64_t r = r0 + tid; r < r1; r += 256) y[r] = 0.0;
+    } else if (r1 > r0) {
       const int64_t q0 = n0 & ~3ll;
       // All streaming loads of the block are issued before the first dependent gather, and all
       // gathers before the first LDS store: two memory latencies per block instead of two per
@@ -205,6 +209,10 @@ __global__ void __launch_bounds__(256)
   const int64_t r0 = rowblocks[L], r1 = rowblocks[L + 1];
   if (r1 <= r0) return;
   const int64_t n0 = rowptr[r0], n1 = rowptr[r1];
+  if (n1 <= n0) {                                  // a block of empty rows: see k_spmv_stream
+    for (int64_t r = r0 + tid; r < r1; r += 256) y[r] = 0.0;
+    return;
+  }
   constexpr int SL = CAP / 256;
   double v[SL];
   int32_t c[SL];
