@@ -280,7 +280,21 @@ extern "C" int tg_pool_trim(void) {
   return 0;
 }
 
+// TIGAR_POOL_POISON=1 (debugging): every block handed out -- fresh or recycled -- is filled with 0x7f bytes first (column
+// indices of 2.1e9, doubles of 1.4e306), so that a kernel that reads what it has not written faults or shows NaN / Inf
+// instead of getting away with the zeros of fresh memory.
+static int tg_dmalloc_bytes_raw(void **p, size_t bytes);
 int tg_dmalloc_bytes(void **p, size_t bytes) {
+  static const int poison = getenv("TIGAR_POOL_POISON") ? atoi(getenv("TIGAR_POOL_POISON")) : 0;
+  const int rc = tg_dmalloc_bytes_raw(p, bytes);
+  if (!rc && poison && *p && g_tg.ready) {
+    auto it = g_pool_size.find(*p);
+    const size_t n = it != g_pool_size.end() ? it->second : bytes;
+    if (hipMemsetAsync(*p, 0x7f, n, g_tg.stream) != hipSuccess) (void)hipGetLastError();
+  }
+  return rc;
+}
+static int tg_dmalloc_bytes_raw(void **p, size_t bytes) {
   *p = nullptr;
   if (bytes == 0) bytes = 1;
   bytes = (bytes + 255) & ~(size_t)255;
