@@ -97,6 +97,16 @@ class BSpline1(object):
         retval /= float(self.p)
         return retval
 
+    def grevilleAll(self):
+        """``greville(i)`` for every control point: the same additions in the same order (knots i+1 ... i+p, then / p), each
+        knot looked up once instead of p times"""
+        n, p = self.getNcp(), self.p
+        kn = numpy.array([self.getKnot(j) for j in range(1, n + p)], dtype=numpy.float64)
+        g = numpy.zeros(n)
+        for q in range(p):
+            g = g + kn[q:q + n]
+        return g / float(p)
+
     def computeNcp(self):
         return len(self.knots) - int(self.multiplicities[0])
 
@@ -452,7 +462,7 @@ class ExplicitBSplineControlMesh(AbstractControlMesh):
         if direction < self.nvar:
             facs = [numpy.ones(n) for n in ncps]
             s = sp_.splines[direction]
-            facs[direction] = numpy.array([s.greville(i) for i in range(s.getNcp())])
+            facs[direction] = s.grevilleAll()
             return facs
         return [numpy.zeros(n) for n in ncps]
 
