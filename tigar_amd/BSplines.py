@@ -442,7 +442,7 @@ class ExplicitBSplineControlMesh(AbstractControlMesh):
         loop at tIGAr/common.py:373-375)."""
         sp_ = self.scalarSpline
         ncps = [s.getNcp() for s in sp_.splines]
-        grev = [numpy.array([s.greville(i) for i in range(s.getNcp())]) for s in sp_.splines]
+        grev = [s.grevilleAll() for s in sp_.splines]
         P = numpy.zeros((sp_.getNcp(), self.nsd + 1))
         idx = numpy.arange(sp_.getNcp())
         stride = 1
