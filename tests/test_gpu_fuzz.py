@@ -1,0 +1,53 @@
+"""Seeded random patches through generateM / extractMatrix / extractVector / solveLinearSystem against the oracle
+(`tools/fuzz_parity.py`: dimension, degrees per direction, element counts, periodic directions, repeated and non-uniform
+knots, several fields, boundary dofs, FE matrices on and off the element-coupling pattern), once per set of environment
+switches so that every family of kernels sees them (tIGAr/common.py:1516-1578, 1142-1204, 1236-1263)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py")] + args, env=e, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, r.stdout[-2000:]
+    return r.returncode, json.loads(lines[-1]), [l for l in lines[:-1]]
+
+
+@pytest.mark.parametrize("seed,env", [
+    (101, {}),
+    (102, {"TIGAR_POOL_POISON": "1"}),
+    (103, {"TIGAR_IMPLICIT_M": "1"}),
+    (104, {"TIGAR_PTAP_TENSOR": "0"}),
+    (105, {"TIGAR_PTAP_TENSOR": "0", "TIGAR_PTAP_FACTORED": "0"}),
+    (106, {"TIGAR_PTAP_TENSOR": "0", "TIGAR_PTAP_FACTORED": "0", "TIGAR_PTAP_WAVE": "1"}),
+    (107, {"TIGAR_KSP_PERSISTENT": "1"}),
+    (108, {"TIGAR_PTAP_UNWRAP": "0"}),
+    (109, {"TIGAR_EXTRACT_KRON": "0"}),
+])
+def test_random_patches_match_the_oracle(seed, env):
+    rc, summary, failures = _run(["--seed", str(seed), "--cases", "80"], env)
+    assert rc == 0 and summary["failed"] == 0, "\n".join(failures)[:4000]
+    if not env:
+        assert summary["cases_on_the_tensor_walks"] > 0
+
+
+def test_hand_added_couplings_that_end_inside_an_element_of_a_repeated_knot_direction():
+    """found by the random run: the line kernel of the sum-factorised stages stores a contracted line over the head of its
+    own line of the box, which needs (functions reachable from the box) <= (nodes of the box) per OUTPUT ROW; the host
+    compared the maxima only.  A coupling added by hand can end a box inside an element, and with repeated knots that
+    element brings more functions than the box has nodes of it: such rows are declined now (general kernels)."""
+    force = json.dumps({"matrix": "random_extra", "nfields": 1})
+    for first in (1, 185, 197, 291):
+        rc, summary, failures = _run(["--seed", "5", "--first", str(first), "--cases", "1", "--force", force], {})
+        assert rc == 0 and summary["failed"] == 0, "\n".join(failures)[:4000]

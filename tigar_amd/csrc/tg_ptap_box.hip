@@ -768,7 +768,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAMAX <
   ilo = __builtin_amdgcn_readfirstlane(ilo);
   ihi = __builtin_amdgcn_readfirstlane(ihi);
   const int D = ihi >= ilo ? ihi - ilo + 1 : 0;
-  if (D > DMAXT || Ba > BAMAX) {
+  // (D > Ba: the contracted line is stored over the head of its own line of the box, which then has to be at least as
+  // long.  The host compares the maxima only; a box that ends inside an element of a direction with repeated knots --
+  // a coupling added by hand reaches there -- sees more functions than it has nodes.  Declined: general kernels.)
+  if (D > DMAXT || Ba > BAMAX || D > Ba) {
     if (lane == 0) atomicMax(status, TG_BOX_TOOBIG);
     return;
   }

@@ -1,0 +1,258 @@
+"""Randomised differential run of the hot path against the oracle (developer tool; `tests/test_gpu_fuzz.py` runs a fixed
+seeded set of its cases in the GPU suite).
+
+Every case draws a patch (dimension, degrees, element counts, periodic directions, repeated / non-uniform knots, number of
+fields), boundary dofs, an FE matrix (Laplace + mass, a random matrix on the element-coupling pattern, the same with
+couplings added by hand) and a load vector, runs generateM / extractMatrix / extractVector / solveLinearSystem of the product
+(tIGAr/common.py:1516-1578, 1142-1204, 1236-1263) and compares with `oracle/tigar_oracle.py` on the same inputs:
+
+* M: pattern and values bit for bit (`generate_M_tensor`);
+* K = M^T A M with MatZeroRowsColumns: pattern equal (when A lies on the element-coupling pattern), values to 1e-12 of
+  the largest entry; a second call gives the same bits;
+* M^T b to 1e-12; the solution of K U = M^T b by the default solver and by Krylov solvers at rtol 1e-11 against a direct
+  solve of the oracle's system, prolonged: to 1e-7 of the largest nodal value.
+
+    python tools/fuzz_parity.py [--seed S] [--cases N] [--first I] [--max-rows R] [--case '<json>'] [-v]
+
+The paths a case takes depend on the environment (TIGAR_IMPLICIT_M, TIGAR_PTAP_TENSOR, TIGAR_PTAP_FACTORED,
+TIGAR_PTAP_WAVE, TIGAR_PTAP_UNWRAP, TIGAR_KSP_PERSISTENT, TIGAR_POOL_POISON ...): run the tool once per setting.  Exit
+status 1 and one JSON line per failing case (`--case` reruns it)."""
+import argparse
+import json
+import os
+import sys
+import traceback
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import tigar_oracle as O  # noqa: E402
+
+
+def draw_case(rng, max_rows):
+    while True:
+        d = int(rng.choice([1, 2, 2, 3, 3]))
+        pmax = 4 if d < 3 else 3
+        p0 = int(rng.integers(1, pmax + 1))
+        equal = rng.random() < 0.8
+        ps = [p0 if equal else int(rng.integers(1, pmax + 1)) for _ in range(d)]
+        nmax = int({1: 40, 2: 14, 3: 7}[d] * max(1.0, max_rows / 40000.0) ** (1.0 / d))
+        kinds, nels, drops = [], [], []
+        for k in range(d):
+            kind = str(rng.choice(["uniform", "uniform", "periodic", "drop", "nonuniform"]))
+            nel = int(rng.integers(1, nmax + 1))
+            drop = 0
+            if kind == "periodic":
+                nel = max(nel, ps[k] + 1)
+            if kind == "drop":
+                if ps[k] == 1:
+                    kind = "uniform"
+                else:
+                    drop = int(rng.integers(1, ps[k]))
+            kinds.append(kind), nels.append(nel), drops.append(drop)
+        deg = max(ps)
+        rows = int(np.prod([deg * n + 1 for n in nels]))
+        nfields = int(rng.choice([1, 1, 1, 2, 3]))
+        if rows * nfields <= max_rows:
+            break
+    return {"d": d, "ps": ps, "kinds": kinds, "nels": nels, "drops": drops, "nfields": nfields,
+            "knot_seed": int(rng.integers(1 << 30)), "bc": str(rng.choice(["sides", "sides2", "some", "none"])),
+            "diag": float(rng.choice([1.0, 1.5, 1e3])), "matrix": str(rng.choice(["laplace_mass", "random", "random_extra"])),
+            "val_seed": int(rng.integers(1 << 30)), "apply_bcs": bool(rng.random() < 0.85)}
+
+
+def knot_vectors(case, uniform_knots):
+    kvs = []
+    rng = np.random.default_rng(case["knot_seed"])
+    for k in range(case["d"]):
+        p, nel, kind = case["ps"][k], case["nels"][k], case["kinds"][k]
+        if kind == "nonuniform":
+            # open knot vector on random break points with random interior multiplicities 1..p
+            br = np.concatenate([[0.0], np.sort(rng.uniform(0.05, 0.95, nel - 1)), [1.0]])
+            if nel > 1 and np.min(np.diff(br)) < 1e-3:
+                br = np.linspace(0.0, 1.0, nel + 1) ** 1.3
+            kv = [0.0] * (p + 1)
+            for x in br[1:-1]:
+                kv += [float(x)] * int(rng.integers(1, p + 1) if rng.random() < 0.3 else 1)
+            kv += [1.0] * (p + 1)
+        else:
+            kv = list(uniform_knots(p, 0.0, 1.0, nel, kind == "periodic", case["drops"][k]))
+        kvs.append(kv)
+    return kvs
+
+
+def run_case(case, verbose=False):
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, forms as F, device as dev
+    d, ps, nf = case["d"], case["ps"], case["nfields"]
+    kvs = knot_vectors(case, B.uniformKnots)
+    kvo = knot_vectors(case, O.uniform_knots)
+    assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(kvs, kvo)), "uniformKnots differs from the oracle's"
+    gen = t.EqualOrderSpline(nf, B.ExplicitBSplineControlMesh(ps, kvs))
+    so = O.BSpline(ps, kvo)
+    ncp1 = so.getNcp()
+    rng = np.random.default_rng(case["val_seed"])
+    sp0 = gen.getScalarSpline(0)
+    if case["bc"] in ("sides", "sides2"):
+        for f in range(nf):
+            for k in range(d):
+                if case["kinds"][k] != "periodic":
+                    for side in (0, 1):
+                        nl = 2 if (case["bc"] == "sides2" and so.splines[k].getNcp() > 4) else 1
+                        gen.addZeroDofs(f, sp0.getSideDofs(k, side, nLayers=nl))
+    elif case["bc"] == "some":
+        for f in range(nf):
+            gen.addZeroDofs(f, [int(i) for i in rng.integers(0, ncp1, size=3)])
+    spline = t.ExtractedSpline(gen, 2 * max(ps))
+    # ---- M
+    Mo = O.generate_M_tensor(so, nfields=nf)
+    M = gen.M.to_scipy() if hasattr(gen.M, "to_scipy") else None
+    if M is not None:
+        M.sort_indices()
+        assert M.shape == Mo.shape, "shape of M %s != %s" % (M.shape, Mo.shape)
+        assert np.array_equal(M.indptr, Mo.indptr) and np.array_equal(M.indices, Mo.indices), "pattern of M"
+        assert np.array_equal(M.data, Mo.data), "values of M not bit-exact: %g" % abs(M - Mo).max()
+    # ---- FE matrix on V (all field blocks) and load vector
+    V1 = spline.V if nf == 1 else t.ExtractedSpline(t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh(ps, kvs)), 2 * max(ps)).V
+    A1 = (F.LaplaceForm().assemble_matrix(V1).to_scipy() + 0.7 * F.MassForm().assemble_matrix(V1).to_scipy()).tocsr()
+    nfe1 = Mo.shape[0] // nf
+    assert A1.shape[0] == nfe1
+    if nf > 1:
+        A1 = sp.block_diag([A1] * nf, format="csr")
+    on_pattern = True
+    if case["matrix"] == "laplace_mass":
+        A = A1
+    else:
+        S1 = A1[:nfe1, :nfe1].tocsr()
+        S1.data[:] = 1.0
+        blocks = [[None] * nf for _ in range(nf)]
+        for f in range(nf):
+            for g in range(nf):
+                Bfg = S1.copy()
+                Bfg.data = rng.standard_normal(S1.nnz)
+                blocks[f][g] = Bfg
+        A = sp.bmat(blocks, format="csr")
+        # diagonally dominant, so that every solver applies
+        A = (A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + 1.0)).tocsr()
+        if case["matrix"] == "random_extra":
+            n = A.shape[0]
+            extra = sp.csr_matrix((rng.standard_normal(4), (rng.integers(0, n, 4), rng.integers(0, n, 4))), shape=A.shape)
+            A = (A + extra).tocsr()
+            on_pattern = False
+    A.sort_indices()
+    b = rng.standard_normal(A.shape[0])
+    zd = list(spline.zeroDofs)
+    bcs = case["apply_bcs"]
+    # ---- K
+    Ko = O.extract_matrix(Mo, A, zd, applyBCs=bcs, diag=case["diag"])
+    # numbering of the product's IGA vectors and rows of K: the reference's, except several fields on an implicit /
+    # distributed operator (plane by plane across the fields: ExtractedSpline.localDofIndices)
+    idx = np.asarray(spline.localDofIndices(), dtype=np.int64)
+    renumbered = not np.array_equal(idx, np.arange(Ko.shape[0]))
+    if renumbered:
+        assert np.array_equal(np.sort(idx), np.arange(Ko.shape[0])), "localDofIndices is not a permutation"
+        Ko = Ko.tocsr()[idx][:, idx].tocsr()
+    Ko.sort_indices()
+    dev.prof_reset()
+    Kd = spline.extractMatrix(A, applyBCs=bcs, diag=case["diag"])
+    K = Kd.to_scipy()
+    K.sort_indices()
+    walks = int(dev.prof_get(5)[1])
+    assert K.shape == Ko.shape, "shape of K"
+    scale = abs(Ko).max()
+    err = abs(K - Ko).max() / scale
+    assert err <= 1e-12, "values of K: %g" % err
+    if on_pattern:
+        assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices), \
+            "pattern of K (nnz %d, oracle %d)" % (K.nnz, Ko.nnz)
+    K2 = spline.extractMatrix(A, applyBCs=bcs, diag=case["diag"]).to_scipy()
+    K2.sort_indices()
+    assert np.array_equal(K2.indices, K.indices) and np.array_equal(K2.data.view(np.int64), K.data.view(np.int64)), \
+        "K is not bit-reproducible"
+    # ---- M^T b
+    yo = O.extract_vector(Mo, b, zd, applyBCs=bcs)[idx]
+    yd = spline.extractVector(b, applyBCs=bcs)
+    y = yd.get_local()
+    assert np.max(np.abs(y - yo)) <= 1e-12 * max(1.0, np.max(np.abs(yo))), "M^T b: %g" % np.max(np.abs(y - yo))
+    # ---- solves (the system is regular: A is positive definite or diagonally dominant; with the boundary rows replaced
+    # by diag when applyBCs, K restricted to the rest stays regular because M has full column rank)
+    solved = []
+    if bcs or case["bc"] == "none":
+        Uo = spla.spsolve(Ko.tocsc(), yo)
+        Uref = np.zeros_like(Uo)
+        Uref[idx] = Uo
+        uo = Mo @ Uref
+        ref = max(1e-300, np.max(np.abs(uo)))
+        sym = case["matrix"] == "laplace_mass"
+        solvers = [None, ("gmres", "jacobi"), ("bicgstab", "jacobi")] + ([("cg", "jacobi"), ("cg", "chebyshev")] if sym else [])
+        pick = [solvers[i] for i in sorted(set(rng.integers(0, len(solvers), size=2).tolist()))]
+        for s in pick:
+            if s is None:
+                spline.setSolverOptions(linearSolver=None)
+            else:
+                ks = t.PETScKrylovSolver(*s)
+                ks.parameters["relative_tolerance"] = 1e-11
+                ks.parameters["maximum_iterations"] = 20000
+                spline.setSolverOptions(linearSolver=ks)
+            u = t.Function(spline.V)
+            try:
+                spline.solveLinearSystem(Kd, yd, u)
+            except RuntimeError as e:
+                # a Krylov method that does not converge on this matrix says so (dolfin's behaviour); not a parity failure
+                # unless the direct solver is the one that gives up
+                if s is None:
+                    raise
+                solved.append("%s: %s" % ("/".join(s), str(e)[:60]))
+                continue
+            uh = u.vector().get_local()
+            e = np.max(np.abs(uh - uo)) / ref
+            cond_guard = 1e-7
+            assert e <= cond_guard, "solution by %s: %g" % (s, e)
+            solved.append("%s %.1e" % ("lu" if s is None else "/".join(s), e))
+    if verbose:
+        print("  rows %d dofs %d nnzK %d walks %d K err %.1e %s" % (A.shape[0], K.shape[0], K.nnz, walks, err, solved), flush=True)
+    return {"walks": walks}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cases", type=int, default=50)
+    ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--max-rows", type=int, default=40000)
+    ap.add_argument("--case", type=str, default=None)
+    ap.add_argument("--force", type=str, default=None, help='JSON object of case fields to overwrite, e.g. {"matrix": "random_extra"}')
+    ap.add_argument("-v", action="store_true")
+    a = ap.parse_args()
+    if a.case:
+        cases = [json.loads(a.case)]
+    else:
+        rng = np.random.default_rng(a.seed)
+        cases = [draw_case(rng, a.max_rows) for _ in range(a.first + a.cases)][a.first:]
+        if a.force:
+            cases = [dict(c, **json.loads(a.force)) for c in cases]
+    bad = 0
+    walks = 0
+    declined = 0
+    for i, c in enumerate(cases):
+        if a.v:
+            print("case %d: %s" % (a.first + i, json.dumps(c)), flush=True)
+        try:
+            walks += run_case(c, a.v)["walks"] > 0
+        except Exception as e:  # noqa: BLE001
+            if isinstance(e, ValueError) and "open knot vector in the slab direction" in str(e):
+                declined += 1        # documented limit: streamed / distributed with a periodic LAST direction
+                continue
+            bad += 1
+            print(json.dumps({"failed": a.first + i, "error": "%s: %s" % (type(e).__name__, str(e)[:300]), "case": c}), flush=True)
+            if a.v:
+                traceback.print_exc()
+    print(json.dumps({"cases": len(cases), "failed": bad, "declined_periodic_slab_direction": declined,
+                      "cases_on_the_tensor_walks": walks, "seed": a.seed}))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
