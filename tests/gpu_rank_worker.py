@@ -23,13 +23,17 @@ def main():
     rank_r, world_r, kind = dcomm.info()
     periodic0 = os.environ.get("TIGAR_TEST_PERIODIC0") == "1"      # direction 0 periodic (the slab direction stays open)
     explicit = os.environ.get("TIGAR_TEST_EXPLICIT_A")             # "device" / "scipy": an assembled A instead of a form
-    kv = [B.uniformKnots(p, 0., 1., nel, periodic0 and k == 0) for k in range(d)]
+    # (optional) element counts per direction and the set of periodic directions (never the last one: the slab direction)
+    nels = [int(v) for v in os.environ["TIGAR_TEST_NELS"].split(",")] if os.environ.get("TIGAR_TEST_NELS") else [nel] * d
+    per = set(int(c) for c in os.environ.get("TIGAR_TEST_PERIODIC", "0" if periodic0 else ""))
+    kv = [B.uniformKnots(p, 0., 1., nels[k], k in per) for k in range(d)]
     gen = t.EqualOrderSpline(comm, 1, B.ExplicitBSplineControlMesh([p] * d, kv))
     assert getattr(gen.M, "is_implicit", False)          # several ranks: no rank holds all rows of M
     sp0 = gen.getScalarSpline(0)
-    for direction in range(1 if periodic0 else 0, d):
-        for side in (0, 1):
-            gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
+    for direction in range(d):
+        if direction not in per:
+            for side in (0, 1):
+                gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
     spline = t.ExtractedSpline(gen, 2 * p)
     from tigar_amd import device as dev
     dev.prof_reset()

@@ -18,15 +18,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _single(d, p, nel, method, periodic0=False, explicit=False):
+def _single(d, p, nel, method, periodic0=False, explicit=False, nels=None, periodic=None):
     import tigar_amd as t
     from tigar_amd import BSplines as B, forms as F, common as tc
-    kv = [B.uniformKnots(p, 0., 1., nel, periodic0 and k == 0) for k in range(d)]
+    nels = [nel] * d if nels is None else list(nels)
+    per = set(periodic) if periodic is not None else ({0} if periodic0 else set())
+    kv = [B.uniformKnots(p, 0., 1., nels[k], k in per) for k in range(d)]
     gen = t.EqualOrderSpline(tc.selfcomm, 1, B.ExplicitBSplineControlMesh([p] * d, kv))
     sp0 = gen.getScalarSpline(0)
-    for direction in range(1 if periodic0 else 0, d):
-        for side in (0, 1):
-            gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
+    for direction in range(d):
+        if direction not in per:
+            for side in (0, 1):
+                gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
     spline = t.ExtractedSpline(gen, 2 * p, comm=tc.selfcomm)
     if explicit:
         A = F.LaplaceForm().assemble_matrix(spline.V).to_scipy().tolil()
@@ -57,7 +60,7 @@ def _run_ranks(tmp_path, world, kind, d, p, nel, method, port, env_more=None):
     return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
 
 
-def _compare(parts, ref, world, kind):
+def _compare(parts, ref, world, kind, its_slack=1):
     Ks, rhs, U, u, its, cp0, MTu = ref
     Ks = Ks.tocsr()
     dof_cover = np.zeros(Ks.shape[0], dtype=int)
@@ -73,11 +76,12 @@ def _compare(parts, ref, world, kind):
         assert np.max(np.abs(z["U"] - U[g0:g1])) <= 1e-8 * np.max(np.abs(U))
         assert np.max(np.abs(z["u"] - u[r0:r1])) <= 1e-8 * np.max(np.abs(u))
         assert np.max(np.abs(z["cp0"] - cp0[r0:r1])) <= 1e-14
-        assert abs(int(z["its"][0]) - its) <= 1          # same Krylov iteration count as the single-rank solve
+        assert abs(int(z["its"][0]) - its) <= its_slack  # same Krylov iteration count as the single-rank solve
         assert int(z["its"][1]) <= 2                     # restart from the solution: (almost) converged at once
         # the initial guess solveLinearSystem takes from u (M^T u, tIGAr/common.py:1250-1254): every contribution there,
         # also for the dofs next to a slab boundary (ghost rows of u from the z-neighbours)
-        assert np.max(np.abs(z["guess"] - MTu[g0:g1])) <= 1e-12 * np.max(np.abs(MTu))
+        # (M^T of the RANKS' u against M^T of the single-rank u: as close as the two solutions are)
+        assert np.max(np.abs(z["guess"] - MTu[g0:g1])) <= (1e-12 if its_slack == 1 else 1e-8) * np.max(np.abs(MTu))
         assert np.max(np.abs(z["U2"] - z["U"])) <= 1e-8 * np.max(np.abs(U))
         dof_cover[g0:g1] += 1
         fe_cover[r0:r1] += 1
@@ -158,6 +162,26 @@ def test_patch_periodic_across_the_slabs_with_several_ranks(tmp_path):
     _compare(parts, ref, world, "ipc")
     # every rank's rows of K came out of the tensor line walks (on the unwrapped space, then folded: kronptap.unwrapped)
     assert all(int(q["tensor_walks"][0]) > 0 for q in parts)
+
+
+@pytest.mark.parametrize("p,nels,periodic,world,method", [
+    (2, (5, 11, 13), (), 3, "cg"),                 # different element counts per direction
+    (3, (9, 4, 12), (0,), 2, "cg"),                # few elements across, periodic in x
+    (2, (6, 7, 9), (0, 1), 3, "gmres"),            # periodic in both directions of the planes
+    (3, (4, 5, 7), (1,), 2, "bicgstab"),           # slabs of 5 dof planes each
+    (1, (7, 6, 8), (), 3, "cg"),                   # trilinear
+])
+def test_unequal_directions_on_several_ranks(tmp_path, p, nels, periodic, world, method):
+    """element counts that differ per direction, periodic directions other than the slab direction in every combination,
+    thin slabs, p = 1: the rank-local rows of K, M^T b, the solution and the prolongation equal the single-rank run
+    (tIGAr/common.py:1194-1195, 1255-1261 on PETSc's row blocks)"""
+    d = 3
+    ref = _single(d, p, nels[0], method, nels=nels, periodic=periodic)
+    env = {"TIGAR_TEST_NELS": ",".join(str(n) for n in nels), "TIGAR_TEST_PERIODIC": "".join(str(k) for k in periodic)}
+    parts = _run_ranks(tmp_path, world, "ipc", d, p, nels[0], method, 36011 + 13 * (p * 10 + world + len(periodic)), env)
+    # (BiCGStab's recurrences amplify the last bits of the dot products, which several ranks sum in another order:
+    #  the iteration count may move by a few, the solution is held to the same 1e-8)
+    _compare(parts, ref, world, "ipc", its_slack=6 if method == "bicgstab" else 1)
 
 
 @pytest.mark.parametrize("case,world,kind", [("shell2d", 2, "ipc"), ("elasticity3d", 3, "ipc"), ("shell2d", 3, "host")])
