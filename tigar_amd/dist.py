@@ -343,7 +343,15 @@ class SlabHotPath(object):
                 #  what a row of K needs, is the faster one there -- 10.7 against 15.0 s at cfg3; one block: the library's rule)
                 old_pref = dev.ptap_prefer(2) if nslabs > 1 else None
                 try:
-                    plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], S["m_rows"][0], S["dofs"][0])
+                    try:
+                        plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], S["m_rows"][0], S["dofs"][0])
+                    except dev.TigarHipError as e:
+                        if "does not cover" not in str(e):
+                            raise
+                        # columns beyond the FE rows the slab's elements couple to (a coupling added by hand): all rows of M
+                        del M
+                        M = dev.extract_csr_tensor(sp1, axes, 0, self.ncp, self.eps, 0, self.n_fe)
+                        plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], 0, S["dofs"][0])
                 finally:
                     if old_pref is not None:
                         dev.ptap_prefer(old_pref)

@@ -171,6 +171,17 @@ def run_case(case, verbose=False):
     K2.sort_indices()
     assert np.array_equal(K2.indices, K.indices) and np.array_equal(K2.data.view(np.int64), K.data.view(np.int64)), \
         "K is not bit-reproducible"
+    # ---- the form-driven entry (assembleMatrix: the FE matrix may never be materialised -- Kronecker-sum forms fused into
+    # the first pass, row blocks requested sub-slab by sub-slab; tIGAr/common.py:1206-1220)
+    if nf == 1 and case["matrix"] == "laplace_mass":
+        Al = F.LaplaceForm().assemble_matrix(V1).to_scipy().tocsr()
+        Kfo = O.extract_matrix(Mo, Al, zd, applyBCs=bcs, diag=case["diag"])
+        Kfo.sort_indices()
+        Kf = spline.assembleMatrix(F.LaplaceForm(), applyBCs=bcs, diag=case["diag"]).to_scipy()
+        Kf.sort_indices()
+        assert np.array_equal(Kf.indptr, Kfo.indptr) and np.array_equal(Kf.indices, Kfo.indices), "pattern of K (assembleMatrix)"
+        ef = abs(Kf - Kfo).max() / abs(Kfo).max()
+        assert ef <= 1e-12, "values of K (assembleMatrix): %g" % ef
     # ---- M^T b
     yo = O.extract_vector(Mo, b, zd, applyBCs=bcs)[idx]
     yd = spline.extractVector(b, applyBCs=bcs)
