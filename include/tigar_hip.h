@@ -114,6 +114,10 @@ int tg_csr_transpose(tg_csr_t m, tg_csr_t *out);
 /* C = A + B on the union of the two patterns (MatAXPY, DIFFERENT_NONZERO_PATTERN [ext]); ascending columns. */
 int tg_csr_add(tg_csr_t a, tg_csr_t b, tg_csr_t *out);
 int tg_csr_block(tg_csr_t a, int64_t r0, int64_t r1, int64_t c0, int64_t c1, tg_csr_t *out);
+/* A copy of `a` (same shape) without the entries whose column c has keep[c] == 0 (host array, ncols bytes).  Used to split
+ * M^T A M by residue classes of the columns when a row of the product exceeds the per-row tables of the general kernels
+ * (3-D patches of degree >= 5; tIGAr/common.py:1194-1195 has no degree limit). */
+int tg_csr_select_columns(tg_csr_t a, const uint8_t *keep, tg_csr_t *out);
 int tg_csr_from_blocks(int nf, const tg_csr_t *blocks, tg_csr_t *out);
 /* out row r = row rows[r] of a (host index array; any selection or order, repetitions allowed), columns untouched */
 int tg_csr_gather_rows(tg_csr_t a, const int64_t *rows, int64_t n, tg_csr_t *out);

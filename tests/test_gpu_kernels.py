@@ -861,3 +861,48 @@ def test_factor_table_cache_and_staged_uploads(dev):
     xb = rng.standard_normal(n)
     yb = dev.tensor_apply_1d(dev.DeviceVector(data=xb), [n], 0, Fb)
     assert np.max(np.abs(yb.get_local() - Fb @ xb)) < 1e-12
+
+
+def test_products_with_rows_beyond_the_per_row_tables_are_split_by_columns():
+    """3-D patches of degree >= 5: a row of A M holds up to (3p+1)^3 = 4096 keys, beyond the per-row LDS tables of the general
+    kernels.  The reference's MatPtAP has no degree limit (tIGAr/common.py:1194-1195): such products run as a sum over
+    residue classes of M's columns (device.SplitPtAPPlan, tg_csr_select_columns).  Against the oracle's product."""
+    import scipy.sparse as sp
+    from tigar_amd import device as dev
+    rng = np.random.default_rng(3)
+    # the column selection by itself
+    X = sp.random(300, 500, density=0.05, random_state=rng, format="csr")
+    X.sort_indices()
+    keep = rng.random(500) < 0.4
+    Y = dev.DeviceCSR.from_scipy(X).select_columns(keep).to_scipy()
+    Yo = X @ sp.diags(keep.astype(float))
+    Yo.eliminate_zeros()
+    assert Y.shape == X.shape and abs(Y - Yo).max() == 0 and Y.nnz == Yo.nnz
+    # a degree-5 patch with non-uniform knots (no tensor plan: general stages) and couplings added by hand
+    p, nel = 5, [3, 4, 3]
+    kv = []
+    for n in nel:
+        br = np.linspace(0.0, 1.0, n + 1) ** 1.2
+        kv.append([0.0] * (p + 1) + [float(x) for x in br[1:-1]] + [1.0] * (p + 1))
+    s = O.BSpline([p] * 3, kv)
+    Mo = O.generate_M_tensor(s)
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, forms as F
+    gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p] * 3, kv))
+    gen.addZeroDofs(0, [0, 7, 11])
+    spline = t.ExtractedSpline(gen, 2 * p)
+    A = (F.LaplaceForm().assemble_matrix(spline.V).to_scipy() + F.MassForm().assemble_matrix(spline.V).to_scipy()).tolil()
+    A[3, A.shape[1] - 9] = 0.5
+    A[A.shape[0] - 2, 17] = -0.25
+    A = A.tocsr()
+    K = spline.extractMatrix(A, diag=2.0).to_scipy()
+    Ko = O.extract_matrix(Mo, A, list(spline.zeroDofs), diag=2.0)
+    assert K.shape == Ko.shape and abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+    # the one-shot general product on the stored operators (what a non-Kronecker M of this density takes)
+    Md, Ad = dev.DeviceCSR.from_scipy(Mo), dev.DeviceCSR.from_scipy(A)
+    MT = Md.transpose()
+    plan = dev.ptap_symbolic(Ad, Md, MT)
+    K1 = dev.ptap_numeric(plan, Ad, Md, MT, list(spline.zeroDofs), 2.0).to_scipy()
+    assert abs(K1 - Ko).max() <= 1e-12 * abs(Ko).max()
+    K1.sort_indices(), Ko.sort_indices()
+    assert np.array_equal(K1.indptr, Ko.indptr) and np.array_equal(K1.indices, Ko.indices)

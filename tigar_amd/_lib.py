@@ -90,6 +90,7 @@ PROTOTYPES = {
     "tg_csr_add": (C.c_int, [handle, handle, C.POINTER(handle)]),
     "tg_tensor_split": (C.c_int, [handle, handle, C.POINTER(handle), C.POINTER(handle)]),
     "tg_csr_block": (C.c_int, [handle, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(handle)]),
+    "tg_csr_select_columns": (C.c_int, [handle, C.POINTER(C.c_uint8), C.POINTER(handle)]),
     "tg_csr_from_blocks": (C.c_int, [C.c_int, C.POINTER(handle), C.POINTER(handle)]),
     "tg_csr_gather_rows": (C.c_int, [handle, c_i64p, C.c_int64, C.POINTER(handle)]),
     "tg_partition_mode": (C.c_int, [handle, c_i32p, C.c_int, c_i32p]),

@@ -618,6 +618,87 @@ extern "C" int tg_csr_block(tg_csr_t a, int64_t r0, int64_t r1, int64_t c0, int6
   return 0;
 }
 
+// ---- a copy without the columns whose mask byte is 0 (shape kept): the operand of a product split by columns
+__global__ void __launch_bounds__(256)
+    k_select_count(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const uint8_t *__restrict__ keep, int64_t n,
+                   int64_t *__restrict__ out_len) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n; r += nwaves) {
+    const int64_t a = rowptr[r], e = rowptr[r + 1];
+    int cnt = 0;
+    for (int64_t q = a + lane; q < e; q += 64) cnt += keep[col[q]] ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) out_len[r] = cnt;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_select_fill(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+                  const uint8_t *__restrict__ keep, const int64_t *__restrict__ orowptr, int64_t n, int32_t *__restrict__ ocol,
+                  double *__restrict__ oval) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n; r += nwaves) {
+    const int64_t a = rowptr[r], e = rowptr[r + 1];
+    int64_t o = orowptr[r];
+    for (int64_t q0 = a; q0 < e; q0 += 64) {          // (uniform trip count: the ballot sees every lane)
+      const int64_t q = q0 + lane;
+      const bool k = q < e && keep[col[q]] != 0;
+      const unsigned long long b = __ballot(k);
+      if (k) {
+        const int pos = __popcll(b & ((1ull << lane) - 1ull));
+        ocol[o + pos] = col[q];
+        oval[o + pos] = val[q];
+      }
+      o += __popcll(b);
+    }
+  }
+}
+
+extern "C" int tg_csr_select_columns(tg_csr_t a, const uint8_t *keep_host, tg_csr_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(a && keep_host && out, "bad arguments to tg_csr_select_columns");
+  TG_REQUIRE_CANONICAL(a);
+  const int64_t n = a->nrows;
+  int64_t *len = nullptr;
+  uint8_t *keep = nullptr;
+  int rc = tg_dmalloc(&len, n + 1) || tg_dmalloc(&keep, std::max<int64_t>(a->ncols, 1));
+  tg_csr_s *m = nullptr;
+  int64_t total = 0;
+  if (!rc && a->ncols > 0 &&
+      hipMemcpyAsync(keep, keep_host, (size_t)a->ncols, hipMemcpyHostToDevice, g_tg.stream) != hipSuccess)
+    rc = 1;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16));
+  if (!rc && n > 0) {
+    hipLaunchKernelGGL(k_select_count, dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, keep, n, len);
+    if (hipGetLastError() != hipSuccess) rc = 1;
+  }
+  if (!rc) rc = tg_exclusive_scan_i64(len, n, &total);
+  if (!rc) rc = tg_csr_alloc(n, a->ncols, total, &m);
+  if (!rc) {
+    if (hipMemcpyAsync(m->rowptr, len, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess)
+      rc = 1;
+    if (!rc && total > 0) {
+      hipLaunchKernelGGL(k_select_fill, dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val, keep, m->rowptr, n,
+                         m->col, m->val);
+      if (hipGetLastError() != hipSuccess) rc = 1;
+    }
+  }
+  if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
+  tg_dfree(len);
+  tg_dfree(keep);
+  if (rc) {
+    if (m) tg_csr_destroy(m);
+    tg_set_error("tg_csr_select_columns failed");
+    return 1;
+  }
+  *out = m;
+  return 0;
+}
+
 struct tg_merge_args {
   const int64_t *rowptr[16];     // [i * nf + j] (one block row at a time: nf entries used)
   const int32_t *col[16];

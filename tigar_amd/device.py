@@ -222,6 +222,16 @@ class DeviceCSR(object):
         check(_lib.lib().tg_csr_block(self._h, int(r0), int(r1), int(c0), int(c1), C.byref(h)), "tg_csr_block")
         return DeviceCSR(h)
 
+    def select_columns(self, keep):
+        """copy of the same shape without the entries of the columns whose ``keep`` flag is False (tg_csr_select_columns)"""
+        k = np.ascontiguousarray(np.asarray(keep) != 0, dtype=np.uint8)
+        if k.size != self.shape[1]:
+            raise ValueError("select_columns: %d flags for %d columns" % (k.size, self.shape[1]))
+        h = handle()
+        check(_lib.lib().tg_csr_select_columns(self._h, k.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(h)),
+              "tg_csr_select_columns")
+        return DeviceCSR(h)
+
     def gather_rows(self, rows):
         """new matrix whose row r is row ``rows[r]`` of this one (tg_csr_gather_rows)"""
         m = np.ascontiguousarray(rows, dtype=np.int64)
@@ -481,11 +491,92 @@ class PtAPPlan(object):
             pass
 
 
-def ptap_symbolic(A, M, MT, a_row0=0, m_row0=0, mt_row0=0):
+def _capacity_error(e):
+    """a row of the product (or of A M) exceeds the per-row LDS tables of the general kernels"""
+    msg = str(e)
+    return "too dense for the LDS tables" in msg or "LDS hash slots" in msg
+
+
+class SplitPtAPPlan(object):
+    """M^T A M as a sum of partial products over residue classes of columns:
+
+        K = sum_t sum_r  M^T A_t M_r      A_t = the columns c = t (mod nt) of A,  M_r = the columns c = r (mod nr) of M
+
+    (``tg_csr_select_columns``; the classes are disjoint, so the sums are unions).  A row of M^T A_t holds about 1/nt of the
+    keys of a row of M^T A, a row of a partial product about 1/nr of a row of K: rows beyond the per-row LDS tables of the
+    general kernels -- 3-D patches of degree >= 5, where a row of M^T A reaches (3p+1)^3 > 4096 FE nodes -- come back inside
+    them.  The reference's MatPtAP has no degree limit (tIGAr/common.py:1194-1195); this is the route such products take
+    here: nt x nr passes over the operands instead of an error.  The classes are kept, the selections of A are redone at
+    every numeric product (its values change between calls)."""
+
+    LADDER = ((4, 1), (1, 4), (16, 1), (4, 4), (64, 1), (16, 4), (64, 4), (256, 4), (64, 16), (256, 16), (1024, 16))
+
+    def __init__(self, A, M, MT, a_row0, m_row0, mt_row0):
+        self.rows = (int(a_row0), int(m_row0), int(mt_row0))
+        self._first_of = A
+        ca, cm = np.arange(A.shape[1]), np.arange(M.shape[1])
+        last = None
+        for nt, nr in self.LADDER:
+            try:
+                parts = []
+                Ms = [(M.select_columns((cm % nr) == r) if nr > 1 else M) for r in range(nr)]
+                for t_ in range(nt):
+                    mask = (ca % nt) == t_
+                    At = A.select_columns(mask) if nt > 1 else A
+                    if At.nnz == 0:
+                        continue
+                    for Mr in Ms:
+                        if Mr.nnz:
+                            parts.append((mask if nt > 1 else None, Mr, _ptap_symbolic_plain(At, Mr, MT, *self.rows)))
+                    del At
+                # (the symbolic pass looks at a sample of rows: the numeric product of every part is tried once here, so
+                #  that a plan that is handed out works)
+                self.parts, self.split = parts, (nt, nr)
+                self._first = self._numeric(A, MT)
+                return
+            except TigarHipError as e:
+                if not _capacity_error(e):
+                    raise
+                last = e
+        raise last
+
+    def _numeric(self, A, MT):
+        K, cur_mask, At = None, False, None
+        for mask, Mr, plan in self.parts:
+            if mask is not cur_mask:
+                At = A.select_columns(mask) if mask is not None else A
+                cur_mask = mask
+            Kr = _ptap_numeric_plain(plan, At, Mr, MT, None, 1.0)
+            K = Kr if K is None else K.add(Kr)
+            del Kr
+        return K
+
+    def numeric(self, A, MT, zero_dofs=None, diag=1.0):
+        K = self.__dict__.pop("_first", None)        # (the product formed while the plan was made, for the same A)
+        if K is None or self._first_of is not A:
+            K = self._numeric(A, MT)
+        self._first_of = None
+        if zero_dofs is not None and len(zero_dofs):
+            K.zero_rows_cols(zero_dofs, diag, self.rows[2])
+        return K
+
+
+def _ptap_symbolic_plain(A, M, MT, a_row0=0, m_row0=0, mt_row0=0):
     h = handle()
     check(_lib.lib().tg_ptap_symbolic(A._h, int(a_row0), M._h, int(m_row0), MT._h, int(mt_row0), C.byref(h)),
           "tg_ptap_symbolic")
-    return PtAPPlan(h)
+    plan = PtAPPlan(h)
+    plan._rows = (int(a_row0), int(m_row0), int(mt_row0))
+    return plan
+
+
+def ptap_symbolic(A, M, MT, a_row0=0, m_row0=0, mt_row0=0):
+    try:
+        return _ptap_symbolic_plain(A, M, MT, a_row0, m_row0, mt_row0)
+    except TigarHipError as e:
+        if not _capacity_error(e):
+            raise
+        return SplitPtAPPlan(A, M, MT, a_row0, m_row0, mt_row0)
 
 
 def ptap_prefer(kernels):
@@ -495,6 +586,18 @@ def ptap_prefer(kernels):
 
 
 def ptap_numeric(plan, A, M, MT, zero_dofs=None, diag=1.0):
+    if isinstance(plan, SplitPtAPPlan):
+        return plan.numeric(A, MT, zero_dofs, diag)
+    try:
+        return _ptap_numeric_plain(plan, A, M, MT, zero_dofs, diag)
+    except TigarHipError as e:
+        if not _capacity_error(e) or not hasattr(plan, "_rows"):
+            raise
+        # (the symbolic pass samples rows; a denser one shows up here)
+        return SplitPtAPPlan(A, M, MT, *plan._rows).numeric(A, MT, zero_dofs, diag)
+
+
+def _ptap_numeric_plain(plan, A, M, MT, zero_dofs=None, diag=1.0):
     h = handle()
     if zero_dofs is not None and len(zero_dofs):
         zd = _i32(zero_dofs)
