@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, env):
+def _run(args, env, tool="fuzz_parity.py"):
     e = dict(os.environ)
     e.update(env)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py")] + args, env=e, cwd=ROOT,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, env=e, cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert lines, r.stdout[-2000:]
@@ -51,3 +51,13 @@ def test_hand_added_couplings_that_end_inside_an_element_of_a_repeated_knot_dire
     for first in (1, 185, 197, 291):
         rc, summary, failures = _run(["--seed", "5", "--first", str(first), "--cases", "1", "--force", force], {})
         assert rc == 0 and summary["failed"] == 0, "\n".join(failures)[:4000]
+
+
+@pytest.mark.parametrize("seed,env", [(201, {}), (202, {"TIGAR_PTAP_WAVE": "1"}), (203, {"TIGAR_PTAP_ACCUM": "int"}),
+                                      (204, {"TIGAR_POOL_POISON": "1", "TIGAR_KSP_PERSISTENT": "1"})])
+def test_random_sparse_matrices_through_the_kernels(seed, env):
+    """`tools/fuzz_kernels.py`: matrices of any shape and row-length profile (empty, one row, empty rows, a few rows that fill
+    the matrix) through SpMV / M^T b / transpose / add / selections / the general PtAP (structural pattern, values,
+    MatZeroRowsColumns, the same bits twice) / the Krylov solvers, against scipy"""
+    rc, summary, failures = _run(["--seed", str(seed), "--cases", "25"], env, tool="fuzz_kernels.py")
+    assert rc == 0 and summary["failed"] == 0, "\n".join(failures)[:4000]

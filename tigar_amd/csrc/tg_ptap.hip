@@ -706,7 +706,10 @@ extern "C" int tg_ptap_numeric(tg_ptap_t plan, tg_csr_t a, tg_csr_t m, tg_csr_t 
     int ts1 = plan->ts1, ts2 = plan->ts2;
     int64_t capacity = (int64_t)(plan->mean_k * 1.05 * (double)plan->nrows) + plan->max_k + 1024;
     rc = tg_dmalloc(&cnt, plan->nrows + 1) || tg_dmalloc(&off, plan->nrows + 1) || tg_dmalloc(&cursor, 1);
-    for (int attempt = 0; attempt < 8 && !rc; attempt++) {
+    // (tables and capacity start from the symbolic pass's SAMPLE of rows; a matrix with a few rows far longer than the rest
+    //  needs several rounds: double at first, quadruple from the fourth round on)
+    const int max_attempts = 20;
+    for (int attempt = 0; attempt < max_attempts && !rc; attempt++) {
       rc = tg_dmalloc(&tcol, capacity + TG_CSR_PAD) || tg_dmalloc(&tval, capacity + TG_CSR_PAD);
       if (rc) break;
       P.ts1 = std::max(ts1, ts2);
@@ -739,9 +742,9 @@ extern "C" int tg_ptap_numeric(tg_ptap_t plan, tg_csr_t a, tg_csr_t m, tg_csr_t 
       tcol = nullptr;
       tval = nullptr;
       if (h == TG_PTAP_CAP) capacity = std::max<int64_t>((int64_t)used + 1024, capacity * 2);
-      if (h == TG_PTAP_OVF1) ts1 *= 2;
-      if (h == TG_PTAP_OVF2) ts2 *= 2;
-      if (attempt == 7) {
+      if (h == TG_PTAP_OVF1) ts1 *= attempt >= 3 ? 4 : 2;
+      if (h == TG_PTAP_OVF2) ts2 *= attempt >= 3 ? 4 : 2;
+      if (attempt == max_attempts - 1) {
         tg_set_error("PtAP numeric: could not size tables / output (status %d)", h);
         rc = 4;
       }

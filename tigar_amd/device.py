@@ -494,7 +494,7 @@ class PtAPPlan(object):
 def _capacity_error(e):
     """a row of the product (or of A M) exceeds the per-row LDS tables of the general kernels"""
     msg = str(e)
-    return "too dense for the LDS tables" in msg or "LDS hash slots" in msg
+    return "too dense for the LDS tables" in msg or "LDS hash slots" in msg or "could not size tables" in msg
 
 
 class SplitPtAPPlan(object):
