@@ -739,6 +739,14 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
         kx = self._kron_tables(basis, grid)
         if kx is None or not kx.products_stay_above(eps):
             return None
+        if self.comm.size == 1:
+            # the sub-slab engine behind an implicit M cuts the LAST direction into slabs and needs an open knot vector
+            # there (tigar_amd/dist.py: ZSlabLayout); a patch that is periodic in that direction keeps a stored M on one
+            # rank -- also when TIGAR_IMPLICIT_M=1 asks for the implicit one
+            s_last = kx.basis.splines[-1]
+            kn, pl = numpy.asarray(s_last.knots, dtype=float), int(s_last.p)
+            if not (numpy.all(kn[:pl + 1] == kn[0]) and numpy.all(kn[-(pl + 1):] == kn[-1])):
+                return None
         if env != "1" and self.comm.size == 1:
             free_b = _dev.mem_info()[0] + _dev.pool_stats()[0]      # idle blocks of the caching allocator count as free
             nf = self.getNFields() if several_fields else 1

@@ -345,6 +345,7 @@ class SlabHotPath(object):
                 try:
                     try:
                         plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], S["m_rows"][0], S["dofs"][0])
+                        kblk = dev.ptap_numeric(plan, A, M, MT, zero_dofs, diag)
                     except dev.TigarHipError as e:
                         if "does not cover" not in str(e):
                             raise
@@ -352,10 +353,10 @@ class SlabHotPath(object):
                         del M
                         M = dev.extract_csr_tensor(sp1, axes, 0, self.ncp, self.eps, 0, self.n_fe)
                         plan = dev.ptap_symbolic(A, M, MT, S["a_rows"][0], 0, S["dofs"][0])
+                        kblk = dev.ptap_numeric(plan, A, M, MT, zero_dofs, diag)
                 finally:
                     if old_pref is not None:
                         dev.ptap_prefer(old_pref)
-                kblk = dev.ptap_numeric(plan, A, M, MT, zero_dofs, diag)
             tick("ptap", t0)
             t0 = time.perf_counter()
             if kblk is True:

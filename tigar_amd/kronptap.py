@@ -277,15 +277,17 @@ def contract(kx, cur, done, group, a_planes, c_planes, out_rows, zero_dofs=None,
     Pm = kx.P(done, group, c_planes[0] * pl_in, c_planes[1] * pl_in)
     try:
         plan = _dev.ptap_symbolic(cur, Pm, MT, a_planes[0] * pl_in, c_planes[0] * pl_in, out_rows[0])
+        return _dev.ptap_numeric(plan, cur, Pm, MT, zero_dofs, diag)
     except _dev.TigarHipError as e:
         nlast = kx.dims(done)[-1]
         if "does not cover" not in str(e) or tuple(c_planes) == (0, nlast):
             raise
-        # a row block of a streamed / distributed product whose columns reach beyond the planes its elements couple to
-        # (a coupling added by hand, tIGAr/common.py:1194-1195 takes any A): the operator on all planes
-        del Pm
-        Pm = kx.P(done, group, 0, nlast * pl_in)
-        plan = _dev.ptap_symbolic(cur, Pm, MT, a_planes[0] * pl_in, 0, out_rows[0])
+    # a row block of a streamed / distributed product whose columns reach beyond the planes its elements couple to (a
+    # coupling added by hand, tIGAr/common.py:1194-1195 takes any A; the symbolic pass samples rows, so the numeric
+    # product may be the one that meets it): the operator on all planes
+    del Pm
+    Pm = kx.P(done, group, 0, nlast * pl_in)
+    plan = _dev.ptap_symbolic(cur, Pm, MT, a_planes[0] * pl_in, 0, out_rows[0])
     return _dev.ptap_numeric(plan, cur, Pm, MT, zero_dofs, diag)
 
 
