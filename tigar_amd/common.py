@@ -1692,25 +1692,25 @@ class ExtractedSpline(object):
         full = numpy.zeros(n)
         full[ua:ub] = host
         tr = self.comm.transport()
-        for nb in (rank - 1, rank + 1):
-            if nb < 0 or nb >= world:
-                continue
-            # what the neighbour needs of my rows, what I need of its rows (both follow from the layout alone)
-            if nb < rank:
-                s0, s1 = ua, min(ub, need[nb][1])            # my lowest rows, up to the end of its window
-                r0, r1 = max(need[rank][0], own[nb][0]), ua
-                if need[rank][0] < own[nb][0]:
-                    raise NotImplementedError("ghost rows reach beyond the neighbouring rank (slabs thinner than the coupling)")
-            else:
-                s0, s1 = max(ua, need[nb][0]), ub
-                r0, r1 = ub, min(need[rank][1], own[nb][1])
-                if need[rank][1] > own[nb][1]:
-                    raise NotImplementedError("ghost rows reach beyond the neighbouring rank (slabs thinner than the coupling)")
-            send = numpy.ascontiguousarray(full[s0:s1]) if s1 > s0 else numpy.zeros(0)
-            recv = numpy.zeros(max(0, r1 - r0))
-            tr.sendrecv(nb, send, recv)
-            if r1 > r0:
-                full[r0:r1] = recv
+        # The transport links z-neighbours only, and a window may reach past the neighbour (slabs thinner than the
+        # coupling), so the ghost rows travel in two sweeps along the chain of ranks.  The windows move upwards with the
+        # rank, hence need[r-1] contains every row rank r wants from below (and need[r+1] every row it wants from above):
+        # upwards, rank r first receives its lower ghost rows from r-1, then hands r+1 what that rank wants from below --
+        # its own rows and, if the window is that long, rows it has just received; downwards likewise.  Which rows go
+        # where follows from the layout alone.
+        empty = numpy.zeros(0)
+        if rank > 0 and ua > need[rank][0]:
+            recv = numpy.zeros(ua - need[rank][0])
+            tr.sendrecv(rank - 1, empty, recv)
+            full[need[rank][0]:ua] = recv
+        if rank + 1 < world and own[rank + 1][0] > need[rank + 1][0]:
+            tr.sendrecv(rank + 1, numpy.ascontiguousarray(full[need[rank + 1][0]:own[rank + 1][0]]), numpy.zeros(0))
+        if rank + 1 < world and need[rank][1] > ub:
+            recv = numpy.zeros(need[rank][1] - ub)
+            tr.sendrecv(rank + 1, empty, recv)
+            full[ub:need[rank][1]] = recv
+        if rank > 0 and need[rank - 1][1] > own[rank - 1][1]:
+            tr.sendrecv(rank - 1, numpy.ascontiguousarray(full[own[rank - 1][1]:need[rank - 1][1]]), numpy.zeros(0))
         return DeviceVector(data=full)
 
     def globalNorm(self, v, kind="l2"):

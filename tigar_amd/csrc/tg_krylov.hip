@@ -1010,15 +1010,25 @@ __global__ void __launch_bounds__(256) k_scaled_copy_norm(const double *x, const
   nn = tg_block_sum256(nn, lds4);
   if (threadIdx.x == 0) partial[blockIdx.x] = nn;
 }
-// Lanczos on D^-1/2 K D^-1/2 (eigenvalue estimates): v0 = sqrt(dinv) .* b (unnormalised), partial of (v0, v0)
-__global__ void __launch_bounds__(256) k_lz_start(const double *__restrict__ b, const double *__restrict__ dinv, int64_t n,
+// Lanczos on D^-1/2 K D^-1/2 (eigenvalue estimates): v0 = sqrt(dinv) .* b .* (1 + h/2) (unnormalised), partial of (v0, v0).
+// h in [-1, 1) is a hash of the GLOBAL row index: a right-hand side that is (close to) one eigenvector -- the sine load of
+// the demos on a uniform degree-1 patch is exactly that -- would end the recurrence after one step with the upper end of
+// the spectrum unseen, and a Chebyshev interval that ends below lambda_max amplifies the rounding noise of every other
+// component until the recurrence breaks down.  The modulation puts all frequencies into the start vector; the same bits on
+// any number of ranks.
+__global__ void __launch_bounds__(256) k_lz_start(const double *__restrict__ b, const double *__restrict__ dinv, int64_t n, int64_t row0,
                                                   double *__restrict__ v, double *__restrict__ partial) {
   __shared__ double lds4[4];
   double nn = 0.0;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    const double vi = sqrt(fabs(dinv[i])) * b[i];
+    unsigned long long z = (unsigned long long)(row0 + i) + 0x9e3779b97f4a7c15ull;      // splitmix64
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    const double h = (double)(long long)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;   // [-1, 1)
+    const double vi = sqrt(fabs(dinv[i])) * b[i] * (1.0 + 0.5 * h);
     v[i] = vi;
     nn += vi * vi;
   }
@@ -1202,7 +1212,7 @@ static int tg_pcg_cheb(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int degree, double
     constexpr int LZ = 12;
     double al[LZ], be[LZ + 1];
     int kdim = 0;
-    hipLaunchKernelGGL(k_lz_start, dim3(vg), dim3(256), 0, g_tg.stream, b->d, dinv, n, g, part);
+    hipLaunchKernelGGL(k_lz_start, dim3(vg), dim3(256), 0, g_tg.stream, b->d, dinv, n, (int64_t)row0, g, part);
     double nn = 0.0;
     TG_TRY(reduce(1, &nn));
     if (!(nn > 0.0)) {                                // b = 0

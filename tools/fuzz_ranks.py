@@ -1,0 +1,58 @@
+"""Random patches on several ranks sharing one GPU against the single-rank run (developer tool): degree, element counts
+per direction, periodic x / y, number of ranks, communicator, Krylov method and an assembled matrix with a coupling added by
+hand are drawn; the checks are those of tests/test_gpu_multirank.py (`_compare`: rank-local rows of K incl. pattern,
+M^T b, solution, prolongation, control functions, initial guess, partition of the rows).
+
+    python tools/fuzz_ranks.py [--seed S] [--cases N]"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cases", type=int, default=20)
+    a = ap.parse_args()
+    import test_gpu_multirank as T
+    bad = 0
+    for i in range(a.cases):
+        rng = np.random.default_rng([a.seed, i])
+        p = int(rng.integers(1, 4))
+        world = int(rng.choice([2, 3]))
+        nels = [int(rng.integers(max(2, p), 10)) for _ in range(2)] + [int(rng.integers(2 * world + p, 14))]
+        periodic = tuple(k for k in (0, 1) if rng.random() < 0.3 and nels[k] >= p + 1)
+        method = str(rng.choice(["cg", "gmres", "bicgstab", "cg:chebyshev"]))
+        kind = str(rng.choice(["ipc", "ipc", "host"]))
+        explicit = str(rng.choice(["", "", "device", "scipy"]))
+        if explicit and method.startswith("cg"):
+            method = "gmres"                      # (the hand-added coupling makes the matrix non-symmetric)
+        case = {"p": p, "nels": nels, "periodic": periodic, "world": world, "method": method, "kind": kind, "explicit": explicit}
+        try:
+            ref = T._single(3, p, nels[0], method, nels=nels, periodic=periodic, explicit=bool(explicit))
+            env = {"TIGAR_TEST_NELS": ",".join(str(n) for n in nels), "TIGAR_TEST_PERIODIC": "".join(str(k) for k in periodic)}
+            if explicit:
+                env["TIGAR_TEST_EXPLICIT_A"] = explicit
+            with tempfile.TemporaryDirectory() as td:
+                parts = T._run_ranks(td, world, kind, 3, p, nels[0], method, 37000 + (a.seed * 131 + i * 7) % 2000, env)
+                T._compare(parts, ref, world, kind, its_slack=8 if method == "bicgstab" else (3 if explicit else 1))
+            print("ok   %s" % json.dumps(case), flush=True)
+        except BaseException as e:  # noqa: BLE001
+            bad += 1
+            print("FAIL %s: %s: %s" % (json.dumps(case), type(e).__name__, str(e)[:300]), flush=True)
+            traceback.print_exc()
+    print(json.dumps({"cases": a.cases, "failed": bad, "seed": a.seed}))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
