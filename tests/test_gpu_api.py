@@ -509,3 +509,37 @@ def test_loose_row_stage_results(T):
         loose.mult(x)
     with pytest.raises(_lib.TigarHipError):
         loose.transpose()
+
+
+def test_random_patches_generated_by_the_reference(T):
+    """56 random patches whose extraction matrices and side-dof lists were computed by the REFERENCE's own classes
+    (tests/golden/golden_random.npz, drawn by the generator of tools/fuzz_parity.py): generateM of the product bit for bit
+    (stored operator, its transpose, and the general count / fill kernels with TIGAR_EXTRACT_KRON=0), getSideDofs, getNcp."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_random.npz"))
+    B, t = T.B, T.t
+    for kron in ("1", "0"):
+        os.environ["TIGAR_EXTRACT_KRON"] = kron
+        try:
+            for name in [str(n) for n in g["names"]]:
+                pre = name + "/"
+                degs = [int(x) for x in g[pre + "degrees"]]
+                kvecs = [[float(v) for v in g[pre + "kvec%d" % k]] for k in range(len(degs))]
+                gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh(degs, kvecs))
+                M = gen.M.to_scipy()
+                M.sort_indices()
+                assert np.array_equal(M.indptr, g[pre + "M_rowptr"]) and np.array_equal(M.indices, g[pre + "M_col"]), name
+                assert np.array_equal(M.data, g[pre + "M_val"]), name                       # bit-exact
+                MT = gen.MT.to_scipy().T.tocsr()
+                MT.sort_indices()
+                assert np.array_equal(MT.indices, g[pre + "M_col"]) and np.array_equal(MT.data, g[pre + "M_val"]), name
+                if kron == "1":
+                    s = gen.getScalarSpline(0)
+                    assert s.getNcp() == int(g[pre + "ncp"]) and s.getDegree() == int(g[pre + "degree"])
+                    for direction in range(len(degs)):
+                        for side in (0, 1):
+                            for nl in (1, 2):
+                                assert list(s.getSideDofs(direction, side, nl)) == \
+                                    list(g[pre + "side_%d_%d_%d" % (direction, side, nl)]), (name, direction, side, nl)
+        finally:
+            del os.environ["TIGAR_EXTRACT_KRON"]

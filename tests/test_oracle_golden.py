@@ -178,3 +178,33 @@ def test_krylov_restatements_against_direct():
     assert np.linalg.norm(Uc - Ud) <= 1e-8 * np.linalg.norm(Ud)
     assert np.linalg.norm(Ug - Ud) <= 1e-8 * np.linalg.norm(Ud)
     assert 0 < itc < 200 and 0 < itg < 400
+
+
+def test_random_patches_generated_by_the_reference():
+    """56 patches drawn by the generator of the random parity runs (tools/fuzz_parity.py: dimension, degrees per direction,
+    element counts, periodic directions, continuityDrop, non-uniform knots with random multiplicities), their extraction
+    matrices and side-dof lists computed by the reference's own classes (tests/golden/make_golden_random.py): the oracle
+    those runs compare with reproduces them bit for bit."""
+    g = _load("golden_random.npz")
+    for name in [str(n) for n in g["names"]]:
+        pre = name + "/"
+        degs = [int(v) for v in g[pre + "degrees"]]
+        kvs = [g[pre + "kvec%d" % k] for k in range(len(degs))]
+        s = O.BSpline(degs, [list(kv) for kv in kvs])
+        assert s.getNcp() == int(g[pre + "ncp"]) and s.getDegree() == int(g[pre + "degree"])
+        M = O.generate_M_tensor(s)
+        assert np.array_equal(M.indptr, g[pre + "M_rowptr"]), name
+        assert np.array_equal(M.indices, g[pre + "M_col"]), name
+        assert np.array_equal(M.data, g[pre + "M_val"]), name                    # bit-exact
+        for direction in range(len(degs)):
+            for side in (0, 1):
+                for nl in (1, 2):
+                    got = np.array(s.getSideDofs(direction, side, nl), dtype=np.int64)
+                    assert np.array_equal(got, g[pre + "side_%d_%d_%d" % (direction, side, nl)]), (name, direction, side, nl)
+    # uniform knot vectors of the cases: the oracle's uniformKnots gives the reference's bits
+    import json
+    for name, meta in zip([str(n) for n in g["names"]], [json.loads(str(m)) for m in g["meta"]]):
+        for k, kind in enumerate(meta["kinds"]):
+            if kind != "nonuniform":
+                kv = O.uniform_knots(meta["ps"][k], 0.0, 1.0, meta["nels"][k], kind == "periodic", meta["drops"][k])
+                assert np.array_equal(np.asarray(kv, dtype=np.float64), g[name + "/kvec%d" % k]), (name, k)
