@@ -39,6 +39,18 @@ def main():
         ("rt2d_per", "RT", [2, 1], [True, False], [2, 2], [B.uniformKnots(2, 0., 1., 5), B.uniformKnots(2, 0., 1., 4)]),
         ("n3d", "N", [2, 1, 1], None, [2, 2, 2], [B.uniformKnots(2, 0., 1., 2), B.uniformKnots(2, 0., 1., 3), B.uniformKnots(2, 0., 3., 2)]),
     ]
+    # seeded random cases: type, dimension, degrees k' per direction, periodicities, control-mesh degree and knot vectors
+    rng = np.random.default_rng(31)
+    for i in range(24):
+        d = int(rng.choice([2, 2, 3]))
+        kind = str(rng.choice(["RT", "N"]))
+        degs = [int(rng.integers(1, 4 if d == 2 else 3)) for _ in range(d)]
+        per = [bool(rng.random() < 0.25) for _ in range(d)]
+        per = per if any(per) else None
+        cdeg = [int(rng.integers(1, 3))] * d
+        ckv = [B.uniformKnots(cdeg[j], float(rng.choice([0., -1.])), float(rng.choice([1., 2.5])),
+                              int(rng.integers(max(degs) + 2, 7 if d == 2 else 5))) for j in range(d)]
+        cases.append(("rnd%02d" % i, kind, degs, per, cdeg, ckv))
     for name, kind, degs, per, cdeg, ckv in cases:
         cm = _CM(B.BSpline(cdeg, ckv))
         fields = C.generateFieldsCompat(cm, kind, degs, periodicities=per)
