@@ -1010,12 +1010,13 @@ __global__ void __launch_bounds__(256) k_scaled_copy_norm(const double *x, const
   nn = tg_block_sum256(nn, lds4);
   if (threadIdx.x == 0) partial[blockIdx.x] = nn;
 }
-// Lanczos on D^-1/2 K D^-1/2 (eigenvalue estimates): v0 = sqrt(dinv) .* b .* (1 + h/2) (unnormalised), partial of (v0, v0).
+// Lanczos on D^-1/2 K D^-1/2 (eigenvalue estimates): v0 = sqrt(dinv) .* b .* (1 + h/16) (unnormalised), partial of (v0, v0).
 // h in [-1, 1) is a hash of the GLOBAL row index: a right-hand side that is (close to) one eigenvector -- the sine load of
 // the demos on a uniform degree-1 patch is exactly that -- would end the recurrence after one step with the upper end of
 // the spectrum unseen, and a Chebyshev interval that ends below lambda_max amplifies the rounding noise of every other
-// component until the recurrence breaks down.  The modulation puts all frequencies into the start vector; the same bits on
-// any number of ranks.
+// component until the recurrence breaks down.  The modulation puts all frequencies into the start vector (a sixteenth is
+// enough for the upper end -- Lanczos needs one more step to set the dominant component aside -- and leaves the estimate of the
+// lower end, which tells an easy system from a hard one, to the content of b); the same bits on any number of ranks.
 __global__ void __launch_bounds__(256) k_lz_start(const double *__restrict__ b, const double *__restrict__ dinv, int64_t n, int64_t row0,
                                                   double *__restrict__ v, double *__restrict__ partial) {
   __shared__ double lds4[4];
@@ -1028,7 +1029,7 @@ __global__ void __launch_bounds__(256) k_lz_start(const double *__restrict__ b, 
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
     z ^= z >> 31;
     const double h = (double)(long long)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;   // [-1, 1)
-    const double vi = sqrt(fabs(dinv[i])) * b[i] * (1.0 + 0.5 * h);
+    const double vi = sqrt(fabs(dinv[i])) * b[i] * (1.0 + 0.0625 * h);
     v[i] = vi;
     nn += vi * vi;
   }
