@@ -36,9 +36,19 @@
 #ifdef __HIPCC__
 #define TT_DEV __device__ __forceinline__
 #define TT_MEM __device__ __forceinline__
+// stores of the intermediates B1 / B2 (written once, read once by the next pass, far too large for the caches).  Measured at
+// cfg3 with -DTT_NT_STORES (nontemporal stores): the PtAP stage 0.33-0.37 s against 0.166-0.173 s, same box, alternating runs
+// -- the lanes of a wave write 392-byte segments (49 columns x 8 B) that the L2 merges into full lines; bypassing it writes
+// partial lines.  Plain stores it is.
+#ifdef TT_NT_STORES
+#define TT_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define TT_ST(p, v) (*(p) = (v))
+#endif
 #else
 #define TT_DEV static inline
 #define TT_MEM inline
+#define TT_ST(p, v) (*(p) = (v))
 #endif
 
 // Small read-only tables (local weights, prefix sums) are read through the constant address space: with a
@@ -264,7 +274,7 @@ struct tt_io_x {
     if (!valid || i < elo || i >= ehi) return;
     double *d = out + ostride_i * i;
 #pragma unroll
-    for (int m = 0; m < 2 * P + 1; m++) d[m * ostride_m] = row[m];
+    for (int m = 0; m < 2 * P + 1; m++) TT_ST(&d[m * ostride_m], row[m]);
   }
 };
 
@@ -374,7 +384,7 @@ struct tt_io_xg {
     if (!valid || i < elo || i >= ehi) return;
     double *d = out + ostride_i * i;
 #pragma unroll
-    for (int m = 0; m < 2 * P + 1; m++) d[m * ostride_m] = row[m];
+    for (int m = 0; m < 2 * P + 1; m++) TT_ST(&d[m * ostride_m], row[m]);
   }
 };
 
@@ -461,7 +471,7 @@ struct tt_io_y {
     if (!valid || i < elo || i >= ehi) return;
     double *d = out + ostride_i * i;
 #pragma unroll
-    for (int m = 0; m < 2 * P + 1; m++) d[m * ostride_m] = row[m];
+    for (int m = 0; m < 2 * P + 1; m++) TT_ST(&d[m * ostride_m], row[m]);
   }
 };
 
