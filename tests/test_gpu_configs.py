@@ -354,3 +354,25 @@ def test_all_golden_compatible_spline_cases_extract_like_oracle(T):
             K = spline.extractMatrix(A).to_scipy()
             Ko = O.extract_matrix(Mo, A, list(spline.zeroDofs))
             assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max(), name
+
+
+def test_multipatch_evaluations_match_the_reference(T):
+    """``MultiBSpline.getNodesAndEvals`` at 1 278 sample points (element corners, edges, interiors) of ten seeded random
+    multi-patch configurations against the REFERENCE class's output (tests/golden/golden_multipatch.npz): the same columns in
+    the same order, the values bit for bit (generateM of such spaces against the row loop: test_multipatch_bspline_extraction_is_patchwise)."""
+    import json
+    import os
+    B, t = T.B, T.t
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_multipatch.npz"))
+    npts = 0
+    for m in json.loads(str(g["meta"])):
+        name, npatch, degs = m["name"], m["npatch"], m["degrees"]
+        patches = [B.BSpline(degs, [[float(v) for v in g["%s_p%d_kv%d_in" % (name, k, d)]] for d in range(2)]) for k in range(npatch)]
+        mb = B.MultiBSpline(patches)
+        pts, ptr, cols, vals = g[name + "_pts"], g[name + "_ptr"], g[name + "_cols"], g[name + "_vals"]
+        for i in range(pts.shape[0]):
+            ne = mb.getNodesAndEvals(pts[i])
+            assert [int(e[0]) for e in ne] == cols[ptr[i]:ptr[i + 1]].tolist(), (name, i)
+            assert np.array_equal(np.array([e[1] for e in ne]), vals[ptr[i]:ptr[i + 1]]), (name, i)
+        npts += pts.shape[0]
+    assert npts == 1278

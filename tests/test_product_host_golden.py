@@ -88,3 +88,23 @@ def test_side_dof_lists_drop_their_array_when_edited():
         assert np.array_equal(G._index_array(d), np.asarray(list(d), dtype=np.int64))
     d = s.getSideDofs(1, 0)
     assert type(d + [1]) is list and type(d[1:3]) is list and d.array is not None      # copies are plain lists
+
+
+def test_product_multipatch_bookkeeping_matches_the_reference():
+    """MultiBSpline (tIGAr/BSplines.py:651-700, 884-908) on ten seeded random configurations computed by the reference's class
+    (tests/golden/make_golden_multipatch.py): knot vectors normalised to (0, 1), dof offsets, ncp, nel, getPatchSideDofs"""
+    import json
+    from tigar_amd import BSplines as B
+    g = _load("golden_multipatch.npz")
+    for m in json.loads(str(g["meta"])):
+        name, npatch, degs = m["name"], m["npatch"], m["degrees"]
+        patches = [B.BSpline(degs, [[float(v) for v in g["%s_p%d_kv%d_in" % (name, k, d)]] for d in range(2)]) for k in range(npatch)]
+        mb = B.MultiBSpline(patches)
+        assert list(mb.doffsets) == g[name + "_doffsets"].tolist()
+        assert mb.getNcp() == int(g[name + "_ncp"]) and mb.nel == int(g[name + "_nel"])
+        for k in range(npatch):
+            for d in range(2):
+                assert np.array_equal(np.asarray(patches[k].splines[d].knots, dtype=np.float64), g["%s_p%d_kv%d_norm" % (name, k, d)])
+                for side in (0, 1):
+                    for nl in (1, 2):
+                        assert list(mb.getPatchSideDofs(k, d, side, nl)) == g["%s_p%d_side_%d_%d_%d" % (name, k, d, side, nl)].tolist()
