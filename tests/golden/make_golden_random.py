@@ -79,6 +79,30 @@ def main(ncases=56, seed=2024, max_rows=700):
             for side in (0, 1):
                 for nl in (1, 2):
                     out[pre + "side_%d_%d_%d" % (direction, side, nl)] = np.array(s.getSideDofs(direction, side, nl), dtype=np.int64)
+        # evaluations at points that are NOT mesh nodes: random interior points, and per direction a unique knot with its two
+        # floating-point neighbours (the span search's tie-breaking, tIGAr/BSplines.py:285-308)
+        prng = np.random.default_rng(case["knot_seed"] + 1)
+        lo = [float(s.splines[k].uniqueKnots[0]) for k in range(d)]
+        hi = [float(s.splines[k].uniqueKnots[-1]) for k in range(d)]
+        pts = [[lo[k] + (hi[k] - lo[k]) * float(prng.random()) for k in range(d)] for _ in range(16)]
+        for k in range(d):
+            uk = s.splines[k].uniqueKnots
+            kn = float(uk[int(prng.integers(0, len(uk)))])
+            for x in (kn, float(np.nextafter(kn, -np.inf)), float(np.nextafter(kn, np.inf))):
+                if lo[k] <= x <= hi[k]:
+                    q = [lo[j] + (hi[j] - lo[j]) * float(prng.random()) for j in range(d)]
+                    q[k] = x
+                    pts.append(q)
+        ec, ev, ep = [], [], [0]
+        for q in pts:
+            ne = s.getNodesAndEvals(q)
+            ec += [int(e[0]) for e in ne]
+            ev += [float(e[1]) for e in ne]
+            ep.append(len(ec))
+        out[pre + "ev_pts"] = np.array(pts, dtype=np.float64).reshape(len(pts), d)
+        out[pre + "ev_ptr"] = np.array(ep, dtype=np.int64)
+        out[pre + "ev_cols"] = np.array(ec, dtype=np.int64)
+        out[pre + "ev_vals"] = np.array(ev, dtype=np.float64)
         names.append(name)
         metas.append(json.dumps({k: case[k] for k in ("d", "ps", "kinds", "nels", "drops", "knot_seed")}))
         print("  ", name, metas[-1], "rows", nrows, "nnz", len(mc))

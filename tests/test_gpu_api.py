@@ -543,3 +543,36 @@ def test_random_patches_generated_by_the_reference(T):
                                     list(g[pre + "side_%d_%d_%d" % (direction, side, nl)]), (name, direction, side, nl)
         finally:
             del os.environ["TIGAR_EXTRACT_KRON"]
+
+
+def test_random_patches_point_evaluations_match_the_reference(T):
+    """getNodesAndEvals of the 56 random reference patches at points that are not mesh nodes (random interior points, a knot
+    and its two floating-point neighbours per direction; golden_random.npz): the single-point API (columns in the
+    reference's order, values bit for bit) and the explicit-coordinate extraction kernel (`tg_extract_csr_points`: the rows
+    of M for dolfin-supplied node coordinates, with generateM's filter and sorted columns)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_random.npz"))
+    B, dev = T.B, T.dev
+    n = 0
+    for name in [str(x) for x in g["names"]]:
+        pre = name + "/"
+        degs = [int(v) for v in g[pre + "degrees"]]
+        s = B.BSpline(degs, [[float(v) for v in g[pre + "kvec%d" % k]] for k in range(len(degs))])
+        pts, ptr, cols, vals = g[pre + "ev_pts"], g[pre + "ev_ptr"], g[pre + "ev_cols"], g[pre + "ev_vals"]
+        for i in range(pts.shape[0]):
+            ne = s.getNodesAndEvals(pts[i])
+            assert [int(e[0]) for e in ne] == cols[ptr[i]:ptr[i + 1]].tolist(), (name, i)
+            assert np.array_equal(np.array([e[1] for e in ne]), vals[ptr[i]:ptr[i + 1]]), (name, i)
+            n += 1
+        # all points at once through the points kernel: one row per point = generateM's loop body (:1566-1571)
+        Mp = dev.extract_csr_points(s.splines, pts, 0, s.getNcp(), 1e-15).to_scipy()
+        Mp.sort_indices()
+        for i in range(pts.shape[0]):
+            row = {}
+            for c, v in zip(cols[ptr[i]:ptr[i + 1]], vals[ptr[i]:ptr[i + 1]]):
+                if abs(v) > 1e-15:
+                    row[int(c)] = float(v)
+            a, b = Mp.indptr[i], Mp.indptr[i + 1]
+            assert Mp.indices[a:b].tolist() == sorted(row), (name, i)
+            assert np.array_equal(Mp.data[a:b], np.array([row[c] for c in sorted(row)])), (name, i)
+    assert n > 1000

@@ -208,3 +208,21 @@ def test_random_patches_generated_by_the_reference():
             if kind != "nonuniform":
                 kv = O.uniform_knots(meta["ps"][k], 0.0, 1.0, meta["nels"][k], kind == "periodic", meta["drops"][k])
                 assert np.array_equal(np.asarray(kv, dtype=np.float64), g[name + "/kvec%d" % k]), (name, k)
+
+
+def test_random_patches_point_evaluations():
+    """getNodesAndEvals of the 56 random patches at points that are not mesh nodes (random interior points; a knot and its two
+    floating-point neighbours per direction): columns in the reference's order, values bit for bit."""
+    g = _load("golden_random.npz")
+    n = 0
+    for name in [str(x) for x in g["names"]]:
+        pre = name + "/"
+        degs = [int(v) for v in g[pre + "degrees"]]
+        s = O.BSpline(degs, [list(g[pre + "kvec%d" % k]) for k in range(len(degs))])
+        pts, ptr, cols, vals = g[pre + "ev_pts"], g[pre + "ev_ptr"], g[pre + "ev_cols"], g[pre + "ev_vals"]
+        for i in range(pts.shape[0]):
+            ne = s.getNodesAndEvals(pts[i])
+            assert [int(e[0]) for e in ne] == cols[ptr[i]:ptr[i + 1]].tolist(), (name, i)
+            assert np.array_equal(np.array([e[1] for e in ne]), vals[ptr[i]:ptr[i + 1]]), (name, i)
+            n += 1
+    assert n > 1000
