@@ -3,9 +3,9 @@ stand-in of SURVEY 8f-1, tIGAr/common.py:917-945, 1206-1220) against ``oracle.ma
 1-3 embedded in 1-3 space dimensions, degrees 1-4, non-uniform element sizes, perturbed and rational geometries, Gauss
 points p+1 / p+2.
 
-    python tools/fuzz_assembly.py [cases]"""
+    python tests/fuzz/fuzz_assembly.py [cases]"""
 import sys, json, numpy as np
-sys.path.insert(0,'.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from oracle import tigar_oracle as O
 from tigar_amd import device as dev
 bad=0

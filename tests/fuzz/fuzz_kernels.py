@@ -7,7 +7,7 @@ matrices -- through
   second product on the plan bit-identical, MatZeroRowsColumns fused;
 * the Krylov solvers on diagonally dominant systems.
 
-    python tools/fuzz_kernels.py [--seed S] [--cases N] [-v]
+    python tests/fuzz/fuzz_kernels.py [--seed S] [--cases N] [-v]
 
 The kernel family follows the environment (TIGAR_PTAP_WAVE, TIGAR_PTAP_ACCUM, TIGAR_KSP_PERSISTENT, TIGAR_POOL_POISON)."""
 import argparse
@@ -20,7 +20,7 @@ import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def rand_csr(rng, n, m, kind):

@@ -1,14 +1,14 @@
 """Random patches through the Newton driver (solveNonlinearVariationalProblem, tIGAr/common.py:1304-1348) on
 -lap u + u^3 = f against ``oracle.newton_semilinear`` (developer tool): the history of relative norms and the solution.
 
-    python tools/fuzz_newton.py [cases]"""
+    python tests/fuzz/fuzz_newton.py [cases]"""
 import json
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import tigar_oracle as O  # noqa: E402
 import fuzz_parity as fz  # noqa: E402

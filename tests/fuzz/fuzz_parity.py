@@ -12,7 +12,7 @@ couplings added by hand) and a load vector, runs generateM / extractMatrix / ext
 * M^T b to 1e-12; the solution of K U = M^T b by the default solver and by Krylov solvers at rtol 1e-11 against a direct
   solve of the oracle's system, prolonged: to 1e-7 of the largest nodal value.
 
-    python tools/fuzz_parity.py [--seed S] [--cases N] [--first I] [--max-rows R] [--case '<json>'] [-v]
+    python tests/fuzz/fuzz_parity.py [--seed S] [--cases N] [--first I] [--max-rows R] [--case '<json>'] [-v]
 
 The paths a case takes depend on the environment (TIGAR_IMPLICIT_M, TIGAR_PTAP_TENSOR, TIGAR_PTAP_FACTORED,
 TIGAR_PTAP_WAVE, TIGAR_PTAP_UNWRAP, TIGAR_KSP_PERSISTENT, TIGAR_POOL_POISON ...): run the tool once per setting.  Exit
@@ -27,7 +27,7 @@ import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import tigar_oracle as O  # noqa: E402
 
 

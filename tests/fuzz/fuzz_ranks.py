@@ -3,7 +3,7 @@ per direction, periodic x / y, number of ranks, communicator, Krylov method and 
 hand are drawn; the checks are those of tests/test_gpu_multirank.py (`_compare`: rank-local rows of K incl. pattern,
 M^T b, solution, prolongation, control functions, initial guess, partition of the rows).
 
-    python tools/fuzz_ranks.py [--seed S] [--cases N]"""
+    python tests/fuzz/fuzz_ranks.py [--seed S] [--cases N]"""
 import argparse
 import json
 import os
@@ -13,7 +13,7 @@ import traceback
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

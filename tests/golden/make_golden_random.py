@@ -2,7 +2,7 @@
 """
 Golden fixtures for RANDOM tensor patches, from the REFERENCE's own source (stub import of ``_ref_stub_import.py``; works
 only in the build container, where /root/reference exists).  The cases are drawn by the generator of the random parity runs
-(``tools/fuzz_parity.py: draw_case`` -- dimension, degrees per direction, element counts, periodic directions, repeated
+(``tests/fuzz/fuzz_parity.py: draw_case`` -- dimension, degrees per direction, element counts, periodic directions, repeated
 knots by continuityDrop, non-uniform knots with random multiplicities), so that the oracle those runs compare with is pinned
 to the reference on the same kind of input.  Run:
 
@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
 from _ref_stub_import import import_reference  # noqa: E402
 from make_golden import fe_nodes_1d  # noqa: E402
 import fuzz_parity as fz  # noqa: E402

@@ -513,7 +513,7 @@ def test_loose_row_stage_results(T):
 
 def test_random_patches_generated_by_the_reference(T):
     """56 random patches whose extraction matrices and side-dof lists were computed by the REFERENCE's own classes
-    (tests/golden/golden_random.npz, drawn by the generator of tools/fuzz_parity.py): generateM of the product bit for bit
+    (tests/golden/golden_random.npz, drawn by the generator of tests/fuzz/fuzz_parity.py): generateM of the product bit for bit
     (stored operator, its transpose, and the general count / fill kernels with TIGAR_EXTRACT_KRON=0), getSideDofs, getNcp."""
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_random.npz"))

@@ -1,5 +1,5 @@
 """Seeded random patches through generateM / extractMatrix / extractVector / solveLinearSystem against the oracle
-(`tools/fuzz_parity.py`: dimension, degrees per direction, element counts, periodic directions, repeated and non-uniform
+(`tests/fuzz/fuzz_parity.py`: dimension, degrees per direction, element counts, periodic directions, repeated and non-uniform
 knots, several fields, boundary dofs, FE matrices on and off the element-coupling pattern), once per set of environment
 switches so that every family of kernels sees them (tIGAr/common.py:1516-1578, 1142-1204, 1236-1263)."""
 import json
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(args, env, tool="fuzz_parity.py"):
     e = dict(os.environ)
     e.update(env)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, env=e, cwd=ROOT,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", tool)] + args, env=e, cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert lines, r.stdout[-2000:]
@@ -57,7 +57,7 @@ def test_hand_added_couplings_that_end_inside_an_element_of_a_repeated_knot_dire
 @pytest.mark.parametrize("seed,env", [(201, {}), (202, {"TIGAR_PTAP_WAVE": "1"}), (203, {"TIGAR_PTAP_ACCUM": "int"}),
                                       (204, {"TIGAR_POOL_POISON": "1", "TIGAR_KSP_PERSISTENT": "1"})])
 def test_random_sparse_matrices_through_the_kernels(seed, env):
-    """`tools/fuzz_kernels.py`: matrices of any shape and row-length profile (empty, one row, empty rows, a few rows that fill
+    """`tests/fuzz/fuzz_kernels.py`: matrices of any shape and row-length profile (empty, one row, empty rows, a few rows that fill
     the matrix) through SpMV / M^T b / transpose / add / selections / the general PtAP (structural pattern, values,
     MatZeroRowsColumns, the same bits twice) / the Krylov solvers, against scipy"""
     rc, summary, failures = _run(["--seed", str(seed), "--cases", "25"], env, tool="fuzz_kernels.py")

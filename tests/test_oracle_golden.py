@@ -181,7 +181,7 @@ def test_krylov_restatements_against_direct():
 
 
 def test_random_patches_generated_by_the_reference():
-    """56 patches drawn by the generator of the random parity runs (tools/fuzz_parity.py: dimension, degrees per direction,
+    """56 patches drawn by the generator of the random parity runs (tests/fuzz/fuzz_parity.py: dimension, degrees per direction,
     element counts, periodic directions, continuityDrop, non-uniform knots with random multiplicities), their extraction
     matrices and side-dof lists computed by the reference's own classes (tests/golden/make_golden_random.py): the oracle
     those runs compare with reproduces them bit for bit."""
