@@ -171,8 +171,12 @@ def run_case(case, verbose=False):
         assert np.array_equal(np.sort(idx), np.arange(Ko.shape[0])), "localDofIndices is not a permutation"
         Ko = Ko.tocsr()[idx][:, idx].tocsr()
     Ko.sort_indices()
+    # the inputs as the caller may hold them: scipy / numpy on the host, or already on the device
+    rng2 = np.random.default_rng(case["val_seed"] + 7)
+    A_in = dev.DeviceCSR.from_scipy(A) if rng2.random() < 0.5 else A
+    b_in = dev.DeviceVector(data=b) if rng2.random() < 0.5 else b
     dev.prof_reset()
-    Kd = spline.extractMatrix(A, applyBCs=bcs, diag=case["diag"])
+    Kd = spline.extractMatrix(A_in, applyBCs=bcs, diag=case["diag"])
     K = Kd.to_scipy()
     K.sort_indices()
     walks = int(dev.prof_get(5)[1])
@@ -183,7 +187,7 @@ def run_case(case, verbose=False):
     if on_pattern:
         assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices), \
             "pattern of K (nnz %d, oracle %d)" % (K.nnz, Ko.nnz)
-    K2 = spline.extractMatrix(A, applyBCs=bcs, diag=case["diag"]).to_scipy()
+    K2 = spline.extractMatrix(A_in, applyBCs=bcs, diag=case["diag"]).to_scipy()
     K2.sort_indices()
     assert np.array_equal(K2.indices, K.indices) and np.array_equal(K2.data.view(np.int64), K.data.view(np.int64)), \
         "K is not bit-reproducible"
@@ -200,7 +204,7 @@ def run_case(case, verbose=False):
         assert ef <= 1e-12, "values of K (assembleMatrix): %g" % ef
     # ---- M^T b
     yo = O.extract_vector(Mo, b, zd, applyBCs=bcs)[idx]
-    yd = spline.extractVector(b, applyBCs=bcs)
+    yd = spline.extractVector(b_in, applyBCs=bcs)
     y = yd.get_local()
     assert np.max(np.abs(y - yo)) <= 1e-12 * max(1.0, np.max(np.abs(yo))), "M^T b: %g" % np.max(np.abs(y - yo))
     # ---- solves (the system is regular: A is positive definite or diagonally dominant; with the boundary rows replaced
