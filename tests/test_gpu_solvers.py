@@ -357,3 +357,26 @@ def test_chebyshev_cg_with_a_right_hand_side_that_is_one_eigenvector():
         its, res, status = dev.krylov_solve(Kd, dev.DeviceVector(data=b), x, "cg", "chebyshev", 1e-10, 1e-300, 500, degree)
         assert status == 0 and its <= 3
         assert np.linalg.norm(K @ x.get_local() - b) <= 1e-9 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("n1", [12, 40])        # 144 unknowns: the multi-kernel loops; 1 600: the persistent kernels
+def test_nan_in_the_matrix_or_the_right_hand_side_is_a_breakdown_for_every_solver(n1):
+    """a NaN in K (an FE matrix with a NaN entry goes through M^T A M entry by entry, as PETSc's product would) or in b ends
+    every Krylov solver with status -2 (dolfin: RuntimeError) within a few iterations -- found by probing: Chebyshev-CG took
+    the NaN norm of its Lanczos start vector for "b = 0" and returned x = 0 as converged."""
+    from tigar_amd import device as dev
+    T1 = sp.diags([-np.ones(n1 - 1), 2.0 * np.ones(n1), -np.ones(n1 - 1)], [-1, 0, 1])
+    K = (sp.kron(T1, sp.identity(n1)) + sp.kron(sp.identity(n1), T1)).tocsr()
+    K.sort_indices()
+    b = np.ones(K.shape[0])
+    Kbad = K.copy()
+    Kbad.data[Kbad.nnz // 2] = np.nan
+    bbad = b.copy()
+    bbad[7] = np.nan
+    for Km, bm in ((Kbad, b), (K, bbad)):
+        Kd = dev.DeviceCSR.from_scipy(Km)
+        for method, pc in (("cg", "jacobi"), ("cg", "none"), ("cg", "chebyshev"), ("gmres", "jacobi"), ("bicgstab", "jacobi")):
+            x = dev.DeviceVector(K.shape[0])
+            its, res, status = dev.krylov_solve(Kd, dev.DeviceVector(data=bm), x, method, pc, 1e-10, 1e-300, 500, 30)
+            assert status == -2, (method, pc, status, its)
+            assert its <= 35, (method, pc, its)

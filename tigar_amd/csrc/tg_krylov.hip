@@ -1216,6 +1216,12 @@ static int tg_pcg_cheb(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int degree, double
     hipLaunchKernelGGL(k_lz_start, dim3(vg), dim3(256), 0, g_tg.stream, b->d, dinv, n, (int64_t)row0, g, part);
     double nn = 0.0;
     TG_TRY(reduce(1, &nn));
+    if (nn != nn) {                                   // NaN in b or on the diagonal of K: breakdown, not "b = 0"
+      *iters = 0;
+      *resnorm = nn;
+      *status = -2;
+      return 0;
+    }
     if (!(nn > 0.0)) {                                // b = 0
       TG_CHECK_HIP(hipMemsetAsync(x->d, 0, (size_t)std::max<int64_t>(n, 1) * sizeof(double), g_tg.stream));
       *iters = 0;
