@@ -363,7 +363,8 @@ def test_chebyshev_cg_with_a_right_hand_side_that_is_one_eigenvector():
 def test_nan_in_the_matrix_or_the_right_hand_side_is_a_breakdown_for_every_solver(n1):
     """a NaN in K (an FE matrix with a NaN entry goes through M^T A M entry by entry, as PETSc's product would) or in b ends
     every Krylov solver with status -2 (dolfin: RuntimeError) within a few iterations -- found by probing: Chebyshev-CG took
-    the NaN norm of its Lanczos start vector for "b = 0" and returned x = 0 as converged."""
+    the NaN norm of its Lanczos start vector for "b = 0" and returned x = 0 as converged; BiCGStab's max(0, ||r||^2) turned a
+    NaN into 0 = converged (an Inf in K)."""
     from tigar_amd import device as dev
     T1 = sp.diags([-np.ones(n1 - 1), 2.0 * np.ones(n1), -np.ones(n1 - 1)], [-1, 0, 1])
     K = (sp.kron(T1, sp.identity(n1)) + sp.kron(sp.identity(n1), T1)).tocsr()
@@ -373,7 +374,9 @@ def test_nan_in_the_matrix_or_the_right_hand_side_is_a_breakdown_for_every_solve
     Kbad.data[Kbad.nnz // 2] = np.nan
     bbad = b.copy()
     bbad[7] = np.nan
-    for Km, bm in ((Kbad, b), (K, bbad)):
+    Kinf = K.copy()
+    Kinf.data[5] = np.inf
+    for Km, bm in ((Kbad, b), (K, bbad), (Kinf, b)):
         Kd = dev.DeviceCSR.from_scipy(Km)
         for method, pc in (("cg", "jacobi"), ("cg", "none"), ("cg", "chebyshev"), ("gmres", "jacobi"), ("bicgstab", "jacobi")):
             x = dev.DeviceVector(K.shape[0])

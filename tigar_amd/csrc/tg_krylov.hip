@@ -1534,7 +1534,9 @@ static int tg_bicgstab(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rto
       hipLaunchKernelGGL(k_bcgs_x, dim3(vg), dim3(256), 0, g_tg.stream, pv, op, t, alpha, omega, n, x->d, r);
       TG_LAUNCH_CHECK();
       const double rho_new = hs - omega * ht;
-      const double rn2 = std::max(0.0, ss - 2.0 * omega * ts + omega * omega * tt);
+      // (max / fmax return the other argument for a NaN: a NaN in the sums -- an Inf in K, say -- must stay one)
+      const double rn2raw = (ss - 2.0 * omega * ts + omega * omega * tt) + 0.0 * (ts + tt + hs + ht);
+      const double rn2 = rn2raw < 0.0 ? 0.0 : rn2raw;
       znorm = sqrt(rn2);
       *iters = it;
       if (!(znorm == znorm)) {

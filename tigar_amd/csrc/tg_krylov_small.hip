@@ -851,7 +851,9 @@ __global__ void __launch_bounds__(PS_NT) k_bicgstab_persistent(tg_pg_args Q) {
         L.r[i] = L.s[i] - omega * L.t[i];
       }
       const double rho_new = hs - omega * ht;
-      const double rn2 = fmax(0.0, ss - 2.0 * omega * ts + omega * omega * tt);
+      // (fmax returns the other argument for a NaN: a NaN in the sums -- an Inf in K, say -- must stay one)
+      const double rn2raw = (ss - 2.0 * omega * ts + omega * omega * tt) + 0.0 * (ts + tt + hs + ht);
+      const double rn2 = rn2raw < 0.0 ? 0.0 : rn2raw;
       znorm = sqrt(rn2);
       its = it;
       if (!(znorm == znorm)) {
