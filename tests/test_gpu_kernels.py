@@ -906,3 +906,30 @@ def test_products_with_rows_beyond_the_per_row_tables_are_split_by_columns():
     assert abs(K1 - Ko).max() <= 1e-12 * abs(Ko).max()
     K1.sort_indices(), Ko.sort_indices()
     assert np.array_equal(K1.indptr, Ko.indptr) and np.array_equal(K1.indices, Ko.indices)
+
+
+def test_invalid_inputs_are_errors_not_reads_of_foreign_memory():
+    """what a caller can get wrong at the boundary (found by probing): a CSR structure with a column outside the matrix,
+    operands of the wrong size, vectors of the wrong length -- Python exceptions with the C side's message, nothing is read
+    or written outside the operands; boundary dofs outside the space are ignored (bounds-checked marks)."""
+    import scipy.sparse as sp
+    from tigar_amd import device as dev
+    from tigar_amd._lib import TigarHipError
+    bad = sp.csr_matrix((3, 3))
+    bad = sp.csr_matrix((np.ones(2), np.array([0, 9], dtype=np.int32), np.array([0, 1, 2, 2])), shape=(3, 3))
+    with pytest.raises(ValueError):
+        dev.DeviceCSR.from_scipy(bad)
+    A = dev.DeviceCSR.from_scipy(sp.identity(5, format="csr"))
+    with pytest.raises(TigarHipError):
+        A.mult(dev.DeviceVector(4))
+    with pytest.raises(TigarHipError):
+        A.mult_transpose(dev.DeviceVector(6))
+    R = dev.DeviceCSR.from_scipy(sp.random(5, 4, density=0.5, random_state=1, format="csr"))
+    with pytest.raises(TigarHipError):
+        dev.krylov_solve(R, dev.DeviceVector(5), dev.DeviceVector(5))
+    K = dev.DeviceCSR.from_scipy(sp.identity(5, format="csr") * 2.0)
+    K.zero_rows_cols(np.array([1, 7, -3], dtype=np.int32), 4.0)          # 7 and -3 are outside: ignored
+    assert np.array_equal(K.to_scipy().diagonal(), [2.0, 4.0, 2.0, 2.0, 2.0])
+    y = dev.DeviceVector(data=np.ones(5))
+    y.zero_entries(np.array([0, 9], dtype=np.int32))
+    assert np.array_equal(y.get_local(), [0.0, 1.0, 1.0, 1.0, 1.0])

@@ -139,6 +139,11 @@ class DeviceCSR(object):
         rowptr = _i64(A.indptr)
         col = _i32(A.indices)
         val = _f64(A.data)
+        # (the kernels trust the structure: a column outside the matrix would be read as an address)
+        if col.size and (int(col.min()) < 0 or int(col.max()) >= A.shape[1]):
+            raise ValueError("DeviceCSR.from_scipy: column index outside [0, %d)" % A.shape[1])
+        if rowptr.size != A.shape[0] + 1 or int(rowptr[0]) != 0 or int(rowptr[-1]) != col.size or np.any(np.diff(rowptr) < 0):
+            raise ValueError("DeviceCSR.from_scipy: row pointer is not a non-decreasing array from 0 to nnz")
         h = handle()
         check(_lib.lib().tg_csr_from_host(A.shape[0], A.shape[1], _p(rowptr, c_i64p), _p(col, c_i32p),
                                           _p(val, c_f64p), C.byref(h)), "tg_csr_from_host")
