@@ -184,9 +184,9 @@ def run_case(case, verbose=False):
     scale = abs(Ko).max()
     err = abs(K - Ko).max() / scale
     assert err <= 1e-12, "values of K: %g" % err
-    if on_pattern:
-        assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices), \
-            "pattern of K (nnz %d, oracle %d)" % (K.nnz, Ko.nnz)
+    # (also with couplings added by hand: the structural pattern of the whole product)
+    assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices), \
+        "pattern of K (nnz %d, oracle %d)" % (K.nnz, Ko.nnz)
     K2 = spline.extractMatrix(A_in, applyBCs=bcs, diag=case["diag"]).to_scipy()
     K2.sort_indices()
     assert np.array_equal(K2.indices, K.indices) and np.array_equal(K2.data.view(np.int64), K.data.view(np.int64)), \

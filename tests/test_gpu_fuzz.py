@@ -62,3 +62,13 @@ def test_random_sparse_matrices_through_the_kernels(seed, env):
     MatZeroRowsColumns, the same bits twice) / the Krylov solvers, against scipy"""
     rc, summary, failures = _run(["--seed", str(seed), "--cases", "25"], env, tool="fuzz_kernels.py")
     assert rc == 0 and summary["failed"] == 0, "\n".join(failures)[:4000]
+
+
+def test_sequences_of_different_matrices_through_one_spline():
+    """`tests/fuzz/fuzz_sequences.py`: eight FE matrices in a row through ONE ExtractedSpline per random patch (Laplace, random
+    values, three matrices with the same number of hand-added couplings at different places, Laplace again, mass, the first
+    again) -- cached symbolic products, tensor plans, fold plans must never serve a matrix they were not made for; pattern
+    (the structural product, also for the hand-added couplings) and values against the oracle.  Found this way: a field block
+    that holds only hand-added couplings came back on the full tensor pattern with stored zeros."""
+    rc, summary, failures = _run(["--seed", "3", "--cases", "70"], {}, tool="fuzz_sequences.py")
+    assert rc == 0 and summary["failed"] == 0, "\n".join(failures)[:4000]

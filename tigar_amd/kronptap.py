@@ -322,7 +322,10 @@ def ptap_factored(kx, A, a_planes, c_planes, k_planes, zero_dofs=None, diag=1.0,
         whole = (za, zb) == (0, kx.nfe[-1]) and (k0, k1) == (0, kx.ncp[-1]) and A.shape[0] == A.shape[1]
         if _split and whole and os.environ.get("TIGAR_PTAP_SPLIT", "1") != "0":
             parts = plan.split(A)
-            if parts is not None and parts[1].nnz <= 0.25 * A.nnz:
+            # (`on` comes back on the FULL element-coupling pattern: where A has no entry there, a zero is stored.  An
+            #  assembled FE matrix has them all; one that lacks some would get stored zeros in K that MatPtAP's symbolic
+            #  product does not create -- such a matrix takes the general stages)
+            if parts is not None and parts[1].nnz <= 0.25 * A.nnz and A.nnz - parts[1].nnz == parts[0].nnz:
                 on, off = parts
                 K = plan.zstage([plan.planes(on, 0, za, zb)], k0, k1)
                 if off.nnz:
