@@ -274,9 +274,9 @@ def test_matrix_with_entries_outside_the_pattern_is_split(p, nels):
     entries of the element-coupling pattern missing: the part on the pattern goes through the line walks, the rest
     through the general kernels, the products are added on the union of their patterns and the boundary conditions
     applied to the sum.  Against the oracle's M^T A M (values; pattern = structural pattern of the product), and the
-    pieces themselves against A.  Entries of the pattern that A does not store count as stored zeros on this path: the
-    product's pattern is that of the full band plus the remainder's -- a superset of what PETSc's symbolic product
-    would allocate for such an A (and the diagonal of a constrained row always exists for MatZeroRowsColumns)."""
+    pieces themselves against A.  The split itself pads the pattern part with stored zeros where A has no entry; since
+    round 4 only a matrix that stores the WHOLE pattern takes it (plus whatever was added), one with entries missing takes the
+    general stages, so that the product's pattern is always the structural product of what A stores."""
     from tigar_amd.tensorptap import TensorPtAP
     from tigar_amd import device as dev
     gen, spline = _patch(p, nels)
@@ -310,12 +310,20 @@ def test_matrix_with_entries_outside_the_pattern_is_split(p, nels):
     Ko = O.extract_matrix(Mo, A, zd, diag=2.0)
     K = spline.extractMatrix(A, diag=2.0).to_scipy()
     assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
-    # pattern: union of the band (structural product of the pattern part) and the product of the remainder
-    band = O.extract_matrix(Mo, sp.csr_matrix((np.ones(A0.nnz), A0.indices, A0.indptr), shape=A0.shape), [], 1.0)
-    rest = O.extract_matrix(Mo, sp.csr_matrix((np.ones(off_s.nnz), off_s.indices, off_s.indptr), shape=A0.shape), [], 1.0)
-    union = ((abs(band) + abs(rest)) > 0).tocsr()
-    union.sort_indices()
-    assert np.array_equal(K.indptr, union.indptr) and np.array_equal(K.indices, union.indices)
+    # pattern: the structural product of what A stores (round 4: a matrix that LACKS entries of the pattern takes the general
+    # stages -- the split would pad its on-part with stored zeros and K would get entries MatPtAP does not create)
+    K.sort_indices(), Ko.sort_indices()
+    assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices)
+    # with nothing missing the split is taken (the line walks run) and the pattern is again the structural product
+    Af = (A0 + off_s).tocsr()
+    Af.sort_indices()
+    dev.prof_reset()
+    Kf = spline.extractMatrix(Af, diag=2.0).to_scipy()
+    assert dev.prof_get(5)[1] > 0
+    Kfo = O.extract_matrix(Mo, Af, zd, diag=2.0)
+    Kf.sort_indices(), Kfo.sort_indices()
+    assert abs(Kf - Kfo).max() <= 1e-12 * abs(Kfo).max()
+    assert np.array_equal(Kf.indptr, Kfo.indptr) and np.array_equal(Kf.indices, Kfo.indices)
     # the same result with the split switched off (general line kernels on the whole matrix)
     os.environ["TIGAR_PTAP_SPLIT"] = "0"
     try:
