@@ -576,3 +576,44 @@ def test_random_patches_point_evaluations_match_the_reference(T):
             assert Mp.indices[a:b].tolist() == sorted(row), (name, i)
             assert np.array_equal(Mp.data[a:b], np.array([row[c] for c in sorted(row)])), (name, i)
     assert n > 1000
+
+
+def test_no_device_memory_growth_over_repeated_calls(T):
+    """the shell / Newton demos call the path 10^2 - 10^4 times on one ExtractedSpline: handles, plans, the
+    persistent solvers' control blocks and the caching pool must not grow -- device memory in use and the pool's block count
+    are the same after 10 and after 60 rounds of extractMatrix + extractVector + five solvers."""
+    import gc
+    t, B, F, dev = T.t, T.B, T.F, T.dev
+    p, nel = 3, 32
+    gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p, p], [B.uniformKnots(p, 0., 1., nel)] * 2))
+    sp0 = gen.getScalarSpline(0)
+    for k in (0, 1):
+        for side in (0, 1):
+            gen.addZeroDofs(0, sp0.getSideDofs(k, side))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    A = dev.DeviceCSR.from_scipy((F.LaplaceForm().assemble_matrix(spline.V).to_scipy()
+                                  + F.MassForm().assemble_matrix(spline.V).to_scipy()).tocsr())
+    b = dev.DeviceVector(data=np.ones(A.shape[0]))
+
+    def used():
+        gc.collect()
+        dev.sync()
+        free, total = dev.mem_info()[:2]
+        return total - free, dev.pool_stats()
+    marks = []
+    for it in range(61):
+        K = spline.extractMatrix(A, diag=1.0)
+        y = spline.extractVector(b)
+        for m in (("cg", "jacobi"), ("gmres", "jacobi"), ("bicgstab", "jacobi"), ("cg", "chebyshev"), None):
+            if m is None:
+                spline.setSolverOptions(linearSolver=None)
+            else:
+                ks = t.PETScKrylovSolver(*m)
+                ks.parameters["relative_tolerance"] = 1e-8
+                spline.setSolverOptions(linearSolver=ks)
+            u = t.Function(spline.V)
+            spline.solveLinearSystem(K, y, u)
+        del K, y, u
+        if it in (10, 60):
+            marks.append(used())
+    assert marks[0] == marks[1], marks
