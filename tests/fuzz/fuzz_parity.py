@@ -202,6 +202,13 @@ def run_case(case, verbose=False):
         assert np.array_equal(Kf.indptr, Kfo.indptr) and np.array_equal(Kf.indices, Kfo.indices), "pattern of K (assembleMatrix)"
         ef = abs(Kf - Kfo).max() / abs(Kfo).max()
         assert ef <= 1e-12, "values of K (assembleMatrix): %g" % ef
+    # ---- the form-driven vector (assembleVector: the FE vector may be produced slab by slab, tIGAr/common.py:1214-1220)
+    if nf == 1:
+        lf = F.SeparableLoadForm([lambda x: np.sin(2.0 * x) + 0.5] * d, scale=1.7)
+        bf = lf.assemble_vector(V1).get_local()
+        yf = spline.assembleVector(lf, applyBCs=bcs).get_local()
+        yfo = O.extract_vector(Mo, bf, zd, applyBCs=bcs)[idx]
+        assert np.max(np.abs(yf - yfo)) <= 1e-12 * max(1e-300, np.max(np.abs(yfo))), "assembleVector: %g" % np.max(np.abs(yf - yfo))
     # ---- M^T b
     yo = O.extract_vector(Mo, b, zd, applyBCs=bcs)[idx]
     yd = spline.extractVector(b_in, applyBCs=bcs)
