@@ -27,7 +27,12 @@ def problem(case, comm):
         d, p, nel, nF, method = 2, 3, 14, 3, "gmres"
     else:                            # 3-D elasticity, p=2, three fields (ElasticityForm: blocks as Kronecker sums)
         d, p, nel, nF, method = 3, 2, 7, 3, "cg"
-    kv = [B.uniformKnots(p, 0., 1., nel) for _ in range(d)]
+    # (optional overrides, set by the tests for both the single-rank reference and the ranks: degree, element counts per
+    #  direction, periodic directions other than the last)
+    p = int(os.environ.get("TIGAR_TEST_FP", p))
+    nels = [int(v) for v in os.environ["TIGAR_TEST_FNELS"].split(",")] if os.environ.get("TIGAR_TEST_FNELS") else [nel] * d
+    per = set(int(c) for c in os.environ.get("TIGAR_TEST_FPER", ""))
+    kv = [B.uniformKnots(p, 0., 1., nels[k], k in per) for k in range(d)]
     gen = t.EqualOrderSpline(comm, nF, B.ExplicitBSplineControlMesh([p] * d, kv))
     for f in range(nF):
         s0 = gen.getScalarSpline(f)

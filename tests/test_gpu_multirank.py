@@ -194,6 +194,33 @@ def test_unequal_directions_on_several_ranks(tmp_path, p, nels, periodic, world,
 
 @pytest.mark.parametrize("case,world,kind", [("shell2d", 2, "ipc"), ("elasticity3d", 3, "ipc"), ("shell2d", 3, "host")])
 def test_several_fields_on_several_ranks(tmp_path, case, world, kind):
+    _several_fields(tmp_path, case, world, kind, {})
+
+
+@pytest.mark.parametrize("case,world,p,nels,periodic", [
+    ("elasticity3d", 2, 1, (5, 3, 8), ""),            # trilinear, different element counts
+    ("elasticity3d", 3, 2, (3, 6, 9), "0"),           # periodic in x
+    ("elasticity3d", 2, 3, (4, 4, 6), "01"),          # cubic, periodic in x and y
+    ("shell2d", 3, 2, (9, 12), "0"),                  # 2-D three fields, periodic in x
+    ("shell2d", 2, 4, (6, 9), ""),                    # quartic
+])
+def test_several_fields_on_several_ranks_other_shapes(tmp_path, case, world, p, nels, periodic):
+    """the same checks on patches with other degrees, element counts per direction and periodic directions (found by hand
+    after the random single-field multi-rank runs: this combination had no coverage)"""
+    env = {"TIGAR_TEST_FP": str(p), "TIGAR_TEST_FNELS": ",".join(str(n) for n in nels), "TIGAR_TEST_FPER": periodic}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        _several_fields(tmp_path, case, world, "ipc", env)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _several_fields(tmp_path, case, world, kind, env_more):
     """EqualOrderSpline(nFields = 3) split into z-slabs (VERDICT r2 missing #2): a rank owns the dof planes of every field,
     the dofs are interleaved plane by plane so that its rows of K are one contiguous block (localDofIndices() gives the
     reference index of every local dof); K = [M_s^T A_fg M_s] block by block through the scalar slab engine -- an
@@ -213,8 +240,9 @@ def test_several_fields_on_several_ranks(tmp_path, case, world, kind):
     Kref, rref, uref, its = K.to_scipy().tocsr(), rhs.get_local(), u.vector().get_local(), solver.last["iterations"]
     from tigar_amd.launch import spawn_local
     env = {"PYTHONPATH": ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), "TIGAR_COMM": kind, "TIGAR_DEVICE": "0"}
+    env.update(env_more)
     rc = spawn_local(world, [os.path.join(ROOT, "tests", "gpu_rank_worker_fields.py"), str(tmp_path), case], env_extra=env,
-                     port=35011 + 13 * world + len(case))
+                     port=35011 + 13 * world + len(case) + 7 * len(env_more.get("TIGAR_TEST_FNELS", "")))
     assert rc == 0
     parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     n = Kref.shape[0]
