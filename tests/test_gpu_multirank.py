@@ -328,7 +328,11 @@ def test_several_fields_streamed_through_one_gpu():
 
 
 @pytest.mark.parametrize("world,kind,d,p,nel,with_dofs", [(2, "ipc", 2, 2, 12, False), (3, "ipc", 2, 3, 12, True),
-                                                          (2, "host", 3, 2, 8, True)])
+                                                          (2, "host", 3, 2, 8, True),
+                                                          # slabs of 2-3 dof planes: the forms' ghost rows come from beyond
+                                                          # the neighbour (two sweeps along the chain of ranks)
+                                                          (3, "ipc", 3, 2, 6, True), (4, "ipc", 2, 2, 7, False),
+                                                          (3, "host", 2, 3, 8, True)])
 def test_newton_on_several_ranks(tmp_path, capfd, world, kind, d, p, nel, with_dofs):
     """solveNonlinearVariationalProblem with several ranks (VERDICT r3 missing #1; tIGAr/common.py:1304-1348 is MPI-aware:
     ||M^T R|| at :1330 is a global norm, u.assign(u - du) at :1343 works on distributed vectors): u, du and the IGA dofs
@@ -355,7 +359,8 @@ def test_newton_on_several_ranks(tmp_path, capfd, world, kind, d, p, nel, with_d
         for a, b in zip(z["hist"], hist):
             assert abs(a - b) <= 1e-12, (list(z["hist"]), hist)
         assert z["u"].size == r1 - r0                          # rank-local rows only
-        assert np.max(np.abs(z["u"] - uref[r0:r1])) <= 1e-10 * np.max(np.abs(uref))
+        # (a rank of a thin slab may own no FE rows at all)
+        assert r1 == r0 or np.max(np.abs(z["u"] - uref[r0:r1])) <= 1e-10 * np.max(np.abs(uref))
         if with_dofs:
             assert z["dofs"].size == g1 - g0
             assert np.max(np.abs(z["dofs"] - dref[g0:g1])) <= 1e-10 * np.max(np.abs(dref))

@@ -1685,6 +1685,13 @@ class ExtractedSpline(object):
         ranges = split_range(lay.ncp, world)
         own = [lay.slab(a, b)["u_rows"] for (a, b) in ranges]
         need = [lay.slab(a, b)["m_rows"] for (a, b) in ranges]
+        # (a rank of a thin slab may own NO FE rows -- the layout reports (0, 0) -- but its forms still read a window: place
+        #  the empty range where it belongs in the chain, at the end of the rows owned below it)
+        pos = 0
+        for r_ in range(world):
+            if own[r_][1] <= own[r_][0]:
+                own[r_] = (pos, pos)
+            pos = own[r_][1]
         ua, ub = own[rank]
         if vec.size() != ub - ua:
             raise ValueError("ghostedVector: the function does not hold this rank's FE rows")
