@@ -422,6 +422,17 @@ typedef struct {
 int tg_assemble_mapped_matrix(const tg_patch_t *patch, int form, tg_csr_t *out);
 /* L(v) = (f_h, v) with f_h the nodal interpolant of fnodal */
 int tg_assemble_mapped_load(const tg_patch_t *patch, tg_vec_t fnodal, tg_vec_t out);
+/* Row blocks of the same objects, as the z-slab pipeline of extractMatrix / extractVector consumes them (PETSc's row-block
+ * MatPtAP, tIGAr/common.py:1194-1195; the assembled matrix of BASELINE cfg3 would hold 684 GB): rows [row0, row1) = whole
+ * node planes of the LAST direction, global column indices, the element-coupling pattern with its certificate
+ * (tg_tensor_planes then reads no column index).  patch->cp[c] (and fnodal) hold the FE nodes [cp_node0, cp_node0 + n) --
+ * a window that must cover every element touching the rows -- so a rank never needs the control functions outside its
+ * slab.  3-D patches with nq = p + 1 <= 4: sum-factorised element matrices, one wave per element
+ * (csrc/tg_assemble.hip, k_asf3). */
+int tg_assemble_mapped_matrix_rows(const tg_patch_t *patch, int form, int64_t row0, int64_t row1, int64_t cp_node0,
+                                   tg_csr_t *out);
+int tg_assemble_mapped_load_rows(const tg_patch_t *patch, tg_vec_t fnodal, int64_t row0, int64_t row1, int64_t cp_node0,
+                                 tg_vec_t out);
 
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------- */
 int tg_comm_unique_id(char *id128);                          /* ncclGetUniqueId   */

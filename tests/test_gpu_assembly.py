@@ -158,3 +158,203 @@ def test_mapped_assembly_is_bit_reproducible(T):
         if Ko is not None:
             assert abs(runs[0][0] - Ko).max() <= 1e-12 * abs(Ko).max()
             assert np.max(np.abs(runs[0][1] - bo)) <= 1e-13 * np.max(np.abs(bo))
+
+
+# ---- round 5: sum-factorised element kernel (3-D), row blocks, the streamed and the multi-rank path ---------------------
+def _volume_generator(T, p, nels, comm=None):
+    from geom_util import rational_volume
+    from tigar_amd import common as tc
+    kvs, C = rational_volume(p, nels)
+    cm = T.N.NURBSControlMesh([p] * 3, kvs, C)
+    return T.t.EqualOrderSpline(comm if comm is not None else tc.selfcomm, 1, cm), kvs
+
+
+@pytest.mark.parametrize("p,nels", [(1, (3, 2, 4)), (2, (3, 4, 3)), (3, (2, 3, 2)), (3, (1, 1, 1)), (2, (5, 1, 2))])
+def test_sum_factorised_element_kernel_matches_oracle(T, p, nels, monkeypatch):
+    """3-D patches with p + 1 Gauss points per direction take the wave-per-element kernel (k_asf3): against the oracle's
+    plain element loop on a rational volume map, and against the plain O((p+1)^9) kernel it replaces"""
+    gen, kvs = _volume_generator(T, p, nels)
+    g = gen.V.grids[0]
+    uks = [np.asarray(g.vertices[k]) for k in range(3)]
+    cp = [f.vector().get_local() for f in gen.cpFuncs]
+    Mo, Ko, _ = O.mapped_fe_system(uks, p, cp)
+    dcp = [f.vector() for f in gen.cpFuncs]
+    Mf = T.dev.assemble_mapped_matrix(uks, p, dcp, "mass")
+    Kf = T.dev.assemble_mapped_matrix(uks, p, dcp, "laplace")
+    _close(Mf, Mo)
+    _close(Kf, Ko)
+    monkeypatch.setenv("TIGAR_ASM_LEGACY", "1")
+    Kl = T.dev.assemble_mapped_matrix(uks, p, dcp, "laplace").to_scipy()
+    monkeypatch.delenv("TIGAR_ASM_LEGACY")
+    Kf = Kf.to_scipy()
+    assert np.array_equal(Kl.indptr, Kf.indptr) and np.array_equal(Kl.indices, Kf.indices)
+    assert abs(Kl - Kf).max() <= 1e-12 * abs(Kl).max()
+    # bit-reproducible (stored by the first contributor, added colour by colour)
+    K2 = T.dev.assemble_mapped_matrix(uks, p, dcp, "laplace").to_scipy()
+    assert np.array_equal(K2.data.view(np.int64), Kf.data.view(np.int64))
+
+
+@pytest.mark.parametrize("p,nels", [(3, (3, 2, 4)), (2, (3, 3, 5)), (4, (2, 1, 3))])
+def test_row_blocks_with_control_function_windows(T, p, nels):
+    """rows of whole node planes from control functions given on a window of planes only: bit for bit the rows of the
+    whole matrix / vector (p = 4: the plain kernel, which takes the same arguments)"""
+    import scipy.sparse as sps
+    gen, kvs = _volume_generator(T, p, nels)
+    g = gen.V.grids[0]
+    uks = [np.asarray(g.vertices[k]) for k in range(3)]
+    n0, n1, n2 = g.shape()
+    plane = n0 * n1
+    cp = [f.vector().get_local() for f in gen.cpFuncs]
+    fn = np.sin(3.0 * cp[0]) + cp[1]
+    dcp = [f.vector() for f in gen.cpFuncs]
+    whole = {f: T.dev.assemble_mapped_matrix(uks, p, dcp, f).to_scipy() for f in ("mass", "laplace")}
+    bw = T.dev.assemble_mapped_load(uks, p, dcp, T.dev.DeviceVector(data=fn)).get_local()
+    cuts = [0, 1, p, p + 2, 2 * p, n2 - 1, n2]
+    cuts = sorted(set(c for c in cuts if 0 <= c <= n2))
+    parts = {"mass": [], "laplace": []}
+    bparts = []
+    for za, zb in zip(cuts[:-1], cuts[1:]):
+        e0 = za // p - 1 if (za > 0 and za % p == 0) else za // p
+        e1 = min(nels[2], (zb - 1) // p + 1)
+        fa, fb = e0 * p, e1 * p + 1
+        win = [T.dev.DeviceVector(data=c[fa * plane:fb * plane]) for c in cp]
+        for f in parts:
+            parts[f].append(T.dev.assemble_mapped_matrix(uks, p, win, f, row0=za * plane, row1=zb * plane,
+                                                         cp_node0=fa * plane).to_scipy())
+        bparts.append(T.dev.assemble_mapped_load(uks, p, win, T.dev.DeviceVector(data=fn[fa * plane:fb * plane]),
+                                                 row0=za * plane, row1=zb * plane, cp_node0=fa * plane).get_local())
+    for f in parts:
+        S = sps.vstack(parts[f]).tocsr()
+        assert np.array_equal(S.indptr, whole[f].indptr) and np.array_equal(S.indices, whole[f].indices)
+        assert np.array_equal(S.data.view(np.int64), whole[f].data.view(np.int64))
+    assert np.array_equal(np.concatenate(bparts).view(np.int64), bw.view(np.int64))
+    # a window that does not cover the elements of the rows is refused
+    with pytest.raises(T.dev.TigarHipError):
+        T.dev.assemble_mapped_matrix(uks, p, [T.dev.DeviceVector(data=c[:plane]) for c in cp], "mass", row0=0,
+                                     row1=plane * n2, cp_node0=0)
+
+
+def _zero_all_faces(gen):
+    sp0 = gen.getScalarSpline(0)
+    for direction in range(3):
+        for side in (0, 1):
+            gen.addZeroDofs(0, sp0.getSideDofs(direction, side))
+
+
+@pytest.mark.parametrize("p,nels,sub", [(3, (3, 3, 5), 2), (2, (4, 3, 6), 3), (4, (2, 2, 3), 2)])
+def test_mapped_forms_streamed_through_the_slab_engine(T, p, nels, sub, monkeypatch):
+    """assembleMatrix / assembleVector of mapped forms with the operator kept implicit and the patch streamed in
+    sub-slabs of dof planes (what cfg3's size needs): the forms hand out row blocks, the tensor-pattern passes take them
+    on their certificate -- against the oracle's M^T A M and M^T b on the same rational volume"""
+    monkeypatch.setenv("TIGAR_IMPLICIT_M", "1")
+    monkeypatch.setenv("TIGAR_SUB_PLANES", str(sub))
+    gen, kvs = _volume_generator(T, p, nels)
+    _zero_all_faces(gen)
+    assert getattr(gen.M, "is_implicit", False)
+    spline = T.t.ExtractedSpline(gen, 2 * p, comm=gen.comm)
+    T.dev.prof_reset()
+    K = spline.assembleMatrix(T.F.LaplaceForm(geometry=gen), diag=2.0).to_scipy()
+    walks = T.dev.prof_get(5)[1]
+    certified = T.dev.prof_get(3)[1]
+    b = spline.assembleVector(T.F.NodalLoadForm(lambda x: np.sin(x[:, 0]) + x[:, 1] * x[:, 2], gen)).get_local()
+    g = gen.V.grids[0]
+    uks = [np.asarray(g.vertices[k]) for k in range(3)]
+    cp = [f.vector().get_local() for f in gen.cpFuncs]
+    X = np.stack([cp[i] / cp[3] for i in range(3)], axis=1)
+    _, Ko, bo = O.mapped_fe_system(uks, p, cp, fnodal=np.sin(X[:, 0]) + X[:, 1] * X[:, 2])
+    s = O.BSpline([p] * 3, [list(k) for k in kvs])
+    Mo = O.generate_M_tensor(s)
+    zd = [int(i) for i in gen.zeroDofsArray()]
+    Kr = O.extract_matrix(Mo, Ko, zd, diag=2.0)
+    br = O.extract_vector(Mo, bo, zd)
+    assert np.array_equal(K.indptr, Kr.indptr) and np.array_equal(K.indices, Kr.indices)
+    assert abs(K - Kr).max() <= 1e-12 * abs(Kr).max()
+    assert np.max(np.abs(b - br)) <= 1e-12 * np.max(np.abs(br))
+    if p <= 4:
+        assert walks > 0 and certified > 0       # the line walks ran, on the certificate of the assembled row blocks
+
+
+def test_poisson_on_a_nurbs_volume_converges_3d(T, monkeypatch):
+    """demos/poisson/poisson-nurbs.py in 3-D without FEniCS: thick quarter cylinder (exact rational geometry, degree 2),
+    u = (r-1)(2-r) sin(2 theta) sin(pi z), zero on the whole boundary; streamed in sub-slabs.  Max nodal error drops
+    at the optimal rate (p + 1 = 3)."""
+    from geom_util import quarter_cylinder_shell
+    from tigar_amd import common as tc
+    monkeypatch.setenv("TIGAR_IMPLICIT_M", "1")
+    monkeypatch.setenv("TIGAR_SUB_PLANES", "4")
+
+    def exact(x):
+        r, th = np.hypot(x[:, 0], x[:, 1]), np.arctan2(x[:, 1], x[:, 0])
+        return (r - 1.0) * (2.0 - r) * np.sin(2.0 * th) * np.sin(np.pi * x[:, 2])
+
+    def rhs(x):   # -(u_rr + u_r/r + u_thth/r^2 + u_zz)
+        r, th = np.hypot(x[:, 0], x[:, 1]), np.arctan2(x[:, 1], x[:, 0])
+        R = (r - 1.0) * (2.0 - r)
+        lap_r = -2.0 + (3.0 - 2.0 * r) / r - 4.0 * R / r ** 2
+        return -(lap_r - np.pi ** 2 * R) * np.sin(2.0 * th) * np.sin(np.pi * x[:, 2])
+
+    errs = []
+    for nel in (3, 6, 12):
+        kvs, C = quarter_cylinder_shell(nel)
+        gen = T.t.EqualOrderSpline(tc.selfcomm, 1, T.N.NURBSControlMesh([2, 2, 2], kvs, C))
+        _zero_all_faces(gen)
+        spline = T.t.ExtractedSpline(gen, 4, comm=tc.selfcomm)
+        solver = T.t.PETScKrylovSolver("cg", "jacobi")
+        solver.parameters["relative_tolerance"] = 1e-12
+        spline.setSolverOptions(linearSolver=solver)
+        u = T.t.Function(spline.V)
+        spline.solveLinearVariationalProblem(T.F.Equation(T.F.LaplaceForm(geometry=gen), T.F.NodalLoadForm(rhs, gen)), u)
+        cp = [f.vector().get_local() for f in gen.cpFuncs]
+        X = np.stack([cp[i] / cp[3] for i in range(3)], axis=1)
+        errs.append(np.max(np.abs(u.vector().get_local() - exact(X))))
+    assert errs[1] < errs[0] / 5.0 and errs[2] < errs[1] / 5.0
+    assert errs[2] < 5e-4
+
+
+@pytest.mark.parametrize("kind,p,nels,world,comm", [("volume", 3, (3, 2, 6), 2, "ipc"), ("volume", 2, (3, 3, 7), 3, "host"),
+                                                    ("identity", 3, (2, 3, 5), 2, "ipc")])
+def test_mapped_forms_on_several_ranks(tmp_path, kind, p, nels, world, comm):
+    """the patch in z-slabs over 2-3 ranks (sharing the one GPU of the test box): every rank assembles the row blocks of
+    its slab from the control functions on its own window of FE planes; rows of K and M^T b, the solution and the
+    iteration count against the single-rank run and -- K, M^T b -- against the oracle"""
+    import os
+    import sys
+    import scipy.sparse as sps
+    from tigar_amd.launch import spawn_local
+    from tigar_amd import common as tc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import gpu_rank_worker_mapped as W
+    gen, spline, K, rhs, U, u, its = W.run(tc.selfcomm, kind, p, list(nels))
+    Ks, rhs, U, u = K.to_scipy(), rhs.get_local(), U.get_local(), u.vector().get_local()
+    # the single-rank run against the oracle
+    g = gen.V.grids[0]
+    uks = [np.asarray(g.vertices[k]) for k in range(3)]
+    cp = [f.vector().get_local() for f in gen.cpFuncs]
+    X = np.stack([cp[i] / cp[3] for i in range(3)], axis=1)
+    _, Ko, bo = O.mapped_fe_system(uks, p, cp, fnodal=W.load(X))
+    s = O.BSpline([p] * 3, [list(sp1.knots) for sp1 in gen.getScalarSpline(0).splines])
+    Mo = O.generate_M_tensor(s)
+    zd = [int(i) for i in gen.zeroDofsArray()]
+    Kr = O.extract_matrix(Mo, Ko, zd, diag=1.5)
+    assert np.array_equal(Ks.indptr, Kr.indptr) and np.array_equal(Ks.indices, Kr.indices)
+    assert abs(Ks - Kr).max() <= 1e-12 * abs(Kr).max()
+    assert np.max(np.abs(rhs - O.extract_vector(Mo, bo, zd))) <= 1e-12 * np.max(np.abs(rhs))
+    env = {"PYTHONPATH": root + os.pathsep + os.environ.get("PYTHONPATH", ""), "TIGAR_COMM": comm, "TIGAR_DEVICE": "0"}
+    rc = spawn_local(world, [os.path.join(root, "tests", "gpu_rank_worker_mapped.py"), str(tmp_path), kind, str(p),
+                             ",".join(str(n) for n in nels)], env_extra=env, port=29500 + 41 * (p * 10 + world) + len(kind))
+    assert rc == 0, "a rank failed"
+    cover = np.zeros(Ks.shape[0], dtype=int)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        g0, g1, r0, r1 = [int(v) for v in z["g"]]
+        Kl = sps.csr_matrix((z["K_data"], z["K_indices"], z["K_indptr"]), shape=(g1 - g0, Ks.shape[1]))
+        assert np.array_equal(Kl.indptr, Ks[g0:g1].indptr) and np.array_equal(Kl.indices, Ks[g0:g1].indices)
+        assert abs(Kl - Ks[g0:g1]).max() <= 1e-12 * abs(Ks).max()
+        assert np.max(np.abs(z["rhs"] - rhs[g0:g1])) <= 1e-12 * np.max(np.abs(rhs))
+        assert np.max(np.abs(z["U"] - U[g0:g1])) <= 1e-8 * np.max(np.abs(U))
+        if r1 > r0:
+            assert np.max(np.abs(z["u"] - u[r0:r1])) <= 1e-8 * np.max(np.abs(u))
+        assert abs(int(z["its"][0]) - its) <= 1
+        cover[g0:g1] += 1
+    assert np.all(cover == 1)

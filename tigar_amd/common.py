@@ -526,6 +526,8 @@ class AbstractExtractionGenerator(object):
             elif self._kron is not None and self.M is self.M_control:
                 kx_c = self._kron
         separable = kx_c is not None
+        self._cp_source = {"kx": kx_c if separable else (self.M_control.kx if getattr(self.M_control, "is_implicit", False) else None),
+                           "separable": separable, "P": []}
         for i in range(self.nsd + 1):
             if separable:
                 # (M_z g_z) (x) (M_y g_y) (x) (M_x g_x) -- one write pass over the FE rows this rank owns
@@ -542,6 +544,7 @@ class AbstractExtractionGenerator(object):
                 if P is None:
                     P = self._homogeneousCoordinateArray()
                 Pi = DeviceVector(data=P[:, i])
+            self._cp_source["P"].append(Pi)
             if self._slab_engine is not None:
                 f = Function(self.V_control, self._slab_engine.mine["u_rows"])
                 f._vec = self._slab_engine._prolong_tensor(Pi, 0)
@@ -550,6 +553,48 @@ class AbstractExtractionGenerator(object):
                 self.M_control.mult(Pi, f.vector())               # stays in HBM
             self.cpFuncs += [f]
         self.zeroDofs = []
+
+    def controlFunctionWindow(self, fa, fb):
+        """The nsd+1 control functions cpFuncs[i] = M_control P[:, i] (tIGAr/common.py:367-380) on the FE node planes
+        [fa, fb) of the last parametric direction, as DeviceVectors -- what the forms of a rank read when they assemble a
+        block of FE rows on a mapped patch.  Evaluated from the control net (replicated on every rank) through the rows
+        of M_control that belong to the window: no rank needs another rank's part of the control functions.  The last
+        two windows are kept (the matrix and the vector form of one sub-slab ask for the same one)."""
+        key = (int(fa), int(fb))
+        cache = self.__dict__.setdefault("_cp_windows", [])
+        for k_, v_ in cache:
+            if k_ == key:
+                return v_
+        src = self.__dict__.get("_cp_source") or {}
+        kx = src.get("kx")
+        if kx is None:
+            raise NotImplementedError("control functions on a window of FE planes: tensor-product control mesh")
+        pf = int(numpy.prod(kx.nfe[:-1], dtype=numpy.int64)) if kx.d > 1 else 1
+        out = []
+        if src["separable"]:
+            cm = self.getControlMesh()
+            for i in range(self.nsd + 1):
+                facs = cm.homogeneousCoordinateFactors(i)
+                fe1d = [kx.M1[k] @ numpy.asarray(facs[k], dtype=numpy.float64) for k in range(kx.d)]
+                out.append(_dev.vec_tensor3(fe1d, 1.0, key[0] * pf, key[1] * pf))
+        else:
+            # rows [fa, fb) of the last 1-D factor name the dof planes [k_lo, k_hi): only those planes of the control net
+            # go through the plane-local passes
+            Mz = kx.M1[-1][key[0]:key[1]].tocsr()
+            k_lo, k_hi = int(Mz.indices.min()), int(Mz.indices.max()) + 1
+            pd = int(numpy.prod(kx.ncp[:-1], dtype=numpy.int64)) if kx.d > 1 else 1
+            for Pi in src["P"]:
+                x = DeviceVector((k_hi - k_lo) * pd)
+                _dev.vec_copy_range(x, 0, Pi, k_lo * pd, (k_hi - k_lo) * pd)
+                dims = list(kx.ncp[:-1]) + [k_hi - k_lo]
+                t = x
+                for k in range(kx.d - 1):
+                    t = _dev.tensor_apply_1d(t, dims, k, kx.M1[k])
+                    dims[k] = kx.nfe[k]
+                out.append(_dev.tensor_apply_1d(t, dims, kx.d - 1, Mz, col_shift=k_lo))
+        cache.append((key, out))
+        del cache[:-2]
+        return out
 
     def _fieldGrid(self, field, dg):
         """Node grid of one scalar field (degree getDegree(field) on the shared knot mesh)."""
@@ -1304,6 +1349,7 @@ class ExtractedSpline(object):
         self.M_control = generator.M_control
         self.comm = generator.getComm()
         self._generator_engine = getattr(generator, "_slab_engine", None)
+        self._generator = generator
         self._kron = getattr(generator, "_kron", None)
         self._kron_scalar = getattr(generator, "_kron_scalar", None)
         self.zeroDofs = generator.zeroDofsArray().astype(INDEX_TYPE)

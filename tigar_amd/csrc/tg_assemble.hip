@@ -35,8 +35,11 @@ struct tg_asm_args {
   double *val;
   const double *fnod;          // load: nodal values
   double *bout;
-  int colour[3];               // this launch: the elements with el[k] = colour[k] (mod 2) -- they share no node
-  int ncol[3];                 // ... of which there are ncol[k] per direction
+  int efirst[3];               // this launch: the elements el[k] = efirst[k] + 2 i, i < ncol[k] -- one parity per direction,
+  int ncol[3];                 // so they share no node (the colour of the launch = the parities of efirst)
+  // row blocks (the z-slab pipeline asks for the FE rows of a range of node planes of the LAST direction):
+  int64_t row0, row1;          // rows written: [row0, row1); rowptr / val / bout are those of the block (row - row0)
+  int64_t cp_node0;            // the control functions (and fnod) hold the nodes from cp_node0 on
 };
 
 __device__ __forceinline__ void tg_sym_inverse(int d, const double *g, double *gi, double *det) {
@@ -96,13 +99,13 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
   // (global floating-point atomics added the contributions of the elements around a node in arrival order)
   int64_t e = blockIdx.x;
   int el[3] = {0, 0, 0};
-  el[0] = 2 * (int)(e % P.ncol[0]) + P.colour[0];
+  el[0] = 2 * (int)(e % P.ncol[0]) + P.efirst[0];
   e /= P.ncol[0];
   if (d > 1) {
-    el[1] = 2 * (int)(e % P.ncol[1]) + P.colour[1];
+    el[1] = 2 * (int)(e % P.ncol[1]) + P.efirst[1];
     e /= P.ncol[1];
   }
-  if (d > 2) el[2] = 2 * (int)e + P.colour[2];
+  if (d > 2) el[2] = 2 * (int)e + P.efirst[2];
   double h[3] = {1.0, 1.0, 1.0};
   for (int k = 0; k < d; k++) h[k] = P.verts[k][el[k] + 1] - P.verts[k][el[k]];
   for (int s = tid; s < 2 * p1 * nq1 + nq1; s += nt) tl[s] = P.tab[s];
@@ -110,8 +113,8 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
     const int a0 = a % p1, a1 = (a / p1) % p1, a2 = a / (p1 * p1);
     const int64_t node = (int64_t)(el[0] * P.p + a0) + (int64_t)P.n[0] * ((d > 1 ? el[1] * P.p + a1 : 0) +
                                                                          (int64_t)P.n[1] * (d > 2 ? el[2] * P.p + a2 : 0));
-    for (int c = 0; c <= P.nsd; c++) cpl[c * nloc + a] = P.cp[c][node];
-    if (P.form == 2) fl[a] = P.fnod[node];
+    for (int c = 0; c <= P.nsd; c++) cpl[c * nloc + a] = P.cp[c][node - P.cp_node0];
+    if (P.form == 2) fl[a] = P.fnod[node - P.cp_node0];
   }
   __syncthreads();
   // quadrature-point data
@@ -166,7 +169,7 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
       }
       const int64_t node = (int64_t)(el[0] * P.p + ak[0]) +
                            (int64_t)P.n[0] * ((d > 1 ? el[1] * P.p + ak[1] : 0) + (int64_t)P.n[1] * (d > 2 ? el[2] * P.p + ak[2] : 0));
-      P.bout[node] += acc;
+      if (node >= P.row0 && node < P.row1) P.bout[node - P.row0] += acc;
     }
     return;
   }
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
       pos += pstride * (c - lo);
       pstride *= width;
     }
-    P.val[P.rowptr[row] + pos] += acc;
+    if (row >= P.row0 && row < P.row1) P.val[P.rowptr[row - P.row0] + pos] += acc;
   }
 }
 
@@ -239,7 +242,370 @@ static void tg_gauss01(int n, std::vector<double> &x, std::vector<double> &w) {
   }
 }
 
-static int tg_assemble_common(const tg_patch_t *pt, int form, tg_csr_t *mout, tg_vec_t fnod, tg_vec_t bout) {
+
+// ------------------------------------------------------------------------------------------------------
+// Sum-factorised element matrices of 3-D patches (round 5; SURVEY.md 8f-1: "cfg3 can be fused: element matrices never
+// leave LDS" needs an element kernel that is not O((p+1)^(3d)) first).
+//
+//   A_e[a][b] = sum_q sum_km  d_k phi_a(q) G_km(q) d_m phi_b(q),     G = w_q sqrt(det g) g^-1  (reference coordinates
+//   of the element: DF, g and the gradients of the Lagrange functions all refer to xi_hat in [0,1]^3, so no element
+//   size appears -- the chain rule holds in any parametrisation, tIGAr/calculusUtils.py:56-70)
+//
+// with phi_a(q) = l[a0][q0] l[a1][q1] l[a2][q2]: one WAVE per element (p = 3; two elements per wave at p = 2, eight at
+// p = 1), nq = p + 1 Gauss points per direction.
+//   phase 0  lane = quadrature point: control functions and their xi_hat-gradients by three 1-D contractions through the
+//            wave's LDS area (cross-lane), quotient rule, metric, w sqrt(det g) g^-1 -> LDS (6 + 1 doubles per point);
+//   phase 1  lane = COLUMN b of the element matrix, the 64 rows in registers:  X_k(q) = sum_m G_km(q) d_m phi_b(q)
+//            (G: LDS broadcast; phi_b: lane constants), then the three contractions with the WAVE-UNIFORM 1-D tables
+//            (scalar registers) pencil by pencil -- Y[a0] over q0, Z[a0][a1] over q1, acc[a0][a1][a2] over q2 -- with the
+//            derivative index merged as soon as two terms share their remaining tables: 2.9e3 fused multiply-adds per
+//            lane and element (184e3 per element against 2.4e6 of the plain triple loop), no cross-lane traffic;
+//   phase 2  row a of the element leaves as ONE store of the wave: the 64 columns are contiguous in the CSR row of an
+//            element-interior node (512 B), runs of p + 1 otherwise; positions in closed form.
+// Entries that several elements contribute to (both nodes on a shared face) are STORED by the contributor with even
+// index in every shared direction and ADDED by the others; the launches go colour by colour (parities of the element
+// index) in ascending order, so the storing element always comes first, no two elements of a launch touch one entry and
+// the sum is formed in a fixed order: bit-reproducible, no memset, one pass over 83 % of the entries.
+typedef const double __attribute__((address_space(4))) *tg_cdp4;
+typedef double __attribute__((address_space(1))) *tg_gdp1;
+
+struct tg_asf_args {
+  int nel[3], n[3];
+  const double *cp[4];       // the four homogeneous control functions on the nodes from cp_node0 on
+  int64_t cp_node0;
+  const double *tab;         // l[a][q] | dl[a][q] | w[q]   (p+1 points per direction)
+  double *val;               // values of the row block
+  int64_t base;              // position of the first entry of FE plane za in the whole matrix (subtracted)
+  int za, zb;                // FE planes of the last direction whose rows are written
+  int efirst[3], ncol[3];
+  int ngx;                   // groups of EPW elements per line of direction 0
+  int64_t ngroups;
+};
+
+__device__ __forceinline__ void tg_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#define TG_ASF_NW 4          // waves per workgroup (each works on its own elements)
+
+template <int P1, int EPW, int FORM>
+__global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3(tg_asf_args A) {
+  constexpr int P = P1 - 1, NL = P1 * P1 * P1, LPE = 64 / EPW, PP = P1 * P1;
+  static_assert(NL <= LPE, "an element needs a lane per local node");
+  __shared__ __attribute__((aligned(16))) double s_tab[2 * PP + P1];
+  __shared__ __attribute__((aligned(16))) double s_w[TG_ASF_NW][24 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int s = tid; s < 2 * PP + P1; s += 64 * TG_ASF_NW) s_tab[s] = A.tab[s];
+  __syncthreads();
+  const int64_t grp = (int64_t)blockIdx.x * TG_ASF_NW + wv;
+  if (grp >= A.ngroups) return;
+  const double *TL = s_tab, *TD = s_tab + PP, *TW = s_tab + 2 * PP;
+  tg_cdp4 UL = (tg_cdp4)A.tab, UD = (tg_cdp4)A.tab + PP;
+  double *W = s_w[wv];
+  const int es = lane / LPE, li = lane - es * LPE, eb = es * LPE;
+  const bool active = li < NL;
+  const int x0 = li % P1, x1 = (li / P1) % P1, x2 = (li / PP) % P1;
+  const int gx = (int)(grp % A.ngx);
+  const int64_t rest = grp / A.ngx;
+  const int i1 = (int)(rest % A.ncol[1]), i2 = (int)(rest / A.ncol[1]);
+  const int i0 = gx * EPW + es;
+  const bool evalid = i0 < A.ncol[0];
+  const int e0 = A.efirst[0] + 2 * (evalid ? i0 : A.ncol[0] - 1), e1 = A.efirst[1] + 2 * i1, e2 = A.efirst[2] + 2 * i2;
+
+  // ---- phase 0 ----------------------------------------------------------------------------------------------
+  if (active) {
+    const int64_t node = (int64_t)(e0 * P + x0) + (int64_t)A.n[0] * ((e1 * P + x1) + (int64_t)A.n[1] * (e2 * P + x2)) - A.cp_node0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) W[c * 64 + lane] = A.cp[c][node];
+  }
+  tg_wave_sync();
+  if (active) {        // lane (q0, a1, a2): contraction over a0
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      double vl = 0.0, vd = 0.0;
+#pragma unroll
+      for (int a = 0; a < P1; a++) {
+        const double v = W[c * 64 + eb + a + P1 * (x1 + P1 * x2)];
+        vl = fma(TL[a * P1 + x0], v, vl);
+        vd = fma(TD[a * P1 + x0], v, vd);
+      }
+      W[256 + c * 64 + lane] = vl;
+      W[256 + (4 + c) * 64 + lane] = vd;
+    }
+  }
+  tg_wave_sync();
+  if (active) {        // lane (q0, q1, a2): contraction over a1
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      double ll = 0.0, dl = 0.0, ld = 0.0;
+#pragma unroll
+      for (int a = 0; a < P1; a++) {
+        const double vl = W[256 + c * 64 + eb + x0 + P1 * (a + P1 * x2)];
+        const double vd = W[256 + (4 + c) * 64 + eb + x0 + P1 * (a + P1 * x2)];
+        const double tl = TL[a * P1 + x1], td = TD[a * P1 + x1];
+        ll = fma(tl, vl, ll);
+        dl = fma(tl, vd, dl);
+        ld = fma(td, vl, ld);
+      }
+      W[768 + c * 64 + lane] = ll;
+      W[768 + (4 + c) * 64 + lane] = dl;
+      W[768 + (8 + c) * 64 + lane] = ld;
+    }
+  }
+  tg_wave_sync();
+  double G[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (active) {        // lane (q0, q1, q2): contraction over a2, then the metric
+    double N[4], dN[4][3];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      double v = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
+#pragma unroll
+      for (int a = 0; a < P1; a++) {
+        const double ll = W[768 + c * 64 + eb + x0 + P1 * (x1 + P1 * a)];
+        const double dl = W[768 + (4 + c) * 64 + eb + x0 + P1 * (x1 + P1 * a)];
+        const double ld = W[768 + (8 + c) * 64 + eb + x0 + P1 * (x1 + P1 * a)];
+        const double tl = TL[a * P1 + x2], td = TD[a * P1 + x2];
+        v = fma(tl, ll, v);
+        d0 = fma(tl, dl, d0);
+        d1 = fma(tl, ld, d1);
+        d2 = fma(td, ll, d2);
+      }
+      N[c] = v;
+      dN[c][0] = d0;
+      dN[c][1] = d1;
+      dN[c][2] = d2;
+    }
+    const double Wt = N[3];
+    double g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      double df[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) df[k] = (dN[i][k] * Wt - N[i] * dN[3][k]) / (Wt * Wt);
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int m = 0; m < 3; m++) g[k * 3 + m] += df[k] * df[m];
+    }
+    double gi[9], det;
+    tg_sym_inverse(3, g, gi, &det);
+    const double s = TW[x0] * TW[x1] * TW[x2] * sqrt(fabs(det));
+    G[0] = s * gi[0];
+    G[1] = s * gi[1];
+    G[2] = s * gi[2];
+    G[3] = s * gi[4];
+    G[4] = s * gi[5];
+    G[5] = s * gi[8];
+    G[6] = s;
+  }
+  tg_wave_sync();      // (the area of the nodal values and of the first contraction is free: nobody reads it any more)
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 7; j++) W[(eb + li) * 8 + j] = G[j];
+  }
+  tg_wave_sync();
+
+  // ---- phase 1: lane = column b = (x0, x1, x2) -----------------------------------------------------------------
+  double acc[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) acc[i] = 0.0;
+  double l0[P1], d0[P1];
+#pragma unroll
+  for (int q = 0; q < P1; q++) {
+    l0[q] = TL[x0 * P1 + q];
+    d0[q] = TD[x0 * P1 + q];
+  }
+#pragma unroll
+  for (int q2 = 0; q2 < P1; q2++) {
+    const double l2q = TL[x2 * P1 + q2], d2q = TD[x2 * P1 + q2];
+    double Zl[PP], Zd[PP];
+#pragma unroll
+    for (int i = 0; i < PP; i++) Zl[i] = Zd[i] = 0.0;
+#pragma unroll
+    for (int q1 = 0; q1 < P1; q1++) {
+      const double l1q = TL[x1 * P1 + q1], d1q = TD[x1 * P1 + q1];
+      if (FORM == 1) {
+        const double mll = l1q * l2q, mdl = d1q * l2q, mld = l1q * d2q;
+        double Y0[P1], Y1[P1], Y2[P1];
+#pragma unroll
+        for (int a = 0; a < P1; a++) Y0[a] = Y1[a] = Y2[a] = 0.0;
+#pragma unroll
+        for (int q0 = 0; q0 < P1; q0++) {
+          const double *Gq = W + (eb + q0 + P1 * (q1 + P1 * q2)) * 8;
+          const double f0 = d0[q0] * mll, f1 = l0[q0] * mdl, f2 = l0[q0] * mld;
+          const double X0 = fma(Gq[2], f2, fma(Gq[1], f1, Gq[0] * f0));
+          const double X1 = fma(Gq[4], f2, fma(Gq[3], f1, Gq[1] * f0));
+          const double X2 = fma(Gq[5], f2, fma(Gq[4], f1, Gq[2] * f0));
+#pragma unroll
+          for (int a = 0; a < P1; a++) {
+            Y0[a] = fma(UD[a * P1 + q0], X0, Y0[a]);
+            Y1[a] = fma(UL[a * P1 + q0], X1, Y1[a]);
+            Y2[a] = fma(UL[a * P1 + q0], X2, Y2[a]);
+          }
+        }
+#pragma unroll
+        for (int a1 = 0; a1 < P1; a1++)
+#pragma unroll
+          for (int a0 = 0; a0 < P1; a0++) {
+            Zl[a0 + P1 * a1] = fma(UD[a1 * P1 + q1], Y1[a0], fma(UL[a1 * P1 + q1], Y0[a0], Zl[a0 + P1 * a1]));
+            Zd[a0 + P1 * a1] = fma(UL[a1 * P1 + q1], Y2[a0], Zd[a0 + P1 * a1]);
+          }
+      } else {
+        const double mll = l1q * l2q;
+        double Y0[P1];
+#pragma unroll
+        for (int a = 0; a < P1; a++) Y0[a] = 0.0;
+#pragma unroll
+        for (int q0 = 0; q0 < P1; q0++) {
+          const double X0 = W[(eb + q0 + P1 * (q1 + P1 * q2)) * 8 + 6] * (l0[q0] * mll);
+#pragma unroll
+          for (int a = 0; a < P1; a++) Y0[a] = fma(UL[a * P1 + q0], X0, Y0[a]);
+        }
+#pragma unroll
+        for (int a1 = 0; a1 < P1; a1++)
+#pragma unroll
+          for (int a0 = 0; a0 < P1; a0++) Zl[a0 + P1 * a1] = fma(UL[a1 * P1 + q1], Y0[a0], Zl[a0 + P1 * a1]);
+      }
+    }
+#pragma unroll
+    for (int a2 = 0; a2 < P1; a2++)
+#pragma unroll
+      for (int i = 0; i < PP; i++) {
+        if (FORM == 1)
+          acc[i + PP * a2] = fma(UD[a2 * P1 + q2], Zd[i], fma(UL[a2 * P1 + q2], Zl[i], acc[i + PP * a2]));
+        else
+          acc[i + PP * a2] = fma(UL[a2 * P1 + q2], Zl[i], acc[i + PP * a2]);
+      }
+  }
+
+  // ---- phase 2: the rows of the element, one store of the wave per row ---------------------------------------------
+  // 1-D row data of node r = P e + a: n = row length, o = position of the element's first column in the row,
+  // rps = entries of the 1-D rows before r; T = entries of all 1-D rows
+  const int64_t T0 = (int64_t)P1 * A.n[0] + (int64_t)P * (A.nel[0] - 1), T1 = (int64_t)P1 * A.n[1] + (int64_t)P * (A.nel[1] - 1);
+  const int par0 = e0 & 1, par1 = e1 & 1, par2 = e2 & 1;
+#pragma unroll
+  for (int a2 = 0; a2 < P1; a2++) {
+    const int r2 = P * e2 + a2;
+    if (r2 < A.za || r2 >= A.zb) continue;                        // (wave-uniform)
+    const bool v2 = (a2 == 0 && e2 > 0) || (a2 == P && e2 < A.nel[2] - 1);
+    const int n2 = v2 ? 2 * P + 1 : P1, o2 = (a2 == 0 && e2 > 0) ? P : 0;
+    const int64_t rps2 = (int64_t)P1 * r2 + (a2 > 0 ? (int64_t)P * e2 : (e2 > 0 ? (int64_t)P * (e2 - 1) : 0));
+    const bool add2 = v2 && par2 && x2 == a2;
+#pragma unroll
+    for (int a1 = 0; a1 < P1; a1++) {
+      const int r1 = P * e1 + a1;
+      const bool v1 = (a1 == 0 && e1 > 0) || (a1 == P && e1 < A.nel[1] - 1);
+      const int n1 = v1 ? 2 * P + 1 : P1, o1 = (a1 == 0 && e1 > 0) ? P : 0;
+      const int64_t rps1 = (int64_t)P1 * r1 + (a1 > 0 ? (int64_t)P * e1 : (e1 > 0 ? (int64_t)P * (e1 - 1) : 0));
+      const bool add1 = v1 && par1 && x1 == a1;
+#pragma unroll
+      for (int a0 = 0; a0 < P1; a0++) {
+        const int r0 = P * e0 + a0;                               // (per lane when EPW > 1)
+        const bool v0 = (a0 == 0 && e0 > 0) || (a0 == P && e0 < A.nel[0] - 1);
+        const int n0 = v0 ? 2 * P + 1 : P1, o0 = (a0 == 0 && e0 > 0) ? P : 0;
+        const int64_t rps0 = (int64_t)P1 * r0 + (a0 > 0 ? (int64_t)P * e0 : (e0 > 0 ? (int64_t)P * (e0 - 1) : 0));
+        const bool add0 = v0 && par0 && x0 == a0;
+        const int64_t R = T0 * T1 * rps2 - A.base + (int64_t)n2 * (T0 * rps1 + (int64_t)n1 * rps0);
+        const int64_t pos = (int64_t)((x2 + o2) * n1 + (x1 + o1)) * n0 + (x0 + o0);
+        const double v = acc[a0 + P1 * (a1 + P1 * a2)];
+        if (active && evalid) {
+          double *dst = A.val + R + pos;
+          if (add0 || add1 || add2)
+            __builtin_amdgcn_global_atomic_fadd_f64((tg_gdp1)dst, v);   // (one contributor per launch: an ordered sum)
+          else
+            *dst = v;
+        }
+      }
+    }
+  }
+}
+
+static inline int64_t tg_rps_host(int p, int a) { return (int64_t)(p + 1) * a + (a > 0 ? (int64_t)p * ((a - 1) / p) : 0); }
+
+template <int P1, int EPW>
+static void tg_asf_launch(int form, const tg_asf_args &A, unsigned nblk) {
+  if (form == 1)
+    hipLaunchKernelGGL((k_asf3<P1, EPW, 1>), dim3(nblk), dim3(64 * TG_ASF_NW), 0, g_tg.stream, A);
+  else
+    hipLaunchKernelGGL((k_asf3<P1, EPW, 0>), dim3(nblk), dim3(64 * TG_ASF_NW), 0, g_tg.stream, A);
+}
+
+// reference-element tables l[a][q] | dl[a][q] | w[q]: equispaced Lagrange nodes a/p at the Gauss points
+static void tg_asm_tables(int p, int nq, std::vector<double> &tab) {
+  const int p1 = p + 1;
+  std::vector<double> gx, gw;
+  tg_gauss01(nq, gx, gw);
+  tab.assign(2 * (size_t)p1 * nq + nq, 0.0);
+  for (int a = 0; a < p1; a++)
+    for (int q = 0; q < nq; q++) {
+      const double t = gx[q];
+      double l = 1.0, dl = 0.0;
+      for (int m = 0; m < p1; m++)
+        if (m != a) l *= (t - (double)m / p) / ((double)a / p - (double)m / p);
+      for (int m = 0; m < p1; m++) {
+        if (m == a) continue;
+        double term = 1.0 / ((double)a / p - (double)m / p);
+        for (int r = 0; r < p1; r++)
+          if (r != a && r != m) term *= (t - (double)r / p) / ((double)a / p - (double)r / p);
+        dl += term;
+      }
+      tab[(size_t)a * nq + q] = l;
+      tab[(size_t)p1 * nq + (size_t)a * nq + q] = dl;
+    }
+  for (int q = 0; q < nq; q++) tab[2 * (size_t)p1 * nq + q] = gw[q];
+}
+
+// Device copies of the small per-call tables (element vertices, reference-element tables) of the last patch description: the
+// z-slab pipeline calls once per sub-slab with the same patch, and the uploads with the wait that keeps the host arrays
+// alive stood between the kernels of consecutive sub-slabs.
+struct tg_asm_cache_t {
+  int d = 0, p = 0, nq = 0, nverts[3] = {0, 0, 0};
+  std::vector<double> hverts[3];
+  double *verts[3] = {nullptr, nullptr, nullptr};
+  double *tab = nullptr;
+};
+static tg_asm_cache_t g_asm_cache;
+
+void tg_asm_cache_clear(void) {
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  for (int k = 0; k < 3; k++) {
+    tg_dfree(g_asm_cache.verts[k]);
+    g_asm_cache.verts[k] = nullptr;
+  }
+  tg_dfree(g_asm_cache.tab);
+  g_asm_cache = tg_asm_cache_t();
+}
+
+static int tg_asm_cache_get(const tg_patch_t *pt) {
+  tg_asm_cache_t &C = g_asm_cache;
+  bool same = C.d == pt->d && C.p == pt->p && C.nq == pt->nq && C.tab;
+  for (int k = 0; k < pt->d && same; k++)
+    same = C.nverts[k] == pt->nverts[k] && memcmp(C.hverts[k].data(), pt->verts[k], sizeof(double) * pt->nverts[k]) == 0;
+  if (same) return 0;
+  tg_asm_cache_clear();
+  C.d = pt->d;
+  C.p = pt->p;
+  C.nq = pt->nq;
+  for (int k = 0; k < pt->d; k++) {
+    C.nverts[k] = pt->nverts[k];
+    C.hverts[k].assign(pt->verts[k], pt->verts[k] + pt->nverts[k]);
+    TG_TRY(tg_dmalloc(&C.verts[k], pt->nverts[k]));
+    TG_CHECK_HIP(hipMemcpyAsync(C.verts[k], C.hverts[k].data(), pt->nverts[k] * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
+  }
+  std::vector<double> tab;
+  tg_asm_tables(pt->p, pt->nq, tab);
+  TG_TRY(tg_dmalloc(&C.tab, (int64_t)tab.size()));
+  TG_CHECK_HIP(hipMemcpyAsync(C.tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));      // (the host copies of the tables go out of scope)
+  return 0;
+}
+
+// rows [row0, row1) of the matrix / vector -- whole node planes of the LAST direction (any range when d == 1); the control
+// functions (and fnod) hold the nodes [cp_node0, cp_node0 + n), which must cover every element that touches the rows
+static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int64_t row1, int64_t cp_node0, tg_csr_t *mout,
+                              tg_vec_t fnod, tg_vec_t bout) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(pt && pt->d >= 1 && pt->d <= 3 && pt->p >= 1 && pt->p <= TG_MAX_DEGREE && pt->nsd >= pt->d && pt->nsd <= 3,
              "bad patch description");
@@ -258,73 +624,53 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, tg_csr_t *mout, tg
   A.nsd = pt->nsd;
   A.nq = pt->nq;
   A.form = form;
-  int64_t nnodes = 1, nelem = 1;
+  int64_t nnodes = 1, plane = 1;
   for (int k = 0; k < 3; k++) {
     A.nel[k] = 1;
     A.n[k] = 1;
   }
-  std::vector<void *> dev;
-  auto cleanup = [&]() {
-    hipStreamSynchronize(g_tg.stream);
-    for (void *q : dev) tg_dfree(q);
-  };
   for (int k = 0; k < d; k++) {
     TG_REQUIRE(pt->nverts[k] >= 2 && pt->verts[k], "direction %d needs at least one element", k);
     A.nel[k] = pt->nverts[k] - 1;
     A.n[k] = A.nel[k] * p + 1;
     nnodes *= A.n[k];
-    nelem *= A.nel[k];
-    double *dv = nullptr;
-    if (tg_dmalloc(&dv, pt->nverts[k])) {
-      cleanup();
-      return 1;
-    }
-    dev.push_back(dv);
-    hipMemcpyAsync(dv, pt->verts[k], pt->nverts[k] * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
-    A.verts[k] = dv;
+    if (k < d - 1) plane *= A.n[k];
   }
-  TG_REQUIRE(nelem < (1ll << 31), "too many elements for one launch");
+  if (row0 < 0 && row1 < 0) {
+    row0 = 0;
+    row1 = nnodes;
+  }
+  TG_REQUIRE(row0 >= 0 && row1 >= row0 && row1 <= nnodes && row0 % plane == 0 && row1 % plane == 0,
+             "row range [%lld, %lld): whole node planes of the last direction (%lld nodes each) of the %lld FE nodes",
+             (long long)row0, (long long)row1, (long long)plane, (long long)nnodes);
+  const int za = (int)(row0 / plane), zb = (int)(row1 / plane);
+  // element layers of the last direction that touch the node planes [za, zb), and the nodes they need
+  const int nelL = A.nel[d - 1];
+  int ez0 = 0, ez1 = 0;
+  if (zb > za) {
+    ez0 = (za > 0 && za % p == 0) ? za / p - 1 : za / p;
+    ez1 = std::min(nelL, (zb - 1) / p + 1);
+    if (ez0 >= nelL) ez0 = nelL - 1;           // (the last node plane belongs to the last layer)
+  }
+  const int64_t need0 = (int64_t)ez0 * p * plane, need1 = (zb > za) ? ((int64_t)ez1 * p + 1) * plane : need0;
   for (int c = 0; c <= pt->nsd; c++) {
-    if (!(pt->cp[c] && pt->cp[c]->n == nnodes)) {
-      cleanup();
-      tg_set_error("control function %d must be a vector on the %lld FE nodes", c, (long long)nnodes);
-      return 2;
-    }
+    TG_REQUIRE(pt->cp[c], "control function %d missing", c);
+    TG_REQUIRE(cp_node0 >= 0 && cp_node0 <= need0 && cp_node0 + pt->cp[c]->n >= need1,
+               "control function %d holds the FE nodes [%lld, %lld), the rows need [%lld, %lld)", c, (long long)cp_node0,
+               (long long)(cp_node0 + pt->cp[c]->n), (long long)need0, (long long)need1);
     A.cp[c] = pt->cp[c]->d;
   }
-  // reference-element tables: equispaced Lagrange nodes a/p at the Gauss points
-  std::vector<double> gx, gw;
-  tg_gauss01(pt->nq, gx, gw);
-  std::vector<double> tab(2 * (size_t)p1 * pt->nq + pt->nq);
-  for (int a = 0; a < p1; a++)
-    for (int q = 0; q < pt->nq; q++) {
-      const double t = gx[q];
-      double l = 1.0, dl = 0.0;
-      for (int m = 0; m < p1; m++)
-        if (m != a) l *= (t - (double)m / p) / ((double)a / p - (double)m / p);
-      for (int m = 0; m < p1; m++) {
-        if (m == a) continue;
-        double term = 1.0 / ((double)a / p - (double)m / p);
-        for (int r = 0; r < p1; r++)
-          if (r != a && r != m) term *= (t - (double)r / p) / ((double)a / p - (double)r / p);
-        dl += term;
-      }
-      tab[(size_t)a * pt->nq + q] = l;
-      tab[(size_t)p1 * pt->nq + (size_t)a * pt->nq + q] = dl;
-    }
-  for (int q = 0; q < pt->nq; q++) tab[2 * (size_t)p1 * pt->nq + q] = gw[q];
-  double *dtab = nullptr;
-  if (tg_dmalloc(&dtab, (int64_t)tab.size())) {
-    cleanup();
-    return 1;
-  }
-  dev.push_back(dtab);
-  hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
-  A.tab = dtab;
+  A.cp_node0 = cp_node0;
+  A.row0 = row0;
+  A.row1 = row1;
+  TG_TRY(tg_asm_cache_get(pt));
+  for (int k = 0; k < d; k++) A.verts[k] = g_asm_cache.verts[k];
+  A.tab = g_asm_cache.tab;
+  const bool fast = form != 2 && d == 3 && pt->nsd == 3 && pt->nq == p1 && p <= 3 && !getenv("TIGAR_ASM_LEGACY");
 
   tg_csr_s *m = nullptr;
   if (form != 2) {
-    // pattern: Kronecker product of the 1-D element-coupling patterns, zero values
+    // pattern: Kronecker product of the 1-D element-coupling patterns (carries the pattern certificate of tg_kron_sum_csr)
     std::vector<std::vector<int32_t>> rp(d), cl(d);
     std::vector<std::vector<double>> vl(d);
     tg_kron_dir_t dirs[3];
@@ -351,49 +697,80 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, tg_csr_t *mout, tg
       dirs[k].val = vl[k].data();
     }
     tg_csr_t pat = nullptr;
-    const int rc = tg_kron_sum_csr(d, 1, dirs, 0, nnodes, &pat);
-    if (rc) {
-      cleanup();
-      return rc;
-    }
+    TG_TRY(tg_kron_sum_csr(d, 1, dirs, row0, row1, &pat));
     m = pat;
-    hipMemsetAsync(m->val, 0, (size_t)m->nnz * sizeof(double), g_tg.stream);
+    // (the pattern kernel wrote 0 * 0 * 0 into every value: the plain kernel adds into that; the sum-factorised kernel
+    //  stores every entry before anybody adds to it)
     A.rowptr = m->rowptr;
     A.val = m->val;
   } else {
-    if (!(fnod && fnod->n == nnodes && bout && bout->n == nnodes)) {
-      cleanup();
-      tg_set_error("load assembly needs nodal values and an output vector on the %lld FE nodes", (long long)nnodes);
-      return 2;
-    }
+    TG_REQUIRE(fnod && cp_node0 + fnod->n >= need1 && bout && bout->n == row1 - row0,
+               "load assembly needs nodal values on the nodes of the control functions and an output vector of %lld rows",
+               (long long)(row1 - row0));
     A.fnod = fnod->d;
     A.bout = bout->d;
-    hipMemsetAsync(bout->d, 0, (size_t)nnodes * sizeof(double), g_tg.stream);
+    TG_CHECK_HIP(hipMemsetAsync(bout->d, 0, (size_t)(row1 - row0) * sizeof(double), g_tg.stream));
   }
   const size_t lds = ((size_t)2 * p1 * pt->nq + pt->nq + (size_t)(pt->nsd + 1) * nloc + (size_t)nqt * 10 + nloc) * sizeof(double);
-  if (lds > 64 * 1024) {
+  if (!fast && lds > 64 * 1024) {
     if (m) tg_csr_destroy(m);
-    cleanup();
     tg_set_error("element data (%zu B) does not fit in LDS", lds);
     return 2;
   }
+  tg_asf_args F;
+  memset(&F, 0, sizeof(F));
+  if (fast) {
+    for (int k = 0; k < 3; k++) {
+      F.nel[k] = A.nel[k];
+      F.n[k] = A.n[k];
+    }
+    for (int c = 0; c < 4; c++) F.cp[c] = A.cp[c];
+    F.cp_node0 = cp_node0;
+    F.tab = A.tab;
+    F.val = m->val;
+    F.za = za;
+    F.zb = zb;
+    const int64_t T0 = (int64_t)p1 * A.n[0] + (int64_t)p * (A.nel[0] - 1), T1 = (int64_t)p1 * A.n[1] + (int64_t)p * (A.nel[1] - 1);
+    F.base = T0 * T1 * tg_rps_host(p, za);
+  }
   const int nt = (form == 2) ? 128 : 256;
   bool bad = false;
-  for (int c = 0; c < (1 << d) && !bad; c++) {       // one launch per colour (parity of the element index per direction)
+  // one launch per colour (parity of the element index per direction), colours in ascending order
+  for (int c = 0; c < (1 << d) && !bad && zb > za; c++) {
     int64_t nblk = 1;
     for (int k = 0; k < 3; k++) {
-      A.colour[k] = k < d ? (c >> k) & 1 : 0;
-      A.ncol[k] = k < d ? (A.nel[k] - A.colour[k] + 1) / 2 : 1;
+      const int par = k < d ? (c >> k) & 1 : 0;
+      int lo = 0, hi = A.nel[k];
+      if (k == d - 1) {
+        lo = ez0;
+        hi = ez1;
+      }
+      const int first = lo + (((par - lo) % 2) + 2) % 2;       // first index >= lo with this parity
+      A.efirst[k] = F.efirst[k] = k < d ? first : 0;
+      A.ncol[k] = F.ncol[k] = k < d ? (hi > first ? (hi - first + 1) / 2 : 0) : 1;
       nblk *= A.ncol[k];
     }
     if (nblk == 0) continue;
-    hipLaunchKernelGGL(k_assemble_mapped, dim3((unsigned)nblk), dim3(nt), lds, g_tg.stream, A);
+    if (fast) {
+      const int epw = p == 3 ? 1 : (p == 2 ? 2 : 8);
+      F.ngx = (F.ncol[0] + epw - 1) / epw;
+      F.ngroups = (int64_t)F.ngx * F.ncol[1] * F.ncol[2];
+      const unsigned nb = (unsigned)((F.ngroups + TG_ASF_NW - 1) / TG_ASF_NW);
+      if (p == 3)
+        tg_asf_launch<4, 1>(form, F, nb);
+      else if (p == 2)
+        tg_asf_launch<3, 2>(form, F, nb);
+      else
+        tg_asf_launch<2, 8>(form, F, nb);
+    } else {
+      TG_REQUIRE(nblk < (1ll << 31), "too many elements for one launch");
+      hipLaunchKernelGGL(k_assemble_mapped, dim3((unsigned)nblk), dim3(nt), lds, g_tg.stream, A);
+    }
     bad = hipGetLastError() != hipSuccess;
   }
-  cleanup();
   if (bad) {
     if (m) tg_csr_destroy(m);
-    tg_set_error("k_assemble_mapped failed to launch");
+    tg_set_error("the assembly kernel failed to launch");
     return 1;
   }
   if (mout) *mout = m;
@@ -402,9 +779,20 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, tg_csr_t *mout, tg
 
 extern "C" int tg_assemble_mapped_matrix(const tg_patch_t *patch, int form, tg_csr_t *out) {
   TG_REQUIRE(out && (form == 0 || form == 1), "form: 0 = mass, 1 = laplace");
-  return tg_assemble_common(patch, form, out, nullptr, nullptr);
+  return tg_assemble_common(patch, form, -1, -1, 0, out, nullptr, nullptr);
 }
 
 extern "C" int tg_assemble_mapped_load(const tg_patch_t *patch, tg_vec_t fnodal, tg_vec_t out) {
-  return tg_assemble_common(patch, 2, nullptr, fnodal, out);
+  return tg_assemble_common(patch, 2, -1, -1, 0, nullptr, fnodal, out);
+}
+
+extern "C" int tg_assemble_mapped_matrix_rows(const tg_patch_t *patch, int form, int64_t row0, int64_t row1, int64_t cp_node0,
+                                              tg_csr_t *out) {
+  TG_REQUIRE(out && (form == 0 || form == 1), "form: 0 = mass, 1 = laplace");
+  return tg_assemble_common(patch, form, row0, row1, cp_node0, out, nullptr, nullptr);
+}
+
+extern "C" int tg_assemble_mapped_load_rows(const tg_patch_t *patch, tg_vec_t fnodal, int64_t row0, int64_t row1,
+                                            int64_t cp_node0, tg_vec_t out) {
+  return tg_assemble_common(patch, 2, row0, row1, cp_node0, nullptr, fnodal, out);
 }

@@ -126,6 +126,7 @@ extern "C" int tg_shutdown(void) {
     if (g_tg.streams[i]) hipStreamSynchronize(g_tg.streams[i]);
   tg_sell_cache_clear();
   tg_kron_cache_clear();
+  tg_asm_cache_clear();
   tg_stage_release();
   tg_pool_trim();
   hipFree(g_tg.scratches[0]);

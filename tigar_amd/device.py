@@ -86,6 +86,9 @@ class DeviceVector(object):
     def zero(self):
         check(_lib.lib().tg_vec_fill(self._h, 0.0))
 
+    def fill(self, a):
+        check(_lib.lib().tg_vec_fill(self._h, float(a)))
+
     def axpy(self, a, x):
         check(_lib.lib().tg_vec_axpy(self._h, float(a), x._h))
 
@@ -844,22 +847,32 @@ def _patch(vertices, p, cp, nq):
     return pt, keep
 
 
-def assemble_mapped_matrix(vertices, p, cp, form, nq=None):
+def assemble_mapped_matrix(vertices, p, cp, form, nq=None, row0=None, row1=None, cp_node0=0):
     """FE mass (form 'mass') or stiffness ('laplace') matrix of the scalar Q_p space on the tensor
     grid with element ``vertices`` per direction, geometry F = cp[i]/cp[nsd] given by DeviceVectors on
-    the FE nodes (dolfin.assemble stand-in, tIGAr/common.py:1206-1220, 917-945)."""
+    the FE nodes (dolfin.assemble stand-in, tIGAr/common.py:1206-1220, 917-945).  ``row0, row1``: the rows of
+    whole node planes of the last direction only (global columns), ``cp`` then holding the nodes from ``cp_node0`` on."""
     pt, keep = _patch(vertices, p, cp, p + 1 if nq is None else nq)
     h = handle()
-    check(_lib.lib().tg_assemble_mapped_matrix(C.byref(pt), {"mass": 0, "laplace": 1}[form], C.byref(h)),
-          "tg_assemble_mapped_matrix")
+    if row0 is None and row1 is None and not cp_node0:
+        check(_lib.lib().tg_assemble_mapped_matrix(C.byref(pt), {"mass": 0, "laplace": 1}[form], C.byref(h)),
+              "tg_assemble_mapped_matrix")
+    else:
+        check(_lib.lib().tg_assemble_mapped_matrix_rows(C.byref(pt), {"mass": 0, "laplace": 1}[form], int(row0), int(row1),
+                                                        int(cp_node0), C.byref(h)), "tg_assemble_mapped_matrix_rows")
     return DeviceCSR(h)
 
 
-def assemble_mapped_load(vertices, p, cp, fnodal, nq=None):
-    """L(v) = int f_h v dx with f_h the nodal interpolant of the DeviceVector ``fnodal``."""
+def assemble_mapped_load(vertices, p, cp, fnodal, nq=None, row0=None, row1=None, cp_node0=0):
+    """L(v) = int f_h v dx with f_h the nodal interpolant of the DeviceVector ``fnodal`` (on the nodes of ``cp``)."""
     pt, keep = _patch(vertices, p, cp, p + 1 if nq is None else nq)
-    out = DeviceVector(n=fnodal.size())
-    check(_lib.lib().tg_assemble_mapped_load(C.byref(pt), fnodal._h, out._h), "tg_assemble_mapped_load")
+    if row0 is None and row1 is None and not cp_node0:
+        out = DeviceVector(n=fnodal.size())
+        check(_lib.lib().tg_assemble_mapped_load(C.byref(pt), fnodal._h, out._h), "tg_assemble_mapped_load")
+    else:
+        out = DeviceVector(n=int(row1) - int(row0))
+        check(_lib.lib().tg_assemble_mapped_load_rows(C.byref(pt), fnodal._h, int(row0), int(row1), int(cp_node0), out._h),
+              "tg_assemble_mapped_load_rows")
     return out
 
 

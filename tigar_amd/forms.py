@@ -152,16 +152,55 @@ def _memo(obj, V, build):
     return cache[key]
 
 
-def _mapped(geometry, V, form):
+def _plane_window(g, row0, row1):
+    """node planes [za, zb) of the last direction that hold the FE rows [row0, row1), and the planes [fa, fb) of the
+    elements that touch them (whose control values the assembly reads)"""
+    shape = g.shape()
+    plane = int(numpy.prod(shape[:-1], dtype=numpy.int64)) if len(shape) > 1 else 1
+    n_last, p = shape[-1], int(g.degree)
+    nel = (n_last - 1) // p
+    za, zb = int(row0) // plane, -(-int(row1) // plane)
+    if zb <= za:
+        return plane, za, zb, za, za
+    e0 = za // p - 1 if (za > 0 and za % p == 0) else za // p
+    e0 = min(e0, nel - 1)
+    e1 = min(nel, (zb - 1) // p + 1)
+    return plane, za, zb, e0 * p, e1 * p + 1
+
+
+def _control_window(geometry, plane, fa, fb):
+    """(the nsd+1 control functions as DeviceVectors, index of their first node): the functions themselves when they
+    are held in full, else their values on the node planes [fa, fb) -- a rank of a distributed run holds only the rows
+    it owns, and its forms read a window around them (``AbstractExtractionGenerator.controlFunctionWindow``)"""
+    cpf = geometry.cpFuncs
+    if all(getattr(fn, "local_range", None) is None for fn in cpf):
+        return [fn.vector() for fn in cpf], 0
+    gen = getattr(geometry, "_generator", geometry)
+    return gen.controlFunctionWindow(fa, fb), fa * plane
+
+
+def _mapped(geometry, V, form, row0=None, row1=None):
     """dolfin.assemble stand-in on a mapped patch: ``geometry`` is a generator / ExtractedSpline
     whose ``cpFuncs`` (nsd+1 homogeneous control functions on the FE nodes of ``V_control``) define
-    F = cpFuncs[i]/cpFuncs[nsd] (tIGAr/common.py:917-921); metric-based measure and gradient."""
+    F = cpFuncs[i]/cpFuncs[nsd] (tIGAr/common.py:917-921); metric-based measure and gradient.  ``row0, row1``: the FE
+    rows of a block only (global columns), as the z-slab pipeline asks for them."""
     g = _single_grid(V)
     gc = _single_grid(geometry.V_control)
     if gc.shape() != g.shape():
         raise ValueError("the geometry lives on a different node grid than the space")
-    cp = [f.vector() for f in geometry.cpFuncs]
-    return _dev.assemble_mapped_matrix([g.vertices[k] for k in range(g.dim())], g.degree, cp, form)
+    verts = [g.vertices[k] for k in range(g.dim())]
+    n = g.num_nodes()
+    if (row0 is None and row1 is None) or (int(row0), int(row1)) == (0, n):
+        cp, node0 = _control_window(geometry, 1, 0, g.shape()[-1])
+        if node0 == 0 and all(v.size() == n for v in cp):
+            return _dev.assemble_mapped_matrix(verts, g.degree, cp, form)
+        row0, row1 = 0, n
+    plane, za, zb, fa, fb = _plane_window(g, row0, row1)
+    cp, node0 = _control_window(geometry, plane, fa, fb)
+    A = _dev.assemble_mapped_matrix(verts, g.degree, cp, form, row0=za * plane, row1=zb * plane, cp_node0=node0)
+    if (za * plane, zb * plane) != (int(row0), int(row1)):           # (a range that cuts through node planes)
+        A = A.block(int(row0) - za * plane, int(row1) - za * plane, 0, n)
+    return A
 
 
 class LaplaceForm(object):
@@ -182,9 +221,7 @@ class LaplaceForm(object):
 
     def assemble_matrix(self, V, row0=None, row1=None):
         if self.geometry is not None:
-            if row0 is not None or row1 is not None:
-                raise NotImplementedError("row blocks of mapped forms")
-            return _mapped(self.geometry, V, "laplace")
+            return _mapped(self.geometry, V, "laplace", row0, row1)
         return _dev.kron_sum_csr(self.factors(V), row0, row1)
 
 
@@ -255,32 +292,56 @@ class MassForm(object):
 
     def assemble_matrix(self, V, row0=None, row1=None):
         if self.geometry is not None:
-            if row0 is not None or row1 is not None:
-                raise NotImplementedError("row blocks of mapped forms")
-            return _mapped(self.geometry, V, "mass")
+            return _mapped(self.geometry, V, "mass", row0, row1)
         return _dev.kron_sum_csr(self.factors(V), row0, row1)
 
 
 class NodalLoadForm(object):
-    """L(v) = int f_h v dx on the mapped patch, f_h = nodal interpolant of ``f`` evaluated at the
-    physical node positions x = F(node) (array of shape [nnodes, nsd] -> values), or given node
-    values directly."""
+    """L(v) = int f_h v dx on the mapped patch, f_h = nodal interpolant of ``f``: a callable evaluated at the
+    physical node positions x = F(node) (array of shape [nnodes, nsd] -> values), a number (constant load), or the node
+    values themselves (array / DeviceVector on all FE nodes)."""
 
     def __init__(self, f, geometry):
         self.f, self.geometry = f, geometry
 
-    def assemble_vector(self, V, row0=None, row1=None):
-        if row0 is not None or row1 is not None:
-            raise NotImplementedError("row blocks of mapped forms")
-        g = _single_grid(V)
-        cp = [fn.vector() for fn in self.geometry.cpFuncs]
+    def _nodal_values(self, cp, node0, n_nodes):
+        """f on the nodes [node0, node0 + n_nodes) that the control functions ``cp`` are given on"""
         if callable(self.f):
             c = [v.get_local() for v in cp]
             x = numpy.stack([c[i] / c[-1] for i in range(len(c) - 1)], axis=1)
-            fn = _dev.DeviceVector(data=numpy.asarray(self.f(x), dtype=numpy.float64))
+            return _dev.DeviceVector(data=numpy.asarray(self.f(x), dtype=numpy.float64))
+        if numpy.isscalar(self.f):
+            fn = _dev.DeviceVector(n_nodes, zero=False)
+            fn.fill(float(self.f))
+            return fn
+        full = self.f if isinstance(self.f, _dev.DeviceVector) else _dev.DeviceVector(data=self.f)
+        if node0 == 0 and full.size() == n_nodes:
+            return full
+        piece = _dev.DeviceVector(n_nodes, zero=False)
+        _dev.vec_copy_range(piece, 0, full, node0, n_nodes)
+        return piece
+
+    def assemble_vector(self, V, row0=None, row1=None):
+        g = _single_grid(V)
+        verts = [g.vertices[k] for k in range(g.dim())]
+        n = g.num_nodes()
+        if (row0 is None and row1 is None) or (int(row0), int(row1)) == (0, n):
+            cp, node0 = _control_window(self.geometry, 1, 0, g.shape()[-1])
+            if node0 == 0 and all(v.size() == n for v in cp):
+                return _dev.assemble_mapped_load(verts, g.degree, cp, self._nodal_values(cp, 0, n))
+            row0, row1 = 0, n
+        plane, za, zb, fa, fb = _plane_window(g, row0, row1)
+        cp, node0 = _control_window(self.geometry, plane, fa, fb)
+        if node0 == 0 and cp[0].size() == n:
+            fn = self._nodal_values(cp, 0, n)
         else:
-            fn = self.f if isinstance(self.f, _dev.DeviceVector) else _dev.DeviceVector(data=self.f)
-        return _dev.assemble_mapped_load([g.vertices[k] for k in range(g.dim())], g.degree, cp, fn)
+            fn = self._nodal_values(cp, node0, cp[0].size())
+        b = _dev.assemble_mapped_load(verts, g.degree, cp, fn, row0=za * plane, row1=zb * plane, cp_node0=node0)
+        if (za * plane, zb * plane) != (int(row0), int(row1)):
+            piece = _dev.DeviceVector(int(row1) - int(row0), zero=False)
+            _dev.vec_copy_range(piece, 0, b, int(row0) - za * plane, int(row1) - int(row0))
+            b = piece
+        return b
 
 
 class SeparableLoadForm(object):
