@@ -270,7 +270,7 @@ def test_mapped_forms_streamed_through_the_slab_engine(T, p, nels, sub, monkeypa
     assert np.array_equal(K.indptr, Kr.indptr) and np.array_equal(K.indices, Kr.indices)
     assert abs(K - Kr).max() <= 1e-12 * abs(Kr).max()
     assert np.max(np.abs(b - br)) <= 1e-12 * np.max(np.abs(br))
-    if p <= 4:
+    if p <= 3:                                   # (3-D quartics: the general stages)
         assert walks > 0 and certified > 0       # the line walks ran, on the certificate of the assembled row blocks
 
 
