@@ -109,6 +109,24 @@ def quarter_annulus_mesh(p, nel):
     return NURBSControlMesh([p, p], [kv, kv], Pf)
 
 
+def rational_volume_mesh(p, nel):
+    """The mapped-geometry companion's patch: a smooth rational volume map of degree p on nel^3 elements
+    -- control points = a non-affine, non-separable map of the Greville points, weights varying; a control net in
+    homogeneous coordinates as tIGAr/NURBS.py:46-74 reads it from igakit -- deterministic, no RNG."""
+    from tigar_amd.BSplines import uniformKnots
+    from tigar_amd.NURBS import NURBSControlMesh
+    kv = np.asarray(uniformKnots(p, 0.0, 1.0, nel), dtype=np.float64)
+    g = np.array([np.sum(kv[i + 1:i + p + 1]) / p for i in range(len(kv) - p - 1)])
+    g0, g1, g2 = g[:, None, None], g[None, :, None], g[None, None, :]
+    w = 1.0 + 0.25 * g0 * g1 + 0.1 * g2
+    C = np.empty((len(g), len(g), len(g), 4))
+    C[..., 0] = w * (g0 + 0.15 * g1 * g2)
+    C[..., 1] = w * (g1 + 0.2 * g0 ** 2 - 0.1 * g2)
+    C[..., 2] = w * (g2 * (1.0 + 0.3 * g0) + 0.05 * np.sin(2.0 * g1))
+    C[..., 3] = w
+    return NURBSControlMesh([p] * 3, [kv] * 3, C)
+
+
 def hashed_values(n, seed):
     """counter-based hash -> doubles in (-1, 1): value k depends on (seed, k) only (splitmix64)"""
     with np.errstate(over="ignore"):
@@ -131,7 +149,9 @@ def run(args, wl, d, p, nel):
     from tigar_amd.common import (EqualOrderSpline, ExtractedSpline, PETScKrylovSolver, PETScLUSolver, Function,
                                   TensorFunctionSpace)
     from tigar_amd.BSplines import ExplicitBSplineControlMesh, uniformKnots
-    from tigar_amd.forms import LaplaceForm, SeparableLoadForm, BiharmonicForm, SumOfSeparableLoads
+    from tigar_amd.forms import LaplaceForm, SeparableLoadForm, BiharmonicForm, SumOfSeparableLoads, NodalLoadForm
+    mapped = getattr(args, "geometry", "identity") == "volume"
+    assert not mapped or (d == 3 and wl in ("cfg2", "cfg3")), "the rational volume map is a 3-D Poisson configuration"
 
     comm = tc.worldcomm                       # size / rank from the launcher's environment
     rank, world = comm.rank, comm.size
@@ -144,6 +164,8 @@ def run(args, wl, d, p, nel):
     method = args.solver if args.solver != "auto" else DEFAULT_SOLVER.get(wl, "cg")
     if wl == "cfg5":
         controlMesh, nf, nlayers = quarter_annulus_mesh(p, nel), 3, 2
+    elif mapped:
+        controlMesh = rational_volume_mesh(p, nel)
     else:
         if wl == "cfg4":
             lo, nlayers = -1.0, 2
@@ -166,7 +188,7 @@ def run(args, wl, d, p, nel):
     t0 = time.perf_counter()
     V_in = TensorFunctionSpace([basis.generateMesh(degree=p)], "Lagrange")
     free_b = dev.mem_info()[0] + dev.pool_stats()[0]
-    a_resident = world == 1 and args.slab != 1 and \
+    a_resident = world == 1 and args.slab != 1 and not mapped and \
         12.0 * (2 * cnt["nnzM"] + cnt["nnzA"] + 2 * cnt["nnzK"]) <= 0.6 * free_b
     if wl == "cfg5":
         # a deterministic non-symmetric, diagonally dominant matrix on the 3-field Q_p pattern, values
@@ -189,7 +211,7 @@ def run(args, wl, d, p, nel):
         a_resident = True
     else:
         A_in = lap.assemble_matrix(V_in) if a_resident else None
-        b_in = load.assemble_vector(V_in) if world == 1 else None
+        b_in = load.assemble_vector(V_in) if (world == 1 and not mapped) else None
     dev.sync()
     t_input_pre = time.perf_counter() - t0
     if not a_resident:
@@ -234,9 +256,13 @@ def run(args, wl, d, p, nel):
         spline = ExtractedSpline(gen, 2 * p)               # M^T
         mark("transpose")
         spline.stage_timers = {}
-        K = spline.extractMatrix(A_in) if a_resident else spline.assembleMatrix(lap)   # M^T A M + zeroRowsColumns
+        # (mapped geometry: the forms integrate on the mapped patch, F = cpFuncs[i] / cpFuncs[nsd] of THIS generator --
+        #  dolfin.assemble with the spline's measures, tIGAr/common.py:917-945, 1206-1220 -- in row blocks, inside the step)
+        lap_s = LaplaceForm(geometry=gen) if mapped else lap
+        load_s = NodalLoadForm(1.0, gen) if mapped else load
+        K = spline.extractMatrix(A_in) if a_resident else spline.assembleMatrix(lap_s)   # M^T A M + zeroRowsColumns
         mark("ptap")
-        rhs = spline.extractVector(b_in) if b_in is not None else spline.assembleVector(load)   # M^T b + BCs
+        rhs = spline.extractVector(b_in) if b_in is not None else spline.assembleVector(load_s)   # M^T b + BCs
         mark("mtb")
         solver = make_solver()
         spline.setSolverOptions(linearSolver=solver)
@@ -342,7 +368,7 @@ def run(args, wl, d, p, nel):
     verified = companions.get("pattern_verified")
 
     nodal_error = None
-    if args.check and rank == 0 and wl != "cfg5":
+    if args.check and rank == 0 and wl != "cfg5" and not mapped:
         # manufactured solution at the FE nodes this rank owns
         grid = spline.V.grids[0]
         r0, r1 = spline.localFERange()
@@ -390,7 +416,7 @@ def run(args, wl, d, p, nel):
             "comm_requested": getattr(dcomm, "requested_kind", None) if dcomm is not None else None,
             "comm_fallback": getattr(dcomm, "fallback_notes", None) if dcomm is not None else None,
             "comm_devices": (dcomm.rank_devices() if (dcomm is not None and info[2] == "ipc") else None),
-            "devices_visible": ndev}
+            "devices_visible": ndev, "mapped": mapped}
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
@@ -522,6 +548,12 @@ def main():
     ap.add_argument("--live-traffic", type=int, default=-1,
                     help="1 / 0: measure the HBM traffic of the product kernel with rocprofv3 --pmc in a child run of this "
                          "command (default: when N = 1, the headline workload, rocprofv3 present and no profiler around this run)")
+    ap.add_argument("--geometry", default="identity",
+                    help="identity (the benchmark's unit cube) | volume: a smooth rational volume map -- the forms integrate on "
+                         "the mapped patch (sum-factorised element matrices in row blocks, csrc/tg_assemble.hip)")
+    ap.add_argument("--mapped-companion", type=int, default=-1,
+                    help="1 / 0: after the timed run, one step of the same size on the rational volume map (default: on "
+                         "for the headline workload on one rank)")
     ap.add_argument("--companion", type=int, default=1,
                     help="1: after the timed loop run one more step with the FE matrix' pattern verified entry by entry")
     args = ap.parse_args()
@@ -570,6 +602,19 @@ def main():
         except Exception as e:                          # noqa: BLE001
             log("[bench] live PMC pass skipped: %s" % (e,))
     res = run(args, wl, d, p, nel)
+    # ---- companion: the same size on a MAPPED patch (rational volume), measured live: one warm-up and one step
+    mapped_res = None
+    mc = args.mapped_companion
+    if mc < 0:
+        mc = int(wl == "cfg3" and world == 1 and args.geometry == "identity" and bool(args.companion))
+    if mc and args.geometry == "identity" and d == 3 and wl in ("cfg2", "cfg3"):
+        import copy
+        a2 = copy.copy(args)
+        a2.geometry, a2.steps, a2.warmup, a2.companion, a2.check = "volume", 1, 1, 0, 0
+        try:
+            mapped_res = run(a2, wl, d, p, nel)
+        except Exception as e:                           # noqa: BLE001  (a companion must not break the line)
+            log("[bench] mapped-geometry companion failed: %r" % (e,))
     if rank != 0:
         return
     cnt = counts(d, p, nel, res["nf"])
@@ -622,7 +667,8 @@ def main():
     step_s = res["elapsed"] / args.steps
     t_in_timed = res["t_input"] if res["t_input_in_timed_region"] else 0.0
     desc = {"cfg4": "B-spline biharmonic on (-1,1)^2, two clamped layers (demos/biharmonic)",
-            "cfg5": "NURBS quarter annulus, 3 fields, hashed non-symmetric A on the 3-field pattern"}.get(wl, "B-spline Poisson")
+            "cfg5": "NURBS quarter annulus, 3 fields, hashed non-symmetric A on the 3-field pattern"}.get(
+                wl, "Poisson on a rational volume map (mapped forms)" if res.get("mapped") else "B-spline Poisson")
     pc_name = {"jacobi": "Jacobi", "none": "unpreconditioned", "chebyshev": "Chebyshev(%d)-Jacobi" % args.cheb_degree}[args.pc]
     solver_desc = {"cg": "%s-CG rtol %.0e" % (pc_name, args.rtol), "gmres": "%s-GMRES(30) rtol %.0e" % (pc_name, args.rtol),
                    "bicgstab": "%s-BiCGStab rtol %.0e" % (pc_name, args.rtol),
@@ -664,6 +710,18 @@ def main():
                    "value_fe_matrix_materialised": (res["ncp"] / res["materialised_step_s"]) if res.get("materialised_step_s") else None,
                    "ms_per_step_fe_matrix_materialised": 1e3 * res["materialised_step_s"] if res.get("materialised_step_s") else None,
                    "fe_matrix_fused_into_ptap": res.get("fused"),
+                   # the same size on a mapped patch (rational volume map; the forms integrate with the spline's measures,
+                   # element matrices sum-factorised in row blocks inside the step): one step measured live after the timed run
+                   "value_mapped_geometry": (mapped_res["ncp"] / mapped_res["elapsed"]) if mapped_res else None,
+                   "mapped_geometry": ({"ms_per_step": 1e3 * mapped_res["elapsed"],
+                                        "stages_s": {k: round(v, 6) for k, v in mapped_res["stages"].items()},
+                                        "cg_iterations": mapped_res["iterations"],
+                                        "self_check_rel_residual": mapped_res.get("self_check"),
+                                        "ptap_certified_passes": mapped_res.get("ptap_certified"),
+                                        "geometry": "rational volume map: control points = smooth non-affine map of the Greville "
+                                                    "points, varying weights (bench.rational_volume_mesh); f = 1, zero Dirichlet "
+                                                    "data on all faces",
+                                        "forms": "LaplaceForm(geometry=gen), NodalLoadForm(1.0, gen)"} if mapped_res else None),
                    "self_check_rel_residual_all_ranks": res.get("self_check"),
                    "communicator_host_waits_in_timed_steps": res.get("comm_host_waits"),
                    "ptap": {"stage_s": res["stages"].get("ptap"), "algorithmic_bytes": ptap_bytes(cnt),

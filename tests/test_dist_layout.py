@@ -159,3 +159,40 @@ def test_host_rendezvous_skips_a_busy_port():
     finally:
         blocker.close()
     assert [r[0] for r in res] == [0, 1] and all(r[1] for r in res)
+
+
+def _framing_worker(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    from tigar_amd.launch import SocketTransport
+    tr = SocketTransport(rank, world)
+    peer = 1 - rank
+    # a matched pair, both directions at once, different lengths
+    recv = np.zeros(3 if rank == 0 else 5)
+    tr.sendrecv(peer, np.arange(5.0) if rank == 0 else np.arange(3.0) + 10.0, recv, tag=7)
+    ok = np.array_equal(recv, np.arange(3.0) + 10.0 if rank == 0 else np.arange(5.0))
+    # calls that do not pair up: rank 0 expects 2 values, rank 1 sends 4 (and the other way round the tags differ)
+    try:
+        tr.sendrecv(peer, np.ones(4), np.zeros(2 if rank == 0 else 4), tag=8 + rank)
+        raised = False
+    except RuntimeError as e:
+        raised = "out of step" in str(e)
+    q.put((rank, ok, raised))
+
+
+def test_socket_transport_messages_are_framed():
+    """sendrecv was a raw byte stream -- two ranks whose exchanges did not pair up (different numbers of ghost
+    updates per assembly) read each other's bytes as data or stalled for a minute.  Every message now carries a header
+    (magic, tag, length) that the receiver checks."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_framing_worker, args=(r, 2, 29411, q)) for r in range(2)]
+    for p in reversed(procs):
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True, True), (1, True, True)]

@@ -355,6 +355,6 @@ def test_mapped_forms_on_several_ranks(tmp_path, kind, p, nels, world, comm):
         assert np.max(np.abs(z["U"] - U[g0:g1])) <= 1e-8 * np.max(np.abs(U))
         if r1 > r0:
             assert np.max(np.abs(z["u"] - u[r0:r1])) <= 1e-8 * np.max(np.abs(u))
-        assert abs(int(z["its"][0]) - its) <= 1
+        assert abs(int(z["its"][0]) - its) <= 3
         cover[g0:g1] += 1
     assert np.all(cover == 1)

@@ -293,13 +293,25 @@ class Function(object):
     def ghosted(self):
         """FE coefficients as a vector of the full length of V, valid on every row the forms of THIS rank read: its own
         rows plus the ghost rows held by the z-neighbours (dolfin's ghost update of a distributed Function [ext]; the
-        reference's forms read the ghosted vector after ``u.assign``, tIGAr/common.py:1343).  One rank: the vector itself."""
+        reference's forms read the ghosted vector after ``u.assign``, tIGAr/common.py:1343).  One rank: the vector itself.
+        The exchange happens ONCE per assembly: the spline that drives the solve stamps its assemblies
+        (``ExtractedSpline._ghost_epoch``) and the ghosted vector is kept until the stamp changes -- the forms ask for it once
+        per row block, and the number of row blocks differs from rank to rank (the exchanges of z-neighbours
+        would no longer pair up)."""
         if self.local_range is None:
             return self._vec
         if self._ghoster is None:
             raise RuntimeError("a rank-local Function can only be read by forms after the spline that owns it has been "
                                "asked for a ghost update (ExtractedSpline.ghostedVector / solveNonlinearVariationalProblem)")
-        return self._ghoster(self)
+        owner = getattr(self._ghoster, "__self__", None)
+        epoch = getattr(owner, "_ghost_epoch", None)
+        cached = self.__dict__.get("_ghost_cache")
+        if epoch is not None and cached is not None and cached[0] == epoch and cached[1] is self._vec:
+            return cached[2]
+        g = self._ghoster(self)
+        if epoch is not None:
+            self.__dict__["_ghost_cache"] = (epoch, self._vec, g)
+        return g
 
     def function_space(self):
         return self.V
@@ -1444,6 +1456,8 @@ class ExtractedSpline(object):
         """``form``: anything with ``.assemble_vector(V)`` (see ``tigar_amd.forms``) or an
         already assembled FE vector (tIGAr/common.py:1162-1173).  With several ranks the form is
         asked for the FE rows each rank needs (``assemble_vector(V, row0, row1)``)."""
+        if not self.__dict__.get("_in_system"):
+            self._ghost_epoch = self.__dict__.get("_ghost_epoch", 0) + 1
         if hasattr(form, "assemble_vector"):
             if self._distributed():
                 from .implicit import LazyFEVector
@@ -1650,6 +1664,8 @@ class ExtractedSpline(object):
         """tIGAr/common.py:1206-1220.  When the assembled FE matrix cannot be resident next to K (implicit
         M: cfg3's A is 684 GB) or the patch is spread over several ranks, the form is asked for row blocks
         (``assemble_matrix(V, row0, row1)``) as the z-slab pipeline consumes them."""
+        if not self.__dict__.get("_in_system"):
+            self._ghost_epoch = self.__dict__.get("_ghost_epoch", 0) + 1
         if hasattr(form, "assemble_matrix"):
             if self._implicit() or self._distributed():
                 from .implicit import LazyFEMatrix
@@ -1669,7 +1685,13 @@ class ExtractedSpline(object):
         return self.extractMatrix(A, applyBCs=applyBCs, diag=diag)
 
     def assembleLinearSystem(self, lhsForm, rhsForm, applyBCs=True):
-        return (self.assembleMatrix(lhsForm, applyBCs), self.assembleVector(rhsForm, applyBCs))
+        # one ghost update of the rank-local functions the forms read serves both assemblies (Function.ghosted)
+        self._ghost_epoch = self.__dict__.get("_ghost_epoch", 0) + 1
+        self._in_system = True
+        try:
+            return (self.assembleMatrix(lhsForm, applyBCs), self.assembleVector(rhsForm, applyBCs))
+        finally:
+            self._in_system = False
 
     # -- a-12
     def solveLinearSystem(self, MTAM, MTb, u):
@@ -1754,16 +1776,16 @@ class ExtractedSpline(object):
         empty = numpy.zeros(0)
         if rank > 0 and ua > need[rank][0]:
             recv = numpy.zeros(ua - need[rank][0])
-            tr.sendrecv(rank - 1, empty, recv)
+            tr.sendrecv(rank - 1, empty, recv, tag=71)
             full[need[rank][0]:ua] = recv
         if rank + 1 < world and own[rank + 1][0] > need[rank + 1][0]:
-            tr.sendrecv(rank + 1, numpy.ascontiguousarray(full[need[rank + 1][0]:own[rank + 1][0]]), numpy.zeros(0))
+            tr.sendrecv(rank + 1, numpy.ascontiguousarray(full[need[rank + 1][0]:own[rank + 1][0]]), numpy.zeros(0), tag=71)
         if rank + 1 < world and need[rank][1] > ub:
             recv = numpy.zeros(need[rank][1] - ub)
-            tr.sendrecv(rank + 1, empty, recv)
+            tr.sendrecv(rank + 1, empty, recv, tag=72)
             full[ub:need[rank][1]] = recv
         if rank > 0 and need[rank - 1][1] > own[rank - 1][1]:
-            tr.sendrecv(rank - 1, numpy.ascontiguousarray(full[own[rank - 1][1]:need[rank - 1][1]]), numpy.zeros(0))
+            tr.sendrecv(rank - 1, numpy.ascontiguousarray(full[own[rank - 1][1]:need[rank - 1][1]]), numpy.zeros(0), tag=72)
         return DeviceVector(data=full)
 
     def globalNorm(self, v, kind="l2"):

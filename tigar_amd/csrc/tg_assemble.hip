@@ -251,8 +251,9 @@ static void tg_gauss01(int n, std::vector<double> &x, std::vector<double> &w) {
 //   of the element: DF, g and the gradients of the Lagrange functions all refer to xi_hat in [0,1]^3, so no element
 //   size appears -- the chain rule holds in any parametrisation, tIGAr/calculusUtils.py:56-70)
 //
-// with phi_a(q) = l[a0][q0] l[a1][q1] l[a2][q2]: one WAVE per element (p = 3; two elements per wave at p = 2, eight at
-// p = 1), nq = p + 1 Gauss points per direction.
+// with phi_a(q) = l[a0][q0] l[a1][q1] l[a2][q2] and nq = p + 1 Gauss points per direction.  A WAVE walks a piece of a
+// LINE of elements along direction 0 (p = 3: one line; two lines side by side at p = 2, eight at p = 1), element by
+// element:
 //   phase 0  lane = quadrature point: control functions and their xi_hat-gradients by three 1-D contractions through the
 //            wave's LDS area (cross-lane), quotient rule, metric, w sqrt(det g) g^-1 -> LDS (6 + 1 doubles per point);
 //   phase 1  lane = COLUMN b of the element matrix, the 64 rows in registers:  X_k(q) = sum_m G_km(q) d_m phi_b(q)
@@ -260,25 +261,36 @@ static void tg_gauss01(int n, std::vector<double> &x, std::vector<double> &w) {
 //            (scalar registers) pencil by pencil -- Y[a0] over q0, Z[a0][a1] over q1, acc[a0][a1][a2] over q2 -- with the
 //            derivative index merged as soon as two terms share their remaining tables: 2.9e3 fused multiply-adds per
 //            lane and element (184e3 per element against 2.4e6 of the plain triple loop), no cross-lane traffic;
-//   phase 2  row a of the element leaves as ONE store of the wave: the 64 columns are contiguous in the CSR row of an
-//            element-interior node (512 B), runs of p + 1 otherwise; positions in closed form.
-// Entries that several elements contribute to (both nodes on a shared face) are STORED by the contributor with even
-// index in every shared direction and ADDED by the others; the launches go colour by colour (parities of the element
-// index) in ascending order, so the storing element always comes first, no two elements of a launch touch one entry and
-// the sum is formed in a fixed order: bit-reproducible, no memset, one pass over 83 % of the entries.
+//   phase 2  row a of the element leaves as one store of the wave, positions in closed form.  The rows of the element's
+//            LAST node plane in direction 0 are shared with the next element of the walk: they stay in registers
+//            ("carry") and leave together with that element's first rows, as complete runs of 2p + 1 columns.
+// Why the walk: an element writes p + 1 of the 2p + 1 direction-0 columns of a vertex row.  Written element by element
+// (round 5's first version: one wave per element, eight colours) half of all stores were 32-byte fragments at 8-byte
+// alignment, every 128-byte line of those rows was completed by a LATER launch, and the stores alone took 7.0 of
+// the kernel's 7.8 ms at 64^3 elements (1 TB/s).  With the walk the shortest run is 4 (p + 1) x (2p + 1) doubles.
+// A piece starts one element early (that element only feeds the carry), so that every FE row is written by exactly one
+// wave: no seams, no colouring in direction 0.
+// Entries that elements of different lines contribute to (both nodes on a face shared in direction 1 or 2) are STORED
+// by the contributor with even index in every shared direction and read, added to and stored again by the others; the
+// launches go colour by colour (parities of the element index in directions 1, 2) in ascending order, so the storing
+// element always comes first, no two waves of a launch touch one entry and every sum is formed in a fixed order:
+// bit-reproducible, no memset, one pass over most entries.  (Global floating-point atomics instead of the read-add-store
+// were tried first: 12 of 21 ms -- 1.8e8 lane operations at 15 G/s.)
 typedef const double __attribute__((address_space(4))) *tg_cdp4;
-typedef double __attribute__((address_space(1))) *tg_gdp1;
 
 struct tg_asf_args {
   int nel[3], n[3];
   const double *cp[4];       // the four homogeneous control functions on the nodes from cp_node0 on
+  const double *fnod;        // load: nodal values, same nodes
   int64_t cp_node0;
   const double *tab;         // l[a][q] | dl[a][q] | w[q]   (p+1 points per direction)
-  double *val;               // values of the row block
-  int64_t base;              // position of the first entry of FE plane za in the whole matrix (subtracted)
+  double *val;               // matrix: values of the row block; load: the rows of the vector
+  int64_t base;              // matrix: position of the first entry of FE plane za in the whole matrix (subtracted)
+  int64_t row0;              // load: first row held by val
   int za, zb;                // FE planes of the last direction whose rows are written
-  int efirst[3], ncol[3];
-  int ngx;                   // groups of EPW elements per line of direction 0
+  int efirst[3], ncol[3];    // this launch: elements efirst[k] + 2 i, i < ncol[k] (matrix: k = 1, 2 only)
+  int chunk, nchunks;        // matrix: elements per piece of a line, pieces per line
+  int ngy;                   // groups of EPW lines (matrix) / EPW elements along direction 0 (load)
   int64_t ngroups;
 };
 
@@ -289,41 +301,31 @@ __device__ __forceinline__ void tg_wave_sync() {
 }
 
 #define TG_ASF_NW 4          // waves per workgroup (each works on its own elements)
+// raw buffer access with a per-lane switch: an offset at or beyond the descriptor's range is dropped by the hardware
+#define TG_BUF_RANGE 0xfffffff0u
+#define TG_BUF_OOB 0xffffffffu
+typedef unsigned int tg_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double tg_buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+}
+__device__ __forceinline__ void tg_buf_store(double v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(tg_v2u, v), r, off, 0, 0);
+}
+#define TG_ASF_AREA(NC) (5 * (NC) * 64)   // doubles of LDS per wave: NC nodal functions, first contraction 2 NC, second 3 NC
+                                        // (of which NC take the place of the nodal values, dead by then)
+#define TG_ASF_CARRY (16 * 64)  // ... and of the carried rows (matrix kernel): (p+1)^2 rows x 64 columns
 
-template <int P1, int EPW, int FORM>
-__global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3(tg_asf_args A) {
-  constexpr int P = P1 - 1, NL = P1 * P1 * P1, LPE = 64 / EPW, PP = P1 * P1;
-  static_assert(NL <= LPE, "an element needs a lane per local node");
-  __shared__ __attribute__((aligned(16))) double s_tab[2 * PP + P1];
-  __shared__ __attribute__((aligned(16))) double s_w[TG_ASF_NW][24 * 64];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int s = tid; s < 2 * PP + P1; s += 64 * TG_ASF_NW) s_tab[s] = A.tab[s];
-  __syncthreads();
-  const int64_t grp = (int64_t)blockIdx.x * TG_ASF_NW + wv;
-  if (grp >= A.ngroups) return;
-  const double *TL = s_tab, *TD = s_tab + PP, *TW = s_tab + 2 * PP;
-  tg_cdp4 UL = (tg_cdp4)A.tab, UD = (tg_cdp4)A.tab + PP;
-  double *W = s_w[wv];
-  const int es = lane / LPE, li = lane - es * LPE, eb = es * LPE;
-  const bool active = li < NL;
-  const int x0 = li % P1, x1 = (li / P1) % P1, x2 = (li / PP) % P1;
-  const int gx = (int)(grp % A.ngx);
-  const int64_t rest = grp / A.ngx;
-  const int i1 = (int)(rest % A.ncol[1]), i2 = (int)(rest / A.ncol[1]);
-  const int i0 = gx * EPW + es;
-  const bool evalid = i0 < A.ncol[0];
-  const int e0 = A.efirst[0] + 2 * (evalid ? i0 : A.ncol[0] - 1), e1 = A.efirst[1] + 2 * i1, e2 = A.efirst[2] + 2 * i2;
-
-  // ---- phase 0 ----------------------------------------------------------------------------------------------
-  if (active) {
-    const int64_t node = (int64_t)(e0 * P + x0) + (int64_t)A.n[0] * ((e1 * P + x1) + (int64_t)A.n[1] * (e2 * P + x2)) - A.cp_node0;
-#pragma unroll
-    for (int c = 0; c < 4; c++) W[c * 64 + lane] = A.cp[c][node];
-  }
-  tg_wave_sync();
+// NC nodal functions given at the element's nodes in W[c * 64 + slot] (slot = eb + local node) -> value and xi_hat-gradient
+// at the lane's quadrature point (x0, x1, x2): three 1-D contractions, each a pass through the wave's LDS area
+template <int P1, int NC>
+__device__ __forceinline__ void tg_asf_to_points(double *W, const double *TL, const double *TD, int lane, int eb, int x0, int x1,
+                                                 int x2, bool active, double *N, double (*dN)[3]) {
+  double *B1 = W + NC * 64;
+  // the second contraction's 3 NC results: the first NC over the nodal values (dead), the others behind the first's
+#define TG_B2(j) (W + ((j) < NC ? (j) : 2 * NC + (j)) * 64)
   if (active) {        // lane (q0, a1, a2): contraction over a0
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < NC; c++) {
       double vl = 0.0, vd = 0.0;
 #pragma unroll
       for (int a = 0; a < P1; a++) {
@@ -331,41 +333,39 @@ __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3(tg_asf_args A) {
         vl = fma(TL[a * P1 + x0], v, vl);
         vd = fma(TD[a * P1 + x0], v, vd);
       }
-      W[256 + c * 64 + lane] = vl;
-      W[256 + (4 + c) * 64 + lane] = vd;
+      B1[c * 64 + lane] = vl;
+      B1[(NC + c) * 64 + lane] = vd;
     }
   }
   tg_wave_sync();
   if (active) {        // lane (q0, q1, a2): contraction over a1
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < NC; c++) {
       double ll = 0.0, dl = 0.0, ld = 0.0;
 #pragma unroll
       for (int a = 0; a < P1; a++) {
-        const double vl = W[256 + c * 64 + eb + x0 + P1 * (a + P1 * x2)];
-        const double vd = W[256 + (4 + c) * 64 + eb + x0 + P1 * (a + P1 * x2)];
+        const double vl = B1[c * 64 + eb + x0 + P1 * (a + P1 * x2)];
+        const double vd = B1[(NC + c) * 64 + eb + x0 + P1 * (a + P1 * x2)];
         const double tl = TL[a * P1 + x1], td = TD[a * P1 + x1];
         ll = fma(tl, vl, ll);
         dl = fma(tl, vd, dl);
         ld = fma(td, vl, ld);
       }
-      W[768 + c * 64 + lane] = ll;
-      W[768 + (4 + c) * 64 + lane] = dl;
-      W[768 + (8 + c) * 64 + lane] = ld;
+      TG_B2(c)[lane] = ll;
+      TG_B2(NC + c)[lane] = dl;
+      TG_B2(2 * NC + c)[lane] = ld;
     }
   }
   tg_wave_sync();
-  double G[7] = {0, 0, 0, 0, 0, 0, 0};
-  if (active) {        // lane (q0, q1, q2): contraction over a2, then the metric
-    double N[4], dN[4][3];
+  if (active) {        // lane (q0, q1, q2): contraction over a2
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < NC; c++) {
       double v = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
 #pragma unroll
       for (int a = 0; a < P1; a++) {
-        const double ll = W[768 + c * 64 + eb + x0 + P1 * (x1 + P1 * a)];
-        const double dl = W[768 + (4 + c) * 64 + eb + x0 + P1 * (x1 + P1 * a)];
-        const double ld = W[768 + (8 + c) * 64 + eb + x0 + P1 * (x1 + P1 * a)];
+        const double ll = TG_B2(c)[eb + x0 + P1 * (x1 + P1 * a)];
+        const double dl = TG_B2(NC + c)[eb + x0 + P1 * (x1 + P1 * a)];
+        const double ld = TG_B2(2 * NC + c)[eb + x0 + P1 * (x1 + P1 * a)];
         const double tl = TL[a * P1 + x2], td = TD[a * P1 + x2];
         v = fma(tl, ll, v);
         d0 = fma(tl, dl, d0);
@@ -377,159 +377,557 @@ __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3(tg_asf_args A) {
       dN[c][1] = d1;
       dN[c][2] = d2;
     }
-    const double Wt = N[3];
-    double g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      double df[3];
-#pragma unroll
-      for (int k = 0; k < 3; k++) df[k] = (dN[i][k] * Wt - N[i] * dN[3][k]) / (Wt * Wt);
-#pragma unroll
-      for (int k = 0; k < 3; k++)
-#pragma unroll
-        for (int m = 0; m < 3; m++) g[k * 3 + m] += df[k] * df[m];
-    }
-    double gi[9], det;
-    tg_sym_inverse(3, g, gi, &det);
-    const double s = TW[x0] * TW[x1] * TW[x2] * sqrt(fabs(det));
-    G[0] = s * gi[0];
-    G[1] = s * gi[1];
-    G[2] = s * gi[2];
-    G[3] = s * gi[4];
-    G[4] = s * gi[5];
-    G[5] = s * gi[8];
-    G[6] = s;
   }
-  tg_wave_sync();      // (the area of the nodal values and of the first contraction is free: nobody reads it any more)
-  if (active) {
+#undef TG_B2
+}
+
+// w sqrt(det g) g^-1 (G[0..5]: 00 01 02 11 12 22) and w sqrt(det g) (G[6]) at the lane's quadrature point
+__device__ __forceinline__ void tg_asf_metric(const double *N, const double (*dN)[3], double w, double *G) {
+  const double Wt = N[3];
+  double g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 7; j++) W[(eb + li) * 8 + j] = G[j];
+  for (int i = 0; i < 3; i++) {
+    double df[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) df[k] = (dN[i][k] * Wt - N[i] * dN[3][k]) / (Wt * Wt);
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int m = 0; m < 3; m++) g[k * 3 + m] += df[k] * df[m];
+  }
+  double gi[9], det;
+  tg_sym_inverse(3, g, gi, &det);
+  const double s = w * sqrt(fabs(det));
+  G[0] = s * gi[0];
+  G[1] = s * gi[1];
+  G[2] = s * gi[2];
+  G[3] = s * gi[4];
+  G[4] = s * gi[5];
+  G[5] = s * gi[8];
+  G[6] = s;
+}
+
+// 1-D row data of node a of element e (direction with nel elements): vertex shared with a neighbour?, row length,
+// position of the element's first column in the row, entries of the 1-D rows before the node
+template <int P>
+__device__ __forceinline__ void tg_asf_row1d(int a, int e, int nel, bool &v, int &n, int &o, int64_t &rps) {
+  v = (a == 0 && e > 0) || (a == P && e < nel - 1);
+  n = v ? 2 * P + 1 : P + 1;
+  o = (a == 0 && e > 0) ? P : 0;
+  rps = (int64_t)(P + 1) * (P * e + a) + (a > 0 ? (int64_t)P * e : (e > 0 ? (int64_t)P * (e - 1) : 0));
+}
+
+template <int P1, int EPW, int FORM>
+__global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3(tg_asf_args A) {
+  constexpr int P = P1 - 1, NL = P1 * P1 * P1, LPE = 64 / EPW, PP = P1 * P1;
+  constexpr int AH = P1;                 // (rows of the first local index a0 handled at once: all)
+  static_assert(NL <= LPE, "an element needs a lane per local node");
+  __shared__ __attribute__((aligned(16))) double s_tab[2 * PP + P1];
+  __shared__ __attribute__((aligned(16))) double s_w[TG_ASF_NW][TG_ASF_AREA(4)];
+  __shared__ __attribute__((aligned(16))) double s_c[TG_ASF_NW][TG_ASF_CARRY];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // (wave-uniform: element indices and row positions are scalars)
+  for (int s = tid; s < 2 * PP + P1; s += 64 * TG_ASF_NW) s_tab[s] = A.tab[s];
+  __syncthreads();
+  const int64_t grp = (int64_t)blockIdx.x * TG_ASF_NW + wv;
+  if (grp >= A.ngroups) return;
+  const double *TL = s_tab, *TD = s_tab + PP, *TW = s_tab + 2 * PP;
+  tg_cdp4 UL = (tg_cdp4)A.tab, UD = (tg_cdp4)A.tab + PP;
+  double *W = s_w[wv];
+  const int es = lane / LPE, eb = es * LPE;
+  // the piece of the walk and the line(s) of this wave
+  const int piece = (int)(grp % A.nchunks);
+  int64_t rest = grp / A.nchunks;
+  const int gy = (int)(rest % A.ngy), i2 = (int)(rest / A.ngy);
+  const int i1 = gy * EPW + es;
+  const bool evalid = i1 < A.ncol[1];
+  const int e1_ = A.efirst[1] + 2 * (evalid ? i1 : A.ncol[1] - 1), e2_ = A.efirst[2] + 2 * i2;
+  const int e_lo = piece * A.chunk, e_hi = min(A.nel[0], e_lo + A.chunk);
+  const int nel0 = A.nel[0];
+  double *CR = s_c[wv];                 // carried rows [a1 + P1 a2][lane]
+  double cpn[4];
+  {
+    const int li = lane - eb, x0 = li % P1, x1 = (li / P1) % P1, x2 = (li / PP) % P1;
+    const int64_t nodebase = (int64_t)x0 + (int64_t)A.n[0] * ((e1_ * P + x1) + (int64_t)A.n[1] * (e2_ * P + x2)) - A.cp_node0;
+    const int ef = e_lo > 0 ? e_lo - 1 : 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) cpn[c] = li < NL ? A.cp[c][nodebase + (int64_t)ef * P] : 0.0;
+  }
+
+  for (int e0 = (e_lo > 0 ? e_lo - 1 : 0); e0 < e_hi; e0++) {
+    const bool carry_only = e0 < e_lo;
+    // Everything that depends on the lane or on the line is re-derived per element from values the compiler cannot see
+    // through: hoisted out of the walk, the row positions, lane tables and predicates of phase 2 alone would take more
+    // registers than the kernel has.
+    int ln = lane, e1 = e1_, e2 = e2_;
+    asm volatile("" : "+v"(ln));
+    if (EPW == 1)
+      asm volatile("" : "+s"(e1));
+    else
+      asm volatile("" : "+v"(e1));
+    asm volatile("" : "+s"(e2));
+    const int li = ln - eb;
+    const bool active = li < NL;
+    const bool live = active && evalid;
+    const int x0 = li % P1, x1 = (li / P1) % P1, x2 = (li / PP) % P1;
+    const int64_t T0 = (int64_t)P1 * A.n[0] + (int64_t)P * (A.nel[0] - 1), T1 = (int64_t)P1 * A.n[1] + (int64_t)P * (A.nel[1] - 1);
+    const int par1 = e1 & 1, par2 = e2 & 1;
+    // ---- phase 0 --------------------------------------------------------------------------------------------
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) W[c * 64 + ln] = cpn[c];
+    }
+    tg_wave_sync();
+    if (e0 + 1 < e_hi) {                 // the next element's nodal values travel while this one is integrated
+      const int64_t nodebase = (int64_t)x0 + (int64_t)A.n[0] * ((e1 * P + x1) + (int64_t)A.n[1] * (e2 * P + x2)) - A.cp_node0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) cpn[c] = active ? A.cp[c][nodebase + (int64_t)(e0 + 1) * P] : 0.0;
+    }
+    {
+      double N[4], dN[4][3], G[7] = {0, 0, 0, 0, 0, 0, 0};
+      tg_asf_to_points<P1, 4>(W, TL, TD, ln, eb, x0, x1, x2, active, N, dN);
+      if (active) tg_asf_metric(N, dN, TW[x0] * TW[x1] * TW[x2], G);
+      tg_wave_sync();      // (the area of the nodal values is free: nobody reads it any more)
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) W[(eb + li) * 8 + j] = G[j];
+      }
+      tg_wave_sync();
+    }
+
+    const bool last0 = e0 == nel0 - 1;
+    // (Forming the rows in two halves of a0 -- accumulators and intermediates halved, the integrand computed twice, +25 %
+    //  multiply-adds -- was meant to fit 256 registers and two waves per SIMD: the compiler shares the integrand between
+    //  unrolled halves (1 250 values in scratch) and trades vector for scalar registers in a loop over them (400): 30 ms
+    //  against 14 at 64^3 elements.  Dropped; the constant h below is what is left of it.)
+    {
+      constexpr int h = 0, ab = 0;
+      // ---- phase 1: lane = column b = (x0, x1, x2) -------------------------------------------------------------
+      double acc[AH * PP];
+#pragma unroll
+      for (int i = 0; i < AH * PP; i++) acc[i] = 0.0;
+      {
+        const int xh0 = x0;
+        double *Wh = W;
+        double l0[P1], d0[P1];
+#pragma unroll
+        for (int q = 0; q < P1; q++) {
+          l0[q] = TL[xh0 * P1 + q];
+          d0[q] = TD[xh0 * P1 + q];
+        }
+
+#pragma unroll
+        for (int q2 = 0; q2 < P1; q2++) {
+          const double l2q = TL[x2 * P1 + q2], d2q = TD[x2 * P1 + q2];
+          double Zl[AH * P1], Zd[AH * P1];
+#pragma unroll
+          for (int i = 0; i < AH * P1; i++) Zl[i] = Zd[i] = 0.0;
+#pragma unroll
+          for (int q1 = 0; q1 < P1; q1++) {
+            const double l1q = TL[x1 * P1 + q1], d1q = TD[x1 * P1 + q1];
+            if (FORM == 1) {
+              const double mll = l1q * l2q, mdl = d1q * l2q, mld = l1q * d2q;
+              double Y0[AH], Y1[AH], Y2[AH];
+#pragma unroll
+              for (int a = 0; a < AH; a++) Y0[a] = Y1[a] = Y2[a] = 0.0;
+#pragma unroll
+              for (int q0 = 0; q0 < P1; q0++) {
+                const double *Gq = Wh + (eb + q0 + P1 * (q1 + P1 * q2)) * 8;
+                const double f0 = d0[q0] * mll, f1 = l0[q0] * mdl, f2 = l0[q0] * mld;
+                const double X0 = fma(Gq[2], f2, fma(Gq[1], f1, Gq[0] * f0));
+                const double X1 = fma(Gq[4], f2, fma(Gq[3], f1, Gq[1] * f0));
+                const double X2 = fma(Gq[5], f2, fma(Gq[4], f1, Gq[2] * f0));
+#pragma unroll
+                for (int a = 0; a < AH; a++) {
+                  Y0[a] = fma(UD[a * P1 + q0], X0, Y0[a]);
+                  Y1[a] = fma(UL[a * P1 + q0], X1, Y1[a]);
+                  Y2[a] = fma(UL[a * P1 + q0], X2, Y2[a]);
+                }
+              }
+#pragma unroll
+              for (int a1 = 0; a1 < P1; a1++)
+#pragma unroll
+                for (int a0 = 0; a0 < AH; a0++) {
+                  Zl[a0 + AH * a1] = fma(UD[a1 * P1 + q1], Y1[a0], fma(UL[a1 * P1 + q1], Y0[a0], Zl[a0 + AH * a1]));
+                  Zd[a0 + AH * a1] = fma(UL[a1 * P1 + q1], Y2[a0], Zd[a0 + AH * a1]);
+                }
+            } else {
+              const double mll = l1q * l2q;
+              double Y0[AH];
+#pragma unroll
+              for (int a = 0; a < AH; a++) Y0[a] = 0.0;
+#pragma unroll
+              for (int q0 = 0; q0 < P1; q0++) {
+                const double X0 = Wh[(eb + q0 + P1 * (q1 + P1 * q2)) * 8 + 6] * (l0[q0] * mll);
+#pragma unroll
+                for (int a = 0; a < AH; a++) Y0[a] = fma(UL[a * P1 + q0], X0, Y0[a]);
+              }
+#pragma unroll
+              for (int a1 = 0; a1 < P1; a1++)
+#pragma unroll
+                for (int a0 = 0; a0 < AH; a0++) Zl[a0 + AH * a1] = fma(UL[a1 * P1 + q1], Y0[a0], Zl[a0 + AH * a1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (one pencil at a time: the scheduler otherwise pulls the LDS reads of all of them up)
+          }
+#pragma unroll
+          for (int a2 = 0; a2 < P1; a2++)
+#pragma unroll
+            for (int i = 0; i < AH * P1; i++) {
+              if (FORM == 1)
+                acc[i + AH * P1 * a2] = fma(UD[a2 * P1 + q2], Zd[i], fma(UL[a2 * P1 + q2], Zl[i], acc[i + AH * P1 * a2]));
+              else
+                acc[i + AH * P1 * a2] = fma(UL[a2 * P1 + q2], Zl[i], acc[i + AH * P1 * a2]);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+
+      // ---- phase 2 -----------------------------------------------------------------------------------------------
+      // Positions: one base per node plane of direction 2 (a buffer descriptor), everything below it a 32-bit byte
+      // offset (the entries of one plane of rows: (2p+1) T0 T1 < 2^29, checked on the host).  Reads and stores are RAW
+      // BUFFER operations: a lane that has nothing to read or write carries an offset beyond the descriptor's range -- the
+      // hardware drops the access -- so the whole phase is straight-line code without a branch per row.
+      // Two sweeps over the rows of the half: the first issues ALL reads of entries that hold earlier contributions (rows
+      // on faces shared in directions 1, 2, lanes of the shared columns), the second adds and stores: one round trip to
+      // memory per half, not one per (a1, a2) group of rows (12 of ~3 us per element: 67 % of the wave's cycles).
+      const int srcP = min(63, ln - x0 + P);           // the lane that holds column b0 = p of this lane's (b1, b2)
+      const unsigned uT0 = (unsigned)T0;
+      if (!carry_only) {
+        // (p = 3, stiffness: the registers hold the reads of ONE a2 layer of rows at a time -- four round trips per element)
+        constexpr bool LAYERED = FORM == 1 && P1 == 4;
+        constexpr int NPASS = LAYERED ? P1 : 1;
+        double old[(LAYERED ? P1 : PP) * (AH + 1)];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; pass++) {
+#pragma unroll
+          for (int sweep = 0; sweep < 2; sweep++) {
+            // (the offsets are formed again in the second sweep: kept from the first, they would sit in registers)
+            int xs0 = x0, xs1 = x1, xs2 = x2;
+            asm volatile("" : "+v"(xs0), "+v"(xs1), "+v"(xs2));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a2 = LAYERED ? pass : 0; a2 < (LAYERED ? pass + 1 : P1); a2++) {
+              const int r2 = P * e2 + a2;
+              if (r2 < A.za || r2 >= A.zb) continue;                    // (wave-uniform)
+              bool v2;
+              int n2, o2;
+              int64_t rps2;
+              tg_asf_row1d<P>(a2, e2, A.nel[2], v2, n2, o2, rps2);
+              const bool add2 = v2 && par2 && x2 == a2;
+              const __amdgpu_buffer_rsrc_t plane =
+                  __builtin_amdgcn_make_buffer_rsrc(A.val + (T0 * T1 * rps2 - A.base), 0, TG_BUF_RANGE, 0x00020000);
+#pragma unroll
+              for (int a1 = 0; a1 < P1; a1++) {
+                bool v1;
+                int n1, o1;
+                int64_t rps1;
+                tg_asf_row1d<P>(a1, e1, A.nel[1], v1, n1, o1, rps1);
+                const bool add = live && (add2 || (v1 && par1 && x1 == a1));
+                const bool edge12 = a2 == 0 || a2 == P || a1 == 0 || a1 == P;     // rows that may hold earlier contributions
+                const unsigned R12 = (unsigned)n2 * uT0 * (unsigned)rps1;
+                const unsigned n12 = (unsigned)(n2 * n1);
+                const unsigned p12 = (unsigned)((xs2 + o2) * n1 + (xs1 + o1));
+                double *og = old + (a1 + (LAYERED ? 0 : P1 * a2)) * (AH + 1);
+                // first node plane of the element: the rows of the previous element's last plane, completed
+                if (h == 0 && e0 > 0) {
+                  const unsigned rps0 = (unsigned)(P1 * P * e0 + P * (e0 - 1));
+                  const unsigned ro = R12 + n12 * rps0 + p12 * (2 * P + 1);
+                  const unsigned oprev = (ro + (unsigned)xs0) * 8u, ocur = (ro + (unsigned)(P + xs0)) * 8u;
+                  if (sweep == 0) {
+                    og[0] = edge12 ? tg_buf_load(plane, add ? ocur : TG_BUF_OOB) : 0.0;
+                    og[AH] = edge12 ? tg_buf_load(plane, (add && x0 < P) ? oprev : TG_BUF_OOB) : 0.0;
+                  } else {
+                    const double cP = CR[(a1 + P1 * a2) * 64 + srcP];     // column b0 = p of the previous element = b0 = 0 here
+                    double vcur = acc[0 + AH * (a1 + P1 * a2)] + (x0 == 0 ? cP : 0.0);
+                    double vprev = CR[(a1 + P1 * a2) * 64 + ln];
+                    if (edge12) {
+                      vcur += og[0];
+                      vprev += og[AH];
+                    }
+                    tg_buf_store(vprev, plane, (live && x0 < P) ? oprev : TG_BUF_OOB);
+                    tg_buf_store(vcur, plane, live ? ocur : TG_BUF_OOB);
+                  }
+                }
+#pragma unroll
+                for (int ah = 0; ah < AH; ah++) {
+                  const int a0 = ab + ah;                                 // (wave-uniform)
+                  if (a0 > P) continue;
+                  if (a0 == 0 && e0 > 0) continue;                        // (written above, merged)
+                  if (a0 == P && !last0) continue;                        // (carried to the next element)
+                  const unsigned rps0 = (unsigned)(P1 * (P * e0 + a0) + (a0 > 0 ? P * e0 : 0));
+                  const unsigned off = (R12 + n12 * rps0 + p12 * P1 + (unsigned)xs0) * 8u;
+                  if (sweep == 0) {
+                    og[ah] = edge12 ? tg_buf_load(plane, add ? off : TG_BUF_OOB) : 0.0;
+                  } else {
+                    double v = acc[ah + AH * (a1 + P1 * a2)];
+                    if (edge12) v += og[ah];
+                    tg_buf_store(v, plane, live ? off : TG_BUF_OOB);
+                  }
+                }
+                if (sweep == 1) __builtin_amdgcn_sched_barrier(0);      // (stores group by group: their operands are not collected up front)
+              }
+            }
+          }
+        }
+      }
+      // the element's last node plane in direction 0 becomes the carry
+      if (!last0) {
+#pragma unroll
+        for (int i = 0; i < PP; i++) CR[i * 64 + ln] = acc[P + AH * i];
+      }
+    }
+    tg_wave_sync();        // (the next element's nodal values overwrite the area G sits in)
+  }
+}
+
+// The same element matrices with ONE ELEMENT PER WAVE and eight colours (parities of the element index in all three
+// directions): no walk, no carry -- rows of vertices in direction 0 leave as runs of p + 1 columns.  Kept for the p = 3
+// stiffness matrix, where the walk's loop costs more registers than the kernel has (512 and 300 values in scratch;
+// 14 ms against this kernel's 7 ms at 64^3 elements); every other (p, form) is faster on the walk (§DESIGN 6b).
+template <int P1, int EPW, int FORM>
+__global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3_elem(tg_asf_args A) {
+  constexpr int P = P1 - 1, NL = P1 * P1 * P1, LPE = 64 / EPW, PP = P1 * P1;
+  static_assert(NL <= LPE, "an element needs a lane per local node");
+  __shared__ __attribute__((aligned(16))) double s_tab[2 * PP + P1];
+  __shared__ __attribute__((aligned(16))) double s_w[TG_ASF_NW][TG_ASF_AREA(4)];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int s = tid; s < 2 * PP + P1; s += 64 * TG_ASF_NW) s_tab[s] = A.tab[s];
+  __syncthreads();
+  const int64_t grp = (int64_t)blockIdx.x * TG_ASF_NW + wv;
+  if (grp >= A.ngroups) return;
+  const double *TL = s_tab, *TD = s_tab + PP, *TW = s_tab + 2 * PP;
+  tg_cdp4 UL = (tg_cdp4)A.tab, UD = (tg_cdp4)A.tab + PP;
+  double *W = s_w[wv];
+  const int es = lane / LPE, li = lane - es * LPE, eb = es * LPE;
+  const bool active = li < NL;
+  const int x0 = li % P1, x1 = (li / P1) % P1, x2 = (li / PP) % P1;
+  const int gx = (int)(grp % A.ngy);
+  const int64_t rest = grp / A.ngy;
+  const int i1 = (int)(rest % A.ncol[1]), i2 = (int)(rest / A.ncol[1]);
+  const int i0 = gx * EPW + es;
+  const bool evalid = i0 < A.ncol[0];
+  const bool live = active && evalid;
+  const int e0 = A.efirst[0] + 2 * (evalid ? i0 : A.ncol[0] - 1), e1 = A.efirst[1] + 2 * i1, e2 = A.efirst[2] + 2 * i2;
+  // ---- phase 0 ----------------------------------------------------------------------------------------------
+  if (active) {
+    const int64_t node = (int64_t)(e0 * P + x0) + (int64_t)A.n[0] * ((e1 * P + x1) + (int64_t)A.n[1] * (e2 * P + x2)) - A.cp_node0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) W[c * 64 + lane] = A.cp[c][node];
   }
   tg_wave_sync();
-
+  {
+    double N[4], dN[4][3], G[7] = {0, 0, 0, 0, 0, 0, 0};
+    tg_asf_to_points<P1, 4>(W, TL, TD, lane, eb, x0, x1, x2, active, N, dN);
+    if (active) tg_asf_metric(N, dN, TW[x0] * TW[x1] * TW[x2], G);
+    tg_wave_sync();
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 7; j++) W[(eb + li) * 8 + j] = G[j];
+    }
+    tg_wave_sync();
+  }
   // ---- phase 1: lane = column b = (x0, x1, x2) -----------------------------------------------------------------
   double acc[NL];
 #pragma unroll
   for (int i = 0; i < NL; i++) acc[i] = 0.0;
-  double l0[P1], d0[P1];
+  {
+    double l0[P1], d0[P1];
 #pragma unroll
-  for (int q = 0; q < P1; q++) {
-    l0[q] = TL[x0 * P1 + q];
-    d0[q] = TD[x0 * P1 + q];
-  }
-#pragma unroll
-  for (int q2 = 0; q2 < P1; q2++) {
-    const double l2q = TL[x2 * P1 + q2], d2q = TD[x2 * P1 + q2];
-    double Zl[PP], Zd[PP];
-#pragma unroll
-    for (int i = 0; i < PP; i++) Zl[i] = Zd[i] = 0.0;
-#pragma unroll
-    for (int q1 = 0; q1 < P1; q1++) {
-      const double l1q = TL[x1 * P1 + q1], d1q = TD[x1 * P1 + q1];
-      if (FORM == 1) {
-        const double mll = l1q * l2q, mdl = d1q * l2q, mld = l1q * d2q;
-        double Y0[P1], Y1[P1], Y2[P1];
-#pragma unroll
-        for (int a = 0; a < P1; a++) Y0[a] = Y1[a] = Y2[a] = 0.0;
-#pragma unroll
-        for (int q0 = 0; q0 < P1; q0++) {
-          const double *Gq = W + (eb + q0 + P1 * (q1 + P1 * q2)) * 8;
-          const double f0 = d0[q0] * mll, f1 = l0[q0] * mdl, f2 = l0[q0] * mld;
-          const double X0 = fma(Gq[2], f2, fma(Gq[1], f1, Gq[0] * f0));
-          const double X1 = fma(Gq[4], f2, fma(Gq[3], f1, Gq[1] * f0));
-          const double X2 = fma(Gq[5], f2, fma(Gq[4], f1, Gq[2] * f0));
-#pragma unroll
-          for (int a = 0; a < P1; a++) {
-            Y0[a] = fma(UD[a * P1 + q0], X0, Y0[a]);
-            Y1[a] = fma(UL[a * P1 + q0], X1, Y1[a]);
-            Y2[a] = fma(UL[a * P1 + q0], X2, Y2[a]);
-          }
-        }
-#pragma unroll
-        for (int a1 = 0; a1 < P1; a1++)
-#pragma unroll
-          for (int a0 = 0; a0 < P1; a0++) {
-            Zl[a0 + P1 * a1] = fma(UD[a1 * P1 + q1], Y1[a0], fma(UL[a1 * P1 + q1], Y0[a0], Zl[a0 + P1 * a1]));
-            Zd[a0 + P1 * a1] = fma(UL[a1 * P1 + q1], Y2[a0], Zd[a0 + P1 * a1]);
-          }
-      } else {
-        const double mll = l1q * l2q;
-        double Y0[P1];
-#pragma unroll
-        for (int a = 0; a < P1; a++) Y0[a] = 0.0;
-#pragma unroll
-        for (int q0 = 0; q0 < P1; q0++) {
-          const double X0 = W[(eb + q0 + P1 * (q1 + P1 * q2)) * 8 + 6] * (l0[q0] * mll);
-#pragma unroll
-          for (int a = 0; a < P1; a++) Y0[a] = fma(UL[a * P1 + q0], X0, Y0[a]);
-        }
-#pragma unroll
-        for (int a1 = 0; a1 < P1; a1++)
-#pragma unroll
-          for (int a0 = 0; a0 < P1; a0++) Zl[a0 + P1 * a1] = fma(UL[a1 * P1 + q1], Y0[a0], Zl[a0 + P1 * a1]);
-      }
+    for (int q = 0; q < P1; q++) {
+      l0[q] = TL[x0 * P1 + q];
+      d0[q] = TD[x0 * P1 + q];
     }
 #pragma unroll
-    for (int a2 = 0; a2 < P1; a2++)
+    for (int q2 = 0; q2 < P1; q2++) {
+      const double l2q = TL[x2 * P1 + q2], d2q = TD[x2 * P1 + q2];
+      double Zl[PP], Zd[PP];
 #pragma unroll
-      for (int i = 0; i < PP; i++) {
-        if (FORM == 1)
-          acc[i + PP * a2] = fma(UD[a2 * P1 + q2], Zd[i], fma(UL[a2 * P1 + q2], Zl[i], acc[i + PP * a2]));
-        else
-          acc[i + PP * a2] = fma(UL[a2 * P1 + q2], Zl[i], acc[i + PP * a2]);
+      for (int i = 0; i < PP; i++) Zl[i] = Zd[i] = 0.0;
+#pragma unroll
+      for (int q1 = 0; q1 < P1; q1++) {
+        const double l1q = TL[x1 * P1 + q1], d1q = TD[x1 * P1 + q1];
+        if (FORM == 1) {
+          const double mll = l1q * l2q, mdl = d1q * l2q, mld = l1q * d2q;
+          double Y0[P1], Y1[P1], Y2[P1];
+#pragma unroll
+          for (int a = 0; a < P1; a++) Y0[a] = Y1[a] = Y2[a] = 0.0;
+#pragma unroll
+          for (int q0 = 0; q0 < P1; q0++) {
+            const double *Gq = W + (eb + q0 + P1 * (q1 + P1 * q2)) * 8;
+            const double f0 = d0[q0] * mll, f1 = l0[q0] * mdl, f2 = l0[q0] * mld;
+            const double X0 = fma(Gq[2], f2, fma(Gq[1], f1, Gq[0] * f0));
+            const double X1 = fma(Gq[4], f2, fma(Gq[3], f1, Gq[1] * f0));
+            const double X2 = fma(Gq[5], f2, fma(Gq[4], f1, Gq[2] * f0));
+#pragma unroll
+            for (int a = 0; a < P1; a++) {
+              Y0[a] = fma(UD[a * P1 + q0], X0, Y0[a]);
+              Y1[a] = fma(UL[a * P1 + q0], X1, Y1[a]);
+              Y2[a] = fma(UL[a * P1 + q0], X2, Y2[a]);
+            }
+          }
+#pragma unroll
+          for (int a1 = 0; a1 < P1; a1++)
+#pragma unroll
+            for (int a0 = 0; a0 < P1; a0++) {
+              Zl[a0 + P1 * a1] = fma(UD[a1 * P1 + q1], Y1[a0], fma(UL[a1 * P1 + q1], Y0[a0], Zl[a0 + P1 * a1]));
+              Zd[a0 + P1 * a1] = fma(UL[a1 * P1 + q1], Y2[a0], Zd[a0 + P1 * a1]);
+            }
+        } else {
+          const double mll = l1q * l2q;
+          double Y0[P1];
+#pragma unroll
+          for (int a = 0; a < P1; a++) Y0[a] = 0.0;
+#pragma unroll
+          for (int q0 = 0; q0 < P1; q0++) {
+            const double X0 = W[(eb + q0 + P1 * (q1 + P1 * q2)) * 8 + 6] * (l0[q0] * mll);
+#pragma unroll
+            for (int a = 0; a < P1; a++) Y0[a] = fma(UL[a * P1 + q0], X0, Y0[a]);
+          }
+#pragma unroll
+          for (int a1 = 0; a1 < P1; a1++)
+#pragma unroll
+            for (int a0 = 0; a0 < P1; a0++) Zl[a0 + P1 * a1] = fma(UL[a1 * P1 + q1], Y0[a0], Zl[a0 + P1 * a1]);
+        }
       }
+#pragma unroll
+      for (int a2 = 0; a2 < P1; a2++)
+#pragma unroll
+        for (int i = 0; i < PP; i++) {
+          if (FORM == 1)
+            acc[i + PP * a2] = fma(UD[a2 * P1 + q2], Zd[i], fma(UL[a2 * P1 + q2], Zl[i], acc[i + PP * a2]));
+          else
+            acc[i + PP * a2] = fma(UL[a2 * P1 + q2], Zl[i], acc[i + PP * a2]);
+        }
+    }
   }
-
-  // ---- phase 2: the rows of the element, one store of the wave per row ---------------------------------------------
-  // 1-D row data of node r = P e + a: n = row length, o = position of the element's first column in the row,
-  // rps = entries of the 1-D rows before r; T = entries of all 1-D rows
+  // ---- phase 2: layer by layer of a2; per layer all reads of earlier contributions, then the stores ------------------
   const int64_t T0 = (int64_t)P1 * A.n[0] + (int64_t)P * (A.nel[0] - 1), T1 = (int64_t)P1 * A.n[1] + (int64_t)P * (A.nel[1] - 1);
+  const unsigned uT0 = (unsigned)T0;
   const int par0 = e0 & 1, par1 = e1 & 1, par2 = e2 & 1;
 #pragma unroll
   for (int a2 = 0; a2 < P1; a2++) {
     const int r2 = P * e2 + a2;
     if (r2 < A.za || r2 >= A.zb) continue;                        // (wave-uniform)
-    const bool v2 = (a2 == 0 && e2 > 0) || (a2 == P && e2 < A.nel[2] - 1);
-    const int n2 = v2 ? 2 * P + 1 : P1, o2 = (a2 == 0 && e2 > 0) ? P : 0;
-    const int64_t rps2 = (int64_t)P1 * r2 + (a2 > 0 ? (int64_t)P * e2 : (e2 > 0 ? (int64_t)P * (e2 - 1) : 0));
+    bool v2;
+    int n2, o2;
+    int64_t rps2;
+    tg_asf_row1d<P>(a2, e2, A.nel[2], v2, n2, o2, rps2);
     const bool add2 = v2 && par2 && x2 == a2;
+    const __amdgpu_buffer_rsrc_t plane =
+        __builtin_amdgcn_make_buffer_rsrc(A.val + (T0 * T1 * rps2 - A.base), 0, TG_BUF_RANGE, 0x00020000);
+    double old[PP];
 #pragma unroll
-    for (int a1 = 0; a1 < P1; a1++) {
-      const int r1 = P * e1 + a1;
-      const bool v1 = (a1 == 0 && e1 > 0) || (a1 == P && e1 < A.nel[1] - 1);
-      const int n1 = v1 ? 2 * P + 1 : P1, o1 = (a1 == 0 && e1 > 0) ? P : 0;
-      const int64_t rps1 = (int64_t)P1 * r1 + (a1 > 0 ? (int64_t)P * e1 : (e1 > 0 ? (int64_t)P * (e1 - 1) : 0));
-      const bool add1 = v1 && par1 && x1 == a1;
+    for (int sweep = 0; sweep < 2; sweep++) {
+      int xs0 = x0, xs1 = x1, xs2 = x2;
+      asm volatile("" : "+v"(xs0), "+v"(xs1), "+v"(xs2));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int a0 = 0; a0 < P1; a0++) {
-        const int r0 = P * e0 + a0;                               // (per lane when EPW > 1)
-        const bool v0 = (a0 == 0 && e0 > 0) || (a0 == P && e0 < A.nel[0] - 1);
-        const int n0 = v0 ? 2 * P + 1 : P1, o0 = (a0 == 0 && e0 > 0) ? P : 0;
-        const int64_t rps0 = (int64_t)P1 * r0 + (a0 > 0 ? (int64_t)P * e0 : (e0 > 0 ? (int64_t)P * (e0 - 1) : 0));
-        const bool add0 = v0 && par0 && x0 == a0;
-        const int64_t R = T0 * T1 * rps2 - A.base + (int64_t)n2 * (T0 * rps1 + (int64_t)n1 * rps0);
-        const int64_t pos = (int64_t)((x2 + o2) * n1 + (x1 + o1)) * n0 + (x0 + o0);
-        const double v = acc[a0 + P1 * (a1 + P1 * a2)];
-        if (active && evalid) {
-          double *dst = A.val + R + pos;
-          if (add0 || add1 || add2)
-            __builtin_amdgcn_global_atomic_fadd_f64((tg_gdp1)dst, v);   // (one contributor per launch: an ordered sum)
-          else
-            *dst = v;
+      for (int a1 = 0; a1 < P1; a1++) {
+        bool v1;
+        int n1, o1;
+        int64_t rps1;
+        tg_asf_row1d<P>(a1, e1, A.nel[1], v1, n1, o1, rps1);
+        const bool add1 = v1 && par1 && x1 == a1;
+#pragma unroll
+        for (int a0 = 0; a0 < P1; a0++) {
+          bool v0;
+          int n0, o0;
+          int64_t rps0;
+          tg_asf_row1d<P>(a0, e0, A.nel[0], v0, n0, o0, rps0);
+          const bool add = live && (add2 || add1 || (v0 && par0 && x0 == a0));
+          const bool edge = a2 == 0 || a2 == P || a1 == 0 || a1 == P || a0 == 0 || a0 == P;
+          const unsigned off = ((unsigned)n2 * (uT0 * (unsigned)rps1 + (unsigned)n1 * (unsigned)rps0) +
+                                (unsigned)(((xs2 + o2) * n1 + (xs1 + o1)) * n0 + (xs0 + o0))) * 8u;
+          if (sweep == 0) {
+            old[a0 + P1 * a1] = edge ? tg_buf_load(plane, add ? off : TG_BUF_OOB) : 0.0;
+          } else {
+            double v = acc[a0 + P1 * (a1 + P1 * a2)];
+            if (edge) v += old[a0 + P1 * a1];
+            tg_buf_store(v, plane, live ? off : TG_BUF_OOB);
+          }
         }
       }
     }
   }
 }
 
+// L(v) = int f_h v: lane = quadrature point computes w sqrt(det g) f_h, three 1-D contractions back to the nodes (through
+// LDS), each node's value added to the vector (zeroed before; colour by colour, elements of a launch share no node)
+template <int P1, int EPW>
+__global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3_load(tg_asf_args A) {
+  constexpr int P = P1 - 1, NL = P1 * P1 * P1, LPE = 64 / EPW, PP = P1 * P1;
+  __shared__ __attribute__((aligned(16))) double s_tab[2 * PP + P1];
+  __shared__ __attribute__((aligned(16))) double s_w[TG_ASF_NW][TG_ASF_AREA(5)];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int s = tid; s < 2 * PP + P1; s += 64 * TG_ASF_NW) s_tab[s] = A.tab[s];
+  __syncthreads();
+  const int64_t grp = (int64_t)blockIdx.x * TG_ASF_NW + wv;
+  if (grp >= A.ngroups) return;
+  const double *TL = s_tab, *TD = s_tab + PP, *TW = s_tab + 2 * PP;
+  double *W = s_w[wv];
+  const int es = lane / LPE, li = lane - es * LPE, eb = es * LPE;
+  const bool active = li < NL;
+  const int x0 = li % P1, x1 = (li / P1) % P1, x2 = (li / PP) % P1;
+  const int gx = (int)(grp % A.ngy);
+  const int64_t rest = grp / A.ngy;
+  const int i1 = (int)(rest % A.ncol[1]), i2 = (int)(rest / A.ncol[1]);
+  const int i0 = gx * EPW + es;
+  const bool evalid = i0 < A.ncol[0];
+  const int e0 = A.efirst[0] + 2 * (evalid ? i0 : A.ncol[0] - 1), e1 = A.efirst[1] + 2 * i1, e2 = A.efirst[2] + 2 * i2;
+  const int64_t node = (int64_t)(e0 * P + x0) + (int64_t)A.n[0] * ((e1 * P + x1) + (int64_t)A.n[1] * (e2 * P + x2));
+  if (active) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) W[c * 64 + lane] = A.cp[c][node - A.cp_node0];
+    W[4 * 64 + lane] = A.fnod[node - A.cp_node0];
+  }
+  tg_wave_sync();
+  double N[5], dN[5][3], G[7] = {0, 0, 0, 0, 0, 0, 0};
+  tg_asf_to_points<P1, 5>(W, TL, TD, lane, eb, x0, x1, x2, active, N, dN);
+  if (active) tg_asf_metric(N, dN, TW[x0] * TW[x1] * TW[x2], G);
+  tg_wave_sync();
+  // s(q) = w sqrt(det g) f_h(q) back to the nodes: lane (a0, q1, q2), then (a0, a1, q2), then (a0, a1, a2)
+  double *S0 = W, *S1 = W + 64, *S2 = W + 128;
+  if (active) S0[lane] = G[6] * N[4];
+  tg_wave_sync();
+  if (active) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < P1; q++) v = fma(TL[x0 * P1 + q], S0[eb + q + P1 * (x1 + P1 * x2)], v);
+    S1[lane] = v;
+  }
+  tg_wave_sync();
+  if (active) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < P1; q++) v = fma(TL[x1 * P1 + q], S1[eb + x0 + P1 * (q + P1 * x2)], v);
+    S2[lane] = v;
+  }
+  tg_wave_sync();
+  if (active && evalid) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < P1; q++) v = fma(TL[x2 * P1 + q], S2[eb + x0 + P1 * (x1 + P1 * q)], v);
+    const int r2 = P * e2 + x2;
+    if (r2 >= A.za && r2 < A.zb) A.val[node - A.row0] += v;
+  }
+}
+
 static inline int64_t tg_rps_host(int p, int a) { return (int64_t)(p + 1) * a + (a > 0 ? (int64_t)p * ((a - 1) / p) : 0); }
 
 template <int P1, int EPW>
-static void tg_asf_launch(int form, const tg_asf_args &A, unsigned nblk) {
-  if (form == 1)
+static void tg_asf_launch(int form, const tg_asf_args &A, unsigned nblk, bool walk) {
+  if (!walk && form == 1)
+    hipLaunchKernelGGL((k_asf3_elem<P1, EPW, 1>), dim3(nblk), dim3(64 * TG_ASF_NW), 0, g_tg.stream, A);
+  else if (!walk && form == 0)
+    hipLaunchKernelGGL((k_asf3_elem<P1, EPW, 0>), dim3(nblk), dim3(64 * TG_ASF_NW), 0, g_tg.stream, A);
+  else if (form == 1)
     hipLaunchKernelGGL((k_asf3<P1, EPW, 1>), dim3(nblk), dim3(64 * TG_ASF_NW), 0, g_tg.stream, A);
-  else
+  else if (form == 0)
     hipLaunchKernelGGL((k_asf3<P1, EPW, 0>), dim3(nblk), dim3(64 * TG_ASF_NW), 0, g_tg.stream, A);
+  else
+    hipLaunchKernelGGL((k_asf3_load<P1, EPW>), dim3(nblk), dim3(64 * TG_ASF_NW), 0, g_tg.stream, A);
 }
 
 // reference-element tables l[a][q] | dl[a][q] | w[q]: equispaced Lagrange nodes a/p at the Gauss points
@@ -666,7 +1064,11 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
   TG_TRY(tg_asm_cache_get(pt));
   for (int k = 0; k < d; k++) A.verts[k] = g_asm_cache.verts[k];
   A.tab = g_asm_cache.tab;
-  const bool fast = form != 2 && d == 3 && pt->nsd == 3 && pt->nq == p1 && p <= 3 && !getenv("TIGAR_ASM_LEGACY");
+  bool fast = d == 3 && pt->nsd == 3 && pt->nq == p1 && p <= 3 && !getenv("TIGAR_ASM_LEGACY");
+  if (fast) {   // the walk kernel addresses the entries of one plane of rows in 32 bits
+    const double t0 = (double)p1 * A.n[0] + (double)p * (A.nel[0] - 1), t1 = (double)p1 * A.n[1] + (double)p * (A.nel[1] - 1);
+    if ((2.0 * p + 1.0) * t0 * t1 * 8.0 >= 4294967000.0) fast = false;      // (byte offsets inside one plane of rows)
+  }
 
   tg_csr_s *m = nullptr;
   if (form != 2) {
@@ -725,18 +1127,34 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
       F.n[k] = A.n[k];
     }
     for (int c = 0; c < 4; c++) F.cp[c] = A.cp[c];
+    F.fnod = A.fnod;
     F.cp_node0 = cp_node0;
     F.tab = A.tab;
-    F.val = m->val;
+    F.val = form == 2 ? A.bout : m->val;
+    F.row0 = row0;
     F.za = za;
     F.zb = zb;
     const int64_t T0 = (int64_t)p1 * A.n[0] + (int64_t)p * (A.nel[0] - 1), T1 = (int64_t)p1 * A.n[1] + (int64_t)p * (A.nel[1] - 1);
     F.base = T0 * T1 * tg_rps_host(p, za);
+    // pieces of a line of elements: long enough that the element a piece starts early with (it only feeds the carry)
+    // costs little, short enough that a launch has waves for every SIMD
+    int chunk = getenv("TIGAR_ASM_CHUNK") ? atoi(getenv("TIGAR_ASM_CHUNK")) : 16;
+    if (chunk < 1) chunk = 1;
+    F.chunk = chunk;
+    F.nchunks = (A.nel[0] + chunk - 1) / chunk;
   }
   const int nt = (form == 2) ? 128 : 256;
   bool bad = false;
-  // one launch per colour (parity of the element index per direction), colours in ascending order
+  const bool timeit = getenv("TIGAR_ASM_TIME") != nullptr;
+  if (timeit) hipEventRecord(g_tg.ev0[0], g_tg.stream);
+  const int epw = p == 3 ? 1 : (p == 2 ? 2 : 8);
+  // one launch per colour (parity of the element index per direction), colours in ascending order; the walks of the
+  // sum-factorised matrix kernel need no colouring in direction 0
+  // the walk along direction 0 for every matrix form but the p = 3 stiffness matrix (see k_asf3_elem); TIGAR_ASM_WALK=0/1 forces
+  bool walk = fast && form != 2 && !(p == 3 && form == 1) && p != 1;
+  if (fast && form != 2 && getenv("TIGAR_ASM_WALK")) walk = atoi(getenv("TIGAR_ASM_WALK")) != 0;
   for (int c = 0; c < (1 << d) && !bad && zb > za; c++) {
+    if (walk && (c & 1)) continue;
     int64_t nblk = 1;
     for (int k = 0; k < 3; k++) {
       const int par = k < d ? (c >> k) & 1 : 0;
@@ -748,25 +1166,37 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
       const int first = lo + (((par - lo) % 2) + 2) % 2;       // first index >= lo with this parity
       A.efirst[k] = F.efirst[k] = k < d ? first : 0;
       A.ncol[k] = F.ncol[k] = k < d ? (hi > first ? (hi - first + 1) / 2 : 0) : 1;
-      nblk *= A.ncol[k];
+      if (!(walk && k == 0)) nblk *= A.ncol[k];
     }
     if (nblk == 0) continue;
     if (fast) {
-      const int epw = p == 3 ? 1 : (p == 2 ? 2 : 8);
-      F.ngx = (F.ncol[0] + epw - 1) / epw;
-      F.ngroups = (int64_t)F.ngx * F.ncol[1] * F.ncol[2];
+      if (walk) {
+        F.ngy = (F.ncol[1] + epw - 1) / epw;
+        F.ngroups = (int64_t)F.nchunks * F.ngy * F.ncol[2];
+      } else {
+        F.ngy = (F.ncol[0] + epw - 1) / epw;
+        F.ngroups = (int64_t)F.ngy * F.ncol[1] * F.ncol[2];
+      }
       const unsigned nb = (unsigned)((F.ngroups + TG_ASF_NW - 1) / TG_ASF_NW);
       if (p == 3)
-        tg_asf_launch<4, 1>(form, F, nb);
+        tg_asf_launch<4, 1>(form, F, nb, walk);
       else if (p == 2)
-        tg_asf_launch<3, 2>(form, F, nb);
+        tg_asf_launch<3, 2>(form, F, nb, walk);
       else
-        tg_asf_launch<2, 8>(form, F, nb);
+        tg_asf_launch<2, 8>(form, F, nb, walk);
     } else {
       TG_REQUIRE(nblk < (1ll << 31), "too many elements for one launch");
       hipLaunchKernelGGL(k_assemble_mapped, dim3((unsigned)nblk), dim3(nt), lds, g_tg.stream, A);
     }
     bad = hipGetLastError() != hipSuccess;
+  }
+  if (timeit) {
+    hipEventRecord(g_tg.ev1[0], g_tg.stream);
+    hipEventSynchronize(g_tg.ev1[0]);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, g_tg.ev0[0], g_tg.ev1[0]);
+    fprintf(stderr, "[tg_assemble] form %d rows [%lld, %lld): element kernels %.3f ms (%s)\n", form, (long long)row0, (long long)row1,
+            ms, fast ? "sum-factorised" : "plain");
   }
   if (bad) {
     if (m) tg_csr_destroy(m);

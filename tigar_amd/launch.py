@@ -216,26 +216,50 @@ class SocketTransport(Transport):
     def barrier(self):
         self.allreduce_max(0.0)
 
-    def sendrecv(self, peer, send, recv):
+    def sendrecv(self, peer, send, recv, tag=0):
         """Exchange with a neighbour rank: ``send`` goes out while ``recv`` (a writable float64 array) fills;
-        interleaved with select() so that two ranks sending large pieces to each other cannot block."""
+        interleaved with select() so that two ranks sending large pieces to each other cannot block.  Every message is
+        FRAMED: a 24-byte header (magic, ``tag``, payload bytes) travels in front of the payload and the receiver checks it
+        against what it expects -- two ranks whose calls do not pair up (different numbers of exchanges, a different
+        window) raise here instead of reading each other's bytes as data."""
         c = self.nbr[int(peer)]
-        out = memoryview(np.ascontiguousarray(send, dtype=np.float64)).cast("B") if send is not None and len(send) else b""
+        out = memoryview(np.ascontiguousarray(send, dtype=np.float64)).cast("B") if send is not None and len(send) else memoryview(b"")
         inn = memoryview(recv).cast("B") if recv is not None and len(recv) else memoryview(bytearray(0))
-        so, ro = 0, 0
+        magic = 0x7469674672616D65
+        hdr_out = memoryview(struct.pack("<QqQ", magic, int(tag), len(out)))
+        hdr_in = memoryview(bytearray(24))
+        outs, ins = [hdr_out, out], [hdr_in, inn]
+        so, ro = [0, 0], [0, 0]
+        checked = False
+
+        def pending(bufs, pos):
+            for k in (0, 1):
+                if pos[k] < len(bufs[k]):
+                    return k
+            return -1
         c.setblocking(False)
         try:
-            while so < len(out) or ro < len(inn):
-                rl, wl, _ = select.select([c] if ro < len(inn) else [], [c] if so < len(out) else [], [], 60.0)
+            while True:
+                ko, ki = pending(outs, so), pending(ins, ro)
+                if ki != 0 and not checked:
+                    m, t, nb = struct.unpack("<QqQ", bytes(hdr_in))
+                    if m != magic or t != int(tag) or nb != len(inn):
+                        raise RuntimeError("sendrecv with rank %d out of step: expected tag %d with %d bytes, the peer sent tag "
+                                           "%d with %d bytes (magic %s) -- the ranks' exchanges do not pair up"
+                                           % (peer, int(tag), len(inn), t, nb, "ok" if m == magic else "bad"))
+                    checked = True
+                if ko < 0 and ki < 0:
+                    break
+                rl, wl, _ = select.select([c] if ki >= 0 else [], [c] if ko >= 0 else [], [], 60.0)
                 if not rl and not wl:
                     raise TimeoutError("sendrecv with rank %d stalled" % peer)
                 if wl:
-                    so += c.send(out[so:so + (1 << 20)])
+                    so[ko] += c.send(outs[ko][so[ko]:so[ko] + (1 << 20)])
                 if rl:
-                    got = c.recv_into(inn[ro:], len(inn) - ro)
+                    got = c.recv_into(ins[ki][ro[ki]:], len(ins[ki]) - ro[ki])
                     if got == 0:
                         raise ConnectionError("neighbour rank %d closed the connection" % peer)
-                    ro += got
+                    ro[ki] += got
         finally:
             c.setblocking(True)
 
