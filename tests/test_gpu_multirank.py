@@ -429,3 +429,40 @@ def test_rccl_ranks_one_gpu_each(tmp_path, d, p, nel, method):
     ref = _single(d, p, nel, method)
     parts = _run_ranks(tmp_path, world, "rccl", d, p, nel, method, 29900 + world)
     _compare(parts, ref, world, "rccl")
+
+
+def test_bench_launcher_with_two_ranks_on_the_shared_gpu(tmp_path):
+    """the first real multi-GPU run must not also be the first run of ``bench.py --gpus N`` itself.  The
+    launcher path (bench.py spawns its ranks through tigar_amd.launch.spawn_local, the ranks find each other, rank 0 prints
+    ONE JSON line) with two ranks SHARING the test box's GPU over the IPC communicator: devices actually used = 1, the
+    communicator says what served, per-rank stage times are there, the self-check of the timed solve passes, and the
+    iteration count is that of a one-rank run of the same command."""
+    import json
+    import subprocess
+
+    def run(gpus, extra_env):
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(29500 + 53 * gpus + 7))
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        env.update(extra_env)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "cfg2",
+                              "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--companion", "0", "--live-traffic", "0"],
+                             env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, "exactly one JSON line: %r" % (out.stdout[-500:],)
+        return json.loads(lines[0])
+
+    one = run(1, {})
+    two = run(2, {"TIGAR_COMM": "ipc", "TIGAR_DEVICE": "0"})
+    cfg = two["config"]
+    assert two["n_gpus"] == 1                               # devices actually used, not what argv asked for
+    assert cfg["ranks"] == 2 and cfg["communicator"] == "ipc"
+    assert cfg["per_rank_stages_s"] is not None and len(cfg["per_rank_stages_s"]) == 2
+    assert all(set(("extract", "ptap", "mtb", "solve")) <= set(r) for r in cfg["per_rank_stages_s"])
+    assert sum(r["dof_rows"] for r in cfg["per_rank_stages_s"]) == cfg["dofs"] == one["config"]["dofs"]
+    assert cfg["self_check_rel_residual_all_ranks"] is not None and cfg["self_check_rel_residual_all_ranks"] <= 1e-6
+    assert cfg["cg_iterations"] == one["config"]["cg_iterations"]
+    assert two["metric"] == one["metric"] and two["unit"] == "DoF/s" and two["steps"] == 1
+    assert "roofline" in two and two["roofline"]["bound"] == "hbm"
