@@ -293,6 +293,22 @@ typedef struct {
 typedef struct tg_tensor_plan_s *tg_tensor_plan_t;
 typedef struct tg_tensor_planes_s *tg_tensor_planes_t;
 int tg_tensor_plan_create(int d, const tg_tensor_dir_t *dirs, tg_tensor_plan_t *out);
+/* The same plan for ONE BLOCK of a space whose fields sit on different spline bases over one FE node grid -- the
+ * components of a div- or curl-conforming B-spline (tIGAr/compatibleSplines.py:21-66: generateFieldsCompat; the spaces of
+ * demos/taylor-green/taylor-green-3d.py:42-43), a FieldListSpline (tIGAr/common.py:1949-1970):
+ *     K_fg = M_f^T A_fg M_g   with  M_f != M_g.
+ * Per direction: p = degree of the FE grid (all fields of such a space extract to one Q_p grid: BSpline.getDegree is the
+ * largest directional degree, tIGAr/BSplines.py:580-588), pr / pc = spline degree of the row / column side (<= p), wlr /
+ * wlc = their local weights [nel][p+1][p+1] padded with zeros to p + 1 functions per element.  The passes are those of the
+ * square plan; the last one writes the true pattern (row function i x column functions [i - pr, i + pc]) and leaves the
+ * padding out.  tg_tensor_zstage takes no zero dofs for such a plan (MatZeroRowsColumns acts on the assembled matrix). */
+typedef struct {
+  int p, nel;
+  int pr, pc;
+  const double *wlr, *wlc;
+} tg_tensor_pair_dir_t;
+int tg_tensor_plan_create_pair(int d, const tg_tensor_pair_dir_t *dirs, tg_tensor_plan_t *out);
+
 int tg_tensor_plan_destroy(tg_tensor_plan_t plan);
 /* The same for a patch with TWO parametric directions and nfields fields on one scalar basis (M = I (x) M_y (x) M_x,
  * dofs field after field; degrees 1..4): K = M^T A M of the whole matrix in two passes, MatZeroRowsColumns fused.

@@ -493,3 +493,70 @@ def test_kronecker_sum_forms_are_fused_into_the_x_pass_bit_for_bit():
         Ko = O.extract_matrix(Mo, Ao, list(spline.zeroDofs), diag=2.0)
         assert np.array_equal(Ks[0].indices, Ko.indices)
         assert np.max(np.abs(Ks[0].data - Ko.data)) <= 1e-12 * np.max(np.abs(Ko.data))
+
+
+# ---- round 5: blocks with different spline bases on the row and the column side (fields of compatible splines) -----------
+def _compat_fields(kind, degs, nels):
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, common as tc
+    from tigar_amd.compatibleSplines import BSplineCompat
+    from tigar_amd.kronptap import KronExtraction
+    kv = [B.uniformKnots(degs[k], 0., 1. + 0.25 * k, nels[k]) for k in range(3)]
+    gen = BSplineCompat(tc.selfcomm, B.ExplicitBSplineControlMesh(list(degs), kv), kind, list(degs))
+    kxs = [KronExtraction(gen.getFieldSpline(f), gen.V.grids[f]) for f in range(3)]
+    return gen, kxs
+
+
+@pytest.mark.parametrize("kind,degs,nels", [("RT", (1, 1, 1), (3, 4, 5)), ("RT", (2, 2, 2), (3, 2, 4)), ("N", (1, 1, 1), (2, 3, 3)),
+                                            ("RT", (1, 1, 1), (1, 1, 2))])
+def test_tensor_walks_with_different_bases_on_rows_and_columns(kind, degs, nels):
+    """K_fg = M_f^T A_fg M_g for the components of a compatible B-spline (tIGAr/compatibleSplines.py:21-66): all fields
+    extract to one Q_P grid (P = base degree + 1), the bases differ in degree per direction.  The line walks with separate
+    row- and column-side weights (padded to P + 1 functions per element), the last pass writing the true pattern: against
+    scipy's product of the Kronecker operators, pattern = the oracle's structural product, streamed in pieces of planes."""
+    import scipy.sparse as sps
+    from tigar_amd import device as dev, forms as F
+    from tigar_amd.tensorptap import TensorPtAP
+    from oracle import tigar_oracle as O
+    dev.device_info()
+    gen, kxs = _compat_fields(kind, degs, nels)
+    g = gen.V.grids[0]
+    P = g.degree
+    assert P == max(degs) + 1 and all(np.array_equal(a, b) for gi in gen.V.grids for a, b in zip(gi.axes, g.axes))
+    # an FE matrix on the element-coupling pattern of the Q_P grid with arbitrary (non-symmetric) values
+    V1 = type(gen.V)([g], gen.V.element)
+    A = F.LaplaceForm().assemble_matrix(V1).to_scipy().tocsr()
+    rng = np.random.default_rng(5)
+    A.data = A.data + 0.3 * rng.standard_normal(A.nnz)
+    Ad = dev.DeviceCSR.from_scipy(A)
+    nz = g.shape()[-1]
+    Ms = [sps.kron(kx.M1[2], sps.kron(kx.M1[1], kx.M1[0])).tocsr() for kx in kxs]
+    for Mk in Ms:
+        Mk.eliminate_zeros()           # (scipy's kron of CSR operands stores whole blocks)
+        Mk.sort_indices()
+    dev.prof_reset()
+    for f in range(3):
+        for gg in range(3):
+            plan = TensorPtAP.for_pair(kxs[f], kxs[gg])
+            assert plan is not None
+            cut = max(1, nz // 2)
+            pieces = [plan.planes(Ad, 0, 0, cut), plan.planes(Ad, 0, cut, nz)] if cut < nz else [plan.planes(Ad, 0, 0, nz)]
+            assert all(pc is not None for pc in pieces)
+            ncr2 = kxs[f].ncp[2]
+            K = plan.zstage(pieces, 0, ncr2).to_scipy()
+            assert K.nnz == plan.k_nnz(0, ncr2)
+            # rows of a range of dof planes only
+            if ncr2 > 2:
+                Kp = plan.zstage(pieces, 1, ncr2 - 1).to_scipy()
+                pd = kxs[f].ncp[0] * kxs[f].ncp[1]
+                assert abs(Kp - K[pd:(ncr2 - 1) * pd]).max() == 0.0
+            # the oracle's product of block (f, g): pattern (structural product) and values
+            Mf, Mg = Ms[f], Ms[gg]
+            Kr = (Mf.T @ A @ Mg).tocsr()
+            ones = lambda X: sps.csr_matrix((np.ones(X.nnz), X.indices, X.indptr), shape=X.shape)
+            S = (ones(Mf).T @ ones(A) @ ones(Mg)).tocsr()
+            S.sort_indices()
+            assert K.shape == Kr.shape
+            assert np.array_equal(K.indptr, S.indptr) and np.array_equal(K.indices, S.indices)
+            assert abs(K - Kr).max() <= 1e-12 * abs(Kr).max()
+    assert dev.prof_get(5)[1] >= 9

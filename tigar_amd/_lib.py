@@ -37,6 +37,10 @@ class tg_tensor_dir_t(C.Structure):
     _fields_ = [("p", C.c_int), ("nel", C.c_int), ("wl", c_f64p)]
 
 
+class tg_tensor_pair_dir_t(C.Structure):
+    _fields_ = [("p", C.c_int), ("nel", C.c_int), ("pr", C.c_int), ("pc", C.c_int), ("wlr", c_f64p), ("wlc", c_f64p)]
+
+
 class tg_kron_dir_t(C.Structure):
     _fields_ = [("n", C.c_int64), ("rowptr", c_i32p), ("col", c_i32p), ("val", c_f64p)]
 
@@ -139,6 +143,7 @@ PROTOTYPES = {
     "tg_ptap_kron_append": (C.c_int, [handle, C.c_int64, C.c_int, c_i64p, C.POINTER(tg_kron1d_t), C.c_int64, C.c_int64,
                                       c_i32p, C.c_int64, C.c_double, handle]),
     "tg_tensor_plan_create": (C.c_int, [C.c_int, C.POINTER(tg_tensor_dir_t), C.POINTER(handle)]),
+    "tg_tensor_plan_create_pair": (C.c_int, [C.c_int, C.POINTER(tg_tensor_pair_dir_t), C.POINTER(handle)]),
     "tg_tensor_plan_destroy": (C.c_int, [handle]),
     "tg_tensor2_plan_create": (C.c_int, [C.c_int, C.POINTER(tg_tensor_dir_t), C.POINTER(handle)]),
     "tg_tensor2_ptap": (C.c_int, [handle, handle, c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),

@@ -28,6 +28,11 @@ struct tg_tensor_plan_s {
   double *kcv[3] = {nullptr, nullptr, nullptr};
   uint64_t kcv_key = 0;
   int kcv_terms = 0;
+  // blocks with different spline bases on the row and the column side (tg_tensor_plan_create_pair): true function counts
+  // and degrees per direction; pair == false: square (ncr = ncc = nel + P, pr = pc = P)
+  bool pair = false;
+  int ncr[3] = {0, 0, 0}, ncc[3] = {0, 0, 0}, pr[3] = {0, 0, 0}, pc[3] = {0, 0, 0};
+  double *wlr[3] = {nullptr, nullptr, nullptr};
   uint64_t expect_tag = 0; // tg_pattern_hash of the element-coupling pattern the passes rely on
   std::vector<int32_t> h_ecol[3];   // that pattern's 1-D column indices (rows as in h_rps)
   int *status = nullptr;   // device flag
@@ -114,6 +119,7 @@ extern "C" int tg_tensor_plan_destroy(tg_tensor_plan_t p) {
   if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
   for (int k = 0; k < 3; k++) {
     tg_dfree(p->wl[k]);
+    tg_dfree(p->wlr[k]);
     tg_dfree(p->rps[k]);
     tg_dfree(p->kps[k]);
   }
@@ -125,35 +131,46 @@ extern "C" int tg_tensor_plan_destroy(tg_tensor_plan_t p) {
   return 0;
 }
 
-extern "C" int tg_tensor_plan_create(int d, const tg_tensor_dir_t *dirs, tg_tensor_plan_t *out) {
-  TG_REQUIRE_INIT();
-  TG_REQUIRE(d == 3 && dirs && out, "tg_tensor_plan_create: three parametric directions expected");
+static int tt_plan_create3(const tg_tensor_pair_dir_t *dirs, bool pair, tg_tensor_plan_t *out) {
   const int P = dirs[0].p;
   TG_REQUIRE(P >= 1 && P <= 3 && dirs[1].p == P && dirs[2].p == P,
              "tg_tensor_plan_create: equal degrees 1..3 in all directions ((2p+1)^2 lanes must fit a wave)");
   tg_tensor_plan_s *pl = new tg_tensor_plan_s();
   pl->P = P;
+  pl->pair = pair;
   int rc = 0;
   for (int k = 0; k < 3 && !rc; k++) {
     const int nel = dirs[k].nel, nfe = P * nel + 1, ncp = nel + P;
-    if (nel < 1 || !dirs[k].wl) {
-      tg_set_error("tg_tensor_plan_create: bad direction %d", k);
+    const int pr = pair ? dirs[k].pr : P, pc = pair ? dirs[k].pc : P;
+    if (nel < 1 || !dirs[k].wlc || (pair && !dirs[k].wlr) || pr < 1 || pr > P || pc < 1 || pc > P) {
+      tg_set_error("tg_tensor_plan_create: bad direction %d (spline degrees 1..%d on both sides)", k, P);
       rc = 2;
       break;
     }
-    std::vector<double> w(dirs[k].wl, dirs[k].wl + (size_t)nel * (P + 1) * (P + 1));
+    const int ncr = nel + pr, ncc = nel + pc;
+    pl->pr[k] = pr;
+    pl->pc[k] = pc;
+    pl->ncr[k] = ncr;
+    pl->ncc[k] = ncc;
+    std::vector<double> w(dirs[k].wlc, dirs[k].wlc + (size_t)nel * (P + 1) * (P + 1));
     pl->h_rps[k].assign(nfe + 1, 0);
     for (int a = 0; a < nfe; a++) pl->h_rps[k][a + 1] = pl->h_rps[k][a] + tt_rn_host(P, a, nfe);
-    pl->h_kps[k].assign(ncp + 1, 0);
-    for (int i = 0; i < ncp; i++)
-      pl->h_kps[k][i + 1] = pl->h_kps[k][i] + (std::min(ncp - 1, i + P) - std::max(0, i - P) + 1);
+    // 1-D pattern of the product: row function i couples to the column functions [i - pr, i + pc], clipped
+    pl->h_kps[k].assign(ncr + 1, 0);
+    for (int i = 0; i < ncr; i++)
+      pl->h_kps[k][i + 1] = pl->h_kps[k][i] + (std::min(ncc - 1, i + pc) - std::max(0, i - pr) + 1);
     rc = tt_upload(&pl->wl[k], w);
+    if (!rc && pair) {
+      std::vector<double> wr(dirs[k].wlr, dirs[k].wlr + (size_t)nel * (P + 1) * (P + 1));
+      rc = tt_upload(&pl->wlr[k], wr);
+    }
     if (!rc) rc = tt_upload(&pl->rps[k], pl->h_rps[k]);
     if (!rc) rc = tt_upload(&pl->kps[k], pl->h_kps[k]);
     pl->dir[k].nel = nel;
     pl->dir[k].nfe = nfe;
-    pl->dir[k].ncp = ncp;
+    pl->dir[k].ncp = ncp;                 // (padded: the layout of the intermediates)
     pl->dir[k].wl = pl->wl[k];
+    pl->dir[k].wlr = pair ? pl->wlr[k] : nullptr;
     pl->dir[k].rps = pl->rps[k];
     pl->dir[k].kps = pl->kps[k];
   }
@@ -191,6 +208,26 @@ extern "C" int tg_tensor_plan_create(int d, const tg_tensor_dir_t *dirs, tg_tens
   }
   *out = pl;
   return 0;
+}
+
+extern "C" int tg_tensor_plan_create(int d, const tg_tensor_dir_t *dirs, tg_tensor_plan_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(d == 3 && dirs && out, "tg_tensor_plan_create: three parametric directions expected");
+  tg_tensor_pair_dir_t pd[3];
+  for (int k = 0; k < 3; k++) {
+    pd[k].p = dirs[k].p;
+    pd[k].nel = dirs[k].nel;
+    pd[k].pr = pd[k].pc = dirs[k].p;
+    pd[k].wlr = nullptr;
+    pd[k].wlc = dirs[k].wl;
+  }
+  return tt_plan_create3(pd, false, out);
+}
+
+extern "C" int tg_tensor_plan_create_pair(int d, const tg_tensor_pair_dir_t *dirs, tg_tensor_plan_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(d == 3 && dirs && out, "tg_tensor_plan_create_pair: three parametric directions expected");
+  return tt_plan_create3(dirs, true, out);
 }
 
 extern "C" int tg_tensor_planes_destroy(tg_tensor_planes_t p) {
@@ -728,7 +765,10 @@ extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tenso
   TG_REQUIRE(pl->d == 3, "tg_tensor_zstage: 3-D plans only");
   const int P = pl->P, W = 2 * P + 1;
   const tt_dir_t &D0 = pl->dir[0], &D1 = pl->dir[1], &D2 = pl->dir[2];
-  TG_REQUIRE(ka >= 0 && kb > ka && kb <= D2.ncp, "tg_tensor_zstage: dof planes out of range");
+  const int ncr0 = pl->ncr[0], ncr1 = pl->ncr[1], ncr2 = pl->ncr[2];
+  TG_REQUIRE(ka >= 0 && kb > ka && kb <= ncr2, "tg_tensor_zstage: dof planes out of range");
+  TG_REQUIRE(!pl->pair || !(zero_dofs && nzero > 0), "tg_tensor_zstage: blocks with different bases on the two sides take no zero dofs "
+                                                     "(MatZeroRowsColumns belongs to the assembled matrix)");
   const int e_begin = std::max(0, ka - P), e_end = std::min(D2.nel, kb);
   const int plo = e_begin == 0 ? 0 : P * e_begin + 1, phi = P * e_end;      // FE planes read: [plo, phi]
   std::vector<const double *> ptr(phi - plo + 1, nullptr);
@@ -739,11 +779,12 @@ extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tenso
   }
   for (size_t i = 0; i < ptr.size(); i++)
     TG_REQUIRE(ptr[i], "tg_tensor_zstage: FE plane %d is in none of the pieces", plo + (int)i);
-  const int64_t pd = (int64_t)D0.ncp * D1.ncp;
+  const int64_t pd = (int64_t)ncr0 * ncr1;                   // rows of K per dof plane (true functions of the row side)
+  const int64_t pd_pad = (int64_t)D0.ncp * D1.ncp;           // lines the walk covers (padded functions included)
   const int64_t nrows = (int64_t)(kb - ka) * pd;
-  const int64_t w01 = (int64_t)pl->h_kps[0][D0.ncp] * pl->h_kps[1][D1.ncp];
+  const int64_t w01 = (int64_t)pl->h_kps[0][ncr0] * pl->h_kps[1][ncr1];
   const int64_t nnz = w01 * (pl->h_kps[2][kb] - pl->h_kps[2][ka]);
-  const int64_t ncols = pd * D2.ncp;
+  const int64_t ncols = (int64_t)pl->ncc[0] * pl->ncc[1] * pl->ncc[2];
   // destination
   tg_csr_s *m = nullptr;
   int64_t row_at = 0, nnz_at = 0;
@@ -766,8 +807,8 @@ extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tenso
     R.kps0 = D0.kps;
     R.kps1 = D1.kps;
     R.kps2 = D2.kps;
-    R.ncp0 = D0.ncp;
-    R.ncp1 = D1.ncp;
+    R.ncp0 = ncr0;
+    R.ncp1 = ncr1;
     R.ka = ka;
     R.kb = kb;
     R.base = nnz_at;
@@ -786,9 +827,16 @@ extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tenso
     Z.kps1 = D1.kps;
     Z.ka = ka;
     Z.kb = kb;
+    Z.ncr0 = ncr0;
+    Z.ncr1 = ncr1;
+    Z.ncc0 = pl->ncc[0];
+    Z.ncc1 = pl->ncc[1];
+    Z.pr0 = pl->pr[0];
+    Z.pr1 = pl->pr[1];
+    Z.pr2 = pl->pr[2];
     Z.L = std::max(1, 64 / (W * W));
     // the diagonal is recorded while the rows are written (only while every row so far came from here)
-    if (row_at == 0 && !m->diag_cache) {
+    if (row_at == 0 && !m->diag_cache && !pl->pair) {
       if (tg_dmalloc(&m->diag_cache, m->nrows)) m->diag_cache = nullptr;
       m->diag_rows = 0;
     }
@@ -798,7 +846,7 @@ extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tenso
     Z.kval = m->val + nnz_at;
     Z.mask = mask;
     Z.diag = diag;
-    const unsigned grid = (unsigned)tg_cdiv(pd, Z.L);
+    const unsigned grid = (unsigned)tg_cdiv(pd_pad, Z.L);
 #define TT_Z(PP) hipLaunchKernelGGL((k_tt_z<PP>), dim3(grid), dim3(64), 0, g_tg.stream, Z)
     TT_DISPATCH_P(P, TT_Z);
 #undef TT_Z

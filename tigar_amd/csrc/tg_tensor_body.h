@@ -72,7 +72,12 @@ typedef const double *tt_gdp;
 
 struct tt_dir_t {
   int nel, nfe, ncp;
-  const double *wl;      // [nel][P+1][P+1] local extraction weights (see above)
+  const double *wl;      // [nel][P+1][P+1] local extraction weights (see above): the COLUMN side of the product
+  // Row side of the product when it differs (block (f, g) of a space whose fields sit on different spline bases, e.g. the
+  // components of a div-conforming B-spline, tIGAr/compatibleSplines.py:21-66: K_fg = M_f^T A_fg M_g): the weights of basis f
+  // at the same nodes.  A basis of lower degree than the FE grid is PADDED to P + 1 functions per element (weights 0):
+  // its rows / columns beyond the true function count come out as zeros and are left out by the last pass.  Null: wl.
+  const double *wlr;
   const int32_t *rps;    // [nfe+1] exclusive prefix sums of the 1-D row lengths of the FE pattern
   const int32_t *kps;    // [ncp+1] exclusive prefix sums of the widths of K's 1-D rows (clipped band)
 };
@@ -109,6 +114,7 @@ TT_DEV void tt_walk(const tt_dir_t &D, int e_begin, int e_end, IO &io) {
 #pragma unroll
     for (int m = 0; m < W; m++) acc[r][m] = 0.0;
 
+  tt_cdp wrow = TT_CD(D.wlr ? D.wlr : D.wl);
   if (e_begin == 0) {   // opening vertex: node 0 = node j = 0 of element 0
     tt_cdp we = TT_CD(D.wl);
     double v[Q], C[Q];
@@ -122,13 +128,14 @@ TT_DEV void tt_walk(const tt_dir_t &D, int e_begin, int e_end, IO &io) {
     }
 #pragma unroll
     for (int r = 0; r < Q; r++) {
-      const double wr = we[r];                    // node j = 0, dof 0 + r
+      const double wr = wrow[r];                  // node j = 0, dof 0 + r
 #pragma unroll
       for (int q = 0; q < Q; q++) acc[r][q - r + P] = fma(wr, C[q], acc[r][q - r + P]);
     }
   }
   for (int e = e_begin; e < e_end; e++) {
     tt_cdp we = TT_CD(D.wl) + (int64_t)e * NW;
+    tt_cdp wre = wrow + (int64_t)e * NW;
     const int a0 = P * e;
     // interior nodes of element e: columns = the element's P+1 nodes
 #pragma unroll
@@ -144,7 +151,7 @@ TT_DEV void tt_walk(const tt_dir_t &D, int e_begin, int e_end, IO &io) {
       }
 #pragma unroll
       for (int r = 0; r < Q; r++) {
-        const double wr = we[j * Q + r];
+        const double wr = wre[j * Q + r];
 #pragma unroll
         for (int q = 0; q < Q; q++) acc[r][q - r + P] = fma(wr, C[q], acc[r][q - r + P]);
       }
@@ -171,7 +178,7 @@ TT_DEV void tt_walk(const tt_dir_t &D, int e_begin, int e_end, IO &io) {
       }
 #pragma unroll
       for (int r = 0; r < Q; r++) {
-        const double wr = we[P * Q + r];
+        const double wr = wre[P * Q + r];
 #pragma unroll
         for (int q = 0; q <= Q; q++) {
           // column dof e+q against output dof e+r; q - r + P == 2P+1 only for (q, r) = (P+1, 0), whose row weight
@@ -191,7 +198,7 @@ TT_DEV void tt_walk(const tt_dir_t &D, int e_begin, int e_end, IO &io) {
       }
 #pragma unroll
       for (int r = 0; r < Q; r++) {
-        const double wr = we[P * Q + r];
+        const double wr = wre[P * Q + r];
 #pragma unroll
         for (int q = 0; q < Q; q++) acc[r][q - r + P] = fma(wr, C[q], acc[r][q - r + P]);
       }
@@ -513,6 +520,11 @@ struct tt_z_args {
   double *kdiag;                 // diagonal of the rows written (index: row - first row of dof plane ka), or null
   const uint8_t *mask;           // zeroDofs as a byte mask over all dofs, or null
   double diag;
+  // Blocks with different bases on the row and the column side (see tt_dir_t::wlr); 0 = the square default.  ncp0 / ncp1
+  // above stay the PADDED counts nel + P (the layout of B2); these are the true ones and the spline degrees per side:
+  // row dof i couples to the column dofs [i - pr, i + pc] (clipped), i.e. to the slots m in [P - min(pr, i), ...) of the walk
+  int ncr0, ncr1, ncc0, ncc1;    // true row / column function counts of directions 0, 1
+  int pr0, pr1, pr2;             // spline degree of the row side per direction
 };
 
 template <int P>
@@ -524,6 +536,7 @@ struct tt_io_z {
   // K addressing
   const int32_t *kps2;
   int ka, kb, i0, i1, m0, m1, ncp0, ncp1, w0n, w1n, w0lo, w1lo;
+  int ncc0, ncc1, pr2;           // (ncp0 / ncp1 here: the true ROW counts)
   int64_t w01tot, rowoff01;
   int32_t *kcol;
   double *kval;
@@ -543,17 +556,17 @@ struct tt_io_z {
   TT_MEM void emit(int i2, const double *row) {
     if (!valid || !inwin || i2 < ka || i2 >= kb) return;
     const int w2n = kps2[i2 + 1] - kps2[i2];
-    const int w2lo = i2 < P ? P - i2 : 0;
+    const int w2lo = P - (i2 < pr2 ? i2 : pr2);
     const int64_t rowstart = w01tot * (kps2[i2] - kps2[ka]) + (int64_t)w2n * rowoff01;
     const int64_t R = i0 + (int64_t)ncp0 * (i1 + (int64_t)ncp1 * i2);
     const bool mrow = mask && mask[R];
     const int64_t within = (int64_t)(m1 - w1lo) * w0n + (m0 - w0lo);
-    const int64_t c01 = (i0 - P + m0) + (int64_t)ncp0 * (i1 - P + m1);
+    const int64_t c01 = (i0 - P + m0) + (int64_t)ncc0 * (i1 - P + m1);
 #pragma unroll
     for (int m2 = 0; m2 < 2 * P + 1; m2++) {
       if (m2 >= w2lo && m2 < w2lo + w2n) {
         const int64_t pos = rowstart + (int64_t)(m2 - w2lo) * w1n * w0n + within;
-        const int64_t c = c01 + (int64_t)ncp0 * ncp1 * (i2 - P + m2);
+        const int64_t c = c01 + (int64_t)ncc0 * ncc1 * (i2 - P + m2);
         double v = row[m2];
         if (mask && (mrow || mask[c])) v = (mrow && c == R) ? diag : 0.0;
         kcol[pos] = (int32_t)c;
@@ -574,6 +587,11 @@ TT_DEV void tt_z_lane(const tt_z_args &A, int bx, int lane) {
   io.valid = sub < A.L && line < (int64_t)A.ncp0 * A.ncp1;
   const int i0 = io.valid ? (int)(line % A.ncp0) : 0, i1 = io.valid ? (int)(line / A.ncp0) : 0;
   const int m0 = l % W, m1 = l / W;
+  // true function counts and row-side degrees (square blocks: the padded counts, P)
+  const int ncr0 = A.ncr0 ? A.ncr0 : A.ncp0, ncr1 = A.ncr1 ? A.ncr1 : A.ncp1;
+  const int pr0 = A.pr0 ? A.pr0 : P, pr1 = A.pr1 ? A.pr1 : P;
+  const bool real = i0 < ncr0 && i1 < ncr1;       // (rows of functions the padding added are not written)
+  const int j0 = real ? i0 : 0, j1 = real ? i1 : 0;
   io.planes = A.planes;
   io.plane_lo = A.plane_lo;
   io.clane = (int64_t)lpl * (i0 + (int64_t)A.ncp0 * i1) + l;
@@ -584,16 +602,19 @@ TT_DEV void tt_z_lane(const tt_z_args &A, int bx, int lane) {
   io.i1 = i1;
   io.m0 = m0;
   io.m1 = m1;
-  io.ncp0 = A.ncp0;
-  io.ncp1 = A.ncp1;
-  io.w0n = A.kps0[i0 + 1] - A.kps0[i0];
-  io.w1n = A.kps1[i1 + 1] - A.kps1[i1];
-  io.w0lo = i0 < P ? P - i0 : 0;
-  io.w1lo = i1 < P ? P - i1 : 0;
-  io.inwin = m0 >= io.w0lo && m0 < io.w0lo + io.w0n && m1 >= io.w1lo && m1 < io.w1lo + io.w1n;
-  const int64_t w0tot = A.kps0[A.ncp0], w1tot = A.kps1[A.ncp1];
+  io.ncp0 = ncr0;
+  io.ncp1 = ncr1;
+  io.ncc0 = A.ncc0 ? A.ncc0 : A.ncp0;
+  io.ncc1 = A.ncc1 ? A.ncc1 : A.ncp1;
+  io.pr2 = A.pr2 ? A.pr2 : P;
+  io.w0n = A.kps0[j0 + 1] - A.kps0[j0];
+  io.w1n = A.kps1[j1 + 1] - A.kps1[j1];
+  io.w0lo = P - (i0 < pr0 ? i0 : pr0);
+  io.w1lo = P - (i1 < pr1 ? i1 : pr1);
+  io.inwin = real && m0 >= io.w0lo && m0 < io.w0lo + io.w0n && m1 >= io.w1lo && m1 < io.w1lo + io.w1n;
+  const int64_t w0tot = A.kps0[ncr0], w1tot = A.kps1[ncr1];
   io.w01tot = w0tot * w1tot;
-  io.rowoff01 = w0tot * A.kps1[i1] + (int64_t)io.w1n * A.kps0[i0];
+  io.rowoff01 = w0tot * A.kps1[j1] + (int64_t)io.w1n * A.kps0[j0];
   io.kcol = A.kcol;
   io.kval = A.kval;
   io.kdiag = A.kdiag;

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _lib
 from . import device as _dev
-from ._lib import check, handle, c_f64p, c_i32p, tg_tensor_dir_t
+from ._lib import check, handle, c_f64p, c_i32p, tg_tensor_dir_t, tg_tensor_pair_dir_t
 
 
 # Structure checks and plans are functions of the 1-D extraction matrices alone; generators are rebuilt often (every
@@ -87,6 +87,38 @@ def local_weights(M1, p, nel):
     return wl
 
 
+def local_weights_padded(M1, P, nel, ps):
+    """``local_weights`` for a spline of degree ``ps`` <= P extracted to the CG degree-P grid (a component of a compatible
+    spline, tIGAr/compatibleSplines.py:21-66: FE degree = the largest directional degree of the field): wl[e, j, q] =
+    M1[P*e + j, e + q] for q <= ps, zero for the P - ps functions the padding adds.  None when a stored entry lies outside
+    [e, e + ps] or a function e + q is stored at no node of element e (the product's band would not be full)."""
+    M1 = M1.tocsr()
+    nfe, ncp = M1.shape
+    if ps < 1 or ps > P or nfe != P * nel + 1 or ncp != nel + ps:
+        return None
+    a = np.repeat(np.arange(nfe), np.diff(M1.indptr))
+    c, v = M1.indices.astype(np.int64), M1.data
+    keep = v != 0.0
+    a, c, v = a[keep], c[keep], v[keep]
+    wl = np.zeros((nel, P + 1, P + 1))
+    m1 = a < nfe - 1
+    e1, j1 = a[m1] // P, a[m1] % P
+    q1 = c[m1] - e1
+    m2 = ((a % P) == 0) & (a > 0)
+    e2 = a[m2] // P - 1
+    q2 = c[m2] - e2
+    if np.any(q1 < 0) or np.any(q1 > ps) or np.any(q2 < 0) or np.any(q2 > ps):
+        return None
+    wl[e1, j1, q1] = v[m1]
+    wl[e2, P, q2] = v[m2]
+    if not (wl[:, :, :ps + 1] != 0.0).any(axis=1).all():
+        return None
+    # (the closing vertex of an element carries no weight of the element's first function: the walk relies on it)
+    if nel > 1 and np.any(wl[:-1, P, 0] != 0.0):
+        return None
+    return wl
+
+
 def band_pattern_ok(M1, p, nel):
     """structural pattern of the 1-D K (= M1^T pattern(A1) M1 as PETSc's symbolic product sees it) is the
     full band |i - i'| <= p clipped to the matrix: with every stored column of element e's nodes inside
@@ -117,16 +149,32 @@ class TensorPlanes(object):
 class TensorPtAP(object):
     """Plan of the tensor-pattern PtAP for one patch (1-D tables in HBM)."""
 
-    def __init__(self, p, nels, wls):
+    def __init__(self, p, nels, wls, pair=None):
+        """``pair``: (row-side weights, row degrees, column degrees) per direction for a block with different spline bases
+        on its two sides (``wls`` then being the column side's, padded) -- ``tg_tensor_plan_create_pair``"""
         self.p, self.nels = int(p), [int(n) for n in nels]
         self._keep = [np.ascontiguousarray(w, dtype=np.float64) for w in wls]
-        arr = (tg_tensor_dir_t * 3)()
+        self._h = handle()
+        if pair is None:
+            self.pr = self.pc = [self.p] * 3
+            arr = (tg_tensor_dir_t * 3)()
+            for k in range(3):
+                arr[k].p = self.p
+                arr[k].nel = self.nels[k]
+                arr[k].wl = self._keep[k].ctypes.data_as(c_f64p)
+            check(_lib.lib().tg_tensor_plan_create(3, arr, C.byref(self._h)), "tg_tensor_plan_create")
+            return
+        wlr, self.pr, self.pc = pair
+        self.pr, self.pc = [int(v) for v in self.pr], [int(v) for v in self.pc]
+        self._keep_r = [np.ascontiguousarray(w, dtype=np.float64) for w in wlr]
+        arr = (tg_tensor_pair_dir_t * 3)()
         for k in range(3):
             arr[k].p = self.p
             arr[k].nel = self.nels[k]
-            arr[k].wl = self._keep[k].ctypes.data_as(c_f64p)
-        self._h = handle()
-        check(_lib.lib().tg_tensor_plan_create(3, arr, C.byref(self._h)), "tg_tensor_plan_create")
+            arr[k].pr, arr[k].pc = self.pr[k], self.pc[k]
+            arr[k].wlr = self._keep_r[k].ctypes.data_as(c_f64p)
+            arr[k].wlc = self._keep[k].ctypes.data_as(c_f64p)
+        check(_lib.lib().tg_tensor_plan_create_pair(3, arr, C.byref(self._h)), "tg_tensor_plan_create_pair")
 
     def __del__(self):
         try:
@@ -170,13 +218,57 @@ class TensorPtAP(object):
                 if st is not None else None
         return kx._tensor_plan
 
+    @staticmethod
+    def structure_pair(kx_row, kx_col):
+        """(P, nels, column weights, (row weights, row degrees, column degrees), keys) when block (row basis, column basis)
+        of a space on ONE Q_P node grid has the structure of the walks, else None"""
+        if kx_row.d != 3 or kx_col.d != 3:
+            return None
+        g, g2 = kx_row.grid, kx_col.grid
+        if getattr(g, "dg", False) or getattr(g2, "dg", False) or g.degree != g2.degree or g.degree < 1 or g.degree > 3:
+            return None
+        if any(not np.array_equal(a, b) for a, b in zip(g.axes, g2.axes)):
+            return None
+        P = int(g.degree)
+        nels, wlc, wlr, pr, pc, keys = [], [], [], [], [], []
+        for k in range(3):
+            nel = len(g.vertices[k]) - 1
+            psr, psc = int(kx_row.basis.splines[k].p), int(kx_col.basis.splines[k].p)
+            wr, wc = local_weights_padded(kx_row.M1[k], P, nel, psr), local_weights_padded(kx_col.M1[k], P, nel, psc)
+            if wr is None or wc is None:
+                return None
+            nels.append(nel)
+            wlr.append(wr)
+            wlc.append(wc)
+            pr.append(psr)
+            pc.append(psc)
+            keys.append((P, nel, psr, psc, _digest(kx_row.M1[k]), _digest(kx_col.M1[k])))
+        return P, nels, wlc, (wlr, pr, pc), keys
+
+    @staticmethod
+    def for_pair(kx_row, kx_col):
+        """plan of block (row basis, column basis); the square plan when both are the same object"""
+        if kx_row is kx_col:
+            plan = TensorPtAP.for_extraction(kx_row)
+            if plan is not None:
+                return plan
+        if os.environ.get("TIGAR_PTAP_TENSOR", "1") == "0":
+            return None
+        cache = kx_row.__dict__.setdefault("_tensor_pair_plans", {})
+        if id(kx_col) not in cache:
+            st = TensorPtAP.structure_pair(kx_row, kx_col)
+            cache[id(kx_col)] = (kx_col, _cached_plan("3d-pair", st[0], st[1], 1, st[4],
+                                                      lambda: TensorPtAP(st[0], st[1], st[2], pair=st[3]))
+                                 if st is not None else None)
+        return cache[id(kx_col)][1]
+
     def k_nnz(self, ka, kb):
         """entries of the rows of K of the dof planes [ka, kb) (clipped band, Kronecker product)"""
-        def widths(nel):
-            n = nel + self.p
-            i = np.arange(n)
-            return np.minimum(n - 1, i + self.p) - np.maximum(0, i - self.p) + 1
-        w0, w1, w2 = [widths(n) for n in self.nels]
+        def widths(nel, pr, pc):
+            nr, nc = nel + pr, nel + pc
+            i = np.arange(nr)
+            return np.minimum(nc - 1, i + pc) - np.maximum(0, i - pr) + 1
+        w0, w1, w2 = [widths(n, self.pr[k], self.pc[k]) for k, n in enumerate(self.nels)]
         return int(w0.sum()) * int(w1.sum()) * int(w2[ka:kb].sum())
 
     def planes(self, A, a_row0, z0, z1):
