@@ -109,7 +109,8 @@ int tg_csr_transpose(tg_csr_t m, tg_csr_t *out);
  * re-sorted: MatPermute with identity rows. */
 /* Field blocks of a matrix on a mixed space whose dofs are numbered field after field (the FE matrices of
  * EqualOrderSpline(nFields > 1), tIGAr/common.py:1891-1914): tg_csr_block cuts out rows [r0, r1) x columns [c0, c1)
- * (columns renumbered from 0); tg_csr_from_blocks puts nf x nf blocks of one shape together, blocks[i * nf + j] at block
+ * (columns renumbered from 0); tg_csr_from_blocks puts nf x nf blocks together (equal row counts along a block row, equal column
+ * counts down a block column: the fields of a FieldListSpline differ in size), blocks[i * nf + j] at block
  * row i, block column j.  Used to run the scalar tensor-pattern PtAP block by block. */
 /* C = A + B on the union of the two patterns (MatAXPY, DIFFERENT_NONZERO_PATTERN [ext]); ascending columns. */
 int tg_csr_add(tg_csr_t a, tg_csr_t b, tg_csr_t *out);

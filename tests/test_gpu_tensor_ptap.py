@@ -560,3 +560,56 @@ def test_tensor_walks_with_different_bases_on_rows_and_columns(kind, degs, nels)
             assert np.array_equal(K.indptr, S.indptr) and np.array_equal(K.indices, S.indices)
             assert abs(K - Kr).max() <= 1e-12 * abs(Kr).max()
     assert dev.prof_get(5)[1] >= 9
+
+
+def _rt_problem(degs, nels, comm=None):
+    """BSplineCompat RT space on an identity-geometry patch with the demos' normal-direction boundary conditions
+    (demos/taylor-green/taylor-green-3d.py:42-50) and the oracle's block-diagonal extraction operator"""
+    import scipy.sparse as sps
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, common as tc
+    from tigar_amd.compatibleSplines import BSplineCompat
+    kv = [B.uniformKnots(degs[k], 0., 1. + 0.25 * k, nels[k]) for k in range(3)]
+    gen = BSplineCompat(comm if comm is not None else tc.selfcomm, B.ExplicitBSplineControlMesh(list(degs), kv), "RT", list(degs))
+    for field in range(3):
+        sp_f = gen.getFieldSpline(field)
+        for side in (0, 1):
+            gen.addZeroDofs(field, sp_f.getSideDofs(field, side))
+    blocks = []
+    for i in range(3):
+        f = gen.getFieldSpline(i)
+        blocks.append(O.generate_M_tensor(O.BSpline([s1.p for s1 in f.splines], [np.asarray(s1.knots) for s1 in f.splines])))
+    return gen, sps.block_diag(blocks, format="csr")
+
+
+@pytest.mark.parametrize("degs,nels", [((1, 1, 1), (4, 3, 5)), ((2, 2, 2), (2, 3, 3))])
+def test_extract_matrix_on_a_compatible_spline_takes_the_pair_walks(degs, nels, monkeypatch):
+    """extractMatrix on BSplineCompat("RT") -- the space of the reference's only Krylov + MPI demos -- with an assembled
+    block matrix (the linear-elasticity form on the common Q_P grid): every block through the line walks with different
+    row / column bases, K against the oracle (pattern and values), then with a hand-added coupling off the pattern
+    (general kernels for the blocks concerned)."""
+    import tigar_amd as t
+    from tigar_amd import device as dev, forms as F
+    gen, Mo = _rt_problem(degs, nels)
+    assert gen._kron_fields is not None and len(gen._kron_fields) == 3
+    spline = t.ExtractedSpline(gen, 2 * (max(degs) + 1))
+    A = F.ElasticityForm(1.3, 0.7).assemble_matrix(spline.V)
+    zd = [int(i) for i in gen.zeroDofsArray()]
+    dev.prof_reset()
+    K = spline.extractMatrix(A, diag=2.5).to_scipy()
+    assert dev.prof_get(5)[1] == 9                       # nine blocks, nine final passes of the walks
+    Kr = O.extract_matrix(Mo, A.to_scipy(), zd, diag=2.5)
+    assert np.array_equal(K.indptr, Kr.indptr) and np.array_equal(K.indices, Kr.indices)
+    assert abs(K - Kr).max() <= 1e-12 * abs(Kr).max()
+    # a coupling dolfin would not have assembled (hand-added): the blocks that carry it go through the general kernels
+    Ah = A.to_scipy().tolil()
+    Ah[3, Ah.shape[1] - 5] = 0.25
+    Ah = Ah.tocsr()
+    K2 = spline.extractMatrix(Ah, diag=2.5).to_scipy()
+    K2r = O.extract_matrix(Mo, Ah, zd, diag=2.5)
+    assert np.array_equal(K2.indptr, K2r.indptr) and np.array_equal(K2.indices, K2r.indices)
+    assert abs(K2 - K2r).max() <= 1e-12 * abs(K2r).max()
+    # the same product with the walks switched off
+    monkeypatch.setenv("TIGAR_PTAP_TENSOR", "0")
+    K3 = spline.extractMatrix(A, diag=2.5).to_scipy()
+    assert np.array_equal(K3.indices, Kr.indices) and abs(K3 - Kr).max() <= 1e-12 * abs(Kr).max()

@@ -491,6 +491,7 @@ class AbstractExtractionGenerator(object):
         # enables the sum-factorised M^T A M of tigar_amd/kronptap.py
         self._kron = None
         self._kron_scalar = None           # several fields on ONE tensor basis (EqualOrderSpline(nFields > 1)): its tables
+        self._kron_fields = None           # several fields on different tensor bases: one set of tables per field
         if getattr(self.M, "is_implicit", False) and getattr(self.M, "nfields", 1) > 1:
             self._kron_scalar = self.M.kx        # diag(M_s, ..., M_s), never stored
         elif getattr(self.M, "is_implicit", False):
@@ -518,6 +519,14 @@ class AbstractExtractionGenerator(object):
                 if kx is not None and self.M.nnz == self.getNFields() * kx.nnz_product and \
                         kx.products_stay_above(self.getIgnoreEps()):
                     self._kron_scalar = kx
+                if self._kron_scalar is None:
+                    # fields on DIFFERENT tensor bases (FieldListSpline, the components of a compatible spline:
+                    # tIGAr/common.py:1949-1970, tIGAr/compatibleSplines.py:21-101): M = diag(M_0, ..., M_{nF-1}), every
+                    # block exactly the Kronecker product of its own 1-D factors (entry count checked)
+                    kxs = [self._kron_tables(*self._fast_blocks[k]) for k in keys]
+                    if all(kx is not None and kx.products_stay_above(self.getIgnoreEps()) for kx in kxs) and \
+                            self.M.nnz == sum(kx.nnz_product for kx in kxs):
+                        self._kron_fields = kxs
         self.cpFuncs = []
         cm = self.getControlMesh() if hasattr(self, "getControlMesh") else None
         P = None
@@ -629,6 +638,7 @@ class AbstractExtractionGenerator(object):
         self.MT = self.M.transpose()
         self._kron = None                      # (M is no Kronecker product in the new numbering)
         self._kron_scalar = None
+        self._kron_fields = None
         self._fast_blocks = {}
         self.zeroDofs = new_of_old[self.zeroDofsArray()].tolist()
 
@@ -1364,6 +1374,7 @@ class ExtractedSpline(object):
         self._generator = generator
         self._kron = getattr(generator, "_kron", None)
         self._kron_scalar = getattr(generator, "_kron_scalar", None)
+        self._kron_fields = getattr(generator, "_kron_fields", None)
         self.zeroDofs = generator.zeroDofsArray().astype(INDEX_TYPE)
 
     def genericSetup(self):
@@ -1519,6 +1530,11 @@ class ExtractedSpline(object):
             K = self._extract_matrix_by_field_blocks(A, zd, float(diag))
             if K is not None:
                 return K
+        if self._kron is None and not by_blocks and getattr(self, "_kron_fields", None) is not None and \
+                os.environ.get("TIGAR_PTAP_FACTORED", "1") != "0":
+            K = self._extract_matrix_by_field_list(A, zd, float(diag))
+            if K is not None:
+                return K
         if self._kron is not None:
             from .kronptap import default_groups, ptap_factored
             kx = self._kron
@@ -1651,6 +1667,75 @@ class ExtractedSpline(object):
                     del pieces
                 if Kij is None:
                     Kij = general(Aij)
+                row.append(Kij)
+                del Aij
+            blocks.append(row)
+        K = _dev.csr_from_blocks(blocks)
+        del blocks
+        if zd is not None and len(zd):
+            K.zero_rows_cols(numpy.asarray(zd, dtype=numpy.int32), diag)
+        return K
+
+    def _extract_matrix_by_field_list(self, A, zd, diag):
+        """M^T A M for fields on DIFFERENT tensor bases (M = diag(M_f)): block (f, g) = M_f^T A_fg M_g by the line walks with
+        separate row- and column-side weights where the pair qualifies (all fields on one Q_P node grid, degrees <= 3:
+        ``TensorPtAP.for_pair``, csrc/tg_tensor_body.h), by the general kernels on the scalar operands otherwise; the
+        blocks are put together and MatZeroRowsColumns is applied to the whole (tIGAr/common.py:1194-1200).  None when A
+        is not a matrix on this mixed space."""
+        from .tensorptap import TensorPtAP
+        kxs = self._kron_fields
+        nF = self.nFields
+        nfe = [int(numpy.prod(kx.nfe, dtype=numpy.int64)) for kx in kxs]
+        ncp = [int(numpy.prod(kx.ncp, dtype=numpy.int64)) for kx in kxs]
+        fo, co = numpy.concatenate([[0], numpy.cumsum(nfe)]), numpy.concatenate([[0], numpy.cumsum(ncp)])
+        if A.shape != (int(fo[-1]), int(fo[-1])):
+            return None
+        scalar = {}
+
+        def general(f, g, Aij):
+            import scipy.sparse as _sp
+            for q in (f, g):
+                if q not in scalar:
+                    Mq = self.M.block(int(fo[q]), int(fo[q + 1]), int(co[q]), int(co[q + 1]))
+                    scalar[q] = (Mq, Mq.transpose())
+            if f == g:
+                return _dev.ptap_numeric(_dev.ptap_symbolic(Aij, scalar[f][0], scalar[f][1]), Aij, scalar[f][0], scalar[f][1])
+            # the general kernels form P^T A P with ONE operator: block (0, 1) of the product on the two-field space
+            # diag(M_f, M_g) with A_fg as its only non-zero block
+            def zero(r, cc):
+                return DeviceCSR.from_scipy(_sp.csr_matrix((int(r), int(cc))))
+            Mp = _dev.csr_from_blocks([[scalar[f][0], zero(nfe[f], ncp[g])], [zero(nfe[g], ncp[f]), scalar[g][0]]])
+            Ap = _dev.csr_from_blocks([[zero(nfe[f], nfe[f]), Aij], [zero(nfe[g], nfe[f]), zero(nfe[g], nfe[g])]])
+            MpT = Mp.transpose()
+            Kp = _dev.ptap_numeric(_dev.ptap_symbolic(Ap, Mp, MpT), Ap, Mp, MpT)
+            return Kp.block(0, ncp[f], ncp[f], ncp[f] + ncp[g])
+
+        blocks = []
+        for f in range(nF):
+            row = []
+            for g in range(nF):
+                Aij = A.block(int(fo[f]), int(fo[f + 1]), int(fo[g]), int(fo[g + 1]))
+                Kij = None
+                if Aij.nnz == 0:
+                    import scipy.sparse as _sp
+                    Kij = DeviceCSR.from_scipy(_sp.csr_matrix((ncp[f], ncp[g])))
+                else:
+                    plan = TensorPtAP.for_pair(kxs[f], kxs[g]) if (kxs[f].d == 3 and not Aij.is_loose()) else None
+                    if plan is not None:
+                        nz, kz = int(kxs[f].nfe[-1]), int(kxs[f].ncp[-1])
+                        step = max(int(kxs[f].grid.degree), min(nz, int(2.0e10 // max(1.0, 12.0 * 2.5 * Aij.nnz / nz))))
+                        pieces = []
+                        for z0 in range(0, nz, step):
+                            pc = plan.planes(Aij, 0, z0, min(nz, z0 + step))
+                            if pc is None:
+                                pieces = None
+                                break
+                            pieces.append(pc)
+                        if pieces is not None:
+                            Kij = plan.zstage(pieces, 0, kz)
+                        del pieces
+                    if Kij is None:
+                        Kij = general(f, g, Aij)
                 row.append(Kij)
                 del Aij
             blocks.append(row)

@@ -704,7 +704,8 @@ struct tg_merge_args {
   const int32_t *col[16];
   const double *val[16];
   int nf;
-  int64_t n, m;                  // rows and columns of one block
+  int64_t n;                     // rows of the blocks of this block row
+  int64_t coff[16];              // first column of block column j in the result
 };
 
 __global__ void k_merge_count(tg_merge_args A, int64_t *__restrict__ out_len) {
@@ -727,7 +728,7 @@ __global__ void __launch_bounds__(256)
     int64_t o = orowptr[r];
     for (int j = 0; j < A.nf; j++) {
       const int64_t a = A.rowptr[j][r], len = A.rowptr[j][r + 1] - a;
-      const int32_t shift = (int32_t)(j * A.m);
+      const int32_t shift = (int32_t)A.coff[j];
       for (int64_t q = lane; q < len; q += 64) {
         ocol[o + q] = A.col[j][a + q] + shift;
         oval[o + q] = A.val[j][a + q];
@@ -737,28 +738,40 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// blocks[i * nf + j] (all n x m): the matrix with field-major rows and columns whose (i, j) block is blocks[i*nf+j]
+// blocks[i * nf + j]: the matrix with field-major rows and columns whose (i, j) block is blocks[i*nf+j]; the blocks of a block
+// row share their row count, those of a block column their column count (fields on different bases: the counts differ
+// from field to field)
 extern "C" int tg_csr_from_blocks(int nf, const tg_csr_t *blocks, tg_csr_t *out) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(nf >= 1 && nf <= 16 && blocks && out, "bad arguments to tg_csr_from_blocks");
-  const int64_t n = blocks[0] ? blocks[0]->nrows : 0, mcols = blocks[0] ? blocks[0]->ncols : 0;
-  int64_t nnz = 0;
+  int64_t nnz = 0, rows_total = 0, cols_total = 0;
+  int64_t rown[16], coff[17];
+  coff[0] = 0;
+  for (int q = 0; q < nf; q++) {
+    TG_REQUIRE(blocks[q * nf + q], "tg_csr_from_blocks: null block");
+    rown[q] = blocks[q * nf + q]->nrows;
+    coff[q + 1] = coff[q] + blocks[q * nf + q]->ncols;
+    rows_total += rown[q];
+  }
+  cols_total = coff[nf];
   for (int q = 0; q < nf * nf; q++) {
-    TG_REQUIRE(blocks[q] && blocks[q]->nrows == n && blocks[q]->ncols == mcols, "tg_csr_from_blocks: block %d has another shape", q);
+    TG_REQUIRE(blocks[q] && blocks[q]->nrows == rown[q / nf] && blocks[q]->ncols == coff[q % nf + 1] - coff[q % nf],
+               "tg_csr_from_blocks: block %d has another shape than its block row / column", q);
     TG_REQUIRE_CANONICAL(blocks[q]);
     nnz += blocks[q]->nnz;
   }
-  TG_REQUIRE((int64_t)nf * mcols < 0x7fffffffll, "tg_csr_from_blocks: more than 2^31 columns");
+  TG_REQUIRE(cols_total < 0x7fffffffll, "tg_csr_from_blocks: more than 2^31 columns");
   tg_csr_s *m = nullptr;
-  TG_TRY(tg_csr_alloc((int64_t)nf * n, (int64_t)nf * mcols, nnz, &m));
+  TG_TRY(tg_csr_alloc(rows_total, cols_total, nnz, &m));
   int rc = 0;
-  int64_t at = 0;
+  int64_t at = 0, row_at = 0;
   for (int i = 0; i < nf && !rc; i++) {
     tg_merge_args A;
     memset(&A, 0, sizeof(A));
+    const int64_t n = rown[i];
     A.nf = nf;
     A.n = n;
-    A.m = mcols;
+    for (int j = 0; j < nf; j++) A.coff[j] = coff[j];
     int64_t block_row_nnz = 0;
     for (int j = 0; j < nf; j++) {
       A.rowptr[j] = blocks[i * nf + j]->rowptr;
@@ -766,7 +779,8 @@ extern "C" int tg_csr_from_blocks(int nf, const tg_csr_t *blocks, tg_csr_t *out)
       A.val[j] = blocks[i * nf + j]->val;
       block_row_nnz += blocks[i * nf + j]->nnz;
     }
-    int64_t *orp = m->rowptr + (int64_t)i * n;
+    int64_t *orp = m->rowptr + row_at;
+    row_at += n;
     if (n > 0) {
       hipLaunchKernelGGL(k_merge_count, dim3(tg_grid_1d(n, 256)), dim3(256), 0, g_tg.stream, A, orp);
       if (hipGetLastError() != hipSuccess) rc = 1;
@@ -791,8 +805,8 @@ extern "C" int tg_csr_from_blocks(int nf, const tg_csr_t *blocks, tg_csr_t *out)
       if (hipGetLastError() != hipSuccess) rc = 1;
     }
     at += total;
+    if (!rc && n == 0 && hipMemcpyAsync(orp, &at, sizeof(int64_t), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess) rc = 1;
   }
-  if (!rc && n == 0) hipMemsetAsync(m->rowptr, 0, sizeof(int64_t), g_tg.stream);
   if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
   if (rc) {
     tg_csr_destroy(m);

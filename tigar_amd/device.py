@@ -409,7 +409,8 @@ def extract_csr_bezier(bern, eoff, nodes, coef, col_offset, ncols, eps):
 
 
 def csr_from_blocks(blocks):
-    """nf x nf blocks of one shape (list of rows of DeviceCSR) -> the matrix with field-major rows and columns"""
+    """nf x nf blocks (list of rows of DeviceCSR; block (i, j) has the rows of field i and the columns of field j) -> the matrix
+    with field-major rows and columns"""
     nf = len(blocks)
     flat = [b for row in blocks for b in row]
     if any(len(row) != nf for row in blocks):
