@@ -23,6 +23,22 @@ def problem(case, comm):
     import scipy.sparse as sp
     import tigar_amd as t
     from tigar_amd import BSplines as B, forms as F
+    if case == "rt3d":
+        # the space of demos/taylor-green/taylor-green-3d.py:42-50: BSplineCompat("RT") -- three fields on DIFFERENT bases (one
+        # degree higher along their own direction) over one Q_(k+1) node grid, normal-direction boundary conditions
+        from tigar_amd.compatibleSplines import BSplineCompat
+        degs = [int(v) for v in os.environ.get("TIGAR_TEST_FDEGS", "1,1,1").split(",")]
+        nels = [int(v) for v in os.environ.get("TIGAR_TEST_FNELS", "5,4,9").split(",")]
+        kv = [B.uniformKnots(degs[k], 0., 1. + 0.25 * k, nels[k]) for k in range(3)]
+        gen = BSplineCompat(comm, B.ExplicitBSplineControlMesh(degs, kv), "RT", degs)
+        for f in range(3):
+            s0 = gen.getFieldSpline(f)
+            for side in (0, 1):
+                gen.addZeroDofs(f, s0.getSideDofs(f, side))
+        spline = t.ExtractedSpline(gen, 2 * (max(degs) + 1))
+        K = spline.assembleMatrix(F.ElasticityForm(2.0, 1.0), diag=1.5)
+        rhs = spline.extractVector(hashed(spline.V.dim(), 79))
+        return gen, spline, K, rhs, "gmres"
     if case == "shell2d":            # cfg5-like: 2-D p=3, three fields, hashed non-symmetric A on the 3-field pattern
         d, p, nel, nF, method = 2, 3, 14, 3, "gmres"
     else:                            # 3-D elasticity, p=2, three fields (ElasticityForm: blocks as Kronecker sums)

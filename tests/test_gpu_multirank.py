@@ -223,6 +223,75 @@ def test_several_fields_on_several_ranks_other_shapes(tmp_path, case, world, p, 
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("world,kind,degs,nels", [(2, "ipc", "1,1,1", "5,4,9"), (3, "host", "1,1,1", "3,4,8"), (2, "ipc", "2,2,2", "3,3,6"),
+                                                  (3, "ipc", "1,1,1", "4,3,4")])
+def test_fields_on_different_bases_on_several_ranks(tmp_path, world, kind, degs, nels):
+    """BSplineCompat("RT") -- the space of the reference's Krylov + MPI demos (demos/taylor-green/taylor-green-3d.py:42-90;
+    tIGAr/compatibleSplines.py:21-101) -- in z-slabs over 2-3 ranks: one split of the plane index for the three fields (they
+    have different numbers of planes), the dofs interleaved plane by plane, every block K_fg = M_f^T A_fg M_g by the line
+    walks with different row / column bases; rows of K, M^T b, the GMRES solution and u = M U of every rank against the
+    single-rank resident run (which the kernel- and API-level tests pin to the oracle)."""
+    env = {"TIGAR_TEST_FDEGS": degs, "TIGAR_TEST_FNELS": nels}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        _several_fields(tmp_path, "rt3d", world, kind, env)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_fields_on_different_bases_streamed_through_one_gpu():
+    """the same engine on ONE rank with the operator kept implicit and the patch streamed in sub-slabs of two dof planes:
+    K and M^T b equal the resident path's after undoing the plane-wise interleaving, the walks ran for all nine blocks, and
+    the solution / prolongation agree"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_rank_worker_fields as W
+    import tigar_amd as t
+    from tigar_amd import common as tc, device as dev
+    gen, spline, K, rhs, method = W.problem("rt3d", tc.selfcomm)
+    Kref, rref = K.to_scipy().tocsr(), rhs.get_local()
+    os.environ["TIGAR_IMPLICIT_M"] = "1"
+    os.environ["TIGAR_SUB_PLANES"] = "2"
+    try:
+        dev.prof_reset()
+        gen2, spline2, K2, rhs2, _ = W.problem("rt3d", tc.selfcomm)
+        assert getattr(gen2.M, "is_implicit", False) and gen2.M.nfields == 3
+        assert dev.prof_get(5)[1] >= 9 * 3                      # nine blocks, several sub-slabs each
+        dofs = spline2.localDofIndices()
+        n2o = spline2._slab_path().new_of_old()
+        n = Kref.shape[0]
+        old_of_new = np.empty(n, dtype=np.int64)
+        old_of_new[n2o] = np.arange(n)
+        K2s = K2.to_scipy().tocsr()
+        Kr = Kref[dofs][:, old_of_new].tocsr()
+        Kr.sort_indices()
+        K2s.sort_indices()
+        assert np.array_equal(K2s.indptr, Kr.indptr) and np.array_equal(K2s.indices, Kr.indices)
+        assert abs(K2s - Kr).max() <= 1e-12 * abs(Kref).max()
+        assert np.max(np.abs(rhs2.get_local() - rref[dofs])) <= 1e-13 * np.max(np.abs(rref))
+        solver = t.PETScKrylovSolver("gmres", "jacobi")
+        solver.parameters["relative_tolerance"] = 1e-11
+        for s_ in (spline, spline2):
+            s_.setSolverOptions(linearSolver=solver)
+        u, u2 = t.Function(spline.V), t.Function(spline2.V, spline2.localFERange())
+        U = spline.solveLinearSystem(K, rhs, u).get_local()
+        U2 = spline2.solveLinearSystem(K2, rhs2, u2).get_local()
+        assert np.max(np.abs(U2 - U[dofs])) <= 1e-8 * np.max(np.abs(U))
+        assert np.max(np.abs(u2.vector().get_local() - u.vector().get_local())) <= 1e-8 * np.max(np.abs(u.vector().get_local()))
+        # an assembled FE matrix on the same spline goes through the same engine and numbering
+        from tigar_amd import forms as F
+        K3 = spline2.extractMatrix(F.ElasticityForm(2.0, 1.0).assemble_matrix(spline.V), diag=1.5).to_scipy().tocsr()
+        K3.sort_indices()
+        assert np.array_equal(K3.indices, Kr.indices) and abs(K3 - Kr).max() <= 1e-12 * abs(Kref).max()
+    finally:
+        os.environ.pop("TIGAR_IMPLICIT_M", None)
+        os.environ.pop("TIGAR_SUB_PLANES", None)
+
+
 def _several_fields(tmp_path, case, world, kind, env_more):
     """EqualOrderSpline(nFields = 3) split into z-slabs (VERDICT r2 missing #2): a rank owns the dof planes of every field,
     the dofs are interleaved plane by plane so that its rows of K are one contiguous block (localDofIndices() gives the
@@ -267,7 +336,8 @@ def _several_fields(tmp_path, case, world, kind, env_more):
         assert np.max(np.abs(z["rhs"] - rref[dofs])) <= 1e-13 * np.max(np.abs(rref))
         assert np.max(np.abs(z["U"] - U[dofs])) <= 1e-8 * np.max(np.abs(U))
         rows = np.concatenate([np.arange(a, b) for a, b in z["fe"]])
-        assert np.max(np.abs(z["u"] - uref[rows])) <= 1e-8 * np.max(np.abs(uref))
+        if rows.size:                                # (a rank of a thin slab may own no FE rows)
+            assert np.max(np.abs(z["u"] - uref[rows])) <= 1e-8 * np.max(np.abs(uref))
         assert abs(int(z["its"][0]) - its) <= max(1, its // 20)
         if kind == "ipc":
             assert int(z["host_waits"][0]) == 0 and int(z["kind"][0]) == 2

@@ -492,7 +492,9 @@ class AbstractExtractionGenerator(object):
         self._kron = None
         self._kron_scalar = None           # several fields on ONE tensor basis (EqualOrderSpline(nFields > 1)): its tables
         self._kron_fields = None           # several fields on different tensor bases: one set of tables per field
-        if getattr(self.M, "is_implicit", False) and getattr(self.M, "nfields", 1) > 1:
+        if getattr(self.M, "is_implicit", False) and hasattr(self.M, "kxs"):
+            self._kron_fields = self.M.kxs       # diag(M_0, ..., M_{nF-1}) on different bases, never stored
+        elif getattr(self.M, "is_implicit", False) and getattr(self.M, "nfields", 1) > 1:
             self._kron_scalar = self.M.kx        # diag(M_s, ..., M_s), never stored
         elif getattr(self.M, "is_implicit", False):
             self._kron = self.M.kx
@@ -866,12 +868,44 @@ class AbstractCoordinateChartSpline(AbstractExtractionGenerator):
             # scalar operator stands in for the matrix
             from .implicit import BlockImplicitExtraction
             return BlockImplicitExtraction(self.M_control.kx, self.getNFields(), self.M_control.eps)
+        if self.getNFields() > 1 and not support_only and not self._fields_on_control_basis():
+            lazy = self._implicit_field_list()
+            if lazy is not None:
+                return lazy
         blocks = []
         offset = 0
         for field in range(self.getNFields()):
             blocks.append(self._generate_block(field, offset, totalDofs, self.V.grids[field], support_only))
             offset += self.getNcp(field)
         return blocks[0] if len(blocks) == 1 else _dev.csr_vstack(blocks)
+
+    def _implicit_field_list(self):
+        """``FieldListImplicitExtraction`` for fields on different tensor B-spline bases over ONE node grid when the patch is
+        spread over several ranks (no rank ever holds all rows) or TIGAR_IMPLICIT_M=1 asks for it; every field's operator
+        must be exactly the Kronecker product of its 1-D factors (the filter of tIGAr/common.py:1569 dropped nothing but
+        exact zeros) and the slab direction must carry open knot vectors.  None otherwise (stored blocks)."""
+        from .BSplines import BSpline
+        from .implicit import FieldListImplicitExtraction
+        env = os.environ.get("TIGAR_IMPLICIT_M")
+        if env == "0" or (env != "1" and self.comm.size == 1):
+            return None
+        kxs = []
+        g0 = self.V.grids[0]
+        for field in range(self.getNFields()):
+            basis, grid = self.getScalarSpline(field), self.V.grids[field]
+            if not (isinstance(basis, BSpline) and type(basis).getNodesAndEvals is BSpline.getNodesAndEvals) or \
+                    not isinstance(grid, TensorNodeGrid) or grid.dg or grid.degree != g0.degree or \
+                    any(not numpy.array_equal(a, b) for a, b in zip(grid.axes, g0.axes)):
+                return None
+            kx = self._kron_tables(basis, grid)
+            if kx is None or not kx.products_stay_above(self.getIgnoreEps()):
+                return None
+            s_last = basis.splines[-1]
+            kn, pl = numpy.asarray(s_last.knots, dtype=float), int(s_last.p)
+            if not (numpy.all(kn[:pl + 1] == kn[0]) and numpy.all(kn[-(pl + 1):] == kn[-1])):
+                return None
+            kxs.append(kx)
+        return FieldListImplicitExtraction(kxs, self.getIgnoreEps())
 
     def feRowOwners(self, nparts):
         """Rank of every FE row when the FE side is cut into ``nparts`` pieces the way this package cuts it: every
@@ -1405,9 +1439,17 @@ class ExtractedSpline(object):
             self._slab = FieldSlabPath(kx.basis, kx.grid, self.nFields, self.comm.rank if dc is not None else 0,
                                        self.comm.size if dc is not None else 1, dc, sub_planes="auto",
                                        eps=getattr(self.M, "eps", DEFAULT_BASIS_FUNC_IGNORE_EPS), kx=kx)
+        if self._slab is None and self._kron is None and getattr(self, "_kron_fields", None) is not None:
+            # fields on different tensor bases over one node grid: one split of the plane index, pair walks per block
+            from .dist import FieldListSlabPath
+            dc = self.comm.device() if self._distributed() else None
+            self._slab = FieldListSlabPath(self._kron_fields, self.comm.rank if dc is not None else 0,
+                                           self.comm.size if dc is not None else 1, dc, sub_planes="auto",
+                                           eps=getattr(self.M, "eps", DEFAULT_BASIS_FUNC_IGNORE_EPS))
         if self._slab is None:
             if self._kron is None:
-                raise NotImplementedError("the streamed / multi-GPU path needs tensor-product B-spline fields on one basis")
+                raise NotImplementedError("the streamed / multi-GPU path needs tensor-product B-spline fields (one basis, or "
+                                          "several bases over one node grid)")
             from .dist import SlabHotPath
             kx = self._kron
             dc = self.comm.device() if self._distributed() else None
@@ -1491,7 +1533,8 @@ class ExtractedSpline(object):
             #  numbering -- the same guard as extractVector / solveLinearSystem, so that K, M^T b and U share it;
             #  an explicit A -- FEtoIGA's identity, an uploaded matrix -- is cut into the blocks the engine asks for)
             a_fac = None
-            if self.nFields > 1 and self._kron is None and getattr(self, "_kron_scalar", None) is not None:
+            if self.nFields > 1 and self._kron is None and (getattr(self, "_kron_scalar", None) is not None or
+                                                            getattr(self, "_kron_fields", None) is not None):
                 return self._slab_path().assemble_matrix(self._block_producer(A), zd, float(diag),
                                                          getattr(self, "stage_timers", None),
                                                          block_factors=getattr(A, "block_factors", None))

@@ -769,7 +769,7 @@ extern "C" int tg_tensor_zstage(tg_tensor_plan_t pl, int npieces, const tg_tenso
   TG_REQUIRE(ka >= 0 && kb > ka && kb <= ncr2, "tg_tensor_zstage: dof planes out of range");
   TG_REQUIRE(!pl->pair || !(zero_dofs && nzero > 0), "tg_tensor_zstage: blocks with different bases on the two sides take no zero dofs "
                                                      "(MatZeroRowsColumns belongs to the assembled matrix)");
-  const int e_begin = std::max(0, ka - P), e_end = std::min(D2.nel, kb);
+  const int e_begin = std::max(0, ka - pl->pr[2]), e_end = std::min(D2.nel, kb);   // (row function i lives on the elements [i - pr, i])
   const int plo = e_begin == 0 ? 0 : P * e_begin + 1, phi = P * e_end;      // FE planes read: [plo, phi]
   std::vector<const double *> ptr(phi - plo + 1, nullptr);
   for (int q = 0; q < npieces; q++) {

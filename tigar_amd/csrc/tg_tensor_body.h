@@ -621,7 +621,8 @@ TT_DEV void tt_z_lane(const tt_z_args &A, int bx, int lane) {
   io.mask = A.mask;
   io.diag = A.diag;
   const int nel = A.d2.nel;
-  const int e_begin = A.ka - P > 0 ? A.ka - P : 0;
+  const int pr2 = A.pr2 ? A.pr2 : P;              // (row function i lives on the elements [i - pr2, i])
+  const int e_begin = A.ka - pr2 > 0 ? A.ka - pr2 : 0;
   const int e_end = A.kb < nel ? A.kb : nel;
   tt_walk<P>(A.d2, e_begin, e_end, io);
 }

@@ -90,6 +90,9 @@ class ZSlabLayout(object):
 
     # ---- row ranges (global indices) of everything a slab of K rows needs ------------------
     def slab(self, k0, k1):
+        if k1 <= k0:                      # (a rank without planes of this basis: fields of unequal plane counts share one split)
+            return {"dofs": (k0 * self.plane_dofs, k0 * self.plane_dofs), "a_rows": (0, 0), "m_rows": (0, 0), "halo": (0, 0),
+                    "u_rows": (0, 0)}
         za, zb = self.fe_planes_of_dofs(k0, k1)
         ca, cb = self.fe_planes_coupled(za, zb)
         hl, hh = self.dof_halo(k0, k1)
@@ -147,7 +150,9 @@ class SlabHotPath(object):
 
     With world == 1 and one sub-slab this is exactly the single-GPU path."""
 
-    def __init__(self, basis, grid, rank=0, world=1, comm=None, sub_planes=None, eps=1e-15, factored=None, kx=None):
+    def __init__(self, basis, grid, rank=0, world=1, comm=None, sub_planes=None, eps=1e-15, factored=None, kx=None, planes=None):
+        """``planes``: the dof planes [k0, k1) of this rank when they are not the balanced split of the basis' own planes
+        (fields on different bases share one split of the plane index, ``FieldListSlabPath``)"""
         from . import device as dev
         from .kronptap import KronExtraction
         self.dev = dev
@@ -174,7 +179,7 @@ class SlabHotPath(object):
         self.rank, self.world, self.comm = rank, world, comm
         self.eps = eps
         self.layout = layout_for(basis, grid)
-        self.k0, self.k1 = split_range(self.layout.ncp, world)[rank]
+        self.k0, self.k1 = split_range(self.layout.ncp, world)[rank] if planes is None else (int(planes[0]), int(planes[1]))
         if sub_planes == "auto" and os.environ.get("TIGAR_SUB_PLANES"):
             sub_planes = int(os.environ["TIGAR_SUB_PLANES"])          # (experiments)
         if sub_planes == "auto":
@@ -208,12 +213,16 @@ class SlabHotPath(object):
         parts = -(-n // max(1, self.sub_planes))
         return [(self.k0 + (n * q) // parts, self.k0 + (n * (q + 1)) // parts) for q in range(parts)]
 
-    def assemble(self, a_rows, b_rows, zero_dofs, diag=1.0, timers=None, a_factors=None):
+    def assemble(self, a_rows, b_rows, zero_dofs, diag=1.0, timers=None, a_factors=None, col=None):
         """K_loc (rows of this rank, global columns, BCs applied) and rhs_loc = (M^T b)_loc.
         ``a_rows(r0, r1)`` / ``b_rows(r0, r1)`` return the FE matrix rows (DeviceCSR, global
-        columns) / FE vector entries (DeviceVector) of global FE rows [r0, r1)."""
+        columns) / FE vector entries (DeviceVector) of global FE rows [r0, r1).
+        ``col``: the ``KronExtraction`` of the COLUMN side when it is another basis than this engine's (block (f, g) of a
+        space whose fields sit on different bases over one node grid: K_fg = M_f^T A_fg M_g) -- tensor line walks only."""
         import time
         dev = self.dev
+        if col is not None:
+            return self._assemble_pair(a_rows, col, timers, a_factors)
         sp1, axes = self.basis.splines, self.grid.axes
         zero_dofs = np.asarray(zero_dofs if zero_dofs is not None else [], dtype=np.int32)
         with_rhs = b_rows is not None
@@ -397,6 +406,56 @@ class SlabHotPath(object):
             rhs = rhs_parts[0] if len(rhs_parts) == 1 else dev.vec_concat(rhs_parts)
         tick("stack", t0)
         return K, rhs
+
+    def _assemble_pair(self, a_rows, col, timers=None, a_factors=None):
+        """rows [k0, k1) of K_fg = M_f^T A_fg M_g, f = this engine's basis, g = ``col``: the same sub-slab pipeline with the
+        pair plan of the tensor-pattern walks (x / y passes once per FE plane, kept in the ring; the z pass appends the
+        rows at closed-form positions); no boundary conditions (they belong to the assembled matrix)"""
+        import time
+        from .tensorptap import TensorPtAP
+        dev = self.dev
+        t = timers if timers is not None else {}
+        tplan = TensorPtAP.for_pair(self.kx, col)
+        if tplan is None:
+            raise NotImplementedError("the streamed / multi-GPU path for fields on different bases needs tensor-product B-spline "
+                                      "fields of degree <= 3 on one 3-D node grid (the line walks)")
+        packed = tplan.pack_kron_factors(a_factors) if (a_factors is not None and os.environ.get("TIGAR_PTAP_FUSED", "1") != "0") else None
+        subs = self.sub_slabs()
+        pd = self.layout.plane_dofs
+        ncols = int(np.prod(col.ncp, dtype=np.int64))
+        nrows = (self.k1 - self.k0) * pd
+        if not subs:
+            import scipy.sparse as sp
+            return dev.DeviceCSR.from_scipy(sp.csr_matrix((0, ncols))), None
+        builder = dev.CSRBuilder(nrows, ncols, tplan.k_nnz(self.k0, self.k1)) if len(subs) > 1 else None
+        pieces, hi, out = [], 0, None
+        pf = self.layout.plane_fe
+        for (ka, kb) in subs:
+            S = self.layout.slab(ka, kb)
+            za, zb = S["a_rows"][0] // pf, S["a_rows"][1] // pf
+            new_lo = max(za, hi)
+            t0 = time.perf_counter()
+            if zb > new_lo:
+                if packed is not None:
+                    piece = tplan.planes_kron(packed, new_lo, zb)
+                    if piece is None:
+                        packed = None
+                if packed is None:
+                    A = a_rows(new_lo * pf, zb * pf)
+                    dev.sync()
+                    t["input"] = t.get("input", 0.0) + time.perf_counter() - t0
+                    piece = tplan.planes(A, new_lo * pf, new_lo, zb)
+                    del A
+                if piece is None:
+                    raise NotImplementedError("the streamed / multi-GPU path for fields on different bases needs FE matrices "
+                                              "on the element-coupling pattern of the node grid")
+                pieces.append((new_lo, zb, piece))
+                hi = zb
+            pieces = [pc for pc in pieces if pc[1] > za]
+            out = tplan.zstage([pc[2] for pc in pieces], ka, kb, None, 1.0, append_to=builder)
+            dev.sync()
+            t["ptap"] = t.get("ptap", 0.0) + time.perf_counter() - t0
+        return (builder.finish() if builder is not None else out), None
 
     def assemble_matrix(self, a_rows, zero_dofs, diag=1.0, timers=None, a_factors=None):
         """K_loc = rows of M^T A M owned by this rank (extractMatrix, tIGAr/common.py:1176-1204)."""
@@ -659,4 +718,167 @@ class FieldSlabPath(object):
             for k in range(nplanes):
                 dev.vec_copy_range(xf, k * pd, x, (k * nF + f) * pd, pd)
             out.append(S._prolong_tensor(xf, plane0))
+        return dev.vec_concat(out)
+
+
+class FieldListSlabPath(object):
+    """The z-slab path for fields on DIFFERENT tensor bases over one FE node grid -- ``FieldListSpline``, the components of a
+    compatible B-spline (tIGAr/common.py:1949-1970, tIGAr/compatibleSplines.py:21-101; the spaces of the reference's
+    Krylov + MPI demos, demos/taylor-green/taylor-green-3d.py:42-90).  M = diag(M_0, ..., M_{nF-1}); field f has its own number
+    of dof planes nk_f (elements + degree in the slab direction) and of dofs per plane pd_f.
+
+    One split of the PLANE INDEX k serves all fields: a rank owns the planes [K0, K1) of every field that has them.  The
+    distributed numbering interleaves the fields plane by plane,
+
+        new index of (field f, plane k, in-plane index ij)  =  off[k] + sum_{f' < f, k < nk_f'} pd_f' + ij,
+
+    so that a rank's rows of K are one contiguous block and the Krylov halo is a contiguous run of max-degree planes on either
+    side (functions (f, i) and (g, j) couple for j in [i - p_f, i + p_g], in their own plane indices) -- a renumbering of the
+    IGA dofs for parallel runs as the reference's ``generatePermutation`` is one; ``local_dof_indices()`` names the reference
+    (field-after-field) index of every local entry.  Block (f, g) = M_f^T A_fg M_g comes from the scalar engine of field f
+    with the column side of field g (``SlabHotPath.assemble(col=...)``: the line walks with separate row / column weights)."""
+
+    def __init__(self, kxs, rank=0, world=1, comm=None, sub_planes="auto", eps=1e-15):
+        from . import device as dev
+        self.dev = dev
+        self.kxs = list(kxs)
+        self.nF = len(self.kxs)
+        self.rank, self.world, self.comm = rank, world, comm
+        g0 = self.kxs[0].grid
+        if any(kx.d != self.kxs[0].d or any(not np.array_equal(a, b) for a, b in zip(kx.grid.axes, g0.axes)) for kx in self.kxs):
+            raise NotImplementedError("the streamed / multi-GPU path needs all fields on one FE node grid")
+        self.nk = [int(kx.ncp[-1]) for kx in self.kxs]
+        self.pd = [int(np.prod(kx.ncp[:-1], dtype=np.int64)) if kx.d > 1 else 1 for kx in self.kxs]
+        self.ncp_f = [nk * pd for nk, pd in zip(self.nk, self.pd)]
+        self.nfe1 = int(np.prod(self.kxs[0].nfe, dtype=np.int64))
+        self.ncp = int(sum(self.ncp_f))
+        self.Kmax = max(self.nk)
+        self.K0, self.K1 = split_range(self.Kmax, world)[rank]
+        nF = self.nF
+        # off[k]: first new index of plane k; present[k][f]
+        self.width = np.array([[self.pd[f] if k < self.nk[f] else 0 for f in range(nF)] for k in range(self.Kmax)], dtype=np.int64)
+        self.off = np.concatenate([[0], np.cumsum(self.width.sum(axis=1))])
+        self.engines = []
+        for f, kx in enumerate(self.kxs):
+            k0, k1 = min(self.K0, self.nk[f]), min(self.K1, self.nk[f])
+            self.engines.append(SlabHotPath(kx.basis, kx.grid, rank, world, None, sub_planes, eps, kx=kx, planes=(k0, k1)))
+        self.sub_planes = self.engines[0].sub_planes
+        H = max(max(s1.p for s1 in kx.basis.splines[-1:]) for kx in self.kxs)
+        lo, hi = max(0, self.K0 - H), min(self.Kmax, self.K1 + H)
+        self.halo_planes = (self.K0 - lo, hi - self.K1)
+        self.mine = {"dofs": (int(self.off[self.K0]), int(self.off[self.K1])),
+                     "halo": (int(self.off[self.K0] - self.off[lo]), int(self.off[hi] - self.off[self.K1])),
+                     "u_rows": [(f * self.nfe1 + e.mine["u_rows"][0], f * self.nfe1 + e.mine["u_rows"][1])
+                                for f, e in enumerate(self.engines)]}
+        if comm is not None and world > 1:
+            comm.set_slab(self.mine["dofs"][0], self.mine["dofs"][1], self.mine["halo"][0], self.mine["halo"][1], self.ncp)
+
+    # ---- numbering ------------------------------------------------------------------------------------------
+    def _field_offsets_old(self):
+        return np.concatenate([[0], np.cumsum(self.ncp_f)])
+
+    def new_of_old(self):
+        """distributed index of every reference (field-after-field) dof"""
+        out = np.empty(self.ncp, dtype=np.int64)
+        fo = self._field_offsets_old()
+        for f in range(self.nF):
+            k = np.repeat(np.arange(self.nk[f], dtype=np.int64), self.pd[f])
+            ij = np.tile(np.arange(self.pd[f], dtype=np.int64), self.nk[f])
+            out[fo[f]:fo[f + 1]] = self.off[k] + self.width[k, :f].sum(axis=1) + ij
+        return out
+
+    def local_dof_indices(self):
+        """reference (field-after-field) index of every entry of this rank's vectors / rows of K, in local order"""
+        n2o = np.empty(self.ncp, dtype=np.int64)
+        n2o[self.new_of_old()] = np.arange(self.ncp, dtype=np.int64)
+        return n2o[self.mine["dofs"][0]:self.mine["dofs"][1]]
+
+    def _local_rows_field_major(self):
+        """for every local entry in the interleaved order: its position in the field-major local stacking
+        [field 0: planes k0_0..k1_0][field 1: ...] that the blocks come in"""
+        pos, base = [], 0
+        starts = []
+        for f, e in enumerate(self.engines):
+            starts.append(base)
+            base += (e.k1 - e.k0) * self.pd[f]
+        for k in range(self.K0, self.K1):
+            for f, e in enumerate(self.engines):
+                if k < self.nk[f]:
+                    pos.append(starts[f] + (k - e.k0) * self.pd[f] + np.arange(self.pd[f], dtype=np.int64))
+        return np.concatenate(pos) if pos else np.zeros(0, dtype=np.int64)
+
+    def _interleave_vec(self, parts):
+        dev = self.dev
+        out = dev.DeviceVector(self.mine["dofs"][1] - self.mine["dofs"][0])
+        at = 0
+        for k in range(self.K0, self.K1):
+            for f, e in enumerate(self.engines):
+                if k < self.nk[f]:
+                    dev.vec_copy_range(out, at, parts[f], (k - e.k0) * self.pd[f], self.pd[f])
+                    at += self.pd[f]
+        return out
+
+    # ---- the path ---------------------------------------------------------------------------------------------
+    def assemble_matrix(self, a_block, zero_dofs, diag=1.0, timers=None, block_factors=None):
+        """``a_block(f, g, r0, r1)``: rows [r0, r1) of block (f, g) of the FE matrix (FE rows of field f counted from 0) as a
+        DeviceCSR with the columns of field g (0 .. nfe-1), or None when the fields are not coupled; ``block_factors[f][g]``:
+        the block as a Kronecker sum of 1-D matrices (formed inside the first pass)."""
+        import scipy.sparse as sp
+        dev, nF = self.dev, self.nF
+        blocks = []
+        for f, e in enumerate(self.engines):
+            row = []
+            nloc = (e.k1 - e.k0) * self.pd[f]
+            for g in range(nF):
+                fac = block_factors[f][g] if block_factors is not None else None
+                ar = e.mine["a_rows"]
+                empty = e.k1 <= e.k0
+                probe = None
+                if not empty:
+                    probe = a_block(f, g, ar[0], min(ar[0] + 1, ar[1])) if fac is not None else a_block(f, g, ar[0], ar[1])
+                if empty or probe is None or (fac is None and probe.nnz == 0):
+                    row.append(dev.DeviceCSR.from_scipy(sp.csr_matrix((nloc, self.ncp_f[g]))))
+                    continue
+                del probe
+                Kfg = e.assemble(lambda r0, r1, f=f, g=g: a_block(f, g, r0, r1), None, None, 1.0, timers, fac, col=self.kxs[g])[0]
+                row.append(Kfg)
+            blocks.append(row)
+        K = dev.csr_from_blocks(blocks)            # rows field-major local, columns field-after-field (reference numbering)
+        del blocks
+        K = K.gather_rows(self._local_rows_field_major())
+        n2o = self.new_of_old()
+        K = K.permute_columns(n2o)
+        if zero_dofs is not None and len(zero_dofs):
+            K.zero_rows_cols(n2o[np.asarray(zero_dofs, dtype=np.int64)].astype(np.int32), diag, self.mine["dofs"][0])
+        return K
+
+    def assemble_vector(self, b_rows, zero_dofs=None, timers=None):
+        parts = []
+        for f, e in enumerate(self.engines):
+            if e.k1 > e.k0:
+                parts.append(e.assemble_vector(lambda r0, r1, f=f: b_rows(f * self.nfe1 + r0, f * self.nfe1 + r1), None, timers))
+            else:
+                parts.append(self.dev.DeviceVector(0))
+        y = self._interleave_vec(parts)
+        if zero_dofs is not None and len(zero_dofs):
+            y.zero_entries(self.new_of_old()[np.asarray(zero_dofs, dtype=np.int64)].astype(np.int32), self.mine["dofs"][0])
+        return y
+
+    def prolong(self, U):
+        """FE rows of u = M U this rank owns, field after field (``mine["u_rows"]``), from the local U (interleaved)"""
+        dev = self.dev
+        hl, hh = self.halo_planes
+        if self.world > 1:
+            x = self.comm.halo_extend(U)
+            kk0, kk1 = self.K0 - hl, self.K1 + hh
+        else:
+            x, kk0, kk1 = U, self.K0, self.K1
+        out = []
+        for f, e in enumerate(self.engines):
+            ka, kb = min(kk0, self.nk[f]), min(kk1, self.nk[f])
+            xf = dev.DeviceVector(max(0, kb - ka) * self.pd[f])
+            for k in range(ka, kb):
+                src = int(self.off[k] - self.off[kk0] + self.width[k, :f].sum())
+                dev.vec_copy_range(xf, (k - ka) * self.pd[f], x, src, self.pd[f])
+            out.append(e._prolong_tensor(xf, ka))
         return dev.vec_concat(out)

@@ -182,3 +182,62 @@ class BlockImplicitExtraction(object):
     def to_scipy(self):
         import scipy.sparse as sp
         return sp.block_diag([self.scalar.to_scipy()] * self.nfields, format="csr")
+
+
+class FieldListImplicitExtraction(object):
+    """M = diag(M_0, ..., M_{nF-1}) of fields on DIFFERENT tensor bases (``FieldListSpline``, the components of a compatible
+    B-spline: tIGAr/common.py:1949-1970, tIGAr/compatibleSplines.py:21-101), FE rows and dofs field after field, every M_f
+    the implicit Kronecker operator of its own basis -- not stored.  Stands in for the matrix object when the patch is
+    spread over several ranks (no rank holds all rows) or TIGAR_IMPLICIT_M=1 asks for it."""
+
+    is_implicit = True
+
+    def __init__(self, kxs, eps, transposed=False, _pair=None):
+        self.kxs, self.eps, self.transposed = list(kxs), float(eps), bool(transposed)
+        self.nfields = len(self.kxs)
+        self.scalars = [ImplicitExtraction(kx, eps, transposed) for kx in self.kxs]
+        self._T = _pair
+        self._shape = (sum(s.shape[0] for s in self.scalars), sum(s.shape[1] for s in self.scalars))
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def nnz(self):
+        return sum(kx.nnz_product for kx in self.kxs)
+
+    def transpose(self):
+        if self._T is None:
+            self._T = FieldListImplicitExtraction(self.kxs, self.eps, not self.transposed, _pair=self)
+        return self._T
+
+    def _apply(self, x, ops, y=None):
+        out = y if y is not None else _dev.DeviceVector(sum(op.shape[0] for op in ops))
+        r0 = c0 = 0
+        for op in ops:
+            r, c = op.shape
+            xf = _dev.DeviceVector(c)
+            _dev.vec_copy_range(xf, 0, x, c0, c)
+            _dev.vec_copy_range(out, r0, op.mult(xf), 0, r)
+            r0 += r
+            c0 += c
+        return out
+
+    def mult(self, x, y=None):
+        return self._apply(x, self.scalars, y)
+
+    def mult_transpose(self, b, y=None):
+        return self._apply(b, [s.transpose() for s in self.scalars], y)
+
+    def __mul__(self, x):
+        if isinstance(x, _dev.DeviceVector):
+            return self.mult(x)
+        return NotImplemented
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.block_diag([s.to_scipy() for s in self.scalars], format="csr")
+
+    def materialise(self):
+        return _dev.DeviceCSR.from_scipy(self.to_scipy())
