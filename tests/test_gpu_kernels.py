@@ -933,3 +933,29 @@ def test_invalid_inputs_are_errors_not_reads_of_foreign_memory():
     y = dev.DeviceVector(data=np.ones(5))
     y.zero_entries(np.array([0, 9], dtype=np.int32))
     assert np.array_equal(y.get_local(), [0.0, 1.0, 1.0, 1.0, 1.0])
+
+
+def test_gather_rows_beyond_the_capped_grid(dev):
+    """tg_csr_gather_rows on more rows than one capped launch covers (8 x CUs x 256 threads): the length kernel had no
+    grid-stride loop, so rows beyond 524 288 kept whatever their buffer held -- first reached in round 5 by a three-field
+    product with 836 550 local rows (GMRES then ran on garbage).  Every row-wise helper takes this size here."""
+    import scipy.sparse as sp
+    n = 700001
+    rng = np.random.default_rng(11)
+    A = sp.diags([np.arange(1.0, n + 1.0), np.full(n - 1, 0.5)], [0, 1], format="csr")
+    perm = rng.permutation(n)
+    G = dev.DeviceCSR.from_scipy(A).gather_rows(perm).to_scipy()
+    R = A[perm]
+    assert G.nnz == A.nnz and np.array_equal(G.indptr, R.indptr) and np.array_equal(G.indices, R.indices)
+    assert np.array_equal(G.data, R.data)
+    # neighbours of the same family at that size: blocks put together, columns renamed, a block cut out
+    B2 = dev.csr_from_blocks([[dev.DeviceCSR.from_scipy(A), dev.DeviceCSR.from_scipy(sp.csr_matrix((n, 5)))],
+                              [dev.DeviceCSR.from_scipy(sp.csr_matrix((5, n))), dev.DeviceCSR.from_scipy(sp.identity(5, format="csr"))]])
+    Bs = B2.to_scipy()
+    assert Bs.shape == (n + 5, n + 5) and abs(Bs - sp.bmat([[A, None], [None, sp.identity(5)]], format="csr")).max() == 0.0
+    P = dev.DeviceCSR.from_scipy(A).permute_columns(perm.astype(np.int32)).to_scipy()
+    Rp = sp.csr_matrix((A.data, perm[A.indices], A.indptr), shape=A.shape)
+    Rp.sort_indices()
+    assert np.array_equal(P.indices, Rp.indices) and np.array_equal(P.data, Rp.data)
+    blk = dev.DeviceCSR.from_scipy(A).block(600000, n, 599990, n).to_scipy()
+    assert abs(blk - A[600000:n, 599990:n]).max() == 0.0

@@ -1171,8 +1171,10 @@ extern "C" int tg_csr_combine(double a, tg_csr_t X, double b, tg_csr_t Y, tg_vec
 // distributed numbering (tigar_amd/dist.py: FieldSlabPath).
 __global__ void k_gather_len(const int64_t *__restrict__ arp, const int64_t *__restrict__ rows, int64_t n,
                              int64_t *__restrict__ len) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n) len[r] = arp[rows[r] + 1] - arp[rows[r]];
+  // (tg_grid_1d caps the grid: grid-stride loop.  Without it the rows beyond 8 x CUs x 256 = 524 288 kept whatever the
+  //  buffer held -- found in round 5 by the first multi-field product with more local rows than that)
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) len[r] = arp[rows[r] + 1] - arp[rows[r]];
 }
 __global__ void __launch_bounds__(256)
     k_gather_copy(const int64_t *__restrict__ arp, const int32_t *__restrict__ ac, const double *__restrict__ av,
@@ -1220,12 +1222,14 @@ extern "C" int tg_csr_gather_rows(tg_csr_t a, const int64_t *rows, int64_t n, tg
       if (hipGetLastError() != hipSuccess) rc = 1;
     }
   }
-  if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;     // (`rows` is the caller's host array)
+  const hipError_t sync_rc = hipStreamSynchronize(g_tg.stream);     // (`rows` is the caller's host array)
+  if (sync_rc != hipSuccess) rc = 1;
   tg_dfree(d_rows);
   tg_dfree(len);
   if (rc) {
     if (m) tg_csr_destroy(m);
-    tg_set_error("tg_csr_gather_rows failed");
+    tg_set_error("tg_csr_gather_rows failed (%s; %lld rows of %lld, %lld entries)", hipGetErrorString(sync_rc), (long long)n,
+                 (long long)a->nrows, (long long)total);
     return 1;
   }
   m->nnz = total;
