@@ -120,6 +120,13 @@ int tg_csr_block(tg_csr_t a, int64_t r0, int64_t r1, int64_t c0, int64_t c1, tg_
  * (3-D patches of degree >= 5; tIGAr/common.py:1194-1195 has no degree limit). */
 int tg_csr_select_columns(tg_csr_t a, const uint8_t *keep, tg_csr_t *out);
 int tg_csr_from_blocks(int nf, const tg_csr_t *blocks, tg_csr_t *out);
+/* a = d + r on a cell-local FE space (nodes numbered cell after cell, b per cell): d = the entries of the diagonal b x b cell
+ * blocks, r = all others, both with a's shape.  100: some row does not hold all b entries of its own block (a is not "what
+ * dolfin assembles on the mesh of disconnected cells" plus extra couplings).  The matrix of demos/kl-shell-svk/reef-knot.py:
+ * 455-467 -- a T-spline stiffness matrix with contact terms added by hand, the reason extractMatrix takes any A
+ * (tIGAr/common.py:1175) -- splits this way: d goes through the cell-block product (tg_cellplan_ptap), r through the general
+ * kernels, the results are added on the union pattern (tg_csr_add). */
+int tg_csr_split_cells(tg_csr_t a, int b, tg_csr_t *d_out, tg_csr_t *r_out);
 /* out row r = row rows[r] of a (host index array; any selection or order, repetitions allowed), columns untouched */
 int tg_csr_gather_rows(tg_csr_t a, const int64_t *rows, int64_t n, tg_csr_t *out);
 int tg_partition_mode(tg_csr_t mt, const int32_t *fe_owner, int world, int32_t *owner_out);
@@ -235,6 +242,14 @@ int tg_cellplan_create(int64_t ncell, int b, int nfmax, int64_t ncols, const dou
                        const int32_t *nf_host, tg_csr_t incidence, int max_k, double mean_k, tg_cellplan_t *out);
 int tg_cellplan_ptap(tg_cellplan_t plan, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out);
 int tg_cellplan_destroy(tg_cellplan_t plan);
+/* The same product for a matrix that holds its dense cell blocks PLUS couplings outside them (contact / penalty terms added by
+ * hand to a T-spline matrix: demos/kl-shell-svk/reef-knot.py:455-467, the reason extractMatrix takes any A, tIGAr/common.py:
+ * 1175): k_out = M^T D M from the blocks D read in place (no copy of A), r_out = the remainder A - D with A's shape, whose
+ * product goes through the general kernels and is added on the union pattern (tg_csr_add).  100: some row lacks entries of
+ * its own block.  No boundary conditions here (MatZeroRowsColumns follows the sum). */
+int tg_cellplan_ptap_extras(tg_cellplan_t plan, tg_csr_t a, tg_csr_t *k_out, tg_csr_t *r_out);
+/* The rows of `a` that hold entries, ascending, into rows_host[0 .. min(*count, cap)); cap = 0 asks for the count only. */
+int tg_csr_nonempty_rows(tg_csr_t a, int64_t cap, int64_t *rows_host, int64_t *count);
 
 /* K = R^T K_u R for a 0/1 matrix R with ONE entry per row, MatZeroRowsColumns (tIGAr/common.py:1196-1204) fused, on a PLAN:
  * after the tensor line walks ran on the unwrapped space of a patch with periodic directions (tIGAr/BSplines.py:204-212,

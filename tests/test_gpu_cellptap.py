@@ -90,3 +90,65 @@ def test_tspline_extract_matrix_takes_the_cell_block_product(monkeypatch):
     Kg = spline.extractMatrix(A).to_scipy().tocsr()
     Kg.sort_indices()
     assert np.array_equal(Kg.indices, K.indices) and abs(Kg - K).max() <= 1e-12 * abs(Ko).max()
+
+
+@pytest.mark.parametrize("ncell,b,ncp,nextra", [(300, 16, 260, 40), (500, 9, 200, 3), (120, 27, 350, 500)])
+def test_cell_blocks_plus_couplings_outside_the_blocks(ncell, b, ncp, nextra, monkeypatch):
+    """the reef-knot kind of matrix (demos/kl-shell-svk/reef-knot.py:455-467: a T-spline stiffness matrix plus
+    contact terms added by hand -- the reason extractMatrix takes any A, tIGAr/common.py:1175).  The device splits A into its
+    dense cell blocks and the remainder, the blocks go through the cell-block product, the remainder through the general
+    kernels, the results are added on the union pattern: K against the oracle (structural pattern and values), a penalty
+    of 1e9 among the extras, zero dofs; the same K as with the cell path switched off; plan reuse across calls."""
+    import tigar_amd as t
+    from tigar_amd import device as dev, common as tc
+    from tigar_amd.device import DeviceCSR
+    from tigar_amd.cellptap import split_cells, cell_size_with_extras
+    rng = np.random.default_rng(ncell + nextra)
+    M, A = _cells(rng, ncell, b, ncp, 4, min(40, ncp // 3))
+    n = A.shape[0]
+    r, c = rng.integers(0, n, nextra), rng.integers(0, n, nextra)
+    keep = (r // b) != (c // b)
+    v = rng.standard_normal(nextra)
+    v[0] = 1e9                                                       # a penalty term
+    E = sp.csr_matrix((v[keep], (r[keep], c[keep])), shape=(n, n))
+    E.sum_duplicates()
+    Ax = (A + E).tocsr()
+    Ax.sort_indices()
+    Ad = DeviceCSR.from_scipy(Ax)
+    assert cell_size_with_extras(Ad) == b
+    D, R = split_cells(Ad, b)
+    assert abs(D.to_scipy() - A).max() == 0.0 and abs(R.to_scipy() - E).max() == 0.0
+    # through the API: an ExtractedSpline whose M is this cell-local operator
+    spline = t.ExtractedSpline.__new__(t.ExtractedSpline)
+    spline.M, spline.MT = DeviceCSR.from_scipy(M), DeviceCSR.from_scipy(M.T.tocsr())
+    spline.M._T = spline.MT
+    spline.nFields, spline.comm, spline._kron, spline._kron_scalar, spline._kron_fields = 1, tc.selfcomm, None, None, None
+    spline._ptap_plan = spline._ptap_plan_key = spline._slab = None
+    zd = np.unique(rng.integers(0, ncp, size=5)).astype(np.int32)
+    spline.zeroDofs = zd
+    K = spline.extractMatrix(Ad, diag=3.0).to_scipy().tocsr()
+    assert spline.__dict__.get("_cellR_key") is not None               # the split path ran
+    Ko = O.extract_matrix(M, Ax, list(zd), diag=3.0).tocsr()
+    K.sort_indices(), Ko.sort_indices()
+    assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices)
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+    # entries away from the penalty keep their own accuracy (the two parts are summed separately)
+    small = abs(Ko.data) < 1e3
+    assert np.max(np.abs(K.data[small] - Ko.data[small])) <= 1e-10 * max(1.0, np.max(np.abs(Ko.data[small])))
+    K2 = spline.extractMatrix(Ad, diag=3.0).to_scipy().tocsr()          # plans reused
+    assert np.array_equal(K2.data.view(np.int64), K.data.view(np.int64))
+    monkeypatch.setenv("TIGAR_PTAP_CELLS", "0")
+    Kg = spline.extractMatrix(Ad, diag=3.0).to_scipy().tocsr()
+    Kg.sort_indices()
+    assert np.array_equal(Kg.indices, K.indices) and abs(Kg - K).max() <= 1e-12 * abs(Ko).max()
+    # a matrix whose cell blocks are incomplete is declined by the split and still extracted
+    monkeypatch.delenv("TIGAR_PTAP_CELLS")
+    A3 = Ax.tolil()
+    A3[1, 0] = 0.0
+    A3 = A3.tocsr()
+    A3.eliminate_zeros()
+    assert split_cells(DeviceCSR.from_scipy(A3), b) is None
+    K3 = spline.extractMatrix(DeviceCSR.from_scipy(A3), diag=3.0).to_scipy().tocsr()
+    K3o = O.extract_matrix(M, A3, list(zd), diag=3.0).tocsr()
+    K3.sort_indices(), K3o.sort_indices()
+    assert np.array_equal(K3.indices, K3o.indices) and abs(K3 - K3o).max() <= 1e-12 * abs(K3o).max()

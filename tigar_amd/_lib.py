@@ -95,6 +95,9 @@ PROTOTYPES = {
     "tg_tensor_split": (C.c_int, [handle, handle, C.POINTER(handle), C.POINTER(handle)]),
     "tg_csr_block": (C.c_int, [handle, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(handle)]),
     "tg_csr_select_columns": (C.c_int, [handle, C.POINTER(C.c_uint8), C.POINTER(handle)]),
+    "tg_cellplan_ptap_extras": (C.c_int, [handle, handle, C.POINTER(handle), C.POINTER(handle)]),
+    "tg_csr_nonempty_rows": (C.c_int, [handle, C.c_int64, c_i64p, C.POINTER(C.c_int64)]),
+    "tg_csr_split_cells": (C.c_int, [handle, C.c_int, C.POINTER(handle), C.POINTER(handle)]),
     "tg_csr_from_blocks": (C.c_int, [C.c_int, C.POINTER(handle), C.POINTER(handle)]),
     "tg_csr_gather_rows": (C.c_int, [handle, c_i64p, C.c_int64, C.POINTER(handle)]),
     "tg_partition_mode": (C.c_int, [handle, c_i32p, C.c_int, c_i32p]),

@@ -31,6 +31,51 @@ def block_size_of(A):
     return int(b) if 2 <= b <= 64 and n % b == 0 else 0
 
 
+def cell_size_with_extras(A):
+    """b if ``A`` can be a block-diagonal matrix with dense b x b cell blocks PLUS a few couplings outside the blocks (fewer
+    than one per row on average: contact or penalty terms added by hand, demos/kl-shell-svk/reef-knot.py:455-467), else 0"""
+    n = A.shape[0]
+    if n == 0 or A.shape[1] != n:
+        return 0
+    b = A.nnz // n
+    return int(b) if 2 <= b <= 64 and n % b == 0 and A.nnz > n * b else 0
+
+
+def split_cells(A, b):
+    """(D, R) with A = D + R: the dense diagonal cell blocks and the remainder (``tg_csr_split_cells``), or None when some
+    row lacks entries of its own block"""
+    d, r = handle(), handle()
+    rc = _lib.lib().tg_csr_split_cells(A._h, int(b), C.byref(d), C.byref(r))
+    if rc == 100:
+        return None
+    check(rc, "tg_csr_split_cells")
+    return DeviceCSR(d), DeviceCSR(r)
+
+
+def nonempty_rows(R):
+    """ascending indices of the rows of the DeviceCSR ``R`` that hold entries (``tg_csr_nonempty_rows``)"""
+    from ._lib import c_i64p
+    n = C.c_int64()
+    check(_lib.lib().tg_csr_nonempty_rows(R._h, 0, None, C.byref(n)), "tg_csr_nonempty_rows")
+    rows = np.zeros(max(1, n.value), dtype=np.int64)
+    if n.value:
+        check(_lib.lib().tg_csr_nonempty_rows(R._h, n.value, rows.ctypes.data_as(c_i64p), C.byref(n)), "tg_csr_nonempty_rows")
+    return rows[:n.value]
+
+
+def remainder_product(R, M):
+    """M^T R M for a matrix R with few non-empty rows (the couplings outside the cell blocks): the general kernels on the
+    operands restricted to those rows -- M^T's columns and R's rows compacted to the rows that hold anything -- instead of
+    a pass over every row of M^T"""
+    from . import device as _dev
+    rows = nonempty_rows(R)
+    if rows.size == 0:
+        return None
+    Rs = R.gather_rows(rows)                     # (few rows, global columns)
+    MTs = M.gather_rows(rows).transpose()        # dofs x those rows
+    return _dev.ptap_numeric(_dev.ptap_symbolic(Rs, M, MTs), Rs, M, MTs)
+
+
 class CellBlockPtAP(object):
     def __init__(self, M, b):
         """``M``: the extraction operator (DeviceCSR, FE rows x dofs), ``b``: nodes per cell.  Raises ValueError when the
@@ -84,6 +129,16 @@ class CellBlockPtAP(object):
             return None
         check(rc, "tg_cellplan_ptap")
         return DeviceCSR(h)
+
+    def ptap_extras(self, A):
+        """(M^T D M, R) for A = D + R, D the dense cell blocks read in place, R the couplings outside them (A's shape); None
+        when some row lacks entries of its own block (``tg_cellplan_ptap_extras``)"""
+        k, r = handle(), handle()
+        rc = _lib.lib().tg_cellplan_ptap_extras(self._h, A._h, C.byref(k), C.byref(r))
+        if rc == 100:
+            return None
+        check(rc, "tg_cellplan_ptap_extras")
+        return DeviceCSR(k), DeviceCSR(r)
 
     def __del__(self):
         try:

@@ -1594,8 +1594,12 @@ class ExtractedSpline(object):
         # diagonal with one dense block per cell and the product is a sum of small dense triple products
         # (tigar_amd/cellptap.py); the plan depends on M only and is kept, A is verified on the device at every call
         if os.environ.get("TIGAR_PTAP_CELLS", "1") != "0":
-            from .cellptap import CellBlockPtAP, block_size_of
+            from .cellptap import CellBlockPtAP, block_size_of, cell_size_with_extras, split_cells
             b = block_size_of(A)
+            extras = False
+            if not b:
+                b = cell_size_with_extras(A)
+                extras = bool(b)
             if b and A.shape[0] == self.M.shape[0]:
                 plans = self.__dict__.setdefault("_cell_plans", {})
                 if b not in plans:
@@ -1603,10 +1607,29 @@ class ExtractedSpline(object):
                         plans[b] = CellBlockPtAP(self.M, b)
                     except ValueError:
                         plans[b] = None
-                if plans[b] is not None:
+                if plans[b] is not None and not extras:
                     K = plans[b].ptap(A, zd, float(diag))
                     if K is not None:
                         return K
+                elif plans[b] is not None:
+                    # couplings outside the cell blocks (contact / penalty terms added by hand: the reason extractMatrix takes
+                    # any A, tIGAr/common.py:1175; demos/kl-shell-svk/reef-knot.py:455-467): A = D + R on the device, the
+                    # dense blocks D through the cell-block product, the few entries of R through the general kernels, the
+                    # two added on the union of their patterns (= the structural product of A), then MatZeroRowsColumns
+                    parts = plans[b].ptap_extras(A)
+                    if parts is not None:
+                        KD, R = parts
+                        if KD is not None:
+                            from .cellptap import remainder_product
+                            KR = remainder_product(R, self.M)
+                            self._cellR_key = ("cells-R", R.shape, R.nnz)
+                            if KR is None:
+                                KR = DeviceCSR.from_scipy(_scipy_zero(KD.shape))
+                            K = KD.add(KR)
+                            del KD, KR
+                            if zd is not None and len(zd):
+                                K.zero_rows_cols(numpy.asarray(zd, dtype=numpy.int32), float(diag))
+                            return K
         key = (A.shape, A.nnz)
         fresh = self._ptap_plan is None or self._ptap_plan_key != key
         if fresh:
@@ -2020,6 +2043,11 @@ class ExtractedSpline(object):
             raise RuntimeError("Nonlinear solver failed to converge.")
         return history
 
+
+
+def _scipy_zero(shape):
+    import scipy.sparse as _sp
+    return _sp.csr_matrix((int(shape[0]), int(shape[1])))
 
 
 def _scipy_identity(n):

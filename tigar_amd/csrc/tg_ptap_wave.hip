@@ -976,8 +976,8 @@ __global__ void __launch_bounds__(256)
 // one wave per cell: E_c = M_c^T (A_c M_c).  Lanes: groups of G = 2^LGF lanes <-> the function index f, 64 / G rows at once.
 template <int LGF>
 __global__ void __launch_bounds__(256)
-    k_cell_element(const double *__restrict__ aval, const double *__restrict__ md, const int32_t *__restrict__ nfc, int64_t ncell,
-                   int b, int nfmax, double *__restrict__ eval) {
+    k_cell_element(const double *__restrict__ aval, const int64_t *__restrict__ rstart, const double *__restrict__ md,
+                   const int32_t *__restrict__ nfc, int64_t ncell, int b, int nfmax, double *__restrict__ eval) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 1 << LGF, NG = 64 >> LGF;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & (G - 1), grp = lane >> LGF;
@@ -988,7 +988,11 @@ __global__ void __launch_bounds__(256)
   if (c >= ncell) return;
   const int nf = nfc[c];
   const double *ac = aval + c * (int64_t)b * b, *mc = md + c * (int64_t)b * nfmax;
-  for (int s = lane; s < b * b; s += 64) As[s] = ac[s];
+  if (rstart) {        // (the cell's rows hold other entries besides their block: where the block's b values start, row by row)
+    for (int s = lane; s < b * b; s += 64) As[s] = aval[rstart[c * b + s / b] + s % b];
+  } else {
+    for (int s = lane; s < b * b; s += 64) As[s] = ac[s];
+  }
   for (int s = lane; s < b * nfmax; s += 64) Ms[s] = mc[s];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   // T = A_c M_c : [b][nf]
@@ -1112,22 +1116,25 @@ static void gw_launch_shared(int lg, unsigned grid, size_t lds, const gw_args &P
 #undef GW_GOS
 }
 
-extern "C" int tg_cellplan_ptap(tg_cellplan_t pl, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out) {
-  TG_REQUIRE_INIT();
-  TG_REQUIRE(pl && a && k_out, "null argument to tg_cellplan_ptap");
-  TG_REQUIRE_CANONICAL(a);
+// rstart (device, one entry per FE row, or null): where the b values of the row's own cell block start in a->val -- for a
+// matrix that holds other entries besides its dense cell blocks (tg_cellplan_ptap_extras); null: a is verified to consist of
+// the blocks alone
+static int tg_cellplan_ptap_impl(tg_cellplan_t pl, tg_csr_t a, const int64_t *rstart, const int32_t *zero_dofs, int64_t nzero,
+                                 double diag, tg_csr_t *k_out) {
   const int64_t nfe = pl->ncell * pl->b;
-  if (a->nrows != nfe || a->ncols != nfe || a->nnz != nfe * pl->b) return 100;
+  if (a->nrows != nfe || a->ncols != nfe || (!rstart && a->nnz != nfe * pl->b)) return 100;
   int *status = (int *)g_tg.scratch;
   unsigned long long *sum = (unsigned long long *)(status + 2);
-  int hbad = 0;
-  hipMemsetAsync(status, 0, 4 * sizeof(int), g_tg.stream);
-  hipLaunchKernelGGL(k_cell_check, dim3((unsigned)std::min<int64_t>(tg_cdiv(nfe, 256), (int64_t)g_tg.num_cu * 16)), dim3(256), 0,
-                     g_tg.stream, a->rowptr, a->col, nfe, pl->b, status);
-  TG_LAUNCH_CHECK();
-  TG_CHECK_HIP(hipMemcpyAsync(&hbad, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream));
-  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
-  if (hbad) return 100;                     // not block diagonal with dense b x b blocks: the general kernels
+  if (!rstart) {
+    int hbad = 0;
+    hipMemsetAsync(status, 0, 4 * sizeof(int), g_tg.stream);
+    hipLaunchKernelGGL(k_cell_check, dim3((unsigned)std::min<int64_t>(tg_cdiv(nfe, 256), (int64_t)g_tg.num_cu * 16)), dim3(256), 0,
+                       g_tg.stream, a->rowptr, a->col, nfe, pl->b, status);
+    TG_LAUNCH_CHECK();
+    TG_CHECK_HIP(hipMemcpyAsync(&hbad, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream));
+    TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+    if (hbad) return 100;                     // not block diagonal with dense b x b blocks: the general kernels
+  }
   uint8_t *mask = nullptr;
   if (nzero > 0) TG_TRY(tg_build_dof_mask(zero_dofs, nzero, pl->ncols, &mask));
   double *eval = nullptr;
@@ -1159,8 +1166,8 @@ extern "C" int tg_cellplan_ptap(tg_cellplan_t pl, tg_csr_t a, const int32_t *zer
 #define CELL_GO(LGV)                                                                                                    \
   do {                                                                                                                  \
     hipFuncSetAttribute((const void *)k_cell_element<LGV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
-    hipLaunchKernelGGL((k_cell_element<LGV>), dim3(grid), dim3(256), lds, g_tg.stream, a->val, pl->md, pl->nf, pl->ncell, \
-                       pl->b, pl->nfmax, eval);                                                                         \
+    hipLaunchKernelGGL((k_cell_element<LGV>), dim3(grid), dim3(256), lds, g_tg.stream, a->val, rstart, pl->md, pl->nf,   \
+                       pl->ncell, pl->b, pl->nfmax, eval);                                                              \
   } while (0)
     if (lds > 160 * 1024) {
       cleanup();
@@ -1342,6 +1349,159 @@ extern "C" int tg_cellplan_ptap(tg_cellplan_t pl, tg_csr_t a, const int32_t *zer
     return rc;
   }
   *k_out = k;
+  return 0;
+}
+
+extern "C" int tg_cellplan_ptap(tg_cellplan_t pl, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(pl && a && k_out, "null argument to tg_cellplan_ptap");
+  TG_REQUIRE_CANONICAL(a);
+  return tg_cellplan_ptap_impl(pl, a, nullptr, zero_dofs, nzero, diag, k_out);
+}
+
+// ---- cell blocks PLUS couplings outside them (demos/kl-shell-svk/reef-knot.py:455-467: contact terms added by hand) --------
+// per row: how many entries lie outside its cell block, and where the block's b entries start (rows are sorted: they are
+// consecutive); bad: a row without all b entries of its block
+__global__ void __launch_bounds__(256)
+    k_cellx_count(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int b, int64_t n, int64_t *__restrict__ len_r,
+                  int64_t *__restrict__ rstart, int *__restrict__ bad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n; r += nwaves) {
+    const int64_t a = rowptr[r], e = rowptr[r + 1];
+    const int64_t c0 = (r / b) * b;
+    int in = 0, before = 0;
+    for (int64_t q = a + lane; q < e; q += 64) {
+      const int32_t c = col[q];
+      in += (c >= c0 && c < c0 + b) ? 1 : 0;
+      before += c < c0 ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      in += __shfl_xor(in, o, 64);
+      before += __shfl_xor(before, o, 64);
+    }
+    if (lane == 0) {
+      len_r[r] = (e - a) - in;
+      rstart[r] = a + before;
+      if (in != b) atomicOr(bad, 1);
+    }
+  }
+}
+__global__ void __launch_bounds__(256)
+    k_cellx_rest(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val, int b,
+                 const int64_t *__restrict__ orowptr, int64_t n, int32_t *__restrict__ ocol, double *__restrict__ oval) {
+  // (thread per row: the rows with anything to copy are few and hold few entries)
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+    int64_t o = orowptr[r];
+    if (orowptr[r + 1] == o) continue;
+    const int64_t c0 = (r / b) * b;
+    for (int64_t q = rowptr[r]; q < rowptr[r + 1]; q++)
+      if (col[q] < c0 || col[q] >= c0 + b) {
+        ocol[o] = col[q];
+        oval[o] = val[q];
+        o++;
+      }
+  }
+}
+
+extern "C" int tg_cellplan_ptap_extras(tg_cellplan_t pl, tg_csr_t a, tg_csr_t *k_out, tg_csr_t *r_out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(pl && a && k_out && r_out, "null argument to tg_cellplan_ptap_extras");
+  TG_REQUIRE_CANONICAL(a);
+  const int64_t n = pl->ncell * pl->b;
+  if (a->nrows != n || a->ncols != n) return 100;
+  int64_t *len_r = nullptr, *rstart = nullptr;
+  int *bad = nullptr;
+  tg_csr_s *mr = nullptr;
+  int rc = tg_dmalloc(&len_r, n + 1) || tg_dmalloc(&rstart, n) || tg_dmalloc(&bad, 4);
+  int h_bad = 0;
+  int64_t tot_r = 0;
+  auto cleanup = [&]() {
+    tg_dfree(len_r);
+    tg_dfree(rstart);
+    tg_dfree(bad);
+  };
+  if (!rc) {
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16));
+    hipMemsetAsync(bad, 0, sizeof(int), g_tg.stream);
+    hipLaunchKernelGGL(k_cellx_count, dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, pl->b, n, len_r, rstart, bad);
+    if (hipGetLastError() != hipSuccess) rc = 1;
+    if (!rc && hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
+  }
+  if (!rc) rc = tg_exclusive_scan_i64(len_r, n, &tot_r);          // (synchronises: h_bad is valid afterwards)
+  if (!rc && h_bad) {
+    cleanup();
+    return 100;                                                    // a row lacks entries of its own cell block
+  }
+  if (!rc) rc = tg_csr_alloc(n, n, tot_r, &mr);
+  if (!rc) {
+    if (hipMemcpyAsync(mr->rowptr, len_r, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess) rc = 1;
+    if (!rc && tot_r > 0) {
+      hipLaunchKernelGGL(k_cellx_rest, dim3((unsigned)std::min<int64_t>(tg_cdiv(n, 256), (int64_t)g_tg.num_cu * 16)), dim3(256), 0,
+                         g_tg.stream, a->rowptr, a->col, a->val, pl->b, mr->rowptr, n, mr->col, mr->val);
+      if (hipGetLastError() != hipSuccess) rc = 1;
+    }
+  }
+  tg_csr_t k = nullptr;
+  if (!rc) rc = tg_cellplan_ptap_impl(pl, a, rstart, nullptr, 0, 1.0, &k);
+  if (hipStreamSynchronize(g_tg.stream) != hipSuccess && !rc) rc = 1;
+  cleanup();
+  if (rc) {
+    if (mr) tg_csr_destroy(mr);
+    if (rc != 100) tg_set_error("tg_cellplan_ptap_extras failed");
+    return rc;
+  }
+  mr->nnz = tot_r;
+  *k_out = k;
+  *r_out = mr;
+  return 0;
+}
+
+// the rows of a matrix that hold entries, ascending: rows_host[0 .. min(*count, cap)) (two-call protocol: cap = 0 asks for
+// the count); used to restrict a product with a nearly empty operand to the rows that matter
+__global__ void __launch_bounds__(256) k_row_flags(const int64_t *__restrict__ rowptr, int64_t n, int64_t *__restrict__ flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) flag[r] = rowptr[r + 1] > rowptr[r] ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_row_compact(const int64_t *__restrict__ pos, int64_t n, int64_t *__restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride)
+    if (pos[r + 1] > pos[r]) out[pos[r]] = r;
+}
+extern "C" int tg_csr_nonempty_rows(tg_csr_t a, int64_t cap, int64_t *rows_host, int64_t *count) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(a && count && (rows_host || cap == 0), "bad arguments to tg_csr_nonempty_rows");
+  TG_REQUIRE_CANONICAL(a);
+  const int64_t n = a->nrows;
+  int64_t *flag = nullptr, *out = nullptr;
+  int64_t total = 0;
+  int rc = tg_dmalloc(&flag, n + 1);
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(n, 256), (int64_t)g_tg.num_cu * 16));
+  if (!rc && n > 0) {
+    hipLaunchKernelGGL(k_row_flags, dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, n, flag);
+    if (hipGetLastError() != hipSuccess) rc = 1;
+  }
+  if (!rc) rc = tg_exclusive_scan_i64(flag, n, &total);
+  *count = total;
+  if (!rc && cap > 0 && total > 0) {
+    const int64_t m = std::min(cap, total);
+    rc = tg_dmalloc(&out, total);
+    if (!rc) {
+      hipLaunchKernelGGL(k_row_compact, dim3(grid), dim3(256), 0, g_tg.stream, flag, n, out);
+      if (hipGetLastError() != hipSuccess ||
+          hipMemcpyAsync(rows_host, out, (size_t)m * sizeof(int64_t), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess)
+        rc = 1;
+    }
+  }
+  if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
+  tg_dfree(flag);
+  tg_dfree(out);
+  if (rc) {
+    tg_set_error("tg_csr_nonempty_rows failed");
+    return 1;
+  }
   return 0;
 }
 

@@ -699,6 +699,113 @@ extern "C" int tg_csr_select_columns(tg_csr_t a, const uint8_t *keep_host, tg_cs
   return 0;
 }
 
+// ---- A = D + R for a cell-local FE space with hand-added couplings (demos/kl-shell-svk/reef-knot.py:455-467: T-spline
+// K plus contact terms): D = the entries inside the diagonal b x b cell blocks -- accepted only when every row holds all b of
+// them (dense blocks, what dolfin assembles on a mesh of disconnected cells) --, R = everything else, both with A's shape.
+// side 0: count / copy the in-block entries, side 1: the others.
+__global__ void __launch_bounds__(256)
+    k_cells_count(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int b, int64_t n, int64_t *__restrict__ len_d,
+                  int64_t *__restrict__ len_r, int *__restrict__ bad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n; r += nwaves) {
+    const int64_t a = rowptr[r], e = rowptr[r + 1];
+    const int64_t c0 = (r / b) * b;
+    int cnt = 0;
+    for (int64_t q = a + lane; q < e; q += 64) cnt += (col[q] >= c0 && col[q] < c0 + b) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) {
+      len_d[r] = cnt;
+      len_r[r] = (e - a) - cnt;
+      if (cnt != b) atomicOr(bad, 1);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_cells_fill(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val, int b, int side,
+                 const int64_t *__restrict__ orowptr, int64_t n, int32_t *__restrict__ ocol, double *__restrict__ oval) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n; r += nwaves) {
+    const int64_t a = rowptr[r], e = rowptr[r + 1];
+    const int64_t c0 = (r / b) * b;
+    int64_t o = orowptr[r];
+    for (int64_t q0 = a; q0 < e; q0 += 64) {          // (uniform trip count: the ballot sees every lane)
+      const int64_t q = q0 + lane;
+      const bool in = q < e && col[q] >= c0 && col[q] < c0 + b;
+      const bool k = q < e && (side == 0 ? in : !in);
+      const unsigned long long m = __ballot(k);
+      if (k) {
+        const int pos = __popcll(m & ((1ull << lane) - 1ull));
+        ocol[o + pos] = col[q];
+        oval[o + pos] = val[q];
+      }
+      o += __popcll(m);
+    }
+  }
+}
+
+extern "C" int tg_csr_split_cells(tg_csr_t a, int b, tg_csr_t *d_out, tg_csr_t *r_out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(a && d_out && r_out && b >= 1, "bad arguments to tg_csr_split_cells");
+  TG_REQUIRE_CANONICAL(a);
+  const int64_t n = a->nrows;
+  if (n == 0 || a->ncols != n || n % b) return 100;
+  int64_t *len_d = nullptr, *len_r = nullptr;
+  int *bad = nullptr;
+  tg_csr_s *md = nullptr, *mr = nullptr;
+  int rc = tg_dmalloc(&len_d, n + 1) || tg_dmalloc(&len_r, n + 1) || tg_dmalloc(&bad, 4);
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16));
+  int h_bad = 0;
+  if (!rc) {
+    hipMemsetAsync(bad, 0, sizeof(int), g_tg.stream);
+    hipLaunchKernelGGL(k_cells_count, dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, b, n, len_d, len_r, bad);
+    if (hipGetLastError() != hipSuccess) rc = 1;
+    if (!rc && hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess) rc = 1;
+  }
+  int64_t tot_d = 0, tot_r = 0;
+  if (!rc) rc = tg_exclusive_scan_i64(len_d, n, &tot_d);      // (synchronises: h_bad is valid afterwards)
+  if (!rc && h_bad) {
+    tg_dfree(len_d);
+    tg_dfree(len_r);
+    tg_dfree(bad);
+    return 100;                                                // some row lacks entries of its own cell block
+  }
+  if (!rc) rc = tg_exclusive_scan_i64(len_r, n, &tot_r);
+  if (!rc) rc = tg_csr_alloc(n, n, tot_d, &md);
+  if (!rc) rc = tg_csr_alloc(n, n, tot_r, &mr);
+  if (!rc) {
+    if (hipMemcpyAsync(md->rowptr, len_d, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess ||
+        hipMemcpyAsync(mr->rowptr, len_r, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess)
+      rc = 1;
+    if (!rc && tot_d > 0)
+      hipLaunchKernelGGL(k_cells_fill, dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val, b, 0, md->rowptr, n, md->col,
+                         md->val);
+    if (!rc && tot_r > 0)
+      hipLaunchKernelGGL(k_cells_fill, dim3(grid), dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val, b, 1, mr->rowptr, n, mr->col,
+                         mr->val);
+    if (hipGetLastError() != hipSuccess) rc = 1;
+  }
+  if (hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
+  tg_dfree(len_d);
+  tg_dfree(len_r);
+  tg_dfree(bad);
+  if (rc) {
+    if (md) tg_csr_destroy(md);
+    if (mr) tg_csr_destroy(mr);
+    tg_set_error("tg_csr_split_cells failed");
+    return 1;
+  }
+  md->nnz = tot_d;
+  mr->nnz = tot_r;
+  *d_out = md;
+  *r_out = mr;
+  return 0;
+}
+
 struct tg_merge_args {
   const int64_t *rowptr[16];     // [i * nf + j] (one block row at a time: nf entries used)
   const int32_t *col[16];

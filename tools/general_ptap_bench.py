@@ -7,7 +7,11 @@ by generateM's filter), and the functions carry a RANDOM global numbering -- no 
 nothing the Kronecker / box / line / tensor kernels could use.  A is what dolfin assembles on such a mesh: one dense 16 x 16
 block per cell (here: SPD blocks with a deterministic perturbation per cell).
 
-    python tools/general_ptap_bench.py [cells_per_side=256] [reps=5]
+    python tools/general_ptap_bench.py [cells_per_side=256] [reps=5] [extra=0.0]
+
+extra > 0: that fraction of the FE rows additionally gets one coupling to a node of ANOTHER cell (contact / penalty terms
+added by hand, demos/kl-shell-svk/reef-knot.py:455-467); the product then runs as extractMatrix runs it -- split on the
+device into cell blocks + remainder, cell-block product + general kernels on the remainder, sum on the union pattern.
 
 Prints one JSON line: sizes, PtAP time (first call = symbolic + numeric, later calls = numeric on the plan), SURVEY 8(d)'s
 algorithmic bytes / time against the 8 TB/s peak, and the check K x = M^T (A (M x)) on a random x.
@@ -60,10 +64,80 @@ def build(n, seed=0):
     return M, A
 
 
+def with_extras(n, reps, extra, M, A):
+    from tigar_amd.cellptap import CellBlockPtAP, split_cells, cell_size_with_extras
+    rng = np.random.default_rng(7)
+    nfe = A.shape[0]
+    ne = max(1, int(round(extra * nfe)))
+    r = rng.choice(nfe, size=ne, replace=False)
+    c = (r + 16 * rng.integers(1, nfe // 16, size=ne)) % nfe              # a node of another cell
+    E = sp.csr_matrix((rng.standard_normal(ne), (r, c)), shape=A.shape)
+    Ax = (A + E).tocsr()
+    Ax.sort_indices()
+    Md, Ad = dev.DeviceCSR.from_scipy(M), dev.DeviceCSR.from_scipy(Ax)
+    MT = Md.transpose()
+    dev.sync()
+    # the general kernels on the whole matrix (what round 4 did with such a matrix)
+    plan = dev.ptap_symbolic(Ad, Md, MT)
+    Kg = dev.ptap_numeric(plan, Ad, Md, MT)
+    dev.sync()
+    tg = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        Kg = dev.ptap_numeric(plan, Ad, Md, MT)
+        dev.sync()
+        tg.append(time.perf_counter() - t0)
+    # the split path, as ExtractedSpline.extractMatrix runs it: cell blocks read in place + remainder restricted to its rows
+    from tigar_amd.cellptap import remainder_product
+    assert cell_size_with_extras(Ad) == 16
+    cplan = CellBlockPtAP(Md, 16)
+    stages = {"cells_and_split": [], "remainder": [], "add": []}
+
+    def once():
+        t0 = time.perf_counter()
+        KD, R = cplan.ptap_extras(Ad)
+        dev.sync()
+        t1 = time.perf_counter()
+        KR = remainder_product(R, Md)
+        dev.sync()
+        t2 = time.perf_counter()
+        K = KD.add(KR)
+        dev.sync()
+        t3 = time.perf_counter()
+        return K, (t1 - t0, t2 - t1, t3 - t2)
+    K, _ = once()
+    ts = []
+    for _ in range(reps):
+        K, tt = once()
+        ts.append(sum(tt))
+        for k_, v in zip(stages, tt):
+            stages[k_].append(v)
+    Ks, Kgs = K.to_scipy().tocsr(), Kg.to_scipy().tocsr()
+    Ks.sort_indices(), Kgs.sort_indices()
+    x = np.random.default_rng(1).standard_normal(M.shape[1])
+    yref = M.T @ (Ax @ (M @ x))
+    err = float(np.max(np.abs(Ks @ x - yref)) / np.max(np.abs(yref)))
+    algo = 12.0 * Ax.nnz + 24.0 * M.nnz + 12.0 * K.nnz + 8.0 * (2 * M.shape[0] + 2 * M.shape[1])
+    best = min(ts)
+    print(json.dumps({
+        "workload": "non-Kronecker M: %d x %d disconnected bicubic cells, scrambled dof numbering, + %d couplings between cells "
+                    "(%.2f %% of the FE rows)" % (n, n, ne, 100.0 * ne / nfe),
+        "fe_rows": int(M.shape[0]), "dofs": int(M.shape[1]), "nnz_M": int(M.nnz), "nnz_A": int(Ax.nnz), "nnz_K": int(K.nnz),
+        "algorithmic_bytes": algo, "bytes_definition": "SURVEY.md 8d: 12 nnz(A) + 24 nnz(M) + 12 nnz(K) + row pointers",
+        "general_kernels_whole_matrix_ms": 1e3 * min(tg), "general_kernels_frac_of_hbm_peak": algo / min(tg) / 8e12,
+        "split_path_ms": 1e3 * best, "split_path_achieved_GBps": algo / best / 1e9, "split_path_frac_of_hbm_peak": algo / best / 8e12,
+        "split_path_stages_ms": {k_: 1e3 * min(v) for k_, v in stages.items()},
+        "pattern_equals_general_kernels": bool(np.array_equal(Ks.indices, Kgs.indices)),
+        "max_rel_diff_vs_general_kernels": float(abs(Ks - Kgs).max() / abs(Kgs).max()), "rel_error_Kx_vs_MtAMx": err}))
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    extra = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
     M, A = build(n)
+    if extra > 0.0:
+        return with_extras(n, reps, extra, M, A)
     Md, Ad = dev.DeviceCSR.from_scipy(M), dev.DeviceCSR.from_scipy(A)
     MT = Md.transpose()
     dev.sync()
