@@ -1621,7 +1621,7 @@ class ExtractedSpline(object):
                         KD, R = parts
                         if KD is not None:
                             from .cellptap import remainder_product
-                            KR = remainder_product(R, self.M)
+                            KR = remainder_product(R, self.M, self.__dict__.setdefault("_cellR_cache", {}))
                             self._cellR_key = ("cells-R", R.shape, R.nnz)
                             if KR is None:
                                 KR = DeviceCSR.from_scipy(_scipy_zero(KD.shape))

@@ -92,20 +92,23 @@ def with_extras(n, reps, extra, M, A):
     assert cell_size_with_extras(Ad) == 16
     cplan = CellBlockPtAP(Md, 16)
     stages = {"cells_and_split": [], "remainder": [], "add": []}
+    rcache = {}
 
     def once():
         t0 = time.perf_counter()
         KD, R = cplan.ptap_extras(Ad)
         dev.sync()
         t1 = time.perf_counter()
-        KR = remainder_product(R, Md)
+        KR = remainder_product(R, Md, rcache)
         dev.sync()
         t2 = time.perf_counter()
         K = KD.add(KR)
         dev.sync()
         t3 = time.perf_counter()
         return K, (t1 - t0, t2 - t1, t3 - t2)
+    t0 = time.perf_counter()
     K, _ = once()
+    first_ms = time.perf_counter() - t0
     ts = []
     for _ in range(reps):
         K, tt = once()
@@ -127,6 +130,7 @@ def with_extras(n, reps, extra, M, A):
         "general_kernels_whole_matrix_ms": 1e3 * min(tg), "general_kernels_frac_of_hbm_peak": algo / min(tg) / 8e12,
         "split_path_ms": 1e3 * best, "split_path_achieved_GBps": algo / best / 1e9, "split_path_frac_of_hbm_peak": algo / best / 8e12,
         "split_path_stages_ms": {k_: 1e3 * min(v) for k_, v in stages.items()},
+        "split_path_first_call_ms": 1e3 * first_ms,
         "pattern_equals_general_kernels": bool(np.array_equal(Ks.indices, Kgs.indices)),
         "max_rel_diff_vs_general_kernels": float(abs(Ks - Kgs).max() / abs(Kgs).max()), "rel_error_Kx_vs_MtAMx": err}))
 
