@@ -1099,6 +1099,7 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
       dirs[k].val = vl[k].data();
     }
     tg_csr_t pat = nullptr;
+    if (fast) tg_kron_pattern_only();     // (the sum-factorised kernels store every entry before anybody adds to it)
     TG_TRY(tg_kron_sum_csr(d, 1, dirs, row0, row1, &pat));
     m = pat;
     // (the pattern kernel wrote 0 * 0 * 0 into every value: the plain kernel adds into that; the sum-factorised kernel

@@ -181,6 +181,7 @@ void tg_sell_drop(tg_csr_s *a);
 void tg_sell_cache_clear(void);
 void tg_kron_cache_clear(void);
 void tg_asm_cache_clear(void);
+void tg_kron_pattern_only(void);
 int tg_h2d_staged(void *dst, const void *src, size_t bytes);   // stream-ordered upload of a small host table, no wait
 int tg_sell_spmv(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y);
 int64_t tg_sell_slice_rows(void);

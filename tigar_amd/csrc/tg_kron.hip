@@ -4,6 +4,11 @@
 // assemble() would hand to extractMatrix (tIGAr/common.py:1206-1220).  Rows are z-slab
 // ranges [row0,row1) in lexicographic node order (direction 0 fastest); columns global.
 #include "tg_common.h"
+// The next tg_kron_sum_csr call writes row pointer and columns only and leaves the values UNWRITTEN (one-shot switch, for
+// callers inside the library that store every value themselves -- the sum-factorised mapped assembly: a third of the
+// pattern kernel's bytes and time for nothing otherwise, 0.11 of 0.17 s per step at 256^3 p = 3)
+static bool g_k3_skip_val = false;
+void tg_kron_pattern_only(void) { g_k3_skip_val = true; }
 #include <algorithm>
 #include <chrono>
 static double tg_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -314,6 +319,7 @@ int tg_kron_build(int d, int nterms, const tg_kron_dir_t *dirs, int64_t row0, in
 int tg_kron_build_rect(int d, int nterms, const tg_kron_dir_t *dirs, const int64_t *cdim, int64_t row0, int64_t row1,
                        int filter, double eps, int64_t col_offset, int64_t ncols_total, tg_csr_t *out) {
   TG_REQUIRE_INIT();
+  g_k3_skip_val = false;                 // (this builder always writes values)
   const double _t0 = tg_now();
   TG_REQUIRE(d >= 1 && d <= 3 && nterms >= 1 && nterms <= TG_KRON_MAX_TERMS && dirs && out,
              "bad arguments to tg_kron_sum_csr");
@@ -618,7 +624,9 @@ struct tg_kron3_args {
   int64_t npencils;
   int nterms;                    // Kronecker SUM: values are term-major, cv[k][t * nnz1d[k] + q]
   int64_t nnz1d[3];
+  int skip_val;                  // pattern only: the caller overwrites every value (tg_kron_pattern_only)
 };
+
 
 __device__ __forceinline__ int64_t tg_kron3_rowstart(const tg_kron3_args &A, int64_t a, int64_t b, int64_t c) {
   // entries before row (a, b, c): separable prefix sums of n0 * n1 * n2
@@ -892,7 +900,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int z = 0; z < TG_K3_Z; z++) {
         crow[t0 + 64 * z] = cc[z];
-        vrow[t0 + 64 * z] = sum[z];
+        if (!A.skip_val) vrow[t0 + 64 * z] = sum[z];
       }
     }
 #pragma unroll
@@ -903,7 +911,7 @@ __global__ void __launch_bounds__(256)
         int32_t cidx;
         entry((unsigned)t, v, cidx);
         crow[t] = cidx;
-        vrow[t] = v;
+        if (!A.skip_val) vrow[t] = v;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -972,6 +980,8 @@ static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const in
   TG_REQUIRE_INIT();
   TG_REQUIRE(d >= 1 && d <= 3 && dirs && cdim && out && nterms >= 0 && nterms <= TG_KRON3_MAXT, "bad arguments to tg_kron3_csr");
   const int nval = nterms > 0 ? nterms : 1;
+  const bool skip_val = g_k3_skip_val;       // (one-shot: whatever this call does, the next one writes values again)
+  g_k3_skip_val = false;
   tg_kron3_args A;
   memset(&A, 0, sizeof(A));
   A.d = d;
@@ -1092,6 +1102,7 @@ static int tg_kron3_build(int d, int nterms, const tg_kron_dir_t *dirs, const in
         const dim3 grid((unsigned)(p_last - p_first + 1));
         const size_t lds = (size_t)(nterms + 1) * A.slot * sizeof(double);
 #define TG_K3_LAUNCH(NT, Z) hipLaunchKernelGGL((k_kron3_fill_sum_rows<NT, Z>), grid, dim3(256), lds, g_tg.stream, A, m->col, m->val)
+        A.skip_val = skip_val ? 1 : 0;
         if (nterms == 1) TG_K3_LAUNCH(1, 2);
         else if (nterms == 2) TG_K3_LAUNCH(2, 2);
         else TG_K3_LAUNCH(3, 2);      // (1, 2 or 4 entries per pass: equal within the spread, A/B inside one process)
