@@ -612,6 +612,12 @@ def main():
         a2 = copy.copy(args)
         a2.geometry, a2.steps, a2.warmup, a2.companion, a2.check = "volume", 1, 1, 0, 0
         try:
+            # the identity run's blocks (sliced K, walk buffers) sit idle in the caching allocator with sizes the mapped
+            # run does not ask for; hand them back first, or every mapped step trims under pressure inside its stages
+            import gc
+            from tigar_amd import _lib
+            gc.collect()
+            _lib.lib().tg_pool_trim()
             mapped_res = run(a2, wl, d, p, nel)
         except Exception as e:                           # noqa: BLE001  (a companion must not break the line)
             log("[bench] mapped-geometry companion failed: %r" % (e,))
