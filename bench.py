@@ -308,6 +308,8 @@ def run(args, wl, d, p, nel):
     comm_host_waits = dev.prof_get(4)[1]
     sell_classes, sell_padded = K.spmv_sell(True)         # which product kernel the solver used
     K.spmv_sell(False)
+    symgrid_solves = dev.prof_get(7)[1]                   # CG solves on the half-storage copy (csrc/tg_symgrid.hip)
+    symgrid = K.mult_symgrid()[1] if symgrid_solves > 0 else None
     its = solver.last.get("iterations", 0) if solver.last else 0
     mean_stages = {k: float(np.mean(v)) for k, v in stages.items()}
 
@@ -407,7 +409,7 @@ def run(args, wl, d, p, nel):
             "spmv_ms_total": spmv_ms, "spmv_count": spmv_n, "ksp_persistent": ksp_persistent, "iterations": its, "stages": mean_stages,
             "t_input": mean_stages.get("fe_input", 0.0), "t_input_in_timed_region": not a_resident,
             "t_input_pre": t_input_pre, "sub_planes": spline._slab.sub_planes if spline._slab is not None else None,
-            "sell_classes": sell_classes, "sell_padded": sell_padded, "implicit_M": bool(getattr(gen.M, "is_implicit", False)),
+            "sell_classes": sell_classes, "sell_padded": sell_padded, "symgrid": symgrid, "symgrid_solves": symgrid_solves, "implicit_M": bool(getattr(gen.M, "is_implicit", False)),
             "ptap_certified": int(ptap_certified), "nodal_error": nodal_error, "method": method, "nf": nf,
             "solver_last": {k: v for k, v in (solver.last or {}).items() if isinstance(v, (int, float, str, bool))},
             "self_check": self_check, "verified_step_s": verified, "materialised_step_s": companions.get("materialised"),
@@ -642,6 +644,12 @@ def main():
     # (values only; the offset dictionary is cache resident), class id + address per slice, x once and y once;
     # the general CSR kernel moves SURVEY.md section 8(d)'s CSR bytes
     fmt_bytes = (8.0 * res["sell_padded"] + 12.0 * ((ncp_l + 63) // 64) + 16.0 * ncp_l) if sell else float(csr_bytes)
+    sym = res.get("symgrid") if (res.get("symgrid_solves", 0) > 0 and not persistent) else None
+    if sym:
+        # CG on a symmetric box-stencil K: the diagonal and the upper triangle only (16 B per pair of positions and row),
+        # the LDS windows written to the staging array by the product kernel and read by the one that sums them, x, y
+        kernel = "k_symgrid_spmv + k_symgrid_combine"
+        fmt_bytes = float(sym["value_bytes"] + 2 * sym["staging_bytes"] + 16 * ncp_l)
     achieved = fmt_bytes / spmv_avg_s / 1e9 if spmv_avg_s > 0 else 0.0
     # HBM traffic of this kernel from the PMC passes (rocprofv3 --pmc in separate runs, as the microarchitecture
     # guide prescribes; committed under profiles/): an OFFLINE measurement, quoted only for the workload and
@@ -658,12 +666,13 @@ def main():
         except Exception:
             traffic = None
     if pmc_rows:                                     # the live passes taken before the run (see above)
-        rows = [r for r in pmc_rows if r["kernel"].startswith(kernel)]
+        names = [k.strip() for k in kernel.split("+")]
+        rows = [r for r in pmc_rows if any(nm in r["kernel"] for nm in names)]
         solves = 2                                      # (the child: one warm-up + one step)
         gated = 2 * solves if res["method"] == "cg" else 0     # products enqueued past convergence return at once
         if rows and rows[0]["launches"] > gated:
             n_real = rows[0]["launches"] - gated
-            live_traffic = (rows[0]["hbm_read_GB_total_corrected"] + rows[0]["hbm_write_GB_total"]) * 1e9 / n_real
+            live_traffic = sum(r["hbm_read_GB_total_corrected"] + r["hbm_write_GB_total"] for r in rows) * 1e9 / n_real
             if 0.5 * fmt_bytes < live_traffic < 4.0 * fmt_bytes:      # (a sane count: else the offline figure stays)
                 traffic = live_traffic
                 traffic_src = ("live: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE in two child runs of this command "
@@ -748,7 +757,12 @@ def main():
                      "bytes_per_launch": fmt_bytes,
                      "bytes_definition": ("sliced, pattern-compressed copy of K's values: 8 B per stored position + "
                                           "12 B per 64-row slice + x read once + y written once (what this kernel "
-                                          "must move; no column indices are streamed)") if sell else
+                                          "must move; no column indices are streamed)") if sell and not sym else
+                                         ("half storage of a symmetric box-stencil K (csrc/tg_symgrid.hip): 16 B per pair of "
+                                          "stored positions and row (the diagonal and the entries above it, each used for "
+                                          "its row and for the transposed entry) + the LDS windows written to and read from "
+                                          "the staging array + x read once + y written once; the time is that of both "
+                                          "kernels of a product") if sym else
                                          "CSR: 12 B per entry + row pointers + x + y (SURVEY.md 8d)",
                      "csr_bytes_per_launch": csr_bytes,
                      "effective_csr_GBps": csr_bytes / spmv_avg_s / 1e9 if spmv_avg_s > 0 else 0.0,

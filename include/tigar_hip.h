@@ -58,9 +58,10 @@ int tg_timer_stop(int slot, double *ms);   /* synchronises; elapsed ms since sta
  * RCCL and for the IPC communicator, whose exchanges are enqueued only; slot 5 (count only): final stages of the
  * tensor-pattern PtAP (tg_tensor_zstage, tg_tensor2_ptap) that delivered rows of K -- "the line walks ran"; slot 6: CG /
  * GMRES solves that ran as ONE persistent kernel (small systems, csrc/tg_krylov_small.hip): count, and the time of those kernels
- * (their products are also counted in slot 0, with the kernel time spread over them -- an iteration, not a product). */
+ * (their products are also counted in slot 0, with the kernel time spread over them -- an iteration, not a product);
+ * slot 7 (count only): CG solves whose products ran on the half-storage copy of csrc/tg_symgrid.hip. */
 enum { TG_PROF_KSP_SPMV = 0, TG_PROF_KSP_OVERLAPPED = 1, TG_PROF_SELL_SHAPE_REUSED = 2, TG_PROF_PTAP_CERTIFIED = 3,
-       TG_PROF_COMM_HOST_WAITS = 4, TG_PROF_PTAP_TENSOR_WALKS = 5, TG_PROF_KSP_PERSISTENT = 6, TG_PROF_NSLOTS = 8 };
+       TG_PROF_COMM_HOST_WAITS = 4, TG_PROF_PTAP_TENSOR_WALKS = 5, TG_PROF_KSP_PERSISTENT = 6, TG_PROF_KSP_SYMGRID = 7, TG_PROF_NSLOTS = 8 };
 int tg_prof_reset(void);
 int tg_prof_get(int slot, double *total_ms, int64_t *count);
 
@@ -209,6 +210,15 @@ int tg_spmv_offset(tg_csr_t a, tg_vec_t x, int64_t x_col0, tg_vec_t y);
  * sequentially in ascending column order (PETSc's order); padded positions add +0.0.
  * enable = 0 drops the copy.  nclasses / padded (may be NULL): dictionary size, doubles stored. */
 int tg_spmv_sell(tg_csr_t a, int enable, int *nclasses, int64_t *padded);
+/* Half-storage product (csrc/tg_symgrid.hip) -- what the CG solve of tg_krylov_solve uses for its K p when K is a
+ * SYMMETRIC box stencil of radius 1..3 on a 3-D grid held by one rank (K = M^T A M of one scalar field on a 3-D patch;
+ * the reference hands K to PETSc's KSPCG, tIGAr/common.py:1255-1258, whose premise is a symmetric operator): the diagonal
+ * and the entries above it are stored once (172 of 343 per row for p = 3) and used for the row and for the transposed
+ * entry; the scatter goes through a ring of LDS windows per (x, y) patch walked along z, deterministically (no global
+ * atomics).  This entry point plans the copy for `a`, checks it against the CSR product on a pseudo-random vector, and,
+ * with x and y given, computes y = a x with it.  *accepted = 0: `a` has no such structure or is not symmetric (nothing
+ * is computed).  value_bytes / staging_bytes (may be NULL): bytes of K one product reads / size of the window staging. */
+int tg_spmv_symgrid(tg_csr_t a, tg_vec_t x, tg_vec_t y, int *accepted, int64_t *value_bytes, int64_t *staging_bytes);
 /* Y = A X for k <= 4 right-hand sides (cpFuncs = M_control * P, tIGAr/common.py:367-380);
  * X, Y are column-major host arrays. */
 int tg_spmm_host(tg_csr_t a, const double *X, int k, double *Y);

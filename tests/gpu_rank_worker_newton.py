@@ -62,8 +62,11 @@ def main():
     spline, u, dofs, hist = run(comm, d, p, nel, with_dofs)
     g0, g1 = spline.localDofRange()
     r0, r1 = spline.localFERange()
+    full = spline.gatherFunction(u)                  # the replicated function again (every rank: all FE rows)
+    assert full.local_range is None and full.vector().size() == spline.V.dim()
     np.savez(os.path.join(outdir, "rank%d.npz" % comm.rank), g=np.array([g0, g1, r0, r1]), hist=np.array(hist),
-             u=u.vector().get_local(), dofs=dofs.get_local() if dofs is not None else np.zeros(0))
+             u=u.vector().get_local(), dofs=dofs.get_local() if dofs is not None else np.zeros(0),
+             u_gathered=full.vector().get_local())
     comm.barrier()
 
 

@@ -196,3 +196,55 @@ def test_socket_transport_messages_are_framed():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True, True), (1, True, True)]
+
+
+def test_solver_stand_ins_are_announced_with_a_warning():
+    """dolfin's solver / preconditioner names that this library has no implementation of are honoured with a stand-in
+    (tIGAr/common.py:1255-1258 passes whatever the user configured) -- and say so at construction, not only in the message of
+    a failed solve; names that run as requested stay silent"""
+    import warnings
+    import pytest
+    import tigar_amd as t
+    with pytest.warns(UserWarning, match="Chebyshev polynomial preconditioner stands in"):
+        s = t.PETScKrylovSolver("cg", "ilu")
+    assert (s.method, s.preconditioner, s.preconditioner_requested) == ("cg", "chebyshev", "ilu")
+    with pytest.warns(UserWarning, match="Jacobi stands in"):
+        s = t.PETScKrylovSolver("gmres", "hypre_amg")
+    assert s.preconditioner == "jacobi"
+    with pytest.warns(UserWarning, match="'minres' requested: gmres runs in its place"):
+        s = t.PETScKrylovSolver("minres", "jacobi")
+    assert s.method == "gmres" and s.method_requested == "minres"
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        t.PETScKrylovSolver("cg", "jacobi")
+        t.PETScKrylovSolver("gmres", "none")
+        t.PETScKrylovSolver("default", "default")
+        t.PETScKrylovSolver("cg", "chebyshev")
+
+
+def test_chebyshev_breakdown_falls_back_to_jacobi_cg(monkeypatch):
+    """status -2 of Chebyshev-CG (an eigenvalue estimate that missed the upper end of the spectrum) is not reported as a
+    breakdown of the solve: Jacobi-CG runs instead, with a warning and a note in ``last``; a breakdown of that
+    solve as well (NaN in K or b) stays status -2 and raises"""
+    import pytest
+    import tigar_amd as t
+    from tigar_amd import common as tc
+    calls = []
+
+    def fake(A, b, x, method, pc, *a, **k):
+        calls.append((method, pc))
+        return (7, float("nan"), -2) if pc == "chebyshev" else (41, 1e-9, 0)
+
+    monkeypatch.setattr(tc, "_as_device_csr", lambda a: a)
+    monkeypatch.setattr(tc, "_as_device_vector", lambda v: v)
+    monkeypatch.setattr(tc._dev, "krylov_solve", fake)
+    s = t.PETScKrylovSolver("cg", "chebyshev")
+    with pytest.warns(UserWarning, match="broke down"):
+        its = s.solve(object(), object(), object())
+    assert its == 41 and calls == [("cg", "chebyshev"), ("cg", "jacobi")]
+    assert s.last["status"] == 0 and s.last["preconditioner"] == "jacobi" and s.last["preconditioner_requested"] == "chebyshev"
+    assert s.last["fallback"] == {"preconditioner": "jacobi", "after_iterations": 7}
+    monkeypatch.setattr(tc._dev, "krylov_solve", lambda *a, **k: (3, float("nan"), -2))
+    with pytest.warns(UserWarning), pytest.raises(RuntimeError, match="breakdown"):
+        s.solve(object(), object(), object())
+    assert s.last["status"] == -2

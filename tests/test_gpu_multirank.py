@@ -438,6 +438,11 @@ def test_newton_on_several_ranks(tmp_path, capfd, world, kind, d, p, nel, with_d
             assert z["dofs"].size == g1 - g0
             assert np.max(np.abs(z["dofs"] - dref[g0:g1])) <= 1e-10 * np.max(np.abs(dref))
         cover[r0:r1] += 1
+        # gatherFunction: the full-length function on every rank, the same bits everywhere
+        assert z["u_gathered"].size == uref.size
+        assert np.max(np.abs(z["u_gathered"] - uref)) <= 1e-10 * np.max(np.abs(uref))
+        assert np.array_equal(z["u_gathered"].view(np.int64), parts[0]["u_gathered"].view(np.int64))
+        assert r1 == r0 or np.array_equal(z["u_gathered"][r0:r1], z["u"])
     assert np.all(cover == 1)
     out = capfd.readouterr().out
     assert out.count("Solver iteration: 0 ,") == 1            # rank 0 alone prints the reference's progress line

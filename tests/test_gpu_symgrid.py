@@ -1,0 +1,184 @@
+"""-m gpu: the half-storage product of the CG solve (csrc/tg_symgrid.hip) -- the K p of ``linearSolver.solve(MTAM, MTU, MTb)``
+(tIGAr/common.py:1255-1258) for a symmetric box-stencil K on a 3-D grid of control points: upper triangle stored once, the
+transposed entries scattered through LDS windows.  Checked against scipy and the CSR kernel (products), against the sliced
+copy (solves), for grids whose sizes are no multiples of the patch sizes, for matrices that must be declined, and for
+bit-reproducibility."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from tigar_amd import device
+    device.device_info()          # raises loudly if the library / GPU is missing
+    return device
+
+
+def _box_stencil(rng, shape, reach, symmetric=True):
+    """random box-stencil matrix on an (n0, n1, n2) grid (x fastest), truncated at the boundary, general CSR"""
+    n = int(np.prod(shape))
+    idx = np.arange(n).reshape(shape[::-1])
+    rows, cols = [], []
+    for off in itertools.product(*[range(-reach, reach + 1)] * 3):
+        src = [slice(max(0, -o), s - max(0, o)) for o, s in zip(off[::-1], shape[::-1])]
+        dst = [slice(max(0, o), s - max(0, -o)) for o, s in zip(off[::-1], shape[::-1])]
+        rows.append(idx[tuple(src)].ravel())
+        cols.append(idx[tuple(dst)].ravel())
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    A = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(n, n))
+    if symmetric:
+        A = (A + A.T).tocsr()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("shape,reach", [((41, 33, 19), 3), ((24, 16, 8), 3), ((25, 17, 9), 2), ((49, 35, 11), 2),
+                                         ((16, 50, 21), 1), ((73, 18, 30), 1), ((47, 47, 47), 3)])
+def test_half_storage_product_matches_scipy(dev, shape, reach):
+    rng = np.random.default_rng(sum(shape) + reach)
+    A = _box_stencil(rng, shape, reach)
+    x = rng.standard_normal(A.shape[0])
+    dA, dx = dev.DeviceCSR.from_scipy(A), dev.DeviceVector(data=x)
+    y, info = dA.mult_symgrid(dx)
+    assert info is not None, "a symmetric box stencil was declined"
+    ref = A @ x
+    scale = np.abs(A) @ np.abs(x)
+    assert np.max(np.abs(y.get_local() - ref) / scale) < 1e-14
+    # the diagonal and what follows it: ((2 reach + 1)^3 + 1) / 2 positions per row (padded to pairs), 8 B each
+    npos = ((2 * reach + 1) ** 3 + 1) // 2
+    assert info["value_bytes"] == A.shape[0] * ((npos + 1) // 2) * 16
+    if min(shape) >= 40:      # (little boundary truncation: about half of the 8 B per stored entry of the sliced copy)
+        assert info["value_bytes"] < 0.6 * 8 * A.nnz
+    # the same bits in every run (one wave per window, LDS operations of a wave in order, windows summed in a fixed order)
+    y2, _ = dA.mult_symgrid(dx)
+    assert np.array_equal(y.get_local().view(np.int64), y2.get_local().view(np.int64))
+
+
+def test_matrices_without_the_structure_are_declined(dev):
+    rng = np.random.default_rng(3)
+    shape = (30, 20, 12)
+    x = dev.DeviceVector(data=rng.standard_normal(int(np.prod(shape))))
+    # not symmetric: found by the comparison with the CSR product
+    A = _box_stencil(rng, shape, 2, symmetric=False)
+    assert dev.DeviceCSR.from_scipy(A).mult_symgrid(x) == (None, None)
+    # symmetric, but one value off in the lower triangle (which the copy never reads)
+    B = _box_stencil(rng, shape, 2)
+    r = 3000
+    lo = B.indptr[r]
+    assert B.indices[lo] < r
+    B.data[lo] += 0.5
+    assert dev.DeviceCSR.from_scipy(B).mult_symgrid(x) == (None, None)
+    # a row with an entry missing from the box (another row length), and one with a column outside it
+    Cm = _box_stencil(rng, shape, 2).tolil()
+    i = 4000
+    j = Cm.rows[i][5]
+    Cm[i, j] = 0.0
+    Cm[j, i] = 0.0
+    Cm = Cm.tocsr()
+    Cm.eliminate_zeros()
+    assert dev.DeviceCSR.from_scipy(Cm).mult_symgrid(x) == (None, None)
+    D = _box_stencil(rng, shape, 2).tocoo()
+    far = sp.coo_matrix(([1.0, 1.0], ([10, 5000], [5000, 10])), shape=D.shape)
+    Dm = (D + far).tocsr()
+    Dm.sort_indices()
+    assert dev.DeviceCSR.from_scipy(Dm).mult_symgrid(x) == (None, None)
+    # two dimensions / no grid at all
+    E = sp.diags([1.0, 4.0, 1.0], [-1, 0, 1], shape=(6000, 6000)).tocsr()
+    assert dev.DeviceCSR.from_scipy(E).mult_symgrid(dev.DeviceVector(6000)) == (None, None)
+
+
+def _poisson3d(p, nel, mapped=False):
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, forms as F
+    kv = [B.uniformKnots(p, 0., 1., n) for n in nel]
+    if mapped:
+        from geom_util import rational_volume
+        from tigar_amd import NURBS as N
+        kvs, C = rational_volume(p, nel)
+        mesh = N.NURBSControlMesh([p] * 3, kvs, C)
+    else:
+        mesh = B.ExplicitBSplineControlMesh([p] * 3, kv)
+    gen = t.EqualOrderSpline(1, mesh)
+    s0 = gen.getScalarSpline(0)
+    for direction in range(3):
+        for side in (0, 1):
+            gen.addZeroDofs(0, s0.getSideDofs(direction, side))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    if mapped:
+        K = spline.assembleMatrix(F.LaplaceForm(geometry=gen))
+        rhs = spline.assembleVector(F.NodalLoadForm(1.0, gen))
+    else:
+        K = spline.assembleMatrix(F.LaplaceForm())
+        rhs = spline.assembleVector(F.SeparableLoadForm([lambda x: np.sin(np.pi * x)] * 3, scale=3 * np.pi ** 2))
+    return spline, K, rhs
+
+
+@pytest.mark.parametrize("p,nel,mapped", [(3, (38, 38, 38), False), (2, (45, 37, 41), False), (1, (50, 44, 40), False),
+                                          (2, (40, 40, 40), True)])
+def test_cg_solve_on_the_half_storage_copy(dev, p, nel, mapped, monkeypatch):
+    """the K of the API (Dirichlet rows and columns included) is accepted; the solve agrees with the one on the sliced copy:
+    same iteration count (+-1: the rows are summed in another order) and the same solution to the tolerance"""
+    import tigar_amd as t
+    from tigar_amd.device import DeviceVector
+    spline, K, rhs = _poisson3d(p, nel, mapped)
+    n = K.shape[0]
+    assert n >= 65536
+    x = DeviceVector(data=np.random.default_rng(1).standard_normal(n))
+    y, info = K.mult_symgrid(x)
+    assert info is not None
+    y0 = K.mult(x).get_local()
+    assert np.max(np.abs(y.get_local() - y0)) <= 1e-13 * np.max(np.abs(y0))
+    res = {}
+    monkeypatch.setenv("TIGAR_KSP_PERSISTENT", "0")      # (a K that fits into the registers of the chip never gets here)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TIGAR_SPMV_SYM", mode)
+        ks = t.PETScKrylovSolver("cg", "jacobi")
+        ks.parameters["relative_tolerance"] = 1e-9
+        U = DeviceVector(n)
+        c0 = dev.prof_get(7)[1]
+        its = ks.solve(K, U, rhs)
+        assert ks.last["status"] == 0
+        assert dev.prof_get(7)[1] - c0 == int(mode)
+        res[mode] = (its, U.get_local())
+    assert abs(res["0"][0] - res["1"][0]) <= 1, (res["0"][0], res["1"][0])
+    assert np.max(np.abs(res["0"][1] - res["1"][1])) <= 1e-7 * np.max(np.abs(res["0"][1]))
+    r = rhs.get_local() - K.to_scipy() @ res["1"][1]
+    assert np.linalg.norm(r) <= 1e-7 * np.linalg.norm(rhs.get_local())
+    # bit for bit the same in a second solve
+    monkeypatch.setenv("TIGAR_SPMV_SYM", "1")
+    ks = t.PETScKrylovSolver("cg", "jacobi")
+    ks.parameters["relative_tolerance"] = 1e-9
+    U2 = DeviceVector(n)
+    assert ks.solve(K, U2, rhs) == res["1"][0]
+    assert np.array_equal(U2.get_local().view(np.int64), res["1"][1].view(np.int64))
+
+
+def test_small_systems_and_other_solvers_keep_their_kernels(dev, monkeypatch):
+    """below 65536 rows (the persistent kernels' range) and for gmres nothing changes; TIGAR_SPMV_SYM=2 forces the copy"""
+    import tigar_amd as t
+    from tigar_amd.device import DeviceVector
+    rng = np.random.default_rng(9)
+    A = _box_stencil(rng, (20, 18, 17), 2)
+    A = (A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + 1.0)).tocsr()
+    A.sort_indices()
+    b = rng.standard_normal(A.shape[0])
+    dA, db = dev.DeviceCSR.from_scipy(A), DeviceVector(data=b)
+    out = {}
+    for mode in ("1", "2"):
+        monkeypatch.setenv("TIGAR_SPMV_SYM", mode)
+        monkeypatch.setenv("TIGAR_KSP_PERSISTENT", "0")
+        ks = t.PETScKrylovSolver("cg", "jacobi")
+        ks.parameters["relative_tolerance"] = 1e-10
+        U = DeviceVector(A.shape[0])
+        c0 = dev.prof_get(7)[1]
+        ks.solve(dA, U, db)
+        out[mode] = (dev.prof_get(7)[1] - c0, U.get_local())
+    assert out["1"][0] == 0 and out["2"][0] == 1
+    assert np.max(np.abs(out["1"][1] - out["2"][1])) <= 1e-8 * np.max(np.abs(out["1"][1]))
+    assert np.linalg.norm(A @ out["2"][1] - b) <= 1e-8 * np.linalg.norm(b)

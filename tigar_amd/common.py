@@ -1153,6 +1153,14 @@ class PETScKrylovSolver(object):
         if preconditioner == "chebyshev" and method != "cg":
             raise ValueError("the Chebyshev polynomial preconditioner serves cg (a fixed symmetric polynomial)")
         self.method, self.preconditioner = method, preconditioner
+        if method != self.method_requested and self.method_requested != "default":
+            note = (note or "") + " (method %r requested: %s runs in its place)" % (self.method_requested, method)
+        if note:
+            # the request is honoured with a stand-in, and says so where the user sees it, not only in the
+            # message of a failed solve
+            import warnings
+            warnings.warn("PETScKrylovSolver(%r, %r): running (%r, %r)%s" % (self.method_requested, self.preconditioner_requested,
+                                                                            method, preconditioner, note), stacklevel=2)
         self.parameters = {"relative_tolerance": 1e-6, "absolute_tolerance": 1e-15,
                            "maximum_iterations": 10000, "error_on_nonconvergence": True,
                            "nonzero_initial_guess": False, "gmres_restart": 30,
@@ -1174,13 +1182,40 @@ class PETScKrylovSolver(object):
         """``x`` is the output; with ``parameters["nonzero_initial_guess"]`` it also holds the start vector
         (the convergence test stays relative to ||B b||, PETSc's default [ext])."""
         A, x, b = _as_device_csr(A), _as_device_vector(x), _as_device_vector(b)
-        its, res, status = _dev.krylov_solve(
-            A, b, x, self.method, self.preconditioner, self.parameters["relative_tolerance"],
-            self.parameters["absolute_tolerance"], self.parameters["maximum_iterations"],
-            self.parameters["chebyshev_degree"] if self.preconditioner == "chebyshev" else self.parameters["gmres_restart"],
-            self.comm, nonzero_initial_guess=bool(self.parameters["nonzero_initial_guess"]),
-            stagnation_guard=bool(self.parameters.get("stagnation_guard", False)))
-        self.last = {"iterations": its, "residual_norm": res, "status": status}
+        guess = bool(self.parameters["nonzero_initial_guess"])
+
+        def run(pc):
+            return _dev.krylov_solve(
+                A, b, x, self.method, pc, self.parameters["relative_tolerance"],
+                self.parameters["absolute_tolerance"], self.parameters["maximum_iterations"],
+                self.parameters["chebyshev_degree"] if pc == "chebyshev" else self.parameters["gmres_restart"],
+                self.comm, nonzero_initial_guess=guess,
+                stagnation_guard=bool(self.parameters.get("stagnation_guard", False)))
+
+        x0 = None
+        if self.preconditioner == "chebyshev" and guess:
+            x0 = DeviceVector(x.size())
+            _dev.vec_copy_range(x0, 0, x, 0, x.size())
+        its, res, status = run(self.preconditioner)
+        fallback = None
+        if status == -2 and self.preconditioner == "chebyshev":
+            # the polynomial is built on an ESTIMATE of the largest eigenvalue of D^-1 K (a few power iterations); an estimate
+            # that is too small makes the polynomial indefinite and the recurrence breaks down although K is fine.
+            # Jacobi-CG needs no estimate: run it instead of reporting a breakdown (ADVICE r4).  A K or b that holds NaN breaks
+            # it down as well and the status stays -2.
+            import warnings
+            warnings.warn("PETScKrylovSolver: Chebyshev-preconditioned CG broke down (eigenvalue estimate); "
+                          "solving with Jacobi-CG instead", stacklevel=2)
+            if x0 is not None:
+                _dev.vec_copy_range(x, 0, x0, 0, x.size())
+            its_c = its
+            its, res, status = run("jacobi")
+            fallback = {"preconditioner": "jacobi", "after_iterations": its_c}
+        self.last = {"iterations": its, "residual_norm": res, "status": status, "method": self.method,
+                     "preconditioner": fallback["preconditioner"] if fallback else self.preconditioner,
+                     "method_requested": self.method_requested, "preconditioner_requested": self.preconditioner_requested}
+        if fallback:
+            self.last["fallback"] = fallback
         if status < 0 and self.parameters["error_on_nonconvergence"]:
             raise RuntimeError("Krylov solver (%s, %s) did not converge: %s after %d iterations, preconditioned "
                                "residual %.3e.%s" % (self.method, self.preconditioner,
@@ -1887,6 +1922,27 @@ class ExtractedSpline(object):
                 _dev.vec_copy_range(f.vector(), 0, src, int(rng[0]), int(rng[1]) - int(rng[0]))
         return f
 
+    def gatherFunction(self, u):
+        """The replicated, full-length Function of a rank-local one: every rank gets all FE rows (summed through the
+        transport in rank order, the same bits everywhere).  After ``solveLinearSystem`` /
+        ``solveNonlinearVariationalProblem`` on several ranks ``u.vector()`` holds THIS rank's FE rows only
+        (``u.local_range``; the reference's distributed PETSc vector, tIGAr/common.py:1259-1261, 1343) -- code written for
+        one rank that reads the whole solution (error norms, output) calls this first.  One rank, or a function that is
+        already replicated: ``u`` itself."""
+        vec = _as_device_vector(u)
+        n = self.V.dim()
+        if not self._distributed() or getattr(u, "local_range", None) is None or vec.size() == n:
+            return u
+        rng = u.local_range
+        pieces = rng if (len(rng) and isinstance(rng[0], (tuple, list))) else [rng]
+        host, full, pos = vec.get_local(), numpy.zeros(n), 0
+        for (a, b) in pieces:
+            a, b = int(a), int(b)
+            full[a:b] = host[pos:pos + b - a]
+            pos += b - a
+        self.comm.transport().allreduce_sum(full)
+        return Function(self.V, None, DeviceVector(data=full))
+
     def ghostedVector(self, u):
         """Full-length vector with the rank-local FE function ``u`` in place and the ghost rows the rank's forms read --
         the FE rows its rows of A couple to beyond its own, ``m_rows`` of its slab -- fetched from the z-neighbours
@@ -2009,7 +2065,9 @@ class ExtractedSpline(object):
         dist = self._distributed()
         if dist:
             # several ranks: u, du and igaDoFs are rank-local (FE rows localFERange(), dofs localDofRange()), the norm is
-            # global, the forms read u through Function.ghosted() -- the reference's loop on distributed PETSc vectors
+            # global, the forms read u through Function.ghosted() -- the reference's loop on distributed PETSc vectors.
+            # NOTE: a replicated ``u`` handed in becomes rank-local IN PLACE (u.vector() = this rank's rows, u.local_range
+            # set); ``gatherFunction(u)`` returns the full-length function again
             if u.local_range is None:
                 loc = self.localFunction(u)          # a replicated Function: every rank keeps its rows
                 u._vec, u.local_range = loc.vector(), loc.local_range

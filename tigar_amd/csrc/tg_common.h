@@ -188,6 +188,13 @@ int64_t tg_sell_slice_rows(void);
 int tg_sell_spmv_rows(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y, int64_t r0,
                       int64_t r1, const double *gate, double gate_tol);
 
+// half-storage product for symmetric box-stencil matrices on a 3-D grid (tg_symgrid.hip)
+struct tg_symgrid_s;
+int tg_symgrid_build(tg_csr_s *a, int verify, tg_symgrid_s **out);   // *out = nullptr: declined
+void tg_symgrid_free(tg_symgrid_s *s);
+int tg_symgrid_spmv(tg_symgrid_s *s, const double *x, double *y, const double *gate, double gate_tol);
+void tg_symgrid_info(const tg_symgrid_s *s, int64_t *val_bytes, int64_t *stage_bytes);
+
 int tg_csr_sort_rows(tg_csr_s *m);
 int tg_csr_transpose_block(tg_csr_s *m, int64_t row_base, int64_t out_ncols, tg_csr_s **out);
 // persistent single-kernel Krylov loop for small systems (tg_krylov_small.hip)

@@ -23,8 +23,8 @@ struct tg_sell_guard {
   tg_csr_s *k;
   bool temp = false;
   int rc = 0;
-  explicit tg_sell_guard(tg_csr_s *m) : k(m) {
-    if (k->sell_state == 0) {
+  explicit tg_sell_guard(tg_csr_s *m, bool skip = false) : k(m) {
+    if (k->sell_state == 0 && !skip) {
       rc = tg_sell_plan(k);
       temp = true;
     }
@@ -35,6 +35,13 @@ struct tg_sell_guard {
       k->sell_state = 0;
     }
   }
+};
+
+// CG only (a symmetric K is its premise): the half-storage copy of tg_symgrid.hip when K is a box stencil on a 3-D grid
+// and this rank holds all of it; built for the solve like the sliced copy, which is then not needed.
+struct tg_symgrid_guard {
+  tg_symgrid_s *s = nullptr;
+  ~tg_symgrid_guard() { tg_symgrid_free(s); }
 };
 
 static double tk_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -303,7 +310,16 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
   tg_cg_scal *sc = (tg_cg_scal *)(g_tg.scratch + TG_SCRATCH_DOUBLES - 2048);   // two parities
   const int vg = tg_vec_grid(n);
   TG_TRY(tg_spmv_plan(k));
-  tg_sell_guard sell_guard(k);   // sliced copy of the values for the products of this solve
+  tg_symgrid_guard sym;
+  {
+    // (TIGAR_SPMV_SYM: 0 = off, 1 = systems of at least 65536 rows [default], 2 = every size the plan accepts)
+    const int sym_on = getenv("TIGAR_SPMV_SYM") ? atoi(getenv("TIGAR_SPMV_SYM")) : 1;
+    const int sym_verify = getenv("TIGAR_SPMV_SYM_VERIFY") ? atoi(getenv("TIGAR_SPMV_SYM_VERIFY")) : 1;
+    if (sym_on && (n >= 65536 || sym_on > 1) && !(comm && comm->world > 1) && k->sell_state != 1 && hlo == 0 && hhi == 0)
+      TG_TRY(tg_symgrid_build(k, sym_verify, &sym.s));
+    if (sym.s) g_tg.prof_n[TG_PROF_KSP_SYMGRID] += 1;
+  }
+  tg_sell_guard sell_guard(k, sym.s != nullptr);   // sliced copy of the values for the products of this solve
   TG_TRY(sell_guard.rc);
   tg_cg_ring ring;
   TG_TRY(ring.init());
@@ -384,6 +400,7 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
       return 0;
     }
     TG_TRY(tg_comm_halo_exchange(comm, uext));
+    if (sym.s) return tg_symgrid_spmv(sym.s, u, w, gate, tol2_dev);
     if (sliced && gate) return tg_sell_spmv_rows(k, ushift, cmin, cmax, w, 0, n, gate, tol2_dev);
     return tg_spmv_raw(k, ushift, cmin, cmax, w);
   };

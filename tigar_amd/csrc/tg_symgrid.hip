@@ -1,0 +1,678 @@
+// Half-storage product for the K p of a CG solve (tIGAr/common.py:1255-1258 hands K to a PETSc KSP; CG is only
+// defined for a symmetric K, and PETSc's own answer to that is the SBAIJ format).
+//
+// The sliced copy of tg_sell.hip moves 8 B per stored entry and sits at 0.71-0.78 of the HBM peak: the only way to a
+// faster product is fewer bytes.  K = M^T A M of ONE scalar field on a 3-D tensor-product patch is a box stencil of
+// radius P on an n0 x n1 x n2 grid of control points, and symmetric.  This plan stores the diagonal and the entries
+// above it only ((2P+1)^3 + 1) / 2 per row: 172 of 343 for P = 3) and uses each of them twice,
+//
+//     y[i]       += K[i][i+off] * x[i+off]       (the row, as before)
+//     y[i+off]   += K[i][i+off] * x[i]           (the transposed entry),
+//
+// so a product moves HALF the bytes.  The second line is a scatter; what makes it cheap is the geometry, not the CSR
+// arrays: the grid is cut into patches of at most 24 x 16 points in (x, y), a wave owns one patch and walks it plane by
+// plane along z.  Everything the wave scatters lands in the window (patch + P points on every side) of the current and
+// the next P planes, which it keeps in LDS as a ring of P + 1 planes (21 KB for P = 3) and feeds with ds_add_f64 -- one
+// wave per window, LDS operations of a wave complete in order, so the sums are the same bit for bit in every run.  When
+// a plane is finished its window goes to a staging array (1 % of the value bytes); a second small kernel adds, for
+// every row, the windows that cover it (its own patch, up to 3 x 3 neighbours in the plane, the previous z chunk) in a
+// fixed order.  No global atomics.
+//
+// Nothing about the origin of the matrix is assumed: P, n0, n1, n2 are read off the column offsets of one interior
+// row, the conversion checks the length and every column index of every row it copies against the box stencil, and the
+// finished plan is compared with the CSR product on a pseudo-random vector (which a matrix that is not symmetric fails
+// by O(1)).  A matrix that does not pass keeps the sliced copy / the CSR kernel.
+#include "tg_common.h"
+#include <algorithm>
+#include <utility>
+#include <vector>
+
+#define SG_PX 24          // widest / highest patch (points)
+#define SG_PY 16
+#define SG_TAB (SG_PX * SG_PY)
+
+typedef double sg_d2 __attribute__((ext_vector_type(2)));
+
+template <int P>
+struct sg_c {
+  static constexpr int S = 2 * P + 1, NF = S * S * S, LC = (NF - 1) / 2;
+  static constexpr int NP = LC + 1;          // stored positions per row: the diagonal and what follows it
+  static constexpr int NG = (NP + 1) / 2;    // pairs of positions (16 bytes per lane)
+  static constexpr int Wx = SG_PX + 2 * P, Wy = SG_PY + 2 * P, W = Wx * Wy;
+};
+// position -> offset in the box, positions in ascending column order starting at the diagonal
+__host__ __device__ constexpr int sg_dx(int P, int pos) { return (pos + ((2 * P + 1) * (2 * P + 1) * (2 * P + 1) - 1) / 2) % (2 * P + 1) - P; }
+__host__ __device__ constexpr int sg_dy(int P, int pos) {
+  return ((pos + ((2 * P + 1) * (2 * P + 1) * (2 * P + 1) - 1) / 2) / (2 * P + 1)) % (2 * P + 1) - P;
+}
+__host__ __device__ constexpr int sg_dz(int P, int pos) {
+  return (pos + ((2 * P + 1) * (2 * P + 1) * (2 * P + 1) - 1) / 2) / ((2 * P + 1) * (2 * P + 1)) - P;
+}
+
+// STORAGE order of the positions of a row.  Positions with the same in-plane offset (dx, dy) form a group, one member
+// per plane dz = 1 .. P (and dz = 0 where (0, dy, dx) lies above the diagonal): consecutive stored values scatter into
+// DIFFERENT planes of the window ring, so the read - add - write sequences of a group are independent (see the product
+// kernel).  The S^2 - n0 groups without a dz = 0 member come first (P values each), then the n0 = (S^2 + 1) / 2 groups
+// with one (P + 1 values each, the diagonal in the first of them).  Batches of the product kernel are whole groups.
+template <int P>
+struct sg_lay {
+  static constexpr int S = 2 * P + 1, N0 = (S * S + 1) / 2;
+  static constexpr int NA = (S * S - N0) * P, NP = NA + N0 * (P + 1);
+  __host__ __device__ static constexpr int pos(int k) {       // storage index -> position
+    const int i = k < NA ? N0 + k / P : (k - NA) / (P + 1);
+    const int dz = k < NA ? k % P + 1 : (((k - NA) % (P + 1)) < P ? (k - NA) % (P + 1) + 1 : 0);
+    return dz == 0 ? i : N0 + (dz - 1) * S * S + i;
+  }
+  __host__ __device__ static constexpr int inv(int pos) {     // position -> storage index
+    const int dz = pos < N0 ? 0 : (pos - N0) / (S * S) + 1;
+    const int i = pos < N0 ? pos : (pos - N0) % (S * S);
+    return i < N0 ? NA + i * (P + 1) + (dz == 0 ? P : dz - 1) : (i - N0) * P + (dz - 1);
+  }
+  // batches: storage indices [bstart(b), bstart(b + 1)), even boundaries on group boundaries; their number is a multiple
+  // of 4 (the product kernel keeps 4 batches of values and 2 of x in registers, buffer = batch mod 4 / mod 2)
+  static constexpr int NBATCH = P == 3 ? 24 : P == 2 ? 12 : 4;
+  __host__ __device__ static constexpr int bstart(int b) {
+    return P == 3   ? (b <= 12 ? 6 * b : b < 24 ? 72 + 8 * (b - 12) : 172)
+           : P == 2 ? (b <= 6 ? 4 * b : b < 12 ? 24 + 6 * (b - 6) : 64)
+                    : (b <= 2 ? 2 * b : b == 3 ? 8 : 14);
+  }
+  static constexpr int GBMAX = P == 3 ? 6 : P == 2 ? 5 : 3;   // pairs in the longest batch
+};
+static_assert(sg_lay<3>::NP == sg_c<3>::NP && sg_lay<2>::NP == sg_c<2>::NP && sg_lay<1>::NP == sg_c<1>::NP, "positions");
+static_assert(sg_lay<3>::bstart(24) == 2 * sg_c<3>::NG && sg_lay<2>::bstart(12) == 2 * sg_c<2>::NG &&
+                  sg_lay<1>::bstart(4) == 2 * sg_c<1>::NG, "batches cover the stored pairs");
+static_assert(sg_lay<3>::inv(sg_lay<3>::pos(171)) == 171 && sg_lay<3>::inv(sg_lay<3>::pos(72)) == 72 &&
+                  sg_lay<2>::inv(sg_lay<2>::pos(40)) == 40 && sg_lay<3>::pos(sg_lay<3>::NA + 3) == 0, "storage order");
+
+template <int... I, typename F>
+__device__ __forceinline__ void sg_each(std::integer_sequence<int, I...>, F &&f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+
+struct tg_symgrid_s {
+  int P = 0, n0 = 0, n1 = 0, n2 = 0;
+  int npx = 0, npy = 0, nch = 0, m = 0, czmax = 0;
+  int32_t *tabs = nullptr;      // device: x0[npx+1] | y0[npy+1] | z0[nch+1] | px_of[n0] | py_of[n1] | pc_of[n2]
+  sg_d2 *val = nullptr;         // [patch][plane][sub-step][pair][lane]
+  double *stage = nullptr;      // [patch][chunk][plane of the chunk + P][W]
+  int64_t val_bytes = 0, stage_bytes = 0;
+  int64_t rows_stored = 0;      // lanes that hold a row (the bytes a product reads: rows_stored * NG * 16)
+};
+
+struct sg_dev {
+  int n0, n1, n2, npx, npy, nch, m, czmax;
+  const int32_t *x0, *y0, *z0, *px_of, *py_of, *pc_of;
+};
+
+static sg_dev sg_view(const tg_symgrid_s *s) {
+  sg_dev d;
+  d.n0 = s->n0, d.n1 = s->n1, d.n2 = s->n2, d.npx = s->npx, d.npy = s->npy, d.nch = s->nch, d.m = s->m, d.czmax = s->czmax;
+  d.x0 = s->tabs;
+  d.y0 = d.x0 + s->npx + 1;
+  d.z0 = d.y0 + s->npy + 1;
+  d.px_of = d.z0 + s->nch + 1;
+  d.py_of = d.px_of + s->n0;
+  d.pc_of = d.py_of + s->n1;
+  return d;
+}
+
+void tg_symgrid_free(tg_symgrid_s *s) {
+  if (!s) return;
+  if (g_tg.ready) {
+    tg_dfree(s->tabs);
+    tg_dfree(s->val);
+    tg_dfree(s->stage);
+  }
+  delete s;
+}
+
+// ---- conversion.  Row (ix, iy, iz) of a box stencil holds the entries dx in [-min(P, ix), min(P, n0-1-ix)] x (same in
+// y, z) in lexicographic (dz, dy, dx) = ascending column order: the stored half is the TAIL of the CSR row from the
+// diagonal on, one contiguous piece per row.  A workgroup takes 32 rows of a (patch, plane, sub-step) block: every wave
+// streams the tails of 8 rows (coalesced), places the values by position in an LDS tile [row][position] and the tile goes
+// out as [pair of positions][lane] pieces of 512 bytes.  fail[0] is set when a row has another length than its box or
+// another column index at one of its places.
+#define SG_CV_ROWS 32
+template <int P>
+__global__ void __launch_bounds__(256)
+    k_symgrid_convert(sg_dev G, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                      const double *__restrict__ val, sg_d2 *__restrict__ out, int64_t nblk, int *__restrict__ fail) {
+  typedef sg_c<P> C;
+  constexpr int LD = 2 * C::NG + 1;          // odd row length of the tile
+  __shared__ double tile[SG_CV_ROWS * LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t blk = (int64_t)blockIdx.x >> 1;
+  const int half = (int)(blockIdx.x & 1);
+  const int sub = (int)(blk % G.m);
+  const int64_t pz = blk / G.m;
+  const int z = (int)(pz % G.n2), patch = (int)(pz / G.n2);
+  const int a = patch % G.npx, b = patch / G.npx;
+  const int xa = G.x0[a], pxv = G.x0[a + 1] - xa, ya = G.y0[b], pyv = G.y0[b + 1] - ya;
+  const int cnt = pxv * pyv;
+  const int t0 = sub * 64 + half * SG_CV_ROWS;
+  if (sub * 64 >= cnt) return;                 // (a block no product touches)
+  for (int i = tid; i < SG_CV_ROWS * LD; i += 256) tile[i] = 0.0;
+  __syncthreads();
+  const int n0 = G.n0, n01 = G.n0 * G.n1;
+  const int dzlo = -min(P, z), dzhi = min(P, G.n2 - 1 - z), nz = dzhi - dzlo + 1;
+  // lane rr < 8 of a wave looks up row rr of the wave's eight
+  int my_row = -1, my_len = 0;
+  int64_t my_e0 = 0;
+  {
+    const int t = t0 + w * 8 + lane;
+    if (lane < 8 && t < cnt) {                 // (lanes of the block beyond the patch get zeros: the product loads them)
+      const int ly = t / pxv, lx = t - ly * pxv;
+      my_row = (z * G.n1 + ya + ly) * n0 + xa + lx;
+      my_e0 = rowptr[my_row];
+      my_len = (int)(rowptr[my_row + 1] - my_e0);
+    }
+  }
+  bool bad = false;
+#pragma unroll
+  for (int rr = 0; rr < 8; rr++) {
+    const int row = __builtin_amdgcn_readlane(my_row, rr);
+    if (row < 0) break;
+    const int len = __builtin_amdgcn_readlane(my_len, rr);
+    const int64_t e0 = ((int64_t)__builtin_amdgcn_readlane((int)(my_e0 >> 32), rr) << 32) |
+                       (unsigned)__builtin_amdgcn_readlane((int)(my_e0 & 0xffffffff), rr);
+    const int ix = row % n0, iy = (row / n0) % G.n1;
+    const int dxlo = -min(P, ix), dxhi = min(P, n0 - 1 - ix), nx = dxhi - dxlo + 1;
+    const int dylo = -min(P, iy), dyhi = min(P, G.n1 - 1 - iy), ny = dyhi - dylo + 1;
+    if (len != nx * ny * nz) {
+      bad = true;
+      continue;
+    }
+    const int nxy = nx * ny;
+    const int mxy = (65536 + nxy - 1) / nxy, mx = (65536 + nx - 1) / nx;    // k / d = (k * m) >> 16 for k d < 65536
+    const int kd = ((0 - dzlo) * ny + (0 - dylo)) * nx + (0 - dxlo);          // the diagonal
+    double *trow = tile + (w * 8 + rr) * LD;
+    for (int k = kd + lane; k < len; k += 64) {
+      const double v = __builtin_nontemporal_load(val + e0 + k);
+      const int c = __builtin_nontemporal_load(col + e0 + k);
+      const int qz = (k * mxy) >> 16, rem = k - qz * nxy;
+      const int qy = (rem * mx) >> 16, qx = rem - qy * nx;
+      const int dz = qz + dzlo, dy = qy + dylo, dx = qx + dxlo;
+      bad |= c != row + dx + n0 * dy + n01 * dz;
+      trow[sg_lay<P>::inv(((dz + P) * C::S + dy + P) * C::S + dx + P - C::LC)] = v;
+    }
+  }
+  __syncthreads();
+  sg_d2 *o = out + blk * (int64_t)(C::NG * 64) + half * SG_CV_ROWS;
+  for (int i = tid; i < C::NG * SG_CV_ROWS; i += 256) {
+    const int g = i / SG_CV_ROWS, l = i - g * SG_CV_ROWS;
+    sg_d2 v;
+    v.x = tile[l * LD + 2 * g], v.y = tile[l * LD + 2 * g + 1];
+    o[g * 64 + l] = v;
+  }
+  if (bad) atomicExch(fail, 1);
+}
+
+// ---- the product: one wave per (patch, z chunk).  The stream of values is what bounds the kernel, and with one wave
+// per 21 KB window there are only 7 waves on a CU: the loads of the NEXT batch of positions (of the next sub-step / plane
+// at the end of one) are issued three batches (18 KB per wave) before they are multiplied: with one batch in flight the
+// kernel ran at waves x batch / HBM latency = 5 TB/s whatever else was done to it.
+//
+// window[place] += v for the 64 lanes of the wave (64 distinct places) is a plain read - add - write, not ds_add_f64: the LDS
+// adds fp64 atomics at about one lane per clock, which alone would take as long as the whole product.  It is safe because
+// the wave is the only one on its window and its LDS operations complete in order -- but the places of DIFFERENT lanes
+// overlap between positions (lane i at dx + 1 is lane i + 1 at dx), so the order of these accesses must stay what the
+// program says, whatever the compiler can prove about one lane's own addresses: a compiler barrier after every group
+// (`volatile` would do as well but makes the backend wait for ALL outstanding loads at every access).  The members of a
+// group (see sg_lay) go to different planes of the ring, their reads are issued together and then their writes.
+struct sg_ctx {
+  int row, lb;
+  double xi;
+  const sg_d2 *v;
+};
+
+template <int P>
+__global__ void __launch_bounds__(64, 2)      // (two waves per SIMD: 256 registers; the windows allow 7 waves per CU)
+    k_symgrid_spmv(sg_dev G, const sg_d2 *__restrict__ val, const double *__restrict__ x, double *__restrict__ stage,
+                   int64_t nrows, int64_t nwaves, const double *__restrict__ gate, double gate_tol) {
+  typedef sg_c<P> C;
+  typedef sg_lay<P> Y;
+  constexpr int Wx = C::Wx, W = C::W, GB = Y::GBMAX, NB = Y::NBATCH;
+  __shared__ double acc[(P + 1) * W];
+  __shared__ unsigned short tab[SG_TAB];
+  if (gate && !(*gate > gate_tol)) return;
+  const int lane = threadIdx.x;
+  const int64_t L = tg_xcd_block(blockIdx.x, nwaves);
+  if (L >= nwaves) return;
+  const int c = (int)(L % G.nch), patch = (int)(L / G.nch);
+  const int a = patch % G.npx, b = patch / G.npx;
+  const int xa = G.x0[a], pxv = G.x0[a + 1] - xa, ya = G.y0[b], pyv = G.y0[b + 1] - ya;
+  const int za = G.z0[c], zb = G.z0[c + 1];
+  const int cnt = pxv * pyv, msub = (cnt + 63) >> 6;
+  for (int t = lane; t < cnt; t += 64) {
+    const int ly = t / pxv;
+    tab[t] = (unsigned short)((ly << 8) | (t - ly * pxv));
+  }
+  for (int e = lane; e < (P + 1) * W; e += 64) acc[e] = 0.0;
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t xr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, (unsigned)(nrows * 8), 0x00020000);
+  const int n0 = G.n0, n01 = G.n0 * G.n1;
+  double *st = stage + ((int64_t)patch * G.nch + c) * (int64_t)(G.czmax + P) * W;
+  const sg_d2 *vp = val + (int64_t)patch * G.n2 * G.m * (int64_t)(C::NG * 64) + lane;
+
+  auto ctx_of = [&](int z, int sub) {
+    // (lanes beyond the patch in its last sub-step: stored zeros times the x of point 0; a look-ahead beyond the last
+    // plane of the grid re-reads the last plane and is not used)
+    sg_ctx k;
+    const int t = sub * 64 + lane, zc = min(z, G.n2 - 1);
+    const int tl = t < cnt ? tab[t] : 0, ly = tl >> 8, lx = tl & 255;
+    k.row = (zc * G.n1 + ya + ly) * n0 + xa + lx;
+    k.lb = ly * Wx + lx;
+    k.v = vp + ((int64_t)zc * G.m + sub) * (C::NG * 64);
+    k.xi = x[k.row];
+    return k;
+  };
+  // batches of values / of x held in registers.  The same depth for both: vmcnt counts loads in the order of issue, so
+  // waiting for an x gather issued one batch ahead would also wait for every value load issued before it
+  constexpr int VD = 4, XD = 4;
+  sg_d2 vv[VD][GB];
+  double xx[XD][2 * GB];
+  // loads of batch BT (compile-time) of the row block k: the values (the HBM stream, VD - 1 batches ahead) ...
+  auto issue_v = [&](const sg_ctx &k, auto btc) {
+    constexpr int BT = decltype(btc)::value, b0 = Y::bstart(BT), b1 = Y::bstart(BT + 1);
+#pragma unroll
+    for (int j = 0; j < (b1 - b0) / 2; j++) vv[BT % VD][j] = __builtin_nontemporal_load(k.v + (b0 / 2 + j) * 64);
+  };
+  // ... and the x they multiply (cache hits mostly)
+  auto issue_x = [&](const sg_ctx &k, auto btc) {
+    constexpr int BT = decltype(btc)::value, b0 = Y::bstart(BT), b1 = Y::bstart(BT + 1);
+#pragma unroll
+    for (int l = 0; l < b1 - b0; l++) {
+      constexpr int Pc = P;
+      const int pos = b0 + l < Y::NP ? Y::pos(b0 + l) : 0;
+      if (pos > 0) {
+        const int off = sg_dx(Pc, pos) + n0 * sg_dy(Pc, pos) + n01 * sg_dz(Pc, pos);
+        xx[BT % XD][l] =
+            __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xr, (unsigned)(k.row + off) * 8u, 0, 0));
+      }
+    }
+  };
+  sg_ctx cur = ctx_of(za, 0);
+  sg_each(std::make_integer_sequence<int, VD - 1>{}, [&](auto btc) {
+    issue_v(cur, btc);
+    issue_x(cur, btc);
+  });
+  for (int z = za; z < zb; z++) {
+    int so[P + 1];
+#pragma unroll
+    for (int d = 0; d <= P; d++) so[d] = ((z + d) % (P + 1)) * W;
+    for (int sub = 0; sub < msub; sub++) {
+      const sg_ctx nxt = (sub + 1 < msub) ? ctx_of(z, sub + 1) : ctx_of(z + 1, 0);
+      double sum = 0.0;
+      sg_each(std::make_integer_sequence<int, NB>{}, [&](auto btc) {
+        constexpr int BT = decltype(btc)::value;
+        if constexpr (BT + VD - 1 < NB)
+          issue_v(cur, std::integral_constant<int, BT + VD - 1>{});
+        else
+          issue_v(nxt, std::integral_constant<int, BT + VD - 1 - NB>{});
+        if constexpr (BT + XD - 1 < NB)
+          issue_x(cur, std::integral_constant<int, BT + XD - 1>{});
+        else
+          issue_x(nxt, std::integral_constant<int, BT + XD - 1 - NB>{});
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int b0 = Y::bstart(BT), b1 = Y::bstart(BT + 1);
+        constexpr int gs = b0 < Y::NA ? P : P + 1, ng = (b1 - b0 + gs - 1) / gs;
+#pragma unroll
+        for (int gq = 0; gq < ng; gq++) {
+          double r[gs], cc[gs];
+          int idx[gs];
+#pragma unroll
+          for (int t = 0; t < gs; t++) {
+            constexpr int Pc = P;
+            const int kk = b0 + gq * gs + t, l = kk - b0;
+            const int pos = (kk < b1 && kk < Y::NP) ? Y::pos(kk) : -1;
+            const double vq = (l & 1) ? vv[BT % VD][l >> 1].y : vv[BT % VD][l >> 1].x;
+            if (pos == 0) {
+              sum += vq * cur.xi;
+            } else if (pos > 0) {
+              sum += vq * xx[BT % XD][l];
+              idx[t] = so[sg_dz(Pc, pos)] + cur.lb + (sg_dy(Pc, pos) + P) * Wx + sg_dx(Pc, pos) + P;
+              r[t] = acc[idx[t]];
+              cc[t] = vq * cur.xi;
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < gs; t++) {
+            const int kk = b0 + gq * gs + t;
+            const int pos = (kk < b1 && kk < Y::NP) ? Y::pos(kk) : -1;
+            if (pos > 0) acc[idx[t]] = r[t] + cc[t];
+          }
+          asm volatile("" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      acc[so[0] + cur.lb + P * Wx + P] += sum;
+      asm volatile("" ::: "memory");
+      cur = nxt;
+    }
+    __syncthreads();
+    // plane z is complete as far as this wave goes: out to the staging array, slot free for plane z + P + 1
+    double *sp = st + (int64_t)(z - za) * W;
+    for (int e = lane; e < W; e += 64) {
+      sp[e] = acc[so[0] + e];
+      acc[so[0] + e] = 0.0;
+    }
+    __syncthreads();
+  }
+  // what was scattered beyond the chunk: planes zb .. zb + P - 1 (the next chunk's first planes)
+#pragma unroll
+  for (int d = 0; d < P; d++) {
+    const int z = zb + d;
+    if (z >= G.n2) break;
+    const int s0 = (z % (P + 1)) * W;
+    double *sp = st + (int64_t)(z - za) * W;
+    for (int e = lane; e < W; e += 64) sp[e] = acc[s0 + e];
+  }
+}
+
+// y[i] = sum of the windows that cover point i, in a fixed order
+template <int P>
+__global__ void __launch_bounds__(256)
+    k_symgrid_combine(sg_dev G, const double *__restrict__ stage, double *__restrict__ y, int64_t nrows,
+                      const double *__restrict__ gate, double gate_tol) {
+  typedef sg_c<P> C;
+  constexpr int Wx = C::Wx, W = C::W;
+  if (gate && !(*gate > gate_tol)) return;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t cstride = (int64_t)(G.czmax + P) * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nrows; i += stride) {
+    const int ix = (int)(i % G.n0);
+    const int64_t q = i / G.n0;
+    const int iy = (int)(q % G.n1), iz = (int)(q / G.n1);
+    const int a0 = G.px_of[ix], b0 = G.py_of[iy], c0 = G.pc_of[iz];
+    const int alo = (a0 > 0 && ix - G.x0[a0] < P) ? a0 - 1 : a0;
+    const int ahi = (a0 + 1 < G.npx && G.x0[a0 + 1] - ix <= P) ? a0 + 1 : a0;
+    const int blo = (b0 > 0 && iy - G.y0[b0] < P) ? b0 - 1 : b0;
+    const int bhi = (b0 + 1 < G.npy && G.y0[b0 + 1] - iy <= P) ? b0 + 1 : b0;
+    const int clo = (c0 > 0 && iz - G.z0[c0] < P) ? c0 - 1 : c0;
+    double s = 0.0;
+    for (int c = clo; c <= c0; c++)
+      for (int b = blo; b <= bhi; b++)
+        for (int a = alo; a <= ahi; a++) {
+          const int64_t pc = (int64_t)(b * G.npx + a) * G.nch + c;
+          s += stage[pc * cstride + (int64_t)(iz - G.z0[c]) * W + (iy - G.y0[b] + P) * Wx + (ix - G.x0[a] + P)];
+        }
+    y[i] = s;
+  }
+}
+
+// ---- check of a finished plan against the CSR product
+__global__ void k_symgrid_random(double *x, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull;
+    z ^= z >> 31;
+    z *= 0xD6E8FEB86659FD93ull;
+    z ^= z >> 29;
+    x[i] = (double)(long long)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;   // (-1, 1)
+  }
+}
+__global__ void k_symgrid_compare(const double *__restrict__ y1, const double *__restrict__ y2, int64_t n,
+                                  unsigned long long *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double d = 0.0, m = 0.0;
+  bool nan = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double u = y1[i], v = y2[i];
+    nan |= !(fabs(u - v) <= 1.7e308);
+    d = fmax(d, fabs(u - v));
+    m = fmax(m, fabs(u));
+  }
+  if (nan) d = 1.7e308;
+  // (non-negative doubles compare like their bit patterns)
+  atomicMax(out, (unsigned long long)__double_as_longlong(d));
+  atomicMax(out + 1, (unsigned long long)__double_as_longlong(m));
+}
+
+template <int P>
+static void sg_launch_convert(const tg_symgrid_s *s, tg_csr_s *a, int *fail) {
+  const int64_t nblk = (int64_t)s->npx * s->npy * s->n2 * s->m;
+  hipLaunchKernelGGL(k_symgrid_convert<P>, dim3((unsigned)(nblk * 2)), dim3(256), 0, g_tg.stream, sg_view(s),
+                     a->rowptr, a->col, a->val, s->val, nblk, fail);
+}
+template <int P>
+static void sg_launch_spmv(const tg_symgrid_s *s, const double *x, double *y, int64_t nrows, const double *gate,
+                           double tol) {
+  const int64_t nw = (int64_t)s->npx * s->npy * s->nch;
+  hipLaunchKernelGGL(k_symgrid_spmv<P>, dim3((unsigned)(tg_cdiv(nw, 8) * 8)), dim3(64), 0, g_tg.stream, sg_view(s),
+                     s->val, x, s->stage, nrows, nw, gate, tol);
+  hipLaunchKernelGGL(k_symgrid_combine<P>, dim3((unsigned)std::min<int64_t>(tg_cdiv(nrows, 256), (int64_t)g_tg.num_cu * 16)),
+                     dim3(256), 0, g_tg.stream, sg_view(s), s->stage, y, nrows, gate, tol);
+}
+
+// y = K x (x, y: nrows doubles; x is NOT addressed through a halo: one rank only)
+int tg_symgrid_spmv(tg_symgrid_s *s, const double *x, double *y, const double *gate, double gate_tol) {
+  const int64_t nrows = (int64_t)s->n0 * s->n1 * s->n2;
+  switch (s->P) {
+    case 1: sg_launch_spmv<1>(s, x, y, nrows, gate, gate_tol); break;
+    case 2: sg_launch_spmv<2>(s, x, y, nrows, gate, gate_tol); break;
+    default: sg_launch_spmv<3>(s, x, y, nrows, gate, gate_tol); break;
+  }
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// the longest row (the first of them): an interior row of a box stencil, if there is one
+__global__ void k_symgrid_longest(const int64_t *__restrict__ rowptr, int64_t n, unsigned long long *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long best = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const unsigned long long len = (unsigned long long)(rowptr[i + 1] - rowptr[i]);
+    const unsigned long long key = (len << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+    best = best > key ? best : key;
+  }
+  atomicMax(out, best);
+}
+
+// P, n0, n1, n2 from the column offsets of one interior row ((2P+1)^3 entries, the diagonal in the middle)
+static int sg_detect(tg_csr_s *a, int *Pout, int *n0o, int *n1o, int *n2o, bool *found) {
+  *found = false;
+  const int64_t n = a->nrows;
+  unsigned long long *o = (unsigned long long *)(g_tg.scratch + 96);
+  unsigned long long key = 0;
+  TG_CHECK_HIP(hipMemcpyAsync(o, &key, sizeof(key), hipMemcpyHostToDevice, g_tg.stream));
+  hipLaunchKernelGGL(k_symgrid_longest, dim3(tg_grid_1d(n, 256)), dim3(256), 0, g_tg.stream, a->rowptr, n, o);
+  TG_LAUNCH_CHECK();
+  TG_CHECK_HIP(hipMemcpyAsync(&key, o, sizeof(key), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  const int64_t len = (int64_t)(key >> 32), r = (int64_t)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+  int P = 0;
+  for (int p = 1; p <= 3; p++)
+    if (len == (int64_t)(2 * p + 1) * (2 * p + 1) * (2 * p + 1)) P = p;
+  if (!P || r < 0 || r >= n) return 0;
+  int64_t e0 = 0;
+  TG_CHECK_HIP(hipMemcpyAsync(&e0, a->rowptr + r, sizeof(e0), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  std::vector<int32_t> c((size_t)len);
+  TG_CHECK_HIP(hipMemcpyAsync(c.data(), a->col + e0, sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  const int S = 2 * P + 1, LC = (S * S * S - 1) / 2;
+  if ((int64_t)c[(size_t)LC] != r) return 0;
+  const int64_t n0 = (int64_t)c[(size_t)(LC + P + 1)] - r + P;                 // (dx, dy, dz) = (-P, 1, 0)
+  const int64_t o1 = (int64_t)c[(size_t)((P + 1) * S * S)] - r;                // (-P, -P, 1)
+  if (n0 < 2 * P + 1) return 0;
+  const int64_t n01 = o1 + P * n0 + P;
+  if (n01 <= 0 || n01 % n0 || n % n01) return 0;
+  for (int l = 0; l < S * S * S; l++) {
+    const int dx = l % S - P, dy = (l / S) % S - P, dz = l / (S * S) - P;
+    if ((int64_t)c[(size_t)l] - r != dx + n0 * dy + n01 * dz) return 0;
+  }
+  *Pout = P, *n0o = (int)n0, *n1o = (int)(n01 / n0), *n2o = (int)(n / n01);
+  *found = true;
+  return 0;
+}
+
+// Builds the plan for a square matrix held entirely by this rank; *out stays nullptr when the matrix is not a
+// symmetric box stencil on a 3-D grid (or there is no room for the copy).  verify: compare with the CSR product.
+int tg_symgrid_build(tg_csr_s *a, int verify, tg_symgrid_s **out) {
+  *out = nullptr;
+  const bool trace = getenv("TIGAR_TRACE") != nullptr;
+  if (a->rowcnt || a->view || a->nrows != a->ncols || a->nrows < 1024 || a->nrows >= (int64_t)1 << 28) return 0;
+  int P = 0, n0 = 0, n1 = 0, n2 = 0;
+  bool found = false;
+  TG_TRY(sg_detect(a, &P, &n0, &n1, &n2, &found));
+  if (!found || n0 < 16 || n1 < 16 || n2 < 2 * P + 2) {
+    if (trace) fprintf(stderr, "[trace] symgrid: no 3-D box stencil found (%lld rows)\n", (long long)a->nrows);
+    return 0;
+  }
+  tg_symgrid_s *s = new tg_symgrid_s;
+  s->P = P, s->n0 = n0, s->n1 = n1, s->n2 = n2;
+  s->npx = (n0 + SG_PX - 1) / SG_PX;
+  s->npy = (n1 + SG_PY - 1) / SG_PY;
+  const int64_t npatch = (int64_t)s->npx * s->npy;
+  {
+    int want = getenv("TIGAR_SYMGRID_CHUNKS") ? atoi(getenv("TIGAR_SYMGRID_CHUNKS")) : 0;
+    if (want <= 0) want = (int)tg_cdiv((int64_t)g_tg.num_cu * 14, npatch);
+    const int minplanes = std::max(P, 4);
+    s->nch = std::max(1, std::min(want, n2 / minplanes));
+  }
+  std::vector<int32_t> h;
+  auto split = [&](int n, int parts) {
+    for (int k = 0; k <= parts; k++) h.push_back((int32_t)((int64_t)k * n / parts));
+  };
+  const size_t ox = 0;
+  split(n0, s->npx);
+  const size_t oy = h.size();
+  split(n1, s->npy);
+  const size_t oz = h.size();
+  split(n2, s->nch);
+  auto owner = [&](size_t o, int parts, int n) {
+    int k = 0;
+    for (int i = 0; i < n; i++) {
+      while (k + 1 < parts && h[o + k + 1] <= i) k++;
+      h.push_back(k);
+    }
+  };
+  owner(ox, s->npx, n0);
+  owner(oy, s->npy, n1);
+  owner(oz, s->nch, n2);
+  int cmax = 0;
+  for (int x = 0; x < s->npx; x++)
+    for (int y = 0; y < s->npy; y++) cmax = std::max(cmax, (h[ox + x + 1] - h[ox + x]) * (h[oy + y + 1] - h[oy + y]));
+  s->m = (cmax + 63) / 64;
+  for (int c = 0; c < s->nch; c++) s->czmax = std::max(s->czmax, h[oz + c + 1] - h[oz + c]);
+  const int NG = P == 1 ? sg_c<1>::NG : P == 2 ? sg_c<2>::NG : sg_c<3>::NG;
+  const int W = P == 1 ? sg_c<1>::W : P == 2 ? sg_c<2>::W : sg_c<3>::W;
+  s->val_bytes = npatch * n2 * s->m * (int64_t)NG * 64 * 16;
+  s->stage_bytes = npatch * s->nch * (int64_t)(s->czmax + P) * W * 8;
+  s->rows_stored = a->nrows;
+  int rc = 0;
+  bool declined = false;
+  do {
+    if ((rc = tg_dmalloc(&s->tabs, (int64_t)h.size()))) break;
+    if ((rc = tg_h2d_staged(s->tabs, h.data(), h.size() * sizeof(int32_t)))) break;
+    void *p = nullptr;
+    if (tg_dmalloc_bytes(&p, (size_t)s->val_bytes)) {
+      declined = true;      // no room: not an error
+      break;
+    }
+    s->val = (sg_d2 *)p;
+    if (tg_dmalloc_bytes(&p, (size_t)s->stage_bytes)) {
+      declined = true;
+      break;
+    }
+    s->stage = (double *)p;
+    int *ctl = (int *)(g_tg.scratch + 64);
+    int hflag[2] = {0, 0};
+    if (hipMemcpyAsync(ctl, hflag, sizeof(hflag), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess) {
+      rc = 1;
+      break;
+    }
+    switch (P) {
+      case 1: sg_launch_convert<1>(s, a, ctl); break;
+      case 2: sg_launch_convert<2>(s, a, ctl); break;
+      default: sg_launch_convert<3>(s, a, ctl); break;
+    }
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(hflag, ctl, sizeof(hflag), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
+        hipStreamSynchronize(g_tg.stream) != hipSuccess) {
+      tg_set_error("tg_symgrid_build: conversion failed to run");
+      rc = 1;
+      break;
+    }
+    if (hflag[0]) {
+      if (trace) fprintf(stderr, "[trace] symgrid: a row is not the box stencil (P=%d, %d x %d x %d): declined\n", P, n0, n1, n2);
+      declined = true;
+      break;
+    }
+    if (verify) {
+      double *t = nullptr;
+      if ((rc = tg_dmalloc(&t, 3 * a->nrows))) break;
+      double *x = t, *y1 = t + a->nrows, *y2 = y1 + a->nrows;
+      unsigned long long *o = (unsigned long long *)(g_tg.scratch + 80);
+      unsigned long long ho[2] = {0, 0};
+      const int vg = tg_grid_1d(a->nrows, 256);
+      hipLaunchKernelGGL(k_symgrid_random, dim3(vg), dim3(256), 0, g_tg.stream, x, a->nrows);
+      rc = tg_spmv_plan(a);
+      if (!rc) rc = tg_spmv_raw(a, x, 0, a->ncols - 1, y1);
+      if (!rc) rc = tg_symgrid_spmv(s, x, y2, nullptr, 0.0);
+      if (!rc && hipMemcpyAsync(o, ho, sizeof(ho), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess) rc = 1;
+      if (!rc) {
+        hipLaunchKernelGGL(k_symgrid_compare, dim3(vg), dim3(256), 0, g_tg.stream, y1, y2, a->nrows, o);
+        if (hipMemcpyAsync(ho, o, sizeof(ho), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
+            hipStreamSynchronize(g_tg.stream) != hipSuccess)
+          rc = 1;
+      }
+      tg_dfree(t);
+      if (rc) break;
+      double d, mx;
+      memcpy(&d, &ho[0], 8);
+      memcpy(&mx, &ho[1], 8);
+      if (trace) fprintf(stderr, "[trace] symgrid: check vs CSR product: max |diff| %.3e, max |y| %.3e\n", d, mx);
+      if (!(d <= 1e-10 * mx)) {
+        if (trace) fprintf(stderr, "[trace] symgrid: the matrix is not symmetric (or the copy is wrong): declined\n");
+        declined = true;
+        break;
+      }
+    }
+  } while (0);
+  if (rc || declined) {
+    if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+    tg_symgrid_free(s);
+    return rc;
+  }
+  if (trace)
+    fprintf(stderr, "[trace] symgrid: P=%d grid %d x %d x %d, %d x %d patches, %d chunks, %d sub-steps, values %.2f GB, staging %.2f GB\n",
+            P, n0, n1, n2, s->npx, s->npy, s->nch, s->m, s->val_bytes / 1e9, s->stage_bytes / 1e9);
+  *out = s;
+  return 0;
+}
+
+void tg_symgrid_info(const tg_symgrid_s *s, int64_t *val_bytes, int64_t *stage_bytes) {
+  const int NG = s->P == 1 ? sg_c<1>::NG : s->P == 2 ? sg_c<2>::NG : sg_c<3>::NG;
+  if (val_bytes) *val_bytes = s->rows_stored * NG * 16;
+  if (stage_bytes) *stage_bytes = s->stage_bytes;
+}
+
+/* Plans the half-storage product for a matrix and runs y = K x with it (tests, bench accounting): *accepted = 0 when the
+ * matrix is not a symmetric 3-D box stencil.  value_bytes: what one product reads of K; staging_bytes: window staging. */
+extern "C" int tg_spmv_symgrid(tg_csr_t a, tg_vec_t x, tg_vec_t y, int *accepted, int64_t *value_bytes,
+                               int64_t *staging_bytes) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(a && accepted, "null argument to tg_spmv_symgrid");
+  TG_REQUIRE_CANONICAL(a);
+  *accepted = 0;
+  tg_symgrid_s *s = nullptr;
+  TG_TRY(tg_symgrid_build(a, 1, &s));
+  if (!s) return 0;
+  int rc = 0;
+  if (x && y) {
+    if (x->n != a->ncols || y->n != a->nrows) {
+      tg_set_error("tg_spmv_symgrid: vector sizes %lld / %lld for a %lld x %lld matrix", (long long)x->n, (long long)y->n,
+                   (long long)a->nrows, (long long)a->ncols);
+      rc = 2;
+    } else {
+      rc = tg_symgrid_spmv(s, x->d, y->d, nullptr, 0.0);
+    }
+  }
+  *accepted = 1;
+  tg_symgrid_info(s, value_bytes, staging_bytes);
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  tg_symgrid_free(s);
+  return rc;
+}
