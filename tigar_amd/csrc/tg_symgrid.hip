@@ -12,8 +12,8 @@
 // so a product moves HALF the bytes.  The second line is a scatter; what makes it cheap is the geometry, not the CSR
 // arrays: the grid is cut into patches of at most 24 x 16 points in (x, y), a wave owns one patch and walks it plane by
 // plane along z.  Everything the wave scatters lands in the window (patch + P points on every side) of the current and
-// the next P planes, which it keeps in LDS as a ring of P + 1 planes (21 KB for P = 3) and feeds with ds_add_f64 -- one
-// wave per window, LDS operations of a wave complete in order, so the sums are the same bit for bit in every run.  When
+// the next P planes, which it keeps in LDS as a ring of P + 1 planes (21 KB for P = 3) and adds to by read - add - write --
+// one wave per window, LDS operations of a wave complete in order, so the sums are the same bit for bit in every run.  When
 // a plane is finished its window goes to a staging array (1 % of the value bytes); a second small kernel adds, for
 // every row, the windows that cover it (its own patch, up to 3 x 3 neighbours in the plane, the previous z chunk) in a
 // fixed order.  No global atomics.
@@ -69,7 +69,7 @@ struct sg_lay {
     return i < N0 ? NA + i * (P + 1) + (dz == 0 ? P : dz - 1) : (i - N0) * P + (dz - 1);
   }
   // batches: storage indices [bstart(b), bstart(b + 1)), even boundaries on group boundaries; their number is a multiple
-  // of 4 (the product kernel keeps 4 batches of values and 2 of x in registers, buffer = batch mod 4 / mod 2)
+  // of 4 (the product kernel keeps 4 batches of values and of x in registers, buffer = batch mod 4)
   static constexpr int NBATCH = P == 3 ? 24 : P == 2 ? 12 : 4;
   __host__ __device__ static constexpr int bstart(int b) {
     return P == 3   ? (b <= 12 ? 6 * b : b < 24 ? 72 + 8 * (b - 12) : 172)
@@ -370,34 +370,36 @@ __global__ void __launch_bounds__(64, 2)      // (two waves per SIMD: 256 regist
   }
 }
 
-// y[i] = sum of the windows that cover point i, in a fixed order
+// y[i] = sum of the windows that cover point i, in a fixed order.  One workgroup per grid line (iy, iz): which patch rows
+// and chunks cover the line is wave-uniform, a thread only looks up the patch column of its ix.
 template <int P>
 __global__ void __launch_bounds__(256)
-    k_symgrid_combine(sg_dev G, const double *__restrict__ stage, double *__restrict__ y, int64_t nrows,
+    k_symgrid_combine(sg_dev G, const double *__restrict__ stage, double *__restrict__ y, int64_t nlines,
                       const double *__restrict__ gate, double gate_tol) {
   typedef sg_c<P> C;
   constexpr int Wx = C::Wx, W = C::W;
   if (gate && !(*gate > gate_tol)) return;
-  const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t cstride = (int64_t)(G.czmax + P) * W;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nrows; i += stride) {
-    const int ix = (int)(i % G.n0);
-    const int64_t q = i / G.n0;
-    const int iy = (int)(q % G.n1), iz = (int)(q / G.n1);
-    const int a0 = G.px_of[ix], b0 = G.py_of[iy], c0 = G.pc_of[iz];
-    const int alo = (a0 > 0 && ix - G.x0[a0] < P) ? a0 - 1 : a0;
-    const int ahi = (a0 + 1 < G.npx && G.x0[a0 + 1] - ix <= P) ? a0 + 1 : a0;
+  for (int64_t line = blockIdx.x; line < nlines; line += gridDim.x) {
+    const int iy = (int)(line % G.n1), iz = (int)(line / G.n1);
+    const int b0 = G.py_of[iy], c0 = G.pc_of[iz];
     const int blo = (b0 > 0 && iy - G.y0[b0] < P) ? b0 - 1 : b0;
     const int bhi = (b0 + 1 < G.npy && G.y0[b0 + 1] - iy <= P) ? b0 + 1 : b0;
     const int clo = (c0 > 0 && iz - G.z0[c0] < P) ? c0 - 1 : c0;
-    double s = 0.0;
-    for (int c = clo; c <= c0; c++)
-      for (int b = blo; b <= bhi; b++)
-        for (int a = alo; a <= ahi; a++) {
-          const int64_t pc = (int64_t)(b * G.npx + a) * G.nch + c;
-          s += stage[pc * cstride + (int64_t)(iz - G.z0[c]) * W + (iy - G.y0[b] + P) * Wx + (ix - G.x0[a] + P)];
+    double *yl = y + line * G.n0;
+    for (int ix = threadIdx.x; ix < G.n0; ix += 256) {
+      const int a0 = G.px_of[ix];
+      const int alo = (a0 > 0 && ix - G.x0[a0] < P) ? a0 - 1 : a0;
+      const int ahi = (a0 + 1 < G.npx && G.x0[a0 + 1] - ix <= P) ? a0 + 1 : a0;
+      double s = 0.0;
+      for (int c = clo; c <= c0; c++)
+        for (int b = blo; b <= bhi; b++) {
+          const double *sb = stage + ((int64_t)(b * G.npx) * G.nch + c) * cstride + (int64_t)(iz - G.z0[c]) * W +
+                             (iy - G.y0[b] + P) * Wx + P;
+          for (int a = alo; a <= ahi; a++) s += sb[(int64_t)a * G.nch * cstride + (ix - G.x0[a])];
         }
-    y[i] = s;
+      yl[ix] = s;
+    }
   }
 }
 
@@ -441,8 +443,9 @@ static void sg_launch_spmv(const tg_symgrid_s *s, const double *x, double *y, in
   const int64_t nw = (int64_t)s->npx * s->npy * s->nch;
   hipLaunchKernelGGL(k_symgrid_spmv<P>, dim3((unsigned)(tg_cdiv(nw, 8) * 8)), dim3(64), 0, g_tg.stream, sg_view(s),
                      s->val, x, s->stage, nrows, nw, gate, tol);
-  hipLaunchKernelGGL(k_symgrid_combine<P>, dim3((unsigned)std::min<int64_t>(tg_cdiv(nrows, 256), (int64_t)g_tg.num_cu * 16)),
-                     dim3(256), 0, g_tg.stream, sg_view(s), s->stage, y, nrows, gate, tol);
+  const int64_t nlines = (int64_t)s->n1 * s->n2;
+  hipLaunchKernelGGL(k_symgrid_combine<P>, dim3((unsigned)std::min<int64_t>(nlines, (int64_t)g_tg.num_cu * 64)), dim3(256), 0,
+                     g_tg.stream, sg_view(s), s->stage, y, nlines, gate, tol);
 }
 
 // y = K x (x, y: nrows doubles; x is NOT addressed through a halo: one rank only)

@@ -20,6 +20,10 @@ headline)
   stats cfg3 python $R/bench.py --steps 5 --warmup 1 $W
   pmc cfg3 python $R/bench.py --steps 2 --warmup 1 $W
   ;;
+mappedbench)
+  timeout 900 python bench.py --geometry volume --steps 3 --warmup 1 --no-cpu-baseline --companion 0 --live-traffic 0 > $O/r5_bench_cfg3_mapped_geometry.json 2> $O/r5_bench_cfg3_mapped_geometry.log
+  stats cfg3_mapped python $R/bench.py --geometry volume --steps 2 --warmup 1 $W
+  ;;
 mapped)
   timeout 900 python bench.py --geometry volume --steps 3 --warmup 1 --no-cpu-baseline --companion 0 --live-traffic 0 > $O/r5_bench_cfg3_mapped_geometry.json 2> $O/r5_bench_cfg3_mapped_geometry.log
   stats cfg3_mapped python $R/bench.py --geometry volume --steps 2 --warmup 1 $W
