@@ -309,7 +309,7 @@ def run(args, wl, d, p, nel):
     sell_classes, sell_padded = K.spmv_sell(True)         # which product kernel the solver used
     K.spmv_sell(False)
     symgrid_solves = dev.prof_get(7)[1]                   # CG solves on the half-storage copy (csrc/tg_symgrid.hip)
-    symgrid = K.mult_symgrid()[1] if symgrid_solves > 0 else None
+    symgrid = K.mult_symgrid(row0=(dcomm.g0 if dcomm is not None else 0))[1] if symgrid_solves > 0 else None
     its = solver.last.get("iterations", 0) if solver.last else 0
     mean_stages = {k: float(np.mean(v)) for k, v in stages.items()}
 

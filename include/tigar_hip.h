@@ -215,10 +215,14 @@ int tg_spmv_sell(tg_csr_t a, int enable, int *nclasses, int64_t *padded);
  * the reference hands K to PETSc's KSPCG, tIGAr/common.py:1255-1258, whose premise is a symmetric operator): the diagonal
  * and the entries above it are stored once (172 of 343 per row for p = 3) and used for the row and for the transposed
  * entry; the scatter goes through a ring of LDS windows per (x, y) patch walked along z, deterministically (no global
- * atomics).  This entry point plans the copy for `a`, checks it against the CSR product on a pseudo-random vector, and,
- * with x and y given, computes y = a x with it.  *accepted = 0: `a` has no such structure or is not symmetric (nothing
+ * atomics).  `a` is the whole matrix (row0 = 0) or the block of rows [row0, row0 + nrows) a rank holds -- whole planes of
+ * the grid, all columns: rows in its first planes also take their entries below the block from the CSR arrays (the
+ * previous rank stores those as ITS upper triangle), what is scattered beyond the block is dropped; the solve does this
+ * per z slab after the usual halo exchange of the vector.  This entry point plans the copy for `a`, checks it against the
+ * CSR product on a pseudo-random vector, and, with x (all columns) and y given, computes y = a x with it.  *accepted = 0: `a` has no such structure or is not symmetric (nothing
  * is computed).  value_bytes / staging_bytes (may be NULL): bytes of K one product reads / size of the window staging. */
-int tg_spmv_symgrid(tg_csr_t a, tg_vec_t x, tg_vec_t y, int *accepted, int64_t *value_bytes, int64_t *staging_bytes);
+int tg_spmv_symgrid(tg_csr_t a, int64_t row0, tg_vec_t x, tg_vec_t y, int *accepted, int64_t *value_bytes,
+                    int64_t *staging_bytes);
 /* Y = A X for k <= 4 right-hand sides (cpFuncs = M_control * P, tIGAr/common.py:367-380);
  * X, Y are column-major host arrays. */
 int tg_spmm_host(tg_csr_t a, const double *X, int k, double *Y);

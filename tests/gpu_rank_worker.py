@@ -56,6 +56,7 @@ def main():
     U = spline.solveLinearSystem(K, rhs, u)
     its1 = solver.last["iterations"]
     overlapped = dev.prof_get(1)[1]                      # products that ran beside their halo exchange
+    symgrid = dev.prof_get(7)[1]                         # CG solves on the half-storage copy of this rank's z slab
     host_waits = dev.prof_get(4)[1]                      # host waits of the communicator inside the exchanges of the solve
     resnorm = solver.last.get("residual_norm", np.nan)
     # second solve from the converged state: must stop at once (non-zero initial guess path with halo)
@@ -87,7 +88,7 @@ def main():
              comm=np.array([rank_r, world_r, dev.Comm.KINDS.index(kind)]), cp0=cp0,
              U2=U2.get_local(), overlapped=np.array([overlapped]), host_waits=np.array([host_waits]),
              resnorm=np.array([resnorm]), ladder_U=np.array(ladder_U), ladder_res=np.array(ladder_res),
-             ladder_its=np.array(ladder_its), tensor_walks=np.array([tensor_walks]))
+             ladder_its=np.array(ladder_its), tensor_walks=np.array([tensor_walks]), symgrid=np.array([symgrid]))
     comm.barrier()
 
 

@@ -102,6 +102,20 @@ def test_host_staged_ranks_sharing_one_gpu(tmp_path, d, p, nel, method, world):
     _compare(parts, ref, world, "host")
 
 
+@pytest.mark.parametrize("kind,d,p,nel,world", [("host", 3, 2, 24, 2), ("ipc", 3, 3, 20, 2), ("ipc", 3, 2, 24, 3)])
+def test_half_storage_product_on_several_ranks(tmp_path, kind, d, p, nel, world):
+    """CG on z slabs with every rank multiplying by the half-storage copy of ITS rows (csrc/tg_symgrid.hip: entries above
+    the slab gathered, not scattered; entries below it taken from the CSR rows of the first planes) after the halo exchange
+    of the direction vector: the checks of the sliced copy, and the same iteration count"""
+    ref = _single(d, p, nel, "cg")
+    parts = _run_ranks(tmp_path, world, kind, d, p, nel, "cg", 30700 + 41 * (p * 10 + world) + (kind == "ipc"),
+                       {"TIGAR_SPMV_SYM": "2", "TIGAR_KSP_PERSISTENT": "0"})
+    _compare(parts, ref, world, kind)
+    for z in parts:
+        assert int(z["symgrid"][0]) >= 1
+        assert int(z["overlapped"][0]) >= int(z["its"][0])     # (all z chunks but the last beside the halo exchange)
+
+
 def test_products_beside_the_halo_exchange_change_nothing(tmp_path):
     """CG computes the rows without halo columns while the halo of the direction vector travels (tg_comm_halo_begin /
     _end on the communicator's stream); every row is summed by the same kernel in the same order either way, so the

@@ -60,6 +60,37 @@ def test_half_storage_product_matches_scipy(dev, shape, reach):
     assert np.array_equal(y.get_local().view(np.int64), y2.get_local().view(np.int64))
 
 
+@pytest.mark.parametrize("shape,reach,cuts", [((20, 18, 24), 2, (0, 8, 16, 24)), ((26, 17, 30), 3, (0, 9, 19, 30)),
+                                              ((16, 33, 12), 1, (0, 4, 8, 12))])
+def test_half_storage_product_of_a_z_slab(dev, shape, reach, cuts):
+    """several ranks: a rank holds whole planes [z0, z1) of the grid (all columns) and x with the halo planes of its
+    neighbours.  Its rows' entries ABOVE the slab are multiplied but not scattered (the next rank owns those rows), the
+    entries BELOW the slab of its first planes come straight from the CSR arrays (the previous rank stores them as its upper
+    triangle): the block product equals the rows of A x, for the first, an inner and the last slab"""
+    rng = np.random.default_rng(sum(shape) * reach)
+    A = _box_stencil(rng, shape, reach)
+    x = rng.standard_normal(A.shape[0])
+    dx = dev.DeviceVector(data=x)
+    n01 = shape[0] * shape[1]
+    ref_all = A @ x
+    scale = np.abs(A) @ np.abs(x)
+    for z0, z1 in zip(cuts[:-1], cuts[1:]):
+        r0, r1 = z0 * n01, z1 * n01
+        B = A[r0:r1].tocsr()
+        B.sort_indices()
+        dB = dev.DeviceCSR.from_scipy(B)
+        y, info = dB.mult_symgrid(dx, row0=r0)
+        assert info is not None, (z0, z1)
+        assert np.max(np.abs(y.get_local() - ref_all[r0:r1]) / scale[r0:r1]) < 1e-14, (z0, z1)
+        y2, _ = dB.mult_symgrid(dx, row0=r0)
+        assert np.array_equal(y.get_local().view(np.int64), y2.get_local().view(np.int64))
+    # a slab thinner than 2 reach + 2 planes keeps the sliced copy; so does a block that is not made of whole planes
+    thin = A[0:(2 * reach + 1) * n01].tocsr()
+    assert dev.DeviceCSR.from_scipy(thin).mult_symgrid(dx, row0=0) == (None, None)
+    odd = A[n01 + 5:10 * n01 + 5].tocsr()
+    assert dev.DeviceCSR.from_scipy(odd).mult_symgrid(dx, row0=n01 + 5) == (None, None)
+
+
 def test_matrices_without_the_structure_are_declined(dev):
     rng = np.random.default_rng(3)
     shape = (30, 20, 12)

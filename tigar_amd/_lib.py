@@ -124,7 +124,7 @@ PROTOTYPES = {
     "tg_spmv": (C.c_int, [handle, handle, handle]),
     "tg_spmv_offset": (C.c_int, [handle, handle, C.c_int64, handle]),
     "tg_spmv_sell": (C.c_int, [handle, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
-    "tg_spmv_symgrid": (C.c_int, [handle, handle, handle, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "tg_spmv_symgrid": (C.c_int, [handle, C.c_int64, handle, handle, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tg_spmm_host": (C.c_int, [handle, c_f64p, C.c_int, c_f64p]),
     "tg_spmv_t": (C.c_int, [handle, handle, handle]),
     "tg_ptap_symbolic": (C.c_int, [handle, C.c_int64, handle, C.c_int64, handle, C.c_int64,

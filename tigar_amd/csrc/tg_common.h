@@ -190,9 +190,12 @@ int tg_sell_spmv_rows(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_
 
 // half-storage product for symmetric box-stencil matrices on a 3-D grid (tg_symgrid.hip)
 struct tg_symgrid_s;
-int tg_symgrid_build(tg_csr_s *a, int verify, tg_symgrid_s **out);   // *out = nullptr: declined
+int tg_symgrid_build(tg_csr_s *a, int64_t row0, int verify, tg_symgrid_s **out);   // *out = nullptr: declined
 void tg_symgrid_free(tg_symgrid_s *s);
-int tg_symgrid_spmv(tg_symgrid_s *s, const double *x, double *y, const double *gate, double gate_tol);
+// part 0: the whole product; 1: what needs no halo of x (may run beside the exchange); 2: the rest
+int tg_symgrid_spmv(tg_symgrid_s *s, tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y, int part,
+                    const double *gate, double gate_tol);
+int tg_symgrid_chunks(const tg_symgrid_s *s);
 void tg_symgrid_info(const tg_symgrid_s *s, int64_t *val_bytes, int64_t *stage_bytes);
 
 int tg_csr_sort_rows(tg_csr_s *m);

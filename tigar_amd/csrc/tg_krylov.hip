@@ -315,8 +315,9 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
     // (TIGAR_SPMV_SYM: 0 = off, 1 = systems of at least 65536 rows [default], 2 = every size the plan accepts)
     const int sym_on = getenv("TIGAR_SPMV_SYM") ? atoi(getenv("TIGAR_SPMV_SYM")) : 1;
     const int sym_verify = getenv("TIGAR_SPMV_SYM_VERIFY") ? atoi(getenv("TIGAR_SPMV_SYM_VERIFY")) : 1;
-    if (sym_on && (n >= 65536 || sym_on > 1) && !(comm && comm->world > 1) && k->sell_state != 1 && hlo == 0 && hhi == 0)
-      TG_TRY(tg_symgrid_build(k, sym_verify, &sym.s));
+    // (several ranks: every rank decides for its own z slab -- the products are local once the halo of u has arrived)
+    if (sym_on && (n >= 65536 || sym_on > 1) && k->sell_state != 1)
+      TG_TRY(tg_symgrid_build(k, row0, sym_verify, &sym.s));
     if (sym.s) g_tg.prof_n[TG_PROF_KSP_SYMGRID] += 1;
   }
   tg_sell_guard sell_guard(k, sym.s != nullptr);   // sliced copy of the values for the products of this solve
@@ -399,8 +400,17 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
       g_tg.prof_n[TG_PROF_KSP_OVERLAPPED] += 1;
       return 0;
     }
+    if (sym.s && comm && comm->world > 1 && overlap_on && tg_symgrid_chunks(sym.s) > 1) {
+      // all z chunks but the last read no halo plane of u: they run while it travels
+      TG_TRY(tg_comm_halo_begin(comm, uext));
+      int rc = tg_symgrid_spmv(sym.s, k, ushift, cmin, cmax, w, 1, gate, tol2_dev);
+      TG_TRY(tg_comm_halo_end(comm, uext));
+      TG_TRY(rc);
+      g_tg.prof_n[TG_PROF_KSP_OVERLAPPED] += 1;
+      return tg_symgrid_spmv(sym.s, k, ushift, cmin, cmax, w, 2, gate, tol2_dev);
+    }
     TG_TRY(tg_comm_halo_exchange(comm, uext));
-    if (sym.s) return tg_symgrid_spmv(sym.s, u, w, gate, tol2_dev);
+    if (sym.s) return tg_symgrid_spmv(sym.s, k, ushift, cmin, cmax, w, 0, gate, tol2_dev);
     if (sliced && gate) return tg_sell_spmv_rows(k, ushift, cmin, cmax, w, 0, n, gate, tol2_dev);
     return tg_spmv_raw(k, ushift, cmin, cmax, w);
   };

@@ -90,7 +90,9 @@ __device__ __forceinline__ void sg_each(std::integer_sequence<int, I...>, F &&f)
 }
 
 struct tg_symgrid_s {
-  int P = 0, n0 = 0, n1 = 0, n2 = 0;
+  int P = 0, n0 = 0, n1 = 0, n2 = 0;     // n2: planes of THIS row block
+  int n2g = 0, zoff = 0;                 // planes of the whole grid, first plane of the block (several ranks: z slabs)
+  int64_t row0 = 0;
   int npx = 0, npy = 0, nch = 0, m = 0, czmax = 0;
   int32_t *tabs = nullptr;      // device: x0[npx+1] | y0[npy+1] | z0[nch+1] | px_of[n0] | py_of[n1] | pc_of[n2]
   sg_d2 *val = nullptr;         // [patch][plane][sub-step][pair][lane]
@@ -100,13 +102,14 @@ struct tg_symgrid_s {
 };
 
 struct sg_dev {
-  int n0, n1, n2, npx, npy, nch, m, czmax;
+  int n0, n1, n2, npx, npy, nch, m, czmax, n2g, zoff;
   const int32_t *x0, *y0, *z0, *px_of, *py_of, *pc_of;
 };
 
 static sg_dev sg_view(const tg_symgrid_s *s) {
   sg_dev d;
   d.n0 = s->n0, d.n1 = s->n1, d.n2 = s->n2, d.npx = s->npx, d.npy = s->npy, d.nch = s->nch, d.m = s->m, d.czmax = s->czmax;
+  d.n2g = s->n2g, d.zoff = s->zoff;
   d.x0 = s->tabs;
   d.y0 = d.x0 + s->npx + 1;
   d.z0 = d.y0 + s->npy + 1;
@@ -154,7 +157,9 @@ __global__ void __launch_bounds__(256)
   for (int i = tid; i < SG_CV_ROWS * LD; i += 256) tile[i] = 0.0;
   __syncthreads();
   const int n0 = G.n0, n01 = G.n0 * G.n1;
-  const int dzlo = -min(P, z), dzhi = min(P, G.n2 - 1 - z), nz = dzhi - dzlo + 1;
+  const int zg = z + G.zoff;                  // (a z slab of the grid: the rows hold the box of the WHOLE grid)
+  const int dzlo = -min(P, zg), dzhi = min(P, G.n2g - 1 - zg), nz = dzhi - dzlo + 1;
+  const int grow0 = G.zoff * n01;              // global index of local row 0
   // lane rr < 8 of a wave looks up row rr of the wave's eight
   int my_row = -1, my_len = 0;
   int64_t my_e0 = 0;
@@ -192,7 +197,7 @@ __global__ void __launch_bounds__(256)
       const int qz = (k * mxy) >> 16, rem = k - qz * nxy;
       const int qy = (rem * mx) >> 16, qx = rem - qy * nx;
       const int dz = qz + dzlo, dy = qy + dylo, dx = qx + dxlo;
-      bad |= c != row + dx + n0 * dy + n01 * dz;
+      bad |= c != grow0 + row + dx + n0 * dy + n01 * dz;
       trow[sg_lay<P>::inv(((dz + P) * C::S + dy + P) * C::S + dx + P - C::LC)] = v;
     }
   }
@@ -227,8 +232,13 @@ struct sg_ctx {
 
 template <int P>
 __global__ void __launch_bounds__(64, 2)      // (two waves per SIMD: 256 registers; the windows allow 7 waves per CU)
-    k_symgrid_spmv(sg_dev G, const sg_d2 *__restrict__ val, const double *__restrict__ x, double *__restrict__ stage,
-                   int64_t nrows, int64_t nwaves, const double *__restrict__ gate, double gate_tol) {
+    k_symgrid_spmv(sg_dev G, const sg_d2 *__restrict__ val, const double *__restrict__ xw, int xoff, int xlen,
+                   double *__restrict__ stage, int64_t nwaves, int c_begin, int c_count, const double *__restrict__ gate,
+                   double gate_tol) {
+  // xw: the window of x this rank may read (its own rows and the halo planes of its z neighbours), local row r at
+  // xw[xoff + r]; entries of K that reach beyond the window are stored zeros (rows at the faces of the grid) -- reads
+  // beyond it return 0 (buffer range check).  What is scattered beyond the block's last plane is dropped: those rows
+  // belong to the next rank, which holds the transposed entries in ITS rows (k_symgrid_lowhalo)
   typedef sg_c<P> C;
   typedef sg_lay<P> Y;
   constexpr int Wx = C::Wx, W = C::W, GB = Y::GBMAX, NB = Y::NBATCH;
@@ -238,7 +248,8 @@ __global__ void __launch_bounds__(64, 2)      // (two waves per SIMD: 256 regist
   const int lane = threadIdx.x;
   const int64_t L = tg_xcd_block(blockIdx.x, nwaves);
   if (L >= nwaves) return;
-  const int c = (int)(L % G.nch), patch = (int)(L / G.nch);
+  // (this launch: the z chunks [c_begin, c_begin + c_count) of every patch)
+  const int c = c_begin + (int)(L % c_count), patch = (int)(L / c_count);
   const int a = patch % G.npx, b = patch / G.npx;
   const int xa = G.x0[a], pxv = G.x0[a + 1] - xa, ya = G.y0[b], pyv = G.y0[b + 1] - ya;
   const int za = G.z0[c], zb = G.z0[c + 1];
@@ -250,7 +261,8 @@ __global__ void __launch_bounds__(64, 2)      // (two waves per SIMD: 256 regist
   for (int e = lane; e < (P + 1) * W; e += 64) acc[e] = 0.0;
   __syncthreads();
   const __amdgpu_buffer_rsrc_t xr =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, (unsigned)(nrows * 8), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(xw), 0, (unsigned)xlen * 8u, 0x00020000);
+  const double *__restrict__ x = xw + xoff;
   const int n0 = G.n0, n01 = G.n0 * G.n1;
   double *st = stage + ((int64_t)patch * G.nch + c) * (int64_t)(G.czmax + P) * W;
   const sg_d2 *vp = val + (int64_t)patch * G.n2 * G.m * (int64_t)(C::NG * 64) + lane;
@@ -288,7 +300,7 @@ __global__ void __launch_bounds__(64, 2)      // (two waves per SIMD: 256 regist
       if (pos > 0) {
         const int off = sg_dx(Pc, pos) + n0 * sg_dy(Pc, pos) + n01 * sg_dz(Pc, pos);
         xx[BT % XD][l] =
-            __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xr, (unsigned)(k.row + off) * 8u, 0, 0));
+            __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xr, (unsigned)(k.row + off + xoff) * 8u, 0, 0));
       }
     }
   };
@@ -403,11 +415,33 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Rows in the first P planes of a z slab that is not the first: their entries in planes BELOW the slab (the head of the CSR
+// row, columns < row0) are the transposed entries of rows the previous rank holds; they are read from the CSR arrays as
+// they are (3 planes of rows, <= 147 entries each) and added to y after the windows.  One wave per row, fixed tree.
+__global__ void __launch_bounds__(256)
+    k_symgrid_lowhalo(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+                      int64_t nrows_low, int row0, const double *__restrict__ xs, double *__restrict__ y,
+                      const double *__restrict__ gate, double gate_tol) {
+  if (gate && !(*gate > gate_tol)) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < nrows_low; r += nw) {
+    const int64_t e0 = rowptr[r], e1 = rowptr[r + 1];
+    double s = 0.0;
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+      const int c = col[e];
+      if (c < row0) s += val[e] * xs[c];
+    }
+    s = tg_wave_sum(s);
+    if (lane == 0) y[r] += s;
+  }
+}
+
 // ---- check of a finished plan against the CSR product
-__global__ void k_symgrid_random(double *x, int64_t n) {
+__global__ void k_symgrid_random(double *x, int64_t n, int64_t first) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull;
+    unsigned long long z = (unsigned long long)(i + first) * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull;
     z ^= z >> 31;
     z *= 0xD6E8FEB86659FD93ull;
     z ^= z >> 29;
@@ -437,28 +471,47 @@ static void sg_launch_convert(const tg_symgrid_s *s, tg_csr_s *a, int *fail) {
   hipLaunchKernelGGL(k_symgrid_convert<P>, dim3((unsigned)(nblk * 2)), dim3(256), 0, g_tg.stream, sg_view(s),
                      a->rowptr, a->col, a->val, s->val, nblk, fail);
 }
+// part 0: all of it; 1: the chunks that read no halo plane of x (all but the last one of every patch) -- what may run while
+// the halo of x is still travelling; 2: the rest (last chunks, the sum of the windows, the rows next to the previous slab)
 template <int P>
-static void sg_launch_spmv(const tg_symgrid_s *s, const double *x, double *y, int64_t nrows, const double *gate,
-                           double tol) {
-  const int64_t nw = (int64_t)s->npx * s->npy * s->nch;
-  hipLaunchKernelGGL(k_symgrid_spmv<P>, dim3((unsigned)(tg_cdiv(nw, 8) * 8)), dim3(64), 0, g_tg.stream, sg_view(s),
-                     s->val, x, s->stage, nrows, nw, gate, tol);
+static void sg_launch_spmv(const tg_symgrid_s *s, tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y,
+                           int part, const double *gate, double tol) {
+  const double *xw = x_shifted + cmin;
+  const int xoff = (int)(s->row0 - cmin), xlen = (int)(cmax - cmin + 1);
+  const int64_t npatch = (int64_t)s->npx * s->npy;
+  auto chunks = [&](int c0, int cn) {
+    if (cn <= 0) return;
+    const int64_t nw = npatch * cn;
+    hipLaunchKernelGGL(k_symgrid_spmv<P>, dim3((unsigned)(tg_cdiv(nw, 8) * 8)), dim3(64), 0, g_tg.stream, sg_view(s), s->val,
+                       xw, xoff, xlen, s->stage, nw, c0, cn, gate, tol);
+  };
+  if (part == 0) chunks(0, s->nch);
+  if (part == 1) chunks(0, s->nch - 1);
+  if (part == 2) chunks(s->nch - 1, 1);
+  if (part == 1) return;
   const int64_t nlines = (int64_t)s->n1 * s->n2;
   hipLaunchKernelGGL(k_symgrid_combine<P>, dim3((unsigned)std::min<int64_t>(nlines, (int64_t)g_tg.num_cu * 64)), dim3(256), 0,
                      g_tg.stream, sg_view(s), s->stage, y, nlines, gate, tol);
+  if (s->zoff > 0) {
+    const int64_t low = (int64_t)std::min(s->P, s->n2) * s->n0 * s->n1;
+    hipLaunchKernelGGL(k_symgrid_lowhalo, dim3((unsigned)std::min<int64_t>(tg_cdiv(low, 4), (int64_t)g_tg.num_cu * 32)),
+                       dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->val, low, (int)s->row0, x_shifted, y, gate, tol);
+  }
 }
 
-// y = K x (x, y: nrows doubles; x is NOT addressed through a halo: one rank only)
-int tg_symgrid_spmv(tg_symgrid_s *s, const double *x, double *y, const double *gate, double gate_tol) {
-  const int64_t nrows = (int64_t)s->n0 * s->n1 * s->n2;
+// y = K x for the row block the plan was built for; x addressed by GLOBAL column index (x_shifted[col]), readable in
+// [cmin, cmax] (the rank's rows and the halo of its z neighbours; one rank: [0, n - 1]).  part: see sg_launch_spmv
+int tg_symgrid_spmv(tg_symgrid_s *s, tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y, int part,
+                    const double *gate, double gate_tol) {
   switch (s->P) {
-    case 1: sg_launch_spmv<1>(s, x, y, nrows, gate, gate_tol); break;
-    case 2: sg_launch_spmv<2>(s, x, y, nrows, gate, gate_tol); break;
-    default: sg_launch_spmv<3>(s, x, y, nrows, gate, gate_tol); break;
+    case 1: sg_launch_spmv<1>(s, a, x_shifted, cmin, cmax, y, part, gate, gate_tol); break;
+    case 2: sg_launch_spmv<2>(s, a, x_shifted, cmin, cmax, y, part, gate, gate_tol); break;
+    default: sg_launch_spmv<3>(s, a, x_shifted, cmin, cmax, y, part, gate, gate_tol); break;
   }
   TG_LAUNCH_CHECK();
   return 0;
 }
+int tg_symgrid_chunks(const tg_symgrid_s *s) { return s->nch; }
 
 // the longest row (the first of them): an interior row of a box stencil, if there is one
 __global__ void k_symgrid_longest(const int64_t *__restrict__ rowptr, int64_t n, unsigned long long *out) {
@@ -473,7 +526,7 @@ __global__ void k_symgrid_longest(const int64_t *__restrict__ rowptr, int64_t n,
 }
 
 // P, n0, n1, n2 from the column offsets of one interior row ((2P+1)^3 entries, the diagonal in the middle)
-static int sg_detect(tg_csr_s *a, int *Pout, int *n0o, int *n1o, int *n2o, bool *found) {
+static int sg_detect(tg_csr_s *a, int64_t row0, int *Pout, int *n0o, int *n1o, int *n2o, bool *found) {
   *found = false;
   const int64_t n = a->nrows;
   unsigned long long *o = (unsigned long long *)(g_tg.scratch + 96);
@@ -483,13 +536,14 @@ static int sg_detect(tg_csr_s *a, int *Pout, int *n0o, int *n1o, int *n2o, bool 
   TG_LAUNCH_CHECK();
   TG_CHECK_HIP(hipMemcpyAsync(&key, o, sizeof(key), hipMemcpyDeviceToHost, g_tg.stream));
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
-  const int64_t len = (int64_t)(key >> 32), r = (int64_t)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+  const int64_t len = (int64_t)(key >> 32), rl = (int64_t)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+  const int64_t r = rl + row0;          // (global index of that row)
   int P = 0;
   for (int p = 1; p <= 3; p++)
     if (len == (int64_t)(2 * p + 1) * (2 * p + 1) * (2 * p + 1)) P = p;
-  if (!P || r < 0 || r >= n) return 0;
+  if (!P || rl < 0 || rl >= n) return 0;
   int64_t e0 = 0;
-  TG_CHECK_HIP(hipMemcpyAsync(&e0, a->rowptr + r, sizeof(e0), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipMemcpyAsync(&e0, a->rowptr + rl, sizeof(e0), hipMemcpyDeviceToHost, g_tg.stream));
   TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
   std::vector<int32_t> c((size_t)len);
   TG_CHECK_HIP(hipMemcpyAsync(c.data(), a->col + e0, sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost, g_tg.stream));
@@ -500,7 +554,7 @@ static int sg_detect(tg_csr_s *a, int *Pout, int *n0o, int *n1o, int *n2o, bool 
   const int64_t o1 = (int64_t)c[(size_t)((P + 1) * S * S)] - r;                // (-P, -P, 1)
   if (n0 < 2 * P + 1) return 0;
   const int64_t n01 = o1 + P * n0 + P;
-  if (n01 <= 0 || n01 % n0 || n % n01) return 0;
+  if (n01 <= 0 || n01 % n0 || n % n01 || row0 % n01 || a->ncols % n01) return 0;
   for (int l = 0; l < S * S * S; l++) {
     const int dx = l % S - P, dy = (l / S) % S - P, dz = l / (S * S) - P;
     if ((int64_t)c[(size_t)l] - r != dx + n0 * dy + n01 * dz) return 0;
@@ -510,27 +564,32 @@ static int sg_detect(tg_csr_s *a, int *Pout, int *n0o, int *n1o, int *n2o, bool 
   return 0;
 }
 
-// Builds the plan for a square matrix held entirely by this rank; *out stays nullptr when the matrix is not a
-// symmetric box stencil on a 3-D grid (or there is no room for the copy).  verify: compare with the CSR product.
-int tg_symgrid_build(tg_csr_s *a, int verify, tg_symgrid_s **out) {
+// Builds the plan for the rows [row0, row0 + nrows) of a square matrix (the whole matrix, or the z slab of planes one
+// rank holds: whole planes of the grid); *out stays nullptr when the matrix is not a symmetric box stencil on a 3-D grid
+// (or there is no room for the copy).  verify: compare with the CSR product on a pseudo-random vector.
+int tg_symgrid_build(tg_csr_s *a, int64_t row0, int verify, tg_symgrid_s **out) {
   *out = nullptr;
   const bool trace = getenv("TIGAR_TRACE") != nullptr;
-  if (a->rowcnt || a->view || a->nrows != a->ncols || a->nrows < 1024 || a->nrows >= (int64_t)1 << 28) return 0;
+  if (a->rowcnt || a->view || a->nrows < 1024 || a->ncols >= (int64_t)1 << 28 || row0 < 0 || row0 + a->nrows > a->ncols)
+    return 0;
   int P = 0, n0 = 0, n1 = 0, n2 = 0;
   bool found = false;
-  TG_TRY(sg_detect(a, &P, &n0, &n1, &n2, &found));
+  TG_TRY(sg_detect(a, row0, &P, &n0, &n1, &n2, &found));
   if (!found || n0 < 16 || n1 < 16 || n2 < 2 * P + 2) {
     if (trace) fprintf(stderr, "[trace] symgrid: no 3-D box stencil found (%lld rows)\n", (long long)a->nrows);
     return 0;
   }
   tg_symgrid_s *s = new tg_symgrid_s;
   s->P = P, s->n0 = n0, s->n1 = n1, s->n2 = n2;
+  s->row0 = row0, s->zoff = (int)(row0 / ((int64_t)n0 * n1)), s->n2g = (int)(a->ncols / ((int64_t)n0 * n1));
   s->npx = (n0 + SG_PX - 1) / SG_PX;
   s->npy = (n1 + SG_PY - 1) / SG_PY;
   const int64_t npatch = (int64_t)s->npx * s->npy;
   {
     int want = getenv("TIGAR_SYMGRID_CHUNKS") ? atoi(getenv("TIGAR_SYMGRID_CHUNKS")) : 0;
-    if (want <= 0) want = (int)tg_cdiv((int64_t)g_tg.num_cu * 14, npatch);
+    // (measured, 64^3 .. 256^3, p = 2, 3: chunks of 11-13 planes are best -- a chunk pays for P extra window planes and
+    // the start of its load pipeline -- as long as there are about two waves per CU)
+    if (want <= 0) want = (int)std::max<int64_t>(n2 / 12, tg_cdiv((int64_t)g_tg.num_cu * 2, npatch));
     const int minplanes = std::max(P, 4);
     s->nch = std::max(1, std::min(want, n2 / minplanes));
   }
@@ -604,16 +663,20 @@ int tg_symgrid_build(tg_csr_s *a, int verify, tg_symgrid_s **out) {
       break;
     }
     if (verify) {
+      // x on the window of columns the block reads: P planes on either side (as far as the grid goes)
+      const int64_t n01 = (int64_t)n0 * n1;
+      const int64_t cmin = std::max<int64_t>(0, row0 - P * n01), cmax = std::min<int64_t>(a->ncols, row0 + a->nrows + P * n01) - 1;
+      const int64_t nx = cmax - cmin + 1;
       double *t = nullptr;
-      if ((rc = tg_dmalloc(&t, 3 * a->nrows))) break;
-      double *x = t, *y1 = t + a->nrows, *y2 = y1 + a->nrows;
+      if ((rc = tg_dmalloc(&t, nx + 2 * a->nrows))) break;
+      double *x = t, *y1 = t + nx, *y2 = y1 + a->nrows;
       unsigned long long *o = (unsigned long long *)(g_tg.scratch + 80);
       unsigned long long ho[2] = {0, 0};
       const int vg = tg_grid_1d(a->nrows, 256);
-      hipLaunchKernelGGL(k_symgrid_random, dim3(vg), dim3(256), 0, g_tg.stream, x, a->nrows);
+      hipLaunchKernelGGL(k_symgrid_random, dim3(tg_grid_1d(nx, 256)), dim3(256), 0, g_tg.stream, x, nx, cmin);
       rc = tg_spmv_plan(a);
-      if (!rc) rc = tg_spmv_raw(a, x, 0, a->ncols - 1, y1);
-      if (!rc) rc = tg_symgrid_spmv(s, x, y2, nullptr, 0.0);
+      if (!rc) rc = tg_spmv_raw(a, x - cmin, cmin, cmax, y1);
+      if (!rc) rc = tg_symgrid_spmv(s, a, x - cmin, cmin, cmax, y2, 0, nullptr, 0.0);
       if (!rc && hipMemcpyAsync(o, ho, sizeof(ho), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess) rc = 1;
       if (!rc) {
         hipLaunchKernelGGL(k_symgrid_compare, dim3(vg), dim3(256), 0, g_tg.stream, y1, y2, a->nrows, o);
@@ -640,8 +703,8 @@ int tg_symgrid_build(tg_csr_s *a, int verify, tg_symgrid_s **out) {
     return rc;
   }
   if (trace)
-    fprintf(stderr, "[trace] symgrid: P=%d grid %d x %d x %d, %d x %d patches, %d chunks, %d sub-steps, values %.2f GB, staging %.2f GB\n",
-            P, n0, n1, n2, s->npx, s->npy, s->nch, s->m, s->val_bytes / 1e9, s->stage_bytes / 1e9);
+    fprintf(stderr, "[trace] symgrid: P=%d grid %d x %d x %d (planes %d..%d of %d), %d x %d patches, %d chunks, %d sub-steps, values %.2f GB, staging %.2f GB\n",
+            P, n0, n1, n2, s->zoff, s->zoff + n2, s->n2g, s->npx, s->npy, s->nch, s->m, s->val_bytes / 1e9, s->stage_bytes / 1e9);
   *out = s;
   return 0;
 }
@@ -652,16 +715,17 @@ void tg_symgrid_info(const tg_symgrid_s *s, int64_t *val_bytes, int64_t *stage_b
   if (stage_bytes) *stage_bytes = s->stage_bytes;
 }
 
-/* Plans the half-storage product for a matrix and runs y = K x with it (tests, bench accounting): *accepted = 0 when the
- * matrix is not a symmetric 3-D box stencil.  value_bytes: what one product reads of K; staging_bytes: window staging. */
-extern "C" int tg_spmv_symgrid(tg_csr_t a, tg_vec_t x, tg_vec_t y, int *accepted, int64_t *value_bytes,
+/* Plans the half-storage product for a matrix -- or for the block of rows [row0, row0 + nrows) of one, whole planes of
+ * the grid -- and runs y = K x with it (tests, bench accounting); x covers ALL columns.  *accepted = 0 when the matrix is
+ * not a symmetric 3-D box stencil.  value_bytes: what one product reads of K; staging_bytes: window staging. */
+extern "C" int tg_spmv_symgrid(tg_csr_t a, int64_t row0, tg_vec_t x, tg_vec_t y, int *accepted, int64_t *value_bytes,
                                int64_t *staging_bytes) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(a && accepted, "null argument to tg_spmv_symgrid");
   TG_REQUIRE_CANONICAL(a);
   *accepted = 0;
   tg_symgrid_s *s = nullptr;
-  TG_TRY(tg_symgrid_build(a, 1, &s));
+  TG_TRY(tg_symgrid_build(a, row0, 1, &s));
   if (!s) return 0;
   int rc = 0;
   if (x && y) {
@@ -670,7 +734,7 @@ extern "C" int tg_spmv_symgrid(tg_csr_t a, tg_vec_t x, tg_vec_t y, int *accepted
                    (long long)a->nrows, (long long)a->ncols);
       rc = 2;
     } else {
-      rc = tg_symgrid_spmv(s, x->d, y->d, nullptr, 0.0);
+      rc = tg_symgrid_spmv(s, a, x->d, 0, a->ncols - 1, y->d, 0, nullptr, 0.0);
     }
   }
   *accepted = 1;

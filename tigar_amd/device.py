@@ -282,14 +282,15 @@ class DeviceCSR(object):
         check(_lib.lib().tg_spmv_sell(self._h, 1 if enable else 0, C.byref(n), C.byref(padded)), "tg_spmv_sell")
         return n.value, padded.value
 
-    def mult_symgrid(self, x=None, y=None):
+    def mult_symgrid(self, x=None, y=None, row0=0):
         """The half-storage product of the CG solve (tg_spmv_symgrid): plans the copy, checks it against the CSR product
-        and, with x given, returns (y, info); info = None when the matrix is not a symmetric 3-D box stencil (y is then
+        and, with x given, returns (y, info); ``row0``: this matrix holds the rows [row0, row0 + nrows) of a square one (a z
+        slab, all columns; x covers all columns).  info = None when the matrix is not a symmetric 3-D box stencil (y is then
         None as well), else {"value_bytes": bytes of K one product reads, "staging_bytes": ...}."""
         ok, vb, sb = C.c_int(0), C.c_int64(0), C.c_int64(0)
         if x is not None and y is None:
             y = DeviceVector(self.shape[0])
-        check(_lib.lib().tg_spmv_symgrid(self._h, x._h if x is not None else None, y._h if x is not None else None,
+        check(_lib.lib().tg_spmv_symgrid(self._h, int(row0), x._h if x is not None else None, y._h if x is not None else None,
                                          C.byref(ok), C.byref(vb), C.byref(sb)), "tg_spmv_symgrid")
         if not ok.value:
             return None, None
