@@ -23,6 +23,7 @@ typedef struct tg_csr_s *tg_csr_t;   /* device-resident CSR row block           
 typedef struct tg_vec_s *tg_vec_t;   /* device-resident fp64 vector              */
 typedef struct tg_ptap_s *tg_ptap_t; /* symbolic plan of K = M^T A M             */
 typedef struct tg_cellplan_s *tg_cellplan_t; /* K = M^T A M on a cell-local FE space: dense blocks per cell */
+typedef struct tg_elemsplit_s *tg_elemsplit_t; /* a matrix on a CONNECTED mesh split into one dense block per cell */
 typedef struct tg_comm_s *tg_comm_t; /* RCCL communicator + z-slab descriptor    */
 
 /* ---- runtime ------------------------------------------------------------------ */
@@ -256,6 +257,21 @@ int tg_cellplan_create(int64_t ncell, int b, int nfmax, int64_t ncols, const dou
                        const int32_t *nf_host, tg_csr_t incidence, int max_k, double mean_k, tg_cellplan_t *out);
 int tg_cellplan_ptap(tg_cellplan_t plan, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out);
 int tg_cellplan_destroy(tg_cellplan_t plan);
+/* The cell-block product for CONNECTED meshes (cells share nodes: what dolfin assembles on a Q_p / P_p mesh, tIGAr/common.py:
+ * 1194-1195 with an M that is no Kronecker product).  A = sum_c R_c^T A_c R_c for ANY splitting of its entries over the cells
+ * that hold both nodes, hence K = sum_c (R_c M)^T A_c (R_c M): the dense cell products above on rows of M repeated per cell.
+ * tg_cellplan_create_from_rows: the plan for cells given by node lists (cellnodes_host [ncell][b], ascending per cell; rows
+ * of m), dense rows of M gathered on the device.  tg_elemsplit_create: assigns every entry of `a` to the lowest cell holding
+ * both its nodes (nptr_host [nrows + 1] / ncells_host: the cells of every node, ascending); 100 = an entry couples nodes
+ * without a common cell.  tg_elemsplit_ptap: gathers the values of `a` (same pattern) into blocks and runs the product. */
+int tg_cellplan_create_from_rows(int64_t ncell, int b, int nfmax, tg_csr_t m, const int32_t *cellnodes_host,
+                                 const int32_t *fl_host, const int32_t *nf_host, tg_csr_t incidence, int max_k, double mean_k,
+                                 tg_cellplan_t *out);
+int tg_elemsplit_create(tg_csr_t a, int64_t ncell, int b, const int32_t *cellnodes_host, const int32_t *nptr_host,
+                        const int32_t *ncells_host, tg_elemsplit_t *out);
+int tg_elemsplit_ptap(tg_elemsplit_t split, tg_cellplan_t plan, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag,
+                      tg_csr_t *k_out);
+int tg_elemsplit_destroy(tg_elemsplit_t split);
 /* The same product for a matrix that holds its dense cell blocks PLUS couplings outside them (contact / penalty terms added by
  * hand to a T-spline matrix: demos/kl-shell-svk/reef-knot.py:455-467, the reason extractMatrix takes any A, tIGAr/common.py:
  * 1175): k_out = M^T D M from the blocks D read in place (no copy of A), r_out = the remainder A - D with A's shape, whose

@@ -1,0 +1,83 @@
+"""-m gpu: the cell-block product for CONNECTED meshes (tigar_amd/elemptap.py, csrc tg_elemsplit_*): A assembled on a mesh whose
+cells share nodes is split into one dense block per cell (every entry to the lowest cell holding both nodes) and
+K = M^T A M = sum_c (R_c M)^T A_c (R_c M) runs as dense cell products -- MatPtAP of tIGAr/common.py:1194-1195 for ANY values of
+A and an M that is used as a general CSR matrix.  Checked against scipy's triple product and the general
+kernels: pattern and values, non-symmetric A, MatZeroRowsColumns fused, a matrix with an entry outside every cell declined."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _operands(d, p, nels, seed=0):
+    from tigar_amd import device as dev
+    from tigar_amd.common import TensorFunctionSpace, _cell_dofs_arrays
+    from tigar_amd.BSplines import ExplicitBSplineControlMesh, uniformKnots
+    from tigar_amd.forms import LaplaceForm
+    cm = ExplicitBSplineControlMesh([p] * d, [uniformKnots(p, 0., 1., n) for n in nels])
+    basis = cm.getScalarSpline()
+    grid = basis.generateMesh(degree=p)
+    V = TensorFunctionSpace([grid], "Lagrange")
+    A = LaplaceForm().assemble_matrix(V)
+    M = dev.extract_csr_tensor(basis.splines, grid.axes, 0, basis.getNcp(), 1e-15)
+    return A, M, _cell_dofs_arrays(grid)
+
+
+@pytest.mark.parametrize("d,p,nels", [(3, 3, (5, 4, 6)), (3, 2, (7, 5, 6)), (2, 3, (17, 12)), (3, 1, (9, 8, 7)), (2, 2, (20, 15))])
+def test_element_split_product_matches_scipy(d, p, nels):
+    from tigar_amd import device as dev
+    from tigar_amd.elemptap import ElementSplitPtAP
+    A, M, cells = _operands(d, p, nels)
+    rng = np.random.default_rng(d * 10 + p)
+    As = A.to_scipy().tocsr()
+    As.sort_indices()
+    As.data = As.data * (1.0 + 0.3 * rng.standard_normal(As.nnz)) + 0.01 * rng.standard_normal(As.nnz)     # not symmetric
+    A2 = dev.DeviceCSR.from_scipy(As)
+    Ms = M.to_scipy().tocsr()
+    plan = ElementSplitPtAP(M, cells)
+    assert plan.b == (p + 1) ** d
+    K = plan.ptap(A2)
+    assert K is not None
+    Ks = K.to_scipy().tocsr()
+    Ks.sort_indices()
+    ref = (Ms.T @ As @ Ms).tocsr()
+    ref.sort_indices()
+    pat = (abs(Ms).T @ sp.csr_matrix((np.ones(As.nnz), As.indices, As.indptr), shape=As.shape) @ abs(Ms)).tocsr()
+    pat.sort_indices()
+    assert np.array_equal(Ks.indptr, pat.indptr) and np.array_equal(Ks.indices, pat.indices)       # the structural pattern
+    assert abs(Ks - ref).max() <= 1e-12 * abs(ref).max()
+    # the general kernels give the same matrix
+    MT = M.transpose()
+    Kg = dev.ptap_numeric(dev.ptap_symbolic(A2, M, MT), A2, M, MT).to_scipy().tocsr()
+    assert abs(Ks - Kg).max() <= 1e-12 * abs(ref).max()
+    # a second product on the plan (places known): bit for bit the same; other values, same pattern: the splitting is reused
+    K2 = plan.ptap(A2).to_scipy().tocsr()
+    K2.sort_indices()
+    assert np.array_equal(K2.data.view(np.int64), Ks.data.view(np.int64))
+    As3 = As.copy()
+    As3.data = rng.standard_normal(As.nnz)
+    K3 = plan.ptap(dev.DeviceCSR.from_scipy(As3)).to_scipy()
+    ref3 = (Ms.T @ As3 @ Ms)
+    assert abs(K3 - ref3).max() <= 1e-12 * abs(ref3).max()
+    # MatZeroRowsColumns fused (tIGAr/common.py:1196-1200)
+    zd = np.unique(rng.integers(0, Ms.shape[1], 25)).astype(np.int32)
+    Kz = plan.ptap(A2, zero_dofs=zd, diag=1.0).to_scipy().tolil()
+    refz = ref.tolil()
+    refz[zd, :] = 0.0
+    refz[:, zd] = 0.0
+    for i in zd:
+        refz[i, i] = 1.0
+    assert abs(Kz.tocsr() - refz.tocsr()).max() <= 1e-12 * abs(ref).max()
+
+
+def test_an_entry_outside_every_cell_is_declined():
+    from tigar_amd import device as dev
+    from tigar_amd.elemptap import ElementSplitPtAP
+    A, M, cells = _operands(2, 2, (8, 8))
+    As = A.to_scipy().tolil()
+    n = As.shape[0]
+    As[0, n - 1] = 1.0                               # opposite corners of the mesh: no common cell
+    plan = ElementSplitPtAP(M, cells)
+    assert plan.ptap(dev.DeviceCSR.from_scipy(As.tocsr())) is None
+    assert plan.ptap(A) is not None

@@ -137,6 +137,11 @@ PROTOTYPES = {
                                      C.POINTER(handle)]),
     "tg_cellplan_ptap": (C.c_int, [handle, handle, c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
     "tg_cellplan_destroy": (C.c_int, [handle]),
+    "tg_cellplan_create_from_rows": (C.c_int, [C.c_int64, C.c_int, C.c_int, handle, c_i32p, c_i32p, c_i32p, handle, C.c_int,
+                                               C.c_double, C.POINTER(handle)]),
+    "tg_elemsplit_create": (C.c_int, [handle, C.c_int64, C.c_int, c_i32p, c_i32p, c_i32p, C.POINTER(handle)]),
+    "tg_elemsplit_ptap": (C.c_int, [handle, handle, handle, c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
+    "tg_elemsplit_destroy": (C.c_int, [handle]),
     "tg_foldplan_create": (C.c_int, [handle, C.c_int64, handle, handle, C.c_int64, handle, C.POINTER(handle)]),
     "tg_foldplan_apply": (C.c_int, [handle, handle, c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
     "tg_foldplan_destroy": (C.c_int, [handle]),

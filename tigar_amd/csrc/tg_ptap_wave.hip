@@ -902,21 +902,24 @@ struct tg_cellplan_s {
   double mean_k = 0.0;
   tg_gw_plan gw;
   // known after the first product: the columns of K and, for every entry (c, q, r) of the element matrices, its PLACE in its
-  // row of K (the slot of column fl[c][r] in row fl[c][q]; rows of at most 255 entries) -- the merge then needs no look-up
+  // row of K (the slot of column fl[c][r] in row fl[c][q]; rows of at most TG_CELL_ROWCAP - 1 entries) -- the merge then needs
+  // no look-up
   int32_t *k_col = nullptr;
-  uint8_t *slot = nullptr;       // [ncell * nfmax][nfmax]
+  uint16_t *slot = nullptr;      // [ncell * nfmax][nfmax]
 };
 
-// slot[(c, q)][r] = position of column fl[c][r] in row fl[c][q] of K (binary search in the sorted row), 255 = not an entry
+#define TG_CELL_ROWCAP 512      // accumulators per row of K in the merge by places (3-D p = 3: 343 entries per row)
+#define TG_CELL_NOSLOT 0xffffu
+// slot[(c, q)][r] = position of column fl[c][r] in row fl[c][q] of K (binary search in the sorted row), 0xffff = not an entry
 __global__ void __launch_bounds__(256) k_cell_slots(const uint32_t *__restrict__ flmix, const int32_t *__restrict__ nfc, int64_t ncell,
                                                     int nfmax, const int64_t *__restrict__ krowptr, const int32_t *__restrict__ kcol,
-                                                    uint8_t *__restrict__ slot, int *__restrict__ bad) {
+                                                    uint16_t *__restrict__ slot, int *__restrict__ bad) {
   const int64_t total = ncell * (int64_t)nfmax * nfmax, stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const int r = (int)(t % nfmax);
     const int64_t cq = t / nfmax, c = cq / nfmax;
     const int q = (int)(cq - c * nfmax), nf = nfc[c];
-    uint8_t sl = 255;
+    uint16_t sl = TG_CELL_NOSLOT;
     if (q < nf && r < nf) {
       const int64_t i = gw_unmix(flmix[c * nfmax + q]);
       const int32_t j = (int32_t)gw_unmix(flmix[c * nfmax + r]);
@@ -926,7 +929,7 @@ __global__ void __launch_bounds__(256) k_cell_slots(const uint32_t *__restrict__
         const int64_t mid = (lo + hi) >> 1;
         if (kcol[mid] < j) lo = mid + 1; else hi = mid;
       }
-      if (lo < krowptr[i + 1] && kcol[lo] == j && lo - a < 255) sl = (uint8_t)(lo - a);
+      if (lo < krowptr[i + 1] && kcol[lo] == j && lo - a < TG_CELL_ROWCAP) sl = (uint16_t)(lo - a);
       else atomicOr(bad, 1);
     }
     slot[t] = sl;
@@ -939,24 +942,25 @@ __global__ void __launch_bounds__(256) k_cell_slots(const uint32_t *__restrict__
 template <int LGR>
 __global__ void __launch_bounds__(256)
     k_cell_merge(const int64_t *__restrict__ irowptr, const int32_t *__restrict__ icol, const double *__restrict__ eval,
-                 const uint8_t *__restrict__ slot, const int32_t *__restrict__ nfc, int nfmax, int64_t nrows,
+                 const uint16_t *__restrict__ slot, const int32_t *__restrict__ nfc, int nfmax, int64_t nrows,
                  const int64_t *__restrict__ krowptr, const int32_t *__restrict__ kcol, const uint8_t *__restrict__ mask, double diag,
                  double *__restrict__ kval) {
   constexpr int LPR = 1 << LGR, NG = 64 >> LGR;
-  __shared__ double acc_all[4][NG][256];
+  constexpr int CAP = NG == 1 ? TG_CELL_ROWCAP : 256;     // (64 KB of static LDS: the long rows belong to the 64-function cells)
+  __shared__ double acc_all[4][NG][CAP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> LGR, sub = lane & (LPR - 1);
-  double(*acc)[256] = acc_all[wave];
+  double(*acc)[CAP] = acc_all[wave];
   const int64_t wstride = (int64_t)gridDim.x * 4;
   for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < nrows; i += wstride) {
     const int64_t k0 = krowptr[i];
     const int n = (int)(krowptr[i + 1] - k0);
-    for (int e = lane; e < NG * 256; e += 64) acc[0][e] = 0.0;       // (rows of one wave: no barrier needed, LDS ops are in order)
+    for (int e = lane; e < NG * CAP; e += 64) acc[0][e] = 0.0;       // (rows of one wave: no barrier needed, LDS ops are in order)
     for (int64_t x = irowptr[i] + grp; x < irowptr[i + 1]; x += NG) {
       const int64_t cq = icol[x];
       const int nf = nfc[cq / nfmax];
       for (int r = sub; r < nf; r += LPR) {
-        const uint8_t sl = slot[cq * nfmax + r];
-        if (sl != 255) acc[grp][sl] += eval[cq * nfmax + r];
+        const uint16_t sl = slot[cq * nfmax + r];
+        if (sl != TG_CELL_NOSLOT) acc[grp][sl] += eval[cq * nfmax + r];
       }
     }
     const bool mrow = mask && mask[i];
@@ -1017,6 +1021,73 @@ __global__ void __launch_bounds__(256)
 }
 
 // every row of A: b entries, the first at column (row / b) * b, the last at + b - 1 (rows are sorted: the block, dense)
+// Cells too large for four of them in the LDS of a workgroup (3-D p = 3: 64 nodes, 64 functions): ONE cell per workgroup,
+// thread (ti, tj) of 16 x 16 holds a 4 x 4 tile of T = A_c M_c and then of E = M_c^T T in registers -- 8 LDS reads per 16
+// multiply-adds instead of 2 per 1.  A_c and T share their LDS (T is written when A_c is no longer read).
+__global__ void __launch_bounds__(256)
+    k_cell_element_big(const double *__restrict__ aval, const double *__restrict__ md, const int32_t *__restrict__ nfc,
+                       int64_t ncell, int b, int nfmax, double *__restrict__ eval) {
+  constexpr int LA = 65;
+  __shared__ double As[64 * LA];     // A_c [row][q], then T [r][s] with row length 64
+  __shared__ double Ms[64 * 64];     // M_c [node][function], zero-padded to 64 x 64
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  for (int64_t c = blockIdx.x; c < ncell; c += gridDim.x) {
+    const int nf = nfc[c];
+    const double *ac = aval + c * (int64_t)b * b, *mc = md + c * (int64_t)b * nfmax;
+    __syncthreads();
+    for (int t = tid; t < 64 * 64; t += 256) {
+      const int i = t >> 6, j = t & 63;
+      As[i * LA + j] = (i < b && j < b) ? ac[i * b + j] : 0.0;
+      Ms[t] = (i < b && j < nf) ? mc[i * nfmax + j] : 0.0;
+    }
+    __syncthreads();
+    double acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) acc[u][v] = 0.0;
+    for (int q = 0; q < b; q++) {
+      double a4[4], m4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) a4[u] = As[(4 * ti + u) * LA + q];
+#pragma unroll
+      for (int v = 0; v < 4; v++) m4[v] = Ms[q * 64 + 4 * tj + v];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[u][v] = fma(a4[u], m4[v], acc[u][v]);
+    }
+    __syncthreads();                       // (everyone is done with A_c)
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        As[(4 * ti + u) * 64 + 4 * tj + v] = acc[u][v];
+        acc[u][v] = 0.0;
+      }
+    __syncthreads();
+    for (int r = 0; r < b; r++) {
+      double q4[4], t4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) q4[u] = Ms[r * 64 + 4 * ti + u];
+#pragma unroll
+      for (int v = 0; v < 4; v++) t4[v] = As[r * 64 + 4 * tj + v];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[u][v] = fma(q4[u], t4[v], acc[u][v]);
+    }
+    double *ec = eval + c * (int64_t)nfmax * nfmax;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int q = 4 * ti + u, sidx = 4 * tj + v;
+        if (q < nf && sidx < nf) ec[(int64_t)q * nfmax + sidx] = acc[u][v];
+      }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_cell_check(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nrows,
                                                   int b, int *__restrict__ bad) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1030,10 +1101,11 @@ __global__ void __launch_bounds__(256) k_cell_check(const int64_t *__restrict__ 
   if (wrong) atomicMax(bad, 1);
 }
 
-extern "C" int tg_cellplan_create(int64_t ncell, int b, int nfmax, int64_t ncols, const double *md_host, const int32_t *fl_host,
-                                  const int32_t *nf_host, tg_csr_t incidence, int max_k, double mean_k, tg_cellplan_t *out) {
+// md_host == nullptr: the dense rows of M are filled in on the device afterwards (tg_cellplan_create_from_rows)
+static int tg_cellplan_create_common(int64_t ncell, int b, int nfmax, int64_t ncols, const double *md_host, const int32_t *fl_host,
+                                     const int32_t *nf_host, tg_csr_t incidence, int max_k, double mean_k, tg_cellplan_t *out) {
   TG_REQUIRE_INIT();
-  TG_REQUIRE(ncell > 0 && b >= 1 && b <= 64 && nfmax >= 1 && nfmax <= 64 && md_host && fl_host && nf_host && incidence && out,
+  TG_REQUIRE(ncell > 0 && b >= 1 && b <= 64 && nfmax >= 1 && nfmax <= 64 && fl_host && nf_host && incidence && out,
              "bad arguments to tg_cellplan_create");
   TG_REQUIRE(incidence->nrows == ncols && incidence->ncols == ncell * nfmax, "tg_cellplan_create: incidence of the wrong shape");
   tg_cellplan_s *pl = new tg_cellplan_s();
@@ -1059,7 +1131,10 @@ extern "C" int tg_cellplan_create(int64_t ncell, int b, int nfmax, int64_t ncols
   int rc = tg_dmalloc(&pl->md, ncell * (int64_t)b * nfmax) || tg_dmalloc(&pl->flmix, nrowsE + TG_CSR_PAD) || tg_dmalloc(&pl->nf, ncell) ||
            tg_dmalloc(&pl->e_start, nrowsE) || tg_dmalloc(&pl->e_start_mix, nrowsE) || tg_dmalloc(&pl->e_cnt, nrowsE);
   if (!rc) {
-    hipMemcpyAsync(pl->md, md_host, (size_t)(ncell * (int64_t)b * nfmax) * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
+    if (md_host)
+      hipMemcpyAsync(pl->md, md_host, (size_t)(ncell * (int64_t)b * nfmax) * sizeof(double), hipMemcpyHostToDevice, g_tg.stream);
+    else
+      hipMemsetAsync(pl->md, 0, (size_t)(ncell * (int64_t)b * nfmax) * sizeof(double), g_tg.stream);
     hipMemsetAsync(pl->flmix, 0, (size_t)(nrowsE + TG_CSR_PAD) * sizeof(uint32_t), g_tg.stream);
     hipMemcpyAsync(pl->flmix, mix.data(), mix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, g_tg.stream);
     hipMemcpyAsync(pl->nf, nf_host, (size_t)ncell * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
@@ -1077,6 +1152,76 @@ extern "C" int tg_cellplan_create(int64_t ncell, int b, int nfmax, int64_t ncols
   pl->gw.lg_am = gw_lg_group((double)nfmax);
   pl->gw.max_k = max_k;
   pl->gw.mean_k = mean_k;
+  *out = pl;
+  return 0;
+}
+
+extern "C" int tg_cellplan_create(int64_t ncell, int b, int nfmax, int64_t ncols, const double *md_host, const int32_t *fl_host,
+                                  const int32_t *nf_host, tg_csr_t incidence, int max_k, double mean_k, tg_cellplan_t *out) {
+  TG_REQUIRE(md_host, "bad arguments to tg_cellplan_create");
+  return tg_cellplan_create_common(ncell, b, nfmax, ncols, md_host, fl_host, nf_host, incidence, max_k, mean_k, out);
+}
+
+// md[c][i][pos of f in fl[c]] = M[cellnodes[c][i]][f]: one wave per (cell, node); *bad: a function missing from the cell's list
+__global__ void __launch_bounds__(256)
+    k_cell_fill_md(const int64_t *__restrict__ mrowptr, const int32_t *__restrict__ mcol, const double *__restrict__ mval,
+                   const int32_t *__restrict__ cellnodes, const int32_t *__restrict__ fl, const int32_t *__restrict__ nfc,
+                   int64_t nrowsC, int b, int nfmax, double *__restrict__ md, int *__restrict__ bad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < nrowsC; k += nw) {
+    const int64_t c = k / b;
+    const int32_t *f = fl + c * nfmax;
+    const int nf = nfc[c];
+    const int64_t r = cellnodes[k];
+    for (int64_t e = mrowptr[r] + lane; e < mrowptr[r + 1]; e += 64) {
+      const int32_t col = mcol[e];
+      int lo = 0, hi = nf;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (f[mid] < col) lo = mid + 1; else hi = mid;
+      }
+      if (lo < nf && f[lo] == col) md[k * nfmax + lo] = mval[e];
+      else atomicOr(bad, 1);
+    }
+  }
+}
+
+/* The plan of the cell-block product for cells that SHARE nodes (a connected grid split into elements, tg_elemsplit_*): cell c
+ * holds the FE nodes cellnodes[c][0..b) (rows of `m`), fl / nf / incidence as for tg_cellplan_create; the dense rows of M per
+ * cell are gathered on the device. */
+extern "C" int tg_cellplan_create_from_rows(int64_t ncell, int b, int nfmax, tg_csr_t m, const int32_t *cellnodes_host,
+                                            const int32_t *fl_host, const int32_t *nf_host, tg_csr_t incidence, int max_k,
+                                            double mean_k, tg_cellplan_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(m && cellnodes_host && out, "null argument to tg_cellplan_create_from_rows");
+  TG_REQUIRE_CANONICAL(m);
+  tg_cellplan_t pl = nullptr;
+  TG_TRY(tg_cellplan_create_common(ncell, b, nfmax, m->ncols, nullptr, fl_host, nf_host, incidence, max_k, mean_k, &pl));
+  int32_t *cn = nullptr, *fl = nullptr;
+  int rc = tg_dmalloc(&cn, ncell * b) || tg_dmalloc(&fl, ncell * nfmax);
+  int *bad = (int *)g_tg.scratch;
+  int hbad = 0;
+  if (!rc) {
+    hipMemcpyAsync(cn, cellnodes_host, (size_t)(ncell * b) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+    hipMemcpyAsync(fl, fl_host, (size_t)(ncell * nfmax) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+    hipMemsetAsync(bad, 0, sizeof(int), g_tg.stream);
+    hipLaunchKernelGGL(k_cell_fill_md, dim3((unsigned)std::min<int64_t>(tg_cdiv(ncell * b, 4), (int64_t)g_tg.num_cu * 32)), dim3(256), 0,
+                       g_tg.stream, m->rowptr, m->col, m->val, cn, fl, pl->nf, ncell * b, b, nfmax, pl->md, bad);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
+        hipStreamSynchronize(g_tg.stream) != hipSuccess)
+      rc = 1;
+  }
+  tg_dfree(cn);
+  tg_dfree(fl);
+  if (!rc && hbad) {
+    tg_set_error("tg_cellplan_create_from_rows: a row of M names a function that is not in its cell's list");
+    rc = 2;
+  }
+  if (rc) {
+    tg_cellplan_destroy(pl);
+    return rc;
+  }
   *out = pl;
   return 0;
 }
@@ -1119,13 +1264,15 @@ static void gw_launch_shared(int lg, unsigned grid, size_t lds, const gw_args &P
 // rstart (device, one entry per FE row, or null): where the b values of the row's own cell block start in a->val -- for a
 // matrix that holds other entries besides its dense cell blocks (tg_cellplan_ptap_extras); null: a is verified to consist of
 // the blocks alone
+// trusted: a->val IS the array of dense blocks [ncell][b][b] (tg_elemsplit_ptap: written by this library), nothing else of
+// `a` is looked at
 static int tg_cellplan_ptap_impl(tg_cellplan_t pl, tg_csr_t a, const int64_t *rstart, const int32_t *zero_dofs, int64_t nzero,
-                                 double diag, tg_csr_t *k_out) {
+                                 double diag, tg_csr_t *k_out, bool trusted = false) {
   const int64_t nfe = pl->ncell * pl->b;
-  if (a->nrows != nfe || a->ncols != nfe || (!rstart && a->nnz != nfe * pl->b)) return 100;
+  if (!trusted && (a->nrows != nfe || a->ncols != nfe || (!rstart && a->nnz != nfe * pl->b))) return 100;
   int *status = (int *)g_tg.scratch;
   unsigned long long *sum = (unsigned long long *)(status + 2);
-  if (!rstart) {
+  if (!rstart && !trusted) {
     int hbad = 0;
     hipMemsetAsync(status, 0, 4 * sizeof(int), g_tg.stream);
     hipLaunchKernelGGL(k_cell_check, dim3((unsigned)std::min<int64_t>(tg_cdiv(nfe, 256), (int64_t)g_tg.num_cu * 16)), dim3(256), 0,
@@ -1169,10 +1316,14 @@ static int tg_cellplan_ptap_impl(tg_cellplan_t pl, tg_csr_t a, const int64_t *rs
     hipLaunchKernelGGL((k_cell_element<LGV>), dim3(grid), dim3(256), lds, g_tg.stream, a->val, rstart, pl->md, pl->nf,   \
                        pl->ncell, pl->b, pl->nfmax, eval);                                                              \
   } while (0)
-    if (lds > 160 * 1024) {
+    if (lds > 160 * 1024 && rstart) {
       cleanup();
       return 100;
     }
+    if (lds > 160 * 1024) {
+      hipLaunchKernelGGL(k_cell_element_big, dim3((unsigned)std::min<int64_t>(pl->ncell, (int64_t)g_tg.num_cu * 64)), dim3(256), 0,
+                         g_tg.stream, a->val, pl->md, pl->nf, pl->ncell, pl->b, pl->nfmax, eval);
+    } else
     switch (lgf) {
       case 3: CELL_GO(3); break;
       case 4: CELL_GO(4); break;
@@ -1315,7 +1466,7 @@ static int tg_cellplan_ptap_impl(tg_cellplan_t pl, tg_csr_t a, const int64_t *rs
         plan->k_nnz = nnz;
         // the places of the element entries in their rows of K, for all later products -- and for THIS one: its values
         // are formed again by places, so that every product on the plan adds in the same order (bit for bit the same K)
-        if (plan->max_k <= 255 && nnz < 0x7fffffffll * 4 && !getenv("TIGAR_CELL_MERGE_HASH")) {
+        if (plan->max_k < (pl->nfmax > 32 ? TG_CELL_ROWCAP : 256) && nnz < 0x7fffffffll * 4 && !getenv("TIGAR_CELL_MERGE_HASH")) {
           tg_dfree(pl->k_col);
           tg_dfree(pl->slot);
           pl->k_col = nullptr;
@@ -1706,4 +1857,147 @@ extern "C" int tg_foldplan_apply(tg_foldplan_t pl, tg_csr_t ku, const int32_t *z
   }
   *k_out = k;
   return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Element splitting (round 5): the cell-block product for CONNECTED grids.  A matrix assembled on a mesh whose
+// cells share nodes is a sum of element matrices; ANY splitting A = sum_c R_c^T A_c R_c into b x b blocks over the cells'
+// node lists gives  K = M^T A M = sum_c (R_c M)^T A_c (R_c M)  -- the cell-block product above with rows of M repeated per
+// cell.  The splitting used: an entry (r, s) goes to the LOWEST cell that holds both nodes.  Nothing about a lattice is
+// assumed: the cells' node lists are what dolfin's dofmap gives (V.dofmap().cell_dofs), A may hold any values on entries that
+// couple nodes of a common cell (every assembled FE matrix does; one that does not is declined, status 100).
+struct tg_elemsplit_s {
+  int64_t ncell = 0, nnz = 0, nrows = 0;
+  int b = 0;
+  int32_t *amap = nullptr;      // [ncell][b][b]: the entry of A that block position holds, -1 = none
+};
+
+__global__ void __launch_bounds__(256)
+    k_elem_assign(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ cellnodes,
+                  const int32_t *__restrict__ nptr, const int32_t *__restrict__ ncl, int64_t ncell, int b,
+                  int32_t *__restrict__ amap, unsigned long long *__restrict__ count) {
+  __shared__ int32_t nodes[64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned long long mine = 0;
+  for (int64_t c = blockIdx.x; c < ncell; c += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x < b) nodes[threadIdx.x] = cellnodes[c * b + threadIdx.x];
+    __syncthreads();
+    for (int i = w; i < b; i += 4) {
+      const int32_t r = nodes[i];
+      const int p0 = nptr[r], p1 = nptr[r + 1];
+      for (int64_t e = rowptr[r] + lane; e < rowptr[r + 1]; e += 64) {
+        const int32_t s = col[e];
+        int lo = 0, hi = b;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (nodes[mid] < s) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= b || nodes[lo] != s) continue;
+        // the lowest cell that holds r and s owns the entry: is there one below c ?
+        bool owner = true;
+        for (int q = p0; q < p1 && owner; q++) {
+          const int32_t c2 = ncl[q];
+          if (c2 >= c) break;                       // (ascending)
+          const int32_t *n2 = cellnodes + (int64_t)c2 * b;
+          int l2 = 0, h2 = b;
+          while (l2 < h2) {
+            const int mid = (l2 + h2) >> 1;
+            if (n2[mid] < s) l2 = mid + 1; else h2 = mid;
+          }
+          if (l2 < b && n2[l2] == s) owner = false;
+        }
+        if (owner) {
+          amap[(c * b + i) * (int64_t)b + lo] = (int32_t)e;
+          mine++;
+        }
+      }
+    }
+  }
+  mine = tg_wave_incl_scan_i64((int64_t)mine);
+  if (lane == 63 && mine) atomicAdd(count, mine);
+}
+
+__global__ void __launch_bounds__(256)
+    k_elem_gather(const int32_t *__restrict__ amap, const double *__restrict__ aval, int64_t n, double *__restrict__ blocks) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+    const int32_t e = amap[k];
+    blocks[k] = e >= 0 ? aval[e] : 0.0;
+  }
+}
+
+/* cellnodes_host [ncell][b]: the nodes of every cell in ASCENDING order; nptr_host [nrows + 1] / ncells_host: for every node
+ * the cells that hold it, ascending (the transposed list).  100: A holds an entry whose nodes share no cell. */
+extern "C" int tg_elemsplit_create(tg_csr_t a, int64_t ncell, int b, const int32_t *cellnodes_host, const int32_t *nptr_host,
+                                   const int32_t *ncells_host, tg_elemsplit_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(a && cellnodes_host && nptr_host && ncells_host && out && ncell > 0 && b >= 1 && b <= 64,
+             "bad arguments to tg_elemsplit_create");
+  TG_REQUIRE_CANONICAL(a);
+  TG_REQUIRE(a->nrows == a->ncols && a->nnz < 0x7fffffffll && a->nrows < 0x7fffffffll, "tg_elemsplit_create: matrix too large");
+  tg_elemsplit_s *sp = new tg_elemsplit_s();
+  sp->ncell = ncell, sp->b = b, sp->nnz = a->nnz, sp->nrows = a->nrows;
+  int32_t *cn = nullptr, *np = nullptr, *nc = nullptr;
+  const int64_t nb = ncell * (int64_t)b * b;
+  unsigned long long *cnt = (unsigned long long *)(g_tg.scratch + 8), h = 0;
+  int rc = tg_dmalloc(&sp->amap, nb) || tg_dmalloc(&cn, ncell * b) || tg_dmalloc(&np, a->nrows + 1) || tg_dmalloc(&nc, ncell * b);
+  if (!rc) {
+    hipMemcpyAsync(cn, cellnodes_host, (size_t)(ncell * b) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+    hipMemcpyAsync(np, nptr_host, (size_t)(a->nrows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+    hipMemcpyAsync(nc, ncells_host, (size_t)(ncell * b) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
+    hipMemsetAsync(sp->amap, 0xff, (size_t)nb * sizeof(int32_t), g_tg.stream);
+    hipMemsetAsync(cnt, 0, sizeof(h), g_tg.stream);
+    hipLaunchKernelGGL(k_elem_assign, dim3((unsigned)std::min<int64_t>(ncell, (int64_t)g_tg.num_cu * 64)), dim3(256), 0, g_tg.stream,
+                       a->rowptr, a->col, cn, np, nc, ncell, b, sp->amap, cnt);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
+        hipStreamSynchronize(g_tg.stream) != hipSuccess) {
+      tg_set_error("tg_elemsplit_create: the assignment kernel failed to run");
+      rc = 1;
+    }
+  }
+  tg_dfree(cn);
+  tg_dfree(np);
+  tg_dfree(nc);
+  if (!rc && (int64_t)h != a->nnz) rc = 100;      // an entry couples nodes without a common cell (or a node list is not sorted)
+  if (rc) {
+    tg_dfree(sp->amap);
+    delete sp;
+    return rc;
+  }
+  *out = sp;
+  return 0;
+}
+
+extern "C" int tg_elemsplit_destroy(tg_elemsplit_t sp) {
+  if (!sp) return 0;
+  if (g_tg.ready) {
+    hipStreamSynchronize(g_tg.stream);
+    tg_dfree(sp->amap);
+  }
+  delete sp;
+  return 0;
+}
+
+/* K = M^T A M through the element blocks of `sp` (the values of `a` gathered into [ncell][b][b]) and the cell plan made with
+ * tg_cellplan_create_from_rows for the same cells.  `a` must have the pattern the splitting was made for. */
+extern "C" int tg_elemsplit_ptap(tg_elemsplit_t sp, tg_cellplan_t plan, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero,
+                                 double diag, tg_csr_t *k_out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(sp && plan && a && k_out, "null argument to tg_elemsplit_ptap");
+  TG_REQUIRE(a->nnz == sp->nnz && a->nrows == sp->nrows && plan->ncell == sp->ncell && plan->b == sp->b,
+             "tg_elemsplit_ptap: the matrix or the cell plan is not the one the splitting was made for");
+  const int64_t nb = sp->ncell * (int64_t)sp->b * sp->b;
+  double *blocks = nullptr;
+  TG_TRY(tg_dmalloc(&blocks, nb + TG_CSR_PAD));
+  hipLaunchKernelGGL(k_elem_gather, dim3((unsigned)std::min<int64_t>(tg_cdiv(nb, 256), (int64_t)g_tg.num_cu * 32)), dim3(256), 0,
+                     g_tg.stream, sp->amap, a->val, nb, blocks);
+  tg_csr_s fake;
+  fake.val = blocks;
+  int rc = hipGetLastError() != hipSuccess ? 1 : tg_cellplan_ptap_impl(plan, &fake, nullptr, zero_dofs, nzero, diag, k_out, true);
+  fake.val = nullptr;
+  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+  tg_dfree(blocks);
+  return rc;
 }
