@@ -81,3 +81,50 @@ def test_an_entry_outside_every_cell_is_declined():
     plan = ElementSplitPtAP(M, cells)
     assert plan.ptap(dev.DeviceCSR.from_scipy(As.tocsr())) is None
     assert plan.ptap(A) is not None
+
+
+@pytest.mark.parametrize("d,p,nel", [(3, 2, 6), (2, 3, 14), (3, 3, 4)])
+def test_extract_matrix_takes_the_element_split_product(monkeypatch, d, p, nel):
+    """through the API (tIGAr/common.py:1194-1200): with the Kronecker paths switched off ``extractMatrix`` on an assembled
+    matrix runs the element-split product; a matrix with couplings beyond the cells (a band) falls through to the general
+    kernels; both equal scipy's triple product, Dirichlet rows and columns fused"""
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, forms as F
+    monkeypatch.setenv("TIGAR_PTAP_TENSOR", "0")
+    monkeypatch.setenv("TIGAR_PTAP_FACTORED", "0")
+    monkeypatch.setenv("TIGAR_PTAP_ELEMENTS", "2")
+    gen = t.EqualOrderSpline(1, B.ExplicitBSplineControlMesh([p] * d, [B.uniformKnots(p, 0., 1., nel)] * d))
+    s0 = gen.getScalarSpline(0)
+    for side in (0, 1):
+        gen.addZeroDofs(0, s0.getSideDofs(0, side))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    A = F.LaplaceForm().assemble_matrix(spline.V).to_scipy().tocsr()
+    rng = np.random.default_rng(p)
+    A.data = A.data + 0.1 * rng.standard_normal(A.nnz)
+    K = spline.extractMatrix(A).to_scipy().tocsr()
+    plan = spline.__dict__.get("_elem_plan")
+    assert plan is not None and plan[1] is not None and plan[1]._split is not None          # the element path ran
+    M = gen.M.to_scipy()
+    ref = (M.T @ A @ M).tolil()
+    zd = np.asarray(gen.zeroDofsArray(), dtype=np.int64)
+    ref[zd, :] = 0.0
+    ref[:, zd] = 0.0
+    for i in zd:
+        ref[i, i] = 1.0
+    ref = ref.tocsr()
+    assert abs(K - ref).max() <= 1e-12 * abs(ref).max()
+    # a band that reaches beyond the cells: declined by the splitting, the general kernels take it
+    i = np.arange(p * nel + 1)
+    C1 = sp.csr_matrix(np.abs(i[:, None] - i[None, :]) <= p)
+    P = C1
+    for _ in range(d - 1):
+        P = sp.kron(C1, P, format="csr")
+    Bm = P.astype(np.float64).tocsr()
+    Bm.data = rng.standard_normal(Bm.nnz)
+    K2 = spline.extractMatrix(Bm).to_scipy().tocsr()
+    ref2 = (M.T @ Bm @ M).tolil()
+    ref2[zd, :] = 0.0
+    ref2[:, zd] = 0.0
+    for i2 in zd:
+        ref2[i2, i2] = 1.0
+    assert abs(K2 - ref2.tocsr()).max() <= 1e-12 * abs(ref2).max()

@@ -1665,6 +1665,12 @@ class ExtractedSpline(object):
                             if zd is not None and len(zd):
                                 K.zero_rows_cols(numpy.asarray(zd, dtype=numpy.int32), float(diag))
                             return K
+        # connected meshes (what dolfin assembles on the Q_p / P_p mesh of the extraction, with an M that is used as a general
+        # CSR matrix): A split into one dense block per cell, then the same dense cell products (tigar_amd/elemptap.py)
+        if os.environ.get("TIGAR_PTAP_ELEMENTS", "1") != "0" and not A.is_loose():
+            K = self._extract_matrix_by_elements(A, zd, float(diag))
+            if K is not None:
+                return K
         key = (A.shape, A.nnz)
         fresh = self._ptap_plan is None or self._ptap_plan_key != key
         if fresh:
@@ -1686,6 +1692,31 @@ class ExtractedSpline(object):
             # recomputes the symbolic product on every call (tIGAr/common.py:1194-1195) -- plan again
             self._ptap_plan = _dev.ptap_symbolic(A, self.M, self.MT)
             return _dev.ptap_numeric(self._ptap_plan, A, self.M, self.MT, zd, float(diag))
+
+    def _extract_matrix_by_elements(self, A, zd, diag):
+        """M^T A M by the element-split cell-block product, or None when it does not apply: one field on one mesh whose cells
+        hold at most 64 nodes (the cells' node lists are the dofmap of ``self.V``), a system large enough for the plan to pay
+        (``TIGAR_PTAP_ELEMENTS=2``: any size), every entry of A between nodes of a common cell (any assembled FE matrix;
+        others fall through to the general kernels)"""
+        grids = getattr(self.V, "grids", None)
+        if self.nFields != 1 or not grids or len(grids) != 1 or A.shape != (self.M.shape[0], self.M.shape[0]):
+            return None
+        if self.M.shape[0] < 20000 and os.environ.get("TIGAR_PTAP_ELEMENTS", "1") != "2":
+            return None
+        g = grids[0]
+        if (int(g.degree) + 1) ** g.dim() > 64 or int(g.degree) < 1 or getattr(g, "dg", False):
+            return None
+        plan = self.__dict__.get("_elem_plan")
+        if plan is None or plan[0] is not self.M:
+            from .elemptap import ElementSplitPtAP
+            try:
+                plan = (self.M, ElementSplitPtAP(self.M, _cell_dofs_arrays(g)))
+            except (ValueError, _dev.TigarHipError):
+                plan = (self.M, None)
+            self.__dict__["_elem_plan"] = plan
+        if plan[1] is None:
+            return None
+        return plan[1].ptap(A, zd, diag)
 
     def _block_producer(self, A):
         """``a_block(f, g, r0, r1)`` for the field-block engine: rows [r0, r1) of block (f, g) of an FE matrix on the mixed
