@@ -35,6 +35,7 @@ def _run(args, env, tool="fuzz_parity.py"):
     (108, {"TIGAR_PTAP_UNWRAP": "0"}),
     (109, {"TIGAR_EXTRACT_KRON": "0"}),
     (110, {"TIGAR_FUZZ_ROUNDTRIP": "1"}),        # through writeExtraction / ExtractedSpline(dirname): a stored M without structure
+    (111, {"TIGAR_PTAP_TENSOR": "0", "TIGAR_PTAP_FACTORED": "0", "TIGAR_PTAP_ELEMENTS": "2"}),   # element-split cell products
 ])
 def test_random_patches_match_the_oracle(seed, env):
     rc, summary, failures = _run(["--seed", str(seed), "--cases", "80"], env)

@@ -1698,7 +1698,7 @@ class ExtractedSpline(object):
         hold at most 64 nodes (the cells' node lists are the dofmap of ``self.V``), a system large enough for the plan to pay
         (``TIGAR_PTAP_ELEMENTS=2``: any size), every entry of A between nodes of a common cell (any assembled FE matrix;
         others fall through to the general kernels)"""
-        grids = getattr(self.V, "grids", None)
+        grids = getattr(getattr(self, "V", None), "grids", None)
         if self.nFields != 1 or not grids or len(grids) != 1 or A.shape != (self.M.shape[0], self.M.shape[0]):
             return None
         if self.M.shape[0] < 20000 and os.environ.get("TIGAR_PTAP_ELEMENTS", "1") != "2":
