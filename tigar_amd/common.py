@@ -1701,22 +1701,29 @@ class ExtractedSpline(object):
         grids = getattr(getattr(self, "V", None), "grids", None)
         if self.nFields != 1 or not grids or len(grids) != 1 or A.shape != (self.M.shape[0], self.M.shape[0]):
             return None
-        if self.M.shape[0] < 20000 and os.environ.get("TIGAR_PTAP_ELEMENTS", "1") != "2":
-            return None
-        g = grids[0]
-        if (int(g.degree) + 1) ** g.dim() > 64 or int(g.degree) < 1 or getattr(g, "dg", False):
-            return None
         plan = self.__dict__.get("_elem_plan")
         if plan is None or plan[0] is not self.M:
-            from .elemptap import ElementSplitPtAP
-            try:
-                plan = (self.M, ElementSplitPtAP(self.M, _cell_dofs_arrays(g)))
-            except (ValueError, _dev.TigarHipError):
-                plan = (self.M, None)
+            plan = (self.M, self._element_plan_for(self.M))
             self.__dict__["_elem_plan"] = plan
         if plan[1] is None:
             return None
         return plan[1].ptap(A, zd, diag)
+
+    def _element_plan_for(self, M):
+        """ElementSplitPtAP for the scalar extraction operator ``M`` on the (first) mesh of the FE space, or None"""
+        if os.environ.get("TIGAR_PTAP_ELEMENTS", "1") == "0":
+            return None
+        grids = getattr(getattr(self, "V", None), "grids", None)
+        if not grids or (M.shape[0] < 20000 and os.environ.get("TIGAR_PTAP_ELEMENTS", "1") != "2"):
+            return None
+        g = grids[0]
+        if (int(g.degree) + 1) ** g.dim() > 64 or int(g.degree) < 1 or getattr(g, "dg", False) or g.num_nodes() != M.shape[0]:
+            return None
+        from .elemptap import ElementSplitPtAP
+        try:
+            return ElementSplitPtAP(M, _cell_dofs_arrays(g))
+        except (ValueError, _dev.TigarHipError):
+            return None
 
     def _block_producer(self, A):
         """``a_block(f, g, r0, r1)`` for the field-block engine: rows [r0, r1) of block (f, g) of an FE matrix on the mixed
@@ -1774,6 +1781,12 @@ class ExtractedSpline(object):
             if not scalar:
                 scalar["M"] = self.M.block(0, nfe, 0, ncp)
                 scalar["MT"] = scalar["M"].transpose()
+                scalar["elem"] = self._element_plan_for(scalar["M"])
+            if scalar["elem"] is not None and not Aij.is_loose():
+                # (every block of an assembled matrix on the mixed space couples nodes of common cells of the scalar mesh)
+                Kij = scalar["elem"].ptap(Aij, None, 1.0)
+                if Kij is not None:
+                    return Kij
             return _dev.ptap_numeric(_dev.ptap_symbolic(Aij, scalar["M"], scalar["MT"]), Aij, scalar["M"], scalar["MT"])
 
         blocks = []
