@@ -190,6 +190,27 @@ def test_cg_solve_on_the_half_storage_copy(dev, p, nel, mapped, monkeypatch):
     assert np.array_equal(U2.get_local().view(np.int64), res["1"][1].view(np.int64))
 
 
+def test_chebyshev_cg_on_the_half_storage_copy(dev, monkeypatch):
+    """CG with the Chebyshev polynomial preconditioner multiplies by the same copy (degree products per iteration)"""
+    import tigar_amd as t
+    from tigar_amd.device import DeviceVector
+    spline, K, rhs = _poisson3d(2, (40, 40, 40))
+    n = K.shape[0]
+    monkeypatch.setenv("TIGAR_KSP_PERSISTENT", "0")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TIGAR_SPMV_SYM", mode)
+        ks = t.PETScKrylovSolver("cg", "chebyshev")
+        ks.parameters["relative_tolerance"] = 1e-9
+        U = DeviceVector(n)
+        c0 = dev.prof_get(7)[1]
+        its = ks.solve(K, U, rhs)
+        assert ks.last["status"] == 0 and dev.prof_get(7)[1] - c0 == int(mode)
+        out[mode] = (its, U.get_local())
+    assert abs(out["0"][0] - out["1"][0]) <= 1
+    assert np.max(np.abs(out["0"][1] - out["1"][1])) <= 1e-7 * np.max(np.abs(out["0"][1]))
+
+
 def test_small_systems_and_other_solvers_keep_their_kernels(dev, monkeypatch):
     """below 65536 rows (the persistent kernels' range) and for gmres nothing changes; TIGAR_SPMV_SYM=2 forces the copy"""
     import tigar_amd as t

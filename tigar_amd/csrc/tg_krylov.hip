@@ -1193,7 +1193,14 @@ static int tg_pcg_cheb(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int degree, double
   double *sc = g_tg.scratch + TG_SCRATCH_DOUBLES - 2048;
   const int vg = tg_vec_grid(n);
   TG_TRY(tg_spmv_plan(k));
-  tg_sell_guard sell_guard(k);
+  tg_symgrid_guard sym;        // (CG with a polynomial preconditioner: the same premise, the same half-storage copy)
+  {
+    const int sym_on = getenv("TIGAR_SPMV_SYM") ? atoi(getenv("TIGAR_SPMV_SYM")) : 1;
+    const int sym_verify = getenv("TIGAR_SPMV_SYM_VERIFY") ? atoi(getenv("TIGAR_SPMV_SYM_VERIFY")) : 1;
+    if (sym_on && (n >= 65536 || sym_on > 1) && k->sell_state != 1) TG_TRY(tg_symgrid_build(k, row0, sym_verify, &sym.s));
+    if (sym.s) g_tg.prof_n[TG_PROF_KSP_SYMGRID] += 1;
+  }
+  tg_sell_guard sell_guard(k, sym.s != nullptr);
   TG_TRY(sell_guard.rc);
   const double *ushift = uext - (row0 - hlo);
   const int64_t cmin = row0 - hlo, cmax = row0 - hlo + next - 1;
@@ -1209,6 +1216,7 @@ static int tg_pcg_cheb(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int degree, double
   } evg{e0, e1};
   auto product = [&](double *out) -> int {            // out = K (vector in uext)
     TG_TRY(tg_comm_halo_exchange(comm, uext));
+    if (sym.s) return tg_symgrid_spmv(sym.s, k, ushift, cmin, cmax, out, 0, nullptr, 0.0);
     return tg_spmv_raw(k, ushift, cmin, cmax, out);
   };
   auto reduce = [&](int cnt, double *host) -> int {    // folds `cnt` interleaved partial streams, sums over ranks, reads

@@ -12,8 +12,9 @@
 // so a product moves HALF the bytes.  The second line is a scatter; what makes it cheap is the geometry, not the CSR
 // arrays: the grid is cut into patches of at most 24 x 16 points in (x, y), a wave owns one patch and walks it plane by
 // plane along z.  Everything the wave scatters lands in the window (patch + P points on every side) of the current and
-// the next P planes, which it keeps in LDS as a ring of P + 1 planes (21 KB for P = 3) and adds to by read - add - write --
-// one wave per window, LDS operations of a wave complete in order, so the sums are the same bit for bit in every run.  When
+// the next P planes, which it keeps in LDS as a ring of P + 1 planes (21 KB for P = 3, beside a ring of the same planes of
+// x) and adds to by read - add - write -- one wave per window, LDS operations of a wave complete in order, so the sums are
+// the same bit for bit in every run.  When
 // a plane is finished its window goes to a staging array (1 % of the value bytes); a second small kernel adds, for
 // every row, the windows that cover it (its own patch, up to 3 x 3 neighbours in the plane, the previous z chunk) in a
 // fixed order.  No global atomics.
@@ -27,8 +28,12 @@
 #include <utility>
 #include <vector>
 
+#ifndef SG_PX
 #define SG_PX 24          // widest / highest patch (points)
+#endif
+#ifndef SG_PY
 #define SG_PY 16
+#endif
 #define SG_TAB (SG_PX * SG_PY)
 
 typedef double sg_d2 __attribute__((ext_vector_type(2)));
@@ -69,7 +74,7 @@ struct sg_lay {
     return i < N0 ? NA + i * (P + 1) + (dz == 0 ? P : dz - 1) : (i - N0) * P + (dz - 1);
   }
   // batches: storage indices [bstart(b), bstart(b + 1)), even boundaries on group boundaries; their number is a multiple
-  // of 4 (the product kernel keeps 4 batches of values and of x in registers, buffer = batch mod 4)
+  // of 4 (the product kernel keeps 4 batches of values in registers, buffer = batch mod 4)
   static constexpr int NBATCH = P == 3 ? 24 : P == 2 ? 12 : 4;
   __host__ __device__ static constexpr int bstart(int b) {
     return P == 3   ? (b <= 12 ? 6 * b : b < 24 ? 72 + 8 * (b - 12) : 172)
@@ -212,43 +217,41 @@ __global__ void __launch_bounds__(256)
   if (bad) atomicExch(fail, 1);
 }
 
-// ---- the product: one wave per (patch, z chunk).  The stream of values is what bounds the kernel, and with one wave
-// per 21 KB window there are only 7 waves on a CU: the loads of the NEXT batch of positions (of the next sub-step / plane
-// at the end of one) are issued three batches (18 KB per wave) before they are multiplied: with one batch in flight the
-// kernel ran at waves x batch / HBM latency = 5 TB/s whatever else was done to it.
+// ---- the product: one wave per (patch, z chunk).  Two rings of P + 1 window planes in LDS: the sums (current plane and
+// the P planes the transposed entries reach) and the x the wave multiplies with (loaded once per plane, 43 KB together at
+// P = 3 -> 3 waves per CU).  For a stored value a = K[i][i+off] ONE window index serves both uses: sum_i += a * xs[idx],
+// acc[idx] += a * x_i.  The vector memory pipe carries the value stream only; its loads are issued three batches (18 KB
+// per wave) before they are multiplied.  (With x gathered from global memory -- 171 gathers per row through the L1, whose
+// 32 KB do not hold the windows of the waves of a CU -- the product took 0.55 ms longer at cfg3's size, and vmcnt, which
+// counts in issue order, tied the depth of the value ring to that of the gathers.)
 //
-// window[place] += v for the 64 lanes of the wave (64 distinct places) is a plain read - add - write, not ds_add_f64: the LDS
+// acc[idx] += v for the 64 lanes of the wave (64 distinct places) is a plain read - add - write, not ds_add_f64: the LDS
 // adds fp64 atomics at about one lane per clock, which alone would take as long as the whole product.  It is safe because
 // the wave is the only one on its window and its LDS operations complete in order -- but the places of DIFFERENT lanes
 // overlap between positions (lane i at dx + 1 is lane i + 1 at dx), so the order of these accesses must stay what the
 // program says, whatever the compiler can prove about one lane's own addresses: a compiler barrier after every group
 // (`volatile` would do as well but makes the backend wait for ALL outstanding loads at every access).  The members of a
 // group (see sg_lay) go to different planes of the ring, their reads are issued together and then their writes.
-struct sg_ctx {
-  int row, lb;
-  double xi;
-  const sg_d2 *v;
-};
-
+//
+// xw: the window of x this rank may read (its own rows and the halo planes of its z neighbours), local row r at
+// xw[xoff + r]; reads beyond it return 0 (buffer range check; such entries of K are stored zeros: rows at the faces of the
+// grid).  What is scattered beyond the block's last plane is dropped: those rows belong to the next rank, which holds the
+// transposed entries in ITS rows (k_symgrid_lowhalo).
 template <int P>
-__global__ void __launch_bounds__(64, 2)      // (two waves per SIMD: 256 registers; the windows allow 7 waves per CU)
+__global__ void __launch_bounds__(64, 2)
     k_symgrid_spmv(sg_dev G, const sg_d2 *__restrict__ val, const double *__restrict__ xw, int xoff, int xlen,
-                   double *__restrict__ stage, int64_t nwaves, int c_begin, int c_count, const double *__restrict__ gate,
-                   double gate_tol) {
-  // xw: the window of x this rank may read (its own rows and the halo planes of its z neighbours), local row r at
-  // xw[xoff + r]; entries of K that reach beyond the window are stored zeros (rows at the faces of the grid) -- reads
-  // beyond it return 0 (buffer range check).  What is scattered beyond the block's last plane is dropped: those rows
-  // belong to the next rank, which holds the transposed entries in ITS rows (k_symgrid_lowhalo)
+                      double *__restrict__ stage, int64_t nwaves, int c_begin, int c_count, const double *__restrict__ gate,
+                      double gate_tol) {
   typedef sg_c<P> C;
   typedef sg_lay<P> Y;
-  constexpr int Wx = C::Wx, W = C::W, GB = Y::GBMAX, NB = Y::NBATCH;
+  constexpr int Wx = C::Wx, W = C::W, GB = Y::GBMAX, NB = Y::NBATCH, NXL = (W + 63) / 64;
   __shared__ double acc[(P + 1) * W];
+  __shared__ double xs[(P + 1) * W];
   __shared__ unsigned short tab[SG_TAB];
   if (gate && !(*gate > gate_tol)) return;
   const int lane = threadIdx.x;
   const int64_t L = tg_xcd_block(blockIdx.x, nwaves);
   if (L >= nwaves) return;
-  // (this launch: the z chunks [c_begin, c_begin + c_count) of every patch)
   const int c = c_begin + (int)(L % c_count), patch = (int)(L / c_count);
   const int a = patch % G.npx, b = patch / G.npx;
   const int xa = G.x0[a], pxv = G.x0[a + 1] - xa, ya = G.y0[b], pyv = G.y0[b + 1] - ya;
@@ -259,62 +262,70 @@ __global__ void __launch_bounds__(64, 2)      // (two waves per SIMD: 256 regist
     tab[t] = (unsigned short)((ly << 8) | (t - ly * pxv));
   }
   for (int e = lane; e < (P + 1) * W; e += 64) acc[e] = 0.0;
-  __syncthreads();
   const __amdgpu_buffer_rsrc_t xr =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(xw), 0, (unsigned)xlen * 8u, 0x00020000);
-  const double *__restrict__ x = xw + xoff;
   const int n0 = G.n0, n01 = G.n0 * G.n1;
+  // in-plane offset of this lane's window entries (the same for every plane); out of the grid: no read (0)
+  unsigned woff[NXL];
+#pragma unroll
+  for (int k = 0; k < NXL; k++) {
+    const int e = k * 64 + lane, wy = e / Wx, wx = e - wy * Wx;
+    const int gy = ya - P + wy, gx = xa - P + wx;
+    woff[k] = (e < W && gy >= 0 && gy < G.n1 && gx >= 0 && gx < n0) ? (unsigned)(gy * n0 + gx + xoff) : 0xffffffffu;
+  }
+  auto load_plane = [&](int zp, double *dst) {       // plane zp of the window (beyond the block: the halo, else 0)
+#pragma unroll
+    for (int k = 0; k < NXL; k++)
+      dst[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                              xr, woff[k] == 0xffffffffu ? 0xffffffffu : (woff[k] + (unsigned)(zp * n01)) * 8u, 0, 0));
+  };
+  auto store_plane = [&](int zp, const double *src) {
+    const int s0 = (zp % (P + 1)) * W;
+#pragma unroll
+    for (int k = 0; k < NXL; k++)
+      if (k * 64 + lane < W) xs[s0 + k * 64 + lane] = src[k];
+  };
+  {
+    double tmp[NXL];
+#pragma unroll
+    for (int d = 0; d <= P; d++) {
+      load_plane(za + d, tmp);
+      store_plane(za + d, tmp);
+    }
+  }
+  __syncthreads();
   double *st = stage + ((int64_t)patch * G.nch + c) * (int64_t)(G.czmax + P) * W;
   const sg_d2 *vp = val + (int64_t)patch * G.n2 * G.m * (int64_t)(C::NG * 64) + lane;
-
+  struct ctx_t {
+    int lb;
+    const sg_d2 *v;
+  };
   auto ctx_of = [&](int z, int sub) {
-    // (lanes beyond the patch in its last sub-step: stored zeros times the x of point 0; a look-ahead beyond the last
-    // plane of the grid re-reads the last plane and is not used)
-    sg_ctx k;
+    ctx_t k;
     const int t = sub * 64 + lane, zc = min(z, G.n2 - 1);
     const int tl = t < cnt ? tab[t] : 0, ly = tl >> 8, lx = tl & 255;
-    k.row = (zc * G.n1 + ya + ly) * n0 + xa + lx;
     k.lb = ly * Wx + lx;
     k.v = vp + ((int64_t)zc * G.m + sub) * (C::NG * 64);
-    k.xi = x[k.row];
     return k;
   };
-  // batches of values / of x held in registers.  The same depth for both: vmcnt counts loads in the order of issue, so
-  // waiting for an x gather issued one batch ahead would also wait for every value load issued before it
-  constexpr int VD = 4, XD = 4;
+  constexpr int VD = 4;      // batches of values held in registers (deeper rings: no gain)
   sg_d2 vv[VD][GB];
-  double xx[XD][2 * GB];
-  // loads of batch BT (compile-time) of the row block k: the values (the HBM stream, VD - 1 batches ahead) ...
-  auto issue_v = [&](const sg_ctx &k, auto btc) {
+  auto issue_v = [&](const ctx_t &k, auto btc) {
     constexpr int BT = decltype(btc)::value, b0 = Y::bstart(BT), b1 = Y::bstart(BT + 1);
 #pragma unroll
     for (int j = 0; j < (b1 - b0) / 2; j++) vv[BT % VD][j] = __builtin_nontemporal_load(k.v + (b0 / 2 + j) * 64);
   };
-  // ... and the x they multiply (cache hits mostly)
-  auto issue_x = [&](const sg_ctx &k, auto btc) {
-    constexpr int BT = decltype(btc)::value, b0 = Y::bstart(BT), b1 = Y::bstart(BT + 1);
-#pragma unroll
-    for (int l = 0; l < b1 - b0; l++) {
-      constexpr int Pc = P;
-      const int pos = b0 + l < Y::NP ? Y::pos(b0 + l) : 0;
-      if (pos > 0) {
-        const int off = sg_dx(Pc, pos) + n0 * sg_dy(Pc, pos) + n01 * sg_dz(Pc, pos);
-        xx[BT % XD][l] =
-            __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xr, (unsigned)(k.row + off + xoff) * 8u, 0, 0));
-      }
-    }
-  };
-  sg_ctx cur = ctx_of(za, 0);
-  sg_each(std::make_integer_sequence<int, VD - 1>{}, [&](auto btc) {
-    issue_v(cur, btc);
-    issue_x(cur, btc);
-  });
+  ctx_t cur = ctx_of(za, 0);
+  sg_each(std::make_integer_sequence<int, VD - 1>{}, [&](auto btc) { issue_v(cur, btc); });
   for (int z = za; z < zb; z++) {
     int so[P + 1];
 #pragma unroll
     for (int d = 0; d <= P; d++) so[d] = ((z + d) % (P + 1)) * W;
+    double xnext[NXL];
+    load_plane(z + P + 1, xnext);                      // (arrives while the plane is multiplied)
     for (int sub = 0; sub < msub; sub++) {
-      const sg_ctx nxt = (sub + 1 < msub) ? ctx_of(z, sub + 1) : ctx_of(z + 1, 0);
+      const ctx_t nxt = (sub + 1 < msub) ? ctx_of(z, sub + 1) : ctx_of(z + 1, 0);
+      const double xi = xs[so[0] + cur.lb + P * Wx + P];
       double sum = 0.0;
       sg_each(std::make_integer_sequence<int, NB>{}, [&](auto btc) {
         constexpr int BT = decltype(btc)::value;
@@ -322,10 +333,6 @@ __global__ void __launch_bounds__(64, 2)      // (two waves per SIMD: 256 regist
           issue_v(cur, std::integral_constant<int, BT + VD - 1>{});
         else
           issue_v(nxt, std::integral_constant<int, BT + VD - 1 - NB>{});
-        if constexpr (BT + XD - 1 < NB)
-          issue_x(cur, std::integral_constant<int, BT + XD - 1>{});
-        else
-          issue_x(nxt, std::integral_constant<int, BT + XD - 1 - NB>{});
         __builtin_amdgcn_sched_barrier(0);
         constexpr int b0 = Y::bstart(BT), b1 = Y::bstart(BT + 1);
         constexpr int gs = b0 < Y::NA ? P : P + 1, ng = (b1 - b0 + gs - 1) / gs;
@@ -340,12 +347,12 @@ __global__ void __launch_bounds__(64, 2)      // (two waves per SIMD: 256 regist
             const int pos = (kk < b1 && kk < Y::NP) ? Y::pos(kk) : -1;
             const double vq = (l & 1) ? vv[BT % VD][l >> 1].y : vv[BT % VD][l >> 1].x;
             if (pos == 0) {
-              sum += vq * cur.xi;
+              sum += vq * xi;
             } else if (pos > 0) {
-              sum += vq * xx[BT % XD][l];
               idx[t] = so[sg_dz(Pc, pos)] + cur.lb + (sg_dy(Pc, pos) + P) * Wx + sg_dx(Pc, pos) + P;
+              sum += vq * xs[idx[t]];
               r[t] = acc[idx[t]];
-              cc[t] = vq * cur.xi;
+              cc[t] = vq * xi;
             }
           }
 #pragma unroll
@@ -363,15 +370,14 @@ __global__ void __launch_bounds__(64, 2)      // (two waves per SIMD: 256 regist
       cur = nxt;
     }
     __syncthreads();
-    // plane z is complete as far as this wave goes: out to the staging array, slot free for plane z + P + 1
     double *sp = st + (int64_t)(z - za) * W;
     for (int e = lane; e < W; e += 64) {
       sp[e] = acc[so[0] + e];
       acc[so[0] + e] = 0.0;
     }
+    store_plane(z + P + 1, xnext);                     // (into the slot of plane z, which no row reads any more)
     __syncthreads();
   }
-  // what was scattered beyond the chunk: planes zb .. zb + P - 1 (the next chunk's first planes)
 #pragma unroll
   for (int d = 0; d < P; d++) {
     const int z = zb + d;
