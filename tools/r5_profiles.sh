@@ -23,6 +23,7 @@ headline)
 mappedbench)
   timeout 900 python bench.py --geometry volume --steps 3 --warmup 1 --no-cpu-baseline --companion 0 --live-traffic 0 > $O/r5_bench_cfg3_mapped_geometry.json 2> $O/r5_bench_cfg3_mapped_geometry.log
   stats cfg3_mapped python $R/bench.py --geometry volume --steps 2 --warmup 1 $W
+  pmc cfg3_mapped python $R/bench.py --geometry volume --steps 1 --warmup 1 $W
   ;;
 mapped)
   timeout 900 python bench.py --geometry volume --steps 3 --warmup 1 --no-cpu-baseline --companion 0 --live-traffic 0 > $O/r5_bench_cfg3_mapped_geometry.json 2> $O/r5_bench_cfg3_mapped_geometry.log
@@ -35,6 +36,16 @@ mapped)
 rt)
   stats rt64_k1_streamed env TIGAR_IMPLICIT_M=1 python $R/tools/rt_bench.py 64 1 3
   pmc rt64_k1_streamed env TIGAR_IMPLICIT_M=1 python $R/tools/rt_bench.py 64 1 2
+  ;;
+table)
+  stats cfg2 python $R/bench.py --workload cfg2 --steps 10 --warmup 2 $W
+  pmc cfg2 python $R/bench.py --workload cfg2 --steps 5 --warmup 1 $W
+  stats cfg4 python $R/bench.py --workload cfg4 --solver cg --rtol 1e-10 --steps 3 --warmup 1 $W
+  pmc cfg4 python $R/bench.py --workload cfg4 --solver cg --rtol 1e-10 --steps 2 --warmup 1 $W
+  stats cfg5 python $R/bench.py --workload cfg5 --rtol 1e-10 --steps 5 --warmup 1 $W
+  pmc cfg5 python $R/bench.py --workload cfg5 --rtol 1e-10 --steps 3 --warmup 1 $W
+  stats elemsplit python $R/tools/elem_ptap_bench.py 3 64 /dev/null 0
+  pmc elemsplit python $R/tools/elem_ptap_bench.py 3 64 /dev/null 0
   ;;
 small)
   timeout 600 python bench.py --workload cfg2 --steps 10 --warmup 2 --no-cpu-baseline > $O/r5_bench_cfg2.json 2> $O/r5_bench_cfg2.log
