@@ -388,36 +388,36 @@ __global__ void __launch_bounds__(64)
   }
 }
 
-// y[i] = sum of the windows that cover point i, in a fixed order (own patch, its neighbours in the plane where i lies within P
-// of the patch edge, the previous z chunk for the first P planes of a chunk).  One thread per row, 32-bit index arithmetic.
+// y[i] = sum of the windows that cover point i, in a fixed order.  One workgroup per grid line (iy, iz): which patch rows
+// and chunks cover the line is wave-uniform, a thread only looks up the patch column of its ix.
 template <int P>
 __global__ void __launch_bounds__(256)
-    k_symgrid_combine(sg_dev G, const double *__restrict__ stage, double *__restrict__ y, unsigned nrows,
+    k_symgrid_combine(sg_dev G, const double *__restrict__ stage, double *__restrict__ y, int64_t nlines,
                       const double *__restrict__ gate, double gate_tol) {
   typedef sg_c<P> C;
   constexpr int Wx = C::Wx, W = C::W;
   if (gate && !(*gate > gate_tol)) return;
   const int64_t cstride = (int64_t)(G.czmax + P) * W;
-  const unsigned n0 = (unsigned)G.n0, n1 = (unsigned)G.n1, stride = gridDim.x * 256u;
-  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nrows; i += stride) {
-    const unsigned line = i / n0;
-    const int ix = (int)(i - line * n0);
-    const unsigned uz = line / n1;
-    const int iy = (int)(line - uz * n1), iz = (int)uz;
-    const int a0 = G.px_of[ix], b0 = G.py_of[iy], c0 = G.pc_of[iz];
-    const int alo = (a0 > 0 && ix - G.x0[a0] < P) ? a0 - 1 : a0;
-    const int ahi = (a0 + 1 < G.npx && G.x0[a0 + 1] - ix <= P) ? a0 + 1 : a0;
+  for (int64_t line = blockIdx.x; line < nlines; line += gridDim.x) {
+    const int iy = (int)(line % G.n1), iz = (int)(line / G.n1);
+    const int b0 = G.py_of[iy], c0 = G.pc_of[iz];
     const int blo = (b0 > 0 && iy - G.y0[b0] < P) ? b0 - 1 : b0;
     const int bhi = (b0 + 1 < G.npy && G.y0[b0 + 1] - iy <= P) ? b0 + 1 : b0;
     const int clo = (c0 > 0 && iz - G.z0[c0] < P) ? c0 - 1 : c0;
-    double s = 0.0;
-    for (int c = clo; c <= c0; c++)
-      for (int b = blo; b <= bhi; b++) {
-        const double *sb = stage + ((int64_t)(b * G.npx) * G.nch + c) * cstride + (int64_t)(iz - G.z0[c]) * W +
-                           (iy - G.y0[b] + P) * Wx + P;
-        for (int a = alo; a <= ahi; a++) s += sb[(int64_t)a * G.nch * cstride + (ix - G.x0[a])];
-      }
-    y[i] = s;
+    double *yl = y + line * G.n0;
+    for (int ix = threadIdx.x; ix < G.n0; ix += 256) {
+      const int a0 = G.px_of[ix];
+      const int alo = (a0 > 0 && ix - G.x0[a0] < P) ? a0 - 1 : a0;
+      const int ahi = (a0 + 1 < G.npx && G.x0[a0 + 1] - ix <= P) ? a0 + 1 : a0;
+      double s = 0.0;
+      for (int c = clo; c <= c0; c++)
+        for (int b = blo; b <= bhi; b++) {
+          const double *sb = stage + ((int64_t)(b * G.npx) * G.nch + c) * cstride + (int64_t)(iz - G.z0[c]) * W +
+                             (iy - G.y0[b] + P) * Wx + P;
+          for (int a = alo; a <= ahi; a++) s += sb[(int64_t)a * G.nch * cstride + (ix - G.x0[a])];
+        }
+      yl[ix] = s;
+    }
   }
 }
 
@@ -495,9 +495,9 @@ static void sg_launch_spmv(const tg_symgrid_s *s, tg_csr_s *a, const double *x_s
   if (part == 1) chunks(0, s->nch - 1);
   if (part == 2) chunks(s->nch - 1, 1);
   if (part == 1) return;
-  const int64_t nrows = (int64_t)s->n0 * s->n1 * s->n2;
-  hipLaunchKernelGGL(k_symgrid_combine<P>, dim3((unsigned)std::min<int64_t>(tg_cdiv(nrows, 256), (int64_t)g_tg.num_cu * 32)), dim3(256),
-                     0, g_tg.stream, sg_view(s), s->stage, y, (unsigned)nrows, gate, tol);
+  const int64_t nlines = (int64_t)s->n1 * s->n2;
+  hipLaunchKernelGGL(k_symgrid_combine<P>, dim3((unsigned)std::min<int64_t>(nlines, (int64_t)g_tg.num_cu * 64)), dim3(256), 0,
+                     g_tg.stream, sg_view(s), s->stage, y, nlines, gate, tol);
   if (s->zoff > 0) {
     const int64_t low = (int64_t)std::min(s->P, s->n2) * s->n0 * s->n1;
     hipLaunchKernelGGL(k_symgrid_lowhalo, dim3((unsigned)std::min<int64_t>(tg_cdiv(low, 4), (int64_t)g_tg.num_cu * 32)),
