@@ -263,7 +263,8 @@ int tg_cellplan_destroy(tg_cellplan_t plan);
  * tg_cellplan_create_from_rows: the plan for cells given by node lists (cellnodes_host [ncell][b], ascending per cell; rows
  * of m), dense rows of M gathered on the device.  tg_elemsplit_create: assigns every entry of `a` to the lowest cell holding
  * both its nodes (nptr_host [nrows + 1] / ncells_host: the cells of every node, ascending); 100 = an entry couples nodes
- * without a common cell.  tg_elemsplit_ptap: gathers the values of `a` (same pattern) into blocks and runs the product. */
+ * without a common cell.  tg_elemsplit_ptap: gathers the values of `a` into blocks and runs the product; 100 when `a` does
+ * not have the pattern the splitting was made for (hash of row pointer and column indices: make a new splitting). */
 int tg_cellplan_create_from_rows(int64_t ncell, int b, int nfmax, tg_csr_t m, const int32_t *cellnodes_host,
                                  const int32_t *fl_host, const int32_t *nf_host, tg_csr_t incidence, int max_k, double mean_k,
                                  tg_cellplan_t *out);

@@ -71,6 +71,35 @@ def test_element_split_product_matches_scipy(d, p, nels):
     assert abs(Kz.tocsr() - refz.tocsr()).max() <= 1e-12 * abs(ref).max()
 
 
+def test_another_pattern_of_the_same_size_is_split_again():
+    """the splitting maps block positions to entries of the matrix it was made for; a matrix with as many rows and entries but
+    another pattern (here: one coupling moved within a cell) must not be read through it -- the reference redoes the symbolic
+    product at every call (tIGAr/common.py:1194-1195)"""
+    from tigar_amd import device as dev
+    from tigar_amd.elemptap import ElementSplitPtAP
+    A, M, cells = _operands(2, 2, (9, 7))
+    Ms = M.to_scipy().tocsr()
+    full = A.to_scipy().tocsr()
+    c = cells[5]
+    e1, e2 = (int(c[0]), int(c[3])), (int(c[4]), int(c[7]))
+    assert full[e1] != 0.0 and full[e2] != 0.0
+
+    def without(entry):
+        L = full.tolil()
+        L[entry] = 0.0
+        L = L.tocsr()
+        L.eliminate_zeros()
+        return L
+
+    B1, B2 = without(e1), without(e2)                 # as many rows and entries, another pattern
+    assert B1.nnz == B2.nnz == full.nnz - 1
+    plan = ElementSplitPtAP(M, cells)
+    for B in (B1, B2, B1):
+        K = plan.ptap(dev.DeviceCSR.from_scipy(B)).to_scipy()
+        ref = Ms.T @ B @ Ms
+        assert abs(K - ref).max() <= 1e-12 * abs(ref).max()
+
+
 def test_an_entry_outside_every_cell_is_declined():
     from tigar_amd import device as dev
     from tigar_amd.elemptap import ElementSplitPtAP

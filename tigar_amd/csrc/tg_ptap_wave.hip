@@ -1869,6 +1869,7 @@ extern "C" int tg_foldplan_apply(tg_foldplan_t pl, tg_csr_t ku, const int32_t *z
 // couple nodes of a common cell (every assembled FE matrix does; one that does not is declined, status 100).
 struct tg_elemsplit_s {
   int64_t ncell = 0, nnz = 0, nrows = 0;
+  unsigned long long pattern = 0;   // order-independent hash of (row pointer, column indices) of the matrix it was made for
   int b = 0;
   int32_t *amap = nullptr;      // [ncell][b][b]: the entry of A that block position holds, -1 = none
 };
@@ -1919,6 +1920,37 @@ __global__ void __launch_bounds__(256)
   if (lane == 63 && mine) atomicAdd(count, mine);
 }
 
+// sum over the entries of mix(position, column) + sum over the rows of mix(row, start): integers, any order
+__global__ void __launch_bounds__(256)
+    k_elem_pattern_hash(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nrows, int64_t nnz,
+                        unsigned long long *__restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  unsigned long long h = 0;
+  auto mix = [](unsigned long long z) {
+    z *= 0x9E3779B97F4A7C15ull;
+    z ^= z >> 32;
+    z *= 0xD6E8FEB86659FD93ull;
+    z ^= z >> 29;
+    return z;
+  };
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += stride)
+    h += mix(((unsigned long long)e << 32) ^ (unsigned long long)(unsigned)col[e]);
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= nrows; r += stride)
+    h += mix(((unsigned long long)r * 0x100000001B3ull) ^ (unsigned long long)rowptr[r] ^ 0xA5A5A5A5ull);
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+static int tg_elem_pattern_hash(tg_csr_t a, unsigned long long *host) {
+  unsigned long long *d = (unsigned long long *)(g_tg.scratch + 16);
+  TG_CHECK_HIP(hipMemsetAsync(d, 0, sizeof(*d), g_tg.stream));
+  hipLaunchKernelGGL(k_elem_pattern_hash, dim3((unsigned)std::min<int64_t>(tg_cdiv(a->nnz + a->nrows + 1, 256), (int64_t)g_tg.num_cu * 32)),
+                     dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->nrows, a->nnz, d);
+  TG_LAUNCH_CHECK();
+  TG_CHECK_HIP(hipMemcpyAsync(host, d, sizeof(*host), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  return 0;
+}
+
 __global__ void __launch_bounds__(256)
     k_elem_gather(const int32_t *__restrict__ amap, const double *__restrict__ aval, int64_t n, double *__restrict__ blocks) {
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -1961,6 +1993,7 @@ extern "C" int tg_elemsplit_create(tg_csr_t a, int64_t ncell, int b, const int32
   tg_dfree(np);
   tg_dfree(nc);
   if (!rc && (int64_t)h != a->nnz) rc = 100;      // an entry couples nodes without a common cell (or a node list is not sorted)
+  if (!rc) rc = tg_elem_pattern_hash(a, &sp->pattern);
   if (rc) {
     tg_dfree(sp->amap);
     delete sp;
@@ -1986,8 +2019,16 @@ extern "C" int tg_elemsplit_ptap(tg_elemsplit_t sp, tg_cellplan_t plan, tg_csr_t
                                  double diag, tg_csr_t *k_out) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(sp && plan && a && k_out, "null argument to tg_elemsplit_ptap");
-  TG_REQUIRE(a->nnz == sp->nnz && a->nrows == sp->nrows && plan->ncell == sp->ncell && plan->b == sp->b,
-             "tg_elemsplit_ptap: the matrix or the cell plan is not the one the splitting was made for");
+  TG_REQUIRE(plan->ncell == sp->ncell && plan->b == sp->b, "tg_elemsplit_ptap: the cell plan is not the one the splitting was made for");
+  TG_REQUIRE_CANONICAL(a);
+  if (a->nnz != sp->nnz || a->nrows != sp->nrows) return 100;
+  {
+    // the splitting maps block positions to ENTRIES of the matrix it was made for: another pattern of the same size (the
+    // reference redoes the symbolic product at every call, tIGAr/common.py:1194-1195) must not be read through it
+    unsigned long long hh = 0;
+    TG_TRY(tg_elem_pattern_hash(a, &hh));
+    if (hh != sp->pattern) return 100;
+  }
   const int64_t nb = sp->ncell * (int64_t)sp->b * sp->b;
   double *blocks = nullptr;
   TG_TRY(tg_dmalloc(&blocks, nb + TG_CSR_PAD));

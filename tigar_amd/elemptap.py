@@ -120,14 +120,20 @@ class ElementSplitPtAP(object):
         """M^T A M with MatZeroRowsColumns fused, or None when A holds an entry whose nodes share no cell"""
         if A.shape != (self.nfe, self.nfe):
             return None
-        s = self._splitting(A)
-        if s is None:
-            return None
-        h = handle()
         zd = np.ascontiguousarray(zero_dofs if zero_dofs is not None else [], dtype=np.int32)
-        check(_lib.lib().tg_elemsplit_ptap(s, self._h, A._h, zd.ctypes.data_as(c_i32p) if zd.size else None, zd.size,
-                                           float(diag), C.byref(h)), "tg_elemsplit_ptap")
-        return DeviceCSR(h)
+        for attempt in (0, 1):
+            s = self._splitting(A)
+            if s is None:
+                return None
+            h = handle()
+            rc = _lib.lib().tg_elemsplit_ptap(s, self._h, A._h, zd.ctypes.data_as(c_i32p) if zd.size else None, zd.size,
+                                              float(diag), C.byref(h))
+            if rc == 100 and attempt == 0:
+                self._drop_split()            # same size, another pattern: split again (once)
+                continue
+            check(rc, "tg_elemsplit_ptap")
+            return DeviceCSR(h)
+        return None
 
     def _drop_split(self):
         if getattr(self, "_split", None):
