@@ -144,11 +144,17 @@ def test_cfg3_full_size_through_the_api_against_kronecker_oracle():
     K.spmv_sell(False)
     scale = np.max(np.abs(y_csr))
     assert np.max(np.abs(y_sell - y_csr)) <= 1e-13 * scale
+    # the half-storage copy the CG solve multiplies with (csrc/tg_symgrid.hip: diagonal + upper triangle, transposed entries
+    # scattered through LDS windows): accepted at this size, half the bytes, all 17.4 M entries of the product
+    y_sym, info = K.mult_symgrid(dx)
+    assert info is not None and info["value_bytes"] == 16 * 86 * ncp and info["value_bytes"] < 0.52 * 8 * K.nnz
+    y_sym = y_sym.get_local()
+    assert np.max(np.abs(y_sym - y_csr)) <= 1e-13 * scale
     for r in rows[:20] + far:
         cols, vals = _oracle_row(r, n, k1, m1, zmask, diag)
         yr = float(vals @ x[cols])
         bound = 4e-16 * np.sqrt(len(cols)) * float(np.abs(vals) @ np.abs(x[cols])) + 1e-300
-        assert abs(y_csr[r] - yr) <= 50 * bound and abs(y_sell[r] - yr) <= 50 * bound
+        assert abs(y_csr[r] - yr) <= 50 * bound and abs(y_sell[r] - yr) <= 50 * bound and abs(y_sym[r] - yr) <= 50 * bound
 
     # ---- whole-matrix checks (every one of the 5.8e9 entries takes part):
     # (a) K x for a separable x = xz (x) xy (x) xx that vanishes on the boundary: zeroRowsColumns(K0) x = P (K0 x), and
