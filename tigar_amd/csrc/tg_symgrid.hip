@@ -398,25 +398,31 @@ __global__ void __launch_bounds__(256)
   constexpr int Wx = C::Wx, W = C::W;
   if (gate && !(*gate > gate_tol)) return;
   const int64_t cstride = (int64_t)(G.czmax + P) * W;
-  for (int64_t line = blockIdx.x; line < nlines; line += gridDim.x) {
-    const int iy = (int)(line % G.n1), iz = (int)(line / G.n1);
-    const int b0 = G.py_of[iy], c0 = G.pc_of[iz];
-    const int blo = (b0 > 0 && iy - G.y0[b0] < P) ? b0 - 1 : b0;
-    const int bhi = (b0 + 1 < G.npy && G.y0[b0 + 1] - iy <= P) ? b0 + 1 : b0;
-    const int clo = (c0 > 0 && iz - G.z0[c0] < P) ? c0 - 1 : c0;
-    double *yl = y + line * G.n0;
-    for (int ix = threadIdx.x; ix < G.n0; ix += 256) {
-      const int a0 = G.px_of[ix];
-      const int alo = (a0 > 0 && ix - G.x0[a0] < P) ? a0 - 1 : a0;
-      const int ahi = (a0 + 1 < G.npx && G.x0[a0 + 1] - ix <= P) ? a0 + 1 : a0;
+  // a thread keeps its ix for every line of the workgroup: which patch columns cover it is looked up once
+  for (int ix = threadIdx.x; ix < G.n0; ix += 256) {
+    const int a0 = G.px_of[ix];
+    const int alo = (a0 > 0 && ix - G.x0[a0] < P) ? a0 - 1 : a0;
+    const int ahi = (a0 + 1 < G.npx && G.x0[a0 + 1] - ix <= P) ? a0 + 1 : a0;
+    const int64_t astride = (int64_t)G.nch * cstride;
+    const int64_t o0 = (int64_t)a0 * astride + (ix - G.x0[a0]);
+    const int64_t olo = alo < a0 ? (int64_t)alo * astride + (ix - G.x0[alo]) : -1;
+    const int64_t ohi = ahi > a0 ? (int64_t)ahi * astride + (ix - G.x0[ahi]) : -1;
+    for (int64_t line = blockIdx.x; line < nlines; line += gridDim.x) {
+      const int iy = (int)(line % G.n1), iz = (int)(line / G.n1);
+      const int b0 = G.py_of[iy], c0 = G.pc_of[iz];
+      const int blo = (b0 > 0 && iy - G.y0[b0] < P) ? b0 - 1 : b0;
+      const int bhi = (b0 + 1 < G.npy && G.y0[b0 + 1] - iy <= P) ? b0 + 1 : b0;
+      const int clo = (c0 > 0 && iz - G.z0[c0] < P) ? c0 - 1 : c0;
       double s = 0.0;
       for (int c = clo; c <= c0; c++)
         for (int b = blo; b <= bhi; b++) {
           const double *sb = stage + ((int64_t)(b * G.npx) * G.nch + c) * cstride + (int64_t)(iz - G.z0[c]) * W +
                              (iy - G.y0[b] + P) * Wx + P;
-          for (int a = alo; a <= ahi; a++) s += sb[(int64_t)a * G.nch * cstride + (ix - G.x0[a])];
+          if (olo >= 0) s += sb[olo];        // (ascending patch column: the order of the sum is fixed)
+          s += sb[o0];
+          if (ohi >= 0) s += sb[ohi];
         }
-      yl[ix] = s;
+      y[line * G.n0 + ix] = s;
     }
   }
 }
