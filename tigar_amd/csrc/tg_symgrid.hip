@@ -177,14 +177,33 @@ __global__ void __launch_bounds__(256)
       my_len = (int)(rowptr[my_row + 1] - my_e0);
     }
   }
+  // phase 1: every load of the wave's eight tails is issued (addresses from the row pointers alone) ...
+  constexpr int IT = (C::NP + 63) / 64;       // a tail holds at most NP entries
+  double vv[8][IT];
+  int cc[8][IT];
   bool bad = false;
+#pragma unroll
+  for (int rr = 0; rr < 8; rr++) {
+    const int row = __builtin_amdgcn_readlane(my_row, rr);
+    const int len = __builtin_amdgcn_readlane(my_len, rr);
+    const int64_t e0 = ((int64_t)__builtin_amdgcn_readlane((int)(my_e0 >> 32), rr) << 32) |
+                       (unsigned)__builtin_amdgcn_readlane((int)(my_e0 & 0xffffffff), rr);
+    const int ix = row % n0, iy = (row / n0) % G.n1;
+    const int kd = row < 0 ? 0 : ((0 - dzlo) * (min(P, G.n1 - 1 - iy) + min(P, iy) + 1) + min(P, iy)) * (min(P, n0 - 1 - ix) + min(P, ix) + 1) + min(P, ix);
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+      const int k = kd + lane + 64 * it;
+      const bool on = row >= 0 && k < len;
+      vv[rr][it] = on ? __builtin_nontemporal_load(val + e0 + k) : 0.0;
+      cc[rr][it] = on ? __builtin_nontemporal_load(col + e0 + k) : 0;
+    }
+  }
+  // ... phase 2: the values go to their places in the tile
 #pragma unroll
   for (int rr = 0; rr < 8; rr++) {
     const int row = __builtin_amdgcn_readlane(my_row, rr);
     if (row < 0) break;
     const int len = __builtin_amdgcn_readlane(my_len, rr);
-    const int64_t e0 = ((int64_t)__builtin_amdgcn_readlane((int)(my_e0 >> 32), rr) << 32) |
-                       (unsigned)__builtin_amdgcn_readlane((int)(my_e0 & 0xffffffff), rr);
     const int ix = row % n0, iy = (row / n0) % G.n1;
     const int dxlo = -min(P, ix), dxhi = min(P, n0 - 1 - ix), nx = dxhi - dxlo + 1;
     const int dylo = -min(P, iy), dyhi = min(P, G.n1 - 1 - iy), ny = dyhi - dylo + 1;
@@ -196,14 +215,16 @@ __global__ void __launch_bounds__(256)
     const int mxy = (65536 + nxy - 1) / nxy, mx = (65536 + nx - 1) / nx;    // k / d = (k * m) >> 16 for k d < 65536
     const int kd = ((0 - dzlo) * ny + (0 - dylo)) * nx + (0 - dxlo);          // the diagonal
     double *trow = tile + (w * 8 + rr) * LD;
-    for (int k = kd + lane; k < len; k += 64) {
-      const double v = __builtin_nontemporal_load(val + e0 + k);
-      const int c = __builtin_nontemporal_load(col + e0 + k);
-      const int qz = (k * mxy) >> 16, rem = k - qz * nxy;
-      const int qy = (rem * mx) >> 16, qx = rem - qy * nx;
-      const int dz = qz + dzlo, dy = qy + dylo, dx = qx + dxlo;
-      bad |= c != grow0 + row + dx + n0 * dy + n01 * dz;
-      trow[sg_lay<P>::inv(((dz + P) * C::S + dy + P) * C::S + dx + P - C::LC)] = v;
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+      const int k = kd + lane + 64 * it;
+      if (k < len) {
+        const int qz = (k * mxy) >> 16, rem = k - qz * nxy;
+        const int qy = (rem * mx) >> 16, qx = rem - qy * nx;
+        const int dz = qz + dzlo, dy = qy + dylo, dx = qx + dxlo;
+        bad |= cc[rr][it] != grow0 + row + dx + n0 * dy + n01 * dz;
+        trow[sg_lay<P>::inv(((dz + P) * C::S + dy + P) * C::S + dx + P - C::LC)] = vv[rr][it];
+      }
     }
   }
   __syncthreads();
