@@ -403,7 +403,10 @@ int tg_krylov_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, int pc, doub
                     double *resnorm, int *status);
 /* same with flags: TG_KSP_NONZERO_GUESS = x holds the initial guess (dolfin's solver parameter
  * "nonzero_initial_guess" [ext]; the convergence test stays relative to ||B b||, PETSc's default) */
-enum { TG_KSP_NONZERO_GUESS = 1, TG_KSP_STAGNATION_GUARD = 2 };
+enum { TG_KSP_NONZERO_GUESS = 1, TG_KSP_STAGNATION_GUARD = 2, TG_KSP_SYMMETRIC = 4 };
+/* TG_KSP_SYMMETRIC: the caller vouches that k is symmetric (the premise of KSPCG, which PETSc does not check either; set by
+ * ExtractedSpline.assembleMatrix for forms that are symmetric by construction): the half-storage copy of a CG solve is still
+ * built from rows that are checked one by one against the box stencil, but not compared with the CSR product. */
 int tg_krylov_solve_flags(tg_csr_t k, tg_vec_t b, tg_vec_t x, int method, int pc, double rtol,
                           double atol, int maxit, int restart, int flags, tg_comm_t comm, int *iters,
                           double *resnorm, int *status);

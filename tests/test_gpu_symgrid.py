@@ -211,6 +211,31 @@ def test_chebyshev_cg_on_the_half_storage_copy(dev, monkeypatch):
     assert np.max(np.abs(out["0"][1] - out["1"][1])) <= 1e-7 * np.max(np.abs(out["0"][1]))
 
 
+def test_matrices_of_symmetric_forms_skip_the_comparison_with_the_csr_product(dev, monkeypatch):
+    """``assembleMatrix`` of a form that is symmetric by construction marks K; the CG solve then passes TG_KSP_SYMMETRIC and
+    the half-storage copy is built without the check against the CSR product (its rows are still checked one by one against
+    the box stencil).  The flag is the caller's word, as with KSPCG: a matrix that is NOT symmetric is accepted with it and
+    declined without it -- which is why only this package's own symmetric forms set it."""
+    import tigar_amd as t
+    from tigar_amd.device import DeviceVector
+    spline, K, rhs = _poisson3d(2, (40, 40, 40))
+    assert K.symmetric_by_construction is True
+    from tigar_amd import forms as F
+    K2 = spline.extractMatrix(F.LaplaceForm().assemble_matrix(spline.V))          # a matrix handed over: no mark
+    assert not getattr(K2, "symmetric_by_construction", False)
+    monkeypatch.setenv("TIGAR_KSP_PERSISTENT", "0")
+    monkeypatch.setenv("TIGAR_SPMV_SYM", "2")
+    rng = np.random.default_rng(4)
+    A = _box_stencil(rng, (24, 20, 12), 2, symmetric=False)
+    A = (A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + 1.0)).tocsr()
+    A.sort_indices()
+    dA, b = dev.DeviceCSR.from_scipy(A), DeviceVector(data=rng.standard_normal(A.shape[0]))
+    for hint, used in ((False, 0), (True, 1)):
+        c0 = dev.prof_get(7)[1]
+        dev.krylov_solve(dA, b, DeviceVector(A.shape[0]), "cg", "jacobi", 1e-8, 1e-300, 20, 30, symmetric=hint)
+        assert dev.prof_get(7)[1] - c0 == used
+
+
 def test_small_systems_and_other_solvers_keep_their_kernels(dev, monkeypatch):
     """below 65536 rows (the persistent kernels' range) and for gmres nothing changes; TIGAR_SPMV_SYM=2 forces the copy"""
     import tigar_amd as t

@@ -1190,7 +1190,10 @@ class PETScKrylovSolver(object):
                 self.parameters["absolute_tolerance"], self.parameters["maximum_iterations"],
                 self.parameters["chebyshev_degree"] if pc == "chebyshev" else self.parameters["gmres_restart"],
                 self.comm, nonzero_initial_guess=guess,
-                stagnation_guard=bool(self.parameters.get("stagnation_guard", False)))
+                stagnation_guard=bool(self.parameters.get("stagnation_guard", False)),
+                # (a matrix this package assembled from a form that is symmetric by construction: the half-storage copy
+                #  of a CG solve is not compared with the CSR product again, csrc/tg_symgrid.hip)
+                symmetric=bool(getattr(A, "symmetric_by_construction", False)))
 
         x0 = None
         if self.preconditioner == "chebyshev" and guess:
@@ -1912,7 +1915,12 @@ class ExtractedSpline(object):
                 A = form.assemble_matrix(self.V)
         else:
             A = form
-        return self.extractMatrix(A, applyBCs=applyBCs, diag=diag)
+        K = self.extractMatrix(A, applyBCs=applyBCs, diag=diag)
+        if getattr(form, "symmetric", False) and isinstance(K, DeviceCSR):
+            # M^T A M of a symmetric A with MatZeroRowsColumns: symmetric (to rounding); a NEW object after every change of
+            # the values but zero_rows_cols (DeviceCSR has no other in-place operation)
+            K.symmetric_by_construction = True
+        return K
 
     def assembleLinearSystem(self, lhsForm, rhsForm, applyBCs=True):
         # one ghost update of the rank-local functions the forms read serves both assemblies (Function.ghosted)

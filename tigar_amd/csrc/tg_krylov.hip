@@ -37,6 +37,7 @@ struct tg_sell_guard {
   }
 };
 
+static int g_ksp_symmetric_hint = 0;      // TG_KSP_SYMMETRIC of the solve under way (tg_krylov_solve_flags)
 // CG only (a symmetric K is its premise): the half-storage copy of tg_symgrid.hip when K is a box stencil on a 3-D grid
 // and this rank holds all of it; built for the solve like the sliced copy, which is then not needed.
 struct tg_symgrid_guard {
@@ -314,7 +315,7 @@ static int tg_cg(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int pc, double rtol, dou
   {
     // (TIGAR_SPMV_SYM: 0 = off, 1 = systems of at least 65536 rows [default], 2 = every size the plan accepts)
     const int sym_on = getenv("TIGAR_SPMV_SYM") ? atoi(getenv("TIGAR_SPMV_SYM")) : 1;
-    const int sym_verify = getenv("TIGAR_SPMV_SYM_VERIFY") ? atoi(getenv("TIGAR_SPMV_SYM_VERIFY")) : 1;
+    const int sym_verify = getenv("TIGAR_SPMV_SYM_VERIFY") ? atoi(getenv("TIGAR_SPMV_SYM_VERIFY")) : !g_ksp_symmetric_hint;
     // (several ranks: every rank decides for its own z slab -- the products are local once the halo of u has arrived)
     if (sym_on && (n >= 65536 || sym_on > 1) && k->sell_state != 1)
       TG_TRY(tg_symgrid_build(k, row0, sym_verify, &sym.s));
@@ -1196,7 +1197,7 @@ static int tg_pcg_cheb(tg_csr_s *k, tg_vec_s *b, tg_vec_s *x, int degree, double
   tg_symgrid_guard sym;        // (CG with a polynomial preconditioner: the same premise, the same half-storage copy)
   {
     const int sym_on = getenv("TIGAR_SPMV_SYM") ? atoi(getenv("TIGAR_SPMV_SYM")) : 1;
-    const int sym_verify = getenv("TIGAR_SPMV_SYM_VERIFY") ? atoi(getenv("TIGAR_SPMV_SYM_VERIFY")) : 1;
+    const int sym_verify = getenv("TIGAR_SPMV_SYM_VERIFY") ? atoi(getenv("TIGAR_SPMV_SYM_VERIFY")) : !g_ksp_symmetric_hint;
     if (sym_on && (n >= 65536 || sym_on > 1) && k->sell_state != 1) TG_TRY(tg_symgrid_build(k, row0, sym_verify, &sym.s));
     if (sym.s) g_tg.prof_n[TG_PROF_KSP_SYMGRID] += 1;
   }
@@ -1605,6 +1606,7 @@ extern "C" int tg_krylov_solve_flags(tg_csr_t k, tg_vec_t b, tg_vec_t x, int met
                                      int maxit, int restart, int flags, tg_comm_t comm, int *iters, double *resnorm,
                                      int *status) {
   const int g_krylov_nonzero_guess = (flags & TG_KSP_NONZERO_GUESS) ? 1 : 0;
+  g_ksp_symmetric_hint = (flags & TG_KSP_SYMMETRIC) ? 1 : 0;
   TG_REQUIRE_INIT();
   TG_REQUIRE(k && b && x && iters && resnorm && status, "null argument to tg_krylov_solve");
   TG_REQUIRE(b->n == k->nrows && x->n == k->nrows, "tg_krylov_solve: vector length != local rows");

@@ -13,6 +13,7 @@ TG_KSP_CG, TG_KSP_GMRES, TG_KSP_BICGSTAB = 0, 1, 2
 TG_PC_NONE, TG_PC_JACOBI, TG_PC_CHEBYSHEV = 0, 1, 2
 TG_KSP_NONZERO_GUESS = 1
 TG_KSP_STAGNATION_GUARD = 2
+TG_KSP_SYMMETRIC = 4
 
 
 def _f64(a):
@@ -723,11 +724,12 @@ def ptap_kron(cur, cur_row0, dims_in, factors, out_row0, out_row1, zero_dofs=Non
 
 # ------------------------------------------------------------------------------- Krylov
 def krylov_solve(K, b, x, method="cg", pc="jacobi", rtol=1e-6, atol=1e-15, maxit=10000, restart=30, comm=None,
-                 nonzero_initial_guess=False, stagnation_guard=False):
+                 nonzero_initial_guess=False, stagnation_guard=False, symmetric=False):
     meth = {"cg": TG_KSP_CG, "gmres": TG_KSP_GMRES, "bicgstab": TG_KSP_BICGSTAB}[method]
     pcc = {"none": TG_PC_NONE, "jacobi": TG_PC_JACOBI, "chebyshev": TG_PC_CHEBYSHEV}[pc]
     iters, status, res = C.c_int(), C.c_int(), C.c_double()
-    flags = (TG_KSP_NONZERO_GUESS if nonzero_initial_guess else 0) | (TG_KSP_STAGNATION_GUARD if stagnation_guard else 0)
+    flags = (TG_KSP_NONZERO_GUESS if nonzero_initial_guess else 0) | (TG_KSP_STAGNATION_GUARD if stagnation_guard else 0) | \
+        (TG_KSP_SYMMETRIC if symmetric else 0)
     check(_lib.lib().tg_krylov_solve_flags(K._h, b._h, x._h, meth, pcc, float(rtol), float(atol), int(maxit),
                                            int(restart), flags, comm._h if comm is not None else None,
                                            C.byref(iters), C.byref(res), C.byref(status)), "tg_krylov_solve")

@@ -207,6 +207,7 @@ class LaplaceForm(object):
     """a(u,v) = int grad u . grad v: on the parametric box (Kronecker sum of 1-D factors), or --
     with ``geometry`` (a generator or ExtractedSpline) -- in physical space on the mapped patch,
     grad and dx as ``spline.grad`` / ``spline.dx`` (tIGAr/common.py:917-945)."""
+    symmetric = True      # a(u, v) = a(v, u): the assembled matrix is symmetric (ExtractedSpline.assembleMatrix marks K)
 
     def __init__(self, geometry=None):
         self.geometry = geometry
@@ -232,6 +233,7 @@ class ElasticityForm(object):
     each a Kronecker sum of 1-D factors (mass M, stiffness K, G[a,b] = int phi_a' phi_b) on the element-coupling pattern,
     written block by block by the Kronecker-sum kernel and put together on the device.  What a dolfin user writes as
     ``inner(sigma(u), eps(v))*dx`` for ``demos``-style linear elasticity on an identity-geometry patch."""
+    symmetric = True      # a(u, v) = a(v, u): the assembled matrix is symmetric (ExtractedSpline.assembleMatrix marks K)
 
     def __init__(self, lmbda=1.0, mu=1.0):
         self.lmbda, self.mu = float(lmbda), float(mu)
@@ -282,6 +284,7 @@ class ElasticityForm(object):
 
 class MassForm(object):
     """a(u,v) = int u v (``geometry``: see LaplaceForm)."""
+    symmetric = True      # a(u, v) = a(v, u): the assembled matrix is symmetric (ExtractedSpline.assembleMatrix marks K)
 
     def __init__(self, geometry=None):
         self.geometry = geometry
@@ -363,6 +366,7 @@ class SeparableLoadForm(object):
 class BiharmonicForm(object):
     """a(u,v) = int (lap u)(lap v), element-wise (demos/biharmonic/biharmonic.py:100-103), 2-D:
     S2xM + MxS2 + C^T x C + C x C^T with C[a,b] = int phi_a'' phi_b."""
+    symmetric = True      # a(u, v) = a(v, u): the assembled matrix is symmetric (ExtractedSpline.assembleMatrix marks K)
 
     def factors(self, V):
         g = _single_grid(V)
