@@ -220,8 +220,9 @@ int tg_spmv_sell(tg_csr_t a, int enable, int *nclasses, int64_t *padded);
  * the grid, all columns: rows in its first planes also take their entries below the block from the CSR arrays (the
  * previous rank stores those as ITS upper triangle), what is scattered beyond the block is dropped; the solve does this
  * per z slab after the usual halo exchange of the vector.  This entry point plans the copy for `a`, checks it against the
- * CSR product on a pseudo-random vector, and, with x (all columns) and y given, computes y = a x with it.  *accepted = 0: `a` has no such structure or is not symmetric (nothing
- * is computed).  value_bytes / staging_bytes (may be NULL): bytes of K one product reads / size of the window staging. */
+ * CSR product on a pseudo-random vector, and, with x (all columns) and y given, computes y = a x with it.  *accepted = 0:
+ * `a` has no such structure or is not symmetric (nothing is computed).  value_bytes / staging_bytes (may be NULL): bytes of
+ * K one product reads / size of the window staging. */
 int tg_spmv_symgrid(tg_csr_t a, int64_t row0, tg_vec_t x, tg_vec_t y, int *accepted, int64_t *value_bytes,
                     int64_t *staging_bytes);
 /* Y = A X for k <= 4 right-hand sides (cpFuncs = M_control * P, tIGAr/common.py:367-380);
