@@ -274,6 +274,58 @@ def test_mapped_forms_streamed_through_the_slab_engine(T, p, nels, sub, monkeypa
         assert walks > 0 and certified > 0       # the line walks ran, on the certificate of the assembled row blocks
 
 
+@pytest.mark.parametrize("nels,subs", [((80, 72, 64), (7, 12)), ((256, 256, 256), (12, 9))])
+def test_mapped_forms_at_scale_keep_their_invariants(T, monkeypatch, nels, subs):
+    """p = 3 on a rational volume map, streamed in sub-slabs, at 80 x 72 x 64 elements (10 M FE nodes) and at the benchmark's
+    256^3 (454 M FE nodes, 17.4 M dofs) -- far beyond what the oracle's element loop does in seconds; properties that hold at
+    any size: constants are in the kernel of the stiffness form (M reproduces constants: K 1 = M^T A 1_fe = 0), the mass form
+    and the load vector of f = 1 integrate the same functions (K_mass 1 = M^T b), symmetry, the same bits from another
+    sub-slab size, and the volume against the oracle's on a COARSE mesh of the same map family."""
+    monkeypatch.setenv("TIGAR_IMPLICIT_M", "1")
+    p = 3
+    out = {}
+    for sub in subs:
+        monkeypatch.setenv("TIGAR_SUB_PLANES", str(sub))
+        gen, kvs = _volume_generator(T, p, nels)
+        spline = T.t.ExtractedSpline(gen, 2 * p, comm=gen.comm)
+        rng = np.random.default_rng(5)
+        T.dev.prof_reset()
+        K = spline.assembleMatrix(T.F.LaplaceForm(geometry=gen), applyBCs=False)
+        assert T.dev.prof_get(5)[1] > 0                                    # the tensor line walks ran
+        n = K.shape[0]
+        one = T.dev.DeviceVector(data=np.ones(n))
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        dx, dy = T.dev.DeviceVector(data=x), T.dev.DeviceVector(data=y)
+        kx, ky = K.mult(dx).get_local(), K.mult(dy).get_local()
+        k1 = K.mult(one).get_local()
+        assert np.max(np.abs(k1)) <= 1e-11 * np.max(np.abs(kx)), (np.max(np.abs(k1)), np.max(np.abs(kx)))
+        a1, a2 = float(y @ kx), float(x @ ky)
+        assert abs(a1 - a2) <= 1e-10 * (abs(a1) + abs(a2))
+        head, tail = K.rows_to_scipy(0, 4000).data.copy(), K.rows_to_scipy(n - 4000, n).data.copy()
+        del K
+        Km = spline.assembleMatrix(T.F.MassForm(geometry=gen), applyBCs=False)
+        m1 = Km.mult(one).get_local()
+        a1, a2 = float(y @ Km.mult(dx).get_local()), float(x @ Km.mult(dy).get_local())
+        assert abs(a1 - a2) <= 1e-10 * (abs(a1) + abs(a2))
+        del Km
+        bl = spline.assembleVector(T.F.NodalLoadForm(1.0, gen), applyBCs=False).get_local()
+        assert np.max(np.abs(m1 - bl)) <= 1e-12 * np.max(np.abs(bl))       # int N_i * 1 either way
+        vol = float(np.sum(bl))
+        assert np.all(bl > 0.0)
+        out[sub] = (head, tail, bl, vol)
+        del spline, gen, dx, dy, one
+    u, v = out[subs[0]], out[subs[1]]
+    for k in range(3):
+        assert np.array_equal(u[k].view(np.int64), v[k].view(np.int64))
+    # the volume against the oracle's on a coarse mesh of the same family: the maps differ by O(h^2) in their control nets
+    gen_c, _ = _volume_generator(T, p, (6, 6, 6))
+    g = gen_c.V.grids[0]
+    uks = [np.asarray(g.vertices[k]) for k in range(3)]
+    cp = [f.vector().get_local() for f in gen_c.cpFuncs]
+    _, _, bo = O.mapped_fe_system(uks, p, cp, fnodal=np.ones(cp[0].size))
+    assert abs(float(np.sum(bo)) - u[3]) <= 0.02 * u[3]
+
+
 def test_poisson_on_a_nurbs_volume_converges_3d(T, monkeypatch):
     """demos/poisson/poisson-nurbs.py in 3-D without FEniCS: thick quarter cylinder (exact rational geometry, degree 2),
     u = (r-1)(2-r) sin(2 theta) sin(pi z), zero on the whole boundary; streamed in sub-slabs.  Max nodal error drops
