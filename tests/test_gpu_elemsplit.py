@@ -157,3 +157,31 @@ def test_extract_matrix_takes_the_element_split_product(monkeypatch, d, p, nel):
     for i2 in zd:
         ref2[i2, i2] = 1.0
     assert abs(K2 - ref2.tocsr()).max() <= 1e-12 * abs(ref2).max()
+
+
+def test_element_split_at_a_size_the_oracle_does_not_reach():
+    """32^3 elements, p = 3 (0.9 M FE rows, 1.1e8 entries of A, 32 768 cells of 64 nodes: the one-cell-per-workgroup kernel and
+    the 16-bit places): K x = M^T (A (M x)) for random x, the entry count of the general kernels' K, symmetry carried over from
+    A, and the same bits in a second product"""
+    from tigar_amd import device as dev
+    from tigar_amd.elemptap import ElementSplitPtAP
+    A, M, cells = _operands(3, 3, (32, 32, 32))
+    plan = ElementSplitPtAP(M, cells)
+    assert plan.b == 64 and plan.nfmax == 64
+    K = plan.ptap(A)
+    rng = np.random.default_rng(1)
+    for _ in range(2):
+        x = dev.DeviceVector(data=rng.standard_normal(K.shape[0]))
+        y1 = K.mult(x).get_local()
+        y2 = M.mult_transpose(A.mult(M.mult(x))).get_local()
+        assert np.max(np.abs(y1 - y2)) <= 1e-13 * np.max(np.abs(y2))
+    MT = M.transpose()
+    Kg = dev.ptap_numeric(dev.ptap_symbolic(A, M, MT), A, M, MT)
+    assert Kg.nnz == K.nnz
+    xs, ys = rng.standard_normal(K.shape[0]), rng.standard_normal(K.shape[0])
+    a1 = float(ys @ K.mult(dev.DeviceVector(data=xs)).get_local())
+    a2 = float(xs @ K.mult(dev.DeviceVector(data=ys)).get_local())
+    assert abs(a1 - a2) <= 1e-11 * (abs(a1) + abs(a2))
+    K2 = plan.ptap(A)
+    r = K.shape[0] // 2
+    assert np.array_equal(K.rows_to_scipy(r, r + 2000).data.view(np.int64), K2.rows_to_scipy(r, r + 2000).data.view(np.int64))
