@@ -91,6 +91,39 @@ def test_half_storage_product_of_a_z_slab(dev, shape, reach, cuts):
     assert dev.DeviceCSR.from_scipy(odd).mult_symgrid(dx, row0=n01 + 5) == (None, None)
 
 
+def test_random_grids_slabs_and_chunkings(dev, monkeypatch):
+    """seeded random run: stencil radius, grid sizes (patch sizes 24 x 16 and the sub-steps of 64 rows never divide them),
+    z cuts into slabs and the number of z chunks per patch -- whole matrix and every slab against scipy"""
+    rng = np.random.default_rng(20250929)
+    for case in range(24):
+        reach = int(rng.integers(1, 4))
+        shape = (int(rng.integers(16, 58)), int(rng.integers(16, 40)), int(rng.integers(2 * reach + 2, 26)))
+        while np.prod(shape) * (2 * reach + 1) ** 3 > 9e6:
+            shape = (shape[0] - 3, shape[1] - 2, shape[2])
+            if shape[0] < 16 or shape[1] < 16:
+                shape = (16, 16, shape[2])
+                break
+        monkeypatch.setenv("TIGAR_SYMGRID_CHUNKS", str(int(rng.integers(0, 7))))
+        A = _box_stencil(rng, shape, reach)
+        x = rng.standard_normal(A.shape[0])
+        dx = dev.DeviceVector(data=x)
+        ref = A @ x
+        scale = np.abs(A) @ np.abs(x)
+        y, info = dev.DeviceCSR.from_scipy(A).mult_symgrid(dx)
+        assert info is not None, (case, shape, reach)
+        assert np.max(np.abs(y.get_local() - ref) / scale) < 1e-14, (case, shape, reach)
+        n01, n2 = shape[0] * shape[1], shape[2]
+        if n2 >= 2 * (2 * reach + 2):
+            cut = int(rng.integers(2 * reach + 2, n2 - (2 * reach + 2) + 1))
+            for z0, z1 in ((0, cut), (cut, n2)):
+                B = A[z0 * n01:z1 * n01].tocsr()
+                B.sort_indices()
+                yb, infob = dev.DeviceCSR.from_scipy(B).mult_symgrid(dx, row0=z0 * n01)
+                assert infob is not None, (case, shape, reach, z0, z1)
+                assert np.max(np.abs(yb.get_local() - ref[z0 * n01:z1 * n01]) / scale[z0 * n01:z1 * n01]) < 1e-14, \
+                    (case, shape, reach, z0, z1)
+
+
 def test_matrices_without_the_structure_are_declined(dev):
     rng = np.random.default_rng(3)
     shape = (30, 20, 12)
