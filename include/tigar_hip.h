@@ -23,7 +23,6 @@ typedef struct tg_csr_s *tg_csr_t;   /* device-resident CSR row block           
 typedef struct tg_vec_s *tg_vec_t;   /* device-resident fp64 vector              */
 typedef struct tg_ptap_s *tg_ptap_t; /* symbolic plan of K = M^T A M             */
 typedef struct tg_cellplan_s *tg_cellplan_t; /* K = M^T A M on a cell-local FE space: dense blocks per cell */
-typedef struct tg_elemsplit_s *tg_elemsplit_t; /* a matrix on a CONNECTED mesh split into one dense block per cell */
 typedef struct tg_comm_s *tg_comm_t; /* RCCL communicator + z-slab descriptor    */
 
 /* ---- runtime ------------------------------------------------------------------ */
@@ -258,22 +257,35 @@ int tg_cellplan_create(int64_t ncell, int b, int nfmax, int64_t ncols, const dou
                        const int32_t *nf_host, tg_csr_t incidence, int max_k, double mean_k, tg_cellplan_t *out);
 int tg_cellplan_ptap(tg_cellplan_t plan, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out);
 int tg_cellplan_destroy(tg_cellplan_t plan);
-/* The cell-block product for CONNECTED meshes (cells share nodes: what dolfin assembles on a Q_p / P_p mesh, tIGAr/common.py:
- * 1194-1195 with an M that is no Kronecker product).  A = sum_c R_c^T A_c R_c for ANY splitting of its entries over the cells
- * that hold both nodes, hence K = sum_c (R_c M)^T A_c (R_c M): the dense cell products above on rows of M repeated per cell.
- * tg_cellplan_create_from_rows: the plan for cells given by node lists (cellnodes_host [ncell][b], ascending per cell; rows
- * of m), dense rows of M gathered on the device.  tg_elemsplit_create: assigns every entry of `a` to the lowest cell holding
- * both its nodes (nptr_host [nrows + 1] / ncells_host: the cells of every node, ascending); 100 = an entry couples nodes
- * without a common cell.  tg_elemsplit_ptap: gathers the values of `a` into blocks and runs the product; 100 when `a` does
- * not have the pattern the splitting was made for (hash of row pointer and column indices: make a new splitting). */
-int tg_cellplan_create_from_rows(int64_t ncell, int b, int nfmax, tg_csr_t m, const int32_t *cellnodes_host,
-                                 const int32_t *fl_host, const int32_t *nf_host, tg_csr_t incidence, int max_k, double mean_k,
-                                 tg_cellplan_t *out);
-int tg_elemsplit_create(tg_csr_t a, int64_t ncell, int b, const int32_t *cellnodes_host, const int32_t *nptr_host,
-                        const int32_t *ncells_host, tg_elemsplit_t *out);
-int tg_elemsplit_ptap(tg_elemsplit_t split, tg_cellplan_t plan, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag,
-                      tg_csr_t *k_out);
-int tg_elemsplit_destroy(tg_elemsplit_t split);
+/* extractMatrix for ARBITRARY sparse operands on a CONNECTED mesh (cells share nodes: what dolfin assembles on a Q_p / P_p mesh,
+ * tIGAr/common.py:1194-1195 with an M that is not used as a Kronecker product), csrc/tg_elemsplit.hip.  A = sum_c R_c^T A_c R_c
+ * for ANY splitting of its entries over the cells that hold both nodes, hence K = sum_c (R_c M)^T A_c (R_c M): dense products
+ * per cell, merged into K by stored places.  Everything runs on the device; the input besides the CSR operands is the cells'
+ * node lists (dolfin: V.dofmap().cell_dofs(c)).
+ * tg_cells_t: node lists [ncell][b] (b <= 128), from a host array or, for this package's stand-in of the FE space (continuous
+ * Q_p on a tensor-product grid of nodes, direction 0 fastest), generated on the device for a box of elements.
+ * tg_elemplan_create: the plan for the cells [own0, own1) of `cells` -- listed cells outside that range only take part in the
+ * ownership rule (an entry of A belongs to the FIRST listed cell that holds both its nodes), so a mesh can be worked off in
+ * chunks whose K are added.  m holds the rows [m_row0, ...) of M (global columns) of all nodes of the own cells; `cells` and `m`
+ * are borrowed for the plan's lifetime.  Status 100: the cells do not qualify (more than 128 functions in a cell, a function in
+ * more than 128 cells).
+ * tg_elemplan_ptap: rows [dof0, dof1) (tg_elemplan_info) of sum over the own cells, global columns, MatZeroRowsColumns applied
+ * when zero_dofs is given.  a holds the rows [a_row0, ...) of A; every entry of the rows [check_row0, check_row1) must couple two
+ * nodes of a listed cell, else status 100 (a coupling added by hand, demos/kl-shell-svk/reef-knot.py:455-467: take tg_ptap_*).
+ * The pattern of K and the places are found on the first product and kept by the plan. */
+typedef struct tg_cells_s *tg_cells_t;
+typedef struct tg_elemplan_s *tg_elemplan_t;
+int tg_cells_from_host(const int32_t *nodes_host, int64_t ncell, int b, tg_cells_t *out);
+int tg_cells_from_grid(int d, const int64_t *nodes_per_dir, int degree, const int64_t *elem_lo, const int64_t *elem_hi,
+                       tg_cells_t *out);
+int tg_cells_dims(tg_cells_t cells, int64_t *ncell, int *b);
+int tg_cells_download(tg_cells_t cells, int32_t *nodes_host);
+int tg_cells_destroy(tg_cells_t cells);
+int tg_elemplan_create(tg_cells_t cells, int64_t own0, int64_t own1, tg_csr_t m, int64_t m_row0, tg_elemplan_t *out);
+int tg_elemplan_info(tg_elemplan_t plan, int64_t *dof0, int64_t *dof1, int *nfmax, int *ninc_max, int64_t *k_nnz);
+int tg_elemplan_ptap(tg_elemplan_t plan, tg_csr_t a, int64_t a_row0, int64_t check_row0, int64_t check_row1,
+                     const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *k_out);
+int tg_elemplan_destroy(tg_elemplan_t plan);
 /* The same product for a matrix that holds its dense cell blocks PLUS couplings outside them (contact / penalty terms added by
  * hand to a T-spline matrix: demos/kl-shell-svk/reef-knot.py:455-467, the reason extractMatrix takes any A, tIGAr/common.py:
  * 1175): k_out = M^T D M from the blocks D read in place (no copy of A), r_out = the remainder A - D with A's shape, whose

@@ -132,7 +132,7 @@ def test_extract_matrix_takes_the_element_split_product(monkeypatch, d, p, nel):
     A.data = A.data + 0.1 * rng.standard_normal(A.nnz)
     K = spline.extractMatrix(A).to_scipy().tocsr()
     plan = spline.__dict__.get("_elem_plan")
-    assert plan is not None and plan[1] is not None and plan[1]._split is not None          # the element path ran
+    assert plan is not None and plan[1] is not None and plan[1]._chunk is not None          # the element path ran
     M = gen.M.to_scipy()
     ref = (M.T @ A @ M).tolil()
     zd = np.asarray(gen.zeroDofsArray(), dtype=np.int64)
@@ -185,3 +185,67 @@ def test_element_split_at_a_size_the_oracle_does_not_reach():
     K2 = plan.ptap(A)
     r = K.shape[0] // 2
     assert np.array_equal(K.rows_to_scipy(r, r + 2000).data.view(np.int64), K2.rows_to_scipy(r, r + 2000).data.view(np.int64))
+
+
+@pytest.mark.parametrize("d,p,nels", [(3, 2, (4, 3, 5)), (2, 3, (6, 5)), (3, 1, (3, 4, 2)), (1, 4, (9,))])
+def test_cell_node_lists_generated_on_the_device(d, p, nels):
+    """``CellNodes.from_grid`` (the dofmap of the Q_p stand-in, generated by a kernel) against the host arrays of
+    ``common._cell_dofs_arrays``: all cells, and a box of elements"""
+    from tigar_amd.common import _cell_dofs_arrays
+    from tigar_amd.BSplines import ExplicitBSplineControlMesh, uniformKnots
+    from tigar_amd.elemptap import CellNodes
+    cm = ExplicitBSplineControlMesh([p] * d, [uniformKnots(p, 0., 1., n) for n in nels])
+    grid = cm.getScalarSpline().generateMesh(degree=p)
+    ref = _cell_dofs_arrays(grid)
+    got = CellNodes.from_grid(grid).to_host()
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    lo = [n // 3 for n in nels]
+    hi = [max(l + 1, n - 1) for l, n in zip(lo, nels)]
+    box = CellNodes.from_grid(grid, lo, hi).to_host()
+    e = np.meshgrid(*[np.arange(a, b) for a, b in zip(lo, hi)], indexing="ij")
+    idx = sum(c.ravel(order="F") * int(np.prod(nels[:k])) for k, c in enumerate(e))
+    assert np.array_equal(box, ref[idx])
+
+
+@pytest.mark.parametrize("d,p,nels,cuts", [(3, 2, (5, 4, 9), (0, 3, 4, 9)), (2, 3, (7, 12), (0, 5, 12)), (3, 3, (3, 3, 7), (0, 2, 5, 7)),
+                                           (3, 1, (4, 4, 6), (0, 1, 2, 6))])
+def test_chunks_of_cells_add_up_to_the_whole_product(d, p, nels, cuts):
+    """The mesh worked off in chunks of element layers of the last direction (``ElementChunk``): a chunk lists the layer below
+    it as well (ownership of the entries on the shared node plane), sees only the rows of A and M of its own cells' nodes, and
+    checks the rows whose cells are all listed; the chunks' K -- rows of their own functions, global columns -- add up to
+    M^T A M.  An entry without a common cell is declined by the chunk that checks its row."""
+    from tigar_amd import device as dev
+    from tigar_amd.elemptap import CellNodes, ElementChunk
+    A, M, _ = _operands(d, p, nels)
+    rng = np.random.default_rng(p + d)
+    As = A.to_scipy().tocsr()
+    As.sort_indices()
+    As.data = As.data * (1.0 + 0.3 * rng.standard_normal(As.nnz)) + 0.01 * rng.standard_normal(As.nnz)
+    Ms = M.to_scipy().tocsr()
+    ref = (Ms.T @ As @ Ms).tocsr()
+    from tigar_amd.BSplines import ExplicitBSplineControlMesh, uniformKnots
+    grid = ExplicitBSplineControlMesh([p] * d, [uniformKnots(p, 0., 1., n) for n in nels]).getScalarSpline().generateMesh(degree=p)
+    plane = int(np.prod(grid.shape()[:-1]))
+    per_layer = int(np.prod(nels[:-1]))
+    total = sp.csr_matrix(ref.shape)
+    bad = As.tolil()
+    r_bad = (cuts[1] * p) * plane + 1                     # a row on the node plane two chunks share
+    bad[r_bad, As.shape[0] - 1] = 1.0
+    bad = bad.tocsr()
+    declined = 0
+    for e0, e1 in zip(cuts[:-1], cuts[1:]):
+        f0 = max(e0 - 1, 0)
+        lo, hi = [0] * (d - 1) + [f0], list(nels[:-1]) + [e1]
+        cells = CellNodes.from_grid(grid, lo, hi)
+        r0, r1 = e0 * p * plane, (e1 * p + 1) * plane
+        Mc = dev.DeviceCSR.from_scipy(Ms[r0:r1])
+        chunk = ElementChunk(cells, Mc, r0, own=((e0 - f0) * per_layer, (e1 - f0) * per_layer))
+        chk = (r0, r1 if e1 == nels[-1] else e1 * p * plane)
+        K = chunk.ptap(dev.DeviceCSR.from_scipy(As[r0:r1]), r0, chk)
+        assert K is not None and K.shape == (chunk.dofs[1] - chunk.dofs[0], ref.shape[1])
+        Kc = K.to_scipy().tocsr()
+        total = total + sp.vstack([sp.csr_matrix((chunk.dofs[0], ref.shape[1])), Kc,
+                                   sp.csr_matrix((ref.shape[0] - chunk.dofs[1], ref.shape[1]))]).tocsr()
+        declined += chunk.ptap(dev.DeviceCSR.from_scipy(bad[r0:r1]), r0, chk) is None
+    assert abs(total - ref).max() <= 1e-12 * abs(ref).max()
+    assert declined == 1

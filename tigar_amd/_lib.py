@@ -137,11 +137,16 @@ PROTOTYPES = {
                                      C.POINTER(handle)]),
     "tg_cellplan_ptap": (C.c_int, [handle, handle, c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
     "tg_cellplan_destroy": (C.c_int, [handle]),
-    "tg_cellplan_create_from_rows": (C.c_int, [C.c_int64, C.c_int, C.c_int, handle, c_i32p, c_i32p, c_i32p, handle, C.c_int,
-                                               C.c_double, C.POINTER(handle)]),
-    "tg_elemsplit_create": (C.c_int, [handle, C.c_int64, C.c_int, c_i32p, c_i32p, c_i32p, C.POINTER(handle)]),
-    "tg_elemsplit_ptap": (C.c_int, [handle, handle, handle, c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
-    "tg_elemsplit_destroy": (C.c_int, [handle]),
+    "tg_cells_from_host": (C.c_int, [c_i32p, C.c_int64, C.c_int, C.POINTER(handle)]),
+    "tg_cells_from_grid": (C.c_int, [C.c_int, c_i64p, C.c_int, c_i64p, c_i64p, C.POINTER(handle)]),
+    "tg_cells_dims": (C.c_int, [handle, c_i64p, C.POINTER(C.c_int)]),
+    "tg_cells_download": (C.c_int, [handle, c_i32p]),
+    "tg_cells_destroy": (C.c_int, [handle]),
+    "tg_elemplan_create": (C.c_int, [handle, C.c_int64, C.c_int64, handle, C.c_int64, C.POINTER(handle)]),
+    "tg_elemplan_info": (C.c_int, [handle, c_i64p, c_i64p, C.POINTER(C.c_int), C.POINTER(C.c_int), c_i64p]),
+    "tg_elemplan_ptap": (C.c_int, [handle, handle, C.c_int64, C.c_int64, C.c_int64, c_i32p, C.c_int64, C.c_double,
+                                   C.POINTER(handle)]),
+    "tg_elemplan_destroy": (C.c_int, [handle]),
     "tg_foldplan_create": (C.c_int, [handle, C.c_int64, handle, handle, C.c_int64, handle, C.POINTER(handle)]),
     "tg_foldplan_apply": (C.c_int, [handle, handle, c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
     "tg_foldplan_destroy": (C.c_int, [handle]),

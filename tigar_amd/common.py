@@ -1722,9 +1722,9 @@ class ExtractedSpline(object):
         g = grids[0]
         if (int(g.degree) + 1) ** g.dim() > 64 or int(g.degree) < 1 or getattr(g, "dg", False) or g.num_nodes() != M.shape[0]:
             return None
-        from .elemptap import ElementSplitPtAP
+        from .elemptap import ElementSplitPtAP, CellNodes
         try:
-            return ElementSplitPtAP(M, _cell_dofs_arrays(g))
+            return ElementSplitPtAP(M, CellNodes.from_grid(g))       # (the dofmap of V, generated on the device)
         except (ValueError, _dev.TigarHipError):
             return None
 

@@ -1162,70 +1162,6 @@ extern "C" int tg_cellplan_create(int64_t ncell, int b, int nfmax, int64_t ncols
   return tg_cellplan_create_common(ncell, b, nfmax, ncols, md_host, fl_host, nf_host, incidence, max_k, mean_k, out);
 }
 
-// md[c][i][pos of f in fl[c]] = M[cellnodes[c][i]][f]: one wave per (cell, node); *bad: a function missing from the cell's list
-__global__ void __launch_bounds__(256)
-    k_cell_fill_md(const int64_t *__restrict__ mrowptr, const int32_t *__restrict__ mcol, const double *__restrict__ mval,
-                   const int32_t *__restrict__ cellnodes, const int32_t *__restrict__ fl, const int32_t *__restrict__ nfc,
-                   int64_t nrowsC, int b, int nfmax, double *__restrict__ md, int *__restrict__ bad) {
-  const int lane = threadIdx.x & 63;
-  const int64_t nw = (int64_t)gridDim.x * 4;
-  for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < nrowsC; k += nw) {
-    const int64_t c = k / b;
-    const int32_t *f = fl + c * nfmax;
-    const int nf = nfc[c];
-    const int64_t r = cellnodes[k];
-    for (int64_t e = mrowptr[r] + lane; e < mrowptr[r + 1]; e += 64) {
-      const int32_t col = mcol[e];
-      int lo = 0, hi = nf;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (f[mid] < col) lo = mid + 1; else hi = mid;
-      }
-      if (lo < nf && f[lo] == col) md[k * nfmax + lo] = mval[e];
-      else atomicOr(bad, 1);
-    }
-  }
-}
-
-/* The plan of the cell-block product for cells that SHARE nodes (a connected grid split into elements, tg_elemsplit_*): cell c
- * holds the FE nodes cellnodes[c][0..b) (rows of `m`), fl / nf / incidence as for tg_cellplan_create; the dense rows of M per
- * cell are gathered on the device. */
-extern "C" int tg_cellplan_create_from_rows(int64_t ncell, int b, int nfmax, tg_csr_t m, const int32_t *cellnodes_host,
-                                            const int32_t *fl_host, const int32_t *nf_host, tg_csr_t incidence, int max_k,
-                                            double mean_k, tg_cellplan_t *out) {
-  TG_REQUIRE_INIT();
-  TG_REQUIRE(m && cellnodes_host && out, "null argument to tg_cellplan_create_from_rows");
-  TG_REQUIRE_CANONICAL(m);
-  tg_cellplan_t pl = nullptr;
-  TG_TRY(tg_cellplan_create_common(ncell, b, nfmax, m->ncols, nullptr, fl_host, nf_host, incidence, max_k, mean_k, &pl));
-  int32_t *cn = nullptr, *fl = nullptr;
-  int rc = tg_dmalloc(&cn, ncell * b) || tg_dmalloc(&fl, ncell * nfmax);
-  int *bad = (int *)g_tg.scratch;
-  int hbad = 0;
-  if (!rc) {
-    hipMemcpyAsync(cn, cellnodes_host, (size_t)(ncell * b) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
-    hipMemcpyAsync(fl, fl_host, (size_t)(ncell * nfmax) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
-    hipMemsetAsync(bad, 0, sizeof(int), g_tg.stream);
-    hipLaunchKernelGGL(k_cell_fill_md, dim3((unsigned)std::min<int64_t>(tg_cdiv(ncell * b, 4), (int64_t)g_tg.num_cu * 32)), dim3(256), 0,
-                       g_tg.stream, m->rowptr, m->col, m->val, cn, fl, pl->nf, ncell * b, b, nfmax, pl->md, bad);
-    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
-        hipStreamSynchronize(g_tg.stream) != hipSuccess)
-      rc = 1;
-  }
-  tg_dfree(cn);
-  tg_dfree(fl);
-  if (!rc && hbad) {
-    tg_set_error("tg_cellplan_create_from_rows: a row of M names a function that is not in its cell's list");
-    rc = 2;
-  }
-  if (rc) {
-    tg_cellplan_destroy(pl);
-    return rc;
-  }
-  *out = pl;
-  return 0;
-}
-
 extern "C" int tg_cellplan_destroy(tg_cellplan_t pl) {
   if (!pl) return 0;
   if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
@@ -1857,188 +1793,4 @@ extern "C" int tg_foldplan_apply(tg_foldplan_t pl, tg_csr_t ku, const int32_t *z
   }
   *k_out = k;
   return 0;
-}
-
-
-// ------------------------------------------------------------------------------------------------------------------
-// Element splitting (round 5): the cell-block product for CONNECTED grids.  A matrix assembled on a mesh whose
-// cells share nodes is a sum of element matrices; ANY splitting A = sum_c R_c^T A_c R_c into b x b blocks over the cells'
-// node lists gives  K = M^T A M = sum_c (R_c M)^T A_c (R_c M)  -- the cell-block product above with rows of M repeated per
-// cell.  The splitting used: an entry (r, s) goes to the LOWEST cell that holds both nodes.  Nothing about a lattice is
-// assumed: the cells' node lists are what dolfin's dofmap gives (V.dofmap().cell_dofs), A may hold any values on entries that
-// couple nodes of a common cell (every assembled FE matrix does; one that does not is declined, status 100).
-struct tg_elemsplit_s {
-  int64_t ncell = 0, nnz = 0, nrows = 0;
-  unsigned long long pattern = 0;   // order-independent hash of (row pointer, column indices) of the matrix it was made for
-  int b = 0;
-  int32_t *amap = nullptr;      // [ncell][b][b]: the entry of A that block position holds, -1 = none
-};
-
-__global__ void __launch_bounds__(256)
-    k_elem_assign(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ cellnodes,
-                  const int32_t *__restrict__ nptr, const int32_t *__restrict__ ncl, int64_t ncell, int b,
-                  int32_t *__restrict__ amap, unsigned long long *__restrict__ count) {
-  __shared__ int32_t nodes[64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  unsigned long long mine = 0;
-  for (int64_t c = blockIdx.x; c < ncell; c += gridDim.x) {
-    __syncthreads();
-    if (threadIdx.x < b) nodes[threadIdx.x] = cellnodes[c * b + threadIdx.x];
-    __syncthreads();
-    for (int i = w; i < b; i += 4) {
-      const int32_t r = nodes[i];
-      const int p0 = nptr[r], p1 = nptr[r + 1];
-      for (int64_t e = rowptr[r] + lane; e < rowptr[r + 1]; e += 64) {
-        const int32_t s = col[e];
-        int lo = 0, hi = b;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (nodes[mid] < s) lo = mid + 1; else hi = mid;
-        }
-        if (lo >= b || nodes[lo] != s) continue;
-        // the lowest cell that holds r and s owns the entry: is there one below c ?
-        bool owner = true;
-        for (int q = p0; q < p1 && owner; q++) {
-          const int32_t c2 = ncl[q];
-          if (c2 >= c) break;                       // (ascending)
-          const int32_t *n2 = cellnodes + (int64_t)c2 * b;
-          int l2 = 0, h2 = b;
-          while (l2 < h2) {
-            const int mid = (l2 + h2) >> 1;
-            if (n2[mid] < s) l2 = mid + 1; else h2 = mid;
-          }
-          if (l2 < b && n2[l2] == s) owner = false;
-        }
-        if (owner) {
-          amap[(c * b + i) * (int64_t)b + lo] = (int32_t)e;
-          mine++;
-        }
-      }
-    }
-  }
-  mine = tg_wave_incl_scan_i64((int64_t)mine);
-  if (lane == 63 && mine) atomicAdd(count, mine);
-}
-
-// sum over the entries of mix(position, column) + sum over the rows of mix(row, start): integers, any order
-__global__ void __launch_bounds__(256)
-    k_elem_pattern_hash(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nrows, int64_t nnz,
-                        unsigned long long *__restrict__ out) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  unsigned long long h = 0;
-  auto mix = [](unsigned long long z) {
-    z *= 0x9E3779B97F4A7C15ull;
-    z ^= z >> 32;
-    z *= 0xD6E8FEB86659FD93ull;
-    z ^= z >> 29;
-    return z;
-  };
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += stride)
-    h += mix(((unsigned long long)e << 32) ^ (unsigned long long)(unsigned)col[e]);
-  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= nrows; r += stride)
-    h += mix(((unsigned long long)r * 0x100000001B3ull) ^ (unsigned long long)rowptr[r] ^ 0xA5A5A5A5ull);
-  for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
-}
-static int tg_elem_pattern_hash(tg_csr_t a, unsigned long long *host) {
-  unsigned long long *d = (unsigned long long *)(g_tg.scratch + 16);
-  TG_CHECK_HIP(hipMemsetAsync(d, 0, sizeof(*d), g_tg.stream));
-  hipLaunchKernelGGL(k_elem_pattern_hash, dim3((unsigned)std::min<int64_t>(tg_cdiv(a->nnz + a->nrows + 1, 256), (int64_t)g_tg.num_cu * 32)),
-                     dim3(256), 0, g_tg.stream, a->rowptr, a->col, a->nrows, a->nnz, d);
-  TG_LAUNCH_CHECK();
-  TG_CHECK_HIP(hipMemcpyAsync(host, d, sizeof(*host), hipMemcpyDeviceToHost, g_tg.stream));
-  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
-  return 0;
-}
-
-__global__ void __launch_bounds__(256)
-    k_elem_gather(const int32_t *__restrict__ amap, const double *__restrict__ aval, int64_t n, double *__restrict__ blocks) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
-    const int32_t e = amap[k];
-    blocks[k] = e >= 0 ? aval[e] : 0.0;
-  }
-}
-
-/* cellnodes_host [ncell][b]: the nodes of every cell in ASCENDING order; nptr_host [nrows + 1] / ncells_host: for every node
- * the cells that hold it, ascending (the transposed list).  100: A holds an entry whose nodes share no cell. */
-extern "C" int tg_elemsplit_create(tg_csr_t a, int64_t ncell, int b, const int32_t *cellnodes_host, const int32_t *nptr_host,
-                                   const int32_t *ncells_host, tg_elemsplit_t *out) {
-  TG_REQUIRE_INIT();
-  TG_REQUIRE(a && cellnodes_host && nptr_host && ncells_host && out && ncell > 0 && b >= 1 && b <= 64,
-             "bad arguments to tg_elemsplit_create");
-  TG_REQUIRE_CANONICAL(a);
-  TG_REQUIRE(a->nrows == a->ncols && a->nnz < 0x7fffffffll && a->nrows < 0x7fffffffll, "tg_elemsplit_create: matrix too large");
-  tg_elemsplit_s *sp = new tg_elemsplit_s();
-  sp->ncell = ncell, sp->b = b, sp->nnz = a->nnz, sp->nrows = a->nrows;
-  int32_t *cn = nullptr, *np = nullptr, *nc = nullptr;
-  const int64_t nb = ncell * (int64_t)b * b;
-  unsigned long long *cnt = (unsigned long long *)(g_tg.scratch + 8), h = 0;
-  int rc = tg_dmalloc(&sp->amap, nb) || tg_dmalloc(&cn, ncell * b) || tg_dmalloc(&np, a->nrows + 1) || tg_dmalloc(&nc, ncell * b);
-  if (!rc) {
-    hipMemcpyAsync(cn, cellnodes_host, (size_t)(ncell * b) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
-    hipMemcpyAsync(np, nptr_host, (size_t)(a->nrows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
-    hipMemcpyAsync(nc, ncells_host, (size_t)(ncell * b) * sizeof(int32_t), hipMemcpyHostToDevice, g_tg.stream);
-    hipMemsetAsync(sp->amap, 0xff, (size_t)nb * sizeof(int32_t), g_tg.stream);
-    hipMemsetAsync(cnt, 0, sizeof(h), g_tg.stream);
-    hipLaunchKernelGGL(k_elem_assign, dim3((unsigned)std::min<int64_t>(ncell, (int64_t)g_tg.num_cu * 64)), dim3(256), 0, g_tg.stream,
-                       a->rowptr, a->col, cn, np, nc, ncell, b, sp->amap, cnt);
-    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
-        hipStreamSynchronize(g_tg.stream) != hipSuccess) {
-      tg_set_error("tg_elemsplit_create: the assignment kernel failed to run");
-      rc = 1;
-    }
-  }
-  tg_dfree(cn);
-  tg_dfree(np);
-  tg_dfree(nc);
-  if (!rc && (int64_t)h != a->nnz) rc = 100;      // an entry couples nodes without a common cell (or a node list is not sorted)
-  if (!rc) rc = tg_elem_pattern_hash(a, &sp->pattern);
-  if (rc) {
-    tg_dfree(sp->amap);
-    delete sp;
-    return rc;
-  }
-  *out = sp;
-  return 0;
-}
-
-extern "C" int tg_elemsplit_destroy(tg_elemsplit_t sp) {
-  if (!sp) return 0;
-  if (g_tg.ready) {
-    hipStreamSynchronize(g_tg.stream);
-    tg_dfree(sp->amap);
-  }
-  delete sp;
-  return 0;
-}
-
-/* K = M^T A M through the element blocks of `sp` (the values of `a` gathered into [ncell][b][b]) and the cell plan made with
- * tg_cellplan_create_from_rows for the same cells.  `a` must have the pattern the splitting was made for. */
-extern "C" int tg_elemsplit_ptap(tg_elemsplit_t sp, tg_cellplan_t plan, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero,
-                                 double diag, tg_csr_t *k_out) {
-  TG_REQUIRE_INIT();
-  TG_REQUIRE(sp && plan && a && k_out, "null argument to tg_elemsplit_ptap");
-  TG_REQUIRE(plan->ncell == sp->ncell && plan->b == sp->b, "tg_elemsplit_ptap: the cell plan is not the one the splitting was made for");
-  TG_REQUIRE_CANONICAL(a);
-  if (a->nnz != sp->nnz || a->nrows != sp->nrows) return 100;
-  {
-    // the splitting maps block positions to ENTRIES of the matrix it was made for: another pattern of the same size (the
-    // reference redoes the symbolic product at every call, tIGAr/common.py:1194-1195) must not be read through it
-    unsigned long long hh = 0;
-    TG_TRY(tg_elem_pattern_hash(a, &hh));
-    if (hh != sp->pattern) return 100;
-  }
-  const int64_t nb = sp->ncell * (int64_t)sp->b * sp->b;
-  double *blocks = nullptr;
-  TG_TRY(tg_dmalloc(&blocks, nb + TG_CSR_PAD));
-  hipLaunchKernelGGL(k_elem_gather, dim3((unsigned)std::min<int64_t>(tg_cdiv(nb, 256), (int64_t)g_tg.num_cu * 32)), dim3(256), 0,
-                     g_tg.stream, sp->amap, a->val, nb, blocks);
-  tg_csr_s fake;
-  fake.val = blocks;
-  int rc = hipGetLastError() != hipSuccess ? 1 : tg_cellplan_ptap_impl(plan, &fake, nullptr, zero_dofs, nzero, diag, k_out, true);
-  fake.val = nullptr;
-  if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
-  tg_dfree(blocks);
-  return rc;
 }
