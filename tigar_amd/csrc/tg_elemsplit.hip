@@ -40,6 +40,7 @@
 #define EL_POSBITS 7          // node -> cell list entries: (cell << 7) | position of the node in the cell
 #define EL_MAXNODES 128
 #define EL_MAXROW 1024        // longest row of K (3-D p = 4: 729)
+#define EL_BLOCK 4096         // entries of the temporary a wave reserves at a time (one atomic per block, not per row)
 
 struct tg_cells_s {
   int64_t ncell = 0;
@@ -57,6 +58,8 @@ struct tg_elemplan_s {
   int64_t *nptr = nullptr;       // [nnode + 1]
   int32_t *nlist = nullptr;      // (cell << 7 | pos), ascending per node
   int32_t *fl = nullptr, *nf = nullptr;   // own cells: [nown][EL_FLS], [nown]
+  uint8_t *mpos = nullptr;                // [nown][b][64]: position in the cell's list of the first 64 entries of every node's row
+                                          // of M, entry e at byte (e % 4) * 16 + e / 4 (the 16 entries a thread gathers are adjacent)
   int64_t dof0 = 0, dof1 = 0;
   int64_t *iptr = nullptr;       // [ndof + 1]
   int32_t *ient = nullptr;       // c_own * S + q, ascending per function
@@ -74,6 +77,15 @@ struct tg_elemplan_s {
     __builtin_amdgcn_wave_barrier();                     \
   } while (0)
 
+// Atomics of many waves on ONE address are a serial resource (about 12 ns each at the L2, whatever the value): statistics are
+// read first and updated only when that changes them.
+__device__ __forceinline__ void el_stat_min(int *p, int v) {
+  if (v < __builtin_nontemporal_load(p)) atomicMin(p, v);
+}
+__device__ __forceinline__ void el_stat_max(int *p, int v) {
+  if (v > __builtin_nontemporal_load(p)) atomicMax(p, v);
+}
+
 // minimum over the 64 lanes, in every lane (all lanes must be active): butterflies inside the rows of 16 lanes by DPP (xor 1,
 // xor 2, half-row mirror, row mirror), then the four rows through scalar registers
 __device__ __forceinline__ int el_wave_min(int v) {
@@ -84,6 +96,58 @@ __device__ __forceinline__ int el_wave_min(int v) {
   const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32),
             d = __builtin_amdgcn_readlane(v, 48);
   return min(min(a, b), min(c, d));
+}
+
+// The merge both symbolic kernels run: sorted lists staged in LDS (list x at L + x * LD), lane `lane` walks list `lane` (n0
+// entries) and, with TWO, list lane + 64 (n1 entries).  Every step takes the smallest head m (the next element of the union)
+// and stores it in U[k]; with PLACES the lanes whose head it is store the step number in place of the list entry (its rank in
+// the union).  A lane keeps a WINDOW of its next eight entries in registers, refilled every eight steps (a lane moves on at
+// most once per step): one LDS round trip per eight steps instead of one per step on the chain min -> compare -> min
+// (measured: 800 cycles per step with the head read from LDS in the step).  Returns the number of steps (= size of the union),
+// -1 when that exceeds ucap.  All lanes must be active.
+template <bool PLACES, bool TWO>
+__device__ __forceinline__ int el_merge_staged(int32_t *L, int LD, int lane, int n0, int n1, int32_t *U, int ucap) {
+  int32_t *L0 = L + lane * LD, *L1 = L + (lane + 64) * LD;
+  int c0 = 0, c1 = 0, k = 0;
+  for (;;) {
+    int w[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int t = L0[max(min(c0 + j, n0 - 1), 0)];
+      w[j] = c0 + j < n0 ? t : EL_INF;
+    }
+    if (TWO) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int t = L1[max(min(c1 + j, n1 - 1), 0)];
+        v[j] = c1 + j < n1 ? t : EL_INF;
+      }
+    }
+    // (opaque to the compiler: it otherwise proves w[j] == L0[c0 + j], carries seven values around the loop and reads the
+    //  eighth inside the step -- the LDS round trip back on the chain)
+    asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
+    if (TWO) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int m = el_wave_min(TWO ? min(w[0], v[0]) : w[0]);
+      if (m == EL_INF) return k;
+      if (k >= ucap) return -1;
+      const bool a0 = w[0] == m;
+      if (PLACES && a0) L0[c0] = k;
+      c0 += a0 ? 1 : 0;
+#pragma unroll
+      for (int j = 0; j < 7; j++) w[j] = a0 ? w[j + 1] : w[j];
+      if (TWO) {
+        const bool a1 = v[0] == m;
+        if (PLACES && a1) L1[c1] = k;
+        c1 += a1 ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) v[j] = a1 ? v[j + 1] : v[j];
+      }
+      U[k] = m;            // (every lane, one address, one value)
+      k++;
+    }
+  }
 }
 
 // ---- the cells' node lists ------------------------------------------------------------------------------------------
@@ -208,8 +272,8 @@ __global__ void __launch_bounds__(256) k_el_minmax(const int32_t *__restrict__ v
     hi = max(hi, __shfl_xor(hi, o, 64));
   }
   if ((threadIdx.x & 63) == 0) {
-    atomicMin(mm, lo);
-    atomicMax(mm + 1, hi);
+    el_stat_min(mm, lo);
+    el_stat_max(mm + 1, hi);
   }
 }
 
@@ -253,63 +317,103 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---- function lists of the own cells: union of the columns of the rows of M of the cell's nodes ------------------------
+// one wave per cell: the rows of M of its nodes staged in LDS (coalesced), then el_merge_staged
 // stats: [0] smallest function, [1] largest function, [2] longest list, [3] bad (1: a node outside the rows of M, 2: more than
-// EL_FLS functions)
+// EL_FLS functions in a cell or in a row of M)
+template <bool TWO>
 __global__ void __launch_bounds__(256)
     k_el_fl(const int64_t *__restrict__ mrowptr, const int32_t *__restrict__ mcol, int64_t m_row0, int64_t m_nrows,
-            const int32_t *__restrict__ cn, int64_t own0, int64_t nown, int b, int32_t *__restrict__ fl, int32_t *__restrict__ nf,
-            int *__restrict__ stats) {
-  const int lane = threadIdx.x & 63;
-  const int64_t nw = (int64_t)gridDim.x * 4;
-  for (int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); c < nown; c += nw) {
-    int64_t p0 = 0, e0 = 0, p1 = 0, e1 = 0;
-    bool bad = false;
+            const int32_t *__restrict__ cn, int64_t own0, int64_t nown, int b, int LD, int wave_words, int waves,
+            int32_t *__restrict__ fl, int32_t *__restrict__ nf, uint8_t *__restrict__ mpos, int *__restrict__ stats, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) int32_t el_smem[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (w >= waves) return;
+  int32_t *L = el_smem + (size_t)w * wave_words;
+  int32_t *U = L + (size_t)wave_words - EL_FLS;
+  const int64_t nw = (int64_t)gridDim.x * waves;
+  int s_first = EL_INF, s_last = -1, s_nf = 0;
+  for (int64_t c = (int64_t)blockIdx.x * waves + w; c < nown; c += nw) {
+    int64_t p0 = 0, p1 = 0;
+    int n0 = 0, n1 = 0;
+    bool bad = false, longrow = false;
     if (lane < b) {
       const int64_t r = cn[(own0 + c) * b + lane] - m_row0;
       if (r < 0 || r >= m_nrows) bad = true;
-      else p0 = mrowptr[r], e0 = mrowptr[r + 1];
+      else {
+        p0 = mrowptr[r];
+        const int64_t len = mrowptr[r + 1] - p0;
+        if (len >= LD) longrow = true;
+        n0 = (int)len;
+      }
     }
-    if (lane + 64 < b) {
+    if (TWO && lane + 64 < b) {
       const int64_t r = cn[(own0 + c) * b + lane + 64] - m_row0;
       if (r < 0 || r >= m_nrows) bad = true;
-      else p1 = mrowptr[r], e1 = mrowptr[r + 1];
+      else {
+        p1 = mrowptr[r];
+        const int64_t len = mrowptr[r + 1] - p1;
+        if (len >= LD) longrow = true;
+        n1 = (int)len;
+      }
     }
-    if (__any(bad)) {
-      if (lane == 0) atomicOr(stats + 3, 1);
-      if (lane == 0) nf[c] = 0;
+    if (__any(bad || longrow)) {
+      if (lane == 0) atomicOr(stats + 3, __any(bad) ? 1 : 2), nf[c] = 0;
       continue;
     }
-    int h0 = p0 < e0 ? mcol[p0] : EL_INF, h1 = p1 < e1 ? mcol[p1] : EL_INF;
-    int k = 0, first = EL_INF, last = -1;
-    for (;;) {
-      const int m = el_wave_min(min(h0, h1));
-      if (m == EL_INF) break;
-      if (k >= EL_FLS) {
-        if (lane == 0) atomicOr(stats + 3, 2);
-        break;
+    EL_WAVE_SYNC();
+    for (int xb = 0; xb < b; xb += 16) {        // (sixteen rows in flight: loads first -- the column arrays are padded by
+      int32_t ta[16], tb[16];                   //  TG_CSR_PAD entries, reading past a row's end is safe -- then the LDS stores)
+      int nx[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int x = xb + u;
+        const int64_t pa = __shfl(p0, x & 63, 64), pb = TWO ? __shfl(p1, x & 63, 64) : 0;
+        const int na = __shfl(n0, x & 63, 64), nb = TWO ? __shfl(n1, x & 63, 64) : 0;
+        const int64_t px = x < 64 ? pa : pb;
+        nx[u] = x >= b ? 0 : (x < 64 ? na : nb);
+        ta[u] = mcol[px + lane];
+        tb[u] = LD > 65 ? mcol[px + lane + 64] : 0;
       }
-      if (h0 == m) {
-        p0++;
-        h0 = p0 < e0 ? mcol[p0] : EL_INF;
-      }
-      if (h1 == m) {
-        p1++;
-        h1 = p1 < e1 ? mcol[p1] : EL_INF;
-      }
-      if (lane == 0) fl[c * EL_FLS + k] = m;
-      if (k == 0) first = m;
-      last = m;
-      k++;
-    }
-    if (lane == 0) {
-      nf[c] = k;
-      if (k > 0) {
-        atomicMin(stats, first);
-        atomicMax(stats + 1, last);
-        atomicMax(stats + 2, k);
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int x = xb + u;
+        if (lane < nx[u]) L[x * LD + lane] = ta[u];
+        if (lane + 64 < nx[u]) L[x * LD + lane + 64] = tb[u];
       }
     }
+    if (dbg == 1) continue;
+    EL_WAVE_SYNC();
+    const int k = dbg == 2 ? 0 : el_merge_staged<true, TWO>(L, LD, lane, n0, n1, U, EL_FLS);
+    if (k < 0) {
+      if (lane == 0) atomicOr(stats + 3, 2), nf[c] = 0;
+      continue;
+    }
+    EL_WAVE_SYNC();
+    // the ranks the merge left in place of the rows' entries = their positions in the list (the first 64 of a row; the
+    // kernel that gathers M_c looks the others up)
+    for (int x = 0; x < b; x++) {
+      const int nx = x < 64 ? __shfl(n0, x & 63, 64) : (TWO ? __shfl(n1, x & 63, 64) : 0);
+      if (lane < nx) mpos[((c * b + x) << 6) + ((lane & 3) << 4) + (lane >> 2)] = (uint8_t)L[x * LD + lane];
+    }
+    if (lane < k) fl[c * EL_FLS + lane] = U[lane];
+    if (lane + 64 < k) fl[c * EL_FLS + lane + 64] = U[lane + 64];
+    if (lane == 0) nf[c] = k;
+    if (k > 0) s_first = min(s_first, U[0]), s_last = max(s_last, U[k - 1]), s_nf = max(s_nf, k);
   }
+  if (lane == 0 && s_nf > 0) {
+    el_stat_min(stats, s_first);
+    el_stat_max(stats + 1, s_last);
+    el_stat_max(stats + 2, s_nf);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_el_maxrow(const int64_t *__restrict__ rowptr, int64_t nrows, int *__restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nrows; i += stride)
+    m = max(m, (int)min(rowptr[i + 1] - rowptr[i], (int64_t)0x7fffffff));
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) el_stat_max(out, m);
 }
 
 // ---- function -> rows of the element matrices ---------------------------------------------------------------------------
@@ -363,7 +467,7 @@ __global__ void __launch_bounds__(256)
     if (lane + 64 < n) ient[a + r1] = k1;
   }
   for (int o = 32; o > 0; o >>= 1) longest = max(longest, __shfl_xor(longest, o, 64));
-  if (lane == 0) atomicMax(stat, longest);
+  if (lane == 0) el_stat_max(stat, longest);
 }
 
 // ---- the splitting: one pass over the entries of A --------------------------------------------------------------------------
@@ -452,10 +556,12 @@ __global__ void __launch_bounds__(256)
     n_foreign += __shfl_xor(n_foreign, o, 64);
     n_unc += __shfl_xor(n_unc, o, 64);
   }
-  if (lane == 0) {
-    if (n_own) atomicAdd(counters, n_own);
-    if (n_foreign) atomicAdd(counters + 1, n_foreign);
-    if (n_unc) atomicAdd(counters + 2, n_unc);
+  __shared__ unsigned long long tot[4][3];
+  if (lane == 0) tot[threadIdx.x >> 6][0] = n_own, tot[threadIdx.x >> 6][1] = n_foreign, tot[threadIdx.x >> 6][2] = n_unc;
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const unsigned long long t = tot[0][threadIdx.x] + tot[1][threadIdx.x] + tot[2][threadIdx.x] + tot[3][threadIdx.x];
+    if (t) atomicAdd(counters + threadIdx.x, t);
   }
 }
 
@@ -540,6 +646,149 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- the same product on the matrix cores: v_mfma_f64_16x16x4_f64 ------------------------------------------------------------------
+// The register-tile kernel above is LDS-bound (8 LDS reads per 16 multiply-adds: 2 MB of LDS reads per 64-node cell against the
+// 128 B per clock of a CU); a 16 x 16 x 4 matrix instruction takes 128 operand doubles for 1024 multiply-adds.  Operand layout
+// (cdna_hip_programming.md, fragment layout: f64 is its own case): A lane l = A[row l % 16][k l / 16], B lane l = B[k l / 16]
+// [col l % 16], D lane l, register i = D[row l / 16 + 4 i][col l % 16].  A_c is staged TRANSPOSED ([q][row], stride W + 1) so that
+// both operands are read along consecutive lanes; wave w computes the 16 rows [16 w, 16 w + 16) of T = A_c M_c, then of
+// E = M_c^T T, all NB column tiles at once.  fp64 matrix and vector instructions share one multiplier array
+// (profiles/r5_fp64_rate_valu_vs_mfma.txt): the gain is the LDS traffic, not the peak.
+typedef double el_v4d __attribute__((ext_vector_type(4)));
+// The global loads of the NEXT cell are issued between the phases of the current one, in the order of their dependences (block
+// of A and node numbers before the first product, row pointers of M after it, entries of M before the second): a cell's inputs
+// are in registers when its turn comes.  (Without that: 13.7 ms at 64^3 elements p = 3, of which the matrix instructions 3.5.)
+template <int NB>
+__global__ void __launch_bounds__(256, 2)          // (two workgroups per CU: one loads while the other multiplies)
+    k_el_dense_mfma(double *__restrict__ blocks, int S, int64_t nown, const int32_t *__restrict__ cn, int64_t own0, int b,
+                    const int64_t *__restrict__ mrowptr, const int32_t *__restrict__ mcol, const double *__restrict__ mval,
+                    int64_t m_row0, const int32_t *__restrict__ fl, const int32_t *__restrict__ nf, const uint8_t *__restrict__ mpos) {
+  constexpr int W = 16 * NB, LA = W + 1, NA = (W * W + 255) / 256;
+  __shared__ double At[W * LA];     // A_c^T [q][row] with row length LA, then T [r][s] with row length W
+  __shared__ double Ms[W * W];      // M_c [node][function], zero-padded
+  __shared__ int32_t fls[EL_FLS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+  const int gi = tid >> 2, gs = tid & 3;          // the row of M_c this thread gathers (4 threads per row), its phase
+  // inputs of a cell in registers
+  double areg[NA], mv[16];
+  uint4 mp = make_uint4(0, 0, 0, 0);      // the positions of this thread's 16 entries in the cell's list, one byte each
+  int64_t c_of_regs = 0;
+  int32_t flreg = EL_INF, nfc = 0;
+  int64_t e0 = 0, e1 = 0, rnode = -1;
+  auto load_a = [&](int64_t c) {
+    const double *blk = blocks + c * (int64_t)S * S;
+#pragma unroll
+    for (int u = 0; u < NA; u++) {
+      const int t = tid + 256 * u, i = t / W, j = t - i * W;
+      areg[u] = (t < W * W && i < S && j < S) ? blk[i * S + j] : 0.0;
+    }
+    rnode = gi < b ? (int64_t)cn[(own0 + c) * b + gi] - m_row0 : -1;
+    c_of_regs = c;
+    nfc = nf[c];
+    flreg = tid < EL_FLS ? fl[c * EL_FLS + tid] : EL_INF;
+  };
+  auto load_ptr = [&]() {
+    e0 = rnode >= 0 ? mrowptr[rnode] : 0;
+    e1 = rnode >= 0 ? mrowptr[rnode + 1] : 0;
+  };
+  auto load_m = [&]() {
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int64_t e = e0 + gs + 4 * u;
+      mv[u] = e < e1 ? mval[e] : 0.0;
+    }
+    if (gi < b) mp = *reinterpret_cast<const uint4 *>(mpos + ((c_of_regs * b + gi) << 6) + (gs << 4));
+  };
+  int64_t c = tg_xcd_block(blockIdx.x, gridDim.x);
+  if (c < nown) {
+    load_a(c);
+    load_ptr();
+    load_m();
+  }
+  for (; c < nown; c += gridDim.x) {
+    const int64_t cnext = c + gridDim.x;
+    const int nf_c = nfc;
+    double *blk = blocks + c * (int64_t)S * S;
+    __syncthreads();
+    if (tid < EL_FLS) fls[tid] = tid < nf_c ? flreg : EL_INF;
+#pragma unroll
+    for (int u = 0; u < NA; u++) {
+      const int t = tid + 256 * u, i = t / W, j = t - i * W;
+      if (t < W * W) At[j * LA + i] = areg[u], Ms[t] = 0.0;
+    }
+    __syncthreads();
+    if (gi < b) {
+      const unsigned pw[4] = {mp.x, mp.y, mp.z, mp.w};
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (e0 + gs + 4 * u < e1) Ms[gi * W + ((pw[u >> 2] >> (8 * (u & 3))) & 0xffu)] = mv[u];
+      for (int64_t e = e0 + gs + 64; e < e1; e += 4) {       // (rows of M of more than 64 entries)
+        const int32_t col = mcol[e];
+        int lo = 0, hi = nf_c;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (fls[mid] < col) lo = mid + 1; else hi = mid;
+        }
+        Ms[gi * W + lo] = mval[e];
+      }
+    }
+    for (int i2 = gi + 64; i2 < b; i2 += 64) {               // (cells of more than 64 nodes do not come here; kept general)
+      const int64_t r = cn[(own0 + c) * b + i2] - m_row0;
+      for (int64_t e = mrowptr[r] + gs; e < mrowptr[r + 1]; e += 4) {
+        const int32_t col = mcol[e];
+        int lo = 0, hi = nf_c;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (fls[mid] < col) lo = mid + 1; else hi = mid;
+        }
+        Ms[i2 * W + lo] = mval[e];
+      }
+    }
+    if (cnext < nown) load_a(cnext);
+    __syncthreads();
+    el_v4d acc[NB];
+    if (wave < NB) {
+#pragma unroll
+      for (int n = 0; n < NB; n++) acc[n] = (el_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+      for (int k4 = 0; k4 < W / 4; k4++) {
+        const double a = At[(4 * k4 + lk) * LA + 16 * wave + lr];
+#pragma unroll
+        for (int n = 0; n < NB; n++)
+          acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ms[(4 * k4 + lk) * W + 16 * n + lr], acc[n], 0, 0, 0);
+      }
+    }
+    if (cnext < nown) load_ptr();
+    __syncthreads();                       // (everyone is done with A_c)
+    if (wave < NB) {
+#pragma unroll
+      for (int n = 0; n < NB; n++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) At[(16 * wave + lk + 4 * i) * W + 16 * n + lr] = acc[n][i];
+    }
+    if (cnext < nown) load_m();
+    __syncthreads();
+    if (wave < NB) {
+#pragma unroll
+      for (int n = 0; n < NB; n++) acc[n] = (el_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+      for (int k4 = 0; k4 < W / 4; k4++) {
+        const double a = Ms[(4 * k4 + lk) * W + 16 * wave + lr];          // M_c^T [q][r]
+#pragma unroll
+        for (int n = 0; n < NB; n++)
+          acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, At[(4 * k4 + lk) * W + 16 * n + lr], acc[n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int n = 0; n < NB; n++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int q = 16 * wave + lk + 4 * i, sidx = 16 * n + lr;
+          if (q < nf_c && sidx < nf_c) blk[(int64_t)q * S + sidx] = acc[n][i];
+        }
+    }
+  }
+}
+
 // ---- rows of K: pattern and places ------------------------------------------------------------------------------------------
 // One wave per function i (row dof0 + i of K).  The function lists of the cells that hold i are staged in LDS (row x of LD
 // words = list of the x-th incident element row); lane x walks list x (and x + 64).  Every step takes the smallest head
@@ -547,6 +796,7 @@ __global__ void __launch_bounds__(256)
 // row -- and move on.  mode 0: count only (rows row_phase, row_phase + row_step, ...: the sum goes to *cursor); 1: columns into
 // tcol at a reserved offset (off / cnt per row), places into slot.  status: 1 = tcol too small (cnt is complete then), 2 = a row
 // longer than EL_MAXROW.
+template <bool TWO>
 __global__ void __launch_bounds__(256)
     k_el_rowsym(const int64_t *__restrict__ iptr, const int32_t *__restrict__ ient, int64_t ndof, const int32_t *__restrict__ fl,
                 const int32_t *__restrict__ nf, int S, int LD, int wave_words, int waves, int mode, int64_t row_step,
@@ -560,6 +810,8 @@ __global__ void __launch_bounds__(256)
   int32_t *U = keys + 128;                            // [EL_MAXROW]
   const int64_t nw = (int64_t)gridDim.x * waves;
   unsigned long long counted = 0;
+  long long blk_next = 0;
+  int blk_left = 0;
   for (int64_t t = (int64_t)blockIdx.x * waves + w;; t += nw) {
     const int64_t i = row_phase + t * row_step;
     if (i >= ndof) break;
@@ -570,43 +822,36 @@ __global__ void __launch_bounds__(256)
       continue;
     }
     EL_WAVE_SYNC();
-    const int key0 = lane < ninc ? ient[x0 + lane] : -1, key1 = lane + 64 < ninc ? ient[x0 + lane + 64] : -1;
+    const int key0 = lane < ninc ? ient[x0 + lane] : -1, key1 = (TWO && lane + 64 < ninc) ? ient[x0 + lane + 64] : -1;
     keys[lane] = key0;
-    keys[lane + 64] = key1;
+    if (TWO) keys[lane + 64] = key1;
     const int n0 = key0 >= 0 ? nf[key0 / S] : 0, n1 = key1 >= 0 ? nf[key1 / S] : 0;
-    EL_WAVE_SYNC();
-    for (int x = 0; x < ninc; x++) {
-      const int c = keys[x] / S;
-      const int n = nf[c];
-      if (lane < n) L[x * LD + lane] = fl[(int64_t)c * EL_FLS + lane];
-      if (lane + 64 < n) L[x * LD + lane + 64] = fl[(int64_t)c * EL_FLS + lane + 64];
+    // (the loads of the staging loop depend on registers only: several lists are in flight at once)
+    for (int xb = 0; xb < ninc; xb += 16) {        // (loads first, sixteen lists in flight; then the LDS stores)
+      int32_t ta[16], tb[16];
+      int nx[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int x = xb + u;
+        const int ka = __shfl(key0, x & 63, 64), kb = TWO ? __shfl(key1, x & 63, 64) : 0;
+        const int na = __shfl(n0, x & 63, 64), nb = TWO ? __shfl(n1, x & 63, 64) : 0;
+        const int kx = x < 64 ? ka : kb;
+        nx[u] = x >= ninc ? 0 : (x < 64 ? na : nb);
+        const int32_t *src = fl + (int64_t)(max(kx, 0) / S) * EL_FLS;
+        ta[u] = src[lane];
+        tb[u] = LD > 65 ? src[lane + 64] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int x = xb + u;
+        if (lane < nx[u]) L[x * LD + lane] = ta[u];
+        if (lane + 64 < nx[u]) L[x * LD + lane + 64] = tb[u];
+      }
     }
     EL_WAVE_SYNC();
-    int c0 = 0, c1 = 0;
-    int32_t *L0 = L + lane * LD, *L1 = L + (lane + 64) * LD;
-    int h0 = c0 < n0 ? L0[0] : EL_INF, h1 = c1 < n1 ? L1[0] : EL_INF;
-    int k = 0;
-    bool too_long = false;
-    for (;;) {
-      const int m = el_wave_min(min(h0, h1));
-      if (m == EL_INF) break;
-      if (k >= EL_MAXROW) {
-        too_long = true;
-        break;
-      }
-      if (h0 == m) {
-        L0[c0] = k;
-        c0++;
-        h0 = c0 < n0 ? L0[c0] : EL_INF;
-      }
-      if (h1 == m) {
-        L1[c1] = k;
-        c1++;
-        h1 = c1 < n1 ? L1[c1] : EL_INF;
-      }
-      if (lane == 0) U[k] = m;
-      k++;
-    }
+    const int k = mode == 0 ? el_merge_staged<false, TWO>(L, LD, lane, n0, n1, U, EL_MAXROW)
+                            : el_merge_staged<true, TWO>(L, LD, lane, n0, n1, U, EL_MAXROW);
+    const bool too_long = k < 0;
     if (too_long) {
       if (lane == 0) atomicMax(status, 2);
       if (mode == 1 && lane == 0) cnt[i] = 0, off[i] = 0;
@@ -616,25 +861,34 @@ __global__ void __launch_bounds__(256)
       counted += (unsigned long long)k;
       continue;
     }
-    long long o = 0;
-    if (lane == 0) {
-      o = (long long)atomicAdd(cursor, (unsigned long long)k);
-      cnt[i] = k;
-      off[i] = o;
+    if (k > blk_left) {                  // (a new block: what is left of the old one stays unused)
+      long long nb = 0;
+      if (lane == 0) nb = (long long)atomicAdd(cursor, (unsigned long long)EL_BLOCK);
+      blk_next = __shfl(nb, 0, 64);
+      blk_left = EL_BLOCK;
     }
-    o = __shfl(o, 0, 64);
+    const long long o = blk_next;
+    blk_next += k;
+    blk_left -= k;
+    if (lane == 0) cnt[i] = k, off[i] = o;
     if (o + k > cap) {
       if (lane == 0) atomicMax(status, 1);
       continue;
     }
     EL_WAVE_SYNC();
     for (int e = lane; e < k; e += 64) tcol[o + e] = U[e];
-    for (int x = 0; x < ninc; x++) {
-      const int key = keys[x];
-      const int n = nf[key / S];
-      uint16_t *sl = slot + (int64_t)key * S;
-      if (lane < n) sl[lane] = (uint16_t)L[x * LD + lane];
-      if (lane + 64 < n) sl[lane + 64] = (uint16_t)L[x * LD + lane + 64];
+    for (int xb = 0; xb < ninc; xb += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int x = xb + u;
+        const int ka = __shfl(key0, x & 63, 64), kb = TWO ? __shfl(key1, x & 63, 64) : 0;
+        const int na = __shfl(n0, x & 63, 64), nb = TWO ? __shfl(n1, x & 63, 64) : 0;
+        const int key = x < 64 ? ka : kb;
+        const int n = x >= ninc ? 0 : (x < 64 ? na : nb);
+        uint16_t *sl = slot + (int64_t)max(key, 0) * S;
+        if (lane < n) sl[lane] = (uint16_t)L[x * LD + lane];
+        if (lane + 64 < n) sl[lane + 64] = (uint16_t)L[x * LD + lane + 64];
+      }
     }
   }
   if (mode == 0 && lane == 0 && counted) atomicAdd(cursor, counted);
@@ -651,7 +905,7 @@ __global__ void __launch_bounds__(256)
     longest = max(longest, (int)n);
     for (int64_t q = lane; q < n; q += 64) col[dst + q] = tcol[src + q];
   }
-  if (lane == 0 && longest) atomicMax(maxrow, longest);
+  if (lane == 0 && longest) el_stat_max(maxrow, longest);
 }
 
 // ---- values of K by places: one wave per row; the 64 / LPR groups of lanes take the incident element rows in turn and add
@@ -706,6 +960,7 @@ extern "C" int tg_elemplan_destroy(tg_elemplan_t pl) {
     tg_dfree(pl->nlist);
     tg_dfree(pl->fl);
     tg_dfree(pl->nf);
+    tg_dfree(pl->mpos);
     tg_dfree(pl->iptr);
     tg_dfree(pl->ient);
     tg_dfree(pl->k_rowptr);
@@ -769,10 +1024,36 @@ extern "C" int tg_elemplan_create(tg_cells_t cells, int64_t own0, int64_t own1, 
   tg_dfree(cur);
   cur = nullptr;
   // ---- function lists of the own cells
-  rc = tg_dmalloc(&pl->fl, nown * EL_FLS) || tg_dmalloc(&pl->nf, nown);
+  rc = tg_dmalloc(&pl->fl, nown * EL_FLS) || tg_dmalloc(&pl->nf, nown) || tg_dmalloc(&pl->mpos, nown * cells->b * 64 + 64);
   if (rc) return fail(rc);
-  hipLaunchKernelGGL(k_el_fl, dim3((unsigned)std::min<int64_t>(tg_cdiv(nown, 4), (int64_t)g_tg.num_cu * 64)), dim3(256), 0, g_tg.stream,
-                     m->rowptr, m->col, m_row0, m->nrows, cells->nodes, own0, nown, cells->b, pl->fl, pl->nf, st + 4);
+  {
+    // longest row of M: the stride of the staged rows (a row of more than EL_FLS entries cannot be part of a cell's list)
+    hipMemsetAsync(st + 2, 0, sizeof(int), g_tg.stream);
+    hipLaunchKernelGGL(k_el_maxrow, dim3(tg_grid_1d(m->nrows, 256)), dim3(256), 0, g_tg.stream, m->rowptr, m->nrows, st + 2);
+    int hmax = 0;
+    if (hipMemcpyAsync(&hmax, st + 2, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
+        hipStreamSynchronize(g_tg.stream) != hipSuccess) {
+      tg_set_error("tg_elemplan_create: the row-length kernel failed to run");
+      return fail(1);
+    }
+    hipMemsetAsync(st + 2, 0, sizeof(int), g_tg.stream);
+    const int LD = std::min(hmax, EL_FLS) + 1;
+    const bool two = cells->b > 64;
+    const int wave_words = (two ? 128 : 64) * LD + EL_FLS;
+    const int waves = (size_t)wave_words * 4 > 16 * 1024 ? 1 : 4;
+    const size_t lds = (size_t)waves * wave_words * sizeof(int32_t);
+    if (lds > 160 * 1024) return fail(100);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(nown, waves), (int64_t)g_tg.num_cu * 64));
+    if (two) {
+      hipFuncSetAttribute((const void *)k_el_fl<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((k_el_fl<true>), dim3(grid), dim3(64 * waves), lds, g_tg.stream, m->rowptr, m->col, m_row0, m->nrows, cells->nodes, own0,
+                         nown, cells->b, LD, wave_words, waves, pl->fl, pl->nf, pl->mpos, st + 4, getenv("TIGAR_EL_DBG") ? atoi(getenv("TIGAR_EL_DBG")) : 0);
+    } else {
+      hipFuncSetAttribute((const void *)k_el_fl<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((k_el_fl<false>), dim3(grid), dim3(64 * waves), lds, g_tg.stream, m->rowptr, m->col, m_row0, m->nrows, cells->nodes, own0,
+                         nown, cells->b, LD, wave_words, waves, pl->fl, pl->nf, pl->mpos, st + 4, getenv("TIGAR_EL_DBG") ? atoi(getenv("TIGAR_EL_DBG")) : 0);
+    }
+  }
   if (EL_SYNC_STATS()) {
     tg_set_error("tg_elemplan_create: the function-list kernels failed to run");
     return fail(1);
@@ -832,13 +1113,15 @@ extern "C" int tg_elemplan_info(tg_elemplan_t pl, int64_t *dof0, int64_t *dof1, 
 static int el_symbolic(tg_elemplan_s *pl) {
   const int64_t ndof = pl->dof1 - pl->dof0, nown = pl->own1 - pl->own0;
   const int LD = pl->nfmax + 1;
-  const int nlists = pl->ninc_max <= 64 ? 64 : 128;
+  const bool two = pl->ninc_max > 64;
+  const int nlists = two ? 128 : 64;
   const int wave_words = nlists * LD + 128 + EL_MAXROW;
-  int waves = (int)std::min<int64_t>(4, (64 * 1024) / ((int64_t)wave_words * 4));
-  if (waves < 1) waves = 1;
+  // (one wave per workgroup when a wave's lists take more than 16 KB: more workgroups fit a CU's LDS than waves of one would)
+  const int waves = getenv("TIGAR_EL_WAVES") ? atoi(getenv("TIGAR_EL_WAVES")) : ((size_t)wave_words * 4 > 16 * 1024 ? 1 : 4);
   const size_t lds = (size_t)waves * wave_words * sizeof(int32_t);
   if (lds > 160 * 1024) return 100;
-  hipFuncSetAttribute((const void *)k_el_rowsym, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute((const void *)k_el_rowsym<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute((const void *)k_el_rowsym<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   int *status = (int *)g_tg.scratch;
   unsigned long long *cursor = (unsigned long long *)(g_tg.scratch + 2);
   int64_t *off = nullptr, *cnt = nullptr;
@@ -853,7 +1136,7 @@ static int el_symbolic(tg_elemplan_s *pl) {
     cleanup();
     return rc;
   }
-  const unsigned grid_all = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(ndof, waves), (int64_t)g_tg.num_cu * 16));
+  const unsigned grid_all = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(ndof, waves), (int64_t)g_tg.num_cu * 32));
   // a sample of the rows gives the capacity of the temporary (1/32 of the work); a pass that comes out short has counted every
   // row, the next one is exact
   const int64_t step = ndof >= 8192 ? 32 : 1;
@@ -863,9 +1146,13 @@ static int el_symbolic(tg_elemplan_s *pl) {
   {
     const int64_t nsample = tg_cdiv(ndof, step);
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(nsample, waves), (int64_t)g_tg.num_cu * 16));
-    hipLaunchKernelGGL(k_el_rowsym, dim3(grid), dim3(256), lds, g_tg.stream, pl->iptr, pl->ient, ndof, pl->fl, pl->nf, pl->S, LD, wave_words,
-                       waves, 0, step, (int64_t)(step / 2), (int32_t *)nullptr, cursor, (int64_t)0, (int64_t *)nullptr, (int64_t *)nullptr,
-                       (uint16_t *)nullptr, status);
+#define EL_ROWSYM(GRID, ...)                                                                                                   \
+  do {                                                                                                                         \
+    if (two) hipLaunchKernelGGL((k_el_rowsym<true>), dim3(GRID), dim3(64 * waves), lds, g_tg.stream, __VA_ARGS__);              \
+    else hipLaunchKernelGGL((k_el_rowsym<false>), dim3(GRID), dim3(64 * waves), lds, g_tg.stream, __VA_ARGS__);                 \
+  } while (0)
+    EL_ROWSYM(grid, pl->iptr, pl->ient, ndof, pl->fl, pl->nf, pl->S, LD, wave_words, waves, 0, step, (int64_t)(step / 2), (int32_t *)nullptr,
+              cursor, (int64_t)0, (int64_t *)nullptr, (int64_t *)nullptr, (uint16_t *)nullptr, status);
     if (hipMemcpyAsync(&hsum, cursor, sizeof(hsum), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
         hipMemcpyAsync(&hstat, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
         hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
@@ -878,13 +1165,18 @@ static int el_symbolic(tg_elemplan_s *pl) {
       return 100;
     }
   }
-  int64_t cap = step == 1 ? (int64_t)hsum : (int64_t)((double)hsum * (double)step * 1.04) + 64 * EL_MAXROW;
+  // the waves reserve the temporary in blocks of EL_BLOCK entries: besides the entries themselves room for the unused tail of
+  // every block (less than a row each; from the sample's mean row) and for one open block per wave.  A pass that comes out short
+  // has reserved exactly what the next one -- same rows per wave -- will ask for.
+  const int64_t nwaves_all = (int64_t)grid_all * waves, nsampled = std::max<int64_t>(1, tg_cdiv(ndof, step));
+  const double mean_row = (double)hsum / (double)nsampled, est = step == 1 ? (double)hsum : (double)hsum * (double)step * 1.04;
+  int64_t cap = (int64_t)(est * (1.0 + 1.25 * std::min(mean_row, (double)EL_MAXROW) / EL_BLOCK)) + (nwaves_all + 2) * EL_BLOCK;
   for (int attempt = 0; attempt < 2; attempt++) {
     rc = tg_dmalloc(&tcol, cap + 16);
     if (rc) break;
     hipMemsetAsync(status, 0, 4 * sizeof(double), g_tg.stream);
-    hipLaunchKernelGGL(k_el_rowsym, dim3(grid_all), dim3(256), lds, g_tg.stream, pl->iptr, pl->ient, ndof, pl->fl, pl->nf, pl->S, LD, wave_words,
-                       waves, 1, (int64_t)1, (int64_t)0, tcol, cursor, cap, off, cnt, pl->slot, status);
+    EL_ROWSYM(grid_all, pl->iptr, pl->ient, ndof, pl->fl, pl->nf, pl->S, LD, wave_words, waves, 1, (int64_t)1, (int64_t)0, tcol, cursor, cap,
+              off, cnt, pl->slot, status);
     if (hipMemcpyAsync(&hsum, cursor, sizeof(hsum), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
         hipMemcpyAsync(&hstat, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
         hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
@@ -958,7 +1250,7 @@ extern "C" int tg_elemplan_ptap(tg_elemplan_t pl, tg_csr_t a, int64_t a_row0, in
   hipMemsetAsync(blocks, 0, (size_t)(nown * (int64_t)S * S) * sizeof(double), g_tg.stream);
   hipMemsetAsync(counters, 0, sizeof(hc), g_tg.stream);
   if (a->nrows > 0)
-    hipLaunchKernelGGL(k_el_scatter, dim3(el_grid8(std::min<int64_t>(tg_cdiv(a->nrows, 4), (int64_t)g_tg.num_cu * 64))), dim3(256), 0,
+    hipLaunchKernelGGL(k_el_scatter, dim3(el_grid8(std::min<int64_t>(tg_cdiv(a->nrows, 4), (int64_t)g_tg.num_cu * 32))), dim3(256), 0,
                        g_tg.stream, a->rowptr, a->col, a->val, a->nrows, a_row0, pl->node0, pl->nnode, pl->nptr, pl->nlist, pl->own0, pl->own1,
                        S, check_row0, check_row1, blocks, counters);
   if (hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
@@ -976,17 +1268,27 @@ extern "C" int tg_elemplan_ptap(tg_elemplan_t pl, tg_csr_t a, int64_t a_row0, in
   }
   {
     const unsigned grid = el_grid8(std::min<int64_t>(nown, (int64_t)g_tg.num_cu * 64));
-#define EL_DENSE(TSV)                                                                                                           \
-  hipLaunchKernelGGL((k_el_dense<TSV>), dim3(grid), dim3(256), 0, g_tg.stream, blocks, S, nown, pl->cells->nodes, pl->own0, pl->b, \
-                     pl->m->rowptr, pl->m->col, pl->m->val, pl->m_row0, pl->fl, pl->nf)
-    if (S <= 16) EL_DENSE(1);
-    else if (S <= 32) EL_DENSE(2);
-    else if (S <= 64) EL_DENSE(4);
-    else {
+#define EL_DENSE(KERNEL)                                                                                                        \
+  hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(256), 0, g_tg.stream, blocks, S, nown, pl->cells->nodes, pl->own0, pl->b, pl->m->rowptr, \
+                     pl->m->col, pl->m->val, pl->m_row0, pl->fl, pl->nf)
+#define EL_DENSE_MFMA(NBV)                                                                                                      \
+  hipLaunchKernelGGL((k_el_dense_mfma<NBV>), dim3(grid), dim3(256), 0, g_tg.stream, blocks, S, nown, pl->cells->nodes, pl->own0, pl->b, \
+                     pl->m->rowptr, pl->m->col, pl->m->val, pl->m_row0, pl->fl, pl->nf, pl->mpos)
+    const bool valu = getenv("TIGAR_EL_VALU") != nullptr;       // (the register-tile kernels: A/B runs)
+    if (S <= 16) {
+      if (valu) EL_DENSE(k_el_dense<1>); else EL_DENSE_MFMA(1);
+    } else if (S <= 32) {
+      if (valu) EL_DENSE(k_el_dense<2>); else EL_DENSE_MFMA(2);
+    } else if (S <= 48) {
+      if (valu) EL_DENSE(k_el_dense<4>); else EL_DENSE_MFMA(3);
+    } else if (S <= 64) {
+      if (valu) EL_DENSE(k_el_dense<4>); else EL_DENSE_MFMA(4);
+    } else {
       cleanup();
       return 100;                 // (cells of more than 64 nodes / functions: not yet)
     }
 #undef EL_DENSE
+#undef EL_DENSE_MFMA
     if (hipGetLastError() != hipSuccess) {
       tg_set_error("element split: the element kernel failed to launch");
       cleanup();

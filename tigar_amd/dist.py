@@ -223,6 +223,12 @@ class SlabHotPath(object):
         dev = self.dev
         if col is not None:
             return self._assemble_pair(a_rows, col, timers, a_factors)
+        if not self.factored and os.environ.get("TIGAR_PTAP_ELEMENTS", "1") != "0":
+            # nothing assumed about M or the values of A: the element split in chunks of element layers (csrc/tg_elemsplit.hip);
+            # an FE matrix with an entry between nodes of no common cell is declined and takes the row-wise stages below
+            out = self._assemble_by_elements(a_rows, b_rows, zero_dofs, diag, timers)
+            if out is not None:
+                return out
         sp1, axes = self.basis.splines, self.grid.axes
         zero_dofs = np.asarray(zero_dofs if zero_dofs is not None else [], dtype=np.int32)
         with_rhs = b_rows is not None
@@ -406,6 +412,161 @@ class SlabHotPath(object):
             rhs = rhs_parts[0] if len(rhs_parts) == 1 else dev.vec_concat(rhs_parts)
         tick("stack", t0)
         return K, rhs
+
+    def elem_layers(self):
+        """element layers [e0, e1) of the slab direction whose cells carry functions of this rank's dof planes, and the number
+        of layers of the direction"""
+        lay = self.layout
+        if self.k1 <= self.k0:
+            return 0, 0, lay.nel
+        za, zb = lay.fe_planes_of_dofs(self.k0, self.k1)          # FE planes [za, zb) in the (closed) supports
+        q = lay.q
+        return max(0, za // q), min(lay.nel, -(-(zb - 1) // q)), lay.nel
+
+    def _assemble_by_elements(self, a_rows, b_rows, zero_dofs, diag, timers):
+        """K_loc and (M^T b)_loc with M and A used as GENERAL sparse matrices (tIGAr/common.py:1194-1200): the element split
+        (``elemptap.ElementChunk``) over chunks of element layers of the slab direction, worked off from the bottom up.  A
+        chunk sees the FE rows of its own layers (M materialised for them, A from ``a_rows``), lists the layer below it for
+        the ownership rule, and gives the rows of K of its cells' functions; dof planes whose cells all lie in finished chunks
+        are final and go to the result, the top planes of a chunk are carried and added to the next chunk's rows.  Several
+        ranks: every rank works off the layers in the support of ITS dof planes (the layers at a rank boundary twice: no
+        exchange).  Returns None when the FE space or the matrix does not qualify (the row-wise stages take over)."""
+        import time
+        dev, lay, grid = self.dev, self.layout, self.grid
+        from .elemptap import CellNodes, ElementChunk
+        d, q = grid.dim(), int(grid.degree)
+        if getattr(grid, "dg", False) or q < 1 or (q + 1) ** d > 64 or lay.q != q:
+            return None
+        t = timers if timers is not None else {}
+
+        def tick(name, t0):
+            dev.sync()
+            t[name] = t.get(name, 0.0) + time.perf_counter() - t0
+
+        zero_dofs = np.asarray(zero_dofs if zero_dofs is not None else [], dtype=np.int32)
+        g0, g1 = self.mine["dofs"]
+        ncols = self.ncp
+        import scipy.sparse as sp
+        if g1 <= g0:
+            rhs = self.assemble_vector(b_rows, zero_dofs, timers) if b_rows is not None else None
+            return dev.DeviceCSR.from_scipy(sp.csr_matrix((0, ncols))), rhs
+        e_lo, e_hi, nel_z = self.elem_layers()
+        nn = list(grid.shape())
+        nel_other = [(n - 1) // q for n in nn[:-1]]
+        cells_per_layer = int(np.prod(nel_other, dtype=np.int64)) if nel_other else 1
+        pf, pd = lay.plane_fe, lay.plane_dofs
+        L = self._elem_chunk_layers(d, q, cells_per_layer, pf, pd, e_hi - e_lo)
+        sp1, axes = self.basis.splines, grid.axes
+        builder, single = None, None
+        pending, pend0 = None, 0          # rows [pend0, pend0 + pending.shape[0]) of K: sums over the chunks so far
+        emitted = g0
+
+        def rows_of(Kb, base, r0, r1):
+            return Kb.block(r0 - base, r1 - base, 0, ncols)
+
+        def emit(Kb, base, r0, r1):
+            """rows [r0, r1) of the block Kb (whose first row is `base`) are final: those of this rank go to the result"""
+            nonlocal builder, single, emitted
+            r0, r1 = max(r0, g0, emitted), min(r1, g1)
+            if r1 <= r0:
+                return
+            assert r0 == emitted, "element chunks: rows must come in order"
+            blk = Kb if (r0 == base and r1 == base + Kb.shape[0]) else rows_of(Kb, base, r0, r1)
+            if r0 == g0 and r1 == g1:
+                single = blk
+            else:
+                if builder is None:
+                    est = int(blk.nnz / max(1, r1 - r0) * (g1 - g0) * 1.03) + 1024
+                    builder = dev.CSRBuilder(g1 - g0, ncols, est)
+                builder.append(blk)
+            emitted = r1
+
+        e0 = e_lo
+        while e0 < e_hi:
+            e1 = min(e_hi, e0 + L)
+            t0 = time.perf_counter()
+            f0 = max(e0 - 1, 0)
+            cells = CellNodes.from_grid(grid, [0] * (d - 1) + [f0], nel_other + [e1])
+            r0, r1 = e0 * q * pf, (e1 * q + 1) * pf
+            M = dev.extract_csr_tensor(sp1, axes, 0, self.ncp, self.eps, r0, r1)
+            tick("extract", t0)
+            t0 = time.perf_counter()
+            A = a_rows(r0, r1)
+            tick("input", t0)
+            t0 = time.perf_counter()
+            try:
+                chunk = ElementChunk(cells, M, r0, own=((e0 - f0) * cells_per_layer, (e1 - f0) * cells_per_layer))
+            except ValueError:
+                return None
+            Kc = chunk.ptap(A, r0, (r0, r1 if e1 == nel_z else e1 * q * pf))
+            if Kc is None:
+                return None                      # an entry between nodes of no common cell: the row-wise stages
+            d0, d1 = chunk.dofs
+            del chunk, A, M, cells
+            tick("ptap", t0)
+            t0 = time.perf_counter()
+            # dof planes whose cells all lie below the top of this chunk are complete
+            done_planes = int(np.searchsorted(lay.sup_hi, e1 * q + 1, side="right")) if e1 < nel_z else lay.ncp
+            done_row = done_planes * pd
+            if pending is not None:
+                p1 = pend0 + pending.shape[0]
+                if d0 > pend0:                                   # (rows below the new chunk: nothing more comes for them)
+                    emit(pending, pend0, pend0, min(d0, p1))
+                ov0, ov1 = max(d0, pend0), min(p1, d1)
+                parts = []
+                if ov1 > ov0:
+                    parts.append(rows_of(pending, pend0, ov0, ov1).add(rows_of(Kc, d0, ov0, ov1)))
+                if d1 > max(p1, d0):
+                    parts.append(rows_of(Kc, d0, max(p1, d0), d1))
+                if p1 > d1:
+                    parts.append(rows_of(pending, pend0, max(d1, pend0), p1))
+                start = min(ov0, max(p1, d0)) if ov1 > ov0 else max(p1, d0)
+                pending, pend0 = (parts[0] if len(parts) == 1 else dev.csr_vstack(parts)), start
+                del parts
+            else:
+                pending, pend0 = Kc, d0
+            del Kc
+            p1 = pend0 + pending.shape[0]
+            cut = min(max(done_row, pend0), p1)
+            if cut > pend0:
+                emit(pending, pend0, pend0, cut)
+                pending = rows_of(pending, pend0, cut, p1) if cut < p1 else None
+                pend0 = cut
+            tick("stack", t0)
+            e0 = e1
+        t0 = time.perf_counter()
+        if pending is not None:
+            emit(pending, pend0, pend0, pend0 + pending.shape[0])
+            pending = None
+        if emitted != g1:
+            raise RuntimeError("element chunks: rows %d .. %d of this rank were not produced" % (emitted, g1))
+        K = single if builder is None else builder.finish()
+        if zero_dofs.size:
+            K.zero_rows_cols(zero_dofs, diag, g0)
+        tick("stack", t0)
+        rhs = self.assemble_vector(b_rows, zero_dofs, timers) if b_rows is not None else None
+        return K, rhs
+
+    def _elem_chunk_layers(self, d, q, cells_per_layer, pf, pd, nlayers):
+        """element layers per chunk of the element-split stage: blocks + places + lists of the layer's cells, q node planes of A
+        and M, the chunk's rows of K (and their copies while chunks are added) in about 40 % of the free device memory"""
+        if os.environ.get("TIGAR_ELEM_LAYERS"):
+            return max(1, int(os.environ["TIGAR_ELEM_LAYERS"]))
+        dev = self.dev
+        free_b = dev.mem_info()[0] + dev.pool_stats()[0]
+        if self.world > 1:
+            try:
+                local = int(os.environ.get("LOCAL_WORLD_SIZE", self.world))
+                free_b //= max(1, -(-local // max(1, dev.device_count())))
+            except Exception:
+                pass
+        b = (q + 1) ** d
+        per_cell = b * b * 10 + b * 64 + 128 * 4 + b * 8
+        per_node = ((2 * q + 1) ** d) * 0.55 * 12.0 + ((q + 1) ** d) * 12.0 * 1.2
+        per_dof = ((2 * q + 1) ** d) * 12.0 * 3.0
+        per_layer = cells_per_layer * per_cell + q * pf * per_node + pd * per_dof
+        fixed = pf * per_node + (q + 1) * pd * per_dof
+        return int(max(1, min(nlayers, (0.4 * free_b - fixed) // per_layer)))
 
     def _assemble_pair(self, a_rows, col, timers=None, a_factors=None):
         """rows [k0, k1) of K_fg = M_f^T A_fg M_g, f = this engine's basis, g = ``col``: the same sub-slab pipeline with the
