@@ -249,3 +249,72 @@ def test_chunks_of_cells_add_up_to_the_whole_product(d, p, nels, cuts):
         declined += chunk.ptap(dev.DeviceCSR.from_scipy(bad[r0:r1]), r0, chk) is None
     assert abs(total - ref).max() <= 1e-12 * abs(ref).max()
     assert declined == 1
+
+
+@pytest.mark.parametrize("d,p,nels,layers,world", [(3, 2, (5, 4, 11), 3, 1), (3, 3, (3, 4, 9), 2, 3), (2, 3, (9, 14), 4, 2),
+                                                    (3, 1, (4, 3, 8), 1, 2), (3, 2, (4, 4, 6), 100, 1)])
+def test_streamed_element_chunks_in_the_slab_engine(monkeypatch, d, p, nels, layers, world):
+    """``dist.SlabHotPath`` with nothing assumed about M (``factored=False``): the element split over chunks of ``layers`` element
+    layers -- M materialised chunk by chunk, A handed out in row blocks, the planes at a chunk's top carried and added, the rows
+    of every rank of a ``world`` of ranks computed without any exchange.  Against scipy's triple product with MatZeroRowsColumns;
+    non-symmetric values; M^T b as well.  An A with a coupling beyond the cells falls through to the row-wise stages."""
+    from tigar_amd import device as dev
+    from tigar_amd.dist import SlabHotPath
+    from tigar_amd.BSplines import ExplicitBSplineControlMesh, uniformKnots
+    monkeypatch.setenv("TIGAR_ELEM_LAYERS", str(layers))
+    monkeypatch.setenv("TIGAR_PTAP_ELEMENTS", "2")
+    A, M, _ = _operands(d, p, nels)
+    rng = np.random.default_rng(7 * p + d)
+    As = A.to_scipy().tocsr()
+    As.sort_indices()
+    As.data = As.data * (1.0 + 0.3 * rng.standard_normal(As.nnz)) + 0.01 * rng.standard_normal(As.nnz)
+    Ms = M.to_scipy().tocsr()
+    b = rng.standard_normal(As.shape[0])
+    zd = np.unique(rng.integers(0, Ms.shape[1], 17)).astype(np.int32)
+    ref = (Ms.T @ As @ Ms).tolil()
+    ref[zd, :] = 0.0
+    ref[:, zd] = 0.0
+    for i in zd:
+        ref[i, i] = 2.5
+    ref = ref.tocsr()
+    yref = Ms.T @ b
+    yref[zd] = 0.0
+    basis = ExplicitBSplineControlMesh([p] * d, [uniformKnots(p, 0., 1., n) for n in nels]).getScalarSpline()
+    grid = basis.generateMesh(degree=p)
+    calls = []
+
+    def a_rows(r0, r1, mat=As):
+        calls.append((r0, r1))
+        return dev.DeviceCSR.from_scipy(mat[int(r0):int(r1)])
+
+    def b_rows(r0, r1):
+        return dev.DeviceVector(data=b[int(r0):int(r1)])
+
+    Krows, yparts = [], []
+    for rank in range(world):
+        eng = SlabHotPath(basis, grid, rank, world, None, sub_planes=2, factored=False)
+        timers = {}
+        K, y = eng.assemble(a_rows, b_rows, zd, 2.5, timers)
+        assert K.shape == (eng.mine["dofs"][1] - eng.mine["dofs"][0], Ms.shape[1])
+        Krows.append(K.to_scipy().tocsr())
+        yparts.append(y.get_local())
+    Kall = sp.vstack(Krows).tocsr()
+    Kall.sort_indices()
+    pat = (abs(Ms).T @ sp.csr_matrix((np.ones(As.nnz), As.indices, As.indptr), shape=As.shape) @ abs(Ms)).tocsr()
+    pat.sort_indices()
+    assert np.array_equal(Kall.indptr, pat.indptr) and np.array_equal(Kall.indices, pat.indices)     # the structural pattern
+    assert abs(Kall - ref).max() <= 1e-12 * abs(ref).max()
+    assert np.max(np.abs(np.concatenate(yparts) - yref)) <= 1e-12 * np.max(np.abs(yref))
+    # the blocks asked for were element layers (+ the node plane on top), several of them unless one chunk covers the rank
+    plane = int(np.prod(grid.shape()[:-1]))
+    assert all((r1 - r0) % plane == 0 and ((r1 - r0) // plane - 1) % p == 0 for r0, r1 in calls)
+    if layers < nels[-1] // world:
+        assert len(calls) > world
+    # a coupling between nodes of no common cell: declined by the chunk that checks its row, same result from the row-wise stages
+    bad = As.tolil()
+    bad[1, As.shape[0] - 2] = 0.75
+    bad = bad.tocsr()
+    eng = SlabHotPath(basis, grid, 0, 1, None, sub_planes=3, factored=False)
+    K2 = eng.assemble(lambda r0, r1: a_rows(r0, r1, bad), None, None, 1.0, {})[0].to_scipy()
+    ref2 = Ms.T @ bad @ Ms
+    assert abs(K2 - ref2).max() <= 1e-12 * abs(ref2).max()
