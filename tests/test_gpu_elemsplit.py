@@ -40,6 +40,7 @@ def test_element_split_product_matches_scipy(d, p, nels):
     K = plan.ptap(A2)
     assert K is not None
     Ks = K.to_scipy().tocsr()
+    assert all(np.all(np.diff(Ks.indices[a:b]) > 0) for a, b in zip(Ks.indptr[:-1], Ks.indptr[1:]))        # canonical rows
     Ks.sort_indices()
     ref = (Ms.T @ As @ Ms).tocsr()
     ref.sort_indices()

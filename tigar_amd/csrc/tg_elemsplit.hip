@@ -894,6 +894,188 @@ __global__ void __launch_bounds__(256)
   if (mode == 0 && lane == 0 && counted) atomicAdd(cursor, counted);
 }
 
+// ---- the same by hashing (rows whose function is in at most 64 cells of at most 64 functions: every spline space of degree <= 3)
+// The merge above is a chain of as many steps as the row has entries, ~50 instructions each (17 k per row of 343).  Here the 64 x 64
+// candidates of a row sit in registers (lane = position in the list, register = list); they are put into a hash SET in LDS
+// (one compare-and-swap each, independent of one another), the set is read out, sorted in registers (bitonic network, R keys
+// per lane: in-lane stages are min / max, the others one shuffle per key), every sorted key writes its rank next to its table
+// slot, and a candidate's place is the rank at the slot it remembered: ~2.8 k instructions per row without a long dependent
+// chain.  The result is the same sorted row and the same places (deterministic: nothing depends on the order of insertion).
+template <int R>
+__device__ __forceinline__ void el_sort_regs(int (&r)[R], int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64 * R; k <<= 1) {
+    const bool asc_lane = ((lane * R) & k) == 0;          // (for k > R: the direction of this lane's keys)
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j < R) {
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+          if (t & j) continue;
+          const bool asc = k < R ? ((t & k) == 0) : asc_lane;
+          const int a = r[t], b = r[t | j], lo = min(a, b), hi = max(a, b);
+          r[t] = asc ? lo : hi;
+          r[t | j] = asc ? hi : lo;
+        }
+      } else {
+        const int d = j / R;
+        const bool keep_min = (((lane & d) == 0) == asc_lane);
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+          const int pv = __shfl_xor(r[t], d, 64);
+          r[t] = keep_min ? min(r[t], pv) : max(r[t], pv);
+        }
+      }
+    }
+  }
+}
+
+// status: 1 = tcol too small, 2 = a row longer than EL_MAXROW, 3 = a row longer than 64 R (take the next instantiation)
+template <int R>
+__global__ void __launch_bounds__(256)
+    k_el_rowhash(const int64_t *__restrict__ iptr, const int32_t *__restrict__ ient, int64_t ndof, const int32_t *__restrict__ fl,
+                 const int32_t *__restrict__ nf, int S, int waves, int mode, int64_t row_step, int64_t row_phase,
+                 int32_t *__restrict__ tcol, unsigned long long *__restrict__ cursor, int64_t cap, int64_t *__restrict__ off,
+                 int64_t *__restrict__ cnt, uint16_t *__restrict__ slot, int *__restrict__ status) {
+  constexpr int T = 256 * R, LGT = R == 8 ? 11 : 12, NU = 64 * R;
+  static_assert(R == 8 || R == 16, "k_el_rowhash: 8 or 16 keys per lane");
+  extern __shared__ __attribute__((aligned(16))) int32_t el_smem[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (w >= waves) return;
+  int32_t *tab = el_smem + (size_t)w * (T + T / 2 + NU);       // [T] keys, -1 = empty
+  uint16_t *place = reinterpret_cast<uint16_t *>(tab + T);     // [T] rank of the key in the slot
+  int32_t *U = tab + T + T / 2;                                // [NU]
+  const int64_t nw = (int64_t)gridDim.x * waves;
+  unsigned long long counted = 0;
+  long long blk_next = 0;
+  int blk_left = 0;
+  for (int64_t t = (int64_t)blockIdx.x * waves + w;; t += nw) {
+    const int64_t i = row_phase + t * row_step;
+    if (i >= ndof) break;
+    const int64_t x0 = iptr[i];
+    const int ninc = (int)(iptr[i + 1] - x0);
+    if (ninc == 0) {
+      if (mode == 1 && lane == 0) cnt[i] = 0, off[i] = 0;
+      continue;
+    }
+    const int key0 = lane < ninc ? ient[x0 + lane] : 0;
+    const int n0 = lane < ninc ? nf[key0 / S] : 0;
+    // ---- candidates: register x = list x, lane = position
+    int kx[64];
+#pragma unroll
+    for (int x = 0; x < 64; x++) {
+      const int c = __shfl(key0, x, 64) / S, nx = __shfl(n0, x, 64);
+      kx[x] = lane < nx ? fl[(int64_t)c * EL_FLS + lane] : -1;
+    }
+    EL_WAVE_SYNC();
+    {
+      int4 *t4 = reinterpret_cast<int4 *>(tab);
+#pragma unroll
+      for (int q = 0; q < T / 256; q++) t4[lane + 64 * q] = make_int4(-1, -1, -1, -1);
+    }
+    EL_WAVE_SYNC();
+    // ---- the set: slot of every candidate, two 16-bit indices per register
+    unsigned hx[32];
+#pragma unroll
+    for (int x = 0; x < 64; x++) {
+      unsigned h = 0;
+      if (x < ninc) {                         // (uniform)
+        const int k = kx[x];
+        if (k >= 0) {
+          h = ((unsigned)k * 0x9E3779B1u) >> (32 - LGT);
+          for (;;) {
+            const int old = atomicCAS(&tab[h], -1, k);
+            if (old == -1 || old == k) break;
+            h = (h + 1) & (T - 1);
+          }
+        }
+      }
+      if (x & 1) hx[x >> 1] |= h << 16; else hx[x >> 1] = h;
+    }
+    EL_WAVE_SYNC();
+    // ---- read the set out: lane l owns the slots [l T / 64, (l + 1) T / 64)
+    int mine = 0;
+    {
+      const int4 *t4 = reinterpret_cast<const int4 *>(tab + lane * (T / 64));
+#pragma unroll
+      for (int q = 0; q < T / 256; q++) {
+        const int4 v = t4[q];
+        mine += (v.x >= 0) + (v.y >= 0) + (v.z >= 0) + (v.w >= 0);
+      }
+    }
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    const int n = __shfl(incl, 63, 64);
+    if (n > NU || n > EL_MAXROW) {
+      if (lane == 0) atomicMax(status, n > EL_MAXROW ? 2 : 3);
+      if (mode == 1 && lane == 0) cnt[i] = 0, off[i] = 0;
+      continue;
+    }
+    if (mode == 0) {
+      counted += (unsigned long long)n;
+      continue;
+    }
+    for (int e = lane; e < NU; e += 64) U[e] = EL_INF;
+    EL_WAVE_SYNC();
+    {
+      int at = incl - mine;
+#pragma unroll
+      for (int q = 0; q < T / 64; q++) {
+        const int v = tab[lane * (T / 64) + q];
+        if (v >= 0) U[at++] = v;
+      }
+    }
+    EL_WAVE_SYNC();
+    int r[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) r[q] = U[lane * R + q];
+    el_sort_regs<R>(r, lane);
+    EL_WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < R; q++) U[lane * R + q] = r[q];
+    // ---- the rank of every key, next to its slot
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const int k = r[q];
+      if (k != EL_INF) {
+        unsigned h = ((unsigned)k * 0x9E3779B1u) >> (32 - LGT);
+        while (tab[h] != k) h = (h + 1) & (T - 1);
+        place[h] = (uint16_t)(lane * R + q);
+      }
+    }
+    EL_WAVE_SYNC();
+    // ---- outputs
+    if (n > blk_left) {                  // (a new block: what is left of the old one stays unused)
+      long long nb = 0;
+      if (lane == 0) nb = (long long)atomicAdd(cursor, (unsigned long long)EL_BLOCK);
+      blk_next = __shfl(nb, 0, 64);
+      blk_left = EL_BLOCK;
+    }
+    const long long o = blk_next;
+    blk_next += n;
+    blk_left -= n;
+    if (lane == 0) cnt[i] = n, off[i] = o;
+    if (o + n > cap) {
+      if (lane == 0) atomicMax(status, 1);
+      continue;
+    }
+    for (int e = lane; e < n; e += 64) tcol[o + e] = U[e];
+#pragma unroll
+    for (int x = 0; x < 64; x++) {
+      if (x < ninc) {
+        const int key = __shfl(key0, x, 64);
+        const unsigned h = (x & 1) ? (hx[x >> 1] >> 16) : (hx[x >> 1] & 0xffffu);
+        if (kx[x] >= 0) slot[(int64_t)key * S + lane] = place[h];
+      }
+    }
+  }
+  if (mode == 0 && lane == 0 && counted) atomicAdd(cursor, counted);
+}
+
 __global__ void __launch_bounds__(256)
     k_el_reorder(const int64_t *__restrict__ rowptr, const int64_t *__restrict__ off, const int32_t *__restrict__ tcol, int64_t nrows,
                  int32_t *__restrict__ col, int *__restrict__ maxrow) {
@@ -1112,16 +1294,21 @@ extern "C" int tg_elemplan_info(tg_elemplan_t pl, int64_t *dof0, int64_t *dof1, 
 
 static int el_symbolic(tg_elemplan_s *pl) {
   const int64_t ndof = pl->dof1 - pl->dof0, nown = pl->own1 - pl->own0;
+  // the merge kernel (any cell the plan accepts)
   const int LD = pl->nfmax + 1;
   const bool two = pl->ninc_max > 64;
-  const int nlists = two ? 128 : 64;
-  const int wave_words = nlists * LD + 128 + EL_MAXROW;
+  const int wave_words = (two ? 128 : 64) * LD + 128 + EL_MAXROW;
   // (one wave per workgroup when a wave's lists take more than 16 KB: more workgroups fit a CU's LDS than waves of one would)
-  const int waves = getenv("TIGAR_EL_WAVES") ? atoi(getenv("TIGAR_EL_WAVES")) : ((size_t)wave_words * 4 > 16 * 1024 ? 1 : 4);
-  const size_t lds = (size_t)waves * wave_words * sizeof(int32_t);
-  if (lds > 160 * 1024) return 100;
+  const int mwaves = (size_t)wave_words * 4 > 16 * 1024 ? 1 : 4;
+  const size_t mlds = (size_t)mwaves * wave_words * sizeof(int32_t);
+  // the hash kernel: functions in at most 64 cells of at most 64 functions; 8 keys per lane (rows of up to 512 entries), 16 when a
+  // row turns out longer (status 3)
+  int hashR = (pl->ninc_max <= 64 && pl->nfmax <= 64 && !getenv("TIGAR_EL_MERGE")) ? 8 : 0;
+  if (!hashR && mlds > 160 * 1024) return 100;
   hipFuncSetAttribute((const void *)k_el_rowsym<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipFuncSetAttribute((const void *)k_el_rowsym<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute((const void *)k_el_rowhash<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute((const void *)k_el_rowhash<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   int *status = (int *)g_tg.scratch;
   unsigned long long *cursor = (unsigned long long *)(g_tg.scratch + 2);
   int64_t *off = nullptr, *cnt = nullptr;
@@ -1136,67 +1323,84 @@ static int el_symbolic(tg_elemplan_s *pl) {
     cleanup();
     return rc;
   }
-  const unsigned grid_all = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(ndof, waves), (int64_t)g_tg.num_cu * 32));
-  // a sample of the rows gives the capacity of the temporary (1/32 of the work); a pass that comes out short has counted every
-  // row, the next one is exact
-  const int64_t step = ndof >= 8192 ? 32 : 1;
   unsigned long long hsum = 0;
   int hstat = 0;
-  hipMemsetAsync(status, 0, 4 * sizeof(double), g_tg.stream);
-  {
-    const int64_t nsample = tg_cdiv(ndof, step);
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(nsample, waves), (int64_t)g_tg.num_cu * 16));
-#define EL_ROWSYM(GRID, ...)                                                                                                   \
-  do {                                                                                                                         \
-    if (two) hipLaunchKernelGGL((k_el_rowsym<true>), dim3(GRID), dim3(64 * waves), lds, g_tg.stream, __VA_ARGS__);              \
-    else hipLaunchKernelGGL((k_el_rowsym<false>), dim3(GRID), dim3(64 * waves), lds, g_tg.stream, __VA_ARGS__);                 \
-  } while (0)
-    EL_ROWSYM(grid, pl->iptr, pl->ient, ndof, pl->fl, pl->nf, pl->S, LD, wave_words, waves, 0, step, (int64_t)(step / 2), (int32_t *)nullptr,
-              cursor, (int64_t)0, (int64_t *)nullptr, (int64_t *)nullptr, (uint16_t *)nullptr, status);
+  auto launch = [&](int mode, int64_t step, int64_t phase, int64_t cap, unsigned *grid_out) -> int {
+    const int waves = hashR == 8 ? 2 : hashR == 16 ? 1 : mwaves;
+    const size_t lds = hashR ? (size_t)waves * (256 * hashR * 3 / 2 + 64 * hashR) * sizeof(int32_t) : mlds;
+    const int64_t nrows = tg_cdiv(ndof, step);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(nrows, waves), (int64_t)g_tg.num_cu * 32));
+    if (grid_out) *grid_out = grid * (unsigned)waves;
+    hipMemsetAsync(status, 0, 4 * sizeof(double), g_tg.stream);
+    int32_t *tc = mode ? tcol : nullptr;
+    int64_t *po = mode ? off : nullptr, *pc = mode ? cnt : nullptr;
+    uint16_t *ps = mode ? pl->slot : nullptr;
+    if (hashR == 8)
+      hipLaunchKernelGGL((k_el_rowhash<8>), dim3(grid), dim3(64 * waves), lds, g_tg.stream, pl->iptr, pl->ient, ndof, pl->fl, pl->nf, pl->S, waves,
+                         mode, step, phase, tc, cursor, cap, po, pc, ps, status);
+    else if (hashR == 16)
+      hipLaunchKernelGGL((k_el_rowhash<16>), dim3(grid), dim3(64 * waves), lds, g_tg.stream, pl->iptr, pl->ient, ndof, pl->fl, pl->nf, pl->S, waves,
+                         mode, step, phase, tc, cursor, cap, po, pc, ps, status);
+    else if (two)
+      hipLaunchKernelGGL((k_el_rowsym<true>), dim3(grid), dim3(64 * waves), lds, g_tg.stream, pl->iptr, pl->ient, ndof, pl->fl, pl->nf, pl->S, LD,
+                         wave_words, waves, mode, step, phase, tc, cursor, cap, po, pc, ps, status);
+    else
+      hipLaunchKernelGGL((k_el_rowsym<false>), dim3(grid), dim3(64 * waves), lds, g_tg.stream, pl->iptr, pl->ient, ndof, pl->fl, pl->nf, pl->S, LD,
+                         wave_words, waves, mode, step, phase, tc, cursor, cap, po, pc, ps, status);
     if (hipMemcpyAsync(&hsum, cursor, sizeof(hsum), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
         hipMemcpyAsync(&hstat, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
         hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
-      tg_set_error("element split: the row sample failed to run (LDS %zu B)", lds);
-      cleanup();
+      tg_set_error("element split: the symbolic pass failed to run (LDS %zu B)", lds);
       return 1;
     }
-    if (hstat == 2) {
-      cleanup();
-      return 100;
+    return 0;
+  };
+  // a sample of the rows gives the capacity of the temporary (1/32 of the work).  The waves reserve the temporary in blocks of
+  // EL_BLOCK entries: besides the entries themselves room for the unused tail of every block (less than a row each; from the
+  // sample's mean row) and for one open block per wave.  A pass that comes out short has reserved exactly what the next one --
+  // same rows per wave -- will ask for.
+  const int64_t step = ndof >= 8192 ? 32 : 1;
+  int64_t cap = 0;
+  for (int attempt = 0; attempt < 4 && !rc; attempt++) {
+    if (cap == 0) {
+      rc = launch(0, step, step / 2, 0, nullptr);
+      if (rc) break;
+      if (hstat == 3 && hashR == 8) {
+        hashR = 16;
+        continue;
+      }
+      if (hstat >= 2) {
+        rc = 100;
+        break;
+      }
+      unsigned nwaves_all = 0;
+      {
+        const int waves = hashR == 8 ? 2 : hashR == 16 ? 1 : mwaves;
+        nwaves_all = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tg_cdiv(ndof, waves), (int64_t)g_tg.num_cu * 32)) * (unsigned)waves;
+      }
+      const int64_t nsampled = std::max<int64_t>(1, tg_cdiv(ndof, step));
+      const double mean_row = (double)hsum / (double)nsampled, est = step == 1 ? (double)hsum : (double)hsum * (double)step * 1.04;
+      cap = (int64_t)(est * (1.0 + 1.25 * std::min(mean_row, (double)EL_MAXROW) / EL_BLOCK)) + ((int64_t)nwaves_all + 2) * EL_BLOCK;
     }
-  }
-  // the waves reserve the temporary in blocks of EL_BLOCK entries: besides the entries themselves room for the unused tail of
-  // every block (less than a row each; from the sample's mean row) and for one open block per wave.  A pass that comes out short
-  // has reserved exactly what the next one -- same rows per wave -- will ask for.
-  const int64_t nwaves_all = (int64_t)grid_all * waves, nsampled = std::max<int64_t>(1, tg_cdiv(ndof, step));
-  const double mean_row = (double)hsum / (double)nsampled, est = step == 1 ? (double)hsum : (double)hsum * (double)step * 1.04;
-  int64_t cap = (int64_t)(est * (1.0 + 1.25 * std::min(mean_row, (double)EL_MAXROW) / EL_BLOCK)) + (nwaves_all + 2) * EL_BLOCK;
-  for (int attempt = 0; attempt < 2; attempt++) {
     rc = tg_dmalloc(&tcol, cap + 16);
     if (rc) break;
-    hipMemsetAsync(status, 0, 4 * sizeof(double), g_tg.stream);
-    EL_ROWSYM(grid_all, pl->iptr, pl->ient, ndof, pl->fl, pl->nf, pl->S, LD, wave_words, waves, 1, (int64_t)1, (int64_t)0, tcol, cursor, cap,
-              off, cnt, pl->slot, status);
-    if (hipMemcpyAsync(&hsum, cursor, sizeof(hsum), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
-        hipMemcpyAsync(&hstat, status, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
-        hipStreamSynchronize(g_tg.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
-      tg_set_error("element split: the symbolic pass failed to run");
-      rc = 1;
-      break;
-    }
-    if (hstat == 2) {
-      rc = 100;
-      break;
-    }
+    rc = launch(1, 1, 0, cap, nullptr);
+    if (rc) break;
     if (hstat == 0) break;
-    if (attempt == 1) {
-      tg_set_error("element split: the symbolic pass came out short twice");
-      rc = 1;
-      break;
-    }
     tg_dfree(tcol);
     tcol = nullptr;
-    cap = (int64_t)hsum;
+    if (hstat == 3 && hashR == 8) {           // (a row of more than 512 entries the sample did not see)
+      hashR = 16;
+      cap = 0;
+    } else if (hstat == 1) {
+      cap = (int64_t)hsum;
+    } else {
+      rc = 100;
+    }
+    if (attempt == 3 && !rc) {
+      tg_set_error("element split: the symbolic pass did not come to an end");
+      rc = 1;
+    }
   }
   int64_t nnz = 0;
   if (!rc) rc = tg_exclusive_scan_i64(cnt, ndof, &nnz);

@@ -472,6 +472,10 @@ class SlabHotPath(object):
                 return
             assert r0 == emitted, "element chunks: rows must come in order"
             blk = Kb if (r0 == base and r1 == base + Kb.shape[0]) else rows_of(Kb, base, r0, r1)
+            if os.environ.get("TIGAR_DEBUG"):
+                import sys
+                sys.stderr.write("[tigar] element chunks: rows %d..%d final, %d entries (block of %d rows from %d, %d entries)\n"
+                                 % (r0, r1, blk.nnz, Kb.shape[0], base, Kb.nnz))
             if r0 == g0 and r1 == g1:
                 single = blk
             else:
@@ -533,6 +537,10 @@ class SlabHotPath(object):
                 pending = rows_of(pending, pend0, cut, p1) if cut < p1 else None
                 pend0 = cut
             tick("stack", t0)
+            if os.environ.get("TIGAR_DEBUG"):
+                import sys
+                sys.stderr.write("[tigar] element chunk layers %d..%d of %d..%d: cumulative %s\n"
+                                 % (e0, e1, e_lo, e_hi, {k_: round(v, 3) for k_, v in t.items()}))
             e0 = e1
         t0 = time.perf_counter()
         if pending is not None:
