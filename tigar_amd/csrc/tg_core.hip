@@ -263,6 +263,12 @@ static size_t tg_pool_limit() {
 }
 
 extern "C" int tg_pool_stats(int64_t *pooled_bytes, int64_t *pooled_blocks, int64_t *live_blocks) {
+  if (getenv("TIGAR_TRACE") && atoi(getenv("TIGAR_TRACE")) >= 3) {       // (what sits idle, largest first)
+    fprintf(stderr, "[trace] idle blocks (MB):");
+    int shown = 0;
+    for (auto it = g_pool_free.rbegin(); it != g_pool_free.rend() && shown < 48; ++it, ++shown) fprintf(stderr, " %.0f", it->first / 1048576.0);
+    fprintf(stderr, "\n");
+  }
   if (pooled_bytes) *pooled_bytes = (int64_t)g_pool_bytes;
   if (pooled_blocks) *pooled_blocks = (int64_t)g_pool_free.size();
   if (live_blocks) *live_blocks = (int64_t)g_pool_size.size() - (int64_t)g_pool_free.size();
@@ -346,13 +352,46 @@ static int tg_dmalloc_bytes_raw(void **p, size_t bytes) {
   }
   const bool trace = getenv("TIGAR_TRACE") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  hipError_t e = hipMalloc(p, bytes);
+  // (a request the device cannot serve is not sent to the driver at all: a hipMalloc that FAILS takes its time -- measured below)
+  hipError_t e = hipErrorOutOfMemory;
+  {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr >= bytes + ((size_t)64 << 20)) e = hipMalloc(p, bytes);
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    if (trace) fprintf(stderr, "[trace] hipMalloc(%.1f MB) failed with %.1f GB pooled -> trim\n", bytes / 1048576.0,
-                       g_pool_bytes / 1073741824.0);
-    tg_pool_trim();
-    e = hipMalloc(p, bytes);
+    if (trace) {
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      fprintf(stderr, "[trace] hipMalloc(%.1f MB) not served with %.1f GB pooled in %zu blocks (%.1f ms) -> trim\n", bytes / 1048576.0,
+              g_pool_bytes / 1073741824.0, g_pool_free.size(), ms);
+    }
+    // Give back just enough of the idle blocks (smallest first; hipFree and the hipMalloc that replaces a block later both cost
+    // by the byte: 9 and 30 ms per GB here -- emptying a pool of 165 GB took 1.5-2 s of every step of a streamed assembly whose
+    // first allocation of a step, 3.5 GB of control functions, found its size class evicted); everything only if that fails.
+    {
+      tg_pool_sync_all();
+      size_t freed = 0;
+      const size_t want = bytes + bytes / 4 + ((size_t)256 << 20);
+      while (freed < want && !g_pool_free.empty()) {
+        auto sm = g_pool_free.begin();
+        freed += sm->first;
+        g_pool_bytes -= sm->first;
+        g_pool_size.erase(sm->second);
+        tg_pool_drop_events(sm->second);
+        hipFree(sm->second);
+        g_pool_free.erase(sm);
+      }
+      if (trace) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "[trace]   gave back %.1f MB, %zu blocks left (%.1f ms)\n", freed / 1048576.0, g_pool_free.size(), ms);
+      }
+      e = hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      tg_pool_trim();
+      e = hipMalloc(p, bytes);
+    }
   }
   if (trace) {
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -480,7 +480,11 @@ class SlabHotPath(object):
                 single = blk
             else:
                 if builder is None:
-                    est = int(blk.nnz / max(1, r1 - r0) * (g1 - g0) * 1.03) + 1024
+                    # capacity from the densest part of the first rows: their last dof plane (rows near the patch boundary are
+                    # shorter; a builder that has to grow allocates and copies K a second time -- 75 GB at 256^3 p = 3)
+                    nr = blk.shape[0]
+                    last = (blk.nnz - blk.rowptr_at(nr - pd)) / float(pd) if nr >= pd else blk.nnz / float(max(1, nr))
+                    est = int(max(blk.nnz / float(max(1, nr)), last) * (g1 - g0) * 1.01) + 1024
                     builder = dev.CSRBuilder(g1 - g0, ncols, est)
                 builder.append(blk)
             emitted = r1
