@@ -24,7 +24,8 @@ def _operands(d, p, nels, seed=0):
     return A, M, _cell_dofs_arrays(grid)
 
 
-@pytest.mark.parametrize("d,p,nels", [(3, 3, (5, 4, 6)), (3, 2, (7, 5, 6)), (2, 3, (17, 12)), (3, 1, (9, 8, 7)), (2, 2, (20, 15))])
+@pytest.mark.parametrize("d,p,nels", [(3, 3, (5, 4, 6)), (3, 2, (7, 5, 6)), (2, 3, (17, 12)), (3, 1, (9, 8, 7)), (2, 2, (20, 15)),
+                                      (3, 4, (3, 2, 4)), (2, 5, (7, 6)), (2, 7, (5, 4))])      # (125-node cells: the panel kernel)
 def test_element_split_product_matches_scipy(d, p, nels):
     from tigar_amd import device as dev
     from tigar_amd.elemptap import ElementSplitPtAP
@@ -253,7 +254,7 @@ def test_chunks_of_cells_add_up_to_the_whole_product(d, p, nels, cuts):
 
 
 @pytest.mark.parametrize("d,p,nels,layers,world", [(3, 2, (5, 4, 11), 3, 1), (3, 3, (3, 4, 9), 2, 3), (2, 3, (9, 14), 4, 2),
-                                                    (3, 1, (4, 3, 8), 1, 2), (3, 2, (4, 4, 6), 100, 1)])
+                                                    (3, 1, (4, 3, 8), 1, 2), (3, 2, (4, 4, 6), 100, 1), (3, 4, (2, 2, 7), 2, 2)])
 def test_streamed_element_chunks_in_the_slab_engine(monkeypatch, d, p, nels, layers, world):
     """``dist.SlabHotPath`` with nothing assumed about M (``factored=False``): the element split over chunks of ``layers`` element
     layers -- M materialised chunk by chunk, A handed out in row blocks, the planes at a chunk's top carried and added, the rows
@@ -319,3 +320,46 @@ def test_streamed_element_chunks_in_the_slab_engine(monkeypatch, d, p, nels, lay
     K2 = eng.assemble(lambda r0, r1: a_rows(r0, r1, bad), None, None, 1.0, {})[0].to_scipy()
     ref2 = Ms.T @ bad @ Ms
     assert abs(K2 - ref2).max() <= 1e-12 * abs(ref2).max()
+
+
+def test_several_fields_on_element_chunks(monkeypatch):
+    """Three fields on one basis (elasticity, tIGAr/common.py:1891-1914) with the operator kept implicit and NOTHING assumed about
+    M or A in the product (``TIGAR_PTAP_FACTORED=0``): every field block (f, g) = M_s^T A_fg M_s runs through the element chunks
+    of the scalar engine (``dist.FieldSlabPath`` -> ``SlabHotPath._assemble_by_elements``), the blocks are interleaved plane by
+    plane.  Against the resident path's K; an explicit scipy A takes the same way."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import gpu_rank_worker_fields as W
+    from tigar_amd import common as tc, dist
+    gen, spline, K, rhs, method = W.problem("elasticity3d", tc.selfcomm)
+    Kref = K.to_scipy().tocsr()
+    monkeypatch.setenv("TIGAR_IMPLICIT_M", "1")
+    monkeypatch.setenv("TIGAR_PTAP_FACTORED", "0")
+    monkeypatch.setenv("TIGAR_PTAP_TENSOR", "0")
+    monkeypatch.setenv("TIGAR_PTAP_ELEMENTS", "2")
+    monkeypatch.setenv("TIGAR_ELEM_LAYERS", "2")
+    calls = []
+    orig = dist.SlabHotPath._assemble_by_elements
+
+    def spy(self, *a, **k):
+        out = orig(self, *a, **k)
+        calls.append(out is not None)
+        return out
+    monkeypatch.setattr(dist.SlabHotPath, "_assemble_by_elements", spy)
+    gen2, spline2, K2, rhs2, _ = W.problem("elasticity3d", tc.selfcomm)
+    assert getattr(gen2.M, "is_implicit", False)
+    assert len(calls) == 9 and all(calls)                    # nine field blocks, each on the element chunks
+    dofs = spline2.localDofIndices()
+    n2o = spline2._slab_path().new_of_old()
+    n = Kref.shape[0]
+    old_of_new = np.empty(n, dtype=np.int64)
+    old_of_new[n2o] = np.arange(n)
+    Kr = Kref[dofs][:, old_of_new].tocsr()
+    K2s = K2.to_scipy().tocsr()
+    assert abs(K2s - Kr).max() <= 1e-12 * abs(Kref).max()
+    from tigar_amd import forms as F
+    A3 = F.ElasticityForm(2.0, 1.0).assemble_matrix(spline.V).to_scipy()
+    K3 = spline2.extractMatrix(A3, diag=1.5).to_scipy().tocsr()
+    assert abs(K3 - Kr).max() <= 1e-12 * abs(Kref).max()

@@ -1698,7 +1698,7 @@ class ExtractedSpline(object):
 
     def _extract_matrix_by_elements(self, A, zd, diag):
         """M^T A M by the element-split cell-block product, or None when it does not apply: one field on one mesh whose cells
-        hold at most 64 nodes (the cells' node lists are the dofmap of ``self.V``), a system large enough for the plan to pay
+        hold at most 125 nodes (the cells' node lists are the dofmap of ``self.V``), a system large enough for the plan to pay
         (``TIGAR_PTAP_ELEMENTS=2``: any size), every entry of A between nodes of a common cell (any assembled FE matrix;
         others fall through to the general kernels)"""
         grids = getattr(getattr(self, "V", None), "grids", None)
@@ -1720,7 +1720,7 @@ class ExtractedSpline(object):
         if not grids or (M.shape[0] < 20000 and os.environ.get("TIGAR_PTAP_ELEMENTS", "1") != "2"):
             return None
         g = grids[0]
-        if (int(g.degree) + 1) ** g.dim() > 64 or int(g.degree) < 1 or getattr(g, "dg", False) or g.num_nodes() != M.shape[0]:
+        if (int(g.degree) + 1) ** g.dim() > 125 or int(g.degree) < 1 or getattr(g, "dg", False) or g.num_nodes() != M.shape[0]:
             return None
         from .elemptap import ElementSplitPtAP, CellNodes
         try:

@@ -789,6 +789,93 @@ __global__ void __launch_bounds__(256, 2)          // (two workgroups per CU: on
   }
 }
 
+// ---- cells of more than 64 nodes (3-D p = 4: 125 nodes, 125 functions): A_c and M_c do not fit the LDS together -------------------
+// M_c stays (126 doubles per row), A_c goes through in panels of 16 rows: T_p = A_p M_c (16 x S) through LDS, then
+// E += M_p^T T_p with ALL of E in registers (S^2 / 256 = 64 doubles per lane: 16 tiles of 16 x 16 per wave).  One workgroup per
+// CU (158 KB of LDS).  S <= 126.
+#define EL_BIG_MS 126
+__global__ void __launch_bounds__(256)
+    k_el_dense_big(double *__restrict__ blocks, int S, int64_t nown, const int32_t *__restrict__ cn, int64_t own0, int b,
+                   const int64_t *__restrict__ mrowptr, const int32_t *__restrict__ mcol, const double *__restrict__ mval,
+                   int64_t m_row0, const int32_t *__restrict__ fl, const int32_t *__restrict__ nf) {
+  extern __shared__ __attribute__((aligned(16))) double el_dsm[];
+  double *Ms = el_dsm;                          // [128][EL_BIG_MS]  M_c [node][function], zero-padded
+  double *Ap = Ms + 128 * EL_BIG_MS;            // [16][129]         the panel of A_c [row][q]
+  double *Tp = Ap + 16 * 129;                   // [16][128]         T_p [row][s]
+  int32_t *fls = reinterpret_cast<int32_t *>(Tp);   // (the cell's function list: needed only while M_c is gathered)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+  for (int64_t c = tg_xcd_block(blockIdx.x, gridDim.x); c < nown; c += gridDim.x) {
+    const int nfc = nf[c];
+    double *blk = blocks + c * (int64_t)S * S;
+    __syncthreads();
+    if (tid < EL_FLS) fls[tid] = tid < nfc ? fl[c * EL_FLS + tid] : EL_INF;
+    for (int t = tid; t < 128 * EL_BIG_MS; t += 256) Ms[t] = 0.0;
+    __syncthreads();
+    for (int i = tid >> 2; i < b; i += 64) {
+      const int64_t r = cn[(own0 + c) * b + i] - m_row0;
+      for (int64_t e = mrowptr[r] + (tid & 3); e < mrowptr[r + 1]; e += 4) {
+        const int32_t col = mcol[e];
+        int lo = 0, hi = nfc;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (fls[mid] < col) lo = mid + 1; else hi = mid;
+        }
+        Ms[i * EL_BIG_MS + lo] = mval[e];
+      }
+    }
+    el_v4d acc[2][8];          // E tiles (q tile 2 wave + u, s tile n)
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int n = 0; n < 8; n++) acc[u][n] = (el_v4d){0.0, 0.0, 0.0, 0.0};
+    for (int p0 = 0; p0 < b; p0 += 16) {
+      __syncthreads();                       // (M_c is complete / the last panel is done with)
+      for (int t = tid; t < 16 * 128; t += 256) {
+        const int i = t >> 7, j = t & 127;
+        Ap[i * 129 + j] = (p0 + i < S && j < S) ? blk[(int64_t)(p0 + i) * S + j] : 0.0;
+      }
+      __syncthreads();
+      // T_p = A_p M_c: wave w the column tiles 2 w, 2 w + 1
+      el_v4d tt[2] = {(el_v4d){0.0, 0.0, 0.0, 0.0}, (el_v4d){0.0, 0.0, 0.0, 0.0}};
+#pragma unroll 4
+      for (int k4 = 0; k4 < 32; k4++) {
+        const double a = Ap[lr * 129 + 4 * k4 + lk];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+          tt[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ms[(4 * k4 + lk) * EL_BIG_MS + 16 * (2 * wave + u) + lr], tt[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) Tp[(lk + 4 * i) * 128 + 16 * (2 * wave + u) + lr] = tt[u][i];
+      __syncthreads();
+      // E += M_p^T T_p: the q tiles 2 w, 2 w + 1, all s tiles
+#pragma unroll
+      for (int k4 = 0; k4 < 4; k4++) {
+        double a2[2], b8[8];
+#pragma unroll
+        for (int u = 0; u < 2; u++) a2[u] = Ms[(p0 + 4 * k4 + lk) * EL_BIG_MS + 16 * (2 * wave + u) + lr];
+#pragma unroll
+        for (int n = 0; n < 8; n++) b8[n] = Tp[(4 * k4 + lk) * 128 + 16 * n + lr];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+          for (int n = 0; n < 8; n++) acc[u][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[u], b8[n], acc[u][n], 0, 0, 0);
+      }
+    }
+    __syncthreads();                         // (every panel of A_c has been read: E goes over it)
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int n = 0; n < 8; n++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int q = 16 * (2 * wave + u) + lk + 4 * i, sidx = 16 * n + lr;
+          if (q < nfc && sidx < nfc) blk[(int64_t)q * S + sidx] = acc[u][n][i];
+        }
+  }
+}
+
 // ---- rows of K: pattern and places ------------------------------------------------------------------------------------------
 // One wave per function i (row dof0 + i of K).  The function lists of the cells that hold i are staged in LDS (row x of LD
 // words = list of the x-th incident element row); lane x walks list x (and x + 64).  Every step takes the smallest head
@@ -1487,9 +1574,14 @@ extern "C" int tg_elemplan_ptap(tg_elemplan_t pl, tg_csr_t a, int64_t a_row0, in
       if (valu) EL_DENSE(k_el_dense<4>); else EL_DENSE_MFMA(3);
     } else if (S <= 64) {
       if (valu) EL_DENSE(k_el_dense<4>); else EL_DENSE_MFMA(4);
+    } else if (S <= EL_BIG_MS) {   // (3-D p = 4: 125 nodes; one workgroup per CU)
+      const size_t lds = (size_t)(128 * EL_BIG_MS + 16 * 129 + 16 * 128) * sizeof(double);
+      hipFuncSetAttribute((const void *)k_el_dense_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(k_el_dense_big, dim3(el_grid8(std::min<int64_t>(nown, (int64_t)g_tg.num_cu * 8))), dim3(256), lds, g_tg.stream, blocks, S,
+                         nown, pl->cells->nodes, pl->own0, pl->b, pl->m->rowptr, pl->m->col, pl->m->val, pl->m_row0, pl->fl, pl->nf);
     } else {
       cleanup();
-      return 100;                 // (cells of more than 64 nodes / functions: not yet)
+      return 100;                 // (cells of more than 126 nodes / functions)
     }
 #undef EL_DENSE
 #undef EL_DENSE_MFMA

@@ -435,7 +435,7 @@ class SlabHotPath(object):
         dev, lay, grid = self.dev, self.layout, self.grid
         from .elemptap import CellNodes, ElementChunk
         d, q = grid.dim(), int(grid.degree)
-        if getattr(grid, "dg", False) or q < 1 or (q + 1) ** d > 64 or lay.q != q:
+        if getattr(grid, "dg", False) or q < 1 or (q + 1) ** d > 125 or lay.q != q:
             return None
         t = timers if timers is not None else {}
 
