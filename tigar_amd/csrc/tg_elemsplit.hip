@@ -57,6 +57,7 @@ struct tg_elemplan_s {
   int64_t node0 = 0, nnode = 0;
   int64_t *nptr = nullptr;       // [nnode + 1]
   int32_t *nlist = nullptr;      // (cell << 7 | pos), ascending per node
+  int32_t *nfix = nullptr;       // [nnode][8] the same as a table, when no node lies in more than 8 cells
   int32_t *fl = nullptr, *nf = nullptr;   // own cells: [nown][EL_FLS], [nown]
   uint8_t *mpos = nullptr;                // [nown][b][64]: position in the cell's list of the first 64 entries of every node's row
                                           // of M, entry e at byte (e % 4) * 16 + e / 4 (the 16 entries a thread gathers are adjacent)
@@ -300,8 +301,10 @@ __global__ void __launch_bounds__(256) k_el_node_fill(const int32_t *__restrict_
 __global__ void __launch_bounds__(256)
     k_el_node_sort(const int64_t *__restrict__ nptr, int64_t nnode, int32_t *__restrict__ nlist, int *__restrict__ bad) {
   const int64_t stride = (int64_t)gridDim.x * 256;
+  int longest = 0;
   for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nnode; n += stride) {
     const int64_t a = nptr[n], e = nptr[n + 1];
+    longest = max(longest, (int)(e - a));
     for (int64_t i = a + 1; i < e; i++) {
       const int32_t v = nlist[i];
       int64_t j = i - 1;
@@ -314,6 +317,8 @@ __global__ void __launch_bounds__(256)
     for (int64_t i = a + 1; i < e; i++)
       if ((nlist[i] >> EL_POSBITS) == (nlist[i - 1] >> EL_POSBITS)) atomicOr(bad, 1);
   }
+  for (int o = 32; o > 0; o >>= 1) longest = max(longest, __shfl_xor(longest, o, 64));
+  if ((threadIdx.x & 63) == 0) el_stat_max(bad - 1, longest);          // (stats[2]: the longest list of a node)
 }
 
 // ---- function lists of the own cells: union of the columns of the rows of M of the cell's nodes ------------------------
@@ -562,6 +567,100 @@ __global__ void __launch_bounds__(256)
   if (threadIdx.x < 3) {
     const unsigned long long t = tot[0][threadIdx.x] + tot[1][threadIdx.x] + tot[2][threadIdx.x] + tot[3][threadIdx.x];
     if (t) atomicAdd(counters + threadIdx.x, t);
+  }
+}
+
+// The same pass when no node lies in more than 8 cells (every hexahedral / quadrilateral mesh): the cells of a node sit in a table
+// of 8 entries per node (-1 = none), read with two 16-byte loads at an address that follows from the column index alone -- one
+// dependent load less per entry than row pointer + list -- and the row's own cells are scalars; two entries per lane in flight.
+__global__ void __launch_bounds__(256)
+    k_el_scatter8(const int64_t *__restrict__ arowptr, const int32_t *__restrict__ acol, const double *__restrict__ aval,
+                  int64_t a_nrows, int64_t a_row0, int64_t node0, int64_t nnode, const int32_t *__restrict__ nfix, int64_t own0,
+                  int64_t own1, int S, int64_t check0, int64_t check1, double *__restrict__ blocks,
+                  unsigned long long *__restrict__ counters) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  constexpr int PM = (1 << EL_POSBITS) - 1;
+  unsigned long long n_own = 0, n_foreign = 0, n_unc = 0;
+  for (int64_t row = tg_xcd_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6); row < a_nrows; row += nw) {
+    const int64_t r = a_row0 + row, rn = r - node0;
+    const int64_t e0 = arowptr[row], e1 = arowptr[row + 1];
+    const bool checked = r >= check0 && r < check1;
+    if (rn < 0 || rn >= nnode) {
+      if (checked && lane == 0) n_unc += (unsigned long long)(e1 - e0);
+      continue;
+    }
+    int rs[8];
+    {
+      const int4 *rp = reinterpret_cast<const int4 *>(nfix + rn * 8);
+      const int4 ra = rp[0], rb = rp[1];
+      rs[0] = __builtin_amdgcn_readfirstlane(ra.x), rs[1] = __builtin_amdgcn_readfirstlane(ra.y);
+      rs[2] = __builtin_amdgcn_readfirstlane(ra.z), rs[3] = __builtin_amdgcn_readfirstlane(ra.w);
+      rs[4] = __builtin_amdgcn_readfirstlane(rb.x), rs[5] = __builtin_amdgcn_readfirstlane(rb.y);
+      rs[6] = __builtin_amdgcn_readfirstlane(rb.z), rs[7] = __builtin_amdgcn_readfirstlane(rb.w);
+    }
+    // the lowest common cell of r and s: the first entry of the (ascending) list of s whose cell is one of r's
+    auto owner = [&](const int4 &sa, const int4 &sb, int &fj) -> int {
+      const int sl[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+      int found = -1;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int cs = sl[k] >> EL_POSBITS;
+        int hit = -1;
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+          if (rs[x] >= 0 && (rs[x] >> EL_POSBITS) == cs) hit = rs[x];
+        if (found < 0 && sl[k] >= 0 && hit >= 0) found = hit, fj = sl[k] & PM;
+      }
+      return found;
+    };
+    auto put = [&](int found, int fj, int64_t e, bool valid) {
+      if (!valid) return;
+      if (found >= 0) {
+        const int64_t c = found >> EL_POSBITS;
+        if (c >= own0 && c < own1) {
+          blocks[((c - own0) * S + (found & PM)) * (int64_t)S + fj] = aval[e];
+          n_own++;
+        } else
+          n_foreign++;
+      } else if (checked)
+        n_unc++;
+    };
+    for (int64_t e = e0 + lane; e < e1; e += 128) {
+      const bool v1 = e + 64 < e1;
+      const int64_t s0 = (int64_t)acol[e] - node0, s1 = v1 ? (int64_t)acol[e + 64] - node0 : -1;
+      const bool in0 = s0 >= 0 && s0 < nnode, in1 = s1 >= 0 && s1 < nnode;
+      const int4 *q0 = reinterpret_cast<const int4 *>(nfix + (in0 ? s0 : 0) * 8), *q1 = reinterpret_cast<const int4 *>(nfix + (in1 ? s1 : 0) * 8);
+      const int4 a0 = q0[0], b0 = q0[1], a1 = q1[0], b1 = q1[1];
+      int j0 = 0, j1 = 0;
+      const int f0 = in0 ? owner(a0, b0, j0) : -1, f1 = in1 ? owner(a1, b1, j1) : -1;
+      put(f0, j0, e, true);
+      put(f1, j1, e + 64, v1);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    n_own += __shfl_xor(n_own, o, 64);
+    n_foreign += __shfl_xor(n_foreign, o, 64);
+    n_unc += __shfl_xor(n_unc, o, 64);
+  }
+  __shared__ unsigned long long tot[4][3];
+  if (lane == 0) tot[threadIdx.x >> 6][0] = n_own, tot[threadIdx.x >> 6][1] = n_foreign, tot[threadIdx.x >> 6][2] = n_unc;
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const unsigned long long t = tot[0][threadIdx.x] + tot[1][threadIdx.x] + tot[2][threadIdx.x] + tot[3][threadIdx.x];
+    if (t) atomicAdd(counters + threadIdx.x, t);
+  }
+}
+
+// [nnode][8] table of the nodes' cells from the lists (only when no list is longer than 8)
+__global__ void __launch_bounds__(256)
+    k_el_node_fix(const int64_t *__restrict__ nptr, const int32_t *__restrict__ nlist, int64_t nnode, int32_t *__restrict__ nfix) {
+  const int64_t stride = (int64_t)gridDim.x * 256, total = nnode * 8;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+    const int64_t n = t >> 3;
+    const int k = (int)(t & 7);
+    const int64_t a = nptr[n];
+    nfix[t] = a + k < nptr[n + 1] ? nlist[a + k] : -1;
   }
 }
 
@@ -1227,6 +1326,7 @@ extern "C" int tg_elemplan_destroy(tg_elemplan_t pl) {
     hipStreamSynchronize(g_tg.stream);
     tg_dfree(pl->nptr);
     tg_dfree(pl->nlist);
+    tg_dfree(pl->nfix);
     tg_dfree(pl->fl);
     tg_dfree(pl->nf);
     tg_dfree(pl->mpos);
@@ -1296,16 +1396,22 @@ extern "C" int tg_elemplan_create(tg_cells_t cells, int64_t own0, int64_t own1, 
   rc = tg_dmalloc(&pl->fl, nown * EL_FLS) || tg_dmalloc(&pl->nf, nown) || tg_dmalloc(&pl->mpos, nown * cells->b * 64 + 64);
   if (rc) return fail(rc);
   {
-    // longest row of M: the stride of the staged rows (a row of more than EL_FLS entries cannot be part of a cell's list)
-    hipMemsetAsync(st + 2, 0, sizeof(int), g_tg.stream);
-    hipLaunchKernelGGL(k_el_maxrow, dim3(tg_grid_1d(m->nrows, 256)), dim3(256), 0, g_tg.stream, m->rowptr, m->nrows, st + 2);
-    int hmax = 0;
-    if (hipMemcpyAsync(&hmax, st + 2, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
+    // longest row of M: the stride of the staged rows (a row of more than EL_FLS entries cannot be part of a cell's list); with
+    // it comes the longest node -> cells list (k_el_node_sort): up to 8, the lists are also kept as a table (k_el_scatter8)
+    hipMemsetAsync(st + 1, 0, sizeof(int), g_tg.stream);
+    hipLaunchKernelGGL(k_el_maxrow, dim3(tg_grid_1d(m->nrows, 256)), dim3(256), 0, g_tg.stream, m->rowptr, m->nrows, st + 1);
+    int hmax = 0, hnode = 0;
+    if (hipMemcpyAsync(&hmax, st + 1, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
+        hipMemcpyAsync(&hnode, st + 2, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
         hipStreamSynchronize(g_tg.stream) != hipSuccess) {
       tg_set_error("tg_elemplan_create: the row-length kernel failed to run");
       return fail(1);
     }
-    hipMemsetAsync(st + 2, 0, sizeof(int), g_tg.stream);
+    if (hnode <= 8 && !getenv("TIGAR_EL_LISTS")) {
+      rc = tg_dmalloc(&pl->nfix, pl->nnode * 8 + 16);
+      if (rc) return fail(rc);
+      hipLaunchKernelGGL(k_el_node_fix, dim3(tg_grid_1d(pl->nnode * 8, 256)), dim3(256), 0, g_tg.stream, pl->nptr, pl->nlist, pl->nnode, pl->nfix);
+    }
     const int LD = std::min(hmax, EL_FLS) + 1;
     const bool two = cells->b > 64;
     const int wave_words = (two ? 128 : 64) * LD + EL_FLS;
@@ -1540,7 +1646,11 @@ extern "C" int tg_elemplan_ptap(tg_elemplan_t pl, tg_csr_t a, int64_t a_row0, in
   unsigned long long *counters = (unsigned long long *)(g_tg.scratch + 8), hc[4];
   hipMemsetAsync(blocks, 0, (size_t)(nown * (int64_t)S * S) * sizeof(double), g_tg.stream);
   hipMemsetAsync(counters, 0, sizeof(hc), g_tg.stream);
-  if (a->nrows > 0)
+  if (a->nrows > 0 && pl->nfix)
+    hipLaunchKernelGGL(k_el_scatter8, dim3(el_grid8(std::min<int64_t>(tg_cdiv(a->nrows, 4), (int64_t)g_tg.num_cu * 32))), dim3(256), 0,
+                       g_tg.stream, a->rowptr, a->col, a->val, a->nrows, a_row0, pl->node0, pl->nnode, pl->nfix, pl->own0, pl->own1, S, check_row0,
+                       check_row1, blocks, counters);
+  else if (a->nrows > 0)
     hipLaunchKernelGGL(k_el_scatter, dim3(el_grid8(std::min<int64_t>(tg_cdiv(a->nrows, 4), (int64_t)g_tg.num_cu * 32))), dim3(256), 0,
                        g_tg.stream, a->rowptr, a->col, a->val, a->nrows, a_row0, pl->node0, pl->nnode, pl->nptr, pl->nlist, pl->own0, pl->own1,
                        S, check_row0, check_row1, blocks, counters);
