@@ -38,7 +38,7 @@ class GlooTransport(Transport):
     def barrier(self):
         self.dist.barrier()
 
-    def sendrecv(self, peer, send, recv):
+    def sendrecv(self, peer, send, recv, tag=0):
         reqs = []
         if send is not None and len(send):
             reqs.append(self.dist.isend(self.torch.from_numpy(np.ascontiguousarray(send)), peer))

@@ -245,28 +245,55 @@ def test_chebyshev_cg_on_the_half_storage_copy(dev, monkeypatch):
 
 
 def test_matrices_of_symmetric_forms_skip_the_comparison_with_the_csr_product(dev, monkeypatch):
-    """``assembleMatrix`` of a form that is symmetric by construction marks K; the CG solve then passes TG_KSP_SYMMETRIC and
-    the half-storage copy is built without the check against the CSR product (its rows are still checked one by one against
-    the box stencil).  The flag is the caller's word, as with KSPCG: a matrix that is NOT symmetric is accepted with it and
-    declined without it -- which is why only this package's own symmetric forms set it."""
+    """``assembleMatrix`` marks K when its symmetry is PROVED: the form says a(u, v) = a(v, u) for its own class (an instance
+    attribute: a subclass that adds terms does not inherit it) and A is a Kronecker sum whose 1-D terms are checked
+    to be symmetric.  The CG solve then passes TG_KSP_SYMMETRIC and the half-storage copy is built without the check against the
+    CSR product (its rows are still checked one by one against the box stencil).  Every other matrix is compared ONCE: the
+    result stays on the matrix -- a second solve does not compare again, a matrix that failed is not tried again.  The flag
+    itself is the caller's word, as with KSPCG: a matrix that is NOT symmetric is accepted with it."""
     import tigar_amd as t
     from tigar_amd.device import DeviceVector
+    from tigar_amd import forms as F, common as tc
     spline, K, rhs = _poisson3d(2, (40, 40, 40))
     assert K.symmetric_by_construction is True
-    from tigar_amd import forms as F
     K2 = spline.extractMatrix(F.LaplaceForm().assemble_matrix(spline.V))          # a matrix handed over: no mark
     assert not getattr(K2, "symmetric_by_construction", False)
+
+    class Convected(F.LaplaceForm):                                               # a subclass: the mark is not inherited
+        pass
+    assert F.LaplaceForm().symmetric is True and Convected().symmetric is False
+    assert not getattr(spline.assembleMatrix(Convected()), "symmetric_by_construction", False)
+    # the proof looks at the 1-D factors: symmetric terms, or terms that come with their transposes
+    Cx = sp.random(9, 9, 0.4, random_state=1, format="csr")
+    Sx = (Cx + Cx.T).tocsr()
+    assert tc._kron_sum_is_symmetric([[Sx, Sx]]) and tc._kron_sum_is_symmetric([[Cx.T.tocsr(), Cx], [Cx, Cx.T.tocsr()], [Sx, Sx]])
+    assert not tc._kron_sum_is_symmetric([[Cx, Sx]]) and not tc._kron_sum_is_symmetric([[Cx.T.tocsr(), Cx], [Sx, Sx]])
+    assert not tc._kron_sum_is_symmetric(None)
     monkeypatch.setenv("TIGAR_KSP_PERSISTENT", "0")
     monkeypatch.setenv("TIGAR_SPMV_SYM", "2")
     rng = np.random.default_rng(4)
     A = _box_stencil(rng, (24, 20, 12), 2, symmetric=False)
     A = (A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + 1.0)).tocsr()
     A.sort_indices()
-    dA, b = dev.DeviceCSR.from_scipy(A), DeviceVector(data=rng.standard_normal(A.shape[0]))
+    b = DeviceVector(data=rng.standard_normal(A.shape[0]))
     for hint, used in ((False, 0), (True, 1)):
+        dA = dev.DeviceCSR.from_scipy(A)
         c0 = dev.prof_get(7)[1]
         dev.krylov_solve(dA, b, DeviceVector(A.shape[0]), "cg", "jacobi", 1e-8, 1e-300, 20, 30, symmetric=hint)
         assert dev.prof_get(7)[1] - c0 == used
+        if not hint:
+            # compared once and found wanting: declined from now on, whatever the caller says
+            dev.krylov_solve(dA, b, DeviceVector(A.shape[0]), "cg", "jacobi", 1e-8, 1e-300, 20, 30, symmetric=True)
+            assert dev.prof_get(7)[1] - c0 == 0
+    # a symmetric matrix handed in: compared at the first solve, not at the second (TIGAR_TRACE prints the comparison)
+    As = _box_stencil(rng, (24, 20, 12), 2, symmetric=True)
+    As = (As + sp.diags(np.asarray(abs(As).sum(axis=1)).ravel() + 1.0)).tocsr()
+    As.sort_indices()
+    dS = dev.DeviceCSR.from_scipy(As)
+    for _ in range(2):
+        c0 = dev.prof_get(7)[1]
+        dev.krylov_solve(dS, b, DeviceVector(As.shape[0]), "cg", "jacobi", 1e-8, 1e-300, 20, 30)
+        assert dev.prof_get(7)[1] - c0 == 1
 
 
 def test_small_systems_and_other_solvers_keep_their_kernels(dev, monkeypatch):

@@ -215,6 +215,36 @@ def _knot_mesh_arrays(g):
     return X, base[:, None] + corners[None, :]
 
 
+def _kron_sum_is_symmetric(factors):
+    """True when sum_t kron(F_t[d-1], ..., F_t[0]) is symmetric because of its 1-D factors: every term is a product of
+    symmetric matrices, or its transpose (factor by factor) is another term of the sum (C^T x C + C x C^T).  1-D matrices:
+    a few thousand entries, compared on the host."""
+    if not factors:
+        return False
+    try:
+        import scipy.sparse as _sp
+        terms = [[_sp.csr_matrix(F) for F in t] for t in factors]
+
+        def same(A, B):
+            if A.shape != B.shape:
+                return False
+            D = abs(A - B)
+            return (D.max() if D.nnz else 0.0) <= 1e-13 * max(abs(A).max() if A.nnz else 0.0, 1e-300)
+        left = list(range(len(terms)))
+        while left:
+            t = left.pop(0)
+            if all(same(F, F.T.tocsr()) for F in terms[t]):
+                continue
+            mate = next((u for u in left if len(terms[u]) == len(terms[t]) and
+                         all(same(G, F.T.tocsr()) for F, G in zip(terms[t], terms[u]))), None)
+            if mate is None:
+                return False
+            left.remove(mate)
+        return True
+    except Exception:
+        return False
+
+
 def _cell_dofs_arrays(g):
     """[ncells, (p+1)^d] node numbers of every knot-mesh cell, in this package's numbering (direction 0 fastest; a dolfin
     ``FunctionSpace`` on the same mesh numbers them its own way, which cannot be reproduced without dolfin)."""
@@ -312,6 +342,12 @@ class Function(object):
         if epoch is not None:
             self.__dict__["_ghost_cache"] = (epoch, self._vec, g)
         return g
+
+    def invalidate_ghosts(self):
+        """Forget the ghost rows fetched for the current assembly: call after changing the coefficients in place outside the
+        drivers (``vector().axpy`` / ``set_local``) when a form, functional or error norm reads the function next --
+        ``solveLinearSystem`` and the Newton update do it themselves."""
+        self.__dict__.pop("_ghost_cache", None)
 
     def function_space(self):
         return self.V
@@ -1548,7 +1584,7 @@ class ExtractedSpline(object):
         already assembled FE vector (tIGAr/common.py:1162-1173).  With several ranks the form is
         asked for the FE rows each rank needs (``assemble_vector(V, row0, row1)``)."""
         if not self.__dict__.get("_in_system"):
-            self._ghost_epoch = self.__dict__.get("_ghost_epoch", 0) + 1
+            self._new_ghost_epoch()
         if hasattr(form, "assemble_vector"):
             if self._distributed():
                 from .implicit import LazyFEVector
@@ -1898,7 +1934,7 @@ class ExtractedSpline(object):
         M: cfg3's A is 684 GB) or the patch is spread over several ranks, the form is asked for row blocks
         (``assemble_matrix(V, row0, row1)``) as the z-slab pipeline consumes them."""
         if not self.__dict__.get("_in_system"):
-            self._ghost_epoch = self.__dict__.get("_ghost_epoch", 0) + 1
+            self._new_ghost_epoch()
         if hasattr(form, "assemble_matrix"):
             if self._implicit() or self._distributed():
                 from .implicit import LazyFEMatrix
@@ -1916,15 +1952,21 @@ class ExtractedSpline(object):
         else:
             A = form
         K = self.extractMatrix(A, applyBCs=applyBCs, diag=diag)
-        if getattr(form, "symmetric", False) and isinstance(K, DeviceCSR):
-            # M^T A M of a symmetric A with MatZeroRowsColumns: symmetric (to rounding); a NEW object after every change of
-            # the values but zero_rows_cols (DeviceCSR has no other in-place operation)
+        proof = None
+        if getattr(form, "symmetric", False) is True and isinstance(K, DeviceCSR) and self.nFields == 1 and \
+                hasattr(form, "factors") and getattr(form, "geometry", None) is None:
+            proof = getattr(A, "kron_factors", None) or form.factors(self.V)      # (what A was formed from, either way)
+        if proof is not None and _kron_sum_is_symmetric(proof):
+            # PROVED symmetric: A is a Kronecker sum whose terms are (checked here, on the 1-D matrices) symmetric or come with
+            # their transposes, so M^T A M with MatZeroRowsColumns is symmetric to rounding.  Then the solver builds its
+            # half-storage copy without comparing it with the CSR product (TG_KSP_SYMMETRIC).  Every other K -- mapped forms,
+            # matrices handed in, subclasses of the forms -- is compared once (the result is kept on the matrix).
             K.symmetric_by_construction = True
         return K
 
     def assembleLinearSystem(self, lhsForm, rhsForm, applyBCs=True):
         # one ghost update of the rank-local functions the forms read serves both assemblies (Function.ghosted)
-        self._ghost_epoch = self.__dict__.get("_ghost_epoch", 0) + 1
+        self._new_ghost_epoch()
         self._in_system = True
         try:
             return (self.assembleMatrix(lhsForm, applyBCs), self.assembleVector(rhsForm, applyBCs))
@@ -1957,15 +1999,37 @@ class ExtractedSpline(object):
             u._vec, u.local_range = u_loc, self._slab_path().mine["u_rows"]
         else:
             self.M.mult(MTU, _as_device_vector(u))
+        if hasattr(u, "invalidate_ghosts"):
+            u.invalidate_ghosts()              # (new coefficients: ghost rows fetched before are stale)
         return MTU
 
     # -- rank-local FE functions (tIGAr/common.py:1304-1348 runs on distributed PETSc vectors with ghost updates)
+    def _register_ghosted(self, f):
+        """``f`` is a rank-local Function whose ghost rows this spline fetches (weak reference, in registration order)"""
+        import weakref
+        f._ghoster = self.ghostedVector
+        regs = self.__dict__.setdefault("_ghost_functions", [])
+        regs[:] = [r for r in regs if r() is not None]
+        if not any(r() is f for r in regs):
+            regs.append(weakref.ref(f))
+
+    def _new_ghost_epoch(self):
+        """A new assembly: the ghost rows of every registered rank-local function are fetched NOW, by every rank -- also one
+        whose slab holds no row block and whose forms therefore never ask (its neighbours would wait for it until the
+        transport's time-out) -- and kept for the assembly (``Function.ghosted``)."""
+        self._ghost_epoch = self.__dict__.get("_ghost_epoch", 0) + 1
+        if self._distributed():
+            for r in list(self.__dict__.get("_ghost_functions", [])):
+                f = r()
+                if f is not None and f.local_range is not None:
+                    f.ghosted()
+
     def localFunction(self, u=None):
         """A Function that holds the FE rows this rank owns (``localFERange()``): a fresh one, or the rows of ``u`` cut out
         of a replicated full-length Function / vector.  The form objects read it through ``Function.ghosted()``."""
         rng = self.localFERange()
         f = Function(self.V, rng if self._distributed() else None)
-        f._ghoster = self.ghostedVector
+        self._register_ghosted(f)
         if u is not None:
             src = _as_device_vector(u)
             if src.size() == f.vector().size():
@@ -2123,7 +2187,7 @@ class ExtractedSpline(object):
             if u.local_range is None:
                 loc = self.localFunction(u)          # a replicated Function: every rank keeps its rows
                 u._vec, u.local_range = loc.vector(), loc.local_range
-            u._ghoster = self.ghostedVector
+            self._register_ghosted(u)
             if returningDoFs:
                 u._vec = self._slab_path().prolong(igaDoFs)
         uv = _as_device_vector(u)
@@ -2147,6 +2211,8 @@ class ExtractedSpline(object):
             du = Function(self.V, self.localFERange() if dist else None)
             igaIncrement = self.solveLinearSystem(MTAM, MTb, du)
             uv.axpy(-1.0, du.vector())
+            if hasattr(u, "invalidate_ghosts"):
+                u.invalidate_ghosts()
             if returningDoFs:
                 igaDoFs.axpy(-1.0, igaIncrement)
         if not converged:

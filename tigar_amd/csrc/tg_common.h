@@ -102,6 +102,10 @@ struct tg_csr_s {
   uint64_t pattern_tag = 0;
   int64_t pattern_row0 = 0;
   int sell_state = 0;            // 0 = not tried, 1 = in use, -1 = declined
+  // half-storage product (tg_symgrid.hip): 1 = the copy of THESE values was compared with the CSR product once and agreed
+  // (later solves with the same matrix do not compare again), -1 = it did not (not symmetric: no further attempts), 0 = not
+  // compared yet.  Reset by every function that changes values.
+  int sym_verified = 0;
   // diagonal of a square row block (entry (r, row0 + r)) recorded by the kernel that wrote the values (the z pass of
   // the tensor-pattern PtAP): the Jacobi set-up of the Krylov solvers then needs no pass over the matrix.  Dropped
   // by every function that changes values afterwards.

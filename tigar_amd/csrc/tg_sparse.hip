@@ -1199,6 +1199,7 @@ extern "C" int tg_zero_rows_cols(tg_csr_t k, int64_t row0, const int32_t *dofs, 
   tg_dfree(k->diag_cache);      // values change: a recorded diagonal is stale
   k->diag_cache = nullptr;
   k->diag_rows = 0;
+  k->sym_verified = 0;          // (and so is what was found out about the symmetry of the old values)
   uint8_t *mask = nullptr;
   TG_TRY(tg_build_dof_mask(dofs, n, k->ncols, &mask));
   const unsigned grid = (unsigned)std::min<int64_t>(tg_cdiv(k->nrows, 4), (int64_t)g_tg.num_cu * 16);

@@ -605,6 +605,7 @@ int tg_symgrid_build(tg_csr_s *a, int64_t row0, int verify, tg_symgrid_s **out) 
   const bool trace = getenv("TIGAR_TRACE") != nullptr;
   if (a->rowcnt || a->view || a->nrows < 1024 || a->ncols >= (int64_t)1 << 28 || row0 < 0 || row0 + a->nrows > a->ncols)
     return 0;
+  if (a->sym_verified < 0) return 0;          // (these values failed the comparison before: not symmetric)
   int P = 0, n0 = 0, n1 = 0, n2 = 0;
   bool found = false;
   TG_TRY(sg_detect(a, row0, &P, &n0, &n1, &n2, &found));
@@ -695,7 +696,7 @@ int tg_symgrid_build(tg_csr_s *a, int64_t row0, int verify, tg_symgrid_s **out) 
       declined = true;
       break;
     }
-    if (verify) {
+    if (verify && a->sym_verified != 1) {
       // x on the window of columns the block reads: P planes on either side (as far as the grid goes)
       const int64_t n01 = (int64_t)n0 * n1;
       const int64_t cmin = std::max<int64_t>(0, row0 - P * n01), cmax = std::min<int64_t>(a->ncols, row0 + a->nrows + P * n01) - 1;
@@ -725,9 +726,11 @@ int tg_symgrid_build(tg_csr_s *a, int64_t row0, int verify, tg_symgrid_s **out) 
       if (trace) fprintf(stderr, "[trace] symgrid: check vs CSR product: max |diff| %.3e, max |y| %.3e\n", d, mx);
       if (!(d <= 1e-10 * mx)) {
         if (trace) fprintf(stderr, "[trace] symgrid: the matrix is not symmetric (or the copy is wrong): declined\n");
+        a->sym_verified = -1;
         declined = true;
         break;
       }
+      a->sym_verified = 1;
     }
   } while (0);
   if (rc || declined) {

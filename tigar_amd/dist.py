@@ -150,9 +150,12 @@ class SlabHotPath(object):
 
     With world == 1 and one sub-slab this is exactly the single-GPU path."""
 
-    def __init__(self, basis, grid, rank=0, world=1, comm=None, sub_planes=None, eps=1e-15, factored=None, kx=None, planes=None):
+    def __init__(self, basis, grid, rank=0, world=1, comm=None, sub_planes=None, eps=1e-15, factored=None, kx=None, planes=None,
+                 resident_blocks=1):
         """``planes``: the dof planes [k0, k1) of this rank when they are not the balanced split of the basis' own planes
-        (fields on different bases share one split of the plane index, ``FieldListSlabPath``)"""
+        (fields on different bases share one split of the plane index, ``FieldListSlabPath``); ``resident_blocks``: how many
+        blocks the size of this engine's K stay on the device while it streams (nF x nF field blocks + their stacked copy):
+        ``sub_planes='auto'`` sizes the sub-slabs for what is left"""
         from . import device as dev
         from .kronptap import KronExtraction
         self.dev = dev
@@ -195,6 +198,11 @@ class SlabHotPath(object):
                     pass
             pmax = max(s1.p for s1 in basis.splines)
             nelmax = max(s1.nel for s1 in basis.splines)
+            if resident_blocks > 1:
+                # (K of one block: rows of this rank x (2 p + 1)^d entries of 12 bytes; pick_sub_planes leaves half of what it
+                #  is given to ONE such block already)
+                k_block = (self.k1 - self.k0) * float(self.layout.plane_dofs) * float((2 * pmax + 1) ** basis.nvar) * 12.0
+                free_b = max(free_b - int((resident_blocks - 1) * k_block), free_b // 8)
             sub_planes = pick_sub_planes(basis.nvar, pmax, nelmax, self.k1 - self.k0, free_b)
         self.sub_planes = sub_planes or (self.k1 - self.k0)
         self.mine = self.layout.slab(self.k0, self.k1)
@@ -765,6 +773,28 @@ class SlabHotPath(object):
         return dev.extract_apply_tensor(self.basis.splines, self.grid.axes, 0, self.eps, x, x_col0, r0, r1)
 
 
+def _block_is_empty(a_block, f, g, ar, plane_fe, fac):
+    """Are fields f and g uncoupled on the FE rows [ar[0], ar[1]) of a rank?  The producer says so itself (None), or three node
+    planes of the block -- the first, the middle, the last of the rows -- hold no entry.  (Until round 5 the whole row block of
+    the rank was assembled for this question and thrown away: twice the FE assembly, and in ONE piece the rows the sub-slab
+    pipeline exists to avoid holding at once -- ADVICE r5.  A block of an assembled form is structurally empty or it has
+    entries on every node plane; couplings added by hand come as explicit matrices, whose blocks are cut out, not assembled.)"""
+    r0, r1 = int(ar[0]), int(ar[1])
+    if r1 <= r0:
+        return True
+    if fac is not None:
+        return a_block(f, g, r0, min(r0 + 1, r1)) is None
+    pf = max(1, int(plane_fe))
+    starts = sorted({r0, r0 + ((r1 - r0) // (2 * pf)) * pf, max(r0, r1 - pf)})
+    for q0 in starts:
+        probe = a_block(f, g, q0, min(q0 + pf, r1))
+        if probe is None:
+            return True
+        if probe.nnz:
+            return False
+    return True
+
+
 class FieldSlabPath(object):
     """The z-slab path for ``nfields`` fields on ONE tensor basis (M = diag(M_s, ..., M_s); the reference numbers such dofs
     field after field, tIGAr/common.py:242-252).  A rank owns the dof planes [k0, k1) of EVERY field, so that its rows of
@@ -784,7 +814,7 @@ class FieldSlabPath(object):
         self.dev = dev
         self.nF = int(nfields)
         # the scalar engine never talks to the communicator: the slab of the Krylov vectors is set here, for all fields
-        self.scalar = SlabHotPath(basis, grid, rank, world, None, sub_planes, eps, kx=kx)
+        self.scalar = SlabHotPath(basis, grid, rank, world, None, sub_planes, eps, kx=kx, resident_blocks=2 * self.nF * self.nF)
         self.rank, self.world, self.comm = rank, world, comm
         S = self.scalar
         self.layout = S.layout
@@ -842,13 +872,10 @@ class FieldSlabPath(object):
             row = []
             for g in range(nF):
                 fac = block_factors[f][g] if block_factors is not None else None
-                ar = S.mine["a_rows"]
-                probe = a_block(f, g, ar[0], min(ar[0] + 1, ar[1])) if fac is not None else a_block(f, g, ar[0], ar[1])
-                if probe is None or (fac is None and probe.nnz == 0):
+                if _block_is_empty(a_block, f, g, S.mine["a_rows"], S.layout.plane_fe, fac):
                     # fields f and g are not coupled (on this rank's rows): no entries in this block of the product
                     row.append(dev.DeviceCSR.from_scipy(sp.csr_matrix((nloc1, self.ncp1))))
                     continue
-                del probe
                 S._tensor_declined = False          # (every block is judged on its own pattern)
                 Kfg = S.assemble(lambda r0, r1, f=f, g=g: a_block(f, g, r0, r1), None, None, 1.0, timers, fac)[0]
                 row.append(Kfg)
@@ -934,7 +961,8 @@ class FieldListSlabPath(object):
         self.engines = []
         for f, kx in enumerate(self.kxs):
             k0, k1 = min(self.K0, self.nk[f]), min(self.K1, self.nk[f])
-            self.engines.append(SlabHotPath(kx.basis, kx.grid, rank, world, None, sub_planes, eps, kx=kx, planes=(k0, k1)))
+            self.engines.append(SlabHotPath(kx.basis, kx.grid, rank, world, None, sub_planes, eps, kx=kx, planes=(k0, k1),
+                                            resident_blocks=2 * self.nF * self.nF))
         self.sub_planes = self.engines[0].sub_planes
         H = max(max(s1.p for s1 in kx.basis.splines[-1:]) for kx in self.kxs)
         lo, hi = max(0, self.K0 - H), min(self.Kmax, self.K1 + H)
@@ -1004,15 +1032,9 @@ class FieldListSlabPath(object):
             nloc = (e.k1 - e.k0) * self.pd[f]
             for g in range(nF):
                 fac = block_factors[f][g] if block_factors is not None else None
-                ar = e.mine["a_rows"]
-                empty = e.k1 <= e.k0
-                probe = None
-                if not empty:
-                    probe = a_block(f, g, ar[0], min(ar[0] + 1, ar[1])) if fac is not None else a_block(f, g, ar[0], ar[1])
-                if empty or probe is None or (fac is None and probe.nnz == 0):
+                if e.k1 <= e.k0 or _block_is_empty(a_block, f, g, e.mine["a_rows"], e.layout.plane_fe, fac):
                     row.append(dev.DeviceCSR.from_scipy(sp.csr_matrix((nloc, self.ncp_f[g]))))
                     continue
-                del probe
                 Kfg = e.assemble(lambda r0, r1, f=f, g=g: a_block(f, g, r0, r1), None, None, 1.0, timers, fac, col=self.kxs[g])[0]
                 row.append(Kfg)
             blocks.append(row)

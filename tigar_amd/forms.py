@@ -190,7 +190,8 @@ def _mapped(geometry, V, form, row0=None, row1=None):
         raise ValueError("the geometry lives on a different node grid than the space")
     verts = [g.vertices[k] for k in range(g.dim())]
     n = g.num_nodes()
-    if (row0 is None and row1 is None) or (int(row0), int(row1)) == (0, n):
+    row0, row1 = (0 if row0 is None else int(row0)), (n if row1 is None else int(row1))       # (either may be left out)
+    if (row0, row1) == (0, n):
         cp, node0 = _control_window(geometry, 1, 0, g.shape()[-1])
         if node0 == 0 and all(v.size() == n for v in cp):
             return _dev.assemble_mapped_matrix(verts, g.degree, cp, form)
@@ -207,9 +208,10 @@ class LaplaceForm(object):
     """a(u,v) = int grad u . grad v: on the parametric box (Kronecker sum of 1-D factors), or --
     with ``geometry`` (a generator or ExtractedSpline) -- in physical space on the mapped patch,
     grad and dx as ``spline.grad`` / ``spline.dx`` (tIGAr/common.py:917-945)."""
-    symmetric = True      # a(u, v) = a(v, u): the assembled matrix is symmetric (ExtractedSpline.assembleMatrix marks K)
 
     def __init__(self, geometry=None):
+        # a(u, v) = a(v, u) for THIS class; a subclass that adds terms says so itself (ADVICE r5: not inherited)
+        self.symmetric = type(self) is LaplaceForm
         self.geometry = geometry
 
     def factors(self, V):
@@ -233,9 +235,10 @@ class ElasticityForm(object):
     each a Kronecker sum of 1-D factors (mass M, stiffness K, G[a,b] = int phi_a' phi_b) on the element-coupling pattern,
     written block by block by the Kronecker-sum kernel and put together on the device.  What a dolfin user writes as
     ``inner(sigma(u), eps(v))*dx`` for ``demos``-style linear elasticity on an identity-geometry patch."""
-    symmetric = True      # a(u, v) = a(v, u): the assembled matrix is symmetric (ExtractedSpline.assembleMatrix marks K)
 
     def __init__(self, lmbda=1.0, mu=1.0):
+        # a(u, v) = a(v, u) for THIS class; a subclass that adds terms says so itself (ADVICE r5: not inherited)
+        self.symmetric = type(self) is ElasticityForm
         self.lmbda, self.mu = float(lmbda), float(mu)
 
     def _grid(self, V):
@@ -284,9 +287,10 @@ class ElasticityForm(object):
 
 class MassForm(object):
     """a(u,v) = int u v (``geometry``: see LaplaceForm)."""
-    symmetric = True      # a(u, v) = a(v, u): the assembled matrix is symmetric (ExtractedSpline.assembleMatrix marks K)
 
     def __init__(self, geometry=None):
+        # a(u, v) = a(v, u) for THIS class; a subclass that adds terms says so itself (ADVICE r5: not inherited)
+        self.symmetric = type(self) is MassForm
         self.geometry = geometry
 
     def factors(self, V):
@@ -310,9 +314,18 @@ class NodalLoadForm(object):
     def _nodal_values(self, cp, node0, n_nodes):
         """f on the nodes [node0, node0 + n_nodes) that the control functions ``cp`` are given on"""
         if callable(self.f):
-            c = [v.get_local() for v in cp]
-            x = numpy.stack([c[i] / c[-1] for i in range(len(c) - 1)], axis=1)
-            return _dev.DeviceVector(data=numpy.asarray(self.f(x), dtype=numpy.float64))
+            # f at the physical node positions x = F(node): evaluated on the host (f is the user's Python function), once per
+            # window of control functions -- the sub-slabs of one assembly and the assemblies of a Newton iteration ask for the
+            # same windows again (keyed on the vectors' identity: a new geometry means new control functions)
+            key = (tuple(id(v) for v in cp), int(node0), int(n_nodes))
+            cache = self.__dict__.setdefault("_fnodal", {})
+            if key not in cache:
+                if len(cache) > 64:
+                    cache.clear()
+                c = [v.get_local() for v in cp]
+                x = numpy.stack([c[i] / c[-1] for i in range(len(c) - 1)], axis=1)
+                cache[key] = (_dev.DeviceVector(data=numpy.asarray(self.f(x), dtype=numpy.float64)), cp)   # (cp kept alive: ids)
+            return cache[key][0]
         if numpy.isscalar(self.f):
             fn = _dev.DeviceVector(n_nodes, zero=False)
             fn.fill(float(self.f))
@@ -328,7 +341,8 @@ class NodalLoadForm(object):
         g = _single_grid(V)
         verts = [g.vertices[k] for k in range(g.dim())]
         n = g.num_nodes()
-        if (row0 is None and row1 is None) or (int(row0), int(row1)) == (0, n):
+        row0, row1 = (0 if row0 is None else int(row0)), (n if row1 is None else int(row1))   # (either may be left out)
+        if (row0, row1) == (0, n):
             cp, node0 = _control_window(self.geometry, 1, 0, g.shape()[-1])
             if node0 == 0 and all(v.size() == n for v in cp):
                 return _dev.assemble_mapped_load(verts, g.degree, cp, self._nodal_values(cp, 0, n))
@@ -366,7 +380,10 @@ class SeparableLoadForm(object):
 class BiharmonicForm(object):
     """a(u,v) = int (lap u)(lap v), element-wise (demos/biharmonic/biharmonic.py:100-103), 2-D:
     S2xM + MxS2 + C^T x C + C x C^T with C[a,b] = int phi_a'' phi_b."""
-    symmetric = True      # a(u, v) = a(v, u): the assembled matrix is symmetric (ExtractedSpline.assembleMatrix marks K)
+
+    def __init__(self):
+        # a(u, v) = a(v, u) for THIS class; a subclass that adds terms says so itself (ADVICE r5: not inherited)
+        self.symmetric = type(self) is BiharmonicForm
 
     def factors(self, V):
         g = _single_grid(V)

@@ -49,7 +49,9 @@ class Transport(object):
     def allreduce_max(self, value):
         return value
 
-    def sendrecv(self, peer, send, recv):
+    def sendrecv(self, peer, send, recv, tag=0):
+        """exchange with rank ``peer``: ``send`` (float64 array or None) goes out, ``recv`` (writable float64 array or None) is
+        filled; ``tag`` names the exchange (transports that frame their messages check it on arrival, others ignore it)"""
         raise RuntimeError("sendrecv on a single-rank transport")
 
     def barrier(self):

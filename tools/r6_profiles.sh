@@ -1,0 +1,40 @@
+# round-6 profile set (run on the GPU box through gpurun; results under gpurun_out/r6prof, copied to profiles/ afterwards)
+set -u
+O=gpurun_out/r6prof
+mkdir -p $O
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+W="--no-cpu-baseline --companion 0 --mapped-companion 0 --live-traffic 0"
+stats() { # name cmd...   rocprofv3 --kernel-trace --stats of the command + per-kernel summary of the trace database
+  n=$1; shift
+  rm -rf /tmp/kt_$n; mkdir -p /tmp/kt_$n
+  (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d /tmp/kt_$n -o k --output-format csv -- "$@" > /tmp/kt_$n/log 2>&1)
+  f=$(find /tmp/kt_$n -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $O/r6_${n}_rocprofv3_kernel_stats.csv
+  python tools/kernel_trace.py --sum -- "$@" > $O/r6_${n}_kernel_stats.txt 2>&1
+}
+pmc() { n=$1; shift; timeout 1800 python tools/pmc_hbm.py $O/r6_${n}_pmc_hbm.json -- "$@" > $O/r6_${n}_pmc.log 2>&1; }
+GEN="env TIGAR_PTAP_TENSOR=0 TIGAR_PTAP_FACTORED=0 TIGAR_IMPLICIT_M=1"
+case "${1:-all}" in
+elemsplit)
+  # the general PtAP by element split, resident 64^3 p = 3 (CSR operands; nothing Kronecker used), against the row-wise kernels
+  python tools/elem_ptap_bench.py 3 64 $O/r6_element_split_ptap_64cubed_p3.json 1 > $O/r6_element_split_ptap_64cubed_p3.log 2>&1
+  python tools/elem_ptap_bench.py 3 32 $O/r6_element_split_ptap_32cubed_p3.json 1 > /dev/null 2>&1
+  python tools/elem_ptap_bench.py 2 96 $O/r6_element_split_ptap_96cubed_p2.json 1 > /dev/null 2>&1
+  stats elemsplit python $R/tools/elem_ptap_bench.py 3 64 /dev/null 0
+  pmc elemsplit python $R/tools/elem_ptap_bench.py 3 64 /dev/null 0
+  python tools/pmc_sq.py k_el_ -- python tools/elem_ptap_bench.py 3 64 /dev/null 0 > $O/r6_elemsplit_sq_counters.txt 2>&1
+  ;;
+general)
+  # cfg3's size with NOTHING assumed about M or A: M materialised chunk by chunk, A in row blocks, element chunks
+  $GEN timeout 900 python bench.py --workload cfg3 --steps 3 --warmup 1 $W > $O/r6_bench_cfg3_general_elements.json 2> $O/r6_bench_cfg3_general_elements.log
+  stats cfg3_general $GEN python $R/bench.py --workload cfg3 --steps 2 --warmup 1 $W
+  pmc cfg3_general $GEN python $R/bench.py --workload cfg3 --steps 1 --warmup 1 $W
+  ;;
+headline)
+  timeout 900 python bench.py --steps 10 --warmup 2 > $O/r6_bench_cfg3.json 2> $O/r6_bench_cfg3.log
+  stats cfg3 python $R/bench.py --steps 5 --warmup 1 $W
+  pmc cfg3 python $R/bench.py --steps 2 --warmup 1 $W
+  ;;
+esac
+ls $O | head -60
