@@ -393,12 +393,14 @@ def run(args, wl, d, p, nel):
     stage_names = sorted(mean_stages)
     per_rank = None
     if world > 1:
-        tab = np.zeros((world, len(stage_names) + 2))
+        tab = np.zeros((world, len(stage_names) + 3))
         tab[rank, :len(stage_names)] = [mean_stages[k] for k in stage_names]
-        tab[rank, -2], tab[rank, -1] = float(K.shape[0]), float(K.nnz)
+        tab[rank, -3], tab[rank, -2] = float(K.shape[0]), float(K.nnz)
+        # what a rank RECEIVES per product of the solve: its halo of the direction vector, p planes from either z-neighbour
+        tab[rank, -1] = 8.0 * float(dcomm.halo_lo + dcomm.halo_hi) if dcomm is not None else 0.0
         transport.allreduce_sum(tab)
-        per_rank = [dict({k: round(float(tab[r, i]), 6) for i, k in enumerate(stage_names)}, rank=r, dof_rows=int(tab[r, -2]),
-                         nnz_K=int(tab[r, -1])) for r in range(world)]
+        per_rank = [dict({k: round(float(tab[r, i]), 6) for i, k in enumerate(stage_names)}, rank=r, dof_rows=int(tab[r, -3]),
+                         nnz_K=int(tab[r, -2]), halo_bytes_per_product=int(tab[r, -1])) for r in range(world)]
     info = dcomm.info() if dcomm is not None else (0, 1, "none")
     ndev = dev.device_count()
     n_used = 1

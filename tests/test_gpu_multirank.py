@@ -555,3 +555,36 @@ def test_bench_launcher_with_two_ranks_on_the_shared_gpu(tmp_path):
     assert cfg["cg_iterations"] == one["config"]["cg_iterations"]
     assert two["metric"] == one["metric"] and two["unit"] == "DoF/s" and two["steps"] == 1
     assert "roofline" in two and two["roofline"]["bound"] == "hbm"
+
+
+def test_rccl_asked_for_on_a_shared_gpu_falls_back_to_ipc(tmp_path):
+    """``TIGAR_COMM=rccl`` with two ranks on ONE device -- RCCL cannot form that communicator (it refuses two
+    ranks of one GPU, or its initialisation does not return: ``tg_nccl_init_with_timeout``, csrc/tg_dist.hip) -- must end in the
+    IPC communicator on every rank, agreed through the transport, with a note that says why, and the run must give what one
+    rank gives: the path a first multi-GPU node takes when RCCL is not usable there."""
+    import json
+    import subprocess
+
+    def run(gpus, extra_env):
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(29500 + 61 * gpus + 11))
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        env.update(extra_env)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "cfg2",
+                              "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--companion", "0", "--live-traffic", "0"],
+                             env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0]), out.stderr
+
+    one, _ = run(1, {})
+    two, err = run(2, {"TIGAR_COMM": "rccl", "TIGAR_DEVICE": "0", "TIGAR_RCCL_TIMEOUT_S": "25", "TIGAR_COMM_SELFTEST_S": "25"})
+    cfg = two["config"]
+    assert cfg["ranks"] == 2 and cfg["communicator_requested"] == "rccl" and cfg["communicator"] == "ipc"
+    assert cfg["communicator_fallback"] and "RCCL" in cfg["communicator_fallback"][0]
+    assert "using the IPC communicator" in err
+    assert cfg["cg_iterations"] == one["config"]["cg_iterations"]
+    assert cfg["self_check_rel_residual_all_ranks"] <= 1e-6
+    assert all(r["halo_bytes_per_product"] > 0 for r in cfg["per_rank_stages_s"])
