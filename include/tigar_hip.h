@@ -374,6 +374,10 @@ int tg_tensor_plan_destroy(tg_tensor_plan_t plan);
  * dofs field after field; degrees 1..4): K = M^T A M of the whole matrix in two passes, MatZeroRowsColumns fused.
  * A must hold nfields^2 blocks that all carry the element-coupling pattern (verified; 100 = another pattern). */
 int tg_tensor2_plan_create(int nfields, const tg_tensor_dir_t *dirs, tg_tensor_plan_t *out);
+/* The same for ONE block (f, g) of fields on different tensor bases over one 2-D Q_P node grid (2-D compatible B-splines,
+ * tIGAr/compatibleSplines.py:21-66, demos/taylor-green/taylor-green-2d.py): dirs[2] as for tg_tensor_plan_create_pair;
+ * tg_tensor2_ptap then takes the scalar block A_fg and returns K_fg = M_f^T A_fg M_g (no boundary conditions). */
+int tg_tensor2_plan_create_pair(const tg_tensor_pair_dir_t *dirs, tg_tensor_plan_t *out);
 int tg_tensor2_ptap(tg_tensor_plan_t plan, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag, tg_csr_t *out);
 /* x and y passes over the FE planes [z0,z1) of the last direction; `a` holds FE rows from a_row0 on (whole
  * planes, global columns).  The result (dense blocks, no indices) feeds tg_tensor_zstage and can be kept

@@ -354,6 +354,29 @@ def test_all_golden_compatible_spline_cases_extract_like_oracle(T):
             K = spline.extractMatrix(A).to_scipy()
             Ko = O.extract_matrix(Mo, A, list(spline.zeroDofs))
             assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max(), name
+            # an ASSEMBLED matrix (every block on the element-coupling pattern of the common Q_P grid, random values): the
+            # 2-D cases without periodic directions take the pair walks of round 6, block by block
+            grids = spline.V.grids
+            if len(m["cdeg"]) == 2 and m["periodicities"] is None and all(
+                    gr.shape() == grids[0].shape() and not getattr(gr, "dg", False) for gr in grids):
+                from tigar_amd import forms as F, device as dev
+                V1 = type(spline.V)([grids[0]], spline.V.element)
+                L = F.LaplaceForm().assemble_matrix(V1).to_scipy().tocsr()
+                rng = np.random.default_rng(len(name))
+                nF = m["nfields"]
+                blk = [[None] * nF for _ in range(nF)]
+                for a in range(nF):
+                    for b in range(nF):
+                        Bm = L.copy()
+                        Bm.data = Bm.data + 0.2 * rng.standard_normal(Bm.nnz)
+                        blk[a][b] = Bm
+                A2 = sp.bmat(blk, format="csr")
+                dev.prof_reset()
+                K2 = spline.extractMatrix(A2).to_scipy()
+                assert dev.prof_get(5)[1] == nF * nF, name                 # every block through the walks
+                K2o = O.extract_matrix(Mo, A2, list(spline.zeroDofs))
+                assert np.array_equal(K2.indptr, K2o.indptr) and np.array_equal(K2.indices, K2o.indices), name
+                assert abs(K2 - K2o).max() <= 1e-12 * abs(K2o).max(), name
 
 
 def test_multipatch_evaluations_match_the_reference(T):

@@ -613,3 +613,102 @@ def test_extract_matrix_on_a_compatible_spline_takes_the_pair_walks(degs, nels, 
     monkeypatch.setenv("TIGAR_PTAP_TENSOR", "0")
     K3 = spline.extractMatrix(A, diag=2.5).to_scipy()
     assert np.array_equal(K3.indices, Kr.indices) and abs(K3 - Kr).max() <= 1e-12 * abs(Kr).max()
+
+
+# ---- round 6: the same for 2-D compatible splines (demos/taylor-green/taylor-green-2d.py) ---------------------------------------
+def _compat_fields_2d(kind, degs, nels):
+    from tigar_amd import BSplines as B, common as tc
+    from tigar_amd.compatibleSplines import BSplineCompat
+    from tigar_amd.kronptap import KronExtraction
+    kv = [B.uniformKnots(degs[k], 0., 1. + 0.25 * k, nels[k]) for k in range(2)]
+    gen = BSplineCompat(tc.selfcomm, B.ExplicitBSplineControlMesh(list(degs), kv), kind, list(degs))
+    kxs = [KronExtraction(gen.getFieldSpline(f), gen.V.grids[f]) for f in range(2)]
+    return gen, kxs
+
+
+@pytest.mark.parametrize("kind,degs,nels", [("RT", (1, 1), (5, 4)), ("RT", (2, 2), (4, 6)), ("N", (1, 1), (3, 5)), ("RT", (3, 3), (5, 3)),
+                                            ("N", (2, 2), (6, 4)), ("RT", (1, 1), (1, 2))])
+def test_2d_walks_with_different_bases_on_rows_and_columns(kind, degs, nels):
+    """K_fg = M_f^T A_fg M_g for the components of a 2-D compatible B-spline (tIGAr/compatibleSplines.py:21-66): both fields
+    extract to one Q_P grid (P = base degree + 1), the bases differ in degree per direction.  ``TensorPtAP2D.for_pair``: the
+    two line walks with separate row- and column-side weights (padded to P + 1 functions per element), the last pass writing
+    the true pattern -- against scipy's product of the Kronecker operators; pattern = the structural product."""
+    import scipy.sparse as sps
+    from tigar_amd import device as dev, forms as F
+    from tigar_amd.tensorptap import TensorPtAP2D
+    dev.device_info()
+    gen, kxs = _compat_fields_2d(kind, degs, nels)
+    g = gen.V.grids[0]
+    assert g.degree == max(degs) + 1
+    V1 = type(gen.V)([g], gen.V.element)
+    A = F.LaplaceForm().assemble_matrix(V1).to_scipy().tocsr()
+    rng = np.random.default_rng(11)
+    A.data = A.data + 0.3 * rng.standard_normal(A.nnz)
+    Ad = dev.DeviceCSR.from_scipy(A)
+    Ms = [sps.kron(kx.M1[1], kx.M1[0]).tocsr() for kx in kxs]
+    for Mk in Ms:
+        Mk.eliminate_zeros()
+        Mk.sort_indices()
+    dev.prof_reset()
+    ones = lambda X: sps.csr_matrix((np.ones(X.nnz), X.indices, X.indptr), shape=X.shape)
+    for f in range(2):
+        for gg in range(2):
+            plan = TensorPtAP2D.for_pair(kxs[f], kxs[gg])
+            assert plan is not None
+            K = plan.ptap(Ad)
+            assert K is not None
+            K = K.to_scipy()
+            Kr = (Ms[f].T @ A @ Ms[gg]).tocsr()
+            S = (ones(Ms[f]).T @ ones(A) @ ones(Ms[gg])).tocsr()
+            S.sort_indices()
+            assert K.shape == Kr.shape
+            assert np.array_equal(K.indptr, S.indptr) and np.array_equal(K.indices, S.indices)
+            assert abs(K - Kr).max() <= 1e-12 * abs(Kr).max()
+    assert dev.prof_get(5)[1] >= 4
+    # a block off the element-coupling pattern is declined (the caller takes the general kernels)
+    Ab = A.tolil()
+    Ab[0, A.shape[1] - 1] = 1.0
+    assert TensorPtAP2D.for_pair(kxs[0], kxs[1]).ptap(dev.DeviceCSR.from_scipy(Ab.tocsr())) is None
+
+
+@pytest.mark.parametrize("degs,nels", [((1, 1), (7, 5)), ((2, 2), (4, 5))])
+def test_extract_matrix_on_a_2d_compatible_spline_takes_the_pair_walks(degs, nels, monkeypatch):
+    """extractMatrix on a 2-D BSplineCompat("RT") space (demos/taylor-green/taylor-green-2d.py:68) with an assembled block matrix
+    on the common Q_P grid: all four blocks through the 2-D walks with different row / column bases, K against the oracle
+    (pattern and values, normal-direction boundary conditions), and the same with the walks switched off."""
+    import scipy.sparse as sps
+    import tigar_amd as t
+    from tigar_amd import device as dev, forms as F, BSplines as B, common as tc
+    from tigar_amd.compatibleSplines import BSplineCompat
+    kv = [B.uniformKnots(degs[k], 0., 1. + 0.25 * k, nels[k]) for k in range(2)]
+    gen = BSplineCompat(tc.selfcomm, B.ExplicitBSplineControlMesh(list(degs), kv), "RT", list(degs))
+    for field in range(2):
+        sp_f = gen.getFieldSpline(field)
+        for side in (0, 1):
+            gen.addZeroDofs(field, sp_f.getSideDofs(field, side))
+    blocks = []
+    for i in range(2):
+        f = gen.getFieldSpline(i)
+        blocks.append(O.generate_M_tensor(O.BSpline([s1.p for s1 in f.splines], [np.asarray(s1.knots) for s1 in f.splines])))
+    Mo = sps.block_diag(blocks, format="csr")
+    assert gen._kron_fields is not None and len(gen._kron_fields) == 2
+    spline = t.ExtractedSpline(gen, 2 * (max(degs) + 1))
+    g = spline.V.grids[0]
+    V1 = type(spline.V)([g], spline.V.element)
+    L = F.LaplaceForm().assemble_matrix(V1).to_scipy().tocsr()
+    rng = np.random.default_rng(3)
+    blk = [[L.copy() for _ in range(2)] for _ in range(2)]
+    for r in blk:
+        for Bm in r:
+            Bm.data = Bm.data + 0.2 * rng.standard_normal(Bm.nnz)
+    A = sps.bmat(blk, format="csr")
+    zd = [int(i) for i in gen.zeroDofsArray()]
+    dev.prof_reset()
+    K = spline.extractMatrix(A, diag=2.5).to_scipy()
+    assert dev.prof_get(5)[1] == 4                       # four blocks, four final passes of the walks
+    Kr = O.extract_matrix(Mo, A, zd, diag=2.5)
+    assert np.array_equal(K.indptr, Kr.indptr) and np.array_equal(K.indices, Kr.indices)
+    assert abs(K - Kr).max() <= 1e-12 * abs(Kr).max()
+    monkeypatch.setenv("TIGAR_PTAP_TENSOR", "0")
+    K3 = spline.extractMatrix(A, diag=2.5).to_scipy()
+    assert np.array_equal(K3.indices, Kr.indices) and abs(K3 - Kr).max() <= 1e-12 * abs(Kr).max()

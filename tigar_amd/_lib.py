@@ -160,6 +160,7 @@ PROTOTYPES = {
     "tg_tensor_plan_create_pair": (C.c_int, [C.c_int, C.POINTER(tg_tensor_pair_dir_t), C.POINTER(handle)]),
     "tg_tensor_plan_destroy": (C.c_int, [handle]),
     "tg_tensor2_plan_create": (C.c_int, [C.c_int, C.POINTER(tg_tensor_dir_t), C.POINTER(handle)]),
+    "tg_tensor2_plan_create_pair": (C.c_int, [C.POINTER(tg_tensor_pair_dir_t), C.POINTER(handle)]),
     "tg_tensor2_ptap": (C.c_int, [handle, handle, c_i32p, C.c_int64, C.c_double, C.POINTER(handle)]),
     "tg_tensor_planes": (C.c_int, [handle, handle, C.c_int64, C.c_int, C.c_int, C.POINTER(handle)]),
     "tg_tensor_planes_destroy": (C.c_int, [handle]),

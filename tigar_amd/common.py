@@ -1862,8 +1862,9 @@ class ExtractedSpline(object):
 
     def _extract_matrix_by_field_list(self, A, zd, diag):
         """M^T A M for fields on DIFFERENT tensor bases (M = diag(M_f)): block (f, g) = M_f^T A_fg M_g by the line walks with
-        separate row- and column-side weights where the pair qualifies (all fields on one Q_P node grid, degrees <= 3:
-        ``TensorPtAP.for_pair``, csrc/tg_tensor_body.h), by the general kernels on the scalar operands otherwise; the
+        separate row- and column-side weights where the pair qualifies (all fields on one Q_P node grid, degrees <= 3 in 3-D:
+        ``TensorPtAP.for_pair``, <= 4 in 2-D: ``TensorPtAP2D.for_pair``; csrc/tg_tensor_body.h), by the general kernels on the
+        scalar operands otherwise; the
         blocks are put together and MatZeroRowsColumns is applied to the whole (tIGAr/common.py:1194-1200).  None when A
         is not a matrix on this mixed space."""
         from .tensorptap import TensorPtAP
@@ -1918,6 +1919,12 @@ class ExtractedSpline(object):
                         if pieces is not None:
                             Kij = plan.zstage(pieces, 0, kz)
                         del pieces
+                    if Kij is None and kxs[f].d == 2 and not Aij.is_loose():
+                        # 2-D compatible splines (demos/taylor-green/taylor-green-2d.py): the block in two walks
+                        from .tensorptap import TensorPtAP2D
+                        plan2 = TensorPtAP2D.for_pair(kxs[f], kxs[g])
+                        if plan2 is not None:
+                            Kij = plan2.ptap(Aij)
                     if Kij is None:
                         Kij = general(f, g, Aij)
                 row.append(Kij)

@@ -930,37 +930,46 @@ __global__ void __launch_bounds__(256) k_tt_rowptr2(tt_rowptr2_args A, int64_t n
   if (i < n) tt_rowptr2_one(A, i);
 }
 
-extern "C" int tg_tensor2_plan_create(int nfields, const tg_tensor_dir_t *dirs, tg_tensor_plan_t *out) {
-  TG_REQUIRE_INIT();
-  TG_REQUIRE(dirs && out && nfields >= 1, "bad arguments to tg_tensor2_plan_create");
+static int tt_plan_create2(int nfields, const tg_tensor_pair_dir_t *dirs, bool pair, tg_tensor_plan_t *out) {
   const int P = dirs[0].p;
   TG_REQUIRE(P >= 1 && P <= 4 && dirs[1].p == P, "tg_tensor2_plan_create: equal degrees 1..4 in both directions");
   TG_REQUIRE((2 * P + 1) * nfields <= 64, "tg_tensor2_plan_create: (2p+1) * nfields lanes must fit a wave");
+  TG_REQUIRE(!pair || nfields == 1, "tg_tensor2_plan_create_pair: one field on either side");
   tg_tensor_plan_s *pl = new tg_tensor_plan_s();
   pl->P = P;
   pl->d = 2;
   pl->nF = nfields;
+  pl->pair = pair;
   int rc = 0;
   for (int k = 0; k < 2 && !rc; k++) {
     const int nel = dirs[k].nel, nfe = P * nel + 1, ncp = nel + P;
-    if (nel < 1 || !dirs[k].wl) {
-      tg_set_error("tg_tensor2_plan_create: bad direction %d", k);
+    const int pr = pair ? dirs[k].pr : P, pc = pair ? dirs[k].pc : P;
+    if (nel < 1 || !dirs[k].wlc || (pair && !dirs[k].wlr) || pr < 1 || pr > P || pc < 1 || pc > P) {
+      tg_set_error("tg_tensor2_plan_create: bad direction %d (spline degrees 1..%d on both sides)", k, P);
       rc = 2;
       break;
     }
-    std::vector<double> w(dirs[k].wl, dirs[k].wl + (size_t)nel * (P + 1) * (P + 1));
+    const int ncr = nel + pr, ncc = nel + pc;
+    pl->pr[k] = pr, pl->pc[k] = pc, pl->ncr[k] = ncr, pl->ncc[k] = ncc;
+    std::vector<double> w(dirs[k].wlc, dirs[k].wlc + (size_t)nel * (P + 1) * (P + 1));
     pl->h_rps[k].assign(nfe + 1, 0);
     for (int a = 0; a < nfe; a++) pl->h_rps[k][a + 1] = pl->h_rps[k][a] + tt_rn_host(P, a, nfe);
-    pl->h_kps[k].assign(ncp + 1, 0);
-    for (int i = 0; i < ncp; i++)
-      pl->h_kps[k][i + 1] = pl->h_kps[k][i] + (std::min(ncp - 1, i + P) - std::max(0, i - P) + 1);
+    // 1-D pattern of the product: row function i couples to the column functions [i - pr, i + pc], clipped
+    pl->h_kps[k].assign(ncr + 1, 0);
+    for (int i = 0; i < ncr; i++)
+      pl->h_kps[k][i + 1] = pl->h_kps[k][i] + (std::min(ncc - 1, i + pc) - std::max(0, i - pr) + 1);
     rc = tt_upload(&pl->wl[k], w);
+    if (!rc && pair) {
+      std::vector<double> wr(dirs[k].wlr, dirs[k].wlr + (size_t)nel * (P + 1) * (P + 1));
+      rc = tt_upload(&pl->wlr[k], wr);
+    }
     if (!rc) rc = tt_upload(&pl->rps[k], pl->h_rps[k]);
     if (!rc) rc = tt_upload(&pl->kps[k], pl->h_kps[k]);
     pl->dir[k].nel = nel;
     pl->dir[k].nfe = nfe;
-    pl->dir[k].ncp = ncp;
+    pl->dir[k].ncp = ncp;                 // (padded: the layout of the intermediate)
     pl->dir[k].wl = pl->wl[k];
+    pl->dir[k].wlr = pair ? pl->wlr[k] : nullptr;
     pl->dir[k].rps = pl->rps[k];
     pl->dir[k].kps = pl->kps[k];
   }
@@ -1008,6 +1017,30 @@ extern "C" int tg_tensor2_plan_create(int nfields, const tg_tensor_dir_t *dirs, 
   return 0;
 }
 
+extern "C" int tg_tensor2_plan_create(int nfields, const tg_tensor_dir_t *dirs, tg_tensor_plan_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(dirs && out && nfields >= 1, "bad arguments to tg_tensor2_plan_create");
+  tg_tensor_pair_dir_t pd[2];
+  for (int k = 0; k < 2; k++) {
+    pd[k].p = dirs[k].p;
+    pd[k].nel = dirs[k].nel;
+    pd[k].pr = pd[k].pc = dirs[k].p;
+    pd[k].wlr = nullptr;
+    pd[k].wlc = dirs[k].wl;
+  }
+  return tt_plan_create2(nfields, pd, false, out);
+}
+
+/* Block (f, g) of a space whose fields sit on DIFFERENT tensor bases over one 2-D Q_P node grid (the components of a 2-D
+ * compatible B-spline, tIGAr/compatibleSplines.py:21-66; demos/taylor-green/taylor-green-2d.py): K_fg = M_f^T A_fg M_g in
+ * the same two passes with separate row- and column-side weights (padded to P + 1 functions per element), the last pass
+ * writing the true pattern. */
+extern "C" int tg_tensor2_plan_create_pair(const tg_tensor_pair_dir_t *dirs, tg_tensor_plan_t *out) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(dirs && out, "bad arguments to tg_tensor2_plan_create_pair");
+  return tt_plan_create2(1, dirs, true, out);
+}
+
 extern "C" int tg_tensor2_ptap(tg_tensor_plan_t pl, tg_csr_t a, const int32_t *zero_dofs, int64_t nzero, double diag,
                                tg_csr_t *out) {
   TG_REQUIRE_INIT();
@@ -1020,9 +1053,13 @@ extern "C" int tg_tensor2_ptap(tg_tensor_plan_t pl, tg_csr_t a, const int32_t *z
   if (a->nrows != nF * nfe || a->ncols != nF * nfe) return 100;        // not a matrix on this mixed space
   const int64_t t0 = pl->h_rps[0][D0.nfe], t1 = pl->h_rps[1][D1.nfe];
   if (a->nnz != (int64_t)nF * nF * t0 * t1) return 100;                 // (cheap: the pattern has exactly this many entries)
-  const int64_t w0tot = pl->h_kps[0][D0.ncp], w1tot = pl->h_kps[1][D1.ncp];
-  const int64_t knnz = (int64_t)nF * nF * w0tot * w1tot, krows = nF * ncp;
-  TG_REQUIRE(nF * nfe < 0x7fffffffll && krows < 0x7fffffffll, "tg_tensor2_ptap: index range");
+  const int ncr0 = pl->pair ? pl->ncr[0] : D0.ncp, ncr1 = pl->pair ? pl->ncr[1] : D1.ncp;
+  const int ncc0 = pl->pair ? pl->ncc[0] : D0.ncp, ncc1 = pl->pair ? pl->ncc[1] : D1.ncp;
+  const int64_t w0tot = pl->h_kps[0][ncr0], w1tot = pl->h_kps[1][ncr1];
+  const int64_t knnz = (int64_t)nF * nF * w0tot * w1tot, krows = (int64_t)nF * ncr0 * ncr1, kcols = (int64_t)nF * ncc0 * ncc1;
+  (void)ncp;
+  TG_REQUIRE(nF * nfe < 0x7fffffffll && krows < 0x7fffffffll && kcols < 0x7fffffffll, "tg_tensor2_ptap: index range");
+  TG_REQUIRE(!pl->pair || !(zero_dofs && nzero > 0), "tg_tensor2_ptap: boundary conditions belong to the assembled matrix, not to a block");
   // elements per piece of the walks: enough pieces to give the chip a few thousand waves, not so short that the P
   // re-read elements of a piece dominate
   auto pick_ech = [&](int nel, int64_t waves_per_piece, const char *env, int floor_ech) {
@@ -1041,7 +1078,7 @@ extern "C" int tg_tensor2_ptap(tg_tensor_plan_t pl, tg_csr_t a, const int32_t *z
   int64_t *d_pb1 = nullptr;
   int32_t *d_planes = nullptr;
   int rc = tg_dmalloc(&b1, plane_b1 * nF);
-  if (!rc) rc = tg_csr_alloc(krows, krows, knnz, &m);
+  if (!rc) rc = tg_csr_alloc(krows, kcols, knnz, &m);
   if (!rc && zero_dofs && nzero > 0) rc = tg_build_dof_mask(zero_dofs, nzero, krows, &mask);
   {
     std::vector<int64_t> pb1(nF + 1, 0);
@@ -1121,8 +1158,8 @@ extern "C" int tg_tensor2_ptap(tg_tensor_plan_t pl, tg_csr_t a, const int32_t *z
     tt_rowptr2_args R;
     R.kps0 = D0.kps;
     R.kps1 = D1.kps;
-    R.ncp0 = D0.ncp;
-    R.ncp1 = D1.ncp;
+    R.ncp0 = ncr0;
+    R.ncp1 = ncr1;
     R.nF = nF;
     R.rowptr_out = m->rowptr;
     hipLaunchKernelGGL(k_tt_rowptr2, dim3((unsigned)tg_cdiv(krows, 256)), dim3(256), 0, g_tg.stream, R, krows);
@@ -1134,11 +1171,13 @@ extern "C" int tg_tensor2_ptap(tg_tensor_plan_t pl, tg_csr_t a, const int32_t *z
     Y.ncp0 = D0.ncp;
     Y.nF = nF;
     Y.kps0 = D0.kps;
+    Y.ncr0 = Y.ncr1 = Y.ncc0 = Y.ncc1 = Y.pr0 = Y.pr1 = 0;
+    if (pl->pair) Y.ncr0 = ncr0, Y.ncr1 = ncr1, Y.ncc0 = ncc0, Y.ncc1 = ncc1, Y.pr0 = pl->pr[0], Y.pr1 = pl->pr[1];
     Y.L = std::max(1, 64 / (W * nF));
     const unsigned gx = (unsigned)tg_cdiv(D0.ncp, Y.L);
     Y.ech = pick_ech(D1.nel, (int64_t)gx * nF, "TIGAR_TT2_ECH_Y", 2 * P);
     const unsigned np1 = Y.ech ? (unsigned)tg_cdiv(D1.nel, Y.ech) : 1u;
-    if (!m->diag_cache && tg_dmalloc(&m->diag_cache, krows)) m->diag_cache = nullptr;
+    if (!pl->pair && !m->diag_cache && tg_dmalloc(&m->diag_cache, krows)) m->diag_cache = nullptr;
     Y.kdiag = m->diag_cache;
     Y.kcol = m->col;
     Y.kval = m->val;

@@ -643,6 +643,10 @@ struct tt_y2_args {
   double *kdiag;                 // diagonal of K (index: row), or null
   const uint8_t *mask;           // zeroDofs as a byte mask over all dofs, or null
   double diag;
+  // A block with different bases on the row and the column side (one field each: nF = 1; see tt_dir_t::wlr and tt_z_args),
+  // 0 = the square default.  ncp0 / d1.ncp stay the PADDED counts nel + P (the layout of B1); these are the true function
+  // counts and the row-side spline degrees: row dof i couples to the column dofs [i - pr, i + pc] (clipped)
+  int ncr0, ncr1, ncc0, ncc1, pr0, pr1;
 };
 
 template <int P>
@@ -654,6 +658,8 @@ struct tt_io_y2 {
   int elo, ehi;
   tt_cip kps1;
   int f, g, i0, m0, ncp0, ncp1, nF, w0n, w0lo;
+  int ncc0, ncc1, pr1;           // (ncp0 / ncp1 here: the true ROW counts; ncc: the column side's; pr1: row degree of direction 1)
+  bool square;
   int64_t w0tot, w1tot, kp0;     // kp0 = kps0[i0]
   int32_t *kcol;
   double *kval;
@@ -670,25 +676,25 @@ struct tt_io_y2 {
     for (int j = 0; j < N; j++) v[j] = in[o + j];
   }
   TT_MEM void emit(int i1, const double *row) {
-    if (!valid || !inwin || i1 < elo || i1 >= ehi) return;
+    if (!valid || !inwin || i1 < elo || i1 >= ehi || i1 >= ncp1) return;       // (ncp1: rows of functions the padding added)
     const int w1n = kps1[i1 + 1] - kps1[i1];
-    const int w1lo = i1 < P ? P - i1 : 0;
-    const int64_t pd = (int64_t)ncp0 * ncp1;
+    const int w1lo = P - (i1 < pr1 ? i1 : pr1);
+    const int64_t pd = (int64_t)ncp0 * ncp1, pdc = (int64_t)ncc0 * ncc1;
     const int64_t R = i0 + (int64_t)ncp0 * i1 + pd * f;
     const int64_t rowstart = (int64_t)nF * ((int64_t)f * w0tot * w1tot + w0tot * kps1[i1] + (int64_t)w1n * kp0);
     const int64_t base = rowstart + (int64_t)g * w1n * w0n + (m0 - w0lo);
-    const int64_t c0g = (i0 - P + m0) + pd * g;
+    const int64_t c0g = (i0 - P + m0) + pdc * g;
     const bool mrow = mask && mask[R];
 #pragma unroll
     for (int m1 = 0; m1 < 2 * P + 1; m1++) {
       if (m1 >= w1lo && m1 < w1lo + w1n) {
         const int64_t pos = base + (int64_t)(m1 - w1lo) * w0n;
-        const int64_t c = c0g + (int64_t)ncp0 * (i1 - P + m1);
+        const int64_t c = c0g + (int64_t)ncc0 * (i1 - P + m1);
         double v = row[m1];
         if (mask && (mrow || mask[c])) v = (mrow && c == R) ? diag : 0.0;
         kcol[pos] = (int32_t)c;
         kval[pos] = v;
-        if (kdiag && c == R) kdiag[R] = v;
+        if (kdiag && square && c == R) kdiag[R] = v;
       }
     }
   }
@@ -714,15 +720,24 @@ TT_DEV void tt_y2_lane(const tt_y2_args &A, int bx, int by, int piece, int lane)
   io.g = g;
   io.i0 = io.valid ? i0 : 0;
   io.m0 = m0;
-  io.ncp0 = A.ncp0;
-  io.ncp1 = A.d1.ncp;
+  // true function counts and row-side degrees (square blocks: the padded counts, P)
+  const int ncr0 = A.ncr0 ? A.ncr0 : A.ncp0, ncr1 = A.ncr1 ? A.ncr1 : A.d1.ncp;
+  const int pr0 = A.pr0 ? A.pr0 : P;
+  const bool real = io.i0 < ncr0;                 // (rows of functions the padding added are not written)
+  const int j0 = real ? io.i0 : 0;
+  io.ncp0 = ncr0;
+  io.ncp1 = ncr1;
+  io.ncc0 = A.ncc0 ? A.ncc0 : A.ncp0;
+  io.ncc1 = A.ncc1 ? A.ncc1 : A.d1.ncp;
+  io.pr1 = A.pr1 ? A.pr1 : P;
+  io.square = A.ncr0 == 0;
   io.nF = A.nF;
-  io.kp0 = A.kps0[io.i0];
-  io.w0n = A.kps0[io.i0 + 1] - A.kps0[io.i0];
-  io.w0lo = io.i0 < P ? P - io.i0 : 0;
-  io.inwin = m0 >= io.w0lo && m0 < io.w0lo + io.w0n;
-  io.w0tot = A.kps0[A.ncp0];
-  io.w1tot = A.d1.kps[A.d1.ncp];
+  io.kp0 = A.kps0[j0];
+  io.w0n = A.kps0[j0 + 1] - A.kps0[j0];
+  io.w0lo = P - (io.i0 < pr0 ? io.i0 : pr0);
+  io.inwin = real && m0 >= io.w0lo && m0 < io.w0lo + io.w0n;
+  io.w0tot = A.kps0[ncr0];
+  io.w1tot = A.d1.kps[ncr1];
   io.kcol = A.kcol;
   io.kval = A.kval;
   io.kdiag = A.kdiag;

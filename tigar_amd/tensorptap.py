@@ -365,15 +365,29 @@ class TensorPtAP2D(object):
     """Plan of the tensor-pattern PtAP for a patch with TWO parametric directions and ``nfields`` fields on one scalar
     basis (csrc/tg_ptap_tensor.hip: tg_tensor2_*): the whole product in two line-walk passes, degrees 1..4."""
 
-    def __init__(self, p, nels, wls, nfields=1):
+    def __init__(self, p, nels, wls, nfields=1, pair=None):
+        """``pair``: (row-side weights, row degrees, column degrees) per direction for ONE block with different spline bases on
+        its two sides (``wls`` then being the column side's, padded; ``nfields`` = 1) -- ``tg_tensor2_plan_create_pair``"""
         self.p, self.nels, self.nfields = int(p), [int(n) for n in nels], int(nfields)
         self._keep = [np.ascontiguousarray(w, dtype=np.float64) for w in wls]
+        self._h = handle()
+        if pair is not None:
+            wlr, pr, pc = pair
+            self._keep_r = [np.ascontiguousarray(w, dtype=np.float64) for w in wlr]
+            arr = (tg_tensor_pair_dir_t * 2)()
+            for k in range(2):
+                arr[k].p = self.p
+                arr[k].nel = self.nels[k]
+                arr[k].pr, arr[k].pc = int(pr[k]), int(pc[k])
+                arr[k].wlr = self._keep_r[k].ctypes.data_as(c_f64p)
+                arr[k].wlc = self._keep[k].ctypes.data_as(c_f64p)
+            check(_lib.lib().tg_tensor2_plan_create_pair(arr, C.byref(self._h)), "tg_tensor2_plan_create_pair")
+            return
         arr = (tg_tensor_dir_t * 2)()
         for k in range(2):
             arr[k].p = self.p
             arr[k].nel = self.nels[k]
             arr[k].wl = self._keep[k].ctypes.data_as(c_f64p)
-        self._h = handle()
         check(_lib.lib().tg_tensor2_plan_create(self.nfields, arr, C.byref(self._h)), "tg_tensor2_plan_create")
 
     def __del__(self):
@@ -419,6 +433,50 @@ class TensorPtAP2D(object):
             cache[nfields] = _cached_plan("2d", st[0], st[1], nfields, kx._tensor_keys,
                                           lambda: TensorPtAP2D(*st, nfields=nfields)) if ok else None
         return cache[nfields]
+
+    @staticmethod
+    def structure_pair(kx_row, kx_col):
+        """(P, nels, column weights, (row weights, row degrees, column degrees), keys) when block (row basis, column basis) of a
+        space on ONE 2-D Q_P node grid has the structure of the walks, else None"""
+        if kx_row.d != 2 or kx_col.d != 2:
+            return None
+        g, g2 = kx_row.grid, kx_col.grid
+        if getattr(g, "dg", False) or getattr(g2, "dg", False) or g.degree != g2.degree or g.degree < 1 or g.degree > 4:
+            return None
+        if any(not np.array_equal(a, b) for a, b in zip(g.axes, g2.axes)):
+            return None
+        P = int(g.degree)
+        nels, wlc, wlr, pr, pc, keys = [], [], [], [], [], []
+        for k in range(2):
+            nel = len(g.vertices[k]) - 1
+            psr, psc = int(kx_row.basis.splines[k].p), int(kx_col.basis.splines[k].p)
+            wr, wc = local_weights_padded(kx_row.M1[k], P, nel, psr), local_weights_padded(kx_col.M1[k], P, nel, psc)
+            if wr is None or wc is None:
+                return None
+            nels.append(nel)
+            wlr.append(wr)
+            wlc.append(wc)
+            pr.append(psr)
+            pc.append(psc)
+            keys.append((P, nel, psr, psc, _digest(kx_row.M1[k]), _digest(kx_col.M1[k])))
+        return P, nels, wlc, (wlr, pr, pc), keys
+
+    @staticmethod
+    def for_pair(kx_row, kx_col):
+        """plan of block (row basis, column basis) of a 2-D space; the square plan when both are the same object"""
+        if os.environ.get("TIGAR_PTAP_TENSOR", "1") == "0":
+            return None
+        if kx_row is kx_col:
+            plan = TensorPtAP2D.for_extraction(kx_row, 1)
+            if plan is not None:
+                return plan
+        cache = kx_row.__dict__.setdefault("_tensor2_pair_plans", {})
+        if id(kx_col) not in cache:
+            st = TensorPtAP2D.structure_pair(kx_row, kx_col)
+            cache[id(kx_col)] = (kx_col, _cached_plan("2d-pair", st[0], st[1], 1, st[4],
+                                                      lambda: TensorPtAP2D(st[0], st[1], st[2], 1, pair=st[3]))
+                                 if st is not None else None)
+        return cache[id(kx_col)][1]
 
     def ptap(self, A, zero_dofs=None, diag=1.0):
         """K = M^T A M with MatZeroRowsColumns fused, or None when A does not carry the element-coupling pattern in all
