@@ -7,6 +7,8 @@ RND = sys.argv[1] if len(sys.argv) > 1 else "3"
 WORK = [("cfg3 (256^3 p=3)", "r%s_cfg3_kernel_stats.txt" % RND, "r%s_cfg3_pmc_hbm.json" % RND),
         ("cfg3 size, mapped geometry", "r%s_cfg3_mapped_kernel_stats.txt" % RND, "r%s_cfg3_mapped_pmc_hbm.json" % RND),
         ("general PtAP, element split (64^3 p=3)", "r%s_elemsplit_kernel_stats.txt" % RND, "r%s_elemsplit_pmc_hbm.json" % RND),
+        ("cfg3 size, nothing assumed about M or A (element chunks)", "r%s_cfg3_general_kernel_stats.txt" % RND,
+         "r%s_cfg3_general_pmc_hbm.json" % RND),
         ("cfg2 (128^3 p=2)", "r%s_cfg2_kernel_stats.txt" % RND, "r%s_cfg2_pmc_hbm.json" % RND),
         ("cfg4 (256^2 p=4, CG)", "r%s_cfg4_kernel_stats.txt" % RND, "r%s_cfg4_pmc_hbm.json" % RND),
         ("cfg5 (128^2 p=3, 3 fields)", "r%s_cfg5_kernel_stats.txt" % RND, "r%s_cfg5_pmc_hbm.json" % RND),
