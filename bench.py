@@ -791,7 +791,10 @@ def main():
         for key, fn in (("fe_matrix_materialised_in_row_blocks", "r3_bench_cfg3_fe_matrix_materialised.json"),
                         ("fe_matrix_pattern_verified_entry_by_entry", "r3_bench_cfg3_pattern_verified.json"),
                         ("arbitrary_A_kronecker_M_line_kernels", "r4_bench_cfg3_general_line.json"),
-                        ("fully_general_hash_ptap_M_slabs_materialised", "r4_bench_cfg3_general_hash.json")):
+                        ("fully_general_hash_ptap_M_slabs_materialised", "r4_bench_cfg3_general_hash.json"),
+                        # round 6: the same contract -- M materialised chunk by chunk as a general CSR matrix, A in row blocks,
+                        # nothing assumed about either -- through the element chunks (csrc/tg_elemsplit.hip)
+                        ("fully_general_element_chunks_M_materialised", "r6_bench_cfg3_general_elements.json")):
             try:
                 g = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 ref[key] = {"value": g["value"], "ms_per_step": g["ms_per_step"], "ptap_s": g["config"]["stages_s"]["ptap"],
@@ -826,7 +829,7 @@ def main():
             one_nel = max(4, cpu_nel // 2)
         gpu_general = None
         gref = out["config"].get("general_path_reference", {})
-        for key in ("fully_general_hash_ptap_M_slabs_materialised",):
+        for key in ("fully_general_hash_ptap_M_slabs_materialised", "fully_general_element_chunks_M_materialised"):   # (the last one found)
             if key in gref:
                 gpu_general = {"value": gref[key]["value"], "unit": "DoF/s", "what": key, "source": gref[key]["source"]}
         out["cpu_baseline"] = cpu_baseline(d, p, cpu_nel, one_nel, nel, res["iterations"], gpu_general)
