@@ -325,8 +325,9 @@ def test_streamed_element_chunks_in_the_slab_engine(monkeypatch, d, p, nels, lay
 def test_several_fields_on_element_chunks(monkeypatch):
     """Three fields on one basis (elasticity, tIGAr/common.py:1891-1914) with the operator kept implicit and NOTHING assumed about
     M or A in the product (``TIGAR_PTAP_FACTORED=0``): every field block (f, g) = M_s^T A_fg M_s runs through the element chunks
-    of the scalar engine (``dist.FieldSlabPath`` -> ``SlabHotPath._assemble_by_elements``), the blocks are interleaved plane by
-    plane.  Against the resident path's K; an explicit scipy A takes the same way."""
+    of the scalar engine, all nine on ONE pass (``dist.FieldSlabPath`` -> ``SlabHotPath.assemble_blocks_by_elements``: a chunk's
+    plan depends on M only), the blocks are interleaved plane by plane.  Against the resident path's K; an explicit scipy A
+    takes the same way."""
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -341,16 +342,16 @@ def test_several_fields_on_element_chunks(monkeypatch):
     monkeypatch.setenv("TIGAR_PTAP_ELEMENTS", "2")
     monkeypatch.setenv("TIGAR_ELEM_LAYERS", "2")
     calls = []
-    orig = dist.SlabHotPath._assemble_by_elements
+    orig = dist.SlabHotPath.assemble_blocks_by_elements
 
-    def spy(self, *a, **k):
-        out = orig(self, *a, **k)
-        calls.append(out is not None)
+    def spy(self, producers, *a, **k):
+        out = orig(self, producers, *a, **k)
+        calls.append((len(producers), out is not None))
         return out
-    monkeypatch.setattr(dist.SlabHotPath, "_assemble_by_elements", spy)
+    monkeypatch.setattr(dist.SlabHotPath, "assemble_blocks_by_elements", spy)
     gen2, spline2, K2, rhs2, _ = W.problem("elasticity3d", tc.selfcomm)
     assert getattr(gen2.M, "is_implicit", False)
-    assert len(calls) == 9 and all(calls)                    # nine field blocks, each on the element chunks
+    assert calls == [(9, True)]                              # nine field blocks on ONE pass over the element chunks
     dofs = spline2.localDofIndices()
     n2o = spline2._slab_path().new_of_old()
     n = Kref.shape[0]
@@ -363,6 +364,7 @@ def test_several_fields_on_element_chunks(monkeypatch):
     A3 = F.ElasticityForm(2.0, 1.0).assemble_matrix(spline.V).to_scipy()
     K3 = spline2.extractMatrix(A3, diag=1.5).to_scipy().tocsr()
     assert abs(K3 - Kr).max() <= 1e-12 * abs(Kref).max()
+    assert calls[-1] == (9, True)
 
 
 @pytest.mark.parametrize("p,drops,nels,world", [(2, (0, 0, 1), (4, 3, 7), 2), (3, (1, 0, 2), (3, 3, 6), 1), (2, (1, 1, 1), (4, 4, 5), 3)])

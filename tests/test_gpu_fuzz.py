@@ -36,6 +36,12 @@ def _run(args, env, tool="fuzz_parity.py"):
     (109, {"TIGAR_EXTRACT_KRON": "0"}),
     (110, {"TIGAR_FUZZ_ROUNDTRIP": "1"}),        # through writeExtraction / ExtractedSpline(dirname): a stored M without structure
     (111, {"TIGAR_PTAP_TENSOR": "0", "TIGAR_PTAP_FACTORED": "0", "TIGAR_PTAP_ELEMENTS": "2"}),   # element-split cell products
+    # round 6: the element chunks of the streamed engine (implicit M, two element layers per chunk), and the element split on its
+    # alternative kernels (multi-way merge for the row patterns, vector-unit cell products, node -> cells as lists)
+    (112, {"TIGAR_PTAP_TENSOR": "0", "TIGAR_PTAP_FACTORED": "0", "TIGAR_PTAP_ELEMENTS": "2", "TIGAR_IMPLICIT_M": "1",
+           "TIGAR_ELEM_LAYERS": "2"}),
+    (113, {"TIGAR_PTAP_TENSOR": "0", "TIGAR_PTAP_FACTORED": "0", "TIGAR_PTAP_ELEMENTS": "2", "TIGAR_EL_MERGE": "1",
+           "TIGAR_EL_VALU": "1", "TIGAR_EL_LISTS": "1"}),
 ])
 def test_random_patches_match_the_oracle(seed, env):
     rc, summary, failures = _run(["--seed", str(seed), "--cases", "80"], env)
@@ -53,6 +59,23 @@ def test_hand_added_couplings_that_end_inside_an_element_of_a_repeated_knot_dire
     for first in (1, 185, 197, 291):
         rc, summary, failures = _run(["--seed", "5", "--first", str(first), "--cases", "1", "--force", force], {})
         assert rc == 0 and summary["failed"] == 0, "\n".join(failures)[:4000]
+
+
+def test_hand_added_couplings_on_patches_with_repeated_knots_take_the_general_kernels():
+    """found by the random runs of round 6 (seeds 6901 / 51 and 6902 / 291; present since round 3): ONE coupling added by hand to
+    a block of a 3-D p = 3 patch with repeated knots came out with wrong values (16 rows of K) or with entries missing (57)
+    from the box / line kernels of the direction-by-direction product.  With repeated knots only a matrix that has exactly the
+    element-coupling pattern's number of entries takes those kernels now (``KronExtraction.box_kernels_safe``)."""
+    cases = [{"d": 3, "ps": [3, 3, 3], "kinds": ["drop", "drop", "nonuniform"], "nels": [7, 2, 3], "drops": [2, 1, 0], "nfields": 2,
+              "knot_seed": 885604054, "bc": "none", "diag": 1000.0, "matrix": "random_extra", "val_seed": 919211811,
+              "apply_bcs": True},
+             {"d": 3, "ps": [3, 3, 3], "kinds": ["uniform", "nonuniform", "drop"], "nels": [5, 4, 6], "drops": [0, 0, 2], "nfields": 2,
+              "knot_seed": 307650820, "bc": "sides2", "diag": 1000.0, "matrix": "random_extra", "val_seed": 681249583,
+              "apply_bcs": True}]
+    for case in cases:
+        for env in ({}, {"TIGAR_IMPLICIT_M": "1"}):
+            rc, summary, failures = _run(["--case", json.dumps(case)], env)
+            assert rc == 0 and summary["failed"] == 0, "\n".join(failures)[:4000]
 
 
 @pytest.mark.parametrize("seed,env", [(201, {}), (202, {"TIGAR_PTAP_WAVE": "1"}), (203, {"TIGAR_PTAP_ACCUM": "int"}),

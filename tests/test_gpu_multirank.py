@@ -84,7 +84,8 @@ def _compare(parts, ref, world, kind, its_slack=1):
         if r1 > r0:                                  # (a rank of a thin slab may own no FE rows)
             assert np.max(np.abs(z["u"] - u[r0:r1])) <= 1e-8 * np.max(np.abs(u))
             assert np.max(np.abs(z["cp0"] - cp0[r0:r1])) <= 1e-14
-        assert abs(int(z["its"][0]) - its) <= its_slack  # same Krylov iteration count as the single-rank solve
+        # same Krylov iteration count as the single-rank solve
+        assert abs(int(z["its"][0]) - its) <= its_slack, "iterations %d on %d ranks, %d on one" % (int(z["its"][0]), world, its)
         assert int(z["its"][1]) <= 2                     # restart from the solution: (almost) converged at once
         # the initial guess solveLinearSystem takes from u (M^T u, tIGAr/common.py:1250-1254): every contribution there,
         # also for the dofs next to a slab boundary (ghost rows of u from the z-neighbours)

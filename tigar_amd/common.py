@@ -1662,8 +1662,10 @@ class ExtractedSpline(object):
                 return ptap_factored(kx, A, (0, kx.nfe[-1]), (0, kx.nfe[-1]), (0, kx.ncp[-1]), zd, float(diag), groups,
                                      stored=stored)
         if self._implicit():
-            raise NotImplementedError("general PtAP with an implicit extraction operator: materialise M "
-                                      "(TIGAR_IMPLICIT_M=0) or pass a tensor-product FE matrix")
+            # an implicit operator that is not to be used as a Kronecker product (TIGAR_PTAP_FACTORED=0) with an assembled A: the
+            # streamed engine materialises M chunk by chunk and takes its general stages -- element chunks, or the row-wise
+            # kernels for a matrix they decline (round 6; until then: NotImplementedError)
+            return self._slab_path().assemble_matrix(self._row_blocks_of(A), zd, float(diag), getattr(self, "stage_timers", None))
         # cell-local FE spaces (T-splines, multi-patch B-splines: meshes of disconnected cells): an assembled A is block
         # diagonal with one dense block per cell and the product is a sum of small dense triple products
         # (tigar_amd/cellptap.py); the plan depends on M only and is kept, A is verified on the device at every call

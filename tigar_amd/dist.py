@@ -135,6 +135,75 @@ def pick_sub_planes(d, p, nel, planes_mine, free_bytes):
     return int(max(1, min(planes_mine, budget // per_dof_plane)))
 
 
+class _ChunkRows(object):
+    """Rows [g0, g1) of a matrix that arrives as CHUNKS of rows to be ADDED (the element chunks of ``SlabHotPath``): rows below
+    ``done_row`` after a chunk are final and go to the result (a ``CSRBuilder`` sized from the densest plane of the first rows),
+    the rows above are carried and added to the next chunk's on the union pattern."""
+
+    def __init__(self, dev, g0, g1, ncols, plane_rows):
+        self.dev, self.g0, self.g1, self.ncols, self.pd = dev, int(g0), int(g1), int(ncols), int(plane_rows)
+        self.builder, self.single = None, None
+        self.pending, self.pend0 = None, 0        # rows [pend0, pend0 + pending.shape[0]): sums over the chunks so far
+        self.emitted = self.g0
+
+    def _rows(self, Kb, base, r0, r1):
+        return Kb.block(r0 - base, r1 - base, 0, self.ncols)
+
+    def _emit(self, Kb, base, r0, r1):
+        """rows [r0, r1) of the block Kb (whose first row is ``base``) are final: those of this rank go to the result"""
+        r0, r1 = max(r0, self.g0, self.emitted), min(r1, self.g1)
+        if r1 <= r0:
+            return
+        assert r0 == self.emitted, "element chunks: rows must come in order"
+        blk = Kb if (r0 == base and r1 == base + Kb.shape[0]) else self._rows(Kb, base, r0, r1)
+        if r0 == self.g0 and r1 == self.g1:
+            self.single = blk
+        else:
+            if self.builder is None:
+                # capacity from the densest part of the first rows: their last dof plane (rows near the patch boundary are
+                # shorter; a builder that has to grow allocates and copies K a second time -- 75 GB at 256^3 p = 3)
+                nr, pd = blk.shape[0], self.pd
+                last = (blk.nnz - blk.rowptr_at(nr - pd)) / float(pd) if nr >= pd else blk.nnz / float(max(1, nr))
+                est = int(max(blk.nnz / float(max(1, nr)), last) * (self.g1 - self.g0) * 1.01) + 1024
+                self.builder = self.dev.CSRBuilder(self.g1 - self.g0, self.ncols, est)
+            self.builder.append(blk)
+        self.emitted = r1
+
+    def add_chunk(self, Kc, d0, d1, done_row):
+        """``Kc``: rows [d0, d1) of a chunk's contribution; rows below ``done_row`` receive nothing after it"""
+        if self.pending is not None:
+            pend0, pending = self.pend0, self.pending
+            p1 = pend0 + pending.shape[0]
+            if d0 > pend0:                                   # (rows below the new chunk: nothing more comes for them)
+                self._emit(pending, pend0, pend0, min(d0, p1))
+            ov0, ov1 = max(d0, pend0), min(p1, d1)
+            parts = []
+            if ov1 > ov0:
+                parts.append(self._rows(pending, pend0, ov0, ov1).add(self._rows(Kc, d0, ov0, ov1)))
+            if d1 > max(p1, d0):
+                parts.append(self._rows(Kc, d0, max(p1, d0), d1))
+            if p1 > d1:
+                parts.append(self._rows(pending, pend0, max(d1, pend0), p1))
+            start = min(ov0, max(p1, d0)) if ov1 > ov0 else max(p1, d0)
+            self.pending, self.pend0 = (parts[0] if len(parts) == 1 else self.dev.csr_vstack(parts)), start
+        else:
+            self.pending, self.pend0 = Kc, d0
+        p1 = self.pend0 + self.pending.shape[0]
+        cut = min(max(done_row, self.pend0), p1)
+        if cut > self.pend0:
+            self._emit(self.pending, self.pend0, self.pend0, cut)
+            self.pending = self._rows(self.pending, self.pend0, cut, p1) if cut < p1 else None
+            self.pend0 = cut
+
+    def finish(self):
+        if self.pending is not None:
+            self._emit(self.pending, self.pend0, self.pend0, self.pend0 + self.pending.shape[0])
+            self.pending = None
+        if self.emitted != self.g1:
+            raise RuntimeError("element chunks: rows %d .. %d of this rank were not produced" % (self.emitted, self.g1))
+        return self.single if self.builder is None else self.builder.finish()
+
+
 class _TensorDeclined(Exception):
     """the FE matrix does not have the element-coupling pattern the tensor-pattern PtAP needs"""
 
@@ -433,12 +502,35 @@ class SlabHotPath(object):
 
     def _assemble_by_elements(self, a_rows, b_rows, zero_dofs, diag, timers):
         """K_loc and (M^T b)_loc with M and A used as GENERAL sparse matrices (tIGAr/common.py:1194-1200): the element split
-        (``elemptap.ElementChunk``) over chunks of element layers of the slab direction, worked off from the bottom up.  A
-        chunk sees the FE rows of its own layers (M materialised for them, A from ``a_rows``), lists the layer below it for
-        the ownership rule, and gives the rows of K of its cells' functions; dof planes whose cells all lie in finished chunks
-        are final and go to the result, the top planes of a chunk are carried and added to the next chunk's rows.  Several
+        (``elemptap.ElementChunk``) over chunks of element layers of the slab direction, worked off from the bottom up
+        (``assemble_blocks_by_elements``), MatZeroRowsColumns on the finished rows.  Returns None when the FE space or the matrix
+        does not qualify (the row-wise stages take over)."""
+        import time
+        dev = self.dev
+        out = self.assemble_blocks_by_elements([a_rows], timers)
+        if out is None:
+            return None
+        K = out[0]
+        zero_dofs = np.asarray(zero_dofs if zero_dofs is not None else [], dtype=np.int32)
+        if zero_dofs.size and K.shape[0]:
+            t0 = time.perf_counter()
+            K.zero_rows_cols(zero_dofs, diag, self.mine["dofs"][0])
+            if timers is not None:
+                dev.sync()
+                timers["stack"] = timers.get("stack", 0.0) + time.perf_counter() - t0
+        rhs = self.assemble_vector(b_rows, zero_dofs, timers) if b_rows is not None else None
+        return K, rhs
+
+    def assemble_blocks_by_elements(self, producers, timers=None):
+        """Rows of this rank of M^T A_j M for SEVERAL FE matrices A_j on the scalar space (``producers[j](r0, r1)`` = FE rows
+        [r0, r1) of A_j as a DeviceCSR with global columns) -- the field blocks of a space with several fields on one basis.
+        Chunks of element layers from the bottom up: a chunk sees the FE rows of its own layers (M materialised for them, A_j
+        from the producers), lists the layer below it for the ownership rule, and its PLAN (function lists, incidence, pattern
+        and places of K: the costly half) is built once and serves every A_j; dof planes whose cells all lie in finished chunks
+        are final and go to the results, the top planes of a chunk are carried and added to the next chunk's rows.  Several
         ranks: every rank works off the layers in the support of ITS dof planes (the layers at a rank boundary twice: no
-        exchange).  Returns None when the FE space or the matrix does not qualify (the row-wise stages take over)."""
+        exchange).  No boundary conditions.  Returns the list of K_j, or None when the FE space or one of the matrices does not
+        qualify (the caller takes the row-wise stages)."""
         import time
         dev, lay, grid = self.dev, self.layout, self.grid
         from .elemptap import CellNodes, ElementChunk
@@ -451,52 +543,19 @@ class SlabHotPath(object):
             dev.sync()
             t[name] = t.get(name, 0.0) + time.perf_counter() - t0
 
-        zero_dofs = np.asarray(zero_dofs if zero_dofs is not None else [], dtype=np.int32)
         g0, g1 = self.mine["dofs"]
         ncols = self.ncp
         import scipy.sparse as sp
         if g1 <= g0:
-            rhs = self.assemble_vector(b_rows, zero_dofs, timers) if b_rows is not None else None
-            return dev.DeviceCSR.from_scipy(sp.csr_matrix((0, ncols))), rhs
+            return [dev.DeviceCSR.from_scipy(sp.csr_matrix((0, ncols))) for _ in producers]
         e_lo, e_hi, nel_z = self.elem_layers()
         nn = list(grid.shape())
         nel_other = [(n - 1) // q for n in nn[:-1]]
         cells_per_layer = int(np.prod(nel_other, dtype=np.int64)) if nel_other else 1
         pf, pd = lay.plane_fe, lay.plane_dofs
-        L = self._elem_chunk_layers(d, q, cells_per_layer, pf, pd, e_hi - e_lo)
+        L = self._elem_chunk_layers(d, q, cells_per_layer, pf, pd, e_hi - e_lo, len(producers))
         sp1, axes = self.basis.splines, grid.axes
-        builder, single = None, None
-        pending, pend0 = None, 0          # rows [pend0, pend0 + pending.shape[0]) of K: sums over the chunks so far
-        emitted = g0
-
-        def rows_of(Kb, base, r0, r1):
-            return Kb.block(r0 - base, r1 - base, 0, ncols)
-
-        def emit(Kb, base, r0, r1):
-            """rows [r0, r1) of the block Kb (whose first row is `base`) are final: those of this rank go to the result"""
-            nonlocal builder, single, emitted
-            r0, r1 = max(r0, g0, emitted), min(r1, g1)
-            if r1 <= r0:
-                return
-            assert r0 == emitted, "element chunks: rows must come in order"
-            blk = Kb if (r0 == base and r1 == base + Kb.shape[0]) else rows_of(Kb, base, r0, r1)
-            if os.environ.get("TIGAR_DEBUG"):
-                import sys
-                sys.stderr.write("[tigar] element chunks: rows %d..%d final, %d entries (block of %d rows from %d, %d entries)\n"
-                                 % (r0, r1, blk.nnz, Kb.shape[0], base, Kb.nnz))
-            if r0 == g0 and r1 == g1:
-                single = blk
-            else:
-                if builder is None:
-                    # capacity from the densest part of the first rows: their last dof plane (rows near the patch boundary are
-                    # shorter; a builder that has to grow allocates and copies K a second time -- 75 GB at 256^3 p = 3)
-                    nr = blk.shape[0]
-                    last = (blk.nnz - blk.rowptr_at(nr - pd)) / float(pd) if nr >= pd else blk.nnz / float(max(1, nr))
-                    est = int(max(blk.nnz / float(max(1, nr)), last) * (g1 - g0) * 1.01) + 1024
-                    builder = dev.CSRBuilder(g1 - g0, ncols, est)
-                builder.append(blk)
-            emitted = r1
-
+        acc = [_ChunkRows(dev, g0, g1, ncols, pd) for _ in producers]
         e0 = e_lo
         while e0 < e_hi:
             e1 = min(e_hi, e0 + L)
@@ -507,67 +566,40 @@ class SlabHotPath(object):
             M = dev.extract_csr_tensor(sp1, axes, 0, self.ncp, self.eps, r0, r1)
             tick("extract", t0)
             t0 = time.perf_counter()
-            A = a_rows(r0, r1)
-            tick("input", t0)
-            t0 = time.perf_counter()
             try:
                 chunk = ElementChunk(cells, M, r0, own=((e0 - f0) * cells_per_layer, (e1 - f0) * cells_per_layer))
             except ValueError:
                 return None
-            Kc = chunk.ptap(A, r0, (r0, r1 if e1 == nel_z else e1 * q * pf))
-            if Kc is None:
-                return None                      # an entry between nodes of no common cell: the row-wise stages
             d0, d1 = chunk.dofs
-            del chunk, A, M, cells
-            tick("ptap", t0)
-            t0 = time.perf_counter()
             # dof planes whose cells all lie below the top of this chunk are complete
             done_planes = int(np.searchsorted(lay.sup_hi, e1 * q + 1, side="right")) if e1 < nel_z else lay.ncp
-            done_row = done_planes * pd
-            if pending is not None:
-                p1 = pend0 + pending.shape[0]
-                if d0 > pend0:                                   # (rows below the new chunk: nothing more comes for them)
-                    emit(pending, pend0, pend0, min(d0, p1))
-                ov0, ov1 = max(d0, pend0), min(p1, d1)
-                parts = []
-                if ov1 > ov0:
-                    parts.append(rows_of(pending, pend0, ov0, ov1).add(rows_of(Kc, d0, ov0, ov1)))
-                if d1 > max(p1, d0):
-                    parts.append(rows_of(Kc, d0, max(p1, d0), d1))
-                if p1 > d1:
-                    parts.append(rows_of(pending, pend0, max(d1, pend0), p1))
-                start = min(ov0, max(p1, d0)) if ov1 > ov0 else max(p1, d0)
-                pending, pend0 = (parts[0] if len(parts) == 1 else dev.csr_vstack(parts)), start
-                del parts
-            else:
-                pending, pend0 = Kc, d0
-            del Kc
-            p1 = pend0 + pending.shape[0]
-            cut = min(max(done_row, pend0), p1)
-            if cut > pend0:
-                emit(pending, pend0, pend0, cut)
-                pending = rows_of(pending, pend0, cut, p1) if cut < p1 else None
-                pend0 = cut
-            tick("stack", t0)
+            tick("ptap", t0)
+            for j, a_rows in enumerate(producers):
+                t0 = time.perf_counter()
+                A = a_rows(r0, r1)
+                tick("input", t0)
+                t0 = time.perf_counter()
+                Kc = chunk.ptap(A, r0, (r0, r1 if e1 == nel_z else e1 * q * pf))
+                del A
+                if Kc is None:
+                    return None                  # an entry between nodes of no common cell: the row-wise stages
+                tick("ptap", t0)
+                t0 = time.perf_counter()
+                acc[j].add_chunk(Kc, d0, d1, done_planes * pd)
+                del Kc
+                tick("stack", t0)
+            del chunk, M, cells
             if os.environ.get("TIGAR_DEBUG"):
                 import sys
                 sys.stderr.write("[tigar] element chunk layers %d..%d of %d..%d: cumulative %s\n"
                                  % (e0, e1, e_lo, e_hi, {k_: round(v, 3) for k_, v in t.items()}))
             e0 = e1
         t0 = time.perf_counter()
-        if pending is not None:
-            emit(pending, pend0, pend0, pend0 + pending.shape[0])
-            pending = None
-        if emitted != g1:
-            raise RuntimeError("element chunks: rows %d .. %d of this rank were not produced" % (emitted, g1))
-        K = single if builder is None else builder.finish()
-        if zero_dofs.size:
-            K.zero_rows_cols(zero_dofs, diag, g0)
+        out = [a.finish() for a in acc]
         tick("stack", t0)
-        rhs = self.assemble_vector(b_rows, zero_dofs, timers) if b_rows is not None else None
-        return K, rhs
+        return out
 
-    def _elem_chunk_layers(self, d, q, cells_per_layer, pf, pd, nlayers):
+    def _elem_chunk_layers(self, d, q, cells_per_layer, pf, pd, nlayers, nblocks=1):
         """element layers per chunk of the element-split stage: blocks + places + lists of the layer's cells, q node planes of A
         and M, the chunk's rows of K (and their copies while chunks are added) in about 40 % of the free device memory"""
         if os.environ.get("TIGAR_ELEM_LAYERS"):
@@ -585,7 +617,9 @@ class SlabHotPath(object):
         per_node = ((2 * q + 1) ** d) * 0.55 * 12.0 + ((q + 1) ** d) * 12.0 * 1.2
         per_dof = ((2 * q + 1) ** d) * 12.0 * 3.0
         per_layer = cells_per_layer * per_cell + q * pf * per_node + pd * per_dof
-        fixed = pf * per_node + (q + 1) * pd * per_dof
+        # (several blocks on one plan: the carried planes of every block stay, and so do the blocks' finished rows -- K of the
+        #  whole rank per block; the caller's sub-slab sizing has subtracted those already where it knows them)
+        fixed = pf * per_node + nblocks * (q + 1) * pd * per_dof
         return int(max(1, min(nlayers, (0.4 * free_b - fixed) // per_layer)))
 
     def _assemble_pair(self, a_rows, col, timers=None, a_factors=None):
@@ -696,11 +730,13 @@ class SlabHotPath(object):
         if A_new is not None:
             cur, done = A_new, set()
             ca, cb = lay.fe_planes_coupled(new_lo, new_hi)
+            if not kx.box_kernels_safe(A_new, new_lo, new_hi):
+                ring["nobox"] = True           # (repeated knots + a matrix off the element-coupling pattern: see KronExtraction)
             for group in self.groups[:-1]:
                 after = done | set(group)
                 pl_out = kx.plane(after)
                 cur = contract(kx, cur, done, group, (new_lo, new_hi), (ca, cb), (new_lo * pl_out, new_hi * pl_out),
-                               intermediate=True)
+                               intermediate=True, box=not ring.get("nobox", False))
                 done = after
             ring["pieces"].append((new_lo, new_hi, cur))
             ring["hi"] = new_hi
@@ -718,7 +754,7 @@ class SlabHotPath(object):
         ca, cb = lay.fe_planes_coupled(lo, zb)
         pl_out = kx.plane(done | set(self.groups[-1]))
         return contract(kx, cur, done, self.groups[-1], (lo, zb), (ca, cb), (ka * pl_out, kb * pl_out), zero_dofs, diag,
-                        append_to=builder)
+                        append_to=builder, box=not ring.get("nobox", False))
 
     def solve(self, K, rhs, method="cg", pc="jacobi", rtol=1e-6, atol=1e-15, maxit=10000, restart=30, x0=None):
         dev = self.dev
@@ -867,19 +903,34 @@ class FieldSlabPath(object):
         dev, S, nF, pd = self.dev, self.scalar, self.nF, self.pd
         nloc1 = (self.k1 - self.k0) * pd
         import scipy.sparse as sp
+        empty = [[_block_is_empty(a_block, f, g, S.mine["a_rows"], S.layout.plane_fe,
+                                  block_factors[f][g] if block_factors is not None else None) for g in range(nF)] for f in range(nF)]
+        together = None
+        if not S.factored and os.environ.get("TIGAR_PTAP_ELEMENTS", "1") != "0":
+            # nothing assumed about M or A: ONE pass over the element chunks serves all coupled blocks (a chunk's plan is the
+            # costly half and depends on M only)
+            pairs = [(f, g) for f in range(nF) for g in range(nF) if not empty[f][g]]
+            outs = S.assemble_blocks_by_elements([(lambda r0, r1, f=f, g=g: a_block(f, g, r0, r1)) for f, g in pairs], timers) \
+                if pairs else []
+            if outs is not None:
+                together = dict(zip(pairs, outs))
         blocks = []
         for f in range(nF):
             row = []
             for g in range(nF):
                 fac = block_factors[f][g] if block_factors is not None else None
-                if _block_is_empty(a_block, f, g, S.mine["a_rows"], S.layout.plane_fe, fac):
+                if empty[f][g]:
                     # fields f and g are not coupled (on this rank's rows): no entries in this block of the product
                     row.append(dev.DeviceCSR.from_scipy(sp.csr_matrix((nloc1, self.ncp1))))
+                    continue
+                if together is not None:
+                    row.append(together[(f, g)])
                     continue
                 S._tensor_declined = False          # (every block is judged on its own pattern)
                 Kfg = S.assemble(lambda r0, r1, f=f, g=g: a_block(f, g, r0, r1), None, None, 1.0, timers, fac)[0]
                 row.append(Kfg)
             blocks.append(row)
+        del together
         K = dev.csr_from_blocks(blocks)            # rows (f, k - k0, ij) local, columns (g, k', ij') field-major
         del blocks
         nk = self.k1 - self.k0
