@@ -516,6 +516,14 @@ int tg_assemble_mapped_matrix_rows(const tg_patch_t *patch, int form, int64_t ro
                                    tg_csr_t *out);
 int tg_assemble_mapped_load_rows(const tg_patch_t *patch, tg_vec_t fnodal, int64_t row0, int64_t row1, int64_t cp_node0,
                                  tg_vec_t out);
+/* Block (fi, fj) of linear elasticity a(u,v) = int lambda div u div v + 2 mu eps(u):eps(v) dx on the mapped patch, u, v in
+ * the d-field space on the patch's node grid (nsd == d): lambda (d_fi phi_a, d_fj phi_b) + mu (d_fj phi_a, d_fi phi_b)
+ * + delta mu (grad phi_a, grad phi_b) with the Cartesian derivatives of spline.grad / spline.div (tIGAr/common.py:1022-1040,
+ * calculusUtils.py:255-276) -- what dolfin.assemble gives for inner(sigma(u), eps(v))*spline.dx restricted to test
+ * component fi, trial component fj.  Rows and control-function window as tg_assemble_mapped_matrix_rows
+ * (row0 = row1 = -1: the whole block); same pattern, same kernels (the coefficient tensor per point is not symmetric). */
+int tg_assemble_mapped_elasticity_rows(const tg_patch_t *patch, int fi, int fj, double lambda, double mu, int64_t row0,
+                                       int64_t row1, int64_t cp_node0, tg_csr_t *out);
 
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------- */
 int tg_comm_unique_id(char *id128);                          /* ncclGetUniqueId   */

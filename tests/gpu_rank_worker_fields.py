@@ -39,6 +39,22 @@ def problem(case, comm):
         K = spline.assembleMatrix(F.ElasticityForm(2.0, 1.0), diag=1.5)
         rhs = spline.extractVector(hashed(spline.V.dim(), 79))
         return gen, spline, K, rhs, "gmres"
+    if case == "mapped_elasticity3d":
+        # three displacement fields on a rational volume (a NURBS control mesh): ElasticityForm(geometry=...) hands out row
+        # blocks of its nine field blocks from the element kernels, on the control-function window of the rank's slab
+        from tigar_amd import NURBS
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from geom_util import rational_volume
+        p = int(os.environ.get("TIGAR_TEST_FP", 2))
+        nels = [int(v) for v in os.environ["TIGAR_TEST_FNELS"].split(",")] if os.environ.get("TIGAR_TEST_FNELS") else [4, 3, 7]
+        kvs, C = rational_volume(p, nels)
+        gen = t.EqualOrderSpline(comm, 3, NURBS.NURBSControlMesh([p] * 3, kvs, C))
+        for f in range(3):
+            gen.addZeroDofs(f, gen.getScalarSpline(f).getSideDofs(2, 0))
+        spline = t.ExtractedSpline(gen, 2 * p)
+        K = spline.assembleMatrix(F.ElasticityForm(2.0, 1.0, geometry=gen), diag=1.5)
+        rhs = spline.extractVector(hashed(spline.V.dim(), 80))
+        return gen, spline, K, rhs, "cg"
     if case == "shell2d":            # cfg5-like: 2-D p=3, three fields, hashed non-symmetric A on the 3-field pattern
         d, p, nel, nF, method = 2, 3, 14, 3, "gmres"
     else:                            # 3-D elasticity, p=2, three fields (ElasticityForm: blocks as Kronecker sums)

@@ -210,7 +210,8 @@ def test_unequal_directions_on_several_ranks(tmp_path, p, nels, periodic, world,
     _compare(parts, ref, world, "ipc", its_slack=6 if method == "bicgstab" else 1)
 
 
-@pytest.mark.parametrize("case,world,kind", [("shell2d", 2, "ipc"), ("elasticity3d", 3, "ipc"), ("shell2d", 3, "host")])
+@pytest.mark.parametrize("case,world,kind", [("shell2d", 2, "ipc"), ("elasticity3d", 3, "ipc"), ("shell2d", 3, "host"),
+                                             ("mapped_elasticity3d", 2, "ipc"), ("mapped_elasticity3d", 3, "ipc")])
 def test_several_fields_on_several_ranks(tmp_path, case, world, kind):
     _several_fields(tmp_path, case, world, kind, {})
 

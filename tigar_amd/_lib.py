@@ -193,6 +193,8 @@ PROTOTYPES = {
     "tg_assemble_mapped_matrix_rows": (C.c_int, [C.POINTER(tg_patch_t), C.c_int, C.c_int64, C.c_int64, C.c_int64,
                                                   C.POINTER(handle)]),
     "tg_assemble_mapped_load_rows": (C.c_int, [C.POINTER(tg_patch_t), handle, C.c_int64, C.c_int64, C.c_int64, handle]),
+    "tg_assemble_mapped_elasticity_rows": (C.c_int, [C.POINTER(tg_patch_t), C.c_int, C.c_int, C.c_double, C.c_double,
+                                                      C.c_int64, C.c_int64, C.c_int64, C.POINTER(handle)]),
     "tg_comm_unique_id": (C.c_int, [C.c_char_p]),
     "tg_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(handle)]),
     "tg_comm_create2": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(handle)]),

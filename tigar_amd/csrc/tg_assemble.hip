@@ -9,6 +9,11 @@
 //     mass      a(u,v) = int u v sqrt(det g) dxi
 //     laplace   a(u,v) = int (grad_xi u)^T g^-1 (grad_xi v) sqrt(det g) dxi   (= grad_x u . grad_x v dx)
 //     load      L(v)   = int f_h v sqrt(det g) dxi,  f_h the nodal interpolant of given node values
+//     elasticity, block (i, j) of a(u,v) = int lambda div u div v + 2 mu eps(u):eps(v) dx on the d-field space (nsd == d):
+//               lambda int d_i phi_a d_j phi_b + mu int d_j phi_a d_i phi_b + delta_ij mu int grad phi_a . grad phi_b
+//               with d_i = sum_k Jinv[k][i] d/dxi_k (spline.grad / spline.div, tIGAr/common.py:1022-1040,
+//               calculusUtils.py:255-276), i.e. the Laplace integrand with the NON-symmetric coefficient tensor
+//               C_km = w |det DF| (lambda Jinv[k][i] Jinv[m][j] + mu Jinv[k][j] Jinv[m][i] + delta_ij mu g^-1[k][m])
 // nsd >= d is allowed (surfaces in 3-D: Laplace-Beltrami), geometry is rational (quotient rule).
 //
 // One workgroup per element: local control values and the 1-D Lagrange tables go to LDS, one
@@ -30,7 +35,9 @@ struct tg_asm_args {
   const double *verts[3];      // device: element vertices
   const double *cp[4];         // device: nsd+1 control functions on the node grid
   const double *tab;           // device: l[a][q] (p+1)*nq | dl[a][q] (p+1)*nq | w[q] nq   (reference element [0,1])
-  int form;                    // 0 mass, 1 laplace, 2 load
+  int form;                    // 0 mass, 1 laplace, 2 load, 3 block (ei, ej) of the elasticity form
+  int ei, ej;
+  double lam, mu;
   const int64_t *rowptr;       // pattern (matrix forms)
   double *val;
   const double *fnod;          // load: nodal values
@@ -141,9 +148,9 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
     }
     // DF[i][k] = d(N_i / W)/dxi_k ; metric g = DF^T DF
     const double W = N[P.nsd];
-    double g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, DF[3][3] = {{0}};
     for (int i = 0; i < P.nsd; i++) {
-      double df[3];
+      double *df = DF[i];
       for (int k = 0; k < d; k++) df[k] = (dN[i][k] * W - N[i] * dN[P.nsd][k]) / (W * W);
       for (int k = 0; k < d; k++)
         for (int m = 0; m < d; m++) g[k * d + m] += df[k] * df[m];
@@ -153,7 +160,21 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
     double wq = 1.0;
     for (int k = 0; k < d; k++) wq *= tw[qk[k]] * h[k];
     const double s = wq * sqrt(fabs(det));
-    for (int k = 0; k < d * d; k++) G[(size_t)q * 9 + k] = s * gi[k];
+    if (P.form == 3) {
+      // Jinv[k][i] = d xi_k / d x_i = (g^-1 DF^T)[k][i]   (nsd == d: checked on the host)
+      double ji[3] = {0, 0, 0}, jj[3] = {0, 0, 0};
+      for (int k = 0; k < d; k++)
+        for (int m = 0; m < d; m++) {
+          ji[k] += gi[k * d + m] * DF[P.ei][m];
+          jj[k] += gi[k * d + m] * DF[P.ej][m];
+        }
+      for (int k = 0; k < d; k++)
+        for (int m = 0; m < d; m++)
+          G[(size_t)q * 9 + k * d + m] =
+              s * (P.lam * ji[k] * jj[m] + P.mu * jj[k] * ji[m] + (P.ei == P.ej ? P.mu * gi[k * d + m] : 0.0));
+    } else {
+      for (int k = 0; k < d * d; k++) G[(size_t)q * 9 + k] = s * gi[k];
+    }
     S[q] = (P.form == 2) ? s * fh : s;
   }
   __syncthreads();
@@ -292,6 +313,8 @@ struct tg_asf_args {
   int chunk, nchunks;        // matrix: elements per piece of a line, pieces per line
   int ngy;                   // groups of EPW lines (matrix) / EPW elements along direction 0 (load)
   int64_t ngroups;
+  int ei, ej;                // elasticity: the block
+  double lam, mu;
 };
 
 __device__ __forceinline__ void tg_wave_sync() {
@@ -407,6 +430,67 @@ __device__ __forceinline__ void tg_asf_metric(const double *N, const double (*dN
   G[6] = s;
 }
 
+// block (ei, ej) of the elasticity form: the coefficient tensor C[k][m] (G[3 k + m], row index k = derivative of the TEST
+// function) = w |det DF| (lambda Jinv[k][ei] Jinv[m][ej] + mu Jinv[k][ej] Jinv[m][ei] + delta mu sum_l Jinv[k][l] Jinv[m][l]),
+// Jinv = DF^-1 by cofactors
+__device__ __forceinline__ void tg_asf_elast(const double *N, const double (*dN)[3], double w, int ei, int ej, double lam,
+                                             double mu, double *G) {
+  const double Wt = N[3];
+  double F[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) F[i][k] = (dN[i][k] * Wt - N[i] * dN[3][k]) / (Wt * Wt);
+  // J[k][i] = cofactor(F)[i][k] / det
+  double J[3][3];
+  J[0][0] = F[1][1] * F[2][2] - F[1][2] * F[2][1];
+  J[0][1] = F[0][2] * F[2][1] - F[0][1] * F[2][2];
+  J[0][2] = F[0][1] * F[1][2] - F[0][2] * F[1][1];
+  J[1][0] = F[1][2] * F[2][0] - F[1][0] * F[2][2];
+  J[1][1] = F[0][0] * F[2][2] - F[0][2] * F[2][0];
+  J[1][2] = F[0][2] * F[1][0] - F[0][0] * F[1][2];
+  J[2][0] = F[1][0] * F[2][1] - F[1][1] * F[2][0];
+  J[2][1] = F[0][1] * F[2][0] - F[0][0] * F[2][1];
+  J[2][2] = F[0][0] * F[1][1] - F[0][1] * F[1][0];
+  const double det = F[0][0] * J[0][0] + F[0][1] * J[1][0] + F[0][2] * J[2][0];
+  const double rd = 1.0 / det;
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int i = 0; i < 3; i++) J[k][i] *= rd;
+  const double s = w * fabs(det);
+  // (ei, ej are wave-uniform: selects, no indexed register access)
+  double ji[3], jj[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    ji[k] = ei == 0 ? J[k][0] : (ei == 1 ? J[k][1] : J[k][2]);
+    jj[k] = ej == 0 ? J[k][0] : (ej == 1 ? J[k][1] : J[k][2]);
+  }
+  const double dm = ei == ej ? mu : 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+      const double gkm = J[k][0] * J[m][0] + J[k][1] * J[m][1] + J[k][2] * J[m][2];
+      G[3 * k + m] = s * (lam * ji[k] * jj[m] + mu * jj[k] * ji[m] + dm * gkm);
+    }
+}
+
+// X_k = sum_m C_km f_m at one quadrature point: FORM 1 -- the symmetric tensor of tg_asf_metric (6 values), FORM 2 -- the full
+// tensor of tg_asf_elast (9 values)
+template <int FORM>
+__device__ __forceinline__ void tg_asf_flux(const double *Gq, double f0, double f1, double f2, double &X0, double &X1, double &X2) {
+  if (FORM == 2) {
+    X0 = fma(Gq[2], f2, fma(Gq[1], f1, Gq[0] * f0));
+    X1 = fma(Gq[5], f2, fma(Gq[4], f1, Gq[3] * f0));
+    X2 = fma(Gq[8], f2, fma(Gq[7], f1, Gq[6] * f0));
+  } else {
+    X0 = fma(Gq[2], f2, fma(Gq[1], f1, Gq[0] * f0));
+    X1 = fma(Gq[4], f2, fma(Gq[3], f1, Gq[1] * f0));
+    X2 = fma(Gq[5], f2, fma(Gq[4], f1, Gq[2] * f0));
+  }
+}
+
 // 1-D row data of node a of element e (direction with nel elements): vertex shared with a neighbour?, row length,
 // position of the element's first column in the row, entries of the 1-D rows before the node
 template <int P>
@@ -421,6 +505,7 @@ template <int P1, int EPW, int FORM>
 __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3(tg_asf_args A) {
   constexpr int P = P1 - 1, NL = P1 * P1 * P1, LPE = 64 / EPW, PP = P1 * P1;
   constexpr int AH = P1;                 // (rows of the first local index a0 handled at once: all)
+  constexpr int GS = FORM == 2 ? 10 : 8, GN = FORM == 2 ? 9 : 7;     // doubles per quadrature point in LDS: stride, values
   static_assert(NL <= LPE, "an element needs a lane per local node");
   __shared__ __attribute__((aligned(16))) double s_tab[2 * PP + P1];
   __shared__ __attribute__((aligned(16))) double s_w[TG_ASF_NW][TG_ASF_AREA(4)];
@@ -484,13 +569,20 @@ __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3(tg_asf_args A) {
       for (int c = 0; c < 4; c++) cpn[c] = active ? A.cp[c][nodebase + (int64_t)(e0 + 1) * P] : 0.0;
     }
     {
-      double N[4], dN[4][3], G[7] = {0, 0, 0, 0, 0, 0, 0};
+      double N[4], dN[4][3], G[GN];
+#pragma unroll
+      for (int j = 0; j < GN; j++) G[j] = 0.0;
       tg_asf_to_points<P1, 4>(W, TL, TD, ln, eb, x0, x1, x2, active, N, dN);
-      if (active) tg_asf_metric(N, dN, TW[x0] * TW[x1] * TW[x2], G);
+      if (active) {
+        if constexpr (FORM == 2)
+          tg_asf_elast(N, dN, TW[x0] * TW[x1] * TW[x2], A.ei, A.ej, A.lam, A.mu, G);
+        else
+          tg_asf_metric(N, dN, TW[x0] * TW[x1] * TW[x2], G);
+      }
       tg_wave_sync();      // (the area of the nodal values is free: nobody reads it any more)
       if (active) {
 #pragma unroll
-        for (int j = 0; j < 7; j++) W[(eb + li) * 8 + j] = G[j];
+        for (int j = 0; j < GN; j++) W[(eb + li) * GS + j] = G[j];
       }
       tg_wave_sync();
     }
@@ -525,18 +617,17 @@ __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3(tg_asf_args A) {
 #pragma unroll
           for (int q1 = 0; q1 < P1; q1++) {
             const double l1q = TL[x1 * P1 + q1], d1q = TD[x1 * P1 + q1];
-            if (FORM == 1) {
+            if (FORM >= 1) {
               const double mll = l1q * l2q, mdl = d1q * l2q, mld = l1q * d2q;
               double Y0[AH], Y1[AH], Y2[AH];
 #pragma unroll
               for (int a = 0; a < AH; a++) Y0[a] = Y1[a] = Y2[a] = 0.0;
 #pragma unroll
               for (int q0 = 0; q0 < P1; q0++) {
-                const double *Gq = Wh + (eb + q0 + P1 * (q1 + P1 * q2)) * 8;
+                const double *Gq = Wh + (eb + q0 + P1 * (q1 + P1 * q2)) * GS;
                 const double f0 = d0[q0] * mll, f1 = l0[q0] * mdl, f2 = l0[q0] * mld;
-                const double X0 = fma(Gq[2], f2, fma(Gq[1], f1, Gq[0] * f0));
-                const double X1 = fma(Gq[4], f2, fma(Gq[3], f1, Gq[1] * f0));
-                const double X2 = fma(Gq[5], f2, fma(Gq[4], f1, Gq[2] * f0));
+                double X0, X1, X2;
+                tg_asf_flux<FORM>(Gq, f0, f1, f2, X0, X1, X2);
 #pragma unroll
                 for (int a = 0; a < AH; a++) {
                   Y0[a] = fma(UD[a * P1 + q0], X0, Y0[a]);
@@ -573,7 +664,7 @@ __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3(tg_asf_args A) {
           for (int a2 = 0; a2 < P1; a2++)
 #pragma unroll
             for (int i = 0; i < AH * P1; i++) {
-              if (FORM == 1)
+              if (FORM >= 1)
                 acc[i + AH * P1 * a2] = fma(UD[a2 * P1 + q2], Zd[i], fma(UL[a2 * P1 + q2], Zl[i], acc[i + AH * P1 * a2]));
               else
                 acc[i + AH * P1 * a2] = fma(UL[a2 * P1 + q2], Zl[i], acc[i + AH * P1 * a2]);
@@ -594,7 +685,7 @@ __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3(tg_asf_args A) {
       const unsigned uT0 = (unsigned)T0;
       if (!carry_only) {
         // (p = 3, stiffness: the registers hold the reads of ONE a2 layer of rows at a time -- four round trips per element)
-        constexpr bool LAYERED = FORM == 1 && P1 == 4;
+        constexpr bool LAYERED = FORM >= 1 && P1 == 4;
         constexpr int NPASS = LAYERED ? P1 : 1;
         double old[(LAYERED ? P1 : PP) * (AH + 1)];
 #pragma unroll
@@ -687,6 +778,7 @@ __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3(tg_asf_args A) {
 template <int P1, int EPW, int FORM>
 __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3_elem(tg_asf_args A) {
   constexpr int P = P1 - 1, NL = P1 * P1 * P1, LPE = 64 / EPW, PP = P1 * P1;
+  constexpr int GS = FORM == 2 ? 10 : 8, GN = FORM == 2 ? 9 : 7;
   static_assert(NL <= LPE, "an element needs a lane per local node");
   __shared__ __attribute__((aligned(16))) double s_tab[2 * PP + P1];
   __shared__ __attribute__((aligned(16))) double s_w[TG_ASF_NW][TG_ASF_AREA(4)];
@@ -717,13 +809,20 @@ __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3_elem(tg_asf_args A) {
   }
   tg_wave_sync();
   {
-    double N[4], dN[4][3], G[7] = {0, 0, 0, 0, 0, 0, 0};
+    double N[4], dN[4][3], G[GN];
+#pragma unroll
+    for (int j = 0; j < GN; j++) G[j] = 0.0;
     tg_asf_to_points<P1, 4>(W, TL, TD, lane, eb, x0, x1, x2, active, N, dN);
-    if (active) tg_asf_metric(N, dN, TW[x0] * TW[x1] * TW[x2], G);
+    if (active) {
+      if constexpr (FORM == 2)
+        tg_asf_elast(N, dN, TW[x0] * TW[x1] * TW[x2], A.ei, A.ej, A.lam, A.mu, G);
+      else
+        tg_asf_metric(N, dN, TW[x0] * TW[x1] * TW[x2], G);
+    }
     tg_wave_sync();
     if (active) {
 #pragma unroll
-      for (int j = 0; j < 7; j++) W[(eb + li) * 8 + j] = G[j];
+      for (int j = 0; j < GN; j++) W[(eb + li) * GS + j] = G[j];
     }
     tg_wave_sync();
   }
@@ -747,18 +846,17 @@ __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3_elem(tg_asf_args A) {
 #pragma unroll
       for (int q1 = 0; q1 < P1; q1++) {
         const double l1q = TL[x1 * P1 + q1], d1q = TD[x1 * P1 + q1];
-        if (FORM == 1) {
+        if (FORM >= 1) {
           const double mll = l1q * l2q, mdl = d1q * l2q, mld = l1q * d2q;
           double Y0[P1], Y1[P1], Y2[P1];
 #pragma unroll
           for (int a = 0; a < P1; a++) Y0[a] = Y1[a] = Y2[a] = 0.0;
 #pragma unroll
           for (int q0 = 0; q0 < P1; q0++) {
-            const double *Gq = W + (eb + q0 + P1 * (q1 + P1 * q2)) * 8;
+            const double *Gq = W + (eb + q0 + P1 * (q1 + P1 * q2)) * GS;
             const double f0 = d0[q0] * mll, f1 = l0[q0] * mdl, f2 = l0[q0] * mld;
-            const double X0 = fma(Gq[2], f2, fma(Gq[1], f1, Gq[0] * f0));
-            const double X1 = fma(Gq[4], f2, fma(Gq[3], f1, Gq[1] * f0));
-            const double X2 = fma(Gq[5], f2, fma(Gq[4], f1, Gq[2] * f0));
+            double X0, X1, X2;
+            tg_asf_flux<FORM>(Gq, f0, f1, f2, X0, X1, X2);
 #pragma unroll
             for (int a = 0; a < P1; a++) {
               Y0[a] = fma(UD[a * P1 + q0], X0, Y0[a]);
@@ -794,7 +892,7 @@ __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3_elem(tg_asf_args A) {
       for (int a2 = 0; a2 < P1; a2++)
 #pragma unroll
         for (int i = 0; i < PP; i++) {
-          if (FORM == 1)
+          if (FORM >= 1)
             acc[i + PP * a2] = fma(UD[a2 * P1 + q2], Zd[i], fma(UL[a2 * P1 + q2], Zl[i], acc[i + PP * a2]));
           else
             acc[i + PP * a2] = fma(UL[a2 * P1 + q2], Zl[i], acc[i + PP * a2]);
@@ -918,7 +1016,11 @@ static inline int64_t tg_rps_host(int p, int a) { return (int64_t)(p + 1) * a + 
 
 template <int P1, int EPW>
 static void tg_asf_launch(int form, const tg_asf_args &A, unsigned nblk, bool walk) {
-  if (!walk && form == 1)
+  if (!walk && form == 3)
+    hipLaunchKernelGGL((k_asf3_elem<P1, EPW, 2>), dim3(nblk), dim3(64 * TG_ASF_NW), 0, g_tg.stream, A);
+  else if (form == 3)
+    hipLaunchKernelGGL((k_asf3<P1, EPW, 2>), dim3(nblk), dim3(64 * TG_ASF_NW), 0, g_tg.stream, A);
+  else if (!walk && form == 1)
     hipLaunchKernelGGL((k_asf3_elem<P1, EPW, 1>), dim3(nblk), dim3(64 * TG_ASF_NW), 0, g_tg.stream, A);
   else if (!walk && form == 0)
     hipLaunchKernelGGL((k_asf3_elem<P1, EPW, 0>), dim3(nblk), dim3(64 * TG_ASF_NW), 0, g_tg.stream, A);
@@ -1002,8 +1104,13 @@ static int tg_asm_cache_get(const tg_patch_t *pt) {
 
 // rows [row0, row1) of the matrix / vector -- whole node planes of the LAST direction (any range when d == 1); the control
 // functions (and fnod) hold the nodes [cp_node0, cp_node0 + n), which must cover every element that touches the rows
+struct tg_elast_block {
+  int i, j;
+  double lam, mu;
+};
+
 static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int64_t row1, int64_t cp_node0, tg_csr_t *mout,
-                              tg_vec_t fnod, tg_vec_t bout) {
+                              tg_vec_t fnod, tg_vec_t bout, const tg_elast_block *eb = nullptr) {
   TG_REQUIRE_INIT();
   TG_REQUIRE(pt && pt->d >= 1 && pt->d <= 3 && pt->p >= 1 && pt->p <= TG_MAX_DEGREE && pt->nsd >= pt->d && pt->nsd <= 3,
              "bad patch description");
@@ -1022,6 +1129,14 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
   A.nsd = pt->nsd;
   A.nq = pt->nq;
   A.form = form;
+  if (form == 3) {
+    TG_REQUIRE(eb && pt->nsd == pt->d && eb->i >= 0 && eb->i < pt->d && eb->j >= 0 && eb->j < pt->d,
+               "elasticity block (i, j): as many physical as parametric directions (nsd == d = %d), 0 <= i, j < d", pt->d);
+    A.ei = eb->i;
+    A.ej = eb->j;
+    A.lam = eb->lam;
+    A.mu = eb->mu;
+  }
   int64_t nnodes = 1, plane = 1;
   for (int k = 0; k < 3; k++) {
     A.nel[k] = 1;
@@ -1143,6 +1258,10 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
     if (chunk < 1) chunk = 1;
     F.chunk = chunk;
     F.nchunks = (A.nel[0] + chunk - 1) / chunk;
+    F.ei = A.ei;
+    F.ej = A.ej;
+    F.lam = A.lam;
+    F.mu = A.mu;
   }
   const int nt = (form == 2) ? 128 : 256;
   bool bad = false;
@@ -1152,7 +1271,7 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
   // one launch per colour (parity of the element index per direction), colours in ascending order; the walks of the
   // sum-factorised matrix kernel need no colouring in direction 0
   // the walk along direction 0 for every matrix form but the p = 3 stiffness matrix (see k_asf3_elem); TIGAR_ASM_WALK=0/1 forces
-  bool walk = fast && form != 2 && !(p == 3 && form == 1) && p != 1;
+  bool walk = fast && form != 2 && !(p == 3 && (form == 1 || form == 3)) && p != 1;
   if (fast && form != 2 && getenv("TIGAR_ASM_WALK")) walk = atoi(getenv("TIGAR_ASM_WALK")) != 0;
   for (int c = 0; c < (1 << d) && !bad && zb > za; c++) {
     if (walk && (c & 1)) continue;
@@ -1221,6 +1340,13 @@ extern "C" int tg_assemble_mapped_matrix_rows(const tg_patch_t *patch, int form,
                                               tg_csr_t *out) {
   TG_REQUIRE(out && (form == 0 || form == 1), "form: 0 = mass, 1 = laplace");
   return tg_assemble_common(patch, form, row0, row1, cp_node0, out, nullptr, nullptr);
+}
+
+extern "C" int tg_assemble_mapped_elasticity_rows(const tg_patch_t *patch, int fi, int fj, double lambda, double mu, int64_t row0,
+                                                  int64_t row1, int64_t cp_node0, tg_csr_t *out) {
+  TG_REQUIRE(out, "null output");
+  const tg_elast_block eb = {fi, fj, lambda, mu};
+  return tg_assemble_common(patch, 3, row0, row1, cp_node0, out, nullptr, nullptr, &eb);
 }
 
 extern "C" int tg_assemble_mapped_load_rows(const tg_patch_t *patch, tg_vec_t fnodal, int64_t row0, int64_t row1,

@@ -880,6 +880,17 @@ def assemble_mapped_matrix(vertices, p, cp, form, nq=None, row0=None, row1=None,
     return DeviceCSR(h)
 
 
+def assemble_mapped_elasticity_block(vertices, p, cp, i, j, lmbda, mu, nq=None, row0=None, row1=None, cp_node0=0):
+    """Block (i, j) (test component i, trial component j) of a(u,v) = int lambda div u div v + 2 mu eps(u):eps(v) dx on the
+    mapped patch (nsd == d), rows / window as ``assemble_mapped_matrix`` (``tg_assemble_mapped_elasticity_rows``)."""
+    pt, keep = _patch(vertices, p, cp, p + 1 if nq is None else nq)
+    h = handle()
+    r0, r1 = (-1, -1) if (row0 is None and row1 is None) else (int(row0), int(row1))
+    check(_lib.lib().tg_assemble_mapped_elasticity_rows(C.byref(pt), int(i), int(j), float(lmbda), float(mu), r0, r1,
+                                                        int(cp_node0), C.byref(h)), "tg_assemble_mapped_elasticity_rows")
+    return DeviceCSR(h)
+
+
 def assemble_mapped_load(vertices, p, cp, fnodal, nq=None, row0=None, row1=None, cp_node0=0):
     """L(v) = int f_h v dx with f_h the nodal interpolant of the DeviceVector ``fnodal`` (on the nodes of ``cp``)."""
     pt, keep = _patch(vertices, p, cp, p + 1 if nq is None else nq)

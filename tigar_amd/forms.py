@@ -179,26 +179,35 @@ def _control_window(geometry, plane, fa, fb):
     return gen.controlFunctionWindow(fa, fb), fa * plane
 
 
-def _mapped(geometry, V, form, row0=None, row1=None):
+def _mapped(geometry, V, form, row0=None, row1=None, grid=None, block=None):
     """dolfin.assemble stand-in on a mapped patch: ``geometry`` is a generator / ExtractedSpline
     whose ``cpFuncs`` (nsd+1 homogeneous control functions on the FE nodes of ``V_control``) define
     F = cpFuncs[i]/cpFuncs[nsd] (tIGAr/common.py:917-921); metric-based measure and gradient.  ``row0, row1``: the FE
-    rows of a block only (global columns), as the z-slab pipeline asks for them."""
-    g = _single_grid(V)
+    rows of a block only (global columns), as the z-slab pipeline asks for them.  ``form`` "elasticity": ``block`` =
+    (i, j, lambda, mu), ``grid`` the node grid the fields share."""
+    g = _single_grid(V) if grid is None else grid
     gc = _single_grid(geometry.V_control)
     if gc.shape() != g.shape():
         raise ValueError("the geometry lives on a different node grid than the space")
     verts = [g.vertices[k] for k in range(g.dim())]
     n = g.num_nodes()
+
+    def assemble(cp, **rows):
+        if form == "elasticity":
+            if len(cp) - 1 != g.dim():
+                raise ValueError("the elasticity form needs as many physical as parametric directions")
+            return _dev.assemble_mapped_elasticity_block(verts, g.degree, cp, block[0], block[1], block[2], block[3], **rows)
+        return _dev.assemble_mapped_matrix(verts, g.degree, cp, form, **rows)
+
     row0, row1 = (0 if row0 is None else int(row0)), (n if row1 is None else int(row1))       # (either may be left out)
     if (row0, row1) == (0, n):
         cp, node0 = _control_window(geometry, 1, 0, g.shape()[-1])
         if node0 == 0 and all(v.size() == n for v in cp):
-            return _dev.assemble_mapped_matrix(verts, g.degree, cp, form)
+            return assemble(cp)
         row0, row1 = 0, n
     plane, za, zb, fa, fb = _plane_window(g, row0, row1)
     cp, node0 = _control_window(geometry, plane, fa, fb)
-    A = _dev.assemble_mapped_matrix(verts, g.degree, cp, form, row0=za * plane, row1=zb * plane, cp_node0=node0)
+    A = assemble(cp, row0=za * plane, row1=zb * plane, cp_node0=node0)
     if (za * plane, zb * plane) != (int(row0), int(row1)):           # (a range that cuts through node planes)
         A = A.block(int(row0) - za * plane, int(row1) - za * plane, 0, n)
     return A
@@ -234,12 +243,18 @@ class ElasticityForm(object):
     block (i, j) = lambda int d_i phi_a d_j phi_b + mu int d_j phi_a d_i phi_b + delta_ij mu int grad phi_a . grad phi_b,
     each a Kronecker sum of 1-D factors (mass M, stiffness K, G[a,b] = int phi_a' phi_b) on the element-coupling pattern,
     written block by block by the Kronecker-sum kernel and put together on the device.  What a dolfin user writes as
-    ``inner(sigma(u), eps(v))*dx`` for ``demos``-style linear elasticity on an identity-geometry patch."""
+    ``inner(sigma(u), eps(v))*dx`` for ``demos``-style linear elasticity on an identity-geometry patch.
 
-    def __init__(self, lmbda=1.0, mu=1.0):
+    With ``geometry`` (a generator or ExtractedSpline with nsd == d): in physical space on the mapped patch --
+    ``inner(sigma(u), spline.sym(spline.grad(v)))*spline.dx`` with the Cartesian derivatives of ``spline.grad`` /
+    ``spline.div`` (tIGAr/common.py:1022-1040, calculusUtils.py:255-276); each block from the element kernels of
+    csrc/tg_assemble.hip (no Kronecker factors: the PtAP takes the assembled blocks)."""
+
+    def __init__(self, lmbda=1.0, mu=1.0, geometry=None):
         # a(u, v) = a(v, u) for THIS class; a subclass that adds terms says so itself (ADVICE r5: not inherited)
         self.symmetric = type(self) is ElasticityForm
         self.lmbda, self.mu = float(lmbda), float(mu)
+        self.geometry = geometry
 
     def _grid(self, V):
         g = V.grids[0]
@@ -249,7 +264,10 @@ class ElasticityForm(object):
         return g
 
     def block_factors(self, V):
-        """factors[i][j] = list of terms, each a list of d 1-D matrices (direction 0 first)"""
+        """factors[i][j] = list of terms, each a list of d 1-D matrices (direction 0 first); None on a mapped patch"""
+        if self.geometry is not None:
+            return None
+
         def build():
             g = self._grid(V)
             d = g.dim()
@@ -275,11 +293,16 @@ class ElasticityForm(object):
 
     def assemble_block(self, V, i, j, row0=None, row1=None):
         """rows [row0, row1) of block (i, j) (fields i, j; columns of one field)"""
+        if self.geometry is not None:
+            return _mapped(self.geometry, V, "elasticity", row0, row1, grid=self._grid(V), block=(i, j, self.lmbda, self.mu))
         return _dev.kron_sum_csr(self.block_factors(V)[i][j], row0, row1)
 
     def assemble_matrix(self, V, row0=None, row1=None):
         if row0 is not None or row1 is not None:
             raise NotImplementedError("row blocks of the elasticity form: use assemble_block")
+        if self.geometry is not None:
+            d = self._grid(V).dim()
+            return _dev.csr_from_blocks([[self.assemble_block(V, i, j) for j in range(d)] for i in range(d)])
         fac = self.block_factors(V)
         d = len(fac)
         return _dev.csr_from_blocks([[_dev.kron_sum_csr(fac[i][j]) for j in range(d)] for i in range(d)])

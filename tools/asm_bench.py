@@ -1,6 +1,6 @@
 """developer tool: the mapped FE assembly alone (pattern kernel + element kernel) on a rational volume map.
 
-    python tools/asm_bench.py [p] [nel] [form] [reps]
+    python tools/asm_bench.py [p] [nel] [form] [reps]          form: laplace | mass | elast<i><j> (block of the elasticity form)
 """
 import os
 import sys
@@ -28,13 +28,16 @@ def main():
     for r in range(reps + 1):
         dev.sync()
         t0 = time.perf_counter()
-        A = dev.assemble_mapped_matrix(uks, p, cp, form)
+        if form.startswith("elast"):
+            A = dev.assemble_mapped_elasticity_block(uks, p, cp, int(form[5]), int(form[6]), 1.3, 0.7)
+        else:
+            A = dev.assemble_mapped_matrix(uks, p, cp, form)
         dev.sync()
         dt = time.perf_counter() - t0
         nnz = A.nnz
         del A
         if r:
-            fl = {"laplace": {1: 0, 2: 0, 3: 2 * 184e3}.get(p, 0), "mass": 0}[form]
+            fl = {"laplace": {1: 0, 2: 0, 3: 2 * 184e3}.get(p, 0), "mass": 0}.get(form, 0)
             print("p=%d nel=%d %s: %.3f ms  (%.1f ns/element, nnz %.3e, %.0f GB/s of 12 B/nnz%s)"
                   % (p, nel, form, dt * 1e3, dt / nelem * 1e9, nnz, 12.0 * nnz / dt / 1e9,
                      ", %.1f TFLOP/s" % (fl * nelem / dt / 1e12) if fl else ""))
