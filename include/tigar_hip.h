@@ -501,7 +501,9 @@ typedef struct {
   tg_vec_t cp[4];           /* nsd+1 homogeneous control functions on the FE nodes    */
   int nq;                   /* Gauss points per direction                             */
 } tg_patch_t;
-/* form: 0 = (u,v), 1 = (grad u, grad v); result on the element-coupling pattern */
+/* form: 0 = (u,v), 1 = (grad u, grad v), 4 = (lap u, lap v) element by element with lap = spline.div(spline.grad(.)) and
+ * the second derivatives of the map (nsd == d; demos/biharmonic/biharmonic.py:100-103); result on the element-coupling
+ * pattern */
 int tg_assemble_mapped_matrix(const tg_patch_t *patch, int form, tg_csr_t *out);
 /* L(v) = (f_h, v) with f_h the nodal interpolant of fnodal */
 int tg_assemble_mapped_load(const tg_patch_t *patch, tg_vec_t fnodal, tg_vec_t out);

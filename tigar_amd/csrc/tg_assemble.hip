@@ -14,6 +14,10 @@
 //               with d_i = sum_k Jinv[k][i] d/dxi_k (spline.grad / spline.div, tIGAr/common.py:1022-1040,
 //               calculusUtils.py:255-276), i.e. the Laplace integrand with the NON-symmetric coefficient tensor
 //               C_km = w |det DF| (lambda Jinv[k][i] Jinv[m][j] + mu Jinv[k][j] Jinv[m][i] + delta_ij mu g^-1[k][m])
+//     biharmonic a(u,v) = int (lap u)(lap v) dx element by element, lap = spline.div(spline.grad(.)) (nsd == d;
+//               demos/biharmonic/biharmonic.py:100-103, tIGAr/common.py:1022-1040): with Jinv = DF^-1 and the second derivatives
+//               H_r,sm of the (rational) map,  lap phi = sum_km g^-1[k][m] d_k d_m phi + sum_k b_k d_k phi,
+//               b_k = -sum_r Jinv[k][r] sum_sm g^-1[s][m] H_r,sm   (d_m Jinv = -Jinv (d_m DF) Jinv).  Plain kernel only.
 // nsd >= d is allowed (surfaces in 3-D: Laplace-Beltrami), geometry is rational (quotient rule).
 //
 // One workgroup per element: local control values and the 1-D Lagrange tables go to LDS, one
@@ -34,8 +38,8 @@ struct tg_asm_args {
   int nel[3], n[3];            // elements / nodes per direction
   const double *verts[3];      // device: element vertices
   const double *cp[4];         // device: nsd+1 control functions on the node grid
-  const double *tab;           // device: l[a][q] (p+1)*nq | dl[a][q] (p+1)*nq | w[q] nq   (reference element [0,1])
-  int form;                    // 0 mass, 1 laplace, 2 load, 3 block (ei, ej) of the elasticity form
+  const double *tab;           // device: l[a][q] (p+1)*nq | dl[a][q] (p+1)*nq | w[q] nq | d2l[a][q] (p+1)*nq  (reference element [0,1])
+  int form;                    // 0 mass, 1 laplace, 2 load, 3 block (ei, ej) of the elasticity form, 4 biharmonic
   int ei, ej;
   double lam, mu;
   const int64_t *rowptr;       // pattern (matrix forms)
@@ -96,8 +100,9 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
   double *tl = reinterpret_cast<double *>(smem);   // l[a][q]
   double *tdl = tl + p1 * nq1;                     // dl[a][q]
   double *tw = tdl + p1 * nq1;                     // w[q]
-  double *cpl = tw + nq1;                          // [nsd+1][nloc]
-  double *G = cpl + (P.nsd + 1) * nloc;            // [nqt][9]  w sqrt(det g) g^-1
+  double *td2 = tw + nq1;                          // d2l[a][q]
+  double *cpl = td2 + p1 * nq1;                    // [nsd+1][nloc]
+  double *G = cpl + (P.nsd + 1) * nloc;            // [nqt][9]  w sqrt(det g) g^-1   (biharmonic: g^-1 (6) | b (3))
   double *S = G + (size_t)nqt * 9;                 // [nqt]     w sqrt(det g)   (load: times f_h)
   double *fl = S + nqt;                            // [nloc]    load: nodal values
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -115,7 +120,7 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
   if (d > 2) el[2] = 2 * (int)e + P.efirst[2];
   double h[3] = {1.0, 1.0, 1.0};
   for (int k = 0; k < d; k++) h[k] = P.verts[k][el[k] + 1] - P.verts[k][el[k]];
-  for (int s = tid; s < 2 * p1 * nq1 + nq1; s += nt) tl[s] = P.tab[s];
+  for (int s = tid; s < 3 * p1 * nq1 + nq1; s += nt) tl[s] = P.tab[s];
   for (int a = tid; a < nloc; a += nt) {
     const int a0 = a % p1, a1 = (a / p1) % p1, a2 = a / (p1 * p1);
     const int64_t node = (int64_t)(el[0] * P.p + a0) + (int64_t)P.n[0] * ((d > 1 ? el[1] * P.p + a1 : 0) +
@@ -128,6 +133,7 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
   for (int q = tid; q < nqt; q += nt) {
     const int qk[3] = {q % nq1, (q / nq1) % nq1, q / (nq1 * nq1)};
     double N[4] = {0, 0, 0, 0}, dN[4][3] = {{0}}, fh = 0.0;
+    double d2N[4][6] = {{0}};      // biharmonic: second derivatives 00 01 02 11 12 22 of the control functions
     for (int a = 0; a < nloc; a++) {
       const int ak[3] = {a % p1, (a / p1) % p1, a / (p1 * p1)};
       double l[3] = {1, 1, 1}, dl[3] = {0, 0, 0};
@@ -145,6 +151,16 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
         dN[c][2] += v * g2;
       }
       if (P.form == 2) fh += fl[a] * phi;
+      if (P.form == 4) {
+        double d2[3] = {0, 0, 0};
+        for (int k = 0; k < d; k++) d2[k] = td2[ak[k] * nq1 + qk[k]] / (h[k] * h[k]);
+        const double hh[6] = {d2[0] * l[1] * l[2], dl[0] * dl[1] * l[2], dl[0] * l[1] * dl[2],
+                              l[0] * d2[1] * l[2], l[0] * dl[1] * dl[2], l[0] * l[1] * d2[2]};
+        for (int c = 0; c <= P.nsd; c++) {
+          const double v = cpl[c * nloc + a];
+          for (int j = 0; j < 6; j++) d2N[c][j] += v * hh[j];
+        }
+      }
     }
     // DF[i][k] = d(N_i / W)/dxi_k ; metric g = DF^T DF
     const double W = N[P.nsd];
@@ -172,6 +188,30 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
         for (int m = 0; m < d; m++)
           G[(size_t)q * 9 + k * d + m] =
               s * (P.lam * ji[k] * jj[m] + P.mu * jj[k] * ji[m] + (P.ei == P.ej ? P.mu * gi[k * d + m] : 0.0));
+    } else if (P.form == 4) {
+      // second derivatives of F_r = N_r / W:  H_r,km = (N_r,km - F_r,m W,k - F_r,k W,m - F_r W,km) / W
+      const int sy[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+      double t[3] = {0, 0, 0};                     // t_r = sum_sm g^-1[s][m] H_r,sm
+      for (int r = 0; r < d; r++) {
+        const double Fr = N[r] / W;
+        for (int k = 0; k < d; k++)
+          for (int m = 0; m < d; m++) {
+            const double Hkm = (d2N[r][sy[k][m]] - DF[r][m] * dN[P.nsd][k] - DF[r][k] * dN[P.nsd][m] - Fr * d2N[P.nsd][sy[k][m]]) / W;
+            t[r] += gi[k * d + m] * Hkm;
+          }
+      }
+      double *Gq = G + (size_t)q * 9;
+      for (int j = 0; j < 9; j++) Gq[j] = 0.0;
+      for (int k = 0; k < d; k++) {
+        double bk = 0.0;
+        for (int r = 0; r < d; r++) {
+          double jkr = 0.0;                        // Jinv[k][r] = (g^-1 DF^T)[k][r]
+          for (int m = 0; m < d; m++) jkr += gi[k * d + m] * DF[r][m];
+          bk -= jkr * t[r];
+        }
+        Gq[6 + k] = bk;
+        for (int m = k; m < d; m++) Gq[sy[k][m]] = gi[k * d + m];
+      }
     } else {
       for (int k = 0; k < d * d; k++) G[(size_t)q * 9 + k] = s * gi[k];
     }
@@ -210,6 +250,20 @@ __global__ void __launch_bounds__(256) k_assemble_mapped(tg_asm_args P) {
       }
       if (P.form == 0) {
         acc += S[q] * (la[0] * la[1] * la[2]) * (lb[0] * lb[1] * lb[2]);
+      } else if (P.form == 4) {
+        double ea[3] = {0, 0, 0}, eb[3] = {0, 0, 0};
+        for (int k = 0; k < d; k++) {
+          ea[k] = td2[ak[k] * nq1 + qk[k]] / (h[k] * h[k]);
+          eb[k] = td2[bk[k] * nq1 + qk[k]] / (h[k] * h[k]);
+        }
+        const double *Gq = G + (size_t)q * 9;
+        const double La = Gq[0] * (ea[0] * la[1] * la[2]) + Gq[3] * (la[0] * ea[1] * la[2]) + Gq[5] * (la[0] * la[1] * ea[2]) +
+                          2.0 * (Gq[1] * (da[0] * da[1] * la[2]) + Gq[2] * (da[0] * la[1] * da[2]) + Gq[4] * (la[0] * da[1] * da[2])) +
+                          Gq[6] * (da[0] * la[1] * la[2]) + Gq[7] * (la[0] * da[1] * la[2]) + Gq[8] * (la[0] * la[1] * da[2]);
+        const double Lb = Gq[0] * (eb[0] * lb[1] * lb[2]) + Gq[3] * (lb[0] * eb[1] * lb[2]) + Gq[5] * (lb[0] * lb[1] * eb[2]) +
+                          2.0 * (Gq[1] * (db[0] * db[1] * lb[2]) + Gq[2] * (db[0] * lb[1] * db[2]) + Gq[4] * (lb[0] * db[1] * db[2])) +
+                          Gq[6] * (db[0] * lb[1] * lb[2]) + Gq[7] * (lb[0] * db[1] * lb[2]) + Gq[8] * (lb[0] * lb[1] * db[2]);
+        acc += S[q] * La * Lb;
       } else {
         const double ga[3] = {da[0] * la[1] * la[2], la[0] * da[1] * la[2], la[0] * la[1] * da[2]};
         const double gb[3] = {db[0] * lb[1] * lb[2], lb[0] * db[1] * lb[2], lb[0] * lb[1] * db[2]};
@@ -1037,7 +1091,7 @@ static void tg_asm_tables(int p, int nq, std::vector<double> &tab) {
   const int p1 = p + 1;
   std::vector<double> gx, gw;
   tg_gauss01(nq, gx, gw);
-  tab.assign(2 * (size_t)p1 * nq + nq, 0.0);
+  tab.assign(3 * (size_t)p1 * nq + nq, 0.0);
   for (int a = 0; a < p1; a++)
     for (int q = 0; q < nq; q++) {
       const double t = gx[q];
@@ -1051,8 +1105,21 @@ static void tg_asm_tables(int p, int nq, std::vector<double> &tab) {
           if (r != a && r != m) term *= (t - (double)r / p) / ((double)a / p - (double)r / p);
         dl += term;
       }
+      // second derivative: sum over ordered pairs (m, r) of the product without both factors
+      double d2l = 0.0;
+      for (int m = 0; m < p1; m++) {
+        if (m == a) continue;
+        for (int r = 0; r < p1; r++) {
+          if (r == a || r == m) continue;
+          double term = 1.0 / (((double)a / p - (double)m / p) * ((double)a / p - (double)r / p));
+          for (int u = 0; u < p1; u++)
+            if (u != a && u != m && u != r) term *= (t - (double)u / p) / ((double)a / p - (double)u / p);
+          d2l += term;
+        }
+      }
       tab[(size_t)a * nq + q] = l;
       tab[(size_t)p1 * nq + (size_t)a * nq + q] = dl;
+      tab[2 * (size_t)p1 * nq + nq + (size_t)a * nq + q] = d2l;
     }
   for (int q = 0; q < nq; q++) tab[2 * (size_t)p1 * nq + q] = gw[q];
 }
@@ -1129,6 +1196,7 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
   A.nsd = pt->nsd;
   A.nq = pt->nq;
   A.form = form;
+  if (form == 4) TG_REQUIRE(pt->nsd == pt->d, "the biharmonic form needs as many physical as parametric directions");
   if (form == 3) {
     TG_REQUIRE(eb && pt->nsd == pt->d && eb->i >= 0 && eb->i < pt->d && eb->j >= 0 && eb->j < pt->d,
                "elasticity block (i, j): as many physical as parametric directions (nsd == d = %d), 0 <= i, j < d", pt->d);
@@ -1179,7 +1247,7 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
   TG_TRY(tg_asm_cache_get(pt));
   for (int k = 0; k < d; k++) A.verts[k] = g_asm_cache.verts[k];
   A.tab = g_asm_cache.tab;
-  bool fast = d == 3 && pt->nsd == 3 && pt->nq == p1 && p <= 3 && !getenv("TIGAR_ASM_LEGACY");
+  bool fast = d == 3 && pt->nsd == 3 && pt->nq == p1 && p <= 3 && form != 4 && !getenv("TIGAR_ASM_LEGACY");
   if (fast) {   // the walk kernel addresses the entries of one plane of rows in 32 bits
     const double t0 = (double)p1 * A.n[0] + (double)p * (A.nel[0] - 1), t1 = (double)p1 * A.n[1] + (double)p * (A.nel[1] - 1);
     if ((2.0 * p + 1.0) * t0 * t1 * 8.0 >= 4294967000.0) fast = false;      // (byte offsets inside one plane of rows)
@@ -1229,7 +1297,7 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
     A.bout = bout->d;
     TG_CHECK_HIP(hipMemsetAsync(bout->d, 0, (size_t)(row1 - row0) * sizeof(double), g_tg.stream));
   }
-  const size_t lds = ((size_t)2 * p1 * pt->nq + pt->nq + (size_t)(pt->nsd + 1) * nloc + (size_t)nqt * 10 + nloc) * sizeof(double);
+  const size_t lds = ((size_t)3 * p1 * pt->nq + pt->nq + (size_t)(pt->nsd + 1) * nloc + (size_t)nqt * 10 + nloc) * sizeof(double);
   if (!fast && lds > 64 * 1024) {
     if (m) tg_csr_destroy(m);
     tg_set_error("element data (%zu B) does not fit in LDS", lds);
@@ -1328,7 +1396,7 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
 }
 
 extern "C" int tg_assemble_mapped_matrix(const tg_patch_t *patch, int form, tg_csr_t *out) {
-  TG_REQUIRE(out && (form == 0 || form == 1), "form: 0 = mass, 1 = laplace");
+  TG_REQUIRE(out && (form == 0 || form == 1 || form == 4), "form: 0 = mass, 1 = laplace, 4 = biharmonic");
   return tg_assemble_common(patch, form, -1, -1, 0, out, nullptr, nullptr);
 }
 
@@ -1338,7 +1406,7 @@ extern "C" int tg_assemble_mapped_load(const tg_patch_t *patch, tg_vec_t fnodal,
 
 extern "C" int tg_assemble_mapped_matrix_rows(const tg_patch_t *patch, int form, int64_t row0, int64_t row1, int64_t cp_node0,
                                               tg_csr_t *out) {
-  TG_REQUIRE(out && (form == 0 || form == 1), "form: 0 = mass, 1 = laplace");
+  TG_REQUIRE(out && (form == 0 || form == 1 || form == 4), "form: 0 = mass, 1 = laplace, 4 = biharmonic");
   return tg_assemble_common(patch, form, row0, row1, cp_node0, out, nullptr, nullptr);
 }
 

@@ -864,18 +864,22 @@ def _patch(vertices, p, cp, nq):
     return pt, keep
 
 
+_MAPPED_FORMS = {"mass": 0, "laplace": 1, "biharmonic": 4}
+
+
 def assemble_mapped_matrix(vertices, p, cp, form, nq=None, row0=None, row1=None, cp_node0=0):
-    """FE mass (form 'mass') or stiffness ('laplace') matrix of the scalar Q_p space on the tensor
+    """FE mass (form 'mass'), stiffness ('laplace') or element-wise biharmonic ('biharmonic': int lap u lap v, nsd == d)
+    matrix of the scalar Q_p space on the tensor
     grid with element ``vertices`` per direction, geometry F = cp[i]/cp[nsd] given by DeviceVectors on
     the FE nodes (dolfin.assemble stand-in, tIGAr/common.py:1206-1220, 917-945).  ``row0, row1``: the rows of
     whole node planes of the last direction only (global columns), ``cp`` then holding the nodes from ``cp_node0`` on."""
     pt, keep = _patch(vertices, p, cp, p + 1 if nq is None else nq)
     h = handle()
     if row0 is None and row1 is None and not cp_node0:
-        check(_lib.lib().tg_assemble_mapped_matrix(C.byref(pt), {"mass": 0, "laplace": 1}[form], C.byref(h)),
+        check(_lib.lib().tg_assemble_mapped_matrix(C.byref(pt), _MAPPED_FORMS[form], C.byref(h)),
               "tg_assemble_mapped_matrix")
     else:
-        check(_lib.lib().tg_assemble_mapped_matrix_rows(C.byref(pt), {"mass": 0, "laplace": 1}[form], int(row0), int(row1),
+        check(_lib.lib().tg_assemble_mapped_matrix_rows(C.byref(pt), _MAPPED_FORMS[form], int(row0), int(row1),
                                                         int(cp_node0), C.byref(h)), "tg_assemble_mapped_matrix_rows")
     return DeviceCSR(h)
 

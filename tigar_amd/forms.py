@@ -402,11 +402,14 @@ class SeparableLoadForm(object):
 
 class BiharmonicForm(object):
     """a(u,v) = int (lap u)(lap v), element-wise (demos/biharmonic/biharmonic.py:100-103), 2-D:
-    S2xM + MxS2 + C^T x C + C x C^T with C[a,b] = int phi_a'' phi_b."""
+    S2xM + MxS2 + C^T x C + C x C^T with C[a,b] = int phi_a'' phi_b.  With ``geometry`` (nsd == d, 2-D or 3-D): on the
+    mapped patch, lap = spline.div(spline.grad(.)) with the second derivatives of the (rational) map
+    (tIGAr/common.py:1022-1040; csrc/tg_assemble.hip, plain element kernel)."""
 
-    def __init__(self):
+    def __init__(self, geometry=None):
         # a(u, v) = a(v, u) for THIS class; a subclass that adds terms says so itself (ADVICE r5: not inherited)
         self.symmetric = type(self) is BiharmonicForm
+        self.geometry = geometry
 
     def factors(self, V):
         g = _single_grid(V)
@@ -416,6 +419,8 @@ class BiharmonicForm(object):
         return [[S2x, My], [Mx, S2y], [Cx.T.tocsr(), Cy], [Cx, Cy.T.tocsr()]]
 
     def assemble_matrix(self, V, row0=None, row1=None):
+        if self.geometry is not None:
+            return _mapped(self.geometry, V, "biharmonic", row0, row1)
         return _dev.kron_sum_csr(self.factors(V), row0, row1)
 
 
