@@ -276,15 +276,26 @@ def main():
     ap.add_argument("--case", type=str, default=None)
     ap.add_argument("--pbonus", type=int, default=0, help="raise the largest degree drawn (default: 4 in 1-D / 2-D, 3 in 3-D)")
     ap.add_argument("--force", type=str, default=None, help='JSON object of case fields to overwrite, e.g. {"matrix": "random_extra"}')
+    ap.add_argument("--drop-all", action="store_true", help="repeated interior knots in every direction of degree >= 2 that is "
+                    "not periodic (continuityDrop drawn from the knot seed): the shapes the box kernels' defect of round 6 needed")
+    ap.add_argument("--vary", type=int, default=1, help="with --case: that many copies of the case with other value seeds (the "
+                    "couplings added by hand land elsewhere)")
     ap.add_argument("-v", action="store_true")
     a = ap.parse_args()
     if a.case:
-        cases = [json.loads(a.case)]
+        c0 = json.loads(a.case)
+        cases = [dict(c0, val_seed=int(c0["val_seed"]) + 7919 * i) for i in range(max(1, a.vary))]
     else:
         rng = np.random.default_rng(a.seed)
         cases = [draw_case(rng, a.max_rows, a.pbonus) for _ in range(a.first + a.cases)][a.first:]
         if a.force:
             cases = [dict(c, **json.loads(a.force)) for c in cases]
+        if a.drop_all:
+            for c in cases:
+                for k in range(c["d"]):
+                    if c["ps"][k] >= 2 and c["kinds"][k] in ("uniform", "drop"):
+                        c["kinds"][k] = "drop"
+                        c["drops"][k] = 1 + (c["knot_seed"] + k) % (c["ps"][k] - 1)
     bad = 0
     walks = 0
     declined = 0

@@ -1359,6 +1359,13 @@ static int tg_ptap_kron_impl(tg_csr_t cur, int64_t cur_row0, int d, const int64_
   for (int q = 0; q < nc; q += 2) c1need = std::max(c1need, sz[q]);
   for (int q = 1; q < nc; q += 2) cap = (int)std::max<int64_t>(cap, sz[q]);
   const int cap1 = (int)((c1need + 7) & ~7);
+  // The "touched" flags of both buffers are carved as cap bytes each.  Without repeated knots a window of B nodes reaches
+  // at most B functions, so the box after a contraction (cap1) is no larger than before it (cap).  With repeated knots it
+  // can be: a window that ends inside an element of a C^0 direction sees ALL functions of that element (a coupling added
+  // by hand widens the windows beyond whole elements) -- then the flags of the second buffer ran past the end of the LDS
+  // allocation, the writes were dropped and the tail of the row came out as untouched: rows of K short by their last
+  // entries (found by the random runs of round 6; present since the kernel was written).
+  if (cap1 > cap) cap = cap1;
   P.ctab = ctab;
   P.nlist = nlist;
   P.cap1 = cap1;
