@@ -31,6 +31,13 @@ general)
   stats cfg3_general $GEN python $R/bench.py --workload cfg3 --steps 2 --warmup 1 $W
   pmc cfg3_general $GEN python $R/bench.py --workload cfg3 --steps 1 --warmup 1 $W
   ;;
+mapped)
+  # element kernels of the mapped forms added in round 6 (a block of the elasticity form; the biharmonic form on the plain kernel)
+  stats asm_elast_p3 python $R/tools/asm_bench.py 3 64 elast12 3
+  pmc asm_elast_p3 python $R/tools/asm_bench.py 3 64 elast12 3
+  python tools/pmc_sq.py k_asf3 -- python tools/asm_bench.py 3 64 elast12 3 > $O/r6_asm_elast_p3_sq_counters.txt 2>&1
+  stats asm_elast_p2 python $R/tools/asm_bench.py 2 64 elast12 3
+  ;;
 headline)
   timeout 900 python bench.py --steps 10 --warmup 2 > $O/r6_bench_cfg3.json 2> $O/r6_bench_cfg3.log
   stats cfg3 python $R/bench.py --steps 5 --warmup 1 $W
