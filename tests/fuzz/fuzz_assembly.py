@@ -1,7 +1,8 @@
 """Random mapped patches through the FE-side assembly (csrc/tg_assemble.hip: mass, Laplace, nodal load; the dolfin.assemble
 stand-in of SURVEY 8f-1, tIGAr/common.py:917-945, 1206-1220) against ``oracle.mapped_fe_system`` (developer tool): dimension
 1-3 embedded in 1-3 space dimensions, degrees 1-4, non-uniform element sizes, perturbed and rational geometries, Gauss
-points p+1 / p+2.
+points p+1 / p+2.  Where nsd == d also two field blocks of the elasticity form (one and its transposed partner) against
+``oracle.mapped_elasticity_fe_system`` and the biharmonic form against ``oracle.mapped_biharmonic_fe_system`` (round 6).
 
     python tests/fuzz/fuzz_assembly.py [cases]"""
 import sys, json, numpy as np
@@ -51,6 +52,22 @@ for i in range(N):
         b=dev.assemble_mapped_load(uks,p,cpd,dev.DeviceVector(data=fn),nq=(nq or None)).get_local()
         e=np.max(np.abs(b-bo))/np.max(np.abs(bo))
         assert e<=1e-12, "load: %g"%e
+        if nsd==d:
+            lam,mu=float(rng.uniform(0.2,3.0)),float(rng.uniform(0.2,2.0))
+            Eo=O.mapped_elasticity_fe_system(uks,p,cp,lam,mu,nq=(nq or None))
+            Nn=Eo.shape[0]//d; sc=abs(Eo).max()
+            bi,bj=int(rng.integers(0,d)),int(rng.integers(0,d))
+            Bij=dev.assemble_mapped_elasticity_block(uks,p,cpd,bi,bj,lam,mu,nq=(nq or None)).to_scipy()
+            Bji=dev.assemble_mapped_elasticity_block(uks,p,cpd,bj,bi,lam,mu,nq=(nq or None)).to_scipy()
+            e=abs(Bij-Eo[bi*Nn:(bi+1)*Nn,bj*Nn:(bj+1)*Nn]).max()/sc
+            assert e<=1e-11, "elasticity block (%d,%d): %g"%(bi,bj,e)
+            e=abs(Bij-Bji.T).max()/sc
+            assert e<=1e-11, "elasticity block (%d,%d) against the transposed partner: %g"%(bi,bj,e)
+            Ho=O.mapped_biharmonic_fe_system(uks,p,cp,nq=(nq or None))
+            H=dev.assemble_mapped_matrix(uks,p,cpd,"biharmonic",nq=(nq or None)).to_scipy()
+            if abs(Ho).max()>0:
+                e=abs(H-Ho).max()/abs(Ho).max()
+                assert e<=1e-10, "biharmonic: %g"%e
     except Exception as ex:
         bad+=1; print("FAIL",json.dumps(case),type(ex).__name__,str(ex)[:200],flush=True)
 print(json.dumps({"cases":N,"failed":bad}))

@@ -98,3 +98,12 @@ def test_sequences_of_different_matrices_through_one_spline():
     that holds only hand-added couplings came back on the full tensor pattern with stored zeros."""
     rc, summary, failures = _run(["--seed", "3", "--cases", "70"], {}, tool="fuzz_sequences.py")
     assert rc == 0 and summary["failed"] == 0, "\n".join(failures)[:4000]
+
+
+def test_random_mapped_patches_through_the_assembly():
+    """`tests/fuzz/fuzz_assembly.py`: 80 random mapped patches (1-3 parametric in 1-3 physical dimensions, degrees 1-4, rational
+    and perturbed maps, non-uniform elements, p+1 / p+2 Gauss points) through the element kernels of csrc/tg_assemble.hip:
+    mass, Laplace(-Beltrami), nodal load, and -- where nsd == d -- field blocks of the elasticity form and the biharmonic form
+    (round 6), each against its element-loop oracle"""
+    rc, summary, failures = _run(["80"], {}, tool="fuzz_assembly.py")
+    assert rc == 0 and summary["failed"] == 0, "\n".join(failures)[:4000]
