@@ -29,6 +29,7 @@
 // benchmark configurations use the Kronecker-sum generator (tg_kron.hip) instead.
 #include "tg_common.h"
 #include <cmath>
+#include <utility>
 
 #define TG_ASM_MAXLOC 128      // (p+1)^d local nodes: p <= 4 in 3-D, p <= 8 in 2-D (<= 81), any p <= 8 in 1-D
 #define TG_ASM_MAXQ1 10        // Gauss points per direction
@@ -1004,6 +1005,234 @@ __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3_elem(tg_asf_args A) {
   }
 }
 
+// The element kernel above with the FOUR WAVES OF A WORKGROUP ON FOUR CONSECUTIVE ELEMENTS of a line along direction 0
+// (round 6); launches go by the parities of (group index, element index in direction 1, in direction 2).
+// Why: with independent elements and eight colours the rows of vertices in direction 0 (half of all rows) leave as 32-byte
+// runs whose 56-byte stretches are completed by a LATER launch -- every such line reaches the memory twice, partially
+// written (PMC: 4.9 GB written for 2.8 GB of values), and the stores are what the kernel waits for.  Inside a group the
+// two halves of a stretch are now written by two waves of one CU within a microsecond of each other and meet in the L2;
+// what is left of the fragments are the seams between groups (one face in four).  Unlike the walk (k_asf3) there is no loop
+// and no carried row -- that loop needs 300 registers more than exist at p = 3 (and so does a plain loop around this body:
+// 1.5 - 3 KB of scratch per lane) -- only the 16 x 16 block of a shared face (both nodes on it) changes hands: the wave whose
+// element ends on the face leaves it in LDS, its neighbour adds it to its own and stores the sum; no entry is read back.
+// Seams between groups and faces shared in directions 1, 2: stored by the contributor with even parity, read - added -
+// stored by the others in launches of ascending colour, as before: bit-reproducible, no atomics.  The groups depend on
+// nel[0] only, not on the window [za, zb) of rows: row blocks are bit-identical to the whole matrix.
+#define TG_ASF_FACE (16 * 16)
+template <typename F>
+__device__ __forceinline__ void tg_asf_each4(F &&f) {
+  f(std::integral_constant<int, 0>{});
+  f(std::integral_constant<int, 1>{});
+  f(std::integral_constant<int, 2>{});
+  f(std::integral_constant<int, 3>{});
+}
+template <int P1, int FORM, int PRE, int LOOP>
+__global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3_quad(tg_asf_args A) {
+  constexpr int P = P1 - 1, NL = P1 * P1 * P1, PP = P1 * P1;
+  constexpr int GS = FORM == 2 ? 10 : 8, GN = FORM == 2 ? 9 : 7;
+  static_assert(NL == 64 && PP <= 16, "one element per wave, a lane per local node");
+  __shared__ __attribute__((aligned(16))) double s_tab[2 * PP + P1];
+  __shared__ __attribute__((aligned(16))) double s_w[TG_ASF_NW][TG_ASF_AREA(4)];
+  // faces in three generations: a wave may write the face of its next element while its neighbour still reads the last one
+  __shared__ __attribute__((aligned(16))) double s_f[LOOP ? 3 : 1][TG_ASF_NW][TG_ASF_FACE + 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int s = tid; s < 2 * PP + P1; s += 64 * TG_ASF_NW) s_tab[s] = A.tab[s];
+  __syncthreads();
+  const double *TL = s_tab, *TD = s_tab + PP, *TW = s_tab + 2 * PP;
+  tg_cdp4 UL = (tg_cdp4)A.tab, UD = (tg_cdp4)A.tab + PP;
+  double *W = s_w[wv];
+  const int64_t grp = blockIdx.x;
+  const int gx = (int)(grp % A.ngy);
+  const int64_t rest = grp / A.ngy;
+  const int i1 = (int)(rest % A.ncol[1]), i2 = (int)(rest / A.ncol[1]);
+  const int piece = A.efirst[0] + 2 * gx, pc = piece & 1;
+  const int e1_ = A.efirst[1] + 2 * i1, e2_ = A.efirst[2] + 2 * i2;
+  const int nq = (A.nel[0] + TG_ASF_NW - 1) / TG_ASF_NW;
+  const int q_lo = LOOP ? piece * A.chunk : piece, q_hi = LOOP ? min(nq, q_lo + A.chunk) : q_lo + 1;
+  const int64_t T0 = (int64_t)P1 * A.n[0] + (int64_t)P * (A.nel[0] - 1), T1 = (int64_t)P1 * A.n[1] + (int64_t)P * (A.nel[1] - 1);
+  const unsigned uT0 = (unsigned)T0;
+  double cpn[4];
+  {
+    const int x0 = lane % P1, x1 = (lane / P1) % P1, x2 = lane / PP;
+    const int e0 = min(q_lo * TG_ASF_NW + wv, A.nel[0] - 1);
+    const int64_t node = (int64_t)(e0 * P + x0) + (int64_t)A.n[0] * ((e1_ * P + x1) + (int64_t)A.n[1] * (e2_ * P + x2)) - A.cp_node0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) cpn[c] = A.cp[c][node];
+  }
+  for (int q = q_lo; q < q_hi; q++) {
+    // (LOOP: what depends on the lane or on the line is re-derived per group from values the compiler cannot see through --
+    //  hoisted out of the loop it would sit in the registers phase 1 needs)
+    int ln = lane, e1 = e1_, e2 = e2_;
+    if (LOOP) {
+      asm volatile("" : "+v"(ln));
+      asm volatile("" : "+s"(e1));
+      asm volatile("" : "+s"(e2));
+    }
+    const int x0 = ln % P1, x1 = (ln / P1) % P1, x2 = ln / PP;
+    const int e0u = q * TG_ASF_NW + wv;
+    const bool live = e0u < A.nel[0];          // (the last group of a line may be short: its idle waves keep the barrier)
+    const int e0 = live ? e0u : A.nel[0] - 1;
+    const bool firstp = wv == 0 && q == q_lo, lastp = (wv == TG_ASF_NW - 1 && q == q_hi - 1) || e0u >= A.nel[0] - 1;
+    const int gen = LOOP ? q % 3 : 0;
+    double *FW = s_f[gen][wv];
+    const double *CF = wv > 0 ? s_f[gen][wv - 1] : s_f[LOOP ? (q + 2) % 3 : 0][TG_ASF_NW - 1];
+    const int par1 = e1 & 1, par2 = e2 & 1;
+    // ---- phase 0 ----------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int c = 0; c < 4; c++) W[c * 64 + ln] = cpn[c];
+    tg_wave_sync();
+    {
+      double N[4], dN[4][3], G[GN];
+      tg_asf_to_points<P1, 4>(W, TL, TD, ln, 0, x0, x1, x2, true, N, dN);
+      if constexpr (FORM == 2)
+        tg_asf_elast(N, dN, TW[x0] * TW[x1] * TW[x2], A.ei, A.ej, A.lam, A.mu, G);
+      else
+        tg_asf_metric(N, dN, TW[x0] * TW[x1] * TW[x2], G);
+      tg_wave_sync();
+#pragma unroll
+      for (int j = 0; j < GN; j++) W[ln * GS + j] = G[j];
+      tg_wave_sync();
+    }
+    double acc[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) acc[i] = 0.0;
+    // ---- phase 2 (defined here, run in two parts): the rows leave.  Two sweeps: the reads of entries that hold earlier
+    // contributions (faces shared in directions 1, 2, seams between pieces: written by EARLIER launches, so they can be
+    // requested before phase 1 -- PRE -- and arrive while the wave computes; otherwise layer by layer of a2, a round trip
+    // each), then the stores.
+    double old[PRE ? NL : PP];
+    auto rows = [&](auto sweepc, auto a2c) {
+      constexpr int sweep = decltype(sweepc)::value, a2 = decltype(a2c)::value;
+      const int r2 = P * e2 + a2;
+      if (r2 < A.za || r2 >= A.zb) return;                          // (wave-uniform)
+      bool v2;
+      int n2, o2;
+      int64_t rps2;
+      tg_asf_row1d<P>(a2, e2, A.nel[2], v2, n2, o2, rps2);
+      const __amdgpu_buffer_rsrc_t plane =
+          __builtin_amdgcn_make_buffer_rsrc(A.val + (T0 * T1 * rps2 - A.base), 0, TG_BUF_RANGE, 0x00020000);
+      int xs0 = x0, xs1 = x1, xs2 = x2;
+      asm volatile("" : "+v"(xs0), "+v"(xs1), "+v"(xs2));
+      __builtin_amdgcn_sched_barrier(0);
+      const bool add2 = v2 && par2 && xs2 == a2;
+#pragma unroll
+      for (int a1 = 0; a1 < P1; a1++) {
+        bool v1;
+        int n1, o1;
+        int64_t rps1;
+        tg_asf_row1d<P>(a1, e1, A.nel[1], v1, n1, o1, rps1);
+        const bool add1 = v1 && par1 && xs1 == a1;
+#pragma unroll
+        for (int a0 = 0; a0 < P1; a0++) {
+          bool v0;
+          int n0, o0;
+          int64_t rps0;
+          tg_asf_row1d<P>(a0, e0, A.nel[0], v0, n0, o0, rps0);
+          // direction 0: a seam between pieces is a colour (read by the odd piece), a face inside the piece is not
+          const bool seam = (a0 == 0 && firstp) || (a0 == P && lastp);
+          const bool addx = v0 && seam && pc && xs0 == a0;
+          const bool add = add2 || add1 || addx;
+          const bool edge = a2 == 0 || a2 == P || a1 == 0 || a1 == P || ((a0 == 0 || a0 == P) && seam);
+          const bool inner_hi = a0 == P && !lastp;                // the face goes to the next element of the piece
+          const bool inner_lo = a0 == 0 && !firstp;               // ... and arrives from the previous one
+          const bool mine = live && !(inner_hi && xs0 == P);
+          const unsigned off = ((unsigned)n2 * (uT0 * (unsigned)rps1 + (unsigned)n1 * (unsigned)rps0) +
+                                (unsigned)(((xs2 + o2) * n1 + (xs1 + o1)) * n0 + (xs0 + o0))) * 8u;
+          double &og = old[a0 + P1 * a1 + (PRE ? PP * a2 : 0)];
+          if (sweep == 0) {
+            og = edge ? tg_buf_load(plane, (add && mine) ? off : TG_BUF_OOB) : 0.0;
+          } else {
+            double v = acc[a0 + P1 * (a1 + P1 * a2)];
+            if (inner_lo) {
+              const double cf = CF[(a1 + P1 * a2) * 16 + xs1 + P1 * xs2];
+              v += xs0 == 0 ? cf : 0.0;
+            }
+            if (edge) v += og;
+            tg_buf_store(v, plane, mine ? off : TG_BUF_OOB);
+          }
+        }
+      }
+    };
+    if constexpr (PRE) {
+      tg_asf_each4([&](auto a2c) { rows(std::integral_constant<int, 0>{}, a2c); });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- phase 1: lane = column b = (x0, x1, x2) -----------------------------------------------------------------
+    {
+      double l0[P1], d0[P1];
+#pragma unroll
+      for (int qq = 0; qq < P1; qq++) {
+        l0[qq] = TL[x0 * P1 + qq];
+        d0[qq] = TD[x0 * P1 + qq];
+      }
+#pragma unroll
+      for (int q2 = 0; q2 < P1; q2++) {
+        const double l2q = TL[x2 * P1 + q2], d2q = TD[x2 * P1 + q2];
+        double Zl[PP], Zd[PP];
+#pragma unroll
+        for (int i = 0; i < PP; i++) Zl[i] = Zd[i] = 0.0;
+#pragma unroll
+        for (int q1 = 0; q1 < P1; q1++) {
+          const double l1q = TL[x1 * P1 + q1], d1q = TD[x1 * P1 + q1];
+          const double mll = l1q * l2q, mdl = d1q * l2q, mld = l1q * d2q;
+          double Y0[P1], Y1[P1], Y2[P1];
+#pragma unroll
+          for (int a = 0; a < P1; a++) Y0[a] = Y1[a] = Y2[a] = 0.0;
+#pragma unroll
+          for (int q0 = 0; q0 < P1; q0++) {
+            const double *Gq = W + (q0 + P1 * (q1 + P1 * q2)) * GS;
+            const double f0 = d0[q0] * mll, f1 = l0[q0] * mdl, f2 = l0[q0] * mld;
+            double X0, X1, X2;
+            tg_asf_flux<FORM>(Gq, f0, f1, f2, X0, X1, X2);
+#pragma unroll
+            for (int a = 0; a < P1; a++) {
+              Y0[a] = fma(UD[a * P1 + q0], X0, Y0[a]);
+              Y1[a] = fma(UL[a * P1 + q0], X1, Y1[a]);
+              Y2[a] = fma(UL[a * P1 + q0], X2, Y2[a]);
+            }
+          }
+#pragma unroll
+          for (int a1 = 0; a1 < P1; a1++)
+#pragma unroll
+            for (int a0 = 0; a0 < P1; a0++) {
+              Zl[a0 + P1 * a1] = fma(UD[a1 * P1 + q1], Y1[a0], fma(UL[a1 * P1 + q1], Y0[a0], Zl[a0 + P1 * a1]));
+              Zd[a0 + P1 * a1] = fma(UL[a1 * P1 + q1], Y2[a0], Zd[a0 + P1 * a1]);
+            }
+        }
+#pragma unroll
+        for (int a2 = 0; a2 < P1; a2++)
+#pragma unroll
+          for (int i = 0; i < PP; i++)
+            acc[i + PP * a2] = fma(UD[a2 * P1 + q2], Zd[i], fma(UL[a2 * P1 + q2], Zl[i], acc[i + PP * a2]));
+      }
+    }
+    // the block of the face this element shares with the next one: to the neighbour wave (straight-line: every lane
+    // stores, the lanes off the face into a spare slot -- a branch here splits the block phase 1 is scheduled in and costs
+    // 160 registers)
+    {
+      const int fo = x0 == P ? x1 + P1 * x2 : TG_ASF_FACE + ln;
+#pragma unroll
+      for (int i = 0; i < PP; i++) FW[(x0 == P ? i * 16 : 0) + fo] = acc[P + P1 * i];
+    }
+    if (LOOP) {       // the next group's nodal values travel while the rows of this one leave
+      const int en = min(min(q + 1, q_hi - 1) * TG_ASF_NW + wv, A.nel[0] - 1);
+      const int64_t node = (int64_t)(en * P + x0) + (int64_t)A.n[0] * ((e1 * P + x1) + (int64_t)A.n[1] * (e2 * P + x2)) - A.cp_node0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) cpn[c] = A.cp[c][node];
+    }
+    __syncthreads();
+    if constexpr (PRE) {
+      tg_asf_each4([&](auto a2c) { rows(std::integral_constant<int, 1>{}, a2c); });
+    } else {
+      tg_asf_each4([&](auto a2c) {
+        rows(std::integral_constant<int, 0>{}, a2c);
+        rows(std::integral_constant<int, 1>{}, a2c);
+      });
+    }
+  }
+}
+
 // L(v) = int f_h v: lane = quadrature point computes w sqrt(det g) f_h, three 1-D contractions back to the nodes (through
 // LDS), each node's value added to the vector (zeroed before; colour by colour, elements of a launch share no node)
 template <int P1, int EPW>
@@ -1069,7 +1298,30 @@ __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3_load(tg_asf_args A) {
 static inline int64_t tg_rps_host(int p, int a) { return (int64_t)(p + 1) * a + (a > 0 ? (int64_t)p * ((a - 1) / p) : 0); }
 
 template <int P1, int EPW>
-static void tg_asf_launch(int form, const tg_asf_args &A, unsigned nblk, bool walk) {
+static void tg_asf_launch(int form, const tg_asf_args &A, unsigned nblk, bool walk, bool line) {
+  if constexpr (P1 == 4) {
+    const bool pre = !(getenv("TIGAR_ASM_PRE") && atoi(getenv("TIGAR_ASM_PRE")) == 0);
+    const bool loop = A.chunk > 1;             // (pieces of several groups: the workgroup loops)
+    const dim3 g(nblk), b(64 * TG_ASF_NW);
+    if (line && form == 3) {
+      if (loop)
+        hipLaunchKernelGGL((k_asf3_quad<P1, 2, 1, 1>), g, b, 0, g_tg.stream, A);
+      else if (pre)
+        hipLaunchKernelGGL((k_asf3_quad<P1, 2, 1, 0>), g, b, 0, g_tg.stream, A);
+      else
+        hipLaunchKernelGGL((k_asf3_quad<P1, 2, 0, 0>), g, b, 0, g_tg.stream, A);
+      return;
+    }
+    if (line && form == 1) {
+      if (loop)
+        hipLaunchKernelGGL((k_asf3_quad<P1, 1, 1, 1>), g, b, 0, g_tg.stream, A);
+      else if (pre)
+        hipLaunchKernelGGL((k_asf3_quad<P1, 1, 1, 0>), g, b, 0, g_tg.stream, A);
+      else
+        hipLaunchKernelGGL((k_asf3_quad<P1, 1, 0, 0>), g, b, 0, g_tg.stream, A);
+      return;
+    }
+  }
   if (!walk && form == 3)
     hipLaunchKernelGGL((k_asf3_elem<P1, EPW, 2>), dim3(nblk), dim3(64 * TG_ASF_NW), 0, g_tg.stream, A);
   else if (form == 3)
@@ -1341,6 +1593,18 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
   // the walk along direction 0 for every matrix form but the p = 3 stiffness matrix (see k_asf3_elem); TIGAR_ASM_WALK=0/1 forces
   bool walk = fast && form != 2 && !(p == 3 && (form == 1 || form == 3)) && p != 1;
   if (fast && form != 2 && getenv("TIGAR_ASM_WALK")) walk = atoi(getenv("TIGAR_ASM_WALK")) != 0;
+  // p = 3 stiffness / elasticity: the four waves of a workgroup on four consecutive elements of a line (k_asf3_quad;
+  // TIGAR_ASM_QUAD=0: independent elements); direction 0 of a colour then counts GROUPS
+  bool line = fast && !walk && p == 3 && (form == 1 || form == 3);
+  if (line && getenv("TIGAR_ASM_QUAD")) line = atoi(getenv("TIGAR_ASM_QUAD")) != 0;
+  if (line) {           // pieces of `chunk` groups of four elements (a function of nothing but the environment: the seams
+                        // fix the order of the sums, and row blocks must reproduce the whole matrix bit for bit)
+    int chunk = getenv("TIGAR_ASM_QUAD_CHUNK") ? atoi(getenv("TIGAR_ASM_QUAD_CHUNK")) : 8;
+    if (chunk < 1) chunk = 1;
+    const int nq = (A.nel[0] + TG_ASF_NW - 1) / TG_ASF_NW;
+    F.chunk = chunk;
+    F.nchunks = (nq + chunk - 1) / chunk;
+  }
   for (int c = 0; c < (1 << d) && !bad && zb > za; c++) {
     if (walk && (c & 1)) continue;
     int64_t nblk = 1;
@@ -1351,6 +1615,7 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
         lo = ez0;
         hi = ez1;
       }
+      if (line && k == 0) hi = F.nchunks;
       const int first = lo + (((par - lo) % 2) + 2) % 2;       // first index >= lo with this parity
       A.efirst[k] = F.efirst[k] = k < d ? first : 0;
       A.ncol[k] = F.ncol[k] = k < d ? (hi > first ? (hi - first + 1) / 2 : 0) : 1;
@@ -1365,13 +1630,13 @@ static int tg_assemble_common(const tg_patch_t *pt, int form, int64_t row0, int6
         F.ngy = (F.ncol[0] + epw - 1) / epw;
         F.ngroups = (int64_t)F.ngy * F.ncol[1] * F.ncol[2];
       }
-      const unsigned nb = (unsigned)((F.ngroups + TG_ASF_NW - 1) / TG_ASF_NW);
+      const unsigned nb = line ? (unsigned)F.ngroups : (unsigned)((F.ngroups + TG_ASF_NW - 1) / TG_ASF_NW);   // (quad: a workgroup per group)
       if (p == 3)
-        tg_asf_launch<4, 1>(form, F, nb, walk);
+        tg_asf_launch<4, 1>(form, F, nb, walk, line);
       else if (p == 2)
-        tg_asf_launch<3, 2>(form, F, nb, walk);
+        tg_asf_launch<3, 2>(form, F, nb, walk, false);
       else
-        tg_asf_launch<2, 8>(form, F, nb, walk);
+        tg_asf_launch<2, 8>(form, F, nb, walk, false);
     } else {
       TG_REQUIRE(nblk < (1ll << 31), "too many elements for one launch");
       hipLaunchKernelGGL(k_assemble_mapped, dim3((unsigned)nblk), dim3(nt), lds, g_tg.stream, A);
