@@ -29,9 +29,13 @@ class NURBSControlMesh(AbstractControlMesh):
         control = numpy.asarray(control, dtype=numpy.float64)
         nvar = len(degrees)
         dim = control.shape[-1]
-        # bnet[ij2dof(i,j,M), :] = control[i, j, :]   (tIGAr/NURBS.py:46-66): first index fastest
-        self.bnet = control.reshape((-1, dim), order="F") if nvar == 1 else \
-            numpy.stack([control[..., c].ravel(order="F") for c in range(dim)], axis=1)
+        # bnet[ij2dof(i,j,M), :] = control[i, j, :]   (tIGAr/NURBS.py:46-66): first index fastest.  Stored column by
+        # column (Fortran order): a coordinate of all control points is one contiguous piece -- what M_control multiplies
+        n = int(numpy.prod(control.shape[:-1]))
+        self.bnet = numpy.empty((n, dim), order="F")
+        for c in range(dim):
+            self.bnet[:, c] = control[..., c].ravel(order="F")
+        self._device_columns = {}
         if self.bnet.shape[0] != self.scalarSpline.getNcp():
             raise ValueError("control net has %d points, the spline space %d"
                              % (self.bnet.shape[0], self.scalarSpline.getNcp()))
@@ -46,7 +50,19 @@ class NURBSControlMesh(AbstractControlMesh):
         return self.bnet
 
     def homogeneousCoordinateDeviceVector(self, direction):
-        return _dev.DeviceVector(data=numpy.ascontiguousarray(self.bnet[:, direction]))
+        """Column ``direction`` of the control net in HBM.  The control net is an INPUT of the path, like the knot vectors:
+        it is uploaded once per control mesh and stays resident (a generator built from the same mesh again -- every step
+        of a Newton or time loop, every step of bench.py -- reads the resident copy; at cfg3's size the strided host
+        gather + the upload of the four columns cost 0.12 s per generator).  ``bnet`` is not expected to change after
+        construction; ``invalidateDeviceCopy()`` drops the resident columns if it does."""
+        v = self._device_columns.get(direction)
+        if v is None:
+            v = _dev.DeviceVector(data=numpy.ascontiguousarray(self.bnet[:, direction]))
+            self._device_columns[direction] = v
+        return v
+
+    def invalidateDeviceCopy(self):
+        self._device_columns = {}
 
     def getNsd(self):
         return self.bnet.shape[1] - 1

@@ -252,11 +252,14 @@ static size_t tg_pool_limit() {
     // end of a step (111 GB) plus K (75 GB, freed when the next step starts) need 186 GB -- with the
     // former 160 GB limit K's arrays or ~25 GB of smaller blocks were given back and re-allocated
     // EVERY step (0.7-2 s).  A failing hipMalloc trims the pool and retries, so the limit is not a
-    // safety margin.
+    // safety margin.  Round 6: nine tenths -- the streamed assembly on a mapped patch cycles through 237 GB (K, its
+    // half-storage copy, the row blocks of A, the control functions); with three quarters 21 GB of the smallest blocks
+    // were given back at the start of every step and one of the hipMallocs that replaced them took 0.6-0.7 s on the
+    // nearly full device.
     const char *s = getenv("TIGAR_POOL_GB");
     double gb = 160.0;
     size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) gb = 0.75 * (double)tot / (double)((size_t)1 << 30);
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) gb = 0.9 * (double)tot / (double)((size_t)1 << 30);
     lim = (size_t)((s ? atof(s) : gb) * (double)((size_t)1 << 30));
   }
   return lim;

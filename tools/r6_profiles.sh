@@ -38,6 +38,18 @@ mapped)
   python tools/pmc_sq.py k_asf3 -- python tools/asm_bench.py 3 64 elast12 3 > $O/r6_asm_elast_p3_sq_counters.txt 2>&1
   stats asm_elast_p2 python $R/tools/asm_bench.py 2 64 elast12 3
   ;;
+quad)
+  # p = 3 stiffness / elasticity element kernel, four waves on four consecutive elements, looping over a piece of a line
+  # (k_asf3_quad) against the element-per-wave kernel it replaces (TIGAR_ASM_QUAD=0)
+  { for q in 0 1; do for a in "3 64 laplace" "3 64 elast12" "3 128 laplace"; do echo "# TIGAR_ASM_QUAD=$q asm_bench $a"; TIGAR_ASM_QUAD=$q TIGAR_ASM_TIME=1 python tools/asm_bench.py $a 3 2>&1 | grep -E "element kernels|ns/element" | tail -2; done; done; } > $O/r6_asm_quad_kernel_times.txt 2>&1
+  stats asm_quad_p3 python $R/tools/asm_bench.py 3 64 laplace 3
+  pmc asm_quad_p3 python $R/tools/asm_bench.py 3 64 laplace 3
+  python tools/pmc_sq.py k_asf3 -- python tools/asm_bench.py 3 64 laplace 3 > $O/r6_asm_quad_p3_sq_counters.txt 2>&1
+  TIGAR_ASM_QUAD=0 timeout 600 python tools/pmc_hbm.py $O/r6_asm_elem_p3_pmc_hbm.json -- python tools/asm_bench.py 3 64 laplace 3 > $O/r6_asm_elem_p3_pmc.log 2>&1
+  timeout 900 python bench.py --steps 3 --warmup 1 $W --geometry volume > $O/r6_bench_cfg3_mapped_geometry.json 2> $O/r6_bench_cfg3_mapped_geometry.log
+  stats cfg3_mapped python $R/bench.py --steps 2 --warmup 1 $W --geometry volume
+  pmc cfg3_mapped python $R/bench.py --steps 1 --warmup 1 $W --geometry volume
+  ;;
 headline)
   timeout 900 python bench.py --steps 10 --warmup 2 > $O/r6_bench_cfg3.json 2> $O/r6_bench_cfg3.log
   stats cfg3 python $R/bench.py --steps 5 --warmup 1 $W
