@@ -1018,6 +1018,12 @@ __global__ void __launch_bounds__(64 * TG_ASF_NW) k_asf3_elem(tg_asf_args A) {
 // Seams between groups and faces shared in directions 1, 2: stored by the contributor with even parity, read - added -
 // stored by the others in launches of ascending colour, as before: bit-reproducible, no atomics.  The groups depend on
 // nel[0] only, not on the window [za, zb) of rows: row blocks are bit-identical to the whole matrix.
+// LOOP: the workgroup walks a piece of A.chunk groups (faces in three generations of LDS buffers, the next group's nodal
+// values requested while the rows of this one leave); the loop fits the registers because its body has no branch.
+// Measured and not kept: the four waves on four different LINES, each walking its own piece with the face carried inside
+// the wave (no barrier in the loop): waits 17 -> 7 % of the wave cycles, VALU active 46 -> 49 %, but the two halves of a
+// stretch are then stored 17 us apart and the L2 has let go of the line: 11.7 instead of 9.4 GB written per matrix at 64^3
+// elements, 34.9 - 43 ms instead of 34.4 - 37 ms at 128^3.
 #define TG_ASF_FACE (16 * 16)
 template <typename F>
 __device__ __forceinline__ void tg_asf_each4(F &&f) {
