@@ -410,3 +410,52 @@ def test_mapped_forms_on_several_ranks(tmp_path, kind, p, nels, world, comm):
         assert abs(int(z["its"][0]) - its) <= 3
         cover[g0:g1] += 1
     assert np.all(cover == 1)
+
+
+# ---- round 6: the p = 3 stiffness / elasticity kernel with four waves on four consecutive elements (k_asf3_quad) -----------
+@pytest.mark.parametrize("nels", [(37, 2, 3), (5, 3, 2), (9, 2, 2), (33, 1, 1)])
+def test_quad_element_kernel_pieces_seams_and_short_groups(T, nels, monkeypatch):
+    """lines of elements that do not divide into groups of four or into pieces (a seam between pieces at 32 elements, a last
+    group of one, one or two elements in all), against the oracle's element loop, the element-per-wave kernel it replaces and
+    itself with other piece lengths; an elasticity block; row blocks bit for bit the rows of the whole matrix"""
+    import scipy.sparse as sps
+    p = 3
+    gen, kvs = _volume_generator(T, p, nels)
+    g = gen.V.grids[0]
+    uks = [np.asarray(g.vertices[k]) for k in range(3)]
+    n0, n1, n2 = g.shape()
+    plane = n0 * n1
+    cp = [f.vector().get_local() for f in gen.cpFuncs]
+    dcp = [f.vector() for f in gen.cpFuncs]
+    _, Ko, _ = O.mapped_fe_system(uks, p, cp)
+    K = T.dev.assemble_mapped_matrix(uks, p, dcp, "laplace").to_scipy()
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+    K2 = T.dev.assemble_mapped_matrix(uks, p, dcp, "laplace").to_scipy()
+    assert np.array_equal(K2.data.view(np.int64), K.data.view(np.int64))            # bit-reproducible
+    for env in ({"TIGAR_ASM_QUAD": "0"}, {"TIGAR_ASM_QUAD_CHUNK": "1"}, {"TIGAR_ASM_QUAD_CHUNK": "1", "TIGAR_ASM_PRE": "0"},
+                {"TIGAR_ASM_QUAD_CHUNK": "2"}, {"TIGAR_ASM_QUAD_CHUNK": "3"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        Kv = T.dev.assemble_mapped_matrix(uks, p, dcp, "laplace").to_scipy()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        assert np.array_equal(Kv.indices, K.indices)
+        assert abs(Kv - K).max() <= 1e-13 * abs(K).max(), env
+    # a block of the elasticity form (the same kernel, nine coefficients per point)
+    Eo = O.mapped_elasticity_fe_system(uks, p, cp, 1.3, 0.7)
+    Nn = Eo.shape[0] // 3
+    B12 = T.dev.assemble_mapped_elasticity_block(uks, p, dcp, 1, 2, 1.3, 0.7).to_scipy()
+    assert abs(B12 - Eo[Nn:2 * Nn, 2 * Nn:3 * Nn]).max() <= 1e-12 * abs(Eo).max()
+    # row blocks on windows of the control functions
+    cuts = sorted(set(c for c in (0, 1, p, p + 2, 2 * p, n2 - 1, n2) if 0 <= c <= n2))
+    parts = []
+    for za, zb in zip(cuts[:-1], cuts[1:]):
+        e0 = za // p - 1 if (za > 0 and za % p == 0) else za // p
+        e1 = min(nels[2], (zb - 1) // p + 1)
+        fa, fb = e0 * p, e1 * p + 1
+        win = [T.dev.DeviceVector(data=c[fa * plane:fb * plane]) for c in cp]
+        parts.append(T.dev.assemble_mapped_matrix(uks, p, win, "laplace", row0=za * plane, row1=zb * plane,
+                                                  cp_node0=fa * plane).to_scipy())
+    S = sps.vstack(parts).tocsr()
+    assert np.array_equal(S.indptr, K.indptr) and np.array_equal(S.indices, K.indices)
+    assert np.array_equal(S.data.view(np.int64), K.data.view(np.int64))
