@@ -9,8 +9,10 @@ WORK = [("cfg3 (256^3 p=3)", "r%s_cfg3_kernel_stats.txt" % RND, "r%s_cfg3_pmc_hb
         ("general PtAP, element split (64^3 p=3)", "r%s_elemsplit_kernel_stats.txt" % RND, "r%s_elemsplit_pmc_hbm.json" % RND),
         ("cfg3 size, nothing assumed about M or A (element chunks)", "r%s_cfg3_general_kernel_stats.txt" % RND,
          "r%s_cfg3_general_pmc_hbm.json" % RND),
-        ("mapped elasticity, one field block (64^3 p=3 elements)", "r%s_asm_elast_p3_kernel_stats.txt" % RND,
-         "r%s_asm_elast_p3_pmc_hbm.json" % RND),
+        ("mapped elasticity, one field block (64^3 p=3 elements; element-per-wave kernel, before k_asf3_quad)",
+         "r%s_asm_elast_p3_kernel_stats.txt" % RND, "r%s_asm_elast_p3_pmc_hbm.json" % RND),
+        ("mapped stiffness matrix (64^3 p=3 elements; k_asf3_quad)", "r%s_asm_quad_p3_kernel_stats.txt" % RND,
+         "r%s_asm_quad_p3_pmc_hbm.json" % RND),
         ("cfg2 (128^3 p=2)", "r%s_cfg2_kernel_stats.txt" % RND, "r%s_cfg2_pmc_hbm.json" % RND),
         ("cfg4 (256^2 p=4, CG)", "r%s_cfg4_kernel_stats.txt" % RND, "r%s_cfg4_pmc_hbm.json" % RND),
         ("cfg5 (128^2 p=3, 3 fields)", "r%s_cfg5_kernel_stats.txt" % RND, "r%s_cfg5_pmc_hbm.json" % RND),
