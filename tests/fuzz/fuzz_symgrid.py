@@ -1,5 +1,5 @@
 """Random box-stencil matrices through the half-storage product (csrc/tg_symgrid.hip) against scipy (developer tool): stencil
-radius 1-3, grid sizes that the 24 x 16 patches and the 64-row sub-steps never divide, random z cuts into slabs (the several-rank
+radius 1-4, grid sizes that the 24 x 16 patches and the 64-row sub-steps never divide, random z cuts into slabs (the several-rank
 form: entries above the slab gathered only, entries below it from the CSR rows), random numbers of z chunks, matrices that must
 be declined (non-symmetric, an entry moved).
 
@@ -42,7 +42,7 @@ def main():
     bad = 0
     for case in range(args.cases):
         rng = np.random.default_rng([args.seed, case])
-        reach = int(rng.integers(1, 4))
+        reach = int(rng.integers(1, 5))
         shape = [int(rng.integers(16, 70)), int(rng.integers(16, 50)), int(rng.integers(2 * reach + 2, 40))]
         while np.prod(shape) * (2 * reach + 1) ** 3 > 2.5e7:
             k = int(np.argmax(shape))

@@ -29,12 +29,15 @@
 #include <vector>
 
 #ifndef SG_PX
-#define SG_PX 24          // widest / highest patch (points)
+#define SG_PX 24          // widest / highest patch (points), P <= 3
 #endif
 #ifndef SG_PY
 #define SG_PY 16
 #endif
-#define SG_TAB (SG_PX * SG_PY)
+// P = 4 (round 6; 3-D quartics: 729 entries per row, 365 stored): patches of 16 x 12 points -- two rings of five window
+// planes of 24 x 20 entries are 38 KB, as many waves per CU as at P = 3 (with 24 x 16 patches: 61 KB, two waves)
+#define SG_PX4 16
+#define SG_PY4 12
 
 typedef double sg_d2 __attribute__((ext_vector_type(2)));
 
@@ -43,8 +46,11 @@ struct sg_c {
   static constexpr int S = 2 * P + 1, NF = S * S * S, LC = (NF - 1) / 2;
   static constexpr int NP = LC + 1;          // stored positions per row: the diagonal and what follows it
   static constexpr int NG = (NP + 1) / 2;    // pairs of positions (16 bytes per lane)
-  static constexpr int Wx = SG_PX + 2 * P, Wy = SG_PY + 2 * P, W = Wx * Wy;
+  static constexpr int PX = P == 4 ? SG_PX4 : SG_PX, PY = P == 4 ? SG_PY4 : SG_PY, TAB = PX * PY;
+  static constexpr int Wx = PX + 2 * P, Wy = PY + 2 * P, W = Wx * Wy;
 };
+static inline int sg_px(int P) { return P == 4 ? SG_PX4 : SG_PX; }
+static inline int sg_py(int P) { return P == 4 ? SG_PY4 : SG_PY; }
 // position -> offset in the box, positions in ascending column order starting at the diagonal
 __host__ __device__ constexpr int sg_dx(int P, int pos) { return (pos + ((2 * P + 1) * (2 * P + 1) * (2 * P + 1) - 1) / 2) % (2 * P + 1) - P; }
 __host__ __device__ constexpr int sg_dy(int P, int pos) {
@@ -75,17 +81,25 @@ struct sg_lay {
   }
   // batches: storage indices [bstart(b), bstart(b + 1)), even boundaries on group boundaries; their number is a multiple
   // of 4 (the product kernel keeps 4 batches of values in registers, buffer = batch mod 4)
-  static constexpr int NBATCH = P == 3 ? 24 : P == 2 ? 12 : 4;
+  // (P = 4: NA = 160 = 17 batches of two groups (8 values) + 6 of one (4), then 41 groups of 5: 20 batches of two (10) and
+  //  the last group with the padding (6): 44 batches)
+  static constexpr int NBATCH = P == 4 ? 44 : P == 3 ? 24 : P == 2 ? 12 : 4;
   __host__ __device__ static constexpr int bstart(int b) {
-    return P == 3   ? (b <= 12 ? 6 * b : b < 24 ? 72 + 8 * (b - 12) : 172)
+    return P == 4   ? (b <= 17 ? 8 * b : b <= 23 ? 136 + 4 * (b - 17) : b < 44 ? 160 + 10 * (b - 23) : 366)
+           : P == 3 ? (b <= 12 ? 6 * b : b < 24 ? 72 + 8 * (b - 12) : 172)
            : P == 2 ? (b <= 6 ? 4 * b : b < 12 ? 24 + 6 * (b - 6) : 64)
                     : (b <= 2 ? 2 * b : b == 3 ? 8 : 14);
   }
-  static constexpr int GBMAX = P == 3 ? 6 : P == 2 ? 5 : 3;   // pairs in the longest batch
+  static constexpr int GBMAX = P == 4 ? 5 : P == 3 ? 6 : P == 2 ? 5 : 3;   // pairs in the longest batch
 };
-static_assert(sg_lay<3>::NP == sg_c<3>::NP && sg_lay<2>::NP == sg_c<2>::NP && sg_lay<1>::NP == sg_c<1>::NP, "positions");
+static_assert(sg_lay<3>::NP == sg_c<3>::NP && sg_lay<2>::NP == sg_c<2>::NP && sg_lay<1>::NP == sg_c<1>::NP &&
+                  sg_lay<4>::NP == sg_c<4>::NP && sg_lay<4>::NA == 160, "positions");
 static_assert(sg_lay<3>::bstart(24) == 2 * sg_c<3>::NG && sg_lay<2>::bstart(12) == 2 * sg_c<2>::NG &&
-                  sg_lay<1>::bstart(4) == 2 * sg_c<1>::NG, "batches cover the stored pairs");
+                  sg_lay<1>::bstart(4) == 2 * sg_c<1>::NG && sg_lay<4>::bstart(44) == 2 * sg_c<4>::NG &&
+                  sg_lay<4>::bstart(23) == sg_lay<4>::NA && sg_lay<4>::bstart(43) == 360,
+              "batches cover the stored pairs");
+static_assert(sg_lay<4>::inv(sg_lay<4>::pos(364)) == 364 && sg_lay<4>::inv(sg_lay<4>::pos(161)) == 161 &&
+                  sg_lay<4>::pos(sg_lay<4>::NA + 4) == 0, "storage order, P = 4");
 static_assert(sg_lay<3>::inv(sg_lay<3>::pos(171)) == 171 && sg_lay<3>::inv(sg_lay<3>::pos(72)) == 72 &&
                   sg_lay<2>::inv(sg_lay<2>::pos(40)) == 40 && sg_lay<3>::pos(sg_lay<3>::NA + 3) == 0, "storage order");
 
@@ -140,17 +154,22 @@ void tg_symgrid_free(tg_symgrid_s *s) {
 // streams the tails of 8 rows (coalesced), places the values by position in an LDS tile [row][position] and the tile goes
 // out as [pair of positions][lane] pieces of 512 bytes.  fail[0] is set when a row has another length than its box or
 // another column index at one of its places.
-#define SG_CV_ROWS 32
+// (P = 4: 16 rows per workgroup -- the tile of 32 rows x 367 values would not fit the 64 KB of static LDS)
+template <int P>
+struct sg_cv {
+  static constexpr int ROWS = P == 4 ? 16 : 32, RW = ROWS / 4, PARTS = 64 / ROWS;
+};
 template <int P>
 __global__ void __launch_bounds__(256)
     k_symgrid_convert(sg_dev G, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                       const double *__restrict__ val, sg_d2 *__restrict__ out, int64_t nblk, int *__restrict__ fail) {
   typedef sg_c<P> C;
+  constexpr int SG_CV_ROWS = sg_cv<P>::ROWS, RW = sg_cv<P>::RW, PARTS = sg_cv<P>::PARTS;
   constexpr int LD = 2 * C::NG + 1;          // odd row length of the tile
   __shared__ double tile[SG_CV_ROWS * LD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t blk = (int64_t)blockIdx.x >> 1;
-  const int half = (int)(blockIdx.x & 1);
+  const int64_t blk = (int64_t)blockIdx.x / PARTS;
+  const int half = (int)(blockIdx.x % PARTS);
   const int sub = (int)(blk % G.m);
   const int64_t pz = blk / G.m;
   const int z = (int)(pz % G.n2), patch = (int)(pz / G.n2);
@@ -165,12 +184,12 @@ __global__ void __launch_bounds__(256)
   const int zg = z + G.zoff;                  // (a z slab of the grid: the rows hold the box of the WHOLE grid)
   const int dzlo = -min(P, zg), dzhi = min(P, G.n2g - 1 - zg), nz = dzhi - dzlo + 1;
   const int grow0 = G.zoff * n01;              // global index of local row 0
-  // lane rr < 8 of a wave looks up row rr of the wave's eight
+  // lane rr < RW of a wave looks up row rr of the wave's eight (four at P = 4)
   int my_row = -1, my_len = 0;
   int64_t my_e0 = 0;
   {
-    const int t = t0 + w * 8 + lane;
-    if (lane < 8 && t < cnt) {                 // (lanes of the block beyond the patch get zeros: the product loads them)
+    const int t = t0 + w * RW + lane;
+    if (lane < RW && t < cnt) {                 // (lanes of the block beyond the patch get zeros: the product loads them)
       const int ly = t / pxv, lx = t - ly * pxv;
       my_row = (z * G.n1 + ya + ly) * n0 + xa + lx;
       my_e0 = rowptr[my_row];
@@ -179,11 +198,11 @@ __global__ void __launch_bounds__(256)
   }
   // phase 1: every load of the wave's eight tails is issued (addresses from the row pointers alone) ...
   constexpr int IT = (C::NP + 63) / 64;       // a tail holds at most NP entries
-  double vv[8][IT];
-  int cc[8][IT];
+  double vv[RW][IT];
+  int cc[RW][IT];
   bool bad = false;
 #pragma unroll
-  for (int rr = 0; rr < 8; rr++) {
+  for (int rr = 0; rr < RW; rr++) {
     const int row = __builtin_amdgcn_readlane(my_row, rr);
     const int len = __builtin_amdgcn_readlane(my_len, rr);
     const int64_t e0 = ((int64_t)__builtin_amdgcn_readlane((int)(my_e0 >> 32), rr) << 32) |
@@ -200,7 +219,7 @@ __global__ void __launch_bounds__(256)
   }
   // ... phase 2: the values go to their places in the tile
 #pragma unroll
-  for (int rr = 0; rr < 8; rr++) {
+  for (int rr = 0; rr < RW; rr++) {
     const int row = __builtin_amdgcn_readlane(my_row, rr);
     if (row < 0) break;
     const int len = __builtin_amdgcn_readlane(my_len, rr);
@@ -214,7 +233,7 @@ __global__ void __launch_bounds__(256)
     const int nxy = nx * ny;
     const int mxy = (65536 + nxy - 1) / nxy, mx = (65536 + nx - 1) / nx;    // k / d = (k * m) >> 16 for k d < 65536
     const int kd = ((0 - dzlo) * ny + (0 - dylo)) * nx + (0 - dxlo);          // the diagonal
-    double *trow = tile + (w * 8 + rr) * LD;
+    double *trow = tile + (w * RW + rr) * LD;
 #pragma unroll
     for (int it = 0; it < IT; it++) {
       const int k = kd + lane + 64 * it;
@@ -268,7 +287,7 @@ __global__ void __launch_bounds__(64)
   constexpr int Wx = C::Wx, W = C::W, GB = Y::GBMAX, NB = Y::NBATCH, NXL = (W + 63) / 64;
   __shared__ double acc[(P + 1) * W];
   __shared__ double xs[(P + 1) * W];
-  __shared__ unsigned short tab[SG_TAB];
+  __shared__ unsigned short tab[C::TAB];
   if (gate && !(*gate > gate_tol)) return;
   const int lane = threadIdx.x;
   const int64_t L = tg_xcd_block(blockIdx.x, nwaves);
@@ -501,7 +520,7 @@ __global__ void k_symgrid_compare(const double *__restrict__ y1, const double *_
 template <int P>
 static void sg_launch_convert(const tg_symgrid_s *s, tg_csr_s *a, int *fail) {
   const int64_t nblk = (int64_t)s->npx * s->npy * s->n2 * s->m;
-  hipLaunchKernelGGL(k_symgrid_convert<P>, dim3((unsigned)(nblk * 2)), dim3(256), 0, g_tg.stream, sg_view(s),
+  hipLaunchKernelGGL(k_symgrid_convert<P>, dim3((unsigned)(nblk * sg_cv<P>::PARTS)), dim3(256), 0, g_tg.stream, sg_view(s),
                      a->rowptr, a->col, a->val, s->val, nblk, fail);
 }
 // part 0: all of it; 1: the chunks that read no halo plane of x (all but the last one of every patch) -- what may run while
@@ -539,6 +558,7 @@ int tg_symgrid_spmv(tg_symgrid_s *s, tg_csr_s *a, const double *x_shifted, int64
   switch (s->P) {
     case 1: sg_launch_spmv<1>(s, a, x_shifted, cmin, cmax, y, part, gate, gate_tol); break;
     case 2: sg_launch_spmv<2>(s, a, x_shifted, cmin, cmax, y, part, gate, gate_tol); break;
+    case 4: sg_launch_spmv<4>(s, a, x_shifted, cmin, cmax, y, part, gate, gate_tol); break;
     default: sg_launch_spmv<3>(s, a, x_shifted, cmin, cmax, y, part, gate, gate_tol); break;
   }
   TG_LAUNCH_CHECK();
@@ -572,7 +592,7 @@ static int sg_detect(tg_csr_s *a, int64_t row0, int *Pout, int *n0o, int *n1o, i
   const int64_t len = (int64_t)(key >> 32), rl = (int64_t)(0xffffffffu - (unsigned)(key & 0xffffffffu));
   const int64_t r = rl + row0;          // (global index of that row)
   int P = 0;
-  for (int p = 1; p <= 3; p++)
+  for (int p = 1; p <= 4; p++)
     if (len == (int64_t)(2 * p + 1) * (2 * p + 1) * (2 * p + 1)) P = p;
   if (!P || rl < 0 || rl >= n) return 0;
   int64_t e0 = 0;
@@ -616,8 +636,8 @@ int tg_symgrid_build(tg_csr_s *a, int64_t row0, int verify, tg_symgrid_s **out) 
   tg_symgrid_s *s = new tg_symgrid_s;
   s->P = P, s->n0 = n0, s->n1 = n1, s->n2 = n2;
   s->row0 = row0, s->zoff = (int)(row0 / ((int64_t)n0 * n1)), s->n2g = (int)(a->ncols / ((int64_t)n0 * n1));
-  s->npx = (n0 + SG_PX - 1) / SG_PX;
-  s->npy = (n1 + SG_PY - 1) / SG_PY;
+  s->npx = (n0 + sg_px(P) - 1) / sg_px(P);
+  s->npy = (n1 + sg_py(P) - 1) / sg_py(P);
   const int64_t npatch = (int64_t)s->npx * s->npy;
   {
     int want = getenv("TIGAR_SYMGRID_CHUNKS") ? atoi(getenv("TIGAR_SYMGRID_CHUNKS")) : 0;
@@ -652,8 +672,8 @@ int tg_symgrid_build(tg_csr_s *a, int64_t row0, int verify, tg_symgrid_s **out) 
     for (int y = 0; y < s->npy; y++) cmax = std::max(cmax, (h[ox + x + 1] - h[ox + x]) * (h[oy + y + 1] - h[oy + y]));
   s->m = (cmax + 63) / 64;
   for (int c = 0; c < s->nch; c++) s->czmax = std::max(s->czmax, h[oz + c + 1] - h[oz + c]);
-  const int NG = P == 1 ? sg_c<1>::NG : P == 2 ? sg_c<2>::NG : sg_c<3>::NG;
-  const int W = P == 1 ? sg_c<1>::W : P == 2 ? sg_c<2>::W : sg_c<3>::W;
+  const int NG = P == 1 ? sg_c<1>::NG : P == 2 ? sg_c<2>::NG : P == 4 ? sg_c<4>::NG : sg_c<3>::NG;
+  const int W = P == 1 ? sg_c<1>::W : P == 2 ? sg_c<2>::W : P == 4 ? sg_c<4>::W : sg_c<3>::W;
   s->val_bytes = npatch * n2 * s->m * (int64_t)NG * 64 * 16;
   s->stage_bytes = npatch * s->nch * (int64_t)(s->czmax + P) * W * 8;
   s->rows_stored = a->nrows;
@@ -682,6 +702,7 @@ int tg_symgrid_build(tg_csr_s *a, int64_t row0, int verify, tg_symgrid_s **out) 
     switch (P) {
       case 1: sg_launch_convert<1>(s, a, ctl); break;
       case 2: sg_launch_convert<2>(s, a, ctl); break;
+      case 4: sg_launch_convert<4>(s, a, ctl); break;
       default: sg_launch_convert<3>(s, a, ctl); break;
     }
     if (hipGetLastError() != hipSuccess ||
@@ -746,7 +767,7 @@ int tg_symgrid_build(tg_csr_s *a, int64_t row0, int verify, tg_symgrid_s **out) 
 }
 
 void tg_symgrid_info(const tg_symgrid_s *s, int64_t *val_bytes, int64_t *stage_bytes) {
-  const int NG = s->P == 1 ? sg_c<1>::NG : s->P == 2 ? sg_c<2>::NG : sg_c<3>::NG;
+  const int NG = s->P == 1 ? sg_c<1>::NG : s->P == 2 ? sg_c<2>::NG : s->P == 4 ? sg_c<4>::NG : sg_c<3>::NG;
   if (val_bytes) *val_bytes = s->rows_stored * NG * 16;
   if (stage_bytes) *stage_bytes = s->stage_bytes;
 }
