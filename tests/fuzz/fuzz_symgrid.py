@@ -77,6 +77,20 @@ def main():
                 r = int(rng.integers(n01, A.shape[0]))
                 C.data[C.indptr[r]] += 0.25
                 assert dev.DeviceCSR.from_scipy(C).mult_symgrid(dx)[1] is None, "asymmetric value accepted"
+            # several fields on the grid (round 6): nf x nf blocks, symmetric as a whole; every third case
+            if case % 3 == 0 and reach <= 3:
+                nf = int(rng.integers(2, 4))
+                sh = tuple(min(s_, m_) for s_, m_ in zip(shape, (40, 30, 20)))
+                blocks = [[box_stencil(rng, sh, reach, symmetric=False) for _ in range(nf)] for _ in range(nf)]
+                M = sp.bmat(blocks, format="csr")
+                M = (M + M.T).tocsr()
+                M.sort_indices()
+                xm = rng.standard_normal(M.shape[0])
+                ym, im = dev.DeviceCSR.from_scipy(M).mult_symgrid(dev.DeviceVector(data=xm))
+                assert im is not None, "%d fields declined" % nf
+                assert np.max(np.abs(ym.get_local() - M @ xm) / (np.abs(M) @ np.abs(xm))) < 1e-14, "%d fields" % nf
+                M.data[M.indptr[M.shape[0] // nf + 7] + 1] += 0.25            # one value of an off-diagonal pair changed
+                assert dev.DeviceCSR.from_scipy(M).mult_symgrid(dev.DeviceVector(data=xm))[1] is None, "asymmetric pair accepted"
         except AssertionError as e:
             bad += 1
             desc["error"] = str(e)

@@ -320,3 +320,102 @@ def test_small_systems_and_other_solvers_keep_their_kernels(dev, monkeypatch):
     assert out["1"][0] == 0 and out["2"][0] == 1
     assert np.max(np.abs(out["1"][1] - out["2"][1])) <= 1e-8 * np.max(np.abs(out["1"][1]))
     assert np.linalg.norm(A @ out["2"][1] - b) <= 1e-8 * np.linalg.norm(b)
+
+
+# ---- round 6: several fields on one scalar grid (K of nF x nF box-stencil blocks, symmetric as a whole) ---------------------
+def _block_box_stencil(rng, shape, reach, nf, symmetric=True):
+    """field-major matrix of nf x nf random box-stencil blocks on one grid (the pattern of an elasticity K)"""
+    blocks = [[_box_stencil(rng, shape, reach, symmetric=False) for _ in range(nf)] for _ in range(nf)]
+    A = sp.bmat(blocks, format="csr")
+    if symmetric:
+        A = (A + A.T).tocsr()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("shape,reach,nf", [((24, 17, 12), 3, 3), ((37, 29, 16), 2, 3), ((18, 21, 9), 1, 2), ((33, 35, 21), 3, 2),
+                                            ((16, 16, 8), 3, 4)])
+def test_half_storage_product_of_several_fields(dev, shape, reach, nf, monkeypatch):
+    """diagonal blocks stored half, an off-diagonal pair stored once (the full box of K_fg) and used for its rows and for
+    the rows of K_gf: against scipy, bit-reproducible, about half the bytes of the sliced copy; a matrix whose off-diagonal
+    pair is not each other's transpose is declined"""
+    rng = np.random.default_rng(sum(shape) * reach + nf)
+    A = _block_box_stencil(rng, shape, reach, nf)
+    x = rng.standard_normal(A.shape[0])
+    dA, dx = dev.DeviceCSR.from_scipy(A), dev.DeviceVector(data=x)
+    y, info = dA.mult_symgrid(dx)
+    assert info is not None, "a symmetric matrix of box-stencil blocks was declined"
+    ref, scale = A @ x, np.abs(A) @ np.abs(x)
+    assert np.max(np.abs(y.get_local() - ref) / scale) < 1e-14
+    y2, _ = dA.mult_symgrid(dx)
+    assert np.array_equal(y.get_local().view(np.int64), y2.get_local().view(np.int64))
+    # per node: nf diagonal blocks of ((2r+1)^3 + 1) / 2 positions, nf (nf - 1) / 2 full boxes, padded to pairs, 8 B each
+    s3 = (2 * reach + 1) ** 3
+    assert info["value_bytes"] == int(np.prod(shape)) * 16 * (nf * (((s3 + 1) // 2 + 1) // 2) + nf * (nf - 1) // 2 * ((s3 + 1) // 2))
+    assert info["value_bytes"] < 0.56 * 8 * nf * nf * s3 * int(np.prod(shape))
+    for chunks in ("1", "3"):
+        monkeypatch.setenv("TIGAR_SYMGRID_CHUNKS", chunks)
+        y3, info3 = dA.mult_symgrid(dx)
+        assert info3 is not None and np.max(np.abs(y3.get_local() - ref) / scale) < 1e-14, chunks
+    monkeypatch.delenv("TIGAR_SYMGRID_CHUNKS")
+    # the same matrix with the fields numbered plane by plane (dist.FieldSlabPath: k nF pd + f pd + ij)
+    pd, n2 = shape[0] * shape[1], shape[2]
+    f_, k_, ij_ = np.meshgrid(np.arange(nf), np.arange(n2), np.arange(pd), indexing="ij")
+    new_of_old = (k_ * nf * pd + f_ * pd + ij_).ravel()
+    old_of_new = np.argsort(new_of_old)
+    Ap = A[old_of_new][:, old_of_new].tocsr()
+    Ap.sort_indices()
+    yp, infop = dev.DeviceCSR.from_scipy(Ap).mult_symgrid(dev.DeviceVector(data=x[old_of_new]))
+    assert infop is not None and infop["value_bytes"] == info["value_bytes"]
+    assert np.max(np.abs(yp.get_local() - ref[old_of_new]) / scale[old_of_new]) < 1e-14
+    B = _block_box_stencil(rng, shape, reach, nf, symmetric=False)
+    yb, infob = dev.DeviceCSR.from_scipy(B).mult_symgrid(dx)
+    assert infob is None
+    assert dev.DeviceCSR.from_scipy(B[old_of_new][:, old_of_new].tocsr()).mult_symgrid(dx)[1] is None
+    # one entry of one off-diagonal block moved out of the box: declined as well
+    C = A.tolil()
+    n = int(np.prod(shape))
+    C[5, n + 5 + (reach + 1)] = 1.0
+    C[n + 5 + (reach + 1), 5] = 1.0
+    C = C.tocsr()
+    C.sort_indices()
+    assert dev.DeviceCSR.from_scipy(C).mult_symgrid(dx)[1] is None
+
+
+def test_cg_solve_of_three_displacement_fields_on_the_half_storage_copy(dev, monkeypatch):
+    """linear elasticity on a 3-D patch (EqualOrderSpline(3, ...), tIGAr/common.py:1891-1914): the CG solve runs on the
+    half-storage copy of the nine-block K and agrees with the solve on the sliced copy"""
+    import tigar_amd as t
+    from tigar_amd import BSplines as B, forms as F
+    from tigar_amd.device import DeviceVector
+    p, nels = 2, (26, 27, 28)
+    kvs = [B.uniformKnots(p, 0., 1., n) for n in nels]
+    gen = t.EqualOrderSpline(3, B.ExplicitBSplineControlMesh([p] * 3, kvs))
+    sp0 = gen.getScalarSpline(0)
+    for f in range(3):
+        gen.addZeroDofs(f, sp0.getSideDofs(0, 0))
+    spline = t.ExtractedSpline(gen, 2 * p)
+    K = spline.assembleMatrix(F.ElasticityForm(1.3, 0.7))
+    n = K.shape[0]
+    assert n >= 65536
+    rhs = DeviceVector(data=np.random.default_rng(3).standard_normal(n))
+    rhs.zero_entries(np.asarray(sorted(spline.zeroDofs), dtype=np.int64), 0) if hasattr(rhs, "zero_entries") else None
+    x = DeviceVector(data=np.random.default_rng(1).standard_normal(n))
+    y, info = K.mult_symgrid(x)
+    assert info is not None
+    y0 = K.mult(x).get_local()
+    assert np.max(np.abs(y.get_local() - y0)) <= 1e-13 * np.max(np.abs(y0))
+    monkeypatch.setenv("TIGAR_KSP_PERSISTENT", "0")
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TIGAR_SPMV_SYM", mode)
+        ks = t.PETScKrylovSolver("cg", "jacobi")
+        ks.parameters["relative_tolerance"] = 1e-9
+        U = DeviceVector(n)
+        c0 = dev.prof_get(7)[1]
+        its = ks.solve(K, U, rhs)
+        assert ks.last["status"] == 0
+        assert dev.prof_get(7)[1] - c0 == int(mode)
+        res[mode] = (its, U.get_local())
+    assert abs(res["0"][0] - res["1"][0]) <= 1
+    assert np.max(np.abs(res["0"][1] - res["1"][1])) <= 1e-7 * np.max(np.abs(res["0"][1]))

@@ -40,6 +40,7 @@
 #define SG_PY4 12
 
 typedef double sg_d2 __attribute__((ext_vector_type(2)));
+typedef unsigned int sg_u2 __attribute__((ext_vector_type(2)));
 
 template <int P>
 struct sg_c {
@@ -118,10 +119,22 @@ struct tg_symgrid_s {
   double *stage = nullptr;      // [patch][chunk][plane of the chunk + P][W]
   int64_t val_bytes = 0, stage_bytes = 0;
   int64_t rows_stored = 0;      // lanes that hold a row (the bytes a product reads: rows_stored * NG * 16)
+  // several fields on one scalar basis (nf > 1): this object is the container -- gd / gf hold the geometry (tables, staging
+  // array) of the diagonal and of the full blocks, vd[f] / vf[f * 4 + g] (f < g) the values
+  int nf = 1;
+  int64_t ncp = 0;
+  // numbering of the fields: entry (field f, plane z, in-plane index ij) of x / y at f * fs + z * zs + ij -- field after field
+  // (fs = ncp, zs = n0 n1: tIGAr/common.py:242-252) or plane by plane (fs = n0 n1, zs = nF n0 n1: dist.FieldSlabPath)
+  int64_t fs = 0, zs = 0;
+  tg_symgrid_s *gd = nullptr, *gf = nullptr;
+  sg_d2 *vd[4] = {nullptr, nullptr, nullptr, nullptr};
+  sg_d2 *vf[16] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 struct sg_dev {
   int n0, n1, n2, npx, npy, nch, m, czmax, n2g, zoff;
+  int zs;                  // entries of x / y between two planes of the grid (n0 n1; several fields plane by plane: nF n0 n1)
   const int32_t *x0, *y0, *z0, *px_of, *py_of, *pc_of;
 };
 
@@ -129,6 +142,7 @@ static sg_dev sg_view(const tg_symgrid_s *s) {
   sg_dev d;
   d.n0 = s->n0, d.n1 = s->n1, d.n2 = s->n2, d.npx = s->npx, d.npy = s->npy, d.nch = s->nch, d.m = s->m, d.czmax = s->czmax;
   d.n2g = s->n2g, d.zoff = s->zoff;
+  d.zs = s->zs > 0 ? (int)s->zs : s->n0 * s->n1;
   d.x0 = s->tabs;
   d.y0 = d.x0 + s->npx + 1;
   d.z0 = d.y0 + s->npy + 1;
@@ -144,7 +158,11 @@ void tg_symgrid_free(tg_symgrid_s *s) {
     tg_dfree(s->tabs);
     tg_dfree(s->val);
     tg_dfree(s->stage);
+    for (int i = 0; i < 4; i++) tg_dfree(s->vd[i]);
+    for (int i = 0; i < 16; i++) tg_dfree(s->vf[i]);
   }
+  tg_symgrid_free(s->gd);
+  tg_symgrid_free(s->gf);
   delete s;
 }
 
@@ -304,7 +322,7 @@ __global__ void __launch_bounds__(64)
   for (int e = lane; e < (P + 1) * W; e += 64) acc[e] = 0.0;
   const __amdgpu_buffer_rsrc_t xr =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(xw), 0, (unsigned)xlen * 8u, 0x00020000);
-  const int n0 = G.n0, n01 = G.n0 * G.n1;
+  const int n0 = G.n0;
   // in-plane offset of this lane's window entries (the same for every plane); out of the grid: no read (0)
   unsigned woff[NXL];
 #pragma unroll
@@ -317,7 +335,7 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
     for (int k = 0; k < NXL; k++)
       dst[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                                              xr, woff[k] == 0xffffffffu ? 0xffffffffu : (woff[k] + (unsigned)(zp * n01)) * 8u, 0, 0));
+                                              xr, woff[k] == 0xffffffffu ? 0xffffffffu : (woff[k] + (unsigned)(zp * G.zs)) * 8u, 0, 0));
   };
   auto store_plane = [&](int zp, const double *src) {
     const int s0 = (zp % (P + 1)) * W;
@@ -428,6 +446,282 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Several fields on one scalar basis (round 6): K of nF x nF blocks K_fg, every block the box stencil of the scalar grid,
+// K symmetric as a whole (K_gf = K_fg^T) -- the stiffness matrix of linear elasticity, tIGAr/common.py:1891-1914 +
+// 1255-1258.  The diagonal blocks are symmetric box stencils themselves: half storage and the kernels above, block by
+// block.  An off-diagonal pair is stored ONCE, as the full box of K_fg (f < g, (2P+1)^3 positions per row), and used twice,
+//     y_f[i]       += K_fg[i][i+off] * x_g[i+off]      (the row)
+//     y_g[i+off]   += K_fg[i][i+off] * x_f[i]          (the row of K_gf, transposed),
+// so a product moves nF (S^3 + 1) / 2 + nF (nF - 1) / 2 S^3 values per node instead of nF^2 S^3: a half.  The scatter now
+// reaches the P planes BELOW the row's plane as well: rings of 2P + 1 window planes (patches of 16 x 12 points: 44 KB at
+// P = 3), a finished plane is the one P below the current, and a chunk hands P planes of windows to the chunk before it as
+// well as to the next.  The row sums go straight to y_f (each row belongs to one lane of one wave of the launch: a plain
+// read - add - write, the launches of a product in a fixed order), the windows through the staging array to y_g.
+template <int P>
+struct sg_cf {
+  static constexpr int S = 2 * P + 1, NP = S * S * S, NG = (NP + 1) / 2, NR = S;     // NR: planes of a ring
+  static constexpr int PX = SG_PX4, PY = SG_PY4, TAB = PX * PY;
+  static constexpr int Wx = PX + 2 * P, Wy = PY + 2 * P, W = Wx * Wy;
+  // storage order: groups of equal (dx, dy), members dz = -P .. P (consecutive values go to different planes of the ring)
+  __host__ __device__ static constexpr int inv(int dx, int dy, int dz) { return ((dy + P) * S + (dx + P)) * S + (dz + P); }
+  static constexpr int NBR = (S * S + 1) / 2, NBATCH = (NBR + 3) / 4 * 4;           // batches of two groups; empty ones pad
+  __host__ __device__ static constexpr int bstart(int b) { return b < NBR ? b * 2 * S : 2 * NG; }
+  static constexpr int GBMAX = S;
+};
+static_assert(sg_cf<3>::bstart(sg_cf<3>::NBR) - sg_cf<3>::bstart(sg_cf<3>::NBR - 1) == 8 && sg_cf<2>::NBATCH == 16, "full boxes");
+
+// conversion of block (f, g) of the rows of K: one wave per row of the scalar grid, the entries of the block straight to
+// their places (the copies are zeroed before: lanes beyond a patch, positions beyond the grid).  FULL: the whole box;
+// otherwise the tail from the diagonal on in the order of sg_lay (the diagonal blocks).  Every row's length and every
+// column index of the block are checked against the box stencil.
+struct sg_blk {
+  int nf, f, g;
+  int64_t ncp;                 // points of the scalar grid = rows per field
+  int64_t fs, zs;              // numbering: (field, plane, in-plane index) at f fs + z zs + ij
+};
+template <int P, bool FULL>
+__global__ void __launch_bounds__(256)
+    k_symgrid_convert_blk(sg_dev G, sg_blk B, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                          const double *__restrict__ val, double *__restrict__ out, int *__restrict__ fail) {
+  typedef sg_c<P> C;
+  constexpr int NG = FULL ? sg_cf<P>::NG : C::NG;
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  const int n0 = G.n0, n01 = G.n0 * G.n1;
+  bool bad = false;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < B.ncp; row += nw) {
+    const int ix = (int)(row % n0), iy = (int)((row / n0) % G.n1), z = (int)(row / n01);
+    const int a = G.px_of[ix], b = G.py_of[iy];
+    const int xa = G.x0[a], pxv = G.x0[a + 1] - xa, ya = G.y0[b];
+    const int t = (iy - ya) * pxv + (ix - xa), sub = t >> 6, l = t & 63;
+    const int64_t blk = ((int64_t)(b * G.npx + a) * G.n2 + z) * G.m + sub;
+    double *o = out + (blk * (int64_t)(NG * 64) + l) * 2;
+    const int dxlo = -min(P, ix), nx = min(P, n0 - 1 - ix) - dxlo + 1;
+    const int dylo = -min(P, iy), ny = min(P, G.n1 - 1 - iy) - dylo + 1;
+    const int dzlo = -min(P, z), nz = min(P, G.n2 - 1 - z) - dzlo + 1;
+    const int len = nx * ny * nz;
+    const int64_t ij = row - (int64_t)z * n01;
+    const int64_t r = B.f * B.fs + z * B.zs + ij, e0 = rowptr[r];
+    if (rowptr[r + 1] - e0 != (int64_t)len * B.nf) {
+      bad = true;
+      continue;
+    }
+    const int nxy = nx * ny;
+    const int kd = FULL ? 0 : ((0 - dzlo) * ny + (0 - dylo)) * nx + (0 - dxlo);
+    // (the columns of a row ascend: field after field, the nF boxes follow each other; plane by plane, the nF pieces of a
+    //  plane dz do -- a piece = the nx ny entries of box g in that plane)
+    const bool fm = B.zs == n01;
+    const int64_t cb = B.g * B.fs + z * B.zs + ij;
+    for (int k = kd + lane; k < len; k += 64) {
+      const int qz = k / nxy, rem = k - qz * nxy, qy = rem / nx, qx = rem - qy * nx;
+      const int dz = qz + dzlo, dy = qy + dylo, dx = qx + dxlo;
+      const int64_t e = fm ? e0 + (int64_t)B.g * len + k : e0 + ((int64_t)qz * B.nf + B.g) * nxy + rem;
+      bad |= (int64_t)col[e] != cb + dx + n0 * dy + B.zs * dz;
+      const int si = FULL ? sg_cf<P>::inv(dx, dy, dz) : sg_lay<P>::inv(((dz + P) * C::S + dy + P) * C::S + dx + P - C::LC);
+      o[(int64_t)(si >> 1) * 128 + (si & 1)] = val[e];
+    }
+  }
+  if (bad) atomicExch(fail, 1);
+}
+
+// product with a stored full block: one wave per (patch, z chunk), as k_symgrid_spmv with rings of 2P + 1 planes
+template <int P>
+__global__ void __launch_bounds__(64)
+    k_symgrid_spmv_full(sg_dev G, const sg_d2 *__restrict__ val, const double *__restrict__ xg, const double *__restrict__ xf,
+                        double *__restrict__ yf, int xlen, int ylen, double *__restrict__ stage, int64_t nwaves,
+                        const double *__restrict__ gate, double gate_tol) {
+  typedef sg_cf<P> Y;
+  constexpr int Wx = Y::Wx, W = Y::W, GB = Y::GBMAX, NB = Y::NBATCH, NXL = (W + 63) / 64, NR = Y::NR, S = Y::S;
+  __shared__ double acc[NR * W];
+  __shared__ double xs[NR * W];
+  __shared__ unsigned short tab[Y::TAB];
+  if (gate && !(*gate > gate_tol)) return;
+  const int lane = threadIdx.x;
+  const int64_t L = tg_xcd_block(blockIdx.x, nwaves);
+  if (L >= nwaves) return;
+  const int c = (int)(L % G.nch), patch = (int)(L / G.nch);
+  const int a = patch % G.npx, b = patch / G.npx;
+  const int xa = G.x0[a], pxv = G.x0[a + 1] - xa, ya = G.y0[b], pyv = G.y0[b + 1] - ya;
+  const int za = G.z0[c], zb = G.z0[c + 1];
+  const int cnt = pxv * pyv, msub = (cnt + 63) >> 6;
+  for (int t = lane; t < cnt; t += 64) {
+    const int ly = t / pxv;
+    tab[t] = (unsigned short)((ly << 8) | (t - ly * pxv));
+  }
+  for (int e = lane; e < NR * W; e += 64) acc[e] = 0.0;
+  const __amdgpu_buffer_rsrc_t xr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(xg), 0, (unsigned)xlen * 8u, 0x00020000);
+  const int n0 = G.n0;
+  unsigned woff[NXL];
+#pragma unroll
+  for (int k = 0; k < NXL; k++) {
+    const int e = k * 64 + lane, wy = e / Wx, wx = e - wy * Wx;
+    const int gy = ya - P + wy, gx = xa - P + wx;
+    woff[k] = (e < W && gy >= 0 && gy < G.n1 && gx >= 0 && gx < n0) ? (unsigned)(gy * n0 + gx) : 0xffffffffu;
+  }
+  auto slot = [&](int zp) { return ((zp + NR) % NR) * W; };      // (zp >= -P)
+  auto load_plane = [&](int zp, double *dst) {       // plane zp of the window of x_g (outside the grid: 0)
+    const bool in = zp >= 0 && zp < G.n2;
+#pragma unroll
+    for (int k = 0; k < NXL; k++)
+      dst[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                              xr, (woff[k] == 0xffffffffu || !in) ? 0xffffffffu : (woff[k] + (unsigned)(zp * G.zs)) * 8u, 0, 0));
+  };
+  auto store_plane = [&](int zp, const double *src) {
+    const int s0 = slot(zp);
+#pragma unroll
+    for (int k = 0; k < NXL; k++)
+      if (k * 64 + lane < W) xs[s0 + k * 64 + lane] = src[k];
+  };
+  {
+    double tmp[NXL];
+#pragma unroll
+    for (int d = -P; d <= P; d++) {
+      load_plane(za + d, tmp);
+      store_plane(za + d, tmp);
+    }
+  }
+  __syncthreads();
+  double *st = stage + ((int64_t)patch * G.nch + c) * (int64_t)(G.czmax + 2 * P) * W;      // planes za - P .. zb + P - 1
+  const sg_d2 *vp = val + (int64_t)patch * G.n2 * G.m * (int64_t)(Y::NG * 64) + lane;
+  // (no branch inside the walk: a lane without a row reads row 0 and stores through the buffer descriptor with an offset
+  //  beyond its range, which the hardware drops -- a divergent `if` around the store splits the block the value loads are
+  //  scheduled in and the loads of a whole row end up in flight at once: 4 KB of scratch per lane)
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(yf, 0, (unsigned)ylen * 8u, 0x00020000);
+  struct ctx_t {
+    int lb;
+    const sg_d2 *v;
+    unsigned yoff;           // byte offset of the row in y_f, 0xffffffff: no row in this lane
+    double xi, yo;
+  };
+  auto ctx_of = [&](int z, int sub) {
+    ctx_t k;
+    const int t = sub * 64 + lane, zc = min(z, G.n2 - 1);
+    const bool on = t < cnt && z < zb;
+    const int tl = t < cnt ? tab[t] : 0, ly = tl >> 8, lx = tl & 255;
+    k.lb = ly * Wx + lx;
+    k.v = vp + ((int64_t)zc * G.m + sub) * (Y::NG * 64);
+    const int row = on ? zc * G.zs + (ya + ly) * n0 + xa + lx : 0;
+    k.yoff = on ? (unsigned)row * 8u : 0xffffffffu;
+    k.xi = xf[row];
+    k.yo = yf[row];
+    return k;
+  };
+  constexpr int VD = 4;
+  sg_d2 vv[VD][GB];
+  auto issue_v = [&](const ctx_t &k, auto btc) {
+    constexpr int BT = decltype(btc)::value, b0 = Y::bstart(BT), b1 = Y::bstart(BT + 1);
+#pragma unroll
+    for (int j = 0; j < (b1 - b0) / 2; j++) vv[BT % VD][j] = __builtin_nontemporal_load(k.v + (b0 / 2 + j) * 64);
+  };
+  ctx_t cur = ctx_of(za, 0);
+  sg_each(std::make_integer_sequence<int, VD - 1>{}, [&](auto btc) { issue_v(cur, btc); });
+  for (int z = za; z < zb; z++) {
+    int so[NR];
+#pragma unroll
+    for (int d = 0; d < NR; d++) so[d] = slot(z + d - P);
+    double xnext[NXL];
+    load_plane(z + P + 1, xnext);
+    for (int sub = 0; sub < msub; sub++) {
+      const ctx_t nxt = (sub + 1 < msub) ? ctx_of(z, sub + 1) : ctx_of(z + 1, 0);
+      const double xi = cur.xi;
+      double sum = 0.0;
+      sg_each(std::make_integer_sequence<int, NB>{}, [&](auto btc) {
+        constexpr int BT = decltype(btc)::value;
+        if constexpr (BT + VD - 1 < NB)
+          issue_v(cur, std::integral_constant<int, BT + VD - 1>{});
+        else
+          issue_v(nxt, std::integral_constant<int, BT + VD - 1 - NB>{});
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int b0 = Y::bstart(BT), b1 = Y::bstart(BT + 1);
+        constexpr int ng = (b1 - b0 + S - 1) / S;
+#pragma unroll
+        for (int gq = 0; gq < ng; gq++) {
+          double r[S], cc[S];
+          int idx[S];
+#pragma unroll
+          for (int t = 0; t < S; t++) {
+            const int kk = b0 + gq * S + t, l = kk - b0;
+            const bool on = kk < b1 && kk < Y::NP;
+            const int gi = kk / S, dz = kk - gi * S - P, dx = gi % S - P, dy = gi / S - P;
+            const double vq = (l & 1) ? vv[BT % VD][l >> 1].y : vv[BT % VD][l >> 1].x;
+            if (on) {
+              idx[t] = so[dz + P] + cur.lb + (dy + P) * Wx + dx + P;
+              sum += vq * xs[idx[t]];
+              r[t] = acc[idx[t]];
+              cc[t] = vq * xi;
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < S; t++) {
+            const int kk = b0 + gq * S + t;
+            if (kk < b1 && kk < Y::NP) acc[idx[t]] = r[t] + cc[t];
+          }
+          asm volatile("" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sg_u2, cur.yo + sum), yr, cur.yoff, 0, 0);
+      cur = nxt;
+    }
+    __syncthreads();
+    // plane z - P is finished: no later row of the chunk reaches it
+    double *sp = st + (int64_t)(z - za) * W;
+    for (int e = lane; e < W; e += 64) {
+      sp[e] = acc[so[0] + e];
+      acc[so[0] + e] = 0.0;
+    }
+    store_plane(z + P + 1, xnext);                     // (into the slot of plane z - P, which no row reads any more)
+    __syncthreads();
+  }
+#pragma unroll
+  for (int d = 0; d < 2 * P; d++) {                    // planes zb - P .. zb + P - 1
+    const int z = zb - P + d;
+    double *sp = st + (int64_t)(z - (za - P)) * W;
+    for (int e = lane; e < W; e += 64) sp[e] = acc[slot(z) + e];
+  }
+}
+
+// y_g[i] += sum of the windows of a full block that cover point i (its own chunk, P planes handed down by the next chunk,
+// P planes handed up by the one before), in a fixed order
+template <int P>
+__global__ void __launch_bounds__(256)
+    k_symgrid_combine_full(sg_dev G, const double *__restrict__ stage, double *__restrict__ y, int64_t nlines,
+                           const double *__restrict__ gate, double gate_tol) {
+  typedef sg_cf<P> Y;
+  constexpr int Wx = Y::Wx, W = Y::W;
+  if (gate && !(*gate > gate_tol)) return;
+  const int64_t cstride = (int64_t)(G.czmax + 2 * P) * W;
+  for (int ix = threadIdx.x; ix < G.n0; ix += 256) {
+    const int a0 = G.px_of[ix];
+    const int alo = (a0 > 0 && ix - G.x0[a0] < P) ? a0 - 1 : a0;
+    const int ahi = (a0 + 1 < G.npx && G.x0[a0 + 1] - ix <= P) ? a0 + 1 : a0;
+    const int64_t astride = (int64_t)G.nch * cstride;
+    const int64_t o0 = (int64_t)a0 * astride + (ix - G.x0[a0]);
+    const int64_t olo = alo < a0 ? (int64_t)alo * astride + (ix - G.x0[alo]) : -1;
+    const int64_t ohi = ahi > a0 ? (int64_t)ahi * astride + (ix - G.x0[ahi]) : -1;
+    for (int64_t line = blockIdx.x; line < nlines; line += gridDim.x) {
+      const int iy = (int)(line % G.n1), iz = (int)(line / G.n1);
+      const int b0 = G.py_of[iy], c0 = G.pc_of[iz];
+      const int blo = (b0 > 0 && iy - G.y0[b0] < P) ? b0 - 1 : b0;
+      const int bhi = (b0 + 1 < G.npy && G.y0[b0 + 1] - iy <= P) ? b0 + 1 : b0;
+      const int clo = (c0 > 0 && iz - G.z0[c0] < P) ? c0 - 1 : c0;
+      const int chi = (c0 + 1 < G.nch && G.z0[c0 + 1] - iz <= P) ? c0 + 1 : c0;
+      double s = 0.0;
+      for (int c = clo; c <= chi; c++)
+        for (int b = blo; b <= bhi; b++) {
+          const double *sb = stage + ((int64_t)(b * G.npx) * G.nch + c) * cstride + (int64_t)(iz - (G.z0[c] - P)) * W +
+                             (iy - G.y0[b] + P) * Wx + P;
+          if (olo >= 0) s += sb[olo];
+          s += sb[o0];
+          if (ohi >= 0) s += sb[ohi];
+        }
+      y[(int64_t)iz * G.zs + iy * G.n0 + ix] += s;
+    }
+  }
+}
+
 // y[i] = sum of the windows that cover point i, in a fixed order.  One workgroup per grid line (iy, iz): which patch rows
 // and chunks cover the line is wave-uniform, a thread only looks up the patch column of its ix.
 template <int P>
@@ -462,7 +756,7 @@ __global__ void __launch_bounds__(256)
           s += sb[o0];
           if (ohi >= 0) s += sb[ohi];
         }
-      y[line * G.n0 + ix] = s;
+      y[(int64_t)iz * G.zs + iy * G.n0 + ix] = s;
     }
   }
 }
@@ -553,8 +847,13 @@ static void sg_launch_spmv(const tg_symgrid_s *s, tg_csr_s *a, const double *x_s
 
 // y = K x for the row block the plan was built for; x addressed by GLOBAL column index (x_shifted[col]), readable in
 // [cmin, cmax] (the rank's rows and the halo of its z neighbours; one rank: [0, n - 1]).  part: see sg_launch_spmv
+static int sg_multi_spmv(tg_symgrid_s *s, tg_csr_s *a, const double *x, double *y, const double *gate, double gate_tol);
 int tg_symgrid_spmv(tg_symgrid_s *s, tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y, int part,
                     const double *gate, double gate_tol) {
+  if (s->nf > 1) {         // (one rank, all columns: part is 0)
+    TG_REQUIRE(part == 0 && cmin == 0 && cmax == a->ncols - 1, "the several-field half-storage product runs on one rank");
+    return sg_multi_spmv(s, a, x_shifted, y, gate, gate_tol);
+  }
   switch (s->P) {
     case 1: sg_launch_spmv<1>(s, a, x_shifted, cmin, cmax, y, part, gate, gate_tol); break;
     case 2: sg_launch_spmv<2>(s, a, x_shifted, cmin, cmax, y, part, gate, gate_tol); break;
@@ -564,7 +863,7 @@ int tg_symgrid_spmv(tg_symgrid_s *s, tg_csr_s *a, const double *x_shifted, int64
   TG_LAUNCH_CHECK();
   return 0;
 }
-int tg_symgrid_chunks(const tg_symgrid_s *s) { return s->nch; }
+int tg_symgrid_chunks(const tg_symgrid_s *s) { return s->nf > 1 ? 1 : s->nch; }
 
 // the longest row (the first of them): an interior row of a box stencil, if there is one
 __global__ void k_symgrid_longest(const int64_t *__restrict__ rowptr, int64_t n, unsigned long long *out) {
@@ -617,6 +916,263 @@ static int sg_detect(tg_csr_s *a, int64_t row0, int *Pout, int *n0o, int *n1o, i
   return 0;
 }
 
+// ---- several fields on one scalar grid (see k_symgrid_spmv_full)
+// nF, P, n0, n1, n2 from the longest row: nF boxes of (2P+1)^3 columns, box g shifted by g * ncp
+static int sg_detect_multi(tg_csr_s *a, int *nfo, int *Pout, int *n0o, int *n1o, int *n2o, int *byplane, bool *found) {
+  *found = false;
+  const int64_t n = a->nrows;
+  unsigned long long *o = (unsigned long long *)(g_tg.scratch + 96);
+  unsigned long long key = 0;
+  TG_CHECK_HIP(hipMemcpyAsync(o, &key, sizeof(key), hipMemcpyHostToDevice, g_tg.stream));
+  hipLaunchKernelGGL(k_symgrid_longest, dim3(tg_grid_1d(n, 256)), dim3(256), 0, g_tg.stream, a->rowptr, n, o);
+  TG_LAUNCH_CHECK();
+  TG_CHECK_HIP(hipMemcpyAsync(&key, o, sizeof(key), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  const int64_t len = (int64_t)(key >> 32), rl = (int64_t)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+  int P = 0, nf = 0;
+  for (int f = 2; f <= 4 && !P; f++)
+    for (int p = 1; p <= 3; p++)
+      if (len == (int64_t)f * (2 * p + 1) * (2 * p + 1) * (2 * p + 1) && n % f == 0) P = p, nf = f;
+  if (!P || rl < 0 || rl >= n) return 0;
+  const int64_t ncp = n / nf;
+  int64_t e0 = 0;
+  TG_CHECK_HIP(hipMemcpyAsync(&e0, a->rowptr + rl, sizeof(e0), hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  std::vector<int32_t> c((size_t)len);
+  TG_CHECK_HIP(hipMemcpyAsync(c.data(), a->col + e0, sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost, g_tg.stream));
+  TG_CHECK_HIP(hipStreamSynchronize(g_tg.stream));
+  const int S = 2 * P + 1, S3 = S * S * S;
+  // n0 from the first two lines of the first box (both numberings start a row with the dx run of (dy, dz) = (-P, -P) of
+  // field 0, followed by the run of dy = -P + 1), the plane from the numbering that fits all columns
+  const int64_t n0 = (int64_t)c[(size_t)S] - (int64_t)c[0];
+  if (n0 < 2 * P + 1) return 0;
+  for (int bp = 0; bp < 2 && !*found; bp++) {
+    // field after field: box g at [g S3, (g+1) S3), plane stride n01; plane by plane: plane dz holds the nf pieces of S*S
+    const int64_t second = bp ? (int64_t)c[(size_t)(nf * S * S)] : (int64_t)c[(size_t)(S * S)];      // first column of plane dz = -P + 1
+    const int64_t zs = second - (int64_t)c[0];
+    const int64_t n01 = bp ? zs / nf : zs;
+    if (zs <= 0 || (bp && zs % nf) || n01 <= 0 || n01 % n0 || ncp % n01) continue;
+    const int64_t fs = bp ? n01 : ncp;
+    // the row itself: (field f, plane z, in-plane ij)
+    int64_t f, z, ij;
+    if (bp) {
+      z = rl / zs, f = (rl % zs) / n01, ij = rl % n01;
+    } else {
+      f = rl / ncp, z = (rl % ncp) / n01, ij = rl % n01;
+    }
+    (void)f;
+    bool ok = true;
+    for (int g = 0; g < nf && ok; g++)
+      for (int l = 0; l < S3 && ok; l++) {
+        const int dx = l % S - P, dy = (l / S) % S - P, dz = l / (S * S) - P;
+        const size_t at = bp ? (size_t)(((dz + P) * nf + g) * S * S + l % (S * S)) : (size_t)(g * S3 + l);
+        ok = (int64_t)c[at] == g * fs + (z + dz) * zs + ij + dx + n0 * dy;
+      }
+    if (!ok) continue;
+    *nfo = nf, *Pout = P, *n0o = (int)n0, *n1o = (int)(n01 / n0), *n2o = (int)(ncp / n01), *byplane = bp;
+    *found = true;
+  }
+  return 0;
+}
+
+// patches, chunks and their tables for an n0 x n1 x n2 grid cut into px x py patches (what tg_symgrid_build does inline for
+// the scalar plan); staging for `overhang` planes of windows beyond a chunk
+static int sg_geometry(tg_symgrid_s *s, int px, int py, int overhang, int W) {
+  const int n0 = s->n0, n1 = s->n1, n2 = s->n2, P = s->P;
+  s->npx = (n0 + px - 1) / px;
+  s->npy = (n1 + py - 1) / py;
+  const int64_t npatch = (int64_t)s->npx * s->npy;
+  int want = getenv("TIGAR_SYMGRID_CHUNKS") ? atoi(getenv("TIGAR_SYMGRID_CHUNKS")) : 0;
+  if (want <= 0) want = (int)std::max<int64_t>(n2 / 12, tg_cdiv((int64_t)g_tg.num_cu * 2, npatch));
+  s->nch = std::max(1, std::min(want, n2 / std::max(P, 4)));
+  std::vector<int32_t> h;
+  auto split = [&](int n, int parts) {
+    for (int k = 0; k <= parts; k++) h.push_back((int32_t)((int64_t)k * n / parts));
+  };
+  const size_t ox = 0;
+  split(n0, s->npx);
+  const size_t oy = h.size();
+  split(n1, s->npy);
+  const size_t oz = h.size();
+  split(n2, s->nch);
+  auto owner = [&](size_t o, int parts, int n) {
+    int k = 0;
+    for (int i = 0; i < n; i++) {
+      while (k + 1 < parts && h[o + k + 1] <= i) k++;
+      h.push_back(k);
+    }
+  };
+  owner(ox, s->npx, n0);
+  owner(oy, s->npy, n1);
+  owner(oz, s->nch, n2);
+  int cmax = 0;
+  for (int x = 0; x < s->npx; x++)
+    for (int y = 0; y < s->npy; y++) cmax = std::max(cmax, (h[ox + x + 1] - h[ox + x]) * (h[oy + y + 1] - h[oy + y]));
+  s->m = (cmax + 63) / 64;
+  s->czmax = 0;
+  for (int c = 0; c < s->nch; c++) s->czmax = std::max(s->czmax, h[oz + c + 1] - h[oz + c]);
+  s->stage_bytes = npatch * s->nch * (int64_t)(s->czmax + overhang) * W * 8;
+  TG_TRY(tg_dmalloc(&s->tabs, (int64_t)h.size()));
+  TG_TRY(tg_h2d_staged(s->tabs, h.data(), h.size() * sizeof(int32_t)));
+  void *p = nullptr;
+  if (tg_dmalloc_bytes(&p, (size_t)s->stage_bytes)) return 100;      // no room: declined
+  s->stage = (double *)p;
+  return 0;
+}
+
+template <int P>
+static int sg_multi_convert(tg_symgrid_s *s, tg_csr_s *a, int *ctl) {
+  const int nf = s->nf;
+  for (int f = 0; f < nf; f++)
+    for (int g = f; g < nf; g++) {
+      tg_symgrid_s *geo = f == g ? s->gd : s->gf;
+      const int NG = f == g ? sg_c<P>::NG : sg_cf<P>::NG;
+      const int64_t bytes = (int64_t)geo->npx * geo->npy * geo->n2 * geo->m * NG * 64 * 16;
+      void *p = nullptr;
+      if (tg_dmalloc_bytes(&p, (size_t)bytes)) return 100;
+      (f == g ? s->vd[f] : s->vf[f * 4 + g]) = (sg_d2 *)p;
+      TG_CHECK_HIP(hipMemsetAsync(p, 0, (size_t)bytes, g_tg.stream));
+      s->val_bytes += s->ncp * (int64_t)NG * 16;       // (what a product reads of the block: the lanes that hold a row)
+      const sg_blk B = {nf, f, g, s->ncp, s->fs, s->zs};
+      const unsigned grid = (unsigned)std::min<int64_t>(tg_cdiv(s->ncp, 4), (int64_t)g_tg.num_cu * 64);
+      if (f == g)
+        hipLaunchKernelGGL((k_symgrid_convert_blk<P, false>), dim3(grid), dim3(256), 0, g_tg.stream, sg_view(geo), B, a->rowptr,
+                           a->col, a->val, (double *)p, ctl);
+      else
+        hipLaunchKernelGGL((k_symgrid_convert_blk<P, true>), dim3(grid), dim3(256), 0, g_tg.stream, sg_view(geo), B, a->rowptr,
+                           a->col, a->val, (double *)p, ctl);
+      TG_LAUNCH_CHECK();
+    }
+  return 0;
+}
+
+template <int P>
+static int sg_multi_spmv_p(tg_symgrid_s *s, tg_csr_s *a, const double *x, double *y, const double *gate, double tol) {
+  const int nf = s->nf;
+  const int64_t fs = s->fs, n = a->ncols;
+  // the diagonal blocks: y_f = K_ff x_f (the scalar kernels on the geometry gd; x / y from the field's first entry on)
+  for (int f = 0; f < nf; f++) {
+    tg_symgrid_s view = *s->gd;
+    view.val = s->vd[f];
+    view.gd = view.gf = nullptr;
+    sg_launch_spmv<P>(&view, a, x + f * fs, 0, n - f * fs - 1, y + f * fs, 0, gate, tol);
+    view.tabs = nullptr, view.val = nullptr, view.stage = nullptr;
+  }
+  // the pairs f < g: y_f += K_fg x_g in the product kernel, y_g += K_fg^T x_f from its windows
+  const tg_symgrid_s *G = s->gf;
+  const int64_t nw = (int64_t)G->npx * G->npy * G->nch, nlines = (int64_t)G->n1 * G->n2;
+  for (int f = 0; f < nf; f++)
+    for (int g = f + 1; g < nf; g++) {
+      hipLaunchKernelGGL(k_symgrid_spmv_full<P>, dim3((unsigned)(tg_cdiv(nw, 8) * 8)), dim3(64), 0, g_tg.stream, sg_view(G),
+                         s->vf[f * 4 + g], x + g * fs, x + f * fs, y + f * fs, (int)(n - g * fs), (int)(n - f * fs), G->stage, nw,
+                         gate, tol);
+      hipLaunchKernelGGL(k_symgrid_combine_full<P>, dim3((unsigned)std::min<int64_t>(nlines, (int64_t)g_tg.num_cu * 64)),
+                         dim3(256), 0, g_tg.stream, sg_view(G), G->stage, y + g * fs, nlines, gate, tol);
+    }
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+static int sg_multi_spmv(tg_symgrid_s *s, tg_csr_s *a, const double *x, double *y, const double *gate, double gate_tol) {
+  switch (s->P) {
+    case 1: return sg_multi_spmv_p<1>(s, a, x, y, gate, gate_tol);
+    case 2: return sg_multi_spmv_p<2>(s, a, x, y, gate, gate_tol);
+    default: return sg_multi_spmv_p<3>(s, a, x, y, gate, gate_tol);
+  }
+}
+
+static int sg_build_multi(tg_csr_s *a, int verify, tg_symgrid_s **out) {
+  const bool trace = getenv("TIGAR_TRACE") != nullptr;
+  int nf = 0, P = 0, n0 = 0, n1 = 0, n2 = 0, byplane = 0;
+  bool found = false;
+  TG_TRY(sg_detect_multi(a, &nf, &P, &n0, &n1, &n2, &byplane, &found));
+  if (!found || n0 < 16 || n1 < 16 || n2 < 2 * P + 2) {
+    if (trace) fprintf(stderr, "[trace] symgrid: no 3-D box stencil found (%lld rows)\n", (long long)a->nrows);
+    return 0;
+  }
+  tg_symgrid_s *s = new tg_symgrid_s;
+  s->P = P, s->n0 = n0, s->n1 = n1, s->n2 = n2, s->n2g = n2, s->nf = nf, s->ncp = (int64_t)n0 * n1 * n2;
+  s->fs = byplane ? (int64_t)n0 * n1 : s->ncp;
+  s->zs = byplane ? (int64_t)nf * n0 * n1 : (int64_t)n0 * n1;
+  s->rows_stored = a->nrows;
+  int rc = 0;
+  bool declined = false;
+  do {
+    for (int k = 0; k < 2; k++) {
+      tg_symgrid_s *g = new tg_symgrid_s;
+      (k == 0 ? s->gd : s->gf) = g;
+      g->P = P, g->n0 = n0, g->n1 = n1, g->n2 = n2, g->n2g = n2, g->zs = s->zs;
+      const int W = k == 0 ? (P == 1 ? sg_c<1>::W : P == 2 ? sg_c<2>::W : sg_c<3>::W)
+                           : (P == 1 ? sg_cf<1>::W : P == 2 ? sg_cf<2>::W : sg_cf<3>::W);
+      rc = sg_geometry(g, k == 0 ? SG_PX : SG_PX4, k == 0 ? SG_PY : SG_PY4, k == 0 ? P : 2 * P, W);
+      if (rc) break;
+      s->stage_bytes += g->stage_bytes;
+    }
+    if (rc) break;
+    int *ctl = (int *)(g_tg.scratch + 64);
+    int hflag[2] = {0, 0};
+    if (hipMemcpyAsync(ctl, hflag, sizeof(hflag), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess) {
+      rc = 1;
+      break;
+    }
+    rc = P == 1 ? sg_multi_convert<1>(s, a, ctl) : P == 2 ? sg_multi_convert<2>(s, a, ctl) : sg_multi_convert<3>(s, a, ctl);
+    if (rc) break;
+    if (hipMemcpyAsync(hflag, ctl, sizeof(hflag), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
+        hipStreamSynchronize(g_tg.stream) != hipSuccess) {
+      tg_set_error("tg_symgrid_build: conversion failed to run");
+      rc = 1;
+      break;
+    }
+    if (hflag[0]) {
+      if (trace) fprintf(stderr, "[trace] symgrid: a row is not %d box stencils (P=%d, %d x %d x %d): declined\n", nf, P, n0, n1, n2);
+      declined = true;
+      break;
+    }
+    if (verify && a->sym_verified != 1) {          // against the CSR product on a pseudo-random vector, as the scalar plan
+      const int64_t nx = a->ncols;
+      double *t = nullptr;
+      if ((rc = tg_dmalloc(&t, nx + 2 * a->nrows))) break;
+      double *x = t, *y1 = t + nx, *y2 = y1 + a->nrows;
+      unsigned long long *o = (unsigned long long *)(g_tg.scratch + 80);
+      unsigned long long ho[2] = {0, 0};
+      hipLaunchKernelGGL(k_symgrid_random, dim3(tg_grid_1d(nx, 256)), dim3(256), 0, g_tg.stream, x, nx, (int64_t)0);
+      rc = tg_spmv_plan(a);
+      if (!rc) rc = tg_spmv_raw(a, x, 0, nx - 1, y1);
+      if (!rc) rc = sg_multi_spmv(s, a, x, y2, nullptr, 0.0);
+      if (!rc && hipMemcpyAsync(o, ho, sizeof(ho), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess) rc = 1;
+      if (!rc) {
+        hipLaunchKernelGGL(k_symgrid_compare, dim3(tg_grid_1d(a->nrows, 256)), dim3(256), 0, g_tg.stream, y1, y2, a->nrows, o);
+        if (hipMemcpyAsync(ho, o, sizeof(ho), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
+            hipStreamSynchronize(g_tg.stream) != hipSuccess)
+          rc = 1;
+      }
+      tg_dfree(t);
+      if (rc) break;
+      double d, mx;
+      memcpy(&d, &ho[0], 8);
+      memcpy(&mx, &ho[1], 8);
+      if (trace) fprintf(stderr, "[trace] symgrid (%d fields): check vs CSR product: max |diff| %.3e, max |y| %.3e\n", nf, d, mx);
+      if (!(d <= 1e-10 * mx)) {
+        if (trace) fprintf(stderr, "[trace] symgrid: the matrix is not symmetric (or the copy is wrong): declined\n");
+        a->sym_verified = -1;
+        declined = true;
+        break;
+      }
+      a->sym_verified = 1;
+    }
+  } while (0);
+  if (rc == 100) rc = 0, declined = true;
+  if (rc || declined) {
+    if (g_tg.ready) hipStreamSynchronize(g_tg.stream);
+    tg_symgrid_free(s);
+    return rc;
+  }
+  if (trace)
+    fprintf(stderr, "[trace] symgrid: %d fields (numbered %s), P=%d grid %d x %d x %d, values %.2f GB (CSR: %.2f GB of values), staging %.2f GB\n",
+            nf, byplane ? "plane by plane" : "field after field", P, n0, n1, n2, s->val_bytes / 1e9, 8.0 * a->nnz / 1e9, s->stage_bytes / 1e9);
+  *out = s;
+  return 0;
+}
+
 // Builds the plan for the rows [row0, row0 + nrows) of a square matrix (the whole matrix, or the z slab of planes one
 // rank holds: whole planes of the grid); *out stays nullptr when the matrix is not a symmetric box stencil on a 3-D grid
 // (or there is no room for the copy).  verify: compare with the CSR product on a pseudo-random vector.
@@ -629,6 +1185,8 @@ int tg_symgrid_build(tg_csr_s *a, int64_t row0, int verify, tg_symgrid_s **out) 
   int P = 0, n0 = 0, n1 = 0, n2 = 0;
   bool found = false;
   TG_TRY(sg_detect(a, row0, &P, &n0, &n1, &n2, &found));
+  if (!found && row0 == 0 && a->nrows == a->ncols && !(getenv("TIGAR_SPMV_SYM_FIELDS") && atoi(getenv("TIGAR_SPMV_SYM_FIELDS")) == 0))
+    return sg_build_multi(a, verify, out);          // several fields on one scalar grid? (*out stays nullptr if not)
   if (!found || n0 < 16 || n1 < 16 || n2 < 2 * P + 2) {
     if (trace) fprintf(stderr, "[trace] symgrid: no 3-D box stencil found (%lld rows)\n", (long long)a->nrows);
     return 0;
@@ -767,6 +1325,11 @@ int tg_symgrid_build(tg_csr_s *a, int64_t row0, int verify, tg_symgrid_s **out) 
 }
 
 void tg_symgrid_info(const tg_symgrid_s *s, int64_t *val_bytes, int64_t *stage_bytes) {
+  if (s->nf > 1) {
+    if (val_bytes) *val_bytes = s->val_bytes;
+    if (stage_bytes) *stage_bytes = s->stage_bytes;
+    return;
+  }
   const int NG = s->P == 1 ? sg_c<1>::NG : s->P == 2 ? sg_c<2>::NG : s->P == 4 ? sg_c<4>::NG : sg_c<3>::NG;
   if (val_bytes) *val_bytes = s->rows_stored * NG * 16;
   if (stage_bytes) *stage_bytes = s->stage_bytes;
