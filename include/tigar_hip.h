@@ -59,9 +59,11 @@ int tg_timer_stop(int slot, double *ms);   /* synchronises; elapsed ms since sta
  * tensor-pattern PtAP (tg_tensor_zstage, tg_tensor2_ptap) that delivered rows of K -- "the line walks ran"; slot 6: CG /
  * GMRES solves that ran as ONE persistent kernel (small systems, csrc/tg_krylov_small.hip): count, and the time of those kernels
  * (their products are also counted in slot 0, with the kernel time spread over them -- an iteration, not a product);
- * slot 7 (count only): CG solves whose products ran on the half-storage copy of csrc/tg_symgrid.hip. */
+ * slot 7 (count only): CG solves whose products ran on the half-storage copy of csrc/tg_symgrid.hip; slot 8 (count only):
+ * direct solves (tg_lu_solve) that ran as a banded Cholesky factorisation (csrc/tg_chol.hip: symmetric positive definite K). */
 enum { TG_PROF_KSP_SPMV = 0, TG_PROF_KSP_OVERLAPPED = 1, TG_PROF_SELL_SHAPE_REUSED = 2, TG_PROF_PTAP_CERTIFIED = 3,
-       TG_PROF_COMM_HOST_WAITS = 4, TG_PROF_PTAP_TENSOR_WALKS = 5, TG_PROF_KSP_PERSISTENT = 6, TG_PROF_KSP_SYMGRID = 7, TG_PROF_NSLOTS = 8 };
+       TG_PROF_COMM_HOST_WAITS = 4, TG_PROF_PTAP_TENSOR_WALKS = 5, TG_PROF_KSP_PERSISTENT = 6, TG_PROF_KSP_SYMGRID = 7,
+       TG_PROF_LU_CHOLESKY = 8, TG_PROF_NSLOTS = 9 };
 int tg_prof_reset(void);
 int tg_prof_get(int slot, double *total_ms, int64_t *count);
 

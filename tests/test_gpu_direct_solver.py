@@ -265,3 +265,66 @@ def test_default_solver_tries_the_rcm_band_before_giving_lu_up():
     U = spline.solveLinearSystem(K, rhs, u)
     assert solver.last["iterations"] == 2
     assert np.array_equal(U.get_local(), want.get_local())
+
+
+# ---- round 6: symmetric positive definite systems are factorised as L L^T (csrc/tg_chol.hip) ------------------------------
+def _spd_band(rng, n, kl):
+    """symmetric band matrix with random off-diagonals, positive definite by diagonal dominance (condition ~ 10)"""
+    offs = list(range(1, kl + 1))
+    vals = [rng.standard_normal(n - o) for o in offs]
+    B = sp.diags(vals + vals, offs + [-o for o in offs], shape=(n, n), format="csr")
+    d = np.asarray(abs(B).sum(axis=1)).ravel() * (1.1 + rng.random(n))
+    A = (B + sp.diags(d)).tocsr()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("n,kl", [(64, 8), (257, 31), (1000, 40), (3001, 130), (5000, 333), (1300, 1100)])
+def test_banded_cholesky_of_spd_systems(n, kl, monkeypatch):
+    """band widths below, at and above the block width and the tile width, a last block of one column, a band wider than most
+    of the matrix: the solve runs on the Cholesky path and agrees with SuperLU and with the LU path"""
+    from tigar_amd import device as dev
+    rng = np.random.default_rng(n + kl)
+    A = _spd_band(rng, n, kl)
+    xs = rng.standard_normal(n)
+    b = A @ xs
+    K = dev.DeviceCSR.from_scipy(A)
+    c0 = dev.prof_get(8)[1]
+    x = dev.DeviceVector(n)
+    assert dev.lu_solve(K, dev.DeviceVector(data=b), x) == 0
+    assert dev.prof_get(8)[1] == c0 + 1, "the Cholesky path did not run"
+    ref = spla.spsolve(A.tocsc(), b)
+    res = np.linalg.norm(A @ x.get_local() - b) / np.linalg.norm(b)
+    res_ref = np.linalg.norm(A @ ref - b) / np.linalg.norm(b)
+    assert res < 1e-10 and res <= 100 * max(res_ref, 1e-16), (res, res_ref)
+    monkeypatch.setenv("TIGAR_LU_CHOLESKY", "0")
+    x2 = dev.DeviceVector(n)
+    assert dev.lu_solve(K, dev.DeviceVector(data=b), x2) == 0
+    assert dev.prof_get(8)[1] == c0 + 1
+    res2 = np.linalg.norm(A @ x2.get_local() - b) / np.linalg.norm(b)
+    assert res <= 100 * max(res2, 1e-16)                    # (as small a backward error as the LU's)
+
+
+def test_cholesky_is_left_for_the_lu_when_the_premise_fails():
+    """a symmetric indefinite matrix (a pivot is not positive), a matrix that is not symmetric, one whose pattern is: the LU"""
+    from tigar_amd import device as dev
+    rng = np.random.default_rng(5)
+    n, kl = 900, 25
+    A = _spd_band(rng, n, kl)
+    xs = rng.standard_normal(n)
+    ind = (A - sp.diags(np.where(np.arange(n) == 400, 2.0 * A.diagonal(), 0.0))).tocsr()        # one negative diagonal entry: indefinite
+    asym = A.copy().tolil()
+    asym[10, 12] += 0.5
+    asym = asym.tocsr()
+    pat = A.copy().tolil()
+    pat[20, 21] = 0.0
+    pat = pat.tocsr()
+    pat.eliminate_zeros()
+    for M in (ind, asym, pat):
+        M.sort_indices()
+        b = M @ xs
+        c0 = dev.prof_get(8)[1]
+        x = dev.DeviceVector(n)
+        assert dev.lu_solve(dev.DeviceCSR.from_scipy(M), dev.DeviceVector(data=b), x) == 0
+        assert dev.prof_get(8)[1] == c0
+        assert np.linalg.norm(M @ x.get_local() - b) <= 1e-9 * np.linalg.norm(b)

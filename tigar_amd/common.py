@@ -1308,6 +1308,7 @@ class PETScLUSolver(object):
         if nb > self.parameters["max_band_bytes"]:
             raise MemoryError("direct solve: the band storage of this %d x %d system (half-bandwidths %d / %d) needs %.1f GB; "
                               "use a Krylov solver (PETScKrylovSolver) for systems of this size" % (n, n, kl, ku, nb / 2 ** 30))
+        chol0 = _dev.prof_get(8)[1]
         if perm is not None:
             bp = DeviceVector(data=b.get_local()[perm])
             xp = DeviceVector(n)
@@ -1318,7 +1319,10 @@ class PETScLUSolver(object):
                 x.set_local(out)
         else:
             info = _dev.lu_solve(A, b, x)
-        self.last = {"info": info, "kl": kl, "ku": ku, "band_bytes": nb, "reordered": perm is not None}
+        # (a symmetric positive definite system is factorised as L L^T -- blocked banded Cholesky on the matrix cores,
+        #  csrc/tg_chol.hip -- instead of P A = L U; TIGAR_LU_CHOLESKY=0: always the LU)
+        self.last = {"info": info, "kl": kl, "ku": ku, "band_bytes": nb, "reordered": perm is not None,
+                     "factorisation": "cholesky" if _dev.prof_get(8)[1] > chol0 else "lu"}
         if info != 0:
             raise RuntimeError("direct solve: the matrix is singular (exact zero pivot in column %d)" % (info - 1))
         return 1

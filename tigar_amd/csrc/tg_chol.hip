@@ -1,0 +1,452 @@
+// Direct solve of K U = M^T b when K is symmetric positive definite: blocked banded Cholesky on the matrix cores.
+//
+// With `linearSolver == None` the reference calls dolfin's `solve(A, x, b)`, a sparse direct LU (tIGAr/common.py:1255-1256
+// [ext]); tg_lu.hip restates it as a banded LU with partial pivoting, whose column-by-column pivot search is a chain of
+// 67 600 dependent steps at cfg4 (0.26 s of panel + trailing kernels, 0.09 s of substitution).  The systems the reference's
+// demos hand to it are mostly Galerkin matrices of coercive forms with Dirichlet rows and columns replaced by the identity
+// (MatZeroRowsColumns): symmetric positive definite.  For those no pivoting is needed and the factorisation is dense block
+// algebra: per block of NB = 32 columns a 32 x 32 Cholesky factor, a triangular solve for the kl rows below it, and a
+// symmetric rank-32 update of the trailing kl x kl triangle on `v_mfma_f64_16x16x4_f64` -- two launches per 32 columns
+// instead of two per 16 with a pivot search each, and substitutions that go block by block.
+//
+// tg_lu_solve tries this first: K's values are compared with their transposes (relative 1e-11: a K that is symmetric "to
+// rounding", as M^T A M comes out, qualifies -- the factor is that of the lower triangle, a perturbation of the order of the
+// rounding errors K carries anyway); a pivot that is not positive ends the attempt and the LU runs as before
+// (TIGAR_LU_CHOLESKY=0: never tried).  The solution is that of the same system, to the rounding of a backward stable
+// direct method; PETSc users select it by hand (-pc_type cholesky [ext]).
+//
+// Storage: LAPACK's dpbtrf 'L' layout, lb[(r - c) + ldl * c] for c <= r <= c + kl, ldl = kl + 1.
+#include "tg_common.h"
+#include <algorithm>
+
+#define CH_NB 32
+typedef double ch_v4d __attribute__((ext_vector_type(4)));
+typedef unsigned int ch_u2 __attribute__((ext_vector_type(2)));
+
+struct ch_stats {
+  unsigned long long lower, upper;     // entries strictly below / above the diagonal
+  unsigned long long maxabs;           // bit pattern of max |a|
+  int asym;                            // an entry differs from its transpose
+  int notpd;                           // 1 + column of the first pivot that is not positive
+};
+
+__global__ void __launch_bounds__(256)
+    k_chol_scatter(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val, int64_t n,
+                   int64_t ldl, double *__restrict__ lb, ch_stats *st) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  unsigned long long lo = 0, up = 0;
+  double mx = 0.0;
+  for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < n; r += nw)
+    for (int64_t q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) {
+      const int64_t c = col[q];
+      const double v = val[q];
+      mx = fmax(mx, fabs(v));
+      if (c <= r) {
+        lb[(r - c) + ldl * c] += v;       // (+=: duplicate entries of a row add up, as in MatSetValues ADD)
+        lo += c < r;
+      } else
+        up++;
+    }
+  // (one atomic per wave and counter)
+  for (int o = 32; o > 0; o >>= 1) {
+    lo += __shfl_down(lo, o);
+    up += __shfl_down(up, o);
+    mx = fmax(mx, __shfl_down(mx, o));
+  }
+  if (lane == 0) {
+    if (lo) atomicAdd(&st->lower, lo);
+    if (up) atomicAdd(&st->upper, up);
+    atomicMax(&st->maxabs, (unsigned long long)__double_as_longlong(mx));
+  }
+}
+
+// every entry above the diagonal against the entry below it that the scatter kernel has placed
+__global__ void __launch_bounds__(256)
+    k_chol_symcheck(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val, int64_t n,
+                    int kl, int64_t ldl, const double *__restrict__ lb, double tol_rel, ch_stats *st) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const double tol = tol_rel * __longlong_as_double((long long)st->maxabs);
+  bool bad = false;
+  for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < n; r += nw)
+    for (int64_t q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) {
+      const int64_t c = col[q];
+      if (c > r) bad |= (c - r > kl) || !(fabs(val[q] - lb[(c - r) + ldl * r]) <= tol);
+    }
+  if (bad) atomicExch(&st->asym, 1);
+}
+
+__device__ __forceinline__ double ch_readlane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// One block of NB columns: every workgroup factorises the NB x NB diagonal block (wave 0, a lane per row, the row in
+// registers, a finished column goes round through LDS; workgroup 0 hands the factor on), then its 256 threads take a row of
+// the panel below each: x L11^T = a, column by column (x_u final -> every later entry of the row updated: independent
+// multiply-adds, L11 broadcast from LDS).  Rows of the bottom triangle (r > j0 + kl) start at column r - kl.
+// (The factor of the diagonal block goes to `l11` first, not into the band: the other workgroups read the block while
+//  workgroup 0 would overwrite it.  The update kernel, which does not touch the block, puts it in place.  dinv: 1 / L(j, j),
+//  what the substitutions multiply with.)
+__global__ void __launch_bounds__(256)
+    k_chol_panel(double *__restrict__ lb, int64_t ldl, int64_t n, int kl, int64_t j0, double *__restrict__ l11,
+                 double *__restrict__ dinv_g, ch_stats *st) {
+  __shared__ double D[2 * CH_NB][CH_NB + 1];  // the diagonal block, then its factor (lower triangle); rows 32 .. 63: spare
+                                             // (the shadow lanes of wave 0 store there: no branch in the loop)
+  __shared__ double dinv[CH_NB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nbc = (int)min((int64_t)CH_NB, n - j0);
+  // the thread's row of the panel is requested before the diagonal block is factorised
+  const int64_t r = j0 + nbc + (int64_t)blockIdx.x * 256 + tid;
+  const int64_t rmax = min(n - 1, j0 + nbc - 1 + kl);
+  const bool mine = r <= rmax;
+  const int t0 = (int)max((int64_t)0, r - kl - j0);          // first column of the block this row holds
+  double a[CH_NB];
+  {
+    // (one clamped address per entry and a select: no branch around a load)
+    const int64_t rc = mine ? r : rmax;
+#pragma unroll
+    for (int t = 0; t < CH_NB; t++) {
+      const bool in = mine && t >= t0 && t < nbc;
+      const int tc = in ? t : (int)min((int64_t)nbc - 1, max((int64_t)t0, (int64_t)0));
+      const double v = lb[(rc - j0 - tc) + ldl * (j0 + tc)];
+      a[t] = in ? v : 0.0;
+    }
+  }
+  for (int i = tid; i < CH_NB * CH_NB; i += 256) {
+    const int rr = i / CH_NB, c = i % CH_NB;
+    const bool in = rr < nbc && c <= rr && rr - c <= kl;
+    D[rr][c] = in ? lb[(rr - c) + ldl * (j0 + c)] : ((c == rr) ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  if (tid < 64) {
+    // wave 0: a lane per row of the block (lanes 32 .. 63 shadow 0 .. 31), the row in registers; a finished column goes
+    // round through LDS (where the row solve below finds the factor) and every later entry of the row is updated with it
+    const int rr = lane & (CH_NB - 1);
+    double row[CH_NB];
+#pragma unroll
+    for (int c = 0; c < CH_NB; c++) row[c] = D[rr][c];
+    int bad = 0;
+#pragma unroll
+    for (int t = 0; t < CH_NB; t++) {
+      const double dtt = ch_readlane(row[t], t);
+      if (!(dtt > 0.0) && t < nbc && bad == 0) bad = t + 1;
+      const double inv = 1.0 / sqrt(dtt);
+      const double lrt = rr == t ? dtt * inv : row[t] * inv;
+      row[t] = lrt;
+      D[lane][t] = rr >= t ? lrt : 0.0;                      // column t of the factor: D[.][t]
+      dinv[t] = inv;                                         // (the same value from every lane)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int c = t + 1; c < CH_NB; c++) row[c] = fma(-lrt, D[c][t], row[c]);     // (entries above the diagonal: never used)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lane < CH_NB && blockIdx.x == 0) {
+#pragma unroll
+      for (int c = 0; c < CH_NB; c++) l11[rr * CH_NB + c] = row[c];
+      if (rr < nbc) dinv_g[j0 + rr] = dinv[rr];
+    }
+    if (bad && lane == 0 && blockIdx.x == 0) atomicCAS(&st->notpd, 0, (int)(j0 + bad));
+  }
+  __syncthreads();
+  if (!mine) return;
+#pragma unroll
+  for (int u = 0; u < CH_NB; u++) {
+    const double xu = a[u] * dinv[u];
+    a[u] = xu;
+#pragma unroll
+    for (int t = u + 1; t < CH_NB; t++) a[t] = fma(-xu, D[t][u], a[t]);
+    __builtin_amdgcn_sched_barrier(0);     // (column by column: the scheduler otherwise requests all 496 entries of L11 at once)
+  }
+  // (the stores go through a buffer descriptor per column, a lane without an entry there carries an offset beyond its range,
+  //  which the hardware drops: 32 divergent `if`s after the solve split the block it is scheduled in -- 2.4 KB of scratch)
+#pragma unroll
+  for (int t = 0; t < CH_NB; t++) {
+    const __amdgpu_buffer_rsrc_t col = __builtin_amdgcn_make_buffer_rsrc(lb + ldl * (j0 + min(t, nbc - 1)), 0,
+                                                                         (unsigned)(kl + 1) * 8u, 0x00020000);
+    const unsigned off = (t >= t0 && t < nbc) ? (unsigned)(r - j0 - t) * 8u : 0xffffffffu;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ch_u2, a[t]), col, off, 0, 0);
+  }
+}
+
+// trailing update A(r, c) -= sum_t L(r, j0 + t) L(c, j0 + t) for j1 <= c <= r <= rmax, in tiles of 64 x 64 on the matrix
+// cores; the tile is computed transposed (D[c][r]: the lanes of a result register run along r, contiguous in the band)
+__global__ void __launch_bounds__(256)
+    k_chol_syrk(double *__restrict__ lb, int64_t ldl, int64_t n, int kl, int64_t j0, int nbc, int ntile,
+                const double *__restrict__ l11) {
+  __shared__ double Lr[CH_NB][64 + 1], Lc[CH_NB][64 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  if ((int)blockIdx.x == ntile * (ntile + 1) / 2) {          // the last workgroup: the factor of the diagonal block into the band
+    for (int i = tid; i < CH_NB * CH_NB; i += 256) {
+      const int r = i / CH_NB, c = i % CH_NB;
+      if (r < nbc && c <= r && r - c <= kl) lb[(r - c) + ldl * (j0 + c)] = l11[i];
+    }
+    return;
+  }
+  // linear index -> (ti >= tj)
+  int ti = 0, rest = blockIdx.x;
+  while (rest > ti) {
+    rest -= ti + 1;
+    ti++;
+  }
+  const int tj = rest;
+  const int64_t j1 = j0 + nbc, rmax = min(n - 1, j0 + nbc - 1 + kl);
+  const int64_t r0 = j1 + 64 * (int64_t)ti, c0 = j1 + 64 * (int64_t)tj;
+  for (int i = tid; i < CH_NB * 64; i += 256) {
+    const int k = i >> 6, l = i & 63;
+    const int64_t rr = r0 + l, rc = c0 + l;
+    Lr[k][l] = (k < nbc && rr <= rmax && rr - j0 - k <= kl) ? lb[(rr - j0 - k) + ldl * (j0 + k)] : 0.0;
+    Lc[k][l] = (k < nbc && rc <= rmax && rc - j0 - k <= kl) ? lb[(rc - j0 - k) + ldl * (j0 + k)] : 0.0;
+  }
+  __syncthreads();
+  ch_v4d acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) acc[q] = (ch_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k4 = 0; k4 < CH_NB / 4; k4++) {
+    const double a = Lc[4 * k4 + lk][16 * wave + lr];        // A operand: rows = matrix columns c of this wave
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lr[4 * k4 + lk][16 * q + lr], acc[q], 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int64_t c = c0 + 16 * wave + lk + 4 * i, r = r0 + 16 * q + lr;
+      if (r >= c && r <= rmax) lb[(r - c) + ldl * c] -= acc[q][i];
+    }
+}
+
+// L y = b block by block (one workgroup, NT threads): the window of x that the blocks ahead still change lives in an LDS ring
+// (entry r at r mod W).  Per block: the entries of the thread's row of the panel are requested first, wave 0 solves the
+// NB x NB triangle (a lane per unknown, broadcasts by readlane, reciprocals of the diagonal from the factorisation),
+// everyone subtracts its row's share.  Nothing in a step waits for a load that was not issued a phase earlier.
+#define CH_NT 1024
+static_assert(CH_NT == CH_NB * CH_NB, "the substitution kernels load one entry of the diagonal block per thread");
+__global__ void __launch_bounds__(CH_NT) k_chol_fwd(const double *__restrict__ lb, const double *__restrict__ dinv_g, int64_t ldl,
+                                                     int64_t n, int kl, int W, double *__restrict__ x) {
+  extern __shared__ double ch_sm[];
+  double *xw = ch_sm;                    // [W]
+  double *yb = ch_sm + W;                // [NB]
+  double *Ls = yb + CH_NB;               // [NB][NB + 1]: the diagonal block of the factor
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int RT = (kl + CH_NT - 1) / CH_NT;       // rows of the panel per thread
+  for (int64_t r = tid; r < min(n, (int64_t)CH_NB + kl); r += CH_NT) xw[r & (W - 1)] = x[r];
+  __syncthreads();
+  for (int64_t j0 = 0; j0 < n; j0 += CH_NB) {
+    const int nbc = (int)min((int64_t)CH_NB, n - j0);
+    const int64_t rmax = min(n - 1, j0 + nbc - 1 + kl);
+    // the first panel row of every thread, requested before the triangle is solved
+    double pv[CH_NB];
+    {
+      const int64_t r = j0 + nbc + tid;
+      const int t0 = (int)max((int64_t)0, r - kl - j0);
+      const int64_t rc = min(r, rmax);
+#pragma unroll
+      for (int t = 0; t < CH_NB; t++) {      // (a clamped address and a select: no branch around a load)
+        const bool in = r <= rmax && t >= t0 && t < nbc;
+        const int tc = in ? t : nbc - 1;
+        const double v = lb[(rc - j0 - tc) + ldl * (j0 + tc)];
+        pv[t] = in ? v : 0.0;
+      }
+    }
+    {
+      const int rr = tid >> 5, c = tid & (CH_NB - 1);          // (CH_NT = NB * NB: an entry of the block per thread)
+      Ls[rr * (CH_NB + 1) + c] = (rr < nbc && c < rr && rr - c <= kl) ? lb[(rr - c) + ldl * (j0 + c)] : 0.0;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int rr = lane & (CH_NB - 1);
+      const double di = rr < nbc ? dinv_g[j0 + rr] : 1.0;
+      double v = rr < nbc ? xw[(j0 + rr) & (W - 1)] : 0.0;
+#pragma unroll
+      for (int s8 = 0; s8 < CH_NB; s8 += 8) {
+        double l[8];                         // entries s8 .. s8 + 7 of row rr of L11 (0 for the lanes above)
+#pragma unroll
+        for (int i = 0; i < 8; i++) l[i] = Ls[rr * (CH_NB + 1) + s8 + i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const double ys = ch_readlane(v * di, s8 + i);
+          v = rr == s8 + i ? ys : fma(-l[i], ys, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (lane < CH_NB) yb[lane] = lane < nbc ? v : 0.0;       // (all of yb: the panel products read every entry)
+      if (lane < nbc) x[j0 + lane] = v;
+    }
+    __syncthreads();
+    {
+      const int64_t r = j0 + nbc + tid;
+      if (r <= rmax) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < CH_NB; t++) s = fma(pv[t], yb[t], s);
+        xw[r & (W - 1)] -= s;
+      }
+    }
+    for (int q = 1; q < RT; q++) {                   // (bands wider than the workgroup)
+      const int64_t r = j0 + nbc + tid + (int64_t)q * CH_NT;
+      const int t0 = (int)max((int64_t)0, r - kl - j0);
+      const int64_t rc = min(r, rmax);
+#pragma unroll
+      for (int t = 0; t < CH_NB; t++) {
+        const bool in = r <= rmax && t >= t0 && t < nbc;
+        const int tc = in ? t : nbc - 1;
+        const double v = lb[(rc - j0 - tc) + ldl * (j0 + tc)];
+        pv[t] = in ? v : 0.0;
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int t = 0; t < CH_NB; t++) s = fma(pv[t], yb[t], s);
+      if (r <= rmax) xw[r & (W - 1)] -= s;
+    }
+    // the rows that enter the window with the next block
+    {
+      const int64_t r = j0 + CH_NB + kl + tid;
+      if (tid < CH_NB && r < n) xw[r & (W - 1)] = x[r];
+    }
+    __syncthreads();
+  }
+}
+
+// L^T x = y from the last block to the first: column c of L below the block is contiguous, a wave takes two columns of the
+// block, multiplies them with the window of x (eight independent loads at a time) and reduces; wave 0 solves the transposed
+// triangle.
+__global__ void __launch_bounds__(CH_NT) k_chol_bwd(const double *__restrict__ lb, const double *__restrict__ dinv_g, int64_t ldl,
+                                                     int64_t n, int kl, int W, double *__restrict__ x) {
+  extern __shared__ double ch_sm[];
+  double *xw = ch_sm;                    // [W]: final x of the rows behind the current block
+  double *sb = ch_sm + W;                // [NB]
+  double *Ls = sb + CH_NB;               // [NB][NB + 1]: Ls[c][u] = L11[u][c], the diagonal block transposed
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t nblk = (n + CH_NB - 1) / CH_NB;
+  for (int64_t b = nblk - 1; b >= 0; b--) {
+    const int64_t j0 = b * CH_NB;
+    const int nbc = (int)min((int64_t)CH_NB, n - j0);
+    {
+      const int u = tid >> 5, c = tid & (CH_NB - 1);
+      Ls[c * (CH_NB + 1) + u] = (u < nbc && c < u && u - c <= kl) ? lb[(u - c) + ldl * (j0 + c)] : 0.0;
+    }
+    // s_t = sum over the rows r below the block (r <= j0 + t + kl) of L(r, j0 + t) x_r
+    for (int t = wave; t < nbc; t += CH_NT / 64) {
+      const int64_t c = j0 + t, ra = j0 + nbc, rb = min(n - 1, c + kl);
+      const double *lc = lb + ldl * c - c;             // lc[r] = L(r, c)
+      double s = 0.0;
+      for (int64_t r8 = ra + lane; r8 <= rb; r8 += 8 * 64) {
+        double lv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) lv[i] = r8 + 64 * i <= rb ? lc[r8 + 64 * i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {          // (beyond the column's last row the ring holds whatever the LDS held: no 0 * NaN)
+          const double xv = xw[(r8 + 64 * i) & (W - 1)];
+          s = fma(lv[i], r8 + 64 * i <= rb ? xv : 0.0, s);
+        }
+      }
+      s = tg_wave_sum(s);
+      if (lane == 0) sb[t] = s;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int rr = lane & (CH_NB - 1);
+      const double di = rr < nbc ? dinv_g[j0 + rr] : 1.0;
+      double v = rr < nbc ? x[j0 + rr] - sb[rr] : 0.0;
+#pragma unroll
+      for (int s8 = CH_NB - 8; s8 >= 0; s8 -= 8) {
+        double l[8];                         // L11[s8 + i][rr] (0 for the lanes below)
+#pragma unroll
+        for (int i = 0; i < 8; i++) l[i] = Ls[rr * (CH_NB + 1) + s8 + i];
+#pragma unroll
+        for (int i = 7; i >= 0; i--) {
+          const double xs = ch_readlane(v * di, s8 + i);
+          v = rr == s8 + i ? xs : fma(-l[i], xs, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (lane < nbc) {
+        x[j0 + lane] = v;
+        xw[(j0 + lane) & (W - 1)] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// 0 = solved by Cholesky (*done = 1) or not applicable (*done = 0: the caller goes on with the LU)
+int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *done) {
+  *done = 0;
+  if (getenv("TIGAR_LU_CHOLESKY") && atoi(getenv("TIGAR_LU_CHOLESKY")) == 0) return 0;
+  const int64_t n = k->nrows;
+  if (kl != ku || kl < 8 || n < 2 * CH_NB) return 0;
+  int W = 64;
+  while (W < kl + 2 * CH_NB) W <<= 1;
+  const size_t lds = (size_t)(W + CH_NB + CH_NB * (CH_NB + 1)) * sizeof(double);
+  if (lds > 150 * 1024) return 0;
+  const bool trace = getenv("TIGAR_TRACE") != nullptr;
+  const int64_t ldl = (int64_t)kl + 1;
+  double *lb = nullptr, *l11 = nullptr, *dinv = nullptr;
+  ch_stats *st = nullptr;
+  if (tg_dmalloc(&lb, ldl * n)) {
+    (void)hipGetLastError();
+    return 0;                        // (no room: the LU reports it)
+  }
+  int rc = tg_dmalloc_bytes((void **)&st, sizeof(ch_stats)) || tg_dmalloc(&l11, CH_NB * CH_NB) || tg_dmalloc(&dinv, n);
+  ch_stats h;
+  memset(&h, 0, sizeof(h));
+  if (!rc && (hipMemsetAsync(lb, 0, (size_t)(ldl * n) * sizeof(double), g_tg.stream) != hipSuccess ||
+              hipMemcpyAsync(st, &h, sizeof(h), hipMemcpyHostToDevice, g_tg.stream) != hipSuccess))
+    rc = 1;
+  if (!rc) {
+    const unsigned g = (unsigned)std::min<int64_t>(tg_cdiv(n, 4), (int64_t)g_tg.num_cu * 16);
+    hipLaunchKernelGGL(k_chol_scatter, dim3(g), dim3(256), 0, g_tg.stream, k->rowptr, k->col, k->val, n, ldl, lb, st);
+    hipLaunchKernelGGL(k_chol_symcheck, dim3(g), dim3(256), 0, g_tg.stream, k->rowptr, k->col, k->val, n, kl, ldl, lb, 1e-11, st);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
+        hipStreamSynchronize(g_tg.stream) != hipSuccess)
+      rc = 1;
+  }
+  bool go = !rc && !h.asym && h.lower == h.upper;
+  if (!rc && !go && trace) fprintf(stderr, "[trace] cholesky: the matrix is not symmetric: LU\n");
+  if (go) {
+    if (hipFuncSetAttribute((const void *)k_chol_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_chol_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      go = false;
+    }
+  }
+  if (go) {
+    for (int64_t j0 = 0; j0 < n; j0 += CH_NB) {
+      const int nbc = (int)std::min<int64_t>(CH_NB, n - j0);
+      const int64_t m = std::min<int64_t>(kl, n - j0 - nbc);        // rows below the block
+      hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max<int64_t>(1, tg_cdiv(m, 256))), dim3(256), 0, g_tg.stream, lb, ldl, n,
+                         kl, j0, l11, dinv, st);
+      const int nt = (int)tg_cdiv(std::max<int64_t>(m, 0), 64);
+      hipLaunchKernelGGL(k_chol_syrk, dim3((unsigned)(nt * (nt + 1) / 2 + 1)), dim3(256), 0, g_tg.stream, lb, ldl, n, kl, j0, nbc, nt,
+                         (const double *)l11);
+    }
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
+        hipStreamSynchronize(g_tg.stream) != hipSuccess)
+      rc = 1;
+    if (!rc && h.notpd) {
+      if (trace) fprintf(stderr, "[trace] cholesky: pivot %d is not positive: LU\n", h.notpd - 1);
+      go = false;
+    }
+  }
+  if (!rc && go) {
+    if (x != b && hipMemcpyAsync(x, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess) rc = 1;
+    if (!rc) {
+      hipLaunchKernelGGL(k_chol_fwd, dim3(1), dim3(CH_NT), lds, g_tg.stream, (const double *)lb, (const double *)dinv, ldl, n, kl, W, x);
+      hipLaunchKernelGGL(k_chol_bwd, dim3(1), dim3(CH_NT), lds, g_tg.stream, (const double *)lb, (const double *)dinv, ldl, n, kl, W, x);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
+    }
+    if (!rc) *done = 1;
+    if (!rc && trace) fprintf(stderr, "[trace] cholesky: %lld x %lld, kl = %d, band %.2f GB\n", (long long)n, (long long)n, kl, ldl * n * 8e-9);
+  }
+  if (rc) tg_set_error("tg_chol_try: a kernel or a copy failed");
+  tg_dfree(lb);
+  tg_dfree(l11);
+  tg_dfree(dinv);
+  tg_dfree(st);
+  return rc;
+}

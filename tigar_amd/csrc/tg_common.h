@@ -192,6 +192,8 @@ int64_t tg_sell_slice_rows(void);
 int tg_sell_spmv_rows(tg_csr_s *a, const double *x_shifted, int64_t cmin, int64_t cmax, double *y, int64_t r0,
                       int64_t r1, const double *gate, double gate_tol);
 
+// banded Cholesky for symmetric positive definite systems (tg_chol.hip): *done = 1 when it solved K x = b
+int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *done);
 // half-storage product for symmetric box-stencil matrices on a 3-D grid (tg_symgrid.hip)
 struct tg_symgrid_s;
 int tg_symgrid_build(tg_csr_s *a, int64_t row0, int verify, tg_symgrid_s **out);   // *out = nullptr: declined

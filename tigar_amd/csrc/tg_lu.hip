@@ -959,6 +959,12 @@ extern "C" int tg_lu_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *info) {
   int kl = 0, ku = 0;
   int64_t bytes = 0;
   TG_TRY(tg_lu_band_info(k, &kl, &ku, &bytes));
+  {   // a symmetric positive definite system: blocked banded Cholesky (tg_chol.hip); otherwise -- or TIGAR_LU_CHOLESKY=0 -- the LU
+    int done = 0;
+    TG_TRY(tg_chol_try(k, kl, ku, b->d, x->d, &done));
+    g_tg.prof_n[TG_PROF_LU_CHOLESKY] += done;
+    if (done) return 0;
+  }
   const int kv = kl + ku;
   const int64_t ldab = 2 * (int64_t)kl + ku + 1;
   double *ab = nullptr;
