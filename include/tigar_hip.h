@@ -444,6 +444,12 @@ int tg_extract_csr_bezier(int64_t nel, int nloc, int nbern, const double *bern, 
 int tg_lu_band_info(tg_csr_t k, int *kl, int *ku, int64_t *bytes);
 /* x = K^-1 b (x may be b); info > 0: U(info-1,info-1) == 0 exactly, nothing was solved */
 int tg_lu_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *info);
+/* The same system by a blocked banded Cholesky factorisation on the matrix cores (csrc/tg_chol.hip) when K is symmetric
+ * (values compared with their transposes) and positive definite (every pivot positive): *done = 1 and x = K^-1 b (x may
+ * be b); otherwise *done = 0 and x is untouched.  tg_lu_solve tries this itself first; the entry exists for systems
+ * beyond the LU's limits (3-D patches: n kl^2 multiply-adds and n (kl + 1) doubles instead of 4 n kl^2 and 3 n kl), where
+ * the caller's alternative is a Krylov method (tigar_amd.common._DefaultSolver). */
+int tg_chol_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *done);
 
 /* ---- synthetic FE-side input (NOT on the timed path) --------- */
 /* A = sum_t (x)_k F[t][k] with 1-D CSR factors sharing one pattern per direction

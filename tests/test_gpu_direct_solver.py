@@ -161,7 +161,7 @@ def test_default_solver_is_direct_on_the_biharmonic_demo_flow():
     assert errs[64] < errs[16] / 50.0 and errs[256] < 1e-3
 
 
-def test_default_solver_reorders_field_major_systems_and_hands_large_ones_to_gmres():
+def test_default_solver_reorders_field_major_systems_and_hands_large_ones_to_cholesky_or_gmres():
     import tigar_amd as t
     from tigar_amd import BSplines as B, forms as F, common as tc, device as dev
     # three fields numbered field after field: bandwidth ~ 2 n/3 as numbered, small after reverse Cuthill-McKee
@@ -203,11 +203,25 @@ def test_default_solver_reorders_field_major_systems_and_hands_large_ones_to_gmr
     spl3 = t.ExtractedSpline(gen3, 2 * p)
     f1 = lambda x_: np.sin(np.pi * x_)
     K3, b3 = spl3.assembleLinearSystem(F.LaplaceForm(), F.SeparableLoadForm([f1] * 3, scale=3 * np.pi ** 2))
+    # (round 6: the system is symmetric positive definite -- the banded Cholesky factorisation takes it, beyond the LU's budget)
     d = tc._default_linear_solver()
     x3 = dev.DeviceVector(K3.shape[0])
     d.solve(K3, x3, b3)
-    assert d.last["solver"] == "gmres" and d.last["status"] == 0
+    assert d.last["solver"] == "lu" and d.last["factorisation"] == "cholesky"
     r = K3.mult(x3)
+    r.axpy(-1.0, b3)
+    assert r.norm() <= 1e-9 * b3.norm()
+    # the same system with a convection-like skew part is not symmetric: Jacobi-GMRES, as before
+    S3 = K3.to_scipy().tocsr()
+    up = sp.triu(S3, k=1).tocsr()
+    N3 = (S3 + 0.05 * up - 0.05 * up.T).tocsr()
+    N3.sort_indices()
+    Kn = dev.DeviceCSR.from_scipy(N3)
+    d = tc._default_linear_solver()
+    xn = dev.DeviceVector(Kn.shape[0])
+    d.solve(Kn, xn, b3)
+    assert d.last["solver"] == "gmres" and d.last["status"] == 0
+    r = Kn.mult(xn)
     r.axpy(-1.0, b3)
     assert r.norm() <= 1e-9 * b3.norm()
 

@@ -179,6 +179,7 @@ PROTOTYPES = {
                                         C.POINTER(C.c_int)]),
     "tg_lu_band_info": (C.c_int, [handle, C.POINTER(C.c_int), C.POINTER(C.c_int), c_i64p]),
     "tg_lu_solve": (C.c_int, [handle, handle, handle, C.POINTER(C.c_int)]),
+    "tg_chol_solve": (C.c_int, [handle, handle, handle, C.POINTER(C.c_int)]),
     "tg_kron_sum_csr": (C.c_int, [C.c_int, C.c_int, C.POINTER(tg_kron_dir_t), C.c_int64, C.c_int64,
                                   C.POINTER(handle)]),
     "tg_kron_csr_rect": (C.c_int, [C.c_int, C.c_int, C.POINTER(tg_kron_dir_t), c_i64p, C.c_int64, C.c_int64,

@@ -450,3 +450,19 @@ int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *do
   tg_dfree(st);
   return rc;
 }
+
+extern "C" int tg_chol_solve(tg_csr_t k, tg_vec_t b, tg_vec_t x, int *done) {
+  TG_REQUIRE_INIT();
+  TG_REQUIRE(k && b && x && done, "null argument to tg_chol_solve");
+  TG_REQUIRE_CANONICAL(k);
+  const int64_t n = k->nrows;
+  TG_REQUIRE(k->ncols == n && b->n == n && x->n == n, "tg_chol_solve: square system with matching vectors expected");
+  *done = 0;
+  if (n == 0) return 0;
+  int kl = 0, ku = 0;
+  int64_t bytes = 0;
+  TG_TRY(tg_lu_band_info(k, &kl, &ku, &bytes));
+  TG_TRY(tg_chol_try(k, kl, ku, b->d, x->d, done));
+  g_tg.prof_n[TG_PROF_LU_CHOLESKY] += *done;
+  return 0;
+}

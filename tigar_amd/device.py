@@ -750,6 +750,14 @@ def lu_solve(K, b, x):
     return info.value
 
 
+def chol_solve(K, b, x):
+    """x = K^-1 b by the blocked banded Cholesky factorisation (csrc/tg_chol.hip) if K is symmetric positive definite:
+    True when it solved the system, False (x untouched) when K does not qualify"""
+    done = C.c_int()
+    check(_lib.lib().tg_chol_solve(K._h, b._h, x._h, C.byref(done)), "tg_chol_solve")
+    return bool(done.value)
+
+
 # ------------------------------------------------------------------------------- synthetic inputs
 def kron_sum_csr(factors, row0=None, row1=None):
     """A = sum_t kron(F[t][d-1], ..., F[t][0]) (direction 0 fastest).  ``factors[t][k]`` are
