@@ -689,7 +689,10 @@ def main():
     pc_name = {"jacobi": "Jacobi", "none": "unpreconditioned", "chebyshev": "Chebyshev(%d)-Jacobi" % args.cheb_degree}[args.pc]
     solver_desc = {"cg": "%s-CG rtol %.0e" % (pc_name, args.rtol), "gmres": "%s-GMRES(30) rtol %.0e" % (pc_name, args.rtol),
                    "bicgstab": "%s-BiCGStab rtol %.0e" % (pc_name, args.rtol),
-                   "lu": "direct banded LU (the reference's default solver)"}[res["method"]]
+                   "lu": "direct banded solve (the reference's default solver is a direct LU): " +
+                         ("blocked Cholesky on the matrix cores, K found symmetric positive definite (csrc/tg_chol.hip)"
+                          if (res.get("solver_last") or {}).get("factorisation") == "cholesky" else "LU with partial pivoting")
+                   }[res["method"]]
     solver_api = {"cg": "PETScKrylovSolver('cg','%s')" % args.pc, "gmres": "PETScKrylovSolver('gmres','%s')" % args.pc,
                   "bicgstab": "PETScKrylovSolver('bicgstab','%s')" % args.pc, "lu": "PETScLUSolver()"}[res["method"]]
     out = {
