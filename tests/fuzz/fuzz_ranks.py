@@ -44,9 +44,11 @@ def main():
                 env["TIGAR_TEST_EXPLICIT_A"] = explicit
             with tempfile.TemporaryDirectory() as td:
                 parts = T._run_ranks(td, world, kind, 3, p, nels[0], method, 37000 + (a.seed * 131 + i * 7) % 2000, env)
-                # (GMRES: the reduction order of the ranks moves the last iterations of a solve that ends near its tolerance)
+                # (GMRES: the reduction order of the ranks moves the last iterations of a solve that ends near its tolerance;
+                #  BiCGStab: its residual history is erratic and a different reduction order moves the count by a fifth -- sweep
+                #  7900: 62 iterations on three ranks against 76 on one, same solution to 1e-8)
                 T._compare(parts, ref, world, kind,
-                           its_slack=8 if method == "bicgstab" else (3 if explicit else (2 if method == "gmres" else 1)))
+                           its_slack=max(8, int(ref[4]) // 4) if method == "bicgstab" else (3 if explicit else (2 if method == "gmres" else 1)))
             print("ok   %s" % json.dumps(case), flush=True)
         except BaseException as e:  # noqa: BLE001
             bad += 1
