@@ -1201,9 +1201,25 @@ int tg_symgrid_build(tg_csr_s *a, int64_t row0, int verify, tg_symgrid_s **out) 
     int want = getenv("TIGAR_SYMGRID_CHUNKS") ? atoi(getenv("TIGAR_SYMGRID_CHUNKS")) : 0;
     // (measured, 64^3 .. 256^3, p = 2, 3: chunks of 11-13 planes are best -- a chunk pays for P extra window planes and
     // the start of its load pipeline -- as long as there are about two waves per CU)
+    const bool chosen = want > 0;
     if (want <= 0) want = (int)std::max<int64_t>(n2 / 12, tg_cdiv((int64_t)g_tg.num_cu * 2, npatch));
     const int minplanes = std::max(P, 4);
     s->nch = std::max(1, std::min(want, n2 / minplanes));
+    // Few planes (the z slab of one of several ranks, a short patch): the waves of a product are one or two rounds of what
+    // the chip holds, and the number of chunks decides how full the last round is -- 67 planes of cfg3's grid: 5 chunks
+    // (935 waves on 768 places) 1.38 ms, 4 chunks (748 waves) 1.15 ms.  Cost of a choice: rounds x (planes per chunk + the P + 1
+    // planes a chunk pays for its start); with three rounds or more the rounds overlap and the 11-13 planes above stand.
+    const int64_t lds_wave = (int64_t)2 * (P + 1) * (sg_px(P) + 2 * P) * (sg_py(P) + 2 * P) * 8 + 1024;
+    const int64_t places = (int64_t)g_tg.num_cu * std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / lds_wave));
+    if (!chosen && npatch * s->nch < 3 * places) {
+      double best = 1e300;
+      int pick = s->nch;
+      for (int c = 1; c <= std::max(1, n2 / minplanes); c++) {
+        const double cost = (double)tg_cdiv(npatch * c, places) * ((double)n2 / c + P + 1);
+        if (cost < best - 1e-9) best = cost, pick = c;
+      }
+      s->nch = pick;
+    }
   }
   std::vector<int32_t> h;
   auto split = [&](int n, int parts) {
