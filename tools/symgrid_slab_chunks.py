@@ -1,4 +1,5 @@
-"""developer tool: the half-storage product on a grid of 259 x 259 x (nz + 3) points (the z slab of one of several ranks at cfg3) for\ndifferent numbers of z chunks (TIGAR_SYMGRID_CHUNKS; 0 = the library's choice).  usage: symgrid_slab_chunks.py [nz]"""
+"""developer tool: the half-storage product on a grid of 259 x 259 x (nz + 3) points (the z slab of one of several ranks at cfg3) for
+different numbers of z chunks (TIGAR_SYMGRID_CHUNKS; 0 = the library's choice).  usage: symgrid_slab_chunks.py [nz]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
