@@ -410,7 +410,7 @@ def run(args, wl, d, p, nel):
     return {"ncp": ncp, "nnzK": nnzK, "nnzK_local": nnzK_local, "ncp_local": ncp_local, "elapsed": elapsed,
             "spmv_ms_total": spmv_ms, "spmv_count": spmv_n, "ksp_persistent": ksp_persistent, "iterations": its, "stages": mean_stages,
             "t_input": mean_stages.get("fe_input", 0.0), "t_input_in_timed_region": not a_resident,
-            "t_input_pre": t_input_pre, "sub_planes": spline._slab.sub_planes if spline._slab is not None else None,
+            "t_input_pre": t_input_pre, "sub_planes": getattr(spline._slab, "sub_planes_used", spline._slab.sub_planes) if spline._slab is not None else None,
             "sell_classes": sell_classes, "sell_padded": sell_padded, "symgrid": symgrid, "symgrid_solves": symgrid_solves, "implicit_M": bool(getattr(gen.M, "is_implicit", False)),
             "ptap_certified": int(ptap_certified), "nodal_error": nodal_error, "method": method, "nf": nf,
             "solver_last": {k: v for k, v in (solver.last or {}).items() if isinstance(v, (int, float, str, bool))},
