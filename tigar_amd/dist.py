@@ -263,7 +263,10 @@ class SlabHotPath(object):
                 # (eight ranks of cfg3 on one GPU ran out of memory when every one of them sized its sub-slabs for all of it)
                 try:
                     local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-                    free_b //= max(1, -(-local // max(1, dev.device_count())))
+                    share = max(1, -(-local // max(1, dev.device_count())))
+                    free_b //= share
+                    if share > 1:
+                        self._sub_auto = False        # (ranks sharing a device: no larger sub-slabs for the fused forms either)
                 except Exception:
                     pass
             pmax = max(s1.p for s1 in basis.splines)
