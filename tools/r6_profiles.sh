@@ -50,6 +50,15 @@ quad)
   stats cfg3_mapped python $R/bench.py --steps 2 --warmup 1 $W --geometry volume
   pmc cfg3_mapped python $R/bench.py --steps 1 --warmup 1 $W --geometry volume
   ;;
+halfstorage)
+  # the half-storage products added in the second half of the round: stencil radius 4 (3-D quartics), several fields (elasticity)
+  stats symgrid_p4 python $R/tools/symgrid_bench.py 160 4
+  pmc symgrid_p4 python $R/tools/symgrid_bench.py 160 4
+  stats symgrid_fields env TIGAR_IMPLICIT_M=1 python $R/tools/symgrid_fields_bench.py 96 3
+  pmc symgrid_fields env TIGAR_IMPLICIT_M=1 python $R/tools/symgrid_fields_bench.py 96 3
+  stats cfg4_cholesky python $R/bench.py --workload cfg4 --solver lu --steps 3 --warmup 1 --no-cpu-baseline --companion 0
+  pmc cfg4_cholesky python $R/bench.py --workload cfg4 --solver lu --steps 2 --warmup 1 --no-cpu-baseline --companion 0
+  ;;
 headline)
   timeout 900 python bench.py --steps 10 --warmup 2 > $O/r6_bench_cfg3.json 2> $O/r6_bench_cfg3.log
   stats cfg3 python $R/bench.py --steps 5 --warmup 1 $W

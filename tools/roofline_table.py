@@ -13,6 +13,10 @@ WORK = [("cfg3 (256^3 p=3)", "r%s_cfg3_kernel_stats.txt" % RND, "r%s_cfg3_pmc_hb
          "r%s_asm_elast_p3_kernel_stats.txt" % RND, "r%s_asm_elast_p3_pmc_hbm.json" % RND),
         ("mapped stiffness matrix (64^3 p=3 elements; k_asf3_quad)", "r%s_asm_quad_p3_kernel_stats.txt" % RND,
          "r%s_asm_quad_p3_pmc_hbm.json" % RND),
+        ("half-storage product, stencil radius 4 (160^3 p=4)", "r%s_symgrid_p4_kernel_stats.txt" % RND, "r%s_symgrid_p4_pmc_hbm.json" % RND),
+        ("half-storage product, three fields (elasticity 96^3 p=3)", "r%s_symgrid_fields_kernel_stats.txt" % RND,
+         "r%s_symgrid_fields_pmc_hbm.json" % RND),
+        ("cfg4, banded Cholesky (256^2 p=4)", "r%s_cfg4_cholesky_kernel_stats.txt" % RND, "r%s_cfg4_cholesky_pmc_hbm.json" % RND),
         ("cfg2 (128^3 p=2)", "r%s_cfg2_kernel_stats.txt" % RND, "r%s_cfg2_pmc_hbm.json" % RND),
         ("cfg4 (256^2 p=4, CG)", "r%s_cfg4_kernel_stats.txt" % RND, "r%s_cfg4_pmc_hbm.json" % RND),
         ("cfg5 (128^2 p=3, 3 fields)", "r%s_cfg5_kernel_stats.txt" % RND, "r%s_cfg5_pmc_hbm.json" % RND),
