@@ -374,6 +374,158 @@ __global__ void __launch_bounds__(CH_NT) k_chol_bwd(const double *__restrict__ l
   }
 }
 
+// ---- the substitutions on SEVERAL workgroups (round 6, after the single-workgroup sweeps above proved bound by what one CU
+// streams: 0.56 GB of factor in 25.8 + 17.8 ms at cfg4 = 22 - 31 GB/s).  Blocks of 32 rows / columns are owned cyclically by
+// CH_SG workgroups.  Forward (L y = b), right-looking: the owner of block J solves its 32 x 32 triangle, publishes y_J (global
+// memory + a flag per block, release / acquire at agent scope) and every workgroup subtracts the tiles L(b, J) y_J from the
+// row blocks b it owns; backward (L^T x = y) the same from the last block to the first, with the tiles transposed and the
+// pending sums owned by column block.  A workgroup takes the blocks in order, so whoever owns block J + 1 has applied
+// everything up to J before it solves: no dead-lock as long as the CH_SG workgroups are resident (8 on 256 CUs).  The waits
+// give up after two seconds (err[0] = 1: the caller falls back to the single-workgroup sweeps).
+#define CH_SG 8
+// (what is published is the data itself: `pub` starts as NaNs and the 32 threads that need y_J poll their own entry -- one
+//  round trip through the L2 instead of a flag's and then the data's; the tiles of block J and the diagonal block of the next
+//  block this workgroup owns are static data and are requested BEFORE the wait.)
+template <bool FWD>
+__global__ void __launch_bounds__(256) k_chol_sweep(const double *__restrict__ lb, const double *__restrict__ dinv_g, int64_t ldl,
+                                                     int64_t n, int kl, int W, double *x, double *pub, int *err) {
+  extern __shared__ double ch_sm[];
+  double *xw = ch_sm;                    // [W]: FWD: running right-hand side of the owned rows; else pending sums of owned columns
+  double *yb = ch_sm + W;                // [NB]: the block just published
+  double *Ls = yb + CH_NB;               // [NB][NB + 1]
+  __shared__ int s_abort;
+  const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x;
+  if (tid == 0) s_abort = 0;
+  const int64_t nblk = (n + CH_NB - 1) / CH_NB;
+  const int reach = (kl + 2 * CH_NB - 1) / CH_NB;          // blocks a block's tiles reach
+  const long long tmo = 2ll * 100000000ll;                 // (wall_clock64 counts at 100 MHz)
+  if (FWD) {
+    for (int64_t r = tid; r < min(n, (int64_t)CH_NB + kl); r += 256)
+      if ((r / CH_NB) % CH_SG == g) xw[r & (W - 1)] = x[r];
+  } else {
+    for (int i = tid; i < W; i += 256) xw[i] = 0.0;
+  }
+  // the diagonal block of block J into Ls: FWD Ls[a][c] = L11[a][c] (c < a), else Ls[a][c] = L11[c][a] (a < c)
+  auto load_diag = [&](int64_t J) {
+    const int64_t j0 = J * CH_NB;
+    const int nbc = (int)min((int64_t)CH_NB, n - j0);
+#pragma unroll
+    for (int k = 0; k < CH_NB * CH_NB / 256; k++) {
+      const int i = tid + 256 * k, a = i >> 5, c = i & (CH_NB - 1);
+      const int rr = FWD ? a : c, cc = FWD ? c : a;
+      const bool in = rr < nbc && cc < rr && rr - cc <= kl;
+      const double v = lb[(in ? rr - cc : 0) + ldl * (j0 + (in ? cc : 0))];
+      Ls[a * (CH_NB + 1) + c] = in ? v : 0.0;
+    }
+  };
+  {
+    const int64_t J0 = FWD ? 0 : nblk - 1;
+    if (J0 % CH_SG == g) load_diag(J0);
+  }
+  __syncthreads();
+  for (int64_t step = 0; step < nblk; step++) {
+    const int64_t J = FWD ? step : nblk - 1 - step;
+    const int64_t j0 = J * CH_NB;
+    const int nbc = (int)min((int64_t)CH_NB, n - j0);
+    const bool owner = J % CH_SG == g;
+    // the blocks this workgroup owns among those block J reaches: FWD rows of the blocks b in (J, J + reach], else columns of
+    // the blocks b in [J - reach, J); a group of 32 threads per block, the first pass requested now
+    const int64_t b_lo = FWD ? J + 1 : max((int64_t)0, J - reach), b_hi = FWD ? min(nblk - 1, J + reach) : J - 1;
+    const int64_t b0 = b_lo + ((g - b_lo % CH_SG) % CH_SG + CH_SG) % CH_SG;
+    const int64_t bb1 = b0 + (int64_t)(tid >> 5) * CH_SG;
+    const int64_t q1 = bb1 * CH_NB + (tid & (CH_NB - 1));        // FWD: the row; else the column
+    const bool on1 = bb1 <= b_hi && q1 < n;
+    auto tile = [&](int64_t q, bool on, double *pv) {
+#pragma unroll
+      for (int t = 0; t < CH_NB; t++) {
+        if (FWD) {
+          const int64_t c = j0 + t;
+          const bool in = on && t < nbc && q - c <= kl;
+          const double v = lb[(in ? q - c : 0) + ldl * (in ? c : j0)];
+          pv[t] = in ? v : 0.0;
+        } else {
+          const int64_t rr = j0 + t;
+          const bool in = on && t < nbc && rr - q <= kl;
+          const double v = lb[(in ? rr - q : 0) + ldl * (in ? q : j0)];
+          pv[t] = in ? v : 0.0;
+        }
+      }
+    };
+    double pv[CH_NB];
+    tile(q1, on1, pv);
+    {
+      const int64_t Jn = FWD ? J + 1 : J - 1;
+      if (Jn >= 0 && Jn < nblk && Jn % CH_SG == g) load_diag(Jn);       // (this workgroup does not own J: Ls is free)
+    }
+    if (owner) {
+      if (tid < 64) {
+        const int rr = lane & (CH_NB - 1);
+        const double di = rr < nbc ? dinv_g[j0 + rr] : 1.0;
+        double v = 0.0;
+        if (rr < nbc) v = FWD ? xw[(j0 + rr) & (W - 1)] : x[j0 + rr] - xw[(j0 + rr) & (W - 1)];
+#pragma unroll
+        for (int s8 = 0; s8 < CH_NB; s8 += 8) {
+          double l[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) l[i] = Ls[rr * (CH_NB + 1) + (FWD ? s8 + i : CH_NB - 1 - s8 - i)];
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const int sidx = FWD ? s8 + i : CH_NB - 1 - s8 - i;
+            const double ys = ch_readlane(v * di, sidx);
+            v = rr == sidx ? ys : fma(-l[i], ys, v);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (lane < CH_NB) {
+          const double out = lane < nbc ? v : 0.0;
+          yb[lane] = out;
+          __hip_atomic_store(&pub[J * CH_NB + lane], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane < nbc) {
+            x[j0 + lane] = v;
+            if (!FWD) xw[(j0 + lane) & (W - 1)] = 0.0;    // (the slot serves a later column)
+          }
+        }
+      }
+    } else if (tid < CH_NB) {
+      const long long t0 = wall_clock64();
+      double v = __hip_atomic_load(&pub[J * CH_NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      while (v != v) {
+        if ((++spins & 63) == 0 && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > tmo)) {
+          __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_abort = 1;
+          v = 0.0;
+          break;
+        }
+        v = __hip_atomic_load(&pub[J * CH_NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      yb[tid] = v;
+    }
+    __syncthreads();
+    if (s_abort) return;                 // (the same decision in every thread)
+    for (int64_t bb = bb1; bb <= b_hi; bb += 8 * CH_SG) {
+      const int64_t q = bb * CH_NB + (tid & (CH_NB - 1));
+      if (bb != bb1) tile(q, q < n, pv);
+      if (q < n) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < CH_NB; t++) s = fma(pv[t], yb[t], s);
+        if (FWD) {
+          if (q <= min(n - 1, j0 + nbc - 1 + kl)) xw[q & (W - 1)] -= s;
+        } else {
+          if (j0 - q <= kl) xw[q & (W - 1)] += s;       // (columns the block does not reach share their slots with others)
+        }
+      }
+    }
+    if (FWD) {
+      // owned rows that the next block reaches for the first time
+      const int64_t r = j0 + CH_NB + kl + tid;
+      if (tid < CH_NB && r < n && (r / CH_NB) % CH_SG == g) xw[r & (W - 1)] = x[r];
+    }
+    __syncthreads();
+  }
+}
+
 // 0 = solved by Cholesky (*done = 1) or not applicable (*done = 0: the caller goes on with the LU)
 int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *done) {
   *done = 0;
@@ -436,8 +588,42 @@ int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *do
   if (!rc && go) {
     if (x != b && hipMemcpyAsync(x, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess) rc = 1;
     if (!rc) {
-      hipLaunchKernelGGL(k_chol_fwd, dim3(1), dim3(CH_NT), lds, g_tg.stream, (const double *)lb, (const double *)dinv, ldl, n, kl, W, x);
-      hipLaunchKernelGGL(k_chol_bwd, dim3(1), dim3(CH_NT), lds, g_tg.stream, (const double *)lb, (const double *)dinv, ldl, n, kl, W, x);
+      // several workgroups with a flag per block (TIGAR_CHOL_SWEEP=0, or a wait that gave up: one workgroup)
+      bool swept = false;
+      const int64_t nblk = tg_cdiv(n, CH_NB);
+      if (!(getenv("TIGAR_CHOL_SWEEP") && atoi(getenv("TIGAR_CHOL_SWEEP")) == 0) && nblk >= 4 * CH_SG && g_tg.num_cu >= 2 * CH_SG) {
+        double *pub = nullptr, *xsave = nullptr;
+        int *errf = nullptr;
+        const int64_t npub = 2 * nblk * CH_NB;
+        if (!tg_dmalloc(&pub, npub) && !tg_dmalloc(&xsave, n) && !tg_dmalloc(&errf, 4) &&
+            hipMemsetAsync(pub, 0xff, (size_t)npub * sizeof(double), g_tg.stream) == hipSuccess &&          // (NaNs: nothing published)
+            hipMemsetAsync(errf, 0, 4 * sizeof(int), g_tg.stream) == hipSuccess &&
+            hipMemcpyAsync(xsave, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream) == hipSuccess &&
+            hipFuncSetAttribute((const void *)k_chol_sweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+            hipFuncSetAttribute((const void *)k_chol_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
+          hipLaunchKernelGGL(k_chol_sweep<true>, dim3(CH_SG), dim3(256), lds, g_tg.stream, (const double *)lb, (const double *)dinv, ldl,
+                             n, kl, W, x, pub, errf);
+          hipLaunchKernelGGL(k_chol_sweep<false>, dim3(CH_SG), dim3(256), lds, g_tg.stream, (const double *)lb, (const double *)dinv, ldl,
+                             n, kl, W, x, pub + nblk * CH_NB, errf);
+          int herr = 1;
+          if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&herr, errf, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) == hipSuccess &&
+              hipStreamSynchronize(g_tg.stream) == hipSuccess && herr == 0)
+            swept = true;
+          else {
+            (void)hipGetLastError();
+            if (trace) fprintf(stderr, "[trace] cholesky: the sweeps on several workgroups gave up: one workgroup\n");
+            if (hipMemcpyAsync(x, xsave, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess) rc = 1;
+          }
+        } else
+          (void)hipGetLastError();
+        tg_dfree(pub);
+        tg_dfree(errf);
+        tg_dfree(xsave);
+      }
+      if (!rc && !swept) {
+        hipLaunchKernelGGL(k_chol_fwd, dim3(1), dim3(CH_NT), lds, g_tg.stream, (const double *)lb, (const double *)dinv, ldl, n, kl, W, x);
+        hipLaunchKernelGGL(k_chol_bwd, dim3(1), dim3(CH_NT), lds, g_tg.stream, (const double *)lb, (const double *)dinv, ldl, n, kl, W, x);
+      }
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(g_tg.stream) != hipSuccess) rc = 1;
     }
     if (!rc) *done = 1;
