@@ -319,6 +319,33 @@ def test_banded_cholesky_of_spd_systems(n, kl, monkeypatch):
     assert res <= 100 * max(res2, 1e-16)                    # (as small a backward error as the LU's)
 
 
+@pytest.mark.parametrize("wgs", ["2", "3", "13", "64"])
+def test_cholesky_substitutions_on_several_workgroups(wgs, monkeypatch, capfd):
+    """the substitution sweeps with 2 .. 64 workgroups owning the blocks of 32 cyclically (a last block of 9 columns, a band of 21.9
+    blocks) give what the single-workgroup substitutions give, and none of their waits gives up"""
+    from tigar_amd import device as dev
+    rng = np.random.default_rng(77)
+    n, kl = 9001, 700
+    A = _spd_band(rng, n, kl)
+    b = A @ rng.standard_normal(n)
+    K = dev.DeviceCSR.from_scipy(A)
+    monkeypatch.setenv("TIGAR_CHOL_SWEEP", "0")
+    x1 = dev.DeviceVector(n)
+    assert dev.lu_solve(K, dev.DeviceVector(data=b), x1) == 0
+    monkeypatch.setenv("TIGAR_CHOL_SWEEP", "1")
+    monkeypatch.setenv("TIGAR_CHOL_SWEEP_WGS", wgs)
+    monkeypatch.setenv("TIGAR_TRACE", "1")
+    capfd.readouterr()
+    c0 = dev.prof_get(8)[1]
+    x2 = dev.DeviceVector(n)
+    assert dev.lu_solve(K, dev.DeviceVector(data=b), x2) == 0
+    err = capfd.readouterr().err
+    assert dev.prof_get(8)[1] == c0 + 1
+    assert "%s workgroups" % wgs in err and "gave up" not in err, err
+    assert np.max(np.abs(x2.get_local() - x1.get_local())) <= 1e-12 * np.max(np.abs(x1.get_local()))
+    assert np.linalg.norm(A @ x2.get_local() - b) <= 1e-12 * np.linalg.norm(b)
+
+
 def test_cholesky_is_left_for_the_lu_when_the_premise_fails():
     """a symmetric indefinite matrix (a pivot is not positive), a matrix that is not symmetric, one whose pattern is: the LU"""
     from tigar_amd import device as dev

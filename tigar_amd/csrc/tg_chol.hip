@@ -376,13 +376,14 @@ __global__ void __launch_bounds__(CH_NT) k_chol_bwd(const double *__restrict__ l
 
 // ---- the substitutions on SEVERAL workgroups (round 6, after the single-workgroup sweeps above proved bound by what one CU
 // streams: 0.56 GB of factor in 25.8 + 17.8 ms at cfg4 = 22 - 31 GB/s).  Blocks of 32 rows / columns are owned cyclically by
-// CH_SG workgroups.  Forward (L y = b), right-looking: the owner of block J solves its 32 x 32 triangle, publishes y_J (global
+// G workgroups (8 .. 64: a quarter of the blocks a block's tiles reach).  Forward (L y = b), right-looking: the owner of block J solves its 32 x 32 triangle, publishes y_J (global
 // memory + a flag per block, release / acquire at agent scope) and every workgroup subtracts the tiles L(b, J) y_J from the
 // row blocks b it owns; backward (L^T x = y) the same from the last block to the first, with the tiles transposed and the
 // pending sums owned by column block.  A workgroup takes the blocks in order, so whoever owns block J + 1 has applied
-// everything up to J before it solves: no dead-lock as long as the CH_SG workgroups are resident (8 on 256 CUs).  The waits
+// everything up to J before it solves: no dead-lock as long as the G workgroups are resident (<= 64 on 256 CUs).  The waits
 // give up after two seconds (err[0] = 1: the caller falls back to the single-workgroup sweeps).
-#define CH_SG 8
+#define CH_SG_MIN 8
+#define CH_SG_MAX 64
 // (what is published is the data itself: `pub` starts as NaNs and the 32 threads that need y_J poll their own entry -- one
 //  round trip through the L2 instead of a flag's and then the data's; the tiles of block J and the diagonal block of the next
 //  block this workgroup owns are static data and are requested BEFORE the wait.)
@@ -394,14 +395,14 @@ __global__ void __launch_bounds__(256) k_chol_sweep(const double *__restrict__ l
   double *yb = ch_sm + W;                // [NB]: the block just published
   double *Ls = yb + CH_NB;               // [NB][NB + 1]
   __shared__ int s_abort;
-  const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x, G = gridDim.x;
   if (tid == 0) s_abort = 0;
   const int64_t nblk = (n + CH_NB - 1) / CH_NB;
   const int reach = (kl + 2 * CH_NB - 1) / CH_NB;          // blocks a block's tiles reach
   const long long tmo = 2ll * 100000000ll;                 // (wall_clock64 counts at 100 MHz)
   if (FWD) {
     for (int64_t r = tid; r < min(n, (int64_t)CH_NB + kl); r += 256)
-      if ((r / CH_NB) % CH_SG == g) xw[r & (W - 1)] = x[r];
+      if ((r / CH_NB) % G == g) xw[r & (W - 1)] = x[r];
   } else {
     for (int i = tid; i < W; i += 256) xw[i] = 0.0;
   }
@@ -420,19 +421,19 @@ __global__ void __launch_bounds__(256) k_chol_sweep(const double *__restrict__ l
   };
   {
     const int64_t J0 = FWD ? 0 : nblk - 1;
-    if (J0 % CH_SG == g) load_diag(J0);
+    if (J0 % G == g) load_diag(J0);
   }
   __syncthreads();
   for (int64_t step = 0; step < nblk; step++) {
     const int64_t J = FWD ? step : nblk - 1 - step;
     const int64_t j0 = J * CH_NB;
     const int nbc = (int)min((int64_t)CH_NB, n - j0);
-    const bool owner = J % CH_SG == g;
+    const bool owner = J % G == g;
     // the blocks this workgroup owns among those block J reaches: FWD rows of the blocks b in (J, J + reach], else columns of
     // the blocks b in [J - reach, J); a group of 32 threads per block, the first pass requested now
     const int64_t b_lo = FWD ? J + 1 : max((int64_t)0, J - reach), b_hi = FWD ? min(nblk - 1, J + reach) : J - 1;
-    const int64_t b0 = b_lo + ((g - b_lo % CH_SG) % CH_SG + CH_SG) % CH_SG;
-    const int64_t bb1 = b0 + (int64_t)(tid >> 5) * CH_SG;
+    const int64_t b0 = b_lo + ((g - b_lo % G) % G + G) % G;
+    const int64_t bb1 = b0 + (int64_t)(tid >> 5) * G;
     const int64_t q1 = bb1 * CH_NB + (tid & (CH_NB - 1));        // FWD: the row; else the column
     const bool on1 = bb1 <= b_hi && q1 < n;
     auto tile = [&](int64_t q, bool on, double *pv) {
@@ -455,7 +456,7 @@ __global__ void __launch_bounds__(256) k_chol_sweep(const double *__restrict__ l
     tile(q1, on1, pv);
     {
       const int64_t Jn = FWD ? J + 1 : J - 1;
-      if (Jn >= 0 && Jn < nblk && Jn % CH_SG == g) load_diag(Jn);       // (this workgroup does not own J: Ls is free)
+      if (Jn >= 0 && Jn < nblk && Jn % G == g) load_diag(Jn);       // (this workgroup does not own J: Ls is free)
     }
     if (owner) {
       if (tid < 64) {
@@ -503,7 +504,7 @@ __global__ void __launch_bounds__(256) k_chol_sweep(const double *__restrict__ l
     }
     __syncthreads();
     if (s_abort) return;                 // (the same decision in every thread)
-    for (int64_t bb = bb1; bb <= b_hi; bb += 8 * CH_SG) {
+    for (int64_t bb = bb1; bb <= b_hi; bb += 8 * G) {
       const int64_t q = bb * CH_NB + (tid & (CH_NB - 1));
       if (bb != bb1) tile(q, q < n, pv);
       if (q < n) {
@@ -520,7 +521,7 @@ __global__ void __launch_bounds__(256) k_chol_sweep(const double *__restrict__ l
     if (FWD) {
       // owned rows that the next block reaches for the first time
       const int64_t r = j0 + CH_NB + kl + tid;
-      if (tid < CH_NB && r < n && (r / CH_NB) % CH_SG == g) xw[r & (W - 1)] = x[r];
+      if (tid < CH_NB && r < n && (r / CH_NB) % G == g) xw[r & (W - 1)] = x[r];
     }
     __syncthreads();
   }
@@ -591,7 +592,10 @@ int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *do
       // several workgroups with a flag per block (TIGAR_CHOL_SWEEP=0, or a wait that gave up: one workgroup)
       bool swept = false;
       const int64_t nblk = tg_cdiv(n, CH_NB);
-      if (!(getenv("TIGAR_CHOL_SWEEP") && atoi(getenv("TIGAR_CHOL_SWEEP")) == 0) && nblk >= 4 * CH_SG && g_tg.num_cu >= 2 * CH_SG) {
+      // a workgroup's eight groups of 32 threads take the tiles of ~4 owned blocks per step in one pass
+      int sg = (int)std::min<int64_t>(CH_SG_MAX, std::max<int64_t>(CH_SG_MIN, (kl + 2 * CH_NB - 1) / CH_NB / 4));
+      if (getenv("TIGAR_CHOL_SWEEP_WGS") && atoi(getenv("TIGAR_CHOL_SWEEP_WGS")) > 1) sg = std::min(atoi(getenv("TIGAR_CHOL_SWEEP_WGS")), 128);
+      if (!(getenv("TIGAR_CHOL_SWEEP") && atoi(getenv("TIGAR_CHOL_SWEEP")) == 0) && nblk >= 4 * sg && g_tg.num_cu >= 2 * sg) {
         double *pub = nullptr, *xsave = nullptr;
         int *errf = nullptr;
         const int64_t npub = 2 * nblk * CH_NB;
@@ -601,15 +605,17 @@ int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *do
             hipMemcpyAsync(xsave, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream) == hipSuccess &&
             hipFuncSetAttribute((const void *)k_chol_sweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
             hipFuncSetAttribute((const void *)k_chol_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
-          hipLaunchKernelGGL(k_chol_sweep<true>, dim3(CH_SG), dim3(256), lds, g_tg.stream, (const double *)lb, (const double *)dinv, ldl,
+          hipLaunchKernelGGL(k_chol_sweep<true>, dim3(sg), dim3(256), lds, g_tg.stream, (const double *)lb, (const double *)dinv, ldl,
                              n, kl, W, x, pub, errf);
-          hipLaunchKernelGGL(k_chol_sweep<false>, dim3(CH_SG), dim3(256), lds, g_tg.stream, (const double *)lb, (const double *)dinv, ldl,
+          hipLaunchKernelGGL(k_chol_sweep<false>, dim3(sg), dim3(256), lds, g_tg.stream, (const double *)lb, (const double *)dinv, ldl,
                              n, kl, W, x, pub + nblk * CH_NB, errf);
           int herr = 1;
           if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&herr, errf, sizeof(int), hipMemcpyDeviceToHost, g_tg.stream) == hipSuccess &&
               hipStreamSynchronize(g_tg.stream) == hipSuccess && herr == 0)
+          {
             swept = true;
-          else {
+            if (trace) fprintf(stderr, "[trace] cholesky: substitutions on %d workgroups\n", sg);
+          } else {
             (void)hipGetLastError();
             if (trace) fprintf(stderr, "[trace] cholesky: the sweeps on several workgroups gave up: one workgroup\n");
             if (hipMemcpyAsync(x, xsave, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess) rc = 1;
