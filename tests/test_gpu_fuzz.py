@@ -107,3 +107,12 @@ def test_random_mapped_patches_through_the_assembly():
     (round 6), each against its element-loop oracle"""
     rc, summary, failures = _run(["80"], {}, tool="fuzz_assembly.py")
     assert rc == 0 and summary["failed"] == 0, "\n".join(failures)[:4000]
+
+
+def test_random_spd_band_systems_through_the_direct_solve():
+    """`tests/fuzz/fuzz_direct.py` (round 6): random SPD band systems -- sizes the blocks of 32 never divide, half-widths 1 .. 1300,
+    bands with holes, 2 .. 64 sweep workgroups or one -- against LAPACK's banded Cholesky, and matrices that are not SPD handed on
+    to the LU; once more with the allocator handing out NaNs"""
+    for env in ({}, {"TIGAR_POOL_POISON": "1"}):
+        rc, summary, failures = _run(["--seed", "11", "--cases", "40"], env, tool="fuzz_direct.py")
+        assert rc == 0 and summary["failed"] == 0, "\n".join(failures)[:4000]
