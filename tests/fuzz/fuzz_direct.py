@@ -1,7 +1,7 @@
 """Random symmetric positive definite band systems through the direct solve behind the C-ABI (`tg_lu_solve`: blocked banded
 Cholesky of csrc/tg_chol.hip, substitutions on one or on several workgroups) against LAPACK's banded Cholesky (developer tool;
 `tests/test_gpu_fuzz.py` runs a seeded set): sizes that the blocks of 32 columns and the 64 x 64 tiles never divide, half-widths
-from 1 to beyond the matrix, bands with holes, a random number of sweep workgroups, and every fifth case a matrix the
+from 1 to beyond the matrix, bands with holes, a random number of sweep workgroups, one to seven panels per trailing update, and every fifth case a matrix the
 factorisation must hand on to the LU (a pivot that is not positive, a value that breaks the symmetry).
 
     python tests/fuzz/fuzz_direct.py [--seed S] [--cases N]
@@ -51,7 +51,8 @@ def main():
         else:
             os.environ.pop("TIGAR_CHOL_SWEEP_WGS", None)
         os.environ["TIGAR_CHOL_SWEEP"] = "0" if rng.random() < 0.15 else "1"
-        desc = {"case": case, "n": n, "kl": kl, "wgs": wgs, "sweep": os.environ["TIGAR_CHOL_SWEEP"]}
+        os.environ["TIGAR_CHOL_GROUP"] = str(int(rng.choice([0, 1, 2, 3, 4, 7])))       # panels per trailing update (0: by the band)
+        desc = {"case": case, "n": n, "kl": kl, "wgs": wgs, "sweep": os.environ["TIGAR_CHOL_SWEEP"], "group": os.environ["TIGAR_CHOL_GROUP"]}
         try:
             A = spd_band(rng, n, kl, holes=rng.random() < 0.3)
             nrhs_x = rng.standard_normal(n)

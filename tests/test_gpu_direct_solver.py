@@ -293,11 +293,16 @@ def _spd_band(rng, n, kl):
     return A
 
 
-@pytest.mark.parametrize("n,kl", [(64, 8), (257, 31), (1000, 40), (3001, 130), (5000, 333), (1300, 1100)])
-def test_banded_cholesky_of_spd_systems(n, kl, monkeypatch):
+@pytest.mark.parametrize("group", [0, 2, 3, 4])
+@pytest.mark.parametrize("n,kl", [(64, 8), (257, 31), (1000, 40), (3001, 130), (5000, 333), (1300, 1100), (2337, 500)])
+def test_banded_cholesky_of_spd_systems(n, kl, group, monkeypatch):
     """band widths below, at and above the block width and the tile width, a last block of one column, a band wider than most
-    of the matrix: the solve runs on the Cholesky path and agrees with SuperLU and with the LU path"""
+    of the matrix, an odd number of blocks with a short last one: the solve runs on the Cholesky path and agrees with SuperLU and
+    with the LU path; `group`: that many panels per pass over the trailing triangle (bands of half-width >= 2048 get two, >= 4096
+    four)"""
     from tigar_amd import device as dev
+    if group:
+        monkeypatch.setenv("TIGAR_CHOL_GROUP", str(group))
     rng = np.random.default_rng(n + kl)
     A = _spd_band(rng, n, kl)
     xs = rng.standard_normal(n)

@@ -1351,6 +1351,28 @@ class _DefaultSolver(object):
             kl, ku, nb = _dev.lu_band_info(A)
             flops = 2.0 * A.shape[0] * kl * (kl + ku)
             fits = nb <= 8 * 2 ** 30 and flops <= 4e12 and A.shape[0] <= 400000
+            # Beyond the LU's limits (3-D patches): a symmetric positive definite system -- the common case -- still gets
+            # a direct solve, by the banded Cholesky factorisation: a quarter of the LU's multiply-adds, on the matrix
+            # cores, a third of its band (csrc/tg_chol.hip; it declines what is not SPD and the next choice runs).
+            chol_fits = kl == ku and 8.0 * A.shape[0] * (kl + 1) <= 96 * 2 ** 30 and float(A.shape[0]) * kl * kl <= 4e13 \
+                and kl <= 16000 and os.environ.get("TIGAR_LU_CHOLESKY", "1") != "0"
+
+            def cholesky():
+                xd, bd = _as_device_vector(x), _as_device_vector(b)
+                if not _dev.chol_solve(A, bd, xd):
+                    return False
+                self.last = {"solver": "lu", "factorisation": "cholesky", "info": 0, "kl": kl, "ku": ku,
+                             "band_bytes": 8 * A.shape[0] * (kl + 1), "reordered": False}
+                return True
+
+            # a band as numbered (kl well below n: one field) goes there at once; a field-major system of several fields
+            # (kl ~ n (nF-1)/nF) has its reordered band evaluated first (a download of K and a host ordering: 0.2-0.45 s for
+            # 15-34 M entries, which the single-field solves paid for nothing)
+            chol_tried = False
+            if not fits and chol_fits and 4 * kl < A.shape[0]:
+                if cholesky():
+                    return 1
+                chol_tried = True
             if not fits and A.shape[0] <= 400000 and A.nnz <= 2e8:
                 # as numbered the band is too wide -- field-major systems of several fields (kl ~ n (nF-1)/nF): the saddle
                 # point and elasticity cases where the reference's direct solver matters.  Evaluate the band of the
@@ -1373,16 +1395,8 @@ class _DefaultSolver(object):
                 lu.solve(A, x, b)
                 self.last = dict(lu.last, solver="lu")
                 return 1
-            # Beyond the LU's limits (3-D patches): a symmetric positive definite system -- the common case -- still gets
-            # a direct solve, by the banded Cholesky factorisation: a quarter of the LU's multiply-adds, on the matrix
-            # cores, a third of its band (csrc/tg_chol.hip; it declines what is not SPD and the Krylov method below runs).
-            if kl == ku and 8.0 * A.shape[0] * (kl + 1) <= 96 * 2 ** 30 and float(A.shape[0]) * kl * kl <= 4e13 \
-                    and kl <= 16000 and os.environ.get("TIGAR_LU_CHOLESKY", "1") != "0":
-                xd, bd = _as_device_vector(x), _as_device_vector(b)
-                if _dev.chol_solve(A, bd, xd):
-                    self.last = {"solver": "lu", "factorisation": "cholesky", "info": 0, "kl": kl, "ku": ku,
-                                 "band_bytes": 8 * A.shape[0] * (kl + 1), "reordered": False}
-                    return 1
+            if chol_fits and not chol_tried and cholesky():
+                return 1
         ks = PETScKrylovSolver(self.method, "jacobi", comm=self.comm)
         ks.parameters["relative_tolerance"] = 1e-12
         ks.parameters["maximum_iterations"] = 10000

@@ -171,52 +171,78 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// trailing update A(r, c) -= sum_t L(r, j0 + t) L(c, j0 + t) for j1 <= c <= r <= rmax, in tiles of 64 x 64 on the matrix
-// cores; the tile is computed transposed (D[c][r]: the lanes of a result register run along r, contiguous in the band)
+// trailing update A(r, c) -= sum_{t < nk} L(r, j0 + t) L(c, j0 + t) for jc <= c <= r <= rmax, c < jc + cw, in tiles of 64 x 64
+// (anchored at jc) on the matrix cores; the tile is computed transposed (D[c][r]: the lanes of a result register run along r,
+// contiguous in the band).  nk = 32: one panel; nk = 64 / 128: two / four panels per pass over the trailing triangle (wide
+// bands, where the pass is bound by the triangle it reads and writes: 4 flop per byte with one panel) -- then the columns of
+// the later panels of the group have had their share of the earlier ones from launches with col0 = 1, cw = 32 (the tiles of
+// the first tile column only).
+// The last workgroup puts the factor of the diagonal block at column jl (nbl columns) in place.
 __global__ void __launch_bounds__(256)
-    k_chol_syrk(double *__restrict__ lb, int64_t ldl, int64_t n, int kl, int64_t j0, int nbc, int ntile,
-                const double *__restrict__ l11) {
+    k_chol_syrk(double *__restrict__ lb, int64_t ldl, int64_t n, int kl, int64_t j0, int nk, int64_t jc, int cw, int ntile, int col0,
+                const double *__restrict__ l11, int64_t jl, int nbl) {
   __shared__ double Lr[CH_NB][64 + 1], Lc[CH_NB][64 + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  if ((int)blockIdx.x == ntile * (ntile + 1) / 2) {          // the last workgroup: the factor of the diagonal block into the band
+  if ((int)blockIdx.x == (col0 ? ntile : ntile * (ntile + 1) / 2)) {
     for (int i = tid; i < CH_NB * CH_NB; i += 256) {
       const int r = i / CH_NB, c = i % CH_NB;
-      if (r < nbc && c <= r && r - c <= kl) lb[(r - c) + ldl * (j0 + c)] = l11[i];
+      if (r < nbl && c <= r && r - c <= kl) lb[(r - c) + ldl * (jl + c)] = l11[i];
     }
     return;
   }
   // linear index -> (ti >= tj)
   int ti = 0, rest = blockIdx.x;
-  while (rest > ti) {
-    rest -= ti + 1;
-    ti++;
-  }
+  if (col0) {
+    ti = rest;
+    rest = 0;
+  } else
+    while (rest > ti) {
+      rest -= ti + 1;
+      ti++;
+    }
   const int tj = rest;
-  const int64_t j1 = j0 + nbc, rmax = min(n - 1, j0 + nbc - 1 + kl);
-  const int64_t r0 = j1 + 64 * (int64_t)ti, c0 = j1 + 64 * (int64_t)tj;
-  for (int i = tid; i < CH_NB * 64; i += 256) {
-    const int k = i >> 6, l = i & 63;
-    const int64_t rr = r0 + l, rc = c0 + l;
-    Lr[k][l] = (k < nbc && rr <= rmax && rr - j0 - k <= kl) ? lb[(rr - j0 - k) + ldl * (j0 + k)] : 0.0;
-    Lc[k][l] = (k < nbc && rc <= rmax && rc - j0 - k <= kl) ? lb[(rc - j0 - k) + ldl * (j0 + k)] : 0.0;
+  const int64_t rmax = min(n - 1, j0 + nk - 1 + kl), cmax = jc + cw - 1;
+  const int64_t r0 = jc + 64 * (int64_t)ti, c0 = jc + 64 * (int64_t)tj;
+  // the tile of A is requested first: the read-modify-write after the products waited a full memory latency with nothing else
+  // in flight.  (The products are summed on their own and subtracted once: accumulating on A itself rounds every one of the
+  // 32 / 64 terms at the magnitude of A -- residuals of the 3-D solves 6-12 x larger.)
+  ch_v4d acc[4], apre[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    acc[q] = (ch_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int64_t c = c0 + 16 * wave + lk + 4 * i, r = r0 + 16 * q + lr;
+      const bool ok = r >= c && r <= rmax && c <= cmax;
+      const double v = lb[ok ? (r - c) + ldl * c : 0];
+      apre[q][i] = ok ? v : 0.0;
+    }
   }
-  __syncthreads();
-  ch_v4d acc[4];
+  for (int kh = 0; kh < nk; kh += CH_NB) {
+    if (kh) __syncthreads();
+    const int nkc = min(CH_NB, nk - kh);
+    const int64_t jk = j0 + kh;
+    for (int i = tid; i < CH_NB * 64; i += 256) {
+      const int k = i >> 6, l = i & 63;
+      const int64_t rr = r0 + l, rc = c0 + l;
+      Lr[k][l] = (k < nkc && rr <= rmax && rr - jk - k <= kl) ? lb[(rr - jk - k) + ldl * (jk + k)] : 0.0;
+      Lc[k][l] = (k < nkc && rc <= rmax && rc - jk - k <= kl) ? lb[(rc - jk - k) + ldl * (jk + k)] : 0.0;
+    }
+    __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 4; q++) acc[q] = (ch_v4d){0.0, 0.0, 0.0, 0.0};
+    for (int k4 = 0; k4 < CH_NB / 4; k4++) {
+      const double a = Lc[4 * k4 + lk][16 * wave + lr];        // A operand: rows = matrix columns c of this wave
 #pragma unroll
-  for (int k4 = 0; k4 < CH_NB / 4; k4++) {
-    const double a = Lc[4 * k4 + lk][16 * wave + lr];        // A operand: rows = matrix columns c of this wave
-#pragma unroll
-    for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lr[4 * k4 + lk][16 * q + lr], acc[q], 0, 0, 0);
+      for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lr[4 * k4 + lk][16 * q + lr], acc[q], 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int q = 0; q < 4; q++)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int64_t c = c0 + 16 * wave + lk + 4 * i, r = r0 + 16 * q + lr;
-      if (r >= c && r <= rmax) lb[(r - c) + ldl * c] -= acc[q][i];
+      if (r >= c && r <= rmax && c <= cmax) lb[(r - c) + ldl * c] = apre[q][i] - acc[q][i];
     }
 }
 
@@ -569,14 +595,34 @@ int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *do
     }
   }
   if (go) {
-    for (int64_t j0 = 0; j0 < n; j0 += CH_NB) {
-      const int nbc = (int)std::min<int64_t>(CH_NB, n - j0);
-      const int64_t m = std::min<int64_t>(kl, n - j0 - nbc);        // rows below the block
-      hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max<int64_t>(1, tg_cdiv(m, 256))), dim3(256), 0, g_tg.stream, lb, ldl, n,
-                         kl, j0, l11, dinv, st);
-      const int nt = (int)tg_cdiv(std::max<int64_t>(m, 0), 64);
-      hipLaunchKernelGGL(k_chol_syrk, dim3((unsigned)(nt * (nt + 1) / 2 + 1)), dim3(256), 0, g_tg.stream, lb, ldl, n, kl, j0, nbc, nt,
-                         (const double *)l11);
+    // wide bands: groups of 2 / 4 panels per pass over the trailing triangle (TIGAR_CHOL_PAIR_KL: the half-width from which on
+    // two, twice that: four; TIGAR_CHOL_GROUP=g: always g).  Inside a group the 32 columns of the next block get their share of
+    // the panels before them from the tiles of one tile column (col0 = 1, cw = 32).
+    const int pair_kl = getenv("TIGAR_CHOL_PAIR_KL") ? atoi(getenv("TIGAR_CHOL_PAIR_KL")) : 2048;
+    int ng = kl >= 2 * (int64_t)pair_kl ? 4 : kl >= pair_kl ? 2 : 1;
+    if (getenv("TIGAR_CHOL_GROUP") && atoi(getenv("TIGAR_CHOL_GROUP")) > 0) ng = std::min(atoi(getenv("TIGAR_CHOL_GROUP")), 16);
+    const int big = 1 << 30;
+    for (int64_t j0 = 0; j0 < n;) {
+      int64_t jg = j0;
+      int nk = 0;
+      for (int g = 0; g < ng && jg < n; g++) {
+        const int nbc = (int)std::min<int64_t>(CH_NB, n - jg);
+        const int64_t mrows = std::min<int64_t>(kl, n - jg - nbc);        // rows below the block
+        hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max<int64_t>(1, tg_cdiv(mrows, 256))), dim3(256), 0, g_tg.stream, lb, ldl,
+                           n, kl, jg, l11, dinv, st);
+        nk += nbc;
+        const int64_t jn = jg + nbc;
+        const int64_t m = std::max<int64_t>(0, std::min<int64_t>(n - 1, j0 + nk - 1 + kl) - jn + 1);
+        const int nt = (int)tg_cdiv(m, 64);
+        if (g + 1 < ng && jn < n)
+          hipLaunchKernelGGL(k_chol_syrk, dim3((unsigned)(nt + 1)), dim3(256), 0, g_tg.stream, lb, ldl, n, kl, j0, nk, jn, CH_NB, nt, 1,
+                             (const double *)l11, jg, nbc);
+        else
+          hipLaunchKernelGGL(k_chol_syrk, dim3((unsigned)(nt * (nt + 1) / 2 + 1)), dim3(256), 0, g_tg.stream, lb, ldl, n, kl, j0, nk, jn,
+                             big, nt, 0, (const double *)l11, jg, nbc);
+        jg = jn;
+      }
+      j0 = jg;
     }
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
         hipStreamSynchronize(g_tg.stream) != hipSuccess)
