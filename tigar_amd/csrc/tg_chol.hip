@@ -81,6 +81,48 @@ __device__ __forceinline__ double ch_readlane(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
+// Cholesky factor of the NB x NB block in D (lower triangle; rows >= nbc: identity) by ONE wave: a lane per row (lanes 32 .. 63
+// shadow 0 .. 31), the row in registers; column t of the factor is final after step t and every later entry of the row is
+// updated with it -- L(c, t) comes from lane c by readlane (a scalar operand of the multiply-add), and 1 / sqrt(d) from
+// v_rsq_f64 + two Newton steps: the 32 steps are a chain of dependent latencies, and the LDS round trip of the column plus the
+// full-precision sqrt and division made a step ~600 cycles (8 us per block, a quarter of a block's two launches at cfg4).
+// FILL: the factor (lower triangle, zeros above) and the reciprocals of its diagonal into D / dinv for a row solve.
+// l11 (if not null): the rows as they stand in the registers (entries above the diagonal: never used), dinv_g: 1 / L(j, j).
+template <bool FILL>
+__device__ __forceinline__ void ch_potrf_wave(double (*D)[CH_NB + 1], double *dinv, int lane, int nbc, int64_t j0, double *l11,
+                                              double *dinv_g, ch_stats *st) {
+  const int rr = lane & (CH_NB - 1);
+  double row[CH_NB];
+#pragma unroll
+  for (int c = 0; c < CH_NB; c++) row[c] = D[rr][c];
+  int bad = 0;
+  double myinv = 1.0;
+#pragma unroll
+  for (int t = 0; t < CH_NB; t++) {
+    const double dtt = ch_readlane(row[t], t);
+    if (!(dtt > 0.0) && t < nbc && bad == 0) bad = t + 1;
+    double inv = __builtin_amdgcn_rsq(dtt);
+#pragma unroll
+    for (int it = 0; it < 2; it++) inv = fma(0.5 * inv, fma(-dtt * inv, inv, 1.0), inv);
+    const double lrt = rr == t ? dtt * inv : row[t] * inv;
+    row[t] = lrt;
+    myinv = rr == t ? inv : myinv;
+#pragma unroll
+    for (int c = t + 1; c < CH_NB; c++) row[c] = fma(-lrt, ch_readlane(lrt, c), row[c]);     // (above the diagonal: never used)
+  }
+  if (FILL && lane < CH_NB) {
+#pragma unroll
+    for (int c = 0; c < CH_NB; c++) D[rr][c] = c <= rr ? row[c] : 0.0;
+    dinv[rr] = myinv;
+  }
+  if (lane < CH_NB && l11) {
+#pragma unroll
+    for (int c = 0; c < CH_NB; c++) l11[rr * CH_NB + c] = row[c];
+    if (rr < nbc) dinv_g[j0 + rr] = myinv;
+  }
+  if (bad && lane == 0 && l11) atomicCAS(&st->notpd, 0, (int)(j0 + bad));
+}
+
 // One block of NB columns: every workgroup factorises the NB x NB diagonal block (wave 0, a lane per row, the row in
 // registers, a finished column goes round through LDS; workgroup 0 hands the factor on), then its 256 threads take a row of
 // the panel below each: x L11^T = a, column by column (x_u final -> every later entry of the row updated: independent
@@ -90,7 +132,7 @@ __device__ __forceinline__ double ch_readlane(double v, int l) {
 //  what the substitutions multiply with.)
 __global__ void __launch_bounds__(256)
     k_chol_panel(double *__restrict__ lb, int64_t ldl, int64_t n, int kl, int64_t j0, double *__restrict__ l11,
-                 double *__restrict__ dinv_g, ch_stats *st) {
+                 double *__restrict__ dinv_g, ch_stats *st, const double *__restrict__ l11_in) {
   __shared__ double D[2 * CH_NB][CH_NB + 1];  // the diagonal block, then its factor (lower triangle); rows 32 .. 63: spare
                                              // (the shadow lanes of wave 0 store there: no branch in the loop)
   __shared__ double dinv[CH_NB];
@@ -113,42 +155,21 @@ __global__ void __launch_bounds__(256)
       a[t] = in ? v : 0.0;
     }
   }
-  for (int i = tid; i < CH_NB * CH_NB; i += 256) {
-    const int rr = i / CH_NB, c = i % CH_NB;
-    const bool in = rr < nbc && c <= rr && rr - c <= kl;
-    D[rr][c] = in ? lb[(rr - c) + ldl * (j0 + c)] : ((c == rr) ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  if (tid < 64) {
-    // wave 0: a lane per row of the block (lanes 32 .. 63 shadow 0 .. 31), the row in registers; a finished column goes
-    // round through LDS (where the row solve below finds the factor) and every later entry of the row is updated with it
-    const int rr = lane & (CH_NB - 1);
-    double row[CH_NB];
-#pragma unroll
-    for (int c = 0; c < CH_NB; c++) row[c] = D[rr][c];
-    int bad = 0;
-#pragma unroll
-    for (int t = 0; t < CH_NB; t++) {
-      const double dtt = ch_readlane(row[t], t);
-      if (!(dtt > 0.0) && t < nbc && bad == 0) bad = t + 1;
-      const double inv = 1.0 / sqrt(dtt);
-      const double lrt = rr == t ? dtt * inv : row[t] * inv;
-      row[t] = lrt;
-      D[lane][t] = rr >= t ? lrt : 0.0;                      // column t of the factor: D[.][t]
-      dinv[t] = inv;                                         // (the same value from every lane)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int c = t + 1; c < CH_NB; c++) row[c] = fma(-lrt, D[c][t], row[c]);     // (entries above the diagonal: never used)
-      __builtin_amdgcn_sched_barrier(0);
+  if (l11_in) {
+    // the factor of this block came out of the previous update kernel (its first tile holds the block: see k_chol_syrk)
+    for (int i = tid; i < CH_NB * CH_NB; i += 256) {
+      const int rr = i / CH_NB, c = i % CH_NB;
+      D[rr][c] = c <= rr ? l11_in[i] : 0.0;
     }
-    if (lane < CH_NB && blockIdx.x == 0) {
-#pragma unroll
-      for (int c = 0; c < CH_NB; c++) l11[rr * CH_NB + c] = row[c];
-      if (rr < nbc) dinv_g[j0 + rr] = dinv[rr];
+    if (tid < CH_NB) dinv[tid] = tid < nbc ? dinv_g[j0 + tid] : 1.0;
+  } else {
+    for (int i = tid; i < CH_NB * CH_NB; i += 256) {
+      const int rr = i / CH_NB, c = i % CH_NB;
+      const bool in = rr < nbc && c <= rr && rr - c <= kl;
+      D[rr][c] = in ? lb[(rr - c) + ldl * (j0 + c)] : ((c == rr) ? 1.0 : 0.0);
     }
-    if (bad && lane == 0 && blockIdx.x == 0) atomicCAS(&st->notpd, 0, (int)(j0 + bad));
+    __syncthreads();
+    if (tid < 64) ch_potrf_wave<true>(D, dinv, lane, nbc, j0, blockIdx.x == 0 ? l11 : nullptr, dinv_g, st);
   }
   __syncthreads();
   if (!mine) return;
@@ -178,10 +199,13 @@ __global__ void __launch_bounds__(256)
 // the later panels of the group have had their share of the earlier ones from launches with col0 = 1, cw = 32 (the tiles of
 // the first tile column only).
 // The last workgroup puts the factor of the diagonal block at column jl (nbl columns) in place.
+template <bool AHEAD>
 __global__ void __launch_bounds__(256)
     k_chol_syrk(double *__restrict__ lb, int64_t ldl, int64_t n, int kl, int64_t j0, int nk, int64_t jc, int cw, int ntile, int col0,
-                const double *__restrict__ l11, int64_t jl, int nbl) {
-  __shared__ double Lr[CH_NB][64 + 1], Lc[CH_NB][64 + 1];
+                const double *__restrict__ l11, int64_t jl, int nbl, double *__restrict__ l11_next, double *__restrict__ dinv_g,
+                ch_stats *st) {
+  __shared__ double sm[2][CH_NB][64 + 1];
+  double(*Lr)[64 + 1] = sm[0], (*Lc)[64 + 1] = sm[1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   if ((int)blockIdx.x == (col0 ? ntile : ntile * (ntile + 1) / 2)) {
@@ -244,6 +268,28 @@ __global__ void __launch_bounds__(256)
       const int64_t c = c0 + 16 * wave + lk + 4 * i, r = r0 + 16 * q + lr;
       if (r >= c && r <= rmax && c <= cmax) lb[(r - c) + ldl * c] = apre[q][i] - acc[q][i];
     }
+  // Look-ahead (narrow bands: the two launches per block are a chain of latencies): the first tile holds the diagonal block of
+  // the NEXT panel, final with this update -- its factor is computed here, by one wave of one workgroup while the others still
+  // update, and the next panel kernel starts with its row solve (6 of its 20 us at cfg4 were the 32 dependent steps of the
+  // factorisation).  Needs the whole block inside the rows this update reaches (the host checks kl >= 64).
+  if (AHEAD && l11_next && blockIdx.x == 0) {
+    double(*D)[CH_NB + 1] = (double(*)[CH_NB + 1]) & sm[0][0][0];          // [2 NB][NB + 1] + dinv[NB]: inside sm
+    double *dinv = &sm[0][0][0] + 2 * CH_NB * (CH_NB + 1);
+    static_assert(2 * CH_NB * (CH_NB + 1) + CH_NB <= 2 * CH_NB * (64 + 1), "the block and its reciprocals fit into the operand tiles");
+    const int nbn = (int)min((int64_t)CH_NB, n - jc);
+    __syncthreads();                       // (every wave is done with the operand tiles)
+    if (wave < 2) {
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int cc = 16 * wave + lk + 4 * i, rr = 16 * q + lr;
+          D[rr][cc] = (rr < nbn && cc <= rr) ? apre[q][i] - acc[q][i] : (rr == cc ? 1.0 : 0.0);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) ch_potrf_wave<false>(D, dinv, lane, nbn, jc, l11_next, dinv_g, st);
+  }
 }
 
 // L y = b block by block (one workgroup, NT threads): the window of x that the blocks ahead still change lives in an LDS ring
@@ -412,7 +458,11 @@ __global__ void __launch_bounds__(CH_NT) k_chol_bwd(const double *__restrict__ l
 #define CH_SG_MAX 64
 // (what is published is the data itself: `pub` starts as NaNs and the 32 threads that need y_J poll their own entry -- one
 //  round trip through the L2 instead of a flag's and then the data's; the tiles of block J and the diagonal block of the next
-//  block this workgroup owns are static data and are requested BEFORE the wait.)
+//  block this workgroup owns are static data and are requested BEFORE the wait.  Loads return in order within a wave: the wave
+//  that polls, solves and publishes -- wave 3 -- requests nothing else but the 32 reciprocals (and right-hand sides) of its next
+//  block, a step ahead; the tiles, the diagonal blocks and the rows that enter the window belong to waves 0 .. 2.  With the
+//  polls queued behind a wave's 32 tile loads a step took 6.5 us at cfg4.)
+#define CH_SW_GRP 6                      // groups of 32 threads that take tiles (waves 0 .. 2)
 template <bool FWD>
 __global__ void __launch_bounds__(256) k_chol_sweep(const double *__restrict__ lb, const double *__restrict__ dinv_g, int64_t ldl,
                                                      int64_t n, int kl, int W, double *x, double *pub, int *err) {
@@ -422,6 +472,7 @@ __global__ void __launch_bounds__(256) k_chol_sweep(const double *__restrict__ l
   double *Ls = yb + CH_NB;               // [NB][NB + 1]
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x, G = gridDim.x;
+  const bool lat = tid >= 32 * CH_SW_GRP;                  // the wave of the hand-over
   if (tid == 0) s_abort = 0;
   const int64_t nblk = (n + CH_NB - 1) / CH_NB;
   const int reach = (kl + 2 * CH_NB - 1) / CH_NB;          // blocks a block's tiles reach
@@ -432,90 +483,127 @@ __global__ void __launch_bounds__(256) k_chol_sweep(const double *__restrict__ l
   } else {
     for (int i = tid; i < W; i += 256) xw[i] = 0.0;
   }
-  // the diagonal block of block J into Ls: FWD Ls[a][c] = L11[a][c] (c < a), else Ls[a][c] = L11[c][a] (a < c)
+  // the diagonal block of block J into Ls (waves 0 .. 2): FWD Ls[a][c] = L11[a][c] (c < a), else Ls[a][c] = L11[c][a] (a < c)
   auto load_diag = [&](int64_t J) {
     const int64_t j0 = J * CH_NB;
     const int nbc = (int)min((int64_t)CH_NB, n - j0);
 #pragma unroll
-    for (int k = 0; k < CH_NB * CH_NB / 256; k++) {
-      const int i = tid + 256 * k, a = i >> 5, c = i & (CH_NB - 1);
+    for (int k = 0; k < (CH_NB * CH_NB + 32 * CH_SW_GRP - 1) / (32 * CH_SW_GRP); k++) {
+      const int i = min(tid + 32 * CH_SW_GRP * k, CH_NB * CH_NB - 1), a = i >> 5, c = i & (CH_NB - 1);     // (the tail: twice)
       const int rr = FWD ? a : c, cc = FWD ? c : a;
       const bool in = rr < nbc && cc < rr && rr - cc <= kl;
       const double v = lb[(in ? rr - cc : 0) + ldl * (j0 + (in ? cc : 0))];
       Ls[a * (CH_NB + 1) + c] = in ? v : 0.0;
     }
   };
-  {
-    const int64_t J0 = FWD ? 0 : nblk - 1;
-    if (J0 % G == g) load_diag(J0);
-  }
-  __syncthreads();
-  for (int64_t step = 0; step < nblk; step++) {
-    const int64_t J = FWD ? step : nblk - 1 - step;
+  // what the hand-over wave needs of a block it owns: the reciprocals of the diagonal, and (backward) the right-hand side
+  double dcur = 1.0, xcur = 0.0;
+  auto small = [&](int64_t J, double &d, double &xv) {
     const int64_t j0 = J * CH_NB;
     const int nbc = (int)min((int64_t)CH_NB, n - j0);
-    const bool owner = J % G == g;
-    // the blocks this workgroup owns among those block J reaches: FWD rows of the blocks b in (J, J + reach], else columns of
-    // the blocks b in [J - reach, J); a group of 32 threads per block, the first pass requested now
-    const int64_t b_lo = FWD ? J + 1 : max((int64_t)0, J - reach), b_hi = FWD ? min(nblk - 1, J + reach) : J - 1;
-    const int64_t b0 = b_lo + ((g - b_lo % G) % G + G) % G;
-    const int64_t bb1 = b0 + (int64_t)(tid >> 5) * G;
-    const int64_t q1 = bb1 * CH_NB + (tid & (CH_NB - 1));        // FWD: the row; else the column
-    const bool on1 = bb1 <= b_hi && q1 < n;
-    auto tile = [&](int64_t q, bool on, double *pv) {
-#pragma unroll
-      for (int t = 0; t < CH_NB; t++) {
-        if (FWD) {
-          const int64_t c = j0 + t;
-          const bool in = on && t < nbc && q - c <= kl;
-          const double v = lb[(in ? q - c : 0) + ldl * (in ? c : j0)];
-          pv[t] = in ? v : 0.0;
-        } else {
-          const int64_t rr = j0 + t;
-          const bool in = on && t < nbc && rr - q <= kl;
-          const double v = lb[(in ? rr - q : 0) + ldl * (in ? q : j0)];
-          pv[t] = in ? v : 0.0;
-        }
-      }
-    };
-    double pv[CH_NB];
-    tile(q1, on1, pv);
-    {
-      const int64_t Jn = FWD ? J + 1 : J - 1;
-      if (Jn >= 0 && Jn < nblk && Jn % G == g) load_diag(Jn);       // (this workgroup does not own J: Ls is free)
+    const int rr = lane & (CH_NB - 1);
+    const double dl = dinv_g[j0 + min(rr, nbc - 1)];
+    d = rr < nbc ? dl : 1.0;
+    if (!FWD) {
+      const double xl = x[j0 + min(rr, nbc - 1)];
+      xv = rr < nbc ? xl : 0.0;
     }
-    if (owner) {
-      if (tid < 64) {
-        const int rr = lane & (CH_NB - 1);
-        const double di = rr < nbc ? dinv_g[j0 + rr] : 1.0;
-        double v = 0.0;
-        if (rr < nbc) v = FWD ? xw[(j0 + rr) & (W - 1)] : x[j0 + rr] - xw[(j0 + rr) & (W - 1)];
+  };
+  {
+    const int64_t J0 = FWD ? 0 : nblk - 1;
+    if (J0 % G == g) {
+      if (lat) small(J0, dcur, xcur);
+      else load_diag(J0);
+    }
+  }
+  // the tiles of a step: of the blocks this workgroup owns among those block J reaches -- FWD rows of the blocks b in
+  // (J, J + reach], else columns of the blocks b in [J - reach, J) -- a group of 32 threads per block; the first pass is
+  // requested at the top of the step.  (Requested a step ahead into a second register array -- so that the update would wait for
+  // nothing but y_J -- the kernel came out at 256 registers + 7 spilled and the sweeps took 26.9 + 16.4 ms instead of 11.4 + 10.4.)
+  struct geom_t {
+    int64_t J, j0, b_hi, bb1;
+    int nbc;
+  };
+  auto geom = [&](int64_t step) {
+    geom_t e;
+    e.J = FWD ? step : nblk - 1 - step;
+    e.j0 = e.J * CH_NB;
+    e.nbc = (int)min((int64_t)CH_NB, n - e.j0);
+    const int64_t b_lo = FWD ? e.J + 1 : max((int64_t)0, e.J - reach);
+    e.b_hi = FWD ? min(nblk - 1, e.J + reach) : e.J - 1;
+    const int64_t b0 = b_lo + ((g - b_lo % G) % G + G) % G;
+    e.bb1 = b0 + (int64_t)(tid >> 5) * G;
+    return e;
+  };
+  auto tile = [&](const geom_t &e, int64_t q, bool on, double *pv) {
 #pragma unroll
-        for (int s8 = 0; s8 < CH_NB; s8 += 8) {
-          double l[8];
+    for (int t = 0; t < CH_NB; t++) {
+      if (FWD) {
+        const int64_t c = e.j0 + t;
+        const bool in = on && t < e.nbc && q - c <= kl;
+        const double v = lb[(in ? q - c : 0) + ldl * (in ? c : e.j0)];
+        pv[t] = in ? v : 0.0;
+      } else {
+        const int64_t rr = e.j0 + t;
+        const bool in = on && t < e.nbc && rr - q <= kl;
+        const double v = lb[(in ? rr - q : 0) + ldl * (in ? q : e.j0)];
+        pv[t] = in ? v : 0.0;
+      }
+    }
+  };
+  auto first_tiles = [&](int64_t step, double *pv) {
+    if (step >= nblk) return;
+    const geom_t e = geom(step);
+    const int64_t q1 = e.bb1 * CH_NB + (tid & (CH_NB - 1));        // FWD: the row; else the column
+    tile(e, q1, e.bb1 <= e.b_hi && q1 < n, pv);
+  };
+  // one step; false: a wait gave up
+  auto body = [&](int64_t step, double *pv) -> bool {
+    const geom_t e = geom(step);
+    const int64_t J = e.J, j0 = e.j0;
+    const int nbc = e.nbc;
+    const bool owner = J % G == g;
+    const int64_t Jn = FWD ? J + 1 : J - 1;
+    const bool own_next = Jn >= 0 && Jn < nblk && Jn % G == g;
+    double xin = 0.0;
+    const int64_t rin = j0 + CH_NB + kl + tid;          // FWD: an owned row that the next block reaches for the first time
+    const bool in_on = FWD && tid < CH_NB && rin < n && (rin / CH_NB) % G == g;
+    if (!lat) {
+      first_tiles(step, pv);
+      if (FWD && tid < CH_NB) {
+        const double v = x[in_on ? rin : 0];
+        xin = in_on ? v : 0.0;
+      }
+      if (own_next) load_diag(Jn);                      // (this workgroup does not own J then: Ls is free)
+    } else if (owner) {
+      const int rr = lane & (CH_NB - 1);
+      double v = 0.0;
+      if (rr < nbc) v = FWD ? xw[(j0 + rr) & (W - 1)] : xcur - xw[(j0 + rr) & (W - 1)];
 #pragma unroll
-          for (int i = 0; i < 8; i++) l[i] = Ls[rr * (CH_NB + 1) + (FWD ? s8 + i : CH_NB - 1 - s8 - i)];
+      for (int s8 = 0; s8 < CH_NB; s8 += 8) {
+        double l[8];
 #pragma unroll
-          for (int i = 0; i < 8; i++) {
-            const int sidx = FWD ? s8 + i : CH_NB - 1 - s8 - i;
-            const double ys = ch_readlane(v * di, sidx);
-            v = rr == sidx ? ys : fma(-l[i], ys, v);
-          }
-          __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 8; i++) l[i] = Ls[rr * (CH_NB + 1) + (FWD ? s8 + i : CH_NB - 1 - s8 - i)];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int sidx = FWD ? s8 + i : CH_NB - 1 - s8 - i;
+          const double ys = ch_readlane(v * dcur, sidx);
+          v = rr == sidx ? ys : fma(-l[i], ys, v);
         }
-        if (lane < CH_NB) {
-          const double out = lane < nbc ? v : 0.0;
-          yb[lane] = out;
-          __hip_atomic_store(&pub[J * CH_NB + lane], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (lane < nbc) {
-            x[j0 + lane] = v;
-            if (!FWD) xw[(j0 + lane) & (W - 1)] = 0.0;    // (the slot serves a later column)
-          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (lane < CH_NB) {
+        const double out = lane < nbc ? v : 0.0;
+        yb[lane] = out;
+        __hip_atomic_store(&pub[J * CH_NB + lane], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < nbc) {
+          x[j0 + lane] = v;
+          if (!FWD) xw[(j0 + lane) & (W - 1)] = 0.0;    // (the slot serves a later column)
         }
       }
-    } else if (tid < CH_NB) {
+    } else if (lane < CH_NB) {
       const long long t0 = wall_clock64();
-      double v = __hip_atomic_load(&pub[J * CH_NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      double v = __hip_atomic_load(&pub[J * CH_NB + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int spins = 0;
       while (v != v) {
         if ((++spins & 63) == 0 && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > tmo)) {
@@ -524,33 +612,38 @@ __global__ void __launch_bounds__(256) k_chol_sweep(const double *__restrict__ l
           v = 0.0;
           break;
         }
-        v = __hip_atomic_load(&pub[J * CH_NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __hip_atomic_load(&pub[J * CH_NB + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      yb[tid] = v;
+      yb[lane] = v;
     }
     __syncthreads();
-    if (s_abort) return;                 // (the same decision in every thread)
-    for (int64_t bb = bb1; bb <= b_hi; bb += 8 * G) {
-      const int64_t q = bb * CH_NB + (tid & (CH_NB - 1));
-      if (bb != bb1) tile(q, q < n, pv);
-      if (q < n) {
-        double s = 0.0;
+    if (s_abort) return false;           // (the same decision in every thread)
+    if (lat) {
+      if (own_next) small(Jn, dcur, xcur);              // (in flight while the others update; the next polls queue behind it)
+    } else {
+      for (int64_t bb = e.bb1; bb <= e.b_hi; bb += CH_SW_GRP * G) {
+        const int64_t q = bb * CH_NB + (tid & (CH_NB - 1));
+        if (bb != e.bb1) tile(e, q, q < n, pv);
+        if (q < n) {
+          double sacc = 0.0;
 #pragma unroll
-        for (int t = 0; t < CH_NB; t++) s = fma(pv[t], yb[t], s);
-        if (FWD) {
-          if (q <= min(n - 1, j0 + nbc - 1 + kl)) xw[q & (W - 1)] -= s;
-        } else {
-          if (j0 - q <= kl) xw[q & (W - 1)] += s;       // (columns the block does not reach share their slots with others)
+          for (int t = 0; t < CH_NB; t++) sacc = fma(pv[t], yb[t], sacc);
+          if (FWD) {
+            if (q <= min(n - 1, j0 + nbc - 1 + kl)) xw[q & (W - 1)] -= sacc;
+          } else {
+            if (j0 - q <= kl) xw[q & (W - 1)] += sacc;     // (columns the block does not reach share their slots with others)
+          }
         }
       }
-    }
-    if (FWD) {
-      // owned rows that the next block reaches for the first time
-      const int64_t r = j0 + CH_NB + kl + tid;
-      if (tid < CH_NB && r < n && (r / CH_NB) % G == g) xw[r & (W - 1)] = x[r];
+      if (in_on) xw[rin & (W - 1)] = xin;
     }
     __syncthreads();
-  }
+    return true;
+  };
+  double pv[CH_NB];
+  __syncthreads();
+  for (int64_t step = 0; step < nblk; step++)
+    if (!body(step, pv)) return;
 }
 
 // 0 = solved by Cholesky (*done = 1) or not applicable (*done = 0: the caller goes on with the LU)
@@ -565,13 +658,14 @@ int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *do
   if (lds > 150 * 1024) return 0;
   const bool trace = getenv("TIGAR_TRACE") != nullptr;
   const int64_t ldl = (int64_t)kl + 1;
-  double *lb = nullptr, *l11 = nullptr, *dinv = nullptr;
+  double *lb = nullptr, *l11 = nullptr, *l11b = nullptr, *dinv = nullptr;
   ch_stats *st = nullptr;
   if (tg_dmalloc(&lb, ldl * n)) {
     (void)hipGetLastError();
     return 0;                        // (no room: the LU reports it)
   }
-  int rc = tg_dmalloc_bytes((void **)&st, sizeof(ch_stats)) || tg_dmalloc(&l11, CH_NB * CH_NB) || tg_dmalloc(&dinv, n);
+  int rc = tg_dmalloc_bytes((void **)&st, sizeof(ch_stats)) || tg_dmalloc(&l11, CH_NB * CH_NB) || tg_dmalloc(&l11b, CH_NB * CH_NB) ||
+           tg_dmalloc(&dinv, n);
   ch_stats h;
   memset(&h, 0, sizeof(h));
   if (!rc && (hipMemsetAsync(lb, 0, (size_t)(ldl * n) * sizeof(double), g_tg.stream) != hipSuccess ||
@@ -602,6 +696,10 @@ int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *do
     int ng = kl >= 2 * (int64_t)pair_kl ? 4 : kl >= pair_kl ? 2 : 1;
     if (getenv("TIGAR_CHOL_GROUP") && atoi(getenv("TIGAR_CHOL_GROUP")) > 0) ng = std::min(atoi(getenv("TIGAR_CHOL_GROUP")), 16);
     const int big = 1 << 30;
+    // one panel per update: the factor of the next diagonal block comes out of the update kernel (TIGAR_CHOL_LOOKAHEAD=0: not)
+    const bool ahead = ng == 1 && kl >= 64 && l11b && !(getenv("TIGAR_CHOL_LOOKAHEAD") && atoi(getenv("TIGAR_CHOL_LOOKAHEAD")) == 0);
+    double *lcur = l11, *lnext = l11b;
+    bool have = false;
     for (int64_t j0 = 0; j0 < n;) {
       int64_t jg = j0;
       int nk = 0;
@@ -609,17 +707,22 @@ int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *do
         const int nbc = (int)std::min<int64_t>(CH_NB, n - jg);
         const int64_t mrows = std::min<int64_t>(kl, n - jg - nbc);        // rows below the block
         hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max<int64_t>(1, tg_cdiv(mrows, 256))), dim3(256), 0, g_tg.stream, lb, ldl,
-                           n, kl, jg, l11, dinv, st);
+                           n, kl, jg, lcur, dinv, st, have ? (const double *)lcur : (const double *)nullptr);
         nk += nbc;
         const int64_t jn = jg + nbc;
         const int64_t m = std::max<int64_t>(0, std::min<int64_t>(n - 1, j0 + nk - 1 + kl) - jn + 1);
         const int nt = (int)tg_cdiv(m, 64);
+        have = ahead && nt > 0;
         if (g + 1 < ng && jn < n)
-          hipLaunchKernelGGL(k_chol_syrk, dim3((unsigned)(nt + 1)), dim3(256), 0, g_tg.stream, lb, ldl, n, kl, j0, nk, jn, CH_NB, nt, 1,
-                             (const double *)l11, jg, nbc);
+          hipLaunchKernelGGL(k_chol_syrk<false>, dim3((unsigned)(nt + 1)), dim3(256), 0, g_tg.stream, lb, ldl, n, kl, j0, nk, jn, CH_NB,
+                             nt, 1, (const double *)lcur, jg, nbc, (double *)nullptr, dinv, st);
+        else if (have)
+          hipLaunchKernelGGL(k_chol_syrk<true>, dim3((unsigned)(nt * (nt + 1) / 2 + 1)), dim3(256), 0, g_tg.stream, lb, ldl, n, kl, j0,
+                             nk, jn, big, nt, 0, (const double *)lcur, jg, nbc, lnext, dinv, st);
         else
-          hipLaunchKernelGGL(k_chol_syrk, dim3((unsigned)(nt * (nt + 1) / 2 + 1)), dim3(256), 0, g_tg.stream, lb, ldl, n, kl, j0, nk, jn,
-                             big, nt, 0, (const double *)l11, jg, nbc);
+          hipLaunchKernelGGL(k_chol_syrk<false>, dim3((unsigned)(nt * (nt + 1) / 2 + 1)), dim3(256), 0, g_tg.stream, lb, ldl, n, kl, j0,
+                             nk, jn, big, nt, 0, (const double *)lcur, jg, nbc, (double *)nullptr, dinv, st);
+        if (have) std::swap(lcur, lnext);
         jg = jn;
       }
       j0 = jg;
@@ -638,7 +741,7 @@ int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *do
       // several workgroups with a flag per block (TIGAR_CHOL_SWEEP=0, or a wait that gave up: one workgroup)
       bool swept = false;
       const int64_t nblk = tg_cdiv(n, CH_NB);
-      // a workgroup's eight groups of 32 threads take the tiles of ~4 owned blocks per step in one pass
+      // a workgroup's six groups of 32 threads take the tiles of ~4 owned blocks per step in one pass
       int sg = (int)std::min<int64_t>(CH_SG_MAX, std::max<int64_t>(CH_SG_MIN, (kl + 2 * CH_NB - 1) / CH_NB / 4));
       if (getenv("TIGAR_CHOL_SWEEP_WGS") && atoi(getenv("TIGAR_CHOL_SWEEP_WGS")) > 1) sg = std::min(atoi(getenv("TIGAR_CHOL_SWEEP_WGS")), 128);
       if (!(getenv("TIGAR_CHOL_SWEEP") && atoi(getenv("TIGAR_CHOL_SWEEP")) == 0) && nblk >= 4 * sg && g_tg.num_cu >= 2 * sg) {
@@ -684,6 +787,7 @@ int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *do
   if (rc) tg_set_error("tg_chol_try: a kernel or a copy failed");
   tg_dfree(lb);
   tg_dfree(l11);
+  tg_dfree(l11b);
   tg_dfree(dinv);
   tg_dfree(st);
   return rc;
