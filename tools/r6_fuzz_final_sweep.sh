@@ -17,4 +17,7 @@ run sequences timeout 2400 python tests/fuzz/fuzz_sequences.py --seed $((S+12)) 
 run sequences_elements env $GEN timeout 2400 python tests/fuzz/fuzz_sequences.py --seed $((S+13)) --cases 60
 run kernels timeout 2400 python tests/fuzz/fuzz_kernels.py --seed $((S+14)) --cases 300
 run newton timeout 2400 python tests/fuzz/fuzz_newton.py 60
+run direct timeout 2400 python tests/fuzz/fuzz_direct.py --seed $((S+15)) --cases 150
+run direct_poison env TIGAR_POOL_POISON=1 timeout 2400 python tests/fuzz/fuzz_direct.py --seed $((S+16)) --cases 100
+run symgrid_kernels timeout 2400 python tests/fuzz/fuzz_symgrid.py --seed $((S+17)) --cases 60
 cat $F

@@ -59,6 +59,14 @@ halfstorage)
   stats cfg4_cholesky python $R/bench.py --workload cfg4 --solver lu --steps 3 --warmup 1 --no-cpu-baseline --companion 0
   pmc cfg4_cholesky python $R/bench.py --workload cfg4 --solver lu --steps 2 --warmup 1 --no-cpu-baseline --companion 0
   ;;
+cholesky)
+  # the direct solves on the final tree: cfg4 (narrow band: look-ahead, sweeps) and a 3-D system (wide band: groups of panels)
+  timeout 300 python bench.py --workload cfg4 --solver lu --steps 5 --warmup 1 --no-cpu-baseline --companion 0 > $O/r6_bench_cfg4_cholesky.json 2> $O/r6_bench_cfg4_cholesky.log
+  stats cfg4_cholesky python $R/bench.py --workload cfg4 --solver lu --steps 3 --warmup 1 --no-cpu-baseline --companion 0
+  pmc cfg4_cholesky python $R/bench.py --workload cfg4 --solver lu --steps 2 --warmup 1 --no-cpu-baseline --companion 0
+  python tools/kernel_trace.py --sum -- python tools/direct3d_bench.py 2 64 > $O/r6_direct3d_64_kernel_stats.txt 2>&1
+  { for a in "2 48" "2 64" "3 40"; do TIGAR_TRACE=1 timeout 300 python tools/direct3d_bench.py $a 2>&1 | grep "default solver\|K:\|workgroups"; done; } > $O/r6_direct3d_final.txt 2>&1
+  ;;
 headline)
   timeout 900 python bench.py --steps 10 --warmup 2 > $O/r6_bench_cfg3.json 2> $O/r6_bench_cfg3.log
   stats cfg3 python $R/bench.py --steps 5 --warmup 1 $W
