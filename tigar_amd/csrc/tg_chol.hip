@@ -173,13 +173,24 @@ __global__ void __launch_bounds__(256)
   }
   __syncthreads();
   if (!mine) return;
+  // (column by column -- the scheduler otherwise requests all 496 entries of L11 at once -- with the next column requested
+  //  before the multiply-adds of this one: two register copies of a column that change roles)
+  double dcol[2][CH_NB], dv[2];
+#pragma unroll
+  for (int t = 1; t < CH_NB; t++) dcol[0][t] = D[t][0];
+  dv[0] = dinv[0];
 #pragma unroll
   for (int u = 0; u < CH_NB; u++) {
-    const double xu = a[u] * dinv[u];
+    if (u + 1 < CH_NB) {
+#pragma unroll
+      for (int t = u + 2; t < CH_NB; t++) dcol[(u + 1) & 1][t] = D[t][u + 1];
+      dv[(u + 1) & 1] = dinv[u + 1];
+    }
+    const double xu = a[u] * dv[u & 1];
     a[u] = xu;
 #pragma unroll
-    for (int t = u + 1; t < CH_NB; t++) a[t] = fma(-xu, D[t][u], a[t]);
-    __builtin_amdgcn_sched_barrier(0);     // (column by column: the scheduler otherwise requests all 496 entries of L11 at once)
+    for (int t = u + 1; t < CH_NB; t++) a[t] = fma(-xu, dcol[u & 1][t], a[t]);
+    __builtin_amdgcn_sched_barrier(0);
   }
   // (the stores go through a buffer descriptor per column, a lane without an entry there carries an offset beyond its range,
   //  which the hardware drops: 32 divergent `if`s after the solve split the block it is scheduled in -- 2.4 KB of scratch)
