@@ -52,7 +52,9 @@ def main():
             os.environ.pop("TIGAR_CHOL_SWEEP_WGS", None)
         os.environ["TIGAR_CHOL_SWEEP"] = "0" if rng.random() < 0.15 else "1"
         os.environ["TIGAR_CHOL_GROUP"] = str(int(rng.choice([0, 1, 2, 3, 4, 7])))       # panels per trailing update (0: by the band)
-        desc = {"case": case, "n": n, "kl": kl, "wgs": wgs, "sweep": os.environ["TIGAR_CHOL_SWEEP"], "group": os.environ["TIGAR_CHOL_GROUP"]}
+        os.environ["TIGAR_CHOL_FUSED"] = "0" if rng.random() < 0.3 else "1"             # one launch per block / a panel and an update kernel
+        os.environ["TIGAR_CHOL_LOOKAHEAD"] = "0" if rng.random() < 0.15 else "1"
+        desc = {"case": case, "n": n, "kl": kl, "wgs": wgs, "fused": os.environ["TIGAR_CHOL_FUSED"], "ahead": os.environ["TIGAR_CHOL_LOOKAHEAD"], "sweep": os.environ["TIGAR_CHOL_SWEEP"], "group": os.environ["TIGAR_CHOL_GROUP"]}
         try:
             A = spd_band(rng, n, kl, holes=rng.random() < 0.3)
             nrhs_x = rng.standard_normal(n)

@@ -303,6 +303,150 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// One launch per block of 32 columns (narrow bands, where a block's two launches are a chain of latencies): every workgroup
+// of the trailing update solves the 2 x 64 rows of the panel its tile needs ITSELF -- x L11^T = a with the factor of the
+// diagonal block that the previous launch's first tile computed; a row costs 496 multiply-adds, a tile 131 k -- instead of
+// waiting for a panel kernel.  The solved rows cannot go into the band at once (other workgroups still read the unsolved ones):
+// the workgroups of tile column 0 put them into a side buffer (`pan`, column-major like the band), and CH_NCOPY extra
+// workgroups of the NEXT launch (or k_chol_pancopy) copy them into place.  The rest is k_chol_syrk<true>.
+#define CH_NCOPY 8
+__device__ __forceinline__ void ch_pancopy(double *__restrict__ lb, int64_t ldl, int64_t n, int kl, int64_t jp, const double *__restrict__ pan,
+                                           int64_t ph, int w, int tid) {
+  const int64_t jp1 = jp + CH_NB, rows = min(n - 1, jp + CH_NB - 1 + kl) - jp1 + 1;
+  for (int64_t idx = (int64_t)w * 256 + tid; idx < rows * CH_NB; idx += CH_NCOPY * 256) {
+    const int t = (int)(idx / rows);
+    const int64_t i = idx - t * rows, r = jp1 + i;           // (i fastest: contiguous in the band and in pan)
+    if (r - (jp + t) <= kl) lb[(r - jp - t) + ldl * (jp + t)] = pan[t * ph + i];
+  }
+}
+__global__ void __launch_bounds__(256)
+    k_chol_pancopy(double *__restrict__ lb, int64_t ldl, int64_t n, int kl, int64_t jp, const double *__restrict__ pan, int64_t ph) {
+  ch_pancopy(lb, ldl, n, kl, jp, pan, ph, blockIdx.x, threadIdx.x);
+}
+__global__ void __launch_bounds__(256)
+    k_chol_fused(double *__restrict__ lb, int64_t ldl, int64_t n, int kl, int64_t j0, int ntile, const double *__restrict__ l11,
+                 double *__restrict__ l11_next, double *__restrict__ dinv_g, ch_stats *st, double *__restrict__ pan, int64_t ph,
+                 const double *__restrict__ pan_prev, int64_t j0_prev) {
+  __shared__ double sm[2][CH_NB][64 + 1];
+  __shared__ double Dl[CH_NB][CH_NB + 1];
+  __shared__ double dls[CH_NB];
+  double(*Lr)[64 + 1] = sm[0], (*Lc)[64 + 1] = sm[1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int ntri = ntile * (ntile + 1) / 2;
+  if ((int)blockIdx.x == ntri) {                             // the factor of this block's diagonal block into the band
+    for (int i = tid; i < CH_NB * CH_NB; i += 256) {
+      const int r = i / CH_NB, c = i % CH_NB;
+      if (c <= r && r - c <= kl) lb[(r - c) + ldl * (j0 + c)] = l11[i];
+    }
+    return;
+  }
+  if ((int)blockIdx.x > ntri) {                              // the solved panel of the previous block into the band
+    if (pan_prev) ch_pancopy(lb, ldl, n, kl, j0_prev, pan_prev, ph, (int)blockIdx.x - ntri - 1, tid);
+    return;
+  }
+  int ti = 0, rest = blockIdx.x;
+  while (rest > ti) {
+    rest -= ti + 1;
+    ti++;
+  }
+  const int tj = rest;
+  const int64_t j1 = j0 + CH_NB, rmax = min(n - 1, j0 + CH_NB - 1 + kl);
+  const int64_t r0 = j1 + 64 * (int64_t)ti, c0 = j1 + 64 * (int64_t)tj;
+  ch_v4d acc[4], apre[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    acc[q] = (ch_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int64_t c = c0 + 16 * wave + lk + 4 * i, r = r0 + 16 * q + lr;
+      const bool ok = r >= c && r <= rmax;
+      const double v = lb[ok ? (r - c) + ldl * c : 0];
+      apre[q][i] = ok ? v : 0.0;
+    }
+  }
+  // waves 0 / 1: a thread per row of the tile's row set / column set
+  const int64_t myr = (tid < 64 ? r0 : c0) + lane;
+  const bool mine = tid < 128 && myr <= rmax;
+  const int t0 = (int)max((int64_t)0, myr - kl - j0);        // first column of the block the row holds
+  double a[CH_NB];
+  if (tid < 128) {
+#pragma unroll
+    for (int t = 0; t < CH_NB; t++) {                        // (a safe address and a select: no branch around a load)
+      const bool in = mine && t >= t0;
+      const double v = lb[in ? (myr - j0 - t) + ldl * (j0 + t) : 0];
+      a[t] = in ? v : 0.0;
+    }
+  }
+  for (int i = tid; i < CH_NB * CH_NB; i += 256) {
+    const int rr = i / CH_NB, c = i % CH_NB;
+    Dl[rr][c] = c <= rr ? l11[i] : 0.0;
+  }
+  if (tid < CH_NB) dls[tid] = dinv_g[j0 + tid];
+  __syncthreads();
+  if (tid < 128) {
+    double dcol[2][CH_NB], dv[2];
+#pragma unroll
+    for (int t = 1; t < CH_NB; t++) dcol[0][t] = Dl[t][0];
+    dv[0] = dls[0];
+#pragma unroll
+    for (int u = 0; u < CH_NB; u++) {
+      if (u + 1 < CH_NB) {
+#pragma unroll
+        for (int t = u + 2; t < CH_NB; t++) dcol[(u + 1) & 1][t] = Dl[t][u + 1];
+        dv[(u + 1) & 1] = dls[u + 1];
+      }
+      const double xu = a[u] * dv[u & 1];
+      a[u] = xu;
+#pragma unroll
+      for (int t = u + 1; t < CH_NB; t++) a[t] = fma(-xu, dcol[u & 1][t], a[t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    double *dst = tid < 64 ? &Lr[0][0] : &Lc[0][0];
+#pragma unroll
+    for (int t = 0; t < CH_NB; t++) dst[t * (64 + 1) + lane] = a[t];
+    // (the side buffer through a descriptor: a lane that has nothing to put there carries an offset beyond its range)
+    const __amdgpu_buffer_rsrc_t pb = __builtin_amdgcn_make_buffer_rsrc(pan, 0, (unsigned)(ph * CH_NB) * 8u, 0x00020000);
+    const bool put = mine && tid < 64 && tj == 0;
+#pragma unroll
+    for (int t = 0; t < CH_NB; t++) {
+      const unsigned off = put ? (unsigned)(t * ph + (myr - j1)) * 8u : 0xffffffffu;
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ch_u2, a[t]), pb, off, 0, 0);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k4 = 0; k4 < CH_NB / 4; k4++) {
+    const double av = Lc[4 * k4 + lk][16 * wave + lr];
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Lr[4 * k4 + lk][16 * q + lr], acc[q], 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int64_t c = c0 + 16 * wave + lk + 4 * i, r = r0 + 16 * q + lr;
+      if (r >= c && r <= rmax) lb[(r - c) + ldl * c] = apre[q][i] - acc[q][i];
+    }
+  if (blockIdx.x == 0) {                                     // the factor of the next diagonal block (see k_chol_syrk)
+    double(*D)[CH_NB + 1] = (double(*)[CH_NB + 1]) & sm[0][0][0];
+    double *dinv = &sm[0][0][0] + 2 * CH_NB * (CH_NB + 1);
+    const int nbn = (int)min((int64_t)CH_NB, n - j1);
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int cc = 16 * wave + lk + 4 * i, rr = 16 * q + lr;
+          D[rr][cc] = (rr < nbn && cc <= rr) ? apre[q][i] - acc[q][i] : (rr == cc ? 1.0 : 0.0);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) ch_potrf_wave<false>(D, dinv, lane, nbn, j1, l11_next, dinv_g, st);
+  }
+}
+
 // L y = b block by block (one workgroup, NT threads): the window of x that the blocks ahead still change lives in an LDS ring
 // (entry r at r mod W).  Per block: the entries of the thread's row of the panel are requested first, wave 0 solves the
 // NB x NB triangle (a lane per unknown, broadcasts by readlane, reciprocals of the diagonal from the factorisation),
@@ -711,7 +855,42 @@ int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *do
     const bool ahead = ng == 1 && kl >= 64 && l11b && !(getenv("TIGAR_CHOL_LOOKAHEAD") && atoi(getenv("TIGAR_CHOL_LOOKAHEAD")) == 0);
     double *lcur = l11, *lnext = l11b;
     bool have = false;
+    // ... and with its factor known a block takes ONE launch: the update kernel solves the rows of the panel it needs itself
+    // (k_chol_fused; TIGAR_CHOL_FUSED=0: a panel and an update kernel per block)
+    const int64_t ph = (int64_t)kl + 2 * CH_NB;
+    double *pan[2] = {nullptr, nullptr};
+    bool fused = ahead && !(getenv("TIGAR_CHOL_FUSED") && atoi(getenv("TIGAR_CHOL_FUSED")) == 0);
+    if (fused && (tg_dmalloc(&pan[0], ph * CH_NB) || tg_dmalloc(&pan[1], ph * CH_NB))) {
+      (void)hipGetLastError();
+      fused = false;
+    }
+    int pcur = 0;
+    bool pending = false;                  // a solved panel waits in pan[pcur ^ 1] for its copy into the band
+    int64_t jpend = 0;
+    auto flush = [&]() {
+      if (pending)
+        hipLaunchKernelGGL(k_chol_pancopy, dim3(CH_NCOPY), dim3(256), 0, g_tg.stream, lb, ldl, n, kl, jpend, (const double *)pan[pcur ^ 1], ph);
+      pending = false;
+    };
     for (int64_t j0 = 0; j0 < n;) {
+      if (fused && have) {
+        // (ng == 1; `have`: the previous launch saw rows below its block, so this block is a full one)
+        const int64_t j1 = j0 + CH_NB;
+        const int64_t m = std::max<int64_t>(0, std::min<int64_t>(n - 1, j0 + CH_NB - 1 + kl) - j1 + 1);
+        const int nt = (int)tg_cdiv(m, 64);
+        if (nt > 0) {
+          hipLaunchKernelGGL(k_chol_fused, dim3((unsigned)(nt * (nt + 1) / 2 + 1 + CH_NCOPY)), dim3(256), 0, g_tg.stream, lb, ldl, n, kl,
+                             j0, nt, (const double *)lcur, lnext, dinv, st, pan[pcur], ph,
+                             pending ? (const double *)pan[pcur ^ 1] : (const double *)nullptr, jpend);
+          pending = true;
+          jpend = j0;
+          pcur ^= 1;
+          std::swap(lcur, lnext);
+          j0 = j1;
+          continue;
+        }
+      }
+      flush();
       int64_t jg = j0;
       int nk = 0;
       for (int g = 0; g < ng && jg < n; g++) {
@@ -738,6 +917,7 @@ int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *do
       }
       j0 = jg;
     }
+    flush();
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, g_tg.stream) != hipSuccess ||
         hipStreamSynchronize(g_tg.stream) != hipSuccess)
       rc = 1;
@@ -745,6 +925,8 @@ int tg_chol_try(tg_csr_s *k, int kl, int ku, const double *b, double *x, int *do
       if (trace) fprintf(stderr, "[trace] cholesky: pivot %d is not positive: LU\n", h.notpd - 1);
       go = false;
     }
+    tg_dfree(pan[0]);
+    tg_dfree(pan[1]);
   }
   if (!rc && go) {
     if (x != b && hipMemcpyAsync(x, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_tg.stream) != hipSuccess) rc = 1;
