@@ -7,7 +7,10 @@
 // (MatZeroRowsColumns): symmetric positive definite.  For those no pivoting is needed and the factorisation is dense block
 // algebra: per block of NB = 32 columns a 32 x 32 Cholesky factor, a triangular solve for the kl rows below it, and a
 // symmetric rank-32 update of the trailing kl x kl triangle on `v_mfma_f64_16x16x4_f64` -- two launches per 32 columns
-// instead of two per 16 with a pivot search each, and substitutions that go block by block.
+// instead of two per 16 with a pivot search each (k_chol_panel + k_chol_syrk), ONE where the band is narrow and the launches
+// are a chain of latencies (k_chol_fused: the update's workgroups solve the panel rows they need, the next diagonal block is
+// factorised by the first tile), groups of 2 / 4 panels per pass where it is wide and the pass is bound by the triangle it
+// moves -- and substitutions that go block by block on 8 .. 64 workgroups (k_chol_sweep).
 //
 // tg_lu_solve tries this first: K's values are compared with their transposes (relative 1e-11: a K that is symmetric "to
 // rounding", as M^T A M comes out, qualifies -- the factor is that of the lower triangle, a perturbation of the order of the
